@@ -1,0 +1,208 @@
+/* fdo_geometry.c — TEST INFRASTRUCTURE (see fd_oracle.h).
+ * Restates: src/utils/convert.rs, src/structure/coordinate.rs, src/structure/core.rs:378-403,
+ * src/controller/feature.rs:11-24,84-99,198-231, src/geometry/pdb_tr.rs:21-162,
+ * src/utils/combination.rs:4-44. */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "fd_oracle.h"
+
+/* Rust `f32 as u32`: saturating, NaN -> 0 */
+static uint32_t sat_u32(float v) {
+    if (!(v == v)) return 0;
+    if (v <= 0.0f) return 0;
+    if (v >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)v;
+}
+
+/* src/utils/convert.rs:53-81 map_aa_to_u8 */
+uint8_t fdo_map_aa_to_u8(const uint8_t aa[3]) {
+    static const struct { const char *names; uint8_t v; } tab[] = {
+        {"ALA ABA ORN DAL AIB ALC MDO MAA DAB", 0},
+        {"ARG DAR CIR AGM", 1},
+        {"ASN DSG MEN SNN", 2},
+        {"ASP 0TD DAS IAS PHD BFD ASX", 3},
+        {"CYS CSO CSD CME OCS CAS CSX CSS YCM DCY SMC SCH SCY CAF SNC SEC", 4},
+        {"GLN DGN CRQ MEQ", 5},
+        {"GLU PCA DGL CGU FGA B3E GLX", 6},
+        {"GLY CR2 SAR GHP GL3", 7},
+        {"HIS HIC DHI NEP CR8 MHS", 8},
+        {"ILE DIL", 9},
+        {"LEU DLE NLE MLE MK8", 10},
+        {"LYS KCX LLP MLY M3L ALY MLZ DLY KPI PYL", 11},
+        {"MET MSE FME NRQ CXM SME MHO MED", 12},
+        {"PHE DPN PHI MEA PHL", 13},
+        {"PRO HYP DPR", 14},
+        {"SER CSH SEP DSN SAC GYS DHA OAS", 15},
+        {"THR TPO CRO DTH BMT CRF", 16},
+        {"TRP DTR TRQ TOX 0AF", 17},
+        {"TYR PTR TYS TPQ DTY OMY", 18},
+        {"VAL DVA MVA FVA", 19},
+    };
+    for (size_t t = 0; t < sizeof tab / sizeof tab[0]; ++t) {
+        const char *p = tab[t].names;
+        while (*p) {
+            if (p[0] == (char)aa[0] && p[1] == (char)aa[1] && p[2] == (char)aa[2]) return tab[t].v;
+            p += 3;
+            if (*p == ' ') ++p;
+        }
+    }
+    return 255;
+}
+
+/* src/utils/convert.rs map_u8_to_aa */
+const char *fdo_map_u8_to_aa(uint8_t aa) {
+    static const char *names[20] = {"ALA", "ARG", "ASN", "ASP", "CYS", "GLN", "GLU", "GLY", "HIS", "ILE",
+                                    "LEU", "LYS", "MET", "PHE", "PRO", "SER", "THR", "TRP", "TYR", "VAL"};
+    return aa < 20 ? names[aa] : "UNK";
+}
+
+/* src/utils/convert.rs:32-36 discretize_f32_value_into_u32 */
+uint32_t fdo_discretize(float val, float min, float max, float num_bin) {
+    float cont_f = (max - min) / (num_bin - 1.0f);
+    float disc_f = 1.0f / cont_f;
+    return sat_u32((val - min) * disc_f + 0.5f);
+}
+static float continuize(uint32_t val, float min, float max, float num_bin) {
+    float cont_f = (max - min) / (num_bin - 1.0f);
+    return (float)val * cont_f + min;
+}
+
+typedef struct { float x, y, z; } v3;
+static v3 sub(v3 a, v3 b) { v3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
+static float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static v3 cross(v3 a, v3 b) {
+    v3 r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+    return r;
+}
+static float norm(v3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+static v3 normalize(v3 a) {
+    float n = norm(a);
+    v3 r = {a.x / n, a.y / n, a.z / n};
+    return r;
+}
+/* coordinate.rs:109-115 */
+static float calc_distance(v3 a, v3 b) {
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+/* coordinate.rs:118-133 (powf(x,2.0) == x*x after LLVM's pow->mul fold) */
+static float calc_angle(v3 a, v3 b, v3 c, v3 d) {
+    v3 v1 = {b.x - a.x, b.y - a.y, b.z - a.z};
+    v3 v2 = {d.x - c.x, d.y - c.y, d.z - c.z};
+    float dt = v1.x * v2.x + v1.y * v2.y + v1.z * v2.z;
+    float l1 = sqrtf(v1.x * v1.x + v1.y * v1.y + v1.z * v1.z);
+    float l2 = sqrtf(v2.x * v2.x + v2.y * v2.y + v2.z * v2.z);
+    float cs = dt / (l1 * l2);
+    return acosf(cs);
+}
+/* coordinate.rs:204-215 */
+static float calc_torsion_radian(v3 a, v3 b, v3 c, v3 d) {
+    v3 v1 = sub(b, a), v2 = sub(c, b), v3_ = sub(d, c);
+    v3 r = normalize(cross(v1, v2));
+    v3 s = normalize(cross(v2, v3_));
+    v3 t = normalize(cross(r, normalize(v2)));
+    float x = dot(r, s);
+    float y = dot(s, t);
+    return -atan2f(y, x);
+}
+
+static v3 at(const float *p, int64_t i) { v3 r = {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; return r; }
+
+/* controller/feature.rs:11-24,84-99 + structure/core.rs:378-403 */
+int fdo_pair_feature(const fdo_structure *s, int64_t i, int64_t j, float dist_cutoff, float feature[9]) {
+    if (i == j) return 0;
+    if (s->aa[i] == 255 || s->aa[j] == 255) return 0;
+    if (!s->cb_ok[i] || !s->cb_ok[j]) return 0;
+    v3 ca1 = at(s->ca_xyz, i), ca2 = at(s->ca_xyz, j);
+    v3 cb1 = at(s->cb_xyz, i), cb2 = at(s->cb_xyz, j);
+    v3 n1 = at(s->n_xyz, i), n2 = at(s->n_xyz, j);
+    float ca_dist = calc_distance(ca1, ca2);
+    if (ca_dist > dist_cutoff) return 0;
+    float cb_dist = calc_distance(cb1, cb2);
+    float ang = calc_angle(ca1, cb1, ca2, cb2);
+    float t1 = calc_torsion_radian(n1, ca1, cb1, cb2);
+    float t2 = calc_torsion_radian(cb1, cb2, ca2, n2);
+    feature[0] = (float)s->aa[i];
+    feature[1] = (float)s->aa[j];
+    feature[2] = ca_dist;
+    feature[3] = cb_dist;
+    feature[4] = ang;
+    feature[5] = t1;
+    feature[6] = t2;
+    return 1;
+}
+
+/* geometry/pdb_tr.rs:21-75 */
+uint32_t fdo_hash_pdbtr(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle) {
+    float nd = nbin_dist > 16 ? 16.0f : (nbin_dist == 0 ? 16.0f : (float)nbin_dist);
+    float na = nbin_angle > 4 ? 4.0f : (nbin_angle == 0 ? 4.0f : (float)nbin_angle);
+    uint32_t res1 = sat_u32(f[0]), res2 = sat_u32(f[1]);
+    uint32_t ca = fdo_discretize(f[2], 2.0f, 20.0f, nd);
+    uint32_t cb = fdo_discretize(f[3], 2.0f, 20.0f, nd);
+    uint32_t s0 = fdo_discretize(sinf(f[4]), -1.0f, 1.0f, na);
+    uint32_t c0 = fdo_discretize(cosf(f[4]), -1.0f, 1.0f, na);
+    uint32_t s1 = fdo_discretize(sinf(f[5]), -1.0f, 1.0f, na);
+    uint32_t c1 = fdo_discretize(cosf(f[5]), -1.0f, 1.0f, na);
+    uint32_t s2 = fdo_discretize(sinf(f[6]), -1.0f, 1.0f, na);
+    uint32_t c2 = fdo_discretize(cosf(f[6]), -1.0f, 1.0f, na);
+    /* Rust `<<` on u32 panics on overflow shifts only; values are OR-ed unmasked */
+    return res1 << 25 | res2 << 20 | ca << 16 | cb << 12 | s0 << 10 | c0 << 8 | s1 << 6 | c1 << 4 | s2 << 2 | c2;
+}
+
+/* geometry/pdb_tr.rs:95-136 reverse_hash (default bins), angles in degrees */
+void fdo_reverse_hash_pdbtr(uint32_t h, float out[7]) {
+    const float PIS_IN_180 = 57.2957795130823208767981548141051703f; /* f32::to_degrees */
+    out[0] = (float)((h >> 25) & 0x1f);
+    out[1] = (float)((h >> 20) & 0x1f);
+    out[2] = continuize((h >> 16) & 0xf, 2.0f, 20.0f, 16.0f);
+    out[3] = continuize((h >> 12) & 0xf, 2.0f, 20.0f, 16.0f);
+    float s0 = continuize((h >> 10) & 3, -1.0f, 1.0f, 4.0f), c0 = continuize((h >> 8) & 3, -1.0f, 1.0f, 4.0f);
+    float s1 = continuize((h >> 6) & 3, -1.0f, 1.0f, 4.0f), c1 = continuize((h >> 4) & 3, -1.0f, 1.0f, 4.0f);
+    float s2 = continuize((h >> 2) & 3, -1.0f, 1.0f, 4.0f), c2 = continuize(h & 3, -1.0f, 1.0f, 4.0f);
+    out[4] = atan2f(s0, c0) * PIS_IN_180;
+    out[5] = atan2f(s1, c1) * PIS_IN_180;
+    out[6] = atan2f(s2, c2) * PIS_IN_180;
+}
+/* geometry/pdb_tr.rs:158-162 */
+int fdo_hash_is_symmetric(uint32_t h) {
+    float v[7];
+    fdo_reverse_hash_pdbtr(h, v);
+    return v[0] == v[1] && v[5] == v[6];
+}
+
+/* controller/feature.rs:198-231 with CombinationIterator order (combination.rs:23-44) */
+int fdo_hash_structure(const fdo_structure *s, uint64_t nbin_dist, uint64_t nbin_angle, float dist_cutoff,
+                       uint32_t **out, uint64_t *n_out) {
+    uint64_t cap = 1024, n = 0;
+    uint32_t *v = (uint32_t *)malloc(cap * sizeof *v);
+    float feat[9] = {0};
+    for (int64_t i = 0; i < s->n; ++i) {
+        for (int64_t j = 0; j < s->n; ++j) {
+            if (i == j) continue;
+            if (!fdo_pair_feature(s, i, j, dist_cutoff, feat)) continue;
+            uint32_t h = (nbin_dist == 0 || nbin_angle == 0) ? fdo_hash_pdbtr(feat, 16, 4)
+                                                            : fdo_hash_pdbtr(feat, nbin_dist, nbin_angle);
+            if (n == cap) { cap *= 2; v = (uint32_t *)realloc(v, cap * sizeof *v); }
+            v[n++] = h;
+        }
+    }
+    *out = v;
+    *n_out = n;
+    return 0;
+}
+
+static int cmp_u32(const void *a, const void *b) {
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : x > y;
+}
+/* controller/mod.rs:343-345 sort_unstable + dedup */
+uint64_t fdo_sort_dedup_u32(uint32_t *v, uint64_t n) {
+    if (n == 0) return 0;
+    qsort(v, n, sizeof *v, cmp_u32);
+    uint64_t m = 1;
+    for (uint64_t k = 1; k < n; ++k)
+        if (v[k] != v[m - 1]) v[m++] = v[k];
+    return m;
+}
+void fdo_free(void *p) { free(p); }

@@ -1,0 +1,260 @@
+"""Pins the CPU oracle (oracle/) against every literal the reference holds for this path.
+
+G1  src/controller/graph.rs:71-79       six PDBTrRosetta hashes of the 4CHA catalytic triad
+G2  README.md:216-241                   end-to-end rows: index data/serine_peptidases, query 4CHA B57,B102,C195
+G3  src/index/indextable.rs:471-499     varint / offset known answer (hand-derived from the test's insert sequence)
+G4  src/utils/combination.rs:51-63, src/utils/convert.rs:138-165, src/controller/query.rs:426-465,
+    src/structure/kabsch.rs:563-616     pair order, AA map, query grammar, Kabsch triads
+D   SURVEY.md App. D                    index shape of data/serine_peptidases
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+SER = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "serine_peptidases", "*.pdb")))
+Q4CHA = os.path.join(os.path.dirname(__file__), "golden", "query", "4CHA.pdb")
+
+
+@pytest.fixture(scope="module")
+def ser_index():
+    structs = [oracle.read_pdb(p) for p in SER]
+    ix, nres, plddt = oracle.build_index(structs)
+    return structs, ix, nres, plddt
+
+
+def test_g1_six_triad_hashes():
+    s = oracle.read_pdb(Q4CHA)
+    L = oracle.lib()
+    b57, b102, c195 = (L.fdo_get_index(s.ptr, ord(c), r) for c, r in (("B", 57), ("B", 102), ("C", 195)))
+    got = [oracle.pair_hash(s, a, b)[0] for a, b in
+           [(b102, b57), (b102, c195), (b57, b102), (b57, c195), (c195, b102), (c195, b57)]]
+    assert got == [109329223, 116878724, 271858548, 284511716, 506948936, 512052558]
+    # F/G copy of the triad shares three of them (graph.rs:74-79)
+    f57, f102, g195 = (L.fdo_get_index(s.ptr, ord(c), r) for c, r in (("F", 57), ("F", 102), ("G", 195)))
+    assert oracle.pair_hash(s, f57, f102)[0] == 271858548
+    assert oracle.pair_hash(s, f57, g195)[0] == 284511716
+    # (the toy graph in graph.rs wires 512052558 onto g195->f102; the real pair carrying it is G195->F57,
+    #  as for chain B/C where C195->B57 = 512052558)
+    assert oracle.pair_hash(s, g195, f57)[0] == 512052558
+
+
+def test_d_index_shape(ser_index):
+    structs, ix, nres, plddt = ser_index
+    assert [os.path.basename(p) for p in SER] == ["1azw.pdb", "1ju3.pdb", "1l7a.pdb", "1pq5.pdb", "4cha.pdb"]
+    assert ix.H == 217612
+    assert len(ix.values()) == 225674
+    h = ix.hashes()
+    assert int(h.min()) == 79992 and int(h.max()) == 658505709
+    assert np.all(np.diff(h.astype(np.int64)) > 0)
+    off = ix.offsets()
+    assert off[0] == 0 and off[-1] == 225674
+    # posting-length histogram: 1:209,969 2:7,258 3:357 4:22 5:6
+    lens = np.diff(off.astype(np.int64))
+    assert dict(zip(*np.unique(lens, return_counts=True))) == {1: 209969, 2: 7258, 3: 357, 4: 22, 5: 6}
+    uniq = [len(np.unique(oracle.hash_structure(s))) for s in structs]
+    assert uniq == [47512, 67129, 46795, 23853, 40385]
+    assert list(nres) == [626, 570, 636, 224, 477]
+
+
+def test_g2_prefilter_rows(ser_index):
+    structs, ix, nres, plddt = ser_index
+    q = oracle.read_pdb(Q4CHA)
+    m = oracle.make_query_map(q, "B57,B102,C195", ix, float(len(structs)))
+    assert len(m.arrays()["hash"]) == 16
+    res = {r["nid"]: r for r in oracle.count_query(m, ix, nres)}
+    # README.md:237-241: idf total_match node edge nres plddt db_key
+    exp = {4: ("0.6138", 8, 3, 6, 477, "13.5404"), 3: ("0.4869", 4, 3, 4, 224, "5.1340"),
+           1: ("0.0617", 2, 2, 2, 570, "19.4881"), 2: ("0.0584", 2, 2, 2, 636, "11.7037"),
+           0: ("0.1856", 2, 2, 2, 626, "34.2399")}
+    assert set(res) == set(exp)
+    for nid, (idf, tm, nc, ec, nr, pl) in exp.items():
+        r = res[nid]
+        assert "%.4f" % r["idf"] == idf
+        assert (r["total_match_count"], r["node_count"], r["edge_count"]) == (tm, nc, ec)
+        assert int(nres[nid]) == nr and "%.4f" % plddt[nid] == pl
+
+
+def _rows(structs, q, m, ca_distance=1.0):
+    rows = set()
+    for nid, t in enumerate(structs):
+        R = oracle.retrieve(t, q, m, ca_distance_cutoff=ca_distance)
+        for mt in R["processed"]:
+            res = ",".join("_" if x is None else f"{x[0]}{x[1]}" for x in mt["residues"])
+            rows.add((nid, sum(x is not None for x in mt["residues"]), "%.4f" % mt["idf"], "%.4f" % mt["rmsd"], res))
+    return rows
+
+
+def test_g2_match_rows(ser_index):
+    structs, ix, nres, plddt = ser_index
+    q = oracle.read_pdb(Q4CHA)
+    m = oracle.make_query_map(q, "B57,B102,C195", ix, float(len(structs)))
+    rows = _rows(structs, q, m)
+    # README.md:218-223 (the 1azw row :224 is stale under the current --ca-distance 1.0)
+    assert rows == {
+        (4, 3, "8.7616", "0.0000", "B57,B102,C195"),
+        (4, 3, "8.7616", "0.0874", "F57,F102,G195"),
+        (3, 3, "4.1178", "0.2609", "A56,A99,A195"),
+        (1, 2, "1.4739", "0.7792", "_,A223,A234"),
+        (2, 2, "1.4739", "0.7883", "_,A146,A127"),
+        (2, 2, "1.4739", "0.8078", "_,B146,B127"),
+    }
+    # with --ca-distance 1.5 the stale README row reappears bit-for-bit
+    rows15 = _rows(structs, q, m, ca_distance=1.5)
+    assert (0, 2, "4.6439", "0.9234", "A179,_,B176") in rows15
+
+
+def test_g3_varint_offsets_known_answer(tmp_path):
+    # insert sequence of indextable.rs:471-499: ids 0,10,128,655345 over hashes 0..8
+    L = oracle.lib()
+    ids = [0, 10, 128, 655345]
+
+    def hashes_for(i):  # hashes1 (id 0), hashes4 (id 10), hashes3 (id 128), hashes2 (id 655345)
+        return {0: range(0, 7), 10: range(0, 9), 128: [2, 4, 6, 8], 655345: [1, 3, 5, 7]}[i]
+
+    ix = L.fdo_index_new(30)
+    for fn in (L.fdo_index_count_single_entry, L.fdo_index_add_single_entry):
+        for i in ids:
+            for h in hashes_for(i):
+                fn(ix, h, i)
+        if fn is L.fdo_index_count_single_entry:
+            L.fdo_index_allocate_entries(ix)
+    L.fdo_index_finish(ix)
+    o = oracle.OIndex(ix)
+    # every list must decode back to what was inserted
+    for h in range(9):
+        want = [i for i in ids if h in hashes_for(i)]
+        assert list(o.entries(h)) == want
+    # explicit byte-level known answer for the canonical SURVEY G3 layout
+    ix2 = L.fdo_index_new(30)
+    g3 = {0: [0, 10], 1: [0, 10, 655345], 2: [0, 10, 128], 3: [0, 10, 655345], 4: [0, 10, 128],
+          5: [0, 10, 655345], 6: [0, 10, 128], 7: [10, 655345], 8: [10, 128]}
+    for fn in (L.fdo_index_count_single_entry, L.fdo_index_add_single_entry):
+        for i in ids:
+            for h, lst in g3.items():
+                if i in lst:
+                    fn(ix2, h, i)
+        if fn is L.fdo_index_count_single_entry:
+            L.fdo_index_allocate_entries(ix2)
+    L.fdo_index_finish(ix2)
+    o2 = oracle.OIndex(ix2)
+    want = bytes.fromhex("000A" "000AE7FF27" "000A76" "000AE7FF27" "000A76" "000AE7FF27" "000A76" "0AE7FF27" "0A76")
+    assert bytes(o2.values()) == want and len(want) == 32
+    assert list(o2.hashes()) == list(range(9))
+    assert list(o2.offsets()) == [0, 2, 7, 10, 15, 18, 23, 26, 30, 32]
+    # on-disk format: u64 H | u32 hashes[H] | u64 offsets[H+1]
+    prefix = str(tmp_path / "g3")
+    o2.save(prefix)
+    raw = open(prefix + ".offset", "rb").read()
+    assert len(raw) == 8 + 4 * 9 + 8 * 10
+    assert int.from_bytes(raw[:8], "little") == 9
+    assert open(prefix, "rb").read() == want
+    o3 = oracle.load_index(prefix)
+    assert list(o3.entries(7)) == [10, 655345]
+
+
+def test_g4_varint_split():
+    L = oracle.lib()
+    buf = (C.c_uint8 * 10)()
+    for v, want in [(0, [0]), (1, [1]), (127, [127]), (128, [0x80, 1]), (655335, [0xE7, 0xFF, 0x27]),
+                    (2 ** 21, [0x80, 0x80, 0x80, 1])]:
+        n = L.fdo_split_by_seven_bits(v, buf)
+        assert list(buf[:n]) == want
+
+
+def test_g4_aa_map():
+    L = oracle.lib()
+    # utils/convert.rs:138-165
+    std = ["ALA", "ARG", "ASN", "ASP", "CYS", "GLN", "GLU", "GLY", "HIS", "ILE", "LEU", "LYS", "MET", "PHE",
+           "PRO", "SER", "THR", "TRP", "TYR", "VAL"]
+    for k, nm in enumerate(std):
+        assert L.fdo_map_aa_to_u8(nm.encode()) == k
+    for nm, v in [("MSE", 12), ("SEC", 4), ("PYL", 11), ("ASX", 3), ("GLX", 6), ("UNK", 255), ("HOH", 255)]:
+        assert L.fdo_map_aa_to_u8(nm.encode()) == v
+
+
+def test_g4_query_grammar():
+    # controller/query.rs:426-465
+    _, q = oracle.parse_query_string("A250,A232,A269")
+    assert [(chr(c), r) for c, r, _ in q] == [("A", 250), ("A", 232), ("A", 269)]
+    _, q = oracle.parse_query_string("A250,B232,C269")
+    assert [(chr(c), r) for c, r, _ in q] == [("A", 250), ("B", 232), ("C", 269)]
+    _, q = oracle.parse_query_string("A250, A232, A269")
+    assert [(chr(c), r) for c, r, _ in q] == [("A", 250), ("A", 232), ("A", 269)]
+    _, q = oracle.parse_query_string("250,232,269")
+    assert [(chr(c), r) for c, r, _ in q] == [("A", 250), ("A", 232), ("A", 269)]
+    _, q = oracle.parse_query_string("A1-3,B5", ord("C"))
+    assert [(chr(c), r) for c, r, _ in q] == [("A", 1), ("A", 2), ("A", 3), ("B", 5)]
+    _, q = oracle.parse_query_string("1-2", ord("C"))
+    assert [(chr(c), r) for c, r, _ in q] == [("C", 1), ("C", 2)]
+    _, q = oracle.parse_query_string("164:H,195,247:ND")
+    assert q[0][2] == [8] and q[1][2] is None and q[2][2] == [2, 3]
+    _, q = oracle.parse_query_string("11:X")
+    assert q[0][2] == list(range(20))
+    _, q = oracle.parse_query_string("")
+    assert q == []
+
+
+def test_g4_kabsch_triads():
+    # structure/kabsch.rs:563-616
+    src = np.array([[6.994, 8.354, 42.405], [9.429, 7.479, 48.266], [5.547, 0.158, 42.050]], np.float32)
+    t1 = np.array([[-13.958, -1.741, -4.223], [-12.833, 3.134, -7.780], [-5.720, -2.218, -3.368]], np.float32)
+    t2 = np.array([[-4.924, 5.813, -9.485], [-0.499, 10.073, -8.059], [-0.792, 0.658, -4.430]], np.float32)
+    for t in (t1, t2):
+        rmsd, R, tr = oracle.kabsch(t, src)  # set_atoms(fixed=src, moving=t) -> kabsch(coords=t, reference=src)
+        assert rmsd < 0.2
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-5) and abs(np.linalg.det(R) - 1) < 1e-5
+    c = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]], np.float32)
+    assert oracle.kabsch(c, c)[0] < 1e-6
+
+
+def test_g4_pair_order_and_dedup():
+    # combination.rs:23-44 row-major order incl. both (i,j) and (j,i); mod.rs:343-345 sort+dedup
+    s = oracle.read_pdb(Q4CHA)
+    raw = oracle.hash_structure(s)
+    L = oracle.lib()
+    feat = (C.c_float * 9)()
+    first = []
+    for i in range(3):
+        for j in range(s.n):
+            if L.fdo_pair_feature(s.ptr, i, j, 20.0, feat):
+                first.append(int(L.fdo_hash_pdbtr(feat, 16, 4)))
+    assert list(raw[: len(first)]) == first
+    u = np.unique(raw)
+    buf = np.ascontiguousarray(raw.copy())
+    n = L.fdo_sort_dedup_u32(buf.ctypes.data_as(oracle.u32p), len(buf))
+    assert n == len(u) and np.array_equal(buf[:n], u)
+
+
+def test_compact_build_quirks():
+    # App. B #2: chain / b-factor of residue k come from the first atom of residue k+1; the last atom is lost
+    names = [b" N  ", b" CA ", b" C  ", b" CB "] * 3
+    res = [b"ALA"] * 4 + [b"SER"] * 4 + [b"HIS"] * 4
+    serial = [1] * 4 + [2] * 4 + [3] * 4
+    chain = [ord("A")] * 4 + [ord("B")] * 4 + [ord("C")] * 4
+    bf = [10.0] * 4 + [20.0] * 4 + [30.0] * 4
+    xyz = np.arange(36, dtype=np.float32).reshape(12, 3)
+    s = oracle.OStructure(oracle.lib().fdo_structure_from_atoms(
+        12, xyz.ctypes.data_as(oracle.f32p),
+        (C.c_uint8 * 48).from_buffer_copy(b"".join(names)), (C.c_uint8 * 36).from_buffer_copy(b"".join(res)),
+        (C.c_uint64 * 12)(*serial), (C.c_uint8 * 12)(*chain), (C.c_float * 12)(*bf)))
+    a = s.arrays()
+    # residue 3 loses its last atom (CB) -> virtual CB from (ca, n, c); all three kept
+    assert s.n == 3
+    assert list(a["chain"]) == [ord("B"), ord("C"), ord("C")]
+    assert list(a["bfac"]) == [20.0, 30.0, 30.0]
+    assert list(a["aa"]) == [0, 15, 8]
+    assert np.array_equal(a["cb_xyz"][0], xyz[3]) and not np.array_equal(a["cb_xyz"][2], xyz[11])
+
+
+def test_f32_display():
+    L = oracle.lib()
+    buf = C.create_string_buffer(64)
+    for v, want in [(50.0, "50"), (0.0, "0"), (13.540419, "13.540419"), (0.1, "0.1"), (1e-7, "0.0000001"),
+                    (float("nan"), "NaN"), (1.5e10, "15000000000"), (34.239895, "34.239895")]:
+        L.fdo_format_f32_display(v, buf, 64)
+        assert buf.value.decode() == want, (v, buf.value)
