@@ -1,0 +1,101 @@
+"""ctypes binding of libfdgpu.so (include/fdgpu.h). The library is the product; there is no
+Python or CPU fallback: if the shared object is missing or no MI355X answers, calls raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfdgpu.so")
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+f32p = C.POINTER(C.c_float)
+VP = C.c_void_p
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [("n_struct", C.c_uint64), ("res_off", u64p), ("n_xyz", f32p), ("ca_xyz", f32p), ("cb_xyz", f32p),
+                ("aa", u8p), ("cb_valid", u8p)]
+
+
+class HashParams(C.Structure):
+    _fields_ = [("nbin_dist", C.c_uint32), ("nbin_angle", C.c_uint32), ("dist_cutoff", C.c_float)]
+
+
+class CountRec(C.Structure):
+    _fields_ = [("nid", C.c_uint32), ("total_match_count", C.c_uint32), ("node_count", C.c_uint32),
+                ("edge_count", C.c_uint32), ("idf", C.c_float)]
+
+
+class PairRec(C.Structure):
+    _fields_ = [("cand", C.c_uint32), ("i", C.c_uint32), ("j", C.c_uint32), ("hash", C.c_uint32)]
+
+
+class CandRec(C.Structure):
+    _fields_ = [("cand", C.c_uint32), ("qi", C.c_uint32), ("i", C.c_uint32), ("j", C.c_uint32)]
+
+
+class MatchQuery(C.Structure):
+    _fields_ = [("hashes", u32p), ("n_hashes", C.c_uint64), ("aad_aa1", u8p), ("aad_aa2", u8p), ("aad_dist", f32p),
+                ("aad_qi", u32p), ("n_aad", C.c_uint64), ("ca_distance_cutoff", C.c_float), ("use_aa_prefilter", C.c_int)]
+
+
+# every symbol include/fdgpu.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("fdgpu_create", C.c_int, [C.c_int, C.POINTER(VP)]),
+    ("fdgpu_destroy", None, [VP]),
+    ("fdgpu_set_stream", C.c_int, [VP, VP]),
+    ("fdgpu_synchronize", C.c_int, [VP]),
+    ("fdgpu_last_error", C.c_char_p, [VP]),
+    ("fdgpu_free", None, [VP]),
+    ("fdgpu_version", C.c_char_p, []),
+    ("fdgpu_batch_upload", C.c_int, [VP, C.POINTER(BatchDesc), C.POINTER(VP)]),
+    ("fdgpu_batch_wrap_device", C.c_int, [VP, C.POINTER(BatchDesc), C.c_uint64, C.POINTER(VP)]),
+    ("fdgpu_batch_destroy", None, [VP]),
+    ("fdgpu_batch_num_structures", C.c_uint64, [VP]),
+    ("fdgpu_batch_num_residues", C.c_uint64, [VP]),
+    ("fdgpu_hash_batch", C.c_int, [VP, VP, C.POINTER(HashParams), C.c_int, C.POINTER(u32p), C.POINTER(u64p)]),
+    ("fdgpu_index_build", C.c_int, [VP, VP, C.POINTER(HashParams), C.c_uint64, C.POINTER(VP)]),
+    ("fdgpu_index_export", C.c_int, [VP, VP, C.POINTER(u8p), u64p, C.POINTER(u32p), C.POINTER(u64p), u64p]),
+    ("fdgpu_index_load", C.c_int, [VP, u32p, u64p, C.c_uint64, u8p, C.c_uint64, C.c_uint64, C.POINTER(VP)]),
+    ("fdgpu_index_destroy", None, [VP]),
+    ("fdgpu_index_num_hashes", C.c_uint64, [VP]),
+    ("fdgpu_index_value_len", C.c_uint64, [VP]),
+    ("fdgpu_index_num_postings", C.c_uint64, [VP]),
+    ("fdgpu_index_save", C.c_int, [VP, VP, C.c_char_p]),
+    ("fdgpu_posting_lengths", C.c_int, [VP, VP, u32p, C.c_uint64, u64p]),
+    ("fdgpu_count_query", C.c_int, [VP, VP, u32p, u32p, u32p, f32p, C.c_uint64, f32p, C.POINTER(C.POINTER(CountRec)), u64p]),
+    ("fdgpu_match_pairs", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(MatchQuery), C.POINTER(HashParams),
+                                    C.POINTER(C.POINTER(PairRec)), u64p, C.POINTER(C.POINTER(CandRec)), u64p]),
+    ("fdgpu_kabsch_batch", C.c_int, [VP, f32p, f32p, u64p, C.c_uint64, f32p, f32p, f32p]),
+    ("fdgpu_last_timings", C.c_int, [VP, C.POINTER(C.c_char_p), f32p, u64p, C.c_int]),
+    ("fdgpu_enable_timing", C.c_int, [VP, C.c_int]),
+    ("fdgpu_debug_libm", C.c_int, [VP, C.c_int, f32p, f32p, f32p, C.c_uint64]),
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libfdgpu.so. `import torch` first (if torch is installed) so that the HIP runtime torch
+    bundles is the one both share (same SONAME libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m folddisco_amd.build` (hipcc, gfx950). "
+            "folddisco_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (shares the HIP runtime; optional)
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L

@@ -1,0 +1,273 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C ABI.
+
+Names follow the reference: `Folddisco` index builder (src/controller/mod.rs:49-71),
+`FolddiscoIndex` (src/index/indextable.rs:8-18), `count_query` (src/controller/count_query.rs:82),
+`get_geometric_hash_as_u32_from_structure` (src/controller/feature.rs:198).  Everything numeric
+happens in libfdgpu.so on the GPU; this module only marshals numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import BatchDesc, CountRec, HashParams, f32p, u8p, u32p, u64p
+
+
+class FdgpuError(RuntimeError):
+    pass
+
+
+def _ptr(a: np.ndarray, t):
+    return a.ctypes.data_as(t)
+
+
+@dataclass
+class PackedStructures:
+    """CompactStructure batch flattened (fd_batch_desc). res_off[s]..res_off[s+1] = residues of structure s."""
+    res_off: np.ndarray   # u64 [S+1]
+    n_xyz: np.ndarray     # f32 [R,3]
+    ca_xyz: np.ndarray
+    cb_xyz: np.ndarray
+    aa: np.ndarray        # u8 [R]
+    cb_valid: np.ndarray | None = None
+
+    def __post_init__(self):
+        self.res_off = np.ascontiguousarray(self.res_off, dtype=np.uint64)
+        self.n_xyz = np.ascontiguousarray(self.n_xyz, dtype=np.float32).reshape(-1, 3)
+        self.ca_xyz = np.ascontiguousarray(self.ca_xyz, dtype=np.float32).reshape(-1, 3)
+        self.cb_xyz = np.ascontiguousarray(self.cb_xyz, dtype=np.float32).reshape(-1, 3)
+        self.aa = np.ascontiguousarray(self.aa, dtype=np.uint8)
+        if self.cb_valid is not None:
+            self.cb_valid = np.ascontiguousarray(self.cb_valid, dtype=np.uint8)
+        R = int(self.res_off[-1])
+        if not (len(self.n_xyz) == len(self.ca_xyz) == len(self.cb_xyz) == len(self.aa) == R):
+            raise ValueError("PackedStructures: array lengths do not match res_off[-1]")
+
+    @property
+    def n_struct(self) -> int:
+        return len(self.res_off) - 1
+
+    @property
+    def nres(self) -> np.ndarray:
+        return np.diff(self.res_off.astype(np.int64)).astype(np.uint64)
+
+    @staticmethod
+    def concat(items) -> "PackedStructures":
+        items = list(items)
+        lens = [len(it["aa"]) for it in items]
+        off = np.zeros(len(items) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(lens)
+        cat = lambda k, w: (np.concatenate([np.asarray(it[k]).reshape(-1, w) for it in items]) if items else np.zeros((0, w)))
+        cbv = None
+        if any(it.get("cb_ok") is not None for it in items):
+            cbv = np.concatenate([np.asarray(it.get("cb_ok") if it.get("cb_ok") is not None else np.ones(len(it["aa"]), np.uint8)) for it in items])
+        return PackedStructures(off, cat("n_xyz", 3), cat("ca_xyz", 3), cat("cb_xyz", 3),
+                                np.concatenate([np.asarray(it["aa"], dtype=np.uint8) for it in items]) if items else np.zeros(0, np.uint8), cbv)
+
+
+class Context:
+    """fdgpu_ctx: one per GPU."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        rc = self.L.fdgpu_create(device, C.byref(h))
+        self.h = h
+        if rc != 0:
+            msg = self.L.fdgpu_last_error(h).decode() if h else "fdgpu_create failed"
+            if h:
+                self.L.fdgpu_destroy(h)
+            self.h = None
+            raise FdgpuError(f"fdgpu_create({device}) failed ({rc}): {msg}")
+        if stream is not None:
+            self.check(self.L.fdgpu_set_stream(self.h, C.c_void_p(stream)))
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise FdgpuError(f"libfdgpu error {rc}: {self.L.fdgpu_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fdgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self.check(self.L.fdgpu_synchronize(self.h))
+
+    def enable_timing(self, on: bool = True):
+        self.check(self.L.fdgpu_enable_timing(self.h, int(on)))
+
+    def last_timings(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        by = (C.c_uint64 * cap)()
+        n = self.L.fdgpu_last_timings(self.h, names, ms, by, cap)
+        return [(names[i].decode(), float(ms[i]), int(by[i])) for i in range(n)]
+
+    # ---- batches
+    def upload(self, ps: PackedStructures) -> "Batch":
+        d = BatchDesc(ps.n_struct, _ptr(ps.res_off, u64p), _ptr(ps.n_xyz, f32p), _ptr(ps.ca_xyz, f32p), _ptr(ps.cb_xyz, f32p),
+                      _ptr(ps.aa, u8p), _ptr(ps.cb_valid, u8p) if ps.cb_valid is not None else None)
+        h = C.c_void_p()
+        self.check(self.L.fdgpu_batch_upload(self.h, C.byref(d), C.byref(h)))
+        return Batch(self, h, ps.n_struct)
+
+    def wrap_device(self, n_struct: int, total_residues: int, res_off_ptr: int, n_ptr: int, ca_ptr: int, cb_ptr: int, aa_ptr: int,
+                    cb_valid_ptr: int | None = None, keepalive=None) -> "Batch":
+        d = BatchDesc(n_struct, C.cast(res_off_ptr, u64p), C.cast(n_ptr, f32p), C.cast(ca_ptr, f32p), C.cast(cb_ptr, f32p),
+                      C.cast(aa_ptr, u8p), C.cast(cb_valid_ptr, u8p) if cb_valid_ptr else None)
+        h = C.c_void_p()
+        self.check(self.L.fdgpu_batch_wrap_device(self.h, C.byref(d), total_residues, C.byref(h)))
+        b = Batch(self, h, n_struct)
+        b._keepalive = keepalive
+        return b
+
+
+class Batch:
+    def __init__(self, ctx: Context, h, n_struct: int):
+        self.ctx, self.h, self.n_struct = ctx, h, n_struct
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.L.fdgpu_batch_destroy(self.h)
+        except Exception:
+            pass
+
+
+def _params(nbin_dist=0, nbin_angle=0, dist_cutoff=20.0) -> HashParams:
+    return HashParams(nbin_dist, nbin_angle, dist_cutoff)
+
+
+def get_geometric_hash_as_u32(ctx: Context, batch: Batch, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, sort_dedup=True):
+    """S1 for every structure of the batch -> (hashes u32[...], off u64[S+1])."""
+    p = _params(nbin_dist, nbin_angle, dist_cutoff)
+    hp, op = u32p(), u64p()
+    ctx.check(ctx.L.fdgpu_hash_batch(ctx.h, batch.h, C.byref(p), int(sort_dedup), C.byref(hp), C.byref(op)))
+    off = np.ctypeslib.as_array(op, shape=(batch.n_struct + 1,)).copy()
+    n = int(off[-1])
+    h = np.ctypeslib.as_array(hp, shape=(max(n, 1),))[:n].copy()
+    ctx.L.fdgpu_free(hp)
+    ctx.L.fdgpu_free(op)
+    return h, off
+
+
+class FolddiscoIndex:
+    """Inverted index resident in HBM (fdgpu_index)."""
+
+    def __init__(self, ctx: Context, h, n_structures: int, first_id: int = 0):
+        self.ctx, self.h, self.n_structures, self.first_id = ctx, h, n_structures, first_id
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.L.fdgpu_index_destroy(self.h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def build(ctx: Context, batch: Batch, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, first_id=0) -> "FolddiscoIndex":
+        p = _params(nbin_dist, nbin_angle, dist_cutoff)
+        h = C.c_void_p()
+        ctx.check(ctx.L.fdgpu_index_build(ctx.h, batch.h, C.byref(p), first_id, C.byref(h)))
+        return FolddiscoIndex(ctx, h, batch.n_struct, first_id)
+
+    @staticmethod
+    def load(ctx: Context, hashes: np.ndarray, offsets: np.ndarray, value: np.ndarray, n_structures: int) -> "FolddiscoIndex":
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        value = np.ascontiguousarray(value, dtype=np.uint8)
+        h = C.c_void_p()
+        ctx.check(ctx.L.fdgpu_index_load(ctx.h, _ptr(hashes, u32p), _ptr(offsets, u64p), len(hashes), _ptr(value, u8p), len(value),
+                                         n_structures, C.byref(h)))
+        return FolddiscoIndex(ctx, h, n_structures)
+
+    @property
+    def num_hashes(self) -> int:
+        return int(self.ctx.L.fdgpu_index_num_hashes(self.h))
+
+    @property
+    def value_len(self) -> int:
+        return int(self.ctx.L.fdgpu_index_value_len(self.h))
+
+    @property
+    def num_postings(self) -> int:
+        return int(self.ctx.L.fdgpu_index_num_postings(self.h))
+
+    def export(self):
+        """-> (value u8[], hashes u32[H], offsets u64[H+1]) in the on-disk layout."""
+        vp, hp, op = u8p(), u32p(), u64p()
+        vl, H = C.c_uint64(), C.c_uint64()
+        L = self.ctx.L
+        self.ctx.check(L.fdgpu_index_export(self.ctx.h, self.h, C.byref(vp), C.byref(vl), C.byref(hp), C.byref(op), C.byref(H)))
+        v = np.ctypeslib.as_array(vp, shape=(max(vl.value, 1),))[: vl.value].copy()
+        h = np.ctypeslib.as_array(hp, shape=(max(H.value, 1),))[: H.value].copy()
+        o = np.ctypeslib.as_array(op, shape=(H.value + 1,)).copy()
+        for p in (vp, hp, op):
+            L.fdgpu_free(p)
+        return v, h, o
+
+    def save(self, prefix: str):
+        self.ctx.check(self.ctx.L.fdgpu_index_save(self.ctx.h, self.h, prefix.encode()))
+
+    def posting_lengths(self, q_hash: np.ndarray) -> np.ndarray:
+        q = np.ascontiguousarray(q_hash, dtype=np.uint32)
+        out = np.zeros(len(q), dtype=np.uint64)
+        self.ctx.check(self.ctx.L.fdgpu_posting_lengths(self.ctx.h, self.h, _ptr(q, u32p), len(q), _ptr(out, u64p)))
+        return out
+
+
+def length_penalty(nres: np.ndarray, lp: float = 0.5) -> np.ndarray:
+    """(nres as f32).powf(-lp) per structure (count_query.rs:200), evaluated with the C library's powf."""
+    libm = C.CDLL("libm.so.6")
+    libm.powf.restype = C.c_float
+    libm.powf.argtypes = [C.c_float, C.c_float]
+    return np.array([libm.powf(float(np.float32(n)), -lp) for n in np.asarray(nres)], dtype=np.float32)
+
+
+def idf_of_lengths(lengths: np.ndarray, total_structures: int) -> np.ndarray:
+    """log2(S / len) in f32 with the C library's log2f (query.rs:26, count_query.rs:130)."""
+    libm = C.CDLL("libm.so.6")
+    libm.log2f.restype = C.c_float
+    libm.log2f.argtypes = [C.c_float]
+    S = np.float32(total_structures)
+    out = np.zeros(len(lengths), dtype=np.float32)
+    for k, n in enumerate(np.asarray(lengths)):
+        out[k] = libm.log2f(float(S / np.float32(n))) if n > 0 else np.inf
+    return out
+
+
+def count_query(ctx: Context, index: FolddiscoIndex, q_hash, q_node, q_edge_j, penalty: np.ndarray, total_structures: int | None = None,
+                freq_filter: float | None = None):
+    """count_query (src/controller/count_query.rs:82-220) -> list of fd_count_rec dicts, ascending nid."""
+    q_hash = np.ascontiguousarray(q_hash, dtype=np.uint32)
+    q_node = np.ascontiguousarray(q_node, dtype=np.uint32)
+    q_edge_j = np.ascontiguousarray(q_edge_j, dtype=np.uint32)
+    S = index.n_structures if total_structures is None else total_structures
+    lens = index.posting_lengths(q_hash)
+    keep = np.ones(len(q_hash), dtype=bool)
+    if freq_filter is not None:
+        keep &= ~((lens.astype(np.float32) / np.float32(S)) > np.float32(freq_filter))
+    keep &= lens > 0
+    idf = idf_of_lengths(lens, S)
+    qh, qn, qe, qi = (np.ascontiguousarray(a[keep]) for a in (q_hash, q_node, q_edge_j, idf.astype(np.float32)))
+    pen = np.ascontiguousarray(penalty, dtype=np.float32)
+    out = C.POINTER(CountRec)()
+    n = C.c_uint64()
+    ctx.check(ctx.L.fdgpu_count_query(ctx.h, index.h, _ptr(qh, u32p), _ptr(qn, u32p), _ptr(qe, u32p), _ptr(qi, f32p), len(qh),
+                                      _ptr(pen, f32p), C.byref(out), C.byref(n)))
+    res = [dict(nid=out[k].nid, total_match_count=out[k].total_match_count, node_count=out[k].node_count,
+                edge_count=out[k].edge_count, idf=float(out[k].idf)) for k in range(n.value)]
+    ctx.L.fdgpu_free(out)
+    return res

@@ -1,0 +1,59 @@
+"""Builds folddisco_amd/libfdgpu.so (gfx950) in-tree with hipcc.
+
+Flags that matter for bit-parity with the reference (see csrc/fd_libm.h):
+  -ffp-contract=off   no FMA contraction: every f32/f64 op rounds like the Rust/glibc original
+  (no -ffast-math)    IEEE division and sqrt (hipcc default: correctly rounded), denormals kept
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libfdgpu.so")
+SOURCES = ["fdgpu_api.hip", "k_hash.hip", "k_sort.hip", "k_index.hip", "k_query.hip", "k_match.hip"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "fdgpu.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for s in srcs:
+        o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+               "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((subprocess.Popen(cmd), s))
+        objs.append(o)
+    for p, s in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,46 @@
+// fd_device.h — internal device-side types shared by the kernels and the C ABI glue.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fd_geom.h"
+
+#define FD_WAVE 64
+
+// Packed structures resident in HBM (fdgpu_batch). Coordinates stay in the caller's
+// interleaved xyz layout (12 B per atom, 37 B per residue with aa): they are 37·R bytes against
+// ~8·80·R bytes of keys written, so their layout is irrelevant for HBM traffic; what matters is
+// that one structure (R·37 B ≈ 12 KB) stays L1/L2 resident while its R/64 tiles are processed.
+struct fd_batch_view {
+    const float *n_xyz, *ca_xyz, *cb_xyz;
+    const uint8_t *aa;
+    const uint8_t *hash_ok;      // aa != 255 && cb_valid (precomputed at upload)
+    const uint32_t *res_off;     // [S+1]
+    const uint32_t *wi_struct;   // [W] work item -> structure
+    const uint32_t *wi_i0;       // [W] work item -> first residue (absolute) of its 64-residue i-tile
+    uint32_t n_struct;
+    uint32_t n_work;
+};
+
+struct fd_hash_consts {
+    fd_quant q;
+    float d2_max;   // largest f32 whose sqrt is <= dist_cutoff: sqrtf(d2) > cutoff  <=>  d2 > d2_max
+};
+
+__device__ __forceinline__ fd_v3 fd_load3(const float *p, uint32_t r) {
+    const float *q = p + 3ull * r;
+    return {q[0], q[1], q[2]};
+}
+
+// XCD-aware work remap: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md); map
+// consecutive logical work items (tiles of the same structure) to the same XCD so that a
+// structure's coordinates are fetched into one L2 only.
+__device__ __forceinline__ uint32_t fd_xcd_remap(uint32_t b, uint32_t n) {
+    uint32_t per = (n + 7u) / 8u;
+    uint32_t w = (b & 7u) * per + (b >> 3);
+    return w;  // may be >= n for the padded tail; caller checks
+}
+
+__device__ __forceinline__ uint32_t fd_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t fd_mbcnt(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}

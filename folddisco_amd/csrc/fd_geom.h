@@ -1,0 +1,93 @@
+// fd_geom.h — residue-pair descriptor and PDBTrRosetta hash, device side.
+// Operation order follows the reference exactly so that every f32 intermediate is
+// bit-identical (compile with -ffp-contract=off):
+//   descriptor   src/structure/core.rs:378-403 (get_pdb_tr_feature)
+//   distance     src/structure/coordinate.rs:109-115
+//   angle        src/structure/coordinate.rs:118-133
+//   torsion      src/structure/coordinate.rs:204-215 (+ cross/normalize/dot :39-76)
+//   quantiser    src/utils/convert.rs:32-36
+//   hash         src/geometry/pdb_tr.rs:21-75
+#pragma once
+#include "fd_libm.h"
+
+struct fd_v3 { float x, y, z; };
+
+FD_HD fd_v3 fd_sub(fd_v3 a, fd_v3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+FD_HD float fd_dot(fd_v3 a, fd_v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+FD_HD fd_v3 fd_cross(fd_v3 a, fd_v3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+FD_HD fd_v3 fd_normalize(fd_v3 a) {
+    float n = fd_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    return {a.x / n, a.y / n, a.z / n};
+}
+FD_HD float fd_dist(fd_v3 a, fd_v3 b) {
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return fd_sqrtf(dx * dx + dy * dy + dz * dz);
+}
+FD_HD float fd_dist2(fd_v3 a, fd_v3 b) {  // the argument of the sqrt above, same rounding
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// Rust `as u32` on f32: saturating, NaN -> 0
+FD_HD uint32_t fd_sat_u32(float v) {
+    if (!(v == v)) return 0u;
+    if (v <= 0.0f) return 0u;
+    if (v >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)v;
+}
+
+// quantiser constants (min, 1/((max-min)/(nb-1))) are computed once on the host in f32
+struct fd_quant {
+    float dist_disc;   // 1/((20-2)/(nbin_dist-1))
+    float ang_disc;    // 1/((1-(-1))/(nbin_angle-1))
+};
+FD_HD uint32_t fd_q(float v, float mn, float disc) { return fd_sat_u32((v - mn) * disc + 0.5f); }
+
+struct fd_feature { float ca_dist, cb_dist, angle, tor1, tor2; };
+
+// angle between (cb1-ca1) and (cb2-ca2) — coordinate.rs:118-133 with a=ca1,b=cb1,c=ca2,d=cb2
+FD_HD float fd_calc_angle(fd_v3 a, fd_v3 b, fd_v3 c, fd_v3 d) {
+    fd_v3 v1 = {b.x - a.x, b.y - a.y, b.z - a.z};
+    fd_v3 v2 = {d.x - c.x, d.y - c.y, d.z - c.z};
+    float dt = v1.x * v2.x + v1.y * v2.y + v1.z * v2.z;
+    float l1 = fd_sqrtf(v1.x * v1.x + v1.y * v1.y + v1.z * v1.z);
+    float l2 = fd_sqrtf(v2.x * v2.x + v2.y * v2.y + v2.z * v2.z);
+    return fdd_acosf(dt / (l1 * l2));
+}
+FD_HD float fd_calc_torsion(fd_v3 a, fd_v3 b, fd_v3 c, fd_v3 d) {
+    fd_v3 v1 = fd_sub(b, a), v2 = fd_sub(c, b), v3 = fd_sub(d, c);
+    fd_v3 r = fd_normalize(fd_cross(v1, v2));
+    fd_v3 s = fd_normalize(fd_cross(v2, v3));
+    fd_v3 t = fd_normalize(fd_cross(r, fd_normalize(v2)));
+    float x = fd_dot(r, s);
+    float y = fd_dot(s, t);
+    return -fdd_atan2f(y, x);
+}
+
+// full descriptor for an ordered pair; the caller has already applied the rejection rules
+// (i != j, aa != 255, CB present, d_CA <= cutoff)
+FD_HD fd_feature fd_pair_feature(fd_v3 n1, fd_v3 ca1, fd_v3 cb1, fd_v3 n2, fd_v3 ca2, fd_v3 cb2) {
+    fd_feature f;
+    f.ca_dist = fd_dist(ca1, ca2);
+    f.cb_dist = fd_dist(cb1, cb2);
+    f.angle = fd_calc_angle(ca1, cb1, ca2, cb2);
+    f.tor1 = fd_calc_torsion(n1, ca1, cb1, cb2);
+    f.tor2 = fd_calc_torsion(cb1, cb2, ca2, n2);
+    return f;
+}
+
+// pdb_tr.rs:21-75; fields OR-ed unmasked
+FD_HD uint32_t fd_hash_pdbtr(uint32_t aa1, uint32_t aa2, fd_feature f, fd_quant q) {
+    uint32_t ca = fd_q(f.ca_dist, 2.0f, q.dist_disc);
+    uint32_t cb = fd_q(f.cb_dist, 2.0f, q.dist_disc);
+    float s0, c0, s1, c1, s2, c2;
+    fdd_sincosf(f.angle, &s0, &c0);
+    fdd_sincosf(f.tor1, &s1, &c1);
+    fdd_sincosf(f.tor2, &s2, &c2);
+    uint32_t qs0 = fd_q(s0, -1.0f, q.ang_disc), qc0 = fd_q(c0, -1.0f, q.ang_disc);
+    uint32_t qs1 = fd_q(s1, -1.0f, q.ang_disc), qc1 = fd_q(c1, -1.0f, q.ang_disc);
+    uint32_t qs2 = fd_q(s2, -1.0f, q.ang_disc), qc2 = fd_q(c2, -1.0f, q.ang_disc);
+    return aa1 << 25 | aa2 << 20 | ca << 16 | cb << 12 | qs0 << 10 | qc0 << 8 | qs1 << 6 | qc1 << 4 | qs2 << 2 | qc2;
+}

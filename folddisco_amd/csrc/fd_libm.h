@@ -235,3 +235,110 @@ FD_HD float fd_atan2f(float y, float x) {
         default: return (z - pi_lo) - pi;
     }
 }
+
+// =============================================================================
+// Branch-lean forms used inside the gfx950 kernels.  Same IEEE operations on the
+// same operands as the functions above (so bit-identical results), but written
+// with selects instead of region branches so that a 64-lane wavefront does not
+// serialise over the regions.  tools/check_libm.c checks them too.
+// =============================================================================
+
+// sinf(y) and cosf(y) together: one sine- and one cosine-polynomial evaluation.
+// For |y| < 0.75 glibc skips the reduction; the reduction yields n = 0, xr = y
+// exactly there, so the unified path is identical (tiny |y| handled by select).
+FD_HD void fdd_sincosf(float y, float *sn, float *cs) {
+    uint32_t top = (fd_f2u(y) >> 20) & 0x7ff;
+    double x = (double)y;
+    double r = x * FD_HPI_INV;
+    // outside |y| < 120 (incl. NaN/inf) the result is NaN; keep the int conversion defined
+    int valid = top < 0x42f;
+    int n = valid ? (((int32_t)r + 0x800000) >> 24) : 0;
+    double xr = fd_fma(-(double)n, FD_HPI, x);
+    double x2 = xr * xr;
+    double sgn = ((n + 1) & 2) ? -1.0 : 1.0;  // sign[n&3] = {1,-1,-1,1}
+    float S = fd_sin_poly(xr * sgn, x2);
+    float Cp = fd_cos_poly(x2, n & 2);
+    float s_out = (n & 1) ? Cp : S;
+    float c_out = (n & 1) ? S : Cp;
+    if (top < 0x398) { s_out = y; c_out = 1.0f; }
+    if (!valid) { s_out = fd_u2f(0x7fc00000u); c_out = s_out; }
+    *sn = s_out;
+    *cs = c_out;
+}
+
+FD_HD float fdd_acosf(float x) {
+    const float one = 1.0f, pi = fd_u2f(0x40490fdau), pio2_hi = fd_u2f(0x3fc90fdau),
+                pio2_lo = fd_u2f(0x33a22168u),
+                pS0 = fd_u2f(0x3e2aaaabu), pS1 = fd_u2f(0xbea6b090u), pS2 = fd_u2f(0x3e4e0aa8u),
+                pS3 = fd_u2f(0xbd241146u), pS4 = fd_u2f(0x3a4f7f04u), pS5 = fd_u2f(0x3811ef08u),
+                qS1 = fd_u2f(0xc019d139u), qS2 = fd_u2f(0x4001572du), qS3 = fd_u2f(0xbf303361u),
+                qS4 = fd_u2f(0x3d9dc62eu);
+    int32_t hx = (int32_t)fd_f2u(x);
+    int32_t ix = hx & 0x7fffffff;
+    int small = ix < 0x3f000000;
+    float z = small ? x * x : ((hx < 0 ? one + x : one - x) * 0.5f);
+    float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    float r = p / q;
+    float s = fd_sqrtf(z);
+    float res_small = pio2_hi - (x - (pio2_lo - x * r));
+    float w_neg = r * s - pio2_lo;
+    float res_neg = pi - 2.0f * (s + w_neg);
+    float df = fd_u2f(fd_f2u(s) & 0xfffff000u);
+    float c = (z - df * df) / (s + df);
+    float w_pos = r * s + c;
+    float res_pos = 2.0f * (df + w_pos);
+    float res = small ? res_small : (hx < 0 ? res_neg : res_pos);
+    if (small && ix <= 0x32800000) res = pio2_hi + pio2_lo;
+    if (ix == 0x3f800000) res = hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ix > 0x3f800000) res = fd_u2f(0x7fc00000u);
+    return res;
+}
+
+FD_HD float fdd_atanf(float x) {
+    const float aT0 = fd_u2f(0x3eaaaaabu), aT1 = fd_u2f(0xbe4ccccdu), aT2 = fd_u2f(0x3e124925u),
+                aT3 = fd_u2f(0xbde38e38u), aT4 = fd_u2f(0x3dba2e6eu), aT5 = fd_u2f(0xbd9d8795u),
+                aT6 = fd_u2f(0x3d886b35u), aT7 = fd_u2f(0xbd6ef16bu), aT8 = fd_u2f(0x3d4bda59u),
+                aT9 = fd_u2f(0xbd15a221u), aT10 = fd_u2f(0x3c8569d7u);
+    int32_t hx = (int32_t)fd_f2u(x);
+    int32_t ix = hx & 0x7fffffff;
+    float ax = fd_fabsf(x);
+    // region: -1 (|x|<7/16), 0, 1, 2, 3
+    int id = ix < 0x3ee00000 ? -1 : (ix < 0x3f300000 ? 0 : (ix < 0x3f980000 ? 1 : (ix < 0x401c0000 ? 2 : 3)));
+    float num = id == 0 ? 2.0f * ax - 1.0f : (id == 1 ? ax - 1.0f : (id == 2 ? ax - 1.5f : -1.0f));
+    float den = id == 0 ? 2.0f + ax : (id == 1 ? ax + 1.0f : (id == 2 ? 1.0f + 1.5f * ax : ax));
+    float xr = id < 0 ? x : num / den;
+    float hi = id == 0 ? fd_u2f(0x3eed6338u) : (id == 1 ? fd_u2f(0x3f490fdau) : (id == 2 ? fd_u2f(0x3f7b985eu) : fd_u2f(0x3fc90fdau)));
+    float lo = id == 0 ? fd_u2f(0x31ac3769u) : (id == 1 ? fd_u2f(0x33222168u) : (id == 2 ? fd_u2f(0x33140fb4u) : fd_u2f(0x33a22168u)));
+    float z = xr * xr;
+    float w = z * z;
+    float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    float zz = hi - ((xr * (s1 + s2) - lo) - xr);
+    float res = id < 0 ? xr - xr * (s1 + s2) : (hx < 0 ? -zz : zz);
+    if (ix < 0x31000000) res = x;
+    if (ix >= 0x4c000000) {
+        float big = fd_u2f(0x3fc90fdau) + fd_u2f(0x33a22168u);
+        res = ix > 0x7f800000 ? x + x : (hx > 0 ? big : -big);
+    }
+    return res;
+}
+
+// atan2f with the generic path branch-free; special operands fall back to fd_atan2f's logic.
+FD_HD float fdd_atan2f(float y, float x) {
+    const float pi = fd_u2f(0x40490fdbu), pi_lo = fd_u2f(0xb3bbbd2eu), pi_o_2 = fd_u2f(0x3fc90fdbu);
+    int32_t hx = (int32_t)fd_f2u(x), hy = (int32_t)fd_f2u(y);
+    int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    // anything unusual (NaN, inf, zero operand, x == 1.0): exact slow path
+    if (ix >= 0x7f800000 || iy >= 0x7f800000 || ix == 0 || iy == 0 || hx == 0x3f800000) return fd_atan2f(y, x);
+    int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    int32_t k = (iy - ix) >> 23;
+    float z = fdd_atanf(fd_fabsf(y / x));
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    float r0 = z;
+    float r1 = fd_u2f(fd_f2u(z) ^ 0x80000000u);
+    float r2 = pi - (z - pi_lo);
+    float r3 = (z - pi_lo) - pi;
+    return m == 0 ? r0 : (m == 1 ? r1 : (m == 2 ? r2 : r3));
+}

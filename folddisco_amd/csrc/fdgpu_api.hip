@@ -1,0 +1,752 @@
+// fdgpu_api.hip — C ABI of libfdgpu.so (include/fdgpu.h): context, HBM residency, and the
+// orchestration of the kernels in k_hash.hip / k_sort.hip / k_index.hip / k_query.hip / k_match.hip.
+// No CPU fallback exists: every entry point fails with FDGPU_EHIP if no gfx950 device answers.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include "fdgpu_internal.h"
+
+#define HIPCHK(ctx, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) {                                                                             \
+            char _b[512];                                                                                   \
+            snprintf(_b, sizeof _b, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));  \
+            (ctx)->err = _b;                                                                                \
+            return FDGPU_EHIP;                                                                              \
+        }                                                                                                   \
+    } while (0)
+
+#define FAIL(ctx, code, msg) do { (ctx)->err = (msg); return (code); } while (0)
+
+// ---- small kernels used only here ------------------------------------------------------------------
+__global__ void k_uniq_flags(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ids, uint64_t n, uint8_t *__restrict__ flags) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) flags[p] = (p == 0 || keys[p] != keys[p - 1] || ids[p] != ids[p - 1]) ? 1 : 0;
+}
+__global__ void k_compact(const uint32_t *__restrict__ keys, const uint8_t *__restrict__ flags, const uint64_t *__restrict__ pos, uint64_t n,
+                          uint32_t *__restrict__ out) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && flags[p]) out[pos[p]] = keys[p];
+}
+__global__ void k_gather_u64(const uint64_t *__restrict__ src, const uint64_t *__restrict__ idx, uint64_t n, uint64_t *__restrict__ dst) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) dst[p] = src[idx[p]];
+}
+void fd_launch_uniq_flags(const uint32_t *keys, const uint32_t *ids, uint64_t n, uint8_t *flags, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_uniq_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, ids, n, flags);
+}
+void fd_launch_compact(const uint32_t *keys, const uint8_t *flags, const uint64_t *pos, uint64_t n, uint32_t *out, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_compact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, flags, pos, n, out);
+}
+void fd_launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t n, uint64_t *dst, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_gather_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, idx, n, dst);
+}
+
+// ---- timing helpers -------------------------------------------------------------------------------------
+static hipEvent_t next_event(fdgpu_ctx *c) {
+    if (c->event_used == c->event_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->event_pool.push_back(e);
+    }
+    return c->event_pool[c->event_used++];
+}
+struct StageTimer {
+    fdgpu_ctx *c;
+    size_t idx = (size_t)-1;
+    StageTimer(fdgpu_ctx *ctx, const char *name, uint64_t bytes) : c(ctx) {
+        if (!c->timing) return;
+        fd_timing_entry t;
+        t.name = name; t.bytes = bytes; t.ev0 = next_event(c); t.ev1 = next_event(c);
+        if (!t.ev0 || !t.ev1) return;
+        (void)hipEventRecord(t.ev0, c->stream);
+        c->timings.push_back(t);
+        idx = c->timings.size() - 1;
+    }
+    void set_bytes(uint64_t b) { if (idx != (size_t)-1) c->timings[idx].bytes = b; }
+    ~StageTimer() { if (idx != (size_t)-1) (void)hipEventRecord(c->timings[idx].ev1, c->stream); }
+};
+static void reset_timings(fdgpu_ctx *c) { c->timings.clear(); c->event_used = 0; }
+
+// ---- context ------------------------------------------------------------------------------------------------
+extern "C" const char *fdgpu_version(void) { return "folddisco_amd 0.1 (gfx950)"; }
+
+extern "C" int fdgpu_create(int device, fdgpu_ctx **out) {
+    if (!out) return FDGPU_EINVAL;
+    *out = nullptr;
+    fdgpu_ctx *c = new (std::nothrow) fdgpu_ctx();
+    if (!c) return FDGPU_ENOMEM;
+    c->device = device;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        // keep the context so that the caller can read the message, but report failure
+        c->err = e != hipSuccess ? std::string("hipGetDeviceCount: ") + hipGetErrorString(e) : "no such HIP device";
+        *out = c;
+        return FDGPU_EHIP;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess) {
+        c->err = std::string("hipSetDevice/hipStreamCreate: ") + hipGetErrorString(e);
+        *out = c;
+        return FDGPU_EHIP;
+    }
+    c->own_stream = true;
+    *out = c;
+    return FDGPU_OK;
+}
+extern "C" void fdgpu_destroy(fdgpu_ctx *c) {
+    if (!c) return;
+    for (auto &b : c->ws) b.release();
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" int fdgpu_set_stream(fdgpu_ctx *c, void *s) {
+    if (!c) return FDGPU_EINVAL;
+    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    if (s) { c->stream = (hipStream_t)s; return FDGPU_OK; }
+    HIPCHK(c, hipStreamCreate(&c->stream));
+    c->own_stream = true;
+    return FDGPU_OK;
+}
+extern "C" int fdgpu_synchronize(fdgpu_ctx *c) {
+    if (!c) return FDGPU_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDGPU_OK;
+}
+extern "C" const char *fdgpu_last_error(const fdgpu_ctx *c) { return c ? c->err.c_str() : "null context"; }
+extern "C" void fdgpu_free(void *p) { free(p); }
+extern "C" int fdgpu_enable_timing(fdgpu_ctx *c, int on) { if (!c) return FDGPU_EINVAL; c->timing = on != 0; return FDGPU_OK; }
+extern "C" int fdgpu_last_timings(const fdgpu_ctx *c, const char **names, float *ms, uint64_t *bytes, int cap) {
+    if (!c) return FDGPU_EINVAL;
+    int n = 0;
+    for (auto &t : c->timings) {
+        if (n >= cap) break;
+        float m = 0.f;
+        if (hipEventElapsedTime(&m, t.ev0, t.ev1) != hipSuccess) m = -1.f;
+        if (names) names[n] = t.name;
+        if (ms) ms[n] = m;
+        if (bytes) bytes[n] = t.bytes;
+        ++n;
+    }
+    return n;
+}
+
+// ---- batches ---------------------------------------------------------------------------------------------------
+static int build_work_items(fdgpu_ctx *c, fdgpu_batch *b) {
+    // one work item per (structure, 64-residue i-tile)
+    std::vector<uint32_t> ws, wi;
+    std::vector<uint32_t> ro(b->n_struct + 1);
+    for (uint64_t s = 0; s <= b->n_struct; ++s) ro[s] = (uint32_t)b->h_res_off[s];
+    for (uint64_t s = 0; s < b->n_struct; ++s) {
+        uint64_t R = b->h_res_off[s + 1] - b->h_res_off[s];
+        if (R > 65535) FAIL(c, FDGPU_ERANGE, "structure with more than 65535 residues (reference max_residue, controller/mod.rs:40)");
+        for (uint64_t t = 0; t < R; t += FD_WAVE) { ws.push_back((uint32_t)s); wi.push_back((uint32_t)(b->h_res_off[s] + t)); }
+    }
+    if (ws.size() > 0xfffffff0ull) FAIL(c, FDGPU_ERANGE, "too many tiles in one batch");
+    b->n_work = (uint32_t)ws.size();
+    HIPCHK(c, hipMalloc((void **)&b->res_off, ro.size() * 4));
+    HIPCHK(c, hipMalloc((void **)&b->wi_struct, std::max<size_t>(ws.size(), 1) * 4));
+    HIPCHK(c, hipMalloc((void **)&b->wi_i0, std::max<size_t>(wi.size(), 1) * 4));
+    HIPCHK(c, hipMemcpyAsync(b->res_off, ro.data(), ro.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (!ws.empty()) {
+        HIPCHK(c, hipMemcpyAsync(b->wi_struct, ws.data(), ws.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(b->wi_i0, wi.data(), wi.size() * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipMalloc((void **)&b->hash_ok, std::max<uint64_t>(b->n_res, 1)));
+    fd_launch_hash_ok(b->aa, b->cb_valid, b->hash_ok, b->n_res, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
+    return FDGPU_OK;
+}
+
+extern "C" int fdgpu_batch_upload(fdgpu_ctx *c, const fd_batch_desc *h, fdgpu_batch **out) {
+    if (!c || !h || !out || !h->res_off || (h->n_struct && (!h->n_xyz || !h->ca_xyz || !h->cb_xyz || !h->aa))) return FDGPU_EINVAL;
+    *out = nullptr;
+    if (h->n_struct >= 0xffffffffull) FAIL(c, FDGPU_ERANGE, "too many structures in one batch");
+    uint64_t R = h->res_off[h->n_struct];
+    if (R >= 0xffffffffull) FAIL(c, FDGPU_ERANGE, "more than 2^32 residues in one batch");
+    fdgpu_batch *b = new (std::nothrow) fdgpu_batch();
+    if (!b) return FDGPU_ENOMEM;
+    b->ctx = c; b->owns = true; b->n_struct = h->n_struct; b->n_res = R;
+    b->h_res_off.assign(h->res_off, h->res_off + h->n_struct + 1);
+    size_t rb = std::max<uint64_t>(R, 1);
+    int rc = FDGPU_OK;
+    auto up = [&](void **d, const void *src, size_t bytes) -> int {
+        HIPCHK(c, hipMalloc(d, std::max<size_t>(bytes, 4)));
+        if (bytes) HIPCHK(c, hipMemcpyAsync(*d, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return FDGPU_OK;
+    };
+    if ((rc = up((void **)&b->n_xyz, h->n_xyz, R * 12)) || (rc = up((void **)&b->ca_xyz, h->ca_xyz, R * 12)) ||
+        (rc = up((void **)&b->cb_xyz, h->cb_xyz, R * 12)) || (rc = up((void **)&b->aa, h->aa, R))) { fdgpu_batch_destroy(b); return rc; }
+    if (h->cb_valid && (rc = up((void **)&b->cb_valid, h->cb_valid, R))) { fdgpu_batch_destroy(b); return rc; }
+    (void)rb;
+    if ((rc = build_work_items(c, b))) { fdgpu_batch_destroy(b); return rc; }
+    *out = b;
+    return FDGPU_OK;
+}
+
+extern "C" int fdgpu_batch_wrap_device(fdgpu_ctx *c, const fd_batch_desc *d, uint64_t total_residues, fdgpu_batch **out) {
+    if (!c || !d || !out || !d->res_off) return FDGPU_EINVAL;
+    *out = nullptr;
+    fdgpu_batch *b = new (std::nothrow) fdgpu_batch();
+    if (!b) return FDGPU_ENOMEM;
+    b->ctx = c; b->owns = false; b->n_struct = d->n_struct; b->n_res = total_residues;
+    b->n_xyz = (float *)d->n_xyz; b->ca_xyz = (float *)d->ca_xyz; b->cb_xyz = (float *)d->cb_xyz;
+    b->aa = (uint8_t *)d->aa; b->cb_valid = (uint8_t *)d->cb_valid;
+    b->h_res_off.resize(d->n_struct + 1);
+    hipError_t e = hipMemcpy(b->h_res_off.data(), d->res_off, (d->n_struct + 1) * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { c->err = std::string("wrap_device: ") + hipGetErrorString(e); delete b; return FDGPU_EHIP; }
+    if (b->h_res_off[d->n_struct] != total_residues) { c->err = "wrap_device: res_off[n] != total_residues"; delete b; return FDGPU_EINVAL; }
+    int rc = build_work_items(c, b);
+    if (rc) { fdgpu_batch_destroy(b); return rc; }
+    *out = b;
+    return FDGPU_OK;
+}
+
+extern "C" void fdgpu_batch_destroy(fdgpu_batch *b) {
+    if (!b) return;
+    if (b->owns) { (void)hipFree(b->n_xyz); (void)hipFree(b->ca_xyz); (void)hipFree(b->cb_xyz); (void)hipFree(b->aa); (void)hipFree(b->cb_valid); }
+    (void)hipFree(b->hash_ok); (void)hipFree(b->res_off); (void)hipFree(b->wi_struct); (void)hipFree(b->wi_i0);
+    delete b;
+}
+extern "C" uint64_t fdgpu_batch_num_structures(const fdgpu_batch *b) { return b ? b->n_struct : 0; }
+extern "C" uint64_t fdgpu_batch_num_residues(const fdgpu_batch *b) { return b ? b->n_res : 0; }
+
+// ---- hash constants ------------------------------------------------------------------------------------------------
+static fd_hash_consts make_consts(const fd_hash_params *p) {
+    // pdb_tr.rs:22-35 clamps; convert.rs:32-36 quantiser factors evaluated in f32 exactly like the reference
+    float nd = p->nbin_dist > 16 ? 16.0f : (p->nbin_dist == 0 ? 16.0f : (float)p->nbin_dist);
+    float na = p->nbin_angle > 4 ? 4.0f : (p->nbin_angle == 0 ? 4.0f : (float)p->nbin_angle);
+    fd_hash_consts C;
+    volatile float cont_d = (20.0f - 2.0f) / (nd - 1.0f);
+    volatile float cont_a = (1.0f - (-1.0f)) / (na - 1.0f);
+    C.q.dist_disc = 1.0f / cont_d;
+    C.q.ang_disc = 1.0f / cont_a;
+    // largest f32 d2 with sqrtf(d2) <= cutoff (sqrtf is correctly rounded on host and device)
+    float cut = p->dist_cutoff;
+    float d2 = cut * cut;
+    while (sqrtf(d2) > cut) d2 = nextafterf(d2, 0.0f);
+    while (sqrtf(nextafterf(d2, INFINITY)) <= cut) d2 = nextafterf(d2, INFINITY);
+    C.d2_max = d2;
+    return C;
+}
+
+static int d2h_u64(fdgpu_ctx *c, const uint64_t *dev, uint64_t *host) {
+    HIPCHK(c, hipMemcpyAsync(host, dev, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDGPU_OK;
+}
+
+// pair count -> segment offsets; returns total pairs
+static int count_and_scan(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_consts &C, uint64_t *P) {
+    uint64_t S = b->n_struct;
+    HIPCHK(c, c->ws[WS_COUNTS].ensure((S + 1) * 4));
+    HIPCHK(c, c->ws[WS_CURSOR].ensure((S + 1) * 4));
+    HIPCHK(c, c->ws[WS_SEGOFF].ensure((S + 2) * 8));
+    HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(std::max<uint64_t>(S, b->n_res)) * 8 + 64));
+    HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_COUNTS].p, 0, (S + 1) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_CURSOR].p, 0, (S + 1) * 4, c->stream));
+    {
+        StageTimer t(c, "pair_count", b->n_res * 13);
+        fd_launch_pair_count(b->view(), C, c->ws[WS_COUNTS].as<uint32_t>(), c->stream);
+    }
+    {
+        StageTimer t(c, "segment_scan", S * 12);
+        fd_exclusive_scan<uint32_t>(c->ws[WS_COUNTS].as<uint32_t>(), S, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
+                                    c->ws[WS_TOTAL].as<uint64_t>(), c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    return d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), P);
+}
+
+static int ensure_sort_ws(fdgpu_ctx *c, uint64_t P) {
+    size_t kb = std::max<uint64_t>(P, 1) * 4;
+    HIPCHK(c, c->ws[WS_KEYS_A].ensure(kb));
+    HIPCHK(c, c->ws[WS_IDS_A].ensure(kb));
+    HIPCHK(c, c->ws[WS_KEYS_B].ensure(kb));
+    HIPCHK(c, c->ws[WS_IDS_B].ensure(kb));
+    HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * std::max<uint32_t>(fd_rs_num_tiles(P), 1) * 4));
+    HIPCHK(c, c->ws[WS_TOT].ensure(256 * 8));
+    return FDGPU_OK;
+}
+
+// ---- S1 ---------------------------------------------------------------------------------------------------------------
+extern "C" int fdgpu_hash_batch(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_params *p, int sort_dedup, uint32_t **hashes,
+                                uint64_t **hash_off) {
+    if (!c || !b || !p || !hashes || !hash_off) return FDGPU_EINVAL;
+    *hashes = nullptr; *hash_off = nullptr;
+    reset_timings(c);
+    fd_hash_consts C = make_consts(p);
+    uint64_t S = b->n_struct, R = b->n_res;
+    uint64_t *h_off = (uint64_t *)malloc((S + 1) * 8);
+    if (!h_off) return FDGPU_ENOMEM;
+    hipStream_t st = c->stream;
+    if (!sort_dedup) {
+        // row-major raw list: per-residue row counts -> row offsets -> ordered emit
+        HIPCHK(c, c->ws[WS_MISC0].ensure((R + 1) * 4));
+        HIPCHK(c, c->ws[WS_MISC1].ensure((R + 2) * 8));
+        HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(std::max<uint64_t>(S, R)) * 8 + 64));
+        HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_MISC0].p, 0, (R + 1) * 4, st));
+        fd_launch_row_count(b->view(), C, c->ws[WS_MISC0].as<uint32_t>(), st);
+        fd_exclusive_scan<uint32_t>(c->ws[WS_MISC0].as<uint32_t>(), R, c->ws[WS_MISC1].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
+                                    c->ws[WS_TOTAL].as<uint64_t>(), st);
+        HIPCHK(c, hipGetLastError());
+        uint64_t P = 0;
+        int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &P);
+        if (rc) { free(h_off); return rc; }
+        HIPCHK(c, c->ws[WS_KEYS_A].ensure(std::max<uint64_t>(P, 1) * 4));
+        fd_launch_row_emit(b->view(), C, c->ws[WS_MISC1].as<uint64_t>(), c->ws[WS_KEYS_A].as<uint32_t>(), st);
+        HIPCHK(c, hipGetLastError());
+        uint32_t *h = (uint32_t *)malloc(std::max<uint64_t>(P, 1) * 4);
+        std::vector<uint64_t> row_off(R + 1);
+        if (!h) { free(h_off); return FDGPU_ENOMEM; }
+        HIPCHK(c, hipMemcpyAsync(h, c->ws[WS_KEYS_A].p, P * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(row_off.data(), c->ws[WS_MISC1].p, (R + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        for (uint64_t s = 0; s <= S; ++s) h_off[s] = row_off[b->h_res_off[s]];
+        *hashes = h; *hash_off = h_off;
+        return FDGPU_OK;
+    }
+    uint64_t P = 0;
+    int rc = count_and_scan(c, b, C, &P);
+    if (rc) { free(h_off); return rc; }
+    if (P >= 0xffffffffull) { free(h_off); FAIL(c, FDGPU_ERANGE, "more than 2^32 residue pairs in one batch; split the batch"); }
+    if ((rc = ensure_sort_ws(c, P))) { free(h_off); return rc; }
+    uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *ia = c->ws[WS_IDS_A].as<uint32_t>();
+    uint32_t *kb = c->ws[WS_KEYS_B].as<uint32_t>(), *ib = c->ws[WS_IDS_B].as<uint32_t>();
+    fd_launch_pair_emit(b->view(), C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, ia, 0u, st);
+    // sort by hash, then (stable) by structure -> (structure, hash) order
+    int cur = fd_radix_sort_pairs(ka, ia, kb, ib, P, 30, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st);
+    uint32_t *k1 = cur ? kb : ka, *i1 = cur ? ib : ia, *k2 = cur ? ka : kb, *i2 = cur ? ia : ib;
+    int id_bits = 1;
+    while (id_bits < 32 && (1ull << id_bits) < std::max<uint64_t>(S, 2)) ++id_bits;
+    int cur2 = fd_radix_sort_pairs(i1, k1, i2, k2, P, id_bits, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st);
+    uint32_t *ids_s = cur2 ? i2 : i1, *keys_s = cur2 ? k2 : k1, *spare = cur2 ? k1 : k2;
+    // adjacent-unique compaction
+    HIPCHK(c, c->ws[WS_MISC0].ensure(std::max<uint64_t>(P, 1)));
+    HIPCHK(c, c->ws[WS_MISC1].ensure((P + 2) * 8));
+    HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(std::max<uint64_t>(P, S)) * 8 + 64));
+    fd_launch_uniq_flags(keys_s, ids_s, P, c->ws[WS_MISC0].as<uint8_t>(), st);
+    fd_exclusive_scan<uint8_t>(c->ws[WS_MISC0].as<uint8_t>(), P, c->ws[WS_MISC1].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
+                               c->ws[WS_TOTAL].as<uint64_t>(), st);
+    fd_launch_compact(keys_s, c->ws[WS_MISC0].as<uint8_t>(), c->ws[WS_MISC1].as<uint64_t>(), P, spare, st);
+    // hash_off[s] = unique position at the first raw element of structure s (segments survive the stable sort by id)
+    HIPCHK(c, c->ws[WS_MISC2].ensure((S + 2) * 8));
+    fd_launch_gather_u64(c->ws[WS_MISC1].as<uint64_t>(), c->ws[WS_SEGOFF].as<uint64_t>(), S + 1, c->ws[WS_MISC2].as<uint64_t>(), st);
+    HIPCHK(c, hipGetLastError());
+    uint64_t U = 0;
+    if ((rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &U))) { free(h_off); return rc; }
+    uint32_t *h = (uint32_t *)malloc(std::max<uint64_t>(U, 1) * 4);
+    if (!h) { free(h_off); return FDGPU_ENOMEM; }
+    HIPCHK(c, hipMemcpyAsync(h, spare, U * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_off, c->ws[WS_MISC2].p, (S + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *hashes = h; *hash_off = h_off;
+    return FDGPU_OK;
+}
+
+// ---- S2 ---------------------------------------------------------------------------------------------------------------
+extern "C" void fdgpu_index_destroy(fdgpu_index *ix) {
+    if (!ix) return;
+    (void)hipFree(ix->hashes); (void)hipFree(ix->offsets); (void)hipFree(ix->value);
+    delete ix;
+}
+extern "C" uint64_t fdgpu_index_num_hashes(const fdgpu_index *ix) { return ix ? ix->n_hashes : 0; }
+extern "C" uint64_t fdgpu_index_value_len(const fdgpu_index *ix) { return ix ? ix->value_len : 0; }
+extern "C" uint64_t fdgpu_index_num_postings(const fdgpu_index *ix) { return ix ? ix->n_postings : 0; }
+
+extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_params *p, uint64_t first_id, fdgpu_index **out) {
+    if (!c || !b || !p || !out) return FDGPU_EINVAL;
+    *out = nullptr;
+    reset_timings(c);
+    if (first_id + b->n_struct > 0xffffffffull) FAIL(c, FDGPU_ERANGE, "structure ids exceed 32 bits");
+    fd_hash_consts C = make_consts(p);
+    hipStream_t st = c->stream;
+    uint64_t S = b->n_struct, P = 0;
+    int rc = count_and_scan(c, b, C, &P);
+    if (rc) return rc;
+    if (P >= 0xffffffffull) FAIL(c, FDGPU_ERANGE, "more than 2^32 residue pairs in one build call; split the shard");
+    if ((rc = ensure_sort_ws(c, P))) return rc;
+    uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *ia = c->ws[WS_IDS_A].as<uint32_t>();
+    uint32_t *kb = c->ws[WS_KEYS_B].as<uint32_t>(), *ib = c->ws[WS_IDS_B].as<uint32_t>();
+    {
+        StageTimer t(c, "pair_emit", b->n_res * 37 + P * 8);
+        fd_launch_pair_emit(b->view(), C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, ia, (uint32_t)first_id, st);
+    }
+    int cur;
+    {
+        StageTimer t(c, "radix_sort", P * 20 * 4);
+        cur = fd_radix_sort_pairs(ka, ia, kb, ib, P, 30, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st);
+    }
+    const uint32_t *ks = cur ? kb : ka, *is = cur ? ib : ia;
+    uint32_t nt = std::max<uint32_t>(fd_enc_num_tiles(P), 1);
+    HIPCHK(c, c->ws[WS_TILE_B].ensure((size_t)(nt + 1) * 4));
+    HIPCHK(c, c->ws[WS_TILE_H].ensure((size_t)(nt + 1) * 4));
+    HIPCHK(c, c->ws[WS_TILE_P].ensure((size_t)(nt + 1) * 4));
+    HIPCHK(c, c->ws[WS_TILE_BO].ensure((size_t)(nt + 2) * 8));
+    HIPCHK(c, c->ws[WS_TILE_HO].ensure((size_t)(nt + 2) * 8));
+    HIPCHK(c, c->ws[WS_TILE_PO].ensure((size_t)(nt + 2) * 8));
+    HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(std::max<uint64_t>(nt, S)) * 8 + 64));
+    HIPCHK(c, c->ws[WS_MISC3].ensure(64));
+    uint64_t tot[3] = {0, 0, 0};
+    uint64_t nt_eff = P ? fd_enc_num_tiles(P) : 0;
+    {
+        StageTimer t(c, "encode_sizes", P * 8);
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_TILE_B].p, 0, (size_t)(nt + 1) * 4, st));
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_TILE_H].p, 0, (size_t)(nt + 1) * 4, st));
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_TILE_P].p, 0, (size_t)(nt + 1) * 4, st));
+        fd_launch_enc_sizes(ks, is, P, c->ws[WS_TILE_B].as<uint32_t>(), c->ws[WS_TILE_H].as<uint32_t>(), c->ws[WS_TILE_P].as<uint32_t>(), st);
+        uint64_t *totd = c->ws[WS_MISC3].as<uint64_t>();
+        fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_B].as<uint32_t>(), nt_eff, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 0, st);
+        fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_H].as<uint32_t>(), nt_eff, c->ws[WS_TILE_HO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 1, st);
+        fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_P].as<uint32_t>(), nt_eff, c->ws[WS_TILE_PO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 2, st);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_MISC3].p, 24, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    fdgpu_index *ix = new (std::nothrow) fdgpu_index();
+    if (!ix) return FDGPU_ENOMEM;
+    ix->ctx = c; ix->value_len = tot[0]; ix->n_hashes = tot[1]; ix->n_postings = tot[2]; ix->n_structures = S; ix->first_id = first_id;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&ix->value, std::max<uint64_t>(ix->value_len, 4))) != hipSuccess ||
+        (e = hipMalloc((void **)&ix->hashes, std::max<uint64_t>(ix->n_hashes, 1) * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&ix->offsets, (ix->n_hashes + 1) * 8)) != hipSuccess) {
+        c->err = std::string("index alloc: ") + hipGetErrorString(e);
+        fdgpu_index_destroy(ix);
+        return FDGPU_EHIP;
+    }
+    {
+        StageTimer t(c, "encode_write", P * 8 + ix->value_len + ix->n_hashes * 12);
+        fd_launch_enc_write(ks, is, P, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_TILE_HO].as<uint64_t>(), ix->value, ix->hashes, ix->offsets,
+                            c->ws[WS_MISC3].as<uint64_t>(), ix->n_hashes, st);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) { c->err = std::string("encode launch: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }
+    *out = ix;
+    return FDGPU_OK;
+}
+
+extern "C" int fdgpu_index_export(fdgpu_ctx *c, const fdgpu_index *ix, uint8_t **value, uint64_t *value_len, uint32_t **hashes,
+                                  uint64_t **offsets, uint64_t *n_hashes) {
+    if (!c || !ix || !value || !value_len || !hashes || !offsets || !n_hashes) return FDGPU_EINVAL;
+    uint8_t *v = (uint8_t *)malloc(std::max<uint64_t>(ix->value_len, 1));
+    uint32_t *h = (uint32_t *)malloc(std::max<uint64_t>(ix->n_hashes, 1) * 4);
+    uint64_t *o = (uint64_t *)malloc((ix->n_hashes + 1) * 8);
+    if (!v || !h || !o) { free(v); free(h); free(o); return FDGPU_ENOMEM; }
+    hipError_t e = hipSuccess;
+    if (ix->value_len) e = hipMemcpyAsync(v, ix->value, ix->value_len, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && ix->n_hashes) e = hipMemcpyAsync(h, ix->hashes, ix->n_hashes * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(o, ix->offsets, (ix->n_hashes + 1) * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { free(v); free(h); free(o); c->err = std::string("index export: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+    *value = v; *value_len = ix->value_len; *hashes = h; *offsets = o; *n_hashes = ix->n_hashes;
+    return FDGPU_OK;
+}
+
+extern "C" int fdgpu_index_load(fdgpu_ctx *c, const uint32_t *hashes, const uint64_t *offsets, uint64_t H, const uint8_t *value,
+                                uint64_t vlen, uint64_t n_structures, fdgpu_index **out) {
+    if (!c || !out || (H && (!hashes || !offsets)) || (vlen && !value)) return FDGPU_EINVAL;
+    *out = nullptr;
+    fdgpu_index *ix = new (std::nothrow) fdgpu_index();
+    if (!ix) return FDGPU_ENOMEM;
+    ix->ctx = c; ix->n_hashes = H; ix->value_len = vlen; ix->n_structures = n_structures;
+    hipError_t e;
+    uint64_t zero = 0;
+    if ((e = hipMalloc((void **)&ix->value, std::max<uint64_t>(vlen, 4))) != hipSuccess ||
+        (e = hipMalloc((void **)&ix->hashes, std::max<uint64_t>(H, 1) * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&ix->offsets, (H + 1) * 8)) != hipSuccess ||
+        (vlen && (e = hipMemcpyAsync(ix->value, value, vlen, hipMemcpyHostToDevice, c->stream)) != hipSuccess) ||
+        (H && (e = hipMemcpyAsync(ix->hashes, hashes, H * 4, hipMemcpyHostToDevice, c->stream)) != hipSuccess) ||
+        (e = hipMemcpyAsync(ix->offsets, H ? offsets : &zero, (H + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+        c->err = std::string("index load: ") + hipGetErrorString(e);
+        fdgpu_index_destroy(ix);
+        return FDGPU_EHIP;
+    }
+    // postings = bytes without continuation bit; counted lazily by the query path when needed
+    ix->n_postings = 0;
+    *out = ix;
+    return FDGPU_OK;
+}
+
+// byte-identical to wrapup_offset_and_save_entries + save_offset_to_file (indextable.rs:239-264, 297-326)
+extern "C" int fdgpu_index_save(fdgpu_ctx *c, const fdgpu_index *ix, const char *prefix) {
+    if (!c || !ix || !prefix) return FDGPU_EINVAL;
+    uint8_t *v = nullptr; uint32_t *h = nullptr; uint64_t *o = nullptr; uint64_t vl = 0, H = 0;
+    int rc = fdgpu_index_export(c, ix, &v, &vl, &h, &o, &H);
+    if (rc) return rc;
+    std::string p(prefix);
+    FILE *f = fopen(p.c_str(), "wb");
+    bool ok = f != nullptr;
+    if (ok && vl) ok = fwrite(v, 1, vl, f) == vl;
+    if (f) fclose(f);
+    f = ok ? fopen((p + ".offset").c_str(), "wb") : nullptr;
+    ok = ok && f != nullptr;
+    if (ok) ok = fwrite(&H, 8, 1, f) == 1 && (H == 0 || fwrite(h, 4, H, f) == H) && fwrite(o, 8, H + 1, f) == H + 1;
+    if (f) fclose(f);
+    free(v); free(h); free(o);
+    if (!ok) FAIL(c, FDGPU_EINVAL, "index save: cannot write " + p);
+    return FDGPU_OK;
+}
+
+// ---- S3 ---------------------------------------------------------------------------------------------------------------
+extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths) {
+    if (!c || !ix || (nq && (!q_hash || !lengths))) return FDGPU_EINVAL;
+    if (!nq) return FDGPU_OK;
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->ws[WS_MISC0].ensure(nq * 4));
+    HIPCHK(c, c->ws[WS_MISC1].ensure(nq * 8));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st));
+    fd_launch_posting_lengths(ix->hashes, ix->offsets, ix->value, ix->n_hashes, c->ws[WS_MISC0].as<uint32_t>(), nq, c->ws[WS_MISC1].as<uint64_t>(), st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(lengths, c->ws[WS_MISC1].p, nq * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return FDGPU_OK;
+}
+
+extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j,
+                                 const float *q_idf, uint64_t nq, const float *penalty, fd_count_rec **out, uint64_t *n_out) {
+    if (!c || !ix || !out || !n_out || (nq && (!q_hash || !q_node || !q_edge_j || !q_idf)) || (ix->n_structures && !penalty)) return FDGPU_EINVAL;
+    *out = nullptr; *n_out = 0;
+    reset_timings(c);
+    hipStream_t st = c->stream;
+    const uint64_t S = ix->n_structures;
+    if (S == 0 || nq == 0) { *out = (fd_count_rec *)malloc(sizeof(fd_count_rec)); return *out ? FDGPU_OK : FDGPU_ENOMEM; }
+    if (S >= 0xffffffe0ull) FAIL(c, FDGPU_ERANGE, "too many structures");
+    // dense node / edge numbering (node = first query residue of the pair, edge = (first, second))
+    std::vector<uint32_t> nodes(q_node, q_node + nq);
+    std::sort(nodes.begin(), nodes.end());
+    nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+    std::vector<uint64_t> edges(nq);
+    for (uint64_t k = 0; k < nq; ++k) edges[k] = ((uint64_t)q_node[k] << 32) | q_edge_j[k];
+    std::sort(edges.begin(), edges.end());
+    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+    std::vector<uint32_t> nidx(nq), eidx(nq);
+    std::vector<uint64_t> idf_fix(nq);
+    for (uint64_t k = 0; k < nq; ++k) {
+        nidx[k] = (uint32_t)(std::lower_bound(nodes.begin(), nodes.end(), q_node[k]) - nodes.begin());
+        eidx[k] = (uint32_t)(std::lower_bound(edges.begin(), edges.end(), ((uint64_t)q_node[k] << 32) | q_edge_j[k]) - edges.begin());
+        double v = (double)q_idf[k];
+        idf_fix[k] = (v > 0.0 && v < 1.0e6) ? (uint64_t)(v * 1099511627776.0 + 0.5) : 0ull;
+    }
+    const uint32_t NN = (uint32_t)nodes.size(), NE = (uint32_t)edges.size();
+    const uint32_t words = (uint32_t)((S + 31) / 32);
+    // workspace
+    HIPCHK(c, c->ws[WS_MISC0].ensure(nq * 4));   // q_hash
+    HIPCHK(c, c->ws[WS_MISC1].ensure(nq * 4));   // node idx
+    HIPCHK(c, c->ws[WS_MISC2].ensure(nq * 4));   // edge idx
+    HIPCHK(c, c->ws[WS_MISC3].ensure(nq * 8));   // idf fixed
+    HIPCHK(c, c->ws[WS_COUNTS].ensure(S * 4));   // match
+    HIPCHK(c, c->ws[WS_SEGOFF].ensure((S + 2) * 8));  // idf sums, later reused? no: keep separate below
+    HIPCHK(c, c->ws[WS_KEYS_A].ensure((size_t)NN * words * 4));
+    HIPCHK(c, c->ws[WS_KEYS_B].ensure((size_t)NE * words * 4));
+    HIPCHK(c, c->ws[WS_IDS_A].ensure(S * 4));    // node counts
+    HIPCHK(c, c->ws[WS_IDS_B].ensure(S * 4));    // edge counts
+    HIPCHK(c, c->ws[WS_MISC4].ensure(S + 8));    // flags
+    HIPCHK(c, c->ws[WS_TILE_BO].ensure((S + 2) * 8));  // positions
+    HIPCHK(c, c->ws[WS_MISC5].ensure(S * 4));    // penalty
+    HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(S) * 8 + 64));
+    HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, nidx.data(), nq * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, eidx.data(), nq * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC3].p, idf_fix.data(), nq * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_COUNTS].p, 0, S * 4, st));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_SEGOFF].p, 0, S * 8, st));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_KEYS_A].p, 0, (size_t)NN * words * 4, st));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_KEYS_B].p, 0, (size_t)NE * words * 4, st));
+    cq_args A;
+    A.hashes = ix->hashes; A.offsets = ix->offsets; A.value = ix->value; A.H = ix->n_hashes;
+    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.q_node_idx = c->ws[WS_MISC1].as<uint32_t>(); A.q_edge_idx = c->ws[WS_MISC2].as<uint32_t>();
+    A.q_idf_fix = c->ws[WS_MISC3].as<uint64_t>(); A.nq = nq;
+    A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>();
+    A.node_bits = c->ws[WS_KEYS_A].as<uint32_t>(); A.edge_bits = c->ws[WS_KEYS_B].as<uint32_t>();
+    A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
+    {
+        StageTimer t(c, "cq_accumulate", 0);
+        fd_launch_cq_accumulate(A, st);
+    }
+    {
+        StageTimer t(c, "cq_finalize", (uint64_t)(NN + NE) * words * 4 + S * 12);
+        fd_launch_cq_finalize(A.match, A.idf, A.node_bits, NN, A.edge_bits, NE, words, (uint32_t)S, c->ws[WS_IDS_A].as<uint32_t>(),
+                              c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), st);
+        fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), S, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
+                                   c->ws[WS_TOTAL].as<uint64_t>(), st);
+    }
+    HIPCHK(c, hipGetLastError());
+    uint64_t n = 0;
+    int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &n);
+    if (rc) return rc;
+    fd_count_rec *r = (fd_count_rec *)malloc(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec));
+    if (!r) return FDGPU_ENOMEM;
+    HIPCHK(c, c->ws[WS_TILE_HO].ensure(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec)));
+    fd_launch_cq_compact(A.match, A.idf, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(),
+                         c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_MISC5].as<float>(), (uint32_t)S, (uint32_t)ix->first_id, c->ws[WS_TILE_HO].p, st);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && n) e = hipMemcpyAsync(r, c->ws[WS_TILE_HO].p, n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { free(r); c->err = std::string("count_query: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+    *out = r; *n_out = n;
+    return FDGPU_OK;
+}
+
+// ---- S4 ---------------------------------------------------------------------------------------------------------------
+extern "C" int fdgpu_match_pairs(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
+                                 const fd_match_query *q, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
+                                 fd_cand_rec **cands, uint64_t *n_cands) {
+    if (!c || !db || !q || !p || !found || !n_found || !cands || !n_cands || (n_cand && !cand)) return FDGPU_EINVAL;
+    *found = nullptr; *cands = nullptr; *n_found = 0; *n_cands = 0;
+    reset_timings(c);
+    hipStream_t st = c->stream;
+    // work items: (candidate slot, 64-residue i-tile)
+    std::vector<uint32_t> wc, wi;
+    for (uint64_t k = 0; k < n_cand; ++k) {
+        if (cand[k] >= db->n_struct) FAIL(c, FDGPU_EINVAL, "match_pairs: candidate id outside the batch");
+        uint64_t r0 = db->h_res_off[cand[k]], r1 = db->h_res_off[cand[k] + 1];
+        for (uint64_t t = r0; t < r1; t += FD_WAVE) { wc.push_back((uint32_t)k); wi.push_back((uint32_t)t); }
+    }
+    uint32_t m1 = 0, m2 = 0;
+    for (uint64_t k = 0; k < q->n_hashes; ++k) { m1 |= 1u << ((q->hashes[k] >> 25) & 31u); m2 |= 1u << ((q->hashes[k] >> 20) & 31u); }
+    size_t nw = wc.size();
+    HIPCHK(c, c->ws[WS_MISC0].ensure(std::max<size_t>(n_cand, 1) * 4));
+    HIPCHK(c, c->ws[WS_MISC1].ensure(std::max<size_t>(nw, 1) * 4));
+    HIPCHK(c, c->ws[WS_MISC2].ensure(std::max<size_t>(nw, 1) * 4));
+    HIPCHK(c, c->ws[WS_MISC3].ensure(std::max<uint64_t>(q->n_hashes, 1) * 4));
+    HIPCHK(c, c->ws[WS_MISC4].ensure(std::max<uint64_t>(q->n_aad, 1) * 10 + 64));
+    HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
+    uint8_t *aad_base = c->ws[WS_MISC4].as<uint8_t>();
+    size_t na = q->n_aad, na4 = (na + 3) & ~(size_t)3;
+    float *d_dist = (float *)aad_base;
+    uint32_t *d_qi = (uint32_t *)(aad_base + 4 * na4);
+    uint8_t *d_a1 = aad_base + 8 * na4, *d_a2 = aad_base + 9 * na4;
+    if (n_cand) HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, cand, n_cand * 4, hipMemcpyHostToDevice, st));
+    if (nw) {
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, wc.data(), nw * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, wi.data(), nw * 4, hipMemcpyHostToDevice, st));
+    }
+    if (q->n_hashes) HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC3].p, q->hashes, q->n_hashes * 4, hipMemcpyHostToDevice, st));
+    if (na) {
+        HIPCHK(c, hipMemcpyAsync(d_dist, q->aad_dist, na * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(d_qi, q->aad_qi, na * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(d_a1, q->aad_aa1, na, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(d_a2, q->aad_aa2, na, hipMemcpyHostToDevice, st));
+    }
+    uint8_t *d_std = nullptr;
+    if (resname_std) {
+        HIPCHK(c, c->ws[WS_MISC5].ensure(std::max<uint64_t>(db->n_res, 1)));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, resname_std, db->n_res, hipMemcpyHostToDevice, st));
+        d_std = c->ws[WS_MISC5].as<uint8_t>();
+    }
+    mp_args A;
+    A.B = db->view(); A.C = make_consts(p); A.cutoff = p->dist_cutoff;
+    A.cand = c->ws[WS_MISC0].as<uint32_t>(); A.n_cand = (uint32_t)n_cand;
+    A.wi_cand = c->ws[WS_MISC1].as<uint32_t>(); A.wi_i0 = c->ws[WS_MISC2].as<uint32_t>(); A.n_work = (uint32_t)nw;
+    A.resname_std = d_std; A.aa1_mask = m1; A.aa2_mask = m2; A.use_prefilter = q->use_aa_prefilter;
+    A.q_hashes = c->ws[WS_MISC3].as<uint32_t>(); A.n_hashes = (uint32_t)q->n_hashes;
+    A.aad_aa1 = d_a1; A.aad_aa2 = d_a2; A.aad_dist = d_dist; A.aad_qi = d_qi; A.n_aad = (uint32_t)na; A.ca_window = q->ca_distance_cutoff;
+    A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.found = nullptr; A.cands = nullptr;
+    uint64_t tot[2] = {0, 0};
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_TOTAL].p, 0, 16, st));
+    {
+        StageTimer t(c, "match_pairs_count", 0);
+        fd_launch_match_pairs(A, false, st);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_TOTAL].p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, c->ws[WS_KEYS_A].ensure(std::max<uint64_t>(tot[0], 1) * sizeof(fd_pair_rec)));
+    HIPCHK(c, c->ws[WS_KEYS_B].ensure(std::max<uint64_t>(tot[1], 1) * sizeof(fd_cand_rec)));
+    A.found = c->ws[WS_KEYS_A].as<fd_pair_rec>(); A.cands = c->ws[WS_KEYS_B].as<fd_cand_rec>();
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_TOTAL].p, 0, 16, st));
+    {
+        StageTimer t(c, "match_pairs_emit", 0);
+        fd_launch_match_pairs(A, true, st);
+    }
+    HIPCHK(c, hipGetLastError());
+    fd_pair_rec *hf = (fd_pair_rec *)malloc(std::max<uint64_t>(tot[0], 1) * sizeof(fd_pair_rec));
+    fd_cand_rec *hc = (fd_cand_rec *)malloc(std::max<uint64_t>(tot[1], 1) * sizeof(fd_cand_rec));
+    if (!hf || !hc) { free(hf); free(hc); return FDGPU_ENOMEM; }
+    hipError_t e = hipSuccess;
+    if (tot[0]) e = hipMemcpyAsync(hf, A.found, tot[0] * sizeof(fd_pair_rec), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && tot[1]) e = hipMemcpyAsync(hc, A.cands, tot[1] * sizeof(fd_cand_rec), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { free(hf); free(hc); c->err = std::string("match_pairs: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+    // restore the reference's scan order (row-major over the prefilter sets, retrieve.rs:146-153): the
+    // kernel appends with atomics, one contiguous run per (i, j) in observed-list order
+    std::stable_sort(hf, hf + tot[0], [](const fd_pair_rec &a, const fd_pair_rec &b) {
+        if (a.cand != b.cand) return a.cand < b.cand;
+        if (a.i != b.i) return a.i < b.i;
+        return a.j < b.j;
+    });
+    std::stable_sort(hc, hc + tot[1], [](const fd_cand_rec &a, const fd_cand_rec &b) {
+        if (a.cand != b.cand) return a.cand < b.cand;
+        if (a.i != b.i) return a.i < b.i;
+        return a.j < b.j;
+    });
+    *found = hf; *n_found = tot[0]; *cands = hc; *n_cands = tot[1];
+    return FDGPU_OK;
+}
+
+extern "C" int fdgpu_kabsch_batch(fdgpu_ctx *c, const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot,
+                                  float *tran) {
+    if (!c || (n && (!x || !y || !off || !rmsd || !rot || !tran))) return FDGPU_EINVAL;
+    if (!n) return FDGPU_OK;
+    hipStream_t st = c->stream;
+    uint64_t npts = off[n];
+    HIPCHK(c, c->ws[WS_MISC0].ensure(std::max<uint64_t>(npts, 1) * 12));
+    HIPCHK(c, c->ws[WS_MISC1].ensure(std::max<uint64_t>(npts, 1) * 12));
+    HIPCHK(c, c->ws[WS_MISC2].ensure((n + 1) * 8));
+    HIPCHK(c, c->ws[WS_MISC3].ensure(n * 4));
+    HIPCHK(c, c->ws[WS_MISC4].ensure(n * 36));
+    HIPCHK(c, c->ws[WS_MISC5].ensure(n * 12));
+    if (npts) {
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, x, npts * 12, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, y, npts * 12, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    fd_launch_kabsch(c->ws[WS_MISC0].as<float>(), c->ws[WS_MISC1].as<float>(), c->ws[WS_MISC2].as<uint64_t>(), n, c->ws[WS_MISC3].as<float>(),
+                     c->ws[WS_MISC4].as<float>(), c->ws[WS_MISC5].as<float>(), st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(rmsd, c->ws[WS_MISC3].p, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(rot, c->ws[WS_MISC4].p, n * 36, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(tran, c->ws[WS_MISC5].p, n * 12, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return FDGPU_OK;
+}
+
+// ---- diagnostics --------------------------------------------------------------------------------------------------------
+__global__ void k_debug_libm(int op, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint64_t n) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    float x = a[k], s, c;
+    switch (op) {
+        case 0: fdd_sincosf(x, &s, &c); out[k] = s; break;
+        case 1: fdd_sincosf(x, &s, &c); out[k] = c; break;
+        case 2: out[k] = fdd_acosf(x); break;
+        case 3: out[k] = fdd_atanf(x); break;
+        default: out[k] = fdd_atan2f(x, b[k]); break;
+    }
+}
+extern "C" int fdgpu_debug_libm(fdgpu_ctx *c, int op, const float *a, const float *b, float *out, uint64_t n) {
+    if (!c || !a || !out || (op == 4 && !b) || op < 0 || op > 4) return FDGPU_EINVAL;
+    if (!n) return FDGPU_OK;
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->ws[WS_MISC0].ensure(n * 4));
+    HIPCHK(c, c->ws[WS_MISC1].ensure(n * 4));
+    HIPCHK(c, c->ws[WS_MISC2].ensure(n * 4));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, a, n * 4, hipMemcpyHostToDevice, st));
+    if (b) HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, b, n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_debug_libm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op, c->ws[WS_MISC0].as<float>(),
+                       c->ws[WS_MISC1].as<float>(), c->ws[WS_MISC2].as<float>(), n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->ws[WS_MISC2].p, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return FDGPU_OK;
+}

@@ -1,0 +1,126 @@
+// fdgpu_internal.h — host-side objects behind the opaque handles of include/fdgpu.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/fdgpu.h"
+#include "fd_device.h"
+
+struct fd_devbuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 16 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct fd_timing_entry { const char *name; hipEvent_t ev0, ev1; uint64_t bytes; };
+
+enum {
+    WS_COUNTS, WS_CURSOR, WS_SEGOFF, WS_SCANTMP, WS_TOTAL, WS_KEYS_A, WS_IDS_A, WS_KEYS_B, WS_IDS_B, WS_GHIST, WS_TOT,
+    WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5,
+    WS_COUNT
+};
+
+struct fdgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    fd_devbuf ws[WS_COUNT];
+    bool timing = false;
+    std::vector<fd_timing_entry> timings;
+    std::vector<hipEvent_t> event_pool;
+    size_t event_used = 0;
+};
+
+struct fdgpu_batch {
+    fdgpu_ctx *ctx = nullptr;
+    bool owns = false;
+    uint64_t n_struct = 0, n_res = 0;
+    uint32_t n_work = 0;
+    // device
+    float *n_xyz = nullptr, *ca_xyz = nullptr, *cb_xyz = nullptr;
+    uint8_t *aa = nullptr, *cb_valid = nullptr, *hash_ok = nullptr;
+    uint32_t *res_off = nullptr, *wi_struct = nullptr, *wi_i0 = nullptr;
+    std::vector<uint64_t> h_res_off;  // host copy
+    fd_batch_view view() const {
+        fd_batch_view v;
+        v.n_xyz = n_xyz; v.ca_xyz = ca_xyz; v.cb_xyz = cb_xyz; v.aa = aa; v.hash_ok = hash_ok; v.res_off = res_off;
+        v.wi_struct = wi_struct; v.wi_i0 = wi_i0; v.n_struct = (uint32_t)n_struct; v.n_work = n_work;
+        return v;
+    }
+};
+
+struct fdgpu_index {
+    fdgpu_ctx *ctx = nullptr;
+    uint64_t n_hashes = 0, value_len = 0, n_postings = 0, n_structures = 0, first_id = 0;
+    uint32_t *hashes = nullptr;   // device [H]
+    uint64_t *offsets = nullptr;  // device [H+1]
+    uint8_t *value = nullptr;     // device [value_len]
+};
+
+// kernels / launchers implemented in the k_*.hip files
+void fd_launch_hash_ok(const uint8_t *aa, const uint8_t *cb_valid, uint8_t *ok, uint64_t n, hipStream_t st);
+void fd_launch_pair_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *counts, hipStream_t st);
+void fd_launch_pair_emit(const fd_batch_view &B, const fd_hash_consts &C, const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys,
+                         uint32_t *ids, uint32_t first_id, hipStream_t st);
+void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, hipStream_t st);
+void fd_launch_row_emit(const fd_batch_view &B, const fd_hash_consts &C, const uint64_t *row_off, uint32_t *keys, hipStream_t st);
+template <typename TIn>
+void fd_exclusive_scan(const TIn *in, uint64_t n, uint64_t *out, uint64_t *chunk_tmp, uint64_t *total_dev, hipStream_t st);
+uint64_t fd_scan_tmp_elems(uint64_t n);
+uint32_t fd_rs_num_tiles(uint64_t n);
+int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits, uint32_t *ghist,
+                        uint64_t *tot, hipStream_t st);
+uint32_t fd_enc_num_tiles(uint64_t n);
+void fd_launch_enc_sizes(const uint32_t *keys, const uint32_t *ids, uint64_t n, uint32_t *tb, uint32_t *th, uint32_t *tp, hipStream_t st);
+void fd_launch_enc_write(const uint32_t *keys, const uint32_t *ids, uint64_t n, const uint64_t *tbo, const uint64_t *tho, uint8_t *value,
+                         uint32_t *hashes, uint64_t *offsets, const uint64_t *total_bytes_dev, uint64_t H, hipStream_t st);
+void fd_launch_uniq_flags(const uint32_t *keys, const uint32_t *ids, uint64_t n, uint8_t *flags, hipStream_t st);
+void fd_launch_compact(const uint32_t *keys, const uint8_t *flags, const uint64_t *pos, uint64_t n, uint32_t *out, hipStream_t st);
+void fd_launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t n, uint64_t *dst, hipStream_t st);
+
+// k_query.hip
+struct cq_args {
+    const uint32_t *hashes; const uint64_t *offsets; const uint8_t *value; uint64_t H;
+    const uint32_t *q_hash; const uint32_t *q_node_idx; const uint32_t *q_edge_idx; const uint64_t *q_idf_fix; uint64_t nq;
+    uint32_t *match; unsigned long long *idf; uint32_t *node_bits; uint32_t *edge_bits; uint32_t words; uint32_t first_id; uint32_t S;
+};
+void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,
+                               uint64_t nq, uint64_t *lengths, hipStream_t st);
+void fd_launch_cq_accumulate(const cq_args &A, hipStream_t st);
+void fd_launch_cq_finalize(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_bits, uint32_t n_nodes,
+                           const uint32_t *edge_bits, uint32_t n_edges, uint32_t words, uint32_t S, uint32_t *node_cnt, uint32_t *edge_cnt,
+                           uint8_t *flags, hipStream_t st);
+void fd_launch_cq_compact(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_cnt, const uint32_t *edge_cnt,
+                          const uint8_t *flags, const uint64_t *pos, const float *penalty, uint32_t S, uint32_t first_id, void *out,
+                          hipStream_t st);
+
+// k_match.hip
+struct mp_args {
+    fd_batch_view B;
+    fd_hash_consts C;
+    float cutoff;
+    const uint32_t *cand; uint32_t n_cand;
+    const uint32_t *wi_cand; const uint32_t *wi_i0; uint32_t n_work;
+    const uint8_t *resname_std;
+    uint32_t aa1_mask, aa2_mask;
+    int use_prefilter;
+    const uint32_t *q_hashes; uint32_t n_hashes;
+    const uint8_t *aad_aa1, *aad_aa2; const float *aad_dist; const uint32_t *aad_qi; uint32_t n_aad;
+    float ca_window;
+    unsigned long long *n_found, *n_cands;
+    fd_pair_rec *found; fd_cand_rec *cands;
+};
+void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st);
+void fd_launch_kabsch(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, hipStream_t st);

@@ -1,0 +1,178 @@
+// k_hash.hip — residue-pair enumeration + PDBTrRosetta hashing on gfx950.
+//
+// Replaces HOT LOOP A of the reference (src/controller/feature.rs:198-231 driven by
+// src/utils/combination.rs:23-44): all ordered residue pairs (i, j), i != j, both residues
+// hashable, CA-CA distance <= cutoff.
+//
+// Mapping: one 64-lane wavefront (= one 64-thread workgroup) per (structure, 64-residue i-tile).
+// Lane l owns residue i = tile_start + l and walks j over the whole structure with
+// wave-uniform (scalar) loads of CA_j, so the CA-distance filter costs ~15 VALU issues per 64
+// pair tests.  Only ~25 % of the tests pass, so running the ~700-instruction descriptor under
+// that exec mask would idle 3/4 of the lanes; instead the passing (i, j) are compacted with
+// ballot + mbcnt prefix into a per-wave LDS queue and the descriptor is evaluated in full
+// 64-entry drains (one queue entry per lane).  No MFMA: this is f32/f64 VALU + irregular gather.
+#include "fd_device.h"
+
+// ------------------------------------------------------------------ count pass
+// counts[s] += number of ordered pairs of structure s that will be emitted
+__global__ __launch_bounds__(FD_WAVE) void k_pair_count(fd_batch_view B, fd_hash_consts C, uint32_t *__restrict__ counts) {
+    uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
+    if (w >= B.n_work) return;
+    const uint32_t s = B.wi_struct[w];
+    const uint32_t r0 = B.res_off[s], r1 = B.res_off[s + 1];
+    const uint32_t i = B.wi_i0[w] + threadIdx.x;
+    const bool vi = i < r1 && B.hash_ok[i];
+    fd_v3 cai = {0.f, 0.f, 0.f};
+    if (vi) cai = fd_load3(B.ca_xyz, i);
+    uint32_t cnt = 0;
+    for (uint32_t j = r0; j < r1; ++j) {
+        if (!B.hash_ok[j]) continue;  // wave-uniform
+        fd_v3 caj = fd_load3(B.ca_xyz, j);
+        float d2 = fd_dist2(cai, caj);
+        cnt += (vi && i != j && !(d2 > C.d2_max)) ? 1u : 0u;
+    }
+    // wave reduction
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, FD_WAVE);
+    if (threadIdx.x == 0 && cnt) atomicAdd(&counts[s], cnt);
+}
+
+// ------------------------------------------------------------------ emit pass
+// keys/ids are written into the structure's segment [seg_off[s], seg_off[s+1]); the order inside a
+// segment is unspecified (slots are claimed with one atomicAdd per 64-entry drain) — the build
+// sorts by hash afterwards, and a stable sort keeps ids ascending because segments are id-major.
+template <bool WRITE_IDS>
+__device__ __forceinline__ void drain(const fd_batch_view &B, const fd_hash_consts &C, const uint32_t *q, uint32_t n,
+                                      uint32_t i0, uint32_t r0, uint32_t s, uint32_t id, const uint64_t *seg_off,
+                                      uint32_t *cursor, uint32_t *keys, uint32_t *ids) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&cursor[s], n);
+    base = __shfl(base, 0, FD_WAVE);
+    if (lane < n) {
+        uint32_t e = q[lane];
+        uint32_t i = i0 + (e >> 16), j = r0 + (e & 0xffffu);
+        fd_v3 n1 = fd_load3(B.n_xyz, i), ca1 = fd_load3(B.ca_xyz, i), cb1 = fd_load3(B.cb_xyz, i);
+        fd_v3 n2 = fd_load3(B.n_xyz, j), ca2 = fd_load3(B.ca_xyz, j), cb2 = fd_load3(B.cb_xyz, j);
+        fd_feature f = fd_pair_feature(n1, ca1, cb1, n2, ca2, cb2);
+        uint32_t h = fd_hash_pdbtr(B.aa[i], B.aa[j], f, C.q);
+        uint64_t pos = seg_off[s] + base + lane;
+        keys[pos] = h;
+        if (WRITE_IDS) ids[pos] = id;
+    }
+}
+
+template <bool WRITE_IDS>
+__global__ __launch_bounds__(FD_WAVE) void k_pair_emit(fd_batch_view B, fd_hash_consts C, const uint64_t *__restrict__ seg_off,
+                                                       uint32_t *__restrict__ cursor, uint32_t *__restrict__ keys,
+                                                       uint32_t *__restrict__ ids, uint32_t first_id) {
+    __shared__ uint32_t q[2 * FD_WAVE];
+    uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
+    if (w >= B.n_work) return;
+    const uint32_t s = B.wi_struct[w];
+    const uint32_t r0 = B.res_off[s], r1 = B.res_off[s + 1];
+    const uint32_t i0 = B.wi_i0[w];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = i0 + lane;
+    const bool vi = i < r1 && B.hash_ok[i];
+    fd_v3 cai = {0.f, 0.f, 0.f};
+    if (vi) cai = fd_load3(B.ca_xyz, i);
+    uint32_t qn = 0;  // wave-uniform
+    for (uint32_t j = r0; j < r1; ++j) {
+        if (!B.hash_ok[j]) continue;
+        fd_v3 caj = fd_load3(B.ca_xyz, j);
+        float d2 = fd_dist2(cai, caj);
+        bool pass = vi && i != j && !(d2 > C.d2_max);
+        uint64_t m = __ballot(pass);
+        if (m == 0) continue;
+        if (pass) q[qn + fd_mbcnt(m)] = (lane << 16) | (j - r0);
+        qn += (uint32_t)__popcll(m);
+        if (qn >= FD_WAVE) {
+            __syncthreads();
+            qn -= FD_WAVE;
+            drain<WRITE_IDS>(B, C, q + qn, FD_WAVE, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
+            __syncthreads();
+        }
+    }
+    if (qn) {
+        __syncthreads();
+        drain<WRITE_IDS>(B, C, q, qn, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
+    }
+}
+
+// ------------------------------------------------------------------ ordered variant (API S1, sort_dedup = 0)
+// Same pairs, but written in the reference's row-major (i, j) order: one lane per i computes its
+// row offset by a prefix over row counts.  Used for parity tests of the raw hash list; not on the
+// index-build fast path.
+__global__ __launch_bounds__(FD_WAVE) void k_row_count(fd_batch_view B, fd_hash_consts C, uint32_t *__restrict__ row_cnt) {
+    uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
+    if (w >= B.n_work) return;
+    const uint32_t s = B.wi_struct[w];
+    const uint32_t r0 = B.res_off[s], r1 = B.res_off[s + 1];
+    const uint32_t i = B.wi_i0[w] + threadIdx.x;
+    if (i >= r1) return;
+    const bool vi = B.hash_ok[i];
+    fd_v3 cai = fd_load3(B.ca_xyz, i);
+    uint32_t cnt = 0;
+    for (uint32_t j = r0; j < r1; ++j) {
+        if (!B.hash_ok[j]) continue;
+        float d2 = fd_dist2(cai, fd_load3(B.ca_xyz, j));
+        cnt += (vi && i != j && !(d2 > C.d2_max)) ? 1u : 0u;
+    }
+    row_cnt[i] = cnt;
+}
+
+__global__ __launch_bounds__(FD_WAVE) void k_row_emit(fd_batch_view B, fd_hash_consts C, const uint64_t *__restrict__ row_off,
+                                                      uint32_t *__restrict__ keys) {
+    uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
+    if (w >= B.n_work) return;
+    const uint32_t s = B.wi_struct[w];
+    const uint32_t r0 = B.res_off[s], r1 = B.res_off[s + 1];
+    const uint32_t i = B.wi_i0[w] + threadIdx.x;
+    if (i >= r1 || !B.hash_ok[i]) return;
+    fd_v3 n1 = fd_load3(B.n_xyz, i), ca1 = fd_load3(B.ca_xyz, i), cb1 = fd_load3(B.cb_xyz, i);
+    uint32_t aa1 = B.aa[i];
+    uint64_t pos = row_off[i];
+    for (uint32_t j = r0; j < r1; ++j) {
+        if (!B.hash_ok[j] || i == j) continue;
+        fd_v3 ca2 = fd_load3(B.ca_xyz, j);
+        if (fd_dist2(ca1, ca2) > C.d2_max) continue;
+        fd_v3 n2 = fd_load3(B.n_xyz, j), cb2 = fd_load3(B.cb_xyz, j);
+        fd_feature f = fd_pair_feature(n1, ca1, cb1, n2, ca2, cb2);
+        keys[pos++] = fd_hash_pdbtr(aa1, B.aa[j], f, C.q);
+    }
+}
+
+// aa / cb_valid -> hash_ok
+__global__ void k_hash_ok(const uint8_t *__restrict__ aa, const uint8_t *__restrict__ cb_valid, uint8_t *__restrict__ ok, uint64_t n) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) ok[k] = (aa[k] != 255 && (cb_valid == nullptr || cb_valid[k])) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ launchers (called from fdgpu_api.hip)
+extern "C++" {
+void fd_launch_hash_ok(const uint8_t *aa, const uint8_t *cb_valid, uint8_t *ok, uint64_t n, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_hash_ok, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, aa, cb_valid, ok, n);
+}
+static inline unsigned grid_for(uint32_t n_work) { return ((n_work + 7u) / 8u) * 8u; }
+void fd_launch_pair_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *counts, hipStream_t st) {
+    if (!B.n_work) return;
+    hipLaunchKernelGGL(k_pair_count, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, counts);
+}
+void fd_launch_pair_emit(const fd_batch_view &B, const fd_hash_consts &C, const uint64_t *seg_off, uint32_t *cursor,
+                         uint32_t *keys, uint32_t *ids, uint32_t first_id, hipStream_t st) {
+    if (!B.n_work) return;
+    if (ids)
+        hipLaunchKernelGGL(k_pair_emit<true>, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, seg_off, cursor, keys, ids, first_id);
+    else
+        hipLaunchKernelGGL(k_pair_emit<false>, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, seg_off, cursor, keys, ids, first_id);
+}
+void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, hipStream_t st) {
+    if (!B.n_work) return;
+    hipLaunchKernelGGL(k_row_count, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, row_cnt);
+}
+void fd_launch_row_emit(const fd_batch_view &B, const fd_hash_consts &C, const uint64_t *row_off, uint32_t *keys, hipStream_t st) {
+    if (!B.n_work) return;
+    hipLaunchKernelGGL(k_row_emit, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, row_off, keys);
+}
+}

@@ -1,0 +1,190 @@
+// k_query.hip — posting-list lookup, varint decode and per-structure scoring on gfx950.
+//
+// Replaces HOT LOOP C of the reference: FolddiscoIndex::get_raw_entries / get_entries
+// (src/index/indextable.rs:53-86, 421-463: binary search + serial varint-delta decode) and
+// count_query (src/controller/count_query.rs:82-220: per query node, scan the postings of its
+// hashes, match_count += 1, idf_sum += log2(S/len), node / edge occupancy bit-vectors, then merge).
+//
+// Mapping: one wavefront per query hash. The list is consumed in 64-byte blocks (one byte per
+// lane): a ballot over the continuation bits finds the terminator lanes, each terminator
+// reassembles its value from the (<= 4) preceding lanes with shuffles, a wave prefix sum over the
+// deltas turns them into structure ids, and the ids are scored with integer atomics:
+//   match_count  u32 add
+//   idf_sum      u64 add of round(idf * 2^40)  (order-independent, unlike the reference's f32 sum whose
+//                order follows FxHashMap iteration; BASELINE.md §2 states the 1e-5 tolerance)
+//   node / edge occupancy  atomicOr into [n_nodes + n_edges][ceil(S/32)] bit matrices.
+// The finalize kernel counts set bits per structure with bit-sliced (carry-save) counters, 32
+// structures per lane, so its cost is (nodes+edges)·S/8 bytes of reads — SURVEY §8(d)'s figure.
+#include "fdgpu_internal.h"
+
+#define IDF_SCALE 1099511627776.0 /* 2^40 */
+
+__device__ __forceinline__ int64_t find_hash(const uint32_t *__restrict__ hashes, uint64_t H, uint32_t h) {
+    uint64_t lo = 0, hi = H;
+    while (lo < hi) {
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if (hashes[mid] < h) lo = mid + 1; else hi = mid;
+    }
+    return (lo < H && hashes[lo] == h) ? (int64_t)lo : -1;
+}
+
+// number of ids in each query hash's posting list (= bytes without the continuation bit)
+__global__ __launch_bounds__(FD_WAVE) void k_posting_lengths(const uint32_t *__restrict__ hashes, const uint64_t *__restrict__ offsets,
+                                                             const uint8_t *__restrict__ value, uint64_t H, const uint32_t *__restrict__ q_hash,
+                                                             uint64_t nq, uint64_t *__restrict__ lengths) {
+    uint64_t q = blockIdx.x;
+    if (q >= nq) return;
+    int64_t k = find_hash(hashes, H, q_hash[q]);
+    uint64_t cnt = 0;
+    if (k >= 0) {
+        uint64_t b0 = offsets[k], b1 = offsets[k + 1];
+        for (uint64_t p = b0 + threadIdx.x; p < b1; p += FD_WAVE) cnt += (value[p] & 0x80u) ? 0u : 1u;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, FD_WAVE);
+    if (threadIdx.x == 0) lengths[q] = cnt;
+}
+
+
+__global__ __launch_bounds__(FD_WAVE) void k_cq_accumulate(cq_args A) {
+    uint64_t q = blockIdx.x;
+    if (q >= A.nq) return;
+    int64_t k = find_hash(A.hashes, A.H, A.q_hash[q]);
+    if (k < 0) return;
+    const uint64_t b0 = A.offsets[k], b1 = A.offsets[k + 1];
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long idf_fix = A.q_idf_fix[q];
+    uint32_t *nb = A.node_bits + (uint64_t)A.q_node_idx[q] * A.words;
+    uint32_t *eb = A.edge_bits + (uint64_t)A.q_edge_idx[q] * A.words;
+    uint32_t run_id = 0;        // last decoded id (wave-uniform)
+    bool have_first = false;    // first value of the list is absolute
+    uint32_t carry_val = 0;     // partial varint spilling over from the previous block
+    uint32_t carry_shift = 0;
+    for (uint64_t base = b0; base < b1; base += FD_WAVE) {
+        uint64_t p = base + lane;
+        bool in = p < b1;
+        uint32_t byte = in ? A.value[p] : 0x80u;  // padding lanes look like continuation bytes
+        bool term = in && !(byte & 0x80u);
+        uint64_t tm = __ballot(term);
+        // start lane of the varint that ends at this terminator: one past the previous terminator
+        uint64_t below = tm & ((1ull << lane) - 1ull);
+        int prev_t = below ? 63 - __clzll(below) : -1;
+        uint32_t len_here = lane - (uint32_t)(prev_t + 1) + 1;  // bytes of this varint inside the block
+        // reassemble: little-endian 7-bit groups
+        uint32_t v = 0;
+        uint32_t pay = byte & 0x7fu;
+#pragma unroll
+        for (int back = 4; back >= 0; --back) {
+            uint32_t pb = __shfl(pay, (int)lane - back, FD_WAVE);
+            if ((uint32_t)back < len_here) v |= pb << (7u * (len_here - 1u - (uint32_t)back));
+        }
+        if (term && prev_t < 0) v = carry_val | (v << carry_shift);  // first terminator continues the spilled varint
+        // deltas -> ids: inclusive prefix sum over terminator lanes
+        uint32_t d = term ? v : 0u;
+        bool is_abs = term && !have_first && prev_t < 0;   // very first value of the list is the absolute id
+        uint32_t s = d;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(s, off, FD_WAVE);
+            if ((int)lane >= off) s += t;
+        }
+        uint32_t id = (have_first ? run_id : 0u) + s;
+        (void)is_abs;
+        if (term) {
+            uint32_t rel = id - A.first_id;
+            if (id >= A.first_id && rel < A.S) {
+                atomicAdd(&A.match[rel], 1u);
+                atomicAdd(&A.idf[rel], idf_fix);
+                atomicOr(&nb[rel >> 5], 1u << (rel & 31u));
+                atomicOr(&eb[rel >> 5], 1u << (rel & 31u));
+            }
+        }
+        // carry state to the next block (wave-uniform)
+        if (tm) {
+            int last_t = 63 - __clzll(tm);
+            run_id = __shfl(id, last_t, FD_WAVE);
+            have_first = true;
+            // bytes after the last terminator form a partial varint
+            uint32_t tail = 63u - (uint32_t)last_t;
+            uint32_t pv = 0;
+            for (uint32_t t2 = 0; t2 < tail && t2 < 5; ++t2) pv |= __shfl(pay, last_t + 1 + (int)t2, FD_WAVE) << (7u * t2);
+            carry_val = pv;
+            carry_shift = 7u * tail;
+        } else {
+            // whole block is continuation bytes (cannot happen for ids < 2^35, kept for safety)
+            uint32_t pv = carry_val;
+            for (uint32_t t2 = 0; t2 < 5; ++t2) pv |= __shfl(pay, (int)t2, FD_WAVE) << (carry_shift + 7u * t2);
+            carry_val = pv;
+            carry_shift += 7u * FD_WAVE;
+        }
+    }
+}
+
+// bit-sliced per-structure popcount over `rows` bit-vectors: lane handles one 32-structure word column
+__device__ __forceinline__ void sliced_add(uint32_t *pl, uint32_t x) {
+#pragma unroll
+    for (int k = 0; k < 20; ++k) {
+        uint32_t c = pl[k] & x;
+        pl[k] ^= x;
+        x = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cq_finalize(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ idf,
+                                                     const uint32_t *__restrict__ node_bits, uint32_t n_nodes,
+                                                     const uint32_t *__restrict__ edge_bits, uint32_t n_edges, uint32_t words, uint32_t S,
+                                                     uint32_t *__restrict__ node_cnt, uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    uint32_t any = 0;
+    uint32_t pn[20], pe[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) { pn[k] = 0; pe[k] = 0; }
+    for (uint32_t n = 0; n < n_nodes; ++n) { uint32_t x = node_bits[(uint64_t)n * words + w]; any |= x; sliced_add(pn, x); }
+    if (any) for (uint32_t e = 0; e < n_edges; ++e) sliced_add(pe, edge_bits[(uint64_t)e * words + w]);
+    for (uint32_t b = 0; b < 32; ++b) {
+        uint32_t nid = w * 32 + b;
+        if (nid >= S) break;
+        uint32_t nc = 0, ec = 0;
+#pragma unroll
+        for (int k = 0; k < 20; ++k) { nc |= ((pn[k] >> b) & 1u) << k; ec |= ((pe[k] >> b) & 1u) << k; }
+        node_cnt[nid] = nc;
+        edge_cnt[nid] = ec;
+        flags[nid] = match[nid] > 0 ? 1 : 0;
+    }
+}
+
+struct fd_count_rec_dev { uint32_t nid, total_match_count, node_count, edge_count; float idf; };
+
+__global__ __launch_bounds__(256) void k_cq_compact(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ idf,
+                                                    const uint32_t *__restrict__ node_cnt, const uint32_t *__restrict__ edge_cnt,
+                                                    const uint8_t *__restrict__ flags, const uint64_t *__restrict__ pos,
+                                                    const float *__restrict__ penalty, uint32_t S, uint32_t first_id,
+                                                    fd_count_rec_dev *__restrict__ out) {
+    uint32_t nid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nid >= S || !flags[nid]) return;
+    fd_count_rec_dev r;
+    r.nid = nid + first_id;
+    r.total_match_count = match[nid];
+    r.node_count = node_cnt[nid];
+    r.edge_count = edge_cnt[nid];
+    float sum = (float)((double)idf[nid] * (1.0 / IDF_SCALE));
+    r.idf = sum * penalty[nid];  // count_query.rs:200 idf_sum *= nres^(-lp)
+    out[pos[nid]] = r;
+}
+
+void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,
+                               uint64_t nq, uint64_t *lengths, hipStream_t st) {
+    if (nq) hipLaunchKernelGGL(k_posting_lengths, dim3((unsigned)nq), dim3(FD_WAVE), 0, st, hashes, offsets, value, H, q_hash, nq, lengths);
+}
+void fd_launch_cq_accumulate(const cq_args &A, hipStream_t st) {
+    if (A.nq) hipLaunchKernelGGL(k_cq_accumulate, dim3((unsigned)A.nq), dim3(FD_WAVE), 0, st, A);
+}
+void fd_launch_cq_finalize(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_bits, uint32_t n_nodes,
+                           const uint32_t *edge_bits, uint32_t n_edges, uint32_t words, uint32_t S, uint32_t *node_cnt, uint32_t *edge_cnt,
+                           uint8_t *flags, hipStream_t st) {
+    if (words) hipLaunchKernelGGL(k_cq_finalize, dim3((words + 255) / 256), dim3(256), 0, st, match, idf, node_bits, n_nodes, edge_bits, n_edges, words, S, node_cnt, edge_cnt, flags);
+}
+void fd_launch_cq_compact(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_cnt, const uint32_t *edge_cnt,
+                          const uint8_t *flags, const uint64_t *pos, const float *penalty, uint32_t S, uint32_t first_id, void *out,
+                          hipStream_t st) {
+    if (S) hipLaunchKernelGGL(k_cq_compact, dim3((S + 255) / 256), dim3(256), 0, st, match, idf, node_cnt, edge_cnt, flags, pos, penalty, S, first_id, (fd_count_rec_dev *)out);
+}

@@ -1,0 +1,254 @@
+// k_sort.hip — device-wide primitives for the posting build: exclusive scans and a stable
+// LSD radix sort of (u32 hash key, u32 structure id) pairs.
+//
+// Replaces HOT LOOP B of the reference (src/controller/mod.rs:349-358 +
+// src/index/indextable.rs:88-105,171-202: random read-modify-write into dense 2^30-entry tables)
+// with sort-based grouping: keys arrive id-major (segments per structure), a *stable* sort by the
+// 30-bit hash therefore yields, for every hash, its structure ids in ascending order — exactly the
+// order in which the reference appends to a posting list.
+//
+// HBM-bound integer work; wavefront idioms used: ballot-based multi-split for stable in-wave ranks
+// (wave64: one 64-bit ballot per digit bit), LDS-staged reorder so that global writes go out as
+// per-digit runs instead of 64 scattered dwords.
+#include "fd_device.h"
+
+// ------------------------------------------------------------------------ generic exclusive scan
+// out[k] = sum_{t<k} in[t], out[n] = total.  Three launches: chunk sums -> scan of sums -> apply.
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 16
+#define SCAN_CHUNK (SCAN_THREADS * SCAN_ITEMS)
+
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
+    uint32_t lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint64_t t = __shfl_up(v, off, FD_WAVE);
+        if ((int)lane >= off) v += t;
+    }
+    return v;
+}
+// block-wide exclusive scan of one value per thread (blockDim.x <= 1024); returns exclusive prefix,
+// *total = block sum.  sm must hold 16 u64.
+__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t *sm, uint64_t *total) {
+    uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    uint64_t inc = wave_incl_scan_u64(v);
+    if (lane == 63) sm[wid] = inc;
+    __syncthreads();
+    if (wid == 0) {
+        uint64_t t = lane < nw ? sm[lane] : 0;
+        uint64_t ti = wave_incl_scan_u64(t);
+        if (lane < nw) sm[lane] = ti - t;
+        if (lane == nw - 1) sm[16] = ti;
+    }
+    __syncthreads();
+    uint64_t r = inc - v + sm[wid];
+    *total = sm[16];
+    __syncthreads();
+    return r;
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const TIn *__restrict__ in, uint64_t n, uint64_t *__restrict__ chunk_sum) {
+    __shared__ uint64_t sm[17];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
+    uint64_t s = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t idx = base + (uint64_t)k * SCAN_THREADS + threadIdx.x;
+        if (idx < n) s += (uint64_t)in[idx];
+    }
+    uint64_t tot;
+    block_excl_scan_u64(s, sm, &tot);
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = tot;
+}
+// single block: exclusive scan of chunk sums in place; writes grand total to total_out[0]
+__global__ __launch_bounds__(1024) void k_scan_sums(uint64_t *__restrict__ chunk_sum, uint64_t n_chunks, uint64_t *__restrict__ total_out) {
+    __shared__ uint64_t sm[17];
+    uint64_t carry = 0;
+    for (uint64_t b = 0; b < n_chunks; b += 1024) {
+        uint64_t idx = b + threadIdx.x;
+        uint64_t v = idx < n_chunks ? chunk_sum[idx] : 0;
+        uint64_t tot;
+        uint64_t ex = block_excl_scan_u64(v, sm, &tot);
+        if (idx < n_chunks) chunk_sum[idx] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) total_out[0] = carry;
+}
+template <typename TIn>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const TIn *__restrict__ in, uint64_t n, const uint64_t *__restrict__ chunk_sum,
+                                                             const uint64_t *__restrict__ total, uint64_t *__restrict__ out) {
+    __shared__ uint64_t sm[17];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS];
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t idx = base + k;
+        v[k] = idx < n ? (uint64_t)in[idx] : 0;
+        s += v[k];
+    }
+    uint64_t tot;
+    uint64_t ex = block_excl_scan_u64(s, sm, &tot) + chunk_sum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t idx = base + k;
+        if (idx < n) out[idx] = ex;
+        ex += v[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total[0];
+}
+
+// NOTE: reduce uses a strided item->thread map, apply a blocked one; both cover the same chunk.
+template <typename TIn>
+void fd_exclusive_scan(const TIn *in, uint64_t n, uint64_t *out /*[n+1]*/, uint64_t *chunk_tmp, uint64_t *total_dev, hipStream_t st) {
+    uint64_t nc = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (nc == 0) nc = 1;
+    hipLaunchKernelGGL(k_scan_reduce<TIn>, dim3((unsigned)nc), dim3(SCAN_THREADS), 0, st, in, n, chunk_tmp);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, chunk_tmp, nc, total_dev);
+    hipLaunchKernelGGL(k_scan_apply<TIn>, dim3((unsigned)nc), dim3(SCAN_THREADS), 0, st, in, n, chunk_tmp, total_dev, out);
+}
+template void fd_exclusive_scan<uint32_t>(const uint32_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *, hipStream_t);
+template void fd_exclusive_scan<uint8_t>(const uint8_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *, hipStream_t);
+uint64_t fd_scan_tmp_elems(uint64_t n) { return (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1; }
+
+// ------------------------------------------------------------------------ radix sort
+#define RS_THREADS 256
+#define RS_ITEMS 16
+#define RS_TILE (RS_THREADS * RS_ITEMS)   // 4096 keys per workgroup
+#define RS_WAVES (RS_THREADS / 64)
+#define RS_BINS 256
+
+// tile histogram -> ghist[digit * nb + block]
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t *__restrict__ keys, uint64_t n, uint32_t shift, uint32_t mask,
+                                                        uint32_t *__restrict__ ghist, uint32_t nb) {
+    __shared__ uint32_t h[RS_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        uint64_t idx = base + (uint64_t)k * RS_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    ghist[(uint64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+// one workgroup per digit: exclusive scan of its row of nb tile counts (in place), row total -> tot[d]
+__global__ __launch_bounds__(1024) void k_rs_scan_rows(uint32_t *__restrict__ ghist, uint32_t nb, uint64_t *__restrict__ tot) {
+    __shared__ uint64_t sm[17];
+    uint32_t *row = ghist + (uint64_t)blockIdx.x * nb;
+    uint64_t carry = 0;
+    for (uint32_t b = 0; b < nb; b += 1024) {
+        uint32_t idx = b + threadIdx.x;
+        uint64_t v = idx < nb ? row[idx] : 0;
+        uint64_t t;
+        uint64_t ex = block_excl_scan_u64(v, sm, &t);
+        if (idx < nb) row[idx] = (uint32_t)(carry + ex);
+        carry += t;
+    }
+    if (threadIdx.x == 0) tot[blockIdx.x] = carry;
+}
+__global__ __launch_bounds__(RS_BINS) void k_rs_scan_tot(uint64_t *__restrict__ tot) {
+    __shared__ uint64_t sm[17];
+    uint64_t v = tot[threadIdx.x], t;
+    uint64_t ex = block_excl_scan_u64(v, sm, &t);
+    tot[threadIdx.x] = ex;
+}
+
+// stable scatter of one tile. Wave w owns the contiguous sub-tile [w*1024, (w+1)*1024) and walks it
+// in 64-key chunks (chunk c, lane l -> element c*64 + l) so that "earlier element" == "earlier
+// chunk or lower lane".
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                           uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
+                                                           uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
+                                                           const uint64_t *__restrict__ dbase) {
+    __shared__ uint32_t s_keys[RS_TILE];
+    __shared__ uint32_t s_vals[RS_TILE];
+    __shared__ uint32_t s_cnt[RS_WAVES][RS_BINS];  // per-wave digit counts, then running local positions
+    __shared__ uint32_t s_dstart[RS_BINS];         // tile-local start of each digit
+    __shared__ int64_t s_gofs[RS_BINS];            // global position = local position + s_gofs[digit]
+    __shared__ uint64_t sm[17];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint64_t tile_base = (uint64_t)blockIdx.x * RS_TILE;
+    const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * RS_ITEMS);
+    const uint32_t n_tile = (uint32_t)((n - tile_base) < RS_TILE ? (n - tile_base) : RS_TILE);
+
+    for (int w = 0; w < RS_WAVES; ++w) s_cnt[w][tid] = 0;
+    __syncthreads();
+
+    uint32_t key[RS_ITEMS], val[RS_ITEMS];
+#pragma unroll
+    for (int c = 0; c < RS_ITEMS; ++c) {
+        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
+        bool ok = idx < n;
+        key[c] = ok ? keys_in[idx] : 0xffffffffu;
+        val[c] = ok ? vals_in[idx] : 0u;
+        if (ok) atomicAdd(&s_cnt[wid][(key[c] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    // thread d: totals and per-wave bases for digit d
+    {
+        uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
+        uint64_t tot;
+        uint32_t dstart = (uint32_t)block_excl_scan_u64((uint64_t)(c0 + c1 + c2 + c3), sm, &tot);
+        s_dstart[tid] = dstart;
+        s_cnt[0][tid] = dstart;
+        s_cnt[1][tid] = dstart + c0;
+        s_cnt[2][tid] = dstart + c0 + c1;
+        s_cnt[3][tid] = dstart + c0 + c1 + c2;
+        s_gofs[tid] = (int64_t)(dbase[tid] + ghist[(uint64_t)tid * nb + blockIdx.x]) - (int64_t)dstart;
+    }
+    __syncthreads();
+    // in-wave stable ranks by ballot multi-split, running positions in s_cnt[wid][*]
+#pragma unroll
+    for (int c = 0; c < RS_ITEMS; ++c) {
+        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
+        bool ok = idx < n;
+        uint32_t d = (key[c] >> shift) & mask;
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            uint64_t bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        uint32_t rank = fd_mbcnt(peers);               // peers in lower lanes
+        uint32_t pcount = (uint32_t)__popcll(peers);
+        uint32_t pos = 0;
+        if (ok) pos = s_cnt[wid][d] + rank;
+        // the wave's LDS ops execute in order: every read above precedes the update below
+        if (ok && rank == pcount - 1) s_cnt[wid][d] = pos + 1;
+        if (ok) { s_keys[pos] = key[c]; s_vals[pos] = val[c]; }
+    }
+    __syncthreads();
+    // digit-contiguous in LDS -> runs in global memory
+    for (uint32_t k = tid; k < n_tile; k += RS_THREADS) {
+        uint32_t kk = s_keys[k];
+        int64_t g = (int64_t)k + s_gofs[(kk >> shift) & mask];
+        keys_out[g] = kk;
+        vals_out[g] = s_vals[k];
+    }
+}
+
+uint32_t fd_rs_num_tiles(uint64_t n) { return (uint32_t)((n + RS_TILE - 1) / RS_TILE); }
+
+// Sort (keys, vals) by the low `key_bits` bits of keys, stable. Buffers a/b ping-pong; returns which
+// buffer (0 = a, 1 = b) holds the result. ghist: u32[256 * tiles], tot: u64[256].
+int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits,
+                        uint32_t *ghist, uint64_t *tot, hipStream_t st) {
+    if (n == 0) return 0;
+    uint32_t nb = fd_rs_num_tiles(n);
+    int cur = 0;
+    for (int shift = 0; shift < key_bits; shift += 8) {
+        int bits = key_bits - shift < 8 ? key_bits - shift : 8;
+        uint32_t mask = (1u << bits) - 1u;
+        uint32_t *ki = cur ? keys_b : keys_a, *vi = cur ? vals_b : vals_a;
+        uint32_t *ko = cur ? keys_a : keys_b, *vo = cur ? vals_a : vals_b;
+        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(RS_THREADS), 0, st, ki, n, (uint32_t)shift, mask, ghist, nb);
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
+        hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, nb, tot);
+        cur ^= 1;
+    }
+    return cur;
+}

@@ -1,0 +1,177 @@
+/* fdgpu.h — C ABI of libfdgpu.so, the MI355X (gfx950) implementation of Folddisco's
+ * geometric-hash index-build and motif-query hot path.
+ *
+ * The reference (steineggerlab/folddisco, Rust) has no FFI for this path; its call seams
+ * are plain Rust functions.  Each entry point below replaces one seam and
+ * is what a `#[link(name = "fdgpu")] extern "C"` block in the reference would bind
+ * (INTEGRATION.md shows the Rust side).  Conventions follow the one FFI precedent in the
+ * reference, Foldcomp (lib/foldcomp/foldcompffi.h:8-21, src/structure/io/fcz.rs:82-93):
+ * opaque handles, borrowed inputs, malloc'd outputs owned by the caller and released with
+ * fdgpu_free().  Unlike Foldcomp nothing aborts: every call returns 0 or a negative
+ * FDGPU_E* code and fdgpu_last_error() gives the text.
+ *
+ * All pointers are plain host pointers unless a parameter says "device".  No torch types.
+ */
+#ifndef FDGPU_H
+#define FDGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDGPU_OK 0
+#define FDGPU_EINVAL (-1)   /* bad argument */
+#define FDGPU_EHIP (-2)     /* HIP runtime error (no device, launch failure, OOM) */
+#define FDGPU_ENOMEM (-3)   /* host allocation failed */
+#define FDGPU_ERANGE (-4)   /* size limit exceeded (e.g. structure > 65535 residues) */
+
+typedef struct fdgpu_ctx fdgpu_ctx;       /* one per GPU / HIP stream */
+typedef struct fdgpu_batch fdgpu_batch;   /* packed structures resident in HBM */
+typedef struct fdgpu_index fdgpu_index;   /* inverted index resident in HBM */
+
+/* ---- context ------------------------------------------------------------------------- */
+int fdgpu_create(int device, fdgpu_ctx **out);
+void fdgpu_destroy(fdgpu_ctx *ctx);
+/* use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream */
+int fdgpu_set_stream(fdgpu_ctx *ctx, void *hip_stream);
+int fdgpu_synchronize(fdgpu_ctx *ctx);
+const char *fdgpu_last_error(const fdgpu_ctx *ctx);
+void fdgpu_free(void *host_ptr);
+const char *fdgpu_version(void);
+
+/* ---- packed structures --------------------------------------------------------------------
+ * One batch = one rayon chunk of the reference (src/controller/mod.rs:282-348).  Residue k of
+ * structure s lives at r = res_off[s] + k.  This is CompactStructure
+ * (src/structure/core.rs:56-67) flattened: coordinates interleaved x,y,z as f32. */
+typedef struct fd_batch_desc {
+    uint64_t n_struct;
+    const uint64_t *res_off;   /* [n_struct+1], res_off[0] = 0 */
+    const float *n_xyz;        /* [3*R] backbone N  */
+    const float *ca_xyz;       /* [3*R] C-alpha     */
+    const float *cb_xyz;       /* [3*R] C-beta (real or approx_cb virtual); ignored where !cb_valid */
+    const uint8_t *aa;         /* [R] map_aa_to_u8 (src/utils/convert.rs:53-81): 0..19, 255 = unknown */
+    const uint8_t *cb_valid;   /* [R] 1 if CB is Some (src/structure/core.rs:147-155); NULL = all 1 */
+} fd_batch_desc;
+
+/* Parameters of the encoding: HashType::PDBTrRosetta (src/geometry/pdb_tr.rs:21-75).
+ * nbin_dist / nbin_angle follow the reference: 0 -> defaults 16 / 4, larger values clamp. */
+typedef struct fd_hash_params {
+    uint32_t nbin_dist;
+    uint32_t nbin_angle;
+    float dist_cutoff;         /* CA-CA cutoff in Angstrom (strict >, src/structure/core.rs:391) */
+} fd_hash_params;
+
+/* copy a host batch into HBM */
+int fdgpu_batch_upload(fdgpu_ctx *ctx, const fd_batch_desc *host, fdgpu_batch **out);
+/* wrap arrays that already live in HBM (all pointers in `dev` are device pointers; res_off too).
+ * The memory is borrowed, not owned. */
+int fdgpu_batch_wrap_device(fdgpu_ctx *ctx, const fd_batch_desc *dev, uint64_t total_residues,
+                            fdgpu_batch **out);
+void fdgpu_batch_destroy(fdgpu_batch *b);
+uint64_t fdgpu_batch_num_structures(const fdgpu_batch *b);
+uint64_t fdgpu_batch_num_residues(const fdgpu_batch *b);
+
+/* ---- S1: per-structure hashes -------------------------------------------------------------
+ * Replaces get_geometric_hash_as_u32_from_structure (src/controller/feature.rs:198-231)
+ * followed by the caller's sort_unstable(); dedup() (src/controller/mod.rs:343-345), for every
+ * structure of the batch.  *hashes = concatenated sorted-unique lists, (*hash_off)[s] .. [s+1].
+ * With sort_dedup = 0 the raw list in the reference's row-major pair order is returned. */
+int fdgpu_hash_batch(fdgpu_ctx *ctx, const fdgpu_batch *b, const fd_hash_params *p, int sort_dedup,
+                     uint32_t **hashes, uint64_t **hash_off);
+
+/* ---- S2: inverted index build ----------------------------------------------------------------
+ * Replaces Folddisco::collect_and_count + allocate_entries + add_entries +
+ * wrapup_offset_and_save_entries + prune_to_sparse (src/controller/mod.rs:274-441,
+ * src/index/indextable.rs:88-295) for the structures of `b`, which receive ids
+ * first_id, first_id+1, ...  The result (value bytes, sparse hashes, offsets) stays in HBM. */
+int fdgpu_index_build(fdgpu_ctx *ctx, const fdgpu_batch *b, const fd_hash_params *p, uint64_t first_id,
+                      fdgpu_index **out);
+/* copy the index to the host in the reference's on-disk layout:
+ * value = PREFIX file, hashes/offsets = payload of PREFIX.offset. */
+int fdgpu_index_export(fdgpu_ctx *ctx, const fdgpu_index *ix, uint8_t **value, uint64_t *value_len,
+                       uint32_t **hashes, uint64_t **offsets, uint64_t *n_hashes);
+/* upload an existing index (load_folddisco_index, src/index/indextable.rs:331-394).
+ * nres[S] = per-structure residue counts from the .lookup file (length penalty). */
+int fdgpu_index_load(fdgpu_ctx *ctx, const uint32_t *hashes, const uint64_t *offsets, uint64_t n_hashes,
+                     const uint8_t *value, uint64_t value_len, uint64_t n_structures, fdgpu_index **out);
+void fdgpu_index_destroy(fdgpu_index *ix);
+uint64_t fdgpu_index_num_hashes(const fdgpu_index *ix);
+uint64_t fdgpu_index_value_len(const fdgpu_index *ix);
+uint64_t fdgpu_index_num_postings(const fdgpu_index *ix);
+/* write PREFIX and PREFIX.offset byte-identically to save_offset_to_file (indextable.rs:297-326) */
+int fdgpu_index_save(fdgpu_ctx *ctx, const fdgpu_index *ix, const char *prefix);
+
+/* ---- S3: posting-list scoring -----------------------------------------------------------------
+ * posting-list lengths of query hashes: FolddiscoIndex::get_entries(h).len()
+ * (indextable.rs:83-86) — what calculate_idf_for_hash (src/controller/query.rs:17-32) and
+ * count_query (src/controller/count_query.rs:121-130) need for log2(S / len). */
+int fdgpu_posting_lengths(fdgpu_ctx *ctx, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t n_q,
+                          uint64_t *lengths);
+
+typedef struct fd_count_rec {   /* one touched structure (StructureResult prefilter fields) */
+    uint32_t nid;
+    uint32_t total_match_count;
+    uint32_t node_count;
+    uint32_t edge_count;
+    float idf;                  /* sum_hits log2(S/len) * nres^(-length_penalty) */
+} fd_count_rec;
+
+/* Replaces count_query (src/controller/count_query.rs:82-220), no sampling.
+ * q_hash[k] belongs to query edge (q_node[k], q_edge_j[k]) (= first / second query residue).
+ * q_idf[k] = log2(S / len(posting(q_hash[k]))) as computed by the caller (glibc log2f keeps the
+ * reference's bits); hashes failing freq_filter must be dropped by the caller.
+ * penalty[nid] = (nres[nid] as f32).powf(-lp) (count_query.rs:200), n_structures entries.
+ * Results: touched structures in ascending nid. */
+int fdgpu_count_query(fdgpu_ctx *ctx, const fdgpu_index *ix, const uint32_t *q_hash, const uint32_t *q_node,
+                      const uint32_t *q_edge_j, const float *q_idf, uint64_t n_q, const float *penalty,
+                      fd_count_rec **out, uint64_t *n_out);
+
+/* ---- S4: candidate matching + RMSD --------------------------------------------------------------
+ * Pair scan of retrieve_with_prefilter (src/controller/retrieve.rs:52-156) over candidate
+ * structures of a resident batch.  For candidate c = cand[k] every ordered residue pair (i,j)
+ * that passes the CA cutoff, the amino-acid/CA-distance window test against the query's
+ * observed (aa_i, aa_j, dist, qi) list and has a feature is a "candidate pair"; those whose
+ * hash is in the (sorted) query hash set are "found" triples. */
+typedef struct fd_pair_rec { uint32_t cand; uint32_t i; uint32_t j; uint32_t hash; } fd_pair_rec;
+typedef struct fd_cand_rec { uint32_t cand; uint32_t qi; uint32_t i; uint32_t j; } fd_cand_rec;
+typedef struct fd_match_query {
+    const uint32_t *hashes;     /* sorted unique query hashes */
+    uint64_t n_hashes;
+    const uint8_t *aad_aa1, *aad_aa2;   /* observed_distance_map flattened (query.rs:271-281) */
+    const float *aad_dist;
+    const uint32_t *aad_qi;
+    uint64_t n_aad;
+    float ca_distance_cutoff;   /* --ca-distance, default 1.0 */
+    int use_aa_prefilter;       /* prefilter_amino_acid active (<= 200 query hashes, retrieve.rs:569) */
+} fd_match_query;
+/* resname_std[r] = 1 if the residue's 3-letter name equals map_u8_to_aa(aa) (retrieve.rs:580-586);
+ * needed only when use_aa_prefilter. Pass NULL to treat every residue with aa < 20 as standard. */
+int fdgpu_match_pairs(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *resname_std,
+                      const uint32_t *cand, uint64_t n_cand, const fd_match_query *q, const fd_hash_params *p,
+                      fd_pair_rec **found, uint64_t *n_found, fd_cand_rec **cands, uint64_t *n_cands);
+
+/* Batched Kabsch (src/structure/kabsch.rs:157-554, mode 2): problem k superposes
+ * x[off[k]..off[k+1]) (moving = target points) onto y[...] (fixed = query points);
+ * points are xyz f32.  rmsd[k] f32, rot[9k..], tran[3k..]. */
+int fdgpu_kabsch_batch(fdgpu_ctx *ctx, const float *x, const float *y, const uint64_t *off, uint64_t n_problems,
+                       float *rmsd, float *rot, float *tran);
+
+/* ---- profiling hooks ------------------------------------------------------------------------------
+ * Per-kernel timing of the last fdgpu_index_build / fdgpu_count_query call, measured with
+ * HIP events on the context's stream. names[i] is a static string. Returns the number of
+ * entries written (<= cap). */
+int fdgpu_last_timings(const fdgpu_ctx *ctx, const char **names, float *ms, uint64_t *bytes, int cap);
+int fdgpu_enable_timing(fdgpu_ctx *ctx, int on);
+
+/* ---- diagnostics ---------------------------------------------------------------------------------------
+ * Evaluates the device restatements of glibc's sinf/cosf/acosf/atanf/atan2f (csrc/fd_libm.h) or the
+ * pair descriptor on arrays, so that tests can compare the gfx950 arithmetic bit-for-bit with the host.
+ * op: 0 sinf, 1 cosf, 2 acosf, 3 atanf, 4 atan2f(a, b). */
+int fdgpu_debug_libm(fdgpu_ctx *ctx, int op, const float *a, const float *b, float *out, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

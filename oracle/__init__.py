@@ -92,6 +92,8 @@ def lib():
     L.fdo_get_index.argtypes = [SP, C.c_uint8, C.c_uint64]
     L.fdo_map_aa_to_u8.restype = C.c_uint8
     L.fdo_map_aa_to_u8.argtypes = [C.c_char_p]
+    L.fdo_map_u8_to_aa.restype = C.c_char_p
+    L.fdo_map_u8_to_aa.argtypes = [C.c_uint8]
     L.fdo_pair_feature.restype = C.c_int
     L.fdo_pair_feature.argtypes = [SP, C.c_int64, C.c_int64, C.c_float, f32p]
     L.fdo_discretize.restype = C.c_uint32

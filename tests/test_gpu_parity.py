@@ -1,0 +1,225 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI
+(libfdgpu.so) and is compared with the CPU oracle on the same inputs.
+Bit-exact: u32 hashes, posting bytes, offsets, counts, residue indices. RMSD: |d| <= 1e-4. idf: rel 1e-5."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.helpers import (Q4CHA, SER, oracle_structs_to_packed, packed_to_oracle_structs, synthetic_packed)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import folddisco_amd as fd
+    c = fd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ser(ctx):
+    structs = [oracle.read_pdb(p) for p in SER]
+    ps, std = oracle_structs_to_packed(structs)
+    batch = ctx.upload(ps)
+    return structs, ps, std, batch
+
+
+def _bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_device_libm_bit_exact(ctx):
+    """gfx950 evaluation of csrc/fd_libm.h == host glibc, bit for bit, on 4M samples per function."""
+    rng = np.random.Generator(np.random.PCG64(7))
+    libm = C.CDLL("libm.so.6")
+    n = 1 << 22
+    def run(op, a, b=None):
+        a = np.ascontiguousarray(a, np.float32)
+        out = np.zeros_like(a)
+        bp = None if b is None else np.ascontiguousarray(b, np.float32)
+        ctx.check(ctx.L.fdgpu_debug_libm(ctx.h, op, a.ctypes.data_as(C.POINTER(C.c_float)),
+                                         None if bp is None else bp.ctypes.data_as(C.POINTER(C.c_float)),
+                                         out.ctypes.data_as(C.POINTER(C.c_float)), len(a)))
+        return out
+    ang = np.concatenate([rng.uniform(-np.pi, np.pi, n - 8).astype(np.float32),
+                          np.array([0, -0.0, np.pi, -np.pi, 1e-8, np.nan, 0.75, 0.7499999], np.float32)])
+    for op, fn in ((0, np.sin), (1, np.cos)):
+        cfn = getattr(libm, "sinf" if op == 0 else "cosf")
+        cfn.restype = C.c_float; cfn.argtypes = [C.c_float]
+        got = run(op, ang)
+        idx = rng.integers(0, n, 200000)
+        ref = np.array([cfn(float(x)) for x in ang[idx]], np.float32)
+        ok = (_bits(got[idx]) == _bits(ref)) | (np.isnan(got[idx]) & np.isnan(ref))
+        assert ok.all()
+    x = np.concatenate([rng.uniform(-1.0000001, 1.0000001, n - 4).astype(np.float32), np.array([1, -1, 0, np.nan], np.float32)])
+    libm.acosf.restype = C.c_float; libm.acosf.argtypes = [C.c_float]
+    got = run(2, x)
+    idx = rng.integers(0, n, 200000)
+    ref = np.array([libm.acosf(float(v)) for v in x[idx]], np.float32)
+    assert ((_bits(got[idx]) == _bits(ref)) | (np.isnan(got[idx]) & np.isnan(ref))).all()
+    y = rng.uniform(-1, 1, n).astype(np.float32)
+    z = rng.uniform(-1, 1, n).astype(np.float32)
+    y[:4] = [0, -0.0, 1e-30, np.nan]
+    libm.atan2f.restype = C.c_float; libm.atan2f.argtypes = [C.c_float, C.c_float]
+    got = run(4, y, z)
+    idx = np.concatenate([np.arange(8), rng.integers(0, n, 200000)])
+    ref = np.array([libm.atan2f(float(a), float(b)) for a, b in zip(y[idx], z[idx])], np.float32)
+    assert ((_bits(got[idx]) == _bits(ref)) | (np.isnan(got[idx]) & np.isnan(ref))).all()
+
+
+def test_hash_raw_order_serine(ctx, ser):
+    import folddisco_amd as fd
+    structs, ps, std, batch = ser
+    h, off = fd.get_geometric_hash_as_u32(ctx, batch, sort_dedup=False)
+    assert list(np.diff(off.astype(np.int64))) == [71946, 68430, 74664, 24148, 57974]
+    for s, st in enumerate(structs):
+        ref = oracle.hash_structure(st)
+        assert np.array_equal(h[int(off[s]):int(off[s + 1])], ref), f"structure {s}"
+
+
+def test_hash_sorted_unique_serine(ctx, ser):
+    import folddisco_amd as fd
+    structs, ps, std, batch = ser
+    h, off = fd.get_geometric_hash_as_u32(ctx, batch, sort_dedup=True)
+    assert list(np.diff(off.astype(np.int64))) == [47512, 67129, 46795, 23853, 40385]
+    for s, st in enumerate(structs):
+        assert np.array_equal(h[int(off[s]):int(off[s + 1])], np.unique(oracle.hash_structure(st)))
+
+
+def test_index_build_serine_byte_identical(ctx, ser, tmp_path):
+    import folddisco_amd as fd
+    structs, ps, std, batch = ser
+    ix = fd.FolddiscoIndex.build(ctx, batch)
+    assert ix.num_hashes == 217612 and ix.value_len == 225674 and ix.num_postings == 225674
+    v, h, o = ix.export()
+    oix, nres, plddt = oracle.build_index(structs)
+    assert np.array_equal(h, oix.hashes()) and np.array_equal(o, oix.offsets()) and np.array_equal(v, oix.values())
+    # on-disk files byte-identical to the reference format written by the oracle
+    ix.save(str(tmp_path / "gpu"))
+    oix.save(str(tmp_path / "cpu"))
+    for ext in ("", ".offset"):
+        assert open(str(tmp_path / "gpu") + ext, "rb").read() == open(str(tmp_path / "cpu") + ext, "rb").read()
+
+
+@pytest.mark.parametrize("n_struct,seed", [(1, 3), (37, 11), (160, 5)])
+def test_index_build_synthetic(ctx, n_struct, seed):
+    import folddisco_amd as fd
+    ps = synthetic_packed(n_struct, seed)
+    batch = ctx.upload(ps)
+    ix = fd.FolddiscoIndex.build(ctx, batch)
+    v, h, o = ix.export()
+    structs = packed_to_oracle_structs(ps)
+    oix, _, _ = oracle.build_index(structs)
+    assert np.array_equal(h, oix.hashes()) and np.array_equal(o, oix.offsets()) and np.array_equal(v, oix.values())
+
+
+def test_index_edge_cases(ctx):
+    import folddisco_amd as fd
+    # empty batch, empty structures, unknown residues, missing CB, multi-byte varints via first_id
+    ps = fd.PackedStructures(np.zeros(1, np.uint64), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0, np.uint8))
+    ix = fd.FolddiscoIndex.build(ctx, ctx.upload(ps))
+    v, h, o = ix.export()
+    assert len(v) == 0 and len(h) == 0 and list(o) == [0]
+    base = synthetic_packed(6, 21, lengths=np.array([40, 64, 65, 128, 1, 200]))
+    aa = base.aa.copy(); aa[5] = 255; aa[70] = 255
+    cbv = np.ones(len(aa), np.uint8); cbv[10] = 0; cbv[150] = 0
+    # insert an empty structure in the middle (skipped/oversize structures keep their id, mod.rs:313-318)
+    off = base.res_off.astype(np.int64)
+    off2 = np.concatenate([off[:3], off[2:3], off[3:]]).astype(np.uint64)
+    ps = fd.PackedStructures(off2, base.n_xyz, base.ca_xyz, base.cb_xyz, aa, cbv)
+    first_id = 16380  # ids straddle the 1->2->3 byte varint boundaries (16384)
+    ix = fd.FolddiscoIndex.build(ctx, ctx.upload(ps), first_id=first_id)
+    v, h, o = ix.export()
+    structs = packed_to_oracle_structs(ps)
+    lists = [np.unique(oracle.hash_structure(s)) for s in structs]
+    L = oracle.lib()
+    oix = L.fdo_index_new(30)
+    for fn in (L.fdo_index_count_single_entry, L.fdo_index_add_single_entry):
+        for s, lst in enumerate(lists):
+            for x in lst:
+                fn(oix, int(x), first_id + s)
+        if fn is L.fdo_index_count_single_entry:
+            L.fdo_index_allocate_entries(oix)
+    L.fdo_index_finish(oix)
+    oi = oracle.OIndex(oix)
+    assert np.array_equal(h, oi.hashes()) and np.array_equal(o, oi.offsets()) and np.array_equal(v, oi.values())
+    assert len(lists[3]) == 0 and len(lists[5]) == 0  # the inserted empty structure and the 1-residue one
+
+
+def _query_arrays(m):
+    a = m.arrays()
+    return a["hash"], a["qi"].astype(np.uint32), a["qj"].astype(np.uint32)
+
+
+def test_posting_lengths_and_count_query_serine(ctx, ser):
+    import folddisco_amd as fd
+    structs, ps, std, batch = ser
+    ix = fd.FolddiscoIndex.build(ctx, batch)
+    oix, nres, plddt = oracle.build_index(structs)
+    q = oracle.read_pdb(Q4CHA)
+    m = oracle.make_query_map(q, "B57,B102,C195", oix, float(len(structs)))
+    qh, qi, qj = _query_arrays(m)
+    lens = ix.posting_lengths(qh)
+    assert list(lens) == [len(oix.entries(int(x))) for x in qh]
+    absent = ix.posting_lengths(np.array([0, 1, 2 ** 30 - 1], np.uint32))
+    assert list(absent) == [0, 0, 0]
+    pen = fd.length_penalty(nres, 0.5)
+    got = fd.count_query(ctx, ix, qh, qi, qj, pen)
+    ref = oracle.count_query(m, oix, nres)
+    assert [(r["nid"], r["total_match_count"], r["node_count"], r["edge_count"]) for r in got] == \
+           [(r["nid"], r["total_match_count"], r["node_count"], r["edge_count"]) for r in ref]
+    for g, r in zip(got, ref):
+        assert abs(g["idf"] - r["idf"]) <= 1e-5 * max(abs(r["idf"]), 1e-30)
+    # README.md:237-241 directly
+    assert {(r["nid"], "%.4f" % r["idf"]) for r in got} == {(4, "0.6138"), (3, "0.4869"), (1, "0.0617"), (2, "0.0584"), (0, "0.1856")}
+
+
+def test_count_query_synthetic_long_postings(ctx):
+    """lists with multi-byte deltas and > 64-byte blocks: whole-structure query of structure 0 against 300 structures."""
+    import folddisco_amd as fd
+    ps = synthetic_packed(300, 9, lengths=np.full(300, 60))
+    batch = ctx.upload(ps)
+    ix = fd.FolddiscoIndex.build(ctx, batch, first_id=0)
+    structs = packed_to_oracle_structs(ps)
+    oix, nres, _ = oracle.build_index(structs)
+    m = oracle.make_query_map(structs[0], "", oix, 300.0)
+    qh, qi, qj = _query_arrays(m)
+    assert list(ix.posting_lengths(qh)) == [len(oix.entries(int(x))) for x in qh]
+    got = fd.count_query(ctx, ix, qh, qi, qj, fd.length_penalty(nres))
+    ref = oracle.count_query(m, oix, nres)
+    assert [(r["nid"], r["total_match_count"], r["node_count"], r["edge_count"]) for r in got] == \
+           [(r["nid"], r["total_match_count"], r["node_count"], r["edge_count"]) for r in ref]
+    for g, r in zip(got, ref):
+        assert abs(g["idf"] - r["idf"]) <= 1e-5 * max(abs(r["idf"]), 1e-30)
+
+
+def test_match_pairs_and_kabsch_serine(ctx, ser):
+    from folddisco_amd import match
+    structs, ps, std, batch = ser
+    oix, nres, _ = oracle.build_index(structs)
+    q = oracle.read_pdb(Q4CHA)
+    m = oracle.make_query_map(q, "B57,B102,C195", oix, float(len(structs)))
+    a = m.arrays()
+    for ca_cut in (1.0, 1.5):
+        found, cands = match.match_pairs(ctx, batch, std, np.arange(5, dtype=np.uint32), a, ca_distance_cutoff=ca_cut)
+        for nid, t in enumerate(structs):
+            R = oracle.retrieve(t, q, m, ca_distance_cutoff=ca_cut)
+            f = found[found[:, 0] == nid][:, 1:]
+            c = cands[cands[:, 0] == nid][:, 1:]
+            assert np.array_equal(f.astype(np.uint64), R["found"]), (nid, ca_cut)
+            assert np.array_equal(c.astype(np.uint64), R["cand"]), (nid, ca_cut)
+    # Kabsch on the reference's own triads (structure/kabsch.rs:563-616) + the oracle's results
+    src = np.array([[6.994, 8.354, 42.405], [9.429, 7.479, 48.266], [5.547, 0.158, 42.050]], np.float32)
+    t1 = np.array([[-13.958, -1.741, -4.223], [-12.833, 3.134, -7.780], [-5.720, -2.218, -3.368]], np.float32)
+    t2 = np.array([[-4.924, 5.813, -9.485], [-0.499, 10.073, -8.059], [-0.792, 0.658, -4.430]], np.float32)
+    xs = np.concatenate([t1, t2, src]); ys = np.concatenate([src, src, src])
+    rmsd, rot, tran = match.kabsch_batch(ctx, xs, ys, np.array([0, 3, 6, 9], np.uint64))
+    for k, (x, y) in enumerate(((t1, src), (t2, src), (src, src))):
+        r, R, T = oracle.kabsch(x, y)
+        assert abs(rmsd[k] - r) <= 1e-4 and np.allclose(rot[k], R, atol=1e-4) and np.allclose(tran[k], T, atol=1e-3)
+    assert rmsd[0] < 0.2 and rmsd[1] < 0.2 and rmsd[2] < 1e-6

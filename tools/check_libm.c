@@ -27,6 +27,13 @@ int main(int argc, char **argv) {
 #pragma omp parallel for schedule(static) reduction(+ : bad_sin, bad_cos, bad_acos, bad_atan)
     for (uint64_t u = 0; u < (1ull << 32); u += step) {
         float x = fd_u2f((uint32_t)u);
+        if (!same(fdd_acosf(x), acosf(x))) { if (bad_acos++ < 3) fprintf(stderr, "fdd_acosf %08x\n", (unsigned)u); }
+        if (!same(fdd_atanf(x), atanf(x))) { if (bad_atan++ < 3) fprintf(stderr, "fdd_atanf %08x\n", (unsigned)u); }
+        if (fabsf(x) < 120.0f || x != x) {
+            float ss, cc; fdd_sincosf(x, &ss, &cc);
+            if (!same(ss, sinf(x))) { if (bad_sin++ < 3) fprintf(stderr, "fdd_sin %08x\n", (unsigned)u); }
+            if (!same(cc, cosf(x))) { if (bad_cos++ < 3) fprintf(stderr, "fdd_cos %08x\n", (unsigned)u); }
+        }
         if (!same(fd_acosf(x), acosf(x))) { if (bad_acos++ < 3) fprintf(stderr, "acosf %08x\n", (unsigned)u); }
         if (!same(fd_atanf(x), atanf(x))) { if (bad_atan++ < 3) fprintf(stderr, "atanf %08x\n", (unsigned)u); }
         if (fabsf(x) < 120.0f) {
@@ -54,13 +61,16 @@ int main(int argc, char **argv) {
             if (!same(fd_atan2f(y, x), atan2f(y, x))) {
                 if (bad_atan2++ < 3) fprintf(stderr, "atan2f %08x %08x\n", fd_f2u(y), fd_f2u(x));
             }
+            if (!same(fdd_atan2f(y, x), atan2f(y, x))) {
+                if (bad_atan2++ < 3) fprintf(stderr, "fdd_atan2f %08x %08x\n", fd_f2u(y), fd_f2u(x));
+            }
         }
     }
     static const float sp[] = {0.f, -0.f, 1.f, -1.f, INFINITY, -INFINITY, NAN, 1e-30f, -1e-30f, 1e30f, -1e30f,
                                0.5f, -0.5f, 2.f, 1e-45f, 3.4e38f};
     for (unsigned a = 0; a < sizeof sp / 4; ++a)
         for (unsigned b = 0; b < sizeof sp / 4; ++b)
-            if (!same(fd_atan2f(sp[a], sp[b]), atan2f(sp[a], sp[b]))) {
+            if (!same(fd_atan2f(sp[a], sp[b]), atan2f(sp[a], sp[b])) || !same(fdd_atan2f(sp[a], sp[b]), atan2f(sp[a], sp[b]))) {
                 bad_atan2++; fprintf(stderr, "atan2f special %g %g\n", sp[a], sp[b]);
             }
     printf("mismatches: sinf %llu cosf %llu acosf %llu atanf %llu atan2f %llu\n", bad_sin, bad_cos, bad_acos,
