@@ -148,7 +148,7 @@ def test_index_edge_cases(ctx):
     L.fdo_index_finish(oix)
     oi = oracle.OIndex(oix)
     assert np.array_equal(h, oi.hashes()) and np.array_equal(o, oi.offsets()) and np.array_equal(v, oi.values())
-    assert len(lists[3]) == 0 and len(lists[5]) == 0  # the inserted empty structure and the 1-residue one
+    assert len(lists[2]) == 0 and len(lists[5]) == 0  # the inserted empty structure and the 1-residue one
 
 
 def _query_arrays(m):
