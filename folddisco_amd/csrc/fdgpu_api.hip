@@ -45,30 +45,6 @@ void fd_launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t n, 
     if (n) hipLaunchKernelGGL(k_gather_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, idx, n, dst);
 }
 
-// ---- timing helpers -------------------------------------------------------------------------------------
-static hipEvent_t next_event(fdgpu_ctx *c) {
-    if (c->event_used == c->event_pool.size()) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return nullptr;
-        c->event_pool.push_back(e);
-    }
-    return c->event_pool[c->event_used++];
-}
-struct StageTimer {
-    fdgpu_ctx *c;
-    size_t idx = (size_t)-1;
-    StageTimer(fdgpu_ctx *ctx, const char *name, uint64_t bytes) : c(ctx) {
-        if (!c->timing) return;
-        fd_timing_entry t;
-        t.name = name; t.bytes = bytes; t.ev0 = next_event(c); t.ev1 = next_event(c);
-        if (!t.ev0 || !t.ev1) return;
-        (void)hipEventRecord(t.ev0, c->stream);
-        c->timings.push_back(t);
-        idx = c->timings.size() - 1;
-    }
-    void set_bytes(uint64_t b) { if (idx != (size_t)-1) c->timings[idx].bytes = b; }
-    ~StageTimer() { if (idx != (size_t)-1) (void)hipEventRecord(c->timings[idx].ev1, c->stream); }
-};
 static void reset_timings(fdgpu_ctx *c) { c->timings.clear(); c->event_used = 0; }
 
 // ---- context ------------------------------------------------------------------------------------------------
@@ -380,10 +356,7 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
         fd_launch_pair_emit(b->view(), C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, ia, (uint32_t)first_id, st);
     }
     int cur;
-    {
-        StageTimer t(c, "radix_sort", P * 20 * 4);
-        cur = fd_radix_sort_pairs(ka, ia, kb, ib, P, 30, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st);
-    }
+    cur = fd_radix_sort_pairs(ka, ia, kb, ib, P, 30, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st, c);
     const uint32_t *ks = cur ? kb : ka, *is = cur ? ib : ia;
     uint32_t nt = std::max<uint32_t>(fd_enc_num_tiles(P), 1);
     HIPCHK(c, c->ws[WS_TILE_B].ensure((size_t)(nt + 1) * 4));

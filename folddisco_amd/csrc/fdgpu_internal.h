@@ -43,6 +43,30 @@ struct fdgpu_ctx {
     size_t event_used = 0;
 };
 
+// HIP-event stage timer (active only after fdgpu_enable_timing(ctx, 1))
+static inline hipEvent_t fd_next_event(fdgpu_ctx *c) {
+    if (c->event_used == c->event_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->event_pool.push_back(e);
+    }
+    return c->event_pool[c->event_used++];
+}
+struct StageTimer {
+    fdgpu_ctx *c;
+    size_t idx = (size_t)-1;
+    StageTimer(fdgpu_ctx *ctx, const char *name, uint64_t bytes) : c(ctx) {
+        if (!c || !c->timing) return;
+        fd_timing_entry t;
+        t.name = name; t.bytes = bytes; t.ev0 = fd_next_event(c); t.ev1 = fd_next_event(c);
+        if (!t.ev0 || !t.ev1) return;
+        (void)hipEventRecord(t.ev0, c->stream);
+        c->timings.push_back(t);
+        idx = c->timings.size() - 1;
+    }
+    ~StageTimer() { if (idx != (size_t)-1) (void)hipEventRecord(c->timings[idx].ev1, c->stream); }
+};
+
 struct fdgpu_batch {
     fdgpu_ctx *ctx = nullptr;
     bool owns = false;
@@ -81,7 +105,7 @@ void fd_exclusive_scan(const TIn *in, uint64_t n, uint64_t *out, uint64_t *chunk
 uint64_t fd_scan_tmp_elems(uint64_t n);
 uint32_t fd_rs_num_tiles(uint64_t n);
 int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits, uint32_t *ghist,
-                        uint64_t *tot, hipStream_t st);
+                        uint64_t *tot, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr);
 uint32_t fd_enc_num_tiles(uint64_t n);
 void fd_launch_enc_sizes(const uint32_t *keys, const uint32_t *ids, uint64_t n, uint32_t *tb, uint32_t *th, uint32_t *tp, hipStream_t st);
 void fd_launch_enc_write(const uint32_t *keys, const uint32_t *ids, uint64_t n, const uint64_t *tbo, const uint64_t *tho, uint8_t *value,

@@ -10,7 +10,7 @@
 // HBM-bound integer work; wavefront idioms used: ballot-based multi-split for stable in-wave ranks
 // (wave64: one 64-bit ballot per digit bit), LDS-staged reorder so that global writes go out as
 // per-digit runs instead of 64 scattered dwords.
-#include "fd_device.h"
+#include "fdgpu_internal.h"
 
 // ------------------------------------------------------------------------ generic exclusive scan
 // out[k] = sum_{t<k} in[t], out[n] = total.  Three launches: chunk sums -> scan of sums -> apply.
@@ -235,7 +235,7 @@ uint32_t fd_rs_num_tiles(uint64_t n) { return (uint32_t)((n + RS_TILE - 1) / RS_
 // Sort (keys, vals) by the low `key_bits` bits of keys, stable. Buffers a/b ping-pong; returns which
 // buffer (0 = a, 1 = b) holds the result. ghist: u32[256 * tiles], tot: u64[256].
 int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits,
-                        uint32_t *ghist, uint64_t *tot, hipStream_t st) {
+                        uint32_t *ghist, uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
     if (n == 0) return 0;
     uint32_t nb = fd_rs_num_tiles(n);
     int cur = 0;
@@ -244,10 +244,19 @@ int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, ui
         uint32_t mask = (1u << bits) - 1u;
         uint32_t *ki = cur ? keys_b : keys_a, *vi = cur ? vals_b : vals_a;
         uint32_t *ko = cur ? keys_a : keys_b, *vo = cur ? vals_a : vals_b;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(RS_THREADS), 0, st, ki, n, (uint32_t)shift, mask, ghist, nb);
-        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
-        hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, nb, tot);
+        {
+            StageTimer t(tc, "rs_hist", n * 4 + (uint64_t)nb * RS_BINS * 4);
+            hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(RS_THREADS), 0, st, ki, n, (uint32_t)shift, mask, ghist, nb);
+        }
+        {
+            StageTimer t(tc, "rs_scan", (uint64_t)nb * RS_BINS * 8);
+            hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
+            hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
+        }
+        {
+            StageTimer t(tc, "rs_scatter", n * 16);
+            hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, nb, tot);
+        }
         cur ^= 1;
     }
     return cur;
