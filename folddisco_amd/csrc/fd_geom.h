@@ -91,3 +91,75 @@ FD_HD uint32_t fd_hash_pdbtr(uint32_t aa1, uint32_t aa2, fd_feature f, fd_quant 
     uint32_t qs2 = fd_q(s2, -1.0f, q.ang_disc), qc2 = fd_q(c2, -1.0f, q.ang_disc);
     return aa1 << 25 | aa2 << 20 | ca << 16 | cb << 12 | qs0 << 10 | qc0 << 8 | qs1 << 6 | qc1 << 4 | qs2 << 2 | qc2;
 }
+
+// =============================================================================================
+// Shared-subexpression form used by the index-build kernel: per-residue frames + both orientations
+// of an unordered pair at once.  Everything is bit-identical to fd_pair_feature()/fd_hash_pdbtr()
+// above; the savings come from IEEE identities that hold exactly:
+//   a*b == b*a,  fl(-x) exact,  fl(p - q) == -fl(q - p),  normalize(-v) == -normalize(v)
+// so that   cross(a, b) == -cross(b, a)   and   cross(-a, -b) == cross(a, b)   hold bit for bit.
+// With v1 = cb_i-ca_i, v2 = cb_j-ca_j, v3 = cb_j-cb_i,  A = n^(v1 x v3),  B = n^(v3 x v2):
+//   torsion1(i,j): r = r1_i, s =  A, t = t1_i          torsion2(i,j): r = -B, s = s2_j, t = n^(r x nv2_j)
+//   torsion1(j,i): r = r1_j, s =  B, t = t1_j          torsion2(j,i): r = -A, s = s2_i, t = n^(r x nv2_i)
+// and d_CA, d_CB, theta are symmetric.  8 normalisations per ordered pair become 2.
+// =============================================================================================
+struct fd_frame {
+    fd_v3 ca, cb;
+    fd_v3 r1, t1;    // torsion(n, ca, cb, *):  r = n^((ca-n) x (cb-ca)),  t = n^(r x n^(cb-ca))
+    fd_v3 s2, nv2;   // torsion(*, cb, ca, n):  s = n^((ca-cb) x (n-ca)),  n^(ca-cb)
+    float len;       // |cb-ca| as evaluated by calc_angle
+    float pad;
+};
+
+FD_HD fd_frame fd_make_frame(fd_v3 n, fd_v3 ca, fd_v3 cb) {
+    fd_frame F;
+    F.ca = ca; F.cb = cb;
+    fd_v3 v1 = fd_sub(ca, n), v2 = fd_sub(cb, ca);
+    F.r1 = fd_normalize(fd_cross(v1, v2));
+    F.t1 = fd_normalize(fd_cross(F.r1, fd_normalize(v2)));
+    fd_v3 w2 = fd_sub(ca, cb), w3 = fd_sub(n, ca);
+    F.s2 = fd_normalize(fd_cross(w2, w3));
+    F.nv2 = fd_normalize(w2);
+    fd_v3 a = {cb.x - ca.x, cb.y - ca.y, cb.z - ca.z};
+    F.len = fd_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    F.pad = 0.0f;
+    return F;
+}
+FD_HD fd_v3 fd_neg(fd_v3 a) { return {-a.x, -a.y, -a.z}; }
+
+FD_HD void fd_pair_both(const fd_frame &Fi, const fd_frame &Fj, uint32_t aai, uint32_t aaj, fd_quant q, uint32_t *h_ij, uint32_t *h_ji) {
+    fd_feature f, g;
+    f.ca_dist = fd_dist(Fi.ca, Fj.ca);
+    f.cb_dist = fd_dist(Fi.cb, Fj.cb);
+    fd_v3 v1 = {Fi.cb.x - Fi.ca.x, Fi.cb.y - Fi.ca.y, Fi.cb.z - Fi.ca.z};
+    fd_v3 v2 = {Fj.cb.x - Fj.ca.x, Fj.cb.y - Fj.ca.y, Fj.cb.z - Fj.ca.z};
+    float dt = v1.x * v2.x + v1.y * v2.y + v1.z * v2.z;
+    f.angle = fdd_acosf(dt / (Fi.len * Fj.len));
+    fd_v3 v3 = fd_sub(Fj.cb, Fi.cb);
+    fd_v3 A = fd_normalize(fd_cross(v1, v3));
+    fd_v3 B = fd_normalize(fd_cross(v3, v2));
+    // (i, j)
+    f.tor1 = -fdd_atan2f(fd_dot(A, Fi.t1), fd_dot(Fi.r1, A));
+    fd_v3 rB = fd_neg(B);
+    fd_v3 tB = fd_normalize(fd_cross(rB, Fj.nv2));
+    f.tor2 = -fdd_atan2f(fd_dot(Fj.s2, tB), fd_dot(rB, Fj.s2));
+    // (j, i)
+    g.ca_dist = f.ca_dist; g.cb_dist = f.cb_dist; g.angle = f.angle;
+    g.tor1 = -fdd_atan2f(fd_dot(B, Fj.t1), fd_dot(Fj.r1, B));
+    fd_v3 rA = fd_neg(A);
+    fd_v3 tA = fd_normalize(fd_cross(rA, Fi.nv2));
+    g.tor2 = -fdd_atan2f(fd_dot(Fi.s2, tA), fd_dot(rA, Fi.s2));
+    // quantise: distances and theta once
+    uint32_t ca = fd_q(f.ca_dist, 2.0f, q.dist_disc), cb = fd_q(f.cb_dist, 2.0f, q.dist_disc);
+    float s0, c0, s1, c1, s2, c2, s3, c3, s4, c4;
+    fdd_sincosf(f.angle, &s0, &c0);
+    fdd_sincosf(f.tor1, &s1, &c1);
+    fdd_sincosf(f.tor2, &s2, &c2);
+    fdd_sincosf(g.tor1, &s3, &c3);
+    fdd_sincosf(g.tor2, &s4, &c4);
+    uint32_t mid = ca << 16 | cb << 12 | fd_q(s0, -1.0f, q.ang_disc) << 10 | fd_q(c0, -1.0f, q.ang_disc) << 8;
+    *h_ij = aai << 25 | aaj << 20 | mid | fd_q(s1, -1.0f, q.ang_disc) << 6 | fd_q(c1, -1.0f, q.ang_disc) << 4 |
+            fd_q(s2, -1.0f, q.ang_disc) << 2 | fd_q(c2, -1.0f, q.ang_disc);
+    *h_ji = aaj << 25 | aai << 20 | mid | fd_q(s3, -1.0f, q.ang_disc) << 6 | fd_q(c3, -1.0f, q.ang_disc) << 4 |
+            fd_q(s4, -1.0f, q.ang_disc) << 2 | fd_q(c4, -1.0f, q.ang_disc);
+}

@@ -218,7 +218,7 @@ static int d2h_u64(fdgpu_ctx *c, const uint64_t *dev, uint64_t *host) {
 }
 
 // pair count -> segment offsets; returns total pairs
-static int count_and_scan(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_consts &C, uint64_t *P) {
+static int count_and_scan(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_consts &C, uint64_t *P, bool unordered = false) {
     uint64_t S = b->n_struct;
     HIPCHK(c, c->ws[WS_COUNTS].ensure((S + 1) * 4));
     HIPCHK(c, c->ws[WS_CURSOR].ensure((S + 1) * 4));
@@ -229,7 +229,8 @@ static int count_and_scan(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_cons
     HIPCHK(c, hipMemsetAsync(c->ws[WS_CURSOR].p, 0, (S + 1) * 4, c->stream));
     {
         StageTimer t(c, "pair_count", b->n_res * 13);
-        fd_launch_pair_count(b->view(), C, c->ws[WS_COUNTS].as<uint32_t>(), c->stream);
+        if (unordered) fd_launch_pair_count2(b->view(), C, c->ws[WS_COUNTS].as<uint32_t>(), c->stream);
+        else fd_launch_pair_count(b->view(), C, c->ws[WS_COUNTS].as<uint32_t>(), c->stream);
     }
     {
         StageTimer t(c, "segment_scan", S * 12);
@@ -345,7 +346,12 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
     fd_hash_consts C = make_consts(p);
     hipStream_t st = c->stream;
     uint64_t S = b->n_struct, P = 0;
-    int rc = count_and_scan(c, b, C, &P);
+    HIPCHK(c, c->ws[WS_FRAMES].ensure(std::max<uint64_t>(b->n_res, 1) * sizeof(fd_frame)));
+    {
+        StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame)));
+        fd_launch_frames(b->view(), b->n_res, c->ws[WS_FRAMES].p, st);
+    }
+    int rc = count_and_scan(c, b, C, &P, true);
     if (rc) return rc;
     if (P >= 0xffffffffull) FAIL(c, FDGPU_ERANGE, "more than 2^32 residue pairs in one build call; split the shard");
     if ((rc = ensure_sort_ws(c, P))) return rc;
@@ -353,7 +359,8 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
     uint32_t *kb = c->ws[WS_KEYS_B].as<uint32_t>(), *ib = c->ws[WS_IDS_B].as<uint32_t>();
     {
         StageTimer t(c, "pair_emit", b->n_res * 37 + P * 8);
-        fd_launch_pair_emit(b->view(), C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, ia, (uint32_t)first_id, st);
+        fd_launch_pair_emit2(b->view(), c->ws[WS_FRAMES].p, C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, ia,
+                             (uint32_t)first_id, st);
     }
     int cur;
     cur = fd_radix_sort_pairs(ka, ia, kb, ib, P, 30, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st, c);

@@ -99,6 +99,107 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_emit(fd_batch_view B, fd_hash_
     }
 }
 
+// ------------------------------------------------------------------ frames + unordered-pair fast path
+// Index-build path.  Per-residue frames (fd_make_frame) are computed once; the pair kernel visits
+// every unordered pair {i < j} once and produces both ordered hashes with fd_pair_both(), which
+// shares d_CA, d_CB, theta and the two pair-dependent normalised cross products between the two
+// orientations (bit-exact, see fd_geom.h).  Same wave-per-(structure, i-tile) mapping and LDS
+// compaction queue as above; a drain of n unordered pairs writes 2n keys.
+__global__ __launch_bounds__(256) void k_frames(fd_batch_view B, uint32_t n_res, fd_frame *__restrict__ frames) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_res) return;
+    fd_frame F;
+    if (B.hash_ok[r]) F = fd_make_frame(fd_load3(B.n_xyz, r), fd_load3(B.ca_xyz, r), fd_load3(B.cb_xyz, r));
+    else { F = fd_frame{}; F.ca = fd_load3(B.ca_xyz, r); }
+    frames[r] = F;
+}
+
+__global__ __launch_bounds__(FD_WAVE) void k_pair_count2(fd_batch_view B, fd_hash_consts C, uint32_t *__restrict__ counts) {
+    uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
+    if (w >= B.n_work) return;
+    const uint32_t s = B.wi_struct[w];
+    const uint32_t r1 = B.res_off[s + 1];
+    const uint32_t i0 = B.wi_i0[w];
+    const uint32_t i = i0 + threadIdx.x;
+    const bool vi = i < r1 && B.hash_ok[i];
+    fd_v3 cai = {0.f, 0.f, 0.f};
+    if (vi) cai = fd_load3(B.ca_xyz, i);
+    uint32_t cnt = 0;
+    for (uint32_t j = i0 + 1; j < r1; ++j) {
+        if (!B.hash_ok[j]) continue;  // wave-uniform
+        float d2 = fd_dist2(cai, fd_load3(B.ca_xyz, j));
+        cnt += (vi && j > i && !(d2 > C.d2_max)) ? 2u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, FD_WAVE);
+    if (threadIdx.x == 0 && cnt) atomicAdd(&counts[s], cnt);
+}
+
+__device__ __forceinline__ fd_frame load_frame(const fd_frame *__restrict__ frames, uint32_t r) {
+    const float4 *p = reinterpret_cast<const float4 *>(frames + r);
+    float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+    fd_frame F;
+    F.ca = {a.x, a.y, a.z}; F.cb = {a.w, b.x, b.y}; F.r1 = {b.z, b.w, c.x}; F.t1 = {c.y, c.z, c.w};
+    F.s2 = {d.x, d.y, d.z}; F.nv2 = {d.w, e.x, e.y}; F.len = e.z; F.pad = e.w;
+    return F;
+}
+
+__device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *__restrict__ frames, const fd_hash_consts &C,
+                                       const uint32_t *q, uint32_t n, uint32_t i0, uint32_t r0, uint32_t s, uint32_t id,
+                                       const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys, uint32_t *ids) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&cursor[s], 2u * n);
+    base = __shfl(base, 0, FD_WAVE);
+    if (lane < n) {
+        uint32_t e = q[lane];
+        uint32_t i = i0 + (e >> 16), j = r0 + (e & 0xffffu);
+        fd_frame Fi = load_frame(frames, i), Fj = load_frame(frames, j);
+        uint32_t h_ij, h_ji;
+        fd_pair_both(Fi, Fj, B.aa[i], B.aa[j], C.q, &h_ij, &h_ji);
+        uint64_t pos = seg_off[s] + base + lane;
+        keys[pos] = h_ij;
+        keys[pos + n] = h_ji;
+        ids[pos] = id;
+        ids[pos + n] = id;
+    }
+}
+
+__global__ __launch_bounds__(FD_WAVE) void k_pair_emit2(fd_batch_view B, const fd_frame *__restrict__ frames, fd_hash_consts C,
+                                                        const uint64_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
+                                                        uint32_t *__restrict__ keys, uint32_t *__restrict__ ids, uint32_t first_id) {
+    __shared__ uint32_t q[2 * FD_WAVE];
+    uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
+    if (w >= B.n_work) return;
+    const uint32_t s = B.wi_struct[w];
+    const uint32_t r0 = B.res_off[s], r1 = B.res_off[s + 1];
+    const uint32_t i0 = B.wi_i0[w];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = i0 + lane;
+    const bool vi = i < r1 && B.hash_ok[i];
+    fd_v3 cai = {0.f, 0.f, 0.f};
+    if (vi) cai = fd_load3(B.ca_xyz, i);
+    uint32_t qn = 0;  // wave-uniform
+    for (uint32_t j = i0 + 1; j < r1; ++j) {
+        if (!B.hash_ok[j]) continue;
+        float d2 = fd_dist2(cai, fd_load3(B.ca_xyz, j));
+        bool pass = vi && j > i && !(d2 > C.d2_max);
+        uint64_t m = __ballot(pass);
+        if (m == 0) continue;
+        if (pass) q[qn + fd_mbcnt(m)] = (lane << 16) | (j - r0);
+        qn += (uint32_t)__popcll(m);
+        if (qn >= FD_WAVE) {
+            __syncthreads();
+            qn -= FD_WAVE;
+            drain2(B, frames, C, q + qn, FD_WAVE, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
+            __syncthreads();
+        }
+    }
+    if (qn) {
+        __syncthreads();
+        drain2(B, frames, C, q, qn, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
+    }
+}
+
 // ------------------------------------------------------------------ ordered variant (API S1, sort_dedup = 0)
 // Same pairs, but written in the reference's row-major (i, j) order: one lane per i computes its
 // row offset by a prefix over row counts.  Used for parity tests of the raw hash list; not on the
@@ -166,6 +267,19 @@ void fd_launch_pair_emit(const fd_batch_view &B, const fd_hash_consts &C, const 
         hipLaunchKernelGGL(k_pair_emit<true>, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, seg_off, cursor, keys, ids, first_id);
     else
         hipLaunchKernelGGL(k_pair_emit<false>, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, seg_off, cursor, keys, ids, first_id);
+}
+void fd_launch_frames(const fd_batch_view &B, uint64_t n_res, void *frames, hipStream_t st) {
+    if (!n_res) return;
+    hipLaunchKernelGGL(k_frames, dim3((unsigned)((n_res + 255) / 256)), dim3(256), 0, st, B, (uint32_t)n_res, (fd_frame *)frames);
+}
+void fd_launch_pair_count2(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *counts, hipStream_t st) {
+    if (!B.n_work) return;
+    hipLaunchKernelGGL(k_pair_count2, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, counts);
+}
+void fd_launch_pair_emit2(const fd_batch_view &B, const void *frames, const fd_hash_consts &C, const uint64_t *seg_off, uint32_t *cursor,
+                          uint32_t *keys, uint32_t *ids, uint32_t first_id, hipStream_t st) {
+    if (!B.n_work) return;
+    hipLaunchKernelGGL(k_pair_emit2, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, (const fd_frame *)frames, C, seg_off, cursor, keys, ids, first_id);
 }
 void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, hipStream_t st) {
     if (!B.n_work) return;

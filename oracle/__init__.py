@@ -137,6 +137,8 @@ def lib():
     L.fdo_build_index.argtypes = [C.POINTER(SP), C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_uint64, u64p, f32p]
     L.fdo_build_index_from_lists.restype = VP
     L.fdo_build_index_from_lists.argtypes = [u32p, u64p, C.c_uint64]
+    L.fdo_build_index_from_lists_mt.restype = VP
+    L.fdo_build_index_from_lists_mt.argtypes = [u32p, u64p, C.c_uint64, C.c_int]
     L.fdo_hash_batch.restype = C.c_int
     L.fdo_hash_batch.argtypes = [C.POINTER(SP), C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.POINTER(u32p), C.POINTER(u64p)]
     L.fdo_save_lookup.restype = C.c_int
@@ -299,6 +301,12 @@ def build_index_from_lists(hashes: np.ndarray, off: np.ndarray) -> OIndex:
     hashes = np.ascontiguousarray(hashes, dtype=np.uint32)
     off = np.ascontiguousarray(off, dtype=np.uint64)
     return OIndex(lib().fdo_build_index_from_lists(hashes.ctypes.data_as(u32p), off.ctypes.data_as(u64p), len(off) - 1))
+
+
+def build_index_from_lists_mt(hashes: np.ndarray, off: np.ndarray, n_threads: int) -> OIndex:
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint32)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    return OIndex(lib().fdo_build_index_from_lists_mt(hashes.ctypes.data_as(u32p), off.ctypes.data_as(u64p), len(off) - 1, n_threads))
 
 
 def hash_batch(structs, nbin_dist=0, nbin_angle=0, cutoff=20.0):

@@ -100,6 +100,7 @@ fdo_index *fdo_build_index_from_lists(const uint32_t *hashes, const uint64_t *of
 /* OpenMP fan-out of the per-structure hash+sort+dedup stage (cpu_baseline only): CSR out, fdo_free both */
 int fdo_hash_batch(const fdo_structure *const *structs, uint64_t S, uint64_t nbin_dist, uint64_t nbin_angle,
                    float dist_cutoff, uint32_t **out_hashes, uint64_t **out_off);
+fdo_index *fdo_build_index_from_lists_mt(const uint32_t *hashes, const uint64_t *off, uint64_t S, int n_threads);
 int fdo_save_lookup(const char *path, const char *const *tids, const uint64_t *nres, const float *plddt,
                     const uint64_t *db_key, uint64_t S);
 int fdo_save_type(const char *path, uint64_t chunk_size, float grid_width, uint64_t max_residue,

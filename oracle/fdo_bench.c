@@ -32,3 +32,30 @@ int fdo_hash_batch(const fdo_structure *const *structs, uint64_t S, uint64_t nbi
     *out_off = cnt;
     return 0;
 }
+
+/* Table build with the reference's lock-free ownership partition (controller/mod.rs:349-358,
+ * 427-437): T workers each scan the whole (hash, id) stream and handle only the hashes they own.
+ * The reference assigns ownership by hash % T; here ownership is by table page ((hash >> 6) % T) so
+ * that two workers never allocate the same page — same idea, same cost structure (every worker
+ * reads every key). */
+#include <omp.h>
+fdo_index *fdo_build_index_from_lists_mt(const uint32_t *hashes, const uint64_t *off, uint64_t S, int T) {
+    fdo_index *ix = fdo_index_new(30);
+    if (T < 1) T = 1;
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma omp parallel num_threads(T)
+        {
+            uint32_t tid = (uint32_t)omp_get_thread_num(), nt = (uint32_t)omp_get_num_threads();
+            for (uint64_t id = 0; id < S; ++id)
+                for (uint64_t k = off[id]; k < off[id + 1]; ++k) {
+                    uint32_t h = hashes[k];
+                    if ((h >> 6) % nt != tid) continue;
+                    if (pass == 0) fdo_index_count_single_entry(ix, h, id);
+                    else fdo_index_add_single_entry(ix, h, id);
+                }
+        }
+        if (pass == 0) fdo_index_allocate_entries(ix);
+    }
+    fdo_index_finish(ix);
+    return ix;
+}
