@@ -24,6 +24,7 @@ struct fd_batch_view {
 struct fd_hash_consts {
     fd_quant q;
     float d2_max;   // largest f32 whose sqrt is <= dist_cutoff: sqrtf(d2) > cutoff  <=>  d2 > d2_max
+    int use_tab;    // 1: default 4 angle bins -> table form of the angle fields (fd_bin_tables.h)
 };
 
 __device__ __forceinline__ fd_v3 fd_load3(const float *p, uint32_t r) {

@@ -9,6 +9,7 @@
 //   hash         src/geometry/pdb_tr.rs:21-75
 #pragma once
 #include "fd_libm.h"
+#include "fd_bin_tables.h"
 
 struct fd_v3 { float x, y, z; };
 
@@ -162,4 +163,82 @@ FD_HD void fd_pair_both(const fd_frame &Fi, const fd_frame &Fj, uint32_t aai, ui
             fd_q(s2, -1.0f, q.ang_disc) << 2 | fd_q(c2, -1.0f, q.ang_disc);
     *h_ji = aaj << 25 | aai << 20 | mid | fd_q(s3, -1.0f, q.ang_disc) << 6 | fd_q(c3, -1.0f, q.ang_disc) << 4 |
             fd_q(s4, -1.0f, q.ang_disc) << 2 | fd_q(c4, -1.0f, q.ang_disc);
+}
+
+// =============================================================================================
+// Table form of the angle fields (default 4 angle bins only).  fd_bin_tables.h lists, from an
+// exhaustive scan of every float through glibc, where (q(sin), q(cos)) changes as a function of
+//   c = cos(theta) argument of acosf            (theta fields)
+//   u = |y/x| per sign quadrant of atan2f(y, x) (torsion fields)
+// so acosf / atanf / sinf / cosf / the quantiser collapse into a handful of compares — bit-identical
+// by construction.  Special atan2f operands (zero, inf, NaN) take the generic path.
+// Packed table (FD_BINTAB_WORDS u32): [0..5] theta thresholds 1..6, [6] theta keys (4 bits each),
+// then per quadrant m: 4 thresholds (u bit patterns) + packed keys.
+// =============================================================================================
+#define FD_BINTAB_WORDS 27
+FD_HD void fd_fill_bintab(uint32_t *t) {
+    for (int k = 1; k < FD_THETA_NSEG; ++k) t[k - 1] = fd_theta_thr_bits[k];
+    uint32_t pk = 0;
+    for (int k = 0; k < FD_THETA_NSEG; ++k) pk |= (uint32_t)fd_theta_key[k] << (4 * k);
+    t[6] = pk;
+    for (int m = 0; m < 4; ++m) {
+        uint32_t kk = 0;
+        for (int k = 0; k < FD_TOR_MAXSEG; ++k) {
+            if (k >= 1) t[7 + 5 * m + (k - 1)] = fd_tor_thr_bits[m][k];
+            kk |= (uint32_t)fd_tor_key[m][k] << (4 * k);
+        }
+        t[7 + 5 * m + 4] = kk;
+    }
+}
+#if FD_THETA_NSEG != 7 || FD_TOR_MAXSEG != 5
+#error "fd_bin_tables.h layout changed: update FD_BINTAB_WORDS / fd_fill_bintab"
+#endif
+
+FD_HD uint32_t fd_theta_key_of(float c, const uint32_t *t) {
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) n += (c >= fd_u2f(t[k])) ? 1u : 0u;
+    uint32_t key = (t[6] >> (4u * n)) & 15u;
+    return (c >= -1.0f && c <= 1.0f) ? key : 0u;   // |c| > 1 or NaN: acosf -> NaN -> both bins 0
+}
+// generic (exact, slow) evaluation of the two torsion bins from the atan2f operands
+FD_HD uint32_t fd_tor_key_generic(float y, float x, float ang_disc) {
+    float s, c;
+    fdd_sincosf(-fd_atan2f(y, x), &s, &c);
+    return fd_q(s, -1.0f, ang_disc) << 2 | fd_q(c, -1.0f, ang_disc);
+}
+FD_HD uint32_t fd_tor_key_of(float y, float x, const uint32_t *t) {
+    uint32_t hx = fd_f2u(x), hy = fd_f2u(y);
+    uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+    if (ix >= 0x7f800000u || iy >= 0x7f800000u || ix == 0u || iy == 0u) return fd_tor_key_generic(y, x, 1.5f);
+    uint32_t m = (hy >> 31) | ((hx >> 30) & 2u);
+    uint32_t ub = fd_f2u(y / x) & 0x7fffffffu;
+    const uint32_t *q = t + 7 + 5 * m;
+    uint32_t n = (ub >= q[0] ? 1u : 0u) + (ub >= q[1] ? 1u : 0u) + (ub >= q[2] ? 1u : 0u) + (ub >= q[3] ? 1u : 0u);
+    return (q[4] >> (4u * n)) & 15u;
+}
+
+// both orientations of an unordered pair, default angle bins, tables in `tab` (LDS on the device)
+FD_HD void fd_pair_both_tab(const fd_frame &Fi, const fd_frame &Fj, uint32_t aai, uint32_t aaj, fd_quant q, const uint32_t *tab,
+                            uint32_t *h_ij, uint32_t *h_ji) {
+    float ca_dist = fd_dist(Fi.ca, Fj.ca);
+    float cb_dist = fd_dist(Fi.cb, Fj.cb);
+    fd_v3 v1 = {Fi.cb.x - Fi.ca.x, Fi.cb.y - Fi.ca.y, Fi.cb.z - Fi.ca.z};
+    fd_v3 v2 = {Fj.cb.x - Fj.ca.x, Fj.cb.y - Fj.ca.y, Fj.cb.z - Fj.ca.z};
+    float dt = v1.x * v2.x + v1.y * v2.y + v1.z * v2.z;
+    uint32_t kth = fd_theta_key_of(dt / (Fi.len * Fj.len), tab);
+    fd_v3 v3 = fd_sub(Fj.cb, Fi.cb);
+    fd_v3 A = fd_normalize(fd_cross(v1, v3));
+    fd_v3 B = fd_normalize(fd_cross(v3, v2));
+    uint32_t k1 = fd_tor_key_of(fd_dot(A, Fi.t1), fd_dot(Fi.r1, A), tab);
+    fd_v3 rB = fd_neg(B);
+    fd_v3 tB = fd_normalize(fd_cross(rB, Fj.nv2));
+    uint32_t k2 = fd_tor_key_of(fd_dot(Fj.s2, tB), fd_dot(rB, Fj.s2), tab);
+    uint32_t k3 = fd_tor_key_of(fd_dot(B, Fj.t1), fd_dot(Fj.r1, B), tab);
+    fd_v3 rA = fd_neg(A);
+    fd_v3 tA = fd_normalize(fd_cross(rA, Fi.nv2));
+    uint32_t k4 = fd_tor_key_of(fd_dot(Fi.s2, tA), fd_dot(rA, Fi.s2), tab);
+    uint32_t mid = fd_q(ca_dist, 2.0f, q.dist_disc) << 16 | fd_q(cb_dist, 2.0f, q.dist_disc) << 12 | kth << 8;
+    *h_ij = aai << 25 | aaj << 20 | mid | k1 << 4 | k2;
+    *h_ji = aaj << 25 | aai << 20 | mid | k3 << 4 | k4;
 }

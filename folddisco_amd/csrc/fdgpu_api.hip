@@ -208,6 +208,7 @@ static fd_hash_consts make_consts(const fd_hash_params *p) {
     while (sqrtf(d2) > cut) d2 = nextafterf(d2, 0.0f);
     while (sqrtf(nextafterf(d2, INFINITY)) <= cut) d2 = nextafterf(d2, INFINITY);
     C.d2_max = d2;
+    C.use_tab = (na == 4.0f) ? 1 : 0;
     return C;
 }
 

@@ -143,8 +143,9 @@ __device__ __forceinline__ fd_frame load_frame(const fd_frame *__restrict__ fram
     return F;
 }
 
+template <bool TAB>
 __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *__restrict__ frames, const fd_hash_consts &C,
-                                       const uint32_t *q, uint32_t n, uint32_t i0, uint32_t r0, uint32_t s, uint32_t id,
+                                       const uint32_t *tab, const uint32_t *q, uint32_t n, uint32_t i0, uint32_t r0, uint32_t s, uint32_t id,
                                        const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys, uint32_t *ids) {
     const uint32_t lane = threadIdx.x;
     uint32_t base = 0;
@@ -155,7 +156,8 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
         uint32_t i = i0 + (e >> 16), j = r0 + (e & 0xffffu);
         fd_frame Fi = load_frame(frames, i), Fj = load_frame(frames, j);
         uint32_t h_ij, h_ji;
-        fd_pair_both(Fi, Fj, B.aa[i], B.aa[j], C.q, &h_ij, &h_ji);
+        if (TAB) fd_pair_both_tab(Fi, Fj, B.aa[i], B.aa[j], C.q, tab, &h_ij, &h_ji);
+        else fd_pair_both(Fi, Fj, B.aa[i], B.aa[j], C.q, &h_ij, &h_ji);
         uint64_t pos = seg_off[s] + base + lane;
         keys[pos] = h_ij;
         keys[pos + n] = h_ji;
@@ -164,12 +166,18 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
     }
 }
 
+template <bool TAB>
 __global__ __launch_bounds__(FD_WAVE) void k_pair_emit2(fd_batch_view B, const fd_frame *__restrict__ frames, fd_hash_consts C,
                                                         const uint64_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ ids, uint32_t first_id) {
     __shared__ uint32_t q[2 * FD_WAVE];
+    __shared__ uint32_t tab[32];
     uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
     if (w >= B.n_work) return;
+    if (TAB) {
+        if (threadIdx.x == 0) fd_fill_bintab(tab);
+        __syncthreads();
+    }
     const uint32_t s = B.wi_struct[w];
     const uint32_t r0 = B.res_off[s], r1 = B.res_off[s + 1];
     const uint32_t i0 = B.wi_i0[w];
@@ -190,13 +198,13 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_emit2(fd_batch_view B, const f
         if (qn >= FD_WAVE) {
             __syncthreads();
             qn -= FD_WAVE;
-            drain2(B, frames, C, q + qn, FD_WAVE, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
+            drain2<TAB>(B, frames, C, tab, q + qn, FD_WAVE, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
             __syncthreads();
         }
     }
     if (qn) {
         __syncthreads();
-        drain2(B, frames, C, q, qn, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
+        drain2<TAB>(B, frames, C, tab, q, qn, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
     }
 }
 
@@ -279,7 +287,10 @@ void fd_launch_pair_count2(const fd_batch_view &B, const fd_hash_consts &C, uint
 void fd_launch_pair_emit2(const fd_batch_view &B, const void *frames, const fd_hash_consts &C, const uint64_t *seg_off, uint32_t *cursor,
                           uint32_t *keys, uint32_t *ids, uint32_t first_id, hipStream_t st) {
     if (!B.n_work) return;
-    hipLaunchKernelGGL(k_pair_emit2, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, (const fd_frame *)frames, C, seg_off, cursor, keys, ids, first_id);
+    if (C.use_tab)
+        hipLaunchKernelGGL(k_pair_emit2<true>, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, (const fd_frame *)frames, C, seg_off, cursor, keys, ids, first_id);
+    else
+        hipLaunchKernelGGL(k_pair_emit2<false>, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, (const fd_frame *)frames, C, seg_off, cursor, keys, ids, first_id);
 }
 void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, hipStream_t st) {
     if (!B.n_work) return;

@@ -26,6 +26,10 @@ static long check_structure(const fdo_structure *s, fd_quant q, float cutoff) {
             uint32_t o_ji = fdo_hash_pdbtr(feat, 16, 4);
             uint32_t h_ij, h_ji;
             fd_pair_both(F[i], F[j], s->aa[i], s->aa[j], q, &h_ij, &h_ji);
+            uint32_t t_ij, t_ji, tab[FD_BINTAB_WORDS];
+            fd_fill_bintab(tab);
+            fd_pair_both_tab(F[i], F[j], s->aa[i], s->aa[j], q, tab, &t_ij, &t_ji);
+            if (t_ij != o_ij || t_ji != o_ji) { if (bad++ < 5) fprintf(stderr, "table mismatch (%d,%d): %08x/%08x oracle %08x/%08x\n", i, j, t_ij, t_ji, o_ij, o_ji); }
             fd_feature f = fd_pair_feature(at(s->n_xyz, i), at(s->ca_xyz, i), at(s->cb_xyz, i), at(s->n_xyz, j), at(s->ca_xyz, j), at(s->cb_xyz, j));
             uint32_t d_ij = fd_hash_pdbtr(s->aa[i], s->aa[j], f, q);
             ++n;
@@ -82,6 +86,10 @@ int main(int argc, char **argv) {
                     uint32_t o_ji = fdo_hash_pdbtr(feat, 16, 4);
                     uint32_t h_ij, h_ji;
                     fd_pair_both(F[i], F[j], s->aa[i], s->aa[j], q, &h_ij, &h_ji);
+                    uint32_t t_ij, t_ji, tab[FD_BINTAB_WORDS];
+                    fd_fill_bintab(tab);
+                    fd_pair_both_tab(F[i], F[j], s->aa[i], s->aa[j], q, tab, &t_ij, &t_ji);
+                    if (t_ij != o_ij || t_ji != o_ji) { if (b++ < 3) fprintf(stderr, "cloud %d table (%d,%d): %08x/%08x vs %08x/%08x\n", rep, i, j, t_ij, t_ji, o_ij, o_ji); }
                     if (h_ij != o_ij || h_ji != o_ji) { if (b++ < 3) fprintf(stderr, "cloud %d (%d,%d): %08x/%08x vs %08x/%08x\n", rep, i, j, h_ij, h_ji, o_ij, o_ji); }
                 }
         }

@@ -13,7 +13,7 @@ def find(pattern):
 
 
 print("== kernel trace stats (rocprofv3 --kernel-trace --stats) ==")
-for f in find("prof_trace/**/*kernel_stats.csv"):
+for f in find("trace/**/*kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
     for r in rows[:25]:
         print("%-70s calls=%-6s total_ms=%10.3f avg_us=%10.2f pct=%s" % (
@@ -31,7 +31,7 @@ def pmc(dirname):
     return acc
 
 
-for d in ("prof_pmc_sq", "prof_pmc_fetch", "prof_pmc_write"):
+for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
     acc = pmc(d)
     if not acc:
         continue
