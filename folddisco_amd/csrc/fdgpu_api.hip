@@ -250,7 +250,17 @@ static int ensure_sort_ws(fdgpu_ctx *c, uint64_t P) {
     HIPCHK(c, c->ws[WS_IDS_B].ensure(kb));
     HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * std::max<uint32_t>(fd_rs_num_tiles(P), 1) * 4));
     HIPCHK(c, c->ws[WS_TOT].ensure(256 * 8));
+    HIPCHK(c, c->ws[WS_OSDESC].ensure((size_t)std::max<uint32_t>(fd_os_num_tiles(P), 1) * 256 * 8));
+    HIPCHK(c, c->ws[WS_OSHIST].ensure(4 * 256 * 8 + 64));
     return FDGPU_OK;
+}
+
+// stable sort of (keys, vals) by the low key_bits of keys; FDGPU_SORT=classic selects the 3-kernel LSD variant
+static int sort_pairs(fdgpu_ctx *c, uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb, uint64_t n, int key_bits) {
+    static const bool classic = [] { const char *e = getenv("FDGPU_SORT"); return e && !strcmp(e, "classic"); }();
+    if (classic) return fd_radix_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), c->stream, c);
+    unsigned long long *gh = c->ws[WS_OSHIST].as<unsigned long long>();
+    return fd_onesweep_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_OSDESC].as<unsigned long long>(), gh, (uint32_t *)(gh + 4 * 256), c->stream, c);
 }
 
 // ---- S1 ---------------------------------------------------------------------------------------------------------------
@@ -300,11 +310,11 @@ extern "C" int fdgpu_hash_batch(fdgpu_ctx *c, const fdgpu_batch *b, const fd_has
     uint32_t *kb = c->ws[WS_KEYS_B].as<uint32_t>(), *ib = c->ws[WS_IDS_B].as<uint32_t>();
     fd_launch_pair_emit(b->view(), C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, ia, 0u, st);
     // sort by hash, then (stable) by structure -> (structure, hash) order
-    int cur = fd_radix_sort_pairs(ka, ia, kb, ib, P, 30, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st);
+    int cur = sort_pairs(c, ka, ia, kb, ib, P, 30);
     uint32_t *k1 = cur ? kb : ka, *i1 = cur ? ib : ia, *k2 = cur ? ka : kb, *i2 = cur ? ia : ib;
     int id_bits = 1;
     while (id_bits < 32 && (1ull << id_bits) < std::max<uint64_t>(S, 2)) ++id_bits;
-    int cur2 = fd_radix_sort_pairs(i1, k1, i2, k2, P, id_bits, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st);
+    int cur2 = sort_pairs(c, i1, k1, i2, k2, P, id_bits);
     uint32_t *ids_s = cur2 ? i2 : i1, *keys_s = cur2 ? k2 : k1, *spare = cur2 ? k1 : k2;
     // adjacent-unique compaction
     HIPCHK(c, c->ws[WS_MISC0].ensure(std::max<uint64_t>(P, 1)));
@@ -364,7 +374,7 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
                              (uint32_t)first_id, st);
     }
     int cur;
-    cur = fd_radix_sort_pairs(ka, ia, kb, ib, P, 30, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st, c);
+    cur = sort_pairs(c, ka, ia, kb, ib, P, 30);
     const uint32_t *ks = cur ? kb : ka, *is = cur ? ib : ia;
     uint32_t nt = std::max<uint32_t>(fd_enc_num_tiles(P), 1);
     HIPCHK(c, c->ws[WS_TILE_B].ensure((size_t)(nt + 1) * 4));

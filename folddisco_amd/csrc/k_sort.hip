@@ -230,6 +230,175 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *__res
     }
 }
 
+
+// ------------------------------------------------------------------------ onesweep variant
+// One kernel per digit: the global digit histograms of all passes come from ONE upfront read of the
+// keys (the key multiset does not change between passes), and the per-tile digit offsets are
+// resolved inside the scatter kernel by decoupled look-back over per-(tile, digit) descriptors
+// instead of a histogram pass + scan per digit.  Inter-workgroup visibility on gfx950 (per-XCD L2s are
+// not coherent): a descriptor is ONE naturally aligned 8-byte word {value:62, state:2} written and
+// read with relaxed agent-scope atomics (sc1 store / sc1 load), the "granule" form of
+// MI355X_MICROARCH.md — no separate flag, so no ordering between two words is needed.  Tiles take
+// their index from an atomic ticket so that every predecessor a tile waits for is already running.
+#define OS_THREADS 512
+#define OS_ITEMS 16
+#define OS_TILE (OS_THREADS * OS_ITEMS)   // 8192 keys
+#define OS_WAVES (OS_THREADS / 64)
+#define OS_AGG 1ull
+#define OS_INC 2ull
+
+__global__ __launch_bounds__(256) void k_os_hist(const uint32_t *__restrict__ keys, uint64_t n, int key_bits,
+                                                 unsigned long long *__restrict__ ghist /*[4][256]*/) {
+    __shared__ uint32_t h[4][RS_BINS];
+    for (int k = threadIdx.x; k < 4 * RS_BINS; k += blockDim.x) (&h[0][0])[k] = 0;
+    __syncthreads();
+    const int npass = (key_bits + 7) / 8;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+        uint32_t k = keys[idx];
+        for (int p = 0; p < npass; ++p) {
+            int bits = key_bits - 8 * p < 8 ? key_bits - 8 * p : 8;
+            atomicAdd(&h[p][(k >> (8 * p)) & ((1u << bits) - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 4 * RS_BINS; k += blockDim.x) {
+        uint32_t v = (&h[0][0])[k];
+        if (v) atomicAdd(&ghist[k], (unsigned long long)v);
+    }
+}
+// exclusive scan of each pass's 256 global counts (in place)
+__global__ __launch_bounds__(RS_BINS) void k_os_scan(unsigned long long *__restrict__ ghist) {
+    __shared__ uint64_t sm[17];
+    unsigned long long *row = ghist + (uint64_t)blockIdx.x * RS_BINS;
+    uint64_t v = row[threadIdx.x], t;
+    uint64_t ex = block_excl_scan_u64(v, sm, &t);
+    row[threadIdx.x] = ex;
+}
+
+__global__ __launch_bounds__(OS_THREADS) void k_os_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                           uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
+                                                           uint32_t shift, uint32_t mask, const unsigned long long *__restrict__ dbase /*[256]*/,
+                                                           unsigned long long *__restrict__ desc /*[tiles][256]*/, uint32_t *__restrict__ ticket) {
+    __shared__ uint32_t s_keys[OS_TILE];
+    __shared__ uint32_t s_vals[OS_TILE];
+    __shared__ uint32_t s_cnt[OS_WAVES][RS_BINS];
+    __shared__ long long s_gofs[RS_BINS];
+    __shared__ uint64_t sm[17];
+    __shared__ uint32_t s_tile;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    for (int k = tid; k < OS_WAVES * RS_BINS; k += OS_THREADS) (&s_cnt[0][0])[k] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint64_t tile_base = (uint64_t)tile * OS_TILE;
+    const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * OS_ITEMS);
+    const uint32_t n_tile = (uint32_t)((n - tile_base) < OS_TILE ? (n - tile_base) : OS_TILE);
+
+    uint32_t key[OS_ITEMS], val[OS_ITEMS];
+#pragma unroll
+    for (int c = 0; c < OS_ITEMS; ++c) {
+        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
+        bool ok = idx < n;
+        key[c] = ok ? keys_in[idx] : 0xffffffffu;
+        val[c] = ok ? vals_in[idx] : 0u;
+        if (ok) atomicAdd(&s_cnt[wid][(key[c] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    uint32_t my_total = 0, dstart = 0;
+    if (tid < RS_BINS) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < OS_WAVES; ++w) run += s_cnt[w][tid];
+        my_total = run;
+        // publish the tile aggregate (tile 0: already inclusive)
+        unsigned long long d0 = ((unsigned long long)my_total << 2) | (tile == 0 ? OS_INC : OS_AGG);
+        __hip_atomic_store(&desc[(uint64_t)tile * RS_BINS + tid], d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    {
+        uint64_t tot;
+        uint64_t ex = block_excl_scan_u64(tid < RS_BINS ? (uint64_t)my_total : 0ull, sm, &tot);
+        dstart = (uint32_t)ex;
+    }
+    if (tid < RS_BINS) {
+        // per-wave local bases (running positions during ranking)
+        uint32_t run = dstart;
+#pragma unroll
+        for (int w = 0; w < OS_WAVES; ++w) { uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
+        // decoupled look-back for digit `tid`
+        unsigned long long excl = 0;
+        if (tile > 0) {
+            int64_t t = (int64_t)tile - 1;
+            while (true) {
+                unsigned long long d = __hip_atomic_load(&desc[(uint64_t)t * RS_BINS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long st = d & 3ull;
+                if (st == 0ull) { __builtin_amdgcn_s_sleep(1); continue; }
+                excl += d >> 2;
+                if (st == OS_INC) break;
+                --t;  // aggregate only: keep looking back (t cannot underflow: tile 0 is always inclusive)
+            }
+            unsigned long long d1 = ((excl + my_total) << 2) | OS_INC;
+            __hip_atomic_store(&desc[(uint64_t)tile * RS_BINS + tid], d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_gofs[tid] = (long long)(dbase[tid] + excl) - (long long)dstart;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < OS_ITEMS; ++c) {
+        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
+        bool ok = idx < n;
+        uint32_t d = (key[c] >> shift) & mask;
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            uint64_t bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        uint32_t rank = fd_mbcnt(peers);
+        uint32_t pcount = (uint32_t)__popcll(peers);
+        uint32_t pos = 0;
+        if (ok) pos = s_cnt[wid][d] + rank;
+        if (ok && rank == pcount - 1) s_cnt[wid][d] = pos + 1;
+        if (ok) { s_keys[pos] = key[c]; s_vals[pos] = val[c]; }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < n_tile; k += OS_THREADS) {
+        uint32_t kk = s_keys[k];
+        long long g = (long long)k + s_gofs[(kk >> shift) & mask];
+        keys_out[g] = kk;
+        vals_out[g] = s_vals[k];
+    }
+}
+
+uint32_t fd_os_num_tiles(uint64_t n) { return (uint32_t)((n + OS_TILE - 1) / OS_TILE); }
+// workspace: desc u64[tiles*256], ghist u64[4*256], ticket u32[4]
+int fd_onesweep_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits,
+                           unsigned long long *desc, unsigned long long *ghist, uint32_t *ticket, hipStream_t st, fdgpu_ctx *tc) {
+    if (n == 0) return 0;
+    uint32_t nb = fd_os_num_tiles(n);
+    (void)hipMemsetAsync(ghist, 0, 4 * RS_BINS * 8, st);
+    (void)hipMemsetAsync(ticket, 0, 16, st);
+    {
+        StageTimer t(tc, "os_hist", n * 4);
+        hipLaunchKernelGGL(k_os_hist, dim3(2048), dim3(256), 0, st, keys_a, n, key_bits, ghist);
+        hipLaunchKernelGGL(k_os_scan, dim3(4), dim3(RS_BINS), 0, st, ghist);
+    }
+    int cur = 0, pass = 0;
+    for (int shift = 0; shift < key_bits; shift += 8, ++pass) {
+        int bits = key_bits - shift < 8 ? key_bits - shift : 8;
+        uint32_t mask = (1u << bits) - 1u;
+        uint32_t *ki = cur ? keys_b : keys_a, *vi = cur ? vals_b : vals_a;
+        uint32_t *ko = cur ? keys_a : keys_b, *vo = cur ? vals_a : vals_b;
+        StageTimer t(tc, "os_scatter", n * 16);
+        (void)hipMemsetAsync(desc, 0, (size_t)nb * RS_BINS * 8, st);
+        hipLaunchKernelGGL(k_os_scatter, dim3(nb), dim3(OS_THREADS), 0, st, ki, vi, ko, vo, n, (uint32_t)shift, mask,
+                           ghist + (size_t)pass * RS_BINS, desc, ticket + pass);
+        cur ^= 1;
+    }
+    return cur;
+}
+
 uint32_t fd_rs_num_tiles(uint64_t n) { return (uint32_t)((n + RS_TILE - 1) / RS_TILE); }
 
 // Sort (keys, vals) by the low `key_bits` bits of keys, stable. Buffers a/b ping-pong; returns which

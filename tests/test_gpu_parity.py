@@ -223,3 +223,24 @@ def test_match_pairs_and_kabsch_serine(ctx, ser):
         r, R, T = oracle.kabsch(x, y)
         assert abs(rmsd[k] - r) <= 1e-4 and np.allclose(rot[k], R, atol=1e-4) and np.allclose(tran[k], T, atol=1e-3)
     assert rmsd[0] < 0.2 and rmsd[1] < 0.2 and rmsd[2] < 1e-6
+
+
+def test_index_build_medium_multitile(ctx):
+    """~20M postings: many radix tiles, look-back chains across XCDs, multi-tile encode; byte-identical to the oracle."""
+    import folddisco_amd as fd
+    ps = synthetic_packed(600, 77)
+    batch = ctx.upload(ps)
+    structs = packed_to_oracle_structs(ps)
+    h, off = oracle.hash_batch(structs)
+    oix = oracle.build_index_from_lists_mt(h, off, 8)
+    for first_id in (0, 1 << 20):
+        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id)
+        v, hh, o = ix.export()
+        if first_id == 0:
+            assert np.array_equal(hh, oix.hashes()) and np.array_equal(o, oix.offsets()) and np.array_equal(v, oix.values())
+        else:
+            assert np.array_equal(hh, oix.hashes())  # same hashes, longer varints
+            assert ix.num_postings == len(h)
+    # per-structure API agrees as well
+    gh, goff = fd.get_geometric_hash_as_u32(ctx, batch, sort_dedup=True)
+    assert np.array_equal(goff, off) and np.array_equal(gh, h)
