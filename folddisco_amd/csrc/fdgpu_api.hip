@@ -76,6 +76,7 @@ extern "C" int fdgpu_create(int device, fdgpu_ctx **out) {
 extern "C" void fdgpu_destroy(fdgpu_ctx *c) {
     if (!c) return;
     for (auto &b : c->ws) b.release();
+    for (auto &b : c->pool) (void)hipFree(b.p);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -257,8 +258,15 @@ static int ensure_sort_ws(fdgpu_ctx *c, uint64_t P) {
 
 // stable sort of (keys, vals) by the low key_bits of keys; FDGPU_SORT=classic selects the 3-kernel LSD variant
 static int sort_pairs(fdgpu_ctx *c, uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb, uint64_t n, int key_bits) {
-    static const bool classic = [] { const char *e = getenv("FDGPU_SORT"); return e && !strcmp(e, "classic"); }();
-    if (classic) return fd_radix_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), c->stream, c);
+    // FDGPU_SORT = onesweep | classic0..classic3 (default classic3: 512x16 tiles, XCD-aware tile order)
+    static const int mode = [] {
+        const char *e = getenv("FDGPU_SORT");
+        if (e && !strcmp(e, "onesweep")) return -1;
+        if (e && !strncmp(e, "classic", 7) && e[7] >= '0' && e[7] <= '3') return e[7] - '0';
+        return 3;
+    }();
+    if (mode >= 0) fd_rs_set_variant(mode);
+    if (mode >= 0) return fd_radix_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), c->stream, c);
     unsigned long long *gh = c->ws[WS_OSHIST].as<unsigned long long>();
     return fd_onesweep_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_OSDESC].as<unsigned long long>(), gh, (uint32_t *)(gh + 4 * 256), c->stream, c);
 }
@@ -342,7 +350,9 @@ extern "C" int fdgpu_hash_batch(fdgpu_ctx *c, const fdgpu_batch *b, const fd_has
 // ---- S2 ---------------------------------------------------------------------------------------------------------------
 extern "C" void fdgpu_index_destroy(fdgpu_index *ix) {
     if (!ix) return;
-    (void)hipFree(ix->hashes); (void)hipFree(ix->offsets); (void)hipFree(ix->value);
+    if (ix->ctx) {
+        ix->ctx->pool_free(ix->hashes, ix->cap_hashes); ix->ctx->pool_free(ix->offsets, ix->cap_offsets); ix->ctx->pool_free(ix->value, ix->cap_value);
+    } else { (void)hipFree(ix->hashes); (void)hipFree(ix->offsets); (void)hipFree(ix->value); }
     delete ix;
 }
 extern "C" uint64_t fdgpu_index_num_hashes(const fdgpu_index *ix) { return ix ? ix->n_hashes : 0; }
@@ -405,9 +415,10 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
     if (!ix) return FDGPU_ENOMEM;
     ix->ctx = c; ix->value_len = tot[0]; ix->n_hashes = tot[1]; ix->n_postings = tot[2]; ix->n_structures = S; ix->first_id = first_id;
     hipError_t e;
-    if ((e = hipMalloc((void **)&ix->value, std::max<uint64_t>(ix->value_len, 4))) != hipSuccess ||
-        (e = hipMalloc((void **)&ix->hashes, std::max<uint64_t>(ix->n_hashes, 1) * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&ix->offsets, (ix->n_hashes + 1) * 8)) != hipSuccess) {
+    ix->value = (uint8_t *)c->pool_alloc(std::max<uint64_t>(ix->value_len, 4), &e); ix->cap_value = c->last_cap;
+    if (e == hipSuccess) { ix->hashes = (uint32_t *)c->pool_alloc(std::max<uint64_t>(ix->n_hashes, 1) * 4, &e); ix->cap_hashes = c->last_cap; }
+    if (e == hipSuccess) { ix->offsets = (uint64_t *)c->pool_alloc((ix->n_hashes + 1) * 8, &e); ix->cap_offsets = c->last_cap; }
+    if (e != hipSuccess) {
         c->err = std::string("index alloc: ") + hipGetErrorString(e);
         fdgpu_index_destroy(ix);
         return FDGPU_EHIP;
@@ -446,7 +457,7 @@ extern "C" int fdgpu_index_load(fdgpu_ctx *c, const uint32_t *hashes, const uint
     *out = nullptr;
     fdgpu_index *ix = new (std::nothrow) fdgpu_index();
     if (!ix) return FDGPU_ENOMEM;
-    ix->ctx = c; ix->n_hashes = H; ix->value_len = vlen; ix->n_structures = n_structures;
+    ix->ctx = nullptr; ix->n_hashes = H; ix->value_len = vlen; ix->n_structures = n_structures;
     hipError_t e;
     uint64_t zero = 0;
     if ((e = hipMalloc((void **)&ix->value, std::max<uint64_t>(vlen, 4))) != hipSuccess ||

@@ -41,6 +41,34 @@ struct fdgpu_ctx {
     std::vector<fd_timing_entry> timings;
     std::vector<hipEvent_t> event_pool;
     size_t event_used = 0;
+    // device blocks of destroyed indices, reused by the next build (steady-state builds do not call
+    // hipMalloc/hipFree, which would serialise the stream)
+    struct pooled { void *p; size_t cap; };
+    std::vector<pooled> pool;
+    void *pool_alloc(size_t bytes, hipError_t *err) {
+        *err = hipSuccess;
+        size_t best = (size_t)-1;
+        for (size_t k = 0; k < pool.size(); ++k)
+            if (pool[k].cap >= bytes && pool[k].cap <= bytes + bytes / 4 + 4096 && (best == (size_t)-1 || pool[k].cap < pool[best].cap)) best = k;
+        if (best != (size_t)-1) { void *p = pool[best].p; last_cap = pool[best].cap; pool.erase(pool.begin() + best); return p; }
+        void *p = nullptr;
+        size_t want = bytes + bytes / 32 + 256;
+        *err = hipMalloc(&p, want);
+        if (*err != hipSuccess) {  // drop the cache and retry once
+            for (auto &b : pool) (void)hipFree(b.p);
+            pool.clear();
+            *err = hipMalloc(&p, want);
+            if (*err != hipSuccess) return nullptr;
+        }
+        last_cap = want;
+        return p;
+    }
+    void pool_free(void *p, size_t cap) {
+        if (!p) return;
+        if (pool.size() >= 12) { (void)hipFree(p); return; }
+        pool.push_back({p, cap});
+    }
+    size_t last_cap = 0;
 };
 
 // HIP-event stage timer (active only after fdgpu_enable_timing(ctx, 1))
@@ -91,6 +119,7 @@ struct fdgpu_index {
     uint32_t *hashes = nullptr;   // device [H]
     uint64_t *offsets = nullptr;  // device [H+1]
     uint8_t *value = nullptr;     // device [value_len]
+    size_t cap_hashes = 0, cap_offsets = 0, cap_value = 0;
 };
 
 // kernels / launchers implemented in the k_*.hip files
@@ -108,6 +137,7 @@ template <typename TIn>
 void fd_exclusive_scan(const TIn *in, uint64_t n, uint64_t *out, uint64_t *chunk_tmp, uint64_t *total_dev, hipStream_t st);
 uint64_t fd_scan_tmp_elems(uint64_t n);
 uint32_t fd_rs_num_tiles(uint64_t n);
+void fd_rs_set_variant(int v);
 int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits, uint32_t *ghist,
                         uint64_t *tot, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr);
 uint32_t fd_os_num_tiles(uint64_t n);

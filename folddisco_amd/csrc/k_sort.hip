@@ -111,26 +111,26 @@ template void fd_exclusive_scan<uint8_t>(const uint8_t *, uint64_t, uint64_t *, 
 uint64_t fd_scan_tmp_elems(uint64_t n) { return (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1; }
 
 // ------------------------------------------------------------------------ radix sort
-#define RS_THREADS 256
-#define RS_ITEMS 16
-#define RS_TILE (RS_THREADS * RS_ITEMS)   // 4096 keys per workgroup
-#define RS_WAVES (RS_THREADS / 64)
 #define RS_BINS 256
 
-// tile histogram -> ghist[digit * nb + block]
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t *__restrict__ keys, uint64_t n, uint32_t shift, uint32_t mask,
-                                                        uint32_t *__restrict__ ghist, uint32_t nb) {
+// tile histogram -> ghist[digit * nb + tile]
+template <int THREADS, int ITEMS, bool XCD>
+__global__ __launch_bounds__(THREADS) void k_rs_hist(const uint32_t *__restrict__ keys, uint64_t n, uint32_t shift, uint32_t mask,
+                                                     uint32_t *__restrict__ ghist, uint32_t nb) {
+    constexpr int TILE = THREADS * ITEMS;
     __shared__ uint32_t h[RS_BINS];
-    h[threadIdx.x] = 0;
+    const uint32_t tile = XCD ? fd_xcd_remap(blockIdx.x, nb) : blockIdx.x;
+    if (tile >= nb) return;
+    for (int k = threadIdx.x; k < RS_BINS; k += THREADS) h[k] = 0;
     __syncthreads();
-    uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
+    uint64_t base = (uint64_t)tile * TILE;
 #pragma unroll
-    for (int k = 0; k < RS_ITEMS; ++k) {
-        uint64_t idx = base + (uint64_t)k * RS_THREADS + threadIdx.x;
+    for (int k = 0; k < ITEMS; ++k) {
+        uint64_t idx = base + (uint64_t)k * THREADS + threadIdx.x;
         if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
     }
     __syncthreads();
-    ghist[(uint64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+    for (int k = threadIdx.x; k < RS_BINS; k += THREADS) ghist[(uint64_t)k * nb + tile] = h[k];
 }
 
 // one workgroup per digit: exclusive scan of its row of nb tile counts (in place), row total -> tot[d]
@@ -155,31 +155,34 @@ __global__ __launch_bounds__(RS_BINS) void k_rs_scan_tot(uint64_t *__restrict__ 
     tot[threadIdx.x] = ex;
 }
 
-// stable scatter of one tile. Wave w owns the contiguous sub-tile [w*1024, (w+1)*1024) and walks it
-// in 64-key chunks (chunk c, lane l -> element c*64 + l) so that "earlier element" == "earlier
-// chunk or lower lane".
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                           uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
-                                                           uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
-                                                           const uint64_t *__restrict__ dbase) {
-    __shared__ uint32_t s_keys[RS_TILE];
-    __shared__ uint32_t s_vals[RS_TILE];
-    __shared__ uint32_t s_cnt[RS_WAVES][RS_BINS];  // per-wave digit counts, then running local positions
-    __shared__ uint32_t s_dstart[RS_BINS];         // tile-local start of each digit
-    __shared__ int64_t s_gofs[RS_BINS];            // global position = local position + s_gofs[digit]
+// stable scatter of one tile. Wave w owns a contiguous sub-tile and walks it in 64-key chunks
+// (chunk c, lane l -> element c*64 + l) so that "earlier element" == "earlier chunk or lower lane".
+template <int THREADS, int ITEMS, bool XCD>
+__global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                        uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
+                                                        uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
+                                                        const uint64_t *__restrict__ dbase) {
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / 64;
+    __shared__ uint32_t s_keys[TILE];
+    __shared__ uint32_t s_vals[TILE];
+    __shared__ uint32_t s_cnt[WAVES][RS_BINS];  // per-wave digit counts, then running local positions
+    __shared__ long long s_gofs[RS_BINS];       // global position = local position + s_gofs[digit]
     __shared__ uint64_t sm[17];
 
+    const uint32_t tile = XCD ? fd_xcd_remap(blockIdx.x, nb) : blockIdx.x;
+    if (tile >= nb) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint64_t tile_base = (uint64_t)blockIdx.x * RS_TILE;
-    const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * RS_ITEMS);
-    const uint32_t n_tile = (uint32_t)((n - tile_base) < RS_TILE ? (n - tile_base) : RS_TILE);
+    const uint64_t tile_base = (uint64_t)tile * TILE;
+    const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * ITEMS);
+    const uint32_t n_tile = (uint32_t)((n - tile_base) < TILE ? (n - tile_base) : TILE);
 
-    for (int w = 0; w < RS_WAVES; ++w) s_cnt[w][tid] = 0;
+    for (int k = tid; k < WAVES * RS_BINS; k += THREADS) (&s_cnt[0][0])[k] = 0;
     __syncthreads();
 
-    uint32_t key[RS_ITEMS], val[RS_ITEMS];
+    uint32_t key[ITEMS], val[ITEMS];
 #pragma unroll
-    for (int c = 0; c < RS_ITEMS; ++c) {
+    for (int c = 0; c < ITEMS; ++c) {
         uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
         bool ok = idx < n;
         key[c] = ok ? keys_in[idx] : 0xffffffffu;
@@ -187,22 +190,25 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *__res
         if (ok) atomicAdd(&s_cnt[wid][(key[c] >> shift) & mask], 1u);
     }
     __syncthreads();
-    // thread d: totals and per-wave bases for digit d
     {
-        uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
+        uint32_t my_total = 0;
+        if (tid < RS_BINS) {
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) my_total += s_cnt[w][tid];
+        }
         uint64_t tot;
-        uint32_t dstart = (uint32_t)block_excl_scan_u64((uint64_t)(c0 + c1 + c2 + c3), sm, &tot);
-        s_dstart[tid] = dstart;
-        s_cnt[0][tid] = dstart;
-        s_cnt[1][tid] = dstart + c0;
-        s_cnt[2][tid] = dstart + c0 + c1;
-        s_cnt[3][tid] = dstart + c0 + c1 + c2;
-        s_gofs[tid] = (int64_t)(dbase[tid] + ghist[(uint64_t)tid * nb + blockIdx.x]) - (int64_t)dstart;
+        uint32_t dstart = (uint32_t)block_excl_scan_u64(tid < RS_BINS ? (uint64_t)my_total : 0ull, sm, &tot);
+        if (tid < RS_BINS) {
+            uint32_t run = dstart;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) { uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
+            s_gofs[tid] = (long long)(dbase[tid] + ghist[(uint64_t)tid * nb + tile]) - (long long)dstart;
+        }
     }
     __syncthreads();
     // in-wave stable ranks by ballot multi-split, running positions in s_cnt[wid][*]
 #pragma unroll
-    for (int c = 0; c < RS_ITEMS; ++c) {
+    for (int c = 0; c < ITEMS; ++c) {
         uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
         bool ok = idx < n;
         uint32_t d = (key[c] >> shift) & mask;
@@ -222,14 +228,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *__res
     }
     __syncthreads();
     // digit-contiguous in LDS -> runs in global memory
-    for (uint32_t k = tid; k < n_tile; k += RS_THREADS) {
+    for (uint32_t k = tid; k < n_tile; k += THREADS) {
         uint32_t kk = s_keys[k];
-        int64_t g = (int64_t)k + s_gofs[(kk >> shift) & mask];
+        long long g = (long long)k + s_gofs[(kk >> shift) & mask];
         keys_out[g] = kk;
         vals_out[g] = s_vals[k];
     }
 }
-
 
 // ------------------------------------------------------------------------ onesweep variant
 // One kernel per digit: the global digit histograms of all passes come from ONE upfront read of the
@@ -240,6 +245,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *__res
 // read with relaxed agent-scope atomics (sc1 store / sc1 load), the "granule" form of
 // MI355X_MICROARCH.md — no separate flag, so no ordering between two words is needed.  Tiles take
 // their index from an atomic ticket so that every predecessor a tile waits for is already running.
+#define RS_WAVES_UNUSED 0
 #define OS_THREADS 512
 #define OS_ITEMS 16
 #define OS_TILE (OS_THREADS * OS_ITEMS)   // 8192 keys
@@ -399,32 +405,46 @@ int fd_onesweep_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b,
     return cur;
 }
 
-uint32_t fd_rs_num_tiles(uint64_t n) { return (uint32_t)((n + RS_TILE - 1) / RS_TILE); }
+// classic LSD variants: 0 = 256x16 tiles, 1 = 256x16 + XCD-aware tile order, 2 = 512x16, 3 = 512x16 + XCD-aware
+static int g_rs_variant = 1;
+void fd_rs_set_variant(int v) { g_rs_variant = v; }
+static inline uint32_t rs_tile(int v) { return (v >= 2 ? 512u : 256u) * 16u; }
+uint32_t fd_rs_num_tiles(uint64_t n) { return (uint32_t)((n + 4096 - 1) / 4096); }  // upper bound over variants (workspace sizing)
 
-// Sort (keys, vals) by the low `key_bits` bits of keys, stable. Buffers a/b ping-pong; returns which
-// buffer (0 = a, 1 = b) holds the result. ghist: u32[256 * tiles], tot: u64[256].
+template <int THREADS, int ITEMS, bool XCD>
+static void rs_pass(uint32_t *ki, uint32_t *vi, uint32_t *ko, uint32_t *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist,
+                    uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
+    uint32_t nb = (uint32_t)((n + THREADS * ITEMS - 1) / (THREADS * ITEMS));
+    uint32_t grid = XCD ? ((nb + 7u) / 8u) * 8u : nb;
+    {
+        StageTimer t(tc, "rs_hist", n * 4 + (uint64_t)nb * RS_BINS * 4);
+        hipLaunchKernelGGL((k_rs_hist<THREADS, ITEMS, XCD>), dim3(grid), dim3(THREADS), 0, st, ki, n, shift, mask, ghist, nb);
+    }
+    {
+        StageTimer t(tc, "rs_scan", (uint64_t)nb * RS_BINS * 8);
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
+        hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
+    }
+    {
+        StageTimer t(tc, "rs_scatter", n * 16);
+        hipLaunchKernelGGL((k_rs_scatter<THREADS, ITEMS, XCD>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
+    }
+}
+
 int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits,
                         uint32_t *ghist, uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
     if (n == 0) return 0;
-    uint32_t nb = fd_rs_num_tiles(n);
     int cur = 0;
     for (int shift = 0; shift < key_bits; shift += 8) {
         int bits = key_bits - shift < 8 ? key_bits - shift : 8;
         uint32_t mask = (1u << bits) - 1u;
         uint32_t *ki = cur ? keys_b : keys_a, *vi = cur ? vals_b : vals_a;
         uint32_t *ko = cur ? keys_a : keys_b, *vo = cur ? vals_a : vals_b;
-        {
-            StageTimer t(tc, "rs_hist", n * 4 + (uint64_t)nb * RS_BINS * 4);
-            hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(RS_THREADS), 0, st, ki, n, (uint32_t)shift, mask, ghist, nb);
-        }
-        {
-            StageTimer t(tc, "rs_scan", (uint64_t)nb * RS_BINS * 8);
-            hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
-            hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
-        }
-        {
-            StageTimer t(tc, "rs_scatter", n * 16);
-            hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, nb, tot);
+        switch (g_rs_variant) {
+            case 0: rs_pass<256, 16, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 1: rs_pass<256, 16, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 2: rs_pass<512, 16, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            default: rs_pass<512, 16, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
         }
         cur ^= 1;
     }
