@@ -42,6 +42,17 @@ class MatchQuery(C.Structure):
                 ("aad_qi", u32p), ("n_aad", C.c_uint64), ("ca_distance_cutoff", C.c_float), ("use_aa_prefilter", C.c_int)]
 
 
+class QueryMap(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("hash", u32p), ("qi", u32p), ("qj", u32p), ("is_primary", u8p), ("idf", f32p),
+                ("n_indices", C.c_uint64), ("indices", u32p),
+                ("n_aad", C.c_uint64), ("aad_aa1", u8p), ("aad_aa2", u8p), ("aad_dist", f32p), ("aad_qi", u32p)]
+
+
+class MatchRec(C.Structure):
+    _fields_ = [("cand", C.c_uint32), ("same", C.c_uint32), ("idf", C.c_float), ("rmsd", C.c_float), ("rmsd_from_hash", C.c_float),
+                ("rot", C.c_float * 9), ("tran", C.c_float * 3)]
+
+
 # every symbol include/fdgpu.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("fdgpu_create", C.c_int, [C.c_int, C.POINTER(VP)]),
@@ -72,6 +83,14 @@ SYMBOLS = [
     ("fdgpu_kabsch_batch", C.c_int, [VP, f32p, f32p, u64p, C.c_uint64, f32p, f32p, f32p]),
     ("fdgpu_last_timings", C.c_int, [VP, C.POINTER(C.c_char_p), f32p, u64p, C.c_int]),
     ("fdgpu_enable_timing", C.c_int, [VP, C.c_int]),
+    ("fdgpu_pair_features", C.c_int, [VP, VP, C.c_uint64, u32p, u32p, C.c_uint64, C.POINTER(HashParams), f32p, u8p]),
+    ("fdgpu_hash_features", C.c_int, [VP, f32p, C.c_uint64, C.POINTER(HashParams), u32p]),
+    ("fdgpu_make_query_map", C.c_int, [VP, VP, u32p, C.c_uint64, C.POINTER(u8p), u32p, f32p, C.c_uint64, f32p, C.c_uint64,
+                                       C.POINTER(HashParams), VP, C.c_float, C.POINTER(C.POINTER(QueryMap))]),
+    ("fdgpu_query_map_free", None, [C.POINTER(QueryMap)]),
+    ("fdgpu_retrieve", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(QueryMap), VP, C.POINTER(HashParams), C.c_float, C.c_uint32,
+                                 C.POINTER(C.POINTER(MatchRec)), u64p, C.POINTER(C.POINTER(C.c_int32))]),
+    ("fdgpu_matches_free", None, [C.POINTER(MatchRec), C.POINTER(C.c_int32)]),
     ("fdgpu_debug_libm", C.c_int, [VP, C.c_int, f32p, f32p, f32p, C.c_uint64]),
 ]
 

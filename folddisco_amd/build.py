@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfdgpu.so")
-SOURCES = ["fdgpu_api.hip", "k_hash.hip", "k_sort.hip", "k_index.hip", "k_query.hip", "k_match.hip"]
+SOURCES = ["fdgpu_api.hip", "k_hash.hip", "k_sort.hip", "k_index.hip", "k_query.hip", "k_match.hip", "fd_host_query.hip"]
 
 
 def hipcc() -> str:

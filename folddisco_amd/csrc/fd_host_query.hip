@@ -1,0 +1,456 @@
+// fd_host_query.hip — host-side (C++) half of the query path around the GPU kernels:
+//   make_query_map        (src/controller/query.rs:208-329, helpers :53-206)   features + hashes on the GPU,
+//                          expansion / substitution / first-insert-wins bookkeeping on the host
+//   retrieval             (src/controller/retrieve.rs:364-552)                pair scan + Kabsch on the GPU,
+//                          graph components (src/controller/graph.rs:16-50), residue voting
+//                          (retrieve.rs:604-702) and rescue (:479-515) on the host
+// The reference is compiled code, so this glue is C++ behind the same C ABI; it contains no f32
+// arithmetic that decides a hash bit (that all happens in the kernels) except the query expansion's
+// feature +- delta adds, which are single IEEE f32 adds exactly like the reference's.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <vector>
+#include "fdgpu_internal.h"
+
+#define HIPCHK(ctx, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) {                                                                             \
+            char _b[512];                                                                                   \
+            snprintf(_b, sizeof _b, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));  \
+            (ctx)->err = _b;                                                                                \
+            return FDGPU_EHIP;                                                                              \
+        }                                                                                                   \
+    } while (0)
+
+fd_hash_consts fd_make_consts(const fd_hash_params *p);  // fdgpu_api.hip
+
+// ------------------------------------------------------------------------------------------ kernels
+// get_single_feature (src/controller/feature.rs:11-24, 84-99) for explicit residue pairs of one structure
+__global__ void k_pair_features(fd_batch_view B, uint32_t s, const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj, uint32_t n,
+                                float cutoff, float *__restrict__ feat /*[n][7]*/, uint8_t *__restrict__ valid) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t r0 = B.res_off[s], r1 = B.res_off[s + 1];
+    uint32_t i = r0 + pi[k], j = r0 + pj[k];
+    bool ok = i < r1 && j < r1 && i != j && B.hash_ok[i] && B.hash_ok[j];
+    fd_feature f = {0, 0, 0, 0, 0};
+    if (ok) {
+        fd_v3 ca1 = fd_load3(B.ca_xyz, i), ca2 = fd_load3(B.ca_xyz, j);
+        float d = fd_dist(ca1, ca2);
+        if (d > cutoff) ok = false;
+        else f = fd_pair_feature(fd_load3(B.n_xyz, i), ca1, fd_load3(B.cb_xyz, i), fd_load3(B.n_xyz, j), ca2, fd_load3(B.cb_xyz, j));
+    }
+    valid[k] = ok ? 1 : 0;
+    float *o = feat + 7ull * k;
+    o[0] = ok ? (float)B.aa[i] : 0.f; o[1] = ok ? (float)B.aa[j] : 0.f;
+    o[2] = f.ca_dist; o[3] = f.cb_dist; o[4] = f.angle; o[5] = f.tor1; o[6] = f.tor2;
+}
+// GeometricHash::perfect_hash (src/geometry/pdb_tr.rs:21-75) on explicit feature vectors
+__global__ void k_hash_features(const float *__restrict__ feat, uint64_t n, fd_quant q, uint32_t *__restrict__ out) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float *f = feat + 7 * k;
+    fd_feature ft = {f[2], f[3], f[4], f[5], f[6]};
+    out[k] = fd_hash_pdbtr(fd_sat_u32(f[0]), fd_sat_u32(f[1]), ft, q);
+}
+
+extern "C" int fdgpu_pair_features(fdgpu_ctx *c, const fdgpu_batch *b, uint64_t s, const uint32_t *pi, const uint32_t *pj, uint64_t n,
+                                   const fd_hash_params *p, float *features, uint8_t *valid) {
+    if (!c || !b || !p || s >= b->n_struct || (n && (!pi || !pj || !features || !valid))) return FDGPU_EINVAL;
+    if (!n) return FDGPU_OK;
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->ws[WS_MISC0].ensure(n * 4));
+    HIPCHK(c, c->ws[WS_MISC1].ensure(n * 4));
+    HIPCHK(c, c->ws[WS_MISC2].ensure(n * 28));
+    HIPCHK(c, c->ws[WS_MISC3].ensure(n));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, pi, n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, pj, n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_pair_features, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, b->view(), (uint32_t)s, c->ws[WS_MISC0].as<uint32_t>(),
+                       c->ws[WS_MISC1].as<uint32_t>(), (uint32_t)n, p->dist_cutoff, c->ws[WS_MISC2].as<float>(), c->ws[WS_MISC3].as<uint8_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(features, c->ws[WS_MISC2].p, n * 28, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(valid, c->ws[WS_MISC3].p, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return FDGPU_OK;
+}
+
+extern "C" int fdgpu_hash_features(fdgpu_ctx *c, const float *features, uint64_t n, const fd_hash_params *p, uint32_t *hashes) {
+    if (!c || !p || (n && (!features || !hashes))) return FDGPU_EINVAL;
+    if (!n) return FDGPU_OK;
+    hipStream_t st = c->stream;
+    fd_hash_consts C = fd_make_consts(p);
+    HIPCHK(c, c->ws[WS_MISC2].ensure(n * 28));
+    HIPCHK(c, c->ws[WS_MISC0].ensure(n * 4));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, features, n * 28, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_hash_features, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, c->ws[WS_MISC2].as<float>(), n, C.q, c->ws[WS_MISC0].as<uint32_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(hashes, c->ws[WS_MISC0].p, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return FDGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------ make_query_map
+template <typename T> static T *dup_vec(const std::vector<T> &v) {
+    T *p = (T *)malloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+extern "C" void fdgpu_query_map_free(fd_query_map *m) {
+    if (!m) return;
+    free(m->hash); free(m->qi); free(m->qj); free(m->is_primary); free(m->idf); free(m->indices);
+    free(m->aad_aa1); free(m->aad_aa2); free(m->aad_dist); free(m->aad_qi);
+    free(m);
+}
+
+extern "C" int fdgpu_make_query_map(fdgpu_ctx *c, const fdgpu_batch *qb, const uint32_t *q_index, uint64_t n_q, const uint8_t *const *subs,
+                                    const uint32_t *n_subs, const float *dist_thr, uint64_t n_dist, const float *angle_thr_deg, uint64_t n_angle,
+                                    const fd_hash_params *p, const fdgpu_index *index, float total_structures, fd_query_map **out) {
+    if (!c || !qb || !p || !out || qb->n_struct < 1 || (n_q && !q_index)) return FDGPU_EINVAL;
+    *out = nullptr;
+    const uint64_t R = qb->h_res_off[1] - qb->h_res_off[0];
+    // all ordered pairs of the query residues, row-major (CombinationIterator, utils/combination.rs:23-44)
+    std::vector<uint32_t> pi, pj;
+    for (uint64_t a = 0; a < n_q; ++a)
+        for (uint64_t b = 0; b < n_q; ++b)
+            if (a != b && q_index[a] < R && q_index[b] < R) { pi.push_back(q_index[a]); pj.push_back(q_index[b]); }
+    const uint64_t np = pi.size();
+    std::vector<float> feat(std::max<uint64_t>(np, 1) * 7);
+    std::vector<uint8_t> valid(std::max<uint64_t>(np, 1));
+    int rc = fdgpu_pair_features(c, qb, 0, pi.data(), pj.data(), np, p, feat.data(), valid.data());
+    if (rc) return rc;
+    // substitution map keyed by residue index: a later entry for the same residue overrides (query.rs:236-246)
+    std::map<uint32_t, std::pair<const uint8_t *, uint32_t>> sub_of;
+    if (subs && n_subs)
+        for (uint64_t a = 0; a < n_q; ++a)
+            if (subs[a]) sub_of[q_index[a]] = std::make_pair(subs[a], n_subs[a]);
+    const float RADS_PER_DEG = 3.14159274101257324f / 180.0f;  // f32::to_radians
+    std::vector<float> athr(n_angle);
+    for (uint64_t t = 0; t < n_angle; ++t) athr[t] = angle_thr_deg[t] * RADS_PER_DEG;
+    // candidate list in the reference's insertion order; hashed in one GPU call, then first-insert-wins
+    struct cand_t { uint32_t qi, qj; uint8_t primary; uint32_t pair; };
+    std::vector<float> vf;      // 7 floats per candidate
+    std::vector<cand_t> cands;
+    auto push = [&](const float *f, uint32_t qi, uint32_t qj, bool primary, uint32_t pair) {
+        vf.insert(vf.end(), f, f + 7);
+        cands.push_back({qi, qj, (uint8_t)(primary ? 1 : 0), pair});
+    };
+    std::vector<uint8_t> a1, a2;
+    std::vector<float> ad;
+    std::vector<uint32_t> aq;
+    for (uint64_t k = 0; k < np; ++k) {
+        if (!valid[k]) continue;
+        const float *f = &feat[7 * k];
+        uint32_t qi = pi[k], qj = pj[k];
+        // observed (aa_i, aa_j, CA distance) list (structure/core.rs:462-477: distance <= 20.0)
+        if (f[2] <= 20.0f) { a1.push_back((uint8_t)f[0]); a2.push_back((uint8_t)f[1]); ad.push_back(f[2]); aq.push_back(qi); }
+        push(f, qi, qj, true, (uint32_t)k);
+        float near[7], far[7];
+        memcpy(near, f, sizeof near);
+        memcpy(far, f, sizeof far);
+        auto si = sub_of.find(qi), sj = sub_of.find(qj);
+        if (si != sub_of.end()) {  // apply_substitutions (query.rs:86-156)
+            for (uint32_t a = 0; a < si->second.second; ++a) { float t[7]; memcpy(t, near, sizeof t); t[0] = (float)si->second.first[a]; push(t, qi, qj, false, (uint32_t)k); }
+            if (sj != sub_of.end())
+                for (uint32_t a = 0; a < si->second.second; ++a)
+                    for (uint32_t b = 0; b < sj->second.second; ++b) {
+                        float t[7]; memcpy(t, near, sizeof t);
+                        t[0] = (float)si->second.first[a]; t[1] = (float)sj->second.first[b];
+                        push(t, qi, qj, false, (uint32_t)k);
+                    }
+        } else if (sj != sub_of.end()) {
+            for (uint32_t b = 0; b < sj->second.second; ++b) { float t[7]; memcpy(t, near, sizeof t); t[1] = (float)sj->second.first[b]; push(t, qi, qj, false, (uint32_t)k); }
+        }
+        auto expand = [&](const int *idxs, int n_idx, const float *thr, uint64_t n_thr) {  // expand_and_insert (query.rs:179-206)
+            for (uint64_t t = 0; t < n_thr; ++t)
+                for (int z = 0; z < n_idx; ++z) {
+                    int idx = idxs[z];
+                    near[idx] = near[idx] - thr[t];
+                    far[idx] = far[idx] + thr[t];
+                    push(near, qi, qj, false, (uint32_t)k);
+                    push(far, qi, qj, false, (uint32_t)k);
+                    // the reference restores with += / -= (f32, not an exact inverse): keep the drift
+                    near[idx] = near[idx] + thr[t];
+                    far[idx] = far[idx] - thr[t];
+                }
+        };
+        static const int di[2] = {2, 3}, ai[3] = {4, 5, 6};
+        expand(di, 2, dist_thr, n_dist);
+        expand(ai, 3, athr.data(), n_angle);
+    }
+    const uint64_t nc = cands.size();
+    std::vector<uint32_t> hashes(std::max<uint64_t>(nc, 1));
+    if ((rc = fdgpu_hash_features(c, vf.data(), nc, p, hashes.data()))) return rc;
+    // idf of every pair's observed (primary) hash: log2(S / len) (query.rs:17-32)
+    std::vector<float> pair_idf(std::max<uint64_t>(np, 1), 0.0f);
+    if (index) {
+        std::vector<uint32_t> ph;
+        std::vector<uint32_t> pk;
+        for (uint64_t t = 0; t < nc; ++t)
+            if (cands[t].primary) { ph.push_back(hashes[t]); pk.push_back(cands[t].pair); }
+        std::vector<uint64_t> lens(std::max<size_t>(ph.size(), 1));
+        if ((rc = fdgpu_posting_lengths(c, index, ph.data(), ph.size(), lens.data()))) return rc;
+        for (size_t t = 0; t < ph.size(); ++t)
+            pair_idf[pk[t]] = lens[t] > 0 ? log2f(total_structures / (float)lens[t]) : 0.0f;
+    }
+    std::vector<uint32_t> mh, mqi, mqj;
+    std::vector<uint8_t> mp;
+    std::vector<float> mi;
+    {
+        std::vector<uint32_t> seen;  // sorted set for membership (query maps are small; whole-structure ones ~1e5)
+        std::map<uint32_t, char> have;
+        for (uint64_t t = 0; t < nc; ++t) {
+            if (have.count(hashes[t])) continue;
+            have[hashes[t]] = 1;
+            mh.push_back(hashes[t]); mqi.push_back(cands[t].qi); mqj.push_back(cands[t].qj); mp.push_back(cands[t].primary);
+            mi.push_back(pair_idf[cands[t].pair]);
+        }
+    }
+    fd_query_map *m = (fd_query_map *)calloc(1, sizeof *m);
+    if (!m) return FDGPU_ENOMEM;
+    m->n = mh.size();
+    m->hash = dup_vec(mh); m->qi = dup_vec(mqi); m->qj = dup_vec(mqj); m->is_primary = dup_vec(mp); m->idf = dup_vec(mi);
+    std::vector<uint32_t> idx(q_index, q_index + n_q);
+    m->n_indices = n_q; m->indices = dup_vec(idx);
+    m->n_aad = ad.size(); m->aad_aa1 = dup_vec(a1); m->aad_aa2 = dup_vec(a2); m->aad_dist = dup_vec(ad); m->aad_qi = dup_vec(aq);
+    *out = m;
+    return FDGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------ retrieval glue
+namespace {
+struct Graph {
+    std::vector<uint32_t> w;           // node -> residue index (first-appearance order, graph.rs:16-26)
+    std::vector<uint32_t> es, et, eh;  // edges in insertion order
+    uint32_t node_of(uint32_t res) {
+        for (uint32_t k = 0; k < w.size(); ++k) if (w[k] == res) return k;
+        w.push_back(res);
+        return (uint32_t)w.size() - 1;
+    }
+};
+
+// SCCs (Tarjan) and weakly connected components, as sorted node lists (graph.rs:29-50)
+static std::vector<std::vector<uint32_t>> components(const Graph &g, size_t min_nodes) {
+    const uint32_t n = (uint32_t)g.w.size();
+    std::vector<std::vector<uint32_t>> adj(n);
+    for (size_t e = 0; e < g.es.size(); ++e) adj[g.es[e]].push_back(g.et[e]);
+    std::vector<int> idx(n, -1), low(n, 0), comp(n, -1);
+    std::vector<char> on(n, 0);
+    std::vector<uint32_t> stk;
+    int counter = 0, ncomp = 0;
+    struct Fr { uint32_t v; size_t it; };
+    for (uint32_t root = 0; root < n; ++root) {
+        if (idx[root] >= 0) continue;
+        std::vector<Fr> cs;
+        cs.push_back({root, 0});
+        idx[root] = low[root] = counter++; stk.push_back(root); on[root] = 1;
+        while (!cs.empty()) {
+            Fr &f = cs.back();
+            if (f.it < adj[f.v].size()) {
+                uint32_t x = adj[f.v][f.it++];
+                if (idx[x] < 0) { idx[x] = low[x] = counter++; stk.push_back(x); on[x] = 1; cs.push_back({x, 0}); }
+                else if (on[x]) low[f.v] = std::min(low[f.v], idx[x]);
+            } else {
+                uint32_t v = f.v;
+                if (low[v] == idx[v]) {
+                    uint32_t x;
+                    do { x = stk.back(); stk.pop_back(); on[x] = 0; comp[x] = ncomp; } while (x != v);
+                    ++ncomp;
+                }
+                cs.pop_back();
+                if (!cs.empty()) low[cs.back().v] = std::min(low[cs.back().v], low[v]);
+            }
+        }
+    }
+    std::vector<uint32_t> uf(n);
+    for (uint32_t v = 0; v < n; ++v) uf[v] = v;
+    auto find = [&](uint32_t x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; };
+    for (size_t e = 0; e < g.es.size(); ++e) { uint32_t a = find(g.es[e]), b = find(g.et[e]); if (a != b) uf[a] = b; }
+    std::map<int, std::vector<uint32_t>> by_scc, by_wcc;
+    for (uint32_t v = 0; v < n; ++v) { by_scc[comp[v]].push_back(v); by_wcc[(int)find(v)].push_back(v); }
+    std::vector<std::vector<uint32_t>> all;
+    for (auto &kv : by_scc) if (kv.second.size() >= min_nodes) all.push_back(kv.second);
+    for (auto &kv : by_wcc) if (kv.second.size() >= min_nodes) all.push_back(kv.second);
+    for (auto &cc : all) std::sort(cc.begin(), cc.end());
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    return all;
+}
+}  // namespace
+
+extern "C" void fdgpu_matches_free(fd_match_rec *m, int32_t *residues) { free(m); free(residues); }
+
+extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
+                              const fd_query_map *qm, const fdgpu_batch *qb, const fd_hash_params *p, float ca_distance_cutoff,
+                              uint32_t node_count, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues) {
+    if (!c || !db || !qm || !qb || !p || !matches || !n_matches || !residues) return FDGPU_EINVAL;
+    *matches = nullptr; *n_matches = 0; *residues = nullptr;
+    const uint64_t NQ = qm->n_indices;
+    // sorted unique query hashes + lookup hash -> query map entry
+    std::map<uint32_t, uint32_t> entry;
+    for (uint64_t k = 0; k < qm->n; ++k) entry.emplace(qm->hash[k], (uint32_t)k);
+    std::vector<uint32_t> qh;
+    for (auto &kv : entry) qh.push_back(kv.first);
+    fd_match_query q;
+    q.hashes = qh.data(); q.n_hashes = qh.size();
+    q.aad_aa1 = qm->aad_aa1; q.aad_aa2 = qm->aad_aa2; q.aad_dist = qm->aad_dist; q.aad_qi = qm->aad_qi; q.n_aad = qm->n_aad;
+    q.ca_distance_cutoff = ca_distance_cutoff;
+    q.use_aa_prefilter = qh.size() <= 200 ? 1 : 0;  // PREFILTER_AA_SKIPPING_SIZE (retrieve.rs:24, 569)
+    fd_pair_rec *found = nullptr; fd_cand_rec *cands = nullptr;
+    uint64_t nf = 0, nc = 0;
+    int rc = fdgpu_match_pairs(c, db, resname_std, cand, n_cand, &q, p, &found, &nf, &cands, &nc);
+    if (rc) return rc;
+    // symmetry flags (geometry/pdb_tr.rs:158-162): aa equal and atan2(sin, cos) of the two torsion fields equal
+    auto is_sym = [](uint32_t h) {
+        auto cont = [](uint32_t v) { float cf = (1.0f - (-1.0f)) / (4.0f - 1.0f); return (float)v * cf + (-1.0f); };
+        const float D = 57.2957795130823208767981548141051703f;
+        float p1 = atan2f(cont((h >> 6) & 3), cont((h >> 4) & 3)) * D, p2 = atan2f(cont((h >> 2) & 3), cont(h & 3)) * D;
+        return ((h >> 25) & 31u) == ((h >> 20) & 31u) && p1 == p2;
+    };
+    uint32_t q_size = 1;
+    for (uint64_t k = 0; k < qm->n; ++k) q_size = std::max(q_size, std::max(qm->qi[k], qm->qj[k]) + 1);
+    // per candidate: graph -> components -> vote -> rescue; Kabsch problems collected for one GPU batch
+    std::vector<fd_match_rec> recs;
+    std::vector<int32_t> res;               // 2 * NQ per match: from_hash then processed target residue index (-1 = none)
+    std::vector<float> kx, ky;              // Kabsch points (target = moving x, query = fixed y)
+    std::vector<uint64_t> koff(1, 0);
+    struct Pend { size_t rec; int which; }; // which: 0 from_hash, 1 processed
+    std::vector<Pend> pend;
+    // host copies of the coordinates needed for the Kabsch point lists
+    std::vector<float> q_ca((qb->h_res_off[1] - qb->h_res_off[0]) * 3), q_cb(q_ca.size());
+    HIPCHK(c, hipMemcpy(q_ca.data(), qb->ca_xyz, q_ca.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(q_cb.data(), qb->cb_xyz, q_cb.size() * 4, hipMemcpyDeviceToHost));
+    size_t fpos = 0, cpos = 0;
+    for (uint64_t slot = 0; slot < n_cand; ++slot) {
+        size_t f0 = fpos, c0 = cpos;
+        while (fpos < nf && found[fpos].cand == slot) ++fpos;
+        while (cpos < nc && cands[cpos].cand == slot) ++cpos;
+        if (fpos == f0) continue;
+        Graph g;
+        for (size_t e = f0; e < fpos; ++e) {
+            uint32_t a = g.node_of(found[e].i), b = g.node_of(found[e].j);
+            g.es.push_back(a); g.et.push_back(b); g.eh.push_back(found[e].hash);
+        }
+        auto comps = components(g, node_count);
+        if (comps.empty()) continue;
+        const uint32_t s = cand[slot];
+        const uint64_t r0 = db->h_res_off[s], Rt = db->h_res_off[s + 1] - r0;
+        std::vector<float> t_ca(Rt * 3), t_cb(Rt * 3);
+        HIPCHK(c, hipMemcpy(t_ca.data(), db->ca_xyz + 3 * r0, Rt * 12, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(t_cb.data(), db->cb_xyz + 3 * r0, Rt * 12, hipMemcpyDeviceToHost));
+        for (auto &cc : comps) {
+            std::vector<char> inc(g.w.size(), 0);
+            uint32_t r_size = 1;
+            for (uint32_t v : cc) { inc[v] = 1; r_size = std::max(r_size, g.w[v] + 1); }
+            float sub_idf = 0.0f;
+            std::vector<uint8_t> counts((size_t)q_size * r_size, 0), best_c(q_size, 0);
+            std::vector<uint32_t> best_r(q_size, 0);
+            for (size_t e = 0; e < g.es.size(); ++e) {
+                if (!inc[g.es[e]] || !inc[g.et[e]]) continue;
+                auto it = entry.find(g.eh[e]);
+                if (it == entry.end()) continue;
+                uint32_t k = it->second;
+                sub_idf += qm->idf[k];                      // calculate_subgraph_idf (retrieve.rs:705-719)
+                uint32_t qi = qm->qi[k], qj = qm->qj[k], ri = g.w[g.es[e]], rj = g.w[g.et[e]];
+                uint32_t pq[2], pr[2];
+                if (is_sym(g.eh[e])) { pq[0] = std::min(qi, qj); pq[1] = std::max(qi, qj); pr[0] = std::min(ri, rj); pr[1] = std::max(ri, rj); }
+                else { pq[0] = qi; pr[0] = ri; pq[1] = qj; pr[1] = rj; }
+                for (int z = 0; z < 2; ++z) {
+                    uint8_t &cc2 = counts[(size_t)pq[z] * r_size + pr[z]];
+                    if (cc2 < 255) ++cc2;
+                    if (cc2 > best_c[pq[z]] || (cc2 == best_c[pq[z]] && pr[z] < best_r[pq[z]])) { best_c[pq[z]] = cc2; best_r[pq[z]] = pr[z]; }
+                }
+            }
+            std::vector<uint32_t> q_idx, r_idx;
+            std::vector<char> q_used(q_size, 0), r_used(r_size, 0);
+            bool done = false;
+            for (int bucket = 255; bucket >= 1 && !done; --bucket)
+                for (uint32_t qq = 0; qq < q_size && !done; ++qq) {
+                    if (best_c[qq] != bucket) continue;
+                    uint32_t rr = best_r[qq];
+                    if (!q_used[qq] && !r_used[rr]) {
+                        q_idx.push_back(qq); r_idx.push_back(rr); q_used[qq] = 1; r_used[rr] = 1;
+                        if (q_idx.size() == cc.size()) done = true;
+                    }
+                }
+            // residue assignment + rescue (retrieve.rs:430-516)
+            std::vector<int32_t> from_hash(NQ, -1), processed(NQ, -1);
+            std::vector<uint32_t> qs_sc, rs_sc;
+            for (uint64_t pos = 0; pos < NQ; ++pos) {
+                uint32_t qi = qm->indices[pos];
+                int32_t mapped = -1;
+                for (size_t k = 0; k < q_idx.size(); ++k) if (q_idx[k] == qi) { mapped = (int32_t)r_idx[k]; break; }
+                if (mapped >= 0) {
+                    from_hash[pos] = mapped;
+                    auto itp = std::find(rs_sc.begin(), rs_sc.end(), (uint32_t)mapped);
+                    if (itp == rs_sc.end()) { processed[pos] = mapped; qs_sc.push_back(qi); rs_sc.push_back((uint32_t)mapped); }
+                    else {
+                        size_t pp = (size_t)(itp - rs_sc.begin());
+                        if (pp < NQ) processed[pp] = -1;   // the reference indexes res_vec with the scanned position
+                        processed[pos] = mapped;
+                        qs_sc.erase(qs_sc.begin() + pp); rs_sc.erase(rs_sc.begin() + pp);
+                        qs_sc.push_back(qi); rs_sc.push_back((uint32_t)mapped);
+                    }
+                } else {
+                    std::vector<std::pair<uint32_t, uint32_t>> cnt;  // (target residue, votes)
+                    for (size_t e = c0; e < cpos; ++e) {
+                        if (cands[e].qi != qi) continue;
+                        if (std::find(r_idx.begin(), r_idx.end(), cands[e].j) == r_idx.end()) continue;
+                        bool hit = false;
+                        for (auto &kv : cnt) if (kv.first == cands[e].i) { kv.second++; hit = true; break; }
+                        if (!hit) cnt.emplace_back(cands[e].i, 1u);
+                    }
+                    if (!cnt.empty()) {
+                        uint32_t mx = 0, nmx = 0, arg = 0;
+                        for (auto &kv : cnt) mx = std::max(mx, kv.second);
+                        for (auto &kv : cnt) if (kv.second == mx) { ++nmx; arg = kv.first; }
+                        if (nmx == 1 && mx >= 2 && std::find(rs_sc.begin(), rs_sc.end(), arg) == rs_sc.end()) {
+                            processed[pos] = (int32_t)arg; qs_sc.push_back(qi); rs_sc.push_back(arg);
+                        }
+                    }
+                }
+            }
+            fd_match_rec rec;
+            memset(&rec, 0, sizeof rec);
+            rec.cand = (uint32_t)slot; rec.idf = sub_idf;
+            rec.same = from_hash == processed ? 1 : 0;
+            recs.push_back(rec);
+            res.insert(res.end(), from_hash.begin(), from_hash.end());
+            res.insert(res.end(), processed.begin(), processed.end());
+            auto add_problem = [&](const std::vector<uint32_t> &qv, const std::vector<uint32_t> &rv, int which) {
+                for (size_t k = 0; k < qv.size(); ++k) {   // [CA, CB] interleaved (retrieve.rs:761-767)
+                    for (int z = 0; z < 3; ++z) ky.push_back(q_ca[3 * qv[k] + z]);
+                    for (int z = 0; z < 3; ++z) ky.push_back(q_cb[3 * qv[k] + z]);
+                    for (int z = 0; z < 3; ++z) kx.push_back(t_ca[3 * rv[k] + z]);
+                    for (int z = 0; z < 3; ++z) kx.push_back(t_cb[3 * rv[k] + z]);
+                }
+                koff.push_back(koff.back() + 2 * qv.size());
+                pend.push_back({recs.size() - 1, which});
+            };
+            add_problem(q_idx, r_idx, 0);
+            if (!rec.same) add_problem(qs_sc, rs_sc, 1);
+        }
+    }
+    free(found); free(cands);
+    const uint64_t nprob = pend.size();
+    std::vector<float> rmsd(std::max<uint64_t>(nprob, 1)), rot(std::max<uint64_t>(nprob, 1) * 9), tran(std::max<uint64_t>(nprob, 1) * 3);
+    if (nprob && (rc = fdgpu_kabsch_batch(c, kx.data(), ky.data(), koff.data(), nprob, rmsd.data(), rot.data(), tran.data()))) return rc;
+    for (uint64_t k = 0; k < nprob; ++k) {
+        fd_match_rec &r = recs[pend[k].rec];
+        if (pend[k].which == 0) {
+            r.rmsd_from_hash = rmsd[k];
+            if (r.same) { r.rmsd = rmsd[k]; memcpy(r.rot, &rot[9 * k], 36); memcpy(r.tran, &tran[3 * k], 12); }
+        } else { r.rmsd = rmsd[k]; memcpy(r.rot, &rot[9 * k], 36); memcpy(r.tran, &tran[3 * k], 12); }
+    }
+    fd_match_rec *om = (fd_match_rec *)malloc(std::max<size_t>(recs.size(), 1) * sizeof(fd_match_rec));
+    int32_t *orr = (int32_t *)malloc(std::max<size_t>(res.size(), 1) * sizeof(int32_t));
+    if (!om || !orr) { free(om); free(orr); return FDGPU_ENOMEM; }
+    if (!recs.empty()) memcpy(om, recs.data(), recs.size() * sizeof(fd_match_rec));
+    if (!res.empty()) memcpy(orr, res.data(), res.size() * sizeof(int32_t));
+    *matches = om; *n_matches = recs.size(); *residues = orr;
+    return FDGPU_OK;
+}

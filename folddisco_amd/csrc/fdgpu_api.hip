@@ -213,6 +213,8 @@ static fd_hash_consts make_consts(const fd_hash_params *p) {
     return C;
 }
 
+fd_hash_consts fd_make_consts(const fd_hash_params *p) { return make_consts(p); }
+
 static int d2h_u64(fdgpu_ctx *c, const uint64_t *dev, uint64_t *host) {
     HIPCHK(c, hipMemcpyAsync(host, dev, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -1,0 +1,191 @@
+"""Query-side host mirror: parse_query_string (src/controller/query.rs:331-384), make_query_map, retrieval and the
+query_pdb workflow (src/cli/workflows/query_pdb.rs:348-519) over the C ABI.  Numerics (features, hashes, postings,
+pair scan, Kabsch) run in libfdgpu.so; this module only marshals and formats."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from ._lib import HashParams, MatchRec, QueryMap, f32p, u8p, u32p, u64p
+from .api import Batch, Context, FolddiscoIndex, PackedStructures, count_query, length_penalty
+from .structure import CompactStructure
+
+_ONE = "ARNDCQEGHILKMFPSTWYV"
+_GROUPS = {"B": [2, 3], "Z": [5, 6], "X": list(range(20)), "x": list(range(20)), "J": [9, 10], "U": [4], "O": [11],
+           "p": [1, 8, 11], "n": [3, 6], "h": [2, 5, 15, 16, 18], "b": [0, 4, 7, 9, 10, 12, 13, 14, 19], "a": [8, 13, 17, 18]}
+
+
+def _one_letter(c: str):
+    if c in _ONE:
+        return [_ONE.index(c)]
+    return _GROUPS.get(c, [255])
+
+
+def parse_query_string(q: str, default_chain: int = ord("A")):
+    """-> list of (chain u8, serial, substitutions or None); raises ValueError where the reference panics."""
+    out = []
+    if not q:
+        return out
+    if not chr(default_chain).isalpha() or default_chain > 127:
+        default_chain = ord("A")
+    for seg in q.replace(" ", "").split(","):
+        chain = default_chain
+        if seg and seg[0].isascii() and seg[0].isalpha():
+            chain, seg = ord(seg[0]), seg[1:]
+        subs = None
+        if ":" in seg:
+            seg, s = seg.split(":", 1)
+            subs = [v for ch in s if ch.isascii() and ch.isalpha() for v in _one_letter(ch)]
+        def num(t):
+            t2 = t[1:] if t.startswith("+") else t
+            if not t2.isdigit():
+                raise ValueError(f"Invalid residue '{t}'")
+            return int(t2)
+        if "-" in seg:
+            a, b = seg.split("-", 1)
+            for r in range(num(a), num(b) + 1):
+                out.append((chain, r, None if subs is None else list(subs)))
+        else:
+            out.append((chain, num(seg), subs))
+    return out
+
+
+def res_chain_to_string(res):
+    return ",".join(f"{chr(c)}{r}" for c, r, _ in res)
+
+
+@dataclass
+class QueryMapResult:
+    hash: np.ndarray
+    qi: np.ndarray
+    qj: np.ndarray
+    is_primary: np.ndarray
+    idf: np.ndarray
+    indices: np.ndarray
+    aad_aa1: np.ndarray
+    aad_aa2: np.ndarray
+    aad_dist: np.ndarray
+    aad_qi: np.ndarray
+    handle: object = field(default=None, repr=False)
+    ctx: Context = field(default=None, repr=False)
+
+    def __del__(self):
+        try:
+            if self.handle is not None and self.ctx is not None and self.ctx.h:
+                self.ctx.L.fdgpu_query_map_free(self.handle)
+        except Exception:
+            pass
+
+
+def _arr(ptr, n, dt):
+    return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].astype(dt, copy=True)
+
+
+def make_query_map(ctx: Context, qbatch: Batch, q_indices, subs=None, index: FolddiscoIndex | None = None,
+                   total_structures: float = 0.0, dist_thr=(0.5,), angle_thr=(5.0,), nbin_dist=0, nbin_angle=0,
+                   dist_cutoff=20.0) -> QueryMapResult:
+    qi = np.ascontiguousarray(q_indices, dtype=np.uint32)
+    n = len(qi)
+    sub_ptrs = (u8p * max(n, 1))()
+    n_subs = np.zeros(max(n, 1), np.uint32)
+    keep = []
+    if subs is not None:
+        for k, s in enumerate(subs):
+            if s is not None:
+                a = np.ascontiguousarray(s if len(s) else [0], dtype=np.uint8)
+                keep.append(a)
+                sub_ptrs[k] = a.ctypes.data_as(u8p)
+                n_subs[k] = len(s)
+    d = np.ascontiguousarray(dist_thr, np.float32)
+    a = np.ascontiguousarray(angle_thr, np.float32)
+    p = HashParams(nbin_dist, nbin_angle, dist_cutoff)
+    out = C.POINTER(QueryMap)()
+    ctx.check(ctx.L.fdgpu_make_query_map(ctx.h, qbatch.h, qi.ctypes.data_as(u32p), n, sub_ptrs, n_subs.ctypes.data_as(u32p),
+                                         d.ctypes.data_as(f32p), len(d), a.ctypes.data_as(f32p), len(a), C.byref(p),
+                                         index.h if index is not None else None, total_structures, C.byref(out)))
+    m = out.contents
+    return QueryMapResult(_arr(m.hash, m.n, np.uint32), _arr(m.qi, m.n, np.uint32), _arr(m.qj, m.n, np.uint32),
+                          _arr(m.is_primary, m.n, np.uint8), _arr(m.idf, m.n, np.float32), _arr(m.indices, m.n_indices, np.uint32),
+                          _arr(m.aad_aa1, m.n_aad, np.uint8), _arr(m.aad_aa2, m.n_aad, np.uint8), _arr(m.aad_dist, m.n_aad, np.float32),
+                          _arr(m.aad_qi, m.n_aad, np.uint32), handle=out, ctx=ctx)
+
+
+def retrieve(ctx: Context, db: Batch, resname_std, cand, qm: QueryMapResult, qbatch: Batch, ca_distance_cutoff=1.0,
+             node_count=2, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0):
+    """-> list of dicts per match: cand slot, idf, rmsd, from_hash / processed target residue indices (-1 = none)."""
+    cand = np.ascontiguousarray(cand, dtype=np.uint32)
+    std = None if resname_std is None else np.ascontiguousarray(resname_std, np.uint8)
+    p = HashParams(nbin_dist, nbin_angle, dist_cutoff)
+    mp = C.POINTER(MatchRec)()
+    rp = C.POINTER(C.c_int32)()
+    nm = C.c_uint64()
+    ctx.check(ctx.L.fdgpu_retrieve(ctx.h, db.h, None if std is None else std.ctypes.data_as(u8p), cand.ctypes.data_as(u32p), len(cand),
+                                   qm.handle, qbatch.h, C.byref(p), ca_distance_cutoff, node_count, C.byref(mp), C.byref(nm), C.byref(rp)))
+    nq = len(qm.indices)
+    out = []
+    for k in range(nm.value):
+        r = mp[k]
+        base = 2 * nq * k
+        out.append(dict(cand=int(r.cand), idf=float(r.idf), rmsd=float(r.rmsd), rmsd_from_hash=float(r.rmsd_from_hash), same=bool(r.same),
+                        from_hash=[rp[base + z] for z in range(nq)], processed=[rp[base + nq + z] for z in range(nq)],
+                        rot=np.array(list(r.rot), np.float32).reshape(3, 3), tran=np.array(list(r.tran), np.float32)))
+    ctx.L.fdgpu_matches_free(mp, rp)
+    return out
+
+
+def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[CompactStructure], tids: list[str], nres, plddt,
+              query: CompactStructure, query_string: str, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance=1.0, top_n=None,
+              length_penalty_power=0.5, skip_match=False, serial_query=False, freq_filter=None):
+    """The per-query body of query_pdb (src/cli/workflows/query_pdb.rs:348-519) with default filters.
+    Returns (structure rows, match rows) as lists of dicts, sorted like the reference's default strategies."""
+    S = len(tids)
+    qres = parse_query_string(query_string, query.chains[0] if query.chains else ord("A"))
+    if qres:
+        idx, subs = [], []
+        for c, r, s in qres:
+            k = r if serial_query else query.get_index(c, r)
+            if k is not None:
+                idx.append(k); subs.append(s)
+    else:
+        idx = [query.get_index(int(query.chain[k]), int(query.serial[k])) for k in range(query.n)]
+        subs = [None] * len(idx)
+    qbatch = ctx.upload(PackedStructures.concat([query.as_item()]))
+    qm = make_query_map(ctx, qbatch, idx, subs, index, float(S), dist_thr, angle_thr)
+    pen = length_penalty(nres, length_penalty_power)
+    rows = count_query(ctx, index, qm.hash, qm.qi, qm.qj, pen, total_structures=S, freq_filter=freq_filter)
+    for r in rows:
+        r.update(tid=tids[r["nid"]], nres=int(nres[r["nid"]]), plddt=float(plddt[r["nid"]]), db_key=r["nid"], matches=[],
+                 max_matching_node_count=0, min_rmsd_with_max_match=0.0)
+    rows.sort(key=lambda r: -r["idf"])  # par_sort_by idf desc, stable (query_pdb.rs:404)
+    if top_n is not None:
+        rows = rows[:top_n]
+    match_rows = []
+    if not skip_match and rows:
+        std = np.concatenate([s.resname_std() for s in db_structs])
+        cand = np.array([r["nid"] for r in rows], np.uint32)
+        ms = retrieve(ctx, db, std, cand, qm, qbatch, ca_distance)
+        for m in ms:
+            r = rows[m["cand"]]
+            t = db_structs[r["nid"]]
+            lab = lambda lst: ["_" if x < 0 else f"{chr(int(t.chain[x]))}{int(t.serial[x])}" for x in lst]
+            m2 = dict(tid=r["tid"], nid=r["nid"], node_count=sum(x >= 0 for x in m["processed"]), idf=m["idf"], rmsd=m["rmsd"],
+                      matching_residues=",".join(lab(m["processed"])), query_residues=res_chain_to_string(qres) if qres else query_string)
+            r["matches"].append(m2)
+            cnt = m2["node_count"]
+            if cnt > r["max_matching_node_count"]:
+                r["max_matching_node_count"], r["min_rmsd_with_max_match"] = cnt, m["rmsd"]
+            elif cnt == r["max_matching_node_count"] and m["rmsd"] < r["min_rmsd_with_max_match"]:
+                r["min_rmsd_with_max_match"] = m["rmsd"]
+            match_rows.append(m2)
+        # MatchSortStrategy::default: idf desc, rmsd asc (sort.rs:217-222), stable
+        match_rows.sort(key=lambda m: (-m["idf"], m["rmsd"]))
+        if top_n is not None:
+            match_rows = match_rows[:top_n]
+    return rows, match_rows
+
+
+def format_match_row(m) -> str:
+    """default per-match columns (result.rs:331-339), floats {:.4}"""
+    return "\t".join([m["tid"], str(m["node_count"]), "%.4f" % m["idf"], "%.4f" % m["rmsd"], m["matching_residues"], m["query_residues"]])

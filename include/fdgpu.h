@@ -158,6 +158,46 @@ int fdgpu_match_pairs(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *resn
 int fdgpu_kabsch_batch(fdgpu_ctx *ctx, const float *x, const float *y, const uint64_t *off, uint64_t n_problems,
                        float *rmsd, float *rot, float *tran);
 
+/* ---- query map and retrieval (host glue in C++, numerics on the GPU) ------------------------------------
+ * get_single_feature (src/controller/feature.rs:11-24, 84-99) for explicit residue pairs (i, j) of
+ * structure s of a batch: features[k] = {aa_i, aa_j, d_CA, d_CB, theta, tau1, tau2}, valid[k] = has a feature. */
+int fdgpu_pair_features(fdgpu_ctx *ctx, const fdgpu_batch *b, uint64_t s, const uint32_t *pair_i, const uint32_t *pair_j,
+                        uint64_t n, const fd_hash_params *p, float *features /*[n][7]*/, uint8_t *valid);
+/* GeometricHash::perfect_hash (src/geometry/pdb_tr.rs:21-75) on explicit 7-float feature vectors */
+int fdgpu_hash_features(fdgpu_ctx *ctx, const float *features, uint64_t n, const fd_hash_params *p, uint32_t *hashes);
+
+typedef struct fd_query_map {   /* make_query_map output (src/controller/query.rs:208-329), first-insertion order */
+    uint64_t n;
+    uint32_t *hash; uint32_t *qi; uint32_t *qj; uint8_t *is_primary; float *idf;
+    uint64_t n_indices; uint32_t *indices;                 /* all_query_indices */
+    uint64_t n_aad; uint8_t *aad_aa1; uint8_t *aad_aa2; float *aad_dist; uint32_t *aad_qi;   /* observed_distance_map */
+} fd_query_map;
+/* qb = batch holding the query structure as structure 0; q_index[k] = residue index of the k-th query
+ * residue (after parse_query_string + get_index / --serial-index resolution on the caller's side);
+ * subs[k] = amino-acid substitution list of residue k or NULL; thresholds as given to -d / -a (angles in
+ * degrees); index may be NULL (idf 0). */
+int fdgpu_make_query_map(fdgpu_ctx *ctx, const fdgpu_batch *qb, const uint32_t *q_index, uint64_t n_q,
+                         const uint8_t *const *subs, const uint32_t *n_subs, const float *dist_thr, uint64_t n_dist,
+                         const float *angle_thr_deg, uint64_t n_angle, const fd_hash_params *p, const fdgpu_index *index,
+                         float total_structures, fd_query_map **out);
+void fdgpu_query_map_free(fd_query_map *m);
+
+typedef struct fd_match_rec {   /* one connected component of one candidate (retrieval_wrapper, retrieve.rs:364-552) */
+    uint32_t cand;              /* slot in the candidate list */
+    uint32_t same;              /* processed mapping == from-hash mapping */
+    float idf;                  /* subgraph idf */
+    float rmsd;                 /* of the processed mapping (what the per-match output prints) */
+    float rmsd_from_hash;
+    float rot[9], tran[3];      /* target -> query superposition of the processed mapping */
+} fd_match_rec;
+/* residues: 2 * n_indices int32 per match — target residue index (relative to its structure, -1 = "_") for
+ * every query residue, first the from-hash mapping then the processed (rescued) one. Release both with
+ * fdgpu_matches_free. Matches are ordered by candidate slot, then by component as in graph.rs:43-45. */
+int fdgpu_retrieve(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
+                   const fd_query_map *qm, const fdgpu_batch *qb, const fd_hash_params *p, float ca_distance_cutoff,
+                   uint32_t node_count, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues);
+void fdgpu_matches_free(fd_match_rec *m, int32_t *residues);
+
 /* ---- profiling hooks ------------------------------------------------------------------------------
  * Per-kernel timing of the last fdgpu_index_build / fdgpu_count_query call, measured with
  * HIP events on the context's stream. names[i] is a static string. Returns the number of

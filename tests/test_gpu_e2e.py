@@ -1,0 +1,107 @@
+"""End-to-end on the GPU through the product path only (host ingest -> C ABI -> kernels), checked against the
+reference's README rows (G2) and against the oracle for the intermediate products."""
+import numpy as np
+import pytest
+
+import oracle
+from tests.helpers import Q1G2F, Q4CHA, SER
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import folddisco_amd as fd
+    from folddisco_amd import structure as st
+    ctx = fd.Context(0)
+    structs = [st.read_compact_structure(p) for p in SER]
+    ps = fd.PackedStructures.concat([s.as_item() for s in structs])
+    batch = ctx.upload(ps)
+    ix = fd.FolddiscoIndex.build(ctx, batch)
+    nres = np.array([s.n for s in structs], np.uint64)
+    plddt = np.array([s.avg_plddt() for s in structs], np.float32)
+    tids = ["data/serine_peptidases/" + p.split("/")[-1] for p in SER]
+    yield ctx, structs, batch, ix, nres, plddt, tids
+    ctx.close()
+
+
+def test_readme_rows_through_product_path(env):
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    ctx, structs, batch, ix, nres, plddt, tids = env
+    q = st.read_compact_structure(Q4CHA)
+    rows, matches = fq.query_pdb(ctx, ix, batch, structs, tids, nres, plddt, q, "B57,B102,C195")
+    got = [fq.format_match_row(m) for m in matches]
+    # README.md:218-223, in the reference's default order (idf desc, rmsd asc)
+    assert got == [
+        "data/serine_peptidases/4cha.pdb\t3\t8.7616\t0.0000\tB57,B102,C195\tB57,B102,C195",
+        "data/serine_peptidases/4cha.pdb\t3\t8.7616\t0.0874\tF57,F102,G195\tB57,B102,C195",
+        "data/serine_peptidases/1pq5.pdb\t3\t4.1178\t0.2609\tA56,A99,A195\tB57,B102,C195",
+        "data/serine_peptidases/1ju3.pdb\t2\t1.4739\t0.7792\t_,A223,A234\tB57,B102,C195",
+        "data/serine_peptidases/1l7a.pdb\t2\t1.4739\t0.7883\t_,A146,A127\tB57,B102,C195",
+        "data/serine_peptidases/1l7a.pdb\t2\t1.4739\t0.8078\t_,B146,B127\tB57,B102,C195",
+    ]
+    # README.md:237-241 per-structure columns
+    st_rows = {r["tid"].split("/")[-1]: ("%.4f" % r["idf"], r["total_match_count"], r["node_count"], r["edge_count"],
+                                         r["max_matching_node_count"], "%.4f" % r["min_rmsd_with_max_match"], r["nres"], "%.4f" % r["plddt"], r["db_key"])
+               for r in rows}
+    assert st_rows["4cha.pdb"] == ("0.6138", 8, 3, 6, 3, "0.0000", 477, "13.5404", 4)
+    assert st_rows["1pq5.pdb"] == ("0.4869", 4, 3, 4, 3, "0.2609", 224, "5.1340", 3)
+    assert st_rows["1ju3.pdb"] == ("0.0617", 2, 2, 2, 2, "0.7792", 570, "19.4881", 1)
+    assert st_rows["1l7a.pdb"] == ("0.0584", 2, 2, 2, 2, "0.7883", 636, "11.7037", 2)
+    assert st_rows["1azw.pdb"][:4] == ("0.1856", 2, 2, 2)
+    # stale README row reappears with --ca-distance 1.5
+    _, m15 = fq.query_pdb(ctx, ix, batch, structs, tids, nres, plddt, q, "B57,B102,C195", ca_distance=1.5)
+    assert "data/serine_peptidases/1azw.pdb\t2\t4.6439\t0.9234\tA179,_,B176\tB57,B102,C195" in [fq.format_match_row(m) for m in m15]
+
+
+@pytest.mark.parametrize("qpath,qstr", [(Q4CHA, "B57,B102,C195"), (Q1G2F, "F207,F212,F225,F229"), (Q1G2F, "F207:C,F212,F225:HX,F229"),
+                                        (Q4CHA, "B57-60,C195:ST")])
+def test_make_query_map_matches_oracle(env, qpath, qstr):
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    ctx, structs, batch, ix, nres, plddt, tids = env
+    ostructs = [oracle.read_pdb(p) for p in SER]
+    oix, _, _ = oracle.build_index(ostructs)
+    oq = oracle.read_pdb(qpath)
+    om = oracle.make_query_map(oq, qstr, oix, 5.0).arrays()
+    q = st.read_compact_structure(qpath)
+    res = fq.parse_query_string(qstr, q.chains[0])
+    idx = [q.get_index(c, r) for c, r, _ in res]
+    subs = [s for _, _, s in res]
+    qb = ctx.upload(fd.PackedStructures.concat([q.as_item()]))
+    m = fq.make_query_map(ctx, qb, idx, subs, ix, 5.0)
+    assert np.array_equal(m.hash, om["hash"]) and np.array_equal(m.qi, om["qi"]) and np.array_equal(m.qj, om["qj"])
+    assert np.array_equal(m.is_primary, om["is_primary"])
+    assert np.array_equal(m.idf.view(np.uint32), om["idf"].view(np.uint32))   # glibc log2f on both sides
+    assert np.array_equal(m.aad_aa1, om["aad_aa1"]) and np.array_equal(m.aad_aa2, om["aad_aa2"])
+    assert np.array_equal(m.aad_dist.view(np.uint32), om["aad_dist"].view(np.uint32)) and np.array_equal(m.aad_qi, om["aad_qi"])
+
+
+def test_retrieve_matches_oracle(env):
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    ctx, structs, batch, ix, nres, plddt, tids = env
+    ostructs = [oracle.read_pdb(p) for p in SER]
+    oix, _, _ = oracle.build_index(ostructs)
+    for qpath, qstr in ((Q4CHA, "B57,B102,C195"), (Q4CHA, "B57,B102,C195,B189,B190")):
+        oq = oracle.read_pdb(qpath)
+        om = oracle.make_query_map(oq, qstr, oix, 5.0)
+        q = st.read_compact_structure(qpath)
+        res = fq.parse_query_string(qstr, q.chains[0])
+        qb = ctx.upload(fd.PackedStructures.concat([q.as_item()]))
+        m = fq.make_query_map(ctx, qb, [q.get_index(c, r) for c, r, _ in res], [s for _, _, s in res], ix, 5.0)
+        std = np.concatenate([s.resname_std() for s in structs])
+        for ca_cut in (1.0, 1.5, 3.0):
+            got = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=ca_cut)
+            for nid in range(5):
+                R = oracle.retrieve(ostructs[nid], oq, om, ca_distance_cutoff=ca_cut)
+                mine = [g for g in got if g["cand"] == nid]
+                assert len(mine) == len(R["processed"]), (qstr, ca_cut, nid)
+                for g, rp, rh in zip(mine, R["processed"], R["from_hash"]):
+                    assert g["processed"] == [-1 if x is None else x[2] for x in rp["residues"]]
+                    assert g["from_hash"] == [-1 if x is None else x[2] for x in rh["residues"]]
+                    assert abs(g["rmsd"] - rp["rmsd"]) <= 1e-4 and abs(g["rmsd_from_hash"] - rh["rmsd"]) <= 1e-4
+                    assert g["idf"] == pytest.approx(rp["idf"], rel=1e-6)
