@@ -86,13 +86,15 @@ def test_retrieve_matches_oracle(env):
     ctx, structs, batch, ix, nres, plddt, tids = env
     ostructs = [oracle.read_pdb(p) for p in SER]
     oix, _, _ = oracle.build_index(ostructs)
-    for qpath, qstr in ((Q4CHA, "B57,B102,C195"), (Q4CHA, "B57,B102,C195,B189,B190")):
+    for qpath, qstr in ((Q4CHA, "B57,B102,C195"), (Q4CHA, "B57,B102,C195,B58,B59,C999")):
         oq = oracle.read_pdb(qpath)
         om = oracle.make_query_map(oq, qstr, oix, 5.0)
         q = st.read_compact_structure(qpath)
         res = fq.parse_query_string(qstr, q.chains[0])
         qb = ctx.upload(fd.PackedStructures.concat([q.as_item()]))
-        m = fq.make_query_map(ctx, qb, [q.get_index(c, r) for c, r, _ in res], [s for _, _, s in res], ix, 5.0)
+        pairs = [(q.get_index(c, r), s) for c, r, s in res]
+        pairs = [(i, s) for i, s in pairs if i is not None]   # unresolved residues are dropped (query.rs:238-246)
+        m = fq.make_query_map(ctx, qb, [i for i, _ in pairs], [s for _, s in pairs], ix, 5.0)
         std = np.concatenate([s.resname_std() for s in structs])
         for ca_cut in (1.0, 1.5, 3.0):
             got = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=ca_cut)
