@@ -1,0 +1,60 @@
+"""Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI on ROCm).
+
+Index build shards by structure: rank r owns the contiguous id range [r*S/N, (r+1)*S/N) and builds a complete
+sub-index for it with no communication (ids ascend inside every posting list because the range is contiguous).
+A query is scored by every rank against its own shard — all per-structure counters are complete locally — and
+the only exchange is an all-gather of the candidate records (20 B each), after which every rank holds the global
+ranking.  The same code runs over gloo on CPUs (tests/test_dist_gloo.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REC_DTYPE = np.dtype([("nid", np.uint32), ("total_match_count", np.uint32), ("node_count", np.uint32),
+                      ("edge_count", np.uint32), ("idf", np.float32)])
+
+
+def shard_range(rank: int, world: int, n_structures: int):
+    """contiguous, balanced id ranges; the union over ranks is [0, n_structures)"""
+    base, rem = divmod(n_structures, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def rank_hits(recs: np.ndarray, top_n: int | None = None) -> np.ndarray:
+    """idf descending, ties by ascending nid (= the reference's stable sort over nid-ordered input,
+    src/cli/workflows/query_pdb.rs:404-411)"""
+    order = np.lexsort((recs["nid"], -recs["idf"].astype(np.float64)))
+    out = recs[order]
+    return out if top_n is None else out[:top_n]
+
+
+def records_from_rows(rows) -> np.ndarray:
+    a = np.zeros(len(rows), dtype=REC_DTYPE)
+    for k, r in enumerate(rows):
+        a[k] = (r["nid"], r["total_match_count"], r["node_count"], r["edge_count"], r["idf"])
+    return a
+
+
+def allgather_hits(local: np.ndarray, device: torch.device, top_n: int | None = None) -> np.ndarray:
+    """all-gather of per-rank candidate records (variable length): sizes first, then one padded all_gather of the
+    raw 20-byte records.  Returns the global ranking (identical on every rank)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rank_hits(local, top_n)
+    world = dist.get_world_size()
+    if top_n is not None:
+        local = rank_hits(local, top_n)  # a rank never contributes more than top_n rows
+    n = torch.tensor([len(local)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(max(sizes), 1)
+    buf = np.zeros(mx, dtype=REC_DTYPE)
+    buf[: len(local)] = local
+    t = torch.from_numpy(buf.view(np.uint8).copy()).to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    parts = [o.cpu().numpy().view(REC_DTYPE)[:s] for o, s in zip(out, sizes)]
+    return rank_hits(np.concatenate(parts), top_n)

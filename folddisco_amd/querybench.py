@@ -1,0 +1,100 @@
+"""Motif-query leg of bench.py: Q planted motif queries scored against the resident shard(s).
+
+A query = 4 residues of a shard structure that lie within 10 A of each other (so it has hits by construction),
+default expansion (-d 0.5 -a 5).  Per query every rank runs make_query_map (features / hashes / posting lengths on
+the GPU), count_query on its shard, keeps its top-N candidates and the ranks all-gather the candidate records
+(RCCL).  queries/s = Q / wall time of the loop (max over ranks).  With match=True the top candidates of the local
+shard additionally go through the pair scan + graph + Kabsch (retrieval)."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from . import dist as fdist
+from .api import PackedStructures, count_query, length_penalty
+from .query import make_query_map, retrieve
+
+
+def _pick_queries(d, S, n_queries, seed, k=4):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    off = d["res_off"].cpu().numpy()
+    out = []
+    tries = 0
+    while len(out) < n_queries and tries < 50 * n_queries:
+        tries += 1
+        s = int(rng.integers(0, S))
+        a, b = int(off[s]), int(off[s + 1])
+        if b - a < 30:
+            continue
+        ca = d["ca_xyz"][a:b].cpu().numpy()
+        c = int(rng.integers(0, b - a))
+        near = np.nonzero(np.linalg.norm(ca - ca[c], axis=1) < 10.0)[0]
+        if len(near) < k:
+            continue
+        idx = np.sort(rng.choice(near, size=k, replace=False))
+        item = dict(n_xyz=d["n_xyz"][a:b].cpu().numpy(), ca_xyz=ca, cb_xyz=d["cb_xyz"][a:b].cpu().numpy(), aa=d["aa"][a:b].cpu().numpy())
+        out.append((s, idx.astype(np.uint32), item))
+    return out
+
+
+def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, match_top=32, seed=4242):
+    queries = _pick_queries(d, S, n_queries, seed)        # the same list on every rank (same seed; rank 0's shard layout)
+    nres = np.diff(d["res_off"].cpu().numpy()).astype(np.uint64)
+    pen = length_penalty(nres, 0.5)
+    S_total = S * world
+    qbatches = [ctx.upload(PackedStructures.concat([it])) for _, _, it in queries]
+
+    def one(k, match):
+        s, idx, _ = queries[k]
+        qm = make_query_map(ctx, qbatches[k], idx, None, ix, float(S_total))
+        rows = count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total)
+        recs = fdist.records_from_rows(rows)
+        glob = fdist.allgather_hits(recs, dev, top_n=top_n)
+        n_match = 0
+        if match and len(recs):
+            local_top = fdist.rank_hits(recs, match_top)
+            cand = (local_top["nid"] - ix.first_id).astype(np.uint32)
+            ms = retrieve(ctx, batch, None, cand, qm, qbatches[k])
+            n_match = len(ms)
+        return len(glob), len(qm.hash), n_match
+
+    def timed(match):
+        one(0, match)  # warm
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        tot_hits = tot_hashes = tot_m = 0
+        for k in range(len(queries)):
+            h, q, m = one(k, match)
+            tot_hits += h; tot_hashes += q; tot_m += m
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, tot_hits, tot_hashes, tot_m
+
+    dt1, hits, hashes, _ = timed(False)
+    dt2, _, _, nm = timed(True)
+    # roofline of the scoring kernel for the last query (HIP events on the context's stream)
+    ctx.enable_timing(True)
+    s, idx, _ = queries[-1]
+    qm = make_query_map(ctx, qbatches[-1], idx, None, ix, float(S_total))
+    lens = ix.posting_lengths(qm.hash)
+    rows = count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total)
+    ctx.synchronize()
+    st = {n: ms for n, ms, _ in ctx.last_timings()}
+    ctx.enable_timing(False)
+    return {
+        "metric": "motif queries/sec", "value": len(queries) / dt1, "unit": "queries/s", "n_queries": len(queries),
+        "mode": "prefilter (count_query) + all-gather of candidate hits", "ms_per_query": dt1 / len(queries) * 1e3,
+        "with_matching": {"value": len(queries) / dt2, "ms_per_query": dt2 / len(queries) * 1e3, "matches": nm, "match_top": match_top},
+        "avg_query_hashes": hashes / len(queries), "avg_hits": hits / len(queries),
+        "last_query": {"hashes": int(len(qm.hash)), "postings_decoded": int(lens.sum()), "touched": len(rows), "stages_ms": st},
+    }
