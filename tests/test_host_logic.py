@@ -1,0 +1,148 @@
+"""CPU-only tests (no GPU): the C ABI library loads and exports every declared symbol, host-side logic
+(ingest, query grammar, ranking/sharding) agrees with the oracle, and the device arithmetic headers — compiled for
+the host — are bit-identical to glibc / the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.helpers import Q1G2F, Q4CHA, SER
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from folddisco_amd import _lib
+    from folddisco_amd import build as fb
+    fb.build()
+    L = _lib.load()
+    header = open(os.path.join(ROOT, "include", "fdgpu.h")).read()
+    declared = set(re.findall(r"\b(fdgpu_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/fdgpu.h but not exported"
+    bound = {n for n, _, _ in _lib.SYMBOLS}
+    assert declared <= bound, f"unbound: {declared - bound}"
+    assert b"gfx950" in L.fdgpu_version()
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import folddisco_amd as fd
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(fd.FdgpuError):
+        fd.Context(0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "folddisco_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in src and "from oracle" not in src and "fd_oracle.h" not in src and "libfdoracle" not in src, f
+
+
+def test_ingest_matches_oracle_parser():
+    from folddisco_amd import structure as st
+    for p in SER + [Q1G2F]:
+        a = st.read_compact_structure(p)
+        o = oracle.read_pdb(p).arrays()
+        for k in ("n_xyz", "ca_xyz", "cb_xyz", "cb_ok", "aa", "chain", "serial", "bfac"):
+            assert np.array_equal(getattr(a, k), o[k]), (p, k)
+        assert np.float32(a.avg_plddt()).view(np.uint32) == np.float32(oracle.read_pdb(p).avg_plddt()).view(np.uint32)
+    s = st.read_compact_structure(SER[4])
+    assert s.n == 477 and "%.4f" % s.avg_plddt() == "13.5404"   # README.md:237
+
+
+def test_query_grammar_matches_oracle():
+    from folddisco_amd import query as fq
+    for q, dc in [("A250,A232,A269", ord("A")), ("250,232,269", ord("C")), ("A1-3,B5", ord("C")), ("164:H,195,247:ND,297:Xp", ord("A")),
+                  ("B57 , B102:a,C195", ord("Q")), ("11:X", ord("1")), ("", ord("A"))]:
+        _, ref = oracle.parse_query_string(q, dc)
+        got = fq.parse_query_string(q, dc)
+        assert [(c, r) for c, r, _ in got] == [(c, r) for c, r, _ in ref]
+        assert [s for _, _, s in got] == [s for _, _, s in ref]
+    with pytest.raises(ValueError):
+        fq.parse_query_string("A12,,B3")
+    with pytest.raises(ValueError):
+        oracle.parse_query_string("A12,,B3")
+
+
+def test_shard_ranges_and_ranking():
+    from folddisco_amd import dist as fdist
+    for S, N in [(542000, 8), (7, 3), (5, 8), (0, 2)]:
+        rs = [fdist.shard_range(r, N, S) for r in range(N)]
+        assert rs[0][0] == 0 and rs[-1][1] == S and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+        assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
+    recs = np.zeros(5, fdist.REC_DTYPE)
+    recs["nid"] = [4, 3, 1, 2, 0]
+    recs["idf"] = [0.5, 0.9, 0.5, 0.1, 0.5]
+    assert list(fdist.rank_hits(recs)["nid"]) == [3, 0, 1, 4, 2]       # idf desc, ties by nid asc
+    assert list(fdist.rank_hits(recs, 2)["nid"]) == [3, 0]
+
+
+def _gcc(src, out, extra=()):
+    subprocess.check_call(["gcc" if src.endswith(".c") else "g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", src, "-o", out, *extra, "-lm"],
+                          cwd=ROOT)
+
+
+def test_device_libm_header_equals_glibc_sampled(tmp_path):
+    """folddisco_amd/csrc/fd_libm.h compiled for the host == glibc, on a 1/4096 stride of all float bit patterns and 2M atan2f
+    pairs (the exhaustive run — stride 1, 4e9 pairs, 0 mismatches on glibc 2.35 — is `tools/check_libm 1 4000000000`)."""
+    exe = str(tmp_path / "check_libm")
+    _gcc("tools/check_libm.c", exe)
+    out = subprocess.run([exe, "4096", "2000000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "sinf 0 cosf 0 acosf 0 atanf 0 atan2f 0" in out.stdout
+
+
+def test_device_geometry_header_equals_oracle(tmp_path):
+    """fd_geom.h (direct, shared-subexpression and table forms) compiled for the host == oracle on every residue pair of the
+    five serine_peptidases structures and on degenerate random clouds."""
+    oracle.build()
+    exe = str(tmp_path / "check_geom")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "tools/check_geom.cpp", "-Loracle", "-lfdoracle",
+                           f"-Wl,-rpath,{ROOT}/oracle", "-o", exe], cwd=ROOT)
+    out = subprocess.run([exe] + SER, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "total mismatches: 0" in out.stdout
+
+
+def test_bin_tables_are_consistent_with_glibc():
+    """spot-check folddisco_amd/csrc/fd_bin_tables.h (generated exhaustively by tools/gen_bin_tables.c) against glibc at and
+    around every breakpoint."""
+    hdr = open(os.path.join(ROOT, "folddisco_amd", "csrc", "fd_bin_tables.h")).read()
+    thr = [int(x, 16) for x in re.search(r"fd_theta_thr_bits\[FD_THETA_NSEG\] = \{([^}]*)\}", hdr).group(1).replace("u", "").split(",")]
+    keys = [int(x) for x in re.search(r"fd_theta_key\[FD_THETA_NSEG\] = \{([^}]*)\}", hdr).group(1).split(",")]
+    libm = C.CDLL("libm.so.6")
+    for f in ("acosf", "sinf", "cosf"):
+        getattr(libm, f).restype = C.c_float
+        getattr(libm, f).argtypes = [C.c_float]
+
+    def q4(v):
+        t = np.float32(np.float32(np.float32(v) + np.float32(1.0)) * np.float32(1.5)) + np.float32(0.5)
+        return 0 if not (t == t) or t <= 0 else int(t)
+
+    def key_ref(c):
+        a = libm.acosf(float(c))
+        return (q4(np.float32(libm.sinf(a))) << 2) | q4(np.float32(libm.cosf(a)))
+
+    def key_tab(c):
+        n = sum(1 for t in thr[1:] if c >= np.uint32(t).view(np.float32))
+        return keys[n] if -1.0 <= c <= 1.0 else 0
+
+    for t in thr:
+        for d in (-2, -1, 0, 1, 2):
+            b = np.uint32(t + d if not (t & 0x80000000) else t - d)
+            c = b.view(np.float32)
+            if -1.0 <= c <= 1.0:
+                assert key_tab(c) == key_ref(c), hex(int(b))
+    rng = np.random.Generator(np.random.PCG64(1))
+    for c in rng.uniform(-1, 1, 20000).astype(np.float32):
+        assert key_tab(c) == key_ref(c)
