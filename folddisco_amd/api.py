@@ -248,9 +248,14 @@ def idf_of_lengths(lengths: np.ndarray, total_structures: int) -> np.ndarray:
     return out
 
 
+REC_DTYPE = np.dtype([("nid", np.uint32), ("total_match_count", np.uint32), ("node_count", np.uint32),
+                      ("edge_count", np.uint32), ("idf", np.float32)])
+
+
 def count_query(ctx: Context, index: FolddiscoIndex, q_hash, q_node, q_edge_j, penalty: np.ndarray, total_structures: int | None = None,
-                freq_filter: float | None = None):
-    """count_query (src/controller/count_query.rs:82-220) -> list of fd_count_rec dicts, ascending nid."""
+                freq_filter: float | None = None, as_array: bool = False):
+    """count_query (src/controller/count_query.rs:82-220) -> fd_count_rec rows in ascending nid
+    (list of dicts, or a numpy structured array with as_array=True)."""
     q_hash = np.ascontiguousarray(q_hash, dtype=np.uint32)
     q_node = np.ascontiguousarray(q_node, dtype=np.uint32)
     q_edge_j = np.ascontiguousarray(q_edge_j, dtype=np.uint32)
@@ -267,7 +272,9 @@ def count_query(ctx: Context, index: FolddiscoIndex, q_hash, q_node, q_edge_j, p
     n = C.c_uint64()
     ctx.check(ctx.L.fdgpu_count_query(ctx.h, index.h, _ptr(qh, u32p), _ptr(qn, u32p), _ptr(qe, u32p), _ptr(qi, f32p), len(qh),
                                       _ptr(pen, f32p), C.byref(out), C.byref(n)))
-    res = [dict(nid=out[k].nid, total_match_count=out[k].total_match_count, node_count=out[k].node_count,
-                edge_count=out[k].edge_count, idf=float(out[k].idf)) for k in range(n.value)]
+    arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n.value, 1) * 20,))[: n.value * 20].copy().view(REC_DTYPE)
     ctx.L.fdgpu_free(out)
-    return res
+    if as_array:
+        return arr
+    return [dict(nid=int(r["nid"]), total_match_count=int(r["total_match_count"]), node_count=int(r["node_count"]),
+                 edge_count=int(r["edge_count"]), idf=float(r["idf"])) for r in arr]

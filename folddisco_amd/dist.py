@@ -12,8 +12,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-REC_DTYPE = np.dtype([("nid", np.uint32), ("total_match_count", np.uint32), ("node_count", np.uint32),
-                      ("edge_count", np.uint32), ("idf", np.float32)])
+from .api import REC_DTYPE  # fd_count_rec layout (20 bytes)
 
 
 def shard_range(rank: int, world: int, n_structures: int):

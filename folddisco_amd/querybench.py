@@ -49,8 +49,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     def one(k, match):
         s, idx, _ = queries[k]
         qm = make_query_map(ctx, qbatches[k], idx, None, ix, float(S_total))
-        rows = count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total)
-        recs = fdist.records_from_rows(rows)
+        recs = count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total, as_array=True)
         glob = fdist.allgather_hits(recs, dev, top_n=top_n)
         n_match = 0
         if match and len(recs):
