@@ -378,16 +378,22 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
     if (rc) return rc;
     if (P >= 0xffffffffull) FAIL(c, FDGPU_ERANGE, "more than 2^32 residue pairs in one build call; split the shard");
     if ((rc = ensure_sort_ws(c, P))) return rc;
-    uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *ia = c->ws[WS_IDS_A].as<uint32_t>();
-    uint32_t *kb = c->ws[WS_KEYS_B].as<uint32_t>(), *ib = c->ws[WS_IDS_B].as<uint32_t>();
+    uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *kb = c->ws[WS_KEYS_B].as<uint32_t>();
+    void *ia = c->ws[WS_IDS_A].p, *ib = c->ws[WS_IDS_B].p;
+    // shards of <= 2^18 structures use 6-byte sort elements (key = hash << 2 | local id bits 17:16, u16 payload);
+    // FDGPU_IDS32=1 forces the 8-byte form
+    static const bool force32 = [] { const char *e = getenv("FDGPU_IDS32"); return e && e[0] == '1'; }();
+    const bool ids16 = !force32 && S <= (1ull << 18);
     {
-        StageTimer t(c, "pair_emit", b->n_res * 37 + P * 8);
-        fd_launch_pair_emit2(b->view(), c->ws[WS_FRAMES].p, C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, ia,
+        StageTimer t(c, "pair_emit", b->n_res * 37 + P * (ids16 ? 6 : 8));
+        fd_launch_pair_emit2(b->view(), c->ws[WS_FRAMES].p, C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, ia, ids16,
                              (uint32_t)first_id, st);
     }
     int cur;
-    cur = sort_pairs(c, ka, ia, kb, ib, P, 30);
-    const uint32_t *ks = cur ? kb : ka, *is = cur ? ib : ia;
+    if (ids16) cur = fd_radix_sort_pairs16(ka, (uint16_t *)ia, kb, (uint16_t *)ib, P, 32, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st, c);
+    else cur = sort_pairs(c, ka, (uint32_t *)ia, kb, (uint32_t *)ib, P, 30);
+    const uint32_t *ks = cur ? kb : ka;
+    const void *is = cur ? ib : ia;
     uint32_t nt = std::max<uint32_t>(fd_enc_num_tiles(P), 1);
     HIPCHK(c, c->ws[WS_TILE_B].ensure((size_t)(nt + 1) * 4));
     HIPCHK(c, c->ws[WS_TILE_H].ensure((size_t)(nt + 1) * 4));
@@ -400,11 +406,11 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
     uint64_t tot[3] = {0, 0, 0};
     uint64_t nt_eff = P ? fd_enc_num_tiles(P) : 0;
     {
-        StageTimer t(c, "encode_sizes", P * 8);
+        StageTimer t(c, "encode_sizes", P * (ids16 ? 6 : 8));
         HIPCHK(c, hipMemsetAsync(c->ws[WS_TILE_B].p, 0, (size_t)(nt + 1) * 4, st));
         HIPCHK(c, hipMemsetAsync(c->ws[WS_TILE_H].p, 0, (size_t)(nt + 1) * 4, st));
         HIPCHK(c, hipMemsetAsync(c->ws[WS_TILE_P].p, 0, (size_t)(nt + 1) * 4, st));
-        fd_launch_enc_sizes(ks, is, P, c->ws[WS_TILE_B].as<uint32_t>(), c->ws[WS_TILE_H].as<uint32_t>(), c->ws[WS_TILE_P].as<uint32_t>(), st);
+        fd_launch_enc_sizes(ks, is, ids16, (uint32_t)first_id, P, c->ws[WS_TILE_B].as<uint32_t>(), c->ws[WS_TILE_H].as<uint32_t>(), c->ws[WS_TILE_P].as<uint32_t>(), st);
         uint64_t *totd = c->ws[WS_MISC3].as<uint64_t>();
         fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_B].as<uint32_t>(), nt_eff, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 0, st);
         fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_H].as<uint32_t>(), nt_eff, c->ws[WS_TILE_HO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 1, st);
@@ -426,8 +432,8 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
         return FDGPU_EHIP;
     }
     {
-        StageTimer t(c, "encode_write", P * 8 + ix->value_len + ix->n_hashes * 12);
-        fd_launch_enc_write(ks, is, P, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_TILE_HO].as<uint64_t>(), ix->value, ix->hashes, ix->offsets,
+        StageTimer t(c, "encode_write", P * (ids16 ? 6 : 8) + ix->value_len + ix->n_hashes * 12);
+        fd_launch_enc_write(ks, is, ids16, (uint32_t)first_id, P, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_TILE_HO].as<uint64_t>(), ix->value, ix->hashes, ix->offsets,
                             c->ws[WS_MISC3].as<uint64_t>(), ix->n_hashes, st);
     }
     e = hipGetLastError();

@@ -130,7 +130,9 @@ void fd_launch_pair_emit(const fd_batch_view &B, const fd_hash_consts &C, const 
 void fd_launch_frames(const fd_batch_view &B, uint64_t n_res, void *frames, hipStream_t st);
 void fd_launch_pair_count2(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *counts, hipStream_t st);
 void fd_launch_pair_emit2(const fd_batch_view &B, const void *frames, const fd_hash_consts &C, const uint64_t *seg_off, uint32_t *cursor,
-                          uint32_t *keys, uint32_t *ids, uint32_t first_id, hipStream_t st);
+                          uint32_t *keys, void *ids, bool ids16, uint32_t first_id, hipStream_t st);
+int fd_radix_sort_pairs16(uint32_t *keys_a, uint16_t *vals_a, uint32_t *keys_b, uint16_t *vals_b, uint64_t n, int key_bits, uint32_t *ghist,
+                          uint64_t *tot, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr);
 void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, hipStream_t st);
 void fd_launch_row_emit(const fd_batch_view &B, const fd_hash_consts &C, const uint64_t *row_off, uint32_t *keys, hipStream_t st);
 template <typename TIn>
@@ -144,9 +146,10 @@ uint32_t fd_os_num_tiles(uint64_t n);
 int fd_onesweep_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits,
                            unsigned long long *desc, unsigned long long *ghist, uint32_t *ticket, hipStream_t st, fdgpu_ctx *tc = nullptr);
 uint32_t fd_enc_num_tiles(uint64_t n);
-void fd_launch_enc_sizes(const uint32_t *keys, const uint32_t *ids, uint64_t n, uint32_t *tb, uint32_t *th, uint32_t *tp, hipStream_t st);
-void fd_launch_enc_write(const uint32_t *keys, const uint32_t *ids, uint64_t n, const uint64_t *tbo, const uint64_t *tho, uint8_t *value,
-                         uint32_t *hashes, uint64_t *offsets, const uint64_t *total_bytes_dev, uint64_t H, hipStream_t st);
+void fd_launch_enc_sizes(const uint32_t *keys, const void *ids, bool ids16, uint32_t first_id, uint64_t n, uint32_t *tb, uint32_t *th, uint32_t *tp,
+                         hipStream_t st);
+void fd_launch_enc_write(const uint32_t *keys, const void *ids, bool ids16, uint32_t first_id, uint64_t n, const uint64_t *tbo, const uint64_t *tho,
+                         uint8_t *value, uint32_t *hashes, uint64_t *offsets, const uint64_t *total_bytes_dev, uint64_t H, hipStream_t st);
 void fd_launch_uniq_flags(const uint32_t *keys, const uint32_t *ids, uint64_t n, uint8_t *flags, hipStream_t st);
 void fd_launch_compact(const uint32_t *keys, const uint8_t *flags, const uint64_t *pos, uint64_t n, uint32_t *out, hipStream_t st);
 void fd_launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t n, uint64_t *dst, hipStream_t st);

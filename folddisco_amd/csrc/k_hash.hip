@@ -143,10 +143,11 @@ __device__ __forceinline__ fd_frame load_frame(const fd_frame *__restrict__ fram
     return F;
 }
 
-template <bool TAB>
+// IDS16: 6-byte elements — key = hash << 2 | (s >> 16), 16-bit payload = s & 0xffff (s = structure index inside the shard)
+template <bool TAB, bool IDS16>
 __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *__restrict__ frames, const fd_hash_consts &C,
                                        const uint32_t *tab, const uint32_t *q, uint32_t n, uint32_t i0, uint32_t r0, uint32_t s, uint32_t id,
-                                       const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys, uint32_t *ids) {
+                                       const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys, void *ids) {
     const uint32_t lane = threadIdx.x;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&cursor[s], 2u * n);
@@ -159,17 +160,26 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
         if (TAB) fd_pair_both_tab(Fi, Fj, B.aa[i], B.aa[j], C.q, tab, &h_ij, &h_ji);
         else fd_pair_both(Fi, Fj, B.aa[i], B.aa[j], C.q, &h_ij, &h_ji);
         uint64_t pos = seg_off[s] + base + lane;
-        keys[pos] = h_ij;
-        keys[pos + n] = h_ji;
-        ids[pos] = id;
-        ids[pos + n] = id;
+        if (IDS16) {
+            uint32_t hi = s >> 16;
+            uint16_t lo = (uint16_t)(s & 0xffffu);
+            keys[pos] = (h_ij << 2) | hi;
+            keys[pos + n] = (h_ji << 2) | hi;
+            ((uint16_t *)ids)[pos] = lo;
+            ((uint16_t *)ids)[pos + n] = lo;
+        } else {
+            keys[pos] = h_ij;
+            keys[pos + n] = h_ji;
+            ((uint32_t *)ids)[pos] = id;
+            ((uint32_t *)ids)[pos + n] = id;
+        }
     }
 }
 
-template <bool TAB>
+template <bool TAB, bool IDS16>
 __global__ __launch_bounds__(FD_WAVE) void k_pair_emit2(fd_batch_view B, const fd_frame *__restrict__ frames, fd_hash_consts C,
                                                         const uint64_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
-                                                        uint32_t *__restrict__ keys, uint32_t *__restrict__ ids, uint32_t first_id) {
+                                                        uint32_t *__restrict__ keys, void *__restrict__ ids, uint32_t first_id) {
     __shared__ uint32_t q[2 * FD_WAVE];
     __shared__ uint32_t tab[32];
     uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
@@ -198,13 +208,13 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_emit2(fd_batch_view B, const f
         if (qn >= FD_WAVE) {
             __syncthreads();
             qn -= FD_WAVE;
-            drain2<TAB>(B, frames, C, tab, q + qn, FD_WAVE, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
+            drain2<TAB, IDS16>(B, frames, C, tab, q + qn, FD_WAVE, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
             __syncthreads();
         }
     }
     if (qn) {
         __syncthreads();
-        drain2<TAB>(B, frames, C, tab, q, qn, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
+        drain2<TAB, IDS16>(B, frames, C, tab, q, qn, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
     }
 }
 
@@ -285,12 +295,14 @@ void fd_launch_pair_count2(const fd_batch_view &B, const fd_hash_consts &C, uint
     hipLaunchKernelGGL(k_pair_count2, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, counts);
 }
 void fd_launch_pair_emit2(const fd_batch_view &B, const void *frames, const fd_hash_consts &C, const uint64_t *seg_off, uint32_t *cursor,
-                          uint32_t *keys, uint32_t *ids, uint32_t first_id, hipStream_t st) {
+                          uint32_t *keys, void *ids, bool ids16, uint32_t first_id, hipStream_t st) {
     if (!B.n_work) return;
-    if (C.use_tab)
-        hipLaunchKernelGGL(k_pair_emit2<true>, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, (const fd_frame *)frames, C, seg_off, cursor, keys, ids, first_id);
-    else
-        hipLaunchKernelGGL(k_pair_emit2<false>, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, (const fd_frame *)frames, C, seg_off, cursor, keys, ids, first_id);
+    dim3 g(grid_for(B.n_work)), b(FD_WAVE);
+    const fd_frame *F = (const fd_frame *)frames;
+    if (C.use_tab && ids16) hipLaunchKernelGGL((k_pair_emit2<true, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else if (C.use_tab) hipLaunchKernelGGL((k_pair_emit2<true, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else if (ids16) hipLaunchKernelGGL((k_pair_emit2<false, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else hipLaunchKernelGGL((k_pair_emit2<false, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
 }
 void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, hipStream_t st) {
     if (!B.n_work) return;

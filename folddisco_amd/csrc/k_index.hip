@@ -20,13 +20,28 @@ __device__ __forceinline__ uint32_t varint_len(uint32_t v) {
     return v == 0 ? 1u : 1u + (31u - (uint32_t)__clz(v)) / 7u;
 }
 
-struct enc_item { uint32_t len; uint32_t head; uint32_t delta; };
+struct enc_item { uint32_t len; uint32_t head; uint32_t delta; uint32_t hash; };
 
-__device__ __forceinline__ enc_item enc_classify(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ids, uint64_t p) {
+// two element encodings of the sorted stream:
+//   V = uint32_t : keys[p] = hash,                     vals[p] = structure id
+//   V = uint16_t : keys[p] = hash << 2 | (local >> 16), vals[p] = local & 0xffff, id = first_id + local  (6-byte elements)
+template <typename V> struct enc_codec;
+template <> struct enc_codec<uint32_t> {
+    static __device__ __forceinline__ uint32_t hash(uint32_t k) { return k; }
+    static __device__ __forceinline__ uint32_t id(uint32_t, uint32_t v, uint32_t) { return v; }
+};
+template <> struct enc_codec<uint16_t> {
+    static __device__ __forceinline__ uint32_t hash(uint32_t k) { return k >> 2; }
+    static __device__ __forceinline__ uint32_t id(uint32_t k, uint16_t v, uint32_t first_id) { return first_id + (((k & 3u) << 16) | v); }
+};
+
+template <typename V>
+__device__ __forceinline__ enc_item enc_classify(const uint32_t *__restrict__ keys, const V *__restrict__ ids, uint64_t p, uint32_t first_id) {
     enc_item it;
-    uint32_t k = keys[p], id = ids[p];
+    uint32_t k = enc_codec<V>::hash(keys[p]), id = enc_codec<V>::id(keys[p], ids[p], first_id);
     bool first = p == 0;
-    uint32_t pk = first ? 0u : keys[p - 1], pid = first ? 0u : ids[p - 1];
+    uint32_t pk = first ? 0u : enc_codec<V>::hash(keys[p - 1]), pid = first ? 0u : enc_codec<V>::id(keys[p - 1], ids[p - 1], first_id);
+    it.hash = k;
     bool head = first || pk != k;
     bool dup = !head && pid == id;
     it.head = head ? 1u : 0u;
@@ -63,7 +78,8 @@ __device__ __forceinline__ uint64_t block_excl_scan_packed(uint64_t v, uint64_t 
 }
 
 // pass 1: per-tile (bytes, heads, postings) sums
-__global__ __launch_bounds__(ENC_THREADS) void k_enc_sizes(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ids, uint64_t n,
+template <typename V>
+__global__ __launch_bounds__(ENC_THREADS) void k_enc_sizes(const uint32_t *__restrict__ keys, const V *__restrict__ ids, uint64_t n, uint32_t first_id,
                                                            uint32_t *__restrict__ tile_bytes, uint32_t *__restrict__ tile_heads,
                                                            uint32_t *__restrict__ tile_posts) {
     __shared__ uint64_t sm[ENC_THREADS / 64];
@@ -73,7 +89,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_sizes(const uint32_t *__res
     for (int k = 0; k < ENC_ITEMS; ++k) {
         uint64_t p = base + k;
         if (p < n) {
-            enc_item it = enc_classify(keys, ids, p);
+            enc_item it = enc_classify<V>(keys, ids, p, first_id);
             bytes += it.len;
             heads += it.head;
             posts += it.len ? 1u : 0u;
@@ -97,7 +113,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_sizes(const uint32_t *__res
 }
 
 // pass 2: write varint bytes, sparse hashes and list start offsets
-__global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ids, uint64_t n,
+template <typename V>
+__global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__restrict__ keys, const V *__restrict__ ids, uint64_t n, uint32_t first_id,
                                                            const uint64_t *__restrict__ tile_byte_off, const uint64_t *__restrict__ tile_head_off,
                                                            uint8_t *__restrict__ value, uint32_t *__restrict__ hashes, uint64_t *__restrict__ offsets) {
     __shared__ uint64_t sm[ENC_THREADS / 64];
@@ -107,8 +124,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__res
 #pragma unroll
     for (int k = 0; k < ENC_ITEMS; ++k) {
         uint64_t p = base + k;
-        if (p < n) it[k] = enc_classify(keys, ids, p);
-        else { it[k].len = 0; it[k].head = 0; it[k].delta = 0; }
+        if (p < n) it[k] = enc_classify<V>(keys, ids, p, first_id);
+        else { it[k].len = 0; it[k].head = 0; it[k].delta = 0; it[k].hash = 0; }
         bytes += it[k].len;
         heads += it[k].head;
     }
@@ -121,7 +138,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__res
         uint64_t p = base + k;
         if (p >= n) break;
         if (it[k].head) {
-            hashes[hoff] = keys[p];
+            hashes[hoff] = it[k].hash;
             offsets[hoff] = boff;
             ++hoff;
         }
@@ -137,12 +154,17 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__res
 __global__ void k_set_u64(uint64_t *dst, uint64_t idx, const uint64_t *src) { dst[idx] = src[0]; }
 
 uint32_t fd_enc_num_tiles(uint64_t n) { return (uint32_t)((n + ENC_TILE - 1) / ENC_TILE); }
-void fd_launch_enc_sizes(const uint32_t *keys, const uint32_t *ids, uint64_t n, uint32_t *tb, uint32_t *th, uint32_t *tp, hipStream_t st) {
+void fd_launch_enc_sizes(const uint32_t *keys, const void *ids, bool ids16, uint32_t first_id, uint64_t n, uint32_t *tb, uint32_t *th, uint32_t *tp,
+                         hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_enc_sizes, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, ids, n, tb, th, tp);
+    if (ids16) hipLaunchKernelGGL(k_enc_sizes<uint16_t>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, (const uint16_t *)ids, n, first_id, tb, th, tp);
+    else hipLaunchKernelGGL(k_enc_sizes<uint32_t>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, (const uint32_t *)ids, n, first_id, tb, th, tp);
 }
-void fd_launch_enc_write(const uint32_t *keys, const uint32_t *ids, uint64_t n, const uint64_t *tbo, const uint64_t *tho, uint8_t *value,
-                         uint32_t *hashes, uint64_t *offsets, const uint64_t *total_bytes_dev, uint64_t H, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_enc_write, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, ids, n, tbo, tho, value, hashes, offsets);
+void fd_launch_enc_write(const uint32_t *keys, const void *ids, bool ids16, uint32_t first_id, uint64_t n, const uint64_t *tbo, const uint64_t *tho,
+                         uint8_t *value, uint32_t *hashes, uint64_t *offsets, const uint64_t *total_bytes_dev, uint64_t H, hipStream_t st) {
+    if (n) {
+        if (ids16) hipLaunchKernelGGL(k_enc_write<uint16_t>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, (const uint16_t *)ids, n, first_id, tbo, tho, value, hashes, offsets);
+        else hipLaunchKernelGGL(k_enc_write<uint32_t>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, (const uint32_t *)ids, n, first_id, tbo, tho, value, hashes, offsets);
+    }
     hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, offsets, H, total_bytes_dev);
 }

@@ -157,15 +157,15 @@ __global__ __launch_bounds__(RS_BINS) void k_rs_scan_tot(uint64_t *__restrict__ 
 
 // stable scatter of one tile. Wave w owns a contiguous sub-tile and walks it in 64-key chunks
 // (chunk c, lane l -> element c*64 + l) so that "earlier element" == "earlier chunk or lower lane".
-template <int THREADS, int ITEMS, bool XCD>
-__global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                        uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
+template <int THREADS, int ITEMS, bool XCD, typename V>
+__global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                                        uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n,
                                                         uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
                                                         const uint64_t *__restrict__ dbase) {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int WAVES = THREADS / 64;
     __shared__ uint32_t s_keys[TILE];
-    __shared__ uint32_t s_vals[TILE];
+    __shared__ V s_vals[TILE];
     __shared__ uint32_t s_cnt[WAVES][RS_BINS];  // per-wave digit counts, then running local positions
     __shared__ long long s_gofs[RS_BINS];       // global position = local position + s_gofs[digit]
     __shared__ uint64_t sm[17];
@@ -180,13 +180,14 @@ __global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint32_t *__restri
     for (int k = tid; k < WAVES * RS_BINS; k += THREADS) (&s_cnt[0][0])[k] = 0;
     __syncthreads();
 
-    uint32_t key[ITEMS], val[ITEMS];
+    uint32_t key[ITEMS];
+    V val[ITEMS];
 #pragma unroll
     for (int c = 0; c < ITEMS; ++c) {
         uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
         bool ok = idx < n;
         key[c] = ok ? keys_in[idx] : 0xffffffffu;
-        val[c] = ok ? vals_in[idx] : 0u;
+        val[c] = ok ? vals_in[idx] : (V)0;
         if (ok) atomicAdd(&s_cnt[wid][(key[c] >> shift) & mask], 1u);
     }
     __syncthreads();
@@ -411,8 +412,8 @@ void fd_rs_set_variant(int v) { g_rs_variant = v; }
 static inline uint32_t rs_tile(int v) { return (v >= 2 ? 512u : 256u) * 16u; }
 uint32_t fd_rs_num_tiles(uint64_t n) { return (uint32_t)((n + 4096 - 1) / 4096); }  // upper bound over variants (workspace sizing)
 
-template <int THREADS, int ITEMS, bool XCD>
-static void rs_pass(uint32_t *ki, uint32_t *vi, uint32_t *ko, uint32_t *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist,
+template <int THREADS, int ITEMS, bool XCD, typename V>
+static void rs_pass(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist,
                     uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
     uint32_t nb = (uint32_t)((n + THREADS * ITEMS - 1) / (THREADS * ITEMS));
     uint32_t grid = XCD ? ((nb + 7u) / 8u) * 8u : nb;
@@ -426,27 +427,37 @@ static void rs_pass(uint32_t *ki, uint32_t *vi, uint32_t *ko, uint32_t *vo, uint
         hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
     }
     {
-        StageTimer t(tc, "rs_scatter", n * 16);
-        hipLaunchKernelGGL((k_rs_scatter<THREADS, ITEMS, XCD>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
+        StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
+        hipLaunchKernelGGL((k_rs_scatter<THREADS, ITEMS, XCD, V>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
     }
 }
 
-int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits,
-                        uint32_t *ghist, uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
+template <typename V>
+static int radix_sort_pairs_t(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_b, uint64_t n, int key_bits, uint32_t *ghist,
+                              uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
     if (n == 0) return 0;
     int cur = 0;
     for (int shift = 0; shift < key_bits; shift += 8) {
         int bits = key_bits - shift < 8 ? key_bits - shift : 8;
-        uint32_t mask = (1u << bits) - 1u;
-        uint32_t *ki = cur ? keys_b : keys_a, *vi = cur ? vals_b : vals_a;
-        uint32_t *ko = cur ? keys_a : keys_b, *vo = cur ? vals_a : vals_b;
+        uint32_t mask = (uint32_t)((1ull << bits) - 1ull);
+        uint32_t *ki = cur ? keys_b : keys_a, *ko = cur ? keys_a : keys_b;
+        V *vi = cur ? vals_b : vals_a, *vo = cur ? vals_a : vals_b;
         switch (g_rs_variant) {
-            case 0: rs_pass<256, 16, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 1: rs_pass<256, 16, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 2: rs_pass<512, 16, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            default: rs_pass<512, 16, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 0: rs_pass<256, 16, false, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 1: rs_pass<256, 16, true, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 2: rs_pass<512, 16, false, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            default: rs_pass<512, 16, true, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
         }
         cur ^= 1;
     }
     return cur;
+}
+int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits,
+                        uint32_t *ghist, uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
+    return radix_sort_pairs_t<uint32_t>(keys_a, vals_a, keys_b, vals_b, n, key_bits, ghist, tot, st, tc);
+}
+// 6-byte elements: 32-bit keys with 16-bit payload (index build with <= 2^18 structures per shard)
+int fd_radix_sort_pairs16(uint32_t *keys_a, uint16_t *vals_a, uint32_t *keys_b, uint16_t *vals_b, uint64_t n, int key_bits,
+                          uint32_t *ghist, uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
+    return radix_sort_pairs_t<uint16_t>(keys_a, vals_a, keys_b, vals_b, n, key_bits, ghist, tot, st, tc);
 }
