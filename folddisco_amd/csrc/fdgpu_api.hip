@@ -259,18 +259,23 @@ static int ensure_sort_ws(fdgpu_ctx *c, uint64_t P) {
 }
 
 // stable sort of (keys, vals) by the low key_bits of keys; FDGPU_SORT=classic selects the 3-kernel LSD variant
+static int sort_mode();
 static int sort_pairs(fdgpu_ctx *c, uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb, uint64_t n, int key_bits) {
+    const int mode = sort_mode();
+    if (mode >= 0) return fd_radix_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), c->stream, c);
+    unsigned long long *gh = c->ws[WS_OSHIST].as<unsigned long long>();
+    return fd_onesweep_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_OSDESC].as<unsigned long long>(), gh, (uint32_t *)(gh + 4 * 256), c->stream, c);
+}
+static int sort_mode() {
     // FDGPU_SORT = onesweep | classic0..classic3 (default classic3: 512x16 tiles, XCD-aware tile order)
     static const int mode = [] {
         const char *e = getenv("FDGPU_SORT");
         if (e && !strcmp(e, "onesweep")) return -1;
-        if (e && !strncmp(e, "classic", 7) && e[7] >= '0' && e[7] <= '3') return e[7] - '0';
+        if (e && !strncmp(e, "classic", 7) && e[7] >= '0' && e[7] <= '4') return e[7] - '0';
         return 3;
     }();
     if (mode >= 0) fd_rs_set_variant(mode);
-    if (mode >= 0) return fd_radix_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), c->stream, c);
-    unsigned long long *gh = c->ws[WS_OSHIST].as<unsigned long long>();
-    return fd_onesweep_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_OSDESC].as<unsigned long long>(), gh, (uint32_t *)(gh + 4 * 256), c->stream, c);
+    return mode;
 }
 
 // ---- S1 ---------------------------------------------------------------------------------------------------------------
@@ -390,6 +395,7 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
                              (uint32_t)first_id, st);
     }
     int cur;
+    (void)sort_mode();
     if (ids16) cur = fd_radix_sort_pairs16(ka, (uint16_t *)ia, kb, (uint16_t *)ib, P, 32, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st, c);
     else cur = sort_pairs(c, ka, (uint32_t *)ia, kb, (uint32_t *)ib, P, 30);
     const uint32_t *ks = cur ? kb : ka;

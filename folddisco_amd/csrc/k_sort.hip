@@ -406,7 +406,112 @@ int fd_onesweep_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b,
     return cur;
 }
 
-// classic LSD variants: 0 = 256x16 tiles, 1 = 256x16 + XCD-aware tile order, 2 = 512x16, 3 = 512x16 + XCD-aware
+// persistent, software-pipelined scatter: a fixed grid (PERSIST_BLOCKS_PER_CU x 256 CUs) walks the tiles; the keys
+// and values of the NEXT tile are requested (global loads in flight) before the current tile is ranked and
+// written, so every CU always has reads outstanding instead of alternating load / LDS / store phases.
+// Tile order is XCD-aware: the blocks of one XCD (b % 8) sweep one contiguous eighth of the tiles together, so
+// the partial-line digit runs of neighbouring tiles merge in that XCD's L2.
+#define PERSIST_BLOCKS_PER_CU 4
+template <int THREADS, int ITEMS, typename V>
+__global__ __launch_bounds__(THREADS) void k_rs_scatter_p(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                                          uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n,
+                                                          uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
+                                                          const uint64_t *__restrict__ dbase) {
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / 64;
+    __shared__ uint32_t s_keys[TILE];
+    __shared__ V s_vals[TILE];
+    __shared__ uint32_t s_cnt[WAVES][RS_BINS];
+    __shared__ long long s_gofs[RS_BINS];
+    __shared__ uint64_t sm[17];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
+    const uint32_t per = (nb + 7u) / 8u;
+    const uint32_t t_lo = xcd * per, t_hi = (t_lo + per < nb) ? t_lo + per : nb;
+    uint32_t tile = t_lo + j;
+    if (tile >= t_hi) return;
+
+    uint32_t key[ITEMS], nkey[ITEMS];
+    V val[ITEMS], nval[ITEMS];
+    auto load_tile = [&](uint32_t t, uint32_t *k, V *v) {
+        const uint64_t wb = (uint64_t)t * TILE + (uint64_t)wid * (64 * ITEMS);
+#pragma unroll
+        for (int c = 0; c < ITEMS; ++c) {
+            uint64_t idx = wb + (uint64_t)c * 64 + lane;
+            bool ok = idx < n;
+            k[c] = ok ? keys_in[idx] : 0xffffffffu;
+            v[c] = ok ? vals_in[idx] : (V)0;
+        }
+    };
+    load_tile(tile, key, val);
+    for (;;) {
+        const uint32_t next = tile + per_xcd_blocks;
+        const bool has_next = next < t_hi;
+        if (has_next) load_tile(next, nkey, nval);   // in flight while this tile is processed
+
+        const uint64_t tile_base = (uint64_t)tile * TILE;
+        const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * ITEMS);
+        const uint32_t n_tile = (uint32_t)((n - tile_base) < TILE ? (n - tile_base) : TILE);
+        for (int k = tid; k < WAVES * RS_BINS; k += THREADS) (&s_cnt[0][0])[k] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < ITEMS; ++c) {
+            uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
+            if (idx < n) atomicAdd(&s_cnt[wid][(key[c] >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        {
+            uint32_t my_total = 0;
+            if (tid < RS_BINS) {
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) my_total += s_cnt[w][tid];
+            }
+            uint64_t tot;
+            uint32_t dstart = (uint32_t)block_excl_scan_u64(tid < RS_BINS ? (uint64_t)my_total : 0ull, sm, &tot);
+            if (tid < RS_BINS) {
+                uint32_t run = dstart;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) { uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
+                s_gofs[tid] = (long long)(dbase[tid] + ghist[(uint64_t)tid * nb + tile]) - (long long)dstart;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < ITEMS; ++c) {
+            uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
+            bool ok = idx < n;
+            uint32_t d = (key[c] >> shift) & mask;
+            uint64_t peers = __ballot(ok);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                uint64_t bal = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            uint32_t rank = fd_mbcnt(peers);
+            uint32_t pcount = (uint32_t)__popcll(peers);
+            uint32_t pos = 0;
+            if (ok) pos = s_cnt[wid][d] + rank;
+            if (ok && rank == pcount - 1) s_cnt[wid][d] = pos + 1;
+            if (ok) { s_keys[pos] = key[c]; s_vals[pos] = val[c]; }
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < n_tile; k += THREADS) {
+            uint32_t kk = s_keys[k];
+            long long g = (long long)k + s_gofs[(kk >> shift) & mask];
+            keys_out[g] = kk;
+            vals_out[g] = s_vals[k];
+        }
+        if (!has_next) break;
+        __syncthreads();   // LDS is reused by the next tile
+        tile = next;
+#pragma unroll
+        for (int c = 0; c < ITEMS; ++c) { key[c] = nkey[c]; val[c] = nval[c]; }
+    }
+}
+
+// LSD variants: 0 = 256x16 tiles, 1 = 256x16 + XCD-aware tile order, 2 = 512x16, 3 = 512x16 + XCD-aware,
+// 4 = 256x16 persistent software-pipelined scatter (XCD-aware)
 static int g_rs_variant = 1;
 void fd_rs_set_variant(int v) { g_rs_variant = v; }
 static inline uint32_t rs_tile(int v) { return (v >= 2 ? 512u : 256u) * 16u; }
@@ -432,6 +537,27 @@ static void rs_pass(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32
     }
 }
 
+template <int THREADS, int ITEMS, typename V>
+static void rs_pass_p(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist, uint64_t *tot,
+                      hipStream_t st, fdgpu_ctx *tc) {
+    uint32_t nb = (uint32_t)((n + THREADS * ITEMS - 1) / (THREADS * ITEMS));
+    uint32_t grid = ((nb + 7u) / 8u) * 8u;
+    {
+        StageTimer t(tc, "rs_hist", n * 4 + (uint64_t)nb * RS_BINS * 4);
+        hipLaunchKernelGGL((k_rs_hist<THREADS, ITEMS, true>), dim3(grid), dim3(THREADS), 0, st, ki, n, shift, mask, ghist, nb);
+    }
+    {
+        StageTimer t(tc, "rs_scan", (uint64_t)nb * RS_BINS * 8);
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
+        hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
+    }
+    {
+        StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
+        uint32_t pg = 256u * PERSIST_BLOCKS_PER_CU;   // multiple of 8
+        hipLaunchKernelGGL((k_rs_scatter_p<THREADS, ITEMS, V>), dim3(pg), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
+    }
+}
+
 template <typename V>
 static int radix_sort_pairs_t(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_b, uint64_t n, int key_bits, uint32_t *ghist,
                               uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
@@ -443,6 +569,7 @@ static int radix_sort_pairs_t(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *
         uint32_t *ki = cur ? keys_b : keys_a, *ko = cur ? keys_a : keys_b;
         V *vi = cur ? vals_b : vals_a, *vo = cur ? vals_a : vals_b;
         switch (g_rs_variant) {
+            case 4: rs_pass_p<256, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 0: rs_pass<256, 16, false, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 1: rs_pass<256, 16, true, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 2: rs_pass<512, 16, false, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
