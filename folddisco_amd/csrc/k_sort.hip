@@ -157,7 +157,9 @@ __global__ __launch_bounds__(RS_BINS) void k_rs_scan_tot(uint64_t *__restrict__ 
 
 // stable scatter of one tile. Wave w owns a contiguous sub-tile and walks it in 64-key chunks
 // (chunk c, lane l -> element c*64 + l) so that "earlier element" == "earlier chunk or lower lane".
-template <int THREADS, int ITEMS, bool XCD, typename V>
+// NT: streaming (non-temporal) loads of the input so that the once-read input does not evict the dirty partial
+// output lines from the XCD's L2 before the neighbouring tile completes them
+template <int THREADS, int ITEMS, bool XCD, typename V, bool NT = false>
 __global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
                                                         uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n,
                                                         uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
@@ -186,8 +188,13 @@ __global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint32_t *__restri
     for (int c = 0; c < ITEMS; ++c) {
         uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
         bool ok = idx < n;
-        key[c] = ok ? keys_in[idx] : 0xffffffffu;
-        val[c] = ok ? vals_in[idx] : (V)0;
+        if (NT) {
+            key[c] = ok ? __builtin_nontemporal_load(&keys_in[idx]) : 0xffffffffu;
+            val[c] = ok ? __builtin_nontemporal_load(&vals_in[idx]) : (V)0;
+        } else {
+            key[c] = ok ? keys_in[idx] : 0xffffffffu;
+            val[c] = ok ? vals_in[idx] : (V)0;
+        }
         if (ok) atomicAdd(&s_cnt[wid][(key[c] >> shift) & mask], 1u);
     }
     __syncthreads();
@@ -517,7 +524,7 @@ void fd_rs_set_variant(int v) { g_rs_variant = v; }
 static inline uint32_t rs_tile(int v) { return (v >= 2 ? 512u : 256u) * 16u; }
 uint32_t fd_rs_num_tiles(uint64_t n) { return (uint32_t)((n + 4096 - 1) / 4096); }  // upper bound over variants (workspace sizing)
 
-template <int THREADS, int ITEMS, bool XCD, typename V>
+template <int THREADS, int ITEMS, bool XCD, typename V, bool NT = false>
 static void rs_pass(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist,
                     uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
     uint32_t nb = (uint32_t)((n + THREADS * ITEMS - 1) / (THREADS * ITEMS));
@@ -533,7 +540,7 @@ static void rs_pass(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32
     }
     {
         StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
-        hipLaunchKernelGGL((k_rs_scatter<THREADS, ITEMS, XCD, V>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
+        hipLaunchKernelGGL((k_rs_scatter<THREADS, ITEMS, XCD, V, NT>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
     }
 }
 
@@ -570,6 +577,9 @@ static int radix_sort_pairs_t(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *
         V *vi = cur ? vals_b : vals_a, *vo = cur ? vals_a : vals_b;
         switch (g_rs_variant) {
             case 4: rs_pass_p<256, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 5: rs_pass<256, 16, true, V, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 6: rs_pass<256, 32, true, V, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 7: rs_pass<256, 32, true, V, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 0: rs_pass<256, 16, false, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 1: rs_pass<256, 16, true, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 2: rs_pass<512, 16, false, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
