@@ -271,7 +271,7 @@ static int sort_mode() {
     static const int mode = [] {
         const char *e = getenv("FDGPU_SORT");
         if (e && !strcmp(e, "onesweep")) return -1;
-        if (e && !strncmp(e, "classic", 7) && e[7] >= '0' && e[7] <= '7') return e[7] - '0';
+        if (e && !strncmp(e, "classic", 7) && e[7] >= '0' && e[7] <= '9') return e[7] - '0';
         return 1;
     }();
     if (mode >= 0) fd_rs_set_variant(mode);

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_scatter_p(const uint32_t *__rest
 static int g_rs_variant = 1;
 void fd_rs_set_variant(int v) { g_rs_variant = v; }
 static inline uint32_t rs_tile(int v) { return (v >= 2 ? 512u : 256u) * 16u; }
-uint32_t fd_rs_num_tiles(uint64_t n) { return (uint32_t)((n + 4096 - 1) / 4096); }  // upper bound over variants (workspace sizing)
+uint32_t fd_rs_num_tiles(uint64_t n) { return (uint32_t)((n + 2048 - 1) / 2048); }  // upper bound over variants (workspace sizing)
 
 template <int THREADS, int ITEMS, bool XCD, typename V, bool NT = false>
 static void rs_pass(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist,
@@ -578,8 +578,10 @@ static int radix_sort_pairs_t(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *
         switch (g_rs_variant) {
             case 4: rs_pass_p<256, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 5: rs_pass<256, 16, true, V, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 6: rs_pass<256, 32, true, V, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 7: rs_pass<256, 32, true, V, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 6: rs_pass<1024, 4, true, V, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 7: rs_pass<512, 8, true, V, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 8: rs_pass<256, 8, true, V, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 9: rs_pass<1024, 8, true, V, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 0: rs_pass<256, 16, false, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 1: rs_pass<256, 16, true, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 2: rs_pass<512, 16, false, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
