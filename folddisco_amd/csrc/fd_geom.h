@@ -201,8 +201,13 @@ FD_HD uint32_t fd_theta_key_of(float c, const uint32_t *t) {
     uint32_t key = (t[6] >> (4u * n)) & 15u;
     return (c >= -1.0f && c <= 1.0f) ? key : 0u;   // |c| > 1 or NaN: acosf -> NaN -> both bins 0
 }
-// generic (exact, slow) evaluation of the two torsion bins from the atan2f operands
-FD_HD uint32_t fd_tor_key_generic(float y, float x, float ang_disc) {
+// generic (exact, slow) evaluation of the two torsion bins from the atan2f operands; out of line on the device:
+// it is reached only for zero / inf / NaN operands and would otherwise be inlined at every torsion site
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline)) uint32_t fd_tor_key_generic(float y, float x, float ang_disc) {
+#else
+static inline uint32_t fd_tor_key_generic(float y, float x, float ang_disc) {
+#endif
     float s, c;
     fdd_sincosf(-fd_atan2f(y, x), &s, &c);
     return fd_q(s, -1.0f, ang_disc) << 2 | fd_q(c, -1.0f, ang_disc);

@@ -197,24 +197,27 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_emit2(fd_batch_view B, const f
     fd_v3 cai = {0.f, 0.f, 0.f};
     if (vi) cai = fd_load3(B.ca_xyz, i);
     uint32_t qn = 0;  // wave-uniform
-    for (uint32_t j = i0 + 1; j < r1; ++j) {
-        if (!B.hash_ok[j]) continue;
-        float d2 = fd_dist2(cai, fd_load3(B.ca_xyz, j));
-        bool pass = vi && j > i && !(d2 > C.d2_max);
-        uint64_t m = __ballot(pass);
-        if (m == 0) continue;
-        if (pass) q[qn + fd_mbcnt(m)] = (lane << 16) | (j - r0);
-        qn += (uint32_t)__popcll(m);
-        if (qn >= FD_WAVE) {
+    // single drain site (the descriptor code is ~2k instructions; two inlined copies would not fit the I-cache):
+    // the loop runs one extra iteration (j == r1) that only flushes the queue
+    for (uint32_t j = i0 + 1; j <= r1; ++j) {
+        const bool last = j == r1;
+        if (!last) {
+            if (!B.hash_ok[j]) continue;
+            float d2 = fd_dist2(cai, fd_load3(B.ca_xyz, j));
+            bool pass = vi && j > i && !(d2 > C.d2_max);
+            uint64_t m = __ballot(pass);
+            if (m != 0) {
+                if (pass) q[qn + fd_mbcnt(m)] = (lane << 16) | (j - r0);
+                qn += (uint32_t)__popcll(m);
+            }
+        }
+        if (qn >= FD_WAVE || (last && qn)) {
             __syncthreads();
-            qn -= FD_WAVE;
-            drain2<TAB, IDS16>(B, frames, C, tab, q + qn, FD_WAVE, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
+            uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
+            qn -= n;
+            drain2<TAB, IDS16>(B, frames, C, tab, q + qn, n, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
             __syncthreads();
         }
-    }
-    if (qn) {
-        __syncthreads();
-        drain2<TAB, IDS16>(B, frames, C, tab, q, qn, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
     }
 }
 
