@@ -125,10 +125,21 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_count2(fd_batch_view B, fd_has
     fd_v3 cai = {0.f, 0.f, 0.f};
     if (vi) cai = fd_load3(B.ca_xyz, i);
     uint32_t cnt = 0;
-    for (uint32_t j = i0 + 1; j < r1; ++j) {
-        if (!B.hash_ok[j]) continue;  // wave-uniform
-        float d2 = fd_dist2(cai, fd_load3(B.ca_xyz, j));
-        cnt += (vi && j > i && !(d2 > C.d2_max)) ? 2u : 0u;
+    // j is walked in blocks of 64: one coalesced load per block (lane l holds CA of j = jb + l), then the 64
+    // candidates are broadcast lane by lane with v_readlane — no per-j memory latency in the filter loop
+    for (uint32_t jb = i0; jb < r1; jb += FD_WAVE) {
+        const uint32_t jl = jb + threadIdx.x;
+        const bool jin = jl < r1;
+        fd_v3 cj = {0.f, 0.f, 0.f};
+        if (jin) cj = fd_load3(B.ca_xyz, jl);
+        const uint64_t okm = __ballot(jin && B.hash_ok[jl]);
+        const uint32_t nj = (r1 - jb) < FD_WAVE ? (r1 - jb) : FD_WAVE;
+        for (uint32_t k = 0; k < nj; ++k) {
+            if (!((okm >> k) & 1ull)) continue;  // wave-uniform
+            fd_v3 caj = {__shfl(cj.x, (int)k, FD_WAVE), __shfl(cj.y, (int)k, FD_WAVE), __shfl(cj.z, (int)k, FD_WAVE)};
+            float d2 = fd_dist2(cai, caj);
+            cnt += (vi && (jb + k) > i && !(d2 > C.d2_max)) ? 2u : 0u;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, FD_WAVE);
     if (threadIdx.x == 0 && cnt) atomicAdd(&counts[s], cnt);
@@ -197,26 +208,37 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_emit2(fd_batch_view B, const f
     fd_v3 cai = {0.f, 0.f, 0.f};
     if (vi) cai = fd_load3(B.ca_xyz, i);
     uint32_t qn = 0;  // wave-uniform
-    // single drain site (the descriptor code is ~2k instructions; two inlined copies would not fit the I-cache):
-    // the loop runs one extra iteration (j == r1) that only flushes the queue
-    for (uint32_t j = i0 + 1; j <= r1; ++j) {
-        const bool last = j == r1;
-        if (!last) {
-            if (!B.hash_ok[j]) continue;
-            float d2 = fd_dist2(cai, fd_load3(B.ca_xyz, j));
-            bool pass = vi && j > i && !(d2 > C.d2_max);
-            uint64_t m = __ballot(pass);
-            if (m != 0) {
-                if (pass) q[qn + fd_mbcnt(m)] = (lane << 16) | (j - r0);
-                qn += (uint32_t)__popcll(m);
+    // single drain site (two inlined copies of the descriptor code would not fit the I-cache); the queue is
+    // flushed on the last candidate. j is walked in blocks of 64: one coalesced load per block, then v_readlane
+    // broadcasts — no per-j memory latency in the filter loop.
+    for (uint32_t jb = i0; jb < r1; jb += FD_WAVE) {
+        const uint32_t jl = jb + lane;
+        const bool jin = jl < r1;
+        fd_v3 cj = {0.f, 0.f, 0.f};
+        if (jin) cj = fd_load3(B.ca_xyz, jl);
+        const uint64_t okm = __ballot(jin && B.hash_ok[jl]);
+        const uint32_t nj = (r1 - jb) < FD_WAVE ? (r1 - jb) : FD_WAVE;
+        const bool last_block = jb + FD_WAVE >= r1;
+        for (uint32_t k = 0; k < nj; ++k) {
+            const bool last = last_block && k + 1 == nj;
+            if ((okm >> k) & 1ull) {  // wave-uniform
+                fd_v3 caj = {__shfl(cj.x, (int)k, FD_WAVE), __shfl(cj.y, (int)k, FD_WAVE), __shfl(cj.z, (int)k, FD_WAVE)};
+                float d2 = fd_dist2(cai, caj);
+                const uint32_t j = jb + k;
+                bool pass = vi && j > i && !(d2 > C.d2_max);
+                uint64_t m = __ballot(pass);
+                if (m != 0) {
+                    if (pass) q[qn + fd_mbcnt(m)] = (lane << 16) | (j - r0);
+                    qn += (uint32_t)__popcll(m);
+                }
             }
-        }
-        if (qn >= FD_WAVE || (last && qn)) {
-            __syncthreads();
-            uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
-            qn -= n;
-            drain2<TAB, IDS16>(B, frames, C, tab, q + qn, n, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
-            __syncthreads();
+            if (qn >= FD_WAVE || (last && qn)) {
+                __syncthreads();
+                uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
+                qn -= n;
+                drain2<TAB, IDS16>(B, frames, C, tab, q + qn, n, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
+                __syncthreads();
+            }
         }
     }
 }
