@@ -232,7 +232,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_emit2(fd_batch_view B, const f
                     qn += (uint32_t)__popcll(m);
                 }
             }
-            if (qn >= FD_WAVE || (last && qn)) {
+            while (qn >= FD_WAVE || (last && qn)) {   // on the last candidate up to two drains may be pending
                 __syncthreads();
                 uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
                 qn -= n;
