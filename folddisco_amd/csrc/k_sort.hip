@@ -124,10 +124,23 @@ __global__ __launch_bounds__(THREADS) void k_rs_hist(const uint32_t *__restrict_
     for (int k = threadIdx.x; k < RS_BINS; k += THREADS) h[k] = 0;
     __syncthreads();
     uint64_t base = (uint64_t)tile * TILE;
+    if (base + TILE <= n) {
+        // full tile: 16-byte loads (4 consecutive keys per lane), 1 KiB per wave instruction
+        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + base);
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-        uint64_t idx = base + (uint64_t)k * THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+        for (int k = 0; k < ITEMS / 4; ++k) {
+            uint4 v = __builtin_nontemporal_load(&k4[k * THREADS + threadIdx.x]);
+            atomicAdd(&h[(v.x >> shift) & mask], 1u);
+            atomicAdd(&h[(v.y >> shift) & mask], 1u);
+            atomicAdd(&h[(v.z >> shift) & mask], 1u);
+            atomicAdd(&h[(v.w >> shift) & mask], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            uint64_t idx = base + (uint64_t)k * THREADS + threadIdx.x;
+            if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+        }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < RS_BINS; k += THREADS) ghist[(uint64_t)k * nb + tile] = h[k];
