@@ -126,10 +126,11 @@ __global__ __launch_bounds__(THREADS) void k_rs_hist(const uint32_t *__restrict_
     uint64_t base = (uint64_t)tile * TILE;
     if (base + TILE <= n) {
         // full tile: 16-byte loads (4 consecutive keys per lane), 1 KiB per wave instruction
-        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + base);
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys + base);
 #pragma unroll
         for (int k = 0; k < ITEMS / 4; ++k) {
-            uint4 v = __builtin_nontemporal_load(&k4[k * THREADS + threadIdx.x]);
+            u32x4 v = __builtin_nontemporal_load(&k4[k * THREADS + threadIdx.x]);
             atomicAdd(&h[(v.x >> shift) & mask], 1u);
             atomicAdd(&h[(v.y >> shift) & mask], 1u);
             atomicAdd(&h[(v.z >> shift) & mask], 1u);
