@@ -50,6 +50,56 @@ __device__ __forceinline__ enc_item enc_classify(const uint32_t *__restrict__ ke
     return it;
 }
 
+// Loads the ENC_ITEMS (= 8) consecutive elements owned by this thread with 16-byte loads (full tiles) and
+// classifies them; the predecessor of the thread's first element comes from the neighbouring lane (shuffle)
+// or, for lane 0 of a wave, from memory.
+template <typename V>
+__device__ __forceinline__ void enc_load_classify(const uint32_t *__restrict__ keys, const V *__restrict__ ids, uint64_t n, uint64_t base,
+                                                  uint32_t first_id, enc_item *it) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t k[ENC_ITEMS], v[ENC_ITEMS];
+    const bool full = base + ENC_ITEMS <= n;
+    if (full) {
+        const u32x4 *kp = reinterpret_cast<const u32x4 *>(keys + base);
+        u32x4 a = __builtin_nontemporal_load(&kp[0]), b = __builtin_nontemporal_load(&kp[1]);
+        k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+        if (sizeof(V) == 2) {
+            u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(ids + base));
+            v[0] = w.x & 0xffffu; v[1] = w.x >> 16; v[2] = w.y & 0xffffu; v[3] = w.y >> 16;
+            v[4] = w.z & 0xffffu; v[5] = w.z >> 16; v[6] = w.w & 0xffffu; v[7] = w.w >> 16;
+        } else {
+            const u32x4 *vp = reinterpret_cast<const u32x4 *>(ids + base);
+            u32x4 c = __builtin_nontemporal_load(&vp[0]), d = __builtin_nontemporal_load(&vp[1]);
+            v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w; v[4] = d.x; v[5] = d.y; v[6] = d.z; v[7] = d.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ENC_ITEMS; ++j) {
+            uint64_t p = base + j;
+            k[j] = p < n ? keys[p] : 0u;
+            v[j] = p < n ? (uint32_t)ids[p] : 0u;
+        }
+    }
+    // predecessor of element 0
+    uint32_t pk = __shfl_up(k[ENC_ITEMS - 1], 1, FD_WAVE), pv = __shfl_up(v[ENC_ITEMS - 1], 1, FD_WAVE);
+    if ((threadIdx.x & 63) == 0 && base > 0 && base < n) { pk = keys[base - 1]; pv = (uint32_t)ids[base - 1]; }
+    uint32_t ph = enc_codec<V>::hash(pk), pid = enc_codec<V>::id(pk, (V)pv, first_id);
+    bool have_prev = base > 0;
+#pragma unroll
+    for (int j = 0; j < ENC_ITEMS; ++j) {
+        uint64_t p = base + j;
+        uint32_t h = enc_codec<V>::hash(k[j]), id = enc_codec<V>::id(k[j], (V)v[j], first_id);
+        bool in = p < n;
+        bool head = !have_prev || ph != h;
+        bool dup = !head && pid == id;
+        it[j].hash = h;
+        it[j].head = (in && head) ? 1u : 0u;
+        it[j].delta = head ? id : id - pid;
+        it[j].len = (!in || dup) ? 0u : varint_len(it[j].delta);
+        ph = h; pid = id; have_prev = true;
+    }
+}
+
 __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
     uint32_t lane = threadIdx.x & 63;
     for (int off = 1; off < 64; off <<= 1) {
@@ -85,15 +135,13 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_sizes(const uint32_t *__res
     __shared__ uint64_t sm[ENC_THREADS / 64];
     uint64_t base = (uint64_t)blockIdx.x * ENC_TILE + (uint64_t)threadIdx.x * ENC_ITEMS;
     uint32_t bytes = 0, heads = 0, posts = 0;
+    enc_item it[ENC_ITEMS];
+    enc_load_classify<V>(keys, ids, n, base, first_id, it);
 #pragma unroll
     for (int k = 0; k < ENC_ITEMS; ++k) {
-        uint64_t p = base + k;
-        if (p < n) {
-            enc_item it = enc_classify<V>(keys, ids, p, first_id);
-            bytes += it.len;
-            heads += it.head;
-            posts += it.len ? 1u : 0u;
-        }
+        bytes += it[k].len;
+        heads += it[k].head;
+        posts += it[k].len ? 1u : 0u;
     }
     uint64_t tot;
     block_excl_scan_packed(((uint64_t)bytes << 32) | heads, sm, &tot);
@@ -118,25 +166,24 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__res
                                                            const uint64_t *__restrict__ tile_byte_off, const uint64_t *__restrict__ tile_head_off,
                                                            uint8_t *__restrict__ value, uint32_t *__restrict__ hashes, uint64_t *__restrict__ offsets) {
     __shared__ uint64_t sm[ENC_THREADS / 64];
+    // varint bytes of the tile are assembled in LDS (pre-shifted by the global misalignment) and leave as
+    // 16-byte stores instead of one global byte store per byte
+    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[ENC_TILE * 5 + 32];
     uint64_t base = (uint64_t)blockIdx.x * ENC_TILE + (uint64_t)threadIdx.x * ENC_ITEMS;
     enc_item it[ENC_ITEMS];
     uint32_t bytes = 0, heads = 0;
+    enc_load_classify<V>(keys, ids, n, base, first_id, it);
 #pragma unroll
-    for (int k = 0; k < ENC_ITEMS; ++k) {
-        uint64_t p = base + k;
-        if (p < n) it[k] = enc_classify<V>(keys, ids, p, first_id);
-        else { it[k].len = 0; it[k].head = 0; it[k].delta = 0; it[k].hash = 0; }
-        bytes += it[k].len;
-        heads += it[k].head;
-    }
+    for (int k = 0; k < ENC_ITEMS; ++k) { bytes += it[k].len; heads += it[k].head; }
     uint64_t tot;
     uint64_t ex = block_excl_scan_packed(((uint64_t)bytes << 32) | heads, sm, &tot);
-    uint64_t boff = tile_byte_off[blockIdx.x] + (ex >> 32);
+    const uint64_t tile_b0 = tile_byte_off[blockIdx.x];
+    const uint32_t shift = (uint32_t)(tile_b0 & 15ull);
+    uint32_t lo = shift + (uint32_t)(ex >> 32);           // LDS position of this thread's first byte
+    uint64_t boff = tile_b0 + (ex >> 32);
     uint64_t hoff = tile_head_off[blockIdx.x] + (uint32_t)ex;
 #pragma unroll
     for (int k = 0; k < ENC_ITEMS; ++k) {
-        uint64_t p = base + k;
-        if (p >= n) break;
         if (it[k].head) {
             hashes[hoff] = it[k].hash;
             offsets[hoff] = boff;
@@ -146,7 +193,20 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__res
         for (uint32_t b = 0; b < it[k].len; ++b) {
             uint32_t byte = v & 0x7fu;
             v >>= 7;
-            value[boff++] = (uint8_t)(byte | (b + 1 < it[k].len ? 0x80u : 0u));
+            s_bytes[lo++] = (uint8_t)(byte | (b + 1 < it[k].len ? 0x80u : 0u));
+        }
+        boff += it[k].len;
+    }
+    __syncthreads();
+    const uint32_t tile_len = (uint32_t)(tot >> 32);
+    const uint32_t end = shift + tile_len;                 // LDS range [shift, end) holds the tile's bytes
+    uint8_t *gbase = value + (tile_b0 - shift);            // 16-byte aligned (value comes from hipMalloc)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    for (uint32_t c = threadIdx.x * 16; c < end; c += ENC_THREADS * 16) {
+        if (c >= shift && c + 16 <= end) {
+            *reinterpret_cast<u32x4 *>(gbase + c) = *reinterpret_cast<const u32x4 *>(s_bytes + c);
+        } else {
+            for (uint32_t b = c < shift ? shift : c; b < c + 16 && b < end; ++b) gbase[b] = s_bytes[b];
         }
     }
 }
