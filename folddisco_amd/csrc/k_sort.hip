@@ -147,17 +147,22 @@ __global__ __launch_bounds__(THREADS) void k_rs_hist(const uint32_t *__restrict_
     for (int k = threadIdx.x; k < RS_BINS; k += THREADS) ghist[(uint64_t)k * nb + tile] = h[k];
 }
 
-// one workgroup per digit: exclusive scan of its row of nb tile counts (in place), row total -> tot[d]
+// one workgroup per digit: exclusive scan of its row of nb tile counts (in place), row total -> tot[d];
+// 8 consecutive counts per thread and iteration
 __global__ __launch_bounds__(1024) void k_rs_scan_rows(uint32_t *__restrict__ ghist, uint32_t nb, uint64_t *__restrict__ tot) {
     __shared__ uint64_t sm[17];
     uint32_t *row = ghist + (uint64_t)blockIdx.x * nb;
     uint64_t carry = 0;
-    for (uint32_t b = 0; b < nb; b += 1024) {
-        uint32_t idx = b + threadIdx.x;
-        uint64_t v = idx < nb ? row[idx] : 0;
+    for (uint32_t b = 0; b < nb; b += 1024 * 8) {
+        uint32_t i0 = b + threadIdx.x * 8;
+        uint32_t v[8];
+        uint64_t s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = (i0 + k) < nb ? row[i0 + k] : 0u; s += v[k]; }
         uint64_t t;
-        uint64_t ex = block_excl_scan_u64(v, sm, &t);
-        if (idx < nb) row[idx] = (uint32_t)(carry + ex);
+        uint64_t ex = carry + block_excl_scan_u64(s, sm, &t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { if (i0 + k < nb) row[i0 + k] = (uint32_t)ex; ex += v[k]; }
         carry += t;
     }
     if (threadIdx.x == 0) tot[blockIdx.x] = carry;
