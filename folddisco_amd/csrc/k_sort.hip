@@ -392,7 +392,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_scatter(const uint32_t *__res
         uint32_t pos = 0;
         if (ok) pos = s_cnt[wid][d] + rank;
         if (ok && rank == pcount - 1) s_cnt[wid][d] = pos + 1;
-        if (ok) s_kv[pos] = make_uint2(key[c], (uint32_t)val[c]);
+        if (ok) { s_keys[pos] = key[c]; s_vals[pos] = val[c]; }
     }
     __syncthreads();
     for (uint32_t k = tid; k < n_tile; k += OS_THREADS) {
