@@ -185,7 +185,8 @@ __global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint32_t *__restri
                                                         const uint64_t *__restrict__ dbase) {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int WAVES = THREADS / 64;
-    __shared__ uint2 s_kv[TILE];                 // {key, value}: one 8-byte LDS write + one read per element
+    __shared__ uint32_t s_keys[TILE];
+    __shared__ V s_vals[TILE];
     __shared__ uint32_t s_cnt[WAVES][RS_BINS];  // per-wave digit counts, then running local positions
     __shared__ long long s_gofs[RS_BINS];       // global position = local position + s_gofs[digit]
     __shared__ uint64_t sm[17];
@@ -250,15 +251,15 @@ __global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint32_t *__restri
         if (ok) pos = s_cnt[wid][d] + rank;
         // the wave's LDS ops execute in order: every read above precedes the update below
         if (ok && rank == pcount - 1) s_cnt[wid][d] = pos + 1;
-        if (ok) s_kv[pos] = make_uint2(key[c], (uint32_t)val[c]);
+        if (ok) { s_keys[pos] = key[c]; s_vals[pos] = val[c]; }
     }
     __syncthreads();
     // digit-contiguous in LDS -> runs in global memory
     for (uint32_t k = tid; k < n_tile; k += THREADS) {
-        uint2 kv = s_kv[k];
-        long long g = (long long)k + s_gofs[(kv.x >> shift) & mask];
-        keys_out[g] = kv.x;
-        vals_out[g] = (V)kv.y;
+        uint32_t kk = s_keys[k];
+        long long g = (long long)k + s_gofs[(kk >> shift) & mask];
+        keys_out[g] = kk;
+        vals_out[g] = s_vals[k];
     }
 }
 
