@@ -42,6 +42,25 @@ def parse_args():
     return ap.parse_args()
 
 
+def pmc_traffic(stage, S):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/*pmc_traffic_S<structures>.json, tools/profile_bench.sh): 2 x FETCH_SIZE (gfx950 reports half of a
+    coalesced stream, MI355X_MICROARCH.md; checked on k_enc_sizes / k_rs_hist whose read bytes are known) +
+    WRITE_SIZE (matches the known write bytes of k_frames and k_pair_emit2).  None when no profile of this
+    workload size is committed."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_traffic_S{S}.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if k.startswith("k_" + stage):
+                return {"bytes_per_launch": 2.0 * v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], "kernel": k,
+                        "rocprof_avg_us": v.get("avg_us"), "source": os.path.basename(f)}
+    return None
+
+
 def cpu_baseline(ps_sample, n_threads):
     """CPU restatement of the reference path (oracle/, OpenMP over structures for the hash stage like the
     reference's rayon par_iter, serial dense-table count+fill), timed on the host cores of this box."""
@@ -129,7 +148,9 @@ def main():
     dom_name, (dom_ms, dom_bytes, dom_n) = dom
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": dom_name, "launches_per_step": dom_n, "avg_ms": dom_ms / max(dom_n, 1),
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": dom_bytes / max(dom_n, 1),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(dom_name, S),
                 "stages_ms": {k: round(v[0], 3) for k, v in agg.items()},
                 "stages_gbs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0.0 for k, v in agg.items()}}
 
