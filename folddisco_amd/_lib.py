@@ -91,6 +91,8 @@ SYMBOLS = [
     ("fdgpu_retrieve", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(QueryMap), VP, C.POINTER(HashParams), C.c_float, C.c_uint32,
                                  C.POINTER(C.POINTER(MatchRec)), u64p, C.POINTER(C.POINTER(C.c_int32))]),
     ("fdgpu_matches_free", None, [C.POINTER(MatchRec), C.POINTER(C.c_int32)]),
+    ("fdgpu_merge_subindices", C.c_int, [C.c_uint64, C.POINTER(u8p), C.POINTER(u32p), C.POINTER(u64p), u64p, C.POINTER(u8p), u64p,
+                                         C.POINTER(u32p), C.POINTER(u64p), u64p]),
     ("fdgpu_debug_libm", C.c_int, [VP, C.c_int, f32p, f32p, f32p, C.c_uint64]),
 ]
 

@@ -454,3 +454,69 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
     *matches = om; *n_matches = recs.size(); *residues = orr;
     return FDGPU_OK;
 }
+
+// ------------------------------------------------------------------------------------------ sub-index merge
+// Index build shards by structure (one sub-index per GPU / per batch, contiguous ascending id ranges).  The
+// reference's single on-disk index is the per-hash concatenation of the shards' posting lists in shard order;
+// only the first varint of every continuation (an absolute id in its own sub-index) must be re-encoded as the
+// delta from the last id of the list so far (src/index/indextable.rs:171-202 semantics).  Host-side, streaming.
+static inline uint64_t fd_decode_last(const uint8_t *b, uint64_t n, uint64_t *first_len, uint64_t *first_val) {
+    uint64_t acc = 0, prev = 0, cur = 0;
+    unsigned shift = 0;
+    bool first = true;
+    for (uint64_t k = 0; k < n; ++k) {
+        acc |= (uint64_t)(b[k] & 0x7f) << shift;
+        if (b[k] & 0x80) { shift += 7; continue; }
+        if (first) { cur = acc; *first_len = k + 1; *first_val = acc; first = false; }
+        else cur = prev + acc;
+        prev = cur; acc = 0; shift = 0;
+    }
+    return cur;
+}
+static inline unsigned fd_put_varint(uint64_t v, uint8_t *out) {
+    unsigned n = 0;
+    do { uint8_t byte = v & 0x7f; v >>= 7; out[n++] = byte | (v ? 0x80 : 0); } while (v);
+    return n;
+}
+
+extern "C" int fdgpu_merge_subindices(uint64_t n_parts, const uint8_t *const *values, const uint32_t *const *hashes,
+                                      const uint64_t *const *offsets, const uint64_t *n_hashes, uint8_t **out_value, uint64_t *out_value_len,
+                                      uint32_t **out_hashes, uint64_t **out_offsets, uint64_t *out_n_hashes) {
+    if (!values || !hashes || !offsets || !n_hashes || !out_value || !out_value_len || !out_hashes || !out_offsets || !out_n_hashes) return FDGPU_EINVAL;
+    uint64_t tot_h = 0, tot_v = 0;
+    for (uint64_t p = 0; p < n_parts; ++p) { tot_h += n_hashes[p]; tot_v += offsets[p][n_hashes[p]]; }
+    uint8_t *V = (uint8_t *)malloc(std::max<uint64_t>(tot_v + 8, 8));          // re-based first deltas are never longer than the absolute ids
+    uint32_t *H = (uint32_t *)malloc(std::max<uint64_t>(tot_h, 1) * 4);
+    uint64_t *O = (uint64_t *)malloc((tot_h + 1) * 8);
+    if (!V || !H || !O) { free(V); free(H); free(O); return FDGPU_ENOMEM; }
+    std::vector<uint64_t> pos(n_parts, 0);
+    uint64_t nh = 0, nv = 0;
+    O[0] = 0;
+    for (;;) {
+        bool any = false;
+        uint32_t hmin = 0;
+        for (uint64_t p = 0; p < n_parts; ++p)
+            if (pos[p] < n_hashes[p] && (!any || hashes[p][pos[p]] < hmin)) { hmin = hashes[p][pos[p]]; any = true; }
+        if (!any) break;
+        bool have_last = false;
+        uint64_t last = 0;
+        for (uint64_t p = 0; p < n_parts; ++p) {   // shard order = ascending id ranges
+            if (pos[p] >= n_hashes[p] || hashes[p][pos[p]] != hmin) continue;
+            const uint8_t *b = values[p] + offsets[p][pos[p]];
+            uint64_t len = offsets[p][pos[p] + 1] - offsets[p][pos[p]];
+            uint64_t flen = 0, fval = 0;
+            uint64_t lst = fd_decode_last(b, len, &flen, &fval);
+            if (!have_last) { memcpy(V + nv, b, len); nv += len; }
+            else {
+                if (fval <= last) { free(V); free(H); free(O); return FDGPU_EINVAL; }   // id ranges must ascend across parts
+                nv += fd_put_varint(fval - last, V + nv);
+                memcpy(V + nv, b + flen, len - flen); nv += len - flen;
+            }
+            last = lst; have_last = true;
+            ++pos[p];
+        }
+        H[nh] = hmin; O[++nh] = nv;
+    }
+    *out_value = V; *out_value_len = nv; *out_hashes = H; *out_offsets = O; *out_n_hashes = nh;
+    return FDGPU_OK;
+}

@@ -198,6 +198,13 @@ int fdgpu_retrieve(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *resname
                    uint32_t node_count, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues);
 void fdgpu_matches_free(fd_match_rec *m, int32_t *residues);
 
+/* ---- merging per-GPU / per-batch sub-indices into the reference's single index ----------------------------
+ * Parts must cover ascending, disjoint id ranges in the order given (index build shards by structure).  Output is
+ * the on-disk layout (value bytes, sparse hashes, offsets[H+1]); host-side, buffers released with fdgpu_free. */
+int fdgpu_merge_subindices(uint64_t n_parts, const uint8_t *const *values, const uint32_t *const *hashes,
+                           const uint64_t *const *offsets, const uint64_t *n_hashes, uint8_t **out_value,
+                           uint64_t *out_value_len, uint32_t **out_hashes, uint64_t **out_offsets, uint64_t *out_n_hashes);
+
 /* ---- profiling hooks ------------------------------------------------------------------------------
  * Per-kernel timing of the last fdgpu_index_build / fdgpu_count_query call, measured with
  * HIP events on the context's stream. names[i] is a static string. Returns the number of

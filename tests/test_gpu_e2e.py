@@ -107,3 +107,40 @@ def test_retrieve_matches_oracle(env):
                     assert g["from_hash"] == [-1 if x is None else x[2] for x in rh["residues"]]
                     assert abs(g["rmsd"] - rp["rmsd"]) <= 1e-4 and abs(g["rmsd_from_hash"] - rh["rmsd"]) <= 1e-4
                     assert g["idf"] == pytest.approx(rp["idf"], rel=1e-6)
+
+
+def test_sharded_build_merge_and_disk_roundtrip(env, tmp_path):
+    """index build shards by structure: two sub-indices built with id offsets merge into the byte-identical single index;
+    the files written to disk load back (product loader and oracle loader) and answer the query identically."""
+    import folddisco_amd as fd
+    from folddisco_amd import indexio
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    ctx, structs, batch, ix, nres, plddt, tids = env
+    whole = ix.export()
+    parts = []
+    for lo, hi in ((0, 2), (2, 5)):
+        ps = fd.PackedStructures.concat([s.as_item() for s in structs[lo:hi]])
+        sub = fd.FolddiscoIndex.build(ctx, ctx.upload(ps), first_id=lo)
+        parts.append(sub.export())
+    v, h, o = indexio.merge_subindices(parts)
+    assert np.array_equal(v, whole[0]) and np.array_equal(h, whole[1]) and np.array_equal(o, whole[2])
+    pre = str(tmp_path / "serine_folddisco")
+    indexio.write_index_files(pre, v, h, o)
+    indexio.save_lookup(pre + ".lookup", tids, nres, plddt)
+    indexio.save_type(pre + ".type", len(tids))
+    ix.save(str(tmp_path / "direct"))
+    for ext in ("", ".offset"):
+        assert open(pre + ext, "rb").read() == open(str(tmp_path / "direct") + ext, "rb").read()
+    # load back
+    oix = oracle.load_index(pre)
+    assert oix.H == 217612
+    v2, h2, o2 = indexio.read_index_files(pre)
+    t2, n2, p2, _ = indexio.load_lookup(pre + ".lookup")
+    ix2 = fd.FolddiscoIndex.load(ctx, h2, o2, v2, len(t2))
+    q = st.read_compact_structure(Q4CHA)
+    rows1, m1 = fq.query_pdb(ctx, ix, batch, structs, tids, nres, plddt, q, "B57,B102,C195")
+    rows2, m2 = fq.query_pdb(ctx, ix2, batch, structs, t2, n2, p2, q, "B57,B102,C195")
+    assert [fq.format_match_row(m) for m in m1] == [fq.format_match_row(m) for m in m2]
+    assert [(r["nid"], r["total_match_count"], r["node_count"], r["edge_count"], r["idf"]) for r in rows1] == \
+           [(r["nid"], r["total_match_count"], r["node_count"], r["edge_count"], r["idf"]) for r in rows2]

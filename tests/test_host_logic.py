@@ -146,3 +146,59 @@ def test_bin_tables_are_consistent_with_glibc():
     rng = np.random.Generator(np.random.PCG64(1))
     for c in rng.uniform(-1, 1, 20000).astype(np.float32):
         assert key_tab(c) == key_ref(c)
+
+
+def test_merge_subindices_equals_single_build_oracle():
+    """per-shard sub-indices (oracle-built here, so the test runs without a GPU) merge into the byte-identical single index"""
+    from folddisco_amd import indexio
+    structs = [oracle.read_pdb(p) for p in SER]
+    lists = [np.unique(oracle.hash_structure(s)) for s in structs]
+    L = oracle.lib()
+
+    def build(ids):
+        ix = L.fdo_index_new(30)
+        for fn in (L.fdo_index_count_single_entry, L.fdo_index_add_single_entry):
+            for i in ids:
+                for x in lists[i % 5]:
+                    fn(ix, int(x), i)
+            if fn is L.fdo_index_count_single_entry:
+                L.fdo_index_allocate_entries(ix)
+        L.fdo_index_finish(ix)
+        o = oracle.OIndex(ix)
+        return o.values(), o.hashes(), o.offsets()
+    ids = list(range(0, 5)) + list(range(16380, 16390))          # multi-byte deltas across the shard boundary
+    whole = build(ids)
+    for cut in ([5], [2, 9], [1, 2, 3, 4, 14]):
+        bounds = [0] + cut + [len(ids)]
+        parts = [build(ids[a:b]) for a, b in zip(bounds, bounds[1:])]
+        v, h, o = indexio.merge_subindices(parts)
+        assert np.array_equal(v, whole[0]) and np.array_equal(h, whole[1]) and np.array_equal(o, whole[2]), cut
+    with pytest.raises(RuntimeError):
+        indexio.merge_subindices([build(ids[5:]), build(ids[:5])])
+
+
+def test_index_files_roundtrip_and_text_files(tmp_path):
+    from folddisco_amd import indexio
+    structs = [oracle.read_pdb(p) for p in SER]
+    oix, nres, plddt = oracle.build_index(structs)
+    pre = str(tmp_path / "o")
+    oix.save(pre)
+    v, h, o = indexio.read_index_files(pre)
+    assert np.array_equal(v, oix.values()) and np.array_equal(h, oix.hashes()) and np.array_equal(o, oix.offsets())
+    indexio.write_index_files(str(tmp_path / "w"), v, h, o)
+    for ext in ("", ".offset"):
+        assert open(pre + ext, "rb").read() == open(str(tmp_path / "w") + ext, "rb").read()
+    tids = ["data/serine_peptidases/" + os.path.basename(p) for p in SER]
+    indexio.save_lookup(pre + ".lookup", tids, nres, plddt)
+    # same bytes as the oracle's writer (Rust `{}` float formatting restated on both sides)
+    arr = (C.c_char_p * 5)(*[t.encode() for t in tids])
+    oracle.lib().fdo_save_lookup((pre + ".lookup2").encode(), arr, nres.ctypes.data_as(oracle.u64p), plddt.ctypes.data_as(oracle.f32p), None, 5)
+    assert open(pre + ".lookup").read() == open(pre + ".lookup2").read()
+    t2, n2, p2, k2 = indexio.load_lookup(pre + ".lookup")
+    assert t2 == tids and np.array_equal(n2, nres) and np.array_equal(p2.view(np.uint32), plddt.view(np.uint32)) and list(k2) == [0, 1, 2, 3, 4]
+    indexio.save_type(pre + ".type", 5)
+    cfg = indexio.load_type(pre + ".type")
+    assert cfg == {"chunk_size": 5, "grid_width": 20.0, "hash_type": "PDBTrRosetta", "input_format": "PDB", "max_residue": 50000,
+                   "num_bin_angle": 0, "num_bin_dist": 0}
+    for x, want in [(50.0, "50"), (0.0, "0"), (13.540419, "13.540419"), (0.1, "0.1"), (1e-7, "0.0000001"), (float("nan"), "NaN"), (1.5e10, "15000000000")]:
+        assert indexio.format_f32_display(x) == want
