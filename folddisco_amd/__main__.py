@@ -1,0 +1,149 @@
+"""`python -m folddisco_amd index|query …` — the reference's two hot-path subcommands with its flag names and defaults
+(src/cli/main.rs:26-110, src/cli/workflows/build_index.rs:64-241, src/cli/workflows/query_pdb.rs:144-519), driving the
+GPU path through the C ABI.  Structure order = lexicographic path order (the reference uses readdir order, which is
+filesystem dependent; SURVEY §7 hard part 3).  Only the default PDBTrRosetta encoding and PDB(.gz) input are supported."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+
+def _load_paths(d: str, recursive: bool):
+    out = []
+    if os.path.isfile(d):
+        return [d]
+    for root, dirs, files in os.walk(d):
+        for f in files:
+            if f.lower().endswith((".pdb", ".ent", ".pdb.gz", ".ent.gz")):
+                out.append(os.path.join(root, f))
+        if not recursive:
+            break
+    return sorted(out)
+
+
+def cmd_index(a):
+    import folddisco_amd as fd
+    from folddisco_amd import indexio, structure
+    paths = _load_paths(a.pdbs, a.recursive)
+    if not paths:
+        sys.exit(f"[FAIL] no structures under {a.pdbs}")
+    prefix = a.index or (a.pdbs.rstrip("/") + "_folddisco")
+    ctx = fd.Context(a.device)
+    structs = []
+    for p in paths:
+        s = structure.read_compact_structure(p)
+        if s.num_residues_raw > 65535:  # DEFAULT_MAX_RESIDUE (controller/mod.rs:40,313-318): id kept, no hashes
+            print(f"[WARN] {p} has too many residues. Skipping", file=sys.stderr)
+            s = structure.build_compact([])
+        structs.append(s)
+    nres = np.array([s.n for s in structs], np.uint64)
+    plddt = np.array([s.avg_plddt() if s.n else 0.0 for s in structs], np.float32)
+    batch = ctx.upload(fd.PackedStructures.concat([s.as_item() for s in structs]))
+    ix = fd.FolddiscoIndex.build(ctx, batch, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid)
+    ix.save(prefix)
+    indexio.save_lookup(prefix + ".lookup", paths, nres, plddt)
+    indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance)
+    if a.verbose:
+        print(f"[DONE] {len(paths)} structures, {ix.num_hashes} hashes, {ix.value_len} value bytes -> {prefix}", file=sys.stderr)
+
+
+def cmd_query(a):
+    import folddisco_amd as fd
+    from folddisco_amd import indexio, query, structure
+    if not a.index:
+        sys.exit("[FAIL] -i/--index is required")
+    ctx = fd.Context(a.device)
+    v, h, o = indexio.read_index_files(a.index)
+    tids, nres, plddt, _ = indexio.load_lookup(a.index + ".lookup")
+    cfg = indexio.load_type(a.index + ".type")
+    ix = fd.FolddiscoIndex.load(ctx, h, o, v, len(tids))
+    if a.query.endswith((".txt", ".tsv")):
+        queries = []
+        for line in open(a.query):
+            p = line.rstrip("\n").split("\t")
+            queries.append((p[0], p[1] if len(p) > 1 else "", p[2] if len(p) > 2 else ""))
+    else:
+        queries = [(a.pdb, a.query, a.output)]
+    # candidate coordinates: resolve tids like resolve_tid_path_from_index_prefix (controller/io.rs:488-528)
+    def resolve(t):
+        if os.path.isfile(t):
+            return t
+        cand = os.path.join(os.path.dirname(os.path.abspath(a.index)), t)
+        return cand if os.path.isfile(cand) else t
+    db_structs, batch = None, None
+    if not a.skip_match:
+        db_structs = [structure.read_compact_structure(resolve(t)) for t in tids]
+        batch = ctx.upload(fd.PackedStructures.concat([s.as_item() for s in db_structs]))
+    dthr = [float(x) for x in a.distance.replace(" ", "").split(",") if x]
+    athr = [float(x) for x in a.angle.replace(" ", "").split(",") if x]
+    for pdb, qstr, outp in queries:
+        q = structure.read_compact_structure(pdb)
+        rows, matches = query.query_pdb(ctx, ix, batch, db_structs, tids, nres, plddt, q, qstr, dist_thr=dthr, angle_thr=athr,
+                                        ca_distance=a.ca_distance, top_n=a.top, skip_match=a.skip_match, serial_query=a.serial_index,
+                                        freq_filter=a.freq_filter, length_penalty_power=0.5 if a.length_penalty is None else a.length_penalty,
+                                        dist_cutoff=float(cfg.get("grid_width", 20.0)), nbin_dist=int(cfg.get("num_bin_dist", 0)),
+                                        nbin_angle=int(cfg.get("num_bin_angle", 0)))
+        fh = open(outp, "w") if outp else sys.stdout
+        if a.skip_match or a.per_structure:
+            if a.header:
+                fh.write("tid\tidf\ttotal_match_count\tnode_count\tedge_count\tmax_node_cov\tmin_rmsd\tnres\tplddt\tmatching_residues\tdb_key\tquery_residues\n")
+            rows.sort(key=lambda r: (-r["idf"], r["min_rmsd_with_max_match"]))   # StructureSortStrategy::default (sort.rs:453-458)
+            for r in rows:
+                fh.write(query.format_structure_row(r, qstr) + "\n")
+        else:
+            if a.header:
+                fh.write("tid\tnode_count\tidf\trmsd\tmatching_residues\tquery_residues\n")
+            for m in matches:
+                fh.write(query.format_match_row(m) + "\n")
+        if outp:
+            fh.close()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="folddisco_amd")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    pi = sub.add_parser("index")
+    pi.add_argument("-p", "--pdbs", required=True)
+    pi.add_argument("-i", "--index", default="")
+    pi.add_argument("-t", "--threads", type=int, default=1)            # accepted, unused: the GPU does the work
+    pi.add_argument("-y", "--type", default="default")
+    pi.add_argument("-d", "--distance", type=int, default=0)           # number of distance bins (0 -> 16), main.rs:38
+    pi.add_argument("-a", "--angle", type=int, default=0)              # number of angle bins (0 -> 4)
+    pi.add_argument("-g", "--grid", type=float, default=20.0)          # CA cutoff
+    pi.add_argument("-n", "--max-residue", type=int, default=50000)
+    pi.add_argument("-r", "--recursive", action="store_true")
+    pi.add_argument("-v", "--verbose", action="store_true")
+    pi.add_argument("--device", type=int, default=0)
+    pq = sub.add_parser("query")
+    pq.add_argument("-p", "--pdb", default="")
+    pq.add_argument("-q", "--query", default="")
+    pq.add_argument("-i", "--index", default="")
+    pq.add_argument("-t", "--threads", type=int, default=1)
+    pq.add_argument("-d", "--distance", default="0.5")
+    pq.add_argument("-a", "--angle", default="5")
+    pq.add_argument("--ca-distance", type=float, default=1.0)
+    pq.add_argument("--top", type=int, default=None)
+    pq.add_argument("--skip-match", action="store_true")
+    pq.add_argument("--per-structure", action="store_true")
+    pq.add_argument("--per-match", action="store_true")
+    pq.add_argument("--header", action="store_true")
+    pq.add_argument("--serial-index", action="store_true")
+    pq.add_argument("--freq-filter", type=float, default=None)
+    pq.add_argument("--length-penalty", type=float, default=None)
+    pq.add_argument("-o", "--output", default="")
+    pq.add_argument("-v", "--verbose", action="store_true")
+    pq.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    if a.cmd == "index":
+        if a.type not in ("default", "folddisco", "pdbtr", "PDBTrRosetta"):
+            sys.exit("[FAIL] only the default PDBTrRosetta encoding is implemented")
+        cmd_index(a)
+    else:
+        cmd_query(a)
+
+
+if __name__ == "__main__":
+    main()

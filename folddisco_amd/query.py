@@ -137,7 +137,7 @@ def retrieve(ctx: Context, db: Batch, resname_std, cand, qm: QueryMapResult, qba
 
 def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[CompactStructure], tids: list[str], nres, plddt,
               query: CompactStructure, query_string: str, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance=1.0, top_n=None,
-              length_penalty_power=0.5, skip_match=False, serial_query=False, freq_filter=None):
+              length_penalty_power=0.5, skip_match=False, serial_query=False, freq_filter=None, dist_cutoff=20.0, nbin_dist=0, nbin_angle=0):
     """The per-query body of query_pdb (src/cli/workflows/query_pdb.rs:348-519) with default filters.
     Returns (structure rows, match rows) as lists of dicts, sorted like the reference's default strategies."""
     S = len(tids)
@@ -152,7 +152,8 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
         idx = [query.get_index(int(query.chain[k]), int(query.serial[k])) for k in range(query.n)]
         subs = [None] * len(idx)
     qbatch = ctx.upload(PackedStructures.concat([query.as_item()]))
-    qm = make_query_map(ctx, qbatch, idx, subs, index, float(S), dist_thr, angle_thr)
+    qm = make_query_map(ctx, qbatch, idx, subs, index, float(S), dist_thr, angle_thr, nbin_dist=nbin_dist, nbin_angle=nbin_angle,
+                        dist_cutoff=dist_cutoff)
     pen = length_penalty(nres, length_penalty_power)
     rows = count_query(ctx, index, qm.hash, qm.qi, qm.qj, pen, total_structures=S, freq_filter=freq_filter)
     for r in rows:
@@ -165,11 +166,12 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
     if not skip_match and rows:
         std = np.concatenate([s.resname_std() for s in db_structs])
         cand = np.array([r["nid"] for r in rows], np.uint32)
-        ms = retrieve(ctx, db, std, cand, qm, qbatch, ca_distance)
+        ms = retrieve(ctx, db, std, cand, qm, qbatch, ca_distance, nbin_dist=nbin_dist, nbin_angle=nbin_angle, dist_cutoff=dist_cutoff)
         for m in ms:
             r = rows[m["cand"]]
             t = db_structs[r["nid"]]
             lab = lambda lst: ["_" if x < 0 else f"{chr(int(t.chain[x]))}{int(t.serial[x])}" for x in lst]
+            r.setdefault("match_strs", []).append(",".join(lab(m["processed"])) + ":%.4f" % m["rmsd"])
             m2 = dict(tid=r["tid"], nid=r["nid"], node_count=sum(x >= 0 for x in m["processed"]), idf=m["idf"], rmsd=m["rmsd"],
                       matching_residues=",".join(lab(m["processed"])), query_residues=res_chain_to_string(qres) if qres else query_string)
             r["matches"].append(m2)
@@ -189,3 +191,11 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
 def format_match_row(m) -> str:
     """default per-match columns (result.rs:331-339), floats {:.4}"""
     return "\t".join([m["tid"], str(m["node_count"]), "%.4f" % m["idf"], "%.4f" % m["rmsd"], m["matching_residues"], m["query_residues"]])
+
+
+def format_structure_row(r, query_residues: str) -> str:
+    """default per-structure columns (result.rs:301-314), floats {:.4}"""
+    ms = ";".join(r.get("match_strs", [])) or "NA"
+    return "\t".join([r["tid"], "%.4f" % r["idf"], str(r["total_match_count"]), str(r["node_count"]), str(r["edge_count"]),
+                      str(r["max_matching_node_count"]), "%.4f" % r["min_rmsd_with_max_match"], str(r["nres"]), "%.4f" % r["plddt"], ms,
+                      str(r["db_key"]), query_residues])
