@@ -1,5 +1,7 @@
 """End-to-end on the GPU through the product path only (host ingest -> C ABI -> kernels), checked against the
 reference's README rows (G2) and against the oracle for the intermediate products."""
+import os
+
 import numpy as np
 import pytest
 
