@@ -167,19 +167,19 @@ def test_cli_index_and_query_reproduce_readme(tmp_path):
     assert os.path.getsize(pre) == 225674 and os.path.getsize(pre + ".offset") == 2611360
     out = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", pre, "--header"],
                          cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
-    assert out[0] == "tid\\tnode_count\\tidf\\trmsd\\tmatching_residues\\tquery_residues"
+    assert out[0] == "tid\tnode_count\tidf\trmsd\tmatching_residues\tquery_residues"
     assert out[1:] == [
-        "data/serine_peptidases/4cha.pdb\\t3\\t8.7616\\t0.0000\\tB57,B102,C195\\tB57,B102,C195",
-        "data/serine_peptidases/4cha.pdb\\t3\\t8.7616\\t0.0874\\tF57,F102,G195\\tB57,B102,C195",
-        "data/serine_peptidases/1pq5.pdb\\t3\\t4.1178\\t0.2609\\tA56,A99,A195\\tB57,B102,C195",
-        "data/serine_peptidases/1ju3.pdb\\t2\\t1.4739\\t0.7792\\t_,A223,A234\\tB57,B102,C195",
-        "data/serine_peptidases/1l7a.pdb\\t2\\t1.4739\\t0.7883\\t_,A146,A127\\tB57,B102,C195",
-        "data/serine_peptidases/1l7a.pdb\\t2\\t1.4739\\t0.8078\\t_,B146,B127\\tB57,B102,C195",
+        "data/serine_peptidases/4cha.pdb\t3\t8.7616\t0.0000\tB57,B102,C195\tB57,B102,C195",
+        "data/serine_peptidases/4cha.pdb\t3\t8.7616\t0.0874\tF57,F102,G195\tB57,B102,C195",
+        "data/serine_peptidases/1pq5.pdb\t3\t4.1178\t0.2609\tA56,A99,A195\tB57,B102,C195",
+        "data/serine_peptidases/1ju3.pdb\t2\t1.4739\t0.7792\t_,A223,A234\tB57,B102,C195",
+        "data/serine_peptidases/1l7a.pdb\t2\t1.4739\t0.7883\t_,A146,A127\tB57,B102,C195",
+        "data/serine_peptidases/1l7a.pdb\t2\t1.4739\t0.8078\t_,B146,B127\tB57,B102,C195",
     ]
     ps = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", pre, "--per-structure"],
                         cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
     # README.md:237-240 (the 1azw row's match columns are stale)
-    assert ps[0] == "data/serine_peptidases/4cha.pdb\\t0.6138\\t8\\t3\\t6\\t3\\t0.0000\\t477\\t13.5404\\tB57,B102,C195:0.0000;F57,F102,G195:0.0874\\t4\\tB57,B102,C195"
-    assert ps[1] == "data/serine_peptidases/1pq5.pdb\\t0.4869\\t4\\t3\\t4\\t3\\t0.2609\\t224\\t5.1340\\tA56,A99,A195:0.2609\\t3\\tB57,B102,C195"
-    assert "data/serine_peptidases/1ju3.pdb\\t0.0617\\t2\\t2\\t2\\t2\\t0.7792\\t570\\t19.4881\\t_,A223,A234:0.7792\\t1\\tB57,B102,C195" in ps
-    assert "data/serine_peptidases/1l7a.pdb\\t0.0584\\t2\\t2\\t2\\t2\\t0.7883\\t636\\t11.7037\\t_,A146,A127:0.7883;_,B146,B127:0.8078\\t2\\tB57,B102,C195" in ps
+    assert ps[0] == "data/serine_peptidases/4cha.pdb\t0.6138\t8\t3\t6\t3\t0.0000\t477\t13.5404\tB57,B102,C195:0.0000;F57,F102,G195:0.0874\t4\tB57,B102,C195"
+    assert ps[1] == "data/serine_peptidases/1pq5.pdb\t0.4869\t4\t3\t4\t3\t0.2609\t224\t5.1340\tA56,A99,A195:0.2609\t3\tB57,B102,C195"
+    assert "data/serine_peptidases/1ju3.pdb\t0.0617\t2\t2\t2\t2\t0.7792\t570\t19.4881\t_,A223,A234:0.7792\t1\tB57,B102,C195" in ps
+    assert "data/serine_peptidases/1l7a.pdb\t0.0584\t2\t2\t2\t2\t0.7883\t636\t11.7037\t_,A146,A127:0.7883;_,B146,B127:0.8078\t2\tB57,B102,C195" in ps
