@@ -278,3 +278,30 @@ def count_query(ctx: Context, index: FolddiscoIndex, q_hash, q_node, q_edge_j, p
         return arr
     return [dict(nid=int(r["nid"]), total_match_count=int(r["total_match_count"]), node_count=int(r["node_count"]),
                  edge_count=int(r["edge_count"]), idf=float(r["idf"])) for r in arr]
+
+
+def count_query_batch(ctx: Context, index: FolddiscoIndex, queries, penalty: np.ndarray, total_structures: int | None = None):
+    """queries: list of (q_hash, q_node, q_edge_j) arrays.  One posting-length launch + one scoring pass for the whole
+    batch.  Returns a list of REC_DTYPE arrays (ascending nid), one per query."""
+    S = index.n_structures if total_structures is None else total_structures
+    qh = np.ascontiguousarray(np.concatenate([np.asarray(q[0], np.uint32) for q in queries]) if queries else np.zeros(0, np.uint32))
+    qn = np.ascontiguousarray(np.concatenate([np.asarray(q[1], np.uint32) for q in queries]) if queries else np.zeros(0, np.uint32))
+    qe = np.ascontiguousarray(np.concatenate([np.asarray(q[2], np.uint32) for q in queries]) if queries else np.zeros(0, np.uint32))
+    lens_all = index.posting_lengths(qh)
+    idf = idf_of_lengths(lens_all, S).astype(np.float32)
+    keep = lens_all > 0
+    qid = np.repeat(np.arange(len(queries)), [len(q[0]) for q in queries])
+    kept_per_q = np.bincount(qid[keep], minlength=len(queries))
+    q_off = np.concatenate([[0], np.cumsum(kept_per_q)]).astype(np.uint64)
+    qh, qn, qe, idf = (np.ascontiguousarray(a[keep]) for a in (qh, qn, qe, idf))
+    pen = np.ascontiguousarray(penalty, dtype=np.float32)
+    out = C.POINTER(CountRec)()
+    ooff = u64p()
+    ctx.check(ctx.L.fdgpu_count_query_batch(ctx.h, index.h, len(queries), _ptr(q_off, u64p), _ptr(qh, u32p), _ptr(qn, u32p), _ptr(qe, u32p),
+                                            _ptr(idf, f32p), _ptr(pen, f32p), C.byref(out), C.byref(ooff)))
+    off = np.ctypeslib.as_array(ooff, shape=(len(queries) + 1,)).copy()
+    n = int(off[-1])
+    arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n, 1) * 20,))[: n * 20].copy().view(REC_DTYPE)
+    ctx.L.fdgpu_free(out)
+    ctx.L.fdgpu_free(ooff)
+    return [arr[int(off[t]): int(off[t + 1])] for t in range(len(queries))]

@@ -613,6 +613,109 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     return FDGPU_OK;
 }
 
+// batched count_query: queries [q_off[t], q_off[t+1]) of the concatenated hash arrays; results of query t are
+// (*out)[(*out_off)[t] .. (*out_off)[t+1])
+extern "C" int fdgpu_count_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
+                                       const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty,
+                                       fd_count_rec **out, uint64_t **out_off) {
+    if (!c || !ix || !out || !out_off || !q_off || (ix->n_structures && !penalty)) return FDGPU_EINVAL;
+    *out = nullptr; *out_off = nullptr;
+    reset_timings(c);
+    hipStream_t st = c->stream;
+    const uint64_t S = ix->n_structures, nq = q_off[n_queries];
+    uint64_t *ooff = (uint64_t *)calloc(n_queries + 1, 8);
+    if (!ooff) return FDGPU_ENOMEM;
+    if (S == 0 || nq == 0 || n_queries == 0) { *out = (fd_count_rec *)malloc(sizeof(fd_count_rec)); *out_off = ooff; return *out ? FDGPU_OK : FDGPU_ENOMEM; }
+    if (!q_hash || !q_node || !q_edge_j || !q_idf) { free(ooff); return FDGPU_EINVAL; }
+    if (S >= 0xffffffe0ull || n_queries * S >= (1ull << 34)) { free(ooff); FAIL(c, FDGPU_ERANGE, "count_query_batch: n_queries x n_structures too large; split the batch"); }
+    // global row numbering of the occupancy matrices: per query, its distinct nodes then its distinct edges
+    std::vector<uint32_t> nrow(nq), erow(nq), qq(nq), row_off(4 * n_queries);
+    std::vector<uint64_t> idf_fix(nq);
+    uint32_t n_node_rows = 0, n_edge_rows = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        uint64_t a = q_off[t], b = q_off[t + 1];
+        std::vector<uint32_t> nodes(q_node + a, q_node + b);
+        std::sort(nodes.begin(), nodes.end());
+        nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+        std::vector<uint64_t> edges(b - a);
+        for (uint64_t k = a; k < b; ++k) edges[k - a] = ((uint64_t)q_node[k] << 32) | q_edge_j[k];
+        std::sort(edges.begin(), edges.end());
+        edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+        for (uint64_t k = a; k < b; ++k) {
+            nrow[k] = n_node_rows + (uint32_t)(std::lower_bound(nodes.begin(), nodes.end(), q_node[k]) - nodes.begin());
+            erow[k] = n_edge_rows + (uint32_t)(std::lower_bound(edges.begin(), edges.end(), ((uint64_t)q_node[k] << 32) | q_edge_j[k]) - edges.begin());
+            qq[k] = (uint32_t)t;
+            double v = (double)q_idf[k];
+            idf_fix[k] = (v > 0.0 && v < 1.0e6) ? (uint64_t)(v * 1099511627776.0 + 0.5) : 0ull;
+        }
+        row_off[4 * t] = n_node_rows; row_off[4 * t + 1] = n_node_rows + (uint32_t)nodes.size();
+        row_off[4 * t + 2] = n_edge_rows; row_off[4 * t + 3] = n_edge_rows + (uint32_t)edges.size();
+        n_node_rows += (uint32_t)nodes.size(); n_edge_rows += (uint32_t)edges.size();
+    }
+    const uint32_t words = (uint32_t)((S + 31) / 32);
+    const uint64_t QS = n_queries * S;
+    hipError_t e = hipSuccess;
+    auto need = [&](int w, size_t bytes) { if (e == hipSuccess) e = c->ws[w].ensure(bytes); };
+    need(WS_MISC0, nq * 4); need(WS_MISC1, nq * 4); need(WS_MISC2, nq * 4); need(WS_MISC3, nq * 8); need(WS_TILE_B, nq * 4);
+    need(WS_TILE_H, n_queries * 16 + 16); need(WS_COUNTS, QS * 4); need(WS_SEGOFF, QS * 8 + 16);
+    need(WS_KEYS_A, (size_t)std::max<uint32_t>(n_node_rows, 1) * words * 4); need(WS_KEYS_B, (size_t)std::max<uint32_t>(n_edge_rows, 1) * words * 4);
+    need(WS_IDS_A, QS * 4); need(WS_IDS_B, QS * 4); need(WS_MISC4, QS + 8); need(WS_TILE_BO, (QS + 2) * 8); need(WS_MISC5, S * 4);
+    need(WS_SCANTMP, fd_scan_tmp_elems(QS) * 8 + 64); need(WS_TOTAL, 64);
+    if (e != hipSuccess) { free(ooff); c->err = std::string("count_query_batch workspace: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+    (void)hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(c->ws[WS_MISC1].p, nrow.data(), nq * 4, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(c->ws[WS_MISC2].p, erow.data(), nq * 4, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(c->ws[WS_MISC3].p, idf_fix.data(), nq * 8, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(c->ws[WS_TILE_B].p, qq.data(), nq * 4, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(c->ws[WS_TILE_H].p, row_off.data(), n_queries * 16, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st);
+    (void)hipMemsetAsync(c->ws[WS_COUNTS].p, 0, QS * 4, st);
+    (void)hipMemsetAsync(c->ws[WS_SEGOFF].p, 0, QS * 8, st);
+    (void)hipMemsetAsync(c->ws[WS_KEYS_A].p, 0, (size_t)std::max<uint32_t>(n_node_rows, 1) * words * 4, st);
+    (void)hipMemsetAsync(c->ws[WS_KEYS_B].p, 0, (size_t)std::max<uint32_t>(n_edge_rows, 1) * words * 4, st);
+    cq_args A;
+    A.hashes = ix->hashes; A.offsets = ix->offsets; A.value = ix->value; A.H = ix->n_hashes;
+    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.q_node_idx = c->ws[WS_MISC1].as<uint32_t>(); A.q_edge_idx = c->ws[WS_MISC2].as<uint32_t>();
+    A.q_idf_fix = c->ws[WS_MISC3].as<uint64_t>(); A.nq = nq;
+    A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>();
+    A.node_bits = c->ws[WS_KEYS_A].as<uint32_t>(); A.edge_bits = c->ws[WS_KEYS_B].as<uint32_t>();
+    A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
+    {
+        StageTimer t(c, "cq_batch", 0);
+        fd_launch_cq_batch(A, c->ws[WS_TILE_B].as<uint32_t>(), (uint32_t)n_queries, c->ws[WS_TILE_H].as<uint32_t>(), c->ws[WS_IDS_A].as<uint32_t>(),
+                           c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), st);
+        fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), QS, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
+                                   c->ws[WS_TOTAL].as<uint64_t>(), st);
+    }
+    uint64_t n = 0;
+    int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &n);
+    if (rc) { free(ooff); return rc; }
+    fd_count_rec *r = (fd_count_rec *)malloc(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec));
+    if (!r) { free(ooff); return FDGPU_ENOMEM; }
+    e = c->ws[WS_TILE_HO].ensure(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec));
+    if (e == hipSuccess) e = c->ws[WS_TILE_PO].ensure((n_queries + 1) * 8 + 64);
+    if (e == hipSuccess) {
+        fd_launch_cq_compact_batch(A, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(),
+                                   c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_MISC5].as<float>(), QS, c->ws[WS_TILE_HO].p, st);
+        // out_off[t] = scan position at t * S
+        std::vector<uint64_t> idx(n_queries + 1);
+        for (uint64_t t = 0; t <= n_queries; ++t) idx[t] = t * S;
+        e = c->ws[WS_MISC1].ensure((n_queries + 1) * 8);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->ws[WS_MISC1].p, idx.data(), (n_queries + 1) * 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            fd_launch_gather_u64(c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_MISC1].as<uint64_t>(), n_queries + 1, c->ws[WS_TILE_PO].as<uint64_t>(), st);
+            e = hipMemcpyAsync(ooff, c->ws[WS_TILE_PO].p, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);   // idx must outlive the copy
+    }
+    if (e == hipSuccess && n) e = hipMemcpyAsync(r, c->ws[WS_TILE_HO].p, n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { free(r); free(ooff); c->err = std::string("count_query_batch: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+    *out = r; *out_off = ooff;
+    return FDGPU_OK;
+}
+
 // ---- S4 ---------------------------------------------------------------------------------------------------------------
 extern "C" int fdgpu_match_pairs(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
                                  const fd_match_query *q, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,

@@ -18,6 +18,7 @@
 #include "fdgpu_internal.h"
 
 #define IDF_SCALE 1099511627776.0 /* 2^40 */
+struct fd_count_rec_dev { uint32_t nid, total_match_count, node_count, edge_count; float idf; };
 
 __device__ __forceinline__ int64_t find_hash(const uint32_t *__restrict__ hashes, uint64_t H, uint32_t h) {
     uint64_t lo = 0, hi = H;
@@ -152,7 +153,6 @@ __global__ __launch_bounds__(256) void k_cq_finalize(const uint32_t *__restrict_
     }
 }
 
-struct fd_count_rec_dev { uint32_t nid, total_match_count, node_count, edge_count; float idf; };
 
 __global__ __launch_bounds__(256) void k_cq_compact(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ idf,
                                                     const uint32_t *__restrict__ node_cnt, const uint32_t *__restrict__ edge_cnt,
@@ -169,6 +169,124 @@ __global__ __launch_bounds__(256) void k_cq_compact(const uint32_t *__restrict__
     float sum = (float)((double)idf[nid] * (1.0 / IDF_SCALE));
     r.idf = sum * penalty[nid];  // count_query.rs:200 idf_sum *= nres^(-lp)
     out[pos[nid]] = r;
+}
+
+// ------------------------------------------------------------------ batched scoring (many queries, one launch each)
+// Same arithmetic as above; query hash k belongs to query A.q_query[k]; accumulators are [n_queries][S], the
+// occupancy bit matrix has one row per (query, node) and per (query, edge) (A.q_node_idx / q_edge_idx are global rows).
+__global__ __launch_bounds__(FD_WAVE) void k_cq_accumulate_batch(cq_args A, const uint32_t *__restrict__ q_query) {
+    uint64_t q = blockIdx.x;
+    if (q >= A.nq) return;
+    int64_t k = find_hash(A.hashes, A.H, A.q_hash[q]);
+    if (k < 0) return;
+    const uint64_t b0 = A.offsets[k], b1 = A.offsets[k + 1];
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long idf_fix = A.q_idf_fix[q];
+    const uint64_t qbase = (uint64_t)q_query[q] * A.S;
+    uint32_t *match = A.match + qbase;
+    unsigned long long *idf = A.idf + qbase;
+    uint32_t *nb = A.node_bits + (uint64_t)A.q_node_idx[q] * A.words;
+    uint32_t *eb = A.edge_bits + (uint64_t)A.q_edge_idx[q] * A.words;
+    uint32_t run_id = 0, carry_val = 0, carry_shift = 0;
+    bool have_first = false;
+    for (uint64_t base = b0; base < b1; base += FD_WAVE) {
+        uint64_t p = base + lane;
+        bool in = p < b1;
+        uint32_t byte = in ? A.value[p] : 0x80u;
+        bool term = in && !(byte & 0x80u);
+        uint64_t tm = __ballot(term);
+        uint64_t below = tm & ((1ull << lane) - 1ull);
+        int prev_t = below ? 63 - __clzll(below) : -1;
+        uint32_t len_here = lane - (uint32_t)(prev_t + 1) + 1;
+        uint32_t v = 0, pay = byte & 0x7fu;
+#pragma unroll
+        for (int back = 4; back >= 0; --back) {
+            uint32_t pb = __shfl(pay, (int)lane - back, FD_WAVE);
+            if ((uint32_t)back < len_here) v |= pb << (7u * (len_here - 1u - (uint32_t)back));
+        }
+        if (term && prev_t < 0) v = carry_val | (v << carry_shift);
+        uint32_t s2 = term ? v : 0u;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(s2, off, FD_WAVE);
+            if ((int)lane >= off) s2 += t;
+        }
+        uint32_t id = (have_first ? run_id : 0u) + s2;
+        if (term) {
+            uint32_t rel = id - A.first_id;
+            if (id >= A.first_id && rel < A.S) {
+                atomicAdd(&match[rel], 1u);
+                atomicAdd(&idf[rel], idf_fix);
+                atomicOr(&nb[rel >> 5], 1u << (rel & 31u));
+                atomicOr(&eb[rel >> 5], 1u << (rel & 31u));
+            }
+        }
+        if (tm) {
+            int last_t = 63 - __clzll(tm);
+            run_id = __shfl(id, last_t, FD_WAVE);
+            have_first = true;
+            uint32_t tail = 63u - (uint32_t)last_t, pv = 0;
+            for (uint32_t t2 = 0; t2 < tail && t2 < 5; ++t2) pv |= __shfl(pay, last_t + 1 + (int)t2, FD_WAVE) << (7u * t2);
+            carry_val = pv;
+            carry_shift = 7u * tail;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cq_finalize_batch(const uint32_t *__restrict__ match, const uint32_t *__restrict__ node_bits,
+                                                           const uint32_t *__restrict__ edge_bits, const uint32_t *__restrict__ row_off /*[4*nQ]: n0,n1,e0,e1*/,
+                                                           uint32_t words, uint32_t S, uint32_t *__restrict__ node_cnt,
+                                                           uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t qy = blockIdx.y;
+    if (w >= words) return;
+    const uint32_t n0 = row_off[4 * qy], n1 = row_off[4 * qy + 1], e0 = row_off[4 * qy + 2], e1 = row_off[4 * qy + 3];
+    uint32_t any = 0, pn[20], pe[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) { pn[k] = 0; pe[k] = 0; }
+    for (uint32_t n = n0; n < n1; ++n) { uint32_t x = node_bits[(uint64_t)n * words + w]; any |= x; sliced_add(pn, x); }
+    if (any) for (uint32_t e = e0; e < e1; ++e) sliced_add(pe, edge_bits[(uint64_t)e * words + w]);
+    const uint64_t qbase = (uint64_t)qy * S;
+    for (uint32_t b = 0; b < 32; ++b) {
+        uint32_t nid = w * 32 + b;
+        if (nid >= S) break;
+        uint32_t nc = 0, ec = 0;
+#pragma unroll
+        for (int k = 0; k < 20; ++k) { nc |= ((pn[k] >> b) & 1u) << k; ec |= ((pe[k] >> b) & 1u) << k; }
+        node_cnt[qbase + nid] = nc;
+        edge_cnt[qbase + nid] = ec;
+        flags[qbase + nid] = match[qbase + nid] > 0 ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cq_compact_batch(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ idf,
+                                                          const uint32_t *__restrict__ node_cnt, const uint32_t *__restrict__ edge_cnt,
+                                                          const uint8_t *__restrict__ flags, const uint64_t *__restrict__ pos,
+                                                          const float *__restrict__ penalty, uint32_t S, uint64_t total, uint32_t first_id,
+                                                          fd_count_rec_dev *__restrict__ out) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total || !flags[g]) return;
+    uint32_t nid = (uint32_t)(g % S);
+    fd_count_rec_dev r;
+    r.nid = nid + first_id;
+    r.total_match_count = match[g];
+    r.node_count = node_cnt[g];
+    r.edge_count = edge_cnt[g];
+    float sum = (float)((double)idf[g] * (1.0 / IDF_SCALE));
+    r.idf = sum * penalty[nid];
+    out[pos[g]] = r;
+}
+
+void fd_launch_cq_batch(const cq_args &A, const uint32_t *q_query, uint32_t n_queries, const uint32_t *row_off, uint32_t *node_cnt, uint32_t *edge_cnt,
+                        uint8_t *flags, hipStream_t st) {
+    if (A.nq) hipLaunchKernelGGL(k_cq_accumulate_batch, dim3((unsigned)A.nq), dim3(FD_WAVE), 0, st, A, q_query);
+    if (A.words && n_queries)
+        hipLaunchKernelGGL(k_cq_finalize_batch, dim3((A.words + 255) / 256, n_queries), dim3(256), 0, st, A.match, A.node_bits, A.edge_bits, row_off,
+                           A.words, A.S, node_cnt, edge_cnt, flags);
+}
+void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, const uint32_t *edge_cnt, const uint8_t *flags, const uint64_t *pos,
+                                const float *penalty, uint64_t total, void *out, hipStream_t st) {
+    if (total) hipLaunchKernelGGL(k_cq_compact_batch, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A.match, A.idf, node_cnt, edge_cnt, flags,
+                                  pos, penalty, A.S, total, A.first_id, (fd_count_rec_dev *)out);
 }
 
 void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,

@@ -25,9 +25,18 @@ def shard_range(rank: int, world: int, n_structures: int):
 def rank_hits(recs: np.ndarray, top_n: int | None = None) -> np.ndarray:
     """idf descending, ties by ascending nid (= the reference's stable sort over nid-ordered input,
     src/cli/workflows/query_pdb.rs:404-411)"""
-    order = np.lexsort((recs["nid"], -recs["idf"].astype(np.float64)))
-    out = recs[order]
-    return out if top_n is None else out[:top_n]
+    if len(recs) == 0:
+        return recs
+    # one u64 key per record: order-preserving image of the f32 idf (inverted for descending) above the nid
+    b = (recs["idf"] + np.float32(0.0)).view(np.uint32)
+    ordered = np.where(b & np.uint32(0x80000000), ~b, b | np.uint32(0x80000000))
+    key = ((~ordered).astype(np.uint64) << np.uint64(32)) | recs["nid"].astype(np.uint64)
+    if top_n is not None and top_n < len(recs):
+        part = np.argpartition(key, top_n)[:top_n]
+        order = part[np.argsort(key[part], kind="stable")]
+    else:
+        order = np.argsort(key, kind="stable")
+    return recs[order]
 
 
 def records_from_rows(rows) -> np.ndarray:

@@ -128,6 +128,12 @@ int fdgpu_count_query(fdgpu_ctx *ctx, const fdgpu_index *ix, const uint32_t *q_h
                       const uint32_t *q_edge_j, const float *q_idf, uint64_t n_q, const float *penalty,
                       fd_count_rec **out, uint64_t *n_out);
 
+/* Batched form: n_queries queries scored in one set of launches.  Query t owns entries [q_off[t], q_off[t+1]) of the
+ * concatenated q_* arrays; its results are (*out)[(*out_off)[t] .. (*out_off)[t+1]) (ascending nid). */
+int fdgpu_count_query_batch(fdgpu_ctx *ctx, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off,
+                            const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf,
+                            const float *penalty, fd_count_rec **out, uint64_t **out_off);
+
 /* ---- S4: candidate matching + RMSD --------------------------------------------------------------
  * Pair scan of retrieve_with_prefilter (src/controller/retrieve.rs:52-156) over candidate
  * structures of a resident batch.  For candidate c = cand[k] every ordered residue pair (i,j)

@@ -244,3 +244,33 @@ def test_index_build_medium_multitile(ctx):
     # per-structure API agrees as well
     gh, goff = fd.get_geometric_hash_as_u32(ctx, batch, sort_dedup=True)
     assert np.array_equal(goff, off) and np.array_equal(gh, h)
+
+
+@pytest.mark.gpu
+def test_count_query_batch_equals_single(ctx):
+    """fdgpu_count_query_batch == fdgpu_count_query per query (same records, same order), incl. an empty query and
+    a query with only absent hashes."""
+    import folddisco_amd as fd
+    from folddisco_amd import synth
+    ps = synth.to_packed(synth.generate(300, seed=77))
+    batch = ctx.upload(ps)
+    ix = fd.FolddiscoIndex.build(ctx, batch, first_id=5)
+    hashes, _, _ = ix.export()[1], None, None
+    rng = np.random.Generator(np.random.PCG64(5))
+    nres = np.diff(ps.res_off).astype(np.uint64)
+    pen = fd.length_penalty(nres, 0.5)
+    queries = []
+    for t in range(9):
+        n = int(rng.integers(1, 40))
+        qh = rng.choice(hashes, size=n, replace=False).astype(np.uint32)
+        qi = rng.integers(0, 5, size=n).astype(np.uint32)
+        qj = rng.integers(0, 5, size=n).astype(np.uint32)
+        queries.append((qh, qi, qj))
+    queries.insert(3, (np.zeros(0, np.uint32),) * 3)
+    queries.insert(6, (np.array([0x3fffffff, 0x3ffffffe], np.uint32), np.array([0, 1], np.uint32), np.array([1, 0], np.uint32)))
+    got = fd.count_query_batch(ctx, ix, queries, pen, total_structures=300)
+    assert len(got) == len(queries)
+    for (qh, qi, qj), g in zip(queries, got):
+        want = fd.count_query(ctx, ix, qh, qi, qj, pen, total_structures=300, as_array=True)
+        assert g.tobytes() == want.tobytes()
+    assert len(got[3]) == 0 and len(got[6]) == 0
