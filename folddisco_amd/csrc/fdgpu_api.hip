@@ -267,12 +267,13 @@ static int sort_pairs(fdgpu_ctx *c, uint32_t *ka, uint32_t *va, uint32_t *kb, ui
     return fd_onesweep_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_OSDESC].as<unsigned long long>(), gh, (uint32_t *)(gh + 4 * 256), c->stream, c);
 }
 static int sort_mode() {
-    // FDGPU_SORT = onesweep | classic0..classic3 (default classic1: 256x16 tiles, XCD-aware tile order; measured fastest)
+    // FDGPU_SORT = onesweep | classic0..classic15 (default classic18: 512x16 tiles, XCD-aware tile order, atomics-free
+    // rank-first VALU-lean scatter; measured fastest, see k_sort.hip radix_sort_pairs_t for the list)
     static const int mode = [] {
         const char *e = getenv("FDGPU_SORT");
         if (e && !strcmp(e, "onesweep")) return -1;
-        if (e && !strncmp(e, "classic", 7) && e[7] >= '0' && e[7] <= '9') return e[7] - '0';
-        return 1;
+        if (e && !strncmp(e, "classic", 7) && e[7] >= '0' && e[7] <= '9') return atoi(e + 7);
+        return 18;
     }();
     if (mode >= 0) fd_rs_set_variant(mode);
     return mode;

@@ -114,6 +114,11 @@ __global__ __launch_bounds__(256) void k_frames(fd_batch_view B, uint32_t n_res,
     frames[r] = F;
 }
 
+// wave-uniform lane index -> v_readlane_b32 (SGPR broadcast), not the ds_bpermute a general __shfl becomes
+__device__ __forceinline__ float bcast_lane(float v, uint32_t k) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)k));
+}
+
 __global__ __launch_bounds__(FD_WAVE) void k_pair_count2(fd_batch_view B, fd_hash_consts C, uint32_t *__restrict__ counts) {
     uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
     if (w >= B.n_work) return;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_count2(fd_batch_view B, fd_has
         const uint32_t nj = (r1 - jb) < FD_WAVE ? (r1 - jb) : FD_WAVE;
         for (uint32_t k = 0; k < nj; ++k) {
             if (!((okm >> k) & 1ull)) continue;  // wave-uniform
-            fd_v3 caj = {__shfl(cj.x, (int)k, FD_WAVE), __shfl(cj.y, (int)k, FD_WAVE), __shfl(cj.z, (int)k, FD_WAVE)};
+            fd_v3 caj = {bcast_lane(cj.x, k), bcast_lane(cj.y, k), bcast_lane(cj.z, k)};
             float d2 = fd_dist2(cai, caj);
             cnt += (vi && (jb + k) > i && !(d2 > C.d2_max)) ? 2u : 0u;
         }
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_emit2(fd_batch_view B, const f
         for (uint32_t k = 0; k < nj; ++k) {
             const bool last = last_block && k + 1 == nj;
             if ((okm >> k) & 1ull) {  // wave-uniform
-                fd_v3 caj = {__shfl(cj.x, (int)k, FD_WAVE), __shfl(cj.y, (int)k, FD_WAVE), __shfl(cj.z, (int)k, FD_WAVE)};
+                fd_v3 caj = {bcast_lane(cj.x, k), bcast_lane(cj.y, k), bcast_lane(cj.z, k)};
                 float d2 = fd_dist2(cai, caj);
                 const uint32_t j = jb + k;
                 bool pass = vi && j > i && !(d2 > C.d2_max);

@@ -263,6 +263,314 @@ __global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint32_t *__restri
     }
 }
 
+// Variant without LDS atomics: the ballot multi-split runs FIRST and yields each element's running rank among the
+// wave's keys of the same digit (leader lane keeps the per-wave digit counter), the cross-wave digit starts are
+// scanned afterwards and added when the element is placed.
+template <int THREADS, int ITEMS, bool XCD, typename V>
+__global__ __launch_bounds__(THREADS) void k_rs_scatter2(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                                         uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n,
+                                                         uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
+                                                         const uint64_t *__restrict__ dbase) {
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / 64;
+    __shared__ uint32_t s_keys[TILE];
+    __shared__ V s_vals[TILE];
+    __shared__ uint32_t s_cnt[WAVES][RS_BINS];
+    __shared__ long long s_gofs[RS_BINS];
+    __shared__ uint64_t sm[17];
+
+    const uint32_t tile = XCD ? fd_xcd_remap(blockIdx.x, nb) : blockIdx.x;
+    if (tile >= nb) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint64_t tile_base = (uint64_t)tile * TILE;
+    const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * ITEMS);
+    const uint32_t n_tile = (uint32_t)((n - tile_base) < TILE ? (n - tile_base) : TILE);
+
+    for (int k = tid; k < WAVES * RS_BINS; k += THREADS) (&s_cnt[0][0])[k] = 0;
+    uint32_t key[ITEMS];
+    V val[ITEMS];
+#pragma unroll
+    for (int c = 0; c < ITEMS; ++c) {
+        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
+        bool ok = idx < n;
+        key[c] = ok ? keys_in[idx] : 0xffffffffu;
+        val[c] = ok ? vals_in[idx] : (V)0;
+    }
+    __syncthreads();
+    uint16_t rnk[ITEMS];
+    uint32_t *cnt = s_cnt[wid];
+#pragma unroll
+    for (int c = 0; c < ITEMS; ++c) {
+        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
+        bool ok = idx < n;
+        uint32_t d = (key[c] >> shift) & mask;
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            uint64_t bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        uint32_t rank = fd_mbcnt(peers);
+        uint32_t pcount = (uint32_t)__popcll(peers);
+        uint32_t base = ok ? cnt[d] : 0u;
+        // in-order LDS within the wave: all reads above precede the leader's update
+        if (ok && rank == pcount - 1) cnt[d] = base + pcount;
+        rnk[c] = (uint16_t)(base + rank);
+    }
+    __syncthreads();
+    {
+        uint32_t my_total = 0;
+        if (tid < RS_BINS) {
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) my_total += s_cnt[w][tid];
+        }
+        uint64_t tot;
+        uint32_t dstart = (uint32_t)block_excl_scan_u64(tid < RS_BINS ? (uint64_t)my_total : 0ull, sm, &tot);
+        if (tid < RS_BINS) {
+            uint32_t run = dstart;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) { uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
+            s_gofs[tid] = (long long)(dbase[tid] + ghist[(uint64_t)tid * nb + tile]) - (long long)dstart;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ITEMS; ++c) {
+        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
+        if (idx < n) {
+            uint32_t pos = cnt[(key[c] >> shift) & mask] + rnk[c];
+            s_keys[pos] = key[c];
+            s_vals[pos] = val[c];
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < n_tile; k += THREADS) {
+        uint32_t kk = s_keys[k];
+        long long g = (long long)k + s_gofs[(kk >> shift) & mask];
+        keys_out[g] = kk;
+        vals_out[g] = s_vals[k];
+    }
+}
+
+// As k_rs_scatter2 with 16-bit per-wave counters and the global digit offsets aliased onto the counter array once the
+// placement is done: 52.1 KiB of LDS per 512x16 tile -> three workgroups per CU instead of two.
+template <int THREADS, int ITEMS, typename V>
+__global__ __launch_bounds__(THREADS) void k_rs_scatter3(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                                         uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n,
+                                                         uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
+                                                         const uint64_t *__restrict__ dbase) {
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / 64;
+    static_assert(TILE <= 65535 && WAVES * RS_BINS * 2 >= RS_BINS * 8, "u16 counters / gofs alias");
+    __shared__ uint32_t s_keys[TILE];
+    __shared__ V s_vals[TILE];
+    __shared__ __attribute__((aligned(8))) uint16_t s_cnt[WAVES][RS_BINS];
+    __shared__ uint64_t sm[17];
+    long long *s_gofs = reinterpret_cast<long long *>(&s_cnt[0][0]);
+
+    const uint32_t tile = fd_xcd_remap(blockIdx.x, nb);
+    if (tile >= nb) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint64_t tile_base = (uint64_t)tile * TILE;
+    const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * ITEMS);
+    const uint32_t n_tile = (uint32_t)((n - tile_base) < TILE ? (n - tile_base) : TILE);
+
+    for (int k = tid; k < WAVES * RS_BINS / 2; k += THREADS) reinterpret_cast<uint32_t *>(&s_cnt[0][0])[k] = 0;
+    uint32_t key[ITEMS];
+    V val[ITEMS];
+#pragma unroll
+    for (int c = 0; c < ITEMS; ++c) {
+        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
+        bool ok = idx < n;
+        key[c] = ok ? keys_in[idx] : 0xffffffffu;
+        val[c] = ok ? vals_in[idx] : (V)0;
+    }
+    long long gbase = 0;
+    if (tid < RS_BINS) gbase = (long long)(dbase[tid] + ghist[(uint64_t)tid * nb + tile]);
+    __syncthreads();
+    uint16_t rnk[ITEMS];
+    uint16_t *cnt = s_cnt[wid];
+#pragma unroll
+    for (int c = 0; c < ITEMS; ++c) {
+        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
+        bool ok = idx < n;
+        uint32_t d = (key[c] >> shift) & mask;
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            uint64_t bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        uint32_t rank = fd_mbcnt(peers);
+        uint32_t pcount = (uint32_t)__popcll(peers);
+        uint32_t base = ok ? cnt[d] : 0u;
+        if (ok && rank == pcount - 1) cnt[d] = (uint16_t)(base + pcount);
+        rnk[c] = (uint16_t)(base + rank);
+    }
+    __syncthreads();
+    uint32_t dstart = 0;
+    {
+        uint32_t my_total = 0;
+        if (tid < RS_BINS) {
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) my_total += s_cnt[w][tid];
+        }
+        uint64_t tot;
+        dstart = (uint32_t)block_excl_scan_u64(tid < RS_BINS ? (uint64_t)my_total : 0ull, sm, &tot);
+        if (tid < RS_BINS) {
+            uint32_t run = dstart;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) { uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = (uint16_t)run; run += c; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ITEMS; ++c) {
+        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
+        if (idx < n) {
+            uint32_t pos = (uint32_t)cnt[(key[c] >> shift) & mask] + rnk[c];
+            s_keys[pos] = key[c];
+            s_vals[pos] = val[c];
+        }
+    }
+    __syncthreads();
+    if (tid < RS_BINS) s_gofs[tid] = gbase - (long long)dstart;
+    __syncthreads();
+    for (uint32_t k = tid; k < n_tile; k += THREADS) {
+        uint32_t kk = s_keys[k];
+        long long g = (long long)k + s_gofs[(kk >> shift) & mask];
+        keys_out[g] = kk;
+        vals_out[g] = s_vals[k];
+    }
+}
+
+// VALU-lean form of k_rs_scatter2 (the scatter is VALU-issue bound: ~130 VALU per 64-key chunk at 4 cycles each):
+// the per-bit peer mask update is ONE v_bitop3_b32 per 32-bit half (peers & ~(ballot ^ bitmask), truth table 0x90),
+// full tiles run without any bounds predicate, ranks stay in 32-bit registers.
+template <int THREADS, int ITEMS, typename V, bool FULL, bool PACK = false>
+__device__ __forceinline__ void rs_scatter4_body(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                                 uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n, uint32_t shift,
+                                                 uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb, const uint64_t *__restrict__ dbase,
+                                                 uint32_t tile, uint32_t *s_keys, V *s_vals, uint32_t (*s_cnt)[RS_BINS], long long *s_gofs,
+                                                 uint64_t *sm) {
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / 64;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint64_t tile_base = (uint64_t)tile * TILE;
+    const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * ITEMS);
+    const uint32_t n_tile = FULL ? TILE : (uint32_t)(n - tile_base);
+    const uint32_t n_wave = FULL ? 64 * ITEMS : (n_tile > wid * 64 * ITEMS ? n_tile - wid * 64 * ITEMS : 0u);   // valid keys of this wave
+
+    for (int k = tid; k < WAVES * RS_BINS; k += THREADS) (&s_cnt[0][0])[k] = 0;
+    uint32_t key[ITEMS];
+    V val[ITEMS];
+    const uint32_t *kp = keys_in + wave_base + lane;
+    const V *vp = vals_in + wave_base + lane;
+#pragma unroll
+    for (int c = 0; c < ITEMS; ++c) {
+        bool ok = FULL || (uint32_t)(c * 64) + lane < n_wave;
+        key[c] = ok ? kp[c * 64] : 0xffffffffu;
+        val[c] = ok ? vp[c * 64] : (V)0;
+    }
+    long long gbase = 0;
+    if (tid < RS_BINS) gbase = (long long)(dbase[tid] + ghist[(uint64_t)tid * nb + tile]);
+    __syncthreads();
+    uint32_t rnk[ITEMS];
+    uint32_t *cnt = s_cnt[wid];
+#pragma unroll
+    for (int c = 0; c < ITEMS; ++c) {
+        const uint32_t d = (key[c] >> shift) & mask;
+        uint32_t plo = ~0u, phi = ~0u;
+        bool ok = true;
+        if (!FULL) {
+            ok = (uint32_t)(c * 64) + lane < n_wave;
+            uint64_t okm = __ballot(ok);
+            plo = (uint32_t)okm; phi = (uint32_t)(okm >> 32);
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int32_t m = __builtin_amdgcn_sbfe((int32_t)d, b, 1);      // 0 or ~0
+            const uint64_t bal = __ballot(m != 0);
+            plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, (uint32_t)m, 0x90);
+            phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), (uint32_t)m, 0x90);
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        const uint32_t pcount = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+        uint32_t base = 0;
+        if (ok) base = cnt[d];
+        if (ok && rank == pcount - 1) cnt[d] = base + pcount;   // in-order LDS within the wave: reads above precede this write
+        rnk[c] = base + rank;
+    }
+    __syncthreads();
+    uint32_t dstart;
+    {
+        uint32_t my_total = 0;
+        if (tid < RS_BINS) {
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) my_total += s_cnt[w][tid];
+        }
+        uint64_t tot;
+        dstart = (uint32_t)block_excl_scan_u64(tid < RS_BINS ? (uint64_t)my_total : 0ull, sm, &tot);
+        if (tid < RS_BINS) {
+            uint32_t run = dstart;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) { uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
+            s_gofs[tid] = gbase - (long long)dstart;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ITEMS; ++c) {
+        if (FULL || (uint32_t)(c * 64) + lane < n_wave) {
+            uint32_t pos = cnt[(key[c] >> shift) & mask] + rnk[c];
+            if (PACK) reinterpret_cast<uint2 *>(s_keys)[pos] = make_uint2(key[c], (uint32_t)val[c]);
+            else { s_keys[pos] = key[c]; s_vals[pos] = val[c]; }
+        }
+    }
+    __syncthreads();
+    if (FULL) {
+#pragma unroll
+        for (int c = 0; c < ITEMS; ++c) {
+            uint32_t k = c * THREADS + tid;
+            uint32_t kk, vv;
+            if (PACK) { uint2 e = reinterpret_cast<const uint2 *>(s_keys)[k]; kk = e.x; vv = e.y; }
+            else { kk = s_keys[k]; vv = (uint32_t)s_vals[k]; }
+            long long g = (long long)k + s_gofs[(kk >> shift) & mask];
+            keys_out[g] = kk;
+            vals_out[g] = (V)vv;
+        }
+    } else {
+        for (uint32_t k = tid; k < n_tile; k += THREADS) {
+            uint32_t kk, vv;
+            if (PACK) { uint2 e = reinterpret_cast<const uint2 *>(s_keys)[k]; kk = e.x; vv = e.y; }
+            else { kk = s_keys[k]; vv = (uint32_t)s_vals[k]; }
+            long long g = (long long)k + s_gofs[(kk >> shift) & mask];
+            keys_out[g] = kk;
+            vals_out[g] = (V)vv;
+        }
+    }
+}
+
+template <int THREADS, int ITEMS, typename V, bool PACK = false>
+__global__ __launch_bounds__(THREADS) void k_rs_scatter4(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                                         uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n,
+                                                         uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
+                                                         const uint64_t *__restrict__ dbase) {
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / 64;
+    __shared__ __attribute__((aligned(8))) uint32_t s_keys[PACK ? 2 * TILE : TILE];
+    __shared__ V s_vals[PACK ? 1 : TILE];
+    __shared__ uint32_t s_cnt[WAVES][RS_BINS];
+    __shared__ long long s_gofs[RS_BINS];
+    __shared__ uint64_t sm[17];
+    const uint32_t tile = fd_xcd_remap(blockIdx.x, nb);
+    if (tile >= nb) return;
+    if ((uint64_t)(tile + 1) * TILE <= n)
+        rs_scatter4_body<THREADS, ITEMS, V, true, PACK>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, ghist, nb, dbase, tile, s_keys, s_vals, s_cnt, s_gofs, sm);
+    else
+        rs_scatter4_body<THREADS, ITEMS, V, false, PACK>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, ghist, nb, dbase, tile, s_keys, s_vals, s_cnt, s_gofs, sm);
+}
+
 // ------------------------------------------------------------------------ onesweep variant
 // One kernel per digit: the global digit histograms of all passes come from ONE upfront read of the
 // keys (the key multiset does not change between passes), and the per-tile digit offsets are
@@ -538,7 +846,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_scatter_p(const uint32_t *__rest
 
 // LSD variants: 0 = 256x16 tiles, 1 = 256x16 + XCD-aware tile order, 2 = 512x16, 3 = 512x16 + XCD-aware,
 // 4 = 256x16 persistent software-pipelined scatter (XCD-aware)
-static int g_rs_variant = 1;
+static int g_rs_variant = 18;
 void fd_rs_set_variant(int v) { g_rs_variant = v; }
 static inline uint32_t rs_tile(int v) { return (v >= 2 ? 512u : 256u) * 16u; }
 uint32_t fd_rs_num_tiles(uint64_t n) { return (uint32_t)((n + 2048 - 1) / 2048); }  // upper bound over variants (workspace sizing)
@@ -560,6 +868,66 @@ static void rs_pass(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32
     {
         StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
         hipLaunchKernelGGL((k_rs_scatter<THREADS, ITEMS, XCD, V, NT>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
+    }
+}
+
+template <int THREADS, int ITEMS, typename V>
+static void rs_pass2(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist, uint64_t *tot,
+                     hipStream_t st, fdgpu_ctx *tc) {
+    uint32_t nb = (uint32_t)((n + THREADS * ITEMS - 1) / (THREADS * ITEMS));
+    uint32_t grid = ((nb + 7u) / 8u) * 8u;
+    {
+        StageTimer t(tc, "rs_hist", n * 4 + (uint64_t)nb * RS_BINS * 4);
+        hipLaunchKernelGGL((k_rs_hist<THREADS, ITEMS, true>), dim3(grid), dim3(THREADS), 0, st, ki, n, shift, mask, ghist, nb);
+    }
+    {
+        StageTimer t(tc, "rs_scan", (uint64_t)nb * RS_BINS * 8);
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
+        hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
+    }
+    {
+        StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
+        hipLaunchKernelGGL((k_rs_scatter2<THREADS, ITEMS, true, V>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
+    }
+}
+
+template <int THREADS, int ITEMS, typename V>
+static void rs_pass3(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist, uint64_t *tot,
+                     hipStream_t st, fdgpu_ctx *tc) {
+    uint32_t nb = (uint32_t)((n + THREADS * ITEMS - 1) / (THREADS * ITEMS));
+    uint32_t grid = ((nb + 7u) / 8u) * 8u;
+    {
+        StageTimer t(tc, "rs_hist", n * 4 + (uint64_t)nb * RS_BINS * 4);
+        hipLaunchKernelGGL((k_rs_hist<THREADS, ITEMS, true>), dim3(grid), dim3(THREADS), 0, st, ki, n, shift, mask, ghist, nb);
+    }
+    {
+        StageTimer t(tc, "rs_scan", (uint64_t)nb * RS_BINS * 8);
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
+        hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
+    }
+    {
+        StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
+        hipLaunchKernelGGL((k_rs_scatter3<THREADS, ITEMS, V>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
+    }
+}
+
+template <int THREADS, int ITEMS, typename V, bool PACK = false>
+static void rs_pass4(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist, uint64_t *tot,
+                     hipStream_t st, fdgpu_ctx *tc) {
+    uint32_t nb = (uint32_t)((n + THREADS * ITEMS - 1) / (THREADS * ITEMS));
+    uint32_t grid = ((nb + 7u) / 8u) * 8u;
+    {
+        StageTimer t(tc, "rs_hist", n * 4 + (uint64_t)nb * RS_BINS * 4);
+        hipLaunchKernelGGL((k_rs_hist<THREADS, ITEMS, true>), dim3(grid), dim3(THREADS), 0, st, ki, n, shift, mask, ghist, nb);
+    }
+    {
+        StageTimer t(tc, "rs_scan", (uint64_t)nb * RS_BINS * 8);
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
+        hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
+    }
+    {
+        StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
+        hipLaunchKernelGGL((k_rs_scatter4<THREADS, ITEMS, V, PACK>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
     }
 }
 
@@ -595,6 +963,19 @@ static int radix_sort_pairs_t(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *
         uint32_t *ki = cur ? keys_b : keys_a, *ko = cur ? keys_a : keys_b;
         V *vi = cur ? vals_b : vals_a, *vo = cur ? vals_a : vals_b;
         switch (g_rs_variant) {
+            case 10: rs_pass2<256, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 11: rs_pass2<512, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 16: rs_pass3<512, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 17: rs_pass3<256, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 18: rs_pass4<512, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 19: rs_pass4<256, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 20: rs_pass4<512, 8, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 21: rs_pass4<512, 16, V, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 22: rs_pass4<256, 16, V, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 12: rs_pass2<1024, 8, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 13: rs_pass2<1024, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 14: rs_pass2<512, 24, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 15: rs_pass2<256, 32, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 4: rs_pass_p<256, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 5: rs_pass<256, 16, true, V, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 6: rs_pass<1024, 4, true, V, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;

@@ -4,7 +4,7 @@ REPO=$(pwd); OUT=$REPO/gpurun_out; RAW=/tmp/fdpmc; rm -rf $RAW; mkdir -p $OUT $R
 export TMPDIR=/tmp; cd /tmp
 CMD="python $REPO/bench.py --structures 16384 --steps 1 --warmup 0 --no-query --no-cpu-baseline"
 INC='--kernel-include-regex k_rs_scatter.*'
-run() { name=$1; shift; rocprofv3 --output-format csv $INC --pmc "$@" -d $RAW/$name -o $name -- $CMD > $OUT/pmc_$name.log 2>&1; }
+run() { name=$1; shift; timeout 180 rocprofv3 --output-format csv $INC --pmc "$@" -d $RAW/$name -o $name -- $CMD > $OUT/pmc_$name.log 2>&1; }
 run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
 run sq2 SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAIT_INST_LDS
 run tcc1 TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_TAG_STALL_sum TCC_IB_STALL_sum
