@@ -151,6 +151,10 @@ def main():
                 "algorithmic_bytes_per_launch": dom_bytes / max(dom_n, 1),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(dom_name, S),
+                # SURVEY §8(d) end-to-end figure: B_idx = 37 R + 4 U + 4 U + v U + 12 H/S bytes per structure
+                "end_to_end": (lambda b: {"algorithmic_bytes_per_structure": b, "achieved": value / world * b / 1e9, "unit": "GB/s",
+                                          "frac": value / world * b / 1e9 / HBM_PEAK_GBS})(
+                    37.0 * R / S + 8.0 * n_post / S + vlen / S + 12.0 * n_hash / S),
                 "stages_ms": {k: round(v[0], 3) for k, v in agg.items()},
                 "stages_gbs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0.0 for k, v in agg.items()}}
 
