@@ -79,6 +79,7 @@ SYMBOLS = [
     ("fdgpu_posting_lengths", C.c_int, [VP, VP, u32p, C.c_uint64, u64p]),
     ("fdgpu_count_query", C.c_int, [VP, VP, u32p, u32p, u32p, f32p, C.c_uint64, f32p, C.POINTER(C.POINTER(CountRec)), u64p]),
     ("fdgpu_count_query_batch", C.c_int, [VP, VP, C.c_uint64, u64p, u32p, u32p, u32p, f32p, f32p, C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
+    ("fdgpu_spec_fallbacks", C.c_int, [VP, u64p]),
     ("fdgpu_match_pairs", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(MatchQuery), C.POINTER(HashParams),
                                     C.POINTER(C.POINTER(PairRec)), u64p, C.POINTER(C.POINTER(CandRec)), u64p]),
     ("fdgpu_kabsch_batch", C.c_int, [VP, f32p, f32p, u64p, C.c_uint64, f32p, f32p, f32p]),

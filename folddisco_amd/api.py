@@ -101,6 +101,12 @@ class Context:
         except Exception:
             pass
 
+    def spec_fallbacks(self) -> int:
+        """pairs re-evaluated by the exact routine since the last call (speculative torsion path of the index build)"""
+        out = np.zeros(1, np.uint64)
+        self.check(self.L.fdgpu_spec_fallbacks(self.h, _ptr(out, u64p)))
+        return int(out[0])
+
     def synchronize(self):
         self.check(self.L.fdgpu_synchronize(self.h))
 

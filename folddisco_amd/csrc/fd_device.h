@@ -24,7 +24,8 @@ struct fd_batch_view {
 struct fd_hash_consts {
     fd_quant q;
     float d2_max;   // largest f32 whose sqrt is <= dist_cutoff: sqrtf(d2) > cutoff  <=>  d2 > d2_max
-    int use_tab;    // 1: default 4 angle bins -> table form of the angle fields (fd_bin_tables.h)
+    int use_tab;    // 1: default 4 angle bins -> table form of the angle fields (fd_bin_tables.h); 2: + speculative torsions
+    unsigned long long *spec_miss;   // device counter of pairs the speculative path handed to the exact routine (may be null)
 };
 
 __device__ __forceinline__ fd_v3 fd_load3(const float *p, uint32_t r) {

@@ -247,3 +247,89 @@ FD_HD void fd_pair_both_tab(const fd_frame &Fi, const fd_frame &Fj, uint32_t aai
     *h_ij = aai << 25 | aaj << 20 | mid | k1 << 4 | k2;
     *h_ji = aaj << 25 | aai << 20 | mid | k3 << 4 | k4;
 }
+
+#if defined(__HIPCC__)
+// =============================================================================================
+// Speculative evaluation of the four torsion fields (device, index build).  The exact chain spends most of its
+// instructions on four IEEE normalisations (sqrt + 3 divisions each).  Here the normalisations use v_rsq_f32 and the
+// atan2 operand ratio is never formed: for every table threshold t the sign of  g = |y| - t|x|  decides the segment,
+// and the decision is accepted only if |g| exceeds a bound M on how far the speculative (y, x) can be from the
+// operands the reference arithmetic produces.  Otherwise the pair is re-evaluated by the exact routine.
+//
+// Bounds (eps = 2^-24; r1, t1, s2, nv2 are unit vectors; c = v1 x v3 is computed by the SAME operations in both
+// evaluations, only what follows a normalisation differs):
+//   A  = c/|c|:           |A_f - A_ref|  <= 5 eps |A_k|                              (rsq 1 ulp + mul  vs  sqrt, div)
+//   y1 = A.t1, x1 = r1.A: |dy|, |dx|     <= 8 eps + 6 eps (product/sum roundings)     -> E1 = 32 eps
+//   X  = (-A) x nv2:      |dX_k|         <= 16 eps                                    (|dX| <= 28 eps)
+//   tA = X/|X|:           |dtA_k|        <= 56 eps/|X| + 10 eps
+//   y4 = s2.tA:           |dy4|          <= 97 eps/|X| + 24 eps                       -> 128 eps/|X| + 32 eps
+//   x4 = (-A).s2:         |dx4|          <= 20 eps                                    -> 32 eps
+//   reference decision:   |RN(y/x)| >= t  <=>  |y| - t|x| >= -eps t|x|  (|y| <= 1)    -> + 2^-20 in M
+// All bounds are multiplied by FD_SPEC_SAFETY = 4.  M = E_y + t E_x; signs must be certain (|y| > E_y, |x| > E_x),
+// which also routes zero / NaN / inf operands to the exact path.
+// =============================================================================================
+#define FD_SPEC_E1 7.62939453125e-06f      /* 4 * 32 eps = 2^-17 */
+#define FD_SPEC_EY_SLACK 3.814697265625e-06f /* 4 * 2^-20 */
+#define FD_SPEC_EX4 7.62939453125e-06f     /* 4 * 32 eps */
+#define FD_SPEC_EY4_A 3.0517578125e-05f    /* 4 * 128 eps = 2^-15, times 1/|X| */
+#define FD_SPEC_EY4_B 7.62939453125e-06f   /* 4 * 32 eps */
+
+// tab_f: per quadrant m, 4 float thresholds (padding clamped to FLT_MAX) + packed keys (same layout as the exact table).
+// `margin` accumulates min(decision distance - bound) over everything decided here; the result is trusted iff the final
+// margin is > 0 (a NaN operand compares false in `fin`).
+__device__ __forceinline__ uint32_t fd_tor_key_spec(float y, float x, float Ey, float Ex, const uint32_t *tab_f, float &margin, bool &fin) {
+    const float ay = __builtin_fabsf(y), ax = __builtin_fabsf(x);
+    fin = fin && (ay < 2.0f) && (ax < 2.0f);
+    margin = __builtin_fminf(margin, __builtin_fminf(ay - Ey, ax - Ex));
+    const uint32_t m = (fd_f2u(y) >> 31) | ((fd_f2u(x) >> 30) & 2u);
+    const uint32_t *q = tab_f + 7 + 5 * m;
+    uint32_t neg = 0;   // sign bits of g_0..g_3 (thresholds ascend: the negatives form the tail)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float t = fd_u2f(q[k]);
+        const float g = __builtin_fmaf(-t, ax, ay);
+        const float M = __builtin_fmaf(t, Ex, Ey);
+        neg = __builtin_amdgcn_alignbit(neg, fd_f2u(g), 31);   // (neg << 1) | sign(g)
+        margin = __builtin_fminf(margin, __builtin_fabsf(g) - M);
+    }
+    const uint32_t n = 4u - (uint32_t)__builtin_popcount(neg & 15u);
+    return (q[4] >> (4u * n)) & 15u;
+}
+
+__device__ __forceinline__ fd_v3 fd_normalize_spec(fd_v3 v, float *rs_out) {
+    const float rs = __builtin_amdgcn_rsqf(v.x * v.x + v.y * v.y + v.z * v.z);
+    *rs_out = rs;
+    return {v.x * rs, v.y * rs, v.z * rs};
+}
+
+// returns false when any field is not provably identical to the reference arithmetic (caller falls back to fd_pair_both_tab)
+__device__ __forceinline__ bool fd_pair_both_spec(const fd_frame &Fi, const fd_frame &Fj, uint32_t aai, uint32_t aaj, fd_quant q,
+                                                  const uint32_t *tab, const uint32_t *tab_f, uint32_t *h_ij, uint32_t *h_ji) {
+    float ca_dist = fd_dist(Fi.ca, Fj.ca);
+    float cb_dist = fd_dist(Fi.cb, Fj.cb);
+    fd_v3 v1 = {Fi.cb.x - Fi.ca.x, Fi.cb.y - Fi.ca.y, Fi.cb.z - Fi.ca.z};
+    fd_v3 v2 = {Fj.cb.x - Fj.ca.x, Fj.cb.y - Fj.ca.y, Fj.cb.z - Fj.ca.z};
+    float dt = v1.x * v2.x + v1.y * v2.y + v1.z * v2.z;
+    uint32_t kth = fd_theta_key_of(dt / (Fi.len * Fj.len), tab);     // exact: one division, no normalisation upstream
+    fd_v3 v3 = fd_sub(Fj.cb, Fi.cb);
+    float rsA, rsB, rsXA, rsXB;
+    fd_v3 A = fd_normalize_spec(fd_cross(v1, v3), &rsA);
+    fd_v3 B = fd_normalize_spec(fd_cross(v3, v2), &rsB);
+    bool fin = true;
+    float margin = 1.0f;
+    const float E1y = FD_SPEC_E1 + FD_SPEC_EY_SLACK;
+    uint32_t k1 = fd_tor_key_spec(fd_dot(A, Fi.t1), fd_dot(Fi.r1, A), E1y, FD_SPEC_E1, tab_f, margin, fin);
+    uint32_t k3 = fd_tor_key_spec(fd_dot(B, Fj.t1), fd_dot(Fj.r1, B), E1y, FD_SPEC_E1, tab_f, margin, fin);
+    fd_v3 rB = fd_neg(B), rA = fd_neg(A);
+    fd_v3 tB = fd_normalize_spec(fd_cross(rB, Fj.nv2), &rsXB);
+    fd_v3 tA = fd_normalize_spec(fd_cross(rA, Fi.nv2), &rsXA);
+    const float E4c = FD_SPEC_EY4_B + FD_SPEC_EY_SLACK;
+    uint32_t k2 = fd_tor_key_spec(fd_dot(Fj.s2, tB), fd_dot(rB, Fj.s2), __builtin_fmaf(FD_SPEC_EY4_A, rsXB, E4c), FD_SPEC_EX4, tab_f, margin, fin);
+    uint32_t k4 = fd_tor_key_spec(fd_dot(Fi.s2, tA), fd_dot(rA, Fi.s2), __builtin_fmaf(FD_SPEC_EY4_A, rsXA, E4c), FD_SPEC_EX4, tab_f, margin, fin);
+    uint32_t mid = fd_q(ca_dist, 2.0f, q.dist_disc) << 16 | fd_q(cb_dist, 2.0f, q.dist_disc) << 12 | kth << 8;
+    *h_ij = aai << 25 | aaj << 20 | mid | k1 << 4 | k2;
+    *h_ji = aaj << 25 | aai << 20 | mid | k3 << 4 | k4;
+    // rsq of a zero / denormal cross product is inf: margins become NaN or -inf; NaN must fail, so test "> 0" positively
+    return fin && (margin > 0.0f) && (rsXA < 3.0e38f) && (rsXB < 3.0e38f) && (rsA < 3.0e38f) && (rsB < 3.0e38f);
+}
+#endif

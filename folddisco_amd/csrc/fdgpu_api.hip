@@ -70,11 +70,24 @@ extern "C" int fdgpu_create(int device, fdgpu_ctx **out) {
         return FDGPU_EHIP;
     }
     c->own_stream = true;
+    if (hipMalloc((void **)&c->spec_miss, 8) == hipSuccess) (void)hipMemset(c->spec_miss, 0, 8);
+    else c->spec_miss = nullptr;
     *out = c;
+    return FDGPU_OK;
+}
+// number of residue pairs the speculative torsion evaluation handed to the exact routine since the last call (profiling hook)
+extern "C" int fdgpu_spec_fallbacks(fdgpu_ctx *c, uint64_t *out) {
+    if (!c || !out) return FDGPU_EINVAL;
+    *out = 0;
+    if (!c->spec_miss) return FDGPU_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->spec_miss, 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemset(c->spec_miss, 0, 8));
     return FDGPU_OK;
 }
 extern "C" void fdgpu_destroy(fdgpu_ctx *c) {
     if (!c) return;
+    if (c->spec_miss) (void)hipFree(c->spec_miss);
     for (auto &b : c->ws) b.release();
     for (auto &b : c->pool) (void)hipFree(b.p);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
@@ -209,7 +222,12 @@ static fd_hash_consts make_consts(const fd_hash_params *p) {
     while (sqrtf(d2) > cut) d2 = nextafterf(d2, 0.0f);
     while (sqrtf(nextafterf(d2, INFINITY)) <= cut) d2 = nextafterf(d2, INFINITY);
     C.d2_max = d2;
-    C.use_tab = (na == 4.0f) ? 1 : 0;
+    // default angle bins: table form; the index build evaluates the torsion fields speculatively with an exact fallback
+    // (fd_geom.h fd_pair_both_spec) unless FDGPU_EXACT=1
+    const char *ex = getenv("FDGPU_EXACT");   // read per call: tests flip it inside one process
+    const bool exact_only = ex && ex[0] == '1';
+    C.use_tab = (na == 4.0f) ? (exact_only ? 1 : 2) : 0;
+    C.spec_miss = nullptr;
     return C;
 }
 
@@ -373,6 +391,7 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
     reset_timings(c);
     if (first_id + b->n_struct > 0xffffffffull) FAIL(c, FDGPU_ERANGE, "structure ids exceed 32 bits");
     fd_hash_consts C = make_consts(p);
+    C.spec_miss = c->spec_miss;
     hipStream_t st = c->stream;
     uint64_t S = b->n_struct, P = 0;
     HIPCHK(c, c->ws[WS_FRAMES].ensure(std::max<uint64_t>(b->n_res, 1) * sizeof(fd_frame)));

@@ -38,6 +38,7 @@ struct fdgpu_ctx {
     std::string err;
     fd_devbuf ws[WS_COUNT];
     bool timing = false;
+    unsigned long long *spec_miss = nullptr;   // device counter: pairs the speculative torsion path re-evaluated exactly
     std::vector<fd_timing_entry> timings;
     std::vector<hipEvent_t> event_pool;
     size_t event_used = 0;

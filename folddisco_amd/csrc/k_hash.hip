@@ -160,7 +160,18 @@ __device__ __forceinline__ fd_frame load_frame(const fd_frame *__restrict__ fram
 }
 
 // IDS16: 6-byte elements — key = hash << 2 | (s >> 16), 16-bit payload = s & 0xffff (s = structure index inside the shard)
-template <bool TAB, bool IDS16>
+// exact table evaluation, out of line: the fallback of the speculative path (and the whole path with FDGPU_EXACT=1)
+__device__ __attribute__((noinline)) uint2 pair_both_tab_exact(const fd_frame *__restrict__ frames, uint32_t i, uint32_t j, uint32_t aai,
+                                                               uint32_t aaj, float dist_disc, float ang_disc, const uint32_t *tab) {
+    fd_frame Fi = load_frame(frames, i), Fj = load_frame(frames, j);
+    fd_quant q;
+    q.dist_disc = dist_disc; q.ang_disc = ang_disc;
+    uint32_t a, b;
+    fd_pair_both_tab(Fi, Fj, aai, aaj, q, tab, &a, &b);
+    return make_uint2(a, b);
+}
+
+template <int TAB, bool IDS16>
 __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *__restrict__ frames, const fd_hash_consts &C,
                                        const uint32_t *tab, const uint32_t *q, uint32_t n, uint32_t i0, uint32_t r0, uint32_t s, uint32_t id,
                                        const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys, void *ids) {
@@ -171,10 +182,21 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
     if (lane < n) {
         uint32_t e = q[lane];
         uint32_t i = i0 + (e >> 16), j = r0 + (e & 0xffffu);
-        fd_frame Fi = load_frame(frames, i), Fj = load_frame(frames, j);
         uint32_t h_ij, h_ji;
-        if (TAB) fd_pair_both_tab(Fi, Fj, B.aa[i], B.aa[j], C.q, tab, &h_ij, &h_ji);
-        else fd_pair_both(Fi, Fj, B.aa[i], B.aa[j], C.q, &h_ij, &h_ji);
+        if (TAB == 2) {
+            fd_frame Fi = load_frame(frames, i), Fj = load_frame(frames, j);
+            if (!fd_pair_both_spec(Fi, Fj, B.aa[i], B.aa[j], C.q, tab, tab + 32, &h_ij, &h_ji)) {
+                uint2 h = pair_both_tab_exact(frames, i, j, B.aa[i], B.aa[j], C.q.dist_disc, C.q.ang_disc, tab);
+                h_ij = h.x; h_ji = h.y;
+                if (C.spec_miss) atomicAdd(C.spec_miss, 1ull);
+            }
+        } else if (TAB == 1) {
+            uint2 h = pair_both_tab_exact(frames, i, j, B.aa[i], B.aa[j], C.q.dist_disc, C.q.ang_disc, tab);
+            h_ij = h.x; h_ji = h.y;
+        } else {
+            fd_frame Fi = load_frame(frames, i), Fj = load_frame(frames, j);
+            fd_pair_both(Fi, Fj, B.aa[i], B.aa[j], C.q, &h_ij, &h_ji);
+        }
         uint64_t pos = seg_off[s] + base + lane;
         if (IDS16) {
             uint32_t hi = s >> 16;
@@ -192,16 +214,21 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
     }
 }
 
-template <bool TAB, bool IDS16>
+template <int TAB, bool IDS16>
 __global__ __launch_bounds__(FD_WAVE) void k_pair_emit2(fd_batch_view B, const fd_frame *__restrict__ frames, fd_hash_consts C,
                                                         const uint64_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
                                                         uint32_t *__restrict__ keys, void *__restrict__ ids, uint32_t first_id) {
     __shared__ uint32_t q[2 * FD_WAVE];
-    __shared__ uint32_t tab[32];
+    __shared__ uint32_t tab[64];   // [0,27) exact table (bit patterns), [32,59) the same with float thresholds for the speculative path
     uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
     if (w >= B.n_work) return;
     if (TAB) {
-        if (threadIdx.x == 0) fd_fill_bintab(tab);
+        if (threadIdx.x == 0) {
+            fd_fill_bintab(tab);
+            for (int k = 0; k < FD_BINTAB_WORDS; ++k) tab[32 + k] = tab[k];
+            for (int m = 0; m < 4; ++m)
+                for (int k = 0; k < 4; ++k) { uint32_t v = tab[32 + 7 + 5 * m + k]; tab[32 + 7 + 5 * m + k] = v > 0x7f7fffffu ? 0x7f7fffffu : v; }
+        }
         __syncthreads();
     }
     const uint32_t s = B.wi_struct[w];
@@ -329,10 +356,12 @@ void fd_launch_pair_emit2(const fd_batch_view &B, const void *frames, const fd_h
     if (!B.n_work) return;
     dim3 g(grid_for(B.n_work)), b(FD_WAVE);
     const fd_frame *F = (const fd_frame *)frames;
-    if (C.use_tab && ids16) hipLaunchKernelGGL((k_pair_emit2<true, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
-    else if (C.use_tab) hipLaunchKernelGGL((k_pair_emit2<true, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
-    else if (ids16) hipLaunchKernelGGL((k_pair_emit2<false, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
-    else hipLaunchKernelGGL((k_pair_emit2<false, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    if (C.use_tab == 2 && ids16) hipLaunchKernelGGL((k_pair_emit2<2, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else if (C.use_tab == 2) hipLaunchKernelGGL((k_pair_emit2<2, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else if (C.use_tab && ids16) hipLaunchKernelGGL((k_pair_emit2<1, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else if (C.use_tab) hipLaunchKernelGGL((k_pair_emit2<1, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else if (ids16) hipLaunchKernelGGL((k_pair_emit2<0, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else hipLaunchKernelGGL((k_pair_emit2<0, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
 }
 void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, hipStream_t st) {
     if (!B.n_work) return;

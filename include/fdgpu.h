@@ -211,6 +211,10 @@ int fdgpu_merge_subindices(uint64_t n_parts, const uint8_t *const *values, const
                            const uint64_t *const *offsets, const uint64_t *n_hashes, uint8_t **out_value,
                            uint64_t *out_value_len, uint32_t **out_hashes, uint64_t **out_offsets, uint64_t *out_n_hashes);
 
+/* Pairs that the speculative torsion evaluation of the index build (fd_geom.h, fd_pair_both_spec) re-evaluated with the
+ * exact routine since the previous call; FDGPU_EXACT=1 in the environment disables the speculative path altogether. */
+int fdgpu_spec_fallbacks(fdgpu_ctx *ctx, uint64_t *out);
+
 /* ---- profiling hooks ------------------------------------------------------------------------------
  * Per-kernel timing of the last fdgpu_index_build / fdgpu_count_query call, measured with
  * HIP events on the context's stream. names[i] is a static string. Returns the number of

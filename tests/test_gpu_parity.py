@@ -274,3 +274,24 @@ def test_count_query_batch_equals_single(ctx):
         want = fd.count_query(ctx, ix, qh, qi, qj, pen, total_structures=300, as_array=True)
         assert g.tobytes() == want.tobytes()
     assert len(got[3]) == 0 and len(got[6]) == 0
+
+
+@pytest.mark.gpu
+def test_speculative_torsions_equal_exact_path(ctx, monkeypatch):
+    """The index build evaluates the torsion fields speculatively (rsq normalisations, sign-of-(|y| - t|x|) segment
+    decisions with error margins) and re-evaluates undecided pairs exactly: the index must be byte-identical to the one
+    built with FDGPU_EXACT=1, and the fallback must actually be exercised."""
+    import folddisco_amd as fd
+    from folddisco_amd import synth
+    ps = synth.to_packed(synth.generate(1500, seed=99))
+    batch = ctx.upload(ps)
+    ctx.spec_fallbacks()
+    monkeypatch.delenv("FDGPU_EXACT", raising=False)
+    spec = fd.FolddiscoIndex.build(ctx, batch).export()
+    n_fallback = ctx.spec_fallbacks()
+    monkeypatch.setenv("FDGPU_EXACT", "1")
+    exact = fd.FolddiscoIndex.build(ctx, batch).export()
+    assert ctx.spec_fallbacks() == 0
+    for a, b in zip(spec, exact):
+        assert a.tobytes() == b.tobytes()
+    assert n_fallback > 0          # ~2.4e-4 of ~2.4e7 pairs
