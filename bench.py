@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-query", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=0, help="extra leg: builds issued from this many host threads / HIP streams (0 = skip)")
     return ap.parse_args()
 
 
@@ -133,6 +134,46 @@ def main():
     value = world * S * args.steps / dt
     n_post, n_hash, vlen = ix.num_postings, ix.num_hashes, ix.value_len
 
+    # ---- extra leg: the same K builds issued from P host threads, each with its own context / stream / workspace, so that the
+    # VALU-bound pair kernel of one build overlaps the HBM-bound sort/encode of another (how a multi-shard job would run)
+    pipelined = None
+    if args.pipeline > 1:
+        import threading
+        P = args.pipeline
+        ctxs = [ctx] + [fd.Context(local_rank) for _ in range(P - 1)]
+        bts = [batch] + [c.wrap_device(S, R, res_off.data_ptr(), d["n_xyz"].data_ptr(), d["ca_xyz"].data_ptr(), d["cb_xyz"].data_ptr(),
+                                       d["aa"].data_ptr(), None, keepalive=keep) for c in ctxs[1:]]
+        per = [(args.steps + P - 1 - t) // P for t in range(P)]
+
+        def worker(t, n):
+            torch.cuda.set_device(local_rank)   # the current HIP device is per host thread
+            x = None
+            for _ in range(n):
+                x = None
+                x = fd.FolddiscoIndex.build(ctxs[t], bts[t], first_id=first_id)
+            ctxs[t].synchronize()
+
+        def run_all(counts):
+            th = [threading.Thread(target=worker, args=(t, counts[t])) for t in range(P)]
+            for x in th: x.start()
+            for x in th: x.join()
+        ix = None
+        run_all([1] * P)   # warm every context (workspace allocation)
+        barrier()
+        t0p = time.perf_counter()
+        run_all(per)
+        barrier()
+        dtp = time.perf_counter() - t0p
+        if dist is not None:
+            t = torch.tensor([dtp], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtp = float(t.item())
+        pipelined = {"value": world * S * args.steps / dtp, "unit": "structures/s", "streams": P, "ms_per_step": dtp / args.steps * 1e3,
+                     "note": "same K builds, issued concurrently from %d host threads on %d HIP streams" % (P, P)}
+        del bts
+        for c in ctxs[1:]:
+            c.close()
+
     # ---- per-kernel timings of one more (untimed) step with HIP events on the build stream -> roofline
     ctx.enable_timing(True)
     ix = None
@@ -188,7 +229,7 @@ def main():
             "config": {"workload": f"Swiss-Prot/8 shard per GPU: {S} synthetic AFDB-shaped structures ({R} residues, "
                                    f"{n_post} postings, {n_hash} distinct hashes, {vlen} value bytes) index build, PDBTrRosetta default",
                        "structures_per_gpu": S, "residues_per_gpu": R, "postings_per_gpu": n_post, "parallelism": f"shard-by-structure x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "query": query,
+            "roofline": roofline, "pipelined": pipelined, "cpu_baseline": cpu, "query": query,
         }
         print(json.dumps(out))
     if dist is not None:
