@@ -14,6 +14,7 @@
 #include <map>
 #include <vector>
 #include "fdgpu_internal.h"
+#include <chrono>
 
 #define HIPCHK(ctx, expr)                                                                                   \
     do {                                                                                                    \
@@ -284,11 +285,26 @@ static std::vector<std::vector<uint32_t>> components(const Graph &g, size_t min_
 
 extern "C" void fdgpu_matches_free(fd_match_rec *m, int32_t *residues) { free(m); free(residues); }
 
+// coordinates of all candidates in one launch + one copy (a hipMemcpy per candidate costs more than the pair scan)
+__global__ __launch_bounds__(256) void k_gather_xyz(const float *__restrict__ ca, const float *__restrict__ cb, const uint64_t *__restrict__ src,
+                                                    const uint64_t *__restrict__ dst, uint64_t total, float *__restrict__ out) {
+    const uint64_t k = blockIdx.x;
+    const uint64_t s3 = 3 * src[k], d3 = 3 * dst[k], n3 = 3 * (dst[k + 1] - dst[k]);
+    for (uint64_t t = threadIdx.x; t < n3; t += blockDim.x) {
+        out[d3 + t] = ca[s3 + t];
+        out[3 * total + d3 + t] = cb[s3 + t];
+    }
+}
+
 extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
                               const fd_query_map *qm, const fdgpu_batch *qb, const fd_hash_params *p, float ca_distance_cutoff,
                               uint32_t node_count, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues) {
     if (!c || !db || !qm || !qb || !p || !matches || !n_matches || !residues) return FDGPU_EINVAL;
     *matches = nullptr; *n_matches = 0; *residues = nullptr;
+    const bool trace = getenv("FDGPU_TRACE") != nullptr;
+    auto t_now = [] { return std::chrono::steady_clock::now(); };
+    auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto T0 = t_now();
     const uint64_t NQ = qm->n_indices;
     // sorted unique query hashes + lookup hash -> query map entry
     std::map<uint32_t, uint32_t> entry;
@@ -304,6 +320,7 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
     uint64_t nf = 0, nc = 0;
     int rc = fdgpu_match_pairs(c, db, resname_std, cand, n_cand, &q, p, &found, &nf, &cands, &nc);
     if (rc) return rc;
+    auto T1 = t_now();
     // symmetry flags (geometry/pdb_tr.rs:158-162): aa equal and atan2(sin, cos) of the two torsion fields equal
     auto is_sym = [](uint32_t h) {
         auto cont = [](uint32_t v) { float cf = (1.0f - (-1.0f)) / (4.0f - 1.0f); return (float)v * cf + (-1.0f); };
@@ -324,6 +341,25 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
     std::vector<float> q_ca((qb->h_res_off[1] - qb->h_res_off[0]) * 3), q_cb(q_ca.size());
     HIPCHK(c, hipMemcpy(q_ca.data(), qb->ca_xyz, q_ca.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(q_cb.data(), qb->cb_xyz, q_cb.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> g_src(std::max<uint64_t>(n_cand, 1)), g_dst(n_cand + 1, 0);
+    for (uint64_t k = 0; k < n_cand; ++k) {
+        g_src[k] = db->h_res_off[cand[k]];
+        g_dst[k + 1] = g_dst[k] + (db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]]);
+    }
+    const uint64_t g_total = g_dst[n_cand];
+    std::vector<float> t_all(std::max<uint64_t>(6 * g_total, 1));
+    if (g_total && nf) {
+        HIPCHK(c, c->ws[WS_MISC0].ensure(n_cand * 8));
+        HIPCHK(c, c->ws[WS_MISC1].ensure((n_cand + 1) * 8));
+        HIPCHK(c, c->ws[WS_MISC2].ensure(6 * g_total * 4));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, g_src.data(), n_cand * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, g_dst.data(), (n_cand + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_gather_xyz, dim3((unsigned)n_cand), dim3(256), 0, c->stream, db->ca_xyz, db->cb_xyz, c->ws[WS_MISC0].as<uint64_t>(),
+                           c->ws[WS_MISC1].as<uint64_t>(), g_total, c->ws[WS_MISC2].as<float>());
+        HIPCHK(c, hipMemcpyAsync(t_all.data(), c->ws[WS_MISC2].p, 6 * g_total * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    auto T2 = t_now();
     size_t fpos = 0, cpos = 0;
     for (uint64_t slot = 0; slot < n_cand; ++slot) {
         size_t f0 = fpos, c0 = cpos;
@@ -338,17 +374,18 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
         auto comps = components(g, node_count);
         if (comps.empty()) continue;
         const uint32_t s = cand[slot];
-        const uint64_t r0 = db->h_res_off[s], Rt = db->h_res_off[s + 1] - r0;
-        std::vector<float> t_ca(Rt * 3), t_cb(Rt * 3);
-        HIPCHK(c, hipMemcpy(t_ca.data(), db->ca_xyz + 3 * r0, Rt * 12, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(t_cb.data(), db->cb_xyz + 3 * r0, Rt * 12, hipMemcpyDeviceToHost));
+        (void)s;
+        const float *t_ca = t_all.data() + 3 * g_dst[slot], *t_cb = t_all.data() + 3 * g_total + 3 * g_dst[slot];
         for (auto &cc : comps) {
             std::vector<char> inc(g.w.size(), 0);
-            uint32_t r_size = 1;
-            for (uint32_t v : cc) { inc[v] = 1; r_size = std::max(r_size, g.w[v] + 1); }
+            for (uint32_t v : cc) inc[v] = 1;
             float sub_idf = 0.0f;
-            std::vector<uint8_t> counts((size_t)q_size * r_size, 0), best_c(q_size, 0);
-            std::vector<uint32_t> best_r(q_size, 0);
+            // votes (query residue, target residue) -> saturating u8 count (retrieve.rs:631-666).  Sparse: a component has a
+            // handful of edges, the dense q_size x r_size table of the reference is ~1 MB per component for a motif taken
+            // from a long chain.  best_c[q] = max count, best_r[q] = smallest target residue holding it (what the
+            // reference's running update converges to, counts only grow).
+            struct Vote { uint32_t q, r; uint32_t c; };
+            std::vector<Vote> votes;
             for (size_t e = 0; e < g.es.size(); ++e) {
                 if (!inc[g.es[e]] || !inc[g.et[e]]) continue;
                 auto it = entry.find(g.eh[e]);
@@ -360,23 +397,27 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
                 if (is_sym(g.eh[e])) { pq[0] = std::min(qi, qj); pq[1] = std::max(qi, qj); pr[0] = std::min(ri, rj); pr[1] = std::max(ri, rj); }
                 else { pq[0] = qi; pr[0] = ri; pq[1] = qj; pr[1] = rj; }
                 for (int z = 0; z < 2; ++z) {
-                    uint8_t &cc2 = counts[(size_t)pq[z] * r_size + pr[z]];
-                    if (cc2 < 255) ++cc2;
-                    if (cc2 > best_c[pq[z]] || (cc2 == best_c[pq[z]] && pr[z] < best_r[pq[z]])) { best_c[pq[z]] = cc2; best_r[pq[z]] = pr[z]; }
+                    bool seen = false;
+                    for (auto &v : votes) if (v.q == pq[z] && v.r == pr[z]) { if (v.c < 255) ++v.c; seen = true; break; }
+                    if (!seen) votes.push_back({pq[z], pr[z], 1u});
                 }
             }
+            struct Best { uint32_t q, c, r; };
+            std::vector<Best> best;
+            for (auto &v : votes) {
+                Best *bq = nullptr;
+                for (auto &x : best) if (x.q == v.q) { bq = &x; break; }
+                if (!bq) { best.push_back({v.q, v.c, v.r}); continue; }
+                if (v.c > bq->c || (v.c == bq->c && v.r < bq->r)) { bq->c = v.c; bq->r = v.r; }
+            }
+            // greedy assignment in (count descending, query residue ascending) order (retrieve.rs:668-690)
+            std::sort(best.begin(), best.end(), [](const Best &x, const Best &y) { return x.c != y.c ? x.c > y.c : x.q < y.q; });
             std::vector<uint32_t> q_idx, r_idx;
-            std::vector<char> q_used(q_size, 0), r_used(r_size, 0);
-            bool done = false;
-            for (int bucket = 255; bucket >= 1 && !done; --bucket)
-                for (uint32_t qq = 0; qq < q_size && !done; ++qq) {
-                    if (best_c[qq] != bucket) continue;
-                    uint32_t rr = best_r[qq];
-                    if (!q_used[qq] && !r_used[rr]) {
-                        q_idx.push_back(qq); r_idx.push_back(rr); q_used[qq] = 1; r_used[rr] = 1;
-                        if (q_idx.size() == cc.size()) done = true;
-                    }
-                }
+            for (auto &x : best) {
+                if (q_idx.size() == cc.size()) break;
+                if (std::find(r_idx.begin(), r_idx.end(), x.r) != r_idx.end()) continue;
+                q_idx.push_back(x.q); r_idx.push_back(x.r);
+            }
             // residue assignment + rescue (retrieve.rs:430-516)
             std::vector<int32_t> from_hash(NQ, -1), processed(NQ, -1);
             std::vector<uint32_t> qs_sc, rs_sc;
@@ -438,7 +479,10 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
     free(found); free(cands);
     const uint64_t nprob = pend.size();
     std::vector<float> rmsd(std::max<uint64_t>(nprob, 1)), rot(std::max<uint64_t>(nprob, 1) * 9), tran(std::max<uint64_t>(nprob, 1) * 3);
+    auto T3 = t_now();
     if (nprob && (rc = fdgpu_kabsch_batch(c, kx.data(), ky.data(), koff.data(), nprob, rmsd.data(), rot.data(), tran.data()))) return rc;
+    if (trace) fprintf(stderr, "[fdgpu_retrieve] match_pairs %.3f ms (found %llu, cands %llu), gather %.3f, graph/vote %.3f, kabsch(%llu) %.3f\n", t_ms(T0, T1),
+                       (unsigned long long)nf, (unsigned long long)nc, t_ms(T1, T2), t_ms(T2, T3), (unsigned long long)nprob, t_ms(T3, t_now()));
     for (uint64_t k = 0; k < nprob; ++k) {
         fd_match_rec &r = recs[pend[k].rec];
         if (pend[k].which == 0) {

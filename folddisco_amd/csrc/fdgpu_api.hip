@@ -791,24 +791,26 @@ extern "C" int fdgpu_match_pairs(fdgpu_ctx *c, const fdgpu_batch *db, const uint
     A.q_hashes = c->ws[WS_MISC3].as<uint32_t>(); A.n_hashes = (uint32_t)q->n_hashes;
     A.aad_aa1 = d_a1; A.aad_aa2 = d_a2; A.aad_dist = d_dist; A.aad_qi = d_qi; A.n_aad = (uint32_t)na; A.ca_window = q->ca_distance_cutoff;
     A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.found = nullptr; A.cands = nullptr;
+    // one emitting pass into buffers sized by the previous calls; a pass that overflows only counts, the buffers grow and
+    // the pass is repeated (the scan is deterministic up to record order, which is restored below)
     uint64_t tot[2] = {0, 0};
-    HIPCHK(c, hipMemsetAsync(c->ws[WS_TOTAL].p, 0, 16, st));
-    {
-        StageTimer t(c, "match_pairs_count", 0);
-        fd_launch_match_pairs(A, false, st);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        uint64_t capf = std::max<uint64_t>(c->ws[WS_KEYS_A].cap / sizeof(fd_pair_rec), 0), capc = c->ws[WS_KEYS_B].cap / sizeof(fd_cand_rec);
+        if (capf < 4096 || capf < tot[0]) { HIPCHK(c, c->ws[WS_KEYS_A].ensure(std::max<uint64_t>(2 * tot[0], 65536) * sizeof(fd_pair_rec))); }
+        if (capc < 4096 || capc < tot[1]) { HIPCHK(c, c->ws[WS_KEYS_B].ensure(std::max<uint64_t>(2 * tot[1], 65536) * sizeof(fd_cand_rec))); }
+        A.found = c->ws[WS_KEYS_A].as<fd_pair_rec>(); A.cands = c->ws[WS_KEYS_B].as<fd_cand_rec>();
+        A.cap_found = c->ws[WS_KEYS_A].cap / sizeof(fd_pair_rec); A.cap_cands = c->ws[WS_KEYS_B].cap / sizeof(fd_cand_rec);
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_TOTAL].p, 0, 16, st));
+        {
+            StageTimer t(c, "match_pairs", 0);
+            fd_launch_match_pairs(A, true, st);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_TOTAL].p, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (tot[0] <= A.cap_found && tot[1] <= A.cap_cands) break;
+        if (attempt == 2) FAIL(c, FDGPU_ERANGE, "match_pairs: output did not fit after regrowing");
     }
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_TOTAL].p, 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    HIPCHK(c, c->ws[WS_KEYS_A].ensure(std::max<uint64_t>(tot[0], 1) * sizeof(fd_pair_rec)));
-    HIPCHK(c, c->ws[WS_KEYS_B].ensure(std::max<uint64_t>(tot[1], 1) * sizeof(fd_cand_rec)));
-    A.found = c->ws[WS_KEYS_A].as<fd_pair_rec>(); A.cands = c->ws[WS_KEYS_B].as<fd_cand_rec>();
-    HIPCHK(c, hipMemsetAsync(c->ws[WS_TOTAL].p, 0, 16, st));
-    {
-        StageTimer t(c, "match_pairs_emit", 0);
-        fd_launch_match_pairs(A, true, st);
-    }
-    HIPCHK(c, hipGetLastError());
     fd_pair_rec *hf = (fd_pair_rec *)malloc(std::max<uint64_t>(tot[0], 1) * sizeof(fd_pair_rec));
     fd_cand_rec *hc = (fd_cand_rec *)malloc(std::max<uint64_t>(tot[1], 1) * sizeof(fd_cand_rec));
     if (!hf || !hc) { free(hf); free(hc); return FDGPU_ENOMEM; }

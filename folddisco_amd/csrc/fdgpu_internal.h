@@ -186,6 +186,7 @@ struct mp_args {
     float ca_window;
     unsigned long long *n_found, *n_cands;
     fd_pair_rec *found; fd_cand_rec *cands;
+    unsigned long long cap_found, cap_cands;   // records the buffers hold (EMIT counts beyond them without writing)
 };
 void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st);
 void fd_launch_kabsch(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, hipStream_t st);

@@ -23,10 +23,96 @@ __device__ __forceinline__ bool hash_in_set(const uint32_t *__restrict__ h, uint
     return lo < n && h[lo] == x;
 }
 
+// descriptor + hash + output of one surviving (i, j) per lane (full-wave drains of the compaction queue: executed
+// divergently per survivor this part — ~3000 instructions with the exact libm chain — was 95 % of the kernel time)
+template <bool EMIT>
+__device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q, uint32_t n, uint32_t slot, uint32_t r0, uint32_t i0,
+                                            const uint16_t *s_aa, const float *s_d, const uint32_t *tab) {
+    const uint32_t lane = threadIdx.x;
+    const bool on = lane < n;
+    const uint32_t e0 = on ? q[lane] : 0u;
+    const uint32_t i = i0 + (e0 >> 16), j = r0 + (e0 & 0xffffu);
+    uint32_t aai = 255u, aaj = 255u, n_win = 0, h = 0;
+    fd_v3 cai = {0.f, 0.f, 0.f}, caj = {0.f, 0.f, 0.f};
+    float d = 0.f;
+    uint32_t key = 0;
+    bool hit = false;
+    if (on) {
+        aai = A.B.aa[i]; aaj = A.B.aa[j];
+        cai = fd_load3(A.B.ca_xyz, i); caj = fd_load3(A.B.ca_xyz, j);
+        d = fd_dist(cai, caj);
+        key = (aai << 8) | aaj;
+        for (uint32_t e = 0; e < A.n_aad; ++e) {
+            bool m = s_aa ? (s_aa[e] == key && fd_fabsf(d - s_d[e]) < A.ca_window)
+                          : (A.aad_aa1[e] == aai && A.aad_aa2[e] == aaj && fd_fabsf(d - A.aad_dist[e]) < A.ca_window);
+            n_win += m ? 1u : 0u;
+        }
+        if (A.C.use_tab) {
+            // default angle bins: frames + exhaustive tables (fd_geom.h) — same bits as the generic chain, a tenth of the code
+            fd_frame Fi = fd_make_frame(fd_load3(A.B.n_xyz, i), cai, fd_load3(A.B.cb_xyz, i));
+            fd_frame Fj = fd_make_frame(fd_load3(A.B.n_xyz, j), caj, fd_load3(A.B.cb_xyz, j));
+            uint32_t h_ji;
+            fd_pair_both_tab(Fi, Fj, aai, aaj, A.C.q, tab, &h, &h_ji);
+        } else {
+            fd_feature f = fd_pair_feature(fd_load3(A.B.n_xyz, i), cai, fd_load3(A.B.cb_xyz, i), fd_load3(A.B.n_xyz, j), caj, fd_load3(A.B.cb_xyz, j));
+            h = fd_hash_pdbtr(aai, aaj, f, A.C.q);
+        }
+        hit = hash_in_set(A.q_hashes, A.n_hashes, h);
+    }
+    // one atomic per counter and drain (per-record atomics on two addresses serialise in one L2 channel: that, not the
+    // arithmetic, was the kernel time)
+    uint32_t incl = n_win;
+    for (int off = 1; off < FD_WAVE; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off, FD_WAVE);
+        if ((int)lane >= off) incl += t;
+    }
+    const uint32_t tot_win = __shfl(incl, FD_WAVE - 1, FD_WAVE);
+    const uint64_t hm = __ballot(hit);
+    unsigned long long cbase = 0, fbase = 0;
+    if (lane == 0) {
+        if (tot_win) cbase = atomicAdd(A.n_cands, (unsigned long long)tot_win);
+        if (hm) fbase = atomicAdd(A.n_found, (unsigned long long)__popcll(hm));
+    }
+    cbase = ((unsigned long long)(uint32_t)__shfl((int)(cbase >> 32), 0, FD_WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)cbase, 0, FD_WAVE);
+    fbase = ((unsigned long long)(uint32_t)__shfl((int)(fbase >> 32), 0, FD_WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)fbase, 0, FD_WAVE);
+    unsigned long long cpos = cbase + (incl - n_win);
+    const unsigned long long fpos = fbase + fd_mbcnt(hm);
+    // EMIT with capacities: records beyond the caller's buffers are counted but not written (the caller grows and reruns)
+    if (EMIT && on && cpos + n_win <= A.cap_cands && (!hit || fpos < A.cap_found)) {
+        for (uint32_t e = 0; e < A.n_aad; ++e) {
+            bool m = s_aa ? (s_aa[e] == key && fd_fabsf(d - s_d[e]) < A.ca_window)
+                          : (A.aad_aa1[e] == aai && A.aad_aa2[e] == aaj && fd_fabsf(d - A.aad_dist[e]) < A.ca_window);
+            if (m) {
+                fd_cand_rec c; c.cand = slot; c.qi = A.aad_qi[e]; c.i = i - r0; c.j = j - r0;
+                A.cands[cpos++] = c;
+            }
+        }
+        if (hit) { fd_pair_rec p; p.cand = slot; p.i = i - r0; p.j = j - r0; p.hash = h; A.found[fpos] = p; }
+    }
+}
+
+#define MP_AAD_LDS 1024
 template <bool EMIT>
 __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A) {
+    __shared__ uint32_t q[2 * FD_WAVE];
+    __shared__ uint32_t tab[32];
+    __shared__ uint16_t s_aa_buf[MP_AAD_LDS];
+    __shared__ float s_d_buf[MP_AAD_LDS];
     const uint32_t w = blockIdx.x;
     if (w >= A.n_work) return;
+    // the query's observed (aa_i, aa_j, CA distance) list, staged in LDS (per-pair global reads of it made the scan
+    // latency-bound); longer lists (whole-structure queries) are read from global memory
+    const bool staged = A.n_aad <= MP_AAD_LDS;
+    if (threadIdx.x == 0 && A.C.use_tab) fd_fill_bintab(tab);
+    if (staged) {
+        for (uint32_t e = threadIdx.x; e < A.n_aad; e += FD_WAVE) {
+            s_aa_buf[e] = (uint16_t)(((uint32_t)A.aad_aa1[e] << 8) | A.aad_aa2[e]);
+            s_d_buf[e] = A.aad_dist[e];
+        }
+    }
+    __syncthreads();
+    const uint16_t *s_aa = staged ? s_aa_buf : nullptr;
+    const float *s_d = s_d_buf;
     const uint32_t slot = A.wi_cand[w];
     const uint32_t s = A.cand[slot];
     const uint32_t r0 = A.B.res_off[s], r1 = A.B.res_off[s + 1];
@@ -44,39 +130,73 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A) {
         }
         full = !(any1 && any2);
     }
-    const uint32_t i = A.wi_i0[w] + lane;
-    if (i >= r1) return;
-    const uint32_t aai = A.B.aa[i];
+    const uint32_t i0 = A.wi_i0[w];
+    const uint32_t i = i0 + lane;
+    const bool in_i = i < r1;
+    const uint32_t aai = in_i ? A.B.aa[i] : 255u;
     const bool std_i = aai < 20u && (A.resname_std == nullptr || A.resname_std[i]);
-    if (!full && !(std_i && ((A.aa1_mask >> aai) & 1u))) return;
-    const fd_v3 cai = fd_load3(A.B.ca_xyz, i);
-    for (uint32_t j = r0; j < r1; ++j) {
-        const uint32_t aaj = A.B.aa[j];
-        if (!full) {
-            bool std_j = aaj < 20u && (A.resname_std == nullptr || A.resname_std[j]);
-            if (!(std_j && ((A.aa2_mask >> aaj) & 1u))) continue;
-        }
-        const fd_v3 caj = fd_load3(A.B.ca_xyz, j);
-        const float d = fd_dist(cai, caj);
-        if (!(d <= A.cutoff)) continue;
-        uint32_t n_win = 0;
-        for (uint32_t e = 0; e < A.n_aad; ++e)
-            if (A.aad_aa1[e] == aai && A.aad_aa2[e] == aaj && fd_fabsf(d - A.aad_dist[e]) < A.ca_window) ++n_win;
-        if (!n_win) continue;
-        // get_single_feature (controller/feature.rs:11-24, 84-99)
-        if (i == j || aai == 255u || aaj == 255u || !A.B.hash_ok[i] || !A.B.hash_ok[j]) continue;
-        fd_feature f = fd_pair_feature(fd_load3(A.B.n_xyz, i), cai, fd_load3(A.B.cb_xyz, i), fd_load3(A.B.n_xyz, j), caj, fd_load3(A.B.cb_xyz, j));
-        uint32_t h = fd_hash_pdbtr(aai, aaj, f, A.C.q);
-        bool hit = hash_in_set(A.q_hashes, A.n_hashes, h);
-        unsigned long long cpos = atomicAdd(A.n_cands, (unsigned long long)n_win);
-        unsigned long long fpos = hit ? atomicAdd(A.n_found, 1ull) : 0ull;
-        if (EMIT) {
-            for (uint32_t e = 0; e < A.n_aad; ++e)
-                if (A.aad_aa1[e] == aai && A.aad_aa2[e] == aaj && fd_fabsf(d - A.aad_dist[e]) < A.ca_window) {
-                    fd_cand_rec c; c.cand = slot; c.qi = A.aad_qi[e]; c.i = i - r0; c.j = j - r0;
-                    A.cands[cpos++] = c;
+    // get_single_feature (controller/feature.rs:11-24, 84-99) rejects unknown residues / missing CB
+    const bool act = in_i && (full || (std_i && ((A.aa1_mask >> aai) & 1u))) && aai != 255u && A.B.hash_ok[i];
+    fd_v3 cai = {0.f, 0.f, 0.f};
+    if (in_i) cai = fd_load3(A.B.ca_xyz, i);
+    // partner residue types this lane's residue type has any observation with (aa < 32): one register test per pair
+    uint32_t row_mask = 0;
+    for (uint32_t e = 0; e < A.n_aad; ++e) {
+        uint32_t a1 = staged ? (uint32_t)(s_aa_buf[e] >> 8) : (uint32_t)A.aad_aa1[e];
+        uint32_t a2 = staged ? (uint32_t)(s_aa_buf[e] & 0xffu) : (uint32_t)A.aad_aa2[e];
+        if (a1 == aai && a2 < 32u) row_mask |= 1u << a2;
+    }
+    const uint32_t keyi = aai << 8;
+    uint32_t qn = 0;   // wave-uniform
+    // j in blocks of 64: one coalesced load of (aa, CA) per block, then wave-uniform broadcasts (v_readlane)
+    for (uint32_t jb = r0; jb < r1; jb += FD_WAVE) {
+        const uint32_t jl = jb + lane;
+        const bool jin = jl < r1;
+        const uint32_t aaj_l = jin ? A.B.aa[jl] : 255u;
+        fd_v3 cj = {0.f, 0.f, 0.f};
+        if (jin) cj = fd_load3(A.B.ca_xyz, jl);
+        bool okj = jin && aaj_l != 255u && A.B.hash_ok[jl];
+        if (!full) okj = okj && aaj_l < 20u && (A.resname_std == nullptr || A.resname_std[jl]) && ((A.aa2_mask >> aaj_l) & 1u);
+        const uint64_t okm = __ballot(okj);
+        const uint32_t nj = (r1 - jb) < FD_WAVE ? (r1 - jb) : FD_WAVE;
+        for (uint32_t k = 0; k < nj; ++k) {
+            if ((okm >> k) & 1ull) {   // wave-uniform
+                const uint32_t j = jb + k;
+                const uint32_t aaj = (uint32_t)__builtin_amdgcn_readlane((int)aaj_l, (int)k);
+                const fd_v3 caj = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cj.x), (int)k)),
+                                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cj.y), (int)k)),
+                                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cj.z), (int)k))};
+                bool pass = false;
+                if (act && i != j && aaj < 32u && ((row_mask >> aaj) & 1u)) {
+                    const float d = fd_dist(cai, caj);
+                    if (d <= A.cutoff) {
+                        const uint32_t key = keyi | aaj;
+                        // branch-free: a short-circuit chain costs one LDS round trip per entry
+                        uint32_t any = 0;
+                        if (staged) {
+                            for (uint32_t e = 0; e < A.n_aad; ++e)
+                                any |= (uint32_t)(s_aa_buf[e] == key) & (uint32_t)(fd_fabsf(d - s_d_buf[e]) < A.ca_window);
+                        } else {
+                            for (uint32_t e = 0; e < A.n_aad; ++e)
+                                any |= (uint32_t)(A.aad_aa1[e] == aai) & (uint32_t)(A.aad_aa2[e] == aaj) & (uint32_t)(fd_fabsf(d - A.aad_dist[e]) < A.ca_window);
+                        }
+                        pass = any != 0;
+                    }
                 }
-            if (hit) { fd_pair_rec p; p.cand = slot; p.i = i - r0; p.j = j - r0; p.hash = h; A.found[fpos] = p; }
+                const uint64_t m = __ballot(pass);
+                if (m) {
+                    if (pass) q[qn + fd_mbcnt(m)] = (lane << 16) | (j - r0);
+                    qn += (uint32_t)__popcll(m);
+                }
+            }
+            const bool last = (jb + FD_WAVE >= r1) && (k + 1 == nj);
+            while (qn >= FD_WAVE || (last && qn)) {
+                __syncthreads();
+                uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
+                qn -= n;
+                match_drain<EMIT>(A, q + qn, n, slot, r0, i0, s_aa, s_d, tab);
+                __syncthreads();
+            }
         }
     }
 }

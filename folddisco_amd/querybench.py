@@ -79,16 +79,21 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             dt = float(t.item())
         return dt, tot_hits, tot_hashes, tot_m
 
-    def batched(chunk=32):
-        """throughput mode: query maps per query, then ONE posting-length launch + ONE scoring pass per chunk of queries"""
+    def batched(chunk=32, match=False):
+        """throughput mode: query maps per query, then ONE posting-length launch + ONE scoring pass per chunk of queries;
+        with match=True the local top candidates of every query additionally go through retrieval"""
         def go():
             tot = 0
             for c0 in range(0, len(queries), chunk):
                 ks = range(c0, min(c0 + chunk, len(queries)))
-                qms = [make_query_map(ctx, qbatches[k], queries[k][1], None, None, float(S_total)) for k in ks]
+                qms = [make_query_map(ctx, qbatches[k], queries[k][1], None, ix if match else None, float(S_total)) for k in ks]
                 recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total)
-                for r in recs:
-                    tot += len(fdist.allgather_hits(r, dev, top_n=top_n))
+                for k, qm, r in zip(ks, qms, recs):
+                    n = len(fdist.allgather_hits(r, dev, top_n=top_n))
+                    if match and len(r):
+                        cand = (fdist.rank_hits(r, match_top)["nid"] - ix.first_id).astype(np.uint32)
+                        n = len(retrieve(ctx, batch, None, cand, qm, qbatches[k]))
+                    tot += n
             return tot
         go()
         torch.cuda.synchronize()
@@ -108,6 +113,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
 
     dt1, hits, hashes, _ = timed(False)
     dtb, hits_b = batched()
+    dtbm, nm_b = batched(match=True)
     dt2, _, _, nm = timed(True)
     # roofline of the scoring kernel for the last query (HIP events on the context's stream)
     ctx.enable_timing(True)
@@ -123,6 +129,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         "mode": "prefilter (count_query) + all-gather of candidate hits", "ms_per_query": dt1 / len(queries) * 1e3,
         "batched": {"value": len(queries) / dtb, "ms_per_query": dtb / len(queries) * 1e3, "chunk": 32, "avg_hits": hits_b / len(queries),
                     "mode": "count_query_batch: one scoring pass per 32 queries"},
+        "batched_with_matching": {"value": len(queries) / dtbm, "ms_per_query": dtbm / len(queries) * 1e3, "matches": nm_b, "match_top": match_top},
         "with_matching": {"value": len(queries) / dt2, "ms_per_query": dt2 / len(queries) * 1e3, "matches": nm, "match_top": match_top},
         "avg_query_hashes": hashes / len(queries), "avg_hits": hits / len(queries),
         "last_query": {"hashes": int(len(qm.hash)), "postings_decoded": int(lens.sum()), "touched": len(rows), "stages_ms": st},
