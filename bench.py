@@ -204,7 +204,13 @@ def main():
     if not args.no_query:
         try:
             from folddisco_amd import querybench
-            query = querybench.run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=args.queries)
+            if os.environ.get("FD_PROFILE_QUERY"):
+                import cProfile, pstats
+                pr = cProfile.Profile(); pr.enable()
+                query = querybench.run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=args.queries)
+                pr.disable(); pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(14)
+            else:
+                query = querybench.run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=args.queries)
         except Exception as e:  # the index-build line must still be printed
             query = {"error": repr(e)}
 

@@ -12,8 +12,11 @@ struct fd_devbuf {
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        // small buffers grow geometrically (query-sized scratch would otherwise be re-allocated for every slightly larger
+        // query: hipFree synchronises the device); big ones take what they need
         size_t want = bytes + bytes / 16 + 256;
+        if (cap && cap < (64u << 20) && want < cap + cap / 2) want = cap + cap / 2;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { p = nullptr; return e; }
         cap = want;
