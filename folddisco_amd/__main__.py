@@ -85,12 +85,17 @@ def cmd_query(a):
                                         ca_distance=a.ca_distance, top_n=a.top, skip_match=a.skip_match, serial_query=a.serial_index,
                                         freq_filter=a.freq_filter, length_penalty_power=0.5 if a.length_penalty is None else a.length_penalty,
                                         dist_cutoff=float(cfg.get("grid_width", 20.0)), nbin_dist=int(cfg.get("num_bin_dist", 0)),
-                                        nbin_angle=int(cfg.get("num_bin_angle", 0)))
+                                        nbin_angle=int(cfg.get("num_bin_angle", 0)), sampling_ratio=a.sampling_ratio,
+                                        sampling_count=a.sampling_count, sort_by=a.sort_by,
+                                        filters=dict(total_match=a.total_match, covered_node=a.covered_node, covered_node_ratio=a.covered_node_ratio,
+                                                     max_node=a.max_node, max_node_ratio=a.max_node_ratio, score=a.score,
+                                                     connected_node=a.connected_node, connected_node_ratio=a.connected_node_ratio,
+                                                     num_residue=a.num_residue, plddt=a.plddt, rmsd=a.rmsd))
         fh = open(outp, "w") if outp else sys.stdout
         if a.skip_match or a.per_structure:
             if a.header:
                 fh.write("tid\tidf\ttotal_match_count\tnode_count\tedge_count\tmax_node_cov\tmin_rmsd\tnres\tplddt\tmatching_residues\tdb_key\tquery_residues\n")
-            rows.sort(key=lambda r: (-r["idf"], r["min_rmsd_with_max_match"]))   # StructureSortStrategy::default (sort.rs:453-458)
+            query.sort_rows(rows, query.parse_sort_by(a.sort_by, True))   # StructureSortStrategy (sort.rs:400-458)
             for r in rows:
                 fh.write(query.format_structure_row(r, qstr) + "\n")
         else:
@@ -132,6 +137,20 @@ def main(argv=None):
     pq.add_argument("--header", action="store_true")
     pq.add_argument("--serial-index", action="store_true")
     pq.add_argument("--freq-filter", type=float, default=None)
+    pq.add_argument("--sampling-count", type=int, default=None)
+    pq.add_argument("--sampling-ratio", type=float, default=None)
+    pq.add_argument("--total-match", type=int, default=0)
+    pq.add_argument("--covered-node", type=int, default=0)
+    pq.add_argument("--covered-node-ratio", type=float, default=0.0)
+    pq.add_argument("--max-node", type=int, default=0)
+    pq.add_argument("--max-node-ratio", type=float, default=0.0)
+    pq.add_argument("--score", type=float, default=0.0)
+    pq.add_argument("--connected-node", type=int, default=0)
+    pq.add_argument("--connected-node-ratio", type=float, default=0.0)
+    pq.add_argument("--num-residue", type=int, default=50000)
+    pq.add_argument("--plddt", type=float, default=0.0)
+    pq.add_argument("--rmsd", type=float, default=0.0)
+    pq.add_argument("--sort-by", default="node_count,rmsd")          # query_pdb.rs:573
     pq.add_argument("--length-penalty", type=float, default=None)
     pq.add_argument("-o", "--output", default="")
     pq.add_argument("-v", "--verbose", action="store_true")

@@ -135,11 +135,85 @@ def retrieve(ctx: Context, db: Batch, resname_std, cand, qm: QueryMapResult, qba
     return out
 
 
+_MATCH_KEYS = {"node_count": ("node_count", -1), "node-count": ("node_count", -1), "nodes": ("node_count", -1), "node": ("node_count", -1),
+               "n": ("node_count", -1), "idf": ("idf", -1), "score": ("idf", -1), "rmsd": ("rmsd", 1)}
+_STRUCT_KEYS = {"max_node_count": ("max_matching_node_count", -1), "max-node-count": ("max_matching_node_count", -1),
+                "max_node": ("max_matching_node_count", -1), "max-node": ("max_matching_node_count", -1),
+                "max_nodes": ("max_matching_node_count", -1), "max-nodes": ("max_matching_node_count", -1),
+                "node_count": ("node_count", -1), "node-count": ("node_count", -1), "nodes": ("node_count", -1), "node": ("node_count", -1),
+                "n": ("node_count", -1), "idf": ("idf", -1), "score": ("idf", -1), "min_rmsd": ("min_rmsd_with_max_match", 1),
+                "min-rmsd": ("min_rmsd_with_max_match", 1), "rmsd": ("min_rmsd_with_max_match", 1),
+                "total_match_count": ("total_match_count", -1), "total-match-count": ("total_match_count", -1),
+                "total_match": ("total_match_count", -1), "total-match": ("total_match_count", -1), "matches": ("total_match_count", -1),
+                "match": ("total_match_count", -1), "edge_count": ("edge_count", -1), "edge-count": ("edge_count", -1),
+                "edges": ("edge_count", -1), "edge": ("edge_count", -1), "e": ("edge_count", -1), "nres": ("nres", -1),
+                "num_residues": ("nres", -1), "num-residues": ("nres", -1), "length": ("nres", -1), "residues": ("nres", -1),
+                "residue": ("nres", -1), "l": ("nres", -1), "plddt": ("plddt", -1)}
+
+
+def parse_sort_by(s: str, per_structure: bool):
+    """--sort-by grammar of src/controller/sort.rs:160-204 / 400-440: comma-separated keys, optional :asc / :desc, default
+    order per key; empty -> default strategy (idf desc, rmsd asc).  Returns [(dict key, sign)] (sign -1 = descending)."""
+    table = _STRUCT_KEYS if per_structure else _MATCH_KEYS
+    out = []
+    for part in (s or "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        comps = part.split(":")
+        if len(comps) > 2:
+            raise ValueError(f"Invalid format: '{part}'. Use 'key:order' or just 'key'")
+        k = comps[0].strip().lower()
+        if k not in table:
+            raise ValueError(f"Unknown sort key: '{comps[0]}'")
+        field, sign = table[k]
+        if len(comps) == 2:
+            o = comps[1].strip().lower()
+            if o in ("asc", "ascending", "a"):
+                sign = 1
+            elif o in ("desc", "descending", "d"):
+                sign = -1
+            else:
+                raise ValueError(f"Unknown sort order: '{comps[1]}'")
+        out.append((field, sign))
+    if not out:
+        out = [("idf", -1), ("min_rmsd_with_max_match" if per_structure else "rmsd", 1)]
+    return out
+
+
+def sort_rows(rows, strategy):
+    """stable multi-key sort (Vec::sort_by with the strategy's compare)"""
+    for field, sign in reversed(strategy):
+        rows.sort(key=lambda r: sign * r[field])
+    return rows
+
+
+def sample_query_hashes(index: FolddiscoIndex, q_hash, sampling_ratio=None, sampling_count=None):
+    """sample_query (src/controller/count_query.rs:222-253): keep the hashes with the shortest posting lists (stable sort by
+    length); ratio -> ceil(ratio * n) evaluated in f32; both or neither given -> all.  Returns the kept positions."""
+    n = len(q_hash)
+    if (sampling_ratio is None) == (sampling_count is None):
+        return np.arange(n)
+    lens = index.posting_lengths(np.ascontiguousarray(q_hash, np.uint32))
+    order = np.argsort(lens, kind="stable")
+    if sampling_ratio is not None:
+        keep = int(np.ceil(np.float32(sampling_ratio) * np.float32(n)))
+    else:
+        keep = int(sampling_count)
+    return order[: max(0, min(keep, n))]
+
+
 def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[CompactStructure], tids: list[str], nres, plddt,
               query: CompactStructure, query_string: str, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance=1.0, top_n=None,
-              length_penalty_power=0.5, skip_match=False, serial_query=False, freq_filter=None, dist_cutoff=20.0, nbin_dist=0, nbin_angle=0):
-    """The per-query body of query_pdb (src/cli/workflows/query_pdb.rs:348-519) with default filters.
-    Returns (structure rows, match rows) as lists of dicts, sorted like the reference's default strategies."""
+              length_penalty_power=0.5, skip_match=False, serial_query=False, freq_filter=None, dist_cutoff=20.0, nbin_dist=0, nbin_angle=0,
+              sampling_ratio=None, sampling_count=None, filters=None, sort_by=""):
+    """The per-query body of query_pdb (src/cli/workflows/query_pdb.rs:348-519).  `filters`: the reference's filtering options
+    (total_match, covered_node, covered_node_ratio, max_node, max_node_ratio, score, connected_node, connected_node_ratio,
+    num_residue, plddt, rmsd; 0 / absent = off), applied as StructureFilter before / after matching and MatchFilter
+    (controller/filter.rs:76-131, 194-235).  Returns (structure rows, match rows) as lists of dicts."""
+    F = dict(total_match=0, covered_node=0, covered_node_ratio=0.0, max_node=0, max_node_ratio=0.0, score=0.0, connected_node=0,
+             connected_node_ratio=0.0, num_residue=0, plddt=0.0, rmsd=0.0)
+    F.update(filters or {})
     S = len(tids)
     qres = parse_query_string(query_string, query.chains[0] if query.chains else ord("A"))
     if qres:
@@ -155,10 +229,23 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
     qm = make_query_map(ctx, qbatch, idx, subs, index, float(S), dist_thr, angle_thr, nbin_dist=nbin_dist, nbin_angle=nbin_angle,
                         dist_cutoff=dist_cutoff)
     pen = length_penalty(nres, length_penalty_power)
-    rows = count_query(ctx, index, qm.hash, qm.qi, qm.qj, pen, total_structures=S, freq_filter=freq_filter)
+    keep = sample_query_hashes(index, qm.hash, sampling_ratio, sampling_count)
+    rows = count_query(ctx, index, qm.hash[keep], qm.qi[keep], qm.qj[keep], pen, total_structures=S, freq_filter=freq_filter)
+    n_expected = np.float32(len(idx))   # residue_count: number of query residues (query_pdb.rs:384-389)
     for r in rows:
         r.update(tid=tids[r["nid"]], nres=int(nres[r["nid"]]), plddt=float(plddt[r["nid"]]), db_key=r["nid"], matches=[],
                  max_matching_node_count=0, min_rmsd_with_max_match=0.0)
+
+    def before(r):   # StructureFilter::filter_before_matching
+        ok = True
+        if F["total_match"] > 0: ok = ok and r["total_match_count"] >= F["total_match"]
+        if F["covered_node"] > 0: ok = ok and r["node_count"] >= F["covered_node"]
+        if F["covered_node_ratio"] > 0.0: ok = ok and np.float32(r["node_count"]) / n_expected >= np.float32(F["covered_node_ratio"])
+        if F["score"] > 0.0: ok = ok and np.float32(r["idf"]) >= np.float32(F["score"])
+        if F["num_residue"] > 0: ok = ok and r["nres"] <= F["num_residue"]
+        if F["plddt"] > 0.0: ok = ok and np.float32(r["plddt"]) >= np.float32(F["plddt"])
+        return ok
+    rows = [r for r in rows if before(r)]
     rows.sort(key=lambda r: -r["idf"])  # par_sort_by idf desc, stable (query_pdb.rs:404)
     if top_n is not None:
         rows = rows[:top_n]
@@ -181,8 +268,24 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
             elif cnt == r["max_matching_node_count"] and m["rmsd"] < r["min_rmsd_with_max_match"]:
                 r["min_rmsd_with_max_match"] = m["rmsd"]
             match_rows.append(m2)
-        # MatchSortStrategy::default: idf desc, rmsd asc (sort.rs:217-222), stable
-        match_rows.sort(key=lambda m: (-m["idf"], m["rmsd"]))
+        def after(r):    # StructureFilter::filter_after_matching
+            ok = True
+            if F["max_node"] > 0: ok = ok and r["max_matching_node_count"] >= F["max_node"]
+            if F["max_node_ratio"] > 0.0: ok = ok and np.float32(r["max_matching_node_count"]) / n_expected >= np.float32(F["max_node_ratio"])
+            if F["rmsd"] > 0.0: ok = ok and np.float32(r["min_rmsd_with_max_match"]) <= np.float32(F["rmsd"])
+            return ok
+        rows = [r for r in rows if after(r)]
+        kept = {r["nid"] for r in rows}
+
+        def mfilter(m):  # MatchFilter::filter
+            ok = m["nid"] in kept
+            if F["connected_node"] > 0: ok = ok and m["node_count"] >= F["connected_node"]
+            if F["connected_node_ratio"] > 0.0: ok = ok and np.float32(m["node_count"]) / n_expected >= np.float32(F["connected_node_ratio"])
+            if F["score"] > 0.0: ok = ok and np.float32(m["idf"]) >= np.float32(F["score"])
+            if F["rmsd"] > 0.0: ok = ok and np.float32(m["rmsd"]) <= np.float32(F["rmsd"])
+            return ok
+        match_rows = [m for m in match_rows if mfilter(m)]
+        sort_rows(match_rows, parse_sort_by(sort_by, False))
         if top_n is not None:
             match_rows = match_rows[:top_n]
     return rows, match_rows

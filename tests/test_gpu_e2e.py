@@ -183,3 +183,64 @@ def test_cli_index_and_query_reproduce_readme(tmp_path):
     assert ps[1] == "data/serine_peptidases/1pq5.pdb\t0.4869\t4\t3\t4\t3\t0.2609\t224\t5.1340\tA56,A99,A195:0.2609\t3\tB57,B102,C195"
     assert "data/serine_peptidases/1ju3.pdb\t0.0617\t2\t2\t2\t2\t0.7792\t570\t19.4881\t_,A223,A234:0.7792\t1\tB57,B102,C195" in ps
     assert "data/serine_peptidases/1l7a.pdb\t0.0584\t2\t2\t2\t2\t0.7883\t636\t11.7037\t_,A146,A127:0.7883;_,B146,B127:0.8078\t2\tB57,B102,C195" in ps
+
+
+@pytest.mark.gpu
+def test_cli_filters_sort_and_sampling(tmp_path):
+    """filtering options, --sort-by and --sampling-* of the query subcommand (query_pdb.rs:60-84, controller/filter.rs,
+    controller/sort.rs, count_query.rs:222-253) on the README example"""
+    import shutil
+    import subprocess
+    import sys
+    d = tmp_path / "data" / "serine_peptidases"
+    d.mkdir(parents=True)
+    for p in SER:
+        shutil.copy(p, d / os.path.basename(p))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    pre = str(tmp_path / "serine_folddisco")
+    subprocess.check_call([sys.executable, "-m", "folddisco_amd", "index", "-p", "data/serine_peptidases", "-i", pre], cwd=tmp_path, env=env)
+
+    def q(*extra):
+        return subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", pre, *extra],
+                              cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
+    base = q()
+    assert len(base) == 6
+    # MatchFilter: connected node count / ratio, rmsd, idf score
+    assert q("--connected-node", "3") == base[:3]
+    assert q("--connected-node-ratio", "0.9") == base[:3]
+    assert q("--rmsd", "0.1") == base[:2]
+    # --score is both the per-structure prefilter idf cutoff (0.6138 / 0.4869 pass, 0.0617 / 0.0584 / 0.1856 do not) and the per-match one
+    assert q("--score", "0.4") == base[:3] and q("--score", "4.0") == []
+    # StructureFilter before matching: covered nodes (prefilter node_count: 3 only for 4cha and 1pq5), after matching: max node
+    assert q("--covered-node", "3") == base[:3]
+    assert q("--max-node", "3") == base[:3]
+    assert q("--num-residue", "300") == [r for r in base if "1pq5" in r]
+    # --sort-by: idf ascending puts the 2-node matches (idf 1.4739) first, rmsd ascending inside ties
+    by_idf = q("--sort-by", "idf:asc,rmsd")
+    assert sorted(by_idf) == sorted(base) and [r.split("\t")[2] for r in by_idf] == ["1.4739"] * 3 + ["4.1178"] + ["8.7616"] * 2
+    # sampling: all hashes kept == no sampling; keeping fewer hashes can only lower the prefilter counts
+    assert q("--sampling-ratio", "1.0") == base
+    full = q("--per-structure", "--skip-match")
+    half = q("--per-structure", "--skip-match", "--sampling-ratio", "0.5")
+    tot = lambda rows: {r.split("\t")[0]: int(r.split("\t")[2]) for r in rows}
+    assert all(tot(half).get(k, 0) <= v for k, v in tot(full).items()) and sum(tot(half).values()) < sum(tot(full).values())
+
+
+@pytest.mark.gpu
+def test_sample_query_keeps_shortest_posting_lists():
+    import folddisco_amd as fd
+    from folddisco_amd import synth
+    from folddisco_amd.query import sample_query_hashes
+    ctx = fd.Context(0)
+    ps = synth.to_packed(synth.generate(200, seed=5))
+    ix = fd.FolddiscoIndex.build(ctx, ctx.upload(ps))
+    _, hashes, _ = ix.export()
+    rng = np.random.Generator(np.random.PCG64(1))
+    qh = rng.choice(hashes, size=37, replace=False).astype(np.uint32)
+    lens = ix.posting_lengths(qh)
+    order = np.argsort(lens, kind="stable")
+    assert list(sample_query_hashes(ix, qh)) == list(range(37))
+    assert list(sample_query_hashes(ix, qh, sampling_ratio=0.5, sampling_count=3)) == list(range(37))    # both given -> all
+    assert list(sample_query_hashes(ix, qh, sampling_count=5)) == list(order[:5])
+    assert list(sample_query_hashes(ix, qh, sampling_ratio=0.3)) == list(order[: int(np.ceil(np.float32(0.3) * np.float32(37)))])

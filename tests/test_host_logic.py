@@ -202,3 +202,20 @@ def test_index_files_roundtrip_and_text_files(tmp_path):
                    "num_bin_angle": 0, "num_bin_dist": 0}
     for x, want in [(50.0, "50"), (0.0, "0"), (13.540419, "13.540419"), (0.1, "0.1"), (1e-7, "0.0000001"), (float("nan"), "NaN"), (1.5e10, "15000000000")]:
         assert indexio.format_f32_display(x) == want
+
+
+def test_sort_by_grammar():
+    """--sort-by (src/controller/sort.rs:160-204, 400-440; unit tests :512-548, :671-698)"""
+    from folddisco_amd.query import parse_sort_by, sort_rows
+    assert parse_sort_by("node_count,rmsd", False) == [("node_count", -1), ("rmsd", 1)]
+    assert parse_sort_by("", False) == [("idf", -1), ("rmsd", 1)]                     # MatchSortStrategy::default
+    assert parse_sort_by("  ", True) == [("idf", -1), ("min_rmsd_with_max_match", 1)]  # StructureSortStrategy::default
+    assert parse_sort_by("NODE_COUNT:ASC, score", False) == [("node_count", 1), ("idf", -1)]
+    assert parse_sort_by("rmsd,max-node:a", True) == [("min_rmsd_with_max_match", 1), ("max_matching_node_count", 1)]
+    for bad in ("tm_score", "rmsd:up", "a:b:c"):
+        with pytest.raises(ValueError):
+            parse_sort_by(bad, False)
+    rows = [dict(node_count=2, rmsd=0.5, idf=1.0, k=0), dict(node_count=3, rmsd=0.9, idf=0.5, k=1), dict(node_count=3, rmsd=0.1, idf=0.2, k=2),
+            dict(node_count=3, rmsd=0.1, idf=0.9, k=3)]
+    assert [r["k"] for r in sort_rows(list(rows), parse_sort_by("node_count,rmsd", False))] == [2, 3, 1, 0]   # stable on ties
+    assert [r["k"] for r in sort_rows(list(rows), parse_sort_by("idf", False))] == [0, 3, 1, 2]
