@@ -1,7 +1,7 @@
 """`python -m folddisco_amd index|query …` — the reference's two hot-path subcommands with its flag names and defaults
 (src/cli/main.rs:26-110, src/cli/workflows/build_index.rs:64-241, src/cli/workflows/query_pdb.rs:144-519), driving the
 GPU path through the C ABI.  Structure order = lexicographic path order (the reference uses readdir order, which is
-filesystem dependent; SURVEY §7 hard part 3).  Only the default PDBTrRosetta encoding and PDB(.gz) input are supported."""
+filesystem dependent; SURVEY §7 hard part 3).  Only the default PDBTrRosetta encoding is supported; input is PDB or mmCIF, optionally gzip."""
 from __future__ import annotations
 
 import argparse
@@ -17,7 +17,7 @@ def _load_paths(d: str, recursive: bool):
         return [d]
     for root, dirs, files in os.walk(d):
         for f in files:
-            if f.lower().endswith((".pdb", ".ent", ".pdb.gz", ".ent.gz")):
+            if f.lower().endswith((".pdb", ".ent", ".pdb.gz", ".ent.gz", ".cif", ".cif.gz", ".mmcif", ".mmcif.gz")):
                 out.append(os.path.join(root, f))
         if not recursive:
             break
@@ -32,13 +32,14 @@ def cmd_index(a):
         sys.exit(f"[FAIL] no structures under {a.pdbs}")
     prefix = a.index or (a.pdbs.rstrip("/") + "_folddisco")
     ctx = fd.Context(a.device)
-    structs = []
-    for p in paths:
-        s = structure.read_compact_structure(p)
-        if s.num_residues_raw > 65535:  # DEFAULT_MAX_RESIDUE (controller/mod.rs:40,313-318): id kept, no hashes
+    # native multi-threaded ingest (csrc/fd_ingest.cpp); a structure above --max-residue keeps its id but has no hashes,
+    # nres 0 and plddt 0 (controller/mod.rs:313-318)
+    structs, ok = structure.read_compact_structures(paths, threads=a.threads, max_residue=a.max_residue)
+    for p, s, good in zip(paths, structs, ok):
+        if not good:
+            print(f"[WARN] {p} could not be read. Skipping", file=sys.stderr)
+        elif s.num_residues_raw > a.max_residue > 0:
             print(f"[WARN] {p} has too many residues. Skipping", file=sys.stderr)
-            s = structure.build_compact([])
-        structs.append(s)
     nres = np.array([s.n for s in structs], np.uint64)
     plddt = np.array([s.avg_plddt() if s.n else 0.0 for s in structs], np.float32)
     batch = ctx.upload(fd.PackedStructures.concat([s.as_item() for s in structs]))
@@ -75,12 +76,12 @@ def cmd_query(a):
         return cand if os.path.isfile(cand) else t
     db_structs, batch = None, None
     if not a.skip_match:
-        db_structs = [structure.read_compact_structure(resolve(t)) for t in tids]
+        db_structs, _ = structure.read_compact_structures([resolve(t) for t in tids], threads=a.threads)
         batch = ctx.upload(fd.PackedStructures.concat([s.as_item() for s in db_structs]))
     dthr = [float(x) for x in a.distance.replace(" ", "").split(",") if x]
     athr = [float(x) for x in a.angle.replace(" ", "").split(",") if x]
     for pdb, qstr, outp in queries:
-        q = structure.read_compact_structure(pdb)
+        q = structure.read_compact_structures([pdb], threads=1)[0][0]
         rows, matches = query.query_pdb(ctx, ix, batch, db_structs, tids, nres, plddt, q, qstr, dist_thr=dthr, angle_thr=athr,
                                         ca_distance=a.ca_distance, top_n=a.top, skip_match=a.skip_match, serial_query=a.serial_index,
                                         freq_filter=a.freq_filter, length_penalty_power=0.5 if a.length_penalty is None else a.length_penalty,

@@ -53,6 +53,12 @@ class MatchRec(C.Structure):
                 ("rot", C.c_float * 9), ("tran", C.c_float * 3)]
 
 
+class Parsed(C.Structure):
+    _fields_ = [("n_struct", C.c_uint64), ("n_res", C.c_uint64), ("res_off", u64p), ("n_xyz", f32p), ("ca_xyz", f32p), ("cb_xyz", f32p),
+                ("aa", u8p), ("cb_valid", u8p), ("chain", u8p), ("resname_std", u8p), ("serial", u64p), ("bfac", f32p),
+                ("resname", C.POINTER(C.c_char)), ("nres_raw", u64p), ("plddt", f32p), ("ok", u8p), ("first_chain", u8p)]
+
+
 # every symbol include/fdgpu.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("fdgpu_create", C.c_int, [C.c_int, C.POINTER(VP)]),
@@ -80,6 +86,8 @@ SYMBOLS = [
     ("fdgpu_count_query", C.c_int, [VP, VP, u32p, u32p, u32p, f32p, C.c_uint64, f32p, C.POINTER(C.POINTER(CountRec)), u64p]),
     ("fdgpu_count_query_batch", C.c_int, [VP, VP, C.c_uint64, u64p, u32p, u32p, u32p, f32p, f32p, C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
     ("fdgpu_spec_fallbacks", C.c_int, [VP, u64p]),
+    ("fdgpu_parse_structures", C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(Parsed))]),
+    ("fdgpu_parsed_free", None, [C.POINTER(Parsed)]),
     ("fdgpu_match_pairs", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(MatchQuery), C.POINTER(HashParams),
                                     C.POINTER(C.POINTER(PairRec)), u64p, C.POINTER(C.POINTER(CandRec)), u64p]),
     ("fdgpu_kabsch_batch", C.c_int, [VP, f32p, f32p, u64p, C.c_uint64, f32p, f32p, f32p]),

@@ -1,0 +1,409 @@
+// fd_ingest.cpp — structure ingest at speed: PDB / mmCIF (optionally gzip) text -> the packed
+// CompactStructure arrays the GPU path consumes, multi-threaded over files.
+//
+// Restates, quirks included:
+//   * PDB reader          src/structure/io/pdb.rs:37-77, fixed columns src/structure/io/parser.rs:3-56: only "ATOM  "
+//                         records, first model, a record with an unparsable number is skipped
+//   * mmCIF reader        src/structure/io/cif.rs:102-296: the loop whose header holds _atom_site.group_PDB; ATOM and HETATM
+//                         rows alike; first model number only; residue number auth_seq_id else label_seq_id; chain
+//                         auth_asym_id if one character else label_asym_id; B factor default 1.0
+//   * CompactStructure    src/structure/core.rs:70-214: residue boundary = change of the residue number only; the flush
+//                         also fires at the last atom index before that atom is examined; chain and b-factor of residue k
+//                         are read from the first atom of residue k+1; C is never reset (a virtual CB may use a stale C);
+//                         a GLY N is captured through the GLY branch; virtual CB src/structure/coordinate.rs:167-186
+//   * amino-acid map      src/utils/convert.rs:53-81
+// Host code only (no device work): text parsing is what remains of an index build once hashing runs on the GPU.
+#include <zlib.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/fdgpu.h"
+
+namespace {
+
+struct Atom {
+    float x, y, z, b;
+    char name[4], res[3];
+    uint8_t chain;
+    uint64_t rser;
+};
+
+struct Compact {
+    std::vector<float> n, ca, cb, bfac;
+    std::vector<uint8_t> aa, cb_ok, chain, std_name;
+    std::vector<uint64_t> serial;
+    std::vector<char> resname;
+    uint64_t nres_raw = 0;
+    uint8_t first_chain = ' ';   // chains[0] of the raw atom list (default chain of a query string)
+    bool ok = false;
+};
+
+const char *AA_GROUPS[20] = {
+    "ALA ABA ORN DAL AIB ALC MDO MAA DAB", "ARG DAR CIR AGM", "ASN DSG MEN SNN", "ASP 0TD DAS IAS PHD BFD ASX",
+    "CYS CSO CSD CME OCS CAS CSX CSS YCM DCY SMC SCH SCY CAF SNC SEC", "GLN DGN CRQ MEQ", "GLU PCA DGL CGU FGA B3E GLX",
+    "GLY CR2 SAR GHP GL3", "HIS HIC DHI NEP CR8 MHS", "ILE DIL", "LEU DLE NLE MLE MK8",
+    "LYS KCX LLP MLY M3L ALY MLZ DLY KPI PYL", "MET MSE FME NRQ CXM SME MHO MED", "PHE DPN PHI MEA PHL", "PRO HYP DPR",
+    "SER CSH SEP DSN SAC GYS DHA OAS", "THR TPO CRO DTH BMT CRF", "TRP DTR TRQ TOX 0AF", "TYR PTR TYS TPQ DTY OMY",
+    "VAL DVA MVA FVA"};
+
+uint8_t map_aa(const char r[3], bool *is_std) {
+    *is_std = false;
+    for (int k = 0; k < 20; ++k) {
+        const char *g = AA_GROUPS[k];
+        for (int pos = 0; g[pos]; pos += 4) {
+            if (g[pos] == r[0] && g[pos + 1] == r[1] && g[pos + 2] == r[2]) { *is_std = pos == 0; return (uint8_t)k; }
+            if (!g[pos + 3]) break;
+        }
+    }
+    return 255;
+}
+
+// Rust str::parse::<f32>() on a trimmed field: decimal / exponent / inf / nan, correctly rounded; nothing else
+bool parse_f32(const char *s, size_t n, float *out) {
+    while (n && (*s == ' ' || *s == '\t')) { ++s; --n; }
+    while (n && (s[n - 1] == ' ' || s[n - 1] == '\t' || s[n - 1] == '\r')) --n;
+    if (!n || n > 63) return false;
+    char buf[64];
+    bool digit = false, word = false;
+    for (size_t k = 0; k < n; ++k) {
+        char c = s[k];
+        if (c >= '0' && c <= '9') digit = true;
+        else if (c == '+' || c == '-' || c == '.' || c == 'e' || c == 'E') {}
+        else if (strchr("infatyINFATY", c)) word = true;
+        else return false;
+        buf[k] = c;
+    }
+    buf[n] = 0;
+    if (word) {   // only the spellings Rust accepts
+        const char *p = buf;
+        if (*p == '+' || *p == '-') ++p;
+        if (strcasecmp(p, "inf") && strcasecmp(p, "infinity") && strcasecmp(p, "nan")) return false;
+    } else if (!digit) return false;
+    char *end = nullptr;
+    float v = strtof(buf, &end);
+    if (end != buf + n) return false;
+    *out = v;
+    return true;
+}
+
+// Rust str::parse::<u64>() on a trimmed field: optional '+', digits, no overflow
+bool parse_u64(const char *s, size_t n, uint64_t *out) {
+    while (n && *s == ' ') { ++s; --n; }
+    while (n && (s[n - 1] == ' ' || s[n - 1] == '\r')) --n;
+    if (n && *s == '+') { ++s; --n; }
+    if (!n) return false;
+    uint64_t v = 0;
+    for (size_t k = 0; k < n; ++k) {
+        if (s[k] < '0' || s[k] > '9') return false;
+        uint64_t d = (uint64_t)(s[k] - '0');
+        if (v > (UINT64_MAX - d) / 10) return false;
+        v = v * 10 + d;
+    }
+    *out = v;
+    return true;
+}
+
+bool read_all(const char *path, std::string *out) {
+    gzFile f = gzopen(path, "rb");   // transparent for uncompressed files
+    if (!f) return false;
+    gzbuffer(f, 1 << 18);
+    out->clear();
+    char buf[1 << 16];
+    for (;;) {
+        int n = gzread(f, buf, sizeof buf);
+        if (n < 0) { gzclose(f); return false; }
+        if (n == 0) break;
+        out->append(buf, (size_t)n);
+    }
+    gzclose(f);
+    return true;
+}
+
+void parse_pdb(const std::string &txt, std::vector<Atom> *atoms) {
+    int model = 0;
+    size_t pos = 0, N = txt.size();
+    while (pos < N) {
+        size_t e = txt.find('\n', pos);
+        if (e == std::string::npos) e = N;
+        size_t len = e - pos;
+        const char *L = txt.data() + pos;
+        pos = e + 1;
+        if (len && L[len - 1] == '\r') --len;
+        if (model > 1) break;
+        if (len < 6) continue;
+        if (!memcmp(L, "MODEL ", 6)) { ++model; continue; }
+        if (memcmp(L, "ATOM  ", 6) || len < 54) continue;
+        Atom a;
+        uint64_t aser;
+        if (!parse_f32(L + 30, 8, &a.x) || !parse_f32(L + 38, 8, &a.y) || !parse_f32(L + 46, 8, &a.z)) continue;
+        if (!parse_u64(L + 6, 5, &aser) || !parse_u64(L + 22, 4, &a.rser)) continue;
+        a.b = 1.0f;
+        if (len >= 66 && !parse_f32(L + 60, 6, &a.b)) continue;
+        memcpy(a.name, L + 12, 4);
+        memcpy(a.res, L + 17, 3);
+        a.chain = (uint8_t)L[21];
+        atoms->push_back(a);
+    }
+}
+
+// ---- mmCIF: just enough of the CIF grammar for the atom_site loop
+struct CifTok { const char *p; size_t n; bool quoted; };
+
+// next token starting at *pos (skips whitespace and comments); returns false at end of input
+bool cif_next(const std::string &t, size_t *pos, CifTok *tok, bool *at_line_start) {
+    size_t i = *pos, N = t.size();
+    for (;;) {
+        while (i < N && (t[i] == ' ' || t[i] == '\t' || t[i] == '\r' || t[i] == '\n')) ++i;
+        if (i < N && t[i] == '#') { while (i < N && t[i] != '\n') ++i; continue; }
+        break;
+    }
+    if (i >= N) { *pos = i; return false; }
+    bool bol = i == 0 || t[i - 1] == '\n';
+    *at_line_start = bol;
+    if (bol && t[i] == ';') {   // text field: up to a line that starts with ';'
+        size_t s = i + 1, e = t.find("\n;", s);
+        if (e == std::string::npos) e = N;
+        *tok = {t.data() + s, e - s, true};
+        *pos = e + 2 <= N ? e + 2 : N;
+        return true;
+    }
+    if (t[i] == '\'' || t[i] == '"') {
+        char q = t[i];
+        size_t s = i + 1, e = s;
+        while (e < N && !(t[e] == q && (e + 1 >= N || t[e + 1] == ' ' || t[e + 1] == '\t' || t[e + 1] == '\n' || t[e + 1] == '\r')) && t[e] != '\n') ++e;
+        *tok = {t.data() + s, e - s, true};
+        *pos = e < N ? e + 1 : N;
+        return true;
+    }
+    size_t s = i;
+    while (i < N && t[i] != ' ' && t[i] != '\t' && t[i] != '\n' && t[i] != '\r') ++i;
+    *tok = {t.data() + s, i - s, false};
+    *pos = i;
+    return true;
+}
+
+bool tok_is(const CifTok &k, const char *s) { return !k.quoted && k.n == strlen(s) && !strncasecmp(k.p, s, k.n); }
+bool tok_missing(const CifTok &k) { return !k.quoted && k.n == 1 && (k.p[0] == '.' || k.p[0] == '?'); }
+// lexer's numeric value as the reference reads it (f32); integers must be integral (cif.rs get_isize)
+bool tok_f32(const CifTok &k, float *v) { return !k.quoted && !tok_missing(k) && parse_f32(k.p, k.n, v); }
+bool tok_int(const CifTok &k, uint64_t *v) {
+    float f;
+    if (!tok_f32(k, &f) || !(std::trunc(f) == f) || !(f >= -9.2233720368547758e18f && f < 9.2233720368547758e18f)) return false;
+    *v = (uint64_t)(int64_t)f;
+    return true;
+}
+
+void parse_cif(const std::string &txt, std::vector<Atom> *atoms) {
+    size_t pos = 0;
+    CifTok tk;
+    bool bol;
+    bool have = cif_next(txt, &pos, &tk, &bol);
+    while (have) {
+        if (!tok_is(tk, "loop_")) { have = cif_next(txt, &pos, &tk, &bol); continue; }
+        std::vector<std::string> header;
+        while ((have = cif_next(txt, &pos, &tk, &bol)) && !tk.quoted && tk.n && tk.p[0] == '_') header.emplace_back(tk.p + 1, tk.n - 1);
+        auto col = [&](const char *name) { for (size_t k = 0; k < header.size(); ++k) if (header[k] == name) return (int)k; return -1; };
+        const bool is_atoms = col("atom_site.group_PDB") >= 0;
+        const int c_asym = col("atom_site.label_asym_id"), c_aasym = col("atom_site.auth_asym_id"), c_b = col("atom_site.B_iso_or_equiv"),
+                  c_comp = col("atom_site.label_comp_id"), c_id = col("atom_site.id"), c_model = col("atom_site.pdbx_PDB_model_num"),
+                  c_name = col("atom_site.label_atom_id"), c_seq = col("atom_site.label_seq_id"), c_aseq = col("atom_site.auth_seq_id"),
+                  c_type = col("atom_site.type_symbol"), c_x = col("atom_site.Cartn_x"), c_y = col("atom_site.Cartn_y"), c_z = col("atom_site.Cartn_z");
+        const bool usable = is_atoms && c_asym >= 0 && c_comp >= 0 && c_id >= 0 && c_name >= 0 && c_seq >= 0 && c_type >= 0 && c_x >= 0 && c_y >= 0 && c_z >= 0;
+        // rows: values until the next loop_ / data name / data_ / save_ keyword
+        std::vector<CifTok> row;
+        const size_t W = header.size();
+        uint64_t first_model = 0, index = 0;
+        bool stop = false;
+        while (have) {
+            if (!tk.quoted && tk.n && (tk.p[0] == '_' || tok_is(tk, "loop_") || (tk.n >= 5 && (!strncasecmp(tk.p, "data_", 5) || !strncasecmp(tk.p, "save_", 5))))) break;
+            row.push_back(tk);
+            have = cif_next(txt, &pos, &tk, &bol);
+            if (row.size() < W || !W) continue;
+            if (usable && !stop) {
+                uint64_t model = 1, id, rser;
+                if (c_model >= 0) { uint64_t m; if (tok_int(row[c_model], &m)) model = m; }
+                if (index == 0) first_model = model;
+                else if (model != first_model) stop = true;
+                ++index;
+                Atom a;
+                bool good = !stop;
+                const CifTok &nm = row[c_name], &rs = row[c_comp];
+                if (good && (tok_missing(nm) || nm.n < 1 || nm.n > 4)) good = false;
+                if (good) {
+                    memset(a.name, ' ', 4);
+                    if (nm.n == 4) memcpy(a.name, nm.p, 4); else memcpy(a.name + 1, nm.p, nm.n);
+                    memset(a.res, ' ', 3);
+                    if (tok_missing(rs)) good = false;
+                    else if (rs.n <= 3) memcpy(a.res, rs.p, rs.n);   // longer names become blank (cif.rs:333-336)
+                }
+                if (good && !tok_int(row[c_id], &id)) good = false;
+                if (good && !((c_aseq >= 0 && tok_int(row[c_aseq], &rser)) || tok_int(row[c_seq], &rser))) good = false;
+                if (good) {
+                    const CifTok *ch = (c_aasym >= 0 && !tok_missing(row[c_aasym]) && row[c_aasym].n == 1) ? &row[c_aasym] : &row[c_asym];
+                    if (tok_missing(*ch) || ch->n != 1) good = false; else a.chain = (uint8_t)ch->p[0];
+                }
+                if (good && !(tok_f32(row[c_x], &a.x) && tok_f32(row[c_y], &a.y) && tok_f32(row[c_z], &a.z))) good = false;
+                if (good) { a.b = 1.0f; if (c_b >= 0) { float b; if (tok_f32(row[c_b], &b)) a.b = b; } a.rser = rser; atoms->push_back(a); }
+            }
+            row.clear();
+        }
+    }
+}
+
+inline void norm3(const float v[3], float o[3]) {
+    float n = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
+}
+// src/structure/coordinate.rs:167-186, every operation rounded to f32 in the reference's order
+void approx_cb(const float ca[3], const float n[3], const float c[3], float out[3]) {
+    float d1[3] = {c[0] - ca[0], c[1] - ca[1], c[2] - ca[2]}, d2[3] = {n[0] - ca[0], n[1] - ca[1], n[2] - ca[2]};
+    float v1[3], v2[3], b1[3], b2[3], u1[3], u2[3], v4[3];
+    norm3(d1, v1); norm3(d2, v2);
+    const float third = 1.0f / 3.0f;
+    for (int k = 0; k < 3; ++k) b1[k] = v2[k] + v1[k] * third;
+    b2[0] = v1[1] * b1[2] - v1[2] * b1[1]; b2[1] = v1[2] * b1[0] - v1[0] * b1[2]; b2[2] = v1[0] * b1[1] - v1[1] * b1[0];
+    norm3(b1, u1); norm3(b2, u2);
+    const float mh = -1.0f / 2.0f, s32 = sqrtf(3.0f) / 2.0f, s83 = sqrtf(8.0f) / 3.0f, mt = -1.0f / 3.0f;
+    for (int k = 0; k < 3; ++k) v4[k] = u1[k] * mh - u2[k] * s32;
+    for (int k = 0; k < 3; ++k) v4[k] = v4[k] * s83;
+    for (int k = 0; k < 3; ++k) v4[k] = v4[k] + v1[k] * mt;
+    for (int k = 0; k < 3; ++k) out[k] = ca[k] + v4[k] * 1.5336f;
+}
+
+void build_compact(const std::vector<Atom> &atoms, Compact *C) {
+    if (!atoms.empty()) C->first_chain = atoms[0].chain;
+    uint64_t rec_serial = 0;
+    for (const Atom &a : atoms) if (rec_serial != a.rser) { ++C->nres_raw; rec_serial = a.rser; }
+    bool have_prev = false, hn = false, hca = false, hcb = false, hc = false, hgn = false, hgc = false;
+    uint64_t prev_serial = 0;
+    char prev_name[3] = {' ', ' ', ' '};
+    float n[3], ca[3], cb[3], c[3], gn[3], gc[3];
+    const size_t na = atoms.size();
+    for (size_t idx = 0; idx < na; ++idx) {
+        const Atom &a = atoms[idx];
+        if (!have_prev || prev_serial != a.rser || idx == na - 1) {
+            if (hn && hca) {
+                float cbv[3] = {0.f, 0.f, 0.f};
+                uint8_t ok = 1;
+                if (hcb) memcpy(cbv, cb, 12);
+                else if (!memcmp(prev_name, "GLY", 3) && hgn && hgc) approx_cb(ca, gn, gc, cbv);
+                else if (hc) approx_cb(ca, n, c, cbv);
+                else ok = 0;
+                C->n.insert(C->n.end(), n, n + 3); C->ca.insert(C->ca.end(), ca, ca + 3); C->cb.insert(C->cb.end(), cbv, cbv + 3);
+                C->cb_ok.push_back(ok); C->serial.push_back(prev_serial);
+                C->resname.insert(C->resname.end(), prev_name, prev_name + 3);
+                bool is_std;
+                C->aa.push_back(map_aa(prev_name, &is_std));
+                C->std_name.push_back(is_std ? 1 : 0);
+                C->chain.push_back(a.chain); C->bfac.push_back(a.b);     // quirk: taken from the atom that triggered the flush
+            }
+            hca = hcb = hn = false;
+            prev_serial = a.rser; memcpy(prev_name, a.res, 3); have_prev = true;
+        }
+        const float xyz[3] = {a.x, a.y, a.z};
+        const bool gly = !memcmp(a.res, "GLY", 3);
+        if (!memcmp(a.name, " CA ", 4)) { memcpy(ca, xyz, 12); hca = true; }
+        else if (!memcmp(a.name, " CB ", 4)) { memcpy(cb, xyz, 12); hcb = true; }
+        else if (!memcmp(a.name, " C  ", 4)) { memcpy(c, xyz, 12); hc = true; if (gly) { /* the C branch wins: GLY C is not recorded as gly_c */ } }
+        else if (!memcmp(a.name, " N  ", 4) && !gly) { memcpy(n, xyz, 12); hn = true; }
+        else if (gly) {
+            if (!memcmp(a.name, " N  ", 4)) { memcpy(gn, xyz, 12); hgn = true; memcpy(n, xyz, 12); hn = true; }
+            else if (!memcmp(a.name, " C  ", 4)) { memcpy(gc, xyz, 12); hgc = true; }
+        }
+    }
+    C->ok = true;
+}
+
+bool ends_with_ci(const std::string &s, const char *suf) {
+    size_t n = strlen(suf);
+    return s.size() >= n && !strcasecmp(s.c_str() + s.size() - n, suf);
+}
+
+}  // namespace
+
+extern "C" int fdgpu_parse_structures(const char *const *paths, uint64_t n, uint32_t n_threads, uint64_t max_residue, fd_parsed **out) {
+    if (!out || (n && !paths)) return FDGPU_EINVAL;
+    *out = nullptr;
+    std::vector<Compact> parts(n);
+    std::atomic<uint64_t> next(0);
+    auto work = [&]() {
+        std::string txt;
+        std::vector<Atom> atoms;
+        for (;;) {
+            uint64_t k = next.fetch_add(1);
+            if (k >= n) break;
+            Compact &C = parts[k];
+            if (!paths[k] || !read_all(paths[k], &txt)) continue;
+            atoms.clear();
+            std::string p(paths[k]);
+            if (ends_with_ci(p, ".cif") || ends_with_ci(p, ".cif.gz") || ends_with_ci(p, ".mmcif") || ends_with_ci(p, ".mmcif.gz")) parse_cif(txt, &atoms);
+            else parse_pdb(txt, &atoms);
+            build_compact(atoms, &C);
+            if (max_residue && C.nres_raw > max_residue) {   // controller/mod.rs:313-318: id kept, no hashes, nres = 0
+                uint64_t raw = C.nres_raw;
+                uint8_t fc = C.first_chain;
+                C = Compact();
+                C.nres_raw = raw; C.first_chain = fc; C.ok = true;
+            }
+        }
+    };
+    uint32_t T = n_threads ? n_threads : std::max(1u, std::thread::hardware_concurrency());
+    T = (uint32_t)std::min<uint64_t>(T, std::max<uint64_t>(n, 1));
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+
+    fd_parsed *P = (fd_parsed *)calloc(1, sizeof(fd_parsed));
+    if (!P) return FDGPU_ENOMEM;
+    uint64_t R = 0;
+    for (auto &C : parts) R += C.aa.size();
+    P->n_struct = n; P->n_res = R;
+    const uint64_t R1 = R ? R : 1, S1 = n ? n : 1;
+    P->res_off = (uint64_t *)malloc((n + 1) * 8);
+    P->n_xyz = (float *)malloc(R1 * 12); P->ca_xyz = (float *)malloc(R1 * 12); P->cb_xyz = (float *)malloc(R1 * 12);
+    P->aa = (uint8_t *)malloc(R1); P->cb_valid = (uint8_t *)malloc(R1); P->chain = (uint8_t *)malloc(R1); P->resname_std = (uint8_t *)malloc(R1);
+    P->serial = (uint64_t *)malloc(R1 * 8); P->bfac = (float *)malloc(R1 * 4); P->resname = (char *)malloc(R1 * 3);
+    P->nres_raw = (uint64_t *)malloc(S1 * 8); P->plddt = (float *)malloc(S1 * 4); P->ok = (uint8_t *)malloc(S1); P->first_chain = (uint8_t *)malloc(S1);
+    if (!P->res_off || !P->n_xyz || !P->ca_xyz || !P->cb_xyz || !P->aa || !P->cb_valid || !P->chain || !P->resname_std || !P->serial || !P->bfac ||
+        !P->resname || !P->nres_raw || !P->plddt || !P->ok || !P->first_chain) { fdgpu_parsed_free(P); return FDGPU_ENOMEM; }
+    uint64_t off = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+        const Compact &C = parts[k];
+        const uint64_t m = C.aa.size();
+        P->res_off[k] = off;
+        if (m) {
+            memcpy(P->n_xyz + 3 * off, C.n.data(), m * 12); memcpy(P->ca_xyz + 3 * off, C.ca.data(), m * 12); memcpy(P->cb_xyz + 3 * off, C.cb.data(), m * 12);
+            memcpy(P->aa + off, C.aa.data(), m); memcpy(P->cb_valid + off, C.cb_ok.data(), m); memcpy(P->chain + off, C.chain.data(), m);
+            memcpy(P->resname_std + off, C.std_name.data(), m); memcpy(P->serial + off, C.serial.data(), m * 8); memcpy(P->bfac + off, C.bfac.data(), m * 4);
+            memcpy(P->resname + 3 * off, C.resname.data(), m * 3);
+        }
+        // get_avg_plddt (structure/core.rs:450-456): sequential f32 sum / n (NaN for an empty structure; the index
+        // workflow stores 0 for skipped structures, controller/mod.rs:313-318)
+        float s = 0.0f;
+        for (uint64_t r = 0; r < m; ++r) s = s + C.bfac[r];
+        P->plddt[k] = (max_residue && C.nres_raw > max_residue) ? 0.0f : s / (float)m;
+        P->nres_raw[k] = C.nres_raw;
+        P->ok[k] = C.ok ? 1 : 0;
+        P->first_chain[k] = C.first_chain;
+        off += m;
+    }
+    P->res_off[n] = off;
+    *out = P;
+    return FDGPU_OK;
+}
+
+extern "C" void fdgpu_parsed_free(fd_parsed *P) {
+    if (!P) return;
+    free(P->res_off); free(P->n_xyz); free(P->ca_xyz); free(P->cb_xyz); free(P->aa); free(P->cb_valid); free(P->chain); free(P->resname_std);
+    free(P->serial); free(P->bfac); free(P->resname); free(P->nres_raw); free(P->plddt); free(P->ok); free(P->first_chain);
+    free(P);
+}

@@ -204,6 +204,31 @@ int fdgpu_retrieve(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *resname
                    uint32_t node_count, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues);
 void fdgpu_matches_free(fd_match_rec *m, int32_t *residues);
 
+/* ---- structure ingest (host, multi-threaded) ---------------------------------------------------------------
+ * PDB / mmCIF text (optionally gzip) -> the packed arrays of fd_batch_desc plus what the .lookup file and the result
+ * printer need.  Replaces read_structure_from_path + CompactStructure::build inside the index / query workflows
+ * (src/controller/io.rs, src/structure/io/pdb.rs:37-77, src/structure/io/cif.rs:102-296, src/structure/core.rs:70-214,
+ * quirks kept).  A structure with more than max_residue residues (0 = no limit) keeps its slot but has no residues and
+ * pLDDT 0 (src/controller/mod.rs:313-318); an unreadable file has ok = 0 and no residues.  Format by file name:
+ * *.cif / *.mmcif (+ .gz) = mmCIF, everything else = PDB.  Release with fdgpu_parsed_free. */
+typedef struct fd_parsed {
+    uint64_t n_struct, n_res;
+    uint64_t *res_off;               /* [n_struct + 1] */
+    float *n_xyz, *ca_xyz, *cb_xyz;  /* [3 * n_res] */
+    uint8_t *aa, *cb_valid;          /* [n_res] 0..19 / 255; 1 = CB present (measured or virtual) */
+    uint8_t *chain;                  /* [n_res] chain id (of the next residue's first atom, core.rs:116) */
+    uint8_t *resname_std;            /* [n_res] 1 = the residue name is the standard 3-letter code of `aa` */
+    uint64_t *serial;                /* [n_res] residue number */
+    float *bfac;                     /* [n_res] */
+    char *resname;                   /* [3 * n_res] */
+    uint64_t *nres_raw;              /* [n_struct] residue count of the raw atom list (what max_residue is compared with) */
+    float *plddt;                    /* [n_struct] mean b-factor, f32 sequential sum (core.rs:450-456) */
+    uint8_t *ok;                     /* [n_struct] */
+    uint8_t *first_chain;            /* [n_struct] chain id of the first atom (default chain of a query string) */
+} fd_parsed;
+int fdgpu_parse_structures(const char *const *paths, uint64_t n, uint32_t n_threads, uint64_t max_residue, fd_parsed **out);
+void fdgpu_parsed_free(fd_parsed *p);
+
 /* ---- merging per-GPU / per-batch sub-indices into the reference's single index ----------------------------
  * Parts must cover ascending, disjoint id ranges in the order given (index build shards by structure).  Output is
  * the on-disk layout (value bytes, sparse hashes, offsets[H+1]); host-side, buffers released with fdgpu_free. */

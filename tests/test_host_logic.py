@@ -219,3 +219,43 @@ def test_sort_by_grammar():
             dict(node_count=3, rmsd=0.1, idf=0.9, k=3)]
     assert [r["k"] for r in sort_rows(list(rows), parse_sort_by("node_count,rmsd", False))] == [2, 3, 1, 0]   # stable on ties
     assert [r["k"] for r in sort_rows(list(rows), parse_sort_by("idf", False))] == [0, 3, 1, 2]
+
+
+def test_native_ingest_matches_python_and_oracle(tmp_path):
+    """csrc/fd_ingest.cpp (fdgpu_parse_structures; host only, no GPU needed) against the Python restatement and the oracle's C
+    parser on the reference's PDB fixtures (incl. a gzipped .ent), and mmCIF against PDB for an AlphaFold model, whose two
+    files hold the same ATOM records (data/io_test/cif/)."""
+    import glob
+    import gzip
+    import oracle
+    from folddisco_amd import structure
+    here = os.path.dirname(os.path.abspath(__file__))
+    pdbs = sorted(glob.glob(os.path.join(here, "golden", "serine_peptidases", "*.pdb"))) + sorted(glob.glob(os.path.join(here, "golden", "query", "*.pdb")))
+    io = os.path.join(here, "golden", "io")
+    gz = [os.path.join(io, "1b72a-.ent.gz"), os.path.join(io, "2wnb.pdb.gz"), os.path.join(io, "AF-A0A4S3KKF6-F1-model_v4.pdb.gz")]
+    nat, ok = structure.read_compact_structures(pdbs + gz, threads=3)
+    assert ok.tolist() == [1] * len(nat)
+
+    def same(a, b):
+        return (a.n == b.n and a.n_xyz.tobytes() == b.n_xyz.tobytes() and a.ca_xyz.tobytes() == b.ca_xyz.tobytes() and a.cb_xyz.tobytes() == b.cb_xyz.tobytes()
+                and a.cb_ok.tobytes() == b.cb_ok.tobytes() and a.aa.tobytes() == b.aa.tobytes() and list(a.resname) == list(b.resname)
+                and a.chain.tobytes() == b.chain.tobytes() and a.serial.tobytes() == b.serial.tobytes() and a.bfac.tobytes() == b.bfac.tobytes()
+                and a.num_residues_raw == b.num_residues_raw)
+    for p, a in zip(pdbs + gz, nat):
+        assert same(a, structure.read_compact_structure(p)), p
+        assert a.chains[:1] == structure.read_compact_structure(p).chains[:1]
+    for p, a in zip(pdbs, nat):                      # the oracle reads plain files
+        os_ = oracle.read_pdb(p)
+        o = os_.arrays()
+        assert a.n == os_.n and a.ca_xyz.tobytes() == o["ca_xyz"].tobytes() and a.cb_xyz.tobytes() == o["cb_xyz"].tobytes()
+        assert a.n_xyz.tobytes() == o["n_xyz"].tobytes() and a.aa.tobytes() == o["aa"].tobytes()
+        assert np.float32(a.avg_plddt()).tobytes() == np.float32(os_.avg_plddt()).tobytes()
+    # mmCIF: same model, same arrays; HETATM rows are not dropped by the reference's reader (cif.rs:279-287)
+    cif, ok2 = structure.read_compact_structures([os.path.join(io, "AF-A0A4S3KKF6-F1-model_v4.cif.gz"), os.path.join(io, "2wnb.cif.gz")], threads=2)
+    assert ok2.tolist() == [1, 1] and same(cif[0], nat[-1]) and cif[0].n == 738
+    assert cif[1].n == 273 and nat[-2].n == 270 and cif[1].num_residues_raw == 642
+    # plain-text mmCIF, a missing file, max_residue
+    plain = tmp_path / "af.cif"
+    plain.write_bytes(gzip.open(os.path.join(io, "AF-A0A4S3KKF6-F1-model_v4.cif.gz")).read())
+    r, okf = structure.read_compact_structures([str(plain), str(tmp_path / "nope.pdb"), pdbs[0]], threads=2, max_residue=700)
+    assert okf.tolist() == [1, 0, 1] and r[0].n == 0 and r[0].num_residues_raw == 738 and r[1].n == 0 and r[2].n == nat[0].n
