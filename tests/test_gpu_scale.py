@@ -1,0 +1,132 @@
+"""Full-size parity through size-independent properties (BASELINE.json configs[1]: E. coli-scale index build + motif
+queries on one GPU).  The oracle needs minutes at this size, so the checks are:
+
+* the index exported by fdgpu_index_build (unordered pairs + frames + tables + speculative torsions + radix sort + varint
+  encode) is byte-identical to the HOST inversion of the per-structure sorted-unique hash lists returned by
+  fdgpu_hash_batch — the S1 entry point, an independent kernel (row-major ordered pairs, generic exact libm chain) that
+  the small-size tests pin to the oracle;
+* encode -> decode round trip: the decoded posting lists are strictly ascending, inside the shard's id range, and their
+  multiset equals the (hash, id) pairs;
+* count_query on planted motifs equals a numpy recount over the decoded postings (match / node / edge counts exact, idf
+  relative 1e-5 — the tolerance DESIGN.md states for the f32 sum).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ECOLI = 4400
+
+
+def _host_inversion(h, off, first_id):
+    """(hashes, offsets, value bytes) of the reference's index layout from per-structure sorted-unique
+    hash lists: stable sort by hash keeps ids ascending; deltas as LEB128."""
+    ids = np.repeat(np.arange(len(off) - 1, dtype=np.uint64) + np.uint64(first_id), np.diff(off).astype(np.int64))
+    order = np.argsort(h, kind="stable")
+    hs, idsrt = h[order], ids[order]
+    first = np.ones(len(hs), bool)
+    first[1:] = hs[1:] != hs[:-1]
+    delta = idsrt.copy()
+    delta[1:] = np.where(first[1:], idsrt[1:], idsrt[1:] - idsrt[:-1])
+    nb = np.ones(len(delta), np.int64)
+    for k in range(1, 10):
+        nb += (delta >= (np.uint64(1) << np.uint64(7 * k))).astype(np.int64)
+    pos = np.concatenate([[0], np.cumsum(nb)])
+    value = np.zeros(pos[-1], np.uint8)
+    rem = delta.copy()
+    for k in range(int(nb.max())):
+        sel = nb > k
+        byte = (rem[sel] & np.uint64(0x7f)).astype(np.uint8)
+        more = (nb[sel] > k + 1)
+        value[pos[:-1][sel] + k] = byte | (more.astype(np.uint8) << 7)
+        rem[sel] >>= np.uint64(7)
+    uh = hs[first]
+    starts = np.nonzero(first)[0]
+    offsets = np.concatenate([pos[starts], [pos[-1]]]).astype(np.uint64)
+    return uh, offsets, value, hs, idsrt
+
+
+@pytest.fixture(scope="module")
+def ecoli():
+    import folddisco_amd as fd
+    from folddisco_amd import synth
+    ctx = fd.Context(0)
+    d = synth.generate(ECOLI, seed=4400)
+    ps = synth.to_packed(d)
+    batch = ctx.upload(ps)
+    first_id = 1000                      # a shard that does not start at 0: absolute first ids take two varint bytes
+    ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id)
+    return ctx, ps, batch, ix, first_id
+
+
+def test_index_equals_host_inversion_of_s1_hash_lists(ecoli):
+    import folddisco_amd as fd
+    ctx, ps, batch, ix, first_id = ecoli
+    h, off = fd.get_geometric_hash_as_u32(ctx, batch)          # sorted unique per structure
+    for s in (0, 1, ECOLI // 2, ECOLI - 1):
+        seg = h[int(off[s]):int(off[s + 1])]
+        assert np.all(seg[1:] > seg[:-1])
+    uh, offsets, value, _, _ = _host_inversion(h, off, first_id)
+    v, hh, oo = ix.export()
+    assert ix.num_hashes == len(uh) and ix.value_len == len(value)
+    assert np.array_equal(hh, uh) and np.array_equal(oo, offsets) and np.array_equal(v, value)
+
+
+def test_round_trip_and_count_query_at_scale(ecoli):
+    import folddisco_amd as fd
+    from folddisco_amd import querybench
+    from folddisco_amd.query import make_query_map
+    ctx, ps, batch, ix, first_id = ecoli
+    v, hh, oo = ix.export()
+    # decode every posting list on the host
+    term = (v & 0x80) == 0
+    assert term[-1] and term[oo[1:].astype(np.int64) - 1].all()          # every list ends on a terminator
+    tpos = np.nonzero(term)[0]
+    L = np.diff(np.concatenate([[-1], tpos]))                              # bytes per varint
+    start = tpos - L + 1
+    vals = np.zeros(len(tpos), np.uint64)
+    for k in range(int(L.max())):
+        sel = L > k
+        vals[sel] |= (v[start[sel] + k] & 0x7f).astype(np.uint64) << np.uint64(7 * k)
+    list_of_val = np.searchsorted(oo, tpos, side="right") - 1
+    starts = np.searchsorted(list_of_val, np.arange(len(hh)))
+    csum = np.cumsum(vals)
+    base = np.where(starts > 0, csum[np.maximum(starts, 1) - 1], np.uint64(0))
+    ids = csum - base[list_of_val]
+    assert ids.min() >= first_id and ids.max() < first_id + ECOLI
+    same = list_of_val[1:] == list_of_val[:-1]
+    assert np.all(ids[1:][same] > ids[:-1][same])                          # strictly ascending inside a list
+    h1, off1 = fd.get_geometric_hash_as_u32(ctx, batch)
+    assert len(ids) == len(h1)                                             # one posting per (structure, distinct hash)
+    # planted motifs: GPU scoring vs a numpy recount over the decoded postings
+    import torch
+    d = dict(res_off=torch.from_numpy(ps.res_off.astype(np.int64)), n_xyz=torch.from_numpy(ps.n_xyz), ca_xyz=torch.from_numpy(ps.ca_xyz),
+             cb_xyz=torch.from_numpy(ps.cb_xyz), aa=torch.from_numpy(ps.aa))
+    queries = querybench._pick_queries(d, ECOLI, 6, seed=7)
+    nres = np.diff(ps.res_off).astype(np.uint64)
+    pen = fd.length_penalty(nres, 0.5)
+    for s, idx, item in queries:
+        qb = ctx.upload(fd.PackedStructures.concat([item]))
+        qm = make_query_map(ctx, qb, idx, None, ix, float(ECOLI))
+        recs = fd.count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=ECOLI, as_array=True)
+        match = np.zeros(ECOLI, np.int64)
+        idf = np.zeros(ECOLI, np.float64)
+        nodes, edges = {}, {}
+        for qh, qi, qj in zip(qm.hash, qm.qi, qm.qj):
+            k = np.searchsorted(hh, qh)
+            if k >= len(hh) or hh[k] != qh:
+                continue
+            a, b = starts[k], (starts[k + 1] if k + 1 < len(hh) else len(ids))
+            loc = (ids[a:b] - first_id).astype(np.int64)
+            match[loc] += 1
+            idf[loc] += float(np.log2(np.float32(ECOLI) / np.float32(len(loc))))
+            nodes.setdefault(int(qi), np.zeros(ECOLI, bool))[loc] = True
+            edges.setdefault((int(qi), int(qj)), np.zeros(ECOLI, bool))[loc] = True
+        touched = np.nonzero(match)[0]
+        assert np.array_equal(recs["nid"].astype(np.int64) - first_id, touched)
+        assert np.array_equal(recs["total_match_count"], match[touched])
+        assert np.array_equal(recs["node_count"], sum(x.astype(np.int64) for x in nodes.values())[touched])
+        assert np.array_equal(recs["edge_count"], sum(x.astype(np.int64) for x in edges.values())[touched])
+        want = idf[touched] * pen[touched].astype(np.float64)
+        assert np.allclose(recs["idf"], want, rtol=1e-5, atol=1e-6)
+        assert s in touched                                                   # the structure the motif was cut from is a hit
