@@ -376,6 +376,17 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
         const uint32_t s = cand[slot];
         (void)s;
         const float *t_ca = t_all.data() + 3 * g_dst[slot], *t_cb = t_all.data() + 3 * g_total + 3 * g_dst[slot];
+        const uint32_t Rt = (uint32_t)(g_dst[slot + 1] - g_dst[slot]);
+        // candidate pairs of this structure bucketed by query residue (counting sort, order inside a bucket preserved)
+        std::vector<uint32_t> by_qi_off(q_size + 2, 0), by_qi_i(cpos - c0), by_qi_j(cpos - c0);
+        for (size_t e = c0; e < cpos; ++e) if (cands[e].qi < q_size) ++by_qi_off[cands[e].qi + 1];
+        for (uint32_t z = 0; z <= q_size; ++z) by_qi_off[z + 1] += by_qi_off[z];
+        {
+            std::vector<uint32_t> cur(by_qi_off.begin(), by_qi_off.end() - 1);
+            for (size_t e = c0; e < cpos; ++e) if (cands[e].qi < q_size) { uint32_t k = cur[cands[e].qi]++; by_qi_i[k] = cands[e].i; by_qi_j[k] = cands[e].j; }
+        }
+        std::vector<uint32_t> vote_of(Rt, 0), vote_touched;
+        std::vector<char> mapped_r(Rt, 0);
         for (auto &cc : comps) {
             std::vector<char> inc(g.w.size(), 0);
             for (uint32_t v : cc) inc[v] = 1;
@@ -418,6 +429,7 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
                 if (std::find(r_idx.begin(), r_idx.end(), x.r) != r_idx.end()) continue;
                 q_idx.push_back(x.q); r_idx.push_back(x.r);
             }
+            for (uint32_t r : r_idx) if (r < Rt) mapped_r[r] = 1;
             // residue assignment + rescue (retrieve.rs:430-516)
             std::vector<int32_t> from_hash(NQ, -1), processed(NQ, -1);
             std::vector<uint32_t> qs_sc, rs_sc;
@@ -437,13 +449,18 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
                         qs_sc.push_back(qi); rs_sc.push_back((uint32_t)mapped);
                     }
                 } else {
-                    std::vector<std::pair<uint32_t, uint32_t>> cnt;  // (target residue, votes)
-                    for (size_t e = c0; e < cpos; ++e) {
-                        if (cands[e].qi != qi) continue;
-                        if (std::find(r_idx.begin(), r_idx.end(), cands[e].j) == r_idx.end()) continue;
-                        bool hit = false;
-                        for (auto &kv : cnt) if (kv.first == cands[e].i) { kv.second++; hit = true; break; }
-                        if (!hit) cnt.emplace_back(cands[e].i, 1u);
+                    // votes per target residue among this query residue's candidate pairs whose partner is already mapped;
+                    // the candidate's pairs are bucketed by query residue once (whole-structure queries have millions)
+                    std::vector<std::pair<uint32_t, uint32_t>> cnt;  // (target residue, votes), first-seen order
+                    if (qi < q_size) {
+                        for (uint32_t t : vote_touched) vote_of[t] = 0;
+                        vote_touched.clear();
+                        for (uint32_t z = by_qi_off[qi]; z < by_qi_off[qi + 1]; ++z) {
+                            const uint32_t ci = by_qi_i[z], cj = by_qi_j[z];
+                            if (cj >= Rt || ci >= Rt || !mapped_r[cj]) continue;
+                            if (vote_of[ci]++ == 0) vote_touched.push_back(ci);
+                        }
+                        for (uint32_t t : vote_touched) cnt.emplace_back(t, vote_of[t]);
                     }
                     if (!cnt.empty()) {
                         uint32_t mx = 0, nmx = 0, arg = 0;
@@ -455,6 +472,7 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
                     }
                 }
             }
+            for (uint32_t r : r_idx) if (r < Rt) mapped_r[r] = 0;
             fd_match_rec rec;
             memset(&rec, 0, sizeof rec);
             rec.cand = (uint32_t)slot; rec.idf = sub_idf;

@@ -758,24 +758,40 @@ extern "C" int fdgpu_match_pairs(fdgpu_ctx *c, const fdgpu_batch *db, const uint
     HIPCHK(c, c->ws[WS_MISC1].ensure(std::max<size_t>(nw, 1) * 4));
     HIPCHK(c, c->ws[WS_MISC2].ensure(std::max<size_t>(nw, 1) * 4));
     HIPCHK(c, c->ws[WS_MISC3].ensure(std::max<uint64_t>(q->n_hashes, 1) * 4));
-    HIPCHK(c, c->ws[WS_MISC4].ensure(std::max<uint64_t>(q->n_aad, 1) * 10 + 64));
+    // aa_dist_map grouped by (aa_i, aa_j): stable order inside a group = the observed-list order the reference emits in
+    std::vector<uint32_t> a_start(1025, 0), a_qi;
+    std::vector<float> a_dist;
+    {
+        std::vector<uint32_t> cnt(1025, 0);
+        for (uint64_t e = 0; e < q->n_aad; ++e)
+            if (q->aad_aa1[e] < 32 && q->aad_aa2[e] < 32) ++cnt[q->aad_aa1[e] * 32u + q->aad_aa2[e] + 1];   // residue type 255 never passes get_single_feature
+        for (int k = 0; k < 1024; ++k) cnt[k + 1] += cnt[k];
+        a_start = cnt;
+        a_qi.resize(cnt[1024]); a_dist.resize(cnt[1024]);
+        std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+        for (uint64_t e = 0; e < q->n_aad; ++e)
+            if (q->aad_aa1[e] < 32 && q->aad_aa2[e] < 32) {
+                uint32_t k = cur[q->aad_aa1[e] * 32u + q->aad_aa2[e]]++;
+                a_qi[k] = q->aad_qi[e]; a_dist[k] = q->aad_dist[e];
+            }
+    }
+    size_t na = a_dist.size();
+    HIPCHK(c, c->ws[WS_MISC4].ensure(std::max<size_t>(na, 1) * 8 + 1025 * 4 + 64));
     HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
     uint8_t *aad_base = c->ws[WS_MISC4].as<uint8_t>();
-    size_t na = q->n_aad, na4 = (na + 3) & ~(size_t)3;
-    float *d_dist = (float *)aad_base;
-    uint32_t *d_qi = (uint32_t *)(aad_base + 4 * na4);
-    uint8_t *d_a1 = aad_base + 8 * na4, *d_a2 = aad_base + 9 * na4;
+    uint32_t *d_start = (uint32_t *)aad_base;
+    float *d_dist = (float *)(aad_base + 1025 * 4 + 12);
+    uint32_t *d_qi = (uint32_t *)(aad_base + 1025 * 4 + 12 + 4 * std::max<size_t>(na, 1));
     if (n_cand) HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, cand, n_cand * 4, hipMemcpyHostToDevice, st));
     if (nw) {
         HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, wc.data(), nw * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, wi.data(), nw * 4, hipMemcpyHostToDevice, st));
     }
     if (q->n_hashes) HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC3].p, q->hashes, q->n_hashes * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_start, a_start.data(), 1025 * 4, hipMemcpyHostToDevice, st));
     if (na) {
-        HIPCHK(c, hipMemcpyAsync(d_dist, q->aad_dist, na * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(d_qi, q->aad_qi, na * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(d_a1, q->aad_aa1, na, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(d_a2, q->aad_aa2, na, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(d_dist, a_dist.data(), na * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(d_qi, a_qi.data(), na * 4, hipMemcpyHostToDevice, st));
     }
     uint8_t *d_std = nullptr;
     if (resname_std) {
@@ -789,7 +805,7 @@ extern "C" int fdgpu_match_pairs(fdgpu_ctx *c, const fdgpu_batch *db, const uint
     A.wi_cand = c->ws[WS_MISC1].as<uint32_t>(); A.wi_i0 = c->ws[WS_MISC2].as<uint32_t>(); A.n_work = (uint32_t)nw;
     A.resname_std = d_std; A.aa1_mask = m1; A.aa2_mask = m2; A.use_prefilter = q->use_aa_prefilter;
     A.q_hashes = c->ws[WS_MISC3].as<uint32_t>(); A.n_hashes = (uint32_t)q->n_hashes;
-    A.aad_aa1 = d_a1; A.aad_aa2 = d_a2; A.aad_dist = d_dist; A.aad_qi = d_qi; A.n_aad = (uint32_t)na; A.ca_window = q->ca_distance_cutoff;
+    A.aad_start = d_start; A.aad_dist = d_dist; A.aad_qi = d_qi; A.n_aad = (uint32_t)na; A.ca_window = q->ca_distance_cutoff;
     A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.found = nullptr; A.cands = nullptr;
     // one emitting pass into buffers sized by the previous calls; a pass that overflows only counts, the buffers grow and
     // the pass is repeated (the scan is deterministic up to record order, which is restored below)

@@ -185,7 +185,8 @@ struct mp_args {
     uint32_t aa1_mask, aa2_mask;
     int use_prefilter;
     const uint32_t *q_hashes; uint32_t n_hashes;
-    const uint8_t *aad_aa1, *aad_aa2; const float *aad_dist; const uint32_t *aad_qi; uint32_t n_aad;
+    const uint32_t *aad_start;   // [1025] start of the (aa_i * 32 + aa_j) group in aad_dist / aad_qi (stable order)
+    const float *aad_dist; const uint32_t *aad_qi; uint32_t n_aad;
     float ca_window;
     unsigned long long *n_found, *n_cands;
     fd_pair_rec *found; fd_cand_rec *cands;

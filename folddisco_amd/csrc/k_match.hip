@@ -27,7 +27,7 @@ __device__ __forceinline__ bool hash_in_set(const uint32_t *__restrict__ h, uint
 // divergently per survivor this part — ~3000 instructions with the exact libm chain — was 95 % of the kernel time)
 template <bool EMIT>
 __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q, uint32_t n, uint32_t slot, uint32_t r0, uint32_t i0,
-                                            const uint16_t *s_aa, const float *s_d, const uint32_t *tab) {
+                                            const uint32_t *st_tab, const float *dist_tab, const uint32_t *tab) {
     const uint32_t lane = threadIdx.x;
     const bool on = lane < n;
     const uint32_t e0 = on ? q[lane] : 0u;
@@ -35,18 +35,15 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
     uint32_t aai = 255u, aaj = 255u, n_win = 0, h = 0;
     fd_v3 cai = {0.f, 0.f, 0.f}, caj = {0.f, 0.f, 0.f};
     float d = 0.f;
-    uint32_t key = 0;
+    uint32_t key = 0, e_lo = 0, e_hi = 0;
     bool hit = false;
     if (on) {
         aai = A.B.aa[i]; aaj = A.B.aa[j];
         cai = fd_load3(A.B.ca_xyz, i); caj = fd_load3(A.B.ca_xyz, j);
         d = fd_dist(cai, caj);
-        key = (aai << 8) | aaj;
-        for (uint32_t e = 0; e < A.n_aad; ++e) {
-            bool m = s_aa ? (s_aa[e] == key && fd_fabsf(d - s_d[e]) < A.ca_window)
-                          : (A.aad_aa1[e] == aai && A.aad_aa2[e] == aaj && fd_fabsf(d - A.aad_dist[e]) < A.ca_window);
-            n_win += m ? 1u : 0u;
-        }
+        key = (aai & 31u) * 32u + (aaj & 31u);   // queued pairs have aa < 32
+        e_lo = st_tab[key]; e_hi = st_tab[key + 1];
+        for (uint32_t e = e_lo; e < e_hi; ++e) n_win += (fd_fabsf(d - dist_tab[e]) < A.ca_window) ? 1u : 0u;
         if (A.C.use_tab) {
             // default angle bins: frames + exhaustive tables (fd_geom.h) — same bits as the generic chain, a tenth of the code
             fd_frame Fi = fd_make_frame(fd_load3(A.B.n_xyz, i), cai, fd_load3(A.B.cb_xyz, i));
@@ -79,10 +76,8 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
     const unsigned long long fpos = fbase + fd_mbcnt(hm);
     // EMIT with capacities: records beyond the caller's buffers are counted but not written (the caller grows and reruns)
     if (EMIT && on && cpos + n_win <= A.cap_cands && (!hit || fpos < A.cap_found)) {
-        for (uint32_t e = 0; e < A.n_aad; ++e) {
-            bool m = s_aa ? (s_aa[e] == key && fd_fabsf(d - s_d[e]) < A.ca_window)
-                          : (A.aad_aa1[e] == aai && A.aad_aa2[e] == aaj && fd_fabsf(d - A.aad_dist[e]) < A.ca_window);
-            if (m) {
+        for (uint32_t e = e_lo; e < e_hi; ++e) {
+            if (fd_fabsf(d - dist_tab[e]) < A.ca_window) {
                 fd_cand_rec c; c.cand = slot; c.qi = A.aad_qi[e]; c.i = i - r0; c.j = j - r0;
                 A.cands[cpos++] = c;
             }
@@ -96,23 +91,20 @@ template <bool EMIT>
 __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A) {
     __shared__ uint32_t q[2 * FD_WAVE];
     __shared__ uint32_t tab[32];
-    __shared__ uint16_t s_aa_buf[MP_AAD_LDS];
     __shared__ float s_d_buf[MP_AAD_LDS];
+    __shared__ uint32_t s_start[1025];
     const uint32_t w = blockIdx.x;
     if (w >= A.n_work) return;
-    // the query's observed (aa_i, aa_j, CA distance) list, staged in LDS (per-pair global reads of it made the scan
-    // latency-bound); longer lists (whole-structure queries) are read from global memory
+    // the query's observed (aa_i, aa_j) -> CA distance lists (aa_dist_map, controller/query.rs), grouped by residue-type pair:
+    // aad_start[aa_i * 32 + aa_j] .. [+1] indexes the distance / query-residue arrays (host-sorted, stable).  Start table and,
+    // for motif-sized queries, the distances live in LDS: per-pair global reads made the scan latency-bound.
     const bool staged = A.n_aad <= MP_AAD_LDS;
     if (threadIdx.x == 0 && A.C.use_tab) fd_fill_bintab(tab);
-    if (staged) {
-        for (uint32_t e = threadIdx.x; e < A.n_aad; e += FD_WAVE) {
-            s_aa_buf[e] = (uint16_t)(((uint32_t)A.aad_aa1[e] << 8) | A.aad_aa2[e]);
-            s_d_buf[e] = A.aad_dist[e];
-        }
-    }
+    for (uint32_t e = threadIdx.x; e < 1025; e += FD_WAVE) s_start[e] = A.aad_start[e];
+    if (staged)
+        for (uint32_t e = threadIdx.x; e < A.n_aad; e += FD_WAVE) s_d_buf[e] = A.aad_dist[e];
     __syncthreads();
-    const uint16_t *s_aa = staged ? s_aa_buf : nullptr;
-    const float *s_d = s_d_buf;
+    const float *dist_tab = staged ? s_d_buf : A.aad_dist;
     const uint32_t slot = A.wi_cand[w];
     const uint32_t s = A.cand[slot];
     const uint32_t r0 = A.B.res_off[s], r1 = A.B.res_off[s + 1];
@@ -141,12 +133,8 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A) {
     if (in_i) cai = fd_load3(A.B.ca_xyz, i);
     // partner residue types this lane's residue type has any observation with (aa < 32): one register test per pair
     uint32_t row_mask = 0;
-    for (uint32_t e = 0; e < A.n_aad; ++e) {
-        uint32_t a1 = staged ? (uint32_t)(s_aa_buf[e] >> 8) : (uint32_t)A.aad_aa1[e];
-        uint32_t a2 = staged ? (uint32_t)(s_aa_buf[e] & 0xffu) : (uint32_t)A.aad_aa2[e];
-        if (a1 == aai && a2 < 32u) row_mask |= 1u << a2;
-    }
-    const uint32_t keyi = aai << 8;
+    if (aai < 32u)
+        for (uint32_t a2 = 0; a2 < 32u; ++a2) row_mask |= (s_start[aai * 32u + a2 + 1] > s_start[aai * 32u + a2] ? 1u : 0u) << a2;
     uint32_t qn = 0;   // wave-uniform
     // j in blocks of 64: one coalesced load of (aa, CA) per block, then wave-uniform broadcasts (v_readlane)
     for (uint32_t jb = r0; jb < r1; jb += FD_WAVE) {
@@ -170,16 +158,10 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A) {
                 if (act && i != j && aaj < 32u && ((row_mask >> aaj) & 1u)) {
                     const float d = fd_dist(cai, caj);
                     if (d <= A.cutoff) {
-                        const uint32_t key = keyi | aaj;
-                        // branch-free: a short-circuit chain costs one LDS round trip per entry
+                        // branch-free over the pair's own list: a short-circuit chain costs one LDS round trip per entry
+                        const uint32_t e_lo = s_start[aai * 32u + aaj], e_hi = s_start[aai * 32u + aaj + 1];
                         uint32_t any = 0;
-                        if (staged) {
-                            for (uint32_t e = 0; e < A.n_aad; ++e)
-                                any |= (uint32_t)(s_aa_buf[e] == key) & (uint32_t)(fd_fabsf(d - s_d_buf[e]) < A.ca_window);
-                        } else {
-                            for (uint32_t e = 0; e < A.n_aad; ++e)
-                                any |= (uint32_t)(A.aad_aa1[e] == aai) & (uint32_t)(A.aad_aa2[e] == aaj) & (uint32_t)(fd_fabsf(d - A.aad_dist[e]) < A.ca_window);
-                        }
+                        for (uint32_t e = e_lo; e < e_hi; ++e) any |= (uint32_t)(fd_fabsf(d - dist_tab[e]) < A.ca_window);
                         pass = any != 0;
                     }
                 }
@@ -194,7 +176,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A) {
                 __syncthreads();
                 uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
                 qn -= n;
-                match_drain<EMIT>(A, q + qn, n, slot, r0, i0, s_aa, s_d, tab);
+                match_drain<EMIT>(A, q + qn, n, slot, r0, i0, s_start, dist_tab, tab);
                 __syncthreads();
             }
         }
