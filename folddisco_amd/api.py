@@ -239,7 +239,10 @@ def length_penalty(nres: np.ndarray, lp: float = 0.5) -> np.ndarray:
     libm = C.CDLL("libm.so.6")
     libm.powf.restype = C.c_float
     libm.powf.argtypes = [C.c_float, C.c_float]
-    return np.array([libm.powf(float(np.float32(n)), -lp) for n in np.asarray(nres)], dtype=np.float32)
+    nres = np.asarray(nres)
+    uniq, inv = np.unique(nres, return_inverse=True)          # one libm call per distinct length
+    lut = np.array([libm.powf(float(np.float32(n)), -lp) for n in uniq], dtype=np.float32)
+    return lut[inv] if len(nres) else np.zeros(0, np.float32)
 
 
 def idf_of_lengths(lengths: np.ndarray, total_structures: int) -> np.ndarray:
@@ -248,10 +251,10 @@ def idf_of_lengths(lengths: np.ndarray, total_structures: int) -> np.ndarray:
     libm.log2f.restype = C.c_float
     libm.log2f.argtypes = [C.c_float]
     S = np.float32(total_structures)
-    out = np.zeros(len(lengths), dtype=np.float32)
-    for k, n in enumerate(np.asarray(lengths)):
-        out[k] = libm.log2f(float(S / np.float32(n))) if n > 0 else np.inf
-    return out
+    lengths = np.asarray(lengths)
+    uniq, inv = np.unique(lengths, return_inverse=True)       # one libm call per distinct length
+    lut = np.array([libm.log2f(float(S / np.float32(n))) if n > 0 else np.inf for n in uniq], dtype=np.float32)
+    return lut[inv] if len(lengths) else np.zeros(0, np.float32)
 
 
 REC_DTYPE = np.dtype([("nid", np.uint32), ("total_match_count", np.uint32), ("node_count", np.uint32),
