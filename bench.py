@@ -88,8 +88,14 @@ def main():
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("FD_BENCH_BACKEND", "nccl")   # "gloo": several ranks on ONE GPU (plumbing smoke test)
+        if backend != "nccl":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -128,7 +134,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     value = world * S * args.steps / dt
@@ -165,7 +171,7 @@ def main():
         barrier()
         dtp = time.perf_counter() - t0p
         if dist is not None:
-            t = torch.tensor([dtp], dtype=torch.float64, device=dev)
+            t = torch.tensor([dtp], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtp = float(t.item())
         pipelined = {"value": world * S * args.steps / dtp, "unit": "structures/s", "streams": P, "ms_per_step": dtp / args.steps * 1e3,

@@ -52,6 +52,8 @@ def allgather_hits(local: np.ndarray, device: torch.device, top_n: int | None = 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return rank_hits(local, top_n)
     world = dist.get_world_size()
+    if dist.get_backend() != "nccl":
+        device = torch.device("cpu")     # gloo (CPU tests, single-GPU smoke runs): host tensors
     if top_n is not None:
         local = rank_hits(local, top_n)  # a rank never contributes more than top_n rows
     n = torch.tensor([len(local)], dtype=torch.int64, device=device)

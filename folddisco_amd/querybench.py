@@ -40,7 +40,12 @@ def _pick_queries(d, S, n_queries, seed, k=4):
 
 
 def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, match_top=32, seed=4242):
-    queries = _pick_queries(d, S, n_queries, seed)        # the same list on every rank (same seed; rank 0's shard layout)
+    # rank 0 cuts the motifs out of its shard and broadcasts them: every rank scores the SAME queries against its own shard
+    queries = _pick_queries(d, S, n_queries, seed) if rank == 0 else None
+    if dist is not None:
+        box = [queries]
+        dist.broadcast_object_list(box, src=0, device=dev if dist.get_backend() == "nccl" else None)
+        queries = box[0]
     nres = np.diff(d["res_off"].cpu().numpy()).astype(np.uint64)
     pen = length_penalty(nres, 0.5)
     S_total = S * world
@@ -75,7 +80,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             dist.barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, tot_hits, tot_hashes, tot_m
@@ -107,7 +112,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             dist.barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, tot
