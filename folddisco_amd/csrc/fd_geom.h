@@ -104,7 +104,7 @@ FD_HD uint32_t fd_hash_pdbtr(uint32_t aa1, uint32_t aa2, fd_feature f, fd_quant 
 //   torsion1(j,i): r = r1_j, s =  B, t = t1_j          torsion2(j,i): r = -A, s = s2_i, t = n^(r x nv2_i)
 // and d_CA, d_CB, theta are symmetric.  8 normalisations per ordered pair become 2.
 // =============================================================================================
-struct fd_frame {
+struct fd_frame {     // 20 floats = five 16-byte loads (a sixth load for a stored cb-ca costs more than the three subtractions)
     fd_v3 ca, cb;
     fd_v3 r1, t1;    // torsion(n, ca, cb, *):  r = n^((ca-n) x (cb-ca)),  t = n^(r x n^(cb-ca))
     fd_v3 s2, nv2;   // torsion(*, cb, ca, n):  s = n^((ca-cb) x (n-ca)),  n^(ca-cb)
@@ -132,8 +132,8 @@ FD_HD void fd_pair_both(const fd_frame &Fi, const fd_frame &Fj, uint32_t aai, ui
     fd_feature f, g;
     f.ca_dist = fd_dist(Fi.ca, Fj.ca);
     f.cb_dist = fd_dist(Fi.cb, Fj.cb);
-    fd_v3 v1 = {Fi.cb.x - Fi.ca.x, Fi.cb.y - Fi.ca.y, Fi.cb.z - Fi.ca.z};
-    fd_v3 v2 = {Fj.cb.x - Fj.ca.x, Fj.cb.y - Fj.ca.y, Fj.cb.z - Fj.ca.z};
+    const fd_v3 v1 = {Fi.cb.x - Fi.ca.x, Fi.cb.y - Fi.ca.y, Fi.cb.z - Fi.ca.z};
+    const fd_v3 v2 = {Fj.cb.x - Fj.ca.x, Fj.cb.y - Fj.ca.y, Fj.cb.z - Fj.ca.z};
     float dt = v1.x * v2.x + v1.y * v2.y + v1.z * v2.z;
     f.angle = fdd_acosf(dt / (Fi.len * Fj.len));
     fd_v3 v3 = fd_sub(Fj.cb, Fi.cb);
@@ -196,8 +196,17 @@ FD_HD void fd_fill_bintab(uint32_t *t) {
 
 FD_HD uint32_t fd_theta_key_of(float c, const uint32_t *t) {
     uint32_t n = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // c >= t  <=>  the f32 difference c - t is not negative (it is exact near zero, and x - x = +0): collect the six sign
+    // bits with v_alignbit, no compare / carry chains.  A NaN c is rejected by the range test below.
+    uint32_t neg = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) neg = __builtin_amdgcn_alignbit(neg, fd_f2u(c - fd_u2f(t[k])), 31);
+    n = 6u - (uint32_t)__builtin_popcount(neg & 63u);
+#else
 #pragma unroll
     for (int k = 0; k < 6; ++k) n += (c >= fd_u2f(t[k])) ? 1u : 0u;
+#endif
     uint32_t key = (t[6] >> (4u * n)) & 15u;
     return (c >= -1.0f && c <= 1.0f) ? key : 0u;   // |c| > 1 or NaN: acosf -> NaN -> both bins 0
 }
@@ -227,12 +236,12 @@ FD_HD uint32_t fd_tor_key_of(float y, float x, const uint32_t *t) {
 FD_HD void fd_pair_both_tab(const fd_frame &Fi, const fd_frame &Fj, uint32_t aai, uint32_t aaj, fd_quant q, const uint32_t *tab,
                             uint32_t *h_ij, uint32_t *h_ji) {
     float ca_dist = fd_dist(Fi.ca, Fj.ca);
-    float cb_dist = fd_dist(Fi.cb, Fj.cb);
-    fd_v3 v1 = {Fi.cb.x - Fi.ca.x, Fi.cb.y - Fi.ca.y, Fi.cb.z - Fi.ca.z};
-    fd_v3 v2 = {Fj.cb.x - Fj.ca.x, Fj.cb.y - Fj.ca.y, Fj.cb.z - Fj.ca.z};
+    const fd_v3 v1 = {Fi.cb.x - Fi.ca.x, Fi.cb.y - Fi.ca.y, Fi.cb.z - Fi.ca.z};
+    const fd_v3 v2 = {Fj.cb.x - Fj.ca.x, Fj.cb.y - Fj.ca.y, Fj.cb.z - Fj.ca.z};
     float dt = v1.x * v2.x + v1.y * v2.y + v1.z * v2.z;
     uint32_t kth = fd_theta_key_of(dt / (Fi.len * Fj.len), tab);
     fd_v3 v3 = fd_sub(Fj.cb, Fi.cb);
+    float cb_dist = fd_sqrtf(v3.x * v3.x + v3.y * v3.y + v3.z * v3.z);   // == fd_dist(Fi.cb, Fj.cb): (p-q)^2 == (q-p)^2 bit for bit
     fd_v3 A = fd_normalize(fd_cross(v1, v3));
     fd_v3 B = fd_normalize(fd_cross(v3, v2));
     uint32_t k1 = fd_tor_key_of(fd_dot(A, Fi.t1), fd_dot(Fi.r1, A), tab);
@@ -306,12 +315,12 @@ __device__ __forceinline__ fd_v3 fd_normalize_spec(fd_v3 v, float *rs_out) {
 __device__ __forceinline__ bool fd_pair_both_spec(const fd_frame &Fi, const fd_frame &Fj, uint32_t aai, uint32_t aaj, fd_quant q,
                                                   const uint32_t *tab, const uint32_t *tab_f, uint32_t *h_ij, uint32_t *h_ji) {
     float ca_dist = fd_dist(Fi.ca, Fj.ca);
-    float cb_dist = fd_dist(Fi.cb, Fj.cb);
-    fd_v3 v1 = {Fi.cb.x - Fi.ca.x, Fi.cb.y - Fi.ca.y, Fi.cb.z - Fi.ca.z};
-    fd_v3 v2 = {Fj.cb.x - Fj.ca.x, Fj.cb.y - Fj.ca.y, Fj.cb.z - Fj.ca.z};
+    const fd_v3 v1 = {Fi.cb.x - Fi.ca.x, Fi.cb.y - Fi.ca.y, Fi.cb.z - Fi.ca.z};
+    const fd_v3 v2 = {Fj.cb.x - Fj.ca.x, Fj.cb.y - Fj.ca.y, Fj.cb.z - Fj.ca.z};
     float dt = v1.x * v2.x + v1.y * v2.y + v1.z * v2.z;
     uint32_t kth = fd_theta_key_of(dt / (Fi.len * Fj.len), tab);     // exact: one division, no normalisation upstream
     fd_v3 v3 = fd_sub(Fj.cb, Fi.cb);
+    float cb_dist = fd_sqrtf(v3.x * v3.x + v3.y * v3.y + v3.z * v3.z);   // == fd_dist(Fi.cb, Fj.cb): (p-q)^2 == (q-p)^2 bit for bit
     float rsA, rsB, rsXA, rsXB;
     fd_v3 A = fd_normalize_spec(fd_cross(v1, v3), &rsA);
     fd_v3 B = fd_normalize_spec(fd_cross(v3, v2), &rsB);

@@ -490,7 +490,7 @@ __device__ __forceinline__ void rs_scatter4_body(const uint32_t *__restrict__ ke
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const int32_t m = __builtin_amdgcn_sbfe((int32_t)d, b, 1);      // 0 or ~0
-            const uint64_t bal = __ballot(m != 0);
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(m < 0);   // sign test of the extracted bit: one v_cmp on m itself
             plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, (uint32_t)m, 0x90);
             phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), (uint32_t)m, 0x90);
         }
@@ -548,6 +548,36 @@ __device__ __forceinline__ void rs_scatter4_body(const uint32_t *__restrict__ ke
             keys_out[g] = kk;
             vals_out[g] = (V)vv;
         }
+    }
+}
+
+// measurement aid (FDGPU_SORT=classic30): the scatter's memory skeleton without ranking — load the tile like k_rs_scatter4, stage
+// through LDS, store the tile back in place order.  NOT a sort; used only to read off the kernel's memory floor.
+template <int THREADS, int ITEMS, typename V>
+__global__ __launch_bounds__(THREADS) void k_rs_copy_floor(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                                           uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n, uint32_t nb) {
+    constexpr int TILE = THREADS * ITEMS;
+    __shared__ uint32_t s_keys[TILE];
+    __shared__ V s_vals[TILE];
+    const uint32_t tile = fd_xcd_remap(blockIdx.x, nb);
+    if (tile >= nb || (uint64_t)(tile + 1) * TILE > n) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint64_t tile_base = (uint64_t)tile * TILE;
+    const uint32_t *kp = keys_in + tile_base + (uint64_t)wid * (64 * ITEMS) + lane;
+    const V *vp = vals_in + tile_base + (uint64_t)wid * (64 * ITEMS) + lane;
+    uint32_t key[ITEMS];
+    V val[ITEMS];
+#pragma unroll
+    for (int c = 0; c < ITEMS; ++c) { key[c] = kp[c * 64]; val[c] = vp[c * 64]; }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ITEMS; ++c) { uint32_t pos = wid * 64 * ITEMS + c * 64 + lane; s_keys[pos] = key[c]; s_vals[pos] = val[c]; }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ITEMS; ++c) {
+        uint32_t k = c * THREADS + tid;
+        keys_out[tile_base + k] = s_keys[k];
+        vals_out[tile_base + k] = s_vals[k];
     }
 }
 
@@ -972,6 +1002,12 @@ static int radix_sort_pairs_t(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *
             case 20: rs_pass4<512, 8, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 21: rs_pass4<512, 16, V, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 22: rs_pass4<256, 16, V, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            case 30: {   // memory floor of the scatter (see k_rs_copy_floor); the result is NOT sorted
+                uint32_t nb = (uint32_t)((n + 8191) / 8192), grid = ((nb + 7u) / 8u) * 8u;
+                StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
+                hipLaunchKernelGGL((k_rs_copy_floor<512, 16, V>), dim3(grid), dim3(512), 0, st, ki, vi, ko, vo, n, nb);
+                break;
+            }
             case 12: rs_pass2<1024, 8, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 13: rs_pass2<1024, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 14: rs_pass2<512, 24, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
