@@ -91,7 +91,8 @@ def cmd_query(a):
                                         filters=dict(total_match=a.total_match, covered_node=a.covered_node, covered_node_ratio=a.covered_node_ratio,
                                                      max_node=a.max_node, max_node_ratio=a.max_node_ratio, score=a.score,
                                                      connected_node=a.connected_node, connected_node_ratio=a.connected_node_ratio,
-                                                     num_residue=a.num_residue, plddt=a.plddt, rmsd=a.rmsd))
+                                                     num_residue=a.num_residue, plddt=a.plddt, rmsd=a.rmsd, tm_score=a.tm_score,
+                                                     gdt_ts=a.gdt_ts, gdt_ha=a.gdt_ha, chamfer=a.chamfer, hausdorff=a.hausdorff))
         fh = open(outp, "w") if outp else sys.stdout
         if a.skip_match or a.per_structure:
             if a.header:
@@ -100,10 +101,14 @@ def cmd_query(a):
             for r in rows:
                 fh.write(query.format_structure_row(r, qstr) + "\n")
         else:
+            cols = [c.strip() for c in a.format_output.split(",") if c.strip()] or ["tid", "node_count", "idf", "rmsd", "matching_residues", "query_residues"]
+            for c in cols:
+                if c not in query.MATCH_COLUMNS:
+                    sys.exit(f"[FAIL] unknown --format-output column '{c}' (per-match: {', '.join(query.MATCH_COLUMNS)})")
             if a.header:
-                fh.write("tid\tnode_count\tidf\trmsd\tmatching_residues\tquery_residues\n")
+                fh.write("\t".join(cols) + "\n")
             for m in matches:
-                fh.write(query.format_match_row(m) + "\n")
+                fh.write(query.format_match_columns(m, cols) + "\n")
         if outp:
             fh.close()
 
@@ -151,6 +156,12 @@ def main(argv=None):
     pq.add_argument("--num-residue", type=int, default=50000)
     pq.add_argument("--plddt", type=float, default=0.0)
     pq.add_argument("--rmsd", type=float, default=0.0)
+    pq.add_argument("--tm-score", type=float, default=0.0)
+    pq.add_argument("--gdt-ts", type=float, default=0.0)
+    pq.add_argument("--gdt-ha", type=float, default=0.0)
+    pq.add_argument("--chamfer", type=float, default=0.0)
+    pq.add_argument("--hausdorff", type=float, default=0.0)
+    pq.add_argument("--format-output", default="")
     pq.add_argument("--sort-by", default="node_count,rmsd")          # query_pdb.rs:573
     pq.add_argument("--length-penalty", type=float, default=None)
     pq.add_argument("-o", "--output", default="")

@@ -130,12 +130,18 @@ def retrieve(ctx: Context, db: Batch, resname_std, cand, qm: QueryMapResult, qba
         base = 2 * nq * k
         out.append(dict(cand=int(r.cand), idf=float(r.idf), rmsd=float(r.rmsd), rmsd_from_hash=float(r.rmsd_from_hash), same=bool(r.same),
                         from_hash=[rp[base + z] for z in range(nq)], processed=[rp[base + nq + z] for z in range(nq)],
-                        rot=np.array(list(r.rot), np.float32).reshape(3, 3), tran=np.array(list(r.tran), np.float32)))
+                        rot=np.array(list(r.rot), np.float32).reshape(3, 3), tran=np.array(list(r.tran), np.float32),
+                        metrics=np.array(list(r.metrics), np.float32)))
     ctx.L.fdgpu_matches_free(mp, rp)
     return out
 
 
-_MATCH_KEYS = {"node_count": ("node_count", -1), "node-count": ("node_count", -1), "nodes": ("node_count", -1), "node": ("node_count", -1),
+_MATCH_KEYS = {"tm_score": ("tm_score", -1), "tm-score": ("tm_score", -1), "tmscore": ("tm_score", -1), "tm": ("tm_score", -1),
+               "gdt_ts": ("gdt_ts", -1), "gdt-ts": ("gdt_ts", -1), "gdtts": ("gdt_ts", -1), "gdt": ("gdt_ts", -1), "gdt_ha": ("gdt_ha", -1), "gdt-ha": ("gdt_ha", -1),
+               "gdtha": ("gdt_ha", -1), "chamfer_distance": ("chamfer_distance", 1), "chamfer-distance": ("chamfer_distance", 1),
+               "chamfer": ("chamfer_distance", 1), "hausdorff_distance": ("hausdorff_distance", 1),
+               "hausdorff-distance": ("hausdorff_distance", 1), "hausdorff": ("hausdorff_distance", 1),
+               "node_count": ("node_count", -1), "node-count": ("node_count", -1), "nodes": ("node_count", -1), "node": ("node_count", -1),
                "n": ("node_count", -1), "idf": ("idf", -1), "score": ("idf", -1), "rmsd": ("rmsd", 1)}
 _STRUCT_KEYS = {"max_node_count": ("max_matching_node_count", -1), "max-node-count": ("max_matching_node_count", -1),
                 "max_node": ("max_matching_node_count", -1), "max-node": ("max_matching_node_count", -1),
@@ -212,7 +218,7 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
     num_residue, plddt, rmsd; 0 / absent = off), applied as StructureFilter before / after matching and MatchFilter
     (controller/filter.rs:76-131, 194-235).  Returns (structure rows, match rows) as lists of dicts."""
     F = dict(total_match=0, covered_node=0, covered_node_ratio=0.0, max_node=0, max_node_ratio=0.0, score=0.0, connected_node=0,
-             connected_node_ratio=0.0, num_residue=0, plddt=0.0, rmsd=0.0)
+             connected_node_ratio=0.0, num_residue=0, plddt=0.0, rmsd=0.0, tm_score=0.0, gdt_ts=0.0, gdt_ha=0.0, chamfer=0.0, hausdorff=0.0)
     F.update(filters or {})
     S = len(tids)
     qres = parse_query_string(query_string, query.chains[0] if query.chains else ord("A"))
@@ -260,7 +266,10 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
             lab = lambda lst: ["_" if x < 0 else f"{chr(int(t.chain[x]))}{int(t.serial[x])}" for x in lst]
             r.setdefault("match_strs", []).append(",".join(lab(m["processed"])) + ":%.4f" % m["rmsd"])
             m2 = dict(tid=r["tid"], nid=r["nid"], node_count=sum(x >= 0 for x in m["processed"]), idf=m["idf"], rmsd=m["rmsd"],
-                      matching_residues=",".join(lab(m["processed"])), query_residues=res_chain_to_string(qres) if qres else query_string)
+                      matching_residues=",".join(lab(m["processed"])), query_residues=res_chain_to_string(qres) if qres else query_string,
+                      tm_score=float(m["metrics"][0]), gdt_ts=float(m["metrics"][1]), gdt_ha=float(m["metrics"][2]),
+                      chamfer_distance=float(m["metrics"][3]), hausdorff_distance=float(m["metrics"][4]), db_key=r["nid"],
+                      u_matrix=m["rot"], t_vector=m["tran"])
             r["matches"].append(m2)
             cnt = m2["node_count"]
             if cnt > r["max_matching_node_count"]:
@@ -283,6 +292,11 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
             if F["connected_node_ratio"] > 0.0: ok = ok and np.float32(m["node_count"]) / n_expected >= np.float32(F["connected_node_ratio"])
             if F["score"] > 0.0: ok = ok and np.float32(m["idf"]) >= np.float32(F["score"])
             if F["rmsd"] > 0.0: ok = ok and np.float32(m["rmsd"]) <= np.float32(F["rmsd"])
+            if F["tm_score"] > 0.0: ok = ok and np.float32(m["tm_score"]) >= np.float32(F["tm_score"])
+            if F["gdt_ts"] > 0.0: ok = ok and np.float32(m["gdt_ts"]) >= np.float32(F["gdt_ts"])
+            if F["gdt_ha"] > 0.0: ok = ok and np.float32(m["gdt_ha"]) >= np.float32(F["gdt_ha"])
+            if F["chamfer"] > 0.0: ok = ok and np.float32(m["chamfer_distance"]) <= np.float32(F["chamfer"])
+            if F["hausdorff"] > 0.0: ok = ok and np.float32(m["hausdorff_distance"]) <= np.float32(F["hausdorff"])
             return ok
         match_rows = [m for m in match_rows if mfilter(m)]
         sort_rows(match_rows, parse_sort_by(sort_by, False))
@@ -302,3 +316,19 @@ def format_structure_row(r, query_residues: str) -> str:
     return "\t".join([r["tid"], "%.4f" % r["idf"], str(r["total_match_count"]), str(r["node_count"]), str(r["edge_count"]),
                       str(r["max_matching_node_count"]), "%.4f" % r["min_rmsd_with_max_match"], str(r["nres"]), "%.4f" % r["plddt"], ms,
                       str(r["db_key"]), query_residues])
+
+
+# --format-output column names of the per-match table (src/controller/result.rs:280-298); floats {:.4}
+MATCH_COLUMNS = {
+    "tid": lambda m: m["tid"], "nid": lambda m: str(m["nid"]), "db_key": lambda m: str(m["db_key"]),
+    "node_count": lambda m: str(m["node_count"]), "idf": lambda m: "%.4f" % m["idf"], "rmsd": lambda m: "%.4f" % m["rmsd"],
+    "matching_residues": lambda m: m["matching_residues"], "query_residues": lambda m: m["query_residues"],
+    "tm_score": lambda m: "%.4f" % m["tm_score"], "gdt_ts": lambda m: "%.4f" % m["gdt_ts"], "gdt_ha": lambda m: "%.4f" % m["gdt_ha"],
+    "chamfer_distance": lambda m: "%.4f" % m["chamfer_distance"], "hausdorff_distance": lambda m: "%.4f" % m["hausdorff_distance"],
+    "u_matrix": lambda m: ",".join("%.4f" % x for x in np.asarray(m["u_matrix"]).reshape(-1)),
+    "t_vector": lambda m: ",".join("%.4f" % x for x in np.asarray(m["t_vector"]).reshape(-1)),
+}
+
+
+def format_match_columns(m, columns) -> str:
+    return "\t".join(MATCH_COLUMNS[c](m) for c in columns)

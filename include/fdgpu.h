@@ -195,6 +195,7 @@ typedef struct fd_match_rec {   /* one connected component of one candidate (ret
     float rmsd;                 /* of the processed mapping (what the per-match output prints) */
     float rmsd_from_hash;
     float rot[9], tran[3];      /* target -> query superposition of the processed mapping */
+    float metrics[5];           /* tm_score, gdt_ts, gdt_ha, chamfer, hausdorff of that superposition (structure/metrics.rs) */
 } fd_match_rec;
 /* residues: 2 * n_indices int32 per match — target residue index (relative to its structure, -1 = "_") for
  * every query residue, first the from-hash mapping then the processed (rescued) one. Release both with

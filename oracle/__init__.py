@@ -162,6 +162,8 @@ def lib():
     L.fdo_retrieval_free.argtypes = [C.POINTER(Retrieval)]
     L.fdo_kabsch.restype = C.c_float
     L.fdo_kabsch.argtypes = [f32p, f32p, C.c_uint64, C.c_int, f32p, f32p]
+    L.fdo_metrics.restype = None
+    L.fdo_metrics.argtypes = [f32p, f32p, C.c_uint64, f32p, f32p, f32p]
     _lib = L
     return L
 
@@ -416,3 +418,14 @@ def kabsch(x: np.ndarray, y: np.ndarray, mode=2):
     tran = (C.c_float * 3)()
     r = lib().fdo_kabsch(xp, yp, len(x.reshape(-1, 3)), mode, rot, tran)
     return float(r), np.array(list(rot), dtype=np.float32).reshape(3, 3), np.array(list(tran), dtype=np.float32)
+
+
+def metrics(ref: np.ndarray, mov: np.ndarray, rot: np.ndarray, tran: np.ndarray) -> np.ndarray:
+    """{tm_score, gdt_ts, gdt_ha, chamfer, hausdorff} of rot * mov + tran against ref (src/structure/metrics.rs)"""
+    r_, rp = _f32(ref)
+    m_, mp = _f32(mov)
+    ro, rop = _f32(rot)
+    t_, tp = _f32(tran)
+    out = np.zeros(5, np.float32)
+    lib().fdo_metrics(rp, mp, len(r_.reshape(-1, 3)), rop, tp, out.ctypes.data_as(f32p))
+    return out

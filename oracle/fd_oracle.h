@@ -179,6 +179,7 @@ fdo_retrieval *fdo_retrieve(const fdo_structure *target, const fdo_structure *qu
 void fdo_retrieval_free(fdo_retrieval *r);
 /* kabsch(x = coords, y = reference, mode) (kabsch.rs:157-554). returns rmsd as f32 */
 float fdo_kabsch(const float *x, const float *y, uint64_t n, int mode, float rot[9], float tran[3]);
+void fdo_metrics(const float *ref, const float *mov, uint64_t n, const float rot[9], const float tran[3], float out[5]);
 
 #ifdef __cplusplus
 }

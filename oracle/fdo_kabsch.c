@@ -192,3 +192,47 @@ float fdo_kabsch(const float *xf, const float *yf, uint64_t n, int mode, float r
     if (rf != rf) rf = FLT_MAX;
     return rf;
 }
+
+/* Similarity metrics of one superposition (src/structure/metrics.rs:62-251 after KabschSuperimposer::run,
+ * src/structure/kabsch.rs:86-95,145-154): ref = fixed points (query), mov = moving points (target), transformed =
+ * rot * mov + tran in f32; pairwise f32 distances evaluated in f64; out = {tm_score, gdt_ts, gdt_ha, chamfer, hausdorff}.
+ * Quirk kept: tm_score and gdt compare the DISTANCE (not its square) with d0^2 / cutoff^2 (metrics.rs:141-143,160-163). */
+void fdo_metrics(const float *ref, const float *mov, uint64_t n, const float rot[9], const float tran[3], float out[5]) {
+    if (n == 0) { out[0] = out[1] = out[2] = 0.0f; out[3] = out[4] = INFINITY; return; }
+    float *tr = (float *)malloc(n * 3 * sizeof(float));
+    for (uint64_t i = 0; i < n; ++i)
+        for (int r = 0; r < 3; ++r) {
+            float v = rot[3 * r] * mov[3 * i] + rot[3 * r + 1] * mov[3 * i + 1] + rot[3 * r + 2] * mov[3 * i + 2];
+            tr[3 * i + r] = v + tran[r];
+        }
+    #define FDO_DIST(c, r) ((float)sqrt(((double)ref[3 * (r)] - (double)tr[3 * (c)]) * ((double)ref[3 * (r)] - (double)tr[3 * (c)]) + \
+                                        ((double)ref[3 * (r) + 1] - (double)tr[3 * (c) + 1]) * ((double)ref[3 * (r) + 1] - (double)tr[3 * (c) + 1]) + \
+                                        ((double)ref[3 * (r) + 2] - (double)tr[3 * (c) + 2]) * ((double)ref[3 * (r) + 2] - (double)tr[3 * (c) + 2])))
+    float d0 = n > 21 ? 1.24f * powf((float)n - 15.0f, 1.0f / 3.0f) - 1.8f : 0.5f;
+    double d0_sq = (double)(d0 * d0), tm = 0.0, dn = (double)n;
+    for (uint64_t i = 0; i < n; ++i) tm += 1.0 / (1.0 + (double)FDO_DIST(i, i) / d0_sq);
+    out[0] = (float)(tm / dn);
+    const double ts[4] = {1.0, 2.0, 4.0, 8.0}, ha[4] = {0.5, 1.0, 2.0, 4.0};
+    for (int which = 0; which < 2; ++which) {
+        const double *cut = which ? ha : ts;
+        double sum = 0.0;
+        for (int k = 0; k < 4; ++k) {
+            uint64_t cnt = 0;
+            for (uint64_t i = 0; i < n; ++i) if ((double)FDO_DIST(i, i) <= cut[k] * cut[k]) ++cnt;
+            sum += (double)cnt / dn;
+        }
+        out[1 + which] = (float)(sum / 4.0);
+    }
+    double ch = 0.0;
+    float hd = 0.0f;
+    for (uint64_t i = 0; i < n; ++i) {
+        float mn = FDO_DIST(i, 0);
+        for (uint64_t j = 1; j < n; ++j) { float d = FDO_DIST(i, j); if (d < mn) mn = d; }
+        ch += (double)mn;
+        if (i == 0 || mn > hd) hd = mn;
+    }
+    out[3] = (float)(ch / dn);
+    out[4] = hd;
+    #undef FDO_DIST
+    free(tr);
+}

@@ -212,7 +212,8 @@ def test_sort_by_grammar():
     assert parse_sort_by("  ", True) == [("idf", -1), ("min_rmsd_with_max_match", 1)]  # StructureSortStrategy::default
     assert parse_sort_by("NODE_COUNT:ASC, score", False) == [("node_count", 1), ("idf", -1)]
     assert parse_sort_by("rmsd,max-node:a", True) == [("min_rmsd_with_max_match", 1), ("max_matching_node_count", 1)]
-    for bad in ("tm_score", "rmsd:up", "a:b:c"):
+    assert parse_sort_by("tm_score,chamfer", False) == [("tm_score", -1), ("chamfer_distance", 1)]
+    for bad in ("lddt", "rmsd:up", "a:b:c"):
         with pytest.raises(ValueError):
             parse_sort_by(bad, False)
     rows = [dict(node_count=2, rmsd=0.5, idf=1.0, k=0), dict(node_count=3, rmsd=0.9, idf=0.5, k=1), dict(node_count=3, rmsd=0.1, idf=0.2, k=2),

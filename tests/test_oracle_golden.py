@@ -258,3 +258,18 @@ def test_f32_display():
                     (float("nan"), "NaN"), (1.5e10, "15000000000"), (34.239895, "34.239895")]:
         L.fdo_format_f32_display(v, buf, 64)
         assert buf.value.decode() == want, (v, buf.value)
+
+
+def test_metrics_identical_coordinates_known_answer():
+    """src/structure/metrics.rs tests::test_metrics_calculate_all_with_identical: identical point sets give tm_score = gdt_ts =
+    gdt_ha = 1, chamfer = hausdorff = 0 (the reference's only asserting metrics test); plus the reference's
+    distance-vs-squared-threshold quirk on a rigid shift."""
+    pts = np.array([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0], [7.0, 8.0, 9.0], [10.0, 11.0, 12.5]], np.float32)
+    eye, zero = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    m = oracle.metrics(pts, pts, eye, zero)
+    assert abs(m[0] - 1.0) < 1e-6 and abs(m[1] - 1.0) < 1e-6 and abs(m[2] - 1.0) < 1e-6 and abs(m[3]) < 1e-6 and abs(m[4]) < 1e-6
+    d = np.float32(np.sqrt(3 * 0.3 ** 2))
+    m = oracle.metrics(pts, pts, eye, np.full(3, 0.3, np.float32))
+    assert m[0] == pytest.approx(1.0 / (1.0 + d / 0.25), rel=1e-5)       # d0 = 0.5 for <= 21 points; distance, not its square
+    assert m[1] == pytest.approx(1.0) and m[2] == pytest.approx(0.75)     # 0.52 <= 1, 4, 16, 64; not <= 0.25
+    assert m[3] == pytest.approx(d, rel=1e-5) and m[4] == pytest.approx(d, rel=1e-5)
