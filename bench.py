@@ -197,7 +197,10 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom_name, "launches_per_step": dom_n, "avg_ms": dom_ms / max(dom_n, 1),
                 "algorithmic_bytes_per_launch": dom_bytes / max(dom_n, 1),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dom_name, S),
+                # HBM bytes per launch from the committed PMC passes of this same command (number, or null when no profile of this
+                # workload size is committed); provenance in traffic_detail
+                "traffic": (lambda t: t["bytes_per_launch"] if t else None)(pmc_traffic(dom_name, S)),
+                "traffic_detail": pmc_traffic(dom_name, S),
                 # SURVEY §8(d) end-to-end figure: B_idx = 37 R + 4 U + 4 U + v U + 12 H/S bytes per structure
                 "end_to_end": (lambda b: {"algorithmic_bytes_per_structure": b, "achieved": value / world * b / 1e9, "unit": "GB/s",
                                           "frac": value / world * b / 1e9 / HBM_PEAK_GBS})(
