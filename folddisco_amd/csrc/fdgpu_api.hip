@@ -271,29 +271,23 @@ static int ensure_sort_ws(fdgpu_ctx *c, uint64_t P) {
     HIPCHK(c, c->ws[WS_IDS_B].ensure(kb));
     HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * std::max<uint32_t>(fd_rs_num_tiles(P), 1) * 4));
     HIPCHK(c, c->ws[WS_TOT].ensure(256 * 8));
-    HIPCHK(c, c->ws[WS_OSDESC].ensure((size_t)std::max<uint32_t>(fd_os_num_tiles(P), 1) * 256 * 8));
-    HIPCHK(c, c->ws[WS_OSHIST].ensure(4 * 256 * 8 + 64));
     return FDGPU_OK;
 }
 
 // stable sort of (keys, vals) by the low key_bits of keys; FDGPU_SORT=classic selects the 3-kernel LSD variant
 static int sort_mode();
 static int sort_pairs(fdgpu_ctx *c, uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb, uint64_t n, int key_bits) {
-    const int mode = sort_mode();
-    if (mode >= 0) return fd_radix_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), c->stream, c);
-    unsigned long long *gh = c->ws[WS_OSHIST].as<unsigned long long>();
-    return fd_onesweep_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_OSDESC].as<unsigned long long>(), gh, (uint32_t *)(gh + 4 * 256), c->stream, c);
+    (void)sort_mode();
+    return fd_radix_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), c->stream, c);
 }
 static int sort_mode() {
-    // FDGPU_SORT = onesweep | classic0..classic15 (default classic18: 512x16 tiles, XCD-aware tile order, atomics-free
-    // rank-first VALU-lean scatter; measured fastest, see k_sort.hip radix_sort_pairs_t for the list)
+    // FDGPU_SORT = classic18 (default: 512x16-key tiles) | classic19 | classic20 | classic21 | classic30, see k_sort.hip
     static const int mode = [] {
         const char *e = getenv("FDGPU_SORT");
-        if (e && !strcmp(e, "onesweep")) return -1;
         if (e && !strncmp(e, "classic", 7) && e[7] >= '0' && e[7] <= '9') return atoi(e + 7);
         return 18;
     }();
-    if (mode >= 0) fd_rs_set_variant(mode);
+    fd_rs_set_variant(mode);
     return mode;
 }
 

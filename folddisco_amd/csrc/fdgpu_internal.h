@@ -30,7 +30,7 @@ struct fd_timing_entry { const char *name; hipEvent_t ev0, ev1; uint64_t bytes; 
 
 enum {
     WS_COUNTS, WS_CURSOR, WS_SEGOFF, WS_SCANTMP, WS_TOTAL, WS_KEYS_A, WS_IDS_A, WS_KEYS_B, WS_IDS_B, WS_GHIST, WS_TOT,
-    WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES, WS_OSDESC, WS_OSHIST,
+    WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
     WS_COUNT
 };
 
@@ -146,9 +146,6 @@ uint32_t fd_rs_num_tiles(uint64_t n);
 void fd_rs_set_variant(int v);
 int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits, uint32_t *ghist,
                         uint64_t *tot, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr);
-uint32_t fd_os_num_tiles(uint64_t n);
-int fd_onesweep_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits,
-                           unsigned long long *desc, unsigned long long *ghist, uint32_t *ticket, hipStream_t st, fdgpu_ctx *tc = nullptr);
 uint32_t fd_enc_num_tiles(uint64_t n);
 void fd_launch_enc_sizes(const uint32_t *keys, const void *ids, bool ids16, uint32_t first_id, uint64_t n, uint32_t *tb, uint32_t *th, uint32_t *tp,
                          hipStream_t st);

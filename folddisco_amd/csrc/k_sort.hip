@@ -174,279 +174,17 @@ __global__ __launch_bounds__(RS_BINS) void k_rs_scan_tot(uint64_t *__restrict__ 
     tot[threadIdx.x] = ex;
 }
 
-// stable scatter of one tile. Wave w owns a contiguous sub-tile and walks it in 64-key chunks
-// (chunk c, lane l -> element c*64 + l) so that "earlier element" == "earlier chunk or lower lane".
-// NT: streaming (non-temporal) loads of the input so that the once-read input does not evict the dirty partial
-// output lines from the XCD's L2 before the neighbouring tile completes them
-template <int THREADS, int ITEMS, bool XCD, typename V, bool NT = false>
-__global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
-                                                        uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n,
-                                                        uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
-                                                        const uint64_t *__restrict__ dbase) {
-    constexpr int TILE = THREADS * ITEMS;
-    constexpr int WAVES = THREADS / 64;
-    __shared__ uint32_t s_keys[TILE];
-    __shared__ V s_vals[TILE];
-    __shared__ uint32_t s_cnt[WAVES][RS_BINS];  // per-wave digit counts, then running local positions
-    __shared__ long long s_gofs[RS_BINS];       // global position = local position + s_gofs[digit]
-    __shared__ uint64_t sm[17];
 
-    const uint32_t tile = XCD ? fd_xcd_remap(blockIdx.x, nb) : blockIdx.x;
-    if (tile >= nb) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint64_t tile_base = (uint64_t)tile * TILE;
-    const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * ITEMS);
-    const uint32_t n_tile = (uint32_t)((n - tile_base) < TILE ? (n - tile_base) : TILE);
-
-    for (int k = tid; k < WAVES * RS_BINS; k += THREADS) (&s_cnt[0][0])[k] = 0;
-    __syncthreads();
-
-    uint32_t key[ITEMS];
-    V val[ITEMS];
-#pragma unroll
-    for (int c = 0; c < ITEMS; ++c) {
-        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
-        bool ok = idx < n;
-        if (NT) {
-            key[c] = ok ? __builtin_nontemporal_load(&keys_in[idx]) : 0xffffffffu;
-            val[c] = ok ? __builtin_nontemporal_load(&vals_in[idx]) : (V)0;
-        } else {
-            key[c] = ok ? keys_in[idx] : 0xffffffffu;
-            val[c] = ok ? vals_in[idx] : (V)0;
-        }
-        if (ok) atomicAdd(&s_cnt[wid][(key[c] >> shift) & mask], 1u);
-    }
-    __syncthreads();
-    {
-        uint32_t my_total = 0;
-        if (tid < RS_BINS) {
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) my_total += s_cnt[w][tid];
-        }
-        uint64_t tot;
-        uint32_t dstart = (uint32_t)block_excl_scan_u64(tid < RS_BINS ? (uint64_t)my_total : 0ull, sm, &tot);
-        if (tid < RS_BINS) {
-            uint32_t run = dstart;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) { uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
-            s_gofs[tid] = (long long)(dbase[tid] + ghist[(uint64_t)tid * nb + tile]) - (long long)dstart;
-        }
-    }
-    __syncthreads();
-    // in-wave stable ranks by ballot multi-split, running positions in s_cnt[wid][*]
-#pragma unroll
-    for (int c = 0; c < ITEMS; ++c) {
-        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
-        bool ok = idx < n;
-        uint32_t d = (key[c] >> shift) & mask;
-        uint64_t peers = __ballot(ok);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            uint64_t bal = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? bal : ~bal;
-        }
-        uint32_t rank = fd_mbcnt(peers);               // peers in lower lanes
-        uint32_t pcount = (uint32_t)__popcll(peers);
-        uint32_t pos = 0;
-        if (ok) pos = s_cnt[wid][d] + rank;
-        // the wave's LDS ops execute in order: every read above precedes the update below
-        if (ok && rank == pcount - 1) s_cnt[wid][d] = pos + 1;
-        if (ok) { s_keys[pos] = key[c]; s_vals[pos] = val[c]; }
-    }
-    __syncthreads();
-    // digit-contiguous in LDS -> runs in global memory
-    for (uint32_t k = tid; k < n_tile; k += THREADS) {
-        uint32_t kk = s_keys[k];
-        long long g = (long long)k + s_gofs[(kk >> shift) & mask];
-        keys_out[g] = kk;
-        vals_out[g] = s_vals[k];
-    }
-}
-
-// Variant without LDS atomics: the ballot multi-split runs FIRST and yields each element's running rank among the
-// wave's keys of the same digit (leader lane keeps the per-wave digit counter), the cross-wave digit starts are
-// scanned afterwards and added when the element is placed.
-template <int THREADS, int ITEMS, bool XCD, typename V>
-__global__ __launch_bounds__(THREADS) void k_rs_scatter2(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
-                                                         uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n,
-                                                         uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
-                                                         const uint64_t *__restrict__ dbase) {
-    constexpr int TILE = THREADS * ITEMS;
-    constexpr int WAVES = THREADS / 64;
-    __shared__ uint32_t s_keys[TILE];
-    __shared__ V s_vals[TILE];
-    __shared__ uint32_t s_cnt[WAVES][RS_BINS];
-    __shared__ long long s_gofs[RS_BINS];
-    __shared__ uint64_t sm[17];
-
-    const uint32_t tile = XCD ? fd_xcd_remap(blockIdx.x, nb) : blockIdx.x;
-    if (tile >= nb) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint64_t tile_base = (uint64_t)tile * TILE;
-    const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * ITEMS);
-    const uint32_t n_tile = (uint32_t)((n - tile_base) < TILE ? (n - tile_base) : TILE);
-
-    for (int k = tid; k < WAVES * RS_BINS; k += THREADS) (&s_cnt[0][0])[k] = 0;
-    uint32_t key[ITEMS];
-    V val[ITEMS];
-#pragma unroll
-    for (int c = 0; c < ITEMS; ++c) {
-        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
-        bool ok = idx < n;
-        key[c] = ok ? keys_in[idx] : 0xffffffffu;
-        val[c] = ok ? vals_in[idx] : (V)0;
-    }
-    __syncthreads();
-    uint16_t rnk[ITEMS];
-    uint32_t *cnt = s_cnt[wid];
-#pragma unroll
-    for (int c = 0; c < ITEMS; ++c) {
-        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
-        bool ok = idx < n;
-        uint32_t d = (key[c] >> shift) & mask;
-        uint64_t peers = __ballot(ok);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            uint64_t bal = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? bal : ~bal;
-        }
-        uint32_t rank = fd_mbcnt(peers);
-        uint32_t pcount = (uint32_t)__popcll(peers);
-        uint32_t base = ok ? cnt[d] : 0u;
-        // in-order LDS within the wave: all reads above precede the leader's update
-        if (ok && rank == pcount - 1) cnt[d] = base + pcount;
-        rnk[c] = (uint16_t)(base + rank);
-    }
-    __syncthreads();
-    {
-        uint32_t my_total = 0;
-        if (tid < RS_BINS) {
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) my_total += s_cnt[w][tid];
-        }
-        uint64_t tot;
-        uint32_t dstart = (uint32_t)block_excl_scan_u64(tid < RS_BINS ? (uint64_t)my_total : 0ull, sm, &tot);
-        if (tid < RS_BINS) {
-            uint32_t run = dstart;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) { uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
-            s_gofs[tid] = (long long)(dbase[tid] + ghist[(uint64_t)tid * nb + tile]) - (long long)dstart;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < ITEMS; ++c) {
-        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
-        if (idx < n) {
-            uint32_t pos = cnt[(key[c] >> shift) & mask] + rnk[c];
-            s_keys[pos] = key[c];
-            s_vals[pos] = val[c];
-        }
-    }
-    __syncthreads();
-    for (uint32_t k = tid; k < n_tile; k += THREADS) {
-        uint32_t kk = s_keys[k];
-        long long g = (long long)k + s_gofs[(kk >> shift) & mask];
-        keys_out[g] = kk;
-        vals_out[g] = s_vals[k];
-    }
-}
-
-// As k_rs_scatter2 with 16-bit per-wave counters and the global digit offsets aliased onto the counter array once the
-// placement is done: 52.1 KiB of LDS per 512x16 tile -> three workgroups per CU instead of two.
-template <int THREADS, int ITEMS, typename V>
-__global__ __launch_bounds__(THREADS) void k_rs_scatter3(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
-                                                         uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n,
-                                                         uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
-                                                         const uint64_t *__restrict__ dbase) {
-    constexpr int TILE = THREADS * ITEMS;
-    constexpr int WAVES = THREADS / 64;
-    static_assert(TILE <= 65535 && WAVES * RS_BINS * 2 >= RS_BINS * 8, "u16 counters / gofs alias");
-    __shared__ uint32_t s_keys[TILE];
-    __shared__ V s_vals[TILE];
-    __shared__ __attribute__((aligned(8))) uint16_t s_cnt[WAVES][RS_BINS];
-    __shared__ uint64_t sm[17];
-    long long *s_gofs = reinterpret_cast<long long *>(&s_cnt[0][0]);
-
-    const uint32_t tile = fd_xcd_remap(blockIdx.x, nb);
-    if (tile >= nb) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint64_t tile_base = (uint64_t)tile * TILE;
-    const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * ITEMS);
-    const uint32_t n_tile = (uint32_t)((n - tile_base) < TILE ? (n - tile_base) : TILE);
-
-    for (int k = tid; k < WAVES * RS_BINS / 2; k += THREADS) reinterpret_cast<uint32_t *>(&s_cnt[0][0])[k] = 0;
-    uint32_t key[ITEMS];
-    V val[ITEMS];
-#pragma unroll
-    for (int c = 0; c < ITEMS; ++c) {
-        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
-        bool ok = idx < n;
-        key[c] = ok ? keys_in[idx] : 0xffffffffu;
-        val[c] = ok ? vals_in[idx] : (V)0;
-    }
-    long long gbase = 0;
-    if (tid < RS_BINS) gbase = (long long)(dbase[tid] + ghist[(uint64_t)tid * nb + tile]);
-    __syncthreads();
-    uint16_t rnk[ITEMS];
-    uint16_t *cnt = s_cnt[wid];
-#pragma unroll
-    for (int c = 0; c < ITEMS; ++c) {
-        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
-        bool ok = idx < n;
-        uint32_t d = (key[c] >> shift) & mask;
-        uint64_t peers = __ballot(ok);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            uint64_t bal = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? bal : ~bal;
-        }
-        uint32_t rank = fd_mbcnt(peers);
-        uint32_t pcount = (uint32_t)__popcll(peers);
-        uint32_t base = ok ? cnt[d] : 0u;
-        if (ok && rank == pcount - 1) cnt[d] = (uint16_t)(base + pcount);
-        rnk[c] = (uint16_t)(base + rank);
-    }
-    __syncthreads();
-    uint32_t dstart = 0;
-    {
-        uint32_t my_total = 0;
-        if (tid < RS_BINS) {
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) my_total += s_cnt[w][tid];
-        }
-        uint64_t tot;
-        dstart = (uint32_t)block_excl_scan_u64(tid < RS_BINS ? (uint64_t)my_total : 0ull, sm, &tot);
-        if (tid < RS_BINS) {
-            uint32_t run = dstart;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) { uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = (uint16_t)run; run += c; }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < ITEMS; ++c) {
-        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
-        if (idx < n) {
-            uint32_t pos = (uint32_t)cnt[(key[c] >> shift) & mask] + rnk[c];
-            s_keys[pos] = key[c];
-            s_vals[pos] = val[c];
-        }
-    }
-    __syncthreads();
-    if (tid < RS_BINS) s_gofs[tid] = gbase - (long long)dstart;
-    __syncthreads();
-    for (uint32_t k = tid; k < n_tile; k += THREADS) {
-        uint32_t kk = s_keys[k];
-        long long g = (long long)k + s_gofs[(kk >> shift) & mask];
-        keys_out[g] = kk;
-        vals_out[g] = s_vals[k];
-    }
-}
-
-// VALU-lean form of k_rs_scatter2 (the scatter is VALU-issue bound: ~130 VALU per 64-key chunk at 4 cycles each):
-// the per-bit peer mask update is ONE v_bitop3_b32 per 32-bit half (peers & ~(ballot ^ bitmask), truth table 0x90),
-// full tiles run without any bounds predicate, ranks stay in 32-bit registers.
+// Stable scatter of one tile.  Wave w owns a contiguous sub-tile and walks it in 64-key chunks (chunk c, lane l -> element
+// c*64 + l) so that "earlier element" == "earlier chunk or lower lane".
+//   1. rank first, no LDS atomics: a ballot multi-split gives every key its running rank among the wave's keys of the same
+//      digit (the leader lane keeps the per-wave digit counter); the per-bit peer mask update is ONE v_bitop3_b32 per 32-bit
+//      half (peers & ~(ballot ^ bitmask), truth table 0x90), the ballot one v_cmp on the extracted bit;
+//   2. cross-wave exclusive scan of the digit counts, global offsets from the tile histogram pass;
+//   3. keys / payloads are placed digit-contiguously in LDS and leave as runs (neighbouring tiles of one XCD complete each
+//      other's partial lines in L2: PMC traffic 1.03x algorithmic).
+// Full tiles run without any bounds predicate.  The kernel sits at 5.9 ms per pass against 4.8 ms for its own memory
+// skeleton (k_rs_copy_floor).
 template <int THREADS, int ITEMS, typename V, bool FULL, bool PACK = false>
 __device__ __forceinline__ void rs_scatter4_body(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
                                                  uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n, uint32_t shift,
@@ -601,345 +339,13 @@ __global__ __launch_bounds__(THREADS) void k_rs_scatter4(const uint32_t *__restr
         rs_scatter4_body<THREADS, ITEMS, V, false, PACK>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, ghist, nb, dbase, tile, s_keys, s_vals, s_cnt, s_gofs, sm);
 }
 
-// ------------------------------------------------------------------------ onesweep variant
-// One kernel per digit: the global digit histograms of all passes come from ONE upfront read of the
-// keys (the key multiset does not change between passes), and the per-tile digit offsets are
-// resolved inside the scatter kernel by decoupled look-back over per-(tile, digit) descriptors
-// instead of a histogram pass + scan per digit.  Inter-workgroup visibility on gfx950 (per-XCD L2s are
-// not coherent): a descriptor is ONE naturally aligned 8-byte word {value:62, state:2} written and
-// read with relaxed agent-scope atomics (sc1 store / sc1 load), the "granule" form of
-// MI355X_MICROARCH.md — no separate flag, so no ordering between two words is needed.  Tiles take
-// their index from an atomic ticket so that every predecessor a tile waits for is already running.
-#define RS_WAVES_UNUSED 0
-#define OS_THREADS 512
-#define OS_ITEMS 16
-#define OS_TILE (OS_THREADS * OS_ITEMS)   // 8192 keys
-#define OS_WAVES (OS_THREADS / 64)
-#define OS_AGG 1ull
-#define OS_INC 2ull
-
-__global__ __launch_bounds__(256) void k_os_hist(const uint32_t *__restrict__ keys, uint64_t n, int key_bits,
-                                                 unsigned long long *__restrict__ ghist /*[4][256]*/) {
-    __shared__ uint32_t h[4][RS_BINS];
-    for (int k = threadIdx.x; k < 4 * RS_BINS; k += blockDim.x) (&h[0][0])[k] = 0;
-    __syncthreads();
-    const int npass = (key_bits + 7) / 8;
-    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
-        uint32_t k = keys[idx];
-        for (int p = 0; p < npass; ++p) {
-            int bits = key_bits - 8 * p < 8 ? key_bits - 8 * p : 8;
-            atomicAdd(&h[p][(k >> (8 * p)) & ((1u << bits) - 1u)], 1u);
-        }
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < 4 * RS_BINS; k += blockDim.x) {
-        uint32_t v = (&h[0][0])[k];
-        if (v) atomicAdd(&ghist[k], (unsigned long long)v);
-    }
-}
-// exclusive scan of each pass's 256 global counts (in place)
-__global__ __launch_bounds__(RS_BINS) void k_os_scan(unsigned long long *__restrict__ ghist) {
-    __shared__ uint64_t sm[17];
-    unsigned long long *row = ghist + (uint64_t)blockIdx.x * RS_BINS;
-    uint64_t v = row[threadIdx.x], t;
-    uint64_t ex = block_excl_scan_u64(v, sm, &t);
-    row[threadIdx.x] = ex;
-}
-
-__global__ __launch_bounds__(OS_THREADS) void k_os_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                           uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
-                                                           uint32_t shift, uint32_t mask, const unsigned long long *__restrict__ dbase /*[256]*/,
-                                                           unsigned long long *__restrict__ desc /*[tiles][256]*/, uint32_t *__restrict__ ticket) {
-    __shared__ uint32_t s_keys[OS_TILE];
-    __shared__ uint32_t s_vals[OS_TILE];
-    __shared__ uint32_t s_cnt[OS_WAVES][RS_BINS];
-    __shared__ long long s_gofs[RS_BINS];
-    __shared__ uint64_t sm[17];
-    __shared__ uint32_t s_tile;
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    for (int k = tid; k < OS_WAVES * RS_BINS; k += OS_THREADS) (&s_cnt[0][0])[k] = 0;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    const uint64_t tile_base = (uint64_t)tile * OS_TILE;
-    const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * OS_ITEMS);
-    const uint32_t n_tile = (uint32_t)((n - tile_base) < OS_TILE ? (n - tile_base) : OS_TILE);
-
-    uint32_t key[OS_ITEMS], val[OS_ITEMS];
-#pragma unroll
-    for (int c = 0; c < OS_ITEMS; ++c) {
-        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
-        bool ok = idx < n;
-        key[c] = ok ? keys_in[idx] : 0xffffffffu;
-        val[c] = ok ? vals_in[idx] : 0u;
-        if (ok) atomicAdd(&s_cnt[wid][(key[c] >> shift) & mask], 1u);
-    }
-    __syncthreads();
-    uint32_t my_total = 0, dstart = 0;
-    if (tid < RS_BINS) {
-        uint32_t run = 0;
-#pragma unroll
-        for (int w = 0; w < OS_WAVES; ++w) run += s_cnt[w][tid];
-        my_total = run;
-        // publish the tile aggregate (tile 0: already inclusive)
-        unsigned long long d0 = ((unsigned long long)my_total << 2) | (tile == 0 ? OS_INC : OS_AGG);
-        __hip_atomic_store(&desc[(uint64_t)tile * RS_BINS + tid], d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    {
-        uint64_t tot;
-        uint64_t ex = block_excl_scan_u64(tid < RS_BINS ? (uint64_t)my_total : 0ull, sm, &tot);
-        dstart = (uint32_t)ex;
-    }
-    if (tid < RS_BINS) {
-        // per-wave local bases (running positions during ranking)
-        uint32_t run = dstart;
-#pragma unroll
-        for (int w = 0; w < OS_WAVES; ++w) { uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
-        // decoupled look-back for digit `tid`
-        unsigned long long excl = 0;
-        if (tile > 0) {
-            int64_t t = (int64_t)tile - 1;
-            while (true) {
-                unsigned long long d = __hip_atomic_load(&desc[(uint64_t)t * RS_BINS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned long long st = d & 3ull;
-                if (st == 0ull) { __builtin_amdgcn_s_sleep(1); continue; }
-                excl += d >> 2;
-                if (st == OS_INC) break;
-                --t;  // aggregate only: keep looking back (t cannot underflow: tile 0 is always inclusive)
-            }
-            unsigned long long d1 = ((excl + my_total) << 2) | OS_INC;
-            __hip_atomic_store(&desc[(uint64_t)tile * RS_BINS + tid], d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        s_gofs[tid] = (long long)(dbase[tid] + excl) - (long long)dstart;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < OS_ITEMS; ++c) {
-        uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
-        bool ok = idx < n;
-        uint32_t d = (key[c] >> shift) & mask;
-        uint64_t peers = __ballot(ok);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            uint64_t bal = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? bal : ~bal;
-        }
-        uint32_t rank = fd_mbcnt(peers);
-        uint32_t pcount = (uint32_t)__popcll(peers);
-        uint32_t pos = 0;
-        if (ok) pos = s_cnt[wid][d] + rank;
-        if (ok && rank == pcount - 1) s_cnt[wid][d] = pos + 1;
-        if (ok) { s_keys[pos] = key[c]; s_vals[pos] = val[c]; }
-    }
-    __syncthreads();
-    for (uint32_t k = tid; k < n_tile; k += OS_THREADS) {
-        uint32_t kk = s_keys[k];
-        long long g = (long long)k + s_gofs[(kk >> shift) & mask];
-        keys_out[g] = kk;
-        vals_out[g] = s_vals[k];
-    }
-}
-
-uint32_t fd_os_num_tiles(uint64_t n) { return (uint32_t)((n + OS_TILE - 1) / OS_TILE); }
-// workspace: desc u64[tiles*256], ghist u64[4*256], ticket u32[4]
-int fd_onesweep_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits,
-                           unsigned long long *desc, unsigned long long *ghist, uint32_t *ticket, hipStream_t st, fdgpu_ctx *tc) {
-    if (n == 0) return 0;
-    uint32_t nb = fd_os_num_tiles(n);
-    (void)hipMemsetAsync(ghist, 0, 4 * RS_BINS * 8, st);
-    (void)hipMemsetAsync(ticket, 0, 16, st);
-    {
-        StageTimer t(tc, "os_hist", n * 4);
-        hipLaunchKernelGGL(k_os_hist, dim3(2048), dim3(256), 0, st, keys_a, n, key_bits, ghist);
-        hipLaunchKernelGGL(k_os_scan, dim3(4), dim3(RS_BINS), 0, st, ghist);
-    }
-    int cur = 0, pass = 0;
-    for (int shift = 0; shift < key_bits; shift += 8, ++pass) {
-        int bits = key_bits - shift < 8 ? key_bits - shift : 8;
-        uint32_t mask = (1u << bits) - 1u;
-        uint32_t *ki = cur ? keys_b : keys_a, *vi = cur ? vals_b : vals_a;
-        uint32_t *ko = cur ? keys_a : keys_b, *vo = cur ? vals_a : vals_b;
-        StageTimer t(tc, "os_scatter", n * 16);
-        (void)hipMemsetAsync(desc, 0, (size_t)nb * RS_BINS * 8, st);
-        hipLaunchKernelGGL(k_os_scatter, dim3(nb), dim3(OS_THREADS), 0, st, ki, vi, ko, vo, n, (uint32_t)shift, mask,
-                           ghist + (size_t)pass * RS_BINS, desc, ticket + pass);
-        cur ^= 1;
-    }
-    return cur;
-}
-
-// persistent, software-pipelined scatter: a fixed grid (PERSIST_BLOCKS_PER_CU x 256 CUs) walks the tiles; the keys
-// and values of the NEXT tile are requested (global loads in flight) before the current tile is ranked and
-// written, so every CU always has reads outstanding instead of alternating load / LDS / store phases.
-// Tile order is XCD-aware: the blocks of one XCD (b % 8) sweep one contiguous eighth of the tiles together, so
-// the partial-line digit runs of neighbouring tiles merge in that XCD's L2.
-#define PERSIST_BLOCKS_PER_CU 4
-template <int THREADS, int ITEMS, typename V>
-__global__ __launch_bounds__(THREADS) void k_rs_scatter_p(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
-                                                          uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n,
-                                                          uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb,
-                                                          const uint64_t *__restrict__ dbase) {
-    constexpr int TILE = THREADS * ITEMS;
-    constexpr int WAVES = THREADS / 64;
-    __shared__ uint32_t s_keys[TILE];
-    __shared__ V s_vals[TILE];
-    __shared__ uint32_t s_cnt[WAVES][RS_BINS];
-    __shared__ long long s_gofs[RS_BINS];
-    __shared__ uint64_t sm[17];
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
-    const uint32_t per = (nb + 7u) / 8u;
-    const uint32_t t_lo = xcd * per, t_hi = (t_lo + per < nb) ? t_lo + per : nb;
-    uint32_t tile = t_lo + j;
-    if (tile >= t_hi) return;
-
-    uint32_t key[ITEMS], nkey[ITEMS];
-    V val[ITEMS], nval[ITEMS];
-    auto load_tile = [&](uint32_t t, uint32_t *k, V *v) {
-        const uint64_t wb = (uint64_t)t * TILE + (uint64_t)wid * (64 * ITEMS);
-#pragma unroll
-        for (int c = 0; c < ITEMS; ++c) {
-            uint64_t idx = wb + (uint64_t)c * 64 + lane;
-            bool ok = idx < n;
-            k[c] = ok ? keys_in[idx] : 0xffffffffu;
-            v[c] = ok ? vals_in[idx] : (V)0;
-        }
-    };
-    load_tile(tile, key, val);
-    for (;;) {
-        const uint32_t next = tile + per_xcd_blocks;
-        const bool has_next = next < t_hi;
-        if (has_next) load_tile(next, nkey, nval);   // in flight while this tile is processed
-
-        const uint64_t tile_base = (uint64_t)tile * TILE;
-        const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * ITEMS);
-        const uint32_t n_tile = (uint32_t)((n - tile_base) < TILE ? (n - tile_base) : TILE);
-        for (int k = tid; k < WAVES * RS_BINS; k += THREADS) (&s_cnt[0][0])[k] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < ITEMS; ++c) {
-            uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
-            if (idx < n) atomicAdd(&s_cnt[wid][(key[c] >> shift) & mask], 1u);
-        }
-        __syncthreads();
-        {
-            uint32_t my_total = 0;
-            if (tid < RS_BINS) {
-#pragma unroll
-                for (int w = 0; w < WAVES; ++w) my_total += s_cnt[w][tid];
-            }
-            uint64_t tot;
-            uint32_t dstart = (uint32_t)block_excl_scan_u64(tid < RS_BINS ? (uint64_t)my_total : 0ull, sm, &tot);
-            if (tid < RS_BINS) {
-                uint32_t run = dstart;
-#pragma unroll
-                for (int w = 0; w < WAVES; ++w) { uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
-                s_gofs[tid] = (long long)(dbase[tid] + ghist[(uint64_t)tid * nb + tile]) - (long long)dstart;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < ITEMS; ++c) {
-            uint64_t idx = wave_base + (uint64_t)c * 64 + lane;
-            bool ok = idx < n;
-            uint32_t d = (key[c] >> shift) & mask;
-            uint64_t peers = __ballot(ok);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                uint64_t bal = __ballot((d >> b) & 1u);
-                peers &= ((d >> b) & 1u) ? bal : ~bal;
-            }
-            uint32_t rank = fd_mbcnt(peers);
-            uint32_t pcount = (uint32_t)__popcll(peers);
-            uint32_t pos = 0;
-            if (ok) pos = s_cnt[wid][d] + rank;
-            if (ok && rank == pcount - 1) s_cnt[wid][d] = pos + 1;
-            if (ok) { s_keys[pos] = key[c]; s_vals[pos] = val[c]; }
-        }
-        __syncthreads();
-        for (uint32_t k = tid; k < n_tile; k += THREADS) {
-            uint32_t kk = s_keys[k];
-            long long g = (long long)k + s_gofs[(kk >> shift) & mask];
-            keys_out[g] = kk;
-            vals_out[g] = s_vals[k];
-        }
-        if (!has_next) break;
-        __syncthreads();   // LDS is reused by the next tile
-        tile = next;
-#pragma unroll
-        for (int c = 0; c < ITEMS; ++c) { key[c] = nkey[c]; val[c] = nval[c]; }
-    }
-}
-
-// LSD variants: 0 = 256x16 tiles, 1 = 256x16 + XCD-aware tile order, 2 = 512x16, 3 = 512x16 + XCD-aware,
-// 4 = 256x16 persistent software-pipelined scatter (XCD-aware)
+// LSD radix sort, 8-bit digits.  FDGPU_SORT=classicN selects measured alternatives: 18 = 512x16-key tiles (default, fastest),
+// 19 = 256x16, 20 = 512x8, 21 = 512x16 with packed 8-byte LDS staging, 30 = memory skeleton only (NOT a sort, see
+// k_rs_copy_floor).  Earlier generations (LDS-atomic ranking, persistent software-pipelined scatter, 16-bit counters for a third
+// workgroup per CU, decoupled-look-back onesweep, 3 x 10-bit digits) were slower and are documented in DESIGN.md §4 / §9.
 static int g_rs_variant = 18;
 void fd_rs_set_variant(int v) { g_rs_variant = v; }
-static inline uint32_t rs_tile(int v) { return (v >= 2 ? 512u : 256u) * 16u; }
 uint32_t fd_rs_num_tiles(uint64_t n) { return (uint32_t)((n + 2048 - 1) / 2048); }  // upper bound over variants (workspace sizing)
-
-template <int THREADS, int ITEMS, bool XCD, typename V, bool NT = false>
-static void rs_pass(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist,
-                    uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
-    uint32_t nb = (uint32_t)((n + THREADS * ITEMS - 1) / (THREADS * ITEMS));
-    uint32_t grid = XCD ? ((nb + 7u) / 8u) * 8u : nb;
-    {
-        StageTimer t(tc, "rs_hist", n * 4 + (uint64_t)nb * RS_BINS * 4);
-        hipLaunchKernelGGL((k_rs_hist<THREADS, ITEMS, XCD>), dim3(grid), dim3(THREADS), 0, st, ki, n, shift, mask, ghist, nb);
-    }
-    {
-        StageTimer t(tc, "rs_scan", (uint64_t)nb * RS_BINS * 8);
-        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
-        hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
-    }
-    {
-        StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
-        hipLaunchKernelGGL((k_rs_scatter<THREADS, ITEMS, XCD, V, NT>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
-    }
-}
-
-template <int THREADS, int ITEMS, typename V>
-static void rs_pass2(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist, uint64_t *tot,
-                     hipStream_t st, fdgpu_ctx *tc) {
-    uint32_t nb = (uint32_t)((n + THREADS * ITEMS - 1) / (THREADS * ITEMS));
-    uint32_t grid = ((nb + 7u) / 8u) * 8u;
-    {
-        StageTimer t(tc, "rs_hist", n * 4 + (uint64_t)nb * RS_BINS * 4);
-        hipLaunchKernelGGL((k_rs_hist<THREADS, ITEMS, true>), dim3(grid), dim3(THREADS), 0, st, ki, n, shift, mask, ghist, nb);
-    }
-    {
-        StageTimer t(tc, "rs_scan", (uint64_t)nb * RS_BINS * 8);
-        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
-        hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
-    }
-    {
-        StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
-        hipLaunchKernelGGL((k_rs_scatter2<THREADS, ITEMS, true, V>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
-    }
-}
-
-template <int THREADS, int ITEMS, typename V>
-static void rs_pass3(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist, uint64_t *tot,
-                     hipStream_t st, fdgpu_ctx *tc) {
-    uint32_t nb = (uint32_t)((n + THREADS * ITEMS - 1) / (THREADS * ITEMS));
-    uint32_t grid = ((nb + 7u) / 8u) * 8u;
-    {
-        StageTimer t(tc, "rs_hist", n * 4 + (uint64_t)nb * RS_BINS * 4);
-        hipLaunchKernelGGL((k_rs_hist<THREADS, ITEMS, true>), dim3(grid), dim3(THREADS), 0, st, ki, n, shift, mask, ghist, nb);
-    }
-    {
-        StageTimer t(tc, "rs_scan", (uint64_t)nb * RS_BINS * 8);
-        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
-        hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
-    }
-    {
-        StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
-        hipLaunchKernelGGL((k_rs_scatter3<THREADS, ITEMS, V>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
-    }
-}
 
 template <int THREADS, int ITEMS, typename V, bool PACK = false>
 static void rs_pass4(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist, uint64_t *tot,
@@ -961,27 +367,6 @@ static void rs_pass4(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint3
     }
 }
 
-template <int THREADS, int ITEMS, typename V>
-static void rs_pass_p(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint32_t shift, uint32_t mask, uint32_t *ghist, uint64_t *tot,
-                      hipStream_t st, fdgpu_ctx *tc) {
-    uint32_t nb = (uint32_t)((n + THREADS * ITEMS - 1) / (THREADS * ITEMS));
-    uint32_t grid = ((nb + 7u) / 8u) * 8u;
-    {
-        StageTimer t(tc, "rs_hist", n * 4 + (uint64_t)nb * RS_BINS * 4);
-        hipLaunchKernelGGL((k_rs_hist<THREADS, ITEMS, true>), dim3(grid), dim3(THREADS), 0, st, ki, n, shift, mask, ghist, nb);
-    }
-    {
-        StageTimer t(tc, "rs_scan", (uint64_t)nb * RS_BINS * 8);
-        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
-        hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
-    }
-    {
-        StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
-        uint32_t pg = 256u * PERSIST_BLOCKS_PER_CU;   // multiple of 8
-        hipLaunchKernelGGL((k_rs_scatter_p<THREADS, ITEMS, V>), dim3(pg), dim3(THREADS), 0, st, ki, vi, ko, vo, n, shift, mask, ghist, nb, tot);
-    }
-}
-
 template <typename V>
 static int radix_sort_pairs_t(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_b, uint64_t n, int key_bits, uint32_t *ghist,
                               uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
@@ -993,35 +378,16 @@ static int radix_sort_pairs_t(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *
         uint32_t *ki = cur ? keys_b : keys_a, *ko = cur ? keys_a : keys_b;
         V *vi = cur ? vals_b : vals_a, *vo = cur ? vals_a : vals_b;
         switch (g_rs_variant) {
-            case 10: rs_pass2<256, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 11: rs_pass2<512, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 16: rs_pass3<512, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 17: rs_pass3<256, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 18: rs_pass4<512, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 19: rs_pass4<256, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 20: rs_pass4<512, 8, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 21: rs_pass4<512, 16, V, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 22: rs_pass4<256, 16, V, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
             case 30: {   // memory floor of the scatter (see k_rs_copy_floor); the result is NOT sorted
                 uint32_t nb = (uint32_t)((n + 8191) / 8192), grid = ((nb + 7u) / 8u) * 8u;
                 StageTimer t(tc, "rs_scatter", n * (8 + 2 * sizeof(V)));
                 hipLaunchKernelGGL((k_rs_copy_floor<512, 16, V>), dim3(grid), dim3(512), 0, st, ki, vi, ko, vo, n, nb);
                 break;
             }
-            case 12: rs_pass2<1024, 8, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 13: rs_pass2<1024, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 14: rs_pass2<512, 24, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 15: rs_pass2<256, 32, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 4: rs_pass_p<256, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 5: rs_pass<256, 16, true, V, true>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 6: rs_pass<1024, 4, true, V, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 7: rs_pass<512, 8, true, V, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 8: rs_pass<256, 8, true, V, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 9: rs_pass<1024, 8, true, V, false>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 0: rs_pass<256, 16, false, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 1: rs_pass<256, 16, true, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            case 2: rs_pass<512, 16, false, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
-            default: rs_pass<512, 16, true, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+            default: rs_pass4<512, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
         }
         cur ^= 1;
     }
