@@ -12,6 +12,11 @@
 // ballot + mbcnt prefix into a per-wave LDS queue and the descriptor is evaluated in full
 // 64-entry drains (one queue entry per lane).  No MFMA: this is f32/f64 VALU + irregular gather.
 #include "fd_device.h"
+// waves per SIMD the pair kernel is compiled for: 5 (88 VGPRs, 48 B of scratch) measured 15.0 ms against 16.2 (4 waves,
+// 114 VGPRs) and 16.1 (6 waves, 80 VGPRs, 96 B of scratch)
+#ifndef FD_EMIT_WAVES
+#define FD_EMIT_WAVES 5
+#endif
 
 // ------------------------------------------------------------------ count pass
 // counts[s] += number of ordered pairs of structure s that will be emitted
@@ -215,7 +220,7 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
 }
 
 template <int TAB, bool IDS16>
-__global__ __launch_bounds__(FD_WAVE) void k_pair_emit2(fd_batch_view B, const fd_frame *__restrict__ frames, fd_hash_consts C,
+__global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_view B, const fd_frame *__restrict__ frames, fd_hash_consts C,
                                                         const uint64_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
                                                         uint32_t *__restrict__ keys, void *__restrict__ ids, uint32_t first_id) {
     __shared__ uint32_t q[2 * FD_WAVE];
