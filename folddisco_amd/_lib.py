@@ -95,6 +95,8 @@ SYMBOLS = [
     ("fdgpu_enable_timing", C.c_int, [VP, C.c_int]),
     ("fdgpu_pair_features", C.c_int, [VP, VP, C.c_uint64, u32p, u32p, C.c_uint64, C.POINTER(HashParams), f32p, u8p]),
     ("fdgpu_hash_features", C.c_int, [VP, f32p, C.c_uint64, C.POINTER(HashParams), u32p]),
+    ("fdgpu_make_query_map_batch", C.c_int, [VP, VP, C.c_uint64, u32p, u64p, u32p, C.POINTER(u8p), u32p, f32p, C.c_uint64, f32p, C.c_uint64,
+                                              C.POINTER(HashParams), VP, C.c_float, C.POINTER(C.POINTER(QueryMap))]),
     ("fdgpu_make_query_map", C.c_int, [VP, VP, u32p, C.c_uint64, C.POINTER(u8p), u32p, f32p, C.c_uint64, f32p, C.c_uint64,
                                        C.POINTER(HashParams), VP, C.c_float, C.POINTER(C.POINTER(QueryMap))]),
     ("fdgpu_query_map_free", None, [C.POINTER(QueryMap)]),

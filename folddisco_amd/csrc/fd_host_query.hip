@@ -35,7 +35,8 @@ __global__ void k_pair_features(fd_batch_view B, uint32_t s, const uint32_t *__r
                                 float cutoff, float *__restrict__ feat /*[n][7]*/, uint8_t *__restrict__ valid) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const uint32_t r0 = B.res_off[s], r1 = B.res_off[s + 1];
+    // s == 0xffffffff: pi / pj are residue indices of the whole batch (pairs of many structures in one launch)
+    const uint32_t r0 = s == 0xffffffffu ? 0u : B.res_off[s], r1 = s == 0xffffffffu ? B.res_off[B.n_struct] : B.res_off[s + 1];
     uint32_t i = r0 + pi[k], j = r0 + pj[k];
     bool ok = i < r1 && j < r1 && i != j && B.hash_ok[i] && B.hash_ok[j];
     fd_feature f = {0, 0, 0, 0, 0};
@@ -61,7 +62,7 @@ __global__ void k_hash_features(const float *__restrict__ feat, uint64_t n, fd_q
 
 extern "C" int fdgpu_pair_features(fdgpu_ctx *c, const fdgpu_batch *b, uint64_t s, const uint32_t *pi, const uint32_t *pj, uint64_t n,
                                    const fd_hash_params *p, float *features, uint8_t *valid) {
-    if (!c || !b || !p || s >= b->n_struct || (n && (!pi || !pj || !features || !valid))) return FDGPU_EINVAL;
+    if (!c || !b || !p || (s >= b->n_struct && s != 0xffffffffull) || (n && (!pi || !pj || !features || !valid))) return FDGPU_EINVAL;
     if (!n) return FDGPU_OK;
     hipStream_t st = c->stream;
     HIPCHK(c, c->ws[WS_MISC0].ensure(n * 4));
@@ -108,80 +109,98 @@ extern "C" void fdgpu_query_map_free(fd_query_map *m) {
     free(m);
 }
 
-extern "C" int fdgpu_make_query_map(fdgpu_ctx *c, const fdgpu_batch *qb, const uint32_t *q_index, uint64_t n_q, const uint8_t *const *subs,
-                                    const uint32_t *n_subs, const float *dist_thr, uint64_t n_dist, const float *angle_thr_deg, uint64_t n_angle,
-                                    const fd_hash_params *p, const fdgpu_index *index, float total_structures, fd_query_map **out) {
-    if (!c || !qb || !p || !out || qb->n_struct < 1 || (n_q && !q_index)) return FDGPU_EINVAL;
-    *out = nullptr;
-    const uint64_t R = qb->h_res_off[1] - qb->h_res_off[0];
-    // all ordered pairs of the query residues, row-major (CombinationIterator, utils/combination.rs:23-44)
+// make_query_map (src/controller/query.rs:208-329) for MANY queries with three launches in total (pair features, hashes of
+// the expanded candidates, posting lengths of the primary hashes): query t is structure q_struct[t] of qb with the residues
+// q_index[q_off[t] .. q_off[t+1]); subs / n_subs run parallel to q_index.  out[t] is released with fdgpu_query_map_free.
+extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, uint64_t n_queries, const uint32_t *q_struct, const uint64_t *q_off,
+                                          const uint32_t *q_index, const uint8_t *const *subs, const uint32_t *n_subs, const float *dist_thr,
+                                          uint64_t n_dist, const float *angle_thr_deg, uint64_t n_angle, const fd_hash_params *p,
+                                          const fdgpu_index *index, float total_structures, fd_query_map **out) {
+    if (!c || !qb || !p || !out || !q_off || (n_queries && !q_struct) || (q_off[n_queries] && !q_index)) return FDGPU_EINVAL;
+    for (uint64_t t = 0; t < n_queries; ++t) { out[t] = nullptr; if (q_struct[t] >= qb->n_struct) return FDGPU_EINVAL; }
+    // all ordered pairs of every query's residues, row-major (CombinationIterator, utils/combination.rs:23-44), as residue
+    // indices of the whole batch
     std::vector<uint32_t> pi, pj;
-    for (uint64_t a = 0; a < n_q; ++a)
-        for (uint64_t b = 0; b < n_q; ++b)
-            if (a != b && q_index[a] < R && q_index[b] < R) { pi.push_back(q_index[a]); pj.push_back(q_index[b]); }
+    std::vector<uint64_t> pair_off(n_queries + 1, 0);
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        const uint64_t r0 = qb->h_res_off[q_struct[t]], R = qb->h_res_off[q_struct[t] + 1] - r0;
+        const uint32_t *qi = q_index + q_off[t];
+        const uint64_t n_q = q_off[t + 1] - q_off[t];
+        for (uint64_t a = 0; a < n_q; ++a)
+            for (uint64_t b = 0; b < n_q; ++b)
+                if (a != b && qi[a] < R && qi[b] < R) { pi.push_back((uint32_t)(r0 + qi[a])); pj.push_back((uint32_t)(r0 + qi[b])); }
+        pair_off[t + 1] = pi.size();
+    }
     const uint64_t np = pi.size();
     std::vector<float> feat(std::max<uint64_t>(np, 1) * 7);
     std::vector<uint8_t> valid(std::max<uint64_t>(np, 1));
-    int rc = fdgpu_pair_features(c, qb, 0, pi.data(), pj.data(), np, p, feat.data(), valid.data());
+    int rc = fdgpu_pair_features(c, qb, 0xffffffffull, pi.data(), pj.data(), np, p, feat.data(), valid.data());
     if (rc) return rc;
-    // substitution map keyed by residue index: a later entry for the same residue overrides (query.rs:236-246)
-    std::map<uint32_t, std::pair<const uint8_t *, uint32_t>> sub_of;
-    if (subs && n_subs)
-        for (uint64_t a = 0; a < n_q; ++a)
-            if (subs[a]) sub_of[q_index[a]] = std::make_pair(subs[a], n_subs[a]);
     const float RADS_PER_DEG = 3.14159274101257324f / 180.0f;  // f32::to_radians
     std::vector<float> athr(n_angle);
     for (uint64_t t = 0; t < n_angle; ++t) athr[t] = angle_thr_deg[t] * RADS_PER_DEG;
-    // candidate list in the reference's insertion order; hashed in one GPU call, then first-insert-wins
+    // candidate lists in the reference's insertion order; hashed in one GPU call, then first-insert-wins per query
     struct cand_t { uint32_t qi, qj; uint8_t primary; uint32_t pair; };
     std::vector<float> vf;      // 7 floats per candidate
     std::vector<cand_t> cands;
+    std::vector<uint64_t> cand_off(n_queries + 1, 0);
+    struct Aad { std::vector<uint8_t> a1, a2; std::vector<float> ad; std::vector<uint32_t> aq; };
+    std::vector<Aad> aads(n_queries);
     auto push = [&](const float *f, uint32_t qi, uint32_t qj, bool primary, uint32_t pair) {
         vf.insert(vf.end(), f, f + 7);
         cands.push_back({qi, qj, (uint8_t)(primary ? 1 : 0), pair});
     };
-    std::vector<uint8_t> a1, a2;
-    std::vector<float> ad;
-    std::vector<uint32_t> aq;
-    for (uint64_t k = 0; k < np; ++k) {
-        if (!valid[k]) continue;
-        const float *f = &feat[7 * k];
-        uint32_t qi = pi[k], qj = pj[k];
-        // observed (aa_i, aa_j, CA distance) list (structure/core.rs:462-477: distance <= 20.0)
-        if (f[2] <= 20.0f) { a1.push_back((uint8_t)f[0]); a2.push_back((uint8_t)f[1]); ad.push_back(f[2]); aq.push_back(qi); }
-        push(f, qi, qj, true, (uint32_t)k);
-        float near[7], far[7];
-        memcpy(near, f, sizeof near);
-        memcpy(far, f, sizeof far);
-        auto si = sub_of.find(qi), sj = sub_of.find(qj);
-        if (si != sub_of.end()) {  // apply_substitutions (query.rs:86-156)
-            for (uint32_t a = 0; a < si->second.second; ++a) { float t[7]; memcpy(t, near, sizeof t); t[0] = (float)si->second.first[a]; push(t, qi, qj, false, (uint32_t)k); }
-            if (sj != sub_of.end())
-                for (uint32_t a = 0; a < si->second.second; ++a)
-                    for (uint32_t b = 0; b < sj->second.second; ++b) {
-                        float t[7]; memcpy(t, near, sizeof t);
-                        t[0] = (float)si->second.first[a]; t[1] = (float)sj->second.first[b];
-                        push(t, qi, qj, false, (uint32_t)k);
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        const uint64_t r0 = qb->h_res_off[q_struct[t]];
+        const uint32_t *qidx = q_index + q_off[t];
+        const uint64_t n_q = q_off[t + 1] - q_off[t];
+        // substitution map keyed by residue index: a later entry for the same residue overrides (query.rs:236-246)
+        std::map<uint32_t, std::pair<const uint8_t *, uint32_t>> sub_of;
+        if (subs && n_subs)
+            for (uint64_t a = 0; a < n_q; ++a)
+                if (subs[q_off[t] + a]) sub_of[qidx[a]] = std::make_pair(subs[q_off[t] + a], n_subs[q_off[t] + a]);
+        Aad &A = aads[t];
+        for (uint64_t k = pair_off[t]; k < pair_off[t + 1]; ++k) {
+            if (!valid[k]) continue;
+            const float *f = &feat[7 * k];
+            uint32_t qi = (uint32_t)(pi[k] - r0), qj = (uint32_t)(pj[k] - r0);
+            // observed (aa_i, aa_j, CA distance) list (structure/core.rs:462-477: distance <= 20.0)
+            if (f[2] <= 20.0f) { A.a1.push_back((uint8_t)f[0]); A.a2.push_back((uint8_t)f[1]); A.ad.push_back(f[2]); A.aq.push_back(qi); }
+            push(f, qi, qj, true, (uint32_t)k);
+            float near[7], far[7];
+            memcpy(near, f, sizeof near);
+            memcpy(far, f, sizeof far);
+            auto si = sub_of.find(qi), sj = sub_of.find(qj);
+            if (si != sub_of.end()) {  // apply_substitutions (query.rs:86-156)
+                for (uint32_t a = 0; a < si->second.second; ++a) { float t2[7]; memcpy(t2, near, sizeof t2); t2[0] = (float)si->second.first[a]; push(t2, qi, qj, false, (uint32_t)k); }
+                if (sj != sub_of.end())
+                    for (uint32_t a = 0; a < si->second.second; ++a)
+                        for (uint32_t b = 0; b < sj->second.second; ++b) {
+                            float t2[7]; memcpy(t2, near, sizeof t2);
+                            t2[0] = (float)si->second.first[a]; t2[1] = (float)sj->second.first[b];
+                            push(t2, qi, qj, false, (uint32_t)k);
+                        }
+            } else if (sj != sub_of.end()) {
+                for (uint32_t b = 0; b < sj->second.second; ++b) { float t2[7]; memcpy(t2, near, sizeof t2); t2[1] = (float)sj->second.first[b]; push(t2, qi, qj, false, (uint32_t)k); }
+            }
+            auto expand = [&](const int *idxs, int n_idx, const float *thr, uint64_t n_thr) {  // expand_and_insert (query.rs:179-206)
+                for (uint64_t z2 = 0; z2 < n_thr; ++z2)
+                    for (int z = 0; z < n_idx; ++z) {
+                        int idx = idxs[z];
+                        near[idx] = near[idx] - thr[z2];
+                        far[idx] = far[idx] + thr[z2];
+                        push(near, qi, qj, false, (uint32_t)k);
+                        push(far, qi, qj, false, (uint32_t)k);
+                        // the reference restores with += / -= (f32, not an exact inverse): keep the drift
+                        near[idx] = near[idx] + thr[z2];
+                        far[idx] = far[idx] - thr[z2];
                     }
-        } else if (sj != sub_of.end()) {
-            for (uint32_t b = 0; b < sj->second.second; ++b) { float t[7]; memcpy(t, near, sizeof t); t[1] = (float)sj->second.first[b]; push(t, qi, qj, false, (uint32_t)k); }
+            };
+            static const int di[2] = {2, 3}, ai[3] = {4, 5, 6};
+            expand(di, 2, dist_thr, n_dist);
+            expand(ai, 3, athr.data(), n_angle);
         }
-        auto expand = [&](const int *idxs, int n_idx, const float *thr, uint64_t n_thr) {  // expand_and_insert (query.rs:179-206)
-            for (uint64_t t = 0; t < n_thr; ++t)
-                for (int z = 0; z < n_idx; ++z) {
-                    int idx = idxs[z];
-                    near[idx] = near[idx] - thr[t];
-                    far[idx] = far[idx] + thr[t];
-                    push(near, qi, qj, false, (uint32_t)k);
-                    push(far, qi, qj, false, (uint32_t)k);
-                    // the reference restores with += / -= (f32, not an exact inverse): keep the drift
-                    near[idx] = near[idx] + thr[t];
-                    far[idx] = far[idx] - thr[t];
-                }
-        };
-        static const int di[2] = {2, 3}, ai[3] = {4, 5, 6};
-        expand(di, 2, dist_thr, n_dist);
-        expand(ai, 3, athr.data(), n_angle);
+        cand_off[t + 1] = cands.size();
     }
     const uint64_t nc = cands.size();
     std::vector<uint32_t> hashes(std::max<uint64_t>(nc, 1));
@@ -189,8 +208,7 @@ extern "C" int fdgpu_make_query_map(fdgpu_ctx *c, const fdgpu_batch *qb, const u
     // idf of every pair's observed (primary) hash: log2(S / len) (query.rs:17-32)
     std::vector<float> pair_idf(std::max<uint64_t>(np, 1), 0.0f);
     if (index) {
-        std::vector<uint32_t> ph;
-        std::vector<uint32_t> pk;
+        std::vector<uint32_t> ph, pk;
         for (uint64_t t = 0; t < nc; ++t)
             if (cands[t].primary) { ph.push_back(hashes[t]); pk.push_back(cands[t].pair); }
         std::vector<uint64_t> lens(std::max<size_t>(ph.size(), 1));
@@ -198,28 +216,38 @@ extern "C" int fdgpu_make_query_map(fdgpu_ctx *c, const fdgpu_batch *qb, const u
         for (size_t t = 0; t < ph.size(); ++t)
             pair_idf[pk[t]] = lens[t] > 0 ? log2f(total_structures / (float)lens[t]) : 0.0f;
     }
-    std::vector<uint32_t> mh, mqi, mqj;
-    std::vector<uint8_t> mp;
-    std::vector<float> mi;
-    {
-        std::vector<uint32_t> seen;  // sorted set for membership (query maps are small; whole-structure ones ~1e5)
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        std::vector<uint32_t> mh, mqi, mqj;
+        std::vector<uint8_t> mp;
+        std::vector<float> mi;
         std::map<uint32_t, char> have;
-        for (uint64_t t = 0; t < nc; ++t) {
-            if (have.count(hashes[t])) continue;
-            have[hashes[t]] = 1;
-            mh.push_back(hashes[t]); mqi.push_back(cands[t].qi); mqj.push_back(cands[t].qj); mp.push_back(cands[t].primary);
-            mi.push_back(pair_idf[cands[t].pair]);
+        for (uint64_t z = cand_off[t]; z < cand_off[t + 1]; ++z) {
+            if (have.count(hashes[z])) continue;
+            have[hashes[z]] = 1;
+            mh.push_back(hashes[z]); mqi.push_back(cands[z].qi); mqj.push_back(cands[z].qj); mp.push_back(cands[z].primary);
+            mi.push_back(pair_idf[cands[z].pair]);
         }
+        fd_query_map *m = (fd_query_map *)calloc(1, sizeof *m);
+        if (!m) { for (uint64_t u = 0; u < t; ++u) { fdgpu_query_map_free(out[u]); out[u] = nullptr; } return FDGPU_ENOMEM; }
+        m->n = mh.size();
+        m->hash = dup_vec(mh); m->qi = dup_vec(mqi); m->qj = dup_vec(mqj); m->is_primary = dup_vec(mp); m->idf = dup_vec(mi);
+        std::vector<uint32_t> idx(q_index + q_off[t], q_index + q_off[t + 1]);
+        m->n_indices = idx.size(); m->indices = dup_vec(idx);
+        const Aad &A = aads[t];
+        m->n_aad = A.ad.size(); m->aad_aa1 = dup_vec(A.a1); m->aad_aa2 = dup_vec(A.a2); m->aad_dist = dup_vec(A.ad); m->aad_qi = dup_vec(A.aq);
+        out[t] = m;
     }
-    fd_query_map *m = (fd_query_map *)calloc(1, sizeof *m);
-    if (!m) return FDGPU_ENOMEM;
-    m->n = mh.size();
-    m->hash = dup_vec(mh); m->qi = dup_vec(mqi); m->qj = dup_vec(mqj); m->is_primary = dup_vec(mp); m->idf = dup_vec(mi);
-    std::vector<uint32_t> idx(q_index, q_index + n_q);
-    m->n_indices = n_q; m->indices = dup_vec(idx);
-    m->n_aad = ad.size(); m->aad_aa1 = dup_vec(a1); m->aad_aa2 = dup_vec(a2); m->aad_dist = dup_vec(ad); m->aad_qi = dup_vec(aq);
-    *out = m;
     return FDGPU_OK;
+}
+
+// one query = structure 0 of qb
+extern "C" int fdgpu_make_query_map(fdgpu_ctx *c, const fdgpu_batch *qb, const uint32_t *q_index, uint64_t n_q, const uint8_t *const *subs,
+                                    const uint32_t *n_subs, const float *dist_thr, uint64_t n_dist, const float *angle_thr_deg, uint64_t n_angle,
+                                    const fd_hash_params *p, const fdgpu_index *index, float total_structures, fd_query_map **out) {
+    if (!c || !qb || !p || !out || qb->n_struct < 1 || (n_q && !q_index)) return FDGPU_EINVAL;
+    const uint32_t s0 = 0;
+    const uint64_t off[2] = {0, n_q};
+    return fdgpu_make_query_map_batch(c, qb, 1, &s0, off, q_index, subs, n_subs, dist_thr, n_dist, angle_thr_deg, n_angle, p, index, total_structures, out);
 }
 
 // ------------------------------------------------------------------------------------------ retrieval glue

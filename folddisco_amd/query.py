@@ -112,6 +112,46 @@ def make_query_map(ctx: Context, qbatch: Batch, q_indices, subs=None, index: Fol
                           _arr(m.aad_qi, m.n_aad, np.uint32), handle=out, ctx=ctx)
 
 
+def _wrap_query_map(ctx, out) -> QueryMapResult:
+    m = out.contents
+    return QueryMapResult(_arr(m.hash, m.n, np.uint32), _arr(m.qi, m.n, np.uint32), _arr(m.qj, m.n, np.uint32),
+                          _arr(m.is_primary, m.n, np.uint8), _arr(m.idf, m.n, np.float32), _arr(m.indices, m.n_indices, np.uint32),
+                          _arr(m.aad_aa1, m.n_aad, np.uint8), _arr(m.aad_aa2, m.n_aad, np.uint8), _arr(m.aad_dist, m.n_aad, np.float32),
+                          _arr(m.aad_qi, m.n_aad, np.uint32), handle=out, ctx=ctx)
+
+
+def make_query_maps(ctx: Context, qbatch: Batch, queries, index: FolddiscoIndex | None = None, total_structures: float = 0.0,
+                    dist_thr=(0.5,), angle_thr=(5.0,), nbin_dist=0, nbin_angle=0, dist_cutoff=20.0):
+    """Many query maps with three launches in total (fdgpu_make_query_map_batch).  queries: list of (structure index in
+    qbatch, residue indices[, substitution lists]).  -> list of QueryMapResult."""
+    nq = len(queries)
+    q_struct = np.ascontiguousarray([q[0] for q in queries], np.uint32)
+    idx = [np.ascontiguousarray(q[1], np.uint32) for q in queries]
+    q_off = np.concatenate([[0], np.cumsum([len(x) for x in idx])]).astype(np.uint64)
+    q_index = np.ascontiguousarray(np.concatenate(idx) if idx else np.zeros(0, np.uint32))
+    ntot = len(q_index)
+    sub_ptrs = (u8p * max(ntot, 1))()
+    n_subs = np.zeros(max(ntot, 1), np.uint32)
+    keep = []
+    for t, q in enumerate(queries):
+        if len(q) > 2 and q[2] is not None:
+            for k, sl in enumerate(q[2]):
+                if sl is not None:
+                    a = np.ascontiguousarray(sl if len(sl) else [0], dtype=np.uint8)
+                    keep.append(a)
+                    sub_ptrs[int(q_off[t]) + k] = a.ctypes.data_as(u8p)
+                    n_subs[int(q_off[t]) + k] = len(sl)
+    d = np.ascontiguousarray(dist_thr, np.float32)
+    a = np.ascontiguousarray(angle_thr, np.float32)
+    p = HashParams(nbin_dist, nbin_angle, dist_cutoff)
+    outs = (C.POINTER(QueryMap) * max(nq, 1))()
+    ctx.check(ctx.L.fdgpu_make_query_map_batch(ctx.h, qbatch.h, nq, q_struct.ctypes.data_as(u32p), q_off.ctypes.data_as(u64p),
+                                               q_index.ctypes.data_as(u32p), sub_ptrs, n_subs.ctypes.data_as(u32p), d.ctypes.data_as(f32p), len(d),
+                                               a.ctypes.data_as(f32p), len(a), C.byref(p), index.h if index is not None else None,
+                                               total_structures, outs))
+    return [_wrap_query_map(ctx, outs[t]) for t in range(nq)]
+
+
 def retrieve(ctx: Context, db: Batch, resname_std, cand, qm: QueryMapResult, qbatch: Batch, ca_distance_cutoff=1.0,
              node_count=2, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0):
     """-> list of dicts per match: cand slot, idf, rmsd, from_hash / processed target residue indices (-1 = none)."""

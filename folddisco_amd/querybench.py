@@ -14,7 +14,7 @@ import torch
 
 from . import dist as fdist
 from .api import PackedStructures, count_query, count_query_batch, length_penalty
-from .query import make_query_map, retrieve
+from .query import make_query_map, make_query_maps, retrieve
 
 
 def _pick_queries(d, S, n_queries, seed, k=4):
@@ -50,6 +50,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     pen = length_penalty(nres, 0.5)
     S_total = S * world
     qbatches = [ctx.upload(PackedStructures.concat([it])) for _, _, it in queries]
+    qall = ctx.upload(PackedStructures.concat([it for _, _, it in queries]))    # every query structure in one batch (batched legs)
 
     def one(k, match):
         s, idx, _ = queries[k]
@@ -92,7 +93,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             tot = 0
             for c0 in range(0, len(queries), chunk):
                 ks = range(c0, min(c0 + chunk, len(queries)))
-                qms = [make_query_map(ctx, qbatches[k], queries[k][1], None, ix if match else None, float(S_total)) for k in ks]
+                qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix if match else None, float(S_total))
                 recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total)
                 for k, qm, r in zip(ks, qms, recs):
                     n = len(fdist.allgather_hits(r, dev, top_n=top_n))
@@ -134,7 +135,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         "metric": "motif queries/sec", "value": len(queries) / dt1, "unit": "queries/s", "n_queries": len(queries),
         "mode": "prefilter (count_query) + all-gather of candidate hits", "ms_per_query": dt1 / len(queries) * 1e3,
         "batched": {"value": len(queries) / dtb, "ms_per_query": dtb / len(queries) * 1e3, "chunk": 32, "avg_hits": hits_b / len(queries),
-                    "mode": "count_query_batch: one scoring pass per 32 queries"},
+                    "mode": "make_query_map_batch + count_query_batch: six launches per 32 queries"},
         "batched_with_matching": {"value": len(queries) / dtbm, "ms_per_query": dtbm / len(queries) * 1e3, "matches": nm_b, "match_top": match_top},
         "with_matching": {"value": len(queries) / dt2, "ms_per_query": dt2 / len(queries) * 1e3, "matches": nm, "match_top": match_top},
         "avg_query_hashes": hashes / len(queries), "avg_hits": hits / len(queries),

@@ -186,6 +186,12 @@ int fdgpu_make_query_map(fdgpu_ctx *ctx, const fdgpu_batch *qb, const uint32_t *
                          const uint8_t *const *subs, const uint32_t *n_subs, const float *dist_thr, uint64_t n_dist,
                          const float *angle_thr_deg, uint64_t n_angle, const fd_hash_params *p, const fdgpu_index *index,
                          float total_structures, fd_query_map **out);
+/* Many queries, three launches in total: query t = structure q_struct[t] of qb with residues q_index[q_off[t] .. q_off[t+1]);
+ * subs / n_subs run parallel to q_index (may be NULL); out[t] per query, each released with fdgpu_query_map_free. */
+int fdgpu_make_query_map_batch(fdgpu_ctx *ctx, const fdgpu_batch *qb, uint64_t n_queries, const uint32_t *q_struct, const uint64_t *q_off,
+                               const uint32_t *q_index, const uint8_t *const *subs, const uint32_t *n_subs, const float *dist_thr,
+                               uint64_t n_dist, const float *angle_thr_deg, uint64_t n_angle, const fd_hash_params *p,
+                               const fdgpu_index *index, float total_structures, fd_query_map **out);
 void fdgpu_query_map_free(fd_query_map *m);
 
 typedef struct fd_match_rec {   /* one connected component of one candidate (retrieval_wrapper, retrieve.rs:364-552) */

@@ -281,3 +281,30 @@ def test_cli_format_output_metrics(tmp_path):
     keep = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", pre, "--tm-score", "0.9"],
                           cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
     assert len(keep) == sum(float(r[2]) >= 0.9 for r in rows) and len(keep) >= 1
+
+
+@pytest.mark.gpu
+def test_query_map_batch_equals_single(env):
+    """fdgpu_make_query_map_batch == fdgpu_make_query_map per query (same hashes in the same insertion order, same node / edge
+    labels, idf, observed-distance lists), with substitutions and an unresolvable residue in the mix"""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    ctx, structs, batch, ix, nres, plddt, tids = env
+    q1, q2 = st.read_compact_structure(Q4CHA), st.read_compact_structure(Q1G2F)
+    qall = ctx.upload(fd.PackedStructures.concat([q1.as_item(), q2.as_item()]))
+    specs = [(0, q1, "B57,B102,C195"), (1, q2, "F207,F212,F225,F229"), (0, q1, "B57:HKR,B102,C195:ST"), (1, q2, "F207:C,F212,F225:HX,F229")]
+    reqs, singles = [], []
+    for sidx, q, qstr in specs:
+        res = fq.parse_query_string(qstr, q.chains[0])
+        pairs = [(q.get_index(c, r), s) for c, r, s in res]
+        pairs = [(i, s) for i, s in pairs if i is not None]
+        reqs.append((sidx, [i for i, _ in pairs], [s for _, s in pairs]))
+        qb = ctx.upload(fd.PackedStructures.concat([q.as_item()]))
+        singles.append(fq.make_query_map(ctx, qb, [i for i, _ in pairs], [s for _, s in pairs], ix, 5.0))
+    got = fq.make_query_maps(ctx, qall, reqs, ix, 5.0)
+    assert len(got) == len(singles)
+    for g, w in zip(got, singles):
+        for f in ("hash", "qi", "qj", "is_primary", "idf", "indices", "aad_aa1", "aad_aa2", "aad_dist", "aad_qi"):
+            assert getattr(g, f).tobytes() == getattr(w, f).tobytes(), f
+    assert all(len(g.hash) > 0 for g in got) and len(got[2].hash) > len(got[0].hash)      # substitutions add hashes

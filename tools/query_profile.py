@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import folddisco_amd as fd
 from folddisco_amd import synth, querybench, dist as fdist
-from folddisco_amd.query import make_query_map
+from folddisco_amd.query import make_query_map, make_query_maps
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 67750
 dev = torch.device("cuda", 0)
 d = synth.generate(S, seed=20260927, device=dev)
@@ -16,9 +16,10 @@ queries = querybench._pick_queries(d, S, 64, 4242)
 nres = np.diff(res_off.cpu().numpy()).astype(np.uint64)
 pen = fd.length_penalty(nres, 0.5)
 qb = [ctx.upload(fd.PackedStructures.concat([it])) for _, _, it in queries]
+qall = ctx.upload(fd.PackedStructures.concat([it for _, _, it in queries]))
 def go():
     for c0 in range(0, 64, 32):
-        qms = [make_query_map(ctx, qb[k], queries[k][1], None, None, float(S)) for k in range(c0, c0 + 32)]
+        qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in range(c0, c0 + 32)], None, float(S))
         recs = fd.count_query_batch(ctx, ix, [(q.hash, q.qi, q.qj) for q in qms], pen, total_structures=S)
         for r in recs:
             fdist.allgather_hits(r, dev, top_n=1000)
