@@ -289,9 +289,12 @@ def count_query(ctx: Context, index: FolddiscoIndex, q_hash, q_node, q_edge_j, p
                  edge_count=int(r["edge_count"]), idf=float(r["idf"])) for r in arr]
 
 
-def count_query_batch(ctx: Context, index: FolddiscoIndex, queries, penalty: np.ndarray, total_structures: int | None = None):
+def count_query_batch(ctx: Context, index: FolddiscoIndex, queries, penalty: np.ndarray, total_structures: int | None = None,
+                      top_n: int = 0):
     """queries: list of (q_hash, q_node, q_edge_j) arrays.  One posting-length launch + one scoring pass for the whole
-    batch.  Returns a list of REC_DTYPE arrays (ascending nid), one per query."""
+    batch.  Returns a list of REC_DTYPE arrays, one per query: every touched structure in ascending nid, or with top_n > 0
+    only the records that can be among the top_n by idf (ties of the cut-off included, unordered; rank them with
+    dist.rank_hits)."""
     S = index.n_structures if total_structures is None else total_structures
     qh = np.ascontiguousarray(np.concatenate([np.asarray(q[0], np.uint32) for q in queries]) if queries else np.zeros(0, np.uint32))
     qn = np.ascontiguousarray(np.concatenate([np.asarray(q[1], np.uint32) for q in queries]) if queries else np.zeros(0, np.uint32))
@@ -306,8 +309,8 @@ def count_query_batch(ctx: Context, index: FolddiscoIndex, queries, penalty: np.
     pen = np.ascontiguousarray(penalty, dtype=np.float32)
     out = C.POINTER(CountRec)()
     ooff = u64p()
-    ctx.check(ctx.L.fdgpu_count_query_batch(ctx.h, index.h, len(queries), _ptr(q_off, u64p), _ptr(qh, u32p), _ptr(qn, u32p), _ptr(qe, u32p),
-                                            _ptr(idf, f32p), _ptr(pen, f32p), C.byref(out), C.byref(ooff)))
+    ctx.check(ctx.L.fdgpu_count_query_batch_top(ctx.h, index.h, len(queries), _ptr(q_off, u64p), _ptr(qh, u32p), _ptr(qn, u32p), _ptr(qe, u32p),
+                                                _ptr(idf, f32p), _ptr(pen, f32p), int(top_n), C.byref(out), C.byref(ooff)))
     off = np.ctypeslib.as_array(ooff, shape=(len(queries) + 1,)).copy()
     n = int(off[-1])
     arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n, 1) * 20,))[: n * 20].copy().view(REC_DTYPE)

@@ -629,9 +629,9 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
 
 // batched count_query: queries [q_off[t], q_off[t+1]) of the concatenated hash arrays; results of query t are
 // (*out)[(*out_off)[t] .. (*out_off)[t+1])
-extern "C" int fdgpu_count_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
-                                       const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty,
-                                       fd_count_rec **out, uint64_t **out_off) {
+static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
+                                  const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
+                                  fd_count_rec **out, uint64_t **out_off) {
     if (!c || !ix || !out || !out_off || !q_off || (ix->n_structures && !penalty)) return FDGPU_EINVAL;
     *out = nullptr; *out_off = nullptr;
     reset_timings(c);
@@ -704,8 +704,9 @@ extern "C" int fdgpu_count_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, uint
     uint64_t n = 0;
     int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &n);
     if (rc) { free(ooff); return rc; }
-    fd_count_rec *r = (fd_count_rec *)malloc(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec));
-    if (!r) { free(ooff); return FDGPU_ENOMEM; }
+    const bool select = top_n > 0 && n > (uint64_t)top_n * n_queries;   // worth preselecting on the device
+    fd_count_rec *r = select ? nullptr : (fd_count_rec *)malloc(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec));
+    if (!select && !r) { free(ooff); return FDGPU_ENOMEM; }
     e = c->ws[WS_TILE_HO].ensure(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec));
     if (e == hipSuccess) e = c->ws[WS_TILE_PO].ensure((n_queries + 1) * 8 + 64);
     if (e == hipSuccess) {
@@ -722,12 +723,62 @@ extern "C" int fdgpu_count_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, uint
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st);   // idx must outlive the copy
     }
+    if (e == hipSuccess && select) {
+        // per-query preselection of the top_n by idf on the device (k_cq_topn); a query whose threshold bin overflows the
+        // fixed-stride output falls back to its full list
+        const uint32_t cap = top_n + 1024;
+        std::vector<uint32_t> cnt(n_queries);
+        std::vector<fd_count_rec> sel((size_t)n_queries * cap);
+        e = c->ws[WS_KEYS_A].ensure((size_t)n_queries * cap * sizeof(fd_count_rec));
+        if (e == hipSuccess) e = c->ws[WS_MISC2].ensure(n_queries * 4);
+        if (e == hipSuccess) {
+            fd_launch_cq_topn(c->ws[WS_TILE_HO].p, c->ws[WS_TILE_PO].as<uint64_t>(), (uint32_t)n_queries, top_n, cap, c->ws[WS_KEYS_A].p,
+                              c->ws[WS_MISC2].as<uint32_t>(), st);
+            e = hipMemcpyAsync(cnt.data(), c->ws[WS_MISC2].p, n_queries * 4, hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(sel.data(), c->ws[WS_KEYS_A].p, sel.size() * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { free(ooff); c->err = std::string("count_query_batch: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+        uint64_t tot = 0;
+        for (uint64_t t = 0; t < n_queries; ++t) tot += cnt[t] <= cap ? cnt[t] : (ooff[t + 1] - ooff[t]);
+        r = (fd_count_rec *)malloc(std::max<uint64_t>(tot, 1) * sizeof(fd_count_rec));
+        if (!r) { free(ooff); return FDGPU_ENOMEM; }
+        std::vector<uint64_t> noff(n_queries + 1, 0);
+        for (uint64_t t = 0; t < n_queries; ++t) {
+            if (cnt[t] <= cap) {
+                memcpy(r + noff[t], sel.data() + (size_t)t * cap, (size_t)cnt[t] * sizeof(fd_count_rec));
+                noff[t + 1] = noff[t] + cnt[t];
+            } else {
+                uint64_t m = ooff[t + 1] - ooff[t];
+                if (hipMemcpy(r + noff[t], (const fd_count_rec *)c->ws[WS_TILE_HO].p + ooff[t], m * sizeof(fd_count_rec), hipMemcpyDeviceToHost) != hipSuccess) {
+                    free(r); free(ooff); c->err = "count_query_batch: fallback copy failed"; return FDGPU_EHIP;
+                }
+                noff[t + 1] = noff[t] + m;
+            }
+        }
+        memcpy(ooff, noff.data(), (n_queries + 1) * 8);
+        *out = r; *out_off = ooff;
+        return FDGPU_OK;
+    }
     if (e == hipSuccess && n) e = hipMemcpyAsync(r, c->ws[WS_TILE_HO].p, n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { free(r); free(ooff); c->err = std::string("count_query_batch: ") + hipGetErrorString(e); return FDGPU_EHIP; }
     *out = r; *out_off = ooff;
     return FDGPU_OK;
+}
+extern "C" int fdgpu_count_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
+                                       const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty,
+                                       fd_count_rec **out, uint64_t **out_off) {
+    return count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, 0, out, out_off);
+}
+// as above, but per query only the records that can be among the top_n by idf are returned (every record whose idf is >= the
+// top_n-th largest, in no particular order): the candidate selection of query_pdb.rs:404-411 sorts that short list
+extern "C" int fdgpu_count_query_batch_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
+                                           const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty,
+                                           uint32_t top_n, fd_count_rec **out, uint64_t **out_off) {
+    return count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off);
 }
 
 // ---- S4 ---------------------------------------------------------------------------------------------------------------

@@ -195,3 +195,5 @@ void fd_launch_cq_batch(const cq_args &A, const uint32_t *q_query, uint32_t n_qu
                         uint8_t *flags, hipStream_t st);
 void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, const uint32_t *edge_cnt, const uint8_t *flags, const uint64_t *pos,
                                 const float *penalty, uint64_t total, void *out, hipStream_t st);
+void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries, uint32_t top_n, uint32_t cap, void *out, uint32_t *out_cnt,
+                       hipStream_t st);

@@ -276,6 +276,73 @@ __global__ __launch_bounds__(256) void k_cq_compact_batch(const uint32_t *__rest
     out[pos[g]] = r;
 }
 
+// ------------------------------------------------------------------ per-query top-N preselection (candidate selection, query_pdb.rs:404-411)
+// The reference sorts every touched structure by idf (descending) and truncates to --top.  Here a two-level radix select on the
+// order-preserving image of the f32 idf (11 + 11 bits) finds, per query, the 22-bit threshold below which a record cannot be in
+// the top N; records at or above it (>= N of them unless fewer exist; ties of the threshold bin included) are copied out, so
+// the host sorts ~N records instead of every touched structure.  One workgroup per query.
+#define TOPN_BINS 2048
+__device__ __forceinline__ uint32_t idf_order_key(float v) {
+    uint32_t b = __float_as_uint(v + 0.0f);   // -0 -> +0
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ __launch_bounds__(256) void k_cq_topn(const fd_count_rec_dev *__restrict__ recs, const uint64_t *__restrict__ off, uint32_t top_n,
+                                                 uint32_t cap, fd_count_rec_dev *__restrict__ out, uint32_t *__restrict__ out_cnt) {
+    __shared__ uint32_t hist[TOPN_BINS];
+    __shared__ uint32_t s_thr, s_above, s_cnt;
+    const uint32_t q = blockIdx.x;
+    const fd_count_rec_dev *r = recs + off[q];
+    const uint64_t m = off[q + 1] - off[q];
+    uint32_t thr22 = 0;   // keep everything
+    if (m > top_n) {
+        // level 1: top 11 bits
+        for (int k = threadIdx.x; k < TOPN_BINS; k += 256) hist[k] = 0;
+        __syncthreads();
+        for (uint64_t i = threadIdx.x; i < m; i += 256) atomicAdd(&hist[idf_order_key(r[i].idf) >> 21], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0;
+            int b = TOPN_BINS - 1;
+            for (; b > 0; --b) { if (acc + hist[b] >= top_n) break; acc += hist[b]; }
+            s_thr = (uint32_t)b; s_above = acc;
+        }
+        __syncthreads();
+        const uint32_t b1 = s_thr, above = s_above;
+        // level 2: next 11 bits inside the threshold bin
+        for (int k = threadIdx.x; k < TOPN_BINS; k += 256) hist[k] = 0;
+        __syncthreads();
+        for (uint64_t i = threadIdx.x; i < m; i += 256) {
+            uint32_t key = idf_order_key(r[i].idf);
+            if ((key >> 21) == b1) atomicAdd(&hist[(key >> 10) & (TOPN_BINS - 1)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t acc = above;
+            int b = TOPN_BINS - 1;
+            for (; b > 0; --b) { if (acc + hist[b] >= top_n) break; acc += hist[b]; }
+            s_thr = (b1 << 11) | (uint32_t)b;
+        }
+        __syncthreads();
+        thr22 = s_thr;
+    }
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    for (uint64_t i = threadIdx.x; i < m; i += 256) {
+        fd_count_rec_dev x = r[i];
+        if ((idf_order_key(x.idf) >> 10) >= thr22) {
+            uint32_t pos = atomicAdd(&s_cnt, 1u);
+            if (pos < cap) out[(uint64_t)q * cap + pos] = x;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out_cnt[q] = s_cnt;   // > cap: the caller falls back to the full list of this query
+}
+void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries, uint32_t top_n, uint32_t cap, void *out, uint32_t *out_cnt,
+                       hipStream_t st) {
+    if (n_queries) hipLaunchKernelGGL(k_cq_topn, dim3(n_queries), dim3(256), 0, st, (const fd_count_rec_dev *)recs, off, top_n, cap,
+                                      (fd_count_rec_dev *)out, out_cnt);
+}
+
 void fd_launch_cq_batch(const cq_args &A, const uint32_t *q_query, uint32_t n_queries, const uint32_t *row_off, uint32_t *node_cnt, uint32_t *edge_cnt,
                         uint8_t *flags, hipStream_t st) {
     if (A.nq) hipLaunchKernelGGL(k_cq_accumulate_batch, dim3((unsigned)A.nq), dim3(FD_WAVE), 0, st, A, q_query);

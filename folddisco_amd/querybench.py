@@ -94,7 +94,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             for c0 in range(0, len(queries), chunk):
                 ks = range(c0, min(c0 + chunk, len(queries)))
                 qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix if match else None, float(S_total))
-                recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total)
+                recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=top_n)
                 for k, qm, r in zip(ks, qms, recs):
                     n = len(fdist.allgather_hits(r, dev, top_n=top_n))
                     if match and len(r):
