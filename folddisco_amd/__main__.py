@@ -32,23 +32,39 @@ def cmd_index(a):
         sys.exit(f"[FAIL] no structures under {a.pdbs}")
     prefix = a.index or (a.pdbs.rstrip("/") + "_folddisco")
     ctx = fd.Context(a.device)
-    # native multi-threaded ingest (csrc/fd_ingest.cpp); a structure above --max-residue keeps its id but has no hashes,
-    # nres 0 and plddt 0 (controller/mod.rs:313-318)
-    structs, ok = structure.read_compact_structures(paths, threads=a.threads, max_residue=a.max_residue)
-    for p, s, good in zip(paths, structs, ok):
-        if not good:
-            print(f"[WARN] {p} could not be read. Skipping", file=sys.stderr)
-        elif s.num_residues_raw > a.max_residue > 0:
-            print(f"[WARN] {p} has too many residues. Skipping", file=sys.stderr)
-    nres = np.array([s.n for s in structs], np.uint64)
-    plddt = np.array([s.avg_plddt() if s.n else 0.0 for s in structs], np.float32)
-    batch = ctx.upload(fd.PackedStructures.concat([s.as_item() for s in structs]))
-    ix = fd.FolddiscoIndex.build(ctx, batch, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid)
-    ix.save(prefix)
+    # Chunks of --chunk structures (the reference walks T*128-structure chunks, controller/mod.rs:289-294): ingest (native,
+    # multi-threaded; a structure above --max-residue keeps its id but has no hashes, nres 0 and plddt 0,
+    # controller/mod.rs:313-318) -> one sub-index per chunk on the GPU -> per-hash concatenation of the sub-indices
+    # (fdgpu_merge_subindices).  One chunk = one fdgpu_index_build call (< 2^32 residue pairs).
+    nres_all, plddt_all, parts = [], [], []
+    n_hashes = value_len = 0
+    for c0 in range(0, len(paths), a.chunk):
+        chunk = paths[c0:c0 + a.chunk]
+        structs, ok = structure.read_compact_structures(chunk, threads=a.threads, max_residue=a.max_residue)
+        for p, s, good in zip(chunk, structs, ok):
+            if not good:
+                print(f"[WARN] {p} could not be read. Skipping", file=sys.stderr)
+            elif s.num_residues_raw > a.max_residue > 0:
+                print(f"[WARN] {p} has too many residues. Skipping", file=sys.stderr)
+        nres_all.append(np.array([s.n for s in structs], np.uint64))
+        plddt_all.append(np.array([s.avg_plddt() if s.n else 0.0 for s in structs], np.float32))
+        batch = ctx.upload(fd.PackedStructures.concat([s.as_item() for s in structs]))
+        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid)
+        if len(paths) <= a.chunk:
+            ix.save(prefix)                       # single chunk: the library writes PREFIX and PREFIX.offset itself
+            n_hashes, value_len = ix.num_hashes, ix.value_len
+        else:
+            parts.append(ix.export())
+        del ix, batch
+    if parts:
+        v, h, o = indexio.merge_subindices(parts)
+        indexio.write_index_files(prefix, v, h, o)
+        n_hashes, value_len = len(h), len(v)
+    nres, plddt = np.concatenate(nres_all), np.concatenate(plddt_all)
     indexio.save_lookup(prefix + ".lookup", paths, nres, plddt)
     indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance)
     if a.verbose:
-        print(f"[DONE] {len(paths)} structures, {ix.num_hashes} hashes, {ix.value_len} value bytes -> {prefix}", file=sys.stderr)
+        print(f"[DONE] {len(paths)} structures, {n_hashes} hashes, {value_len} value bytes -> {prefix}", file=sys.stderr)
 
 
 def cmd_query(a):
@@ -128,6 +144,7 @@ def main(argv=None):
     pi.add_argument("-r", "--recursive", action="store_true")
     pi.add_argument("-v", "--verbose", action="store_true")
     pi.add_argument("--device", type=int, default=0)
+    pi.add_argument("--chunk", type=int, default=65536, help="structures per GPU build call (sub-indices are merged)")
     pq = sub.add_parser("query")
     pq.add_argument("-p", "--pdb", default="")
     pq.add_argument("-q", "--query", default="")

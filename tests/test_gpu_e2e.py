@@ -174,6 +174,11 @@ def test_cli_index_and_query_reproduce_readme(tmp_path):
     for ext in ("", ".offset", ".lookup", ".type"):
         assert os.path.exists(pre + ext)
     assert os.path.getsize(pre) == 225674 and os.path.getsize(pre + ".offset") == 2611360
+    # chunked build (two structures per GPU call, sub-indices merged): byte-identical files
+    pre2 = str(tmp_path / "index" / "serine_chunked")
+    subprocess.check_call([sys.executable, "-m", "folddisco_amd", "index", "-p", "data/serine_peptidases", "-i", pre2, "--chunk", "2"], cwd=tmp_path, env=env)
+    for ext in ("", ".offset", ".lookup", ".type"):
+        assert open(pre + ext, "rb").read() == open(pre2 + ext, "rb").read(), ext
     out = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", pre, "--header"],
                          cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
     assert out[0] == "tid\tnode_count\tidf\trmsd\tmatching_residues\tquery_residues"
