@@ -313,3 +313,32 @@ def test_query_map_batch_equals_single(env):
         for f in ("hash", "qi", "qj", "is_primary", "idf", "indices", "aad_aa1", "aad_aa2", "aad_dist", "aad_qi"):
             assert getattr(g, f).tobytes() == getattr(w, f).tobytes(), f
     assert all(len(g.hash) > 0 for g in got) and len(got[2].hash) > len(got[0].hash)      # substitutions add hashes
+
+
+@pytest.mark.gpu
+def test_cli_batch_query_file(tmp_path):
+    """`query -q <file.txt>`: one query per line `pdb<TAB>residues<TAB>[output]` (the reference's query/*.txt, README.md:243-258)"""
+    import shutil
+    import subprocess
+    import sys
+    d = tmp_path / "data" / "serine_peptidases"
+    d.mkdir(parents=True)
+    for p in SER:
+        shutil.copy(p, d / os.path.basename(p))
+    (tmp_path / "query").mkdir()
+    shutil.copy(Q4CHA, tmp_path / "query" / "4CHA.pdb")
+    shutil.copy(Q1G2F, tmp_path / "query" / "1G2F.pdb")
+    here = os.path.dirname(os.path.abspath(__file__))
+    lines = [open(os.path.join(here, "golden", "query", f)).read().rstrip("\n") for f in ("serine_peptidase.txt", "zinc_finger_with_output.txt")]
+    (tmp_path / "batch.txt").write_text("\n".join(lines) + "\n")
+    root = os.path.dirname(here)
+    env = dict(os.environ, PYTHONPATH=root)
+    pre = str(tmp_path / "serine_folddisco")
+    subprocess.check_call([sys.executable, "-m", "folddisco_amd", "index", "-p", "data/serine_peptidases", "-i", pre], cwd=tmp_path, env=env)
+    out = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-q", "batch.txt", "-i", pre], cwd=tmp_path, env=env,
+                         capture_output=True, text=True, check=True).stdout.splitlines()
+    assert len(out) == 6 and out[0] == "data/serine_peptidases/4cha.pdb\t3\t8.7616\t0.0000\tB57,B102,C195\tB57,B102,C195"
+    zf = (tmp_path / "zinc_finger.folddisco.out.tsv").read_text().splitlines()     # no zinc finger among the serine peptidases
+    single = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", "query/1G2F.pdb", "-q", "F207,F212,F225,F229", "-i", pre],
+                            cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
+    assert zf == single
