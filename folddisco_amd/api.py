@@ -262,14 +262,15 @@ REC_DTYPE = np.dtype([("nid", np.uint32), ("total_match_count", np.uint32), ("no
 
 
 def count_query(ctx: Context, index: FolddiscoIndex, q_hash, q_node, q_edge_j, penalty: np.ndarray, total_structures: int | None = None,
-                freq_filter: float | None = None, as_array: bool = False):
+                freq_filter: float | None = None, as_array: bool = False, lengths: np.ndarray | None = None):
     """count_query (src/controller/count_query.rs:82-220) -> fd_count_rec rows in ascending nid
     (list of dicts, or a numpy structured array with as_array=True)."""
     q_hash = np.ascontiguousarray(q_hash, dtype=np.uint32)
     q_node = np.ascontiguousarray(q_node, dtype=np.uint32)
     q_edge_j = np.ascontiguousarray(q_edge_j, dtype=np.uint32)
     S = index.n_structures if total_structures is None else total_structures
-    lens = index.posting_lengths(q_hash)
+    # lengths: posting lengths over the WHOLE database when `index` is one shard of it (dist.global_posting_lengths)
+    lens = index.posting_lengths(q_hash) if lengths is None else np.asarray(lengths, np.uint64)
     keep = np.ones(len(q_hash), dtype=bool)
     if freq_filter is not None:
         keep &= ~((lens.astype(np.float32) / np.float32(S)) > np.float32(freq_filter))
@@ -290,7 +291,7 @@ def count_query(ctx: Context, index: FolddiscoIndex, q_hash, q_node, q_edge_j, p
 
 
 def count_query_batch(ctx: Context, index: FolddiscoIndex, queries, penalty: np.ndarray, total_structures: int | None = None,
-                      top_n: int = 0):
+                      top_n: int = 0, lengths_fn=None):
     """queries: list of (q_hash, q_node, q_edge_j) arrays.  One posting-length launch + one scoring pass for the whole
     batch.  Returns a list of REC_DTYPE arrays, one per query: every touched structure in ascending nid, or with top_n > 0
     only the records that can be among the top_n by idf (ties of the cut-off included, unordered; rank them with
@@ -300,6 +301,8 @@ def count_query_batch(ctx: Context, index: FolddiscoIndex, queries, penalty: np.
     qn = np.ascontiguousarray(np.concatenate([np.asarray(q[1], np.uint32) for q in queries]) if queries else np.zeros(0, np.uint32))
     qe = np.ascontiguousarray(np.concatenate([np.asarray(q[2], np.uint32) for q in queries]) if queries else np.zeros(0, np.uint32))
     lens_all = index.posting_lengths(qh)
+    if lengths_fn is not None:          # sharded index: local lengths -> lengths over the whole database (one all-reduce)
+        lens_all = lengths_fn(lens_all)
     idf = idf_of_lengths(lens_all, S).astype(np.float32)
     keep = lens_all > 0
     qid = np.repeat(np.arange(len(queries)), [len(q[0]) for q in queries])

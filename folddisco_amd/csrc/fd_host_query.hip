@@ -104,7 +104,7 @@ template <typename T> static T *dup_vec(const std::vector<T> &v) {
 
 extern "C" void fdgpu_query_map_free(fd_query_map *m) {
     if (!m) return;
-    free(m->hash); free(m->qi); free(m->qj); free(m->is_primary); free(m->idf); free(m->indices);
+    free(m->hash); free(m->qi); free(m->qj); free(m->is_primary); free(m->idf); free(m->indices); free(m->primary_hash);
     free(m->aad_aa1); free(m->aad_aa2); free(m->aad_dist); free(m->aad_qi);
     free(m);
 }
@@ -207,6 +207,9 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     if ((rc = fdgpu_hash_features(c, vf.data(), nc, p, hashes.data()))) return rc;
     // idf of every pair's observed (primary) hash: log2(S / len) (query.rs:17-32)
     std::vector<float> pair_idf(std::max<uint64_t>(np, 1), 0.0f);
+    std::vector<uint32_t> pair_primary(std::max<uint64_t>(np, 1), 0u);
+    for (uint64_t t = 0; t < nc; ++t)
+        if (cands[t].primary) pair_primary[cands[t].pair] = hashes[t];
     if (index) {
         std::vector<uint32_t> ph, pk;
         for (uint64_t t = 0; t < nc; ++t)
@@ -217,7 +220,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             pair_idf[pk[t]] = lens[t] > 0 ? log2f(total_structures / (float)lens[t]) : 0.0f;
     }
     for (uint64_t t = 0; t < n_queries; ++t) {
-        std::vector<uint32_t> mh, mqi, mqj;
+        std::vector<uint32_t> mh, mqi, mqj, mph;
         std::vector<uint8_t> mp;
         std::vector<float> mi;
         std::map<uint32_t, char> have;
@@ -225,12 +228,12 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             if (have.count(hashes[z])) continue;
             have[hashes[z]] = 1;
             mh.push_back(hashes[z]); mqi.push_back(cands[z].qi); mqj.push_back(cands[z].qj); mp.push_back(cands[z].primary);
-            mi.push_back(pair_idf[cands[z].pair]);
+            mi.push_back(pair_idf[cands[z].pair]); mph.push_back(pair_primary[cands[z].pair]);
         }
         fd_query_map *m = (fd_query_map *)calloc(1, sizeof *m);
         if (!m) { for (uint64_t u = 0; u < t; ++u) { fdgpu_query_map_free(out[u]); out[u] = nullptr; } return FDGPU_ENOMEM; }
         m->n = mh.size();
-        m->hash = dup_vec(mh); m->qi = dup_vec(mqi); m->qj = dup_vec(mqj); m->is_primary = dup_vec(mp); m->idf = dup_vec(mi);
+        m->hash = dup_vec(mh); m->qi = dup_vec(mqi); m->qj = dup_vec(mqj); m->is_primary = dup_vec(mp); m->idf = dup_vec(mi); m->primary_hash = dup_vec(mph);
         std::vector<uint32_t> idx(q_index + q_off[t], q_index + q_off[t + 1]);
         m->n_indices = idx.size(); m->indices = dup_vec(idx);
         const Aad &A = aads[t];

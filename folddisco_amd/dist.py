@@ -68,3 +68,54 @@ def allgather_hits(local: np.ndarray, device: torch.device, top_n: int | None = 
     dist.all_gather(out, t)
     parts = [o.cpu().numpy().view(REC_DTYPE)[:s] for o, s in zip(out, sizes)]
     return rank_hits(np.concatenate(parts), top_n)
+
+
+def reduce_lengths(lens: np.ndarray, device: torch.device | None = None) -> np.ndarray:
+    """posting lengths of one shard -> posting lengths over all shards (all-reduce SUM; identity without a process group).
+    idf = log2(S / len) must see the whole database, or the sharded hit list differs from the single-index one."""
+    lens = np.asarray(lens, np.uint64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return lens
+    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    t = torch.from_numpy(lens.astype(np.int64)).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy().astype(np.uint64)
+
+
+def global_posting_lengths(index, hashes, device: torch.device | None = None) -> np.ndarray:
+    return reduce_lengths(index.posting_lengths(np.ascontiguousarray(hashes, np.uint32)), device)
+
+
+def sharded_query(ctx, shard_index, lo: int, db_shard, qbatch, q_indices, subs, penalty_shard, total_structures: int, device=None,
+                  top_n: int | None = None, resname_std_shard=None, ca_distance=1.0, dist_thr=(0.5,), angle_thr=(5.0,), retrieve_matches=True):
+    """One motif query against an index sharded by structure id: this rank holds the postings and coordinates of
+    structures [lo, lo + shard_index.n_structures).  Scoring is local with idf from GLOBAL posting lengths (one all-reduce),
+    the candidate records are all-gathered and ranked (idf descending, nid ascending, top_n), every candidate is matched on
+    the rank that owns it and the match lists are all-gathered.  Returns (records, matches) — identical on every rank and to
+    the single-index query.  matches: dicts of query.retrieve() with the global structure id under "nid"."""
+    from .api import count_query, idf_of_lengths
+    from .query import make_query_map, retrieve
+    S = int(total_structures)
+    qm = make_query_map(ctx, qbatch, q_indices, subs, None, float(S), dist_thr, angle_thr)
+    lens = global_posting_lengths(shard_index, qm.hash, device)
+    pl = global_posting_lengths(shard_index, qm.primary_hash, device)
+    qm.set_idf(np.where(pl > 0, idf_of_lengths(np.maximum(pl, 1), S), 0.0).astype(np.float32))
+    local = count_query(ctx, shard_index, qm.hash, qm.qi, qm.qj, penalty_shard, total_structures=S, as_array=True, lengths=lens)
+    recs = allgather_hits(local, device if device is not None else torch.device("cpu"), top_n=top_n)
+    matches = []
+    if retrieve_matches:
+        n_local = shard_index.n_structures
+        mine = [int(n) for n in recs["nid"] if lo <= int(n) < lo + n_local]
+        got = []
+        if mine:
+            cand = np.array([n - lo for n in mine], np.uint32)
+            for m in retrieve(ctx, db_shard, resname_std_shard, cand, qm, qbatch, ca_distance):
+                m = dict(m, nid=mine[m["cand"]])
+                got.append(m)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            box = [None] * dist.get_world_size()
+            dist.all_gather_object(box, got)
+            got = [m for part in box for m in part]
+        order = {int(n): k for k, n in enumerate(recs["nid"])}      # candidate order of the global ranking, components in order
+        matches = sorted(got, key=lambda m: order[m["nid"]])
+    return recs, matches

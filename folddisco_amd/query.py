@@ -68,8 +68,17 @@ class QueryMapResult:
     aad_aa2: np.ndarray
     aad_dist: np.ndarray
     aad_qi: np.ndarray
+    primary_hash: np.ndarray = None
     handle: object = field(default=None, repr=False)
     ctx: Context = field(default=None, repr=False)
+
+    def set_idf(self, idf: np.ndarray):
+        """overwrite the per-entry idf (also inside the C struct fdgpu_retrieve reads): a caller that shards the index computes it
+        from GLOBAL posting lengths of primary_hash (dist.global_posting_lengths)"""
+        idf = np.ascontiguousarray(idf, np.float32)
+        assert len(idf) == len(self.hash)
+        C.memmove(self.handle.contents.idf, idf.ctypes.data, idf.nbytes)
+        self.idf = idf.copy()
 
     def __del__(self):
         try:
@@ -105,11 +114,7 @@ def make_query_map(ctx: Context, qbatch: Batch, q_indices, subs=None, index: Fol
     ctx.check(ctx.L.fdgpu_make_query_map(ctx.h, qbatch.h, qi.ctypes.data_as(u32p), n, sub_ptrs, n_subs.ctypes.data_as(u32p),
                                          d.ctypes.data_as(f32p), len(d), a.ctypes.data_as(f32p), len(a), C.byref(p),
                                          index.h if index is not None else None, total_structures, C.byref(out)))
-    m = out.contents
-    return QueryMapResult(_arr(m.hash, m.n, np.uint32), _arr(m.qi, m.n, np.uint32), _arr(m.qj, m.n, np.uint32),
-                          _arr(m.is_primary, m.n, np.uint8), _arr(m.idf, m.n, np.float32), _arr(m.indices, m.n_indices, np.uint32),
-                          _arr(m.aad_aa1, m.n_aad, np.uint8), _arr(m.aad_aa2, m.n_aad, np.uint8), _arr(m.aad_dist, m.n_aad, np.float32),
-                          _arr(m.aad_qi, m.n_aad, np.uint32), handle=out, ctx=ctx)
+    return _wrap_query_map(ctx, out)
 
 
 def _wrap_query_map(ctx, out) -> QueryMapResult:
@@ -117,7 +122,7 @@ def _wrap_query_map(ctx, out) -> QueryMapResult:
     return QueryMapResult(_arr(m.hash, m.n, np.uint32), _arr(m.qi, m.n, np.uint32), _arr(m.qj, m.n, np.uint32),
                           _arr(m.is_primary, m.n, np.uint8), _arr(m.idf, m.n, np.float32), _arr(m.indices, m.n_indices, np.uint32),
                           _arr(m.aad_aa1, m.n_aad, np.uint8), _arr(m.aad_aa2, m.n_aad, np.uint8), _arr(m.aad_dist, m.n_aad, np.float32),
-                          _arr(m.aad_qi, m.n_aad, np.uint32), handle=out, ctx=ctx)
+                          _arr(m.aad_qi, m.n_aad, np.uint32), _arr(m.primary_hash, m.n, np.uint32), handle=out, ctx=ctx)
 
 
 def make_query_maps(ctx: Context, qbatch: Batch, queries, index: FolddiscoIndex | None = None, total_structures: float = 0.0,

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import dist as fdist
-from .api import PackedStructures, count_query, count_query_batch, length_penalty
+from .api import PackedStructures, count_query, count_query_batch, idf_of_lengths, length_penalty
 from .query import make_query_map, make_query_maps, retrieve
 
 
@@ -49,13 +49,18 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     nres = np.diff(d["res_off"].cpu().numpy()).astype(np.uint64)
     pen = length_penalty(nres, 0.5)
     S_total = S * world
+    sharded = dist is not None          # every rank holds the postings of its own structures only
     qbatches = [ctx.upload(PackedStructures.concat([it])) for _, _, it in queries]
     qall = ctx.upload(PackedStructures.concat([it for _, _, it in queries]))    # every query structure in one batch (batched legs)
 
     def one(k, match):
         s, idx, _ = queries[k]
-        qm = make_query_map(ctx, qbatches[k], idx, None, ix, float(S_total))
-        recs = count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total, as_array=True)
+        qm = make_query_map(ctx, qbatches[k], idx, None, None if sharded else ix, float(S_total))
+        lens = fdist.global_posting_lengths(ix, qm.hash, dev) if sharded else None      # idf over the whole database
+        if sharded and match:
+            pl = fdist.global_posting_lengths(ix, qm.primary_hash, dev)
+            qm.set_idf(np.where(pl > 0, idf_of_lengths(np.maximum(pl, 1), S_total), 0.0).astype(np.float32))
+        recs = count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total, as_array=True, lengths=lens)
         glob = fdist.allgather_hits(recs, dev, top_n=top_n)
         n_match = 0
         if match and len(recs):
@@ -93,8 +98,13 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             tot = 0
             for c0 in range(0, len(queries), chunk):
                 ks = range(c0, min(c0 + chunk, len(queries)))
-                qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix if match else None, float(S_total))
-                recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=top_n)
+                qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix if (match and not sharded) else None, float(S_total))
+                if match and sharded:
+                    for qm in qms:
+                        pl = fdist.global_posting_lengths(ix, qm.primary_hash, dev)
+                        qm.set_idf(np.where(pl > 0, idf_of_lengths(np.maximum(pl, 1), S_total), 0.0).astype(np.float32))
+                recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=top_n,
+                                         lengths_fn=(lambda l: fdist.reduce_lengths(l, dev)) if sharded else None)
                 for k, qm, r in zip(ks, qms, recs):
                     n = len(fdist.allgather_hits(r, dev, top_n=top_n))
                     if match and len(r):

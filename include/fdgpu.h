@@ -184,6 +184,8 @@ typedef struct fd_query_map {   /* make_query_map output (src/controller/query.r
     uint32_t *hash; uint32_t *qi; uint32_t *qj; uint8_t *is_primary; float *idf;
     uint64_t n_indices; uint32_t *indices;                 /* all_query_indices */
     uint64_t n_aad; uint8_t *aad_aa1; uint8_t *aad_aa2; float *aad_dist; uint32_t *aad_qi;   /* observed_distance_map */
+    uint32_t *primary_hash;     /* [n] observed hash of the residue pair entry k belongs to: idf[k] = log2(S / posting length of it)
+                                 * — lets a caller that shards the index recompute idf from GLOBAL posting lengths */
 } fd_query_map;
 /* qb = batch holding the query structure as structure 0; q_index[k] = residue index of the k-th query
  * residue (after parse_query_string + get_index / --serial-index resolution on the caller's side);

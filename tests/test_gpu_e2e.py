@@ -342,3 +342,18 @@ def test_cli_batch_query_file(tmp_path):
     single = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", "query/1G2F.pdb", "-q", "F207,F212,F225,F229", "-i", pre],
                             cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
     assert zf == single
+
+
+@pytest.mark.gpu
+def test_sharded_query_equals_single_index():
+    """SURVEY §8e through the product path: two ranks (gloo, one GPU), index and coordinates sharded by structure id, idf from
+    all-reduced posting lengths, all-gather of candidate records and of the matches found on the owning rank — records
+    byte-identical and matches identical to the single-index query (tests/shard_query_worker.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29733", os.path.join(root, "tests", "shard_query_worker.py")],
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    assert "SHARDED_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("QUERY") == 3 and "DIFFERENT" not in out.stdout
