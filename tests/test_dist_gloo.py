@@ -33,6 +33,10 @@ def _worker(rank, world, port, q):
     # empty shard contribution
     e = fdist.allgather_hits(local[:0] if rank == 1 else local, torch.device("cpu"), top_n=5)
     ok = ok and len(e) == min(5, int(touched[: fdist.shard_range(0, world, S)[1]].sum()))
+    # posting lengths of the shards add up to the lengths over the whole database (the idf denominator of a sharded query)
+    per_rank = [np.array([3, 0, 7, 2 ** 33], np.uint64), np.array([1, 0, 0, 5], np.uint64)]
+    tot = fdist.reduce_lengths(per_rank[rank])
+    ok = ok and tot.dtype == np.uint64 and tot.tolist() == [4, 0, 7, 2 ** 33 + 5]
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
