@@ -24,13 +24,44 @@ def _load_paths(d: str, recursive: bool):
     return sorted(out)
 
 
+def _init_dist(a):
+    """torchrun / torch.distributed.run launch: one rank per GPU (backend nccl = RCCL; FD_BENCH_BACKEND=gloo puts several ranks on one
+    GPU for plumbing tests).  -> (rank, world, torch device or None)"""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1, None
+    import torch
+    import torch.distributed as dist
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("FD_BENCH_BACKEND", "nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    a.device = local
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, torch.device("cuda", local)
+
+
+def _shard_prefix(prefix, rank, world):
+    return f"{prefix}.shard{rank}of{world}"
+
+
 def cmd_index(a):
     import folddisco_amd as fd
     from folddisco_amd import indexio, structure
-    paths = _load_paths(a.pdbs, a.recursive)
-    if not paths:
+    rank, world, _dev = _init_dist(a)
+    all_paths = _load_paths(a.pdbs, a.recursive)
+    if not all_paths:
         sys.exit(f"[FAIL] no structures under {a.pdbs}")
     prefix = a.index or (a.pdbs.rstrip("/") + "_folddisco")
+    if world > 1:
+        return _cmd_index_sharded(a, fd, indexio, structure, all_paths, prefix, rank, world)
+    paths = all_paths
     ctx = fd.Context(a.device)
     # Chunks of --chunk structures (the reference walks T*128-structure chunks, controller/mod.rs:289-294): ingest (native,
     # multi-threaded; a structure above --max-residue keeps its id but has no hashes, nres 0 and plddt 0,
@@ -67,16 +98,78 @@ def cmd_index(a):
         print(f"[DONE] {len(paths)} structures, {n_hashes} hashes, {value_len} value bytes -> {prefix}", file=sys.stderr)
 
 
+def _build_chunks(a, fd, structure, ctx, paths, first_id):
+    """chunked GPU builds of paths (ids first_id ...) -> (sub-index parts, nres, plddt)"""
+    nres_all, plddt_all, parts = [], [], []
+    for c0 in range(0, len(paths), a.chunk):
+        chunk = paths[c0:c0 + a.chunk]
+        structs, ok = structure.read_compact_structures(chunk, threads=a.threads, max_residue=a.max_residue)
+        for p, s, good in zip(chunk, structs, ok):
+            if not good:
+                print(f"[WARN] {p} could not be read. Skipping", file=sys.stderr)
+            elif s.num_residues_raw > a.max_residue > 0:
+                print(f"[WARN] {p} has too many residues. Skipping", file=sys.stderr)
+        nres_all.append(np.array([s.n for s in structs], np.uint64))
+        plddt_all.append(np.array([s.avg_plddt() if s.n else 0.0 for s in structs], np.float32))
+        batch = ctx.upload(fd.PackedStructures.concat([s.as_item() for s in structs]))
+        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id + c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid)
+        parts.append(ix.export())
+        del ix, batch
+    z = lambda dt: np.zeros(0, dt)
+    return parts, (np.concatenate(nres_all) if nres_all else z(np.uint64)), (np.concatenate(plddt_all) if plddt_all else z(np.float32))
+
+
+def _cmd_index_sharded(a, fd, indexio, structure, paths, prefix, rank, world):
+    """Index build sharded by structure (SURVEY §8e): rank r indexes the contiguous id range shard_range(r), no data-path collective;
+    the shards stay on disk (PREFIX.shard<r>of<W>, used by the sharded query) and rank 0 concatenates them per hash into the
+    reference's single PREFIX / PREFIX.offset."""
+    import torch.distributed as dist
+    from folddisco_amd import dist as fdist
+    lo, hi = fdist.shard_range(rank, world, len(paths))
+    ctx = fd.Context(a.device)
+    parts, nres, plddt = _build_chunks(a, fd, structure, ctx, paths[lo:hi], lo)
+    v, h, o = indexio.merge_subindices(parts) if len(parts) > 1 else (parts[0] if parts else (np.zeros(0, np.uint8), np.zeros(0, np.uint32), np.zeros(1, np.uint64)))
+    indexio.write_index_files(_shard_prefix(prefix, rank, world), v, h, o)
+    box = [None] * world
+    dist.all_gather_object(box, (nres, plddt))
+    dist.barrier()
+    if rank == 0:
+        shards = [indexio.read_index_files(_shard_prefix(prefix, r, world)) for r in range(world)]
+        mv, mh, mo = indexio.merge_subindices(shards)
+        indexio.write_index_files(prefix, mv, mh, mo)
+        indexio.save_lookup(prefix + ".lookup", paths, np.concatenate([b[0] for b in box]), np.concatenate([b[1] for b in box]))
+        indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance)
+        if a.verbose:
+            print(f"[DONE] {len(paths)} structures over {world} ranks, {len(mh)} hashes, {len(mv)} value bytes -> {prefix}", file=sys.stderr)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def cmd_query(a):
     import folddisco_amd as fd
     from folddisco_amd import indexio, query, structure
     if not a.index:
         sys.exit("[FAIL] -i/--index is required")
+    rank, world, dev = _init_dist(a)
     ctx = fd.Context(a.device)
-    v, h, o = indexio.read_index_files(a.index)
     tids, nres, plddt, _ = indexio.load_lookup(a.index + ".lookup")
     cfg = indexio.load_type(a.index + ".type")
-    ix = fd.FolddiscoIndex.load(ctx, h, o, v, len(tids))
+    shard = None
+    lo, hi = 0, len(tids)
+    if world > 1:
+        # query sharded by structure id: this rank loads its shard of the index (written by the multi-rank index build) and the
+        # coordinates of its own structures; ids in the shard are absolute, so it is loaded over the whole id range
+        from folddisco_amd import dist as fdist
+        sp = _shard_prefix(a.index, rank, world)
+        if not os.path.exists(sp + ".offset"):
+            sys.exit(f"[FAIL] {sp}.offset not found: build the index with the same number of ranks")
+        lo, hi = fdist.shard_range(rank, world, len(tids))
+        v, h, o = indexio.read_index_files(sp)
+        ix = fd.FolddiscoIndex.load(ctx, h, o, v, len(tids))
+        shard = dict(lo=lo, n_local=hi - lo, device=dev if os.environ.get("FD_BENCH_BACKEND", "nccl") == "nccl" else None, absolute=True)
+    else:
+        v, h, o = indexio.read_index_files(a.index)
+        ix = fd.FolddiscoIndex.load(ctx, h, o, v, len(tids))
     if a.query.endswith((".txt", ".tsv")):
         queries = []
         for line in open(a.query):
@@ -92,7 +185,7 @@ def cmd_query(a):
         return cand if os.path.isfile(cand) else t
     db_structs, batch = None, None
     if not a.skip_match:
-        db_structs, _ = structure.read_compact_structures([resolve(t) for t in tids], threads=a.threads)
+        db_structs, _ = structure.read_compact_structures([resolve(t) for t in tids[lo:hi]], threads=a.threads)
         batch = ctx.upload(fd.PackedStructures.concat([s.as_item() for s in db_structs]))
     dthr = [float(x) for x in a.distance.replace(" ", "").split(",") if x]
     athr = [float(x) for x in a.angle.replace(" ", "").split(",") if x]
@@ -108,7 +201,10 @@ def cmd_query(a):
                                                      max_node=a.max_node, max_node_ratio=a.max_node_ratio, score=a.score,
                                                      connected_node=a.connected_node, connected_node_ratio=a.connected_node_ratio,
                                                      num_residue=a.num_residue, plddt=a.plddt, rmsd=a.rmsd, tm_score=a.tm_score,
-                                                     gdt_ts=a.gdt_ts, gdt_ha=a.gdt_ha, chamfer=a.chamfer, hausdorff=a.hausdorff))
+                                                     gdt_ts=a.gdt_ts, gdt_ha=a.gdt_ha, chamfer=a.chamfer, hausdorff=a.hausdorff),
+                                        shard=shard)
+        if rank != 0:
+            continue                      # every rank holds the same result; rank 0 prints
         fh = open(outp, "w") if outp else sys.stdout
         if a.skip_match or a.per_structure:
             if a.header:
@@ -127,6 +223,10 @@ def cmd_query(a):
                 fh.write(query.format_match_columns(m, cols) + "\n")
         if outp:
             fh.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main(argv=None):

@@ -257,8 +257,12 @@ def sample_query_hashes(index: FolddiscoIndex, q_hash, sampling_ratio=None, samp
 def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[CompactStructure], tids: list[str], nres, plddt,
               query: CompactStructure, query_string: str, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance=1.0, top_n=None,
               length_penalty_power=0.5, skip_match=False, serial_query=False, freq_filter=None, dist_cutoff=20.0, nbin_dist=0, nbin_angle=0,
-              sampling_ratio=None, sampling_count=None, filters=None, sort_by=""):
-    """The per-query body of query_pdb (src/cli/workflows/query_pdb.rs:348-519).  `filters`: the reference's filtering options
+              sampling_ratio=None, sampling_count=None, filters=None, sort_by="", shard=None):
+    """The per-query body of query_pdb (src/cli/workflows/query_pdb.rs:348-519).  shard = dict(lo=first structure id, device=torch
+    device or None): `index`, `db` and `db_structs` then cover only structures [lo, lo + len(db_structs)) of the database that
+    tids / nres / plddt describe: idf comes from all-reduced posting lengths, the touched-structure records and the
+    matches found on the owning rank are all-gathered, every rank returns the same result as the single-index call.
+    `filters`: the reference's filtering options
     (total_match, covered_node, covered_node_ratio, max_node, max_node_ratio, score, connected_node, connected_node_ratio,
     num_residue, plddt, rmsd; 0 / absent = off), applied as StructureFilter before / after matching and MatchFilter
     (controller/filter.rs:76-131, 194-235).  Returns (structure rows, match rows) as lists of dicts."""
@@ -277,11 +281,37 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
         idx = [query.get_index(int(query.chain[k]), int(query.serial[k])) for k in range(query.n)]
         subs = [None] * len(idx)
     qbatch = ctx.upload(PackedStructures.concat([query.as_item()]))
-    qm = make_query_map(ctx, qbatch, idx, subs, index, float(S), dist_thr, angle_thr, nbin_dist=nbin_dist, nbin_angle=nbin_angle,
-                        dist_cutoff=dist_cutoff)
     pen = length_penalty(nres, length_penalty_power)
-    keep = sample_query_hashes(index, qm.hash, sampling_ratio, sampling_count)
-    rows = count_query(ctx, index, qm.hash[keep], qm.qi[keep], qm.qj[keep], pen, total_structures=S, freq_filter=freq_filter)
+    if shard is None:
+        lo, n_local = 0, S
+        qm = make_query_map(ctx, qbatch, idx, subs, index, float(S), dist_thr, angle_thr, nbin_dist=nbin_dist, nbin_angle=nbin_angle,
+                            dist_cutoff=dist_cutoff)
+        keep = sample_query_hashes(index, qm.hash, sampling_ratio, sampling_count)
+        rows = count_query(ctx, index, qm.hash[keep], qm.qi[keep], qm.qj[keep], pen, total_structures=S, freq_filter=freq_filter)
+    else:
+        from . import dist as fdist
+        from .api import idf_of_lengths
+        # absolute: the shard index was loaded over the whole id range (fdgpu_index_load of a shard file) and takes the full
+        # penalty vector; otherwise it was built in place with first_id = lo and covers n_local structures
+        lo, dev = int(shard["lo"]), shard.get("device")
+        n_local = int(shard.get("n_local", len(db_structs) if db_structs is not None else index.n_structures))
+        qm = make_query_map(ctx, qbatch, idx, subs, None, float(S), dist_thr, angle_thr, nbin_dist=nbin_dist, nbin_angle=nbin_angle,
+                            dist_cutoff=dist_cutoff)
+        pl = fdist.global_posting_lengths(index, qm.primary_hash, dev)
+        qm.set_idf(np.where(pl > 0, idf_of_lengths(np.maximum(pl, 1), S), 0.0).astype(np.float32))
+        lens = fdist.global_posting_lengths(index, qm.hash, dev)
+        order = np.argsort(lens, kind="stable")                    # sample_query on the global lengths
+        if (sampling_ratio is None) == (sampling_count is None):
+            keep = np.arange(len(lens))
+        else:
+            k = int(np.ceil(np.float32(sampling_ratio) * np.float32(len(lens)))) if sampling_ratio is not None else int(sampling_count)
+            keep = order[: max(0, min(k, len(lens)))]
+        local = count_query(ctx, index, qm.hash[keep], qm.qi[keep], qm.qj[keep], pen if shard.get("absolute") else pen[lo:lo + n_local], total_structures=S,
+                            freq_filter=freq_filter, as_array=True, lengths=lens[keep])
+        allrec = fdist.allgather_hits(local, dev if dev is not None else "cpu")
+        allrec = allrec[np.argsort(allrec["nid"], kind="stable")]  # the single-index call starts from ascending nid
+        rows = [dict(nid=int(r["nid"]), total_match_count=int(r["total_match_count"]), node_count=int(r["node_count"]),
+                     edge_count=int(r["edge_count"]), idf=float(r["idf"])) for r in allrec]
     n_expected = np.float32(len(idx))   # residue_count: number of query residues (query_pdb.rs:384-389)
     for r in rows:
         r.update(tid=tids[r["nid"]], nres=int(nres[r["nid"]]), plddt=float(plddt[r["nid"]]), db_key=r["nid"], matches=[],
@@ -302,13 +332,23 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
         rows = rows[:top_n]
     match_rows = []
     if not skip_match and rows:
-        std = np.concatenate([s.resname_std() for s in db_structs])
-        cand = np.array([r["nid"] for r in rows], np.uint32)
-        ms = retrieve(ctx, db, std, cand, qm, qbatch, ca_distance, nbin_dist=nbin_dist, nbin_angle=nbin_angle, dist_cutoff=dist_cutoff)
+        std = np.concatenate([s.resname_std() for s in db_structs]) if db_structs else np.zeros(0, np.uint8)
+        owned = [k for k, r in enumerate(rows) if lo <= r["nid"] < lo + n_local]       # candidates this rank holds coordinates of
+        cand = np.array([rows[k]["nid"] - lo for k in owned], np.uint32)
+        ms = retrieve(ctx, db, std, cand, qm, qbatch, ca_distance, nbin_dist=nbin_dist, nbin_angle=nbin_angle, dist_cutoff=dist_cutoff) if len(cand) else []
+        for m in ms:
+            m["cand"] = owned[m["cand"]]                                                 # -> position in `rows`
+            t = db_structs[rows[m["cand"]]["nid"] - lo]
+            m["labels"] = ["_" if x < 0 else f"{chr(int(t.chain[x]))}{int(t.serial[x])}" for x in m["processed"]]
+        if shard is not None:
+            import torch.distributed as tdist
+            if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+                box = [None] * tdist.get_world_size()
+                tdist.all_gather_object(box, ms)
+                ms = sorted((m for part in box for m in part), key=lambda m: m["cand"])   # stable: components keep their order
         for m in ms:
             r = rows[m["cand"]]
-            t = db_structs[r["nid"]]
-            lab = lambda lst: ["_" if x < 0 else f"{chr(int(t.chain[x]))}{int(t.serial[x])}" for x in lst]
+            lab = lambda lst: m["labels"]
             r.setdefault("match_strs", []).append(",".join(lab(m["processed"])) + ":%.4f" % m["rmsd"])
             m2 = dict(tid=r["tid"], nid=r["nid"], node_count=sum(x >= 0 for x in m["processed"]), idf=m["idf"], rmsd=m["rmsd"],
                       matching_residues=",".join(lab(m["processed"])), query_residues=res_chain_to_string(qres) if qres else query_string,

@@ -357,3 +357,34 @@ def test_sharded_query_equals_single_index():
                          cwd=root, capture_output=True, text=True, timeout=600)
     assert "SHARDED_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("QUERY") == 3 and "DIFFERENT" not in out.stdout
+
+
+@pytest.mark.gpu
+def test_cli_two_ranks_sharded_index_and_query(tmp_path):
+    """`torch.distributed.run --nproc-per-node 2 -m folddisco_amd index|query` (gloo, both ranks on one GPU): the index build is
+    sharded by structure, rank 0 merges the shards into the reference's single index (byte-identical to the one-rank build);
+    the query runs against the shards (all-reduced posting lengths, all-gathered candidates and matches) and prints what the
+    one-rank query prints."""
+    import shutil
+    import subprocess
+    import sys
+    d = tmp_path / "data" / "serine_peptidases"
+    d.mkdir(parents=True)
+    for p in SER:
+        shutil.copy(p, d / os.path.basename(p))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, FD_BENCH_BACKEND="gloo")
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    subprocess.check_call([sys.executable, "-m", "folddisco_amd", "index", "-p", "data/serine_peptidases", "-i", one], cwd=tmp_path, env=env)
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29744",
+              "-m", "folddisco_amd"]
+    subprocess.run(launch + ["index", "-p", "data/serine_peptidases", "-i", two], cwd=tmp_path, env=env, check=True, capture_output=True, timeout=600)
+    for ext in ("", ".offset", ".lookup", ".type"):
+        assert open(one + ext, "rb").read() == open(two + ext, "rb").read(), ext
+    assert os.path.exists(two + ".shard0of2.offset") and os.path.exists(two + ".shard1of2.offset")
+    for extra in ([], ["--per-structure"], ["--rmsd", "0.5", "--sort-by", "idf"]):
+        q = ["query", "-p", Q4CHA, "-q", "B57,B102,C195"] + extra
+        want = subprocess.run([sys.executable, "-m", "folddisco_amd"] + q + ["-i", one], cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout
+        got = subprocess.run(launch + q + ["-i", two], cwd=tmp_path, env=env, capture_output=True, text=True, check=True, timeout=600).stdout
+        rows = [l for l in got.splitlines() if l.startswith("data/")]
+        assert rows == want.splitlines() and len(rows) >= 2, (extra, got[-2000:])
