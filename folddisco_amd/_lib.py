@@ -88,6 +88,7 @@ SYMBOLS = [
     ("fdgpu_spec_fallbacks", C.c_int, [VP, u64p]),
     ("fdgpu_parse_structures", C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(Parsed))]),
     ("fdgpu_parsed_free", None, [C.POINTER(Parsed)]),
+    ("fdgpu_get_entries", C.c_int, [VP, VP, u32p, C.c_uint64, C.POINTER(u32p), C.POINTER(u64p)]),
     ("fdgpu_count_query_batch_top", C.c_int, [VP, VP, C.c_uint64, u64p, u32p, u32p, u32p, f32p, f32p, C.c_uint32, C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
     ("fdgpu_match_pairs", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(MatchQuery), C.POINTER(HashParams),
                                     C.POINTER(C.POINTER(PairRec)), u64p, C.POINTER(C.POINTER(CandRec)), u64p]),

@@ -227,6 +227,18 @@ class FolddiscoIndex:
     def save(self, prefix: str):
         self.ctx.check(self.ctx.L.fdgpu_index_save(self.ctx.h, self.h, prefix.encode()))
 
+    def get_entries(self, q_hash) -> list:
+        """decoded posting lists (ascending structure ids) of the given hashes (get_entries, index/indextable.rs:83-86)"""
+        q = np.ascontiguousarray(q_hash, dtype=np.uint32)
+        ip, op = u32p(), u64p()
+        self.ctx.check(self.ctx.L.fdgpu_get_entries(self.ctx.h, self.h, _ptr(q, u32p), len(q), C.byref(ip), C.byref(op)))
+        off = np.ctypeslib.as_array(op, shape=(len(q) + 1,)).copy()
+        n = int(off[-1])
+        ids = np.ctypeslib.as_array(ip, shape=(max(n, 1),))[:n].copy()
+        self.ctx.L.fdgpu_free(ip)
+        self.ctx.L.fdgpu_free(op)
+        return [ids[int(off[k]): int(off[k + 1])] for k in range(len(q))]
+
     def posting_lengths(self, q_hash: np.ndarray) -> np.ndarray:
         q = np.ascontiguousarray(q_hash, dtype=np.uint32)
         out = np.zeros(len(q), dtype=np.uint64)

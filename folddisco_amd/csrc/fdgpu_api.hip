@@ -540,6 +540,39 @@ extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const 
     return FDGPU_OK;
 }
 
+// get_entries for many hashes: ids of hash k = (*ids)[(*ids_off)[k] .. (*ids_off)[k+1])
+extern "C" int fdgpu_get_entries(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint32_t **ids, uint64_t **ids_off) {
+    if (!c || !ix || !ids || !ids_off || (nq && !q_hash)) return FDGPU_EINVAL;
+    *ids = nullptr; *ids_off = nullptr;
+    uint64_t *off = (uint64_t *)calloc(nq + 1, 8);
+    if (!off) return FDGPU_ENOMEM;
+    std::vector<uint64_t> lens(std::max<uint64_t>(nq, 1));
+    int rc = fdgpu_posting_lengths(c, ix, q_hash, nq, lens.data());
+    if (rc) { free(off); return rc; }
+    for (uint64_t k = 0; k < nq; ++k) off[k + 1] = off[k] + lens[k];
+    const uint64_t tot = off[nq];
+    uint32_t *out = (uint32_t *)malloc(std::max<uint64_t>(tot, 1) * 4);
+    if (!out) { free(off); return FDGPU_ENOMEM; }
+    if (tot) {
+        hipStream_t st = c->stream;
+        hipError_t e = c->ws[WS_MISC0].ensure(nq * 4);
+        if (e == hipSuccess) e = c->ws[WS_MISC1].ensure((nq + 1) * 8);
+        if (e == hipSuccess) e = c->ws[WS_MISC2].ensure(tot * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->ws[WS_MISC1].p, off, (nq + 1) * 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            fd_launch_get_entries(ix->hashes, ix->offsets, ix->value, ix->n_hashes, c->ws[WS_MISC0].as<uint32_t>(), nq, c->ws[WS_MISC1].as<uint64_t>(),
+                                  c->ws[WS_MISC2].as<uint32_t>(), st);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out, c->ws[WS_MISC2].p, tot * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { free(off); free(out); c->err = std::string("get_entries: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+    }
+    *ids = out; *ids_off = off;
+    return FDGPU_OK;
+}
+
 extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j,
                                  const float *q_idf, uint64_t nq, const float *penalty, fd_count_rec **out, uint64_t *n_out) {
     if (!c || !ix || !out || !n_out || (nq && (!q_hash || !q_node || !q_edge_j || !q_idf)) || (ix->n_structures && !penalty)) return FDGPU_EINVAL;

@@ -46,6 +46,61 @@ __global__ __launch_bounds__(FD_WAVE) void k_posting_lengths(const uint32_t *__r
 }
 
 
+// get_entries (src/index/indextable.rs:83-86, 439-463): posting list of every query hash decoded to structure ids.
+// Same wave-parallel varint decode as the scoring kernel; ids go to out[out_off[q] ...] in list order.
+__global__ __launch_bounds__(FD_WAVE) void k_get_entries(const uint32_t *__restrict__ hashes, const uint64_t *__restrict__ offsets,
+                                                         const uint8_t *__restrict__ value, uint64_t H, const uint32_t *__restrict__ q_hash,
+                                                         uint64_t nq, const uint64_t *__restrict__ out_off, uint32_t *__restrict__ out) {
+    uint64_t q = blockIdx.x;
+    if (q >= nq) return;
+    int64_t k = find_hash(hashes, H, q_hash[q]);
+    if (k < 0) return;
+    const uint64_t b0 = offsets[k], b1 = offsets[k + 1];
+    const uint32_t lane = threadIdx.x;
+    uint32_t *dst = out + out_off[q];
+    uint64_t n_done = 0;        // ids written so far (wave-uniform)
+    uint32_t run_id = 0, carry_val = 0, carry_shift = 0;
+    bool have_first = false;
+    for (uint64_t base = b0; base < b1; base += FD_WAVE) {
+        uint64_t p = base + lane;
+        bool in = p < b1;
+        uint32_t byte = in ? value[p] : 0x80u;
+        bool term = in && !(byte & 0x80u);
+        uint64_t tm = __ballot(term);
+        uint64_t below = tm & ((1ull << lane) - 1ull);
+        int prev_t = below ? 63 - __clzll(below) : -1;
+        uint32_t len_here = lane - (uint32_t)(prev_t + 1) + 1;
+        uint32_t v = 0, pay = byte & 0x7fu;
+#pragma unroll
+        for (int back = 4; back >= 0; --back) {
+            uint32_t pb = __shfl(pay, (int)lane - back, FD_WAVE);
+            if ((uint32_t)back < len_here) v |= pb << (7u * (len_here - 1u - (uint32_t)back));
+        }
+        if (term && prev_t < 0) v = carry_val | (v << carry_shift);
+        uint32_t s2 = term ? v : 0u;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(s2, off, FD_WAVE);
+            if ((int)lane >= off) s2 += t;
+        }
+        uint32_t id = (have_first ? run_id : 0u) + s2;
+        if (term) dst[n_done + (uint32_t)__popcll(below)] = id;
+        if (tm) {
+            int last_t = 63 - __clzll(tm);
+            run_id = __shfl(id, last_t, FD_WAVE);
+            have_first = true;
+            n_done += (uint64_t)__popcll(tm);
+            uint32_t tail = 63u - (uint32_t)last_t, pv = 0;
+            for (uint32_t t2 = 0; t2 < tail && t2 < 5; ++t2) pv |= __shfl(pay, last_t + 1 + (int)t2, FD_WAVE) << (7u * t2);
+            carry_val = pv;
+            carry_shift = 7u * tail;
+        }   // (a 64-byte block always holds a terminator: varints of u32 ids are at most 5 bytes and a list ends on one)
+    }
+}
+void fd_launch_get_entries(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash, uint64_t nq,
+                           const uint64_t *out_off, uint32_t *out, hipStream_t st) {
+    if (nq) hipLaunchKernelGGL(k_get_entries, dim3((unsigned)nq), dim3(FD_WAVE), 0, st, hashes, offsets, value, H, q_hash, nq, out_off, out);
+}
+
 __global__ __launch_bounds__(FD_WAVE) void k_cq_accumulate(cq_args A) {
     uint64_t q = blockIdx.x;
     if (q >= A.nq) return;

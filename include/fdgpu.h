@@ -128,6 +128,10 @@ int fdgpu_count_query(fdgpu_ctx *ctx, const fdgpu_index *ix, const uint32_t *q_h
                       const uint32_t *q_edge_j, const float *q_idf, uint64_t n_q, const float *penalty,
                       fd_count_rec **out, uint64_t *n_out);
 
+/* get_entries (src/index/indextable.rs:83-86; varint decode :421-463) for n_q hashes at once: the structure ids of hash k are
+ * (*ids)[(*ids_off)[k] .. (*ids_off)[k+1]) in ascending order (empty for an absent hash).  Release both with fdgpu_free. */
+int fdgpu_get_entries(fdgpu_ctx *ctx, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t n_q, uint32_t **ids, uint64_t **ids_off);
+
 /* Batched form: n_queries queries scored in one set of launches.  Query t owns entries [q_off[t], q_off[t+1]) of the
  * concatenated q_* arrays; its results are (*out)[(*out_off)[t] .. (*out_off)[t+1]) (ascending nid). */
 int fdgpu_count_query_batch(fdgpu_ctx *ctx, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off,

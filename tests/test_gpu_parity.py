@@ -304,3 +304,28 @@ def test_speculative_torsions_equal_exact_path(ctx, monkeypatch):
     for a, b in zip(spec, exact):
         assert a.tobytes() == b.tobytes()
     assert n_fallback > 0          # ~2.4e-4 of ~2.4e7 pairs
+
+
+@pytest.mark.gpu
+def test_get_entries_decodes_posting_lists(ctx):
+    """fdgpu_get_entries == the oracle's get_entries for present and absent hashes, short and long lists (lists longer than one
+    64-byte decode block, multi-byte varints through first_id), and matches posting_lengths"""
+    import folddisco_amd as fd
+    ps = synthetic_packed(400, 21)
+    batch = ctx.upload(ps)
+    first_id = 70000                                # three-byte absolute ids, two-byte deltas never (deltas < 400)
+    ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id)
+    v, h, o = ix.export()
+    structs = packed_to_oracle_structs(ps)
+    oix, _, _ = oracle.build_index(structs)
+    lens = np.diff(o.astype(np.int64))
+    longest = h[np.argsort(lens)[-5:]]
+    rng = np.random.Generator(np.random.PCG64(3))
+    qh = np.concatenate([longest, rng.choice(h, 200, replace=False), np.array([0x3fffffff, 1], np.uint32)]).astype(np.uint32)
+    got = ix.get_entries(qh)
+    want_len = ix.posting_lengths(qh)
+    assert max(len(g) for g in got) > 64
+    for hh, g, n in zip(qh, got, want_len):
+        w = oix.entries(int(hh))
+        assert len(g) == int(n) == len(w)
+        assert np.array_equal(g.astype(np.int64) - first_id, w.astype(np.int64))
