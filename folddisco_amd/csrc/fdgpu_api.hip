@@ -401,7 +401,8 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
     void *ia = c->ws[WS_IDS_A].p, *ib = c->ws[WS_IDS_B].p;
     // shards of <= 2^18 structures use 6-byte sort elements (key = hash << 2 | local id bits 17:16, u16 payload);
     // FDGPU_IDS32=1 forces the 8-byte form
-    static const bool force32 = [] { const char *e = getenv("FDGPU_IDS32"); return e && e[0] == '1'; }();
+    const char *e32 = getenv("FDGPU_IDS32");   // read per call: tests flip it inside one process
+    const bool force32 = e32 && e32[0] == '1';
     const bool ids16 = !force32 && S <= (1ull << 18);
     {
         StageTimer t(c, "pair_emit", b->n_res * 37 + P * (ids16 ? 6 : 8));

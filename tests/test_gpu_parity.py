@@ -329,3 +329,20 @@ def test_get_entries_decodes_posting_lists(ctx):
         w = oix.entries(int(hh))
         assert len(g) == int(n) == len(w)
         assert np.array_equal(g.astype(np.int64) - first_id, w.astype(np.int64))
+
+
+@pytest.mark.gpu
+def test_both_sort_element_forms_give_the_same_index(ctx, monkeypatch):
+    """6-byte sort elements (hash << 2 | id bits 17:16 with a u16 payload; shards of <= 2^18 structures) and the 8-byte form
+    (u32 hash, u32 id; FDGPU_IDS32=1 or larger shards) build byte-identical indices, both equal to the oracle's"""
+    import folddisco_amd as fd
+    ps = synthetic_packed(120, 8)
+    batch = ctx.upload(ps)
+    monkeypatch.delenv("FDGPU_IDS32", raising=False)
+    a = fd.FolddiscoIndex.build(ctx, batch, first_id=3).export()
+    monkeypatch.setenv("FDGPU_IDS32", "1")
+    b = fd.FolddiscoIndex.build(ctx, batch, first_id=3).export()
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+    oix, _, _ = oracle.build_index(packed_to_oracle_structs(ps))
+    assert np.array_equal(a[1], oix.hashes()) and np.array_equal(a[2], oix.offsets())
