@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-query", action="store_true")
+    ap.add_argument("--chunk", type=int, default=100000, help="structures per fdgpu_index_build call; a larger shard is held as a "
+                    "FolddiscoIndexSet (one resident sub-index per chunk)")
     ap.add_argument("--pipeline", type=int, default=0, help="extra leg: builds issued from this many host threads / HIP streams (0 = skip)")
     return ap.parse_args()
 
@@ -115,6 +117,23 @@ def main():
     batch = ctx.wrap_device(S, R, res_off.data_ptr(), d["n_xyz"].data_ptr(), d["ca_xyz"].data_ptr(), d["cb_xyz"].data_ptr(),
                             d["aa"].data_ptr(), None, keepalive=keep)
     first_id = rank * S
+    # shards beyond --chunk structures (more than 2^32 residue pairs): one build call and one resident sub-index per chunk
+    chunked = S > args.chunk
+    chunk_batches = []
+    if chunked:
+        off_cpu = res_off.cpu()
+        for a in range(0, S, args.chunk):
+            b = min(a + args.chunk, S)
+            r0, r1 = int(off_cpu[a]), int(off_cpu[b])
+            ro = (res_off[a:b + 1] - res_off[a]).contiguous()
+            parts = (ro, d["n_xyz"][r0:r1], d["ca_xyz"][r0:r1], d["cb_xyz"][r0:r1], d["aa"][r0:r1])
+            chunk_batches.append(ctx.wrap_device(b - a, r1 - r0, ro.data_ptr(), parts[1].data_ptr(), parts[2].data_ptr(), parts[3].data_ptr(),
+                                                 parts[4].data_ptr(), None, keepalive=parts))
+
+    def build_shard():
+        if not chunked:
+            return fd.FolddiscoIndex.build(ctx, batch, first_id=first_id)
+        return fd.FolddiscoIndexSet.build(ctx, chunk_batches, first_id=first_id)
 
     def barrier():
         torch.cuda.synchronize()
@@ -123,13 +142,14 @@ def main():
 
     ix = None
     for _ in range(args.warmup):
-        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id)
+        ix = None
+        ix = build_shard()
     ctx.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ix = None  # release the previous index before building the next one
-        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id)
+        ix = build_shard()
     ctx.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -138,7 +158,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     value = world * S * args.steps / dt
-    n_post, n_hash, vlen = ix.num_postings, ix.num_hashes, ix.value_len
+    if chunked:
+        n_post, n_hash, vlen = ix.num_postings, sum(p.num_hashes for p in ix.parts), sum(p.value_len for p in ix.parts)
+    else:
+        n_post, n_hash, vlen = ix.num_postings, ix.num_hashes, ix.value_len
 
     # ---- extra leg: the same K builds issued from P host threads, each with its own context / stream / workspace, so that the
     # VALU-bound pair kernel of one build overlaps the HBM-bound sort/encode of another (how a multi-shard job would run)
@@ -183,9 +206,18 @@ def main():
     # ---- per-kernel timings of one more (untimed) step with HIP events on the build stream -> roofline
     ctx.enable_timing(True)
     ix = None
-    ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id)
-    ctx.synchronize()
-    stages = ctx.last_timings()
+    if chunked:
+        stages, parts, fid = [], [], first_id
+        for cb in chunk_batches:
+            parts.append(fd.FolddiscoIndex.build(ctx, cb, first_id=fid))
+            ctx.synchronize()
+            stages += ctx.last_timings()
+            fid += cb.n_struct
+        ix = fd.FolddiscoIndexSet(parts)
+    else:
+        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id)
+        ctx.synchronize()
+        stages = ctx.last_timings()
     ctx.enable_timing(False)
     agg = {}
     for name, ms, by in stages:
@@ -210,7 +242,9 @@ def main():
 
     # ---- motif queries against the resident shard
     query = None
-    if not args.no_query:
+    if chunked and not args.no_query:
+        query = {"note": "query leg runs on single-part shards only (use folddisco_amd.count_query_set for a FolddiscoIndexSet)"}
+    elif not args.no_query:
         try:
             from folddisco_amd import querybench
             if os.environ.get("FD_PROFILE_QUERY"):

@@ -246,6 +246,62 @@ class FolddiscoIndex:
         return out
 
 
+class FolddiscoIndexSet:
+    """Several resident sub-indices over consecutive, disjoint structure-id ranges, queried as one index: a shard of more than
+    2^32 residue pairs is built as a sequence of fdgpu_index_build calls (one per chunk of structures) and never merged on the
+    device.  Posting lengths add up over the parts and every part scores its own structures, so the concatenated records
+    equal those of the merged index."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+        self.ctx = self.parts[0].ctx if self.parts else None
+        self.first_id = self.parts[0].first_id if self.parts else 0
+        self.n_structures = sum(p.n_structures for p in self.parts)
+        for a, b in zip(self.parts, self.parts[1:]):
+            assert b.first_id == a.first_id + a.n_structures, "parts must cover consecutive id ranges"
+
+    @staticmethod
+    def build(ctx: Context, batches, first_id=0, **kw) -> "FolddiscoIndexSet":
+        parts = []
+        for b in batches:
+            parts.append(FolddiscoIndex.build(ctx, b, first_id=first_id, **kw))
+            first_id += b.n_struct
+        return FolddiscoIndexSet(parts)
+
+    def posting_lengths(self, q_hash) -> np.ndarray:
+        q = np.ascontiguousarray(q_hash, dtype=np.uint32)
+        tot = np.zeros(len(q), np.uint64)
+        for p in self.parts:
+            tot += p.posting_lengths(q)
+        return tot
+
+    def get_entries(self, q_hash) -> list:
+        lists = [p.get_entries(q_hash) for p in self.parts]
+        return [np.concatenate([l[k] for l in lists]) for k in range(len(np.atleast_1d(q_hash)))]
+
+    @property
+    def num_postings(self) -> int:
+        return sum(p.num_postings for p in self.parts)
+
+    def export_merged(self):
+        """-> (value, hashes, offsets) of the single merged index (host-side per-hash concatenation)"""
+        from . import indexio
+        return indexio.merge_subindices([p.export() for p in self.parts])
+
+
+def count_query_set(ctx: Context, iset: FolddiscoIndexSet, q_hash, q_node, q_edge_j, penalty: np.ndarray, total_structures: int | None = None,
+                    freq_filter: float | None = None, lengths: np.ndarray | None = None) -> np.ndarray:
+    """count_query over a FolddiscoIndexSet -> REC_DTYPE array in ascending nid.  penalty covers the set's structures."""
+    S = iset.n_structures if total_structures is None else total_structures
+    lens = iset.posting_lengths(q_hash) if lengths is None else np.asarray(lengths, np.uint64)
+    out, base = [], 0
+    for p in iset.parts:
+        out.append(count_query(ctx, p, q_hash, q_node, q_edge_j, penalty[base:base + p.n_structures], total_structures=S,
+                               freq_filter=freq_filter, as_array=True, lengths=lens))
+        base += p.n_structures
+    return np.concatenate(out) if out else np.zeros(0, REC_DTYPE)
+
+
 def length_penalty(nres: np.ndarray, lp: float = 0.5) -> np.ndarray:
     """(nres as f32).powf(-lp) per structure (count_query.rs:200), evaluated with the C library's powf."""
     libm = C.CDLL("libm.so.6")

@@ -346,3 +346,37 @@ def test_both_sort_element_forms_give_the_same_index(ctx, monkeypatch):
         assert x.tobytes() == y.tobytes()
     oix, _, _ = oracle.build_index(packed_to_oracle_structs(ps))
     assert np.array_equal(a[1], oix.hashes()) and np.array_equal(a[2], oix.offsets())
+
+
+@pytest.mark.gpu
+def test_index_set_equals_single_index(ctx):
+    """A shard built as several fdgpu_index_build calls (FolddiscoIndexSet: one resident sub-index per chunk of structures, the
+    way a shard of more than 2^32 residue pairs is held) answers like the single index: posting lengths, decoded lists, scoring
+    records byte for byte, and its merged export is the single index's."""
+    import folddisco_amd as fd
+    from folddisco_amd import synth
+    d = synth.generate(180, seed=31)
+    ps = synth.to_packed(d)
+    off = ps.res_off.astype(np.int64)
+    cuts = [0, 50, 51, 130, 180]                    # uneven chunks, one of a single structure
+    chunks = []
+    for a, b in zip(cuts, cuts[1:]):
+        sl = slice(off[a], off[b])
+        chunks.append(fd.PackedStructures((ps.res_off[a:b + 1] - ps.res_off[a]).astype(np.uint64), ps.n_xyz[sl], ps.ca_xyz[sl], ps.cb_xyz[sl], ps.aa[sl]))
+    single = fd.FolddiscoIndex.build(ctx, ctx.upload(ps), first_id=7)
+    iset = fd.FolddiscoIndexSet.build(ctx, [ctx.upload(c) for c in chunks], first_id=7)
+    assert iset.n_structures == 180 and iset.num_postings == single.num_postings
+    v, h, o = single.export()
+    mv, mh, mo = iset.export_merged()
+    assert np.array_equal(mv, v) and np.array_equal(mh, h) and np.array_equal(mo, o)
+    rng = np.random.Generator(np.random.PCG64(9))
+    qh = np.concatenate([rng.choice(h, 60, replace=False), np.array([0x3ffffffe], np.uint32)]).astype(np.uint32)
+    assert np.array_equal(iset.posting_lengths(qh), single.posting_lengths(qh))
+    for a, b in zip(iset.get_entries(qh), single.get_entries(qh)):
+        assert np.array_equal(a, b)
+    qi = rng.integers(0, 4, len(qh)).astype(np.uint32)
+    qj = rng.integers(0, 4, len(qh)).astype(np.uint32)
+    pen = fd.length_penalty(np.diff(ps.res_off).astype(np.uint64), 0.5)
+    want = fd.count_query(ctx, single, qh, qi, qj, pen, as_array=True)
+    got = fd.count_query_set(ctx, iset, qh, qi, qj, pen)
+    assert got.tobytes() == want.tobytes() and len(got) > 50
