@@ -816,62 +816,69 @@ extern "C" int fdgpu_count_query_batch_top(fdgpu_ctx *c, const fdgpu_index *ix, 
 }
 
 // ---- S4 ---------------------------------------------------------------------------------------------------------------
-extern "C" int fdgpu_match_pairs(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
-                                 const fd_match_query *q, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
-                                 fd_cand_rec **cands, uint64_t *n_cands) {
-    if (!c || !db || !q || !p || !found || !n_found || !cands || !n_cands || (n_cand && !cand)) return FDGPU_EINVAL;
+// Pair scan for MANY queries in one launch: query t scans the candidates cand[cand_off[t] .. cand_off[t+1]); the records carry the
+// GLOBAL slot (position in cand) and come back sorted by (slot, i, j).
+int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
+                         const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
+                         fd_cand_rec **cands, uint64_t *n_cands) {
+    if (!c || !db || !p || !found || !n_found || !cands || !n_cands || !cand_off || (n_queries && !qs)) return FDGPU_EINVAL;
+    const uint64_t n_cand = cand_off[n_queries];
+    if (n_cand && !cand) return FDGPU_EINVAL;
     *found = nullptr; *cands = nullptr; *n_found = 0; *n_cands = 0;
     reset_timings(c);
     hipStream_t st = c->stream;
-    // work items: (candidate slot, 64-residue i-tile)
-    std::vector<uint32_t> wc, wi;
-    for (uint64_t k = 0; k < n_cand; ++k) {
-        if (cand[k] >= db->n_struct) FAIL(c, FDGPU_EINVAL, "match_pairs: candidate id outside the batch");
-        uint64_t r0 = db->h_res_off[cand[k]], r1 = db->h_res_off[cand[k] + 1];
-        for (uint64_t t = r0; t < r1; t += FD_WAVE) { wc.push_back((uint32_t)k); wi.push_back((uint32_t)t); }
-    }
-    uint32_t m1 = 0, m2 = 0;
-    for (uint64_t k = 0; k < q->n_hashes; ++k) { m1 |= 1u << ((q->hashes[k] >> 25) & 31u); m2 |= 1u << ((q->hashes[k] >> 20) & 31u); }
-    size_t nw = wc.size();
-    HIPCHK(c, c->ws[WS_MISC0].ensure(std::max<size_t>(n_cand, 1) * 4));
-    HIPCHK(c, c->ws[WS_MISC1].ensure(std::max<size_t>(nw, 1) * 4));
-    HIPCHK(c, c->ws[WS_MISC2].ensure(std::max<size_t>(nw, 1) * 4));
-    HIPCHK(c, c->ws[WS_MISC3].ensure(std::max<uint64_t>(q->n_hashes, 1) * 4));
-    // aa_dist_map grouped by (aa_i, aa_j): stable order inside a group = the observed-list order the reference emits in
-    std::vector<uint32_t> a_start(1025, 0), a_qi;
-    std::vector<float> a_dist;
-    {
+    // work items: (query, candidate slot, 64-residue i-tile)
+    std::vector<uint32_t> wc, wi, wq;
+    for (uint64_t t = 0; t < n_queries; ++t)
+        for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) {
+            if (cand[k] >= db->n_struct) FAIL(c, FDGPU_EINVAL, "match_pairs: candidate id outside the batch");
+            uint64_t r0 = db->h_res_off[cand[k]], r1 = db->h_res_off[cand[k] + 1];
+            for (uint64_t r = r0; r < r1; r += FD_WAVE) { wc.push_back((uint32_t)k); wi.push_back((uint32_t)r); wq.push_back((uint32_t)t); }
+        }
+    // per-query tables: sorted hash set, residue-type masks, aa_dist_map grouped by (aa_i, aa_j) — stable order inside a group =
+    // the observed-list order the reference emits in
+    std::vector<mp_query_dev> qtab(std::max<uint64_t>(n_queries, 1));
+    std::vector<uint32_t> all_hashes, all_start, all_qi;
+    std::vector<float> all_dist;
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        const fd_match_query *q = &qs[t];
+        mp_query_dev &Q = qtab[t];
+        Q.qh_off = (uint32_t)all_hashes.size(); Q.n_hashes = (uint32_t)q->n_hashes;
+        all_hashes.insert(all_hashes.end(), q->hashes, q->hashes + q->n_hashes);
+        Q.aa1_mask = Q.aa2_mask = 0;
+        for (uint64_t k = 0; k < q->n_hashes; ++k) { Q.aa1_mask |= 1u << ((q->hashes[k] >> 25) & 31u); Q.aa2_mask |= 1u << ((q->hashes[k] >> 20) & 31u); }
+        Q.use_prefilter = q->use_aa_prefilter; Q.ca_window = q->ca_distance_cutoff;
         std::vector<uint32_t> cnt(1025, 0);
         for (uint64_t e = 0; e < q->n_aad; ++e)
             if (q->aad_aa1[e] < 32 && q->aad_aa2[e] < 32) ++cnt[q->aad_aa1[e] * 32u + q->aad_aa2[e] + 1];   // residue type 255 never passes get_single_feature
         for (int k = 0; k < 1024; ++k) cnt[k + 1] += cnt[k];
-        a_start = cnt;
-        a_qi.resize(cnt[1024]); a_dist.resize(cnt[1024]);
+        Q.aad_off = (uint32_t)all_dist.size(); Q.n_aad = cnt[1024];
+        all_start.insert(all_start.end(), cnt.begin(), cnt.end());
+        all_qi.resize(Q.aad_off + Q.n_aad); all_dist.resize(Q.aad_off + Q.n_aad);
         std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
         for (uint64_t e = 0; e < q->n_aad; ++e)
             if (q->aad_aa1[e] < 32 && q->aad_aa2[e] < 32) {
-                uint32_t k = cur[q->aad_aa1[e] * 32u + q->aad_aa2[e]]++;
-                a_qi[k] = q->aad_qi[e]; a_dist[k] = q->aad_dist[e];
+                uint32_t k = Q.aad_off + cur[q->aad_aa1[e] * 32u + q->aad_aa2[e]]++;
+                all_qi[k] = q->aad_qi[e]; all_dist[k] = q->aad_dist[e];
             }
     }
-    size_t na = a_dist.size();
-    HIPCHK(c, c->ws[WS_MISC4].ensure(std::max<size_t>(na, 1) * 8 + 1025 * 4 + 64));
+    const size_t nw = wc.size(), na = all_dist.size(), nh = all_hashes.size();
+    // one packed host block -> one H2D copy: [cand | wc | wi | wq | hashes | start tables | dist | qi | qtab]
+    auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
+    const size_t o_cand = 0, o_wc = o_cand + up4(n_cand), o_wi = o_wc + up4(nw), o_wq = o_wi + up4(nw), o_h = o_wq + up4(nw),
+                 o_st = o_h + up4(nh), o_d = o_st + up4(all_start.size()), o_qi = o_d + up4(na), o_qt = o_qi + up4(na),
+                 words = o_qt + up4(n_queries * (sizeof(mp_query_dev) / 4)) + 4;
+    std::vector<uint32_t> blk(words, 0);
+    if (n_cand) memcpy(&blk[o_cand], cand, n_cand * 4);
+    if (nw) { memcpy(&blk[o_wc], wc.data(), nw * 4); memcpy(&blk[o_wi], wi.data(), nw * 4); memcpy(&blk[o_wq], wq.data(), nw * 4); }
+    if (nh) memcpy(&blk[o_h], all_hashes.data(), nh * 4);
+    if (!all_start.empty()) memcpy(&blk[o_st], all_start.data(), all_start.size() * 4);
+    if (na) { memcpy(&blk[o_d], all_dist.data(), na * 4); memcpy(&blk[o_qi], all_qi.data(), na * 4); }
+    if (n_queries) memcpy(&blk[o_qt], qtab.data(), n_queries * sizeof(mp_query_dev));
+    HIPCHK(c, c->ws[WS_MISC0].ensure(words * 4));
     HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
-    uint8_t *aad_base = c->ws[WS_MISC4].as<uint8_t>();
-    uint32_t *d_start = (uint32_t *)aad_base;
-    float *d_dist = (float *)(aad_base + 1025 * 4 + 12);
-    uint32_t *d_qi = (uint32_t *)(aad_base + 1025 * 4 + 12 + 4 * std::max<size_t>(na, 1));
-    if (n_cand) HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, cand, n_cand * 4, hipMemcpyHostToDevice, st));
-    if (nw) {
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, wc.data(), nw * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, wi.data(), nw * 4, hipMemcpyHostToDevice, st));
-    }
-    if (q->n_hashes) HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC3].p, q->hashes, q->n_hashes * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_start, a_start.data(), 1025 * 4, hipMemcpyHostToDevice, st));
-    if (na) {
-        HIPCHK(c, hipMemcpyAsync(d_dist, a_dist.data(), na * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(d_qi, a_qi.data(), na * 4, hipMemcpyHostToDevice, st));
-    }
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, blk.data(), words * 4, hipMemcpyHostToDevice, st));
+    const uint32_t *dblk = c->ws[WS_MISC0].as<uint32_t>();
     uint8_t *d_std = nullptr;
     if (resname_std) {
         HIPCHK(c, c->ws[WS_MISC5].ensure(std::max<uint64_t>(db->n_res, 1)));
@@ -879,18 +886,19 @@ extern "C" int fdgpu_match_pairs(fdgpu_ctx *c, const fdgpu_batch *db, const uint
         d_std = c->ws[WS_MISC5].as<uint8_t>();
     }
     mp_args A;
+    memset(&A, 0, sizeof A);
     A.B = db->view(); A.C = make_consts(p); A.cutoff = p->dist_cutoff;
-    A.cand = c->ws[WS_MISC0].as<uint32_t>(); A.n_cand = (uint32_t)n_cand;
-    A.wi_cand = c->ws[WS_MISC1].as<uint32_t>(); A.wi_i0 = c->ws[WS_MISC2].as<uint32_t>(); A.n_work = (uint32_t)nw;
-    A.resname_std = d_std; A.aa1_mask = m1; A.aa2_mask = m2; A.use_prefilter = q->use_aa_prefilter;
-    A.q_hashes = c->ws[WS_MISC3].as<uint32_t>(); A.n_hashes = (uint32_t)q->n_hashes;
-    A.aad_start = d_start; A.aad_dist = d_dist; A.aad_qi = d_qi; A.n_aad = (uint32_t)na; A.ca_window = q->ca_distance_cutoff;
+    A.cand = dblk + o_cand; A.n_cand = (uint32_t)n_cand;
+    A.wi_cand = dblk + o_wc; A.wi_i0 = dblk + o_wi; A.wi_query = dblk + o_wq; A.n_work = (uint32_t)nw;
+    A.resname_std = d_std;
+    A.q_hashes = dblk + o_h; A.aad_start = dblk + o_st; A.aad_dist = (const float *)(dblk + o_d); A.aad_qi = dblk + o_qi;
+    A.qtab = (const mp_query_dev *)(dblk + o_qt);
     A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.found = nullptr; A.cands = nullptr;
     // one emitting pass into buffers sized by the previous calls; a pass that overflows only counts, the buffers grow and
     // the pass is repeated (the scan is deterministic up to record order, which is restored below)
     uint64_t tot[2] = {0, 0};
     for (int attempt = 0; attempt < 3; ++attempt) {
-        uint64_t capf = std::max<uint64_t>(c->ws[WS_KEYS_A].cap / sizeof(fd_pair_rec), 0), capc = c->ws[WS_KEYS_B].cap / sizeof(fd_cand_rec);
+        uint64_t capf = c->ws[WS_KEYS_A].cap / sizeof(fd_pair_rec), capc = c->ws[WS_KEYS_B].cap / sizeof(fd_cand_rec);
         if (capf < 4096 || capf < tot[0]) { HIPCHK(c, c->ws[WS_KEYS_A].ensure(std::max<uint64_t>(2 * tot[0], 65536) * sizeof(fd_pair_rec))); }
         if (capc < 4096 || capc < tot[1]) { HIPCHK(c, c->ws[WS_KEYS_B].ensure(std::max<uint64_t>(2 * tot[1], 65536) * sizeof(fd_cand_rec))); }
         A.found = c->ws[WS_KEYS_A].as<fd_pair_rec>(); A.cands = c->ws[WS_KEYS_B].as<fd_cand_rec>();
@@ -928,6 +936,13 @@ extern "C" int fdgpu_match_pairs(fdgpu_ctx *c, const fdgpu_batch *db, const uint
     });
     *found = hf; *n_found = tot[0]; *cands = hc; *n_cands = tot[1];
     return FDGPU_OK;
+}
+extern "C" int fdgpu_match_pairs(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
+                                 const fd_match_query *q, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
+                                 fd_cand_rec **cands, uint64_t *n_cands) {
+    if (!q) return FDGPU_EINVAL;
+    const uint64_t off[2] = {0, n_cand};
+    return fd_match_pairs_multi(c, db, resname_std, 1, q, cand, off, p, found, n_found, cands, n_cands);
 }
 
 extern "C" int fdgpu_kabsch_batch(fdgpu_ctx *c, const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot,

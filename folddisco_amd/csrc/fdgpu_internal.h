@@ -172,12 +172,20 @@ void fd_launch_cq_compact(const uint32_t *match, const unsigned long long *idf, 
                           hipStream_t st);
 
 // k_match.hip
+struct mp_query_dev {   // per-query table of the pair scan (many queries in one launch)
+    uint32_t qh_off, n_hashes;   // sorted unique hashes: q_hashes[qh_off .. +n_hashes)
+    uint32_t aad_off, n_aad;     // grouped aa_dist_map: aad_dist / aad_qi [aad_off .. +n_aad); start table aad_start[1025 * query]
+    uint32_t aa1_mask, aa2_mask; // residue types of the hashes' first / second residue (prefilter_amino_acid)
+    int use_prefilter;
+    float ca_window;
+};
 struct mp_args {
     fd_batch_view B;
     fd_hash_consts C;
     float cutoff;
     const uint32_t *cand; uint32_t n_cand;
-    const uint32_t *wi_cand; const uint32_t *wi_i0; uint32_t n_work;
+    const uint32_t *wi_cand; const uint32_t *wi_i0; const uint32_t *wi_query; uint32_t n_work;
+    const mp_query_dev *qtab;
     const uint8_t *resname_std;
     uint32_t aa1_mask, aa2_mask;
     int use_prefilter;
@@ -199,3 +207,6 @@ void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries
                        hipStream_t st);
 void fd_launch_get_entries(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash, uint64_t nq,
                            const uint64_t *out_off, uint32_t *out, hipStream_t st);
+int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
+                         const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
+                         fd_cand_rec **cands, uint64_t *n_cands);

@@ -88,7 +88,16 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
 
 #define MP_AAD_LDS 1024
 template <bool EMIT>
-__global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A) {
+__global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
+    // many queries per launch: this work item's query selects its slice of the concatenated tables (wave-uniform loads)
+    mp_args A = A_in;
+    if (blockIdx.x < A_in.n_work) {
+        const uint32_t tq = A_in.wi_query[blockIdx.x];
+        const mp_query_dev Q = A_in.qtab[tq];
+        A.q_hashes = A_in.q_hashes + Q.qh_off; A.n_hashes = Q.n_hashes;
+        A.aad_start = A_in.aad_start + 1025u * tq; A.aad_dist = A_in.aad_dist + Q.aad_off; A.aad_qi = A_in.aad_qi + Q.aad_off; A.n_aad = Q.n_aad;
+        A.aa1_mask = Q.aa1_mask; A.aa2_mask = Q.aa2_mask; A.use_prefilter = Q.use_prefilter; A.ca_window = Q.ca_window;
+    }
     __shared__ uint32_t q[2 * FD_WAVE];
     __shared__ uint32_t tab[32];
     __shared__ float s_d_buf[MP_AAD_LDS];
