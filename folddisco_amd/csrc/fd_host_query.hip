@@ -373,29 +373,43 @@ __global__ __launch_bounds__(256) void k_gather_xyz(const float *__restrict__ ca
     }
 }
 
-extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
-                              const fd_query_map *qm, const fdgpu_batch *qb, const fd_hash_params *p, float ca_distance_cutoff,
-                              uint32_t node_count, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues) {
-    if (!c || !db || !qm || !qb || !p || !matches || !n_matches || !residues) return FDGPU_EINVAL;
-    *matches = nullptr; *n_matches = 0; *residues = nullptr;
+// retrieval_wrapper for MANY queries: one pair scan, one coordinate gather and one Kabsch launch in total.  Query t = structure
+// q_struct[t] of qb with the query map qms[t]; its candidates are cand[cand_off[t] .. cand_off[t+1]).  Matches of query t:
+// (*matches)[(*match_off)[t] .. (*match_off)[t+1]) (cand = slot inside the query's own candidate list), residues
+// (*residues)[(*res_off)[t] ...], 2 * n_indices(t) per match.
+extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand,
+                                    const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
+                                    const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, fd_match_rec **matches,
+                                    uint64_t **match_off, int32_t **residues, uint64_t **res_off) {
+    if (!c || !db || !qb || !p || !matches || !match_off || !residues || !res_off || !cand_off || (n_queries && (!qms || !q_struct))) return FDGPU_EINVAL;
+    *matches = nullptr; *match_off = nullptr; *residues = nullptr; *res_off = nullptr;
+    const uint64_t n_cand = cand_off[n_queries];
+    for (uint64_t t = 0; t < n_queries; ++t) if (!qms[t] || q_struct[t] >= qb->n_struct) return FDGPU_EINVAL;
     const bool trace = getenv("FDGPU_TRACE") != nullptr;
     auto t_now = [] { return std::chrono::steady_clock::now(); };
     auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto T0 = t_now();
-    const uint64_t NQ = qm->n_indices;
-    // sorted unique query hashes + lookup hash -> query map entry
-    std::map<uint32_t, uint32_t> entry;
-    for (uint64_t k = 0; k < qm->n; ++k) entry.emplace(qm->hash[k], (uint32_t)k);
-    std::vector<uint32_t> qh;
-    for (auto &kv : entry) qh.push_back(kv.first);
-    fd_match_query q;
-    q.hashes = qh.data(); q.n_hashes = qh.size();
-    q.aad_aa1 = qm->aad_aa1; q.aad_aa2 = qm->aad_aa2; q.aad_dist = qm->aad_dist; q.aad_qi = qm->aad_qi; q.n_aad = qm->n_aad;
-    q.ca_distance_cutoff = ca_distance_cutoff;
-    q.use_aa_prefilter = qh.size() <= 200 ? 1 : 0;  // PREFILTER_AA_SKIPPING_SIZE (retrieve.rs:24, 569)
+    // per query: sorted unique hashes + lookup hash -> query map entry
+    std::vector<std::map<uint32_t, uint32_t>> entries(n_queries);
+    std::vector<std::vector<uint32_t>> qhs(n_queries);
+    std::vector<fd_match_query> mqs(std::max<uint64_t>(n_queries, 1));
+    std::vector<uint32_t> q_sizes(std::max<uint64_t>(n_queries, 1), 1);
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        const fd_query_map *m = qms[t];
+        for (uint64_t k = 0; k < m->n; ++k) {
+            entries[t].emplace(m->hash[k], (uint32_t)k);
+            q_sizes[t] = std::max(q_sizes[t], std::max(m->qi[k], m->qj[k]) + 1);
+        }
+        for (auto &kv : entries[t]) qhs[t].push_back(kv.first);
+        fd_match_query &q = mqs[t];
+        q.hashes = qhs[t].data(); q.n_hashes = qhs[t].size();
+        q.aad_aa1 = m->aad_aa1; q.aad_aa2 = m->aad_aa2; q.aad_dist = m->aad_dist; q.aad_qi = m->aad_qi; q.n_aad = m->n_aad;
+        q.ca_distance_cutoff = ca_distance_cutoff;
+        q.use_aa_prefilter = qhs[t].size() <= 200 ? 1 : 0;  // PREFILTER_AA_SKIPPING_SIZE (retrieve.rs:24, 569)
+    }
     fd_pair_rec *found = nullptr; fd_cand_rec *cands = nullptr;
     uint64_t nf = 0, nc = 0;
-    int rc = fdgpu_match_pairs(c, db, resname_std, cand, n_cand, &q, p, &found, &nf, &cands, &nc);
+    int rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc);
     if (rc) return rc;
     auto T1 = t_now();
     // symmetry flags (geometry/pdb_tr.rs:158-162): aa equal and atan2(sin, cos) of the two torsion fields equal
@@ -405,8 +419,6 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
         float p1 = atan2f(cont((h >> 6) & 3), cont((h >> 4) & 3)) * D, p2 = atan2f(cont((h >> 2) & 3), cont(h & 3)) * D;
         return ((h >> 25) & 31u) == ((h >> 20) & 31u) && p1 == p2;
     };
-    uint32_t q_size = 1;
-    for (uint64_t k = 0; k < qm->n; ++k) q_size = std::max(q_size, std::max(qm->qi[k], qm->qj[k]) + 1);
     // per candidate: graph -> components -> vote -> rescue; Kabsch problems collected for one GPU batch
     std::vector<fd_match_rec> recs;
     std::vector<int32_t> res;               // 2 * NQ per match: from_hash then processed target residue index (-1 = none)
@@ -414,10 +426,13 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
     std::vector<uint64_t> koff(1, 0);
     struct Pend { size_t rec; int which; }; // which: 0 from_hash, 1 processed
     std::vector<Pend> pend;
-    // host copies of the coordinates needed for the Kabsch point lists
-    std::vector<float> q_ca((qb->h_res_off[1] - qb->h_res_off[0]) * 3), q_cb(q_ca.size());
-    HIPCHK(c, hipMemcpy(q_ca.data(), qb->ca_xyz, q_ca.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(q_cb.data(), qb->cb_xyz, q_cb.size() * 4, hipMemcpyDeviceToHost));
+    // host copies of the coordinates needed for the Kabsch point lists (every query structure of qb)
+    std::vector<float> qb_ca(std::max<uint64_t>(qb->n_res, 1) * 3), qb_cb(qb_ca.size());
+    if (qb->n_res) {
+        HIPCHK(c, hipMemcpy(qb_ca.data(), qb->ca_xyz, qb->n_res * 12, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(qb_cb.data(), qb->cb_xyz, qb->n_res * 12, hipMemcpyDeviceToHost));
+    }
+    std::vector<uint64_t> m_off(n_queries + 1, 0), r_off(n_queries + 1, 0);
     std::vector<uint64_t> g_src(std::max<uint64_t>(n_cand, 1)), g_dst(n_cand + 1, 0);
     for (uint64_t k = 0; k < n_cand; ++k) {
         g_src[k] = db->h_res_off[cand[k]];
@@ -438,7 +453,14 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
     }
     auto T2 = t_now();
     size_t fpos = 0, cpos = 0;
+    uint64_t tq = 0;
     for (uint64_t slot = 0; slot < n_cand; ++slot) {
+        while (slot >= cand_off[tq + 1]) { ++tq; m_off[tq] = recs.size(); r_off[tq] = res.size(); }
+        const fd_query_map *qm = qms[tq];
+        const std::map<uint32_t, uint32_t> &entry = entries[tq];
+        const uint32_t q_size = q_sizes[tq];
+        const uint64_t NQ = qm->n_indices;
+        const float *q_ca = qb_ca.data() + 3 * qb->h_res_off[q_struct[tq]], *q_cb = qb_cb.data() + 3 * qb->h_res_off[q_struct[tq]];
         size_t f0 = fpos, c0 = cpos;
         while (fpos < nf && found[fpos].cand == slot) ++fpos;
         while (cpos < nc && cands[cpos].cand == slot) ++cpos;
@@ -552,7 +574,7 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
             for (uint32_t r : r_idx) if (r < Rt) mapped_r[r] = 0;
             fd_match_rec rec;
             memset(&rec, 0, sizeof rec);
-            rec.cand = (uint32_t)slot; rec.idf = sub_idf;
+            rec.cand = (uint32_t)(slot - cand_off[tq]); rec.idf = sub_idf;
             rec.same = from_hash == processed ? 1 : 0;
             recs.push_back(rec);
             res.insert(res.end(), from_hash.begin(), from_hash.end());
@@ -572,6 +594,7 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
         }
     }
     free(found); free(cands);
+    while (tq < n_queries) { ++tq; m_off[tq] = recs.size(); r_off[tq] = res.size(); }
     const uint64_t nprob = pend.size();
     std::vector<float> rmsd(std::max<uint64_t>(nprob, 1)), rot(std::max<uint64_t>(nprob, 1) * 9), tran(std::max<uint64_t>(nprob, 1) * 3);
     auto T3 = t_now();
@@ -590,12 +613,32 @@ extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t
     }
     fd_match_rec *om = (fd_match_rec *)malloc(std::max<size_t>(recs.size(), 1) * sizeof(fd_match_rec));
     int32_t *orr = (int32_t *)malloc(std::max<size_t>(res.size(), 1) * sizeof(int32_t));
-    if (!om || !orr) { free(om); free(orr); return FDGPU_ENOMEM; }
+    uint64_t *omo = (uint64_t *)malloc((n_queries + 1) * 8), *oro = (uint64_t *)malloc((n_queries + 1) * 8);
+    if (!om || !orr || !omo || !oro) { free(om); free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
     if (!recs.empty()) memcpy(om, recs.data(), recs.size() * sizeof(fd_match_rec));
     if (!res.empty()) memcpy(orr, res.data(), res.size() * sizeof(int32_t));
-    *matches = om; *n_matches = recs.size(); *residues = orr;
+    memcpy(omo, m_off.data(), (n_queries + 1) * 8);
+    memcpy(oro, r_off.data(), (n_queries + 1) * 8);
+    *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
     return FDGPU_OK;
 }
+
+// one query = structure 0 of qb
+extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
+                              const fd_query_map *qm, const fdgpu_batch *qb, const fd_hash_params *p, float ca_distance_cutoff,
+                              uint32_t node_count, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues) {
+    if (!c || !db || !qm || !qb || !p || !matches || !n_matches || !residues) return FDGPU_EINVAL;
+    *matches = nullptr; *n_matches = 0; *residues = nullptr;
+    const uint64_t off[2] = {0, n_cand};
+    const uint32_t s0 = 0;
+    uint64_t *mo = nullptr, *ro = nullptr;
+    int rc = fdgpu_retrieve_batch(c, db, resname_std, 1, cand, off, &qm, qb, &s0, p, ca_distance_cutoff, node_count, matches, &mo, residues, &ro);
+    if (rc) return rc;
+    *n_matches = mo[1];
+    free(mo); free(ro);
+    return FDGPU_OK;
+}
+
 
 // ------------------------------------------------------------------------------------------ sub-index merge
 // Index build shards by structure (one sub-index per GPU / per batch, contiguous ascending id ranges).  The

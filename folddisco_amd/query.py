@@ -254,6 +254,42 @@ def sample_query_hashes(index: FolddiscoIndex, q_hash, sampling_ratio=None, samp
     return order[: max(0, min(keep, n))]
 
 
+def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Batch, q_structs, ca_distance_cutoff=1.0, node_count=2,
+                   nbin_dist=0, nbin_angle=0, dist_cutoff=20.0):
+    """retrieve() for many queries with one pair scan / gather / Kabsch launch in total (fdgpu_retrieve_batch).  cands[t]:
+    candidate structure indices of query t, qms[t] its QueryMapResult, q_structs[t] its structure in qbatch.
+    -> list (per query) of lists of match dicts like retrieve()."""
+    T = len(qms)
+    cl = [np.ascontiguousarray(c, dtype=np.uint32) for c in cands]
+    cand_off = np.concatenate([[0], np.cumsum([len(c) for c in cl])]).astype(np.uint64)
+    cand = np.ascontiguousarray(np.concatenate(cl) if cl else np.zeros(0, np.uint32))
+    std = None if resname_std is None else np.ascontiguousarray(resname_std, np.uint8)
+    qs = np.ascontiguousarray(q_structs, np.uint32)
+    handles = (C.POINTER(QueryMap) * max(T, 1))(*[q.handle for q in qms])
+    p = HashParams(nbin_dist, nbin_angle, dist_cutoff)
+    mp, rp = C.POINTER(MatchRec)(), C.POINTER(C.c_int32)()
+    mo, ro = u64p(), u64p()
+    ctx.check(ctx.L.fdgpu_retrieve_batch(ctx.h, db.h, None if std is None else std.ctypes.data_as(u8p), T, cand.ctypes.data_as(u32p),
+                                         cand_off.ctypes.data_as(u64p), handles, qbatch.h, qs.ctypes.data_as(u32p), C.byref(p), ca_distance_cutoff,
+                                         node_count, C.byref(mp), C.byref(mo), C.byref(rp), C.byref(ro)))
+    out = []
+    for t in range(T):
+        nq = len(qms[t].indices)
+        lst = []
+        for k in range(int(mo[t]), int(mo[t + 1])):
+            r = mp[k]
+            base = int(ro[t]) + 2 * nq * (k - int(mo[t]))
+            lst.append(dict(cand=int(r.cand), idf=float(r.idf), rmsd=float(r.rmsd), rmsd_from_hash=float(r.rmsd_from_hash), same=bool(r.same),
+                            from_hash=[rp[base + z] for z in range(nq)], processed=[rp[base + nq + z] for z in range(nq)],
+                            rot=np.array(list(r.rot), np.float32).reshape(3, 3), tran=np.array(list(r.tran), np.float32),
+                            metrics=np.array(list(r.metrics), np.float32)))
+        out.append(lst)
+    ctx.L.fdgpu_matches_free(mp, rp)
+    ctx.L.fdgpu_free(mo)
+    ctx.L.fdgpu_free(ro)
+    return out
+
+
 def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[CompactStructure], tids: list[str], nres, plddt,
               query: CompactStructure, query_string: str, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance=1.0, top_n=None,
               length_penalty_power=0.5, skip_match=False, serial_query=False, freq_filter=None, dist_cutoff=20.0, nbin_dist=0, nbin_angle=0,

@@ -14,7 +14,7 @@ import torch
 
 from . import dist as fdist
 from .api import PackedStructures, count_query, count_query_batch, idf_of_lengths, length_penalty
-from .query import make_query_map, make_query_maps, retrieve
+from .query import make_query_map, make_query_maps, retrieve, retrieve_batch
 
 
 def _pick_queries(d, S, n_queries, seed, k=4):
@@ -105,12 +105,15 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                         qm.set_idf(np.where(pl > 0, idf_of_lengths(np.maximum(pl, 1), S_total), 0.0).astype(np.float32))
                 recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=top_n,
                                          lengths_fn=(lambda l: fdist.reduce_lengths(l, dev)) if sharded else None)
+                cl = []
                 for k, qm, r in zip(ks, qms, recs):
                     n = len(fdist.allgather_hits(r, dev, top_n=top_n))
-                    if match and len(r):
-                        cand = (fdist.rank_hits(r, match_top)["nid"] - ix.first_id).astype(np.uint32)
-                        n = len(retrieve(ctx, batch, None, cand, qm, qbatches[k]))
-                    tot += n
+                    if match:
+                        cl.append((fdist.rank_hits(r, match_top)["nid"] - ix.first_id).astype(np.uint32) if len(r) else np.zeros(0, np.uint32))
+                    else:
+                        tot += n
+                if match:   # one pair scan / gather / Kabsch launch for the whole chunk of queries
+                    tot += sum(len(m) for m in retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks)))
             return tot
         go()
         torch.cuda.synchronize()

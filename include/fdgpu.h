@@ -222,6 +222,15 @@ typedef struct fd_match_rec {   /* one connected component of one candidate (ret
 int fdgpu_retrieve(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
                    const fd_query_map *qm, const fdgpu_batch *qb, const fd_hash_params *p, float ca_distance_cutoff,
                    uint32_t node_count, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues);
+/* Many queries with one pair scan, one coordinate gather and one Kabsch launch in total: query t = structure q_struct[t] of qb
+ * with the query map qms[t]; its candidates are cand[cand_off[t] .. cand_off[t+1]).  Matches of query t =
+ * (*matches)[(*match_off)[t] .. (*match_off)[t+1]) (cand = slot inside the query's own list), its residues start at
+ * (*residues)[(*res_off)[t]], 2 * qms[t]->n_indices per match.  Release matches/residues with fdgpu_matches_free, the two
+ * offset arrays with fdgpu_free. */
+int fdgpu_retrieve_batch(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand,
+                         const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
+                         const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, fd_match_rec **matches,
+                         uint64_t **match_off, int32_t **residues, uint64_t **res_off);
 void fdgpu_matches_free(fd_match_rec *m, int32_t *residues);
 
 /* ---- structure ingest (host, multi-threaded) ---------------------------------------------------------------

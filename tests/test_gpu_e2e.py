@@ -388,3 +388,35 @@ def test_cli_two_ranks_sharded_index_and_query(tmp_path):
         got = subprocess.run(launch + q + ["-i", two], cwd=tmp_path, env=env, capture_output=True, text=True, check=True, timeout=600).stdout
         rows = [l for l in got.splitlines() if l.startswith("data/")]
         assert rows == want.splitlines() and len(rows) >= 2, (extra, got[-2000:])
+
+
+@pytest.mark.gpu
+def test_retrieve_batch_equals_single(env):
+    """fdgpu_retrieve_batch (one pair scan, one gather, one Kabsch launch for all queries) == fdgpu_retrieve per query: same
+    matches in the same order, bit-identical floats; queries with different candidate lists, one with no candidates"""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    ctx, structs, batch, ix, nres, plddt, tids = env
+    q1, q2 = st.read_compact_structure(Q4CHA), st.read_compact_structure(Q1G2F)
+    qall = ctx.upload(fd.PackedStructures.concat([q1.as_item(), q2.as_item()]))
+    std = np.concatenate([s.resname_std() for s in structs])
+    specs = [(0, q1, "B57,B102,C195", [0, 1, 2, 3, 4]), (1, q2, "F207,F212,F225,F229", [4, 2]), (0, q1, "B57:HKR,B102,C195:ST", [3, 4]),
+             (0, q1, "B57,B102", [])]
+    reqs, singles = [], []
+    for sidx, q, qstr, cand in specs:
+        res = fq.parse_query_string(qstr, q.chains[0])
+        pairs = [(q.get_index(c, r), s) for c, r, s in res]
+        reqs.append((sidx, [i for i, _ in pairs], [s for _, s in pairs]))
+        qb = ctx.upload(fd.PackedStructures.concat([q.as_item()]))
+        qm = fq.make_query_map(ctx, qb, [i for i, _ in pairs], [s for _, s in pairs], ix, 5.0)
+        singles.append(fq.retrieve(ctx, batch, std, np.array(cand, np.uint32), qm, qb))
+    qms = fq.make_query_maps(ctx, qall, reqs, ix, 5.0)
+    got = fq.retrieve_batch(ctx, batch, std, [np.array(sp[3], np.uint32) for sp in specs], qms, qall, [sp[0] for sp in specs])
+    assert [len(g) for g in got] == [len(w) for w in singles] and len(got[0]) == 6 and got[3] == []
+    for g, w in zip(got, singles):
+        for a, b in zip(g, w):
+            assert a["cand"] == b["cand"] and a["processed"] == b["processed"] and a["from_hash"] == b["from_hash"] and a["same"] == b["same"]
+            for f in ("idf", "rmsd", "rmsd_from_hash"):
+                assert np.float32(a[f]).tobytes() == np.float32(b[f]).tobytes(), f
+            assert a["rot"].tobytes() == b["rot"].tobytes() and a["tran"].tobytes() == b["tran"].tobytes() and a["metrics"].tobytes() == b["metrics"].tobytes()
