@@ -254,11 +254,17 @@ def sample_query_hashes(index: FolddiscoIndex, q_hash, sampling_ratio=None, samp
     return order[: max(0, min(keep, n))]
 
 
+MATCH_DTYPE = np.dtype([("cand", np.uint32), ("same", np.uint32), ("idf", np.float32), ("rmsd", np.float32), ("rmsd_from_hash", np.float32),
+                        ("rot", np.float32, (9,)), ("tran", np.float32, (3,)), ("metrics", np.float32, (5,))])
+
+
 def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Batch, q_structs, ca_distance_cutoff=1.0, node_count=2,
-                   nbin_dist=0, nbin_angle=0, dist_cutoff=20.0):
+                   nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, as_arrays=False):
     """retrieve() for many queries with one pair scan / gather / Kabsch launch in total (fdgpu_retrieve_batch).  cands[t]:
     candidate structure indices of query t, qms[t] its QueryMapResult, q_structs[t] its structure in qbatch.
-    -> list (per query) of lists of match dicts like retrieve()."""
+    -> list (per query) of lists of match dicts like retrieve(); with as_arrays=True the raw tables instead:
+    (matches MATCH_DTYPE[], match_off u64[T+1], residues int32[], res_off u64[T+1]) — 2 * len(qms[t].indices) residue indices
+    per match (from-hash mapping, then processed mapping)."""
     T = len(qms)
     cl = [np.ascontiguousarray(c, dtype=np.uint32) for c in cands]
     cand_off = np.concatenate([[0], np.cumsum([len(c) for c in cl])]).astype(np.uint64)
@@ -272,6 +278,17 @@ def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Bat
     ctx.check(ctx.L.fdgpu_retrieve_batch(ctx.h, db.h, None if std is None else std.ctypes.data_as(u8p), T, cand.ctypes.data_as(u32p),
                                          cand_off.ctypes.data_as(u64p), handles, qbatch.h, qs.ctypes.data_as(u32p), C.byref(p), ca_distance_cutoff,
                                          node_count, C.byref(mp), C.byref(mo), C.byref(rp), C.byref(ro)))
+    if as_arrays:
+        moff = np.ctypeslib.as_array(mo, shape=(T + 1,)).copy()
+        roff = np.ctypeslib.as_array(ro, shape=(T + 1,)).copy()
+        nm, nr = int(moff[-1]), int(roff[-1])
+        assert C.sizeof(MatchRec) == MATCH_DTYPE.itemsize
+        marr = np.ctypeslib.as_array(C.cast(mp, C.POINTER(C.c_uint8)), shape=(max(nm, 1) * MATCH_DTYPE.itemsize,))[: nm * MATCH_DTYPE.itemsize].copy().view(MATCH_DTYPE)
+        rarr = np.ctypeslib.as_array(rp, shape=(max(nr, 1),))[:nr].copy()
+        ctx.L.fdgpu_matches_free(mp, rp)
+        ctx.L.fdgpu_free(mo)
+        ctx.L.fdgpu_free(ro)
+        return marr, moff, rarr, roff
     out = []
     for t in range(T):
         nq = len(qms[t].indices)

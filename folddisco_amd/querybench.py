@@ -113,7 +113,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                     else:
                         tot += n
                 if match:   # one pair scan / gather / Kabsch launch for the whole chunk of queries
-                    tot += sum(len(m) for m in retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks)))
+                    tot += len(retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0])
             return tot
         go()
         torch.cuda.synchronize()

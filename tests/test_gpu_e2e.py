@@ -414,6 +414,9 @@ def test_retrieve_batch_equals_single(env):
     qms = fq.make_query_maps(ctx, qall, reqs, ix, 5.0)
     got = fq.retrieve_batch(ctx, batch, std, [np.array(sp[3], np.uint32) for sp in specs], qms, qall, [sp[0] for sp in specs])
     assert [len(g) for g in got] == [len(w) for w in singles] and len(got[0]) == 6 and got[3] == []
+    marr, moff, rarr, roff = fq.retrieve_batch(ctx, batch, std, [np.array(sp[3], np.uint32) for sp in specs], qms, qall, [sp[0] for sp in specs], as_arrays=True)
+    assert moff.tolist() == np.concatenate([[0], np.cumsum([len(g) for g in got])]).tolist() and len(marr) == moff[-1]
+    assert [float(x) for x in marr["rmsd"][:6]] == [g["rmsd"] for g in got[0]] and rarr[:3].tolist() == got[0][0]["from_hash"]
     for g, w in zip(got, singles):
         for a, b in zip(g, w):
             assert a["cand"] == b["cand"] and a["processed"] == b["processed"] and a["from_hash"] == b["from_hash"] and a["same"] == b["same"]
