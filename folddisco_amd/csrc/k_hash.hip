@@ -179,7 +179,7 @@ __device__ __attribute__((noinline)) uint2 pair_both_tab_exact(const fd_frame *_
 template <int TAB, bool IDS16>
 __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *__restrict__ frames, const fd_hash_consts &C,
                                        const uint32_t *tab, const uint32_t *q, uint32_t n, uint32_t i0, uint32_t r0, uint32_t s, uint32_t id,
-                                       const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys, void *ids) {
+                                       const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys, void *ids, const float4 *s_fi) {
     const uint32_t lane = threadIdx.x;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&cursor[s], 2u * n);
@@ -189,7 +189,13 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
         uint32_t i = i0 + (e >> 16), j = r0 + (e & 0xffffu);
         uint32_t h_ij, h_ji;
         if (TAB == 2) {
-            fd_frame Fi = load_frame(frames, i), Fj = load_frame(frames, j);
+            // frame of i from the work item's LDS-staged residue tile ([k][lane] float4 planes), frame of j from L2
+            const uint32_t il = e >> 16;
+            const float4 a4 = s_fi[il], b4 = s_fi[64 + il], c4 = s_fi[128 + il], d4 = s_fi[192 + il], e4 = s_fi[256 + il];
+            fd_frame Fi;
+            Fi.ca = {a4.x, a4.y, a4.z}; Fi.cb = {a4.w, b4.x, b4.y}; Fi.r1 = {b4.z, b4.w, c4.x}; Fi.t1 = {c4.y, c4.z, c4.w};
+            Fi.s2 = {d4.x, d4.y, d4.z}; Fi.nv2 = {d4.w, e4.x, e4.y}; Fi.len = e4.z; Fi.pad = e4.w;
+            fd_frame Fj = load_frame(frames, j);
             if (!fd_pair_both_spec(Fi, Fj, B.aa[i], B.aa[j], C.q, tab, tab + 32, &h_ij, &h_ji)) {
                 uint2 h = pair_both_tab_exact(frames, i, j, B.aa[i], B.aa[j], C.q.dist_disc, C.q.ang_disc, tab);
                 h_ij = h.x; h_ji = h.y;
@@ -244,6 +250,15 @@ __global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_
     const bool vi = i < r1 && B.hash_ok[i];
     fd_v3 cai = {0.f, 0.f, 0.f};
     if (vi) cai = fd_load3(B.ca_xyz, i);
+    // LDS staging of the work item's residue tile: the 64 frames of the i side (5 KB), plane-major so that the fill is
+    // conflict-free; every drain reads its i frames from here instead of gathering them from L2 again
+    __shared__ float4 s_fi[5 * FD_WAVE];
+    if (TAB == 2 && i < r1) {
+        const float4 *fp = reinterpret_cast<const float4 *>(frames + i);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s_fi[k * FD_WAVE + lane] = fp[k];
+    }
+    __syncthreads();
     uint32_t qn = 0;  // wave-uniform
     // single drain site (two inlined copies of the descriptor code would not fit the I-cache); the queue is
     // flushed on the last candidate. j is walked in blocks of 64: one coalesced load per block, then v_readlane
@@ -273,7 +288,7 @@ __global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_
                 __syncthreads();
                 uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
                 qn -= n;
-                drain2<TAB, IDS16>(B, frames, C, tab, q + qn, n, i0, r0, s, first_id + s, seg_off, cursor, keys, ids);
+                drain2<TAB, IDS16>(B, frames, C, tab, q + qn, n, i0, r0, s, first_id + s, seg_off, cursor, keys, ids, s_fi);
                 __syncthreads();
             }
         }
