@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void k_frames(fd_batch_view B, uint32_t n_res,
     fd_frame F;
     if (B.hash_ok[r]) F = fd_make_frame(fd_load3(B.n_xyz, r), fd_load3(B.ca_xyz, r), fd_load3(B.cb_xyz, r));
     else { F = fd_frame{}; F.ca = fd_load3(B.ca_xyz, r); }
+    F.pad = __uint_as_float((uint32_t)B.aa[r]);   // the residue type rides in the frame's spare word (bit pattern, never computed with)
     frames[r] = F;
 }
 
@@ -196,7 +197,7 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
             Fi.ca = {a4.x, a4.y, a4.z}; Fi.cb = {a4.w, b4.x, b4.y}; Fi.r1 = {b4.z, b4.w, c4.x}; Fi.t1 = {c4.y, c4.z, c4.w};
             Fi.s2 = {d4.x, d4.y, d4.z}; Fi.nv2 = {d4.w, e4.x, e4.y}; Fi.len = e4.z; Fi.pad = e4.w;
             fd_frame Fj = load_frame(frames, j);
-            if (!fd_pair_both_spec(Fi, Fj, B.aa[i], B.aa[j], C.q, tab, tab + 32, &h_ij, &h_ji)) {
+            if (!fd_pair_both_spec(Fi, Fj, __float_as_uint(Fi.pad), __float_as_uint(Fj.pad), C.q, tab, tab + 32, &h_ij, &h_ji)) {
                 uint2 h = pair_both_tab_exact(frames, i, j, B.aa[i], B.aa[j], C.q.dist_disc, C.q.ang_disc, tab);
                 h_ij = h.x; h_ji = h.y;
                 if (C.spec_miss) atomicAdd(C.spec_miss, 1ull);
