@@ -71,15 +71,16 @@ def cmd_index(a):
     n_hashes = value_len = 0
     for c0 in range(0, len(paths), a.chunk):
         chunk = paths[c0:c0 + a.chunk]
-        structs, ok = structure.read_compact_structures(chunk, threads=a.threads, max_residue=a.max_residue)
-        for p, s, good in zip(chunk, structs, ok):
-            if not good:
-                print(f"[WARN] {p} could not be read. Skipping", file=sys.stderr)
-            elif s.num_residues_raw > a.max_residue > 0:
-                print(f"[WARN] {p} has too many residues. Skipping", file=sys.stderr)
-        nres_all.append(np.array([s.n for s in structs], np.uint64))
-        plddt_all.append(np.array([s.avg_plddt() if s.n else 0.0 for s in structs], np.float32))
-        batch = ctx.upload(fd.PackedStructures.concat([s.as_item() for s in structs]))
+        # native ingest straight into the flat batch layout (csrc/fd_ingest.cpp), no per-structure Python objects
+        ps, nres_c, plddt_c, raw, ok = structure.read_packed(chunk, threads=a.threads, max_residue=a.max_residue)
+        for k in np.nonzero(ok == 0)[0]:
+            print(f"[WARN] {chunk[k]} could not be read. Skipping", file=sys.stderr)
+        if a.max_residue > 0:
+            for k in np.nonzero(raw > a.max_residue)[0]:
+                print(f"[WARN] {chunk[k]} has too many residues. Skipping", file=sys.stderr)
+        nres_all.append(nres_c)
+        plddt_all.append(np.where(nres_c > 0, plddt_c, np.float32(0.0)).astype(np.float32))
+        batch = ctx.upload(ps)
         ix = fd.FolddiscoIndex.build(ctx, batch, first_id=c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid)
         if len(paths) <= a.chunk:
             ix.save(prefix)                       # single chunk: the library writes PREFIX and PREFIX.offset itself
@@ -103,15 +104,16 @@ def _build_chunks(a, fd, structure, ctx, paths, first_id):
     nres_all, plddt_all, parts = [], [], []
     for c0 in range(0, len(paths), a.chunk):
         chunk = paths[c0:c0 + a.chunk]
-        structs, ok = structure.read_compact_structures(chunk, threads=a.threads, max_residue=a.max_residue)
-        for p, s, good in zip(chunk, structs, ok):
-            if not good:
-                print(f"[WARN] {p} could not be read. Skipping", file=sys.stderr)
-            elif s.num_residues_raw > a.max_residue > 0:
-                print(f"[WARN] {p} has too many residues. Skipping", file=sys.stderr)
-        nres_all.append(np.array([s.n for s in structs], np.uint64))
-        plddt_all.append(np.array([s.avg_plddt() if s.n else 0.0 for s in structs], np.float32))
-        batch = ctx.upload(fd.PackedStructures.concat([s.as_item() for s in structs]))
+        # native ingest straight into the flat batch layout (csrc/fd_ingest.cpp), no per-structure Python objects
+        ps, nres_c, plddt_c, raw, ok = structure.read_packed(chunk, threads=a.threads, max_residue=a.max_residue)
+        for k in np.nonzero(ok == 0)[0]:
+            print(f"[WARN] {chunk[k]} could not be read. Skipping", file=sys.stderr)
+        if a.max_residue > 0:
+            for k in np.nonzero(raw > a.max_residue)[0]:
+                print(f"[WARN] {chunk[k]} has too many residues. Skipping", file=sys.stderr)
+        nres_all.append(nres_c)
+        plddt_all.append(np.where(nres_c > 0, plddt_c, np.float32(0.0)).astype(np.float32))
+        batch = ctx.upload(ps)
         ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id + c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid)
         parts.append(ix.export())
         del ix, batch

@@ -355,7 +355,8 @@ extern "C" int fdgpu_parse_structures(const char *const *paths, uint64_t n, uint
             }
         }
     };
-    uint32_t T = n_threads ? n_threads : std::max(1u, std::thread::hardware_concurrency());
+    // default: every core up to 64 (measured on the 256-thread MI355X host: 19.6 k files/s at 64 threads, 11 k at 256)
+    uint32_t T = n_threads ? n_threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
     T = (uint32_t)std::min<uint64_t>(T, std::max<uint64_t>(n, 1));
     std::vector<std::thread> th;
     for (uint32_t t = 1; t < T; ++t) th.emplace_back(work);

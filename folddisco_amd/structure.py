@@ -222,3 +222,27 @@ def read_compact_structures(paths, threads: int = 0, max_residue: int = 0):
                                     bf[a:b], chains, int(raw[k])))
     L.fdgpu_parsed_free(out)
     return res, okf
+
+
+def read_packed(paths, threads: int = 0, max_residue: int = 0):
+    """Native ingest straight into the flat batch layout (no per-structure Python objects): -> (PackedStructures, nres u64[S],
+    plddt f32[S], nres_raw u64[S], ok u8[S]).  What the index workflow needs: coordinates for the GPU, nres / plddt for .lookup."""
+    import ctypes as C
+    from . import _lib
+    from .api import PackedStructures
+    L = _lib.load()
+    arr = (C.c_char_p * max(len(paths), 1))(*[os.fsencode(p) for p in paths])
+    out = C.POINTER(_lib.Parsed)()
+    rc = L.fdgpu_parse_structures(arr, len(paths), threads, max_residue, C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"fdgpu_parse_structures failed ({rc})")
+    P = out.contents
+    S, R = P.n_struct, P.n_res
+    view = lambda ptr, n, dt: (np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].astype(dt, copy=True))
+    off = view(P.res_off, S + 1, np.uint64)
+    ps = PackedStructures(off, view(P.n_xyz, 3 * R, np.float32).reshape(-1, 3), view(P.ca_xyz, 3 * R, np.float32).reshape(-1, 3),
+                          view(P.cb_xyz, 3 * R, np.float32).reshape(-1, 3), view(P.aa, R, np.uint8), view(P.cb_valid, R, np.uint8))
+    nres = np.diff(off).astype(np.uint64)
+    plddt, raw, okf = view(P.plddt, S, np.float32), view(P.nres_raw, S, np.uint64), view(P.ok, S, np.uint8)
+    L.fdgpu_parsed_free(out)
+    return ps, nres, plddt, raw, okf
