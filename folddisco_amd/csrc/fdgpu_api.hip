@@ -270,7 +270,8 @@ static int ensure_sort_ws(fdgpu_ctx *c, uint64_t P) {
     HIPCHK(c, c->ws[WS_KEYS_B].ensure(kb));
     HIPCHK(c, c->ws[WS_IDS_B].ensure(kb));
     HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * std::max<uint32_t>(fd_rs_num_tiles(P), 1) * 4));
-    HIPCHK(c, c->ws[WS_TOT].ensure(256 * 8));
+    // 256 digit totals + the chunk sums of the tile-major histogram scan ([tiles / 128][256] u64)
+    HIPCHK(c, c->ws[WS_TOT].ensure((256 + (size_t)(fd_rs_num_tiles(P) / 128 + 2) * 256) * 8));
     return FDGPU_OK;
 }
 

@@ -113,7 +113,8 @@ uint64_t fd_scan_tmp_elems(uint64_t n) { return (n + SCAN_CHUNK - 1) / SCAN_CHUN
 // ------------------------------------------------------------------------ radix sort
 #define RS_BINS 256
 
-// tile histogram -> ghist[digit * nb + tile]
+// tile histogram -> ghist[tile * 256 + digit]  (tile-major: a tile's 256 counts are one 1 KiB line group — the hist kernel
+// writes them and the scatter kernel reads them with ONE coalesced access instead of 256 strided 4-byte ones)
 template <int THREADS, int ITEMS, bool XCD>
 __global__ __launch_bounds__(THREADS) void k_rs_hist(const uint32_t *__restrict__ keys, uint64_t n, uint32_t shift, uint32_t mask,
                                                      uint32_t *__restrict__ ghist, uint32_t nb) {
@@ -144,28 +145,44 @@ __global__ __launch_bounds__(THREADS) void k_rs_hist(const uint32_t *__restrict_
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < RS_BINS; k += THREADS) ghist[(uint64_t)k * nb + tile] = h[k];
+    for (int k = threadIdx.x; k < RS_BINS; k += THREADS) ghist[(uint64_t)tile * RS_BINS + k] = h[k];
 }
 
-// one workgroup per digit: exclusive scan of its row of nb tile counts (in place), row total -> tot[d];
-// 8 consecutive counts per thread and iteration
-__global__ __launch_bounds__(1024) void k_rs_scan_rows(uint32_t *__restrict__ ghist, uint32_t nb, uint64_t *__restrict__ tot) {
-    __shared__ uint64_t sm[17];
-    uint32_t *row = ghist + (uint64_t)blockIdx.x * nb;
-    uint64_t carry = 0;
-    for (uint32_t b = 0; b < nb; b += 1024 * 8) {
-        uint32_t i0 = b + threadIdx.x * 8;
-        uint32_t v[8];
-        uint64_t s = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { v[k] = (i0 + k) < nb ? row[i0 + k] : 0u; s += v[k]; }
-        uint64_t t;
-        uint64_t ex = carry + block_excl_scan_u64(s, sm, &t);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { if (i0 + k < nb) row[i0 + k] = (uint32_t)ex; ex += v[k]; }
-        carry += t;
+// Exclusive scan over tiles of every digit's count, in place on the tile-major table (thread = digit, so every access is a
+// coalesced 1 KiB row): chunk sums -> scan of the chunk sums per digit (+ digit totals) -> apply.
+#define RS_SCAN_CHUNK 128   // tiles per workgroup
+__global__ __launch_bounds__(RS_BINS) void k_rs_scan_csum(const uint32_t *__restrict__ ghist, uint32_t nb, uint64_t *__restrict__ csum) {
+    const uint32_t t0 = blockIdx.x * RS_SCAN_CHUNK, t1 = t0 + RS_SCAN_CHUNK < nb ? t0 + RS_SCAN_CHUNK : nb;
+    uint64_t s = 0;
+#pragma unroll 8
+    for (uint32_t t = t0; t < t1; ++t) s += ghist[(uint64_t)t * RS_BINS + threadIdx.x];
+    csum[(uint64_t)blockIdx.x * RS_BINS + threadIdx.x] = s;
+}
+// 16 workgroups of 16 digits x 64 parts: thread (digit d, part p) scans 1/64 of the chunk sums of digit d; the 64 partial totals are
+// combined in LDS
+__global__ __launch_bounds__(1024) void k_rs_scan_chunks(uint64_t *__restrict__ csum, uint32_t n_chunks, uint64_t *__restrict__ tot) {
+    __shared__ uint64_t part[64][16];
+    const uint32_t dl = threadIdx.x & 15u, p = threadIdx.x >> 4, d = blockIdx.x * 16u + dl;
+    const uint32_t per = (n_chunks + 63) / 64, c0 = p * per < n_chunks ? p * per : n_chunks, c1 = c0 + per < n_chunks ? c0 + per : n_chunks;
+    uint64_t s = 0;
+#pragma unroll 4
+    for (uint32_t c = c0; c < c1; ++c) s += csum[(uint64_t)c * RS_BINS + d];
+    part[p][dl] = s;
+    __syncthreads();
+    uint64_t run = 0;
+    for (uint32_t q = 0; q < p; ++q) run += part[q][dl];
+    if (p == 63) tot[d] = run + s;
+    for (uint32_t c = c0; c < c1; ++c) { uint64_t v = csum[(uint64_t)c * RS_BINS + d]; csum[(uint64_t)c * RS_BINS + d] = run; run += v; }
+}
+__global__ __launch_bounds__(RS_BINS) void k_rs_scan_apply(uint32_t *__restrict__ ghist, uint32_t nb, const uint64_t *__restrict__ csum) {
+    const uint32_t t0 = blockIdx.x * RS_SCAN_CHUNK, t1 = t0 + RS_SCAN_CHUNK < nb ? t0 + RS_SCAN_CHUNK : nb;
+    uint32_t run = (uint32_t)csum[(uint64_t)blockIdx.x * RS_BINS + threadIdx.x];   // positions inside one digit bucket fit 32 bits (n < 2^32)
+#pragma unroll 8
+    for (uint32_t t = t0; t < t1; ++t) {
+        uint32_t v = ghist[(uint64_t)t * RS_BINS + threadIdx.x];
+        ghist[(uint64_t)t * RS_BINS + threadIdx.x] = run;
+        run += v;
     }
-    if (threadIdx.x == 0) tot[blockIdx.x] = carry;
 }
 __global__ __launch_bounds__(RS_BINS) void k_rs_scan_tot(uint64_t *__restrict__ tot) {
     __shared__ uint64_t sm[17];
@@ -211,7 +228,7 @@ __device__ __forceinline__ void rs_scatter4_body(const uint32_t *__restrict__ ke
         val[c] = ok ? vp[c * 64] : (V)0;
     }
     long long gbase = 0;
-    if (tid < RS_BINS) gbase = (long long)(dbase[tid] + ghist[(uint64_t)tid * nb + tile]);
+    if (tid < RS_BINS) gbase = (long long)(dbase[tid] + ghist[(uint64_t)tile * RS_BINS + tid]);
     __syncthreads();
     uint32_t rnk[ITEMS];
     uint32_t *cnt = s_cnt[wid];
@@ -358,7 +375,11 @@ static void rs_pass4(uint32_t *ki, V *vi, uint32_t *ko, V *vo, uint64_t n, uint3
     }
     {
         StageTimer t(tc, "rs_scan", (uint64_t)nb * RS_BINS * 8);
-        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, st, ghist, nb, tot);
+        const uint32_t n_chunks = (nb + RS_SCAN_CHUNK - 1) / RS_SCAN_CHUNK;
+        uint64_t *csum = tot + RS_BINS;   // [n_chunks][256] behind the 256 digit totals
+        hipLaunchKernelGGL(k_rs_scan_csum, dim3(n_chunks), dim3(RS_BINS), 0, st, ghist, nb, csum);
+        hipLaunchKernelGGL(k_rs_scan_chunks, dim3(RS_BINS / 16), dim3(1024), 0, st, csum, n_chunks, tot);
+        hipLaunchKernelGGL(k_rs_scan_apply, dim3(n_chunks), dim3(RS_BINS), 0, st, ghist, nb, csum);
         hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(RS_BINS), 0, st, tot);
     }
     {
