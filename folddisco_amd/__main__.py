@@ -215,7 +215,8 @@ def cmd_query(a):
             for r in rows:
                 fh.write(query.format_structure_row(r, qstr) + "\n")
         else:
-            cols = [c.strip() for c in a.format_output.split(",") if c.strip()] or ["tid", "node_count", "idf", "rmsd", "matching_residues", "query_residues"]
+            cols = [c.strip() for c in a.format_output.split(",") if c.strip()] or \
+                (query.MATCH_SUPERPOSE_COLUMNS if a.superpose else ["tid", "node_count", "idf", "rmsd", "matching_residues", "query_residues"])
             for c in cols:
                 if c not in query.MATCH_COLUMNS:
                     sys.exit(f"[FAIL] unknown --format-output column '{c}' (per-match: {', '.join(query.MATCH_COLUMNS)})")
@@ -281,6 +282,7 @@ def main(argv=None):
     pq.add_argument("--chamfer", type=float, default=0.0)
     pq.add_argument("--hausdorff", type=float, default=0.0)
     pq.add_argument("--format-output", default="")
+    pq.add_argument("--superpose", action="store_true")              # print U, T and the matching C-alpha coordinates
     pq.add_argument("--sort-by", default="node_count,rmsd")          # query_pdb.rs:573
     pq.add_argument("--length-penalty", type=float, default=None)
     pq.add_argument("-o", "--output", default="")

@@ -393,6 +393,7 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
             m["cand"] = owned[m["cand"]]                                                 # -> position in `rows`
             t = db_structs[rows[m["cand"]]["nid"] - lo]
             m["labels"] = ["_" if x < 0 else f"{chr(int(t.chain[x]))}{int(t.serial[x])}" for x in m["processed"]]
+            m["ca"] = np.array([t.ca_xyz[x] for x in m["processed"] if x >= 0], np.float32).reshape(-1, 3)   # matching C-alpha coordinates
         if shard is not None:
             import torch.distributed as tdist
             if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
@@ -407,7 +408,7 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
                       matching_residues=",".join(lab(m["processed"])), query_residues=res_chain_to_string(qres) if qres else query_string,
                       tm_score=float(m["metrics"][0]), gdt_ts=float(m["metrics"][1]), gdt_ha=float(m["metrics"][2]),
                       chamfer_distance=float(m["metrics"][3]), hausdorff_distance=float(m["metrics"][4]), db_key=r["nid"],
-                      u_matrix=m["rot"], t_vector=m["tran"])
+                      u_matrix=m["rot"], t_vector=m["tran"], matching_coordinates=m["ca"])
             r["matches"].append(m2)
             cnt = m2["node_count"]
             if cnt > r["max_matching_node_count"]:
@@ -465,7 +466,13 @@ MATCH_COLUMNS = {
     "chamfer_distance": lambda m: "%.4f" % m["chamfer_distance"], "hausdorff_distance": lambda m: "%.4f" % m["hausdorff_distance"],
     "u_matrix": lambda m: ",".join("%.4f" % x for x in np.asarray(m["u_matrix"]).reshape(-1)),
     "t_vector": lambda m: ",".join("%.4f" % x for x in np.asarray(m["t_vector"]).reshape(-1)),
+    # target C-alpha coordinates of the matched residues, in query-residue order (the reference lists them in the order its
+    # rescue pass pushed them, retrieve.rs:769-771 — the same set)
+    "matching_coordinates": lambda m: ",".join("%.4f" % x for x in np.asarray(m["matching_coordinates"]).reshape(-1)),
 }
+# --superpose / --web column set (src/controller/result.rs:341-353)
+MATCH_SUPERPOSE_COLUMNS = ["tid", "node_count", "idf", "rmsd", "matching_residues", "u_matrix", "t_vector", "matching_coordinates", "db_key",
+                           "query_residues"]
 
 
 def format_match_columns(m, columns) -> str:

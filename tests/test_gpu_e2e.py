@@ -283,6 +283,13 @@ def test_cli_format_output_metrics(tmp_path):
     for r in rows[1:]:
         rmsd, tm, ts, ha, ch, hd = map(float, r[1:])
         assert 0.0 < tm < 1.0 and 0.0 <= ha <= ts <= 1.0 and 0.0 < ch <= hd and ch <= rmsd * 1.0001 + 1e-4
+    sup = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", pre, "--superpose"],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
+    f0 = sup[0].split("\t")                          # tid node_count idf rmsd matching_residues u_matrix t_vector matching_coordinates db_key query
+    assert len(f0) == 10 and f0[4] == "B57,B102,C195" and f0[8] == "4"
+    U = np.array(f0[5].split(","), float).reshape(3, 3)
+    assert np.allclose(U, np.eye(3), atol=1e-3) and np.allclose(np.array(f0[6].split(","), float), 0.0, atol=1e-2)   # the query on itself
+    assert len(f0[7].split(",")) == 9               # three C-alpha positions
     keep = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", pre, "--tm-score", "0.9"],
                           cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
     assert len(keep) == sum(float(r[2]) >= 0.9 for r in rows) and len(keep) >= 1
