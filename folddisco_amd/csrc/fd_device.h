@@ -26,6 +26,8 @@ struct fd_hash_consts {
     float d2_max;   // largest f32 whose sqrt is <= dist_cutoff: sqrtf(d2) > cutoff  <=>  d2 > d2_max
     int use_tab;    // 1: default 4 angle bins -> table form of the angle fields (fd_bin_tables.h); 2: + speculative torsions
     unsigned long long *spec_miss;   // device counter of pairs the speculative path handed to the exact routine (may be null)
+    unsigned long long *wide_flag;   // set when a hash does not fit 30 bits (fields are OR-ed unmasked: an infinite distance sets
+                                     // bits 30-31) — the 6-byte sort elements keep 30 hash bits, the build is then redone with 8-byte ones
 };
 
 __device__ __forceinline__ fd_v3 fd_load3(const float *p, uint32_t r) {

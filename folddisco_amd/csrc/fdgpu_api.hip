@@ -339,7 +339,7 @@ extern "C" int fdgpu_hash_batch(fdgpu_ctx *c, const fdgpu_batch *b, const fd_has
     uint32_t *kb = c->ws[WS_KEYS_B].as<uint32_t>(), *ib = c->ws[WS_IDS_B].as<uint32_t>();
     fd_launch_pair_emit(b->view(), C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, ia, 0u, st);
     // sort by hash, then (stable) by structure -> (structure, hash) order
-    int cur = sort_pairs(c, ka, ia, kb, ib, P, 30);
+    int cur = sort_pairs(c, ka, ia, kb, ib, P, 32);   // all 32 bits: unmasked field overflow can set bits 30-31
     uint32_t *k1 = cur ? kb : ka, *i1 = cur ? ib : ia, *k2 = cur ? ka : kb, *i2 = cur ? ia : ib;
     int id_bits = 1;
     while (id_bits < 32 && (1ull << id_bits) < std::max<uint64_t>(S, 2)) ++id_bits;
@@ -380,7 +380,9 @@ extern "C" uint64_t fdgpu_index_num_hashes(const fdgpu_index *ix) { return ix ? 
 extern "C" uint64_t fdgpu_index_value_len(const fdgpu_index *ix) { return ix ? ix->value_len : 0; }
 extern "C" uint64_t fdgpu_index_num_postings(const fdgpu_index *ix) { return ix ? ix->n_postings : 0; }
 
-extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_params *p, uint64_t first_id, fdgpu_index **out) {
+// force32: 8-byte sort elements.  Returns FDGPU_RETRY_WIDE (internal) when the 6-byte form met a hash beyond 30 bits.
+#define FDGPU_RETRY_WIDE 1000
+static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_params *p, uint64_t first_id, fdgpu_index **out, bool force32) {
     if (!c || !b || !p || !out) return FDGPU_EINVAL;
     *out = nullptr;
     reset_timings(c);
@@ -400,11 +402,12 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
     if ((rc = ensure_sort_ws(c, P))) return rc;
     uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *kb = c->ws[WS_KEYS_B].as<uint32_t>();
     void *ia = c->ws[WS_IDS_A].p, *ib = c->ws[WS_IDS_B].p;
-    // shards of <= 2^18 structures use 6-byte sort elements (key = hash << 2 | local id bits 17:16, u16 payload);
-    // FDGPU_IDS32=1 forces the 8-byte form
-    const char *e32 = getenv("FDGPU_IDS32");   // read per call: tests flip it inside one process
-    const bool force32 = e32 && e32[0] == '1';
+    // shards of <= 2^18 structures use 6-byte sort elements (key = hash << 2 | local id bits 17:16, u16 payload) as long as
+    // every hash fits 30 bits; the 8-byte form (u32 hash, u32 id) otherwise
     const bool ids16 = !force32 && S <= (1ull << 18);
+    HIPCHK(c, c->ws[WS_MISC3].ensure(64));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_MISC3].p, 0, 64, st));
+    C.wide_flag = c->ws[WS_MISC3].as<unsigned long long>() + 3;
     {
         StageTimer t(c, "pair_emit", b->n_res * 37 + P * (ids16 ? 6 : 8));
         fd_launch_pair_emit2(b->view(), c->ws[WS_FRAMES].p, C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, ia, ids16,
@@ -413,7 +416,7 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
     int cur;
     (void)sort_mode();
     if (ids16) cur = fd_radix_sort_pairs16(ka, (uint16_t *)ia, kb, (uint16_t *)ib, P, 32, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st, c);
-    else cur = sort_pairs(c, ka, (uint32_t *)ia, kb, (uint32_t *)ib, P, 30);
+    else cur = sort_pairs(c, ka, (uint32_t *)ia, kb, (uint32_t *)ib, P, 32);   // all 32 bits: unmasked field overflow can set bits 30-31
     const uint32_t *ks = cur ? kb : ka;
     const void *is = cur ? ib : ia;
     uint32_t nt = std::max<uint32_t>(fd_enc_num_tiles(P), 1);
@@ -424,8 +427,7 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
     HIPCHK(c, c->ws[WS_TILE_HO].ensure((size_t)(nt + 2) * 8));
     HIPCHK(c, c->ws[WS_TILE_PO].ensure((size_t)(nt + 2) * 8));
     HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(std::max<uint64_t>(nt, S)) * 8 + 64));
-    HIPCHK(c, c->ws[WS_MISC3].ensure(64));
-    uint64_t tot[3] = {0, 0, 0};
+    uint64_t tot[4] = {0, 0, 0, 0};
     uint64_t nt_eff = P ? fd_enc_num_tiles(P) : 0;
     {
         StageTimer t(c, "encode_sizes", P * (ids16 ? 6 : 8));
@@ -439,8 +441,9 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
         fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_P].as<uint32_t>(), nt_eff, c->ws[WS_TILE_PO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 2, st);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_MISC3].p, 24, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_MISC3].p, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    if (ids16 && tot[3]) return FDGPU_RETRY_WIDE;
     fdgpu_index *ix = new (std::nothrow) fdgpu_index();
     if (!ix) return FDGPU_ENOMEM;
     ix->ctx = c; ix->value_len = tot[0]; ix->n_hashes = tot[1]; ix->n_postings = tot[2]; ix->n_structures = S; ix->first_id = first_id;
@@ -462,6 +465,13 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
     if (e != hipSuccess) { c->err = std::string("encode launch: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }
     *out = ix;
     return FDGPU_OK;
+}
+
+extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_params *p, uint64_t first_id, fdgpu_index **out) {
+    const char *e32 = getenv("FDGPU_IDS32");   // FDGPU_IDS32=1 forces the 8-byte sort elements (read per call: tests flip it)
+    int rc = index_build_impl(c, b, p, first_id, out, e32 && e32[0] == '1');
+    if (rc == FDGPU_RETRY_WIDE) rc = index_build_impl(c, b, p, first_id, out, true);
+    return rc;
 }
 
 extern "C" int fdgpu_index_export(fdgpu_ctx *c, const fdgpu_index *ix, uint8_t **value, uint64_t *value_len, uint32_t **hashes,

@@ -211,6 +211,7 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
         }
         uint64_t pos = seg_off[s] + base + lane;
         if (IDS16) {
+            if (((h_ij | h_ji) >> 30) && C.wide_flag) atomicOr(C.wide_flag, 1ull);   // does not fit hash << 2: the caller rebuilds with 8-byte elements
             uint32_t hi = s >> 16;
             uint16_t lo = (uint16_t)(s & 0xffffu);
             keys[pos] = (h_ij << 2) | hi;

@@ -380,3 +380,60 @@ def test_index_set_equals_single_index(ctx):
     want = fd.count_query(ctx, single, qh, qi, qj, pen, as_array=True)
     got = fd.count_query_set(ctx, iset, qh, qi, qj, pen)
     assert got.tobytes() == want.tobytes() and len(got) > 50
+
+
+@pytest.mark.gpu
+def test_degenerate_geometry_matches_oracle(ctx):
+    """Bit-exactness where the arithmetic degenerates: CB on top of CA (zero-length vectors -> NaN angles), duplicated residues
+    (distance 0), collinear N-CA-CB (zero cross products), residues on a perfect line / lattice (torsion operands exactly 0 ->
+    the atan2 special cases), huge and non-finite coordinates.  The raw hash lists (S1, generic chain) and the index (frames,
+    tables, speculative path with its exact fallback) must both equal the oracle."""
+    import folddisco_amd as fd
+    rng = np.random.Generator(np.random.PCG64(123))
+    items = []
+
+    def add(n_xyz, ca_xyz, cb_xyz, aa=None):
+        n = len(ca_xyz)
+        items.append(dict(n_xyz=np.asarray(n_xyz, np.float32), ca_xyz=np.asarray(ca_xyz, np.float32), cb_xyz=np.asarray(cb_xyz, np.float32),
+                          aa=np.asarray(aa if aa is not None else rng.integers(0, 20, n), np.uint8)))
+    base = rng.normal(0, 6, (24, 3)).astype(np.float32)
+    off = lambda s: (base + rng.normal(0, s, base.shape)).astype(np.float32)
+    add(off(1.0), base, base.copy())                                   # CB == CA
+    add(base + 1.0, base, base + np.float32(2.0))                      # N, CA, CB collinear
+    dup = np.repeat(base[:8], 3, axis=0)
+    add(dup + rng.normal(0, 1, dup.shape), dup, dup + rng.normal(0, 1, dup.shape))     # duplicated CA positions (distance 0)
+    line = np.stack([np.arange(20) * 3.8, np.zeros(20), np.zeros(20)], axis=1).astype(np.float32)
+    add(line + [0, 1.46, 0], line, line + [0, 0, 1.53])                # perfect line, parallel frames: torsion operands exactly 0
+    g = np.stack(np.meshgrid(np.arange(3), np.arange(3), np.arange(3)), -1).reshape(-1, 3).astype(np.float32) * 4.0
+    add(g + [1, 0, 0], g, g + [0, 1, 0])                               # cubic lattice
+    big = off(1.0) * np.float32(1e7)
+    add(big + 1.0, big, big - 1.0)                                     # huge coordinates (all pairs beyond the cutoff or absorbed)
+    weird = base.copy(); wn = off(1.0); wb = off(1.0)
+    weird[3, 0] = np.nan; wn[5, 1] = np.inf; wb[7, 2] = -np.inf; weird[9] = 0.0; wn[9] = 0.0; wb[9] = 0.0
+    add(wn, weird, wb)                                                 # NaN / inf coordinates, an all-zero residue
+    tiny = (base * np.float32(1e-20)).astype(np.float32)
+    add(tiny + np.float32(1e-21), tiny, tiny - np.float32(1e-21))      # denormal-scale differences
+    ps = fd.PackedStructures.concat(items)
+    batch = ctx.upload(ps)
+    structs = packed_to_oracle_structs(ps)
+    raw, roff = fd.get_geometric_hash_as_u32(ctx, batch, sort_dedup=False)
+    for s, st in enumerate(structs):
+        want = oracle.hash_structure(st)
+        assert np.array_equal(raw[int(roff[s]):int(roff[s + 1])], want), f"structure {s}"
+    # index of everything: an infinite distance saturates the quantiser and the unmasked OR sets hash bits 30-31 — beyond the
+    # reference's 2^30-entry table (it would panic there), so this part is checked against the S1 lists: the build must keep
+    # the full u32 (it falls back from 6-byte to 8-byte sort elements for such a shard)
+    ix = fd.FolddiscoIndex.build(ctx, batch)
+    v, h, o = ix.export()
+    assert raw.max() >= (1 << 30)
+    assert np.array_equal(h, np.unique(raw))
+    per_hash = [np.unique(np.repeat(np.arange(len(structs)), np.diff(roff).astype(np.int64))[raw == hh]) for hh in (h[0], h[len(h) // 2], h[-1])]
+    for hh, want_ids in zip((h[0], h[len(h) // 2], h[-1]), per_hash):
+        assert np.array_equal(ix.get_entries(np.array([hh], np.uint32))[0], want_ids)
+    # index of the finite structures against the oracle's index, byte for byte
+    keep = [k for k in range(len(items)) if k != 6]
+    ps2 = fd.PackedStructures.concat([items[k] for k in keep])
+    v2, h2, o2 = fd.FolddiscoIndex.build(ctx, ctx.upload(ps2)).export()
+    oix, _, _ = oracle.build_index(packed_to_oracle_structs(ps2))
+    assert np.array_equal(h2, oix.hashes()) and np.array_equal(o2, oix.offsets()) and np.array_equal(v2, oix.values())
+    assert len(h2) > 500
