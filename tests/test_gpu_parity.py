@@ -437,3 +437,26 @@ def test_degenerate_geometry_matches_oracle(ctx):
     oix, _, _ = oracle.build_index(packed_to_oracle_structs(ps2))
     assert np.array_equal(h2, oix.hashes()) and np.array_equal(o2, oix.offsets()) and np.array_equal(v2, oix.values())
     assert len(h2) > 500
+
+
+@pytest.mark.gpu
+def test_random_unknown_residues_and_missing_cb(ctx):
+    """randomly sprinkled unknown residue types (aa = 255) and residues without a CB (cb_valid = 0) — pairs with either are
+    rejected by get_single_feature (controller/feature.rs:11-24) — plus structures of 0, 1 and 2 residues: hash lists and index
+    equal the oracle's"""
+    import folddisco_amd as fd
+    from folddisco_amd import synth
+    rng = np.random.Generator(np.random.PCG64(77))
+    ps = synth.to_packed(synth.generate(70, seed=13, lengths=np.concatenate([[0, 1, 2, 2, 3], rng.integers(40, 180, 65)])))
+    aa = ps.aa.copy()
+    aa[rng.uniform(size=len(aa)) < 0.08] = 255
+    cbv = (rng.uniform(size=len(aa)) >= 0.1).astype(np.uint8)
+    ps = fd.PackedStructures(ps.res_off, ps.n_xyz, ps.ca_xyz, ps.cb_xyz, aa, cbv)
+    batch = ctx.upload(ps)
+    structs = packed_to_oracle_structs(ps)
+    h, off = fd.get_geometric_hash_as_u32(ctx, batch, sort_dedup=False)
+    for s, st in enumerate(structs):
+        assert np.array_equal(h[int(off[s]):int(off[s + 1])], oracle.hash_structure(st)), s
+    v, hh, oo = fd.FolddiscoIndex.build(ctx, batch).export()
+    oix, _, _ = oracle.build_index(structs)
+    assert np.array_equal(hh, oix.hashes()) and np.array_equal(oo, oix.offsets()) and np.array_equal(v, oix.values())
