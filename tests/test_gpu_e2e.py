@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from tests.helpers import Q1G2F, Q4CHA, SER
+from tests.helpers import Q1G2F, Q4CHA, SER, packed_to_oracle_structs
 
 pytestmark = pytest.mark.gpu
 
@@ -430,3 +430,52 @@ def test_retrieve_batch_equals_single(env):
             for f in ("idf", "rmsd", "rmsd_from_hash"):
                 assert np.float32(a[f]).tobytes() == np.float32(b[f]).tobytes(), f
             assert a["rot"].tobytes() == b["rot"].tobytes() and a["tran"].tobytes() == b["tran"].tobytes() and a["metrics"].tobytes() == b["metrics"].tobytes()
+
+
+@pytest.mark.gpu
+def test_synthetic_database_full_query_matches_oracle():
+    """Planted motif queries against a synthetic database (80 AFDB-shaped structures): query map, prefilter records (counts exact,
+    idf rel 1e-5), and retrieval of the top candidates (matched residues exact, subgraph idf rel 1e-6, RMSD 1e-4) against the
+    oracle — the README goldens only exercise five real structures."""
+    import torch
+    import folddisco_amd as fd
+    from folddisco_amd import dist as fdist
+    from folddisco_amd import query as fq
+    from folddisco_amd import querybench, synth
+    ctx = fd.Context(0)
+    S = 80
+    d = synth.generate(S, seed=2024)
+    ps = synth.to_packed(d)
+    batch = ctx.upload(ps)
+    ix = fd.FolddiscoIndex.build(ctx, batch)
+    structs = packed_to_oracle_structs(ps)
+    oix, onres, _ = oracle.build_index(structs)
+    nres = np.diff(ps.res_off).astype(np.uint64)
+    pen = fd.length_penalty(nres, 0.5)
+    n_checked = 0
+    for s, idx, item in querybench._pick_queries(d, S, 6, seed=99):
+        qb = ctx.upload(fd.PackedStructures.concat([item]))
+        qm = fq.make_query_map(ctx, qb, idx, None, ix, float(S))
+        oq = structs[s]
+        om = oracle.make_query_map(oq, ",".join(f"A{int(i) + 1}" for i in idx), oix, float(S))
+        oa = om.arrays()
+        assert np.array_equal(qm.hash, oa["hash"]) and np.array_equal(qm.qi, oa["qi"]) and np.array_equal(qm.qj, oa["qj"])
+        recs = fd.count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S, as_array=True)
+        want = oracle.count_query(om, oix, onres)
+        assert [int(r["nid"]) for r in recs] == [w["nid"] for w in want]
+        for r, w in zip(recs, want):
+            assert (int(r["total_match_count"]), int(r["node_count"]), int(r["edge_count"])) == (w["total_match_count"], w["node_count"], w["edge_count"])
+            assert float(r["idf"]) == pytest.approx(w["idf"], rel=1e-5)
+        assert s in recs["nid"]
+        cand = fdist.rank_hits(recs, 10)["nid"].astype(np.uint32)
+        got = fq.retrieve(ctx, batch, None, cand, qm, qb)
+        for slot, nid in enumerate(cand):
+            R = oracle.retrieve(structs[int(nid)], oq, om)
+            mine = [g for g in got if g["cand"] == slot]
+            assert len(mine) == len(R["processed"]), (s, nid)
+            for g, rp, rh in zip(mine, R["processed"], R["from_hash"]):
+                assert g["processed"] == [-1 if x is None else x[2] for x in rp["residues"]]
+                assert g["from_hash"] == [-1 if x is None else x[2] for x in rh["residues"]]
+                assert abs(g["rmsd"] - rp["rmsd"]) <= 1e-4 and g["idf"] == pytest.approx(rp["idf"], rel=1e-6)
+                n_checked += 1
+    assert n_checked >= 6      # at least every query's own structure matches itself
