@@ -198,7 +198,7 @@ def cmd_query(a):
                                         freq_filter=a.freq_filter, length_penalty_power=0.5 if a.length_penalty is None else a.length_penalty,
                                         dist_cutoff=float(cfg.get("grid_width", 20.0)), nbin_dist=int(cfg.get("num_bin_dist", 0)),
                                         nbin_angle=int(cfg.get("num_bin_angle", 0)), sampling_ratio=a.sampling_ratio,
-                                        sampling_count=a.sampling_count, sort_by=a.sort_by,
+                                        sampling_count=a.sampling_count, sort_by=a.sort_by, partial_fit=a.partial_fit,
                                         filters=dict(total_match=a.total_match, covered_node=a.covered_node, covered_node_ratio=a.covered_node_ratio,
                                                      max_node=a.max_node, max_node_ratio=a.max_node_ratio, score=a.score,
                                                      connected_node=a.connected_node, connected_node_ratio=a.connected_node_ratio,
@@ -258,6 +258,7 @@ def main(argv=None):
     pq.add_argument("--ca-distance", type=float, default=1.0)
     pq.add_argument("--top", type=int, default=None)
     pq.add_argument("--skip-match", action="store_true")
+    pq.add_argument("--partial-fit", action="store_true")            # LMS superposition for matches of > 3 residues (cli/main.rs:92)
     pq.add_argument("--per-structure", action="store_true")
     pq.add_argument("--per-match", action="store_true")
     pq.add_argument("--header", action="store_true")

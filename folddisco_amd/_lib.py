@@ -93,6 +93,7 @@ SYMBOLS = [
     ("fdgpu_match_pairs", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(MatchQuery), C.POINTER(HashParams),
                                     C.POINTER(C.POINTER(PairRec)), u64p, C.POINTER(C.POINTER(CandRec)), u64p]),
     ("fdgpu_kabsch_batch", C.c_int, [VP, f32p, f32p, u64p, C.c_uint64, f32p, f32p, f32p]),
+    ("fdgpu_lms_qcp_batch", C.c_int, [VP, f32p, f32p, u64p, C.c_uint64, f32p, f32p, f32p, u32p, u32p]),
     ("fdgpu_last_timings", C.c_int, [VP, C.POINTER(C.c_char_p), f32p, u64p, C.c_int]),
     ("fdgpu_enable_timing", C.c_int, [VP, C.c_int]),
     ("fdgpu_pair_features", C.c_int, [VP, VP, C.c_uint64, u32p, u32p, C.c_uint64, C.POINTER(HashParams), f32p, u8p]),
@@ -103,9 +104,9 @@ SYMBOLS = [
                                        C.POINTER(HashParams), VP, C.c_float, C.POINTER(C.POINTER(QueryMap))]),
     ("fdgpu_query_map_free", None, [C.POINTER(QueryMap)]),
     ("fdgpu_retrieve_batch", C.c_int, [VP, VP, u8p, C.c_uint64, u32p, u64p, C.POINTER(C.POINTER(QueryMap)), VP, u32p, C.POINTER(HashParams),
-                                        C.c_float, C.c_uint32, C.POINTER(C.POINTER(MatchRec)), C.POINTER(u64p), C.POINTER(C.POINTER(C.c_int32)),
+                                        C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(MatchRec)), C.POINTER(u64p), C.POINTER(C.POINTER(C.c_int32)),
                                         C.POINTER(u64p)]),
-    ("fdgpu_retrieve", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(QueryMap), VP, C.POINTER(HashParams), C.c_float, C.c_uint32,
+    ("fdgpu_retrieve", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(QueryMap), VP, C.POINTER(HashParams), C.c_float, C.c_uint32, C.c_uint32,
                                  C.POINTER(C.POINTER(MatchRec)), u64p, C.POINTER(C.POINTER(C.c_int32))]),
     ("fdgpu_matches_free", None, [C.POINTER(MatchRec), C.POINTER(C.c_int32)]),
     ("fdgpu_merge_subindices", C.c_int, [C.c_uint64, C.POINTER(u8p), C.POINTER(u32p), C.POINTER(u64p), u64p, C.POINTER(u8p), u64p,

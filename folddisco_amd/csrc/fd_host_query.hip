@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_gather_xyz(const float *__restrict__ ca
 // (*residues)[(*res_off)[t] ...], 2 * n_indices(t) per match.
 extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand,
                                     const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
-                                    const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, fd_match_rec **matches,
+                                    const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches,
                                     uint64_t **match_off, int32_t **residues, uint64_t **res_off) {
     if (!c || !db || !qb || !p || !matches || !match_off || !residues || !res_off || !cand_off || (n_queries && (!qms || !q_struct))) return FDGPU_EINVAL;
     *matches = nullptr; *match_off = nullptr; *residues = nullptr; *res_off = nullptr;
@@ -599,6 +599,28 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     std::vector<float> rmsd(std::max<uint64_t>(nprob, 1)), rot(std::max<uint64_t>(nprob, 1) * 9), tran(std::max<uint64_t>(nprob, 1) * 3);
     auto T3 = t_now();
     if (nprob && (rc = fdgpu_kabsch_batch(c, kx.data(), ky.data(), koff.data(), nprob, rmsd.data(), rot.data(), tran.data()))) return rc;
+    if (partial_fit && nprob) {   // --partial-fit: mappings of more than 3 residues take the LMS fit instead (retrieve.rs:733-746)
+        std::vector<uint64_t> which, loff(1, 0);
+        std::vector<float> lx, ly;
+        for (uint64_t k = 0; k < nprob; ++k) {
+            const uint64_t a = koff[k], b = koff[k + 1];
+            if (b - a <= 6) continue;                       // [CA, CB] per residue: index1.len() <= 3 keeps Kabsch
+            which.push_back(k);
+            lx.insert(lx.end(), kx.begin() + 3 * a, kx.begin() + 3 * b);
+            ly.insert(ly.end(), ky.begin() + 3 * a, ky.begin() + 3 * b);
+            loff.push_back(loff.back() + (b - a));
+        }
+        if (!which.empty()) {
+            std::vector<float> lr(which.size()), lrot(which.size() * 9), ltr(which.size() * 3);
+            if ((rc = fdgpu_lms_qcp_batch(c, lx.data(), ly.data(), loff.data(), which.size(), lr.data(), lrot.data(), ltr.data(), nullptr, nullptr)))
+                return rc;
+            for (size_t z = 0; z < which.size(); ++z) {
+                rmsd[which[z]] = lr[z];
+                memcpy(&rot[9 * which[z]], &lrot[9 * z], 36);
+                memcpy(&tran[3 * which[z]], &ltr[3 * z], 12);
+            }
+        }
+    }
     if (trace) fprintf(stderr, "[fdgpu_retrieve] match_pairs %.3f ms (found %llu, cands %llu), gather %.3f, graph/vote %.3f, kabsch(%llu) %.3f\n", t_ms(T0, T1),
                        (unsigned long long)nf, (unsigned long long)nc, t_ms(T1, T2), t_ms(T2, T3), (unsigned long long)nprob, t_ms(T3, t_now()));
     for (uint64_t k = 0; k < nprob; ++k) {
@@ -626,13 +648,13 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
 // one query = structure 0 of qb
 extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
                               const fd_query_map *qm, const fdgpu_batch *qb, const fd_hash_params *p, float ca_distance_cutoff,
-                              uint32_t node_count, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues) {
+                              uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues) {
     if (!c || !db || !qm || !qb || !p || !matches || !n_matches || !residues) return FDGPU_EINVAL;
     *matches = nullptr; *n_matches = 0; *residues = nullptr;
     const uint64_t off[2] = {0, n_cand};
     const uint32_t s0 = 0;
     uint64_t *mo = nullptr, *ro = nullptr;
-    int rc = fdgpu_retrieve_batch(c, db, resname_std, 1, cand, off, &qm, qb, &s0, p, ca_distance_cutoff, node_count, matches, &mo, residues, &ro);
+    int rc = fdgpu_retrieve_batch(c, db, resname_std, 1, cand, off, &qm, qb, &s0, p, ca_distance_cutoff, node_count, partial_fit, matches, &mo, residues, &ro);
     if (rc) return rc;
     *n_matches = mo[1];
     free(mo); free(ro);

@@ -983,6 +983,44 @@ extern "C" int fdgpu_kabsch_batch(fdgpu_ctx *c, const float *x, const float *y, 
     return FDGPU_OK;
 }
 
+// --partial-fit: LmsQcpSuperimposer with its default parameters (src/structure/lms_qcp.rs), one wavefront per problem
+extern "C" int fdgpu_lms_qcp_batch(fdgpu_ctx *c, const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot,
+                                   float *tran, uint32_t *core_len, uint32_t *core) {
+    if (!c || (n && (!x || !y || !off || !rmsd || !rot || !tran))) return FDGPU_EINVAL;
+    if (!n) return FDGPU_OK;
+    for (uint64_t k = 0; k < n; ++k)
+        if (off[k + 1] < off[k] + 3 || off[k + 1] - off[k] > 0xffffffffull) {   // the reference asserts >= 3 pairs (lms_qcp.rs:84)
+            c->err = "fdgpu_lms_qcp_batch: every problem needs at least 3 point pairs";
+            return FDGPU_EINVAL;
+        }
+    hipStream_t st = c->stream;
+    const uint64_t npts = off[n];
+    HIPCHK(c, c->ws[WS_MISC0].ensure(npts * 12));
+    HIPCHK(c, c->ws[WS_MISC1].ensure(npts * 12));
+    HIPCHK(c, c->ws[WS_MISC2].ensure((n + 1) * 8));
+    HIPCHK(c, c->ws[WS_MISC3].ensure(n * 8));       // rmsd f32[n] | core_len u32[n]
+    HIPCHK(c, c->ws[WS_MISC4].ensure(n * 48));      // rot f32[9n] | tran f32[3n]
+    HIPCHK(c, c->ws[WS_MISC5].ensure(npts * 5));    // order u32[npts] | flags u8[npts]
+    float *d_rmsd = c->ws[WS_MISC3].as<float>();
+    uint32_t *d_core = (uint32_t *)(d_rmsd + n);
+    float *d_rot = c->ws[WS_MISC4].as<float>(), *d_tran = d_rot + 9 * n;
+    uint32_t *d_order = c->ws[WS_MISC5].as<uint32_t>();
+    uint8_t *d_flags = (uint8_t *)(d_order + npts);
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, x, npts * 12, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, y, npts * 12, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    fd_launch_lms_qcp(c->ws[WS_MISC0].as<float>(), c->ws[WS_MISC1].as<float>(), c->ws[WS_MISC2].as<uint64_t>(), n, d_rmsd, d_rot, d_tran, d_core,
+                      d_flags, d_order, st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(rmsd, d_rmsd, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(rot, d_rot, n * 36, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(tran, d_tran, n * 12, hipMemcpyDeviceToHost, st));
+    if (core_len) HIPCHK(c, hipMemcpyAsync(core_len, d_core, n * 4, hipMemcpyDeviceToHost, st));
+    if (core) HIPCHK(c, hipMemcpyAsync(core, d_order, npts * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return FDGPU_OK;
+}
+
 // ---- diagnostics --------------------------------------------------------------------------------------------------------
 __global__ void k_debug_libm(int op, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint64_t n) {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -199,6 +199,8 @@ struct mp_args {
 };
 void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st);
 void fd_launch_kabsch(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, hipStream_t st);
+void fd_launch_lms_qcp(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, uint32_t *core_len,
+                       uint8_t *flags, uint32_t *order, hipStream_t st);
 void fd_launch_cq_batch(const cq_args &A, const uint32_t *q_query, uint32_t n_queries, const uint32_t *row_off, uint32_t *node_cnt, uint32_t *edge_cnt,
                         uint8_t *flags, hipStream_t st);
 void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, const uint32_t *edge_cnt, const uint8_t *flags, const uint64_t *pos,

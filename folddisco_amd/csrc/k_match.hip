@@ -357,3 +357,232 @@ __global__ __launch_bounds__(64) void k_kabsch(const float *__restrict__ xs, con
 void fd_launch_kabsch(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_kabsch, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, x, y, off, n, rmsd, rot, tran);
 }
+
+// ------------------------------------------------------------------------------------------ LMS-QCP partial fit
+// --partial-fit (src/structure/lms_qcp.rs:91-249, default parameters): 500 seeded 3-point trials scored by the median
+// squared residual of the other pairs, then forward growth of the core by the closest remaining pair until that pair is
+// farther than 2 A and the core holds n/2 pairs.  One wavefront per problem: lane 0 replays the xorshift stream (the number
+// of draws per trial depends on the collinearity retries, so the stream is sequential) into LDS, the trials then run one per
+// lane, the growth loop scans the pairs 64 at a time.  Arithmetic order follows the reference statement by statement
+// (f64 running sums, f32 residuals, no contraction) so the discrete choices (seed, joining order, stop) are the same.
+#define FD_LMS_TRIALS 500
+
+struct lms_stats { double n, sx[3], sy[3], sxx, syy, syx[3][3]; };
+
+__device__ __forceinline__ void lms_clear(lms_stats &s) {
+    s.n = 0; s.sxx = 0; s.syy = 0;
+    for (int a = 0; a < 3; ++a) { s.sx[a] = 0; s.sy[a] = 0; for (int b = 0; b < 3; ++b) s.syx[a][b] = 0; }
+}
+__device__ __forceinline__ void lms_add(lms_stats &s, const float *xf, const float *yf, uint64_t i) {   // lms_qcp.rs:277-291
+    const double x[3] = {xf[3 * i], xf[3 * i + 1], xf[3 * i + 2]}, y[3] = {yf[3 * i], yf[3 * i + 1], yf[3 * i + 2]};
+    s.n += 1.0;
+    for (int a = 0; a < 3; ++a) { s.sx[a] += x[a]; s.sy[a] += y[a]; }
+    s.sxx += x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    s.syy += y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) s.syx[a][b] += y[a] * x[b];
+}
+
+// rotation + translation of the current statistics (qcp_from_stats :304-344 with qcp_from_a_e0 :349-462 inlined)
+__device__ __noinline__ void lms_solve(const lms_stats &s, float r[9], float t[3]) {
+    const double n = s.n, inv = 1.0 / n;
+    double mx[3], my[3], A[3][3];
+    for (int k = 0; k < 3; ++k) { mx[k] = s.sx[k] * inv; my[k] = s.sy[k] * inv; }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = s.syx[i][j] - n * (my[i] * mx[j]);
+    const double m2x = mx[0] * mx[0] + mx[1] * mx[1] + mx[2] * mx[2], m2y = my[0] * my[0] + my[1] * my[1] + my[2] * my[2];
+    const double e0 = 0.5 * fmax((s.syy - n * m2y) + (s.sxx - n * m2x), 0.0);
+    const double sxx = A[0][0], sxy = A[0][1], sxz = A[0][2], syx = A[1][0], syy = A[1][1], syz = A[1][2], szx = A[2][0], szy = A[2][1],
+                 szz = A[2][2];
+    const double sxx2 = sxx * sxx, syy2 = syy * syy, szz2 = szz * szz, sxy2 = sxy * sxy, syz2 = syz * syz, sxz2 = sxz * sxz, syx2 = syx * syx,
+                 szy2 = szy * szy, szx2 = szx * szx;
+    const double u = 2.0 * (syz * szy - syy * szz);
+    const double v = syy2 + szz2 - sxx2 + syz2 + szy2;
+    const double c2 = -2.0 * (sxx2 + syy2 + szz2 + sxy2 + syx2 + sxz2 + szx2 + syz2 + szy2);
+    const double c1 = 8.0 * (sxx * syz * szy + syy * szx * sxz + szz * sxy * syx - sxx * syy * szz - syz * szx * sxy - szy * syx * sxz);
+    const double xzp = sxz + szx, yzp = syz + szy, xyp = sxy + syx, yzm = syz - szy, xzm = sxz - szx, xym = sxy - syx, xxyyp = sxx + syy,
+                 xxyym = sxx - syy;
+    const double w = sxy2 + sxz2 - syx2 - szx2;
+    const double nxzp = -xzp, nxzm = -xzm, nxym = -xym, tr = xxyyp + szz;
+    const double c0 = w * w + (v + u) * (v - u) + (nxzp * yzm + xym * (xxyym - szz)) * (nxzm * yzp + xym * (xxyym + szz)) +
+                      (nxzp * yzp - xyp * (xxyyp - szz)) * (nxzm * yzm - xyp * tr) +
+                      (xyp * yzp + xzp * (xxyym + szz)) * (nxym * yzm + xzp * tr) +
+                      (xyp * yzm + xzm * (xxyym - szz)) * (nxym * yzp + xzm * (xxyyp - szz));
+    double lam = fmax(e0, 0.0);
+    const double eps = 1e-15;
+    for (int it = 0; it < 10; ++it) {
+        const double x2 = lam * lam, b = (x2 + c2) * lam, aa = b + c1, f = aa * lam + c0, fp = 2.0 * x2 * lam + b + aa;
+        const double nl = fabs(lam - f / (fp + eps));
+        const bool done = fabs(nl - lam) < eps * nl;
+        lam = nl;
+        if (done) break;
+    }
+    const double a11 = xxyyp + szz - lam, a12 = yzm, a13 = nxzm, a14 = xym, a21 = a12, a22 = xxyym - szz - lam, a23 = xyp, a24 = xzp, a31 = a13,
+                 a32 = a23, a33 = syy - sxx - szz - lam, a34 = yzp, a41 = a14, a42 = a24, a43 = a34, a44 = szz - xxyyp - lam;
+    const double m3344 = a33 * a44 - a43 * a34, m3244 = a32 * a44 - a42 * a34, m3243 = a32 * a43 - a42 * a33, m3143 = a31 * a43 - a41 * a33,
+                 m3144 = a31 * a44 - a41 * a34, m3142 = a31 * a42 - a41 * a32;
+    double q1 = a22 * m3344 - a23 * m3244 + a24 * m3243;
+    double q2 = -a21 * m3344 + a23 * m3144 - a24 * m3143;
+    double q3 = a21 * m3244 - a22 * m3144 + a24 * m3142;
+    double q4 = -a21 * m3243 + a22 * m3143 - a23 * m3142;
+    double qs = q1 * q1 + q2 * q2 + q3 * q3 + q4 * q4;
+    double rot[3][3];
+    bool ident = false;
+    if (qs < 1e-12) {
+        q1 = a12 * m3344 - a13 * m3244 + a14 * m3243;
+        q2 = -a11 * m3344 + a13 * m3144 - a14 * m3143;
+        q3 = a11 * m3244 - a12 * m3144 + a14 * m3142;
+        q4 = -a11 * m3243 + a12 * m3143 - a13 * m3142;
+        qs = q1 * q1 + q2 * q2 + q3 * q3 + q4 * q4;
+        ident = qs < 1e-12;
+    }
+    if (ident) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) rot[i][j] = i == j ? 1.0 : 0.0;
+    } else {
+        const double qi = 1.0 / sqrt(qs);
+        q1 *= qi; q2 *= qi; q3 *= qi; q4 *= qi;
+        const double A2 = q1 * q1, X2 = q2 * q2, Y2 = q3 * q3, Z2 = q4 * q4, xy = q2 * q3, az = q1 * q4, zx = q4 * q2, ay = q1 * q3, yz = q3 * q4,
+                     ax = q1 * q2;
+        rot[0][0] = A2 + X2 - Y2 - Z2; rot[0][1] = 2.0 * (xy + az);   rot[0][2] = 2.0 * (zx - ay);
+        rot[1][0] = 2.0 * (xy - az);   rot[1][1] = A2 - X2 + Y2 - Z2; rot[1][2] = 2.0 * (yz + ax);
+        rot[2][0] = 2.0 * (zx + ay);   rot[2][1] = 2.0 * (yz - ax);   rot[2][2] = A2 - X2 - Y2 + Z2;
+    }
+    for (int i = 0; i < 3; ++i) {
+        const double rx = rot[i][0] * mx[0] + rot[i][1] * mx[1] + rot[i][2] * mx[2];
+        t[i] = (float)(my[i] - rx);
+        for (int j = 0; j < 3; ++j) r[3 * i + j] = (float)rot[i][j];
+    }
+}
+
+__device__ __forceinline__ float lms_resid2(const float r[9], const float t[3], const float *xf, const float *yf, uint64_t i) {   // :481-507
+    const float v0 = xf[3 * i], v1 = xf[3 * i + 1], v2 = xf[3 * i + 2];
+    const float p0 = (r[0] * v0 + r[1] * v1 + r[2] * v2) + t[0];
+    const float p1 = (r[3] * v0 + r[4] * v1 + r[5] * v2) + t[1];
+    const float p2 = (r[6] * v0 + r[7] * v1 + r[8] * v2) + t[2];
+    const float dx = p0 - yf[3 * i], dy = p1 - yf[3 * i + 1], dz = p2 - yf[3 * i + 2];
+    return dx * dx + dy * dy + dz * dz;
+}
+
+__device__ __forceinline__ uint64_t lms_rng_next(uint64_t &s) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+
+// lexicographic (value, index) minimum over the wavefront; value = +inf means "none"
+__device__ __forceinline__ void lms_wave_argmin(float &v, uint32_t &ix) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o);
+        const uint32_t oi = __shfl_xor(ix, o);
+        if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_lms_qcp(const float *__restrict__ xs, const float *__restrict__ ys, const uint64_t *__restrict__ off,
+                                                uint64_t n_prob, float *__restrict__ rmsd_out, float *__restrict__ rot_out,
+                                                float *__restrict__ tran_out, uint32_t *__restrict__ core_out, uint8_t *__restrict__ in_core,
+                                                uint32_t *__restrict__ order) {
+    __shared__ uint32_t s_seed[FD_LMS_TRIALS * 3];
+    __shared__ uint8_t s_ok[FD_LMS_TRIALS];
+    const uint64_t pidx = blockIdx.x;
+    if (pidx >= n_prob) return;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t p0 = off[pidx], n = off[pidx + 1] - p0;
+    const float *xf = xs + 3 * p0, *yf = ys + 3 * p0;
+    uint8_t *flag = in_core + p0;
+    uint32_t *ord = order + p0;
+    // ---- the random stream (SmallRng :530-549, sample_three_non_collinear :509-527)
+    if (lane == 0) {
+        uint64_t z = 0xC0FFEE005EEDull + 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        uint64_t st = z ^ (z >> 31);
+        for (int tr = 0; tr < FD_LMS_TRIALS; ++tr) {
+            bool ok = false;
+            for (int tries = 0; tries < 64 && !ok; ++tries) {
+                const uint64_t i = lms_rng_next(st) % n;
+                uint64_t j = lms_rng_next(st) % n; if (j == i) j = (j + 1) % n;
+                uint64_t k = lms_rng_next(st) % n; while (k == i || k == j) k = (k + 1) % n;
+                const float a0 = xf[3 * j] - xf[3 * i], a1 = xf[3 * j + 1] - xf[3 * i + 1], a2 = xf[3 * j + 2] - xf[3 * i + 2];
+                const float b0 = xf[3 * k] - xf[3 * i], b1 = xf[3 * k + 1] - xf[3 * i + 1], b2 = xf[3 * k + 2] - xf[3 * i + 2];
+                const float cx = a1 * b2 - a2 * b1, cy = a2 * b0 - a0 * b2, cz = a0 * b1 - a1 * b0;
+                const float area2 = cx * cx + cy * cy + cz * cz;
+                if (area2 > 1e-6f) { ok = true; s_seed[3 * tr] = (uint32_t)i; s_seed[3 * tr + 1] = (uint32_t)j; s_seed[3 * tr + 2] = (uint32_t)k; }
+            }
+            s_ok[tr] = ok;
+        }
+    }
+    for (uint64_t i = lane; i < n; i += 64) flag[i] = 0;
+    __syncthreads();
+    // ---- one trial per lane: median squared residual of the other pairs (select_quantile_squared :467-477)
+    float r[9], t[3];
+    float best_q = __builtin_inff();
+    uint32_t best_t = 0xffffffffu;
+    const uint64_t m = n - 3;
+    const uint64_t pos = m > 1 ? (uint64_t)roundf(0.5f * (float)(m - 1)) : 0;
+    for (uint32_t tr = lane; tr < FD_LMS_TRIALS; tr += 64) {
+        if (!s_ok[tr]) continue;
+        const uint32_t a = s_seed[3 * tr], b = s_seed[3 * tr + 1], c = s_seed[3 * tr + 2];
+        lms_stats S;
+        lms_clear(S);
+        lms_add(S, xf, yf, a); lms_add(S, xf, yf, b); lms_add(S, xf, yf, c);
+        lms_solve(S, r, t);
+        float qv = 0.0f;
+        if (m > 0) {   // the element of rank pos = the smallest bit pattern with at least pos + 1 residuals at or below it (residuals are >= +0)
+            uint32_t lo = 0, hi = 0x7f800000u;
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                uint64_t cnt = 0;
+                for (uint64_t i = 0; i < n; ++i) {
+                    if (i == a || i == b || i == c) continue;
+                    cnt += __float_as_uint(lms_resid2(r, t, xf, yf, i)) <= mid;
+                }
+                if (cnt >= pos + 1) hi = mid; else lo = mid + 1;
+            }
+            qv = __uint_as_float(lo);
+        }
+        if (qv < best_q) { best_q = qv; best_t = tr; }
+    }
+    lms_wave_argmin(best_q, best_t);
+    uint32_t seed[3] = {0, 1, 2};
+    if (best_q < __builtin_inff() && best_t != 0xffffffffu) { seed[0] = s_seed[3 * best_t]; seed[1] = s_seed[3 * best_t + 1]; seed[2] = s_seed[3 * best_t + 2]; }
+    // ---- forward growth (run() :142-196); lane i mod 64 owns pair i's in-core flag
+    uint64_t min_core = n / 2; if (min_core < 3) min_core = 3;
+    lms_stats S;
+    lms_clear(S);
+    uint64_t nc = 0;
+    for (int k = 0; k < 3; ++k) {
+        lms_add(S, xf, yf, seed[k]);
+        if ((seed[k] & 63u) == lane) flag[seed[k]] = 1;
+        if (lane == 0) ord[nc] = seed[k];
+        ++nc;
+    }
+    for (;;) {
+        lms_solve(S, r, t);
+        float b2 = __builtin_inff();
+        uint32_t bi = 0xffffffffu;
+        for (uint64_t i = lane; i < n; i += 64) {
+            if (flag[i]) continue;
+            const float d2 = lms_resid2(r, t, xf, yf, i);
+            if (d2 < b2) { b2 = d2; bi = (uint32_t)i; }
+        }
+        lms_wave_argmin(b2, bi);
+        if (bi == 0xffffffffu || !(b2 < __builtin_inff())) break;
+        if (nc >= min_core && b2 > 4.0f) break;
+        lms_add(S, xf, yf, bi);
+        if ((bi & 63u) == lane) flag[bi] = 1;
+        if (lane == 0) ord[nc] = bi;
+        ++nc;
+        if (nc == n) break;     // the reference keeps the transform solved before the last pair joined (:186-189)
+    }
+    if (lane == 0) {            // finish() :226-249: f32 sum in joining order
+        float sum = 0.0f;
+        for (uint64_t k = 0; k < nc; ++k) sum += lms_resid2(r, t, xf, yf, ord[k]);
+        rmsd_out[pidx] = sqrtf(sum / (float)nc);
+        for (int k = 0; k < 9; ++k) rot_out[9 * pidx + k] = r[k];
+        for (int k = 0; k < 3; ++k) tran_out[3 * pidx + k] = t[k];
+        core_out[pidx] = (uint32_t)nc;
+    }
+}
+
+void fd_launch_lms_qcp(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, uint32_t *core_len,
+                       uint8_t *flags, uint32_t *order, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_lms_qcp, dim3((unsigned)n), dim3(64), 0, st, x, y, off, n, rmsd, rot, tran, core_len, flags, order);
+}

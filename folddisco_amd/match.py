@@ -49,3 +49,21 @@ def kabsch_batch(ctx: Context, x: np.ndarray, y: np.ndarray, off: np.ndarray):
     ctx.check(ctx.L.fdgpu_kabsch_batch(ctx.h, x.ctypes.data_as(f32p), y.ctypes.data_as(f32p), off.ctypes.data_as(u64p), n,
                                        rmsd.ctypes.data_as(f32p), rot.ctypes.data_as(f32p), tran.ctypes.data_as(f32p)))
     return rmsd, rot, tran
+
+
+def lms_qcp_batch(ctx: Context, x: np.ndarray, y: np.ndarray, off: np.ndarray):
+    """--partial-fit superposition (src/structure/lms_qcp.rs, default parameters) of x[off[k]:off[k+1]] onto y[...], >= 3 pairs each.
+    -> rms over the core[n], rot[n,3,3], tran[n,3], list of core index arrays (joining order)"""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 3)
+    y = np.ascontiguousarray(y, dtype=np.float32).reshape(-1, 3)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    n = len(off) - 1
+    rmsd = np.zeros(n, np.float32)
+    rot = np.zeros((n, 3, 3), np.float32)
+    tran = np.zeros((n, 3), np.float32)
+    clen = np.zeros(max(n, 1), np.uint32)
+    core = np.zeros(max(len(x), 1), np.uint32)
+    ctx.check(ctx.L.fdgpu_lms_qcp_batch(ctx.h, x.ctypes.data_as(f32p), y.ctypes.data_as(f32p), off.ctypes.data_as(u64p), n,
+                                        rmsd.ctypes.data_as(f32p), rot.ctypes.data_as(f32p), tran.ctypes.data_as(f32p),
+                                        clen.ctypes.data_as(u32p), core.ctypes.data_as(u32p)))
+    return rmsd, rot, tran, [core[int(off[k]): int(off[k]) + int(clen[k])].copy() for k in range(n)]

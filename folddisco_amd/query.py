@@ -158,7 +158,7 @@ def make_query_maps(ctx: Context, qbatch: Batch, queries, index: FolddiscoIndex 
 
 
 def retrieve(ctx: Context, db: Batch, resname_std, cand, qm: QueryMapResult, qbatch: Batch, ca_distance_cutoff=1.0,
-             node_count=2, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0):
+             node_count=2, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, partial_fit=False):
     """-> list of dicts per match: cand slot, idf, rmsd, from_hash / processed target residue indices (-1 = none)."""
     cand = np.ascontiguousarray(cand, dtype=np.uint32)
     std = None if resname_std is None else np.ascontiguousarray(resname_std, np.uint8)
@@ -167,7 +167,7 @@ def retrieve(ctx: Context, db: Batch, resname_std, cand, qm: QueryMapResult, qba
     rp = C.POINTER(C.c_int32)()
     nm = C.c_uint64()
     ctx.check(ctx.L.fdgpu_retrieve(ctx.h, db.h, None if std is None else std.ctypes.data_as(u8p), cand.ctypes.data_as(u32p), len(cand),
-                                   qm.handle, qbatch.h, C.byref(p), ca_distance_cutoff, node_count, C.byref(mp), C.byref(nm), C.byref(rp)))
+                                   qm.handle, qbatch.h, C.byref(p), ca_distance_cutoff, node_count, int(bool(partial_fit)), C.byref(mp), C.byref(nm), C.byref(rp)))
     nq = len(qm.indices)
     out = []
     for k in range(nm.value):
@@ -259,7 +259,7 @@ MATCH_DTYPE = np.dtype([("cand", np.uint32), ("same", np.uint32), ("idf", np.flo
 
 
 def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Batch, q_structs, ca_distance_cutoff=1.0, node_count=2,
-                   nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, as_arrays=False):
+                   nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, as_arrays=False, partial_fit=False):
     """retrieve() for many queries with one pair scan / gather / Kabsch launch in total (fdgpu_retrieve_batch).  cands[t]:
     candidate structure indices of query t, qms[t] its QueryMapResult, q_structs[t] its structure in qbatch.
     -> list (per query) of lists of match dicts like retrieve(); with as_arrays=True the raw tables instead:
@@ -277,7 +277,7 @@ def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Bat
     mo, ro = u64p(), u64p()
     ctx.check(ctx.L.fdgpu_retrieve_batch(ctx.h, db.h, None if std is None else std.ctypes.data_as(u8p), T, cand.ctypes.data_as(u32p),
                                          cand_off.ctypes.data_as(u64p), handles, qbatch.h, qs.ctypes.data_as(u32p), C.byref(p), ca_distance_cutoff,
-                                         node_count, C.byref(mp), C.byref(mo), C.byref(rp), C.byref(ro)))
+                                         node_count, int(bool(partial_fit)), C.byref(mp), C.byref(mo), C.byref(rp), C.byref(ro)))
     if as_arrays:
         moff = np.ctypeslib.as_array(mo, shape=(T + 1,)).copy()
         roff = np.ctypeslib.as_array(ro, shape=(T + 1,)).copy()
@@ -310,7 +310,7 @@ def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Bat
 def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[CompactStructure], tids: list[str], nres, plddt,
               query: CompactStructure, query_string: str, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance=1.0, top_n=None,
               length_penalty_power=0.5, skip_match=False, serial_query=False, freq_filter=None, dist_cutoff=20.0, nbin_dist=0, nbin_angle=0,
-              sampling_ratio=None, sampling_count=None, filters=None, sort_by="", shard=None):
+              sampling_ratio=None, sampling_count=None, filters=None, sort_by="", shard=None, partial_fit=False):
     """The per-query body of query_pdb (src/cli/workflows/query_pdb.rs:348-519).  shard = dict(lo=first structure id, device=torch
     device or None): `index`, `db` and `db_structs` then cover only structures [lo, lo + len(db_structs)) of the database that
     tids / nres / plddt describe: idf comes from all-reduced posting lengths, the touched-structure records and the
@@ -388,7 +388,8 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
         std = np.concatenate([s.resname_std() for s in db_structs]) if db_structs else np.zeros(0, np.uint8)
         owned = [k for k, r in enumerate(rows) if lo <= r["nid"] < lo + n_local]       # candidates this rank holds coordinates of
         cand = np.array([rows[k]["nid"] - lo for k in owned], np.uint32)
-        ms = retrieve(ctx, db, std, cand, qm, qbatch, ca_distance, nbin_dist=nbin_dist, nbin_angle=nbin_angle, dist_cutoff=dist_cutoff) if len(cand) else []
+        ms = retrieve(ctx, db, std, cand, qm, qbatch, ca_distance, nbin_dist=nbin_dist, nbin_angle=nbin_angle, dist_cutoff=dist_cutoff,
+                      partial_fit=partial_fit) if len(cand) else []
         for m in ms:
             m["cand"] = owned[m["cand"]]                                                 # -> position in `rows`
             t = db_structs[rows[m["cand"]]["nid"] - lo]

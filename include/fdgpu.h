@@ -174,6 +174,13 @@ int fdgpu_match_pairs(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *resn
  * points are xyz f32.  rmsd[k] f32, rot[9k..], tran[3k..]. */
 int fdgpu_kabsch_batch(fdgpu_ctx *ctx, const float *x, const float *y, const uint64_t *off, uint64_t n_problems,
                        float *rmsd, float *rot, float *tran);
+/* Batched partial fit = LmsQcpSuperimposer::new() + set_atoms(fixed = y, moving = x) + run() with the default parameters
+ * (src/structure/lms_qcp.rs:29-41, 91-249; what --partial-fit selects for matches of more than 3 residues,
+ * src/controller/retrieve.rs:733-746): rmsd[k] = rms over the final core, rot/tran map x onto y.  Every problem needs
+ * >= 3 pairs.  Optional: core_len[k] = size of the core, core[off[k] .. off[k] + core_len[k]) = its pair indices in
+ * joining order. */
+int fdgpu_lms_qcp_batch(fdgpu_ctx *ctx, const float *x, const float *y, const uint64_t *off, uint64_t n_problems,
+                        float *rmsd, float *rot, float *tran, uint32_t *core_len, uint32_t *core);
 
 /* ---- query map and retrieval (host glue in C++, numerics on the GPU) ------------------------------------
  * get_single_feature (src/controller/feature.rs:11-24, 84-99) for explicit residue pairs (i, j) of
@@ -218,10 +225,12 @@ typedef struct fd_match_rec {   /* one connected component of one candidate (ret
 } fd_match_rec;
 /* residues: 2 * n_indices int32 per match — target residue index (relative to its structure, -1 = "_") for
  * every query residue, first the from-hash mapping then the processed (rescued) one. Release both with
- * fdgpu_matches_free. Matches are ordered by candidate slot, then by component as in graph.rs:43-45. */
+ * fdgpu_matches_free. Matches are ordered by candidate slot, then by component as in graph.rs:43-45.
+ * partial_fit != 0 = --partial-fit: mappings of more than 3 residues are superposed by the least-median-of-squares
+ * fit (fdgpu_lms_qcp_batch) and report the rms over its core (retrieve.rs:733-746, 787-812). */
 int fdgpu_retrieve(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
                    const fd_query_map *qm, const fdgpu_batch *qb, const fd_hash_params *p, float ca_distance_cutoff,
-                   uint32_t node_count, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues);
+                   uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues);
 /* Many queries with one pair scan, one coordinate gather and one Kabsch launch in total: query t = structure q_struct[t] of qb
  * with the query map qms[t]; its candidates are cand[cand_off[t] .. cand_off[t+1]).  Matches of query t =
  * (*matches)[(*match_off)[t] .. (*match_off)[t+1]) (cand = slot inside the query's own list), its residues start at
@@ -229,8 +238,8 @@ int fdgpu_retrieve(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *resname
  * offset arrays with fdgpu_free. */
 int fdgpu_retrieve_batch(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand,
                          const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
-                         const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, fd_match_rec **matches,
-                         uint64_t **match_off, int32_t **residues, uint64_t **res_off);
+                         const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, uint32_t partial_fit,
+                         fd_match_rec **matches, uint64_t **match_off, int32_t **residues, uint64_t **res_off);
 void fdgpu_matches_free(fd_match_rec *m, int32_t *residues);
 
 /* ---- structure ingest (host, multi-threaded) ---------------------------------------------------------------

@@ -162,6 +162,8 @@ def lib():
     L.fdo_retrieval_free.argtypes = [C.POINTER(Retrieval)]
     L.fdo_kabsch.restype = C.c_float
     L.fdo_kabsch.argtypes = [f32p, f32p, C.c_uint64, C.c_int, f32p, f32p]
+    L.fdo_lms_qcp.restype = C.c_float
+    L.fdo_lms_qcp.argtypes = [f32p, f32p, C.c_uint64, f32p, f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.fdo_metrics.restype = None
     L.fdo_metrics.argtypes = [f32p, f32p, C.c_uint64, f32p, f32p, f32p]
     _lib = L
@@ -418,6 +420,20 @@ def kabsch(x: np.ndarray, y: np.ndarray, mode=2):
     tran = (C.c_float * 3)()
     r = lib().fdo_kabsch(xp, yp, len(x.reshape(-1, 3)), mode, rot, tran)
     return float(r), np.array(list(rot), dtype=np.float32).reshape(3, 3), np.array(list(tran), dtype=np.float32)
+
+
+def lms_qcp(x: np.ndarray, y: np.ndarray):
+    """partial (least-median-of-squares) superposition of x onto y (src/structure/lms_qcp.rs, default parameters):
+    (rms over the core, rot, tran, core indices in insertion order)"""
+    x, xp = _f32(x)
+    y, yp = _f32(y)
+    n = len(x.reshape(-1, 3))
+    rot = np.zeros(9, np.float32)
+    tran = np.zeros(3, np.float32)
+    core = np.zeros(n, np.uint64)
+    nc = C.c_uint64(0)
+    r = lib().fdo_lms_qcp(xp, yp, n, rot.ctypes.data_as(f32p), tran.ctypes.data_as(f32p), core.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(nc))
+    return float(r), rot.reshape(3, 3), tran, core[:nc.value].copy()
 
 
 def metrics(ref: np.ndarray, mov: np.ndarray, rot: np.ndarray, tran: np.ndarray) -> np.ndarray:

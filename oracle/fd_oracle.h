@@ -180,6 +180,9 @@ void fdo_retrieval_free(fdo_retrieval *r);
 /* kabsch(x = coords, y = reference, mode) (kabsch.rs:157-554). returns rmsd as f32 */
 float fdo_kabsch(const float *x, const float *y, uint64_t n, int mode, float rot[9], float tran[3]);
 void fdo_metrics(const float *ref, const float *mov, uint64_t n, const float rot[9], const float tran[3], float out[5]);
+/* LmsQcpSuperimposer (structure/lms_qcp.rs:91-249, default parameters): x = coords (moving), y = reference; returns the rms
+ * over the final core; core (n slots, may be NULL) receives the core indices in insertion order. */
+float fdo_lms_qcp(const float *x, const float *y, uint64_t n, float rot[9], float tran[3], uint64_t *core, uint64_t *n_core);
 
 #ifdef __cplusplus
 }

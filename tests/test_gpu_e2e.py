@@ -120,6 +120,47 @@ def test_retrieve_matches_oracle(env):
                     assert np.allclose(g["metrics"], want, atol=1e-4), (g["metrics"], want)
 
 
+def test_partial_fit_retrieval_matches_oracle(env):
+    """--partial-fit (retrieve.rs:733-746, 787-812): mappings of more than 3 residues are superposed by the LMS-QCP fit and
+    report the rms over its core; smaller ones keep Kabsch; the mappings themselves do not change."""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    ctx, structs, batch, ix, nres, plddt, tids = env
+    oq = oracle.read_pdb(Q4CHA)
+    oa = oq.arrays()
+    ostructs = [oracle.read_pdb(p) for p in SER]
+    q = st.read_compact_structure(Q4CHA)
+    qb = ctx.upload(fd.PackedStructures.concat([q.as_item()]))
+    std = np.concatenate([s.resname_std() for s in structs])
+    n_lms = 0
+    for qstr in ("B57,B102,C195,B58,B59,C999", "B57,B102,C195,C194,C196,B56,C214"):
+        res = fq.parse_query_string(qstr, q.chains[0])
+        idx = [q.get_index(c, r) for c, r, _ in res]
+        keep = [k for k, i in enumerate(idx) if i is not None]
+        qidx = [idx[k] for k in keep]
+        m = fq.make_query_map(ctx, qb, qidx, [res[k][2] for k in keep], ix, 5.0)
+        plain = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=3.0)
+        part = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=3.0, partial_fit=True)
+        assert len(plain) == len(part)
+        for a, b in zip(plain, part):
+            assert a["cand"] == b["cand"] and a["processed"] == b["processed"] and a["from_hash"] == b["from_hash"]
+            tpos = [x for x in b["processed"] if x >= 0]
+            qpos = [i for i, x in zip(qidx, b["processed"]) if x >= 0]
+            if len(tpos) <= 3:
+                assert b["rmsd"] == a["rmsd"] and np.array_equal(a["rot"], b["rot"])
+                continue
+            n_lms += 1
+            ta = ostructs[b["cand"]].arrays()
+            qpts = np.stack([p for i in qpos for p in (oa["ca_xyz"][i], oa["cb_xyz"][i])])
+            tpts = np.stack([p for i in tpos for p in (ta["ca_xyz"][i], ta["cb_xyz"][i])])
+            rms, rot, tran, core = oracle.lms_qcp(tpts, qpts)
+            assert abs(b["rmsd"] - rms) <= 1e-4, (qstr, b["cand"], b["rmsd"], rms)
+            assert np.allclose(b["rot"], rot, atol=1e-5) and np.allclose(b["tran"], tran, atol=1e-3)
+            assert np.allclose(b["metrics"], oracle.metrics(qpts, tpts, rot, tran), atol=1e-4)
+    assert n_lms > 0
+
+
 def test_sharded_build_merge_and_disk_roundtrip(env, tmp_path):
     """index build shards by structure: two sub-indices built with id offsets merge into the byte-identical single index;
     the files written to disk load back (product loader and oracle loader) and answer the query identically."""

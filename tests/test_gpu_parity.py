@@ -460,3 +460,37 @@ def test_random_unknown_residues_and_missing_cb(ctx):
     v, hh, oo = fd.FolddiscoIndex.build(ctx, batch).export()
     oix, _, _ = oracle.build_index(structs)
     assert np.array_equal(hh, oix.hashes()) and np.array_equal(oo, oix.offsets()) and np.array_equal(v, oix.values())
+
+
+@pytest.mark.gpu
+def test_lms_qcp_batch_matches_oracle(ctx):
+    """--partial-fit superposition (src/structure/lms_qcp.rs): the wavefront-per-problem kernel takes the same discrete decisions
+    as the CPU restatement (seed triple out of the 500 xorshift trials, joining order, stop) and the same numbers: core index
+    lists identical, rms / rotation / translation bit-identical (f64 sums and f32 residuals in the reference's order)."""
+    from folddisco_amd import match
+    from tests.test_oracle_golden import _lms_problem
+    rng = np.random.default_rng(5)
+    probs = []
+    for n, n_out, noise in ((3, 0, 0.0), (4, 1, 0.0), (5, 0, 0.3), (8, 2, 0.05), (16, 5, 0.1), (17, 0, 0.5), (32, 9, 0.0), (63, 20, 0.2),
+                            (64, 3, 0.2), (65, 30, 0.02), (130, 40, 0.3), (400, 150, 0.1)):
+        x, y, _ = _lms_problem(rng, n, n_out, noise)
+        probs.append((x, y))
+    line = np.outer(np.arange(9, dtype=np.float32), np.array([1.0, 2.0, -1.0], np.float32))
+    probs.append((line, line + np.float32(1.0)))                     # collinear moving points: every trial is rejected, seed = 0,1,2
+    pts = (rng.normal(size=(10, 3)) * 3).astype(np.float32)
+    probs.append((pts, pts.copy()))                                  # identical sets
+    dup = pts.copy(); dup[1:6] = dup[0]
+    probs.append((dup, pts))                                         # repeated points: collinearity retries in the random stream
+    xs = np.concatenate([p[0] for p in probs]); ys = np.concatenate([p[1] for p in probs])
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in probs])]).astype(np.uint64)
+    rmsd, rot, tran, cores = match.lms_qcp_batch(ctx, xs, ys, off)
+    for k, (x, y) in enumerate(probs):
+        r, R, T, core = oracle.lms_qcp(x, y)
+        assert np.array_equal(cores[k].astype(np.uint64), core), (k, len(x), cores[k], core)
+        if np.isnan(r):
+            assert np.isnan(rmsd[k])
+            continue
+        assert _bits(rmsd[k]) == _bits(r), (k, len(x), rmsd[k], r)
+        assert np.array_equal(_bits(rot[k]), _bits(R)) and np.array_equal(_bits(tran[k]), _bits(T)), (k, len(x))
+    with pytest.raises(Exception):
+        match.lms_qcp_batch(ctx, xs[:2], ys[:2], np.array([0, 2], np.uint64))     # the reference asserts >= 3 pairs

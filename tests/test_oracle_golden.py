@@ -273,3 +273,42 @@ def test_metrics_identical_coordinates_known_answer():
     assert m[0] == pytest.approx(1.0 / (1.0 + d / 0.25), rel=1e-5)       # d0 = 0.5 for <= 21 points; distance, not its square
     assert m[1] == pytest.approx(1.0) and m[2] == pytest.approx(0.75)     # 0.52 <= 1, 4, 16, 64; not <= 0.25
     assert m[3] == pytest.approx(d, rel=1e-5) and m[4] == pytest.approx(d, rel=1e-5)
+
+
+def _lms_problem(rng, n, n_out, noise=0.0):
+    y = (rng.normal(size=(n, 3)) * 6).astype(np.float32)
+    a, b = rng.uniform(0, np.pi, 2)
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+    x = ((y - rng.normal(size=3) * 4) @ (Rz @ Rx).T).astype(np.float32)
+    if noise:
+        x += (rng.normal(size=x.shape) * noise).astype(np.float32)
+    out = rng.choice(n, size=n_out, replace=False) if n_out else np.zeros(0, np.int64)
+    x[out] += (rng.normal(size=(n_out, 3)) * 9 + 6).astype(np.float32)
+    return x, y, set(int(o) for o in out)
+
+
+def test_lms_qcp_partial_fit_properties():
+    """src/structure/lms_qcp.rs holds no asserting test (its one test is #[ignore]d): the restatement is checked on the
+    properties that test names — the core has >= 3 pairs and superposes exactly — for a planted rigid motion with outliers,
+    plus the structural rules of run(): the core keeps at least n/2 pairs, excludes every planted outlier, lists each pair once,
+    and three pairs are all core."""
+    rng = np.random.default_rng(17)
+    for n, n_out in ((8, 2), (16, 5), (32, 9), (101, 30)):
+        x, y, out = _lms_problem(rng, n, n_out)
+        rms, rot, tran, core = oracle.lms_qcp(x, y)
+        assert rms < 1e-4, (n, rms)
+        assert len(core) >= max(3, n // 2) and len(set(core.tolist())) == len(core)
+        assert not (set(core.tolist()) & out), (n, core, out)
+        assert len(core) == n - n_out
+        assert np.abs(x[core] @ rot.T + tran - y[core]).max() < 1e-3
+        assert abs(np.linalg.det(rot.astype(np.float64)) - 1.0) < 1e-5
+    x, y, _ = _lms_problem(rng, 3, 0)
+    rms, rot, tran, core = oracle.lms_qcp(x, y)
+    assert sorted(core.tolist()) == [0, 1, 2] and rms < 1e-4
+    # every pair consistent: the core grows to all n and the reported transform is the one solved before the last pair joined
+    x, y, _ = _lms_problem(rng, 12, 0, noise=0.05)
+    rms, rot, tran, core = oracle.lms_qcp(x, y)
+    assert len(core) == 12 and 0.0 < rms < 0.2
+    again = oracle.lms_qcp(x, y)
+    assert again[0] == rms and np.array_equal(again[3], core)     # fixed seed: deterministic
