@@ -10,6 +10,8 @@ import sys
 
 import numpy as np
 
+from folddisco_amd._lib import HASH_TYPE_NAMES, hash_type_index
+
 
 def _load_paths(d: str, recursive: bool):
     out = []
@@ -81,7 +83,7 @@ def cmd_index(a):
         nres_all.append(nres_c)
         plddt_all.append(np.where(nres_c > 0, plddt_c, np.float32(0.0)).astype(np.float32))
         batch = ctx.upload(ps)
-        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid)
+        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid, hash_type=a.hash_type)
         if len(paths) <= a.chunk:
             ix.save(prefix)                       # single chunk: the library writes PREFIX and PREFIX.offset itself
             n_hashes, value_len = ix.num_hashes, ix.value_len
@@ -94,7 +96,7 @@ def cmd_index(a):
         n_hashes, value_len = len(h), len(v)
     nres, plddt = np.concatenate(nres_all), np.concatenate(plddt_all)
     indexio.save_lookup(prefix + ".lookup", paths, nres, plddt)
-    indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance)
+    indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type])
     if a.verbose:
         print(f"[DONE] {len(paths)} structures, {n_hashes} hashes, {value_len} value bytes -> {prefix}", file=sys.stderr)
 
@@ -114,7 +116,7 @@ def _build_chunks(a, fd, structure, ctx, paths, first_id):
         nres_all.append(nres_c)
         plddt_all.append(np.where(nres_c > 0, plddt_c, np.float32(0.0)).astype(np.float32))
         batch = ctx.upload(ps)
-        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id + c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid)
+        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id + c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid, hash_type=a.hash_type)
         parts.append(ix.export())
         del ix, batch
     z = lambda dt: np.zeros(0, dt)
@@ -140,7 +142,7 @@ def _cmd_index_sharded(a, fd, indexio, structure, paths, prefix, rank, world):
         mv, mh, mo = indexio.merge_subindices(shards)
         indexio.write_index_files(prefix, mv, mh, mo)
         indexio.save_lookup(prefix + ".lookup", paths, np.concatenate([b[0] for b in box]), np.concatenate([b[1] for b in box]))
-        indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance)
+        indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type])
         if a.verbose:
             print(f"[DONE] {len(paths)} structures over {world} ranks, {len(mh)} hashes, {len(mv)} value bytes -> {prefix}", file=sys.stderr)
     dist.barrier()
@@ -197,7 +199,7 @@ def cmd_query(a):
                                         ca_distance=a.ca_distance, top_n=a.top, skip_match=a.skip_match, serial_query=a.serial_index,
                                         freq_filter=a.freq_filter, length_penalty_power=0.5 if a.length_penalty is None else a.length_penalty,
                                         dist_cutoff=float(cfg.get("grid_width", 20.0)), nbin_dist=int(cfg.get("num_bin_dist", 0)),
-                                        nbin_angle=int(cfg.get("num_bin_angle", 0)), sampling_ratio=a.sampling_ratio,
+                                        nbin_angle=int(cfg.get("num_bin_angle", 0)), hash_type=hash_type_index(cfg.get("hash_type", "PDBTrRosetta")), sampling_ratio=a.sampling_ratio,
                                         sampling_count=a.sampling_count, sort_by=a.sort_by, partial_fit=a.partial_fit,
                                         filters=dict(total_match=a.total_match, covered_node=a.covered_node, covered_node_ratio=a.covered_node_ratio,
                                                      max_node=a.max_node, max_node_ratio=a.max_node_ratio, score=a.score,
@@ -291,8 +293,13 @@ def main(argv=None):
     pq.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
     if a.cmd == "index":
-        if a.type not in ("default", "folddisco", "pdbtr", "PDBTrRosetta"):
-            sys.exit("[FAIL] only the default PDBTrRosetta encoding is implemented")
+        try:
+            a.hash_type = hash_type_index(a.type)
+        except ValueError:
+            sys.exit(f"[FAIL] unknown hash type {a.type}")
+        if a.hash_type not in (0, 1, 3, 7, 8):
+            sys.exit(f"[FAIL] hash type {HASH_TYPE_NAMES[a.hash_type]}: only the encodings over the PDBTrRosetta descriptor are implemented "
+                     "(PDBTrRosetta, PDBMotif, PDBMotifSinCos, FolddiscoAngle, FolddiscoDist)")
         cmd_index(a)
     else:
         cmd_query(a)

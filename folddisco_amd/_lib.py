@@ -21,7 +21,32 @@ class BatchDesc(C.Structure):
 
 
 class HashParams(C.Structure):
-    _fields_ = [("nbin_dist", C.c_uint32), ("nbin_angle", C.c_uint32), ("dist_cutoff", C.c_float)]
+    _fields_ = [("nbin_dist", C.c_uint32), ("nbin_angle", C.c_uint32), ("dist_cutoff", C.c_float), ("hash_type", C.c_uint32)]
+
+    def __init__(self, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, hash_type=3):
+        super().__init__(int(nbin_dist), int(nbin_angle), float(dist_cutoff), int(hash_type))
+
+
+# HashType::get_with_str / to_string (src/geometry/core.rs:42-75); only the encodings over the PDBTrRosetta descriptor are built
+HASH_TYPE_NAMES = {0: "PDBMotif", 1: "PDBMotifSinCos", 2: "TrRosetta", 3: "PDBTrRosetta", 4: "PointPairFeature", 5: "TertiaryInteraction",
+                   6: "Hybrid", 7: "FolddiscoAngle", 8: "FolddiscoDist"}
+_HASH_TYPE_ALIASES = {"pyscomotif": 0, "orig_pdb": 0, "pdb": 1, "trrosetta": 2, "tr": 2, "pdbtr": 3, "default": 3, "folddisco": 3, "ppf": 4,
+                      "tertiary": 5, "3di": 5, "hybrid": 6, "angle": 7, "folddisco_angle": 7, "distance": 8, "dist": 8, "folddisco_dist": 8}
+
+
+def hash_type_index(name) -> int:
+    """HashType::get_with_str: index, canonical name or alias -> HashType index; unknown -> ValueError (the reference's Other)"""
+    if isinstance(name, int):
+        return name
+    s = str(name)
+    if s.isdigit() and int(s) in HASH_TYPE_NAMES:
+        return int(s)
+    for k, v in HASH_TYPE_NAMES.items():
+        if v == s:
+            return k
+    if s in _HASH_TYPE_ALIASES:
+        return _HASH_TYPE_ALIASES[s]
+    raise ValueError(f"unknown hash type {name!r}")
 
 
 class CountRec(C.Structure):

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import BatchDesc, CountRec, HashParams, f32p, u8p, u32p, u64p
+from ._lib import BatchDesc, CountRec, HashParams, f32p, hash_type_index, u8p, u32p, u64p
 
 
 class FdgpuError(RuntimeError):
@@ -152,13 +152,13 @@ class Batch:
             pass
 
 
-def _params(nbin_dist=0, nbin_angle=0, dist_cutoff=20.0) -> HashParams:
-    return HashParams(nbin_dist, nbin_angle, dist_cutoff)
+def _params(nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, hash_type=3) -> HashParams:
+    return HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type_index(hash_type))
 
 
-def get_geometric_hash_as_u32(ctx: Context, batch: Batch, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, sort_dedup=True):
+def get_geometric_hash_as_u32(ctx: Context, batch: Batch, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, sort_dedup=True, hash_type=3):
     """S1 for every structure of the batch -> (hashes u32[...], off u64[S+1])."""
-    p = _params(nbin_dist, nbin_angle, dist_cutoff)
+    p = _params(nbin_dist, nbin_angle, dist_cutoff, hash_type)
     hp, op = u32p(), u64p()
     ctx.check(ctx.L.fdgpu_hash_batch(ctx.h, batch.h, C.byref(p), int(sort_dedup), C.byref(hp), C.byref(op)))
     off = np.ctypeslib.as_array(op, shape=(batch.n_struct + 1,)).copy()
@@ -183,8 +183,8 @@ class FolddiscoIndex:
             pass
 
     @staticmethod
-    def build(ctx: Context, batch: Batch, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, first_id=0) -> "FolddiscoIndex":
-        p = _params(nbin_dist, nbin_angle, dist_cutoff)
+    def build(ctx: Context, batch: Batch, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, first_id=0, hash_type=3) -> "FolddiscoIndex":
+        p = _params(nbin_dist, nbin_angle, dist_cutoff, hash_type)
         h = C.c_void_p()
         ctx.check(ctx.L.fdgpu_index_build(ctx.h, batch.h, C.byref(p), first_id, C.byref(h)))
         return FolddiscoIndex(ctx, h, batch.n_struct, first_id)

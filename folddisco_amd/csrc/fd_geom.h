@@ -42,8 +42,16 @@ FD_HD uint32_t fd_sat_u32(float v) {
 // quantiser constants (min, 1/((max-min)/(nb-1))) are computed once on the host in f32
 struct fd_quant {
     float dist_disc;   // 1/((20-2)/(nbin_dist-1))
-    float ang_disc;    // 1/((1-(-1))/(nbin_angle-1))
+    float ang_disc;    // 1/((max-min)/(nbin_angle-1)): sin/cos fields (-1..1), degrees (0..180, PDBMotif) or radians (-pi..pi, Folddisco*)
+    float ang2_disc;   // FolddiscoAngle / FolddiscoDist: the theta field, 1/((pi-0)/(min(nbin_angle, cap)-1))
+    uint32_t type;     // HashType index of the reference (geometry/core.rs:26-40): 0 PDBMotif, 1 PDBMotifSinCos, 3 PDBTrRosetta,
+                       // 7 FolddiscoAngle, 8 FolddiscoDist — the encodings over the (d_CA, d_CB, theta, tau1, tau2) descriptor
 };
+#define FD_HASH_PDBMOTIF 0u
+#define FD_HASH_PDBMOTIF_SINCOS 1u
+#define FD_HASH_PDBTR 3u
+#define FD_HASH_FD_ANGLE 7u
+#define FD_HASH_FD_DIST 8u
 FD_HD uint32_t fd_q(float v, float mn, float disc) { return fd_sat_u32((v - mn) * disc + 0.5f); }
 
 struct fd_feature { float ca_dist, cb_dist, angle, tor1, tor2; };
@@ -91,6 +99,41 @@ FD_HD uint32_t fd_hash_pdbtr(uint32_t aa1, uint32_t aa2, fd_feature f, fd_quant 
     uint32_t qs1 = fd_q(s1, -1.0f, q.ang_disc), qc1 = fd_q(c1, -1.0f, q.ang_disc);
     uint32_t qs2 = fd_q(s2, -1.0f, q.ang_disc), qc2 = fd_q(c2, -1.0f, q.ang_disc);
     return aa1 << 25 | aa2 << 20 | ca << 16 | cb << 12 | qs0 << 10 | qc0 << 8 | qs1 << 6 | qc1 << 4 | qs2 << 2 | qc2;
+}
+
+// The other encodings over the same descriptor (all fields OR-ed unmasked like the reference):
+//   PDBMotif        pdb_motif.rs:26-50         aa1<<20 | aa2<<15 | ca<<10 | cb<<5 | q(theta in degrees, 0..180)
+//   PDBMotifSinCos  pdb_motif_sincos.rs:17-53  aa1<<21 | aa2<<16 | ca<<12 | cb<<8 | q(sin theta)<<4 | q(cos theta)
+//   FolddiscoAngle  folddisco_angle.rs:25-70   (aa1*20+aa2)<<21 | ca<<18 | cb<<15 | q(theta, 0..pi)<<10 | q(tau1, -pi..pi)<<5 | q(tau2)
+//   FolddiscoDist   folddisco_dist.rs:22-63    (aa1*20+aa2)<<21 | ca<<16 | cb<<11 | q(theta)<<8 | q(tau1)<<4 | q(tau2)
+// f = the feature vector as get_single_feature leaves it (controller/feature.rs:26-99): theta in DEGREES for PDBMotif, radians otherwise
+FD_HD uint32_t fd_hash_enc_feat(uint32_t aa1, uint32_t aa2, fd_feature f, fd_quant q) {
+    if (q.type == FD_HASH_PDBTR) return fd_hash_pdbtr(aa1, aa2, f, q);
+    const uint32_t ca = fd_q(f.ca_dist, 2.0f, q.dist_disc), cb = fd_q(f.cb_dist, 2.0f, q.dist_disc);
+    const float NPI = -3.14159274f;
+    if (q.type == FD_HASH_PDBMOTIF) return aa1 << 20 | aa2 << 15 | ca << 10 | cb << 5 | fd_q(f.angle, 0.0f, q.ang_disc);
+    if (q.type == FD_HASH_PDBMOTIF_SINCOS) {
+        float s0, c0;
+        fdd_sincosf(f.angle, &s0, &c0);
+        return aa1 << 21 | aa2 << 16 | ca << 12 | cb << 8 | fd_q(s0, -1.0f, q.ang_disc) << 4 | fd_q(c0, -1.0f, q.ang_disc);
+    }
+    const uint32_t pair = aa1 * 20u + aa2;
+    const uint32_t th = fd_q(f.angle, 0.0f, q.ang2_disc), t1 = fd_q(f.tor1, NPI, q.ang_disc), t2 = fd_q(f.tor2, NPI, q.ang_disc);
+    if (q.type == FD_HASH_FD_ANGLE) return pair << 21 | ca << 18 | cb << 15 | th << 10 | t1 << 5 | t2;
+    return pair << 21 | ca << 16 | cb << 11 | th << 8 | t1 << 4 | t2;
+}
+// residue types of a hash as the encoding's reverse_hash reports them (prefilter_amino_acid, controller/retrieve.rs:574-577)
+FD_HD void fd_hash_aa_pair(uint32_t type, uint32_t h, uint32_t *aa1, uint32_t *aa2) {
+    if (type == FD_HASH_PDBMOTIF) { *aa1 = (h >> 20) & 31u; *aa2 = (h >> 15) & 31u; }
+    else if (type == FD_HASH_PDBMOTIF_SINCOS) { *aa1 = (h >> 21) & 31u; *aa2 = (h >> 16) & 31u; }
+    else if (type == FD_HASH_FD_ANGLE || type == FD_HASH_FD_DIST) { const uint32_t pair = (h >> 21) & 0x1ffu; *aa1 = pair / 20u; *aa2 = pair % 20u; }
+    else { *aa1 = (h >> 25) & 31u; *aa2 = (h >> 20) & 31u; }
+}
+FD_HD float fd_to_degrees(float rad) { return rad * 57.2957795130823208767981548141051703f; }   // f32::to_degrees
+// f = the descriptor in radians (fd_pair_feature)
+FD_HD uint32_t fd_hash_enc(uint32_t aa1, uint32_t aa2, fd_feature f, fd_quant q) {
+    if (q.type == FD_HASH_PDBMOTIF) f.angle = fd_to_degrees(f.angle);   // get_ca_cb_angle(i, j, false), coordinate.rs:127-129
+    return fd_hash_enc_feat(aa1, aa2, f, q);
 }
 
 // =============================================================================================
@@ -150,6 +193,7 @@ FD_HD void fd_pair_both(const fd_frame &Fi, const fd_frame &Fj, uint32_t aai, ui
     fd_v3 rA = fd_neg(A);
     fd_v3 tA = fd_normalize(fd_cross(rA, Fi.nv2));
     g.tor2 = -fdd_atan2f(fd_dot(Fi.s2, tA), fd_dot(rA, Fi.s2));
+    if (q.type != FD_HASH_PDBTR) { *h_ij = fd_hash_enc(aai, aaj, f, q); *h_ji = fd_hash_enc(aaj, aai, g, q); return; }
     // quantise: distances and theta once
     uint32_t ca = fd_q(f.ca_dist, 2.0f, q.dist_disc), cb = fd_q(f.cb_dist, 2.0f, q.dist_disc);
     float s0, c0, s1, c1, s2, c2, s3, c3, s4, c4;

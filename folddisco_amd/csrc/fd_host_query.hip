@@ -28,11 +28,19 @@
     } while (0)
 
 fd_hash_consts fd_make_consts(const fd_hash_params *p);  // fdgpu_api.hip
+bool fd_hash_type_supported(uint32_t t);
+#define CHECK_TYPE(ctx, p)                                                                                                       \
+    do {                                                                                                                         \
+        if (!fd_hash_type_supported((p)->hash_type)) {                                                                           \
+            (ctx)->err = "hash_type: only the encodings over the (d_CA, d_CB, theta, tau1, tau2) descriptor are built (0, 1, 3, 7, 8)"; \
+            return FDGPU_EINVAL;                                                                                                 \
+        }                                                                                                                        \
+    } while (0)
 
 // ------------------------------------------------------------------------------------------ kernels
 // get_single_feature (src/controller/feature.rs:11-24, 84-99) for explicit residue pairs of one structure
 __global__ void k_pair_features(fd_batch_view B, uint32_t s, const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj, uint32_t n,
-                                float cutoff, float *__restrict__ feat /*[n][7]*/, uint8_t *__restrict__ valid) {
+                                float cutoff, uint32_t type, float *__restrict__ feat /*[n][7]*/, uint8_t *__restrict__ valid) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     // s == 0xffffffff: pi / pj are residue indices of the whole batch (pairs of many structures in one launch)
@@ -49,20 +57,21 @@ __global__ void k_pair_features(fd_batch_view B, uint32_t s, const uint32_t *__r
     valid[k] = ok ? 1 : 0;
     float *o = feat + 7ull * k;
     o[0] = ok ? (float)B.aa[i] : 0.f; o[1] = ok ? (float)B.aa[j] : 0.f;
-    o[2] = f.ca_dist; o[3] = f.cb_dist; o[4] = f.angle; o[5] = f.tor1; o[6] = f.tor2;
+    o[2] = f.ca_dist; o[3] = f.cb_dist; o[4] = type == FD_HASH_PDBMOTIF ? fd_to_degrees(f.angle) : f.angle; o[5] = f.tor1; o[6] = f.tor2;
 }
-// GeometricHash::perfect_hash (src/geometry/pdb_tr.rs:21-75) on explicit feature vectors
+// GeometricHash::perfect_hash (src/geometry/core.rs:213-246 -> pdb_tr.rs:21-75 and the other encodings) on explicit feature vectors
 __global__ void k_hash_features(const float *__restrict__ feat, uint64_t n, fd_quant q, uint32_t *__restrict__ out) {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const float *f = feat + 7 * k;
     fd_feature ft = {f[2], f[3], f[4], f[5], f[6]};
-    out[k] = fd_hash_pdbtr(fd_sat_u32(f[0]), fd_sat_u32(f[1]), ft, q);
+    out[k] = fd_hash_enc_feat(fd_sat_u32(f[0]), fd_sat_u32(f[1]), ft, q);
 }
 
 extern "C" int fdgpu_pair_features(fdgpu_ctx *c, const fdgpu_batch *b, uint64_t s, const uint32_t *pi, const uint32_t *pj, uint64_t n,
                                    const fd_hash_params *p, float *features, uint8_t *valid) {
     if (!c || !b || !p || (s >= b->n_struct && s != 0xffffffffull) || (n && (!pi || !pj || !features || !valid))) return FDGPU_EINVAL;
+    CHECK_TYPE(c, p);
     if (!n) return FDGPU_OK;
     hipStream_t st = c->stream;
     HIPCHK(c, c->ws[WS_MISC0].ensure(n * 4));
@@ -72,7 +81,7 @@ extern "C" int fdgpu_pair_features(fdgpu_ctx *c, const fdgpu_batch *b, uint64_t 
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, pi, n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, pj, n * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_pair_features, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, b->view(), (uint32_t)s, c->ws[WS_MISC0].as<uint32_t>(),
-                       c->ws[WS_MISC1].as<uint32_t>(), (uint32_t)n, p->dist_cutoff, c->ws[WS_MISC2].as<float>(), c->ws[WS_MISC3].as<uint8_t>());
+                       c->ws[WS_MISC1].as<uint32_t>(), (uint32_t)n, p->dist_cutoff, p->hash_type, c->ws[WS_MISC2].as<float>(), c->ws[WS_MISC3].as<uint8_t>());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(features, c->ws[WS_MISC2].p, n * 28, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(valid, c->ws[WS_MISC3].p, n, hipMemcpyDeviceToHost, st));
@@ -82,6 +91,7 @@ extern "C" int fdgpu_pair_features(fdgpu_ctx *c, const fdgpu_batch *b, uint64_t 
 
 extern "C" int fdgpu_hash_features(fdgpu_ctx *c, const float *features, uint64_t n, const fd_hash_params *p, uint32_t *hashes) {
     if (!c || !p || (n && (!features || !hashes))) return FDGPU_EINVAL;
+    CHECK_TYPE(c, p);
     if (!n) return FDGPU_OK;
     hipStream_t st = c->stream;
     fd_hash_consts C = fd_make_consts(p);
@@ -196,9 +206,11 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
                         far[idx] = far[idx] - thr[z2];
                     }
             };
+            // dist_index / angle_index of the encoding (controller/feature.rs:269-291): theta only for the two PDBMotif forms — and
+            // PDBMotif shifts its DEGREE-valued theta by the threshold converted to radians, like the reference
             static const int di[2] = {2, 3}, ai[3] = {4, 5, 6};
             expand(di, 2, dist_thr, n_dist);
-            expand(ai, 3, athr.data(), n_angle);
+            expand(ai, (p->hash_type == FD_HASH_PDBMOTIF || p->hash_type == FD_HASH_PDBMOTIF_SINCOS) ? 1 : 3, athr.data(), n_angle);
         }
         cand_off[t + 1] = cands.size();
     }
@@ -412,8 +424,18 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     int rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc);
     if (rc) return rc;
     auto T1 = t_now();
-    // symmetry flags (geometry/pdb_tr.rs:158-162): aa equal and atan2(sin, cos) of the two torsion fields equal
-    auto is_sym = [](uint32_t h) {
+    // symmetry flags (geometry/pdb_tr.rs:158-162): aa equal and atan2(sin, cos) of the two torsion fields equal; the other encodings
+    // compare their residue fields and (Folddisco*) torsion fields (pdb_motif.rs:98, pdb_motif_sincos.rs:105, folddisco_angle.rs:133,
+    // folddisco_dist.rs:126)
+    const uint32_t htype = p->hash_type;
+    auto is_sym = [htype](uint32_t h) {
+        if (htype == FD_HASH_PDBMOTIF) return ((h >> 20) & 31u) == ((h >> 15) & 31u);
+        if (htype == FD_HASH_PDBMOTIF_SINCOS) return ((h >> 21) & 31u) == ((h >> 16) & 31u);
+        if (htype == FD_HASH_FD_ANGLE || htype == FD_HASH_FD_DIST) {
+            const uint32_t pair = (h >> 21) & 0x1ffu;
+            const uint32_t p1 = htype == FD_HASH_FD_ANGLE ? (h >> 5) & 31u : (h >> 4) & 15u, p2 = htype == FD_HASH_FD_ANGLE ? h & 31u : h & 15u;
+            return pair / 20u == pair % 20u && p1 == p2;
+        }
         auto cont = [](uint32_t v) { float cf = (1.0f - (-1.0f)) / (4.0f - 1.0f); return (float)v * cf + (-1.0f); };
         const float D = 57.2957795130823208767981548141051703f;
         float p1 = atan2f(cont((h >> 6) & 3), cont((h >> 4) & 3)) * D, p2 = atan2f(cont((h >> 2) & 3), cont(h & 3)) * D;

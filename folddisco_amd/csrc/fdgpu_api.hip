@@ -207,15 +207,36 @@ extern "C" uint64_t fdgpu_batch_num_structures(const fdgpu_batch *b) { return b 
 extern "C" uint64_t fdgpu_batch_num_residues(const fdgpu_batch *b) { return b ? b->n_res : 0; }
 
 // ---- hash constants ------------------------------------------------------------------------------------------------
+// per-encoding bin rules: {cap_dist, default_dist, cap_angle, default_angle} (perfect_hash of pdb_motif.rs:27-40,
+// pdb_motif_sincos.rs:19-31, pdb_tr.rs:22-35, folddisco_angle.rs:26-40, folddisco_dist.rs:23-37)
+bool fd_hash_type_supported(uint32_t t) {
+    return t == FD_HASH_PDBMOTIF || t == FD_HASH_PDBMOTIF_SINCOS || t == FD_HASH_PDBTR || t == FD_HASH_FD_ANGLE || t == FD_HASH_FD_DIST;
+}
 static fd_hash_consts make_consts(const fd_hash_params *p) {
-    // pdb_tr.rs:22-35 clamps; convert.rs:32-36 quantiser factors evaluated in f32 exactly like the reference
-    float nd = p->nbin_dist > 16 ? 16.0f : (p->nbin_dist == 0 ? 16.0f : (float)p->nbin_dist);
-    float na = p->nbin_angle > 4 ? 4.0f : (p->nbin_angle == 0 ? 4.0f : (float)p->nbin_angle);
+    // convert.rs:32-36 quantiser factors evaluated in f32 exactly like the reference
+    const uint32_t type = p->hash_type;
+    uint32_t cap_d = 16, def_d = 16, cap_a = 4, def_a = 4;
+    if (type == FD_HASH_PDBMOTIF) { cap_d = 32; def_d = 18; cap_a = 32; def_a = 9; }
+    else if (type == FD_HASH_PDBMOTIF_SINCOS) { cap_d = 16; def_d = 8; cap_a = 16; def_a = 3; }
+    else if (type == FD_HASH_FD_ANGLE) { cap_d = 8; def_d = 8; cap_a = 32; def_a = 32; }
+    else if (type == FD_HASH_FD_DIST) { cap_d = 32; def_d = 32; cap_a = 16; def_a = 16; }
+    // either bin count 0 -> perfect_hash_default (controller/feature.rs:216-223, query.rs:72-77)
+    const bool dflt = p->nbin_dist == 0 || p->nbin_angle == 0;
+    float nd = dflt ? (float)def_d : (p->nbin_dist > cap_d ? (float)cap_d : (float)p->nbin_dist);
+    float na = dflt ? (float)def_a : (p->nbin_angle > cap_a ? (float)cap_a : (float)p->nbin_angle);
     fd_hash_consts C;
+    const float PI_F = 3.14159274f;
+    float a_min = -1.0f, a_max = 1.0f;                                         // sin / cos fields
+    if (type == FD_HASH_PDBMOTIF) { a_min = 0.0f; a_max = 180.0f; }            // degrees
+    else if (type == FD_HASH_FD_ANGLE || type == FD_HASH_FD_DIST) { a_min = -PI_F; a_max = PI_F; }
     volatile float cont_d = (20.0f - 2.0f) / (nd - 1.0f);
-    volatile float cont_a = (1.0f - (-1.0f)) / (na - 1.0f);
+    volatile float cont_a = (a_max - a_min) / (na - 1.0f);
+    float n180 = type == FD_HASH_FD_ANGLE ? fminf(na, 32.0f) : fminf(na, 8.0f);
+    volatile float cont_t = (PI_F - 0.0f) / (n180 - 1.0f);
     C.q.dist_disc = 1.0f / cont_d;
     C.q.ang_disc = 1.0f / cont_a;
+    C.q.ang2_disc = 1.0f / cont_t;
+    C.q.type = type;
     // largest f32 d2 with sqrtf(d2) <= cutoff (sqrtf is correctly rounded on host and device)
     float cut = p->dist_cutoff;
     float d2 = cut * cut;
@@ -226,7 +247,7 @@ static fd_hash_consts make_consts(const fd_hash_params *p) {
     // (fd_geom.h fd_pair_both_spec) unless FDGPU_EXACT=1
     const char *ex = getenv("FDGPU_EXACT");   // read per call: tests flip it inside one process
     const bool exact_only = ex && ex[0] == '1';
-    C.use_tab = (na == 4.0f) ? (exact_only ? 1 : 2) : 0;
+    C.use_tab = (type == FD_HASH_PDBTR && na == 4.0f) ? (exact_only ? 1 : 2) : 0;
     C.spec_miss = nullptr;
     return C;
 }
@@ -297,6 +318,7 @@ extern "C" int fdgpu_hash_batch(fdgpu_ctx *c, const fdgpu_batch *b, const fd_has
                                 uint64_t **hash_off) {
     if (!c || !b || !p || !hashes || !hash_off) return FDGPU_EINVAL;
     *hashes = nullptr; *hash_off = nullptr;
+    if (!fd_hash_type_supported(p->hash_type)) FAIL(c, FDGPU_EINVAL, "hash_type: only the encodings over the (d_CA, d_CB, theta, tau1, tau2) descriptor are built (0, 1, 3, 7, 8)");
     reset_timings(c);
     fd_hash_consts C = make_consts(p);
     uint64_t S = b->n_struct, R = b->n_res;
@@ -385,6 +407,7 @@ extern "C" uint64_t fdgpu_index_num_postings(const fdgpu_index *ix) { return ix 
 static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_params *p, uint64_t first_id, fdgpu_index **out, bool force32) {
     if (!c || !b || !p || !out) return FDGPU_EINVAL;
     *out = nullptr;
+    if (!fd_hash_type_supported(p->hash_type)) FAIL(c, FDGPU_EINVAL, "hash_type: only the encodings over the (d_CA, d_CB, theta, tau1, tau2) descriptor are built (0, 1, 3, 7, 8)");
     reset_timings(c);
     if (first_id + b->n_struct > 0xffffffffull) FAIL(c, FDGPU_ERANGE, "structure ids exceed 32 bits");
     fd_hash_consts C = make_consts(p);
@@ -836,6 +859,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     const uint64_t n_cand = cand_off[n_queries];
     if (n_cand && !cand) return FDGPU_EINVAL;
     *found = nullptr; *cands = nullptr; *n_found = 0; *n_cands = 0;
+    if (!fd_hash_type_supported(p->hash_type)) FAIL(c, FDGPU_EINVAL, "hash_type: only the encodings over the (d_CA, d_CB, theta, tau1, tau2) descriptor are built (0, 1, 3, 7, 8)");
     reset_timings(c);
     hipStream_t st = c->stream;
     // work items: (query, candidate slot, 64-residue i-tile)
@@ -857,7 +881,11 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         Q.qh_off = (uint32_t)all_hashes.size(); Q.n_hashes = (uint32_t)q->n_hashes;
         all_hashes.insert(all_hashes.end(), q->hashes, q->hashes + q->n_hashes);
         Q.aa1_mask = Q.aa2_mask = 0;
-        for (uint64_t k = 0; k < q->n_hashes; ++k) { Q.aa1_mask |= 1u << ((q->hashes[k] >> 25) & 31u); Q.aa2_mask |= 1u << ((q->hashes[k] >> 20) & 31u); }
+        for (uint64_t k = 0; k < q->n_hashes; ++k) {
+            uint32_t a1, a2;
+            fd_hash_aa_pair(p->hash_type, q->hashes[k], &a1, &a2);
+            Q.aa1_mask |= 1u << (a1 & 31u); Q.aa2_mask |= 1u << (a2 & 31u);
+        }
         Q.use_prefilter = q->use_aa_prefilter; Q.ca_window = q->ca_distance_cutoff;
         std::vector<uint32_t> cnt(1025, 0);
         for (uint64_t e = 0; e < q->n_aad; ++e)

@@ -59,7 +59,7 @@ __device__ __forceinline__ void drain(const fd_batch_view &B, const fd_hash_cons
         fd_v3 n1 = fd_load3(B.n_xyz, i), ca1 = fd_load3(B.ca_xyz, i), cb1 = fd_load3(B.cb_xyz, i);
         fd_v3 n2 = fd_load3(B.n_xyz, j), ca2 = fd_load3(B.ca_xyz, j), cb2 = fd_load3(B.cb_xyz, j);
         fd_feature f = fd_pair_feature(n1, ca1, cb1, n2, ca2, cb2);
-        uint32_t h = fd_hash_pdbtr(B.aa[i], B.aa[j], f, C.q);
+        uint32_t h = fd_hash_enc(B.aa[i], B.aa[j], f, C.q);
         uint64_t pos = seg_off[s] + base + lane;
         keys[pos] = h;
         if (WRITE_IDS) ids[pos] = id;
@@ -171,7 +171,7 @@ __device__ __attribute__((noinline)) uint2 pair_both_tab_exact(const fd_frame *_
                                                                uint32_t aaj, float dist_disc, float ang_disc, const uint32_t *tab) {
     fd_frame Fi = load_frame(frames, i), Fj = load_frame(frames, j);
     fd_quant q;
-    q.dist_disc = dist_disc; q.ang_disc = ang_disc;
+    q.dist_disc = dist_disc; q.ang_disc = ang_disc; q.ang2_disc = 0.0f; q.type = FD_HASH_PDBTR;
     uint32_t a, b;
     fd_pair_both_tab(Fi, Fj, aai, aaj, q, tab, &a, &b);
     return make_uint2(a, b);
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_row_emit(fd_batch_view B, fd_hash_c
         if (fd_dist2(ca1, ca2) > C.d2_max) continue;
         fd_v3 n2 = fd_load3(B.n_xyz, j), cb2 = fd_load3(B.cb_xyz, j);
         fd_feature f = fd_pair_feature(n1, ca1, cb1, n2, ca2, cb2);
-        keys[pos++] = fd_hash_pdbtr(aa1, B.aa[j], f, C.q);
+        keys[pos++] = fd_hash_enc(aa1, B.aa[j], f, C.q);
     }
 }
 

@@ -52,7 +52,7 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
             fd_pair_both_tab(Fi, Fj, aai, aaj, A.C.q, tab, &h, &h_ji);
         } else {
             fd_feature f = fd_pair_feature(fd_load3(A.B.n_xyz, i), cai, fd_load3(A.B.cb_xyz, i), fd_load3(A.B.n_xyz, j), caj, fd_load3(A.B.cb_xyz, j));
-            h = fd_hash_pdbtr(aai, aaj, f, A.C.q);
+            h = fd_hash_enc(aai, aaj, f, A.C.q);
         }
         hit = hash_in_set(A.q_hashes, A.n_hashes, h);
     }

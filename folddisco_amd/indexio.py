@@ -53,10 +53,10 @@ def load_lookup(path: str):
 
 
 def save_type(path: str, n_structures: int, grid_width: float = 20.0, max_residue: int = 50000, nbin_angle: int = 0, nbin_dist: int = 0,
-              input_format: str = "PDB"):
+              input_format: str = "PDB", hash_type: str = "PDBTrRosetta"):
     gw = repr(float(grid_width))  # toml prints the f64; 20.0 -> "20.0"
     with open(path, "w") as f:
-        f.write(f"chunk_size = {n_structures}\ngrid_width = {gw}\nhash_type = \"PDBTrRosetta\"\ninput_format = \"{input_format}\"\n"
+        f.write(f"chunk_size = {n_structures}\ngrid_width = {gw}\nhash_type = \"{hash_type}\"\ninput_format = \"{input_format}\"\n"
                 f"max_residue = {max_residue}\nnum_bin_angle = {nbin_angle}\nnum_bin_dist = {nbin_dist}\n")
 
 

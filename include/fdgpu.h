@@ -55,12 +55,22 @@ typedef struct fd_batch_desc {
     const uint8_t *cb_valid;   /* [R] 1 if CB is Some (src/structure/core.rs:147-155); NULL = all 1 */
 } fd_batch_desc;
 
-/* Parameters of the encoding: HashType::PDBTrRosetta (src/geometry/pdb_tr.rs:21-75).
- * nbin_dist / nbin_angle follow the reference: 0 -> defaults 16 / 4, larger values clamp. */
+/* Parameters of the encoding.  hash_type = the reference's HashType index (src/geometry/core.rs:26-40): the encodings over the
+ * (d_CA, d_CB, theta, tau1, tau2) descriptor are built — 3 PDBTrRosetta (the default, pdb_tr.rs:21-75; the fast table /
+ * speculative path), 0 PDBMotif (pdb_motif.rs), 1 PDBMotifSinCos (pdb_motif_sincos.rs), 7 FolddiscoAngle (folddisco_angle.rs),
+ * 8 FolddiscoDist (folddisco_dist.rs); 2 / 4 / 5 / 6 (other descriptors) return FDGPU_EINVAL.
+ * nbin_dist / nbin_angle follow the reference: if either is 0 both take the encoding's defaults
+ * (controller/feature.rs:216-223), larger values clamp per encoding. */
+#define FDGPU_HASH_PDBMOTIF 0u
+#define FDGPU_HASH_PDBMOTIF_SINCOS 1u
+#define FDGPU_HASH_PDBTR 3u
+#define FDGPU_HASH_FOLDDISCO_ANGLE 7u
+#define FDGPU_HASH_FOLDDISCO_DIST 8u
 typedef struct fd_hash_params {
     uint32_t nbin_dist;
     uint32_t nbin_angle;
     float dist_cutoff;         /* CA-CA cutoff in Angstrom (strict >, src/structure/core.rs:391) */
+    uint32_t hash_type;        /* FDGPU_HASH_* */
 } fd_hash_params;
 
 /* copy a host batch into HBM */

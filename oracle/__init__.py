@@ -162,6 +162,11 @@ def lib():
     L.fdo_retrieval_free.argtypes = [C.POINTER(Retrieval)]
     L.fdo_kabsch.restype = C.c_float
     L.fdo_kabsch.argtypes = [f32p, f32p, C.c_uint64, C.c_int, f32p, f32p]
+    L.fdo_set_hash_type.restype = C.c_int
+    L.fdo_set_hash_type.argtypes = [C.c_uint32]
+    L.fdo_get_hash_type.restype = C.c_uint32
+    L.fdo_hash_any.restype = C.c_uint32
+    L.fdo_hash_any.argtypes = [f32p, C.c_uint64, C.c_uint64]
     L.fdo_lms_qcp.restype = C.c_float
     L.fdo_lms_qcp.argtypes = [f32p, f32p, C.c_uint64, f32p, f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.fdo_metrics.restype = None
@@ -420,6 +425,30 @@ def kabsch(x: np.ndarray, y: np.ndarray, mode=2):
     tran = (C.c_float * 3)()
     r = lib().fdo_kabsch(xp, yp, len(x.reshape(-1, 3)), mode, rot, tran)
     return float(r), np.array(list(rot), dtype=np.float32).reshape(3, 3), np.array(list(tran), dtype=np.float32)
+
+
+class hash_type:
+    """with oracle.hash_type(7): ...  — every oracle function inside encodes with that HashType (0 PDBMotif, 1 PDBMotifSinCos,
+    3 PDBTrRosetta, 7 FolddiscoAngle, 8 FolddiscoDist); restored on exit"""
+
+    def __init__(self, t: int):
+        self.t = int(t)
+
+    def __enter__(self):
+        self.prev = int(lib().fdo_get_hash_type())
+        if lib().fdo_set_hash_type(self.t) != 0:
+            raise ValueError(f"oracle: hash type {self.t} is not restated")
+        return self
+
+    def __exit__(self, *exc):
+        lib().fdo_set_hash_type(self.prev)
+        return False
+
+
+def hash_any(feature, nbin_dist=0, nbin_angle=0) -> int:
+    f = np.zeros(9, np.float32)
+    f[: len(feature)] = np.asarray(feature, np.float32)
+    return int(lib().fdo_hash_any(f.ctypes.data_as(f32p), nbin_dist, nbin_angle))
 
 
 def lms_qcp(x: np.ndarray, y: np.ndarray):

@@ -64,6 +64,11 @@ const char *fdo_map_u8_to_aa(uint8_t aa);
 int fdo_pair_feature(const fdo_structure *s, int64_t i, int64_t j, float dist_cutoff, float feature[9]);
 uint32_t fdo_discretize(float val, float min, float max, float num_bin);
 uint32_t fdo_hash_pdbtr(const float feature[9], uint64_t nbin_dist, uint64_t nbin_angle);
+/* process-wide encoding switch for the tests (default 3 = PDBTrRosetta; 0, 1, 7, 8 = the other encodings over the same descriptor,
+ * geometry/{pdb_motif,pdb_motif_sincos,folddisco_angle,folddisco_dist}.rs); every function below encodes through fdo_hash_any */
+int fdo_set_hash_type(uint32_t hash_type);
+uint32_t fdo_get_hash_type(void);
+uint32_t fdo_hash_any(const float feature[9], uint64_t nbin_dist, uint64_t nbin_angle);
 void fdo_reverse_hash_pdbtr(uint32_t hash, float out[7]);
 int fdo_hash_is_symmetric(uint32_t hash);
 /* all ordered pairs row-major (combination.rs:23-44) -> malloc'd list, caller frees with fdo_free */

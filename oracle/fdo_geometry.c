@@ -109,7 +109,18 @@ static float calc_torsion_radian(v3 a, v3 b, v3 c, v3 d) {
 
 static v3 at(const float *p, int64_t i) { v3 r = {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; return r; }
 
-/* controller/feature.rs:11-24,84-99 + structure/core.rs:378-403 */
+/* HashType the restatement encodes with (geometry/core.rs:26-40): 3 PDBTrRosetta unless a test selects one of the other encodings over
+ * the same descriptor (0 PDBMotif, 1 PDBMotifSinCos, 7 FolddiscoAngle, 8 FolddiscoDist).  Test infrastructure: a process-wide switch. */
+static uint32_t g_hash_type = 3;
+int fdo_set_hash_type(uint32_t t) {
+    if (t != 0 && t != 1 && t != 3 && t != 7 && t != 8) return -1;
+    g_hash_type = t;
+    return 0;
+}
+uint32_t fdo_get_hash_type(void) { return g_hash_type; }
+
+/* controller/feature.rs:11-24,26-99 + structure/core.rs:255-297,378-403: the five encodings share the pair rules (both aa known,
+ * CA and CB present, d_CA <= cutoff); tau1 / tau2 are simply unused by the two PDBMotif forms */
 int fdo_pair_feature(const fdo_structure *s, int64_t i, int64_t j, float dist_cutoff, float feature[9]) {
     if (i == j) return 0;
     if (s->aa[i] == 255 || s->aa[j] == 255) return 0;
@@ -127,7 +138,7 @@ int fdo_pair_feature(const fdo_structure *s, int64_t i, int64_t j, float dist_cu
     feature[1] = (float)s->aa[j];
     feature[2] = ca_dist;
     feature[3] = cb_dist;
-    feature[4] = ang;
+    feature[4] = g_hash_type == 0 ? ang * 57.2957795130823208767981548141051703f : ang; /* PDBMotif: get_ca_cb_angle(.., false) = degrees */
     feature[5] = t1;
     feature[6] = t2;
     return 1;
@@ -150,6 +161,49 @@ uint32_t fdo_hash_pdbtr(const float f[9], uint64_t nbin_dist, uint64_t nbin_angl
     return res1 << 25 | res2 << 20 | ca << 16 | cb << 12 | s0 << 10 | c0 << 8 | s1 << 6 | c1 << 4 | s2 << 2 | c2;
 }
 
+static float pick_bins(uint64_t n, float cap, float dflt) { return n > (uint64_t)cap ? cap : (n == 0 ? dflt : (float)n); }
+/* geometry/pdb_motif.rs:26-50 (theta in degrees, 0..180) */
+static uint32_t hash_pdbmotif(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle) {
+    float nd = pick_bins(nbin_dist, 32.0f, 18.0f), na = pick_bins(nbin_angle, 32.0f, 9.0f);
+    uint32_t res1 = sat_u32(f[0]), res2 = sat_u32(f[1]);
+    uint32_t ca = fdo_discretize(f[2], 2.0f, 20.0f, nd), cb = fdo_discretize(f[3], 2.0f, 20.0f, nd);
+    uint32_t ang = fdo_discretize(f[4], 0.0f, 180.0f, na);
+    return res1 << 20 | res2 << 15 | ca << 10 | cb << 5 | ang;
+}
+/* geometry/pdb_motif_sincos.rs:17-53 */
+static uint32_t hash_pdbmotif_sincos(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle) {
+    float nd = pick_bins(nbin_dist, 16.0f, 8.0f), na = pick_bins(nbin_angle, 16.0f, 3.0f);
+    uint32_t res1 = sat_u32(f[0]), res2 = sat_u32(f[1]);
+    uint32_t ca = fdo_discretize(f[2], 2.0f, 20.0f, nd), cb = fdo_discretize(f[3], 2.0f, 20.0f, nd);
+    uint32_t sn = fdo_discretize(sinf(f[4]), -1.0f, 1.0f, na), cs = fdo_discretize(cosf(f[4]), -1.0f, 1.0f, na);
+    return res1 << 21 | res2 << 16 | ca << 12 | cb << 8 | sn << 4 | cs;
+}
+/* geometry/folddisco_angle.rs:25-70 (8 / 32 / 32 bins) and folddisco_dist.rs:22-63 (32 / 8 / 16 bins): angles binned in radians */
+static uint32_t hash_folddisco(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle, int dist_form) {
+    const float PI_F = 3.14159274f;
+    float nd = dist_form ? pick_bins(nbin_dist, 32.0f, 32.0f) : pick_bins(nbin_dist, 8.0f, 8.0f);
+    float na = dist_form ? pick_bins(nbin_angle, 16.0f, 16.0f) : pick_bins(nbin_angle, 32.0f, 32.0f);
+    float n180 = dist_form ? 8.0f : 32.0f;
+    uint32_t res1 = sat_u32(f[0]), res2 = sat_u32(f[1]);
+    uint32_t pair = res1 * 20u + res2; /* map_aa_u32_pair_to_u32 (convert.rs:203-207; asserts < 512) */
+    uint32_t ca = fdo_discretize(f[2], 2.0f, 20.0f, nd), cb = fdo_discretize(f[3], 2.0f, 20.0f, nd);
+    uint32_t th = fdo_discretize(f[4], 0.0f, PI_F, na < n180 ? na : n180);
+    uint32_t p1 = fdo_discretize(f[5], -PI_F, PI_F, na), p2 = fdo_discretize(f[6], -PI_F, PI_F, na);
+    return dist_form ? (pair << 21 | ca << 16 | cb << 11 | th << 8 | p1 << 4 | p2) : (pair << 21 | ca << 18 | cb << 15 | th << 10 | p1 << 5 | p2);
+}
+/* GeometricHash::perfect_hash[_default] (geometry/core.rs:195-246) as the callers use it: either bin count 0 -> the encoding's defaults
+ * (controller/feature.rs:216-223, query.rs:72-77) */
+uint32_t fdo_hash_any(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle) {
+    if (nbin_dist == 0 || nbin_angle == 0) nbin_dist = nbin_angle = 0;
+    switch (g_hash_type) {
+    case 0: return hash_pdbmotif(f, nbin_dist, nbin_angle);
+    case 1: return hash_pdbmotif_sincos(f, nbin_dist, nbin_angle);
+    case 7: return hash_folddisco(f, nbin_dist, nbin_angle, 0);
+    case 8: return hash_folddisco(f, nbin_dist, nbin_angle, 1);
+    default: return fdo_hash_pdbtr(f, nbin_dist, nbin_angle);
+    }
+}
+
 /* geometry/pdb_tr.rs:95-136 reverse_hash (default bins), angles in degrees */
 void fdo_reverse_hash_pdbtr(uint32_t h, float out[7]) {
     const float PIS_IN_180 = 57.2957795130823208767981548141051703f; /* f32::to_degrees */
@@ -166,6 +220,15 @@ void fdo_reverse_hash_pdbtr(uint32_t h, float out[7]) {
 }
 /* geometry/pdb_tr.rs:158-162 */
 int fdo_hash_is_symmetric(uint32_t h) {
+    /* pdb_motif.rs:98-102, pdb_motif_sincos.rs:105-109: residue fields equal; folddisco_angle.rs:133-137, folddisco_dist.rs:126-130:
+     * residues of the pair equal and the two torsion fields equal (their continuize map is strictly increasing) */
+    if (g_hash_type == 0) return ((h >> 20) & 31u) == ((h >> 15) & 31u);
+    if (g_hash_type == 1) return ((h >> 21) & 31u) == ((h >> 16) & 31u);
+    if (g_hash_type == 7 || g_hash_type == 8) {
+        uint32_t pair = (h >> 21) & 0x1ffu;
+        uint32_t p1 = g_hash_type == 7 ? (h >> 5) & 31u : (h >> 4) & 15u, p2 = g_hash_type == 7 ? h & 31u : h & 15u;
+        return pair / 20u == pair % 20u && p1 == p2;
+    }
     float v[7];
     fdo_reverse_hash_pdbtr(h, v);
     return v[0] == v[1] && v[5] == v[6];
@@ -181,8 +244,7 @@ int fdo_hash_structure(const fdo_structure *s, uint64_t nbin_dist, uint64_t nbin
         for (int64_t j = 0; j < s->n; ++j) {
             if (i == j) continue;
             if (!fdo_pair_feature(s, i, j, dist_cutoff, feat)) continue;
-            uint32_t h = (nbin_dist == 0 || nbin_angle == 0) ? fdo_hash_pdbtr(feat, 16, 4)
-                                                            : fdo_hash_pdbtr(feat, nbin_dist, nbin_angle);
+            uint32_t h = fdo_hash_any(feat, nbin_dist, nbin_angle);
             if (n == cap) { cap *= 2; v = (uint32_t *)realloc(v, cap * sizeof *v); }
             v[n++] = h;
         }

@@ -147,8 +147,7 @@ static int qm_find(const fdo_query_map *m, uint32_t h) {
 /* query.rs:53-84 insert_binned_hash (no multiple_bin): first insert wins */
 static void insert_binned_hash(qm_builder *b, const float *feature, uint64_t qi, uint64_t qj, uint64_t nbin_dist,
                                uint64_t nbin_angle, int is_primary, float idf) {
-    uint32_t h = (nbin_dist == 0 || nbin_angle == 0) ? fdo_hash_pdbtr(feature, 16, 4)
-                                                    : fdo_hash_pdbtr(feature, nbin_dist, nbin_angle);
+    uint32_t h = fdo_hash_any(feature, nbin_dist, nbin_angle);
     fdo_query_map *m = b->m;
     if (qm_find(m, h)) return;
     if (m->n == b->cap) {
@@ -247,8 +246,7 @@ fdo_query_map *fdo_make_query_map(const fdo_structure *qs, const fdo_query_spec 
                 }
             }
             /* observed hash + idf (query.rs:17-32, 283-288) */
-            uint32_t oh = (nbin_dist == 0 || nbin_angle == 0) ? fdo_hash_pdbtr(feature, 16, 4)
-                                                             : fdo_hash_pdbtr(feature, nbin_dist, nbin_angle);
+            uint32_t oh = fdo_hash_any(feature, nbin_dist, nbin_angle);
             float idf = 0.0f;
             if (index) {
                 uint64_t *ids = NULL;
@@ -284,7 +282,9 @@ fdo_query_map *fdo_make_query_map(const fdo_structure *qs, const fdo_query_spec 
                 }
             }
             expand_and_insert(&b, dist_idx, 2, dist_thr, n_dist_thr, near, far, ri, rj, nbin_dist, nbin_angle, idf);
-            expand_and_insert(&b, ang_idx, 3, athr, n_angle_thr, near, far, ri, rj, nbin_dist, nbin_angle, idf);
+            /* angle_index (controller/feature.rs:279-291): theta only for the two PDBMotif forms — PDBMotif's degree-valued theta is
+             * shifted by the threshold in radians, as in the reference */
+            expand_and_insert(&b, ang_idx, fdo_get_hash_type() <= 1 ? 1 : 3, athr, n_angle_thr, near, far, ri, rj, nbin_dist, nbin_angle, idf);
         }
     }
     free(athr); free(sub_of); free(nsub_of); free(has_sub);

@@ -190,7 +190,13 @@ fdo_retrieval *fdo_retrieve(const fdo_structure *t, const fdo_structure *qs, con
         uint8_t seen1[256] = {0}, seen2[256] = {0};
         uint8_t *in1 = (uint8_t *)calloc((size_t)(t->n > 0 ? t->n : 1), 1), *in2 = (uint8_t *)calloc((size_t)(t->n > 0 ? t->n : 1), 1);
         for (uint64_t k = 0; k < m->n; ++k) {
-            uint8_t aa1 = (uint8_t)((m->hash[k] >> 25) & 0x1f), aa2 = (uint8_t)((m->hash[k] >> 20) & 0x1f);
+            /* residue types from the encoding's own reverse_hash (retrieve.rs:574-577) */
+            uint32_t hk = m->hash[k], ht = fdo_get_hash_type();
+            uint8_t aa1, aa2;
+            if (ht == 0) { aa1 = (uint8_t)((hk >> 20) & 0x1f); aa2 = (uint8_t)((hk >> 15) & 0x1f); }
+            else if (ht == 1) { aa1 = (uint8_t)((hk >> 21) & 0x1f); aa2 = (uint8_t)((hk >> 16) & 0x1f); }
+            else if (ht == 7 || ht == 8) { uint32_t pr = (hk >> 21) & 0x1ff; aa1 = (uint8_t)(pr / 20); aa2 = (uint8_t)(pr % 20); }
+            else { aa1 = (uint8_t)((hk >> 25) & 0x1f); aa2 = (uint8_t)((hk >> 20) & 0x1f); }
             if (!seen1[aa1]) {
                 seen1[aa1] = 1;
                 const char *nm = fdo_map_u8_to_aa(aa1);
@@ -230,8 +236,7 @@ fdo_retrieval *fdo_retrieve(const fdo_structure *t, const fdo_structure *qs, con
                 if (tmp_q.n == 0) continue;
                 if (!fdo_pair_feature(t, (int64_t)i, (int64_t)j, dist_cutoff, feature)) continue;
                 for (uint64_t e = 0; e < tmp_q.n; ++e) { v_push(&cq, tmp_q.v[e]); v_push(&cI, i); v_push(&cJ, j); }
-                uint32_t h = (nbin_dist == 0 || nbin_angle == 0) ? fdo_hash_pdbtr(feature, 16, 4)
-                                                                : fdo_hash_pdbtr(feature, nbin_dist, nbin_angle);
+                uint32_t h = fdo_hash_any(feature, nbin_dist, nbin_angle);
                 if (qm_lookup(m, h) >= 0) { v_push(&fi, i); v_push(&fj, j); v_push(&fh, h); }
             }
         }

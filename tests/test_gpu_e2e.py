@@ -161,6 +161,60 @@ def test_partial_fit_retrieval_matches_oracle(env):
     assert n_lms > 0
 
 
+@pytest.mark.parametrize("htype", [0, 1, 7, 8])
+def test_other_encodings_query_map_and_retrieval(env, htype, tmp_path):
+    """§8f rank 3, the encodings over the PDBTrRosetta descriptor: make_query_map (threshold expansion over the encoding's own
+    dist / angle feature indices, substitutions), retrieval (pair scan hashes, symmetry flags) and the CLI round trip through
+    `.type` equal the CPU restatement."""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    from folddisco_amd.__main__ import main as cli
+    ctx, structs, batch, _ix, nres, plddt, tids = env
+    ostructs = [oracle.read_pdb(p) for p in SER]
+    ix = fd.FolddiscoIndex.build(ctx, batch, hash_type=htype)
+    std = np.concatenate([s.resname_std() for s in structs])
+    with oracle.hash_type(htype):
+        oix, _, _ = oracle.build_index(ostructs)
+        for qpath, qstr in ((Q4CHA, "B57,B102,C195"), (Q1G2F, "F207:C,F212,F225:HX,F229"), (Q4CHA, "B57,B102,C195,B58,B59")):
+            oq = oracle.read_pdb(qpath)
+            om_ = oracle.make_query_map(oq, qstr, oix, 5.0, dist_thr=(0.5, 1.0), angle_thr=(5.0, 10.0))
+            om = om_.arrays()
+            q = st.read_compact_structure(qpath)
+            res = fq.parse_query_string(qstr, q.chains[0])
+            idx = [q.get_index(c, r) for c, r, _ in res]
+            qb = ctx.upload(fd.PackedStructures.concat([q.as_item()]))
+            m = fq.make_query_map(ctx, qb, idx, [x for _, _, x in res], ix, 5.0, dist_thr=(0.5, 1.0), angle_thr=(5.0, 10.0), hash_type=htype)
+            assert np.array_equal(m.hash, om["hash"]) and np.array_equal(m.qi, om["qi"]) and np.array_equal(m.qj, om["qj"])
+            assert np.array_equal(m.is_primary, om["is_primary"]) and np.array_equal(m.idf.view(np.uint32), om["idf"].view(np.uint32))
+            for ca_cut in (1.0, 3.0):
+                got = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=ca_cut, hash_type=htype)
+                for nid in range(5):
+                    R = oracle.retrieve(ostructs[nid], oq, om_, ca_distance_cutoff=ca_cut)
+                    mine = [g for g in got if g["cand"] == nid]
+                    assert len(mine) == len(R["processed"]), (htype, qstr, ca_cut, nid)
+                    for g, rp, rh in zip(mine, R["processed"], R["from_hash"]):
+                        assert g["processed"] == [-1 if x is None else x[2] for x in rp["residues"]]
+                        assert g["from_hash"] == [-1 if x is None else x[2] for x in rh["residues"]]
+                        assert abs(g["rmsd"] - rp["rmsd"]) <= 1e-4 and g["idf"] == pytest.approx(rp["idf"], rel=1e-6)
+    # CLI: index -y <name> writes the type into PREFIX.type, query reads it back
+    from folddisco_amd._lib import HASH_TYPE_NAMES
+    prefix = str(tmp_path / "ix")
+    cli(["index", "-p", os.path.dirname(SER[0]), "-i", prefix, "-y", HASH_TYPE_NAMES[htype]])
+    assert f'hash_type = "{HASH_TYPE_NAMES[htype]}"' in open(prefix + ".type").read()
+    v, hh, o = ix.export()
+    from folddisco_amd import indexio
+    dv, dh, do = indexio.read_index_files(prefix)
+    assert np.array_equal(dv, v) and np.array_equal(dh, hh) and np.array_equal(do, o)
+    out = str(tmp_path / "out.tsv")
+    cli(["query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", prefix, "-o", out])
+    rows = [l.rstrip("\n").split("\t") for l in open(out)]
+    q = st.read_compact_structure(Q4CHA)
+    _, want = fq.query_pdb(ctx, ix, batch, structs, [os.path.join(os.path.dirname(SER[0]), os.path.basename(p)) for p in SER], nres, plddt, q,
+                           "B57,B102,C195", hash_type=htype, sort_by="node_count,rmsd")      # the CLI's default --sort-by
+    assert [r[1:] for r in rows] == [fq.format_match_row(m).split("\t")[1:] for m in want] and len(rows) > 0
+
+
 def test_sharded_build_merge_and_disk_roundtrip(env, tmp_path):
     """index build shards by structure: two sub-indices built with id offsets merge into the byte-identical single index;
     the files written to disk load back (product loader and oracle loader) and answer the query identically."""

@@ -494,3 +494,43 @@ def test_lms_qcp_batch_matches_oracle(ctx):
         assert np.array_equal(_bits(rot[k]), _bits(R)) and np.array_equal(_bits(tran[k]), _bits(T)), (k, len(x))
     with pytest.raises(Exception):
         match.lms_qcp_batch(ctx, xs[:2], ys[:2], np.array([0, 2], np.uint64))     # the reference asserts >= 3 pairs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("htype,nbd,nba", [(0, 0, 0), (1, 0, 0), (7, 0, 0), (8, 0, 0), (0, 16, 8), (1, 12, 5), (7, 6, 20), (8, 40, 12), (3, 16, 0)])
+def test_other_encodings_hash_index_query(ctx, ser, htype, nbd, nba):
+    """The encodings that share the PDBTrRosetta descriptor (HashType 0 PDBMotif, 1 PDBMotifSinCos, 7 FolddiscoAngle, 8 FolddiscoDist,
+    §8f rank 3): raw and sorted hash lists, the index bytes, posting lengths and count_query records equal the CPU restatement;
+    (3, 16, 0) checks the reference's "either bin count 0 -> both default" rule on the default encoding."""
+    import folddisco_amd as fd
+    structs, ps, std, batch = ser
+    with oracle.hash_type(htype):
+        h, off = fd.get_geometric_hash_as_u32(ctx, batch, nbin_dist=nbd, nbin_angle=nba, sort_dedup=False, hash_type=htype)
+        for s, st in enumerate(structs):
+            ref = oracle.hash_structure(st, nbin_dist=nbd, nbin_angle=nba)
+            assert np.array_equal(h[int(off[s]):int(off[s + 1])], ref), f"structure {s}"
+        ix = fd.FolddiscoIndex.build(ctx, batch, nbin_dist=nbd, nbin_angle=nba, hash_type=htype)
+        oix, nres, plddt = oracle.build_index(structs, nbin_dist=nbd, nbin_angle=nba)
+        v, hh, o = ix.export()
+        assert np.array_equal(hh, oix.hashes()) and np.array_equal(o, oix.offsets()) and np.array_equal(v, oix.values())
+        q = oracle.read_pdb(Q4CHA)
+        m = oracle.make_query_map(q, "B57,B102,C195", oix, float(len(structs)), nbin_dist=nbd, nbin_angle=nba)
+        qh, qi, qj = _query_arrays(m)
+        assert list(ix.posting_lengths(qh)) == [len(oix.entries(int(x))) for x in qh]
+        got = fd.count_query(ctx, ix, qh, qi, qj, fd.length_penalty(nres, 0.5))
+        ref = oracle.count_query(m, oix, nres)
+        assert [(r["nid"], r["total_match_count"], r["node_count"], r["edge_count"]) for r in got] == \
+               [(r["nid"], r["total_match_count"], r["node_count"], r["edge_count"]) for r in ref]
+        for g, r in zip(got, ref):
+            assert abs(g["idf"] - r["idf"]) <= 1e-5 * max(abs(r["idf"]), 1e-30)
+
+
+@pytest.mark.gpu
+def test_unbuilt_encodings_are_refused(ctx, ser):
+    import folddisco_amd as fd
+    structs, ps, std, batch = ser
+    for htype in (2, 4, 5, 6, 9):
+        with pytest.raises(Exception):
+            fd.get_geometric_hash_as_u32(ctx, batch, hash_type=htype)
+        with pytest.raises(Exception):
+            fd.FolddiscoIndex.build(ctx, batch, hash_type=htype)

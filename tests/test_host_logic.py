@@ -260,3 +260,17 @@ def test_native_ingest_matches_python_and_oracle(tmp_path):
     plain.write_bytes(gzip.open(os.path.join(io, "AF-A0A4S3KKF6-F1-model_v4.cif.gz")).read())
     r, okf = structure.read_compact_structures([str(plain), str(tmp_path / "nope.pdb"), pdbs[0]], threads=2, max_residue=700)
     assert okf.tolist() == [1, 0, 1] and r[0].n == 0 and r[0].num_residues_raw == 738 and r[1].n == 0 and r[2].n == nat[0].n
+
+
+def test_hash_type_names_and_aliases():
+    """HashType::get_with_str / to_string (src/geometry/core.rs:42-75)"""
+    from folddisco_amd._lib import HASH_TYPE_NAMES, hash_type_index
+    for k, v in HASH_TYPE_NAMES.items():
+        assert hash_type_index(v) == k and hash_type_index(str(k)) == k
+    for alias, want in (("default", 3), ("folddisco", 3), ("pdbtr", 3), ("pdb", 1), ("pyscomotif", 0), ("orig_pdb", 0), ("tr", 2), ("ppf", 4),
+                        ("3di", 5), ("tertiary", 5), ("hybrid", 6), ("angle", 7), ("folddisco_angle", 7), ("dist", 8), ("distance", 8),
+                        ("folddisco_dist", 8)):
+        assert hash_type_index(alias) == want
+    import pytest
+    with pytest.raises(ValueError):
+        hash_type_index("nonsense")

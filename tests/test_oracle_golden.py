@@ -312,3 +312,50 @@ def test_lms_qcp_partial_fit_properties():
     assert len(core) == 12 and 0.0 < rms < 0.2
     again = oracle.lms_qcp(x, y)
     assert again[0] == rms and np.array_equal(again[3], core)     # fixed seed: deterministic
+
+
+def _disc(v, mn, mx, nb):
+    """convert.rs:32-36 in numpy f32"""
+    f = np.float32
+    cont = (f(mx) - f(mn)) / (f(nb) - f(1.0))
+    disc = f(1.0) / cont
+    return int(np.uint32((f(v) - f(mn)) * disc + f(0.5)))
+
+
+def test_other_encodings_bit_layouts():
+    """The eight non-default encodings hold no asserting tests in the reference (theirs only print).  The restatements of the four
+    that share the PDBTrRosetta descriptor are checked against an independent numpy-f32 evaluation of the published bit layouts
+    (pdb_motif.rs:48, pdb_motif_sincos.rs:50-51, folddisco_angle.rs:68-69, folddisco_dist.rs:61-62) on the reference's own test
+    feature (PHE, VAL, 14.0, 15.9, 116, 80, -100 degrees; e.g. folddisco_angle.rs:163-165), and the either-bin-0 -> defaults rule."""
+    f32 = np.float32
+    PI = f32(3.14159274)
+    rad = lambda d: f32(d) * (PI / f32(180.0))
+    phe, val = 13, 19        # map_aa_to_u8 (convert.rs:53-81)
+    with oracle.hash_type(0):
+        h = oracle.hash_any([phe, val, 14.0, 15.9, 116.0])
+        assert h == (phe << 20 | val << 15 | _disc(14.0, 2, 20, 18) << 10 | _disc(15.9, 2, 20, 18) << 5 | _disc(116.0, 0, 180, 9))
+        assert oracle.hash_any([phe, val, 14.0, 15.9, 116.0], 16, 8) == \
+            (phe << 20 | val << 15 | _disc(14.0, 2, 20, 16) << 10 | _disc(15.9, 2, 20, 16) << 5 | _disc(116.0, 0, 180, 8))
+        assert oracle.hash_any([phe, val, 14.0, 15.9, 116.0], 16, 0) == h      # one bin count 0 -> both default
+    with oracle.hash_type(1):
+        a = rad(116.0)
+        s, c = np.sin(a, dtype=f32), np.cos(a, dtype=f32)
+        assert oracle.hash_any([phe, val, 14.0, 15.9, a], 8, 3) == \
+            (phe << 21 | val << 16 | _disc(14.0, 2, 20, 8) << 12 | _disc(15.9, 2, 20, 8) << 8 | _disc(s, -1, 1, 3) << 4 | _disc(c, -1, 1, 3))
+    feat = [phe, val, 14.0, 15.9, rad(116.0), rad(80.0), rad(-100.0)]
+    pair = phe * 20 + val
+    with oracle.hash_type(7):
+        assert oracle.hash_any(feat) == (pair << 21 | _disc(14.0, 2, 20, 8) << 18 | _disc(15.9, 2, 20, 8) << 15 | _disc(feat[4], 0, PI, 32) << 10 |
+                                         _disc(feat[5], -PI, PI, 32) << 5 | _disc(feat[6], -PI, PI, 32))
+        assert oracle.hash_any(feat, 4, 12) == (pair << 21 | _disc(14.0, 2, 20, 4) << 18 | _disc(15.9, 2, 20, 4) << 15 | _disc(feat[4], 0, PI, 12) << 10 |
+                                                _disc(feat[5], -PI, PI, 12) << 5 | _disc(feat[6], -PI, PI, 12))
+    with oracle.hash_type(8):
+        assert oracle.hash_any(feat) == (pair << 21 | _disc(14.0, 2, 20, 32) << 16 | _disc(15.9, 2, 20, 32) << 11 | _disc(feat[4], 0, PI, 8) << 8 |
+                                         _disc(feat[5], -PI, PI, 16) << 4 | _disc(feat[6], -PI, PI, 16))
+        assert oracle.hash_any(feat, 40, 12) == (pair << 21 | _disc(14.0, 2, 20, 32) << 16 | _disc(15.9, 2, 20, 32) << 11 | _disc(feat[4], 0, PI, 8) << 8 |
+                                                 _disc(feat[5], -PI, PI, 12) << 4 | _disc(feat[6], -PI, PI, 12))
+    with pytest.raises(ValueError):
+        with oracle.hash_type(4):
+            pass
+    # the default encoding is untouched by the switch
+    assert oracle.hash_any(feat) == oracle.hash_any(feat, 16, 4)

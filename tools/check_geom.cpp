@@ -46,6 +46,8 @@ int main(int argc, char **argv) {
     volatile float cd = (20.0f - 2.0f) / (16.0f - 1.0f), ca = 2.0f / 3.0f;
     q.dist_disc = 1.0f / cd;
     q.ang_disc = 1.0f / ca;
+    q.ang2_disc = 0.0f;
+    q.type = FD_HASH_PDBTR;
     long bad = 0;
     for (int a = 1; a < argc; ++a) {
         fdo_structure *s = fdo_read_pdb(argv[a]);
