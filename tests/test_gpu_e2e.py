@@ -574,3 +574,50 @@ def test_synthetic_database_full_query_matches_oracle():
                 assert abs(g["rmsd"] - rp["rmsd"]) <= 1e-4 and g["idf"] == pytest.approx(rp["idf"], rel=1e-6)
                 n_checked += 1
     assert n_checked >= 6      # at least every query's own structure matches itself
+
+
+def test_whole_structure_query_matches_oracle():
+    """BASELINE config 5, whole-structure query mode (no -q): every residue of the query structure is a query residue
+    (query.rs:226-233), the query map has far more than 200 hashes so retrieval scans all N^2 residue pairs without the amino-acid
+    prefilter (retrieve.rs:146-153, 569-571).  Query map, prefilter records and the matches of the top candidates equal the oracle."""
+    import folddisco_amd as fd
+    from folddisco_amd import dist as fdist
+    from folddisco_amd import query as fq
+    from tests.helpers import synthetic_packed
+    ctx = fd.Context(0)
+    S = 24
+    ps = synthetic_packed(S, 31, lengths=np.full(S, 48))
+    batch = ctx.upload(ps)
+    ix = fd.FolddiscoIndex.build(ctx, batch)
+    structs = packed_to_oracle_structs(ps)
+    oix, onres, _ = oracle.build_index(structs)
+    pen = fd.length_penalty(np.diff(ps.res_off).astype(np.uint64), 0.5)
+    for s in (0, 7):
+        a, b = int(ps.res_off[s]), int(ps.res_off[s + 1])
+        item = dict(n_xyz=ps.n_xyz[a:b], ca_xyz=ps.ca_xyz[a:b], cb_xyz=ps.cb_xyz[a:b], aa=ps.aa[a:b])
+        qb = ctx.upload(fd.PackedStructures.concat([item]))
+        qm = fq.make_query_map(ctx, qb, np.arange(b - a, dtype=np.uint32), None, ix, float(S))
+        om = oracle.make_query_map(structs[s], "", oix, float(S))
+        oa = om.arrays()
+        assert len(qm.hash) > 200
+        assert np.array_equal(qm.hash, oa["hash"]) and np.array_equal(qm.qi, oa["qi"]) and np.array_equal(qm.qj, oa["qj"])
+        assert np.array_equal(qm.idf.view(np.uint32), oa["idf"].view(np.uint32))
+        recs = fd.count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S, as_array=True)
+        want = oracle.count_query(om, oix, onres)
+        assert [(int(r["nid"]), int(r["total_match_count"]), int(r["node_count"]), int(r["edge_count"])) for r in recs] == \
+               [(w["nid"], w["total_match_count"], w["node_count"], w["edge_count"]) for w in want]
+        cand = fdist.rank_hits(recs, 4)["nid"].astype(np.uint32)
+        assert int(cand[0]) == s                                  # the structure itself ranks first
+        got = fq.retrieve(ctx, batch, None, cand, qm, qb)
+        n = 0
+        for slot, nid in enumerate(cand):
+            R = oracle.retrieve(structs[int(nid)], structs[s], om)
+            mine = [g for g in got if g["cand"] == slot]
+            assert len(mine) == len(R["processed"]), (s, nid)
+            for g, rp, rh in zip(mine, R["processed"], R["from_hash"]):
+                assert g["processed"] == [-1 if x is None else x[2] for x in rp["residues"]]
+                assert g["from_hash"] == [-1 if x is None else x[2] for x in rh["residues"]]
+                assert abs(g["rmsd"] - rp["rmsd"]) <= 1e-4 and g["idf"] == pytest.approx(rp["idf"], rel=1e-5)
+                n += 1
+        assert n >= 1
+    ctx.close()
