@@ -12,6 +12,7 @@
 #include <string.h>
 #include <algorithm>
 #include <map>
+#include <unordered_map>
 #include <vector>
 #include "fdgpu_internal.h"
 #include <chrono>
@@ -270,10 +271,11 @@ namespace {
 struct Graph {
     std::vector<uint32_t> w;           // node -> residue index (first-appearance order, graph.rs:16-26)
     std::vector<uint32_t> es, et, eh;  // edges in insertion order
+    std::unordered_map<uint32_t, uint32_t> at;
     uint32_t node_of(uint32_t res) {
-        for (uint32_t k = 0; k < w.size(); ++k) if (w[k] == res) return k;
-        w.push_back(res);
-        return (uint32_t)w.size() - 1;
+        auto ins = at.emplace(res, (uint32_t)w.size());
+        if (ins.second) w.push_back(res);
+        return ins.first->second;
     }
 };
 
@@ -421,7 +423,15 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     }
     fd_pair_rec *found = nullptr; fd_cand_rec *cands = nullptr;
     uint64_t nf = 0, nc = 0;
-    int rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc);
+    // Candidate pairs (the rescue's raw material, retrieve.rs:120-121) number ~ pairs x observed-list entries: a whole-structure
+    // query makes millions per candidate structure.  Large queries therefore scan twice: found triples only, then — once the
+    // components and their residue mappings are known — candidate pairs only for partner residues some component mapped
+    // (the rescue counts nothing else, retrieve.rs:498-511).
+    uint64_t max_aad = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) max_aad = std::max<uint64_t>(max_aad, qms[t]->n_aad);
+    const char *tp_env = getenv("FDGPU_TWO_PASS");     // 1 / 0 force the choice (tests)
+    const bool two_pass = tp_env ? tp_env[0] == '1' : max_aad > 4096;
+    int rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc, two_pass ? 1u : 7u);
     if (rc) return rc;
     auto T1 = t_now();
     // symmetry flags (geometry/pdb_tr.rs:158-162): aa equal and atan2(sin, cos) of the two torsion fields equal; the other encodings
@@ -474,6 +484,12 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     auto T2 = t_now();
+    std::vector<uint32_t> mask_off(n_cand + 1, 0), cj_mask((g_total + 31) / 32 + 1, 0);
+    for (uint64_t k = 0; k < n_cand; ++k) mask_off[k] = (uint32_t)g_dst[k];
+    bool any_rescue = false;
+    // plan = true: components and mappings only, marking the mapped residues of every component that leaves a query residue
+    // unmatched (first pass of a large query); plan = false: the full body
+    auto run_slots = [&](const bool plan) {
     size_t fpos = 0, cpos = 0;
     uint64_t tq = 0;
     for (uint64_t slot = 0; slot < n_cand; ++slot) {
@@ -518,6 +534,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             // reference's running update converges to, counts only grow).
             struct Vote { uint32_t q, r; uint32_t c; };
             std::vector<Vote> votes;
+            std::unordered_map<uint64_t, uint32_t> vote_at;     // (q, r) -> position in votes (first-seen order kept in the vector)
             for (size_t e = 0; e < g.es.size(); ++e) {
                 if (!inc[g.es[e]] || !inc[g.et[e]]) continue;
                 auto it = entry.find(g.eh[e]);
@@ -529,17 +546,18 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
                 if (is_sym(g.eh[e])) { pq[0] = std::min(qi, qj); pq[1] = std::max(qi, qj); pr[0] = std::min(ri, rj); pr[1] = std::max(ri, rj); }
                 else { pq[0] = qi; pr[0] = ri; pq[1] = qj; pr[1] = rj; }
                 for (int z = 0; z < 2; ++z) {
-                    bool seen = false;
-                    for (auto &v : votes) if (v.q == pq[z] && v.r == pr[z]) { if (v.c < 255) ++v.c; seen = true; break; }
-                    if (!seen) votes.push_back({pq[z], pr[z], 1u});
+                    auto ins = vote_at.emplace(((uint64_t)pq[z] << 32) | pr[z], (uint32_t)votes.size());
+                    if (ins.second) votes.push_back({pq[z], pr[z], 1u});
+                    else if (votes[ins.first->second].c < 255) ++votes[ins.first->second].c;
                 }
             }
             struct Best { uint32_t q, c, r; };
             std::vector<Best> best;
+            std::unordered_map<uint32_t, uint32_t> best_at;
             for (auto &v : votes) {
-                Best *bq = nullptr;
-                for (auto &x : best) if (x.q == v.q) { bq = &x; break; }
-                if (!bq) { best.push_back({v.q, v.c, v.r}); continue; }
+                auto ins = best_at.emplace(v.q, (uint32_t)best.size());
+                if (ins.second) { best.push_back({v.q, v.c, v.r}); continue; }
+                Best *bq = &best[ins.first->second];
                 if (v.c > bq->c || (v.c == bq->c && v.r < bq->r)) { bq->c = v.c; bq->r = v.r; }
             }
             // greedy assignment in (count descending, query residue ascending) order (retrieve.rs:668-690)
@@ -549,6 +567,15 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
                 if (q_idx.size() == cc.size()) break;
                 if (std::find(r_idx.begin(), r_idx.end(), x.r) != r_idx.end()) continue;
                 q_idx.push_back(x.q); r_idx.push_back(x.r);
+            }
+            if (plan) {   // a query residue without a target leaves work for the rescue: its votes come from pairs whose partner is mapped
+                bool unmatched = false;
+                for (uint64_t pos = 0; pos < NQ && !unmatched; ++pos) unmatched = std::find(q_idx.begin(), q_idx.end(), qm->indices[pos]) == q_idx.end();
+                if (unmatched) {
+                    any_rescue = true;
+                    for (uint32_t r : r_idx) if (r < Rt) { const uint32_t bit = mask_off[slot] + r; cj_mask[bit >> 5] |= 1u << (bit & 31u); }
+                }
+                continue;
             }
             for (uint32_t r : r_idx) if (r < Rt) mapped_r[r] = 1;
             // residue assignment + rescue (retrieve.rs:430-516)
@@ -615,8 +642,33 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             if (!rec.same) add_problem(qs_sc, rs_sc, 1);
         }
     }
-    free(found); free(cands);
     while (tq < n_queries) { ++tq; m_off[tq] = recs.size(); r_off[tq] = res.size(); }
+    };
+    if (two_pass) {
+        run_slots(true);
+        if (trace) fprintf(stderr, "[fdgpu_retrieve] plan pass %.3f ms\n", t_ms(T2, t_now()));
+        free(cands); cands = nullptr; nc = 0;
+        if (any_rescue) {
+            fd_pair_rec *f2 = nullptr; uint64_t nf2 = 0;
+            rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &f2, &nf2, &cands, &nc, 6u, cj_mask.data(),
+                                      mask_off.data(), cj_mask.size());
+            free(f2);
+            if (rc) { free(found); return rc; }
+            if (trace) fprintf(stderr, "[fdgpu_retrieve] second scan done at %.3f ms (cands %llu)\n", t_ms(T2, t_now()), (unsigned long long)nc);
+        }
+    }
+    if (nc) {   // candidate pairs arrive in atomic-append order: group them by candidate slot (counting sort; order inside a slot is free)
+        std::vector<uint64_t> so(n_cand + 2, 0);
+        for (uint64_t e = 0; e < nc; ++e) ++so[cands[e].cand + 1];
+        for (uint64_t k = 0; k < n_cand; ++k) so[k + 1] += so[k];
+        fd_cand_rec *g2 = (fd_cand_rec *)malloc(nc * sizeof(fd_cand_rec));
+        if (!g2) { free(found); free(cands); return FDGPU_ENOMEM; }
+        for (uint64_t e = 0; e < nc; ++e) g2[so[cands[e].cand]++] = cands[e];
+        free(cands); cands = g2;
+    }
+    run_slots(false);
+    if (trace) fprintf(stderr, "[fdgpu_retrieve] slots done at %.3f ms\n", t_ms(T2, t_now()));
+    free(found); free(cands);
     const uint64_t nprob = pend.size();
     std::vector<float> rmsd(std::max<uint64_t>(nprob, 1)), rot(std::max<uint64_t>(nprob, 1) * 9), tran(std::max<uint64_t>(nprob, 1) * 3);
     auto T3 = t_now();

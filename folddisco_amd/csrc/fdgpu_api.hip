@@ -854,7 +854,8 @@ extern "C" int fdgpu_count_query_batch_top(fdgpu_ctx *c, const fdgpu_index *ix, 
 // GLOBAL slot (position in cand) and come back sorted by (slot, i, j).
 int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
                          const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
-                         fd_cand_rec **cands, uint64_t *n_cands) {
+                         fd_cand_rec **cands, uint64_t *n_cands, uint32_t mode, const uint32_t *cj_mask, const uint32_t *mask_off,
+                         uint64_t mask_words) {
     if (!c || !db || !p || !found || !n_found || !cands || !n_cands || !cand_off || (n_queries && !qs)) return FDGPU_EINVAL;
     const uint64_t n_cand = cand_off[n_queries];
     if (n_cand && !cand) return FDGPU_EINVAL;
@@ -926,6 +927,13 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     }
     mp_args A;
     memset(&A, 0, sizeof A);
+    A.mode = mode;
+    if (cj_mask && mask_off) {   // partner-residue filter (second pass of a large query's retrieval)
+        HIPCHK(c, c->ws[WS_MISC1].ensure((mask_words + n_cand + 2) * 4));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, cj_mask, mask_words * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].as<uint32_t>() + mask_words, mask_off, n_cand * 4, hipMemcpyHostToDevice, st));
+        A.cj_mask = c->ws[WS_MISC1].as<uint32_t>(); A.mask_off = A.cj_mask + mask_words;
+    }
     A.B = db->view(); A.C = make_consts(p); A.cutoff = p->dist_cutoff;
     A.cand = dblk + o_cand; A.n_cand = (uint32_t)n_cand;
     A.wi_cand = dblk + o_wc; A.wi_i0 = dblk + o_wi; A.wi_query = dblk + o_wq; A.n_work = (uint32_t)nw;
@@ -968,7 +976,8 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         if (a.i != b.i) return a.i < b.i;
         return a.j < b.j;
     });
-    std::stable_sort(hc, hc + tot[1], [](const fd_cand_rec &a, const fd_cand_rec &b) {
+    // mode bit 2: the caller buckets the candidate pairs itself and does not depend on their order (the rescue only counts them)
+    if (!(mode & 4u)) std::stable_sort(hc, hc + tot[1], [](const fd_cand_rec &a, const fd_cand_rec &b) {
         if (a.cand != b.cand) return a.cand < b.cand;
         if (a.i != b.i) return a.i < b.i;
         return a.j < b.j;

@@ -196,6 +196,9 @@ struct mp_args {
     unsigned long long *n_found, *n_cands;
     fd_pair_rec *found; fd_cand_rec *cands;
     unsigned long long cap_found, cap_cands;   // records the buffers hold (EMIT counts beyond them without writing)
+    uint32_t mode;                 // bit 0: emit found triples, bit 1: emit candidate pairs
+    const uint32_t *cj_mask;       // optional: only partner residues j whose bit mask_off[slot] + (j - r0) is set are scanned
+    const uint32_t *mask_off;      // [n_cand] first bit of every candidate slot
 };
 void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st);
 void fd_launch_kabsch(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, hipStream_t st);
@@ -211,4 +214,5 @@ void fd_launch_get_entries(const uint32_t *hashes, const uint64_t *offsets, cons
                            const uint64_t *out_off, uint32_t *out, hipStream_t st);
 int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
                          const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
-                         fd_cand_rec **cands, uint64_t *n_cands);
+                         fd_cand_rec **cands, uint64_t *n_cands, uint32_t mode = 3, const uint32_t *cj_mask = nullptr,
+                         const uint32_t *mask_off = nullptr, uint64_t mask_words = 0);

@@ -54,7 +54,8 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
             fd_feature f = fd_pair_feature(fd_load3(A.B.n_xyz, i), cai, fd_load3(A.B.cb_xyz, i), fd_load3(A.B.n_xyz, j), caj, fd_load3(A.B.cb_xyz, j));
             h = fd_hash_enc(aai, aaj, f, A.C.q);
         }
-        hit = hash_in_set(A.q_hashes, A.n_hashes, h);
+        hit = (A.mode & 1u) && hash_in_set(A.q_hashes, A.n_hashes, h);
+        if (!(A.mode & 2u)) n_win = 0;
     }
     // one atomic per counter and drain (per-record atomics on two addresses serialise in one L2 channel: that, not the
     // arithmetic, was the kernel time)
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
         if (jin) cj = fd_load3(A.B.ca_xyz, jl);
         bool okj = jin && aaj_l != 255u && A.B.hash_ok[jl];
         if (!full) okj = okj && aaj_l < 20u && (A.resname_std == nullptr || A.resname_std[jl]) && ((A.aa2_mask >> aaj_l) & 1u);
+        if (A.cj_mask && okj) { const uint32_t bit = A.mask_off[slot] + (jl - r0); okj = (A.cj_mask[bit >> 5] >> (bit & 31u)) & 1u; }
         const uint64_t okm = __ballot(okj);
         const uint32_t nj = (r1 - jb) < FD_WAVE ? (r1 - jb) : FD_WAVE;
         for (uint32_t k = 0; k < nj; ++k) {

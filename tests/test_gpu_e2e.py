@@ -621,3 +621,51 @@ def test_whole_structure_query_matches_oracle():
                 n += 1
         assert n >= 1
     ctx.close()
+
+
+def test_two_pass_retrieval_equals_single_pass(env, monkeypatch):
+    """Large queries scan the candidates twice (found triples, then candidate pairs restricted to the partner residues some
+    component mapped — the only ones the rescue counts): same matches, rescued residues included, as the single scan."""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    from tests.helpers import synthetic_packed
+    ctx, structs, batch, ix, nres, plddt, tids = env
+    std = np.concatenate([s.resname_std() for s in structs])
+
+    def same(a, b):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert x["cand"] == y["cand"] and x["processed"] == y["processed"] and x["from_hash"] == y["from_hash"] and x["same"] == y["same"]
+            assert x["rmsd"] == y["rmsd"] and x["rmsd_from_hash"] == y["rmsd_from_hash"] and x["idf"] == y["idf"]
+
+    n_rescued = 0
+    q = st.read_compact_structure(Q4CHA)
+    qb = ctx.upload(fd.PackedStructures.concat([q.as_item()]))
+    for qstr, ca_cut in (("B57,B102,C195", 1.0), ("B57,B102,C195,B58,B59,C999", 3.0), ("B57,B102,C195,C194,C196,B56,C214", 3.0), ("B40-70", 2.0)):
+        res = fq.parse_query_string(qstr, q.chains[0])
+        idx = [i for i in (q.get_index(c, r) for c, r, _ in res) if i is not None]
+        m = fq.make_query_map(ctx, qb, idx, None, ix, 5.0)
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("FDGPU_TWO_PASS", mode)
+            out[mode] = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=ca_cut)
+        same(out["0"], out["1"])
+        n_rescued += sum(1 for g in out["1"] if not g["same"])
+    assert n_rescued > 0          # the rescue path ran
+    # whole-structure queries on a synthetic shard
+    S = 16
+    ps = synthetic_packed(S, 77, lengths=np.full(S, 64))
+    sb = ctx.upload(ps)
+    six = fd.FolddiscoIndex.build(ctx, sb)
+    for s in (3, 9):
+        a, b = int(ps.res_off[s]), int(ps.res_off[s + 1])
+        qb2 = ctx.upload(fd.PackedStructures.concat([dict(n_xyz=ps.n_xyz[a:b], ca_xyz=ps.ca_xyz[a:b], cb_xyz=ps.cb_xyz[a:b], aa=ps.aa[a:b])]))
+        m = fq.make_query_map(ctx, qb2, np.arange(b - a, dtype=np.uint32), None, six, float(S))
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("FDGPU_TWO_PASS", mode)
+            out[mode] = fq.retrieve(ctx, sb, None, np.arange(S, dtype=np.uint32), m, qb2, ca_distance_cutoff=1.5)
+        same(out["0"], out["1"])
+        assert any(g["cand"] == s for g in out["1"])
+    monkeypatch.delenv("FDGPU_TWO_PASS")
