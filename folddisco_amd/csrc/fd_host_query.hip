@@ -514,16 +514,20 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         (void)s;
         const float *t_ca = t_all.data() + 3 * g_dst[slot], *t_cb = t_all.data() + 3 * g_total + 3 * g_dst[slot];
         const uint32_t Rt = (uint32_t)(g_dst[slot + 1] - g_dst[slot]);
-        // candidate pairs of this structure bucketed by query residue (counting sort, order inside a bucket preserved)
-        std::vector<uint32_t> by_qi_off(q_size + 2, 0), by_qi_i(cpos - c0), by_qi_j(cpos - c0);
-        for (size_t e = c0; e < cpos; ++e) if (cands[e].qi < q_size) ++by_qi_off[cands[e].qi + 1];
-        for (uint32_t z = 0; z <= q_size; ++z) by_qi_off[z + 1] += by_qi_off[z];
-        {
-            std::vector<uint32_t> cur(by_qi_off.begin(), by_qi_off.end() - 1);
-            for (size_t e = c0; e < cpos; ++e) if (cands[e].qi < q_size) { uint32_t k = cur[cands[e].qi]++; by_qi_i[k] = cands[e].i; by_qi_j[k] = cands[e].j; }
+        // candidate pairs of this structure bucketed by their partner residue j (counting sort): a component's rescue counts, per
+        // unmatched query residue, the pairs whose partner the component mapped (retrieve.rs:498-511) — one walk over the
+        // buckets of its mapped residues instead of one over every pair per query residue (whole-structure queries: millions)
+        const bool have_c = cpos > c0;
+        auto c_ok = [&](const fd_cand_rec &r) { return r.qi < q_size && r.i < Rt && r.j < Rt; };
+        std::vector<uint32_t> by_cj_off(have_c ? Rt + 2 : 2, 0), by_cj_qi(have_c ? cpos - c0 : 0), by_cj_i(have_c ? cpos - c0 : 0);
+        if (have_c) {
+            for (size_t e = c0; e < cpos; ++e) if (c_ok(cands[e])) ++by_cj_off[cands[e].j + 1];
+            for (uint32_t z = 0; z <= Rt; ++z) by_cj_off[z + 1] += by_cj_off[z];
+            std::vector<uint32_t> cur(by_cj_off.begin(), by_cj_off.end() - 1);
+            for (size_t e = c0; e < cpos; ++e) if (c_ok(cands[e])) { uint32_t k = cur[cands[e].j]++; by_cj_qi[k] = cands[e].qi; by_cj_i[k] = cands[e].i; }
         }
-        std::vector<uint32_t> vote_of(Rt, 0), vote_touched;
-        std::vector<char> mapped_r(Rt, 0);
+        std::vector<uint32_t> votes2(have_c ? (size_t)q_size * Rt : 0, 0), v_touched, q_touched;
+        std::vector<uint32_t> r_mx(q_size, 0), r_nmx(q_size, 0), r_arg(q_size, 0);
         for (auto &cc : comps) {
             std::vector<char> inc(g.w.size(), 0);
             for (uint32_t v : cc) inc[v] = 1;
@@ -577,7 +581,24 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
                 }
                 continue;
             }
-            for (uint32_t r : r_idx) if (r < Rt) mapped_r[r] = 1;
+            // rescue votes of this component: (query residue, target residue) -> pairs whose partner is one of its mapped residues
+            if (have_c) {
+                for (uint32_t r : r_idx) {
+                    if (r >= Rt) continue;
+                    for (uint32_t z = by_cj_off[r]; z < by_cj_off[r + 1]; ++z) {
+                        const uint32_t ix2 = by_cj_qi[z] * Rt + by_cj_i[z];
+                        if (votes2[ix2]++ == 0) v_touched.push_back(ix2);
+                    }
+                }
+                for (uint32_t ix2 : v_touched) {
+                    const uint32_t vq = ix2 / Rt, vr = ix2 % Rt, vc = votes2[ix2];
+                    if (r_mx[vq] == 0) q_touched.push_back(vq);
+                    if (vc > r_mx[vq]) { r_mx[vq] = vc; r_nmx[vq] = 1; r_arg[vq] = vr; }
+                    else if (vc == r_mx[vq]) ++r_nmx[vq];
+                    votes2[ix2] = 0;
+                }
+                v_touched.clear();
+            }
             // residue assignment + rescue (retrieve.rs:430-516)
             std::vector<int32_t> from_hash(NQ, -1), processed(NQ, -1);
             std::vector<uint32_t> qs_sc, rs_sc;
@@ -597,30 +618,14 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
                         qs_sc.push_back(qi); rs_sc.push_back((uint32_t)mapped);
                     }
                 } else {
-                    // votes per target residue among this query residue's candidate pairs whose partner is already mapped;
-                    // the candidate's pairs are bucketed by query residue once (whole-structure queries have millions)
-                    std::vector<std::pair<uint32_t, uint32_t>> cnt;  // (target residue, votes), first-seen order
-                    if (qi < q_size) {
-                        for (uint32_t t : vote_touched) vote_of[t] = 0;
-                        vote_touched.clear();
-                        for (uint32_t z = by_qi_off[qi]; z < by_qi_off[qi + 1]; ++z) {
-                            const uint32_t ci = by_qi_i[z], cj = by_qi_j[z];
-                            if (cj >= Rt || ci >= Rt || !mapped_r[cj]) continue;
-                            if (vote_of[ci]++ == 0) vote_touched.push_back(ci);
-                        }
-                        for (uint32_t t : vote_touched) cnt.emplace_back(t, vote_of[t]);
-                    }
-                    if (!cnt.empty()) {
-                        uint32_t mx = 0, nmx = 0, arg = 0;
-                        for (auto &kv : cnt) mx = std::max(mx, kv.second);
-                        for (auto &kv : cnt) if (kv.second == mx) { ++nmx; arg = kv.first; }
-                        if (nmx == 1 && mx >= 2 && std::find(rs_sc.begin(), rs_sc.end(), arg) == rs_sc.end()) {
-                            processed[pos] = (int32_t)arg; qs_sc.push_back(qi); rs_sc.push_back(arg);
-                        }
+                    // the target residue with the unique highest vote (>= 2) joins, unless it is taken (retrieve.rs:498-511)
+                    if (qi < q_size && r_nmx[qi] == 1 && r_mx[qi] >= 2 && std::find(rs_sc.begin(), rs_sc.end(), r_arg[qi]) == rs_sc.end()) {
+                        processed[pos] = (int32_t)r_arg[qi]; qs_sc.push_back(qi); rs_sc.push_back(r_arg[qi]);
                     }
                 }
             }
-            for (uint32_t r : r_idx) if (r < Rt) mapped_r[r] = 0;
+            for (uint32_t vq : q_touched) { r_mx[vq] = 0; r_nmx[vq] = 0; }
+            q_touched.clear();
             fd_match_rec rec;
             memset(&rec, 0, sizeof rec);
             rec.cand = (uint32_t)(slot - cand_off[tq]); rec.idf = sub_idf;
