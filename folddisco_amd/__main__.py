@@ -291,7 +291,24 @@ def main(argv=None):
     pq.add_argument("-o", "--output", default="")
     pq.add_argument("-v", "--verbose", action="store_true")
     pq.add_argument("--device", type=int, default=0)
+    pa = sub.add_parser("analyze")                                   # src/cli/workflows/analyze.rs:19-40 (summary branch)
+    pa.add_argument("-i", "--index", required=True)
+    pa.add_argument("-p", "--pdbs", default=None)
+    pa.add_argument("-o", "--output", default=None)
+    pa.add_argument("--top", type=int, default=10)
+    pa.add_argument("--p-value", type=float, default=0.0001)
+    pa.add_argument("--min-support", type=int, default=4)
+    pa.add_argument("--max-pos", type=int, default=32)
+    pa.add_argument("-t", "--threads", type=int, default=1)
+    pa.add_argument("-v", "--verbose", action="store_true")
     a = ap.parse_args(argv)
+    if a.cmd == "analyze":
+        from folddisco_amd import analyze
+        if a.pdbs is not None:
+            sys.exit("[FAIL] analyze -p (enrichment against a structure set) is not implemented; only the index summary is")
+        out = a.output or f"{a.index}_summary"                       # analyze.rs:71-84
+        analyze.save_summary(analyze.summarize(a.index), out, a.top)
+        return
     if a.cmd == "index":
         try:
             a.hash_type = hash_type_index(a.type)
