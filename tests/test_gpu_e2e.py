@@ -315,6 +315,8 @@ def test_cli_filters_sort_and_sampling(tmp_path):
                               cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
     base = q()
     assert len(base) == 6
+    # --partial-fit: matches of at most 3 residues keep the Kabsch superposition (retrieve.rs:735-740)
+    assert q("--partial-fit") == base
     # MatchFilter: connected node count / ratio, rmsd, idf score
     assert q("--connected-node", "3") == base[:3]
     assert q("--connected-node-ratio", "0.9") == base[:3]
