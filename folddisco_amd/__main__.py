@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-from folddisco_amd._lib import HASH_TYPE_NAMES, hash_type_index
+from folddisco_amd._lib import HASH_TYPE_NAMES, hash_type_index, parse_multiple_bins
 
 
 def _load_paths(d: str, recursive: bool):
@@ -83,7 +83,7 @@ def cmd_index(a):
         nres_all.append(nres_c)
         plddt_all.append(np.where(nres_c > 0, plddt_c, np.float32(0.0)).astype(np.float32))
         batch = ctx.upload(ps)
-        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid, hash_type=a.hash_type)
+        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid, hash_type=a.hash_type, multiple_bins=a.multi)
         if len(paths) <= a.chunk:
             ix.save(prefix)                       # single chunk: the library writes PREFIX and PREFIX.offset itself
             n_hashes, value_len = ix.num_hashes, ix.value_len
@@ -96,7 +96,7 @@ def cmd_index(a):
         n_hashes, value_len = len(h), len(v)
     nres, plddt = np.concatenate(nres_all), np.concatenate(plddt_all)
     indexio.save_lookup(prefix + ".lookup", paths, nres, plddt)
-    indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type])
+    indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type], multiple_bins=a.multi)
     if a.verbose:
         print(f"[DONE] {len(paths)} structures, {n_hashes} hashes, {value_len} value bytes -> {prefix}", file=sys.stderr)
 
@@ -116,7 +116,7 @@ def _build_chunks(a, fd, structure, ctx, paths, first_id):
         nres_all.append(nres_c)
         plddt_all.append(np.where(nres_c > 0, plddt_c, np.float32(0.0)).astype(np.float32))
         batch = ctx.upload(ps)
-        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id + c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid, hash_type=a.hash_type)
+        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id + c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid, hash_type=a.hash_type, multiple_bins=a.multi)
         parts.append(ix.export())
         del ix, batch
     z = lambda dt: np.zeros(0, dt)
@@ -142,7 +142,7 @@ def _cmd_index_sharded(a, fd, indexio, structure, paths, prefix, rank, world):
         mv, mh, mo = indexio.merge_subindices(shards)
         indexio.write_index_files(prefix, mv, mh, mo)
         indexio.save_lookup(prefix + ".lookup", paths, np.concatenate([b[0] for b in box]), np.concatenate([b[1] for b in box]))
-        indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type])
+        indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type], multiple_bins=a.multi)
         if a.verbose:
             print(f"[DONE] {len(paths)} structures over {world} ranks, {len(mh)} hashes, {len(mv)} value bytes -> {prefix}", file=sys.stderr)
     dist.barrier()
@@ -199,7 +199,7 @@ def cmd_query(a):
                                         ca_distance=a.ca_distance, top_n=a.top, skip_match=a.skip_match, serial_query=a.serial_index,
                                         freq_filter=a.freq_filter, length_penalty_power=0.5 if a.length_penalty is None else a.length_penalty,
                                         dist_cutoff=float(cfg.get("grid_width", 20.0)), nbin_dist=int(cfg.get("num_bin_dist", 0)),
-                                        nbin_angle=int(cfg.get("num_bin_angle", 0)), hash_type=hash_type_index(cfg.get("hash_type", "PDBTrRosetta")), sampling_ratio=a.sampling_ratio,
+                                        nbin_angle=int(cfg.get("num_bin_angle", 0)), hash_type=hash_type_index(cfg.get("hash_type", "PDBTrRosetta")), multiple_bins=cfg.get("multiple_bin"), sampling_ratio=a.sampling_ratio,
                                         sampling_count=a.sampling_count, sort_by=a.sort_by, partial_fit=a.partial_fit,
                                         filters=dict(total_match=a.total_match, covered_node=a.covered_node, covered_node_ratio=a.covered_node_ratio,
                                                      max_node=a.max_node, max_node_ratio=a.max_node_ratio, score=a.score,
@@ -244,6 +244,7 @@ def main(argv=None):
     pi.add_argument("-y", "--type", default="default")
     pi.add_argument("-d", "--distance", type=int, default=0)           # number of distance bins (0 -> 16), main.rs:38
     pi.add_argument("-a", "--angle", type=int, default=0)              # number of angle bins (0 -> 4)
+    pi.add_argument("--multiple-bins", default=None)                   # d1-a1,d2-a2 e.g. 16-4,8-3 (build_index.rs:45)
     pi.add_argument("-g", "--grid", type=float, default=20.0)          # CA cutoff
     pi.add_argument("-n", "--max-residue", type=int, default=50000)
     pi.add_argument("-r", "--recursive", action="store_true")
@@ -317,6 +318,9 @@ def main(argv=None):
         if a.hash_type not in (0, 1, 3, 7, 8):
             sys.exit(f"[FAIL] hash type {HASH_TYPE_NAMES[a.hash_type]}: only the encodings over the PDBTrRosetta descriptor are implemented "
                      "(PDBTrRosetta, PDBMotif, PDBMotifSinCos, FolddiscoAngle, FolddiscoDist)")
+        a.multi = parse_multiple_bins(a.multiple_bins) if a.multiple_bins else None
+        if a.multi is not None and (not a.multi or len(a.multi) > 8 or any(d == 0 or x == 0 for d, x in a.multi)):
+            sys.exit("[FAIL] --multiple-bins: one to eight dist-angle pairs with non-zero counts, e.g. 16-4,8-3")
         cmd_index(a)
     else:
         cmd_query(a)

@@ -21,10 +21,31 @@ class BatchDesc(C.Structure):
 
 
 class HashParams(C.Structure):
-    _fields_ = [("nbin_dist", C.c_uint32), ("nbin_angle", C.c_uint32), ("dist_cutoff", C.c_float), ("hash_type", C.c_uint32)]
+    _fields_ = [("nbin_dist", C.c_uint32), ("nbin_angle", C.c_uint32), ("dist_cutoff", C.c_float), ("hash_type", C.c_uint32),
+                ("n_multiple_bins", C.c_uint32), ("multiple_bins", (C.c_uint32 * 2) * 8)]
 
-    def __init__(self, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, hash_type=3):
+    def __init__(self, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, hash_type=3, multiple_bins=None):
         super().__init__(int(nbin_dist), int(nbin_angle), float(dist_cutoff), int(hash_type))
+        mb = list(multiple_bins or [])
+        if len(mb) > 8:
+            raise ValueError("at most 8 (dist, angle) bin pairs")
+        self.n_multiple_bins = len(mb)
+        for k, (d, a) in enumerate(mb):
+            self.multiple_bins[k][0] = int(d)
+            self.multiple_bins[k][1] = int(a)
+
+
+def parse_multiple_bins(s):
+    """parse_distance_angle_pairs (src/utils/cli.rs:1-16): "16-4,8-3" -> [(16, 4), (8, 3)]; malformed items are dropped"""
+    out = []
+    for item in (s or "").split(","):
+        parts = item.strip().split("-")
+        if len(parts) == 2:
+            try:
+                out.append((int(parts[0]), int(parts[1])))
+            except ValueError:
+                pass
+    return out
 
 
 # HashType::get_with_str / to_string (src/geometry/core.rs:42-75); only the encodings over the PDBTrRosetta descriptor are built

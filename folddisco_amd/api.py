@@ -152,8 +152,8 @@ class Batch:
             pass
 
 
-def _params(nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, hash_type=3) -> HashParams:
-    return HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type_index(hash_type))
+def _params(nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, hash_type=3, multiple_bins=None) -> HashParams:
+    return HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type_index(hash_type), multiple_bins)
 
 
 def get_geometric_hash_as_u32(ctx: Context, batch: Batch, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, sort_dedup=True, hash_type=3):
@@ -183,8 +183,8 @@ class FolddiscoIndex:
             pass
 
     @staticmethod
-    def build(ctx: Context, batch: Batch, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, first_id=0, hash_type=3) -> "FolddiscoIndex":
-        p = _params(nbin_dist, nbin_angle, dist_cutoff, hash_type)
+    def build(ctx: Context, batch: Batch, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, first_id=0, hash_type=3, multiple_bins=None) -> "FolddiscoIndex":
+        p = _params(nbin_dist, nbin_angle, dist_cutoff, hash_type, multiple_bins)
         h = C.c_void_p()
         ctx.check(ctx.L.fdgpu_index_build(ctx.h, batch.h, C.byref(p), first_id, C.byref(h)))
         return FolddiscoIndex(ctx, h, batch.n_struct, first_id)

@@ -22,6 +22,7 @@ struct fd_batch_view {
 };
 
 struct fd_hash_consts {
+    uint32_t seg_mul, seg_cfg;   // --multiple-bins: a structure's segment holds seg_mul copies of its pair list, this launch fills copy seg_cfg
     fd_quant q;
     float d2_max;   // largest f32 whose sqrt is <= dist_cutoff: sqrtf(d2) > cutoff  <=>  d2 > d2_max
     int use_tab;    // 1: default 4 angle bins -> table form of the angle fields (fd_bin_tables.h); 2: + speculative torsions

@@ -29,6 +29,9 @@
     } while (0)
 
 fd_hash_consts fd_make_consts(const fd_hash_params *p);  // fdgpu_api.hip
+fd_hash_consts fd_make_consts_cfg(const fd_hash_params *p, uint32_t k);
+uint32_t fd_num_bin_configs(const fd_hash_params *p);
+bool fd_multiple_bins_valid(const fd_hash_params *p);
 bool fd_hash_type_supported(uint32_t t);
 #define CHECK_TYPE(ctx, p)                                                                                                       \
     do {                                                                                                                         \
@@ -90,12 +93,18 @@ extern "C" int fdgpu_pair_features(fdgpu_ctx *c, const fdgpu_batch *b, uint64_t 
     return FDGPU_OK;
 }
 
+static int hash_features_q(fdgpu_ctx *c, const float *features, uint64_t n, fd_quant q, uint32_t *hashes);
+// the single configuration (nbin_dist, nbin_angle; either count 0 -> the encoding's defaults); multiple_bins is not consulted
 extern "C" int fdgpu_hash_features(fdgpu_ctx *c, const float *features, uint64_t n, const fd_hash_params *p, uint32_t *hashes) {
     if (!c || !p || (n && (!features || !hashes))) return FDGPU_EINVAL;
     CHECK_TYPE(c, p);
+    return hash_features_q(c, features, n, fd_make_consts(p).q, hashes);
+}
+static int hash_features_q(fdgpu_ctx *c, const float *features, uint64_t n, fd_quant q, uint32_t *hashes) {
     if (!n) return FDGPU_OK;
     hipStream_t st = c->stream;
-    fd_hash_consts C = fd_make_consts(p);
+    fd_hash_consts C;
+    C.q = q;
     HIPCHK(c, c->ws[WS_MISC2].ensure(n * 28));
     HIPCHK(c, c->ws[WS_MISC0].ensure(n * 4));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, features, n * 28, hipMemcpyHostToDevice, st));
@@ -218,6 +227,15 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     const uint64_t nc = cands.size();
     std::vector<uint32_t> hashes(std::max<uint64_t>(nc, 1));
     if ((rc = fdgpu_hash_features(c, vf.data(), nc, p, hashes.data()))) return rc;
+    // --multiple-bins: every candidate is inserted under every bin pair, in list order (insert_binned_hash, query.rs:59-70); the
+    // observed hash idf is looked up for stays the single-configuration one (query.rs:283-288)
+    const uint32_t n_cfg = p->n_multiple_bins ? p->n_multiple_bins : 0u;
+    if (!fd_multiple_bins_valid(p)) { c->err = "multiple_bins: at most 8 (dist, angle) bin pairs, no zero counts"; return FDGPU_EINVAL; }
+    std::vector<std::vector<uint32_t>> mh_cfg(n_cfg);
+    for (uint32_t k = 0; k < n_cfg; ++k) {
+        mh_cfg[k].resize(std::max<uint64_t>(nc, 1));
+        if ((rc = hash_features_q(c, vf.data(), nc, fd_make_consts_cfg(p, k).q, mh_cfg[k].data()))) return rc;
+    }
     // idf of every pair's observed (primary) hash: log2(S / len) (query.rs:17-32)
     std::vector<float> pair_idf(std::max<uint64_t>(np, 1), 0.0f);
     std::vector<uint32_t> pair_primary(std::max<uint64_t>(np, 1), 0u);
@@ -238,10 +256,13 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         std::vector<float> mi;
         std::map<uint32_t, char> have;
         for (uint64_t z = cand_off[t]; z < cand_off[t + 1]; ++z) {
-            if (have.count(hashes[z])) continue;
-            have[hashes[z]] = 1;
-            mh.push_back(hashes[z]); mqi.push_back(cands[z].qi); mqj.push_back(cands[z].qj); mp.push_back(cands[z].primary);
-            mi.push_back(pair_idf[cands[z].pair]); mph.push_back(pair_primary[cands[z].pair]);
+            for (uint32_t k = 0; k < std::max(n_cfg, 1u); ++k) {
+                const uint32_t hz = n_cfg ? mh_cfg[k][z] : hashes[z];
+                if (have.count(hz)) continue;
+                have[hz] = 1;
+                mh.push_back(hz); mqi.push_back(cands[z].qi); mqj.push_back(cands[z].qj); mp.push_back(cands[z].primary);
+                mi.push_back(pair_idf[cands[z].pair]); mph.push_back(pair_primary[cands[z].pair]);
+            }
         }
         fd_query_map *m = (fd_query_map *)calloc(1, sizeof *m);
         if (!m) { for (uint64_t u = 0; u < t; ++u) { fdgpu_query_map_free(out[u]); out[u] = nullptr; } return FDGPU_ENOMEM; }

@@ -212,7 +212,10 @@ extern "C" uint64_t fdgpu_batch_num_residues(const fdgpu_batch *b) { return b ? 
 bool fd_hash_type_supported(uint32_t t) {
     return t == FD_HASH_PDBMOTIF || t == FD_HASH_PDBMOTIF_SINCOS || t == FD_HASH_PDBTR || t == FD_HASH_FD_ANGLE || t == FD_HASH_FD_DIST;
 }
-static fd_hash_consts make_consts(const fd_hash_params *p) {
+// nbd / nba: requested bin counts.  either_zero_defaults: the rule of the single-configuration callers (either count 0 -> both
+// defaults, controller/feature.rs:216-223, query.rs:72-77); the per-encoding perfect_hash itself treats the two counts
+// independently (pdb_tr.rs:22-35 etc.), which is what the --multiple-bins list reaches (zero counts are rejected there).
+static fd_hash_consts make_consts_bins(const fd_hash_params *p, uint32_t nbd_req, uint32_t nba_req, bool either_zero_defaults) {
     // convert.rs:32-36 quantiser factors evaluated in f32 exactly like the reference
     const uint32_t type = p->hash_type;
     uint32_t cap_d = 16, def_d = 16, cap_a = 4, def_a = 4;
@@ -221,10 +224,11 @@ static fd_hash_consts make_consts(const fd_hash_params *p) {
     else if (type == FD_HASH_FD_ANGLE) { cap_d = 8; def_d = 8; cap_a = 32; def_a = 32; }
     else if (type == FD_HASH_FD_DIST) { cap_d = 32; def_d = 32; cap_a = 16; def_a = 16; }
     // either bin count 0 -> perfect_hash_default (controller/feature.rs:216-223, query.rs:72-77)
-    const bool dflt = p->nbin_dist == 0 || p->nbin_angle == 0;
-    float nd = dflt ? (float)def_d : (p->nbin_dist > cap_d ? (float)cap_d : (float)p->nbin_dist);
-    float na = dflt ? (float)def_a : (p->nbin_angle > cap_a ? (float)cap_a : (float)p->nbin_angle);
+    const bool dflt = either_zero_defaults && (nbd_req == 0 || nba_req == 0);
+    float nd = (dflt || nbd_req == 0) ? (float)def_d : (nbd_req > cap_d ? (float)cap_d : (float)nbd_req);
+    float na = (dflt || nba_req == 0) ? (float)def_a : (nba_req > cap_a ? (float)cap_a : (float)nba_req);
     fd_hash_consts C;
+    C.seg_mul = 1; C.seg_cfg = 0;
     const float PI_F = 3.14159274f;
     float a_min = -1.0f, a_max = 1.0f;                                         // sin / cos fields
     if (type == FD_HASH_PDBMOTIF) { a_min = 0.0f; a_max = 180.0f; }            // degrees
@@ -252,7 +256,20 @@ static fd_hash_consts make_consts(const fd_hash_params *p) {
     return C;
 }
 
+static fd_hash_consts make_consts(const fd_hash_params *p) { return make_consts_bins(p, p->nbin_dist, p->nbin_angle, true); }
 fd_hash_consts fd_make_consts(const fd_hash_params *p) { return make_consts(p); }
+// configuration k of the --multiple-bins list (k < n_multiple_bins), or the single configuration when the list is empty
+uint32_t fd_num_bin_configs(const fd_hash_params *p) { return p->n_multiple_bins ? p->n_multiple_bins : 1u; }
+fd_hash_consts fd_make_consts_cfg(const fd_hash_params *p, uint32_t k) {
+    if (!p->n_multiple_bins) return make_consts(p);
+    return make_consts_bins(p, p->multiple_bins[k][0], p->multiple_bins[k][1], false);
+}
+bool fd_multiple_bins_valid(const fd_hash_params *p) {
+    if (p->n_multiple_bins > FDGPU_MAX_MULTIPLE_BINS) return false;
+    for (uint32_t k = 0; k < p->n_multiple_bins; ++k)
+        if (p->multiple_bins[k][0] == 0 || p->multiple_bins[k][1] == 0) return false;
+    return true;
+}
 
 static int d2h_u64(fdgpu_ctx *c, const uint64_t *dev, uint64_t *host) {
     HIPCHK(c, hipMemcpyAsync(host, dev, 8, hipMemcpyDeviceToHost, c->stream));
@@ -318,6 +335,7 @@ extern "C" int fdgpu_hash_batch(fdgpu_ctx *c, const fdgpu_batch *b, const fd_has
                                 uint64_t **hash_off) {
     if (!c || !b || !p || !hashes || !hash_off) return FDGPU_EINVAL;
     *hashes = nullptr; *hash_off = nullptr;
+    if (p->n_multiple_bins) FAIL(c, FDGPU_EINVAL, "hash_batch: multiple_bins is honoured by the index build and the query calls only");
     if (!fd_hash_type_supported(p->hash_type)) FAIL(c, FDGPU_EINVAL, "hash_type: only the encodings over the (d_CA, d_CB, theta, tau1, tau2) descriptor are built (0, 1, 3, 7, 8)");
     reset_timings(c);
     fd_hash_consts C = make_consts(p);
@@ -410,7 +428,9 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     if (!fd_hash_type_supported(p->hash_type)) FAIL(c, FDGPU_EINVAL, "hash_type: only the encodings over the (d_CA, d_CB, theta, tau1, tau2) descriptor are built (0, 1, 3, 7, 8)");
     reset_timings(c);
     if (first_id + b->n_struct > 0xffffffffull) FAIL(c, FDGPU_ERANGE, "structure ids exceed 32 bits");
-    fd_hash_consts C = make_consts(p);
+    if (!fd_multiple_bins_valid(p)) FAIL(c, FDGPU_EINVAL, "multiple_bins: at most 8 (dist, angle) bin pairs, no zero counts");
+    const uint32_t n_cfg = fd_num_bin_configs(p);
+    fd_hash_consts C = fd_make_consts_cfg(p, 0);
     C.spec_miss = c->spec_miss;
     hipStream_t st = c->stream;
     uint64_t S = b->n_struct, P = 0;
@@ -419,8 +439,10 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
         StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame)));
         fd_launch_frames(b->view(), b->n_res, c->ws[WS_FRAMES].p, st);
     }
-    int rc = count_and_scan(c, b, C, &P, true);
+    uint64_t P1 = 0;
+    int rc = count_and_scan(c, b, C, &P1, true);
     if (rc) return rc;
+    P = P1 * n_cfg;                         // every bin pair of --multiple-bins contributes one key per ordered residue pair
     if (P >= 0xffffffffull) FAIL(c, FDGPU_ERANGE, "more than 2^32 residue pairs in one build call; split the shard");
     if ((rc = ensure_sort_ws(c, P))) return rc;
     uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *kb = c->ws[WS_KEYS_B].as<uint32_t>();
@@ -433,8 +455,13 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     C.wide_flag = c->ws[WS_MISC3].as<unsigned long long>() + 3;
     {
         StageTimer t(c, "pair_emit", b->n_res * 37 + P * (ids16 ? 6 : 8));
-        fd_launch_pair_emit2(b->view(), c->ws[WS_FRAMES].p, C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, ia, ids16,
-                             (uint32_t)first_id, st);
+        for (uint32_t k = 0; k < n_cfg; ++k) {
+            fd_hash_consts Ck = fd_make_consts_cfg(p, k);
+            Ck.spec_miss = C.spec_miss; Ck.wide_flag = C.wide_flag; Ck.seg_mul = n_cfg; Ck.seg_cfg = k;
+            if (k) HIPCHK(c, hipMemsetAsync(c->ws[WS_CURSOR].p, 0, (S + 1) * 4, st));
+            fd_launch_pair_emit2(b->view(), c->ws[WS_FRAMES].p, Ck, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, ia, ids16,
+                                 (uint32_t)first_id, st);
+        }
     }
     int cur;
     (void)sort_mode();
@@ -934,7 +961,10 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].as<uint32_t>() + mask_words, mask_off, n_cand * 4, hipMemcpyHostToDevice, st));
         A.cj_mask = c->ws[WS_MISC1].as<uint32_t>(); A.mask_off = A.cj_mask + mask_words;
     }
-    A.B = db->view(); A.C = make_consts(p); A.cutoff = p->dist_cutoff;
+    if (!fd_multiple_bins_valid(p)) FAIL(c, FDGPU_EINVAL, "multiple_bins: at most 8 (dist, angle) bin pairs, no zero counts");
+    A.B = db->view(); A.C = fd_make_consts_cfg(p, 0); A.cutoff = p->dist_cutoff;
+    A.n_cfg = fd_num_bin_configs(p);
+    for (uint32_t k = 0; k < A.n_cfg; ++k) A.qk[k] = fd_make_consts_cfg(p, k).q;
     A.cand = dblk + o_cand; A.n_cand = (uint32_t)n_cand;
     A.wi_cand = dblk + o_wc; A.wi_i0 = dblk + o_wi; A.wi_query = dblk + o_wq; A.n_work = (uint32_t)nw;
     A.resname_std = d_std;

@@ -196,6 +196,8 @@ struct mp_args {
     unsigned long long *n_found, *n_cands;
     fd_pair_rec *found; fd_cand_rec *cands;
     unsigned long long cap_found, cap_cands;   // records the buffers hold (EMIT counts beyond them without writing)
+    uint32_t n_cfg;                // --multiple-bins: bin pairs to hash every surviving pair with (1 = the single configuration in C)
+    fd_quant qk[8];                // their quantisers (qk[0] == C.q)
     uint32_t mode;                 // bit 0: emit found triples, bit 1: emit candidate pairs
     const uint32_t *cj_mask;       // optional: only partner residues j whose bit mask_off[slot] + (j - r0) is set are scanned
     const uint32_t *mask_off;      // [n_cand] first bit of every candidate slot

@@ -209,7 +209,10 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
             fd_frame Fi = load_frame(frames, i), Fj = load_frame(frames, j);
             fd_pair_both(Fi, Fj, B.aa[i], B.aa[j], C.q, &h_ij, &h_ji);
         }
-        uint64_t pos = seg_off[s] + base + lane;
+        // --multiple-bins: the structure's segment holds seg_mul copies of its pair list (one per bin pair), so the stream stays
+        // structure-major and the stable sort by hash keeps ids ascending inside every posting list
+        const uint64_t so = seg_off[s];
+        uint64_t pos = so * C.seg_mul + (uint64_t)C.seg_cfg * (seg_off[s + 1] - so) + base + lane;
         if (IDS16) {
             if (((h_ij | h_ji) >> 30) && C.wide_flag) atomicOr(C.wide_flag, 1ull);   // does not fit hash << 2: the caller rebuilds with 8-byte elements
             uint32_t hi = s >> 16;

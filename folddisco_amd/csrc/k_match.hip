@@ -32,7 +32,8 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
     const bool on = lane < n;
     const uint32_t e0 = on ? q[lane] : 0u;
     const uint32_t i = i0 + (e0 >> 16), j = r0 + (e0 & 0xffffu);
-    uint32_t aai = 255u, aaj = 255u, n_win = 0, h = 0;
+    uint32_t aai = 255u, aaj = 255u, n_win = 0, h = 0, hitmask = 0;
+    fd_feature feat = {0.f, 0.f, 0.f, 0.f, 0.f};
     fd_v3 cai = {0.f, 0.f, 0.f}, caj = {0.f, 0.f, 0.f};
     float d = 0.f;
     uint32_t key = 0, e_lo = 0, e_hi = 0;
@@ -44,17 +45,24 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
         key = (aai & 31u) * 32u + (aaj & 31u);   // queued pairs have aa < 32
         e_lo = st_tab[key]; e_hi = st_tab[key + 1];
         for (uint32_t e = e_lo; e < e_hi; ++e) n_win += (fd_fabsf(d - dist_tab[e]) < A.ca_window) ? 1u : 0u;
-        if (A.C.use_tab) {
+        if (A.C.use_tab && A.n_cfg == 1) {
             // default angle bins: frames + exhaustive tables (fd_geom.h) — same bits as the generic chain, a tenth of the code
             fd_frame Fi = fd_make_frame(fd_load3(A.B.n_xyz, i), cai, fd_load3(A.B.cb_xyz, i));
             fd_frame Fj = fd_make_frame(fd_load3(A.B.n_xyz, j), caj, fd_load3(A.B.cb_xyz, j));
             uint32_t h_ji;
             fd_pair_both_tab(Fi, Fj, aai, aaj, A.C.q, tab, &h, &h_ji);
+            hitmask = ((A.mode & 1u) && hash_in_set(A.q_hashes, A.n_hashes, h)) ? 1u : 0u;
         } else {
-            fd_feature f = fd_pair_feature(fd_load3(A.B.n_xyz, i), cai, fd_load3(A.B.cb_xyz, i), fd_load3(A.B.n_xyz, j), caj, fd_load3(A.B.cb_xyz, j));
-            h = fd_hash_enc(aai, aaj, f, A.C.q);
+            // one descriptor, one hash per bin pair (--multiple-bins: a found triple for every bin pair whose hash the query holds,
+            // retrieve.rs:124-131)
+            feat = fd_pair_feature(fd_load3(A.B.n_xyz, i), cai, fd_load3(A.B.cb_xyz, i), fd_load3(A.B.n_xyz, j), caj, fd_load3(A.B.cb_xyz, j));
+            for (uint32_t k = 0; k < A.n_cfg; ++k) {
+                const uint32_t hk = fd_hash_enc(aai, aaj, feat, A.qk[k]);
+                if (k == 0) h = hk;
+                if ((A.mode & 1u) && hash_in_set(A.q_hashes, A.n_hashes, hk)) hitmask |= 1u << k;
+            }
         }
-        hit = (A.mode & 1u) && hash_in_set(A.q_hashes, A.n_hashes, h);
+        hit = hitmask != 0;
         if (!(A.mode & 2u)) n_win = 0;
     }
     // one atomic per counter and drain (per-record atomics on two addresses serialise in one L2 channel: that, not the
@@ -66,24 +74,41 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
     }
     const uint32_t tot_win = __shfl(incl, FD_WAVE - 1, FD_WAVE);
     const uint64_t hm = __ballot(hit);
+    const uint32_t n_hit = (uint32_t)__builtin_popcount(hitmask);
+    uint32_t hincl = n_hit;      // found triples per lane: one per matching bin pair
+    if (A.n_cfg > 1) {
+        for (int off = 1; off < FD_WAVE; off <<= 1) {
+            uint32_t t = __shfl_up(hincl, off, FD_WAVE);
+            if ((int)lane >= off) hincl += t;
+        }
+    }
+    const uint32_t tot_hit = A.n_cfg > 1 ? (uint32_t)__shfl((int)hincl, FD_WAVE - 1, FD_WAVE) : (uint32_t)__popcll(hm);
     unsigned long long cbase = 0, fbase = 0;
     if (lane == 0) {
         if (tot_win) cbase = atomicAdd(A.n_cands, (unsigned long long)tot_win);
-        if (hm) fbase = atomicAdd(A.n_found, (unsigned long long)__popcll(hm));
+        if (tot_hit) fbase = atomicAdd(A.n_found, (unsigned long long)tot_hit);
     }
     cbase = ((unsigned long long)(uint32_t)__shfl((int)(cbase >> 32), 0, FD_WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)cbase, 0, FD_WAVE);
     fbase = ((unsigned long long)(uint32_t)__shfl((int)(fbase >> 32), 0, FD_WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)fbase, 0, FD_WAVE);
     unsigned long long cpos = cbase + (incl - n_win);
-    const unsigned long long fpos = fbase + fd_mbcnt(hm);
+    const unsigned long long fpos = fbase + (A.n_cfg > 1 ? (unsigned long long)(hincl - n_hit) : (unsigned long long)fd_mbcnt(hm));
     // EMIT with capacities: records beyond the caller's buffers are counted but not written (the caller grows and reruns)
-    if (EMIT && on && cpos + n_win <= A.cap_cands && (!hit || fpos < A.cap_found)) {
+    if (EMIT && on && cpos + n_win <= A.cap_cands && (!hit || fpos + n_hit <= A.cap_found)) {
         for (uint32_t e = e_lo; e < e_hi; ++e) {
             if (fd_fabsf(d - dist_tab[e]) < A.ca_window) {
                 fd_cand_rec c; c.cand = slot; c.qi = A.aad_qi[e]; c.i = i - r0; c.j = j - r0;
                 A.cands[cpos++] = c;
             }
         }
-        if (hit) { fd_pair_rec p; p.cand = slot; p.i = i - r0; p.j = j - r0; p.hash = h; A.found[fpos] = p; }
+        if (hit) {
+            fd_pair_rec p; p.cand = slot; p.i = i - r0; p.j = j - r0;
+            if (A.n_cfg == 1) { p.hash = h; A.found[fpos] = p; }
+            else {
+                unsigned long long fp = fpos;
+                for (uint32_t k = 0; k < A.n_cfg; ++k)
+                    if ((hitmask >> k) & 1u) { p.hash = k == 0 ? h : fd_hash_enc(aai, aaj, feat, A.qk[k]); A.found[fp++] = p; }
+            }
+        }
     }
 }
 

@@ -53,11 +53,12 @@ def load_lookup(path: str):
 
 
 def save_type(path: str, n_structures: int, grid_width: float = 20.0, max_residue: int = 50000, nbin_angle: int = 0, nbin_dist: int = 0,
-              input_format: str = "PDB", hash_type: str = "PDBTrRosetta"):
+              input_format: str = "PDB", hash_type: str = "PDBTrRosetta", multiple_bins=None):
     gw = repr(float(grid_width))  # toml prints the f64; 20.0 -> "20.0"
     with open(path, "w") as f:
         f.write(f"chunk_size = {n_structures}\ngrid_width = {gw}\nhash_type = \"{hash_type}\"\ninput_format = \"{input_format}\"\n"
-                f"max_residue = {max_residue}\nnum_bin_angle = {nbin_angle}\nnum_bin_dist = {nbin_dist}\n")
+                f"max_residue = {max_residue}\n" + (("multiple_bin = [" + ", ".join(f"[{d}, {a}]" for d, a in multiple_bins) + "]\n") if multiple_bins else "") +
+                f"num_bin_angle = {nbin_angle}\nnum_bin_dist = {nbin_dist}\n")
 
 
 def load_type(path: str) -> dict:
@@ -65,7 +66,10 @@ def load_type(path: str) -> dict:
     for line in open(path):
         if "=" in line:
             k, v = (t.strip() for t in line.split("=", 1))
-            out[k] = v.strip('"') if v.startswith('"') else (float(v) if "." in v else int(v))
+            if v.startswith("[["):    # multiple_bin = [[16, 4], [8, 3]] (cli/config.rs:48-53, 78-84)
+                out[k] = [tuple(int(x) for x in item.split(",")) for item in v.strip()[2:-2].split("], [")]
+            else:
+                out[k] = v.strip('"') if v.startswith('"') else (float(v) if "." in v else int(v))
     return out
 
 

@@ -13,7 +13,7 @@ PREFILTER_AA_SKIPPING_SIZE = 200  # retrieve.rs:24
 
 
 def match_pairs(ctx: Context, db: Batch, resname_std: np.ndarray | None, cand: np.ndarray, qmap: dict,
-                ca_distance_cutoff: float = 1.0, nbin_dist: int = 0, nbin_angle: int = 0, dist_cutoff: float = 20.0, hash_type: int = 3):
+                ca_distance_cutoff: float = 1.0, nbin_dist: int = 0, nbin_angle: int = 0, dist_cutoff: float = 20.0, hash_type: int = 3, multiple_bins=None):
     """qmap: dict with 'hash', 'aad_aa1', 'aad_aa2', 'aad_dist', 'aad_qi' (make_query_map outputs).
     Returns (found u32[n,4] = cand,i,j,hash ; cands u32[m,4] = cand,qi,i,j) in the reference's scan order."""
     hashes = np.unique(np.asarray(qmap["hash"], dtype=np.uint32))
@@ -24,7 +24,7 @@ def match_pairs(ctx: Context, db: Batch, resname_std: np.ndarray | None, cand: n
     cand = np.ascontiguousarray(cand, dtype=np.uint32)
     q = MatchQuery(hashes.ctypes.data_as(u32p), len(hashes), a1.ctypes.data_as(u8p), a2.ctypes.data_as(u8p), ad.ctypes.data_as(f32p),
                    aq.ctypes.data_as(u32p), len(ad), ca_distance_cutoff, int(len(hashes) <= PREFILTER_AA_SKIPPING_SIZE))
-    p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type)
+    p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type, multiple_bins)
     std = None if resname_std is None else np.ascontiguousarray(resname_std, dtype=np.uint8)
     fp, cp = C.POINTER(PairRec)(), C.POINTER(CandRec)()
     nf, nc = C.c_uint64(), C.c_uint64()

@@ -94,7 +94,7 @@ def _arr(ptr, n, dt):
 
 def make_query_map(ctx: Context, qbatch: Batch, q_indices, subs=None, index: FolddiscoIndex | None = None,
                    total_structures: float = 0.0, dist_thr=(0.5,), angle_thr=(5.0,), nbin_dist=0, nbin_angle=0,
-                   dist_cutoff=20.0, hash_type=3) -> QueryMapResult:
+                   dist_cutoff=20.0, hash_type=3, multiple_bins=None) -> QueryMapResult:
     qi = np.ascontiguousarray(q_indices, dtype=np.uint32)
     n = len(qi)
     sub_ptrs = (u8p * max(n, 1))()
@@ -109,7 +109,7 @@ def make_query_map(ctx: Context, qbatch: Batch, q_indices, subs=None, index: Fol
                 n_subs[k] = len(s)
     d = np.ascontiguousarray(dist_thr, np.float32)
     a = np.ascontiguousarray(angle_thr, np.float32)
-    p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type)
+    p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type, multiple_bins)
     out = C.POINTER(QueryMap)()
     ctx.check(ctx.L.fdgpu_make_query_map(ctx.h, qbatch.h, qi.ctypes.data_as(u32p), n, sub_ptrs, n_subs.ctypes.data_as(u32p),
                                          d.ctypes.data_as(f32p), len(d), a.ctypes.data_as(f32p), len(a), C.byref(p),
@@ -126,7 +126,7 @@ def _wrap_query_map(ctx, out) -> QueryMapResult:
 
 
 def make_query_maps(ctx: Context, qbatch: Batch, queries, index: FolddiscoIndex | None = None, total_structures: float = 0.0,
-                    dist_thr=(0.5,), angle_thr=(5.0,), nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, hash_type=3):
+                    dist_thr=(0.5,), angle_thr=(5.0,), nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, hash_type=3, multiple_bins=None):
     """Many query maps with three launches in total (fdgpu_make_query_map_batch).  queries: list of (structure index in
     qbatch, residue indices[, substitution lists]).  -> list of QueryMapResult."""
     nq = len(queries)
@@ -148,7 +148,7 @@ def make_query_maps(ctx: Context, qbatch: Batch, queries, index: FolddiscoIndex 
                     n_subs[int(q_off[t]) + k] = len(sl)
     d = np.ascontiguousarray(dist_thr, np.float32)
     a = np.ascontiguousarray(angle_thr, np.float32)
-    p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type)
+    p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type, multiple_bins)
     outs = (C.POINTER(QueryMap) * max(nq, 1))()
     ctx.check(ctx.L.fdgpu_make_query_map_batch(ctx.h, qbatch.h, nq, q_struct.ctypes.data_as(u32p), q_off.ctypes.data_as(u64p),
                                                q_index.ctypes.data_as(u32p), sub_ptrs, n_subs.ctypes.data_as(u32p), d.ctypes.data_as(f32p), len(d),
@@ -158,11 +158,11 @@ def make_query_maps(ctx: Context, qbatch: Batch, queries, index: FolddiscoIndex 
 
 
 def retrieve(ctx: Context, db: Batch, resname_std, cand, qm: QueryMapResult, qbatch: Batch, ca_distance_cutoff=1.0,
-             node_count=2, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, partial_fit=False, hash_type=3):
+             node_count=2, nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, partial_fit=False, hash_type=3, multiple_bins=None):
     """-> list of dicts per match: cand slot, idf, rmsd, from_hash / processed target residue indices (-1 = none)."""
     cand = np.ascontiguousarray(cand, dtype=np.uint32)
     std = None if resname_std is None else np.ascontiguousarray(resname_std, np.uint8)
-    p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type)
+    p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type, multiple_bins)
     mp = C.POINTER(MatchRec)()
     rp = C.POINTER(C.c_int32)()
     nm = C.c_uint64()
@@ -259,7 +259,7 @@ MATCH_DTYPE = np.dtype([("cand", np.uint32), ("same", np.uint32), ("idf", np.flo
 
 
 def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Batch, q_structs, ca_distance_cutoff=1.0, node_count=2,
-                   nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, as_arrays=False, partial_fit=False, hash_type=3):
+                   nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, as_arrays=False, partial_fit=False, hash_type=3, multiple_bins=None):
     """retrieve() for many queries with one pair scan / gather / Kabsch launch in total (fdgpu_retrieve_batch).  cands[t]:
     candidate structure indices of query t, qms[t] its QueryMapResult, q_structs[t] its structure in qbatch.
     -> list (per query) of lists of match dicts like retrieve(); with as_arrays=True the raw tables instead:
@@ -272,7 +272,7 @@ def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Bat
     std = None if resname_std is None else np.ascontiguousarray(resname_std, np.uint8)
     qs = np.ascontiguousarray(q_structs, np.uint32)
     handles = (C.POINTER(QueryMap) * max(T, 1))(*[q.handle for q in qms])
-    p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type)
+    p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type, multiple_bins)
     mp, rp = C.POINTER(MatchRec)(), C.POINTER(C.c_int32)()
     mo, ro = u64p(), u64p()
     ctx.check(ctx.L.fdgpu_retrieve_batch(ctx.h, db.h, None if std is None else std.ctypes.data_as(u8p), T, cand.ctypes.data_as(u32p),
@@ -310,7 +310,7 @@ def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Bat
 def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[CompactStructure], tids: list[str], nres, plddt,
               query: CompactStructure, query_string: str, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance=1.0, top_n=None,
               length_penalty_power=0.5, skip_match=False, serial_query=False, freq_filter=None, dist_cutoff=20.0, nbin_dist=0, nbin_angle=0,
-              sampling_ratio=None, sampling_count=None, filters=None, sort_by="", shard=None, partial_fit=False, hash_type=3):
+              sampling_ratio=None, sampling_count=None, filters=None, sort_by="", shard=None, partial_fit=False, hash_type=3, multiple_bins=None):
     """The per-query body of query_pdb (src/cli/workflows/query_pdb.rs:348-519).  shard = dict(lo=first structure id, device=torch
     device or None): `index`, `db` and `db_structs` then cover only structures [lo, lo + len(db_structs)) of the database that
     tids / nres / plddt describe: idf comes from all-reduced posting lengths, the touched-structure records and the
@@ -338,7 +338,7 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
     if shard is None:
         lo, n_local = 0, S
         qm = make_query_map(ctx, qbatch, idx, subs, index, float(S), dist_thr, angle_thr, nbin_dist=nbin_dist, nbin_angle=nbin_angle,
-                            dist_cutoff=dist_cutoff, hash_type=hash_type)
+                            dist_cutoff=dist_cutoff, hash_type=hash_type, multiple_bins=multiple_bins)
         keep = sample_query_hashes(index, qm.hash, sampling_ratio, sampling_count)
         rows = count_query(ctx, index, qm.hash[keep], qm.qi[keep], qm.qj[keep], pen, total_structures=S, freq_filter=freq_filter)
     else:
@@ -349,7 +349,7 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
         lo, dev = int(shard["lo"]), shard.get("device")
         n_local = int(shard.get("n_local", len(db_structs) if db_structs is not None else index.n_structures))
         qm = make_query_map(ctx, qbatch, idx, subs, None, float(S), dist_thr, angle_thr, nbin_dist=nbin_dist, nbin_angle=nbin_angle,
-                            dist_cutoff=dist_cutoff, hash_type=hash_type)
+                            dist_cutoff=dist_cutoff, hash_type=hash_type, multiple_bins=multiple_bins)
         pl = fdist.global_posting_lengths(index, qm.primary_hash, dev)
         qm.set_idf(np.where(pl > 0, idf_of_lengths(np.maximum(pl, 1), S), 0.0).astype(np.float32))
         lens = fdist.global_posting_lengths(index, qm.hash, dev)
@@ -389,7 +389,7 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
         owned = [k for k, r in enumerate(rows) if lo <= r["nid"] < lo + n_local]       # candidates this rank holds coordinates of
         cand = np.array([rows[k]["nid"] - lo for k in owned], np.uint32)
         ms = retrieve(ctx, db, std, cand, qm, qbatch, ca_distance, nbin_dist=nbin_dist, nbin_angle=nbin_angle, dist_cutoff=dist_cutoff,
-                      partial_fit=partial_fit, hash_type=hash_type) if len(cand) else []
+                      partial_fit=partial_fit, hash_type=hash_type, multiple_bins=multiple_bins) if len(cand) else []
         for m in ms:
             m["cand"] = owned[m["cand"]]                                                 # -> position in `rows`
             t = db_structs[rows[m["cand"]]["nid"] - lo]

@@ -66,11 +66,21 @@ typedef struct fd_batch_desc {
 #define FDGPU_HASH_PDBTR 3u
 #define FDGPU_HASH_FOLDDISCO_ANGLE 7u
 #define FDGPU_HASH_FOLDDISCO_DIST 8u
+#define FDGPU_MAX_MULTIPLE_BINS 8
 typedef struct fd_hash_params {
     uint32_t nbin_dist;
     uint32_t nbin_angle;
     float dist_cutoff;         /* CA-CA cutoff in Angstrom (strict >, src/structure/core.rs:391) */
     uint32_t hash_type;        /* FDGPU_HASH_* */
+    /* --multiple-bins d1-a1,d2-a2,... (src/cli/workflows/build_index.rs:45,149-153): every residue pair is hashed once per
+     * (dist, angle) bin pair and all the hashes share one index (controller/feature.rs:211-215); queries insert every
+     * expansion under every bin pair (controller/query.rs:59-70) and retrieval reports a found triple per matching bin pair
+     * (controller/retrieve.rs:124-131).  0 = off.  Zero bin counts inside the list are rejected (the reference treats them
+     * differently at index and at query time).  nbin_dist / nbin_angle above still select the observed hash that idf is
+     * looked up for (query.rs:283-288).  Honoured by fdgpu_index_build, fdgpu_make_query_map[_batch], fdgpu_match_pairs and
+     * fdgpu_retrieve[_batch]; fdgpu_hash_batch returns FDGPU_EINVAL with it. */
+    uint32_t n_multiple_bins;
+    uint32_t multiple_bins[FDGPU_MAX_MULTIPLE_BINS][2];
 } fd_hash_params;
 
 /* copy a host batch into HBM */

@@ -167,6 +167,8 @@ def lib():
     L.fdo_get_hash_type.restype = C.c_uint32
     L.fdo_hash_any.restype = C.c_uint32
     L.fdo_hash_any.argtypes = [f32p, C.c_uint64, C.c_uint64]
+    L.fdo_set_multiple_bins.restype = C.c_int
+    L.fdo_set_multiple_bins.argtypes = [C.c_uint64, u64p]
     L.fdo_lms_qcp.restype = C.c_float
     L.fdo_lms_qcp.argtypes = [f32p, f32p, C.c_uint64, f32p, f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.fdo_metrics.restype = None
@@ -442,6 +444,23 @@ class hash_type:
 
     def __exit__(self, *exc):
         lib().fdo_set_hash_type(self.prev)
+        return False
+
+
+class multiple_bins:
+    """with oracle.multiple_bins([(16, 4), (8, 3)]): ...  — the --multiple-bins list for every oracle function inside"""
+
+    def __init__(self, pairs):
+        self.pairs = [(int(d), int(a)) for d, a in pairs]
+
+    def __enter__(self):
+        arr = np.array(self.pairs, np.uint64).reshape(-1)
+        if lib().fdo_set_multiple_bins(len(self.pairs), arr.ctypes.data_as(u64p)) != 0:
+            raise ValueError("oracle: at most 8 bin pairs")
+        return self
+
+    def __exit__(self, *exc):
+        lib().fdo_set_multiple_bins(0, None)
         return False
 
 

@@ -69,6 +69,12 @@ uint32_t fdo_hash_pdbtr(const float feature[9], uint64_t nbin_dist, uint64_t nbi
 int fdo_set_hash_type(uint32_t hash_type);
 uint32_t fdo_get_hash_type(void);
 uint32_t fdo_hash_any(const float feature[9], uint64_t nbin_dist, uint64_t nbin_angle);
+/* --multiple-bins (process-wide test switch; n = 0 turns it off): pairs = {dist, angle} x n.  fdo_hash_structure / fdo_build_index hash
+ * every residue pair once per bin pair (controller/feature.rs:211-215), fdo_make_query_map inserts every expansion under every
+ * bin pair (query.rs:59-70), fdo_retrieve reports a found triple per matching bin pair (retrieve.rs:124-131). */
+int fdo_set_multiple_bins(uint64_t n, const uint64_t *pairs);
+uint64_t fdo_multiple_bins(uint64_t out[16]);
+uint32_t fdo_hash_cfg(const float feature[9], uint64_t nbin_dist, uint64_t nbin_angle);
 void fdo_reverse_hash_pdbtr(uint32_t hash, float out[7]);
 int fdo_hash_is_symmetric(uint32_t hash);
 /* all ordered pairs row-major (combination.rs:23-44) -> malloc'd list, caller frees with fdo_free */

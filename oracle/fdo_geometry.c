@@ -191,6 +191,28 @@ static uint32_t hash_folddisco(const float f[9], uint64_t nbin_dist, uint64_t nb
     uint32_t p1 = fdo_discretize(f[5], -PI_F, PI_F, na), p2 = fdo_discretize(f[6], -PI_F, PI_F, na);
     return dist_form ? (pair << 21 | ca << 16 | cb << 11 | th << 8 | p1 << 4 | p2) : (pair << 21 | ca << 18 | cb << 15 | th << 10 | p1 << 5 | p2);
 }
+/* --multiple-bins (test-only process-wide switch like the encoding): the (dist, angle) bin pairs every residue pair is hashed with */
+static uint64_t g_multi_n = 0, g_multi[8][2];
+int fdo_set_multiple_bins(uint64_t n, const uint64_t *pairs) {
+    if (n > 8) return -1;
+    g_multi_n = n;
+    for (uint64_t k = 0; k < n; ++k) { g_multi[k][0] = pairs[2 * k]; g_multi[k][1] = pairs[2 * k + 1]; }
+    return 0;
+}
+uint64_t fdo_multiple_bins(uint64_t out[16]) {
+    for (uint64_t k = 0; k < g_multi_n; ++k) { out[2 * k] = g_multi[k][0]; out[2 * k + 1] = g_multi[k][1]; }
+    return g_multi_n;
+}
+/* GeometricHash::perfect_hash_as_u32 (geometry/core.rs:213-246): the encoding's own perfect_hash, each count's 0 / cap handled by itself */
+uint32_t fdo_hash_cfg(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle) {
+    switch (g_hash_type) {
+    case 0: return hash_pdbmotif(f, nbin_dist, nbin_angle);
+    case 1: return hash_pdbmotif_sincos(f, nbin_dist, nbin_angle);
+    case 7: return hash_folddisco(f, nbin_dist, nbin_angle, 0);
+    case 8: return hash_folddisco(f, nbin_dist, nbin_angle, 1);
+    default: return fdo_hash_pdbtr(f, nbin_dist, nbin_angle);
+    }
+}
 /* GeometricHash::perfect_hash[_default] (geometry/core.rs:195-246) as the callers use it: either bin count 0 -> the encoding's defaults
  * (controller/feature.rs:216-223, query.rs:72-77) */
 uint32_t fdo_hash_any(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle) {
@@ -244,9 +266,12 @@ int fdo_hash_structure(const fdo_structure *s, uint64_t nbin_dist, uint64_t nbin
         for (int64_t j = 0; j < s->n; ++j) {
             if (i == j) continue;
             if (!fdo_pair_feature(s, i, j, dist_cutoff, feat)) continue;
-            uint32_t h = fdo_hash_any(feat, nbin_dist, nbin_angle);
-            if (n == cap) { cap *= 2; v = (uint32_t *)realloc(v, cap * sizeof *v); }
-            v[n++] = h;
+            /* one hash per bin pair of --multiple-bins (feature.rs:211-215), else the single configuration */
+            for (uint64_t k = 0; k < (g_multi_n ? g_multi_n : 1); ++k) {
+                uint32_t h = g_multi_n ? fdo_hash_cfg(feat, g_multi[k][0], g_multi[k][1]) : fdo_hash_any(feat, nbin_dist, nbin_angle);
+                if (n == cap) { cap *= 2; v = (uint32_t *)realloc(v, cap * sizeof *v); }
+                v[n++] = h;
+            }
         }
     }
     *out = v;

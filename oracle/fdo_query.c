@@ -144,10 +144,7 @@ static int qm_find(const fdo_query_map *m, uint32_t h) {
         if (m->hash[k] == h) return 1;
     return 0;
 }
-/* query.rs:53-84 insert_binned_hash (no multiple_bin): first insert wins */
-static void insert_binned_hash(qm_builder *b, const float *feature, uint64_t qi, uint64_t qj, uint64_t nbin_dist,
-                               uint64_t nbin_angle, int is_primary, float idf) {
-    uint32_t h = fdo_hash_any(feature, nbin_dist, nbin_angle);
+static void insert_hash(qm_builder *b, uint32_t h, uint64_t qi, uint64_t qj, int is_primary, float idf) {
     fdo_query_map *m = b->m;
     if (qm_find(m, h)) return;
     if (m->n == b->cap) {
@@ -161,6 +158,18 @@ static void insert_binned_hash(qm_builder *b, const float *feature, uint64_t qi,
     m->hash[m->n] = h; m->qi[m->n] = qi; m->qj[m->n] = qj;
     m->is_primary[m->n] = (uint8_t)is_primary; m->idf[m->n] = idf;
     m->n++;
+}
+/* query.rs:53-84 insert_binned_hash: first insert wins; with multiple_bin every bin pair inserts its own hash (either count 0 ->
+ * the encoding's defaults) */
+static void insert_binned_hash(qm_builder *b, const float *feature, uint64_t qi, uint64_t qj, uint64_t nbin_dist,
+                               uint64_t nbin_angle, int is_primary, float idf) {
+    uint64_t mb[16];
+    const uint64_t nmb = fdo_multiple_bins(mb);
+    if (nmb) {
+        for (uint64_t k = 0; k < nmb; ++k) insert_hash(b, fdo_hash_any(feature, mb[2 * k], mb[2 * k + 1]), qi, qj, is_primary, idf);
+        return;
+    }
+    insert_hash(b, fdo_hash_any(feature, nbin_dist, nbin_angle), qi, qj, is_primary, idf);
 }
 
 /* query.rs:179-206 */

@@ -236,8 +236,13 @@ fdo_retrieval *fdo_retrieve(const fdo_structure *t, const fdo_structure *qs, con
                 if (tmp_q.n == 0) continue;
                 if (!fdo_pair_feature(t, (int64_t)i, (int64_t)j, dist_cutoff, feature)) continue;
                 for (uint64_t e = 0; e < tmp_q.n; ++e) { v_push(&cq, tmp_q.v[e]); v_push(&cI, i); v_push(&cJ, j); }
-                uint32_t h = fdo_hash_any(feature, nbin_dist, nbin_angle);
-                if (qm_lookup(m, h) >= 0) { v_push(&fi, i); v_push(&fj, j); v_push(&fh, h); }
+                /* retrieve.rs:124-139: with multiple_bin one (i, j, hash) per bin pair whose hash the query holds */
+                uint64_t mb[16];
+                uint64_t nmb = fdo_multiple_bins(mb);
+                for (uint64_t k = 0; k < (nmb ? nmb : 1); ++k) {
+                    uint32_t h = nmb ? fdo_hash_cfg(feature, mb[2 * k], mb[2 * k + 1]) : fdo_hash_any(feature, nbin_dist, nbin_angle);
+                    if (qm_lookup(m, h) >= 0) { v_push(&fi, i); v_push(&fj, j); v_push(&fh, h); }
+                }
             }
         }
         free(tmp_q.v);

@@ -671,3 +671,65 @@ def test_two_pass_retrieval_equals_single_pass(env, monkeypatch):
         same(out["0"], out["1"])
         assert any(g["cand"] == s for g in out["1"])
     monkeypatch.delenv("FDGPU_TWO_PASS")
+
+
+@pytest.mark.parametrize("htype,bins", [(3, [(16, 4), (8, 3)]), (3, [(12, 4), (16, 4), (6, 2)]), (7, [(8, 32), (4, 12)])])
+def test_multiple_bins_index_query_and_retrieval(env, htype, bins, tmp_path):
+    """--multiple-bins (build_index.rs:45, feature.rs:211-215, query.rs:59-70, retrieve.rs:124-131): every residue pair is hashed
+    once per (dist, angle) bin pair into one index, queries insert every expansion under every bin pair, retrieval reports a
+    found triple per matching bin pair.  Index bytes, query map, count records and matches equal the CPU restatement."""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    ctx, structs, batch, _ix, nres, plddt, tids = env
+    ostructs = [oracle.read_pdb(p) for p in SER]
+    std = np.concatenate([s.resname_std() for s in structs])
+    ix = fd.FolddiscoIndex.build(ctx, batch, hash_type=htype, multiple_bins=bins)
+    with oracle.hash_type(htype), oracle.multiple_bins(bins):
+        oix, onres, _ = oracle.build_index(ostructs)
+        v, hh, o = ix.export()
+        assert np.array_equal(hh, oix.hashes()) and np.array_equal(o, oix.offsets()) and np.array_equal(v, oix.values())
+        pen = fd.length_penalty(onres, 0.5)
+        for qpath, qstr in ((Q4CHA, "B57,B102,C195"), (Q1G2F, "F207:C,F212,F225:HX,F229"), (Q4CHA, "B57,B102,C195,B58,B59")):
+            oq = oracle.read_pdb(qpath)
+            om_ = oracle.make_query_map(oq, qstr, oix, 5.0)
+            om = om_.arrays()
+            q = st.read_compact_structure(qpath)
+            res = fq.parse_query_string(qstr, q.chains[0])
+            idx = [q.get_index(c, r) for c, r, _ in res]
+            qb = ctx.upload(fd.PackedStructures.concat([q.as_item()]))
+            m = fq.make_query_map(ctx, qb, idx, [x for _, _, x in res], ix, 5.0, hash_type=htype, multiple_bins=bins)
+            assert np.array_equal(m.hash, om["hash"]) and np.array_equal(m.qi, om["qi"]) and np.array_equal(m.qj, om["qj"])
+            assert np.array_equal(m.is_primary, om["is_primary"]) and np.array_equal(m.idf.view(np.uint32), om["idf"].view(np.uint32))
+            got = fd.count_query(ctx, ix, m.hash, m.qi, m.qj, pen)
+            ref = oracle.count_query(om_, oix, onres)
+            assert [(r["nid"], r["total_match_count"], r["node_count"], r["edge_count"]) for r in got] == \
+                   [(r["nid"], r["total_match_count"], r["node_count"], r["edge_count"]) for r in ref]
+            for ca_cut in (1.0, 3.0):
+                ms = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=ca_cut, hash_type=htype, multiple_bins=bins)
+                for nid in range(5):
+                    R = oracle.retrieve(ostructs[nid], oq, om_, ca_distance_cutoff=ca_cut)
+                    mine = [g for g in ms if g["cand"] == nid]
+                    assert len(mine) == len(R["processed"]), (qstr, ca_cut, nid)
+                    for g, rp, rh in zip(mine, R["processed"], R["from_hash"]):
+                        assert g["processed"] == [-1 if x is None else x[2] for x in rp["residues"]]
+                        assert g["from_hash"] == [-1 if x is None else x[2] for x in rh["residues"]]
+                        assert abs(g["rmsd"] - rp["rmsd"]) <= 1e-4 and g["idf"] == pytest.approx(rp["idf"], rel=1e-6)
+    # CLI round trip through PREFIX.type
+    from folddisco_amd.__main__ import main as cli
+    from folddisco_amd._lib import HASH_TYPE_NAMES
+    from folddisco_amd import indexio
+    prefix = str(tmp_path / "ix")
+    cli(["index", "-p", os.path.dirname(SER[0]), "-i", prefix, "-y", HASH_TYPE_NAMES[htype], "--multiple-bins", ",".join(f"{d}-{a}" for d, a in bins)])
+    assert indexio.load_type(prefix + ".type")["multiple_bin"] == bins
+    dv, dh, do = indexio.read_index_files(prefix)
+    assert np.array_equal(dv, v) and np.array_equal(dh, hh) and np.array_equal(do, o)
+    out = str(tmp_path / "out.tsv")
+    cli(["query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", prefix, "-o", out])
+    q = st.read_compact_structure(Q4CHA)
+    _, want = fq.query_pdb(ctx, ix, batch, structs, [os.path.join(os.path.dirname(SER[0]), os.path.basename(p)) for p in SER], nres, plddt, q,
+                           "B57,B102,C195", hash_type=htype, multiple_bins=bins, sort_by="node_count,rmsd")
+    rows = [l.rstrip("\n").split("\t") for l in open(out)]
+    assert [r[1:] for r in rows] == [fq.format_match_row(m).split("\t")[1:] for m in want] and len(rows) > 0
+    with pytest.raises(Exception):
+        fd.FolddiscoIndex.build(ctx, batch, multiple_bins=[(16, 0)])
