@@ -315,10 +315,9 @@ def main(argv=None):
             a.hash_type = hash_type_index(a.type)
         except ValueError:
             sys.exit(f"[FAIL] unknown hash type {a.type}")
-        if a.hash_type not in (0, 1, 3, 7, 8):
-            sys.exit(f"[FAIL] hash type {HASH_TYPE_NAMES[a.hash_type]}: only the encodings over the PDBTrRosetta descriptor are implemented "
-                     "(PDBTrRosetta, PDBMotif, PDBMotifSinCos, FolddiscoAngle, FolddiscoDist)")
         a.multi = parse_multiple_bins(a.multiple_bins) if a.multiple_bins else None
+        if a.multi is not None and a.hash_type in (2, 4, 5, 6):
+            sys.exit("[FAIL] --multiple-bins is implemented for the encodings over the PDBTrRosetta descriptor only")
         if a.multi is not None and (not a.multi or len(a.multi) > 8 or any(d == 0 or x == 0 for d, x in a.multi)):
             sys.exit("[FAIL] --multiple-bins: one to eight dist-angle pairs with non-zero counts, e.g. 16-4,8-3")
         cmd_index(a)

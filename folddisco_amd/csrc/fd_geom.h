@@ -127,6 +127,8 @@ FD_HD void fd_hash_aa_pair(uint32_t type, uint32_t h, uint32_t *aa1, uint32_t *a
     if (type == FD_HASH_PDBMOTIF) { *aa1 = (h >> 20) & 31u; *aa2 = (h >> 15) & 31u; }
     else if (type == FD_HASH_PDBMOTIF_SINCOS) { *aa1 = (h >> 21) & 31u; *aa2 = (h >> 16) & 31u; }
     else if (type == FD_HASH_FD_ANGLE || type == FD_HASH_FD_DIST) { const uint32_t pair = (h >> 21) & 0x1ffu; *aa1 = pair / 20u; *aa2 = pair % 20u; }
+    else if (type == 2u) { const uint32_t pair = (h >> 23) & 0x1ffu; *aa1 = pair / 20u; *aa2 = pair % 20u; }   // TrRosetta (trrosetta.rs:98-100)
+    else if (type == 4u) { *aa1 = (h >> 27) & 31u; *aa2 = (h >> 22) & 31u; }                                  // PointPairFeature (ppf.rs:56-57)
     else { *aa1 = (h >> 25) & 31u; *aa2 = (h >> 20) & 31u; }
 }
 FD_HD float fd_to_degrees(float rad) { return rad * 57.2957795130823208767981548141051703f; }   // f32::to_degrees

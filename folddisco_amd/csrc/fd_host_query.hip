@@ -63,11 +63,46 @@ __global__ void k_pair_features(fd_batch_view B, uint32_t s, const uint32_t *__r
     o[0] = ok ? (float)B.aa[i] : 0.f; o[1] = ok ? (float)B.aa[j] : 0.f;
     o[2] = f.ca_dist; o[3] = f.cb_dist; o[4] = type == FD_HASH_PDBMOTIF ? fd_to_degrees(f.angle) : f.angle; o[5] = f.tor1; o[6] = f.tor2;
 }
+// the same for every encoding, in the query map's own record: [0..9) the feature container of get_single_feature, [9] the CA
+// distance and [10], [11] the two residue types (get_list_amino_acids_and_distances, structure/core.rs:462-477 — what the
+// observed-distance map holds whatever the encoding puts into the container)
+#define FD_QF 12
+__global__ void k_pair_features12(fd_batch_view B, const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj, uint32_t n, float cutoff,
+                                  uint32_t type, float *__restrict__ feat /*[n][FD_QF]*/, uint8_t *__restrict__ valid) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t R = B.res_off[B.n_struct];
+    const uint32_t i = pi[k], j = pj[k];      // residue indices of the whole batch
+    float *o = feat + (uint64_t)FD_QF * k;
+    for (int z = 0; z < FD_QF; ++z) o[z] = 0.f;
+    bool ok = i < R && j < R && i != j && B.aa[i] != 255 && B.aa[j] != 255;
+    if (ok) {
+        o[9] = fd_dist(fd_load3(B.ca_xyz, i), fd_load3(B.ca_xyz, j)); o[10] = (float)B.aa[i]; o[11] = (float)B.aa[j];
+        if (fd_own_descriptor(type)) {
+            uint32_t lo = 0, hi = B.n_struct;                  // structure of residue i: res_off[lo] <= i < res_off[lo + 1]
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (B.res_off[mid] <= i) lo = mid; else hi = mid; }
+            const uint32_t r0 = B.res_off[lo], r1 = B.res_off[lo + 1];
+            float f[FD_NFEAT];
+            ok = j >= r0 && j < r1 && fd_feature_other(type, B, r0, r1, i, j, cutoff, f);
+            if (ok) for (int z = 0; z < FD_NFEAT; ++z) o[z] = f[z];
+        } else {
+            ok = B.hash_ok[i] && B.hash_ok[j] && !(o[9] > cutoff);
+            if (ok) {
+                const fd_feature f = fd_pair_feature(fd_load3(B.n_xyz, i), fd_load3(B.ca_xyz, i), fd_load3(B.cb_xyz, i), fd_load3(B.n_xyz, j),
+                                                     fd_load3(B.ca_xyz, j), fd_load3(B.cb_xyz, j));
+                o[0] = o[10]; o[1] = o[11]; o[2] = f.ca_dist; o[3] = f.cb_dist; o[4] = type == FD_HASH_PDBMOTIF ? fd_to_degrees(f.angle) : f.angle;
+                o[5] = f.tor1; o[6] = f.tor2;
+            }
+        }
+    }
+    valid[k] = ok ? 1 : 0;
+}
 // GeometricHash::perfect_hash (src/geometry/core.rs:213-246 -> pdb_tr.rs:21-75 and the other encodings) on explicit feature vectors
-__global__ void k_hash_features(const float *__restrict__ feat, uint64_t n, fd_quant q, uint32_t *__restrict__ out) {
+__global__ void k_hash_features(const float *__restrict__ feat, uint64_t n, uint32_t stride, fd_quant q, uint32_t *__restrict__ out) {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const float *f = feat + 7 * k;
+    const float *f = feat + (uint64_t)stride * k;
+    if (fd_own_descriptor(q.type)) { out[k] = fd_hash_other(q.type, f, q); return; }
     fd_feature ft = {f[2], f[3], f[4], f[5], f[6]};
     out[k] = fd_hash_enc_feat(fd_sat_u32(f[0]), fd_sat_u32(f[1]), ft, q);
 }
@@ -76,6 +111,7 @@ extern "C" int fdgpu_pair_features(fdgpu_ctx *c, const fdgpu_batch *b, uint64_t 
                                    const fd_hash_params *p, float *features, uint8_t *valid) {
     if (!c || !b || !p || (s >= b->n_struct && s != 0xffffffffull) || (n && (!pi || !pj || !features || !valid))) return FDGPU_EINVAL;
     CHECK_TYPE(c, p);
+    if (fd_own_descriptor(p->hash_type)) { c->err = "pair_features: seven-float records hold the PDBTrRosetta descriptor only"; return FDGPU_EINVAL; }
     if (!n) return FDGPU_OK;
     hipStream_t st = c->stream;
     HIPCHK(c, c->ws[WS_MISC0].ensure(n * 4));
@@ -93,22 +129,42 @@ extern "C" int fdgpu_pair_features(fdgpu_ctx *c, const fdgpu_batch *b, uint64_t 
     return FDGPU_OK;
 }
 
-static int hash_features_q(fdgpu_ctx *c, const float *features, uint64_t n, fd_quant q, uint32_t *hashes);
+static int hash_features_q(fdgpu_ctx *c, const float *features, uint64_t n, fd_quant q, uint32_t *hashes, uint32_t stride = 7);
 // the single configuration (nbin_dist, nbin_angle; either count 0 -> the encoding's defaults); multiple_bins is not consulted
 extern "C" int fdgpu_hash_features(fdgpu_ctx *c, const float *features, uint64_t n, const fd_hash_params *p, uint32_t *hashes) {
     if (!c || !p || (n && (!features || !hashes))) return FDGPU_EINVAL;
     CHECK_TYPE(c, p);
+    if (fd_own_descriptor(p->hash_type)) { c->err = "hash_features: seven-float records hold the PDBTrRosetta descriptor only"; return FDGPU_EINVAL; }
     return hash_features_q(c, features, n, fd_make_consts(p).q, hashes);
 }
-static int hash_features_q(fdgpu_ctx *c, const float *features, uint64_t n, fd_quant q, uint32_t *hashes) {
+// internal form of fdgpu_pair_features: batch-wide residue indices, FD_QF floats per pair, every encoding
+static int pair_features12(fdgpu_ctx *c, const fdgpu_batch *b, const uint32_t *pi, const uint32_t *pj, uint64_t n, const fd_hash_params *p,
+                           float *features, uint8_t *valid) {
+    if (!n) return FDGPU_OK;
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->ws[WS_MISC0].ensure(n * 4));
+    HIPCHK(c, c->ws[WS_MISC1].ensure(n * 4));
+    HIPCHK(c, c->ws[WS_MISC2].ensure(n * 4 * FD_QF));
+    HIPCHK(c, c->ws[WS_MISC3].ensure(n));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, pi, n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, pj, n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_pair_features12, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, b->view(), c->ws[WS_MISC0].as<uint32_t>(),
+                       c->ws[WS_MISC1].as<uint32_t>(), (uint32_t)n, p->dist_cutoff, p->hash_type, c->ws[WS_MISC2].as<float>(), c->ws[WS_MISC3].as<uint8_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(features, c->ws[WS_MISC2].p, n * 4 * FD_QF, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(valid, c->ws[WS_MISC3].p, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return FDGPU_OK;
+}
+static int hash_features_q(fdgpu_ctx *c, const float *features, uint64_t n, fd_quant q, uint32_t *hashes, uint32_t stride) {
     if (!n) return FDGPU_OK;
     hipStream_t st = c->stream;
     fd_hash_consts C;
     C.q = q;
-    HIPCHK(c, c->ws[WS_MISC2].ensure(n * 28));
+    HIPCHK(c, c->ws[WS_MISC2].ensure(n * 4 * stride));
     HIPCHK(c, c->ws[WS_MISC0].ensure(n * 4));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, features, n * 28, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_hash_features, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, c->ws[WS_MISC2].as<float>(), n, C.q, c->ws[WS_MISC0].as<uint32_t>());
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, features, n * 4 * stride, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_hash_features, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, c->ws[WS_MISC2].as<float>(), n, stride, C.q, c->ws[WS_MISC0].as<uint32_t>());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hashes, c->ws[WS_MISC0].p, n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -152,22 +208,23 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         pair_off[t + 1] = pi.size();
     }
     const uint64_t np = pi.size();
-    std::vector<float> feat(std::max<uint64_t>(np, 1) * 7);
+    std::vector<float> feat(std::max<uint64_t>(np, 1) * FD_QF);
     std::vector<uint8_t> valid(std::max<uint64_t>(np, 1));
-    int rc = fdgpu_pair_features(c, qb, 0xffffffffull, pi.data(), pj.data(), np, p, feat.data(), valid.data());
+    CHECK_TYPE(c, p);
+    int rc = pair_features12(c, qb, pi.data(), pj.data(), np, p, feat.data(), valid.data());
     if (rc) return rc;
     const float RADS_PER_DEG = 3.14159274101257324f / 180.0f;  // f32::to_radians
     std::vector<float> athr(n_angle);
     for (uint64_t t = 0; t < n_angle; ++t) athr[t] = angle_thr_deg[t] * RADS_PER_DEG;
     // candidate lists in the reference's insertion order; hashed in one GPU call, then first-insert-wins per query
     struct cand_t { uint32_t qi, qj; uint8_t primary; uint32_t pair; };
-    std::vector<float> vf;      // 7 floats per candidate
+    std::vector<float> vf;      // FD_QF floats per candidate
     std::vector<cand_t> cands;
     std::vector<uint64_t> cand_off(n_queries + 1, 0);
     struct Aad { std::vector<uint8_t> a1, a2; std::vector<float> ad; std::vector<uint32_t> aq; };
     std::vector<Aad> aads(n_queries);
     auto push = [&](const float *f, uint32_t qi, uint32_t qj, bool primary, uint32_t pair) {
-        vf.insert(vf.end(), f, f + 7);
+        vf.insert(vf.end(), f, f + FD_QF);
         cands.push_back({qi, qj, (uint8_t)(primary ? 1 : 0), pair});
     };
     for (uint64_t t = 0; t < n_queries; ++t) {
@@ -182,26 +239,29 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         Aad &A = aads[t];
         for (uint64_t k = pair_off[t]; k < pair_off[t + 1]; ++k) {
             if (!valid[k]) continue;
-            const float *f = &feat[7 * k];
+            const float *f = &feat[(size_t)FD_QF * k];
             uint32_t qi = (uint32_t)(pi[k] - r0), qj = (uint32_t)(pj[k] - r0);
             // observed (aa_i, aa_j, CA distance) list (structure/core.rs:462-477: distance <= 20.0)
-            if (f[2] <= 20.0f) { A.a1.push_back((uint8_t)f[0]); A.a2.push_back((uint8_t)f[1]); A.ad.push_back(f[2]); A.aq.push_back(qi); }
+            if (f[9] <= 20.0f) { A.a1.push_back((uint8_t)f[10]); A.a2.push_back((uint8_t)f[11]); A.ad.push_back(f[9]); A.aq.push_back(qi); }
             push(f, qi, qj, true, (uint32_t)k);
-            float near[7], far[7];
+            float near[FD_QF], far[FD_QF];
             memcpy(near, f, sizeof near);
             memcpy(far, f, sizeof far);
-            auto si = sub_of.find(qi), sj = sub_of.find(qj);
+            // substitutions touch the residue fields of the container: encodings without them take none (amino_acid_index,
+            // controller/feature.rs:260-267)
+            const bool has_aa = p->hash_type != FD_HASH_TERTIARY && p->hash_type != FD_HASH_HYBRID;
+            auto si = has_aa ? sub_of.find(qi) : sub_of.end(), sj = has_aa ? sub_of.find(qj) : sub_of.end();
             if (si != sub_of.end()) {  // apply_substitutions (query.rs:86-156)
-                for (uint32_t a = 0; a < si->second.second; ++a) { float t2[7]; memcpy(t2, near, sizeof t2); t2[0] = (float)si->second.first[a]; push(t2, qi, qj, false, (uint32_t)k); }
+                for (uint32_t a = 0; a < si->second.second; ++a) { float t2[FD_QF]; memcpy(t2, near, sizeof t2); t2[0] = (float)si->second.first[a]; push(t2, qi, qj, false, (uint32_t)k); }
                 if (sj != sub_of.end())
                     for (uint32_t a = 0; a < si->second.second; ++a)
                         for (uint32_t b = 0; b < sj->second.second; ++b) {
-                            float t2[7]; memcpy(t2, near, sizeof t2);
+                            float t2[FD_QF]; memcpy(t2, near, sizeof t2);
                             t2[0] = (float)si->second.first[a]; t2[1] = (float)sj->second.first[b];
                             push(t2, qi, qj, false, (uint32_t)k);
                         }
             } else if (sj != sub_of.end()) {
-                for (uint32_t b = 0; b < sj->second.second; ++b) { float t2[7]; memcpy(t2, near, sizeof t2); t2[1] = (float)sj->second.first[b]; push(t2, qi, qj, false, (uint32_t)k); }
+                for (uint32_t b = 0; b < sj->second.second; ++b) { float t2[FD_QF]; memcpy(t2, near, sizeof t2); t2[1] = (float)sj->second.first[b]; push(t2, qi, qj, false, (uint32_t)k); }
             }
             auto expand = [&](const int *idxs, int n_idx, const float *thr, uint64_t n_thr) {  // expand_and_insert (query.rs:179-206)
                 for (uint64_t z2 = 0; z2 < n_thr; ++z2)
@@ -218,15 +278,26 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             };
             // dist_index / angle_index of the encoding (controller/feature.rs:269-291): theta only for the two PDBMotif forms — and
             // PDBMotif shifts its DEGREE-valued theta by the threshold converted to radians, like the reference
-            static const int di[2] = {2, 3}, ai[3] = {4, 5, 6};
-            expand(di, 2, dist_thr, n_dist);
-            expand(ai, (p->hash_type == FD_HASH_PDBMOTIF || p->hash_type == FD_HASH_PDBMOTIF_SINCOS) ? 1 : 3, athr.data(), n_angle);
+            static const int d23[2] = {2, 3}, d2[1] = {2}, d7[1] = {7};
+            static const int a456[3] = {4, 5, 6}, a37[5] = {3, 4, 5, 6, 7}, a345[3] = {3, 4, 5}, a06[7] = {0, 1, 2, 3, 4, 5, 6}, a48[5] = {4, 5, 6, 7, 8};
+            const int *di = d23, *ai = a456;
+            int ndi = 2, nai = 3;
+            switch (p->hash_type) {
+                case FD_HASH_PDBMOTIF: case FD_HASH_PDBMOTIF_SINCOS: nai = 1; break;
+                case FD_HASH_TRROSETTA: di = d2; ndi = 1; ai = a37; nai = 5; break;
+                case FD_HASH_PPF: di = d2; ndi = 1; ai = a345; nai = 3; break;
+                case FD_HASH_TERTIARY: di = d7; ndi = 1; ai = a06; nai = 7; break;
+                case FD_HASH_HYBRID: ai = a48; nai = 5; break;
+                default: break;
+            }
+            expand(di, ndi, dist_thr, n_dist);
+            expand(ai, nai, athr.data(), n_angle);
         }
         cand_off[t + 1] = cands.size();
     }
     const uint64_t nc = cands.size();
     std::vector<uint32_t> hashes(std::max<uint64_t>(nc, 1));
-    if ((rc = fdgpu_hash_features(c, vf.data(), nc, p, hashes.data()))) return rc;
+    if ((rc = hash_features_q(c, vf.data(), nc, fd_make_consts(p).q, hashes.data(), FD_QF))) return rc;
     // --multiple-bins: every candidate is inserted under every bin pair, in list order (insert_binned_hash, query.rs:59-70); the
     // observed hash idf is looked up for stays the single-configuration one (query.rs:283-288)
     const uint32_t n_cfg = p->n_multiple_bins ? p->n_multiple_bins : 0u;
@@ -234,7 +305,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     std::vector<std::vector<uint32_t>> mh_cfg(n_cfg);
     for (uint32_t k = 0; k < n_cfg; ++k) {
         mh_cfg[k].resize(std::max<uint64_t>(nc, 1));
-        if ((rc = hash_features_q(c, vf.data(), nc, fd_make_consts_cfg(p, k).q, mh_cfg[k].data()))) return rc;
+        if ((rc = hash_features_q(c, vf.data(), nc, fd_make_consts_cfg(p, k).q, mh_cfg[k].data(), FD_QF))) return rc;
     }
     // idf of every pair's observed (primary) hash: log2(S / len) (query.rs:17-32)
     std::vector<float> pair_idf(std::max<uint64_t>(np, 1), 0.0f);
@@ -460,6 +531,25 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     // folddisco_dist.rs:126)
     const uint32_t htype = p->hash_type;
     auto is_sym = [htype](uint32_t h) {
+        const float D2 = 57.2957795130823208767981548141051703f;
+        auto c3 = [](uint32_t v, float nb) { float cf = (1.0f - (-1.0f)) / (nb - 1.0f); return (float)v * cf + (-1.0f); };
+        if (htype == FD_HASH_TERTIARY) return false;                                   // tertiary_interaction.rs:145-150
+        if (htype == FD_HASH_TRROSETTA) {                                              // trrosetta.rs:158-162 (default 3 angle bins)
+            const uint32_t pr = (h >> 23) & 0x1ffu;
+            float a[5];
+            for (int k = 0; k < 5; ++k) a[k] = atan2f(c3((h >> (18 - 4 * k)) & 3u, 3.0f), c3((h >> (16 - 4 * k)) & 3u, 3.0f)) * D2;
+            return pr / 20u == pr % 20u && a[1] == a[2] && a[3] == a[4];
+        }
+        if (htype == FD_HASH_PPF) {                                                    // ppf.rs:124-127
+            float a[2];
+            for (int k = 0; k < 2; ++k) a[k] = atan2f(c3((h >> (15 - 6 * k)) & 7u, 3.0f), c3((h >> (12 - 6 * k)) & 7u, 3.0f)) * D2;
+            return ((h >> 27) & 31u) == ((h >> 22) & 31u) && a[0] == a[1];
+        }
+        if (htype == FD_HASH_HYBRID) {                                                 // hybrid.rs:185-189 (4 angle bins)
+            float a[2];
+            for (int k = 0; k < 2; ++k) a[k] = atan2f(c3((h >> (14 - 4 * k)) & 3u, 4.0f), c3((h >> (12 - 4 * k)) & 3u, 4.0f)) * D2;
+            return ((h >> 30) & 3u) == ((h >> 28) & 3u) && a[0] == a[1];
+        }
         if (htype == FD_HASH_PDBMOTIF) return ((h >> 20) & 31u) == ((h >> 15) & 31u);
         if (htype == FD_HASH_PDBMOTIF_SINCOS) return ((h >> 21) & 31u) == ((h >> 16) & 31u);
         if (htype == FD_HASH_FD_ANGLE || htype == FD_HASH_FD_DIST) {

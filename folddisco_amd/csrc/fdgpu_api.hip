@@ -209,9 +209,7 @@ extern "C" uint64_t fdgpu_batch_num_residues(const fdgpu_batch *b) { return b ? 
 // ---- hash constants ------------------------------------------------------------------------------------------------
 // per-encoding bin rules: {cap_dist, default_dist, cap_angle, default_angle} (perfect_hash of pdb_motif.rs:27-40,
 // pdb_motif_sincos.rs:19-31, pdb_tr.rs:22-35, folddisco_angle.rs:26-40, folddisco_dist.rs:23-37)
-bool fd_hash_type_supported(uint32_t t) {
-    return t == FD_HASH_PDBMOTIF || t == FD_HASH_PDBMOTIF_SINCOS || t == FD_HASH_PDBTR || t == FD_HASH_FD_ANGLE || t == FD_HASH_FD_DIST;
-}
+bool fd_hash_type_supported(uint32_t t) { return t <= 8u; }   // HashType::get_with_index 0..8 (geometry/core.rs:26-40)
 // nbd / nba: requested bin counts.  either_zero_defaults: the rule of the single-configuration callers (either count 0 -> both
 // defaults, controller/feature.rs:216-223, query.rs:72-77); the per-encoding perfect_hash itself treats the two counts
 // independently (pdb_tr.rs:22-35 etc.), which is what the --multiple-bins list reaches (zero counts are rejected there).
@@ -223,6 +221,9 @@ static fd_hash_consts make_consts_bins(const fd_hash_params *p, uint32_t nbd_req
     else if (type == FD_HASH_PDBMOTIF_SINCOS) { cap_d = 16; def_d = 8; cap_a = 16; def_a = 3; }
     else if (type == FD_HASH_FD_ANGLE) { cap_d = 8; def_d = 8; cap_a = 32; def_a = 32; }
     else if (type == FD_HASH_FD_DIST) { cap_d = 32; def_d = 32; cap_a = 16; def_a = 16; }
+    else if (type == FD_HASH_TRROSETTA) { cap_d = 8; def_d = 8; cap_a = 4; def_a = 3; }        // trrosetta.rs:62-64, convert.rs NBIN_DIST / NBIN_SIN_COS
+    else if (type == FD_HASH_PPF || type == FD_HASH_TERTIARY) { cap_d = 16; def_d = 8; cap_a = 8; def_a = 3; }   // ppf.rs:16-31, tertiary_interaction.rs:23-36
+    else if (type == FD_HASH_HYBRID) { cap_d = 16; def_d = 16; cap_a = 4; def_a = 4; }         // hybrid.rs:22-35
     // either bin count 0 -> perfect_hash_default (controller/feature.rs:216-223, query.rs:72-77)
     const bool dflt = either_zero_defaults && (nbd_req == 0 || nba_req == 0);
     float nd = (dflt || nbd_req == 0) ? (float)def_d : (nbd_req > cap_d ? (float)cap_d : (float)nbd_req);
@@ -350,7 +351,7 @@ extern "C" int fdgpu_hash_batch(fdgpu_ctx *c, const fdgpu_batch *b, const fd_has
         HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(std::max<uint64_t>(S, R)) * 8 + 64));
         HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
         HIPCHK(c, hipMemsetAsync(c->ws[WS_MISC0].p, 0, (R + 1) * 4, st));
-        fd_launch_row_count(b->view(), C, c->ws[WS_MISC0].as<uint32_t>(), st);
+        fd_launch_row_count(b->view(), C, c->ws[WS_MISC0].as<uint32_t>(), p->dist_cutoff, st);
         fd_exclusive_scan<uint32_t>(c->ws[WS_MISC0].as<uint32_t>(), R, c->ws[WS_MISC1].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
                                     c->ws[WS_TOTAL].as<uint64_t>(), st);
         HIPCHK(c, hipGetLastError());
@@ -358,7 +359,7 @@ extern "C" int fdgpu_hash_batch(fdgpu_ctx *c, const fdgpu_batch *b, const fd_has
         int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &P);
         if (rc) { free(h_off); return rc; }
         HIPCHK(c, c->ws[WS_KEYS_A].ensure(std::max<uint64_t>(P, 1) * 4));
-        fd_launch_row_emit(b->view(), C, c->ws[WS_MISC1].as<uint64_t>(), c->ws[WS_KEYS_A].as<uint32_t>(), st);
+        fd_launch_row_emit(b->view(), C, c->ws[WS_MISC1].as<uint64_t>(), c->ws[WS_KEYS_A].as<uint32_t>(), p->dist_cutoff, nullptr, 0u, st);
         HIPCHK(c, hipGetLastError());
         uint32_t *h = (uint32_t *)malloc(std::max<uint64_t>(P, 1) * 4);
         std::vector<uint64_t> row_off(R + 1);
@@ -370,6 +371,7 @@ extern "C" int fdgpu_hash_batch(fdgpu_ctx *c, const fdgpu_batch *b, const fd_has
         *hashes = h; *hash_off = h_off;
         return FDGPU_OK;
     }
+    if (fd_own_descriptor(p->hash_type)) { free(h_off); FAIL(c, FDGPU_EINVAL, "hash_batch: this encoding is served in the reference's raw order only (sort_dedup = 0)"); }
     uint64_t P = 0;
     int rc = count_and_scan(c, b, C, &P);
     if (rc) { free(h_off); return rc; }
@@ -439,8 +441,29 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
         StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame)));
         fd_launch_frames(b->view(), b->n_res, c->ws[WS_FRAMES].p, st);
     }
+    // the encodings with their own descriptor go one ordered pair at a time through the row kernels (reference order), 8-byte elements
+    const bool own = fd_own_descriptor(p->hash_type);
+    if (own && n_cfg > 1) FAIL(c, FDGPU_EINVAL, "multiple_bins is built for the encodings over the PDBTrRosetta descriptor only");
     uint64_t P1 = 0;
-    int rc = count_and_scan(c, b, C, &P1, true);
+    int rc;
+    if (own) {
+        const uint64_t R = b->n_res;
+        HIPCHK(c, c->ws[WS_MISC0].ensure((R + 1) * 4));
+        HIPCHK(c, c->ws[WS_MISC1].ensure((R + 2) * 8));
+        HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(std::max<uint64_t>(R, S)) * 8 + 64));
+        HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_MISC0].p, 0, (R + 1) * 4, st));
+        {
+            StageTimer t(c, "pair_count", R * 37);
+            fd_launch_row_count(b->view(), C, c->ws[WS_MISC0].as<uint32_t>(), p->dist_cutoff, st);
+            fd_exclusive_scan<uint32_t>(c->ws[WS_MISC0].as<uint32_t>(), R, c->ws[WS_MISC1].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
+                                        c->ws[WS_TOTAL].as<uint64_t>(), st);
+        }
+        HIPCHK(c, hipGetLastError());
+        rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &P1);
+    } else {
+        rc = count_and_scan(c, b, C, &P1, true);
+    }
     if (rc) return rc;
     P = P1 * n_cfg;                         // every bin pair of --multiple-bins contributes one key per ordered residue pair
     if (P >= 0xffffffffull) FAIL(c, FDGPU_ERANGE, "more than 2^32 residue pairs in one build call; split the shard");
@@ -449,13 +472,14 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     void *ia = c->ws[WS_IDS_A].p, *ib = c->ws[WS_IDS_B].p;
     // shards of <= 2^18 structures use 6-byte sort elements (key = hash << 2 | local id bits 17:16, u16 payload) as long as
     // every hash fits 30 bits; the 8-byte form (u32 hash, u32 id) otherwise
-    const bool ids16 = !force32 && S <= (1ull << 18);
+    const bool ids16 = !own && !force32 && S <= (1ull << 18);
     HIPCHK(c, c->ws[WS_MISC3].ensure(64));
     HIPCHK(c, hipMemsetAsync(c->ws[WS_MISC3].p, 0, 64, st));
     C.wide_flag = c->ws[WS_MISC3].as<unsigned long long>() + 3;
     {
         StageTimer t(c, "pair_emit", b->n_res * 37 + P * (ids16 ? 6 : 8));
-        for (uint32_t k = 0; k < n_cfg; ++k) {
+        if (own) fd_launch_row_emit(b->view(), C, c->ws[WS_MISC1].as<uint64_t>(), ka, p->dist_cutoff, (uint32_t *)ia, (uint32_t)first_id, st);
+        else for (uint32_t k = 0; k < n_cfg; ++k) {
             fd_hash_consts Ck = fd_make_consts_cfg(p, k);
             Ck.spec_miss = C.spec_miss; Ck.wide_flag = C.wide_flag; Ck.seg_mul = n_cfg; Ck.seg_cfg = k;
             if (k) HIPCHK(c, hipMemsetAsync(c->ws[WS_CURSOR].p, 0, (S + 1) * 4, st));
@@ -914,7 +938,10 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
             fd_hash_aa_pair(p->hash_type, q->hashes[k], &a1, &a2);
             Q.aa1_mask |= 1u << (a1 & 31u); Q.aa2_mask |= 1u << (a2 & 31u);
         }
-        Q.use_prefilter = q->use_aa_prefilter; Q.ca_window = q->ca_distance_cutoff;
+        // TertiaryInteraction / Hybrid hashes carry no residue types: the reference's prefilter unwraps a None there
+        // (retrieve.rs:576) and panics for queries of <= 200 hashes; every pair is scanned instead
+        const bool no_aa = p->hash_type == FD_HASH_TERTIARY || p->hash_type == FD_HASH_HYBRID;
+        Q.use_prefilter = no_aa ? 0 : q->use_aa_prefilter; Q.ca_window = q->ca_distance_cutoff;
         std::vector<uint32_t> cnt(1025, 0);
         for (uint64_t e = 0; e < q->n_aad; ++e)
             if (q->aad_aa1[e] < 32 && q->aad_aa2[e] < 32) ++cnt[q->aad_aa1[e] * 32u + q->aad_aa2[e] + 1];   // residue type 255 never passes get_single_feature

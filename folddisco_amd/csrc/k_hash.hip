@@ -12,6 +12,7 @@
 // ballot + mbcnt prefix into a per-wave LDS queue and the descriptor is evaluated in full
 // 64-entry drains (one queue entry per lane).  No MFMA: this is f32/f64 VALU + irregular gather.
 #include "fd_device.h"
+#include "fd_geom_other.h"
 // waves per SIMD the pair kernel is compiled for: 5 (88 VGPRs, 48 B of scratch) measured 15.0 ms against 16.2 (4 waves,
 // 114 VGPRs) and 16.1 (6 waves, 80 VGPRs, 96 B of scratch)
 #ifndef FD_EMIT_WAVES
@@ -304,13 +305,22 @@ __global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_
 // Same pairs, but written in the reference's row-major (i, j) order: one lane per i computes its
 // row offset by a prefix over row counts.  Used for parity tests of the raw hash list; not on the
 // index-build fast path.
-__global__ __launch_bounds__(FD_WAVE) void k_row_count(fd_batch_view B, fd_hash_consts C, uint32_t *__restrict__ row_cnt) {
+__global__ __launch_bounds__(FD_WAVE) void k_row_count(fd_batch_view B, fd_hash_consts C, uint32_t *__restrict__ row_cnt, float cutoff) {
     uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
     if (w >= B.n_work) return;
     const uint32_t s = B.wi_struct[w];
     const uint32_t r0 = B.res_off[s], r1 = B.res_off[s + 1];
     const uint32_t i = B.wi_i0[w] + threadIdx.x;
     if (i >= r1) return;
+    if (fd_own_descriptor(C.q.type)) {   // the encodings with their own descriptor and acceptance rule (fd_geom_other.h)
+        uint32_t cnt = 0;
+        float f[FD_NFEAT];
+        if (B.aa[i] != 255)
+            for (uint32_t j = r0; j < r1; ++j)
+                cnt += (j != i && B.aa[j] != 255 && fd_feature_other(C.q.type, B, r0, r1, i, j, cutoff, f)) ? 1u : 0u;
+        row_cnt[i] = cnt;
+        return;
+    }
     const bool vi = B.hash_ok[i];
     fd_v3 cai = fd_load3(B.ca_xyz, i);
     uint32_t cnt = 0;
@@ -323,13 +333,25 @@ __global__ __launch_bounds__(FD_WAVE) void k_row_count(fd_batch_view B, fd_hash_
 }
 
 __global__ __launch_bounds__(FD_WAVE) void k_row_emit(fd_batch_view B, fd_hash_consts C, const uint64_t *__restrict__ row_off,
-                                                      uint32_t *__restrict__ keys) {
+                                                      uint32_t *__restrict__ keys, float cutoff, uint32_t *__restrict__ ids, uint32_t first_id) {
     uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
     if (w >= B.n_work) return;
     const uint32_t s = B.wi_struct[w];
     const uint32_t r0 = B.res_off[s], r1 = B.res_off[s + 1];
     const uint32_t i = B.wi_i0[w] + threadIdx.x;
-    if (i >= r1 || !B.hash_ok[i]) return;
+    if (i >= r1) return;
+    if (fd_own_descriptor(C.q.type)) {
+        if (B.aa[i] == 255) return;
+        uint64_t pos = row_off[i];
+        float f[FD_NFEAT];
+        for (uint32_t j = r0; j < r1; ++j) {
+            if (j == i || B.aa[j] == 255 || !fd_feature_other(C.q.type, B, r0, r1, i, j, cutoff, f)) continue;
+            if (ids) ids[pos] = first_id + s;
+            keys[pos++] = fd_hash_other(C.q.type, f, C.q);
+        }
+        return;
+    }
+    if (!B.hash_ok[i]) return;
     fd_v3 n1 = fd_load3(B.n_xyz, i), ca1 = fd_load3(B.ca_xyz, i), cb1 = fd_load3(B.cb_xyz, i);
     uint32_t aa1 = B.aa[i];
     uint64_t pos = row_off[i];
@@ -339,6 +361,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_row_emit(fd_batch_view B, fd_hash_c
         if (fd_dist2(ca1, ca2) > C.d2_max) continue;
         fd_v3 n2 = fd_load3(B.n_xyz, j), cb2 = fd_load3(B.cb_xyz, j);
         fd_feature f = fd_pair_feature(n1, ca1, cb1, n2, ca2, cb2);
+        if (ids) ids[pos] = first_id + s;
         keys[pos++] = fd_hash_enc(aa1, B.aa[j], f, C.q);
     }
 }
@@ -388,12 +411,13 @@ void fd_launch_pair_emit2(const fd_batch_view &B, const void *frames, const fd_h
     else if (ids16) hipLaunchKernelGGL((k_pair_emit2<0, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
     else hipLaunchKernelGGL((k_pair_emit2<0, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
 }
-void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, hipStream_t st) {
+void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, float cutoff, hipStream_t st) {
     if (!B.n_work) return;
-    hipLaunchKernelGGL(k_row_count, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, row_cnt);
+    hipLaunchKernelGGL(k_row_count, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, row_cnt, cutoff);
 }
-void fd_launch_row_emit(const fd_batch_view &B, const fd_hash_consts &C, const uint64_t *row_off, uint32_t *keys, hipStream_t st) {
+void fd_launch_row_emit(const fd_batch_view &B, const fd_hash_consts &C, const uint64_t *row_off, uint32_t *keys, float cutoff, uint32_t *ids,
+                        uint32_t first_id, hipStream_t st) {
     if (!B.n_work) return;
-    hipLaunchKernelGGL(k_row_emit, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, row_off, keys);
+    hipLaunchKernelGGL(k_row_emit, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, row_off, keys, cutoff, ids, first_id);
 }
 }

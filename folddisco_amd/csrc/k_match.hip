@@ -26,7 +26,7 @@ __device__ __forceinline__ bool hash_in_set(const uint32_t *__restrict__ h, uint
 // descriptor + hash + output of one surviving (i, j) per lane (full-wave drains of the compaction queue: executed
 // divergently per survivor this part — ~3000 instructions with the exact libm chain — was 95 % of the kernel time)
 template <bool EMIT>
-__device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q, uint32_t n, uint32_t slot, uint32_t r0, uint32_t i0,
+__device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q, uint32_t n, uint32_t slot, uint32_t r0, uint32_t r1, uint32_t i0,
                                             const uint32_t *st_tab, const float *dist_tab, const uint32_t *tab) {
     const uint32_t lane = threadIdx.x;
     const bool on = lane < n;
@@ -45,7 +45,16 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
         key = (aai & 31u) * 32u + (aaj & 31u);   // queued pairs have aa < 32
         e_lo = st_tab[key]; e_hi = st_tab[key + 1];
         for (uint32_t e = e_lo; e < e_hi; ++e) n_win += (fd_fabsf(d - dist_tab[e]) < A.ca_window) ? 1u : 0u;
-        if (A.C.use_tab && A.n_cfg == 1) {
+        if (fd_own_descriptor(A.C.q.type)) {
+            // encodings with their own descriptor: the pair may still have no feature (CB / point-pair distance, chain ends)
+            float f9[FD_NFEAT];
+            if (fd_feature_other(A.C.q.type, A.B, r0, r1, i, j, A.cutoff, f9)) {
+                h = fd_hash_other(A.C.q.type, f9, A.C.q);
+                hitmask = ((A.mode & 1u) && hash_in_set(A.q_hashes, A.n_hashes, h)) ? 1u : 0u;
+            } else {
+                n_win = 0;
+            }
+        } else if (A.C.use_tab && A.n_cfg == 1) {
             // default angle bins: frames + exhaustive tables (fd_geom.h) — same bits as the generic chain, a tenth of the code
             fd_frame Fi = fd_make_frame(fd_load3(A.B.n_xyz, i), cai, fd_load3(A.B.cb_xyz, i));
             fd_frame Fj = fd_make_frame(fd_load3(A.B.n_xyz, j), caj, fd_load3(A.B.cb_xyz, j));
@@ -163,7 +172,8 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     const uint32_t aai = in_i ? A.B.aa[i] : 255u;
     const bool std_i = aai < 20u && (A.resname_std == nullptr || A.resname_std[i]);
     // get_single_feature (controller/feature.rs:11-24, 84-99) rejects unknown residues / missing CB
-    const bool act = in_i && (full || (std_i && ((A.aa1_mask >> aai) & 1u))) && aai != 255u && A.B.hash_ok[i];
+    const bool tert = A.C.q.type == FD_HASH_TERTIARY;     // TertiaryInteraction needs no CB (feature.rs:113-160)
+    const bool act = in_i && (full || (std_i && ((A.aa1_mask >> aai) & 1u))) && aai != 255u && (tert || A.B.hash_ok[i]);
     fd_v3 cai = {0.f, 0.f, 0.f};
     if (in_i) cai = fd_load3(A.B.ca_xyz, i);
     // partner residue types this lane's residue type has any observation with (aa < 32): one register test per pair
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
         const uint32_t aaj_l = jin ? A.B.aa[jl] : 255u;
         fd_v3 cj = {0.f, 0.f, 0.f};
         if (jin) cj = fd_load3(A.B.ca_xyz, jl);
-        bool okj = jin && aaj_l != 255u && A.B.hash_ok[jl];
+        bool okj = jin && aaj_l != 255u && (tert || A.B.hash_ok[jl]);
         if (!full) okj = okj && aaj_l < 20u && (A.resname_std == nullptr || A.resname_std[jl]) && ((A.aa2_mask >> aaj_l) & 1u);
         if (A.cj_mask && okj) { const uint32_t bit = A.mask_off[slot] + (jl - r0); okj = (A.cj_mask[bit >> 5] >> (bit & 31u)) & 1u; }
         const uint64_t okm = __ballot(okj);
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                 __syncthreads();
                 uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
                 qn -= n;
-                match_drain<EMIT>(A, q + qn, n, slot, r0, i0, s_start, dist_tab, tab);
+                match_drain<EMIT>(A, q + qn, n, slot, r0, r1, i0, s_start, dist_tab, tab);
                 __syncthreads();
             }
         }

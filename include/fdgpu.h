@@ -55,15 +55,23 @@ typedef struct fd_batch_desc {
     const uint8_t *cb_valid;   /* [R] 1 if CB is Some (src/structure/core.rs:147-155); NULL = all 1 */
 } fd_batch_desc;
 
-/* Parameters of the encoding.  hash_type = the reference's HashType index (src/geometry/core.rs:26-40): the encodings over the
- * (d_CA, d_CB, theta, tau1, tau2) descriptor are built — 3 PDBTrRosetta (the default, pdb_tr.rs:21-75; the fast table /
- * speculative path), 0 PDBMotif (pdb_motif.rs), 1 PDBMotifSinCos (pdb_motif_sincos.rs), 7 FolddiscoAngle (folddisco_angle.rs),
- * 8 FolddiscoDist (folddisco_dist.rs); 2 / 4 / 5 / 6 (other descriptors) return FDGPU_EINVAL.
+/* Parameters of the encoding.  hash_type = the reference's HashType index (src/geometry/core.rs:26-40), all nine built:
+ * 3 PDBTrRosetta (the default, pdb_tr.rs:21-75; the fast table / speculative path) and, over the same
+ * (d_CA, d_CB, theta, tau1, tau2) descriptor, 0 PDBMotif (pdb_motif.rs), 1 PDBMotifSinCos (pdb_motif_sincos.rs),
+ * 7 FolddiscoAngle (folddisco_angle.rs), 8 FolddiscoDist (folddisco_dist.rs); with their own descriptors (one ordered pair at a
+ * time, exact libm, 32-bit hashes) 2 TrRosetta (trrosetta.rs), 4 PointPairFeature (ppf.rs), 5 TertiaryInteraction
+ * (tertiary_interaction.rs), 6 Hybrid (hybrid.rs) — for those four fdgpu_hash_batch serves the raw order only, and
+ * fdgpu_pair_features / fdgpu_hash_features (seven-float records) are not available.  Retrieval with 5 / 6 scans every residue
+ * pair (the reference's amino-acid prefilter panics there for queries of <= 200 hashes).
  * nbin_dist / nbin_angle follow the reference: if either is 0 both take the encoding's defaults
  * (controller/feature.rs:216-223), larger values clamp per encoding. */
 #define FDGPU_HASH_PDBMOTIF 0u
 #define FDGPU_HASH_PDBMOTIF_SINCOS 1u
+#define FDGPU_HASH_TRROSETTA 2u
 #define FDGPU_HASH_PDBTR 3u
+#define FDGPU_HASH_PPF 4u
+#define FDGPU_HASH_TERTIARY 5u
+#define FDGPU_HASH_HYBRID 6u
 #define FDGPU_HASH_FOLDDISCO_ANGLE 7u
 #define FDGPU_HASH_FOLDDISCO_DIST 8u
 #define FDGPU_MAX_MULTIPLE_BINS 8

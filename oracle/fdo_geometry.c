@@ -113,7 +113,7 @@ static v3 at(const float *p, int64_t i) { v3 r = {p[3 * i], p[3 * i + 1], p[3 * 
  * the same descriptor (0 PDBMotif, 1 PDBMotifSinCos, 7 FolddiscoAngle, 8 FolddiscoDist).  Test infrastructure: a process-wide switch. */
 static uint32_t g_hash_type = 3;
 int fdo_set_hash_type(uint32_t t) {
-    if (t != 0 && t != 1 && t != 3 && t != 7 && t != 8) return -1;
+    if (t > 8) return -1;
     g_hash_type = t;
     return 0;
 }
@@ -121,9 +121,76 @@ uint32_t fdo_get_hash_type(void) { return g_hash_type; }
 
 /* controller/feature.rs:11-24,26-99 + structure/core.rs:255-297,378-403: the five encodings share the pair rules (both aa known,
  * CA and CB present, d_CA <= cutoff); tau1 / tau2 are simply unused by the two PDBMotif forms */
+/* coordinate.rs:150-162 */
+static float calc_angle_radian(v3 a, v3 b, v3 c) {
+    v3 v1 = {a.x - b.x, a.y - b.y, a.z - b.z};
+    v3 v2 = {c.x - b.x, c.y - b.y, c.z - b.z};
+    float dt = v1.x * v2.x + v1.y * v2.y + v1.z * v2.z;
+    float l1 = sqrtf(v1.x * v1.x + v1.y * v1.y + v1.z * v1.z);
+    float l2 = sqrtf(v2.x * v2.x + v2.y * v2.y + v2.z * v2.z);
+    return acosf(dt / (l1 * l2));
+}
+static v3 at(const float *p, int64_t i);
+static float calc_torsion_radian(v3 a, v3 b, v3 c, v3 d);
+/* map_aa_to_u8_group (convert.rs:85-130) through the residue type: the two tables agree name by name (checked against the source) */
+static const uint8_t AA_GROUP[20] = {0, 3, 2, 3, 0, 2, 3, 0, 3, 1, 1, 3, 1, 1, 0, 0, 2, 1, 2, 1};
+
+/* the four encodings with their own descriptors (controller/feature.rs:67-82, 100-190; structure/core.rs:310-345, 405-437) */
+static int pair_feature_other(const fdo_structure *s, int64_t i, int64_t j, float dist_cutoff, float f[9]) {
+    const int64_t n = s->n;
+    v3 ca1 = at(s->ca_xyz, i), ca2 = at(s->ca_xyz, j);
+    if (g_hash_type == 2) {            /* TrRosetta: get_trrosetta_feature, cutoff on the CB distance */
+        if (!s->cb_ok[i] || !s->cb_ok[j]) return 0;
+        v3 cb1 = at(s->cb_xyz, i), cb2 = at(s->cb_xyz, j), n1 = at(s->n_xyz, i), n2 = at(s->n_xyz, j);
+        float cb_dist = calc_distance(cb1, cb2);
+        if (cb_dist > dist_cutoff) return 0;
+        f[0] = (float)s->aa[i]; f[1] = (float)s->aa[j]; f[2] = cb_dist;
+        f[3] = calc_torsion_radian(ca1, cb1, cb2, ca2);
+        f[4] = calc_torsion_radian(n1, ca1, cb1, cb2);
+        f[5] = calc_torsion_radian(cb1, cb2, ca2, n2);
+        f[6] = calc_angle_radian(ca1, cb1, cb2);
+        f[7] = calc_angle_radian(cb1, cb2, ca2);
+        return 1;
+    }
+    if (g_hash_type == 4) {            /* PointPairFeature: get_ppf over (cb1 - ca1, cb2 - ca1), coordinate.rs:93-102 */
+        if (!s->cb_ok[i] || !s->cb_ok[j]) return 0;
+        v3 a = sub(at(s->cb_xyz, i), ca1), b = sub(at(s->cb_xyz, j), ca1);
+        v3 n1 = normalize(a), n2 = normalize(b), d = sub(b, a), nd = normalize(d);
+        float dist = norm(d);
+        float a1 = acosf(dot(n1, nd)), a2 = acosf(dot(n2, nd)), a3 = acosf(dot(n1, n2));
+        if (dist > dist_cutoff) return 0;
+        f[0] = (float)s->aa[i]; f[1] = (float)s->aa[j]; f[2] = dist; f[3] = a1; f[4] = a2; f[5] = a3;
+        return 1;
+    }
+    if (i == 0 || j == 0 || i == n - 1 || j == n - 1) return 0;
+    if (g_hash_type == 5) {            /* TertiaryInteraction: seven angles between consecutive-CA directions */
+        float ca_dist = calc_distance(ca1, ca2);
+        if (ca_dist > dist_cutoff) return 0;
+        v3 u1 = normalize(sub(ca1, at(s->ca_xyz, i - 1))), u2 = normalize(sub(at(s->ca_xyz, i + 1), ca1));
+        v3 u3 = normalize(sub(ca2, at(s->ca_xyz, j - 1))), u4 = normalize(sub(at(s->ca_xyz, j + 1), ca2));
+        v3 u5 = normalize(sub(ca2, ca1));
+        f[0] = acosf(dot(u1, u2)); f[1] = acosf(dot(u3, u4)); f[2] = acosf(dot(u1, u5)); f[3] = acosf(dot(u3, u5));
+        f[4] = acosf(dot(u1, u4)); f[5] = acosf(dot(u2, u3)); f[6] = acosf(dot(u1, u3));
+        f[7] = ca_dist; f[8] = (float)j - (float)i;
+        return 1;
+    }
+    /* Hybrid: residue groups + the PDBTrRosetta descriptor + the two pseudo backbone torsions (core.rs:405-437) */
+    if (!s->cb_ok[i] || !s->cb_ok[j]) return 0;
+    v3 cb1 = at(s->cb_xyz, i), cb2 = at(s->cb_xyz, j), n1 = at(s->n_xyz, i), n2 = at(s->n_xyz, j);
+    float ca_dist = calc_distance(ca1, ca2);
+    if (ca_dist > dist_cutoff) return 0;
+    f[0] = (float)AA_GROUP[s->aa[i]]; f[1] = (float)AA_GROUP[s->aa[j]];
+    f[2] = ca_dist; f[3] = calc_distance(cb1, cb2); f[4] = calc_angle(ca1, cb1, ca2, cb2);
+    f[5] = calc_torsion_radian(n1, ca1, cb1, cb2); f[6] = calc_torsion_radian(cb1, cb2, ca2, n2);
+    f[7] = calc_torsion_radian(at(s->ca_xyz, i - 1), n1, ca1, at(s->ca_xyz, i + 1));
+    f[8] = calc_torsion_radian(at(s->ca_xyz, j - 1), n2, ca2, at(s->ca_xyz, j + 1));
+    return 1;
+}
+
 int fdo_pair_feature(const fdo_structure *s, int64_t i, int64_t j, float dist_cutoff, float feature[9]) {
     if (i == j) return 0;
     if (s->aa[i] == 255 || s->aa[j] == 255) return 0;
+    if (g_hash_type == 2 || (g_hash_type >= 4 && g_hash_type <= 6)) return pair_feature_other(s, i, j, dist_cutoff, feature);
     if (!s->cb_ok[i] || !s->cb_ok[j]) return 0;
     v3 ca1 = at(s->ca_xyz, i), ca2 = at(s->ca_xyz, j);
     v3 cb1 = at(s->cb_xyz, i), cb2 = at(s->cb_xyz, j);
@@ -203,9 +270,45 @@ uint64_t fdo_multiple_bins(uint64_t out[16]) {
     for (uint64_t k = 0; k < g_multi_n; ++k) { out[2 * k] = g_multi[k][0]; out[2 * k + 1] = g_multi[k][1]; }
     return g_multi_n;
 }
+/* geometry/trrosetta.rs:56-96 (caps 8 / 4; its default call passes 8 / 3) */
+static uint32_t hash_trrosetta(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle) {
+    float nd = pick_bins(nbin_dist, 8.0f, 8.0f), na = pick_bins(nbin_angle, 4.0f, 3.0f);
+    uint32_t h = (sat_u32(f[0]) * 20u + sat_u32(f[1])) << 23 | fdo_discretize(f[2], 2.0f, 20.0f, nd) << 20;
+    for (int k = 0; k < 5; ++k)
+        h |= fdo_discretize(sinf(f[3 + k]), -1.0f, 1.0f, na) << (18 - 4 * k) | fdo_discretize(cosf(f[3 + k]), -1.0f, 1.0f, na) << (16 - 4 * k);
+    return h;
+}
+/* geometry/ppf.rs:15-49 */
+static uint32_t hash_ppf(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle) {
+    float nd = pick_bins(nbin_dist, 16.0f, 8.0f), na = pick_bins(nbin_angle, 8.0f, 3.0f);
+    uint32_t h = sat_u32(f[0]) << 27 | sat_u32(f[1]) << 22 | fdo_discretize(f[2], 2.0f, 20.0f, nd) << 18;
+    for (int k = 0; k < 3; ++k)
+        h |= fdo_discretize(sinf(f[3 + k]), -1.0f, 1.0f, na) << (15 - 6 * k) | fdo_discretize(cosf(f[3 + k]), -1.0f, 1.0f, na) << (12 - 6 * k);
+    return h;
+}
+/* geometry/tertiary_interaction.rs:21-80; `feature[8] as u32 + 4` saturates negative offsets to 0 first */
+static uint32_t hash_tertiary(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle) {
+    float nd = pick_bins(nbin_dist, 16.0f, 8.0f), na = pick_bins(nbin_angle, 8.0f, 3.0f);
+    uint32_t h = 0;
+    for (int k = 0; k < 7; ++k) h |= fdo_discretize(cosf(f[k]), -1.0f, 1.0f, na) << (26 - 3 * k);
+    uint32_t seq = f[8] < -4.0f ? 0u : (f[8] > 4.0f ? 8u : sat_u32(f[8]) + 4u);
+    return h | fdo_discretize(f[7], 2.0f, 20.0f, nd) << 4 | seq;
+}
+/* geometry/hybrid.rs:20-91 */
+static uint32_t hash_hybrid(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle) {
+    float nd = pick_bins(nbin_dist, 16.0f, 16.0f), na = pick_bins(nbin_angle, 4.0f, 4.0f);
+    uint32_t h = sat_u32(f[0]) << 30 | sat_u32(f[1]) << 28 | fdo_discretize(f[2], 2.0f, 20.0f, nd) << 24 | fdo_discretize(f[3], 2.0f, 20.0f, nd) << 20;
+    for (int k = 0; k < 5; ++k)
+        h |= fdo_discretize(sinf(f[4 + k]), -1.0f, 1.0f, na) << (18 - 4 * k) | fdo_discretize(cosf(f[4 + k]), -1.0f, 1.0f, na) << (16 - 4 * k);
+    return h;
+}
 /* GeometricHash::perfect_hash_as_u32 (geometry/core.rs:213-246): the encoding's own perfect_hash, each count's 0 / cap handled by itself */
 uint32_t fdo_hash_cfg(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle) {
     switch (g_hash_type) {
+    case 2: return hash_trrosetta(f, nbin_dist, nbin_angle);
+    case 4: return hash_ppf(f, nbin_dist, nbin_angle);
+    case 5: return hash_tertiary(f, nbin_dist, nbin_angle);
+    case 6: return hash_hybrid(f, nbin_dist, nbin_angle);
     case 0: return hash_pdbmotif(f, nbin_dist, nbin_angle);
     case 1: return hash_pdbmotif_sincos(f, nbin_dist, nbin_angle);
     case 7: return hash_folddisco(f, nbin_dist, nbin_angle, 0);
@@ -217,6 +320,7 @@ uint32_t fdo_hash_cfg(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle)
  * (controller/feature.rs:216-223, query.rs:72-77) */
 uint32_t fdo_hash_any(const float f[9], uint64_t nbin_dist, uint64_t nbin_angle) {
     if (nbin_dist == 0 || nbin_angle == 0) nbin_dist = nbin_angle = 0;
+    if (g_hash_type == 2 || (g_hash_type >= 4 && g_hash_type <= 6)) return fdo_hash_cfg(f, nbin_dist, nbin_angle);
     switch (g_hash_type) {
     case 0: return hash_pdbmotif(f, nbin_dist, nbin_angle);
     case 1: return hash_pdbmotif_sincos(f, nbin_dist, nbin_angle);
@@ -244,6 +348,29 @@ void fdo_reverse_hash_pdbtr(uint32_t h, float out[7]) {
 int fdo_hash_is_symmetric(uint32_t h) {
     /* pdb_motif.rs:98-102, pdb_motif_sincos.rs:105-109: residue fields equal; folddisco_angle.rs:133-137, folddisco_dist.rs:126-130:
      * residues of the pair equal and the two torsion fields equal (their continuize map is strictly increasing) */
+    if (g_hash_type == 2) {   /* trrosetta.rs:158-162 with reverse_hash_default (3 angle bins): residues, theta1 == theta2, phi1 == phi2 */
+        uint32_t pr = (h >> 23) & 0x1ffu;
+        float a[5];
+        for (int k = 0; k < 5; ++k)
+            a[k] = atan2f(continuize((h >> (18 - 4 * k)) & 3u, -1.0f, 1.0f, 3.0f), continuize((h >> (16 - 4 * k)) & 3u, -1.0f, 1.0f, 3.0f)) *
+                   57.2957795130823208767981548141051703f;
+        return pr / 20u == pr % 20u && a[1] == a[2] && a[3] == a[4];
+    }
+    if (g_hash_type == 4) {   /* ppf.rs:124-127: residues and the first two angles (default 3 bins) */
+        float a[2];
+        for (int k = 0; k < 2; ++k)
+            a[k] = atan2f(continuize((h >> (15 - 6 * k)) & 7u, -1.0f, 1.0f, 3.0f), continuize((h >> (12 - 6 * k)) & 7u, -1.0f, 1.0f, 3.0f)) *
+                   57.2957795130823208767981548141051703f;
+        return ((h >> 27) & 31u) == ((h >> 22) & 31u) && a[0] == a[1];
+    }
+    if (g_hash_type == 5) return 0;   /* tertiary_interaction.rs:145-150 */
+    if (g_hash_type == 6) {   /* hybrid.rs:185-189: residue groups and the two side-chain torsions (4 angle bins) */
+        float a[2];
+        for (int k = 0; k < 2; ++k)
+            a[k] = atan2f(continuize((h >> (14 - 4 * k)) & 3u, -1.0f, 1.0f, 4.0f), continuize((h >> (12 - 4 * k)) & 3u, -1.0f, 1.0f, 4.0f)) *
+                   57.2957795130823208767981548141051703f;
+        return ((h >> 30) & 3u) == ((h >> 28) & 3u) && a[0] == a[1];
+    }
     if (g_hash_type == 0) return ((h >> 20) & 31u) == ((h >> 15) & 31u);
     if (g_hash_type == 1) return ((h >> 21) & 31u) == ((h >> 16) & 31u);
     if (g_hash_type == 7 || g_hash_type == 8) {

@@ -257,7 +257,7 @@ uint64_t fdo_index_get_entries(const fdo_index *ix, uint32_t hash, uint64_t **id
 fdo_index *fdo_build_index(const fdo_structure *const *structs, uint64_t S, uint64_t nbin_dist,
                            uint64_t nbin_angle, float dist_cutoff, uint64_t max_residue, uint64_t *nres,
                            float *plddt) {
-    fdo_index *ix = fdo_index_new(30);
+    fdo_index *ix = fdo_index_new(fdo_get_hash_type() == 3 ? 30 : 32);   /* encoding_bits (geometry/core.rs:79-93); pages are allocated on touch */
     for (int pass = 0; pass < 2; ++pass) {
         for (uint64_t id = 0; id < S; ++id) {
             const fdo_structure *s = structs[id];
@@ -286,7 +286,7 @@ fdo_index *fdo_build_index(const fdo_structure *const *structs, uint64_t S, uint
 }
 
 fdo_index *fdo_build_index_from_lists(const uint32_t *hashes, const uint64_t *off, uint64_t S) {
-    fdo_index *ix = fdo_index_new(30);
+    fdo_index *ix = fdo_index_new(fdo_get_hash_type() == 3 ? 30 : 32);   /* encoding_bits (geometry/core.rs:79-93); pages are allocated on touch */
     for (uint64_t id = 0; id < S; ++id)
         for (uint64_t k = off[id]; k < off[id + 1]; ++k) fdo_index_count_single_entry(ix, hashes[k], id);
     fdo_index_allocate_entries(ix);

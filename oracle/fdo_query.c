@@ -223,8 +223,6 @@ fdo_query_map *fdo_make_query_map(const fdo_structure *qs, const fdo_query_spec 
     const float RADS_PER_DEG = 3.14159274101257324f / 180.0f; /* f32::to_radians */
     float *athr = (float *)malloc((n_angle_thr ? n_angle_thr : 1) * sizeof(float));
     for (uint64_t t = 0; t < n_angle_thr; ++t) athr[t] = angle_thr[t] * RADS_PER_DEG;
-    static const int dist_idx[2] = {2, 3};
-    static const int ang_idx[3] = {4, 5, 6};
 
     float feature[9] = {0}, near[9], far[9];
     uint64_t K = m->n_indices;
@@ -264,8 +262,12 @@ fdo_query_map *fdo_make_query_map(const fdo_structure *qs, const fdo_query_spec 
                 if (cnt > 0) idf = log2f(total_structures / (float)cnt);
             }
             insert_binned_hash(&b, feature, ri, rj, nbin_dist, nbin_angle, 1, idf);
-            /* apply_substitutions (query.rs:86-156), feature = feature_near */
-            if (has_sub[ri]) {
+            /* apply_substitutions (query.rs:86-156), feature = feature_near; only encodings with residue fields
+             * (amino_acid_index, controller/feature.rs:260-267: not TertiaryInteraction / Hybrid) */
+            const uint32_t ht = fdo_get_hash_type();
+            const int has_aa = ht != 5 && ht != 6;
+            if (!has_aa) {
+            } else if (has_sub[ri]) {
                 for (uint64_t a = 0; a < nsub_of[ri]; ++a) {
                     float tmp[9];
                     memcpy(tmp, near, sizeof tmp);
@@ -290,10 +292,19 @@ fdo_query_map *fdo_make_query_map(const fdo_structure *qs, const fdo_query_spec 
                     insert_binned_hash(&b, tmp, ri, rj, nbin_dist, nbin_angle, 0, idf);
                 }
             }
-            expand_and_insert(&b, dist_idx, 2, dist_thr, n_dist_thr, near, far, ri, rj, nbin_dist, nbin_angle, idf);
-            /* angle_index (controller/feature.rs:279-291): theta only for the two PDBMotif forms — PDBMotif's degree-valued theta is
-             * shifted by the threshold in radians, as in the reference */
-            expand_and_insert(&b, ang_idx, fdo_get_hash_type() <= 1 ? 1 : 3, athr, n_angle_thr, near, far, ri, rj, nbin_dist, nbin_angle, idf);
+            /* dist_index / angle_index of the encoding (controller/feature.rs:269-291): theta only for the two PDBMotif forms —
+             * PDBMotif's degree-valued theta is shifted by the threshold in radians, as in the reference */
+            static const int d23[2] = {2, 3}, d2[1] = {2}, d7[1] = {7};
+            static const int a456[3] = {4, 5, 6}, a37[5] = {3, 4, 5, 6, 7}, a345[3] = {3, 4, 5}, a06[7] = {0, 1, 2, 3, 4, 5, 6}, a48[5] = {4, 5, 6, 7, 8};
+            const int *di = d23, *ai = a456;
+            int ndi = 2, nai = 3;
+            if (ht <= 1) nai = 1;
+            else if (ht == 2) { di = d2; ndi = 1; ai = a37; nai = 5; }
+            else if (ht == 4) { di = d2; ndi = 1; ai = a345; nai = 3; }
+            else if (ht == 5) { di = d7; ndi = 1; ai = a06; nai = 7; }
+            else if (ht == 6) { ai = a48; nai = 5; }
+            expand_and_insert(&b, di, ndi, dist_thr, n_dist_thr, near, far, ri, rj, nbin_dist, nbin_angle, idf);
+            expand_and_insert(&b, ai, nai, athr, n_angle_thr, near, far, ri, rj, nbin_dist, nbin_angle, idf);
         }
     }
     free(athr); free(sub_of); free(nsub_of); free(has_sub);

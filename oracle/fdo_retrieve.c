@@ -186,7 +186,9 @@ fdo_retrieval *fdo_retrieve(const fdo_structure *t, const fdo_structure *qs, con
 
     /* prefilter_amino_acid (retrieve.rs:563-602): exact 3-letter name match */
     vec64 set1 = {0}, set2 = {0};
-    if (m->n <= PREFILTER_AA_SKIPPING_SIZE && m->n > 0) {
+    /* TertiaryInteraction / Hybrid hashes carry no residue types: the reference's prefilter unwraps a None there (retrieve.rs:576)
+     * and panics for queries of <= 200 hashes; the restatement scans every pair instead */
+    if (m->n <= PREFILTER_AA_SKIPPING_SIZE && m->n > 0 && fdo_get_hash_type() != 5 && fdo_get_hash_type() != 6) {
         uint8_t seen1[256] = {0}, seen2[256] = {0};
         uint8_t *in1 = (uint8_t *)calloc((size_t)(t->n > 0 ? t->n : 1), 1), *in2 = (uint8_t *)calloc((size_t)(t->n > 0 ? t->n : 1), 1);
         for (uint64_t k = 0; k < m->n; ++k) {
@@ -194,6 +196,8 @@ fdo_retrieval *fdo_retrieve(const fdo_structure *t, const fdo_structure *qs, con
             uint32_t hk = m->hash[k], ht = fdo_get_hash_type();
             uint8_t aa1, aa2;
             if (ht == 0) { aa1 = (uint8_t)((hk >> 20) & 0x1f); aa2 = (uint8_t)((hk >> 15) & 0x1f); }
+            else if (ht == 2) { uint32_t pr = (hk >> 23) & 0x1ff; aa1 = (uint8_t)(pr / 20); aa2 = (uint8_t)(pr % 20); }
+            else if (ht == 4) { aa1 = (uint8_t)((hk >> 27) & 0x1f); aa2 = (uint8_t)((hk >> 22) & 0x1f); }
             else if (ht == 1) { aa1 = (uint8_t)((hk >> 21) & 0x1f); aa2 = (uint8_t)((hk >> 16) & 0x1f); }
             else if (ht == 7 || ht == 8) { uint32_t pr = (hk >> 21) & 0x1ff; aa1 = (uint8_t)(pr / 20); aa2 = (uint8_t)(pr % 20); }
             else { aa1 = (uint8_t)((hk >> 25) & 0x1f); aa2 = (uint8_t)((hk >> 20) & 0x1f); }

@@ -733,3 +733,54 @@ def test_multiple_bins_index_query_and_retrieval(env, htype, bins, tmp_path):
     assert [r[1:] for r in rows] == [fq.format_match_row(m).split("\t")[1:] for m in want] and len(rows) > 0
     with pytest.raises(Exception):
         fd.FolddiscoIndex.build(ctx, batch, multiple_bins=[(16, 0)])
+
+
+@pytest.mark.parametrize("htype,nbd,nba", [(2, 0, 0), (4, 0, 0), (5, 0, 0), (6, 0, 0), (2, 6, 4), (4, 12, 6), (5, 10, 5), (6, 12, 3)])
+def test_own_descriptor_encodings(env, htype, nbd, nba):
+    """§8f rank 3, the encodings with their own pair descriptors — 2 TrRosetta (CB-distance cutoff, five angles), 4 PointPairFeature
+    (orientation-dependent acceptance), 5 TertiaryInteraction and 6 Hybrid (chain-interior residues, neighbouring CA atoms): raw
+    hash lists in the reference's order, index bytes, query map, count records and matches equal the CPU restatement.  For 5 / 6
+    the retrieval prefilter (which panics in the reference for <= 200 query hashes) scans every pair on both sides."""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    ctx, structs, batch, _ix, nres, plddt, tids = env
+    ostructs = [oracle.read_pdb(p) for p in SER]
+    std = np.concatenate([s.resname_std() for s in structs])
+    with oracle.hash_type(htype):
+        h, off = fd.get_geometric_hash_as_u32(ctx, batch, nbin_dist=nbd, nbin_angle=nba, sort_dedup=False, hash_type=htype)
+        for s, ost in enumerate(ostructs):
+            assert np.array_equal(h[int(off[s]):int(off[s + 1])], oracle.hash_structure(ost, nbin_dist=nbd, nbin_angle=nba)), f"structure {s}"
+        ix = fd.FolddiscoIndex.build(ctx, batch, nbin_dist=nbd, nbin_angle=nba, hash_type=htype)
+        oix, onres, _ = oracle.build_index(ostructs, nbin_dist=nbd, nbin_angle=nba)
+        v, hh, o = ix.export()
+        assert np.array_equal(hh, oix.hashes()) and np.array_equal(o, oix.offsets()) and np.array_equal(v, oix.values())
+        pen = fd.length_penalty(onres, 0.5)
+        for qpath, qstr in ((Q4CHA, "B57,B102,C195"), (Q1G2F, "F207:C,F212,F225:HX,F229"), (Q4CHA, "B57,B102,C195,B58,B59")):
+            oq = oracle.read_pdb(qpath)
+            om_ = oracle.make_query_map(oq, qstr, oix, 5.0, dist_thr=(0.5, 1.0), angle_thr=(5.0, 10.0), nbin_dist=nbd, nbin_angle=nba)
+            om = om_.arrays()
+            q = st.read_compact_structure(qpath)
+            res = fq.parse_query_string(qstr, q.chains[0])
+            idx = [q.get_index(c, r) for c, r, _ in res]
+            qb = ctx.upload(fd.PackedStructures.concat([q.as_item()]))
+            m = fq.make_query_map(ctx, qb, idx, [x for _, _, x in res], ix, 5.0, dist_thr=(0.5, 1.0), angle_thr=(5.0, 10.0), nbin_dist=nbd,
+                                  nbin_angle=nba, hash_type=htype)
+            assert np.array_equal(m.hash, om["hash"]) and np.array_equal(m.qi, om["qi"]) and np.array_equal(m.qj, om["qj"])
+            assert np.array_equal(m.is_primary, om["is_primary"]) and np.array_equal(m.idf.view(np.uint32), om["idf"].view(np.uint32))
+            assert np.array_equal(m.aad_aa1, om["aad_aa1"]) and np.array_equal(m.aad_dist.view(np.uint32), om["aad_dist"].view(np.uint32))
+            got = fd.count_query(ctx, ix, m.hash, m.qi, m.qj, pen)
+            ref = oracle.count_query(om_, oix, onres)
+            assert [(r["nid"], r["total_match_count"], r["node_count"], r["edge_count"]) for r in got] == \
+                   [(r["nid"], r["total_match_count"], r["node_count"], r["edge_count"]) for r in ref]
+            for ca_cut in (1.0, 3.0):
+                ms = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=ca_cut, nbin_dist=nbd, nbin_angle=nba,
+                                 hash_type=htype)
+                for nid in range(5):
+                    R = oracle.retrieve(ostructs[nid], oq, om_, ca_distance_cutoff=ca_cut, nbin_dist=nbd, nbin_angle=nba)
+                    mine = [g for g in ms if g["cand"] == nid]
+                    assert len(mine) == len(R["processed"]), (htype, qstr, ca_cut, nid)
+                    for g, rp, rh in zip(mine, R["processed"], R["from_hash"]):
+                        assert g["processed"] == [-1 if x is None else x[2] for x in rp["residues"]]
+                        assert g["from_hash"] == [-1 if x is None else x[2] for x in rh["residues"]]
+                        assert abs(g["rmsd"] - rp["rmsd"]) <= 1e-4 and g["idf"] == pytest.approx(rp["idf"], rel=1e-6)

@@ -355,7 +355,40 @@ def test_other_encodings_bit_layouts():
         assert oracle.hash_any(feat, 40, 12) == (pair << 21 | _disc(14.0, 2, 20, 32) << 16 | _disc(15.9, 2, 20, 32) << 11 | _disc(feat[4], 0, PI, 8) << 8 |
                                                  _disc(feat[5], -PI, PI, 12) << 4 | _disc(feat[6], -PI, PI, 12))
     with pytest.raises(ValueError):
-        with oracle.hash_type(4):
+        with oracle.hash_type(9):
             pass
+    # the encodings with their own descriptors, same independent evaluation; TrRosetta's reference test asserts that the residue
+    # pair of (ALA, ARG, 5.0, -10, 0, 10, 45, 15 degrees) decodes to (0, 1) (geometry/trrosetta.rs:188-207)
+    sc = lambda a, nb: (_disc(np.sin(f32(a), dtype=f32), -1, 1, nb), _disc(np.cos(f32(a), dtype=f32), -1, 1, nb))
+    tr = [0, 1, 5.0, rad(-10.0), rad(0.0), rad(10.0), rad(45.0), rad(15.0)]
+    with oracle.hash_type(2):
+        h = oracle.hash_any(tr)
+        assert ((h >> 23) & 0x1ff) // 20 == 0 and ((h >> 23) & 0x1ff) % 20 == 1
+        want = (0 * 20 + 1) << 23 | _disc(5.0, 2, 20, 8) << 20
+        for k in range(5):
+            s_, c_ = sc(tr[3 + k], 3)
+            want |= s_ << (18 - 4 * k) | c_ << (16 - 4 * k)
+        assert h == want
+    pp = [phe, val, 7.5, rad(40.0), rad(100.0), rad(170.0)]
+    with oracle.hash_type(4):
+        want = phe << 27 | val << 22 | _disc(7.5, 2, 20, 8) << 18
+        for k in range(3):
+            s_, c_ = sc(pp[3 + k], 3)
+            want |= s_ << (15 - 6 * k) | c_ << (12 - 6 * k)
+        assert oracle.hash_any(pp) == want
+    te = [rad(a) for a in (10.0, 50.0, 90.0, 120.0, 150.0, 170.0, 30.0)] + [9.0, -2.0]
+    with oracle.hash_type(5):
+        want = _disc(9.0, 2, 20, 8) << 4 | 4                       # `-2.0 as u32` saturates to 0, + 4
+        for k in range(7):
+            want |= sc(te[k], 3)[1] << (26 - 3 * k)
+        assert oracle.hash_any(te) == want
+        assert oracle.hash_any(te[:8] + [3.0]) & 15 == 7 and oracle.hash_any(te[:8] + [-7.0]) & 15 == 0 and oracle.hash_any(te[:8] + [9.0]) & 15 == 8
+    hy = [1, 3, 14.0, 15.9, rad(116.0), rad(80.0), rad(-100.0), rad(-60.0), rad(135.0)]
+    with oracle.hash_type(6):
+        want = 1 << 30 | 3 << 28 | _disc(14.0, 2, 20, 16) << 24 | _disc(15.9, 2, 20, 16) << 20
+        for k in range(5):
+            s_, c_ = sc(hy[4 + k], 4)
+            want |= s_ << (18 - 4 * k) | c_ << (16 - 4 * k)
+        assert oracle.hash_any(hy) == want
     # the default encoding is untouched by the switch
     assert oracle.hash_any(feat) == oracle.hash_any(feat, 16, 4)
