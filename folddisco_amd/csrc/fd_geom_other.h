@@ -87,6 +87,20 @@ __device__ __forceinline__ bool fd_feature_other(uint32_t type, const fd_batch_v
     return true;
 }
 
+// acceptance alone (the count pass): the same tests as fd_feature_other, bit for bit, without the angles
+__device__ __forceinline__ bool fd_accept_other(uint32_t type, const fd_batch_view &B, uint32_t r0, uint32_t r1, uint32_t i, uint32_t j, float cutoff) {
+    if (type == FD_HASH_TRROSETTA) return B.hash_ok[i] && B.hash_ok[j] && !(fd_dist(fd_load3(B.cb_xyz, i), fd_load3(B.cb_xyz, j)) > cutoff);
+    if (type == FD_HASH_PPF) {
+        if (!B.hash_ok[i] || !B.hash_ok[j]) return false;
+        const fd_v3 ca1 = fd_load3(B.ca_xyz, i);
+        const fd_v3 a = fd_sub(fd_load3(B.cb_xyz, i), ca1), b = fd_sub(fd_load3(B.cb_xyz, j), ca1);
+        return !(fd_norm(fd_sub(b, a)) > cutoff);
+    }
+    if (i == r0 || j == r0 || i + 1 == r1 || j + 1 == r1) return false;
+    if (type == FD_HASH_HYBRID && (!B.hash_ok[i] || !B.hash_ok[j])) return false;
+    return !(fd_dist(fd_load3(B.ca_xyz, i), fd_load3(B.ca_xyz, j)) > cutoff);
+}
+
 // perfect_hash of the four encodings on a feature container; q.dist_disc / q.ang_disc hold the clamped bin counts' factors
 FD_HD uint32_t fd_hash_other(uint32_t type, const float *f, fd_quant q) {
     if (type == FD_HASH_TRROSETTA) {

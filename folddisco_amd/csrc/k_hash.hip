@@ -314,10 +314,9 @@ __global__ __launch_bounds__(FD_WAVE) void k_row_count(fd_batch_view B, fd_hash_
     if (i >= r1) return;
     if (fd_own_descriptor(C.q.type)) {   // the encodings with their own descriptor and acceptance rule (fd_geom_other.h)
         uint32_t cnt = 0;
-        float f[FD_NFEAT];
         if (B.aa[i] != 255)
             for (uint32_t j = r0; j < r1; ++j)
-                cnt += (j != i && B.aa[j] != 255 && fd_feature_other(C.q.type, B, r0, r1, i, j, cutoff, f)) ? 1u : 0u;
+                cnt += (j != i && B.aa[j] != 255 && fd_accept_other(C.q.type, B, r0, r1, i, j, cutoff)) ? 1u : 0u;
         row_cnt[i] = cnt;
         return;
     }
