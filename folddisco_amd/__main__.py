@@ -95,7 +95,7 @@ def cmd_index(a):
         indexio.write_index_files(prefix, v, h, o)
         n_hashes, value_len = len(h), len(v)
     nres, plddt = np.concatenate(nres_all), np.concatenate(plddt_all)
-    indexio.save_lookup(prefix + ".lookup", paths, nres, plddt)
+    indexio.save_lookup(prefix + ".lookup", [indexio.parse_path_by_id_type(x, a.id) for x in paths], nres, plddt)
     indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type], multiple_bins=a.multi)
     if a.verbose:
         print(f"[DONE] {len(paths)} structures, {n_hashes} hashes, {value_len} value bytes -> {prefix}", file=sys.stderr)
@@ -141,7 +141,7 @@ def _cmd_index_sharded(a, fd, indexio, structure, paths, prefix, rank, world):
         shards = [indexio.read_index_files(_shard_prefix(prefix, r, world)) for r in range(world)]
         mv, mh, mo = indexio.merge_subindices(shards)
         indexio.write_index_files(prefix, mv, mh, mo)
-        indexio.save_lookup(prefix + ".lookup", paths, np.concatenate([b[0] for b in box]), np.concatenate([b[1] for b in box]))
+        indexio.save_lookup(prefix + ".lookup", [indexio.parse_path_by_id_type(x, a.id) for x in paths], np.concatenate([b[0] for b in box]), np.concatenate([b[1] for b in box]))
         indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type], multiple_bins=a.multi)
         if a.verbose:
             print(f"[DONE] {len(paths)} structures over {world} ranks, {len(mh)} hashes, {len(mv)} value bytes -> {prefix}", file=sys.stderr)
@@ -200,7 +200,7 @@ def cmd_query(a):
                                         freq_filter=a.freq_filter, length_penalty_power=0.5 if a.length_penalty is None else a.length_penalty,
                                         dist_cutoff=float(cfg.get("grid_width", 20.0)), nbin_dist=int(cfg.get("num_bin_dist", 0)),
                                         nbin_angle=int(cfg.get("num_bin_angle", 0)), hash_type=hash_type_index(cfg.get("hash_type", "PDBTrRosetta")), multiple_bins=cfg.get("multiple_bin"), sampling_ratio=a.sampling_ratio,
-                                        sampling_count=a.sampling_count, sort_by=a.sort_by, partial_fit=a.partial_fit,
+                                        sampling_count=a.sampling_count, sort_by=a.sort_by, partial_fit=a.partial_fit, skip_ca_match=a.skip_ca_match, match_top_n=1000 if a.web else "same",
                                         filters=dict(total_match=a.total_match, covered_node=a.covered_node, covered_node_ratio=a.covered_node_ratio,
                                                      max_node=a.max_node, max_node_ratio=a.max_node_ratio, score=a.score,
                                                      connected_node=a.connected_node, connected_node_ratio=a.connected_node_ratio,
@@ -210,7 +210,7 @@ def cmd_query(a):
         if rank != 0:
             continue                      # every rank holds the same result; rank 0 prints
         fh = open(outp, "w") if outp else sys.stdout
-        if a.skip_match or a.per_structure:
+        if (a.skip_match or a.per_structure) and not a.web:      # QueryMode::from_flags (controller/mode.rs:231-247): web first
             if a.header:
                 fh.write("tid\tidf\ttotal_match_count\tnode_count\tedge_count\tmax_node_cov\tmin_rmsd\tnres\tplddt\tmatching_residues\tdb_key\tquery_residues\n")
             query.sort_rows(rows, query.parse_sort_by(a.sort_by, True))   # StructureSortStrategy (sort.rs:400-458)
@@ -218,7 +218,7 @@ def cmd_query(a):
                 fh.write(query.format_structure_row(r, qstr) + "\n")
         else:
             cols = [c.strip() for c in a.format_output.split(",") if c.strip()] or \
-                (query.MATCH_SUPERPOSE_COLUMNS if a.superpose else ["tid", "node_count", "idf", "rmsd", "matching_residues", "query_residues"])
+                (query.MATCH_SUPERPOSE_COLUMNS if (a.superpose or a.web) else ["tid", "node_count", "idf", "rmsd", "matching_residues", "query_residues"])
             for c in cols:
                 if c not in query.MATCH_COLUMNS:
                     sys.exit(f"[FAIL] unknown --format-output column '{c}' (per-match: {', '.join(query.MATCH_COLUMNS)})")
@@ -248,6 +248,7 @@ def main(argv=None):
     pi.add_argument("-g", "--grid", type=float, default=20.0)          # CA cutoff
     pi.add_argument("-n", "--max-residue", type=int, default=50000)
     pi.add_argument("-r", "--recursive", action="store_true")
+    pi.add_argument("--id", default="relpath")                          # pdb | uniprot | afdb | relpath | abspath | basename ... (build_index.rs:40)
     pi.add_argument("-v", "--verbose", action="store_true")
     pi.add_argument("--device", type=int, default=0)
     pi.add_argument("--chunk", type=int, default=65536, help="structures per GPU build call (sub-indices are merged)")
@@ -261,6 +262,8 @@ def main(argv=None):
     pq.add_argument("--ca-distance", type=float, default=1.0)
     pq.add_argument("--top", type=int, default=None)
     pq.add_argument("--skip-match", action="store_true")
+    pq.add_argument("--skip-ca-match", action="store_true")          # per-match rows before the C-alpha distance check (result.rs:54-69)
+    pq.add_argument("--web", action="store_true")                    # per-match rows with superposition columns, at most 1000 lines (query_pdb.rs:142, 481-493)
     pq.add_argument("--partial-fit", action="store_true")            # LMS superposition for matches of > 3 residues (cli/main.rs:92)
     pq.add_argument("--per-structure", action="store_true")
     pq.add_argument("--per-match", action="store_true")
@@ -322,6 +325,8 @@ def main(argv=None):
             sys.exit("[FAIL] --multiple-bins: one to eight dist-angle pairs with non-zero counts, e.g. 16-4,8-3")
         cmd_index(a)
     else:
+        if a.per_structure and a.per_match:
+            sys.exit("[FAIL] --per-structure and --per-match cannot be combined")     # ContradictoryPrintError
         cmd_query(a)
 
 

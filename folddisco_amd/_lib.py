@@ -96,7 +96,8 @@ class QueryMap(C.Structure):
 
 class MatchRec(C.Structure):
     _fields_ = [("cand", C.c_uint32), ("same", C.c_uint32), ("idf", C.c_float), ("rmsd", C.c_float), ("rmsd_from_hash", C.c_float),
-                ("rot", C.c_float * 9), ("tran", C.c_float * 3), ("metrics", C.c_float * 5)]
+                ("rot", C.c_float * 9), ("tran", C.c_float * 3), ("metrics", C.c_float * 5),
+                ("rot_from_hash", C.c_float * 9), ("tran_from_hash", C.c_float * 3), ("metrics_from_hash", C.c_float * 5)]
 
 
 class Parsed(C.Structure):

@@ -816,7 +816,10 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     for (uint64_t k = 0; k < nprob; ++k) {
         fd_match_rec &r = recs[pend[k].rec];
         const bool is_out = pend[k].which == 1 || r.same;   // the superposition the match reports
-        if (pend[k].which == 0) r.rmsd_from_hash = rmsd[k];
+        if (pend[k].which == 0) {
+            r.rmsd_from_hash = rmsd[k]; memcpy(r.rot_from_hash, &rot[9 * k], 36); memcpy(r.tran_from_hash, &tran[3 * k], 12);
+            fd_similarity_metrics(ky.data() + 3 * koff[k], kx.data() + 3 * koff[k], koff[k + 1] - koff[k], &rot[9 * k], &tran[3 * k], r.metrics_from_hash);
+        }
         if (is_out) {
             r.rmsd = rmsd[k]; memcpy(r.rot, &rot[9 * k], 36); memcpy(r.tran, &tran[3 * k], 12);
             const uint64_t p0 = koff[k], np_ = koff[k + 1] - koff[k];

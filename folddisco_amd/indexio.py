@@ -37,6 +37,36 @@ def format_f32_display(v) -> str:
     return ("-" if neg and out.strip("0.") else "") + out
 
 
+_ID_TYPES = {"Pdb": "pdb", "PDB": "pdb", "pdb": "pdb", "Afdb": "afdb", "AFDB": "afdb", "afdb": "afdb", "Uniprot": "uniprot", "UniProt": "uniprot",
+             "uniprot": "uniprot", "BasenameWithoutExt": "stem", "basename_without_ext": "stem", "basename_no_ext": "stem", "filename": "stem",
+             "BasenameWithExt": "name", "basename_with_ext": "name", "basename": "name", "file": "name", "AbsPath": "abs", "Abspath": "abs",
+             "abspath": "abs", "absolute_path": "abs", "path": "abs", "RelPath": "rel", "Relpath": "rel", "relpath": "rel", "relative_path": "rel",
+             "default": "rel"}
+
+
+def parse_path_by_id_type(path: str, id_type: str) -> str:
+    """--id of the index subcommand: IdType::get_with_str + parse_path_by_id_type (src/controller/mode.rs:18-30, 69-126).
+    file_stem drops only the last extension (x.pdb.gz -> x.pdb), like std::path::Path::file_stem."""
+    import re
+    kind = _ID_TYPES.get(id_type, "other")
+    name = os.path.basename(path.rstrip("/")) if kind != "abs" else ""
+    stem = name[: name.rfind(".")] if name.rfind(".") > 0 else name
+    if kind == "pdb":
+        return stem[3:] if stem.startswith("pdb") else stem
+    if kind in ("afdb", "uniprot"):
+        m = re.search(r"AF-.+-model_v\d", stem)
+        if not m:
+            return stem
+        return m.group(0) if kind == "afdb" else m.group(0).split("-")[1]
+    if kind == "stem":
+        return stem
+    if kind == "name":
+        return name
+    if kind == "abs":
+        return os.path.realpath(path)
+    return path
+
+
 def save_lookup(path: str, tids, nres, plddt, db_keys=None):
     with open(path, "w") as f:
         for i, tid in enumerate(tids):

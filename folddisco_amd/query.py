@@ -176,7 +176,8 @@ def retrieve(ctx: Context, db: Batch, resname_std, cand, qm: QueryMapResult, qba
         out.append(dict(cand=int(r.cand), idf=float(r.idf), rmsd=float(r.rmsd), rmsd_from_hash=float(r.rmsd_from_hash), same=bool(r.same),
                         from_hash=[rp[base + z] for z in range(nq)], processed=[rp[base + nq + z] for z in range(nq)],
                         rot=np.array(list(r.rot), np.float32).reshape(3, 3), tran=np.array(list(r.tran), np.float32),
-                        metrics=np.array(list(r.metrics), np.float32)))
+                        metrics=np.array(list(r.metrics), np.float32), rot_from_hash=np.array(list(r.rot_from_hash), np.float32).reshape(3, 3),
+                        tran_from_hash=np.array(list(r.tran_from_hash), np.float32), metrics_from_hash=np.array(list(r.metrics_from_hash), np.float32)))
     ctx.L.fdgpu_matches_free(mp, rp)
     return out
 
@@ -255,7 +256,8 @@ def sample_query_hashes(index: FolddiscoIndex, q_hash, sampling_ratio=None, samp
 
 
 MATCH_DTYPE = np.dtype([("cand", np.uint32), ("same", np.uint32), ("idf", np.float32), ("rmsd", np.float32), ("rmsd_from_hash", np.float32),
-                        ("rot", np.float32, (9,)), ("tran", np.float32, (3,)), ("metrics", np.float32, (5,))])
+                        ("rot", np.float32, (9,)), ("tran", np.float32, (3,)), ("metrics", np.float32, (5,)),
+                        ("rot_from_hash", np.float32, (9,)), ("tran_from_hash", np.float32, (3,)), ("metrics_from_hash", np.float32, (5,))])
 
 
 def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Batch, q_structs, ca_distance_cutoff=1.0, node_count=2,
@@ -299,7 +301,9 @@ def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Bat
             lst.append(dict(cand=int(r.cand), idf=float(r.idf), rmsd=float(r.rmsd), rmsd_from_hash=float(r.rmsd_from_hash), same=bool(r.same),
                             from_hash=[rp[base + z] for z in range(nq)], processed=[rp[base + nq + z] for z in range(nq)],
                             rot=np.array(list(r.rot), np.float32).reshape(3, 3), tran=np.array(list(r.tran), np.float32),
-                            metrics=np.array(list(r.metrics), np.float32)))
+                            metrics=np.array(list(r.metrics), np.float32), rot_from_hash=np.array(list(r.rot_from_hash), np.float32).reshape(3, 3),
+                            tran_from_hash=np.array(list(r.tran_from_hash), np.float32),
+                            metrics_from_hash=np.array(list(r.metrics_from_hash), np.float32)))
         out.append(lst)
     ctx.L.fdgpu_matches_free(mp, rp)
     ctx.L.fdgpu_free(mo)
@@ -310,7 +314,8 @@ def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Bat
 def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[CompactStructure], tids: list[str], nres, plddt,
               query: CompactStructure, query_string: str, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance=1.0, top_n=None,
               length_penalty_power=0.5, skip_match=False, serial_query=False, freq_filter=None, dist_cutoff=20.0, nbin_dist=0, nbin_angle=0,
-              sampling_ratio=None, sampling_count=None, filters=None, sort_by="", shard=None, partial_fit=False, hash_type=3, multiple_bins=None):
+              sampling_ratio=None, sampling_count=None, filters=None, sort_by="", shard=None, partial_fit=False, hash_type=3, multiple_bins=None,
+              skip_ca_match=False, match_top_n="same"):
     """The per-query body of query_pdb (src/cli/workflows/query_pdb.rs:348-519).  shard = dict(lo=first structure id, device=torch
     device or None): `index`, `db` and `db_structs` then cover only structures [lo, lo + len(db_structs)) of the database that
     tids / nres / plddt describe: idf comes from all-reduced posting lengths, the touched-structure records and the
@@ -395,6 +400,8 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
             t = db_structs[rows[m["cand"]]["nid"] - lo]
             m["labels"] = ["_" if x < 0 else f"{chr(int(t.chain[x]))}{int(t.serial[x])}" for x in m["processed"]]
             m["ca"] = np.array([t.ca_xyz[x] for x in m["processed"] if x >= 0], np.float32).reshape(-1, 3)   # matching C-alpha coordinates
+            m["labels_h"] = ["_" if x < 0 else f"{chr(int(t.chain[x]))}{int(t.serial[x])}" for x in m["from_hash"]]
+            m["ca_h"] = np.array([t.ca_xyz[x] for x in m["from_hash"] if x >= 0], np.float32).reshape(-1, 3)
         if shard is not None:
             import torch.distributed as tdist
             if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
@@ -405,13 +412,18 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
             r = rows[m["cand"]]
             lab = lambda lst: m["labels"]
             r.setdefault("match_strs", []).append(",".join(lab(m["processed"])) + ":%.4f" % m["rmsd"])
-            m2 = dict(tid=r["tid"], nid=r["nid"], node_count=sum(x >= 0 for x in m["processed"]), idf=m["idf"], rmsd=m["rmsd"],
-                      matching_residues=",".join(lab(m["processed"])), query_residues=res_chain_to_string(qres) if qres else query_string,
-                      tm_score=float(m["metrics"][0]), gdt_ts=float(m["metrics"][1]), gdt_ha=float(m["metrics"][2]),
-                      chamfer_distance=float(m["metrics"][3]), hausdorff_distance=float(m["metrics"][4]), db_key=r["nid"],
-                      u_matrix=m["rot"], t_vector=m["tran"], matching_coordinates=m["ca"])
+            # --skip-ca-match: the per-match table shows the from-hash mapping, i.e. before the C-alpha distance rescue
+            # (StructureResult::into_match_query_results, result.rs:54-69); the per-structure columns keep the processed one
+            sk = "_from_hash" if skip_ca_match else ""
+            mres, mlab, mca = (m["from_hash"], m["labels_h"], m["ca_h"]) if skip_ca_match else (m["processed"], m["labels"], m["ca"])
+            mm = m["metrics" + sk]
+            m2 = dict(tid=r["tid"], nid=r["nid"], node_count=sum(x >= 0 for x in mres), idf=m["idf"], rmsd=m["rmsd" + sk],
+                      matching_residues=",".join(mlab), query_residues=res_chain_to_string(qres) if qres else query_string,
+                      tm_score=float(mm[0]), gdt_ts=float(mm[1]), gdt_ha=float(mm[2]),
+                      chamfer_distance=float(mm[3]), hausdorff_distance=float(mm[4]), db_key=r["nid"],
+                      u_matrix=m["rot" + sk], t_vector=m["tran" + sk], matching_coordinates=mca)
             r["matches"].append(m2)
-            cnt = m2["node_count"]
+            cnt = sum(x >= 0 for x in m["processed"])
             if cnt > r["max_matching_node_count"]:
                 r["max_matching_node_count"], r["min_rmsd_with_max_match"] = cnt, m["rmsd"]
             elif cnt == r["max_matching_node_count"] and m["rmsd"] < r["min_rmsd_with_max_match"]:
@@ -440,8 +452,9 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
             return ok
         match_rows = [m for m in match_rows if mfilter(m)]
         sort_rows(match_rows, parse_sort_by(sort_by, False))
-        if top_n is not None:
-            match_rows = match_rows[:top_n]
+        mt = top_n if match_top_n == "same" else match_top_n     # --web prints at most 1000 matches whatever --top says (query_pdb.rs:489)
+        if mt is not None:
+            match_rows = match_rows[:mt]
     return rows, match_rows
 
 

@@ -250,6 +250,7 @@ typedef struct fd_match_rec {   /* one connected component of one candidate (ret
     float rmsd_from_hash;
     float rot[9], tran[3];      /* target -> query superposition of the processed mapping */
     float metrics[5];           /* tm_score, gdt_ts, gdt_ha, chamfer, hausdorff of that superposition (structure/metrics.rs) */
+    float rot_from_hash[9], tran_from_hash[3], metrics_from_hash[5];   /* the same for the from-hash mapping (--skip-ca-match prints it) */
 } fd_match_rec;
 /* residues: 2 * n_indices int32 per match — target residue index (relative to its structure, -1 = "_") for
  * every query residue, first the from-hash mapping then the processed (rescued) one. Release both with

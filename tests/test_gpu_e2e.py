@@ -317,6 +317,22 @@ def test_cli_filters_sort_and_sampling(tmp_path):
     assert len(base) == 6
     # --partial-fit: matches of at most 3 residues keep the Kabsch superposition (retrieve.rs:735-740)
     assert q("--partial-fit") == base
+    # --skip-ca-match: the from-hash mapping of every match (result.rs:54-69): same rows here except where the rescue added a residue
+    sk = q("--skip-ca-match", "--ca-distance", "1.5")
+    pr = q("--ca-distance", "1.5")
+    assert len(sk) == len(pr) and sorted(r.split("\t")[0] for r in sk) == sorted(r.split("\t")[0] for r in pr)
+    assert all(r.split("\t")[4].count("_") >= p_.split("\t")[4].count("_") for r, p_ in zip(sorted(sk), sorted(pr)))
+    # --web: per-match rows with the superposition columns (query_pdb.rs:481-493), whatever --per-structure says
+    web = q("--web", "--per-structure", "--header")
+    assert web[0].split("\t")[:6] == ["tid", "node_count", "idf", "rmsd", "matching_residues", "u_matrix"] and len(web) == 7
+    assert [r.split("\t")[:5] for r in web[1:]] == [b.split("\t")[:5] for b in base]
+    bad = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", pre, "--per-structure", "--per-match"],
+                         cwd=tmp_path, env=env, capture_output=True, text=True)
+    assert bad.returncode != 0
+    # index --id: the lookup ids (controller/mode.rs:69-126)
+    pre_id = str(tmp_path / "serine_ids")
+    subprocess.check_call([sys.executable, "-m", "folddisco_amd", "index", "-p", "data/serine_peptidases", "-i", pre_id, "--id", "pdb"], cwd=tmp_path, env=env)
+    assert [l.split("\t")[1] for l in open(pre_id + ".lookup")] == sorted(os.path.basename(p)[:-4] for p in SER)
     # MatchFilter: connected node count / ratio, rmsd, idf score
     assert q("--connected-node", "3") == base[:3]
     assert q("--connected-node-ratio", "0.9") == base[:3]

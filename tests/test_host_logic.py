@@ -324,3 +324,14 @@ def test_analyze_summary_files(tmp_path):
         assert (int(v[0]), int(v[1])) == (13, 19) and abs(v[2] - 14.0) <= 18.0 / (dd - 1) / 2 + 1e-4 and abs(v[3] - 15.9) <= 18.0 / (dd - 1) / 2 + 1e-4
     with pytest.raises(SystemExit):
         cli(["analyze", "-i", prefix, "-p", "somewhere"])
+
+
+def test_index_id_types():
+    """--id of the index subcommand: IdType::get_with_str + parse_path_by_id_type (src/controller/mode.rs:18-30, 69-126)"""
+    from folddisco_amd.indexio import parse_path_by_id_type as f
+    assert f("data/x/pdb1abc.ent", "pdb") == "1abc" and f("d/1abc.pdb", "PDB") == "1abc"
+    assert f("d/AF-P12345-F1-model_v4.pdb", "afdb") == "AF-P12345-F1-model_v4" and f("d/AF-P12345-F1-model_v4.pdb", "uniprot") == "P12345"
+    assert f("d/zzz.pdb", "afdb") == "zzz" and f("d/zzz.pdb", "uniprot") == "zzz"
+    assert f("d/a.pdb.gz", "filename") == "a.pdb" and f("d/a.pdb.gz", "basename") == "a.pdb.gz"
+    assert f("d/a.pdb", "relpath") == "d/a.pdb" and f("d/a.pdb", "default") == "d/a.pdb" and f("d/a.pdb", "whatever") == "d/a.pdb"
+    assert f("tests/helpers.py", "abspath") == os.path.realpath("tests/helpers.py")
