@@ -79,7 +79,7 @@ typedef struct fd_hash_params {
     uint32_t nbin_dist;
     uint32_t nbin_angle;
     float dist_cutoff;         /* CA-CA cutoff in Angstrom (strict >, src/structure/core.rs:391) */
-    uint32_t hash_type;        /* FDGPU_HASH_* */
+    uint32_t hash_type;        /* FDGPU_HASH_*; NOTE 0 is PDBMotif, as in the reference's numbering: set FDGPU_HASH_PDBTR (3) for the default encoding */
     /* --multiple-bins d1-a1,d2-a2,... (src/cli/workflows/build_index.rs:45,149-153): every residue pair is hashed once per
      * (dist, angle) bin pair and all the hashes share one index (controller/feature.rs:211-215); queries insert every
      * expansion under every bin pair (controller/query.rs:59-70) and retrieval reports a found triple per matching bin pair
