@@ -523,7 +523,9 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     for (uint64_t t = 0; t < n_queries; ++t) max_aad = std::max<uint64_t>(max_aad, qms[t]->n_aad);
     const char *tp_env = getenv("FDGPU_TWO_PASS");     // 1 / 0 force the choice (tests)
     const bool two_pass = tp_env ? tp_env[0] == '1' : max_aad > 4096;
-    int rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc, two_pass ? 1u : 7u);
+    uint32_t *pk_key = nullptr, *pk_val = nullptr;      // packed, device-sorted candidate pairs (see fd_match_pairs_multi, mode bit 3)
+    int rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc, two_pass ? 1u : 15u,
+                                  nullptr, nullptr, 0, &pk_key, &pk_val);
     if (rc) return rc;
     auto T1 = t_now();
     // symmetry flags (geometry/pdb_tr.rs:158-162): aa equal and atan2(sin, cos) of the two torsion fields equal; the other encodings
@@ -600,6 +602,10 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     bool any_rescue = false;
     // plan = true: components and mappings only, marking the mapped residues of every component that leaves a query residue
     // unmatched (first pass of a large query); plan = false: the full body
+    // two-scan retrievals build the components and from-hash mappings once (plan pass) and reuse them in the full pass
+    struct CompPlan { std::vector<uint32_t> q_idx, r_idx; float sub_idf; };
+    std::vector<std::vector<CompPlan>> plan_cache(two_pass ? n_cand : 0);
+    std::vector<char> plan_have(two_pass ? n_cand : 0, 0);
     auto run_slots = [&](const bool plan) {
     size_t fpos = 0, cpos = 0;
     uint64_t tq = 0;
@@ -612,15 +618,26 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         const float *q_ca = qb_ca.data() + 3 * qb->h_res_off[q_struct[tq]], *q_cb = qb_cb.data() + 3 * qb->h_res_off[q_struct[tq]];
         size_t f0 = fpos, c0 = cpos;
         while (fpos < nf && found[fpos].cand == slot) ++fpos;
-        while (cpos < nc && cands[cpos].cand == slot) ++cpos;
+        if (pk_key) while (cpos < nc && (pk_key[cpos] >> 16) == slot) ++cpos;
+        else while (cpos < nc && cands[cpos].cand == slot) ++cpos;
         if (fpos == f0) continue;
+        const bool cached = !plan && two_pass && plan_have[slot];
         Graph g;
-        for (size_t e = f0; e < fpos; ++e) {
-            uint32_t a = g.node_of(found[e].i), b = g.node_of(found[e].j);
-            g.es.push_back(a); g.et.push_back(b); g.eh.push_back(found[e].hash);
+        std::vector<std::vector<uint32_t>> comps;
+        std::vector<int32_t> edge_k;
+        if (!cached) {
+            for (size_t e = f0; e < fpos; ++e) {
+                uint32_t a = g.node_of(found[e].i), b = g.node_of(found[e].j);
+                g.es.push_back(a); g.et.push_back(b); g.eh.push_back(found[e].hash);
+            }
+            comps = components(g, node_count);
+            // query-map entry of every found edge, looked up once per candidate (a whole-structure query has ~10^5 entries and
+            // thousands of edges per candidate; every component walks the edge list)
+            edge_k.resize(g.es.size());
+            for (size_t e = 0; e < g.es.size(); ++e) { auto it = entry.find(g.eh[e]); edge_k[e] = it == entry.end() ? -1 : (int32_t)it->second; }
         }
-        auto comps = components(g, node_count);
-        if (comps.empty()) continue;
+        const size_t n_comps = cached ? plan_cache[slot].size() : comps.size();
+        if (n_comps == 0) continue;
         const uint32_t s = cand[slot];
         (void)s;
         const float *t_ca = t_all.data() + 3 * g_dst[slot], *t_cb = t_all.data() + 3 * g_total + 3 * g_dst[slot];
@@ -630,8 +647,12 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         // buckets of its mapped residues instead of one over every pair per query residue (whole-structure queries: millions)
         const bool have_c = cpos > c0;
         auto c_ok = [&](const fd_cand_rec &r) { return r.qi < q_size && r.i < Rt && r.j < Rt; };
-        std::vector<uint32_t> by_cj_off(have_c ? Rt + 2 : 2, 0), by_cj_qi(have_c ? cpos - c0 : 0), by_cj_i(have_c ? cpos - c0 : 0);
-        if (have_c) {
+        const bool pk = pk_key != nullptr;
+        std::vector<uint32_t> by_cj_off(have_c ? Rt + 2 : 2, 0), by_cj_qi(have_c && !pk ? cpos - c0 : 0), by_cj_i(have_c && !pk ? cpos - c0 : 0);
+        if (have_c && pk) {   // already sorted by partner residue on the device: the bucket of j is a slice of the packed arrays
+            for (size_t e = c0; e < cpos; ++e) { const uint32_t j = pk_key[e] & 0xffffu; if (j < Rt) ++by_cj_off[j + 1]; }
+            for (uint32_t z = 0; z <= Rt; ++z) by_cj_off[z + 1] += by_cj_off[z];
+        } else if (have_c) {
             for (size_t e = c0; e < cpos; ++e) if (c_ok(cands[e])) ++by_cj_off[cands[e].j + 1];
             for (uint32_t z = 0; z <= Rt; ++z) by_cj_off[z + 1] += by_cj_off[z];
             std::vector<uint32_t> cur(by_cj_off.begin(), by_cj_off.end() - 1);
@@ -639,10 +660,15 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         }
         std::vector<uint32_t> votes2(have_c ? (size_t)q_size * Rt : 0, 0), v_touched, q_touched;
         std::vector<uint32_t> r_mx(q_size, 0), r_nmx(q_size, 0), r_arg(q_size, 0);
-        for (auto &cc : comps) {
+        if (plan && two_pass) { plan_cache[slot].resize(n_comps); plan_have[slot] = 1; }
+        for (size_t ci = 0; ci < n_comps; ++ci) {
+            float sub_idf = 0.0f;
+            std::vector<uint32_t> q_idx, r_idx;
+            if (cached) { q_idx = plan_cache[slot][ci].q_idx; r_idx = plan_cache[slot][ci].r_idx; sub_idf = plan_cache[slot][ci].sub_idf; }
+            else {
+            const std::vector<uint32_t> &cc = comps[ci];
             std::vector<char> inc(g.w.size(), 0);
             for (uint32_t v : cc) inc[v] = 1;
-            float sub_idf = 0.0f;
             // votes (query residue, target residue) -> saturating u8 count (retrieve.rs:631-666).  Sparse: a component has a
             // handful of edges, the dense q_size x r_size table of the reference is ~1 MB per component for a motif taken
             // from a long chain.  best_c[q] = max count, best_r[q] = smallest target residue holding it (what the
@@ -651,10 +677,8 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             std::vector<Vote> votes;
             std::unordered_map<uint64_t, uint32_t> vote_at;     // (q, r) -> position in votes (first-seen order kept in the vector)
             for (size_t e = 0; e < g.es.size(); ++e) {
-                if (!inc[g.es[e]] || !inc[g.et[e]]) continue;
-                auto it = entry.find(g.eh[e]);
-                if (it == entry.end()) continue;
-                uint32_t k = it->second;
+                if (!inc[g.es[e]] || !inc[g.et[e]] || edge_k[e] < 0) continue;
+                const uint32_t k = (uint32_t)edge_k[e];
                 sub_idf += qm->idf[k];                      // calculate_subgraph_idf (retrieve.rs:705-719)
                 uint32_t qi = qm->qi[k], qj = qm->qj[k], ri = g.w[g.es[e]], rj = g.w[g.et[e]];
                 uint32_t pq[2], pr[2];
@@ -677,13 +701,14 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             }
             // greedy assignment in (count descending, query residue ascending) order (retrieve.rs:668-690)
             std::sort(best.begin(), best.end(), [](const Best &x, const Best &y) { return x.c != y.c ? x.c > y.c : x.q < y.q; });
-            std::vector<uint32_t> q_idx, r_idx;
             for (auto &x : best) {
                 if (q_idx.size() == cc.size()) break;
                 if (std::find(r_idx.begin(), r_idx.end(), x.r) != r_idx.end()) continue;
                 q_idx.push_back(x.q); r_idx.push_back(x.r);
             }
-            if (plan) {   // a query residue without a target leaves work for the rescue: its votes come from pairs whose partner is mapped
+            }
+            if (plan) {
+                if (two_pass) { plan_cache[slot][ci].q_idx = q_idx; plan_cache[slot][ci].r_idx = r_idx; plan_cache[slot][ci].sub_idf = sub_idf; }   // a query residue without a target leaves work for the rescue: its votes come from pairs whose partner is mapped
                 bool unmatched = false;
                 for (uint64_t pos = 0; pos < NQ && !unmatched; ++pos) unmatched = std::find(q_idx.begin(), q_idx.end(), qm->indices[pos]) == q_idx.end();
                 if (unmatched) {
@@ -697,7 +722,9 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
                 for (uint32_t r : r_idx) {
                     if (r >= Rt) continue;
                     for (uint32_t z = by_cj_off[r]; z < by_cj_off[r + 1]; ++z) {
-                        const uint32_t ix2 = by_cj_qi[z] * Rt + by_cj_i[z];
+                        const uint32_t vq = pk ? pk_val[c0 + z] >> 16 : by_cj_qi[z], vi = pk ? pk_val[c0 + z] & 0xffffu : by_cj_i[z];
+                        if (vq >= q_size || vi >= Rt) continue;
+                        const uint32_t ix2 = vq * Rt + vi;
                         if (votes2[ix2]++ == 0) v_touched.push_back(ix2);
                     }
                 }
@@ -766,14 +793,14 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         free(cands); cands = nullptr; nc = 0;
         if (any_rescue) {
             fd_pair_rec *f2 = nullptr; uint64_t nf2 = 0;
-            rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &f2, &nf2, &cands, &nc, 6u, cj_mask.data(),
-                                      mask_off.data(), cj_mask.size());
+            rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &f2, &nf2, &cands, &nc, 14u, cj_mask.data(),
+                                      mask_off.data(), cj_mask.size(), &pk_key, &pk_val);
             free(f2);
             if (rc) { free(found); return rc; }
             if (trace) fprintf(stderr, "[fdgpu_retrieve] second scan done at %.3f ms (cands %llu)\n", t_ms(T2, t_now()), (unsigned long long)nc);
         }
     }
-    if (nc) {   // candidate pairs arrive in atomic-append order: group them by candidate slot (counting sort; order inside a slot is free)
+    if (nc && !pk_key) {   // unpacked fallback (>= 2^16 candidate slots): atomic-append order -> grouped by candidate slot (counting sort)
         std::vector<uint64_t> so(n_cand + 2, 0);
         for (uint64_t e = 0; e < nc; ++e) ++so[cands[e].cand + 1];
         for (uint64_t k = 0; k < n_cand; ++k) so[k + 1] += so[k];
@@ -784,7 +811,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     }
     run_slots(false);
     if (trace) fprintf(stderr, "[fdgpu_retrieve] slots done at %.3f ms\n", t_ms(T2, t_now()));
-    free(found); free(cands);
+    free(found); free(cands); free(pk_key); free(pk_val);
     const uint64_t nprob = pend.size();
     std::vector<float> rmsd(std::max<uint64_t>(nprob, 1)), rot(std::max<uint64_t>(nprob, 1) * 9), tran(std::max<uint64_t>(nprob, 1) * 3);
     auto T3 = t_now();

@@ -906,7 +906,7 @@ extern "C" int fdgpu_count_query_batch_top(fdgpu_ctx *c, const fdgpu_index *ix, 
 int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
                          const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
                          fd_cand_rec **cands, uint64_t *n_cands, uint32_t mode, const uint32_t *cj_mask, const uint32_t *mask_off,
-                         uint64_t mask_words) {
+                         uint64_t mask_words, uint32_t **pk_key, uint32_t **pk_val) {
     if (!c || !db || !p || !found || !n_found || !cands || !n_cands || !cand_off || (n_queries && !qs)) return FDGPU_EINVAL;
     const uint64_t n_cand = cand_off[n_queries];
     if (n_cand && !cand) return FDGPU_EINVAL;
@@ -1017,6 +1017,42 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         HIPCHK(c, hipStreamSynchronize(st));
         if (tot[0] <= A.cap_found && tot[1] <= A.cap_cands) break;
         if (attempt == 2) FAIL(c, FDGPU_ERANGE, "match_pairs: output did not fit after regrowing");
+    }
+    // mode bit 3 (with pk_key / pk_val): the candidate pairs come back packed — key = slot << 16 | partner residue j, value =
+    // query residue << 16 | residue i — and sorted by key on the device: half the bytes over PCIe and no bucketing on the host
+    // (the rescue walks the pairs of one partner residue at a time).  Needs slots, residues and query residues below 2^16.
+    const bool packed = (mode & 8u) && pk_key && pk_val && n_cand < 65536;
+    if (pk_key) *pk_key = nullptr;
+    if (pk_val) *pk_val = nullptr;
+    if (packed) {
+        const uint64_t n = tot[1];
+        uint32_t *hk = (uint32_t *)malloc(std::max<uint64_t>(n, 1) * 4), *hv = (uint32_t *)malloc(std::max<uint64_t>(n, 1) * 4);
+        fd_pair_rec *hf2 = (fd_pair_rec *)malloc(std::max<uint64_t>(tot[0], 1) * sizeof(fd_pair_rec));
+        if (!hk || !hv || !hf2) { free(hk); free(hv); free(hf2); return FDGPU_ENOMEM; }
+        if (n) {
+            HIPCHK(c, c->ws[WS_MISC2].ensure(n * 4)); HIPCHK(c, c->ws[WS_MISC3].ensure(n * 4));
+            HIPCHK(c, c->ws[WS_MISC4].ensure(n * 4)); HIPCHK(c, c->ws[WS_MISC5].ensure(n * 4));
+            HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * std::max<uint32_t>(fd_rs_num_tiles(n), 1) * 4));
+            HIPCHK(c, c->ws[WS_TOT].ensure((256 + (size_t)(fd_rs_num_tiles(n) / 128 + 2) * 256) * 8));
+            uint32_t *ka = c->ws[WS_MISC2].as<uint32_t>(), *va = c->ws[WS_MISC3].as<uint32_t>(), *kb = c->ws[WS_MISC4].as<uint32_t>(),
+                     *vb = c->ws[WS_MISC5].as<uint32_t>();
+            fd_launch_pack_cands(A.cands, n, ka, va, st);
+            int bits = 17;
+            while (bits < 32 && (1ull << (bits - 16)) < std::max<uint64_t>(n_cand, 2)) ++bits;
+            const int cur = sort_pairs(c, ka, va, kb, vb, n, bits);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(hk, cur ? kb : ka, n * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipMemcpyAsync(hv, cur ? vb : va, n * 4, hipMemcpyDeviceToHost, st));
+        }
+        if (tot[0]) HIPCHK(c, hipMemcpyAsync(hf2, A.found, tot[0] * sizeof(fd_pair_rec), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        std::stable_sort(hf2, hf2 + tot[0], [](const fd_pair_rec &a, const fd_pair_rec &b) {
+            if (a.cand != b.cand) return a.cand < b.cand;
+            if (a.i != b.i) return a.i < b.i;
+            return a.j < b.j;
+        });
+        *found = hf2; *n_found = tot[0]; *cands = nullptr; *n_cands = n; *pk_key = hk; *pk_val = hv;
+        return FDGPU_OK;
     }
     fd_pair_rec *hf = (fd_pair_rec *)malloc(std::max<uint64_t>(tot[0], 1) * sizeof(fd_pair_rec));
     fd_cand_rec *hc = (fd_cand_rec *)malloc(std::max<uint64_t>(tot[1], 1) * sizeof(fd_cand_rec));

@@ -205,6 +205,7 @@ struct mp_args {
     const uint32_t *mask_off;      // [n_cand] first bit of every candidate slot
 };
 void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st);
+void fd_launch_pack_cands(const fd_cand_rec *c, uint64_t n, uint32_t *key, uint32_t *val, hipStream_t st);
 void fd_launch_kabsch(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, hipStream_t st);
 void fd_launch_lms_qcp(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, uint32_t *core_len,
                        uint8_t *flags, uint32_t *order, hipStream_t st);
@@ -219,4 +220,4 @@ void fd_launch_get_entries(const uint32_t *hashes, const uint64_t *offsets, cons
 int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
                          const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
                          fd_cand_rec **cands, uint64_t *n_cands, uint32_t mode = 3, const uint32_t *cj_mask = nullptr,
-                         const uint32_t *mask_off = nullptr, uint64_t mask_words = 0);
+                         const uint32_t *mask_off = nullptr, uint64_t mask_words = 0, uint32_t **pk_key = nullptr, uint32_t **pk_val = nullptr);

@@ -229,6 +229,17 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     }
 }
 
+// candidate pairs -> (slot << 16 | j, qi << 16 | i): 8 bytes instead of 16 for the copy back, and sortable by (slot, partner residue)
+__global__ void k_pack_cands(const fd_cand_rec *__restrict__ c, uint64_t n, uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const fd_cand_rec r = c[k];
+    key[k] = (r.cand << 16) | (r.j & 0xffffu);
+    val[k] = (r.qi << 16) | (r.i & 0xffffu);
+}
+void fd_launch_pack_cands(const fd_cand_rec *c, uint64_t n, uint32_t *key, uint32_t *val, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_pack_cands, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, n, key, val);
+}
 void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st) {
     if (!A.n_work) return;
     if (emit) hipLaunchKernelGGL(k_match_pairs<true>, dim3(A.n_work), dim3(FD_WAVE), 0, st, A);
