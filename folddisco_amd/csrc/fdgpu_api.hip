@@ -1021,7 +1021,9 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     // mode bit 3 (with pk_key / pk_val): the candidate pairs come back packed — key = slot << 16 | partner residue j, value =
     // query residue << 16 | residue i — and sorted by key on the device: half the bytes over PCIe and no bucketing on the host
     // (the rescue walks the pairs of one partner residue at a time).  Needs slots, residues and query residues below 2^16.
-    const bool packed = (mode & 8u) && pk_key && pk_val && n_cand < 65536;
+    const char *pm_env = getenv("FDGPU_PACK_MIN");      // tests force the packed form on small inputs
+    const uint64_t pack_min = pm_env ? strtoull(pm_env, nullptr, 10) : (1ull << 18);   // a motif query's few thousand pairs are cheaper as they are
+    const bool packed = (mode & 8u) && pk_key && pk_val && n_cand < 65536 && tot[1] >= pack_min;
     if (pk_key) *pk_key = nullptr;
     if (pk_val) *pk_val = nullptr;
     if (packed) {

@@ -668,7 +668,10 @@ def test_two_pass_retrieval_equals_single_pass(env, monkeypatch):
         for mode in ("0", "1"):
             monkeypatch.setenv("FDGPU_TWO_PASS", mode)
             out[mode] = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=ca_cut)
-        same(out["0"], out["1"])
+            monkeypatch.setenv("FDGPU_PACK_MIN", "0")      # candidate pairs packed and sorted on the device (the large-query form)
+            out[mode + "p"] = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=ca_cut)
+            monkeypatch.delenv("FDGPU_PACK_MIN")
+        same(out["0"], out["1"]); same(out["0"], out["0p"]); same(out["0"], out["1p"])
         n_rescued += sum(1 for g in out["1"] if not g["same"])
     assert n_rescued > 0          # the rescue path ran
     # whole-structure queries on a synthetic shard
@@ -684,7 +687,10 @@ def test_two_pass_retrieval_equals_single_pass(env, monkeypatch):
         for mode in ("0", "1"):
             monkeypatch.setenv("FDGPU_TWO_PASS", mode)
             out[mode] = fq.retrieve(ctx, sb, None, np.arange(S, dtype=np.uint32), m, qb2, ca_distance_cutoff=1.5)
-        same(out["0"], out["1"])
+            monkeypatch.setenv("FDGPU_PACK_MIN", "0")
+            out[mode + "p"] = fq.retrieve(ctx, sb, None, np.arange(S, dtype=np.uint32), m, qb2, ca_distance_cutoff=1.5)
+            monkeypatch.delenv("FDGPU_PACK_MIN")
+        same(out["0"], out["1"]); same(out["0"], out["0p"]); same(out["0"], out["1p"])
         assert any(g["cand"] == s for g in out["1"])
     monkeypatch.delenv("FDGPU_TWO_PASS")
 
