@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <map>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 #include "fdgpu_internal.h"
 #include <chrono>
@@ -325,12 +326,12 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         std::vector<uint32_t> mh, mqi, mqj, mph;
         std::vector<uint8_t> mp;
         std::vector<float> mi;
-        std::map<uint32_t, char> have;
+        std::unordered_set<uint32_t> have;
+        have.reserve((size_t)(cand_off[t + 1] - cand_off[t]) / 4 + 16);
         for (uint64_t z = cand_off[t]; z < cand_off[t + 1]; ++z) {
             for (uint32_t k = 0; k < std::max(n_cfg, 1u); ++k) {
                 const uint32_t hz = n_cfg ? mh_cfg[k][z] : hashes[z];
-                if (have.count(hz)) continue;
-                have[hz] = 1;
+                if (!have.insert(hz).second) continue;
                 mh.push_back(hz); mqi.push_back(cands[z].qi); mqj.push_back(cands[z].qj); mp.push_back(cands[z].primary);
                 mi.push_back(pair_idf[cands[z].pair]); mph.push_back(pair_primary[cands[z].pair]);
             }
@@ -496,7 +497,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto T0 = t_now();
     // per query: sorted unique hashes + lookup hash -> query map entry
-    std::vector<std::map<uint32_t, uint32_t>> entries(n_queries);
+    std::vector<std::unordered_map<uint32_t, uint32_t>> entries(n_queries);
     std::vector<std::vector<uint32_t>> qhs(n_queries);
     std::vector<fd_match_query> mqs(std::max<uint64_t>(n_queries, 1));
     std::vector<uint32_t> q_sizes(std::max<uint64_t>(n_queries, 1), 1);
@@ -506,7 +507,9 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             entries[t].emplace(m->hash[k], (uint32_t)k);
             q_sizes[t] = std::max(q_sizes[t], std::max(m->qi[k], m->qj[k]) + 1);
         }
+        qhs[t].reserve(entries[t].size());
         for (auto &kv : entries[t]) qhs[t].push_back(kv.first);
+        std::sort(qhs[t].begin(), qhs[t].end());
         fd_match_query &q = mqs[t];
         q.hashes = qhs[t].data(); q.n_hashes = qhs[t].size();
         q.aad_aa1 = m->aad_aa1; q.aad_aa2 = m->aad_aa2; q.aad_dist = m->aad_dist; q.aad_qi = m->aad_qi; q.n_aad = m->n_aad;
@@ -612,7 +615,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     for (uint64_t slot = 0; slot < n_cand; ++slot) {
         while (slot >= cand_off[tq + 1]) { ++tq; m_off[tq] = recs.size(); r_off[tq] = res.size(); }
         const fd_query_map *qm = qms[tq];
-        const std::map<uint32_t, uint32_t> &entry = entries[tq];
+        const std::unordered_map<uint32_t, uint32_t> &entry = entries[tq];
         const uint32_t q_size = q_sizes[tq];
         const uint64_t NQ = qm->n_indices;
         const float *q_ca = qb_ca.data() + 3 * qb->h_res_off[q_struct[tq]], *q_cb = qb_cb.data() + 3 * qb->h_res_off[q_struct[tq]];
