@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include "fdgpu_internal.h"
 
 #define HIPCHK(ctx, expr)                                                                                   \
@@ -1094,6 +1095,9 @@ extern "C" int fdgpu_kabsch_batch(fdgpu_ctx *c, const float *x, const float *y, 
     if (!n) return FDGPU_OK;
     hipStream_t st = c->stream;
     uint64_t npts = off[n];
+    const bool tr = getenv("FDGPU_TRACE") != nullptr;
+    auto k0 = std::chrono::steady_clock::now();
+    if (tr) { (void)hipStreamSynchronize(st); fprintf(stderr, "[kabsch] entry sync %.3f ms, %llu problems, %llu points\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - k0).count(), (unsigned long long)n, (unsigned long long)npts); }
     HIPCHK(c, c->ws[WS_MISC0].ensure(std::max<uint64_t>(npts, 1) * 12));
     HIPCHK(c, c->ws[WS_MISC1].ensure(std::max<uint64_t>(npts, 1) * 12));
     HIPCHK(c, c->ws[WS_MISC2].ensure((n + 1) * 8));
@@ -1112,6 +1116,7 @@ extern "C" int fdgpu_kabsch_batch(fdgpu_ctx *c, const float *x, const float *y, 
     HIPCHK(c, hipMemcpyAsync(rot, c->ws[WS_MISC4].p, n * 36, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(tran, c->ws[WS_MISC5].p, n * 12, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    if (tr) fprintf(stderr, "[kabsch] total %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - k0).count());
     return FDGPU_OK;
 }
 

@@ -250,23 +250,34 @@ void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st) {
 // One lane per superposition problem (2..16 points each): the closed-form eigen solve is ~300 f64
 // operations, so a batch of thousands of matches is one short launch.  f64 like the reference;
 // results are rounded to f32 exactly where the reference rounds (kabsch.rs:537-553).
+// WAVE = true: one wavefront per problem for the large ones (whole-structure matches superpose hundreds of points; a single lane
+// walking them is latency-bound): the two passes over the points are strided over the lanes and reduced with shuffles (f64 sums in
+// tree order, within the 1e-4 RMSD tolerance), the 3x3 eigen solve runs uniformly.  Problems below KB_WAVE_MIN points keep one lane each.
+#define KB_WAVE_MIN 128
+__device__ __forceinline__ double kb_wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <bool WAVE>
 __global__ __launch_bounds__(64) void k_kabsch(const float *__restrict__ xs, const float *__restrict__ ys, const uint64_t *__restrict__ off,
                                                uint64_t n_prob, float *__restrict__ rmsd_out, float *__restrict__ rot_out,
                                                float *__restrict__ tran_out) {
-    uint64_t pidx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t pidx = WAVE ? (uint64_t)blockIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pidx >= n_prob) return;
+    const uint32_t kb_lane = threadIdx.x;
     const int IP[9] = {0, 1, 3, 1, 2, 4, 3, 4, 5};
     const int IP2312[4] = {1, 2, 0, 1};
     const double EPSILON = 1.0e-8, TOLERANCE = 0.01, SQRT3 = 1.7320508075688772;
     const uint64_t p0 = off[pidx], p1 = off[pidx + 1];
     const uint64_t n = p1 - p0;
+    if (WAVE ? n < KB_WAVE_MIN : n >= KB_WAVE_MIN) return;
     const float *xf = xs + 3 * p0, *yf = ys + 3 * p0;
     double u[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, t[3] = {0, 0, 0};
     float rf = 3.40282347e+38f;
     if (n > 0) {
         double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0}, sx[3] = {0, 0, 0}, sy[3] = {0, 0, 0}, sz[3] = {0, 0, 0}, xc[3], yc[3], e[3];
         double r[3][3], a[3][3] = {{0}}, b[3][3] = {{0}}, rr[6], ss[6];
-        for (uint64_t i = 0; i < n; ++i) {
+        for (uint64_t i = WAVE ? kb_lane : 0; i < n; i += WAVE ? 64 : 1) {
             double c1[3] = {xf[3 * i], xf[3 * i + 1], xf[3 * i + 2]};
             double c2[3] = {yf[3 * i], yf[3 * i + 1], yf[3 * i + 2]};
             for (int j = 0; j < 3; ++j) { s1[j] += c1[j]; s2[j] += c2[j]; }
@@ -274,6 +285,8 @@ __global__ __launch_bounds__(64) void k_kabsch(const float *__restrict__ xs, con
             sy[0] += c1[1] * c2[0]; sy[1] += c1[1] * c2[1]; sy[2] += c1[1] * c2[2];
             sz[0] += c1[2] * c2[0]; sz[1] += c1[2] * c2[1]; sz[2] += c1[2] * c2[2];
         }
+        if (WAVE)
+            for (int j = 0; j < 3; ++j) { s1[j] = kb_wave_sum(s1[j]); s2[j] = kb_wave_sum(s2[j]); sx[j] = kb_wave_sum(sx[j]); sy[j] = kb_wave_sum(sy[j]); sz[j] = kb_wave_sum(sz[j]); }
         double dn = (double)n;
         for (int j = 0; j < 3; ++j) { xc[j] = s1[j] / dn; yc[j] = s2[j] / dn; }
         for (int j = 0; j < 3; ++j) {
@@ -386,15 +399,17 @@ __global__ __launch_bounds__(64) void k_kabsch(const float *__restrict__ xs, con
             for (int i = 0; i < 3; ++i) t[i] = yc[i] - (u[i][0] * xc[0] + u[i][1] * xc[1] + u[i][2] * xc[2]);
         }
         double sum_sq = 0.0;
-        for (uint64_t i = 0; i < n; ++i) {
+        for (uint64_t i = WAVE ? kb_lane : 0; i < n; i += WAVE ? 64 : 1) {
             double X = xf[3 * i], Y = xf[3 * i + 1], Z = xf[3 * i + 2];
             double tr[3] = {u[0][0] * X + u[0][1] * Y + u[0][2] * Z + t[0], u[1][0] * X + u[1][1] * Y + u[1][2] * Z + t[1],
                             u[2][0] * X + u[2][1] * Y + u[2][2] * Z + t[2]};
             for (int j = 0; j < 3; ++j) { double diff = tr[j] - (double)yf[3 * i + j]; sum_sq += diff * diff; }
         }
+        if (WAVE) sum_sq = kb_wave_sum(sum_sq);
         rf = (float)sqrt(sum_sq / dn);
         if (rf != rf) rf = 3.40282347e+38f;
     }
+    if (WAVE && kb_lane != 0) return;
     rmsd_out[pidx] = rf;
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) rot_out[9 * pidx + 3 * i + j] = (float)u[i][j];
@@ -403,7 +418,9 @@ __global__ __launch_bounds__(64) void k_kabsch(const float *__restrict__ xs, con
 }
 
 void fd_launch_kabsch(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_kabsch, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, x, y, off, n, rmsd, rot, tran);
+    if (!n) return;
+    hipLaunchKernelGGL(k_kabsch<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, x, y, off, n, rmsd, rot, tran);
+    hipLaunchKernelGGL(k_kabsch<true>, dim3((unsigned)n), dim3(64), 0, st, x, y, off, n, rmsd, rot, tran);   // exits at once for small problems
 }
 
 // ------------------------------------------------------------------------------------------ LMS-QCP partial fit

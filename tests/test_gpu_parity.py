@@ -534,3 +534,26 @@ def test_unknown_encodings_are_refused(ctx, ser):
             fd.get_geometric_hash_as_u32(ctx, batch, hash_type=htype)
         with pytest.raises(Exception):
             fd.FolddiscoIndex.build(ctx, batch, hash_type=htype)
+
+
+@pytest.mark.gpu
+def test_kabsch_large_problems_wave_path(ctx):
+    """Whole-structure matches superpose hundreds of points: problems of >= 128 points take the wavefront-per-problem kernel
+    (tree-order f64 sums).  RMSD within 1e-4 of the restatement, rotation / translation within 1e-4 / 1e-3, next to small problems
+    in the same batch."""
+    from folddisco_amd import match
+    rng = np.random.default_rng(3)
+    probs = []
+    for n in (3, 127, 128, 129, 600, 2000, 16):
+        y = (rng.normal(size=(n, 3)) * 12).astype(np.float32)
+        a = rng.uniform(0, np.pi)
+        R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        x = ((y - 3.0) @ R.T + rng.normal(size=(n, 3)) * 0.4).astype(np.float32)
+        probs.append((x, y))
+    xs = np.concatenate([p[0] for p in probs]); ys = np.concatenate([p[1] for p in probs])
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in probs])]).astype(np.uint64)
+    rmsd, rot, tran = match.kabsch_batch(ctx, xs, ys, off)
+    for k, (x, y) in enumerate(probs):
+        r, R, T = oracle.kabsch(x, y)
+        assert abs(rmsd[k] - r) <= 1e-4, (k, len(x), rmsd[k], r)
+        assert np.allclose(rot[k], R, atol=1e-4) and np.allclose(tran[k], T, atol=1e-3), (k, len(x))
