@@ -14,6 +14,8 @@
 #include <map>
 #include <unordered_map>
 #include <unordered_set>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "fdgpu_internal.h"
 #include <chrono>
@@ -609,21 +611,24 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     struct CompPlan { std::vector<uint32_t> q_idx, r_idx; float sub_idf; };
     std::vector<std::vector<CompPlan>> plan_cache(two_pass ? n_cand : 0);
     std::vector<char> plan_have(two_pass ? n_cand : 0, 0);
-    auto run_slots = [&](const bool plan) {
-    size_t fpos = 0, cpos = 0;
-    uint64_t tq = 0;
-    for (uint64_t slot = 0; slot < n_cand; ++slot) {
-        while (slot >= cand_off[tq + 1]) { ++tq; m_off[tq] = recs.size(); r_off[tq] = res.size(); }
+    // Candidate slots are independent (their own found triples, candidate pairs and outputs): they are processed by a pool of
+    // host threads into per-slot outputs that are merged in slot order afterwards, so the result does not depend on the thread count.
+    struct SlotOut {
+        std::vector<fd_match_rec> recs; std::vector<int32_t> res; std::vector<float> kx, ky; std::vector<uint64_t> klen;
+        std::vector<Pend> pend; std::vector<uint32_t> marks;
+    };
+    std::vector<uint32_t> slot_q(std::max<uint64_t>(n_cand, 1), 0);
+    for (uint64_t t = 0; t < n_queries; ++t) for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) slot_q[k] = (uint32_t)t;
+    std::vector<size_t> f_lo(n_cand + 1, 0), c_lo(n_cand + 1, 0);
+    auto do_slot = [&](const uint64_t slot, const bool plan, SlotOut &o) {
+        const uint64_t tq = slot_q[slot];
         const fd_query_map *qm = qms[tq];
         const std::unordered_map<uint32_t, uint32_t> &entry = entries[tq];
         const uint32_t q_size = q_sizes[tq];
         const uint64_t NQ = qm->n_indices;
         const float *q_ca = qb_ca.data() + 3 * qb->h_res_off[q_struct[tq]], *q_cb = qb_cb.data() + 3 * qb->h_res_off[q_struct[tq]];
-        size_t f0 = fpos, c0 = cpos;
-        while (fpos < nf && found[fpos].cand == slot) ++fpos;
-        if (pk_key) while (cpos < nc && (pk_key[cpos] >> 16) == slot) ++cpos;
-        else while (cpos < nc && cands[cpos].cand == slot) ++cpos;
-        if (fpos == f0) continue;
+        const size_t f0 = f_lo[slot], fpos = f_lo[slot + 1], c0 = c_lo[slot], cpos = c_lo[slot + 1];
+        if (fpos == f0) return;
         const bool cached = !plan && two_pass && plan_have[slot];
         Graph g;
         std::vector<std::vector<uint32_t>> comps;
@@ -640,7 +645,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             for (size_t e = 0; e < g.es.size(); ++e) { auto it = entry.find(g.eh[e]); edge_k[e] = it == entry.end() ? -1 : (int32_t)it->second; }
         }
         const size_t n_comps = cached ? plan_cache[slot].size() : comps.size();
-        if (n_comps == 0) continue;
+        if (n_comps == 0) return;
         const uint32_t s = cand[slot];
         (void)s;
         const float *t_ca = t_all.data() + 3 * g_dst[slot], *t_cb = t_all.data() + 3 * g_total + 3 * g_dst[slot];
@@ -714,10 +719,8 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
                 if (two_pass) { plan_cache[slot][ci].q_idx = q_idx; plan_cache[slot][ci].r_idx = r_idx; plan_cache[slot][ci].sub_idf = sub_idf; }   // a query residue without a target leaves work for the rescue: its votes come from pairs whose partner is mapped
                 bool unmatched = false;
                 for (uint64_t pos = 0; pos < NQ && !unmatched; ++pos) unmatched = std::find(q_idx.begin(), q_idx.end(), qm->indices[pos]) == q_idx.end();
-                if (unmatched) {
-                    any_rescue = true;
-                    for (uint32_t r : r_idx) if (r < Rt) { const uint32_t bit = mask_off[slot] + r; cj_mask[bit >> 5] |= 1u << (bit & 31u); }
-                }
+                if (unmatched)
+                    for (uint32_t r : r_idx) if (r < Rt) o.marks.push_back(r);
                 continue;
             }
             // rescue votes of this component: (query residue, target residue) -> pairs whose partner is one of its mapped residues
@@ -771,24 +774,72 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             memset(&rec, 0, sizeof rec);
             rec.cand = (uint32_t)(slot - cand_off[tq]); rec.idf = sub_idf;
             rec.same = from_hash == processed ? 1 : 0;
-            recs.push_back(rec);
-            res.insert(res.end(), from_hash.begin(), from_hash.end());
-            res.insert(res.end(), processed.begin(), processed.end());
+            o.recs.push_back(rec);
+            o.res.insert(o.res.end(), from_hash.begin(), from_hash.end());
+            o.res.insert(o.res.end(), processed.begin(), processed.end());
             auto add_problem = [&](const std::vector<uint32_t> &qv, const std::vector<uint32_t> &rv, int which) {
                 for (size_t k = 0; k < qv.size(); ++k) {   // [CA, CB] interleaved (retrieve.rs:761-767)
-                    for (int z = 0; z < 3; ++z) ky.push_back(q_ca[3 * qv[k] + z]);
-                    for (int z = 0; z < 3; ++z) ky.push_back(q_cb[3 * qv[k] + z]);
-                    for (int z = 0; z < 3; ++z) kx.push_back(t_ca[3 * rv[k] + z]);
-                    for (int z = 0; z < 3; ++z) kx.push_back(t_cb[3 * rv[k] + z]);
+                    for (int z = 0; z < 3; ++z) o.ky.push_back(q_ca[3 * qv[k] + z]);
+                    for (int z = 0; z < 3; ++z) o.ky.push_back(q_cb[3 * qv[k] + z]);
+                    for (int z = 0; z < 3; ++z) o.kx.push_back(t_ca[3 * rv[k] + z]);
+                    for (int z = 0; z < 3; ++z) o.kx.push_back(t_cb[3 * rv[k] + z]);
                 }
-                koff.push_back(koff.back() + 2 * qv.size());
-                pend.push_back({recs.size() - 1, which});
+                o.klen.push_back(2 * qv.size());
+                o.pend.push_back({o.recs.size() - 1, which});
             };
             add_problem(q_idx, r_idx, 0);
             if (!rec.same) add_problem(qs_sc, rs_sc, 1);
         }
-    }
-    while (tq < n_queries) { ++tq; m_off[tq] = recs.size(); r_off[tq] = res.size(); }
+    };
+    auto run_slots = [&](const bool plan) {
+        // per-slot ranges of the found triples and candidate pairs (both arrive grouped by slot)
+        {
+            size_t fpos = 0, cpos = 0;
+            for (uint64_t slot = 0; slot < n_cand; ++slot) {
+                f_lo[slot] = fpos; c_lo[slot] = cpos;
+                while (fpos < nf && found[fpos].cand == slot) ++fpos;
+                if (pk_key) while (cpos < nc && (pk_key[cpos] >> 16) == slot) ++cpos;
+                else while (cpos < nc && cands && cands[cpos].cand == slot) ++cpos;
+            }
+            f_lo[n_cand] = fpos; c_lo[n_cand] = cpos;
+        }
+        std::vector<SlotOut> outs(n_cand);
+        const char *th_env = getenv("FDGPU_HOST_THREADS");
+        unsigned n_thr = th_env ? (unsigned)atoi(th_env) : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+        n_thr = (unsigned)std::min<uint64_t>(std::max(1u, n_thr), std::max<uint64_t>(1, (uint64_t)nf / 2048 + 1));   // small jobs stay on the caller's thread
+        std::atomic<uint64_t> next(0);
+        auto worker = [&]() {
+            for (;;) {
+                const uint64_t slot = next.fetch_add(1);
+                if (slot >= n_cand) break;
+                do_slot(slot, plan, outs[slot]);
+            }
+        };
+        if (n_thr <= 1) worker();
+        else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t + 1 < n_thr; ++t) pool.emplace_back(worker);
+            worker();
+            for (auto &th : pool) th.join();
+        }
+        // merge in slot order
+        uint64_t tq = 0;
+        for (uint64_t slot = 0; slot < n_cand; ++slot) {
+            while (slot >= cand_off[tq + 1]) { ++tq; m_off[tq] = recs.size(); r_off[tq] = res.size(); }
+            SlotOut &o = outs[slot];
+            if (plan) {
+                for (uint32_t r : o.marks) { any_rescue = true; const uint32_t bit = mask_off[slot] + r; cj_mask[bit >> 5] |= 1u << (bit & 31u); }
+                continue;
+            }
+            const size_t rec0 = recs.size();
+            recs.insert(recs.end(), o.recs.begin(), o.recs.end());
+            res.insert(res.end(), o.res.begin(), o.res.end());
+            kx.insert(kx.end(), o.kx.begin(), o.kx.end());
+            ky.insert(ky.end(), o.ky.begin(), o.ky.end());
+            for (uint64_t l : o.klen) koff.push_back(koff.back() + l);
+            for (const Pend &pe : o.pend) pend.push_back({rec0 + pe.rec, pe.which});
+        }
+        while (tq < n_queries) { ++tq; m_off[tq] = recs.size(); r_off[tq] = res.size(); }
     };
     if (two_pass) {
         run_slots(true);
