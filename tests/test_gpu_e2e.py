@@ -806,3 +806,32 @@ def test_own_descriptor_encodings(env, htype, nbd, nba):
                         assert g["processed"] == [-1 if x is None else x[2] for x in rp["residues"]]
                         assert g["from_hash"] == [-1 if x is None else x[2] for x in rh["residues"]]
                         assert abs(g["rmsd"] - rp["rmsd"]) <= 1e-4 and g["idf"] == pytest.approx(rp["idf"], rel=1e-6)
+
+
+@pytest.mark.parametrize("alias,name", [("trrosetta", "TrRosetta"), ("ppf", "PointPairFeature"), ("3di", "TertiaryInteraction"), ("hybrid", "Hybrid")])
+def test_cli_own_descriptor_encodings(env, alias, name, tmp_path):
+    """`index -y <alias>` / `query` round trip for the encodings with their own descriptors: PREFIX.type carries the HashType name
+    (HashType::get_with_str aliases, geometry/core.rs:42-56), the query reads it back and prints what the API path returns."""
+    from folddisco_amd import indexio
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    from folddisco_amd.__main__ import main as cli
+    from folddisco_amd._lib import hash_type_index
+    import folddisco_amd as fd
+    ctx, structs, batch, _ix, nres, plddt, tids = env
+    prefix = str(tmp_path / "ix")
+    cli(["index", "-p", os.path.dirname(SER[0]), "-i", prefix, "-y", alias])
+    assert indexio.load_type(prefix + ".type")["hash_type"] == name
+    htype = hash_type_index(name)
+    ix = fd.FolddiscoIndex.build(ctx, batch, hash_type=htype)
+    v, hh, o = ix.export()
+    dv, dh, do = indexio.read_index_files(prefix)
+    assert np.array_equal(dv, v) and np.array_equal(dh, hh) and np.array_equal(do, o)
+    out = str(tmp_path / "out.tsv")
+    cli(["query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", prefix, "-o", out, "--ca-distance", "1.5"])
+    q = st.read_compact_structure(Q4CHA)
+    _, want = fq.query_pdb(ctx, ix, batch, structs, [os.path.join(os.path.dirname(SER[0]), os.path.basename(p)) for p in SER], nres, plddt, q,
+                           "B57,B102,C195", hash_type=htype, sort_by="node_count,rmsd", ca_distance=1.5)
+    rows = [l.rstrip("\n").split("\t") for l in open(out)]
+    assert [r[1:] for r in rows] == [fq.format_match_row(m).split("\t")[1:] for m in want]
+    assert any("B57,B102,C195" == r[4] for r in rows)          # 4cha matches itself under every encoding
