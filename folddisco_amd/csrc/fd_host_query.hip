@@ -529,6 +529,10 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     const char *tp_env = getenv("FDGPU_TWO_PASS");     // 1 / 0 force the choice (tests)
     const bool two_pass = tp_env ? tp_env[0] == '1' : max_aad > 4096;
     uint32_t *pk_key = nullptr, *pk_val = nullptr;      // packed, device-sorted candidate pairs (see fd_match_pairs_multi, mode bit 3)
+    struct HostBufs {   // the scan outputs live until the slots are processed; every return path below releases them
+        fd_pair_rec *&f; fd_cand_rec *&c; uint32_t *&k, *&v;
+        ~HostBufs() { free(f); free(c); free(k); free(v); }
+    } host_bufs{found, cands, pk_key, pk_val};
     int rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc, two_pass ? 1u : 15u,
                                   nullptr, nullptr, 0, &pk_key, &pk_val);
     if (rc) return rc;
@@ -850,7 +854,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &f2, &nf2, &cands, &nc, 14u, cj_mask.data(),
                                       mask_off.data(), cj_mask.size(), &pk_key, &pk_val);
             free(f2);
-            if (rc) { free(found); return rc; }
+            if (rc) return rc;
             if (trace) fprintf(stderr, "[fdgpu_retrieve] second scan done at %.3f ms (cands %llu)\n", t_ms(T2, t_now()), (unsigned long long)nc);
         }
     }
@@ -859,13 +863,13 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         for (uint64_t e = 0; e < nc; ++e) ++so[cands[e].cand + 1];
         for (uint64_t k = 0; k < n_cand; ++k) so[k + 1] += so[k];
         fd_cand_rec *g2 = (fd_cand_rec *)malloc(nc * sizeof(fd_cand_rec));
-        if (!g2) { free(found); free(cands); return FDGPU_ENOMEM; }
+        if (!g2) return FDGPU_ENOMEM;
         for (uint64_t e = 0; e < nc; ++e) g2[so[cands[e].cand]++] = cands[e];
         free(cands); cands = g2;
     }
     run_slots(false);
     if (trace) fprintf(stderr, "[fdgpu_retrieve] slots done at %.3f ms\n", t_ms(T2, t_now()));
-    free(found); free(cands); free(pk_key); free(pk_val);
+    free(found); found = nullptr; free(cands); cands = nullptr; free(pk_key); pk_key = nullptr; free(pk_val); pk_val = nullptr;
     const uint64_t nprob = pend.size();
     std::vector<float> rmsd(std::max<uint64_t>(nprob, 1)), rot(std::max<uint64_t>(nprob, 1) * 9), tran(std::max<uint64_t>(nprob, 1) * 3);
     auto T3 = t_now();
