@@ -915,13 +915,22 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     if (!fd_hash_type_supported(p->hash_type)) FAIL(c, FDGPU_EINVAL, "hash_type: only the encodings over the (d_CA, d_CB, theta, tau1, tau2) descriptor are built (0, 1, 3, 7, 8)");
     reset_timings(c);
     hipStream_t st = c->stream;
-    // work items: (query, candidate slot, 64-residue i-tile)
-    std::vector<uint32_t> wc, wi, wq;
+    // work items: (query, candidate slot, 64-residue i-tile); a handful of long candidates (whole-structure queries: the top 20)
+    // would leave most of the chip idle, so the partner residues are split into spans as well until ~2000 wavefronts exist
+    uint64_t n_tiles = 0;
+    for (uint64_t k = 0; k < n_cand; ++k) {
+        if (cand[k] >= db->n_struct) FAIL(c, FDGPU_EINVAL, "match_pairs: candidate id outside the batch");
+        n_tiles += (db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]] + FD_WAVE - 1) / FD_WAVE;
+    }
+    const uint32_t j_span = n_tiles && n_tiles < 1024 ? (n_tiles < 256 ? 64u : 128u) : 0u;
+    std::vector<uint32_t> wc, wi, wq, wj;
     for (uint64_t t = 0; t < n_queries; ++t)
         for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) {
-            if (cand[k] >= db->n_struct) FAIL(c, FDGPU_EINVAL, "match_pairs: candidate id outside the batch");
             uint64_t r0 = db->h_res_off[cand[k]], r1 = db->h_res_off[cand[k] + 1];
-            for (uint64_t r = r0; r < r1; r += FD_WAVE) { wc.push_back((uint32_t)k); wi.push_back((uint32_t)r); wq.push_back((uint32_t)t); }
+            for (uint64_t r = r0; r < r1; r += FD_WAVE)
+                for (uint64_t j0 = r0; j0 < r1; j0 += j_span ? j_span : (r1 - r0)) {
+                    wc.push_back((uint32_t)k); wi.push_back((uint32_t)r); wq.push_back((uint32_t)t); wj.push_back((uint32_t)j0);
+                }
         }
     // per-query tables: sorted hash set, residue-type masks, aa_dist_map grouped by (aa_i, aa_j) — stable order inside a group =
     // the observed-list order the reference emits in
@@ -960,12 +969,12 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     const size_t nw = wc.size(), na = all_dist.size(), nh = all_hashes.size();
     // one packed host block -> one H2D copy: [cand | wc | wi | wq | hashes | start tables | dist | qi | qtab]
     auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
-    const size_t o_cand = 0, o_wc = o_cand + up4(n_cand), o_wi = o_wc + up4(nw), o_wq = o_wi + up4(nw), o_h = o_wq + up4(nw),
+    const size_t o_cand = 0, o_wc = o_cand + up4(n_cand), o_wi = o_wc + up4(nw), o_wq = o_wi + up4(nw), o_wj = o_wq + up4(nw), o_h = o_wj + up4(nw),
                  o_st = o_h + up4(nh), o_d = o_st + up4(all_start.size()), o_qi = o_d + up4(na), o_qt = o_qi + up4(na),
                  words = o_qt + up4(n_queries * (sizeof(mp_query_dev) / 4)) + 4;
     std::vector<uint32_t> blk(words, 0);
     if (n_cand) memcpy(&blk[o_cand], cand, n_cand * 4);
-    if (nw) { memcpy(&blk[o_wc], wc.data(), nw * 4); memcpy(&blk[o_wi], wi.data(), nw * 4); memcpy(&blk[o_wq], wq.data(), nw * 4); }
+    if (nw) { memcpy(&blk[o_wc], wc.data(), nw * 4); memcpy(&blk[o_wi], wi.data(), nw * 4); memcpy(&blk[o_wq], wq.data(), nw * 4); memcpy(&blk[o_wj], wj.data(), nw * 4); }
     if (nh) memcpy(&blk[o_h], all_hashes.data(), nh * 4);
     if (!all_start.empty()) memcpy(&blk[o_st], all_start.data(), all_start.size() * 4);
     if (na) { memcpy(&blk[o_d], all_dist.data(), na * 4); memcpy(&blk[o_qi], all_qi.data(), na * 4); }
@@ -995,6 +1004,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     for (uint32_t k = 0; k < A.n_cfg; ++k) A.qk[k] = fd_make_consts_cfg(p, k).q;
     A.cand = dblk + o_cand; A.n_cand = (uint32_t)n_cand;
     A.wi_cand = dblk + o_wc; A.wi_i0 = dblk + o_wi; A.wi_query = dblk + o_wq; A.n_work = (uint32_t)nw;
+    A.wi_j0 = dblk + o_wj; A.j_span = j_span;
     A.resname_std = d_std;
     A.q_hashes = dblk + o_h; A.aad_start = dblk + o_st; A.aad_dist = (const float *)(dblk + o_d); A.aad_qi = dblk + o_qi;
     A.qtab = (const mp_query_dev *)(dblk + o_qt);

@@ -187,6 +187,7 @@ struct mp_args {
     float cutoff;
     const uint32_t *cand; uint32_t n_cand;
     const uint32_t *wi_cand; const uint32_t *wi_i0; const uint32_t *wi_query; uint32_t n_work;
+    const uint32_t *wi_j0; uint32_t j_span;   // j_span != 0: a work item scans partner residues [wi_j0, wi_j0 + j_span) only (few, long candidates)
     const mp_query_dev *qtab;
     const uint8_t *resname_std;
     uint32_t aa1_mask, aa2_mask;

@@ -182,9 +182,11 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
         for (uint32_t a2 = 0; a2 < 32u; ++a2) row_mask |= (s_start[aai * 32u + a2 + 1] > s_start[aai * 32u + a2] ? 1u : 0u) << a2;
     uint32_t qn = 0;   // wave-uniform
     // j in blocks of 64: one coalesced load of (aa, CA) per block, then wave-uniform broadcasts (v_readlane)
-    for (uint32_t jb = r0; jb < r1; jb += FD_WAVE) {
+    const uint32_t j_lo = A.j_span ? A.wi_j0[w] : r0;
+    const uint32_t j_hi = A.j_span ? (j_lo + A.j_span < r1 ? j_lo + A.j_span : r1) : r1;
+    for (uint32_t jb = j_lo; jb < j_hi; jb += FD_WAVE) {
         const uint32_t jl = jb + lane;
-        const bool jin = jl < r1;
+        const bool jin = jl < j_hi;
         const uint32_t aaj_l = jin ? A.B.aa[jl] : 255u;
         fd_v3 cj = {0.f, 0.f, 0.f};
         if (jin) cj = fd_load3(A.B.ca_xyz, jl);
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
         if (!full) okj = okj && aaj_l < 20u && (A.resname_std == nullptr || A.resname_std[jl]) && ((A.aa2_mask >> aaj_l) & 1u);
         if (A.cj_mask && okj) { const uint32_t bit = A.mask_off[slot] + (jl - r0); okj = (A.cj_mask[bit >> 5] >> (bit & 31u)) & 1u; }
         const uint64_t okm = __ballot(okj);
-        const uint32_t nj = (r1 - jb) < FD_WAVE ? (r1 - jb) : FD_WAVE;
+        const uint32_t nj = (j_hi - jb) < FD_WAVE ? (j_hi - jb) : FD_WAVE;
         for (uint32_t k = 0; k < nj; ++k) {
             if ((okm >> k) & 1ull) {   // wave-uniform
                 const uint32_t j = jb + k;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                     qn += (uint32_t)__popcll(m);
                 }
             }
-            const bool last = (jb + FD_WAVE >= r1) && (k + 1 == nj);
+            const bool last = (jb + FD_WAVE >= j_hi) && (k + 1 == nj);
             while (qn >= FD_WAVE || (last && qn)) {
                 __syncthreads();
                 uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
