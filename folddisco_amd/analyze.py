@@ -20,7 +20,10 @@ _PI = _F(3.14159274)
 _DEG = _F(57.2957795130823208767981548141051703)                # f32::to_degrees
 
 # per encoding: (default dist bins, default angle bins, #dist fields, #angle fields, angle fields are sin/cos pairs)
-_BINS = {0: (18, 9, 2, 1, False), 1: (8, 3, 2, 1, True), 3: (16, 4, 2, 3, True), 7: (8, 32, 2, 3, False), 8: (32, 16, 2, 3, False)}
+_BINS = {0: (18, 9, 2, 1, False), 1: (8, 3, 2, 1, True), 3: (16, 4, 2, 3, True), 7: (8, 32, 2, 3, False), 8: (32, 16, 2, 3, False),
+         4: (8, 3, 1, 3, True)}
+# TrRosetta / TertiaryInteraction / Hybrid decode to 8-9 values; the reference's summary writes them into a 7-slot container
+# (summary.rs:149, 209) and panics, so there is nothing to reproduce for them
 
 
 _libm = None
@@ -89,6 +92,13 @@ def reverse_hash(htype: int, h, nbin_dist: int, nbin_angle: int, angles: bool = 
         if angles:
             s = _cont((u >> 4) & 15, -1.0, 1.0, nbin_angle); c = _cont(u & 15, -1.0, 1.0, nbin_angle)
             out[:, 4] = _atan2f(s, c) * _DEG
+    elif htype == 4:                                            # ppf.rs:55-88
+        out[:, 0] = (u >> 27) & 31; out[:, 1] = (u >> 22) & 31
+        out[:, 2] = _cont((u >> 18) & 15, 2.0, 20.0, nbin_dist)
+        if angles:
+            for k in range(3):
+                sn = _cont((u >> (15 - 6 * k)) & 7, -1.0, 1.0, nbin_angle); cs = _cont((u >> (12 - 6 * k)) & 7, -1.0, 1.0, nbin_angle)
+                out[:, 3 + k] = _atan2f(sn, cs) * _DEG
     elif htype in (7, 8):                                       # folddisco_angle.rs:80-108, folddisco_dist.rs:73-102
         pair = (u >> 21) & 0x1ff
         out[:, 0] = pair // 20; out[:, 1] = pair % 20

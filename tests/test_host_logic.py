@@ -322,6 +322,10 @@ def test_analyze_summary_files(tmp_path):
         dd, da = analyze._BINS[t][:2]
         v = analyze.reverse_hash(t, [h], dd, da)[0]
         assert (int(v[0]), int(v[1])) == (13, 19) and abs(v[2] - 14.0) <= 18.0 / (dd - 1) / 2 + 1e-4 and abs(v[3] - 15.9) <= 18.0 / (dd - 1) / 2 + 1e-4
+    with oracle.hash_type(4):                                    # PointPairFeature: 1 distance, 3 sin/cos angle pairs (8 / 3 bins)
+        h = oracle.hash_any([13, 19, 7.5, 0.7, 1.7, 2.9])
+    v = analyze.reverse_hash(4, [h], 8, 3)[0]
+    assert (int(v[0]), int(v[1])) == (13, 19) and abs(v[2] - 7.5) <= 18.0 / 7 / 2 + 1e-4 and analyze.total_bins(4, 0, 0) == 8 * 729 * 400
     with pytest.raises(SystemExit):
         cli(["analyze", "-i", prefix, "-p", "somewhere"])
 
