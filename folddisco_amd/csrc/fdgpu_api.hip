@@ -303,12 +303,12 @@ static int count_and_scan(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_cons
     return d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), P);
 }
 
-static int ensure_sort_ws(fdgpu_ctx *c, uint64_t P) {
-    size_t kb = std::max<uint64_t>(P, 1) * 4;
+static int ensure_sort_ws(fdgpu_ctx *c, uint64_t P, size_t id_bytes = 4) {
+    size_t kb = std::max<uint64_t>(P, 1) * 4, ib = std::max<uint64_t>(P, 1) * id_bytes + 16;
     HIPCHK(c, c->ws[WS_KEYS_A].ensure(kb));
-    HIPCHK(c, c->ws[WS_IDS_A].ensure(kb));
+    HIPCHK(c, c->ws[WS_IDS_A].ensure(ib));
     HIPCHK(c, c->ws[WS_KEYS_B].ensure(kb));
-    HIPCHK(c, c->ws[WS_IDS_B].ensure(kb));
+    HIPCHK(c, c->ws[WS_IDS_B].ensure(ib));
     HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * std::max<uint32_t>(fd_rs_num_tiles(P), 1) * 4));
     // 256 digit totals + the chunk sums of the tile-major histogram scan ([tiles / 128][256] u64)
     HIPCHK(c, c->ws[WS_TOT].ensure((256 + (size_t)(fd_rs_num_tiles(P) / 128 + 2) * 256) * 8));
@@ -468,12 +468,12 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     if (rc) return rc;
     P = P1 * n_cfg;                         // every bin pair of --multiple-bins contributes one key per ordered residue pair
     if (P >= 0xffffffffull) FAIL(c, FDGPU_ERANGE, "more than 2^32 residue pairs in one build call; split the shard");
-    if ((rc = ensure_sort_ws(c, P))) return rc;
-    uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *kb = c->ws[WS_KEYS_B].as<uint32_t>();
-    void *ia = c->ws[WS_IDS_A].p, *ib = c->ws[WS_IDS_B].p;
     // shards of <= 2^18 structures use 6-byte sort elements (key = hash << 2 | local id bits 17:16, u16 payload) as long as
     // every hash fits 30 bits; the 8-byte form (u32 hash, u32 id) otherwise
     const bool ids16 = !own && !force32 && S <= (1ull << 18);
+    if ((rc = ensure_sort_ws(c, P, ids16 ? 2 : 4))) return rc;
+    uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *kb = c->ws[WS_KEYS_B].as<uint32_t>();
+    void *ia = c->ws[WS_IDS_A].p, *ib = c->ws[WS_IDS_B].p;
     HIPCHK(c, c->ws[WS_MISC3].ensure(64));
     HIPCHK(c, hipMemsetAsync(c->ws[WS_MISC3].p, 0, 64, st));
     C.wide_flag = c->ws[WS_MISC3].as<unsigned long long>() + 3;
