@@ -1,58 +1,75 @@
 #!/usr/bin/env python
-"""bench.py — structures/sec indexed (+ motif queries/sec) on MI355X, BASELINE.json's metric.
+"""bench.py — structures/sec indexed + motif queries/sec at Swiss-Prot scale on MI355X (BASELINE.json's metric).
 
-One step = one pass of the index-build hot path (pair enumeration + PDBTrRosetta hash -> stable radix
-sort -> delta/varint posting encode) over one shard of synthetic AFDB-shaped structures that is already
-resident in HBM.  Weak scaling: every rank indexes its own shard of --structures structures (default
-67,750 = Swiss-Prot 542k / 8, so that --gpus 8 is Swiss-Prot scale) with ids offset by rank; the build
-needs no collective (index build shards by structure).  After the timed build the ranks
-score a batch of motif queries against their shard and all-gather the candidate hits (RCCL), reported
-as queries/s in the "query" object.
+Workload (config.workload): 542,000 synthetic AFDB-shaped structures in total (Swiss-Prot scale), generated in
+eight fixed blocks of 67,750 (seed + 1000 * block) so that every --gpus N indexes the SAME database: rank r of N owns the
+contiguous id range dist.shard_range(r, N, 542000) ("strong" scaling; index build shards by structure, no data-path
+collective).
 
-Contract: python bench.py --gpus N --steps K --warmup W  -> one JSON line on rank 0.
+One step = the whole index build of the rank's shard, inputs resident in HBM: per block of <= 67,750 structures
+frames -> pair count -> pair emit (PDBTrRosetta hash) -> stable radix sort -> delta/varint posting encode
+(fdgpu_index_build), then — when the shard spans several blocks — the device merge of the blocks' sub-indices into ONE
+resident index (fdgpu_index_merge), byte-identical to a single build.  value = 542,000 * steps / time (max over ranks).
+
+After the timed build: the export-inclusive rate (one more step + fdgpu_index_export D2H), the per-kernel HIP-event
+timings of one step (roofline of the dominant kernel), the motif-query leg against the resident index (folddisco_amd/
+querybench.py: queries/s, the scoring kernels' roofline and the oracle's count_query + retrieval on the host cores) and,
+on rank 0 at N=1, the CPU restatement of the index build on a bounded sample.
+
+Contract: python bench.py --gpus N --steps K --warmup W  -> one JSON line on rank 0.  With N > 1 and no WORLD_SIZE in the
+environment the script re-executes itself under torch.distributed.run (one rank per GPU, nccl = RCCL).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+GEN_BLOCK = 67750      # structures per generated block = per fdgpu_index_build call (Swiss-Prot 542,000 / 8)
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--structures", type=int, default=67750, help="structures per GPU (shard)")
+    ap.add_argument("--structures", type=int, default=542000, help="structures in the WHOLE database (split over the ranks)")
     ap.add_argument("--seed", type=int, default=20260927)
-    ap.add_argument("--cpu-sample", type=int, default=8192, help="structures timed on the host for cpu_baseline")
+    ap.add_argument("--cpu-sample", type=int, default=6144, help="structures timed on the host for cpu_baseline")
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-query", action="store_true")
-    ap.add_argument("--chunk", type=int, default=100000, help="structures per fdgpu_index_build call; a larger shard is held as a "
-                    "FolddiscoIndexSet (one resident sub-index per chunk)")
-    ap.add_argument("--pipeline", type=int, default=0, help="extra leg: builds issued from this many host threads / HIP streams (0 = skip)")
+    ap.add_argument("--no-export", action="store_true")
     return ap.parse_args()
 
 
-def pmc_traffic(stage, S):
+def respawn_under_torchrun(args):
+    """python bench.py --gpus N with N > 1: start N ranks (one per GPU) over RCCL and hand them the same arguments"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def pmc_traffic(stage, tag):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/*pmc_traffic_S<structures>.json, tools/profile_bench.sh): 2 x FETCH_SIZE (gfx950 reports half of a
-    coalesced stream, MI355X_MICROARCH.md; checked on k_enc_sizes / k_rs_hist whose read bytes are known) +
-    WRITE_SIZE (matches the known write bytes of k_frames and k_pair_emit2).  None when no profile of this
-    workload size is committed."""
+    (profiles/*pmc_traffic_<tag>.json, tools/profile_bench.sh): 2 x FETCH_SIZE (gfx950 reports half of a coalesced stream,
+    MI355X_MICROARCH.md; checked on k_enc_sizes / k_rs_hist whose read bytes are known) + WRITE_SIZE.  None when no profile
+    of this workload is committed."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_traffic_S{S}.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_traffic_{tag}.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
@@ -64,24 +81,30 @@ def pmc_traffic(stage, S):
     return None
 
 
-def cpu_baseline(ps_sample, n_threads):
-    """CPU restatement of the reference path (oracle/, OpenMP over structures for the hash stage like the
-    reference's rayon par_iter, serial dense-table count+fill), timed on the host cores of this box."""
+def cpu_baseline_build(ps_sample, n_threads):
+    """CPU restatement of the reference's index build (oracle/: OpenMP over structures for both hash passes like the reference's
+    rayon par_iter, count/fill table build with the reference's `hash % T == tid` ownership partition), timed per stage on
+    the host cores of this box."""
     import oracle
     from tests.helpers import packed_to_oracle_structs
     os.environ["OMP_NUM_THREADS"] = str(n_threads)
     structs = packed_to_oracle_structs(ps_sample)
     t0 = time.perf_counter()
-    # the reference hashes every structure twice (count pass + fill pass, controller/mod.rs:274-441)
-    h, off = oracle.hash_batch(structs)
-    h2, off2 = oracle.hash_batch(structs)
-    ix = oracle.build_index_from_lists_mt(h, off, n_threads)
-    dt = time.perf_counter() - t0
-    return len(structs) / dt, dt, ix
+    h, off = oracle.hash_batch(structs)        # pass 1 (collect_and_count, controller/mod.rs:274-365)
+    t1 = time.perf_counter()
+    h2, off2 = oracle.hash_batch(structs)      # pass 2 (add_entries, controller/mod.rs:367-441): the reference hashes twice
+    t2 = time.perf_counter()
+    oracle.build_index_from_lists_mt(h, off, n_threads)
+    t3 = time.perf_counter()
+    return len(structs) / (t3 - t0), {"hash_pass1_s": t1 - t0, "hash_pass2_s": t2 - t1, "count_fill_finalize_s": t3 - t2}
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,41 +127,65 @@ def main():
 
     import folddisco_amd as fd
     from folddisco_amd import synth
+    from folddisco_amd.dist import shard_range
 
-    S = args.structures
-    # ---- synthetic shard generated directly in HBM
-    d = synth.generate(S, seed=args.seed + 1000 * rank, device=dev)
-    res_off = d["res_off"].contiguous()
-    R = int(res_off[-1].item())
+    S_total = args.structures
+    lo, hi = shard_range(rank, world, S_total)
+    S = hi - lo
+    # ---- the rank's slice of the database, generated block by block directly in HBM
+    blocks = []
+    for b in range(lo // GEN_BLOCK, (hi - 1) // GEN_BLOCK + 1 if hi > lo else 0):
+        g0 = b * GEN_BLOCK
+        n_gen = min(GEN_BLOCK, S_total - g0)
+        d = synth.generate(n_gen, seed=args.seed + 1000 * b, device=dev)
+        a, e = max(lo, g0) - g0, min(hi, g0 + n_gen) - g0
+        if a != 0 or e != n_gen:
+            ro = d["res_off"]
+            r0, r1 = int(ro[a]), int(ro[e])
+            d = dict(res_off=(ro[a:e + 1] - ro[a]).contiguous(), n_xyz=d["n_xyz"][r0:r1].contiguous(), ca_xyz=d["ca_xyz"][r0:r1].contiguous(),
+                     cb_xyz=d["cb_xyz"][r0:r1].contiguous(), aa=d["aa"][r0:r1].contiguous(), plddt=d["plddt"][r0:r1].contiguous())
+        blocks.append(d)
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream(dev)
     ctx = fd.Context(local_rank, stream=stream.cuda_stream)
-    keep = (res_off, d["n_xyz"], d["ca_xyz"], d["cb_xyz"], d["aa"])
-    batch = ctx.wrap_device(S, R, res_off.data_ptr(), d["n_xyz"].data_ptr(), d["ca_xyz"].data_ptr(), d["cb_xyz"].data_ptr(),
-                            d["aa"].data_ptr(), None, keepalive=keep)
-    first_id = rank * S
-    # shards beyond --chunk structures (more than 2^32 residue pairs): one build call and one resident sub-index per chunk
-    chunked = S > args.chunk
-    chunk_batches = []
-    if chunked:
-        off_cpu = res_off.cpu()
-        for a in range(0, S, args.chunk):
-            b = min(a + args.chunk, S)
-            r0, r1 = int(off_cpu[a]), int(off_cpu[b])
-            ro = (res_off[a:b + 1] - res_off[a]).contiguous()
-            parts = (ro, d["n_xyz"][r0:r1], d["ca_xyz"][r0:r1], d["cb_xyz"][r0:r1], d["aa"][r0:r1])
-            chunk_batches.append(ctx.wrap_device(b - a, r1 - r0, ro.data_ptr(), parts[1].data_ptr(), parts[2].data_ptr(), parts[3].data_ptr(),
-                                                 parts[4].data_ptr(), None, keepalive=parts))
+
+    def wrap(d):
+        n = len(d["res_off"]) - 1
+        ro = d["res_off"].contiguous()
+        keep = (ro, d["n_xyz"], d["ca_xyz"], d["cb_xyz"], d["aa"])
+        return ctx.wrap_device(n, int(ro[-1].item()), ro.data_ptr(), d["n_xyz"].data_ptr(), d["ca_xyz"].data_ptr(), d["cb_xyz"].data_ptr(),
+                               d["aa"].data_ptr(), None, keepalive=keep)
+    chunk_batches = [wrap(d) for d in blocks]
+    R = sum(int(d["res_off"][-1].item()) for d in blocks)
 
     def build_shard():
-        if not chunked:
-            return fd.FolddiscoIndex.build(ctx, batch, first_id=first_id)
-        return fd.FolddiscoIndexSet.build(ctx, chunk_batches, first_id=first_id)
+        """the rank's whole index: one build call per block, then the device merge into ONE resident index"""
+        parts, fid = [], lo
+        for cb in chunk_batches:
+            parts.append(fd.FolddiscoIndex.build(ctx, cb, first_id=fid))
+            fid += cb.n_struct
+        if len(parts) == 1:
+            return parts[0]
+        return fd.FolddiscoIndexSet(parts).merge()
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
 
     ix = None
     for _ in range(args.warmup):
@@ -152,133 +199,117 @@ def main():
         ix = build_shard()
     ctx.synchronize()
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    value = world * S * args.steps / dt
-    if chunked:
-        n_post, n_hash, vlen = ix.num_postings, sum(p.num_hashes for p in ix.parts), sum(p.value_len for p in ix.parts)
-    else:
-        n_post, n_hash, vlen = ix.num_postings, ix.num_hashes, ix.value_len
+    dt = max_over_ranks(time.perf_counter() - t0)
+    value = S_total * args.steps / dt
+    n_post, n_hash, vlen = ix.num_postings, ix.num_hashes, ix.value_len
 
-    # ---- extra leg: the same K builds issued from P host threads, each with its own context / stream / workspace, so that the
-    # VALU-bound pair kernel of one build overlaps the HBM-bound sort/encode of another (how a multi-shard job would run)
-    pipelined = None
-    if args.pipeline > 1:
-        import threading
-        P = args.pipeline
-        ctxs = [ctx] + [fd.Context(local_rank) for _ in range(P - 1)]
-        bts = [batch] + [c.wrap_device(S, R, res_off.data_ptr(), d["n_xyz"].data_ptr(), d["ca_xyz"].data_ptr(), d["cb_xyz"].data_ptr(),
-                                       d["aa"].data_ptr(), None, keepalive=keep) for c in ctxs[1:]]
-        per = [(args.steps + P - 1 - t) // P for t in range(P)]
-
-        def worker(t, n):
-            torch.cuda.set_device(local_rank)   # the current HIP device is per host thread
-            x = None
-            for _ in range(n):
-                x = None
-                x = fd.FolddiscoIndex.build(ctxs[t], bts[t], first_id=first_id)
-            ctxs[t].synchronize()
-
-        def run_all(counts):
-            th = [threading.Thread(target=worker, args=(t, counts[t])) for t in range(P)]
-            for x in th: x.start()
-            for x in th: x.join()
+    # ---- export-inclusive: one more step that also brings the index to the host in the on-disk layout (fdgpu_index_export)
+    export = None
+    if not args.no_export:
+        import ctypes as C
+        from folddisco_amd._lib import u8p, u32p, u64p
         ix = None
-        run_all([1] * P)   # warm every context (workspace allocation)
         barrier()
-        t0p = time.perf_counter()
-        run_all(per)
+        t0e = time.perf_counter()
+        ix = build_shard()
+        vp, hp, op = u8p(), u32p(), u64p()
+        vl, H = C.c_uint64(), C.c_uint64()
+        ctx.check(ctx.L.fdgpu_index_export(ctx.h, ix.h, C.byref(vp), C.byref(vl), C.byref(hp), C.byref(op), C.byref(H)))
+        t1e = time.perf_counter()
+        for p in (vp, hp, op):
+            ctx.L.fdgpu_free(p)
         barrier()
-        dtp = time.perf_counter() - t0p
-        if dist is not None:
-            t = torch.tensor([dtp], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtp = float(t.item())
-        pipelined = {"value": world * S * args.steps / dtp, "unit": "structures/s", "streams": P, "ms_per_step": dtp / args.steps * 1e3,
-                     "note": "same K builds, issued concurrently from %d host threads on %d HIP streams" % (P, P)}
-        del bts
-        for c in ctxs[1:]:
-            c.close()
+        dte = max_over_ranks(t1e - t0e)
+        export = {"value": S_total / dte, "unit": "structures/s", "ms_per_step": dte * 1e3, "bytes_to_host_per_rank": int(vl.value + 12 * H.value + 8),
+                  "note": "one step + fdgpu_index_export (D2H of value bytes, hashes, offsets into malloc'd host buffers)"}
 
     # ---- per-kernel timings of one more (untimed) step with HIP events on the build stream -> roofline
     ctx.enable_timing(True)
     ix = None
-    if chunked:
-        stages, parts, fid = [], [], first_id
-        for cb in chunk_batches:
-            parts.append(fd.FolddiscoIndex.build(ctx, cb, first_id=fid))
-            ctx.synchronize()
-            stages += ctx.last_timings()
-            fid += cb.n_struct
-        ix = fd.FolddiscoIndexSet(parts)
-    else:
-        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id)
+    stages, parts, fid = [], [], lo
+    for cb in chunk_batches:
+        parts.append(fd.FolddiscoIndex.build(ctx, cb, first_id=fid))
         ctx.synchronize()
-        stages = ctx.last_timings()
+        stages += ctx.last_timings()
+        fid += cb.n_struct
+    if len(parts) > 1:
+        ix = fd.FolddiscoIndexSet(parts).merge()
+        ctx.synchronize()
+        stages += ctx.last_timings()
+    else:
+        ix = parts[0]
+    parts = None
     ctx.enable_timing(False)
     agg = {}
     for name, ms, by in stages:
         a = agg.setdefault(name, [0.0, 0, 0])
         a[0] += ms; a[1] += by; a[2] += 1
-    dom = max(agg.items(), key=lambda kv: kv[1][0])
-    dom_name, (dom_ms, dom_bytes, dom_n) = dom
+    dom_name, (dom_ms, dom_bytes, dom_n) = max(agg.items(), key=lambda kv: kv[1][0])
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    tag = f"S{S_total}" if world == 1 else f"S{S_total}_N{world}"
+    tr = pmc_traffic(dom_name, tag)
+    R_tot, post_tot, vlen_tot, hash_tot = (sum_over_ranks(x) for x in (R, n_post, vlen, n_hash))
+    b_idx = 37.0 * R_tot / S_total + 8.0 * post_tot / S_total + vlen_tot / S_total + 12.0 * hash_tot / S_total
     roofline = {"bound": "hbm", "kernel": dom_name, "launches_per_step": dom_n, "avg_ms": dom_ms / max(dom_n, 1),
                 "algorithmic_bytes_per_launch": dom_bytes / max(dom_n, 1),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                # HBM bytes per launch from the committed PMC passes of this same command (number, or null when no profile of this
-                # workload size is committed); provenance in traffic_detail
-                "traffic": (lambda t: t["bytes_per_launch"] if t else None)(pmc_traffic(dom_name, S)),
-                "traffic_detail": pmc_traffic(dom_name, S),
-                # SURVEY §8(d) end-to-end figure: B_idx = 37 R + 4 U + 4 U + v U + 12 H/S bytes per structure
-                "end_to_end": (lambda b: {"algorithmic_bytes_per_structure": b, "achieved": value / world * b / 1e9, "unit": "GB/s",
-                                          "frac": value / world * b / 1e9 / HBM_PEAK_GBS})(
-                    37.0 * R / S + 8.0 * n_post / S + vlen / S + 12.0 * n_hash / S),
+                "traffic": tr["bytes_per_launch"] if tr else None, "traffic_detail": tr,
+                # SURVEY §8(d) end-to-end figure: B_idx = 37 R + 4 U + 4 U + v U + 12 H/S bytes per structure, per GPU
+                "end_to_end": {"algorithmic_bytes_per_structure": b_idx, "achieved": value / world * b_idx / 1e9, "unit": "GB/s",
+                               "frac": value / world * b_idx / 1e9 / HBM_PEAK_GBS},
                 "stages_ms": {k: round(v[0], 3) for k, v in agg.items()},
                 "stages_gbs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0.0 for k, v in agg.items()}}
 
-    # ---- motif queries against the resident shard
+    # ---- motif queries against the resident index of the shard
     query = None
-    if chunked and not args.no_query:
-        query = {"note": "query leg runs on single-part shards only (use folddisco_amd.count_query_set for a FolddiscoIndexSet)"}
-    elif not args.no_query:
+    if not args.no_query:
         try:
             from folddisco_amd import querybench
-            if os.environ.get("FD_PROFILE_QUERY"):
-                import cProfile, pstats
-                pr = cProfile.Profile(); pr.enable()
-                query = querybench.run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=args.queries)
-                pr.disable(); pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(14)
-            else:
-                query = querybench.run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=args.queries)
+            d_all = {k: (torch.cat([b[k] for b in blocks]) if k != "res_off" else None) for k in blocks[0]}
+            offs, base = [blocks[0]["res_off"][:1]], 0
+            for b in blocks:
+                offs.append(b["res_off"][1:] + base)
+                base += int(b["res_off"][-1].item())
+            d_all["res_off"] = torch.cat(offs).contiguous()
+            chunk_batches = None
+            blocks = None
+            db = wrap(d_all)
+            query = querybench.run(ctx, db, ix, d_all, S, world, rank, dist, dev, n_queries=args.queries, lo=lo, S_total=S_total,
+                                   cpu_baseline=(rank == 0 and world == 1 and not args.no_cpu_baseline))
         except Exception as e:  # the index-build line must still be printed
-            query = {"error": repr(e)}
+            import traceback
+            query = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
 
-    out = None
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            ns = min(args.cpu_sample, S)
-            off = res_off[: ns + 1].cpu().numpy().astype(np.uint64)
+            d0 = d_all if query is not None and "error" not in query else synth.generate(min(GEN_BLOCK, S_total), seed=args.seed, device=dev)
+            ns = min(args.cpu_sample, len(d0["res_off"]) - 1)
+            off = d0["res_off"][: ns + 1].cpu().numpy().astype(np.uint64)
             r_s = int(off[-1])
-            ps = fd.PackedStructures(off, d["n_xyz"][:r_s].cpu().numpy(), d["ca_xyz"][:r_s].cpu().numpy(), d["cb_xyz"][:r_s].cpu().numpy(),
-                                     d["aa"][:r_s].cpu().numpy())
+            ps = fd.PackedStructures(off, d0["n_xyz"][:r_s].cpu().numpy(), d0["ca_xyz"][:r_s].cpu().numpy(), d0["cb_xyz"][:r_s].cpu().numpy(),
+                                     d0["aa"][:r_s].cpu().numpy())
             cores = os.cpu_count() or 1
-            v, secs, _ = cpu_baseline(ps, cores)
-            cpu = {"value": v, "unit": "structures/s", "cores": cores, "kind": "port",
-                   "sample": f"first {ns} structures of the shard ({r_s} residues): 2x hash+sort+dedup (OpenMP over structures) + "
-                             f"count/fill table build with the reference's ownership partition over {cores} threads, {secs:.1f} s"}
+            v_all, st_all = cpu_baseline_build(ps, cores)
+            ps64 = fd.PackedStructures(off[: ns // 4 + 1], ps.n_xyz[: int(off[ns // 4])], ps.ca_xyz[: int(off[ns // 4])], ps.cb_xyz[: int(off[ns // 4])],
+                                       ps.aa[: int(off[ns // 4])])
+            v64, st64 = cpu_baseline_build(ps64, 64)
+            cpu = {"value": v_all, "unit": "structures/s", "cores": cores, "kind": "port",
+                   "sample": f"first {ns} structures of the database ({r_s} residues): 2x hash+sort+dedup (OpenMP over structures) + count/fill "
+                             f"table build with the reference's ownership partition, {cores} threads, {sum(st_all.values()):.1f} s",
+                   "stages_s": {k: round(v, 2) for k, v in st_all.items()},
+                   "t64": {"value": v64, "cores": 64, "sample": f"first {ns // 4} structures, 64 threads (README's -t 64), {sum(st64.values()):.1f} s",
+                           "stages_s": {k: round(v, 2) for k, v in st64.items()}}}
         out = {
             "metric": "structures/sec indexed", "value": value, "unit": "structures/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
-            "config": {"workload": f"Swiss-Prot/8 shard per GPU: {S} synthetic AFDB-shaped structures ({R} residues, "
-                                   f"{n_post} postings, {n_hash} distinct hashes, {vlen} value bytes) index build, PDBTrRosetta default",
-                       "structures_per_gpu": S, "residues_per_gpu": R, "postings_per_gpu": n_post, "parallelism": f"shard-by-structure x{world}"},
-            "roofline": roofline, "pipelined": pipelined, "cpu_baseline": cpu, "query": query,
+            "config": {"workload": f"Swiss-Prot scale: {S_total} synthetic AFDB-shaped structures ({int(R_tot)} residues, {int(post_tot)} postings, "
+                                   f"{int(vlen_tot)} value bytes) index build, PDBTrRosetta default; {world} rank(s), contiguous id ranges, "
+                                   f"per rank {-(-S // GEN_BLOCK)} build call(s) of <= {GEN_BLOCK} structures merged on the device into one resident index",
+                       "structures": S_total, "structures_per_gpu": S, "residues": int(R_tot), "postings": int(post_tot),
+                       "parallelism": f"shard-by-structure x{world}"},
+            "roofline": roofline, "export_inclusive": export, "cpu_baseline": cpu, "query": query,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -158,6 +158,8 @@ SYMBOLS = [
     ("fdgpu_matches_free", None, [C.POINTER(MatchRec), C.POINTER(C.c_int32)]),
     ("fdgpu_merge_subindices", C.c_int, [C.c_uint64, C.POINTER(u8p), C.POINTER(u32p), C.POINTER(u64p), u64p, C.POINTER(u8p), u64p,
                                          C.POINTER(u32p), C.POINTER(u64p), u64p]),
+    ("fdgpu_index_merge", C.c_int, [VP, C.POINTER(VP), C.c_uint64, C.POINTER(VP)]),
+    ("fdgpu_posting_bytes", C.c_int, [VP, VP, u32p, C.c_uint64, u64p]),
     ("fdgpu_debug_libm", C.c_int, [VP, C.c_int, f32p, f32p, f32p, C.c_uint64]),
 ]
 

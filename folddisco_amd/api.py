@@ -246,6 +246,46 @@ class FolddiscoIndex:
         return out
 
 
+    def posting_bytes(self, q_hash: np.ndarray) -> np.ndarray:
+        q = np.ascontiguousarray(q_hash, dtype=np.uint32)
+        out = np.zeros(len(q), dtype=np.uint64)
+        self.ctx.check(self.ctx.L.fdgpu_posting_bytes(self.ctx.h, self.h, _ptr(q, u32p), len(q), _ptr(out, u64p)))
+        return out
+
+    def export_view(self):
+        """export() without the extra host copy: numpy views of the malloc'd buffers (freed with the arrays)"""
+        vp, hp, op = u8p(), u32p(), u64p()
+        vl, H = C.c_uint64(), C.c_uint64()
+        L = self.ctx.L
+        self.ctx.check(L.fdgpu_index_export(self.ctx.h, self.h, C.byref(vp), C.byref(vl), C.byref(hp), C.byref(op), C.byref(H)))
+
+        class _Owner:
+            def __init__(self, ptrs):
+                self.ptrs = ptrs
+
+            def __del__(self):
+                for p in self.ptrs:
+                    L.fdgpu_free(p)
+        own = _Owner((vp, hp, op))
+
+        def view(ptr, n, dt):
+            a = np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n]
+            a = a.view(dt) if a.dtype != dt else a
+            return _Keep(a, own)
+        return view(vp, vl.value, np.uint8), view(hp, H.value, np.uint32), view(op, H.value + 1, np.uint64)
+
+
+class _Keep(np.ndarray):
+    """ndarray view that keeps the owner of its buffer alive"""
+    def __new__(cls, arr, owner):
+        obj = np.asarray(arr).view(cls)
+        obj._owner = owner
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
+
+
 class FolddiscoIndexSet:
     """Several resident sub-indices over consecutive, disjoint structure-id ranges, queried as one index: a shard of more than
     2^32 residue pairs is built as a sequence of fdgpu_index_build calls (one per chunk of structures) and never merged on the
@@ -282,6 +322,14 @@ class FolddiscoIndexSet:
     @property
     def num_postings(self) -> int:
         return sum(p.num_postings for p in self.parts)
+
+    def merge(self) -> "FolddiscoIndex":
+        """ONE resident index over all the parts (fdgpu_index_merge: per-hash concatenation on the device)"""
+        ctx = self.ctx
+        arr = (C.c_void_p * len(self.parts))(*[p.h for p in self.parts])
+        h = C.c_void_p()
+        ctx.check(ctx.L.fdgpu_index_merge(ctx.h, arr, len(self.parts), C.byref(h)))
+        return FolddiscoIndex(ctx, h, self.n_structures, self.first_id)
 
     def export_merged(self):
         """-> (value, hashes, offsets) of the single merged index (host-side per-hash concatenation)"""

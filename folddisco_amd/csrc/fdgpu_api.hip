@@ -592,6 +592,95 @@ extern "C" int fdgpu_index_load(fdgpu_ctx *c, const uint32_t *hashes, const uint
     return FDGPU_OK;
 }
 
+// ---- device merge of sub-indices (k_merge.hip) ---------------------------------------------------------------------
+struct mg_part_h { const uint32_t *hashes; const uint64_t *offsets; const uint8_t *value; uint64_t H; };
+void fd_mg_bitmap_set(const uint32_t *hashes, uint64_t n, uint32_t *bitmap, hipStream_t st);
+void fd_mg_popc(const uint32_t *bitmap, uint64_t n_words, uint32_t *cnt, hipStream_t st);
+void fd_mg_expand(const uint32_t *bitmap, const uint64_t *prefix, uint64_t n_words, uint32_t *out, hipStream_t st);
+void fd_mg_pos_fill(const uint32_t *hashes, uint64_t n, const uint32_t *bitmap, const uint64_t *prefix, uint32_t *pos, uint32_t part, uint32_t n_parts,
+                    hipStream_t st);
+void fd_mg_sizes(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, uint32_t *sizes, hipStream_t st);
+void fd_mg_copy(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, const uint64_t *out_off, uint8_t *out_value, hipStream_t st);
+
+extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, uint64_t n_parts, fdgpu_index **out) {
+    if (!c || !out || !n_parts || !parts) return FDGPU_EINVAL;
+    *out = nullptr;
+    if (n_parts > 64) FAIL(c, FDGPU_ERANGE, "index merge: at most 64 parts per call (merge in rounds)");
+    reset_timings(c);
+    hipStream_t st = c->stream;
+    uint64_t n_struct = 0, n_post = 0, sum_h = 0, sum_v = 0;
+    std::vector<mg_part_h> ph(n_parts);
+    for (uint64_t k = 0; k < n_parts; ++k) {
+        const fdgpu_index *p = parts[k];
+        if (!p) return FDGPU_EINVAL;
+        if (k && p->first_id != parts[k - 1]->first_id + parts[k - 1]->n_structures)
+            FAIL(c, FDGPU_EINVAL, "index merge: parts must cover consecutive structure-id ranges in the order given");
+        ph[k] = {p->hashes, p->offsets, p->value, p->n_hashes};
+        n_struct += p->n_structures; n_post += p->n_postings; sum_h += p->n_hashes; sum_v += p->value_len;
+    }
+    // hash space: 2^30 unless a part holds an overflowed hash (unmasked OR of the fields)
+    uint32_t max_hash = 0;
+    for (uint64_t k = 0; k < n_parts; ++k)
+        if (parts[k]->n_hashes) {
+            uint32_t h = 0;
+            HIPCHK(c, hipMemcpyAsync(&h, parts[k]->hashes + parts[k]->n_hashes - 1, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            max_hash = std::max(max_hash, h);
+        }
+    const uint64_t n_words = max_hash < (1u << 30) ? (1ull << 25) : (1ull << 27);
+    HIPCHK(c, c->ws[WS_KEYS_A].ensure(n_words * 4));
+    HIPCHK(c, c->ws[WS_KEYS_B].ensure(n_words * 4));
+    HIPCHK(c, c->ws[WS_IDS_A].ensure((n_words + 2) * 8));
+    HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(std::max<uint64_t>(n_words, sum_h)) * 8 + 64));
+    HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
+    HIPCHK(c, c->ws[WS_MISC4].ensure(n_parts * sizeof(mg_part_h)));
+    uint32_t *bitmap = c->ws[WS_KEYS_A].as<uint32_t>(), *cnt = c->ws[WS_KEYS_B].as<uint32_t>();
+    uint64_t *prefix = c->ws[WS_IDS_A].as<uint64_t>();
+    uint64_t Ht = 0;
+    {
+        StageTimer t(c, "merge_union", sum_h * 4 + n_words * 24);
+        HIPCHK(c, hipMemsetAsync(bitmap, 0, n_words * 4, st));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC4].p, ph.data(), n_parts * sizeof(mg_part_h), hipMemcpyHostToDevice, st));
+        for (uint64_t k = 0; k < n_parts; ++k) fd_mg_bitmap_set(ph[k].hashes, ph[k].H, bitmap, st);
+        fd_mg_popc(bitmap, n_words, cnt, st);
+        fd_exclusive_scan<uint32_t>(cnt, n_words, prefix, c->ws[WS_SCANTMP].as<uint64_t>(), c->ws[WS_TOTAL].as<uint64_t>(), st);
+    }
+    HIPCHK(c, hipGetLastError());
+    int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &Ht);
+    if (rc) return rc;
+    fdgpu_index *ix = new (std::nothrow) fdgpu_index();
+    if (!ix) return FDGPU_ENOMEM;
+    ix->ctx = c; ix->n_hashes = Ht; ix->n_postings = n_post; ix->n_structures = n_struct; ix->first_id = parts[0]->first_id;
+    hipError_t e;
+    ix->hashes = (uint32_t *)c->pool_alloc(std::max<uint64_t>(Ht, 1) * 4, &e); ix->cap_hashes = c->last_cap;
+    if (e == hipSuccess) { ix->offsets = (uint64_t *)c->pool_alloc((Ht + 1) * 8, &e); ix->cap_offsets = c->last_cap; }
+    if (e == hipSuccess) e = c->ws[WS_IDS_B].ensure(std::max<uint64_t>(Ht, 1) * n_parts * 4);
+    if (e == hipSuccess) e = c->ws[WS_MISC0].ensure(std::max<uint64_t>(Ht, 1) * 4);
+    if (e != hipSuccess) { c->err = std::string("index merge alloc: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }
+    uint32_t *pos = c->ws[WS_IDS_B].as<uint32_t>(), *sizes = c->ws[WS_MISC0].as<uint32_t>();
+    {
+        StageTimer t(c, "merge_sizes", sum_v + sum_h * 20 + Ht * n_parts * 8 + Ht * 16);
+        fd_mg_expand(bitmap, prefix, n_words, ix->hashes, st);
+        (void)hipMemsetAsync(pos, 0xff, std::max<uint64_t>(Ht, 1) * n_parts * 4, st);
+        for (uint64_t k = 0; k < n_parts; ++k) fd_mg_pos_fill(ph[k].hashes, ph[k].H, bitmap, prefix, pos, (uint32_t)k, (uint32_t)n_parts, st);
+        fd_mg_sizes(c->ws[WS_MISC4].p, (uint32_t)n_parts, pos, Ht, sizes, st);
+        fd_exclusive_scan<uint32_t>(sizes, Ht, ix->offsets, c->ws[WS_SCANTMP].as<uint64_t>(), c->ws[WS_TOTAL].as<uint64_t>(), st);
+    }
+    e = hipGetLastError();
+    uint64_t vlen = 0;
+    if (e == hipSuccess) { rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &vlen); if (rc) { fdgpu_index_destroy(ix); return rc; } }
+    if (e == hipSuccess) { ix->value_len = vlen; ix->value = (uint8_t *)c->pool_alloc(std::max<uint64_t>(vlen, 4), &e); ix->cap_value = c->last_cap; }
+    if (e != hipSuccess) { c->err = std::string("index merge: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }
+    {
+        StageTimer t(c, "merge_copy", sum_v + vlen + Ht * n_parts * 4);
+        fd_mg_copy(c->ws[WS_MISC4].p, (uint32_t)n_parts, pos, Ht, ix->offsets, ix->value, st);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) { c->err = std::string("index merge copy: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }
+    *out = ix;
+    return FDGPU_OK;
+}
+
 // byte-identical to wrapup_offset_and_save_entries + save_offset_to_file (indextable.rs:239-264, 297-326)
 extern "C" int fdgpu_index_save(fdgpu_ctx *c, const fdgpu_index *ix, const char *prefix) {
     if (!c || !ix || !prefix) return FDGPU_EINVAL;
@@ -623,6 +712,21 @@ extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const 
     fd_launch_posting_lengths(ix->hashes, ix->offsets, ix->value, ix->n_hashes, c->ws[WS_MISC0].as<uint32_t>(), nq, c->ws[WS_MISC1].as<uint64_t>(), st);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(lengths, c->ws[WS_MISC1].p, nq * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return FDGPU_OK;
+}
+
+void fd_launch_posting_bytes(const uint32_t *hashes, const uint64_t *offsets, uint64_t H, const uint32_t *q_hash, uint64_t nq, uint64_t *bytes, hipStream_t st);
+extern "C" int fdgpu_posting_bytes(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *bytes) {
+    if (!c || !ix || (nq && (!q_hash || !bytes))) return FDGPU_EINVAL;
+    if (!nq) return FDGPU_OK;
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->ws[WS_MISC0].ensure(nq * 4));
+    HIPCHK(c, c->ws[WS_MISC1].ensure(nq * 8));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st));
+    fd_launch_posting_bytes(ix->hashes, ix->offsets, ix->n_hashes, c->ws[WS_MISC0].as<uint32_t>(), nq, c->ws[WS_MISC1].as<uint64_t>(), st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(bytes, c->ws[WS_MISC1].p, nq * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     return FDGPU_OK;
 }

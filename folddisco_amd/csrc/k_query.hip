@@ -46,6 +46,18 @@ __global__ __launch_bounds__(FD_WAVE) void k_posting_lengths(const uint32_t *__r
 }
 
 
+// byte length of each query hash's posting list (get_raw_entries(h).len(), indextable.rs:53-81): the varint bytes a scoring pass reads
+__global__ void k_posting_bytes(const uint32_t *__restrict__ hashes, const uint64_t *__restrict__ offsets, uint64_t H, const uint32_t *__restrict__ q_hash,
+                                uint64_t nq, uint64_t *__restrict__ bytes) {
+    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int64_t k = find_hash(hashes, H, q_hash[q]);
+    bytes[q] = k >= 0 ? offsets[k + 1] - offsets[k] : 0ull;
+}
+void fd_launch_posting_bytes(const uint32_t *hashes, const uint64_t *offsets, uint64_t H, const uint32_t *q_hash, uint64_t nq, uint64_t *bytes, hipStream_t st) {
+    if (nq) hipLaunchKernelGGL(k_posting_bytes, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, hashes, offsets, H, q_hash, nq, bytes);
+}
+
 // get_entries (src/index/indextable.rs:83-86, 439-463): posting list of every query hash decoded to structure ids.
 // Same wave-parallel varint decode as the scoring kernel; ids go to out[out_off[q] ...] in list order.
 __global__ __launch_bounds__(FD_WAVE) void k_get_entries(const uint32_t *__restrict__ hashes, const uint64_t *__restrict__ offsets,

@@ -70,6 +70,72 @@ def allgather_hits(local: np.ndarray, device: torch.device, top_n: int | None = 
     return rank_hits(np.concatenate(parts), top_n)
 
 
+def _active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _dev(device):
+    return device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+
+
+def allreduce_sum(x: int, device: torch.device | None = None) -> int:
+    if not _active():
+        return int(x)
+    t = torch.tensor([int(x)], dtype=torch.int64, device=_dev(device))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def allgather_array(local: np.ndarray, device: torch.device | None = None) -> np.ndarray:
+    """all-gather of a variable-length array of fixed-size records (any dtype, e.g. query.MATCH_DTYPE): sizes first, then one padded
+    all_gather of the raw bytes.  Returns the concatenation in rank order (identical on every rank)."""
+    if not _active():
+        return local
+    world, dv = dist.get_world_size(), _dev(device)
+    n = torch.tensor([len(local)], dtype=torch.int64, device=dv)
+    sizes = torch.zeros(world, dtype=torch.int64, device=dv)
+    dist.all_gather_into_tensor(sizes, n)
+    sizes = sizes.cpu().tolist()
+    isz = local.dtype.itemsize
+    mx = max(max(sizes), 1)
+    buf = np.zeros(mx * isz, np.uint8)
+    buf[: len(local) * isz] = np.ascontiguousarray(local).view(np.uint8).reshape(-1)
+    out = torch.empty(world * mx * isz, dtype=torch.uint8, device=dv)
+    dist.all_gather_into_tensor(out, torch.from_numpy(buf).to(dv))
+    o = out.cpu().numpy().reshape(world, mx * isz)
+    return np.concatenate([o[r, : sizes[r] * isz].view(local.dtype) for r in range(world)])
+
+
+def allgather_hits_many(locals_: list, device: torch.device | None = None, top_n: int | None = None) -> list:
+    """allgather_hits for a batch of queries with TWO collectives in total (all the sizes, then one padded payload): locals_[t] =
+    this rank's candidate records of query t.  Returns the global ranking of every query (identical on every rank)."""
+    if top_n is not None:
+        locals_ = [rank_hits(r, top_n) for r in locals_]
+    if not _active():
+        return [r if top_n is not None else rank_hits(r, None) for r in locals_]
+    world, dv, T = dist.get_world_size(), _dev(device), len(locals_)
+    n = torch.tensor([len(r) for r in locals_], dtype=torch.int64, device=dv)
+    sizes = torch.zeros(world * T, dtype=torch.int64, device=dv)
+    dist.all_gather_into_tensor(sizes, n)
+    sizes = sizes.cpu().numpy().reshape(world, T)
+    tot = sizes.sum(axis=1)
+    mx = max(int(tot.max()), 1)
+    isz = REC_DTYPE.itemsize
+    buf = np.zeros(mx * isz, np.uint8)
+    if T and int(tot[dist.get_rank()]):
+        cat = np.concatenate(locals_)
+        buf[: len(cat) * isz] = cat.view(np.uint8).reshape(-1)
+    out = torch.empty(world * mx * isz, dtype=torch.uint8, device=dv)
+    dist.all_gather_into_tensor(out, torch.from_numpy(buf).to(dv))
+    o = out.cpu().numpy().reshape(world, mx * isz)
+    starts = np.concatenate([np.zeros((world, 1), np.int64), np.cumsum(sizes, axis=1)], axis=1)
+    res = []
+    for t in range(T):
+        parts = [o[r, starts[r, t] * isz: starts[r, t + 1] * isz].view(REC_DTYPE) for r in range(world)]
+        res.append(rank_hits(np.concatenate(parts), top_n))
+    return res
+
+
 def reduce_lengths(lens: np.ndarray, device: torch.device | None = None) -> np.ndarray:
     """posting lengths of one shard -> posting lengths over all shards (all-reduce SUM; identity without a process group).
     idf = log2(S / len) must see the whole database, or the sharded hit list differs from the single-index one."""

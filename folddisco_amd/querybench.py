@@ -1,12 +1,20 @@
-"""Motif-query leg of bench.py: Q planted motif queries scored against the resident shard(s).
+"""Motif-query leg of bench.py: Q planted motif queries scored against the resident index of the rank's shard.
 
-A query = 4 residues of a shard structure that lie within 10 A of each other (so it has hits by construction),
-default expansion (-d 0.5 -a 5).  Per query every rank runs make_query_map (features / hashes / posting lengths on
-the GPU), count_query on its shard, keeps its top-N candidates and the ranks all-gather the candidate records
-(RCCL).  queries/s = Q / wall time of the loop (max over ranks).  With match=True the top candidates of the local
-shard additionally go through the pair scan + graph + Kabsch (retrieval)."""
+A query = 4 residues of a database structure that lie within 10 A of each other (so it has hits by construction),
+default expansion (-d 0.5 -a 5).  The index and the coordinates are sharded by structure id over the ranks;
+per batch of 32 queries every rank runs make_query_map_batch (features / hashes on the GPU), all-reduces the posting
+lengths (idf over the WHOLE database), scores its shard (count_query_batch_top), the ranks all-gather the candidate
+records (RCCL) and rank them globally (idf descending, top_n = 1000).  With matching, the first match_top candidates of
+the GLOBAL ranking are retrieved on the rank that owns them (pair scan + components + Kabsch) and the match records are
+all-gathered.  queries/s = Q / wall time of the loop (max over ranks).
+
+Roofline: B_q = sum of posting bytes of the query's hashes + 8 T (touched structures) + (nodes + edges) S / 8,
+over the HIP-event time of the scoring stage (k_cq_accumulate_batch + finalize + compaction scan).
+cpu_baseline: oracle/fdo_bench.c (the reference's make_query_map + count_query + retrieval per query, OpenMP over queries
+where the reference uses rayon) against the SAME index (the export of the resident index) on the host cores."""
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -14,7 +22,7 @@ import torch
 
 from . import dist as fdist
 from .api import PackedStructures, count_query, count_query_batch, idf_of_lengths, length_penalty
-from .query import make_query_map, make_query_maps, retrieve, retrieve_batch
+from .query import MATCH_DTYPE, make_query_map, make_query_maps, retrieve, retrieve_batch
 
 
 def _pick_queries(d, S, n_queries, seed, k=4):
@@ -39,61 +47,77 @@ def _pick_queries(d, S, n_queries, seed, k=4):
     return out
 
 
-def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, match_top=32, seed=4242):
+def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, match_top=32, seed=4242, lo=0, S_total=None,
+        cpu_baseline=False, hbm_peak_gbs=8000.0):
+    S_total = S * world if S_total is None else S_total
+    sharded = dist is not None          # every rank holds the postings of its own structures only
     # rank 0 cuts the motifs out of its shard and broadcasts them: every rank scores the SAME queries against its own shard
     queries = _pick_queries(d, S, n_queries, seed) if rank == 0 else None
-    if dist is not None:
+    if sharded:
         box = [queries]
         dist.broadcast_object_list(box, src=0, device=dev if dist.get_backend() == "nccl" else None)
         queries = box[0]
-    nres = np.diff(d["res_off"].cpu().numpy()).astype(np.uint64)
+    res_off_h = d["res_off"].cpu().numpy()
+    nres = np.diff(res_off_h).astype(np.uint64)
     pen = length_penalty(nres, 0.5)
-    S_total = S * world
-    sharded = dist is not None          # every rank holds the postings of its own structures only
     qbatches = [ctx.upload(PackedStructures.concat([it])) for _, _, it in queries]
     qall = ctx.upload(PackedStructures.concat([it for _, _, it in queries]))    # every query structure in one batch (batched legs)
+    first = ix.first_id
+
+    def set_global_idf(qm):
+        pl = fdist.global_posting_lengths(ix, qm.primary_hash, dev)
+        qm.set_idf(np.where(pl > 0, idf_of_lengths(np.maximum(pl, 1), S_total), 0.0).astype(np.float32))
+
+    def owned(glob, n):
+        """candidate slots (local structure indices) of the first n records of the global ranking that this rank owns"""
+        nid = glob["nid"][:n].astype(np.int64)
+        mine = nid[(nid >= first) & (nid < first + S)]
+        return (mine - first).astype(np.uint32)
 
     def one(k, match):
         s, idx, _ = queries[k]
         qm = make_query_map(ctx, qbatches[k], idx, None, None if sharded else ix, float(S_total))
         lens = fdist.global_posting_lengths(ix, qm.hash, dev) if sharded else None      # idf over the whole database
         if sharded and match:
-            pl = fdist.global_posting_lengths(ix, qm.primary_hash, dev)
-            qm.set_idf(np.where(pl > 0, idf_of_lengths(np.maximum(pl, 1), S_total), 0.0).astype(np.float32))
+            set_global_idf(qm)
         recs = count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total, as_array=True, lengths=lens)
         glob = fdist.allgather_hits(recs, dev, top_n=top_n)
         n_match = 0
-        if match and len(recs):
-            local_top = fdist.rank_hits(recs, match_top)
-            cand = (local_top["nid"] - ix.first_id).astype(np.uint32)
-            ms = retrieve(ctx, batch, None, cand, qm, qbatches[k])
-            n_match = len(ms)
+        if match and len(glob):
+            cand = owned(glob, match_top)
+            ms = retrieve(ctx, batch, None, cand, qm, qbatches[k]) if len(cand) else []
+            n_match = len(ms) if not sharded else int(fdist.allreduce_sum(len(ms), dev))
         return len(glob), len(qm.hash), n_match
 
-    def timed(match):
-        for k in range(min(8, len(queries))):   # warm: scratch buffers reach their steady-state sizes
-            one(k, match)
+    def timed(fn):
         torch.cuda.synchronize()
-        if dist is not None:
+        if sharded:
             dist.barrier()
         t0 = time.perf_counter()
-        tot_hits = tot_hashes = tot_m = 0
-        for k in range(len(queries)):
-            h, q, m = one(k, match)
-            tot_hits += h; tot_hashes += q; tot_m += m
+        r = fn()
         torch.cuda.synchronize()
-        if dist is not None:
+        if sharded:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if dist is not None:
+        if sharded:
             t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt, tot_hits, tot_hashes, tot_m
+        return dt, r
+
+    def loop(match, ks):
+        def go():
+            th = tq = tm = 0
+            for k in ks:
+                h, q, m = one(k, match)
+                th += h; tq += q; tm += m
+            return th, tq, tm
+        return go
 
     def batched(chunk=32, match=False):
-        """throughput mode: query maps per query, then ONE posting-length launch + ONE scoring pass per chunk of queries;
-        with match=True the local top candidates of every query additionally go through retrieval"""
+        """throughput mode: query maps per chunk of queries, ONE posting-length launch + ONE scoring pass per chunk; with
+        match=True the first match_top candidates of every query's GLOBAL ranking additionally go through retrieval on
+        their owning rank (one pair scan / gather / Kabsch launch per chunk) and the match records are all-gathered"""
         def go():
             tot = 0
             for c0 in range(0, len(queries), chunk):
@@ -101,61 +125,99 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                 qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix if (match and not sharded) else None, float(S_total))
                 if match and sharded:
                     for qm in qms:
-                        pl = fdist.global_posting_lengths(ix, qm.primary_hash, dev)
-                        qm.set_idf(np.where(pl > 0, idf_of_lengths(np.maximum(pl, 1), S_total), 0.0).astype(np.float32))
+                        set_global_idf(qm)
                 recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=top_n,
                                          lengths_fn=(lambda l: fdist.reduce_lengths(l, dev)) if sharded else None)
-                cl = []
-                for k, qm, r in zip(ks, qms, recs):
-                    n = len(fdist.allgather_hits(r, dev, top_n=top_n))
-                    if match:
-                        cl.append((fdist.rank_hits(r, match_top)["nid"] - ix.first_id).astype(np.uint32) if len(r) else np.zeros(0, np.uint32))
-                    else:
-                        tot += n
+                globs = fdist.allgather_hits_many(recs, dev, top_n=top_n)
                 if match:   # one pair scan / gather / Kabsch launch for the whole chunk of queries
-                    tot += len(retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0])
+                    cl = [owned(g, match_top) for g in globs]
+                    marr = retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0]
+                    tot += len(fdist.allgather_array(marr, dev)) if sharded else len(marr)
+                else:
+                    tot += sum(len(g) for g in globs)
             return tot
         go()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        tot = go()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, tot
+        return timed(go)
 
-    dt1, hits, hashes, _ = timed(False)
+    warm = range(min(8, len(queries)))
+    loop(False, warm)()
+    dt1, (hits, hashes, _) = timed(loop(False, range(len(queries))))
     dtb, hits_b = batched()
     dtbm, nm_b = batched(match=True)
-    dt2, _, _, nm = timed(True)
-    # roofline of the scoring kernel for the last query (HIP events on the context's stream)
+    loop(True, warm)()
+    dt2, (_, _, nm) = timed(loop(True, range(len(queries))))
+
+    # ---- roofline of the scoring stage: one batch of 32 queries with HIP events on the context's stream
+    ks = range(min(32, len(queries)))
+    qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], None, float(S_total))
+    lens_fn = (lambda l: fdist.reduce_lengths(l, dev)) if sharded else None
     ctx.enable_timing(True)
-    s, idx, _ = queries[-1]
-    qm = make_query_map(ctx, qbatches[-1], idx, None, ix, float(S_total))
-    lens = ix.posting_lengths(qm.hash)
-    rows = count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total)
+    recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=0, lengths_fn=lens_fn)
     ctx.synchronize()
-    st = {n: ms for n, ms, _ in ctx.last_timings()}
+    st_score = {n: ms for n, ms, _ in ctx.last_timings()}
+    cl = [(fdist.rank_hits(r, match_top)["nid"].astype(np.int64) - first).astype(np.uint32) for r in recs]
+    if not sharded:
+        qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix, float(S_total))
+    marr = retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0]
+    ctx.synchronize()
+    st_match = {n: ms for n, ms, _ in ctx.last_timings()}
     ctx.enable_timing(False)
+    post_bytes = int(sum(int(ix.posting_bytes(qm.hash).sum()) for qm in qms))
+    touched = int(sum(len(r) for r in recs))
+    n_rows = int(sum(len(np.unique(qm.qi)) + len(np.unique(qm.qi.astype(np.uint64) << np.uint64(32) | qm.qj.astype(np.uint64))) for qm in qms))
+    b_q = post_bytes + 8 * touched + n_rows * ((S + 31) // 32) * 4
+    t_score = st_score.get("cq_batch", 0.0)
+    cand_res = int(sum(int(nres[c].sum()) for c in cl))
+    t_match = st_match.get("match_pairs", 0.0)
+    roofline = {
+        "bound": "hbm", "kernel": "cq_batch (k_cq_accumulate_batch + finalize + compaction scan)", "queries_per_launch": len(ks),
+        "algorithmic_bytes_per_launch": b_q, "posting_bytes": post_bytes, "touched_structures": touched, "occupancy_rows": n_rows,
+        "avg_ms": t_score, "achieved": b_q / (t_score * 1e-3) / 1e9 if t_score > 0 else None, "peak": hbm_peak_gbs, "unit": "GB/s",
+        "frac": b_q / (t_score * 1e-3) / 1e9 / hbm_peak_gbs if t_score > 0 else None, "traffic": None,
+        "note": "latency / atomic bound by construction: ~%d KB of postings per query against a %d-structure shard" % (post_bytes // max(len(ks), 1) // 1024, S),
+        "match_pairs": {"algorithmic_bytes_per_launch": 37 * cand_res + 16 * len(marr), "candidates": int(sum(len(c) for c in cl)), "avg_ms": t_match,
+                        "achieved": (37 * cand_res + 16 * len(marr)) / (t_match * 1e-3) / 1e9 if t_match > 0 else None, "unit": "GB/s",
+                        "note": "pair scan of the top %d candidates of %d queries; VALU-bound like the index build's pair kernel" % (match_top, len(ks))},
+    }
+
+    cpu = None
+    if cpu_baseline:
+        try:
+            import oracle
+            v, h, o = ix.export_view()
+            n_xyz, ca_xyz, cb_xyz, aa = (d[k].cpu().numpy() for k in ("n_xyz", "ca_xyz", "cb_xyz", "aa"))
+            cores = os.cpu_count() or 1
+            qlist = [(s, idx) for s, idx, _ in queries]
+            reps = max(1, min(8, cores // max(len(qlist), 1)))     # enough queries to occupy the cores
+            r_all = oracle.query_bench(h, o, v, nres, res_off_h.astype(np.uint64), n_xyz, ca_xyz, cb_xyz, aa, qlist * reps, top_n=top_n,
+                                       match_top=match_top, n_threads=cores)
+            r64 = oracle.query_bench(h, o, v, nres, res_off_h.astype(np.uint64), n_xyz, ca_xyz, cb_xyz, aa, qlist, top_n=top_n,
+                                     match_top=match_top, n_threads=min(64, cores))
+            cpu = {"value": len(qlist) * reps / r_all["wall_s"], "unit": "queries/s", "cores": cores, "kind": "port",
+                   "sample": "the same %d queries x%d against the export of the same resident index (%d structures): make_query_map + count_query + "
+                             "sort/truncate %d + retrieval of the top %d, OpenMP over queries (query_pdb.rs:348), %.1f s wall" %
+                             (len(qlist), reps, S, top_n, match_top, r_all["wall_s"]),
+                   "stage_thread_s": {k: round(x, 2) for k, x in r_all["stage_thread_s"].items()}, "matches": r_all["matches"] // reps,
+                   "t64": {"value": len(qlist) / r64["wall_s"], "cores": min(64, cores), "wall_s": round(r64["wall_s"], 2),
+                           "stage_thread_s": {k: round(x, 2) for k, x in r64["stage_thread_s"].items()}}}
+            del v, h, o
+        except Exception as e:  # noqa: BLE001 — the bench line must still be printed
+            cpu = {"error": repr(e)}
+
     return {
         # headline = the reference's default query (prefilter + candidate selection + matching + RMSD), 32 queries per launch set
         "metric": "motif queries/sec", "value": len(queries) / dtbm, "unit": "queries/s", "n_queries": len(queries),
-        "mode": "full query (make_query_map, count_query, all-gather + top-N, retrieval of the top %d candidates, Kabsch, metrics), "
-                "batches of 32 queries" % match_top,
+        "structures": S_total, "structures_per_gpu": S,
+        "mode": "full query (make_query_map, count_query, all-gather + global top-%d, retrieval of the global top %d candidates on their owning "
+                "rank, Kabsch, metrics), batches of 32 queries" % (top_n, match_top),
         "ms_per_query": dtbm / len(queries) * 1e3,
-        "batched_with_matching": {"value": len(queries) / dtbm, "ms_per_query": dtbm / len(queries) * 1e3, "matches": nm_b, "match_top": match_top},
+        "batched_with_matching": {"value": len(queries) / dtbm, "ms_per_query": dtbm / len(queries) * 1e3, "matches": int(nm_b), "match_top": match_top},
         "batched": {"value": len(queries) / dtb, "ms_per_query": dtb / len(queries) * 1e3, "chunk": 32, "avg_hits": hits_b / len(queries),
-                    "mode": "prefilter only: make_query_map_batch + count_query_batch_top + all-gather, eight launches per 32 queries"},
+                    "mode": "prefilter only: make_query_map_batch + count_query_batch_top + all-gather"},
         "single": {"value": len(queries) / dt1, "ms_per_query": dt1 / len(queries) * 1e3, "mode": "prefilter only, one query per call"},
-        "with_matching": {"value": len(queries) / dt2, "ms_per_query": dt2 / len(queries) * 1e3, "matches": nm, "match_top": match_top,
+        "with_matching": {"value": len(queries) / dt2, "ms_per_query": dt2 / len(queries) * 1e3, "matches": int(nm), "match_top": match_top,
                           "mode": "full query, one query per call"},
         "avg_query_hashes": hashes / len(queries), "avg_hits": hits / len(queries),
-        "last_query": {"hashes": int(len(qm.hash)), "postings_decoded": int(lens.sum()), "touched": len(rows), "stages_ms": st},
+        "roofline": roofline, "cpu_baseline": cpu,
+        "stages_ms_per_32_queries": {**st_score, **st_match},
     }

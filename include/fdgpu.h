@@ -138,6 +138,10 @@ int fdgpu_index_save(fdgpu_ctx *ctx, const fdgpu_index *ix, const char *prefix);
 int fdgpu_posting_lengths(fdgpu_ctx *ctx, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t n_q,
                           uint64_t *lengths);
 
+/* byte length of the posting lists (get_raw_entries(h).len(), indextable.rs:53-81): what a scoring pass reads — the
+ * algorithmic-bytes figure of the query roofline; 0 for an absent hash */
+int fdgpu_posting_bytes(fdgpu_ctx *ctx, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t n_q, uint64_t *bytes);
+
 typedef struct fd_count_rec {   /* one touched structure (StructureResult prefilter fields) */
     uint32_t nid;
     uint32_t total_match_count;
@@ -302,6 +306,13 @@ void fdgpu_parsed_free(fd_parsed *p);
 int fdgpu_merge_subindices(uint64_t n_parts, const uint8_t *const *values, const uint32_t *const *hashes,
                            const uint64_t *const *offsets, const uint64_t *n_hashes, uint8_t **out_value,
                            uint64_t *out_value_len, uint32_t **out_hashes, uint64_t **out_offsets, uint64_t *out_n_hashes);
+
+/* The same merge on the device, for parts that are resident: a shard with more than 2^32 residue pairs is built as several
+ * fdgpu_index_build calls over consecutive id ranges (the reference walks its input in chunks the same way,
+ * src/controller/mod.rs:282-348) and the chunks' posting lists are concatenated per hash — first varint of every continuation
+ * re-based to a delta — into ONE resident index, byte-identical to the index a single build over all the structures produces
+ * (indextable.rs:171-202 appends ids in ascending order).  At most 64 parts per call; the parts stay valid. */
+int fdgpu_index_merge(fdgpu_ctx *ctx, const fdgpu_index *const *parts, uint64_t n_parts, fdgpu_index **out);
 
 /* Pairs that the speculative torsion evaluation of the index build (fd_geom.h, fd_pair_both_spec) re-evaluated with the
  * exact routine since the previous call; FDGPU_EXACT=1 in the environment disables the speculative path altogether. */

@@ -157,6 +157,12 @@ def lib():
     L.fdo_count_query.restype = C.c_uint64
     L.fdo_count_query.argtypes = [C.POINTER(QueryMap), VP, u64p, C.c_uint64, C.c_float, C.c_float,
                                   C.POINTER(C.POINTER(CountResult))]
+    L.fdo_index_borrow.restype = VP
+    L.fdo_index_borrow.argtypes = [u32p, u64p, C.c_uint64, u8p, C.c_uint64]
+    L.fdo_index_free_borrowed.argtypes = [VP]
+    L.fdo_query_bench.restype = C.c_double
+    L.fdo_query_bench.argtypes = [VP, u64p, C.c_uint64, u64p, f32p, f32p, f32p, u8p, C.c_uint64, u64p, u64p, u64p, C.c_uint64, C.c_uint64,
+                                  C.c_int, u64p, u64p, C.POINTER(C.c_double)]
     L.fdo_retrieve.restype = C.POINTER(Retrieval)
     L.fdo_retrieve.argtypes = [SP, SP, C.POINTER(QueryMap), C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float]
     L.fdo_retrieval_free.argtypes = [C.POINTER(Retrieval)]
@@ -493,3 +499,28 @@ def metrics(ref: np.ndarray, mov: np.ndarray, rot: np.ndarray, tran: np.ndarray)
     out = np.zeros(5, np.float32)
     lib().fdo_metrics(rp, mp, len(r_.reshape(-1, 3)), rop, tp, out.ctypes.data_as(f32p))
     return out
+
+
+def query_bench(hashes, offsets, values, nres, res_off, n_xyz, ca_xyz, cb_xyz, aa, queries, top_n=1000, match_top=32, n_threads=1):
+    """bench.py's query cpu_baseline (fdo_query_bench): queries = [(structure index, residue indices)] against the index given as
+    arrays (borrowed, not copied).  -> dict(wall_s, hits, matches, stage thread-seconds)"""
+    hashes = np.ascontiguousarray(hashes, np.uint32); offsets = np.ascontiguousarray(offsets, np.uint64); values = np.ascontiguousarray(values, np.uint8)
+    nres = np.ascontiguousarray(nres, np.uint64); res_off = np.ascontiguousarray(res_off, np.uint64)
+    n_xyz, ca_xyz, cb_xyz = (np.ascontiguousarray(a, np.float32) for a in (n_xyz, ca_xyz, cb_xyz))
+    aa = np.ascontiguousarray(aa, np.uint8)
+    qs = np.ascontiguousarray([q[0] for q in queries], np.uint64)
+    q_off = np.concatenate([[0], np.cumsum([len(q[1]) for q in queries])]).astype(np.uint64)
+    q_res = np.ascontiguousarray(np.concatenate([np.asarray(q[1], np.uint64) for q in queries]), np.uint64)
+    L = lib()
+    ix = L.fdo_index_borrow(hashes.ctypes.data_as(u32p), offsets.ctypes.data_as(u64p), len(hashes), values.ctypes.data_as(u8p), len(values))
+    hits, matches = C.c_uint64(), C.c_uint64()
+    st = (C.c_double * 3)()
+    try:
+        wall = L.fdo_query_bench(ix, nres.ctypes.data_as(u64p), len(nres), res_off.ctypes.data_as(u64p), n_xyz.ctypes.data_as(f32p),
+                                 ca_xyz.ctypes.data_as(f32p), cb_xyz.ctypes.data_as(f32p), aa.ctypes.data_as(u8p), len(queries),
+                                 qs.ctypes.data_as(u64p), q_off.ctypes.data_as(u64p), q_res.ctypes.data_as(u64p), top_n, match_top, n_threads,
+                                 C.byref(hits), C.byref(matches), st)
+    finally:
+        L.fdo_index_free_borrowed(ix)
+    return dict(wall_s=float(wall), hits=int(hits.value), matches=int(matches.value),
+                stage_thread_s=dict(make_query_map=st[0], count_query=st[1], retrieval=st[2]))

@@ -112,6 +112,9 @@ fdo_index *fdo_build_index_from_lists(const uint32_t *hashes, const uint64_t *of
 int fdo_hash_batch(const fdo_structure *const *structs, uint64_t S, uint64_t nbin_dist, uint64_t nbin_angle,
                    float dist_cutoff, uint32_t **out_hashes, uint64_t **out_off);
 fdo_index *fdo_build_index_from_lists_mt(const uint32_t *hashes, const uint64_t *off, uint64_t S, int n_threads);
+/* index over borrowed arrays (bench.py's query cpu_baseline) */
+fdo_index *fdo_index_borrow(const uint32_t *hashes, const uint64_t *offsets, uint64_t H, const uint8_t *values, uint64_t vlen);
+void fdo_index_free_borrowed(fdo_index *ix);
 int fdo_save_lookup(const char *path, const char *const *tids, const uint64_t *nres, const float *plddt,
                     const uint64_t *db_key, uint64_t S);
 int fdo_save_type(const char *path, uint64_t chunk_size, float grid_width, uint64_t max_residue,
@@ -159,6 +162,12 @@ typedef struct fdo_count_result {
 /* count_query (count_query.rs:82-220), no sampling. freq_filter < 0 => None. results nid-ascending. */
 uint64_t fdo_count_query(const fdo_query_map *m, const fdo_index *index, const uint64_t *nres, uint64_t S,
                          float freq_filter, float length_penalty, fdo_count_result **out);
+
+/* query half of bench.py's cpu_baseline (fdo_bench.c): OpenMP over queries like query_pdb.rs:348 */
+double fdo_query_bench(const fdo_index *ix, const uint64_t *nres, uint64_t S, const uint64_t *res_off, const float *n_xyz, const float *ca_xyz,
+                       const float *cb_xyz, const uint8_t *aa, uint64_t n_queries, const uint64_t *q_struct, const uint64_t *q_off,
+                       const uint64_t *q_res, uint64_t top_n, uint64_t match_top, int n_threads, uint64_t *n_hits, uint64_t *n_matches,
+                       double stage_s[3]);
 
 /* ---- retrieval + RMSD (src/controller/retrieve.rs, graph.rs, structure/kabsch.rs) -- */
 typedef struct fdo_match {

@@ -59,3 +59,70 @@ fdo_index *fdo_build_index_from_lists_mt(const uint32_t *hashes, const uint64_t 
     fdo_index_finish(ix);
     return ix;
 }
+
+/* Query half of bench.py's cpu_baseline: Q motif queries against an index, fanned out over queries with OpenMP exactly where the
+ * reference fans out (`queries.into_par_iter()`, cli/workflows/query_pdb.rs:348): per query make_query_map (query.rs:208-329,
+ * two get_entries per observed hash), count_query (count_query.rs:82-220), stable sort by idf descending + truncate
+ * (query_pdb.rs:404-411), retrieval_wrapper on the first match_top candidates (retrieve.rs:364-552; the reference re-reads and
+ * re-parses the candidate's file there — here the packed coordinates are handed over, parse time excluded on both sides).
+ * Query t = residues q_res[q_off[t] .. q_off[t+1]) (0-based indices) of database structure q_struct[t].
+ * stage_s[0..2] = thread-seconds spent in make_query_map / count_query / retrieval, summed over the threads.
+ * Returns the wall time in seconds. */
+#include <stdio.h>
+#include <time.h>
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static fdo_structure *struct_at(const uint64_t *res_off, const float *n_xyz, const float *ca_xyz, const float *cb_xyz, const uint8_t *aa, uint64_t s) {
+    uint64_t a = res_off[s], b = res_off[s + 1];
+    return fdo_structure_from_packed((int32_t)(b - a), n_xyz + 3 * a, ca_xyz + 3 * a, cb_xyz + 3 * a, NULL, aa + a, NULL);
+}
+typedef struct { float idf; uint64_t nid; uint64_t pos; } rank_t;
+static int rank_cmp(const void *x, const void *y) {
+    const rank_t *a = (const rank_t *)x, *b = (const rank_t *)y;
+    if (a->idf > b->idf) return -1;
+    if (a->idf < b->idf) return 1;
+    return a->pos < b->pos ? -1 : (a->pos > b->pos ? 1 : 0);   /* stable */
+}
+double fdo_query_bench(const fdo_index *ix, const uint64_t *nres, uint64_t S, const uint64_t *res_off, const float *n_xyz, const float *ca_xyz,
+                       const float *cb_xyz, const uint8_t *aa, uint64_t n_queries, const uint64_t *q_struct, const uint64_t *q_off,
+                       const uint64_t *q_res, uint64_t top_n, uint64_t match_top, int n_threads, uint64_t *n_hits, uint64_t *n_matches,
+                       double stage_s[3]) {
+    uint64_t hits = 0, matches = 0;
+    double s0 = 0, s1 = 0, s2 = 0;
+    const float dthr[1] = {0.5f}, athr[1] = {5.0f};
+    double t0 = now_s();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : hits, matches, s0, s1, s2)
+    for (int64_t t = 0; t < (int64_t)n_queries; ++t) {
+        double a = now_s();
+        fdo_structure *qs = struct_at(res_off, n_xyz, ca_xyz, cb_xyz, aa, q_struct[t]);
+        char buf[4096]; size_t w = 0;
+        for (uint64_t k = q_off[t]; k < q_off[t + 1] && w + 32 < sizeof buf; ++k)
+            w += (size_t)snprintf(buf + w, sizeof buf - w, "%sA%llu", k > q_off[t] ? "," : "", (unsigned long long)(q_res[k] + 1));
+        fdo_query_spec *sp = fdo_parse_query_string(buf, 'A');
+        fdo_query_map *m = fdo_make_query_map(qs, sp, 0, 0, dthr, 1, athr, 1, 20.0f, 0, ix, (float)S);
+        fdo_query_spec_free(sp);
+        double b = now_s();
+        fdo_count_result *res = NULL;
+        uint64_t n = fdo_count_query(m, ix, nres, S, -1.0f, 0.5f, &res);
+        rank_t *rk = (rank_t *)malloc((n ? n : 1) * sizeof *rk);
+        for (uint64_t k = 0; k < n; ++k) { rk[k].idf = res[k].idf; rk[k].nid = res[k].nid; rk[k].pos = k; }
+        qsort(rk, n, sizeof *rk, rank_cmp);
+        uint64_t keep = n < top_n ? n : top_n;
+        double c = now_s();
+        uint64_t nm = 0;
+        for (uint64_t k = 0; k < keep && k < match_top; ++k) {
+            fdo_structure *tg = struct_at(res_off, n_xyz, ca_xyz, cb_xyz, aa, rk[k].nid);
+            fdo_retrieval *r = fdo_retrieve(tg, qs, m, 2, 0, 0, 20.0f, 1.0f);
+            nm += r->n_matches;
+            fdo_retrieval_free(r);
+            fdo_structure_free(tg);
+        }
+        double d = now_s();
+        hits += keep; matches += nm; s0 += b - a; s1 += c - b; s2 += d - c;
+        free(rk); fdo_free(res); fdo_query_map_free(m); fdo_structure_free(qs);
+    }
+    double dt = now_s() - t0;
+    if (n_hits) *n_hits = hits;
+    if (n_matches) *n_matches = matches;
+    if (stage_s) { stage_s[0] = s0; stage_s[1] = s1; stage_s[2] = s2; }
+    return dt;
+}

@@ -364,3 +364,17 @@ int fdo_save_type(const char *path, uint64_t chunk_size, float grid_width, uint6
     fclose(f);
     return 0;
 }
+
+/* index over BORROWED arrays (bench.py's query cpu_baseline: the arrays are the GPU build's export, which the parity tests pin
+ * byte for byte to fdo_build_index); release with fdo_index_free_borrowed — the arrays stay the caller's */
+fdo_index *fdo_index_borrow(const uint32_t *hashes, const uint64_t *offsets, uint64_t H, const uint8_t *values, uint64_t vlen) {
+    fdo_index *ix = (fdo_index *)calloc(1, sizeof *ix);
+    ix->loaded = 1;
+    ix->H = H;
+    ix->hashes = (uint32_t *)hashes;
+    ix->offsets = (uint64_t *)offsets;
+    ix->entries = (uint8_t *)values;
+    ix->total_entries = vlen;
+    return ix;
+}
+void fdo_index_free_borrowed(fdo_index *ix) { free(ix); }

@@ -37,6 +37,17 @@ def _worker(rank, world, port, q):
     per_rank = [np.array([3, 0, 7, 2 ** 33], np.uint64), np.array([1, 0, 0, 5], np.uint64)]
     tot = fdist.reduce_lengths(per_rank[rank])
     ok = ok and tot.dtype == np.uint64 and tot.tolist() == [4, 0, 7, 2 ** 33 + 5]
+    # batched form: many queries, two collectives; generic fixed-size records; scalar sum
+    many_local = [local, local[:0], local[: len(local) // 2]]
+    many = fdist.allgather_hits_many(many_local, torch.device("cpu"), top_n=50)
+    for got, loc in zip(many, many_local):
+        ok = ok and np.array_equal(got, fdist.allgather_hits(loc, torch.device("cpu"), top_n=50))
+    dt = np.dtype([("a", np.uint32), ("v", np.float32, (3,))])
+    mine = np.zeros(3 + 2 * rank, dt)
+    mine["a"] = 100 * rank + np.arange(len(mine))
+    cat = fdist.allgather_array(mine, torch.device("cpu"))
+    ok = ok and cat["a"].tolist() == [0, 1, 2, 100, 101, 102, 103, 104]
+    ok = ok and fdist.allreduce_sum(rank + 5) == 11
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

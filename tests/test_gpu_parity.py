@@ -383,6 +383,66 @@ def test_index_set_equals_single_index(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("first_id,cuts", [(7, [0, 50, 51, 130, 180]), (70000, [0, 1, 90, 90, 180]), (2100000, [0, 180]), (16380, [0, 3, 6, 60, 61, 62, 100, 180])])
+def test_device_merge_equals_single_index(ctx, first_id, cuts):
+    """fdgpu_index_merge: the parts' posting lists concatenated per hash on the device (first varint of every continuation
+    re-based to a delta) == the index one build over all the structures produces, byte for byte — with hashes absent from
+    some parts, an empty part, a single-part merge, and first ids whose absolute / delta varints differ in length (1, 2, 3 and
+    4 bytes)."""
+    import folddisco_amd as fd
+    from folddisco_amd import synth
+    ps = synth.to_packed(synth.generate(180, seed=31))
+    off = ps.res_off.astype(np.int64)
+    chunks = []
+    for a, b in zip(cuts, cuts[1:]):
+        sl = slice(off[a], off[b])
+        chunks.append(fd.PackedStructures((ps.res_off[a:b + 1] - ps.res_off[a]).astype(np.uint64), ps.n_xyz[sl], ps.ca_xyz[sl], ps.cb_xyz[sl], ps.aa[sl]))
+    single = fd.FolddiscoIndex.build(ctx, ctx.upload(ps), first_id=first_id)
+    iset = fd.FolddiscoIndexSet.build(ctx, [ctx.upload(c) for c in chunks], first_id=first_id)
+    merged = iset.merge()
+    v, h, o = single.export()
+    mv, mh, mo = merged.export()
+    assert merged.num_hashes == single.num_hashes and merged.value_len == single.value_len and merged.num_postings == single.num_postings
+    assert np.array_equal(mh, h) and np.array_equal(mo, o) and np.array_equal(mv, v)
+    if len(cuts) > 2:
+        hv, hh, ho = iset.export_merged()           # the host-side merge agrees too
+        assert np.array_equal(hv, v) and np.array_equal(hh, h) and np.array_equal(ho, o)
+    # the merged index answers queries like the single one
+    rng = np.random.Generator(np.random.PCG64(5))
+    qh = rng.choice(h, 40, replace=False).astype(np.uint32)
+    qi = rng.integers(0, 4, len(qh)).astype(np.uint32)
+    qj = rng.integers(0, 4, len(qh)).astype(np.uint32)
+    pen = fd.length_penalty(np.diff(ps.res_off).astype(np.uint64), 0.5)
+    assert fd.count_query(ctx, merged, qh, qi, qj, pen, as_array=True).tobytes() == fd.count_query(ctx, single, qh, qi, qj, pen, as_array=True).tobytes()
+
+
+@pytest.mark.gpu
+def test_device_merge_long_lists_and_wide_hashes(ctx):
+    """posting lists of thousands of ids (one repeated structure: every hash in every structure, lists longer than the 64-byte
+    decode block, parts of uneven size) and the 2^32 hash space (a part with an overflowed hash, test_degenerate_geometry)"""
+    import folddisco_amd as fd
+    from folddisco_amd import synth
+    one = synth.to_packed(synth.generate(1, seed=77, lengths=np.array([60])))
+    n = 1500
+    item = dict(n_xyz=one.n_xyz, ca_xyz=one.ca_xyz, cb_xyz=one.cb_xyz, aa=one.aa)
+    far = dict(n_xyz=one.n_xyz.copy(), ca_xyz=one.ca_xyz.copy(), cb_xyz=one.cb_xyz.copy(), aa=one.aa)
+    far["cb_xyz"][7] = np.float32(3.0e38)               # CB-CB distance overflows to inf -> hash beyond 30 bits
+    items = [item] * 700 + [far] + [item] * (n - 701)
+    ps = fd.PackedStructures.concat(items)
+    single = fd.FolddiscoIndex.build(ctx, ctx.upload(ps), first_id=100)
+    cuts = [0, 100, 699, 702, 1200, n]
+    parts, fid = [], 100
+    for a, b in zip(cuts, cuts[1:]):
+        parts.append(fd.FolddiscoIndex.build(ctx, ctx.upload(fd.PackedStructures.concat(items[a:b])), first_id=fid))
+        fid += b - a
+    merged = fd.FolddiscoIndexSet(parts).merge()
+    v, h, o = single.export()
+    mv, mh, mo = merged.export()
+    assert h.max() >= (1 << 30) and np.diff(o).max() > 1400
+    assert np.array_equal(mh, h) and np.array_equal(mo, o) and np.array_equal(mv, v)
+
+
+@pytest.mark.gpu
 def test_degenerate_geometry_matches_oracle(ctx):
     """Bit-exactness where the arithmetic degenerates: CB on top of CA (zero-length vectors -> NaN angles), duplicated residues
     (distance 0), collinear N-CA-CB (zero cross products), residues on a perfect line / lattice (torsion operands exactly 0 ->

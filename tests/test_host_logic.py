@@ -339,3 +339,28 @@ def test_index_id_types():
     assert f("d/a.pdb.gz", "filename") == "a.pdb" and f("d/a.pdb.gz", "basename") == "a.pdb.gz"
     assert f("d/a.pdb", "relpath") == "d/a.pdb" and f("d/a.pdb", "default") == "d/a.pdb" and f("d/a.pdb", "whatever") == "d/a.pdb"
     assert f("tests/helpers.py", "abspath") == os.path.realpath("tests/helpers.py")
+
+
+def test_oracle_query_bench_driver_equals_python_driven_oracle():
+    """bench.py's query cpu_baseline driver (oracle/fdo_bench.c: fdo_query_bench over a borrowed index) does the work the
+    Python-driven oracle does query by query: same candidate counts, same number of matches, for 1 and 4 threads."""
+    from folddisco_amd import querybench, synth
+    from tests.helpers import packed_to_oracle_structs
+    S = 40
+    d = synth.generate(S, seed=77)
+    ps = synth.to_packed(d)
+    structs = packed_to_oracle_structs(ps)
+    oix, onres, _ = oracle.build_index(structs)
+    qs = querybench._pick_queries(d, S, 5, seed=3)
+    want_hits = want_matches = 0
+    for s, idx, _ in qs:
+        om = oracle.make_query_map(structs[s], ",".join(f"A{int(i) + 1}" for i in idx), oix, float(S))
+        recs = oracle.count_query(om, oix, onres)
+        order = sorted(range(len(recs)), key=lambda k: -recs[k]["idf"])      # stable
+        want_hits += min(len(recs), 1000)
+        for k in order[:8]:
+            want_matches += len(oracle.retrieve(structs[recs[k]["nid"]], structs[s], om)["processed"])
+    for nt in (1, 4):
+        r = oracle.query_bench(oix.hashes(), oix.offsets(), oix.values(), onres, ps.res_off, ps.n_xyz, ps.ca_xyz, ps.cb_xyz, ps.aa,
+                               [(s, idx) for s, idx, _ in qs], top_n=1000, match_top=8, n_threads=nt)
+        assert (r["hits"], r["matches"]) == (want_hits, want_matches) and want_matches >= 5
