@@ -524,3 +524,20 @@ def query_bench(hashes, offsets, values, nres, res_off, n_xyz, ca_xyz, cb_xyz, a
         L.fdo_index_free_borrowed(ix)
     return dict(wall_s=float(wall), hits=int(hits.value), matches=int(matches.value),
                 stage_thread_s=dict(make_query_map=st[0], count_query=st[1], retrieval=st[2]))
+
+
+class BorrowedIndex(OIndex):
+    """OIndex over arrays that stay the caller's (e.g. the export of a GPU-built index, which the small-size parity tests pin byte
+    for byte to build_index): lets the oracle answer queries at database sizes its own table build would need minutes for."""
+
+    def __init__(self, hashes, offsets, values):
+        self._keep = (np.ascontiguousarray(hashes, np.uint32), np.ascontiguousarray(offsets, np.uint64), np.ascontiguousarray(values, np.uint8))
+        h, o, v = self._keep
+        L = lib()
+        super().__init__(L.fdo_index_borrow(h.ctypes.data_as(u32p), o.ctypes.data_as(u64p), len(h), v.ctypes.data_as(u8p), len(v)))
+
+    def __del__(self):
+        try:
+            lib().fdo_index_free_borrowed(self.ptr)
+        except Exception:
+            pass

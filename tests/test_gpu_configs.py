@@ -1,0 +1,243 @@
+"""BASELINE.json configs 3 and 5 at their own sizes, against the oracle.
+
+* configs[2] "Human AFDB proteome index + batch query/*.txt": a human-scale synthetic database (20,500 AFDB-shaped structures)
+  with the motifs of the reference's five shipped query files (query/*.txt: serine peptidase triad, zinc finger, aminopeptidase,
+  enolase with substitutions, knottin) PLANTED into known structures (rigidly moved copies, half of them with coordinate
+  noise), so every query has real hits.  Query map, prefilter records and the matches of the top candidates — one at a time
+  and through the batched entry points — equal the oracle's; the index is checked through S1 hash lists of sampled structures
+  and through the device merge of five sub-builds.
+* configs[4] whole-structure query mode (no -q): a 300-residue query (90 k hashes) against the same 20,500 structures:
+  prefilter records of every touched structure and the matches of the top 20 equal the oracle's — the large-query code paths
+  (hashed lookup, two scans, packed candidate pairs) at a size where they are the ones that run.
+
+The oracle answers from the EXPORT of the GPU index (oracle.BorrowedIndex): its own table build needs ~15 minutes at this size,
+and the index bytes are pinned to it at the sizes of tests/test_gpu_parity.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HUMAN = 20500
+QDIR = os.path.join(HERE, "golden", "query")
+QUERY_FILES = ["serine_peptidase.txt", "zinc_finger.txt", "aminopeptidase.txt", "enolase.txt", "knottin.txt"]
+N_PLANT = 24
+
+
+def _rot(rng):
+    q, r = np.linalg.qr(rng.normal(size=(3, 3)))
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def _parse_query_file(name):
+    line = open(os.path.join(QDIR, name)).read().rstrip("\n").split("\t")
+    return os.path.join(QDIR, os.path.basename(line[0])), line[1]
+
+
+@pytest.fixture(scope="module")
+def human():
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    from folddisco_amd import synth
+    ctx = fd.Context(0)
+    ps = synth.to_packed(synth.generate(HUMAN, seed=2050, device="cuda"))
+    rng = np.random.Generator(np.random.PCG64(77))
+    queries = []
+    ins_pos, ins = [], dict(n_xyz=[], ca_xyz=[], cb_xyz=[], aa=[])
+    extra = np.zeros(HUMAN, np.int64)
+    free = rng.permutation(HUMAN)
+    for k, name in enumerate(QUERY_FILES):
+        path, qstr = _parse_query_file(name)
+        q = st.read_compact_structure(path)
+        res = fq.parse_query_string(qstr, q.chains[0])
+        pairs = [(q.get_index(c, r), s) for c, r, s in res]
+        assert all(i is not None for i, _ in pairs), name
+        idx = np.array([i for i, _ in pairs])
+        planted = np.sort(free[k * N_PLANT:(k + 1) * N_PLANT])
+        for t, sid in enumerate(planted):
+            R, tr = _rot(rng), rng.normal(0, 30, 3) + 60.0
+            noise = 0.0 if t % 2 == 0 else 0.12
+            for key, src in (("n_xyz", q.n_xyz), ("ca_xyz", q.ca_xyz), ("cb_xyz", q.cb_xyz)):
+                x = src[idx].astype(np.float64) @ R.T + tr + rng.normal(0, 1, (len(idx), 3)) * noise
+                ins[key].append(np.round(x, 3).astype(np.float32))
+            ins["aa"].append(q.aa[idx])
+            ins_pos.append(np.full(len(idx), int(ps.res_off[sid + 1])))
+            extra[sid] += len(idx)
+        queries.append(dict(name=name, path=path, qstr=qstr, q=q, idx=idx.astype(np.uint32), subs=[s for _, s in pairs], planted=planted))
+    pos = np.concatenate(ins_pos)
+    order = np.argsort(pos, kind="stable")
+    cat = {k: np.concatenate(v)[order] for k, v in ins.items()}
+    new_off = ps.res_off.astype(np.int64).copy()
+    new_off[1:] += np.cumsum(extra)
+    ps = fd.PackedStructures(new_off.astype(np.uint64), np.insert(ps.n_xyz, pos[order], cat["n_xyz"], axis=0), np.insert(ps.ca_xyz, pos[order], cat["ca_xyz"], axis=0),
+                             np.insert(ps.cb_xyz, pos[order], cat["cb_xyz"], axis=0), np.insert(ps.aa, pos[order], cat["aa"]))
+    batch = ctx.upload(ps)
+    ix = fd.FolddiscoIndex.build(ctx, batch)
+    v, h, o = ix.export()
+    oix = oracle.BorrowedIndex(h, o, v)
+    nres = np.diff(ps.res_off).astype(np.uint64)
+    return dict(ctx=ctx, ps=ps, batch=batch, ix=ix, oix=oix, nres=nres, pen=fd.length_penalty(nres, 0.5), queries=queries, export=(v, h, o))
+
+
+def _ostruct(ps, s):
+    a, b = int(ps.res_off[s]), int(ps.res_off[s + 1])
+    return oracle.structure_from_packed(ps.n_xyz[a:b], ps.ca_xyz[a:b], ps.cb_xyz[a:b], ps.aa[a:b])
+
+
+def _check_matches(got, cand, ps, oq, om, rmsd_tol=1e-4):
+    n = 0
+    for slot, nid in enumerate(cand):
+        R = oracle.retrieve(_ostruct(ps, int(nid)), oq, om)
+        mine = [g for g in got if g["cand"] == slot]
+        assert len(mine) == len(R["processed"]), (slot, nid)
+        for g, rp, rh in zip(mine, R["processed"], R["from_hash"]):
+            assert g["processed"] == [-1 if x is None else x[2] for x in rp["residues"]], (slot, nid)
+            assert g["from_hash"] == [-1 if x is None else x[2] for x in rh["residues"]], (slot, nid)
+            assert abs(g["rmsd"] - rp["rmsd"]) <= rmsd_tol and g["idf"] == pytest.approx(rp["idf"], rel=1e-5)
+            n += 1
+    return n
+
+
+def test_index_at_human_scale(human):
+    """S1 hash lists of sampled structures <-> decoded posting lists (both directions), and five sub-builds merged on the device
+    == the single build, byte for byte"""
+    import folddisco_amd as fd
+    ctx, ps, ix = human["ctx"], human["ps"], human["ix"]
+    v, h, o = human["export"]
+    rng = np.random.Generator(np.random.PCG64(1))
+    sample = np.sort(rng.choice(HUMAN, 120, replace=False))
+    items = []
+    for s in sample:
+        a, b = int(ps.res_off[s]), int(ps.res_off[s + 1])
+        items.append(dict(n_xyz=ps.n_xyz[a:b], ca_xyz=ps.ca_xyz[a:b], cb_xyz=ps.cb_xyz[a:b], aa=ps.aa[a:b]))
+    hs, off = fd.get_geometric_hash_as_u32(ctx, ctx.upload(fd.PackedStructures.concat(items)))
+    # structure -> index: every (hash, id) of the sampled structures is in the hash's posting list
+    pick = rng.choice(len(hs), 4000, replace=False)
+    sid_of = sample[np.searchsorted(off, pick, side="right") - 1]
+    lists = ix.get_entries(hs[pick])
+    assert all(int(s) in set(l.tolist()) if len(l) < 64 else bool(np.isin(s, l)) for s, l in zip(sid_of, lists))
+    # index -> structure: ids of the sampled structures inside those lists really hold the hash
+    own = {int(s): set(hs[int(off[k]):int(off[k + 1])].tolist()) for k, s in enumerate(sample)}
+    n_back = 0
+    for hq, l in zip(hs[pick][:1500], lists[:1500]):
+        assert np.all(l[1:] > l[:-1]) and l[-1] < HUMAN
+        for s in np.intersect1d(l, sample):
+            assert int(hq) in own[int(s)]
+            n_back += 1
+    assert n_back >= 1500
+    assert ix.num_postings == len(v) - int(np.count_nonzero(v & 0x80))   # one terminator byte per posting
+    # five sub-builds over consecutive id ranges, merged on the device
+    cuts = [0, 4100, 8200, 12300, 16400, HUMAN]
+    parts = []
+    for a, b in zip(cuts, cuts[1:]):
+        sl = slice(int(ps.res_off[a]), int(ps.res_off[b]))
+        chunk = fd.PackedStructures((ps.res_off[a:b + 1] - ps.res_off[a]).astype(np.uint64), ps.n_xyz[sl], ps.ca_xyz[sl], ps.cb_xyz[sl], ps.aa[sl])
+        parts.append(fd.FolddiscoIndex.build(ctx, ctx.upload(chunk), first_id=a))
+    mv, mh, mo = fd.FolddiscoIndexSet(parts).merge().export()
+    assert np.array_equal(mh, h) and np.array_equal(mo, o) and np.array_equal(mv, v)
+
+
+@pytest.mark.parametrize("qk", range(len(QUERY_FILES)))
+def test_shipped_motif_queries_at_human_scale(human, qk):
+    import folddisco_amd as fd
+    from folddisco_amd import dist as fdist
+    from folddisco_amd import query as fq
+    ctx, ps, batch, ix, oix = human["ctx"], human["ps"], human["batch"], human["ix"], human["oix"]
+    Q = human["queries"][qk]
+    q = Q["q"]
+    qb = ctx.upload(fd.PackedStructures.concat([q.as_item()]))
+    qm = fq.make_query_map(ctx, qb, Q["idx"], Q["subs"], ix, float(HUMAN))
+    oq = oracle.read_pdb(Q["path"])
+    om = oracle.make_query_map(oq, Q["qstr"], oix, float(HUMAN))
+    oa = om.arrays()
+    assert np.array_equal(qm.hash, oa["hash"]) and np.array_equal(qm.qi, oa["qi"]) and np.array_equal(qm.qj, oa["qj"])
+    assert np.array_equal(qm.idf.view(np.uint32), oa["idf"].view(np.uint32))
+    recs = fd.count_query(ctx, ix, qm.hash, qm.qi, qm.qj, human["pen"], total_structures=HUMAN, as_array=True)
+    want = oracle.count_query(om, oix, human["nres"])
+    assert [(int(r["nid"]), int(r["total_match_count"]), int(r["node_count"]), int(r["edge_count"])) for r in recs] == \
+           [(w["nid"], w["total_match_count"], w["node_count"], w["edge_count"]) for w in want]
+    assert np.allclose(recs["idf"], [w["idf"] for w in want], rtol=1e-5, atol=0)
+    # the exact copies carry the whole motif
+    by = {int(r["nid"]): r for r in recs}
+    for t, sid in enumerate(Q["planted"]):
+        assert int(sid) in by
+        if t % 2 == 0:
+            assert int(by[int(sid)]["node_count"]) == len(Q["idx"])
+    top = fdist.rank_hits(recs, 40)
+    cand = top["nid"].astype(np.uint32)
+    assert len(np.intersect1d(cand, Q["planted"])) >= N_PLANT // 2          # planted copies lead the ranking
+    std = np.ones(int(ps.res_off[-1]), np.uint8)
+    got = fq.retrieve(ctx, batch, std, cand, qm, qb)
+    n = _check_matches(got, cand, ps, oq, om)
+    full = [g for g in got if sum(1 for x in g["processed"] if x >= 0) == len(Q["idx"])]
+    assert n >= N_PLANT // 2 and len(full) >= N_PLANT // 2 and min(g["rmsd"] for g in full) < 0.01
+
+
+def test_batch_of_shipped_queries_equals_singles(human):
+    """`query -q query/*.txt` as one batch (fdgpu_make_query_map_batch + fdgpu_count_query_batch_top + fdgpu_retrieve_batch): the same
+    candidates and matches as one query at a time"""
+    import folddisco_amd as fd
+    from folddisco_amd import dist as fdist
+    from folddisco_amd import query as fq
+    ctx, ps, batch, ix = human["ctx"], human["ps"], human["batch"], human["ix"]
+    Qs = human["queries"]
+    qall = ctx.upload(fd.PackedStructures.concat([Q["q"].as_item() for Q in Qs]))
+    qms = fq.make_query_maps(ctx, qall, [(k, Q["idx"], Q["subs"]) for k, Q in enumerate(Qs)], ix, float(HUMAN))
+    recs = fd.count_query_batch(ctx, ix, [(m.hash, m.qi, m.qj) for m in qms], human["pen"], total_structures=HUMAN, top_n=1000)
+    std = np.ones(int(ps.res_off[-1]), np.uint8)
+    cands = []
+    for k, (Q, m, r) in enumerate(zip(Qs, qms, recs)):
+        qb = ctx.upload(fd.PackedStructures.concat([Q["q"].as_item()]))
+        single = fq.make_query_map(ctx, qb, Q["idx"], Q["subs"], ix, float(HUMAN))
+        assert single.hash.tobytes() == m.hash.tobytes() and single.idf.tobytes() == m.idf.tobytes()
+        full = fd.count_query(ctx, ix, m.hash, m.qi, m.qj, human["pen"], total_structures=HUMAN, as_array=True)
+        assert fdist.rank_hits(r, 1000).tobytes() == fdist.rank_hits(full, 1000).tobytes()
+        cands.append(fdist.rank_hits(r, 25)["nid"].astype(np.uint32))
+    got = fq.retrieve_batch(ctx, batch, std, cands, qms, qall, list(range(len(Qs))))
+    for k, (Q, m) in enumerate(zip(Qs, qms)):
+        qb = ctx.upload(fd.PackedStructures.concat([Q["q"].as_item()]))
+        single = fq.retrieve(ctx, batch, std, cands[k], fq.make_query_map(ctx, qb, Q["idx"], Q["subs"], ix, float(HUMAN)), qb)
+        assert len(single) == len(got[k]) and len(single) >= N_PLANT // 2
+        for a, b in zip(got[k], single):
+            assert a["cand"] == b["cand"] and a["processed"] == b["processed"] and a["from_hash"] == b["from_hash"]
+            assert a["rmsd"] == b["rmsd"] and a["idf"] == b["idf"]
+
+
+def test_whole_structure_query_at_human_scale(human):
+    """configs[4] (no -q): a ~300-residue database structure as the query, against all 20,500 structures"""
+    import folddisco_amd as fd
+    from folddisco_amd import dist as fdist
+    from folddisco_amd import query as fq
+    ctx, ps, batch, ix, oix = human["ctx"], human["ps"], human["batch"], human["ix"], human["oix"]
+    nres = human["nres"].astype(np.int64)
+    s = int(np.nonzero((nres >= 295) & (nres <= 305))[0][3])
+    a, b = int(ps.res_off[s]), int(ps.res_off[s + 1])
+    item = dict(n_xyz=ps.n_xyz[a:b], ca_xyz=ps.ca_xyz[a:b], cb_xyz=ps.cb_xyz[a:b], aa=ps.aa[a:b])
+    qb = ctx.upload(fd.PackedStructures.concat([item]))
+    qm = fq.make_query_map(ctx, qb, np.arange(b - a, dtype=np.uint32), None, ix, float(HUMAN))
+    oq = _ostruct(ps, s)
+    om = oracle.make_query_map(oq, "", oix, float(HUMAN))
+    oa = om.arrays()
+    assert len(qm.hash) > 50000
+    assert np.array_equal(qm.hash, oa["hash"]) and np.array_equal(qm.qi, oa["qi"]) and np.array_equal(qm.qj, oa["qj"])
+    assert np.array_equal(qm.idf.view(np.uint32), oa["idf"].view(np.uint32))
+    recs = fd.count_query(ctx, ix, qm.hash, qm.qi, qm.qj, human["pen"], total_structures=HUMAN, as_array=True)
+    want = oracle.count_query(om, oix, human["nres"])
+    assert len(recs) == len(want) and len(recs) > HUMAN // 2
+    assert [(int(r["nid"]), int(r["total_match_count"]), int(r["node_count"]), int(r["edge_count"])) for r in recs] == \
+           [(w["nid"], w["total_match_count"], w["node_count"], w["edge_count"]) for w in want]
+    assert np.allclose(recs["idf"], [w["idf"] for w in want], rtol=1e-5, atol=0)
+    cand = fdist.rank_hits(recs, 20)["nid"].astype(np.uint32)
+    assert int(cand[0]) == s
+    got = fq.retrieve(ctx, batch, None, cand, qm, qb)
+    n = _check_matches(got, cand, ps, oq, om)
+    assert n >= 20 and max(sum(1 for x in g["processed"] if x >= 0) for g in got) == b - a     # the structure matches itself entirely
