@@ -99,6 +99,29 @@ def cpu_baseline_build(ps_sample, n_threads):
     return len(structs) / (t3 - t0), {"hash_pass1_s": t1 - t0, "hash_pass2_s": t2 - t1, "count_fill_finalize_s": t3 - t2}
 
 
+def cpu_baseline_query(ix, d, nres, res_off_h, qlist, top_n, match_top, S):
+    """Query half of cpu_baseline: oracle/fdo_bench.c (the reference's make_query_map + count_query + sort/truncate + retrieval per
+    query, OpenMP over queries where the reference uses rayon, query_pdb.rs:348) against the SAME index — the export of the
+    resident index — on the host cores of this box."""
+    import numpy as np
+    import oracle
+    v, h, o = ix.export_view()
+    n_xyz, ca_xyz, cb_xyz, aa = (d[k].cpu().numpy() for k in ("n_xyz", "ca_xyz", "cb_xyz", "aa"))
+    cores = os.cpu_count() or 1
+    reps = max(1, min(8, cores // max(len(qlist), 1)))     # enough queries to occupy the cores
+    r_all = oracle.query_bench(h, o, v, nres, res_off_h.astype(np.uint64), n_xyz, ca_xyz, cb_xyz, aa, qlist * reps, top_n=top_n,
+                               match_top=match_top, n_threads=cores)
+    r64 = oracle.query_bench(h, o, v, nres, res_off_h.astype(np.uint64), n_xyz, ca_xyz, cb_xyz, aa, qlist, top_n=top_n,
+                             match_top=match_top, n_threads=min(64, cores))
+    return {"value": len(qlist) * reps / r_all["wall_s"], "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": "the same %d queries x%d against the export of the same resident index (%d structures): make_query_map + count_query + "
+                      "sort/truncate %d + retrieval of the top %d, OpenMP over queries (query_pdb.rs:348), %.1f s wall" %
+                      (len(qlist), reps, S, top_n, match_top, r_all["wall_s"]),
+            "stage_thread_s": {k: round(x, 2) for k, x in r_all["stage_thread_s"].items()}, "matches": r_all["matches"] // reps,
+            "t64": {"value": len(qlist) / r64["wall_s"], "cores": min(64, cores), "wall_s": round(r64["wall_s"], 2),
+                    "stage_thread_s": {k: round(x, 2) for k, x in r64["stage_thread_s"].items()}}}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -275,7 +298,7 @@ def main():
             blocks = None
             db = wrap(d_all)
             query = querybench.run(ctx, db, ix, d_all, S, world, rank, dist, dev, n_queries=args.queries, lo=lo, S_total=S_total,
-                                   cpu_baseline=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+                                   cpu_baseline_fn=cpu_baseline_query if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None)
         except Exception as e:  # the index-build line must still be printed
             import traceback
             query = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}

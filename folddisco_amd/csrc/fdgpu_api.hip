@@ -542,191 +542,9 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     return FDGPU_OK;
 }
 
-// ---- bucketed build (k_bucket.hip): default encoding, default bins.  Returns FDGPU_RETRY_CLASSIC when the shard holds a hash whose
-// distance fields spill into the residue-type bits (non-finite coordinates): the sort-everything path keeps the full u32 there.
-#define FDGPU_RETRY_CLASSIC 1001
-static int index_build_bucketed(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_params *p, uint64_t first_id, fdgpu_index **out) {
-    *out = nullptr;
-    reset_timings(c);
-    hipStream_t st = c->stream;
-    const uint64_t S = b->n_struct;
-    if (first_id + S > 0xffffffffull) FAIL(c, FDGPU_ERANGE, "structure ids exceed 32 bits");
-    fd_hash_consts C = fd_make_consts_cfg(p, 0);
-    C.spec_miss = c->spec_miss;
-    const uint32_t NB = fd_bk_num_buckets();
-    HIPCHK(c, c->ws[WS_FRAMES].ensure(std::max<uint64_t>(b->n_res, 1) * sizeof(fd_frame)));
-    {
-        StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame)));
-        fd_launch_frames(b->view(), b->n_res, c->ws[WS_FRAMES].p, st);
-    }
-    const uint32_t n_rb = std::max<uint32_t>(fd_bk_row_blocks(S), 1);
-    HIPCHK(c, c->ws[WS_BK_M].ensure(std::max<uint64_t>(S, 1) * NB * 4));
-    HIPCHK(c, c->ws[WS_BK_PART].ensure((uint64_t)n_rb * NB * 4));
-    HIPCHK(c, c->ws[WS_BK_BTOT].ensure((uint64_t)NB * 8));
-    HIPCHK(c, c->ws[WS_BK_BBASE].ensure((uint64_t)(NB + 1) * 8));
-    HIPCHK(c, c->ws[WS_BK_TFIRST].ensure((uint64_t)(NB + 1) * 4));
-    HIPCHK(c, c->ws[WS_MISC3].ensure(64));
-    HIPCHK(c, hipMemsetAsync(c->ws[WS_MISC3].p, 0, 64, st));
-    unsigned long long *flags = c->ws[WS_MISC3].as<unsigned long long>() + 4;   // [0] wide, [1] emit error
-    uint32_t *M = c->ws[WS_BK_M].as<uint32_t>();
-    unsigned long long *btot_d = c->ws[WS_BK_BTOT].as<unsigned long long>();
-    {
-        StageTimer t(c, "bk_count", b->n_res * 13 + S * NB * 4);
-        fd_bk_count(b->view(), c->ws[WS_FRAMES].p, C.d2_max, C.q.dist_disc, M, flags, st);
-    }
-    {
-        StageTimer t(c, "bk_colscan", S * NB * 12);
-        fd_bk_colscan(M, S, c->ws[WS_BK_PART].as<uint32_t>(), btot_d, st);
-    }
-    HIPCHK(c, hipGetLastError());
-    std::vector<unsigned long long> btot(NB);
-    unsigned long long hflags[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(btot.data(), btot_d, (size_t)NB * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(hflags, flags, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    if (hflags[0]) return FDGPU_RETRY_CLASSIC;
-    uint64_t P = 0;
-    for (uint32_t k = 0; k < NB; ++k) P += btot[k];
-    const bool idh = S > 65536;
-    const uint64_t elem = idh ? 5 : 4;
-    // bucket groups: the smallest power of two whose largest group fits two element buffers into what is free now plus what the
-    // sort workspace already holds, after setting aside the index itself (FDGPU_BK_GROUPS overrides)
-    auto group_sizes = [&](uint32_t G, std::vector<uint64_t> &gs) {
-        gs.assign(G, 0);
-        for (uint32_t k = 0; k < NB; ++k) gs[((k / 320u) + ((k / 16u) % 20u)) & (G - 1u)] += btot[k];
-    };
-    uint32_t G = 1;
-    {
-        size_t fr = 0, total = 0;
-        (void)hipMemGetInfo(&fr, &total);
-        const uint64_t have = (uint64_t)fr + c->ws[WS_KEYS_A].cap + c->ws[WS_KEYS_B].cap + c->ws[WS_IDS_A].cap + c->ws[WS_IDS_B].cap + c->ws[WS_GHIST].cap;
-        const uint64_t reserve = (uint64_t)(P * 1.8) * 2 + (4ull << 30);
-        const uint64_t budget = have > reserve ? have - reserve : 0;
-        std::vector<uint64_t> gs;
-        for (; G < 64; G <<= 1) {
-            group_sizes(G, gs);
-            const uint64_t mx = *std::max_element(gs.begin(), gs.end());
-            if (2 * mx * elem + (mx / fd_seg_tile() + NB + 2) * 1024 <= budget) break;
-        }
-        const char *e = getenv("FDGPU_BK_GROUPS");
-        if (e && atoi(e) >= 1) { G = 1; while (G < (uint32_t)atoi(e) && G < 64) G <<= 1; }
-    }
-    std::vector<uint64_t> gs;
-    group_sizes(G, gs);
-    const uint64_t Pmax = *std::max_element(gs.begin(), gs.end());
-    const uint32_t tiles_bound = (uint32_t)(Pmax / fd_seg_tile() + NB + 1);
-    const uint32_t enc_tiles = std::max<uint32_t>(fd_enc_num_tiles(Pmax), 1);
-    HIPCHK(c, c->ws[WS_KEYS_A].ensure(std::max<uint64_t>(Pmax, 1) * 4));
-    HIPCHK(c, c->ws[WS_KEYS_B].ensure(std::max<uint64_t>(Pmax, 1) * 4));
-    if (idh) { HIPCHK(c, c->ws[WS_IDS_A].ensure(std::max<uint64_t>(Pmax, 1) + 16)); HIPCHK(c, c->ws[WS_IDS_B].ensure(std::max<uint64_t>(Pmax, 1) + 16)); }
-    HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * (tiles_bound + 2) * 4));
-    HIPCHK(c, c->ws[WS_TOT].ensure((256 + (size_t)((tiles_bound + 2) / 128 + 2) * 256) * 8));
-    HIPCHK(c, c->ws[WS_BK_TILEB].ensure((size_t)(tiles_bound + 2) * 4));
-    HIPCHK(c, c->ws[WS_BK_ENCB].ensure((size_t)(enc_tiles + 2) * 4));
-    HIPCHK(c, c->ws[WS_TILE_B].ensure((size_t)(enc_tiles + 1) * 4));
-    HIPCHK(c, c->ws[WS_TILE_H].ensure((size_t)(enc_tiles + 1) * 4));
-    HIPCHK(c, c->ws[WS_TILE_P].ensure((size_t)(enc_tiles + 1) * 4));
-    HIPCHK(c, c->ws[WS_TILE_BO].ensure((size_t)(enc_tiles + 2) * 8));
-    HIPCHK(c, c->ws[WS_TILE_HO].ensure((size_t)(enc_tiles + 2) * 8));
-    HIPCHK(c, c->ws[WS_TILE_PO].ensure((size_t)(enc_tiles + 2) * 8));
-    HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(std::max<uint64_t>(enc_tiles, NB)) * 8 + 64));
-    uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *kb = c->ws[WS_KEYS_B].as<uint32_t>();
-    uint8_t *pa = idh ? c->ws[WS_IDS_A].as<uint8_t>() : nullptr, *pb = idh ? c->ws[WS_IDS_B].as<uint8_t>() : nullptr;
-    unsigned long long *bbase = c->ws[WS_BK_BBASE].as<unsigned long long>();
-    uint32_t *tfirst = c->ws[WS_BK_TFIRST].as<uint32_t>(), *tileb = c->ws[WS_BK_TILEB].as<uint32_t>(), *encb = c->ws[WS_BK_ENCB].as<uint32_t>();
-    std::vector<fdgpu_index *> slices(G, nullptr);
-    auto drop = [&]() { for (auto s : slices) if (s) fdgpu_index_destroy(s); };
-    for (uint32_t g = 0; g < G; ++g) {
-        const uint64_t Pg = gs[g];
-        fd_bk_bases(btot_d, g, G, fd_seg_tile(), bbase, tfirst, fd_enc_tile(), tileb, encb, st);
-        {
-            StageTimer t(c, "bk_emit", b->n_res * 37 + S * NB * 4 + Pg * elem);
-            fd_bk_emit(b->view(), c->ws[WS_FRAMES].p, C, M, bbase, g, G, ka, pa, flags + 1, st);
-        }
-        fd_seg_sort16(ka, pa, kb, pb, bbase, tfirst, tileb, NB, tiles_bound, Pg, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st, c);
-        const uint64_t nt_eff = Pg ? fd_enc_num_tiles(Pg) : 0;
-        uint64_t tot[4] = {0, 0, 0, 0};
-        uint64_t *totd = c->ws[WS_MISC3].as<uint64_t>();
-        {
-            StageTimer t(c, "encode_sizes", Pg * elem);
-            fd_launch_enc_sizes_bk(ka, pa, (uint32_t)first_id, Pg, bbase, encb, c->ws[WS_TILE_B].as<uint32_t>(), c->ws[WS_TILE_H].as<uint32_t>(),
-                                   c->ws[WS_TILE_P].as<uint32_t>(), st);
-            fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_B].as<uint32_t>(), nt_eff, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 0, st);
-            fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_H].as<uint32_t>(), nt_eff, c->ws[WS_TILE_HO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 1, st);
-            fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_P].as<uint32_t>(), nt_eff, c->ws[WS_TILE_PO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 2, st);
-        }
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(tot, totd, 24, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(hflags, flags, 16, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { drop(); c->err = std::string("bucketed build: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-        if (hflags[1]) { drop(); return FDGPU_RETRY_CLASSIC; }
-        fdgpu_index *ix = new (std::nothrow) fdgpu_index();
-        if (!ix) { drop(); return FDGPU_ENOMEM; }
-        slices[g] = ix;
-        ix->ctx = c; ix->value_len = tot[0]; ix->n_hashes = tot[1]; ix->n_postings = tot[2]; ix->n_structures = S; ix->first_id = first_id;
-        ix->value = (uint8_t *)c->pool_alloc(std::max<uint64_t>(ix->value_len, 4), &e); ix->cap_value = c->last_cap;
-        if (e == hipSuccess) { ix->hashes = (uint32_t *)c->pool_alloc(std::max<uint64_t>(ix->n_hashes, 1) * 4, &e); ix->cap_hashes = c->last_cap; }
-        if (e == hipSuccess) { ix->offsets = (uint64_t *)c->pool_alloc((ix->n_hashes + 1) * 8, &e); ix->cap_offsets = c->last_cap; }
-        if (e != hipSuccess) { drop(); c->err = std::string("index alloc: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-        {
-            StageTimer t(c, "encode_write", Pg * elem + ix->value_len + ix->n_hashes * 12);
-            fd_launch_enc_write_bk(ka, pa, (uint32_t)first_id, Pg, bbase, encb, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_TILE_HO].as<uint64_t>(), ix->value,
-                                   ix->hashes, ix->offsets, totd, ix->n_hashes, st);
-        }
-        e = hipGetLastError();
-        if (e != hipSuccess) { drop(); c->err = std::string("encode launch: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-    }
-    if (G == 1) { *out = slices[0]; return FDGPU_OK; }
-    // interleave the groups' slices by bucket
-    struct slice_h { const uint32_t *hashes; const uint64_t *offsets; const uint8_t *value; uint64_t H; };
-    std::vector<slice_h> sh(G);
-    uint64_t Ht = 0, Vt = 0, Pt = 0;
-    for (uint32_t g = 0; g < G; ++g) { sh[g] = {slices[g]->hashes, slices[g]->offsets, slices[g]->value, slices[g]->n_hashes}; Ht += slices[g]->n_hashes; Vt += slices[g]->value_len; Pt += slices[g]->n_postings; }
-    hipError_t e = c->ws[WS_BK_ASM].ensure((size_t)G * sizeof(slice_h) + (size_t)NB * (8 + 4 + 8) + (size_t)(NB + 1) * 16 + 256);
-    if (e != hipSuccess) { drop(); c->err = std::string("assemble workspace: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-    uint8_t *w = c->ws[WS_BK_ASM].as<uint8_t>();
-    unsigned long long *src_h0 = (unsigned long long *)w; w += (size_t)NB * 8;
-    unsigned long long *n_b = (unsigned long long *)w; w += (size_t)NB * 8;
-    uint64_t *dst_h0 = (uint64_t *)w; w += (size_t)(NB + 1) * 8;
-    uint64_t *dst_b0 = (uint64_t *)w; w += (size_t)(NB + 1) * 8;
-    uint32_t *n_h = (uint32_t *)w; w += (size_t)NB * 4;
-    w = (uint8_t *)(((uintptr_t)w + 63) & ~(uintptr_t)63);
-    void *slices_d = w;
-    fdgpu_index *fin = new (std::nothrow) fdgpu_index();
-    if (!fin) { drop(); return FDGPU_ENOMEM; }
-    fin->ctx = c; fin->value_len = Vt; fin->n_hashes = Ht; fin->n_postings = Pt; fin->n_structures = S; fin->first_id = first_id;
-    fin->value = (uint8_t *)c->pool_alloc(std::max<uint64_t>(Vt, 4), &e); fin->cap_value = c->last_cap;
-    if (e == hipSuccess) { fin->hashes = (uint32_t *)c->pool_alloc(std::max<uint64_t>(Ht, 1) * 4, &e); fin->cap_hashes = c->last_cap; }
-    if (e == hipSuccess) { fin->offsets = (uint64_t *)c->pool_alloc((Ht + 1) * 8, &e); fin->cap_offsets = c->last_cap; }
-    if (e == hipSuccess) e = hipMemcpyAsync(slices_d, sh.data(), (size_t)G * sizeof(slice_h), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        StageTimer t(c, "bk_assemble", 2 * (Vt + Ht * 12));
-        fd_bk_asm_ranges(slices_d, G, src_h0, n_h, n_b, st);
-        fd_exclusive_scan<uint32_t>(n_h, NB, dst_h0, c->ws[WS_SCANTMP].as<uint64_t>(), c->ws[WS_TOTAL].as<uint64_t>(), st);
-        fd_exclusive_scan<uint64_t>((const uint64_t *)n_b, NB, dst_b0, c->ws[WS_SCANTMP].as<uint64_t>(), c->ws[WS_TOTAL].as<uint64_t>(), st);
-        fd_bk_asm_copy(slices_d, G, src_h0, n_h, dst_h0, dst_b0, fin->hashes, fin->offsets, fin->value, st);
-        e = hipMemcpyAsync(fin->offsets + Ht, &Vt, 8, hipMemcpyHostToDevice, st);
-    }
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(st);   // the slices go back to the pool below
-    drop();
-    if (e != hipSuccess) { fdgpu_index_destroy(fin); c->err = std::string("assemble: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-    *out = fin;
-    return FDGPU_OK;
-}
-
 extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_params *p, uint64_t first_id, fdgpu_index **out) {
     const char *e32 = getenv("FDGPU_IDS32");   // FDGPU_IDS32=1 forces the 8-byte sort elements (read per call: tests flip it)
-    const char *ebk = getenv("FDGPU_BUILD");   // FDGPU_BUILD=classic: sort-everything path (4 radix passes over all the elements)
-    if (!c || !b || !p || !out) return FDGPU_EINVAL;
-    const bool force32 = e32 && e32[0] == '1';
-    if (!(ebk && !strcmp(ebk, "classic")) && !force32 && p->hash_type == FDGPU_HASH_PDBTR && p->n_multiple_bins == 0 && b->n_struct < (1ull << 24) &&
-        fd_make_consts_cfg(p, 0).use_tab) {
-        int rb = index_build_bucketed(c, b, p, first_id, out);
-        if (rb != FDGPU_RETRY_CLASSIC) return rb;
-    }
-    int rc = index_build_impl(c, b, p, first_id, out, force32);
+    int rc = index_build_impl(c, b, p, first_id, out, e32 && e32[0] == '1');
     if (rc == FDGPU_RETRY_WIDE) rc = index_build_impl(c, b, p, first_id, out, true);
     return rc;
 }

@@ -32,7 +32,6 @@ struct fd_timing_entry { const char *name; hipEvent_t ev0, ev1; uint64_t bytes; 
 enum {
     WS_COUNTS, WS_CURSOR, WS_SEGOFF, WS_SCANTMP, WS_TOTAL, WS_KEYS_A, WS_IDS_A, WS_KEYS_B, WS_IDS_B, WS_GHIST, WS_TOT,
     WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
-    WS_BK_M, WS_BK_PART, WS_BK_BTOT, WS_BK_BBASE, WS_BK_TFIRST, WS_BK_TILEB, WS_BK_ENCB, WS_BK_ASM,
     WS_COUNT
 };
 
@@ -157,29 +156,6 @@ void fd_launch_enc_write(const uint32_t *keys, const void *ids, bool ids16, uint
 void fd_launch_uniq_flags(const uint32_t *keys, const uint32_t *ids, uint64_t n, uint8_t *flags, hipStream_t st);
 void fd_launch_compact(const uint32_t *keys, const uint8_t *flags, const uint64_t *pos, uint64_t n, uint32_t *out, hipStream_t st);
 void fd_launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t n, uint64_t *dst, hipStream_t st);
-
-// k_bucket.hip / segmented sort / bucket-aware encoder (bucketed index build)
-uint32_t fd_bk_num_buckets();
-uint32_t fd_bk_row_blocks(uint64_t n_struct);
-void fd_bk_count(const fd_batch_view &B, const void *frames, float d2_max, float dist_disc, uint32_t *M, unsigned long long *wide_flag, hipStream_t st);
-void fd_bk_colscan(uint32_t *M, uint64_t n_struct, uint32_t *part, unsigned long long *btot, hipStream_t st);
-void fd_bk_bases(const unsigned long long *btot, uint32_t group, uint32_t n_groups, uint32_t sort_tile, unsigned long long *bbase, uint32_t *tfirst,
-                 uint32_t enc_tile, uint32_t *tile_bucket, uint32_t *enc_bucket, hipStream_t st);
-void fd_bk_emit(const fd_batch_view &B, const void *frames, const fd_hash_consts &C, const uint32_t *M, const unsigned long long *bbase, uint32_t group,
-                uint32_t n_groups, uint32_t *keys, uint8_t *idh, unsigned long long *err_flag, hipStream_t st);
-void fd_bk_asm_ranges(const void *slices, uint32_t n_groups, unsigned long long *src_h0, uint32_t *n_h, unsigned long long *n_b, hipStream_t st);
-void fd_bk_asm_copy(const void *slices, uint32_t n_groups, const unsigned long long *src_h0, const uint32_t *n_h, const uint64_t *dst_h0, const uint64_t *dst_b0,
-                    uint32_t *out_hashes, uint64_t *out_offsets, uint8_t *out_value, hipStream_t st);
-uint32_t fd_seg_tile();
-void fd_seg_sort16(uint32_t *keys_a, uint8_t *pay_a, uint32_t *keys_b, uint8_t *pay_b, const unsigned long long *bbase, const uint32_t *tfirst,
-                   const uint32_t *tile_bucket, uint32_t n_buckets, uint32_t tiles_bound, uint64_t n_elems, uint32_t *ghist, uint64_t *tot, hipStream_t st,
-                   fdgpu_ctx *tc);
-uint32_t fd_enc_tile();
-void fd_launch_enc_sizes_bk(const uint32_t *keys, const uint8_t *pay, uint32_t first_id, uint64_t n, const unsigned long long *bbase, const uint32_t *enc_bucket,
-                            uint32_t *tb, uint32_t *th, uint32_t *tp, hipStream_t st);
-void fd_launch_enc_write_bk(const uint32_t *keys, const uint8_t *pay, uint32_t first_id, uint64_t n, const unsigned long long *bbase, const uint32_t *enc_bucket,
-                            const uint64_t *tbo, const uint64_t *tho, uint8_t *value, uint32_t *hashes, uint64_t *offsets, const uint64_t *total_bytes_dev, uint64_t H,
-                            hipStream_t st);
 
 // k_query.hip
 struct cq_args {

@@ -211,150 +211,6 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__res
     }
 }
 
-// ---- bucketed element form (k_bucket.hip): keys[p] = (hash & 0xffff) << 16 | (local & 0xffff), optional pay[p] = local >> 16; the
-// top 14 hash bits are the element's bucket: p in [bbase[b], bbase[b + 1]) <=> hash >> 16 == top14(b).  enc_bucket[tile] = bucket of
-// the tile's first element, every thread walks on from there (a hash run never crosses a bucket, so a bucket change is a head).
-__device__ __forceinline__ uint32_t bk_top_of_bucket(uint32_t b) { return (b / 320u) << 9 | ((b / 16u) % 20u) << 4 | (b & 15u); }
-template <bool PAY>
-__device__ __forceinline__ void enc_load_classify_bk(const uint32_t *__restrict__ keys, const uint8_t *__restrict__ pay, uint64_t n, uint64_t base, uint32_t first_id,
-                                                     const unsigned long long *__restrict__ bbase, uint32_t b, enc_item *it) {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    uint32_t k[ENC_ITEMS], v[ENC_ITEMS];
-    if (base + ENC_ITEMS <= n) {
-        const u32x4 *kp = reinterpret_cast<const u32x4 *>(keys + base);
-        u32x4 a = __builtin_nontemporal_load(&kp[0]), c = __builtin_nontemporal_load(&kp[1]);
-        k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = c.x; k[5] = c.y; k[6] = c.z; k[7] = c.w;
-        if (PAY) {
-            const uint2 w = __builtin_nontemporal_load(reinterpret_cast<const uint2 *>(pay + base));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = (w.x >> (8 * j)) & 0xffu; v[4 + j] = (w.y >> (8 * j)) & 0xffu; }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < ENC_ITEMS; ++j) {
-            uint64_t p = base + j;
-            k[j] = p < n ? keys[p] : 0u;
-            v[j] = (PAY && p < n) ? (uint32_t)pay[p] : 0u;
-        }
-    }
-    if (!PAY) {
-#pragma unroll
-        for (int j = 0; j < ENC_ITEMS; ++j) v[j] = 0u;
-    }
-    uint32_t pk = __shfl_up(k[ENC_ITEMS - 1], 1, FD_WAVE), pv = __shfl_up(v[ENC_ITEMS - 1], 1, FD_WAVE);
-    if ((threadIdx.x & 63) == 0 && base > 0 && base < n) { pk = keys[base - 1]; pv = PAY ? (uint32_t)pay[base - 1] : 0u; }
-    if (base >= n) {
-#pragma unroll
-        for (int j = 0; j < ENC_ITEMS; ++j) { it[j].hash = 0; it[j].head = 0; it[j].delta = 0; it[j].len = 0; }
-        return;
-    }
-    while (base >= bbase[b + 1]) ++b;
-    unsigned long long b_lo = bbase[b], b_hi = bbase[b + 1];
-    uint32_t top = bk_top_of_bucket(b) << 16;
-    // predecessor of the thread's first element: inside the same bucket -> its hash shares the top bits, otherwise a different hash
-    bool have_prev = base > b_lo;
-    uint32_t ph = top | (pk >> 16), pid = first_id + ((pv << 16) | (pk & 0xffffu));
-#pragma unroll
-    for (int j = 0; j < ENC_ITEMS; ++j) {
-        const uint64_t p = base + j;
-        const bool in = p < n;
-        if (in && p >= b_hi) {
-            do { ++b; } while (p >= bbase[b + 1]);
-            b_lo = bbase[b]; b_hi = bbase[b + 1];
-            top = bk_top_of_bucket(b) << 16;
-            have_prev = false;
-        }
-        const uint32_t h = top | (k[j] >> 16), id = first_id + ((v[j] << 16) | (k[j] & 0xffffu));
-        const bool head = !have_prev || ph != h;
-        const bool dup = !head && pid == id;
-        it[j].hash = h;
-        it[j].head = (in && head) ? 1u : 0u;
-        it[j].delta = head ? id : id - pid;
-        it[j].len = (!in || dup) ? 0u : varint_len(it[j].delta);
-        ph = h; pid = id; have_prev = true;
-    }
-}
-
-template <bool PAY>
-__global__ __launch_bounds__(ENC_THREADS) void k_enc_sizes_bk(const uint32_t *__restrict__ keys, const uint8_t *__restrict__ pay, uint64_t n, uint32_t first_id,
-                                                              const unsigned long long *__restrict__ bbase, const uint32_t *__restrict__ enc_bucket,
-                                                              uint32_t *__restrict__ tile_bytes, uint32_t *__restrict__ tile_heads, uint32_t *__restrict__ tile_posts) {
-    __shared__ uint64_t sm[ENC_THREADS / 64];
-    uint64_t base = (uint64_t)blockIdx.x * ENC_TILE + (uint64_t)threadIdx.x * ENC_ITEMS;
-    uint32_t bytes = 0, heads = 0, posts = 0;
-    enc_item it[ENC_ITEMS];
-    enc_load_classify_bk<PAY>(keys, pay, n, base, first_id, bbase, enc_bucket[blockIdx.x], it);
-#pragma unroll
-    for (int k = 0; k < ENC_ITEMS; ++k) {
-        bytes += it[k].len;
-        heads += it[k].head;
-        posts += it[k].len ? 1u : 0u;
-    }
-    uint64_t tot;
-    block_excl_scan_packed(((uint64_t)bytes << 32) | heads, sm, &tot);
-    uint32_t pw = posts;
-    for (int off = 32; off > 0; off >>= 1) pw += __shfl_down(pw, off, FD_WAVE);
-    __shared__ uint32_t pp[ENC_THREADS / 64];
-    if ((threadIdx.x & 63) == 0) pp[threadIdx.x >> 6] = pw;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        tile_bytes[blockIdx.x] = (uint32_t)(tot >> 32);
-        tile_heads[blockIdx.x] = (uint32_t)tot;
-        uint32_t t = 0;
-        for (int w = 0; w < ENC_THREADS / 64; ++w) t += pp[w];
-        tile_posts[blockIdx.x] = t;
-    }
-}
-
-template <bool PAY>
-__global__ __launch_bounds__(ENC_THREADS) void k_enc_write_bk(const uint32_t *__restrict__ keys, const uint8_t *__restrict__ pay, uint64_t n, uint32_t first_id,
-                                                              const unsigned long long *__restrict__ bbase, const uint32_t *__restrict__ enc_bucket,
-                                                              const uint64_t *__restrict__ tile_byte_off, const uint64_t *__restrict__ tile_head_off,
-                                                              uint8_t *__restrict__ value, uint32_t *__restrict__ hashes, uint64_t *__restrict__ offsets) {
-    __shared__ uint64_t sm[ENC_THREADS / 64];
-    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[ENC_TILE * 5 + 32];
-    uint64_t base = (uint64_t)blockIdx.x * ENC_TILE + (uint64_t)threadIdx.x * ENC_ITEMS;
-    enc_item it[ENC_ITEMS];
-    uint32_t bytes = 0, heads = 0;
-    enc_load_classify_bk<PAY>(keys, pay, n, base, first_id, bbase, enc_bucket[blockIdx.x], it);
-#pragma unroll
-    for (int k = 0; k < ENC_ITEMS; ++k) { bytes += it[k].len; heads += it[k].head; }
-    uint64_t tot;
-    uint64_t ex = block_excl_scan_packed(((uint64_t)bytes << 32) | heads, sm, &tot);
-    const uint64_t tile_b0 = tile_byte_off[blockIdx.x];
-    const uint32_t shift = (uint32_t)(tile_b0 & 15ull);
-    uint32_t lo = shift + (uint32_t)(ex >> 32);
-    uint64_t boff = tile_b0 + (ex >> 32);
-    uint64_t hoff = tile_head_off[blockIdx.x] + (uint32_t)ex;
-#pragma unroll
-    for (int k = 0; k < ENC_ITEMS; ++k) {
-        if (it[k].head) {
-            hashes[hoff] = it[k].hash;
-            offsets[hoff] = boff;
-            ++hoff;
-        }
-        uint32_t v = it[k].delta;
-        for (uint32_t b = 0; b < it[k].len; ++b) {
-            uint32_t byte = v & 0x7fu;
-            v >>= 7;
-            s_bytes[lo++] = (uint8_t)(byte | (b + 1 < it[k].len ? 0x80u : 0u));
-        }
-        boff += it[k].len;
-    }
-    __syncthreads();
-    const uint32_t tile_len = (uint32_t)(tot >> 32);
-    const uint32_t end = shift + tile_len;
-    uint8_t *gbase = value + (tile_b0 - shift);
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    for (uint32_t c = threadIdx.x * 16; c < end; c += ENC_THREADS * 16) {
-        if (c >= shift && c + 16 <= end) {
-            *reinterpret_cast<u32x4 *>(gbase + c) = *reinterpret_cast<const u32x4 *>(s_bytes + c);
-        } else {
-            for (uint32_t b = c < shift ? shift : c; b < c + 16 && b < end; ++b) gbase[b] = s_bytes[b];
-        }
-    }
-}
-
 __global__ void k_set_u64(uint64_t *dst, uint64_t idx, const uint64_t *src) { dst[idx] = src[0]; }
 
 uint32_t fd_enc_num_tiles(uint64_t n) { return (uint32_t)((n + ENC_TILE - 1) / ENC_TILE); }
@@ -369,23 +225,6 @@ void fd_launch_enc_write(const uint32_t *keys, const void *ids, bool ids16, uint
     if (n) {
         if (ids16) hipLaunchKernelGGL(k_enc_write<uint16_t>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, (const uint16_t *)ids, n, first_id, tbo, tho, value, hashes, offsets);
         else hipLaunchKernelGGL(k_enc_write<uint32_t>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, (const uint32_t *)ids, n, first_id, tbo, tho, value, hashes, offsets);
-    }
-    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, offsets, H, total_bytes_dev);
-}
-
-uint32_t fd_enc_tile() { return ENC_TILE; }
-void fd_launch_enc_sizes_bk(const uint32_t *keys, const uint8_t *pay, uint32_t first_id, uint64_t n, const unsigned long long *bbase, const uint32_t *enc_bucket,
-                            uint32_t *tb, uint32_t *th, uint32_t *tp, hipStream_t st) {
-    if (!n) return;
-    if (pay) hipLaunchKernelGGL(k_enc_sizes_bk<true>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, pay, n, first_id, bbase, enc_bucket, tb, th, tp);
-    else hipLaunchKernelGGL(k_enc_sizes_bk<false>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, pay, n, first_id, bbase, enc_bucket, tb, th, tp);
-}
-void fd_launch_enc_write_bk(const uint32_t *keys, const uint8_t *pay, uint32_t first_id, uint64_t n, const unsigned long long *bbase, const uint32_t *enc_bucket,
-                            const uint64_t *tbo, const uint64_t *tho, uint8_t *value, uint32_t *hashes, uint64_t *offsets, const uint64_t *total_bytes_dev, uint64_t H,
-                            hipStream_t st) {
-    if (n) {
-        if (pay) hipLaunchKernelGGL(k_enc_write_bk<true>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, pay, n, first_id, bbase, enc_bucket, tbo, tho, value, hashes, offsets);
-        else hipLaunchKernelGGL(k_enc_write_bk<false>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, pay, n, first_id, bbase, enc_bucket, tbo, tho, value, hashes, offsets);
     }
     hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, offsets, H, total_bytes_dev);
 }

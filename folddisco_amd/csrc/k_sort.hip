@@ -108,7 +108,6 @@ void fd_exclusive_scan(const TIn *in, uint64_t n, uint64_t *out /*[n+1]*/, uint6
 }
 template void fd_exclusive_scan<uint32_t>(const uint32_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *, hipStream_t);
 template void fd_exclusive_scan<uint8_t>(const uint8_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *, hipStream_t);
-template void fd_exclusive_scan<uint64_t>(const uint64_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *, hipStream_t);
 uint64_t fd_scan_tmp_elems(uint64_t n) { return (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1; }
 
 // ------------------------------------------------------------------------ radix sort
@@ -423,187 +422,4 @@ int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, ui
 int fd_radix_sort_pairs16(uint32_t *keys_a, uint16_t *vals_a, uint32_t *keys_b, uint16_t *vals_b, uint64_t n, int key_bits,
                           uint32_t *ghist, uint64_t *tot, hipStream_t st, fdgpu_ctx *tc) {
     return radix_sort_pairs_t<uint16_t>(keys_a, vals_a, keys_b, vals_b, n, key_bits, ghist, tot, st, tc);
-}
-
-// ------------------------------------------------------------------------ segmented passes (bucketed index build, k_bucket.hip)
-// The element buffer is partitioned into buckets [bbase[b], bbase[b + 1]); a pass sorts every bucket by one digit, stably.  Sort
-// tiles never straddle a bucket (bucket b owns tiles [tfirst[b], tfirst[b + 1]), the last one partial).  The tile histograms go
-// through the SAME global scan as the unsegmented sort (k_rs_scan_*): G[t][d] = count of digit d in all tiles before t, and a
-// bucket's own prefix is a difference of two rows —
-//   position(t, d) = bbase[b] + excl_scan_d(G[tfirst[b+1]][.] - G[tfirst[b]][.])[d] + G[t][d] - G[tfirst[b]][d]
-// (differences of the 32-bit table entries are exact mod 2^32; a bucket holds fewer than 2^32 elements).
-struct seg_desc {
-    const unsigned long long *bbase;   // [NB + 1]
-    const uint32_t *tfirst;            // [NB + 1]
-    const uint32_t *tile_bucket;       // [tiles]
-    uint32_t nb_bucket;                // NB
-    uint32_t nb_bound;                 // rows of the histogram table that are scanned (>= tiles + 1)
-};
-
-template <int THREADS, int ITEMS>
-__global__ __launch_bounds__(THREADS) void k_seg_hist(const uint32_t *__restrict__ keys, seg_desc D, uint32_t shift, uint32_t mask, uint32_t *__restrict__ ghist) {
-    constexpr int TILE = THREADS * ITEMS;
-    __shared__ uint32_t h[RS_BINS];
-    const uint32_t tile = fd_xcd_remap(blockIdx.x, D.nb_bound);
-    if (tile >= D.nb_bound) return;
-    for (int k = threadIdx.x; k < RS_BINS; k += THREADS) h[k] = 0;
-    __syncthreads();
-    if (tile < D.tfirst[D.nb_bucket]) {
-        const uint32_t b = D.tile_bucket[tile];
-        const unsigned long long base = D.bbase[b] + (unsigned long long)(tile - D.tfirst[b]) * TILE, end = D.bbase[b + 1];
-        const uint32_t n = end - base < (unsigned long long)TILE ? (uint32_t)(end - base) : (uint32_t)TILE;
-        const uint32_t *kp = keys + base;
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-            const uint32_t idx = (uint32_t)k * THREADS + threadIdx.x;
-            if (idx < n) atomicAdd(&h[(__builtin_nontemporal_load(&kp[idx]) >> shift) & mask], 1u);
-        }
-        __syncthreads();
-    }
-    for (int k = threadIdx.x; k < RS_BINS; k += THREADS) ghist[(uint64_t)tile * RS_BINS + k] = h[k];   // rows past the last tile: zeros
-}
-
-// one sort tile of one bucket: ranks as in rs_scatter4_body (ballot multi-split with v_bitop3 peer masks, no LDS atomics), keys
-// [+ one payload byte] reordered digit-contiguously in LDS and written as runs
-template <int THREADS, int ITEMS, bool PAYLOAD>
-__global__ __launch_bounds__(THREADS) void k_seg_scatter(const uint32_t *__restrict__ keys_in, const uint8_t *__restrict__ pay_in, uint32_t *__restrict__ keys_out,
-                                                         uint8_t *__restrict__ pay_out, seg_desc D, uint32_t shift, uint32_t mask,
-                                                         const uint32_t *__restrict__ ghist) {
-    constexpr int TILE = THREADS * ITEMS;
-    constexpr int WAVES = THREADS / 64;
-    __shared__ uint32_t s_keys[TILE];
-    __shared__ uint8_t s_pay[PAYLOAD ? TILE : 1];
-    __shared__ uint32_t s_cnt[WAVES][RS_BINS];
-    __shared__ long long s_gofs[RS_BINS];
-    __shared__ uint64_t sm[17];
-    const uint32_t n_tiles = D.tfirst[D.nb_bucket];
-    const uint32_t tile = fd_xcd_remap(blockIdx.x, n_tiles);
-    if (tile >= n_tiles) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint32_t b = D.tile_bucket[tile], tf = D.tfirst[b], tl = D.tfirst[b + 1];
-    const unsigned long long bucket_base = D.bbase[b];
-    const unsigned long long tile_base = bucket_base + (unsigned long long)(tile - tf) * TILE, end = D.bbase[b + 1];
-    const uint32_t n_tile = end - tile_base < (unsigned long long)TILE ? (uint32_t)(end - tile_base) : (uint32_t)TILE;
-    const bool full = n_tile == TILE;
-    const uint32_t wave_first = wid * 64 * ITEMS;
-    const uint32_t n_wave = n_tile > wave_first ? (n_tile - wave_first < 64u * ITEMS ? n_tile - wave_first : 64u * ITEMS) : 0u;
-
-    for (int k = tid; k < WAVES * RS_BINS; k += THREADS) (&s_cnt[0][0])[k] = 0;
-    uint32_t key[ITEMS];
-    uint32_t pay[ITEMS];
-    const uint32_t *kp = keys_in + tile_base + wave_first + lane;
-    const uint8_t *pp = PAYLOAD ? pay_in + tile_base + wave_first + lane : nullptr;
-#pragma unroll
-    for (int c = 0; c < ITEMS; ++c) {
-        const bool ok = full || (uint32_t)(c * 64) + lane < n_wave;
-        key[c] = ok ? kp[c * 64] : 0xffffffffu;
-        pay[c] = (PAYLOAD && ok) ? pp[c * 64] : 0u;
-    }
-    // digit positions of this tile
-    long long gbase = 0;
-    uint32_t bucket_digit = 0;
-    if (tid < RS_BINS) {
-        const uint32_t g_t = ghist[(uint64_t)tile * RS_BINS + tid], g_f = ghist[(uint64_t)tf * RS_BINS + tid], g_l = ghist[(uint64_t)tl * RS_BINS + tid];
-        bucket_digit = g_l - g_f;
-        gbase = (long long)(g_t - g_f);
-    }
-    __syncthreads();
-    {
-        uint64_t tot;
-        const uint64_t ex = block_excl_scan_u64(tid < RS_BINS ? (uint64_t)bucket_digit : 0ull, sm, &tot);
-        gbase += (long long)(bucket_base + ex);
-    }
-    uint32_t rnk[ITEMS];
-    uint32_t *cnt = s_cnt[wid];
-#pragma unroll
-    for (int c = 0; c < ITEMS; ++c) {
-        const uint32_t d = (key[c] >> shift) & mask;
-        uint32_t plo = ~0u, phi = ~0u;
-        bool ok = true;
-        if (!full) {
-            ok = (uint32_t)(c * 64) + lane < n_wave;
-            const uint64_t okm = __ballot(ok);
-            plo = (uint32_t)okm; phi = (uint32_t)(okm >> 32);
-        }
-#pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-            const int32_t m = __builtin_amdgcn_sbfe((int32_t)d, bit, 1);
-            const uint64_t bal = __builtin_amdgcn_ballot_w64(m < 0);
-            plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, (uint32_t)m, 0x90);
-            phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), (uint32_t)m, 0x90);
-        }
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
-        const uint32_t pcount = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
-        uint32_t base = 0;
-        if (ok) base = cnt[d];
-        if (ok && rank == pcount - 1) cnt[d] = base + pcount;
-        rnk[c] = base + rank;
-    }
-    __syncthreads();
-    {
-        uint32_t my_total = 0;
-        if (tid < RS_BINS) {
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) my_total += s_cnt[w][tid];
-        }
-        uint64_t tot;
-        const uint32_t dstart = (uint32_t)block_excl_scan_u64(tid < RS_BINS ? (uint64_t)my_total : 0ull, sm, &tot);
-        if (tid < RS_BINS) {
-            uint32_t run = dstart;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) { uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
-            s_gofs[tid] = gbase - (long long)dstart;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < ITEMS; ++c) {
-        if (full || (uint32_t)(c * 64) + lane < n_wave) {
-            const uint32_t pos = cnt[(key[c] >> shift) & mask] + rnk[c];
-            s_keys[pos] = key[c];
-            if (PAYLOAD) s_pay[pos] = (uint8_t)pay[c];
-        }
-    }
-    __syncthreads();
-    for (uint32_t k = tid; k < n_tile; k += THREADS) {
-        const uint32_t kk = s_keys[k];
-        const long long g = (long long)k + s_gofs[(kk >> shift) & mask];
-        keys_out[g] = kk;
-        if (PAYLOAD) pay_out[g] = s_pay[k];
-    }
-}
-
-// two stable passes over key bits [16, 32) inside every bucket; returns 0 (result in the B buffers' ... see below): pass 1 A -> B,
-// pass 2 B -> A, so the sorted elements end in the A buffers.  tiles_bound >= number of sort tiles (host upper bound).
-#define SEG_THREADS 512
-#define SEG_ITEMS 16
-uint32_t fd_seg_tile() { return SEG_THREADS * SEG_ITEMS; }
-void fd_seg_sort16(uint32_t *keys_a, uint8_t *pay_a, uint32_t *keys_b, uint8_t *pay_b, const unsigned long long *bbase, const uint32_t *tfirst,
-                   const uint32_t *tile_bucket, uint32_t n_buckets, uint32_t tiles_bound, uint64_t n_elems, uint32_t *ghist, uint64_t *tot, hipStream_t st,
-                   fdgpu_ctx *tc) {
-    seg_desc D;
-    D.bbase = bbase; D.tfirst = tfirst; D.tile_bucket = tile_bucket; D.nb_bucket = n_buckets; D.nb_bound = tiles_bound + 1;
-    const uint32_t grid = ((D.nb_bound + 7u) / 8u) * 8u;
-    for (int pass = 0; pass < 2; ++pass) {
-        const uint32_t shift = 16u + 8u * (uint32_t)pass, mask = 0xffu;
-        uint32_t *ki = pass ? keys_b : keys_a, *ko = pass ? keys_a : keys_b;
-        uint8_t *pi = pass ? pay_b : pay_a, *po = pass ? pay_a : pay_b;
-        {
-            StageTimer t(tc, "seg_hist", n_elems * 4 + (uint64_t)D.nb_bound * RS_BINS * 4);
-            hipLaunchKernelGGL((k_seg_hist<SEG_THREADS, SEG_ITEMS>), dim3(grid), dim3(SEG_THREADS), 0, st, ki, D, shift, mask, ghist);
-        }
-        {
-            StageTimer t(tc, "seg_scan", (uint64_t)D.nb_bound * RS_BINS * 8);
-            const uint32_t n_chunks = (D.nb_bound + RS_SCAN_CHUNK - 1) / RS_SCAN_CHUNK;
-            uint64_t *csum = tot + RS_BINS;
-            hipLaunchKernelGGL(k_rs_scan_csum, dim3(n_chunks), dim3(RS_BINS), 0, st, ghist, D.nb_bound, csum);
-            hipLaunchKernelGGL(k_rs_scan_chunks, dim3(RS_BINS / 16), dim3(1024), 0, st, csum, n_chunks, tot);
-            hipLaunchKernelGGL(k_rs_scan_apply, dim3(n_chunks), dim3(RS_BINS), 0, st, ghist, D.nb_bound, csum);
-        }
-        {
-            StageTimer t(tc, "seg_scatter", n_elems * (pay_a ? 10 : 8));
-            if (pay_a) hipLaunchKernelGGL((k_seg_scatter<SEG_THREADS, SEG_ITEMS, true>), dim3(grid), dim3(SEG_THREADS), 0, st, ki, pi, ko, po, D, shift, mask, ghist);
-            else hipLaunchKernelGGL((k_seg_scatter<SEG_THREADS, SEG_ITEMS, false>), dim3(grid), dim3(SEG_THREADS), 0, st, ki, pi, ko, po, D, shift, mask, ghist);
-        }
-    }
 }

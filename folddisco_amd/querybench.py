@@ -10,8 +10,7 @@ all-gathered.  queries/s = Q / wall time of the loop (max over ranks).
 
 Roofline: B_q = sum of posting bytes of the query's hashes + 8 T (touched structures) + (nodes + edges) S / 8,
 over the HIP-event time of the scoring stage (k_cq_accumulate_batch + finalize + compaction scan).
-cpu_baseline: oracle/fdo_bench.c (the reference's make_query_map + count_query + retrieval per query, OpenMP over queries
-where the reference uses rayon) against the SAME index (the export of the resident index) on the host cores."""
+cpu_baseline: supplied by bench.py as a callback (the product package never touches oracle/)."""
 from __future__ import annotations
 
 import os
@@ -48,7 +47,7 @@ def _pick_queries(d, S, n_queries, seed, k=4):
 
 
 def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, match_top=32, seed=4242, lo=0, S_total=None,
-        cpu_baseline=False, hbm_peak_gbs=8000.0):
+        cpu_baseline_fn=None, hbm_peak_gbs=8000.0):
     S_total = S * world if S_total is None else S_total
     sharded = dist is not None          # every rank holds the postings of its own structures only
     # rank 0 cuts the motifs out of its shard and broadcasts them: every rank scores the SAME queries against its own shard
@@ -181,26 +180,9 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     }
 
     cpu = None
-    if cpu_baseline:
+    if cpu_baseline_fn is not None:     # bench.py's cpu_baseline leg (the only place that may use oracle/)
         try:
-            import oracle
-            v, h, o = ix.export_view()
-            n_xyz, ca_xyz, cb_xyz, aa = (d[k].cpu().numpy() for k in ("n_xyz", "ca_xyz", "cb_xyz", "aa"))
-            cores = os.cpu_count() or 1
-            qlist = [(s, idx) for s, idx, _ in queries]
-            reps = max(1, min(8, cores // max(len(qlist), 1)))     # enough queries to occupy the cores
-            r_all = oracle.query_bench(h, o, v, nres, res_off_h.astype(np.uint64), n_xyz, ca_xyz, cb_xyz, aa, qlist * reps, top_n=top_n,
-                                       match_top=match_top, n_threads=cores)
-            r64 = oracle.query_bench(h, o, v, nres, res_off_h.astype(np.uint64), n_xyz, ca_xyz, cb_xyz, aa, qlist, top_n=top_n,
-                                     match_top=match_top, n_threads=min(64, cores))
-            cpu = {"value": len(qlist) * reps / r_all["wall_s"], "unit": "queries/s", "cores": cores, "kind": "port",
-                   "sample": "the same %d queries x%d against the export of the same resident index (%d structures): make_query_map + count_query + "
-                             "sort/truncate %d + retrieval of the top %d, OpenMP over queries (query_pdb.rs:348), %.1f s wall" %
-                             (len(qlist), reps, S, top_n, match_top, r_all["wall_s"]),
-                   "stage_thread_s": {k: round(x, 2) for k, x in r_all["stage_thread_s"].items()}, "matches": r_all["matches"] // reps,
-                   "t64": {"value": len(qlist) / r64["wall_s"], "cores": min(64, cores), "wall_s": round(r64["wall_s"], 2),
-                           "stage_thread_s": {k: round(x, 2) for k, x in r64["stage_thread_s"].items()}}}
-            del v, h, o
+            cpu = cpu_baseline_fn(ix, d, nres, res_off_h, [(s, idx) for s, idx, _ in queries], top_n, match_top, S)
         except Exception as e:  # noqa: BLE001 — the bench line must still be printed
             cpu = {"error": repr(e)}
 
