@@ -190,14 +190,16 @@ class FolddiscoIndex:
         return FolddiscoIndex(ctx, h, batch.n_struct, first_id)
 
     @staticmethod
-    def load(ctx: Context, hashes: np.ndarray, offsets: np.ndarray, value: np.ndarray, n_structures: int) -> "FolddiscoIndex":
+    def load(ctx: Context, hashes: np.ndarray, offsets: np.ndarray, value: np.ndarray, n_structures: int, first_id: int = 0) -> "FolddiscoIndex":
         hashes = np.ascontiguousarray(hashes, dtype=np.uint32)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         value = np.ascontiguousarray(value, dtype=np.uint8)
         h = C.c_void_p()
         ctx.check(ctx.L.fdgpu_index_load(ctx.h, _ptr(hashes, u32p), _ptr(offsets, u64p), len(hashes), _ptr(value, u8p), len(value),
                                          n_structures, C.byref(h)))
-        return FolddiscoIndex(ctx, h, n_structures)
+        if first_id:
+            ctx.check(ctx.L.fdgpu_index_set_first_id(h, first_id))
+        return FolddiscoIndex(ctx, h, n_structures, first_id)
 
     @property
     def num_hashes(self) -> int:

@@ -416,9 +416,11 @@ extern "C" void fdgpu_index_destroy(fdgpu_index *ix) {
     if (!ix) return;
     if (ix->ctx) {
         ix->ctx->pool_free(ix->hashes, ix->cap_hashes); ix->ctx->pool_free(ix->offsets, ix->cap_offsets); ix->ctx->pool_free(ix->value, ix->cap_value);
-    } else { (void)hipFree(ix->hashes); (void)hipFree(ix->offsets); (void)hipFree(ix->value); }
+        ix->ctx->pool_free(ix->last_ids, ix->cap_last);
+    } else { (void)hipFree(ix->hashes); (void)hipFree(ix->offsets); (void)hipFree(ix->value); (void)hipFree(ix->last_ids); }
     delete ix;
 }
+extern "C" int fdgpu_index_set_first_id(fdgpu_index *ix, uint64_t first_id) { if (!ix || first_id + ix->n_structures > 0xffffffffull) return FDGPU_EINVAL; ix->first_id = first_id; return FDGPU_OK; }
 extern "C" uint64_t fdgpu_index_num_hashes(const fdgpu_index *ix) { return ix ? ix->n_hashes : 0; }
 extern "C" uint64_t fdgpu_index_value_len(const fdgpu_index *ix) { return ix ? ix->value_len : 0; }
 extern "C" uint64_t fdgpu_index_num_postings(const fdgpu_index *ix) { return ix ? ix->n_postings : 0; }
@@ -526,6 +528,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     ix->value = (uint8_t *)c->pool_alloc(std::max<uint64_t>(ix->value_len, 4), &e); ix->cap_value = c->last_cap;
     if (e == hipSuccess) { ix->hashes = (uint32_t *)c->pool_alloc(std::max<uint64_t>(ix->n_hashes, 1) * 4, &e); ix->cap_hashes = c->last_cap; }
     if (e == hipSuccess) { ix->offsets = (uint64_t *)c->pool_alloc((ix->n_hashes + 1) * 8, &e); ix->cap_offsets = c->last_cap; }
+    if (e == hipSuccess) { ix->last_ids = (uint32_t *)c->pool_alloc(std::max<uint64_t>(ix->n_hashes, 1) * 4, &e); ix->cap_last = c->last_cap; }
     if (e != hipSuccess) {
         c->err = std::string("index alloc: ") + hipGetErrorString(e);
         fdgpu_index_destroy(ix);
@@ -534,7 +537,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     {
         StageTimer t(c, "encode_write", P * (ids16 ? 6 : 8) + ix->value_len + ix->n_hashes * 12);
         fd_launch_enc_write(ks, is, ids16, (uint32_t)first_id, P, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_TILE_HO].as<uint64_t>(), ix->value, ix->hashes, ix->offsets,
-                            c->ws[WS_MISC3].as<uint64_t>(), ix->n_hashes, st);
+                            ix->last_ids, c->ws[WS_MISC3].as<uint64_t>(), ix->n_hashes, st);
     }
     e = hipGetLastError();
     if (e != hipSuccess) { c->err = std::string("encode launch: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }
@@ -575,7 +578,7 @@ extern "C" int fdgpu_index_load(fdgpu_ctx *c, const uint32_t *hashes, const uint
     ix->ctx = nullptr; ix->n_hashes = H; ix->value_len = vlen; ix->n_structures = n_structures;
     hipError_t e;
     uint64_t zero = 0;
-    if ((e = hipMalloc((void **)&ix->value, std::max<uint64_t>(vlen, 4))) != hipSuccess ||
+    if ((e = hipMalloc((void **)&ix->value, std::max<uint64_t>(vlen, 4) + 16)) != hipSuccess ||
         (e = hipMalloc((void **)&ix->hashes, std::max<uint64_t>(H, 1) * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&ix->offsets, (H + 1) * 8)) != hipSuccess ||
         (vlen && (e = hipMemcpyAsync(ix->value, value, vlen, hipMemcpyHostToDevice, c->stream)) != hipSuccess) ||
@@ -593,13 +596,14 @@ extern "C" int fdgpu_index_load(fdgpu_ctx *c, const uint32_t *hashes, const uint
 }
 
 // ---- device merge of sub-indices (k_merge.hip) ---------------------------------------------------------------------
-struct mg_part_h { const uint32_t *hashes; const uint64_t *offsets; const uint8_t *value; uint64_t H; };
+struct mg_part_h { const uint32_t *hashes; const uint64_t *offsets; const uint8_t *value; const uint32_t *last_ids; uint64_t H; };
+void fd_mg_last_ids(const uint64_t *offsets, const uint8_t *value, uint64_t H, uint32_t *last_ids, hipStream_t st);
 void fd_mg_bitmap_set(const uint32_t *hashes, uint64_t n, uint32_t *bitmap, hipStream_t st);
 void fd_mg_popc(const uint32_t *bitmap, uint64_t n_words, uint32_t *cnt, hipStream_t st);
 void fd_mg_expand(const uint32_t *bitmap, const uint64_t *prefix, uint64_t n_words, uint32_t *out, hipStream_t st);
 void fd_mg_pos_fill(const uint32_t *hashes, uint64_t n, const uint32_t *bitmap, const uint64_t *prefix, uint32_t *pos, uint32_t part, uint32_t n_parts,
                     hipStream_t st);
-void fd_mg_sizes(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, uint32_t *sizes, hipStream_t st);
+void fd_mg_sizes(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, uint32_t *sizes, uint32_t *out_last, hipStream_t st);
 void fd_mg_copy(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, const uint64_t *out_off, uint8_t *out_value, hipStream_t st);
 
 extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, uint64_t n_parts, fdgpu_index **out) {
@@ -615,7 +619,13 @@ extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, 
         if (!p) return FDGPU_EINVAL;
         if (k && p->first_id != parts[k - 1]->first_id + parts[k - 1]->n_structures)
             FAIL(c, FDGPU_EINVAL, "index merge: parts must cover consecutive structure-id ranges in the order given");
-        ph[k] = {p->hashes, p->offsets, p->value, p->n_hashes};
+        if (!p->last_ids && p->n_hashes) {     // a loaded index: last id of every list by one decode pass, kept with the index
+            fdgpu_index *mp = const_cast<fdgpu_index *>(p);
+            hipError_t le = hipMalloc((void **)&mp->last_ids, p->n_hashes * 4);
+            if (le != hipSuccess) { c->err = std::string("index merge: ") + hipGetErrorString(le); return FDGPU_EHIP; }
+            fd_mg_last_ids(p->offsets, p->value, p->n_hashes, mp->last_ids, st);
+        }
+        ph[k] = {p->hashes, p->offsets, p->value, p->last_ids, p->n_hashes};
         n_struct += p->n_structures; n_post += p->n_postings; sum_h += p->n_hashes; sum_v += p->value_len;
     }
     // hash space: 2^30 unless a part holds an overflowed hash (unmasked OR of the fields)
@@ -654,6 +664,7 @@ extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, 
     hipError_t e;
     ix->hashes = (uint32_t *)c->pool_alloc(std::max<uint64_t>(Ht, 1) * 4, &e); ix->cap_hashes = c->last_cap;
     if (e == hipSuccess) { ix->offsets = (uint64_t *)c->pool_alloc((Ht + 1) * 8, &e); ix->cap_offsets = c->last_cap; }
+    if (e == hipSuccess) { ix->last_ids = (uint32_t *)c->pool_alloc(std::max<uint64_t>(Ht, 1) * 4, &e); ix->cap_last = c->last_cap; }
     if (e == hipSuccess) e = c->ws[WS_IDS_B].ensure(std::max<uint64_t>(Ht, 1) * n_parts * 4);
     if (e == hipSuccess) e = c->ws[WS_MISC0].ensure(std::max<uint64_t>(Ht, 1) * 4);
     if (e != hipSuccess) { c->err = std::string("index merge alloc: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }
@@ -663,7 +674,7 @@ extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, 
         fd_mg_expand(bitmap, prefix, n_words, ix->hashes, st);
         (void)hipMemsetAsync(pos, 0xff, std::max<uint64_t>(Ht, 1) * n_parts * 4, st);
         for (uint64_t k = 0; k < n_parts; ++k) fd_mg_pos_fill(ph[k].hashes, ph[k].H, bitmap, prefix, pos, (uint32_t)k, (uint32_t)n_parts, st);
-        fd_mg_sizes(c->ws[WS_MISC4].p, (uint32_t)n_parts, pos, Ht, sizes, st);
+        fd_mg_sizes(c->ws[WS_MISC4].p, (uint32_t)n_parts, pos, Ht, sizes, ix->last_ids, st);
         fd_exclusive_scan<uint32_t>(sizes, Ht, ix->offsets, c->ws[WS_SCANTMP].as<uint64_t>(), c->ws[WS_TOTAL].as<uint64_t>(), st);
     }
     e = hipGetLastError();

@@ -70,7 +70,7 @@ struct fdgpu_ctx {
     }
     void pool_free(void *p, size_t cap) {
         if (!p) return;
-        if (pool.size() >= 12) { (void)hipFree(p); return; }
+        if (pool.size() >= 96) { (void)hipFree(p); return; }   // a shard built as 8 sub-indices + their merge cycles through ~40 blocks per step
         pool.push_back({p, cap});
     }
     size_t last_cap = 0;
@@ -124,7 +124,9 @@ struct fdgpu_index {
     uint32_t *hashes = nullptr;   // device [H]
     uint64_t *offsets = nullptr;  // device [H+1]
     uint8_t *value = nullptr;     // device [value_len]
-    size_t cap_hashes = 0, cap_offsets = 0, cap_value = 0;
+    uint32_t *last_ids = nullptr; // device [H] last structure id of every list (written by the encoder; the device merge re-bases the next
+                                  // part's first delta against it); null for an index that was loaded — computed on demand
+    size_t cap_hashes = 0, cap_offsets = 0, cap_value = 0, cap_last = 0;
 };
 
 // kernels / launchers implemented in the k_*.hip files
@@ -152,7 +154,7 @@ uint32_t fd_enc_num_tiles(uint64_t n);
 void fd_launch_enc_sizes(const uint32_t *keys, const void *ids, bool ids16, uint32_t first_id, uint64_t n, uint32_t *tb, uint32_t *th, uint32_t *tp,
                          hipStream_t st);
 void fd_launch_enc_write(const uint32_t *keys, const void *ids, bool ids16, uint32_t first_id, uint64_t n, const uint64_t *tbo, const uint64_t *tho,
-                         uint8_t *value, uint32_t *hashes, uint64_t *offsets, const uint64_t *total_bytes_dev, uint64_t H, hipStream_t st);
+                         uint8_t *value, uint32_t *hashes, uint64_t *offsets, uint32_t *last_ids, const uint64_t *total_bytes_dev, uint64_t H, hipStream_t st);
 void fd_launch_uniq_flags(const uint32_t *keys, const uint32_t *ids, uint64_t n, uint8_t *flags, hipStream_t st);
 void fd_launch_compact(const uint32_t *keys, const uint8_t *flags, const uint64_t *pos, uint64_t n, uint32_t *out, hipStream_t st);
 void fd_launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t n, uint64_t *dst, hipStream_t st);

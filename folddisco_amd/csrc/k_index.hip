@@ -20,7 +20,7 @@ __device__ __forceinline__ uint32_t varint_len(uint32_t v) {
     return v == 0 ? 1u : 1u + (31u - (uint32_t)__clz(v)) / 7u;
 }
 
-struct enc_item { uint32_t len; uint32_t head; uint32_t delta; uint32_t hash; };
+struct enc_item { uint32_t len; uint32_t head; uint32_t delta; uint32_t hash; uint32_t prev; };   // prev: id of the preceding element (valid at a head that is not the first element)
 
 // two element encodings of the sorted stream:
 //   V = uint32_t : keys[p] = hash,                     vals[p] = structure id
@@ -46,6 +46,7 @@ __device__ __forceinline__ enc_item enc_classify(const uint32_t *__restrict__ ke
     bool dup = !head && pid == id;
     it.head = head ? 1u : 0u;
     it.delta = head ? id : id - pid;
+    it.prev = pid;
     it.len = dup ? 0u : varint_len(it.delta);
     return it;
 }
@@ -95,6 +96,7 @@ __device__ __forceinline__ void enc_load_classify(const uint32_t *__restrict__ k
         it[j].hash = h;
         it[j].head = (in && head) ? 1u : 0u;
         it[j].delta = head ? id : id - pid;
+        it[j].prev = pid;
         it[j].len = (!in || dup) ? 0u : varint_len(it[j].delta);
         ph = h; pid = id; have_prev = true;
     }
@@ -164,7 +166,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_sizes(const uint32_t *__res
 template <typename V>
 __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__restrict__ keys, const V *__restrict__ ids, uint64_t n, uint32_t first_id,
                                                            const uint64_t *__restrict__ tile_byte_off, const uint64_t *__restrict__ tile_head_off,
-                                                           uint8_t *__restrict__ value, uint32_t *__restrict__ hashes, uint64_t *__restrict__ offsets) {
+                                                           uint8_t *__restrict__ value, uint32_t *__restrict__ hashes, uint64_t *__restrict__ offsets,
+                                                           uint32_t *__restrict__ last_ids) {
     __shared__ uint64_t sm[ENC_THREADS / 64];
     // varint bytes of the tile are assembled in LDS (pre-shifted by the global misalignment) and leave as
     // 16-byte stores instead of one global byte store per byte
@@ -187,8 +190,10 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__res
         if (it[k].head) {
             hashes[hoff] = it[k].hash;
             offsets[hoff] = boff;
+            if (hoff) last_ids[hoff - 1] = it[k].prev;        // the list before this head ends on the preceding element
             ++hoff;
         }
+        if (base + k + 1 == n) last_ids[hoff - 1] = it[k].head ? it[k].delta : it[k].prev + it[k].delta;   // last element: its own id
         uint32_t v = it[k].delta;
         for (uint32_t b = 0; b < it[k].len; ++b) {
             uint32_t byte = v & 0x7fu;
@@ -221,10 +226,10 @@ void fd_launch_enc_sizes(const uint32_t *keys, const void *ids, bool ids16, uint
     else hipLaunchKernelGGL(k_enc_sizes<uint32_t>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, (const uint32_t *)ids, n, first_id, tb, th, tp);
 }
 void fd_launch_enc_write(const uint32_t *keys, const void *ids, bool ids16, uint32_t first_id, uint64_t n, const uint64_t *tbo, const uint64_t *tho,
-                         uint8_t *value, uint32_t *hashes, uint64_t *offsets, const uint64_t *total_bytes_dev, uint64_t H, hipStream_t st) {
+                         uint8_t *value, uint32_t *hashes, uint64_t *offsets, uint32_t *last_ids, const uint64_t *total_bytes_dev, uint64_t H, hipStream_t st) {
     if (n) {
-        if (ids16) hipLaunchKernelGGL(k_enc_write<uint16_t>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, (const uint16_t *)ids, n, first_id, tbo, tho, value, hashes, offsets);
-        else hipLaunchKernelGGL(k_enc_write<uint32_t>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, (const uint32_t *)ids, n, first_id, tbo, tho, value, hashes, offsets);
+        if (ids16) hipLaunchKernelGGL(k_enc_write<uint16_t>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, (const uint16_t *)ids, n, first_id, tbo, tho, value, hashes, offsets, last_ids);
+        else hipLaunchKernelGGL(k_enc_write<uint32_t>, dim3(fd_enc_num_tiles(n)), dim3(ENC_THREADS), 0, st, keys, (const uint32_t *)ids, n, first_id, tbo, tho, value, hashes, offsets, last_ids);
     }
     hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, offsets, H, total_bytes_dev);
 }

@@ -9,17 +9,17 @@
 //   union of the parts' hash sets    bitmap over the hash space (2^30 bits, 2^32 when a part holds an overflowed hash) +
 //                                    popcount prefix -> rank(h) = merged slot; coalesced, no sort
 //   slot -> position in every part   pos[slot][part] (u32, NONE = absent), filled by one pass over each part's hashes
-//   sizes / copy                     one wavefront per merged slot: lanes read the part's byte string 64 bytes at a time;
-//                                    the value of a varint stream's LAST id is the sum of all its deltas, i.e. the sum over
-//                                    bytes of (byte & 0x7f) << 7 * (position inside its varint) — a ballot over the
-//                                    terminator bits gives every byte its position, no reassembly needed
-// HBM-bound byte work: 2 reads + 1 write of the value bytes.
+//   sizes                            thread per merged slot: byte lengths from the parts' offsets, the re-based head from the part's
+//                                    first varint and the previous part's LAST id (the encoder stores one u32 per list; for a
+//                                    loaded index k_mg_last_ids sums (byte & 0x7f) << 7 * (position inside its varint) over the list)
+//   copy                             one wavefront per merged slot, eight lanes per part, 16 bytes per lane and step
+// HBM-bound byte work: one read + one write of the value bytes.
 #include "fdgpu_internal.h"
 
 #define MG_NONE 0xffffffffu
 #define MG_MAX_PARTS 64
 
-struct mg_part { const uint32_t *hashes; const uint64_t *offsets; const uint8_t *value; uint64_t H; };
+struct mg_part { const uint32_t *hashes; const uint64_t *offsets; const uint8_t *value; const uint32_t *last_ids; uint64_t H; };
 
 __global__ void k_mg_bitmap_set(const uint32_t *__restrict__ hashes, uint64_t n, uint32_t *__restrict__ bitmap) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,79 +57,141 @@ __device__ __forceinline__ uint32_t mg_wave_sum(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t mg_varint_len(uint32_t v) { return v == 0 ? 1u : 1u + (31u - (uint32_t)__clz(v)) / 7u; }
 
-// One part's byte string [b0, b1) of one hash, walked by a wavefront.  Returns (wave-uniform) the first id (absolute), the last
-// id (= sum of all values) and the byte length of the first varint.  COPY: bytes behind the first varint go to dst (dst points
-// at where the byte b0 + nb_first lands).
-template <bool COPY>
-__device__ __forceinline__ void mg_walk(const uint8_t *__restrict__ value, uint64_t b0, uint64_t b1, uint32_t *first, uint32_t *last,
-                                        uint32_t *nb_first, uint8_t *__restrict__ dst) {
+// last structure id of every list of an index that carries no last_ids (fdgpu_index_load): one wavefront per list, the last id is
+// the sum over the list's bytes of (byte & 0x7f) << 7 * (position inside its varint)
+__global__ __launch_bounds__(256) void k_mg_last_ids(const uint64_t *__restrict__ offsets, const uint8_t *__restrict__ value, uint64_t H, uint32_t *__restrict__ last_ids) {
+    const uint64_t t = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (t >= H) return;
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t acc = 0, acc_first = 0, carry = 0, nf = 0;
+    const uint64_t b0 = offsets[t], b1 = offsets[t + 1];
+    uint32_t acc = 0, carry = 0;
     for (uint64_t base = b0; base < b1; base += FD_WAVE) {
         const uint64_t p = base + lane;
         const bool in = p < b1;
         const uint32_t byte = in ? value[p] : 0x80u;
         const uint64_t tm = __ballot(in && !(byte & 0x80u));
         const uint64_t below = tm & ((1ull << lane) - 1ull);
-        const uint32_t pin = below ? lane - (uint32_t)(63 - __clzll(below)) - 1u : lane + carry;   // position inside the varint
-        const uint32_t c = in ? (byte & 0x7fu) << (7u * (pin < 5u ? pin : 4u)) : 0u;
-        acc += c;
-        if (base == b0) {   // the first varint ends inside the first block (<= 5 bytes)
-            const uint32_t ft = (uint32_t)__ffsll((long long)tm) - 1u;
-            nf = ft + 1u;
-            if (lane <= ft) acc_first = c;
-        }
-        if (COPY && in && p >= b0 + nf) dst[p - (b0 + nf)] = (uint8_t)byte;
+        const uint32_t pin = below ? lane - (uint32_t)(63 - __clzll(below)) - 1u : lane + carry;
+        acc += in ? (byte & 0x7fu) << (7u * (pin < 5u ? pin : 4u)) : 0u;
         carry = tm ? 63u - (uint32_t)(63 - __clzll(tm)) : carry + 64u;
     }
-    *last = mg_wave_sum(acc);
-    *first = mg_wave_sum(acc_first);
-    *nb_first = nf;
+    acc = mg_wave_sum(acc);
+    if (lane == 0) last_ids[t] = acc;
 }
 
-// bytes of merged slot g: sum over the parts that hold the hash of (bytes of the part's list) + (re-based first varint - original)
-template <bool COPY>
-__global__ __launch_bounds__(256) void k_mg_slot(const mg_part *__restrict__ parts, uint32_t n_parts, const uint32_t *__restrict__ pos, uint64_t n_slots,
-                                                 uint32_t *__restrict__ sizes, const uint64_t *__restrict__ out_off, uint8_t *__restrict__ out_value) {
-    const uint64_t g = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+// first varint of a byte string: value and length (<= 5 bytes; the 8 bytes behind p are readable: the value buffers carry slack)
+__device__ __forceinline__ uint32_t mg_first_varint(const uint8_t *__restrict__ p, uint32_t *nf) {
+    unsigned long long w;
+    __builtin_memcpy(&w, p, 8);
+    const unsigned long long stop = ~w & 0x8080808080ull;            // terminator bits of the first five bytes
+    const uint32_t n = ((uint32_t)__ffsll((long long)stop) >> 3);     // 1-based byte index of the first terminator
+    *nf = n;
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 5; ++k) if (k < n) v |= (uint32_t)((w >> (8 * k)) & 0x7full) << (7 * k);
+    return v;
+}
+
+// sizes: thread = merged slot.  size = sum over the parts holding the hash of (bytes of the part's list), the first varint of every
+// continuation re-based from "absolute id" to "delta from the previous part's last id"
+__global__ __launch_bounds__(256) void k_mg_sizes(const mg_part *__restrict__ parts, uint32_t n_parts, const uint32_t *__restrict__ pos, uint64_t n_slots,
+                                                  uint32_t *__restrict__ sizes, uint32_t *__restrict__ out_last) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_slots) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t myp = lane < n_parts ? pos[g * n_parts + lane] : MG_NONE;
-    uint64_t present = __ballot(myp != MG_NONE);
     uint32_t total = 0, prev_last = 0;
     bool have_prev = false;
-    uint8_t *dst = COPY ? out_value + out_off[g] : nullptr;
-    while (present) {
-        const uint32_t k = (uint32_t)__ffsll((long long)present) - 1u;
-        present &= present - 1ull;
-        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)myp, (int)k);
+    for (uint32_t k = 0; k < n_parts; ++k) {
+        const uint32_t t = pos[g * n_parts + k];
+        if (t == MG_NONE) continue;
         const mg_part P = parts[k];
         const uint64_t b0 = P.offsets[t], b1 = P.offsets[t + 1];
-        uint32_t first, last, nf;
-        if (!have_prev) {   // first part holding this hash: bytes unchanged
-            if (COPY) {
-                for (uint64_t p = b0 + lane; p < b1; p += FD_WAVE) dst[p - b0] = P.value[p];
-            }
-            mg_walk<false>(P.value, b0, b1, &first, &last, &nf, nullptr);
-            total += (uint32_t)(b1 - b0);
-            if (COPY) dst += b1 - b0;
-        } else {
-            // re-based head: delta from the previous part's last id (ids of consecutive parts ascend, so delta >= 1)
-            mg_walk<false>(P.value, b0, b0 + 5 < b1 ? b0 + 5 : b1, &first, &last, &nf, nullptr);   // head only: first id + its length
-            const uint32_t delta = first - prev_last, dl = mg_varint_len(delta);
-            if (COPY) {
-                if (lane < dl) dst[lane] = (uint8_t)(((delta >> (7u * lane)) & 0x7fu) | (lane + 1u < dl ? 0x80u : 0u));
-                mg_walk<true>(P.value, b0, b1, &first, &last, &nf, dst + dl);
-                dst += dl + (uint32_t)(b1 - b0) - nf;
-            } else {
-                mg_walk<false>(P.value, b0, b1, &first, &last, &nf, nullptr);
-            }
-            total += dl + (uint32_t)(b1 - b0) - nf;
+        uint32_t len = (uint32_t)(b1 - b0);
+        if (have_prev) {
+            uint32_t nf;
+            const uint32_t first = mg_first_varint(P.value + b0, &nf);
+            len = len - nf + mg_varint_len(first - prev_last);
         }
-        prev_last = last;
+        total += len;
+        prev_last = P.last_ids[t];
         have_prev = true;
     }
-    if (!COPY && lane == 0) sizes[g] = total;
+    sizes[g] = total;
+    out_last[g] = prev_last;
+}
+
+// copy: one wavefront per merged slot, eight lanes per part (parts 8 r .. 8 r + 7 in round r): the parts' byte strings move
+// concurrently, 16 bytes per lane and step (unaligned 16-byte global accesses are native on gfx950)
+typedef unsigned int mg_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_mg_copy(const mg_part *__restrict__ parts, uint32_t n_parts, const uint32_t *__restrict__ pos, uint64_t n_slots,
+                                                 const uint64_t *__restrict__ out_off, uint8_t *__restrict__ out_value) {
+    const uint64_t g = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (g >= n_slots) return;
+    const uint32_t lane = threadIdx.x & 63u, grp = lane >> 3, sub = lane & 7u;
+    uint64_t dst = out_off[g];
+    uint32_t prev_last = 0;
+    bool have_prev = false;
+    for (uint32_t k0 = 0; k0 < n_parts; k0 += 8) {
+        const uint32_t k = k0 + grp;
+        const uint32_t t = k < n_parts ? pos[g * n_parts + k] : MG_NONE;
+        const bool present = t != MG_NONE;
+        uint64_t b0 = 0, b1 = 0;
+        uint32_t first = 0, nf = 0, last = 0;
+        const uint8_t *src = nullptr;
+        if (present) {
+            const mg_part P = parts[k];
+            b0 = P.offsets[t]; b1 = P.offsets[t + 1];
+            src = P.value;
+            first = mg_first_varint(src + b0, &nf);
+            last = P.last_ids[t];
+        }
+        // group leaders -> every lane: which parts are present, their last ids and first ids (8 groups)
+        const uint64_t pm = __ballot(present && sub == 0);      // bit 8 * grp
+        // the previous present part's last id for this group
+        uint32_t my_prev = prev_last;
+        bool my_has_prev = have_prev;
+        uint32_t new_len = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) {
+            const uint32_t lq = __shfl(last, (int)(q * 8), FD_WAVE);
+            const bool pq = (pm >> (q * 8)) & 1ull;
+            if (q < grp && pq) { my_prev = lq; my_has_prev = true; }
+        }
+        uint32_t dl = 0, delta = 0;
+        if (present) {
+            if (my_has_prev) { delta = first - my_prev; dl = mg_varint_len(delta); new_len = (uint32_t)(b1 - b0) - nf + dl; }
+            else { new_len = (uint32_t)(b1 - b0); nf = 0; }
+        }
+        // destination of this group's string: prefix of new_len over the groups before it
+        uint64_t my_dst = dst;
+        uint32_t round_total = 0, round_last = prev_last;
+        bool round_has = have_prev;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) {
+            const uint32_t nl = __shfl(new_len, (int)(q * 8), FD_WAVE);
+            const uint32_t lq = __shfl(last, (int)(q * 8), FD_WAVE);
+            const bool pq = (pm >> (q * 8)) & 1ull;
+            if (q < grp) my_dst += nl;
+            round_total += nl;
+            if (pq) { round_last = lq; round_has = true; }
+        }
+        if (present) {
+            uint8_t *d = out_value + my_dst;
+            if (sub < dl) d[sub] = (uint8_t)(((delta >> (7u * sub)) & 0x7fu) | (sub + 1u < dl ? 0x80u : 0u));
+            const uint8_t *sp = src + b0 + nf;
+            d += dl;
+            const uint64_t n = (b1 - b0) - nf;
+            uint64_t o = (uint64_t)sub * 16u;
+            for (; o + 16 <= n; o += 128) {
+                mg_u32x4 v;
+                __builtin_memcpy(&v, sp + o, 16);
+                __builtin_memcpy(d + o, &v, 16);
+            }
+            if (o < n) for (uint64_t z = o; z < n; ++z) d[z] = sp[z];     // the lane that owns the ragged tail (< 16 bytes)
+        }
+        dst += round_total;
+        prev_last = round_last;
+        have_prev = round_has;
+    }
 }
 
 // ---- launchers
@@ -146,11 +208,12 @@ void fd_mg_pos_fill(const uint32_t *hashes, uint64_t n, const uint32_t *bitmap, 
                     hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_mg_pos_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hashes, n, bitmap, prefix, pos, part, n_parts);
 }
-void fd_mg_sizes(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, uint32_t *sizes, hipStream_t st) {
-    if (n_slots) hipLaunchKernelGGL(k_mg_slot<false>, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, st, (const mg_part *)parts, n_parts, pos, n_slots,
-                                    sizes, (const uint64_t *)nullptr, (uint8_t *)nullptr);
+void fd_mg_last_ids(const uint64_t *offsets, const uint8_t *value, uint64_t H, uint32_t *last_ids, hipStream_t st) {
+    if (H) hipLaunchKernelGGL(k_mg_last_ids, dim3((unsigned)((H + 3) / 4)), dim3(256), 0, st, offsets, value, H, last_ids);
+}
+void fd_mg_sizes(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, uint32_t *sizes, uint32_t *out_last, hipStream_t st) {
+    if (n_slots) hipLaunchKernelGGL(k_mg_sizes, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, (const mg_part *)parts, n_parts, pos, n_slots, sizes, out_last);
 }
 void fd_mg_copy(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, const uint64_t *out_off, uint8_t *out_value, hipStream_t st) {
-    if (n_slots) hipLaunchKernelGGL(k_mg_slot<true>, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, st, (const mg_part *)parts, n_parts, pos, n_slots,
-                                    (uint32_t *)nullptr, out_off, out_value);
+    if (n_slots) hipLaunchKernelGGL(k_mg_copy, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, st, (const mg_part *)parts, n_parts, pos, n_slots, out_off, out_value);
 }

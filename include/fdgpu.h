@@ -124,6 +124,9 @@ int fdgpu_index_export(fdgpu_ctx *ctx, const fdgpu_index *ix, uint8_t **value, u
  * nres[S] = per-structure residue counts from the .lookup file (length penalty). */
 int fdgpu_index_load(fdgpu_ctx *ctx, const uint32_t *hashes, const uint64_t *offsets, uint64_t n_hashes,
                      const uint8_t *value, uint64_t value_len, uint64_t n_structures, fdgpu_index **out);
+/* an uploaded index that is one shard of a database (structures first_id .. first_id + n_structures - 1, as written by a sharded
+ * build): tells scoring and fdgpu_index_merge where the shard's ids start (0 after fdgpu_index_load) */
+int fdgpu_index_set_first_id(fdgpu_index *ix, uint64_t first_id);
 void fdgpu_index_destroy(fdgpu_index *ix);
 uint64_t fdgpu_index_num_hashes(const fdgpu_index *ix);
 uint64_t fdgpu_index_value_len(const fdgpu_index *ix);

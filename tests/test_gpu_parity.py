@@ -617,3 +617,24 @@ def test_kabsch_large_problems_wave_path(ctx):
         r, R, T = oracle.kabsch(x, y)
         assert abs(rmsd[k] - r) <= 1e-4, (k, len(x), rmsd[k], r)
         assert np.allclose(rot[k], R, atol=1e-4) and np.allclose(tran[k], T, atol=1e-3), (k, len(x))
+
+
+@pytest.mark.gpu
+def test_device_merge_of_loaded_indices(ctx):
+    """parts that came through fdgpu_index_load carry no per-list last ids: the merge computes them with one decode pass"""
+    import folddisco_amd as fd
+    from folddisco_amd import synth
+    ps = synth.to_packed(synth.generate(90, seed=8))
+    off = ps.res_off.astype(np.int64)
+    single = fd.FolddiscoIndex.build(ctx, ctx.upload(ps), first_id=300)
+    parts, loaded = [], []
+    for a, b in ((0, 40), (40, 41), (41, 90)):
+        sl = slice(off[a], off[b])
+        chunk = fd.PackedStructures((ps.res_off[a:b + 1] - ps.res_off[a]).astype(np.uint64), ps.n_xyz[sl], ps.ca_xyz[sl], ps.cb_xyz[sl], ps.aa[sl])
+        p = fd.FolddiscoIndex.build(ctx, ctx.upload(chunk), first_id=300 + a)
+        v, h, o = p.export()
+        loaded.append(fd.FolddiscoIndex.load(ctx, h, o, v, b - a, first_id=300 + a))
+    merged = fd.FolddiscoIndexSet(loaded).merge()
+    v, h, o = single.export()
+    mv, mh, mo = merged.export()
+    assert np.array_equal(mh, h) and np.array_equal(mo, o) and np.array_equal(mv, v)
