@@ -215,7 +215,7 @@ def cmd_query(a):
                 fh.write("tid\tidf\ttotal_match_count\tnode_count\tedge_count\tmax_node_cov\tmin_rmsd\tnres\tplddt\tmatching_residues\tdb_key\tquery_residues\n")
             query.sort_rows(rows, query.parse_sort_by(a.sort_by, True))   # StructureSortStrategy (sort.rs:400-458)
             for r in rows:
-                fh.write(query.format_structure_row(r, qstr) + "\n")
+                fh.write(query.format_structure_row(r, r.get("query_residues", qstr)) + "\n")
         else:
             cols = [c.strip() for c in a.format_output.split(",") if c.strip()] or \
                 (query.MATCH_SUPERPOSE_COLUMNS if (a.superpose or a.web) else ["tid", "node_count", "idf", "rmsd", "matching_residues", "query_residues"])
@@ -290,7 +290,7 @@ def main(argv=None):
     pq.add_argument("--hausdorff", type=float, default=0.0)
     pq.add_argument("--format-output", default="")
     pq.add_argument("--superpose", action="store_true")              # print U, T and the matching C-alpha coordinates
-    pq.add_argument("--sort-by", default="node_count,rmsd")          # query_pdb.rs:573
+    pq.add_argument("--sort-by", default="")          # cli/main.rs:84: empty -> MatchSortStrategy / StructureSortStrategy default (idf desc, rmsd asc)
     pq.add_argument("--length-penalty", type=float, default=None)
     pq.add_argument("-o", "--output", default="")
     pq.add_argument("-v", "--verbose", action="store_true")

@@ -111,7 +111,7 @@ __global__ void k_hash_features(const float *__restrict__ feat, uint64_t n, uint
 }
 
 extern "C" int fdgpu_pair_features(fdgpu_ctx *c, const fdgpu_batch *b, uint64_t s, const uint32_t *pi, const uint32_t *pj, uint64_t n,
-                                   const fd_hash_params *p, float *features, uint8_t *valid) {
+                                   const fd_hash_params *p, float *features, uint8_t *valid) { FD_LOCK(c);
     if (!c || !b || !p || (s >= b->n_struct && s != 0xffffffffull) || (n && (!pi || !pj || !features || !valid))) return FDGPU_EINVAL;
     CHECK_TYPE(c, p);
     if (fd_own_descriptor(p->hash_type)) { c->err = "pair_features: seven-float records hold the PDBTrRosetta descriptor only"; return FDGPU_EINVAL; }
@@ -134,7 +134,7 @@ extern "C" int fdgpu_pair_features(fdgpu_ctx *c, const fdgpu_batch *b, uint64_t 
 
 static int hash_features_q(fdgpu_ctx *c, const float *features, uint64_t n, fd_quant q, uint32_t *hashes, uint32_t stride = 7);
 // the single configuration (nbin_dist, nbin_angle; either count 0 -> the encoding's defaults); multiple_bins is not consulted
-extern "C" int fdgpu_hash_features(fdgpu_ctx *c, const float *features, uint64_t n, const fd_hash_params *p, uint32_t *hashes) {
+extern "C" int fdgpu_hash_features(fdgpu_ctx *c, const float *features, uint64_t n, const fd_hash_params *p, uint32_t *hashes) { FD_LOCK(c);
     if (!c || !p || (n && (!features || !hashes))) return FDGPU_EINVAL;
     CHECK_TYPE(c, p);
     if (fd_own_descriptor(p->hash_type)) { c->err = "hash_features: seven-float records hold the PDBTrRosetta descriptor only"; return FDGPU_EINVAL; }
@@ -194,7 +194,7 @@ extern "C" void fdgpu_query_map_free(fd_query_map *m) {
 extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, uint64_t n_queries, const uint32_t *q_struct, const uint64_t *q_off,
                                           const uint32_t *q_index, const uint8_t *const *subs, const uint32_t *n_subs, const float *dist_thr,
                                           uint64_t n_dist, const float *angle_thr_deg, uint64_t n_angle, const fd_hash_params *p,
-                                          const fdgpu_index *index, float total_structures, fd_query_map **out) {
+                                          const fdgpu_index *index, float total_structures, fd_query_map **out) { FD_LOCK(c);
     if (!c || !qb || !p || !out || !q_off || (n_queries && !q_struct) || (q_off[n_queries] && !q_index)) return FDGPU_EINVAL;
     for (uint64_t t = 0; t < n_queries; ++t) { out[t] = nullptr; if (q_struct[t] >= qb->n_struct) return FDGPU_EINVAL; }
     // all ordered pairs of every query's residues, row-major (CombinationIterator, utils/combination.rs:23-44), as residue
@@ -354,7 +354,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
 // one query = structure 0 of qb
 extern "C" int fdgpu_make_query_map(fdgpu_ctx *c, const fdgpu_batch *qb, const uint32_t *q_index, uint64_t n_q, const uint8_t *const *subs,
                                     const uint32_t *n_subs, const float *dist_thr, uint64_t n_dist, const float *angle_thr_deg, uint64_t n_angle,
-                                    const fd_hash_params *p, const fdgpu_index *index, float total_structures, fd_query_map **out) {
+                                    const fd_hash_params *p, const fdgpu_index *index, float total_structures, fd_query_map **out) { FD_LOCK(c);
     if (!c || !qb || !p || !out || qb->n_struct < 1 || (n_q && !q_index)) return FDGPU_EINVAL;
     const uint32_t s0 = 0;
     const uint64_t off[2] = {0, n_q};
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void k_gather_xyz(const float *__restrict__ ca
 extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand,
                                     const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
                                     const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches,
-                                    uint64_t **match_off, int32_t **residues, uint64_t **res_off) {
+                                    uint64_t **match_off, int32_t **residues, uint64_t **res_off) { FD_LOCK(c);
     if (!c || !db || !qb || !p || !matches || !match_off || !residues || !res_off || !cand_off || (n_queries && (!qms || !q_struct))) return FDGPU_EINVAL;
     *matches = nullptr; *match_off = nullptr; *residues = nullptr; *res_off = nullptr;
     const uint64_t n_cand = cand_off[n_queries];
@@ -926,7 +926,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
 // one query = structure 0 of qb
 extern "C" int fdgpu_retrieve(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
                               const fd_query_map *qm, const fdgpu_batch *qb, const fd_hash_params *p, float ca_distance_cutoff,
-                              uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues) {
+                              uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches, uint64_t *n_matches, int32_t **residues) { FD_LOCK(c);
     if (!c || !db || !qm || !qb || !p || !matches || !n_matches || !residues) return FDGPU_EINVAL;
     *matches = nullptr; *n_matches = 0; *residues = nullptr;
     const uint64_t off[2] = {0, n_cand};

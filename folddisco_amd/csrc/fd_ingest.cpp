@@ -127,7 +127,9 @@ bool read_all(const char *path, std::string *out) {
     return true;
 }
 
-void parse_pdb(const std::string &txt, std::vector<Atom> *atoms) {
+// all_models: the reference's gzip reader (read_structure_from_gz, structure/io/pdb.rs:79-124) has no MODEL handling — it keeps the
+// ATOM records of EVERY model, unlike the plain-file reader (pdb.rs:37-77) which stops behind the first one
+void parse_pdb(const std::string &txt, std::vector<Atom> *atoms, bool all_models) {
     int model = 0;
     size_t pos = 0, N = txt.size();
     while (pos < N) {
@@ -137,7 +139,7 @@ void parse_pdb(const std::string &txt, std::vector<Atom> *atoms) {
         const char *L = txt.data() + pos;
         pos = e + 1;
         if (len && L[len - 1] == '\r') --len;
-        if (model > 1) break;
+        if (model > 1 && !all_models) break;
         if (len < 6) continue;
         if (!memcmp(L, "MODEL ", 6)) { ++model; continue; }
         if (memcmp(L, "ATOM  ", 6) || len < 54) continue;
@@ -345,7 +347,7 @@ extern "C" int fdgpu_parse_structures(const char *const *paths, uint64_t n, uint
             atoms.clear();
             std::string p(paths[k]);
             if (ends_with_ci(p, ".cif") || ends_with_ci(p, ".cif.gz") || ends_with_ci(p, ".mmcif") || ends_with_ci(p, ".mmcif.gz")) parse_cif(txt, &atoms);
-            else parse_pdb(txt, &atoms);
+            else parse_pdb(txt, &atoms, ends_with_ci(p, ".gz"));
             build_compact(atoms, &C);
             if (max_residue && C.nres_raw > max_residue) {   // controller/mod.rs:313-318: id kept, no hashes, nres = 0
                 uint64_t raw = C.nres_raw;

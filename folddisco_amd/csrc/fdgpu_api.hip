@@ -51,6 +51,78 @@ static void reset_timings(fdgpu_ctx *c) { c->timings.clear(); c->event_used = 0;
 // ---- context ------------------------------------------------------------------------------------------------
 extern "C" const char *fdgpu_version(void) { return "folddisco_amd 0.1 (gfx950)"; }
 
+// Start-up self-check (FDGPU_SELFCHECK=0 skips it):
+//  1. device known-answer test: the six 4CHA triad hashes of the reference's own test (controller/graph.rs:71-79) through the
+//     generic, table and speculative evaluations (k_selfcheck) — a mismatch fails fdgpu_create;
+//  2. host libm probe: the device restates glibc 2.35's sinf / cosf / acosf / atan2f bit for bit (fd_libm.h).  A reference (Rust)
+//     build on a host whose libm rounds differently (e.g. glibc >= 2.40 CORE-MATH) would hash differently from this library, so the
+//     same restatement compiled for the host is compared with the host's libm around every quantiser threshold; the verdict is
+//     kept in the context (fdgpu_host_libm_matches) and a mismatch is reported once on stderr.
+static fd_hash_consts make_consts(const fd_hash_params *p);
+static int fd_selfcheck(fdgpu_ctx *c) {
+    const char *e = getenv("FDGPU_SELFCHECK");
+    if (e && e[0] == '0') return FDGPU_OK;
+    fd_hash_params p;
+    memset(&p, 0, sizeof p);
+    p.dist_cutoff = 20.0f; p.hash_type = FDGPU_HASH_PDBTR;
+    const fd_hash_consts C = make_consts(&p);
+    uint32_t *d = nullptr, h[18];
+    HIPCHK(c, hipMalloc((void **)&d, sizeof h));
+    fd_launch_selfcheck(C.q, d, c->stream);
+    hipError_t he = hipGetLastError();
+    if (he == hipSuccess) he = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (he != hipSuccess) { c->err = std::string("self-check launch: ") + hipGetErrorString(he); return FDGPU_EHIP; }
+    static const uint32_t want[6] = {109329223u, 116878724u, 271858548u, 284511716u, 506948936u, 512052558u};
+    for (int k = 0; k < 18; ++k)
+        if (h[k] != want[k % 6]) {
+            char b[256];
+            snprintf(b, sizeof b, "self-check failed: 4CHA triad hash %d (%s evaluation) is %u, the reference's literal is %u (controller/graph.rs:71-79)", k % 6,
+                     k < 6 ? "generic" : k < 12 ? "table" : "speculative", h[k], want[k % 6]);
+            c->err = b;
+            return FDGPU_EHIP;
+        }
+    // host libm generation: the restatement (fd_libm.h, compiled for the host here) against libm around the thresholds the quantiser uses
+    int ok = 1;
+    auto same = [](float a, float b) { uint32_t x, y; memcpy(&x, &a, 4); memcpy(&y, &b, 4); return x == y || (a != a && b != b); };
+    for (int k = 1; k < FD_THETA_NSEG && ok; ++k) {
+        float t;
+        memcpy(&t, &fd_theta_thr_bits[k], 4);
+        for (int u = -64; u <= 64 && ok; ++u) {
+            uint32_t bits = fd_theta_thr_bits[k] + (uint32_t)u;
+            float x;
+            memcpy(&x, &bits, 4);
+            if (!(x >= -1.0f && x <= 1.0f)) continue;
+            const float a = acosf(x);
+            ok = same(fd_acosf(x), a) && same(fd_sinf(a), sinf(a)) && same(fd_cosf(a), cosf(a));
+        }
+    }
+    for (int m = 0; m < 4 && ok; ++m)
+        for (int k = 1; k < FD_TOR_MAXSEG && ok; ++k)
+            for (int u = -64; u <= 64 && ok; ++u) {
+                uint32_t bits = fd_tor_thr_bits[m][k] + (uint32_t)u;
+                float r;
+                memcpy(&r, &bits, 4);
+                if (!(r == r) || r > 3.0e38f) continue;
+                const float y = (m & 1) ? -r : r, x = (m & 2) ? -1.0f : 1.0f;
+                const float a = -atan2f(y, x);
+                ok = same(-fd_atan2f(y, x), a) && same(fd_sinf(a), sinf(a)) && same(fd_cosf(a), cosf(a));
+            }
+    c->host_libm_matches = ok;
+    if (!ok) {
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "[fdgpu] warning: this host's libm (sinf/cosf/acosf/atan2f) differs from the glibc 2.35 generation the device arithmetic restates; a "
+                            "reference build on this host can hash residue pairs at bin edges differently (rerun tools/gen_bin_tables.c + tools/check_libm.c)\n");
+        }
+    }
+    return FDGPU_OK;
+}
+// 1 = the host's libm agrees with the restated generation, 0 = it does not, -1 = the self-check was skipped
+extern "C" int fdgpu_host_libm_matches(const fdgpu_ctx *c) { return c ? c->host_libm_matches : -1; }
+
 extern "C" int fdgpu_create(int device, fdgpu_ctx **out) {
     if (!out) return FDGPU_EINVAL;
     *out = nullptr;
@@ -74,10 +146,10 @@ extern "C" int fdgpu_create(int device, fdgpu_ctx **out) {
     if (hipMalloc((void **)&c->spec_miss, 8) == hipSuccess) (void)hipMemset(c->spec_miss, 0, 8);
     else c->spec_miss = nullptr;
     *out = c;
-    return FDGPU_OK;
+    return fd_selfcheck(c);
 }
 // number of residue pairs the speculative torsion evaluation handed to the exact routine since the last call (profiling hook)
-extern "C" int fdgpu_spec_fallbacks(fdgpu_ctx *c, uint64_t *out) {
+extern "C" int fdgpu_spec_fallbacks(fdgpu_ctx *c, uint64_t *out) { FD_LOCK(c);
     if (!c || !out) return FDGPU_EINVAL;
     *out = 0;
     if (!c->spec_miss) return FDGPU_OK;
@@ -95,7 +167,7 @@ extern "C" void fdgpu_destroy(fdgpu_ctx *c) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
-extern "C" int fdgpu_set_stream(fdgpu_ctx *c, void *s) {
+extern "C" int fdgpu_set_stream(fdgpu_ctx *c, void *s) { FD_LOCK(c);
     if (!c) return FDGPU_EINVAL;
     if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); c->own_stream = false; }
     if (s) { c->stream = (hipStream_t)s; return FDGPU_OK; }
@@ -103,15 +175,15 @@ extern "C" int fdgpu_set_stream(fdgpu_ctx *c, void *s) {
     c->own_stream = true;
     return FDGPU_OK;
 }
-extern "C" int fdgpu_synchronize(fdgpu_ctx *c) {
+extern "C" int fdgpu_synchronize(fdgpu_ctx *c) { FD_LOCK(c);
     if (!c) return FDGPU_EINVAL;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FDGPU_OK;
 }
 extern "C" const char *fdgpu_last_error(const fdgpu_ctx *c) { return c ? c->err.c_str() : "null context"; }
 extern "C" void fdgpu_free(void *p) { free(p); }
-extern "C" int fdgpu_enable_timing(fdgpu_ctx *c, int on) { if (!c) return FDGPU_EINVAL; c->timing = on != 0; return FDGPU_OK; }
-extern "C" int fdgpu_last_timings(const fdgpu_ctx *c, const char **names, float *ms, uint64_t *bytes, int cap) {
+extern "C" int fdgpu_enable_timing(fdgpu_ctx *c, int on) { FD_LOCK(c); if (!c) return FDGPU_EINVAL; c->timing = on != 0; return FDGPU_OK; }
+extern "C" int fdgpu_last_timings(const fdgpu_ctx *c, const char **names, float *ms, uint64_t *bytes, int cap) { FD_LOCK(c);
     if (!c) return FDGPU_EINVAL;
     int n = 0;
     for (auto &t : c->timings) {
@@ -154,7 +226,7 @@ static int build_work_items(fdgpu_ctx *c, fdgpu_batch *b) {
     return FDGPU_OK;
 }
 
-extern "C" int fdgpu_batch_upload(fdgpu_ctx *c, const fd_batch_desc *h, fdgpu_batch **out) {
+extern "C" int fdgpu_batch_upload(fdgpu_ctx *c, const fd_batch_desc *h, fdgpu_batch **out) { FD_LOCK(c);
     if (!c || !h || !out || !h->res_off || (h->n_struct && (!h->n_xyz || !h->ca_xyz || !h->cb_xyz || !h->aa))) return FDGPU_EINVAL;
     *out = nullptr;
     if (h->n_struct >= 0xffffffffull) FAIL(c, FDGPU_ERANGE, "too many structures in one batch");
@@ -180,7 +252,7 @@ extern "C" int fdgpu_batch_upload(fdgpu_ctx *c, const fd_batch_desc *h, fdgpu_ba
     return FDGPU_OK;
 }
 
-extern "C" int fdgpu_batch_wrap_device(fdgpu_ctx *c, const fd_batch_desc *d, uint64_t total_residues, fdgpu_batch **out) {
+extern "C" int fdgpu_batch_wrap_device(fdgpu_ctx *c, const fd_batch_desc *d, uint64_t total_residues, fdgpu_batch **out) { FD_LOCK(c);
     if (!c || !d || !out || !d->res_off) return FDGPU_EINVAL;
     *out = nullptr;
     fdgpu_batch *b = new (std::nothrow) fdgpu_batch();
@@ -334,7 +406,7 @@ static int sort_mode() {
 
 // ---- S1 ---------------------------------------------------------------------------------------------------------------
 extern "C" int fdgpu_hash_batch(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_params *p, int sort_dedup, uint32_t **hashes,
-                                uint64_t **hash_off) {
+                                uint64_t **hash_off) { FD_LOCK(c);
     if (!c || !b || !p || !hashes || !hash_off) return FDGPU_EINVAL;
     *hashes = nullptr; *hash_off = nullptr;
     if (p->n_multiple_bins) FAIL(c, FDGPU_EINVAL, "hash_batch: multiple_bins is honoured by the index build and the query calls only");
@@ -414,6 +486,7 @@ extern "C" int fdgpu_hash_batch(fdgpu_ctx *c, const fdgpu_batch *b, const fd_has
 // ---- S2 ---------------------------------------------------------------------------------------------------------------
 extern "C" void fdgpu_index_destroy(fdgpu_index *ix) {
     if (!ix) return;
+    FD_LOCK(ix->ctx);     // the blocks go back to the context's pool
     if (ix->ctx) {
         ix->ctx->pool_free(ix->hashes, ix->cap_hashes); ix->ctx->pool_free(ix->offsets, ix->cap_offsets); ix->ctx->pool_free(ix->value, ix->cap_value);
         ix->ctx->pool_free(ix->last_ids, ix->cap_last);
@@ -545,7 +618,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     return FDGPU_OK;
 }
 
-extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_params *p, uint64_t first_id, fdgpu_index **out) {
+extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_params *p, uint64_t first_id, fdgpu_index **out) { FD_LOCK(c);
     const char *e32 = getenv("FDGPU_IDS32");   // FDGPU_IDS32=1 forces the 8-byte sort elements (read per call: tests flip it)
     int rc = index_build_impl(c, b, p, first_id, out, e32 && e32[0] == '1');
     if (rc == FDGPU_RETRY_WIDE) rc = index_build_impl(c, b, p, first_id, out, true);
@@ -553,7 +626,7 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
 }
 
 extern "C" int fdgpu_index_export(fdgpu_ctx *c, const fdgpu_index *ix, uint8_t **value, uint64_t *value_len, uint32_t **hashes,
-                                  uint64_t **offsets, uint64_t *n_hashes) {
+                                  uint64_t **offsets, uint64_t *n_hashes) { FD_LOCK(c);
     if (!c || !ix || !value || !value_len || !hashes || !offsets || !n_hashes) return FDGPU_EINVAL;
     uint8_t *v = (uint8_t *)malloc(std::max<uint64_t>(ix->value_len, 1));
     uint32_t *h = (uint32_t *)malloc(std::max<uint64_t>(ix->n_hashes, 1) * 4);
@@ -570,7 +643,7 @@ extern "C" int fdgpu_index_export(fdgpu_ctx *c, const fdgpu_index *ix, uint8_t *
 }
 
 extern "C" int fdgpu_index_load(fdgpu_ctx *c, const uint32_t *hashes, const uint64_t *offsets, uint64_t H, const uint8_t *value,
-                                uint64_t vlen, uint64_t n_structures, fdgpu_index **out) {
+                                uint64_t vlen, uint64_t n_structures, fdgpu_index **out) { FD_LOCK(c);
     if (!c || !out || (H && (!hashes || !offsets)) || (vlen && !value)) return FDGPU_EINVAL;
     *out = nullptr;
     fdgpu_index *ix = new (std::nothrow) fdgpu_index();
@@ -606,7 +679,7 @@ void fd_mg_pos_fill(const uint32_t *hashes, uint64_t n, const uint32_t *bitmap, 
 void fd_mg_sizes(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, uint32_t *sizes, uint32_t *out_last, hipStream_t st);
 void fd_mg_copy(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, const uint64_t *out_off, uint8_t *out_value, hipStream_t st);
 
-extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, uint64_t n_parts, fdgpu_index **out) {
+extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, uint64_t n_parts, fdgpu_index **out) { FD_LOCK(c);
     if (!c || !out || !n_parts || !parts) return FDGPU_EINVAL;
     *out = nullptr;
     if (n_parts > 64) FAIL(c, FDGPU_ERANGE, "index merge: at most 64 parts per call (merge in rounds)");
@@ -693,7 +766,7 @@ extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, 
 }
 
 // byte-identical to wrapup_offset_and_save_entries + save_offset_to_file (indextable.rs:239-264, 297-326)
-extern "C" int fdgpu_index_save(fdgpu_ctx *c, const fdgpu_index *ix, const char *prefix) {
+extern "C" int fdgpu_index_save(fdgpu_ctx *c, const fdgpu_index *ix, const char *prefix) { FD_LOCK(c);
     if (!c || !ix || !prefix) return FDGPU_EINVAL;
     uint8_t *v = nullptr; uint32_t *h = nullptr; uint64_t *o = nullptr; uint64_t vl = 0, H = 0;
     int rc = fdgpu_index_export(c, ix, &v, &vl, &h, &o, &H);
@@ -713,7 +786,7 @@ extern "C" int fdgpu_index_save(fdgpu_ctx *c, const fdgpu_index *ix, const char 
 }
 
 // ---- S3 ---------------------------------------------------------------------------------------------------------------
-extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths) {
+extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths) { FD_LOCK(c);
     if (!c || !ix || (nq && (!q_hash || !lengths))) return FDGPU_EINVAL;
     if (!nq) return FDGPU_OK;
     hipStream_t st = c->stream;
@@ -728,7 +801,7 @@ extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const 
 }
 
 void fd_launch_posting_bytes(const uint32_t *hashes, const uint64_t *offsets, uint64_t H, const uint32_t *q_hash, uint64_t nq, uint64_t *bytes, hipStream_t st);
-extern "C" int fdgpu_posting_bytes(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *bytes) {
+extern "C" int fdgpu_posting_bytes(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *bytes) { FD_LOCK(c);
     if (!c || !ix || (nq && (!q_hash || !bytes))) return FDGPU_EINVAL;
     if (!nq) return FDGPU_OK;
     hipStream_t st = c->stream;
@@ -743,7 +816,7 @@ extern "C" int fdgpu_posting_bytes(fdgpu_ctx *c, const fdgpu_index *ix, const ui
 }
 
 // get_entries for many hashes: ids of hash k = (*ids)[(*ids_off)[k] .. (*ids_off)[k+1])
-extern "C" int fdgpu_get_entries(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint32_t **ids, uint64_t **ids_off) {
+extern "C" int fdgpu_get_entries(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint32_t **ids, uint64_t **ids_off) { FD_LOCK(c);
     if (!c || !ix || !ids || !ids_off || (nq && !q_hash)) return FDGPU_EINVAL;
     *ids = nullptr; *ids_off = nullptr;
     uint64_t *off = (uint64_t *)calloc(nq + 1, 8);
@@ -775,8 +848,28 @@ extern "C" int fdgpu_get_entries(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     return FDGPU_OK;
 }
 
+// plan (list positions, CQ_SEG-byte segments) + segment-parallel scoring of the query hashes in A (k_query.hip)
+static int cq_score(fdgpu_ctx *c, const cq_args &A, const uint32_t *q_query) {
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(A.nq * 8));
+    HIPCHK(c, c->ws[WS_CQ_NSEG].ensure(A.nq * 4));
+    HIPCHK(c, c->ws[WS_CQ_WSTART].ensure((A.nq + 2) * 8));
+    HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(A.nq) * 8 + 64));
+    HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
+    fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
+    fd_exclusive_scan<uint32_t>(c->ws[WS_CQ_NSEG].as<uint32_t>(), A.nq, c->ws[WS_CQ_WSTART].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
+                                c->ws[WS_TOTAL].as<uint64_t>(), st);
+    HIPCHK(c, hipGetLastError());
+    uint64_t W = 0;
+    int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &W);
+    if (rc) return rc;
+    HIPCHK(c, c->ws[WS_CQ_SEGSUM].ensure(std::max<uint64_t>(W, 1) * 4));
+    fd_launch_cq_seg(A, q_query, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_WSTART].as<uint64_t>(), c->ws[WS_CQ_SEGSUM].as<uint32_t>(), W, W > A.nq, st);
+    return FDGPU_OK;
+}
+
 extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j,
-                                 const float *q_idf, uint64_t nq, const float *penalty, fd_count_rec **out, uint64_t *n_out) {
+                                 const float *q_idf, uint64_t nq, const float *penalty, fd_count_rec **out, uint64_t *n_out) { FD_LOCK(c);
     if (!c || !ix || !out || !n_out || (nq && (!q_hash || !q_node || !q_edge_j || !q_idf)) || (ix->n_structures && !penalty)) return FDGPU_EINVAL;
     *out = nullptr; *n_out = 0;
     reset_timings(c);
@@ -836,7 +929,8 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
     {
         StageTimer t(c, "cq_accumulate", 0);
-        fd_launch_cq_accumulate(A, st);
+        int rs = cq_score(c, A, nullptr);
+        if (rs) return rs;
     }
     {
         StageTimer t(c, "cq_finalize", (uint64_t)(NN + NE) * words * 4 + S * 12);
@@ -931,6 +1025,8 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
     {
         StageTimer t(c, "cq_batch", 0);
+        int rs = cq_score(c, A, c->ws[WS_TILE_B].as<uint32_t>());
+        if (rs) { free(ooff); return rs; }
         fd_launch_cq_batch(A, c->ws[WS_TILE_B].as<uint32_t>(), (uint32_t)n_queries, c->ws[WS_TILE_H].as<uint32_t>(), c->ws[WS_IDS_A].as<uint32_t>(),
                            c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), st);
         fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), QS, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
@@ -1005,14 +1101,14 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
 }
 extern "C" int fdgpu_count_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                                        const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty,
-                                       fd_count_rec **out, uint64_t **out_off) {
+                                       fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
     return count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, 0, out, out_off);
 }
 // as above, but per query only the records that can be among the top_n by idf are returned (every record whose idf is >= the
 // top_n-th largest, in no particular order): the candidate selection of query_pdb.rs:404-411 sorts that short list
 extern "C" int fdgpu_count_query_batch_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                                            const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty,
-                                           uint32_t top_n, fd_count_rec **out, uint64_t **out_off) {
+                                           uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
     return count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off);
 }
 
@@ -1208,14 +1304,14 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
 }
 extern "C" int fdgpu_match_pairs(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
                                  const fd_match_query *q, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
-                                 fd_cand_rec **cands, uint64_t *n_cands) {
+                                 fd_cand_rec **cands, uint64_t *n_cands) { FD_LOCK(c);
     if (!q) return FDGPU_EINVAL;
     const uint64_t off[2] = {0, n_cand};
     return fd_match_pairs_multi(c, db, resname_std, 1, q, cand, off, p, found, n_found, cands, n_cands);
 }
 
 extern "C" int fdgpu_kabsch_batch(fdgpu_ctx *c, const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot,
-                                  float *tran) {
+                                  float *tran) { FD_LOCK(c);
     if (!c || (n && (!x || !y || !off || !rmsd || !rot || !tran))) return FDGPU_EINVAL;
     if (!n) return FDGPU_OK;
     hipStream_t st = c->stream;
@@ -1247,7 +1343,7 @@ extern "C" int fdgpu_kabsch_batch(fdgpu_ctx *c, const float *x, const float *y, 
 
 // --partial-fit: LmsQcpSuperimposer with its default parameters (src/structure/lms_qcp.rs), one wavefront per problem
 extern "C" int fdgpu_lms_qcp_batch(fdgpu_ctx *c, const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot,
-                                   float *tran, uint32_t *core_len, uint32_t *core) {
+                                   float *tran, uint32_t *core_len, uint32_t *core) { FD_LOCK(c);
     if (!c || (n && (!x || !y || !off || !rmsd || !rot || !tran))) return FDGPU_EINVAL;
     if (!n) return FDGPU_OK;
     for (uint64_t k = 0; k < n; ++k)
@@ -1296,7 +1392,7 @@ __global__ void k_debug_libm(int op, const float *__restrict__ a, const float *_
         default: out[k] = fdd_atan2f(x, b[k]); break;
     }
 }
-extern "C" int fdgpu_debug_libm(fdgpu_ctx *c, int op, const float *a, const float *b, float *out, uint64_t n) {
+extern "C" int fdgpu_debug_libm(fdgpu_ctx *c, int op, const float *a, const float *b, float *out, uint64_t n) { FD_LOCK(c);
     if (!c || !a || !out || (op == 4 && !b) || op < 0 || op > 4) return FDGPU_EINVAL;
     if (!n) return FDGPU_OK;
     hipStream_t st = c->stream;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/fdgpu.h"
@@ -32,6 +33,7 @@ struct fd_timing_entry { const char *name; hipEvent_t ev0, ev1; uint64_t bytes; 
 enum {
     WS_COUNTS, WS_CURSOR, WS_SEGOFF, WS_SCANTMP, WS_TOTAL, WS_KEYS_A, WS_IDS_A, WS_KEYS_B, WS_IDS_B, WS_GHIST, WS_TOT,
     WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
+    WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM,
     WS_COUNT
 };
 
@@ -42,6 +44,11 @@ struct fdgpu_ctx {
     std::string err;
     fd_devbuf ws[WS_COUNT];
     bool timing = false;
+    // Every entry point that takes the context locks it: concurrent callers (the reference calls its seams from rayon workers,
+    // controller/mod.rs:291, query_pdb.rs:348,415) are safe and run one at a time per context — one stream, one scratch set;
+    // callers that want overlap create one context per thread.  Recursive: entry points call each other.
+    mutable std::recursive_mutex mu;
+    int host_libm_matches = -1;   // 1: this host's libm agrees with the glibc generation the device arithmetic restates, 0: it does not
     unsigned long long *spec_miss = nullptr;   // device counter: pairs the speculative torsion path re-evaluated exactly
     std::vector<fd_timing_entry> timings;
     std::vector<hipEvent_t> event_pool;
@@ -100,6 +107,9 @@ struct StageTimer {
     ~StageTimer() { if (idx != (size_t)-1) (void)hipEventRecord(c->timings[idx].ev1, c->stream); }
 };
 
+// the current HIP device is per host thread: a caller thread that never selected the context's device gets it here
+#define FD_LOCK(c) std::unique_lock<std::recursive_mutex> _fd_lk; if (c) { _fd_lk = std::unique_lock<std::recursive_mutex>((c)->mu); (void)hipSetDevice((c)->device); }
+
 struct fdgpu_batch {
     fdgpu_ctx *ctx = nullptr;
     bool owns = false;
@@ -130,6 +140,7 @@ struct fdgpu_index {
 };
 
 // kernels / launchers implemented in the k_*.hip files
+void fd_launch_selfcheck(const fd_quant &q, uint32_t *out, hipStream_t st);
 void fd_launch_hash_ok(const uint8_t *aa, const uint8_t *cb_valid, uint8_t *ok, uint64_t n, hipStream_t st);
 void fd_launch_pair_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *counts, hipStream_t st);
 void fd_launch_pair_emit(const fd_batch_view &B, const fd_hash_consts &C, const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys,
@@ -167,7 +178,9 @@ struct cq_args {
 };
 void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,
                                uint64_t nq, uint64_t *lengths, hipStream_t st);
-void fd_launch_cq_accumulate(const cq_args &A, hipStream_t st);
+void fd_launch_cq_plan(const cq_args &A, long long *kidx, uint32_t *nseg, hipStream_t st);
+void fd_launch_cq_seg(const cq_args &A, const uint32_t *q_query, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
+                      hipStream_t st);
 void fd_launch_cq_finalize(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_bits, uint32_t n_nodes,
                            const uint32_t *edge_bits, uint32_t n_edges, uint32_t words, uint32_t S, uint32_t *node_cnt, uint32_t *edge_cnt,
                            uint8_t *flags, hipStream_t st);

@@ -371,8 +371,40 @@ __global__ void k_hash_ok(const uint8_t *__restrict__ aa, const uint8_t *__restr
     if (k < n) ok[k] = (aa[k] != 255 && (cb_valid == nullptr || cb_valid[k])) ? 1 : 0;
 }
 
+// ------------------------------------------------------------------ start-up known-answer test (fdgpu_create)
+// The catalytic triad of query/4CHA.pdb (HIS B57, ASP B102, SER C195) and its six PDBTrRosetta hashes, the literals of the
+// reference's own test (controller/graph.rs:71-79).  Every ordered pair is evaluated three ways — the generic chain
+// (fd_pair_feature + fd_hash_pdbtr: restated sinf/cosf/acosf/atan2f), the exhaustive-table form (fd_pair_both_tab) and the
+// speculative form (fd_pair_both_spec, exact fallback on refusal) — so a build whose arithmetic drifts (fast-math, FMA contraction,
+// a different table generation) fails loudly instead of producing a subtly different index.
+__global__ void k_selfcheck(fd_quant q, uint32_t *__restrict__ out /*[18]*/) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const fd_v3 N[3] = {{6.661f, 8.291f, 43.860f}, {10.483f, 7.756f, 49.260f}, {5.260f, -1.068f, 41.296f}};
+    const fd_v3 CA[3] = {{6.994f, 8.354f, 42.405f}, {9.429f, 7.479f, 48.266f}, {5.547f, 0.158f, 42.050f}};
+    const fd_v3 CB[3] = {{8.251f, 7.488f, 42.026f}, {10.033f, 6.489f, 47.255f}, {5.773f, 1.360f, 41.130f}};
+    const uint32_t AA[3] = {8u, 3u, 15u};
+    const int PI[6] = {1, 1, 0, 0, 2, 2}, PJ[6] = {0, 2, 1, 2, 1, 0};   // B102->B57, B102->C195, B57->B102, B57->C195, C195->B102, C195->B57
+    uint32_t tab[64];
+    fd_fill_bintab(tab);
+    for (int k = 0; k < FD_BINTAB_WORDS; ++k) tab[32 + k] = tab[k];
+    for (int m = 0; m < 4; ++m)
+        for (int k = 0; k < 4; ++k) { uint32_t v = tab[32 + 7 + 5 * m + k]; tab[32 + 7 + 5 * m + k] = v > 0x7f7fffffu ? 0x7f7fffffu : v; }
+    fd_frame F[3];
+    for (int r = 0; r < 3; ++r) F[r] = fd_make_frame(N[r], CA[r], CB[r]);
+    for (int k = 0; k < 6; ++k) {
+        const int i = PI[k], j = PJ[k];
+        out[k] = fd_hash_pdbtr(AA[i], AA[j], fd_pair_feature(N[i], CA[i], CB[i], N[j], CA[j], CB[j]), q);
+        uint32_t a, b;
+        fd_pair_both_tab(F[i], F[j], AA[i], AA[j], q, tab, &a, &b);
+        out[6 + k] = a;
+        if (!fd_pair_both_spec(F[i], F[j], AA[i], AA[j], q, tab, tab + 32, &a, &b)) fd_pair_both_tab(F[i], F[j], AA[i], AA[j], q, tab, &a, &b);
+        out[12 + k] = a;
+    }
+}
+
 // ------------------------------------------------------------------ launchers (called from fdgpu_api.hip)
 extern "C++" {
+void fd_launch_selfcheck(const fd_quant &q, uint32_t *out, hipStream_t st) { hipLaunchKernelGGL(k_selfcheck, dim3(1), dim3(64), 0, st, q, out); }
 void fd_launch_hash_ok(const uint8_t *aa, const uint8_t *cb_valid, uint8_t *ok, uint64_t n, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_hash_ok, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, aa, cb_valid, ok, n);

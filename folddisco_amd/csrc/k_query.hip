@@ -113,77 +113,137 @@ void fd_launch_get_entries(const uint32_t *hashes, const uint64_t *offsets, cons
     if (nq) hipLaunchKernelGGL(k_get_entries, dim3((unsigned)nq), dim3(FD_WAVE), 0, st, hashes, offsets, value, H, q_hash, nq, out_off, out);
 }
 
-__global__ __launch_bounds__(FD_WAVE) void k_cq_accumulate(cq_args A) {
-    uint64_t q = blockIdx.x;
-    if (q >= A.nq) return;
-    int64_t k = find_hash(A.hashes, A.H, A.q_hash[q]);
-    if (k < 0) return;
-    const uint64_t b0 = A.offsets[k], b1 = A.offsets[k + 1];
+// ------------------------------------------------------------------ segment-parallel scoring
+// One wavefront per posting LIST serialises the decode of a long list (Swiss-Prot scale: lists of 100 k ids = 150 KB = 2,300
+// dependent 64-byte steps, which alone took 4.9 ms of a 32-query batch).  A delta stream can be cut anywhere once every piece
+// knows the id it starts from: a varint belongs to the segment that holds its LAST byte, so
+//   plan     per query hash: list position and number of CQ_SEG-byte segments            (k_cq_plan + exclusive scan -> work items)
+//   sums     per segment: sum of the varint values that end inside it                     (k_cq_seg<true>; skipped when no list is split)
+//   score    per segment: base id = sum of the list's earlier segment sums, then the same 64-byte block decode + integer atomics
+// Work items are walked by a persistent grid (the count stays on the device).
+#define CQ_SEG 2048u
+struct cq_plan {
+    const long long *kidx;        // [nq] position of the hash in the index, -1 = absent
+    const uint64_t *wstart;       // [nq + 1] first work item of every query hash
+    uint32_t *segsum;             // [work items]
+};
+__global__ void k_cq_plan(const uint32_t *__restrict__ hashes, const uint64_t *__restrict__ offsets, uint64_t H, const uint32_t *__restrict__ q_hash, uint64_t nq,
+                          long long *__restrict__ kidx, uint32_t *__restrict__ nseg) {
+    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int64_t k = find_hash(hashes, H, q_hash[q]);
+    kidx[q] = k;
+    nseg[q] = k < 0 ? 0u : (uint32_t)((offsets[k + 1] - offsets[k] + CQ_SEG - 1) / CQ_SEG);
+}
+
+template <bool SUMS>
+__global__ __launch_bounds__(FD_WAVE) void k_cq_seg(cq_args A, const uint32_t *__restrict__ q_query, cq_plan P) {
     const uint32_t lane = threadIdx.x;
-    const unsigned long long idf_fix = A.q_idf_fix[q];
-    uint32_t *nb = A.node_bits + (uint64_t)A.q_node_idx[q] * A.words;
-    uint32_t *eb = A.edge_bits + (uint64_t)A.q_edge_idx[q] * A.words;
-    uint32_t run_id = 0;        // last decoded id (wave-uniform)
-    bool have_first = false;    // first value of the list is absolute
-    uint32_t carry_val = 0;     // partial varint spilling over from the previous block
-    uint32_t carry_shift = 0;
-    for (uint64_t base = b0; base < b1; base += FD_WAVE) {
-        uint64_t p = base + lane;
-        bool in = p < b1;
-        uint32_t byte = in ? A.value[p] : 0x80u;  // padding lanes look like continuation bytes
-        bool term = in && !(byte & 0x80u);
-        uint64_t tm = __ballot(term);
-        // start lane of the varint that ends at this terminator: one past the previous terminator
-        uint64_t below = tm & ((1ull << lane) - 1ull);
-        int prev_t = below ? 63 - __clzll(below) : -1;
-        uint32_t len_here = lane - (uint32_t)(prev_t + 1) + 1;  // bytes of this varint inside the block
-        // reassemble: little-endian 7-bit groups
-        uint32_t v = 0;
-        uint32_t pay = byte & 0x7fu;
-#pragma unroll
-        for (int back = 4; back >= 0; --back) {
-            uint32_t pb = __shfl(pay, (int)lane - back, FD_WAVE);
-            if ((uint32_t)back < len_here) v |= pb << (7u * (len_here - 1u - (uint32_t)back));
-        }
-        if (term && prev_t < 0) v = carry_val | (v << carry_shift);  // first terminator continues the spilled varint
-        // deltas -> ids: inclusive prefix sum over terminator lanes
-        uint32_t d = term ? v : 0u;
-        bool is_abs = term && !have_first && prev_t < 0;   // very first value of the list is the absolute id
-        uint32_t s = d;
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t t = __shfl_up(s, off, FD_WAVE);
-            if ((int)lane >= off) s += t;
-        }
-        uint32_t id = (have_first ? run_id : 0u) + s;
-        (void)is_abs;
-        if (term) {
-            uint32_t rel = id - A.first_id;
-            if (id >= A.first_id && rel < A.S) {
-                atomicAdd(&A.match[rel], 1u);
-                atomicAdd(&A.idf[rel], idf_fix);
-                atomicOr(&nb[rel >> 5], 1u << (rel & 31u));
-                atomicOr(&eb[rel >> 5], 1u << (rel & 31u));
-            }
-        }
-        // carry state to the next block (wave-uniform)
-        if (tm) {
-            int last_t = 63 - __clzll(tm);
-            run_id = __shfl(id, last_t, FD_WAVE);
-            have_first = true;
-            // bytes after the last terminator form a partial varint
-            uint32_t tail = 63u - (uint32_t)last_t;
+    const uint64_t W = P.wstart[A.nq];
+    for (uint64_t w = blockIdx.x; w < W; w += gridDim.x) {
+        // query hash of this work item: last q with wstart[q] <= w
+        uint64_t lo = 0, hi = A.nq;
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (P.wstart[mid] <= w) lo = mid; else hi = mid; }
+        const uint64_t q = lo;
+        const uint64_t w0 = P.wstart[q];
+        const uint32_t j = (uint32_t)(w - w0);
+        if (SUMS && P.wstart[q + 1] - w0 < 2) continue;           // single-segment list: its base is 0
+        const int64_t k = P.kidx[q];
+        const uint64_t b0 = A.offsets[k], b1 = A.offsets[k + 1];
+        const uint64_t s0 = b0 + (uint64_t)j * CQ_SEG, s1 = s0 + CQ_SEG < b1 ? s0 + CQ_SEG : b1;
+        // the varint that straddles the segment start: its leading bytes are the (<= 4) bytes before s0 behind the last terminator
+        uint32_t carry_val = 0, carry_shift = 0;
+        if (j) {
+            const uint64_t p = s0 - 4 + lane;
+            const bool in4 = lane < 4;
+            const uint32_t byte = (in4 && p >= b0) ? A.value[p] : 0u;              // before the list start counts as a boundary
+            const uint32_t tm4 = (uint32_t)__ballot(in4 && !(byte & 0x80u)) & 15u;
+            const int lt = tm4 ? 31 - __clz((int)tm4) : -1;
+            const uint32_t tail = 3u - (uint32_t)lt;
+            const uint32_t pay = byte & 0x7fu;
             uint32_t pv = 0;
-            for (uint32_t t2 = 0; t2 < tail && t2 < 5; ++t2) pv |= __shfl(pay, last_t + 1 + (int)t2, FD_WAVE) << (7u * t2);
-            carry_val = pv;
-            carry_shift = 7u * tail;
-        } else {
-            // whole block is continuation bytes (cannot happen for ids < 2^35, kept for safety)
-            uint32_t pv = carry_val;
-            for (uint32_t t2 = 0; t2 < 5; ++t2) pv |= __shfl(pay, (int)t2, FD_WAVE) << (carry_shift + 7u * t2);
-            carry_val = pv;
-            carry_shift += 7u * FD_WAVE;
+            for (uint32_t t2 = 0; t2 < tail; ++t2) pv |= (uint32_t)__shfl((int)pay, lt + 1 + (int)t2, FD_WAVE) << (7u * t2);
+            carry_val = pv; carry_shift = 7u * tail;
         }
+        uint32_t run_id = 0;
+        if (!SUMS && j) {   // base id: sum of the list's earlier segment sums
+            uint32_t acc = 0;
+            for (uint32_t t = lane; t < j; t += FD_WAVE) acc += P.segsum[w0 + t];
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, FD_WAVE);
+            run_id = acc;
+        }
+        unsigned long long idf_fix = 0;
+        uint32_t *match = nullptr, *nb = nullptr, *eb = nullptr;
+        unsigned long long *idf = nullptr;
+        if (!SUMS) {
+            idf_fix = A.q_idf_fix[q];
+            const uint64_t qbase = q_query ? (uint64_t)q_query[q] * A.S : 0ull;
+            match = A.match + qbase; idf = A.idf + qbase;
+            nb = A.node_bits + (uint64_t)A.q_node_idx[q] * A.words;
+            eb = A.edge_bits + (uint64_t)A.q_edge_idx[q] * A.words;
+        }
+        uint32_t seg_acc = 0;
+        for (uint64_t base = s0; base < s1; base += FD_WAVE) {
+            const uint64_t p = base + lane;
+            const bool in = p < s1;
+            const uint32_t byte = in ? A.value[p] : 0x80u;
+            const bool term = in && !(byte & 0x80u);
+            const uint64_t tm = __ballot(term);
+            const uint64_t below = tm & ((1ull << lane) - 1ull);
+            const int prev_t = below ? 63 - __clzll(below) : -1;
+            const uint32_t len_here = lane - (uint32_t)(prev_t + 1) + 1;
+            uint32_t v = 0;
+            const uint32_t pay = byte & 0x7fu;
+#pragma unroll
+            for (int back = 4; back >= 0; --back) {
+                const uint32_t pb = __shfl(pay, (int)lane - back, FD_WAVE);
+                if ((uint32_t)back < len_here) v |= pb << (7u * (len_here - 1u - (uint32_t)back));
+            }
+            if (term && prev_t < 0) v = carry_val | (v << carry_shift);
+            uint32_t s2 = term ? v : 0u;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(s2, off, FD_WAVE);
+                if ((int)lane >= off) s2 += t;
+            }
+            const uint32_t id = run_id + s2;
+            if (!SUMS && term) {
+                const uint32_t rel = id - A.first_id;
+                if (id >= A.first_id && rel < A.S) {
+                    atomicAdd(&match[rel], 1u);
+                    atomicAdd(&idf[rel], idf_fix);
+                    atomicOr(&nb[rel >> 5], 1u << (rel & 31u));
+                    atomicOr(&eb[rel >> 5], 1u << (rel & 31u));
+                }
+            }
+            if (tm) {
+                const int last_t = 63 - __clzll(tm);
+                run_id = __shfl(id, last_t, FD_WAVE);
+                const uint32_t tail = 63u - (uint32_t)last_t;
+                uint32_t pv = 0;
+                for (uint32_t t2 = 0; t2 < tail && t2 < 5; ++t2) pv |= __shfl(pay, last_t + 1 + (int)t2, FD_WAVE) << (7u * t2);
+                carry_val = pv; carry_shift = 7u * tail;
+            } else {   // a block of continuation bytes only (cannot happen for 32-bit ids; kept consistent)
+                uint32_t pv = carry_val;
+                for (uint32_t t2 = 0; t2 < 5; ++t2) pv |= __shfl(pay, (int)t2, FD_WAVE) << (carry_shift + 7u * t2);
+                carry_val = pv; carry_shift += 7u * FD_WAVE;
+            }
+            if (SUMS) seg_acc = run_id;
+        }
+        if (SUMS && lane == 0) P.segsum[w] = seg_acc;     // run_id started at 0: the sum of the values that end in this segment
     }
+}
+void fd_launch_cq_plan(const cq_args &A, long long *kidx, uint32_t *nseg, hipStream_t st) {
+    if (A.nq) hipLaunchKernelGGL(k_cq_plan, dim3((unsigned)((A.nq + 255) / 256)), dim3(256), 0, st, A.hashes, A.offsets, A.H, A.q_hash, A.nq, kidx, nseg);
+}
+// n_items: number of work items (host copy of wstart[nq]); split: some list has more than one segment
+void fd_launch_cq_seg(const cq_args &A, const uint32_t *q_query, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
+                      hipStream_t st) {
+    if (!A.nq || !n_items) return;
+    cq_plan P;
+    P.kidx = kidx; P.wstart = wstart; P.segsum = segsum;
+    const unsigned grid = (unsigned)(n_items < 16384 ? n_items : 16384);
+    if (split) hipLaunchKernelGGL(k_cq_seg<true>, dim3(grid), dim3(FD_WAVE), 0, st, A, q_query, P);
+    hipLaunchKernelGGL(k_cq_seg<false>, dim3(grid), dim3(FD_WAVE), 0, st, A, q_query, P);
 }
 
 // bit-sliced per-structure popcount over `rows` bit-vectors: lane handles one 32-structure word column
@@ -241,64 +301,6 @@ __global__ __launch_bounds__(256) void k_cq_compact(const uint32_t *__restrict__
 // ------------------------------------------------------------------ batched scoring (many queries, one launch each)
 // Same arithmetic as above; query hash k belongs to query A.q_query[k]; accumulators are [n_queries][S], the
 // occupancy bit matrix has one row per (query, node) and per (query, edge) (A.q_node_idx / q_edge_idx are global rows).
-__global__ __launch_bounds__(FD_WAVE) void k_cq_accumulate_batch(cq_args A, const uint32_t *__restrict__ q_query) {
-    uint64_t q = blockIdx.x;
-    if (q >= A.nq) return;
-    int64_t k = find_hash(A.hashes, A.H, A.q_hash[q]);
-    if (k < 0) return;
-    const uint64_t b0 = A.offsets[k], b1 = A.offsets[k + 1];
-    const uint32_t lane = threadIdx.x;
-    const unsigned long long idf_fix = A.q_idf_fix[q];
-    const uint64_t qbase = (uint64_t)q_query[q] * A.S;
-    uint32_t *match = A.match + qbase;
-    unsigned long long *idf = A.idf + qbase;
-    uint32_t *nb = A.node_bits + (uint64_t)A.q_node_idx[q] * A.words;
-    uint32_t *eb = A.edge_bits + (uint64_t)A.q_edge_idx[q] * A.words;
-    uint32_t run_id = 0, carry_val = 0, carry_shift = 0;
-    bool have_first = false;
-    for (uint64_t base = b0; base < b1; base += FD_WAVE) {
-        uint64_t p = base + lane;
-        bool in = p < b1;
-        uint32_t byte = in ? A.value[p] : 0x80u;
-        bool term = in && !(byte & 0x80u);
-        uint64_t tm = __ballot(term);
-        uint64_t below = tm & ((1ull << lane) - 1ull);
-        int prev_t = below ? 63 - __clzll(below) : -1;
-        uint32_t len_here = lane - (uint32_t)(prev_t + 1) + 1;
-        uint32_t v = 0, pay = byte & 0x7fu;
-#pragma unroll
-        for (int back = 4; back >= 0; --back) {
-            uint32_t pb = __shfl(pay, (int)lane - back, FD_WAVE);
-            if ((uint32_t)back < len_here) v |= pb << (7u * (len_here - 1u - (uint32_t)back));
-        }
-        if (term && prev_t < 0) v = carry_val | (v << carry_shift);
-        uint32_t s2 = term ? v : 0u;
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t t = __shfl_up(s2, off, FD_WAVE);
-            if ((int)lane >= off) s2 += t;
-        }
-        uint32_t id = (have_first ? run_id : 0u) + s2;
-        if (term) {
-            uint32_t rel = id - A.first_id;
-            if (id >= A.first_id && rel < A.S) {
-                atomicAdd(&match[rel], 1u);
-                atomicAdd(&idf[rel], idf_fix);
-                atomicOr(&nb[rel >> 5], 1u << (rel & 31u));
-                atomicOr(&eb[rel >> 5], 1u << (rel & 31u));
-            }
-        }
-        if (tm) {
-            int last_t = 63 - __clzll(tm);
-            run_id = __shfl(id, last_t, FD_WAVE);
-            have_first = true;
-            uint32_t tail = 63u - (uint32_t)last_t, pv = 0;
-            for (uint32_t t2 = 0; t2 < tail && t2 < 5; ++t2) pv |= __shfl(pay, last_t + 1 + (int)t2, FD_WAVE) << (7u * t2);
-            carry_val = pv;
-            carry_shift = 7u * tail;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_cq_finalize_batch(const uint32_t *__restrict__ match, const uint32_t *__restrict__ node_bits,
                                                            const uint32_t *__restrict__ edge_bits, const uint32_t *__restrict__ row_off /*[4*nQ]: n0,n1,e0,e1*/,
                                                            uint32_t words, uint32_t S, uint32_t *__restrict__ node_cnt,
@@ -412,7 +414,6 @@ void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries
 
 void fd_launch_cq_batch(const cq_args &A, const uint32_t *q_query, uint32_t n_queries, const uint32_t *row_off, uint32_t *node_cnt, uint32_t *edge_cnt,
                         uint8_t *flags, hipStream_t st) {
-    if (A.nq) hipLaunchKernelGGL(k_cq_accumulate_batch, dim3((unsigned)A.nq), dim3(FD_WAVE), 0, st, A, q_query);
     if (A.words && n_queries)
         hipLaunchKernelGGL(k_cq_finalize_batch, dim3((A.words + 255) / 256, n_queries), dim3(256), 0, st, A.match, A.node_bits, A.edge_bits, row_off,
                            A.words, A.S, node_cnt, edge_cnt, flags);
@@ -426,9 +427,6 @@ void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, cons
 void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,
                                uint64_t nq, uint64_t *lengths, hipStream_t st) {
     if (nq) hipLaunchKernelGGL(k_posting_lengths, dim3((unsigned)nq), dim3(FD_WAVE), 0, st, hashes, offsets, value, H, q_hash, nq, lengths);
-}
-void fd_launch_cq_accumulate(const cq_args &A, hipStream_t st) {
-    if (A.nq) hipLaunchKernelGGL(k_cq_accumulate, dim3((unsigned)A.nq), dim3(FD_WAVE), 0, st, A);
 }
 void fd_launch_cq_finalize(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_bits, uint32_t n_nodes,
                            const uint32_t *edge_bits, uint32_t n_edges, uint32_t words, uint32_t S, uint32_t *node_cnt, uint32_t *edge_cnt,

@@ -335,8 +335,9 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
             k = r if serial_query else query.get_index(c, r)
             if k is not None:
                 idx.append(k); subs.append(s)
-    else:
-        idx = [query.get_index(int(query.chain[k]), int(query.serial[k])) for k in range(query.n)]
+    else:   # whole-structure query: every residue (query.rs:226-233); --serial-index takes the residue number itself as the index (:236-238)
+        idx = [int(query.serial[k]) if serial_query else query.get_index(int(query.chain[k]), int(query.serial[k])) for k in range(query.n)]
+        idx = [k for k in idx if k is not None]
         subs = [None] * len(idx)
     qbatch = ctx.upload(PackedStructures.concat([query.as_item()]))
     pen = length_penalty(nres, length_penalty_power)
@@ -370,10 +371,12 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
         allrec = allrec[np.argsort(allrec["nid"], kind="stable")]  # the single-index call starts from ascending nid
         rows = [dict(nid=int(r["nid"]), total_match_count=int(r["total_match_count"]), node_count=int(r["node_count"]),
                      edge_count=int(r["edge_count"]), idf=float(r["idf"])) for r in allrec]
-    n_expected = np.float32(len(idx))   # residue_count: number of query residues (query_pdb.rs:384-389)
+    qnorm = res_chain_to_string(qres) if qres else query_string     # both output modes print the normalised form (query_pdb.rs:359-365)
+    # residue_count (query_pdb.rs:354-358): the PARSED residues, resolved in the structure or not; all residues for an empty query
+    n_expected = np.float32(len(qres) if qres else query.n)
     for r in rows:
         r.update(tid=tids[r["nid"]], nres=int(nres[r["nid"]]), plddt=float(plddt[r["nid"]]), db_key=r["nid"], matches=[],
-                 max_matching_node_count=0, min_rmsd_with_max_match=0.0)
+                 max_matching_node_count=0, min_rmsd_with_max_match=0.0, query_residues=qnorm)
 
     def before(r):   # StructureFilter::filter_before_matching
         ok = True

@@ -118,13 +118,14 @@ def _parse_u64(s: str):
 
 
 def read_atoms(path: str):
-    opener = gzip.open if path.endswith(".gz") else open
+    gz = path.endswith(".gz")
+    opener = gzip.open if gz else open
     atoms = []
     model = 0
     with opener(path, "rt", errors="replace") as fh:
         for line in fh:
             line = line.rstrip("\r\n")
-            if model > 1:
+            if model > 1 and not gz:     # read_structure_from_gz (pdb.rs:79-124) keeps the ATOM records of every model
                 break
             if len(line) < 6:
                 continue

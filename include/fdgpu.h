@@ -32,7 +32,13 @@ typedef struct fdgpu_batch fdgpu_batch;   /* packed structures resident in HBM *
 typedef struct fdgpu_index fdgpu_index;   /* inverted index resident in HBM */
 
 /* ---- context ------------------------------------------------------------------------- */
+/* fdgpu_create runs a start-up self-check (FDGPU_SELFCHECK=0 skips it): the six 4CHA triad hashes the reference's own test holds
+ * (src/controller/graph.rs:71-79) through every evaluation path of the pair kernel — a mismatch fails with FDGPU_EHIP — and a probe of
+ * the HOST's libm against the glibc generation the device arithmetic restates (fdgpu_host_libm_matches). */
 int fdgpu_create(int device, fdgpu_ctx **out);
+/* 1: this host's sinf/cosf/acosf/atan2f agree with the restated generation (a reference build here hashes like this library),
+ * 0: they differ (warning on stderr), -1: self-check skipped */
+int fdgpu_host_libm_matches(const fdgpu_ctx *ctx);
 void fdgpu_destroy(fdgpu_ctx *ctx);
 /* use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream */
 int fdgpu_set_stream(fdgpu_ctx *ctx, void *hip_stream);

@@ -211,7 +211,7 @@ def test_other_encodings_query_map_and_retrieval(env, htype, tmp_path):
     rows = [l.rstrip("\n").split("\t") for l in open(out)]
     q = st.read_compact_structure(Q4CHA)
     _, want = fq.query_pdb(ctx, ix, batch, structs, [os.path.join(os.path.dirname(SER[0]), os.path.basename(p)) for p in SER], nres, plddt, q,
-                           "B57,B102,C195", hash_type=htype, sort_by="node_count,rmsd")      # the CLI's default --sort-by
+                           "B57,B102,C195", hash_type=htype, sort_by="")      # the CLI default: no --sort-by (idf descending, rmsd ascending)
     assert [r[1:] for r in rows] == [fq.format_match_row(m).split("\t")[1:] for m in want] and len(rows) > 0
 
 
@@ -292,6 +292,13 @@ def test_cli_index_and_query_reproduce_readme(tmp_path):
     assert ps[1] == "data/serine_peptidases/1pq5.pdb\t0.4869\t4\t3\t4\t3\t0.2609\t224\t5.1340\tA56,A99,A195:0.2609\t3\tB57,B102,C195"
     assert "data/serine_peptidases/1ju3.pdb\t0.0617\t2\t2\t2\t2\t0.7792\t570\t19.4881\t_,A223,A234:0.7792\t1\tB57,B102,C195" in ps
     assert "data/serine_peptidases/1l7a.pdb\t0.0584\t2\t2\t2\t2\t0.7883\t636\t11.7037\t_,A146,A127:0.7883;_,B146,B127:0.8078\t2\tB57,B102,C195" in ps
+    # no --sort-by = StructureSortStrategy::default (idf descending, cli/main.rs:84): 1azw (idf 0.1856, no match) comes third —
+    # "node_count,rmsd" would put it last
+    assert ps[2].startswith("data/serine_peptidases/1azw.pdb\t0.1856\t")
+    # the per-structure table prints the NORMALISED query string (ranges expanded, default chain filled in; query_pdb.rs:359-365)
+    pr = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", Q4CHA, "-q", "57-57,B102,C195", "-i", pre, "--per-structure"],
+                        cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
+    assert pr == ps
 
 
 @pytest.mark.gpu
@@ -750,7 +757,7 @@ def test_multiple_bins_index_query_and_retrieval(env, htype, bins, tmp_path):
     cli(["query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", prefix, "-o", out])
     q = st.read_compact_structure(Q4CHA)
     _, want = fq.query_pdb(ctx, ix, batch, structs, [os.path.join(os.path.dirname(SER[0]), os.path.basename(p)) for p in SER], nres, plddt, q,
-                           "B57,B102,C195", hash_type=htype, multiple_bins=bins, sort_by="node_count,rmsd")
+                           "B57,B102,C195", hash_type=htype, multiple_bins=bins, sort_by="")
     rows = [l.rstrip("\n").split("\t") for l in open(out)]
     assert [r[1:] for r in rows] == [fq.format_match_row(m).split("\t")[1:] for m in want] and len(rows) > 0
     with pytest.raises(Exception):
@@ -831,7 +838,7 @@ def test_cli_own_descriptor_encodings(env, alias, name, tmp_path):
     cli(["query", "-p", Q4CHA, "-q", "B57,B102,C195", "-i", prefix, "-o", out, "--ca-distance", "1.5"])
     q = st.read_compact_structure(Q4CHA)
     _, want = fq.query_pdb(ctx, ix, batch, structs, [os.path.join(os.path.dirname(SER[0]), os.path.basename(p)) for p in SER], nres, plddt, q,
-                           "B57,B102,C195", hash_type=htype, sort_by="node_count,rmsd", ca_distance=1.5)
+                           "B57,B102,C195", hash_type=htype, sort_by="", ca_distance=1.5)
     rows = [l.rstrip("\n").split("\t") for l in open(out)]
     assert [r[1:] for r in rows] == [fq.format_match_row(m).split("\t")[1:] for m in want]
     assert any("B57,B102,C195" == r[4] for r in rows)          # 4cha matches itself under every encoding

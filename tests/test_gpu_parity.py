@@ -638,3 +638,43 @@ def test_device_merge_of_loaded_indices(ctx):
     v, h, o = single.export()
     mv, mh, mo = merged.export()
     assert np.array_equal(mh, h) and np.array_equal(mo, o) and np.array_equal(mv, v)
+
+
+@pytest.mark.gpu
+def test_context_is_safe_under_concurrent_callers(ctx):
+    """the reference calls its seams from many rayon workers (controller/mod.rs:291, query_pdb.rs:348,415).  Four host
+    threads hammer ONE context through the C ABI (ctypes releases the GIL) with index builds, posting lookups and scoring: every
+    result equals the serial one (the context serialises its entry points; one stream, one scratch set)."""
+    import threading
+    import folddisco_amd as fd
+    from folddisco_amd import synth
+    sets = [synth.to_packed(synth.generate(60 + 7 * k, seed=40 + k)) for k in range(4)]
+    batches = [ctx.upload(ps) for ps in sets]
+    want = []
+    for ps, b in zip(sets, batches):
+        ix = fd.FolddiscoIndex.build(ctx, b, first_id=5)
+        v, h, o = ix.export()
+        qh = h[:: max(1, len(h) // 50)][:50].astype(np.uint32)
+        pen = fd.length_penalty(np.diff(ps.res_off).astype(np.uint64), 0.5)
+        recs = fd.count_query(ctx, ix, qh, np.arange(len(qh), dtype=np.uint32) % 3, np.arange(len(qh), dtype=np.uint32) % 5, pen, as_array=True)
+        want.append((v.tobytes(), h.tobytes(), o.tobytes(), ix.posting_lengths(qh).tobytes(), recs.tobytes(), qh, pen))
+    errors = []
+
+    def worker(k):
+        try:
+            for _ in range(6):
+                ix = fd.FolddiscoIndex.build(ctx, batches[k], first_id=5)
+                v, h, o = ix.export()
+                wv, wh, wo, wl, wr, qh, pen = want[k]
+                assert v.tobytes() == wv and h.tobytes() == wh and o.tobytes() == wo
+                assert ix.posting_lengths(qh).tobytes() == wl
+                recs = fd.count_query(ctx, ix, qh, np.arange(len(qh), dtype=np.uint32) % 3, np.arange(len(qh), dtype=np.uint32) % 5, pen, as_array=True)
+                assert recs.tobytes() == wr
+        except BaseException as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors

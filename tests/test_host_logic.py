@@ -364,3 +364,33 @@ def test_oracle_query_bench_driver_equals_python_driven_oracle():
         r = oracle.query_bench(oix.hashes(), oix.offsets(), oix.values(), onres, ps.res_off, ps.n_xyz, ps.ca_xyz, ps.cb_xyz, ps.aa,
                                [(s, idx) for s, idx, _ in qs], top_n=1000, match_top=8, n_threads=nt)
         assert (r["hits"], r["matches"]) == (want_hits, want_matches) and want_matches >= 5
+
+
+def test_multi_model_files_plain_versus_gzip(tmp_path):
+    """The reference's plain-file reader stops behind the first MODEL (pdb.rs:46-58); its gzip reader has no MODEL handling and keeps
+    the ATOM records of every model (pdb.rs:79-124) — a multi-model .pdb.gz therefore yields different residues than the same file
+    uncompressed.  Both ingest paths (fd_ingest.cpp and structure.py) follow it."""
+    import gzip
+    from folddisco_amd import structure as st
+
+    def atom(serial, name, res, chain, rser, x, y, z):
+        return "ATOM  %5d %-4s %3s %1s%4d    %8.3f%8.3f%8.3f  1.00 20.00           C  " % (serial, name, res, chain, rser, x, y, z)
+    lines, k = [], 1
+    for model in (1, 2):
+        lines.append("MODEL     %4d" % model)
+        for r in range(1, 6):
+            for name, dx in ((" N  ", 0.0), (" CA ", 1.4), (" C  ", 2.5), (" CB ", 1.6)):
+                lines.append(atom(k, name, "ALA" if model == 1 else "SER", "A", r + 10 * (model - 1), 3.8 * r + dx, 0.3 * model, 0.1 * r))
+                k += 1
+        lines.append("ENDMDL")
+    txt = "\n".join(lines) + "\n"
+    plain, gz = tmp_path / "m.pdb", tmp_path / "m.pdb.gz"
+    plain.write_text(txt)
+    with gzip.open(gz, "wt") as fh:
+        fh.write(txt)
+    a, b = st.read_compact_structure(str(plain)), st.read_compact_structure(str(gz))
+    assert a.n < b.n and set(a.aa.tolist()) == {0} and set(b.aa.tolist()) == {0, 15}
+    ps = st.read_packed([str(plain), str(gz)], threads=2)[0]
+    off = ps.res_off.astype(int)
+    assert off[1] - off[0] == a.n and off[2] - off[1] == b.n
+    assert np.array_equal(ps.ca_xyz[off[1]:off[2]], b.ca_xyz) and np.array_equal(ps.aa[off[1]:off[2]], b.aa)
