@@ -162,6 +162,7 @@ SYMBOLS = [
     ("fdgpu_posting_bytes", C.c_int, [VP, VP, u32p, C.c_uint64, u64p]),
     ("fdgpu_index_set_first_id", C.c_int, [VP, C.c_uint64]),
     ("fdgpu_host_libm_matches", C.c_int, [VP]),
+    ("fdgpu_metrics_batch", C.c_int, [VP, f32p, f32p, u64p, C.c_uint64, f32p, f32p, f32p]),
     ("fdgpu_debug_libm", C.c_int, [VP, C.c_int, f32p, f32p, f32p, C.c_uint64]),
 ]
 

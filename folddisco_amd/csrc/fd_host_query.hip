@@ -425,51 +425,6 @@ static std::vector<std::vector<uint32_t>> components(const Graph &g, size_t min_
 
 extern "C" void fdgpu_matches_free(fd_match_rec *m, int32_t *residues) { free(m); free(residues); }
 
-// Similarity metrics of one superposition (src/structure/metrics.rs:62-251 applied to KabschSuperimposer's reference /
-// transformed coordinates, src/structure/kabsch.rs:86-95,145-154): ref = fixed (query) points, mov = moving (target) points,
-// transformed = rot * mov + tran in f32, distances evaluated in f64 and stored as f32.  out = {tm_score, gdt_ts, gdt_ha,
-// chamfer, hausdorff}.  Kept as the reference has it: tm_score and gdt compare the distance (not its square) with d0^2 /
-// cutoff^2 (metrics.rs:141-143, 160-163).  Host code: a motif match is a dozen points.
-static void fd_similarity_metrics(const float *ref, const float *mov, uint64_t n, const float *rot, const float *tran, float out[5]) {
-    if (n == 0) { out[0] = out[1] = out[2] = 0.0f; out[3] = out[4] = INFINITY; return; }
-    std::vector<float> tr(3 * n);
-    for (uint64_t i = 0; i < n; ++i)
-        for (int r = 0; r < 3; ++r) {
-            float v = rot[3 * r] * mov[3 * i] + rot[3 * r + 1] * mov[3 * i + 1] + rot[3 * r + 2] * mov[3 * i + 2];
-            tr[3 * i + r] = v + tran[r];
-        }
-    auto dist = [&](uint64_t c, uint64_t r) {
-        double dx = (double)ref[3 * r] - (double)tr[3 * c], dy = (double)ref[3 * r + 1] - (double)tr[3 * c + 1], dz = (double)ref[3 * r + 2] - (double)tr[3 * c + 2];
-        return (float)sqrt(dx * dx + dy * dy + dz * dz);
-    };
-    const float d0 = n > 21 ? 1.24f * powf((float)n - 15.0f, 1.0f / 3.0f) - 1.8f : 0.5f;
-    const double d0_sq = (double)(d0 * d0), dn = (double)n;
-    std::vector<float> diag(n);
-    double tm = 0.0;
-    for (uint64_t i = 0; i < n; ++i) { diag[i] = dist(i, i); tm += 1.0 / (1.0 + (double)diag[i] / d0_sq); }
-    out[0] = (float)(tm / dn);
-    const double ts[4] = {1.0, 2.0, 4.0, 8.0}, ha[4] = {0.5, 1.0, 2.0, 4.0};
-    for (int which = 0; which < 2; ++which) {
-        const double *cut = which ? ha : ts;
-        double sum = 0.0;
-        for (int k = 0; k < 4; ++k) {
-            uint64_t cnt = 0;
-            for (uint64_t i = 0; i < n; ++i) if ((double)diag[i] <= cut[k] * cut[k]) ++cnt;
-            sum += (double)cnt / dn;
-        }
-        out[1 + which] = (float)(sum / 4.0);
-    }
-    double ch = 0.0;
-    float hd = 0.0f;
-    for (uint64_t i = 0; i < n; ++i) {
-        float mn = dist(i, 0);
-        for (uint64_t j = 1; j < n; ++j) mn = std::min(mn, dist(i, j));
-        ch += (double)mn;
-        if (i == 0 || mn > hd) hd = mn;
-    }
-    out[3] = (float)(ch / dn);
-    out[4] = hd;
-}
 
 // coordinates of all candidates in one launch + one copy (a hipMemcpy per candidate costs more than the pair scan)
 __global__ __launch_bounds__(256) void k_gather_xyz(const float *__restrict__ ca, const float *__restrict__ cb, const uint64_t *__restrict__ src,
@@ -898,17 +853,19 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     }
     if (trace) fprintf(stderr, "[fdgpu_retrieve] match_pairs %.3f ms (found %llu, cands %llu), gather %.3f, graph/vote %.3f, kabsch(%llu) %.3f\n", t_ms(T0, T1),
                        (unsigned long long)nf, (unsigned long long)nc, t_ms(T1, T2), t_ms(T2, T3), (unsigned long long)nprob, t_ms(T3, t_now()));
+    // similarity metrics of every superposition on the device (k_metrics), after a possible --partial-fit override of rot / tran
+    std::vector<float> mets(std::max<uint64_t>(nprob, 1) * 5);
+    if (nprob && (rc = fdgpu_metrics_batch(c, ky.data(), kx.data(), koff.data(), nprob, rot.data(), tran.data(), mets.data()))) return rc;
     for (uint64_t k = 0; k < nprob; ++k) {
         fd_match_rec &r = recs[pend[k].rec];
         const bool is_out = pend[k].which == 1 || r.same;   // the superposition the match reports
         if (pend[k].which == 0) {
             r.rmsd_from_hash = rmsd[k]; memcpy(r.rot_from_hash, &rot[9 * k], 36); memcpy(r.tran_from_hash, &tran[3 * k], 12);
-            fd_similarity_metrics(ky.data() + 3 * koff[k], kx.data() + 3 * koff[k], koff[k + 1] - koff[k], &rot[9 * k], &tran[3 * k], r.metrics_from_hash);
+            memcpy(r.metrics_from_hash, &mets[5 * k], 20);
         }
         if (is_out) {
             r.rmsd = rmsd[k]; memcpy(r.rot, &rot[9 * k], 36); memcpy(r.tran, &tran[3 * k], 12);
-            const uint64_t p0 = koff[k], np_ = koff[k + 1] - koff[k];
-            fd_similarity_metrics(ky.data() + 3 * p0, kx.data() + 3 * p0, np_, &rot[9 * k], &tran[3 * k], r.metrics);
+            memcpy(r.metrics, &mets[5 * k], 20);
         }
     }
     fd_match_rec *om = (fd_match_rec *)malloc(std::max<size_t>(recs.size(), 1) * sizeof(fd_match_rec));

@@ -793,7 +793,14 @@ extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const 
     HIPCHK(c, c->ws[WS_MISC0].ensure(nq * 4));
     HIPCHK(c, c->ws[WS_MISC1].ensure(nq * 8));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st));
-    fd_launch_posting_lengths(ix->hashes, ix->offsets, ix->value, ix->n_hashes, c->ws[WS_MISC0].as<uint32_t>(), nq, c->ws[WS_MISC1].as<uint64_t>(), st);
+    HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(nq * 8));
+    HIPCHK(c, c->ws[WS_CQ_NSEG].ensure(nq * 4));
+    HIPCHK(c, c->ws[WS_CQ_WSTART].ensure((nq + 2) * 8));
+    HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(nq) * 8 + 64));
+    HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
+    fd_launch_posting_lengths(ix->hashes, ix->offsets, ix->value, ix->n_hashes, c->ws[WS_MISC0].as<uint32_t>(), nq, c->ws[WS_MISC1].as<uint64_t>(),
+                              c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), c->ws[WS_CQ_WSTART].as<uint64_t>(),
+                              c->ws[WS_SCANTMP].as<uint64_t>(), c->ws[WS_TOTAL].as<uint64_t>(), st);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(lengths, c->ws[WS_MISC1].p, nq * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -1061,16 +1068,23 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
         std::vector<uint32_t> cnt(n_queries);
         std::vector<fd_count_rec> sel((size_t)n_queries * cap);
         e = c->ws[WS_KEYS_A].ensure((size_t)n_queries * cap * sizeof(fd_count_rec));
-        if (e == hipSuccess) e = c->ws[WS_MISC2].ensure(n_queries * 4);
+        const size_t topn_bytes = (size_t)n_queries * 2048 * 4;
+        if (e == hipSuccess && c->ws[WS_CQ_TOPN].cap < topn_bytes) {     // histogram table: zeroed when (re)allocated, the kernels leave it zero
+            e = c->ws[WS_CQ_TOPN].ensure(topn_bytes);
+            if (e == hipSuccess) e = hipMemsetAsync(c->ws[WS_CQ_TOPN].p, 0, c->ws[WS_CQ_TOPN].cap, st);
+        }
+        if (e == hipSuccess) e = c->ws[WS_MISC2].ensure(n_queries * 16);
+        std::vector<uint32_t> tstate((size_t)n_queries * 4);
         if (e == hipSuccess) {
-            fd_launch_cq_topn(c->ws[WS_TILE_HO].p, c->ws[WS_TILE_PO].as<uint64_t>(), (uint32_t)n_queries, top_n, cap, c->ws[WS_KEYS_A].p,
-                              c->ws[WS_MISC2].as<uint32_t>(), st);
-            e = hipMemcpyAsync(cnt.data(), c->ws[WS_MISC2].p, n_queries * 4, hipMemcpyDeviceToHost, st);
+            fd_launch_cq_topn(c->ws[WS_TILE_HO].p, c->ws[WS_TILE_PO].as<uint64_t>(), (uint32_t)n_queries, top_n, cap, c->ws[WS_KEYS_A].p, c->ws[WS_MISC2].p,
+                              c->ws[WS_CQ_TOPN].as<uint32_t>(), st);
+            e = hipMemcpyAsync(tstate.data(), c->ws[WS_MISC2].p, n_queries * 16, hipMemcpyDeviceToHost, st);
         }
         if (e == hipSuccess) e = hipMemcpyAsync(sel.data(), c->ws[WS_KEYS_A].p, sel.size() * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) { free(ooff); c->err = std::string("count_query_batch: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+        for (uint64_t t = 0; t < n_queries; ++t) cnt[t] = tstate[4 * t + 3];
         uint64_t tot = 0;
         for (uint64_t t = 0; t < n_queries; ++t) tot += cnt[t] <= cap ? cnt[t] : (ooff[t + 1] - ooff[t]);
         r = (fd_count_rec *)malloc(std::max<uint64_t>(tot, 1) * sizeof(fd_count_rec));
@@ -1308,6 +1322,42 @@ extern "C" int fdgpu_match_pairs(fdgpu_ctx *c, const fdgpu_batch *db, const uint
     if (!q) return FDGPU_EINVAL;
     const uint64_t off[2] = {0, n_cand};
     return fd_match_pairs_multi(c, db, resname_std, 1, q, cand, off, p, found, n_found, cands, n_cands);
+}
+
+// Similarity metrics of n superpositions on the device (k_metrics): problem k compares ref[off[k] .. off[k+1]) (fixed points) with
+// rot[k] * mov[...] + tran[k]; metrics[5k ..] = {tm_score, gdt_ts, gdt_ha, chamfer, hausdorff} (src/structure/metrics.rs:62-251).
+extern "C" int fdgpu_metrics_batch(fdgpu_ctx *c, const float *ref, const float *mov, const uint64_t *off, uint64_t n, const float *rot, const float *tran,
+                                   float *metrics) { FD_LOCK(c);
+    if (!c || (n && (!ref || !mov || !off || !rot || !tran || !metrics))) return FDGPU_EINVAL;
+    if (!n) return FDGPU_OK;
+    hipStream_t st = c->stream;
+    const uint64_t npts = off[n];
+    std::vector<float> d0(n);
+    for (uint64_t k = 0; k < n; ++k) {   // d0_scale (metrics.rs:117-123) with the host's powf, like the reference
+        const uint64_t len = off[k + 1] - off[k];
+        d0[k] = len > 21 ? 1.24f * powf((float)len - 15.0f, 1.0f / 3.0f) - 1.8f : 0.5f;
+    }
+    HIPCHK(c, c->ws[WS_MISC0].ensure(std::max<uint64_t>(npts, 1) * 12));
+    HIPCHK(c, c->ws[WS_MISC1].ensure(std::max<uint64_t>(npts, 1) * 12));
+    HIPCHK(c, c->ws[WS_MISC2].ensure((n + 1) * 8));
+    HIPCHK(c, c->ws[WS_MISC3].ensure(n * 4));
+    HIPCHK(c, c->ws[WS_MISC4].ensure(n * 36));
+    HIPCHK(c, c->ws[WS_MISC5].ensure(n * 12));
+    HIPCHK(c, c->ws[WS_TILE_PO].ensure(n * 20));
+    if (npts) {
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, ref, npts * 12, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, mov, npts * 12, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC3].p, d0.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC4].p, rot, n * 36, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, tran, n * 12, hipMemcpyHostToDevice, st));
+    fd_launch_metrics(c->ws[WS_MISC0].as<float>(), c->ws[WS_MISC1].as<float>(), c->ws[WS_MISC2].as<uint64_t>(), n, c->ws[WS_MISC4].as<float>(),
+                      c->ws[WS_MISC5].as<float>(), c->ws[WS_MISC3].as<float>(), c->ws[WS_TILE_PO].as<float>(), st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(metrics, c->ws[WS_TILE_PO].p, n * 20, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return FDGPU_OK;
 }
 
 extern "C" int fdgpu_kabsch_batch(fdgpu_ctx *c, const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot,

@@ -33,7 +33,7 @@ struct fd_timing_entry { const char *name; hipEvent_t ev0, ev1; uint64_t bytes; 
 enum {
     WS_COUNTS, WS_CURSOR, WS_SEGOFF, WS_SCANTMP, WS_TOTAL, WS_KEYS_A, WS_IDS_A, WS_KEYS_B, WS_IDS_B, WS_GHIST, WS_TOT,
     WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
-    WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM,
+    WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
     WS_COUNT
 };
 
@@ -177,7 +177,8 @@ struct cq_args {
     uint32_t *match; unsigned long long *idf; uint32_t *node_bits; uint32_t *edge_bits; uint32_t words; uint32_t first_id; uint32_t S;
 };
 void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,
-                               uint64_t nq, uint64_t *lengths, hipStream_t st);
+                               uint64_t nq, uint64_t *lengths, long long *kidx, uint32_t *nseg, uint64_t *wstart, uint64_t *scan_tmp, uint64_t *total,
+                               hipStream_t st);
 void fd_launch_cq_plan(const cq_args &A, long long *kidx, uint32_t *nseg, hipStream_t st);
 void fd_launch_cq_seg(const cq_args &A, const uint32_t *q_query, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
                       hipStream_t st);
@@ -223,13 +224,15 @@ struct mp_args {
 void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st);
 void fd_launch_pack_cands(const fd_cand_rec *c, uint64_t n, uint32_t *key, uint32_t *val, hipStream_t st);
 void fd_launch_kabsch(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, hipStream_t st);
+void fd_launch_metrics(const float *ref, const float *mov, const uint64_t *off, uint64_t n, const float *rot, const float *tran, const float *d0, float *out,
+                       hipStream_t st);
 void fd_launch_lms_qcp(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, uint32_t *core_len,
                        uint8_t *flags, uint32_t *order, hipStream_t st);
 void fd_launch_cq_batch(const cq_args &A, const uint32_t *q_query, uint32_t n_queries, const uint32_t *row_off, uint32_t *node_cnt, uint32_t *edge_cnt,
                         uint8_t *flags, hipStream_t st);
 void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, const uint32_t *edge_cnt, const uint8_t *flags, const uint64_t *pos,
                                 const float *penalty, uint64_t total, void *out, hipStream_t st);
-void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries, uint32_t top_n, uint32_t cap, void *out, uint32_t *out_cnt,
+void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries, uint32_t top_n, uint32_t cap, void *out, void *state, uint32_t *ghist,
                        hipStream_t st);
 void fd_launch_get_entries(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash, uint64_t nq,
                            const uint64_t *out_off, uint32_t *out, hipStream_t st);

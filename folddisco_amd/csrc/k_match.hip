@@ -248,181 +248,252 @@ void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st) {
     else hipLaunchKernelGGL(k_match_pairs<false>, dim3(A.n_work), dim3(FD_WAVE), 0, st, A);
 }
 
-// ------------------------------------------------------------------------------------------ Kabsch
-// One lane per superposition problem (2..16 points each): the closed-form eigen solve is ~300 f64
-// operations, so a batch of thousands of matches is one short launch.  f64 like the reference;
-// results are rounded to f32 exactly where the reference rounds (kabsch.rs:537-553).
-// WAVE = true: one wavefront per problem for the large ones (whole-structure matches superpose hundreds of points; a single lane
-// walking them is latency-bound): the two passes over the points are strided over the lanes and reduced with shuffles (f64 sums in
-// tree order, within the 1e-4 RMSD tolerance), the 3x3 eigen solve runs uniformly.  Problems below KB_WAVE_MIN points keep one lane each.
-#define KB_WAVE_MIN 128
-__device__ __forceinline__ double kb_wave_sum(double v) {
+// ------------------------------------------------------------------------------------------ superposition + similarity metrics
+// Optimal rigid superposition of moving points x onto fixed points y (what KabschSuperimposer::run returns: rotation U, translation
+// t, rmsd; src/structure/kabsch.rs:47-95) and the similarity metrics of the superposed pair (src/structure/metrics.rs:62-251).
+//
+// One WAVEFRONT per problem.  The O(n) parts — centroids and the 3x3 cross-covariance, the residual pass, the per-point distances
+// of TM-score / GDT — and the O(n^2) nearest-neighbour scans of Chamfer / Hausdorff are strided over the 64 lanes and combined with
+// a fixed-order butterfly, so a result does not depend on how many problems share the launch.  The 3x3 algebra in between is tiny
+// and runs redundantly in every lane (uniform control flow, no LDS).
+//
+// The rotation is Kabsch's eigen construction, the same one the reference uses (the eigenvectors of R^T R for the largest and the
+// smallest eigenvalue, Gram-Schmidt, b = R a, U = b a^T), because its answers for rank-deficient inputs — two-point matches, collinear
+// or duplicated points — are part of the output contract: where the construction gives up (no second direction: |a2|^2 <= 0.01
+// twice) the reference reports the identity and a zero translation, and so does this kernel.  f64 throughout, f32 at the end, NaN
+// rmsd -> f32::MAX (kabsch.rs:537-553).
+struct sp_sym3 { double xx, xy, yy, xz, yz, zz; };   // packed symmetric 3x3 (upper triangle by columns)
+
+__device__ __forceinline__ double sp_wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-template <bool WAVE>
-__global__ __launch_bounds__(64) void k_kabsch(const float *__restrict__ xs, const float *__restrict__ ys, const uint64_t *__restrict__ off,
-                                               uint64_t n_prob, float *__restrict__ rmsd_out, float *__restrict__ rot_out,
-                                               float *__restrict__ tran_out) {
-    uint64_t pidx = WAVE ? (uint64_t)blockIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pidx >= n_prob) return;
-    const uint32_t kb_lane = threadIdx.x;
-    const int IP[9] = {0, 1, 3, 1, 2, 4, 3, 4, 5};
-    const int IP2312[4] = {1, 2, 0, 1};
-    const double EPSILON = 1.0e-8, TOLERANCE = 0.01, SQRT3 = 1.7320508075688772;
-    const uint64_t p0 = off[pidx], p1 = off[pidx + 1];
-    const uint64_t n = p1 - p0;
-    if (WAVE ? n < KB_WAVE_MIN : n >= KB_WAVE_MIN) return;
-    const float *xf = xs + 3 * p0, *yf = ys + 3 * p0;
-    double u[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, t[3] = {0, 0, 0};
-    float rf = 3.40282347e+38f;
+// eigenvalues of a positive semi-definite symmetric 3x3 (trigonometric form of the cubic), descending
+__device__ __forceinline__ bool sp_eigenvalues(const sp_sym3 &M, double det_r, double ev[3]) {
+    const double mean = (M.xx + M.yy + M.zz) / 3.0;
+    ev[0] = ev[1] = ev[2] = mean;
+    if (!(mean > 0.0)) return false;
+    const double minors = (((M.yy * M.zz - M.yz * M.yz) + M.xx * M.zz - M.xz * M.xz) + M.xx * M.yy - M.xy * M.xy) / 3.0;
+    const double h = mean * mean - minors;
+    if (!(h > 0.0)) return false;
+    const double g = (mean * minors - det_r * det_r) / 2.0 - mean * h;
+    double disc = h * h * h - g * g;
+    if (disc < 0.0) disc = 0.0;
+    const double third = fabs(g) > 1e18 ? (g > 0.0 ? 3.14159265358979323846 / 3.0 : 0.0) : atan2(sqrt(disc), -g) / 3.0;
+    const double root = sqrt(h), c = root * cos(third), sn = root * 1.7320508075688772 * sin(third);
+    ev[0] = mean + 2.0 * c; ev[1] = mean - c + sn; ev[2] = mean - c - sn;
+    return true;
+}
+// eigenvector of M for eigenvalue l: the largest-diagonal column of adj(M - l I), entries below 1e-8 flushed, normalised (zero vector
+// when the column vanishes)
+__device__ __forceinline__ void sp_eigenvector(const sp_sym3 &M, double l, double v[3]) {
+    double c[6];
+    c[0] = (l - M.yy) * (l - M.zz) - M.yz * M.yz;
+    c[1] = (l - M.zz) * M.xy + M.xz * M.yz;
+    c[2] = (l - M.xx) * (l - M.zz) - M.xz * M.xz;
+    c[3] = (l - M.yy) * M.xz + M.xy * M.yz;
+    c[4] = (l - M.xx) * M.yz + M.xy * M.xz;
+    c[5] = (l - M.xx) * (l - M.yy) - M.xy * M.xy;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (fabs(c[k]) <= 1.0e-8) c[k] = 0.0;
+    const double d0 = fabs(c[0]), d1 = fabs(c[2]), d2 = fabs(c[5]);
+    if (d0 >= d1 && d0 >= d2) { v[0] = c[0]; v[1] = c[1]; v[2] = c[3]; }
+    else if (d1 >= d2) { v[0] = c[1]; v[1] = c[2]; v[2] = c[4]; }
+    else { v[0] = c[3]; v[1] = c[4]; v[2] = c[5]; }
+    const double n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const double inv = n2 > 1.0e-8 ? 1.0 / sqrt(n2) : 0.0;
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+}
+// w <- the unit vector orthogonal to unit vector u that w suggests; when w has (almost) nothing outside u (|w - (w.u)u|^2 <= 0.01) a
+// perpendicular is built from u's two smaller components; false when even that fails
+__device__ __forceinline__ bool sp_orthonormal(const double u[3], double w[3]) {
+    const double along = u[0] * w[0] + u[1] * w[1] + u[2] * w[2];
+    double n2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { w[k] -= along * u[k]; n2 += w[k] * w[k]; }
+    if (n2 > 0.01) {
+        const double inv = 1.0 / sqrt(n2);
+        w[0] *= inv; w[1] *= inv; w[2] *= inv;
+        return true;
+    }
+    int big = 0;
+    double mx = 1.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (mx < fabs(u[k])) { mx = fabs(u[k]); big = k; }
+    const int p = big == 0 ? 1 : (big == 1 ? 2 : 0), q = big == 0 ? 2 : (big == 1 ? 0 : 1);
+    const double len = sqrt(u[p] * u[p] + u[q] * u[q]);
+    if (!(len > 0.01)) return false;
+    w[big] = 0.0; w[p] = -u[q] / len; w[q] = u[p] / len;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_superpose(const float *__restrict__ xs, const float *__restrict__ ys, const uint64_t *__restrict__ off, uint64_t n_prob,
+                                                  float *__restrict__ rmsd_out, float *__restrict__ rot_out, float *__restrict__ tran_out) {
+    const uint64_t prob = blockIdx.x;
+    if (prob >= n_prob) return;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t p0 = off[prob], n = off[prob + 1] - p0;
+    const float *x = xs + 3 * p0, *y = ys + 3 * p0;
+    double U[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, T[3] = {0, 0, 0};
+    float rms = 3.40282347e+38f;
     if (n > 0) {
-        double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0}, sx[3] = {0, 0, 0}, sy[3] = {0, 0, 0}, sz[3] = {0, 0, 0}, xc[3], yc[3], e[3];
-        double r[3][3], a[3][3] = {{0}}, b[3][3] = {{0}}, rr[6], ss[6];
-        for (uint64_t i = WAVE ? kb_lane : 0; i < n; i += WAVE ? 64 : 1) {
-            double c1[3] = {xf[3 * i], xf[3 * i + 1], xf[3 * i + 2]};
-            double c2[3] = {yf[3 * i], yf[3 * i + 1], yf[3 * i + 2]};
-            for (int j = 0; j < 3; ++j) { s1[j] += c1[j]; s2[j] += c2[j]; }
-            sx[0] += c1[0] * c2[0]; sx[1] += c1[0] * c2[1]; sx[2] += c1[0] * c2[2];
-            sy[0] += c1[1] * c2[0]; sy[1] += c1[1] * c2[1]; sy[2] += c1[1] * c2[2];
-            sz[0] += c1[2] * c2[0]; sz[1] += c1[2] * c2[1]; sz[2] += c1[2] * c2[2];
+        // centroid sums and the raw second moments  S[a][b] = sum x_a y_b
+        double sx[3] = {0, 0, 0}, sy[3] = {0, 0, 0}, S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (uint64_t i = lane; i < n; i += 64) {
+            const double xv[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]}, yv[3] = {y[3 * i], y[3 * i + 1], y[3 * i + 2]};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                sx[a] += xv[a]; sy[a] += yv[a];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) S[a][b] += xv[a] * yv[b];
+            }
         }
-        if (WAVE)
-            for (int j = 0; j < 3; ++j) { s1[j] = kb_wave_sum(s1[j]); s2[j] = kb_wave_sum(s2[j]); sx[j] = kb_wave_sum(sx[j]); sy[j] = kb_wave_sum(sy[j]); sz[j] = kb_wave_sum(sz[j]); }
-        double dn = (double)n;
-        for (int j = 0; j < 3; ++j) { xc[j] = s1[j] / dn; yc[j] = s2[j] / dn; }
-        for (int j = 0; j < 3; ++j) {
-            r[j][0] = sx[j] - s1[0] * s2[j] / dn;
-            r[j][1] = sy[j] - s1[1] * s2[j] / dn;
-            r[j][2] = sz[j] - s1[2] * s2[j] / dn;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            sx[a] = sp_wave_sum(sx[a]); sy[a] = sp_wave_sum(sy[a]);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) S[a][b] = sp_wave_sum(S[a][b]);
         }
-        double det_r = r[0][0] * (r[1][1] * r[2][2] - r[1][2] * r[2][1]) - r[0][1] * (r[1][0] * r[2][2] - r[1][2] * r[2][0]) +
-                       r[0][2] * (r[1][0] * r[2][1] - r[1][1] * r[2][0]);
-        int m = 0;
-        for (int j = 0; j < 3; ++j)
-            for (int i = 0; i <= j; ++i) rr[m++] = r[0][i] * r[0][j] + r[1][i] * r[1][j] + r[2][i] * r[2][j];
-        double spur = (rr[0] + rr[2] + rr[5]) / 3.0;
-        double cof = (((rr[2] * rr[5] - rr[4] * rr[4]) + rr[0] * rr[5] - rr[3] * rr[3]) + rr[0] * rr[2] - rr[1] * rr[1]) / 3.0;
-        double det = det_r * det_r;
-        e[0] = e[1] = e[2] = spur;
-        if (spur > 0.0) {
-            double d = spur * spur;
-            double h = d - cof;
-            double g = (spur * cof - det) / 2.0 - spur * h;
-            if (h > 0.0) {
-                double sqrth = sqrt(h);
-                double disc = h * h * h - g * g;
-                if (disc < 0.0) disc = 0.0;
-                double sqrt_disc = sqrt(disc);
-                double d_ang = fabs(g) > 1e18 ? (g > 0.0 ? 3.14159265358979323846 / 3.0 : 0.0) : atan2(sqrt_disc, -g) / 3.0;
-                double cth = sqrth * cos(d_ang);
-                double sth = sqrth * SQRT3 * sin(d_ang);
-                e[0] = spur + 2.0 * cth;
-                e[1] = spur - cth + sth;
-                e[2] = spur - cth - sth;
-                bool a_failed = false, b_failed = false;
-                for (int li = 0; li < 2; ++li) {
-                    int l = li == 0 ? 0 : 2;
-                    double dl = e[l];
-                    ss[0] = (dl - rr[2]) * (dl - rr[5]) - rr[4] * rr[4];
-                    ss[1] = (dl - rr[5]) * rr[1] + rr[3] * rr[4];
-                    ss[2] = (dl - rr[0]) * (dl - rr[5]) - rr[3] * rr[3];
-                    ss[3] = (dl - rr[2]) * rr[3] + rr[1] * rr[4];
-                    ss[4] = (dl - rr[0]) * rr[4] + rr[1] * rr[3];
-                    ss[5] = (dl - rr[0]) * (dl - rr[2]) - rr[1] * rr[1];
-                    for (int k = 0; k < 6; ++k)
-                        if (fabs(ss[k]) <= EPSILON) ss[k] = 0.0;
-                    double Aa = fabs(ss[0]), Bb = fabs(ss[2]), Cc = fabs(ss[5]);
-                    int j = (Aa >= Bb && Aa >= Cc) ? 0 : (Bb >= Cc ? 1 : 2);
-                    double dnorm = 0.0;
-                    for (int i = 0; i < 3; ++i) { int k = IP[3 * j + i]; a[i][l] = ss[k]; dnorm += ss[k] * ss[k]; }
-                    dnorm = dnorm > EPSILON ? 1.0 / sqrt(dnorm) : 0.0;
-                    for (int i = 0; i < 3; ++i) a[i][l] *= dnorm;
+        const double dn = (double)n;
+        const double xc[3] = {sx[0] / dn, sx[1] / dn, sx[2] / dn}, yc[3] = {sy[0] / dn, sy[1] / dn, sy[2] / dn};
+        // R[b][a] = cov(y_b, x_a): the matrix with y = R x in the least-squares sense
+        double R[3][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) R[b][a] = S[a][b] - sx[a] * sy[b] / dn;
+        const double det_r = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) - R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
+                             R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
+        sp_sym3 M;   // R^T R
+        M.xx = R[0][0] * R[0][0] + R[1][0] * R[1][0] + R[2][0] * R[2][0];
+        M.xy = R[0][0] * R[0][1] + R[1][0] * R[1][1] + R[2][0] * R[2][1];
+        M.yy = R[0][1] * R[0][1] + R[1][1] * R[1][1] + R[2][1] * R[2][1];
+        M.xz = R[0][0] * R[0][2] + R[1][0] * R[1][2] + R[2][0] * R[2][2];
+        M.yz = R[0][1] * R[0][2] + R[1][1] * R[1][2] + R[2][1] * R[2][2];
+        M.zz = R[0][2] * R[0][2] + R[1][2] * R[1][2] + R[2][2] * R[2][2];
+        double ev[3];
+        const bool spread = (M.xx + M.yy + M.zz) / 3.0 > 0.0;
+        bool solved = false;
+        if (sp_eigenvalues(M, det_r, ev)) {
+            // right frame: eigenvectors of the largest (a0) and the smallest (a2) eigenvalue; the better separated one is kept as it is
+            double a0[3], a2[3], a1[3];
+            sp_eigenvector(M, ev[0], a0);
+            sp_eigenvector(M, ev[2], a2);
+            const bool keep_first = ev[0] - ev[1] > ev[1] - ev[2];
+            const bool ok_a = keep_first ? sp_orthonormal(a0, a2) : sp_orthonormal(a2, a0);
+            if (ok_a) {
+                a1[0] = a2[1] * a0[2] - a2[2] * a0[1];      // a1 = a2 x a0 (right-handed a0, a1, a2)
+                a1[1] = a2[2] * a0[0] - a2[0] * a0[2];
+                a1[2] = a2[0] * a0[1] - a2[1] * a0[0];
+                // left frame: images of a0 and a1 under R, normalised; b2 completes it
+                double b0[3], b1[3], b2[3];
+                double n0 = 0.0, n1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    b0[k] = R[k][0] * a0[0] + R[k][1] * a0[1] + R[k][2] * a0[2];
+                    b1[k] = R[k][0] * a1[0] + R[k][1] * a1[1] + R[k][2] * a1[2];
+                    n0 += b0[k] * b0[k]; n1 += b1[k] * b1[k];
                 }
-                double dt = a[0][0] * a[0][2] + a[1][0] * a[1][2] + a[2][0] * a[2][2];
-                int m1, mm;
-                if (e[0] - e[1] > e[1] - e[2]) { m1 = 2; mm = 0; } else { m1 = 0; mm = 2; }
-                double p = 0.0;
-                for (int i = 0; i < 3; ++i) { a[i][m1] = a[i][m1] - dt * a[i][mm]; p += a[i][m1] * a[i][m1]; }
-                if (p <= TOLERANCE) {
-                    int j = 0;
-                    p = 1.0;
-                    for (int i = 0; i < 3; ++i)
-                        if (p < fabs(a[i][mm])) { p = fabs(a[i][mm]); j = i; }
-                    int k = IP2312[j], l = IP2312[j + 1];
-                    p = sqrt(a[k][mm] * a[k][mm] + a[l][mm] * a[l][mm]);
-                    if (p > TOLERANCE) { a[j][m1] = 0.0; a[k][m1] = -a[l][mm] / p; a[l][m1] = a[k][mm] / p; }
-                    else a_failed = true;
-                } else {
-                    p = 1.0 / sqrt(p);
-                    for (int i = 0; i < 3; ++i) a[i][m1] *= p;
-                }
-                if (!a_failed) {
-                    a[0][1] = a[1][2] * a[2][0] - a[1][0] * a[2][2];
-                    a[1][1] = a[2][2] * a[0][0] - a[2][0] * a[0][2];
-                    a[2][1] = a[0][2] * a[1][0] - a[0][0] * a[1][2];
-                    for (int l = 0; l < 2; ++l) {
-                        double db = 0.0;
-                        for (int i = 0; i < 3; ++i) {
-                            b[i][l] = r[i][0] * a[0][l] + r[i][1] * a[1][l] + r[i][2] * a[2][l];
-                            db += b[i][l] * b[i][l];
-                        }
-                        db = db > EPSILON ? 1.0 / sqrt(db) : 0.0;
-                        for (int i = 0; i < 3; ++i) b[i][l] *= db;
-                    }
-                    double dot_b = 0.0;
-                    for (int i = 0; i < 3; ++i) dot_b += b[i][0] * b[i][1];
-                    double pb = 0.0;
-                    for (int i = 0; i < 3; ++i) { b[i][1] -= dot_b * b[i][0]; pb += b[i][1] * b[i][1]; }
-                    if (pb <= TOLERANCE) {
-                        pb = 1.0;
-                        int j = 0;
-                        for (int i = 0; i < 3; ++i)
-                            if (pb < fabs(b[i][0])) { pb = fabs(b[i][0]); j = i; }
-                        int k = IP2312[j], l = IP2312[j + 1];
-                        pb = sqrt(b[k][0] * b[k][0] + b[l][0] * b[l][0]);
-                        if (pb > TOLERANCE) { b[j][1] = 0.0; b[k][1] = -b[l][0] / pb; b[l][1] = b[k][0] / pb; }
-                        else b_failed = true;
-                    } else {
-                        pb = 1.0 / sqrt(pb);
-                        for (int i = 0; i < 3; ++i) b[i][1] *= pb;
-                    }
-                    if (!b_failed) {
-                        b[0][2] = b[1][0] * b[2][1] - b[1][1] * b[2][0];
-                        b[1][2] = b[2][0] * b[0][1] - b[2][1] * b[0][0];
-                        b[2][2] = b[0][0] * b[1][1] - b[0][1] * b[1][0];
-                        for (int i = 0; i < 3; ++i)
-                            for (int j = 0; j < 3; ++j) u[i][j] = b[i][0] * a[j][0] + b[i][1] * a[j][1] + b[i][2] * a[j][2];
-                        for (int i = 0; i < 3; ++i) t[i] = yc[i] - (u[i][0] * xc[0] + u[i][1] * xc[1] + u[i][2] * xc[2]);
-                    }
+                const double i0 = n0 > 1.0e-8 ? 1.0 / sqrt(n0) : 0.0, i1 = n1 > 1.0e-8 ? 1.0 / sqrt(n1) : 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { b0[k] *= i0; b1[k] *= i1; }
+                if (sp_orthonormal(b0, b1)) {
+                    b2[0] = b0[1] * b1[2] - b0[2] * b1[1];
+                    b2[1] = b0[2] * b1[0] - b0[0] * b1[2];
+                    b2[2] = b0[0] * b1[1] - b0[1] * b1[0];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) U[r][cc] = b0[r] * a0[cc] + b1[r] * a1[cc] + b2[r] * a2[cc];
+                    solved = true;
                 }
             }
-        } else {
-            for (int i = 0; i < 3; ++i) t[i] = yc[i] - (u[i][0] * xc[0] + u[i][1] * xc[1] + u[i][2] * xc[2]);
         }
-        double sum_sq = 0.0;
-        for (uint64_t i = WAVE ? kb_lane : 0; i < n; i += WAVE ? 64 : 1) {
-            double X = xf[3 * i], Y = xf[3 * i + 1], Z = xf[3 * i + 2];
-            double tr[3] = {u[0][0] * X + u[0][1] * Y + u[0][2] * Z + t[0], u[1][0] * X + u[1][1] * Y + u[1][2] * Z + t[1],
-                            u[2][0] * X + u[2][1] * Y + u[2][2] * Z + t[2]};
-            for (int j = 0; j < 3; ++j) { double diff = tr[j] - (double)yf[3 * i + j]; sum_sq += diff * diff; }
+        // translation: y-centroid minus the rotated x-centroid; for a moving set without spread (all x equal) the rotation stays the
+        // identity; when the frame construction gave up the reference leaves the translation at zero, too
+        if (solved || !spread)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) T[r] = yc[r] - (U[r][0] * xc[0] + U[r][1] * xc[1] + U[r][2] * xc[2]);
+        double ss = 0.0;
+        for (uint64_t i = lane; i < n; i += 64) {
+            const double X = x[3 * i], Y = x[3 * i + 1], Z = x[3 * i + 2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { const double d = U[r][0] * X + U[r][1] * Y + U[r][2] * Z + T[r] - (double)y[3 * i + r]; ss += d * d; }
         }
-        if (WAVE) sum_sq = kb_wave_sum(sum_sq);
-        rf = (float)sqrt(sum_sq / dn);
-        if (rf != rf) rf = 3.40282347e+38f;
+        ss = sp_wave_sum(ss);
+        rms = (float)sqrt(ss / dn);
+        if (rms != rms) rms = 3.40282347e+38f;
     }
-    if (WAVE && kb_lane != 0) return;
-    rmsd_out[pidx] = rf;
-    for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) rot_out[9 * pidx + 3 * i + j] = (float)u[i][j];
-        tran_out[3 * pidx + i] = (float)t[i];
+    if (lane != 0) return;
+    rmsd_out[prob] = rms;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) rot_out[9 * prob + 3 * r + cc] = (float)U[r][cc];
+        tran_out[3 * prob + r] = (float)T[r];
     }
 }
 
+// Similarity metrics of a superposition (metrics.rs:62-251 on KabschSuperimposer's reference / transformed coordinates,
+// kabsch.rs:86-95,145-154): ref = fixed (query) points, mov = moving (target) points, transformed = rot * mov + tran evaluated in f32,
+// every distance in f64 then f32.  out = {tm_score, gdt_ts, gdt_ha, chamfer, hausdorff}.  As the reference has it, tm_score and gdt
+// compare the DISTANCE (not its square) with d0^2 / cutoff^2 (metrics.rs:141-143, 160-163); d0 comes from the host (powf of glibc).
+__device__ __forceinline__ float sp_dist(const float *__restrict__ ref, uint64_t r, float tx, float ty, float tz) {
+    const double dx = (double)ref[3 * r] - (double)tx, dy = (double)ref[3 * r + 1] - (double)ty, dz = (double)ref[3 * r + 2] - (double)tz;
+    return (float)sqrt(dx * dx + dy * dy + dz * dz);
+}
+__global__ __launch_bounds__(64) void k_metrics(const float *__restrict__ refs, const float *__restrict__ movs, const uint64_t *__restrict__ off, uint64_t n_prob,
+                                                const float *__restrict__ rot, const float *__restrict__ tran, const float *__restrict__ d0s,
+                                                float *__restrict__ out) {
+    const uint64_t prob = blockIdx.x;
+    if (prob >= n_prob) return;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t p0 = off[prob], n = off[prob + 1] - p0;
+    float *o = out + 5 * prob;
+    if (n == 0) { if (lane == 0) { o[0] = o[1] = o[2] = 0.0f; o[3] = o[4] = __builtin_inff(); } return; }
+    const float *ref = refs + 3 * p0, *mov = movs + 3 * p0;
+    const float *Rm = rot + 9 * prob, *Tv = tran + 3 * prob;
+    const double d0 = (double)d0s[prob], d0_sq = (double)((float)d0 * (float)d0), dn = (double)n;
+    double tm = 0.0, ch = 0.0;
+    float hd = -1.0f;
+    uint32_t c_ts[4] = {0, 0, 0, 0}, c_ha[4] = {0, 0, 0, 0};
+    for (uint64_t i = lane; i < n; i += 64) {
+        const float mx = mov[3 * i], my = mov[3 * i + 1], mz = mov[3 * i + 2];
+        const float tx = (Rm[0] * mx + Rm[1] * my + Rm[2] * mz) + Tv[0];
+        const float ty = (Rm[3] * mx + Rm[4] * my + Rm[5] * mz) + Tv[1];
+        const float tz = (Rm[6] * mx + Rm[7] * my + Rm[8] * mz) + Tv[2];
+        const double dii = (double)sp_dist(ref, i, tx, ty, tz);
+        tm += 1.0 / (1.0 + dii / d0_sq);
+        const double ts[4] = {1.0, 2.0, 4.0, 8.0}, ha[4] = {0.5, 1.0, 2.0, 4.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c_ts[k] += dii <= ts[k] * ts[k] ? 1u : 0u; c_ha[k] += dii <= ha[k] * ha[k] ? 1u : 0u; }
+        float mn = sp_dist(ref, 0, tx, ty, tz);
+        for (uint64_t j = 1; j < n; ++j) mn = fminf(mn, sp_dist(ref, j, tx, ty, tz));
+        ch += (double)mn;
+        hd = fmaxf(hd, mn);
+    }
+    tm = sp_wave_sum(tm); ch = sp_wave_sum(ch);
+    for (int ofs = 32; ofs > 0; ofs >>= 1) {
+        hd = fmaxf(hd, __shfl_xor(hd, ofs));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c_ts[k] += __shfl_xor(c_ts[k], ofs); c_ha[k] += __shfl_xor(c_ha[k], ofs); }
+    }
+    if (lane != 0) return;
+    o[0] = (float)(tm / dn);
+    double s_ts = 0.0, s_ha = 0.0;
+    for (int k = 0; k < 4; ++k) { s_ts += (double)c_ts[k] / dn; s_ha += (double)c_ha[k] / dn; }
+    o[1] = (float)(s_ts / 4.0);
+    o[2] = (float)(s_ha / 4.0);
+    o[3] = (float)(ch / dn);
+    o[4] = hd;
+}
+
 void fd_launch_kabsch(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, hipStream_t st) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_kabsch<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, x, y, off, n, rmsd, rot, tran);
-    hipLaunchKernelGGL(k_kabsch<true>, dim3((unsigned)n), dim3(64), 0, st, x, y, off, n, rmsd, rot, tran);   // exits at once for small problems
+    if (n) hipLaunchKernelGGL(k_superpose, dim3((unsigned)n), dim3(64), 0, st, x, y, off, n, rmsd, rot, tran);
+}
+void fd_launch_metrics(const float *ref, const float *mov, const uint64_t *off, uint64_t n, const float *rot, const float *tran, const float *d0, float *out,
+                       hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_metrics, dim3((unsigned)n), dim3(64), 0, st, ref, mov, off, n, rot, tran, d0, out);
 }
 
 // ------------------------------------------------------------------------------------------ LMS-QCP partial fit

@@ -15,6 +15,7 @@
 //   node / edge occupancy  atomicOr into [n_nodes + n_edges][ceil(S/32)] bit matrices.
 // The finalize kernel counts set bits per structure with bit-sliced (carry-save) counters, 32
 // structures per lane, so its cost is (nodes+edges)·S/8 bytes of reads — SURVEY §8(d)'s figure.
+#include <algorithm>
 #include "fdgpu_internal.h"
 
 #define IDF_SCALE 1099511627776.0 /* 2^40 */
@@ -28,23 +29,6 @@ __device__ __forceinline__ int64_t find_hash(const uint32_t *__restrict__ hashes
     }
     return (lo < H && hashes[lo] == h) ? (int64_t)lo : -1;
 }
-
-// number of ids in each query hash's posting list (= bytes without the continuation bit)
-__global__ __launch_bounds__(FD_WAVE) void k_posting_lengths(const uint32_t *__restrict__ hashes, const uint64_t *__restrict__ offsets,
-                                                             const uint8_t *__restrict__ value, uint64_t H, const uint32_t *__restrict__ q_hash,
-                                                             uint64_t nq, uint64_t *__restrict__ lengths) {
-    uint64_t q = blockIdx.x;
-    if (q >= nq) return;
-    int64_t k = find_hash(hashes, H, q_hash[q]);
-    uint64_t cnt = 0;
-    if (k >= 0) {
-        uint64_t b0 = offsets[k], b1 = offsets[k + 1];
-        for (uint64_t p = b0 + threadIdx.x; p < b1; p += FD_WAVE) cnt += (value[p] & 0x80u) ? 0u : 1u;
-    }
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, FD_WAVE);
-    if (threadIdx.x == 0) lengths[q] = cnt;
-}
-
 
 // byte length of each query hash's posting list (get_raw_entries(h).len(), indextable.rs:53-81): the varint bytes a scoring pass reads
 __global__ void k_posting_bytes(const uint32_t *__restrict__ hashes, const uint64_t *__restrict__ offsets, uint64_t H, const uint32_t *__restrict__ q_hash,
@@ -134,6 +118,32 @@ __global__ void k_cq_plan(const uint32_t *__restrict__ hashes, const uint64_t *_
     const int64_t k = find_hash(hashes, H, q_hash[q]);
     kidx[q] = k;
     nseg[q] = k < 0 ? 0u : (uint32_t)((offsets[k + 1] - offsets[k] + CQ_SEG - 1) / CQ_SEG);
+}
+
+// number of ids in each query hash's posting list (= bytes without the continuation bit), over the same segments: a list of 100 k
+// ids is ~75 independent 2 KB pieces instead of one wavefront's 2,300 dependent steps; 16 bytes per lane and step
+__global__ __launch_bounds__(FD_WAVE) void k_pl_count(const uint64_t *__restrict__ offsets, const uint8_t *__restrict__ value, const long long *__restrict__ kidx,
+                                                      const uint64_t *__restrict__ wstart, uint64_t nq, unsigned long long *__restrict__ lengths) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t W = wstart[nq];
+    for (uint64_t w = blockIdx.x; w < W; w += gridDim.x) {
+        uint64_t lo = 0, hi = nq;
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (wstart[mid] <= w) lo = mid; else hi = mid; }
+        const uint64_t q = lo;
+        const long long k = kidx[q];
+        const uint64_t b0 = offsets[k], b1 = offsets[k + 1];
+        const uint64_t s0 = b0 + (w - wstart[q]) * CQ_SEG, s1 = s0 + CQ_SEG < b1 ? s0 + CQ_SEG : b1;
+        uint32_t cnt = 0;
+        for (uint64_t p = s0 + (uint64_t)lane * 16; p < s1; p += 64 * 16) {
+            if (p + 16 <= s1) {
+                unsigned long long w0, w1;
+                __builtin_memcpy(&w0, value + p, 8); __builtin_memcpy(&w1, value + p + 8, 8);
+                cnt += 16u - (uint32_t)__popcll(w0 & 0x8080808080808080ull) - (uint32_t)__popcll(w1 & 0x8080808080808080ull);
+            } else for (uint64_t z = p; z < s1; ++z) cnt += (value[z] & 0x80u) ? 0u : 1u;
+        }
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, FD_WAVE);
+        if (lane == 0 && cnt) atomicAdd(&lengths[q], (unsigned long long)cnt);
+    }
 }
 
 template <bool SUMS>
@@ -355,61 +365,84 @@ __device__ __forceinline__ uint32_t idf_order_key(float v) {
     uint32_t b = __float_as_uint(v + 0.0f);   // -0 -> +0
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-__global__ __launch_bounds__(256) void k_cq_topn(const fd_count_rec_dev *__restrict__ recs, const uint64_t *__restrict__ off, uint32_t top_n,
-                                                 uint32_t cap, fd_count_rec_dev *__restrict__ out, uint32_t *__restrict__ out_cnt) {
+// Many workgroups per query: histograms are accumulated in LDS and merged into a global [query][2048] table; the threshold search
+// is one small workgroup per query; the survivors take their slots with one global atomic each (~top_n per query).
+#define TOPN_SPLIT 32   // workgroups per query
+struct topn_state { uint32_t thr_bin, above, thr22, count; };
+__global__ __launch_bounds__(256) void k_topn_hist(const fd_count_rec_dev *__restrict__ recs, const uint64_t *__restrict__ off, uint32_t top_n, int level,
+                                                   const topn_state *__restrict__ st, uint32_t *__restrict__ ghist) {
     __shared__ uint32_t hist[TOPN_BINS];
-    __shared__ uint32_t s_thr, s_above, s_cnt;
-    const uint32_t q = blockIdx.x;
+    const uint32_t q = blockIdx.y;
     const fd_count_rec_dev *r = recs + off[q];
     const uint64_t m = off[q + 1] - off[q];
-    uint32_t thr22 = 0;   // keep everything
-    if (m > top_n) {
-        // level 1: top 11 bits
-        for (int k = threadIdx.x; k < TOPN_BINS; k += 256) hist[k] = 0;
-        __syncthreads();
-        for (uint64_t i = threadIdx.x; i < m; i += 256) atomicAdd(&hist[idf_order_key(r[i].idf) >> 21], 1u);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t acc = 0;
-            int b = TOPN_BINS - 1;
-            for (; b > 0; --b) { if (acc + hist[b] >= top_n) break; acc += hist[b]; }
-            s_thr = (uint32_t)b; s_above = acc;
-        }
-        __syncthreads();
-        const uint32_t b1 = s_thr, above = s_above;
-        // level 2: next 11 bits inside the threshold bin
-        for (int k = threadIdx.x; k < TOPN_BINS; k += 256) hist[k] = 0;
-        __syncthreads();
-        for (uint64_t i = threadIdx.x; i < m; i += 256) {
-            uint32_t key = idf_order_key(r[i].idf);
-            if ((key >> 21) == b1) atomicAdd(&hist[(key >> 10) & (TOPN_BINS - 1)], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t acc = above;
-            int b = TOPN_BINS - 1;
-            for (; b > 0; --b) { if (acc + hist[b] >= top_n) break; acc += hist[b]; }
-            s_thr = (b1 << 11) | (uint32_t)b;
-        }
-        __syncthreads();
-        thr22 = s_thr;
-    }
-    if (threadIdx.x == 0) s_cnt = 0;
+    if (m <= top_n) return;
+    for (int k = threadIdx.x; k < TOPN_BINS; k += 256) hist[k] = 0;
     __syncthreads();
-    for (uint64_t i = threadIdx.x; i < m; i += 256) {
-        fd_count_rec_dev x = r[i];
+    const uint32_t b1 = level ? st[q].thr_bin : 0u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (uint64_t)TOPN_SPLIT * 256) {
+        const uint32_t key = idf_order_key(r[i].idf);
+        if (!level) atomicAdd(&hist[key >> 21], 1u);
+        else if ((key >> 21) == b1) atomicAdd(&hist[(key >> 10) & (TOPN_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < TOPN_BINS; k += 256) if (hist[k]) atomicAdd(&ghist[(uint64_t)q * TOPN_BINS + k], hist[k]);
+}
+// threshold bin: the highest bin b with (records above b) + hist[b] >= top_n; one workgroup per query, suffix sums by 256 threads
+__global__ __launch_bounds__(256) void k_topn_thr(const uint64_t *__restrict__ off, uint32_t top_n, int level, topn_state *__restrict__ st,
+                                                  uint32_t *__restrict__ ghist) {
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t s_bin, s_above;
+    const uint32_t q = blockIdx.x;
+    const uint64_t m = off[q + 1] - off[q];
+    if (m <= top_n) { if (threadIdx.x == 0) { st[q].thr_bin = 0; st[q].above = 0; st[q].thr22 = 0; st[q].count = 0; } return; }
+    uint32_t *h = ghist + (uint64_t)q * TOPN_BINS;
+    // thread t owns bins [8 t, 8 t + 8); suffix sum over threads from the top
+    uint32_t mine = 0;
+    for (int k = 0; k < 8; ++k) mine += h[threadIdx.x * 8 + k];
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = level ? st[q].above : 0u;
+        int t = 255;
+        for (; t > 0; --t) { if (acc + part[t] >= top_n) break; acc += part[t]; }
+        int b = t * 8 + 7;
+        for (; b > t * 8; --b) { if (acc + h[b] >= top_n) break; acc += h[b]; }
+        s_bin = (uint32_t)b; s_above = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!level) { st[q].thr_bin = s_bin; st[q].above = s_above; }
+        else { st[q].thr22 = (st[q].thr_bin << 11) | s_bin; st[q].count = 0; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < TOPN_BINS; k += 256) h[k] = 0;     // ready for the next level / the next call
+}
+__global__ __launch_bounds__(256) void k_topn_emit(const fd_count_rec_dev *__restrict__ recs, const uint64_t *__restrict__ off, uint32_t cap,
+                                                   topn_state *__restrict__ st, fd_count_rec_dev *__restrict__ out) {
+    const uint32_t q = blockIdx.y;
+    const fd_count_rec_dev *r = recs + off[q];
+    const uint64_t m = off[q + 1] - off[q];
+    const uint32_t thr22 = st[q].thr22;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (uint64_t)TOPN_SPLIT * 256) {
+        const fd_count_rec_dev x = r[i];
         if ((idf_order_key(x.idf) >> 10) >= thr22) {
-            uint32_t pos = atomicAdd(&s_cnt, 1u);
+            const uint32_t pos = atomicAdd(&st[q].count, 1u);
             if (pos < cap) out[(uint64_t)q * cap + pos] = x;
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) out_cnt[q] = s_cnt;   // > cap: the caller falls back to the full list of this query
 }
-void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries, uint32_t top_n, uint32_t cap, void *out, uint32_t *out_cnt,
+// state: n_queries topn_state + n_queries * 2048 u32 (zeroed once by the caller; the kernels leave the table zero)
+void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries, uint32_t top_n, uint32_t cap, void *out, void *state, uint32_t *ghist,
                        hipStream_t st) {
-    if (n_queries) hipLaunchKernelGGL(k_cq_topn, dim3(n_queries), dim3(256), 0, st, (const fd_count_rec_dev *)recs, off, top_n, cap,
-                                      (fd_count_rec_dev *)out, out_cnt);
+    if (!n_queries) return;
+    const fd_count_rec_dev *r = (const fd_count_rec_dev *)recs;
+    topn_state *ts = (topn_state *)state;
+    const dim3 g(TOPN_SPLIT, n_queries);
+    hipLaunchKernelGGL(k_topn_hist, g, dim3(256), 0, st, r, off, top_n, 0, ts, ghist);
+    hipLaunchKernelGGL(k_topn_thr, dim3(n_queries), dim3(256), 0, st, off, top_n, 0, ts, ghist);
+    hipLaunchKernelGGL(k_topn_hist, g, dim3(256), 0, st, r, off, top_n, 1, ts, ghist);
+    hipLaunchKernelGGL(k_topn_thr, dim3(n_queries), dim3(256), 0, st, off, top_n, 1, ts, ghist);
+    hipLaunchKernelGGL(k_topn_emit, g, dim3(256), 0, st, r, off, cap, ts, (fd_count_rec_dev *)out);
 }
 
 void fd_launch_cq_batch(const cq_args &A, const uint32_t *q_query, uint32_t n_queries, const uint32_t *row_off, uint32_t *node_cnt, uint32_t *edge_cnt,
@@ -424,9 +457,15 @@ void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, cons
                                   pos, penalty, A.S, total, A.first_id, (fd_count_rec_dev *)out);
 }
 
+// kidx / nseg / wstart / scan_tmp / total: plan workspaces for nq hashes (k_cq_plan + exclusive scan)
 void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,
-                               uint64_t nq, uint64_t *lengths, hipStream_t st) {
-    if (nq) hipLaunchKernelGGL(k_posting_lengths, dim3((unsigned)nq), dim3(FD_WAVE), 0, st, hashes, offsets, value, H, q_hash, nq, lengths);
+                               uint64_t nq, uint64_t *lengths, long long *kidx, uint32_t *nseg, uint64_t *wstart, uint64_t *scan_tmp, uint64_t *total,
+                               hipStream_t st) {
+    if (!nq) return;
+    (void)hipMemsetAsync(lengths, 0, nq * 8, st);
+    hipLaunchKernelGGL(k_cq_plan, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, hashes, offsets, H, q_hash, nq, kidx, nseg);
+    fd_exclusive_scan<uint32_t>(nseg, nq, wstart, scan_tmp, total, st);
+    hipLaunchKernelGGL(k_pl_count, dim3(8192), dim3(FD_WAVE), 0, st, offsets, value, kidx, wstart, nq, (unsigned long long *)lengths);
 }
 void fd_launch_cq_finalize(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_bits, uint32_t n_nodes,
                            const uint32_t *edge_bits, uint32_t n_edges, uint32_t words, uint32_t S, uint32_t *node_cnt, uint32_t *edge_cnt,

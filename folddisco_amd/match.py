@@ -51,6 +51,21 @@ def kabsch_batch(ctx: Context, x: np.ndarray, y: np.ndarray, off: np.ndarray):
     return rmsd, rot, tran
 
 
+def metrics_batch(ctx: Context, ref: np.ndarray, mov: np.ndarray, off: np.ndarray, rot: np.ndarray, tran: np.ndarray) -> np.ndarray:
+    """similarity metrics of n superpositions on the device (fdgpu_metrics_batch): problem k compares the fixed points
+    ref[off[k]:off[k+1]] with rot[k] @ mov[...] + tran[k]. -> [n, 5] = tm_score, gdt_ts, gdt_ha, chamfer, hausdorff"""
+    ref = np.ascontiguousarray(ref, dtype=np.float32).reshape(-1, 3)
+    mov = np.ascontiguousarray(mov, dtype=np.float32).reshape(-1, 3)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    rot = np.ascontiguousarray(rot, dtype=np.float32).reshape(-1, 9)
+    tran = np.ascontiguousarray(tran, dtype=np.float32).reshape(-1, 3)
+    n = len(off) - 1
+    out = np.zeros((n, 5), np.float32)
+    ctx.check(ctx.L.fdgpu_metrics_batch(ctx.h, ref.ctypes.data_as(f32p), mov.ctypes.data_as(f32p), off.ctypes.data_as(u64p), n,
+                                        rot.ctypes.data_as(f32p), tran.ctypes.data_as(f32p), out.ctypes.data_as(f32p)))
+    return out
+
+
 def lms_qcp_batch(ctx: Context, x: np.ndarray, y: np.ndarray, off: np.ndarray):
     """--partial-fit superposition (src/structure/lms_qcp.rs, default parameters) of x[off[k]:off[k+1]] onto y[...], >= 3 pairs each.
     -> rms over the core[n], rot[n,3,3], tran[n,3], list of core index arrays (joining order)"""

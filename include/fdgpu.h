@@ -215,6 +215,12 @@ int fdgpu_match_pairs(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *resn
  * points are xyz f32.  rmsd[k] f32, rot[9k..], tran[3k..]. */
 int fdgpu_kabsch_batch(fdgpu_ctx *ctx, const float *x, const float *y, const uint64_t *off, uint64_t n_problems,
                        float *rmsd, float *rot, float *tran);
+/* Similarity metrics of n superpositions on the device (src/structure/metrics.rs:62-251 applied to KabschSuperimposer's reference /
+ * transformed coordinates, kabsch.rs:86-95,145-154): problem k compares the fixed points ref[off[k] .. off[k+1]) with
+ * rot[9k ..] * mov[...] + tran[3k ..] (f32, as matrix_vector_multiply + add_vec do).  metrics[5k ..] = tm_score, gdt_ts, gdt_ha,
+ * chamfer_distance, hausdorff_distance — what --tm-score / --gdt-ts / --gdt-ha / --chamfer / --hausdorff filter and sort on. */
+int fdgpu_metrics_batch(fdgpu_ctx *ctx, const float *ref, const float *mov, const uint64_t *off, uint64_t n_problems, const float *rot,
+                        const float *tran, float *metrics);
 /* Batched partial fit = LmsQcpSuperimposer::new() + set_atoms(fixed = y, moving = x) + run() with the default parameters
  * (src/structure/lms_qcp.rs:29-41, 91-249; what --partial-fit selects for matches of more than 3 residues,
  * src/controller/retrieve.rs:733-746): rmsd[k] = rms over the final core, rot/tran map x onto y.  Every problem needs

@@ -678,3 +678,47 @@ def test_context_is_safe_under_concurrent_callers(ctx):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.gpu
+def test_superposition_degenerate_inputs_and_device_metrics(ctx):
+    """k_superpose on the inputs where Kabsch's eigen construction degenerates — one point, two points, collinear points, every moving
+    point equal, identical sets, a mirror image (negative determinant), coplanar points — gives the restatement's rmsd / rotation /
+    translation (the reference reports the identity and a zero translation where the frame cannot be built); and k_metrics
+    (TM-score, GDT-TS, GDT-HA, Chamfer, Hausdorff on the device) equals the restatement for 1 ... 700 points."""
+    from folddisco_amd import match
+    rng = np.random.default_rng(11)
+    base = (rng.normal(size=(9, 3)) * 5).astype(np.float32)
+    line = np.outer(np.arange(6, dtype=np.float32), np.array([1.0, 2.0, -0.5], np.float32)).astype(np.float32)
+    plane = np.concatenate([rng.normal(size=(7, 2)) * 4, np.zeros((7, 1))], axis=1).astype(np.float32)
+    probs = [
+        (base[:1] + 1.0, base[:1]),                                          # one point
+        (base[:2] * 1.1, base[:2]),                                          # two points
+        (line + 0.5, line[::-1].copy()),                                     # collinear
+        (np.repeat(base[:1], 5, axis=0), base[:5]),                          # every moving point equal
+        (base.copy(), base.copy()),                                          # identical
+        (base * np.array([1, 1, -1], np.float32), base),                     # mirror image
+        (plane @ np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], np.float32), plane),   # coplanar
+        (np.zeros((4, 3), np.float32), np.zeros((4, 3), np.float32)),        # all zero
+        ((base + rng.normal(size=base.shape) * 0.3).astype(np.float32), base),
+    ]
+    xs = np.concatenate([p[0] for p in probs]); ys = np.concatenate([p[1] for p in probs])
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in probs])]).astype(np.uint64)
+    rmsd, rot, tran = match.kabsch_batch(ctx, xs, ys, off)
+    for k, (x, y) in enumerate(probs):
+        r, R, T = oracle.kabsch(x, y)
+        assert (abs(rmsd[k] - r) <= 1e-4 * max(1.0, abs(r))) or (rmsd[k] == r), (k, rmsd[k], r)
+        assert np.allclose(rot[k], R, atol=1e-4) and np.allclose(tran[k], T, atol=1e-3), (k, rot[k], R, tran[k], T)
+    # metrics: sizes around the d0 switch (21 / 22 points) and beyond one wavefront
+    mp = []
+    for n in (1, 2, 6, 21, 22, 64, 65, 300, 700):
+        y = (rng.normal(size=(n, 3)) * 9).astype(np.float32)
+        x = (y + rng.normal(size=(n, 3)) * rng.choice([0.2, 1.5, 6.0])).astype(np.float32)
+        mp.append((x, y))
+    xs = np.concatenate([p[0] for p in mp]); ys = np.concatenate([p[1] for p in mp])
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in mp])]).astype(np.uint64)
+    rmsd, rot, tran = match.kabsch_batch(ctx, xs, ys, off)
+    got = match.metrics_batch(ctx, ys, xs, off, rot, tran)
+    for k, (x, y) in enumerate(mp):
+        want = oracle.metrics(y, x, rot[k].reshape(9), tran[k])
+        assert np.allclose(got[k], want, rtol=1e-6, atol=1e-6), (k, len(x), got[k], want)
