@@ -305,11 +305,20 @@ def main(argv=None):
     pa.add_argument("--max-pos", type=int, default=32)
     pa.add_argument("-t", "--threads", type=int, default=1)
     pa.add_argument("-v", "--verbose", action="store_true")
+    pa.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
     if a.cmd == "analyze":
         from folddisco_amd import analyze
-        if a.pdbs is not None:
-            sys.exit("[FAIL] analyze -p (enrichment against a structure set) is not implemented; only the index summary is")
+        if a.pdbs is not None:                                       # enrichment branch (analyze.rs:111-132)
+            import folddisco_amd as fd
+            paths = _load_paths(a.pdbs, False)
+            if not paths:
+                sys.exit(f"[FAIL] no structures under {a.pdbs}")
+            out = a.output or f"{a.pdbs}_vs_{a.index.split('/')[-1]}"    # analyze.rs:74-79
+            ctx = fd.Context(getattr(a, "device", 0))
+            en = analyze.enrichment(ctx, a.index, paths, a.p_value, a.threads)
+            analyze.save_enrichment(en, paths, out, a.min_support, a.max_pos)
+            return
         out = a.output or f"{a.index}_summary"                       # analyze.rs:71-84
         analyze.save_summary(analyze.summarize(a.index), out, a.top)
         return

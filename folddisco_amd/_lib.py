@@ -163,6 +163,8 @@ SYMBOLS = [
     ("fdgpu_index_set_first_id", C.c_int, [VP, C.c_uint64]),
     ("fdgpu_host_libm_matches", C.c_int, [VP]),
     ("fdgpu_metrics_batch", C.c_int, [VP, f32p, f32p, u64p, C.c_uint64, f32p, f32p, f32p]),
+    ("fdgpu_hash_batch_rows", C.c_int, [VP, VP, C.POINTER(HashParams), C.POINTER(u32p), C.POINTER(u32p), C.POINTER(u64p)]),
+    ("fdgpu_hypergeom_enrichment", C.c_int, [u64p, u64p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     ("fdgpu_debug_libm", C.c_int, [VP, C.c_int, f32p, f32p, f32p, C.c_uint64]),
 ]
 

@@ -4,7 +4,15 @@ Restates src/cli/workflows/analyze.rs:42-152 (summary branch) over src/controlle
 HashType::{dist_bins, angle_bins, total_bins} (src/controller/feature.rs:293-345): host-side bookkeeping over the sparse
 offset table (hashes[H], offsets[H+1]) — the "count" of an encoding is its posting list's BYTE length
 (summary.rs:495-496), not the number of structures.  Writes PREFIX_summary_{stats.tsv, topN.tsv, aa_pairs.csv,
-count_distribution.tsv}.  The enrichment branch (-p, summary.rs:262-480) is not built.
+count_distribution.tsv}.
+
+`folddisco analyze -i PREFIX -p DIR` — the enrichment branch (analyze_enrichment, summary.rs:262-480): the encodings of a structure
+set tested against the index as background (right-tail hypergeometric test, fdgpu_hypergeom_enrichment), the enriched encodings
+with the residue pairs that carry them, the positions supported by more than --min-support enriched encodings and a query string
+per structure.  The GPU does the per-structure hashing (fdgpu_hash_batch: collect_hash_vec) and the (hash, i, j) stream of every
+residue pair (fdgpu_hash_batch_rows: collect_hash_id_pos); the rest is bookkeeping.  Where the reference's output order is that
+of a concurrent hash map (rows with equal sort keys in *_enriched_positions.tsv, the order of positions inside a row of
+*_enriched_hashes.tsv under several threads) the order here is the single-thread one: structure order, then pair order.
 """
 from __future__ import annotations
 
@@ -179,3 +187,106 @@ def save_summary(st: dict, output_prefix: str, top_n: int = 10):
         if len(st["counts"]):
             for bd, c in count_distribution(st["counts"]):
                 f.write(f"{bd}\t{c}\n")
+
+
+def enrichment(ctx, index_prefix: str, paths, p_value: float = 1e-4, threads: int = 1):
+    """analyze_enrichment up to the three tables (summary.rs:262-345).  -> dict(enriched=[(hash, p)], positions={hash: [(pdb_pos, pos1,
+    pos2)]}, hash_type, nbin_dist, nbin_angle)"""
+    import ctypes as C
+    from . import structure
+    from ._lib import HashParams, u32p, u64p
+    from .api import PackedStructures, get_geometric_hash_as_u32
+    cfg = indexio.load_type(index_prefix + ".type")
+    htype = hash_type_index(cfg.get("hash_type", "PDBTrRosetta"))
+    nbd, nba = int(cfg.get("num_bin_dist", 0)), int(cfg.get("num_bin_angle", 0))
+    _, bg_hashes, offsets = indexio.read_index_files(index_prefix)
+    bg_counts = np.diff(offsets.astype(np.int64)).astype(np.uint64)          # get_hash_count_vec: BYTE lengths (summary.rs:495-496)
+    structs, ok = structure.read_compact_structures(list(paths), threads=threads)
+    batch = ctx.upload(PackedStructures.concat([s.as_item() for s in structs]))
+    # collect_hash_vec: sorted-unique hashes per structure -> number of structures that hold each encoding
+    h, off = get_geometric_hash_as_u32(ctx, batch, nbin_dist=nbd, nbin_angle=nba, hash_type=htype)
+    q_hashes, q_counts = np.unique(h, return_counts=True)
+    total_query, total_bg = int(q_counts.sum()), int(bg_counts.sum())
+    k = np.searchsorted(bg_hashes, q_hashes)
+    kk = np.minimum(k, max(len(bg_hashes) - 1, 0))
+    bg = np.where((k < len(bg_hashes)) & (bg_hashes[kk] == q_hashes), bg_counts[kk], 0).astype(np.uint64) if len(bg_hashes) else np.zeros(len(q_hashes), np.uint64)
+    pv = np.zeros(len(q_hashes), np.float64)
+    qc = np.ascontiguousarray(q_counts, np.uint64)
+    bg = np.ascontiguousarray(bg, np.uint64)
+    rc = ctx.L.fdgpu_hypergeom_enrichment(qc.ctypes.data_as(u64p), bg.ctypes.data_as(u64p), len(qc), total_query, total_bg, max(threads, 1),
+                                          pv.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc:
+        raise RuntimeError(f"fdgpu_hypergeom_enrichment failed ({rc})")
+    sel = np.nonzero(pv < p_value)[0]
+    sel = sel[np.argsort(pv[sel], kind="stable")]                            # par_sort_by p-value ascending (stable: ties stay in hash order)
+    enriched = [(int(q_hashes[i]), float(pv[i])) for i in sel]
+    # collect_hash_id_pos: (hash, i, j) of every residue pair with a feature; kept for the enriched encodings only
+    p = HashParams(nbd, nba, 20.0, htype, None)
+    hp, pj, ro = u32p(), u32p(), u64p()
+    ctx.check(ctx.L.fdgpu_hash_batch_rows(ctx.h, batch.h, C.byref(p), C.byref(hp), C.byref(pj), C.byref(ro)))
+    R = sum(s.n for s in structs)
+    row_off = np.ctypeslib.as_array(ro, shape=(R + 1,)).copy()
+    P = int(row_off[-1])
+    raw = np.ctypeslib.as_array(hp, shape=(max(P, 1),))[:P].copy()
+    part = np.ctypeslib.as_array(pj, shape=(max(P, 1),))[:P].copy()
+    for ptr in (hp, pj, ro):
+        ctx.L.fdgpu_free(ptr)
+    res_struct = np.repeat(np.arange(len(structs)), [s.n for s in structs])
+    labels = np.array([f"{chr(int(c))}{int(r)}" for s in structs for c, r in zip(s.chain, s.serial)], dtype=object)
+    keep = np.nonzero(np.isin(raw, q_hashes[sel]))[0] if len(sel) else np.zeros(0, np.int64)
+    res_i = np.searchsorted(row_off, keep, side="right") - 1                # the row (residue i) an entry belongs to
+    positions = {}
+    for e, i in zip(keep, res_i):
+        positions.setdefault(int(raw[e]), []).append((int(res_struct[i]), labels[i], labels[int(part[e])]))
+    return dict(enriched=enriched, positions=positions, hash_type=htype, nbin_dist=_BINS[htype][0] if nbd == 0 else nbd,
+                nbin_angle=_BINS[htype][1] if nba == 0 else nba)
+
+
+def save_enrichment(en: dict, paths, output_prefix: str, min_support: int = 4, max_pos: int = 32):
+    """the three tables of analyze_enrichment (summary.rs:347-478)"""
+    paths = list(paths)
+    pos_hash, pdb_positions = {}, {}
+    with open(f"{output_prefix}_enriched_hashes.tsv", "w") as f:
+        f.write("hash\tp_value\tfeatures\tpositions\n")
+        for h, pv in en["enriched"]:
+            v = reverse_hash(en["hash_type"], [h], en["nbin_dist"], en["nbin_angle"])[0]
+            feat = "%s,%s,%.4f,%.4f,%.4f,%.4f,%.4f" % (_aa(int(v[0]) & 255), _aa(int(v[1]) & 255), v[2], v[3], v[4], v[5], v[6])
+            plist = []
+            for pdb_pos, p1, p2 in en["positions"].get(h, []):
+                plist.append(f"{paths[pdb_pos]}-{p1}-{p2}")
+                pos_hash.setdefault((pdb_pos, p1), []).append(h)
+                pos_hash.setdefault((pdb_pos, p2), []).append(h)
+                pdb_positions.setdefault(pdb_pos, []).extend([p1, p2])
+            f.write("%d\t%s\t%s\t%s\n" % (h, _rust_exp4(pv), feat, ",".join(plist)))
+    pos_list = sorted(pos_hash.items(), key=lambda kv: (kv[0][0], -len(kv[1])))     # stable: pdb id, then count descending
+    with open(f"{output_prefix}_enriched_positions.tsv", "w") as f:
+        f.write("id\tpos\tcount\thash_list\n")
+        for (pdb_pos, pos), hl in pos_list:
+            if len(hl) <= min_support:
+                continue
+            f.write("%s\t%s\t%d\t%s\n" % (paths[pdb_pos], pos, len(hl), ",".join(str(x) for x in hl)))
+    with open(f"{output_prefix}_query_summary.tsv", "w") as f:
+        f.write("pdb_path\tpositions\n")
+        for pdb_pos in sorted(pdb_positions):
+            uniq = sorted(set(pdb_positions[pdb_pos]))
+            withc = [(pos, len(pos_hash[(pdb_pos, pos)])) for pos in uniq if len(pos_hash.get((pdb_pos, pos), [])) > min_support]
+            withc.sort(key=lambda t: -t[1])                                 # stable, count descending
+            withc = withc[:max_pos]
+
+            def key(pos):
+                try:
+                    idx = int(pos[1:])
+                except ValueError:
+                    idx = 0
+                return (pos[:1] or " ", idx)
+            final = sorted((pos for pos, _ in withc), key=key)
+            if final:
+                f.write("%s\t%s\n" % (paths[pdb_pos], ",".join(final)))
+
+
+def _rust_exp4(x: float) -> str:
+    """Rust `{:.4e}`: mantissa with four decimals, exponent without padding or plus sign (1.2346e-7, 0.0000e0)"""
+    if x == 0.0:
+        return "0.0000e0"
+    m, e = ("%.4e" % x).split("e")
+    return f"{m}e{int(e)}"

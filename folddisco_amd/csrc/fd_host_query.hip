@@ -962,3 +962,50 @@ extern "C" int fdgpu_merge_subindices(uint64_t n_parts, const uint8_t *const *va
     *out_value = V; *out_value_len = nv; *out_hashes = H; *out_offsets = O; *out_n_hashes = nh;
     return FDGPU_OK;
 }
+
+
+// ---- analyze: hypergeometric enrichment of encodings (src/controller/summary.rs:543-628) --------------------------------------------
+// p[k] = P(X >= x) for X ~ Hypergeometric(N = total_bg + total_query, K = bg[k] + query[k], n = total_query), x = query[k]: the sum of
+// the log-space pmf from x to min(n, K) with the reference's log-factorial (exact sum of ln below 20, Stirling's formula above,
+// summary.rs:616-628), clamped to 1.  The terms fall monotonically behind the mode, so the walk stops once a term no longer changes
+// the f64 sum — the value is the one the full loop gives.  Host threads over the encodings.
+namespace {
+inline double fd_log_factorial(uint64_t n) {
+    if (n <= 1) return 0.0;
+    if (n < 20) { double s = 0.0; for (uint64_t i = 2; i <= n; ++i) s += log((double)i); return s; }
+    const double x = (double)n;
+    return x * log(x) - x + 0.5 * log(2.0 * 3.14159265358979323846 * x);
+}
+inline double fd_log_binomial(uint64_t n, uint64_t k) {
+    if (k > n) return -INFINITY;
+    if (k == 0 || k == n) return 0.0;
+    return fd_log_factorial(n) - fd_log_factorial(k) - fd_log_factorial(n - k);
+}
+}
+extern "C" int fdgpu_hypergeom_enrichment(const uint64_t *query_count, const uint64_t *bg_count, uint64_t n_enc, uint64_t total_query, uint64_t total_bg,
+                                          uint32_t n_threads, double *p_value) {
+    if (n_enc && (!query_count || !bg_count || !p_value)) return FDGPU_EINVAL;
+    const uint64_t n = total_query, N = total_bg + total_query;
+    const double log_den = fd_log_binomial(N, n);
+    auto work = [&](uint64_t a, uint64_t b) {
+        for (uint64_t e = a; e < b; ++e) {
+            const uint64_t x = query_count[e], K = bg_count[e] + query_count[e], max_x = n < K ? n : K;
+            const double mode = (double)(n + 1) * (double)(K + 1) / (double)(N + 2);
+            double p = 0.0;
+            for (uint64_t i = x; i <= max_x; ++i) {
+                const double t = exp(fd_log_binomial(K, i) + fd_log_binomial(N - K, n - i) - log_den);
+                const double q = p + t;
+                if (q == p && (double)i > mode) break;
+                p = q;
+            }
+            p_value[e] = p < 1.0 ? p : 1.0;
+        }
+    };
+    const uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(n_threads ? n_threads : 1, 256));
+    if (T == 1 || n_enc < 64) { work(0, n_enc); return FDGPU_OK; }
+    std::vector<std::thread> th;
+    const uint64_t per = (n_enc + T - 1) / T;
+    for (uint32_t t = 0; t < T; ++t) { const uint64_t a = (uint64_t)t * per, b = std::min<uint64_t>(n_enc, a + per); if (a < b) th.emplace_back(work, a, b); }
+    for (auto &x : th) x.join();
+    return FDGPU_OK;
+}

@@ -483,6 +483,46 @@ extern "C" int fdgpu_hash_batch(fdgpu_ctx *c, const fdgpu_batch *b, const fd_has
     return FDGPU_OK;
 }
 
+// Raw hash list with positions: every ordered residue pair that has a feature, in the reference's row-major order, as
+// (hash, partner residue j); entries [row_off[i], row_off[i + 1]) belong to residue i (batch residue indices).  This is the inner loop of
+// collect_hash_id_pos (src/controller/summary.rs:632-690: get_single_feature + perfect_hash for every (i, j)) for a whole batch.
+extern "C" int fdgpu_hash_batch_rows(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_params *p, uint32_t **hashes, uint32_t **partner, uint64_t **row_off) { FD_LOCK(c);
+    if (!c || !b || !p || !hashes || !partner || !row_off) return FDGPU_EINVAL;
+    *hashes = nullptr; *partner = nullptr; *row_off = nullptr;
+    if (p->n_multiple_bins) FAIL(c, FDGPU_EINVAL, "hash_batch_rows: multiple_bins is honoured by the index build and the query calls only");
+    if (!fd_hash_type_supported(p->hash_type)) FAIL(c, FDGPU_EINVAL, "hash_type: unknown encoding");
+    reset_timings(c);
+    const fd_hash_consts C = make_consts(p);
+    const uint64_t R = b->n_res;
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->ws[WS_MISC0].ensure((R + 1) * 4));
+    HIPCHK(c, c->ws[WS_MISC1].ensure((R + 2) * 8));
+    HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(std::max<uint64_t>(b->n_struct, R)) * 8 + 64));
+    HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_MISC0].p, 0, (R + 1) * 4, st));
+    fd_launch_row_count(b->view(), C, c->ws[WS_MISC0].as<uint32_t>(), p->dist_cutoff, st);
+    fd_exclusive_scan<uint32_t>(c->ws[WS_MISC0].as<uint32_t>(), R, c->ws[WS_MISC1].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
+                                c->ws[WS_TOTAL].as<uint64_t>(), st);
+    HIPCHK(c, hipGetLastError());
+    uint64_t P = 0;
+    int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &P);
+    if (rc) return rc;
+    HIPCHK(c, c->ws[WS_KEYS_A].ensure(std::max<uint64_t>(P, 1) * 4));
+    HIPCHK(c, c->ws[WS_IDS_A].ensure(std::max<uint64_t>(P, 1) * 4));
+    fd_launch_row_emit(b->view(), C, c->ws[WS_MISC1].as<uint64_t>(), c->ws[WS_KEYS_A].as<uint32_t>(), p->dist_cutoff, c->ws[WS_IDS_A].as<uint32_t>(), 0u, st, 1);
+    HIPCHK(c, hipGetLastError());
+    uint32_t *h = (uint32_t *)malloc(std::max<uint64_t>(P, 1) * 4), *pj = (uint32_t *)malloc(std::max<uint64_t>(P, 1) * 4);
+    uint64_t *ro = (uint64_t *)malloc((R + 1) * 8);
+    if (!h || !pj || !ro) { free(h); free(pj); free(ro); return FDGPU_ENOMEM; }
+    hipError_t e = hipMemcpyAsync(h, c->ws[WS_KEYS_A].p, P * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(pj, c->ws[WS_IDS_A].p, P * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ro, c->ws[WS_MISC1].p, (R + 1) * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { free(h); free(pj); free(ro); c->err = std::string("hash_batch_rows: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+    *hashes = h; *partner = pj; *row_off = ro;
+    return FDGPU_OK;
+}
+
 // ---- S2 ---------------------------------------------------------------------------------------------------------------
 extern "C" void fdgpu_index_destroy(fdgpu_index *ix) {
     if (!ix) return;

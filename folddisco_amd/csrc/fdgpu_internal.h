@@ -153,7 +153,7 @@ int fd_radix_sort_pairs16(uint32_t *keys_a, uint16_t *vals_a, uint32_t *keys_b, 
                           uint64_t *tot, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr);
 void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, float cutoff, hipStream_t st);
 void fd_launch_row_emit(const fd_batch_view &B, const fd_hash_consts &C, const uint64_t *row_off, uint32_t *keys, float cutoff, uint32_t *ids,
-                        uint32_t first_id, hipStream_t st);
+                        uint32_t first_id, hipStream_t st, int ids_partner = 0);
 template <typename TIn>
 void fd_exclusive_scan(const TIn *in, uint64_t n, uint64_t *out, uint64_t *chunk_tmp, uint64_t *total_dev, hipStream_t st);
 uint64_t fd_scan_tmp_elems(uint64_t n);

@@ -331,8 +331,10 @@ __global__ __launch_bounds__(FD_WAVE) void k_row_count(fd_batch_view B, fd_hash_
     row_cnt[i] = cnt;
 }
 
+// ids (optional): the structure id first_id + s of every entry, or with ids_partner its partner residue j (batch residue index) — the
+// row start row_off[i] gives i, so (hash, i, j) is what collect_hash_id_pos walks (controller/summary.rs:632-690)
 __global__ __launch_bounds__(FD_WAVE) void k_row_emit(fd_batch_view B, fd_hash_consts C, const uint64_t *__restrict__ row_off,
-                                                      uint32_t *__restrict__ keys, float cutoff, uint32_t *__restrict__ ids, uint32_t first_id) {
+                                                      uint32_t *__restrict__ keys, float cutoff, uint32_t *__restrict__ ids, uint32_t first_id, int ids_partner) {
     uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
     if (w >= B.n_work) return;
     const uint32_t s = B.wi_struct[w];
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_row_emit(fd_batch_view B, fd_hash_c
         float f[FD_NFEAT];
         for (uint32_t j = r0; j < r1; ++j) {
             if (j == i || B.aa[j] == 255 || !fd_feature_other(C.q.type, B, r0, r1, i, j, cutoff, f)) continue;
-            if (ids) ids[pos] = first_id + s;
+            if (ids) ids[pos] = ids_partner ? j : first_id + s;
             keys[pos++] = fd_hash_other(C.q.type, f, C.q);
         }
         return;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_row_emit(fd_batch_view B, fd_hash_c
         if (fd_dist2(ca1, ca2) > C.d2_max) continue;
         fd_v3 n2 = fd_load3(B.n_xyz, j), cb2 = fd_load3(B.cb_xyz, j);
         fd_feature f = fd_pair_feature(n1, ca1, cb1, n2, ca2, cb2);
-        if (ids) ids[pos] = first_id + s;
+        if (ids) ids[pos] = ids_partner ? j : first_id + s;
         keys[pos++] = fd_hash_enc(aa1, B.aa[j], f, C.q);
     }
 }
@@ -447,8 +449,8 @@ void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32
     hipLaunchKernelGGL(k_row_count, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, row_cnt, cutoff);
 }
 void fd_launch_row_emit(const fd_batch_view &B, const fd_hash_consts &C, const uint64_t *row_off, uint32_t *keys, float cutoff, uint32_t *ids,
-                        uint32_t first_id, hipStream_t st) {
+                        uint32_t first_id, hipStream_t st, int ids_partner) {
     if (!B.n_work) return;
-    hipLaunchKernelGGL(k_row_emit, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, row_off, keys, cutoff, ids, first_id);
+    hipLaunchKernelGGL(k_row_emit, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, row_off, keys, cutoff, ids, first_id, ids_partner);
 }
 }

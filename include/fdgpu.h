@@ -115,6 +115,11 @@ uint64_t fdgpu_batch_num_residues(const fdgpu_batch *b);
 int fdgpu_hash_batch(fdgpu_ctx *ctx, const fdgpu_batch *b, const fd_hash_params *p, int sort_dedup,
                      uint32_t **hashes, uint64_t **hash_off);
 
+/* The raw list WITH positions: entries [row_off[i], row_off[i + 1]) belong to residue i of the batch (row-major pair order), entry k
+ * pairs it with residue partner[k] and hashes[k] is the pair's hash — the (hash, i, j) stream collect_hash_id_pos walks for
+ * `analyze -p` (src/controller/summary.rs:632-690).  row_off has n_residues + 1 entries.  Release the three arrays with fdgpu_free. */
+int fdgpu_hash_batch_rows(fdgpu_ctx *ctx, const fdgpu_batch *b, const fd_hash_params *p, uint32_t **hashes, uint32_t **partner, uint64_t **row_off);
+
 /* ---- S2: inverted index build ----------------------------------------------------------------
  * Replaces Folddisco::collect_and_count + allocate_entries + add_entries +
  * wrapup_offset_and_save_entries + prune_to_sparse (src/controller/mod.rs:274-441,
@@ -328,6 +333,12 @@ int fdgpu_merge_subindices(uint64_t n_parts, const uint8_t *const *values, const
  * re-based to a delta — into ONE resident index, byte-identical to the index a single build over all the structures produces
  * (indextable.rs:171-202 appends ids in ascending order).  At most 64 parts per call; the parts stay valid. */
 int fdgpu_index_merge(fdgpu_ctx *ctx, const fdgpu_index *const *parts, uint64_t n_parts, fdgpu_index **out);
+
+/* `analyze -p`: right-tail hypergeometric test of every encoding (src/controller/summary.rs:543-628, get_enriched_hashes /
+ * hypergeometric_test with the reference's log-factorial): p_value[k] = P(X >= query_count[k]) for a sample of total_query draws from a
+ * population of total_bg + total_query holding bg_count[k] + query_count[k] successes.  Host threads; no device needed. */
+int fdgpu_hypergeom_enrichment(const uint64_t *query_count, const uint64_t *bg_count, uint64_t n_encodings, uint64_t total_query, uint64_t total_bg,
+                               uint32_t n_threads, double *p_value);
 
 /* Pairs that the speculative torsion evaluation of the index build (fd_geom.h, fd_pair_both_spec) re-evaluated with the
  * exact routine since the previous call; FDGPU_EXACT=1 in the environment disables the speculative path altogether. */
