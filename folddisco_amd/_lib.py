@@ -165,6 +165,14 @@ SYMBOLS = [
     ("fdgpu_metrics_batch", C.c_int, [VP, f32p, f32p, u64p, C.c_uint64, f32p, f32p, f32p]),
     ("fdgpu_hash_batch_rows", C.c_int, [VP, VP, C.POINTER(HashParams), C.POINTER(u32p), C.POINTER(u32p), C.POINTER(u64p)]),
     ("fdgpu_hypergeom_enrichment", C.c_int, [u64p, u64p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
+    ("fdgpu_comm_unique_id", C.c_int, [u8p]),
+    ("fdgpu_comm_init", C.c_int, [VP, u8p, C.c_int, C.c_int, C.POINTER(VP)]),
+    ("fdgpu_comm_destroy", None, [VP]),
+    ("fdgpu_comm_rank", C.c_int, [VP]),
+    ("fdgpu_comm_world", C.c_int, [VP]),
+    ("fdgpu_allreduce_lengths", C.c_int, [VP, VP, u64p, C.c_uint64]),
+    ("fdgpu_sharded_count_query", C.c_int, [VP, VP, VP, C.c_uint64, u64p, u32p, u32p, u32p, f32p, C.c_uint64, C.c_uint32,
+                                            C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
     ("fdgpu_debug_libm", C.c_int, [VP, C.c_int, f32p, f32p, f32p, C.c_uint64]),
 ]
 

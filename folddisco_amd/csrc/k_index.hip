@@ -20,7 +20,7 @@ __device__ __forceinline__ uint32_t varint_len(uint32_t v) {
     return v == 0 ? 1u : 1u + (31u - (uint32_t)__clz(v)) / 7u;
 }
 
-struct enc_item { uint32_t len; uint32_t head; uint32_t delta; uint32_t hash; uint32_t prev; };   // prev: id of the preceding element (valid at a head that is not the first element)
+struct enc_item { uint32_t len; uint32_t head; uint32_t delta; uint32_t hash; };
 
 // two element encodings of the sorted stream:
 //   V = uint32_t : keys[p] = hash,                     vals[p] = structure id
@@ -46,7 +46,6 @@ __device__ __forceinline__ enc_item enc_classify(const uint32_t *__restrict__ ke
     bool dup = !head && pid == id;
     it.head = head ? 1u : 0u;
     it.delta = head ? id : id - pid;
-    it.prev = pid;
     it.len = dup ? 0u : varint_len(it.delta);
     return it;
 }
@@ -56,7 +55,7 @@ __device__ __forceinline__ enc_item enc_classify(const uint32_t *__restrict__ ke
 // or, for lane 0 of a wave, from memory.
 template <typename V>
 __device__ __forceinline__ void enc_load_classify(const uint32_t *__restrict__ keys, const V *__restrict__ ids, uint64_t n, uint64_t base,
-                                                  uint32_t first_id, enc_item *it) {
+                                                  uint32_t first_id, enc_item *it, uint32_t *pred_id = nullptr) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     uint32_t k[ENC_ITEMS], v[ENC_ITEMS];
     const bool full = base + ENC_ITEMS <= n;
@@ -85,6 +84,7 @@ __device__ __forceinline__ void enc_load_classify(const uint32_t *__restrict__ k
     uint32_t pk = __shfl_up(k[ENC_ITEMS - 1], 1, FD_WAVE), pv = __shfl_up(v[ENC_ITEMS - 1], 1, FD_WAVE);
     if ((threadIdx.x & 63) == 0 && base > 0 && base < n) { pk = keys[base - 1]; pv = (uint32_t)ids[base - 1]; }
     uint32_t ph = enc_codec<V>::hash(pk), pid = enc_codec<V>::id(pk, (V)pv, first_id);
+    if (pred_id) *pred_id = pid;     // id of the element before the thread's first one (undefined for element 0)
     bool have_prev = base > 0;
 #pragma unroll
     for (int j = 0; j < ENC_ITEMS; ++j) {
@@ -96,7 +96,6 @@ __device__ __forceinline__ void enc_load_classify(const uint32_t *__restrict__ k
         it[j].hash = h;
         it[j].head = (in && head) ? 1u : 0u;
         it[j].delta = head ? id : id - pid;
-        it[j].prev = pid;
         it[j].len = (!in || dup) ? 0u : varint_len(it[j].delta);
         ph = h; pid = id; have_prev = true;
     }
@@ -175,7 +174,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__res
     uint64_t base = (uint64_t)blockIdx.x * ENC_TILE + (uint64_t)threadIdx.x * ENC_ITEMS;
     enc_item it[ENC_ITEMS];
     uint32_t bytes = 0, heads = 0;
-    enc_load_classify<V>(keys, ids, n, base, first_id, it);
+    uint32_t run_id = 0;   // id of the element before item k (for the per-list last ids)
+    enc_load_classify<V>(keys, ids, n, base, first_id, it, &run_id);
 #pragma unroll
     for (int k = 0; k < ENC_ITEMS; ++k) { bytes += it[k].len; heads += it[k].head; }
     uint64_t tot;
@@ -190,10 +190,11 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__res
         if (it[k].head) {
             hashes[hoff] = it[k].hash;
             offsets[hoff] = boff;
-            if (hoff) last_ids[hoff - 1] = it[k].prev;        // the list before this head ends on the preceding element
+            if (hoff) last_ids[hoff - 1] = run_id;            // the list before this head ends on the preceding element
             ++hoff;
         }
-        if (base + k + 1 == n) last_ids[hoff - 1] = it[k].head ? it[k].delta : it[k].prev + it[k].delta;   // last element: its own id
+        run_id = it[k].head ? it[k].delta : run_id + it[k].delta;
+        if (base + k + 1 == n) last_ids[hoff - 1] = run_id;    // last element: its own id
         uint32_t v = it[k].delta;
         for (uint32_t b = 0; b < it[k].len; ++b) {
             uint32_t byte = v & 0x7fu;

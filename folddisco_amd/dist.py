@@ -185,3 +185,67 @@ def sharded_query(ctx, shard_index, lo: int, db_shard, qbatch, q_indices, subs, 
         order = {int(n): k for k, n in enumerate(recs["nid"])}      # candidate order of the global ranking, components in order
         matches = sorted(got, key=lambda m: order[m["nid"]])
     return recs, matches
+
+
+class Comm:
+    """fdgpu_comm: the RCCL communicator of libfdgpu.so itself (csrc/fd_comm.hip) — the exchange steps of the sharded query behind the
+    C ABI, for hosts that do not run torch.  The 128-byte unique id travels from rank 0 to the others by whatever the host has
+    (here: torch.distributed's broadcast when a process group exists)."""
+
+    def __init__(self, ctx, rank: int = 0, world: int = 1, unique_id: bytes | None = None):
+        import ctypes as C
+        from ._lib import u8p
+        self.ctx, self.rank, self.world = ctx, rank, world
+        if unique_id is None:
+            buf = np.zeros(128, np.uint8)
+            if rank == 0:
+                rc = ctx.L.fdgpu_comm_unique_id(buf.ctypes.data_as(u8p))
+                if rc:
+                    raise RuntimeError("fdgpu_comm_unique_id failed: RCCL is not available")
+            if world > 1:
+                t = torch.from_numpy(buf)
+                dist.broadcast(t, src=0)
+                buf = t.numpy()
+            unique_id = buf.tobytes()
+        self.unique_id = unique_id
+        idb = np.frombuffer(unique_id, np.uint8).copy()
+        h = C.c_void_p()
+        ctx.check(ctx.L.fdgpu_comm_init(ctx.h, idb.ctypes.data_as(u8p), rank, world, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.fdgpu_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allreduce_lengths(self, lens: np.ndarray) -> np.ndarray:
+        from ._lib import u64p
+        a = np.ascontiguousarray(lens, np.uint64).copy()
+        self.ctx.check(self.ctx.L.fdgpu_allreduce_lengths(self.ctx.h, self.h, a.ctypes.data_as(u64p), len(a)))
+        return a
+
+    def sharded_count_query(self, index, queries, penalty_shard, total_structures: int, top_n: int = 0) -> list:
+        """queries: list of (q_hash, q_node, q_edge_j).  -> per query the global ranking (REC_DTYPE), identical on every rank"""
+        import ctypes as C
+        from ._lib import CountRec, f32p, u32p, u64p
+        qh = np.ascontiguousarray(np.concatenate([np.asarray(q[0], np.uint32) for q in queries]) if queries else np.zeros(0, np.uint32))
+        qn = np.ascontiguousarray(np.concatenate([np.asarray(q[1], np.uint32) for q in queries]) if queries else np.zeros(0, np.uint32))
+        qe = np.ascontiguousarray(np.concatenate([np.asarray(q[2], np.uint32) for q in queries]) if queries else np.zeros(0, np.uint32))
+        q_off = np.concatenate([[0], np.cumsum([len(q[0]) for q in queries])]).astype(np.uint64)
+        pen = np.ascontiguousarray(penalty_shard, np.float32)
+        out, ooff = C.POINTER(CountRec)(), u64p()
+        self.ctx.check(self.ctx.L.fdgpu_sharded_count_query(self.ctx.h, self.h, index.h, len(queries), q_off.ctypes.data_as(u64p), qh.ctypes.data_as(u32p),
+                                                            qn.ctypes.data_as(u32p), qe.ctypes.data_as(u32p), pen.ctypes.data_as(f32p), int(total_structures),
+                                                            int(top_n), C.byref(out), C.byref(ooff)))
+        off = np.ctypeslib.as_array(ooff, shape=(len(queries) + 1,)).copy()
+        n = int(off[-1])
+        arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n, 1) * 20,))[: n * 20].copy().view(REC_DTYPE)
+        self.ctx.L.fdgpu_free(out)
+        self.ctx.L.fdgpu_free(ooff)
+        return [arr[int(off[t]): int(off[t + 1])] for t in range(len(queries))]

@@ -295,6 +295,31 @@ int fdgpu_retrieve_batch(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *r
                          fd_match_rec **matches, uint64_t **match_off, int32_t **residues, uint64_t **res_off);
 void fdgpu_matches_free(fd_match_rec *m, int32_t *residues);
 
+/* ---- multi-GPU query path (one process per GPU, RCCL over xGMI) ----------------------------------------------------
+ * The index is sharded by structure id (every rank holds the postings and coordinates of its own id range, fdgpu_index_build with
+ * first_id or fdgpu_index_load + fdgpu_index_set_first_id).  What the reference's query workflow (src/cli/workflows/query_pdb.rs:376-452)
+ * would call instead of the single-index count_query: rank 0 creates a unique id and hands it to the other ranks by any means
+ * (file, MPI, env), every rank calls fdgpu_comm_init on its own context / GPU, then fdgpu_sharded_count_query per batch of queries.
+ * RCCL is bound at run time (dlopen); without it these calls return FDGPU_EHIP. */
+#define FDGPU_COMM_ID_BYTES 128
+typedef struct fdgpu_comm fdgpu_comm;
+int fdgpu_comm_unique_id(uint8_t id[FDGPU_COMM_ID_BYTES]);
+int fdgpu_comm_init(fdgpu_ctx *ctx, const uint8_t id[FDGPU_COMM_ID_BYTES], int rank, int world, fdgpu_comm **out);
+void fdgpu_comm_destroy(fdgpu_comm *comm);
+int fdgpu_comm_rank(const fdgpu_comm *comm);
+int fdgpu_comm_world(const fdgpu_comm *comm);
+/* lengths[k] <- sum over the ranks (ncclAllReduce): posting lengths of a shard -> posting lengths over the whole database, the
+ * denominator of idf = log2(S / len) (src/controller/query.rs:17-32, count_query.rs:130) */
+int fdgpu_allreduce_lengths(fdgpu_ctx *ctx, fdgpu_comm *comm, uint64_t *lengths, uint64_t n);
+/* count_query of a batch of queries against the sharded index: every rank passes the same queries (layout of
+ * fdgpu_count_query_batch, no idf: it is computed here from the all-reduced posting lengths with log2f) and its own shard + penalty
+ * (one entry per structure of the shard).  The ranks score locally, all-gather their candidate records (ncclAllGather) and rank them:
+ * per query (*out)[(*out_off)[t] .. (*out_off)[t+1]) = the global ranking (idf descending, nid ascending; query_pdb.rs:404-411)
+ * truncated to top_n (0 = every touched structure), identical on every rank.  nid = global structure id. */
+int fdgpu_sharded_count_query(fdgpu_ctx *ctx, fdgpu_comm *comm, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off,
+                              const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j, const float *penalty,
+                              uint64_t total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off);
+
 /* ---- structure ingest (host, multi-threaded) ---------------------------------------------------------------
  * PDB / mmCIF text (optionally gzip) -> the packed arrays of fd_batch_desc plus what the .lookup file and the result
  * printer need.  Replaces read_structure_from_path + CompactStructure::build inside the index / query workflows

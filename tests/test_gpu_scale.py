@@ -130,3 +130,48 @@ def test_round_trip_and_count_query_at_scale(ecoli):
         want = idf[touched] * pen[touched].astype(np.float64)
         assert np.allclose(recs["idf"], want, rtol=1e-5, atol=1e-6)
         assert s in touched                                                   # the structure the motif was cut from is a hit
+
+
+def test_sharded_query_equals_single_index_at_ecoli_scale():
+    """SURVEY §8e at configs[1] size: two ranks (gloo, one GPU), 4,400 structures sharded by id, six planted motif queries through
+    dist.sharded_query == the single-index query (records byte-identical, matches identical, candidates from both shards)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29755", os.path.join(root, "tests", "shard_query_worker_synth.py")],
+                         cwd=root, capture_output=True, text=True, timeout=900)
+    assert "SHARDED_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("QUERY") == 6 and "DIFFERENT" not in out.stdout and "both-shards" in out.stdout
+
+
+def test_c_abi_communicator_world_1(ecoli):
+    """fdgpu_comm_* / fdgpu_sharded_count_query (csrc/fd_comm.hip: RCCL bound with dlopen): with one rank the sharded prefilter is the
+    single-index one — posting lengths, idf, device top-N, global ranking — and the communicator really is an RCCL communicator
+    (ncclCommInitRank on this GPU).  The N > 1 exchange is ncclAllReduce / ncclAllGather of the same buffers."""
+    import folddisco_amd as fd
+    from folddisco_amd import dist as fdist
+    from folddisco_amd import querybench
+    from folddisco_amd.query import make_query_map
+    ctx, ps, batch, ix, first_id = ecoli
+    comm = fdist.Comm(ctx, 0, 1)
+    assert len(comm.unique_id) == 128 and any(comm.unique_id)
+    lens = np.array([3, 0, 2 ** 40 + 7], np.uint64)
+    assert np.array_equal(comm.allreduce_lengths(lens), lens)
+    import torch
+    d = dict(res_off=torch.from_numpy(ps.res_off.astype(np.int64)), n_xyz=torch.from_numpy(ps.n_xyz), ca_xyz=torch.from_numpy(ps.ca_xyz),
+             cb_xyz=torch.from_numpy(ps.cb_xyz), aa=torch.from_numpy(ps.aa))
+    pen = fd.length_penalty(np.diff(ps.res_off).astype(np.uint64), 0.5)
+    qs = []
+    for s, idx, item in querybench._pick_queries(d, ECOLI, 5, seed=2):
+        qm = make_query_map(ctx, ctx.upload(fd.PackedStructures.concat([item])), idx, None, ix, float(ECOLI))
+        qs.append((qm.hash, qm.qi, qm.qj))
+    qs.append((np.array([0x3ffffff0], np.uint32), np.zeros(1, np.uint32), np.ones(1, np.uint32)))      # a query without hits
+    for top_n in (0, 50):
+        got = comm.sharded_count_query(ix, qs, pen, ECOLI, top_n=top_n)
+        for g, (qh, qi, qj) in zip(got, qs):
+            want = fdist.rank_hits(fd.count_query(ctx, ix, qh, qi, qj, pen, total_structures=ECOLI, as_array=True), top_n or None)
+            assert g.tobytes() == want.tobytes()
+        assert len(got[-1]) == 0 and len(got[0]) > 0
+    comm.close()
