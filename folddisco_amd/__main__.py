@@ -57,10 +57,17 @@ def cmd_index(a):
     import folddisco_amd as fd
     from folddisco_amd import indexio, structure
     rank, world, _dev = _init_dist(a)
-    all_paths = _load_paths(a.pdbs, a.recursive)
+    # an input that is a file is a Foldcomp database (build_index.rs:109-123): structures = its entries in key order, names from
+    # DB.lookup, ids for the reader = database keys
+    a.fc = structure.FoldcompDb(a.pdbs) if structure.is_foldcomp_db(a.pdbs) else None
+    if a.fc is not None:
+        keep = [k for k, nm in enumerate(a.fc.names) if nm]
+        all_paths, a.fc_keys = [a.fc.names[k] for k in keep], a.fc.keys[keep]
+    else:
+        all_paths, a.fc_keys = _load_paths(a.pdbs, a.recursive), None
     if not all_paths:
         sys.exit(f"[FAIL] no structures under {a.pdbs}")
-    prefix = a.index or (a.pdbs.rstrip("/") + "_folddisco")
+    prefix = a.index or (_default_index_prefix(a.pdbs))
     if world > 1:
         return _cmd_index_sharded(a, fd, indexio, structure, all_paths, prefix, rank, world)
     paths = all_paths
@@ -74,12 +81,7 @@ def cmd_index(a):
     for c0 in range(0, len(paths), a.chunk):
         chunk = paths[c0:c0 + a.chunk]
         # native ingest straight into the flat batch layout (csrc/fd_ingest.cpp), no per-structure Python objects
-        ps, nres_c, plddt_c, raw, ok = structure.read_packed(chunk, threads=a.threads, max_residue=a.max_residue)
-        for k in np.nonzero(ok == 0)[0]:
-            print(f"[WARN] {chunk[k]} could not be read. Skipping", file=sys.stderr)
-        if a.max_residue > 0:
-            for k in np.nonzero(raw > a.max_residue)[0]:
-                print(f"[WARN] {chunk[k]} has too many residues. Skipping", file=sys.stderr)
+        ps, nres_c, plddt_c, raw, ok = _ingest(a, structure, chunk, c0)
         nres_all.append(nres_c)
         plddt_all.append(np.where(nres_c > 0, plddt_c, np.float32(0.0)).astype(np.float32))
         batch = ctx.upload(ps)
@@ -95,10 +97,31 @@ def cmd_index(a):
         indexio.write_index_files(prefix, v, h, o)
         n_hashes, value_len = len(h), len(v)
     nres, plddt = np.concatenate(nres_all), np.concatenate(plddt_all)
-    indexio.save_lookup(prefix + ".lookup", [indexio.parse_path_by_id_type(x, a.id) for x in paths], nres, plddt)
-    indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type], multiple_bins=a.multi)
+    indexio.save_lookup(prefix + ".lookup", [indexio.parse_path_by_id_type(x, a.id) for x in paths], nres, plddt, db_keys=a.fc_keys)
+    indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type], multiple_bins=a.multi,
+                      **(dict(input_format="FCZDB", foldcomp_db=a.pdbs) if a.fc is not None else {}))
     if a.verbose:
         print(f"[DONE] {len(paths)} structures, {n_hashes} hashes, {value_len} value bytes -> {prefix}", file=sys.stderr)
+
+
+def _default_index_prefix(pdbs: str) -> str:
+    """build_index.rs:75-88 / controller/io.rs:460-470: DIR_folddisco; a database named X_foldcomp gives X_folddisco"""
+    p = pdbs.rstrip("/")
+    return p.replace("_foldcomp", "_folddisco") if p.endswith("_foldcomp") else p + "_folddisco"
+
+
+def _ingest(a, structure, chunk, pos0):
+    """native ingest of one chunk of the input (files, or entries pos0 ... of the Foldcomp database) + the reference's warnings"""
+    if a.fc is not None:
+        ps, nres_c, plddt_c, raw, ok = structure.read_packed(a.fc_keys[pos0:pos0 + len(chunk)], threads=a.threads, max_residue=a.max_residue, foldcomp=a.fc)
+    else:
+        ps, nres_c, plddt_c, raw, ok = structure.read_packed(chunk, threads=a.threads, max_residue=a.max_residue)
+    for k in np.nonzero(ok == 0)[0]:
+        print(f"[WARN] {chunk[k]} could not be read. Skipping", file=sys.stderr)
+    if a.max_residue > 0:
+        for k in np.nonzero(raw > a.max_residue)[0]:
+            print(f"[WARN] {chunk[k]} has too many residues. Skipping", file=sys.stderr)
+    return ps, nres_c, plddt_c, raw, ok
 
 
 def _build_chunks(a, fd, structure, ctx, paths, first_id):
@@ -107,12 +130,7 @@ def _build_chunks(a, fd, structure, ctx, paths, first_id):
     for c0 in range(0, len(paths), a.chunk):
         chunk = paths[c0:c0 + a.chunk]
         # native ingest straight into the flat batch layout (csrc/fd_ingest.cpp), no per-structure Python objects
-        ps, nres_c, plddt_c, raw, ok = structure.read_packed(chunk, threads=a.threads, max_residue=a.max_residue)
-        for k in np.nonzero(ok == 0)[0]:
-            print(f"[WARN] {chunk[k]} could not be read. Skipping", file=sys.stderr)
-        if a.max_residue > 0:
-            for k in np.nonzero(raw > a.max_residue)[0]:
-                print(f"[WARN] {chunk[k]} has too many residues. Skipping", file=sys.stderr)
+        ps, nres_c, plddt_c, raw, ok = _ingest(a, structure, chunk, first_id + c0)
         nres_all.append(nres_c)
         plddt_all.append(np.where(nres_c > 0, plddt_c, np.float32(0.0)).astype(np.float32))
         batch = ctx.upload(ps)
@@ -141,8 +159,9 @@ def _cmd_index_sharded(a, fd, indexio, structure, paths, prefix, rank, world):
         shards = [indexio.read_index_files(_shard_prefix(prefix, r, world)) for r in range(world)]
         mv, mh, mo = indexio.merge_subindices(shards)
         indexio.write_index_files(prefix, mv, mh, mo)
-        indexio.save_lookup(prefix + ".lookup", [indexio.parse_path_by_id_type(x, a.id) for x in paths], np.concatenate([b[0] for b in box]), np.concatenate([b[1] for b in box]))
-        indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type], multiple_bins=a.multi)
+        indexio.save_lookup(prefix + ".lookup", [indexio.parse_path_by_id_type(x, a.id) for x in paths], np.concatenate([b[0] for b in box]), np.concatenate([b[1] for b in box]), db_keys=a.fc_keys)
+        indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type], multiple_bins=a.multi,
+                          **(dict(input_format="FCZDB", foldcomp_db=a.pdbs) if a.fc is not None else {}))
         if a.verbose:
             print(f"[DONE] {len(paths)} structures over {world} ranks, {len(mh)} hashes, {len(mv)} value bytes -> {prefix}", file=sys.stderr)
     dist.barrier()
@@ -156,7 +175,7 @@ def cmd_query(a):
         sys.exit("[FAIL] -i/--index is required")
     rank, world, dev = _init_dist(a)
     ctx = fd.Context(a.device)
-    tids, nres, plddt, _ = indexio.load_lookup(a.index + ".lookup")
+    tids, nres, plddt, db_keys = indexio.load_lookup(a.index + ".lookup")
     cfg = indexio.load_type(a.index + ".type")
     shard = None
     lo, hi = 0, len(tids)
@@ -188,19 +207,37 @@ def cmd_query(a):
         cand = os.path.join(os.path.dirname(os.path.abspath(a.index)), t)
         return cand if os.path.isfile(cand) else t
     db_structs, batch = None, None
-    if not a.skip_match:
+    # an index built from a Foldcomp database reads the hit coordinates back from it by db_key (query_pdb.rs:321-343,
+    # retrieve.rs:166-178); the database is the one the index names, else INDEX-PREFIX's X_foldcomp sibling (controller/io.rs:422-448)
+    fc = None
+    if cfg.get("input_format") == "FCZDB" and not a.skip_match:
+        cands = [cfg.get("foldcomp_db", "")]
+        pfx = a.index[:-len("_folddisco")] if a.index.endswith("_folddisco") else a.index
+        cands += [pfx, pfx + "_foldcomp"]
+        dbp = next((c for c in cands if c and structure.is_foldcomp_db(c)), None)
+        if dbp is None:
+            sys.exit(f"[FAIL] Foldcomp database of index {a.index} not found (tried {', '.join(c for c in cands if c)})")
+        fc = structure.FoldcompDb(dbp)
+    if not a.skip_match and fc is not None:
+        db_structs, _ = structure.read_compact_structures(db_keys[lo:hi], threads=a.threads, foldcomp=fc)
+        batch = ctx.upload(fd.PackedStructures.concat([s.as_item() for s in db_structs]))
+    elif not a.skip_match:
         db_structs, _ = structure.read_compact_structures([resolve(t) for t in tids[lo:hi]], threads=a.threads)
         batch = ctx.upload(fd.PackedStructures.concat([s.as_item() for s in db_structs]))
     dthr = [float(x) for x in a.distance.replace(" ", "").split(",") if x]
     athr = [float(x) for x in a.angle.replace(" ", "").split(",") if x]
     for pdb, qstr, outp in queries:
-        q = structure.read_compact_structures([pdb], threads=1)[0][0]
+        if ":" in pdb and not os.path.isfile(pdb):       # DB:NAME = an entry of a Foldcomp database as the query (controller/io.rs:303-333)
+            qdb = structure.FoldcompDb(pdb.split(":")[0])
+            q = structure.read_compact_structures([qdb.key_of(pdb.split(":")[1])], threads=1, foldcomp=qdb)[0][0]
+        else:
+            q = structure.read_compact_structures([pdb], threads=1)[0][0]
         rows, matches = query.query_pdb(ctx, ix, batch, db_structs, tids, nres, plddt, q, qstr, dist_thr=dthr, angle_thr=athr,
                                         ca_distance=a.ca_distance, top_n=a.top, skip_match=a.skip_match, serial_query=a.serial_index,
                                         freq_filter=a.freq_filter, length_penalty_power=0.5 if a.length_penalty is None else a.length_penalty,
                                         dist_cutoff=float(cfg.get("grid_width", 20.0)), nbin_dist=int(cfg.get("num_bin_dist", 0)),
                                         nbin_angle=int(cfg.get("num_bin_angle", 0)), hash_type=hash_type_index(cfg.get("hash_type", "PDBTrRosetta")), multiple_bins=cfg.get("multiple_bin"), sampling_ratio=a.sampling_ratio,
-                                        sampling_count=a.sampling_count, sort_by=a.sort_by, partial_fit=a.partial_fit, skip_ca_match=a.skip_ca_match, match_top_n=1000 if a.web else "same",
+                                        sampling_count=a.sampling_count, sort_by=a.sort_by, partial_fit=a.partial_fit, skip_ca_match=a.skip_ca_match, match_top_n=1000 if a.web else "same", db_keys=db_keys,
                                         filters=dict(total_match=a.total_match, covered_node=a.covered_node, covered_node_ratio=a.covered_node_ratio,
                                                      max_node=a.max_node, max_node_ratio=a.max_node_ratio, score=a.score,
                                                      connected_node=a.connected_node, connected_node_ratio=a.connected_node_ratio,

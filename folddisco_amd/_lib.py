@@ -100,6 +100,11 @@ class MatchRec(C.Structure):
                 ("rot_from_hash", C.c_float * 9), ("tran_from_hash", C.c_float * 3), ("metrics_from_hash", C.c_float * 5)]
 
 
+class FoldcompAtom(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("b", C.c_float), ("name", C.c_char * 4), ("res", C.c_char * 3),
+                ("chain", C.c_uint8), ("rser", C.c_uint64)]
+
+
 class Parsed(C.Structure):
     _fields_ = [("n_struct", C.c_uint64), ("n_res", C.c_uint64), ("res_off", u64p), ("n_xyz", f32p), ("ca_xyz", f32p), ("cb_xyz", f32p),
                 ("aa", u8p), ("cb_valid", u8p), ("chain", u8p), ("resname_std", u8p), ("serial", u64p), ("bfac", f32p),
@@ -135,6 +140,9 @@ SYMBOLS = [
     ("fdgpu_spec_fallbacks", C.c_int, [VP, u64p]),
     ("fdgpu_parse_structures", C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(Parsed))]),
     ("fdgpu_parsed_free", None, [C.POINTER(Parsed)]),
+    ("fdgpu_foldcomp_decode", C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.POINTER(FoldcompAtom)), u64p]),
+    ("fdgpu_foldcomp_db_list", C.c_int, [C.c_char_p, C.POINTER(u64p), C.POINTER(C.c_void_p), u64p]),
+    ("fdgpu_parse_foldcomp_db", C.c_int, [C.c_char_p, u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(Parsed))]),
     ("fdgpu_get_entries", C.c_int, [VP, VP, u32p, C.c_uint64, C.POINTER(u32p), C.POINTER(u64p)]),
     ("fdgpu_count_query_batch_top", C.c_int, [VP, VP, C.c_uint64, u64p, u32p, u32p, u32p, f32p, f32p, C.c_uint32, C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
     ("fdgpu_match_pairs", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(MatchQuery), C.POINTER(HashParams),

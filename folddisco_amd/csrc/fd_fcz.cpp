@@ -1,0 +1,289 @@
+// fd_fcz.cpp — Foldcomp (.fcz / Foldcomp database) input: compressed entry -> the atom records the reference's ingest consumes.
+//
+// The reference reads Foldcomp databases through the vendored Foldcomp library (src/structure/io/fcz.rs:76-146 ->
+// lib/foldcomp/foldcompffi.cpp:11-52: Foldcomp::read + Foldcomp::decompress, then Structure::update per atom).  AFDB is distributed
+// in this form.  This file is an independent decoder of the published format, written for what folddisco needs — the record of
+// every atom (name, residue, numbering, B factor) and the coordinates of the backbone N, CA, C plus O and CB — with the float
+// arithmetic of the format's reference decoder kept operation for operation, because the hashes are functions of these bits:
+//
+//   entry      "FCMP" | header (72 B: residue / atom counts and start numbers, anchor count, chain, first / last residue,
+//              title length, min + step of the six backbone angle quantisers) | anchor residue indices | title |
+//              first N, CA, C | inner anchor N, CA, C triples | last N, CA, C | hasOXT + OXT xyz | 8 B per residue
+//              (type 5 b, omega 11 b, psi 12 b, phi 12 b, three bond angles 8 b each) | side-chain torsions (1 B each) |
+//              B-factor quantiser + 1 B per residue
+//   backbone   per anchor segment: forward NeRF chain from the segment's first three atoms (bond lengths 1.3311 / 1.4581
+//              (1.353 behind a proline) / 1.5281), backward chain from the stored anchor atoms with the bond angles measured on
+//              the forward chain, position-weighted average of the two
+//   O, CB      NeRF from (N, CA, C) and (O, C, CA) with the residue type's bond length / angle and the stored torsion
+//              (torsion = -180 + 360 / 255 * byte)
+// Distances inside the NeRF step are evaluated in double and rounded to float exactly where the format's decoder does (its norm()
+// squares through pow(double), its angle() goes through double sqrt / acos).  Side-chain atoms beyond CB get their records
+// (CompactStructure::build looks at record order, names and B factors) but no coordinates: folddisco never reads them.
+// tests/test_foldcomp.py compares every atom record and the N / CA / C / O / CB coordinates bit for bit with the reference decoder
+// built from lib/foldcomp (oracle/_ref) and with committed golden vectors.
+#include "fd_fcz.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace {
+struct f3 { float x, y, z; };
+
+inline f3 cross(f3 a, f3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+inline float norm(f3 v) { return (float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z); }
+// angle at b (degrees) as the format's decoder measures it: float dot / sizes, double sqrt, double acos
+inline float angle_deg(f3 a, f3 b, f3 c) {
+    const f3 d1 = {a.x - b.x, a.y - b.y, a.z - b.z}, d2 = {c.x - b.x, c.y - b.y, c.z - b.z};
+    const float inner = (d1.x * d2.x) + (d1.y * d2.y) + (d1.z * d2.z);
+    const float s1 = d1.x * d1.x + d1.y * d1.y + d1.z * d1.z, s2 = d2.x * d2.x + d2.y * d2.y + d2.z * d2.z;
+    const float cs = (float)((double)inner / sqrt((double)(s1 * s2)));
+    return (float)(acos((double)cs) * 180.0 / M_PI);
+}
+// next atom from three predecessors, bond length, bond angle and torsion (degrees)
+inline f3 place_atom(const f3 prev[3], float bond_length, float bond_angle, float torsion_angle) {
+    const f3 a = prev[0], b = prev[1], c = prev[2];
+    const f3 ab = {b.x - a.x, b.y - a.y, b.z - a.z}, bc = {c.x - b.x, c.y - b.y, c.z - b.z};
+    const float bc_norm = norm(bc);
+    const f3 bcn = {bc.x / bc_norm, bc.y / bc_norm, bc.z / bc_norm};
+    bond_angle = (float)((double)bond_angle * M_PI / 180.0);
+    torsion_angle = (float)((double)torsion_angle * M_PI / 180.0);
+    const f3 cur = {-1 * bond_length * cosf(bond_angle), bond_length * cosf(torsion_angle) * sinf(bond_angle),
+                    bond_length * sinf(torsion_angle) * sinf(bond_angle)};
+    f3 n = cross(ab, bcn);
+    const float n_norm = norm(n);
+    n.x = n.x / n_norm; n.y = n.y / n_norm; n.z = n.z / n_norm;
+    const f3 nbc = cross(n, bcn);
+    f3 d = {0.0f, 0.0f, 0.0f};
+    d.x += bcn.x * cur.x; d.x += nbc.x * cur.y; d.x += n.x * cur.z;
+    d.y += bcn.y * cur.x; d.y += nbc.y * cur.y; d.y += n.y * cur.z;
+    d.z += bcn.z * cur.x; d.z += nbc.z * cur.y; d.z += n.z * cur.z;
+    d.x += c.x; d.y += c.y; d.z += c.z;
+    return d;
+}
+
+// residue types of the format (5-bit code): atoms behind N, CA, C and the geometry of O and CB
+struct aa_info { const char *three; char one; const char *side; float c_o, ca_c_o, ca_cb, c_ca_cb; };
+const aa_info AA[20] = {
+    {"ALA", 'A', "O CB", 1.23f, 120.31f, 1.52f, 110.852f},
+    {"ARG", 'R', "O CB CG CD NE CZ NH1 NH2", 1.23f, 119.745f, 1.53f, 110.579f},
+    {"ASN", 'N', "O CB CG OD1 ND2", 1.23f, 120.313f, 1.52f, 110.852f},
+    {"ASP", 'D', "O CB CG OD1 OD2", 1.23f, 121.051f, 1.53f, 110.871f},
+    {"CYS", 'C', "O CB SG", 1.23f, 120.063f, 1.53f, 111.078f},
+    {"GLN", 'Q', "O CB CG CD OE1 NE2", 1.23f, 120.211f, 1.53f, 109.5f},
+    {"GLU", 'E', "O CB CG CD OE1 OE2", 1.23f, 120.594f, 1.53f, 110.538f},
+    {"GLY", 'G', "O", 1.23f, 120.522f, 0.0f, 0.0f},
+    {"HIS", 'H', "O CB CG ND1 CD2 CE1 NE2", 1.23f, 120.548f, 1.53f, 111.329f},
+    {"ILE", 'I', "O CB CG1 CG2 CD1", 1.235f, 120.393f, 1.54f, 111.983f},
+    {"LEU", 'L', "O CB CG CD1 CD2", 1.235f, 120.211f, 1.53f, 110.418f},
+    {"LYS", 'K', "O CB CG CD CE NZ", 1.23f, 120.54f, 1.53f, 109.5f},
+    {"MET", 'M', "O CB CG SD CE", 1.23f, 120.148f, 1.53f, 110.833f},
+    {"PHE", 'F', "O CB CG CD1 CD2 CE1 CE2 CZ", 1.23f, 120.283f, 1.53f, 110.846f},
+    {"PRO", 'P', "O CB CG CD", 1.23f, 120.6f, 1.53f, 111.372f},
+    {"SER", 'S', "O CB OG", 1.23f, 120.475f, 1.53f, 110.248f},
+    {"THR", 'T', "O CB OG1 CG2", 1.23f, 120.252f, 1.53f, 110.075f},
+    {"TRP", 'W', "O CB CG CD1 CD2 NE1 CE2 CE3 CZ2 CZ3 CH2", 1.23f, 120.178f, 1.53f, 110.852f},
+    {"TYR", 'Y', "O CB CG CD1 CD2 CE1 CE2 CZ OH", 1.235f, 120.608f, 1.53f, 110.852f},
+    {"VAL", 'V', "O CB CG1 CG2", 1.235f, 120.472f, 1.54f, 111.381f}};
+
+const aa_info AA_UNK = {"UNK", 'X', "", 0.0f, 0.0f, 0.0f, 0.0f};      // type 23: N, CA, C only, no side torsions
+
+#pragma pack(push, 1)
+struct fcz_header {    // 72 bytes, natural alignment of the original struct reproduced with explicit padding
+    uint16_t n_residue, n_atom, idx_residue, idx_atom;
+    uint8_t n_anchor;
+    char chain;
+    uint8_t pad0[2];
+    uint32_t n_side_torsion;
+    char first_residue, last_residue;
+    uint8_t pad1[2];
+    uint32_t len_title;
+    float mins[6], cont_fs[6];
+};
+#pragma pack(pop)
+static_assert(sizeof(fcz_header) == 72, "Foldcomp header is 72 bytes");
+
+struct res_code { uint32_t type, omega, psi, phi, ca_c_n, c_n_ca, n_ca_c; };
+struct res_angles { float phi, psi, omega, n_ca_c, ca_c_n, c_n_ca; };
+
+inline void set_name(char out[4], const char *nm, size_t len) {
+    out[0] = ' '; out[1] = nm[0]; out[2] = len > 1 ? nm[1] : ' '; out[3] = len > 2 ? nm[2] : ' ';
+}
+
+struct reader {
+    const uint8_t *p; size_t n, at = 0;
+    bool ok = true;
+    bool get(void *dst, size_t len) { if (!ok || at + len > n) { ok = false; return false; } memcpy(dst, p + at, len); at += len; return true; }
+};
+}  // namespace
+
+int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out) {
+    out->clear();
+    reader r{data, len};
+    char magic[4];
+    if (!r.get(magic, 4) || memcmp(magic, "FCMP", 4)) return -1;
+    fcz_header H;
+    if (!r.get(&H, sizeof H)) return -1;
+    const int nres = H.n_residue, n_anchor = H.n_anchor;
+    if (nres < 1 || n_anchor < 2) return -1;
+    std::vector<int32_t> anchor_idx(n_anchor);
+    if (!r.get(anchor_idx.data(), (size_t)n_anchor * 4)) return -1;
+    r.at += H.len_title;
+    float first[9], last[9], oxt[3];
+    if (!r.get(first, sizeof first)) return -1;
+    std::vector<float> anchors;     // per segment end: N, CA, C (inner anchors, then the last atoms)
+    anchors.resize((size_t)(n_anchor - 1) * 9);
+    if (n_anchor > 2 && !r.get(anchors.data(), (size_t)(n_anchor - 2) * 36)) return -1;
+    if (!r.get(last, sizeof last)) return -1;
+    memcpy(&anchors[(size_t)(n_anchor - 2) * 9], last, sizeof last);
+    char has_oxt;
+    if (!r.get(&has_oxt, 1) || !r.get(oxt, sizeof oxt)) return -1;
+    std::vector<res_code> code(nres);
+    for (int i = 0; i < nres; ++i) {
+        uint8_t b[8];
+        if (!r.get(b, 8)) return -1;
+        code[i].type = (b[0] & 0xF8) >> 3;
+        code[i].omega = ((uint32_t)(b[0] & 0x07) << 8) | b[1];
+        code[i].psi = ((uint32_t)b[2] << 4) | (b[3] >> 4);
+        code[i].phi = ((uint32_t)(b[3] & 0x0F) << 8) | b[4];
+        code[i].ca_c_n = b[5]; code[i].c_n_ca = b[6]; code[i].n_ca_c = b[7];
+        if (code[i].type >= 20 && code[i].type <= 22) return -2;   // ASX / GLX / STP: the format's decoder has no entry for them (its lookup throws)
+        if (code[i].type > 23) code[i].type = 23;                  // every other code reads as UNK (backbone only)
+    }
+    std::vector<uint8_t> side(H.n_side_torsion);
+    if (H.n_side_torsion && !r.get(side.data(), H.n_side_torsion)) return -1;
+    float b_min, b_step;
+    if (!r.get(&b_min, 4) || !r.get(&b_step, 4)) return -1;
+    std::vector<uint8_t> bq(nres);
+    if (!r.get(bq.data(), nres)) return -1;
+
+    // continuous angles: min + code * step (float)
+    std::vector<res_angles> ang(nres);
+    for (int i = 0; i < nres; ++i) {
+        ang[i].phi = H.mins[0] + ((float)code[i].phi * H.cont_fs[0]);
+        ang[i].psi = H.mins[1] + ((float)code[i].psi * H.cont_fs[1]);
+        ang[i].omega = H.mins[2] + ((float)code[i].omega * H.cont_fs[2]);
+        ang[i].n_ca_c = H.mins[3] + ((float)code[i].n_ca_c * H.cont_fs[3]);
+        ang[i].ca_c_n = H.mins[4] + ((float)code[i].ca_c_n * H.cont_fs[4]);
+        ang[i].c_n_ca = H.mins[5] + ((float)code[i].c_n_ca * H.cont_fs[5]);
+    }
+    // torsion list of the whole chain: psi, omega, phi of residues 0 .. n-2
+    std::vector<float> tors;
+    for (int i = 0; i + 1 < nres; ++i) { tors.push_back(ang[i].psi); tors.push_back(ang[i].omega); tors.push_back(ang[i].phi); }
+
+    // ---- backbone, anchor segment by anchor segment
+    std::vector<f3> bb;                       // N, CA, C of every residue
+    f3 prev[3] = {{first[0], first[1], first[2]}, {first[3], first[4], first[5]}, {first[6], first[7], first[8]}};
+    for (int sgm = 0; sgm < n_anchor - 1; ++sgm) {
+        const int max_idx = nres - 1;
+        const int i0 = anchor_idx[sgm] < max_idx ? anchor_idx[sgm] : max_idx;
+        int i1 = anchor_idx[sgm + 1] + 1 < max_idx ? anchor_idx[sgm + 1] + 1 : max_idx;
+        if (i0 < 0 || i1 < i0) return -1;
+        std::vector<int> sub;
+        for (int i = i0; i < i1; ++i) sub.push_back(i);
+        if (sgm == n_anchor - 2) sub.push_back(nres - 1);
+        // forward chain
+        std::vector<f3> fw = {prev[0], prev[1], prev[2]};
+        for (size_t k = 0; k + 1 < sub.size(); ++k) {
+            const res_angles &A = ang[sub[k]];
+            f3 pc[3] = {fw[3 * k], fw[3 * k + 1], fw[3 * k + 2]};
+            const f3 nn = place_atom(pc, (float)1.3311, A.ca_c_n, A.psi);
+            pc[0] = pc[1]; pc[1] = pc[2]; pc[2] = nn;
+            const f3 ca = place_atom(pc, code[sub[k]].type != 14 ? (float)1.4581 : (float)1.353, A.c_n_ca, A.omega);
+            pc[0] = pc[1]; pc[1] = pc[2]; pc[2] = ca;
+            const f3 cc = place_atom(pc, (float)1.5281, A.n_ca_c, A.phi);
+            fw.push_back(nn); fw.push_back(ca); fw.push_back(cc);
+        }
+        // torsions of the segment
+        const int tmax = (int)tors.size() - 1;
+        std::vector<float> st;
+        if (tmax >= 0) {
+            const int t0 = anchor_idx[sgm] * 3 < tmax ? anchor_idx[sgm] * 3 : tmax, t1 = anchor_idx[sgm + 1] * 3 < tmax ? anchor_idx[sgm + 1] * 3 : tmax;
+            for (int t = t0; t < t1; ++t) st.push_back(tors[t]);
+            if (sgm == n_anchor - 2) st.push_back(tors.back());
+        }
+        // backward chain from the stored anchor atoms, bond angles measured on the forward chain
+        const size_t na = fw.size();
+        std::vector<f3> back = fw;
+        const float *an = &anchors[(size_t)sgm * 9];
+        back[na - 3] = {an[0], an[1], an[2]}; back[na - 2] = {an[3], an[4], an[5]}; back[na - 1] = {an[6], an[7], an[8]};
+        std::vector<float> bang;
+        for (size_t i = 1; i + 1 < na; ++i) bang.push_back(angle_deg(fw[i - 1], fw[i], fw[i + 1]));
+        std::vector<f3> rev(back.rbegin(), back.rend());
+        std::vector<float> rt(st.rbegin(), st.rend()), ra(bang.rbegin(), bang.rend());
+        std::vector<f3> rec = {rev[0], rev[1], rev[2]};
+        for (size_t i = 0; i + 3 < na; ++i) {
+            // atom i + 3 of the reversed chain: kinds cycle C, CA, N from the end; the bond runs from atom i + 3 to atom i + 2
+            const int kind_cur = (int)((na - 1 - (i + 3)) % 3), kind_prev = (int)((na - 1 - (i + 2)) % 3);   // 0 N, 1 CA, 2 C
+            float bl;
+            if (kind_cur == 0 && kind_prev == 1) bl = 1.4581f;        // N_TO_CA
+            else if (kind_cur == 1 && kind_prev == 2) bl = 1.5281f;   // CA_TO_C
+            else bl = 1.3311f;                                        // C_TO_N
+            if (i >= rt.size() || i + 1 >= ra.size()) return -1;
+            const f3 pc[3] = {rec[i], rec[i + 1], rec[i + 2]};
+            rec.push_back(place_atom(pc, bl, ra[i + 1], rt[i]));
+        }
+        std::vector<f3> bw(rec.rbegin(), rec.rend());
+        // position-weighted average
+        std::vector<f3> avg(na);
+        const int total = (int)na;
+        for (int i = 0; i < total; ++i) {
+            avg[i].x = ((fw[i].x * (float)(total - i)) + (bw[i].x * (float)i)) / (float)total;
+            avg[i].y = ((fw[i].y * (float)(total - i)) + (bw[i].y * (float)i)) / (float)total;
+            avg[i].z = ((fw[i].z * (float)(total - i)) + (bw[i].z * (float)i)) / (float)total;
+        }
+        const size_t keep = sgm != n_anchor - 2 ? na - 3 : na;
+        bb.insert(bb.end(), avg.begin(), avg.begin() + keep);
+        prev[0] = avg[na - 3]; prev[1] = avg[na - 2]; prev[2] = avg[na - 1];
+    }
+    if (bb.size() != (size_t)nres * 3) return -1;
+
+    // ---- atom records: N, CA, C, then the residue type's side atoms (O and CB placed, the rest without coordinates)
+    size_t tpos = 0;
+    uint64_t atom_index = H.idx_atom;
+    (void)atom_index;
+    for (int i = 0; i < nres; ++i) {
+        const aa_info &T = code[i].type < 20 ? AA[code[i].type] : AA_UNK;
+        const f3 N = bb[3 * i], CA = bb[3 * i + 1], C = bb[3 * i + 2];
+        const float bf = ((float)bq[i] * b_step) + b_min;
+        auto push = [&](const char *nm, size_t nl, f3 xyz) {
+            fd_fcz_atom a;
+            a.x = xyz.x; a.y = xyz.y; a.z = xyz.z; a.b = bf;
+            set_name(a.name, nm, nl);
+            memcpy(a.res, T.three, 3);
+            a.chain = (uint8_t)H.chain;
+            a.rser = (uint64_t)H.idx_residue + (uint64_t)i;
+            out->push_back(a);
+        };
+        push("N", 1, N); push("CA", 2, CA); push("C", 1, C);
+        f3 O = {0, 0, 0};
+        const char *s = T.side;
+        int k = 0;
+        while (*s) {
+            const char *e = s;
+            while (*e && *e != ' ') ++e;
+            const size_t nl = (size_t)(e - s);
+            if (tpos >= side.size()) return -1;
+            const float tor_step = (180.0f - -180.0f) / (float)255u;            // FixedAngleDiscretizer(255): float division
+            const float tor = ((float)side[tpos] * tor_step) + -180.0f;
+            ++tpos;
+            f3 xyz = {0.0f, 0.0f, 0.0f};
+            if (k == 0) { const f3 pc[3] = {N, CA, C}; O = xyz = place_atom(pc, T.c_o, T.ca_c_o, tor); }
+            else if (k == 1) { const f3 pc[3] = {O, C, CA}; xyz = place_atom(pc, T.ca_cb, T.c_ca_cb, tor); }
+            push(s, nl, xyz);
+            ++k;
+            s = *e ? e + 1 : e;
+        }
+    }
+    if (has_oxt) {
+        fd_fcz_atom a;
+        a.x = oxt[0]; a.y = oxt[1]; a.z = oxt[2];
+        a.b = ((float)bq[nres - 1] * b_step) + b_min;
+        set_name(a.name, "OXT", 3);
+        const char *hit = H.last_residue ? strchr("ARNDCQEGHILKMFPSTWYV", H.last_residue) : nullptr;
+        memcpy(a.res, hit ? AA[hit - "ARNDCQEGHILKMFPSTWYV"].three : "UNK", 3);
+        a.chain = (uint8_t)H.chain;
+        a.rser = (uint64_t)H.n_residue;
+        out->push_back(a);
+    }
+    return 0;
+}

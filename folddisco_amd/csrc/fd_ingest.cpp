@@ -13,8 +13,13 @@
 //                         a GLY N is captured through the GLY branch; virtual CB src/structure/coordinate.rs:167-186
 //   * amino-acid map      src/utils/convert.rs:53-81
 // Host code only (no device work): text parsing is what remains of an index build once hashing runs on the GPU.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -26,6 +31,7 @@
 #include <vector>
 
 #include "../../include/fdgpu.h"
+#include "fd_fcz.h"
 
 namespace {
 
@@ -331,40 +337,10 @@ bool ends_with_ci(const std::string &s, const char *suf) {
 
 }  // namespace
 
-extern "C" int fdgpu_parse_structures(const char *const *paths, uint64_t n, uint32_t n_threads, uint64_t max_residue, fd_parsed **out) {
-    if (!out || (n && !paths)) return FDGPU_EINVAL;
-    *out = nullptr;
-    std::vector<Compact> parts(n);
-    std::atomic<uint64_t> next(0);
-    auto work = [&]() {
-        std::string txt;
-        std::vector<Atom> atoms;
-        for (;;) {
-            uint64_t k = next.fetch_add(1);
-            if (k >= n) break;
-            Compact &C = parts[k];
-            if (!paths[k] || !read_all(paths[k], &txt)) continue;
-            atoms.clear();
-            std::string p(paths[k]);
-            if (ends_with_ci(p, ".cif") || ends_with_ci(p, ".cif.gz") || ends_with_ci(p, ".mmcif") || ends_with_ci(p, ".mmcif.gz")) parse_cif(txt, &atoms);
-            else parse_pdb(txt, &atoms, ends_with_ci(p, ".gz"));
-            build_compact(atoms, &C);
-            if (max_residue && C.nres_raw > max_residue) {   // controller/mod.rs:313-318: id kept, no hashes, nres = 0
-                uint64_t raw = C.nres_raw;
-                uint8_t fc = C.first_chain;
-                C = Compact();
-                C.nres_raw = raw; C.first_chain = fc; C.ok = true;
-            }
-        }
-    };
-    // default: every core up to 64 (measured on the 256-thread MI355X host: 19.6 k files/s at 64 threads, 11 k at 256)
-    uint32_t T = n_threads ? n_threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
-    T = (uint32_t)std::min<uint64_t>(T, std::max<uint64_t>(n, 1));
-    std::vector<std::thread> th;
-    for (uint32_t t = 1; t < T; ++t) th.emplace_back(work);
-    work();
-    for (auto &t : th) t.join();
-
+namespace {
+// the packed arrays of fd_parsed from the per-structure Compact parts
+int pack_parsed(const std::vector<Compact> &parts, uint64_t max_residue, fd_parsed **out) {
+    const uint64_t n = parts.size();
     fd_parsed *P = (fd_parsed *)calloc(1, sizeof(fd_parsed));
     if (!P) return FDGPU_ENOMEM;
     uint64_t R = 0;
@@ -403,10 +379,191 @@ extern "C" int fdgpu_parse_structures(const char *const *paths, uint64_t n, uint
     *out = P;
     return FDGPU_OK;
 }
+}  // namespace
+
+extern "C" int fdgpu_parse_structures(const char *const *paths, uint64_t n, uint32_t n_threads, uint64_t max_residue, fd_parsed **out) {
+    if (!out || (n && !paths)) return FDGPU_EINVAL;
+    *out = nullptr;
+    std::vector<Compact> parts(n);
+    std::atomic<uint64_t> next(0);
+    auto work = [&]() {
+        std::string txt;
+        std::vector<Atom> atoms;
+        for (;;) {
+            uint64_t k = next.fetch_add(1);
+            if (k >= n) break;
+            Compact &C = parts[k];
+            if (!paths[k] || !read_all(paths[k], &txt)) continue;
+            atoms.clear();
+            std::string p(paths[k]);
+            if (ends_with_ci(p, ".cif") || ends_with_ci(p, ".cif.gz") || ends_with_ci(p, ".mmcif") || ends_with_ci(p, ".mmcif.gz")) parse_cif(txt, &atoms);
+            else parse_pdb(txt, &atoms, ends_with_ci(p, ".gz"));
+            build_compact(atoms, &C);
+            if (max_residue && C.nres_raw > max_residue) {   // controller/mod.rs:313-318: id kept, no hashes, nres = 0
+                uint64_t raw = C.nres_raw;
+                uint8_t fc = C.first_chain;
+                C = Compact();
+                C.nres_raw = raw; C.first_chain = fc; C.ok = true;
+            }
+        }
+    };
+    // default: every core up to 64 (measured on the 256-thread MI355X host: 19.6 k files/s at 64 threads, 11 k at 256)
+    uint32_t T = n_threads ? n_threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+    T = (uint32_t)std::min<uint64_t>(T, std::max<uint64_t>(n, 1));
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+
+    return pack_parsed(parts, max_residue, out);
+}
 
 extern "C" void fdgpu_parsed_free(fd_parsed *P) {
     if (!P) return;
     free(P->res_off); free(P->n_xyz); free(P->ca_xyz); free(P->cb_xyz); free(P->aa); free(P->cb_valid); free(P->chain); free(P->resname_std);
     free(P->serial); free(P->bfac); free(P->resname); free(P->nres_raw); free(P->plddt); free(P->ok); free(P->first_chain);
     free(P);
+}
+
+
+// ---- Foldcomp input (fd_fcz.cpp) ---------------------------------------------------------------------------------------------------
+// One entry -> its atom records (what foldcomp_process returns to src/structure/io/fcz.rs:82-93); parity-test seam.
+extern "C" int fdgpu_foldcomp_decode(const uint8_t *entry, uint64_t len, fd_foldcomp_atom **atoms, uint64_t *n_atoms) {
+    if (!entry || !atoms || !n_atoms) return FDGPU_EINVAL;
+    *atoms = nullptr; *n_atoms = 0;
+    std::vector<fd_fcz_atom> v;
+    if (fd_fcz_decode(entry, (size_t)len, &v) != 0) return FDGPU_EINVAL;
+    static_assert(sizeof(fd_foldcomp_atom) == sizeof(fd_fcz_atom), "fd_foldcomp_atom layout");
+    fd_foldcomp_atom *o = (fd_foldcomp_atom *)malloc(std::max<size_t>(v.size(), 1) * sizeof(fd_foldcomp_atom));
+    if (!o) return FDGPU_ENOMEM;
+    if (!v.empty()) memcpy(o, v.data(), v.size() * sizeof(fd_foldcomp_atom));
+    *atoms = o; *n_atoms = v.size();
+    return FDGPU_OK;
+}
+
+namespace {
+bool read_file_bytes(const std::string &path, std::string *out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    out->clear();
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
+    fclose(f);
+    return true;
+}
+struct db_ent { uint64_t key, start, len; };
+// DB.index: "key \t start \t length" per line, sorted by key (FoldcompDbReader::new sorts it, fcz.rs:52-54)
+bool read_db_index(const char *db_path, std::vector<db_ent> *idx) {
+    std::string txt;
+    if (!read_file_bytes(std::string(db_path) + ".index", &txt)) return false;
+    size_t pos = 0;
+    while (pos < txt.size()) {
+        size_t e = txt.find('\n', pos);
+        if (e == std::string::npos) e = txt.size();
+        unsigned long long k, s, l;
+        if (sscanf(txt.substr(pos, e - pos).c_str(), "%llu\t%llu\t%llu", &k, &s, &l) == 3) idx->push_back({k, s, l});
+        pos = e + 1;
+    }
+    std::sort(idx->begin(), idx->end(), [](const db_ent &a, const db_ent &b) { return a.key < b.key; });
+    return true;
+}
+}  // namespace
+
+// The entries of a Foldcomp database in ascending key order: keys (DB.index) and names (DB.lookup column 2, '\n'-joined; empty for a
+// key the lookup does not hold).  The reference builds its path vector and db_key vector the same way
+// (cli/workflows/build_index.rs:114-123, fcz.rs:208-219, controller/mod.rs:151).
+extern "C" int fdgpu_foldcomp_db_list(const char *db_path, uint64_t **keys, char **names, uint64_t *n_entries) {
+    if (!db_path || !keys || !names || !n_entries) return FDGPU_EINVAL;
+    *keys = nullptr; *names = nullptr; *n_entries = 0;
+    std::vector<db_ent> idx;
+    std::string lk_txt;
+    if (!read_db_index(db_path, &idx) || !read_file_bytes(std::string(db_path) + ".lookup", &lk_txt)) return FDGPU_EINVAL;
+    std::vector<std::pair<uint64_t, std::string>> lookup;
+    size_t pos = 0;
+    while (pos < lk_txt.size()) {
+        size_t e = lk_txt.find('\n', pos);
+        if (e == std::string::npos) e = lk_txt.size();
+        const std::string line = lk_txt.substr(pos, e - pos);
+        const size_t t1 = line.find('\t');
+        if (t1 != std::string::npos) {
+            const size_t t2 = line.find('\t', t1 + 1);
+            lookup.push_back({strtoull(line.c_str(), nullptr, 10), line.substr(t1 + 1, t2 == std::string::npos ? std::string::npos : t2 - t1 - 1)});
+        }
+        pos = e + 1;
+    }
+    std::sort(lookup.begin(), lookup.end());
+    const uint64_t n = idx.size();
+    uint64_t *k = (uint64_t *)malloc(std::max<uint64_t>(n, 1) * 8);
+    std::string all;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (k) k[i] = idx[i].key;
+        auto it = std::lower_bound(lookup.begin(), lookup.end(), std::make_pair(idx[i].key, std::string()));
+        if (it != lookup.end() && it->first == idx[i].key) all += it->second;
+        all += '\n';
+    }
+    char *nm = (char *)malloc(all.size() + 1);
+    if (!k || !nm) { free(k); free(nm); return FDGPU_ENOMEM; }
+    memcpy(nm, all.c_str(), all.size() + 1);
+    *keys = k; *names = nm; *n_entries = n;
+    return FDGPU_OK;
+}
+
+// Entries of a Foldcomp database (by key, in the order given; n_keys = 0: every entry in ascending key order) -> the packed arrays,
+// like fdgpu_parse_structures: each entry is decoded (fd_fcz.cpp) and passed through CompactStructure::build, which is what
+// FoldcompDbReader::read_single_structure_by_id + to_compact do (fcz.rs:104-126, controller/mod.rs:301-322).  A key that is not in
+// DB.index, or an entry that does not decode, gives a structure with ok = 0 and no residues.
+extern "C" int fdgpu_parse_foldcomp_db(const char *db_path, const uint64_t *keys, uint64_t n_keys, uint32_t n_threads, uint64_t max_residue, fd_parsed **out) {
+    if (!db_path || !out || (n_keys && !keys)) return FDGPU_EINVAL;
+    *out = nullptr;
+    std::vector<db_ent> idx;
+    if (!read_db_index(db_path, &idx)) return FDGPU_EINVAL;
+    int fdesc = open(db_path, O_RDONLY);
+    if (fdesc < 0) return FDGPU_EINVAL;
+    struct stat sb;
+    if (fstat(fdesc, &sb) != 0) { close(fdesc); return FDGPU_EINVAL; }
+    const size_t db_len = (size_t)sb.st_size;
+    const uint8_t *db = db_len ? (const uint8_t *)mmap(nullptr, db_len, PROT_READ, MAP_PRIVATE, fdesc, 0) : nullptr;
+    close(fdesc);
+    if (db_len && db == (const uint8_t *)MAP_FAILED) return FDGPU_EINVAL;
+    const uint64_t n = n_keys ? n_keys : idx.size();
+    std::vector<Compact> parts(n);
+    std::atomic<uint64_t> next{0};
+    auto work = [&]() {
+        std::vector<Atom> atoms;
+        std::vector<fd_fcz_atom> raw;
+        for (;;) {
+            const uint64_t k = next.fetch_add(1);
+            if (k >= n) break;
+            Compact &C = parts[k];
+            const db_ent *e = nullptr;
+            if (n_keys) {
+                auto it = std::lower_bound(idx.begin(), idx.end(), keys[k], [](const db_ent &a, uint64_t key) { return a.key < key; });
+                if (it != idx.end() && it->key == keys[k]) e = &*it;
+            } else e = &idx[k];
+            if (!e || e->start + e->len > db_len) continue;
+            if (fd_fcz_decode(db + e->start, (size_t)e->len, &raw) != 0) continue;
+            atoms.resize(raw.size());
+            for (size_t a = 0; a < raw.size(); ++a) {
+                atoms[a].x = raw[a].x; atoms[a].y = raw[a].y; atoms[a].z = raw[a].z; atoms[a].b = raw[a].b;
+                memcpy(atoms[a].name, raw[a].name, 4); memcpy(atoms[a].res, raw[a].res, 3);
+                atoms[a].chain = raw[a].chain; atoms[a].rser = raw[a].rser;
+            }
+            build_compact(atoms, &C);
+            if (max_residue && C.nres_raw > max_residue) {
+                const uint64_t rawn = C.nres_raw;
+                const uint8_t fc = C.first_chain;
+                C = Compact();
+                C.nres_raw = rawn; C.first_chain = fc; C.ok = true;
+            }
+        }
+    };
+    uint32_t T = n_threads ? n_threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+    T = (uint32_t)std::min<uint64_t>(T, std::max<uint64_t>(n, 1));
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (db_len) munmap((void *)db, db_len);
+    return pack_parsed(parts, max_residue, out);
 }

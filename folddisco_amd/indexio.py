@@ -83,10 +83,11 @@ def load_lookup(path: str):
 
 
 def save_type(path: str, n_structures: int, grid_width: float = 20.0, max_residue: int = 50000, nbin_angle: int = 0, nbin_dist: int = 0,
-              input_format: str = "PDB", hash_type: str = "PDBTrRosetta", multiple_bins=None):
+              input_format: str = "PDB", hash_type: str = "PDBTrRosetta", multiple_bins=None, foldcomp_db=None):
+    """IndexConfig::to_toml (cli/config.rs:66-87): keys in alphabetical order (toml's table is a BTreeMap)"""
     gw = repr(float(grid_width))  # toml prints the f64; 20.0 -> "20.0"
     with open(path, "w") as f:
-        f.write(f"chunk_size = {n_structures}\ngrid_width = {gw}\nhash_type = \"{hash_type}\"\ninput_format = \"{input_format}\"\n"
+        f.write(f"chunk_size = {n_structures}\n" + (f"foldcomp_db = \"{foldcomp_db}\"\n" if foldcomp_db else "") + f"grid_width = {gw}\nhash_type = \"{hash_type}\"\ninput_format = \"{input_format}\"\n"
                 f"max_residue = {max_residue}\n" + (("multiple_bin = [" + ", ".join(f"[{d}, {a}]" for d, a in multiple_bins) + "]\n") if multiple_bins else "") +
                 f"num_bin_angle = {nbin_angle}\nnum_bin_dist = {nbin_dist}\n")
 

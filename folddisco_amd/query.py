@@ -315,7 +315,7 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
               query: CompactStructure, query_string: str, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance=1.0, top_n=None,
               length_penalty_power=0.5, skip_match=False, serial_query=False, freq_filter=None, dist_cutoff=20.0, nbin_dist=0, nbin_angle=0,
               sampling_ratio=None, sampling_count=None, filters=None, sort_by="", shard=None, partial_fit=False, hash_type=3, multiple_bins=None,
-              skip_ca_match=False, match_top_n="same"):
+              skip_ca_match=False, match_top_n="same", db_keys=None):
     """The per-query body of query_pdb (src/cli/workflows/query_pdb.rs:348-519).  shard = dict(lo=first structure id, device=torch
     device or None): `index`, `db` and `db_structs` then cover only structures [lo, lo + len(db_structs)) of the database that
     tids / nres / plddt describe: idf comes from all-reduced posting lengths, the touched-structure records and the
@@ -375,7 +375,7 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
     # residue_count (query_pdb.rs:354-358): the PARSED residues, resolved in the structure or not; all residues for an empty query
     n_expected = np.float32(len(qres) if qres else query.n)
     for r in rows:
-        r.update(tid=tids[r["nid"]], nres=int(nres[r["nid"]]), plddt=float(plddt[r["nid"]]), db_key=r["nid"], matches=[],
+        r.update(tid=tids[r["nid"]], nres=int(nres[r["nid"]]), plddt=float(plddt[r["nid"]]), db_key=r["nid"] if db_keys is None else int(db_keys[r["nid"]]), matches=[],
                  max_matching_node_count=0, min_rmsd_with_max_match=0.0, query_residues=qnorm)
 
     def before(r):   # StructureFilter::filter_before_matching
@@ -423,7 +423,7 @@ def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[C
             m2 = dict(tid=r["tid"], nid=r["nid"], node_count=sum(x >= 0 for x in mres), idf=m["idf"], rmsd=m["rmsd" + sk],
                       matching_residues=",".join(mlab), query_residues=res_chain_to_string(qres) if qres else query_string,
                       tm_score=float(mm[0]), gdt_ts=float(mm[1]), gdt_ha=float(mm[2]),
-                      chamfer_distance=float(mm[3]), hausdorff_distance=float(mm[4]), db_key=r["nid"],
+                      chamfer_distance=float(mm[3]), hausdorff_distance=float(mm[4]), db_key=r["db_key"],
                       u_matrix=m["rot" + sk], t_vector=m["tran" + sk], matching_coordinates=mca)
             r["matches"].append(m2)
             cnt = sum(x >= 0 for x in m["processed"])

@@ -195,17 +195,76 @@ def read_compact_structure(path: str) -> CompactStructure:
     return build_compact(read_atoms(path))
 
 
-def read_compact_structures(paths, threads: int = 0, max_residue: int = 0):
-    """Multi-threaded native ingest (csrc/fd_ingest.cpp, fdgpu_parse_structures): PDB / mmCIF, optionally gzip.
+class FoldcompDb:
+    """A Foldcomp database (DB, DB.index, DB.lookup) as the index / query workflows see it (reference: FoldcompDbReader,
+    src/structure/io/fcz.rs:41-74): entries in ascending key order, `keys` = the db_key column of the index's .lookup,
+    `names` = the structure names.  Decoding happens in csrc/fd_fcz.cpp through fdgpu_parse_foldcomp_db."""
+
+    def __init__(self, path: str):
+        import ctypes as C
+        from . import _lib
+        L = _lib.load()
+        keys, names, n = _lib.u64p(), C.c_void_p(), C.c_uint64()
+        rc = L.fdgpu_foldcomp_db_list(os.fsencode(path), C.byref(keys), C.byref(names), C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"{path}: not a Foldcomp database (DB.index / DB.lookup unreadable, {rc})")
+        self.path = path
+        self.keys = np.ctypeslib.as_array(keys, shape=(max(n.value, 1),))[:n.value].astype(np.uint64, copy=True)
+        txt = C.string_at(names.value).decode("utf-8", "replace")
+        self.names = txt.split("\n")[:n.value]
+        L.fdgpu_free(keys)
+        L.fdgpu_free(names)
+        self._by_name = None
+
+    def __len__(self):
+        return len(self.keys)
+
+    def key_of(self, name: str) -> int:
+        if self._by_name is None:
+            self._by_name = {nm: int(k) for nm, k in zip(self.names, self.keys)}
+        return self._by_name[name]
+
+
+def is_foldcomp_db(path: str) -> bool:
+    """cli/workflows/build_index.rs:109-123: an input that is a FILE (not a directory) is a Foldcomp database"""
+    return os.path.isfile(path) and os.path.isfile(path + ".index") and os.path.isfile(path + ".lookup")
+
+
+def _native_parse(paths, threads, max_residue, foldcomp):
+    """-> POINTER(fd_parsed); paths = file paths, or (with foldcomp = FoldcompDb) database keys"""
+    import ctypes as C
+    from . import _lib
+    L = _lib.load()
+    out = C.POINTER(_lib.Parsed)()
+    if foldcomp is not None:
+        keys = np.ascontiguousarray(paths, np.uint64)
+        if len(keys) == 0:
+            keys = np.zeros(1, np.uint64)
+            out_n = 0
+        else:
+            out_n = len(keys)
+        if out_n == 0:
+            rc = L.fdgpu_parse_structures((C.c_char_p * 1)(), 0, threads, max_residue, C.byref(out))
+        else:
+            rc = L.fdgpu_parse_foldcomp_db(os.fsencode(foldcomp.path), keys.ctypes.data_as(_lib.u64p), out_n, threads, max_residue, C.byref(out))
+        if rc != 0:
+            raise RuntimeError(f"fdgpu_parse_foldcomp_db failed ({rc})")
+        return out
+    arr = (C.c_char_p * max(len(paths), 1))(*[os.fsencode(p) for p in paths])
+    rc = L.fdgpu_parse_structures(arr, len(paths), threads, max_residue, C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"fdgpu_parse_structures failed ({rc})")
+    return out
+
+
+def read_compact_structures(paths, threads: int = 0, max_residue: int = 0, foldcomp=None):
+    """Multi-threaded native ingest (csrc/fd_ingest.cpp, fdgpu_parse_structures): PDB / mmCIF, optionally gzip — or, with
+    foldcomp = FoldcompDb, the database entries whose keys are given (fdgpu_parse_foldcomp_db).
     -> (list of CompactStructure, ok flags).  Same arrays, bit for bit, as read_compact_structure()."""
     import ctypes as C
     from . import _lib
     L = _lib.load()
-    arr = (C.c_char_p * max(len(paths), 1))(*[os.fsencode(p) for p in paths])
-    out = C.POINTER(_lib.Parsed)()
-    rc = L.fdgpu_parse_structures(arr, len(paths), threads, max_residue, C.byref(out))
-    if rc != 0:
-        raise RuntimeError(f"fdgpu_parse_structures failed ({rc})")
+    out = _native_parse(paths, threads, max_residue, foldcomp)
     P = out.contents
     S, R = P.n_struct, P.n_res
     view = lambda ptr, n, dt: (np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].astype(dt, copy=True))
@@ -225,18 +284,15 @@ def read_compact_structures(paths, threads: int = 0, max_residue: int = 0):
     return res, okf
 
 
-def read_packed(paths, threads: int = 0, max_residue: int = 0):
+def read_packed(paths, threads: int = 0, max_residue: int = 0, foldcomp=None):
     """Native ingest straight into the flat batch layout (no per-structure Python objects): -> (PackedStructures, nres u64[S],
-    plddt f32[S], nres_raw u64[S], ok u8[S]).  What the index workflow needs: coordinates for the GPU, nres / plddt for .lookup."""
+    plddt f32[S], nres_raw u64[S], ok u8[S]).  What the index workflow needs: coordinates for the GPU, nres / plddt for .lookup.
+    With foldcomp = FoldcompDb, paths are database keys."""
     import ctypes as C
     from . import _lib
     from .api import PackedStructures
     L = _lib.load()
-    arr = (C.c_char_p * max(len(paths), 1))(*[os.fsencode(p) for p in paths])
-    out = C.POINTER(_lib.Parsed)()
-    rc = L.fdgpu_parse_structures(arr, len(paths), threads, max_residue, C.byref(out))
-    if rc != 0:
-        raise RuntimeError(f"fdgpu_parse_structures failed ({rc})")
+    out = _native_parse(paths, threads, max_residue, foldcomp)
     P = out.contents
     S, R = P.n_struct, P.n_res
     view = lambda ptr, n, dt: (np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].astype(dt, copy=True))

@@ -345,6 +345,26 @@ typedef struct fd_parsed {
 int fdgpu_parse_structures(const char *const *paths, uint64_t n, uint32_t n_threads, uint64_t max_residue, fd_parsed **out);
 void fdgpu_parsed_free(fd_parsed *p);
 
+/* Foldcomp input (reference: src/structure/io/fcz.rs — FoldcompDbReader::new :41-74, read_single_structure_by_id :203-230,
+ * and the vendored decoder behind foldcomp_process, lib/foldcomp/foldcompffi.cpp).  fdgpu_foldcomp_decode turns one database
+ * entry into the atom records the reference's Structure::update receives (coordinates bit-identical to the vendored decoder's:
+ * backbone rebuilt from the stored torsion/bond angles forward and backward between anchors, O / CB / side chain placed from
+ * them; atoms past CB carry their names but no coordinates — nothing on this path reads them).  fdgpu_foldcomp_db_list gives the
+ * entries of DB.index in ascending key order (keys = the db_key column of the index's .lookup output; names from DB.lookup, joined
+ * by '\n'; both released with fdgpu_free).  fdgpu_parse_foldcomp_db decodes the entries with the given keys (n_keys = 0: all, in
+ * key order) and returns the same packed arrays as fdgpu_parse_structures. */
+typedef struct fd_foldcomp_atom {
+    float x, y, z, b;                /* coordinate, temperature factor (per-residue in Foldcomp) */
+    char name[4];                    /* PDB-style padded atom name (" CA ", " OXT") */
+    char res[3];                     /* residue name */
+    uint8_t chain;
+    uint64_t rser;                   /* residue serial: header.idx_residue + position */
+} fd_foldcomp_atom;
+int fdgpu_foldcomp_decode(const uint8_t *entry, uint64_t len, fd_foldcomp_atom **atoms, uint64_t *n_atoms);
+int fdgpu_foldcomp_db_list(const char *db_path, uint64_t **keys, char **names, uint64_t *n_entries);
+int fdgpu_parse_foldcomp_db(const char *db_path, const uint64_t *keys, uint64_t n_keys, uint32_t n_threads, uint64_t max_residue,
+                            fd_parsed **out);
+
 /* ---- merging per-GPU / per-batch sub-indices into the reference's single index ----------------------------
  * Parts must cover ascending, disjoint id ranges in the order given (index build shards by structure).  Output is
  * the on-disk layout (value bytes, sparse hashes, offsets[H+1]); host-side, buffers released with fdgpu_free. */

@@ -15,6 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libfdoracle.so")
+_REF_FOLDCOMP = os.path.join(_HERE, "_ref", "libfoldcomp_ref.so")
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
@@ -29,6 +30,8 @@ def build(force: bool = False) -> str:
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
+    if os.path.isdir("/root/reference/lib/foldcomp") and not os.path.exists(_REF_FOLDCOMP):
+        subprocess.call(["make", "-C", _HERE, "-s", "ref"])      # the reference's own Foldcomp decoder (oracle/_ref), where the tree exists
     return _LIB_PATH
 
 
@@ -541,3 +544,37 @@ class BorrowedIndex(OIndex):
             lib().fdo_index_free_borrowed(self.ptr)
         except Exception:
             pass
+
+
+class _AtomT(C.Structure):      # lib/foldcomp/foldcompffi.h atom_t
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("atom", C.c_char * 4), ("atomIdx", C.c_uint64), ("chain", C.c_char),
+                ("aa", C.c_char * 3), ("resIdx", C.c_uint64), ("bfactor", C.c_float)]
+
+
+FCZ_ATOM_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("z", np.float32), ("b", np.float32), ("name", "S4"), ("res", "S3"), ("chain", np.uint8),
+                           ("rser", np.uint64)])
+
+
+def foldcomp_ref_available() -> bool:
+    return os.path.exists(_REF_FOLDCOMP)
+
+
+def foldcomp_ref_decode(entry: bytes) -> np.ndarray:
+    """the REFERENCE's Foldcomp decoder (oracle/_ref/libfoldcomp_ref.so = lib/foldcomp built as it lies): foldcomp_create /
+    foldcomp_process / foldcomp_free / foldcomp_destroy exactly as src/structure/io/fcz.rs:82-93 calls them -> FCZ_ATOM_DTYPE records"""
+    L = C.CDLL(_REF_FOLDCOMP)
+    L.foldcomp_create.restype = C.c_void_p
+    L.foldcomp_process.restype = C.POINTER(_AtomT)
+    L.foldcomp_process.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.foldcomp_free.argtypes = [C.POINTER(_AtomT)]
+    L.foldcomp_destroy.argtypes = [C.c_void_p]
+    inst = L.foldcomp_create()
+    n = C.c_size_t()
+    p = L.foldcomp_process(inst, entry, len(entry), C.byref(n))
+    out = np.zeros(n.value, FCZ_ATOM_DTYPE)
+    for k in range(n.value):
+        a = p[k]
+        out[k] = (a.x, a.y, a.z, a.bfactor, bytes(a.atom), bytes(a.aa), a.chain[0], a.resIdx)
+    L.foldcomp_free(p)
+    L.foldcomp_destroy(inst)
+    return out

@@ -944,3 +944,55 @@ def test_analyze_enrichment_against_restatement(tmp_path):
     for r in qrow:
         s = paths.index(r[0])
         assert all(cnt[(s, pos)] > 2 for pos in r[1].split(","))
+
+
+@pytest.mark.gpu
+def test_cli_index_and_query_from_foldcomp_database(tmp_path):
+    """`index -p <Foldcomp DB>` (cli/workflows/build_index.rs:109-123): entries in key order, names from DB.lookup, db_key column,
+    .type naming the database; the index equals the oracle's over the same decoded structures (decoder pinned against the reference's
+    own in tests/test_foldcomp.py); the query reads the hit coordinates back from the database by db_key and accepts DB:NAME as the
+    query structure (controller/io.rs:303-333)."""
+    import shutil
+    import subprocess
+    import sys
+    from folddisco_amd import indexio
+    from folddisco_amd import structure as st
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "foldcomp")
+    d = tmp_path / "data"
+    d.mkdir()
+    for ext in ("", ".index", ".lookup", ".dbtype"):
+        shutil.copy(os.path.join(g, "example_db" + ext), d / ("scop_foldcomp" + ext))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    subprocess.check_call([sys.executable, "-m", "folddisco_amd", "index", "-p", "data/scop_foldcomp", "-t", "4"], cwd=tmp_path, env=env)
+    pre = str(d / "scop_folddisco")                       # X_foldcomp -> X_folddisco (controller/io.rs:460-470)
+    fc = st.FoldcompDb(str(d / "scop_foldcomp"))
+    tids, nres, plddt, keys = indexio.load_lookup(pre + ".lookup")
+    assert tids == fc.names and keys.tolist() == fc.keys.tolist()
+    cfg = indexio.load_type(pre + ".type")
+    assert cfg["input_format"] == "FCZDB" and cfg["foldcomp_db"] == "data/scop_foldcomp" and cfg["chunk_size"] == 24
+    structs, ok = st.read_compact_structures(fc.keys, threads=4, foldcomp=fc)
+    assert ok.all() and nres.tolist() == [s.n for s in structs]
+    import folddisco_amd as fd
+    ostructs = packed_to_oracle_structs(fd.PackedStructures.concat([s.as_item() for s in structs]))
+    oix, onres, oplddt = oracle.build_index(ostructs)
+    v, h, o = indexio.read_index_files(pre)
+    assert np.array_equal(h, oix.hashes()) and np.array_equal(o, oix.offsets()) and np.array_equal(v, oix.values())
+    assert np.array_equal(plddt, np.array([np.float32(indexio.format_f32_display(s.avg_plddt())) for s in structs], np.float32))
+    # chunked build over the database: byte-identical files
+    pre2 = str(tmp_path / "chunked")
+    subprocess.check_call([sys.executable, "-m", "folddisco_amd", "index", "-p", "data/scop_foldcomp", "-i", pre2, "--chunk", "7"], cwd=tmp_path, env=env)
+    for ext in ("", ".offset", ".lookup", ".type"):
+        assert open(pre + ext, "rb").read() == open(pre2 + ext, "rb").read(), ext
+    # query: an entry of the database against the index built from it — itself first, all residues, RMSD 0, db_key printed
+    s0 = structs[3]
+    pick = [0, 5, 9]
+    qstr = ",".join(f"{chr(s0.chain[i])}{int(s0.serial[i])}" for i in pick)
+    out = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", f"data/scop_foldcomp:{fc.names[3]}", "-q", qstr, "-i", pre,
+                          "--format-output", "tid,db_key,node_count,rmsd,matching_residues"], cwd=tmp_path, env=env, capture_output=True, text=True,
+                         check=True).stdout.splitlines()
+    assert out[0] == f"{fc.names[3]}\t{int(fc.keys[3])}\t3\t0.0000\t{qstr}"
+    ps = subprocess.run([sys.executable, "-m", "folddisco_amd", "query", "-p", f"data/scop_foldcomp:{fc.names[3]}", "-q", qstr, "-i", pre, "--per-structure"],
+                        cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
+    f = ps[0].split("\t")
+    assert f[0] == fc.names[3] and f[10] == str(int(fc.keys[3])) and f[9].startswith(qstr + ":0.0000")
