@@ -412,8 +412,8 @@ def count_query_batch(ctx: Context, index: FolddiscoIndex, queries, penalty: np.
                       top_n: int = 0, lengths_fn=None):
     """queries: list of (q_hash, q_node, q_edge_j) arrays.  One posting-length launch + one scoring pass for the whole
     batch.  Returns a list of REC_DTYPE arrays, one per query: every touched structure in ascending nid, or with top_n > 0
-    only the records that can be among the top_n by idf (ties of the cut-off included, unordered; rank them with
-    dist.rank_hits)."""
+    the top_n records ranked like the candidate selection (idf descending, ties by ascending nid — selected and sorted on the
+    device, what dist.rank_hits(recs, top_n) gives on the full list)."""
     S = index.n_structures if total_structures is None else total_structures
     qh = np.ascontiguousarray(np.concatenate([np.asarray(q[0], np.uint32) for q in queries]) if queries else np.zeros(0, np.uint32))
     qn = np.ascontiguousarray(np.concatenate([np.asarray(q[1], np.uint32) for q in queries]) if queries else np.zeros(0, np.uint32))

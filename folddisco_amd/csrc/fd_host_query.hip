@@ -488,10 +488,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         fd_pair_rec *&f; fd_cand_rec *&c; uint32_t *&k, *&v;
         ~HostBufs() { free(f); free(c); free(k); free(v); }
     } host_bufs{found, cands, pk_key, pk_val};
-    int rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc, two_pass ? 1u : 15u,
-                                  nullptr, nullptr, 0, &pk_key, &pk_val);
-    if (rc) return rc;
-    auto T1 = t_now();
+    int rc = 0;
     // symmetry flags (geometry/pdb_tr.rs:158-162): aa equal and atan2(sin, cos) of the two torsion fields equal; the other encodings
     // compare their residue fields and (Folddisco*) torsion fields (pdb_motif.rs:98, pdb_motif_sincos.rs:105, folddisco_angle.rs:133,
     // folddisco_dist.rs:126)
@@ -528,6 +525,150 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         float p1 = atan2f(cont((h >> 6) & 3), cont((h >> 4) & 3)) * D, p2 = atan2f(cont((h >> 2) & 3), cont(h & 3)) * D;
         return ((h >> 25) & 31u) == ((h >> 20) & 31u) && p1 == p2;
     };
+    // ---- device glue (k_retrieve.hip): the scan output never leaves the GPU — per-slot grouping, graph / components / votes /
+    // assignment / rescue one wavefront per candidate, superposition and metrics on the problems it wrote, then ONE copy of the match
+    // records back.  Taken for motif-sized queries (<= 64 query residues, single scan, no --partial-fit); a candidate beyond the
+    // kernel's limits (64 graph nodes, 1024 found triples) raises a flag and the whole call takes the host path below instead.
+    uint64_t max_nq = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) max_nq = std::max<uint64_t>(max_nq, qms[t]->n_indices);
+    const char *hg_env = getenv("FDGPU_HOST_GLUE");      // 1 forces the host path (tests compare the two)
+    const bool dev_glue = !(hg_env && hg_env[0] == '1') && !two_pass && !partial_fit && max_nq <= FD_WAVE && max_nq > 0 && n_cand > 0 && n_cand < (1ull << 24);
+    if (dev_glue) {
+        uint64_t nf_d = 0, nc_d = 0;
+        fd_pair_rec *f_none = nullptr; fd_cand_rec *c_none = nullptr;
+        rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &f_none, &nf_d, &c_none, &nc_d, 19u);
+        if (rc) return rc;
+        auto D1 = t_now();
+        hipStream_t st = c->stream;
+        // tables: one packed host block -> one copy
+        std::vector<rs_query_dev> qt(n_queries);
+        std::vector<uint32_t> t_hash, t_kfirst, t_sym, t_qi, t_qj, t_idf, t_idx;
+        for (uint64_t t = 0; t < n_queries; ++t) {
+            const fd_query_map *m = qms[t];
+            rs_query_dev &Q = qt[t];
+            memset(&Q, 0, sizeof Q);
+            Q.qh_off = (uint32_t)t_hash.size(); Q.n_hashes = (uint32_t)qhs[t].size();
+            for (uint32_t h : qhs[t]) { t_hash.push_back(h); t_kfirst.push_back(entries[t].at(h)); t_sym.push_back(is_sym(h) ? 1u : 0u); }
+            Q.map_off = (uint32_t)t_qi.size();
+            for (uint64_t k = 0; k < m->n; ++k) { t_qi.push_back(m->qi[k]); t_qj.push_back(m->qj[k]); uint32_t w; memcpy(&w, &m->idf[k], 4); t_idf.push_back(w); }
+            Q.idx_off = (uint32_t)t_idx.size(); Q.n_idx = (uint32_t)m->n_indices;
+            t_idx.insert(t_idx.end(), m->indices, m->indices + m->n_indices);
+            Q.q_size = q_sizes[t];
+            Q.q_res0 = (uint32_t)qb->h_res_off[q_struct[t]];
+        }
+        std::vector<uint32_t> t_slotq(n_cand);
+        for (uint64_t t = 0; t < n_queries; ++t) for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) t_slotq[k] = (uint32_t)t;
+        float d0tab[2 * FD_WAVE + 1];
+        for (int len = 0; len <= 2 * FD_WAVE; ++len) d0tab[len] = len > 21 ? 1.24f * powf((float)len - 15.0f, 1.0f / 3.0f) - 1.8f : 0.5f;   // metrics.rs:117-123
+        auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
+        const size_t nh = t_hash.size(), nmap = t_qi.size(), nidx = t_idx.size();
+        const size_t o_qt = 0, o_h = o_qt + up4(n_queries * (sizeof(rs_query_dev) / 4)), o_kf = o_h + up4(nh), o_sy = o_kf + up4(nh), o_qi = o_sy + up4((nh + 3) / 4),
+                     o_qj = o_qi + up4(nmap), o_idf = o_qj + up4(nmap), o_idx = o_idf + up4(nmap), o_sq = o_idx + up4(nidx), o_cd = o_sq + up4(n_cand),
+                     o_d0 = o_cd + up4(n_cand), words = o_d0 + up4(2 * FD_WAVE + 1) + 4;
+        std::vector<uint32_t> blk(words, 0);
+        memcpy(&blk[o_qt], qt.data(), n_queries * sizeof(rs_query_dev));
+        if (nh) { memcpy(&blk[o_h], t_hash.data(), nh * 4); memcpy(&blk[o_kf], t_kfirst.data(), nh * 4); }
+        for (size_t k = 0; k < nh; ++k) ((uint8_t *)&blk[o_sy])[k] = (uint8_t)t_sym[k];
+        if (nmap) { memcpy(&blk[o_qi], t_qi.data(), nmap * 4); memcpy(&blk[o_qj], t_qj.data(), nmap * 4); memcpy(&blk[o_idf], t_idf.data(), nmap * 4); }
+        if (nidx) memcpy(&blk[o_idx], t_idx.data(), nidx * 4);
+        memcpy(&blk[o_sq], t_slotq.data(), n_cand * 4);
+        memcpy(&blk[o_cd], cand, n_cand * 4);
+        memcpy(&blk[o_d0], d0tab, sizeof d0tab);
+        const uint64_t cap_m = std::max<uint64_t>(4096, 4 * n_cand), cap_prob = 2 * cap_m, cap_res = cap_m * 2 * max_nq, cap_pts = cap_prob * 2 * FD_WAVE;
+        HIPCHK(c, c->ws[WS_RS_TAB].ensure(words * 4));
+        HIPCHK(c, c->ws[WS_RS_SEG].ensure((6 * (n_cand + 1) + nf_d + nc_d + 4) * 4));
+        HIPCHK(c, c->ws[WS_RS_OUT].ensure(cap_m * sizeof(rs_match_dev)));
+        HIPCHK(c, c->ws[WS_RS_RES].ensure(cap_res * 4));
+        HIPCHK(c, c->ws[WS_RS_KX].ensure(cap_pts * 12));
+        HIPCHK(c, c->ws[WS_RS_KY].ensure(cap_pts * 12));
+        HIPCHK(c, c->ws[WS_RS_KOFF].ensure((cap_prob + 1) * 8 + cap_prob * 4));
+        HIPCHK(c, c->ws[WS_RS_SOL].ensure(cap_prob * 18 * 4));
+        HIPCHK(c, c->ws[WS_RS_CNT].ensure(64));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_RS_TAB].p, blk.data(), words * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_RS_CNT].p, 0, 64, st));
+        const uint32_t *dblk = c->ws[WS_RS_TAB].as<uint32_t>();
+        uint32_t *sg = c->ws[WS_RS_SEG].as<uint32_t>();
+        uint32_t *d_cnt = sg, *d_seg = sg + 2 * (n_cand + 1), *d_cur = sg + 4 * (n_cand + 1), *d_pf = sg + 6 * (n_cand + 1), *d_pc = d_pf + nf_d;
+        const fd_pair_rec *d_found = c->ws[WS_KEYS_A].as<fd_pair_rec>();
+        const fd_cand_rec *d_cands = c->ws[WS_KEYS_B].as<fd_cand_rec>();
+        fd_launch_rs_group(d_found, nf_d, d_cands, nc_d, (uint32_t)n_cand, d_cnt, d_seg, d_cur, d_pf, d_pc, st);
+        rs_args A;
+        memset(&A, 0, sizeof A);
+        A.found = d_found; A.cands = d_cands; A.seg_f = d_seg; A.seg_c = d_seg + (n_cand + 1); A.perm_f = d_pf; A.perm_c = d_pc;
+        A.cand = dblk + o_cd; A.slot_q = dblk + o_sq;
+        A.db_res_off = db->res_off; A.db_ca = db->ca_xyz; A.db_cb = db->cb_xyz; A.q_ca = qb->ca_xyz; A.q_cb = qb->cb_xyz;
+        A.qt = (const rs_query_dev *)(dblk + o_qt); A.hashes = dblk + o_h; A.kfirst = dblk + o_kf; A.sym = (const uint8_t *)(dblk + o_sy);
+        A.map_qi = dblk + o_qi; A.map_qj = dblk + o_qj; A.map_idf = (const float *)(dblk + o_idf); A.indices = dblk + o_idx;
+        A.d0tab = (const float *)(dblk + o_d0); A.node_count = node_count;
+        A.counters = c->ws[WS_RS_CNT].as<unsigned long long>(); A.flags = (uint32_t *)(A.counters + 4);
+        A.matches = c->ws[WS_RS_OUT].as<rs_match_dev>(); A.residues = c->ws[WS_RS_RES].as<int32_t>();
+        A.kx = c->ws[WS_RS_KX].as<float>(); A.ky = c->ws[WS_RS_KY].as<float>();
+        A.koff = c->ws[WS_RS_KOFF].as<uint64_t>(); A.d0 = (float *)(A.koff + cap_prob + 1);
+        A.cap_matches = cap_m; A.cap_res = cap_res; A.cap_prob = cap_prob; A.cap_pts = cap_pts;
+        {
+            StageTimer tm(c, "retrieve_slots", 0);
+            fd_launch_rs_slots(A, (uint32_t)n_cand, st);
+        }
+        HIPCHK(c, hipGetLastError());
+        unsigned long long cnt_h[5] = {0, 0, 0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(cnt_h, c->ws[WS_RS_CNT].p, 40, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        const uint32_t dflags = (uint32_t)cnt_h[4];
+        auto D2 = t_now();
+        if (dflags == 0) {
+            const uint64_t nm = cnt_h[0], nprob = cnt_h[1] >> 40, npts = cnt_h[1] & ((1ull << 40) - 1ull), nres = cnt_h[2];
+            std::vector<rs_match_dev> hm(std::max<uint64_t>(nm, 1));
+            std::vector<int32_t> hres(std::max<uint64_t>(nres, 1));
+            std::vector<float> sol(std::max<uint64_t>(nprob, 1) * 18);
+            if (nprob) {
+                float *d_rmsd = c->ws[WS_RS_SOL].as<float>(), *d_rot = d_rmsd + nprob, *d_tran = d_rot + 9 * nprob, *d_met = d_tran + 3 * nprob;
+                HIPCHK(c, hipMemcpyAsync(A.koff + nprob, &npts, 8, hipMemcpyHostToDevice, st));
+                fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd, d_rot, d_tran, st);
+                fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot, d_tran, A.d0, d_met, st);
+                HIPCHK(c, hipGetLastError());
+                HIPCHK(c, hipMemcpyAsync(sol.data(), d_rmsd, nprob * 18 * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipMemcpyAsync(hm.data(), A.matches, nm * sizeof(rs_match_dev), hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipMemcpyAsync(hres.data(), A.residues, nres * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+            }
+            const float *h_rmsd = sol.data(), *h_rot = h_rmsd + nprob, *h_tran = h_rot + 9 * nprob, *h_met = h_tran + 3 * nprob;
+            std::vector<uint32_t> order(nm);
+            for (uint64_t k = 0; k < nm; ++k) order[k] = (uint32_t)k;
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hm[a].slot != hm[b].slot ? hm[a].slot < hm[b].slot : hm[a].ci < hm[b].ci; });
+            uint64_t tot_res = 0;
+            for (uint64_t k = 0; k < nm; ++k) tot_res += 2 * qms[t_slotq[hm[k].slot]]->n_indices;
+            fd_match_rec *om = (fd_match_rec *)malloc(std::max<size_t>(nm, 1) * sizeof(fd_match_rec));
+            int32_t *orr = (int32_t *)malloc(std::max<size_t>(tot_res, 1) * sizeof(int32_t));
+            uint64_t *omo = (uint64_t *)malloc((n_queries + 1) * 8), *oro = (uint64_t *)malloc((n_queries + 1) * 8);
+            if (!om || !orr || !omo || !oro) { free(om); free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
+            uint64_t tq = 0, rpos = 0;
+            omo[0] = 0; oro[0] = 0;
+            for (uint64_t k = 0; k < nm; ++k) {
+                const rs_match_dev &m = hm[order[k]];
+                while (m.slot >= cand_off[tq + 1]) { ++tq; omo[tq] = k; oro[tq] = rpos; }
+                fd_match_rec &r = om[k];
+                memset(&r, 0, sizeof r);
+                r.cand = (uint32_t)(m.slot - cand_off[tq]); r.same = m.same; r.idf = m.idf;
+                const uint32_t pf = m.prob0, po = m.same ? m.prob0 : m.prob1;
+                r.rmsd_from_hash = h_rmsd[pf]; memcpy(r.rot_from_hash, h_rot + 9 * pf, 36); memcpy(r.tran_from_hash, h_tran + 3 * pf, 12);
+                memcpy(r.metrics_from_hash, h_met + 5 * pf, 20);
+                r.rmsd = h_rmsd[po]; memcpy(r.rot, h_rot + 9 * po, 36); memcpy(r.tran, h_tran + 3 * po, 12); memcpy(r.metrics, h_met + 5 * po, 20);
+                const uint64_t nq2 = 2 * qms[tq]->n_indices;
+                memcpy(orr + rpos, hres.data() + m.res_pos, nq2 * 4);
+                rpos += nq2;
+            }
+            while (tq < n_queries) { ++tq; omo[tq] = nm; oro[tq] = rpos; }
+            if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue: scan %.3f ms (found %llu, cands %llu), group+slots %.3f, superpose+copy+assemble(%llu) %.3f\n",
+                               t_ms(T0, D1), (unsigned long long)nf_d, (unsigned long long)nc_d, t_ms(D1, D2), (unsigned long long)nprob, t_ms(D2, t_now()));
+            *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
+            return FDGPU_OK;
+        }
+        if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue declined (flags %u): host path\n", dflags);
+    }
+    rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc, two_pass ? 1u : 15u,
+                              nullptr, nullptr, 0, &pk_key, &pk_val);
+    if (rc) return rc;
+    auto T1 = t_now();
     // per candidate: graph -> components -> vote -> rescue; Kabsch problems collected for one GPU batch
     std::vector<fd_match_rec> recs;
     std::vector<int32_t> res;               // 2 * NQ per match: from_hash then processed target residue index (-1 = none)

@@ -1005,6 +1005,17 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
 
 // batched count_query: queries [q_off[t], q_off[t+1]) of the concatenated hash arrays; results of query t are
 // (*out)[(*out_off)[t] .. (*out_off)[t+1])
+// idf descending, ties by ascending structure id (the candidate ranking of query_pdb.rs:404-411), cut to top_n; -> records kept
+static uint64_t fd_rank_trim(fd_count_rec *r, uint64_t n, uint32_t top_n) {
+    auto key = [](const fd_count_rec &x) {
+        float v = x.idf + 0.0f;
+        uint32_t b; memcpy(&b, &v, 4);
+        const uint32_t o = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+        return ((uint64_t)(~o) << 32) | x.nid;
+    };
+    std::sort(r, r + n, [&](const fd_count_rec &a, const fd_count_rec &b) { return key(a) < key(b); });
+    return std::min<uint64_t>(n, top_n);
+}
 static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                                   const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
                                   fd_count_rec **out, uint64_t **out_off) {
@@ -1105,9 +1116,12 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
         // per-query preselection of the top_n by idf on the device (k_cq_topn); a query whose threshold bin overflows the
         // fixed-stride output falls back to its full list
         const uint32_t cap = top_n + 1024;
+        const bool dev_sort = cap <= 4096;          // k_topn_sort ranks and cuts on the device: only top_n records per query cross the bus
+        const uint32_t stride = dev_sort ? top_n : cap;
         std::vector<uint32_t> cnt(n_queries);
-        std::vector<fd_count_rec> sel((size_t)n_queries * cap);
+        std::vector<fd_count_rec> sel((size_t)n_queries * stride);
         e = c->ws[WS_KEYS_A].ensure((size_t)n_queries * cap * sizeof(fd_count_rec));
+        if (e == hipSuccess && dev_sort) e = c->ws[WS_KEYS_B].ensure((size_t)n_queries * top_n * sizeof(fd_count_rec));
         const size_t topn_bytes = (size_t)n_queries * 2048 * 4;
         if (e == hipSuccess && c->ws[WS_CQ_TOPN].cap < topn_bytes) {     // histogram table: zeroed when (re)allocated, the kernels leave it zero
             e = c->ws[WS_CQ_TOPN].ensure(topn_bytes);
@@ -1118,28 +1132,31 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
         if (e == hipSuccess) {
             fd_launch_cq_topn(c->ws[WS_TILE_HO].p, c->ws[WS_TILE_PO].as<uint64_t>(), (uint32_t)n_queries, top_n, cap, c->ws[WS_KEYS_A].p, c->ws[WS_MISC2].p,
                               c->ws[WS_CQ_TOPN].as<uint32_t>(), st);
+            if (dev_sort) fd_launch_cq_topn_sort(c->ws[WS_KEYS_A].p, cap, c->ws[WS_MISC2].p, (uint32_t)n_queries, top_n, c->ws[WS_KEYS_B].p, st);
             e = hipMemcpyAsync(tstate.data(), c->ws[WS_MISC2].p, n_queries * 16, hipMemcpyDeviceToHost, st);
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(sel.data(), c->ws[WS_KEYS_A].p, sel.size() * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(sel.data(), dev_sort ? c->ws[WS_KEYS_B].p : c->ws[WS_KEYS_A].p, sel.size() * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) { free(ooff); c->err = std::string("count_query_batch: ") + hipGetErrorString(e); return FDGPU_EHIP; }
         for (uint64_t t = 0; t < n_queries; ++t) cnt[t] = tstate[4 * t + 3];
         uint64_t tot = 0;
-        for (uint64_t t = 0; t < n_queries; ++t) tot += cnt[t] <= cap ? cnt[t] : (ooff[t + 1] - ooff[t]);
+        for (uint64_t t = 0; t < n_queries; ++t) tot += cnt[t] <= cap ? (dev_sort ? std::min<uint32_t>(cnt[t], top_n) : cnt[t]) : (ooff[t + 1] - ooff[t]);
         r = (fd_count_rec *)malloc(std::max<uint64_t>(tot, 1) * sizeof(fd_count_rec));
         if (!r) { free(ooff); return FDGPU_ENOMEM; }
         std::vector<uint64_t> noff(n_queries + 1, 0);
         for (uint64_t t = 0; t < n_queries; ++t) {
             if (cnt[t] <= cap) {
-                memcpy(r + noff[t], sel.data() + (size_t)t * cap, (size_t)cnt[t] * sizeof(fd_count_rec));
-                noff[t + 1] = noff[t] + cnt[t];
+                uint64_t m = dev_sort ? std::min<uint32_t>(cnt[t], top_n) : cnt[t];
+                memcpy(r + noff[t], sel.data() + (size_t)t * stride, (size_t)m * sizeof(fd_count_rec));
+                if (!dev_sort) m = fd_rank_trim(r + noff[t], m, top_n);
+                noff[t + 1] = noff[t] + m;
             } else {
                 uint64_t m = ooff[t + 1] - ooff[t];
                 if (hipMemcpy(r + noff[t], (const fd_count_rec *)c->ws[WS_TILE_HO].p + ooff[t], m * sizeof(fd_count_rec), hipMemcpyDeviceToHost) != hipSuccess) {
                     free(r); free(ooff); c->err = "count_query_batch: fallback copy failed"; return FDGPU_EHIP;
                 }
-                noff[t + 1] = noff[t] + m;
+                noff[t + 1] = noff[t] + fd_rank_trim(r + noff[t], m, top_n);
             }
         }
         memcpy(ooff, noff.data(), (n_queries + 1) * 8);
@@ -1150,6 +1167,15 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { free(r); free(ooff); c->err = std::string("count_query_batch: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+    if (top_n > 0) {     // few records: ranked and cut on the host, same contract as the device selection
+        uint64_t w = 0;
+        for (uint64_t t = 0; t < n_queries; ++t) {
+            const uint64_t a = ooff[t], m = fd_rank_trim(r + a, ooff[t + 1] - a, top_n);
+            if (w != a) memmove(r + w, r + a, m * sizeof(fd_count_rec));
+            ooff[t] = w; w += m;
+        }
+        ooff[n_queries] = w;
+    }
     *out = r; *out_off = ooff;
     return FDGPU_OK;
 }
@@ -1158,8 +1184,8 @@ extern "C" int fdgpu_count_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, uint
                                        fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
     return count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, 0, out, out_off);
 }
-// as above, but per query only the records that can be among the top_n by idf are returned (every record whose idf is >= the
-// top_n-th largest, in no particular order): the candidate selection of query_pdb.rs:404-411 sorts that short list
+// as above, but per query only the top_n records come back, RANKED as the candidate selection of query_pdb.rs:404-411 ranks them (idf
+// descending, ties by ascending structure id): radix selection + LDS bitonic sort on the device, top_n records per query over the bus
 extern "C" int fdgpu_count_query_batch_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                                            const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty,
                                            uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
@@ -1294,6 +1320,9 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         if (tot[0] <= A.cap_found && tot[1] <= A.cap_cands) break;
         if (attempt == 2) FAIL(c, FDGPU_ERANGE, "match_pairs: output did not fit after regrowing");
     }
+    // mode bit 4: the records stay on the device (ws[WS_KEYS_A] = found triples, ws[WS_KEYS_B] = candidate pairs, in append order) for
+    // the device-side retrieval glue (k_retrieve.hip); only the counts return
+    if (mode & 16u) { *n_found = tot[0]; *n_cands = tot[1]; return FDGPU_OK; }
     // mode bit 3 (with pk_key / pk_val): the candidate pairs come back packed — key = slot << 16 | partner residue j, value =
     // query residue << 16 | residue i — and sorted by key on the device: half the bytes over PCIe and no bucketing on the host
     // (the rescue walks the pairs of one partner residue at a time).  Needs slots, residues and query residues below 2^16.

@@ -34,6 +34,7 @@ enum {
     WS_COUNTS, WS_CURSOR, WS_SEGOFF, WS_SCANTMP, WS_TOTAL, WS_KEYS_A, WS_IDS_A, WS_KEYS_B, WS_IDS_B, WS_GHIST, WS_TOT,
     WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
+    WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT,
     WS_COUNT
 };
 
@@ -234,8 +235,38 @@ void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, cons
                                 const float *penalty, uint64_t total, void *out, hipStream_t st);
 void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries, uint32_t top_n, uint32_t cap, void *out, void *state, uint32_t *ghist,
                        hipStream_t st);
+void fd_launch_cq_topn_sort(const void *sel, uint32_t cap, const void *state, uint32_t n_queries, uint32_t top_n, void *out, hipStream_t st);
 void fd_launch_get_entries(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash, uint64_t nq,
                            const uint64_t *out_off, uint32_t *out, hipStream_t st);
+// k_retrieve.hip: retrieval glue on the device (graph -> components -> votes -> assignment -> rescue -> superposition problems)
+struct rs_query_dev {
+    uint32_t qh_off, n_hashes;   // sorted unique hashes of the query: hashes[qh_off ..), kfirst / sym parallel to them
+    uint32_t map_off;            // its query-map entries: map_qi / map_qj / map_idf [map_off ..)
+    uint32_t idx_off, n_idx;     // all_query_indices
+    uint32_t q_size;             // 1 + largest query residue index any entry names
+    uint32_t q_res0;             // first residue of the query structure in the query batch
+    uint32_t pad;
+};
+struct rs_match_dev { uint32_t slot, ci, same, res_pos, prob0, prob1; float idf; uint32_t pad; };
+struct rs_args {
+    const fd_pair_rec *found; const fd_cand_rec *cands;
+    const uint32_t *seg_f, *seg_c, *perm_f, *perm_c;     // per-slot segments of the (unordered) scan output
+    const uint32_t *cand, *slot_q;                       // slot -> structure of the database batch, slot -> query
+    const uint32_t *db_res_off; const float *db_ca, *db_cb, *q_ca, *q_cb;
+    const rs_query_dev *qt;
+    const uint32_t *hashes, *kfirst; const uint8_t *sym;
+    const uint32_t *map_qi, *map_qj; const float *map_idf;
+    const uint32_t *indices;
+    const float *d0tab;                                  // d0_scale of metrics.rs:117-123 by point count (host powf)
+    uint32_t node_count;
+    unsigned long long *counters;                        // [0] matches, [1] problems << 40 | points, [2] residue ints
+    uint32_t *flags;                                     // bit 0: a slot beyond the kernel's limits, bit 1: an output buffer too small
+    rs_match_dev *matches; int32_t *residues; float *kx, *ky; uint64_t *koff; float *d0;
+    uint64_t cap_matches, cap_res, cap_prob, cap_pts;
+};
+void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec *cands, uint64_t nc, uint32_t n_cand, uint32_t *cnt, uint32_t *seg, uint32_t *cur,
+                        uint32_t *perm_f, uint32_t *perm_c, hipStream_t st);
+void fd_launch_rs_slots(const rs_args &A, uint32_t n_cand, hipStream_t st);
 int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
                          const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
                          fd_cand_rec **cands, uint64_t *n_cands, uint32_t mode = 3, const uint32_t *cj_mask = nullptr,

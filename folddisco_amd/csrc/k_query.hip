@@ -431,6 +431,44 @@ __global__ __launch_bounds__(256) void k_topn_emit(const fd_count_rec_dev *__res
         }
     }
 }
+// The selected records of every query ranked like the candidate selection ranks them (idf descending, ties by ascending structure id,
+// query_pdb.rs:404-411) and cut to top_n: one workgroup per query, bitonic sort of (inverted idf key << 32 | nid) in LDS.  A query whose
+// selection overflowed its slots (count > cap) is left to the host.
+#define TOPN_SORT_MAX 4096
+__global__ __launch_bounds__(256) void k_topn_sort(const fd_count_rec_dev *__restrict__ sel, uint32_t cap, const topn_state *__restrict__ st, uint32_t top_n,
+                                                   fd_count_rec_dev *__restrict__ out) {
+    __shared__ uint64_t key[TOPN_SORT_MAX];
+    __shared__ uint16_t idx[TOPN_SORT_MAX];
+    const uint32_t q = blockIdx.x, cnt = st[q].count;
+    if (cnt > cap || cnt == 0) return;
+    uint32_t n2 = 1;
+    while (n2 < cnt) n2 <<= 1;
+    const fd_count_rec_dev *r = sel + (uint64_t)q * cap;
+    for (uint32_t i = threadIdx.x; i < n2; i += 256) {
+        key[i] = i < cnt ? (((uint64_t)(~idf_order_key(r[i].idf)) << 32) | r[i].nid) : ~0ull;
+        idx[i] = (uint16_t)i;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= n2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n2; i += 256) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const uint64_t a = key[i], b = key[l];
+                    if ((a > b) == up) { key[i] = b; key[l] = a; const uint16_t t = idx[i]; idx[i] = idx[l]; idx[l] = t; }
+                }
+            }
+            __syncthreads();
+        }
+    const uint32_t m = cnt < top_n ? cnt : top_n;
+    for (uint32_t i = threadIdx.x; i < m; i += 256) out[(uint64_t)q * top_n + i] = r[idx[i]];
+}
+void fd_launch_cq_topn_sort(const void *sel, uint32_t cap, const void *state, uint32_t n_queries, uint32_t top_n, void *out, hipStream_t st) {
+    if (n_queries) hipLaunchKernelGGL(k_topn_sort, dim3(n_queries), dim3(256), 0, st, (const fd_count_rec_dev *)sel, cap, (const topn_state *)state, top_n,
+                                      (fd_count_rec_dev *)out);
+}
+
 // state: n_queries topn_state + n_queries * 2048 u32 (zeroed once by the caller; the kernels leave the table zero)
 void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries, uint32_t top_n, uint32_t cap, void *out, void *state, uint32_t *ghist,
                        hipStream_t st) {

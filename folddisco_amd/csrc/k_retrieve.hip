@@ -1,0 +1,370 @@
+// k_retrieve.hip — the per-candidate body of retrieval_wrapper on the device (reference: src/controller/retrieve.rs:364-552 and
+// 604-702, src/controller/graph.rs:16-50): found triples of one candidate structure -> match graph -> strongly + weakly
+// connected components -> residue votes -> greedy assignment -> rescue of unmatched query residues from the candidate
+// pairs -> the residue lists and the [CA, CB] point lists of the superposition problems, which k_superpose / k_metrics
+// (k_match.hip) then solve without leaving the device.
+//
+// One wavefront per candidate slot, and the 64 lanes ARE the graph: lane v holds node v (its residue, its adjacency row,
+// its reachability row as a 64-bit mask), so
+//   * node discovery in first-appearance order (graph.rs:16-26) is one ballot per edge endpoint,
+//   * transitive closure is Warshall with one readlane per pivot (64 steps), SCC(v) = reach[v] & reach^T[v], WCC(v) = closure of
+//     the symmetrised adjacency; a component is kept by its lowest member, WCCs equal to an SCC are dropped, the rest is ordered
+//     like the reference orders its sorted node lists (graph.rs:43-45) by a mask comparison,
+//   * the per-query-residue "best target" table and the assignment list live one entry per lane (ballot = lookup).
+// Everything sequential in the reference (edge order, vote order, the assignment loop with its erase-and-reinsert quirk) runs as
+// wave-uniform loops over LDS, so the result does not depend on scheduling.  Limits (else the slot raises the overflow flag and the
+// caller takes the host path for the whole call): 64 graph nodes, 64 query residues, 1024 found triples per candidate.
+#include "fdgpu_internal.h"
+
+#define RS_EDGE_CAP 1024u
+#define RS_LIST_CAP 2048u
+
+namespace {
+__device__ __forceinline__ uint64_t rs_bcast64(uint64_t v, uint32_t src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)src, FD_WAVE), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src, FD_WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t rs_wave_max64(uint64_t v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, FD_WAVE), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, FD_WAVE);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t rs_wave_max32(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, off, FD_WAVE);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+// a < b for two different node sets read as ascending node lists (the order Vec<Vec<usize>>::sort gives, graph.rs:44)
+__device__ __forceinline__ bool rs_less(uint64_t a, uint64_t b) {
+    const uint32_t d = (uint32_t)__builtin_ctzll(a ^ b);
+    if ((a >> d) & 1ull) return ((b >> d) >> 1) != 0ull;     // a holds d: smaller unless b ended (b is a prefix of a)
+    return ((a >> d) >> 1) == 0ull;                          // b holds d: a is smaller only as a prefix of b
+}
+}  // namespace
+
+#define RS_SYNC() __syncthreads()
+#define RS_OVERFLOW() do { if (threadIdx.x == 0) atomicOr(A.flags, 1u); return; } while (0)
+
+__global__ void k_rs_count(const fd_pair_rec *__restrict__ found, uint64_t nf, const fd_cand_rec *__restrict__ cands, uint64_t nc, uint32_t n_cand,
+                           uint32_t *__restrict__ cnt) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < nf) { const uint32_t s = found[x].cand; if (s < n_cand) atomicAdd(&cnt[s], 1u); }
+    else if (x < nf + nc) { const uint32_t s = cands[x - nf].cand; if (s < n_cand) atomicAdd(&cnt[n_cand + 1 + s], 1u); }
+}
+
+// exclusive scans of the two count arrays (one block; n_cand is a few thousand at most) -> segment starts + scatter cursors
+__global__ __launch_bounds__(256) void k_rs_scan(const uint32_t *__restrict__ cnt, uint32_t n_cand, uint32_t *__restrict__ seg, uint32_t *__restrict__ cur) {
+    __shared__ uint32_t part[256];
+    for (uint32_t which = 0; which < 2; ++which) {
+        const uint32_t *c = cnt + which * (n_cand + 1);
+        uint32_t *sg = seg + which * (n_cand + 1), *cu = cur + which * (n_cand + 1);
+        const uint32_t per = (n_cand + 255u) / 256u, a = threadIdx.x * per, b = min(n_cand, a + per);
+        uint32_t s = 0;
+        for (uint32_t k = a; k < b; ++k) s += c[k];
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t run = 0; for (int k = 0; k < 256; ++k) { const uint32_t t = part[k]; part[k] = run; run += t; } sg[n_cand] = run; }
+        __syncthreads();
+        uint32_t run = part[threadIdx.x];
+        for (uint32_t k = a; k < b; ++k) { sg[k] = run; cu[k] = run; run += c[k]; }
+        __syncthreads();
+    }
+}
+
+__global__ void k_rs_scatter(const fd_pair_rec *__restrict__ found, uint64_t nf, const fd_cand_rec *__restrict__ cands, uint64_t nc, uint32_t n_cand,
+                             uint32_t *__restrict__ cur, uint32_t *__restrict__ perm_f, uint32_t *__restrict__ perm_c) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < nf) { const uint32_t s = found[x].cand; if (s < n_cand) perm_f[atomicAdd(&cur[s], 1u)] = (uint32_t)x; }
+    else if (x < nf + nc) { const uint32_t s = cands[x - nf].cand; if (s < n_cand) perm_c[atomicAdd(&cur[n_cand + 1 + s], 1u)] = (uint32_t)(x - nf); }
+}
+
+__global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
+    __shared__ uint32_t s_a[RS_LIST_CAP];      // raw i | raw j           -> votes: query residue   -> rescue: partner-residue list
+    __shared__ uint32_t s_b[RS_LIST_CAP];      // raw hash | raw position -> votes: target residue  -> rescue: multiplicities
+    __shared__ uint32_t s_i[RS_EDGE_CAP], s_j[RS_EDGE_CAP], s_h[RS_EDGE_CAP];   // edges in (i, j, emission) order
+    __shared__ int32_t s_k[RS_EDGE_CAP];       // query-map entry of the edge's hash
+    __shared__ uint8_t s_es[RS_EDGE_CAP], s_et[RS_EDGE_CAP], s_sym[RS_EDGE_CAP], s_vc[RS_LIST_CAP];
+    __shared__ uint64_t s_cm[2 * FD_WAVE], s_cs[2 * FD_WAVE];
+    __shared__ uint32_t s_aq[FD_WAVE], s_ar[FD_WAVE], s_qs[FD_WAVE], s_rs[FD_WAVE], s_rmx[FD_WAVE], s_rnm[FD_WAVE], s_rarg[FD_WAVE];
+    __shared__ int32_t s_fh[FD_WAVE], s_pr[FD_WAVE];
+    __shared__ uint32_t s_misc[2];
+    const uint32_t slot = blockIdx.x, lane = threadIdx.x;
+    const uint32_t f0 = A.seg_f[slot], F = A.seg_f[slot + 1] - f0;
+    if (F == 0) return;
+    if (F > RS_EDGE_CAP) RS_OVERFLOW();
+    const rs_query_dev Q = A.qt[A.slot_q[slot]];
+    const uint32_t NQ = Q.n_idx;
+    if (NQ > FD_WAVE) RS_OVERFLOW();
+    const uint32_t st = A.cand[slot];
+    const uint32_t r0 = A.db_res_off[st], Rt = A.db_res_off[st + 1] - r0;
+    const uint32_t c0 = A.seg_c[slot], c1 = A.seg_c[slot + 1];
+    // ---- edges in the reference's scan order: (i, j) row-major, several bin pairs of one (i, j) in emission order
+    for (uint32_t x = lane; x < F; x += FD_WAVE) {
+        const uint32_t o = A.perm_f[f0 + x];
+        const fd_pair_rec p = A.found[o];
+        s_a[x] = p.i; s_a[RS_EDGE_CAP + x] = p.j; s_b[x] = p.hash; s_b[RS_EDGE_CAP + x] = o;
+    }
+    RS_SYNC();
+    for (uint32_t x = lane; x < F; x += FD_WAVE) {
+        const uint32_t i = s_a[x], j = s_a[RS_EDGE_CAP + x], o = s_b[RS_EDGE_CAP + x];
+        uint32_t rank = 0;
+        for (uint32_t y = 0; y < F; ++y) {
+            const uint32_t yi = s_a[y], yj = s_a[RS_EDGE_CAP + y], yo = s_b[RS_EDGE_CAP + y];
+            rank += (yi < i || (yi == i && (yj < j || (yj == j && yo < o)))) ? 1u : 0u;
+        }
+        s_i[rank] = i; s_j[rank] = j; s_h[rank] = s_b[x];
+    }
+    RS_SYNC();
+    // query-map entry (first one holding the hash, like the reference's hash map) and symmetry flag of every edge
+    for (uint32_t x = lane; x < F; x += FD_WAVE) {
+        const uint32_t h = s_h[x];
+        const uint32_t *hs = A.hashes + Q.qh_off;
+        uint32_t lo = 0, hi = Q.n_hashes;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (hs[mid] < h) lo = mid + 1; else hi = mid; }
+        const bool ok = lo < Q.n_hashes && hs[lo] == h;
+        s_k[x] = ok ? (int32_t)A.kfirst[Q.qh_off + lo] : -1;
+        s_sym[x] = ok ? A.sym[Q.qh_off + lo] : (uint8_t)0;
+    }
+    // ---- nodes in first-appearance order, adjacency rows
+    uint32_t node_res = 0xffffffffu, n_nodes = 0;
+    uint64_t adj = 0;
+    for (uint32_t e = 0; e < F; ++e) {
+        uint32_t ids[2];
+        for (int z = 0; z < 2; ++z) {
+            const uint32_t r = z ? s_j[e] : s_i[e];
+            const uint64_t m = __ballot(lane < n_nodes && node_res == r);
+            if (m == 0ull) {
+                if (n_nodes == FD_WAVE) RS_OVERFLOW();
+                if (lane == n_nodes) node_res = r;
+                ids[z] = n_nodes++;
+            } else ids[z] = (uint32_t)__builtin_ctzll(m);
+        }
+        if (lane == ids[0]) adj |= 1ull << ids[1];
+        if (lane == 0) { s_es[e] = (uint8_t)ids[0]; s_et[e] = (uint8_t)ids[1]; }
+    }
+    RS_SYNC();
+    // ---- strongly and weakly connected components (graph.rs:29-50)
+    const uint64_t self = lane < n_nodes ? 1ull << lane : 0ull;
+    uint64_t reach = adj | self, adjT = 0, reachT = 0;
+    for (uint32_t k = 0; k < n_nodes; ++k) { const uint64_t rk = rs_bcast64(reach, k); if ((reach >> k) & 1ull) reach |= rk; }
+    for (uint32_t u = 0; u < n_nodes; ++u) {
+        const uint64_t au = rs_bcast64(adj, u), ru = rs_bcast64(reach, u);
+        if ((au >> lane) & 1ull) adjT |= 1ull << u;
+        if ((ru >> lane) & 1ull) reachT |= 1ull << u;
+    }
+    uint64_t wcc = lane < n_nodes ? (adj | adjT | self) : 0ull;
+    for (uint32_t k = 0; k < n_nodes; ++k) { const uint64_t uk = rs_bcast64(wcc, k); if ((wcc >> k) & 1ull) wcc |= uk; }
+    const uint64_t scc = reach & reachT;
+    const bool scc_rep = lane < n_nodes && (uint32_t)__builtin_ctzll(scc) == lane && (uint32_t)__popcll(scc) >= A.node_count;
+    const bool wcc_rep = lane < n_nodes && (uint32_t)__builtin_ctzll(wcc) == lane && (uint32_t)__popcll(wcc) >= A.node_count && wcc != scc;
+    const uint64_t ms = __ballot(scc_rep), mw = __ballot(wcc_rep);
+    const uint32_t n_scc = (uint32_t)__popcll(ms), n_comp = n_scc + (uint32_t)__popcll(mw);
+    if (n_comp == 0) return;
+    if (scc_rep) s_cm[fd_mbcnt(ms)] = scc;
+    if (wcc_rep) s_cm[n_scc + fd_mbcnt(mw)] = wcc;
+    RS_SYNC();
+    for (uint32_t x = lane; x < n_comp; x += FD_WAVE) {
+        const uint64_t a = s_cm[x];
+        uint32_t rank = 0;
+        for (uint32_t y = 0; y < n_comp; ++y) { const uint64_t b = s_cm[y]; if (b != a && rs_less(b, a)) ++rank; }
+        s_cs[rank] = a;
+    }
+    RS_SYNC();
+    const float *q_ca = A.q_ca + 3ull * Q.q_res0, *q_cb = A.q_cb + 3ull * Q.q_res0;
+    const float *t_ca = A.db_ca + 3ull * r0, *t_cb = A.db_cb + 3ull * r0;
+    for (uint32_t ci = 0; ci < n_comp; ++ci) {
+        const uint64_t C = s_cs[ci];
+        const uint32_t csize = (uint32_t)__popcll(C);
+        // ---- votes (query residue, target residue) -> saturating u8 count (retrieve.rs:631-666), subgraph idf (:705-719)
+        uint32_t nv = 0;
+        float sub_idf = 0.0f;
+        for (uint32_t e = 0; e < F; ++e) {
+            const uint32_t a = s_es[e], b = s_et[e];
+            const int32_t k = s_k[e];
+            if (!((C >> a) & 1ull) || !((C >> b) & 1ull) || k < 0) continue;
+            sub_idf += A.map_idf[Q.map_off + (uint32_t)k];
+            const uint32_t qi = A.map_qi[Q.map_off + (uint32_t)k], qj = A.map_qj[Q.map_off + (uint32_t)k];
+            const uint32_t ri = (uint32_t)__shfl((int)node_res, (int)a, FD_WAVE), rj = (uint32_t)__shfl((int)node_res, (int)b, FD_WAVE);
+            uint32_t pq[2], pr[2];
+            if (s_sym[e]) { pq[0] = min(qi, qj); pq[1] = max(qi, qj); pr[0] = min(ri, rj); pr[1] = max(ri, rj); }
+            else { pq[0] = qi; pr[0] = ri; pq[1] = qj; pr[1] = rj; }
+            for (int z = 0; z < 2; ++z) {
+                int32_t at = -1;
+                for (uint32_t base = 0; base < nv && at < 0; base += FD_WAVE) {
+                    const uint32_t x = base + lane;
+                    const uint64_t m = __ballot(x < nv && s_a[x] == pq[z] && s_b[x] == pr[z]);
+                    if (m) at = (int32_t)(base + (uint32_t)__builtin_ctzll(m));
+                }
+                if (at < 0) {
+                    if (nv == RS_LIST_CAP) RS_OVERFLOW();
+                    if (lane == 0) { s_a[nv] = pq[z]; s_b[nv] = pr[z]; s_vc[nv] = 1; }
+                    ++nv;
+                } else if (lane == 0 && s_vc[at] < 255) ++s_vc[at];
+                RS_SYNC();
+            }
+        }
+        // ---- per query residue: highest count, smallest target residue holding it
+        uint32_t bq = 0, bc = 0, br = 0, nb = 0;
+        for (uint32_t v = 0; v < nv; ++v) {
+            const uint32_t q = s_a[v], r = s_b[v], c = s_vc[v];
+            const uint64_t m = __ballot(lane < nb && bq == q);
+            if (m == 0ull) {
+                if (nb == FD_WAVE) RS_OVERFLOW();
+                if (lane == nb) { bq = q; bc = c; br = r; }
+                ++nb;
+            } else if (lane == (uint32_t)__builtin_ctzll(m) && (c > bc || (c == bc && r < br))) { bc = c; br = r; }
+        }
+        // ---- greedy assignment in (count descending, query residue ascending) order (retrieve.rs:668-690)
+        uint32_t my_aq = 0xffffffffu, my_ar = 0xffffffffu, n_asg = 0;
+        bool rem = lane < nb;
+        for (uint32_t it = 0; it < nb && n_asg < csize; ++it) {
+            const uint64_t key = rem ? (((uint64_t)bc << 32) | (0xffffffffu - bq)) : 0ull;
+            const uint64_t mx = rs_wave_max64(key);
+            const uint32_t w = (uint32_t)__builtin_ctzll(__ballot(rem && key == mx));
+            const uint32_t q = (uint32_t)__shfl((int)bq, (int)w, FD_WAVE), r = (uint32_t)__shfl((int)br, (int)w, FD_WAVE);
+            if (__ballot(lane < n_asg && my_ar == r) == 0ull) {
+                if (lane == n_asg) { my_aq = q; my_ar = r; }
+                ++n_asg;
+            }
+            if (lane == w) rem = false;
+        }
+        RS_SYNC();           // the vote arrays are free from here on
+        if (lane < n_asg) { s_aq[lane] = my_aq; s_ar[lane] = my_ar; }
+        RS_SYNC();
+        // ---- rescue votes (retrieve.rs:498-511): for a query residue without a target, the candidate pairs (query residue, i, j)
+        // whose partner j some assignment mapped vote for i; the unique maximum (>= 2) joins
+        for (uint32_t pos = 0; pos < NQ; ++pos) {
+            const uint32_t qi = A.indices[Q.idx_off + pos];
+            uint32_t mx = 0, nmx = 0, arg = 0;
+            if (__ballot(lane < n_asg && my_aq == qi) == 0ull && c1 > c0 && qi < Q.q_size) {
+                uint32_t n_t = 0;
+                for (uint32_t base = c0; base < c1; base += FD_WAVE) {
+                    const uint32_t x = base + lane;
+                    bool ok = false;
+                    uint32_t iv = 0;
+                    if (x < c1) {
+                        const fd_cand_rec cr = A.cands[A.perm_c[x]];
+                        iv = cr.i;
+                        if (cr.qi == qi && cr.i < Rt && cr.j < Rt)
+                            for (uint32_t k = 0; k < n_asg; ++k) ok |= s_ar[k] == cr.j;
+                    }
+                    const uint64_t m = __ballot(ok);
+                    if (ok) { const uint32_t p = n_t + fd_mbcnt(m); if (p < RS_LIST_CAP) s_a[p] = iv; }
+                    n_t += (uint32_t)__popcll(m);
+                }
+                if (n_t > RS_LIST_CAP) RS_OVERFLOW();
+                RS_SYNC();
+                uint32_t lmx = 0;
+                for (uint32_t base = 0; base < n_t; base += FD_WAVE) {
+                    const uint32_t x = base + lane;
+                    if (x < n_t) {
+                        const uint32_t v = s_a[x];
+                        uint32_t cnt = 0;
+                        for (uint32_t y = 0; y < n_t; ++y) cnt += s_a[y] == v ? 1u : 0u;
+                        s_b[x] = cnt;
+                        lmx = max(lmx, cnt);
+                    }
+                }
+                mx = rs_wave_max32(lmx);
+                RS_SYNC();
+                uint32_t n_eq = 0;
+                for (uint32_t base = 0; base < n_t; base += FD_WAVE) {
+                    const uint32_t x = base + lane;
+                    const uint64_t m = __ballot(x < n_t && s_b[x] == mx);
+                    if (m) { n_eq += (uint32_t)__popcll(m); arg = s_a[base + (uint32_t)__builtin_ctzll(m)]; }
+                }
+                nmx = mx ? n_eq / mx : 0u;
+                RS_SYNC();
+            }
+            if (lane == 0) { s_rmx[pos] = mx; s_rnm[pos] = nmx; s_rarg[pos] = arg; }
+        }
+        RS_SYNC();
+        // ---- residue assignment + rescue, sequential as in the reference (retrieve.rs:430-516)
+        if (lane < NQ) { s_fh[lane] = -1; s_pr[lane] = -1; }
+        RS_SYNC();
+        if (lane == 0) {
+            uint32_t n_sc = 0;
+            for (uint32_t pos = 0; pos < NQ; ++pos) {
+                const uint32_t qi = A.indices[Q.idx_off + pos];
+                int32_t mapped = -1;
+                for (uint32_t k = 0; k < n_asg; ++k) if (s_aq[k] == qi) { mapped = (int32_t)s_ar[k]; break; }
+                if (mapped >= 0) {
+                    s_fh[pos] = mapped;
+                    uint32_t pp = n_sc;
+                    for (uint32_t k = 0; k < n_sc; ++k) if (s_rs[k] == (uint32_t)mapped) { pp = k; break; }
+                    if (pp == n_sc) { s_pr[pos] = mapped; s_qs[n_sc] = qi; s_rs[n_sc] = (uint32_t)mapped; ++n_sc; }
+                    else {
+                        if (pp < NQ) s_pr[pp] = -1;          // the reference indexes its residue vector with the scanned position
+                        s_pr[pos] = mapped;
+                        for (uint32_t k = pp; k + 1 < n_sc; ++k) { s_qs[k] = s_qs[k + 1]; s_rs[k] = s_rs[k + 1]; }
+                        s_qs[n_sc - 1] = qi; s_rs[n_sc - 1] = (uint32_t)mapped;
+                    }
+                } else if (qi < Q.q_size && s_rnm[pos] == 1 && s_rmx[pos] >= 2) {
+                    bool taken = false;
+                    for (uint32_t k = 0; k < n_sc; ++k) taken |= s_rs[k] == s_rarg[pos];
+                    if (!taken && n_sc < FD_WAVE) { s_pr[pos] = (int32_t)s_rarg[pos]; s_qs[n_sc] = qi; s_rs[n_sc] = s_rarg[pos]; ++n_sc; }
+                }
+            }
+            bool same = true;
+            for (uint32_t pos = 0; pos < NQ; ++pos) same &= s_fh[pos] == s_pr[pos];
+            s_misc[0] = n_sc; s_misc[1] = same ? 1u : 0u;
+        }
+        RS_SYNC();
+        const uint32_t n_sc = s_misc[0];
+        const bool same = s_misc[1] != 0;
+        // ---- outputs: one record, 2 NQ residues, one or two superposition problems of [CA, CB] points (retrieve.rs:761-767)
+        const uint32_t nprob = same ? 1u : 2u, npts = 2u * n_asg + (same ? 0u : 2u * n_sc);
+        unsigned long long mi = 0, rp = 0, pk = 0;
+        if (lane == 0) {
+            mi = atomicAdd(&A.counters[0], 1ull);
+            rp = atomicAdd(&A.counters[2], 2ull * NQ);
+            pk = atomicAdd(&A.counters[1], ((unsigned long long)nprob << 40) | (unsigned long long)npts);
+        }
+        mi = rs_bcast64(mi, 0); rp = rs_bcast64(rp, 0); pk = rs_bcast64(pk, 0);
+        const uint64_t p0 = pk >> 40, pt0 = pk & ((1ull << 40) - 1ull);
+        if (mi >= A.cap_matches || rp + 2ull * NQ > A.cap_res || p0 + nprob > A.cap_prob || pt0 + npts > A.cap_pts) {
+            if (lane == 0) atomicOr(A.flags, 2u);
+            RS_SYNC();
+            continue;
+        }
+        if (lane == 0) {
+            rs_match_dev m;
+            m.slot = slot; m.ci = ci; m.same = same ? 1u : 0u; m.res_pos = (uint32_t)rp; m.prob0 = (uint32_t)p0; m.prob1 = same ? 0xffffffffu : (uint32_t)(p0 + 1);
+            m.idf = sub_idf; m.pad = 0;
+            A.matches[mi] = m;
+            A.koff[p0] = pt0; A.d0[p0] = A.d0tab[2u * n_asg];
+            if (!same) { A.koff[p0 + 1] = pt0 + 2ull * n_asg; A.d0[p0 + 1] = A.d0tab[2u * n_sc]; }
+        }
+        if (lane < NQ) { A.residues[rp + lane] = s_fh[lane]; A.residues[rp + NQ + lane] = s_pr[lane]; }
+        for (uint32_t w = 0; w < nprob; ++w) {
+            const uint32_t n = w ? n_sc : n_asg;
+            const uint64_t base = pt0 + (w ? 2ull * n_asg : 0ull);
+            if (lane < n) {
+                const uint32_t q = w ? s_qs[lane] : s_aq[lane], r = w ? s_rs[lane] : s_ar[lane];
+                for (int z = 0; z < 3; ++z) {
+                    A.ky[3 * (base + 2 * lane) + z] = q_ca[3 * q + z]; A.ky[3 * (base + 2 * lane + 1) + z] = q_cb[3 * q + z];
+                    A.kx[3 * (base + 2 * lane) + z] = t_ca[3 * r + z]; A.kx[3 * (base + 2 * lane + 1) + z] = t_cb[3 * r + z];
+                }
+            }
+        }
+        RS_SYNC();
+    }
+}
+
+void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec *cands, uint64_t nc, uint32_t n_cand, uint32_t *cnt, uint32_t *seg, uint32_t *cur,
+                        uint32_t *perm_f, uint32_t *perm_c, hipStream_t st) {
+    const uint64_t n = nf + nc;
+    (void)hipMemsetAsync(cnt, 0, (size_t)2 * (n_cand + 1) * 4, st);
+    if (n) hipLaunchKernelGGL(k_rs_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, found, nf, cands, nc, n_cand, cnt);
+    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(256), 0, st, cnt, n_cand, seg, cur);
+    if (n) hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, found, nf, cands, nc, n_cand, cur, perm_f, perm_c);
+}
+
+void fd_launch_rs_slots(const rs_args &A, uint32_t n_cand, hipStream_t st) {
+    if (n_cand) hipLaunchKernelGGL(k_rs_slots, dim3(n_cand), dim3(FD_WAVE), 0, st, A);
+}

@@ -106,10 +106,11 @@ def allgather_array(local: np.ndarray, device: torch.device | None = None) -> np
     return np.concatenate([o[r, : sizes[r] * isz].view(local.dtype) for r in range(world)])
 
 
-def allgather_hits_many(locals_: list, device: torch.device | None = None, top_n: int | None = None) -> list:
+def allgather_hits_many(locals_: list, device: torch.device | None = None, top_n: int | None = None, ranked: bool = False) -> list:
     """allgather_hits for a batch of queries with TWO collectives in total (all the sizes, then one padded payload): locals_[t] =
-    this rank's candidate records of query t.  Returns the global ranking of every query (identical on every rank)."""
-    if top_n is not None:
+    this rank's candidate records of query t.  Returns the global ranking of every query (identical on every rank).
+    ranked=True: the local lists are already ranked and cut to top_n (count_query_batch with top_n > 0 ranks on the device)."""
+    if top_n is not None and not ranked:
         locals_ = [rank_hits(r, top_n) for r in locals_]
     if not _active():
         return [r if top_n is not None else rank_hits(r, None) for r in locals_]

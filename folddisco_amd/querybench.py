@@ -127,7 +127,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                         set_global_idf(qm)
                 recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=top_n,
                                          lengths_fn=(lambda l: fdist.reduce_lengths(l, dev)) if sharded else None)
-                globs = fdist.allgather_hits_many(recs, dev, top_n=top_n)
+                globs = fdist.allgather_hits_many(recs, dev, top_n=top_n, ranked=True)
                 if match:   # one pair scan / gather / Kabsch launch for the whole chunk of queries
                     cl = [owned(g, match_top) for g in globs]
                     marr = retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0]

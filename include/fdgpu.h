@@ -184,9 +184,9 @@ int fdgpu_count_query_batch(fdgpu_ctx *ctx, const fdgpu_index *ix, uint64_t n_qu
                             const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf,
                             const float *penalty, fd_count_rec **out, uint64_t **out_off);
 
-/* As above with the candidate selection of query_pdb.rs:404-411 started on the device: per query only the records that can be
- * among the top_n by idf come back — every record whose idf is >= the top_n-th largest (ties included), in no particular
- * order; the caller sorts that short list (idf descending, nid ascending) and truncates.  top_n = 0: everything. */
+/* As above with the candidate selection of query_pdb.rs:404-411 done on the device: per query only the top_n records come back,
+ * ranked as the reference ranks them (idf descending, ties by ascending nid) — radix selection of the cut-off, then a bitonic sort in
+ * LDS, so top_n records per query cross the bus.  top_n = 0: everything, in ascending nid. */
 int fdgpu_count_query_batch_top(fdgpu_ctx *ctx, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off,
                                 const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf,
                                 const float *penalty, uint32_t top_n, fd_count_rec **out, uint64_t **out_off);

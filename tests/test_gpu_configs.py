@@ -200,7 +200,7 @@ def test_batch_of_shipped_queries_equals_singles(human):
         single = fq.make_query_map(ctx, qb, Q["idx"], Q["subs"], ix, float(HUMAN))
         assert single.hash.tobytes() == m.hash.tobytes() and single.idf.tobytes() == m.idf.tobytes()
         full = fd.count_query(ctx, ix, m.hash, m.qi, m.qj, human["pen"], total_structures=HUMAN, as_array=True)
-        assert fdist.rank_hits(r, 1000).tobytes() == fdist.rank_hits(full, 1000).tobytes()
+        assert r.tobytes() == fdist.rank_hits(full, 1000).tobytes()      # top 1000 of 20,500 ranked on the device
         cands.append(fdist.rank_hits(r, 25)["nid"].astype(np.uint32))
     got = fq.retrieve_batch(ctx, batch, std, cands, qms, qall, list(range(len(Qs))))
     for k, (Q, m) in enumerate(zip(Qs, qms)):

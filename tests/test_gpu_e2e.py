@@ -996,3 +996,81 @@ def test_cli_index_and_query_from_foldcomp_database(tmp_path):
                         cwd=tmp_path, env=env, capture_output=True, text=True, check=True).stdout.splitlines()
     f = ps[0].split("\t")
     assert f[0] == fc.names[3] and f[10] == str(int(fc.keys[3])) and f[9].startswith(qstr + ":0.0000")
+
+
+@pytest.mark.gpu
+def test_device_retrieval_glue_equals_host_glue(env, monkeypatch):
+    """fdgpu_retrieve_batch's device path (k_retrieve.hip: components / votes / assignment / rescue one wavefront per candidate,
+    superposition on the device) against the host C++ path it replaces (FDGPU_HOST_GLUE=1, itself pinned to the oracle by
+    test_retrieve_matches_oracle): identical match tables, bit for bit, on the serine set with substitution and range queries and on
+    a synthetic database with planted motifs; the stage timings prove which path ran."""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    from folddisco_amd import synth
+    from folddisco_amd.api import count_query_batch, length_penalty
+    ctx, structs, batch, ix, nres, plddt, tids = env
+    q1, q2 = st.read_compact_structure(Q4CHA), st.read_compact_structure(Q1G2F)
+    qall = ctx.upload(fd.PackedStructures.concat([q1.as_item(), q2.as_item()]))
+    std = np.concatenate([s.resname_std() for s in structs])
+    specs = [(0, q1, "B57,B102,C195", [0, 1, 2, 3, 4]), (1, q2, "F207,F212,F225,F229", [4, 2, 0]), (0, q1, "B57:HKR,B102,C195:ST", [3, 4, 1]),
+             (0, q1, "B57,B102,C195,B58,B59,C999", [0, 1, 2, 3, 4]), (0, q1, "B57-60,B102,C195", [0, 3])]
+    reqs = []
+    for sidx, q, qstr, cand in specs:
+        res = fq.parse_query_string(qstr, q.chains[0])
+        pairs = [(q.get_index(c, r), s) for c, r, s in res]
+        pairs = [(i, s) for i, s in pairs if i is not None]
+        reqs.append((sidx, [i for i, _ in pairs], [s for _, s in pairs]))
+    qms = fq.make_query_maps(ctx, qall, reqs, ix, 5.0)
+
+    def run(db, stdn, cl, qms_, qb, qs, ca):
+        ctx.enable_timing(True)
+        out = fq.retrieve_batch(ctx, db, stdn, cl, qms_, qb, qs, ca_distance_cutoff=ca, as_arrays=True)
+        ctx.synchronize()
+        names = [n for n, _, _ in ctx.last_timings()]
+        ctx.enable_timing(False)
+        return out, names
+
+    def both(db, stdn, cl, qms_, qb, qs, ca=1.0):
+        monkeypatch.delenv("FDGPU_HOST_GLUE", raising=False)
+        dev, n_dev = run(db, stdn, cl, qms_, qb, qs, ca)
+        monkeypatch.setenv("FDGPU_HOST_GLUE", "1")
+        host, n_host = run(db, stdn, cl, qms_, qb, qs, ca)
+        monkeypatch.delenv("FDGPU_HOST_GLUE", raising=False)
+        assert "retrieve_slots" in n_dev and "retrieve_slots" not in n_host
+        for a, b, what in zip(dev, host, ("matches", "match_off", "residues", "res_off")):
+            assert a.tobytes() == b.tobytes(), what
+        return dev
+
+    for ca in (1.0, 1.5, 3.0):
+        m = both(batch, std, [np.array(sp[3], np.uint32) for sp in specs], qms, qall, [sp[0] for sp in specs], ca)[0]
+        assert len(m) >= 6
+    # planted motifs in a synthetic database: 24 queries x their top 24 candidates
+    S = 1500
+    d = synth.generate(S, seed=91)
+    ps = synth.to_packed(d)
+    sb = ctx.upload(ps)
+    six = fd.FolddiscoIndex.build(ctx, sb)
+    rng = np.random.Generator(np.random.PCG64(5))
+    off = ps.res_off.astype(np.int64)
+    queries = []
+    while len(queries) < 24:
+        s = int(rng.integers(0, S))
+        a, b = int(off[s]), int(off[s + 1])
+        if b - a < 30:
+            continue
+        c = int(rng.integers(0, b - a))
+        near = np.nonzero(np.linalg.norm(ps.ca_xyz[a:b] - ps.ca_xyz[a + c], axis=1) < 10.0)[0]
+        if len(near) < 5:
+            continue
+        idx = sorted(rng.choice(near, 5, replace=False).tolist())
+        item = dict(n_xyz=ps.n_xyz[a:b], ca_xyz=ps.ca_xyz[a:b], cb_xyz=ps.cb_xyz[a:b], aa=ps.aa[a:b], cb_ok=None)
+        queries.append((s, idx, item))
+    qb2 = ctx.upload(fd.PackedStructures.concat([it for _, _, it in queries]))
+    qms2 = fq.make_query_maps(ctx, qb2, [(k, queries[k][1]) for k in range(len(queries))], six, float(S))
+    pen = length_penalty(np.diff(ps.res_off.astype(np.int64)).astype(np.uint64), 0.5)
+    recs = count_query_batch(ctx, six, [(qm.hash, qm.qi, qm.qj) for qm in qms2], pen, total_structures=S, top_n=24)
+    from folddisco_amd import dist as fdist
+    cl = [fdist.rank_hits(r, 24)["nid"].astype(np.uint32) for r in recs]
+    m2 = both(sb, None, cl, qms2, qb2, list(range(len(queries))))[0]
+    assert len(m2) >= len(queries)          # every query finds at least itself

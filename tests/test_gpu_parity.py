@@ -274,13 +274,13 @@ def test_count_query_batch_equals_single(ctx):
         want = fd.count_query(ctx, ix, qh, qi, qj, pen, total_structures=300, as_array=True)
         assert g.tobytes() == want.tobytes()
     assert len(got[3]) == 0 and len(got[6]) == 0
-    # device-side preselection of the top N (k_cq_topn): ranking the short list gives exactly the top N of the full list
+    # device-side selection of the top N (k_topn_* + k_topn_sort): exactly the first N of the ranked full list, in rank order
     from folddisco_amd.dist import rank_hits
     for N in (1, 3, 10, 50, 1000):
         sel = fd.count_query_batch(ctx, ix, queries, pen, total_structures=300, top_n=N)
         for full, short in zip(got, sel):
             assert len(short) <= len(full)
-            assert rank_hits(short, N).tobytes() == rank_hits(full, N).tobytes()
+            assert short.tobytes() == rank_hits(full, N).tobytes()       # ranked and cut on the device (k_topn_sort) / in the library
     big = fd.count_query_batch(ctx, ix, queries, pen, total_structures=300, top_n=3)
     assert any(len(b) < len(f) for b, f in zip(big, got))          # the preselection did drop records
 
