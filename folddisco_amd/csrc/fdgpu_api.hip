@@ -896,6 +896,12 @@ extern "C" int fdgpu_get_entries(fdgpu_ctx *c, const fdgpu_index *ix, const uint
 }
 
 // plan (list positions, CQ_SEG-byte segments) + segment-parallel scoring of the query hashes in A (k_query.hip)
+// idf of a query hash in the accumulators' fixed point (2^-22; count_query.rs:181-200 sums f32 in hash-map order, here the sum is exact
+// and order-independent to 2.4e-7 per addend)
+static inline uint64_t fd_idf_fix(float idf) {
+    const double v = (double)idf;
+    return (v > 0.0 && v < 1.0e6) ? (uint64_t)(v * 4194304.0 + 0.5) : 0ull;
+}
 static int cq_score(fdgpu_ctx *c, const cq_args &A, const uint32_t *q_query) {
     hipStream_t st = c->stream;
     HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(A.nq * 8));
@@ -932,24 +938,25 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     for (uint64_t k = 0; k < nq; ++k) edges[k] = ((uint64_t)q_node[k] << 32) | q_edge_j[k];
     std::sort(edges.begin(), edges.end());
     edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
-    std::vector<uint32_t> nidx(nq), eidx(nq);
+    std::vector<uint32_t> eidx(nq);
     std::vector<uint64_t> idf_fix(nq);
+    bool packed = nq < (1ull << 18);
     for (uint64_t k = 0; k < nq; ++k) {
-        nidx[k] = (uint32_t)(std::lower_bound(nodes.begin(), nodes.end(), q_node[k]) - nodes.begin());
         eidx[k] = (uint32_t)(std::lower_bound(edges.begin(), edges.end(), ((uint64_t)q_node[k] << 32) | q_edge_j[k]) - edges.begin());
-        double v = (double)q_idf[k];
-        idf_fix[k] = (v > 0.0 && v < 1.0e6) ? (uint64_t)(v * 1099511627776.0 + 0.5) : 0ull;
+        idf_fix[k] = fd_idf_fix(q_idf[k]);
+        packed = packed && idf_fix[k] < (1ull << 27);
     }
-    const uint32_t NN = (uint32_t)nodes.size(), NE = (uint32_t)edges.size();
+    const uint32_t NE = (uint32_t)edges.size();
+    std::vector<uint32_t> enode(std::max<uint32_t>(NE, 1));     // node (dense index) of every edge row: rows of one node are contiguous
+    for (uint32_t e = 0; e < NE; ++e) enode[e] = (uint32_t)(std::lower_bound(nodes.begin(), nodes.end(), (uint32_t)(edges[e] >> 32)) - nodes.begin());
     const uint32_t words = (uint32_t)((S + 31) / 32);
     // workspace
     HIPCHK(c, c->ws[WS_MISC0].ensure(nq * 4));   // q_hash
-    HIPCHK(c, c->ws[WS_MISC1].ensure(nq * 4));   // node idx
+    HIPCHK(c, c->ws[WS_MISC1].ensure((size_t)std::max<uint32_t>(NE, 1) * 4));   // node of every edge row
     HIPCHK(c, c->ws[WS_MISC2].ensure(nq * 4));   // edge idx
     HIPCHK(c, c->ws[WS_MISC3].ensure(nq * 8));   // idf fixed
-    HIPCHK(c, c->ws[WS_COUNTS].ensure(S * 4));   // match
-    HIPCHK(c, c->ws[WS_SEGOFF].ensure((S + 2) * 8));  // idf sums, later reused? no: keep separate below
-    HIPCHK(c, c->ws[WS_KEYS_A].ensure((size_t)NN * words * 4));
+    HIPCHK(c, c->ws[WS_COUNTS].ensure(S * 4));   // match counts (wide form)
+    HIPCHK(c, c->ws[WS_SEGOFF].ensure((S + 2) * 8));  // (count, idf sum) accumulators
     HIPCHK(c, c->ws[WS_KEYS_B].ensure((size_t)NE * words * 4));
     HIPCHK(c, c->ws[WS_IDS_A].ensure(S * 4));    // node counts
     HIPCHK(c, c->ws[WS_IDS_B].ensure(S * 4));    // edge counts
@@ -959,20 +966,19 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(S) * 8 + 64));
     HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, nidx.data(), nq * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, enode.data(), (size_t)std::max<uint32_t>(NE, 1) * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, eidx.data(), nq * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC3].p, idf_fix.data(), nq * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(c->ws[WS_COUNTS].p, 0, S * 4, st));
+    if (!packed) HIPCHK(c, hipMemsetAsync(c->ws[WS_COUNTS].p, 0, S * 4, st));
     HIPCHK(c, hipMemsetAsync(c->ws[WS_SEGOFF].p, 0, S * 8, st));
-    HIPCHK(c, hipMemsetAsync(c->ws[WS_KEYS_A].p, 0, (size_t)NN * words * 4, st));
     HIPCHK(c, hipMemsetAsync(c->ws[WS_KEYS_B].p, 0, (size_t)NE * words * 4, st));
     cq_args A;
     A.hashes = ix->hashes; A.offsets = ix->offsets; A.value = ix->value; A.H = ix->n_hashes;
-    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.q_node_idx = c->ws[WS_MISC1].as<uint32_t>(); A.q_edge_idx = c->ws[WS_MISC2].as<uint32_t>();
+    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.q_edge_idx = c->ws[WS_MISC2].as<uint32_t>();
     A.q_idf_fix = c->ws[WS_MISC3].as<uint64_t>(); A.nq = nq;
-    A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>();
-    A.node_bits = c->ws[WS_KEYS_A].as<uint32_t>(); A.edge_bits = c->ws[WS_KEYS_B].as<uint32_t>();
+    A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>(); A.packed = packed ? 1 : 0;
+    A.edge_bits = c->ws[WS_KEYS_B].as<uint32_t>(); A.edge_node = c->ws[WS_MISC1].as<uint32_t>();
     A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
     {
         StageTimer t(c, "cq_accumulate", 0);
@@ -980,9 +986,8 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
         if (rs) return rs;
     }
     {
-        StageTimer t(c, "cq_finalize", (uint64_t)(NN + NE) * words * 4 + S * 12);
-        fd_launch_cq_finalize(A.match, A.idf, A.node_bits, NN, A.edge_bits, NE, words, (uint32_t)S, c->ws[WS_IDS_A].as<uint32_t>(),
-                              c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), st);
+        StageTimer t(c, "cq_finalize", (uint64_t)NE * words * 4 + S * 12);
+        fd_launch_cq_finalize(A, NE, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), st);
         fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), S, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
                                    c->ws[WS_TOTAL].as<uint64_t>(), st);
     }
@@ -993,7 +998,7 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     fd_count_rec *r = (fd_count_rec *)malloc(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec));
     if (!r) return FDGPU_ENOMEM;
     HIPCHK(c, c->ws[WS_TILE_HO].ensure(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec)));
-    fd_launch_cq_compact(A.match, A.idf, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(),
+    fd_launch_cq_compact(packed ? nullptr : A.match, A.idf, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(),
                          c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_MISC5].as<float>(), (uint32_t)S, (uint32_t)ix->first_id, c->ws[WS_TILE_HO].p, st);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && n) e = hipMemcpyAsync(r, c->ws[WS_TILE_HO].p, n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
@@ -1030,9 +1035,10 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     if (!q_hash || !q_node || !q_edge_j || !q_idf) { free(ooff); return FDGPU_EINVAL; }
     if (S >= 0xffffffe0ull || n_queries * S >= (1ull << 34)) { free(ooff); FAIL(c, FDGPU_ERANGE, "count_query_batch: n_queries x n_structures too large; split the batch"); }
     // global row numbering of the occupancy matrices: per query, its distinct nodes then its distinct edges
-    std::vector<uint32_t> nrow(nq), erow(nq), qq(nq), row_off(4 * n_queries);
+    std::vector<uint32_t> erow(nq), qq(nq), row_off(4 * n_queries), enode;
     std::vector<uint64_t> idf_fix(nq);
     uint32_t n_node_rows = 0, n_edge_rows = 0;
+    bool packed = true;
     for (uint64_t t = 0; t < n_queries; ++t) {
         uint64_t a = q_off[t], b = q_off[t + 1];
         std::vector<uint32_t> nodes(q_node + a, q_node + b);
@@ -1042,13 +1048,14 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
         for (uint64_t k = a; k < b; ++k) edges[k - a] = ((uint64_t)q_node[k] << 32) | q_edge_j[k];
         std::sort(edges.begin(), edges.end());
         edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+        packed = packed && (b - a) < (1ull << 18);
         for (uint64_t k = a; k < b; ++k) {
-            nrow[k] = n_node_rows + (uint32_t)(std::lower_bound(nodes.begin(), nodes.end(), q_node[k]) - nodes.begin());
             erow[k] = n_edge_rows + (uint32_t)(std::lower_bound(edges.begin(), edges.end(), ((uint64_t)q_node[k] << 32) | q_edge_j[k]) - edges.begin());
             qq[k] = (uint32_t)t;
-            double v = (double)q_idf[k];
-            idf_fix[k] = (v > 0.0 && v < 1.0e6) ? (uint64_t)(v * 1099511627776.0 + 0.5) : 0ull;
+            idf_fix[k] = fd_idf_fix(q_idf[k]);
+            packed = packed && idf_fix[k] < (1ull << 27);
         }
+        for (uint64_t e : edges) enode.push_back(n_node_rows + (uint32_t)(std::lower_bound(nodes.begin(), nodes.end(), (uint32_t)(e >> 32)) - nodes.begin()));
         row_off[4 * t] = n_node_rows; row_off[4 * t + 1] = n_node_rows + (uint32_t)nodes.size();
         row_off[4 * t + 2] = n_edge_rows; row_off[4 * t + 3] = n_edge_rows + (uint32_t)edges.size();
         n_node_rows += (uint32_t)nodes.size(); n_edge_rows += (uint32_t)edges.size();
@@ -1057,29 +1064,29 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     const uint64_t QS = n_queries * S;
     hipError_t e = hipSuccess;
     auto need = [&](int w, size_t bytes) { if (e == hipSuccess) e = c->ws[w].ensure(bytes); };
-    need(WS_MISC0, nq * 4); need(WS_MISC1, nq * 4); need(WS_MISC2, nq * 4); need(WS_MISC3, nq * 8); need(WS_TILE_B, nq * 4);
-    need(WS_TILE_H, n_queries * 16 + 16); need(WS_COUNTS, QS * 4); need(WS_SEGOFF, QS * 8 + 16);
-    need(WS_KEYS_A, (size_t)std::max<uint32_t>(n_node_rows, 1) * words * 4); need(WS_KEYS_B, (size_t)std::max<uint32_t>(n_edge_rows, 1) * words * 4);
+    if (enode.empty()) enode.push_back(0);
+    need(WS_MISC0, nq * 4); need(WS_MISC1, enode.size() * 4); need(WS_MISC2, nq * 4); need(WS_MISC3, nq * 8); need(WS_TILE_B, nq * 4);
+    need(WS_TILE_H, n_queries * 16 + 16); need(WS_COUNTS, packed ? 64 : QS * 4); need(WS_SEGOFF, QS * 8 + 16);
+    need(WS_KEYS_B, (size_t)std::max<uint32_t>(n_edge_rows, 1) * words * 4);
     need(WS_IDS_A, QS * 4); need(WS_IDS_B, QS * 4); need(WS_MISC4, QS + 8); need(WS_TILE_BO, (QS + 2) * 8); need(WS_MISC5, S * 4);
     need(WS_SCANTMP, fd_scan_tmp_elems(QS) * 8 + 64); need(WS_TOTAL, 64);
     if (e != hipSuccess) { free(ooff); c->err = std::string("count_query_batch workspace: ") + hipGetErrorString(e); return FDGPU_EHIP; }
     (void)hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(c->ws[WS_MISC1].p, nrow.data(), nq * 4, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(c->ws[WS_MISC1].p, enode.data(), enode.size() * 4, hipMemcpyHostToDevice, st);
     (void)hipMemcpyAsync(c->ws[WS_MISC2].p, erow.data(), nq * 4, hipMemcpyHostToDevice, st);
     (void)hipMemcpyAsync(c->ws[WS_MISC3].p, idf_fix.data(), nq * 8, hipMemcpyHostToDevice, st);
     (void)hipMemcpyAsync(c->ws[WS_TILE_B].p, qq.data(), nq * 4, hipMemcpyHostToDevice, st);
     (void)hipMemcpyAsync(c->ws[WS_TILE_H].p, row_off.data(), n_queries * 16, hipMemcpyHostToDevice, st);
     (void)hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st);
-    (void)hipMemsetAsync(c->ws[WS_COUNTS].p, 0, QS * 4, st);
+    if (!packed) (void)hipMemsetAsync(c->ws[WS_COUNTS].p, 0, QS * 4, st);
     (void)hipMemsetAsync(c->ws[WS_SEGOFF].p, 0, QS * 8, st);
-    (void)hipMemsetAsync(c->ws[WS_KEYS_A].p, 0, (size_t)std::max<uint32_t>(n_node_rows, 1) * words * 4, st);
     (void)hipMemsetAsync(c->ws[WS_KEYS_B].p, 0, (size_t)std::max<uint32_t>(n_edge_rows, 1) * words * 4, st);
     cq_args A;
     A.hashes = ix->hashes; A.offsets = ix->offsets; A.value = ix->value; A.H = ix->n_hashes;
-    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.q_node_idx = c->ws[WS_MISC1].as<uint32_t>(); A.q_edge_idx = c->ws[WS_MISC2].as<uint32_t>();
+    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.q_edge_idx = c->ws[WS_MISC2].as<uint32_t>();
     A.q_idf_fix = c->ws[WS_MISC3].as<uint64_t>(); A.nq = nq;
-    A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>();
-    A.node_bits = c->ws[WS_KEYS_A].as<uint32_t>(); A.edge_bits = c->ws[WS_KEYS_B].as<uint32_t>();
+    A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>(); A.packed = packed ? 1 : 0;
+    A.edge_bits = c->ws[WS_KEYS_B].as<uint32_t>(); A.edge_node = c->ws[WS_MISC1].as<uint32_t>();
     A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
     {
         StageTimer t(c, "cq_batch", 0);

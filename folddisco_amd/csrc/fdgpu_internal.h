@@ -174,8 +174,13 @@ void fd_launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t n, 
 // k_query.hip
 struct cq_args {
     const uint32_t *hashes; const uint64_t *offsets; const uint8_t *value; uint64_t H;
-    const uint32_t *q_hash; const uint32_t *q_node_idx; const uint32_t *q_edge_idx; const uint64_t *q_idf_fix; uint64_t nq;
-    uint32_t *match; unsigned long long *idf; uint32_t *node_bits; uint32_t *edge_bits; uint32_t words; uint32_t first_id; uint32_t S;
+    const uint32_t *q_hash; const uint32_t *q_edge_idx; const uint64_t *q_idf_fix; uint64_t nq;
+    uint32_t *match;                 // [queries][S] match counts — wide form only
+    unsigned long long *idf;         // [queries][S] idf sums (2^-22 units); packed form: count << 46 | sum
+    int packed;
+    uint32_t *edge_bits;             // [edge rows][words] occupancy
+    const uint32_t *edge_node;       // [edge rows] node (first query residue) of every edge row: rows of one node are contiguous
+    uint32_t words; uint32_t first_id; uint32_t S;
 };
 void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,
                                uint64_t nq, uint64_t *lengths, long long *kidx, uint32_t *nseg, uint64_t *wstart, uint64_t *scan_tmp, uint64_t *total,
@@ -183,9 +188,7 @@ void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, 
 void fd_launch_cq_plan(const cq_args &A, long long *kidx, uint32_t *nseg, hipStream_t st);
 void fd_launch_cq_seg(const cq_args &A, const uint32_t *q_query, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
                       hipStream_t st);
-void fd_launch_cq_finalize(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_bits, uint32_t n_nodes,
-                           const uint32_t *edge_bits, uint32_t n_edges, uint32_t words, uint32_t S, uint32_t *node_cnt, uint32_t *edge_cnt,
-                           uint8_t *flags, hipStream_t st);
+void fd_launch_cq_finalize(const cq_args &A, uint32_t n_edges, uint32_t *node_cnt, uint32_t *edge_cnt, uint8_t *flags, hipStream_t st);
 void fd_launch_cq_compact(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_cnt, const uint32_t *edge_cnt,
                           const uint8_t *flags, const uint64_t *pos, const float *penalty, uint32_t S, uint32_t first_id, void *out,
                           hipStream_t st);

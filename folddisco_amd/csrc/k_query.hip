@@ -18,7 +18,12 @@
 #include <algorithm>
 #include "fdgpu_internal.h"
 
-#define IDF_SCALE 1099511627776.0 /* 2^40 */
+// Per-structure accumulator: ONE u64 per (query, structure) = match count << 46 | idf sum in units of 2^-22 (a posting costs one
+// 64-bit atomic for both; the sum of <= 2^18 addends below 32 fits the low 46 bits).  A query with 2^18 hashes or more, or an idf outside
+// [0, 32), takes the wide form instead: u32 counts and u64 sums in separate arrays, same 2^-22 resolution, so both forms give the same bits.
+#define IDF_SCALE 4194304.0 /* 2^22 */
+#define CQ_CNT_SHIFT 46
+#define CQ_SUM_MASK ((1ull << CQ_CNT_SHIFT) - 1ull)
 struct fd_count_rec_dev { uint32_t nid, total_match_count, node_count, edge_count; float idf; };
 
 __device__ __forceinline__ int64_t find_hash(const uint32_t *__restrict__ hashes, uint64_t H, uint32_t h) {
@@ -183,13 +188,12 @@ __global__ __launch_bounds__(FD_WAVE) void k_cq_seg(cq_args A, const uint32_t *_
             run_id = acc;
         }
         unsigned long long idf_fix = 0;
-        uint32_t *match = nullptr, *nb = nullptr, *eb = nullptr;
+        uint32_t *match = nullptr, *eb = nullptr;
         unsigned long long *idf = nullptr;
         if (!SUMS) {
-            idf_fix = A.q_idf_fix[q];
+            idf_fix = A.q_idf_fix[q] + (A.packed ? 1ull << CQ_CNT_SHIFT : 0ull);
             const uint64_t qbase = q_query ? (uint64_t)q_query[q] * A.S : 0ull;
             match = A.match + qbase; idf = A.idf + qbase;
-            nb = A.node_bits + (uint64_t)A.q_node_idx[q] * A.words;
             eb = A.edge_bits + (uint64_t)A.q_edge_idx[q] * A.words;
         }
         uint32_t seg_acc = 0;
@@ -218,10 +222,9 @@ __global__ __launch_bounds__(FD_WAVE) void k_cq_seg(cq_args A, const uint32_t *_
             const uint32_t id = run_id + s2;
             if (!SUMS && term) {
                 const uint32_t rel = id - A.first_id;
-                if (id >= A.first_id && rel < A.S) {
-                    atomicAdd(&match[rel], 1u);
+                if (id >= A.first_id && rel < A.S) {     // two atomics per posting: (count, idf) and the edge bit; node bits derive from edges
+                    if (!A.packed) atomicAdd(&match[rel], 1u);
                     atomicAdd(&idf[rel], idf_fix);
-                    atomicOr(&nb[rel >> 5], 1u << (rel & 31u));
                     atomicOr(&eb[rel >> 5], 1u << (rel & 31u));
                 }
             }
@@ -266,28 +269,58 @@ __device__ __forceinline__ void sliced_add(uint32_t *pl, uint32_t x) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_cq_finalize(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ idf,
-                                                     const uint32_t *__restrict__ node_bits, uint32_t n_nodes,
-                                                     const uint32_t *__restrict__ edge_bits, uint32_t n_edges, uint32_t words, uint32_t S,
-                                                     uint32_t *__restrict__ node_cnt, uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
-    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= words) return;
-    uint32_t any = 0;
+// The per-word bit planes of a block's 128 words -> per-structure counts, written COALESCED: each thread unpacks its own word into an
+// LDS tile (row stride 33: conflict-free), then the block streams the tile out structure-major together with the touched flags.  (One
+// thread writing its 32 structures directly costs 32 partial-line stores per wavefront instruction: 0.4 ms per query batch at 542 k
+// structures, eight times the coalesced form.)
+#define CQ_FIN_T 128
+__device__ __forceinline__ void cq_finalize_store(const uint32_t (&pn)[20], const uint32_t (&pe)[20], bool live, uint32_t S, uint64_t qbase,
+                                                  const uint32_t *__restrict__ match, const unsigned long long *__restrict__ acc,
+                                                  uint32_t *__restrict__ node_cnt, uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
+    __shared__ uint32_t t_n[CQ_FIN_T * 33], t_e[CQ_FIN_T * 33];
+    if (live)
+        for (uint32_t b = 0; b < 32; ++b) {
+            uint32_t nc = 0, ec = 0;
+#pragma unroll
+            for (int k = 0; k < 20; ++k) { nc |= ((pn[k] >> b) & 1u) << k; ec |= ((pe[k] >> b) & 1u) << k; }
+            t_n[threadIdx.x * 33 + b] = nc; t_e[threadIdx.x * 33 + b] = ec;
+        }
+    __syncthreads();
+    const uint32_t nid0 = blockIdx.x * CQ_FIN_T * 32;
+    for (uint32_t i = threadIdx.x; i < CQ_FIN_T * 32; i += CQ_FIN_T) {
+        const uint32_t nid = nid0 + i;
+        if (nid >= S) break;
+        const uint32_t at = (i >> 5) * 33 + (i & 31u);
+        node_cnt[qbase + nid] = t_n[at];
+        edge_cnt[qbase + nid] = t_e[at];
+        flags[qbase + nid] = (match ? match[qbase + nid] != 0u : acc[qbase + nid] != 0ull) ? 1 : 0;     // packed form (match == null): count in the top bits
+    }
+}
+
+// node occupancy = OR of the node's edge rows (a matched hash names its node through its edge; edge rows are sorted by (node, partner),
+// so a node's rows are contiguous and edge_node[e] changes exactly at the group boundaries): no node-bit atomics, no node matrix
+__device__ __forceinline__ void cq_count_rows(const uint32_t *__restrict__ edge_bits, const uint32_t *__restrict__ edge_node, uint32_t e0, uint32_t e1,
+                                              uint32_t words, uint32_t w, uint32_t (&pn)[20], uint32_t (&pe)[20]) {
+    uint32_t cur = 0, prev = e0 < e1 ? edge_node[e0] : 0u;
+    for (uint32_t e = e0; e < e1; ++e) {
+        const uint32_t x = edge_bits[(uint64_t)e * words + w], n = edge_node[e];
+        if (n != prev) { sliced_add(pn, cur); cur = 0; prev = n; }
+        cur |= x;
+        sliced_add(pe, x);
+    }
+    sliced_add(pn, cur);
+}
+__global__ __launch_bounds__(CQ_FIN_T) void k_cq_finalize(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ acc,
+                                                          const uint32_t *__restrict__ edge_bits, const uint32_t *__restrict__ edge_node, uint32_t n_edges,
+                                                          uint32_t words, uint32_t S, uint32_t *__restrict__ node_cnt, uint32_t *__restrict__ edge_cnt,
+                                                          uint8_t *__restrict__ flags) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = w < words;
     uint32_t pn[20], pe[20];
 #pragma unroll
     for (int k = 0; k < 20; ++k) { pn[k] = 0; pe[k] = 0; }
-    for (uint32_t n = 0; n < n_nodes; ++n) { uint32_t x = node_bits[(uint64_t)n * words + w]; any |= x; sliced_add(pn, x); }
-    if (any) for (uint32_t e = 0; e < n_edges; ++e) sliced_add(pe, edge_bits[(uint64_t)e * words + w]);
-    for (uint32_t b = 0; b < 32; ++b) {
-        uint32_t nid = w * 32 + b;
-        if (nid >= S) break;
-        uint32_t nc = 0, ec = 0;
-#pragma unroll
-        for (int k = 0; k < 20; ++k) { nc |= ((pn[k] >> b) & 1u) << k; ec |= ((pe[k] >> b) & 1u) << k; }
-        node_cnt[nid] = nc;
-        edge_cnt[nid] = ec;
-        flags[nid] = match[nid] > 0 ? 1 : 0;
-    }
+    if (live) cq_count_rows(edge_bits, edge_node, 0, n_edges, words, w, pn, pe);
+    cq_finalize_store(pn, pe, live, S, 0, match, acc, node_cnt, edge_cnt, flags);
 }
 
 
@@ -300,10 +333,11 @@ __global__ __launch_bounds__(256) void k_cq_compact(const uint32_t *__restrict__
     if (nid >= S || !flags[nid]) return;
     fd_count_rec_dev r;
     r.nid = nid + first_id;
-    r.total_match_count = match[nid];
+    const unsigned long long a = idf[nid];
+    r.total_match_count = match ? match[nid] : (uint32_t)(a >> CQ_CNT_SHIFT);
     r.node_count = node_cnt[nid];
     r.edge_count = edge_cnt[nid];
-    float sum = (float)((double)idf[nid] * (1.0 / IDF_SCALE));
+    float sum = (float)((double)(match ? a : a & CQ_SUM_MASK) * (1.0 / IDF_SCALE));
     r.idf = sum * penalty[nid];  // count_query.rs:200 idf_sum *= nres^(-lp)
     out[pos[nid]] = r;
 }
@@ -311,30 +345,19 @@ __global__ __launch_bounds__(256) void k_cq_compact(const uint32_t *__restrict__
 // ------------------------------------------------------------------ batched scoring (many queries, one launch each)
 // Same arithmetic as above; query hash k belongs to query A.q_query[k]; accumulators are [n_queries][S], the
 // occupancy bit matrix has one row per (query, node) and per (query, edge) (A.q_node_idx / q_edge_idx are global rows).
-__global__ __launch_bounds__(256) void k_cq_finalize_batch(const uint32_t *__restrict__ match, const uint32_t *__restrict__ node_bits,
-                                                           const uint32_t *__restrict__ edge_bits, const uint32_t *__restrict__ row_off /*[4*nQ]: n0,n1,e0,e1*/,
-                                                           uint32_t words, uint32_t S, uint32_t *__restrict__ node_cnt,
-                                                           uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
-    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t qy = blockIdx.y;
-    if (w >= words) return;
-    const uint32_t n0 = row_off[4 * qy], n1 = row_off[4 * qy + 1], e0 = row_off[4 * qy + 2], e1 = row_off[4 * qy + 3];
-    uint32_t any = 0, pn[20], pe[20];
+__global__ __launch_bounds__(CQ_FIN_T) void k_cq_finalize_batch(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ acc,
+                                                                const uint32_t *__restrict__ edge_bits, const uint32_t *__restrict__ edge_node,
+                                                                const uint32_t *__restrict__ row_off /*[4*nQ]: n0,n1,e0,e1*/, uint32_t words, uint32_t S,
+                                                                uint32_t *__restrict__ node_cnt, uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t qy = blockIdx.y;
+    const bool live = w < words;
+    const uint32_t e0 = row_off[4 * qy + 2], e1 = row_off[4 * qy + 3];
+    uint32_t pn[20], pe[20];
 #pragma unroll
     for (int k = 0; k < 20; ++k) { pn[k] = 0; pe[k] = 0; }
-    for (uint32_t n = n0; n < n1; ++n) { uint32_t x = node_bits[(uint64_t)n * words + w]; any |= x; sliced_add(pn, x); }
-    if (any) for (uint32_t e = e0; e < e1; ++e) sliced_add(pe, edge_bits[(uint64_t)e * words + w]);
-    const uint64_t qbase = (uint64_t)qy * S;
-    for (uint32_t b = 0; b < 32; ++b) {
-        uint32_t nid = w * 32 + b;
-        if (nid >= S) break;
-        uint32_t nc = 0, ec = 0;
-#pragma unroll
-        for (int k = 0; k < 20; ++k) { nc |= ((pn[k] >> b) & 1u) << k; ec |= ((pe[k] >> b) & 1u) << k; }
-        node_cnt[qbase + nid] = nc;
-        edge_cnt[qbase + nid] = ec;
-        flags[qbase + nid] = match[qbase + nid] > 0 ? 1 : 0;
-    }
+    if (live) cq_count_rows(edge_bits, edge_node, e0, e1, words, w, pn, pe);
+    cq_finalize_store(pn, pe, live, S, (uint64_t)qy * S, match, acc, node_cnt, edge_cnt, flags);
 }
 
 __global__ __launch_bounds__(256) void k_cq_compact_batch(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ idf,
@@ -347,10 +370,11 @@ __global__ __launch_bounds__(256) void k_cq_compact_batch(const uint32_t *__rest
     uint32_t nid = (uint32_t)(g % S);
     fd_count_rec_dev r;
     r.nid = nid + first_id;
-    r.total_match_count = match[g];
+    const unsigned long long a = idf[g];
+    r.total_match_count = match ? match[g] : (uint32_t)(a >> CQ_CNT_SHIFT);
     r.node_count = node_cnt[g];
     r.edge_count = edge_cnt[g];
-    float sum = (float)((double)idf[g] * (1.0 / IDF_SCALE));
+    float sum = (float)((double)(match ? a : a & CQ_SUM_MASK) * (1.0 / IDF_SCALE));
     r.idf = sum * penalty[nid];
     out[pos[g]] = r;
 }
@@ -486,12 +510,12 @@ void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries
 void fd_launch_cq_batch(const cq_args &A, const uint32_t *q_query, uint32_t n_queries, const uint32_t *row_off, uint32_t *node_cnt, uint32_t *edge_cnt,
                         uint8_t *flags, hipStream_t st) {
     if (A.words && n_queries)
-        hipLaunchKernelGGL(k_cq_finalize_batch, dim3((A.words + 255) / 256, n_queries), dim3(256), 0, st, A.match, A.node_bits, A.edge_bits, row_off,
-                           A.words, A.S, node_cnt, edge_cnt, flags);
+        hipLaunchKernelGGL(k_cq_finalize_batch, dim3((A.words + CQ_FIN_T - 1) / CQ_FIN_T, n_queries), dim3(CQ_FIN_T), 0, st, A.packed ? nullptr : A.match, A.idf,
+                           A.edge_bits, A.edge_node, row_off, A.words, A.S, node_cnt, edge_cnt, flags);
 }
 void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, const uint32_t *edge_cnt, const uint8_t *flags, const uint64_t *pos,
                                 const float *penalty, uint64_t total, void *out, hipStream_t st) {
-    if (total) hipLaunchKernelGGL(k_cq_compact_batch, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A.match, A.idf, node_cnt, edge_cnt, flags,
+    if (total) hipLaunchKernelGGL(k_cq_compact_batch, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A.packed ? nullptr : A.match, A.idf, node_cnt, edge_cnt, flags,
                                   pos, penalty, A.S, total, A.first_id, (fd_count_rec_dev *)out);
 }
 
@@ -505,10 +529,9 @@ void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, 
     fd_exclusive_scan<uint32_t>(nseg, nq, wstart, scan_tmp, total, st);
     hipLaunchKernelGGL(k_pl_count, dim3(8192), dim3(FD_WAVE), 0, st, offsets, value, kidx, wstart, nq, (unsigned long long *)lengths);
 }
-void fd_launch_cq_finalize(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_bits, uint32_t n_nodes,
-                           const uint32_t *edge_bits, uint32_t n_edges, uint32_t words, uint32_t S, uint32_t *node_cnt, uint32_t *edge_cnt,
-                           uint8_t *flags, hipStream_t st) {
-    if (words) hipLaunchKernelGGL(k_cq_finalize, dim3((words + 255) / 256), dim3(256), 0, st, match, idf, node_bits, n_nodes, edge_bits, n_edges, words, S, node_cnt, edge_cnt, flags);
+void fd_launch_cq_finalize(const cq_args &A, uint32_t n_edges, uint32_t *node_cnt, uint32_t *edge_cnt, uint8_t *flags, hipStream_t st) {
+    if (A.words) hipLaunchKernelGGL(k_cq_finalize, dim3((A.words + CQ_FIN_T - 1) / CQ_FIN_T), dim3(CQ_FIN_T), 0, st, A.packed ? nullptr : A.match, A.idf, A.edge_bits,
+                                    A.edge_node, n_edges, A.words, A.S, node_cnt, edge_cnt, flags);
 }
 void fd_launch_cq_compact(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_cnt, const uint32_t *edge_cnt,
                           const uint8_t *flags, const uint64_t *pos, const float *penalty, uint32_t S, uint32_t first_id, void *out,
