@@ -985,9 +985,21 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
         int rs = cq_score(c, A, nullptr);
         if (rs) return rs;
     }
+    std::vector<uint32_t> slices;        // outlives the asynchronous copy below (the stream is synchronised before this function returns)
     {
         StageTimer t(c, "cq_finalize", (uint64_t)NE * words * 4 + S * 12);
-        fd_launch_cq_finalize(A, NE, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), st);
+        // many edge rows (whole-structure queries): cut them into ~64 slices at node boundaries so that the chip is full
+        if (NE >= 2048) {
+            const uint32_t want = 64, per = (NE + want - 1) / want;
+            slices.push_back(0);
+            for (uint32_t e = 1; e < NE; ++e)
+                if (enode[e] != enode[e - 1] && e - slices.back() >= per) slices.push_back(e);
+            slices.push_back(NE);
+            HIPCHK(c, c->ws[WS_TILE_B].ensure(slices.size() * 4));
+            HIPCHK(c, hipMemcpyAsync(c->ws[WS_TILE_B].p, slices.data(), slices.size() * 4, hipMemcpyHostToDevice, st));
+        }
+        fd_launch_cq_finalize(A, NE, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(),
+                              slices.empty() ? nullptr : c->ws[WS_TILE_B].as<uint32_t>(), slices.empty() ? 0u : (uint32_t)slices.size() - 1, st);
         fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), S, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
                                    c->ws[WS_TOTAL].as<uint64_t>(), st);
     }

@@ -529,9 +529,52 @@ void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, 
     fd_exclusive_scan<uint32_t>(nseg, nq, wstart, scan_tmp, total, st);
     hipLaunchKernelGGL(k_pl_count, dim3(8192), dim3(FD_WAVE), 0, st, offsets, value, kidx, wstart, nq, (unsigned long long *)lengths);
 }
-void fd_launch_cq_finalize(const cq_args &A, uint32_t n_edges, uint32_t *node_cnt, uint32_t *edge_cnt, uint8_t *flags, hipStream_t st) {
-    if (A.words) hipLaunchKernelGGL(k_cq_finalize, dim3((A.words + CQ_FIN_T - 1) / CQ_FIN_T), dim3(CQ_FIN_T), 0, st, A.packed ? nullptr : A.match, A.idf, A.edge_bits,
-                                    A.edge_node, n_edges, A.words, A.S, node_cnt, edge_cnt, flags);
+// A whole-structure query has tens of thousands of edge rows and only words / 128 word blocks to read them with (133 workgroups at
+// 542 k structures: a chip mostly idle, every thread walking 28 k dependent loads).  The rows are therefore cut into slices at node
+// boundaries (a node's OR must not straddle two slices); every (word block, slice) workgroup counts its slice and ADDS into the
+// zeroed per-structure counters, coalesced through the same LDS tile.
+__global__ __launch_bounds__(CQ_FIN_T) void k_cq_finalize_sliced(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ acc,
+                                                                 const uint32_t *__restrict__ edge_bits, const uint32_t *__restrict__ edge_node,
+                                                                 const uint32_t *__restrict__ slice /*[n_slices + 1] first edge row*/, uint32_t words, uint32_t S,
+                                                                 uint32_t *__restrict__ node_cnt, uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
+    __shared__ uint32_t t_n[CQ_FIN_T * 33], t_e[CQ_FIN_T * 33];
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = w < words;
+    uint32_t pn[20], pe[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) { pn[k] = 0; pe[k] = 0; }
+    if (live) cq_count_rows(edge_bits, edge_node, slice[blockIdx.y], slice[blockIdx.y + 1], words, w, pn, pe);
+    if (live)
+        for (uint32_t b = 0; b < 32; ++b) {
+            uint32_t nc = 0, ec = 0;
+#pragma unroll
+            for (int k = 0; k < 20; ++k) { nc |= ((pn[k] >> b) & 1u) << k; ec |= ((pe[k] >> b) & 1u) << k; }
+            t_n[threadIdx.x * 33 + b] = nc; t_e[threadIdx.x * 33 + b] = ec;
+        }
+    __syncthreads();
+    const uint32_t nid0 = blockIdx.x * CQ_FIN_T * 32;
+    for (uint32_t i = threadIdx.x; i < CQ_FIN_T * 32; i += CQ_FIN_T) {
+        const uint32_t nid = nid0 + i;
+        if (nid >= S) break;
+        const uint32_t at = (i >> 5) * 33 + (i & 31u);
+        if (t_n[at]) atomicAdd(&node_cnt[nid], t_n[at]);
+        if (t_e[at]) atomicAdd(&edge_cnt[nid], t_e[at]);
+        if (blockIdx.y == 0) flags[nid] = (match ? match[nid] != 0u : acc[nid] != 0ull) ? 1 : 0;
+    }
+}
+// slices: device array of n_slices + 1 edge-row boundaries at node boundaries, or null / n_slices = 0 for the single-pass form
+void fd_launch_cq_finalize(const cq_args &A, uint32_t n_edges, uint32_t *node_cnt, uint32_t *edge_cnt, uint8_t *flags, const uint32_t *slices, uint32_t n_slices,
+                           hipStream_t st) {
+    if (!A.words) return;
+    if (slices && n_slices > 1) {
+        (void)hipMemsetAsync(node_cnt, 0, (size_t)A.S * 4, st);
+        (void)hipMemsetAsync(edge_cnt, 0, (size_t)A.S * 4, st);
+        hipLaunchKernelGGL(k_cq_finalize_sliced, dim3((A.words + CQ_FIN_T - 1) / CQ_FIN_T, n_slices), dim3(CQ_FIN_T), 0, st, A.packed ? nullptr : A.match, A.idf,
+                           A.edge_bits, A.edge_node, slices, A.words, A.S, node_cnt, edge_cnt, flags);
+        return;
+    }
+    hipLaunchKernelGGL(k_cq_finalize, dim3((A.words + CQ_FIN_T - 1) / CQ_FIN_T), dim3(CQ_FIN_T), 0, st, A.packed ? nullptr : A.match, A.idf, A.edge_bits,
+                       A.edge_node, n_edges, A.words, A.S, node_cnt, edge_cnt, flags);
 }
 void fd_launch_cq_compact(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_cnt, const uint32_t *edge_cnt,
                           const uint8_t *flags, const uint64_t *pos, const float *penalty, uint32_t S, uint32_t first_id, void *out,
