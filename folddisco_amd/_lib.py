@@ -145,6 +145,8 @@ SYMBOLS = [
     ("fdgpu_parse_foldcomp_db", C.c_int, [C.c_char_p, u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(Parsed))]),
     ("fdgpu_get_entries", C.c_int, [VP, VP, u32p, C.c_uint64, C.POINTER(u32p), C.POINTER(u64p)]),
     ("fdgpu_count_query_batch_top", C.c_int, [VP, VP, C.c_uint64, u64p, u32p, u32p, u32p, f32p, f32p, C.c_uint32, C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
+    ("fdgpu_index_set_penalty", C.c_int, [VP, VP, f32p]),
+    ("fdgpu_count_query_maps_top", C.c_int, [VP, VP, C.c_uint64, C.c_void_p, f32p, C.c_float, C.c_uint32, C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
     ("fdgpu_match_pairs", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(MatchQuery), C.POINTER(HashParams),
                                     C.POINTER(C.POINTER(PairRec)), u64p, C.POINTER(C.POINTER(CandRec)), u64p]),
     ("fdgpu_kabsch_batch", C.c_int, [VP, f32p, f32p, u64p, C.c_uint64, f32p, f32p, f32p]),

@@ -247,6 +247,12 @@ class FolddiscoIndex:
         self.ctx.check(self.ctx.L.fdgpu_posting_lengths(self.ctx.h, self.h, _ptr(q, u32p), len(q), _ptr(out, u64p)))
         return out
 
+    def set_penalty(self, penalty):
+        """keep the length penalty of the index's structures on the device (fdgpu_index_set_penalty): count queries may then
+        pass penalty=None instead of uploading n_structures floats per call; None drops it"""
+        pen = None if penalty is None else np.ascontiguousarray(penalty, dtype=np.float32)
+        assert pen is None or len(pen) == self.n_structures
+        self.ctx.check(self.ctx.L.fdgpu_index_set_penalty(self.ctx.h, self.h, None if pen is None else _ptr(pen, f32p)))
 
     def posting_bytes(self, q_hash: np.ndarray) -> np.ndarray:
         q = np.ascontiguousarray(q_hash, dtype=np.uint32)
@@ -406,6 +412,27 @@ def count_query(ctx: Context, index: FolddiscoIndex, q_hash, q_node, q_edge_j, p
         return arr
     return [dict(nid=int(r["nid"]), total_match_count=int(r["total_match_count"]), node_count=int(r["node_count"]),
                  edge_count=int(r["edge_count"]), idf=float(r["idf"])) for r in arr]
+
+
+def count_query_maps(ctx: Context, index: FolddiscoIndex, qms, penalty=None, total_structures: int | None = None, top_n: int = 0):
+    """count_query_batch for the QueryMapResults of make_query_maps, handed to the library as they are (fdgpu_count_query_maps_top:
+    posting lengths, idf = log2f(S / len) per hash and the scoring in one call; penalty=None uses FolddiscoIndex.set_penalty's
+    resident copy).  -> list of REC_DTYPE arrays like count_query_batch."""
+    S = index.n_structures if total_structures is None else total_structures
+    T = len(qms)
+    handles = (C.c_void_p * max(T, 1))(*[C.cast(q.handle, C.c_void_p) for q in qms])
+    pen = None if penalty is None else np.ascontiguousarray(penalty, dtype=np.float32)
+    out = C.POINTER(CountRec)()
+    ooff = u64p()
+    ctx.check(ctx.L.fdgpu_count_query_maps_top(ctx.h, index.h, T, handles, None if pen is None else _ptr(pen, f32p), float(S), int(top_n),
+                                               C.byref(out), C.byref(ooff)))
+    off = np.frombuffer((C.c_uint64 * (T + 1)).from_address(C.addressof(ooff.contents)), dtype=np.uint64).copy()
+    n = int(off[-1])
+    arr = (np.frombuffer((C.c_uint8 * (n * 20)).from_address(C.addressof(out.contents)), dtype=np.uint8).copy().view(REC_DTYPE) if n
+           else np.zeros(0, REC_DTYPE))
+    ctx.L.fdgpu_free(out)
+    ctx.L.fdgpu_free(ooff)
+    return [arr[int(off[t]): int(off[t + 1])] for t in range(T)]
 
 
 def count_query_batch(ctx: Context, index: FolddiscoIndex, queries, penalty: np.ndarray, total_structures: int | None = None,

@@ -531,6 +531,7 @@ extern "C" void fdgpu_index_destroy(fdgpu_index *ix) {
         ix->ctx->pool_free(ix->hashes, ix->cap_hashes); ix->ctx->pool_free(ix->offsets, ix->cap_offsets); ix->ctx->pool_free(ix->value, ix->cap_value);
         ix->ctx->pool_free(ix->last_ids, ix->cap_last);
     } else { (void)hipFree(ix->hashes); (void)hipFree(ix->offsets); (void)hipFree(ix->value); (void)hipFree(ix->last_ids); }
+    if (ix->penalty) (void)hipFree(ix->penalty);
     delete ix;
 }
 extern "C" int fdgpu_index_set_first_id(fdgpu_index *ix, uint64_t first_id) { if (!ix || first_id + ix->n_structures > 0xffffffffull) return FDGPU_EINVAL; ix->first_id = first_id; return FDGPU_OK; }
@@ -923,7 +924,7 @@ static int cq_score(fdgpu_ctx *c, const cq_args &A, const uint32_t *q_query) {
 
 extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j,
                                  const float *q_idf, uint64_t nq, const float *penalty, fd_count_rec **out, uint64_t *n_out) { FD_LOCK(c);
-    if (!c || !ix || !out || !n_out || (nq && (!q_hash || !q_node || !q_edge_j || !q_idf)) || (ix->n_structures && !penalty)) return FDGPU_EINVAL;
+    if (!c || !ix || !out || !n_out || (nq && (!q_hash || !q_node || !q_edge_j || !q_idf)) || (ix->n_structures && !penalty && !ix->penalty)) return FDGPU_EINVAL;
     *out = nullptr; *n_out = 0;
     reset_timings(c);
     hipStream_t st = c->stream;
@@ -969,7 +970,8 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, enode.data(), (size_t)std::max<uint32_t>(NE, 1) * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, eidx.data(), nq * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC3].p, idf_fix.data(), nq * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st));
+    if (penalty) HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st));
+    const float *d_penalty = penalty ? c->ws[WS_MISC5].as<float>() : ix->penalty;
     if (!packed) HIPCHK(c, hipMemsetAsync(c->ws[WS_COUNTS].p, 0, S * 4, st));
     HIPCHK(c, hipMemsetAsync(c->ws[WS_SEGOFF].p, 0, S * 8, st));
     HIPCHK(c, hipMemsetAsync(c->ws[WS_KEYS_B].p, 0, (size_t)NE * words * 4, st));
@@ -1011,7 +1013,7 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     if (!r) return FDGPU_ENOMEM;
     HIPCHK(c, c->ws[WS_TILE_HO].ensure(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec)));
     fd_launch_cq_compact(packed ? nullptr : A.match, A.idf, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(),
-                         c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_MISC5].as<float>(), (uint32_t)S, (uint32_t)ix->first_id, c->ws[WS_TILE_HO].p, st);
+                         c->ws[WS_TILE_BO].as<uint64_t>(), d_penalty, (uint32_t)S, (uint32_t)ix->first_id, c->ws[WS_TILE_HO].p, st);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && n) e = hipMemcpyAsync(r, c->ws[WS_TILE_HO].p, n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1036,7 +1038,7 @@ static uint64_t fd_rank_trim(fd_count_rec *r, uint64_t n, uint32_t top_n) {
 static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                                   const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
                                   fd_count_rec **out, uint64_t **out_off) {
-    if (!c || !ix || !out || !out_off || !q_off || (ix->n_structures && !penalty)) return FDGPU_EINVAL;
+    if (!c || !ix || !out || !out_off || !q_off || (ix->n_structures && !penalty && !ix->penalty)) return FDGPU_EINVAL;
     *out = nullptr; *out_off = nullptr;
     reset_timings(c);
     hipStream_t st = c->stream;
@@ -1089,7 +1091,8 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     (void)hipMemcpyAsync(c->ws[WS_MISC3].p, idf_fix.data(), nq * 8, hipMemcpyHostToDevice, st);
     (void)hipMemcpyAsync(c->ws[WS_TILE_B].p, qq.data(), nq * 4, hipMemcpyHostToDevice, st);
     (void)hipMemcpyAsync(c->ws[WS_TILE_H].p, row_off.data(), n_queries * 16, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st);
+    if (penalty) (void)hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st);
+    const float *d_penalty = penalty ? c->ws[WS_MISC5].as<float>() : ix->penalty;
     if (!packed) (void)hipMemsetAsync(c->ws[WS_COUNTS].p, 0, QS * 4, st);
     (void)hipMemsetAsync(c->ws[WS_SEGOFF].p, 0, QS * 8, st);
     (void)hipMemsetAsync(c->ws[WS_KEYS_B].p, 0, (size_t)std::max<uint32_t>(n_edge_rows, 1) * words * 4, st);
@@ -1119,7 +1122,7 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     if (e == hipSuccess) e = c->ws[WS_TILE_PO].ensure((n_queries + 1) * 8 + 64);
     if (e == hipSuccess) {
         fd_launch_cq_compact_batch(A, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(),
-                                   c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_MISC5].as<float>(), QS, c->ws[WS_TILE_HO].p, st);
+                                   c->ws[WS_TILE_BO].as<uint64_t>(), d_penalty, QS, c->ws[WS_TILE_HO].p, st);
         // out_off[t] = scan position at t * S
         std::vector<uint64_t> idx(n_queries + 1);
         for (uint64_t t = 0; t <= n_queries; ++t) idx[t] = t * S;
@@ -1209,6 +1212,50 @@ extern "C" int fdgpu_count_query_batch_top(fdgpu_ctx *c, const fdgpu_index *ix, 
                                            const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty,
                                            uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
     return count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off);
+}
+
+// The length penalty nres^(-lp) of the index's structures (count_query.rs:200), kept on the device: count queries may then pass
+// penalty = NULL instead of uploading S floats per call.  penalty = NULL drops the resident copy.
+extern "C" int fdgpu_index_set_penalty(fdgpu_ctx *c, fdgpu_index *ix, const float *penalty) { FD_LOCK(c);
+    if (!c || !ix) return FDGPU_EINVAL;
+    if (ix->penalty) { (void)hipFree(ix->penalty); ix->penalty = nullptr; }
+    if (!penalty || !ix->n_structures) return FDGPU_OK;
+    HIPCHK(c, hipMalloc((void **)&ix->penalty, ix->n_structures * 4));
+    HIPCHK(c, hipMemcpy(ix->penalty, penalty, ix->n_structures * 4, hipMemcpyHostToDevice));
+    return FDGPU_OK;
+}
+
+// count_query for the query maps fdgpu_make_query_map[_batch] returned, without a round trip through the caller: the entries of
+// every map (hash, (qi, qj)) are scored with idf = log2(total_structures / posting length) of the hash ITSELF (count_query.rs:181-200;
+// the idf inside the map belongs to the pair's observed hash and feeds the retrieval's subgraph idf instead); hashes the index does
+// not hold are dropped.  Output as fdgpu_count_query_batch_top.
+extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty,
+                                          float total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
+    if (!c || !ix || !out || !out_off || (n_queries && !qms)) return FDGPU_EINVAL;
+    uint64_t nq = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) { if (!qms[t]) return FDGPU_EINVAL; nq += qms[t]->n; }
+    std::vector<uint32_t> h(std::max<uint64_t>(nq, 1));
+    std::vector<uint64_t> len(std::max<uint64_t>(nq, 1), 0);
+    uint64_t at = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) { if (qms[t]->n) memcpy(&h[at], qms[t]->hash, qms[t]->n * 4); at += qms[t]->n; }
+    int rc = nq && ix->n_structures ? fdgpu_posting_lengths(c, ix, h.data(), nq, len.data()) : FDGPU_OK;
+    if (rc) return rc;
+    std::vector<uint64_t> q_off(n_queries + 1, 0);
+    std::vector<uint32_t> qh, qn, qe;
+    std::vector<float> qi;
+    qh.reserve(nq); qn.reserve(nq); qe.reserve(nq); qi.reserve(nq);
+    at = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        const fd_query_map *m = qms[t];
+        for (uint64_t k = 0; k < m->n; ++k, ++at) {
+            if (!len[at]) continue;
+            qh.push_back(m->hash[k]); qn.push_back(m->qi[k]); qe.push_back(m->qj[k]);
+            qi.push_back(log2f(total_structures / (float)len[at]));       // f32 like the reference's (total / len).log2()
+        }
+        q_off[t + 1] = qh.size();
+    }
+    if (qh.empty()) { qh.push_back(0); qn.push_back(0); qe.push_back(0); qi.push_back(0.0f); }
+    return count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off);
 }
 
 // ---- S4 ---------------------------------------------------------------------------------------------------------------

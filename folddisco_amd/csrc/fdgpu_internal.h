@@ -138,6 +138,7 @@ struct fdgpu_index {
     uint32_t *last_ids = nullptr; // device [H] last structure id of every list (written by the encoder; the device merge re-bases the next
                                   // part's first delta against it); null for an index that was loaded — computed on demand
     size_t cap_hashes = 0, cap_offsets = 0, cap_value = 0, cap_last = 0;
+    float *penalty = nullptr;     // device [n_structures] length penalty set with fdgpu_index_set_penalty (count queries may then pass NULL)
 };
 
 // kernels / launchers implemented in the k_*.hip files

@@ -4,7 +4,6 @@ pair scan, Kabsch) run in libfdgpu.so; this module only marshals and formats."""
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
 
 import numpy as np
 
@@ -56,29 +55,38 @@ def res_chain_to_string(res):
     return ",".join(f"{chr(c)}{r}" for c, r, _ in res)
 
 
-@dataclass
+_QM_FIELDS = {   # attribute -> (pointer field, length field, dtype) of fd_query_map
+    "hash": ("hash", "n", np.uint32), "qi": ("qi", "n", np.uint32), "qj": ("qj", "n", np.uint32), "is_primary": ("is_primary", "n", np.uint8),
+    "idf": ("idf", "n", np.float32), "indices": ("indices", "n_indices", np.uint32), "aad_aa1": ("aad_aa1", "n_aad", np.uint8),
+    "aad_aa2": ("aad_aa2", "n_aad", np.uint8), "aad_dist": ("aad_dist", "n_aad", np.float32), "aad_qi": ("aad_qi", "n_aad", np.uint32),
+    "primary_hash": ("primary_hash", "n", np.uint32),
+}
+
+
 class QueryMapResult:
-    hash: np.ndarray
-    qi: np.ndarray
-    qj: np.ndarray
-    is_primary: np.ndarray
-    idf: np.ndarray
-    indices: np.ndarray
-    aad_aa1: np.ndarray
-    aad_aa2: np.ndarray
-    aad_dist: np.ndarray
-    aad_qi: np.ndarray
-    primary_hash: np.ndarray = None
-    handle: object = field(default=None, repr=False)
-    ctx: Context = field(default=None, repr=False)
+    """fd_query_map handle + numpy copies of its arrays, made on first use (a batch of queries that goes straight from
+    fdgpu_make_query_map_batch to fdgpu_count_query_maps_top / fdgpu_retrieve_batch never needs them on the Python side)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self.handle, self._cache = ctx, handle, {}
+
+    def __getattr__(self, name):
+        f = _QM_FIELDS.get(name)
+        if f is None:
+            raise AttributeError(name)
+        c = self.__dict__["_cache"]
+        if name not in c:
+            m = self.handle.contents
+            c[name] = _arr(getattr(m, f[0]), getattr(m, f[1]), f[2])
+        return c[name]
 
     def set_idf(self, idf: np.ndarray):
         """overwrite the per-entry idf (also inside the C struct fdgpu_retrieve reads): a caller that shards the index computes it
         from GLOBAL posting lengths of primary_hash (dist.global_posting_lengths)"""
         idf = np.ascontiguousarray(idf, np.float32)
-        assert len(idf) == len(self.hash)
+        assert len(idf) == int(self.handle.contents.n)
         C.memmove(self.handle.contents.idf, idf.ctypes.data, idf.nbytes)
-        self.idf = idf.copy()
+        self._cache["idf"] = idf.copy()
 
     def __del__(self):
         try:
@@ -89,7 +97,10 @@ class QueryMapResult:
 
 
 def _arr(ptr, n, dt):
-    return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].astype(dt, copy=True)
+    n = int(n)
+    if n == 0:
+        return np.zeros(0, dt)
+    return np.frombuffer((ptr._type_ * n).from_address(C.addressof(ptr.contents)), dtype=dt).copy()
 
 
 def make_query_map(ctx: Context, qbatch: Batch, q_indices, subs=None, index: FolddiscoIndex | None = None,
@@ -118,11 +129,7 @@ def make_query_map(ctx: Context, qbatch: Batch, q_indices, subs=None, index: Fol
 
 
 def _wrap_query_map(ctx, out) -> QueryMapResult:
-    m = out.contents
-    return QueryMapResult(_arr(m.hash, m.n, np.uint32), _arr(m.qi, m.n, np.uint32), _arr(m.qj, m.n, np.uint32),
-                          _arr(m.is_primary, m.n, np.uint8), _arr(m.idf, m.n, np.float32), _arr(m.indices, m.n_indices, np.uint32),
-                          _arr(m.aad_aa1, m.n_aad, np.uint8), _arr(m.aad_aa2, m.n_aad, np.uint8), _arr(m.aad_dist, m.n_aad, np.float32),
-                          _arr(m.aad_qi, m.n_aad, np.uint32), _arr(m.primary_hash, m.n, np.uint32), handle=out, ctx=ctx)
+    return QueryMapResult(ctx, out)
 
 
 def make_query_maps(ctx: Context, qbatch: Batch, queries, index: FolddiscoIndex | None = None, total_structures: float = 0.0,

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import dist as fdist
-from .api import PackedStructures, count_query, count_query_batch, idf_of_lengths, length_penalty
+from .api import PackedStructures, count_query, count_query_batch, count_query_maps, idf_of_lengths, length_penalty
 from .query import MATCH_DTYPE, make_query_map, make_query_maps, retrieve, retrieve_batch
 
 
@@ -59,6 +59,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     res_off_h = d["res_off"].cpu().numpy()
     nres = np.diff(res_off_h).astype(np.uint64)
     pen = length_penalty(nres, 0.5)
+    ix.set_penalty(pen)
     qbatches = [ctx.upload(PackedStructures.concat([it])) for _, _, it in queries]
     qall = ctx.upload(PackedStructures.concat([it for _, _, it in queries]))    # every query structure in one batch (batched legs)
     first = ix.first_id
@@ -125,8 +126,11 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                 if match and sharded:
                     for qm in qms:
                         set_global_idf(qm)
-                recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=top_n,
-                                         lengths_fn=(lambda l: fdist.reduce_lengths(l, dev)) if sharded else None)
+                if sharded:     # posting lengths must be all-reduced between the length pass and the scoring
+                    recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=top_n,
+                                             lengths_fn=lambda l: fdist.reduce_lengths(l, dev))
+                else:           # the query maps go back into the library as they are; the penalty is resident (set_penalty)
+                    recs = count_query_maps(ctx, ix, qms, None, total_structures=S_total, top_n=top_n)
                 globs = fdist.allgather_hits_many(recs, dev, top_n=top_n, ranked=True)
                 if match:   # one pair scan / gather / Kabsch launch for the whole chunk of queries
                     cl = [owned(g, match_top) for g in globs]

@@ -190,6 +190,18 @@ int fdgpu_count_query_batch(fdgpu_ctx *ctx, const fdgpu_index *ix, uint64_t n_qu
 int fdgpu_count_query_batch_top(fdgpu_ctx *ctx, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off,
                                 const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf,
                                 const float *penalty, uint32_t top_n, fd_count_rec **out, uint64_t **out_off);
+/* The length penalty nres^(-lp) of the index's structures (count_query.rs:200) kept on the device: fdgpu_count_query* may then be
+ * called with penalty = NULL instead of uploading n_structures floats per call.  penalty = NULL drops the resident copy. */
+int fdgpu_index_set_penalty(fdgpu_ctx *ctx, fdgpu_index *ix, const float *penalty);
+/* count_query for the query maps fdgpu_make_query_map[_batch] returned, without a round trip through the caller: every entry
+ * (hash, (qi, qj)) of every map is scored with idf = log2f(total_structures / posting length of the hash itself)
+ * (count_query.rs:181-200; the idf stored in the map belongs to the pair's observed hash and feeds the subgraph idf of the retrieval),
+ * hashes the index does not hold are dropped.  Output as fdgpu_count_query_batch_top (top_n = 0: everything, ascending nid).
+ * fd_query_map is declared further down. */
+struct fd_query_map;
+int fdgpu_count_query_maps_top(fdgpu_ctx *ctx, const fdgpu_index *ix, uint64_t n_queries, const struct fd_query_map *const *qms,
+                               const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off);
+
 
 /* ---- S4: candidate matching + RMSD --------------------------------------------------------------
  * Pair scan of retrieve_with_prefilter (src/controller/retrieve.rs:52-156) over candidate

@@ -1074,3 +1074,34 @@ def test_device_retrieval_glue_equals_host_glue(env, monkeypatch):
     cl = [fdist.rank_hits(r, 24)["nid"].astype(np.uint32) for r in recs]
     m2 = both(sb, None, cl, qms2, qb2, list(range(len(queries))))[0]
     assert len(m2) >= len(queries)          # every query finds at least itself
+
+
+@pytest.mark.gpu
+def test_count_query_maps_equals_count_query_batch(env):
+    """fdgpu_count_query_maps_top (query maps handed back to the library as they are, posting lengths + idf + scoring in one call,
+    penalty resident on the device) == the posting_lengths / idf_of_lengths / count_query_batch route, byte for byte; with and without
+    the top-N selection; a query with no hash in the index gives no records."""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    ctx, structs, batch, ix, nres, plddt, tids = env
+    q1, q2 = st.read_compact_structure(Q4CHA), st.read_compact_structure(Q1G2F)
+    qall = ctx.upload(fd.PackedStructures.concat([q1.as_item(), q2.as_item()]))
+    reqs = []
+    for sidx, q, qstr in [(0, q1, "B57,B102,C195"), (1, q2, "F207,F212,F225,F229"), (0, q1, "B57:HKR,B102,C195:ST"), (0, q1, "B57-62")]:
+        res = fq.parse_query_string(qstr, q.chains[0])
+        pairs = [(q.get_index(c, r), s) for c, r, s in res]
+        reqs.append((sidx, [i for i, _ in pairs], [s for _, s in pairs]))
+    qms = fq.make_query_maps(ctx, qall, reqs, ix, 5.0)
+    pen = fd.length_penalty(nres, 0.5)
+    for top_n in (0, 3):
+        want = fd.count_query_batch(ctx, ix, [(m.hash, m.qi, m.qj) for m in qms], pen, total_structures=5, top_n=top_n)
+        got = fd.count_query_maps(ctx, ix, qms, pen, total_structures=5, top_n=top_n)
+        ix.set_penalty(pen)
+        res_pen = fd.count_query_maps(ctx, ix, qms, None, total_structures=5, top_n=top_n)
+        ix.set_penalty(None)
+        assert len(got) == len(want) == 4 and sum(len(w) for w in want) > 0
+        for g, w, r in zip(got, want, res_pen):
+            assert g.tobytes() == w.tobytes() and r.tobytes() == w.tobytes()
+    with pytest.raises(Exception):
+        fd.count_query_maps(ctx, ix, qms, None, total_structures=5)          # no penalty given and none resident

@@ -25,7 +25,7 @@ def main():
     import folddisco_amd as fd
     from folddisco_amd import synth
     from folddisco_amd import dist as fdist
-    from folddisco_amd.api import PackedStructures, count_query_batch, length_penalty
+    from folddisco_amd.api import PackedStructures, count_query_batch, count_query_maps, length_penalty
     from folddisco_amd.query import make_query_maps, retrieve_batch
     from folddisco_amd.querybench import _pick_queries
     dev = torch.device("cuda", 0)
@@ -40,6 +40,7 @@ def main():
     queries = _pick_queries(d, S, a.queries, 4242)
     nres = np.diff(ro.cpu().numpy()).astype(np.uint64)
     pen = length_penalty(nres, 0.5)
+    ix.set_penalty(pen)
     qall = ctx.upload(PackedStructures.concat([it for _, _, it in queries]))
     T = {}
 
@@ -49,7 +50,7 @@ def main():
             t0 = time.perf_counter()
             qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix, float(S))
             t1 = time.perf_counter()
-            recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S, top_n=1000)
+            recs = count_query_maps(ctx, ix, qms, None, total_structures=S, top_n=1000)
             t2 = time.perf_counter()
             globs = fdist.allgather_hits_many(recs, None, top_n=1000, ranked=True)
             t3 = time.perf_counter()
