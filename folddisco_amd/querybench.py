@@ -80,8 +80,11 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         lens = fdist.global_posting_lengths(ix, qm.hash, dev) if sharded else None      # idf over the whole database
         if sharded and match:
             set_global_idf(qm)
-        recs = count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total, as_array=True, lengths=lens)
-        glob = fdist.allgather_hits(recs, dev, top_n=top_n)
+        if sharded:
+            recs = count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total, as_array=True, lengths=lens)
+            glob = fdist.allgather_hits(recs, dev, top_n=top_n)
+        else:       # one call: posting lengths, idf, scoring, top_n ranked on the device
+            glob = count_query_maps(ctx, ix, [qm], None, total_structures=S_total, top_n=top_n)[0]
         n_match = 0
         if match and len(glob):
             cand = owned(glob, match_top)
