@@ -600,6 +600,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         A.qt = (const rs_query_dev *)(dblk + o_qt); A.hashes = dblk + o_h; A.kfirst = dblk + o_kf; A.sym = (const uint8_t *)(dblk + o_sy);
         A.map_qi = dblk + o_qi; A.map_qj = dblk + o_qj; A.map_idf = (const float *)(dblk + o_idf); A.indices = dblk + o_idx;
         A.d0tab = (const float *)(dblk + o_d0); A.node_count = node_count;
+        { const char *nc_env = getenv("FDGPU_RS_NODE_CAP"); const long v = nc_env ? atol(nc_env) : 0; A.node_cap = v > 0 && v < FD_WAVE ? (uint32_t)v : FD_WAVE; }
         A.counters = c->ws[WS_RS_CNT].as<unsigned long long>(); A.flags = (uint32_t *)(A.counters + 4);
         A.matches = c->ws[WS_RS_OUT].as<rs_match_dev>(); A.residues = c->ws[WS_RS_RES].as<int32_t>();
         A.kx = c->ws[WS_RS_KX].as<float>(); A.ky = c->ws[WS_RS_KY].as<float>();

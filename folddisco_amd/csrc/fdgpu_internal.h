@@ -264,6 +264,7 @@ struct rs_args {
     const uint32_t *indices;
     const float *d0tab;                                  // d0_scale of metrics.rs:117-123 by point count (host powf)
     uint32_t node_count;
+    uint32_t node_cap;                                   // graph nodes per candidate the kernel accepts (64 lanes; tests lower it to reach the fallback)
     unsigned long long *counters;                        // [0] matches, [1] problems << 40 | points, [2] residue ints
     uint32_t *flags;                                     // bit 0: a slot beyond the kernel's limits, bit 1: an output buffer too small
     rs_match_dev *matches; int32_t *residues; float *kx, *ky; uint64_t *koff; float *d0;

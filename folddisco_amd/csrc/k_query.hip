@@ -287,9 +287,11 @@ __device__ __forceinline__ void cq_finalize_store(const uint32_t (&pn)[20], cons
         }
     __syncthreads();
     const uint32_t nid0 = blockIdx.x * CQ_FIN_T * 32;
-    for (uint32_t i = threadIdx.x; i < CQ_FIN_T * 32; i += CQ_FIN_T) {
+    const uint32_t lim = nid0 < S ? (S - nid0 < CQ_FIN_T * 32 ? S - nid0 : CQ_FIN_T * 32) : 0u;
+    // no early exit inside the loop: the loads of several iterations are in flight together (32 dependent round trips otherwise)
+#pragma unroll 8
+    for (uint32_t i = threadIdx.x; i < lim; i += CQ_FIN_T) {
         const uint32_t nid = nid0 + i;
-        if (nid >= S) break;
         const uint32_t at = (i >> 5) * 33 + (i & 31u);
         node_cnt[qbase + nid] = t_n[at];
         edge_cnt[qbase + nid] = t_e[at];

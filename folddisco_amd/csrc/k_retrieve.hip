@@ -139,7 +139,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
             const uint32_t r = z ? s_j[e] : s_i[e];
             const uint64_t m = __ballot(lane < n_nodes && node_res == r);
             if (m == 0ull) {
-                if (n_nodes == FD_WAVE) RS_OVERFLOW();
+                if (n_nodes == A.node_cap) RS_OVERFLOW();
                 if (lane == n_nodes) node_res = r;
                 ids[z] = n_nodes++;
             } else ids[z] = (uint32_t)__builtin_ctzll(m);

@@ -201,17 +201,16 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
 
             def wq(match):
                 qm = make_query_map(ctx, qb, allres, None, ix, float(S_total))
-                recs = count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total, as_array=True)
+                top = count_query_maps(ctx, ix, [qm], None, total_structures=S_total, top_n=top_n)[0]     # ranked on the device
                 n_m = 0
                 if match:
-                    top = fdist.rank_hits(recs, 20)
-                    n_m = len(retrieve(ctx, batch, None, (top["nid"].astype(np.int64) - first).astype(np.uint32), qm, qb))
-                return len(qm.hash), len(recs), n_m, qm
+                    n_m = len(retrieve(ctx, batch, None, (top["nid"][:20].astype(np.int64) - first).astype(np.uint32), qm, qb))
+                return len(qm.hash), n_m, qm
             wq(True)
-            t_pre, (nh, nt, _, qm) = timed(lambda: wq(False))
-            t_full, (_, _, n_m, _) = timed(lambda: wq(True))
+            t_pre, (nh, _, qm) = timed(lambda: wq(False))
+            t_full, (_, n_m, _) = timed(lambda: wq(True))
             ctx.enable_timing(True)
-            count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total, as_array=True)
+            nt = len(count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total, as_array=True))
             ctx.synchronize()
             stw = {n: ms for n, ms, _ in ctx.last_timings()}
             ctx.enable_timing(False)

@@ -1045,6 +1045,15 @@ def test_device_retrieval_glue_equals_host_glue(env, monkeypatch):
     for ca in (1.0, 1.5, 3.0):
         m = both(batch, std, [np.array(sp[3], np.uint32) for sp in specs], qms, qall, [sp[0] for sp in specs], ca)[0]
         assert len(m) >= 6
+    # a candidate beyond the kernel's limits (here: the node limit lowered to 2) raises the overflow flag and the call falls back to
+    # the host path as a whole: same tables again
+    monkeypatch.setenv("FDGPU_RS_NODE_CAP", "2")
+    over, names = run(batch, std, [np.array(sp[3], np.uint32) for sp in specs], qms, qall, [sp[0] for sp in specs], 1.0)
+    monkeypatch.delenv("FDGPU_RS_NODE_CAP")
+    ref_tables, _ = run(batch, std, [np.array(sp[3], np.uint32) for sp in specs], qms, qall, [sp[0] for sp in specs], 1.0)
+    assert "retrieve_slots" in names
+    for a, b in zip(over, ref_tables):
+        assert a.tobytes() == b.tobytes()
     # planted motifs in a synthetic database: 24 queries x their top 24 candidates
     S = 1500
     d = synth.generate(S, seed=91)
