@@ -54,6 +54,9 @@ struct fdgpu_ctx {
     std::vector<fd_timing_entry> timings;
     std::vector<hipEvent_t> event_pool;
     size_t event_used = 0;
+    // pinned staging of large device-to-host copies (fd_d2h_big in fdgpu_api.hip): FD_PIN_SLOTS buffers of FD_PIN_BYTES, made on first use
+    void *pin[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pin_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // device blocks of destroyed indices, reused by the next build (steady-state builds do not call
     // hipMalloc/hipFree, which would serialise the stream)
     struct pooled { void *p; size_t cap; };
