@@ -1318,8 +1318,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         if (cand[k] >= db->n_struct) FAIL(c, FDGPU_EINVAL, "match_pairs: candidate id outside the batch");
         n_tiles += (db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]] + FD_WAVE - 1) / FD_WAVE;
     }
-    uint32_t j_span = n_tiles && n_tiles < 1024 ? (n_tiles < 256 ? 64u : 128u) : 0u;
-    if (const char *js = getenv("FDGPU_JSPAN")) j_span = (uint32_t)atoi(js);     // measurement aid
+    const uint32_t j_span = n_tiles && n_tiles < 1024 ? (n_tiles < 256 ? 64u : 128u) : 0u;
     std::vector<uint32_t> wc, wi, wq, wj;
     for (uint64_t t = 0; t < n_queries; ++t)
         for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) {
