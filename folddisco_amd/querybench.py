@@ -146,7 +146,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         go()
         return timed(go)
 
-    MT_REPS = 4
+    MT_REPS = 12
 
     def batched_mt(workers=2, chunk=32):
         """the full batched query from `workers` host threads, one context (stream + workspaces) each, sharing the resident index and
@@ -183,14 +183,17 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     dt1, (hits, hashes, _) = timed(loop(False, range(len(queries))))
     dtb, hits_b = batched()
     dtbm, nm_b = batched(match=True)
-    dtb2 = None
+    dtb2, mt_workers, mt_all = None, 0, {}
     if not sharded and len(queries) >= 64:
-        try:
-            dtb2, nm_b2 = batched_mt(2)
-            assert nm_b2 == nm_b * MT_REPS, (nm_b2, nm_b)
-        except Exception as e:  # noqa: BLE001
-            dtb2 = None
-            print("[querybench] two-context leg failed: %r" % (e,), file=sys.stderr)
+        for wk in (2, 3, 4):
+            try:
+                t_w, nm_w = batched_mt(wk)
+                assert nm_w == nm_b * MT_REPS, (nm_w, nm_b)
+                mt_all[wk] = len(queries) * MT_REPS / t_w
+                if dtb2 is None or t_w < dtb2:
+                    dtb2, mt_workers = t_w, wk
+            except Exception as e:  # noqa: BLE001
+                print("[querybench] %d-context leg failed: %r" % (wk, e), file=sys.stderr)
     loop(True, warm)()
     dt2, (_, _, nm) = timed(loop(True, range(len(queries))))
 
@@ -280,12 +283,13 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         "n_queries": len(queries),
         "structures": S_total, "structures_per_gpu": S,
         "mode": "full query (make_query_map, count_query, all-gather + global top-%d, retrieval of the global top %d candidates on their owning "
-                "rank, Kabsch, metrics), batches of 32 queries; value = the better of one host thread and two (batched_with_matching[_2ctx])" % (top_n, match_top),
+                "rank, Kabsch, metrics), batches of 32 queries; value = the better of one host thread and several (batched_with_matching[_mt])" % (top_n, match_top),
         "ms_per_query": min(dtbm / len(queries), dtb2 / (len(queries) * MT_REPS) if dtb2 else 1e9) * 1e3,
         "batched_with_matching": {"value": len(queries) / dtbm, "ms_per_query": dtbm / len(queries) * 1e3, "matches": int(nm_b), "match_top": match_top},
-        "batched_with_matching_2ctx": None if not dtb2 else {
-            "value": len(queries) * MT_REPS / dtb2, "ms_per_query": dtb2 / (len(queries) * MT_REPS) * 1e3, "host_threads": 2, "queries": len(queries) * MT_REPS,
-            "mode": "the same full batched query driven by two host threads with one context (stream + workspaces) each, sharing the resident index"},
+        "batched_with_matching_mt": None if not dtb2 else {
+            "value": len(queries) * MT_REPS / dtb2, "ms_per_query": dtb2 / (len(queries) * MT_REPS) * 1e3, "host_threads": mt_workers, "queries": len(queries) * MT_REPS,
+            "queries_per_s_by_threads": {str(k): v for k, v in mt_all.items()},
+            "mode": "the same full batched query driven by several host threads with one context (stream + workspaces) each, sharing the resident index"},
         "batched": {"value": len(queries) / dtb, "ms_per_query": dtb / len(queries) * 1e3, "chunk": 32, "avg_hits": hits_b / len(queries),
                     "mode": "prefilter only: make_query_map_batch + count_query_batch_top + all-gather"},
         "single": {"value": len(queries) / dt1, "ms_per_query": dt1 / len(queries) * 1e3, "mode": "prefilter only, one query per call"},
