@@ -1114,3 +1114,49 @@ def test_count_query_maps_equals_count_query_batch(env):
             assert g.tobytes() == w.tobytes() and r.tobytes() == w.tobytes()
     with pytest.raises(Exception):
         fd.count_query_maps(ctx, ix, qms, None, total_structures=5)          # no penalty given and none resident
+
+
+@pytest.mark.gpu
+def test_two_contexts_share_one_resident_index(env):
+    """Two host threads, one context (stream + workspaces) each, query the SAME resident index and coordinate batch at the same
+    time (the bench's multi-thread leg; how rayon workers would call the ABI): every result equals the serial one."""
+    import threading
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    ctx, structs, batch, ix, nres, plddt, tids = env
+    q1, q2 = st.read_compact_structure(Q4CHA), st.read_compact_structure(Q1G2F)
+    qall = ctx.upload(fd.PackedStructures.concat([q1.as_item(), q2.as_item()]))
+    std = np.concatenate([s.resname_std() for s in structs])
+    reqs = []
+    for sidx, q, qstr in [(0, q1, "B57,B102,C195"), (1, q2, "F207,F212,F225,F229"), (0, q1, "B57:HKR,B102,C195:ST")]:
+        res = fq.parse_query_string(qstr, q.chains[0])
+        pairs = [(q.get_index(c, r), s) for c, r, s in res]
+        reqs.append((sidx, [i for i, _ in pairs], [s for _, s in pairs]))
+    ix.set_penalty(fd.length_penalty(nres, 0.5))
+
+    def once(cx):
+        qms = fq.make_query_maps(cx, qall, reqs, ix, 5.0)
+        recs = fd.count_query_maps(cx, ix, qms, None, total_structures=5, top_n=5)
+        cl = [r["nid"].astype(np.uint32) for r in recs]
+        tabs = fq.retrieve_batch(cx, batch, std, cl, qms, qall, [r[0] for r in reqs], as_arrays=True)
+        return b"".join(r.tobytes() for r in recs) + b"".join(t.tobytes() for t in tabs)
+
+    want = once(ctx)
+    ctx2 = fd.Context(0)
+    out, errs = {}, []
+
+    def worker(name, cx):
+        try:
+            out[name] = [once(cx) for _ in range(25)]
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=worker, args=("a", ctx)), threading.Thread(target=worker, args=("b", ctx2))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    ix.set_penalty(None)
+    ctx2.close()
+    assert not errs, errs
+    assert all(x == want for x in out["a"]) and all(x == want for x in out["b"])
