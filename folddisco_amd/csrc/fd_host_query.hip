@@ -666,6 +666,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         }
         if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue declined (flags %u): host path\n", dflags);
     }
+    if (trace) fprintf(stderr, "[fdgpu_retrieve] query tables %.3f ms\n", t_ms(T0, t_now()));
     rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc, two_pass ? 1u : 15u,
                               nullptr, nullptr, 0, &pk_key, &pk_val);
     if (rc) return rc;
