@@ -12,7 +12,10 @@
  *   G3  varint/offset known answer from src/index/indextable.rs:471-499
  *   G4  pair order / AA map / query grammar / Kabsch triads (reference unit tests)
  * see tests/test_oracle_golden.py.  The Rust reference itself cannot be built in
- * this image (no cargo/rustc), so there is no oracle/_ref.
+ * this image (no cargo/rustc); oracle/_ref holds only the reference's vendored C++
+ * Foldcomp decoder (oracle/Makefile target `ref`), which pins the Foldcomp ingest.
+ * Parity UNPINNED against reference output (the reference's tests print, they do not
+ * assert): the eight non-default encodings, LMS-QCP, the similarity metrics.
  *
  * Float rule: compile with -O2 -ffp-contract=off -fno-fast-math; libm = glibc
  * sinf/cosf/acosf/atan2f (what Rust's f32::sin etc. lower to on linux-gnu).
