@@ -532,7 +532,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     uint64_t max_nq = 0;
     for (uint64_t t = 0; t < n_queries; ++t) max_nq = std::max<uint64_t>(max_nq, qms[t]->n_indices);
     const char *hg_env = getenv("FDGPU_HOST_GLUE");      // 1 forces the host path (tests compare the two)
-    const bool dev_glue = !(hg_env && hg_env[0] == '1') && !two_pass && !partial_fit && max_nq <= FD_WAVE && max_nq > 0 && n_cand > 0 && n_cand < (1ull << 24);
+    const bool dev_glue = !(hg_env && hg_env[0] == '1') && !two_pass && !partial_fit && max_nq <= FD_WAVE && max_nq > 0 && n_cand > 0 && n_cand < (1ull << 20);
     if (dev_glue) {
         uint64_t nf_d = 0, nc_d = 0;
         fd_pair_rec *f_none = nullptr; fd_cand_rec *c_none = nullptr;
@@ -574,7 +574,8 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         memcpy(&blk[o_sq], t_slotq.data(), n_cand * 4);
         memcpy(&blk[o_cd], cand, n_cand * 4);
         memcpy(&blk[o_d0], d0tab, sizeof d0tab);
-        const uint64_t cap_m = std::max<uint64_t>(4096, 4 * n_cand), cap_prob = 2 * cap_m, cap_res = cap_m * 2 * max_nq, cap_pts = cap_prob * 2 * FD_WAVE;
+        const uint64_t cap_m = std::max<uint64_t>(4096, 4 * n_cand), cap_prob = 2 * cap_m, cap_res = cap_m * 2 * max_nq,
+                       cap_pts = cap_prob * 2 * max_nq;       // a mapping holds at most one target per query residue: <= 2 max_nq [CA, CB] points
         HIPCHK(c, c->ws[WS_RS_TAB].ensure(words * 4));
         HIPCHK(c, c->ws[WS_RS_SEG].ensure((6 * (n_cand + 1) + nf_d + nc_d + 4) * 4));
         HIPCHK(c, c->ws[WS_RS_OUT].ensure(cap_m * sizeof(rs_match_dev)));
