@@ -19,6 +19,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--structures", type=int, default=67750)
     ap.add_argument("--queries", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--no-profile", action="store_true")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -31,12 +33,31 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     S = a.structures
-    d = synth.generate(S, seed=7, device=dev)
     ctx = fd.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    # blocks of <= 67,750 structures (one build call each), merged on the device into one resident index — like bench.py
+    BLK = 67750
+    ds, parts, wraps = [], [], []
+    for b0 in range(0, S, BLK):
+        n = min(BLK, S - b0)
+        db = synth.generate(n, seed=7 + 1000 * (b0 // BLK), device=dev)
+        rb = db["res_off"].contiguous()
+        wb = ctx.wrap_device(n, int(rb[-1].item()), rb.data_ptr(), db["n_xyz"].data_ptr(), db["ca_xyz"].data_ptr(), db["cb_xyz"].data_ptr(),
+                             db["aa"].data_ptr(), None, keepalive=(rb, db))
+        parts.append(fd.FolddiscoIndex.build(ctx, wb, first_id=b0))
+        ds.append(db); wraps.append(wb)
+    ix = parts[0] if len(parts) == 1 else fd.FolddiscoIndexSet(parts).merge()
+    del parts
+    # one batch over all the coordinates (candidates are addressed by global structure index)
+    offs = [0]
+    for db in ds:
+        offs.append(offs[-1] + int(db["res_off"][-1].item()))
+    d = dict(res_off=torch.cat([db["res_off"][(1 if k else 0):] + offs[k] for k, db in enumerate(ds)]),
+             n_xyz=torch.cat([db["n_xyz"] for db in ds]), ca_xyz=torch.cat([db["ca_xyz"] for db in ds]), cb_xyz=torch.cat([db["cb_xyz"] for db in ds]),
+             aa=torch.cat([db["aa"] for db in ds]))
+    del ds, wraps
     ro = d["res_off"].contiguous()
     batch = ctx.wrap_device(S, int(ro[-1].item()), ro.data_ptr(), d["n_xyz"].data_ptr(), d["ca_xyz"].data_ptr(), d["cb_xyz"].data_ptr(),
                             d["aa"].data_ptr(), None, keepalive=(ro, d))
-    ix = fd.FolddiscoIndex.build(ctx, batch)
     queries = _pick_queries(d, S, a.queries, 4242)
     nres = np.diff(ro.cpu().numpy()).astype(np.uint64)
     pen = length_penalty(nres, 0.5)
@@ -63,12 +84,14 @@ def main():
 
     go(True)
     T.clear()
-    n_rep = 10
+    n_rep = a.reps
     t0 = time.perf_counter()
     for _ in range(n_rep):
         go(True)
     dt = time.perf_counter() - t0
     print(f"full batched: {a.queries * n_rep / dt:.0f} q/s; per 32-query batch: " + ", ".join(f"{k} {v / n_rep / (len(queries) / 32) * 1e3:.3f} ms" for k, v in T.items()))
+    if a.no_profile:
+        return
     os.environ["FDGPU_TRACE"] = "1"
     go(True)
     del os.environ["FDGPU_TRACE"]
