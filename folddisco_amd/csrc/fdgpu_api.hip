@@ -1076,7 +1076,7 @@ static uint64_t fd_rank_trim(fd_count_rec *r, uint64_t n, uint32_t top_n) {
 }
 static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                                   const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
-                                  fd_count_rec **out, uint64_t **out_off) {
+                                  fd_count_rec **out, uint64_t **out_off, bool allow_dense = true) {
     if (!c || !ix || !out || !out_off || !q_off || (ix->n_structures && !penalty && !ix->penalty)) return FDGPU_EINVAL;
     *out = nullptr; *out_off = nullptr;
     reset_timings(c);
@@ -1142,14 +1142,61 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>(); A.packed = packed ? 1 : 0;
     A.edge_bits = c->ws[WS_KEYS_B].as<uint32_t>(); A.edge_node = c->ws[WS_MISC1].as<uint32_t>();
     A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
+    const bool dense_topn = allow_dense && packed && top_n > 0 && top_n + 1024 <= 4096;
     {
         StageTimer t(c, "cq_batch", 0);
         int rs = cq_score(c, A, c->ws[WS_TILE_B].as<uint32_t>());
         if (rs) { free(ooff); return rs; }
         fd_launch_cq_batch(A, c->ws[WS_TILE_B].as<uint32_t>(), (uint32_t)n_queries, c->ws[WS_TILE_H].as<uint32_t>(), c->ws[WS_IDS_A].as<uint32_t>(),
                            c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), st);
-        fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), QS, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
-                                   c->ws[WS_TOTAL].as<uint64_t>(), st);
+        if (!dense_topn)
+            fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), QS, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
+                                       c->ws[WS_TOTAL].as<uint64_t>(), st);
+    }
+    if (dense_topn) {
+        // candidate selection straight from the dense accumulators (k_topn_*_dense + k_topn_sort): no flag scan, no compaction of every
+        // touched structure, one synchronisation instead of three
+        const uint32_t cap = top_n + 1024;
+        hipError_t e2 = c->ws[WS_KEYS_A].ensure((size_t)n_queries * cap * sizeof(fd_count_rec));
+        if (e2 == hipSuccess) e2 = c->ws[WS_TILE_HO].ensure((size_t)n_queries * top_n * sizeof(fd_count_rec));
+        const size_t topn_bytes = (size_t)n_queries * 2048 * 4;
+        if (e2 == hipSuccess && c->ws[WS_CQ_TOPN].cap < topn_bytes) {
+            e2 = c->ws[WS_CQ_TOPN].ensure(topn_bytes);
+            if (e2 == hipSuccess) e2 = hipMemsetAsync(c->ws[WS_CQ_TOPN].p, 0, c->ws[WS_CQ_TOPN].cap, st);
+        }
+        if (e2 == hipSuccess) e2 = c->ws[WS_MISC2].ensure(n_queries * 16);
+        std::vector<uint32_t> tstate((size_t)n_queries * 4);
+        std::vector<fd_count_rec> sel((size_t)n_queries * top_n);
+        if (e2 == hipSuccess) {
+            StageTimer t(c, "cq_topn", 0);
+            fd_launch_cq_topn_dense(A, d_penalty, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), (uint32_t)n_queries, top_n, cap,
+                                    c->ws[WS_KEYS_A].p, c->ws[WS_MISC2].p, c->ws[WS_CQ_TOPN].as<uint32_t>(), st);
+            fd_launch_cq_topn_sort(c->ws[WS_KEYS_A].p, cap, c->ws[WS_MISC2].p, (uint32_t)n_queries, top_n, c->ws[WS_TILE_HO].p, st);
+        }
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(tstate.data(), c->ws[WS_MISC2].p, n_queries * 16, hipMemcpyDeviceToHost, st);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(sel.data(), c->ws[WS_TILE_HO].p, sel.size() * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+        if (e2 == hipSuccess) e2 = hipGetLastError();
+        if (e2 != hipSuccess) { free(ooff); c->err = std::string("count_query_batch: ") + hipGetErrorString(e2); return FDGPU_EHIP; }
+        bool overflow = false;
+        uint64_t tot = 0;
+        for (uint64_t t = 0; t < n_queries; ++t) { overflow = overflow || tstate[4 * t + 3] > cap; tot += std::min<uint32_t>(tstate[4 * t + 3], top_n); }
+        if (overflow) {   // more ties at the cut-off than the selection's slots hold: the compacting path ranks that call
+            free(ooff);
+            return count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off, false);
+        }
+        fd_count_rec *rr = (fd_count_rec *)malloc(std::max<uint64_t>(tot, 1) * sizeof(fd_count_rec));
+        if (!rr) { free(ooff); return FDGPU_ENOMEM; }
+        uint64_t w = 0;
+        for (uint64_t t = 0; t < n_queries; ++t) {
+            const uint64_t m = std::min<uint32_t>(tstate[4 * t + 3], top_n);
+            ooff[t] = w;
+            if (m) memcpy(rr + w, sel.data() + (size_t)t * top_n, (size_t)m * sizeof(fd_count_rec));
+            w += m;
+        }
+        ooff[n_queries] = w;
+        *out = rr; *out_off = ooff;
+        return FDGPU_OK;
     }
     uint64_t n = 0;
     int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &n);

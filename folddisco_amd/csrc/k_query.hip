@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_topn_thr(const uint64_t *__restrict__ o
     __shared__ uint32_t part[256];
     __shared__ uint32_t s_bin, s_above;
     const uint32_t q = blockIdx.x;
-    const uint64_t m = off[q + 1] - off[q];
+    const uint64_t m = off ? off[q + 1] - off[q] : ~0ull;       // dense form: the number of touched structures is not known (nor needed)
     if (m <= top_n) { if (threadIdx.x == 0) { st[q].thr_bin = 0; st[q].above = 0; st[q].thr22 = 0; st[q].count = 0; } return; }
     uint32_t *h = ghist + (uint64_t)q * TOPN_BINS;
     // thread t owns bins [8 t, 8 t + 8); suffix sum over threads from the top
@@ -493,6 +493,64 @@ __global__ __launch_bounds__(256) void k_topn_sort(const fd_count_rec_dev *__res
 void fd_launch_cq_topn_sort(const void *sel, uint32_t cap, const void *state, uint32_t n_queries, uint32_t top_n, void *out, hipStream_t st) {
     if (n_queries) hipLaunchKernelGGL(k_topn_sort, dim3(n_queries), dim3(256), 0, st, (const fd_count_rec_dev *)sel, cap, (const topn_state *)state, top_n,
                                       (fd_count_rec_dev *)out);
+}
+
+// The same selection straight from the dense [queries][S] accumulators (packed form): no flag scan, no compaction of every touched
+// structure, two synchronisations fewer — the survivors' records are built at emit time.  Fewer touched structures than top_n: the
+// threshold search ends in bin 0 and everything with a count is emitted.
+struct topn_dense { const unsigned long long *acc; const float *penalty; const uint32_t *node_cnt, *edge_cnt; uint32_t S, first_id; };
+__device__ __forceinline__ bool topn_dense_key(const topn_dense &D, uint32_t q, uint32_t nid, uint32_t *key, float *idf, uint32_t *cnt) {
+    const unsigned long long a = D.acc[(uint64_t)q * D.S + nid];
+    *cnt = (uint32_t)(a >> CQ_CNT_SHIFT);
+    if (!*cnt) return false;
+    const float sum = (float)((double)(a & CQ_SUM_MASK) * (1.0 / IDF_SCALE));
+    *idf = sum * D.penalty[nid];
+    *key = idf_order_key(*idf);
+    return true;
+}
+__global__ __launch_bounds__(256) void k_topn_hist_dense(topn_dense D, int level, const topn_state *__restrict__ st, uint32_t *__restrict__ ghist) {
+    __shared__ uint32_t hist[TOPN_BINS];
+    const uint32_t q = blockIdx.y;
+    for (int k = threadIdx.x; k < TOPN_BINS; k += 256) hist[k] = 0;
+    __syncthreads();
+    const uint32_t b1 = level ? st[q].thr_bin : 0u;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < D.S; i += TOPN_SPLIT * 256) {
+        uint32_t key, cnt; float idf;
+        if (!topn_dense_key(D, q, i, &key, &idf, &cnt)) continue;
+        if (!level) atomicAdd(&hist[key >> 21], 1u);
+        else if ((key >> 21) == b1) atomicAdd(&hist[(key >> 10) & (TOPN_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < TOPN_BINS; k += 256) if (hist[k]) atomicAdd(&ghist[(uint64_t)q * TOPN_BINS + k], hist[k]);
+}
+__global__ __launch_bounds__(256) void k_topn_emit_dense(topn_dense D, uint32_t cap, topn_state *__restrict__ st, fd_count_rec_dev *__restrict__ out) {
+    const uint32_t q = blockIdx.y;
+    const uint32_t thr22 = st[q].thr22;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < D.S; i += TOPN_SPLIT * 256) {
+        uint32_t key, cnt; float idf;
+        if (!topn_dense_key(D, q, i, &key, &idf, &cnt) || (key >> 10) < thr22) continue;
+        const uint32_t pos = atomicAdd(&st[q].count, 1u);
+        if (pos < cap) {
+            fd_count_rec_dev r;
+            r.nid = i + D.first_id; r.total_match_count = cnt;
+            r.node_count = D.node_cnt[(uint64_t)q * D.S + i]; r.edge_count = D.edge_cnt[(uint64_t)q * D.S + i]; r.idf = idf;
+            out[(uint64_t)q * cap + pos] = r;
+        }
+    }
+}
+void fd_launch_cq_topn_dense(const cq_args &A, const float *penalty, const uint32_t *node_cnt, const uint32_t *edge_cnt, uint32_t n_queries, uint32_t top_n,
+                             uint32_t cap, void *out, void *state, uint32_t *ghist, hipStream_t st) {
+    if (!n_queries) return;
+    topn_dense D;
+    D.acc = A.idf; D.penalty = penalty; D.node_cnt = node_cnt; D.edge_cnt = edge_cnt; D.S = A.S; D.first_id = A.first_id;
+    topn_state *ts = (topn_state *)state;
+    (void)hipMemsetAsync(ts, 0, (size_t)n_queries * sizeof(topn_state), st);
+    const dim3 g(TOPN_SPLIT, n_queries);
+    hipLaunchKernelGGL(k_topn_hist_dense, g, dim3(256), 0, st, D, 0, ts, ghist);
+    hipLaunchKernelGGL(k_topn_thr, dim3(n_queries), dim3(256), 0, st, (const uint64_t *)nullptr, top_n, 0, ts, ghist);
+    hipLaunchKernelGGL(k_topn_hist_dense, g, dim3(256), 0, st, D, 1, ts, ghist);
+    hipLaunchKernelGGL(k_topn_thr, dim3(n_queries), dim3(256), 0, st, (const uint64_t *)nullptr, top_n, 1, ts, ghist);
+    hipLaunchKernelGGL(k_topn_emit_dense, g, dim3(256), 0, st, D, cap, ts, (fd_count_rec_dev *)out);
 }
 
 // state: n_queries topn_state + n_queries * 2048 u32 (zeroed once by the caller; the kernels leave the table zero)

@@ -50,11 +50,31 @@ __device__ __forceinline__ bool rs_less(uint64_t a, uint64_t b) {
 #define RS_SYNC() __syncthreads()
 #define RS_OVERFLOW() do { if (threadIdx.x == 0) atomicOr(A.flags, 1u); return; } while (0)
 
+// records of one candidate slot arrive in runs (a drain of the pair scan belongs to one slot): lanes that hold the same counter are
+// merged before the global atomic — one add per distinct slot and wavefront instead of one per record
+__device__ __forceinline__ uint32_t rs_agg_add(uint32_t *ctr, bool on, uint32_t key) {
+    uint32_t ret = 0;
+    uint64_t todo = __ballot(on);
+    while (todo) {
+        const uint32_t lead = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t k = (uint32_t)__shfl((int)key, (int)lead, FD_WAVE);
+        const uint64_t m = __ballot(on && key == k);
+        uint32_t base = 0;
+        if (fd_lane() == lead) base = atomicAdd(&ctr[k], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, (int)lead, FD_WAVE);
+        if (on && key == k) ret = base + fd_mbcnt(m);
+        todo &= ~m;
+    }
+    return ret;
+}
 __global__ void k_rs_count(const fd_pair_rec *__restrict__ found, uint64_t nf, const fd_cand_rec *__restrict__ cands, uint64_t nc, uint32_t n_cand,
                            uint32_t *__restrict__ cnt) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x < nf) { const uint32_t s = found[x].cand; if (s < n_cand) atomicAdd(&cnt[s], 1u); }
-    else if (x < nf + nc) { const uint32_t s = cands[x - nf].cand; if (s < n_cand) atomicAdd(&cnt[n_cand + 1 + s], 1u); }
+    uint32_t key = 0;
+    bool on = false;
+    if (x < nf) { const uint32_t s = found[x].cand; on = s < n_cand; key = s; }
+    else if (x < nf + nc) { const uint32_t s = cands[x - nf].cand; on = s < n_cand; key = n_cand + 1 + s; }
+    (void)rs_agg_add(cnt, on, key);
 }
 
 // exclusive scans of the two count arrays (one block; n_cand is a few thousand at most) -> segment starts + scatter cursors
@@ -79,8 +99,13 @@ __global__ __launch_bounds__(256) void k_rs_scan(const uint32_t *__restrict__ cn
 __global__ void k_rs_scatter(const fd_pair_rec *__restrict__ found, uint64_t nf, const fd_cand_rec *__restrict__ cands, uint64_t nc, uint32_t n_cand,
                              uint32_t *__restrict__ cur, uint32_t *__restrict__ perm_f, uint32_t *__restrict__ perm_c) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x < nf) { const uint32_t s = found[x].cand; if (s < n_cand) perm_f[atomicAdd(&cur[s], 1u)] = (uint32_t)x; }
-    else if (x < nf + nc) { const uint32_t s = cands[x - nf].cand; if (s < n_cand) perm_c[atomicAdd(&cur[n_cand + 1 + s], 1u)] = (uint32_t)(x - nf); }
+    uint32_t key = 0;
+    bool on = false;
+    const bool is_f = x < nf;
+    if (is_f) { const uint32_t s = found[x].cand; on = s < n_cand; key = s; }
+    else if (x < nf + nc) { const uint32_t s = cands[x - nf].cand; on = s < n_cand; key = n_cand + 1 + s; }
+    const uint32_t pos = rs_agg_add(cur, on, key);
+    if (on) { if (is_f) perm_f[pos] = (uint32_t)x; else perm_c[pos] = (uint32_t)(x - nf); }
 }
 
 __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {

@@ -6,7 +6,7 @@ REPO=$(pwd); OUT=$REPO/gpurun_out; RAW=/tmp/fdprofqb
 rm -rf $RAW; mkdir -p $OUT $RAW
 export TMPDIR=/tmp
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- python $REPO/tools/profile_query_host.py --structures 542000 --reps 30 --no-profile > $OUT/r2qb_trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- python $REPO/tools/profile_query_host.py --structures 542000 --reps ${REPS:-30} --chunk ${CHUNK:-32} --no-profile > $OUT/r2qb_trace.log 2>&1
 cd $REPO
 python - "$RAW" > $OUT/r2qb_kernels.txt <<'PY'
 import csv, glob, sys

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--structures", type=int, default=67750)
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--chunk", type=int, default=32, help="queries per batch")
     ap.add_argument("--no-profile", action="store_true")
     a = ap.parse_args()
     import numpy as np
@@ -66,8 +67,8 @@ def main():
     T = {}
 
     def go(match, trace=False):
-        for c0 in range(0, len(queries), 32):
-            ks = range(c0, min(c0 + 32, len(queries)))
+        for c0 in range(0, len(queries), a.chunk):
+            ks = range(c0, min(c0 + a.chunk, len(queries)))
             t0 = time.perf_counter()
             qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix, float(S))
             t1 = time.perf_counter()
@@ -89,7 +90,7 @@ def main():
     for _ in range(n_rep):
         go(True)
     dt = time.perf_counter() - t0
-    print(f"full batched: {a.queries * n_rep / dt:.0f} q/s; per 32-query batch: " + ", ".join(f"{k} {v / n_rep / (len(queries) / 32) * 1e3:.3f} ms" for k, v in T.items()))
+    print(f"full batched: {a.queries * n_rep / dt:.0f} q/s; per 32-query batch: " + ", ".join(f"{k} {v / n_rep / (len(queries) / a.chunk) * 1e3:.3f} ms" for k, v in T.items()))
     if a.no_profile:
         return
     os.environ["FDGPU_TRACE"] = "1"
