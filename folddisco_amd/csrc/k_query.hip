@@ -526,11 +526,18 @@ __global__ __launch_bounds__(256) void k_topn_hist_dense(topn_dense D, int level
 __global__ __launch_bounds__(256) void k_topn_emit_dense(topn_dense D, uint32_t cap, topn_state *__restrict__ st, fd_count_rec_dev *__restrict__ out) {
     const uint32_t q = blockIdx.y;
     const uint32_t thr22 = st[q].thr22;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < D.S; i += TOPN_SPLIT * 256) {
-        uint32_t key, cnt; float idf;
-        if (!topn_dense_key(D, q, i, &key, &idf, &cnt) || (key >> 10) < thr22) continue;
-        const uint32_t pos = atomicAdd(&st[q].count, 1u);
-        if (pos < cap) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i0 = blockIdx.x * 256; i0 < D.S; i0 += TOPN_SPLIT * 256) {       // wave-uniform trip count: one atomic per wavefront and step
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t key = 0, cnt = 0; float idf = 0.0f;
+        const bool keep = i < D.S && topn_dense_key(D, q, i, &key, &idf, &cnt) && (key >> 10) >= thr22;
+        const uint64_t m = __ballot(keep);
+        if (!m) continue;
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&st[q].count, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(m), FD_WAVE);
+        const uint32_t pos = base + fd_mbcnt(m);
+        if (keep && pos < cap) {
             fd_count_rec_dev r;
             r.nid = i + D.first_id; r.total_match_count = cnt;
             r.node_count = D.node_cnt[(uint64_t)q * D.S + i]; r.edge_count = D.edge_cnt[(uint64_t)q * D.S + i]; r.idf = idf;
