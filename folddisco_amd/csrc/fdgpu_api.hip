@@ -942,6 +942,28 @@ static inline uint64_t fd_idf_fix(float idf) {
     const double v = (double)idf;
     return (v > 0.0 && v < 1.0e6) ? (uint64_t)(v * 4194304.0 + 0.5) : 0ull;
 }
+// The rows of one query in (node, partner) order with their metadata word: idf (2^-22 fixed point) << 2 | last row of its node << 1 |
+// last row of its edge.  -> false when an idf does not fit the packed accumulator (>= 32).
+static bool fd_cq_rows(const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, uint64_t a, uint64_t b,
+                       std::vector<uint32_t> &rows_hash, std::vector<unsigned long long> &rows_meta) {
+    std::vector<uint64_t> ord(b - a);
+    for (uint64_t k = a; k < b; ++k) ord[k - a] = k;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint64_t x, uint64_t y) {
+        return q_node[x] != q_node[y] ? q_node[x] < q_node[y] : q_edge_j[x] < q_edge_j[y];
+    });
+    bool fits = true;
+    for (size_t z = 0; z < ord.size(); ++z) {
+        const uint64_t k = ord[z];
+        const uint64_t fix = fd_idf_fix(q_idf[k]);
+        fits = fits && fix < (1ull << 27);
+        const bool last = z + 1 == ord.size();
+        const bool node_end = last || q_node[ord[z + 1]] != q_node[k];
+        const bool edge_end = node_end || q_edge_j[ord[z + 1]] != q_edge_j[k];
+        rows_hash.push_back(q_hash[k]);
+        rows_meta.push_back(((unsigned long long)fix << 2) | (node_end ? 2ull : 0ull) | (edge_end ? 1ull : 0ull));
+    }
+    return fits;
+}
 static int cq_score(fdgpu_ctx *c, const cq_args &A, const uint32_t *q_query) {
     hipStream_t st = c->stream;
     HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(A.nq * 8));
@@ -970,34 +992,17 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     const uint64_t S = ix->n_structures;
     if (S == 0 || nq == 0) { *out = (fd_count_rec *)malloc(sizeof(fd_count_rec)); return *out ? FDGPU_OK : FDGPU_ENOMEM; }
     if (S >= 0xffffffe0ull) FAIL(c, FDGPU_ERANGE, "too many structures");
-    // dense node / edge numbering (node = first query residue of the pair, edge = (first, second))
-    std::vector<uint32_t> nodes(q_node, q_node + nq);
-    std::sort(nodes.begin(), nodes.end());
-    nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
-    std::vector<uint64_t> edges(nq);
-    for (uint64_t k = 0; k < nq; ++k) edges[k] = ((uint64_t)q_node[k] << 32) | q_edge_j[k];
-    std::sort(edges.begin(), edges.end());
-    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
-    std::vector<uint32_t> eidx(nq);
-    std::vector<uint64_t> idf_fix(nq);
-    bool packed = nq < (1ull << 18);
-    for (uint64_t k = 0; k < nq; ++k) {
-        eidx[k] = (uint32_t)(std::lower_bound(edges.begin(), edges.end(), ((uint64_t)q_node[k] << 32) | q_edge_j[k]) - edges.begin());
-        idf_fix[k] = fd_idf_fix(q_idf[k]);
-        packed = packed && idf_fix[k] < (1ull << 27);
-    }
-    const uint32_t NE = (uint32_t)edges.size();
-    std::vector<uint32_t> enode(std::max<uint32_t>(NE, 1));     // node (dense index) of every edge row: rows of one node are contiguous
-    for (uint32_t e = 0; e < NE; ++e) enode[e] = (uint32_t)(std::lower_bound(nodes.begin(), nodes.end(), (uint32_t)(edges[e] >> 32)) - nodes.begin());
+    std::vector<uint32_t> rows_hash;
+    std::vector<unsigned long long> rows_meta;
+    rows_hash.reserve(nq); rows_meta.reserve(nq);
+    const bool packed = fd_cq_rows(q_hash, q_node, q_edge_j, q_idf, 0, nq, rows_hash, rows_meta) && nq < (1ull << 18);
     const uint32_t words = (uint32_t)((S + 31) / 32);
     // workspace
-    HIPCHK(c, c->ws[WS_MISC0].ensure(nq * 4));   // q_hash
-    HIPCHK(c, c->ws[WS_MISC1].ensure((size_t)std::max<uint32_t>(NE, 1) * 4));   // node of every edge row
-    HIPCHK(c, c->ws[WS_MISC2].ensure(nq * 4));   // edge idx
-    HIPCHK(c, c->ws[WS_MISC3].ensure(nq * 8));   // idf fixed
+    HIPCHK(c, c->ws[WS_MISC0].ensure(nq * 4));   // query hashes in row order
+    HIPCHK(c, c->ws[WS_MISC3].ensure(nq * 8));   // row metadata
     HIPCHK(c, c->ws[WS_COUNTS].ensure(S * 4));   // match counts (wide form)
-    HIPCHK(c, c->ws[WS_SEGOFF].ensure((S + 2) * 8));  // (count, idf sum) accumulators
-    HIPCHK(c, c->ws[WS_KEYS_B].ensure((size_t)NE * words * 4));
+    HIPCHK(c, c->ws[WS_SEGOFF].ensure((S + 2) * 8));  // (count, idf sum)
+    HIPCHK(c, c->ws[WS_KEYS_B].ensure((size_t)nq * words * 4));   // occupancy rows
     HIPCHK(c, c->ws[WS_IDS_A].ensure(S * 4));    // node counts
     HIPCHK(c, c->ws[WS_IDS_B].ensure(S * 4));    // edge counts
     HIPCHK(c, c->ws[WS_MISC4].ensure(S + 8));    // flags
@@ -1005,42 +1010,25 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     HIPCHK(c, c->ws[WS_MISC5].ensure(S * 4));    // penalty
     HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(S) * 8 + 64));
     HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, enode.data(), (size_t)std::max<uint32_t>(NE, 1) * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, eidx.data(), nq * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC3].p, idf_fix.data(), nq * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, rows_hash.data(), nq * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC3].p, rows_meta.data(), nq * 8, hipMemcpyHostToDevice, st));
     if (penalty) HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st));
     const float *d_penalty = penalty ? c->ws[WS_MISC5].as<float>() : ix->penalty;
-    if (!packed) HIPCHK(c, hipMemsetAsync(c->ws[WS_COUNTS].p, 0, S * 4, st));
-    HIPCHK(c, hipMemsetAsync(c->ws[WS_SEGOFF].p, 0, S * 8, st));
-    HIPCHK(c, hipMemsetAsync(c->ws[WS_KEYS_B].p, 0, (size_t)NE * words * 4, st));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_KEYS_B].p, 0, (size_t)nq * words * 4, st));
     cq_args A;
     A.hashes = ix->hashes; A.offsets = ix->offsets; A.value = ix->value; A.H = ix->n_hashes;
-    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.q_edge_idx = c->ws[WS_MISC2].as<uint32_t>();
-    A.q_idf_fix = c->ws[WS_MISC3].as<uint64_t>(); A.nq = nq;
+    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.nq = nq;
+    A.hash_bits = c->ws[WS_KEYS_B].as<uint32_t>(); A.row_meta = c->ws[WS_MISC3].as<unsigned long long>();
     A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>(); A.packed = packed ? 1 : 0;
-    A.edge_bits = c->ws[WS_KEYS_B].as<uint32_t>(); A.edge_node = c->ws[WS_MISC1].as<uint32_t>();
     A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
     {
         StageTimer t(c, "cq_accumulate", 0);
         int rs = cq_score(c, A, nullptr);
         if (rs) return rs;
     }
-    std::vector<uint32_t> slices;        // outlives the asynchronous copy below (the stream is synchronised before this function returns)
     {
-        StageTimer t(c, "cq_finalize", (uint64_t)NE * words * 4 + S * 12);
-        // many edge rows (whole-structure queries): cut them into ~64 slices at node boundaries so that the chip is full
-        if (NE >= 2048) {
-            const uint32_t want = 64, per = (NE + want - 1) / want;
-            slices.push_back(0);
-            for (uint32_t e = 1; e < NE; ++e)
-                if (enode[e] != enode[e - 1] && e - slices.back() >= per) slices.push_back(e);
-            slices.push_back(NE);
-            HIPCHK(c, c->ws[WS_TILE_B].ensure(slices.size() * 4));
-            HIPCHK(c, hipMemcpyAsync(c->ws[WS_TILE_B].p, slices.data(), slices.size() * 4, hipMemcpyHostToDevice, st));
-        }
-        fd_launch_cq_finalize(A, NE, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(),
-                              slices.empty() ? nullptr : c->ws[WS_TILE_B].as<uint32_t>(), slices.empty() ? 0u : (uint32_t)slices.size() - 1, st);
+        StageTimer t(c, "cq_finalize", (uint64_t)nq * words * 4 + S * 16);
+        fd_launch_cq_rows_finalize(A, nullptr, 1, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), st);
         fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), S, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
                                    c->ws[WS_TOTAL].as<uint64_t>(), st);
     }
@@ -1087,68 +1075,44 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     if (S == 0 || nq == 0 || n_queries == 0) { *out = (fd_count_rec *)malloc(sizeof(fd_count_rec)); *out_off = ooff; return *out ? FDGPU_OK : FDGPU_ENOMEM; }
     if (!q_hash || !q_node || !q_edge_j || !q_idf) { free(ooff); return FDGPU_EINVAL; }
     if (S >= 0xffffffe0ull || n_queries * S >= (1ull << 34)) { free(ooff); FAIL(c, FDGPU_ERANGE, "count_query_batch: n_queries x n_structures too large; split the batch"); }
-    // global row numbering of the occupancy matrices: per query, its distinct nodes then its distinct edges
-    std::vector<uint32_t> erow(nq), qq(nq), row_off(4 * n_queries), enode;
-    std::vector<uint64_t> idf_fix(nq);
-    uint32_t n_node_rows = 0, n_edge_rows = 0;
+    // occupancy rows: the query hashes of the whole batch, per query in (node, partner) order
+    std::vector<uint32_t> rows_hash;
+    std::vector<unsigned long long> rows_meta;
+    rows_hash.reserve(nq); rows_meta.reserve(nq);
     bool packed = true;
     for (uint64_t t = 0; t < n_queries; ++t) {
-        uint64_t a = q_off[t], b = q_off[t + 1];
-        std::vector<uint32_t> nodes(q_node + a, q_node + b);
-        std::sort(nodes.begin(), nodes.end());
-        nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
-        std::vector<uint64_t> edges(b - a);
-        for (uint64_t k = a; k < b; ++k) edges[k - a] = ((uint64_t)q_node[k] << 32) | q_edge_j[k];
-        std::sort(edges.begin(), edges.end());
-        edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
-        packed = packed && (b - a) < (1ull << 18);
-        for (uint64_t k = a; k < b; ++k) {
-            erow[k] = n_edge_rows + (uint32_t)(std::lower_bound(edges.begin(), edges.end(), ((uint64_t)q_node[k] << 32) | q_edge_j[k]) - edges.begin());
-            qq[k] = (uint32_t)t;
-            idf_fix[k] = fd_idf_fix(q_idf[k]);
-            packed = packed && idf_fix[k] < (1ull << 27);
-        }
-        for (uint64_t e : edges) enode.push_back(n_node_rows + (uint32_t)(std::lower_bound(nodes.begin(), nodes.end(), (uint32_t)(e >> 32)) - nodes.begin()));
-        row_off[4 * t] = n_node_rows; row_off[4 * t + 1] = n_node_rows + (uint32_t)nodes.size();
-        row_off[4 * t + 2] = n_edge_rows; row_off[4 * t + 3] = n_edge_rows + (uint32_t)edges.size();
-        n_node_rows += (uint32_t)nodes.size(); n_edge_rows += (uint32_t)edges.size();
+        packed = packed && (q_off[t + 1] - q_off[t]) < (1ull << 18);
+        packed = fd_cq_rows(q_hash, q_node, q_edge_j, q_idf, q_off[t], q_off[t + 1], rows_hash, rows_meta) && packed;
     }
     const uint32_t words = (uint32_t)((S + 31) / 32);
     const uint64_t QS = n_queries * S;
     hipError_t e = hipSuccess;
     auto need = [&](int w, size_t bytes) { if (e == hipSuccess) e = c->ws[w].ensure(bytes); };
-    if (enode.empty()) enode.push_back(0);
-    need(WS_MISC0, nq * 4); need(WS_MISC1, enode.size() * 4); need(WS_MISC2, nq * 4); need(WS_MISC3, nq * 8); need(WS_TILE_B, nq * 4);
-    need(WS_TILE_H, n_queries * 16 + 16); need(WS_COUNTS, packed ? 64 : QS * 4); need(WS_SEGOFF, QS * 8 + 16);
-    need(WS_KEYS_B, (size_t)std::max<uint32_t>(n_edge_rows, 1) * words * 4);
+    need(WS_MISC0, nq * 4); need(WS_MISC3, nq * 8); need(WS_TILE_H, (n_queries + 1) * 8);
+    need(WS_COUNTS, packed ? 64 : QS * 4); need(WS_SEGOFF, QS * 8 + 16);
+    need(WS_KEYS_B, (size_t)nq * words * 4);
     need(WS_IDS_A, QS * 4); need(WS_IDS_B, QS * 4); need(WS_MISC4, QS + 8); need(WS_TILE_BO, (QS + 2) * 8); need(WS_MISC5, S * 4);
     need(WS_SCANTMP, fd_scan_tmp_elems(QS) * 8 + 64); need(WS_TOTAL, 64);
     if (e != hipSuccess) { free(ooff); c->err = std::string("count_query_batch workspace: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-    (void)hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(c->ws[WS_MISC1].p, enode.data(), enode.size() * 4, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(c->ws[WS_MISC2].p, erow.data(), nq * 4, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(c->ws[WS_MISC3].p, idf_fix.data(), nq * 8, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(c->ws[WS_TILE_B].p, qq.data(), nq * 4, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(c->ws[WS_TILE_H].p, row_off.data(), n_queries * 16, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(c->ws[WS_MISC0].p, rows_hash.data(), nq * 4, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(c->ws[WS_MISC3].p, rows_meta.data(), nq * 8, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(c->ws[WS_TILE_H].p, q_off, (n_queries + 1) * 8, hipMemcpyHostToDevice, st);
     if (penalty) (void)hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st);
     const float *d_penalty = penalty ? c->ws[WS_MISC5].as<float>() : ix->penalty;
-    if (!packed) (void)hipMemsetAsync(c->ws[WS_COUNTS].p, 0, QS * 4, st);
-    (void)hipMemsetAsync(c->ws[WS_SEGOFF].p, 0, QS * 8, st);
-    (void)hipMemsetAsync(c->ws[WS_KEYS_B].p, 0, (size_t)std::max<uint32_t>(n_edge_rows, 1) * words * 4, st);
+    (void)hipMemsetAsync(c->ws[WS_KEYS_B].p, 0, (size_t)nq * words * 4, st);
     cq_args A;
     A.hashes = ix->hashes; A.offsets = ix->offsets; A.value = ix->value; A.H = ix->n_hashes;
-    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.q_edge_idx = c->ws[WS_MISC2].as<uint32_t>();
-    A.q_idf_fix = c->ws[WS_MISC3].as<uint64_t>(); A.nq = nq;
+    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.nq = nq;
+    A.hash_bits = c->ws[WS_KEYS_B].as<uint32_t>(); A.row_meta = c->ws[WS_MISC3].as<unsigned long long>();
     A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>(); A.packed = packed ? 1 : 0;
-    A.edge_bits = c->ws[WS_KEYS_B].as<uint32_t>(); A.edge_node = c->ws[WS_MISC1].as<uint32_t>();
     A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
     const bool dense_topn = allow_dense && packed && top_n > 0 && top_n + 1024 <= 4096;
     {
         StageTimer t(c, "cq_batch", 0);
-        int rs = cq_score(c, A, c->ws[WS_TILE_B].as<uint32_t>());
+        int rs = cq_score(c, A, nullptr);
         if (rs) { free(ooff); return rs; }
-        fd_launch_cq_batch(A, c->ws[WS_TILE_B].as<uint32_t>(), (uint32_t)n_queries, c->ws[WS_TILE_H].as<uint32_t>(), c->ws[WS_IDS_A].as<uint32_t>(),
-                           c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), st);
+        fd_launch_cq_rows_finalize(A, c->ws[WS_TILE_H].as<uint64_t>(), (uint32_t)n_queries, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(),
+                                   c->ws[WS_MISC4].as<uint8_t>(), st);
         if (!dense_topn)
             fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), QS, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
                                        c->ws[WS_TOTAL].as<uint64_t>(), st);

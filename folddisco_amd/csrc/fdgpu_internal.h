@@ -178,22 +178,22 @@ void fd_launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t n, 
 // k_query.hip
 struct cq_args {
     const uint32_t *hashes; const uint64_t *offsets; const uint8_t *value; uint64_t H;
-    const uint32_t *q_hash; const uint32_t *q_edge_idx; const uint64_t *q_idf_fix; uint64_t nq;
-    uint32_t *match;                 // [queries][S] match counts — wide form only
-    unsigned long long *idf;         // [queries][S] idf sums (2^-22 units); packed form: count << 46 | sum
+    const uint32_t *q_hash; uint64_t nq;       // the query hashes of the call, per query sorted by (node, partner): row k of hash_bits belongs to q_hash[k]
+    uint32_t *hash_bits;                       // [nq][words] occupancy: bit s of row k = structure s holds hash k
+    const unsigned long long *row_meta;        // [nq] idf (2^-22 fixed point) << 2 | last row of its node << 1 | last row of its edge
+    uint32_t *match;                           // [queries][S] match counts — wide form only
+    unsigned long long *idf;                   // [queries][S] idf sums (2^-22 units); packed form: count << 46 | sum
     int packed;
-    uint32_t *edge_bits;             // [edge rows][words] occupancy
-    const uint32_t *edge_node;       // [edge rows] node (first query residue) of every edge row: rows of one node are contiguous
     uint32_t words; uint32_t first_id; uint32_t S;
 };
+
 void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,
                                uint64_t nq, uint64_t *lengths, long long *kidx, uint32_t *nseg, uint64_t *wstart, uint64_t *scan_tmp, uint64_t *total,
                                hipStream_t st);
 void fd_launch_cq_plan(const cq_args &A, long long *kidx, uint32_t *nseg, hipStream_t st);
 void fd_launch_cq_seg(const cq_args &A, const uint32_t *q_query, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
                       hipStream_t st);
-void fd_launch_cq_finalize(const cq_args &A, uint32_t n_edges, uint32_t *node_cnt, uint32_t *edge_cnt, uint8_t *flags, const uint32_t *slices, uint32_t n_slices,
-                           hipStream_t st);
+void fd_launch_cq_rows_finalize(const cq_args &A, const uint64_t *q_rows, uint32_t n_queries, uint32_t *node_cnt, uint32_t *edge_cnt, uint8_t *flags, hipStream_t st);
 void fd_launch_cq_compact(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_cnt, const uint32_t *edge_cnt,
                           const uint8_t *flags, const uint64_t *pos, const float *penalty, uint32_t S, uint32_t first_id, void *out,
                           hipStream_t st);
@@ -237,8 +237,6 @@ void fd_launch_metrics(const float *ref, const float *mov, const uint64_t *off, 
                        hipStream_t st);
 void fd_launch_lms_qcp(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, uint32_t *core_len,
                        uint8_t *flags, uint32_t *order, hipStream_t st);
-void fd_launch_cq_batch(const cq_args &A, const uint32_t *q_query, uint32_t n_queries, const uint32_t *row_off, uint32_t *node_cnt, uint32_t *edge_cnt,
-                        uint8_t *flags, hipStream_t st);
 void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, const uint32_t *edge_cnt, const uint8_t *flags, const uint64_t *pos,
                                 const float *penalty, uint64_t total, void *out, hipStream_t st);
 void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries, uint32_t top_n, uint32_t cap, void *out, void *state, uint32_t *ghist,

@@ -5,16 +5,17 @@
 // count_query (src/controller/count_query.rs:82-220: per query node, scan the postings of its
 // hashes, match_count += 1, idf_sum += log2(S/len), node / edge occupancy bit-vectors, then merge).
 //
-// Mapping: one wavefront per query hash. The list is consumed in 64-byte blocks (one byte per
-// lane): a ballot over the continuation bits finds the terminator lanes, each terminator
-// reassembles its value from the (<= 4) preceding lanes with shuffles, a wave prefix sum over the
-// deltas turns them into structure ids, and the ids are scored with integer atomics:
-//   match_count  u32 add
-//   idf_sum      u64 add of round(idf * 2^40)  (order-independent, unlike the reference's f32 sum whose
-//                order follows FxHashMap iteration; BASELINE.md §2 states the 1e-5 tolerance)
-//   node / edge occupancy  atomicOr into [n_nodes + n_edges][ceil(S/32)] bit matrices.
-// The finalize kernel counts set bits per structure with bit-sliced (carry-save) counters, 32
-// structures per lane, so its cost is (nodes+edges)·S/8 bytes of reads — SURVEY §8(d)'s figure.
+// Mapping: posting lists are cut into 2 KB segments (see k_cq_seg).  A segment is consumed in 64-byte blocks (one byte per lane): a
+// ballot over the continuation bits finds the terminator lanes, each terminator reassembles its value from the (<= 4) preceding
+// lanes with shuffles, a wave prefix sum over the deltas turns them into structure ids.  Scoring is ONE integer atomic per posting:
+// the posting sets bit `structure` in the occupancy row of ITS QUERY HASH — a posting list holds a structure at most once, so the
+// matrix [query hashes][ceil(S/32)] holds exactly which (hash, structure) pairs matched.  Everything count_query reports follows
+// from it in k_cq_rows_finalize, one thread per structure walking its query's rows (sorted by (node, partner) on the host):
+//   match_count  number of set rows;   idf_sum  sum of the rows' idf in 2^-22 fixed point (order-independent, unlike the reference's
+//   f32 sum whose order follows FxHashMap iteration; BASELINE.md §2 states the 1e-5 tolerance);   edge_count / node_count  number
+//   of (node, partner) / node groups with a set row.
+// (Before: four atomics per posting — count, idf, node bit, edge bit — then two; measured 16-30 G atomics/s whatever their mix,
+// so the posting's cost IS its atomics: 630 us per 32 motif queries at 542 k structures with two, ~330 with one.)
 #include <algorithm>
 #include "fdgpu_internal.h"
 
@@ -187,15 +188,8 @@ __global__ __launch_bounds__(FD_WAVE) void k_cq_seg(cq_args A, const uint32_t *_
             for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, FD_WAVE);
             run_id = acc;
         }
-        unsigned long long idf_fix = 0;
-        uint32_t *match = nullptr, *eb = nullptr;
-        unsigned long long *idf = nullptr;
-        if (!SUMS) {
-            idf_fix = A.q_idf_fix[q] + (A.packed ? 1ull << CQ_CNT_SHIFT : 0ull);
-            const uint64_t qbase = q_query ? (uint64_t)q_query[q] * A.S : 0ull;
-            match = A.match + qbase; idf = A.idf + qbase;
-            eb = A.edge_bits + (uint64_t)A.q_edge_idx[q] * A.words;
-        }
+        uint32_t *hb = nullptr;
+        if (!SUMS) hb = A.hash_bits + (uint64_t)q * A.words;     // the occupancy row of this query hash
         uint32_t seg_acc = 0;
         for (uint64_t base = s0; base < s1; base += FD_WAVE) {
             const uint64_t p = base + lane;
@@ -222,11 +216,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_cq_seg(cq_args A, const uint32_t *_
             const uint32_t id = run_id + s2;
             if (!SUMS && term) {
                 const uint32_t rel = id - A.first_id;
-                if (id >= A.first_id && rel < A.S) {     // two atomics per posting: (count, idf) and the edge bit; node bits derive from edges
-                    if (!A.packed) atomicAdd(&match[rel], 1u);
-                    atomicAdd(&idf[rel], idf_fix);
-                    atomicOr(&eb[rel >> 5], 1u << (rel & 31u));
-                }
+                if (id >= A.first_id && rel < A.S) atomicOr(&hb[rel >> 5], 1u << (rel & 31u));     // the posting's one atomic
             }
             if (tm) {
                 const int last_t = 63 - __clzll(tm);
@@ -259,70 +249,46 @@ void fd_launch_cq_seg(const cq_args &A, const uint32_t *q_query, const long long
     hipLaunchKernelGGL(k_cq_seg<false>, dim3(grid), dim3(FD_WAVE), 0, st, A, q_query, P);
 }
 
-// bit-sliced per-structure popcount over `rows` bit-vectors: lane handles one 32-structure word column
-__device__ __forceinline__ void sliced_add(uint32_t *pl, uint32_t x) {
+// count_query's per-structure results from the hash occupancy rows: thread = structure, loop = the rows of its query in (node,
+// partner) order; row_meta[r] = idf in 2^-22 fixed point << 2 | last row of its node << 1 | last row of its edge.  The 64 lanes of a
+// wavefront read two words per row (broadcast loads), four rows in flight.
+__global__ __launch_bounds__(256) void k_cq_rows_finalize(const uint32_t *__restrict__ hash_bits, const unsigned long long *__restrict__ row_meta,
+                                                          const uint64_t *__restrict__ q_rows /*[nQ + 1] or null = one query over n_rows*/, uint64_t n_rows,
+                                                          uint32_t words, uint32_t S, int packed, uint32_t *__restrict__ match,
+                                                          unsigned long long *__restrict__ acc, uint32_t *__restrict__ node_cnt,
+                                                          uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
+    const uint32_t nid = blockIdx.x * 256 + threadIdx.x, qy = blockIdx.y;
+    if (nid >= S) return;
+    const uint64_t r0 = q_rows ? q_rows[qy] : 0ull, r1 = q_rows ? q_rows[qy + 1] : n_rows;
+    const uint32_t w = nid >> 5, b = nid & 31u;
+    uint32_t cnt = 0, ec = 0, nc = 0, e_or = 0, n_or = 0;
+    unsigned long long sum = 0;
+    uint64_t r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        uint32_t x[4];
+        unsigned long long m[4];
 #pragma unroll
-    for (int k = 0; k < 20; ++k) {
-        uint32_t c = pl[k] & x;
-        pl[k] ^= x;
-        x = c;
-    }
-}
-
-// The per-word bit planes of a block's 128 words -> per-structure counts, written COALESCED: each thread unpacks its own word into an
-// LDS tile (row stride 33: conflict-free), then the block streams the tile out structure-major together with the touched flags.  (One
-// thread writing its 32 structures directly costs 32 partial-line stores per wavefront instruction: 0.4 ms per query batch at 542 k
-// structures, eight times the coalesced form.)
-#define CQ_FIN_T 128
-__device__ __forceinline__ void cq_finalize_store(const uint32_t (&pn)[20], const uint32_t (&pe)[20], bool live, uint32_t S, uint64_t qbase,
-                                                  const uint32_t *__restrict__ match, const unsigned long long *__restrict__ acc,
-                                                  uint32_t *__restrict__ node_cnt, uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
-    __shared__ uint32_t t_n[CQ_FIN_T * 33], t_e[CQ_FIN_T * 33];
-    if (live)
-        for (uint32_t b = 0; b < 32; ++b) {
-            uint32_t nc = 0, ec = 0;
+        for (int u = 0; u < 4; ++u) { x[u] = hash_bits[(r + u) * words + w]; m[u] = row_meta[r + u]; }
 #pragma unroll
-            for (int k = 0; k < 20; ++k) { nc |= ((pn[k] >> b) & 1u) << k; ec |= ((pe[k] >> b) & 1u) << k; }
-            t_n[threadIdx.x * 33 + b] = nc; t_e[threadIdx.x * 33 + b] = ec;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t bit = (x[u] >> b) & 1u;
+            cnt += bit; sum += bit ? m[u] >> 2 : 0ull; e_or |= bit;
+            if (m[u] & 1ull) { ec += e_or; n_or |= e_or; e_or = 0; }
+            if (m[u] & 2ull) { nc += n_or; n_or = 0; }
         }
-    __syncthreads();
-    const uint32_t nid0 = blockIdx.x * CQ_FIN_T * 32;
-    const uint32_t lim = nid0 < S ? (S - nid0 < CQ_FIN_T * 32 ? S - nid0 : CQ_FIN_T * 32) : 0u;
-    // no early exit inside the loop: the loads of several iterations are in flight together (32 dependent round trips otherwise)
-#pragma unroll 8
-    for (uint32_t i = threadIdx.x; i < lim; i += CQ_FIN_T) {
-        const uint32_t nid = nid0 + i;
-        const uint32_t at = (i >> 5) * 33 + (i & 31u);
-        node_cnt[qbase + nid] = t_n[at];
-        edge_cnt[qbase + nid] = t_e[at];
-        flags[qbase + nid] = (match ? match[qbase + nid] != 0u : acc[qbase + nid] != 0ull) ? 1 : 0;     // packed form (match == null): count in the top bits
     }
-}
-
-// node occupancy = OR of the node's edge rows (a matched hash names its node through its edge; edge rows are sorted by (node, partner),
-// so a node's rows are contiguous and edge_node[e] changes exactly at the group boundaries): no node-bit atomics, no node matrix
-__device__ __forceinline__ void cq_count_rows(const uint32_t *__restrict__ edge_bits, const uint32_t *__restrict__ edge_node, uint32_t e0, uint32_t e1,
-                                              uint32_t words, uint32_t w, uint32_t (&pn)[20], uint32_t (&pe)[20]) {
-    uint32_t cur = 0, prev = e0 < e1 ? edge_node[e0] : 0u;
-    for (uint32_t e = e0; e < e1; ++e) {
-        const uint32_t x = edge_bits[(uint64_t)e * words + w], n = edge_node[e];
-        if (n != prev) { sliced_add(pn, cur); cur = 0; prev = n; }
-        cur |= x;
-        sliced_add(pe, x);
+    for (; r < r1; ++r) {
+        const uint32_t bit = (hash_bits[r * words + w] >> b) & 1u;
+        const unsigned long long m = row_meta[r];
+        cnt += bit; sum += bit ? m >> 2 : 0ull; e_or |= bit;
+        if (m & 1ull) { ec += e_or; n_or |= e_or; e_or = 0; }
+        if (m & 2ull) { nc += n_or; n_or = 0; }
     }
-    sliced_add(pn, cur);
-}
-__global__ __launch_bounds__(CQ_FIN_T) void k_cq_finalize(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ acc,
-                                                          const uint32_t *__restrict__ edge_bits, const uint32_t *__restrict__ edge_node, uint32_t n_edges,
-                                                          uint32_t words, uint32_t S, uint32_t *__restrict__ node_cnt, uint32_t *__restrict__ edge_cnt,
-                                                          uint8_t *__restrict__ flags) {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = w < words;
-    uint32_t pn[20], pe[20];
-#pragma unroll
-    for (int k = 0; k < 20; ++k) { pn[k] = 0; pe[k] = 0; }
-    if (live) cq_count_rows(edge_bits, edge_node, 0, n_edges, words, w, pn, pe);
-    cq_finalize_store(pn, pe, live, S, 0, match, acc, node_cnt, edge_cnt, flags);
+    const uint64_t g = (uint64_t)qy * S + nid;
+    if (packed) acc[g] = ((unsigned long long)cnt << CQ_CNT_SHIFT) | sum;
+    else { acc[g] = sum; match[g] = cnt; }
+    node_cnt[g] = nc; edge_cnt[g] = ec;
+    flags[g] = cnt ? 1 : 0;
 }
 
 
@@ -345,23 +311,7 @@ __global__ __launch_bounds__(256) void k_cq_compact(const uint32_t *__restrict__
 }
 
 // ------------------------------------------------------------------ batched scoring (many queries, one launch each)
-// Same arithmetic as above; query hash k belongs to query A.q_query[k]; accumulators are [n_queries][S], the
-// occupancy bit matrix has one row per (query, node) and per (query, edge) (A.q_node_idx / q_edge_idx are global rows).
-__global__ __launch_bounds__(CQ_FIN_T) void k_cq_finalize_batch(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ acc,
-                                                                const uint32_t *__restrict__ edge_bits, const uint32_t *__restrict__ edge_node,
-                                                                const uint32_t *__restrict__ row_off /*[4*nQ]: n0,n1,e0,e1*/, uint32_t words, uint32_t S,
-                                                                uint32_t *__restrict__ node_cnt, uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t qy = blockIdx.y;
-    const bool live = w < words;
-    const uint32_t e0 = row_off[4 * qy + 2], e1 = row_off[4 * qy + 3];
-    uint32_t pn[20], pe[20];
-#pragma unroll
-    for (int k = 0; k < 20; ++k) { pn[k] = 0; pe[k] = 0; }
-    if (live) cq_count_rows(edge_bits, edge_node, e0, e1, words, w, pn, pe);
-    cq_finalize_store(pn, pe, live, S, (uint64_t)qy * S, match, acc, node_cnt, edge_cnt, flags);
-}
-
+// Same arithmetic as above; the per-structure results are [n_queries][S], the occupancy matrix has one row per query hash of the batch.
 __global__ __launch_bounds__(256) void k_cq_compact_batch(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ idf,
                                                           const uint32_t *__restrict__ node_cnt, const uint32_t *__restrict__ edge_cnt,
                                                           const uint8_t *__restrict__ flags, const uint64_t *__restrict__ pos,
@@ -574,11 +524,11 @@ void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries
     hipLaunchKernelGGL(k_topn_emit, g, dim3(256), 0, st, r, off, cap, ts, (fd_count_rec_dev *)out);
 }
 
-void fd_launch_cq_batch(const cq_args &A, const uint32_t *q_query, uint32_t n_queries, const uint32_t *row_off, uint32_t *node_cnt, uint32_t *edge_cnt,
-                        uint8_t *flags, hipStream_t st) {
-    if (A.words && n_queries)
-        hipLaunchKernelGGL(k_cq_finalize_batch, dim3((A.words + CQ_FIN_T - 1) / CQ_FIN_T, n_queries), dim3(CQ_FIN_T), 0, st, A.packed ? nullptr : A.match, A.idf,
-                           A.edge_bits, A.edge_node, row_off, A.words, A.S, node_cnt, edge_cnt, flags);
+// q_rows: device [n_queries + 1] row ranges (null: one query over all A.nq rows)
+void fd_launch_cq_rows_finalize(const cq_args &A, const uint64_t *q_rows, uint32_t n_queries, uint32_t *node_cnt, uint32_t *edge_cnt, uint8_t *flags, hipStream_t st) {
+    if (A.S && n_queries)
+        hipLaunchKernelGGL(k_cq_rows_finalize, dim3((A.S + 255) / 256, n_queries), dim3(256), 0, st, A.hash_bits, A.row_meta, q_rows, A.nq, A.words, A.S, A.packed,
+                           A.match, A.idf, node_cnt, edge_cnt, flags);
 }
 void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, const uint32_t *edge_cnt, const uint8_t *flags, const uint64_t *pos,
                                 const float *penalty, uint64_t total, void *out, hipStream_t st) {
@@ -595,53 +545,6 @@ void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, 
     hipLaunchKernelGGL(k_cq_plan, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, hashes, offsets, H, q_hash, nq, kidx, nseg);
     fd_exclusive_scan<uint32_t>(nseg, nq, wstart, scan_tmp, total, st);
     hipLaunchKernelGGL(k_pl_count, dim3(8192), dim3(FD_WAVE), 0, st, offsets, value, kidx, wstart, nq, (unsigned long long *)lengths);
-}
-// A whole-structure query has tens of thousands of edge rows and only words / 128 word blocks to read them with (133 workgroups at
-// 542 k structures: a chip mostly idle, every thread walking 28 k dependent loads).  The rows are therefore cut into slices at node
-// boundaries (a node's OR must not straddle two slices); every (word block, slice) workgroup counts its slice and ADDS into the
-// zeroed per-structure counters, coalesced through the same LDS tile.
-__global__ __launch_bounds__(CQ_FIN_T) void k_cq_finalize_sliced(const uint32_t *__restrict__ match, const unsigned long long *__restrict__ acc,
-                                                                 const uint32_t *__restrict__ edge_bits, const uint32_t *__restrict__ edge_node,
-                                                                 const uint32_t *__restrict__ slice /*[n_slices + 1] first edge row*/, uint32_t words, uint32_t S,
-                                                                 uint32_t *__restrict__ node_cnt, uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
-    __shared__ uint32_t t_n[CQ_FIN_T * 33], t_e[CQ_FIN_T * 33];
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = w < words;
-    uint32_t pn[20], pe[20];
-#pragma unroll
-    for (int k = 0; k < 20; ++k) { pn[k] = 0; pe[k] = 0; }
-    if (live) cq_count_rows(edge_bits, edge_node, slice[blockIdx.y], slice[blockIdx.y + 1], words, w, pn, pe);
-    if (live)
-        for (uint32_t b = 0; b < 32; ++b) {
-            uint32_t nc = 0, ec = 0;
-#pragma unroll
-            for (int k = 0; k < 20; ++k) { nc |= ((pn[k] >> b) & 1u) << k; ec |= ((pe[k] >> b) & 1u) << k; }
-            t_n[threadIdx.x * 33 + b] = nc; t_e[threadIdx.x * 33 + b] = ec;
-        }
-    __syncthreads();
-    const uint32_t nid0 = blockIdx.x * CQ_FIN_T * 32;
-    for (uint32_t i = threadIdx.x; i < CQ_FIN_T * 32; i += CQ_FIN_T) {
-        const uint32_t nid = nid0 + i;
-        if (nid >= S) break;
-        const uint32_t at = (i >> 5) * 33 + (i & 31u);
-        if (t_n[at]) atomicAdd(&node_cnt[nid], t_n[at]);
-        if (t_e[at]) atomicAdd(&edge_cnt[nid], t_e[at]);
-        if (blockIdx.y == 0) flags[nid] = (match ? match[nid] != 0u : acc[nid] != 0ull) ? 1 : 0;
-    }
-}
-// slices: device array of n_slices + 1 edge-row boundaries at node boundaries, or null / n_slices = 0 for the single-pass form
-void fd_launch_cq_finalize(const cq_args &A, uint32_t n_edges, uint32_t *node_cnt, uint32_t *edge_cnt, uint8_t *flags, const uint32_t *slices, uint32_t n_slices,
-                           hipStream_t st) {
-    if (!A.words) return;
-    if (slices && n_slices > 1) {
-        (void)hipMemsetAsync(node_cnt, 0, (size_t)A.S * 4, st);
-        (void)hipMemsetAsync(edge_cnt, 0, (size_t)A.S * 4, st);
-        hipLaunchKernelGGL(k_cq_finalize_sliced, dim3((A.words + CQ_FIN_T - 1) / CQ_FIN_T, n_slices), dim3(CQ_FIN_T), 0, st, A.packed ? nullptr : A.match, A.idf,
-                           A.edge_bits, A.edge_node, slices, A.words, A.S, node_cnt, edge_cnt, flags);
-        return;
-    }
-    hipLaunchKernelGGL(k_cq_finalize, dim3((A.words + CQ_FIN_T - 1) / CQ_FIN_T), dim3(CQ_FIN_T), 0, st, A.packed ? nullptr : A.match, A.idf, A.edge_bits,
-                       A.edge_node, n_edges, A.words, A.S, node_cnt, edge_cnt, flags);
 }
 void fd_launch_cq_compact(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_cnt, const uint32_t *edge_cnt,
                           const uint8_t *flags, const uint64_t *pos, const float *penalty, uint32_t S, uint32_t first_id, void *out,
