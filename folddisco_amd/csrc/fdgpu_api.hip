@@ -1026,9 +1026,22 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
         int rs = cq_score(c, A, nullptr);
         if (rs) return rs;
     }
+    std::vector<uint64_t> slices;        // outlives the asynchronous copy below (the stream is synchronised before this function returns)
     {
         StageTimer t(c, "cq_finalize", (uint64_t)nq * words * 4 + S * 16);
-        fd_launch_cq_rows_finalize(A, nullptr, 1, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), st);
+        // thousands of rows (whole-structure queries): S / 4096 workgroups of word columns do not fill the chip — cut the rows into ~32
+        // slices at node boundaries
+        if (nq >= 4096) {
+            const uint64_t per = (nq + 31) / 32;
+            slices.push_back(0);
+            for (uint64_t r = 0; r + 1 < nq; ++r)
+                if ((rows_meta[r] & 2ull) && r + 1 - slices.back() >= per) slices.push_back(r + 1);
+            slices.push_back(nq);
+            HIPCHK(c, c->ws[WS_TILE_B].ensure(slices.size() * 8));
+            HIPCHK(c, hipMemcpyAsync(c->ws[WS_TILE_B].p, slices.data(), slices.size() * 8, hipMemcpyHostToDevice, st));
+        }
+        fd_launch_cq_rows_finalize(A, nullptr, 1, slices.empty() ? nullptr : c->ws[WS_TILE_B].as<uint64_t>(), slices.empty() ? 0u : (uint32_t)slices.size() - 1,
+                                   c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), st);
         fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), S, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
                                    c->ws[WS_TOTAL].as<uint64_t>(), st);
     }
@@ -1107,11 +1120,23 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>(); A.packed = packed ? 1 : 0;
     A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
     const bool dense_topn = allow_dense && packed && top_n > 0 && top_n + 1024 <= 4096;
+    std::vector<uint64_t> slices;        // outlives its asynchronous copy (every path below synchronises the stream before returning)
     {
         StageTimer t(c, "cq_batch", 0);
         int rs = cq_score(c, A, nullptr);
         if (rs) { free(ooff); return rs; }
-        fd_launch_cq_rows_finalize(A, c->ws[WS_TILE_H].as<uint64_t>(), (uint32_t)n_queries, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(),
+        if (n_queries == 1 && nq >= 4096) {      // one query with thousands of rows: slices at node boundaries (see fdgpu_count_query)
+            const uint64_t per = (nq + 31) / 32;
+            slices.push_back(0);
+            for (uint64_t r = 0; r + 1 < nq; ++r)
+                if ((rows_meta[r] & 2ull) && r + 1 - slices.back() >= per) slices.push_back(r + 1);
+            slices.push_back(nq);
+            hipError_t es = c->ws[WS_TILE_B].ensure(slices.size() * 8);
+            if (es == hipSuccess) es = hipMemcpyAsync(c->ws[WS_TILE_B].p, slices.data(), slices.size() * 8, hipMemcpyHostToDevice, st);
+            if (es != hipSuccess) slices.clear();
+        }
+        fd_launch_cq_rows_finalize(A, c->ws[WS_TILE_H].as<uint64_t>(), (uint32_t)n_queries, slices.empty() ? nullptr : c->ws[WS_TILE_B].as<uint64_t>(),
+                                   slices.empty() ? 0u : (uint32_t)slices.size() - 1, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(),
                                    c->ws[WS_MISC4].as<uint8_t>(), st);
         if (!dense_topn)
             fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), QS, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),

@@ -249,46 +249,86 @@ void fd_launch_cq_seg(const cq_args &A, const uint32_t *q_query, const long long
     hipLaunchKernelGGL(k_cq_seg<false>, dim3(grid), dim3(FD_WAVE), 0, st, A, q_query, P);
 }
 
-// count_query's per-structure results from the hash occupancy rows: thread = structure, loop = the rows of its query in (node,
-// partner) order; row_meta[r] = idf in 2^-22 fixed point << 2 | last row of its node << 1 | last row of its edge.  The 64 lanes of a
-// wavefront read two words per row (broadcast loads), four rows in flight.
-__global__ __launch_bounds__(256) void k_cq_rows_finalize(const uint32_t *__restrict__ hash_bits, const unsigned long long *__restrict__ row_meta,
-                                                          const uint64_t *__restrict__ q_rows /*[nQ + 1] or null = one query over n_rows*/, uint64_t n_rows,
-                                                          uint32_t words, uint32_t S, int packed, uint32_t *__restrict__ match,
-                                                          unsigned long long *__restrict__ acc, uint32_t *__restrict__ node_cnt,
-                                                          uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
-    const uint32_t nid = blockIdx.x * 256 + threadIdx.x, qy = blockIdx.y;
-    if (nid >= S) return;
-    const uint64_t r0 = q_rows ? q_rows[qy] : 0ull, r1 = q_rows ? q_rows[qy + 1] : n_rows;
-    const uint32_t w = nid >> 5, b = nid & 31u;
-    uint32_t cnt = 0, ec = 0, nc = 0, e_or = 0, n_or = 0;
-    unsigned long long sum = 0;
-    uint64_t r = r0;
-    for (; r + 4 <= r1; r += 4) {
-        uint32_t x[4];
-        unsigned long long m[4];
+// count_query's per-structure results from the hash occupancy rows.  Thread = one 32-structure word column of one query, loop = the
+// rows of its query in (node, partner) order; row_meta[r] = idf in 2^-22 fixed point << 2 | last row of its node << 1 | last row of
+// its edge.  The work follows the SET bits: a zero word costs one coalesced load and a test; a set bit adds the row's idf to the
+// lane's 32 sums (LDS, stride 33) — match / edge / node counts are bit-sliced carry-save counters in registers (32 structures per
+// add, early exit when the carry dies).  Results leave through the LDS tile, structure-major and coalesced.  A query with tens of
+// thousands of rows (whole-structure mode) has only S / 4096 workgroups of columns: its rows are cut into slices at node boundaries
+// (grid.z) and the slices ADD into zeroed results.
+#define CQ_FIN_T 128
+__device__ __forceinline__ void cq_sliced_add(uint32_t (&p)[20], uint32_t x) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { x[u] = hash_bits[(r + u) * words + w]; m[u] = row_meta[r + u]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t bit = (x[u] >> b) & 1u;
-            cnt += bit; sum += bit ? m[u] >> 2 : 0ull; e_or |= bit;
-            if (m[u] & 1ull) { ec += e_or; n_or |= e_or; e_or = 0; }
-            if (m[u] & 2ull) { nc += n_or; n_or = 0; }
-        }
+    for (int k = 0; k < 20; ++k) {
+        const uint32_t c = p[k] & x;
+        p[k] ^= x;
+        x = c;
+        if (!x) break;
     }
-    for (; r < r1; ++r) {
-        const uint32_t bit = (hash_bits[r * words + w] >> b) & 1u;
+}
+__global__ __launch_bounds__(CQ_FIN_T) void k_cq_rows_finalize(const uint32_t *__restrict__ hash_bits, const unsigned long long *__restrict__ row_meta,
+                                                               const uint64_t *__restrict__ q_rows /*[nQ + 1] or null = one query over n_rows*/, uint64_t n_rows,
+                                                               const uint64_t *__restrict__ slices /*[gridDim.z + 1] row boundaries or null*/,
+                                                               uint32_t words, uint32_t S, int packed, uint32_t *__restrict__ match,
+                                                               unsigned long long *__restrict__ acc, uint32_t *__restrict__ node_cnt,
+                                                               uint32_t *__restrict__ edge_cnt, uint8_t *__restrict__ flags) {
+    __shared__ unsigned long long s_sum[CQ_FIN_T * 33];
+    const uint32_t w = blockIdx.x * CQ_FIN_T + threadIdx.x, qy = blockIdx.y;
+    const bool live = w < words;
+    uint64_t r0 = q_rows ? q_rows[qy] : 0ull, r1 = q_rows ? q_rows[qy + 1] : n_rows;
+    const bool add = slices != nullptr;
+    if (add) { r0 = slices[blockIdx.z]; r1 = slices[blockIdx.z + 1]; }
+    for (int b = 0; b < 32; ++b) s_sum[threadIdx.x * 33 + b] = 0ull;
+    uint32_t pc[20], pe[20], pn[20], e_or = 0, n_or = 0;
+#pragma unroll
+    for (int k = 0; k < 20; ++k) { pc[k] = 0; pe[k] = 0; pn[k] = 0; }
+    unsigned long long *mine = s_sum + threadIdx.x * 33;
+    for (uint64_t r = r0; r < r1; ++r) {
+        uint32_t x = live ? hash_bits[r * words + w] : 0u;
         const unsigned long long m = row_meta[r];
-        cnt += bit; sum += bit ? m >> 2 : 0ull; e_or |= bit;
-        if (m & 1ull) { ec += e_or; n_or |= e_or; e_or = 0; }
-        if (m & 2ull) { nc += n_or; n_or = 0; }
+        if (x) {
+            cq_sliced_add(pc, x);
+            e_or |= x;
+            const unsigned long long fix = m >> 2;
+            while (x) { const int b = __builtin_ctz(x); mine[b] += fix; x &= x - 1u; }
+        }
+        if (m & 1ull) { if (e_or) cq_sliced_add(pe, e_or); n_or |= e_or; e_or = 0; }
+        if (m & 2ull) { if (n_or) cq_sliced_add(pn, n_or); n_or = 0; }
     }
-    const uint64_t g = (uint64_t)qy * S + nid;
-    if (packed) acc[g] = ((unsigned long long)cnt << CQ_CNT_SHIFT) | sum;
-    else { acc[g] = sum; match[g] = cnt; }
-    node_cnt[g] = nc; edge_cnt[g] = ec;
-    flags[g] = cnt ? 1 : 0;
+    // counts of this thread's 32 structures -> the tile, packed with the sums where the packed form applies
+    __shared__ uint32_t s_cnt[CQ_FIN_T * 33];
+    const uint32_t nid0 = blockIdx.x * CQ_FIN_T * 32;
+    const uint32_t lim = nid0 < S ? (S - nid0 < CQ_FIN_T * 32 ? S - nid0 : CQ_FIN_T * 32) : 0u;
+    const uint64_t qbase = (uint64_t)qy * S;
+    for (int pass = 0; pass < 3; ++pass) {      // 0: match counts (+ sums), 1: edge counts, 2: node counts
+        for (uint32_t b = 0; b < 32; ++b) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 20; ++k) v |= (((pass == 0 ? pc[k] : pass == 1 ? pe[k] : pn[k]) >> b) & 1u) << k;
+            s_cnt[threadIdx.x * 33 + b] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (uint32_t i = threadIdx.x; i < lim; i += CQ_FIN_T) {
+            const uint32_t at = (i >> 5) * 33 + (i & 31u);
+            const uint64_t g = qbase + nid0 + i;
+            const uint32_t v = s_cnt[at];
+            if (pass == 0) {
+                const unsigned long long sum = s_sum[at];
+                if (!add) {
+                    if (packed) acc[g] = ((unsigned long long)v << CQ_CNT_SHIFT) | sum; else { acc[g] = sum; match[g] = v; }
+                    flags[g] = v ? 1 : 0;
+                } else if (v) {
+                    if (packed) atomicAdd(&acc[g], ((unsigned long long)v << CQ_CNT_SHIFT) | sum); else { atomicAdd(&acc[g], sum); atomicAdd(&match[g], v); }
+                    flags[g] = 1;       // zeroed by the launcher; every slice that saw the structure says the same
+                }
+            } else {
+                uint32_t *dst = pass == 1 ? edge_cnt : node_cnt;
+                if (!add) dst[g] = v; else if (v) atomicAdd(&dst[g], v);
+            }
+        }
+        __syncthreads();
+    }
 }
 
 
@@ -524,11 +564,20 @@ void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries
     hipLaunchKernelGGL(k_topn_emit, g, dim3(256), 0, st, r, off, cap, ts, (fd_count_rec_dev *)out);
 }
 
-// q_rows: device [n_queries + 1] row ranges (null: one query over all A.nq rows)
-void fd_launch_cq_rows_finalize(const cq_args &A, const uint64_t *q_rows, uint32_t n_queries, uint32_t *node_cnt, uint32_t *edge_cnt, uint8_t *flags, hipStream_t st) {
-    if (A.S && n_queries)
-        hipLaunchKernelGGL(k_cq_rows_finalize, dim3((A.S + 255) / 256, n_queries), dim3(256), 0, st, A.hash_bits, A.row_meta, q_rows, A.nq, A.words, A.S, A.packed,
-                           A.match, A.idf, node_cnt, edge_cnt, flags);
+// q_rows: device [n_queries + 1] row ranges (null: one query over all A.nq rows); slices: device [n_slices + 1] row boundaries at node
+// boundaries for ONE query with many rows (results are then accumulated into zeroed arrays), or null
+void fd_launch_cq_rows_finalize(const cq_args &A, const uint64_t *q_rows, uint32_t n_queries, const uint64_t *slices, uint32_t n_slices, uint32_t *node_cnt,
+                                uint32_t *edge_cnt, uint8_t *flags, hipStream_t st) {
+    if (!A.S || !n_queries) return;
+    const bool add = slices && n_slices > 1 && n_queries == 1;
+    if (add) {
+        const size_t n = (size_t)A.S;
+        (void)hipMemsetAsync(A.idf, 0, n * 8, st); (void)hipMemsetAsync(node_cnt, 0, n * 4, st); (void)hipMemsetAsync(edge_cnt, 0, n * 4, st);
+        (void)hipMemsetAsync(flags, 0, n, st);
+        if (!A.packed) (void)hipMemsetAsync(A.match, 0, n * 4, st);
+    }
+    hipLaunchKernelGGL(k_cq_rows_finalize, dim3((A.words + CQ_FIN_T - 1) / CQ_FIN_T, n_queries, add ? n_slices : 1), dim3(CQ_FIN_T), 0, st, A.hash_bits,
+                       A.row_meta, q_rows, A.nq, add ? slices : nullptr, A.words, A.S, A.packed, A.match, A.idf, node_cnt, edge_cnt, flags);
 }
 void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, const uint32_t *edge_cnt, const uint8_t *flags, const uint64_t *pos,
                                 const float *penalty, uint64_t total, void *out, hipStream_t st) {
