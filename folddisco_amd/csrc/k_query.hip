@@ -283,9 +283,7 @@ __global__ __launch_bounds__(CQ_FIN_T) void k_cq_rows_finalize(const uint32_t *_
 #pragma unroll
     for (int k = 0; k < 20; ++k) { pc[k] = 0; pe[k] = 0; pn[k] = 0; }
     unsigned long long *mine = s_sum + threadIdx.x * 33;
-    for (uint64_t r = r0; r < r1; ++r) {
-        uint32_t x = live ? hash_bits[r * words + w] : 0u;
-        const unsigned long long m = row_meta[r];
+    auto row = [&](uint32_t x, unsigned long long m) {
         if (x) {
             cq_sliced_add(pc, x);
             e_or |= x;
@@ -294,7 +292,16 @@ __global__ __launch_bounds__(CQ_FIN_T) void k_cq_rows_finalize(const uint32_t *_
         }
         if (m & 1ull) { if (e_or) cq_sliced_add(pe, e_or); n_or |= e_or; e_or = 0; }
         if (m & 2ull) { if (n_or) cq_sliced_add(pn, n_or); n_or = 0; }
+    };
+    uint64_t r = r0;
+    for (; r + 8 <= r1; r += 8) {       // eight rows' words in flight: the walk is latency-bound otherwise
+        uint32_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = live ? hash_bits[(r + u) * words + w] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) row(x[u], row_meta[r + u]);
     }
+    for (; r < r1; ++r) row(live ? hash_bits[r * words + w] : 0u, row_meta[r]);
     // counts of this thread's 32 structures -> the tile, packed with the sums where the packed form applies
     __shared__ uint32_t s_cnt[CQ_FIN_T * 33];
     const uint32_t nid0 = blockIdx.x * CQ_FIN_T * 32;
