@@ -1041,7 +1041,7 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
             HIPCHK(c, hipMemcpyAsync(c->ws[WS_TILE_B].p, slices.data(), slices.size() * 8, hipMemcpyHostToDevice, st));
         }
         fd_launch_cq_rows_finalize(A, nullptr, 1, slices.empty() ? nullptr : c->ws[WS_TILE_B].as<uint64_t>(), slices.empty() ? 0u : (uint32_t)slices.size() - 1,
-                                   c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), st);
+                                   c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), nq, st);
         fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), S, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
                                    c->ws[WS_TOTAL].as<uint64_t>(), st);
     }
@@ -1093,7 +1093,9 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     std::vector<unsigned long long> rows_meta;
     rows_hash.reserve(nq); rows_meta.reserve(nq);
     bool packed = true;
+    uint64_t max_rows = 0;
     for (uint64_t t = 0; t < n_queries; ++t) {
+        max_rows = std::max<uint64_t>(max_rows, q_off[t + 1] - q_off[t]);
         packed = packed && (q_off[t + 1] - q_off[t]) < (1ull << 18);
         packed = fd_cq_rows(q_hash, q_node, q_edge_j, q_idf, q_off[t], q_off[t + 1], rows_hash, rows_meta) && packed;
     }
@@ -1137,7 +1139,7 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
         }
         fd_launch_cq_rows_finalize(A, c->ws[WS_TILE_H].as<uint64_t>(), (uint32_t)n_queries, slices.empty() ? nullptr : c->ws[WS_TILE_B].as<uint64_t>(),
                                    slices.empty() ? 0u : (uint32_t)slices.size() - 1, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(),
-                                   c->ws[WS_MISC4].as<uint8_t>(), st);
+                                   c->ws[WS_MISC4].as<uint8_t>(), max_rows, st);
         if (!dense_topn)
             fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), QS, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
                                        c->ws[WS_TOTAL].as<uint64_t>(), st);

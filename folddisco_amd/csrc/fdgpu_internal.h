@@ -194,7 +194,7 @@ void fd_launch_cq_plan(const cq_args &A, long long *kidx, uint32_t *nseg, hipStr
 void fd_launch_cq_seg(const cq_args &A, const uint32_t *q_query, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
                       hipStream_t st);
 void fd_launch_cq_rows_finalize(const cq_args &A, const uint64_t *q_rows, uint32_t n_queries, const uint64_t *slices, uint32_t n_slices, uint32_t *node_cnt,
-                                uint32_t *edge_cnt, uint8_t *flags, hipStream_t st);
+                                uint32_t *edge_cnt, uint8_t *flags, uint64_t max_rows_per_query, hipStream_t st);
 void fd_launch_cq_compact(const uint32_t *match, const unsigned long long *idf, const uint32_t *node_cnt, const uint32_t *edge_cnt,
                           const uint8_t *flags, const uint64_t *pos, const float *penalty, uint32_t S, uint32_t first_id, void *out,
                           hipStream_t st);

@@ -257,15 +257,18 @@ void fd_launch_cq_seg(const cq_args &A, const uint32_t *q_query, const long long
 // thousands of rows (whole-structure mode) has only S / 4096 workgroups of columns: its rows are cut into slices at node boundaries
 // (grid.z) and the slices ADD into zeroed results.
 #define CQ_FIN_T 128
-__device__ __forceinline__ void cq_sliced_add(uint32_t (&p)[20], uint32_t x) {
+template <int NP>
+__device__ __forceinline__ void cq_sliced_add(uint32_t (&p)[NP], uint32_t x) {
 #pragma unroll
-    for (int k = 0; k < 20; ++k) {
+    for (int k = 0; k < NP; ++k) {
         const uint32_t c = p[k] & x;
         p[k] ^= x;
         x = c;
         if (!x) break;
     }
 }
+// NP = counter planes: 8 when no query of the call has 256 rows or more (motif queries), else 20
+template <int NP>
 __global__ __launch_bounds__(CQ_FIN_T) void k_cq_rows_finalize(const uint32_t *__restrict__ hash_bits, const unsigned long long *__restrict__ row_meta,
                                                                const uint64_t *__restrict__ q_rows /*[nQ + 1] or null = one query over n_rows*/, uint64_t n_rows,
                                                                const uint64_t *__restrict__ slices /*[gridDim.z + 1] row boundaries or null*/,
@@ -279,9 +282,9 @@ __global__ __launch_bounds__(CQ_FIN_T) void k_cq_rows_finalize(const uint32_t *_
     const bool add = slices != nullptr;
     if (add) { r0 = slices[blockIdx.z]; r1 = slices[blockIdx.z + 1]; }
     for (int b = 0; b < 32; ++b) s_sum[threadIdx.x * 33 + b] = 0ull;
-    uint32_t pc[20], pe[20], pn[20], e_or = 0, n_or = 0;
+    uint32_t pc[NP], pe[NP], pn[NP], e_or = 0, n_or = 0;
 #pragma unroll
-    for (int k = 0; k < 20; ++k) { pc[k] = 0; pe[k] = 0; pn[k] = 0; }
+    for (int k = 0; k < NP; ++k) { pc[k] = 0; pe[k] = 0; pn[k] = 0; }
     unsigned long long *mine = s_sum + threadIdx.x * 33;
     auto row = [&](uint32_t x, unsigned long long m) {
         if (x) {
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(CQ_FIN_T) void k_cq_rows_finalize(const uint32_t *_
         for (uint32_t b = 0; b < 32; ++b) {
             uint32_t v = 0;
 #pragma unroll
-            for (int k = 0; k < 20; ++k) v |= (((pass == 0 ? pc[k] : pass == 1 ? pe[k] : pn[k]) >> b) & 1u) << k;
+            for (int k = 0; k < NP; ++k) v |= (((pass == 0 ? pc[k] : pass == 1 ? pe[k] : pn[k]) >> b) & 1u) << k;
             s_cnt[threadIdx.x * 33 + b] = v;
         }
         __syncthreads();
@@ -574,7 +577,7 @@ void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries
 // q_rows: device [n_queries + 1] row ranges (null: one query over all A.nq rows); slices: device [n_slices + 1] row boundaries at node
 // boundaries for ONE query with many rows (results are then accumulated into zeroed arrays), or null
 void fd_launch_cq_rows_finalize(const cq_args &A, const uint64_t *q_rows, uint32_t n_queries, const uint64_t *slices, uint32_t n_slices, uint32_t *node_cnt,
-                                uint32_t *edge_cnt, uint8_t *flags, hipStream_t st) {
+                                uint32_t *edge_cnt, uint8_t *flags, uint64_t max_rows_per_query, hipStream_t st) {
     if (!A.S || !n_queries) return;
     const bool add = slices && n_slices > 1 && n_queries == 1;
     if (add) {
@@ -583,8 +586,13 @@ void fd_launch_cq_rows_finalize(const cq_args &A, const uint64_t *q_rows, uint32
         (void)hipMemsetAsync(flags, 0, n, st);
         if (!A.packed) (void)hipMemsetAsync(A.match, 0, n * 4, st);
     }
-    hipLaunchKernelGGL(k_cq_rows_finalize, dim3((A.words + CQ_FIN_T - 1) / CQ_FIN_T, n_queries, add ? n_slices : 1), dim3(CQ_FIN_T), 0, st, A.hash_bits,
-                       A.row_meta, q_rows, A.nq, add ? slices : nullptr, A.words, A.S, A.packed, A.match, A.idf, node_cnt, edge_cnt, flags);
+    const dim3 grid((A.words + CQ_FIN_T - 1) / CQ_FIN_T, n_queries, add ? n_slices : 1);
+    if (max_rows_per_query < 256)
+        hipLaunchKernelGGL(k_cq_rows_finalize<8>, grid, dim3(CQ_FIN_T), 0, st, A.hash_bits, A.row_meta, q_rows, A.nq, add ? slices : nullptr, A.words, A.S, A.packed,
+                           A.match, A.idf, node_cnt, edge_cnt, flags);
+    else
+        hipLaunchKernelGGL(k_cq_rows_finalize<20>, grid, dim3(CQ_FIN_T), 0, st, A.hash_bits, A.row_meta, q_rows, A.nq, add ? slices : nullptr, A.words, A.S, A.packed,
+                           A.match, A.idf, node_cnt, edge_cnt, flags);
 }
 void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, const uint32_t *edge_cnt, const uint8_t *flags, const uint64_t *pos,
                                 const float *penalty, uint64_t total, void *out, hipStream_t st) {
