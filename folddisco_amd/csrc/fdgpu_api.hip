@@ -964,7 +964,7 @@ static bool fd_cq_rows(const uint32_t *q_hash, const uint32_t *q_node, const uin
     }
     return fits;
 }
-static int cq_score(fdgpu_ctx *c, const cq_args &A, const uint32_t *q_query) {
+static int cq_score(fdgpu_ctx *c, const cq_args &A) {
     hipStream_t st = c->stream;
     HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(A.nq * 8));
     HIPCHK(c, c->ws[WS_CQ_NSEG].ensure(A.nq * 4));
@@ -979,7 +979,7 @@ static int cq_score(fdgpu_ctx *c, const cq_args &A, const uint32_t *q_query) {
     int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &W);
     if (rc) return rc;
     HIPCHK(c, c->ws[WS_CQ_SEGSUM].ensure(std::max<uint64_t>(W, 1) * 4));
-    fd_launch_cq_seg(A, q_query, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_WSTART].as<uint64_t>(), c->ws[WS_CQ_SEGSUM].as<uint32_t>(), W, W > A.nq, st);
+    fd_launch_cq_seg(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_WSTART].as<uint64_t>(), c->ws[WS_CQ_SEGSUM].as<uint32_t>(), W, W > A.nq, st);
     return FDGPU_OK;
 }
 
@@ -1023,7 +1023,7 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
     {
         StageTimer t(c, "cq_accumulate", 0);
-        int rs = cq_score(c, A, nullptr);
+        int rs = cq_score(c, A);
         if (rs) return rs;
     }
     std::vector<uint64_t> slices;        // outlives the asynchronous copy below (the stream is synchronised before this function returns)
@@ -1125,7 +1125,7 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     std::vector<uint64_t> slices;        // outlives its asynchronous copy (every path below synchronises the stream before returning)
     {
         StageTimer t(c, "cq_batch", 0);
-        int rs = cq_score(c, A, nullptr);
+        int rs = cq_score(c, A);
         if (rs) { free(ooff); return rs; }
         if (n_queries == 1 && nq >= 4096) {      // one query with thousands of rows: slices at node boundaries (see fdgpu_count_query)
             const uint64_t per = (nq + 31) / 32;

@@ -191,7 +191,7 @@ void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, 
                                uint64_t nq, uint64_t *lengths, long long *kidx, uint32_t *nseg, uint64_t *wstart, uint64_t *scan_tmp, uint64_t *total,
                                hipStream_t st);
 void fd_launch_cq_plan(const cq_args &A, long long *kidx, uint32_t *nseg, hipStream_t st);
-void fd_launch_cq_seg(const cq_args &A, const uint32_t *q_query, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
+void fd_launch_cq_seg(const cq_args &A, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
                       hipStream_t st);
 void fd_launch_cq_rows_finalize(const cq_args &A, const uint64_t *q_rows, uint32_t n_queries, const uint64_t *slices, uint32_t n_slices, uint32_t *node_cnt,
                                 uint32_t *edge_cnt, uint8_t *flags, uint64_t max_rows_per_query, hipStream_t st);

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_pl_count(const uint64_t *__restrict
 }
 
 template <bool SUMS>
-__global__ __launch_bounds__(FD_WAVE) void k_cq_seg(cq_args A, const uint32_t *__restrict__ q_query, cq_plan P) {
+__global__ __launch_bounds__(FD_WAVE) void k_cq_seg(cq_args A, cq_plan P) {
     const uint32_t lane = threadIdx.x;
     const uint64_t W = P.wstart[A.nq];
     for (uint64_t w = blockIdx.x; w < W; w += gridDim.x) {
@@ -239,14 +239,14 @@ void fd_launch_cq_plan(const cq_args &A, long long *kidx, uint32_t *nseg, hipStr
     if (A.nq) hipLaunchKernelGGL(k_cq_plan, dim3((unsigned)((A.nq + 255) / 256)), dim3(256), 0, st, A.hashes, A.offsets, A.H, A.q_hash, A.nq, kidx, nseg);
 }
 // n_items: number of work items (host copy of wstart[nq]); split: some list has more than one segment
-void fd_launch_cq_seg(const cq_args &A, const uint32_t *q_query, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
+void fd_launch_cq_seg(const cq_args &A, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
                       hipStream_t st) {
     if (!A.nq || !n_items) return;
     cq_plan P;
     P.kidx = kidx; P.wstart = wstart; P.segsum = segsum;
     const unsigned grid = (unsigned)(n_items < 16384 ? n_items : 16384);
-    if (split) hipLaunchKernelGGL(k_cq_seg<true>, dim3(grid), dim3(FD_WAVE), 0, st, A, q_query, P);
-    hipLaunchKernelGGL(k_cq_seg<false>, dim3(grid), dim3(FD_WAVE), 0, st, A, q_query, P);
+    if (split) hipLaunchKernelGGL(k_cq_seg<true>, dim3(grid), dim3(FD_WAVE), 0, st, A, P);
+    hipLaunchKernelGGL(k_cq_seg<false>, dim3(grid), dim3(FD_WAVE), 0, st, A, P);
 }
 
 // count_query's per-structure results from the hash occupancy rows.  Thread = one 32-structure word column of one query, loop = the

@@ -722,3 +722,48 @@ def test_superposition_degenerate_inputs_and_device_metrics(ctx):
     for k, (x, y) in enumerate(mp):
         want = oracle.metrics(y, x, rot[k].reshape(9), tran[k])
         assert np.allclose(got[k], want, rtol=1e-6, atol=1e-6), (k, len(x), got[k], want)
+
+
+@pytest.mark.gpu
+def test_count_query_against_recount_packed_and_wide(ctx):
+    """count_query's records against a numpy recount from the decoded posting lists, bit for bit (the idf sum is exact in 2^-22 fixed
+    point on both sides): in the packed accumulator form (idf < 32) and in the wide form that an idf >= 32 selects (here:
+    total_structures = 2^45), through the single and the batched entry point, with and without the device-side top-N."""
+    import folddisco_amd as fd
+    from folddisco_amd import synth
+    from folddisco_amd.dist import rank_hits
+    S = 300
+    ps = synth.to_packed(synth.generate(S, seed=31))
+    ix = fd.FolddiscoIndex.build(ctx, ctx.upload(ps), first_id=0)
+    hashes = ix.export()[1]
+    rng = np.random.Generator(np.random.PCG64(8))
+    pen = fd.length_penalty(np.diff(ps.res_off).astype(np.uint64), 0.5)
+    queries = []
+    for n in (1, 7, 40, 300):
+        qh = rng.choice(hashes, size=n, replace=False).astype(np.uint32)
+        queries.append((qh, rng.integers(0, 6, size=n).astype(np.uint32), rng.integers(0, 6, size=n).astype(np.uint32)))
+    for total in (S, 2 ** 45):
+        want = []
+        for qh, qi, qj in queries:
+            lens = ix.posting_lengths(qh)
+            idf = fd.idf_of_lengths(lens, total).astype(np.float32)
+            fix = np.floor(idf.astype(np.float64) * 4194304.0 + 0.5).astype(np.int64)
+            assert (idf >= 32).all() == (total != S)
+            cnt, acc = np.zeros(S, np.int64), np.zeros(S, np.int64)
+            nodes, edges = [set() for _ in range(S)], [set() for _ in range(S)]
+            for k, ids in enumerate(ix.get_entries(qh)):
+                for s in ids.astype(np.int64):
+                    cnt[s] += 1; acc[s] += fix[k]; nodes[s].add(int(qi[k])); edges[s].add((int(qi[k]), int(qj[k])))
+            rec = np.zeros(int((cnt > 0).sum()), fd.api.REC_DTYPE)
+            t = np.nonzero(cnt)[0]
+            rec["nid"], rec["total_match_count"] = t, cnt[t]
+            rec["node_count"], rec["edge_count"] = [len(nodes[s]) for s in t], [len(edges[s]) for s in t]
+            rec["idf"] = (acc[t].astype(np.float64) / 4194304.0).astype(np.float32) * pen[t]
+            want.append(rec)
+        for (qh, qi, qj), w in zip(queries, want):
+            got = fd.count_query(ctx, ix, qh, qi, qj, pen, total_structures=total, as_array=True)
+            assert got.tobytes() == w.tobytes(), (total, len(qh))
+        gb = fd.count_query_batch(ctx, ix, queries, pen, total_structures=total)
+        gt = fd.count_query_batch(ctx, ix, queries, pen, total_structures=total, top_n=10)
+        for g, g10, w in zip(gb, gt, want):
+            assert g.tobytes() == w.tobytes() and g10.tobytes() == rank_hits(w, 10).tobytes()
