@@ -453,20 +453,31 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     auto t_now = [] { return std::chrono::steady_clock::now(); };
     auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto T0 = t_now();
-    // per query: sorted unique hashes + lookup hash -> query map entry
-    std::vector<std::unordered_map<uint32_t, uint32_t>> entries(n_queries);
-    std::vector<std::vector<uint32_t>> qhs(n_queries);
+    // per query: sorted unique hashes + the map entry each one resolves to (the FIRST entry holding it, like the reference's hash map):
+    // (hash << 32 | entry) keys through an LSD radix sort — a whole-structure query has 10^5 entries, a hash map cost 8 ms here
+    std::vector<std::vector<uint32_t>> qhs(n_queries), qkf(n_queries);
     std::vector<fd_match_query> mqs(std::max<uint64_t>(n_queries, 1));
     std::vector<uint32_t> q_sizes(std::max<uint64_t>(n_queries, 1), 1);
     for (uint64_t t = 0; t < n_queries; ++t) {
         const fd_query_map *m = qms[t];
+        std::vector<uint64_t> key(m->n), tmp(m->n);
         for (uint64_t k = 0; k < m->n; ++k) {
-            entries[t].emplace(m->hash[k], (uint32_t)k);
+            key[k] = ((uint64_t)m->hash[k] << 32) | (uint32_t)k;
             q_sizes[t] = std::max(q_sizes[t], std::max(m->qi[k], m->qj[k]) + 1);
         }
-        qhs[t].reserve(entries[t].size());
-        for (auto &kv : entries[t]) qhs[t].push_back(kv.first);
-        std::sort(qhs[t].begin(), qhs[t].end());
+        if (m->n > 64) {
+            for (int pass = 0; pass < 4; ++pass) {           // entries arrive in ascending k: a stable sort by hash keeps the first entry first
+                const int sh = 32 + 8 * pass;
+                size_t cnt[257] = {0};
+                for (uint64_t k = 0; k < m->n; ++k) ++cnt[((key[k] >> sh) & 255u) + 1];
+                for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+                for (uint64_t k = 0; k < m->n; ++k) tmp[cnt[(key[k] >> sh) & 255u]++] = key[k];
+                key.swap(tmp);
+            }
+        } else std::sort(key.begin(), key.end());
+        qhs[t].reserve(m->n); qkf[t].reserve(m->n);
+        for (uint64_t k = 0; k < m->n; ++k)
+            if (k == 0 || (key[k] >> 32) != (key[k - 1] >> 32)) { qhs[t].push_back((uint32_t)(key[k] >> 32)); qkf[t].push_back((uint32_t)key[k]); }
         fd_match_query &q = mqs[t];
         q.hashes = qhs[t].data(); q.n_hashes = qhs[t].size();
         q.aad_aa1 = m->aad_aa1; q.aad_aa2 = m->aad_aa2; q.aad_dist = m->aad_dist; q.aad_qi = m->aad_qi; q.n_aad = m->n_aad;
@@ -548,7 +559,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             rs_query_dev &Q = qt[t];
             memset(&Q, 0, sizeof Q);
             Q.qh_off = (uint32_t)t_hash.size(); Q.n_hashes = (uint32_t)qhs[t].size();
-            for (uint32_t h : qhs[t]) { t_hash.push_back(h); t_kfirst.push_back(entries[t].at(h)); t_sym.push_back(is_sym(h) ? 1u : 0u); }
+            for (size_t z = 0; z < qhs[t].size(); ++z) { t_hash.push_back(qhs[t][z]); t_kfirst.push_back(qkf[t][z]); t_sym.push_back(is_sym(qhs[t][z]) ? 1u : 0u); }
             Q.map_off = (uint32_t)t_qi.size();
             for (uint64_t k = 0; k < m->n; ++k) { t_qi.push_back(m->qi[k]); t_qj.push_back(m->qj[k]); uint32_t w; memcpy(&w, &m->idf[k], 4); t_idf.push_back(w); }
             Q.idx_off = (uint32_t)t_idx.size(); Q.n_idx = (uint32_t)m->n_indices;
@@ -726,7 +737,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     auto do_slot = [&](const uint64_t slot, const bool plan, SlotOut &o) {
         const uint64_t tq = slot_q[slot];
         const fd_query_map *qm = qms[tq];
-        const std::unordered_map<uint32_t, uint32_t> &entry = entries[tq];
+        const std::vector<uint32_t> &e_hash = qhs[tq], &e_first = qkf[tq];
         const uint32_t q_size = q_sizes[tq];
         const uint64_t NQ = qm->n_indices;
         const float *q_ca = qb_ca.data() + 3 * qb->h_res_off[q_struct[tq]], *q_cb = qb_cb.data() + 3 * qb->h_res_off[q_struct[tq]];
@@ -745,7 +756,10 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             // query-map entry of every found edge, looked up once per candidate (a whole-structure query has ~10^5 entries and
             // thousands of edges per candidate; every component walks the edge list)
             edge_k.resize(g.es.size());
-            for (size_t e = 0; e < g.es.size(); ++e) { auto it = entry.find(g.eh[e]); edge_k[e] = it == entry.end() ? -1 : (int32_t)it->second; }
+            for (size_t e = 0; e < g.es.size(); ++e) {
+                const auto it = std::lower_bound(e_hash.begin(), e_hash.end(), g.eh[e]);
+                edge_k[e] = (it == e_hash.end() || *it != g.eh[e]) ? -1 : (int32_t)e_first[(size_t)(it - e_hash.begin())];
+            }
         }
         const size_t n_comps = cached ? plan_cache[slot].size() : comps.size();
         if (n_comps == 0) return;

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <sys/mman.h>
+#include <atomic>
 #include <thread>
 #include "fdgpu_internal.h"
 
@@ -1335,6 +1336,40 @@ extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, u
     return count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off);
 }
 
+// found triples in the reference's scan order — (slot, i, j), several bin pairs of one (i, j) in emission order — from the kernel's
+// append order: counting sort by slot (stable), then the slots' runs sorted independently on host threads (a whole-structure query
+// returns ~10^5 triples for a handful of slots: one 20 ms std::stable_sort otherwise)
+static void fd_sort_found(fd_pair_rec *f, uint64_t n, uint64_t n_cand) {
+    if (n < 2) return;
+    auto by_ij = [](const fd_pair_rec &a, const fd_pair_rec &b) { return a.i != b.i ? a.i < b.i : a.j < b.j; };
+    if (n < 4096 || n_cand == 0) {
+        std::stable_sort(f, f + n, [&](const fd_pair_rec &a, const fd_pair_rec &b) { return a.cand != b.cand ? a.cand < b.cand : by_ij(a, b); });
+        return;
+    }
+    std::vector<uint64_t> start(n_cand + 2, 0);
+    for (uint64_t k = 0; k < n; ++k) ++start[std::min<uint64_t>(f[k].cand, n_cand) + 1];
+    for (uint64_t s = 0; s <= n_cand; ++s) start[s + 1] += start[s];
+    std::vector<fd_pair_rec> tmp(n);
+    {
+        std::vector<uint64_t> cur(start.begin(), start.end() - 1);
+        for (uint64_t k = 0; k < n; ++k) tmp[cur[std::min<uint64_t>(f[k].cand, n_cand)]++] = f[k];
+    }
+    std::atomic<uint64_t> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const uint64_t s = next.fetch_add(1);
+            if (s > n_cand) break;
+            std::stable_sort(tmp.begin() + start[s], tmp.begin() + start[s + 1], by_ij);
+        }
+    };
+    const unsigned T = (unsigned)std::min<uint64_t>(std::min<uint64_t>(16, std::max(1u, std::thread::hardware_concurrency())), n_cand + 1);
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    memcpy(f, tmp.data(), n * sizeof(fd_pair_rec));
+}
+
 // ---- S4 ---------------------------------------------------------------------------------------------------------------
 // Pair scan for MANY queries in one launch: query t scans the candidates cand[cand_off[t] .. cand_off[t+1]); the records carry the
 // GLOBAL slot (position in cand) and come back sorted by (slot, i, j).
@@ -1496,11 +1531,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         }
         if (tot[0]) HIPCHK(c, hipMemcpyAsync(hf2, A.found, tot[0] * sizeof(fd_pair_rec), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
-        std::stable_sort(hf2, hf2 + tot[0], [](const fd_pair_rec &a, const fd_pair_rec &b) {
-            if (a.cand != b.cand) return a.cand < b.cand;
-            if (a.i != b.i) return a.i < b.i;
-            return a.j < b.j;
-        });
+        fd_sort_found(hf2, tot[0], n_cand);
         *found = hf2; *n_found = tot[0]; *cands = nullptr; *n_cands = n; *pk_key = hk; *pk_val = hv;
         return FDGPU_OK;
     }
@@ -1514,11 +1545,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     if (e != hipSuccess) { free(hf); free(hc); c->err = std::string("match_pairs: ") + hipGetErrorString(e); return FDGPU_EHIP; }
     // restore the reference's scan order (row-major over the prefilter sets, retrieve.rs:146-153): the
     // kernel appends with atomics, one contiguous run per (i, j) in observed-list order
-    std::stable_sort(hf, hf + tot[0], [](const fd_pair_rec &a, const fd_pair_rec &b) {
-        if (a.cand != b.cand) return a.cand < b.cand;
-        if (a.i != b.i) return a.i < b.i;
-        return a.j < b.j;
-    });
+    fd_sort_found(hf, tot[0], n_cand);
     // mode bit 2: the caller buckets the candidate pairs itself and does not depend on their order (the rescue only counts them)
     if (!(mode & 4u)) std::stable_sort(hc, hc + tot[1], [](const fd_cand_rec &a, const fd_cand_rec &b) {
         if (a.cand != b.cand) return a.cand < b.cand;
