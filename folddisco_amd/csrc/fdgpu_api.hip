@@ -757,8 +757,10 @@ void fd_mg_popc(const uint32_t *bitmap, uint64_t n_words, uint32_t *cnt, hipStre
 void fd_mg_expand(const uint32_t *bitmap, const uint64_t *prefix, uint64_t n_words, uint32_t *out, hipStream_t st);
 void fd_mg_pos_fill(const uint32_t *hashes, uint64_t n, const uint32_t *bitmap, const uint64_t *prefix, uint32_t *pos, uint32_t part, uint32_t n_parts,
                     hipStream_t st);
-void fd_mg_sizes(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, uint32_t *sizes, uint32_t *out_last, hipStream_t st);
-void fd_mg_copy(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, const uint64_t *out_off, uint8_t *out_value, hipStream_t st);
+void fd_mg_sizes(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, uint32_t *sizes, uint32_t *out_last, void *plan, uint32_t *plan_dst,
+                 hipStream_t st);
+void fd_mg_copy(const void *parts, uint32_t n_parts, const void *plan, const uint32_t *plan_dst, uint64_t n_slots, const uint64_t *out_off, uint8_t *out_value,
+                hipStream_t st);
 
 extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, uint64_t n_parts, fdgpu_index **out) { FD_LOCK(c);
     if (!c || !out || !n_parts || !parts) return FDGPU_EINVAL;
@@ -821,6 +823,8 @@ extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, 
     if (e == hipSuccess) { ix->last_ids = (uint32_t *)c->pool_alloc(std::max<uint64_t>(Ht, 1) * 4, &e); ix->cap_last = c->last_cap; }
     if (e == hipSuccess) e = c->ws[WS_IDS_B].ensure(std::max<uint64_t>(Ht, 1) * n_parts * 4);
     if (e == hipSuccess) e = c->ws[WS_MISC0].ensure(std::max<uint64_t>(Ht, 1) * 4);
+    if (e == hipSuccess) e = c->ws[WS_FRAMES].ensure(std::max<uint64_t>(Ht, 1) * n_parts * 16);     // copy plan: 16 + 4 bytes per (slot, part)
+    if (e == hipSuccess) e = c->ws[WS_MISC1].ensure(std::max<uint64_t>(Ht, 1) * n_parts * 4);
     if (e != hipSuccess) { c->err = std::string("index merge alloc: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }
     uint32_t *pos = c->ws[WS_IDS_B].as<uint32_t>(), *sizes = c->ws[WS_MISC0].as<uint32_t>();
     {
@@ -828,7 +832,7 @@ extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, 
         fd_mg_expand(bitmap, prefix, n_words, ix->hashes, st);
         (void)hipMemsetAsync(pos, 0xff, std::max<uint64_t>(Ht, 1) * n_parts * 4, st);
         for (uint64_t k = 0; k < n_parts; ++k) fd_mg_pos_fill(ph[k].hashes, ph[k].H, bitmap, prefix, pos, (uint32_t)k, (uint32_t)n_parts, st);
-        fd_mg_sizes(c->ws[WS_MISC4].p, (uint32_t)n_parts, pos, Ht, sizes, ix->last_ids, st);
+        fd_mg_sizes(c->ws[WS_MISC4].p, (uint32_t)n_parts, pos, Ht, sizes, ix->last_ids, c->ws[WS_FRAMES].p, c->ws[WS_MISC1].as<uint32_t>(), st);
         fd_exclusive_scan<uint32_t>(sizes, Ht, ix->offsets, c->ws[WS_SCANTMP].as<uint64_t>(), c->ws[WS_TOTAL].as<uint64_t>(), st);
     }
     e = hipGetLastError();
@@ -838,7 +842,7 @@ extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, 
     if (e != hipSuccess) { c->err = std::string("index merge: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }
     {
         StageTimer t(c, "merge_copy", sum_v + vlen + Ht * n_parts * 4);
-        fd_mg_copy(c->ws[WS_MISC4].p, (uint32_t)n_parts, pos, Ht, ix->offsets, ix->value, st);
+        fd_mg_copy(c->ws[WS_MISC4].p, (uint32_t)n_parts, c->ws[WS_FRAMES].p, c->ws[WS_MISC1].as<uint32_t>(), Ht, ix->offsets, ix->value, st);
     }
     e = hipGetLastError();
     if (e != hipSuccess) { c->err = std::string("index merge copy: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }

@@ -94,104 +94,69 @@ __device__ __forceinline__ uint32_t mg_first_varint(const uint8_t *__restrict__ 
 
 // sizes: thread = merged slot.  size = sum over the parts holding the hash of (bytes of the part's list), the first varint of every
 // continuation re-based from "absolute id" to "delta from the previous part's last id"
+// One thread per merged slot walks the parts that hold its hash: byte size of the merged list (a continuation's first varint shrinks from
+// an absolute id to a delta against the previous part's last id) and a COPY PLAN per (slot, part) — source offset of the bytes that move
+// verbatim, their count, the re-encoded first value and where the piece starts inside the merged list — so that the copy kernel's pieces
+// are independent of each other and sit behind ONE dependent load instead of four (position table -> offsets -> first varint -> bytes).
+struct mg_plan { uint32_t src_lo, src_hi_dl, n, delta; };      // src_hi_dl: bits 0-15 source offset >> 32, bits 16-18 varint length, bit 31 present
 __global__ __launch_bounds__(256) void k_mg_sizes(const mg_part *__restrict__ parts, uint32_t n_parts, const uint32_t *__restrict__ pos, uint64_t n_slots,
-                                                  uint32_t *__restrict__ sizes, uint32_t *__restrict__ out_last) {
+                                                  uint32_t *__restrict__ sizes, uint32_t *__restrict__ out_last, mg_plan *__restrict__ plan,
+                                                  uint32_t *__restrict__ plan_dst) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_slots) return;
     uint32_t total = 0, prev_last = 0;
     bool have_prev = false;
     for (uint32_t k = 0; k < n_parts; ++k) {
         const uint32_t t = pos[g * n_parts + k];
-        if (t == MG_NONE) continue;
-        const mg_part P = parts[k];
-        const uint64_t b0 = P.offsets[t], b1 = P.offsets[t + 1];
-        uint32_t len = (uint32_t)(b1 - b0);
-        if (have_prev) {
-            uint32_t nf;
-            const uint32_t first = mg_first_varint(P.value + b0, &nf);
-            len = len - nf + mg_varint_len(first - prev_last);
+        mg_plan pl = {0u, 0u, 0u, 0u};
+        if (t != MG_NONE) {
+            const mg_part P = parts[k];
+            const uint64_t b0 = P.offsets[t], b1 = P.offsets[t + 1];
+            uint32_t len = (uint32_t)(b1 - b0), nf = 0, dl = 0, delta = 0;
+            if (have_prev) {
+                const uint32_t first = mg_first_varint(P.value + b0, &nf);
+                delta = first - prev_last;
+                dl = mg_varint_len(delta);
+                len = len - nf + dl;
+            }
+            const uint64_t src = b0 + nf;
+            pl.src_lo = (uint32_t)src; pl.src_hi_dl = (uint32_t)(src >> 32) | (dl << 16) | 0x80000000u; pl.n = len - dl; pl.delta = delta;
+            plan_dst[g * n_parts + k] = total;
+            total += len;
+            prev_last = P.last_ids[t];
+            have_prev = true;
         }
-        total += len;
-        prev_last = P.last_ids[t];
-        have_prev = true;
+        plan[g * n_parts + k] = pl;
     }
     sizes[g] = total;
     out_last[g] = prev_last;
 }
 
-// copy: one wavefront per merged slot, eight lanes per part (parts 8 r .. 8 r + 7 in round r): the parts' byte strings move
-// concurrently, 16 bytes per lane and step (unaligned 16-byte global accesses are native on gfx950)
+// copy: eight lanes per (slot, part) piece, 16 bytes per lane and step (unaligned 16-byte global accesses are native on gfx950); the pieces
+// of one slot are adjacent work items, so a merged list still leaves through neighbouring lanes
 typedef unsigned int mg_u32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_mg_copy(const mg_part *__restrict__ parts, uint32_t n_parts, const uint32_t *__restrict__ pos, uint64_t n_slots,
-                                                 const uint64_t *__restrict__ out_off, uint8_t *__restrict__ out_value) {
-    const uint64_t g = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (g >= n_slots) return;
-    const uint32_t lane = threadIdx.x & 63u, grp = lane >> 3, sub = lane & 7u;
-    uint64_t dst = out_off[g];
-    uint32_t prev_last = 0;
-    bool have_prev = false;
-    for (uint32_t k0 = 0; k0 < n_parts; k0 += 8) {
-        const uint32_t k = k0 + grp;
-        const uint32_t t = k < n_parts ? pos[g * n_parts + k] : MG_NONE;
-        const bool present = t != MG_NONE;
-        uint64_t b0 = 0, b1 = 0;
-        uint32_t first = 0, nf = 0, last = 0;
-        const uint8_t *src = nullptr;
-        if (present) {
-            const mg_part P = parts[k];
-            b0 = P.offsets[t]; b1 = P.offsets[t + 1];
-            src = P.value;
-            first = mg_first_varint(src + b0, &nf);
-            last = P.last_ids[t];
-        }
-        // group leaders -> every lane: which parts are present, their last ids and first ids (8 groups)
-        const uint64_t pm = __ballot(present && sub == 0);      // bit 8 * grp
-        // the previous present part's last id for this group
-        uint32_t my_prev = prev_last;
-        bool my_has_prev = have_prev;
-        uint32_t new_len = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 8; ++q) {
-            const uint32_t lq = __shfl(last, (int)(q * 8), FD_WAVE);
-            const bool pq = (pm >> (q * 8)) & 1ull;
-            if (q < grp && pq) { my_prev = lq; my_has_prev = true; }
-        }
-        uint32_t dl = 0, delta = 0;
-        if (present) {
-            if (my_has_prev) { delta = first - my_prev; dl = mg_varint_len(delta); new_len = (uint32_t)(b1 - b0) - nf + dl; }
-            else { new_len = (uint32_t)(b1 - b0); nf = 0; }
-        }
-        // destination of this group's string: prefix of new_len over the groups before it
-        uint64_t my_dst = dst;
-        uint32_t round_total = 0, round_last = prev_last;
-        bool round_has = have_prev;
-#pragma unroll
-        for (uint32_t q = 0; q < 8; ++q) {
-            const uint32_t nl = __shfl(new_len, (int)(q * 8), FD_WAVE);
-            const uint32_t lq = __shfl(last, (int)(q * 8), FD_WAVE);
-            const bool pq = (pm >> (q * 8)) & 1ull;
-            if (q < grp) my_dst += nl;
-            round_total += nl;
-            if (pq) { round_last = lq; round_has = true; }
-        }
-        if (present) {
-            uint8_t *d = out_value + my_dst;
-            if (sub < dl) d[sub] = (uint8_t)(((delta >> (7u * sub)) & 0x7fu) | (sub + 1u < dl ? 0x80u : 0u));
-            const uint8_t *sp = src + b0 + nf;
-            d += dl;
-            const uint64_t n = (b1 - b0) - nf;
-            uint64_t o = (uint64_t)sub * 16u;
-            for (; o + 16 <= n; o += 128) {
-                mg_u32x4 v;
-                __builtin_memcpy(&v, sp + o, 16);
-                __builtin_memcpy(d + o, &v, 16);
-            }
-            if (o < n) for (uint64_t z = o; z < n; ++z) d[z] = sp[z];     // the lane that owns the ragged tail (< 16 bytes)
-        }
-        dst += round_total;
-        prev_last = round_last;
-        have_prev = round_has;
+__global__ __launch_bounds__(256) void k_mg_copy(const mg_part *__restrict__ parts, uint32_t n_parts, const mg_plan *__restrict__ plan,
+                                                 const uint32_t *__restrict__ plan_dst, uint64_t n_pieces, const uint64_t *__restrict__ out_off,
+                                                 uint8_t *__restrict__ out_value) {
+    const uint64_t G = (uint64_t)blockIdx.x * 32u + (threadIdx.x >> 3);
+    if (G >= n_pieces) return;
+    const mg_plan pl = plan[G];
+    if (!(pl.src_hi_dl & 0x80000000u)) return;
+    const uint32_t sub = threadIdx.x & 7u, k = (uint32_t)(G % n_parts);
+    const uint64_t slot = G / n_parts;
+    const uint32_t dl = (pl.src_hi_dl >> 16) & 7u;
+    uint8_t *d = out_value + out_off[slot] + plan_dst[G];
+    if (sub < dl) d[sub] = (uint8_t)(((pl.delta >> (7u * sub)) & 0x7fu) | (sub + 1u < dl ? 0x80u : 0u));
+    const uint8_t *sp = parts[k].value + (((uint64_t)(pl.src_hi_dl & 0xffffu) << 32) | pl.src_lo);
+    d += dl;
+    const uint64_t n = pl.n;
+    uint64_t o = (uint64_t)sub * 16u;
+    for (; o + 16 <= n; o += 128) {
+        mg_u32x4 v;
+        __builtin_memcpy(&v, sp + o, 16);
+        __builtin_memcpy(d + o, &v, 16);
     }
+    if (o < n) for (uint64_t z = o; z < n; ++z) d[z] = sp[z];     // the lane that owns the ragged tail (< 16 bytes)
 }
 
 // ---- launchers
@@ -211,9 +176,14 @@ void fd_mg_pos_fill(const uint32_t *hashes, uint64_t n, const uint32_t *bitmap, 
 void fd_mg_last_ids(const uint64_t *offsets, const uint8_t *value, uint64_t H, uint32_t *last_ids, hipStream_t st) {
     if (H) hipLaunchKernelGGL(k_mg_last_ids, dim3((unsigned)((H + 3) / 4)), dim3(256), 0, st, offsets, value, H, last_ids);
 }
-void fd_mg_sizes(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, uint32_t *sizes, uint32_t *out_last, hipStream_t st) {
-    if (n_slots) hipLaunchKernelGGL(k_mg_sizes, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, (const mg_part *)parts, n_parts, pos, n_slots, sizes, out_last);
+void fd_mg_sizes(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, uint32_t *sizes, uint32_t *out_last, void *plan, uint32_t *plan_dst,
+                 hipStream_t st) {
+    if (n_slots) hipLaunchKernelGGL(k_mg_sizes, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, (const mg_part *)parts, n_parts, pos, n_slots, sizes, out_last,
+                                    (mg_plan *)plan, plan_dst);
 }
-void fd_mg_copy(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, const uint64_t *out_off, uint8_t *out_value, hipStream_t st) {
-    if (n_slots) hipLaunchKernelGGL(k_mg_copy, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, st, (const mg_part *)parts, n_parts, pos, n_slots, out_off, out_value);
+void fd_mg_copy(const void *parts, uint32_t n_parts, const void *plan, const uint32_t *plan_dst, uint64_t n_slots, const uint64_t *out_off, uint8_t *out_value,
+                hipStream_t st) {
+    const uint64_t n_pieces = n_slots * n_parts;
+    if (n_pieces) hipLaunchKernelGGL(k_mg_copy, dim3((unsigned)((n_pieces + 31) / 32)), dim3(256), 0, st, (const mg_part *)parts, n_parts, (const mg_plan *)plan, plan_dst,
+                                     n_pieces, out_off, out_value);
 }
