@@ -127,9 +127,14 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             for c0 in range(0, len(queries), chunk):
                 ks = range(c0, min(c0 + chunk, len(queries)))
                 qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix if (match and not sharded) else None, float(S_total))
-                if match and sharded:
+                if match and sharded:     # idf of every query's entries from GLOBAL posting lengths: one length pass + one all-reduce per batch
+                    ph = np.concatenate([qm.primary_hash for qm in qms]) if qms else np.zeros(0, np.uint32)
+                    pl = fdist.global_posting_lengths(ix, ph, dev)
+                    gi = np.where(pl > 0, idf_of_lengths(np.maximum(pl, 1), S_total), 0.0).astype(np.float32)
+                    at = 0
                     for qm in qms:
-                        set_global_idf(qm)
+                        n = len(qm.primary_hash)
+                        qm.set_idf(gi[at:at + n]); at += n
                 if sharded:     # posting lengths must be all-reduced between the length pass and the scoring
                     recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=top_n,
                                              lengths_fn=lambda l: fdist.reduce_lengths(l, dev))
