@@ -238,6 +238,9 @@ def test_whole_structure_query_at_human_scale(human):
     assert np.allclose(recs["idf"], [w["idf"] for w in want], rtol=1e-5, atol=0)
     cand = fdist.rank_hits(recs, 20)["nid"].astype(np.uint32)
     assert int(cand[0]) == s
+    # the same prefilter through the fused entry point (rows sliced at node boundaries, selection and ranking on the device)
+    top = fd.count_query_maps(ctx, ix, [qm], human["pen"], total_structures=HUMAN, top_n=1000)[0]
+    assert top.tobytes() == fdist.rank_hits(recs, 1000).tobytes()
     got = fq.retrieve(ctx, batch, None, cand, qm, qb)
     n = _check_matches(got, cand, ps, oq, om)
     assert n >= 20 and max(sum(1 for x in g["processed"] if x >= 0) for g in got) == b - a     # the structure matches itself entirely
