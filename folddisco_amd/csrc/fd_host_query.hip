@@ -211,11 +211,15 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         pair_off[t + 1] = pi.size();
     }
     const uint64_t np = pi.size();
+    const bool qtrace = getenv("FDGPU_TRACE") != nullptr;
+    const auto q_t0 = std::chrono::steady_clock::now();
+    auto q_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - q_t0).count(); };
     std::vector<float> feat(std::max<uint64_t>(np, 1) * FD_QF);
     std::vector<uint8_t> valid(std::max<uint64_t>(np, 1));
     CHECK_TYPE(c, p);
     int rc = pair_features12(c, qb, pi.data(), pj.data(), np, p, feat.data(), valid.data());
     if (rc) return rc;
+    if (qtrace) fprintf(stderr, "[fdgpu_query_map] %llu pairs: features at %.3f ms\n", (unsigned long long)np, q_ms());
     const float RADS_PER_DEG = 3.14159274101257324f / 180.0f;  // f32::to_radians
     std::vector<float> athr(n_angle);
     for (uint64_t t = 0; t < n_angle; ++t) athr[t] = angle_thr_deg[t] * RADS_PER_DEG;
@@ -224,6 +228,12 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     std::vector<float> vf;      // FD_QF floats per candidate
     std::vector<cand_t> cands;
     std::vector<uint64_t> cand_off(n_queries + 1, 0);
+    {
+        uint64_t n_valid = 0;
+        for (uint64_t k = 0; k < np; ++k) n_valid += valid[k] ? 1 : 0;
+        const uint64_t per_pair = 1 + 2 * (2 * n_dist + 5 * n_angle);       // observed + near / far per threshold and field (upper bound without substitutions)
+        vf.reserve(n_valid * per_pair * FD_QF); cands.reserve(n_valid * per_pair);
+    }
     struct Aad { std::vector<uint8_t> a1, a2; std::vector<float> ad; std::vector<uint32_t> aq; };
     std::vector<Aad> aads(n_queries);
     auto push = [&](const float *f, uint32_t qi, uint32_t qj, bool primary, uint32_t pair) {
@@ -299,6 +309,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         cand_off[t + 1] = cands.size();
     }
     const uint64_t nc = cands.size();
+    if (qtrace) fprintf(stderr, "[fdgpu_query_map] %llu candidates expanded at %.3f ms\n", (unsigned long long)nc, q_ms());
     std::vector<uint32_t> hashes(std::max<uint64_t>(nc, 1));
     if ((rc = hash_features_q(c, vf.data(), nc, fd_make_consts(p).q, hashes.data(), FD_QF))) return rc;
     // --multiple-bins: every candidate is inserted under every bin pair, in list order (insert_binned_hash, query.rs:59-70); the
@@ -310,6 +321,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         mh_cfg[k].resize(std::max<uint64_t>(nc, 1));
         if ((rc = hash_features_q(c, vf.data(), nc, fd_make_consts_cfg(p, k).q, mh_cfg[k].data(), FD_QF))) return rc;
     }
+    if (qtrace) fprintf(stderr, "[fdgpu_query_map] hashed at %.3f ms\n", q_ms());
     // idf of every pair's observed (primary) hash: log2(S / len) (query.rs:17-32)
     std::vector<float> pair_idf(std::max<uint64_t>(np, 1), 0.0f);
     std::vector<uint32_t> pair_primary(std::max<uint64_t>(np, 1), 0u);
@@ -324,19 +336,41 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         for (size_t t = 0; t < ph.size(); ++t)
             pair_idf[pk[t]] = lens[t] > 0 ? log2f(total_structures / (float)lens[t]) : 0.0f;
     }
+    if (qtrace) fprintf(stderr, "[fdgpu_query_map] posting lengths at %.3f ms\n", q_ms());
     for (uint64_t t = 0; t < n_queries; ++t) {
         std::vector<uint32_t> mh, mqi, mqj, mph;
         std::vector<uint8_t> mp;
         std::vector<float> mi;
-        std::unordered_set<uint32_t> have;
-        have.reserve((size_t)(cand_off[t + 1] - cand_off[t]) / 4 + 16);
-        for (uint64_t z = cand_off[t]; z < cand_off[t + 1]; ++z) {
-            for (uint32_t k = 0; k < std::max(n_cfg, 1u); ++k) {
-                const uint32_t hz = n_cfg ? mh_cfg[k][z] : hashes[z];
-                if (!have.insert(hz).second) continue;
-                mh.push_back(hz); mqi.push_back(cands[z].qi); mqj.push_back(cands[z].qj); mp.push_back(cands[z].primary);
-                mi.push_back(pair_idf[cands[z].pair]); mph.push_back(pair_primary[cands[z].pair]);
+        // first insertion wins (the reference's hash map keeps the entry a hash was first inserted with).  Few candidates: a hash set;
+        // many (whole-structure queries, ~10^5): (hash << 32 | insertion position) keys through an LSD radix sort, first key of every
+        // hash kept, survivors back in insertion order — a third of the hash set's time there
+        const uint64_t c0 = cand_off[t], c1 = cand_off[t + 1], ncfg1 = std::max(n_cfg, 1u), n_ins = (c1 - c0) * ncfg1;
+        auto hash_at = [&](uint64_t pos) { const uint64_t z = c0 + pos / ncfg1; const uint32_t k = (uint32_t)(pos % ncfg1); return n_cfg ? mh_cfg[k][z] : hashes[z]; };
+        std::vector<uint32_t> keep;          // insertion positions (candidate * n_cfg + bin pair) that enter the map, ascending
+        if (n_ins <= 4096 || n_ins >= (1ull << 32)) {
+            std::unordered_set<uint32_t> have;
+            have.reserve((size_t)n_ins / 4 + 16);
+            for (uint64_t pos = 0; pos < n_ins; ++pos) if (have.insert(hash_at(pos)).second) keep.push_back((uint32_t)pos);
+        } else {
+            std::vector<uint64_t> key(n_ins), tmp(n_ins);
+            for (uint64_t pos = 0; pos < n_ins; ++pos) key[pos] = ((uint64_t)hash_at(pos) << 32) | pos;
+            for (int pass = 0; pass < 4; ++pass) {
+                const int sh = 32 + 8 * pass;
+                size_t cnt[257] = {0};
+                for (uint64_t k = 0; k < n_ins; ++k) ++cnt[((key[k] >> sh) & 255u) + 1];
+                for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+                for (uint64_t k = 0; k < n_ins; ++k) tmp[cnt[(key[k] >> sh) & 255u]++] = key[k];
+                key.swap(tmp);
             }
+            std::vector<uint8_t> first(n_ins, 0);      // the stable sort left every hash's earliest insertion first: mark, then walk in order
+            for (uint64_t k = 0; k < n_ins; ++k) if (k == 0 || (key[k] >> 32) != (key[k - 1] >> 32)) first[(uint32_t)key[k]] = 1;
+            for (uint64_t pos = 0; pos < n_ins; ++pos) if (first[pos]) keep.push_back((uint32_t)pos);
+        }
+        mh.reserve(keep.size()); mqi.reserve(keep.size()); mqj.reserve(keep.size()); mp.reserve(keep.size()); mi.reserve(keep.size()); mph.reserve(keep.size());
+        for (uint32_t pos : keep) {
+            const uint64_t z = c0 + pos / ncfg1;
+            mh.push_back(hash_at(pos)); mqi.push_back(cands[z].qi); mqj.push_back(cands[z].qj); mp.push_back(cands[z].primary);
+            mi.push_back(pair_idf[cands[z].pair]); mph.push_back(pair_primary[cands[z].pair]);
         }
         fd_query_map *m = (fd_query_map *)calloc(1, sizeof *m);
         if (!m) { for (uint64_t u = 0; u < t; ++u) { fdgpu_query_map_free(out[u]); out[u] = nullptr; } return FDGPU_ENOMEM; }
@@ -348,6 +382,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         m->n_aad = A.ad.size(); m->aad_aa1 = dup_vec(A.a1); m->aad_aa2 = dup_vec(A.a2); m->aad_dist = dup_vec(A.ad); m->aad_qi = dup_vec(A.aq);
         out[t] = m;
     }
+    if (qtrace) fprintf(stderr, "[fdgpu_query_map] maps built at %.3f ms\n", q_ms());
     return FDGPU_OK;
 }
 

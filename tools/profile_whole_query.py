@@ -41,8 +41,11 @@ def main():
     allres = np.arange(y - x, dtype=np.uint32)
 
     def go(trace):
+        if trace:
+            os.environ["FDGPU_TRACE"] = "1"
         t0 = time.perf_counter()
         qm = make_query_map(ctx, qb, allres, None, ix, float(S))
+        os.environ.pop("FDGPU_TRACE", None)
         t1 = time.perf_counter()
         top = count_query_maps(ctx, ix, [qm], None, total_structures=S, top_n=1000)[0]
         t2 = time.perf_counter()
