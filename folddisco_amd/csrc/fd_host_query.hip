@@ -529,10 +529,10 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     for (uint64_t t = 0; t < n_queries; ++t) max_aad = std::max<uint64_t>(max_aad, qms[t]->n_aad);
     const char *tp_env = getenv("FDGPU_TWO_PASS");     // 1 / 0 force the choice (tests)
     const bool two_pass = tp_env ? tp_env[0] == '1' : max_aad > 4096;
-    uint32_t *pk_key = nullptr, *pk_val = nullptr;      // packed, device-sorted candidate pairs (see fd_match_pairs_multi, mode bit 3)
+    uint32_t *pk_key = nullptr, *pk_val = nullptr;      // packed, device-sorted candidate pairs (see fd_match_pairs_multi, mode bit 3): context-owned pinned buffers
     struct HostBufs {   // the scan outputs live until the slots are processed; every return path below releases them
         fd_pair_rec *&f; fd_cand_rec *&c; uint32_t *&k, *&v;
-        ~HostBufs() { free(f); free(c); free(k); free(v); }
+        ~HostBufs() { free(f); free(c); k = nullptr; v = nullptr; }      // k / v: the context's pinned buffers, not ours to free
     } host_bufs{found, cands, pk_key, pk_val};
     int rc = 0;
     // symmetry flags (geometry/pdb_tr.rs:158-162): aa equal and atan2(sin, cos) of the two torsion fields equal; the other encodings
@@ -1017,7 +1017,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     }
     run_slots(false);
     if (trace) fprintf(stderr, "[fdgpu_retrieve] slots done at %.3f ms\n", t_ms(T2, t_now()));
-    free(found); found = nullptr; free(cands); cands = nullptr; free(pk_key); pk_key = nullptr; free(pk_val); pk_val = nullptr;
+    free(found); found = nullptr; free(cands); cands = nullptr; pk_key = nullptr; pk_val = nullptr;
     const uint64_t nprob = pend.size();
     std::vector<float> rmsd(std::max<uint64_t>(nprob, 1)), rot(std::max<uint64_t>(nprob, 1) * 9), tran(std::max<uint64_t>(nprob, 1) * 3);
     auto T3 = t_now();

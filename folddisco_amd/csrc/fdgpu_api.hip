@@ -168,6 +168,7 @@ extern "C" void fdgpu_destroy(fdgpu_ctx *c) {
     for (auto &b : c->pool) (void)hipFree(b.p);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (int k = 0; k < 8; ++k) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
+    for (int k = 0; k < 2; ++k) if (c->hbuf[k]) (void)hipHostFree(c->hbuf[k]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1515,9 +1516,10 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     if (pk_val) *pk_val = nullptr;
     if (packed) {
         const uint64_t n = tot[1];
-        uint32_t *hk = (uint32_t *)malloc(std::max<uint64_t>(n, 1) * 4), *hv = (uint32_t *)malloc(std::max<uint64_t>(n, 1) * 4);
+        // the packed pairs land in pinned buffers the CONTEXT keeps (valid until the next packed scan on this context; never freed by the caller)
+        uint32_t *hk = (uint32_t *)c->host_pinned(0, std::max<uint64_t>(n, 1) * 4), *hv = (uint32_t *)c->host_pinned(1, std::max<uint64_t>(n, 1) * 4);
         fd_pair_rec *hf2 = (fd_pair_rec *)malloc(std::max<uint64_t>(tot[0], 1) * sizeof(fd_pair_rec));
-        if (!hk || !hv || !hf2) { free(hk); free(hv); free(hf2); return FDGPU_ENOMEM; }
+        if (!hk || !hv || !hf2) { free(hf2); return FDGPU_ENOMEM; }
         if (n) {
             HIPCHK(c, c->ws[WS_MISC2].ensure(n * 4)); HIPCHK(c, c->ws[WS_MISC3].ensure(n * 4));
             HIPCHK(c, c->ws[WS_MISC4].ensure(n * 4)); HIPCHK(c, c->ws[WS_MISC5].ensure(n * 4));

@@ -55,6 +55,19 @@ struct fdgpu_ctx {
     std::vector<hipEvent_t> event_pool;
     size_t event_used = 0;
     // pinned staging of large device-to-host copies (fd_d2h_big in fdgpu_api.hip): FD_PIN_SLOTS buffers of FD_PIN_BYTES, made on first use
+    // pinned host buffers that outlive a call (the packed candidate pairs of a whole-structure retrieval: 2 x ~100 MB per call — as
+    // malloc'd blocks their first-touch page faults and their munmap cost more than the copy)
+    void *hbuf[2] = {nullptr, nullptr};
+    size_t hbuf_cap[2] = {0, 0};
+    void *host_pinned(int k, size_t bytes) {
+        if (hbuf_cap[k] >= bytes) return hbuf[k];
+        if (hbuf[k]) (void)hipHostFree(hbuf[k]);
+        hbuf[k] = nullptr; hbuf_cap[k] = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&hbuf[k], want, hipHostMallocDefault) != hipSuccess) { hbuf[k] = nullptr; return nullptr; }
+        hbuf_cap[k] = want;
+        return hbuf[k];
+    }
     void *pin[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pin_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // device blocks of destroyed indices, reused by the next build (steady-state builds do not call
