@@ -1389,6 +1389,9 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     if (!fd_hash_type_supported(p->hash_type)) FAIL(c, FDGPU_EINVAL, "hash_type: only the encodings over the (d_CA, d_CB, theta, tau1, tau2) descriptor are built (0, 1, 3, 7, 8)");
     reset_timings(c);
     hipStream_t st = c->stream;
+    const bool mp_trace = getenv("FDGPU_TRACE") != nullptr;
+    const auto mp_t0 = std::chrono::steady_clock::now();
+    auto mp_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - mp_t0).count(); };
     // work items: (query, candidate slot, 64-residue i-tile); a handful of long candidates (whole-structure queries: the top 20)
     // would leave most of the chip idle, so the partner residues are split into spans as well until ~2000 wavefronts exist
     uint64_t n_tiles = 0;
@@ -1453,6 +1456,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     if (!all_start.empty()) memcpy(&blk[o_st], all_start.data(), all_start.size() * 4);
     if (na) { memcpy(&blk[o_d], all_dist.data(), na * 4); memcpy(&blk[o_qi], all_qi.data(), na * 4); }
     if (n_queries) memcpy(&blk[o_qt], qtab.data(), n_queries * sizeof(mp_query_dev));
+    if (mp_trace) fprintf(stderr, "[match_pairs] tables at %.3f ms (%zu work items)\n", mp_ms(), nw);
     HIPCHK(c, c->ws[WS_MISC0].ensure(words * 4));
     HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, blk.data(), words * 4, hipMemcpyHostToDevice, st));
@@ -1503,6 +1507,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         if (tot[0] <= A.cap_found && tot[1] <= A.cap_cands) break;
         if (attempt == 2) FAIL(c, FDGPU_ERANGE, "match_pairs: output did not fit after regrowing");
     }
+    if (mp_trace) fprintf(stderr, "[match_pairs] scan done at %.3f ms (found %llu, cands %llu)\n", mp_ms(), (unsigned long long)tot[0], (unsigned long long)tot[1]);
     // mode bit 4: the records stay on the device (ws[WS_KEYS_A] = found triples, ws[WS_KEYS_B] = candidate pairs, in append order) for
     // the device-side retrieval glue (k_retrieve.hip); only the counts return
     if (mode & 16u) { *n_found = tot[0]; *n_cands = tot[1]; return FDGPU_OK; }
@@ -1537,7 +1542,9 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         }
         if (tot[0]) HIPCHK(c, hipMemcpyAsync(hf2, A.found, tot[0] * sizeof(fd_pair_rec), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
+        if (mp_trace) fprintf(stderr, "[match_pairs] packed copy done at %.3f ms\n", mp_ms());
         fd_sort_found(hf2, tot[0], n_cand);
+        if (mp_trace) fprintf(stderr, "[match_pairs] found sorted at %.3f ms\n", mp_ms());
         *found = hf2; *n_found = tot[0]; *cands = nullptr; *n_cands = n; *pk_key = hk; *pk_val = hv;
         return FDGPU_OK;
     }
@@ -1551,7 +1558,9 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     if (e != hipSuccess) { free(hf); free(hc); c->err = std::string("match_pairs: ") + hipGetErrorString(e); return FDGPU_EHIP; }
     // restore the reference's scan order (row-major over the prefilter sets, retrieve.rs:146-153): the
     // kernel appends with atomics, one contiguous run per (i, j) in observed-list order
+    if (mp_trace) fprintf(stderr, "[match_pairs] copy done at %.3f ms\n", mp_ms());
     fd_sort_found(hf, tot[0], n_cand);
+    if (mp_trace) fprintf(stderr, "[match_pairs] found sorted at %.3f ms\n", mp_ms());
     // mode bit 2: the caller buckets the candidate pairs itself and does not depend on their order (the rescue only counts them)
     if (!(mode & 4u)) std::stable_sort(hc, hc + tot[1], [](const fd_cand_rec &a, const fd_cand_rec &b) {
         if (a.cand != b.cand) return a.cand < b.cand;

@@ -44,7 +44,8 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
         d = fd_dist(cai, caj);
         key = (aai & 31u) * 32u + (aaj & 31u);   // queued pairs have aa < 32
         e_lo = st_tab[key]; e_hi = st_tab[key + 1];
-        for (uint32_t e = e_lo; e < e_hi; ++e) n_win += (fd_fabsf(d - dist_tab[e]) < A.ca_window) ? 1u : 0u;
+        if (A.mode & 2u)      // the observed-distance window only feeds the candidate pairs: a found-only scan (first pass of a large query) skips it
+            for (uint32_t e = e_lo; e < e_hi; ++e) n_win += (fd_fabsf(d - dist_tab[e]) < A.ca_window) ? 1u : 0u;
         if (fd_own_descriptor(A.C.q.type)) {
             // encodings with their own descriptor: the pair may still have no feature (CB / point-pair distance, chain ends)
             float f9[FD_NFEAT];

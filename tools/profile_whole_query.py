@@ -57,6 +57,11 @@ def main():
         return (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, len(m)
 
     go(False)
+    ctx.enable_timing(True)
+    go(False)
+    ctx.synchronize()
+    print("kernel stages of the last library call (ms):", {n: round(ms, 3) for n, ms, _ in ctx.last_timings()})
+    ctx.enable_timing(False)
     print("query map %.1f ms, scoring + top 1000 %.1f ms, retrieval of the top 20 %.1f ms, %d matches" % go(False))
     go(True)
 
