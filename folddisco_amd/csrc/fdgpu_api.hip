@@ -985,7 +985,7 @@ static int cq_score(fdgpu_ctx *c, const cq_args &A) {
     int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &W);
     if (rc) return rc;
     HIPCHK(c, c->ws[WS_CQ_SEGSUM].ensure(std::max<uint64_t>(W, 1) * 4));
-    fd_launch_cq_seg(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_WSTART].as<uint64_t>(), c->ws[WS_CQ_SEGSUM].as<uint32_t>(), W, W > A.nq, st);
+    fd_launch_cq_seg(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_WSTART].as<uint64_t>(), c->ws[WS_CQ_SEGSUM].as<uint32_t>(), W, W > 0, st);
     return FDGPU_OK;
 }
 
@@ -1020,7 +1020,6 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC3].p, rows_meta.data(), nq * 8, hipMemcpyHostToDevice, st));
     if (penalty) HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st));
     const float *d_penalty = penalty ? c->ws[WS_MISC5].as<float>() : ix->penalty;
-    HIPCHK(c, hipMemsetAsync(c->ws[WS_KEYS_B].p, 0, (size_t)nq * words * 4, st));
     cq_args A;
     A.hashes = ix->hashes; A.offsets = ix->offsets; A.value = ix->value; A.H = ix->n_hashes;
     A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.nq = nq;
@@ -1120,7 +1119,6 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     (void)hipMemcpyAsync(c->ws[WS_TILE_H].p, q_off, (n_queries + 1) * 8, hipMemcpyHostToDevice, st);
     if (penalty) (void)hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st);
     const float *d_penalty = penalty ? c->ws[WS_MISC5].as<float>() : ix->penalty;
-    (void)hipMemsetAsync(c->ws[WS_KEYS_B].p, 0, (size_t)nq * words * 4, st);
     cq_args A;
     A.hashes = ix->hashes; A.offsets = ix->offsets; A.value = ix->value; A.H = ix->n_hashes;
     A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.nq = nq;

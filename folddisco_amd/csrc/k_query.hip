@@ -7,9 +7,11 @@
 //
 // Mapping: posting lists are cut into 2 KB segments (see k_cq_seg).  A segment is consumed in 64-byte blocks (one byte per lane): a
 // ballot over the continuation bits finds the terminator lanes, each terminator reassembles its value from the (<= 4) preceding
-// lanes with shuffles, a wave prefix sum over the deltas turns them into structure ids.  Scoring is ONE integer atomic per posting:
-// the posting sets bit `structure` in the occupancy row of ITS QUERY HASH — a posting list holds a structure at most once, so the
-// matrix [query hashes][ceil(S/32)] holds exactly which (hash, structure) pairs matched.  Everything count_query reports follows
+// lanes with shuffles, a wave prefix sum over the deltas turns them into structure ids.  Scoring sets ONE bit per posting: bit
+// `structure` in the occupancy row of ITS QUERY HASH — a posting list holds a structure at most once, so the matrix
+// [query hashes][ceil(S/32)] holds exactly which (hash, structure) pairs matched.  A list's ids ascend, so the segment that decodes
+// them OWNS a contiguous run of the row's words: it assembles them in an LDS window and stores them as full lines, zeros included
+// (no memset of the matrix, no atomic per posting); only the words two neighbouring segments share take atomics (k_cq_bounds).  Everything count_query reports follows
 // from it in k_cq_rows_finalize, one thread per structure walking its query's rows (sorted by (node, partner) on the host):
 //   match_count  number of set rows;   idf_sum  sum of the rows' idf in 2^-22 fixed point (order-independent, unlike the reference's
 //   f32 sum whose order follows FxHashMap iteration; BASELINE.md §2 states the 1e-5 tolerance);   edge_count / node_count  number
@@ -109,9 +111,14 @@ void fd_launch_get_entries(const uint32_t *hashes, const uint64_t *offsets, cons
 // knows the id it starts from: a varint belongs to the segment that holds its LAST byte, so
 //   plan     per query hash: list position and number of CQ_SEG-byte segments            (k_cq_plan + exclusive scan -> work items)
 //   sums     per segment: sum of the varint values that end inside it                     (k_cq_seg<true>; skipped when no list is split)
-//   score    per segment: base id = sum of the list's earlier segment sums, then the same 64-byte block decode + integer atomics
+//   bounds   per list: exclusive prefix of its segment sums = the id every segment starts from; the row words two neighbouring
+//            segments share (the word of a segment's start id) are zeroed, rows of absent hashes are zeroed whole   (k_cq_bounds)
+//   score    per segment: the same 64-byte block decode; the ids' bits go into an LDS window over the row words the segment owns
+//            (everything between its two shared words; the first / last segment own the row's head / tail) and leave as full
+//            lines, the shared words take atomic ORs
 // Work items are walked by a persistent grid (the count stays on the device).
 #define CQ_SEG 2048u
+#define CQ_WIN 1024u     // words of an occupancy row in a wavefront's LDS window (32,768 structures)
 struct cq_plan {
     const long long *kidx;        // [nq] position of the hash in the index, -1 = absent
     const uint64_t *wstart;       // [nq + 1] first work item of every query hash
@@ -152,9 +159,44 @@ __global__ __launch_bounds__(FD_WAVE) void k_pl_count(const uint64_t *__restrict
     }
 }
 
+// row word of a structure id, monotone in the id (ids outside the index's range clamp to the row's ends and set no bit)
+__device__ __forceinline__ uint32_t cq_word_of(uint32_t id, uint32_t first_id, uint32_t S) {
+    if (id < first_id) return 0u;
+    const uint32_t rel = id - first_id;
+    return (rel < S ? rel : S - 1u) >> 5;
+}
+// one wavefront per query hash: segment sums -> start ids (in place), shared words zeroed, absent rows zeroed
+__global__ __launch_bounds__(FD_WAVE) void k_cq_bounds(cq_args A, cq_plan P) {
+    const uint32_t lane = threadIdx.x;
+    for (uint64_t q = blockIdx.x; q < A.nq; q += gridDim.x) {
+        const uint64_t w0 = P.wstart[q];
+        const uint32_t n = (uint32_t)(P.wstart[q + 1] - w0);
+        uint32_t *hb = A.hash_bits + (uint64_t)q * A.words;
+        if (n == 0) { for (uint32_t x = lane; x < A.words; x += FD_WAVE) hb[x] = 0u; continue; }
+        uint32_t run = 0;
+        for (uint32_t t0 = 0; t0 < n && n > 1; t0 += FD_WAVE) {
+            const uint32_t t = t0 + lane;
+            const uint32_t v = t < n ? P.segsum[w0 + t] : 0u;
+            uint32_t s2 = v;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t u = __shfl_up(s2, off, FD_WAVE);
+                if ((int)lane >= off) s2 += u;
+            }
+            const uint32_t excl = run + s2 - v;
+            if (t < n) {
+                P.segsum[w0 + t] = excl;
+                if (t) hb[cq_word_of(excl, A.first_id, A.S)] = 0u;
+            }
+            run += __shfl(s2, 63, FD_WAVE);
+        }
+    }
+}
+
 template <bool SUMS>
 __global__ __launch_bounds__(FD_WAVE) void k_cq_seg(cq_args A, cq_plan P) {
+    __shared__ uint32_t win[CQ_WIN];
     const uint32_t lane = threadIdx.x;
+    if (!SUMS) for (uint32_t x = lane; x < CQ_WIN; x += FD_WAVE) win[x] = 0u;
     const uint64_t W = P.wstart[A.nq];
     for (uint64_t w = blockIdx.x; w < W; w += gridDim.x) {
         // query hash of this work item: last q with wstart[q] <= w
@@ -182,14 +224,15 @@ __global__ __launch_bounds__(FD_WAVE) void k_cq_seg(cq_args A, cq_plan P) {
             carry_val = pv; carry_shift = 7u * tail;
         }
         uint32_t run_id = 0;
-        if (!SUMS && j) {   // base id: sum of the list's earlier segment sums
-            uint32_t acc = 0;
-            for (uint32_t t = lane; t < j; t += FD_WAVE) acc += P.segsum[w0 + t];
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, FD_WAVE);
-            run_id = acc;
-        }
         uint32_t *hb = nullptr;
-        if (!SUMS) hb = A.hash_bits + (uint64_t)q * A.words;     // the occupancy row of this query hash
+        // row words [plain_lo, plain_hi) are this segment's alone; lo_word / plain_hi are shared with the neighbours (atomics)
+        uint32_t lo_word = 0xffffffffu, plain_lo = 0, plain_hi = 0, win_base = 0;
+        if (!SUMS) {
+            hb = A.hash_bits + (uint64_t)q * A.words;     // the occupancy row of this query hash
+            if (j) { run_id = P.segsum[w]; lo_word = cq_word_of(run_id, A.first_id, A.S); plain_lo = lo_word + 1u; }
+            plain_hi = w + 1 < P.wstart[q + 1] ? cq_word_of(P.segsum[w + 1], A.first_id, A.S) : A.words;
+            win_base = plain_lo & ~63u;
+        }
         uint32_t seg_acc = 0;
         for (uint64_t base = s0; base < s1; base += FD_WAVE) {
             const uint64_t p = base + lane;
@@ -214,9 +257,28 @@ __global__ __launch_bounds__(FD_WAVE) void k_cq_seg(cq_args A, cq_plan P) {
                 if ((int)lane >= off) s2 += t;
             }
             const uint32_t id = run_id + s2;
-            if (!SUMS && term) {
+            if (!SUMS) {
                 const uint32_t rel = id - A.first_id;
-                if (id >= A.first_id && rel < A.S) atomicOr(&hb[rel >> 5], 1u << (rel & 31u));     // the posting's one atomic
+                const bool valid = term && id >= A.first_id && rel < A.S;
+                const uint32_t wd = rel >> 5, bit = 1u << (rel & 31u);
+                const bool shared = valid && (wd == lo_word || wd == plain_hi);
+                if (shared) atomicOr(&hb[wd], bit);
+                bool todo = valid && !shared;
+                uint64_t pend = __ballot(todo);
+                while (pend) {
+                    if (todo && wd - win_base < CQ_WIN) { atomicOr(&win[wd - win_base], bit); todo = false; }      // ds_or_b32
+                    pend = __ballot(todo);
+                    if (pend) {     // the window leaves as full lines; ids ascend with the lane, so the lowest waiting lane names the next window
+                        const uint32_t next_base = (uint32_t)__shfl((int)wd, __ffsll((unsigned long long)pend) - 1, FD_WAVE) & ~63u;
+                        for (uint32_t x = lane; x < CQ_WIN; x += FD_WAVE) {
+                            const uint32_t g = win_base + x, v = win[x];
+                            win[x] = 0u;
+                            if (g >= plain_lo) hb[g] = v;
+                        }
+                        for (uint32_t g = win_base + CQ_WIN + lane; g < next_base; g += FD_WAVE) hb[g] = 0u;
+                        win_base = next_base;
+                    }
+                }
             }
             if (tm) {
                 const int last_t = 63 - __clzll(tm);
@@ -233,6 +295,14 @@ __global__ __launch_bounds__(FD_WAVE) void k_cq_seg(cq_args A, cq_plan P) {
             if (SUMS) seg_acc = run_id;
         }
         if (SUMS && lane == 0) P.segsum[w] = seg_acc;     // run_id started at 0: the sum of the values that end in this segment
+        if (!SUMS) {        // the rest of the window, then zeros up to the word shared with the next segment (or the row's end)
+            for (uint32_t x = lane; x < CQ_WIN && win_base + (x & ~63u) < plain_hi; x += FD_WAVE) {
+                const uint32_t g = win_base + x, v = win[x];
+                win[x] = 0u;
+                if (g >= plain_lo && g < plain_hi) hb[g] = v;
+            }
+            for (uint32_t g = win_base + CQ_WIN + lane; g < plain_hi; g += FD_WAVE) hb[g] = 0u;
+        }
     }
 }
 void fd_launch_cq_plan(const cq_args &A, long long *kidx, uint32_t *nseg, hipStream_t st) {
@@ -241,11 +311,13 @@ void fd_launch_cq_plan(const cq_args &A, long long *kidx, uint32_t *nseg, hipStr
 // n_items: number of work items (host copy of wstart[nq]); split: some list has more than one segment
 void fd_launch_cq_seg(const cq_args &A, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
                       hipStream_t st) {
-    if (!A.nq || !n_items) return;
+    if (!A.nq) return;
     cq_plan P;
     P.kidx = kidx; P.wstart = wstart; P.segsum = segsum;
+    if (!n_items) { hipLaunchKernelGGL(k_cq_bounds, dim3((unsigned)(A.nq < 16384 ? A.nq : 16384)), dim3(FD_WAVE), 0, st, A, P); return; }
     const unsigned grid = (unsigned)(n_items < 16384 ? n_items : 16384);
     if (split) hipLaunchKernelGGL(k_cq_seg<true>, dim3(grid), dim3(FD_WAVE), 0, st, A, P);
+    hipLaunchKernelGGL(k_cq_bounds, dim3((unsigned)(A.nq < 16384 ? A.nq : 16384)), dim3(FD_WAVE), 0, st, A, P);
     hipLaunchKernelGGL(k_cq_seg<false>, dim3(grid), dim3(FD_WAVE), 0, st, A, P);
 }
 

@@ -20,9 +20,11 @@ def main():
     ap.add_argument("--structures", type=int, default=67750)
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--chunk", type=int, default=32, help="queries per batch")
+    ap.add_argument("--chunk", default="32", help="queries per batch (a comma list measures each in turn)")
     ap.add_argument("--no-profile", action="store_true")
     a = ap.parse_args()
+    chunks = [int(x) for x in str(a.chunk).split(",")]
+    a.chunk = chunks[0]
     import numpy as np
     import torch
     import folddisco_amd as fd
@@ -83,14 +85,18 @@ def main():
             for k, v in (("make_query_maps", t1 - t0), ("count_query_batch", t2 - t1), ("rank", t3 - t2), ("retrieve_batch", t4 - t3)):
                 T[k] = T.get(k, 0.0) + v
 
-    go(True)
-    T.clear()
     n_rep = a.reps
-    t0 = time.perf_counter()
-    for _ in range(n_rep):
+    for ch in chunks:
+        a.chunk = ch
         go(True)
-    dt = time.perf_counter() - t0
-    print(f"full batched: {a.queries * n_rep / dt:.0f} q/s; per 32-query batch: " + ", ".join(f"{k} {v / n_rep / (len(queries) / a.chunk) * 1e3:.3f} ms" for k, v in T.items()))
+        T.clear()
+        t0 = time.perf_counter()
+        for _ in range(n_rep):
+            go(True)
+        dt = time.perf_counter() - t0
+        print(f"full batched: {a.queries * n_rep / dt:.0f} q/s; per {ch}-query batch: " +
+              ", ".join(f"{k} {v / n_rep / (len(queries) / a.chunk) * 1e3:.3f} ms" for k, v in T.items()), flush=True)
+    a.chunk = chunks[0]
     if a.no_profile:
         return
     os.environ["FDGPU_TRACE"] = "1"
