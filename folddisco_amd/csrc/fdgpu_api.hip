@@ -1126,12 +1126,16 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>(); A.packed = packed ? 1 : 0;
     A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
     const bool dense_topn = allow_dense && packed && top_n > 0 && top_n + 1024 <= 4096;
+    // one query with thousands of rows (whole-structure mode): its rows are walked in slices that add into the dense results; motif
+    // queries with a selection skip the dense results altogether (k_cq_rows_keys: ranking keys only, records for the survivors)
+    const bool sliced = n_queries == 1 && nq >= 4096;
+    const bool keys_only = dense_topn && !sliced;
     std::vector<uint64_t> slices;        // outlives its asynchronous copy (every path below synchronises the stream before returning)
     {
         StageTimer t(c, "cq_batch", 0);
         int rs = cq_score(c, A);
         if (rs) { free(ooff); return rs; }
-        if (n_queries == 1 && nq >= 4096) {      // one query with thousands of rows: slices at node boundaries (see fdgpu_count_query)
+        if (sliced) {      // slices at node boundaries (see fdgpu_count_query)
             const uint64_t per = (nq + 31) / 32;
             slices.push_back(0);
             for (uint64_t r = 0; r + 1 < nq; ++r)
@@ -1141,9 +1145,10 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
             if (es == hipSuccess) es = hipMemcpyAsync(c->ws[WS_TILE_B].p, slices.data(), slices.size() * 8, hipMemcpyHostToDevice, st);
             if (es != hipSuccess) slices.clear();
         }
-        fd_launch_cq_rows_finalize(A, c->ws[WS_TILE_H].as<uint64_t>(), (uint32_t)n_queries, slices.empty() ? nullptr : c->ws[WS_TILE_B].as<uint64_t>(),
-                                   slices.empty() ? 0u : (uint32_t)slices.size() - 1, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(),
-                                   c->ws[WS_MISC4].as<uint8_t>(), max_rows, st);
+        if (!keys_only)
+            fd_launch_cq_rows_finalize(A, c->ws[WS_TILE_H].as<uint64_t>(), (uint32_t)n_queries, slices.empty() ? nullptr : c->ws[WS_TILE_B].as<uint64_t>(),
+                                       slices.empty() ? 0u : (uint32_t)slices.size() - 1, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(),
+                                       c->ws[WS_MISC4].as<uint8_t>(), max_rows, st);
         if (!dense_topn)
             fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), QS, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
                                        c->ws[WS_TOTAL].as<uint64_t>(), st);
@@ -1164,8 +1169,12 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
         std::vector<fd_count_rec> sel((size_t)n_queries * top_n);
         if (e2 == hipSuccess) {
             StageTimer t(c, "cq_topn", 0);
-            fd_launch_cq_topn_dense(A, d_penalty, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), (uint32_t)n_queries, top_n, cap,
-                                    c->ws[WS_KEYS_A].p, c->ws[WS_MISC2].p, c->ws[WS_CQ_TOPN].as<uint32_t>(), st);
+            if (keys_only)      // keys in the compaction's position buffer, unused on this path
+                fd_launch_cq_topn_dense(A, c->ws[WS_TILE_H].as<uint64_t>(), d_penalty, c->ws[WS_TILE_BO].as<uint32_t>(), (uint32_t)n_queries, top_n, cap,
+                                        c->ws[WS_KEYS_A].p, c->ws[WS_MISC2].p, c->ws[WS_CQ_TOPN].as<uint32_t>(), st);
+            else
+                fd_launch_cq_topn_acc(A, d_penalty, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), (uint32_t)n_queries, top_n, cap,
+                                      c->ws[WS_KEYS_A].p, c->ws[WS_MISC2].p, c->ws[WS_CQ_TOPN].as<uint32_t>(), st);
             fd_launch_cq_topn_sort(c->ws[WS_KEYS_A].p, cap, c->ws[WS_MISC2].p, (uint32_t)n_queries, top_n, c->ws[WS_TILE_HO].p, st);
         }
         if (e2 == hipSuccess) e2 = hipMemcpyAsync(tstate.data(), c->ws[WS_MISC2].p, n_queries * 16, hipMemcpyDeviceToHost, st);

@@ -255,8 +255,10 @@ void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, cons
                                 const float *penalty, uint64_t total, void *out, hipStream_t st);
 void fd_launch_cq_topn(const void *recs, const uint64_t *off, uint32_t n_queries, uint32_t top_n, uint32_t cap, void *out, void *state, uint32_t *ghist,
                        hipStream_t st);
-void fd_launch_cq_topn_dense(const cq_args &A, const float *penalty, const uint32_t *node_cnt, const uint32_t *edge_cnt, uint32_t n_queries, uint32_t top_n,
-                             uint32_t cap, void *out, void *state, uint32_t *ghist, hipStream_t st);
+void fd_launch_cq_topn_acc(const cq_args &A, const float *penalty, const uint32_t *node_cnt, const uint32_t *edge_cnt, uint32_t n_queries, uint32_t top_n,
+                           uint32_t cap, void *out, void *state, uint32_t *ghist, hipStream_t st);
+void fd_launch_cq_topn_dense(const cq_args &A, const uint64_t *q_rows, const float *penalty, uint32_t *keys, uint32_t n_queries, uint32_t top_n, uint32_t cap,
+                             void *out, void *state, uint32_t *ghist, hipStream_t st);
 void fd_launch_cq_topn_sort(const void *sel, uint32_t cap, const void *state, uint32_t n_queries, uint32_t top_n, void *out, hipStream_t st);
 void fd_launch_get_entries(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash, uint64_t nq,
                            const uint64_t *out_off, uint32_t *out, hipStream_t st);

@@ -567,11 +567,176 @@ void fd_launch_cq_topn_sort(const void *sel, uint32_t cap, const void *state, ui
                                       (fd_count_rec_dev *)out);
 }
 
-// The same selection straight from the dense [queries][S] accumulators (packed form): no flag scan, no compaction of every touched
+// Candidate selection of whole queries in the packed form, without the dense per-structure results: only what RANKS a structure is
+// computed for all of them, the record (counts, idf) only for the survivors.
+//   k_cq_rows_keys     the word-major walk over the occupancy rows of k_cq_rows_finalize, sums only: per structure the ranking key
+//                      (order-preserving image of idf sum x penalty; 0 = untouched), 4 bytes instead of the 17 of accumulator, node
+//                      count, edge count and flag — plus the first-level histogram of the radix select (LDS, 16-bit counters, bins
+//                      of non-negative idf) merged into the global table
+//   k_topn_hist_dense  second level over the keys (four loads in flight per thread)
+//   k_topn_emit_dense  lists the survivors in LDS, then all threads build their records at once: a survivor walks its query's rows
+//                      (~100 independent loads for a motif query) for match / edge / node counts and the exact idf sum
+// Fewer touched structures than top_n: the threshold search ends in bin 0 and everything touched is emitted.
+struct topn_dense {
+    const uint32_t *keys; const float *penalty; const uint32_t *hash_bits; const unsigned long long *row_meta; const uint64_t *q_rows;
+    uint32_t words, S, first_id;
+};
+__global__ __launch_bounds__(CQ_FIN_T) void k_cq_rows_keys(topn_dense D, uint32_t *__restrict__ keys, uint32_t *__restrict__ ghist) {
+    __shared__ unsigned long long s_sum[CQ_FIN_T * 33];
+    __shared__ uint32_t s_hist[512];       // bins 1024..2047 of the 2048 (idf >= 0), two 16-bit counters per word (<= 4,096 structures per workgroup)
+    const uint32_t w = blockIdx.x * CQ_FIN_T + threadIdx.x, qy = blockIdx.y;
+    const bool live = w < D.words;
+    const uint64_t r0 = D.q_rows[qy], r1 = D.q_rows[qy + 1];
+    const uint32_t nid0 = blockIdx.x * CQ_FIN_T * 32;
+    const uint32_t lim = nid0 < D.S ? (D.S - nid0 < CQ_FIN_T * 32 ? D.S - nid0 : CQ_FIN_T * 32) : 0u;
+    float pen[32];      // the penalties of the 32 structures this thread writes keys for (structure-major), requested up front
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { const uint32_t i = k * CQ_FIN_T + threadIdx.x; pen[k] = i < lim ? D.penalty[nid0 + i] : 0.0f; }
+    for (int k = threadIdx.x; k < 512; k += CQ_FIN_T) s_hist[k] = 0;
+    unsigned long long *mine = s_sum + threadIdx.x * 33;
+    for (int b = 0; b < 32; ++b) mine[b] = 0ull;
+    uint32_t touched = 0;
+    uint64_t r = r0;
+    for (; r + 8 <= r1; r += 8) {       // eight rows' words in flight
+        uint32_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = live ? D.hash_bits[(r + u) * D.words + w] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            uint32_t y = x[u];
+            if (!y) continue;
+            touched |= y;
+            const unsigned long long fix = D.row_meta[r + u] >> 2;
+            while (y) { const int b = __builtin_ctz(y); mine[b] += fix; y &= y - 1u; }
+        }
+    }
+    for (; r < r1; ++r) {
+        uint32_t y = live ? D.hash_bits[r * D.words + w] : 0u;
+        if (!y) continue;
+        touched |= y;
+        const unsigned long long fix = D.row_meta[r] >> 2;
+        while (y) { const int b = __builtin_ctz(y); mine[b] += fix; y &= y - 1u; }
+    }
+    while (touched) { const int b = __builtin_ctz(touched); mine[b] |= 1ull << 63; touched &= touched - 1u; }     // a matched row may carry idf 0
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const uint32_t i = k * CQ_FIN_T + threadIdx.x;
+        if (i < lim) {
+            const unsigned long long a = s_sum[(i >> 5) * 33 + (i & 31u)];
+            uint32_t key = 0;
+            if (a >> 63) {
+                key = idf_order_key((float)((double)(a & CQ_SUM_MASK) * (1.0 / IDF_SCALE)) * pen[k]);
+                const uint32_t bin = key >> 21;
+                if (bin >= 1024) atomicAdd(&s_hist[(bin - 1024) >> 1], 1u << ((bin & 1u) * 16));
+                else atomicAdd(&ghist[(uint64_t)qy * TOPN_BINS + bin], 1u);      // a negative idf (negative penalty): never in practice
+            }
+            keys[(uint64_t)qy * D.S + nid0 + i] = key;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 1024; k += CQ_FIN_T) {
+        const uint32_t cn = (s_hist[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+        if (cn) atomicAdd(&ghist[(uint64_t)qy * TOPN_BINS + 1024 + k], cn);
+    }
+}
+__global__ __launch_bounds__(256) void k_topn_hist_dense(topn_dense D, const topn_state *__restrict__ st, uint32_t *__restrict__ ghist) {
+    __shared__ uint32_t hist[TOPN_BINS];
+    const uint32_t q = blockIdx.y;
+    for (int k = threadIdx.x; k < TOPN_BINS; k += 256) hist[k] = 0;
+    __syncthreads();
+    const uint32_t b1 = st[q].thr_bin;
+    const uint32_t *kq = D.keys + (uint64_t)q * D.S;
+    for (uint32_t i0 = blockIdx.x * 1024 + threadIdx.x; i0 < D.S; i0 += TOPN_SPLIT * 1024) {
+        uint32_t k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k4[u] = i0 + u * 256 < D.S ? kq[i0 + u * 256] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k4[u] && (k4[u] >> 21) == b1) atomicAdd(&hist[(k4[u] >> 10) & (TOPN_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < TOPN_BINS; k += 256) if (hist[k]) atomicAdd(&ghist[(uint64_t)q * TOPN_BINS + k], hist[k]);
+}
+__global__ __launch_bounds__(256) void k_topn_emit_dense(topn_dense D, uint32_t cap, topn_state *__restrict__ st, fd_count_rec_dev *__restrict__ out) {
+    __shared__ uint32_t s_idx[2048];
+    __shared__ uint32_t s_n, s_base;
+    const uint32_t q = blockIdx.y;
+    const uint32_t thr22 = st[q].thr22;
+    const uint64_t r0 = D.q_rows[q], r1 = D.q_rows[q + 1];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    auto drain = [&]() {
+        const uint32_t n = s_n;
+        if (threadIdx.x == 0 && n) s_base = atomicAdd(&st[q].count, n);
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < n; e += 256) {
+            const uint32_t i = s_idx[e], pos = s_base + e;
+            if (pos >= cap) continue;
+            // the record of structure i from its query's rows, in (node, partner) order like k_cq_rows_finalize
+            const uint32_t *col = D.hash_bits + (i >> 5);
+            const uint32_t sh = i & 31u;
+            uint32_t cnt = 0, edges = 0, nodes = 0;
+            bool e_any = false, n_any = false;
+            unsigned long long sum = 0;
+            auto row = [&](uint32_t x, unsigned long long m) {
+                if ((x >> sh) & 1u) { ++cnt; e_any = true; sum += m >> 2; }
+                if (m & 1ull) { if (e_any) { ++edges; n_any = true; } e_any = false; }
+                if (m & 2ull) { if (n_any) ++nodes; n_any = false; }
+            };
+            uint64_t r = r0;
+            for (; r + 8 <= r1; r += 8) {
+                uint32_t x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = col[(r + u) * D.words];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) row(x[u], D.row_meta[r + u]);
+            }
+            for (; r < r1; ++r) row(col[r * D.words], D.row_meta[r]);
+            fd_count_rec_dev rec;
+            rec.nid = i + D.first_id; rec.total_match_count = cnt; rec.node_count = nodes; rec.edge_count = edges;
+            rec.idf = (float)((double)sum * (1.0 / IDF_SCALE)) * D.penalty[i];      // count_query.rs:200 idf_sum *= nres^(-lp)
+            out[(uint64_t)q * cap + pos] = rec;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+    };
+    const uint32_t *kq = D.keys + (uint64_t)q * D.S;
+    for (uint32_t j0 = blockIdx.x * 1024; j0 < D.S; j0 += TOPN_SPLIT * 1024) {       // block-uniform trip count; four key loads in flight
+        uint32_t k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t i = j0 + u * 256 + threadIdx.x; k4[u] = i < D.S ? kq[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k4[u] && (k4[u] >> 10) >= thr22) s_idx[atomicAdd(&s_n, 1u)] = j0 + u * 256 + threadIdx.x;     // <= 1,024 per trip, drained beyond 1,024
+        __syncthreads();
+        if (s_n > 1024) drain();
+    }
+    drain();
+}
+// keys: [n_queries][S] u32 scratch; ghist: [n_queries][2048], zero on entry and left zero; q_rows: device [n_queries + 1] row ranges
+void fd_launch_cq_topn_dense(const cq_args &A, const uint64_t *q_rows, const float *penalty, uint32_t *keys, uint32_t n_queries, uint32_t top_n, uint32_t cap,
+                             void *out, void *state, uint32_t *ghist, hipStream_t st) {
+    if (!n_queries || !A.S) return;
+    topn_dense D;
+    D.keys = keys; D.penalty = penalty; D.hash_bits = A.hash_bits; D.row_meta = A.row_meta; D.q_rows = q_rows; D.words = A.words; D.S = A.S; D.first_id = A.first_id;
+    topn_state *ts = (topn_state *)state;
+    (void)hipMemsetAsync(ts, 0, (size_t)n_queries * sizeof(topn_state), st);
+    hipLaunchKernelGGL(k_cq_rows_keys, dim3((A.words + CQ_FIN_T - 1) / CQ_FIN_T, n_queries), dim3(CQ_FIN_T), 0, st, D, keys, ghist);
+    const dim3 g(TOPN_SPLIT, n_queries);
+    hipLaunchKernelGGL(k_topn_thr, dim3(n_queries), dim3(256), 0, st, (const uint64_t *)nullptr, top_n, 0, ts, ghist);
+    hipLaunchKernelGGL(k_topn_hist_dense, g, dim3(256), 0, st, D, ts, ghist);
+    hipLaunchKernelGGL(k_topn_thr, dim3(n_queries), dim3(256), 0, st, (const uint64_t *)nullptr, top_n, 1, ts, ghist);
+    hipLaunchKernelGGL(k_topn_emit_dense, g, dim3(256), 0, st, D, cap, ts, (fd_count_rec_dev *)out);
+}
+
+// The selection straight from the dense [queries][S] accumulators of k_cq_rows_finalize (packed form) — the path of ONE query with
+// thousands of rows, whose finalize runs in row slices (whole-structure mode): no flag scan, no compaction of every touched
 // structure, two synchronisations fewer — the survivors' records are built at emit time.  Fewer touched structures than top_n: the
 // threshold search ends in bin 0 and everything with a count is emitted.
-struct topn_dense { const unsigned long long *acc; const float *penalty; const uint32_t *node_cnt, *edge_cnt; uint32_t S, first_id; };
-__device__ __forceinline__ bool topn_dense_key(const topn_dense &D, uint32_t q, uint32_t nid, uint32_t *key, float *idf, uint32_t *cnt) {
+struct topn_acc { const unsigned long long *acc; const float *penalty; const uint32_t *node_cnt, *edge_cnt; uint32_t S, first_id; };
+__device__ __forceinline__ bool topn_acc_key(const topn_acc &D, uint32_t q, uint32_t nid, uint32_t *key, float *idf, uint32_t *cnt) {
     const unsigned long long a = D.acc[(uint64_t)q * D.S + nid];
     *cnt = (uint32_t)(a >> CQ_CNT_SHIFT);
     if (!*cnt) return false;
@@ -580,7 +745,7 @@ __device__ __forceinline__ bool topn_dense_key(const topn_dense &D, uint32_t q, 
     *key = idf_order_key(*idf);
     return true;
 }
-__global__ __launch_bounds__(256) void k_topn_hist_dense(topn_dense D, int level, const topn_state *__restrict__ st, uint32_t *__restrict__ ghist) {
+__global__ __launch_bounds__(256) void k_topn_hist_acc(topn_acc D, int level, const topn_state *__restrict__ st, uint32_t *__restrict__ ghist) {
     __shared__ uint32_t hist[TOPN_BINS];
     const uint32_t q = blockIdx.y;
     for (int k = threadIdx.x; k < TOPN_BINS; k += 256) hist[k] = 0;
@@ -588,21 +753,21 @@ __global__ __launch_bounds__(256) void k_topn_hist_dense(topn_dense D, int level
     const uint32_t b1 = level ? st[q].thr_bin : 0u;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < D.S; i += TOPN_SPLIT * 256) {
         uint32_t key, cnt; float idf;
-        if (!topn_dense_key(D, q, i, &key, &idf, &cnt)) continue;
+        if (!topn_acc_key(D, q, i, &key, &idf, &cnt)) continue;
         if (!level) atomicAdd(&hist[key >> 21], 1u);
         else if ((key >> 21) == b1) atomicAdd(&hist[(key >> 10) & (TOPN_BINS - 1)], 1u);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < TOPN_BINS; k += 256) if (hist[k]) atomicAdd(&ghist[(uint64_t)q * TOPN_BINS + k], hist[k]);
 }
-__global__ __launch_bounds__(256) void k_topn_emit_dense(topn_dense D, uint32_t cap, topn_state *__restrict__ st, fd_count_rec_dev *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_topn_emit_acc(topn_acc D, uint32_t cap, topn_state *__restrict__ st, fd_count_rec_dev *__restrict__ out) {
     const uint32_t q = blockIdx.y;
     const uint32_t thr22 = st[q].thr22;
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i0 = blockIdx.x * 256; i0 < D.S; i0 += TOPN_SPLIT * 256) {       // wave-uniform trip count: one atomic per wavefront and step
         const uint32_t i = i0 + threadIdx.x;
         uint32_t key = 0, cnt = 0; float idf = 0.0f;
-        const bool keep = i < D.S && topn_dense_key(D, q, i, &key, &idf, &cnt) && (key >> 10) >= thr22;
+        const bool keep = i < D.S && topn_acc_key(D, q, i, &key, &idf, &cnt) && (key >> 10) >= thr22;
         const uint64_t m = __ballot(keep);
         if (!m) continue;
         uint32_t base = 0;
@@ -617,19 +782,19 @@ __global__ __launch_bounds__(256) void k_topn_emit_dense(topn_dense D, uint32_t 
         }
     }
 }
-void fd_launch_cq_topn_dense(const cq_args &A, const float *penalty, const uint32_t *node_cnt, const uint32_t *edge_cnt, uint32_t n_queries, uint32_t top_n,
+void fd_launch_cq_topn_acc(const cq_args &A, const float *penalty, const uint32_t *node_cnt, const uint32_t *edge_cnt, uint32_t n_queries, uint32_t top_n,
                              uint32_t cap, void *out, void *state, uint32_t *ghist, hipStream_t st) {
     if (!n_queries) return;
-    topn_dense D;
+    topn_acc D;
     D.acc = A.idf; D.penalty = penalty; D.node_cnt = node_cnt; D.edge_cnt = edge_cnt; D.S = A.S; D.first_id = A.first_id;
     topn_state *ts = (topn_state *)state;
     (void)hipMemsetAsync(ts, 0, (size_t)n_queries * sizeof(topn_state), st);
     const dim3 g(TOPN_SPLIT, n_queries);
-    hipLaunchKernelGGL(k_topn_hist_dense, g, dim3(256), 0, st, D, 0, ts, ghist);
+    hipLaunchKernelGGL(k_topn_hist_acc, g, dim3(256), 0, st, D, 0, ts, ghist);
     hipLaunchKernelGGL(k_topn_thr, dim3(n_queries), dim3(256), 0, st, (const uint64_t *)nullptr, top_n, 0, ts, ghist);
-    hipLaunchKernelGGL(k_topn_hist_dense, g, dim3(256), 0, st, D, 1, ts, ghist);
+    hipLaunchKernelGGL(k_topn_hist_acc, g, dim3(256), 0, st, D, 1, ts, ghist);
     hipLaunchKernelGGL(k_topn_thr, dim3(n_queries), dim3(256), 0, st, (const uint64_t *)nullptr, top_n, 1, ts, ghist);
-    hipLaunchKernelGGL(k_topn_emit_dense, g, dim3(256), 0, st, D, cap, ts, (fd_count_rec_dev *)out);
+    hipLaunchKernelGGL(k_topn_emit_acc, g, dim3(256), 0, st, D, cap, ts, (fd_count_rec_dev *)out);
 }
 
 // state: n_queries topn_state + n_queries * 2048 u32 (zeroed once by the caller; the kernels leave the table zero)
