@@ -575,7 +575,7 @@ void fd_launch_cq_topn_sort(const void *sel, uint32_t cap, const void *state, ui
 //                      of non-negative idf) merged into the global table
 //   k_topn_hist_dense  second level over the keys (four loads in flight per thread)
 //   k_topn_emit_dense  lists the survivors in LDS, then all threads build their records at once: a survivor walks its query's rows
-//                      (~100 independent loads for a motif query) for match / edge / node counts and the exact idf sum
+//                      (tens of independent loads for a motif query) for match / edge / node counts and the exact idf sum
 // Fewer touched structures than top_n: the threshold search ends in bin 0 and everything touched is emitted.
 struct topn_dense {
     const uint32_t *keys; const float *penalty; const uint32_t *hash_bits; const unsigned long long *row_meta; const uint64_t *q_rows;
