@@ -9,7 +9,7 @@ the GLOBAL ranking are retrieved on the rank that owns them (pair scan + compone
 all-gathered.  queries/s = Q / wall time of the loop (max over ranks).
 
 Roofline: B_q = sum of posting bytes of the query's hashes + 8 T (touched structures) + (nodes + edges) S / 8,
-over the HIP-event time of the scoring stage (k_cq_accumulate_batch + finalize + compaction scan).
+over the HIP-event time of the scoring stage (k_cq_seg + k_cq_bounds + k_cq_rows_finalize + compaction scan).
 cpu_baseline: supplied by bench.py as a callback (the product package never touches oracle/)."""
 from __future__ import annotations
 
@@ -225,11 +225,11 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     cand_res = int(sum(int(nres[c].sum()) for c in cl))
     t_match = st_match.get("match_pairs", 0.0)
     roofline = {
-        "bound": "hbm", "kernel": "cq_batch (k_cq_accumulate_batch + finalize + compaction scan)", "queries_per_launch": len(ks),
+        "bound": "hbm", "kernel": "cq_batch (k_cq_seg + k_cq_bounds + k_cq_rows_finalize + compaction scan)", "queries_per_launch": len(ks),
         "algorithmic_bytes_per_launch": b_q, "posting_bytes": post_bytes, "touched_structures": touched, "occupancy_rows": n_rows,
         "avg_ms": t_score, "achieved": b_q / (t_score * 1e-3) / 1e9 if t_score > 0 else None, "peak": hbm_peak_gbs, "unit": "GB/s",
         "frac": b_q / (t_score * 1e-3) / 1e9 / hbm_peak_gbs if t_score > 0 else None, "traffic": None,
-        "note": "latency / atomic bound by construction: ~%d KB of postings per query against a %d-structure shard" % (post_bytes // max(len(ks), 1) // 1024, S),
+        "note": "latency bound by construction: ~%d KB of postings per query in 2 KB segments against a %d-structure shard" % (post_bytes // max(len(ks), 1) // 1024, S),
         "match_pairs": {"algorithmic_bytes_per_launch": 37 * cand_res + 16 * len(marr), "candidates": int(sum(len(c) for c in cl)), "avg_ms": t_match,
                         "achieved": (37 * cand_res + 16 * len(marr)) / (t_match * 1e-3) / 1e9 if t_match > 0 else None, "unit": "GB/s",
                         "note": "pair scan of the top %d candidates of %d queries; VALU-bound like the index build's pair kernel" % (match_top, len(ks))},
