@@ -23,10 +23,16 @@ __device__ __forceinline__ bool hash_in_set(const uint32_t *__restrict__ h, uint
     return lo < n && h[lo] == x;
 }
 
+// the slice of the concatenated query tables a work item scans against (its query's hashes, observed-distance lists, prefilter sets)
+struct mp_sel {
+    const uint32_t *q_hashes; uint32_t n_hashes;
+    const uint32_t *aad_start; const float *aad_dist; const uint32_t *aad_qi; uint32_t n_aad;
+    uint32_t aa1_mask, aa2_mask; int use_prefilter; float ca_window;
+};
 // descriptor + hash + output of one surviving (i, j) per lane (full-wave drains of the compaction queue: executed
 // divergently per survivor this part — ~3000 instructions with the exact libm chain — was 95 % of the kernel time)
 template <bool EMIT>
-__device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q, uint32_t n, uint32_t slot, uint32_t r0, uint32_t r1, uint32_t i0,
+__device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, const uint32_t *q, uint32_t n, uint32_t slot, uint32_t r0, uint32_t r1, uint32_t i0,
                                             const uint32_t *st_tab, const float *dist_tab, const uint32_t *tab) {
     const uint32_t lane = threadIdx.x;
     const bool on = lane < n;
@@ -45,13 +51,13 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
         key = (aai & 31u) * 32u + (aaj & 31u);   // queued pairs have aa < 32
         e_lo = st_tab[key]; e_hi = st_tab[key + 1];
         if (A.mode & 2u)      // the observed-distance window only feeds the candidate pairs: a found-only scan (first pass of a large query) skips it
-            for (uint32_t e = e_lo; e < e_hi; ++e) n_win += (fd_fabsf(d - dist_tab[e]) < A.ca_window) ? 1u : 0u;
+            for (uint32_t e = e_lo; e < e_hi; ++e) n_win += (fd_fabsf(d - dist_tab[e]) < Sx.ca_window) ? 1u : 0u;
         if (fd_own_descriptor(A.C.q.type)) {
             // encodings with their own descriptor: the pair may still have no feature (CB / point-pair distance, chain ends)
             float f9[FD_NFEAT];
             if (fd_feature_other(A.C.q.type, A.B, r0, r1, i, j, A.cutoff, f9)) {
                 h = fd_hash_other(A.C.q.type, f9, A.C.q);
-                hitmask = ((A.mode & 1u) && hash_in_set(A.q_hashes, A.n_hashes, h)) ? 1u : 0u;
+                hitmask = ((A.mode & 1u) && hash_in_set(Sx.q_hashes, Sx.n_hashes, h)) ? 1u : 0u;
             } else {
                 n_win = 0;
             }
@@ -61,7 +67,7 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
             fd_frame Fj = fd_make_frame(fd_load3(A.B.n_xyz, j), caj, fd_load3(A.B.cb_xyz, j));
             uint32_t h_ji;
             fd_pair_both_tab(Fi, Fj, aai, aaj, A.C.q, tab, &h, &h_ji);
-            hitmask = ((A.mode & 1u) && hash_in_set(A.q_hashes, A.n_hashes, h)) ? 1u : 0u;
+            hitmask = ((A.mode & 1u) && hash_in_set(Sx.q_hashes, Sx.n_hashes, h)) ? 1u : 0u;
         } else {
             // one descriptor, one hash per bin pair (--multiple-bins: a found triple for every bin pair whose hash the query holds,
             // retrieve.rs:124-131)
@@ -69,7 +75,7 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
             for (uint32_t k = 0; k < A.n_cfg; ++k) {
                 const uint32_t hk = fd_hash_enc(aai, aaj, feat, A.qk[k]);
                 if (k == 0) h = hk;
-                if ((A.mode & 1u) && hash_in_set(A.q_hashes, A.n_hashes, hk)) hitmask |= 1u << k;
+                if ((A.mode & 1u) && hash_in_set(Sx.q_hashes, Sx.n_hashes, hk)) hitmask |= 1u << k;
             }
         }
         hit = hitmask != 0;
@@ -105,8 +111,8 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
     // EMIT with capacities: records beyond the caller's buffers are counted but not written (the caller grows and reruns)
     if (EMIT && on && cpos + n_win <= A.cap_cands && (!hit || fpos + n_hit <= A.cap_found)) {
         for (uint32_t e = e_lo; e < e_hi; ++e) {
-            if (fd_fabsf(d - dist_tab[e]) < A.ca_window) {
-                fd_cand_rec c; c.cand = slot; c.qi = A.aad_qi[e]; c.i = i - r0; c.j = j - r0;
+            if (fd_fabsf(d - dist_tab[e]) < Sx.ca_window) {
+                fd_cand_rec c; c.cand = slot; c.qi = Sx.aad_qi[e]; c.i = i - r0; c.j = j - r0;
                 A.cands[cpos++] = c;
             }
         }
@@ -125,14 +131,19 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const uint32_t *q,
 #define MP_AAD_LDS 1024
 template <bool EMIT>
 __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
-    // many queries per launch: this work item's query selects its slice of the concatenated tables (wave-uniform loads)
-    mp_args A = A_in;
+    // many queries per launch: this work item's query selects its slice of the concatenated tables (wave-uniform loads).  The
+    // selection lives in its own few scalars: a modified COPY of the argument block — which holds arrays indexed at run time — is a
+    // 480-byte private-memory object per lane, written by every wavefront at start (100 MB per launch) and read back field by field.
+    const mp_args &A = A_in;
+    mp_sel Sx;
+    Sx.q_hashes = A_in.q_hashes; Sx.n_hashes = A_in.n_hashes; Sx.aad_start = A_in.aad_start; Sx.aad_dist = A_in.aad_dist; Sx.aad_qi = A_in.aad_qi;
+    Sx.n_aad = A_in.n_aad; Sx.aa1_mask = A_in.aa1_mask; Sx.aa2_mask = A_in.aa2_mask; Sx.use_prefilter = A_in.use_prefilter; Sx.ca_window = A_in.ca_window;
     if (blockIdx.x < A_in.n_work) {
         const uint32_t tq = A_in.wi_query[blockIdx.x];
         const mp_query_dev Q = A_in.qtab[tq];
-        A.q_hashes = A_in.q_hashes + Q.qh_off; A.n_hashes = Q.n_hashes;
-        A.aad_start = A_in.aad_start + 1025u * tq; A.aad_dist = A_in.aad_dist + Q.aad_off; A.aad_qi = A_in.aad_qi + Q.aad_off; A.n_aad = Q.n_aad;
-        A.aa1_mask = Q.aa1_mask; A.aa2_mask = Q.aa2_mask; A.use_prefilter = Q.use_prefilter; A.ca_window = Q.ca_window;
+        Sx.q_hashes = A_in.q_hashes + Q.qh_off; Sx.n_hashes = Q.n_hashes;
+        Sx.aad_start = A_in.aad_start + 1025u * tq; Sx.aad_dist = A_in.aad_dist + Q.aad_off; Sx.aad_qi = A_in.aad_qi + Q.aad_off; Sx.n_aad = Q.n_aad;
+        Sx.aa1_mask = Q.aa1_mask; Sx.aa2_mask = Q.aa2_mask; Sx.use_prefilter = Q.use_prefilter; Sx.ca_window = Q.ca_window;
     }
     __shared__ uint32_t q[2 * FD_WAVE];
     __shared__ uint32_t tab[32];
@@ -143,27 +154,27 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     // the query's observed (aa_i, aa_j) -> CA distance lists (aa_dist_map, controller/query.rs), grouped by residue-type pair:
     // aad_start[aa_i * 32 + aa_j] .. [+1] indexes the distance / query-residue arrays (host-sorted, stable).  Start table and,
     // for motif-sized queries, the distances live in LDS: per-pair global reads made the scan latency-bound.
-    const bool staged = A.n_aad <= MP_AAD_LDS;
+    const bool staged = Sx.n_aad <= MP_AAD_LDS;
     if (threadIdx.x == 0 && A.C.use_tab) fd_fill_bintab(tab);
-    for (uint32_t e = threadIdx.x; e < 1025; e += FD_WAVE) s_start[e] = A.aad_start[e];
+    for (uint32_t e = threadIdx.x; e < 1025; e += FD_WAVE) s_start[e] = Sx.aad_start[e];
     if (staged)
-        for (uint32_t e = threadIdx.x; e < A.n_aad; e += FD_WAVE) s_d_buf[e] = A.aad_dist[e];
+        for (uint32_t e = threadIdx.x; e < Sx.n_aad; e += FD_WAVE) s_d_buf[e] = Sx.aad_dist[e];
     __syncthreads();
-    const float *dist_tab = staged ? s_d_buf : A.aad_dist;
+    const float *dist_tab = staged ? s_d_buf : Sx.aad_dist;
     const uint32_t slot = A.wi_cand[w];
     const uint32_t s = A.cand[slot];
     const uint32_t r0 = A.B.res_off[s], r1 = A.B.res_off[s + 1];
     const uint32_t lane = threadIdx.x;
     // prefilter sets (retrieve.rs:563-602); an empty set on either side switches to the full scan
     bool full = true;
-    if (A.use_prefilter) {
+    if (Sx.use_prefilter) {
         uint64_t any1 = 0, any2 = 0;
         for (uint32_t r = r0 + lane; r < r1 + lane; r += FD_WAVE) {
             bool in = r < r1;
             uint32_t a = in ? A.B.aa[r] : 255u;
             bool stdn = in && a < 20u && (A.resname_std == nullptr || A.resname_std[r]);
-            any1 |= __ballot(stdn && ((A.aa1_mask >> a) & 1u));
-            any2 |= __ballot(stdn && ((A.aa2_mask >> a) & 1u));
+            any1 |= __ballot(stdn && ((Sx.aa1_mask >> a) & 1u));
+            any2 |= __ballot(stdn && ((Sx.aa2_mask >> a) & 1u));
         }
         full = !(any1 && any2);
     }
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     const bool std_i = aai < 20u && (A.resname_std == nullptr || A.resname_std[i]);
     // get_single_feature (controller/feature.rs:11-24, 84-99) rejects unknown residues / missing CB
     const bool tert = A.C.q.type == FD_HASH_TERTIARY;     // TertiaryInteraction needs no CB (feature.rs:113-160)
-    const bool act = in_i && (full || (std_i && ((A.aa1_mask >> aai) & 1u))) && aai != 255u && (tert || A.B.hash_ok[i]);
+    const bool act = in_i && (full || (std_i && ((Sx.aa1_mask >> aai) & 1u))) && aai != 255u && (tert || A.B.hash_ok[i]);
     fd_v3 cai = {0.f, 0.f, 0.f};
     if (in_i) cai = fd_load3(A.B.ca_xyz, i);
     // partner residue types this lane's residue type has any observation with (aa < 32): one register test per pair
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
         fd_v3 cj = {0.f, 0.f, 0.f};
         if (jin) cj = fd_load3(A.B.ca_xyz, jl);
         bool okj = jin && aaj_l != 255u && (tert || A.B.hash_ok[jl]);
-        if (!full) okj = okj && aaj_l < 20u && (A.resname_std == nullptr || A.resname_std[jl]) && ((A.aa2_mask >> aaj_l) & 1u);
+        if (!full) okj = okj && aaj_l < 20u && (A.resname_std == nullptr || A.resname_std[jl]) && ((Sx.aa2_mask >> aaj_l) & 1u);
         if (A.cj_mask && okj) { const uint32_t bit = A.mask_off[slot] + (jl - r0); okj = (A.cj_mask[bit >> 5] >> (bit & 31u)) & 1u; }
         const uint64_t okm = __ballot(okj);
         const uint32_t nj = (j_hi - jb) < FD_WAVE ? (j_hi - jb) : FD_WAVE;
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                         // branch-free over the pair's own list: a short-circuit chain costs one LDS round trip per entry
                         const uint32_t e_lo = s_start[aai * 32u + aaj], e_hi = s_start[aai * 32u + aaj + 1];
                         uint32_t any = 0;
-                        for (uint32_t e = e_lo; e < e_hi; ++e) any |= (uint32_t)(fd_fabsf(d - dist_tab[e]) < A.ca_window);
+                        for (uint32_t e = e_lo; e < e_hi; ++e) any |= (uint32_t)(fd_fabsf(d - dist_tab[e]) < Sx.ca_window);
                         pass = any != 0;
                     }
                 }
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                 __syncthreads();
                 uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
                 qn -= n;
-                match_drain<EMIT>(A, q + qn, n, slot, r0, r1, i0, s_start, dist_tab, tab);
+                match_drain<EMIT>(A, Sx, q + qn, n, slot, r0, r1, i0, s_start, dist_tab, tab);
                 __syncthreads();
             }
         }
