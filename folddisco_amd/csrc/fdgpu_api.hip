@@ -1406,7 +1406,9 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         if (cand[k] >= db->n_struct) FAIL(c, FDGPU_EINVAL, "match_pairs: candidate id outside the batch");
         n_tiles += (db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]] + FD_WAVE - 1) / FD_WAVE;
     }
-    const uint32_t j_span = n_tiles && n_tiles < 1024 ? (n_tiles < 256 ? 64u : 128u) : 0u;
+    // many candidates (a batch of motif queries): spans of 256 partners cap the longest work items — the launch ends with its slowest
+    // wavefront (32 queries x 32 candidates: 218 -> 126 us; 128 and 512 measured 148 and 156)
+    const uint32_t j_span = !n_tiles ? 0u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : 256u;
     std::vector<uint32_t> wc, wi, wq, wj;
     for (uint64_t t = 0; t < n_queries; ++t)
         for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) {
