@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-query", action="store_true")
     ap.add_argument("--no-export", action="store_true")
+    ap.add_argument("--no-replicas", action="store_true", help="skip the query-replica leg of --gpus N > 1 (index replicated, queries sharded)")
     return ap.parse_args()
 
 
@@ -302,6 +303,30 @@ def main():
         except Exception as e:  # the index-build line must still be printed
             import traceback
             query = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
+        # ---- query replicas (SURVEY §8e last row): every rank builds the WHOLE index (26 GB of 288) and the queries are dealt to the ranks
+        if world > 1 and not args.no_replicas and query is not None and "error" not in query:
+            try:
+                ix = None; db = None; d_all = None
+                torch.cuda.empty_cache()
+                fblocks = [synth.generate(min(GEN_BLOCK, S_total - g0), seed=args.seed + 1000 * (g0 // GEN_BLOCK), device=dev) for g0 in range(0, S_total, GEN_BLOCK)]
+                parts, fid = [], 0
+                for fb in fblocks:
+                    wb = wrap(fb)
+                    parts.append(fd.FolddiscoIndex.build(ctx, wb, first_id=fid))
+                    fid += wb.n_struct
+                ixf = parts[0] if len(parts) == 1 else fd.FolddiscoIndexSet(parts).merge()
+                parts = None
+                d_full = {k: (torch.cat([b[k] for b in fblocks]) if k != "res_off" else None) for k in fblocks[0]}
+                offs, base = [fblocks[0]["res_off"][:1]], 0
+                for b in fblocks:
+                    offs.append(b["res_off"][1:] + base)
+                    base += int(b["res_off"][-1].item())
+                d_full["res_off"] = torch.cat(offs).contiguous()
+                fblocks = None
+                query["replicas"] = querybench.run_replicas(ctx, wrap(d_full), ixf, d_full, S_total, world, rank, dist, dev, n_queries=args.queries)
+            except Exception as e:
+                import traceback
+                query["replicas"] = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
 
     if rank == 0:
         cpu = None

@@ -183,6 +183,17 @@ SYMBOLS = [
     ("fdgpu_allreduce_lengths", C.c_int, [VP, VP, u64p, C.c_uint64]),
     ("fdgpu_sharded_count_query", C.c_int, [VP, VP, VP, C.c_uint64, u64p, u32p, u32p, u32p, f32p, C.c_uint64, C.c_uint32,
                                             C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
+    ("fdgpu_comm_stats", C.c_int, [VP, u64p, u64p]),
+    ("fdgpu_sharded_count_query_maps", C.c_int, [VP, VP, VP, C.c_uint64, C.c_void_p, f32p, C.c_uint64, C.c_uint32,
+                                                 C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
+    ("fdgpu_sharded_retrieve", C.c_int, [VP, VP, VP, C.c_uint64, u8p, C.c_uint64, u32p, u64p, C.POINTER(C.POINTER(QueryMap)), VP, u32p,
+                                         C.POINTER(HashParams), C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(MatchRec)), C.POINTER(u64p),
+                                         C.POINTER(C.POINTER(C.c_int32)), C.POINTER(u64p)]),
+    ("fdgpu_query_maps_lengths", C.c_int, [VP, VP, C.c_uint64, C.c_void_p, u64p]),
+    ("fdgpu_count_query_maps_top_global", C.c_int, [VP, VP, C.c_uint64, C.c_void_p, u64p, f32p, C.c_float, C.c_uint32,
+                                                    C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
+    ("fdgpu_comm_message_bytes", C.c_uint64, [C.c_uint64, C.c_uint32]),
+    ("fdgpu_debug_merge_gathered", C.c_int, [VP, C.c_uint32, C.c_uint64, C.c_uint32, u8p, C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
     ("fdgpu_debug_libm", C.c_int, [VP, C.c_int, f32p, f32p, f32p, C.c_uint64]),
 ]
 

@@ -1,14 +1,21 @@
 // fd_comm.hip — the multi-GPU exchange steps of the query path behind the C ABI: one process per GPU, RCCL over xGMI.
 //
-// The index is sharded by structure id, so scoring is local; two exchanges remain and both live here:
-//   fdgpu_allreduce_lengths       posting lengths of the query's hashes summed over the shards — idf = log2(S / len) needs the
-//                                 length over the WHOLE database (controller/query.rs:17-32, count_query.rs:130)
-//   fdgpu_sharded_count_query     local count_query (top-N preselected on the device) -> ncclAllGather of the candidate records
-//                                 (sizes first, then one padded payload, both from / into device memory) -> global ranking
-//                                 (idf descending, nid ascending, truncate: query_pdb.rs:404-411) on every rank
-// This is what the reference's query workflow would call per batch of queries (cli/workflows/query_pdb.rs:376-452) instead of the
-// single-index count_query.  RCCL is bound at run time (dlopen of librccl.so.1 — the copy torch already loaded when there is one), so
-// libfdgpu.so itself has no link-time dependency on it; without RCCL the comm entry points fail with FDGPU_EHIP and say so.
+// The index and the coordinates are sharded by structure id, so scoring and matching are local; three exchanges remain and all live here:
+//   fdgpu_allreduce_lengths        posting lengths of the query's hashes summed over the shards — idf = log2(S / len) needs the length over
+//                                  the WHOLE database (controller/query.rs:17-32, count_query.rs:130); ncclAllReduce on a device buffer
+//   fdgpu_sharded_count_query[_maps]  local count_query with the candidate selection on the device -> ONE ncclAllGather of a fixed-stride
+//                                  message per rank (selection state + ranked records, device to device, nothing staged on the host) ->
+//                                  global selection and ranking on the device (k_comm_plan / k_comm_pack + the radix select and bitonic
+//                                  sort of k_query.hip: idf descending, nid ascending, truncate — query_pdb.rs:404-411) -> one copy to the
+//                                  host, identical on every rank.  Calls the device selection does not serve (top_n = 0: every touched
+//                                  structure; top_n > 3072) exchange variable-length lists: counts first, then one padded payload.
+//   fdgpu_sharded_retrieve         every candidate of the global ranking is matched on the rank that owns it (query_pdb.rs:415-452 per
+//                                  shard), the fixed-size match records and residue lists are all-gathered and merged in candidate order
+// Nothing is short-cut for a world of one: the collectives run (a 1-rank all-gather is a device copy inside RCCL), so a single-GPU test
+// executes every line the N-rank path executes.  A rank whose local step fails still takes part in every collective of the call with an
+// error status in its message, and all ranks return the error together — nobody is left waiting inside ncclAllGather.
+// RCCL is bound at run time (dlopen of librccl.so.1 — the copy torch already loaded when there is one), so libfdgpu.so itself has no
+// link-time dependency on it; without RCCL the comm entry points fail with FDGPU_EHIP and say so.
 #include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
@@ -48,6 +55,12 @@ rccl_api &rccl() {
     }();
     return A;
 }
+
+// device scratch of the global merge; owned by a communicator, or by a debug call
+struct merge_bufs {
+    fd_devbuf pack, off, sel, state, fin, flag;
+    void release() { pack.release(); off.release(); sel.release(); state.release(); fin.release(); flag.release(); }
+};
 }  // namespace
 
 struct fdgpu_comm {
@@ -55,6 +68,8 @@ struct fdgpu_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     fd_devbuf send, recv;
+    merge_bufs mb;
+    uint64_t n_allreduce = 0, n_allgather = 0;      // collectives issued so far (fdgpu_comm_stats: tests check that a world of one runs them)
 };
 
 #define FAIL_(ctx, code, msg) do { (ctx)->err = (msg); return (code); } while (0)
@@ -97,20 +112,40 @@ extern "C" void fdgpu_comm_destroy(fdgpu_comm *m) {
     if (!m) return;
     FD_LOCK(m->ctx);
     if (m->comm && rccl().ok) (void)rccl().CommDestroy(m->comm);
-    m->send.release(); m->recv.release();
+    m->send.release(); m->recv.release(); m->mb.release();
     delete m;
 }
 extern "C" int fdgpu_comm_rank(const fdgpu_comm *m) { return m ? m->rank : -1; }
 extern "C" int fdgpu_comm_world(const fdgpu_comm *m) { return m ? m->world : 0; }
+extern "C" int fdgpu_comm_stats(const fdgpu_comm *m, uint64_t *n_allreduce, uint64_t *n_allgather) {
+    if (!m) return FDGPU_EINVAL;
+    if (n_allreduce) *n_allreduce = m->n_allreduce;
+    if (n_allgather) *n_allgather = m->n_allgather;
+    return FDGPU_OK;
+}
+
+// in-place sum over the ranks of n u64 on the device (stream-ordered, no synchronisation)
+static int allreduce_dev(fdgpu_ctx *c, fdgpu_comm *m, uint64_t *dev, uint64_t n) {
+    if (!n) return FDGPU_OK;
+    NCHK(c, rccl().AllReduce(dev, dev, n, ncclUint64, ncclSum, m->comm, c->stream));
+    ++m->n_allreduce;
+    return FDGPU_OK;
+}
+static int allgather_dev(fdgpu_ctx *c, fdgpu_comm *m, const void *send, void *recv, size_t bytes) {
+    NCHK(c, rccl().AllGather(send, recv, bytes, ncclUint8, m->comm, c->stream));
+    ++m->n_allgather;
+    return FDGPU_OK;
+}
 
 // lengths[k] <- sum over ranks (in place, host array)
 extern "C" int fdgpu_allreduce_lengths(fdgpu_ctx *c, fdgpu_comm *m, uint64_t *lengths, uint64_t n) { FD_LOCK(c);
     if (!c || !m || (n && !lengths)) return FDGPU_EINVAL;
-    if (!n || m->world == 1) return FDGPU_OK;
+    if (!n) return FDGPU_OK;
     hipStream_t st = c->stream;
     HCHK(c, m->send.ensure(n * 8));
     HCHK(c, hipMemcpyAsync(m->send.p, lengths, n * 8, hipMemcpyHostToDevice, st));
-    NCHK(c, rccl().AllReduce(m->send.p, m->send.p, n, ncclUint64, ncclSum, m->comm, st));
+    int rc = allreduce_dev(c, m, m->send.as<uint64_t>(), n);
+    if (rc) return rc;
     HCHK(c, hipMemcpyAsync(lengths, m->send.p, n * 8, hipMemcpyDeviceToHost, st));
     HCHK(c, hipStreamSynchronize(st));
     return FDGPU_OK;
@@ -124,7 +159,265 @@ inline uint64_t rank_key(const fd_count_rec &r) {   // idf descending, nid ascen
     const uint32_t ordered = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
     return ((uint64_t)(~ordered) << 32) | r.nid;
 }
+inline void rank_sort(fd_count_rec *a, fd_count_rec *b) {
+    std::sort(a, b, [](const fd_count_rec &x, const fd_count_rec &y) { return rank_key(x) < rank_key(y); });
+}
+
+// ---- the fixed-stride message of the device path ------------------------------------------------------------------------------------
+// rank r contributes, for a call with n_queries queries and a cut at top_n:
+//   comm_hdr                      status (0 = fine, else the rank's FDGPU_E* code negated), n_queries, top_n, cap
+//   sel_state[n_queries]          the selection state k_topn_* leave behind: .count = records the rank selected for the query
+//   fd_count_rec[n_queries][top_n]  its ranked records, min(count, top_n) valid per query
+// padded to 16 bytes.  fdgpu_comm_message_bytes gives the size; tests build such messages by hand (fdgpu_debug_merge_gathered).
+struct comm_hdr { uint32_t status, n_queries, top_n, cap; };
+struct sel_state { uint32_t thr_bin, above, thr22, count; };    // = topn_state of k_query.hip
+inline size_t msg_bytes(uint64_t nq, uint32_t top_n) {
+    return (sizeof(comm_hdr) + nq * sizeof(sel_state) + nq * (size_t)top_n * sizeof(fd_count_rec) + 15) & ~(size_t)15;
+}
+__device__ __forceinline__ const sel_state *msg_state(const uint8_t *recv, uint64_t mb, uint32_t r) { return (const sel_state *)(recv + r * mb + sizeof(comm_hdr)); }
+
+// flags: 1 = a rank reported an error, 2 = a rank's selection overflowed (it should have resolved that locally), 4 = ranks disagree on the call
+__global__ __launch_bounds__(256) void k_comm_plan(const uint8_t *__restrict__ recv, uint32_t W, uint64_t mb, uint32_t nq, uint32_t top_n, uint64_t *__restrict__ off,
+                                                   uint32_t *__restrict__ flags) {
+    for (uint32_t r = threadIdx.x; r < W; r += 256) {
+        const comm_hdr *h = (const comm_hdr *)(recv + r * mb);
+        if (h->status) atomicOr(flags, 1u);
+        if (h->n_queries != nq || h->top_n != top_n) atomicOr(flags, 4u);
+    }
+    for (uint32_t t = threadIdx.x; t < nq; t += 256) {
+        uint64_t tot = 0;
+        for (uint32_t r = 0; r < W; ++r) {
+            const uint32_t cnt = msg_state(recv, mb, r)[t].count, cap = ((const comm_hdr *)(recv + r * mb))->cap;
+            if (cnt > cap) atomicOr(flags, 2u);
+            tot += cnt < top_n ? cnt : top_n;
+        }
+        off[t + 1] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t acc = 0;
+        off[0] = 0;
+        for (uint32_t t = 0; t < nq; ++t) { acc += off[t + 1]; off[t + 1] = acc; }
+    }
+}
+// query t's records of rank r -> packed[off[t] + (records of ranks before r)]: per query one contiguous list, ranks in order
+__global__ __launch_bounds__(128) void k_comm_pack(const uint8_t *__restrict__ recv, uint64_t mb, uint32_t nq, uint32_t top_n, const uint64_t *__restrict__ off,
+                                                   uint32_t *__restrict__ packed) {
+    const uint32_t t = blockIdx.x, r = blockIdx.y;
+    uint64_t base = off[t];
+    for (uint32_t q = 0; q < r; ++q) { const uint32_t c = msg_state(recv, mb, q)[t].count; base += c < top_n ? c : top_n; }
+    uint32_t cnt = msg_state(recv, mb, r)[t].count;
+    cnt = cnt < top_n ? cnt : top_n;
+    const uint32_t *src = (const uint32_t *)(recv + r * mb + sizeof(comm_hdr) + (size_t)nq * sizeof(sel_state)) + ((size_t)t * top_n) * 5;
+    uint32_t *dst = packed + base * 5;
+    for (uint32_t k = threadIdx.x; k < cnt * 5; k += 128) dst[k] = src[k];
+}
+
+// W gathered messages on the device -> per query the global ranking cut to top_n, on the host.  Everything between the gather and the one
+// copy back runs on the device.  status_out: the first non-zero status any rank reported (the call then has no result).
+int merge_gathered(fdgpu_ctx *c, merge_bufs &B, const uint8_t *recv, uint32_t W, uint64_t n_queries, uint32_t top_n, fd_count_rec **out, uint64_t **out_off) {
+    hipStream_t st = c->stream;
+    const size_t mb = msg_bytes(n_queries, top_n);
+    const uint32_t cap = top_n + 1024;
+    const size_t n_pack = std::max<size_t>((size_t)W * n_queries * top_n, 1);
+    HCHK(c, B.pack.ensure(n_pack * sizeof(fd_count_rec)));
+    HCHK(c, B.off.ensure((n_queries + 2) * 8));
+    HCHK(c, B.sel.ensure(std::max<size_t>((size_t)n_queries * cap, 1) * sizeof(fd_count_rec)));
+    HCHK(c, B.state.ensure(std::max<uint64_t>(n_queries, 1) * sizeof(sel_state)));
+    HCHK(c, B.fin.ensure(std::max<size_t>((size_t)n_queries * top_n, 1) * sizeof(fd_count_rec)));
+    HCHK(c, B.flag.ensure(64));
+    const size_t topn_bytes = std::max<uint64_t>(n_queries, 1) * 2048 * 4;      // the radix select's histogram table: zeroed when (re)allocated, left zero
+    if (c->ws[WS_CQ_TOPN].cap < topn_bytes) {
+        HCHK(c, c->ws[WS_CQ_TOPN].ensure(topn_bytes));
+        HCHK(c, hipMemsetAsync(c->ws[WS_CQ_TOPN].p, 0, c->ws[WS_CQ_TOPN].cap, st));
+    }
+    HCHK(c, hipMemsetAsync(B.flag.p, 0, 64, st));
+    std::vector<uint32_t> flags(1, 0);
+    std::vector<sel_state> state(std::max<uint64_t>(n_queries, 1));
+    std::vector<fd_count_rec> fin(std::max<size_t>((size_t)n_queries * top_n, 1));
+    if (n_queries) {
+        hipLaunchKernelGGL(k_comm_plan, dim3(1), dim3(256), 0, st, recv, W, (uint64_t)mb, (uint32_t)n_queries, top_n, B.off.as<uint64_t>(), B.flag.as<uint32_t>());
+        hipLaunchKernelGGL(k_comm_pack, dim3((unsigned)n_queries, W), dim3(128), 0, st, recv, (uint64_t)mb, (uint32_t)n_queries, top_n, B.off.as<uint64_t>(), B.pack.as<uint32_t>());
+        fd_launch_cq_topn(B.pack.p, B.off.as<uint64_t>(), (uint32_t)n_queries, top_n, cap, B.sel.p, B.state.p, c->ws[WS_CQ_TOPN].as<uint32_t>(), st);
+        fd_launch_cq_topn_sort(B.sel.p, cap, B.state.p, (uint32_t)n_queries, top_n, B.fin.p, st);
+        HCHK(c, hipGetLastError());
+        HCHK(c, hipMemcpyAsync(state.data(), B.state.p, n_queries * sizeof(sel_state), hipMemcpyDeviceToHost, st));
+        HCHK(c, hipMemcpyAsync(fin.data(), B.fin.p, (size_t)n_queries * top_n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st));
+    }
+    HCHK(c, hipMemcpyAsync(flags.data(), B.flag.p, 4, hipMemcpyDeviceToHost, st));
+    HCHK(c, hipStreamSynchronize(st));
+    if (flags[0] & 4u) FAIL_(c, FDGPU_EINVAL, "sharded query: the ranks passed different batches (n_queries / top_n differ)");
+    if (flags[0] & 3u) {
+        std::vector<comm_hdr> hd(W);
+        for (uint32_t r = 0; r < W; ++r) HCHK(c, hipMemcpy(&hd[r], recv + r * mb, sizeof(comm_hdr), hipMemcpyDeviceToHost));
+        for (uint32_t r = 0; r < W; ++r)
+            if (hd[r].status) { c->err = "sharded query: rank " + std::to_string(r) + " failed its local step (code " + std::to_string(-(int)hd[r].status) + ")"; return FDGPU_EHIP; }
+        FAIL_(c, FDGPU_EHIP, "sharded query: a rank sent an overflowed selection");
+    }
+    uint64_t *ooff = (uint64_t *)calloc(n_queries + 1, 8);
+    if (!ooff) return FDGPU_ENOMEM;
+    bool overflow = false;
+    uint64_t tot = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) { overflow = overflow || state[t].count > cap; tot += std::min<uint32_t>(state[t].count, top_n); }
+    std::vector<uint64_t> hoff;
+    std::vector<fd_count_rec> hpack;
+    if (overflow) {      // more ties at a cut-off than the selection's slots hold: those queries are ranked here from the packed lists
+        hoff.resize(n_queries + 1);
+        HCHK(c, hipMemcpy(hoff.data(), B.off.p, (n_queries + 1) * 8, hipMemcpyDeviceToHost));
+        hpack.resize(std::max<uint64_t>(hoff[n_queries], 1));
+        if (hoff[n_queries]) HCHK(c, hipMemcpy(hpack.data(), B.pack.p, hoff[n_queries] * sizeof(fd_count_rec), hipMemcpyDeviceToHost));
+        tot = 0;
+        for (uint64_t t = 0; t < n_queries; ++t) tot += std::min<uint64_t>(hoff[t + 1] - hoff[t], top_n);
+    }
+    fd_count_rec *rr = (fd_count_rec *)malloc(std::max<uint64_t>(tot, 1) * sizeof(fd_count_rec));
+    if (!rr) { free(ooff); return FDGPU_ENOMEM; }
+    uint64_t w = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        ooff[t] = w;
+        if (overflow) {
+            fd_count_rec *a = hpack.data() + hoff[t], *b = hpack.data() + hoff[t + 1];
+            rank_sort(a, b);
+            const uint64_t k = std::min<uint64_t>((uint64_t)(b - a), top_n);
+            if (k) memcpy(rr + w, a, k * sizeof(fd_count_rec));
+            w += k;
+        } else {
+            const uint64_t k = std::min<uint32_t>(state[t].count, top_n);
+            if (k) memcpy(rr + w, fin.data() + (size_t)t * top_n, k * sizeof(fd_count_rec));
+            w += k;
+        }
+    }
+    ooff[n_queries] = w;
+    *out = rr; *out_off = ooff;
+    return FDGPU_OK;
+}
+
+// variable-length lists (top_n = 0 or beyond the device selection): per-query counts + a status word first, then one padded payload
+int exchange_lists(fdgpu_ctx *c, fdgpu_comm *m, uint64_t n_queries, uint32_t top_n, int local_rc, fd_count_rec *loc, const uint64_t *loff, fd_count_rec **out,
+                   uint64_t **out_off) {
+    hipStream_t st = c->stream;
+    const int W = m->world;
+    std::vector<fd_count_rec> mine;
+    std::vector<uint64_t> cnt(n_queries + 1, 0);          // [n_queries] = status
+    cnt[n_queries] = local_rc ? (uint64_t)(uint32_t)(-local_rc) : 0;
+    if (!local_rc)
+        for (uint64_t t = 0; t < n_queries; ++t) {        // a rank never contributes more than top_n records per query
+            fd_count_rec *a = loc + loff[t], *b = loc + loff[t + 1];
+            rank_sort(a, b);
+            const uint64_t keep = top_n ? std::min<uint64_t>(top_n, (uint64_t)(b - a)) : (uint64_t)(b - a);
+            mine.insert(mine.end(), a, a + keep);
+            cnt[t] = keep;
+        }
+    const size_t cb = (n_queries + 1) * 8;
+    std::vector<uint64_t> all_cnt((size_t)W * (n_queries + 1));
+    HCHK(c, m->send.ensure(cb));
+    HCHK(c, m->recv.ensure(cb * W));
+    HCHK(c, hipMemcpyAsync(m->send.p, cnt.data(), cb, hipMemcpyHostToDevice, st));
+    int rc = allgather_dev(c, m, m->send.p, m->recv.p, cb);
+    if (rc) return rc;
+    HCHK(c, hipMemcpyAsync(all_cnt.data(), m->recv.p, cb * W, hipMemcpyDeviceToHost, st));
+    HCHK(c, hipStreamSynchronize(st));
+    for (int r = 0; r < W; ++r)
+        if (all_cnt[(size_t)r * (n_queries + 1) + n_queries]) {      // every rank sees the same statuses: all return here, none enters the second gather
+            if (r != m->rank || !local_rc) c->err = "sharded query: rank " + std::to_string(r) + " failed its local step (code -" + std::to_string(all_cnt[(size_t)r * (n_queries + 1) + n_queries]) + ")";
+            return local_rc ? local_rc : FDGPU_EHIP;
+        }
+    uint64_t stride = 1;
+    for (int r = 0; r < W; ++r) {
+        uint64_t tot = 0;
+        for (uint64_t t = 0; t < n_queries; ++t) tot += all_cnt[(size_t)r * (n_queries + 1) + t];
+        stride = std::max(stride, tot);
+    }
+    const size_t bytes = stride * sizeof(fd_count_rec);
+    HCHK(c, m->send.ensure(bytes));
+    HCHK(c, m->recv.ensure(bytes * W));
+    if (!mine.empty()) HCHK(c, hipMemcpyAsync(m->send.p, mine.data(), mine.size() * sizeof(fd_count_rec), hipMemcpyHostToDevice, st));
+    if ((rc = allgather_dev(c, m, m->send.p, m->recv.p, bytes))) return rc;
+    std::vector<fd_count_rec> all(stride * W);
+    HCHK(c, hipMemcpyAsync(all.data(), m->recv.p, bytes * W, hipMemcpyDeviceToHost, st));
+    HCHK(c, hipStreamSynchronize(st));
+    uint64_t *ooff = (uint64_t *)calloc(n_queries + 1, 8);
+    if (!ooff) return FDGPU_ENOMEM;
+    std::vector<fd_count_rec> res;
+    std::vector<uint64_t> base((size_t)W, 0);
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        const size_t s0 = res.size();
+        for (int r = 0; r < W; ++r) {
+            const uint64_t k = all_cnt[(size_t)r * (n_queries + 1) + t];
+            const fd_count_rec *src = all.data() + (size_t)r * stride + base[r];
+            res.insert(res.end(), src, src + k);
+            base[r] += k;
+        }
+        rank_sort(res.data() + s0, res.data() + res.size());
+        if (top_n && res.size() - s0 > top_n) res.resize(s0 + top_n);
+        ooff[t + 1] = res.size();
+    }
+    fd_count_rec *o = (fd_count_rec *)malloc(std::max<size_t>(res.size(), 1) * sizeof(fd_count_rec));
+    if (!o) { free(ooff); return FDGPU_ENOMEM; }
+    if (!res.empty()) memcpy(o, res.data(), res.size() * sizeof(fd_count_rec));
+    *out = o; *out_off = ooff;
+    return FDGPU_OK;
+}
+
+inline bool device_path(uint32_t top_n) { return top_n > 0 && top_n + 1024 <= 4096; }      // the cut k_topn_sort serves (fdgpu_api.hip: dense_topn)
+
+// the exchange after the local scoring: local_rc / dev / (loc, loff) describe what this rank has
+int exchange(fdgpu_ctx *c, fdgpu_comm *m, uint64_t n_queries, uint32_t top_n, int local_rc, const fd_cq_dev_out &dev, fd_count_rec *loc, const uint64_t *loff,
+             fd_count_rec **out, uint64_t **out_off) {
+    if (!device_path(top_n)) return exchange_lists(c, m, n_queries, top_n, local_rc, loc, loff, out, out_off);
+    hipStream_t st = c->stream;
+    const int W = m->world;
+    const size_t mb = msg_bytes(n_queries, top_n);
+    HCHK(c, m->send.ensure(mb));
+    HCHK(c, m->recv.ensure(mb * W));
+    uint8_t *snd = m->send.as<uint8_t>();
+    comm_hdr hd{local_rc ? (uint32_t)(-local_rc) : 0u, (uint32_t)n_queries, top_n, top_n + 1024};
+    std::vector<uint8_t> host_msg;
+    if (!local_rc && dev.got) {       // the selection state and the ranked records go from where the kernels left them into the message
+        HCHK(c, hipMemcpyAsync(snd, &hd, sizeof hd, hipMemcpyHostToDevice, st));
+        if (n_queries) {
+            HCHK(c, hipMemcpyAsync(snd + sizeof hd, dev.state, n_queries * sizeof(sel_state), hipMemcpyDeviceToDevice, st));
+            HCHK(c, hipMemcpyAsync(snd + sizeof hd + n_queries * sizeof(sel_state), dev.recs, (size_t)n_queries * top_n * sizeof(fd_count_rec), hipMemcpyDeviceToDevice, st));
+        }
+    } else {                          // a call the device selection did not serve on this rank (empty shard, wide accumulators, overflow), or an error
+        host_msg.assign(mb, 0);
+        memcpy(host_msg.data(), &hd, sizeof hd);
+        if (!local_rc && loc)
+            for (uint64_t t = 0; t < n_queries; ++t) {
+                fd_count_rec *a = loc + loff[t], *b = loc + loff[t + 1];
+                rank_sort(a, b);
+                const uint32_t k = (uint32_t)std::min<uint64_t>((uint64_t)(b - a), top_n);
+                sel_state s{0, 0, 0, k};
+                memcpy(host_msg.data() + sizeof hd + t * sizeof s, &s, sizeof s);
+                if (k) memcpy(host_msg.data() + sizeof hd + n_queries * sizeof s + (size_t)t * top_n * sizeof(fd_count_rec), a, (size_t)k * sizeof(fd_count_rec));
+            }
+        HCHK(c, hipMemcpyAsync(snd, host_msg.data(), mb, hipMemcpyHostToDevice, st));
+    }
+    int rc = allgather_dev(c, m, snd, m->recv.p, mb);
+    if (rc) return rc;
+    rc = merge_gathered(c, m->mb, m->recv.as<uint8_t>(), (uint32_t)W, n_queries, top_n, out, out_off);
+    if (!host_msg.empty()) HCHK(c, hipStreamSynchronize(st));     // host_msg outlives its copy
+    return local_rc ? local_rc : rc;
+}
 }  // namespace
+
+extern "C" uint64_t fdgpu_comm_message_bytes(uint64_t n_queries, uint32_t top_n) { return msg_bytes(n_queries, top_n); }
+
+// The global merge alone, on `world` messages laid out as the all-gather leaves them (host array, world * fdgpu_comm_message_bytes): what
+// every rank runs after the gather.  Lets a single-GPU test drive the multi-rank unpack / select / rank code with hand-made contributions.
+extern "C" int fdgpu_debug_merge_gathered(fdgpu_ctx *c, uint32_t world, uint64_t n_queries, uint32_t top_n, const uint8_t *messages, fd_count_rec **out,
+                                          uint64_t **out_off) { FD_LOCK(c);
+    if (!c || !world || !messages || !out || !out_off || !device_path(top_n)) return FDGPU_EINVAL;
+    *out = nullptr; *out_off = nullptr;
+    const size_t mb = msg_bytes(n_queries, top_n);
+    fd_devbuf recv;
+    merge_bufs B;
+    hipError_t e = recv.ensure(mb * world);
+    if (e == hipSuccess) e = hipMemcpyAsync(recv.p, messages, mb * world, hipMemcpyHostToDevice, c->stream);
+    int rc = e == hipSuccess ? merge_gathered(c, B, recv.as<uint8_t>(), world, n_queries, top_n, out, out_off) : FDGPU_EHIP;
+    (void)hipStreamSynchronize(c->stream);
+    recv.release(); B.release();
+    return rc;
+}
 
 // The sharded prefilter of a batch of queries.  Every rank passes the SAME queries (q_off / q_hash / q_node / q_edge_j as in
 // fdgpu_count_query_batch, without idf) and its own shard `ix` + penalty (n_structures(ix) entries).  Result, identical on every rank:
@@ -136,11 +429,17 @@ extern "C" int fdgpu_sharded_count_query(fdgpu_ctx *c, fdgpu_comm *m, const fdgp
     *out = nullptr; *out_off = nullptr;
     const uint64_t nq = q_off[n_queries];
     if (nq && (!q_hash || !q_node || !q_edge_j)) return FDGPU_EINVAL;
-    // 1. posting lengths over the whole database -> idf per query hash; absent hashes drop out (count_query.rs:121-130)
-    std::vector<uint64_t> lens(std::max<uint64_t>(nq, 1));
-    int rc = fdgpu_posting_lengths(c, ix, q_hash, nq, lens.data());
+    hipStream_t st = c->stream;
+    // 1. posting lengths over the whole database: counted and summed on the device -> idf per query hash; absent hashes drop out
+    //    (count_query.rs:121-130)
+    std::vector<uint64_t> lens(std::max<uint64_t>(nq, 1), 0);
+    uint64_t *dl = nullptr;
+    int local_rc = fd_posting_lengths_dev(c, ix, q_hash, nq, &dl);
+    if (local_rc) { if (hipMemsetAsync(dl, 0, std::max<uint64_t>(nq, 1) * 8, st) != hipSuccess) return local_rc; }     // no buffer at all: nothing to take part with
+    int rc = allreduce_dev(c, m, dl, nq);
     if (rc) return rc;
-    if ((rc = fdgpu_allreduce_lengths(c, m, lens.data(), nq))) return rc;
+    if (nq) HCHK(c, hipMemcpyAsync(lens.data(), dl, nq * 8, hipMemcpyDeviceToHost, st));
+    HCHK(c, hipStreamSynchronize(st));
     std::vector<uint32_t> kh, kn, ke;
     std::vector<float> kidf;
     std::vector<uint64_t> koff(n_queries + 1, 0);
@@ -153,72 +452,157 @@ extern "C" int fdgpu_sharded_count_query(fdgpu_ctx *c, fdgpu_comm *m, const fdgp
         }
         koff[t + 1] = kh.size();
     }
-    // 2. local scoring with the device-side top-N preselection
+    if (kh.empty()) { kh.push_back(0); kn.push_back(0); ke.push_back(0); kidf.push_back(0.0f); }
+    // 2. local scoring, candidate selection on the device where it applies (the ranked records then stay there)
     fd_count_rec *loc = nullptr;
     uint64_t *loff = nullptr;
-    rc = fdgpu_count_query_batch_top(c, ix, n_queries, koff.data(), kh.data(), kn.data(), ke.data(), kidf.data(), penalty, top_n, &loc, &loff);
-    if (rc) return rc;
-    // a rank never contributes more than top_n records per query
-    std::vector<fd_count_rec> mine;
-    std::vector<uint64_t> cnt(n_queries, 0);
-    for (uint64_t t = 0; t < n_queries; ++t) {
-        fd_count_rec *a = loc + loff[t], *b = loc + loff[t + 1];
-        std::sort(a, b, [](const fd_count_rec &x, const fd_count_rec &y) { return rank_key(x) < rank_key(y); });
-        const uint64_t keep = top_n ? std::min<uint64_t>(top_n, (uint64_t)(b - a)) : (uint64_t)(b - a);
-        mine.insert(mine.end(), a, a + keep);
-        cnt[t] = keep;
-    }
+    fd_cq_dev_out dev;
+    if (!local_rc) local_rc = fd_count_query_batch_impl(c, ix, n_queries, koff.data(), kh.data(), kn.data(), ke.data(), kidf.data(), penalty, top_n, &loc, &loff, true,
+                                                        device_path(top_n) ? &dev : nullptr);
+    if (!local_rc && dev.got && dev.overflow)     // ties beyond the selection's slots: this rank ranks its full lists instead
+        local_rc = fd_count_query_batch_impl(c, ix, n_queries, koff.data(), kh.data(), kn.data(), ke.data(), kidf.data(), penalty, top_n, &loc, &loff, false, nullptr), dev.got = false;
+    // 3. + 4. all-gather and global ranking
+    rc = exchange(c, m, n_queries, top_n, local_rc, dev, loc, loff, out, out_off);
     free(loc); free(loff);
+    return rc;
+}
+
+// The same for query maps handed over as fdgpu_make_query_map[_batch] returned them (index = NULL there: a shard's lengths mean nothing):
+// ONE all-reduce carries the lengths of the maps' hash[] (scoring idf, count_query.rs:181-200) and of their primary_hash[] (the maps' own
+// idf[] — the retrieval's subgraph idf, query.rs:283-288 — is rewritten in place from the global lengths), then as above.  The sharded
+// sibling of fdgpu_count_query_maps_top.
+extern "C" int fdgpu_sharded_count_query_maps(fdgpu_ctx *c, fdgpu_comm *m, const fdgpu_index *ix, uint64_t n_queries, fd_query_map *const *qms, const float *penalty,
+                                              uint64_t total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
+    if (!c || !m || !ix || !out || !out_off || (n_queries && !qms)) return FDGPU_EINVAL;
+    *out = nullptr; *out_off = nullptr;
+    for (uint64_t t = 0; t < n_queries; ++t) if (!qms[t]) return FDGPU_EINVAL;
+    hipStream_t st = c->stream;
+    std::vector<uint32_t> h;
+    const uint64_t nq = fd_maps_hashes(n_queries, qms, h);
+    std::vector<uint64_t> lens(std::max<uint64_t>(2 * nq, 1), 0);
+    uint64_t *dl = nullptr;
+    int local_rc = fd_posting_lengths_dev(c, ix, h.data(), 2 * nq, &dl);
+    if (local_rc) { if (hipMemsetAsync(dl, 0, std::max<uint64_t>(2 * nq, 1) * 8, st) != hipSuccess) return local_rc; }
+    int rc = allreduce_dev(c, m, dl, 2 * nq);
+    if (rc) return rc;
+    if (nq) HCHK(c, hipMemcpyAsync(lens.data(), dl, 2 * nq * 8, hipMemcpyDeviceToHost, st));
+    HCHK(c, hipStreamSynchronize(st));
+    fd_count_rec *loc = nullptr;
+    uint64_t *loff = nullptr;
+    fd_cq_dev_out dev;
+    if (!local_rc) local_rc = fd_count_query_maps_len(c, ix, n_queries, qms, lens.data(), nq ? lens.data() + nq : nullptr, penalty, (float)total_structures, top_n, &loc,
+                                                      &loff, device_path(top_n) ? &dev : nullptr);
+    if (!local_rc && dev.got && dev.overflow) {   // rank the full lists (the compacting path): top_n + 4096 makes the device selection step aside
+        fd_count_rec *l2 = nullptr; uint64_t *o2 = nullptr;
+        local_rc = fd_count_query_maps_len(c, ix, n_queries, qms, lens.data(), nullptr, penalty, (float)total_structures, 0, &l2, &o2, nullptr);
+        loc = l2; loff = o2; dev.got = false;
+    }
+    rc = exchange(c, m, n_queries, top_n, local_rc, dev, loc, loff, out, out_off);
+    free(loc); free(loff);
+    return rc;
+}
+
+// Sharded retrieval: query t's candidates cand_nid[cand_off[t] .. cand_off[t+1]) are GLOBAL structure ids in ranking order (what
+// fdgpu_sharded_count_query[_maps] returned, cut to the number of structures to match); this rank holds the coordinates of structures
+// first_id .. first_id + n_structures(db) - 1 and matches the candidates inside that range (fdgpu_retrieve_batch on its shard), then the
+// ranks all-gather their match records and residue lists (counts first, then one padded payload) and every rank returns what
+// fdgpu_retrieve_batch returns for the unsharded database: matches ordered by candidate slot (slot = position in the query's global
+// list), components of a candidate in graph.rs:43-45 order.  Replaces the par_iter over candidates of query_pdb.rs:415-452.
+extern "C" int fdgpu_sharded_retrieve(fdgpu_ctx *c, fdgpu_comm *m, const fdgpu_batch *db, uint64_t first_id, const uint8_t *resname_std, uint64_t n_queries,
+                                      const uint32_t *cand_nid, const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
+                                      const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches,
+                                      uint64_t **match_off, int32_t **residues, uint64_t **res_off) { FD_LOCK(c);
+    if (!c || !m || !db || !qb || !p || !matches || !match_off || !residues || !res_off || !cand_off || (n_queries && (!qms || !q_struct))) return FDGPU_EINVAL;
+    *matches = nullptr; *match_off = nullptr; *residues = nullptr; *res_off = nullptr;
+    if (cand_off[n_queries] && !cand_nid) return FDGPU_EINVAL;
+    for (uint64_t t = 0; t < n_queries; ++t) if (!qms[t]) return FDGPU_EINVAL;
+    hipStream_t st = c->stream;
     const int W = m->world;
-    std::vector<uint64_t> all_cnt((size_t)W * n_queries);
-    std::vector<fd_count_rec> all;
-    uint64_t stride = 0;
-    if (W == 1) {
-        all_cnt = cnt; all = mine; stride = mine.size();
-    } else {
-        // 3. all-gather: the per-query counts of every rank, then the records padded to the longest contribution
-        hipStream_t st = c->stream;
-        HCHK(c, m->send.ensure(std::max<size_t>(n_queries * 8, 8)));
-        HCHK(c, m->recv.ensure(std::max<size_t>((size_t)W * n_queries * 8, 8)));
-        HCHK(c, hipMemcpyAsync(m->send.p, cnt.data(), n_queries * 8, hipMemcpyHostToDevice, st));
-        NCHK(c, rccl().AllGather(m->send.p, m->recv.p, n_queries, ncclUint64, m->comm, st));
-        HCHK(c, hipMemcpyAsync(all_cnt.data(), m->recv.p, (size_t)W * n_queries * 8, hipMemcpyDeviceToHost, st));
-        HCHK(c, hipStreamSynchronize(st));
-        for (int r = 0; r < W; ++r) {
-            uint64_t tot = 0;
-            for (uint64_t t = 0; t < n_queries; ++t) tot += all_cnt[(size_t)r * n_queries + t];
-            stride = std::max(stride, tot);
-        }
-        stride = std::max<uint64_t>(stride, 1);
-        const size_t bytes = stride * sizeof(fd_count_rec);
-        HCHK(c, m->send.ensure(bytes));
-        HCHK(c, m->recv.ensure(bytes * W));
-        if (!mine.empty()) HCHK(c, hipMemcpyAsync(m->send.p, mine.data(), mine.size() * sizeof(fd_count_rec), hipMemcpyHostToDevice, st));
-        NCHK(c, rccl().AllGather(m->send.p, m->recv.p, bytes, ncclUint8, m->comm, st));
-        all.resize(stride * W);
-        HCHK(c, hipMemcpyAsync(all.data(), m->recv.p, bytes * W, hipMemcpyDeviceToHost, st));
-        HCHK(c, hipStreamSynchronize(st));
-    }
-    // 4. global ranking per query
-    uint64_t *ooff = (uint64_t *)calloc(n_queries + 1, 8);
-    if (!ooff) return FDGPU_ENOMEM;
-    std::vector<fd_count_rec> res;
-    std::vector<uint64_t> base((size_t)W, 0);
+    const uint64_t S = db->n_struct;
+    // 1. the candidates this rank owns, as local structure indices; slot_of[k] = their slot in the query's global list
+    std::vector<uint32_t> lc, slot_of;
+    std::vector<uint64_t> lc_off(n_queries + 1, 0);
     for (uint64_t t = 0; t < n_queries; ++t) {
-        const size_t s0 = res.size();
-        for (int r = 0; r < W; ++r) {
-            const uint64_t k = all_cnt[(size_t)r * n_queries + t];
-            const fd_count_rec *src = all.data() + (size_t)r * stride + base[r];
-            res.insert(res.end(), src, src + k);
-            base[r] += k;
-        }
-        std::sort(res.begin() + s0, res.end(), [](const fd_count_rec &x, const fd_count_rec &y) { return rank_key(x) < rank_key(y); });
-        if (top_n && res.size() - s0 > top_n) res.resize(s0 + top_n);
-        ooff[t + 1] = res.size();
+        for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k)
+            if (cand_nid[k] >= first_id && cand_nid[k] - first_id < S) { lc.push_back((uint32_t)(cand_nid[k] - first_id)); slot_of.push_back((uint32_t)(k - cand_off[t])); }
+        lc_off[t + 1] = lc.size();
     }
-    fd_count_rec *o = (fd_count_rec *)malloc(std::max<size_t>(res.size(), 1) * sizeof(fd_count_rec));
-    if (!o) { free(ooff); return FDGPU_ENOMEM; }
-    if (!res.empty()) memcpy(o, res.data(), res.size() * sizeof(fd_count_rec));
-    *out = o; *out_off = ooff;
+    if (lc.empty()) lc.push_back(0);
+    // 2. local retrieval
+    fd_match_rec *lm = nullptr; uint64_t *lmo = nullptr; int32_t *lr = nullptr; uint64_t *lro = nullptr;
+    int local_rc = fdgpu_retrieve_batch(c, db, resname_std, n_queries, lc.data(), lc_off.data(), qms, qb, q_struct, p, ca_distance_cutoff, node_count, partial_fit, &lm, &lmo,
+                                        &lr, &lro);
+    struct Rel { fd_match_rec *&a; uint64_t *&b; int32_t *&cc; uint64_t *&d; ~Rel() { fdgpu_matches_free(a, cc); free(b); free(d); } } rel{lm, lmo, lr, lro};
+    // 3. counts: per query the number of matches, + status; residue ints per match = 2 * n_indices of the query (same on every rank)
+    std::vector<uint64_t> cnt(n_queries + 1, 0), nres_per(n_queries, 0);
+    for (uint64_t t = 0; t < n_queries; ++t) nres_per[t] = 2 * qms[t]->n_indices;
+    cnt[n_queries] = local_rc ? (uint64_t)(uint32_t)(-local_rc) : 0;
+    uint64_t my_m = 0, my_r = 0;
+    if (!local_rc)
+        for (uint64_t t = 0; t < n_queries; ++t) {
+            cnt[t] = lmo[t + 1] - lmo[t];
+            for (uint64_t k = lmo[t]; k < lmo[t + 1]; ++k) lm[k].cand = slot_of[lc_off[t] + lm[k].cand];      // local slot -> slot in the global list
+            my_m += cnt[t]; my_r += cnt[t] * nres_per[t];
+        }
+    const size_t cb = (n_queries + 1) * 8;
+    std::vector<uint64_t> all_cnt((size_t)W * (n_queries + 1));
+    HCHK(c, m->send.ensure(cb));
+    HCHK(c, m->recv.ensure(cb * W));
+    HCHK(c, hipMemcpyAsync(m->send.p, cnt.data(), cb, hipMemcpyHostToDevice, st));
+    int rc = allgather_dev(c, m, m->send.p, m->recv.p, cb);
+    if (rc) return rc;
+    HCHK(c, hipMemcpyAsync(all_cnt.data(), m->recv.p, cb * W, hipMemcpyDeviceToHost, st));
+    HCHK(c, hipStreamSynchronize(st));
+    for (int r = 0; r < W; ++r)
+        if (all_cnt[(size_t)r * (n_queries + 1) + n_queries]) {
+            if (r != m->rank || !local_rc) c->err = "sharded retrieve: rank " + std::to_string(r) + " failed its local step (code -" + std::to_string(all_cnt[(size_t)r * (n_queries + 1) + n_queries]) + ")";
+            return local_rc ? local_rc : FDGPU_EHIP;
+        }
+    // 4. payload: [match records | residue ints], each part padded to the largest contribution
+    uint64_t max_m = 1, max_r = 1;
+    for (int r = 0; r < W; ++r) {
+        uint64_t tm = 0, tr = 0;
+        for (uint64_t t = 0; t < n_queries; ++t) { tm += all_cnt[(size_t)r * (n_queries + 1) + t]; tr += all_cnt[(size_t)r * (n_queries + 1) + t] * nres_per[t]; }
+        max_m = std::max(max_m, tm); max_r = std::max(max_r, tr);
+    }
+    const size_t mbytes = max_m * sizeof(fd_match_rec), rbytes = ((max_r * 4 + 15) & ~(size_t)15), bytes = mbytes + rbytes;
+    HCHK(c, m->send.ensure(bytes));
+    HCHK(c, m->recv.ensure(bytes * W));
+    if (my_m) HCHK(c, hipMemcpyAsync(m->send.p, lm, my_m * sizeof(fd_match_rec), hipMemcpyHostToDevice, st));
+    if (my_r) HCHK(c, hipMemcpyAsync(m->send.as<uint8_t>() + mbytes, lr, my_r * 4, hipMemcpyHostToDevice, st));
+    if ((rc = allgather_dev(c, m, m->send.p, m->recv.p, bytes))) return rc;
+    std::vector<uint8_t> all(bytes * W);
+    HCHK(c, hipMemcpyAsync(all.data(), m->recv.p, bytes * W, hipMemcpyDeviceToHost, st));
+    HCHK(c, hipStreamSynchronize(st));
+    // 5. merge per query by candidate slot (a slot belongs to one rank, whose matches arrive in slot / component order)
+    uint64_t tot_m = 0, tot_r = 0;
+    for (int r = 0; r < W; ++r)
+        for (uint64_t t = 0; t < n_queries; ++t) { tot_m += all_cnt[(size_t)r * (n_queries + 1) + t]; tot_r += all_cnt[(size_t)r * (n_queries + 1) + t] * nres_per[t]; }
+    fd_match_rec *om = (fd_match_rec *)malloc(std::max<uint64_t>(tot_m, 1) * sizeof(fd_match_rec));
+    int32_t *orr = (int32_t *)malloc(std::max<uint64_t>(tot_r, 1) * 4);
+    uint64_t *omo = (uint64_t *)calloc(n_queries + 1, 8), *oro = (uint64_t *)calloc(n_queries + 1, 8);
+    if (!om || !orr || !omo || !oro) { free(om); free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
+    std::vector<uint64_t> mbase((size_t)W, 0), rbase((size_t)W, 0);
+    struct Ref { uint32_t slot, rank; uint64_t mi, ri; };
+    std::vector<Ref> refs;
+    uint64_t wm = 0, wr = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        refs.clear();
+        for (int r = 0; r < W; ++r) {
+            const uint64_t k = all_cnt[(size_t)r * (n_queries + 1) + t];
+            const fd_match_rec *src = (const fd_match_rec *)(all.data() + (size_t)r * bytes) + mbase[r];
+            for (uint64_t z = 0; z < k; ++z) refs.push_back({src[z].cand, (uint32_t)r, mbase[r] + z, rbase[r] + z * nres_per[t]});
+            mbase[r] += k; rbase[r] += k * nres_per[t];
+        }
+        std::stable_sort(refs.begin(), refs.end(), [](const Ref &a, const Ref &b) { return a.slot < b.slot; });
+        omo[t] = wm; oro[t] = wr;
+        for (const Ref &f : refs) {
+            om[wm++] = ((const fd_match_rec *)(all.data() + (size_t)f.rank * bytes))[f.mi];
+            if (nres_per[t]) memcpy(orr + wr, (const int32_t *)(all.data() + (size_t)f.rank * bytes + mbytes) + f.ri, nres_per[t] * 4);
+            wr += nres_per[t];
+        }
+    }
+    omo[n_queries] = wm; oro[n_queries] = wr;
+    *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
     return FDGPU_OK;
 }

@@ -24,6 +24,7 @@
 #include "fd_fcz.h"
 
 #include <math.h>
+#include <algorithm>
 #include <string.h>
 
 namespace {
@@ -39,7 +40,9 @@ inline float angle_deg(f3 a, f3 b, f3 c) {
     const float cs = (float)((double)inner / sqrt((double)(s1 * s2)));
     return (float)(acos((double)cs) * 180.0 / M_PI);
 }
-// next atom from three predecessors, bond length, bond angle and torsion (degrees)
+// next atom from three predecessors, bond length, bond angle and torsion (degrees).  This routine mirrors the vendored decoder's
+// place_atom (lib/foldcomp/src/nerf.cpp:39-95) operation for operation — same intermediate roundings — because the coordinates must come out
+// bit-identical to it; everything around it is written from the format.
 inline f3 place_atom(const f3 prev[3], float bond_length, float bond_angle, float torsion_angle) {
     const f3 a = prev[0], b = prev[1], c = prev[2];
     const f3 ab = {b.x - a.x, b.y - a.y, b.z - a.z}, bc = {c.x - b.x, c.y - b.y, c.z - b.z};
@@ -125,8 +128,15 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
     if (!r.get(&H, sizeof H)) return -1;
     const int nres = H.n_residue, n_anchor = H.n_anchor;
     if (nres < 1 || n_anchor < 2) return -1;
+    // an entry is untrusted input (one corrupt record must cost that entry, not the ingest): every count is bounded by the bytes that
+    // remain before anything is allocated or indexed with it
+    const size_t remain = len - r.at;
+    if ((size_t)n_anchor > remain / 4 || (size_t)nres > remain / 8 || (size_t)H.n_side_torsion > remain || (size_t)H.len_title > remain) return -1;
     std::vector<int32_t> anchor_idx(n_anchor);
     if (!r.get(anchor_idx.data(), (size_t)n_anchor * 4)) return -1;
+    for (int k = 0; k < n_anchor; ++k)      // anchors are residue indices in strictly ascending order
+        if (anchor_idx[k] < 0 || anchor_idx[k] >= nres || (k && anchor_idx[k] <= anchor_idx[k - 1])) return -1;
+    if (r.at + H.len_title > len) return -1;
     r.at += H.len_title;
     float first[9], last[9], oxt[3];
     if (!r.get(first, sizeof first)) return -1;
@@ -197,7 +207,8 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
         const int tmax = (int)tors.size() - 1;
         std::vector<float> st;
         if (tmax >= 0) {
-            const int t0 = anchor_idx[sgm] * 3 < tmax ? anchor_idx[sgm] * 3 : tmax, t1 = anchor_idx[sgm + 1] * 3 < tmax ? anchor_idx[sgm + 1] * 3 : tmax;
+            const int64_t a0 = (int64_t)anchor_idx[sgm] * 3, a1 = (int64_t)anchor_idx[sgm + 1] * 3;      // 64-bit: 3 * index must not wrap
+            const int t0 = (int)std::min<int64_t>(std::max<int64_t>(a0, 0), tmax), t1 = (int)std::min<int64_t>(std::max<int64_t>(a1, 0), tmax);
             for (int t = t0; t < t1; ++t) st.push_back(tors[t]);
             if (sgm == n_anchor - 2) st.push_back(tors.back());
         }

@@ -541,7 +541,7 @@ extern "C" int fdgpu_parse_foldcomp_db(const char *db_path, const uint64_t *keys
                 auto it = std::lower_bound(idx.begin(), idx.end(), keys[k], [](const db_ent &a, uint64_t key) { return a.key < key; });
                 if (it != idx.end() && it->key == keys[k]) e = &*it;
             } else e = &idx[k];
-            if (!e || e->start + e->len > db_len) continue;
+            if (!e || e->start > db_len || e->len > db_len - e->start) continue;     // no wrap-around: both come from DB.index
             if (fd_fcz_decode(db + e->start, (size_t)e->len, &raw) != 0) continue;
             atoms.resize(raw.size());
             for (size_t a = 0; a < raw.size(); ++a) {

@@ -49,6 +49,15 @@ void fd_launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t n, 
     if (n) hipLaunchKernelGGL(k_gather_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, idx, n, dst);
 }
 
+// postings of an index = varint terminators of its value bytes (bytes without the continuation bit)
+__global__ __launch_bounds__(256) void k_count_postings(const uint8_t *__restrict__ value, uint64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long acc = 0;
+    for (uint64_t p = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; p < n; p += (uint64_t)gridDim.x * 256 * 16)
+        for (uint64_t k = p; k < n && k < p + 16; ++k) acc += !(value[k] & 0x80u);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
 static void reset_timings(fdgpu_ctx *c) { c->timings.clear(); c->event_used = 0; }
 
 // ---- context ------------------------------------------------------------------------------------------------
@@ -644,7 +653,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     if (!ix) return FDGPU_ENOMEM;
     ix->ctx = c; ix->value_len = tot[0]; ix->n_hashes = tot[1]; ix->n_postings = tot[2]; ix->n_structures = S; ix->first_id = first_id;
     hipError_t e;
-    ix->value = (uint8_t *)c->pool_alloc(std::max<uint64_t>(ix->value_len, 4), &e); ix->cap_value = c->last_cap;
+    ix->value = (uint8_t *)c->pool_alloc(ix->value_len + 16, &e); ix->cap_value = c->last_cap;      // + 16: the merge reads 8 bytes at a list's start (mg_first_varint)
     if (e == hipSuccess) { ix->hashes = (uint32_t *)c->pool_alloc(std::max<uint64_t>(ix->n_hashes, 1) * 4, &e); ix->cap_hashes = c->last_cap; }
     if (e == hipSuccess) { ix->offsets = (uint64_t *)c->pool_alloc((ix->n_hashes + 1) * 8, &e); ix->cap_offsets = c->last_cap; }
     if (e == hipSuccess) { ix->last_ids = (uint32_t *)c->pool_alloc(std::max<uint64_t>(ix->n_hashes, 1) * 4, &e); ix->cap_last = c->last_cap; }
@@ -744,8 +753,15 @@ extern "C" int fdgpu_index_load(fdgpu_ctx *c, const uint32_t *hashes, const uint
         fdgpu_index_destroy(ix);
         return FDGPU_EHIP;
     }
-    // postings = bytes without continuation bit; counted lazily by the query path when needed
+    // postings = bytes without the continuation bit
     ix->n_postings = 0;
+    if (vlen) {
+        unsigned long long np = 0;
+        if (c->ws[WS_TOTAL].ensure(64) == hipSuccess && hipMemsetAsync(c->ws[WS_TOTAL].p, 0, 8, c->stream) == hipSuccess) {
+            hipLaunchKernelGGL(k_count_postings, dim3(2048), dim3(256), 0, c->stream, ix->value, vlen, c->ws[WS_TOTAL].as<unsigned long long>());
+            if (hipMemcpyAsync(&np, c->ws[WS_TOTAL].p, 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) ix->n_postings = np;
+        }
+    }
     *out = ix;
     return FDGPU_OK;
 }
@@ -759,7 +775,7 @@ void fd_mg_expand(const uint32_t *bitmap, const uint64_t *prefix, uint64_t n_wor
 void fd_mg_pos_fill(const uint32_t *hashes, uint64_t n, const uint32_t *bitmap, const uint64_t *prefix, uint32_t *pos, uint32_t part, uint32_t n_parts,
                     hipStream_t st);
 void fd_mg_sizes(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, uint32_t *sizes, uint32_t *out_last, void *plan, uint32_t *plan_dst,
-                 hipStream_t st);
+                 uint32_t *err_flag, hipStream_t st);
 void fd_mg_copy(const void *parts, uint32_t n_parts, const void *plan, const uint32_t *plan_dst, uint64_t n_slots, const uint64_t *out_off, uint8_t *out_value,
                 hipStream_t st);
 
@@ -778,8 +794,10 @@ extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, 
             FAIL(c, FDGPU_EINVAL, "index merge: parts must cover consecutive structure-id ranges in the order given");
         if (!p->last_ids && p->n_hashes) {     // a loaded index: last id of every list by one decode pass, kept with the index
             fdgpu_index *mp = const_cast<fdgpu_index *>(p);
-            hipError_t le = hipMalloc((void **)&mp->last_ids, p->n_hashes * 4);
-            if (le != hipSuccess) { c->err = std::string("index merge: ") + hipGetErrorString(le); return FDGPU_EHIP; }
+            hipError_t le = hipSuccess;      // the block is released the way fdgpu_index_destroy releases the part's other blocks: pool for a built index, hipFree for a loaded one
+            if (mp->ctx) { mp->last_ids = (uint32_t *)mp->ctx->pool_alloc(p->n_hashes * 4, &le); mp->cap_last = mp->ctx->last_cap; }
+            else le = hipMalloc((void **)&mp->last_ids, p->n_hashes * 4);
+            if (le != hipSuccess) { mp->last_ids = nullptr; c->err = std::string("index merge: ") + hipGetErrorString(le); return FDGPU_EHIP; }
             fd_mg_last_ids(p->offsets, p->value, p->n_hashes, mp->last_ids, st);
         }
         ph[k] = {p->hashes, p->offsets, p->value, p->last_ids, p->n_hashes};
@@ -833,13 +851,20 @@ extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, 
         fd_mg_expand(bitmap, prefix, n_words, ix->hashes, st);
         (void)hipMemsetAsync(pos, 0xff, std::max<uint64_t>(Ht, 1) * n_parts * 4, st);
         for (uint64_t k = 0; k < n_parts; ++k) fd_mg_pos_fill(ph[k].hashes, ph[k].H, bitmap, prefix, pos, (uint32_t)k, (uint32_t)n_parts, st);
-        fd_mg_sizes(c->ws[WS_MISC4].p, (uint32_t)n_parts, pos, Ht, sizes, ix->last_ids, c->ws[WS_FRAMES].p, c->ws[WS_MISC1].as<uint32_t>(), st);
+        (void)hipMemsetAsync(c->ws[WS_TOTAL].as<uint32_t>() + 4, 0, 4, st);      // "a merged list does not fit 32 bits" flag, behind the scan total
+        fd_mg_sizes(c->ws[WS_MISC4].p, (uint32_t)n_parts, pos, Ht, sizes, ix->last_ids, c->ws[WS_FRAMES].p, c->ws[WS_MISC1].as<uint32_t>(),
+                    c->ws[WS_TOTAL].as<uint32_t>() + 4, st);
         fd_exclusive_scan<uint32_t>(sizes, Ht, ix->offsets, c->ws[WS_SCANTMP].as<uint64_t>(), c->ws[WS_TOTAL].as<uint64_t>(), st);
     }
     e = hipGetLastError();
     uint64_t vlen = 0;
     if (e == hipSuccess) { rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &vlen); if (rc) { fdgpu_index_destroy(ix); return rc; } }
-    if (e == hipSuccess) { ix->value_len = vlen; ix->value = (uint8_t *)c->pool_alloc(std::max<uint64_t>(vlen, 4), &e); ix->cap_value = c->last_cap; }
+    if (e == hipSuccess) {
+        uint32_t too_long = 0;
+        e = hipMemcpy(&too_long, c->ws[WS_TOTAL].as<uint32_t>() + 4, 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && too_long) { fdgpu_index_destroy(ix); FAIL(c, FDGPU_ERANGE, "index merge: a merged posting list reaches 4 GiB"); }
+    }
+    if (e == hipSuccess) { ix->value_len = vlen; ix->value = (uint8_t *)c->pool_alloc(vlen + 16, &e); ix->cap_value = c->last_cap; }
     if (e != hipSuccess) { c->err = std::string("index merge: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }
     {
         StageTimer t(c, "merge_copy", sum_v + vlen + Ht * n_parts * 4);
@@ -872,12 +897,14 @@ extern "C" int fdgpu_index_save(fdgpu_ctx *c, const fdgpu_index *ix, const char 
 }
 
 // ---- S3 ---------------------------------------------------------------------------------------------------------------
-extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths) { FD_LOCK(c);
-    if (!c || !ix || (nq && (!q_hash || !lengths))) return FDGPU_EINVAL;
-    if (!nq) return FDGPU_OK;
+// posting lengths of nq query hashes (host array) left ON THE DEVICE in the context's WS_MISC1 (u64 [nq]); the sharded query all-reduces
+// them there (fd_comm.hip).  No synchronisation.
+int fd_posting_lengths_dev(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t **dev_lengths) {
     hipStream_t st = c->stream;
-    HIPCHK(c, c->ws[WS_MISC0].ensure(nq * 4));
-    HIPCHK(c, c->ws[WS_MISC1].ensure(nq * 8));
+    HIPCHK(c, c->ws[WS_MISC0].ensure(std::max<uint64_t>(nq, 1) * 4));
+    HIPCHK(c, c->ws[WS_MISC1].ensure(std::max<uint64_t>(nq, 1) * 8));
+    *dev_lengths = c->ws[WS_MISC1].as<uint64_t>();
+    if (!nq) return FDGPU_OK;
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(nq * 8));
     HIPCHK(c, c->ws[WS_CQ_NSEG].ensure(nq * 4));
@@ -888,8 +915,16 @@ extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const 
                               c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), c->ws[WS_CQ_WSTART].as<uint64_t>(),
                               c->ws[WS_SCANTMP].as<uint64_t>(), c->ws[WS_TOTAL].as<uint64_t>(), st);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(lengths, c->ws[WS_MISC1].p, nq * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    return FDGPU_OK;
+}
+extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths) { FD_LOCK(c);
+    if (!c || !ix || (nq && (!q_hash || !lengths))) return FDGPU_EINVAL;
+    if (!nq) return FDGPU_OK;
+    uint64_t *d = nullptr;
+    int rc = fd_posting_lengths_dev(c, ix, q_hash, nq, &d);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(lengths, d, nq * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return FDGPU_OK;
 }
 
@@ -1080,9 +1115,13 @@ static uint64_t fd_rank_trim(fd_count_rec *r, uint64_t n, uint32_t top_n) {
     std::sort(r, r + n, [&](const fd_count_rec &a, const fd_count_rec &b) { return key(a) < key(b); });
     return std::min<uint64_t>(n, top_n);
 }
-static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
-                                  const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
-                                  fd_count_rec **out, uint64_t **out_off, bool allow_dense = true) {
+// dev != null: a call whose candidate selection runs on the device (dense_topn below) leaves its result THERE — dev->recs = [n_queries][top_n]
+// ranked records, dev->state = the per-query selection state (count = records selected) — and returns without host records (dev->got); the
+// sharded query all-gathers those buffers (fd_comm.hip).  dev->overflow: more ties at a cut-off than the selection holds (the caller
+// takes the compacting path together with the other ranks).  Calls the device selection does not serve return host records as usual.
+int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
+                              const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
+                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev) {
     if (!c || !ix || !out || !out_off || !q_off || (ix->n_structures && !penalty && !ix->penalty)) return FDGPU_EINVAL;
     *out = nullptr; *out_off = nullptr;
     reset_timings(c);
@@ -1090,6 +1129,7 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
     const uint64_t S = ix->n_structures, nq = q_off[n_queries];
     uint64_t *ooff = (uint64_t *)calloc(n_queries + 1, 8);
     if (!ooff) return FDGPU_ENOMEM;
+    if (dev) { dev->got = false; dev->overflow = false; }
     if (S == 0 || nq == 0 || n_queries == 0) { *out = (fd_count_rec *)malloc(sizeof(fd_count_rec)); *out_off = ooff; return *out ? FDGPU_OK : FDGPU_ENOMEM; }
     if (!q_hash || !q_node || !q_edge_j || !q_idf) { free(ooff); return FDGPU_EINVAL; }
     if (S >= 0xffffffe0ull || n_queries * S >= (1ull << 34)) { free(ooff); FAIL(c, FDGPU_ERANGE, "count_query_batch: n_queries x n_structures too large; split the batch"); }
@@ -1178,16 +1218,21 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
             fd_launch_cq_topn_sort(c->ws[WS_KEYS_A].p, cap, c->ws[WS_MISC2].p, (uint32_t)n_queries, top_n, c->ws[WS_TILE_HO].p, st);
         }
         if (e2 == hipSuccess) e2 = hipMemcpyAsync(tstate.data(), c->ws[WS_MISC2].p, n_queries * 16, hipMemcpyDeviceToHost, st);
-        if (e2 == hipSuccess) e2 = hipMemcpyAsync(sel.data(), c->ws[WS_TILE_HO].p, sel.size() * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
+        if (e2 == hipSuccess && !dev) e2 = hipMemcpyAsync(sel.data(), c->ws[WS_TILE_HO].p, sel.size() * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
         if (e2 == hipSuccess) e2 = hipGetLastError();
         if (e2 != hipSuccess) { free(ooff); c->err = std::string("count_query_batch: ") + hipGetErrorString(e2); return FDGPU_EHIP; }
         bool overflow = false;
         uint64_t tot = 0;
         for (uint64_t t = 0; t < n_queries; ++t) { overflow = overflow || tstate[4 * t + 3] > cap; tot += std::min<uint32_t>(tstate[4 * t + 3], top_n); }
+        if (dev) {        // the ranked selection stays where it is
+            free(ooff);
+            dev->got = true; dev->overflow = overflow; dev->recs = c->ws[WS_TILE_HO].p; dev->state = c->ws[WS_MISC2].p; dev->top_n = top_n; dev->cap = cap;
+            return FDGPU_OK;
+        }
         if (overflow) {   // more ties at the cut-off than the selection's slots hold: the compacting path ranks that call
             free(ooff);
-            return count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off, false);
+            return fd_count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off, false, nullptr);
         }
         fd_count_rec *rr = (fd_count_rec *)malloc(std::max<uint64_t>(tot, 1) * sizeof(fd_count_rec));
         if (!rr) { free(ooff); return FDGPU_ENOMEM; }
@@ -1294,14 +1339,14 @@ static int count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t 
 extern "C" int fdgpu_count_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                                        const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty,
                                        fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
-    return count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, 0, out, out_off);
+    return fd_count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, 0, out, out_off, true, nullptr);
 }
 // as above, but per query only the top_n records come back, RANKED as the candidate selection of query_pdb.rs:404-411 ranks them (idf
 // descending, ties by ascending structure id): radix selection + LDS bitonic sort on the device, top_n records per query over the bus
 extern "C" int fdgpu_count_query_batch_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                                            const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty,
                                            uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
-    return count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off);
+    return fd_count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off, true, nullptr);
 }
 
 // The length penalty nres^(-lp) of the index's structures (count_query.rs:200), kept on the device: count queries may then pass
@@ -1319,6 +1364,43 @@ extern "C" int fdgpu_index_set_penalty(fdgpu_ctx *c, fdgpu_index *ix, const floa
 // every map (hash, (qi, qj)) are scored with idf = log2(total_structures / posting length) of the hash ITSELF (count_query.rs:181-200;
 // the idf inside the map belongs to the pair's observed hash and feeds the retrieval's subgraph idf instead); hashes the index does
 // not hold are dropped.  Output as fdgpu_count_query_batch_top.
+// every map's hash[] (all queries), then every map's primary_hash[]: the 2 * sum(n) hashes whose posting lengths a sharded query needs
+// over the WHOLE database
+uint64_t fd_maps_hashes(uint64_t n_queries, const fd_query_map *const *qms, std::vector<uint32_t> &h) {
+    uint64_t nq = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) nq += qms[t]->n;
+    h.assign(std::max<uint64_t>(2 * nq, 1), 0);
+    uint64_t at = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) { if (qms[t]->n) memcpy(&h[at], qms[t]->hash, qms[t]->n * 4); at += qms[t]->n; }
+    for (uint64_t t = 0; t < n_queries; ++t) { if (qms[t]->n) memcpy(&h[at], qms[t]->primary_hash, qms[t]->n * 4); at += qms[t]->n; }
+    return nq;
+}
+// scoring of query maps with the posting lengths given: len[0 .. nq) belong to the maps' hash[] in order (idf = log2f(total / len), absent
+// hashes drop out); with primary_len the maps' own idf[] (the retrieval's subgraph idf, query.rs:283-288) is rewritten from the lengths
+// of primary_hash[] — what a sharded index needs, whose make_query_map saw one shard only
+int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const uint64_t *len,
+                            const uint64_t *primary_len, const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out,
+                            uint64_t **out_off, fd_cq_dev_out *dev) {
+    uint64_t nq = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) nq += qms[t]->n;
+    std::vector<uint64_t> q_off(n_queries + 1, 0);
+    std::vector<uint32_t> qh, qn, qe;
+    std::vector<float> qi;
+    qh.reserve(nq); qn.reserve(nq); qe.reserve(nq); qi.reserve(nq);
+    uint64_t at = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        const fd_query_map *m = qms[t];
+        for (uint64_t k = 0; k < m->n; ++k, ++at) {
+            if (primary_len) m->idf[k] = primary_len[at] ? log2f(total_structures / (float)primary_len[at]) : 0.0f;
+            if (!len[at]) continue;
+            qh.push_back(m->hash[k]); qn.push_back(m->qi[k]); qe.push_back(m->qj[k]);
+            qi.push_back(log2f(total_structures / (float)len[at]));       // f32 like the reference's (total / len).log2()
+        }
+        q_off[t + 1] = qh.size();
+    }
+    if (qh.empty()) { qh.push_back(0); qn.push_back(0); qe.push_back(0); qi.push_back(0.0f); }
+    return fd_count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off, true, dev);
+}
 extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty,
                                           float total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
     if (!c || !ix || !out || !out_off || (n_queries && !qms)) return FDGPU_EINVAL;
@@ -1330,22 +1412,27 @@ extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, u
     for (uint64_t t = 0; t < n_queries; ++t) { if (qms[t]->n) memcpy(&h[at], qms[t]->hash, qms[t]->n * 4); at += qms[t]->n; }
     int rc = nq && ix->n_structures ? fdgpu_posting_lengths(c, ix, h.data(), nq, len.data()) : FDGPU_OK;
     if (rc) return rc;
-    std::vector<uint64_t> q_off(n_queries + 1, 0);
-    std::vector<uint32_t> qh, qn, qe;
-    std::vector<float> qi;
-    qh.reserve(nq); qn.reserve(nq); qe.reserve(nq); qi.reserve(nq);
-    at = 0;
-    for (uint64_t t = 0; t < n_queries; ++t) {
-        const fd_query_map *m = qms[t];
-        for (uint64_t k = 0; k < m->n; ++k, ++at) {
-            if (!len[at]) continue;
-            qh.push_back(m->hash[k]); qn.push_back(m->qi[k]); qe.push_back(m->qj[k]);
-            qi.push_back(log2f(total_structures / (float)len[at]));       // f32 like the reference's (total / len).log2()
-        }
-        q_off[t + 1] = qh.size();
-    }
-    if (qh.empty()) { qh.push_back(0); qn.push_back(0); qe.push_back(0); qi.push_back(0.0f); }
-    return count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off);
+    return fd_count_query_maps_len(c, ix, n_queries, qms, len.data(), nullptr, penalty, total_structures, top_n, out, out_off, nullptr);
+}
+// The two halves of the sharded form for hosts that bring their own transport (MPI, gloo, ...): the LOCAL posting lengths of the maps'
+// hash[] and primary_hash[] (2 * sum(n) values, fd_maps_hashes order) — the caller sums them over the ranks — and the scoring of the
+// local shard with those GLOBAL lengths (maps' idf[] rewritten from the primary lengths).  With RCCL: fdgpu_sharded_count_query_maps.
+extern "C" int fdgpu_query_maps_lengths(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, uint64_t *lengths) { FD_LOCK(c);
+    if (!c || !ix || (n_queries && !qms) || !lengths) return FDGPU_EINVAL;
+    for (uint64_t t = 0; t < n_queries; ++t) if (!qms[t]) return FDGPU_EINVAL;
+    std::vector<uint32_t> h;
+    const uint64_t nq = fd_maps_hashes(n_queries, qms, h);
+    return nq ? fdgpu_posting_lengths(c, ix, h.data(), 2 * nq, lengths) : FDGPU_OK;
+}
+extern "C" int fdgpu_count_query_maps_top_global(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, fd_query_map *const *qms, const uint64_t *global_lengths,
+                                                 const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
+    if (!c || !ix || !out || !out_off || (n_queries && !qms)) return FDGPU_EINVAL;
+    uint64_t nq = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) { if (!qms[t]) return FDGPU_EINVAL; nq += qms[t]->n; }
+    if (nq && !global_lengths) return FDGPU_EINVAL;
+    const uint64_t zero = 0;
+    return fd_count_query_maps_len(c, ix, n_queries, qms, nq ? global_lengths : &zero, nq ? global_lengths + nq : nullptr, penalty, total_structures, top_n,
+                                   out, out_off, nullptr);
 }
 
 // found triples in the reference's scan order — (slot, i, j), several bin pairs of one (i, j) in emission order — from the kernel's

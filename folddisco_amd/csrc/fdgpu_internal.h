@@ -157,6 +157,17 @@ struct fdgpu_index {
     float *penalty = nullptr;     // device [n_structures] length penalty set with fdgpu_index_set_penalty (count queries may then pass NULL)
 };
 
+// batched scoring with the ranked selection left on the device (fdgpu_api.hip; consumed by the sharded query, fd_comm.hip)
+struct fd_cq_dev_out { bool got = false, overflow = false; const void *recs = nullptr; const void *state = nullptr; uint32_t top_n = 0, cap = 0; };
+int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
+                              const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
+                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev);
+int fd_posting_lengths_dev(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t **dev_lengths);
+uint64_t fd_maps_hashes(uint64_t n_queries, const fd_query_map *const *qms, std::vector<uint32_t> &h);
+int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const uint64_t *len,
+                            const uint64_t *primary_len, const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out,
+                            uint64_t **out_off, fd_cq_dev_out *dev);
+
 // kernels / launchers implemented in the k_*.hip files
 void fd_launch_selfcheck(const fd_quant &q, uint32_t *out, hipStream_t st);
 void fd_launch_hash_ok(const uint8_t *aa, const uint8_t *cb_valid, uint8_t *ok, uint64_t n, hipStream_t st);

@@ -101,7 +101,7 @@ __device__ __forceinline__ uint32_t mg_first_varint(const uint8_t *__restrict__ 
 struct mg_plan { uint32_t src_lo, src_hi_dl, n, delta; };      // src_hi_dl: bits 0-15 source offset >> 32, bits 16-18 varint length, bit 31 present
 __global__ __launch_bounds__(256) void k_mg_sizes(const mg_part *__restrict__ parts, uint32_t n_parts, const uint32_t *__restrict__ pos, uint64_t n_slots,
                                                   uint32_t *__restrict__ sizes, uint32_t *__restrict__ out_last, mg_plan *__restrict__ plan,
-                                                  uint32_t *__restrict__ plan_dst) {
+                                                  uint32_t *__restrict__ plan_dst, uint32_t *__restrict__ err_flag) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_slots) return;
     uint32_t total = 0, prev_last = 0;
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void k_mg_sizes(const mg_part *__restrict__ pa
             const mg_part P = parts[k];
             const uint64_t b0 = P.offsets[t], b1 = P.offsets[t + 1];
             uint32_t len = (uint32_t)(b1 - b0), nf = 0, dl = 0, delta = 0;
+            if (b1 - b0 > 0xffffffffull - total) *err_flag = 1u;      // a merged list of 4 GiB or more does not fit the u32 plan: the call fails (FDGPU_ERANGE)
             if (have_prev) {
                 const uint32_t first = mg_first_varint(P.value + b0, &nf);
                 delta = first - prev_last;
@@ -177,9 +178,9 @@ void fd_mg_last_ids(const uint64_t *offsets, const uint8_t *value, uint64_t H, u
     if (H) hipLaunchKernelGGL(k_mg_last_ids, dim3((unsigned)((H + 3) / 4)), dim3(256), 0, st, offsets, value, H, last_ids);
 }
 void fd_mg_sizes(const void *parts, uint32_t n_parts, const uint32_t *pos, uint64_t n_slots, uint32_t *sizes, uint32_t *out_last, void *plan, uint32_t *plan_dst,
-                 hipStream_t st) {
+                 uint32_t *err_flag, hipStream_t st) {
     if (n_slots) hipLaunchKernelGGL(k_mg_sizes, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, (const mg_part *)parts, n_parts, pos, n_slots, sizes, out_last,
-                                    (mg_plan *)plan, plan_dst);
+                                    (mg_plan *)plan, plan_dst, err_flag);
 }
 void fd_mg_copy(const void *parts, uint32_t n_parts, const void *plan, const uint32_t *plan_dst, uint64_t n_slots, const uint64_t *out_off, uint8_t *out_value,
                 hipStream_t st) {

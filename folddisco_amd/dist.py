@@ -203,10 +203,11 @@ class Comm:
                 rc = ctx.L.fdgpu_comm_unique_id(buf.ctypes.data_as(u8p))
                 if rc:
                     raise RuntimeError("fdgpu_comm_unique_id failed: RCCL is not available")
-            if world > 1:
-                t = torch.from_numpy(buf)
+            if world > 1:       # the id travels over the process group: device tensor under nccl (= RCCL), host tensor under gloo
+                dv = _dev(torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
+                t = torch.from_numpy(buf).to(dv)
                 dist.broadcast(t, src=0)
-                buf = t.numpy()
+                buf = t.cpu().numpy()
             unique_id = buf.tobytes()
         self.unique_id = unique_id
         idb = np.frombuffer(unique_id, np.uint8).copy()
@@ -224,6 +225,13 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+    def stats(self):
+        """(ncclAllReduce calls, ncclAllGather calls) this communicator has issued"""
+        from ._lib import u64p
+        a, g = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        self.ctx.check(self.ctx.L.fdgpu_comm_stats(self.h, a.ctypes.data_as(u64p), g.ctypes.data_as(u64p)))
+        return int(a[0]), int(g[0])
 
     def allreduce_lengths(self, lens: np.ndarray) -> np.ndarray:
         from ._lib import u64p
@@ -250,3 +258,112 @@ class Comm:
         self.ctx.L.fdgpu_free(out)
         self.ctx.L.fdgpu_free(ooff)
         return [arr[int(off[t]): int(off[t + 1])] for t in range(len(queries))]
+
+    @staticmethod
+    def _take_recs(ctx, out, ooff, T):
+        off = np.ctypeslib.as_array(ooff, shape=(T + 1,)).copy()
+        n = int(off[-1])
+        arr = np.ctypeslib.as_array(ctypes_cast_u8(out), shape=(max(n, 1) * 20,))[: n * 20].copy().view(REC_DTYPE)
+        ctx.L.fdgpu_free(out)
+        ctx.L.fdgpu_free(ooff)
+        return [arr[int(off[t]): int(off[t + 1])] for t in range(T)]
+
+    def sharded_count_query_maps(self, index, qms, penalty_shard, total_structures: int, top_n: int = 0) -> list:
+        """fdgpu_sharded_count_query_maps: the QueryMapResults of make_query_maps(index=None) scored against the sharded index — posting
+        lengths all-reduced on the device (the maps' idf is rewritten from the global lengths), local selection, one device-to-device
+        all-gather, global ranking on the device.  penalty_shard=None uses the index's resident penalty."""
+        import ctypes as C
+        from ._lib import CountRec, f32p, u64p
+        T = len(qms)
+        handles = (C.c_void_p * max(T, 1))(*[C.cast(q.handle, C.c_void_p) for q in qms])
+        pen = None if penalty_shard is None else np.ascontiguousarray(penalty_shard, np.float32)
+        out, ooff = C.POINTER(CountRec)(), u64p()
+        self.ctx.check(self.ctx.L.fdgpu_sharded_count_query_maps(self.ctx.h, self.h, index.h, T, handles, None if pen is None else pen.ctypes.data_as(f32p),
+                                                                 int(total_structures), int(top_n), C.byref(out), C.byref(ooff)))
+        return Comm._take_recs(self.ctx, out, ooff, T)
+
+    def sharded_retrieve(self, db_shard, first_id: int, resname_std_shard, cand_nids, qms, qbatch, q_structs, ca_distance_cutoff=1.0, node_count=2,
+                         nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, partial_fit=False, hash_type=3, multiple_bins=None):
+        """fdgpu_sharded_retrieve: cand_nids[t] = GLOBAL structure ids of query t's candidates in ranking order (the same on every rank).
+        -> (matches MATCH_DTYPE[], match_off, residues int32[], res_off) like query.retrieve_batch(as_arrays=True) over the whole
+        database; matches["cand"] = slot in cand_nids[t].  Identical on every rank."""
+        import ctypes as C
+        from ._lib import HashParams, MatchRec, QueryMap, u8p, u32p, u64p
+        from .query import MATCH_DTYPE
+        T = len(qms)
+        cl = [np.ascontiguousarray(c, dtype=np.uint32) for c in cand_nids]
+        cand_off = np.concatenate([[0], np.cumsum([len(c) for c in cl])]).astype(np.uint64)
+        cand = np.ascontiguousarray(np.concatenate(cl) if cl else np.zeros(0, np.uint32))
+        std = None if resname_std_shard is None else np.ascontiguousarray(resname_std_shard, np.uint8)
+        qs = np.ascontiguousarray(q_structs, np.uint32)
+        handles = (C.POINTER(QueryMap) * max(T, 1))(*[q.handle for q in qms])
+        p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type, multiple_bins)
+        mp, rp = C.POINTER(MatchRec)(), C.POINTER(C.c_int32)()
+        mo, ro = u64p(), u64p()
+        ctx = self.ctx
+        ctx.check(ctx.L.fdgpu_sharded_retrieve(ctx.h, self.h, db_shard.h, int(first_id), None if std is None else std.ctypes.data_as(u8p), T,
+                                               cand.ctypes.data_as(u32p), cand_off.ctypes.data_as(u64p), handles, qbatch.h, qs.ctypes.data_as(u32p), C.byref(p),
+                                               ca_distance_cutoff, node_count, int(bool(partial_fit)), C.byref(mp), C.byref(mo), C.byref(rp), C.byref(ro)))
+        moff = np.ctypeslib.as_array(mo, shape=(T + 1,)).copy()
+        roff = np.ctypeslib.as_array(ro, shape=(T + 1,)).copy()
+        nm, nr = int(moff[-1]), int(roff[-1])
+        isz = MATCH_DTYPE.itemsize
+        marr = np.ctypeslib.as_array(C.cast(mp, C.POINTER(C.c_uint8)), shape=(max(nm, 1) * isz,))[: nm * isz].copy().view(MATCH_DTYPE)
+        rarr = np.ctypeslib.as_array(rp, shape=(max(nr, 1),))[:nr].copy()
+        ctx.L.fdgpu_matches_free(mp, rp)
+        ctx.L.fdgpu_free(mo)
+        ctx.L.fdgpu_free(ro)
+        return marr, moff, rarr, roff
+
+
+def ctypes_cast_u8(p):
+    import ctypes as C
+    return C.cast(p, C.POINTER(C.c_uint8))
+
+
+def merge_gathered(ctx, messages: np.ndarray, world: int, n_queries: int, top_n: int) -> list:
+    """fdgpu_debug_merge_gathered: the device merge every rank runs after the all-gather, on hand-made messages (tests)"""
+    import ctypes as C
+    from ._lib import CountRec, u8p, u64p
+    msg = np.ascontiguousarray(messages, np.uint8)
+    out, ooff = C.POINTER(CountRec)(), u64p()
+    ctx.check(ctx.L.fdgpu_debug_merge_gathered(ctx.h, int(world), int(n_queries), int(top_n), msg.ctypes.data_as(u8p), C.byref(out), C.byref(ooff)))
+    return Comm._take_recs(ctx, out, ooff, n_queries)
+
+
+def build_message(ctx, per_query_recs, top_n: int, status: int = 0) -> np.ndarray:
+    """one rank's message of the device exchange (include/fdgpu.h, fdgpu_comm_message_bytes) from its ranked per-query records"""
+    T = len(per_query_recs)
+    mb = int(ctx.L.fdgpu_comm_message_bytes(T, top_n))
+    m = np.zeros(mb, np.uint8)
+    m[:16].view(np.uint32)[:] = (status, T, top_n, top_n + 1024)
+    st = m[16:16 + 16 * T].view(np.uint32).reshape(T, 4)
+    rec = m[16 + 16 * T:16 + 16 * T + 20 * T * top_n].view(REC_DTYPE).reshape(T, top_n) if T else None
+    for t, r in enumerate(per_query_recs):
+        k = min(len(r), top_n)
+        st[t, 3] = len(r) if len(r) <= top_n + 1024 else k
+        rec[t, :k] = r[:k]
+    return m
+
+
+def sharded_count_query_maps(ctx, index, qms, penalty_shard, total_structures: int, top_n: int, device=None, comm: "Comm | None" = None) -> list:
+    """The batched sharded prefilter through the fused library entry points, over either transport: with an fdgpu Comm (RCCL, one GPU per
+    rank) everything happens inside fdgpu_sharded_count_query_maps; without one (gloo: CPU tests, several ranks on one GPU) the two local
+    halves of the same call run here with torch.distributed in between — fdgpu_query_maps_lengths -> all-reduce ->
+    fdgpu_count_query_maps_top_global (idf from the global lengths, device selection of the local top_n) -> all-gather -> ranking."""
+    import ctypes as C
+    from ._lib import CountRec, f32p, u64p
+    if comm is not None:
+        return comm.sharded_count_query_maps(index, qms, penalty_shard, total_structures, top_n)
+    T = len(qms)
+    handles = (C.c_void_p * max(T, 1))(*[C.cast(q.handle, C.c_void_p) for q in qms])
+    nq = int(sum(len(q.hash) for q in qms))
+    lens = np.zeros(max(2 * nq, 1), np.uint64)
+    ctx.check(ctx.L.fdgpu_query_maps_lengths(ctx.h, index.h, T, handles, lens.ctypes.data_as(u64p)))
+    lens = np.ascontiguousarray(reduce_lengths(lens, device))
+    pen = None if penalty_shard is None else np.ascontiguousarray(penalty_shard, np.float32)
+    out, ooff = C.POINTER(CountRec)(), u64p()
+    ctx.check(ctx.L.fdgpu_count_query_maps_top_global(ctx.h, index.h, T, handles, lens.ctypes.data_as(u64p), None if pen is None else pen.ctypes.data_as(f32p),
+                                                      float(total_structures), int(top_n), C.byref(out), C.byref(ooff)))
+    local = Comm._take_recs(ctx, out, ooff, T)
+    return allgather_hits_many(local, device, top_n=top_n if top_n else None, ranked=bool(top_n))

@@ -47,6 +47,24 @@ def _pick_queries(d, S, n_queries, seed, k=4):
     return out
 
 
+def _pmc_query_traffic(S_total, world):
+    """HBM bytes per batch of the prefilter kernels from the committed rocprofv3 PMC passes of the batched query (profiles/*pmc_query_traffic_*.json,
+    tools/pmc_query_traffic.sh): sum over the kernels of 2 x FETCH_SIZE + WRITE_SIZE (gfx950 corrections as in bench.py)"""
+    import glob
+    import json
+    tag = "S%d" % S_total if world == 1 else "S%d_N%d" % (S_total, world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "*pmc_query_traffic_%s.json" % tag)), reverse=True):
+        try:
+            dd = json.load(open(f))
+            tot = sum(2.0 * v["fetch_bytes_per_launch"] * v.get("launches_per_batch", 1) + v["write_bytes_per_launch"] * v.get("launches_per_batch", 1)
+                      for v in dd["kernels"].values())
+            return {"bytes_per_launch": tot, "kernels": sorted(dd["kernels"]), "source": os.path.basename(f)}
+        except Exception:
+            continue
+    return None
+
+
 def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, match_top=32, seed=4242, lo=0, S_total=None,
         cpu_baseline_fn=None, hbm_peak_gbs=8000.0):
     S_total = S * world if S_total is None else S_total
@@ -64,10 +82,26 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     qbatches = [ctx.upload(PackedStructures.concat([it])) for _, _, it in queries]
     qall = ctx.upload(PackedStructures.concat([it for _, _, it in queries]))    # every query structure in one batch (batched legs)
     first = ix.first_id
+    # the exchange: libfdgpu's own RCCL communicator when every rank has its GPU (backend nccl), torch.distributed (gloo) otherwise —
+    # both go through the same fused library entry points (dist.sharded_count_query_maps)
+    comm = None
+    if sharded and dist.get_backend() == "nccl" and os.environ.get("FD_BENCH_COMM", "rccl") == "rccl":
+        comm = fdist.Comm(ctx, rank, world)
 
-    def set_global_idf(qm):
-        pl = fdist.global_posting_lengths(ix, qm.primary_hash, dev)
-        qm.set_idf(np.where(pl > 0, idf_of_lengths(np.maximum(pl, 1), S_total), 0.0).astype(np.float32))
+    def sharded_prefilter(qms):
+        globs = fdist.sharded_count_query_maps(ctx, ix, qms, None, S_total, top_n, dev, comm)
+        for q in qms:
+            q._cache.pop("idf", None)       # rewritten inside the library from the global posting lengths
+        return globs
+
+    def sharded_matches(globs, qms, ks):
+        """matches of the first match_top candidates of every query's GLOBAL ranking, each on the rank that owns it -> number of
+        match records over all ranks (the records themselves are all-gathered)"""
+        if comm is not None:
+            return len(comm.sharded_retrieve(batch, first, None, [g["nid"][:match_top] for g in globs], qms, qall, list(ks))[0])
+        cl = [owned(g, match_top) for g in globs]
+        marr = retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0]
+        return len(fdist.allgather_array(marr, dev))
 
     def owned(glob, n):
         """candidate slots (local structure indices) of the first n records of the global ranking that this rank owns"""
@@ -77,20 +111,17 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
 
     def one(k, match):
         s, idx, _ = queries[k]
-        qm = make_query_map(ctx, qbatches[k], idx, None, None if sharded else ix, float(S_total))
-        lens = fdist.global_posting_lengths(ix, qm.hash, dev) if sharded else None      # idf over the whole database
-        if sharded and match:
-            set_global_idf(qm)
-        if sharded:
-            recs = count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S_total, as_array=True, lengths=lens)
-            glob = fdist.allgather_hits(recs, dev, top_n=top_n)
-        else:       # one call: posting lengths, idf, scoring, top_n ranked on the device
-            glob = count_query_maps(ctx, ix, [qm], None, total_structures=S_total, top_n=top_n)[0]
+        if sharded:     # lengths all-reduced, local selection, all-gather, global ranking; matching on the owning ranks
+            qa = make_query_maps(ctx, qall, [(k, idx)], None, float(S_total))
+            glob = sharded_prefilter(qa)[0]
+            n_match = sharded_matches([glob], qa, [k]) if match else 0
+            return len(glob), len(qa[0].hash), n_match
+        qm = make_query_map(ctx, qbatches[k], idx, None, ix, float(S_total))
+        glob = count_query_maps(ctx, ix, [qm], None, total_structures=S_total, top_n=top_n)[0]     # posting lengths, idf, scoring, top_n ranked on the device
         n_match = 0
         if match and len(glob):
             cand = owned(glob, match_top)
-            ms = retrieve(ctx, batch, None, cand, qm, qbatches[k]) if len(cand) else []
-            n_match = len(ms) if not sharded else int(fdist.allreduce_sum(len(ms), dev))
+            n_match = len(retrieve(ctx, batch, None, cand, qm, qbatches[k])) if len(cand) else 0
         return len(glob), len(qm.hash), n_match
 
     def timed(fn):
@@ -127,24 +158,16 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             for c0 in range(0, len(queries), chunk):
                 ks = range(c0, min(c0 + chunk, len(queries)))
                 qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix if (match and not sharded) else None, float(S_total))
-                if match and sharded:     # idf of every query's entries from GLOBAL posting lengths: one length pass + one all-reduce per batch
-                    ph = np.concatenate([qm.primary_hash for qm in qms]) if qms else np.zeros(0, np.uint32)
-                    pl = fdist.global_posting_lengths(ix, ph, dev)
-                    gi = np.where(pl > 0, idf_of_lengths(np.maximum(pl, 1), S_total), 0.0).astype(np.float32)
-                    at = 0
-                    for qm in qms:
-                        n = len(qm.primary_hash)
-                        qm.set_idf(gi[at:at + n]); at += n
-                if sharded:     # posting lengths must be all-reduced between the length pass and the scoring
-                    recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=top_n,
-                                             lengths_fn=lambda l: fdist.reduce_lengths(l, dev))
+                if sharded:     # the same fused entry points as the single-index leg, with the exchange in between
+                    globs = sharded_prefilter(qms)
                 else:           # the query maps go back into the library as they are; the penalty is resident (set_penalty)
-                    recs = count_query_maps(ctx, ix, qms, None, total_structures=S_total, top_n=top_n)
-                globs = fdist.allgather_hits_many(recs, dev, top_n=top_n, ranked=True)
+                    globs = count_query_maps(ctx, ix, qms, None, total_structures=S_total, top_n=top_n)
                 if match:   # one pair scan / gather / Kabsch launch for the whole chunk of queries
-                    cl = [owned(g, match_top) for g in globs]
-                    marr = retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0]
-                    tot += len(fdist.allgather_array(marr, dev)) if sharded else len(marr)
+                    if sharded:
+                        tot += sharded_matches(globs, qms, ks)
+                    else:
+                        cl = [owned(g, match_top) for g in globs]
+                        tot += len(retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0])
                 else:
                     tot += sum(len(g) for g in globs)
             return tot
@@ -202,17 +225,26 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     loop(True, warm)()
     dt2, (_, _, nm) = timed(loop(True, range(len(queries))))
 
-    # ---- roofline of the scoring stage: one batch of 32 queries with HIP events on the context's stream
+    # ---- roofline of the prefilter the headline runs: one batch of 32 queries through the fused path (posting-length pass, plan, segment
+    # sums + bounds + scoring = "cq_batch"; ranking keys, radix select, records of the survivors, bitonic sort = "cq_topn"), HIP events on
+    # the context's stream.  B_q is SURVEY §8(d)'s figure for the same batch; PMC traffic from the committed profile of this command.
     ks = range(min(32, len(queries)))
-    qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], None, float(S_total))
-    lens_fn = (lambda l: fdist.reduce_lengths(l, dev)) if sharded else None
+    qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], None if sharded else ix, float(S_total))
     ctx.enable_timing(True)
-    recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=0, lengths_fn=lens_fn)
+    if sharded:
+        top = sharded_prefilter(qms)
+    else:
+        top = count_query_maps(ctx, ix, qms, None, total_structures=S_total, top_n=top_n)
     ctx.synchronize()
     st_score = {n: ms for n, ms, _ in ctx.last_timings()}
-    cl = [(fdist.rank_hits(r, match_top)["nid"].astype(np.int64) - first).astype(np.uint32) for r in recs]
-    if not sharded:
-        qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix, float(S_total))
+    ctx.enable_timing(False)
+    lens_fn = (lambda l: fdist.reduce_lengths(l, dev)) if sharded and comm is None else ((lambda l: comm.allreduce_lengths(l)) if sharded else None)
+    recs = count_query_batch(ctx, ix, [(qm.hash, qm.qi, qm.qj) for qm in qms], pen, total_structures=S_total, top_n=0, lengths_fn=lens_fn)    # every touched structure: T of B_q
+    ctx.enable_timing(True)
+    if sharded:
+        cl = [owned(g, match_top) for g in top]
+    else:
+        cl = [(g["nid"][:match_top].astype(np.int64) - first).astype(np.uint32) for g in top]
     marr = retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0]
     ctx.synchronize()
     st_match = {n: ms for n, ms, _ in ctx.last_timings()}
@@ -221,14 +253,19 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     touched = int(sum(len(r) for r in recs))
     n_rows = int(sum(len(np.unique(qm.qi)) + len(np.unique(qm.qi.astype(np.uint64) << np.uint64(32) | qm.qj.astype(np.uint64))) for qm in qms))
     b_q = post_bytes + 8 * touched + n_rows * ((S + 31) // 32) * 4
-    t_score = st_score.get("cq_batch", 0.0)
+    t_score = st_score.get("cq_batch", 0.0) + st_score.get("cq_topn", 0.0)
     cand_res = int(sum(int(nres[c].sum()) for c in cl))
     t_match = st_match.get("match_pairs", 0.0)
+    traffic = _pmc_query_traffic(S_total, world)
     roofline = {
-        "bound": "hbm", "kernel": "cq_batch (k_cq_seg + k_cq_bounds + k_cq_rows_finalize + compaction scan)", "queries_per_launch": len(ks),
+        "bound": "hbm", "kernel": "prefilter of the batched full query: cq_batch (k_cq_plan, scan, k_cq_bounds, k_cq_seg<sums>, k_cq_seg) + cq_topn "
+                                  "(k_cq_rows_keys, k_topn_thr, k_topn_hist_dense, k_topn_emit_dense, k_topn_sort)",
+        "queries_per_launch": len(ks), "top_n": top_n,
         "algorithmic_bytes_per_launch": b_q, "posting_bytes": post_bytes, "touched_structures": touched, "occupancy_rows": n_rows,
-        "avg_ms": t_score, "achieved": b_q / (t_score * 1e-3) / 1e9 if t_score > 0 else None, "peak": hbm_peak_gbs, "unit": "GB/s",
-        "frac": b_q / (t_score * 1e-3) / 1e9 / hbm_peak_gbs if t_score > 0 else None, "traffic": None,
+        "avg_ms": t_score, "stages_ms": {k: round(v, 4) for k, v in st_score.items()},
+        "achieved": b_q / (t_score * 1e-3) / 1e9 if t_score > 0 else None, "peak": hbm_peak_gbs, "unit": "GB/s",
+        "frac": b_q / (t_score * 1e-3) / 1e9 / hbm_peak_gbs if t_score > 0 else None,
+        "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
         "note": "latency bound by construction: ~%d KB of postings per query in 2 KB segments against a %d-structure shard" % (post_bytes // max(len(ks), 1) // 1024, S),
         "match_pairs": {"algorithmic_bytes_per_launch": 37 * cand_res + 16 * len(marr), "candidates": int(sum(len(c) for c in cl)), "avg_ms": t_match,
                         "achieved": (37 * cand_res + 16 * len(marr)) / (t_match * 1e-3) / 1e9 if t_match > 0 else None, "unit": "GB/s",
@@ -303,4 +340,57 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         "avg_query_hashes": hashes / len(queries), "avg_hits": hits / len(queries),
         "roofline": roofline, "whole_structure": whole, "cpu_baseline": cpu,
         "stages_ms_per_32_queries": {**st_score, **st_match},
+        "exchange": None if not sharded else {
+            "transport": "libfdgpu RCCL communicator (fdgpu_sharded_count_query_maps + fdgpu_sharded_retrieve)" if comm is not None else
+                         "torch.distributed %s around fdgpu_query_maps_lengths / fdgpu_count_query_maps_top_global" % dist.get_backend(),
+            "collectives": None if comm is None else dict(zip(("allreduce", "allgather"), comm.stats()))},
     }
+
+
+def run_replicas(ctx, batch, ix, d, S_total, world, rank, dist, dev, n_queries=64, top_n=1000, match_top=32, seed=4242, chunk=32, reps=12):
+    """SURVEY §8e, last row: the index (26 GB at Swiss-Prot scale, of 288) and the coordinates REPLICATED on every GPU, the queries sharded —
+    batch b of `chunk` queries runs on rank b % world through the single-index fused path (no data-path collective), the outputs are
+    gathered at the end (here: their counts).  queries/s = all queries / max-over-ranks wall time."""
+    queries = _pick_queries(d, S_total, n_queries, seed) if rank == 0 else None
+    if dist is not None:
+        box = [queries]
+        dist.broadcast_object_list(box, src=0, device=dev if dist.get_backend() == "nccl" else None)
+        queries = box[0]
+    nres = np.diff(d["res_off"].cpu().numpy()).astype(np.uint64)
+    ix.set_penalty(length_penalty(nres, 0.5))
+    qall = ctx.upload(PackedStructures.concat([it for _, _, it in queries]))
+    first = ix.first_id
+    starts = list(range(0, len(queries), chunk)) * reps
+
+    def go():
+        tot = 0
+        for c0 in starts[rank::world]:
+            ks = range(c0, min(c0 + chunk, len(queries)))
+            qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix, float(S_total))
+            recs = count_query_maps(ctx, ix, qms, None, total_structures=S_total, top_n=top_n)
+            cl = [(g["nid"][:match_top].astype(np.int64) - first).astype(np.uint32) for g in recs]
+            tot += len(retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0])
+        ctx.synchronize()
+        return tot
+    go()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    tot = go()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dv = dev if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=dv)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        m = torch.tensor([tot], dtype=torch.int64, device=dv)
+        dist.all_reduce(m, op=dist.ReduceOp.SUM)     # the gather of outputs, reduced to their count here
+        tot = int(m.item())
+    nq = len(queries) * reps
+    return {"value": nq / dt, "unit": "queries/s", "queries": nq, "ms_per_query": dt / nq * 1e3, "matches": tot, "replicas": world,
+            "mode": "index + coordinates replicated on every GPU, batches of %d queries dealt round-robin to the ranks, full query (prefilter top %d, "
+                    "retrieval of the top %d), one host thread per rank, no data-path collective" % (chunk, top_n, match_top)}

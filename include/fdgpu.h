@@ -308,11 +308,13 @@ int fdgpu_retrieve_batch(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *r
 void fdgpu_matches_free(fd_match_rec *m, int32_t *residues);
 
 /* ---- multi-GPU query path (one process per GPU, RCCL over xGMI) ----------------------------------------------------
- * The index is sharded by structure id (every rank holds the postings and coordinates of its own id range, fdgpu_index_build with
- * first_id or fdgpu_index_load + fdgpu_index_set_first_id).  What the reference's query workflow (src/cli/workflows/query_pdb.rs:376-452)
- * would call instead of the single-index count_query: rank 0 creates a unique id and hands it to the other ranks by any means
- * (file, MPI, env), every rank calls fdgpu_comm_init on its own context / GPU, then fdgpu_sharded_count_query per batch of queries.
- * RCCL is bound at run time (dlopen); without it these calls return FDGPU_EHIP. */
+ * The index and the coordinates are sharded by structure id (every rank holds the postings and coordinates of its own id range,
+ * fdgpu_index_build with first_id or fdgpu_index_load + fdgpu_index_set_first_id).  What the reference's query workflow
+ * (src/cli/workflows/query_pdb.rs:376-452) would call instead of the single-index count_query / retrieval: rank 0 creates a unique id and
+ * hands it to the other ranks by any means (file, MPI, env), every rank calls fdgpu_comm_init on its own context / GPU, then per batch of
+ * queries fdgpu_sharded_count_query[_maps] and fdgpu_sharded_retrieve.  RCCL is bound at run time (dlopen); without it these calls return
+ * FDGPU_EHIP.  The collectives are issued for every world size, one included.  A rank whose local step fails still takes part in the
+ * call's collectives (its message carries the error) and every rank returns an error: no rank is left waiting. */
 #define FDGPU_COMM_ID_BYTES 128
 typedef struct fdgpu_comm fdgpu_comm;
 int fdgpu_comm_unique_id(uint8_t id[FDGPU_COMM_ID_BYTES]);
@@ -320,17 +322,53 @@ int fdgpu_comm_init(fdgpu_ctx *ctx, const uint8_t id[FDGPU_COMM_ID_BYTES], int r
 void fdgpu_comm_destroy(fdgpu_comm *comm);
 int fdgpu_comm_rank(const fdgpu_comm *comm);
 int fdgpu_comm_world(const fdgpu_comm *comm);
+/* collectives this communicator has issued so far (ncclAllReduce / ncclAllGather calls) */
+int fdgpu_comm_stats(const fdgpu_comm *comm, uint64_t *n_allreduce, uint64_t *n_allgather);
 /* lengths[k] <- sum over the ranks (ncclAllReduce): posting lengths of a shard -> posting lengths over the whole database, the
  * denominator of idf = log2(S / len) (src/controller/query.rs:17-32, count_query.rs:130) */
 int fdgpu_allreduce_lengths(fdgpu_ctx *ctx, fdgpu_comm *comm, uint64_t *lengths, uint64_t n);
 /* count_query of a batch of queries against the sharded index: every rank passes the same queries (layout of
- * fdgpu_count_query_batch, no idf: it is computed here from the all-reduced posting lengths with log2f) and its own shard + penalty
- * (one entry per structure of the shard).  The ranks score locally, all-gather their candidate records (ncclAllGather) and rank them:
- * per query (*out)[(*out_off)[t] .. (*out_off)[t+1]) = the global ranking (idf descending, nid ascending; query_pdb.rs:404-411)
- * truncated to top_n (0 = every touched structure), identical on every rank.  nid = global structure id. */
+ * fdgpu_count_query_batch, no idf: it is computed here from the posting lengths all-reduced on the device, with log2f) and its own shard +
+ * penalty (one entry per structure of the shard; NULL = the resident copy of fdgpu_index_set_penalty).  The ranks score locally, select
+ * their top_n on the device, all-gather selection state + ranked records in one device-to-device ncclAllGather and select / rank the union
+ * on the device: per query (*out)[(*out_off)[t] .. (*out_off)[t+1]) = the global ranking (idf descending, nid ascending;
+ * query_pdb.rs:404-411) truncated to top_n, identical on every rank.  nid = global structure id.  top_n = 0 (every touched structure)
+ * and top_n > 3072 exchange variable-length lists instead (counts, then one padded payload) and rank on the host. */
 int fdgpu_sharded_count_query(fdgpu_ctx *ctx, fdgpu_comm *comm, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off,
                               const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j, const float *penalty,
                               uint64_t total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off);
+/* The same for the query maps of fdgpu_make_query_map[_batch] (made with index = NULL): the sharded sibling of
+ * fdgpu_count_query_maps_top.  One all-reduce carries the posting lengths of every map's hash[] (scoring idf) and primary_hash[]; the
+ * maps' idf[] — the retrieval's subgraph idf (query.rs:283-288) — is REWRITTEN in place from the global lengths, so the maps can go on to
+ * fdgpu_sharded_retrieve. */
+int fdgpu_sharded_count_query_maps(fdgpu_ctx *ctx, fdgpu_comm *comm, const fdgpu_index *ix, uint64_t n_queries, fd_query_map *const *qms,
+                                   const float *penalty, uint64_t total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off);
+/* Retrieval against sharded coordinates (the candidate loop of query_pdb.rs:415-452): query t's candidates
+ * cand_nid[cand_off[t] .. cand_off[t+1]) are GLOBAL structure ids in ranking order, the same on every rank; `db` holds the structures
+ * first_id .. first_id + n - 1 of this rank.  Every candidate is matched on the rank that owns it, the match records and residue lists
+ * are all-gathered (counts, then one padded payload) and merged by candidate slot: the output equals fdgpu_retrieve_batch over the whole
+ * database with cand = the global lists (fd_match_rec.cand = slot in the query's list), identical on every rank.  Release like
+ * fdgpu_retrieve_batch's outputs. */
+int fdgpu_sharded_retrieve(fdgpu_ctx *ctx, fdgpu_comm *comm, const fdgpu_batch *db, uint64_t first_id, const uint8_t *resname_std,
+                           uint64_t n_queries, const uint32_t *cand_nid, const uint64_t *cand_off, const fd_query_map *const *qms,
+                           const fdgpu_batch *qb, const uint32_t *q_struct, const fd_hash_params *p, float ca_distance_cutoff,
+                           uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches, uint64_t **match_off, int32_t **residues,
+                           uint64_t **res_off);
+/* For hosts with their own transport (MPI, gloo): the two local halves of fdgpu_sharded_count_query_maps.  fdgpu_query_maps_lengths
+ * writes the LOCAL posting lengths of all maps' hash[] (sum(n) values, maps in order) followed by all maps' primary_hash[] (sum(n) more);
+ * the caller sums the 2 * sum(n) values over the ranks and hands them to fdgpu_count_query_maps_top_global, which rewrites the maps' idf[]
+ * and scores the local shard (output as fdgpu_count_query_maps_top: this rank's top_n, ranked). */
+int fdgpu_query_maps_lengths(fdgpu_ctx *ctx, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, uint64_t *lengths);
+int fdgpu_count_query_maps_top_global(fdgpu_ctx *ctx, const fdgpu_index *ix, uint64_t n_queries, fd_query_map *const *qms,
+                                      const uint64_t *global_lengths, const float *penalty, float total_structures, uint32_t top_n,
+                                      fd_count_rec **out, uint64_t **out_off);
+/* The per-rank message of the device exchange: {u32 status, n_queries, top_n, cap} | {u32 x3, u32 count}[n_queries] |
+ * fd_count_rec[n_queries][top_n], padded to 16 bytes.  fdgpu_debug_merge_gathered runs what every rank runs after the all-gather — unpack,
+ * global selection, ranking, all on the device — on `world` such messages given as one host array (tests drive the multi-rank code with it
+ * on a single GPU).  0 < top_n <= 3072. */
+uint64_t fdgpu_comm_message_bytes(uint64_t n_queries, uint32_t top_n);
+int fdgpu_debug_merge_gathered(fdgpu_ctx *ctx, uint32_t world, uint64_t n_queries, uint32_t top_n, const uint8_t *messages,
+                               fd_count_rec **out, uint64_t **out_off);
 
 /* ---- structure ingest (host, multi-threaded) ---------------------------------------------------------------
  * PDB / mmCIF text (optionally gzip) -> the packed arrays of fd_batch_desc plus what the .lookup file and the result

@@ -52,6 +52,26 @@ for s, idx, item in queries:
         print("QUERY", s, "records", len(recs), "same" if same_recs else "DIFFERENT", "matches", len(a), "same" if a == b else "DIFFERENT",
               "both-shards" if both else "one-shard", flush=True)
         ok = ok and same_recs and a == b and len(recs) == 200 and len(a) >= 1
+# the fused batched form (what bench.py's sharded leg runs under gloo): query maps without an index -> fdgpu_query_maps_lengths -> all-reduce
+# -> fdgpu_count_query_maps_top_global (device selection of the shard's top_n) -> all-gather -> ranking, then retrieval on the owning rank
+qall = ctx.upload(fd.PackedStructures.concat([it for _, _, it in queries]))
+qlist = [(k, queries[k][1]) for k in range(len(queries))]
+maps = fq.make_query_maps(ctx, qall, qlist, None, float(S))
+ix.set_penalty(pen_shard)
+globs = fdist.sharded_count_query_maps(ctx, ix, maps, None, S, 200, None, None)
+for m in maps:
+    m._cache.pop("idf", None)
+cl = [(g["nid"][:20][(g["nid"][:20] >= lo) & (g["nid"][:20] < hi)] - lo).astype(np.uint32) for g in globs]
+marr = fq.retrieve_batch(ctx, shard, None, cl, maps, qall, list(range(len(maps))), as_arrays=True)
+n_all = len(fdist.allgather_array(marr[0]))
+if rank == 0:
+    fix.set_penalty(pen)
+    ref_maps = fq.make_query_maps(ctx, qall, qlist, fix, float(S))
+    want = fd.api.count_query_maps(ctx, fix, ref_maps, None, total_structures=S, top_n=200)
+    same = all(g.tobytes() == w.tobytes() for g, w in zip(globs, want)) and all(np.array_equal(m.idf, r.idf) for m, r in zip(maps, ref_maps))
+    wm = fq.retrieve_batch(ctx, full, None, [w["nid"][:20] for w in want], ref_maps, qall, list(range(len(maps))), as_arrays=True)
+    print("FUSED", "same" if same else "DIFFERENT", "matches", n_all, "same" if n_all == len(wm[0]) else "DIFFERENT", flush=True)
+    ok = ok and same and n_all == len(wm[0]) and n_all > 0
 dist.barrier()
 if rank == 0:
     print("SHARDED_OK" if ok else "SHARDED_MISMATCH", flush=True)

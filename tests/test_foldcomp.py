@@ -81,6 +81,18 @@ def test_malformed_entries_are_rejected():
     bad = bytearray(buf)
     bad[first_res + 8] = (20 << 3) | (bad[first_res + 8] & 7)
     assert isinstance(product_decode(bytes(bad)), int)
+    # hostile anchor indices (3 * index wraps a 32-bit int; non-monotone; out of range) cost the entry, not the process
+    a0 = 4 + 72
+    for i0, i1 in ((0x2AAAAAAB, 272), (5, 3), (-1, 10), (0, 10 ** 6)):
+        bad = bytearray(buf)
+        bad[a0:a0 + 4] = int(i0 & 0xffffffff).to_bytes(4, "little")
+        bad[a0 + 4:a0 + 8] = int(i1 & 0xffffffff).to_bytes(4, "little")
+        assert isinstance(product_decode(bytes(bad)), int), (i0, i1)
+    # counts in the header larger than the entry: refused before anything is allocated with them
+    for field_off in (4 + 0, 4 + 8, 4 + 12, 4 + 20):      # n_residue, n_anchor, n_side_torsion (u16 / u32 fields), len_title
+        bad = bytearray(buf)
+        bad[field_off:field_off + 2] = b"\xff\xff"
+        assert isinstance(product_decode(bytes(bad)), int), field_off
 
 
 def gold_atoms_as_tuples(rec):

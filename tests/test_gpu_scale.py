@@ -147,31 +147,126 @@ def test_sharded_query_equals_single_index_at_ecoli_scale():
 
 
 def test_c_abi_communicator_world_1(ecoli):
-    """fdgpu_comm_* / fdgpu_sharded_count_query (csrc/fd_comm.hip: RCCL bound with dlopen): with one rank the sharded prefilter is the
-    single-index one — posting lengths, idf, device top-N, global ranking — and the communicator really is an RCCL communicator
-    (ncclCommInitRank on this GPU).  The N > 1 exchange is ncclAllReduce / ncclAllGather of the same buffers."""
+    """fdgpu_comm_* / fdgpu_sharded_count_query[_maps] / fdgpu_sharded_retrieve (csrc/fd_comm.hip: RCCL bound with dlopen) with one rank:
+    the collectives are NOT short-cut — every call below issues its ncclAllReduce / ncclAllGather on this GPU (fdgpu_comm_stats counts
+    them) and unpacks through the same stride / per-rank code the N-rank path runs — and the results equal the single-index calls."""
     import folddisco_amd as fd
     from folddisco_amd import dist as fdist
     from folddisco_amd import querybench
-    from folddisco_amd.query import make_query_map
+    from folddisco_amd.query import make_query_map, make_query_maps, retrieve_batch
     ctx, ps, batch, ix, first_id = ecoli
     comm = fdist.Comm(ctx, 0, 1)
     assert len(comm.unique_id) == 128 and any(comm.unique_id)
+    assert comm.stats() == (0, 0)
     lens = np.array([3, 0, 2 ** 40 + 7], np.uint64)
     assert np.array_equal(comm.allreduce_lengths(lens), lens)
+    assert comm.stats() == (1, 0)                                          # ncclAllReduce ran
     import torch
     d = dict(res_off=torch.from_numpy(ps.res_off.astype(np.int64)), n_xyz=torch.from_numpy(ps.n_xyz), ca_xyz=torch.from_numpy(ps.ca_xyz),
              cb_xyz=torch.from_numpy(ps.cb_xyz), aa=torch.from_numpy(ps.aa))
     pen = fd.length_penalty(np.diff(ps.res_off).astype(np.uint64), 0.5)
+    picked = querybench._pick_queries(d, ECOLI, 5, seed=2)
     qs = []
-    for s, idx, item in querybench._pick_queries(d, ECOLI, 5, seed=2):
+    for s, idx, item in picked:
         qm = make_query_map(ctx, ctx.upload(fd.PackedStructures.concat([item])), idx, None, ix, float(ECOLI))
         qs.append((qm.hash, qm.qi, qm.qj))
     qs.append((np.array([0x3ffffff0], np.uint32), np.zeros(1, np.uint32), np.ones(1, np.uint32)))      # a query without hits
-    for top_n in (0, 50):
+    for top_n, gathers in ((0, 2), (50, 1), (4000, 2)):        # lists: counts + payload; device path: ONE gather of state + ranked records
+        a0, g0 = comm.stats()
         got = comm.sharded_count_query(ix, qs, pen, ECOLI, top_n=top_n)
+        assert comm.stats() == (a0 + 1, g0 + gathers)
         for g, (qh, qi, qj) in zip(got, qs):
             want = fdist.rank_hits(fd.count_query(ctx, ix, qh, qi, qj, pen, total_structures=ECOLI, as_array=True), top_n or None)
             assert g.tobytes() == want.tobytes()
         assert len(got[-1]) == 0 and len(got[0]) > 0
+    # query maps straight into the sharded call (made WITHOUT an index: a shard's lengths mean nothing) == the single-index fused call;
+    # the maps' idf is rewritten from the all-reduced lengths of primary_hash
+    qall = ctx.upload(fd.PackedStructures.concat([it for _, _, it in picked]))
+    qlist = [(k, picked[k][1]) for k in range(len(picked))]
+    ix.set_penalty(pen)
+    ref_maps = make_query_maps(ctx, qall, qlist, ix, float(ECOLI))
+    want = fd.api.count_query_maps(ctx, ix, ref_maps, None, total_structures=ECOLI, top_n=100)
+    maps = make_query_maps(ctx, qall, qlist, None, float(ECOLI))
+    assert not np.any(maps[0].idf)
+    a0, g0 = comm.stats()
+    got = comm.sharded_count_query_maps(ix, maps, None, ECOLI, top_n=100)
+    assert comm.stats() == (a0 + 1, g0 + 1)
+    for m in maps:
+        m._cache.pop("idf", None)
+    for g, w, m, r in zip(got, want, maps, ref_maps):
+        assert g.tobytes() == w.tobytes() and len(g) == 100
+        assert np.array_equal(m.idf, r.idf) and np.any(m.idf)
+    # the gloo form of the same call (both local halves through the C ABI, no process group = no exchange) agrees too
+    maps2 = make_query_maps(ctx, qall, qlist, None, float(ECOLI))
+    got2 = fdist.sharded_count_query_maps(ctx, ix, maps2, None, ECOLI, 100, None, None)
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(got2, want))
+    # sharded retrieval: global candidate ids in, matches of the owning rank gathered and merged == retrieve_batch on the database
+    cand_nids = [g["nid"][:12] for g in got]
+    cand_nids[1] = np.concatenate([cand_nids[1][:5], np.array([first_id + ECOLI + 7, 3], np.uint32)])      # ids no rank owns: no matches, slots kept
+    a0, g0 = comm.stats()
+    marr, moff, rarr, roff = comm.sharded_retrieve(batch, first_id, None, cand_nids, maps, qall, list(range(len(maps))))
+    assert comm.stats() == (a0, g0 + 2)
+    local = [(c[(c >= first_id) & (c < first_id + ECOLI)] - first_id).astype(np.uint32) for c in cand_nids]
+    wm, wmo, wr, wro = retrieve_batch(ctx, batch, None, local, ref_maps, qall, list(range(len(maps))), as_arrays=True)
+    assert np.array_equal(moff, wmo) and np.array_equal(roff, wro) and np.array_equal(rarr, wr) and len(marr) > 0
+    for t in range(len(maps)):
+        own = np.nonzero((cand_nids[t] >= first_id) & (cand_nids[t] < first_id + ECOLI))[0]
+        a, b = int(moff[t]), int(moff[t + 1])
+        assert np.array_equal(marr["cand"][a:b], own[wm["cand"][a:b]])                     # slot in the GLOBAL list
+    for f in marr.dtype.names:
+        if f != "cand":
+            assert np.array_equal(marr[f], wm[f]), f
     comm.close()
+
+
+def test_device_merge_of_gathered_messages():
+    """What every rank runs after the all-gather (fd_comm.hip: k_comm_plan / k_comm_pack, the radix select and bitonic sort of the union,
+    all on the device) driven with hand-made contributions of 3 and 8 ranks: different lengths per rank and query, empty contributions,
+    idf ties across ranks (broken by ascending nid), fewer records than top_n, more ties at the cut-off than the selection holds (the host
+    ranks that call), a rank reporting an error."""
+    import folddisco_amd as fd
+    from folddisco_amd import dist as fdist
+    from folddisco_amd.api import REC_DTYPE, FdgpuError
+    ctx = fd.Context(0)
+    rng = np.random.Generator(np.random.PCG64(99))
+
+    def contribution(n, lo, hi, tie=None):
+        r = np.zeros(n, REC_DTYPE)
+        r["nid"] = np.sort(rng.choice(np.arange(lo, hi), size=n, replace=False)).astype(np.uint32)
+        r["total_match_count"] = rng.integers(1, 50, n)
+        r["node_count"] = rng.integers(1, 5, n)
+        r["edge_count"] = rng.integers(1, 9, n)
+        r["idf"] = (rng.integers(0, 40, n) / 8.0 if tie else rng.random(n) * 30.0).astype(np.float32)
+        return fdist.rank_hits(r)
+
+    for W, T, top_n in ((3, 5, 64), (8, 33, 1000), (2, 1, 3072)):
+        per_rank = []
+        for r in range(W):
+            lists = []
+            for t in range(T):
+                n = int(rng.integers(0, top_n + 1)) if (r + t) % 4 else 0          # some empty contributions
+                if t == 2:
+                    n = min(top_n, 7)                                             # fewer than top_n over all ranks
+                lists.append(contribution(n, r * 100000, (r + 1) * 100000, tie=(t % 2 == 0)))
+            per_rank.append(lists)
+        msgs = np.concatenate([fdist.build_message(ctx, per_rank[r], top_n) for r in range(W)])
+        assert len(msgs) == W * int(ctx.L.fdgpu_comm_message_bytes(T, top_n))
+        got = fdist.merge_gathered(ctx, msgs, W, T, top_n)
+        for t in range(T):
+            want = fdist.rank_hits(np.concatenate([per_rank[r][t] for r in range(W)]), top_n)
+            assert got[t].tobytes() == want.tobytes(), (W, T, top_n, t)
+    # more than top_n + 1024 records tie at the cut-off: the device selection overflows and the packed lists are ranked on the host
+    W, T, top_n = 4, 2, 600
+    per_rank = []
+    for r in range(W):
+        a = contribution(600, r * 1000, (r + 1) * 1000)
+        a["idf"] = np.float32(5.0)
+        per_rank.append([a, contribution(10, r * 1000, (r + 1) * 1000)])
+    msgs = np.concatenate([fdist.build_message(ctx, per_rank[r], top_n) for r in range(W)])
+    got = fdist.merge_gathered(ctx, msgs, W, T, top_n)
+    for t in range(T):
+        assert got[t].tobytes() == fdist.rank_hits(np.concatenate([per_rank[r][t] for r in range(W)]), top_n).tobytes()
+    # a rank whose local step failed: every rank sees the status and fails the call
+    bad = np.concatenate([fdist.build_message(ctx, per_rank[0], top_n), fdist.build_message(ctx, [per_rank[1][0][:0]] * T, top_n, status=2)])
+    with pytest.raises(FdgpuError, match="rank 1 failed"):
+        fdist.merge_gathered(ctx, bad, 2, T, top_n)
