@@ -1,0 +1,344 @@
+"""BASELINE.json configs 4 and 5 at their OWN sizes on one MI355X: 542,000 structures (Swiss-Prot scale, the bench's database) and
+2,000,000 structures (AFDB50 scale).  The oracle cannot build an index of this size in test time, so parity rests on
+
+* the S1 entry point (fdgpu_hash_batch: an independent kernel — ordered pairs, exact libm chain — pinned to the oracle at small sizes)
+  for SAMPLED structures against the decoded posting lists, in both directions (indextable.rs:171-295 semantics: every (hash, id) of a
+  structure is in the hash's list; every id of a list that belongs to a sampled structure really holds the hash; ids strictly ascend);
+* the oracle itself for everything per query: query map (bit-identical hashes / idf, the oracle reading posting lengths from a
+  host index re-encoded from the device's own decoded lists), count_query over ALL structures (count_query.rs:82-220), and retrieval of
+  the top candidates (retrieve.rs), on motifs of the reference's shipped query files planted into known structures;
+* at 2,000,000: every structure id beyond 2^21 (the database starts at id 2,100,000 like a late shard would: every list opens with a
+  4-byte varint), a whole-structure query (no -q) whose prefilter is recounted on sampled structures from their S1 lists and whose
+  top 20 go through oracle.retrieve.
+
+Both databases are built the way bench.py builds them: blocks of 67,750 structures, one fdgpu_index_build per block, merged on the device
+(fdgpu_index_merge; at 2,000,000 in two rounds: 8 blocks at a time, then the four group indices)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+GEN_BLOCK = 67750
+SEED = 20260927
+
+
+def _encode_lists(hashes, lists):
+    """host index (hashes, offsets, value bytes) of the reference's layout from decoded posting lists (ascending hashes)"""
+    ids = np.concatenate(lists).astype(np.uint64) if lists else np.zeros(0, np.uint64)
+    lens = np.array([len(l) for l in lists], np.int64)
+    first = np.zeros(len(ids), bool)
+    first[np.concatenate([[0], np.cumsum(lens)[:-1]])[lens > 0]] = True
+    delta = ids.copy()
+    delta[1:] = np.where(first[1:], ids[1:], ids[1:] - ids[:-1])
+    nb = np.ones(len(delta), np.int64)
+    for k in range(1, 6):
+        nb += (delta >= (np.uint64(1) << np.uint64(7 * k))).astype(np.int64)
+    pos = np.concatenate([[0], np.cumsum(nb)])
+    value = np.zeros(int(pos[-1]), np.uint8)
+    rem = delta.copy()
+    for k in range(int(nb.max()) if len(nb) else 0):
+        sel = nb > k
+        value[pos[:-1][sel] + k] = (rem[sel] & np.uint64(0x7f)).astype(np.uint8) | ((nb[sel] > k + 1).astype(np.uint8) << 7)
+        rem[sel] >>= np.uint64(7)
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    return np.ascontiguousarray(hashes, np.uint32), pos[starts].astype(np.uint64), value
+
+
+def _mini_index(ix, hashes, real_ids=True):
+    """oracle.BorrowedIndex over the posting lists of `hashes` only.  real_ids=False: lists of the right LENGTH with zero bytes (what
+    make_query_map reads is get_entries(h).len(), query.rs:17-32) — for query maps of 10^5 hashes"""
+    hs = np.unique(np.asarray(hashes, np.uint32))
+    if real_ids:
+        lists = ix.get_entries(hs)
+        keep = np.array([len(l) > 0 for l in lists])
+        h, o, v = _encode_lists(hs[keep], [l for l in lists if len(l)])
+    else:
+        lens = ix.posting_lengths(hs).astype(np.int64)
+        keep = lens > 0
+        h = np.ascontiguousarray(hs[keep])
+        o = np.concatenate([[0], np.cumsum(lens[keep])]).astype(np.uint64)
+        v = np.zeros(int(o[-1]), np.uint8)
+    return oracle.BorrowedIndex(h, o, v), (h, o, v)
+
+
+def _item(d, s):
+    a, b = int(d["res_off"][s]), int(d["res_off"][s + 1])
+    return dict(n_xyz=d["n_xyz"][a:b].cpu().numpy(), ca_xyz=d["ca_xyz"][a:b].cpu().numpy(), cb_xyz=d["cb_xyz"][a:b].cpu().numpy(), aa=d["aa"][a:b].cpu().numpy())
+
+
+def _ostruct(it):
+    return oracle.structure_from_packed(it["n_xyz"], it["ca_xyz"], it["cb_xyz"], it["aa"])
+
+
+def _sampled_posting_checks(ctx, ix, items, ids, n_pairs, rng, id_lo, id_hi):
+    """both directions between the S1 hash lists of the sampled structures (items, global ids) and the index's decoded posting lists"""
+    import folddisco_amd as fd
+    hs, off = fd.get_geometric_hash_as_u32(ctx, ctx.upload(fd.PackedStructures.concat(items)))
+    ids = np.asarray(ids, np.int64)
+    pick = rng.choice(len(hs), min(n_pairs, len(hs)), replace=False)
+    sid_of = ids[np.searchsorted(off, pick, side="right") - 1]
+    lists = ix.get_entries(hs[pick])
+    for s, l in zip(sid_of, lists):                                      # structure -> index
+        k = np.searchsorted(l, s)
+        assert k < len(l) and int(l[k]) == int(s)
+    own = {int(s): hs[int(off[k]):int(off[k + 1])] for k, s in enumerate(ids)}       # sorted unique per structure
+    n_back = 0
+    for hq, l in zip(hs[pick], lists):                                   # index -> structure
+        assert np.all(l[1:] > l[:-1]) and int(l[0]) >= id_lo and int(l[-1]) < id_hi
+        for s in np.intersect1d(l, ids):
+            o = own[int(s)]
+            k = np.searchsorted(o, hq)
+            assert k < len(o) and int(o[k]) == int(hq)
+            n_back += 1
+    assert n_back >= len(pick)
+    lens = ix.posting_lengths(hs[pick])
+    assert np.array_equal(lens, [len(l) for l in lists])
+    return hs, off
+
+
+def _plant(d, sid, motif, rng):
+    """overwrite the LAST residues of structure sid (device tensors) with a rigidly moved copy of the motif"""
+    import torch
+    from tests.test_gpu_configs import _rot
+    k = len(motif["aa"])
+    b = int(d["res_off"][sid + 1])
+    a = b - k
+    assert a - int(d["res_off"][sid]) >= 20
+    R, tr = _rot(rng), rng.normal(0, 30, 3) + 60.0
+    for key in ("n_xyz", "ca_xyz", "cb_xyz"):
+        x = np.round(motif[key].astype(np.float64) @ R.T + tr, 3).astype(np.float32)
+        d[key][a:b] = torch.from_numpy(x).to(d[key].device)
+    d["aa"][a:b] = torch.from_numpy(motif["aa"]).to(d["aa"].device)
+
+
+def _shipped_query(name):
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    from tests.test_gpu_configs import _parse_query_file
+    path, qstr = _parse_query_file(name)
+    q = st.read_compact_structure(path)
+    res = fq.parse_query_string(qstr, q.chains[0])
+    pairs = [(q.get_index(c, r), s) for c, r, s in res]
+    idx = np.array([i for i, _ in pairs])
+    motif = dict(n_xyz=q.n_xyz[idx], ca_xyz=q.ca_xyz[idx], cb_xyz=q.cb_xyz[idx], aa=q.aa[idx])
+    return dict(name=name, path=path, qstr=qstr, q=q, idx=idx.astype(np.uint32), subs=[s for _, s in pairs], motif=motif)
+
+
+def _wrap(ctx, d):
+    n = len(d["res_off"]) - 1
+    ro = d["res_off"].contiguous()
+    keep = (ro, d["n_xyz"], d["ca_xyz"], d["cb_xyz"], d["aa"])
+    return ctx.wrap_device(n, int(ro[-1].item()), ro.data_ptr(), d["n_xyz"].data_ptr(), d["ca_xyz"].data_ptr(), d["cb_xyz"].data_ptr(), d["aa"].data_ptr(), None,
+                           keepalive=keep)
+
+
+def test_swissprot_scale_542000_index_and_planted_motifs():
+    """configs[3]'s database on one GPU: 8 build calls merged on the device; sampled posting checks; two shipped motifs planted into 16
+    structures each (first and last block included): query map, count_query over all 542,000 structures and the matches of the top 40
+    candidates equal the oracle's"""
+    import torch
+    import folddisco_amd as fd
+    from folddisco_amd import dist as fdist
+    from folddisco_amd import query as fq
+    from folddisco_amd import synth
+    from tests.test_gpu_configs import _check_matches
+    S = 542000
+    dev = torch.device("cuda", 0)
+    ctx = fd.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)      # the generator's stream: wrapped tensors are ordered with the builds
+    rng = np.random.Generator(np.random.PCG64(542))
+    queries = [_shipped_query("serine_peptidase.txt"), _shipped_query("zinc_finger.txt")]
+    n_blocks = -(-S // GEN_BLOCK)
+    for Q in queries:
+        Q["planted"] = []
+    blocks, parts, fid = [], [], 0
+    for b in range(n_blocks):
+        d = synth.generate(min(GEN_BLOCK, S - b * GEN_BLOCK), seed=SEED + 1000 * b, device=dev)
+        nres_b = np.diff(d["res_off"].cpu().numpy())
+        ok = rng.permutation(np.nonzero(nres_b >= 60)[0])
+        for k, Q in enumerate(queries):        # 16 copies per motif: two per block, every block, distinct structures
+            for sid in ok[2 * k:2 * k + 2]:
+                _plant(d, int(sid), Q["motif"], rng)
+                Q["planted"].append(b * GEN_BLOCK + int(sid))
+        blocks.append(d)
+        parts.append(fd.FolddiscoIndex.build(ctx, _wrap(ctx, d), first_id=fid))
+        fid += len(d["res_off"]) - 1
+    ix = fd.FolddiscoIndexSet(parts).merge()
+    assert ix.n_structures == S and ix.num_postings == sum(p.num_postings for p in parts)
+    del parts
+    # ---- sampled posting checks: 12 structures of every block
+    items, ids = [], []
+    for b, d in enumerate(blocks):
+        for s in np.sort(rng.choice(len(d["res_off"]) - 1, 12, replace=False)):
+            items.append(_item(d, int(s))); ids.append(b * GEN_BLOCK + int(s))
+    _sampled_posting_checks(ctx, ix, items, ids, 3000, rng, 0, S)
+    # ---- the whole database as one resident batch (retrieval reads the candidates' coordinates)
+    d_all = {k: torch.cat([b[k] for b in blocks]) for k in ("n_xyz", "ca_xyz", "cb_xyz", "aa")}
+    offs, base = [blocks[0]["res_off"][:1]], 0
+    for b in blocks:
+        offs.append(b["res_off"][1:] + base)
+        base += int(b["res_off"][-1].item())
+    d_all["res_off"] = torch.cat(offs).contiguous()
+    blocks = None
+    db = _wrap(ctx, d_all)
+    res_off = d_all["res_off"].cpu().numpy()
+    nres = np.diff(res_off).astype(np.uint64)
+    pen = fd.length_penalty(nres, 0.5)
+
+    class _PS:      # what _check_matches reads
+        pass
+    for Q in queries:
+        qb = ctx.upload(fd.PackedStructures.concat([Q["q"].as_item()]))
+        qm = fq.make_query_map(ctx, qb, Q["idx"], Q["subs"], ix, float(S))
+        oix, keep = _mini_index(ix, np.concatenate([qm.hash, qm.primary_hash]))
+        oq = oracle.read_pdb(Q["path"])
+        om = oracle.make_query_map(oq, Q["qstr"], oix, float(S))
+        oa = om.arrays()
+        assert np.array_equal(qm.hash, oa["hash"]) and np.array_equal(qm.qi, oa["qi"]) and np.array_equal(qm.qj, oa["qj"])
+        assert np.array_equal(qm.idf.view(np.uint32), oa["idf"].view(np.uint32))
+        recs = fd.count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S, as_array=True)
+        want = oracle.count_query(om, oix, nres)
+        assert len(recs) == len(want) and len(recs) > 1000
+        wn = np.array([(w["nid"], w["total_match_count"], w["node_count"], w["edge_count"]) for w in want], np.int64)
+        assert np.array_equal(np.stack([recs["nid"], recs["total_match_count"], recs["node_count"], recs["edge_count"]], axis=1).astype(np.int64), wn)
+        assert np.allclose(recs["idf"], [w["idf"] for w in want], rtol=1e-5, atol=0)
+        by = dict(zip(recs["nid"].tolist(), recs["node_count"].tolist()))
+        assert all(by.get(int(s), 0) == len(Q["idx"]) for s in Q["planted"])            # every exact copy carries the whole motif
+        # the fused batched entry point ranks the same records on the device
+        top = fd.count_query_maps(ctx, ix, [qm], pen, total_structures=S, top_n=1000)[0]
+        assert top.tobytes() == fdist.rank_hits(recs, 1000).tobytes()
+        cand = top["nid"][:40].astype(np.uint32)
+        assert len(np.intersect1d(cand, Q["planted"])) >= 12                             # the planted copies lead the ranking
+        got = fq.retrieve(ctx, db, None, cand, qm, qb)
+        ps = _PS()
+        ps.res_off = res_off
+        for key in ("n_xyz", "ca_xyz", "cb_xyz", "aa"):
+            setattr(ps, key, _Lazy(d_all[key]))
+        n = _check_matches(got, cand, ps, oq, om)
+        full = [g for g in got if sum(1 for x in g["processed"] if x >= 0) == len(Q["idx"])]
+        assert n >= 12 and len(full) >= 12 and min(g["rmsd"] for g in full) < 0.01
+
+
+class _Lazy:
+    """numpy-style row slicing of a device tensor (only the candidates' rows ever reach the host)"""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __getitem__(self, sl):
+        return self.t[sl].cpu().numpy()
+
+
+def test_afdb50_scale_2000000_ids_beyond_2_21_and_whole_structure_query():
+    """configs[4] on one GPU: 2,000,000 structures with ids 2,100,000 .. 4,099,999 (a shard that starts late: every id lies beyond
+    2^21 = 2,097,152, so every list opens with a 4-byte varint), built as 30 calls merged in two rounds; sampled posting checks in the first,
+    a middle and the last block; one whole-structure query (no -q) cut from the LAST block: prefilter recounted on sampled structures
+    from their S1 lists, the device ranking against the ranking of the full record list, the top 20 against oracle.retrieve"""
+    import torch
+    import folddisco_amd as fd
+    from folddisco_amd import dist as fdist
+    from folddisco_amd import query as fq
+    from folddisco_amd import synth
+    import time
+    S, FIRST = 2000000, 2100000
+    T0 = [time.perf_counter()]
+
+    def lap(what):
+        t = time.perf_counter()
+        print("[2M] %-28s %6.1f s" % (what, t - T0[0]), flush=True)
+        T0[0] = t
+    dev = torch.device("cuda", 0)
+    ctx = fd.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)      # the generator's stream: wrapped tensors are ordered with the builds
+    rng = np.random.Generator(np.random.PCG64(2000000))
+    n_blocks = -(-S // GEN_BLOCK)
+    host, nres_all = [], []
+    groups, parts, fid = [], [], FIRST
+    for b in range(n_blocks):
+        d = synth.generate(min(GEN_BLOCK, S - b * GEN_BLOCK), seed=SEED + 7 + 1000 * b, device=dev)
+        parts.append(fd.FolddiscoIndex.build(ctx, _wrap(ctx, d), first_id=fid))
+        fid += len(d["res_off"]) - 1
+        ctx.synchronize()
+        host.append({k: d[k].cpu() for k in ("res_off", "n_xyz", "ca_xyz", "cb_xyz", "aa")})      # coordinates wait on the host (24 GB): HBM is for the index
+        nres_all.append(np.diff(host[-1]["res_off"].numpy()))
+        d = None
+        if len(parts) == 8 or b == n_blocks - 1:
+            groups.append(fd.FolddiscoIndexSet(parts).merge() if len(parts) > 1 else parts[0])
+            parts = []
+            torch.cuda.empty_cache()
+    lap("generate + build + group merges")
+    n_post = sum(g.num_postings for g in groups)
+    ix = fd.FolddiscoIndexSet(groups).merge()
+    del groups
+    assert ix.n_structures == S and ix.first_id == FIRST and ix.num_postings == n_post and ix.value_len > 60 * 10 ** 9
+    nres = np.concatenate(nres_all).astype(np.uint64)
+    pen = fd.length_penalty(nres, 0.5)
+    # ---- sampled posting checks: first, a middle and the last block (the last one lies beyond id 2^21)
+    items, ids = [], []
+    for b in (0, n_blocks // 2, n_blocks - 1):
+        for s in np.sort(rng.choice(len(nres_all[b]), 20, replace=False)):
+            items.append(_item(host[b], int(s))); ids.append(FIRST + b * GEN_BLOCK + int(s))
+    assert min(ids) >= 1 << 21
+    hs, off = _sampled_posting_checks(ctx, ix, items, ids, 3000, rng, FIRST, FIRST + S)
+    # every list opens with a 4-byte absolute id; the other postings are deltas of (mostly) one byte
+    assert ix.value_len >= ix.num_postings + 3 * ix.num_hashes
+    lap("final merge + posting checks")
+    # ---- whole-structure query from the last block
+    bq = n_blocks - 1
+    s_loc = int(np.nonzero((nres_all[bq] >= 295) & (nres_all[bq] <= 305))[0][2])
+    s_glob = FIRST + bq * GEN_BLOCK + s_loc
+    item = _item(host[bq], s_loc)
+    nq_res = len(item["aa"])
+    qb = ctx.upload(fd.PackedStructures.concat([item]))
+    qm = fq.make_query_map(ctx, qb, np.arange(nq_res, dtype=np.uint32), None, ix, float(S))
+    assert len(qm.hash) > 50000
+    recs = fd.count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=S, as_array=True)
+    assert len(recs) > S // 2 and np.all(recs["nid"][1:] > recs["nid"][:-1]) and int(recs["nid"][0]) >= FIRST and int(recs["nid"][-1]) < FIRST + S
+    lap("query map + count_query")
+    # recount on the sampled structures: an entry (hash, (qi, qj)) of the query map matches structure s iff its hash is in s's S1 list
+    lens = ix.posting_lengths(qm.hash)
+    present = lens > 0
+    idf_h = fd.idf_of_lengths(np.maximum(lens, 1), S).astype(np.float64)
+    pos = np.searchsorted(recs["nid"], ids)
+    for k, sid in enumerate(ids):
+        own = hs[int(off[k]):int(off[k + 1])]
+        hit = present & np.isin(qm.hash, own)
+        if not hit.any():
+            assert pos[k] >= len(recs) or int(recs["nid"][pos[k]]) != sid
+            continue
+        r = recs[pos[k]]
+        assert int(r["nid"]) == sid and int(r["total_match_count"]) == int(hit.sum())
+        assert int(r["node_count"]) == len(np.unique(qm.qi[hit]))
+        assert int(r["edge_count"]) == len(np.unique(qm.qi[hit].astype(np.uint64) << np.uint64(32) | qm.qj[hit].astype(np.uint64)))
+        assert float(r["idf"]) == pytest.approx(float(idf_h[hit].sum() * float(pen[sid - FIRST])), rel=1e-5)
+    # the device selection (rows sliced at node boundaries, radix select, bitonic sort) == ranking of the full list
+    top = fd.count_query_maps(ctx, ix, [qm], pen, total_structures=S, top_n=1000)[0]
+    assert top.tobytes() == fdist.rank_hits(recs, 1000).tobytes() and int(top["nid"][0]) == s_glob
+    lap("recount + device ranking")
+    # ---- top 20 against oracle.retrieve (the candidates' coordinates as a small resident batch)
+    cand_nid = top["nid"][:20].astype(np.int64) - FIRST
+    c_items = [_item(host[int(n) // GEN_BLOCK], int(n) % GEN_BLOCK) for n in cand_nid]
+    cdb = ctx.upload(fd.PackedStructures.concat(c_items))
+    got = fq.retrieve(ctx, cdb, None, np.arange(20, dtype=np.uint32), qm, qb)
+    lap("GPU retrieval of the top 20")
+    oix, keep = _mini_index(ix, np.concatenate([qm.hash, qm.primary_hash]), real_ids=False)
+    oq = _ostruct(item)
+    om = oracle.make_query_map(oq, "", oix, float(S))
+    oa = om.arrays()
+    assert np.array_equal(qm.hash, oa["hash"]) and np.array_equal(qm.qi, oa["qi"]) and np.array_equal(qm.qj, oa["qj"])
+    assert np.array_equal(qm.idf.view(np.uint32), oa["idf"].view(np.uint32))
+    lap("oracle query map")
+    n = 0
+    for slot, it in enumerate(c_items):
+        R = oracle.retrieve(_ostruct(it), oq, om)
+        mine = [g for g in got if g["cand"] == slot]
+        assert len(mine) == len(R["processed"]), slot
+        for g, rp, rh in zip(mine, R["processed"], R["from_hash"]):
+            assert g["processed"] == [-1 if x is None else x[2] for x in rp["residues"]], slot
+            assert g["from_hash"] == [-1 if x is None else x[2] for x in rh["residues"]], slot
+            assert abs(g["rmsd"] - rp["rmsd"]) <= 1e-4 and g["idf"] == pytest.approx(rp["idf"], rel=1e-5)
+            n += 1
+    assert n >= 20 and max(sum(1 for x in g["processed"] if x >= 0) for g in got) == nq_res     # the structure matches itself entirely
+    lap("oracle.retrieve x 20")
