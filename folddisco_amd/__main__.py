@@ -49,6 +49,9 @@ def _init_dist(a):
     return rank, world, torch.device("cuda", local)
 
 
+LAST_TIMINGS = {}      # stage times of the last `index` run in this process (bench.py's drop-in leg reads them)
+
+
 def _shard_prefix(prefix, rank, world):
     return f"{prefix}.shard{rank}of{world}"
 
@@ -71,37 +74,47 @@ def cmd_index(a):
     if world > 1:
         return _cmd_index_sharded(a, fd, indexio, structure, all_paths, prefix, rank, world)
     paths = all_paths
+    import time
+    T = a.timings = {"ingest_s": 0.0, "gpu_build_s": 0.0, "merge_s": 0.0, "export_write_s": 0.0, "chunks": 0}
+    t_all = time.perf_counter()
     ctx = fd.Context(a.device)
-    # Chunks of --chunk structures (the reference walks T*128-structure chunks, controller/mod.rs:289-294): ingest (native,
-    # multi-threaded; a structure above --max-residue keeps its id but has no hashes, nres 0 and plddt 0,
-    # controller/mod.rs:313-318) -> one sub-index per chunk on the GPU -> per-hash concatenation of the sub-indices
-    # (fdgpu_merge_subindices).  One chunk = one fdgpu_index_build call (< 2^32 residue pairs).
-    nres_all, plddt_all, parts = [], [], []
-    n_hashes = value_len = 0
-    for c0 in range(0, len(paths), a.chunk):
-        chunk = paths[c0:c0 + a.chunk]
-        # native ingest straight into the flat batch layout (csrc/fd_ingest.cpp), no per-structure Python objects
-        ps, nres_c, plddt_c, raw, ok = _ingest(a, structure, chunk, c0)
-        nres_all.append(nres_c)
-        plddt_all.append(np.where(nres_c > 0, plddt_c, np.float32(0.0)).astype(np.float32))
-        batch = ctx.upload(ps)
-        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid, hash_type=a.hash_type, multiple_bins=a.multi)
-        if len(paths) <= a.chunk:
-            ix.save(prefix)                       # single chunk: the library writes PREFIX and PREFIX.offset itself
-            n_hashes, value_len = ix.num_hashes, ix.value_len
-        else:
-            parts.append(ix.export())
-        del ix, batch
-    if parts:
-        v, h, o = indexio.merge_subindices(parts)
-        indexio.write_index_files(prefix, v, h, o)
-        n_hashes, value_len = len(h), len(v)
-    nres, plddt = np.concatenate(nres_all), np.concatenate(plddt_all)
+    # The reference walks its input in chunks and parses / hashes a chunk in parallel (controller/mod.rs:282-348).  Here a host thread
+    # ingests chunk k + 1 (native, multi-threaded: csrc/fd_ingest.cpp; a structure above --max-residue keeps its id but has no hashes,
+    # nres 0 and plddt 0, controller/mod.rs:313-318) WHILE the GPU builds the sub-index of chunk k (one fdgpu_index_build call, < 2^32 residue
+    # pairs); the sub-indices stay resident in HBM and are concatenated per hash on the device (fdgpu_index_merge, in rounds of 64), so
+    # the index crosses the bus once, in the reference's on-disk layout.
+    parts, nres, plddt = _build_chunks(a, fd, structure, ctx, paths, 0, resident=True)
+    t0 = time.perf_counter()
+    ix = _merge_resident(fd, parts)
+    ctx.synchronize()
+    T["merge_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ix.save(prefix)                               # the library writes PREFIX and PREFIX.offset itself (byte-identical to save_offset_to_file)
+    n_hashes, value_len = ix.num_hashes, ix.value_len
     indexio.save_lookup(prefix + ".lookup", [indexio.parse_path_by_id_type(x, a.id) for x in paths], nres, plddt, db_keys=a.fc_keys)
     indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type], multiple_bins=a.multi,
                       **(dict(input_format="FCZDB", foldcomp_db=a.pdbs) if a.fc is not None else {}))
+    T["export_write_s"] = time.perf_counter() - t0
+    T["total_s"] = time.perf_counter() - t_all
+    T["structures"] = len(paths)
+    LAST_TIMINGS.clear()
+    LAST_TIMINGS.update(T)
     if a.verbose:
         print(f"[DONE] {len(paths)} structures, {n_hashes} hashes, {value_len} value bytes -> {prefix}", file=sys.stderr)
+        print("[TIME] total %.2f s = %.0f structures/s; ingest %.2f s (host threads, overlapped with the GPU), GPU builds %.2f s, device merge %.2f s, "
+              "export + files %.2f s" % (T["total_s"], len(paths) / max(T["total_s"], 1e-9), T["ingest_s"], T["gpu_build_s"], T["merge_s"], T["export_write_s"]), file=sys.stderr)
+
+
+def _merge_resident(fd, parts):
+    """sub-indices resident in HBM -> one resident index (fdgpu_index_merge takes at most 64 parts: merge in rounds)"""
+    g = max(2, min(64, int(os.environ.get("FD_MERGE_GROUP", "64"))))      # parts per fdgpu_index_merge call (tests lower it to exercise the rounds)
+    while len(parts) > 1:
+        nxt = []
+        for k in range(0, len(parts), g):
+            grp = parts[k:k + g]
+            nxt.append(fd.FolddiscoIndexSet(grp).merge() if len(grp) > 1 else grp[0])
+        parts = nxt
+    return parts[0]
 
 
 def _default_index_prefix(pdbs: str) -> str:
@@ -124,20 +137,42 @@ def _ingest(a, structure, chunk, pos0):
     return ps, nres_c, plddt_c, raw, ok
 
 
-def _build_chunks(a, fd, structure, ctx, paths, first_id):
-    """chunked GPU builds of paths (ids first_id ...) -> (sub-index parts, nres, plddt)"""
+def _build_chunks(a, fd, structure, ctx, paths, first_id, resident=False):
+    """chunked GPU builds of paths (ids first_id ...), double-buffered: a host thread ingests chunk k + 1 while the GPU builds chunk k
+    -> (sub-indices: resident FolddiscoIndex objects, or exported (value, hashes, offsets) triples; nres; plddt)"""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    T = getattr(a, "timings", None) or {}
     nres_all, plddt_all, parts = [], [], []
-    for c0 in range(0, len(paths), a.chunk):
-        chunk = paths[c0:c0 + a.chunk]
-        # native ingest straight into the flat batch layout (csrc/fd_ingest.cpp), no per-structure Python objects
-        ps, nres_c, plddt_c, raw, ok = _ingest(a, structure, chunk, first_id + c0)
-        nres_all.append(nres_c)
-        plddt_all.append(np.where(nres_c > 0, plddt_c, np.float32(0.0)).astype(np.float32))
-        batch = ctx.upload(ps)
-        ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id + c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid, hash_type=a.hash_type, multiple_bins=a.multi)
-        parts.append(ix.export())
-        del ix, batch
+    starts = list(range(0, len(paths), a.chunk))
+
+    def ingest(c0):
+        t0 = time.perf_counter()
+        r = _ingest(a, structure, paths[c0:c0 + a.chunk], first_id + c0)      # native, multi-threaded; releases the GIL
+        return r, time.perf_counter() - t0
+    with ThreadPoolExecutor(1) as pool:
+        fut = pool.submit(ingest, starts[0]) if starts else None
+        for k, c0 in enumerate(starts):
+            (ps, nres_c, plddt_c, raw, ok), t_ing = fut.result()
+            fut = pool.submit(ingest, starts[k + 1]) if k + 1 < len(starts) else None      # the next chunk is parsed while this one is built
+            T["ingest_s"] = T.get("ingest_s", 0.0) + t_ing
+            nres_all.append(nres_c)
+            plddt_all.append(np.where(nres_c > 0, plddt_c, np.float32(0.0)).astype(np.float32))
+            t0 = time.perf_counter()
+            batch = ctx.upload(ps)
+            ix = fd.FolddiscoIndex.build(ctx, batch, first_id=first_id + c0, nbin_dist=a.distance, nbin_angle=a.angle, dist_cutoff=a.grid, hash_type=a.hash_type, multiple_bins=a.multi)
+            if resident:
+                parts.append(ix)
+            else:
+                parts.append(ix.export())
+                del ix
+            del batch
+            ctx.synchronize()
+            T["gpu_build_s"] = T.get("gpu_build_s", 0.0) + time.perf_counter() - t0
+            T["chunks"] = T.get("chunks", 0) + 1
     z = lambda dt: np.zeros(0, dt)
+    if not parts and resident:
+        parts = [fd.FolddiscoIndex.build(ctx, ctx.upload(fd.PackedStructures.concat([])), first_id=first_id)]
     return parts, (np.concatenate(nres_all) if nres_all else z(np.uint64)), (np.concatenate(plddt_all) if plddt_all else z(np.float32))
 
 
@@ -149,9 +184,9 @@ def _cmd_index_sharded(a, fd, indexio, structure, paths, prefix, rank, world):
     from folddisco_amd import dist as fdist
     lo, hi = fdist.shard_range(rank, world, len(paths))
     ctx = fd.Context(a.device)
-    parts, nres, plddt = _build_chunks(a, fd, structure, ctx, paths[lo:hi], lo)
-    v, h, o = indexio.merge_subindices(parts) if len(parts) > 1 else (parts[0] if parts else (np.zeros(0, np.uint8), np.zeros(0, np.uint32), np.zeros(1, np.uint64)))
-    indexio.write_index_files(_shard_prefix(prefix, rank, world), v, h, o)
+    a.timings = {}
+    parts, nres, plddt = _build_chunks(a, fd, structure, ctx, paths[lo:hi], lo, resident=True)
+    _merge_resident(fd, parts).save(_shard_prefix(prefix, rank, world))      # the rank's chunks merged on the device, one export
     box = [None] * world
     dist.all_gather_object(box, (nres, plddt))
     dist.barrier()
@@ -277,7 +312,7 @@ def main(argv=None):
     pi = sub.add_parser("index")
     pi.add_argument("-p", "--pdbs", required=True)
     pi.add_argument("-i", "--index", default="")
-    pi.add_argument("-t", "--threads", type=int, default=1)            # accepted, unused: the GPU does the work
+    pi.add_argument("-t", "--threads", type=int, default=1)            # host threads of the structure ingest (the hashing and the posting build run on the GPU)
     pi.add_argument("-y", "--type", default="default")
     pi.add_argument("-d", "--distance", type=int, default=0)           # number of distance bins (0 -> 16), main.rs:38
     pi.add_argument("-a", "--angle", type=int, default=0)              # number of angle bins (0 -> 4)
@@ -288,7 +323,8 @@ def main(argv=None):
     pi.add_argument("--id", default="relpath")                          # pdb | uniprot | afdb | relpath | abspath | basename ... (build_index.rs:40)
     pi.add_argument("-v", "--verbose", action="store_true")
     pi.add_argument("--device", type=int, default=0)
-    pi.add_argument("--chunk", type=int, default=65536, help="structures per GPU build call (sub-indices are merged)")
+    pi.add_argument("--chunk", type=int, default=16384, help="structures per ingest step and GPU build call (the next chunk is parsed while this one is built; the sub-indices are merged on the device)")
+    pi.add_argument("--mmap-on-disk", action="store_true", help="NOT SUPPORTED (the reference's on-disk build mode, indextable.rs:215-226): the index is built in HBM")
     pq = sub.add_parser("query")
     pq.add_argument("-p", "--pdb", default="")
     pq.add_argument("-q", "--query", default="")
@@ -360,6 +396,9 @@ def main(argv=None):
         analyze.save_summary(analyze.summarize(a.index), out, a.top)
         return
     if a.cmd == "index":
+        if a.mmap_on_disk:
+            sys.exit("[FAIL] --mmap-on-disk is not supported: this build keeps the index in HBM (a Swiss-Prot-scale index is 26 GB of the 288 GB) and "
+                     "writes PREFIX / PREFIX.offset once; run without the flag")
         try:
             a.hash_type = hash_type_index(a.type)
         except ValueError:

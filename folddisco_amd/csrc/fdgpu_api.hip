@@ -568,13 +568,35 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     hipStream_t st = c->stream;
     uint64_t S = b->n_struct, P = 0;
     HIPCHK(c, c->ws[WS_FRAMES].ensure(std::max<uint64_t>(b->n_res, 1) * sizeof(fd_frame)));
-    {
-        StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame)));
-        fd_launch_frames(b->view(), b->n_res, c->ws[WS_FRAMES].p, st);
-    }
     // the encodings with their own descriptor go one ordered pair at a time through the row kernels (reference order), 8-byte elements
     const bool own = fd_own_descriptor(p->hash_type);
     if (own && n_cfg > 1) FAIL(c, FDGPU_EINVAL, "multiple_bins is built for the encodings over the PDBTrRosetta descriptor only");
+    // shards of <= 2^18 structures use 6-byte sort elements (key = hash << 2 | local id bits 17:16, u16 payload) as long as
+    // every hash fits 30 bits; the 8-byte form (u32 hash, u32 id) otherwise
+    const bool ids16 = !own && !force32 && S <= (1ull << 18);
+    // MSD build (default encoding, 6-byte elements): the pair kernel writes the keys partitioned by the top six hash bits (forty buckets,
+    // residues visited in amino-acid order) and every bucket is sorted by the remaining 24 bits — three 8-bit passes instead of four.
+    // FDGPU_MSD=0 selects the structure-major stream + four passes (A/B measurements, tests).
+    static const bool msd_env = [] { const char *e = getenv("FDGPU_MSD"); return !(e && e[0] == '0'); }();
+    const bool msd = msd_env && ids16 && n_cfg == 1 && p->hash_type == FDGPU_HASH_PDBTR && S > 0;
+    const uint32_t NB = 40;
+    fd_batch_view V = b->view();
+    static const bool msd_perm = [] { const char *e = getenv("FDGPU_MSD_PERM"); return !(e && e[0] == '0'); }();      // 0: buckets without the amino-acid order (measurement)
+    if (msd && !msd_perm) {
+        StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame)));
+        fd_launch_frames(b->view(), b->n_res, c->ws[WS_FRAMES].p, st);
+    } else if (msd) {
+        HIPCHK(c, c->ws[WS_CA_PERM].ensure(std::max<uint64_t>(b->n_res, 1) * 12));
+        HIPCHK(c, c->ws[WS_OK_PERM].ensure(std::max<uint64_t>(b->n_res, 1)));
+        HIPCHK(c, c->ws[WS_AA_PERM].ensure(std::max<uint64_t>(b->n_res, 1)));
+        StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame) + 14));
+        fd_launch_frames_perm(V, c->ws[WS_FRAMES].p, c->ws[WS_CA_PERM].as<float>(), c->ws[WS_OK_PERM].as<uint8_t>(), c->ws[WS_AA_PERM].as<uint8_t>(), st);
+        V.ca_xyz = c->ws[WS_CA_PERM].as<float>(); V.hash_ok = c->ws[WS_OK_PERM].as<uint8_t>(); V.aa = c->ws[WS_AA_PERM].as<uint8_t>();
+        V.n_xyz = nullptr; V.cb_xyz = nullptr;      // the pair kernels read frames, not atoms
+    } else {
+        StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame)));
+        fd_launch_frames(b->view(), b->n_res, c->ws[WS_FRAMES].p, st);
+    }
     uint64_t P1 = 0;
     int rc;
     if (own) {
@@ -592,15 +614,32 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
         }
         HIPCHK(c, hipGetLastError());
         rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &P1);
+    } else if (msd) {      // counts / cursors / offsets are [bucket][structure] tables: their exclusive scan IS the bucket-major layout
+        const uint64_t NS = NB * S;
+        HIPCHK(c, c->ws[WS_COUNTS].ensure((NS + 1) * 4));
+        HIPCHK(c, c->ws[WS_CURSOR].ensure((NS + 1) * 4));
+        HIPCHK(c, c->ws[WS_SEGOFF].ensure((NS + 2) * 8));
+        HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(std::max<uint64_t>(NS, b->n_res)) * 8 + 64));
+        HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_COUNTS].p, 0, (NS + 1) * 4, st));
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_CURSOR].p, 0, (NS + 1) * 4, st));
+        {
+            StageTimer t(c, "pair_count", b->n_res * 14);
+            fd_launch_pair_count_msd(V, C, c->ws[WS_COUNTS].as<uint32_t>(), st);
+        }
+        {
+            StageTimer t(c, "segment_scan", NS * 12);
+            fd_exclusive_scan<uint32_t>(c->ws[WS_COUNTS].as<uint32_t>(), NS, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
+                                        c->ws[WS_TOTAL].as<uint64_t>(), st);
+        }
+        HIPCHK(c, hipGetLastError());
+        rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &P1);
     } else {
         rc = count_and_scan(c, b, C, &P1, true);
     }
     if (rc) return rc;
     P = P1 * n_cfg;                         // every bin pair of --multiple-bins contributes one key per ordered residue pair
     if (P >= 0xffffffffull) FAIL(c, FDGPU_ERANGE, "more than 2^32 residue pairs in one build call; split the shard");
-    // shards of <= 2^18 structures use 6-byte sort elements (key = hash << 2 | local id bits 17:16, u16 payload) as long as
-    // every hash fits 30 bits; the 8-byte form (u32 hash, u32 id) otherwise
-    const bool ids16 = !own && !force32 && S <= (1ull << 18);
     if ((rc = ensure_sort_ws(c, P, ids16 ? 2 : 4))) return rc;
     uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *kb = c->ws[WS_KEYS_B].as<uint32_t>();
     void *ia = c->ws[WS_IDS_A].p, *ib = c->ws[WS_IDS_B].p;
@@ -610,6 +649,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     {
         StageTimer t(c, "pair_emit", b->n_res * 37 + P * (ids16 ? 6 : 8));
         if (own) fd_launch_row_emit(b->view(), C, c->ws[WS_MISC1].as<uint64_t>(), ka, p->dist_cutoff, (uint32_t *)ia, (uint32_t)first_id, st);
+        else if (msd) fd_launch_pair_emit_msd(V, c->ws[WS_FRAMES].p, C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, (uint16_t *)ia, st);
         else for (uint32_t k = 0; k < n_cfg; ++k) {
             fd_hash_consts Ck = fd_make_consts_cfg(p, k);
             Ck.spec_miss = C.spec_miss; Ck.wide_flag = C.wide_flag; Ck.seg_mul = n_cfg; Ck.seg_cfg = k;
@@ -620,7 +660,13 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     }
     int cur;
     (void)sort_mode();
-    if (ids16) cur = fd_radix_sort_pairs16(ka, (uint16_t *)ia, kb, (uint16_t *)ib, P, 32, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st, c);
+    if (msd) {      // every bucket by hash bits [0, 24) = key bits [2, 26): three passes; the bucket IS key bits [26, 32)
+        HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * fd_rs_seg_num_tiles(P, NB) * 4));
+        HIPCHK(c, c->ws[WS_TOT].ensure(fd_rs_seg_tot_words(P, NB) * 8));
+        HIPCHK(c, c->ws[WS_SEG_TAB].ensure(fd_rs_seg_tab_bytes(P, NB)));
+        cur = fd_radix_sort_pairs16_seg(ka, (uint16_t *)ia, kb, (uint16_t *)ib, P, c->ws[WS_SEGOFF].as<uint64_t>(), S, NB, 2, 3, c->ws[WS_GHIST].as<uint32_t>(),
+                                        c->ws[WS_TOT].as<uint64_t>(), c->ws[WS_SEG_TAB].p, st, c);
+    } else if (ids16) cur = fd_radix_sort_pairs16(ka, (uint16_t *)ia, kb, (uint16_t *)ib, P, 32, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st, c);
     else cur = sort_pairs(c, ka, (uint32_t *)ia, kb, (uint32_t *)ib, P, 32);   // all 32 bits: unmasked field overflow can set bits 30-31
     const uint32_t *ks = cur ? kb : ka;
     const void *is = cur ? ib : ia;

@@ -34,6 +34,7 @@ enum {
     WS_COUNTS, WS_CURSOR, WS_SEGOFF, WS_SCANTMP, WS_TOTAL, WS_KEYS_A, WS_IDS_A, WS_KEYS_B, WS_IDS_B, WS_GHIST, WS_TOT,
     WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
+    WS_CA_PERM, WS_OK_PERM, WS_AA_PERM, WS_SEG_TAB,
     WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT,
     WS_COUNT
 };
@@ -180,6 +181,15 @@ void fd_launch_pair_emit2(const fd_batch_view &B, const void *frames, const fd_h
                           uint32_t *keys, void *ids, bool ids16, uint32_t first_id, hipStream_t st);
 int fd_radix_sort_pairs16(uint32_t *keys_a, uint16_t *vals_a, uint32_t *keys_b, uint16_t *vals_b, uint64_t n, int key_bits, uint32_t *ghist,
                           uint64_t *tot, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr);
+void fd_launch_frames_perm(const fd_batch_view &B, void *frames, float *ca_perm, uint8_t *ok_perm, uint8_t *aa_perm, hipStream_t st);
+void fd_launch_pair_count_msd(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *counts, hipStream_t st);
+void fd_launch_pair_emit_msd(const fd_batch_view &B, const void *frames, const fd_hash_consts &C, const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys,
+                             uint16_t *ids, hipStream_t st);
+uint32_t fd_rs_seg_num_tiles(uint64_t n, uint32_t n_seg);
+uint64_t fd_rs_seg_tot_words(uint64_t n, uint32_t n_seg);
+size_t fd_rs_seg_tab_bytes(uint64_t n, uint32_t n_seg);
+int fd_radix_sort_pairs16_seg(uint32_t *keys_a, uint16_t *vals_a, uint32_t *keys_b, uint16_t *vals_b, uint64_t n, const uint64_t *seg_off, uint64_t stride,
+                              uint32_t n_seg, int shift0, int passes, uint32_t *ghist, uint64_t *tot, void *seg_tab, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr);
 void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, float cutoff, hipStream_t st);
 void fd_launch_row_emit(const fd_batch_view &B, const fd_hash_consts &C, const uint64_t *row_off, uint32_t *keys, float cutoff, uint32_t *ids,
                         uint32_t first_id, hipStream_t st, int ids_partner = 0);

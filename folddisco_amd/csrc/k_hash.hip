@@ -18,6 +18,7 @@
 #ifndef FD_EMIT_WAVES
 #define FD_EMIT_WAVES 5
 #endif
+#define FD_MSD_BUCKETS 40u   // MSD build: bucket = top six hash bits = aa_i << 1 | aa_j >> 4 (see drain2)
 
 // ------------------------------------------------------------------ count pass
 // counts[s] += number of ordered pairs of structure s that will be emitted
@@ -157,6 +158,92 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_count2(fd_batch_view B, fd_has
     if (threadIdx.x == 0 && cnt) atomicAdd(&counts[s], cnt);
 }
 
+// Frames in AMINO-ACID ORDER (MSD build): one workgroup per structure sorts its residues by type (counting sort, hashable residues
+// first; the order inside a type does not matter — the order of keys inside a structure's segment is arbitrary anyway) and writes the
+// frames together with permuted copies of what the pair kernels read per residue (CA, hashable flag, type).  A 64-residue tile then
+// holds ~4 residue types instead of ~15, which is what keeps the bucket runs of a drain long (k_pair_emit2<.., MSD>).
+__global__ __launch_bounds__(256) void k_frames_perm(fd_batch_view B, fd_frame *__restrict__ frames, float *__restrict__ ca_perm, uint8_t *__restrict__ ok_perm,
+                                                     uint8_t *__restrict__ aa_perm) {
+    __shared__ uint32_t cnt[32], cur[32];
+    const uint32_t s = blockIdx.x;
+    const uint32_t r0 = B.res_off[s], r1 = B.res_off[s + 1];
+    if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        const uint32_t a = B.aa[r];
+        atomicAdd(&cnt[(B.hash_ok[r] && a < 20u) ? a : 20u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int k = 0; k < 21; ++k) { cur[k] = run; run += cnt[k]; } }
+    __syncthreads();
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        const uint32_t a = B.aa[r];
+        const bool ok = B.hash_ok[r] != 0;
+        const uint32_t p = r0 + atomicAdd(&cur[(ok && a < 20u) ? a : 20u], 1u);
+        fd_frame F;
+        const fd_v3 ca = fd_load3(B.ca_xyz, r);
+        if (ok) F = fd_make_frame(fd_load3(B.n_xyz, r), ca, fd_load3(B.cb_xyz, r));
+        else { F = fd_frame{}; F.ca = ca; }
+        F.pad = __uint_as_float(a);
+        frames[p] = F;
+        ca_perm[3ull * p] = ca.x; ca_perm[3ull * p + 1] = ca.y; ca_perm[3ull * p + 2] = ca.z;
+        ok_perm[p] = ok ? 1 : 0;
+        aa_perm[p] = (uint8_t)a;
+    }
+}
+
+// count pass of the MSD build: counts[bucket * S + s] += keys of structure s that fall into the bucket (both orientations of every
+// unordered pair: (aa_i, aa_j >> 4) and (aa_j, aa_i >> 4)).  The forward keys are two per-lane counters (aa_j is wave-uniform per step), the
+// reverse keys two population counts of the pass ballot per step; everything meets in forty LDS counters.  B = the permuted view.
+__global__ __launch_bounds__(FD_WAVE) void k_pair_count_msd(fd_batch_view B, fd_hash_consts C, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t s_cnt[FD_WAVE];
+    uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
+    if (w >= B.n_work) return;
+    const uint32_t s = B.wi_struct[w];
+    const uint32_t r1 = B.res_off[s + 1];
+    const uint32_t i0 = B.wi_i0[w];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = i0 + lane;
+    const bool vi = i < r1 && B.hash_ok[i];
+    fd_v3 cai = {0.f, 0.f, 0.f};
+    uint32_t aai = 0;
+    if (vi) { cai = fd_load3(B.ca_xyz, i); aai = B.aa[i]; }
+    const uint64_t hi_mask = __ballot(vi && aai >= 16u);
+    s_cnt[lane] = 0;
+    __syncthreads();
+    uint32_t c_lo = 0, c_hi = 0;
+    for (uint32_t jb = i0; jb < r1; jb += FD_WAVE) {
+        const uint32_t jl = jb + lane;
+        const bool jin = jl < r1;
+        fd_v3 cj = {0.f, 0.f, 0.f};
+        uint32_t aj = 0;
+        if (jin) { cj = fd_load3(B.ca_xyz, jl); aj = B.aa[jl]; }
+        const uint64_t okm = __ballot(jin && B.hash_ok[jl]);
+        const uint32_t nj = (r1 - jb) < FD_WAVE ? (r1 - jb) : FD_WAVE;
+        int rev_lo = 0, rev_hi = 0;       // lane k: the reverse keys of partner j = jb + k (a compare and two selects per step)
+        for (uint32_t k = 0; k < nj; ++k) {
+            if (!((okm >> k) & 1ull)) continue;  // wave-uniform
+            fd_v3 caj = {bcast_lane(cj.x, k), bcast_lane(cj.y, k), bcast_lane(cj.z, k)};
+            const uint32_t aaj = (uint32_t)__builtin_amdgcn_readlane((int)aj, (int)k);
+            const float d2 = fd_dist2(cai, caj);
+            const bool pass = vi && (jb + k) > i && !(d2 > C.d2_max);
+            const uint64_t m = __ballot(pass);
+            if (m == 0) continue;
+            if (aaj >= 16u) c_hi += pass ? 1u : 0u; else c_lo += pass ? 1u : 0u;
+            const int n_hi = __popcll(m & hi_mask), n_lo = __popcll(m) - n_hi;
+            const bool mine = lane == k;
+            rev_lo = mine ? n_lo : rev_lo;
+            rev_hi = mine ? n_hi : rev_hi;
+        }
+        if (rev_lo) atomicAdd(&s_cnt[aj * 2u], (uint32_t)rev_lo);
+        if (rev_hi) atomicAdd(&s_cnt[aj * 2u + 1u], (uint32_t)rev_hi);
+    }
+    if (c_lo) atomicAdd(&s_cnt[aai * 2u], c_lo);
+    if (c_hi) atomicAdd(&s_cnt[aai * 2u + 1u], c_hi);
+    __syncthreads();
+    if (lane < FD_MSD_BUCKETS && s_cnt[lane]) atomicAdd(&counts[(uint64_t)lane * B.n_struct + s], s_cnt[lane]);
+}
+
 __device__ __forceinline__ fd_frame load_frame(const fd_frame *__restrict__ frames, uint32_t r) {
     const float4 *p = reinterpret_cast<const float4 *>(frames + r);
     float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
@@ -178,27 +265,50 @@ __device__ __attribute__((noinline)) uint2 pair_both_tab_exact(const fd_frame *_
     return make_uint2(a, b);
 }
 
-template <int TAB, bool IDS16>
+// MSD (index build, 6-byte elements, default encoding): the keys leave the kernel already partitioned by the top six hash bits — bucket =
+// hash >> 24 = aa_i << 1 | aa_j >> 4, forty of them — into a BUCKET-major stream (inside a bucket structure-major, so the stable sort that
+// follows still leaves ids ascending inside every hash).  seg_off / cursor are then [bucket][structure] tables; a drain counts its keys
+// per bucket in LDS (two ds_add_rtn per lane), claims the slots with one global atomic per touched bucket and stores every key at its
+// own position.  The residues of a structure are visited in amino-acid order (k_frames_perm), so a drain touches a handful of buckets and
+// the partial lines of one bucket's run are completed in L2 by the drains that follow.  The sort then needs three 8-bit passes, not four.
+template <int TAB, bool IDS16, bool MSD>
 __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *__restrict__ frames, const fd_hash_consts &C,
                                        const uint32_t *tab, const uint32_t *q, uint32_t n, uint32_t i0, uint32_t r0, uint32_t s, uint32_t id,
-                                       const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys, void *ids, const float4 *s_fi) {
+                                       const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys, void *ids, const float4 *s_fi,
+                                       uint32_t *s_bc, uint32_t *s_bb, const uint32_t *s_boff) {
     const uint32_t lane = threadIdx.x;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&cursor[s], 2u * n);
-    base = __shfl(base, 0, FD_WAVE);
+    uint32_t base = 0, gb = 0, slots = 0;
+    if (!MSD) {
+        if (lane == 0) base = atomicAdd(&cursor[s], 2u * n);
+        base = __shfl(base, 0, FD_WAVE);
+    } else {
+        // the buckets of a drain's keys are known before any geometry (the queue entry carries the partner's residue type): count per
+        // bucket in LDS, claim the slots with one global atomic per touched bucket — its latency then hides behind the descriptor
+        s_bc[lane] = 0;
+        __syncthreads();
+        if (lane < n) {
+            const uint32_t e = q[lane], il = (e >> 16) & 63u, aj = e >> 22;
+            const uint32_t ai = TAB == 2 ? __float_as_uint(s_fi[256 + il].w) : (uint32_t)B.aa[i0 + il];
+            const uint32_t bf = ai * 2u + (aj >> 4), br = aj * 2u + (ai >> 4);
+            slots = atomicAdd(&s_bc[bf], 1u) | atomicAdd(&s_bc[br], 1u) << 8 | bf << 16 | br << 24;      // one register across the descriptor
+        }
+        __syncthreads();
+        if (lane < FD_MSD_BUCKETS) { const uint32_t c = s_bc[lane]; if (c) gb = atomicAdd(&cursor[(uint64_t)lane * B.n_struct + s], c); }
+    }
+    uint32_t h_ij = 0, h_ji = 0, aai = 0, aaj = 0;
     if (lane < n) {
         uint32_t e = q[lane];
-        uint32_t i = i0 + (e >> 16), j = r0 + (e & 0xffffu);
-        uint32_t h_ij, h_ji;
+        uint32_t i = i0 + ((e >> 16) & 63u), j = r0 + (e & 0xffffu);
         if (TAB == 2) {
             // frame of i from the work item's LDS-staged residue tile ([k][lane] float4 planes), frame of j from L2
-            const uint32_t il = e >> 16;
+            const uint32_t il = (e >> 16) & 63u;
             const float4 a4 = s_fi[il], b4 = s_fi[64 + il], c4 = s_fi[128 + il], d4 = s_fi[192 + il], e4 = s_fi[256 + il];
             fd_frame Fi;
             Fi.ca = {a4.x, a4.y, a4.z}; Fi.cb = {a4.w, b4.x, b4.y}; Fi.r1 = {b4.z, b4.w, c4.x}; Fi.t1 = {c4.y, c4.z, c4.w};
             Fi.s2 = {d4.x, d4.y, d4.z}; Fi.nv2 = {d4.w, e4.x, e4.y}; Fi.len = e4.z; Fi.pad = e4.w;
             fd_frame Fj = load_frame(frames, j);
-            if (!fd_pair_both_spec(Fi, Fj, __float_as_uint(Fi.pad), __float_as_uint(Fj.pad), C.q, tab, tab + 32, &h_ij, &h_ji)) {
+            aai = __float_as_uint(Fi.pad); aaj = __float_as_uint(Fj.pad);
+            if (!fd_pair_both_spec(Fi, Fj, aai, aaj, C.q, tab, tab + 32, &h_ij, &h_ji)) {
                 uint2 h = pair_both_tab_exact(frames, i, j, B.aa[i], B.aa[j], C.q.dist_disc, C.q.ang_disc, tab);
                 h_ij = h.x; h_ji = h.y;
                 if (C.spec_miss) atomicAdd(C.spec_miss, 1ull);
@@ -210,6 +320,26 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
             fd_frame Fi = load_frame(frames, i), Fj = load_frame(frames, j);
             fd_pair_both(Fi, Fj, B.aa[i], B.aa[j], C.q, &h_ij, &h_ji);
         }
+    }
+    if (MSD) {
+        if (lane < FD_MSD_BUCKETS) s_bb[lane] = gb + s_boff[lane];      // first slot of this drain's keys in every bucket (positions fit 32 bits: P < 2^32)
+        __syncthreads();
+        if (lane < n) {
+            const uint32_t sf = slots & 255u, sr = (slots >> 8) & 255u, bf = (slots >> 16) & 255u, br = slots >> 24;
+            // the bucket comes from the residue types like in the count pass (== hash >> 24 unless a saturated distance field bled into
+            // the type bits: such a hash raises wide_flag and the build is redone with 8-byte elements; its key still lands in a counted slot)
+            if ((((h_ij | h_ji) >> 30) || (h_ij >> 24) != bf || (h_ji >> 24) != br) && C.wide_flag) atomicOr(C.wide_flag, 1ull);
+            const uint32_t pf = s_bb[bf] + sf, pr = s_bb[br] + sr;
+            const uint32_t hi = s >> 16;
+            const uint16_t lo = (uint16_t)(s & 0xffffu);
+            keys[pf] = (h_ij << 2) | hi;
+            keys[pr] = (h_ji << 2) | hi;
+            ((uint16_t *)ids)[pf] = lo;
+            ((uint16_t *)ids)[pr] = lo;
+        }
+        return;
+    }
+    if (lane < n) {
         // --multiple-bins: the structure's segment holds seg_mul copies of its pair list (one per bin pair), so the stream stays
         // structure-major and the stable sort by hash keeps ids ascending inside every posting list
         const uint64_t so = seg_off[s];
@@ -231,7 +361,7 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
     }
 }
 
-template <int TAB, bool IDS16>
+template <int TAB, bool IDS16, bool MSD>
 __global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_view B, const fd_frame *__restrict__ frames, fd_hash_consts C,
                                                         const uint64_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
                                                         uint32_t *__restrict__ keys, void *__restrict__ ids, uint32_t first_id) {
@@ -264,6 +394,8 @@ __global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_
 #pragma unroll
         for (int k = 0; k < 5; ++k) s_fi[k * FD_WAVE + lane] = fp[k];
     }
+    __shared__ uint32_t s_bc[MSD ? FD_WAVE : 1], s_bb[MSD ? FD_WAVE : 1], s_boff[MSD ? FD_WAVE : 1];
+    if (MSD && lane < FD_MSD_BUCKETS) s_boff[lane] = (uint32_t)seg_off[(uint64_t)lane * B.n_struct + s];      // where the structure's keys of every bucket start
     __syncthreads();
     uint32_t qn = 0;  // wave-uniform
     // single drain site (two inlined copies of the descriptor code would not fit the I-cache); the queue is
@@ -274,6 +406,8 @@ __global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_
         const bool jin = jl < r1;
         fd_v3 cj = {0.f, 0.f, 0.f};
         if (jin) cj = fd_load3(B.ca_xyz, jl);
+        uint32_t aj = 0;
+        if (MSD && jin) aj = B.aa[jl];
         const uint64_t okm = __ballot(jin && B.hash_ok[jl]);
         const uint32_t nj = (r1 - jb) < FD_WAVE ? (r1 - jb) : FD_WAVE;
         const bool last_block = jb + FD_WAVE >= r1;
@@ -286,7 +420,9 @@ __global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_
                 bool pass = vi && j > i && !(d2 > C.d2_max);
                 uint64_t m = __ballot(pass);
                 if (m != 0) {
-                    if (pass) q[qn + fd_mbcnt(m)] = (lane << 16) | (j - r0);
+                    // MSD: bits 22-26 = the partner's residue type (wave-uniform, a scalar OR)
+                    const uint32_t tag = MSD ? ((uint32_t)__builtin_amdgcn_readlane((int)aj, (int)k) << 22) | (j - r0) : (j - r0);
+                    if (pass) q[qn + fd_mbcnt(m)] = (lane << 16) | tag;
                     qn += (uint32_t)__popcll(m);
                 }
             }
@@ -294,7 +430,7 @@ __global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_
                 __syncthreads();
                 uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
                 qn -= n;
-                drain2<TAB, IDS16>(B, frames, C, tab, q + qn, n, i0, r0, s, first_id + s, seg_off, cursor, keys, ids, s_fi);
+                drain2<TAB, IDS16, MSD>(B, frames, C, tab, q + qn, n, i0, r0, s, first_id + s, seg_off, cursor, keys, ids, s_fi, s_bc, s_bb, s_boff);
                 __syncthreads();
             }
         }
@@ -437,12 +573,30 @@ void fd_launch_pair_emit2(const fd_batch_view &B, const void *frames, const fd_h
     if (!B.n_work) return;
     dim3 g(grid_for(B.n_work)), b(FD_WAVE);
     const fd_frame *F = (const fd_frame *)frames;
-    if (C.use_tab == 2 && ids16) hipLaunchKernelGGL((k_pair_emit2<2, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
-    else if (C.use_tab == 2) hipLaunchKernelGGL((k_pair_emit2<2, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
-    else if (C.use_tab && ids16) hipLaunchKernelGGL((k_pair_emit2<1, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
-    else if (C.use_tab) hipLaunchKernelGGL((k_pair_emit2<1, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
-    else if (ids16) hipLaunchKernelGGL((k_pair_emit2<0, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
-    else hipLaunchKernelGGL((k_pair_emit2<0, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    if (C.use_tab == 2 && ids16) hipLaunchKernelGGL((k_pair_emit2<2, true, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else if (C.use_tab == 2) hipLaunchKernelGGL((k_pair_emit2<2, false, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else if (C.use_tab && ids16) hipLaunchKernelGGL((k_pair_emit2<1, true, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else if (C.use_tab) hipLaunchKernelGGL((k_pair_emit2<1, false, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else if (ids16) hipLaunchKernelGGL((k_pair_emit2<0, true, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else hipLaunchKernelGGL((k_pair_emit2<0, false, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+}
+// the MSD build (6-byte elements): B = the permuted view (ca_xyz / hash_ok / aa = the arrays k_frames_perm wrote), seg_off / cursor = [40][S]
+void fd_launch_frames_perm(const fd_batch_view &B, void *frames, float *ca_perm, uint8_t *ok_perm, uint8_t *aa_perm, hipStream_t st) {
+    if (!B.n_struct) return;
+    hipLaunchKernelGGL(k_frames_perm, dim3(B.n_struct), dim3(256), 0, st, B, (fd_frame *)frames, ca_perm, ok_perm, aa_perm);
+}
+void fd_launch_pair_count_msd(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *counts, hipStream_t st) {
+    if (!B.n_work) return;
+    hipLaunchKernelGGL(k_pair_count_msd, dim3(grid_for(B.n_work)), dim3(FD_WAVE), 0, st, B, C, counts);
+}
+void fd_launch_pair_emit_msd(const fd_batch_view &B, const void *frames, const fd_hash_consts &C, const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys,
+                             uint16_t *ids, hipStream_t st) {
+    if (!B.n_work) return;
+    dim3 g(grid_for(B.n_work)), b(FD_WAVE);
+    const fd_frame *F = (const fd_frame *)frames;
+    if (C.use_tab == 2) hipLaunchKernelGGL((k_pair_emit2<2, true, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, (void *)ids, 0u);
+    else if (C.use_tab) hipLaunchKernelGGL((k_pair_emit2<1, true, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, (void *)ids, 0u);
+    else hipLaunchKernelGGL((k_pair_emit2<0, true, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, (void *)ids, 0u);
 }
 void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, float cutoff, hipStream_t st) {
     if (!B.n_work) return;

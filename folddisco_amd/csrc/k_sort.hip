@@ -205,15 +205,14 @@ __global__ __launch_bounds__(RS_BINS) void k_rs_scan_tot(uint64_t *__restrict__ 
 template <int THREADS, int ITEMS, typename V, bool FULL, bool PACK = false>
 __device__ __forceinline__ void rs_scatter4_body(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
                                                  uint32_t *__restrict__ keys_out, V *__restrict__ vals_out, uint64_t n, uint32_t shift,
-                                                 uint32_t mask, const uint32_t *__restrict__ ghist, uint32_t nb, const uint64_t *__restrict__ dbase,
-                                                 uint32_t tile, uint32_t *s_keys, V *s_vals, uint32_t (*s_cnt)[RS_BINS], long long *s_gofs,
+                                                 uint32_t mask, const uint32_t *__restrict__ ghist_row, const uint64_t *__restrict__ dbase,
+                                                 uint64_t tile_base, uint32_t n_tile_in, uint32_t *s_keys, V *s_vals, uint32_t (*s_cnt)[RS_BINS], long long *s_gofs,
                                                  uint64_t *sm) {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int WAVES = THREADS / 64;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint64_t tile_base = (uint64_t)tile * TILE;
     const uint64_t wave_base = tile_base + (uint64_t)wid * (64 * ITEMS);
-    const uint32_t n_tile = FULL ? TILE : (uint32_t)(n - tile_base);
+    const uint32_t n_tile = FULL ? TILE : n_tile_in;
     const uint32_t n_wave = FULL ? 64 * ITEMS : (n_tile > wid * 64 * ITEMS ? n_tile - wid * 64 * ITEMS : 0u);   // valid keys of this wave
 
     for (int k = tid; k < WAVES * RS_BINS; k += THREADS) (&s_cnt[0][0])[k] = 0;
@@ -228,7 +227,7 @@ __device__ __forceinline__ void rs_scatter4_body(const uint32_t *__restrict__ ke
         val[c] = ok ? vp[c * 64] : (V)0;
     }
     long long gbase = 0;
-    if (tid < RS_BINS) gbase = (long long)(dbase[tid] + ghist[(uint64_t)tile * RS_BINS + tid]);
+    if (tid < RS_BINS) gbase = (long long)(dbase[tid] + ghist_row[tid]);
     __syncthreads();
     uint32_t rnk[ITEMS];
     uint32_t *cnt = s_cnt[wid];
@@ -350,10 +349,137 @@ __global__ __launch_bounds__(THREADS) void k_rs_scatter4(const uint32_t *__restr
     __shared__ uint64_t sm[17];
     const uint32_t tile = fd_xcd_remap(blockIdx.x, nb);
     if (tile >= nb) return;
-    if ((uint64_t)(tile + 1) * TILE <= n)
-        rs_scatter4_body<THREADS, ITEMS, V, true, PACK>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, ghist, nb, dbase, tile, s_keys, s_vals, s_cnt, s_gofs, sm);
+    const uint64_t tile_base = (uint64_t)tile * TILE;
+    if (tile_base + TILE <= n)
+        rs_scatter4_body<THREADS, ITEMS, V, true, PACK>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, ghist + (uint64_t)tile * RS_BINS, dbase, tile_base, TILE, s_keys,
+                                                        s_vals, s_cnt, s_gofs, sm);
     else
-        rs_scatter4_body<THREADS, ITEMS, V, false, PACK>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, ghist, nb, dbase, tile, s_keys, s_vals, s_cnt, s_gofs, sm);
+        rs_scatter4_body<THREADS, ITEMS, V, false, PACK>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, ghist + (uint64_t)tile * RS_BINS, dbase, tile_base,
+                                                         (uint32_t)(n - tile_base), s_keys, s_vals, s_cnt, s_gofs, sm);
+}
+
+// ------------------------------------------------------------------------ segmented form (MSD index build)
+// The keys arrive partitioned into n_seg buckets (k_pair_emit2<.., MSD>: bucket = top six hash bits) and every bucket is sorted on its own
+// by the remaining 24 hash bits: three passes instead of four.  Tiles stay aligned to multiples of TILE in memory (16-byte loads, full
+// lines); a tile that a bucket boundary cuts becomes two partial "virtual tiles".  Virtual tiles are numbered bucket by bucket, every
+// bucket's first one at a multiple of RS_SCAN_CHUNK, so that a scan chunk never spans two buckets (the padding tiles are empty).
+// rs_seg_tab lives in device memory: bstart[b] = first key of bucket b, vt0[b] = its first virtual tile.
+#define RS_MAX_SEG 64
+struct rs_seg_tab { uint64_t bstart[RS_MAX_SEG + 1]; uint32_t vt0[RS_MAX_SEG + 1]; uint32_t n_seg, pad; };
+__global__ void k_rs_seg_tiles(const uint64_t *__restrict__ seg_off, uint64_t stride, uint32_t n_seg, uint32_t tile, rs_seg_tab *__restrict__ T) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t v = 0;
+    for (uint32_t b = 0; b <= n_seg; ++b) T->bstart[b] = seg_off[(uint64_t)b * stride];
+    for (uint32_t b = 0; b < n_seg; ++b) {
+        T->vt0[b] = v;
+        const uint64_t lo = T->bstart[b], hi = T->bstart[b + 1];
+        const uint32_t nvt = hi > lo ? (uint32_t)((hi + tile - 1) / tile - lo / tile) : 0u;
+        v += (nvt + RS_SCAN_CHUNK - 1) / RS_SCAN_CHUNK * RS_SCAN_CHUNK;
+    }
+    T->vt0[n_seg] = v;
+    T->n_seg = n_seg;
+}
+// virtual tile v -> its bucket and key range (cnt = 0: a padding tile), written once per sort into a 16-byte descriptor per tile: the hist
+// and scatter kernels of the three passes read ONE descriptor instead of walking the bucket table (forty dependent scalar loads per
+// workgroup cost 10 % of a pass)
+struct rs_vtile { uint64_t lo; uint32_t cnt, seg; };
+__global__ __launch_bounds__(256) void k_rs_seg_desc(const rs_seg_tab *__restrict__ T, uint32_t tile, uint32_t nbv, rs_vtile *__restrict__ D) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nbv) return;
+    const uint32_t n_seg = T->n_seg;
+    rs_vtile d = {0, 0, 0};
+    if (v < T->vt0[n_seg]) {
+        uint32_t lo = 0, hi = n_seg;                      // largest b with vt0[b] <= v
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (T->vt0[mid] <= v) lo = mid; else hi = mid; }
+        const uint32_t b = lo;
+        const uint64_t s0 = T->bstart[b], s1 = T->bstart[b + 1];
+        const uint64_t t = s0 / tile + (v - T->vt0[b]);
+        const uint64_t a = t * tile > s0 ? t * tile : s0, e = (t + 1) * tile < s1 ? (t + 1) * tile : s1;
+        d.lo = a; d.seg = b; d.cnt = e > a ? (uint32_t)(e - a) : 0u;
+    }
+    D[v] = d;
+}
+__device__ __forceinline__ void rs_seg_lookup(const rs_vtile *__restrict__ D, uint32_t v, uint32_t *seg, uint64_t *lo, uint32_t *cnt) {
+    const rs_vtile d = D[v];
+    *seg = d.seg; *lo = d.lo; *cnt = d.cnt;
+}
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_rs_hist_seg(const uint32_t *__restrict__ keys, const rs_vtile *__restrict__ D, uint32_t shift, uint32_t mask,
+                                                         uint32_t *__restrict__ ghist, uint32_t nbv) {
+    constexpr int TILE = THREADS * ITEMS;
+    __shared__ uint32_t h[RS_BINS];
+    const uint32_t v = fd_xcd_remap(blockIdx.x, nbv);
+    if (v >= nbv) return;
+    uint32_t seg, cnt;
+    uint64_t base;
+    rs_seg_lookup(D, v, &seg, &base, &cnt);
+    for (int k = threadIdx.x; k < RS_BINS; k += THREADS) h[k] = 0;
+    __syncthreads();
+    if (cnt == TILE) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys + base);
+#pragma unroll
+        for (int k = 0; k < ITEMS / 4; ++k) {
+            u32x4 x = __builtin_nontemporal_load(&k4[k * THREADS + threadIdx.x]);
+            atomicAdd(&h[(x.x >> shift) & mask], 1u);
+            atomicAdd(&h[(x.y >> shift) & mask], 1u);
+            atomicAdd(&h[(x.z >> shift) & mask], 1u);
+            atomicAdd(&h[(x.w >> shift) & mask], 1u);
+        }
+    } else {
+        for (uint32_t k = threadIdx.x; k < cnt; k += THREADS) atomicAdd(&h[(keys[base + k] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < RS_BINS; k += THREADS) ghist[(uint64_t)v * RS_BINS + k] = h[k];
+}
+// per bucket: exclusive scan over its chunks of every digit's chunk sums + the bucket's digit totals.  grid (16, n_seg)
+__global__ __launch_bounds__(1024) void k_rs_scan_chunks_seg(uint64_t *__restrict__ csum, const rs_seg_tab *__restrict__ T, uint64_t *__restrict__ tot) {
+    __shared__ uint64_t part[64][16];
+    const uint32_t b = blockIdx.y;
+    const uint32_t cb0 = T->vt0[b] / RS_SCAN_CHUNK, n_chunks = T->vt0[b + 1] / RS_SCAN_CHUNK - cb0;
+    const uint32_t dl = threadIdx.x & 15u, p = threadIdx.x >> 4, d = blockIdx.x * 16u + dl;
+    const uint32_t per = (n_chunks + 63) / 64, c0 = p * per < n_chunks ? p * per : n_chunks, c1 = c0 + per < n_chunks ? c0 + per : n_chunks;
+    uint64_t s = 0;
+#pragma unroll 4
+    for (uint32_t c = c0; c < c1; ++c) s += csum[(uint64_t)(cb0 + c) * RS_BINS + d];
+    part[p][dl] = s;
+    __syncthreads();
+    uint64_t run = 0;
+    for (uint32_t q = 0; q < p; ++q) run += part[q][dl];
+    if (p == 63) tot[(uint64_t)b * RS_BINS + d] = run + s;
+    for (uint32_t c = c0; c < c1; ++c) { uint64_t x = csum[(uint64_t)(cb0 + c) * RS_BINS + d]; csum[(uint64_t)(cb0 + c) * RS_BINS + d] = run; run += x; }
+}
+// per bucket: digit totals -> absolute position of every digit's first key (bucket start + exclusive scan over the digits)
+__global__ __launch_bounds__(RS_BINS) void k_rs_scan_tot_seg(uint64_t *__restrict__ tot, const rs_seg_tab *__restrict__ T) {
+    __shared__ uint64_t sm[17];
+    const uint32_t b = blockIdx.x;
+    uint64_t x = tot[(uint64_t)b * RS_BINS + threadIdx.x], t;
+    uint64_t ex = block_excl_scan_u64(x, sm, &t);
+    tot[(uint64_t)b * RS_BINS + threadIdx.x] = ex + T->bstart[b];
+}
+template <int THREADS, int ITEMS, typename V>
+__global__ __launch_bounds__(THREADS) void k_rs_scatter4_seg(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+                                                             V *__restrict__ vals_out, const rs_vtile *__restrict__ D, uint32_t shift, uint32_t mask,
+                                                             const uint32_t *__restrict__ ghist, uint32_t nbv, const uint64_t *__restrict__ dbase) {
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / 64;
+    __shared__ __attribute__((aligned(8))) uint32_t s_keys[TILE];
+    __shared__ V s_vals[TILE];
+    __shared__ uint32_t s_cnt[WAVES][RS_BINS];
+    __shared__ long long s_gofs[RS_BINS];
+    __shared__ uint64_t sm[17];
+    const uint32_t v = fd_xcd_remap(blockIdx.x, nbv);
+    if (v >= nbv) return;
+    uint32_t seg, cnt;
+    uint64_t base;
+    rs_seg_lookup(D, v, &seg, &base, &cnt);
+    if (!cnt) return;
+    if (cnt == TILE)
+        rs_scatter4_body<THREADS, ITEMS, V, true, false>(keys_in, vals_in, keys_out, vals_out, 0, shift, mask, ghist + (uint64_t)v * RS_BINS, dbase + (uint64_t)seg * RS_BINS, base,
+                                                         TILE, s_keys, s_vals, s_cnt, s_gofs, sm);
+    else
+        rs_scatter4_body<THREADS, ITEMS, V, false, false>(keys_in, vals_in, keys_out, vals_out, 0, shift, mask, ghist + (uint64_t)v * RS_BINS, dbase + (uint64_t)seg * RS_BINS, base,
+                                                          cnt, s_keys, s_vals, s_cnt, s_gofs, sm);
 }
 
 // LSD radix sort, 8-bit digits.  FDGPU_SORT=classicN selects measured alternatives: 18 = 512x16-key tiles (default, fastest),
@@ -409,6 +535,46 @@ static int radix_sort_pairs_t(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *
                 break;
             }
             default: rs_pass4<512, 16, V>(ki, vi, ko, vo, n, (uint32_t)shift, mask, ghist, tot, st, tc); break;
+        }
+        cur ^= 1;
+    }
+    return cur;
+}
+// workspace of the segmented sort for n keys in n_seg buckets: virtual tiles (rows of the histogram table), u64 words behind `tot`
+uint32_t fd_rs_seg_num_tiles(uint64_t n, uint32_t n_seg) { return (uint32_t)(n / 8192 + 2) + n_seg * (RS_SCAN_CHUNK + 1); }
+uint64_t fd_rs_seg_tot_words(uint64_t n, uint32_t n_seg) { return (uint64_t)n_seg * RS_BINS + (uint64_t)(fd_rs_seg_num_tiles(n, n_seg) / RS_SCAN_CHUNK + 2) * RS_BINS; }
+size_t fd_rs_seg_tab_bytes(uint64_t n, uint32_t n_seg) { return ((sizeof(rs_seg_tab) + 15) & ~(size_t)15) + (size_t)fd_rs_seg_num_tiles(n, n_seg) * sizeof(rs_vtile); }
+// Stable sort of every bucket [seg_off[b * stride], seg_off[(b + 1) * stride]) by key bits [shift0, shift0 + 8 * passes): 6-byte elements.
+// seg_off / seg_tab are device memory; nothing is synchronised.  Returns the buffer (0 = a, 1 = b) that holds the result.
+int fd_radix_sort_pairs16_seg(uint32_t *keys_a, uint16_t *vals_a, uint32_t *keys_b, uint16_t *vals_b, uint64_t n, const uint64_t *seg_off, uint64_t stride,
+                              uint32_t n_seg, int shift0, int passes, uint32_t *ghist, uint64_t *tot, void *seg_tab, hipStream_t st, fdgpu_ctx *tc) {
+    if (n == 0 || n_seg == 0 || n_seg > RS_MAX_SEG) return 0;
+    constexpr int THREADS = 512, ITEMS = 16;
+    rs_seg_tab *T = (rs_seg_tab *)seg_tab;
+    const uint32_t nbv = fd_rs_seg_num_tiles(n, n_seg), grid = ((nbv + 7u) / 8u) * 8u, n_chunks = (nbv + RS_SCAN_CHUNK - 1) / RS_SCAN_CHUNK;
+    uint64_t *csum = tot + (uint64_t)n_seg * RS_BINS;
+    rs_vtile *D = (rs_vtile *)((uint8_t *)seg_tab + ((sizeof(rs_seg_tab) + 15) & ~(size_t)15));
+    hipLaunchKernelGGL(k_rs_seg_tiles, dim3(1), dim3(64), 0, st, seg_off, stride, n_seg, (uint32_t)(THREADS * ITEMS), T);
+    hipLaunchKernelGGL(k_rs_seg_desc, dim3((nbv + 255) / 256), dim3(256), 0, st, T, (uint32_t)(THREADS * ITEMS), nbv, D);
+    int cur = 0;
+    for (int pass = 0; pass < passes; ++pass) {
+        const uint32_t shift = (uint32_t)(shift0 + 8 * pass), mask = 255u;
+        uint32_t *ki = cur ? keys_b : keys_a, *ko = cur ? keys_a : keys_b;
+        uint16_t *vi = cur ? vals_b : vals_a, *vo = cur ? vals_a : vals_b;
+        {
+            StageTimer t(tc, "rs_hist", n * 4 + (uint64_t)nbv * RS_BINS * 4);
+            hipLaunchKernelGGL((k_rs_hist_seg<THREADS, ITEMS>), dim3(grid), dim3(THREADS), 0, st, ki, D, shift, mask, ghist, nbv);
+        }
+        {
+            StageTimer t(tc, "rs_scan", (uint64_t)nbv * RS_BINS * 8);
+            hipLaunchKernelGGL(k_rs_scan_csum, dim3(n_chunks), dim3(RS_BINS), 0, st, ghist, nbv, csum);
+            hipLaunchKernelGGL(k_rs_scan_chunks_seg, dim3(RS_BINS / 16, n_seg), dim3(1024), 0, st, csum, T, tot);
+            hipLaunchKernelGGL(k_rs_scan_apply, dim3(n_chunks), dim3(RS_BINS), 0, st, ghist, nbv, csum);
+            hipLaunchKernelGGL(k_rs_scan_tot_seg, dim3(n_seg), dim3(RS_BINS), 0, st, tot, T);
+        }
+        {
+            StageTimer t(tc, "rs_scatter", n * 12);
+            hipLaunchKernelGGL((k_rs_scatter4_seg<THREADS, ITEMS, uint16_t>), dim3(grid), dim3(THREADS), 0, st, ki, vi, ko, vo, D, shift, mask, ghist, nbv, tot);
         }
         cur ^= 1;
     }

@@ -13,6 +13,7 @@ background frequencies.  Inputs to the GPU path and to the CPU oracle are always
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -139,3 +140,79 @@ def to_packed(d) -> "PackedStructures":
     from .api import PackedStructures
     return PackedStructures(d["res_off"].cpu().numpy().astype(np.uint64), d["n_xyz"].cpu().numpy(), d["ca_xyz"].cpu().numpy(),
                             d["cb_xyz"].cpu().numpy(), d["aa"].cpu().numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------------- files for the ingest leg
+_AA3 = ["ALA", "ARG", "ASN", "ASP", "CYS", "GLN", "GLU", "GLY", "HIS", "ILE", "LEU", "LYS", "MET", "PHE", "PRO", "SER", "THR", "TRP", "TYR", "VAL"]
+
+
+def _pdb_text(n, ca, cb, aa, plddt) -> bytes:
+    """one structure as PDB ATOM records (N, CA, C, O, CB per residue; C and O are fabricated from the trace — the ingest reads them like
+    any backbone atom, the hot path uses N, CA and the explicit CB)"""
+    L = len(aa)
+    nxt = np.roll(ca, -1, axis=0)
+    nxt[-1] = 2 * ca[-1] - ca[-2] if L > 1 else ca[-1] + 1.0
+    u = nxt - ca
+    u /= np.maximum(np.linalg.norm(u, axis=1, keepdims=True), 1e-6)
+    c = ca + 1.52 * u
+    o = c + np.array([0.0, 1.23, 0.0], np.float32)
+    out = []
+    k = 1
+    for r in range(L):
+        rn = _AA3[int(aa[r])] if aa[r] < 20 else "UNK"
+        for nm, xyz, el in ((" N  ", n[r], "N"), (" CA ", ca[r], "C"), (" C  ", c[r], "C"), (" O  ", o[r], "O"), (" CB ", cb[r], "C")):
+            out.append("ATOM  %5d %s %s A%4d    %8.3f%8.3f%8.3f  1.00%6.2f          %2s" % (k % 100000, nm, rn, (r + 1) % 10000, xyz[0], xyz[1], xyz[2], plddt[r], el))
+            k += 1
+    out.append("END")
+    return ("\n".join(out) + "\n").encode()
+
+
+def _write_pdb_range(args):
+    import gzip
+    directory, first, items = args
+    for k, (n, ca, cb, aa, pl) in enumerate(items):
+        with gzip.open("%s/AF-S%07d-F1-model_v4.pdb.gz" % (directory, first + k), "wb", compresslevel=1) as f:
+            f.write(_pdb_text(n, ca, cb, aa, pl))
+    return len(items)
+
+
+def write_pdb_gz(d, directory: str, workers: int = 32) -> int:
+    """the structures of generate()'s dict as gzipped PDB files, written by worker processes -> number of files"""
+    import os
+    from concurrent.futures import ProcessPoolExecutor
+    os.makedirs(directory, exist_ok=True)
+    off = d["res_off"].cpu().numpy()
+    h = {k: d[k].cpu().numpy() for k in ("n_xyz", "ca_xyz", "cb_xyz", "aa", "plddt")}
+    S = len(off) - 1
+    per = max(1, -(-S // (workers * 4)))
+    jobs = []
+    for a in range(0, S, per):
+        b = min(S, a + per)
+        jobs.append((directory, a, [(h["n_xyz"][off[s]:off[s + 1]], h["ca_xyz"][off[s]:off[s + 1]], h["cb_xyz"][off[s]:off[s + 1]], h["aa"][off[s]:off[s + 1]],
+                                     h["plddt"][off[s]:off[s + 1]]) for s in range(a, b)]))
+    with ProcessPoolExecutor(workers) as ex:
+        return sum(ex.map(_write_pdb_range, jobs))
+
+
+def replicate_foldcomp_db(src_db: str, dst_db: str, n_entries: int) -> int:
+    """a Foldcomp database of n_entries built by repeating the entries of src_db (DB, DB.index, DB.lookup, DB.dbtype): real compressed
+    proteins to decode, as many as the ingest leg wants -> number of entries"""
+    import shutil
+    data = open(src_db, "rb").read()
+    ents = [tuple(int(t) for t in line.split()) for line in open(src_db + ".index")]
+    names = {}
+    for line in open(src_db + ".lookup"):
+        p = line.rstrip("\n").split("\t")
+        names[int(p[0])] = p[1]
+    ents.sort()
+    with open(dst_db, "wb") as f, open(dst_db + ".index", "w") as fi, open(dst_db + ".lookup", "w") as fl:
+        pos = 0
+        for k in range(n_entries):
+            key, start, length = ents[k % len(ents)]
+            f.write(data[start:start + length])
+            fi.write("%d\t%d\t%d\n" % (k, pos, length))
+            fl.write("%d\t%s_%06d\t0\n" % (k, names.get(key, "entry"), k))
+            pos += length
+    if os.path.exists(src_db + ".dbtype"):
+        shutil.copy(src_db + ".dbtype", dst_db + ".dbtype")
+    return n_entries

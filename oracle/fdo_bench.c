@@ -7,27 +7,45 @@
 #include <string.h>
 #include "fd_oracle.h"
 
-/* Hash every structure (parallel over structures) into CSR of sorted-unique lists. */
+/* Hash every structure (parallel over structures) into CSR of sorted-unique lists.  Every thread hashes into its own scratch buffer
+ * and appends the sorted-unique list to its own arena (both only grow): no allocation per structure — the per-structure malloc / free
+ * of >= 128 KB blocks this replaced went through mmap / munmap, whose TLB shootdowns made 256 threads no faster than 64.  The arenas are
+ * concatenated in parallel. */
+#include <omp.h>
+int fdo_hash_structure_buf(const fdo_structure *s, uint64_t nbin_dist, uint64_t nbin_angle, float dist_cutoff, uint32_t **buf, uint64_t *cap_io,
+                           uint64_t *n_out);
 int fdo_hash_batch(const fdo_structure *const *structs, uint64_t S, uint64_t nbin_dist, uint64_t nbin_angle,
                    float dist_cutoff, uint32_t **out_hashes, uint64_t **out_off) {
-    uint32_t **lists = (uint32_t **)calloc(S ? S : 1, sizeof *lists);
     uint64_t *cnt = (uint64_t *)calloc(S + 1, sizeof *cnt);
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int64_t id = 0; id < (int64_t)S; ++id) {
-        uint32_t *h = NULL;
-        uint64_t n = 0;
-        fdo_hash_structure(structs[id], nbin_dist, nbin_angle, dist_cutoff, &h, &n);
-        n = fdo_sort_dedup_u32(h, n);
-        lists[id] = h;
-        cnt[id + 1] = n;
+    uint64_t *where = (uint64_t *)calloc(S ? S : 1, sizeof *where);      /* offset of the structure's list inside its thread's arena */
+    int *owner = (int *)calloc(S ? S : 1, sizeof *owner);
+    int T = omp_get_max_threads();
+    uint32_t **arena = (uint32_t **)calloc((size_t)T, sizeof *arena);
+#pragma omp parallel
+    {
+        const int tid = omp_get_thread_num();
+        uint32_t *scratch = NULL, *mine = NULL;
+        uint64_t cap = 0, acap = 0, an = 0;
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t id = 0; id < (int64_t)S; ++id) {
+            uint64_t n = 0;
+            fdo_hash_structure_buf(structs[id], nbin_dist, nbin_angle, dist_cutoff, &scratch, &cap, &n);
+            n = fdo_sort_dedup_u32(scratch, n);
+            if (an + n > acap) { acap = (an + n) * 2 + (1u << 20); mine = (uint32_t *)realloc(mine, acap * sizeof *mine); }
+            memcpy(mine + an, scratch, n * sizeof *mine);
+            where[id] = an; owner[id] = tid; cnt[id + 1] = n;
+            an += n;
+        }
+        arena[tid] = mine;
+        free(scratch);
     }
     for (uint64_t id = 0; id < S; ++id) cnt[id + 1] += cnt[id];
     uint32_t *all = (uint32_t *)malloc((cnt[S] ? cnt[S] : 1) * sizeof *all);
-    for (uint64_t id = 0; id < S; ++id) {
-        memcpy(all + cnt[id], lists[id], (cnt[id + 1] - cnt[id]) * sizeof *all);
-        free(lists[id]);
-    }
-    free(lists);
+#pragma omp parallel for schedule(static)
+    for (int64_t id = 0; id < (int64_t)S; ++id)
+        memcpy(all + cnt[id], arena[owner[id]] + where[id], (cnt[id + 1] - cnt[id]) * sizeof *all);
+    for (int t = 0; t < T; ++t) free(arena[t]);
+    free(arena); free(where); free(owner);
     *out_hashes = all;
     *out_off = cnt;
     return 0;
@@ -38,7 +56,6 @@ int fdo_hash_batch(const fdo_structure *const *structs, uint64_t S, uint64_t nbi
  * The reference assigns ownership by hash % T; here ownership is by table page ((hash >> 6) % T) so
  * that two workers never allocate the same page — same idea, same cost structure (every worker
  * reads every key). */
-#include <omp.h>
 fdo_index *fdo_build_index_from_lists_mt(const uint32_t *hashes, const uint64_t *off, uint64_t S, int T) {
     fdo_index *ix = fdo_index_new(30);
     if (T < 1) T = 1;

@@ -384,6 +384,29 @@ int fdo_hash_is_symmetric(uint32_t h) {
 }
 
 /* controller/feature.rs:198-231 with CombinationIterator order (combination.rs:23-44) */
+/* the same into a caller-owned buffer that only ever grows (*buf / *cap): the multi-threaded bench driver keeps one per thread, so that
+ * hashing a structure costs no mmap / munmap (a 300-residue structure's list is ~128 KB = glibc's mmap threshold; the TLB shootdown of
+ * every munmap serialised 256 threads) */
+int fdo_hash_structure_buf(const fdo_structure *s, uint64_t nbin_dist, uint64_t nbin_angle, float dist_cutoff, uint32_t **buf, uint64_t *cap_io,
+                           uint64_t *n_out) {
+    uint64_t cap = *cap_io, n = 0;
+    uint32_t *v = *buf;
+    if (!v || cap < 1024) { cap = 1024; v = (uint32_t *)realloc(v, cap * sizeof *v); }
+    float feat[9] = {0};
+    for (int64_t i = 0; i < s->n; ++i) {
+        for (int64_t j = 0; j < s->n; ++j) {
+            if (i == j) continue;
+            if (!fdo_pair_feature(s, i, j, dist_cutoff, feat)) continue;
+            for (uint64_t k = 0; k < (g_multi_n ? g_multi_n : 1); ++k) {
+                uint32_t h = g_multi_n ? fdo_hash_cfg(feat, g_multi[k][0], g_multi[k][1]) : fdo_hash_any(feat, nbin_dist, nbin_angle);
+                if (n == cap) { cap *= 2; v = (uint32_t *)realloc(v, cap * sizeof *v); }
+                v[n++] = h;
+            }
+        }
+    }
+    *buf = v; *cap_io = cap; *n_out = n;
+    return 0;
+}
 int fdo_hash_structure(const fdo_structure *s, uint64_t nbin_dist, uint64_t nbin_angle, float dist_cutoff,
                        uint32_t **out, uint64_t *n_out) {
     uint64_t cap = 1024, n = 0;
