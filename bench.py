@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-query", action="store_true")
     ap.add_argument("--no-export", action="store_true")
+    ap.add_argument("--build-chunk-blocks", type=int, default=3, help="generated blocks of 67,750 structures per fdgpu_index_build call (3: 203,250 structures, "
+                    "~6.7e9 keys, the MSD build's 64-bit positions; 1: one call per block as in rounds 1-2)")
     ap.add_argument("--no-cli-index", action="store_true", help="skip the drop-in `index` leg (20,500 structures as .pdb.gz files and as a Foldcomp database)")
     ap.add_argument("--no-replicas", action="store_true", help="skip the query-replica leg of --gpus N > 1 (index replicated, queries sharded)")
     return ap.parse_args()
@@ -103,9 +105,9 @@ def cpu_baseline_build(ps_sample, n_threads, fit_structs=0):
     os.environ["OMP_NUM_THREADS"] = str(n_threads)
     structs = packed_to_oracle_structs(ps_sample)
     t0 = time.perf_counter()
-    h, off = oracle.hash_batch(structs)        # pass 1 (collect_and_count, controller/mod.rs:274-365)
+    h, off = oracle.hash_batch(structs, n_threads=n_threads)        # pass 1 (collect_and_count, controller/mod.rs:274-365)
     t1 = time.perf_counter()
-    h2, off2 = oracle.hash_batch(structs)      # pass 2 (add_entries, controller/mod.rs:367-441): the reference hashes twice
+    h2, off2 = oracle.hash_batch(structs, n_threads=n_threads)      # pass 2 (add_entries, controller/mod.rs:367-441): the reference hashes twice
     t2 = time.perf_counter()
     oracle.build_index_from_lists_mt(h, off, n_threads)
     t3 = time.perf_counter()
@@ -242,8 +244,23 @@ def main():
         keep = (ro, d["n_xyz"], d["ca_xyz"], d["cb_xyz"], d["aa"])
         return ctx.wrap_device(n, int(ro[-1].item()), ro.data_ptr(), d["n_xyz"].data_ptr(), d["ca_xyz"].data_ptr(), d["cb_xyz"].data_ptr(),
                                d["aa"].data_ptr(), None, keepalive=keep)
+    def cat_blocks(bs):
+        if len(bs) == 1:
+            return bs[0]
+        out = {k: torch.cat([b[k] for b in bs]) for k in bs[0] if k != "res_off"}
+        offs, base = [bs[0]["res_off"][:1]], 0
+        for b in bs:
+            offs.append(b["res_off"][1:] + base)
+            base += int(b["res_off"][-1].item())
+        out["res_off"] = torch.cat(offs).contiguous()
+        return out
+    # build calls: groups of consecutive blocks (one fdgpu_index_build each; <= 2^18 structures for the 6-byte sort elements)
+    g = max(1, min(args.build_chunk_blocks, (1 << 18) // GEN_BLOCK))
+    blocks = [cat_blocks(blocks[k:k + g]) for k in range(0, len(blocks), g)]
+    torch.cuda.synchronize()
     chunk_batches = [wrap(d) for d in blocks]
     R = sum(int(d["res_off"][-1].item()) for d in blocks)
+    CALL_MAX = max((len(d["res_off"]) - 1 for d in blocks), default=0)
 
     def build_shard():
         """the rank's whole index: one build call per block, then the device merge into ONE resident index"""
@@ -440,7 +457,7 @@ def main():
             "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
             "config": {"workload": f"Swiss-Prot scale: {S_total} synthetic AFDB-shaped structures ({int(R_tot)} residues, {int(post_tot)} postings, "
                                    f"{int(vlen_tot)} value bytes) index build, PDBTrRosetta default; {world} rank(s), contiguous id ranges, "
-                                   f"per rank {-(-S // GEN_BLOCK)} build call(s) of <= {GEN_BLOCK} structures merged on the device into one resident index",
+                                   f"per rank {len(chunk_batches) if chunk_batches else -(-S // CALL_MAX)} build call(s) of <= {CALL_MAX} structures merged on the device into one resident index",
                        "structures": S_total, "structures_per_gpu": S, "residues": int(R_tot), "postings": int(post_tot),
                        "parallelism": f"shard-by-structure x{world}"},
             "roofline": roofline, "export_inclusive": export, "cpu_baseline": cpu, "query": query, "cli_index": cli_index,

@@ -185,6 +185,7 @@ extern "C" void fdgpu_query_map_free(fd_query_map *m) {
     if (!m) return;
     free(m->hash); free(m->qi); free(m->qj); free(m->is_primary); free(m->idf); free(m->indices); free(m->primary_hash);
     free(m->aad_aa1); free(m->aad_aa2); free(m->aad_dist); free(m->aad_qi);
+    free(m->post_len); free(m->post_seg);
     free(m);
 }
 
@@ -322,31 +323,19 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         if ((rc = hash_features_q(c, vf.data(), nc, fd_make_consts_cfg(p, k).q, mh_cfg[k].data(), FD_QF))) return rc;
     }
     if (qtrace) fprintf(stderr, "[fdgpu_query_map] hashed at %.3f ms\n", q_ms());
-    // idf of every pair's observed (primary) hash: log2(S / len) (query.rs:17-32)
-    std::vector<float> pair_idf(std::max<uint64_t>(np, 1), 0.0f);
     std::vector<uint32_t> pair_primary(std::max<uint64_t>(np, 1), 0u);
     for (uint64_t t = 0; t < nc; ++t)
         if (cands[t].primary) pair_primary[cands[t].pair] = hashes[t];
-    if (index) {
-        std::vector<uint32_t> ph, pk;
-        for (uint64_t t = 0; t < nc; ++t)
-            if (cands[t].primary) { ph.push_back(hashes[t]); pk.push_back(cands[t].pair); }
-        std::vector<uint64_t> lens(std::max<size_t>(ph.size(), 1));
-        if ((rc = fdgpu_posting_lengths(c, index, ph.data(), ph.size(), lens.data()))) return rc;
-        for (size_t t = 0; t < ph.size(); ++t)
-            pair_idf[pk[t]] = lens[t] > 0 ? log2f(total_structures / (float)lens[t]) : 0.0f;
-    }
-    if (qtrace) fprintf(stderr, "[fdgpu_query_map] posting lengths at %.3f ms\n", q_ms());
+    // first insertion wins (the reference's hash map keeps the entry a hash was first inserted with).  Few candidates: a hash set;
+    // many (whole-structure queries, ~10^5): (hash << 32 | insertion position) keys through an LSD radix sort, first key of every
+    // hash kept, survivors back in insertion order — a third of the hash set's time there
+    const uint64_t ncfg1 = std::max(n_cfg, 1u);
+    std::vector<std::vector<uint32_t>> keeps(n_queries);      // per query: insertion positions (candidate * n_cfg + bin pair) that enter the map, ascending
+    uint64_t n_keep = 0;
     for (uint64_t t = 0; t < n_queries; ++t) {
-        std::vector<uint32_t> mh, mqi, mqj, mph;
-        std::vector<uint8_t> mp;
-        std::vector<float> mi;
-        // first insertion wins (the reference's hash map keeps the entry a hash was first inserted with).  Few candidates: a hash set;
-        // many (whole-structure queries, ~10^5): (hash << 32 | insertion position) keys through an LSD radix sort, first key of every
-        // hash kept, survivors back in insertion order — a third of the hash set's time there
-        const uint64_t c0 = cand_off[t], c1 = cand_off[t + 1], ncfg1 = std::max(n_cfg, 1u), n_ins = (c1 - c0) * ncfg1;
+        const uint64_t c0 = cand_off[t], c1 = cand_off[t + 1], n_ins = (c1 - c0) * ncfg1;
         auto hash_at = [&](uint64_t pos) { const uint64_t z = c0 + pos / ncfg1; const uint32_t k = (uint32_t)(pos % ncfg1); return n_cfg ? mh_cfg[k][z] : hashes[z]; };
-        std::vector<uint32_t> keep;          // insertion positions (candidate * n_cfg + bin pair) that enter the map, ascending
+        std::vector<uint32_t> &keep = keeps[t];
         if (n_ins <= 4096 || n_ins >= (1ull << 32)) {
             std::unordered_set<uint32_t> have;
             have.reserve((size_t)n_ins / 4 + 16);
@@ -366,6 +355,38 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             for (uint64_t k = 0; k < n_ins; ++k) if (k == 0 || (key[k] >> 32) != (key[k - 1] >> 32)) first[(uint32_t)key[k]] = 1;
             for (uint64_t pos = 0; pos < n_ins; ++pos) if (first[pos]) keep.push_back((uint32_t)pos);
         }
+        n_keep += keep.size();
+    }
+    if (qtrace) fprintf(stderr, "[fdgpu_query_map] first insertions at %.3f ms\n", q_ms());
+    // ONE posting-length pass: the observed (primary) hash of every pair — idf = log2(S / len), query.rs:17-32 — and every entry that
+    // enters a map; the maps remember the latter (post_len / post_seg) so that scoring them needs no second pass over the same lists
+    std::vector<float> pair_idf(std::max<uint64_t>(np, 1), 0.0f);
+    std::vector<uint64_t> ent_len;
+    std::vector<uint32_t> ent_seg;
+    if (index) {
+        std::vector<uint32_t> ph, pk;
+        ph.reserve(n_keep + np);
+        for (uint64_t t = 0; t < n_queries; ++t) {
+            const uint64_t c0 = cand_off[t];
+            for (uint32_t pos : keeps[t]) { const uint64_t z = c0 + pos / ncfg1; ph.push_back(n_cfg ? mh_cfg[pos % ncfg1][z] : hashes[z]); }
+        }
+        for (uint64_t t = 0; t < nc; ++t)
+            if (cands[t].primary) { ph.push_back(hashes[t]); pk.push_back(cands[t].pair); }
+        ent_len.assign(std::max<size_t>(ph.size(), 1), 0);
+        ent_seg.assign(std::max<size_t>(ph.size(), 1), 0);
+        if ((rc = fd_posting_lengths_segs(c, index, ph.data(), ph.size(), ent_len.data(), ent_seg.data()))) return rc;
+        for (size_t t = 0; t < pk.size(); ++t)
+            pair_idf[pk[t]] = ent_len[n_keep + t] > 0 ? log2f(total_structures / (float)ent_len[n_keep + t]) : 0.0f;
+    }
+    if (qtrace) fprintf(stderr, "[fdgpu_query_map] posting lengths at %.3f ms\n", q_ms());
+    uint64_t keep_at = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        std::vector<uint32_t> mh, mqi, mqj, mph;
+        std::vector<uint8_t> mp;
+        std::vector<float> mi;
+        const uint64_t c0 = cand_off[t];
+        auto hash_at = [&](uint64_t pos) { const uint64_t z = c0 + pos / ncfg1; const uint32_t k = (uint32_t)(pos % ncfg1); return n_cfg ? mh_cfg[k][z] : hashes[z]; };
+        const std::vector<uint32_t> &keep = keeps[t];
         mh.reserve(keep.size()); mqi.reserve(keep.size()); mqj.reserve(keep.size()); mp.reserve(keep.size()); mi.reserve(keep.size()); mph.reserve(keep.size());
         for (uint32_t pos : keep) {
             const uint64_t z = c0 + pos / ncfg1;
@@ -376,6 +397,14 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         if (!m) { for (uint64_t u = 0; u < t; ++u) { fdgpu_query_map_free(out[u]); out[u] = nullptr; } return FDGPU_ENOMEM; }
         m->n = mh.size();
         m->hash = dup_vec(mh); m->qi = dup_vec(mqi); m->qj = dup_vec(mqj); m->is_primary = dup_vec(mp); m->idf = dup_vec(mi); m->primary_hash = dup_vec(mph);
+        if (index && !keep.empty()) {
+            m->post_len = (uint64_t *)malloc(keep.size() * 8); m->post_seg = (uint32_t *)malloc(keep.size() * 4);
+            if (m->post_len && m->post_seg) {
+                memcpy(m->post_len, &ent_len[keep_at], keep.size() * 8); memcpy(m->post_seg, &ent_seg[keep_at], keep.size() * 4);
+                m->post_index_uid = index->uid;
+            } else { free(m->post_len); free(m->post_seg); m->post_len = nullptr; m->post_seg = nullptr; }
+        }
+        keep_at += keep.size();
         std::vector<uint32_t> idx(q_index + q_off[t], q_index + q_off[t + 1]);
         m->n_indices = idx.size(); m->indices = dup_vec(idx);
         const Aad &A = aads[t];

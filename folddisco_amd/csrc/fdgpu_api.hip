@@ -639,7 +639,10 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     }
     if (rc) return rc;
     P = P1 * n_cfg;                         // every bin pair of --multiple-bins contributes one key per ordered residue pair
-    if (P >= 0xffffffffull) FAIL(c, FDGPU_ERANGE, "more than 2^32 residue pairs in one build call; split the shard");
+    // the MSD build addresses its keys with 64 bits (one call then covers 2^18 structures: ~8.7e9 keys of AFDB-shaped ones, 105 GB of sort
+    // workspace); the other paths keep 32-bit positions
+    if (P >= 0xffffffffull && !msd) FAIL(c, FDGPU_ERANGE, "more than 2^32 residue pairs in one build call; split the shard");
+    if (P >= (1ull << 35)) FAIL(c, FDGPU_ERANGE, "more than 2^35 residue pairs in one build call; split the shard");
     if ((rc = ensure_sort_ws(c, P, ids16 ? 2 : 4))) return rc;
     uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *kb = c->ws[WS_KEYS_B].as<uint32_t>();
     void *ia = c->ws[WS_IDS_A].p, *ib = c->ws[WS_IDS_B].p;
@@ -963,6 +966,17 @@ int fd_posting_lengths_dev(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *
     HIPCHK(c, hipGetLastError());
     return FDGPU_OK;
 }
+// lengths and the number of CQ_SEG-byte scoring segments of every hash (what k_cq_plan will find again), one synchronisation
+int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs) {
+    if (!nq) return FDGPU_OK;
+    uint64_t *d = nullptr;
+    int rc = fd_posting_lengths_dev(c, ix, q_hash, nq, &d);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(lengths, d, nq * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(segs, c->ws[WS_CQ_NSEG].p, nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDGPU_OK;
+}
 extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths) { FD_LOCK(c);
     if (!c || !ix || (nq && (!q_hash || !lengths))) return FDGPU_EINVAL;
     if (!nq) return FDGPU_OK;
@@ -1051,7 +1065,7 @@ static bool fd_cq_rows(const uint32_t *q_hash, const uint32_t *q_node, const uin
     }
     return fits;
 }
-static int cq_score(fdgpu_ctx *c, const cq_args &A) {
+static int cq_score(fdgpu_ctx *c, const cq_args &A, int64_t known_segments = -1) {
     hipStream_t st = c->stream;
     HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(A.nq * 8));
     HIPCHK(c, c->ws[WS_CQ_NSEG].ensure(A.nq * 4));
@@ -1062,9 +1076,11 @@ static int cq_score(fdgpu_ctx *c, const cq_args &A) {
     fd_exclusive_scan<uint32_t>(c->ws[WS_CQ_NSEG].as<uint32_t>(), A.nq, c->ws[WS_CQ_WSTART].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
                                 c->ws[WS_TOTAL].as<uint64_t>(), st);
     HIPCHK(c, hipGetLastError());
-    uint64_t W = 0;
-    int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &W);
-    if (rc) return rc;
+    uint64_t W = (uint64_t)known_segments;      // the caller knows the work count (query maps remember their hashes' segments): no round trip
+    if (known_segments < 0) {
+        int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &W);
+        if (rc) return rc;
+    }
     HIPCHK(c, c->ws[WS_CQ_SEGSUM].ensure(std::max<uint64_t>(W, 1) * 4));
     fd_launch_cq_seg(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_WSTART].as<uint64_t>(), c->ws[WS_CQ_SEGSUM].as<uint32_t>(), W, W > 0, st);
     return FDGPU_OK;
@@ -1167,7 +1183,7 @@ static uint64_t fd_rank_trim(fd_count_rec *r, uint64_t n, uint32_t top_n) {
 // takes the compacting path together with the other ranks).  Calls the device selection does not serve return host records as usual.
 int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                               const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
-                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev) {
+                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev, int64_t known_segments) {
     if (!c || !ix || !out || !out_off || !q_off || (ix->n_structures && !penalty && !ix->penalty)) return FDGPU_EINVAL;
     *out = nullptr; *out_off = nullptr;
     reset_timings(c);
@@ -1219,7 +1235,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     std::vector<uint64_t> slices;        // outlives its asynchronous copy (every path below synchronises the stream before returning)
     {
         StageTimer t(c, "cq_batch", 0);
-        int rs = cq_score(c, A);
+        int rs = cq_score(c, A, known_segments);
         if (rs) { free(ooff); return rs; }
         if (sliced) {      // slices at node boundaries (see fdgpu_count_query)
             const uint64_t per = (nq + 31) / 32;
@@ -1278,7 +1294,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         }
         if (overflow) {   // more ties at the cut-off than the selection's slots hold: the compacting path ranks that call
             free(ooff);
-            return fd_count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off, false, nullptr);
+            return fd_count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off, false, nullptr, known_segments);
         }
         fd_count_rec *rr = (fd_count_rec *)malloc(std::max<uint64_t>(tot, 1) * sizeof(fd_count_rec));
         if (!rr) { free(ooff); return FDGPU_ENOMEM; }
@@ -1426,8 +1442,9 @@ uint64_t fd_maps_hashes(uint64_t n_queries, const fd_query_map *const *qms, std:
 // of primary_hash[] — what a sharded index needs, whose make_query_map saw one shard only
 int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const uint64_t *len,
                             const uint64_t *primary_len, const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out,
-                            uint64_t **out_off, fd_cq_dev_out *dev) {
+                            uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg) {
     uint64_t nq = 0;
+    int64_t W = seg ? 0 : -1;
     for (uint64_t t = 0; t < n_queries; ++t) nq += qms[t]->n;
     std::vector<uint64_t> q_off(n_queries + 1, 0);
     std::vector<uint32_t> qh, qn, qe;
@@ -1441,11 +1458,12 @@ int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_quer
             if (!len[at]) continue;
             qh.push_back(m->hash[k]); qn.push_back(m->qi[k]); qe.push_back(m->qj[k]);
             qi.push_back(log2f(total_structures / (float)len[at]));       // f32 like the reference's (total / len).log2()
+            if (seg) W += seg[at];
         }
         q_off[t + 1] = qh.size();
     }
-    if (qh.empty()) { qh.push_back(0); qn.push_back(0); qe.push_back(0); qi.push_back(0.0f); }
-    return fd_count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off, true, dev);
+    if (qh.empty()) { qh.push_back(0); qn.push_back(0); qe.push_back(0); qi.push_back(0.0f); W = seg ? 0 : -1; }
+    return fd_count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off, true, dev, W);
 }
 extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty,
                                           float total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
@@ -1454,11 +1472,20 @@ extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, u
     for (uint64_t t = 0; t < n_queries; ++t) { if (!qms[t]) return FDGPU_EINVAL; nq += qms[t]->n; }
     std::vector<uint32_t> h(std::max<uint64_t>(nq, 1));
     std::vector<uint64_t> len(std::max<uint64_t>(nq, 1), 0);
+    std::vector<uint32_t> seg(std::max<uint64_t>(nq, 1), 0);
+    bool remembered = nq > 0;       // maps made against THIS index carry their hashes' posting lengths and segment counts
+    for (uint64_t t = 0; t < n_queries; ++t) remembered = remembered && (!qms[t]->n || (qms[t]->post_len && qms[t]->post_seg && qms[t]->post_index_uid == ix->uid));
     uint64_t at = 0;
-    for (uint64_t t = 0; t < n_queries; ++t) { if (qms[t]->n) memcpy(&h[at], qms[t]->hash, qms[t]->n * 4); at += qms[t]->n; }
-    int rc = nq && ix->n_structures ? fdgpu_posting_lengths(c, ix, h.data(), nq, len.data()) : FDGPU_OK;
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        if (qms[t]->n) {
+            if (remembered) { memcpy(&len[at], qms[t]->post_len, qms[t]->n * 8); memcpy(&seg[at], qms[t]->post_seg, qms[t]->n * 4); }
+            else memcpy(&h[at], qms[t]->hash, qms[t]->n * 4);
+        }
+        at += qms[t]->n;
+    }
+    int rc = !remembered && nq && ix->n_structures ? fd_posting_lengths_segs(c, ix, h.data(), nq, len.data(), seg.data()) : FDGPU_OK;
     if (rc) return rc;
-    return fd_count_query_maps_len(c, ix, n_queries, qms, len.data(), nullptr, penalty, total_structures, top_n, out, out_off, nullptr);
+    return fd_count_query_maps_len(c, ix, n_queries, qms, len.data(), nullptr, penalty, total_structures, top_n, out, out_off, nullptr, seg.data());
 }
 // The two halves of the sharded form for hosts that bring their own transport (MPI, gloo, ...): the LOCAL posting lengths of the maps'
 // hash[] and primary_hash[] (2 * sum(n) values, fd_maps_hashes order) — the caller sums them over the ranks — and the scoring of the

