@@ -546,6 +546,7 @@ extern "C" void fdgpu_index_destroy(fdgpu_index *ix) {
         ix->ctx->pool_free(ix->last_ids, ix->cap_last);
     } else { (void)hipFree(ix->hashes); (void)hipFree(ix->offsets); (void)hipFree(ix->value); (void)hipFree(ix->last_ids); }
     if (ix->penalty) (void)hipFree(ix->penalty);
+    if (ix->lens) (void)hipFree(ix->lens);
     delete ix;
 }
 extern "C" int fdgpu_index_set_first_id(fdgpu_index *ix, uint64_t first_id) { if (!ix || first_id + ix->n_structures > 0xffffffffull) return FDGPU_EINVAL; ix->first_id = first_id; return FDGPU_OK; }
@@ -957,6 +958,26 @@ int fd_posting_lengths_dev(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(nq * 8));
     HIPCHK(c, c->ws[WS_CQ_NSEG].ensure(nq * 4));
+    static const bool lens_cache = [] { const char *e = getenv("FDGPU_LENS_CACHE"); return !(e && e[0] == '0'); }();
+    if (lens_cache && ix->n_hashes) {
+        // the index remembers the length of every list (4 bytes per hash, one pass over the value bytes on the first request)
+        {
+            std::lock_guard<std::mutex> lk(ix->lens_mu);
+            if (!ix->lens) {
+                uint32_t *l = nullptr;
+                HIPCHK(c, hipMalloc((void **)&l, ix->n_hashes * 4));
+                fd_launch_index_lens(ix->offsets, ix->value, ix->n_hashes, l, st);
+                hipError_t le = hipGetLastError();
+                if (le == hipSuccess) le = hipStreamSynchronize(st);      // other contexts read it from their own streams
+                if (le != hipSuccess) { (void)hipFree(l); c->err = std::string("posting lengths of the index: ") + hipGetErrorString(le); return FDGPU_EHIP; }
+                ix->lens = l;
+            }
+        }
+        fd_launch_posting_lookup(ix->hashes, ix->offsets, ix->lens, ix->n_hashes, c->ws[WS_MISC0].as<uint32_t>(), nq, c->ws[WS_MISC1].as<uint64_t>(),
+                                 c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
+        HIPCHK(c, hipGetLastError());
+        return FDGPU_OK;
+    }
     HIPCHK(c, c->ws[WS_CQ_WSTART].ensure((nq + 2) * 8));
     HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(nq) * 8 + 64));
     HIPCHK(c, c->ws[WS_TOTAL].ensure(64));

@@ -157,6 +157,8 @@ struct fdgpu_index {
     uint32_t *last_ids = nullptr; // device [H] last structure id of every list (written by the encoder; the device merge re-bases the next
                                   // part's first delta against it); null for an index that was loaded — computed on demand
     size_t cap_hashes = 0, cap_offsets = 0, cap_value = 0, cap_last = 0;
+    mutable uint32_t *lens = nullptr;   // device [H] posting length of every list, made on the first length request (fd_posting_lengths_dev)
+    mutable std::mutex lens_mu;         // several contexts (streams) may share one index: the first one fills lens, complete before it is published
     uint64_t uid = fd_next_index_uid();   // identifies the index in what query maps remember about it (an address can be reused)
     float *penalty = nullptr;     // device [n_structures] length penalty set with fdgpu_index_set_penalty (count queries may then pass NULL)
 };
@@ -228,6 +230,9 @@ struct cq_args {
 void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,
                                uint64_t nq, uint64_t *lengths, long long *kidx, uint32_t *nseg, uint64_t *wstart, uint64_t *scan_tmp, uint64_t *total,
                                hipStream_t st);
+void fd_launch_index_lens(const uint64_t *offsets, const uint8_t *value, uint64_t H, uint32_t *lens, hipStream_t st);
+void fd_launch_posting_lookup(const uint32_t *hashes, const uint64_t *offsets, const uint32_t *lens, uint64_t H, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths,
+                              uint32_t *nseg, hipStream_t st);
 void fd_launch_cq_plan(const cq_args &A, long long *kidx, uint32_t *nseg, hipStream_t st);
 void fd_launch_cq_seg(const cq_args &A, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
                       hipStream_t st);

@@ -837,6 +837,41 @@ void fd_launch_cq_compact_batch(const cq_args &A, const uint32_t *node_cnt, cons
                                   pos, penalty, A.S, total, A.first_id, (fd_count_rec_dev *)out);
 }
 
+// Posting length of EVERY list of an index (ids per hash = bytes without the continuation bit), one wavefront per list, four per
+// workgroup: computed once per index, on the first length request — a batch of queries then looks its lengths up (k_pl_lookup) instead
+// of reading its hashes' posting bytes a third time (length pass, segment sums, scoring)
+__global__ __launch_bounds__(256) void k_index_lens(const uint64_t *__restrict__ offsets, const uint8_t *__restrict__ value, uint64_t H, uint32_t *__restrict__ lens) {
+    const uint64_t t = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (t >= H) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t b0 = offsets[t], b1 = offsets[t + 1];
+    uint32_t cnt = 0;
+    for (uint64_t p = b0 + (uint64_t)lane * 16; p < b1; p += 64 * 16) {
+        if (p + 16 <= b1) {
+            unsigned long long w0, w1;
+            __builtin_memcpy(&w0, value + p, 8); __builtin_memcpy(&w1, value + p + 8, 8);
+            cnt += 16u - (uint32_t)__popcll(w0 & 0x8080808080808080ull) - (uint32_t)__popcll(w1 & 0x8080808080808080ull);
+        } else for (uint64_t z = p; z < b1; ++z) cnt += (value[z] & 0x80u) ? 0u : 1u;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, FD_WAVE);
+    if (lane == 0) lens[t] = cnt;
+}
+void fd_launch_index_lens(const uint64_t *offsets, const uint8_t *value, uint64_t H, uint32_t *lens, hipStream_t st) {
+    if (H) hipLaunchKernelGGL(k_index_lens, dim3((unsigned)((H + 3) / 4)), dim3(256), 0, st, offsets, value, H, lens);
+}
+__global__ void k_pl_lookup(const uint32_t *__restrict__ hashes, const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ lens, uint64_t H,
+                            const uint32_t *__restrict__ q_hash, uint64_t nq, unsigned long long *__restrict__ lengths, uint32_t *__restrict__ nseg) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int64_t k = find_hash(hashes, H, q_hash[q]);
+    lengths[q] = k < 0 ? 0ull : (unsigned long long)lens[k];
+    nseg[q] = k < 0 ? 0u : (uint32_t)((offsets[k + 1] - offsets[k] + CQ_SEG - 1) / CQ_SEG);
+}
+void fd_launch_posting_lookup(const uint32_t *hashes, const uint64_t *offsets, const uint32_t *lens, uint64_t H, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths,
+                              uint32_t *nseg, hipStream_t st) {
+    if (nq) hipLaunchKernelGGL(k_pl_lookup, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, hashes, offsets, lens, H, q_hash, nq, (unsigned long long *)lengths, nseg);
+}
+
 // kidx / nseg / wstart / scan_tmp / total: plan workspaces for nq hashes (k_cq_plan + exclusive scan)
 void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,
                                uint64_t nq, uint64_t *lengths, long long *kidx, uint32_t *nseg, uint64_t *wstart, uint64_t *scan_tmp, uint64_t *total,
