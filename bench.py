@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--structures", type=int, default=542000, help="structures in the WHOLE database (split over the ranks)")
     ap.add_argument("--seed", type=int, default=20260927)
     ap.add_argument("--cpu-sample", type=int, default=6144, help="structures timed on the host for cpu_baseline")
-    ap.add_argument("--queries", type=int, default=64)
+    ap.add_argument("--queries", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-query", action="store_true")
     ap.add_argument("--no-export", action="store_true")

@@ -578,11 +578,11 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     // MSD build (default encoding, 6-byte elements): the pair kernel writes the keys partitioned by the top six hash bits (forty buckets,
     // residues visited in amino-acid order) and every bucket is sorted by the remaining 24 bits — three 8-bit passes instead of four.
     // FDGPU_MSD=0 selects the structure-major stream + four passes (A/B measurements, tests).
-    static const bool msd_env = [] { const char *e = getenv("FDGPU_MSD"); return !(e && e[0] == '0'); }();
+    const bool msd_env = [] { const char *e = getenv("FDGPU_MSD"); return !(e && e[0] == '0'); }();      // read per call: tests flip it
     const bool msd = msd_env && ids16 && n_cfg == 1 && p->hash_type == FDGPU_HASH_PDBTR && S > 0;
     const uint32_t NB = 40;
     fd_batch_view V = b->view();
-    static const bool msd_perm = [] { const char *e = getenv("FDGPU_MSD_PERM"); return !(e && e[0] == '0'); }();      // 0: buckets without the amino-acid order (measurement)
+    const bool msd_perm = [] { const char *e = getenv("FDGPU_MSD_PERM"); return !(e && e[0] == '0'); }();      // 0: buckets without the amino-acid order (measurement)
     if (msd && !msd_perm) {
         StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame)));
         fd_launch_frames(b->view(), b->n_res, c->ws[WS_FRAMES].p, st);
@@ -1633,18 +1633,32 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
                 all_qi[k] = q->aad_qi[e]; all_dist[k] = q->aad_dist[e];
             }
     }
+    // queries whose observed-distance lists do not fit the kernel's LDS copy (whole-structure queries: ~10^2 distances per residue-type
+    // pair): a second copy with every group in ascending order — the scan's window test bisects it instead of walking the list
+    bool want_sorted = false;
+    for (uint64_t t = 0; t < n_queries; ++t) want_sorted = want_sorted || qtab[t].n_aad > 1024u;
+    std::vector<float> all_sorted;
+    if (want_sorted) {
+        all_sorted = all_dist;
+        for (uint64_t t = 0; t < n_queries; ++t) {
+            const uint32_t *stt = &all_start[1025 * t];
+            float *base = all_sorted.data() + qtab[t].aad_off;
+            for (int g = 0; g < 1024; ++g) if (stt[g + 1] - stt[g] > 1) std::sort(base + stt[g], base + stt[g + 1]);
+        }
+    }
     const size_t nw = wc.size(), na = all_dist.size(), nh = all_hashes.size();
     // one packed host block -> one H2D copy: [cand | wc | wi | wq | hashes | start tables | dist | qi | qtab]
     auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
     const size_t o_cand = 0, o_wc = o_cand + up4(n_cand), o_wi = o_wc + up4(nw), o_wq = o_wi + up4(nw), o_wj = o_wq + up4(nw), o_h = o_wj + up4(nw),
                  o_st = o_h + up4(nh), o_d = o_st + up4(all_start.size()), o_qi = o_d + up4(na), o_qt = o_qi + up4(na),
-                 words = o_qt + up4(n_queries * (sizeof(mp_query_dev) / 4)) + 4;
+                 o_ds = o_qt + up4(n_queries * (sizeof(mp_query_dev) / 4)), words = o_ds + (want_sorted ? up4(na) : 0) + 4;
     std::vector<uint32_t> blk(words, 0);
     if (n_cand) memcpy(&blk[o_cand], cand, n_cand * 4);
     if (nw) { memcpy(&blk[o_wc], wc.data(), nw * 4); memcpy(&blk[o_wi], wi.data(), nw * 4); memcpy(&blk[o_wq], wq.data(), nw * 4); memcpy(&blk[o_wj], wj.data(), nw * 4); }
     if (nh) memcpy(&blk[o_h], all_hashes.data(), nh * 4);
     if (!all_start.empty()) memcpy(&blk[o_st], all_start.data(), all_start.size() * 4);
     if (na) { memcpy(&blk[o_d], all_dist.data(), na * 4); memcpy(&blk[o_qi], all_qi.data(), na * 4); }
+    if (want_sorted && na) memcpy(&blk[o_ds], all_sorted.data(), na * 4);
     if (n_queries) memcpy(&blk[o_qt], qtab.data(), n_queries * sizeof(mp_query_dev));
     if (mp_trace) fprintf(stderr, "[match_pairs] tables at %.3f ms (%zu work items)\n", mp_ms(), nw);
     HIPCHK(c, c->ws[WS_MISC0].ensure(words * 4));
@@ -1675,6 +1689,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     A.wi_j0 = dblk + o_wj; A.j_span = j_span;
     A.resname_std = d_std;
     A.q_hashes = dblk + o_h; A.aad_start = dblk + o_st; A.aad_dist = (const float *)(dblk + o_d); A.aad_qi = dblk + o_qi;
+    A.aad_sorted = want_sorted ? (const float *)(dblk + o_ds) : nullptr;
     A.qtab = (const mp_query_dev *)(dblk + o_qt);
     A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.found = nullptr; A.cands = nullptr;
     // one emitting pass into buffers sized by the previous calls; a pass that overflows only counts, the buffers grow and

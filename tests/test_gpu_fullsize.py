@@ -137,7 +137,7 @@ def _wrap(ctx, d):
 
 
 def test_swissprot_scale_542000_index_and_planted_motifs():
-    """configs[3]'s database on one GPU: 8 build calls merged on the device; sampled posting checks; two shipped motifs planted into 16
+    """configs[3]'s database on one GPU: 3 build calls of up to 203,250 structures (more than 2^32 keys each) merged on the device; sampled posting checks; two shipped motifs planted into 16
     structures each (first and last block included): query map, count_query over all 542,000 structures and the matches of the top 40
     candidates equal the oracle's"""
     import torch
@@ -164,8 +164,20 @@ def test_swissprot_scale_542000_index_and_planted_motifs():
                 _plant(d, int(sid), Q["motif"], rng)
                 Q["planted"].append(b * GEN_BLOCK + int(sid))
         blocks.append(d)
-        parts.append(fd.FolddiscoIndex.build(ctx, _wrap(ctx, d), first_id=fid))
-        fid += len(d["res_off"]) - 1
+    # build calls of three blocks (203,250 structures, ~6.7e9 keys: the MSD build's 64-bit positions, like bench.py), merged on the device
+    for k in range(0, n_blocks, 3):
+        grp = blocks[k:k + 3]
+        g = {key: torch.cat([b[key] for b in grp]) for key in ("n_xyz", "ca_xyz", "cb_xyz", "aa")}
+        offs, base = [grp[0]["res_off"][:1]], 0
+        for b in grp:
+            offs.append(b["res_off"][1:] + base)
+            base += int(b["res_off"][-1].item())
+        g["res_off"] = torch.cat(offs).contiguous()
+        parts.append(fd.FolddiscoIndex.build(ctx, _wrap(ctx, g), first_id=fid))
+        fid += len(g["res_off"]) - 1
+        ctx.synchronize()
+        del g
+    assert len(parts) == 3 and max(p.num_postings for p in parts) > 2 ** 32
     ix = fd.FolddiscoIndexSet(parts).merge()
     assert ix.n_structures == S and ix.num_postings == sum(p.num_postings for p in parts)
     del parts

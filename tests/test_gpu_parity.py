@@ -767,3 +767,40 @@ def test_count_query_against_recount_packed_and_wide(ctx):
         gt = fd.count_query_batch(ctx, ix, queries, pen, total_structures=total, top_n=10)
         for g, g10, w in zip(gb, gt, want):
             assert g.tobytes() == w.tobytes() and g10.tobytes() == rank_hits(w, 10).tobytes()
+
+
+def test_msd_build_equals_structure_major_build(ctx):
+    """The default index build of the default encoding (keys bucketed by the top six hash bits at emit time, residues visited in
+    amino-acid order, three segmented 8-bit sort passes) against the structure-major stream + four passes (FDGPU_MSD=0) and against the
+    buckets without the amino-acid order (FDGPU_MSD_PERM=0): byte-identical indices, for shapes that stress the bucket bookkeeping — one
+    residue type only, unknown residues and missing CB mixed in, a structure longer than one tile row, empty structures, a shard that
+    starts at a late id."""
+    import os
+    import folddisco_amd as fd
+    from folddisco_amd import synth
+    rng = np.random.Generator(np.random.PCG64(31))
+    d = synth.generate(700, seed=31, lengths=np.concatenate([rng.integers(40, 400, 690), [0, 0, 1, 2, 1500, 2600, 64, 65, 63, 128]]))
+    ps = synth.to_packed(d)
+    aa = ps.aa.copy()
+    off = ps.res_off.astype(np.int64)
+    aa[off[10]:off[11]] = 17                                    # one residue type only (Trp): two buckets
+    aa[off[20]:off[21]] = np.where(rng.random(off[21] - off[20]) < 0.3, 255, aa[off[20]:off[21]])      # unknown residues
+    cbv = np.ones(len(aa), np.uint8)
+    cbv[off[30]:off[31]] = rng.random(off[31] - off[30]) > 0.2  # missing CB
+    ps = fd.PackedStructures(ps.res_off, ps.n_xyz, ps.ca_xyz, ps.cb_xyz, aa, cbv)
+    outs = {}
+    try:
+        for tag, env in (("msd", {}), ("plain", {"FDGPU_MSD": "0"}), ("noperm", {"FDGPU_MSD_PERM": "0"})):
+            for k in ("FDGPU_MSD", "FDGPU_MSD_PERM"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            ix = fd.FolddiscoIndex.build(ctx, ctx.upload(ps), first_id=70000)
+            outs[tag] = ix.export()
+            st = dict((n, ms) for n, ms, _ in ctx.last_timings())
+    finally:
+        for k in ("FDGPU_MSD", "FDGPU_MSD_PERM"):
+            os.environ.pop(k, None)
+    for tag in ("plain", "noperm"):
+        for a, b in zip(outs["msd"], outs[tag]):
+            assert np.array_equal(a, b), tag
+    assert len(outs["msd"][1]) > 10 ** 6
