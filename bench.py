@@ -188,6 +188,12 @@ def cpu_baseline_query(ix, d, nres, res_off_h, qlist, top_n, match_top, S):
                     "stage_thread_s": {k: round(x, 2) for k, x in r64["stage_thread_s"].items()}}}
 
 
+def progress(msg):
+    """FD_BENCH_TRACE=1: a line per leg on stderr (where a multi-rank run spends its time)"""
+    if os.environ.get("FD_BENCH_TRACE"):
+        print("[bench %s r%s] %s" % (time.strftime("%H:%M:%S"), os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -291,6 +297,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
+    progress("database generated, build starts")
     ix = None
     for _ in range(args.warmup):
         ix = None
@@ -307,6 +314,7 @@ def main():
     value = S_total * args.steps / dt
     n_post, n_hash, vlen = ix.num_postings, ix.num_hashes, ix.value_len
 
+    progress("timed build done")
     # ---- export-inclusive: one more step that also brings the index to the host in the on-disk layout (fdgpu_index_export)
     export = None
     if not args.no_export:
@@ -364,6 +372,7 @@ def main():
                 "stages_ms": {k: round(v[0], 3) for k, v in agg.items()},
                 "stages_gbs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0.0 for k, v in agg.items()}}
 
+    progress("stage timings done, query leg starts")
     # ---- motif queries against the resident index of the shard
     query = None
     if not args.no_query:
@@ -383,6 +392,7 @@ def main():
         except Exception as e:  # the index-build line must still be printed
             import traceback
             query = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
+        progress("query leg done")
         # ---- query replicas (SURVEY §8e last row): every rank builds the WHOLE index (26 GB of 288) and the queries are dealt to the ranks
         if world > 1 and not args.no_replicas and query is not None and "error" not in query:
             try:
@@ -403,6 +413,7 @@ def main():
                     base += int(b["res_off"][-1].item())
                 d_full["res_off"] = torch.cat(offs).contiguous()
                 fblocks = None
+                progress("replica index built")
                 query["replicas"] = querybench.run_replicas(ctx, wrap(d_full), ixf, d_full, S_total, world, rank, dist, dev, n_queries=args.queries)
             except Exception as e:
                 import traceback

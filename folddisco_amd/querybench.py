@@ -206,11 +206,19 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             cx.close()
         return out
 
+    def progress(msg):
+        if os.environ.get("FD_BENCH_TRACE"):
+            print("[querybench %s r%d] %s" % (time.strftime("%H:%M:%S"), rank, msg), file=sys.stderr, flush=True)
     warm = range(min(8, len(queries)))
+    progress("queries picked")
     loop(False, warm)()
+    progress("warm-up done")
     dt1, (hits, hashes, _) = timed(loop(False, range(len(queries))))
+    progress("single prefilter leg done")
     dtb, hits_b = batched()
+    progress("batched prefilter leg done")
     dtbm, nm_b = batched(match=True)
+    progress("batched full leg done")
     big = 128 if len(queries) >= 128 else None          # the same full query in batches of 128 (one host thread): the per-batch synchronisations amortise
     dtbm_big = batched(chunk=big, match=True)[0] if big else None
     dtb2, mt_workers, mt_all = None, 0, {}
@@ -224,8 +232,10 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                     dtb2, mt_workers = t_w, wk
             except Exception as e:  # noqa: BLE001
                 print("[querybench] %d-context leg failed: %r" % (wk, e), file=sys.stderr)
+    progress("multi-context legs done")
     loop(True, warm)()
     dt2, (_, _, nm) = timed(loop(True, range(len(queries))))
+    progress("single full leg done")
 
     # ---- roofline of the prefilter the headline runs: one batch of 32 queries through the fused path (posting-length pass, plan, segment
     # sums + bounds + scoring = "cq_batch"; ranking keys, radix select, records of the survivors, bitonic sort = "cq_topn"), HIP events on

@@ -12,6 +12,28 @@
  * of >= 128 KB blocks this replaced went through mmap / munmap, whose TLB shootdowns made 256 threads no faster than 64.  The arenas are
  * concatenated in parallel. */
 #include <omp.h>
+#include <malloc.h>
+/* sort_unstable + dedup (controller/mod.rs:343-345) as an LSD radix sort into a caller-owned buffer: glibc's qsort mallocs a merge
+ * buffer of the list's size per call — above the mmap threshold for a 300-residue structure, i.e. one more mmap / munmap (and its TLB
+ * shootdown across all threads) per structure */
+static uint64_t sort_dedup_radix(uint32_t *v, uint64_t n, uint32_t *tmp) {
+    if (n == 0) return 0;
+    uint32_t *a = v, *b = tmp;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int sh = 8 * pass;
+        uint64_t cnt[257] = {0};
+        for (uint64_t k = 0; k < n; ++k) ++cnt[((a[k] >> sh) & 255u) + 1];
+        if (cnt[((a[0] >> sh) & 255u) + 1] == n) continue;      /* all keys share this digit */
+        for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+        for (uint64_t k = 0; k < n; ++k) b[cnt[(a[k] >> sh) & 255u]++] = a[k];
+        uint32_t *t = a; a = b; b = t;
+    }
+    uint64_t m = 1;
+    v[0] = a[0];
+    for (uint64_t k = 1; k < n; ++k)
+        if (a[k] != v[m - 1]) v[m++] = a[k];      /* a == v: in-place compaction; a == tmp: copy back while compacting (m <= k) */
+    return m;
+}
 int fdo_hash_structure_buf(const fdo_structure *s, uint64_t nbin_dist, uint64_t nbin_angle, float dist_cutoff, uint32_t **buf, uint64_t *cap_io,
                            uint64_t *n_out);
 /* threads of the OpenMP regions below (OMP_NUM_THREADS is read once, when the runtime starts: a bench that times several thread counts
@@ -23,6 +45,8 @@ int fdo_hash_batch(const fdo_structure *const *structs, uint64_t S, uint64_t nbi
     uint64_t *where = (uint64_t *)calloc(S ? S : 1, sizeof *where);      /* offset of the structure's list inside its thread's arena */
     int *owner = (int *)calloc(S ? S : 1, sizeof *owner);
     int T = omp_get_max_threads();
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);     /* the per-thread buffers below grow inside the arenas, not through mmap */
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
     uint32_t **arena = (uint32_t **)calloc((size_t)T, sizeof *arena);
     uint64_t *order = (uint64_t *)malloc((S ? S : 1) * sizeof *order);
     {   /* counting sort of the structures by residue count, descending */
@@ -37,21 +61,22 @@ int fdo_hash_batch(const fdo_structure *const *structs, uint64_t S, uint64_t nbi
 #pragma omp parallel
     {
         const int tid = omp_get_thread_num();
-        uint32_t *scratch = NULL, *mine = NULL;
-        uint64_t cap = 0, acap = 0, an = 0;
+        uint32_t *scratch = NULL, *mine = NULL, *stmp = NULL;
+        uint64_t cap = 0, acap = 0, an = 0, tcap = 0;
 #pragma omp for schedule(dynamic, 1)
         for (int64_t k = 0; k < (int64_t)S; ++k) {
             const int64_t id = (int64_t)order[k];      /* longest structures first: the loop ends with its slowest item (cost ~ residues^2) */
             uint64_t n = 0;
             fdo_hash_structure_buf(structs[id], nbin_dist, nbin_angle, dist_cutoff, &scratch, &cap, &n);
-            n = fdo_sort_dedup_u32(scratch, n);
+            if (n > tcap) { tcap = cap; stmp = (uint32_t *)realloc(stmp, tcap * sizeof *stmp); }
+            n = sort_dedup_radix(scratch, n, stmp);
             if (an + n > acap) { acap = (an + n) * 2 + (1u << 20); mine = (uint32_t *)realloc(mine, acap * sizeof *mine); }
             memcpy(mine + an, scratch, n * sizeof *mine);
             where[id] = an; owner[id] = tid; cnt[id + 1] = n;
             an += n;
         }
         arena[tid] = mine;
-        free(scratch);
+        free(scratch); free(stmp);
     }
     for (uint64_t id = 0; id < S; ++id) cnt[id + 1] += cnt[id];
     uint32_t *all = (uint32_t *)malloc((cnt[S] ? cnt[S] : 1) * sizeof *all);
