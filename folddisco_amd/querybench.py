@@ -221,17 +221,17 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     progress("batched full leg done")
     big = 128 if len(queries) >= 128 else None          # the same full query in batches of 128 (one host thread): the per-batch synchronisations amortise
     dtbm_big = batched(chunk=big, match=True)[0] if big else None
-    dtb2, mt_workers, mt_all = None, 0, {}
+    dtb2, mt_workers, mt_chunk, mt_all = None, 0, 32, {}
     if not sharded and len(queries) >= 64:
-        for wk in (2, 3):
+        for wk, ch in ((2, 32), (3, 32)) + (((3, 128),) if len(queries) >= 128 else ()):
             try:
-                t_w, nm_w = batched_mt(wk)
+                t_w, nm_w = batched_mt(wk, ch)
                 assert nm_w == nm_b * MT_REPS, (nm_w, nm_b)
-                mt_all[wk] = len(queries) * MT_REPS / t_w
+                mt_all["%dx%d" % (wk, ch)] = len(queries) * MT_REPS / t_w
                 if dtb2 is None or t_w < dtb2:
-                    dtb2, mt_workers = t_w, wk
+                    dtb2, mt_workers, mt_chunk = t_w, wk, ch
             except Exception as e:  # noqa: BLE001
-                print("[querybench] %d-context leg failed: %r" % (wk, e), file=sys.stderr)
+                print("[querybench] %d-context leg (batches of %d) failed: %r" % (wk, ch, e), file=sys.stderr)
     progress("multi-context legs done")
     loop(True, warm)()
     dt2, (_, _, nm) = timed(loop(True, range(len(queries))))
@@ -345,8 +345,8 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         "batched_with_matching_128": None if not dtbm_big else {"value": len(queries) / dtbm_big, "ms_per_query": dtbm_big / len(queries) * 1e3, "chunk": big,
                                                                 "host_threads": 1, "mode": "the same full query, 128 queries per batch, one host thread"},
         "batched_with_matching_mt": None if not dtb2 else {
-            "value": len(queries) * MT_REPS / dtb2, "ms_per_query": dtb2 / (len(queries) * MT_REPS) * 1e3, "host_threads": mt_workers, "queries": len(queries) * MT_REPS,
-            "queries_per_s_by_threads": {str(k): v for k, v in mt_all.items()},
+            "value": len(queries) * MT_REPS / dtb2, "ms_per_query": dtb2 / (len(queries) * MT_REPS) * 1e3, "host_threads": mt_workers, "chunk": mt_chunk,
+            "queries": len(queries) * MT_REPS, "queries_per_s_by_threads_x_batch": {str(k): v for k, v in mt_all.items()},
             "mode": "the same full batched query driven by several host threads with one context (stream + workspaces) each, sharing the resident index"},
         "batched": {"value": len(queries) / dtb, "ms_per_query": dtb / len(queries) * 1e3, "chunk": 32, "avg_hits": hits_b / len(queries),
                     "mode": "prefilter only: make_query_map_batch + count_query_batch_top + all-gather"},
