@@ -25,7 +25,6 @@ struct fd_hash_consts {
     uint32_t seg_mul, seg_cfg;   // --multiple-bins: a structure's segment holds seg_mul copies of its pair list, this launch fills copy seg_cfg
     fd_quant q;
     float d2_max;   // largest f32 whose sqrt is <= dist_cutoff: sqrtf(d2) > cutoff  <=>  d2 > d2_max
-    int nt_frames;  // MSD pair kernel: gather the partner's frame with non-temporal loads (measurement switch FDGPU_EMIT_NT)
     int use_tab;    // 1: default 4 angle bins -> table form of the angle fields (fd_bin_tables.h); 2: + speculative torsions
     unsigned long long *spec_miss;   // device counter of pairs the speculative path handed to the exact routine (may be null)
     unsigned long long *wide_flag;   // set when a hash does not fit 30 bits (fields are OR-ed unmasked: an infinite distance sets

@@ -316,7 +316,7 @@ static fd_hash_consts make_consts_bins(const fd_hash_params *p, uint32_t nbd_req
     float nd = (dflt || nbd_req == 0) ? (float)def_d : (nbd_req > cap_d ? (float)cap_d : (float)nbd_req);
     float na = (dflt || nba_req == 0) ? (float)def_a : (nba_req > cap_a ? (float)cap_a : (float)nba_req);
     fd_hash_consts C;
-    C.seg_mul = 1; C.seg_cfg = 0; C.nt_frames = 0;
+    C.seg_mul = 1; C.seg_cfg = 0;
     const float PI_F = 3.14159274f;
     float a_min = -1.0f, a_max = 1.0f;                                         // sin / cos fields
     if (type == FD_HASH_PDBMOTIF) { a_min = 0.0f; a_max = 180.0f; }            // degrees
@@ -566,7 +566,6 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     const uint32_t n_cfg = fd_num_bin_configs(p);
     fd_hash_consts C = fd_make_consts_cfg(p, 0);
     C.spec_miss = c->spec_miss;
-    { const char *e = getenv("FDGPU_EMIT_NT"); C.nt_frames = e && e[0] == '1' ? 1 : 0; }
     hipStream_t st = c->stream;
     uint64_t S = b->n_struct, P = 0;
     HIPCHK(c, c->ws[WS_FRAMES].ensure(std::max<uint64_t>(b->n_res, 1) * sizeof(fd_frame)));

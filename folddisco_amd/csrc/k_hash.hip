@@ -244,16 +244,6 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_count_msd(fd_batch_view B, fd_
     if (lane < FD_MSD_BUCKETS && s_cnt[lane]) atomicAdd(&counts[(uint64_t)lane * B.n_struct + s], s_cnt[lane]);
 }
 
-__device__ __forceinline__ fd_frame load_frame_nt(const fd_frame *__restrict__ frames, uint32_t r) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const f4 *p = reinterpret_cast<const f4 *>(frames + r);
-    const f4 a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1), c = __builtin_nontemporal_load(p + 2), d = __builtin_nontemporal_load(p + 3),
-             e = __builtin_nontemporal_load(p + 4);
-    fd_frame F;
-    F.ca = {a.x, a.y, a.z}; F.cb = {a.w, b.x, b.y}; F.r1 = {b.z, b.w, c.x}; F.t1 = {c.y, c.z, c.w};
-    F.s2 = {d.x, d.y, d.z}; F.nv2 = {d.w, e.x, e.y}; F.len = e.z; F.pad = e.w;
-    return F;
-}
 __device__ __forceinline__ fd_frame load_frame(const fd_frame *__restrict__ frames, uint32_t r) {
     const float4 *p = reinterpret_cast<const float4 *>(frames + r);
     float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
@@ -316,7 +306,7 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
             fd_frame Fi;
             Fi.ca = {a4.x, a4.y, a4.z}; Fi.cb = {a4.w, b4.x, b4.y}; Fi.r1 = {b4.z, b4.w, c4.x}; Fi.t1 = {c4.y, c4.z, c4.w};
             Fi.s2 = {d4.x, d4.y, d4.z}; Fi.nv2 = {d4.w, e4.x, e4.y}; Fi.len = e4.z; Fi.pad = e4.w;
-            fd_frame Fj = (MSD && C.nt_frames) ? load_frame_nt(frames, j) : load_frame(frames, j);
+            fd_frame Fj = load_frame(frames, j);
             aai = __float_as_uint(Fi.pad); aaj = __float_as_uint(Fj.pad);
             if (!fd_pair_both_spec(Fi, Fj, aai, aaj, C.q, tab, tab + 32, &h_ij, &h_ji)) {
                 uint2 h = pair_both_tab_exact(frames, i, j, B.aa[i], B.aa[j], C.q.dist_disc, C.q.ang_disc, tab);
