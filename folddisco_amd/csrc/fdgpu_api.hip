@@ -1634,16 +1634,43 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
             }
     }
     // queries whose observed-distance lists do not fit the kernel's LDS copy (whole-structure queries: ~10^2 distances per residue-type
-    // pair): a second copy with every group in ascending order — the scan's window test bisects it instead of walking the list
-    bool want_sorted = false;
-    for (uint64_t t = 0; t < n_queries; ++t) want_sorted = want_sorted || qtab[t].n_aad > 1024u;
-    std::vector<float> all_sorted;
-    if (want_sorted) {
-        all_sorted = all_dist;
+    // pair): per group the union of the float intervals {d : |d - x| < window} over its observed x, merged — the scan's window test reads
+    // one or two intervals instead of walking the list.  Exact: fl(d - x) is monotone in d, so the set of passing d of one x is an interval
+    // of floats whose ends are found by stepping from x -/+ window to the last float that still passes.
+    bool want_iv = false;
+    for (uint64_t t = 0; t < n_queries; ++t) want_iv = want_iv || qtab[t].n_aad > 1024u;
+    std::vector<uint32_t> iv_start;
+    std::vector<float> iv_lohi;      // lo, hi interleaved (float2 on the device)
+    if (want_iv) {
+        iv_start.assign((size_t)1025 * n_queries, 0);
+        std::vector<std::pair<float, float>> tmp;
         for (uint64_t t = 0; t < n_queries; ++t) {
             const uint32_t *stt = &all_start[1025 * t];
-            float *base = all_sorted.data() + qtab[t].aad_off;
-            for (int g = 0; g < 1024; ++g) if (stt[g + 1] - stt[g] > 1) std::sort(base + stt[g], base + stt[g + 1]);
+            const float *base = all_dist.data() + qtab[t].aad_off;
+            const float w = qtab[t].ca_window;
+            for (int g = 0; g < 1024; ++g) {
+                iv_start[1025 * t + g] = (uint32_t)(iv_lohi.size() / 2);
+                tmp.clear();
+                for (uint32_t e = stt[g]; e < stt[g + 1]; ++e) {
+                    const float x = base[e];
+                    if (!(fabsf(x - x) < w)) continue;                  // window <= 0 or NaN: nothing passes
+                    float hi = x + w, lo = x - w;
+                    while (!(fabsf(hi - x) < w)) hi = nextafterf(hi, -INFINITY);
+                    for (float n2 = nextafterf(hi, INFINITY); fabsf(n2 - x) < w; n2 = nextafterf(hi, INFINITY)) hi = n2;
+                    while (!(fabsf(lo - x) < w)) lo = nextafterf(lo, INFINITY);
+                    for (float n2 = nextafterf(lo, -INFINITY); fabsf(n2 - x) < w; n2 = nextafterf(lo, -INFINITY)) lo = n2;
+                    tmp.emplace_back(lo, hi);
+                }
+                std::sort(tmp.begin(), tmp.end());
+                for (size_t k = 0; k < tmp.size();) {
+                    float lo = tmp[k].first, hi = tmp[k].second;
+                    size_t z = k + 1;
+                    while (z < tmp.size() && tmp[z].first <= nextafterf(hi, INFINITY)) { hi = std::max(hi, tmp[z].second); ++z; }
+                    iv_lohi.push_back(lo); iv_lohi.push_back(hi);
+                    k = z;
+                }
+            }
+            iv_start[1025 * t + 1024] = (uint32_t)(iv_lohi.size() / 2);
         }
     }
     const size_t nw = wc.size(), na = all_dist.size(), nh = all_hashes.size();
@@ -1651,14 +1678,15 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
     const size_t o_cand = 0, o_wc = o_cand + up4(n_cand), o_wi = o_wc + up4(nw), o_wq = o_wi + up4(nw), o_wj = o_wq + up4(nw), o_h = o_wj + up4(nw),
                  o_st = o_h + up4(nh), o_d = o_st + up4(all_start.size()), o_qi = o_d + up4(na), o_qt = o_qi + up4(na),
-                 o_ds = o_qt + up4(n_queries * (sizeof(mp_query_dev) / 4)), words = o_ds + (want_sorted ? up4(na) : 0) + 4;
+                 o_ivs = o_qt + up4(n_queries * (sizeof(mp_query_dev) / 4)), o_iv = o_ivs + (want_iv ? up4(iv_start.size()) : 0),
+                 words = o_iv + (want_iv ? up4(iv_lohi.size()) : 0) + 4;
     std::vector<uint32_t> blk(words, 0);
     if (n_cand) memcpy(&blk[o_cand], cand, n_cand * 4);
     if (nw) { memcpy(&blk[o_wc], wc.data(), nw * 4); memcpy(&blk[o_wi], wi.data(), nw * 4); memcpy(&blk[o_wq], wq.data(), nw * 4); memcpy(&blk[o_wj], wj.data(), nw * 4); }
     if (nh) memcpy(&blk[o_h], all_hashes.data(), nh * 4);
     if (!all_start.empty()) memcpy(&blk[o_st], all_start.data(), all_start.size() * 4);
     if (na) { memcpy(&blk[o_d], all_dist.data(), na * 4); memcpy(&blk[o_qi], all_qi.data(), na * 4); }
-    if (want_sorted && na) memcpy(&blk[o_ds], all_sorted.data(), na * 4);
+    if (want_iv) { memcpy(&blk[o_ivs], iv_start.data(), iv_start.size() * 4); if (!iv_lohi.empty()) memcpy(&blk[o_iv], iv_lohi.data(), iv_lohi.size() * 4); }
     if (n_queries) memcpy(&blk[o_qt], qtab.data(), n_queries * sizeof(mp_query_dev));
     if (mp_trace) fprintf(stderr, "[match_pairs] tables at %.3f ms (%zu work items)\n", mp_ms(), nw);
     HIPCHK(c, c->ws[WS_MISC0].ensure(words * 4));
@@ -1689,7 +1717,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     A.wi_j0 = dblk + o_wj; A.j_span = j_span;
     A.resname_std = d_std;
     A.q_hashes = dblk + o_h; A.aad_start = dblk + o_st; A.aad_dist = (const float *)(dblk + o_d); A.aad_qi = dblk + o_qi;
-    A.aad_sorted = want_sorted ? (const float *)(dblk + o_ds) : nullptr;
+    A.iv_start = want_iv ? dblk + o_ivs : nullptr; A.iv = want_iv ? (const float2 *)(dblk + o_iv) : nullptr;
     A.qtab = (const mp_query_dev *)(dblk + o_qt);
     A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.found = nullptr; A.cands = nullptr;
     // one emitting pass into buffers sized by the previous calls; a pass that overflows only counts, the buffers grow and

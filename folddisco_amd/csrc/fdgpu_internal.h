@@ -264,7 +264,7 @@ struct mp_args {
     const uint32_t *q_hashes; uint32_t n_hashes;
     const uint32_t *aad_start;   // [1025] start of the (aa_i * 32 + aa_j) group in aad_dist / aad_qi (stable order)
     const float *aad_dist; const uint32_t *aad_qi; uint32_t n_aad;
-    const float *aad_sorted;     // optional: aad_dist with every group sorted ascending (queries too large for the LDS copy)
+    const uint32_t *iv_start; const float2 *iv;   // optional (queries too large for the LDS copy of their distances): merged pass intervals per group, [1025 * query] offsets into iv
     float ca_window;
     unsigned long long *n_found, *n_cands;
     fd_pair_rec *found; fd_cand_rec *cands;

@@ -28,7 +28,7 @@ struct mp_sel {
     const uint32_t *q_hashes; uint32_t n_hashes;
     const uint32_t *aad_start; const float *aad_dist; const uint32_t *aad_qi; uint32_t n_aad;
     uint32_t aa1_mask, aa2_mask; int use_prefilter; float ca_window;
-    const float *aad_sorted;      // large queries: every (aa_i, aa_j) group's distances once more in ascending order (the window test by bisection)
+    const uint32_t *iv_start; const float2 *iv;      // large queries: per (aa_i, aa_j) group the merged intervals of distances that pass the window test
 };
 // descriptor + hash + output of one surviving (i, j) per lane (full-wave drains of the compaction queue: executed
 // divergently per survivor this part — ~3000 instructions with the exact libm chain — was 95 % of the kernel time)
@@ -139,14 +139,14 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     mp_sel Sx;
     Sx.q_hashes = A_in.q_hashes; Sx.n_hashes = A_in.n_hashes; Sx.aad_start = A_in.aad_start; Sx.aad_dist = A_in.aad_dist; Sx.aad_qi = A_in.aad_qi;
     Sx.n_aad = A_in.n_aad; Sx.aa1_mask = A_in.aa1_mask; Sx.aa2_mask = A_in.aa2_mask; Sx.use_prefilter = A_in.use_prefilter; Sx.ca_window = A_in.ca_window;
-    Sx.aad_sorted = A_in.aad_sorted;
+    Sx.iv_start = A_in.iv_start; Sx.iv = A_in.iv;
     if (blockIdx.x < A_in.n_work) {
         const uint32_t tq = A_in.wi_query[blockIdx.x];
         const mp_query_dev Q = A_in.qtab[tq];
         Sx.q_hashes = A_in.q_hashes + Q.qh_off; Sx.n_hashes = Q.n_hashes;
         Sx.aad_start = A_in.aad_start + 1025u * tq; Sx.aad_dist = A_in.aad_dist + Q.aad_off; Sx.aad_qi = A_in.aad_qi + Q.aad_off; Sx.n_aad = Q.n_aad;
         Sx.aa1_mask = Q.aa1_mask; Sx.aa2_mask = Q.aa2_mask; Sx.use_prefilter = Q.use_prefilter; Sx.ca_window = Q.ca_window;
-        Sx.aad_sorted = A_in.aad_sorted ? A_in.aad_sorted + Q.aad_off : nullptr;
+        Sx.iv_start = A_in.iv_start ? A_in.iv_start + 1025u * tq : nullptr;      // interval offsets are absolute into A.iv
     }
     __shared__ uint32_t q[2 * FD_WAVE];
     __shared__ uint32_t tab[32];
@@ -224,14 +224,14 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                         // branch-free over the pair's own list: a short-circuit chain costs one LDS round trip per entry
                         const uint32_t e_lo = s_start[aai * 32u + aaj], e_hi = s_start[aai * 32u + aaj + 1];
                         uint32_t any = 0;
-                        if (Sx.aad_sorted && !staged) {
-                            // a whole-structure query observes ~100 distances per residue-type pair and keeps them in global memory: the
-                            // window test only asks whether ANY of them is within the window — the two neighbours of d in the sorted copy
-                            // decide that (|d - x| is monotone in x on either side of d), a bisection instead of a walk over the list
-                            uint32_t lo = e_lo, hi = e_hi;
-                            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (Sx.aad_sorted[mid] < d) lo = mid + 1; else hi = mid; }
-                            if (lo < e_hi) any |= (uint32_t)(fd_fabsf(d - Sx.aad_sorted[lo]) < Sx.ca_window);
-                            if (lo > e_lo) any |= (uint32_t)(fd_fabsf(d - Sx.aad_sorted[lo - 1]) < Sx.ca_window);
+                        if (Sx.iv_start && !staged) {
+                            // a whole-structure query observes ~100 distances per residue-type pair and keeps them in global memory.  The
+                            // window test only asks whether ANY of them is within the window of d: the host merged, per pair of types, the
+                            // float intervals [lo_x, hi_x] = {d : |d - x| < window} of all observed x (exact: |d - x| is monotone in d on
+                            // either side of x) — usually ONE interval per pair of types — so the test is one offset load and one or two
+                            // independent interval loads instead of a walk over the list
+                            const uint32_t v_lo = Sx.iv_start[aai * 32u + aaj], v_hi = Sx.iv_start[aai * 32u + aaj + 1];
+                            for (uint32_t e = v_lo; e < v_hi; ++e) { const float2 w2 = Sx.iv[e]; any |= (uint32_t)(d >= w2.x && d <= w2.y); }
                         } else
                             for (uint32_t e = e_lo; e < e_hi; ++e) any |= (uint32_t)(fd_fabsf(d - dist_tab[e]) < Sx.ca_window);
                         pass = any != 0;
