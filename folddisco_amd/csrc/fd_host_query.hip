@@ -798,6 +798,22 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     std::vector<uint32_t> slot_q(std::max<uint64_t>(n_cand, 1), 0);
     for (uint64_t t = 0; t < n_queries; ++t) for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) slot_q[k] = (uint32_t)t;
     std::vector<size_t> f_lo(n_cand + 1, 0), c_lo(n_cand + 1, 0);
+    // large queries: hash -> map entry through an open-addressing table built once per query (a whole-structure query looks ~10^5 found
+    // edges up in ~10^5 hashes per call: 17 bisection steps each were a quarter of the largest candidate's time)
+    std::vector<std::vector<uint64_t>> e_tab(n_queries);
+    std::vector<uint32_t> e_mask(std::max<uint64_t>(n_queries, 1), 0);
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        if (qhs[t].size() <= 4096) continue;
+        uint32_t cap = 1;
+        while (cap < 2 * qhs[t].size()) cap <<= 1;
+        e_tab[t].assign(cap, ~0ull);
+        e_mask[t] = cap - 1;
+        for (size_t z = 0; z < qhs[t].size(); ++z) {
+            uint32_t at = (qhs[t][z] * 2654435761u) & e_mask[t];
+            while (e_tab[t][at] != ~0ull) at = (at + 1) & e_mask[t];
+            e_tab[t][at] = ((uint64_t)qhs[t][z] << 32) | qkf[t][z];
+        }
+    }
     auto do_slot = [&](const uint64_t slot, const bool plan, SlotOut &o) {
         const uint64_t tq = slot_q[slot];
         const fd_query_map *qm = qms[tq];
@@ -820,6 +836,16 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             // query-map entry of every found edge, looked up once per candidate (a whole-structure query has ~10^5 entries and
             // thousands of edges per candidate; every component walks the edge list)
             edge_k.resize(g.es.size());
+            if (!e_tab[tq].empty()) {
+                const std::vector<uint64_t> &T = e_tab[tq];
+                const uint32_t msk = e_mask[tq];
+                for (size_t e = 0; e < g.es.size(); ++e) {
+                    uint32_t at = (g.eh[e] * 2654435761u) & msk;
+                    int32_t k = -1;
+                    while (T[at] != ~0ull) { if ((uint32_t)(T[at] >> 32) == g.eh[e]) { k = (int32_t)(uint32_t)T[at]; break; } at = (at + 1) & msk; }
+                    edge_k[e] = k;
+                }
+            } else
             for (size_t e = 0; e < g.es.size(); ++e) {
                 const auto it = std::lower_bound(e_hash.begin(), e_hash.end(), g.eh[e]);
                 edge_k[e] = (it == e_hash.end() || *it != g.eh[e]) ? -1 : (int32_t)e_first[(size_t)(it - e_hash.begin())];
@@ -848,6 +874,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             for (size_t e = c0; e < cpos; ++e) if (c_ok(cands[e])) { uint32_t k = cur[cands[e].j]++; by_cj_qi[k] = cands[e].qi; by_cj_i[k] = cands[e].i; }
         }
         std::vector<uint32_t> votes2(have_c ? (size_t)q_size * Rt : 0, 0), v_touched, q_touched;
+        std::vector<uint32_t> vote_pos;      // dense (q, r) -> 1 + vote position of the component at hand (see below)
         std::vector<uint32_t> r_mx(q_size, 0), r_nmx(q_size, 0), r_arg(q_size, 0);
         if (plan && two_pass) { plan_cache[slot].resize(n_comps); plan_have[slot] = 1; }
         for (size_t ci = 0; ci < n_comps; ++ci) {
@@ -864,6 +891,14 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             // reference's running update converges to, counts only grow).
             struct Vote { uint32_t q, r; uint32_t c; };
             std::vector<Vote> votes;
+            // (q, r) -> vote: a dense q_size x n_target table when that is small (whole-structure queries against chains of their own
+            // size: 10^5 votes per component, a hash map insertion each was most of the component's time), a hash map otherwise (a motif
+            // against a long chain: the dense table is ~1 MB per component for a handful of votes)
+            const uint32_t n_tr = (uint32_t)(g_dst[slot + 1] - g_dst[slot]);
+            const bool dense_votes = (uint64_t)q_size * n_tr <= (1u << 20) && g.es.size() > 4096;
+            if (dense_votes) {
+                if (vote_pos.size() < (size_t)q_size * n_tr) vote_pos.assign((size_t)q_size * n_tr, 0u);      // 0 = no vote yet, else 1 + position in votes; cleared below
+            }
             std::unordered_map<uint64_t, uint32_t> vote_at;     // (q, r) -> position in votes (first-seen order kept in the vector)
             for (size_t e = 0; e < g.es.size(); ++e) {
                 if (!inc[g.es[e]] || !inc[g.et[e]] || edge_k[e] < 0) continue;
@@ -874,11 +909,18 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
                 if (is_sym(g.eh[e])) { pq[0] = std::min(qi, qj); pq[1] = std::max(qi, qj); pr[0] = std::min(ri, rj); pr[1] = std::max(ri, rj); }
                 else { pq[0] = qi; pr[0] = ri; pq[1] = qj; pr[1] = rj; }
                 for (int z = 0; z < 2; ++z) {
+                    if (dense_votes && pq[z] < q_size && pr[z] < n_tr) {
+                        uint32_t &slot_v = vote_pos[(size_t)pq[z] * n_tr + pr[z]];
+                        if (!slot_v) { votes.push_back({pq[z], pr[z], 1u}); slot_v = (uint32_t)votes.size(); }
+                        else if (votes[slot_v - 1].c < 255) ++votes[slot_v - 1].c;
+                        continue;
+                    }
                     auto ins = vote_at.emplace(((uint64_t)pq[z] << 32) | pr[z], (uint32_t)votes.size());
                     if (ins.second) votes.push_back({pq[z], pr[z], 1u});
                     else if (votes[ins.first->second].c < 255) ++votes[ins.first->second].c;
                 }
             }
+            if (dense_votes) for (const Vote &v : votes) if (v.q < q_size && v.r < n_tr) vote_pos[(size_t)v.q * n_tr + v.r] = 0u;
             struct Best { uint32_t q, c, r; };
             std::vector<Best> best;
             std::unordered_map<uint32_t, uint32_t> best_at;
