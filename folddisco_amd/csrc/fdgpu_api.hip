@@ -1070,6 +1070,22 @@ static bool fd_cq_rows(const uint32_t *q_hash, const uint32_t *q_node, const uin
                        std::vector<uint32_t> &rows_hash, std::vector<unsigned long long> &rows_meta) {
     std::vector<uint64_t> ord(b - a);
     for (uint64_t k = a; k < b; ++k) ord[k - a] = k;
+    bool small_ids = true;
+    for (uint64_t k = a; k < b && small_ids; ++k) small_ids = q_node[k] < 65536u && q_edge_j[k] < 65536u;
+    if (b - a > 2048 && small_ids) {
+        // a whole-structure query has ~10^5 rows: (node, partner) order by a stable LSD radix sort of node << 16 | partner (a comparison
+        // sort of the index array took several milliseconds of the prefilter)
+        std::vector<uint64_t> tmp(ord.size());
+        for (int pass = 0; pass < 4; ++pass) {
+            const int sh = 8 * pass;
+            size_t cnt[257] = {0};
+            auto key = [&](uint64_t k) { return ((q_node[k] << 16) | q_edge_j[k]) >> sh & 255u; };
+            for (uint64_t k : ord) ++cnt[key(k) + 1];
+            for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+            for (uint64_t k : ord) tmp[cnt[key(k)]++] = k;
+            ord.swap(tmp);
+        }
+    } else
     std::stable_sort(ord.begin(), ord.end(), [&](uint64_t x, uint64_t y) {
         return q_node[x] != q_node[y] ? q_node[x] < q_node[y] : q_edge_j[x] < q_edge_j[y];
     });
