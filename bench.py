@@ -197,7 +197,7 @@ def cpu_baseline_query(ix, d, nres, res_off_h, qlist, top_n, match_top, S):
     v, h, o = ix.export_view()
     n_xyz, ca_xyz, cb_xyz, aa = (d[k].cpu().numpy() for k in ("n_xyz", "ca_xyz", "cb_xyz", "aa"))
     cores = cpu_budget()["usable"]
-    reps = max(1, min(8, cores // max(len(qlist), 1)))     # enough queries to occupy the cores
+    reps = max(1, 2048 // max(len(qlist), 1))     # ~2,000 queries: seconds of CPU work on the granted cores
     r_all = oracle.query_bench(h, o, v, nres, res_off_h.astype(np.uint64), n_xyz, ca_xyz, cb_xyz, aa, qlist * reps, top_n=top_n,
                                match_top=match_top, n_threads=cores)
     r64 = oracle.query_bench(h, o, v, nres, res_off_h.astype(np.uint64), n_xyz, ca_xyz, cb_xyz, aa, qlist, top_n=top_n,
