@@ -254,8 +254,6 @@ int merge_gathered(fdgpu_ctx *c, merge_bufs &B, const uint8_t *recv, uint32_t W,
             if (hd[r].status) { c->err = "sharded query: rank " + std::to_string(r) + " failed its local step (code " + std::to_string(-(int)hd[r].status) + ")"; return FDGPU_EHIP; }
         FAIL_(c, FDGPU_EHIP, "sharded query: a rank sent an overflowed selection");
     }
-    uint64_t *ooff = (uint64_t *)calloc(n_queries + 1, 8);
-    if (!ooff) return FDGPU_ENOMEM;
     bool overflow = false;
     uint64_t tot = 0;
     for (uint64_t t = 0; t < n_queries; ++t) { overflow = overflow || state[t].count > cap; tot += std::min<uint32_t>(state[t].count, top_n); }
@@ -269,8 +267,9 @@ int merge_gathered(fdgpu_ctx *c, merge_bufs &B, const uint8_t *recv, uint32_t W,
         tot = 0;
         for (uint64_t t = 0; t < n_queries; ++t) tot += std::min<uint64_t>(hoff[t + 1] - hoff[t], top_n);
     }
+    uint64_t *ooff = (uint64_t *)calloc(n_queries + 1, 8);
     fd_count_rec *rr = (fd_count_rec *)malloc(std::max<uint64_t>(tot, 1) * sizeof(fd_count_rec));
-    if (!rr) { free(ooff); return FDGPU_ENOMEM; }
+    if (!ooff || !rr) { free(ooff); free(rr); return FDGPU_ENOMEM; }
     uint64_t w = 0;
     for (uint64_t t = 0; t < n_queries; ++t) {
         ooff[t] = w;
@@ -393,9 +392,8 @@ int exchange(fdgpu_ctx *c, fdgpu_comm *m, uint64_t n_queries, uint32_t top_n, in
         HCHK(c, hipMemcpyAsync(snd, host_msg.data(), mb, hipMemcpyHostToDevice, st));
     }
     int rc = allgather_dev(c, m, snd, m->recv.p, mb);
-    if (rc) return rc;
-    rc = merge_gathered(c, m->mb, m->recv.as<uint8_t>(), (uint32_t)W, n_queries, top_n, out, out_off);
-    if (!host_msg.empty()) HCHK(c, hipStreamSynchronize(st));     // host_msg outlives its copy
+    if (!rc) rc = merge_gathered(c, m->mb, m->recv.as<uint8_t>(), (uint32_t)W, n_queries, top_n, out, out_off);
+    if (!host_msg.empty()) (void)hipStreamSynchronize(st);     // host_msg outlives its copy on every path
     return local_rc ? local_rc : rc;
 }
 }  // namespace

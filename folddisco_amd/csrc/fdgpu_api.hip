@@ -582,6 +582,9 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     const bool msd = msd_env && ids16 && n_cfg == 1 && p->hash_type == FDGPU_HASH_PDBTR && S > 0;
     const uint32_t NB = 40;
     fd_batch_view V = b->view();
+    HIPCHK(c, c->ws[WS_MISC3].ensure(64));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_MISC3].p, 0, 64, st));
+    C.wide_flag = c->ws[WS_MISC3].as<unsigned long long>() + 3;
     const bool msd_perm = [] { const char *e = getenv("FDGPU_MSD_PERM"); return !(e && e[0] == '0'); }();      // 0: buckets without the amino-acid order (measurement)
     if (msd && !msd_perm) {
         StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame)));
@@ -591,7 +594,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
         HIPCHK(c, c->ws[WS_OK_PERM].ensure(std::max<uint64_t>(b->n_res, 1)));
         HIPCHK(c, c->ws[WS_AA_PERM].ensure(std::max<uint64_t>(b->n_res, 1)));
         StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame) + 14));
-        fd_launch_frames_perm(V, c->ws[WS_FRAMES].p, c->ws[WS_CA_PERM].as<float>(), c->ws[WS_OK_PERM].as<uint8_t>(), c->ws[WS_AA_PERM].as<uint8_t>(), st);
+        fd_launch_frames_perm(V, c->ws[WS_FRAMES].p, c->ws[WS_CA_PERM].as<float>(), c->ws[WS_OK_PERM].as<uint8_t>(), c->ws[WS_AA_PERM].as<uint8_t>(), C.wide_flag, st);
         V.ca_xyz = c->ws[WS_CA_PERM].as<float>(); V.hash_ok = c->ws[WS_OK_PERM].as<uint8_t>(); V.aa = c->ws[WS_AA_PERM].as<uint8_t>();
         V.n_xyz = nullptr; V.cb_xyz = nullptr;      // the pair kernels read frames, not atoms
     } else {
@@ -647,9 +650,6 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     if ((rc = ensure_sort_ws(c, P, ids16 ? 2 : 4))) return rc;
     uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *kb = c->ws[WS_KEYS_B].as<uint32_t>();
     void *ia = c->ws[WS_IDS_A].p, *ib = c->ws[WS_IDS_B].p;
-    HIPCHK(c, c->ws[WS_MISC3].ensure(64));
-    HIPCHK(c, hipMemsetAsync(c->ws[WS_MISC3].p, 0, 64, st));
-    C.wide_flag = c->ws[WS_MISC3].as<unsigned long long>() + 3;
     {
         StageTimer t(c, "pair_emit", b->n_res * 37 + P * (ids16 ? 6 : 8));
         if (own) fd_launch_row_emit(b->view(), C, c->ws[WS_MISC1].as<uint64_t>(), ka, p->dist_cutoff, (uint32_t *)ia, (uint32_t)first_id, st);

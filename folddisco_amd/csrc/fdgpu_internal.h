@@ -187,7 +187,7 @@ void fd_launch_pair_emit2(const fd_batch_view &B, const void *frames, const fd_h
                           uint32_t *keys, void *ids, bool ids16, uint32_t first_id, hipStream_t st);
 int fd_radix_sort_pairs16(uint32_t *keys_a, uint16_t *vals_a, uint32_t *keys_b, uint16_t *vals_b, uint64_t n, int key_bits, uint32_t *ghist,
                           uint64_t *tot, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr);
-void fd_launch_frames_perm(const fd_batch_view &B, void *frames, float *ca_perm, uint8_t *ok_perm, uint8_t *aa_perm, hipStream_t st);
+void fd_launch_frames_perm(const fd_batch_view &B, void *frames, float *ca_perm, uint8_t *ok_perm, uint8_t *aa_perm, unsigned long long *wide_flag, hipStream_t st);
 void fd_launch_pair_count_msd(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *counts, hipStream_t st);
 void fd_launch_pair_emit_msd(const fd_batch_view &B, const void *frames, const fd_hash_consts &C, const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys,
                              uint16_t *ids, hipStream_t st);

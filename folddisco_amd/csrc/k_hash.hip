@@ -163,7 +163,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_count2(fd_batch_view B, fd_has
 // frames together with permuted copies of what the pair kernels read per residue (CA, hashable flag, type).  A 64-residue tile then
 // holds ~4 residue types instead of ~15, which is what keeps the bucket runs of a drain long (k_pair_emit2<.., MSD>).
 __global__ __launch_bounds__(256) void k_frames_perm(fd_batch_view B, fd_frame *__restrict__ frames, float *__restrict__ ca_perm, uint8_t *__restrict__ ok_perm,
-                                                     uint8_t *__restrict__ aa_perm) {
+                                                     uint8_t *__restrict__ aa_perm, unsigned long long *__restrict__ wide_flag) {
     __shared__ uint32_t cnt[32], cur[32];
     const uint32_t s = blockIdx.x;
     const uint32_t r0 = B.res_off[s], r1 = B.res_off[s + 1];
@@ -178,7 +178,11 @@ __global__ __launch_bounds__(256) void k_frames_perm(fd_batch_view B, fd_frame *
     __syncthreads();
     for (uint32_t r = r0 + threadIdx.x; r < r1; r += 256) {
         const uint32_t a = B.aa[r];
-        const bool ok = B.hash_ok[r] != 0;
+        bool ok = B.hash_ok[r] != 0;
+        if (ok && a >= 20u) {      // a residue type outside map_aa_to_u8's 0..19 marked hashable: forty buckets cannot hold it — the build is redone with the
+            ok = false;            // structure-major 8-byte path, which hashes whatever the caller passed (wide_flag)
+            if (wide_flag) atomicOr(wide_flag, 1ull);
+        }
         const uint32_t p = r0 + atomicAdd(&cur[(ok && a < 20u) ? a : 20u], 1u);
         fd_frame F;
         const fd_v3 ca = fd_load3(B.ca_xyz, r);
@@ -582,9 +586,9 @@ void fd_launch_pair_emit2(const fd_batch_view &B, const void *frames, const fd_h
     else hipLaunchKernelGGL((k_pair_emit2<0, false, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
 }
 // the MSD build (6-byte elements): B = the permuted view (ca_xyz / hash_ok / aa = the arrays k_frames_perm wrote), seg_off / cursor = [40][S]
-void fd_launch_frames_perm(const fd_batch_view &B, void *frames, float *ca_perm, uint8_t *ok_perm, uint8_t *aa_perm, hipStream_t st) {
+void fd_launch_frames_perm(const fd_batch_view &B, void *frames, float *ca_perm, uint8_t *ok_perm, uint8_t *aa_perm, unsigned long long *wide_flag, hipStream_t st) {
     if (!B.n_struct) return;
-    hipLaunchKernelGGL(k_frames_perm, dim3(B.n_struct), dim3(256), 0, st, B, (fd_frame *)frames, ca_perm, ok_perm, aa_perm);
+    hipLaunchKernelGGL(k_frames_perm, dim3(B.n_struct), dim3(256), 0, st, B, (fd_frame *)frames, ca_perm, ok_perm, aa_perm, wide_flag);
 }
 void fd_launch_pair_count_msd(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *counts, hipStream_t st) {
     if (!B.n_work) return;

@@ -788,6 +788,7 @@ def test_msd_build_equals_structure_major_build(ctx):
     cbv = np.ones(len(aa), np.uint8)
     cbv[off[30]:off[31]] = rng.random(off[31] - off[30]) > 0.2  # missing CB
     ps = fd.PackedStructures(ps.res_off, ps.n_xyz, ps.ca_xyz, ps.cb_xyz, aa, cbv)
+    ps_odd = fd.PackedStructures(ps.res_off, ps.n_xyz, ps.ca_xyz, ps.cb_xyz, np.where(np.arange(len(aa)) % 97 == 5, 25, aa).astype(np.uint8), cbv)
     outs = {}
     try:
         for tag, env in (("msd", {}), ("plain", {"FDGPU_MSD": "0"}), ("noperm", {"FDGPU_MSD_PERM": "0"})):
@@ -796,11 +797,16 @@ def test_msd_build_equals_structure_major_build(ctx):
             os.environ.update(env)
             ix = fd.FolddiscoIndex.build(ctx, ctx.upload(ps), first_id=70000)
             outs[tag] = ix.export()
-            st = dict((n, ms) for n, ms, _ in ctx.last_timings())
+            # residue types outside map_aa_to_u8's 0..19 marked hashable: forty buckets cannot hold them — the build falls back to the 8-byte
+            # structure-major path and equals what the plain build gives for the same input
+            outs[tag + "_odd"] = fd.FolddiscoIndex.build(ctx, ctx.upload(ps_odd), first_id=70000).export()
     finally:
         for k in ("FDGPU_MSD", "FDGPU_MSD_PERM"):
             os.environ.pop(k, None)
     for tag in ("plain", "noperm"):
         for a, b in zip(outs["msd"], outs[tag]):
             assert np.array_equal(a, b), tag
+        for a, b in zip(outs["msd_odd"], outs[tag + "_odd"]):
+            assert np.array_equal(a, b), tag
+    assert not np.array_equal(outs["msd"][1], outs["msd_odd"][1])
     assert len(outs["msd"][1]) > 10 ** 6
