@@ -118,6 +118,7 @@ SYMBOLS = [
     ("fdgpu_destroy", None, [VP]),
     ("fdgpu_set_stream", C.c_int, [VP, VP]),
     ("fdgpu_synchronize", C.c_int, [VP]),
+    ("fdgpu_release_workspaces", C.c_int, [VP]),
     ("fdgpu_last_error", C.c_char_p, [VP]),
     ("fdgpu_free", None, [VP]),
     ("fdgpu_version", C.c_char_p, []),

@@ -110,6 +110,10 @@ class Context:
     def synchronize(self):
         self.check(self.L.fdgpu_synchronize(self.h))
 
+    def release_workspaces(self):
+        """fdgpu_release_workspaces: sort buffers, scratch and cached index blocks back to the device (indices stay valid)"""
+        self.check(self.L.fdgpu_release_workspaces(self.h))
+
     def enable_timing(self, on: bool = True):
         self.check(self.L.fdgpu_enable_timing(self.h, int(on)))
 

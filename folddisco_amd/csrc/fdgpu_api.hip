@@ -181,6 +181,16 @@ extern "C" void fdgpu_destroy(fdgpu_ctx *c) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+// Returns the context's workspaces (the sort buffers of the largest build so far, query scratch) and the cached blocks of destroyed indices to
+// the device.  Indices, batches and query maps stay valid; the next call allocates what it needs again.
+extern "C" int fdgpu_release_workspaces(fdgpu_ctx *c) { FD_LOCK(c);
+    if (!c) return FDGPU_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto &b : c->ws) b.release();
+    c->pool_drop();
+    (void)hipGetLastError();
+    return FDGPU_OK;
+}
 extern "C" int fdgpu_set_stream(fdgpu_ctx *c, void *s) { FD_LOCK(c);
     if (!c) return FDGPU_EINVAL;
     if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); c->own_stream = false; }
@@ -391,6 +401,8 @@ static int count_and_scan(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_cons
 
 static int ensure_sort_ws(fdgpu_ctx *c, uint64_t P, size_t id_bytes = 4) {
     size_t kb = std::max<uint64_t>(P, 1) * 4, ib = std::max<uint64_t>(P, 1) * id_bytes + 16;
+    // a call that grows the sort buffers by gigabytes first returns the cached blocks of destroyed indices to the device
+    if (kb > c->ws[WS_KEYS_A].cap + ((size_t)1 << 30) || kb > c->ws[WS_KEYS_B].cap + ((size_t)1 << 30)) c->pool_drop();
     HIPCHK(c, c->ws[WS_KEYS_A].ensure(kb));
     HIPCHK(c, c->ws[WS_IDS_A].ensure(ib));
     HIPCHK(c, c->ws[WS_KEYS_B].ensure(kb));
@@ -579,7 +591,10 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     // residues visited in amino-acid order) and every bucket is sorted by the remaining 24 bits — three 8-bit passes instead of four.
     // FDGPU_MSD=0 selects the structure-major stream + four passes (A/B measurements, tests).
     const bool msd_env = [] { const char *e = getenv("FDGPU_MSD"); return !(e && e[0] == '0'); }();      // read per call: tests flip it
-    const bool msd = msd_env && ids16 && n_cfg == 1 && p->hash_type == FDGPU_HASH_PDBTR && S > 0;
+    // its elements are 6 bytes too, but the bucket carries the top six hash bits: key = (hash & 0xffffff) << 8 | local id bits 23:16 — 2^24 structures
+    const bool msd = msd_env && !own && !force32 && S <= (1ull << 24) && n_cfg == 1 && p->hash_type == FDGPU_HASH_PDBTR && S > 0;
+    const bool el6 = ids16 || msd;                       // 6-byte sort elements
+    const int codec = msd ? 2 : ids16 ? 1 : 0;           // of the sorted stream (k_index.hip)
     const uint32_t NB = 40;
     fd_batch_view V = b->view();
     HIPCHK(c, c->ws[WS_MISC3].ensure(64));
@@ -587,8 +602,14 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     C.wide_flag = c->ws[WS_MISC3].as<unsigned long long>() + 3;
     const bool msd_perm = [] { const char *e = getenv("FDGPU_MSD_PERM"); return !(e && e[0] == '0'); }();      // 0: buckets without the amino-acid order (measurement)
     if (msd && !msd_perm) {
-        StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame)));
-        fd_launch_frames(b->view(), b->n_res, c->ws[WS_FRAMES].p, st);
+        {
+            StageTimer t(c, "frames", b->n_res * (37 + sizeof(fd_frame)));
+            fd_launch_frames(b->view(), b->n_res, c->ws[WS_FRAMES].p, st);
+            fd_launch_aa_check(V, b->n_res, C.wide_flag, st);
+        }
+        uint64_t odd = 0;      // the bucket tables hold residue types 0..19 only: decided BEFORE the pair kernels index them
+        if (int r = d2h_u64(c, (const uint64_t *)C.wide_flag, &odd)) return r;
+        if (odd) return FDGPU_RETRY_WIDE;
     } else if (msd) {
         HIPCHK(c, c->ws[WS_CA_PERM].ensure(std::max<uint64_t>(b->n_res, 1) * 12));
         HIPCHK(c, c->ws[WS_OK_PERM].ensure(std::max<uint64_t>(b->n_res, 1)));
@@ -638,6 +659,9 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
         }
         HIPCHK(c, hipGetLastError());
         rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &P1);
+        uint64_t odd = 0;      // k_frames_perm met a residue type outside 0..19: no point in finishing this form of the build
+        if (!rc) rc = d2h_u64(c, (const uint64_t *)C.wide_flag, &odd);
+        if (!rc && odd) return FDGPU_RETRY_WIDE;
     } else {
         rc = count_and_scan(c, b, C, &P1, true);
     }
@@ -647,11 +671,11 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     // workspace); the other paths keep 32-bit positions
     if (P >= 0xffffffffull && !msd) FAIL(c, FDGPU_ERANGE, "more than 2^32 residue pairs in one build call; split the shard");
     if (P >= (1ull << 35)) FAIL(c, FDGPU_ERANGE, "more than 2^35 residue pairs in one build call; split the shard");
-    if ((rc = ensure_sort_ws(c, P, ids16 ? 2 : 4))) return rc;
+    if ((rc = ensure_sort_ws(c, P, el6 ? 2 : 4))) return rc;
     uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *kb = c->ws[WS_KEYS_B].as<uint32_t>();
     void *ia = c->ws[WS_IDS_A].p, *ib = c->ws[WS_IDS_B].p;
     {
-        StageTimer t(c, "pair_emit", b->n_res * 37 + P * (ids16 ? 6 : 8));
+        StageTimer t(c, "pair_emit", b->n_res * 37 + P * (el6 ? 6 : 8));
         if (own) fd_launch_row_emit(b->view(), C, c->ws[WS_MISC1].as<uint64_t>(), ka, p->dist_cutoff, (uint32_t *)ia, (uint32_t)first_id, st);
         else if (msd) fd_launch_pair_emit_msd(V, c->ws[WS_FRAMES].p, C, c->ws[WS_SEGOFF].as<uint64_t>(), c->ws[WS_CURSOR].as<uint32_t>(), ka, (uint16_t *)ia, st);
         else for (uint32_t k = 0; k < n_cfg; ++k) {
@@ -664,11 +688,11 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     }
     int cur;
     (void)sort_mode();
-    if (msd) {      // every bucket by hash bits [0, 24) = key bits [2, 26): three passes; the bucket IS key bits [26, 32)
+    if (msd) {      // every bucket by hash bits [0, 24) = key bits [8, 32): three passes; the bucket holds the other six
         HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * fd_rs_seg_num_tiles(P, NB) * 4));
         HIPCHK(c, c->ws[WS_TOT].ensure(fd_rs_seg_tot_words(P, NB) * 8));
         HIPCHK(c, c->ws[WS_SEG_TAB].ensure(fd_rs_seg_tab_bytes(P, NB)));
-        cur = fd_radix_sort_pairs16_seg(ka, (uint16_t *)ia, kb, (uint16_t *)ib, P, c->ws[WS_SEGOFF].as<uint64_t>(), S, NB, 2, 3, c->ws[WS_GHIST].as<uint32_t>(),
+        cur = fd_radix_sort_pairs16_seg(ka, (uint16_t *)ia, kb, (uint16_t *)ib, P, c->ws[WS_SEGOFF].as<uint64_t>(), S, NB, 8, 3, c->ws[WS_GHIST].as<uint32_t>(),
                                         c->ws[WS_TOT].as<uint64_t>(), c->ws[WS_SEG_TAB].p, st, c);
     } else if (ids16) cur = fd_radix_sort_pairs16(ka, (uint16_t *)ia, kb, (uint16_t *)ib, P, 32, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st, c);
     else cur = sort_pairs(c, ka, (uint32_t *)ia, kb, (uint32_t *)ib, P, 32);   // all 32 bits: unmasked field overflow can set bits 30-31
@@ -685,11 +709,12 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     uint64_t tot[4] = {0, 0, 0, 0};
     uint64_t nt_eff = P ? fd_enc_num_tiles(P) : 0;
     {
-        StageTimer t(c, "encode_sizes", P * (ids16 ? 6 : 8));
+        StageTimer t(c, "encode_sizes", P * (el6 ? 6 : 8));
         HIPCHK(c, hipMemsetAsync(c->ws[WS_TILE_B].p, 0, (size_t)(nt + 1) * 4, st));
         HIPCHK(c, hipMemsetAsync(c->ws[WS_TILE_H].p, 0, (size_t)(nt + 1) * 4, st));
         HIPCHK(c, hipMemsetAsync(c->ws[WS_TILE_P].p, 0, (size_t)(nt + 1) * 4, st));
-        fd_launch_enc_sizes(ks, is, ids16, (uint32_t)first_id, P, c->ws[WS_TILE_B].as<uint32_t>(), c->ws[WS_TILE_H].as<uint32_t>(), c->ws[WS_TILE_P].as<uint32_t>(), st);
+        fd_launch_enc_sizes(ks, is, codec, (uint32_t)first_id, P, c->ws[WS_TILE_B].as<uint32_t>(), c->ws[WS_TILE_H].as<uint32_t>(), c->ws[WS_TILE_P].as<uint32_t>(),
+                            c->ws[WS_SEGOFF].as<uint64_t>(), S, st);
         uint64_t *totd = c->ws[WS_MISC3].as<uint64_t>();
         fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_B].as<uint32_t>(), nt_eff, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 0, st);
         fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_H].as<uint32_t>(), nt_eff, c->ws[WS_TILE_HO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 1, st);
@@ -698,7 +723,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_MISC3].p, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    if (ids16 && tot[3]) return FDGPU_RETRY_WIDE;
+    if (el6 && tot[3]) return FDGPU_RETRY_WIDE;
     fdgpu_index *ix = new (std::nothrow) fdgpu_index();
     if (!ix) return FDGPU_ENOMEM;
     ix->ctx = c; ix->value_len = tot[0]; ix->n_hashes = tot[1]; ix->n_postings = tot[2]; ix->n_structures = S; ix->first_id = first_id;
@@ -713,9 +738,9 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
         return FDGPU_EHIP;
     }
     {
-        StageTimer t(c, "encode_write", P * (ids16 ? 6 : 8) + ix->value_len + ix->n_hashes * 12);
-        fd_launch_enc_write(ks, is, ids16, (uint32_t)first_id, P, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_TILE_HO].as<uint64_t>(), ix->value, ix->hashes, ix->offsets,
-                            ix->last_ids, c->ws[WS_MISC3].as<uint64_t>(), ix->n_hashes, st);
+        StageTimer t(c, "encode_write", P * (el6 ? 6 : 8) + ix->value_len + ix->n_hashes * 12);
+        fd_launch_enc_write(ks, is, codec, (uint32_t)first_id, P, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_TILE_HO].as<uint64_t>(), ix->value, ix->hashes, ix->offsets,
+                            ix->last_ids, c->ws[WS_MISC3].as<uint64_t>(), ix->n_hashes, c->ws[WS_SEGOFF].as<uint64_t>(), S, st);
     }
     e = hipGetLastError();
     if (e != hipSuccess) { c->err = std::string("encode launch: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }

@@ -16,7 +16,7 @@ struct fd_devbuf {
         if (bytes <= cap) return hipSuccess;
         // small buffers grow geometrically (query-sized scratch would otherwise be re-allocated for every slightly larger
         // query: hipFree synchronises the device); big ones take what they need
-        size_t want = bytes + bytes / 16 + 256;
+        size_t want = bytes + (bytes < ((size_t)4 << 30) ? bytes / 16 : (size_t)0) + 256;      // the sort buffers of a 2^34-key call: no 6 % on 70 GB
         if (cap && cap < (64u << 20) && want < cap + cap / 2) want = cap + cap / 2;
         if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         hipError_t e = hipMalloc(&p, want);
@@ -85,14 +85,15 @@ struct fdgpu_ctx {
         size_t want = bytes + bytes / 32 + 256;
         *err = hipMalloc(&p, want);
         if (*err != hipSuccess) {  // drop the cache and retry once
-            for (auto &b : pool) (void)hipFree(b.p);
-            pool.clear();
+            pool_drop();
+            (void)hipGetLastError();
             *err = hipMalloc(&p, want);
             if (*err != hipSuccess) return nullptr;
         }
         last_cap = want;
         return p;
     }
+    void pool_drop() { for (auto &b : pool) (void)hipFree(b.p); pool.clear(); }
     void pool_free(void *p, size_t cap) {
         if (!p) return;
         if (pool.size() >= 96) { (void)hipFree(p); return; }   // a shard built as 8 sub-indices + their merge cycles through ~40 blocks per step
@@ -187,6 +188,7 @@ void fd_launch_pair_emit2(const fd_batch_view &B, const void *frames, const fd_h
                           uint32_t *keys, void *ids, bool ids16, uint32_t first_id, hipStream_t st);
 int fd_radix_sort_pairs16(uint32_t *keys_a, uint16_t *vals_a, uint32_t *keys_b, uint16_t *vals_b, uint64_t n, int key_bits, uint32_t *ghist,
                           uint64_t *tot, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr);
+void fd_launch_aa_check(const fd_batch_view &B, uint64_t n_res, unsigned long long *wide_flag, hipStream_t st);
 void fd_launch_frames_perm(const fd_batch_view &B, void *frames, float *ca_perm, uint8_t *ok_perm, uint8_t *aa_perm, unsigned long long *wide_flag, hipStream_t st);
 void fd_launch_pair_count_msd(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *counts, hipStream_t st);
 void fd_launch_pair_emit_msd(const fd_batch_view &B, const void *frames, const fd_hash_consts &C, const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys,
@@ -207,10 +209,11 @@ void fd_rs_set_variant(int v);
 int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint64_t n, int key_bits, uint32_t *ghist,
                         uint64_t *tot, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr);
 uint32_t fd_enc_num_tiles(uint64_t n);
-void fd_launch_enc_sizes(const uint32_t *keys, const void *ids, bool ids16, uint32_t first_id, uint64_t n, uint32_t *tb, uint32_t *th, uint32_t *tp,
-                         hipStream_t st);
-void fd_launch_enc_write(const uint32_t *keys, const void *ids, bool ids16, uint32_t first_id, uint64_t n, const uint64_t *tbo, const uint64_t *tho,
-                         uint8_t *value, uint32_t *hashes, uint64_t *offsets, uint32_t *last_ids, const uint64_t *total_bytes_dev, uint64_t H, hipStream_t st);
+void fd_launch_enc_sizes(const uint32_t *keys, const void *ids, int codec, uint32_t first_id, uint64_t n, uint32_t *tb, uint32_t *th, uint32_t *tp,
+                         const uint64_t *seg_off, uint64_t S, hipStream_t st);
+void fd_launch_enc_write(const uint32_t *keys, const void *ids, int codec, uint32_t first_id, uint64_t n, const uint64_t *tbo, const uint64_t *tho,
+                         uint8_t *value, uint32_t *hashes, uint64_t *offsets, uint32_t *last_ids, const uint64_t *total_bytes_dev, uint64_t H,
+                         const uint64_t *seg_off, uint64_t S, hipStream_t st);
 void fd_launch_uniq_flags(const uint32_t *keys, const uint32_t *ids, uint64_t n, uint8_t *flags, hipStream_t st);
 void fd_launch_compact(const uint32_t *keys, const uint8_t *flags, const uint64_t *pos, uint64_t n, uint32_t *out, hipStream_t st);
 void fd_launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t n, uint64_t *dst, hipStream_t st);

@@ -212,10 +212,13 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_count_msd(fd_batch_view B, fd_
     fd_v3 cai = {0.f, 0.f, 0.f};
     uint32_t aai = 0;
     if (vi) { cai = fd_load3(B.ca_xyz, i); aai = B.aa[i]; }
-    const uint64_t hi_mask = __ballot(vi && aai >= 16u);
     s_cnt[lane] = 0;
     __syncthreads();
-    uint32_t c_lo = 0, c_hi = 0;
+    // forward keys (aa_i, aa_j >> 4): two counters per lane, the partner's type is wave-uniform per step.  Reverse keys (aa_j, aa_i >> 4): the
+    // partners are visited in amino-acid order, so aa_j changes ~20 times per structure — ONE more counter per lane for the current
+    // partner type, flushed into the LDS bucket counters when the type changes (a wave-uniform, rare branch)
+    uint32_t c_lo = 0, c_hi = 0, rev = 0, cur_aa = 0xffffffffu;
+    const uint32_t hi_i = aai >> 4;
     for (uint32_t jb = i0; jb < r1; jb += FD_WAVE) {
         const uint32_t jl = jb + lane;
         const bool jin = jl < r1;
@@ -224,24 +227,21 @@ __global__ __launch_bounds__(FD_WAVE) void k_pair_count_msd(fd_batch_view B, fd_
         if (jin) { cj = fd_load3(B.ca_xyz, jl); aj = B.aa[jl]; }
         const uint64_t okm = __ballot(jin && B.hash_ok[jl]);
         const uint32_t nj = (r1 - jb) < FD_WAVE ? (r1 - jb) : FD_WAVE;
-        int rev_lo = 0, rev_hi = 0;       // lane k: the reverse keys of partner j = jb + k (a compare and two selects per step)
         for (uint32_t k = 0; k < nj; ++k) {
             if (!((okm >> k) & 1ull)) continue;  // wave-uniform
             fd_v3 caj = {bcast_lane(cj.x, k), bcast_lane(cj.y, k), bcast_lane(cj.z, k)};
             const uint32_t aaj = (uint32_t)__builtin_amdgcn_readlane((int)aj, (int)k);
+            if (aaj != cur_aa) {      // wave-uniform
+                if (rev) atomicAdd(&s_cnt[cur_aa * 2u + hi_i], rev);
+                rev = 0; cur_aa = aaj;
+            }
             const float d2 = fd_dist2(cai, caj);
-            const bool pass = vi && (jb + k) > i && !(d2 > C.d2_max);
-            const uint64_t m = __ballot(pass);
-            if (m == 0) continue;
-            if (aaj >= 16u) c_hi += pass ? 1u : 0u; else c_lo += pass ? 1u : 0u;
-            const int n_hi = __popcll(m & hi_mask), n_lo = __popcll(m) - n_hi;
-            const bool mine = lane == k;
-            rev_lo = mine ? n_lo : rev_lo;
-            rev_hi = mine ? n_hi : rev_hi;
+            const uint32_t pass = (vi && (jb + k) > i && !(d2 > C.d2_max)) ? 1u : 0u;
+            rev += pass;
+            if (aaj >= 16u) c_hi += pass; else c_lo += pass;
         }
-        if (rev_lo) atomicAdd(&s_cnt[aj * 2u], (uint32_t)rev_lo);
-        if (rev_hi) atomicAdd(&s_cnt[aj * 2u + 1u], (uint32_t)rev_hi);
     }
+    if (rev) atomicAdd(&s_cnt[cur_aa * 2u + hi_i], rev);
     if (c_lo) atomicAdd(&s_cnt[aai * 2u], c_lo);
     if (c_hi) atomicAdd(&s_cnt[aai * 2u + 1u], c_hi);
     __syncthreads();
@@ -334,10 +334,10 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
             // the type bits: such a hash raises wide_flag and the build is redone with 8-byte elements; its key still lands in a counted slot)
             if ((((h_ij | h_ji) >> 30) || (h_ij >> 24) != bf || (h_ji >> 24) != br) && C.wide_flag) atomicOr(C.wide_flag, 1ull);
             const uint64_t pf = s_bb[bf] + sf, pr = s_bb[br] + sr;
-            const uint32_t hi = s >> 16;
+            const uint32_t hi = s >> 16;      // the position says which bucket (the top six hash bits): the key keeps the other 24 and id bits 23:16
             const uint16_t lo = (uint16_t)(s & 0xffffu);
-            keys[pf] = (h_ij << 2) | hi;
-            keys[pr] = (h_ji << 2) | hi;
+            keys[pf] = (h_ij << 8) | hi;
+            keys[pr] = (h_ji << 8) | hi;
             ((uint16_t *)ids)[pf] = lo;
             ((uint16_t *)ids)[pr] = lo;
         }
@@ -548,6 +548,16 @@ __global__ void k_selfcheck(fd_quant q, uint32_t *__restrict__ out /*[18]*/) {
 // ------------------------------------------------------------------ launchers (called from fdgpu_api.hip)
 extern "C++" {
 void fd_launch_selfcheck(const fd_quant &q, uint32_t *out, hipStream_t st) { hipLaunchKernelGGL(k_selfcheck, dim3(1), dim3(64), 0, st, q, out); }
+// FDGPU_MSD_PERM=0 (buckets over the caller's residue order): the check k_frames_perm makes while it permutes
+__global__ void k_aa_check(const uint8_t *__restrict__ aa, const uint8_t *__restrict__ ok, uint64_t n, unsigned long long *__restrict__ wide_flag) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && ok[k] && aa[k] >= 20u) atomicOr(wide_flag, 1ull);
+}
+void fd_launch_aa_check(const fd_batch_view &B, uint64_t n_res, unsigned long long *wide_flag, hipStream_t st) {
+    if (!n_res) return;
+    hipLaunchKernelGGL(k_aa_check, dim3((unsigned)((n_res + 255) / 256)), dim3(256), 0, st, B.aa, B.hash_ok, n_res, wide_flag);
+}
+
 void fd_launch_hash_ok(const uint8_t *aa, const uint8_t *cb_valid, uint8_t *ok, uint64_t n, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_hash_ok, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, aa, cb_valid, ok, n);

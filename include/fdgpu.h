@@ -43,6 +43,10 @@ void fdgpu_destroy(fdgpu_ctx *ctx);
 /* use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream */
 int fdgpu_set_stream(fdgpu_ctx *ctx, void *hip_stream);
 int fdgpu_synchronize(fdgpu_ctx *ctx);
+/* Returns the context's workspaces (an index build keeps 12 bytes per key of its largest call: 80 GB after a 203,250-structure call, 213 GB
+ * after Swiss-Prot in one call) and the cached device blocks of destroyed indices to the device.  Indices, batches and query maps stay valid.
+ * (No reference counterpart: the reference's builder frees its DashMap / Vec buffers when they go out of scope, src/cli/workflows/build_index.rs.) */
+int fdgpu_release_workspaces(fdgpu_ctx *ctx);
 const char *fdgpu_last_error(const fdgpu_ctx *ctx);
 void fdgpu_free(void *host_ptr);
 const char *fdgpu_version(void);
