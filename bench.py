@@ -6,10 +6,12 @@ eight fixed blocks of 67,750 (seed + 1000 * block) so that every --gpus N indexe
 contiguous id range dist.shard_range(r, N, 542000) ("strong" scaling; index build shards by structure, no data-path
 collective).
 
-One step = the whole index build of the rank's shard, inputs resident in HBM: per block of <= 67,750 structures
-frames -> pair count -> pair emit (PDBTrRosetta hash) -> stable radix sort -> delta/varint posting encode
-(fdgpu_index_build), then — when the shard spans several blocks — the device merge of the blocks' sub-indices into ONE
-resident index (fdgpu_index_merge), byte-identical to a single build.  value = 542,000 * steps / time (max over ranks).
+One step = the whole index build of the rank's shard, inputs resident in HBM: frames (residues in amino-acid order) ->
+bucket counts -> pair emit (PDBTrRosetta hash, keys bucketed by the top six hash bits) -> three segmented 8-bit sort
+passes -> delta/varint posting encode (fdgpu_index_build).  The whole shard is ONE call when its sort workspace fits the
+device (12 B per key: 213 GB for Swiss-Prot on one MI355X); otherwise calls of 203,250 structures whose sub-indices are
+merged on the device into ONE resident index (fdgpu_index_merge), byte-identical to a single build.
+value = 542,000 * steps / time (max over ranks).
 
 After the timed build: the export-inclusive rate (one more step + fdgpu_index_export D2H), the per-kernel HIP-event
 timings of one step (roofline of the dominant kernel), the motif-query leg against the resident index (folddisco_amd/
@@ -48,8 +50,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-query", action="store_true")
     ap.add_argument("--no-export", action="store_true")
-    ap.add_argument("--build-chunk-blocks", type=int, default=3, help="generated blocks of 67,750 structures per fdgpu_index_build call (3: 203,250 structures, "
-                    "~6.7e9 keys, the MSD build's 64-bit positions; 1: one call per block as in rounds 1-2)")
+    ap.add_argument("--build-chunk-blocks", type=int, default=0, help="0 (default): the rank's whole shard in ONE fdgpu_index_build call when its sort workspace fits the "
+                    "device, else calls of 3 blocks.  N > 0: N generated blocks of 67,750 structures per call (3: 203,250 structures, ~6.7e9 keys; 1: as in rounds 1-2)")
     ap.add_argument("--no-cli-index", action="store_true", help="skip the drop-in `index` leg (20,500 structures as .pdb.gz files and as a Foldcomp database)")
     ap.add_argument("--no-replicas", action="store_true", help="skip the query-replica leg of --gpus N > 1 (index replicated, queries sharded)")
     return ap.parse_args()
@@ -283,12 +285,41 @@ def main():
             base += int(b["res_off"][-1].item())
         out["res_off"] = torch.cat(offs).contiguous()
         return out
-    # build calls: groups of consecutive blocks (one fdgpu_index_build each; <= 2^18 structures for the 6-byte sort elements)
-    g = max(1, min(args.build_chunk_blocks, (1 << 18) // GEN_BLOCK))
-    blocks = [cat_blocks(blocks[k:k + g]) for k in range(0, len(blocks), g)]
-    torch.cuda.synchronize()
-    chunk_batches = [wrap(d) for d in blocks]
+    # build calls: groups of consecutive blocks, one fdgpu_index_build each.  The MSD build holds 2^24 structures per call (6-byte sort elements:
+    # 24 hash bits + 8 id bits in the key, 16 id bits beside it): the rank's whole shard goes into ONE call — no sub-indices, no merge — when
+    # its 12 bytes of sort workspace per key fit the device next to the index (Swiss-Prot: 17.7e9 keys = 213 + 27 GB of 309), else into calls of
+    # three blocks (203,250 structures).  --build-chunk-blocks N > 0 fixes the group size.
     R = sum(int(d["res_off"][-1].item()) for d in blocks)
+    n_blocks = len(blocks)
+    call_plan = {"blocks_per_call": None, "why": None}
+    def est_one_call_bytes(res):
+        keys = 104.0 * res          # postings per residue of the generator's AFDB-shaped structures: 101.2, + 3 %
+        return keys * (12.0 + 1.6 + 0.13) + res * (80 + 14 + 16) + (6 << 30)
+    if args.build_chunk_blocks > 0:
+        g = max(1, min(args.build_chunk_blocks, (1 << 24) // GEN_BLOCK))
+        call_plan.update(blocks_per_call=g, why="--build-chunk-blocks")
+    else:
+        torch.cuda.empty_cache()
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        need = est_one_call_bytes(R)
+        ranks_here = max(1, world // max(torch.cuda.device_count(), 1)) if os.environ.get("FD_BENCH_BACKEND", "nccl") != "nccl" else 1
+        g = n_blocks if (need < 0.97 * free_b / ranks_here and S <= (1 << 24)) else 3
+        call_plan.update(blocks_per_call=g, why=f"auto: one call needs ~{need / 1e9:.0f} GB, {free_b / 1e9:.0f} GB free")
+    def cat_groups(bl, g):
+        return [cat_blocks(bl[k:k + g]) for k in range(0, len(bl), g)]
+    def split_groups(d, per):
+        """the inverse of cat_blocks: views of `per` structures each (the fall-back when the one-call build does not fit)"""
+        out, n = [], len(d["res_off"]) - 1
+        for a in range(0, n, per):
+            e = min(n, a + per)
+            ro = d["res_off"]
+            r0, r1 = int(ro[a]), int(ro[e])
+            out.append({k: ((ro[a:e + 1] - ro[a]).contiguous() if k == "res_off" else v[r0:r1]) for k, v in d.items()})
+        return out
+    blocks = cat_groups(blocks, max(g, 1))
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    chunk_batches = [wrap(d) for d in blocks]
     CALL_MAX = max((len(d["res_off"]) - 1 for d in blocks), default=0)
 
     def build_shard():
@@ -322,6 +353,20 @@ def main():
 
     progress("database generated, build starts")
     ix = None
+    if len(chunk_batches) == 1 and n_blocks > 3 and args.build_chunk_blocks <= 0:
+        # the one-call plan is an estimate: a device that cannot hold it answers the first build with FDGPU_EHIP (hipMalloc), not with a crash —
+        # then the workspaces go back and the shard is built in calls of three blocks, as in round 3's first half
+        try:
+            ix = build_shard()
+        except fd.FdgpuError as e:
+            progress(f"one-call build did not fit ({e}); falling back to calls of three blocks")
+            ix = None
+            ctx.release_workspaces()
+            chunk_batches = None
+            blocks = split_groups(blocks[0], 3 * GEN_BLOCK)
+            chunk_batches = [wrap(d) for d in blocks]
+            CALL_MAX = max((len(d["res_off"]) - 1 for d in blocks), default=0)
+            call_plan.update(blocks_per_call=3, why=call_plan["why"] + "; one-call build failed: " + str(e)[:200])
     for _ in range(args.warmup):
         ix = None
         ix = build_shard()
@@ -383,6 +428,8 @@ def main():
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     tag = f"S{S_total}" if world == 1 else f"S{S_total}_N{world}"
     tr = pmc_traffic(dom_name, tag)
+    if tr and dom_n and not (0.5 < tr["bytes_per_launch"] / (dom_bytes / dom_n) < 2.0):
+        tr = None      # the committed PMC passes are of another call plan (launch sizes differ): no traffic figure rather than a wrong one
     R_tot, post_tot, vlen_tot, hash_tot = (sum_over_ranks(x) for x in (R, n_post, vlen, n_hash))
     b_idx = 37.0 * R_tot / S_total + 8.0 * post_tot / S_total + vlen_tot / S_total + 12.0 * hash_tot / S_total
     roofline = {"bound": "hbm", "kernel": dom_name, "launches_per_step": dom_n, "avg_ms": dom_ms / max(dom_n, 1),
@@ -395,6 +442,9 @@ def main():
                 "stages_ms": {k: round(v[0], 3) for k, v in agg.items()},
                 "stages_gbs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0.0 for k, v in agg.items()}}
 
+    n_calls = len(chunk_batches)
+    if n_calls == 1 and n_blocks > 3:
+        ctx.release_workspaces()      # 213 GB of sort buffers: not needed by the legs that follow
     progress("stage timings done, query leg starts")
     # ---- motif queries against the resident index of the shard
     query = None
@@ -495,9 +545,9 @@ def main():
             "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
             "config": {"workload": f"Swiss-Prot scale: {S_total} synthetic AFDB-shaped structures ({int(R_tot)} residues, {int(post_tot)} postings, "
                                    f"{int(vlen_tot)} value bytes) index build, PDBTrRosetta default; {world} rank(s), contiguous id ranges, "
-                                   f"per rank {len(chunk_batches) if chunk_batches else -(-S // CALL_MAX)} build call(s) of <= {CALL_MAX} structures merged on the device into one resident index",
+                                   f"per rank {n_calls} build call(s) of <= {CALL_MAX} structures" + (" merged on the device into one resident index" if n_calls > 1 else ": one resident index, no merge"),
                        "structures": S_total, "structures_per_gpu": S, "residues": int(R_tot), "postings": int(post_tot),
-                       "parallelism": f"shard-by-structure x{world}"},
+                       "parallelism": f"shard-by-structure x{world}", "build_calls_per_rank": n_calls, "call_plan": call_plan},
             "roofline": roofline, "export_inclusive": export, "cpu_baseline": cpu, "query": query, "cli_index": cli_index,
         }
         print(json.dumps(out))

@@ -597,7 +597,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     const int codec = msd ? 2 : ids16 ? 1 : 0;           // of the sorted stream (k_index.hip)
     const uint32_t NB = 40;
     fd_batch_view V = b->view();
-    HIPCHK(c, c->ws[WS_MISC3].ensure(64));
+    HIPCHK(c, c->ws[WS_MISC3].ensure(512));     // words 0-2: encode totals, 3: wide flag, 8-48: the MSD stream's bucket starts for the encoder
     HIPCHK(c, hipMemsetAsync(c->ws[WS_MISC3].p, 0, 64, st));
     C.wide_flag = c->ws[WS_MISC3].as<unsigned long long>() + 3;
     const bool msd_perm = [] { const char *e = getenv("FDGPU_MSD_PERM"); return !(e && e[0] == '0'); }();      // 0: buckets without the amino-acid order (measurement)
@@ -714,7 +714,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
         HIPCHK(c, hipMemsetAsync(c->ws[WS_TILE_H].p, 0, (size_t)(nt + 1) * 4, st));
         HIPCHK(c, hipMemsetAsync(c->ws[WS_TILE_P].p, 0, (size_t)(nt + 1) * 4, st));
         fd_launch_enc_sizes(ks, is, codec, (uint32_t)first_id, P, c->ws[WS_TILE_B].as<uint32_t>(), c->ws[WS_TILE_H].as<uint32_t>(), c->ws[WS_TILE_P].as<uint32_t>(),
-                            c->ws[WS_SEGOFF].as<uint64_t>(), S, st);
+                            c->ws[WS_SEGOFF].as<uint64_t>(), S, c->ws[WS_MISC3].as<uint64_t>() + 8, st);
         uint64_t *totd = c->ws[WS_MISC3].as<uint64_t>();
         fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_B].as<uint32_t>(), nt_eff, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 0, st);
         fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_H].as<uint32_t>(), nt_eff, c->ws[WS_TILE_HO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 1, st);
@@ -740,7 +740,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     {
         StageTimer t(c, "encode_write", P * (el6 ? 6 : 8) + ix->value_len + ix->n_hashes * 12);
         fd_launch_enc_write(ks, is, codec, (uint32_t)first_id, P, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_TILE_HO].as<uint64_t>(), ix->value, ix->hashes, ix->offsets,
-                            ix->last_ids, c->ws[WS_MISC3].as<uint64_t>(), ix->n_hashes, c->ws[WS_SEGOFF].as<uint64_t>(), S, st);
+                            ix->last_ids, c->ws[WS_MISC3].as<uint64_t>(), ix->n_hashes, c->ws[WS_MISC3].as<uint64_t>() + 8, st);
     }
     e = hipGetLastError();
     if (e != hipSuccess) { c->err = std::string("encode launch: ") + hipGetErrorString(e); fdgpu_index_destroy(ix); return FDGPU_EHIP; }

@@ -210,10 +210,10 @@ int fd_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, ui
                         uint64_t *tot, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr);
 uint32_t fd_enc_num_tiles(uint64_t n);
 void fd_launch_enc_sizes(const uint32_t *keys, const void *ids, int codec, uint32_t first_id, uint64_t n, uint32_t *tb, uint32_t *th, uint32_t *tp,
-                         const uint64_t *seg_off, uint64_t S, hipStream_t st);
+                         const uint64_t *seg_off, uint64_t S, uint64_t *bo, hipStream_t st);
 void fd_launch_enc_write(const uint32_t *keys, const void *ids, int codec, uint32_t first_id, uint64_t n, const uint64_t *tbo, const uint64_t *tho,
                          uint8_t *value, uint32_t *hashes, uint64_t *offsets, uint32_t *last_ids, const uint64_t *total_bytes_dev, uint64_t H,
-                         const uint64_t *seg_off, uint64_t S, hipStream_t st);
+                         const uint64_t *bo, hipStream_t st);
 void fd_launch_uniq_flags(const uint32_t *keys, const uint32_t *ids, uint64_t n, uint8_t *flags, hipStream_t st);
 void fd_launch_compact(const uint32_t *keys, const uint8_t *flags, const uint64_t *pos, uint64_t n, uint32_t *out, hipStream_t st);
 void fd_launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t n, uint64_t *dst, hipStream_t st);

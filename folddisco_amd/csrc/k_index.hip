@@ -38,28 +38,29 @@ template <> struct enc_codec<uint16_t> {
 };
 
 #define ENC_BUCKETS 40u
-struct enc_b24 {              // B24: where the forty buckets start (LDS copy of seg_off[b * S], b = 0..40) and the tile's first / last bucket
+struct enc_b24 {              // B24: where the forty buckets start (bo[0..40], compact copy of seg_off[b * S]) and the tile's first / last bucket
     const uint64_t *bo;
     uint32_t b0, b1;
-    __device__ __forceinline__ uint32_t at(uint64_t p) const { uint32_t b = b0; while (b < b1 && p >= bo[b + 1]) ++b; return b; }
+    __device__ __forceinline__ uint32_t at(uint64_t p) const { uint32_t b = b0; while (b < b1 && p >= bo[b + 1]) ++b; return b; }      // tiles on a boundary only
 };
-// every thread of the block; s_bo holds ENC_BUCKETS + 1 words
-__device__ __forceinline__ enc_b24 enc_b24_setup(const uint64_t *__restrict__ seg_off, uint64_t S, uint64_t n, uint64_t *s_bo) {
-    if (threadIdx.x <= ENC_BUCKETS) s_bo[threadIdx.x] = seg_off[(uint64_t)threadIdx.x * S];
-    __syncthreads();
+// per wave, no LDS and no barrier: lane l holds bo[l]; called AFTER the tile's key loads are in flight
+__device__ __forceinline__ enc_b24 enc_b24_setup(const uint64_t *__restrict__ bo, uint64_t n) {
     const uint64_t t0 = (uint64_t)blockIdx.x * (256 * 8);
     const uint64_t t1 = (t0 + 256 * 8 < n ? t0 + 256 * 8 : n) - 1;
-    // the predecessor of the tile's first element belongs to the classification too: start the walk one position early
-    const uint64_t tp = t0 ? t0 - 1 : 0;
+    const uint64_t tp = t0 ? t0 - 1 : 0;      // the predecessor of the tile's first element is classified too
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t o = lane <= ENC_BUCKETS ? s_bo[lane] : ~0ull;
+    const bool in = lane >= 1 && lane <= ENC_BUCKETS;
+    const uint64_t o = in ? bo[lane] : ~0ull;
     enc_b24 K;
-    K.bo = s_bo;
-    K.b0 = (uint32_t)__popcll(__ballot(lane >= 1 && lane <= ENC_BUCKETS && o <= tp));      // buckets whose start is <= p, minus bucket 0's
-    K.b1 = (uint32_t)__popcll(__ballot(lane >= 1 && lane <= ENC_BUCKETS && o <= t1));
+    K.bo = bo;
+    K.b0 = (uint32_t)__popcll(__ballot(in && o <= tp));      // buckets 1..40 that start at or before p: the bucket p lies in
+    K.b1 = (uint32_t)__popcll(__ballot(in && o <= t1));
     if (K.b0 >= ENC_BUCKETS) K.b0 = ENC_BUCKETS - 1;
     if (K.b1 >= ENC_BUCKETS) K.b1 = ENC_BUCKETS - 1;
     return K;
+}
+__global__ void k_enc_bucket_starts(const uint64_t *__restrict__ seg_off, uint64_t S, uint64_t *__restrict__ bo) {
+    if (threadIdx.x <= ENC_BUCKETS) bo[threadIdx.x] = seg_off[(uint64_t)threadIdx.x * S];
 }
 
 // Loads the ENC_ITEMS (= 8) consecutive elements owned by this thread with 16-byte loads (full tiles) and
@@ -67,7 +68,7 @@ __device__ __forceinline__ enc_b24 enc_b24_setup(const uint64_t *__restrict__ se
 // or, for lane 0 of a wave, from memory.
 template <typename V, bool B24>
 __device__ __forceinline__ void enc_load_classify(const uint32_t *__restrict__ keys, const V *__restrict__ ids, uint64_t n, uint64_t base,
-                                                  uint32_t first_id, enc_item *it, const enc_b24 &K, uint32_t *pred_id = nullptr) {
+                                                  uint32_t first_id, enc_item *it, const uint64_t *__restrict__ bo, uint32_t *pred_id = nullptr) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     uint32_t k[ENC_ITEMS], v[ENC_ITEMS];
     const bool full = base + ENC_ITEMS <= n;
@@ -96,9 +97,17 @@ __device__ __forceinline__ void enc_load_classify(const uint32_t *__restrict__ k
     uint32_t pk = __shfl_up(k[ENC_ITEMS - 1], 1, FD_WAVE), pv = __shfl_up(v[ENC_ITEMS - 1], 1, FD_WAVE);
     if ((threadIdx.x & 63) == 0 && base > 0 && base < n) { pk = keys[base - 1]; pv = (uint32_t)ids[base - 1]; }
     uint32_t ph, pid;
-    const bool one_bucket = K.b0 == K.b1;      // block-uniform; 40 boundaries in the whole stream: nearly every tile
+    uint32_t hb[ENC_ITEMS];      // B24: the items' bucket << 24 — one value for the whole tile unless it lies on one of the 40 boundaries
     if (B24) {
-        const uint32_t pb = (one_bucket || !base) ? K.b0 : K.at(base - 1);
+        const enc_b24 K = enc_b24_setup(bo, n);
+        uint32_t pb = K.b0;
+#pragma unroll
+        for (int j = 0; j < ENC_ITEMS; ++j) hb[j] = K.b0 << 24;
+        if (K.b0 != K.b1) {      // block-uniform
+            if (base) pb = K.at(base - 1);
+#pragma unroll
+            for (int j = 0; j < ENC_ITEMS; ++j) if (base + j < n) hb[j] = K.at(base + j) << 24;
+        }
         ph = pb << 24 | pk >> 8; pid = first_id + (((pk & 255u) << 16) | pv);
     } else { ph = enc_codec<V>::hash(pk); pid = enc_codec<V>::id(pk, (V)pv, first_id); }
     if (pred_id) *pred_id = pid;     // id of the element before the thread's first one (undefined for element 0)
@@ -107,10 +116,8 @@ __device__ __forceinline__ void enc_load_classify(const uint32_t *__restrict__ k
     for (int j = 0; j < ENC_ITEMS; ++j) {
         uint64_t p = base + j;
         uint32_t h, id;
-        if (B24) {
-            const uint32_t bk = (one_bucket || p >= n) ? K.b0 : K.at(p);
-            h = bk << 24 | k[j] >> 8; id = first_id + (((k[j] & 255u) << 16) | v[j]);
-        } else { h = enc_codec<V>::hash(k[j]); id = enc_codec<V>::id(k[j], (V)v[j], first_id); }
+        if (B24) { h = hb[j] | k[j] >> 8; id = first_id + (((k[j] & 255u) << 16) | v[j]); }
+        else { h = enc_codec<V>::hash(k[j]); id = enc_codec<V>::id(k[j], (V)v[j], first_id); }
         bool in = p < n;
         bool head = !have_prev || ph != h;
         bool dup = !head && pid == id;
@@ -153,15 +160,12 @@ __device__ __forceinline__ uint64_t block_excl_scan_packed(uint64_t v, uint64_t 
 template <typename V, bool B24>
 __global__ __launch_bounds__(ENC_THREADS) void k_enc_sizes(const uint32_t *__restrict__ keys, const V *__restrict__ ids, uint64_t n, uint32_t first_id,
                                                            uint32_t *__restrict__ tile_bytes, uint32_t *__restrict__ tile_heads,
-                                                           uint32_t *__restrict__ tile_posts, const uint64_t *__restrict__ seg_off, uint64_t S) {
+                                                           uint32_t *__restrict__ tile_posts, const uint64_t *__restrict__ bo) {
     __shared__ uint64_t sm[ENC_THREADS / 64];
-    __shared__ uint64_t s_bo[B24 ? ENC_BUCKETS + 1 : 1];
-    enc_b24 K = {s_bo, 0, 0};
-    if (B24) K = enc_b24_setup(seg_off, S, n, s_bo);
     uint64_t base = (uint64_t)blockIdx.x * ENC_TILE + (uint64_t)threadIdx.x * ENC_ITEMS;
     uint32_t bytes = 0, heads = 0, posts = 0;
     enc_item it[ENC_ITEMS];
-    enc_load_classify<V, B24>(keys, ids, n, base, first_id, it, K);
+    enc_load_classify<V, B24>(keys, ids, n, base, first_id, it, bo);
 #pragma unroll
     for (int k = 0; k < ENC_ITEMS; ++k) {
         bytes += it[k].len;
@@ -190,11 +194,8 @@ template <typename V, bool B24>
 __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__restrict__ keys, const V *__restrict__ ids, uint64_t n, uint32_t first_id,
                                                            const uint64_t *__restrict__ tile_byte_off, const uint64_t *__restrict__ tile_head_off,
                                                            uint8_t *__restrict__ value, uint32_t *__restrict__ hashes, uint64_t *__restrict__ offsets,
-                                                           uint32_t *__restrict__ last_ids, const uint64_t *__restrict__ seg_off, uint64_t S) {
+                                                           uint32_t *__restrict__ last_ids, const uint64_t *__restrict__ bo) {
     __shared__ uint64_t sm[ENC_THREADS / 64];
-    __shared__ uint64_t s_bo[B24 ? ENC_BUCKETS + 1 : 1];
-    enc_b24 K = {s_bo, 0, 0};
-    if (B24) K = enc_b24_setup(seg_off, S, n, s_bo);
     // varint bytes of the tile are assembled in LDS (pre-shifted by the global misalignment) and leave as
     // 16-byte stores instead of one global byte store per byte
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[ENC_TILE * 5 + 32];
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__res
     enc_item it[ENC_ITEMS];
     uint32_t bytes = 0, heads = 0;
     uint32_t run_id = 0;   // id of the element before item k (for the per-list last ids)
-    enc_load_classify<V, B24>(keys, ids, n, base, first_id, it, K, &run_id);
+    enc_load_classify<V, B24>(keys, ids, n, base, first_id, it, bo, &run_id);
 #pragma unroll
     for (int k = 0; k < ENC_ITEMS; ++k) { bytes += it[k].len; heads += it[k].head; }
     uint64_t tot;
@@ -247,23 +248,25 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_write(const uint32_t *__res
 __global__ void k_set_u64(uint64_t *dst, uint64_t idx, const uint64_t *src) { dst[idx] = src[0]; }
 
 uint32_t fd_enc_num_tiles(uint64_t n) { return (uint32_t)((n + ENC_TILE - 1) / ENC_TILE); }
-// codec: 0 = (u32 hash, u32 id), 1 = 6-byte elements of the structure-major stream, 2 = 6-byte elements of the MSD stream (seg_off = its [40][S] table)
+// codec: 0 = (u32 hash, u32 id), 1 = 6-byte elements of the structure-major stream, 2 = 6-byte elements of the MSD stream (seg_off = its [40][S]
+// table, bo = 41 words of scratch that receive the bucket starts; fd_launch_enc_write reads them again)
 void fd_launch_enc_sizes(const uint32_t *keys, const void *ids, int codec, uint32_t first_id, uint64_t n, uint32_t *tb, uint32_t *th, uint32_t *tp,
-                         const uint64_t *seg_off, uint64_t S, hipStream_t st) {
+                         const uint64_t *seg_off, uint64_t S, uint64_t *bo, hipStream_t st) {
     if (!n) return;
     const dim3 g(fd_enc_num_tiles(n)), t(ENC_THREADS);
-    if (codec == 2) hipLaunchKernelGGL((k_enc_sizes<uint16_t, true>), g, t, 0, st, keys, (const uint16_t *)ids, n, first_id, tb, th, tp, seg_off, S);
-    else if (codec == 1) hipLaunchKernelGGL((k_enc_sizes<uint16_t, false>), g, t, 0, st, keys, (const uint16_t *)ids, n, first_id, tb, th, tp, seg_off, S);
-    else hipLaunchKernelGGL((k_enc_sizes<uint32_t, false>), g, t, 0, st, keys, (const uint32_t *)ids, n, first_id, tb, th, tp, seg_off, S);
+    if (codec == 2) hipLaunchKernelGGL(k_enc_bucket_starts, dim3(1), dim3(64), 0, st, seg_off, S, bo);
+    if (codec == 2) hipLaunchKernelGGL((k_enc_sizes<uint16_t, true>), g, t, 0, st, keys, (const uint16_t *)ids, n, first_id, tb, th, tp, bo);
+    else if (codec == 1) hipLaunchKernelGGL((k_enc_sizes<uint16_t, false>), g, t, 0, st, keys, (const uint16_t *)ids, n, first_id, tb, th, tp, bo);
+    else hipLaunchKernelGGL((k_enc_sizes<uint32_t, false>), g, t, 0, st, keys, (const uint32_t *)ids, n, first_id, tb, th, tp, bo);
 }
 void fd_launch_enc_write(const uint32_t *keys, const void *ids, int codec, uint32_t first_id, uint64_t n, const uint64_t *tbo, const uint64_t *tho,
                          uint8_t *value, uint32_t *hashes, uint64_t *offsets, uint32_t *last_ids, const uint64_t *total_bytes_dev, uint64_t H,
-                         const uint64_t *seg_off, uint64_t S, hipStream_t st) {
+                         const uint64_t *bo, hipStream_t st) {
     if (n) {
         const dim3 g(fd_enc_num_tiles(n)), t(ENC_THREADS);
-        if (codec == 2) hipLaunchKernelGGL((k_enc_write<uint16_t, true>), g, t, 0, st, keys, (const uint16_t *)ids, n, first_id, tbo, tho, value, hashes, offsets, last_ids, seg_off, S);
-        else if (codec == 1) hipLaunchKernelGGL((k_enc_write<uint16_t, false>), g, t, 0, st, keys, (const uint16_t *)ids, n, first_id, tbo, tho, value, hashes, offsets, last_ids, seg_off, S);
-        else hipLaunchKernelGGL((k_enc_write<uint32_t, false>), g, t, 0, st, keys, (const uint32_t *)ids, n, first_id, tbo, tho, value, hashes, offsets, last_ids, seg_off, S);
+        if (codec == 2) hipLaunchKernelGGL((k_enc_write<uint16_t, true>), g, t, 0, st, keys, (const uint16_t *)ids, n, first_id, tbo, tho, value, hashes, offsets, last_ids, bo);
+        else if (codec == 1) hipLaunchKernelGGL((k_enc_write<uint16_t, false>), g, t, 0, st, keys, (const uint16_t *)ids, n, first_id, tbo, tho, value, hashes, offsets, last_ids, bo);
+        else hipLaunchKernelGGL((k_enc_write<uint32_t, false>), g, t, 0, st, keys, (const uint32_t *)ids, n, first_id, tbo, tho, value, hashes, offsets, last_ids, bo);
     }
     hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, offsets, H, total_bytes_dev);
 }

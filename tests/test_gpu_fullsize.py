@@ -11,8 +11,9 @@
   4-byte varint), a whole-structure query (no -q) whose prefilter is recounted on sampled structures from their S1 lists and whose
   top 20 go through oracle.retrieve.
 
-Both databases are built the way bench.py builds them: blocks of 67,750 structures, one fdgpu_index_build per block, merged on the device
-(fdgpu_index_merge; at 2,000,000 in two rounds: 8 blocks at a time, then the four group indices)."""
+The 542,000 database is built both ways bench.py knows: three fdgpu_index_build calls of <= 203,250 structures merged on the device
+(fdgpu_index_merge), and ONE call of all 542,000 — byte-identical.  The 2,000,000 one in two merge rounds: 8 blocks at a time, then the four
+group indices."""
 import os
 
 import numpy as np
@@ -232,6 +233,22 @@ def test_swissprot_scale_542000_index_and_planted_motifs():
         n = _check_matches(got, cand, ps, oq, om)
         full = [g for g in got if sum(1 for x in g["processed"] if x >= 0) == len(Q["idx"])]
         assert n >= 12 and len(full) >= 12 and min(g["rmsd"] for g in full) < 0.01
+    # ---- the same database in ONE fdgpu_index_build call (bench.py's default plan: 542,000 structures > 2^18, so the key's eight id bits are in
+    # use; 1.77e10 keys > 2^34 positions; 213 GB of sort workspace): byte-identical to the merged index of the three calls
+    import xxhash
+    def digests(index):
+        out = [index.n_structures, index.num_postings]
+        for a in index.export_view():
+            out.append((len(a), xxhash.xxh3_128_hexdigest(memoryview(np.ascontiguousarray(a)).cast("B"))))
+        return out
+    want = digests(ix)
+    del ix, got, top, recs
+    torch.cuda.empty_cache()
+    one = fd.FolddiscoIndex.build(ctx, db, first_id=0)
+    assert one.num_postings > 2 ** 34
+    assert digests(one) == want
+    del one
+    ctx.release_workspaces()
 
 
 class _Lazy:
