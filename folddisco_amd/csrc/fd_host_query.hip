@@ -110,6 +110,65 @@ __global__ void k_hash_features(const float *__restrict__ feat, uint64_t n, uint
     out[k] = fd_hash_enc_feat(fd_sat_u32(f[0]), fd_sat_u32(f[1]), ft, q);
 }
 
+// Large queries without substitutions (whole-structure queries: ~10^5 pairs, 3.7 candidates each): expand_and_insert (query.rs:179-206) per valid
+// pair on the device — the observed container, then near / far per threshold and field in the reference's order, with its f32 restore drift —
+// and the hash of every candidate; nothing but the hashes leaves the kernel.  out[v * per_pair + c], c in insertion order.
+struct qm_expand_par {
+    int di[2], ndi, ai[7], nai;
+    float dthr[8], athr[8];
+    uint32_t n_dist, n_angle, per_pair;
+};
+__device__ __forceinline__ uint32_t qm_hash_of(const float *f, const fd_quant &q) {
+    if (fd_own_descriptor(q.type)) return fd_hash_other(q.type, f, q);
+    fd_feature ft = {f[2], f[3], f[4], f[5], f[6]};
+    return fd_hash_enc_feat(fd_sat_u32(f[0]), fd_sat_u32(f[1]), ft, q);
+}
+__global__ void k_qm_expand_hash(const float *__restrict__ feat, const uint32_t *__restrict__ vp, uint32_t n_valid, qm_expand_par P, fd_quant q,
+                                 uint32_t *__restrict__ out) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_valid) return;
+    const float *f = feat + (uint64_t)FD_QF * vp[v];
+    float near[FD_QF], far[FD_QF];
+    for (int z = 0; z < FD_QF; ++z) { near[z] = f[z]; far[z] = f[z]; }
+    uint32_t *o = out + (uint64_t)v * P.per_pair;
+    *o++ = qm_hash_of(near, q);
+    for (int grp = 0; grp < 2; ++grp) {
+        const int *idxs = grp ? P.ai : P.di;
+        const int n_idx = grp ? P.nai : P.ndi;
+        const float *thr = grp ? P.athr : P.dthr;
+        const uint32_t n_thr = grp ? P.n_angle : P.n_dist;
+        for (uint32_t z2 = 0; z2 < n_thr; ++z2)
+            for (int z = 0; z < n_idx; ++z) {
+                const int idx = idxs[z];
+                // the container field by a run-time index: a select chain over the twelve registers instead of private memory
+                float nv = 0.f, fv = 0.f;
+#pragma unroll
+                for (int w = 0; w < FD_QF; ++w) { nv = w == idx ? near[w] : nv; fv = w == idx ? far[w] : fv; }
+                const float n1 = nv - thr[z2], f1 = fv + thr[z2];
+#pragma unroll
+                for (int w = 0; w < FD_QF; ++w) { near[w] = w == idx ? n1 : near[w]; far[w] = w == idx ? f1 : far[w]; }
+                *o++ = qm_hash_of(near, q);
+                *o++ = qm_hash_of(far, q);
+                const float n2 = n1 + thr[z2], f2 = f1 - thr[z2];      // the reference restores with += / -= (f32, not an exact inverse): keep the drift
+#pragma unroll
+                for (int w = 0; w < FD_QF; ++w) { near[w] = w == idx ? n2 : near[w]; far[w] = w == idx ? f2 : far[w]; }
+            }
+    }
+}
+// first insertion wins: after a stable sort of (hash, insertion position) by hash the first element of every run is the hash's earliest insertion
+__global__ void k_qm_first(const uint32_t *__restrict__ key, const uint32_t *__restrict__ val, uint64_t n, uint8_t *__restrict__ first) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && (k == 0 || key[k] != key[k - 1])) first[val[k]] = 1;
+}
+__global__ void k_qm_iota(uint32_t *__restrict__ v, uint64_t n) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) v[k] = (uint32_t)k;
+}
+__global__ void k_qm_keep(const uint8_t *__restrict__ first, const uint64_t *__restrict__ pos, uint64_t n, uint32_t *__restrict__ keep) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && first[k]) keep[pos[k]] = (uint32_t)k;
+}
+
 extern "C" int fdgpu_pair_features(fdgpu_ctx *c, const fdgpu_batch *b, uint64_t s, const uint32_t *pi, const uint32_t *pj, uint64_t n,
                                    const fd_hash_params *p, float *features, uint8_t *valid) { FD_LOCK(c);
     if (!c || !b || !p || (s >= b->n_struct && s != 0xffffffffull) || (n && (!pi || !pj || !features || !valid))) return FDGPU_EINVAL;
@@ -241,6 +300,39 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         vf.insert(vf.end(), f, f + FD_QF);
         cands.push_back({qi, qj, (uint8_t)(primary ? 1 : 0), pair});
     };
+    // dist_index / angle_index of the encoding (controller/feature.rs:269-291): theta only for the two PDBMotif forms — and
+    // PDBMotif shifts its DEGREE-valued theta by the threshold converted to radians, like the reference
+    static const int d23[2] = {2, 3}, d2[1] = {2}, d7[1] = {7};
+    static const int a456[3] = {4, 5, 6}, a37[5] = {3, 4, 5, 6, 7}, a345[3] = {3, 4, 5}, a06[7] = {0, 1, 2, 3, 4, 5, 6}, a48[5] = {4, 5, 6, 7, 8};
+    const int *di = d23, *ai = a456;
+    int ndi = 2, nai = 3;
+    switch (p->hash_type) {
+        case FD_HASH_PDBMOTIF: case FD_HASH_PDBMOTIF_SINCOS: nai = 1; break;
+        case FD_HASH_TRROSETTA: di = d2; ndi = 1; ai = a37; nai = 5; break;
+        case FD_HASH_PPF: di = d2; ndi = 1; ai = a345; nai = 3; break;
+        case FD_HASH_TERTIARY: di = d7; ndi = 1; ai = a06; nai = 7; break;
+        case FD_HASH_HYBRID: ai = a48; nai = 5; break;
+        default: break;
+    }
+    // ONE large query without substitutions and with one bin configuration (a whole-structure query: ~10^5 pairs, 3 x 10^5 candidates): expansion,
+    // hashes and the first-insertion-wins dedupe run on the device (k_qm_*); only the hashes and the kept positions come back.  cands / vf stay
+    // empty: candidate z is (valid pair z / per_pair, insertion z % per_pair).  FDGPU_QM_DEVICE=0: the host form (tests).
+    std::vector<uint32_t> vpairs;      // device path: the valid pairs, ascending
+    uint64_t dev_pp = 0;
+    std::vector<uint32_t> dev_keep;
+    bool dev_expand = false;
+    {
+        bool any_subs = false;
+        if (subs && n_subs) for (uint64_t a = 0; a < q_off[n_queries] && !any_subs; ++a) any_subs = subs[a] != nullptr;
+        uint64_t n_valid = 0;
+        for (uint64_t k = 0; k < np; ++k) n_valid += valid[k] ? 1 : 0;
+        const uint64_t per_pair = 1 + 2 * ((uint64_t)ndi * n_dist + (uint64_t)nai * n_angle);
+        const char *qd_env = getenv("FDGPU_QM_DEVICE");
+        const uint64_t qd_min = qd_env && qd_env[0] == '1' ? 1 : 32768;      // 1: also for small queries (tests)
+        dev_expand = n_queries == 1 && !any_subs && p->n_multiple_bins == 0 && n_dist <= 8 && n_angle <= 8 && !(qd_env && qd_env[0] == '0') &&
+                     n_valid * per_pair >= qd_min && n_valid * per_pair < (1ull << 31);
+        if (dev_expand) { dev_pp = per_pair; vpairs.reserve(n_valid); for (uint64_t k = 0; k < np; ++k) if (valid[k]) vpairs.push_back((uint32_t)k); }
+    }
     for (uint64_t t = 0; t < n_queries; ++t) {
         const uint64_t r0 = qb->h_res_off[q_struct[t]];
         const uint32_t *qidx = q_index + q_off[t];
@@ -257,6 +349,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             uint32_t qi = (uint32_t)(pi[k] - r0), qj = (uint32_t)(pj[k] - r0);
             // observed (aa_i, aa_j, CA distance) list (structure/core.rs:462-477: distance <= 20.0)
             if (f[9] <= 20.0f) { A.a1.push_back((uint8_t)f[10]); A.a2.push_back((uint8_t)f[11]); A.ad.push_back(f[9]); A.aq.push_back(qi); }
+            if (dev_expand) continue;
             push(f, qi, qj, true, (uint32_t)k);
             float near[FD_QF], far[FD_QF];
             memcpy(near, f, sizeof near);
@@ -290,28 +383,67 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
                         far[idx] = far[idx] - thr[z2];
                     }
             };
-            // dist_index / angle_index of the encoding (controller/feature.rs:269-291): theta only for the two PDBMotif forms — and
-            // PDBMotif shifts its DEGREE-valued theta by the threshold converted to radians, like the reference
-            static const int d23[2] = {2, 3}, d2[1] = {2}, d7[1] = {7};
-            static const int a456[3] = {4, 5, 6}, a37[5] = {3, 4, 5, 6, 7}, a345[3] = {3, 4, 5}, a06[7] = {0, 1, 2, 3, 4, 5, 6}, a48[5] = {4, 5, 6, 7, 8};
-            const int *di = d23, *ai = a456;
-            int ndi = 2, nai = 3;
-            switch (p->hash_type) {
-                case FD_HASH_PDBMOTIF: case FD_HASH_PDBMOTIF_SINCOS: nai = 1; break;
-                case FD_HASH_TRROSETTA: di = d2; ndi = 1; ai = a37; nai = 5; break;
-                case FD_HASH_PPF: di = d2; ndi = 1; ai = a345; nai = 3; break;
-                case FD_HASH_TERTIARY: di = d7; ndi = 1; ai = a06; nai = 7; break;
-                case FD_HASH_HYBRID: ai = a48; nai = 5; break;
-                default: break;
-            }
             expand(di, ndi, dist_thr, n_dist);
             expand(ai, nai, athr.data(), n_angle);
         }
-        cand_off[t + 1] = cands.size();
+        cand_off[t + 1] = dev_expand ? vpairs.size() * dev_pp : cands.size();
     }
-    const uint64_t nc = cands.size();
+    const uint64_t nc = dev_expand ? vpairs.size() * dev_pp : cands.size();
+    // candidate z -> (query residues, observed?, pair): stored by the host expansion, implied by the position on the device path
+    auto cand_at = [&](uint64_t z) -> cand_t {
+        if (!dev_expand) return cands[z];
+        const uint32_t k = vpairs[z / dev_pp];
+        const uint64_t r0 = qb->h_res_off[q_struct[0]];
+        return cand_t{(uint32_t)(pi[k] - r0), (uint32_t)(pj[k] - r0), (uint8_t)(z % dev_pp == 0 ? 1 : 0), k};
+    };
     if (qtrace) fprintf(stderr, "[fdgpu_query_map] %llu candidates expanded at %.3f ms\n", (unsigned long long)nc, q_ms());
     std::vector<uint32_t> hashes(std::max<uint64_t>(nc, 1));
+    if (dev_expand && nc) {
+        hipStream_t st = c->stream;
+        const uint64_t nv = vpairs.size();
+        qm_expand_par P;
+        memset(&P, 0, sizeof P);
+        for (int z = 0; z < ndi; ++z) P.di[z] = di[z];
+        for (int z = 0; z < nai; ++z) P.ai[z] = ai[z];
+        P.ndi = ndi; P.nai = nai; P.n_dist = (uint32_t)n_dist; P.n_angle = (uint32_t)n_angle; P.per_pair = (uint32_t)dev_pp;
+        for (uint64_t z = 0; z < n_dist; ++z) P.dthr[z] = dist_thr[z];
+        for (uint64_t z = 0; z < n_angle; ++z) P.athr[z] = athr[z];
+        // ws[WS_MISC2] still holds the pairs' containers (pair_features12); the sort takes the build's key / id buffers
+        HIPCHK(c, c->ws[WS_MISC0].ensure(nv * 4));
+        HIPCHK(c, c->ws[WS_MISC1].ensure(nc * 4));
+        HIPCHK(c, c->ws[WS_KEYS_A].ensure(nc * 4)); HIPCHK(c, c->ws[WS_KEYS_B].ensure(nc * 4));
+        HIPCHK(c, c->ws[WS_IDS_A].ensure(nc * 4)); HIPCHK(c, c->ws[WS_IDS_B].ensure(nc * 4));
+        HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * std::max<uint32_t>(fd_rs_num_tiles(nc), 1) * 4));
+        HIPCHK(c, c->ws[WS_TOT].ensure((256 + (size_t)(fd_rs_num_tiles(nc) / 128 + 2) * 256) * 8));
+        HIPCHK(c, c->ws[WS_MISC4].ensure(nc + 8));
+        HIPCHK(c, c->ws[WS_TILE_BO].ensure((nc + 2) * 8));
+        HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(nc) * 8 + 64));
+        HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, vpairs.data(), nv * 4, hipMemcpyHostToDevice, st));
+        uint32_t *d_hash = c->ws[WS_MISC1].as<uint32_t>();
+        hipLaunchKernelGGL(k_qm_expand_hash, dim3((unsigned)((nv + 63) / 64)), dim3(64), 0, st, c->ws[WS_MISC2].as<float>(), c->ws[WS_MISC0].as<uint32_t>(), (uint32_t)nv, P,
+                           fd_make_consts(p).q, d_hash);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(hashes.data(), d_hash, nc * 4, hipMemcpyDeviceToHost, st));
+        // first insertion wins: stable sort of (hash, position) by hash, first of every run marked, marks compacted in position order
+        uint32_t *ka = c->ws[WS_KEYS_A].as<uint32_t>(), *kb = c->ws[WS_KEYS_B].as<uint32_t>(), *va = c->ws[WS_IDS_A].as<uint32_t>(), *vb = c->ws[WS_IDS_B].as<uint32_t>();
+        const unsigned gb = (unsigned)((nc + 255) / 256);
+        HIPCHK(c, hipMemcpyAsync(ka, d_hash, nc * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_qm_iota, dim3(gb), dim3(256), 0, st, va, nc);
+        const int cur = fd_radix_sort_pairs(ka, va, kb, vb, nc, 32, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st, nullptr);
+        uint8_t *d_first = c->ws[WS_MISC4].as<uint8_t>();
+        HIPCHK(c, hipMemsetAsync(d_first, 0, nc, st));
+        hipLaunchKernelGGL(k_qm_first, dim3(gb), dim3(256), 0, st, cur ? kb : ka, cur ? vb : va, nc, d_first);
+        fd_exclusive_scan<uint8_t>(d_first, nc, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), c->ws[WS_TOTAL].as<uint64_t>(), st);
+        uint32_t *d_keep = cur ? ka : kb;      // the sort's other buffer is free again
+        hipLaunchKernelGGL(k_qm_keep, dim3(gb), dim3(256), 0, st, d_first, c->ws[WS_TILE_BO].as<uint64_t>(), nc, d_keep);
+        HIPCHK(c, hipGetLastError());
+        uint64_t nk = 0;
+        HIPCHK(c, hipMemcpyAsync(&nk, c->ws[WS_TOTAL].p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        dev_keep.resize(nk);
+        if (nk) HIPCHK(c, hipMemcpy(dev_keep.data(), d_keep, nk * 4, hipMemcpyDeviceToHost));
+    } else
     if ((rc = hash_features_q(c, vf.data(), nc, fd_make_consts(p).q, hashes.data(), FD_QF))) return rc;
     // --multiple-bins: every candidate is inserted under every bin pair, in list order (insert_binned_hash, query.rs:59-70); the
     // observed hash idf is looked up for stays the single-configuration one (query.rs:283-288)
@@ -324,6 +456,8 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     }
     if (qtrace) fprintf(stderr, "[fdgpu_query_map] hashed at %.3f ms\n", q_ms());
     std::vector<uint32_t> pair_primary(std::max<uint64_t>(np, 1), 0u);
+    if (dev_expand) { for (uint64_t v = 0; v < vpairs.size(); ++v) pair_primary[vpairs[v]] = hashes[v * dev_pp]; }
+    else
     for (uint64_t t = 0; t < nc; ++t)
         if (cands[t].primary) pair_primary[cands[t].pair] = hashes[t];
     // first insertion wins (the reference's hash map keeps the entry a hash was first inserted with).  Few candidates: a hash set;
@@ -336,7 +470,8 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         const uint64_t c0 = cand_off[t], c1 = cand_off[t + 1], n_ins = (c1 - c0) * ncfg1;
         auto hash_at = [&](uint64_t pos) { const uint64_t z = c0 + pos / ncfg1; const uint32_t k = (uint32_t)(pos % ncfg1); return n_cfg ? mh_cfg[k][z] : hashes[z]; };
         std::vector<uint32_t> &keep = keeps[t];
-        if (n_ins <= 4096 || n_ins >= (1ull << 32)) {
+        if (dev_expand) keep.swap(dev_keep);
+        else if (n_ins <= 4096 || n_ins >= (1ull << 32)) {
             std::unordered_set<uint32_t> have;
             have.reserve((size_t)n_ins / 4 + 16);
             for (uint64_t pos = 0; pos < n_ins; ++pos) if (have.insert(hash_at(pos)).second) keep.push_back((uint32_t)pos);
@@ -370,6 +505,8 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             const uint64_t c0 = cand_off[t];
             for (uint32_t pos : keeps[t]) { const uint64_t z = c0 + pos / ncfg1; ph.push_back(n_cfg ? mh_cfg[pos % ncfg1][z] : hashes[z]); }
         }
+        if (dev_expand) { for (uint64_t v = 0; v < vpairs.size(); ++v) { ph.push_back(hashes[v * dev_pp]); pk.push_back(vpairs[v]); } }
+        else
         for (uint64_t t = 0; t < nc; ++t)
             if (cands[t].primary) { ph.push_back(hashes[t]); pk.push_back(cands[t].pair); }
         ent_len.assign(std::max<size_t>(ph.size(), 1), 0);
@@ -390,8 +527,9 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         mh.reserve(keep.size()); mqi.reserve(keep.size()); mqj.reserve(keep.size()); mp.reserve(keep.size()); mi.reserve(keep.size()); mph.reserve(keep.size());
         for (uint32_t pos : keep) {
             const uint64_t z = c0 + pos / ncfg1;
-            mh.push_back(hash_at(pos)); mqi.push_back(cands[z].qi); mqj.push_back(cands[z].qj); mp.push_back(cands[z].primary);
-            mi.push_back(pair_idf[cands[z].pair]); mph.push_back(pair_primary[cands[z].pair]);
+            const cand_t cz = cand_at(z);
+            mh.push_back(hash_at(pos)); mqi.push_back(cz.qi); mqj.push_back(cz.qj); mp.push_back(cz.primary);
+            mi.push_back(pair_idf[cz.pair]); mph.push_back(pair_primary[cz.pair]);
         }
         fd_query_map *m = (fd_query_map *)calloc(1, sizeof *m);
         if (!m) { for (uint64_t u = 0; u < t; ++u) { fdgpu_query_map_free(out[u]); out[u] = nullptr; } return FDGPU_ENOMEM; }
@@ -743,8 +881,9 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue declined (flags %u): host path\n", dflags);
     }
     if (trace) fprintf(stderr, "[fdgpu_retrieve] query tables %.3f ms\n", t_ms(T0, t_now()));
+    fd_mp_tables mp_tab;      // work items + query tables: built by the first scan, reused by the second
     rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc, two_pass ? 1u : 15u,
-                              nullptr, nullptr, 0, &pk_key, &pk_val);
+                              nullptr, nullptr, 0, &pk_key, &pk_val, nullptr, &mp_tab);
     if (rc) return rc;
     auto T1 = t_now();
     // per candidate: graph -> components -> vote -> rescue; Kabsch problems collected for one GPU batch
@@ -786,15 +925,22 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     // plan = true: components and mappings only, marking the mapped residues of every component that leaves a query residue
     // unmatched (first pass of a large query); plan = false: the full body
     // two-scan retrievals build the components and from-hash mappings once (plan pass) and reuse them in the full pass
-    struct CompPlan { std::vector<uint32_t> q_idx, r_idx; float sub_idf; };
+    struct CompPlan { std::vector<uint32_t> q_idx, r_idx; float sub_idf; uint32_t rc_ord = 0; };      // rc_ord: 1-based ordinal among the slot's components that need the rescue
     std::vector<std::vector<CompPlan>> plan_cache(two_pass ? n_cand : 0);
     std::vector<char> plan_have(two_pass ? n_cand : 0, 0);
     // Candidate slots are independent (their own found triples, candidate pairs and outputs): they are processed by a pool of
     // host threads into per-slot outputs that are merged in slot order afterwards, so the result does not depend on the thread count.
     struct SlotOut {
         std::vector<fd_match_rec> recs; std::vector<int32_t> res; std::vector<float> kx, ky; std::vector<uint64_t> klen;
-        std::vector<Pend> pend; std::vector<uint32_t> marks;
+        std::vector<Pend> pend; std::vector<uint32_t> marks, mark_ord;
     };
+    // rescue votes counted on the device (second scan, fd_match_pairs_multi mode bit 5): per marked target residue the ordinal of the component
+    // that mapped it; rows of (largest count, holders, which) per (slot, ordinal, query residue) come back instead of the candidate pairs
+    std::vector<uint8_t> cj_comp(two_pass ? g_total + 1 : 1, 0);
+    std::vector<uint32_t> slot_nrc(n_cand + 1, 0);
+    std::vector<uint64_t> row_base(n_cand + 1, 0);
+    std::vector<fd_vote_row> vote_rows;
+    bool vote_conflict = false, have_rows = false;
     std::vector<uint32_t> slot_q(std::max<uint64_t>(n_cand, 1), 0);
     for (uint64_t t = 0; t < n_queries; ++t) for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) slot_q[k] = (uint32_t)t;
     std::vector<size_t> f_lo(n_cand + 1, 0), c_lo(n_cand + 1, 0);
@@ -877,6 +1023,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         std::vector<uint32_t> vote_pos;      // dense (q, r) -> 1 + vote position of the component at hand (see below)
         std::vector<uint32_t> r_mx(q_size, 0), r_nmx(q_size, 0), r_arg(q_size, 0);
         if (plan && two_pass) { plan_cache[slot].resize(n_comps); plan_have[slot] = 1; }
+        uint32_t n_rc = 0;
         for (size_t ci = 0; ci < n_comps; ++ci) {
             float sub_idf = 0.0f;
             std::vector<uint32_t> q_idx, r_idx;
@@ -942,8 +1089,11 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
                 if (two_pass) { plan_cache[slot][ci].q_idx = q_idx; plan_cache[slot][ci].r_idx = r_idx; plan_cache[slot][ci].sub_idf = sub_idf; }   // a query residue without a target leaves work for the rescue: its votes come from pairs whose partner is mapped
                 bool unmatched = false;
                 for (uint64_t pos = 0; pos < NQ && !unmatched; ++pos) unmatched = std::find(q_idx.begin(), q_idx.end(), qm->indices[pos]) == q_idx.end();
-                if (unmatched)
-                    for (uint32_t r : r_idx) if (r < Rt) o.marks.push_back(r);
+                if (unmatched) {
+                    ++n_rc;
+                    if (two_pass) plan_cache[slot][ci].rc_ord = n_rc;
+                    for (uint32_t r : r_idx) if (r < Rt) { o.marks.push_back(r); o.mark_ord.push_back(n_rc); }
+                }
                 continue;
             }
             // rescue votes of this component: (query residue, target residue) -> pairs whose partner is one of its mapped residues
@@ -965,6 +1115,11 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
                     votes2[ix2] = 0;
                 }
                 v_touched.clear();
+            }
+            if (have_rows && cached && plan_cache[slot][ci].rc_ord) {      // the same three numbers per query residue, counted by the second scan itself
+                const fd_vote_row *vr = vote_rows.data() + row_base[slot] + (uint64_t)(plan_cache[slot][ci].rc_ord - 1) * q_size;
+                for (uint32_t vq = 0; vq < q_size; ++vq)
+                    if (vr[vq].mx) { r_mx[vq] = vr[vq].mx; r_nmx[vq] = vr[vq].nmx; r_arg[vq] = vr[vq].arg; q_touched.push_back(vq); }
             }
             // residue assignment + rescue (retrieve.rs:430-516)
             std::vector<int32_t> from_hash(NQ, -1), processed(NQ, -1);
@@ -1051,7 +1206,15 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             while (slot >= cand_off[tq + 1]) { ++tq; m_off[tq] = recs.size(); r_off[tq] = res.size(); }
             SlotOut &o = outs[slot];
             if (plan) {
-                for (uint32_t r : o.marks) { any_rescue = true; const uint32_t bit = mask_off[slot] + r; cj_mask[bit >> 5] |= 1u << (bit & 31u); }
+                for (size_t z = 0; z < o.marks.size(); ++z) {
+                    const uint32_t r = o.marks[z], ord = o.mark_ord[z];
+                    any_rescue = true;
+                    const uint32_t bit = mask_off[slot] + r;
+                    cj_mask[bit >> 5] |= 1u << (bit & 31u);
+                    if (ord > 255u || (cj_comp[bit] && cj_comp[bit] != ord)) vote_conflict = true;      // two rescued components share a target residue: host counting
+                    else cj_comp[bit] = (uint8_t)ord;
+                    slot_nrc[slot] = std::max(slot_nrc[slot], ord);
+                }
                 continue;
             }
             const size_t rec0 = recs.size();
@@ -1068,10 +1231,40 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         run_slots(true);
         if (trace) fprintf(stderr, "[fdgpu_retrieve] plan pass %.3f ms\n", t_ms(T2, t_now()));
         free(cands); cands = nullptr; nc = 0;
-        if (any_rescue) {
+        // the rescue's vote tables fit the device (a whole-structure query against its top 20: 20 x 300 x 1,700 counters): count there
+        uint64_t n_counters = 0, n_rows = 0;
+        std::vector<uint64_t> vt_off(n_cand + 1, 0);
+        std::vector<uint32_t> vt_qs(n_cand + 1, 0);
+        for (uint64_t k = 0; k < n_cand; ++k) {
+            vt_off[k] = n_counters; row_base[k] = n_rows; vt_qs[k] = q_sizes[slot_q[k]];
+            n_counters += (uint64_t)slot_nrc[k] * vt_qs[k] * (g_dst[k + 1] - g_dst[k]);
+            n_rows += (uint64_t)slot_nrc[k] * vt_qs[k];
+        }
+        const char *dv_env = getenv("FDGPU_DEVICE_VOTES");      // 0: the rescue counts on the host from the copied candidate pairs (tests)
+        const bool dev_votes = any_rescue && !vote_conflict && !(dv_env && dv_env[0] == '0') && n_counters <= (1ull << 28) && n_rows <= (1ull << 24) &&
+                               g_total < (1ull << 32);
+        if (dev_votes) {
+            std::vector<uint64_t> row_off(n_rows);
+            std::vector<uint32_t> row_len(n_rows);
+            for (uint64_t k = 0, z = 0; k < n_cand; ++k) {
+                const uint32_t Rk = (uint32_t)(g_dst[k + 1] - g_dst[k]);
+                for (uint64_t rr = 0; rr < (uint64_t)slot_nrc[k] * vt_qs[k]; ++rr, ++z) { row_off[z] = vt_off[k] + rr * Rk; row_len[z] = Rk; }
+            }
+            vote_rows.resize(std::max<uint64_t>(n_rows, 1));
+            fd_vote_plan vp;
+            vp.cj_comp = cj_comp.data(); vp.n_bits = g_total; vp.vt_off = vt_off.data(); vp.vt_qs = vt_qs.data(); vp.n_counters = n_counters;
+            vp.row_off = row_off.data(); vp.row_len = row_len.data(); vp.n_rows = n_rows; vp.rows = vote_rows.data();
+            fd_pair_rec *f2 = nullptr; uint64_t nf2 = 0;
+            rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &f2, &nf2, &cands, &nc, 32u, cj_mask.data(),
+                                      mask_off.data(), cj_mask.size(), nullptr, nullptr, &vp, &mp_tab);
+            free(f2); free(cands); cands = nullptr; nc = 0;
+            if (rc) return rc;
+            have_rows = true;
+            if (trace) fprintf(stderr, "[fdgpu_retrieve] second scan (device votes) done at %.3f ms (%llu rows)\n", t_ms(T2, t_now()), (unsigned long long)n_rows);
+        } else if (any_rescue) {
             fd_pair_rec *f2 = nullptr; uint64_t nf2 = 0;
             rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &f2, &nf2, &cands, &nc, 14u, cj_mask.data(),
-                                      mask_off.data(), cj_mask.size(), &pk_key, &pk_val);
+                                      mask_off.data(), cj_mask.size(), &pk_key, &pk_val, nullptr, &mp_tab);
             free(f2);
             if (rc) return rc;
             if (trace) fprintf(stderr, "[fdgpu_retrieve] second scan done at %.3f ms (cands %llu)\n", t_ms(T2, t_now()), (unsigned long long)nc);

@@ -1610,8 +1610,9 @@ static void fd_sort_found(fd_pair_rec *f, uint64_t n, uint64_t n_cand) {
 int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
                          const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
                          fd_cand_rec **cands, uint64_t *n_cands, uint32_t mode, const uint32_t *cj_mask, const uint32_t *mask_off,
-                         uint64_t mask_words, uint32_t **pk_key, uint32_t **pk_val) {
+                         uint64_t mask_words, uint32_t **pk_key, uint32_t **pk_val, fd_vote_plan *votes, fd_mp_tables *tables) {
     if (!c || !db || !p || !found || !n_found || !cands || !n_cands || !cand_off || (n_queries && !qs)) return FDGPU_EINVAL;
+    if ((mode & 32u) && (!votes || !cj_mask || !mask_off || (mode & 3u))) return FDGPU_EINVAL;
     const uint64_t n_cand = cand_off[n_queries];
     if (n_cand && !cand) return FDGPU_EINVAL;
     *found = nullptr; *cands = nullptr; *n_found = 0; *n_cands = 0;
@@ -1621,16 +1622,22 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     const bool mp_trace = getenv("FDGPU_TRACE") != nullptr;
     const auto mp_t0 = std::chrono::steady_clock::now();
     auto mp_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - mp_t0).count(); };
+    // work items and query tables (below) depend on the queries and candidates only: a caller that scans the same candidates twice (the two
+    // scans of a large query) passes a fd_mp_tables and the second call reuses the host block
+    fd_mp_tables tb_local;
+    fd_mp_tables &TB = tables ? *tables : tb_local;
+    auto build_tables = [&]() -> int {
     // work items: (query, candidate slot, 64-residue i-tile); a handful of long candidates (whole-structure queries: the top 20)
     // would leave most of the chip idle, so the partner residues are split into spans as well until ~2000 wavefronts exist
     uint64_t n_tiles = 0;
     for (uint64_t k = 0; k < n_cand; ++k) {
-        if (cand[k] >= db->n_struct) FAIL(c, FDGPU_EINVAL, "match_pairs: candidate id outside the batch");
+        if (cand[k] >= db->n_struct) { c->err = "match_pairs: candidate id outside the batch"; return FDGPU_EINVAL; }
         n_tiles += (db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]] + FD_WAVE - 1) / FD_WAVE;
     }
     // many candidates (a batch of motif queries): spans of 256 partners cap the longest work items — the launch ends with its slowest
     // wavefront (32 queries x 32 candidates: 218 -> 126 us; 128 and 512 measured 148 and 156)
     const uint32_t j_span = !n_tiles ? 0u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : 256u;
+    TB.j_span = j_span;
     std::vector<uint32_t> wc, wi, wq, wj;
     for (uint64_t t = 0; t < n_queries; ++t)
         for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) {
@@ -1715,13 +1722,17 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         }
     }
     const size_t nw = wc.size(), na = all_dist.size(), nh = all_hashes.size();
+    TB.nw = nw; TB.want_iv = want_iv;
     // one packed host block -> one H2D copy: [cand | wc | wi | wq | hashes | start tables | dist | qi | qtab]
     auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
     const size_t o_cand = 0, o_wc = o_cand + up4(n_cand), o_wi = o_wc + up4(nw), o_wq = o_wi + up4(nw), o_wj = o_wq + up4(nw), o_h = o_wj + up4(nw),
                  o_st = o_h + up4(nh), o_d = o_st + up4(all_start.size()), o_qi = o_d + up4(na), o_qt = o_qi + up4(na),
                  o_ivs = o_qt + up4(n_queries * (sizeof(mp_query_dev) / 4)), o_iv = o_ivs + (want_iv ? up4(iv_start.size()) : 0),
                  words = o_iv + (want_iv ? up4(iv_lohi.size()) : 0) + 4;
-    std::vector<uint32_t> blk(words, 0);
+    const size_t offs[12] = {o_cand, o_wc, o_wi, o_wq, o_wj, o_h, o_st, o_d, o_qi, o_qt, o_ivs, o_iv};
+    memcpy(TB.o, offs, sizeof offs);
+    std::vector<uint32_t> &blk = TB.blk;
+    blk.assign(words, 0);
     if (n_cand) memcpy(&blk[o_cand], cand, n_cand * 4);
     if (nw) { memcpy(&blk[o_wc], wc.data(), nw * 4); memcpy(&blk[o_wi], wi.data(), nw * 4); memcpy(&blk[o_wq], wq.data(), nw * 4); memcpy(&blk[o_wj], wj.data(), nw * 4); }
     if (nh) memcpy(&blk[o_h], all_hashes.data(), nh * 4);
@@ -1729,6 +1740,15 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     if (na) { memcpy(&blk[o_d], all_dist.data(), na * 4); memcpy(&blk[o_qi], all_qi.data(), na * 4); }
     if (want_iv) { memcpy(&blk[o_ivs], iv_start.data(), iv_start.size() * 4); if (!iv_lohi.empty()) memcpy(&blk[o_iv], iv_lohi.data(), iv_lohi.size() * 4); }
     if (n_queries) memcpy(&blk[o_qt], qtab.data(), n_queries * sizeof(mp_query_dev));
+    TB.valid = true;
+    return FDGPU_OK;
+    };
+    if (!TB.valid) { const int rcb = build_tables(); if (rcb) return rcb; }
+    const size_t o_cand = TB.o[0], o_wc = TB.o[1], o_wi = TB.o[2], o_wq = TB.o[3], o_wj = TB.o[4], o_h = TB.o[5], o_st = TB.o[6], o_d = TB.o[7], o_qi = TB.o[8],
+                 o_qt = TB.o[9], o_ivs = TB.o[10], o_iv = TB.o[11], nw = TB.nw, words = TB.blk.size();
+    const bool want_iv = TB.want_iv;
+    const uint32_t j_span = TB.j_span;
+    const std::vector<uint32_t> &blk = TB.blk;
     if (mp_trace) fprintf(stderr, "[match_pairs] tables at %.3f ms (%zu work items)\n", mp_ms(), nw);
     HIPCHK(c, c->ws[WS_MISC0].ensure(words * 4));
     HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
@@ -1748,6 +1768,27 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, cj_mask, mask_words * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].as<uint32_t>() + mask_words, mask_off, n_cand * 4, hipMemcpyHostToDevice, st));
         A.cj_mask = c->ws[WS_MISC1].as<uint32_t>(); A.mask_off = A.cj_mask + mask_words;
+    }
+    fd_vote_row *d_rows = nullptr;
+    if (mode & 32u) {   // rescue votes stay on the device: counters in ws[WS_IDS_A], their tables in ws[WS_IDS_B]
+        const uint64_t nb = votes->n_bits, nr = votes->n_rows;
+        auto up8 = [](uint64_t x) { return (x + 7) & ~(uint64_t)7; };
+        const uint64_t o_off = 0, o_roff = o_off + up8(n_cand * 8), o_rows = o_roff + up8(nr * 8), o_qs = o_rows + up8(nr * sizeof(fd_vote_row)),
+                       o_rlen = o_qs + up8(n_cand * 4), o_comp = o_rlen + up8(nr * 4), bytes = o_comp + up8(nb) + 8;
+        HIPCHK(c, c->ws[WS_IDS_A].ensure(std::max<uint64_t>(votes->n_counters, 1) * 4));
+        HIPCHK(c, c->ws[WS_IDS_B].ensure(bytes));
+        uint8_t *base = c->ws[WS_IDS_B].as<uint8_t>();
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_IDS_A].p, 0, std::max<uint64_t>(votes->n_counters, 1) * 4, st));
+        HIPCHK(c, hipMemcpyAsync(base + o_off, votes->vt_off, n_cand * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(base + o_qs, votes->vt_qs, n_cand * 4, hipMemcpyHostToDevice, st));
+        if (nr) {
+            HIPCHK(c, hipMemcpyAsync(base + o_roff, votes->row_off, nr * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(base + o_rlen, votes->row_len, nr * 4, hipMemcpyHostToDevice, st));
+        }
+        if (nb) HIPCHK(c, hipMemcpyAsync(base + o_comp, votes->cj_comp, nb, hipMemcpyHostToDevice, st));
+        A.votes = c->ws[WS_IDS_A].as<uint32_t>(); A.vt_off = (const uint64_t *)(base + o_off); A.vt_qs = (const uint32_t *)(base + o_qs);
+        A.cj_comp = base + o_comp;
+        d_rows = (fd_vote_row *)(base + o_rows);
     }
     if (!fd_multiple_bins_valid(p)) FAIL(c, FDGPU_EINVAL, "multiple_bins: at most 8 (dist, angle) bin pairs, no zero counts");
     A.B = db->view(); A.C = fd_make_consts_cfg(p, 0); A.cutoff = p->dist_cutoff;
@@ -1782,6 +1823,18 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         if (attempt == 2) FAIL(c, FDGPU_ERANGE, "match_pairs: output did not fit after regrowing");
     }
     if (mp_trace) fprintf(stderr, "[match_pairs] scan done at %.3f ms (found %llu, cands %llu)\n", mp_ms(), (unsigned long long)tot[0], (unsigned long long)tot[1]);
+    if (mode & 32u) {   // the rows of the vote table: (largest count, how many hold it, which) per (slot, component, query residue)
+        const uint8_t *base = c->ws[WS_IDS_B].as<uint8_t>();
+        const uint64_t nr = votes->n_rows;
+        auto up8 = [](uint64_t x) { return (x + 7) & ~(uint64_t)7; };
+        const uint64_t o_roff = up8(n_cand * 8), o_rows = o_roff + up8(nr * 8), o_rlen = o_rows + up8(nr * sizeof(fd_vote_row)) + up8(n_cand * 4);
+        fd_launch_vote_rows(A.votes, (const uint64_t *)(base + o_roff), (const uint32_t *)(base + o_rlen), nr, d_rows, st);
+        HIPCHK(c, hipGetLastError());
+        if (nr) HIPCHK(c, hipMemcpyAsync(votes->rows, d_rows, nr * sizeof(fd_vote_row), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (mp_trace) fprintf(stderr, "[match_pairs] vote rows done at %.3f ms (%llu rows, %llu counters)\n", mp_ms(), (unsigned long long)nr, (unsigned long long)votes->n_counters);
+        return FDGPU_OK;
+    }
     // mode bit 4: the records stay on the device (ws[WS_KEYS_A] = found triples, ws[WS_KEYS_B] = candidate pairs, in append order) for
     // the device-side retrieval glue (k_retrieve.hip); only the counts return
     if (mode & 16u) { *n_found = tot[0]; *n_cands = tot[1]; return FDGPU_OK; }
@@ -1822,19 +1875,49 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         *found = hf2; *n_found = tot[0]; *cands = nullptr; *n_cands = n; *pk_key = hk; *pk_val = hv;
         return FDGPU_OK;
     }
+    // many found triples and no candidate pairs to keep (first scan of a large query: ~10^5 triples, most of them in the slot of the query's own
+    // structure): (slot, i, j) order is made on the device — two stable radix sorts over the record index — instead of one host thread's
+    // stable_sort of that slot.  FDGPU_FOUND_SORT=host: the host form (tests)
+    bool sorted_on_device = false;
+    {
+        uint64_t max_len = 0;
+        for (uint64_t k = 0; k < n_cand; ++k) max_len = std::max<uint64_t>(max_len, db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]]);
+        const char *fs_env = getenv("FDGPU_FOUND_SORT");
+        const uint64_t fs_min = fs_env && !strcmp(fs_env, "device") ? 2 : 32768;
+        if (tot[0] >= fs_min && tot[1] == 0 && n_cand < 65536 && max_len < 65536 && !(fs_env && !strcmp(fs_env, "host"))) {
+            const uint64_t n = tot[0];
+            HIPCHK(c, c->ws[WS_MISC2].ensure(n * 4)); HIPCHK(c, c->ws[WS_MISC3].ensure(n * 4));
+            HIPCHK(c, c->ws[WS_MISC4].ensure(n * 4)); HIPCHK(c, c->ws[WS_MISC5].ensure(n * 4));
+            HIPCHK(c, c->ws[WS_IDS_A].ensure(n * sizeof(fd_pair_rec)));
+            HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * std::max<uint32_t>(fd_rs_num_tiles(n), 1) * 4));
+            HIPCHK(c, c->ws[WS_TOT].ensure((256 + (size_t)(fd_rs_num_tiles(n) / 128 + 2) * 256) * 8));
+            uint32_t *ka = c->ws[WS_MISC2].as<uint32_t>(), *va = c->ws[WS_MISC3].as<uint32_t>(), *kb = c->ws[WS_MISC4].as<uint32_t>(), *vb = c->ws[WS_MISC5].as<uint32_t>();
+            fd_launch_found_key_ij(A.found, n, ka, va, st);
+            int cur = sort_pairs(c, ka, va, kb, vb, n, 32);
+            uint32_t *k1 = cur ? kb : ka, *v1 = cur ? vb : va, *k2 = cur ? ka : kb, *v2 = cur ? va : vb;
+            fd_launch_found_key_slot(A.found, v1, n, k1, st);
+            int bits = 1;
+            while (bits < 16 && (1ull << bits) < std::max<uint64_t>(n_cand, 2)) ++bits;
+            cur = sort_pairs(c, k1, v1, k2, v2, n, bits);
+            fd_launch_found_gather(A.found, cur ? v2 : v1, n, c->ws[WS_IDS_A].as<fd_pair_rec>(), st);
+            HIPCHK(c, hipGetLastError());
+            sorted_on_device = true;
+        }
+    }
     fd_pair_rec *hf = (fd_pair_rec *)malloc(std::max<uint64_t>(tot[0], 1) * sizeof(fd_pair_rec));
     fd_cand_rec *hc = (fd_cand_rec *)malloc(std::max<uint64_t>(tot[1], 1) * sizeof(fd_cand_rec));
     if (!hf || !hc) { free(hf); free(hc); return FDGPU_ENOMEM; }
     hipError_t e = hipSuccess;
-    if (tot[0]) e = hipMemcpyAsync(hf, A.found, tot[0] * sizeof(fd_pair_rec), hipMemcpyDeviceToHost, st);
+    if (sorted_on_device) e = hipMemcpyAsync(hf, c->ws[WS_IDS_A].p, tot[0] * sizeof(fd_pair_rec), hipMemcpyDeviceToHost, st);
+    if (!sorted_on_device && tot[0]) e = hipMemcpyAsync(hf, A.found, tot[0] * sizeof(fd_pair_rec), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && tot[1]) e = hipMemcpyAsync(hc, A.cands, tot[1] * sizeof(fd_cand_rec), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { free(hf); free(hc); c->err = std::string("match_pairs: ") + hipGetErrorString(e); return FDGPU_EHIP; }
     // restore the reference's scan order (row-major over the prefilter sets, retrieve.rs:146-153): the
     // kernel appends with atomics, one contiguous run per (i, j) in observed-list order
     if (mp_trace) fprintf(stderr, "[match_pairs] copy done at %.3f ms\n", mp_ms());
-    fd_sort_found(hf, tot[0], n_cand);
-    if (mp_trace) fprintf(stderr, "[match_pairs] found sorted at %.3f ms\n", mp_ms());
+    if (!sorted_on_device) fd_sort_found(hf, tot[0], n_cand);
+    if (mp_trace) fprintf(stderr, "[match_pairs] found sorted at %.3f ms%s\n", mp_ms(), sorted_on_device ? " (on the device)" : "");
     // mode bit 2: the caller buckets the candidate pairs itself and does not depend on their order (the rescue only counts them)
     if (!(mode & 4u)) std::stable_sort(hc, hc + tot[1], [](const fd_cand_rec &a, const fd_cand_rec &b) {
         if (a.cand != b.cand) return a.cand < b.cand;

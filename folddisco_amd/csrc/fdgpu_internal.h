@@ -277,8 +277,27 @@ struct mp_args {
     uint32_t mode;                 // bit 0: emit found triples, bit 1: emit candidate pairs
     const uint32_t *cj_mask;       // optional: only partner residues j whose bit mask_off[slot] + (j - r0) is set are scanned
     const uint32_t *mask_off;      // [n_cand] first bit of every candidate slot
+    // mode bit 5 (rescue votes on the device, second scan of a large query): instead of leaving the kernel, a candidate pair (qi, i, j) adds one
+    // to votes[vt_off[slot] + ((cj_comp[bit of j] - 1) * vt_qs[slot] + qi) * n_residues(slot) + i] — the table retrieve.rs:498-511 builds per component
+    uint32_t *votes; const uint64_t *vt_off; const uint32_t *vt_qs; const uint8_t *cj_comp;
 };
+// rescue votes of a large query's second scan (fd_match_pairs_multi, mode bit 5).  In: per marked partner residue (bit position as in cj_mask) the
+// 1-based ordinal of the component that mapped it, per slot the first counter and the query's residue count, the table's size in counters.
+// Out: per (slot, ordinal, query residue) row of the table {largest count, number of target residues holding it, one of them}.
+// host block of a pair scan's work items and query tables (fd_match_pairs_multi builds it on the first call, reuses it on the next)
+struct fd_mp_tables { std::vector<uint32_t> blk; size_t o[12] = {0}; size_t nw = 0; bool want_iv = false; uint32_t j_span = 0; bool valid = false; };
+struct fd_vote_row { uint32_t mx, nmx, arg; };
+struct fd_vote_plan {
+    const uint8_t *cj_comp; uint64_t n_bits;
+    const uint64_t *vt_off; const uint32_t *vt_qs; uint64_t n_counters;
+    const uint64_t *row_off; const uint32_t *row_len; uint64_t n_rows;      // every row's first counter and length (the slot's residue count)
+    fd_vote_row *rows;                                                       // [n_rows] host, filled by the call
+};
+void fd_launch_vote_rows(const uint32_t *votes, const uint64_t *row_off, const uint32_t *row_len, uint64_t n_rows, fd_vote_row *out, hipStream_t st);
 void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st);
+void fd_launch_found_key_ij(const fd_pair_rec *f, uint64_t n, uint32_t *key, uint32_t *val, hipStream_t st);
+void fd_launch_found_key_slot(const fd_pair_rec *f, const uint32_t *val, uint64_t n, uint32_t *key, hipStream_t st);
+void fd_launch_found_gather(const fd_pair_rec *f, const uint32_t *val, uint64_t n, fd_pair_rec *out, hipStream_t st);
 void fd_launch_pack_cands(const fd_cand_rec *c, uint64_t n, uint32_t *key, uint32_t *val, hipStream_t st);
 void fd_launch_kabsch(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, hipStream_t st);
 void fd_launch_metrics(const float *ref, const float *mov, const uint64_t *off, uint64_t n, const float *rot, const float *tran, const float *d0, float *out,
@@ -329,4 +348,5 @@ void fd_launch_rs_slots(const rs_args &A, uint32_t n_cand, hipStream_t st);
 int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
                          const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
                          fd_cand_rec **cands, uint64_t *n_cands, uint32_t mode = 3, const uint32_t *cj_mask = nullptr,
-                         const uint32_t *mask_off = nullptr, uint64_t mask_words = 0, uint32_t **pk_key = nullptr, uint32_t **pk_val = nullptr);
+                         const uint32_t *mask_off = nullptr, uint64_t mask_words = 0, uint32_t **pk_key = nullptr, uint32_t **pk_val = nullptr,
+                         fd_vote_plan *votes = nullptr, struct fd_mp_tables *tables = nullptr);

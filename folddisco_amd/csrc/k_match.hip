@@ -44,7 +44,7 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
     fd_v3 cai = {0.f, 0.f, 0.f}, caj = {0.f, 0.f, 0.f};
     float d = 0.f;
     uint32_t key = 0, e_lo = 0, e_hi = 0;
-    bool hit = false;
+    bool hit = false, has_feat = true;
     if (on) {
         aai = A.B.aa[i]; aaj = A.B.aa[j];
         cai = fd_load3(A.B.ca_xyz, i); caj = fd_load3(A.B.ca_xyz, j);
@@ -60,8 +60,10 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
                 h = fd_hash_other(A.C.q.type, f9, A.C.q);
                 hitmask = ((A.mode & 1u) && hash_in_set(Sx.q_hashes, Sx.n_hashes, h)) ? 1u : 0u;
             } else {
-                n_win = 0;
+                n_win = 0; has_feat = false;
             }
+        } else if (!(A.mode & 1u)) {
+            // no found triples wanted (second scan of a large query): the PDBTrRosetta descriptor of a pair that passed hash_ok always exists
         } else if (A.C.use_tab && A.n_cfg == 1) {
             // default angle bins: frames + exhaustive tables (fd_geom.h) — same bits as the generic chain, a tenth of the code
             fd_frame Fi = fd_make_frame(fd_load3(A.B.n_xyz, i), cai, fd_load3(A.B.cb_xyz, i));
@@ -81,6 +83,16 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
         }
         hit = hitmask != 0;
         if (!(A.mode & 2u)) n_win = 0;
+    }
+    if ((A.mode & 32u) && on && has_feat) {
+        // rescue votes on the device: the pair's records (one per observed distance in the window) count into the table of the component
+        // that mapped the partner residue j
+        const uint32_t comp = A.cj_comp[A.mask_off[slot] + (j - r0)], nq = A.vt_qs[slot], nr = r1 - r0;
+        if (comp) {
+            uint32_t *tabv = A.votes + A.vt_off[slot] + (uint64_t)(comp - 1u) * nq * nr + (i - r0);
+            for (uint32_t e = e_lo; e < e_hi; ++e)
+                if (fd_fabsf(d - dist_tab[e]) < Sx.ca_window) { const uint32_t qi = Sx.aad_qi[e]; if (qi < nq) atomicAdd(&tabv[(uint64_t)qi * nr], 1u); }
+        }
     }
     // one atomic per counter and drain (per-record atomics on two addresses serialise in one L2 channel: that, not the
     // arithmetic, was the kernel time)
@@ -265,6 +277,52 @@ __global__ void k_pack_cands(const fd_cand_rec *__restrict__ c, uint64_t n, uint
 }
 void fd_launch_pack_cands(const fd_cand_rec *c, uint64_t n, uint32_t *key, uint32_t *val, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_pack_cands, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, n, key, val);
+}
+// one wavefront per row of the rescue-vote table: largest count, how many residues hold it, one of them (the smallest index; the rescue only
+// uses it when it is the only one, retrieve.rs:498-511)
+__global__ __launch_bounds__(256) void k_vote_rows(const uint32_t *__restrict__ votes, const uint64_t *__restrict__ row_off, const uint32_t *__restrict__ row_len,
+                                                   uint64_t n_rows, fd_vote_row *__restrict__ out) {
+    const uint64_t row = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const uint32_t lane = threadIdx.x & 63u, n = row_len[row];
+    const uint32_t *v = votes + row_off[row];
+    uint32_t mx = 0, nmx = 0, arg = 0xffffffffu;
+    for (uint32_t k = lane; k < n; k += FD_WAVE) {
+        const uint32_t x = v[k];
+        if (x > mx) { mx = x; nmx = 1; arg = k; }
+        else if (x == mx && x) { ++nmx; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t omx = __shfl_xor(mx, off, FD_WAVE), onmx = __shfl_xor(nmx, off, FD_WAVE), oarg = __shfl_xor(arg, off, FD_WAVE);
+        if (omx > mx) { mx = omx; nmx = onmx; arg = oarg; }
+        else if (omx == mx && mx) { nmx += onmx; arg = oarg < arg ? oarg : arg; }
+    }
+    if (lane == 0) { fd_vote_row r; r.mx = mx; r.nmx = mx ? nmx : 0u; r.arg = mx ? arg : 0u; out[row] = r; }
+}
+void fd_launch_vote_rows(const uint32_t *votes, const uint64_t *row_off, const uint32_t *row_len, uint64_t n_rows, fd_vote_row *out, hipStream_t st) {
+    if (n_rows) hipLaunchKernelGGL(k_vote_rows, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, votes, row_off, row_len, n_rows, out);
+}
+// found triples into (slot, i, j) order on the device (two stable radix sorts: by i << 16 | j, then by slot), for scans that return ~10^5 of them
+__global__ void k_found_key_ij(const fd_pair_rec *__restrict__ f, uint64_t n, uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { key[k] = (f[k].i << 16) | (f[k].j & 0xffffu); val[k] = (uint32_t)k; }
+}
+__global__ void k_found_key_slot(const fd_pair_rec *__restrict__ f, const uint32_t *__restrict__ val, uint64_t n, uint32_t *__restrict__ key) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) key[k] = f[val[k]].cand;
+}
+__global__ void k_found_gather(const fd_pair_rec *__restrict__ f, const uint32_t *__restrict__ val, uint64_t n, fd_pair_rec *__restrict__ out) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = f[val[k]];
+}
+void fd_launch_found_key_ij(const fd_pair_rec *f, uint64_t n, uint32_t *key, uint32_t *val, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_found_key_ij, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f, n, key, val);
+}
+void fd_launch_found_key_slot(const fd_pair_rec *f, const uint32_t *val, uint64_t n, uint32_t *key, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_found_key_slot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f, val, n, key);
+}
+void fd_launch_found_gather(const fd_pair_rec *f, const uint32_t *val, uint64_t n, fd_pair_rec *out, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_found_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f, val, n, out);
 }
 void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st) {
     if (!A.n_work) return;

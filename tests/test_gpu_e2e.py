@@ -658,6 +658,40 @@ def test_whole_structure_query_matches_oracle():
     ctx.close()
 
 
+@pytest.mark.parametrize("htype", [3, 0, 1, 2, 4, 5, 6, 7, 8])
+def test_query_map_device_expansion_equals_host_expansion(env, monkeypatch, htype):
+    """Large queries without substitutions expand, hash and dedupe their candidates on the device (k_qm_expand_hash + sort + first-of-run,
+    fd_host_query.hip); FDGPU_QM_DEVICE=1 takes that path for any size, 0 the host loop: every array of the query map is identical — every
+    encoding (their own threshold fields), several threshold lists (the f32 restore drift of expand_and_insert accumulates over them), motif and
+    whole-structure queries, with and without an index."""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from tests.helpers import synthetic_packed
+    ctx = env[0]
+    S = 12
+    ps = synthetic_packed(S, 177 + htype, lengths=np.concatenate([np.full(S - 2, 70), [150, 9]]))
+    sb = ctx.upload(ps)
+    six = fd.FolddiscoIndex.build(ctx, sb, hash_type=htype)
+    fields = ("hash", "qi", "qj", "is_primary", "idf", "indices", "aad_aa1", "aad_aa2", "aad_dist", "aad_qi", "primary_hash")
+    n_checked = 0
+    for s, idx in ((3, None), (10, None), (11, None), (5, [1, 7, 8, 30, 31]), (10, [0, 149])):
+        a, b = int(ps.res_off[s]), int(ps.res_off[s + 1])
+        qb = ctx.upload(fd.PackedStructures.concat([dict(n_xyz=ps.n_xyz[a:b], ca_xyz=ps.ca_xyz[a:b], cb_xyz=ps.cb_xyz[a:b], aa=ps.aa[a:b])]))
+        qi = np.arange(b - a, dtype=np.uint32) if idx is None else np.array(idx, np.uint32)
+        for dthr, athr in (((0.5,), (5.0,)), ((0.5, 1.0, 0.25), (5.0, 10.0)), ((), (7.5,))):
+            for index in (six, None):
+                got = {}
+                for mode in ("0", "1"):
+                    monkeypatch.setenv("FDGPU_QM_DEVICE", mode)
+                    got[mode] = fq.make_query_map(ctx, qb, qi, None, index, float(S), dist_thr=dthr, angle_thr=athr, hash_type=htype)
+                monkeypatch.delenv("FDGPU_QM_DEVICE")
+                for f in fields:
+                    x, y = getattr(got["0"], f), getattr(got["1"], f)
+                    assert x.dtype == y.dtype and x.tobytes() == y.tobytes(), (htype, s, f)
+                n_checked += len(got["0"].hash)
+    assert n_checked > 10000
+
+
 def test_two_pass_retrieval_equals_single_pass(env, monkeypatch):
     """Large queries scan the candidates twice (found triples, then candidate pairs restricted to the partner residues some
     component mapped — the only ones the rescue counts): same matches, rescued residues included, as the single scan."""
@@ -688,7 +722,14 @@ def test_two_pass_retrieval_equals_single_pass(env, monkeypatch):
             monkeypatch.setenv("FDGPU_PACK_MIN", "0")      # candidate pairs packed and sorted on the device (the large-query form)
             out[mode + "p"] = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=ca_cut)
             monkeypatch.delenv("FDGPU_PACK_MIN")
-        same(out["0"], out["1"]); same(out["0"], out["0p"]); same(out["0"], out["1p"])
+        # the second scan counts the rescue votes on the device by default; FDGPU_DEVICE_VOTES=0: candidate pairs copied back and counted on the host
+        monkeypatch.setenv("FDGPU_DEVICE_VOTES", "0")
+        out["1h"] = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=ca_cut)
+        monkeypatch.delenv("FDGPU_DEVICE_VOTES")
+        monkeypatch.setenv("FDGPU_FOUND_SORT", "device")      # the first scan's found triples ordered by two radix sorts on the device (default from 32,768 triples)
+        out["1d"] = fq.retrieve(ctx, batch, std, np.arange(5, dtype=np.uint32), m, qb, ca_distance_cutoff=ca_cut)
+        monkeypatch.delenv("FDGPU_FOUND_SORT")
+        same(out["0"], out["1"]); same(out["0"], out["0p"]); same(out["0"], out["1p"]); same(out["0"], out["1h"]); same(out["0"], out["1d"])
         n_rescued += sum(1 for g in out["1"] if not g["same"])
     assert n_rescued > 0          # the rescue path ran
     # whole-structure queries on a synthetic shard
@@ -707,7 +748,13 @@ def test_two_pass_retrieval_equals_single_pass(env, monkeypatch):
             monkeypatch.setenv("FDGPU_PACK_MIN", "0")
             out[mode + "p"] = fq.retrieve(ctx, sb, None, np.arange(S, dtype=np.uint32), m, qb2, ca_distance_cutoff=1.5)
             monkeypatch.delenv("FDGPU_PACK_MIN")
-        same(out["0"], out["1"]); same(out["0"], out["0p"]); same(out["0"], out["1p"])
+        monkeypatch.setenv("FDGPU_DEVICE_VOTES", "0")
+        out["1h"] = fq.retrieve(ctx, sb, None, np.arange(S, dtype=np.uint32), m, qb2, ca_distance_cutoff=1.5)
+        monkeypatch.delenv("FDGPU_DEVICE_VOTES")
+        monkeypatch.setenv("FDGPU_FOUND_SORT", "device")
+        out["1d"] = fq.retrieve(ctx, sb, None, np.arange(S, dtype=np.uint32), m, qb2, ca_distance_cutoff=1.5)
+        monkeypatch.delenv("FDGPU_FOUND_SORT")
+        same(out["0"], out["1"]); same(out["0"], out["0p"]); same(out["0"], out["1p"]); same(out["0"], out["1h"]); same(out["0"], out["1d"])
         assert any(g["cand"] == s for g in out["1"])
     monkeypatch.delenv("FDGPU_TWO_PASS")
 
