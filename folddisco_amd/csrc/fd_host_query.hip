@@ -259,6 +259,9 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     for (uint64_t t = 0; t < n_queries; ++t) { out[t] = nullptr; if (q_struct[t] >= qb->n_struct) return FDGPU_EINVAL; }
     // all ordered pairs of every query's residues, row-major (CombinationIterator, utils/combination.rs:23-44), as residue
     // indices of the whole batch
+    const bool qtrace = getenv("FDGPU_TRACE") != nullptr;
+    const auto q_t0 = std::chrono::steady_clock::now();
+    auto q_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - q_t0).count(); };
     std::vector<uint32_t> pi, pj;
     std::vector<uint64_t> pair_off(n_queries + 1, 0);
     for (uint64_t t = 0; t < n_queries; ++t) {
@@ -271,9 +274,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         pair_off[t + 1] = pi.size();
     }
     const uint64_t np = pi.size();
-    const bool qtrace = getenv("FDGPU_TRACE") != nullptr;
-    const auto q_t0 = std::chrono::steady_clock::now();
-    auto q_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - q_t0).count(); };
+    if (qtrace) fprintf(stderr, "[fdgpu_query_map] pairs listed at %.3f ms\n", q_ms());
     std::vector<float> feat(std::max<uint64_t>(np, 1) * FD_QF);
     std::vector<uint8_t> valid(std::max<uint64_t>(np, 1));
     CHECK_TYPE(c, p);
@@ -881,6 +882,30 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue declined (flags %u): host path\n", dflags);
     }
     if (trace) fprintf(stderr, "[fdgpu_retrieve] query tables %.3f ms\n", t_ms(T0, t_now()));
+    // large queries: hash -> map entry through an open-addressing table built once per query (a whole-structure query looks ~10^5 found
+    // edges up in ~10^5 hashes per call: 17 bisection steps each were a quarter of the largest candidate's time).  Built by a helper thread
+    // while the first pair scan runs on the GPU (1 ms for 10^5 hashes)
+    std::vector<std::vector<uint64_t>> e_tab(n_queries);
+    std::vector<uint32_t> e_mask(std::max<uint64_t>(n_queries, 1), 0);
+    auto build_e_tab = [&]() {
+        for (uint64_t t = 0; t < n_queries; ++t) {
+            if (qhs[t].size() <= 4096) continue;
+            uint32_t cap = 1;
+            while (cap < 2 * qhs[t].size()) cap <<= 1;
+            e_tab[t].assign(cap, ~0ull);
+            e_mask[t] = cap - 1;
+            for (size_t z = 0; z < qhs[t].size(); ++z) {
+                uint32_t at = (qhs[t][z] * 2654435761u) & e_mask[t];
+                while (e_tab[t][at] != ~0ull) at = (at + 1) & e_mask[t];
+                e_tab[t][at] = ((uint64_t)qhs[t][z] << 32) | qkf[t][z];
+            }
+        }
+    };
+    bool big_tab = false;
+    for (uint64_t t = 0; t < n_queries; ++t) big_tab = big_tab || qhs[t].size() > 4096;
+    std::thread e_tab_thread;
+    if (big_tab) e_tab_thread = std::thread(build_e_tab);
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } e_tab_join{e_tab_thread};      // every return path below waits for it
     fd_mp_tables mp_tab;      // work items + query tables: built by the first scan, reused by the second
     rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc, two_pass ? 1u : 15u,
                               nullptr, nullptr, 0, &pk_key, &pk_val, nullptr, &mp_tab);
@@ -944,22 +969,6 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     std::vector<uint32_t> slot_q(std::max<uint64_t>(n_cand, 1), 0);
     for (uint64_t t = 0; t < n_queries; ++t) for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) slot_q[k] = (uint32_t)t;
     std::vector<size_t> f_lo(n_cand + 1, 0), c_lo(n_cand + 1, 0);
-    // large queries: hash -> map entry through an open-addressing table built once per query (a whole-structure query looks ~10^5 found
-    // edges up in ~10^5 hashes per call: 17 bisection steps each were a quarter of the largest candidate's time)
-    std::vector<std::vector<uint64_t>> e_tab(n_queries);
-    std::vector<uint32_t> e_mask(std::max<uint64_t>(n_queries, 1), 0);
-    for (uint64_t t = 0; t < n_queries; ++t) {
-        if (qhs[t].size() <= 4096) continue;
-        uint32_t cap = 1;
-        while (cap < 2 * qhs[t].size()) cap <<= 1;
-        e_tab[t].assign(cap, ~0ull);
-        e_mask[t] = cap - 1;
-        for (size_t z = 0; z < qhs[t].size(); ++z) {
-            uint32_t at = (qhs[t][z] * 2654435761u) & e_mask[t];
-            while (e_tab[t][at] != ~0ull) at = (at + 1) & e_mask[t];
-            e_tab[t][at] = ((uint64_t)qhs[t][z] << 32) | qkf[t][z];
-        }
-    }
     auto do_slot = [&](const uint64_t slot, const bool plan, SlotOut &o) {
         const uint64_t tq = slot_q[slot];
         const fd_query_map *qm = qms[tq];
@@ -973,12 +982,16 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         Graph g;
         std::vector<std::vector<uint32_t>> comps;
         std::vector<int32_t> edge_k;
+        const bool big_trace = trace && fpos - f0 > 20000;
+        const auto s_t0 = t_now();
         if (!cached) {
             for (size_t e = f0; e < fpos; ++e) {
                 uint32_t a = g.node_of(found[e].i), b = g.node_of(found[e].j);
                 g.es.push_back(a); g.et.push_back(b); g.eh.push_back(found[e].hash);
             }
+            if (big_trace) fprintf(stderr, "[slot %llu] %zu edges: graph at %.3f ms\n", (unsigned long long)slot, fpos - f0, t_ms(s_t0, t_now()));
             comps = components(g, node_count);
+            if (big_trace) fprintf(stderr, "[slot %llu] %zu components at %.3f ms\n", (unsigned long long)slot, comps.size(), t_ms(s_t0, t_now()));
             // query-map entry of every found edge, looked up once per candidate (a whole-structure query has ~10^5 entries and
             // thousands of edges per candidate; every component walks the edge list)
             edge_k.resize(g.es.size());
@@ -998,6 +1011,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             }
         }
         const size_t n_comps = cached ? plan_cache[slot].size() : comps.size();
+        if (big_trace) fprintf(stderr, "[slot %llu] edge entries at %.3f ms (%s)\n", (unsigned long long)slot, t_ms(s_t0, t_now()), plan ? "plan" : "full");
         if (n_comps == 0) return;
         const uint32_t s = cand[slot];
         (void)s;
@@ -1168,7 +1182,9 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             add_problem(q_idx, r_idx, 0);
             if (!rec.same) add_problem(qs_sc, rs_sc, 1);
         }
+        if (big_trace) fprintf(stderr, "[slot %llu] components done at %.3f ms (%s)\n", (unsigned long long)slot, t_ms(s_t0, t_now()), plan ? "plan" : "full");
     };
+    if (e_tab_thread.joinable()) e_tab_thread.join();
     auto run_slots = [&](const bool plan) {
         // per-slot ranges of the found triples and candidate pairs (both arrive grouped by slot)
         {
@@ -1185,6 +1201,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         const char *th_env = getenv("FDGPU_HOST_THREADS");
         unsigned n_thr = th_env ? (unsigned)atoi(th_env) : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
         n_thr = (unsigned)std::min<uint64_t>(std::max(1u, n_thr), std::max<uint64_t>(1, (uint64_t)nf / 2048 + 1));   // small jobs stay on the caller's thread
+        n_thr = (unsigned)std::min<uint64_t>(n_thr, std::max<uint64_t>(1, n_cand));                                   // a thread per slot at most (spawning one costs ~0.1 ms)
         std::atomic<uint64_t> next(0);
         auto worker = [&]() {
             for (;;) {

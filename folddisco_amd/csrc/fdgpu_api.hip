@@ -1636,7 +1636,12 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     }
     // many candidates (a batch of motif queries): spans of 256 partners cap the longest work items — the launch ends with its slowest
     // wavefront (32 queries x 32 candidates: 218 -> 126 us; 128 and 512 measured 148 and 156)
-    const uint32_t j_span = !n_tiles ? 0u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : 256u;
+    // large queries (whole-structure: the window test passes nearly every pair inside the cutoff, so a work item's time is its number of close
+    // pairs x one descriptor + hash each): spans of 32 partners — a diagonal block of 64 x 128 residues was 128 drains on ONE wavefront and the
+    // launch lasted as long as its slowest wavefronts (first scan of the top 20 of a 300-residue query: 5.1 ms at 128, 4.4 at 64, 3.7 at 32 and 16)
+    uint64_t max_aad_q = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) max_aad_q = std::max<uint64_t>(max_aad_q, qs[t].n_aad);
+    const uint32_t j_span = !n_tiles ? 0u : max_aad_q > 4096 ? 32u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : 256u;
     TB.j_span = j_span;
     std::vector<uint32_t> wc, wi, wq, wj;
     for (uint64_t t = 0; t < n_queries; ++t)
@@ -1728,8 +1733,8 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     const size_t o_cand = 0, o_wc = o_cand + up4(n_cand), o_wi = o_wc + up4(nw), o_wq = o_wi + up4(nw), o_wj = o_wq + up4(nw), o_h = o_wj + up4(nw),
                  o_st = o_h + up4(nh), o_d = o_st + up4(all_start.size()), o_qi = o_d + up4(na), o_qt = o_qi + up4(na),
                  o_ivs = o_qt + up4(n_queries * (sizeof(mp_query_dev) / 4)), o_iv = o_ivs + (want_iv ? up4(iv_start.size()) : 0),
-                 words = o_iv + (want_iv ? up4(iv_lohi.size()) : 0) + 4;
-    const size_t offs[12] = {o_cand, o_wc, o_wi, o_wq, o_wj, o_h, o_st, o_d, o_qi, o_qt, o_ivs, o_iv};
+                 o_iv1 = o_iv + (want_iv ? up4(iv_lohi.size()) : 0), words = o_iv1 + (want_iv ? 1024 * n_queries : 0) + 4;
+    const size_t offs[13] = {o_cand, o_wc, o_wi, o_wq, o_wj, o_h, o_st, o_d, o_qi, o_qt, o_ivs, o_iv, o_iv1};
     memcpy(TB.o, offs, sizeof offs);
     std::vector<uint32_t> &blk = TB.blk;
     blk.assign(words, 0);
@@ -1738,14 +1743,25 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     if (nh) memcpy(&blk[o_h], all_hashes.data(), nh * 4);
     if (!all_start.empty()) memcpy(&blk[o_st], all_start.data(), all_start.size() * 4);
     if (na) { memcpy(&blk[o_d], all_dist.data(), na * 4); memcpy(&blk[o_qi], all_qi.data(), na * 4); }
-    if (want_iv) { memcpy(&blk[o_ivs], iv_start.data(), iv_start.size() * 4); if (!iv_lohi.empty()) memcpy(&blk[o_iv], iv_lohi.data(), iv_lohi.size() * 4); }
+    if (want_iv) {
+        memcpy(&blk[o_ivs], iv_start.data(), iv_start.size() * 4);
+        if (!iv_lohi.empty()) memcpy(&blk[o_iv], iv_lohi.data(), iv_lohi.size() * 4);
+        // the scan's LDS copy: per query and group (first interval relative to the query's first) << 8 | number of intervals (a window of 1 A
+        // leaves 1-5 disjoint intervals per group of a 300-residue query, ~700 in all; 255+ intervals of one group: the count saturates and
+        // the scan walks that group in global memory)
+        for (uint64_t t = 0; t < n_queries; ++t)
+            for (int g = 0; g < 1024; ++g) {
+                const uint32_t v_lo = iv_start[1025 * t + g], v_hi = iv_start[1025 * t + g + 1], rel = v_lo - iv_start[1025 * t];
+                blk[o_iv1 + 1024 * t + g] = (std::min<uint32_t>(rel, 0xffffffu) << 8) | std::min<uint32_t>(v_hi - v_lo, 255u);
+            }
+    }
     if (n_queries) memcpy(&blk[o_qt], qtab.data(), n_queries * sizeof(mp_query_dev));
     TB.valid = true;
     return FDGPU_OK;
     };
     if (!TB.valid) { const int rcb = build_tables(); if (rcb) return rcb; }
     const size_t o_cand = TB.o[0], o_wc = TB.o[1], o_wi = TB.o[2], o_wq = TB.o[3], o_wj = TB.o[4], o_h = TB.o[5], o_st = TB.o[6], o_d = TB.o[7], o_qi = TB.o[8],
-                 o_qt = TB.o[9], o_ivs = TB.o[10], o_iv = TB.o[11], nw = TB.nw, words = TB.blk.size();
+                 o_qt = TB.o[9], o_ivs = TB.o[10], o_iv = TB.o[11], o_iv1 = TB.o[12], nw = TB.nw, words = TB.blk.size();
     const bool want_iv = TB.want_iv;
     const uint32_t j_span = TB.j_span;
     const std::vector<uint32_t> &blk = TB.blk;
@@ -1800,6 +1816,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     A.resname_std = d_std;
     A.q_hashes = dblk + o_h; A.aad_start = dblk + o_st; A.aad_dist = (const float *)(dblk + o_d); A.aad_qi = dblk + o_qi;
     A.iv_start = want_iv ? dblk + o_ivs : nullptr; A.iv = want_iv ? (const float2 *)(dblk + o_iv) : nullptr;
+    A.iv_grp = want_iv ? dblk + o_iv1 : nullptr;
     A.qtab = (const mp_query_dev *)(dblk + o_qt);
     A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.found = nullptr; A.cands = nullptr;
     // one emitting pass into buffers sized by the previous calls; a pass that overflows only counts, the buffers grow and

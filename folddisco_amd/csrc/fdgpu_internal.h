@@ -268,6 +268,7 @@ struct mp_args {
     const uint32_t *aad_start;   // [1025] start of the (aa_i * 32 + aa_j) group in aad_dist / aad_qi (stable order)
     const float *aad_dist; const uint32_t *aad_qi; uint32_t n_aad;
     const uint32_t *iv_start; const float2 *iv;   // optional (queries too large for the LDS copy of their distances): merged pass intervals per group, [1025 * query] offsets into iv
+    const uint32_t *iv_grp;                       // with iv_start: [1024 * query] (group's first interval - query's first) << 8 | min(count, 255): the scan's LDS copy
     float ca_window;
     unsigned long long *n_found, *n_cands;
     fd_pair_rec *found; fd_cand_rec *cands;
@@ -285,7 +286,7 @@ struct mp_args {
 // 1-based ordinal of the component that mapped it, per slot the first counter and the query's residue count, the table's size in counters.
 // Out: per (slot, ordinal, query residue) row of the table {largest count, number of target residues holding it, one of them}.
 // host block of a pair scan's work items and query tables (fd_match_pairs_multi builds it on the first call, reuses it on the next)
-struct fd_mp_tables { std::vector<uint32_t> blk; size_t o[12] = {0}; size_t nw = 0; bool want_iv = false; uint32_t j_span = 0; bool valid = false; };
+struct fd_mp_tables { std::vector<uint32_t> blk; size_t o[13] = {0}; size_t nw = 0; bool want_iv = false; uint32_t j_span = 0; bool valid = false; };
 struct fd_vote_row { uint32_t mx, nmx, arg; };
 struct fd_vote_plan {
     const uint8_t *cj_comp; uint64_t n_bits;

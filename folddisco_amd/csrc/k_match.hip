@@ -29,6 +29,7 @@ struct mp_sel {
     const uint32_t *aad_start; const float *aad_dist; const uint32_t *aad_qi; uint32_t n_aad;
     uint32_t aa1_mask, aa2_mask; int use_prefilter; float ca_window;
     const uint32_t *iv_start; const float2 *iv;      // large queries: per (aa_i, aa_j) group the merged intervals of distances that pass the window test
+    const uint32_t *iv_grp;                          // ... and per group (first interval << 8 | count), the form the work item copies into LDS
 };
 // descriptor + hash + output of one surviving (i, j) per lane (full-wave drains of the compaction queue: executed
 // divergently per survivor this part — ~3000 instructions with the exact libm chain — was 95 % of the kernel time)
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     mp_sel Sx;
     Sx.q_hashes = A_in.q_hashes; Sx.n_hashes = A_in.n_hashes; Sx.aad_start = A_in.aad_start; Sx.aad_dist = A_in.aad_dist; Sx.aad_qi = A_in.aad_qi;
     Sx.n_aad = A_in.n_aad; Sx.aa1_mask = A_in.aa1_mask; Sx.aa2_mask = A_in.aa2_mask; Sx.use_prefilter = A_in.use_prefilter; Sx.ca_window = A_in.ca_window;
-    Sx.iv_start = A_in.iv_start; Sx.iv = A_in.iv;
+    Sx.iv_start = A_in.iv_start; Sx.iv = A_in.iv; Sx.iv_grp = A_in.iv_grp;
     if (blockIdx.x < A_in.n_work) {
         const uint32_t tq = A_in.wi_query[blockIdx.x];
         const mp_query_dev Q = A_in.qtab[tq];
@@ -159,10 +160,13 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
         Sx.aad_start = A_in.aad_start + 1025u * tq; Sx.aad_dist = A_in.aad_dist + Q.aad_off; Sx.aad_qi = A_in.aad_qi + Q.aad_off; Sx.n_aad = Q.n_aad;
         Sx.aa1_mask = Q.aa1_mask; Sx.aa2_mask = Q.aa2_mask; Sx.use_prefilter = Q.use_prefilter; Sx.ca_window = Q.ca_window;
         Sx.iv_start = A_in.iv_start ? A_in.iv_start + 1025u * tq : nullptr;      // interval offsets are absolute into A.iv
+        Sx.iv_grp = A_in.iv_grp ? A_in.iv_grp + 1024u * tq : nullptr;
     }
     __shared__ uint32_t q[2 * FD_WAVE];
     __shared__ uint32_t tab[32];
-    __shared__ float s_d_buf[MP_AAD_LDS];
+    // motif-sized queries: the observed distances (4 KB) and the start table.  Large queries: the first 1,024 merged pass intervals of the query (8 KB;
+    // a 300-residue query at a 1 A window has ~700) and, in the start table's place, per (aa_i, aa_j) group (first interval << 8 | count)
+    __shared__ __attribute__((aligned(8))) float s_d_buf[2 * 1024];
     __shared__ uint32_t s_start[1025];
     const uint32_t w = blockIdx.x;
     if (w >= A.n_work) return;
@@ -170,12 +174,23 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     // aad_start[aa_i * 32 + aa_j] .. [+1] indexes the distance / query-residue arrays (host-sorted, stable).  Start table and,
     // for motif-sized queries, the distances live in LDS: per-pair global reads made the scan latency-bound.
     const bool staged = Sx.n_aad <= MP_AAD_LDS;
+    const bool big = !staged && Sx.iv_start != nullptr;      // large query: the only table a work item stages is the dense interval table (8 KB, 16
+                                                              // independent loads per lane) — the start table stays in global memory for the drains
     if (threadIdx.x == 0 && A.C.use_tab) fd_fill_bintab(tab);
-    for (uint32_t e = threadIdx.x; e < 1025; e += FD_WAVE) s_start[e] = Sx.aad_start[e];
+    if (!big) for (uint32_t e = threadIdx.x; e < 1025; e += FD_WAVE) s_start[e] = Sx.aad_start[e];
     if (staged)
         for (uint32_t e = threadIdx.x; e < Sx.n_aad; e += FD_WAVE) s_d_buf[e] = Sx.aad_dist[e];
+    uint32_t iv_base = 0;
+    if (big) {
+        iv_base = Sx.iv_start[0];
+        const uint32_t n_iv = Sx.iv_start[1024] - iv_base;
+#pragma unroll
+        for (uint32_t g = 0; g < 1024; g += FD_WAVE) s_start[g + threadIdx.x] = Sx.iv_grp[g + threadIdx.x];
+        for (uint32_t e = threadIdx.x; e < n_iv && e < 1024u; e += FD_WAVE) reinterpret_cast<float2 *>(s_d_buf)[e] = Sx.iv[iv_base + e];
+    }
     __syncthreads();
     const float *dist_tab = staged ? s_d_buf : Sx.aad_dist;
+    const uint32_t *st_tab = big ? Sx.aad_start : s_start;
     const uint32_t slot = A.wi_cand[w];
     const uint32_t s = A.cand[slot];
     const uint32_t r0 = A.B.res_off[s], r1 = A.B.res_off[s + 1];
@@ -205,8 +220,10 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     if (in_i) cai = fd_load3(A.B.ca_xyz, i);
     // partner residue types this lane's residue type has any observation with (aa < 32): one register test per pair
     uint32_t row_mask = 0;
-    if (aai < 32u)
-        for (uint32_t a2 = 0; a2 < 32u; ++a2) row_mask |= (s_start[aai * 32u + a2 + 1] > s_start[aai * 32u + a2] ? 1u : 0u) << a2;
+    if (aai < 32u) {
+        if (big) for (uint32_t a2 = 0; a2 < 32u; ++a2) row_mask |= ((s_start[aai * 32u + a2] & 255u) ? 1u : 0u) << a2;
+        else for (uint32_t a2 = 0; a2 < 32u; ++a2) row_mask |= (s_start[aai * 32u + a2 + 1] > s_start[aai * 32u + a2] ? 1u : 0u) << a2;
+    }
     uint32_t qn = 0;   // wave-uniform
     // j in blocks of 64: one coalesced load of (aa, CA) per block, then wave-uniform broadcasts (v_readlane)
     const uint32_t j_lo = A.j_span ? A.wi_j0[w] : r0;
@@ -234,18 +251,24 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                     const float d = fd_dist(cai, caj);
                     if (d <= A.cutoff) {
                         // branch-free over the pair's own list: a short-circuit chain costs one LDS round trip per entry
-                        const uint32_t e_lo = s_start[aai * 32u + aaj], e_hi = s_start[aai * 32u + aaj + 1];
                         uint32_t any = 0;
-                        if (Sx.iv_start && !staged) {
+                        if (big) {
                             // a whole-structure query observes ~100 distances per residue-type pair and keeps them in global memory.  The
                             // window test only asks whether ANY of them is within the window of d: the host merged, per pair of types, the
                             // float intervals [lo_x, hi_x] = {d : |d - x| < window} of all observed x (exact: |d - x| is monotone in d on
                             // either side of x) — usually ONE interval per pair of types — so the test is one offset load and one or two
                             // independent interval loads instead of a walk over the list
-                            const uint32_t v_lo = Sx.iv_start[aai * 32u + aaj], v_hi = Sx.iv_start[aai * 32u + aaj + 1];
-                            for (uint32_t e = v_lo; e < v_hi; ++e) { const float2 w2 = Sx.iv[e]; any |= (uint32_t)(d >= w2.x && d <= w2.y); }
-                        } else
+                            const uint32_t gw = s_start[aai * 32u + aaj], v0 = gw >> 8, vn = gw & 255u;      // the group's intervals, from LDS
+                            if (vn < 255u && v0 + vn <= 1024u) {
+                                for (uint32_t e = 0; e < vn; ++e) { const float2 w2 = reinterpret_cast<const float2 *>(s_d_buf)[v0 + e]; any |= (uint32_t)(d >= w2.x && d <= w2.y); }
+                            } else {
+                                const uint32_t v_lo = Sx.iv_start[aai * 32u + aaj], v_hi = Sx.iv_start[aai * 32u + aaj + 1];
+                                for (uint32_t e = v_lo; e < v_hi; ++e) { const float2 w2 = Sx.iv[e]; any |= (uint32_t)(d >= w2.x && d <= w2.y); }
+                            }
+                        } else {
+                            const uint32_t e_lo = s_start[aai * 32u + aaj], e_hi = s_start[aai * 32u + aaj + 1];
                             for (uint32_t e = e_lo; e < e_hi; ++e) any |= (uint32_t)(fd_fabsf(d - dist_tab[e]) < Sx.ca_window);
+                        }
                         pass = any != 0;
                     }
                 }
@@ -260,7 +283,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                 __syncthreads();
                 uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
                 qn -= n;
-                match_drain<EMIT>(A, Sx, q + qn, n, slot, r0, r1, i0, s_start, dist_tab, tab);
+                match_drain<EMIT>(A, Sx, q + qn, n, slot, r0, r1, i0, st_tab, dist_tab, tab);
                 __syncthreads();
             }
         }

@@ -63,7 +63,7 @@ def main():
     print("kernel stages of the last library call (ms):", {n: round(ms, 3) for n, ms, _ in ctx.last_timings()})
     ctx.enable_timing(False)
     print("query map %.1f ms, scoring + top 1000 %.1f ms, retrieval of the top 20 %.1f ms, %d matches" % go(False))
-    go(True)
+    print("traced run: query map %.1f ms, scoring + top 1000 %.1f ms, retrieval of the top 20 %.1f ms, %d matches" % go(True))
 
 
 if __name__ == "__main__":
