@@ -170,6 +170,12 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     __shared__ uint32_t s_start[1025];
     const uint32_t w = blockIdx.x;
     if (w >= A.n_work) return;
+    if (A.dbg_times && threadIdx.x == 0) {
+        A.dbg_times[3ull * w] = wall_clock64();
+        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        A.dbg_times[3ull * w + 2] = ((unsigned long long)xcc << 32) | hwid;
+    }
     // the query's observed (aa_i, aa_j) -> CA distance lists (aa_dist_map, controller/query.rs), grouped by residue-type pair:
     // aad_start[aa_i * 32 + aa_j] .. [+1] indexes the distance / query-residue arrays (host-sorted, stable).  Start table and,
     // for motif-sized queries, the distances live in LDS: per-pair global reads made the scan latency-bound.
@@ -288,6 +294,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
             }
         }
     }
+    if (A.dbg_times && threadIdx.x == 0) A.dbg_times[3ull * w + 1] = wall_clock64();
 }
 
 // candidate pairs -> (slot << 16 | j, qi << 16 | i): 8 bytes instead of 16 for the copy back, and sortable by (slot, partner residue)

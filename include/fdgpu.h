@@ -128,7 +128,10 @@ int fdgpu_hash_batch_rows(fdgpu_ctx *ctx, const fdgpu_batch *b, const fd_hash_pa
  * Replaces Folddisco::collect_and_count + allocate_entries + add_entries +
  * wrapup_offset_and_save_entries + prune_to_sparse (src/controller/mod.rs:274-441,
  * src/index/indextable.rs:88-295) for the structures of `b`, which receive ids
- * first_id, first_id+1, ...  The result (value bytes, sparse hashes, offsets) stays in HBM. */
+ * first_id, first_id+1, ...  The result (value bytes, sparse hashes, offsets) stays in HBM.
+ * One call of the default encoding holds up to 2^24 structures and 2^35 residue-pair keys and needs 12 bytes of workspace per key
+ * (Swiss-Prot, 1.77e10 keys: 213 GB); FDGPU_ERANGE / FDGPU_EHIP (out of memory) beyond that: build consecutive id ranges and
+ * fdgpu_index_merge them.  The other encodings and --multiple-bins: 2^32 keys per call. */
 int fdgpu_index_build(fdgpu_ctx *ctx, const fdgpu_batch *b, const fd_hash_params *p, uint64_t first_id,
                       fdgpu_index **out);
 /* copy the index to the host in the reference's on-disk layout:
@@ -430,7 +433,7 @@ int fdgpu_merge_subindices(uint64_t n_parts, const uint8_t *const *values, const
                            const uint64_t *const *offsets, const uint64_t *n_hashes, uint8_t **out_value,
                            uint64_t *out_value_len, uint32_t **out_hashes, uint64_t **out_offsets, uint64_t *out_n_hashes);
 
-/* The same merge on the device, for parts that are resident: a shard with more than 2^32 residue pairs is built as several
+/* The same merge on the device, for parts that are resident: a shard whose sort workspace does not fit one call is built as several
  * fdgpu_index_build calls over consecutive id ranges (the reference walks its input in chunks the same way,
  * src/controller/mod.rs:282-348) and the chunks' posting lists are concatenated per hash — first varint of every continuation
  * re-based to a delta — into ONE resident index, byte-identical to the index a single build over all the structures produces
