@@ -1819,11 +1819,6 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     A.iv_grp = want_iv ? dblk + o_iv1 : nullptr;
     A.qtab = (const mp_query_dev *)(dblk + o_qt);
     A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.found = nullptr; A.cands = nullptr;
-    if (getenv("FDGPU_MP_TIMES")) {      // TEMPORARY (timing experiment)
-        HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(3 * (size_t)A.n_work * 8 + 64));
-        HIPCHK(c, hipMemsetAsync(c->ws[WS_CQ_KIDX].p, 0, 3 * (size_t)A.n_work * 8, st));
-        A.dbg_times = c->ws[WS_CQ_KIDX].as<unsigned long long>();
-    }
     // one emitting pass into buffers sized by the previous calls; a pass that overflows only counts, the buffers grow and
     // the pass is repeated (the scan is deterministic up to record order, which is restored below)
     uint64_t tot[2] = {0, 0};
@@ -1841,13 +1836,6 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_TOTAL].p, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
-        if (const char *tp = getenv("FDGPU_MP_TIMES")) {      // TEMPORARY (timing experiment)
-            std::vector<unsigned long long> ht(3 * (size_t)A.n_work);
-            (void)hipMemcpy(ht.data(), A.dbg_times, ht.size() * 8, hipMemcpyDeviceToHost);
-            static int call = 0;
-            char name[512]; snprintf(name, sizeof name, "%s.%d.bin", tp, call++);
-            if (FILE *f = fopen(name, "wb")) { fwrite(ht.data(), 8, ht.size(), f); fclose(f); }
-        }
         if (tot[0] <= A.cap_found && tot[1] <= A.cap_cands) break;
         if (attempt == 2) FAIL(c, FDGPU_ERANGE, "match_pairs: output did not fit after regrowing");
     }

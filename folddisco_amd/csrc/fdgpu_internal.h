@@ -281,7 +281,6 @@ struct mp_args {
     // mode bit 5 (rescue votes on the device, second scan of a large query): instead of leaving the kernel, a candidate pair (qi, i, j) adds one
     // to votes[vt_off[slot] + ((cj_comp[bit of j] - 1) * vt_qs[slot] + qi) * n_residues(slot) + i] — the table retrieve.rs:498-511 builds per component
     uint32_t *votes; const uint64_t *vt_off; const uint32_t *vt_qs; const uint8_t *cj_comp;
-    unsigned long long *dbg_times;      // TEMPORARY (timing experiment): [3 * n_work] start, end (wall clock), hw id
 };
 // rescue votes of a large query's second scan (fd_match_pairs_multi, mode bit 5).  In: per marked partner residue (bit position as in cj_mask) the
 // 1-based ordinal of the component that mapped it, per slot the first counter and the query's residue count, the table's size in counters.

@@ -124,7 +124,10 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
     const unsigned long long fpos = fbase + (A.n_cfg > 1 ? (unsigned long long)(hincl - n_hit) : (unsigned long long)fd_mbcnt(hm));
     // EMIT with capacities: records beyond the caller's buffers are counted but not written (the caller grows and reruns)
     if (EMIT && on && cpos + n_win <= A.cap_cands && (!hit || fpos + n_hit <= A.cap_found)) {
-        for (uint32_t e = e_lo; e < e_hi; ++e) {
+        // only pairs that claimed candidate slots walk their list again: a found-only or vote scan (n_win = 0) used to walk the ~200 observed
+        // distances of its group here for nothing — 53 us per drain, 86 % of a whole-structure query's first scan — and a pair without a
+        // descriptor (encodings with their own) wrote its window hits over its neighbours' slots
+        if (n_win) for (uint32_t e = e_lo; e < e_hi; ++e) {
             if (fd_fabsf(d - dist_tab[e]) < Sx.ca_window) {
                 fd_cand_rec c; c.cand = slot; c.qi = Sx.aad_qi[e]; c.i = i - r0; c.j = j - r0;
                 A.cands[cpos++] = c;
@@ -170,12 +173,6 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     __shared__ uint32_t s_start[1025];
     const uint32_t w = blockIdx.x;
     if (w >= A.n_work) return;
-    if (A.dbg_times && threadIdx.x == 0) {
-        A.dbg_times[3ull * w] = wall_clock64();
-        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        A.dbg_times[3ull * w + 2] = ((unsigned long long)xcc << 32) | hwid;
-    }
     // the query's observed (aa_i, aa_j) -> CA distance lists (aa_dist_map, controller/query.rs), grouped by residue-type pair:
     // aad_start[aa_i * 32 + aa_j] .. [+1] indexes the distance / query-residue arrays (host-sorted, stable).  Start table and,
     // for motif-sized queries, the distances live in LDS: per-pair global reads made the scan latency-bound.
@@ -294,7 +291,6 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
             }
         }
     }
-    if (A.dbg_times && threadIdx.x == 0) A.dbg_times[3ull * w + 1] = wall_clock64();
 }
 
 // candidate pairs -> (slot << 16 | j, qi << 16 | i): 8 bytes instead of 16 for the copy back, and sortable by (slot, partner residue)
