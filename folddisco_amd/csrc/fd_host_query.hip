@@ -570,7 +570,14 @@ struct Graph {
     std::vector<uint32_t> w;           // node -> residue index (first-appearance order, graph.rs:16-26)
     std::vector<uint32_t> es, et, eh;  // edges in insertion order
     std::unordered_map<uint32_t, uint32_t> at;
+    std::vector<int32_t> dense;        // residue -> node for residues below dense.size() (a candidate's residue count is known: no hashing
+                                       // for the 6 x 10^4 lookups of a whole-structure query's heaviest candidate)
     uint32_t node_of(uint32_t res) {
+        if (res < dense.size()) {
+            int32_t &n = dense[res];
+            if (n < 0) { n = (int32_t)w.size(); w.push_back(res); }
+            return (uint32_t)n;
+        }
         auto ins = at.emplace(res, (uint32_t)w.size());
         if (ins.second) w.push_back(res);
         return ins.first->second;
@@ -985,6 +992,8 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         const bool big_trace = trace && fpos - f0 > 20000;
         const auto s_t0 = t_now();
         if (!cached) {
+            if (fpos - f0 > 256) g.dense.assign((size_t)(g_dst[slot + 1] - g_dst[slot]), -1);
+            g.es.reserve(fpos - f0); g.et.reserve(fpos - f0); g.eh.reserve(fpos - f0);
             for (size_t e = f0; e < fpos; ++e) {
                 uint32_t a = g.node_of(found[e].i), b = g.node_of(found[e].j);
                 g.es.push_back(a); g.et.push_back(b); g.eh.push_back(found[e].hash);
