@@ -340,7 +340,9 @@ __device__ __forceinline__ void cq_sliced_add(uint32_t (&p)[NP], uint32_t x) {
     }
 }
 // NP = counter planes: 8 when no query of the call has 256 rows or more (motif queries), else 20
-template <int NP>
+// ALIAS (packed form only): the count tile shares the LDS of the sums — pass 0 folds every thread's counts into its own sums
+// (count << CQ_CNT_SHIFT | sum, the packed record itself), passes 1 and 2 reuse the memory — 34 KB per workgroup instead of 51
+template <int NP, bool ALIAS = false>
 __global__ __launch_bounds__(CQ_FIN_T) void k_cq_rows_finalize(const uint32_t *__restrict__ hash_bits, const unsigned long long *__restrict__ row_meta,
                                                                const uint64_t *__restrict__ q_rows /*[nQ + 1] or null = one query over n_rows*/, uint64_t n_rows,
                                                                const uint64_t *__restrict__ slices /*[gridDim.z + 1] row boundaries or null*/,
@@ -378,25 +380,28 @@ __global__ __launch_bounds__(CQ_FIN_T) void k_cq_rows_finalize(const uint32_t *_
     }
     for (; r < r1; ++r) row(live ? hash_bits[r * words + w] : 0u, row_meta[r]);
     // counts of this thread's 32 structures -> the tile, packed with the sums where the packed form applies
-    __shared__ uint32_t s_cnt[CQ_FIN_T * 33];
+    __shared__ uint32_t s_cnt_own[ALIAS ? 1 : CQ_FIN_T * 33];
+    uint32_t *s_cnt = ALIAS ? reinterpret_cast<uint32_t *>(s_sum) : s_cnt_own;
     const uint32_t nid0 = blockIdx.x * CQ_FIN_T * 32;
     const uint32_t lim = nid0 < S ? (S - nid0 < CQ_FIN_T * 32 ? S - nid0 : CQ_FIN_T * 32) : 0u;
     const uint64_t qbase = (uint64_t)qy * S;
     for (int pass = 0; pass < 3; ++pass) {      // 0: match counts (+ sums), 1: edge counts, 2: node counts
+        if (ALIAS && pass) __syncthreads();       // the sums of pass 0 have been read: their memory takes the counts
         for (uint32_t b = 0; b < 32; ++b) {
             uint32_t v = 0;
 #pragma unroll
             for (int k = 0; k < NP; ++k) v |= (((pass == 0 ? pc[k] : pass == 1 ? pe[k] : pn[k]) >> b) & 1u) << k;
-            s_cnt[threadIdx.x * 33 + b] = v;
+            if (ALIAS && pass == 0) s_sum[threadIdx.x * 33 + b] |= (unsigned long long)v << CQ_CNT_SHIFT;
+            else s_cnt[threadIdx.x * 33 + b] = v;
         }
         __syncthreads();
 #pragma unroll 4
         for (uint32_t i = threadIdx.x; i < lim; i += CQ_FIN_T) {
             const uint32_t at = (i >> 5) * 33 + (i & 31u);
             const uint64_t g = qbase + nid0 + i;
-            const uint32_t v = s_cnt[at];
+            const uint32_t v = (ALIAS && pass == 0) ? (uint32_t)(s_sum[at] >> CQ_CNT_SHIFT) : s_cnt[at];
             if (pass == 0) {
-                const unsigned long long sum = s_sum[at];
+                const unsigned long long sum = ALIAS ? (s_sum[at] & CQ_SUM_MASK) : s_sum[at];
                 if (!add) {
                     if (packed) acc[g] = ((unsigned long long)v << CQ_CNT_SHIFT) | sum; else { acc[g] = sum; match[g] = v; }
                     flags[g] = v ? 1 : 0;
@@ -824,8 +829,12 @@ void fd_launch_cq_rows_finalize(const cq_args &A, const uint64_t *q_rows, uint32
         if (!A.packed) (void)hipMemsetAsync(A.match, 0, n * 4, st);
     }
     const dim3 grid((A.words + CQ_FIN_T - 1) / CQ_FIN_T, n_queries, add ? n_slices : 1);
+    static const bool fin_alias = [] { const char *e = getenv("FDGPU_FIN_ALIAS"); return !(e && e[0] == '0'); }();      // 0: the separate count tile (A/B)
     if (max_rows_per_query < 256)
         hipLaunchKernelGGL(k_cq_rows_finalize<8>, grid, dim3(CQ_FIN_T), 0, st, A.hash_bits, A.row_meta, q_rows, A.nq, add ? slices : nullptr, A.words, A.S, A.packed,
+                           A.match, A.idf, node_cnt, edge_cnt, flags);
+    else if (add && A.packed && fin_alias)
+        hipLaunchKernelGGL((k_cq_rows_finalize<20, true>), grid, dim3(CQ_FIN_T), 0, st, A.hash_bits, A.row_meta, q_rows, A.nq, add ? slices : nullptr, A.words, A.S, A.packed,
                            A.match, A.idf, node_cnt, edge_cnt, flags);
     else
         hipLaunchKernelGGL(k_cq_rows_finalize<20>, grid, dim3(CQ_FIN_T), 0, st, A.hash_bits, A.row_meta, q_rows, A.nq, add ? slices : nullptr, A.words, A.S, A.packed,
