@@ -465,6 +465,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     // many (whole-structure queries, ~10^5): (hash << 32 | insertion position) keys through an LSD radix sort, first key of every
     // hash kept, survivors back in insertion order — a third of the hash set's time there
     const uint64_t ncfg1 = std::max(n_cfg, 1u);
+    std::vector<uint64_t> dd_tab;
     std::vector<std::vector<uint32_t>> keeps(n_queries);      // per query: insertion positions (candidate * n_cfg + bin pair) that enter the map, ascending
     uint64_t n_keep = 0;
     for (uint64_t t = 0; t < n_queries; ++t) {
@@ -472,7 +473,18 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         auto hash_at = [&](uint64_t pos) { const uint64_t z = c0 + pos / ncfg1; const uint32_t k = (uint32_t)(pos % ncfg1); return n_cfg ? mh_cfg[k][z] : hashes[z]; };
         std::vector<uint32_t> &keep = keeps[t];
         if (dev_expand) keep.swap(dev_keep);
-        else if (n_ins <= 4096 || n_ins >= (1ull << 32)) {
+        else if (n_ins <= 4096) {      // a motif query's few hundred insertions: a small open-addressing table (a node-based set cost 3x this)
+            uint32_t cap = 64;
+            while (cap < 2 * n_ins) cap <<= 1;
+            dd_tab.assign(cap, ~0ull);
+            keep.reserve((size_t)n_ins);
+            for (uint64_t pos = 0; pos < n_ins; ++pos) {
+                const uint32_t h = hash_at(pos);
+                uint32_t at = (h * 2654435761u) & (cap - 1);
+                while (dd_tab[at] != ~0ull && (uint32_t)dd_tab[at] != h) at = (at + 1) & (cap - 1);
+                if (dd_tab[at] == ~0ull) { dd_tab[at] = h; keep.push_back((uint32_t)pos); }
+            }
+        } else if (n_ins >= (1ull << 32)) {
             std::unordered_set<uint32_t> have;
             have.reserve((size_t)n_ins / 4 + 16);
             for (uint64_t pos = 0; pos < n_ins; ++pos) if (have.insert(hash_at(pos)).second) keep.push_back((uint32_t)pos);
@@ -908,10 +920,36 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             }
         }
     };
+    // the same helper: every query's observed-distance lists in the pair scan's group layout (counting sort by aa_i * 32 + aa_j, entries with
+    // residue types below 32, queries concatenated), every group sorted by distance — what the second scan's vote loop searches (k_match.hip)
+    std::vector<float> sd_dist;
+    std::vector<uint32_t> sd_qi;
+    auto build_sorted_lists = [&]() {
+        std::vector<std::pair<float, uint32_t>> grp;
+        for (uint64_t t = 0; t < n_queries; ++t) {
+            const fd_query_map *m = qms[t];
+            std::vector<uint32_t> cnt(1025, 0);
+            for (uint64_t e = 0; e < m->n_aad; ++e) if (m->aad_aa1[e] < 32 && m->aad_aa2[e] < 32) ++cnt[m->aad_aa1[e] * 32u + m->aad_aa2[e] + 1];
+            for (int k = 0; k < 1024; ++k) cnt[k + 1] += cnt[k];
+            const size_t base = sd_dist.size();
+            sd_dist.resize(base + cnt[1024]); sd_qi.resize(base + cnt[1024]);
+            std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+            for (uint64_t e = 0; e < m->n_aad; ++e)
+                if (m->aad_aa1[e] < 32 && m->aad_aa2[e] < 32) { const uint32_t k = cur[m->aad_aa1[e] * 32u + m->aad_aa2[e]]++; sd_dist[base + k] = m->aad_dist[e]; sd_qi[base + k] = m->aad_qi[e]; }
+            for (int g = 0; g < 1024; ++g) {
+                const uint32_t a = cnt[g], b = cnt[g + 1];
+                if (b - a < 2) continue;
+                grp.clear();
+                for (uint32_t k = a; k < b; ++k) grp.emplace_back(sd_dist[base + k], sd_qi[base + k]);
+                std::stable_sort(grp.begin(), grp.end(), [](const std::pair<float, uint32_t> &x, const std::pair<float, uint32_t> &y) { return x.first < y.first; });
+                for (uint32_t k = a; k < b; ++k) { sd_dist[base + k] = grp[k - a].first; sd_qi[base + k] = grp[k - a].second; }
+            }
+        }
+    };
     bool big_tab = false;
     for (uint64_t t = 0; t < n_queries; ++t) big_tab = big_tab || qhs[t].size() > 4096;
     std::thread e_tab_thread;
-    if (big_tab) e_tab_thread = std::thread(build_e_tab);
+    if (big_tab) e_tab_thread = std::thread([&]() { build_e_tab(); if (two_pass) build_sorted_lists(); });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } e_tab_join{e_tab_thread};      // every return path below waits for it
     fd_mp_tables mp_tab;      // work items + query tables: built by the first scan, reused by the second
     rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &found, &nf, &cands, &nc, two_pass ? 1u : 15u,
@@ -1280,6 +1318,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             fd_vote_plan vp;
             vp.cj_comp = cj_comp.data(); vp.n_bits = g_total; vp.vt_off = vt_off.data(); vp.vt_qs = vt_qs.data(); vp.n_counters = n_counters;
             vp.row_off = row_off.data(); vp.row_len = row_len.data(); vp.n_rows = n_rows; vp.rows = vote_rows.data();
+            vp.sd_dist = sd_dist.empty() ? nullptr : sd_dist.data(); vp.sd_qi = sd_qi.empty() ? nullptr : sd_qi.data(); vp.n_sd = sd_dist.size();
             fd_pair_rec *f2 = nullptr; uint64_t nf2 = 0;
             rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &f2, &nf2, &cands, &nc, 32u, cj_mask.data(),
                                       mask_off.data(), cj_mask.size(), nullptr, nullptr, &vp, &mp_tab);

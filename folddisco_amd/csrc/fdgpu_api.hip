@@ -1790,7 +1790,8 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         const uint64_t nb = votes->n_bits, nr = votes->n_rows;
         auto up8 = [](uint64_t x) { return (x + 7) & ~(uint64_t)7; };
         const uint64_t o_off = 0, o_roff = o_off + up8(n_cand * 8), o_rows = o_roff + up8(nr * 8), o_qs = o_rows + up8(nr * sizeof(fd_vote_row)),
-                       o_rlen = o_qs + up8(n_cand * 4), o_comp = o_rlen + up8(nr * 4), bytes = o_comp + up8(nb) + 8;
+                       o_rlen = o_qs + up8(n_cand * 4), o_comp = o_rlen + up8(nr * 4), o_sdd = o_comp + up8(nb), o_sdq = o_sdd + up8(votes->n_sd * 4),
+                       bytes = o_sdq + up8(votes->n_sd * 4) + 8;
         HIPCHK(c, c->ws[WS_IDS_A].ensure(std::max<uint64_t>(votes->n_counters, 1) * 4));
         HIPCHK(c, c->ws[WS_IDS_B].ensure(bytes));
         uint8_t *base = c->ws[WS_IDS_B].as<uint8_t>();
@@ -1804,6 +1805,11 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         if (nb) HIPCHK(c, hipMemcpyAsync(base + o_comp, votes->cj_comp, nb, hipMemcpyHostToDevice, st));
         A.votes = c->ws[WS_IDS_A].as<uint32_t>(); A.vt_off = (const uint64_t *)(base + o_off); A.vt_qs = (const uint32_t *)(base + o_qs);
         A.cj_comp = base + o_comp;
+        if (votes->sd_dist && votes->sd_qi && votes->n_sd) {
+            HIPCHK(c, hipMemcpyAsync(base + o_sdd, votes->sd_dist, votes->n_sd * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(base + o_sdq, votes->sd_qi, votes->n_sd * 4, hipMemcpyHostToDevice, st));
+            A.sd_dist = (const float *)(base + o_sdd); A.sd_qi = (const uint32_t *)(base + o_sdq);
+        }
         d_rows = (fd_vote_row *)(base + o_rows);
     }
     if (!fd_multiple_bins_valid(p)) FAIL(c, FDGPU_EINVAL, "multiple_bins: at most 8 (dist, angle) bin pairs, no zero counts");

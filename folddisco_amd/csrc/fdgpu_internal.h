@@ -281,6 +281,7 @@ struct mp_args {
     // mode bit 5 (rescue votes on the device, second scan of a large query): instead of leaving the kernel, a candidate pair (qi, i, j) adds one
     // to votes[vt_off[slot] + ((cj_comp[bit of j] - 1) * vt_qs[slot] + qi) * n_residues(slot) + i] — the table retrieve.rs:498-511 builds per component
     uint32_t *votes; const uint64_t *vt_off; const uint32_t *vt_qs; const uint8_t *cj_comp;
+    const float *sd_dist; const uint32_t *sd_qi;      // optional, vote mode: every group's observed (distance, query residue) list sorted by distance
 };
 // rescue votes of a large query's second scan (fd_match_pairs_multi, mode bit 5).  In: per marked partner residue (bit position as in cj_mask) the
 // 1-based ordinal of the component that mapped it, per slot the first counter and the query's residue count, the table's size in counters.
@@ -293,6 +294,9 @@ struct fd_vote_plan {
     const uint64_t *vt_off; const uint32_t *vt_qs; uint64_t n_counters;
     const uint64_t *row_off; const uint32_t *row_len; uint64_t n_rows;      // every row's first counter and length (the slot's residue count)
     fd_vote_row *rows;                                                       // [n_rows] host, filled by the call
+    // optional: the queries' observed-distance lists in the scan's group layout (aad_start offsets), every group sorted by distance — the
+    // entries inside a pair's window are then one contiguous run (fl(d - x) is monotone in x) instead of a walk over the whole group
+    const float *sd_dist; const uint32_t *sd_qi; uint64_t n_sd;
 };
 void fd_launch_vote_rows(const uint32_t *votes, const uint64_t *row_off, const uint32_t *row_len, uint64_t n_rows, fd_vote_row *out, hipStream_t st);
 void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st);

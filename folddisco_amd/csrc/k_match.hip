@@ -30,6 +30,7 @@ struct mp_sel {
     uint32_t aa1_mask, aa2_mask; int use_prefilter; float ca_window;
     const uint32_t *iv_start; const float2 *iv;      // large queries: per (aa_i, aa_j) group the merged intervals of distances that pass the window test
     const uint32_t *iv_grp;                          // ... and per group (first interval << 8 | count), the form the work item copies into LDS
+    const float *sd_dist; const uint32_t *sd_qi;     // vote mode, optional: the group lists sorted by distance
 };
 // descriptor + hash + output of one surviving (i, j) per lane (full-wave drains of the compaction queue: executed
 // divergently per survivor this part — ~3000 instructions with the exact libm chain — was 95 % of the kernel time)
@@ -91,6 +92,16 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
         const uint32_t comp = A.cj_comp[A.mask_off[slot] + (j - r0)], nq = A.vt_qs[slot], nr = r1 - r0;
         if (comp) {
             uint32_t *tabv = A.votes + A.vt_off[slot] + (uint64_t)(comp - 1u) * nq * nr + (i - r0);
+            if (Sx.sd_dist) {
+                // the group sorted by distance x: (d - x) < window is false ... false, true ... true along it (f32 subtraction is monotone), so the
+                // entries inside the window start at the first true and end where |d - x| < window fails again — the same predicate, ~20 of ~200
+                uint32_t lo = e_lo, hi = e_hi;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((d - Sx.sd_dist[mid]) < Sx.ca_window) hi = mid; else lo = mid + 1; }
+                for (uint32_t e = lo; e < e_hi && fd_fabsf(d - Sx.sd_dist[e]) < Sx.ca_window; ++e) {
+                    const uint32_t qi = Sx.sd_qi[e];
+                    if (qi < nq) atomicAdd(&tabv[(uint64_t)qi * nr], 1u);
+                }
+            } else
             for (uint32_t e = e_lo; e < e_hi; ++e)
                 if (fd_fabsf(d - dist_tab[e]) < Sx.ca_window) { const uint32_t qi = Sx.aad_qi[e]; if (qi < nq) atomicAdd(&tabv[(uint64_t)qi * nr], 1u); }
         }
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     mp_sel Sx;
     Sx.q_hashes = A_in.q_hashes; Sx.n_hashes = A_in.n_hashes; Sx.aad_start = A_in.aad_start; Sx.aad_dist = A_in.aad_dist; Sx.aad_qi = A_in.aad_qi;
     Sx.n_aad = A_in.n_aad; Sx.aa1_mask = A_in.aa1_mask; Sx.aa2_mask = A_in.aa2_mask; Sx.use_prefilter = A_in.use_prefilter; Sx.ca_window = A_in.ca_window;
-    Sx.iv_start = A_in.iv_start; Sx.iv = A_in.iv; Sx.iv_grp = A_in.iv_grp;
+    Sx.iv_start = A_in.iv_start; Sx.iv = A_in.iv; Sx.iv_grp = A_in.iv_grp; Sx.sd_dist = A_in.sd_dist; Sx.sd_qi = A_in.sd_qi;
     if (blockIdx.x < A_in.n_work) {
         const uint32_t tq = A_in.wi_query[blockIdx.x];
         const mp_query_dev Q = A_in.qtab[tq];
@@ -164,6 +175,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
         Sx.aa1_mask = Q.aa1_mask; Sx.aa2_mask = Q.aa2_mask; Sx.use_prefilter = Q.use_prefilter; Sx.ca_window = Q.ca_window;
         Sx.iv_start = A_in.iv_start ? A_in.iv_start + 1025u * tq : nullptr;      // interval offsets are absolute into A.iv
         Sx.iv_grp = A_in.iv_grp ? A_in.iv_grp + 1024u * tq : nullptr;
+        Sx.sd_dist = A_in.sd_dist ? A_in.sd_dist + Q.aad_off : nullptr; Sx.sd_qi = A_in.sd_qi ? A_in.sd_qi + Q.aad_off : nullptr;
     }
     __shared__ uint32_t q[2 * FD_WAVE];
     __shared__ uint32_t tab[32];
