@@ -71,7 +71,9 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
             fd_frame Fi = fd_make_frame(fd_load3(A.B.n_xyz, i), cai, fd_load3(A.B.cb_xyz, i));
             fd_frame Fj = fd_make_frame(fd_load3(A.B.n_xyz, j), caj, fd_load3(A.B.cb_xyz, j));
             uint32_t h_ji;
-            fd_pair_both_tab(Fi, Fj, aai, aaj, A.C.q, tab, &h, &h_ji);
+            // the index build's speculative evaluation (fd_pair_both_spec: table lookups on the dot products, exact whenever it answers) with
+            // the exact table form behind it for the pairs it declines — the same frames, so the same bits as the build's keys
+            if (A.C.use_tab != 2 || !fd_pair_both_spec(Fi, Fj, aai, aaj, A.C.q, tab, tab + 32, &h, &h_ji)) fd_pair_both_tab(Fi, Fj, aai, aaj, A.C.q, tab, &h, &h_ji);
             hitmask = ((A.mode & 1u) && hash_in_set(Sx.q_hashes, Sx.n_hashes, h)) ? 1u : 0u;
         } else {
             // one descriptor, one hash per bin pair (--multiple-bins: a found triple for every bin pair whose hash the query holds,
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
         Sx.sd_dist = A_in.sd_dist ? A_in.sd_dist + Q.aad_off : nullptr; Sx.sd_qi = A_in.sd_qi ? A_in.sd_qi + Q.aad_off : nullptr;
     }
     __shared__ uint32_t q[2 * FD_WAVE];
-    __shared__ uint32_t tab[32];
+    __shared__ uint32_t tab[64];      // [0, 27) the exact bin tables (bit patterns), [32, 59) the same with clamped float thresholds for the speculative path
     // motif-sized queries: the observed distances (4 KB) and the start table.  Large queries: the first 1,024 merged pass intervals of the query (8 KB;
     // a 300-residue query at a 1 A window has ~700) and, in the start table's place, per (aa_i, aa_j) group (first interval << 8 | count)
     __shared__ __attribute__((aligned(8))) float s_d_buf[2 * 1024];
@@ -191,7 +193,12 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     const bool staged = Sx.n_aad <= MP_AAD_LDS;
     const bool big = !staged && Sx.iv_start != nullptr;      // large query: the only table a work item stages is the dense interval table (8 KB, 16
                                                               // independent loads per lane) — the start table stays in global memory for the drains
-    if (threadIdx.x == 0 && A.C.use_tab) fd_fill_bintab(tab);
+    if (threadIdx.x == 0 && A.C.use_tab) {
+        fd_fill_bintab(tab);
+        for (int k = 0; k < FD_BINTAB_WORDS; ++k) tab[32 + k] = tab[k];
+        for (int m = 0; m < 4; ++m)
+            for (int k = 0; k < 4; ++k) { const uint32_t v = tab[32 + 7 + 5 * m + k]; tab[32 + 7 + 5 * m + k] = v > 0x7f7fffffu ? 0x7f7fffffu : v; }
+    }
     if (!big) for (uint32_t e = threadIdx.x; e < 1025; e += FD_WAVE) s_start[e] = Sx.aad_start[e];
     if (staged)
         for (uint32_t e = threadIdx.x; e < Sx.n_aad; e += FD_WAVE) s_d_buf[e] = Sx.aad_dist[e];
