@@ -867,9 +867,25 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
                 HIPCHK(c, hipStreamSynchronize(st));
             }
             const float *h_rmsd = sol.data(), *h_rot = h_rmsd + nprob, *h_tran = h_rot + 9 * nprob, *h_met = h_tran + 3 * nprob;
+            // the records arrive in append order: into (slot, component) order by a counting sort over the slots and a sort of every slot's few
+            // records (a comparison sort of all 45 k records of a 512-query batch was 3 of the stage's 3.7 ms)
             std::vector<uint32_t> order(nm);
-            for (uint64_t k = 0; k < nm; ++k) order[k] = (uint32_t)k;
-            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hm[a].slot != hm[b].slot ? hm[a].slot < hm[b].slot : hm[a].ci < hm[b].ci; });
+            {
+                std::vector<uint32_t> at(n_cand + 2, 0);
+                bool in_range = true;
+                for (uint64_t k = 0; k < nm; ++k) { if (hm[k].slot < n_cand) ++at[hm[k].slot + 1]; else in_range = false; }
+                if (in_range) {
+                    for (uint64_t z = 0; z < n_cand; ++z) at[z + 1] += at[z];
+                    std::vector<uint32_t> cur(at.begin(), at.end() - 1);
+                    for (uint64_t k = 0; k < nm; ++k) order[cur[hm[k].slot]++] = (uint32_t)k;
+                    for (uint64_t z = 0; z < n_cand; ++z)
+                        if (at[z + 1] - at[z] > 1)
+                            std::sort(order.begin() + at[z], order.begin() + at[z + 1], [&](uint32_t a, uint32_t b) { return hm[a].ci < hm[b].ci; });
+                } else {
+                    for (uint64_t k = 0; k < nm; ++k) order[k] = (uint32_t)k;
+                    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hm[a].slot != hm[b].slot ? hm[a].slot < hm[b].slot : hm[a].ci < hm[b].ci; });
+                }
+            }
             uint64_t tot_res = 0;
             for (uint64_t k = 0; k < nm; ++k) tot_res += 2 * qms[t_slotq[hm[k].slot]]->n_indices;
             fd_match_rec *om = (fd_match_rec *)malloc(std::max<size_t>(nm, 1) * sizeof(fd_match_rec));
