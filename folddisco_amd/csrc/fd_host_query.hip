@@ -776,14 +776,24 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         // tables: one packed host block -> one copy
         std::vector<rs_query_dev> qt(n_queries);
         std::vector<uint32_t> t_hash, t_kfirst, t_sym, t_qi, t_qj, t_idf, t_idx;
+        {
+            size_t th = 0, tm = 0, ti = 0;
+            for (uint64_t t = 0; t < n_queries; ++t) { th += qhs[t].size(); tm += qms[t]->n; ti += qms[t]->n_indices; }
+            t_hash.reserve(th); t_kfirst.reserve(th); t_sym.reserve(th); t_qi.reserve(tm); t_qj.reserve(tm); t_idf.reserve(tm); t_idx.reserve(ti);
+        }
         for (uint64_t t = 0; t < n_queries; ++t) {
             const fd_query_map *m = qms[t];
             rs_query_dev &Q = qt[t];
             memset(&Q, 0, sizeof Q);
             Q.qh_off = (uint32_t)t_hash.size(); Q.n_hashes = (uint32_t)qhs[t].size();
-            for (size_t z = 0; z < qhs[t].size(); ++z) { t_hash.push_back(qhs[t][z]); t_kfirst.push_back(qkf[t][z]); t_sym.push_back(is_sym(qhs[t][z]) ? 1u : 0u); }
+            t_hash.insert(t_hash.end(), qhs[t].begin(), qhs[t].end());
+            t_kfirst.insert(t_kfirst.end(), qkf[t].begin(), qkf[t].end());
+            for (size_t z = 0; z < qhs[t].size(); ++z) t_sym.push_back(is_sym(qhs[t][z]) ? 1u : 0u);
             Q.map_off = (uint32_t)t_qi.size();
-            for (uint64_t k = 0; k < m->n; ++k) { t_qi.push_back(m->qi[k]); t_qj.push_back(m->qj[k]); uint32_t w; memcpy(&w, &m->idf[k], 4); t_idf.push_back(w); }
+            t_qi.insert(t_qi.end(), m->qi, m->qi + m->n);
+            t_qj.insert(t_qj.end(), m->qj, m->qj + m->n);
+            t_idf.resize(t_idf.size() + m->n);
+            if (m->n) memcpy(t_idf.data() + t_idf.size() - m->n, m->idf, m->n * 4);
             Q.idx_off = (uint32_t)t_idx.size(); Q.n_idx = (uint32_t)m->n_indices;
             t_idx.insert(t_idx.end(), m->indices, m->indices + m->n_indices);
             Q.q_size = q_sizes[t];

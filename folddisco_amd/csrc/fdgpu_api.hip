@@ -1644,6 +1644,14 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     const uint32_t j_span = !n_tiles ? 0u : max_aad_q > 4096 ? 32u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : 256u;
     TB.j_span = j_span;
     std::vector<uint32_t> wc, wi, wq, wj;
+    {
+        size_t n_wi = 0;
+        for (uint64_t k = 0; k < n_cand; ++k) {
+            const uint64_t len = db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]];
+            n_wi += ((len + FD_WAVE - 1) / FD_WAVE) * (j_span ? (len + j_span - 1) / j_span : (len ? 1 : 0));
+        }
+        wc.reserve(n_wi); wi.reserve(n_wi); wq.reserve(n_wi); wj.reserve(n_wi);
+    }
     for (uint64_t t = 0; t < n_queries; ++t)
         for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) {
             uint64_t r0 = db->h_res_off[cand[k]], r1 = db->h_res_off[cand[k] + 1];
@@ -1657,6 +1665,8 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     std::vector<mp_query_dev> qtab(std::max<uint64_t>(n_queries, 1));
     std::vector<uint32_t> all_hashes, all_start, all_qi;
     std::vector<float> all_dist;
+    all_start.assign((size_t)1025 * n_queries, 0u);      // one start table per query, filled in place (a batch of 512 motif queries: 2 MB)
+    std::vector<uint32_t> cur(1024);
     for (uint64_t t = 0; t < n_queries; ++t) {
         const fd_match_query *q = &qs[t];
         mp_query_dev &Q = qtab[t];
@@ -1672,14 +1682,13 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         // (retrieve.rs:576) and panics for queries of <= 200 hashes; every pair is scanned instead
         const bool no_aa = p->hash_type == FD_HASH_TERTIARY || p->hash_type == FD_HASH_HYBRID;
         Q.use_prefilter = no_aa ? 0 : q->use_aa_prefilter; Q.ca_window = q->ca_distance_cutoff;
-        std::vector<uint32_t> cnt(1025, 0);
+        uint32_t *cnt = &all_start[(size_t)1025 * t];
         for (uint64_t e = 0; e < q->n_aad; ++e)
             if (q->aad_aa1[e] < 32 && q->aad_aa2[e] < 32) ++cnt[q->aad_aa1[e] * 32u + q->aad_aa2[e] + 1];   // residue type 255 never passes get_single_feature
         for (int k = 0; k < 1024; ++k) cnt[k + 1] += cnt[k];
         Q.aad_off = (uint32_t)all_dist.size(); Q.n_aad = cnt[1024];
-        all_start.insert(all_start.end(), cnt.begin(), cnt.end());
         all_qi.resize(Q.aad_off + Q.n_aad); all_dist.resize(Q.aad_off + Q.n_aad);
-        std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+        memcpy(cur.data(), cnt, 1024 * 4);
         for (uint64_t e = 0; e < q->n_aad; ++e)
             if (q->aad_aa1[e] < 32 && q->aad_aa2[e] < 32) {
                 uint32_t k = Q.aad_off + cur[q->aad_aa1[e] * 32u + q->aad_aa2[e]]++;
