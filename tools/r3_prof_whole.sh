@@ -14,7 +14,8 @@ rows = []
 for f in glob.glob(raw + "/trace/**/*kernel_stats.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-for r in rows[:25]:
+own = ("k_match_pairs", "k_cq_", "k_vote_rows", "k_qm_", "k_found_", "k_topn", "k_pl_", "k_pair_features", "k_gather_xyz", "k_superpose", "k_metrics")
+for r in [x for x in rows if any(k in x["Name"] for k in own)] + rows[:10]:
     print("%-80s calls=%-6s total_ms=%9.3f avg_us=%10.2f" % (r["Name"][:80], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3))
 # per-dispatch durations of the pair scan
 for f in glob.glob(raw + "/trace/**/*kernel_trace.csv", recursive=True):
