@@ -810,3 +810,36 @@ def test_msd_build_equals_structure_major_build(ctx):
             assert np.array_equal(a, b), tag
     assert not np.array_equal(outs["msd"][1], outs["msd_odd"][1])
     assert len(outs["msd"][1]) > 10 ** 6
+
+
+def test_release_workspaces_keeps_indices_and_batches_valid():
+    """fdgpu_release_workspaces hands the sort buffers, scratch and cached index blocks back to the device: indices, batches and query maps made
+    before stay valid, and the next calls allocate what they need again — same index bytes, same query results."""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd import synth
+    c2 = fd.Context(0)
+    ps = synth.to_packed(synth.generate(300, seed=91))
+    b = c2.upload(ps)
+    ix = fd.FolddiscoIndex.build(c2, b, first_id=5)
+    before = [a.copy() for a in ix.export()]
+    x, y = int(ps.res_off[7]), int(ps.res_off[8])
+    qb = c2.upload(fd.PackedStructures.concat([dict(n_xyz=ps.n_xyz[x:y], ca_xyz=ps.ca_xyz[x:y], cb_xyz=ps.cb_xyz[x:y], aa=ps.aa[x:y])]))
+    qm = fq.make_query_map(c2, qb, np.array([1, 4, 9, 12], np.uint32), None, ix, 300.0)
+    pen = fd.length_penalty(np.diff(ps.res_off).astype(np.uint64), 0.5)
+    r0 = fd.count_query(c2, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=300, as_array=True)
+    junk = fd.FolddiscoIndex.build(c2, b)          # a destroyed index leaves its blocks in the context's pool
+    del junk
+    c2.release_workspaces()
+    c2.release_workspaces()                        # idempotent
+    after = ix.export()
+    for u, v in zip(before, after):
+        assert np.array_equal(u, v)
+    r1 = fd.count_query(c2, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=300, as_array=True)
+    assert r0.tobytes() == r1.tobytes() and len(r0) > 0
+    ix2 = fd.FolddiscoIndex.build(c2, b, first_id=5)
+    for u, v in zip(before, ix2.export()):
+        assert np.array_equal(u, v)
+    got = fq.retrieve(c2, b, None, r1["nid"][:4].astype(np.uint32) - 5, qm, qb)
+    assert any(g["cand"] >= 0 for g in got)
+    c2.close()
