@@ -357,6 +357,8 @@ def main():
         # the one-call plan is an estimate: a device that cannot hold it answers the first build with FDGPU_EHIP (hipMalloc), not with a crash —
         # then the workspaces go back and the shard is built in calls of three blocks, as in round 3's first half
         try:
+            if os.environ.get("FD_BENCH_TEST_FALLBACK"):      # exercises the fall-back without needing a device that is too small
+                raise fd.FdgpuError("forced by FD_BENCH_TEST_FALLBACK")
             ix = build_shard()
         except fd.FdgpuError as e:
             progress(f"one-call build did not fit ({e}); falling back to calls of three blocks")
