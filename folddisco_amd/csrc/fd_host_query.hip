@@ -244,7 +244,7 @@ extern "C" void fdgpu_query_map_free(fd_query_map *m) {
     if (!m) return;
     free(m->hash); free(m->qi); free(m->qj); free(m->is_primary); free(m->idf); free(m->indices); free(m->primary_hash);
     free(m->aad_aa1); free(m->aad_aa2); free(m->aad_dist); free(m->aad_qi);
-    free(m->post_len); free(m->post_seg);
+    free(m->post_len); free(m->post_seg); free(m->post_kidx);
     free(m);
 }
 
@@ -511,6 +511,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     std::vector<float> pair_idf(std::max<uint64_t>(np, 1), 0.0f);
     std::vector<uint64_t> ent_len;
     std::vector<uint32_t> ent_seg;
+    std::vector<long long> ent_kidx;
     if (index) {
         std::vector<uint32_t> ph, pk;
         ph.reserve(n_keep + np);
@@ -524,7 +525,8 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             if (cands[t].primary) { ph.push_back(hashes[t]); pk.push_back(cands[t].pair); }
         ent_len.assign(std::max<size_t>(ph.size(), 1), 0);
         ent_seg.assign(std::max<size_t>(ph.size(), 1), 0);
-        if ((rc = fd_posting_lengths_segs(c, index, ph.data(), ph.size(), ent_len.data(), ent_seg.data()))) return rc;
+        ent_kidx.assign(std::max<size_t>(ph.size(), 1), -1);
+        if ((rc = fd_posting_lengths_segs(c, index, ph.data(), ph.size(), ent_len.data(), ent_seg.data(), ent_kidx.data()))) return rc;
         for (size_t t = 0; t < pk.size(); ++t)
             pair_idf[pk[t]] = ent_len[n_keep + t] > 0 ? log2f(total_structures / (float)ent_len[n_keep + t]) : 0.0f;
     }
@@ -549,11 +551,12 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         m->n = mh.size();
         m->hash = dup_vec(mh); m->qi = dup_vec(mqi); m->qj = dup_vec(mqj); m->is_primary = dup_vec(mp); m->idf = dup_vec(mi); m->primary_hash = dup_vec(mph);
         if (index && !keep.empty()) {
-            m->post_len = (uint64_t *)malloc(keep.size() * 8); m->post_seg = (uint32_t *)malloc(keep.size() * 4);
-            if (m->post_len && m->post_seg) {
+            m->post_len = (uint64_t *)malloc(keep.size() * 8); m->post_seg = (uint32_t *)malloc(keep.size() * 4); m->post_kidx = (long long *)malloc(keep.size() * 8);
+            if (m->post_len && m->post_seg && m->post_kidx) {
                 memcpy(m->post_len, &ent_len[keep_at], keep.size() * 8); memcpy(m->post_seg, &ent_seg[keep_at], keep.size() * 4);
+                memcpy(m->post_kidx, &ent_kidx[keep_at], keep.size() * 8);
                 m->post_index_uid = index->uid;
-            } else { free(m->post_len); free(m->post_seg); m->post_len = nullptr; m->post_seg = nullptr; }
+            } else { free(m->post_len); free(m->post_seg); free(m->post_kidx); m->post_len = nullptr; m->post_seg = nullptr; m->post_kidx = nullptr; }
         }
         keep_at += keep.size();
         std::vector<uint32_t> idx(q_index + q_off[t], q_index + q_off[t + 1]);

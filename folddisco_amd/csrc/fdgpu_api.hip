@@ -559,6 +559,8 @@ extern "C" void fdgpu_index_destroy(fdgpu_index *ix) {
     } else { (void)hipFree(ix->hashes); (void)hipFree(ix->offsets); (void)hipFree(ix->value); (void)hipFree(ix->last_ids); }
     if (ix->penalty) (void)hipFree(ix->penalty);
     if (ix->lens) (void)hipFree(ix->lens);
+    if (ix->ck_meta) (void)hipFree(ix->ck_meta);
+    if (ix->ck_ent) (void)hipFree(ix->ck_ent);
     delete ix;
 }
 extern "C" int fdgpu_index_set_first_id(fdgpu_index *ix, uint64_t first_id) { if (!ix || first_id + ix->n_structures > 0xffffffffull) return FDGPU_EINVAL; ix->first_id = first_id; return FDGPU_OK; }
@@ -999,7 +1001,7 @@ int fd_posting_lengths_dev(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *
             }
         }
         fd_launch_posting_lookup(ix->hashes, ix->offsets, ix->lens, ix->n_hashes, c->ws[WS_MISC0].as<uint32_t>(), nq, c->ws[WS_MISC1].as<uint64_t>(),
-                                 c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
+                                 c->ws[WS_CQ_NSEG].as<uint32_t>(), c->ws[WS_CQ_KIDX].as<long long>(), st);
         HIPCHK(c, hipGetLastError());
         return FDGPU_OK;
     }
@@ -1013,13 +1015,14 @@ int fd_posting_lengths_dev(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *
     return FDGPU_OK;
 }
 // lengths and the number of CQ_SEG-byte scoring segments of every hash (what k_cq_plan will find again), one synchronisation
-int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs) {
+int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs, long long *kidx) {
     if (!nq) return FDGPU_OK;
     uint64_t *d = nullptr;
     int rc = fd_posting_lengths_dev(c, ix, q_hash, nq, &d);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(lengths, d, nq * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(segs, c->ws[WS_CQ_NSEG].p, nq * 4, hipMemcpyDeviceToHost, c->stream));
+    if (kidx) HIPCHK(c, hipMemcpyAsync(kidx, c->ws[WS_CQ_KIDX].p, nq * 8, hipMemcpyDeviceToHost, c->stream));     // both length paths leave the list positions there
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FDGPU_OK;
 }
@@ -1092,7 +1095,8 @@ static inline uint64_t fd_idf_fix(float idf) {
 // The rows of one query in (node, partner) order with their metadata word: idf (2^-22 fixed point) << 2 | last row of its node << 1 |
 // last row of its edge.  -> false when an idf does not fit the packed accumulator (>= 32).
 static bool fd_cq_rows(const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, uint64_t a, uint64_t b,
-                       std::vector<uint32_t> &rows_hash, std::vector<unsigned long long> &rows_meta) {
+                       std::vector<uint32_t> &rows_hash, std::vector<unsigned long long> &rows_meta, const long long *q_kidx = nullptr,
+                       std::vector<long long> *rows_kidx = nullptr) {
     std::vector<uint64_t> ord(b - a);
     for (uint64_t k = a; k < b; ++k) ord[k - a] = k;
     bool small_ids = true;
@@ -1123,6 +1127,7 @@ static bool fd_cq_rows(const uint32_t *q_hash, const uint32_t *q_node, const uin
         const bool node_end = last || q_node[ord[z + 1]] != q_node[k];
         const bool edge_end = node_end || q_edge_j[ord[z + 1]] != q_edge_j[k];
         rows_hash.push_back(q_hash[k]);
+        if (q_kidx && rows_kidx) rows_kidx->push_back(q_kidx[k]);
         rows_meta.push_back(((unsigned long long)fix << 2) | (node_end ? 2ull : 0ull) | (edge_end ? 1ull : 0ull));
     }
     return fits;
@@ -1226,6 +1231,51 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
     return FDGPU_OK;
 }
 
+// The index's checkpoint table for tiled scoring (k_qtile.hip), made on first use for the id range the index has then: sizes per list ->
+// exclusive scan -> one sequential decode of every list long enough to hold entries.  -> FDGPU_OK with the table published, FDGPU_ENOMEM
+// when it does not fit (remembered: the caller keeps the occupancy-row path for this index).
+static int fd_index_checkpoints(fdgpu_ctx *c, const fdgpu_index *ix) {
+    std::lock_guard<std::mutex> lk(ix->lens_mu);
+    if (ix->ck_meta && ix->ck_first == ix->first_id && ix->ck_S == ix->n_structures) return FDGPU_OK;
+    if (ix->ck_failed) return FDGPU_ENOMEM;
+    hipStream_t st = c->stream;
+    const uint64_t H = ix->n_hashes, S = ix->n_structures;
+    if (!H || !S) return FDGPU_ENOMEM;
+    if (ix->ck_meta) { (void)hipStreamSynchronize(st); (void)hipFree(ix->ck_meta); (void)hipFree(ix->ck_ent); ix->ck_meta = nullptr; ix->ck_ent = nullptr; }
+    const uint32_t NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
+    hipError_t e = c->ws[WS_QT_COUNT].ensure(H * 4);
+    if (e == hipSuccess) e = c->ws[WS_QT_RANGES].ensure((H + 2) * 8);
+    if (e == hipSuccess) e = c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(H) * 8 + 64);
+    if (e == hipSuccess) e = c->ws[WS_TOTAL].ensure(64);
+    unsigned long long *meta = nullptr;
+    void *ent = nullptr;
+    uint64_t n_ent = 0;
+    if (e == hipSuccess) {
+        fd_launch_ck_count(ix->offsets, H, NC, c->ws[WS_QT_COUNT].as<uint32_t>(), st);
+        fd_exclusive_scan<uint32_t>(c->ws[WS_QT_COUNT].as<uint32_t>(), H, c->ws[WS_QT_RANGES].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
+                                    c->ws[WS_TOTAL].as<uint64_t>(), st);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_ent, c->ws[WS_TOTAL].p, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMalloc((void **)&meta, H * 8);
+    if (e == hipSuccess) e = hipMalloc(&ent, std::max<uint64_t>(n_ent, 1) * 8);
+    if (e == hipSuccess) {
+        fd_launch_ck_fill(ix->offsets, ix->value, H, NC, (uint32_t)S, (uint32_t)ix->first_id, c->ws[WS_QT_RANGES].as<uint64_t>(), meta, ent, st);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);      // other contexts read the table from their own streams
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (meta) (void)hipFree(meta);
+        if (ent) (void)hipFree(ent);
+        ix->ck_failed = true;
+        return FDGPU_ENOMEM;
+    }
+    ix->ck_meta = meta; ix->ck_ent = ent; ix->ck_n = n_ent; ix->ck_first = ix->first_id; ix->ck_S = S;
+    return FDGPU_OK;
+}
+
 // batched count_query: queries [q_off[t], q_off[t+1]) of the concatenated hash arrays; results of query t are
 // (*out)[(*out_off)[t] .. (*out_off)[t+1])
 // idf descending, ties by ascending structure id (the candidate ranking of query_pdb.rs:404-411), cut to top_n; -> records kept
@@ -1245,7 +1295,7 @@ static uint64_t fd_rank_trim(fd_count_rec *r, uint64_t n, uint32_t top_n) {
 // takes the compacting path together with the other ranks).  Calls the device selection does not serve return host records as usual.
 int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                               const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
-                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev, int64_t known_segments) {
+                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev, int64_t known_segments, const long long *known_kidx) {
     if (!c || !ix || !out || !out_off || !q_off || (ix->n_structures && !penalty && !ix->penalty)) return FDGPU_EINVAL;
     *out = nullptr; *out_off = nullptr;
     reset_timings(c);
@@ -1260,23 +1310,41 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     // occupancy rows: the query hashes of the whole batch, per query in (node, partner) order
     std::vector<uint32_t> rows_hash;
     std::vector<unsigned long long> rows_meta;
+    std::vector<long long> rows_kidx;       // the rows' list positions when the caller knows them (query maps made against this index)
     rows_hash.reserve(nq); rows_meta.reserve(nq);
+    if (known_kidx) rows_kidx.reserve(nq);
     bool packed = true;
     uint64_t max_rows = 0;
     for (uint64_t t = 0; t < n_queries; ++t) {
         max_rows = std::max<uint64_t>(max_rows, q_off[t + 1] - q_off[t]);
         packed = packed && (q_off[t + 1] - q_off[t]) < (1ull << 18);
-        packed = fd_cq_rows(q_hash, q_node, q_edge_j, q_idf, q_off[t], q_off[t + 1], rows_hash, rows_meta) && packed;
+        packed = fd_cq_rows(q_hash, q_node, q_edge_j, q_idf, q_off[t], q_off[t + 1], rows_hash, rows_meta, known_kidx, &rows_kidx) && packed;
     }
     const uint32_t words = (uint32_t)((S + 31) / 32);
     const uint64_t QS = n_queries * S;
+    const bool dense_topn = allow_dense && packed && top_n > 0 && top_n + 1024 <= 4096;
+    // one query with thousands of rows (whole-structure mode): its rows are walked in slices that add into the dense results; motif
+    // queries with a selection skip the dense results altogether: scores per tile of structures in LDS (k_qtile.hip), or, when the
+    // index has no checkpoint table, ranking keys from occupancy rows (k_cq_rows_keys); records only for the survivors either way
+    const bool sliced = n_queries == 1 && nq >= 4096;
+    const bool keys_only = dense_topn && !sliced;
+    const bool qtile_on = [] { const char *e = getenv("FDGPU_QTILE"); return !(e && e[0] == '0'); }();      // 0: occupancy rows (read per call: tests compare the two)
+    const uint32_t qt_tl2 = [] { const char *e = getenv("FDGPU_QT_TILE"); return e && atoi(e) == 13 ? 13u : 14u; }();      // structures per tile (measurement)
+    const uint32_t NT = (uint32_t)((S + (1u << qt_tl2) - 1) >> qt_tl2);
+    const bool tiled = keys_only && qtile_on && max_rows <= QT_MAX_ROWS && nq * (S >> QT_CELL_LOG2) < (1ull << 31) && fd_index_checkpoints(c, ix) == FDGPU_OK;
     hipError_t e = hipSuccess;
     auto need = [&](int w, size_t bytes) { if (e == hipSuccess) e = c->ws[w].ensure(bytes); };
-    need(WS_MISC0, nq * 4); need(WS_MISC3, nq * 8); need(WS_TILE_H, (n_queries + 1) * 8);
-    need(WS_COUNTS, packed ? 64 : QS * 4); need(WS_SEGOFF, QS * 8 + 16);
-    need(WS_KEYS_B, (size_t)nq * words * 4);
-    need(WS_IDS_A, QS * 4); need(WS_IDS_B, QS * 4); need(WS_MISC4, QS + 8); need(WS_TILE_BO, (QS + 2) * 8); need(WS_MISC5, S * 4);
-    need(WS_SCANTMP, fd_scan_tmp_elems(QS) * 8 + 64); need(WS_TOTAL, 64);
+    need(WS_MISC0, nq * 4); need(WS_MISC3, nq * 8); need(WS_TILE_H, (n_queries + 1) * 8); need(WS_MISC5, S * 4); need(WS_TOTAL, 64);
+    if (tiled) {
+        need(WS_CQ_KIDX, nq * 8); need(WS_CQ_NSEG, nq * 4);
+        need(WS_QT_RANGES, (size_t)nq * ((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2) * 16); need(WS_QT_COMPACT, ((size_t)n_queries * NT << qt_tl2) * 8);
+        need(WS_QT_COUNT, (size_t)n_queries * NT * 4); need(WS_QT_AUX, n_queries * sizeof(qt_aux) + 256);
+    } else {
+        need(WS_COUNTS, packed ? 64 : QS * 4); need(WS_SEGOFF, QS * 8 + 16);
+        need(WS_KEYS_B, (size_t)nq * words * 4);
+        need(WS_IDS_A, QS * 4); need(WS_IDS_B, QS * 4); need(WS_MISC4, QS + 8); need(WS_TILE_BO, (QS + 2) * 8);
+        need(WS_SCANTMP, fd_scan_tmp_elems(QS) * 8 + 64);
+    }
     if (e != hipSuccess) { free(ooff); c->err = std::string("count_query_batch workspace: ") + hipGetErrorString(e); return FDGPU_EHIP; }
     (void)hipMemcpyAsync(c->ws[WS_MISC0].p, rows_hash.data(), nq * 4, hipMemcpyHostToDevice, st);
     (void)hipMemcpyAsync(c->ws[WS_MISC3].p, rows_meta.data(), nq * 8, hipMemcpyHostToDevice, st);
@@ -1289,13 +1357,22 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     A.hash_bits = c->ws[WS_KEYS_B].as<uint32_t>(); A.row_meta = c->ws[WS_MISC3].as<unsigned long long>();
     A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>(); A.packed = packed ? 1 : 0;
     A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
-    const bool dense_topn = allow_dense && packed && top_n > 0 && top_n + 1024 <= 4096;
-    // one query with thousands of rows (whole-structure mode): its rows are walked in slices that add into the dense results; motif
-    // queries with a selection skip the dense results altogether (k_cq_rows_keys: ranking keys only, records for the survivors)
-    const bool sliced = n_queries == 1 && nq >= 4096;
-    const bool keys_only = dense_topn && !sliced;
+    qt_args T;
+    if (tiled) {
+        T.value = ix->value; T.offsets = ix->offsets; T.ck_meta = ix->ck_meta; T.ck_ent = (const uint2 *)ix->ck_ent;
+        T.kidx = c->ws[WS_CQ_KIDX].as<long long>(); T.row_meta = A.row_meta; T.q_rows = c->ws[WS_TILE_H].as<uint64_t>(); T.penalty = d_penalty;
+        T.nq = (uint32_t)nq; T.n_queries = (uint32_t)n_queries; T.S = (uint32_t)S; T.first_id = (uint32_t)ix->first_id; T.NT = NT; T.tile_log2 = qt_tl2;
+        T.NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
+        T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.compact = c->ws[WS_QT_COMPACT].as<uint2>(); T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
+        T.ghist = nullptr; T.state = nullptr; T.aux = c->ws[WS_QT_AUX].as<qt_aux>(); T.out = nullptr; T.cap = 0;
+        T.dbg = nullptr;
+        if (getenv("FDGPU_QT_DBG")) {       // phase durations of the tile kernels (measurement aid)
+            T.dbg = (unsigned long long *)(c->ws[WS_QT_AUX].as<uint8_t>() + n_queries * sizeof(qt_aux));
+            (void)hipMemsetAsync(T.dbg, 0, 256, st);
+        }
+    }
     std::vector<uint64_t> slices;        // outlives its asynchronous copy (every path below synchronises the stream before returning)
-    {
+    if (!tiled) {
         StageTimer t(c, "cq_batch", 0);
         int rs = cq_score(c, A, known_segments);
         if (rs) { free(ooff); return rs; }
@@ -1331,7 +1408,33 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         if (e2 == hipSuccess) e2 = c->ws[WS_MISC2].ensure(n_queries * 16);
         std::vector<uint32_t> tstate((size_t)n_queries * 4);
         std::vector<fd_count_rec> sel((size_t)n_queries * top_n);
-        if (e2 == hipSuccess) {
+        if (e2 == hipSuccess && tiled) {
+            T.ghist = c->ws[WS_CQ_TOPN].as<uint32_t>(); T.state = c->ws[WS_MISC2].as<qt_state>(); T.out = c->ws[WS_KEYS_A].p; T.cap = cap;
+            {
+                StageTimer t(c, "cq_batch", 0);
+                if (known_kidx && rows_kidx.size() == nq) (void)hipMemcpyAsync(c->ws[WS_CQ_KIDX].p, rows_kidx.data(), nq * 8, hipMemcpyHostToDevice, st);
+                else fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
+                fd_launch_qt_plan(T, st);
+                fd_launch_qt_score(T, st);
+            }
+            StageTimer t(c, "cq_topn", 0);
+            fd_launch_qt_select(T, top_n, c->ws[WS_TILE_HO].p, st);
+            if (T.dbg) {
+                unsigned long long d[32];
+                if (hipMemcpyAsync(d, T.dbg, 256, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+                    const double wg = (double)NT * (double)n_queries * 100.0;      // ticks of 10 ns -> us per workgroup
+                    fprintf(stderr, "[qt] A: setup %.2f plan %.2f units %.2f decode %.2f wait %.2f final %.2f | B: setup %.2f plan %.2f units %.2f decode %.2f wait %.2f records %.2f us/WG (%u x %llu WGs)\n",
+                            d[0] / wg, d[1] / wg, d[2] / wg, d[3] / wg, d[4] / wg, d[5] / wg, d[8] / wg, d[9] / wg, d[10] / wg, d[11] / wg, d[12] / wg, d[13] / wg, NT,
+                            (unsigned long long)n_queries);
+                    for (int z = 0; z < 2; ++z) {
+                        const unsigned long long *e = d + 16 + 8 * z;
+                        const double nw = (double)NT * (double)n_queries;
+                        fprintf(stderr, "[qt] %c unit loop: units/WG %.1f steps/WG %.1f, wave time mean %.2f us, slowest wave mean %.2f us\n", z ? 'B' : 'A', e[0] / nw, e[1] / nw,
+                                e[3] / (nw * (qt_tl2 == 14 ? 16 : 8) * 100.0), e[2] / (nw * 100.0));
+                    }
+                }
+            }
+        } else if (e2 == hipSuccess) {
             StageTimer t(c, "cq_topn", 0);
             if (keys_only)      // keys in the compaction's position buffer, unused on this path
                 fd_launch_cq_topn_dense(A, c->ws[WS_TILE_H].as<uint64_t>(), d_penalty, c->ws[WS_TILE_BO].as<uint32_t>(), (uint32_t)n_queries, top_n, cap,
@@ -1504,14 +1607,16 @@ uint64_t fd_maps_hashes(uint64_t n_queries, const fd_query_map *const *qms, std:
 // of primary_hash[] — what a sharded index needs, whose make_query_map saw one shard only
 int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const uint64_t *len,
                             const uint64_t *primary_len, const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out,
-                            uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg) {
+                            uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg, const long long *kidx) {
     uint64_t nq = 0;
     int64_t W = seg ? 0 : -1;
     for (uint64_t t = 0; t < n_queries; ++t) nq += qms[t]->n;
     std::vector<uint64_t> q_off(n_queries + 1, 0);
     std::vector<uint32_t> qh, qn, qe;
     std::vector<float> qi;
+    std::vector<long long> qk;
     qh.reserve(nq); qn.reserve(nq); qe.reserve(nq); qi.reserve(nq);
+    if (kidx) qk.reserve(nq);
     uint64_t at = 0;
     for (uint64_t t = 0; t < n_queries; ++t) {
         const fd_query_map *m = qms[t];
@@ -1519,13 +1624,15 @@ int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_quer
             if (primary_len) m->idf[k] = primary_len[at] ? log2f(total_structures / (float)primary_len[at]) : 0.0f;
             if (!len[at]) continue;
             qh.push_back(m->hash[k]); qn.push_back(m->qi[k]); qe.push_back(m->qj[k]);
+            if (kidx) qk.push_back(kidx[at]);
             qi.push_back(log2f(total_structures / (float)len[at]));       // f32 like the reference's (total / len).log2()
             if (seg) W += seg[at];
         }
         q_off[t + 1] = qh.size();
     }
-    if (qh.empty()) { qh.push_back(0); qn.push_back(0); qe.push_back(0); qi.push_back(0.0f); W = seg ? 0 : -1; }
-    return fd_count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off, true, dev, W);
+    if (qh.empty()) { qh.push_back(0); qn.push_back(0); qe.push_back(0); qi.push_back(0.0f); W = seg ? 0 : -1; qk.clear(); }
+    return fd_count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off, true, dev, W,
+                                     kidx && qk.size() == qh.size() ? qk.data() : nullptr);
 }
 extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty,
                                           float total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
@@ -1535,11 +1642,15 @@ extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, u
     std::vector<uint32_t> h(std::max<uint64_t>(nq, 1));
     std::vector<uint64_t> len(std::max<uint64_t>(nq, 1), 0);
     std::vector<uint32_t> seg(std::max<uint64_t>(nq, 1), 0);
-    bool remembered = nq > 0;       // maps made against THIS index carry their hashes' posting lengths and segment counts
+    std::vector<long long> kidx(std::max<uint64_t>(nq, 1), -1);
+    bool remembered = nq > 0;       // maps made against THIS index carry their hashes' posting lengths, segment counts and list positions
     for (uint64_t t = 0; t < n_queries; ++t) remembered = remembered && (!qms[t]->n || (qms[t]->post_len && qms[t]->post_seg && qms[t]->post_index_uid == ix->uid));
+    bool have_kidx = remembered;
+    for (uint64_t t = 0; t < n_queries; ++t) have_kidx = have_kidx && (!qms[t]->n || qms[t]->post_kidx);
     uint64_t at = 0;
     for (uint64_t t = 0; t < n_queries; ++t) {
         if (qms[t]->n) {
+            if (have_kidx) memcpy(&kidx[at], qms[t]->post_kidx, qms[t]->n * 8);
             if (remembered) { memcpy(&len[at], qms[t]->post_len, qms[t]->n * 8); memcpy(&seg[at], qms[t]->post_seg, qms[t]->n * 4); }
             else memcpy(&h[at], qms[t]->hash, qms[t]->n * 4);
         }
@@ -1547,7 +1658,8 @@ extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, u
     }
     int rc = !remembered && nq && ix->n_structures ? fd_posting_lengths_segs(c, ix, h.data(), nq, len.data(), seg.data()) : FDGPU_OK;
     if (rc) return rc;
-    return fd_count_query_maps_len(c, ix, n_queries, qms, len.data(), nullptr, penalty, total_structures, top_n, out, out_off, nullptr, seg.data());
+    return fd_count_query_maps_len(c, ix, n_queries, qms, len.data(), nullptr, penalty, total_structures, top_n, out, out_off, nullptr, seg.data(),
+                                   have_kidx ? kidx.data() : nullptr);
 }
 // The two halves of the sharded form for hosts that bring their own transport (MPI, gloo, ...): the LOCAL posting lengths of the maps'
 // hash[] and primary_hash[] (2 * sum(n) values, fd_maps_hashes order) — the caller sums them over the ranks — and the scoring of the

@@ -34,6 +34,7 @@ enum {
     WS_COUNTS, WS_CURSOR, WS_SEGOFF, WS_SCANTMP, WS_TOTAL, WS_KEYS_A, WS_IDS_A, WS_KEYS_B, WS_IDS_B, WS_GHIST, WS_TOT,
     WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
+    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX,
     WS_CA_PERM, WS_OK_PERM, WS_AA_PERM, WS_SEG_TAB,
     WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT,
     WS_COUNT
@@ -162,19 +163,26 @@ struct fdgpu_index {
     mutable std::mutex lens_mu;         // several contexts (streams) may share one index: the first one fills lens, complete before it is published
     uint64_t uid = fd_next_index_uid();   // identifies the index in what query maps remember about it (an address can be reused)
     float *penalty = nullptr;     // device [n_structures] length penalty set with fdgpu_index_set_penalty (count queries may then pass NULL)
+    // checkpoints of the posting lists (k_qtile.hip): where a list can be entered at a boundary of structure ids.  Derived, device-only,
+    // made on the first tiled scoring call for the (first_id, n_structures) the index has then (lens_mu guards them like lens)
+    mutable unsigned long long *ck_meta = nullptr;   // [H] first entry of the list | stride log2 << 56
+    mutable void *ck_ent = nullptr;                  // uint2 entries {byte offset in the list, id before}
+    mutable uint64_t ck_n = 0, ck_first = 0, ck_S = 0;
+    mutable bool ck_failed = false;                  // the table did not fit: the tiled path is off for this index
 };
 
 // batched scoring with the ranked selection left on the device (fdgpu_api.hip; consumed by the sharded query, fd_comm.hip)
 struct fd_cq_dev_out { bool got = false, overflow = false; const void *recs = nullptr; const void *state = nullptr; uint32_t top_n = 0, cap = 0; };
 int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                               const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
-                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev, int64_t known_segments = -1);
+                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev, int64_t known_segments = -1,
+                              const long long *known_kidx = nullptr);
 int fd_posting_lengths_dev(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t **dev_lengths);
 uint64_t fd_maps_hashes(uint64_t n_queries, const fd_query_map *const *qms, std::vector<uint32_t> &h);
 int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const uint64_t *len,
                             const uint64_t *primary_len, const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out,
-                            uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg = nullptr);
-int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs);
+                            uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg = nullptr, const long long *kidx = nullptr);
+int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs, long long *kidx = nullptr);
 
 // kernels / launchers implemented in the k_*.hip files
 void fd_launch_selfcheck(const fd_quant &q, uint32_t *out, hipStream_t st);
@@ -230,12 +238,42 @@ struct cq_args {
     uint32_t words; uint32_t first_id; uint32_t S;
 };
 
+// k_qtile.hip: tiled scoring of motif batches (posting lists entered per tile of structures, scores in LDS)
+#define QT_CELL_LOG2 11                    /* checkpoint granule: 2,048 structure ids — the piece of a list one (row, tile) work unit is cut into */
+/* structures per workgroup (tile): 2^13 (64 KB of LDS accumulators, two workgroups per CU) or 2^14; qt_args.tile_log2 */
+#define QT_BINS 2048
+#define QT_MAX_ROWS 1024                   /* rows per query the survivors' row bits are laid out for */
+struct qt_state { uint32_t thr_bin, above, thr_key, count; };      // same 16 bytes as topn_state / sel_state: consumers read .count
+struct qt_aux { uint32_t need_l2, shift2, edge, pad; };
+struct qt_args {
+    const uint8_t *value; const uint64_t *offsets;
+    const unsigned long long *ck_meta; const uint2 *ck_ent;
+    const long long *kidx;                 // [nq] list of every row's hash in the index, -1 = absent
+    const unsigned long long *row_meta;    // [nq] idf (2^-22 fixed point) << 2 | last row of its node << 1 | last row of its edge
+    const uint64_t *q_rows;                // [n_queries + 1] row ranges of the queries
+    const float *penalty;                  // [S]
+    uint32_t nq, n_queries, S, first_id, NT, NC, tile_log2;
+    uint4 *ranges;                         // [NC][nq] byte range of (row, cell): first byte lo / hi, bytes (0: decoded with an earlier cell of the tile), id before the first posting
+    uint2 *compact;                        // [n_queries][NT][tile] (structure, ranking key) of the touched structures, any order
+    uint32_t *ccount;                      // [n_queries][NT] entries of compact
+    uint32_t *ghist;                       // [n_queries][QT_BINS], zero on entry and left zero
+    qt_state *state; qt_aux *aux;          // [n_queries]
+    void *out; uint32_t cap;               // fd_count_rec [n_queries][cap]
+    unsigned long long *dbg;               // optional (FDGPU_QT_DBG): [16] phase durations summed over the workgroups
+};
+void fd_launch_ck_count(const uint64_t *offsets, uint64_t H, uint32_t NC, uint32_t *cnt, hipStream_t st);
+void fd_launch_ck_fill(const uint64_t *offsets, const uint8_t *value, uint64_t H, uint32_t NC, uint32_t S, uint32_t first_id, const uint64_t *ent_off,
+                       unsigned long long *meta, void *ent, hipStream_t st);
+void fd_launch_qt_plan(const qt_args &A, hipStream_t st);
+void fd_launch_qt_score(const qt_args &A, hipStream_t st);
+void fd_launch_qt_select(const qt_args &A, uint32_t top_n, void *sorted, hipStream_t st);
+
 void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,
                                uint64_t nq, uint64_t *lengths, long long *kidx, uint32_t *nseg, uint64_t *wstart, uint64_t *scan_tmp, uint64_t *total,
                                hipStream_t st);
 void fd_launch_index_lens(const uint64_t *offsets, const uint8_t *value, uint64_t H, uint32_t *lens, hipStream_t st);
 void fd_launch_posting_lookup(const uint32_t *hashes, const uint64_t *offsets, const uint32_t *lens, uint64_t H, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths,
-                              uint32_t *nseg, hipStream_t st);
+                              uint32_t *nseg, long long *kidx, hipStream_t st);
 void fd_launch_cq_plan(const cq_args &A, long long *kidx, uint32_t *nseg, hipStream_t st);
 void fd_launch_cq_seg(const cq_args &A, const long long *kidx, const uint64_t *wstart, uint32_t *segsum, uint64_t n_items, bool split,
                       hipStream_t st);

@@ -1,0 +1,686 @@
+// k_qtile.hip — motif-batch scoring without the occupancy matrix: posting lists entered per STRUCTURE TILE, scores kept in LDS.
+//
+// Replaces, for batches of motif queries with a top-N selection, the k_cq_seg / k_cq_rows_keys / k_topn_*_dense chain of k_query.hip
+// (count_query, src/controller/count_query.rs:82-220, followed by the candidate selection of src/cli/workflows/query_pdb.rs:404-411).
+// That chain wrote one occupancy row per query hash (rows x S/8 bytes), read it twice and wrote / re-read one ranking key per structure:
+// 5-7x the bytes SURVEY §8(d) counts for a query.  Here a workgroup owns (query, tile of 16,384 structures):
+//   * the index carries CHECKPOINTS (fd_index_checkpoints, built once per index like the posting lengths): for every list long enough,
+//     the byte position and the preceding id at every 2^j-th boundary of 8,192 ids — a delta stream can be entered there.  The on-disk
+//     format is untouched (the table is derived, device-only);
+//   * k_qt_plan turns (row, tile) into a byte range of the row's posting list; k_qt_score<false> decodes the tile's ranges 16 bytes per
+//     lane (lane-local varint decode with a 4-byte look-back, one wave scan per 1 KB instead of one per 64 bytes) and adds
+//     count << 46 | idf into the tile's 128 KB of LDS accumulators with ds_add_u64 — postings are read once, nothing else is written
+//     but (structure, ranking key) of the TOUCHED structures (8 bytes each, the 8·T of §8(d)) and a 2,048-bin histogram per query;
+//   * k_qt_thr / k_qt_hist2 find the key threshold of the top N (bins of 1.5 % relative width: the second level runs only when the
+//     threshold bin holds more than the selection's slack);
+//   * k_qt_score<true> decodes the same ranges again for the SURVIVORS only (a bitmap of the tile + ranks): their (row, structure)
+//     bits go into LDS, and match / edge / node counts and the exact idf sum follow from the rows in (node, partner) order exactly as
+//     k_topn_emit_dense derived them;
+//   * k_topn_sort ranks the survivors (unchanged).
+// Arithmetic (fixed-point idf sums, the ranking key, the record) is the arithmetic of k_query.hip: same bits.
+#include <algorithm>
+#include "fdgpu_internal.h"
+
+#define QT_IDF_SCALE 4194304.0 /* 2^22 */
+#define QT_CNT_SHIFT 46
+#define QT_SUM_MASK ((1ull << QT_CNT_SHIFT) - 1ull)
+struct qt_rec { uint32_t nid, total_match_count, node_count, edge_count; float idf; };      // = fd_count_rec
+
+__device__ __forceinline__ uint32_t qt_order_key(float v) {
+    uint32_t b = __float_as_uint(v + 0.0f);   // -0 -> +0
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+// first selection level: 2,048 bins over the order-preserving key; bins 1..2046 are 2^17 keys wide (64 per binade: 1.5 % relative
+// width) from 2^-16 up, bin 0 holds everything below (idf 0, negative penalties), bin 2047 everything from ~2^16 up
+#define QT_K0 0xB7800000u
+__device__ __forceinline__ uint32_t qt_bin(uint32_t key) {
+    if (key < QT_K0) return 0u;
+    const uint32_t b = ((key - QT_K0) >> 17) + 1u;
+    return b < (QT_BINS - 1u) ? b : (QT_BINS - 1u);
+}
+__device__ __forceinline__ uint32_t qt_edge(uint32_t bin) { return bin ? QT_K0 + ((bin - 1u) << 17) : 0u; }
+__device__ __forceinline__ uint32_t qt_shift2(uint32_t bin) { return bin == 0u ? 21u : bin == QT_BINS - 1u ? 20u : 6u; }
+
+// ------------------------------------------------------------------ checkpoints of an index
+// entries of list k: stride 2^j cells (one cell = 2^QT_CELL_LOG2 structure ids), n_e = ceil(NC / 2^j) chunks, the boundaries 1..n_e-1
+// stored as (byte offset of the first varint whose id falls at or behind the boundary, id of the posting before it).  j is the
+// smallest stride that leaves >= 48 bytes of postings per chunk on average: the table stays below a sixth of the posting bytes.
+__device__ __forceinline__ uint32_t qt_stride(uint64_t bytes, uint32_t NC, uint32_t *n_e) {
+    uint32_t j = 0;
+    for (;; ++j) {
+        const uint32_t ne = (uint32_t)(((uint64_t)NC + (1ull << j) - 1ull) >> j);
+        if (ne <= 1u || bytes >= 48ull * ne) { *n_e = ne ? ne : 1u; return j; }
+    }
+}
+__global__ void k_ck_count(const uint64_t *__restrict__ offsets, uint64_t H, uint32_t NC, uint32_t *__restrict__ cnt) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= H) return;
+    uint32_t ne;
+    (void)qt_stride(offsets[k + 1] - offsets[k], NC, &ne);
+    cnt[k] = ne - 1u;
+}
+__global__ __launch_bounds__(256) void k_ck_fill(const uint64_t *__restrict__ offsets, const uint8_t *__restrict__ value, uint64_t H, uint32_t NC, uint32_t S,
+                                                 uint32_t first_id, const uint64_t *__restrict__ ent_off, unsigned long long *__restrict__ meta,
+                                                 uint2 *__restrict__ ent) {
+    const uint64_t k = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= H) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t b0 = offsets[k], b1 = offsets[k + 1];
+    uint32_t n_e;
+    const uint32_t j = qt_stride(b1 - b0, NC, &n_e);
+    const uint64_t eoff = ent_off[k];
+    if (lane == 0) meta[k] = eoff | ((unsigned long long)j << 56);
+    if (n_e <= 1u) return;
+    uint2 *e = ent + eoff;         // e[b - 1] = boundary b
+    auto entry_of = [&](uint32_t id) -> uint32_t {
+        if (id < first_id) return 0u;
+        const uint32_t rel = id - first_id;
+        return rel >= S ? n_e : ((rel >> QT_CELL_LOG2) >> j);
+    };
+    uint32_t run_id = 0, carry_val = 0, carry_shift = 0, e_last = 0;
+    uint64_t pend_start = b0;      // where the varint that straddles into the next block began
+    for (uint64_t base = b0; base < b1; base += FD_WAVE) {
+        const uint64_t p = base + lane;
+        const bool in = p < b1;
+        const uint32_t byte = in ? value[p] : 0x80u;
+        const bool term = in && !(byte & 0x80u);
+        const uint64_t tm = __ballot(term);
+        const uint64_t below = tm & ((1ull << lane) - 1ull);
+        const int prev_t = below ? 63 - __clzll(below) : -1;
+        const uint32_t len_here = lane - (uint32_t)(prev_t + 1) + 1;
+        uint32_t v = 0;
+        const uint32_t pay = byte & 0x7fu;
+#pragma unroll
+        for (int back = 4; back >= 0; --back) {
+            const uint32_t pb = __shfl(pay, (int)lane - back, FD_WAVE);
+            if ((uint32_t)back < len_here) v |= pb << (7u * (len_here - 1u - (uint32_t)back));
+        }
+        if (term && prev_t < 0) v = carry_val | (v << carry_shift);
+        uint32_t s2 = term ? v : 0u;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(s2, off, FD_WAVE);
+            if ((int)lane >= off) s2 += t;
+        }
+        const uint32_t id = run_id + s2;
+        const uint32_t ec = entry_of(id);
+        // the posting before this one: the terminator lane below, or the last posting of the blocks before
+        const uint32_t id_prev_l = (uint32_t)__shfl((int)id, prev_t < 0 ? 0 : prev_t, FD_WAVE);
+        const uint32_t ec_prev_l = (uint32_t)__shfl((int)ec, prev_t < 0 ? 0 : prev_t, FD_WAVE);
+        const uint32_t id_prev = prev_t < 0 ? run_id : id_prev_l;
+        const uint32_t ec_prev = prev_t < 0 ? e_last : ec_prev_l;
+        if (term && ec > ec_prev) {
+            const uint64_t start = prev_t < 0 ? pend_start : base + (uint64_t)prev_t + 1ull;
+            const uint32_t hi = ec < n_e ? ec : n_e - 1u;
+            for (uint32_t b = ec_prev + 1u; b <= hi; ++b) e[b - 1u] = make_uint2((uint32_t)(start - b0), id_prev);
+        }
+        if (tm) {
+            const int last_t = 63 - __clzll(tm);
+            run_id = (uint32_t)__shfl((int)id, last_t, FD_WAVE);
+            e_last = (uint32_t)__shfl((int)ec, last_t, FD_WAVE);
+            pend_start = base + (uint64_t)last_t + 1ull;
+            const uint32_t tail = 63u - (uint32_t)last_t;
+            uint32_t pv = 0;
+            for (uint32_t t2 = 0; t2 < tail && t2 < 5; ++t2) pv |= (uint32_t)__shfl((int)pay, last_t + 1 + (int)t2, FD_WAVE) << (7u * t2);
+            carry_val = pv; carry_shift = 7u * tail;
+        }
+    }
+    // boundaries behind the last posting: empty chunks at the list's end
+    for (uint32_t b = e_last + 1u + lane; b <= n_e - 1u; b += FD_WAVE) e[b - 1u] = make_uint2((uint32_t)(b1 - b0), run_id);
+}
+void fd_launch_ck_count(const uint64_t *offsets, uint64_t H, uint32_t NC, uint32_t *cnt, hipStream_t st) {
+    if (H) hipLaunchKernelGGL(k_ck_count, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, st, offsets, H, NC, cnt);
+}
+void fd_launch_ck_fill(const uint64_t *offsets, const uint8_t *value, uint64_t H, uint32_t NC, uint32_t S, uint32_t first_id, const uint64_t *ent_off,
+                       unsigned long long *meta, void *ent, hipStream_t st) {
+    if (H) hipLaunchKernelGGL(k_ck_fill, dim3((unsigned)((H + 3) / 4)), dim3(256), 0, st, offsets, value, H, NC, S, first_id, ent_off, meta, (uint2 *)ent);
+}
+
+// ------------------------------------------------------------------ (row, cell) -> byte range
+// ranges[cell * nq + r] = {first byte (absolute, 64 bits), bytes, id before the first posting}: the piece of row r's list that the
+// checkpoints delimit around the cell.  A list whose entries are 2^j cells apart gives the same piece for all cells of an entry: it is
+// handed to the FIRST of them inside the tile, the others get none — a tile decodes every piece once, and no piece is longer than the
+// postings of max(2^j, 1) cells (a wavefront step or two even for the densest lists).
+__global__ void k_qt_plan(qt_args A) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (uint64_t)A.nq * A.NC) return;
+    const uint32_t cell = (uint32_t)(g / A.nq), r = (uint32_t)(g % A.nq);
+    uint4 out = make_uint4(0u, 0u, 0u, 0u);
+    const long long k = A.kidx[r];
+    if (k >= 0) {
+        const uint64_t b0 = A.offsets[k], len = A.offsets[k + 1] - b0;
+        const unsigned long long m = A.ck_meta[k];
+        const uint32_t j = (uint32_t)(m >> 56);
+        const uint2 *e = A.ck_ent + (m & ((1ull << 56) - 1ull));
+        const uint32_t n_e = (uint32_t)(((uint64_t)A.NC + (1ull << j) - 1ull) >> j);
+        const uint32_t cpt_log2 = A.tile_log2 - QT_CELL_LOG2;
+        const uint32_t tile_cell0 = (cell >> cpt_log2) << cpt_log2;
+        const uint32_t e0 = cell >> j;
+        const uint32_t first_cell = (e0 << j) > tile_cell0 ? (e0 << j) : tile_cell0;       // the entry's first cell inside this tile
+        if (cell == first_cell) {
+            uint32_t sb = 0, prev = 0;
+            if (e0 && n_e > 1u) { const uint2 x = e[e0 - 1u]; sb = x.x; prev = x.y; }
+            const uint64_t eb = (e0 + 1u >= n_e || n_e <= 1u) ? len : (uint64_t)e[e0].x;
+            const uint64_t p = b0 + sb;
+            out = make_uint4((uint32_t)p, (uint32_t)(p >> 32), (uint32_t)(eb - sb), prev);
+        }
+    }
+    A.ranges[g] = out;
+}
+
+// ------------------------------------------------------------------ tile scoring
+// inclusive prefix sum over the wavefront in six DPP adds (row_shr 1/2/4/8 inside the rows of 16 lanes, then row_bcast:15 / row_bcast:31
+// carry the row totals across) — __shfl_up costs a ds_bpermute round trip per step
+__device__ __forceinline__ uint32_t qt_wave_incl(uint32_t v, uint32_t /*lane*/) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+// exclusive scan over the workgroup's NTHR values (two barriers); s_w: NTHR / 64 words of LDS
+template <int NTHR>
+__device__ __forceinline__ uint32_t qt_block_excl(uint32_t v, uint32_t tid, uint32_t *s_w, uint32_t *total) {
+    const uint32_t lane = tid & 63u, wv = tid >> 6;
+    const uint32_t incl = qt_wave_incl(v, lane);
+    if (lane == 63u) s_w[wv] = incl;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < NTHR / 64; ++k) { const uint32_t x = s_w[k]; pre += k < wv ? x : 0u; tot += x; }
+    __syncthreads();
+    *total = tot;
+    return pre + incl - v;
+}
+typedef unsigned int qt_u32x4 __attribute__((ext_vector_type(4)));
+struct qt_step { qt_u32x4 w; uint32_t c, pstart, nby, rel; };
+
+// groups (runs of rows that end at a set bit of `ends`) holding at least one set bit of `m`, one 32-row word of a longer row list:
+// adding the non-end hits to the non-end positions lets a hit's carry run up to its group's end bit; carry = the group straddles the word
+__device__ __forceinline__ uint32_t qt_groups_hit(uint32_t m, uint32_t ends, uint32_t valid, uint32_t &carry) {
+    const unsigned long long sum = (unsigned long long)(m & ~ends) + (unsigned long long)(~ends & valid) + carry;
+    carry = (uint32_t)(sum >> 32);
+    return (uint32_t)__popc((((uint32_t)sum) & ends) | (m & ends));
+}
+
+// RICH = false: scores of every structure of the tile (pass A).  RICH = true: the records of the survivors (pass B).
+// TL2: log2 structures per tile; NTHR threads; RB rows planned per batch; RBW words of row bits (pass B)
+template <bool RICH, int TL2, int NTHR, int RB, int RBW>
+__global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
+    constexpr uint32_t TILE = 1u << TL2;
+    __shared__ unsigned long long s_acc[RICH ? 1 : TILE + FD_WAVE];       // A: count << 46 | idf sum per structure of the tile (+ a slot per lane for adds of nothing)
+    __shared__ uint32_t s_hist[RICH ? 1 : QT_BINS / 2];
+    __shared__ uint32_t s_bm[RICH ? TILE / 32 : 1], s_rank[RICH ? TILE / 32 : 1], s_rowbits[RICH ? RBW : 1];      // B: survivors, their ranks, their row bits
+    __shared__ unsigned long long s_meta[RICH ? QT_MAX_ROWS : 1];
+    __shared__ uint32_t s_eend[RICH ? QT_MAX_ROWS / 32 : 1], s_nend[RICH ? QT_MAX_ROWS / 32 : 1];      // B: rows that end an edge / a node
+    __shared__ unsigned long long s_byte0[RB], s_add[RB];
+    __shared__ uint32_t s_P[RB + 1], s_nbytes[RB], s_prev[RB];
+    __shared__ uint16_t s_units[RB];
+    __shared__ uint32_t s_w[NTHR / 64];
+    __shared__ uint32_t s_mark[NTHR / 4];         // 64 bytes per wavefront: first lanes of the rows that begin inside a step
+    __shared__ uint32_t s_nheavy, s_nlight, s_ucur, s_n, s_cnt, s_base;
+    __shared__ uint32_t s_dbg[8];
+    // (query, tile) of the workgroup, tiles of a query on consecutive workgroups = spread over the XCDs (all tiles of a query on ONE XCD
+    // measured 25 % slower: the queries' weights differ and the XCDs finish apart)
+    const uint32_t wg = blockIdx.x;
+    if (wg >= A.NT * A.n_queries) return;
+    const uint32_t t = wg % A.NT, q = wg / A.NT, tid = threadIdx.x, lane = tid & 63u;
+    unsigned long long tstamp = A.dbg ? wall_clock64() : 0ull;
+    auto stamp = [&](int k) {      // FDGPU_QT_DBG: phase durations of the workgroup's first thread, summed over the launch (100 MHz ticks)
+        if (A.dbg && tid == 0) { const unsigned long long now = wall_clock64(); atomicAdd(&A.dbg[(RICH ? 8 : 0) + k], now - tstamp); tstamp = now; }
+    };
+    if (A.dbg && tid < 8) s_dbg[tid] = 0;
+    const uint64_t r0 = A.q_rows[q];
+    const uint32_t nrows = (uint32_t)(A.q_rows[q + 1] - r0);
+    const uint32_t tile_lo = t << TL2;
+    const uint32_t tile_lim = A.S - tile_lo < TILE ? A.S - tile_lo : TILE;
+    const uint32_t tile_id0 = A.first_id + tile_lo;
+    const uint64_t cbase = ((uint64_t)q * A.NT + t) << TL2;
+    // work entries of the tile: (cell of the tile, row), cell-major — entry e = cell e / nrows, row e % nrows
+    constexpr uint32_t CPT = 1u << (TL2 - QT_CELL_LOG2);
+    const uint32_t cell0 = t * CPT, ncell = A.NC - cell0 < CPT ? A.NC - cell0 : CPT;
+    const uint32_t n_ent = nrows * ncell;
+    auto range_of = [&](uint32_t e) -> uint4 { return A.ranges[(uint64_t)(cell0 + e / nrows) * A.nq + r0 + e % nrows]; };
+    // the first batch's ranges are requested before anything else: their latency hides behind the set-up below
+    uint4 rg0 = make_uint4(0u, 0u, 0u, 0u);
+    unsigned long long rm0 = 0ull;
+    if (tid < n_ent && tid < RB) { rg0 = range_of(tid); if (!RICH) rm0 = A.row_meta[r0 + tid % nrows]; }
+    uint32_t n_surv = 0, wpr = 1, per_round = 1, n_rounds = 1, out_base = 0;
+    if (!RICH) {
+        for (uint32_t k = tid; k < TILE; k += NTHR) s_acc[k] = 0ull;
+        for (uint32_t k = tid; k < QT_BINS / 2; k += NTHR) s_hist[k] = 0u;
+        if (tid == 0) s_cnt = 0;
+    } else {
+        // the tile's (structure, key) list: its first entries are requested before its length is known (the buffer holds a full tile)
+        constexpr int SPEC = (TILE / NTHR) < 8 ? (TILE / NTHR) : 8;
+        uint2 x[SPEC];
+#pragma unroll
+        for (int u = 0; u < SPEC; ++u) x[u] = A.compact[cbase + u * NTHR + tid];
+        const uint32_t n = A.ccount[(uint64_t)q * A.NT + t];
+        const uint32_t thr = A.state[q].thr_key;
+        for (uint32_t k = tid; k < TILE / 32; k += NTHR) s_bm[k] = 0u;
+        for (uint32_t k = tid; k < QT_MAX_ROWS / 32; k += NTHR) { s_eend[k] = 0u; s_nend[k] = 0u; }
+        __syncthreads();
+        for (uint32_t k = tid; k < nrows; k += NTHR) {
+            const unsigned long long m = A.row_meta[r0 + k];
+            s_meta[k] = m;
+            if (m & 1ull) atomicOr(&s_eend[k >> 5], 1u << (k & 31u));
+            if (m & 2ull) atomicOr(&s_nend[k >> 5], 1u << (k & 31u));
+        }
+#pragma unroll
+        for (int u = 0; u < SPEC; ++u)
+            if ((uint32_t)u * NTHR + tid < n && x[u].y >= thr) { const uint32_t i = x[u].x - tile_lo; atomicOr(&s_bm[i >> 5], 1u << (i & 31u)); }
+        for (uint32_t e = SPEC * NTHR + tid; e < n; e += NTHR) {
+            const uint2 y = A.compact[cbase + e];
+            if (y.y >= thr) { const uint32_t i = y.x - tile_lo; atomicOr(&s_bm[i >> 5], 1u << (i & 31u)); }
+        }
+        __syncthreads();
+        uint32_t run = 0;
+        for (uint32_t w0 = 0; w0 < TILE / 32; w0 += NTHR) {
+            uint32_t tot;
+            const uint32_t pc = w0 + tid < TILE / 32 ? (uint32_t)__popc(s_bm[w0 + tid]) : 0u;
+            const uint32_t ex = qt_block_excl<NTHR>(pc, tid, s_w, &tot);
+            if (w0 + tid < TILE / 32) s_rank[w0 + tid] = run + ex;
+            run += tot;
+        }
+        n_surv = run;
+        if (!n_surv) return;
+        wpr = (nrows + 31u) >> 5;
+        per_round = (uint32_t)RBW / wpr;            // >= 1: the launcher keeps nrows <= QT_MAX_ROWS
+        n_rounds = (n_surv + per_round - 1u) / per_round;
+        if (tid == 0) out_base = atomicAdd(&A.state[q].count, n_surv);       // the answer is needed when the records are written
+    }
+    __syncthreads();
+    stamp(0);
+    for (uint32_t round = 0; round < n_rounds; ++round) {
+        const uint32_t s_lo = round * per_round;
+        if (RICH) {
+            const uint32_t nw = (n_surv - s_lo < per_round ? n_surv - s_lo : per_round) * wpr;
+            for (uint32_t k = tid; k < nw; k += NTHR) s_rowbits[k] = 0u;
+            __syncthreads();
+        }
+        for (uint32_t ra = 0; ra < n_ent; ra += RB) {
+            // ---- the batch's ranges: empty ones dropped, slot starts by one scan (slots in the low 22 bits, entries above)
+            const uint32_t nb = n_ent - ra < RB ? n_ent - ra : RB;
+            uint4 rg = rg0;
+            unsigned long long rm = rm0;
+            if (ra || round) {
+                rg = make_uint4(0u, 0u, 0u, 0u);
+                if (tid < nb) { rg = range_of(ra + tid); if (!RICH) rm = A.row_meta[r0 + (ra + tid) % nrows]; }
+            }
+            const uint32_t ns = tid < nb ? (rg.z + 15u) >> 4 : 0u;
+            uint32_t tot;
+            const uint32_t ex = qt_block_excl<NTHR>(ns ? (ns | (1u << 22)) : 0u, tid, s_w, &tot);
+            if (ns) {
+                const uint32_t c = ex >> 22;
+                s_P[c] = ex & 0x3fffffu;
+                s_byte0[c] = (unsigned long long)rg.x | ((unsigned long long)rg.y << 32);
+                s_nbytes[c] = rg.z; s_prev[c] = rg.w;
+                s_add[c] = RICH ? (unsigned long long)((ra + tid) % nrows) : ((1ull << QT_CNT_SHIFT) | (rm >> 2));
+            }
+            if (tid == 0) { s_n = tot >> 22; s_P[tot >> 22] = tot & 0x3fffffu; s_nheavy = 0; s_nlight = 0; s_ucur = 0; }
+            __syncthreads();
+            stamp(1);
+            const uint32_t n = s_n;
+            // ---- units: the rows that START in one 64-slot window, processed by one wavefront (a row longer than the window stays whole);
+            // units that open with a multi-step row are handed out first (from the front of s_units, the others from its back)
+            if (tid < n && (tid == 0 || (s_P[tid - 1] >> 6) != (s_P[tid] >> 6))) {
+                if (s_P[tid + 1] - s_P[tid] > FD_WAVE) s_units[atomicAdd(&s_nheavy, 1u)] = (uint16_t)tid;
+                else s_units[RB - 1u - atomicAdd(&s_nlight, 1u)] = (uint16_t)tid;
+            }
+            __syncthreads();
+            stamp(2);
+            const uint32_t n_heavy = s_nheavy, n_units = n_heavy + s_nlight;
+            const unsigned long long t_loop = A.dbg ? wall_clock64() : 0ull;
+            uint32_t my_units = 0, my_steps = 0;
+            for (;;) {
+                uint32_t ui = 0;
+                if (lane == 0) ui = atomicAdd(&s_ucur, 1u);
+                ui = (uint32_t)__builtin_amdgcn_readfirstlane((int)ui);
+                if (ui >= n_units) break;
+                ++my_units;
+                const uint32_t c0 = s_units[ui < n_heavy ? ui : RB - 1u - (ui - n_heavy)], u = s_P[c0] >> 6;
+                const uint32_t pc = c0 + 1u + lane;
+                const uint64_t outm = __ballot(pc >= n || (s_P[pc < n ? pc : n] >> 6) != u);
+                const uint32_t c1 = c0 + 1u + (uint32_t)__builtin_ctzll(outm);
+                const uint32_t s_beg = s_P[c0], s_end = s_P[c1];
+                // a step = 64 slots of 16 bytes; the next step's bytes are requested before this step's are decoded.  The row of a
+                // slot: the rows that start inside the step's window mark their first lane (bytes in the wavefront's scratch), a ballot
+                // of the marks + popcount below the lane counts the rows begun so far
+                // (volatile: the lanes talk to each other through these bytes — without it the compiler forwards a lane's own 0 to its read)
+                volatile uint8_t *mark = reinterpret_cast<volatile uint8_t *>(s_mark) + (tid >> 6) * FD_WAVE;
+                uint32_t c_next = c0;          // first row that has not begun yet
+                auto prep = [&](uint32_t base, qt_step &X) {
+                    mark[lane] = 0;
+                    if (c_next + lane < c1) { const uint32_t pos = s_P[c_next + lane] - base; if (pos < FD_WAVE) mark[pos] = 1; }
+                    const uint64_t begun = __ballot(mark[lane] != 0);
+                    const uint32_t c = c_next - 1u + (uint32_t)__popcll(begun & ((2ull << lane) - 1ull));
+                    c_next += (uint32_t)__popcll(begun);
+                    const bool active = base + lane < s_end;
+                    const uint32_t s = active ? base + lane : s_end - 1u;
+                    X.c = c; X.pstart = s_P[c]; X.rel = s - X.pstart;
+                    const uint32_t nbytes = s_nbytes[c];
+                    X.nby = active ? (nbytes - 16u * X.rel < 16u ? nbytes - 16u * X.rel : 16u) : 0u;
+                    __builtin_memcpy(&X.w, A.value + s_byte0[c] + 16ull * X.rel, 16);
+                };
+                qt_step cur, nxt;
+                prep(s_beg, cur);
+                uint32_t carry = 0, prev_last = 0;
+                for (uint32_t base = s_beg; base < s_end; base += FD_WAVE) {
+                    const bool more = base + FD_WAVE < s_end;
+                    ++my_steps;
+                    if (more) prep(base + FD_WAVE, nxt);
+                    // ---- lane-local decode: the varints that END in these 16 bytes; the leading bytes of the first are the tail of the
+                    // slot before — the lane below's last four bytes (lane 0: lane 63 of the step before)
+                    uint32_t lb = (uint32_t)__shfl_up((int)cur.w[3], 1, FD_WAVE);
+                    if (lane == 0) lb = prev_last;
+                    prev_last = (uint32_t)__builtin_amdgcn_readlane((int)cur.w[3], 63);
+                    uint32_t cv = 0, sh = 0;
+                    if (cur.rel) {
+                        const uint32_t tb = ~lb & 0x80808080u;
+                        const uint32_t kc = tb ? (uint32_t)__clz((int)tb) >> 3 : 4u;         // continuation bytes at the end of the look-back
+                        if (kc) {
+                            const uint32_t x = (lb >> (8u * (4u - kc))) & 0x7f7f7f7fu;
+                            cv = (x & 0x7fu) | ((x >> 1) & 0x3f80u) | ((x >> 2) & 0x1fc000u) | ((x >> 3) & 0xfe00000u);
+                            sh = 7u * kc;
+                        }
+                    }
+                    uint32_t v[16], T = 0, D = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const uint32_t b = (cur.w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                        cv |= (b & 0x7fu) << (sh & 31u);
+                        const bool term = (uint32_t)i < cur.nby && !(b & 0x80u);
+                        v[i] = term ? cv : 0u;
+                        T |= term ? (1u << i) : 0u;
+                        D += v[i];
+                        sh = term ? 0u : sh + 7u;
+                        cv = term ? 0u : cv;
+                    }
+                    // ---- ids: prefix of the lane sums inside the row, from the row's checkpoint id (or the step before)
+                    const uint32_t incl = qt_wave_incl(D, lane);
+                    const uint32_t fl = cur.pstart > base ? cur.pstart - base : 0u;            // the row's first lane in this step
+                    const uint32_t pre = (uint32_t)__shfl((int)(incl - D), (int)fl, FD_WAVE);
+                    const uint32_t row_base = cur.pstart < base ? carry : s_prev[cur.c];
+                    const uint32_t id_first = row_base + (incl - D) - pre;
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)(id_first + D), 63);
+                    const unsigned long long add = s_add[cur.c];
+                    uint32_t id = id_first;
+                    if (!RICH) {
+                        // one returning 64-bit LDS add per posting, eight in flight (lanes without a posting add 0 to a slot of their own);
+                        // a count of 0 before the add = the structure's first posting of this query
+                        uint32_t first = 0;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            unsigned long long old[8];
+                            uint32_t okm = 0;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                id += v[h * 8 + i];
+                                const uint32_t x = id - tile_id0;
+                                const bool ok = ((T >> (h * 8 + i)) & 1u) && x < tile_lim;
+                                okm |= ok ? (1u << i) : 0u;
+                                old[i] = atomicAdd(&s_acc[ok ? x : TILE + lane], ok ? add : 0ull);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) if (((okm >> i) & 1u) && (old[i] >> QT_CNT_SHIFT) == 0ull) first |= 1u << (h * 8 + i);
+                        }
+                        // the touched structures are listed as they are met: the slots of a step's first hits by one LDS atomic per wavefront
+                        const uint32_t nf = (uint32_t)__popc(first), fi = qt_wave_incl(nf, lane);
+                        const uint32_t ftot = (uint32_t)__builtin_amdgcn_readlane((int)fi, 63);
+                        if (ftot) {
+                            uint32_t fb = 0;
+                            if (lane == 0) fb = atomicAdd(&s_cnt, ftot);
+                            uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb) + fi - nf;
+                            id = id_first;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                id += v[i];
+                                if ((first >> i) & 1u) A.compact[cbase + pos++].x = id - A.first_id;
+                            }
+                        }
+                    } else {
+                        // survivors are rare: the bitmap words of all sixteen postings first, the row bits only where one is set
+                        uint32_t hit = 0;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            id += v[i];
+                            const uint32_t x = id - tile_id0;
+                            const bool ok = ((T >> i) & 1u) && x < tile_lim;
+                            const uint32_t wd = s_bm[ok ? x >> 5 : 0u];
+                            hit |= (ok && ((wd >> (x & 31u)) & 1u)) ? (1u << i) : 0u;
+                        }
+                        if (hit) {
+                            id = id_first;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                id += v[i];
+                                if ((hit >> i) & 1u) {
+                                    const uint32_t x = id - tile_id0, wd = s_bm[x >> 5];
+                                    const uint32_t rk = s_rank[x >> 5] + (uint32_t)__popc(wd & ((1u << (x & 31u)) - 1u)) - s_lo;
+                                    if (rk < per_round) atomicOr(&s_rowbits[rk * wpr + ((uint32_t)add >> 5)], 1u << ((uint32_t)add & 31u));
+                                }
+                            }
+                        }
+                    }
+                    if (more) cur = nxt;
+                }
+            }
+            if (A.dbg && lane == 0) {       // per wavefront: units, steps, time in the loop (LDS; the workgroup's first thread reports)
+                const uint32_t dt = (uint32_t)(wall_clock64() - t_loop);
+                atomicAdd(&s_dbg[0], my_units); atomicAdd(&s_dbg[1], my_steps); atomicMax(&s_dbg[2], dt); atomicAdd(&s_dbg[3], dt);
+                if (dt == 0xffffffffu) s_dbg[4] = 0;
+            }
+            stamp(3);
+            __syncthreads();
+            stamp(4);
+            if (A.dbg && tid == 0) {
+                unsigned long long *d = A.dbg + (RICH ? 24 : 16);
+                atomicAdd(&d[0], (unsigned long long)s_dbg[0]); atomicAdd(&d[1], (unsigned long long)s_dbg[1]); atomicAdd(&d[2], (unsigned long long)s_dbg[2]);
+                atomicAdd(&d[3], (unsigned long long)s_dbg[3]);
+                s_dbg[0] = 0; s_dbg[1] = 0; s_dbg[2] = 0; s_dbg[3] = 0;
+            }
+        }
+        if (RICH) {
+            // ---- the survivors' records, one survivor per thread: match count = set rows, edge / node counts = row groups with a set
+            // row (k_topn_emit_dense walked the rows in (node, partner) order for the same numbers), idf sum over the set rows
+            const uint32_t n_here = n_surv - s_lo < per_round ? n_surv - s_lo : per_round;
+            if (round == 0) { if (tid == 0) s_base = out_base; __syncthreads(); }
+            for (uint32_t k = tid; k < n_here; k += NTHR) {
+                const uint32_t rk = s_lo + k;
+                uint32_t lo = 0, hi = TILE / 32;         // the bitmap word that holds the survivor of rank rk: the last word with rank <= rk
+                while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_rank[mid] <= rk) lo = mid; else hi = mid; }
+                uint32_t bits = s_bm[lo];
+                for (uint32_t z = rk - s_rank[lo]; z; --z) bits &= bits - 1u;
+                const uint32_t i = lo * 32u + (uint32_t)__builtin_ctz(bits);
+                const float pen = A.penalty[tile_lo + i];
+                const uint32_t *rb = s_rowbits + k * wpr;
+                uint32_t cnt = 0, edges = 0, nodes = 0, ce = 0, cn = 0;
+                unsigned long long sum = 0;
+                for (uint32_t rw = 0; rw < wpr; ++rw) {
+                    uint32_t m = rb[rw];
+                    const uint32_t left = nrows - rw * 32u, valid = left >= 32u ? 0xffffffffu : (1u << left) - 1u;
+                    cnt += (uint32_t)__popc(m);
+                    edges += qt_groups_hit(m, s_eend[rw], valid, ce);
+                    nodes += qt_groups_hit(m, s_nend[rw], valid, cn);
+                    for (; m; m &= m - 1u) sum += s_meta[rw * 32u + (uint32_t)__builtin_ctz(m)] >> 2;
+                }
+                const uint32_t pos = s_base + rk;
+                if (pos < A.cap) {
+                    qt_rec rec;
+                    rec.nid = tile_lo + i + A.first_id; rec.total_match_count = cnt; rec.node_count = nodes; rec.edge_count = edges;
+                    rec.idf = (float)((double)sum * (1.0 / QT_IDF_SCALE)) * pen;      // count_query.rs:200 idf_sum *= nres^(-lp)
+                    ((qt_rec *)A.out)[(uint64_t)q * A.cap + pos] = rec;
+                }
+            }
+            __syncthreads();
+            stamp(5);
+        }
+    }
+    if (RICH) return;
+    // ---- pass A: ranking keys of the touched structures (listed in the order they were met), first histogram level
+    const uint32_t n_t = s_cnt;
+    for (uint32_t e0 = 0; e0 < n_t; e0 += 4 * NTHR) {       // four structures per thread in flight
+        uint32_t sid[4]; float pen[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t e = e0 + u * NTHR + tid; sid[u] = e < n_t ? A.compact[cbase + e].x : tile_lo; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pen[u] = A.penalty[sid[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t e = e0 + u * NTHR + tid;
+            if (e < n_t) {
+                const unsigned long long a = s_acc[sid[u] - tile_lo];
+                const uint32_t key = qt_order_key((float)((double)(a & QT_SUM_MASK) * (1.0 / QT_IDF_SCALE)) * pen[u]);
+                const uint32_t bin = qt_bin(key);
+                atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
+                A.compact[cbase + e].y = key;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < QT_BINS; k += NTHR) {
+        const uint32_t cn = (s_hist[k >> 1] >> ((k & 1u) * 16u)) & 0xffffu;
+        if (cn) atomicAdd(&A.ghist[(uint64_t)q * QT_BINS + k], cn);
+    }
+    if (tid == 0) A.ccount[(uint64_t)q * A.NT + t] = n_t;
+    stamp(5);
+}
+
+// ------------------------------------------------------------------ threshold
+// The key threshold of a query's top N from its first-level histogram: the highest bin b with (keys above b) + hist[b] >= top_n.  When
+// that many survivors fit the selection's slots the bin's lower edge is the threshold; else (rare: the cut falls into a crowd of nearly
+// equal keys) the workgroup splits the bin once more over the query's (structure, key) lists.  One workgroup per query; the table is left zero.
+__global__ __launch_bounds__(1024) void k_qt_thr(qt_args A, uint32_t top_n) {
+    __shared__ uint32_t hist[QT_BINS];
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t s_bin, s_above, s_at;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    uint32_t *h = A.ghist + (uint64_t)q * QT_BINS;
+    for (uint32_t k = tid; k < QT_BINS; k += 1024) { hist[k] = h[k]; h[k] = 0u; }
+    __syncthreads();
+    auto search = [&](uint32_t above0) {       // -> s_bin, s_above, s_at
+        if (tid < 256) { uint32_t mine = 0; for (int k = 0; k < 8; ++k) mine += hist[tid * 8 + k]; part[tid] = mine; }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t acc = above0;
+            int t = 255;
+            for (; t > 0; --t) { if (acc + part[t] >= top_n) break; acc += part[t]; }
+            int b = t * 8 + 7;
+            for (; b > t * 8; --b) { if (acc + hist[b] >= top_n) break; acc += hist[b]; }
+            s_bin = (uint32_t)b; s_above = acc; s_at = hist[b];
+        }
+        __syncthreads();
+    };
+    search(0u);
+    const uint32_t b1 = s_bin, above = s_above, edge = qt_edge(b1), sh2 = qt_shift2(b1);
+    uint32_t thr_key = edge;
+    if (above + s_at > A.cap) {       // block-uniform
+        __syncthreads();
+        for (uint32_t k = tid; k < QT_BINS; k += 1024) hist[k] = 0u;
+        __syncthreads();
+        for (uint32_t t = 0; t < A.NT; ++t) {
+            const uint32_t n = A.ccount[(uint64_t)q * A.NT + t];
+            const uint2 *e = A.compact + (((uint64_t)q * A.NT + t) << A.tile_log2);
+            for (uint32_t i = tid; i < n; i += 1024) {
+                const uint32_t key = e[i].y;
+                if (qt_bin(key) == b1) { const uint32_t s = (key - edge) >> sh2; atomicAdd(&hist[s < QT_BINS - 1u ? s : QT_BINS - 1u], 1u); }
+            }
+        }
+        __syncthreads();
+        search(above);
+        thr_key = edge + (s_bin << sh2);
+    }
+    if (tid == 0) { qt_state s; s.thr_bin = b1; s.above = above; s.thr_key = thr_key; s.count = 0; A.state[q] = s; }
+}
+
+// ------------------------------------------------------------------ ranking of the survivors
+// idf descending, ties by ascending structure id (query_pdb.rs:404-411), cut to top_n: bitonic sort of (inverted idf key << 32 | nid) with
+// the element's slot as payload, 1,024 threads x up to four elements in REGISTERS — partners 1..32 lanes away by shuffles, 1,024 / 2,048
+// elements away inside the thread; only the 64..512 strides go through LDS (14 barriers for 2,048 elements instead of 66).  A query
+// whose selection overflowed its slots (count > cap) is left to the host.
+#define QT_SORT_T 1024
+__global__ __launch_bounds__(QT_SORT_T) void k_qt_sort(const qt_rec *__restrict__ sel, uint32_t cap, const qt_state *__restrict__ st, uint32_t top_n,
+                                                        qt_rec *__restrict__ out) {
+    __shared__ unsigned long long s_k[4096];
+    __shared__ uint16_t s_i[4096];
+    const uint32_t q = blockIdx.x, cnt = st[q].count, tid = threadIdx.x;
+    if (cnt > cap || cnt == 0 || cnt > 4096u) return;
+    uint32_t n2 = 64;
+    while (n2 < cnt) n2 <<= 1;
+    const uint32_t E = n2 > 1024u ? n2 >> 10 : 1u;
+    const qt_rec *r = sel + (uint64_t)q * cap;
+    unsigned long long key[4];
+    uint32_t idx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t i = e * 1024u + tid;
+        key[e] = ~0ull; idx[e] = i;
+        if ((uint32_t)e < E && i < cnt) key[e] = ((unsigned long long)(~qt_order_key(r[i].idf)) << 32) | r[i].nid;
+    }
+    auto cx = [&](int e, uint32_t i, uint32_t K, uint32_t j, unsigned long long b, uint32_t bi) {
+        const bool up = (i & K) == 0u, low = (i & j) == 0u;
+        const unsigned long long a = key[e];
+        const bool take = (low == up) ? (b < a) : (b > a);
+        if (take) { key[e] = b; idx[e] = bi; }
+    };
+    for (uint32_t K = 2; K <= n2; K <<= 1)
+        for (uint32_t j = K >> 1; j > 0; j >>= 1) {
+            if (j >= 1024u) {          // partner inside the thread
+                if (j == 2048u) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const unsigned long long a = key[e], b = key[e + 2]; const uint32_t ai = idx[e], bi = idx[e + 2];
+                        cx(e, e * 1024u + tid, K, j, b, bi); cx(e + 2, (e + 2) * 1024u + tid, K, j, a, ai);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        if ((uint32_t)e >= E) break;
+                        const unsigned long long a = key[e], b = key[e + 1]; const uint32_t ai = idx[e], bi = idx[e + 1];
+                        cx(e, e * 1024u + tid, K, j, b, bi); cx(e + 1, (e + 1) * 1024u + tid, K, j, a, ai);
+                    }
+                }
+            } else if (j >= 64u) {     // partner in another wavefront
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if ((uint32_t)e < E) { s_k[e * 1024u + tid] = key[e]; s_i[e * 1024u + tid] = (uint16_t)idx[e]; }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if ((uint32_t)e < E) { const uint32_t i = e * 1024u + tid, l = i ^ j; cx(e, i, K, j, s_k[l], s_i[l]); }
+                __syncthreads();
+            } else {                   // partner in this wavefront
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if ((uint32_t)e < E) {
+                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key[e], (int)j, FD_WAVE), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key[e] >> 32), (int)j, FD_WAVE);
+                    const uint32_t bi = (uint32_t)__shfl_xor((int)idx[e], (int)j, FD_WAVE);
+                    cx(e, e * 1024u + tid, K, j, ((unsigned long long)hi << 32) | lo, bi);
+                }
+            }
+        }
+    const uint32_t m = cnt < top_n ? cnt : top_n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const uint32_t i = e * 1024u + tid; if ((uint32_t)e < E && i < m) out[(uint64_t)q * top_n + i] = r[idx[e]]; }
+}
+
+void fd_launch_qt_plan(const qt_args &A, hipStream_t st) {
+    const uint64_t n = (uint64_t)A.nq * A.NC;
+    if (n) hipLaunchKernelGGL(k_qt_plan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A);
+}
+// pass A: scores of every (query, tile) in LDS -> (structure, key) of the touched structures + first histogram level
+void fd_launch_qt_score(const qt_args &A, hipStream_t st) {
+    if (!A.n_queries || !A.S) return;
+    const dim3 g(A.NT * A.n_queries);
+    if (A.tile_log2 == 14) hipLaunchKernelGGL((k_qt_score<false, 14, 1024, 512, 1>), g, dim3(1024), 0, st, A);
+    else hipLaunchKernelGGL((k_qt_score<false, 13, 512, 256, 1>), g, dim3(512), 0, st, A);
+}
+// threshold -> pass B: survivors' records in A.out[query][cap] (any order; A.state[query].count of them, > cap: overflow) -> ranked
+// top_n records per query in sorted[query][top_n]
+void fd_launch_qt_select(const qt_args &A, uint32_t top_n, void *sorted, hipStream_t st) {
+    if (!A.n_queries || !A.S) return;
+    const dim3 g(A.NT * A.n_queries);
+    hipLaunchKernelGGL(k_qt_thr, dim3(A.n_queries), dim3(1024), 0, st, A, top_n);
+    if (A.tile_log2 == 14) hipLaunchKernelGGL((k_qt_score<true, 14, 1024, 512, 6144>), g, dim3(1024), 0, st, A);
+    else hipLaunchKernelGGL((k_qt_score<true, 13, 512, 256, 6144>), g, dim3(512), 0, st, A);
+    hipLaunchKernelGGL(k_qt_sort, dim3(A.n_queries), dim3(QT_SORT_T), 0, st, (const qt_rec *)A.out, A.cap, A.state, top_n, (qt_rec *)sorted);
+}

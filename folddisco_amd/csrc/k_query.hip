@@ -869,16 +869,18 @@ void fd_launch_index_lens(const uint64_t *offsets, const uint8_t *value, uint64_
     if (H) hipLaunchKernelGGL(k_index_lens, dim3((unsigned)((H + 3) / 4)), dim3(256), 0, st, offsets, value, H, lens);
 }
 __global__ void k_pl_lookup(const uint32_t *__restrict__ hashes, const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ lens, uint64_t H,
-                            const uint32_t *__restrict__ q_hash, uint64_t nq, unsigned long long *__restrict__ lengths, uint32_t *__restrict__ nseg) {
+                            const uint32_t *__restrict__ q_hash, uint64_t nq, unsigned long long *__restrict__ lengths, uint32_t *__restrict__ nseg,
+                            long long *__restrict__ kidx) {
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const int64_t k = find_hash(hashes, H, q_hash[q]);
+    kidx[q] = k;
     lengths[q] = k < 0 ? 0ull : (unsigned long long)lens[k];
     nseg[q] = k < 0 ? 0u : (uint32_t)((offsets[k + 1] - offsets[k] + CQ_SEG - 1) / CQ_SEG);
 }
 void fd_launch_posting_lookup(const uint32_t *hashes, const uint64_t *offsets, const uint32_t *lens, uint64_t H, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths,
-                              uint32_t *nseg, hipStream_t st) {
-    if (nq) hipLaunchKernelGGL(k_pl_lookup, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, hashes, offsets, lens, H, q_hash, nq, (unsigned long long *)lengths, nseg);
+                              uint32_t *nseg, long long *kidx, hipStream_t st) {
+    if (nq) hipLaunchKernelGGL(k_pl_lookup, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, hashes, offsets, lens, H, q_hash, nq, (unsigned long long *)lengths, nseg, kidx);
 }
 
 // kidx / nseg / wstart / scan_tmp / total: plan workspaces for nq hashes (k_cq_plan + exclusive scan)

@@ -272,6 +272,7 @@ typedef struct fd_query_map {   /* make_query_map output (src/controller/query.r
      * 2 KB scoring segments of every entry's OWN hash in that index — fdgpu_count_query_maps_top then scores without a second
      * posting-length pass and without asking the device for its work count */
     uint64_t *post_len; uint32_t *post_seg; uint64_t post_index_uid;
+    long long *post_kidx;       /* with post_len: position of every entry's hash in that index's hash array (-1: absent) — scoring skips its own search */
 } fd_query_map;
 /* qb = batch holding the query structure as structure 0; q_index[k] = residue index of the k-th query
  * residue (after parse_query_string + get_index / --serial-index resolution on the caller's side);

@@ -244,3 +244,54 @@ def test_whole_structure_query_at_human_scale(human):
     got = fq.retrieve(ctx, batch, None, cand, qm, qb)
     n = _check_matches(got, cand, ps, oq, om)
     assert n >= 20 and max(sum(1 for x in g["processed"] if x >= 0) for g in got) == b - a     # the structure matches itself entirely
+
+
+def test_tiled_scoring_equals_occupancy_rows(human, monkeypatch):
+    """The tiled scoring of motif batches (k_qtile.hip: posting lists entered at the index's checkpoints, scores in LDS, records for the
+    survivors by a second decode) against the occupancy-row path (FDGPU_QTILE=0) and against the ranked full list, byte for byte: two tiles
+    of structures, queries of 1 to 1,000 rows that mix the longest lists of the index (entered mid-way, many 1 KB steps per wavefront) with
+    short ones (decoded whole by every tile), more survivors than one round of row bits holds, a sub-range of the ids (first_id > 0,
+    ids beyond the range skipped like count_query.rs:133 skips them) and the threshold bin's second level (ties by construction)."""
+    import folddisco_amd as fd
+    from folddisco_amd.dist import rank_hits
+    ctx, ix, pen = human["ctx"], human["ix"], human["pen"]
+    v, h, o = human["export"]
+    rng = np.random.Generator(np.random.PCG64(2026))
+    lens_b = np.diff(o.astype(np.int64))
+    longest = np.argsort(lens_b)[-400:]
+    queries = []
+    for n in (1, 5, 44, 44, 200, 616, 1000):
+        k_long = min(n // 2, 40)
+        pick = np.concatenate([rng.choice(longest, size=k_long, replace=False), rng.choice(len(h), size=n - k_long, replace=False)])
+        qh = np.unique(h[pick]).astype(np.uint32)
+        queries.append((qh, rng.integers(0, 6, size=len(qh)).astype(np.uint32), rng.integers(0, 6, size=len(qh)).astype(np.uint32)))
+    queries.insert(2, (np.zeros(0, np.uint32),) * 3)
+    queries.append((np.array([0x3fffffff], np.uint32), np.zeros(1, np.uint32), np.ones(1, np.uint32)))      # absent hash only
+
+    def run(index, penalty, total, top_n, tiled, tile="13"):
+        monkeypatch.setenv("FDGPU_QTILE", "1" if tiled else "0")
+        monkeypatch.setenv("FDGPU_QT_TILE", tile)
+        return fd.count_query_batch(ctx, index, queries, penalty, total_structures=total, top_n=top_n)
+
+    full = run(ix, pen, HUMAN, 0, False)
+    assert max(len(f) for f in full) > 15000          # most of the tiles touched
+    for N in (1, 20, 1000, 3000):
+        a, a14, b = run(ix, pen, HUMAN, N, True), run(ix, pen, HUMAN, N, True, "14"), run(ix, pen, HUMAN, N, False)
+        for f, x, x14, y in zip(full, a, a14, b):
+            assert x.tobytes() == x14.tobytes() == y.tobytes() == rank_hits(f, N).tobytes(), N
+    # ties: a penalty of 1 makes the key a function of the matched rows alone — thousands of equal keys around the cut
+    one = np.ones_like(pen)
+    full1 = run(ix, one, HUMAN, 0, False)
+    for N in (50, 1000):
+        a = run(ix, one, HUMAN, N, True)
+        for f, x in zip(full1, a):
+            assert x.tobytes() == rank_hits(f, N).tobytes(), N
+    # a shard's view of the same bytes: ids [3000, 3000 + 17000) only
+    sub = fd.FolddiscoIndex.load(ctx, h, o, v, 17000, first_id=3000)
+    pen_s = pen[3000:20000].copy()
+    full_s = run(sub, pen_s, HUMAN, 0, False)
+    assert all((f["nid"] >= 3000).all() and (f["nid"] < 20000).all() for f in full_s if len(f))
+    for N in (10, 1000):
+        a = run(sub, pen_s, HUMAN, N, True)
+        for f, x in zip(full_s, a):
+            assert x.tobytes() == rank_hits(f, N).tobytes(), N
