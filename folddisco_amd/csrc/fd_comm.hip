@@ -461,7 +461,7 @@ extern "C" int fdgpu_sharded_count_query(fdgpu_ctx *c, fdgpu_comm *m, const fdgp
         local_rc = fd_count_query_batch_impl(c, ix, n_queries, koff.data(), kh.data(), kn.data(), ke.data(), kidf.data(), penalty, top_n, &loc, &loff, false, nullptr), dev.got = false;
     // 3. + 4. all-gather and global ranking
     rc = exchange(c, m, n_queries, top_n, local_rc, dev, loc, loff, out, out_off);
-    free(loc); free(loff);
+    fdgpu_free(loc); free(loff);
     return rc;
 }
 
@@ -496,7 +496,7 @@ extern "C" int fdgpu_sharded_count_query_maps(fdgpu_ctx *c, fdgpu_comm *m, const
         loc = l2; loff = o2; dev.got = false;
     }
     rc = exchange(c, m, n_queries, top_n, local_rc, dev, loc, loff, out, out_off);
-    free(loc); free(loff);
+    fdgpu_free(loc); free(loff);
     return rc;
 }
 

@@ -648,7 +648,7 @@ static std::vector<std::vector<uint32_t>> components(const Graph &g, size_t min_
 }
 }  // namespace
 
-extern "C" void fdgpu_matches_free(fd_match_rec *m, int32_t *residues) { free(m); free(residues); }
+extern "C" void fdgpu_matches_free(fd_match_rec *m, int32_t *residues) { fdgpu_free(m); fdgpu_free(residues); }
 
 
 // coordinates of all candidates in one launch + one copy (a hipMemcpy per candidate costs more than the pair scan)
@@ -811,7 +811,10 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         const size_t o_qt = 0, o_h = o_qt + up4(n_queries * (sizeof(rs_query_dev) / 4)), o_kf = o_h + up4(nh), o_sy = o_kf + up4(nh), o_qi = o_sy + up4((nh + 3) / 4),
                      o_qj = o_qi + up4(nmap), o_idf = o_qj + up4(nmap), o_idx = o_idf + up4(nmap), o_sq = o_idx + up4(nidx), o_cd = o_sq + up4(n_cand),
                      o_d0 = o_cd + up4(n_cand), words = o_d0 + up4(2 * FD_WAVE + 1) + 4;
-        std::vector<uint32_t> blk(words, 0);
+        // packed in the context's pinned staging buffer (the pair scan's own block has been copied and the stream synchronised since)
+        std::vector<uint32_t> blk_v;
+        uint32_t *blk = (uint32_t *)c->host_pinned(0, words * 4);
+        if (!blk) { blk_v.assign(words, 0); blk = blk_v.data(); }
         memcpy(&blk[o_qt], qt.data(), n_queries * sizeof(rs_query_dev));
         if (nh) { memcpy(&blk[o_h], t_hash.data(), nh * 4); memcpy(&blk[o_kf], t_kfirst.data(), nh * 4); }
         for (size_t k = 0; k < nh; ++k) ((uint8_t *)&blk[o_sy])[k] = (uint8_t)t_sym[k];
@@ -831,7 +834,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         HIPCHK(c, c->ws[WS_RS_KOFF].ensure((cap_prob + 1) * 8 + cap_prob * 4));
         HIPCHK(c, c->ws[WS_RS_SOL].ensure(cap_prob * 18 * 4));
         HIPCHK(c, c->ws[WS_RS_CNT].ensure(64));
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_RS_TAB].p, blk.data(), words * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_RS_TAB].p, blk, words * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemsetAsync(c->ws[WS_RS_CNT].p, 0, 64, st));
         const uint32_t *dblk = c->ws[WS_RS_TAB].as<uint32_t>();
         uint32_t *sg = c->ws[WS_RS_SEG].as<uint32_t>();
@@ -865,21 +868,27 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         auto D2 = t_now();
         if (dflags == 0) {
             const uint64_t nm = cnt_h[0], nprob = cnt_h[1] >> 40, npts = cnt_h[1] & ((1ull << 40) - 1ull), nres = cnt_h[2];
-            std::vector<rs_match_dev> hm(std::max<uint64_t>(nm, 1));
-            std::vector<int32_t> hres(std::max<uint64_t>(nres, 1));
-            std::vector<float> sol(std::max<uint64_t>(nprob, 1) * 18);
+            // the 32-byte match headers come back for the ordering; the records themselves (fd_match_rec: 39 words from the solution arrays)
+            // and the residue lists are gathered on the device in their final order (k_rs_records) and copied straight into the caller's
+            // page-locked arrays — the host loop over 23 k records of a 512-query batch (8 scattered reads + 232 bytes written each) was
+            // 1.6-2.3 ms of the call
+            std::vector<uint8_t> land_v;
+            const size_t b_hm = std::max<uint64_t>(nm, 1) * sizeof(rs_match_dev);
+            uint8_t *land = (uint8_t *)c->host_pinned(1, b_hm);
+            if (!land) { land_v.resize(b_hm); land = land_v.data(); }
+            rs_match_dev *hm = (rs_match_dev *)land;
+            float *d_rmsd = c->ws[WS_RS_SOL].as<float>(), *d_rot = d_rmsd + nprob, *d_tran = d_rot + 9 * nprob, *d_met = d_tran + 3 * nprob;
             if (nprob) {
-                float *d_rmsd = c->ws[WS_RS_SOL].as<float>(), *d_rot = d_rmsd + nprob, *d_tran = d_rot + 9 * nprob, *d_met = d_tran + 3 * nprob;
                 HIPCHK(c, hipMemcpyAsync(A.koff + nprob, &npts, 8, hipMemcpyHostToDevice, st));
                 fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd, d_rot, d_tran, st);
                 fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot, d_tran, A.d0, d_met, st);
                 HIPCHK(c, hipGetLastError());
-                HIPCHK(c, hipMemcpyAsync(sol.data(), d_rmsd, nprob * 18 * 4, hipMemcpyDeviceToHost, st));
-                HIPCHK(c, hipMemcpyAsync(hm.data(), A.matches, nm * sizeof(rs_match_dev), hipMemcpyDeviceToHost, st));
-                HIPCHK(c, hipMemcpyAsync(hres.data(), A.residues, nres * 4, hipMemcpyDeviceToHost, st));
+            }
+            if (nm) {
+                HIPCHK(c, hipMemcpyAsync(hm, A.matches, nm * sizeof(rs_match_dev), hipMemcpyDeviceToHost, st));
                 HIPCHK(c, hipStreamSynchronize(st));
             }
-            const float *h_rmsd = sol.data(), *h_rot = h_rmsd + nprob, *h_tran = h_rot + 9 * nprob, *h_met = h_tran + 3 * nprob;
+            const auto E1 = t_now();
             // the records arrive in append order: into (slot, component) order by a counting sort over the slots and a sort of every slot's few
             // records (a comparison sort of all 45 k records of a 512-query batch was 3 of the stage's 3.7 ms)
             std::vector<uint32_t> order(nm);
@@ -899,31 +908,46 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
                     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hm[a].slot != hm[b].slot ? hm[a].slot < hm[b].slot : hm[a].ci < hm[b].ci; });
                 }
             }
-            uint64_t tot_res = 0;
-            for (uint64_t k = 0; k < nm; ++k) tot_res += 2 * qms[t_slotq[hm[k].slot]]->n_indices;
-            fd_match_rec *om = (fd_match_rec *)malloc(std::max<size_t>(nm, 1) * sizeof(fd_match_rec));
-            int32_t *orr = (int32_t *)malloc(std::max<size_t>(tot_res, 1) * sizeof(int32_t));
+            const auto E2 = t_now();
+            // the gather plan per output record and the per-query offsets
             uint64_t *omo = (uint64_t *)malloc((n_queries + 1) * 8), *oro = (uint64_t *)malloc((n_queries + 1) * 8);
-            if (!om || !orr || !omo || !oro) { free(om); free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
+            if (!omo || !oro) { free(omo); free(oro); return FDGPU_ENOMEM; }
+            std::vector<uint32_t> plan_v;
+            uint32_t *plan = (uint32_t *)c->host_pinned(0, std::max<uint64_t>(nm, 1) * 16);
+            if (!plan) { plan_v.resize(std::max<uint64_t>(nm, 1) * 4); plan = plan_v.data(); }
             uint64_t tq = 0, rpos = 0;
             omo[0] = 0; oro[0] = 0;
             for (uint64_t k = 0; k < nm; ++k) {
                 const rs_match_dev &m = hm[order[k]];
                 while (m.slot >= cand_off[tq + 1]) { ++tq; omo[tq] = k; oro[tq] = rpos; }
-                fd_match_rec &r = om[k];
-                memset(&r, 0, sizeof r);
-                r.cand = (uint32_t)(m.slot - cand_off[tq]); r.same = m.same; r.idf = m.idf;
-                const uint32_t pf = m.prob0, po = m.same ? m.prob0 : m.prob1;
-                r.rmsd_from_hash = h_rmsd[pf]; memcpy(r.rot_from_hash, h_rot + 9 * pf, 36); memcpy(r.tran_from_hash, h_tran + 3 * pf, 12);
-                memcpy(r.metrics_from_hash, h_met + 5 * pf, 20);
-                r.rmsd = h_rmsd[po]; memcpy(r.rot, h_rot + 9 * po, 36); memcpy(r.tran, h_tran + 3 * po, 12); memcpy(r.metrics, h_met + 5 * po, 20);
                 const uint64_t nq2 = 2 * qms[tq]->n_indices;
-                memcpy(orr + rpos, hres.data() + m.res_pos, nq2 * 4);
+                plan[4 * k] = order[k]; plan[4 * k + 1] = (uint32_t)(m.slot - cand_off[tq]); plan[4 * k + 2] = (uint32_t)rpos; plan[4 * k + 3] = (uint32_t)nq2;
                 rpos += nq2;
             }
             while (tq < n_queries) { ++tq; omo[tq] = nm; oro[tq] = rpos; }
-            if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue: scan %.3f ms (found %llu, cands %llu), group+slots %.3f, superpose+copy+assemble(%llu) %.3f\n",
-                               t_ms(T0, D1), (unsigned long long)nf_d, (unsigned long long)nc_d, t_ms(D1, D2), (unsigned long long)nprob, t_ms(D2, t_now()));
+            const uint64_t tot_res = rpos;
+            if (tot_res >= (1ull << 32)) { free(omo); free(oro); c->err = "retrieve_batch: residue lists beyond 2^32 entries; split the batch"; return FDGPU_ERANGE; }
+            fd_match_rec *om = (fd_match_rec *)fd_out_alloc(std::max<size_t>(nm, 1) * sizeof(fd_match_rec), true);
+            int32_t *orr = (int32_t *)fd_out_alloc(std::max<size_t>(tot_res, 1) * sizeof(int32_t), true);
+            if (!om || !orr) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
+            const auto E3 = t_now();
+            if (nm) {
+                hipError_t e = c->ws[WS_RS_PLAN].ensure(nm * 16);
+                if (e == hipSuccess) e = c->ws[WS_RS_REC].ensure(nm * sizeof(fd_match_rec));
+                if (e == hipSuccess) e = c->ws[WS_RS_RECRES].ensure(std::max<uint64_t>(tot_res, 1) * 4);
+                if (e == hipSuccess) e = hipMemcpyAsync(c->ws[WS_RS_PLAN].p, plan, nm * 16, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) {
+                    fd_launch_rs_records(A.matches, c->ws[WS_RS_PLAN].p, nm, d_rmsd, d_rot, d_tran, d_met, A.residues, c->ws[WS_RS_REC].p, c->ws[WS_RS_RECRES].as<int32_t>(), st);
+                    e = hipGetLastError();
+                }
+                if (e == hipSuccess) e = hipMemcpyAsync(om, c->ws[WS_RS_REC].p, nm * sizeof(fd_match_rec), hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess && tot_res) e = hipMemcpyAsync(orr, c->ws[WS_RS_RECRES].p, tot_res * 4, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e != hipSuccess) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); c->err = std::string("retrieve_batch records: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+            }
+            if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue: scan %.3f ms (found %llu, cands %llu), group+slots %.3f, superpose+copy+assemble(%llu) %.3f (superpose + headers %.3f, order %.3f, plan %.3f, records %.3f)\n",
+                               t_ms(T0, D1), (unsigned long long)nf_d, (unsigned long long)nc_d, t_ms(D1, D2), (unsigned long long)nprob, t_ms(D2, t_now()), t_ms(D2, E1), t_ms(E1, E2),
+                               t_ms(E2, E3), t_ms(E3, t_now()));
             *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
             return FDGPU_OK;
         }

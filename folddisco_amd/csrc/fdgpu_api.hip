@@ -205,7 +205,66 @@ extern "C" int fdgpu_synchronize(fdgpu_ctx *c) { FD_LOCK(c);
     return FDGPU_OK;
 }
 extern "C" const char *fdgpu_last_error(const fdgpu_ctx *c) { return c ? c->err.c_str() : "null context"; }
-extern "C" void fdgpu_free(void *p) { free(p); }
+// Result arrays of the hot query entry points (match records, residue lists, count records: megabytes per batch) come from a small
+// recycling pool: a fresh malloc of that size is an mmap whose pages fault in one by one when the library fills them (1.5 of the 2.3 ms the
+// record assembly of a 512-query batch took) and an munmap when the caller frees them.  Blocks are plain malloc memory; fdgpu_free puts a
+// pooled block back (at most FD_OUT_POOL_BYTES are kept, the rest is freed), anything else goes to free().  Thread-safe.
+#include <mutex>
+#include <unordered_map>
+namespace {
+struct fd_out_blk { size_t cap; bool pinned; };
+struct fd_out_pool {
+    std::mutex mu;
+    std::unordered_map<void *, fd_out_blk> live;             // blocks handed out
+    std::vector<std::pair<fd_out_blk, void *>> idle;         // blocks waiting for reuse
+    size_t idle_bytes = 0;
+};
+fd_out_pool &out_pool() { static fd_out_pool *p = new fd_out_pool(); return *p; }     // never destroyed: callers may free after static destructors ran
+const size_t FD_OUT_POOL_BYTES = (size_t)256 << 20, FD_OUT_POOL_MIN = (size_t)64 << 10;
+}
+// pinned: page-locked host memory (hipHostMalloc) — the device copies its results straight into the caller's array
+void *fd_out_alloc(size_t bytes, bool pinned) {
+    if (bytes < FD_OUT_POOL_MIN) return malloc(bytes ? bytes : 1);
+    fd_out_pool &P = out_pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        size_t best = (size_t)-1;
+        for (size_t k = 0; k < P.idle.size(); ++k)
+            if (P.idle[k].first.pinned == pinned && P.idle[k].first.cap >= bytes && P.idle[k].first.cap <= 2 * bytes + (1u << 20) &&
+                (best == (size_t)-1 || P.idle[k].first.cap < P.idle[best].first.cap)) best = k;
+        if (best != (size_t)-1) {
+            void *p = P.idle[best].second;
+            const fd_out_blk b = P.idle[best].first;
+            P.idle.erase(P.idle.begin() + best);
+            P.idle_bytes -= b.cap;
+            P.live[p] = b;
+            return p;
+        }
+    }
+    const size_t cap = bytes + bytes / 4;
+    void *p = nullptr;
+    bool got_pinned = false;
+    if (pinned && hipHostMalloc(&p, cap, hipHostMallocPortable) == hipSuccess && p) got_pinned = true;
+    else { (void)hipGetLastError(); p = malloc(cap); }
+    if (!p) return nullptr;
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.live[p] = fd_out_blk{cap, got_pinned};
+    return p;
+}
+extern "C" void fdgpu_free(void *p) {
+    if (!p) return;
+    fd_out_pool &P = out_pool();
+    fd_out_blk b;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.live.find(p);
+        if (it == P.live.end()) { free(p); return; }
+        b = it->second;
+        P.live.erase(it);
+        if (P.idle_bytes + b.cap <= FD_OUT_POOL_BYTES) { P.idle.emplace_back(b, p); P.idle_bytes += b.cap; return; }
+    }
+    if (b.pinned) (void)hipHostFree(p); else free(p);
+}
 extern "C" int fdgpu_enable_timing(fdgpu_ctx *c, int on) { FD_LOCK(c); if (!c) return FDGPU_EINVAL; c->timing = on != 0; return FDGPU_OK; }
 extern "C" int fdgpu_last_timings(const fdgpu_ctx *c, const char **names, float *ms, uint64_t *bytes, int cap) { FD_LOCK(c);
     if (!c) return FDGPU_EINVAL;
@@ -1461,7 +1520,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
             free(ooff);
             return fd_count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off, false, nullptr, known_segments);
         }
-        fd_count_rec *rr = (fd_count_rec *)malloc(std::max<uint64_t>(tot, 1) * sizeof(fd_count_rec));
+        fd_count_rec *rr = (fd_count_rec *)fd_out_alloc(std::max<uint64_t>(tot, 1) * sizeof(fd_count_rec));
         if (!rr) { free(ooff); return FDGPU_ENOMEM; }
         uint64_t w = 0;
         for (uint64_t t = 0; t < n_queries; ++t) {
@@ -1857,8 +1916,11 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
                  o_iv1 = o_iv + (want_iv ? up4(iv_lohi.size()) : 0), words = o_iv1 + (want_iv ? 1024 * n_queries : 0) + 4;
     const size_t offs[13] = {o_cand, o_wc, o_wi, o_wq, o_wj, o_h, o_st, o_d, o_qi, o_qt, o_ivs, o_iv, o_iv1};
     memcpy(TB.o, offs, sizeof offs);
-    std::vector<uint32_t> &blk = TB.blk;
-    blk.assign(words, 0);
+    // a caller that keeps the tables (two scans of a large query) gets them in a vector; a one-off block (a batch of motif queries: ~3.5 MB
+    // per 512 queries) is packed straight into the context's pinned staging buffer — the copy below is then a DMA, not a staged pageable copy
+    uint32_t *blk = tables ? nullptr : (uint32_t *)c->host_pinned(0, words * 4);
+    if (!blk) { TB.blk.assign(words, 0); blk = TB.blk.data(); }
+    TB.data = blk; TB.words = words;
     if (n_cand) memcpy(&blk[o_cand], cand, n_cand * 4);
     if (nw) { memcpy(&blk[o_wc], wc.data(), nw * 4); memcpy(&blk[o_wi], wi.data(), nw * 4); memcpy(&blk[o_wq], wq.data(), nw * 4); memcpy(&blk[o_wj], wj.data(), nw * 4); }
     if (nh) memcpy(&blk[o_h], all_hashes.data(), nh * 4);
@@ -1882,14 +1944,13 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     };
     if (!TB.valid) { const int rcb = build_tables(); if (rcb) return rcb; }
     const size_t o_cand = TB.o[0], o_wc = TB.o[1], o_wi = TB.o[2], o_wq = TB.o[3], o_wj = TB.o[4], o_h = TB.o[5], o_st = TB.o[6], o_d = TB.o[7], o_qi = TB.o[8],
-                 o_qt = TB.o[9], o_ivs = TB.o[10], o_iv = TB.o[11], o_iv1 = TB.o[12], nw = TB.nw, words = TB.blk.size();
+                 o_qt = TB.o[9], o_ivs = TB.o[10], o_iv = TB.o[11], o_iv1 = TB.o[12], nw = TB.nw, words = TB.words;
     const bool want_iv = TB.want_iv;
     const uint32_t j_span = TB.j_span;
-    const std::vector<uint32_t> &blk = TB.blk;
     if (mp_trace) fprintf(stderr, "[match_pairs] tables at %.3f ms (%zu work items)\n", mp_ms(), nw);
     HIPCHK(c, c->ws[WS_MISC0].ensure(words * 4));
     HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, blk.data(), words * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, TB.data, words * 4, hipMemcpyHostToDevice, st));
     const uint32_t *dblk = c->ws[WS_MISC0].as<uint32_t>();
     uint8_t *d_std = nullptr;
     if (resname_std) {

@@ -34,7 +34,7 @@ enum {
     WS_COUNTS, WS_CURSOR, WS_SEGOFF, WS_SCANTMP, WS_TOTAL, WS_KEYS_A, WS_IDS_A, WS_KEYS_B, WS_IDS_B, WS_GHIST, WS_TOT,
     WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
-    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX,
+    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES,
     WS_CA_PERM, WS_OK_PERM, WS_AA_PERM, WS_SEG_TAB,
     WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT,
     WS_COUNT
@@ -184,6 +184,8 @@ int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_quer
                             uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg = nullptr, const long long *kidx = nullptr);
 int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs, long long *kidx = nullptr);
 
+void *fd_out_alloc(size_t bytes, bool pinned = false);      // result arrays of the hot query paths: recycled blocks (fdgpu_api.hip); released with fdgpu_free like any other output
+
 // kernels / launchers implemented in the k_*.hip files
 void fd_launch_selfcheck(const fd_quant &q, uint32_t *out, hipStream_t st);
 void fd_launch_hash_ok(const uint8_t *aa, const uint8_t *cb_valid, uint8_t *ok, uint64_t n, hipStream_t st);
@@ -325,7 +327,10 @@ struct mp_args {
 // 1-based ordinal of the component that mapped it, per slot the first counter and the query's residue count, the table's size in counters.
 // Out: per (slot, ordinal, query residue) row of the table {largest count, number of target residues holding it, one of them}.
 // host block of a pair scan's work items and query tables (fd_match_pairs_multi builds it on the first call, reuses it on the next)
-struct fd_mp_tables { std::vector<uint32_t> blk; size_t o[13] = {0}; size_t nw = 0; bool want_iv = false; uint32_t j_span = 0; bool valid = false; };
+struct fd_mp_tables {
+    std::vector<uint32_t> blk; size_t o[13] = {0}; size_t nw = 0; bool want_iv = false; uint32_t j_span = 0; bool valid = false;
+    const uint32_t *data = nullptr; size_t words = 0;      // the packed block: blk, or (tables not kept by the caller) the context's pinned staging buffer
+};
 struct fd_vote_row { uint32_t mx, nmx, arg; };
 struct fd_vote_plan {
     const uint8_t *cj_comp; uint64_t n_bits;
@@ -388,6 +393,8 @@ struct rs_args {
 void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec *cands, uint64_t nc, uint32_t n_cand, uint32_t *cnt, uint32_t *seg, uint32_t *cur,
                         uint32_t *perm_f, uint32_t *perm_c, hipStream_t st);
 void fd_launch_rs_slots(const rs_args &A, uint32_t n_cand, hipStream_t st);
+void fd_launch_rs_records(const void *matches, const void *plan, uint64_t n, const float *rmsd, const float *rot, const float *tran, const float *met,
+                          const int32_t *residues, void *out, int32_t *out_res, hipStream_t st);
 int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
                          const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
                          fd_cand_rec **cands, uint64_t *n_cands, uint32_t mode = 3, const uint32_t *cj_mask = nullptr,

@@ -393,3 +393,35 @@ void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec
 void fd_launch_rs_slots(const rs_args &A, uint32_t n_cand, hipStream_t st) {
     if (n_cand) hipLaunchKernelGGL(k_rs_slots, dim3(n_cand), dim3(FD_WAVE), 0, st, A);
 }
+
+// The caller's match records (fd_match_rec, 39 words) and residue lists in their final order, gathered on the device: one wavefront per
+// record; plan[k] = {source record, candidate slot inside its query, first output residue, residue ints}.  The host only orders the
+// records (a counting sort over 32-byte headers); the 8 scattered reads per record it did in the solution arrays are lanes here.
+__global__ __launch_bounds__(FD_WAVE) void k_rs_records(const rs_match_dev *__restrict__ m, const uint4 *__restrict__ plan, const float *__restrict__ rmsd,
+                                                        const float *__restrict__ rot, const float *__restrict__ tran, const float *__restrict__ met,
+                                                        const int32_t *__restrict__ residues, uint32_t *__restrict__ out, int32_t *__restrict__ out_res) {
+    const uint64_t k = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint4 pl = plan[k];
+    const rs_match_dev r = m[pl.x];
+    const uint32_t pf = r.prob0, po = r.same ? r.prob0 : r.prob1;
+    uint32_t v = 0;
+    if (lane == 0) v = pl.y;
+    else if (lane == 1) v = r.same;
+    else if (lane == 2) v = __float_as_uint(r.idf);
+    else if (lane == 3) v = __float_as_uint(rmsd[po]);
+    else if (lane == 4) v = __float_as_uint(rmsd[pf]);
+    else if (lane < 14) v = __float_as_uint(rot[9ull * po + (lane - 5)]);
+    else if (lane < 17) v = __float_as_uint(tran[3ull * po + (lane - 14)]);
+    else if (lane < 22) v = __float_as_uint(met[5ull * po + (lane - 17)]);
+    else if (lane < 31) v = __float_as_uint(rot[9ull * pf + (lane - 22)]);
+    else if (lane < 34) v = __float_as_uint(tran[3ull * pf + (lane - 31)]);
+    else if (lane < 39) v = __float_as_uint(met[5ull * pf + (lane - 34)]);
+    if (lane < 39) out[39ull * k + lane] = v;
+    for (uint32_t z = lane; z < pl.w; z += FD_WAVE) out_res[(uint64_t)pl.z + z] = residues[(uint64_t)r.res_pos + z];
+}
+void fd_launch_rs_records(const void *matches, const void *plan, uint64_t n, const float *rmsd, const float *rot, const float *tran, const float *met,
+                          const int32_t *residues, void *out, int32_t *out_res, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_rs_records, dim3((unsigned)n), dim3(FD_WAVE), 0, st, (const rs_match_dev *)matches, (const uint4 *)plan, rmsd, rot, tran, met, residues,
+                              (uint32_t *)out, out_res);
+}

@@ -149,7 +149,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             return th, tq, tm
         return go
 
-    def batched(chunk=32, match=False):
+    def batched(chunk=32, match=False, reps=1):
         """throughput mode: query maps per chunk of queries, ONE posting-length launch + ONE scoring pass per chunk; with
         match=True the first match_top candidates of every query's GLOBAL ranking additionally go through retrieval on
         their owning rank (one pair scan / gather / Kabsch launch per chunk) and the match records are all-gathered"""
@@ -172,6 +172,9 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                     tot += sum(len(g) for g in globs)
             return tot
         go()
+        if reps > 1:       # the headline leg: the median of several passes (a pass over 128 queries is a few milliseconds)
+            runs = sorted((timed(go) for _ in range(reps)), key=lambda x: x[0])
+            return runs[len(runs) // 2]
         return timed(go)
 
     MT_REPS = 12
@@ -220,7 +223,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     dtbm, nm_b = batched(match=True)
     progress("batched full leg done")
     big = 128 if len(queries) >= 128 else None          # the same full query in batches of 128 (one host thread): the per-batch synchronisations amortise
-    dtbm_big = batched(chunk=big, match=True)[0] if big else None
+    dtbm_big = batched(chunk=big, match=True, reps=7)[0] if big else None
     # ... and 512 per batch: the 128 queries four times over in ONE batch (every copy is scored and retrieved like any other query)
     dtbm_512, err_512 = None, None
     if big and not sharded:
@@ -287,15 +290,16 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     t_match = st_match.get("match_pairs", 0.0)
     traffic = _pmc_query_traffic(S_total, world)
     roofline = {
-        "bound": "hbm", "kernel": "prefilter of the batched full query: cq_batch (k_cq_plan, scan, k_cq_bounds, k_cq_seg<sums>, k_cq_seg) + cq_topn "
-                                  "(k_cq_rows_keys, k_topn_thr, k_topn_hist_dense, k_topn_emit_dense, k_topn_sort)",
+        "bound": "hbm", "kernel": "prefilter of the batched full query: cq_batch (k_qt_plan, k_qt_score<pass A: scores per tile of structures in LDS>) + cq_topn "
+                                  "(k_qt_thr, k_qt_score<pass B: records of the survivors>, k_qt_sort)",
         "queries_per_launch": len(ks), "top_n": top_n,
         "algorithmic_bytes_per_launch": b_q, "posting_bytes": post_bytes, "touched_structures": touched, "occupancy_rows": n_rows,
         "avg_ms": t_score, "stages_ms": {k: round(v, 4) for k, v in st_score.items()},
         "achieved": b_q / (t_score * 1e-3) / 1e9 if t_score > 0 else None, "peak": hbm_peak_gbs, "unit": "GB/s",
         "frac": b_q / (t_score * 1e-3) / 1e9 / hbm_peak_gbs if t_score > 0 else None,
         "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
-        "note": "latency bound by construction: ~%d KB of postings per query in 2 KB segments against a %d-structure shard" % (post_bytes // max(len(ks), 1) // 1024, S),
+        "note": "~%d KB of postings per query, decoded twice (scores, then the survivors' rows) by workgroups of one (query, 16,384-structure tile) each; "
+                "VALU-issue and latency bound, not bandwidth bound (DESIGN §4)" % (post_bytes // max(len(ks), 1) // 1024),
         "match_pairs": {"algorithmic_bytes_per_launch": 37 * cand_res + 16 * len(marr), "candidates": int(sum(len(c) for c in cl)), "avg_ms": t_match,
                         "achieved": (37 * cand_res + 16 * len(marr)) / (t_match * 1e-3) / 1e9 if t_match > 0 else None, "unit": "GB/s",
                         "note": "pair scan of the top %d candidates of %d queries; VALU-bound like the index build's pair kernel" % (match_top, len(ks))},
@@ -354,14 +358,15 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
 
     return {
         # headline = the reference's default query (prefilter + candidate selection + matching + RMSD), 32 queries per launch set
-        "metric": "motif queries/sec", "value": max(len(queries) / dtbm, len(queries) * MT_REPS / dtb2 if dtb2 else 0.0, len(queries) / dtbm_big if dtbm_big else 0.0,
-                                                    4 * len(queries) / dtbm_512 if dtbm_512 else 0.0), "unit": "queries/s",
+        # headline = ONE host thread, batches of 128 full queries (what one Rust host thread per GPU drives through the ABI; fixed definition
+        # since round 4 — rounds 1-3 took the best of four legs).  Several host threads with a context each are reported beside it (_mt).
+        "metric": "motif queries/sec", "value": len(queries) / (dtbm_big if dtbm_big else dtbm), "unit": "queries/s",
         "n_queries": len(queries),
         "structures": S_total, "structures_per_gpu": S,
         "mode": "full query (make_query_map, count_query, all-gather + global top-%d, retrieval of the global top %d candidates on their owning "
-                "rank, Kabsch, metrics); value = the best of: batches of 32 from one host thread, batches of 128 from one host thread, batches of 32 from several "
-                "host threads with one context each (batched_with_matching, _128, _mt)" % (top_n, match_top),
-        "ms_per_query": min(dtbm / len(queries), dtb2 / (len(queries) * MT_REPS) if dtb2 else 1e9, dtbm_big / len(queries) if dtbm_big else 1e9) * 1e3,
+                "rank, Kabsch, metrics); value = batches of %d from ONE host thread (batched_with_matching_128); batches of 32 / 512 and several host "
+                "threads with one context each are reported beside it (batched_with_matching, _512, _mt)" % (top_n, match_top, big if dtbm_big else 32),
+        "ms_per_query": (dtbm_big if dtbm_big else dtbm) / len(queries) * 1e3,
         "batched_with_matching": {"value": len(queries) / dtbm, "ms_per_query": dtbm / len(queries) * 1e3, "matches": int(nm_b), "match_top": match_top, "chunk": 32,
                                   "host_threads": 1},
         "batched_with_matching_512": ({"error": err_512} if err_512 else None) if not dtbm_512 else {
