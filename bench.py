@@ -314,7 +314,18 @@ def main():
             e = min(n, a + per)
             ro = d["res_off"]
             r0, r1 = int(ro[a]), int(ro[e])
-            out.append({k: ((ro[a:e + 1] - ro[a]).contiguous() if k == "res_off" else v[r0:r1]) for k, v in d.items()})
+            R = int(ro[-1])
+            part = {}
+            for k, v in d.items():       # per-residue fields by residue range, per-structure fields by structure range: anything else is a bug here
+                if k == "res_off":
+                    part[k] = (ro[a:e + 1] - ro[a]).contiguous()
+                elif len(v) == R:
+                    part[k] = v[r0:r1]
+                elif len(v) == n:
+                    part[k] = v[a:e]
+                else:
+                    raise ValueError("split_groups: field %r has %d entries (residues %d, structures %d)" % (k, len(v), R, n))
+            out.append(part)
         return out
     blocks = cat_groups(blocks, max(g, 1))
     torch.cuda.synchronize()

@@ -13,7 +13,10 @@
 //                                  shard), the fixed-size match records and residue lists are all-gathered and merged in candidate order
 // Nothing is short-cut for a world of one: the collectives run (a 1-rank all-gather is a device copy inside RCCL), so a single-GPU test
 // executes every line the N-rank path executes.  A rank whose local step fails still takes part in every collective of the call with an
-// error status in its message, and all ranks return the error together — nobody is left waiting inside ncclAllGather.
+// error status in its message, and all ranks return the error together — nobody is left waiting inside ncclAllGather.  What is NOT covered that
+// way — a rank that cannot get an exchange buffer beyond the reserve made at fdgpu_comm_init, or whose HIP runtime fails between two
+// collectives of a call — aborts the communicator (ncclCommAbort) and marks it dead: a sharded call that returns FDGPU_EHIP leaves the
+// communicator unusable on every rank.
 // RCCL is bound at run time (dlopen of librccl.so.1 — the copy torch already loaded when there is one), so libfdgpu.so itself has no
 // link-time dependency on it; without RCCL the comm entry points fail with FDGPU_EHIP and say so.
 #include <dlfcn.h>
@@ -31,6 +34,7 @@ struct rccl_api {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;        // optional
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -47,6 +51,7 @@ rccl_api &rccl() {
         a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.lib, "ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.lib, "ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
+        a.CommAbort = (decltype(a.CommAbort))dlsym(a.lib, "ncclCommAbort");
         a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
         a.AllGather = (decltype(a.AllGather))dlsym(a.lib, "ncclAllGather");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
@@ -70,7 +75,11 @@ struct fdgpu_comm {
     fd_devbuf send, recv;
     merge_bufs mb;
     uint64_t n_allreduce = 0, n_allgather = 0;      // collectives issued so far (fdgpu_comm_stats: tests check that a world of one runs them)
+    bool dead = false;                              // aborted after a failure between collectives: every later call fails at once
 };
+// reserved at fdgpu_comm_init: the exchange buffers of ordinary calls (a batch of 128 queries x top 1000 is 2.6 MB per rank) exist before any
+// rank-local work, so no rank can fail to allocate them halfway through a call while its peers already wait in a collective
+static const size_t FD_COMM_RESERVE = (size_t)4 << 20;
 
 #define FAIL_(ctx, code, msg) do { (ctx)->err = (msg); return (code); } while (0)
 #define NCHK(c, expr)                                                                                                  \
@@ -82,6 +91,23 @@ struct fdgpu_comm {
     do {                                                                                                     \
         hipError_t _e = (expr);                                                                              \
         if (_e != hipSuccess) { (c)->err = std::string(#expr " -> ") + hipGetErrorString(_e); return FDGPU_EHIP; } \
+    } while (0)
+
+// A HIP failure BETWEEN the collectives of one call (an exchange buffer beyond the reserve that cannot grow, a failed copy): the peers may already
+// wait for this rank inside a collective that it will never enter.  The communicator is aborted (ncclCommAbort: the peers' pending operation
+// ends in an RCCL error instead of a wait without end where the library offers it) and marked dead — every later call on it fails at once.
+static int comm_broken(fdgpu_ctx *c, fdgpu_comm *m, const std::string &what) {
+    if (!m->dead) {
+        m->dead = true;
+        if (m->comm && rccl().CommAbort) { (void)rccl().CommAbort(m->comm); m->comm = nullptr; }
+    }
+    c->err = what + " — the communicator was aborted (a rank failed between the collectives of a call); create a new one";
+    return FDGPU_EHIP;
+}
+#define HCHK_C(c, m, expr)                                                                                             \
+    do {                                                                                                               \
+        hipError_t _e = (expr);                                                                                        \
+        if (_e != hipSuccess) return comm_broken((c), (m), std::string(#expr " -> ") + hipGetErrorString(_e));         \
     } while (0)
 
 extern "C" int fdgpu_comm_unique_id(uint8_t id[FDGPU_COMM_ID_BYTES]) {
@@ -105,6 +131,12 @@ extern "C" int fdgpu_comm_init(fdgpu_ctx *c, const uint8_t id[FDGPU_COMM_ID_BYTE
     memcpy(u.internal, id, FDGPU_COMM_ID_BYTES);
     ncclResult_t r = rccl().CommInitRank(&m->comm, world, u, rank);
     if (r != ncclSuccess) { c->err = std::string("ncclCommInitRank -> ") + rccl().GetErrorString(r); delete m; return FDGPU_EHIP; }
+    if (m->send.ensure(FD_COMM_RESERVE) != hipSuccess || m->recv.ensure(FD_COMM_RESERVE * (size_t)world) != hipSuccess) {
+        (void)hipGetLastError();
+        c->err = "fdgpu_comm_init: exchange buffers";
+        (void)rccl().CommDestroy(m->comm); m->send.release(); m->recv.release(); delete m;
+        return FDGPU_EHIP;
+    }
     *out = m;
     return FDGPU_OK;
 }
@@ -126,12 +158,14 @@ extern "C" int fdgpu_comm_stats(const fdgpu_comm *m, uint64_t *n_allreduce, uint
 
 // in-place sum over the ranks of n u64 on the device (stream-ordered, no synchronisation)
 static int allreduce_dev(fdgpu_ctx *c, fdgpu_comm *m, uint64_t *dev, uint64_t n) {
+    if (m->dead) FAIL_(c, FDGPU_EHIP, "communicator aborted by an earlier failure");
     if (!n) return FDGPU_OK;
     NCHK(c, rccl().AllReduce(dev, dev, n, ncclUint64, ncclSum, m->comm, c->stream));
     ++m->n_allreduce;
     return FDGPU_OK;
 }
 static int allgather_dev(fdgpu_ctx *c, fdgpu_comm *m, const void *send, void *recv, size_t bytes) {
+    if (m->dead) FAIL_(c, FDGPU_EHIP, "communicator aborted by an earlier failure");
     NCHK(c, rccl().AllGather(send, recv, bytes, ncclUint8, m->comm, c->stream));
     ++m->n_allgather;
     return FDGPU_OK;
@@ -308,13 +342,13 @@ int exchange_lists(fdgpu_ctx *c, fdgpu_comm *m, uint64_t n_queries, uint32_t top
         }
     const size_t cb = (n_queries + 1) * 8;
     std::vector<uint64_t> all_cnt((size_t)W * (n_queries + 1));
-    HCHK(c, m->send.ensure(cb));
-    HCHK(c, m->recv.ensure(cb * W));
-    HCHK(c, hipMemcpyAsync(m->send.p, cnt.data(), cb, hipMemcpyHostToDevice, st));
+    HCHK_C(c, m, m->send.ensure(cb));
+    HCHK_C(c, m, m->recv.ensure(cb * W));
+    HCHK_C(c, m, hipMemcpyAsync(m->send.p, cnt.data(), cb, hipMemcpyHostToDevice, st));
     int rc = allgather_dev(c, m, m->send.p, m->recv.p, cb);
     if (rc) return rc;
-    HCHK(c, hipMemcpyAsync(all_cnt.data(), m->recv.p, cb * W, hipMemcpyDeviceToHost, st));
-    HCHK(c, hipStreamSynchronize(st));
+    HCHK_C(c, m, hipMemcpyAsync(all_cnt.data(), m->recv.p, cb * W, hipMemcpyDeviceToHost, st));
+    HCHK_C(c, m, hipStreamSynchronize(st));
     for (int r = 0; r < W; ++r)
         if (all_cnt[(size_t)r * (n_queries + 1) + n_queries]) {      // every rank sees the same statuses: all return here, none enters the second gather
             if (r != m->rank || !local_rc) c->err = "sharded query: rank " + std::to_string(r) + " failed its local step (code -" + std::to_string(all_cnt[(size_t)r * (n_queries + 1) + n_queries]) + ")";
@@ -327,13 +361,13 @@ int exchange_lists(fdgpu_ctx *c, fdgpu_comm *m, uint64_t n_queries, uint32_t top
         stride = std::max(stride, tot);
     }
     const size_t bytes = stride * sizeof(fd_count_rec);
-    HCHK(c, m->send.ensure(bytes));
-    HCHK(c, m->recv.ensure(bytes * W));
-    if (!mine.empty()) HCHK(c, hipMemcpyAsync(m->send.p, mine.data(), mine.size() * sizeof(fd_count_rec), hipMemcpyHostToDevice, st));
+    HCHK_C(c, m, m->send.ensure(bytes));
+    HCHK_C(c, m, m->recv.ensure(bytes * W));
+    if (!mine.empty()) HCHK_C(c, m, hipMemcpyAsync(m->send.p, mine.data(), mine.size() * sizeof(fd_count_rec), hipMemcpyHostToDevice, st));
     if ((rc = allgather_dev(c, m, m->send.p, m->recv.p, bytes))) return rc;
     std::vector<fd_count_rec> all(stride * W);
-    HCHK(c, hipMemcpyAsync(all.data(), m->recv.p, bytes * W, hipMemcpyDeviceToHost, st));
-    HCHK(c, hipStreamSynchronize(st));
+    HCHK_C(c, m, hipMemcpyAsync(all.data(), m->recv.p, bytes * W, hipMemcpyDeviceToHost, st));
+    HCHK_C(c, m, hipStreamSynchronize(st));
     uint64_t *ooff = (uint64_t *)calloc(n_queries + 1, 8);
     if (!ooff) return FDGPU_ENOMEM;
     std::vector<fd_count_rec> res;
@@ -366,16 +400,16 @@ int exchange(fdgpu_ctx *c, fdgpu_comm *m, uint64_t n_queries, uint32_t top_n, in
     hipStream_t st = c->stream;
     const int W = m->world;
     const size_t mb = msg_bytes(n_queries, top_n);
-    HCHK(c, m->send.ensure(mb));
-    HCHK(c, m->recv.ensure(mb * W));
+    HCHK_C(c, m, m->send.ensure(mb));
+    HCHK_C(c, m, m->recv.ensure(mb * W));
     uint8_t *snd = m->send.as<uint8_t>();
     comm_hdr hd{local_rc ? (uint32_t)(-local_rc) : 0u, (uint32_t)n_queries, top_n, top_n + 1024};
     std::vector<uint8_t> host_msg;
     if (!local_rc && dev.got) {       // the selection state and the ranked records go from where the kernels left them into the message
-        HCHK(c, hipMemcpyAsync(snd, &hd, sizeof hd, hipMemcpyHostToDevice, st));
+        HCHK_C(c, m, hipMemcpyAsync(snd, &hd, sizeof hd, hipMemcpyHostToDevice, st));
         if (n_queries) {
-            HCHK(c, hipMemcpyAsync(snd + sizeof hd, dev.state, n_queries * sizeof(sel_state), hipMemcpyDeviceToDevice, st));
-            HCHK(c, hipMemcpyAsync(snd + sizeof hd + n_queries * sizeof(sel_state), dev.recs, (size_t)n_queries * top_n * sizeof(fd_count_rec), hipMemcpyDeviceToDevice, st));
+            HCHK_C(c, m, hipMemcpyAsync(snd + sizeof hd, dev.state, n_queries * sizeof(sel_state), hipMemcpyDeviceToDevice, st));
+            HCHK_C(c, m, hipMemcpyAsync(snd + sizeof hd + n_queries * sizeof(sel_state), dev.recs, (size_t)n_queries * top_n * sizeof(fd_count_rec), hipMemcpyDeviceToDevice, st));
         }
     } else {                          // a call the device selection did not serve on this rank (empty shard, wide accumulators, overflow), or an error
         host_msg.assign(mb, 0);
@@ -389,7 +423,7 @@ int exchange(fdgpu_ctx *c, fdgpu_comm *m, uint64_t n_queries, uint32_t top_n, in
                 memcpy(host_msg.data() + sizeof hd + t * sizeof s, &s, sizeof s);
                 if (k) memcpy(host_msg.data() + sizeof hd + n_queries * sizeof s + (size_t)t * top_n * sizeof(fd_count_rec), a, (size_t)k * sizeof(fd_count_rec));
             }
-        HCHK(c, hipMemcpyAsync(snd, host_msg.data(), mb, hipMemcpyHostToDevice, st));
+        HCHK_C(c, m, hipMemcpyAsync(snd, host_msg.data(), mb, hipMemcpyHostToDevice, st));
     }
     int rc = allgather_dev(c, m, snd, m->recv.p, mb);
     if (!rc) rc = merge_gathered(c, m->mb, m->recv.as<uint8_t>(), (uint32_t)W, n_queries, top_n, out, out_off);
@@ -433,11 +467,14 @@ extern "C" int fdgpu_sharded_count_query(fdgpu_ctx *c, fdgpu_comm *m, const fdgp
     std::vector<uint64_t> lens(std::max<uint64_t>(nq, 1), 0);
     uint64_t *dl = nullptr;
     int local_rc = fd_posting_lengths_dev(c, ix, q_hash, nq, &dl);
-    if (local_rc) { if (hipMemsetAsync(dl, 0, std::max<uint64_t>(nq, 1) * 8, st) != hipSuccess) return local_rc; }     // no buffer at all: nothing to take part with
+    if (local_rc) {     // this rank still takes part in the sum — with zeros, from its own buffer or the communicator's reserve — and reports its status in the gather
+        if (!dl && nq * 8 <= m->send.cap) dl = m->send.as<uint64_t>();
+        if (!dl || hipMemsetAsync(dl, 0, std::max<uint64_t>(nq, 1) * 8, st) != hipSuccess) return comm_broken(c, m, "sharded_count_query: no buffer for the posting lengths");
+    }
     int rc = allreduce_dev(c, m, dl, nq);
     if (rc) return rc;
-    if (nq) HCHK(c, hipMemcpyAsync(lens.data(), dl, nq * 8, hipMemcpyDeviceToHost, st));
-    HCHK(c, hipStreamSynchronize(st));
+    if (nq) HCHK_C(c, m, hipMemcpyAsync(lens.data(), dl, nq * 8, hipMemcpyDeviceToHost, st));
+    HCHK_C(c, m, hipStreamSynchronize(st));
     std::vector<uint32_t> kh, kn, ke;
     std::vector<float> kidf;
     std::vector<uint64_t> koff(n_queries + 1, 0);
@@ -480,19 +517,22 @@ extern "C" int fdgpu_sharded_count_query_maps(fdgpu_ctx *c, fdgpu_comm *m, const
     std::vector<uint64_t> lens(std::max<uint64_t>(2 * nq, 1), 0);
     uint64_t *dl = nullptr;
     int local_rc = fd_posting_lengths_dev(c, ix, h.data(), 2 * nq, &dl);
-    if (local_rc) { if (hipMemsetAsync(dl, 0, std::max<uint64_t>(2 * nq, 1) * 8, st) != hipSuccess) return local_rc; }
+    if (local_rc) {     // as above: zeros into the sum, the status into the gather
+        if (!dl && 2 * nq * 8 <= m->send.cap) dl = m->send.as<uint64_t>();
+        if (!dl || hipMemsetAsync(dl, 0, std::max<uint64_t>(2 * nq, 1) * 8, st) != hipSuccess) return comm_broken(c, m, "sharded_count_query_maps: no buffer for the posting lengths");
+    }
     int rc = allreduce_dev(c, m, dl, 2 * nq);
     if (rc) return rc;
-    if (nq) HCHK(c, hipMemcpyAsync(lens.data(), dl, 2 * nq * 8, hipMemcpyDeviceToHost, st));
-    HCHK(c, hipStreamSynchronize(st));
+    if (nq) HCHK_C(c, m, hipMemcpyAsync(lens.data(), dl, 2 * nq * 8, hipMemcpyDeviceToHost, st));
+    HCHK_C(c, m, hipStreamSynchronize(st));
     fd_count_rec *loc = nullptr;
     uint64_t *loff = nullptr;
     fd_cq_dev_out dev;
     if (!local_rc) local_rc = fd_count_query_maps_len(c, ix, n_queries, qms, lens.data(), nq ? lens.data() + nq : nullptr, penalty, (float)total_structures, top_n, &loc,
                                                       &loff, device_path(top_n) ? &dev : nullptr);
-    if (!local_rc && dev.got && dev.overflow) {   // rank the full lists (the compacting path): top_n + 4096 makes the device selection step aside
+    if (!local_rc && dev.got && dev.overflow) {   // more ties at a cut than the device selection holds: the compacting path ranks and trims to top_n on this rank
         fd_count_rec *l2 = nullptr; uint64_t *o2 = nullptr;
-        local_rc = fd_count_query_maps_len(c, ix, n_queries, qms, lens.data(), nullptr, penalty, (float)total_structures, 0, &l2, &o2, nullptr);
+        local_rc = fd_count_query_maps_len(c, ix, n_queries, qms, lens.data(), nullptr, penalty, (float)total_structures, top_n, &l2, &o2, nullptr, nullptr, nullptr, false);
         loc = l2; loff = o2; dev.got = false;
     }
     rc = exchange(c, m, n_queries, top_n, local_rc, dev, loc, loff, out, out_off);
@@ -544,13 +584,13 @@ extern "C" int fdgpu_sharded_retrieve(fdgpu_ctx *c, fdgpu_comm *m, const fdgpu_b
         }
     const size_t cb = (n_queries + 1) * 8;
     std::vector<uint64_t> all_cnt((size_t)W * (n_queries + 1));
-    HCHK(c, m->send.ensure(cb));
-    HCHK(c, m->recv.ensure(cb * W));
-    HCHK(c, hipMemcpyAsync(m->send.p, cnt.data(), cb, hipMemcpyHostToDevice, st));
+    HCHK_C(c, m, m->send.ensure(cb));
+    HCHK_C(c, m, m->recv.ensure(cb * W));
+    HCHK_C(c, m, hipMemcpyAsync(m->send.p, cnt.data(), cb, hipMemcpyHostToDevice, st));
     int rc = allgather_dev(c, m, m->send.p, m->recv.p, cb);
     if (rc) return rc;
-    HCHK(c, hipMemcpyAsync(all_cnt.data(), m->recv.p, cb * W, hipMemcpyDeviceToHost, st));
-    HCHK(c, hipStreamSynchronize(st));
+    HCHK_C(c, m, hipMemcpyAsync(all_cnt.data(), m->recv.p, cb * W, hipMemcpyDeviceToHost, st));
+    HCHK_C(c, m, hipStreamSynchronize(st));
     for (int r = 0; r < W; ++r)
         if (all_cnt[(size_t)r * (n_queries + 1) + n_queries]) {
             if (r != m->rank || !local_rc) c->err = "sharded retrieve: rank " + std::to_string(r) + " failed its local step (code -" + std::to_string(all_cnt[(size_t)r * (n_queries + 1) + n_queries]) + ")";
@@ -564,14 +604,14 @@ extern "C" int fdgpu_sharded_retrieve(fdgpu_ctx *c, fdgpu_comm *m, const fdgpu_b
         max_m = std::max(max_m, tm); max_r = std::max(max_r, tr);
     }
     const size_t mbytes = max_m * sizeof(fd_match_rec), rbytes = ((max_r * 4 + 15) & ~(size_t)15), bytes = mbytes + rbytes;
-    HCHK(c, m->send.ensure(bytes));
-    HCHK(c, m->recv.ensure(bytes * W));
-    if (my_m) HCHK(c, hipMemcpyAsync(m->send.p, lm, my_m * sizeof(fd_match_rec), hipMemcpyHostToDevice, st));
-    if (my_r) HCHK(c, hipMemcpyAsync(m->send.as<uint8_t>() + mbytes, lr, my_r * 4, hipMemcpyHostToDevice, st));
+    HCHK_C(c, m, m->send.ensure(bytes));
+    HCHK_C(c, m, m->recv.ensure(bytes * W));
+    if (my_m) HCHK_C(c, m, hipMemcpyAsync(m->send.p, lm, my_m * sizeof(fd_match_rec), hipMemcpyHostToDevice, st));
+    if (my_r) HCHK_C(c, m, hipMemcpyAsync(m->send.as<uint8_t>() + mbytes, lr, my_r * 4, hipMemcpyHostToDevice, st));
     if ((rc = allgather_dev(c, m, m->send.p, m->recv.p, bytes))) return rc;
     std::vector<uint8_t> all(bytes * W);
-    HCHK(c, hipMemcpyAsync(all.data(), m->recv.p, bytes * W, hipMemcpyDeviceToHost, st));
-    HCHK(c, hipStreamSynchronize(st));
+    HCHK_C(c, m, hipMemcpyAsync(all.data(), m->recv.p, bytes * W, hipMemcpyDeviceToHost, st));
+    HCHK_C(c, m, hipStreamSynchronize(st));
     // 5. merge per query by candidate slot (a slot belongs to one rank, whose matches arrive in slot / component order)
     uint64_t tot_m = 0, tot_r = 0;
     for (int r = 0; r < W; ++r)

@@ -867,7 +867,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         const uint32_t dflags = (uint32_t)cnt_h[4];
         auto D2 = t_now();
         if (dflags == 0) {
-            const uint64_t nm = cnt_h[0], nprob = cnt_h[1] >> 40, npts = cnt_h[1] & ((1ull << 40) - 1ull), nres = cnt_h[2];
+            const uint64_t nm = cnt_h[0], nprob = cnt_h[1] >> 40, npts = cnt_h[1] & ((1ull << 40) - 1ull);
             // the 32-byte match headers come back for the ordering; the records themselves (fd_match_rec: 39 words from the solution arrays)
             // and the residue lists are gathered on the device in their final order (k_rs_records) and copied straight into the caller's
             // page-locked arrays — the host loop over 23 k records of a 512-query batch (8 scattered reads + 232 bytes written each) was

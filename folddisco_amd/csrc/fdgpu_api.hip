@@ -658,7 +658,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     const int codec = msd ? 2 : ids16 ? 1 : 0;           // of the sorted stream (k_index.hip)
     const uint32_t NB = 40;
     fd_batch_view V = b->view();
-    HIPCHK(c, c->ws[WS_MISC3].ensure(512));     // words 0-2: encode totals, 3: wide flag, 8-48: the MSD stream's bucket starts for the encoder
+    HIPCHK(c, c->ws[WS_MISC3].ensure(512));     // words 0-2: encode totals, 3: wide flag, 4: sort overflow flag, 8-48: the MSD stream's bucket starts for the encoder
     HIPCHK(c, hipMemsetAsync(c->ws[WS_MISC3].p, 0, 64, st));
     C.wide_flag = c->ws[WS_MISC3].as<unsigned long long>() + 3;
     const bool msd_perm = [] { const char *e = getenv("FDGPU_MSD_PERM"); return !(e && e[0] == '0'); }();      // 0: buckets without the amino-acid order (measurement)
@@ -754,7 +754,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
         HIPCHK(c, c->ws[WS_TOT].ensure(fd_rs_seg_tot_words(P, NB) * 8));
         HIPCHK(c, c->ws[WS_SEG_TAB].ensure(fd_rs_seg_tab_bytes(P, NB)));
         cur = fd_radix_sort_pairs16_seg(ka, (uint16_t *)ia, kb, (uint16_t *)ib, P, c->ws[WS_SEGOFF].as<uint64_t>(), S, NB, 8, 3, c->ws[WS_GHIST].as<uint32_t>(),
-                                        c->ws[WS_TOT].as<uint64_t>(), c->ws[WS_SEG_TAB].p, st, c);
+                                        c->ws[WS_TOT].as<uint64_t>(), c->ws[WS_SEG_TAB].p, st, c, c->ws[WS_MISC3].as<unsigned long long>() + 4);
     } else if (ids16) cur = fd_radix_sort_pairs16(ka, (uint16_t *)ia, kb, (uint16_t *)ib, P, 32, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), st, c);
     else cur = sort_pairs(c, ka, (uint32_t *)ia, kb, (uint32_t *)ib, P, 32);   // all 32 bits: unmasked field overflow can set bits 30-31
     const uint32_t *ks = cur ? kb : ka;
@@ -767,7 +767,7 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
     HIPCHK(c, c->ws[WS_TILE_HO].ensure((size_t)(nt + 2) * 8));
     HIPCHK(c, c->ws[WS_TILE_PO].ensure((size_t)(nt + 2) * 8));
     HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(std::max<uint64_t>(nt, S)) * 8 + 64));
-    uint64_t tot[4] = {0, 0, 0, 0};
+    uint64_t tot[5] = {0, 0, 0, 0, 0};
     uint64_t nt_eff = P ? fd_enc_num_tiles(P) : 0;
     {
         StageTimer t(c, "encode_sizes", P * (el6 ? 6 : 8));
@@ -782,8 +782,9 @@ static int index_build_impl(fdgpu_ctx *c, const fdgpu_batch *b, const fd_hash_pa
         fd_exclusive_scan<uint32_t>(c->ws[WS_TILE_P].as<uint32_t>(), nt_eff, c->ws[WS_TILE_PO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(), totd + 2, st);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_MISC3].p, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_MISC3].p, 40, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    if (tot[4]) FAIL(c, FDGPU_ERANGE, "index build: one (residue-pair bucket, key digit) group holds 2^32 keys or more; build the shard in several calls and merge");
     if (el6 && tot[3]) return FDGPU_RETRY_WIDE;
     fdgpu_index *ix = new (std::nothrow) fdgpu_index();
     if (!ix) return FDGPU_ENOMEM;
@@ -893,9 +894,17 @@ extern "C" int fdgpu_index_load(fdgpu_ctx *c, const uint32_t *hashes, const uint
     ix->n_postings = 0;
     if (vlen) {
         unsigned long long np = 0;
+        bool counted = false;
         if (c->ws[WS_TOTAL].ensure(64) == hipSuccess && hipMemsetAsync(c->ws[WS_TOTAL].p, 0, 8, c->stream) == hipSuccess) {
             hipLaunchKernelGGL(k_count_postings, dim3(2048), dim3(256), 0, c->stream, ix->value, vlen, c->ws[WS_TOTAL].as<unsigned long long>());
-            if (hipMemcpyAsync(&np, c->ws[WS_TOTAL].p, 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) ix->n_postings = np;
+            if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&np, c->ws[WS_TOTAL].p, 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                hipStreamSynchronize(c->stream) == hipSuccess) { ix->n_postings = np; counted = true; }
+        }
+        if (!counted) {       // nothing stays latched for the next call; the index would report 0 postings: refuse it
+            (void)hipGetLastError();
+            c->err = "index load: counting the postings failed";
+            fdgpu_index_destroy(ix);
+            return FDGPU_EHIP;
         }
     }
     *out = ix;
@@ -1391,6 +1400,10 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     const uint32_t qt_tl2 = [] { const char *e = getenv("FDGPU_QT_TILE"); return e && atoi(e) == 13 ? 13u : 14u; }();      // structures per tile (measurement)
     const uint32_t NT = (uint32_t)((S + (1u << qt_tl2) - 1) >> qt_tl2);
     const bool tiled = keys_only && qtile_on && max_rows <= QT_MAX_ROWS && nq * (S >> QT_CELL_LOG2) < (1ull << 31) && fd_index_checkpoints(c, ix) == FDGPU_OK;
+    // one query of thousands of rows (a whole structure as the query) with a selection: the same tiles, the rows cut into slices (k_qt_score<BIG>)
+    const uint32_t NT14 = (uint32_t)((S + (1u << 14) - 1) >> 14);
+    const bool tiled_big = dense_topn && sliced && qtile_on && !tiled && nq < (1ull << 18) && nq * NT14 < (1ull << 31) && fd_index_checkpoints(c, ix) == FDGPU_OK;
+    const uint32_t big_slices = (uint32_t)std::min<uint64_t>(32, nq), big_wpr = (uint32_t)((nq + 31) / 32), big_cap = top_n + 1024;
     hipError_t e = hipSuccess;
     auto need = [&](int w, size_t bytes) { if (e == hipSuccess) e = c->ws[w].ensure(bytes); };
     need(WS_MISC0, nq * 4); need(WS_MISC3, nq * 8); need(WS_TILE_H, (n_queries + 1) * 8); need(WS_MISC5, S * 4); need(WS_TOTAL, 64);
@@ -1398,6 +1411,12 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         need(WS_CQ_KIDX, nq * 8); need(WS_CQ_NSEG, nq * 4);
         need(WS_QT_RANGES, (size_t)nq * ((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2) * 16); need(WS_QT_COMPACT, ((size_t)n_queries * NT << qt_tl2) * 8);
         need(WS_QT_COUNT, (size_t)n_queries * NT * 4); need(WS_QT_AUX, n_queries * sizeof(qt_aux) + 256);
+    } else if (tiled_big) {
+        need(WS_CQ_KIDX, nq * 8); need(WS_CQ_NSEG, nq * 4);
+        need(WS_QT_RANGES, (size_t)nq * NT14 * 16); need(WS_QT_COMPACT, ((size_t)NT14 << 14) * 8); need(WS_QT_COUNT, (size_t)NT14 * 4); need(WS_QT_AUX, sizeof(qt_aux) + 256);
+        need(WS_QT_PARTIAL, ((size_t)big_slices * NT14 << 14) * 8);
+        need(WS_QT_SURV, ((size_t)NT14 * 512 * 2 + NT14 + big_cap + 2 * big_wpr) * 4 + (big_slices + 2) * 8 + 64);
+        need(WS_QT_ROWBITS, (size_t)big_cap * big_wpr * 4);
     } else {
         need(WS_COUNTS, packed ? 64 : QS * 4); need(WS_SEGOFF, QS * 8 + 16);
         need(WS_KEYS_B, (size_t)nq * words * 4);
@@ -1424,14 +1443,56 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         T.NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
         T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.compact = c->ws[WS_QT_COMPACT].as<uint2>(); T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
         T.ghist = nullptr; T.state = nullptr; T.aux = c->ws[WS_QT_AUX].as<qt_aux>(); T.out = nullptr; T.cap = 0;
+        T.plan_log2 = QT_CELL_LOG2; T.slices = nullptr; T.n_slices = 0; T.partial = nullptr; T.g_bm = T.g_rank = T.g_tcount = T.g_nid = T.g_rowbits = nullptr;
+        T.g_wpr = 0; T.g_eend = T.g_nend = nullptr;
         T.dbg = nullptr;
         if (getenv("FDGPU_QT_DBG")) {       // phase durations of the tile kernels (measurement aid)
             T.dbg = (unsigned long long *)(c->ws[WS_QT_AUX].as<uint8_t>() + n_queries * sizeof(qt_aux));
             (void)hipMemsetAsync(T.dbg, 0, 256, st);
         }
     }
+    std::vector<uint64_t> big_sl;        // row slices of the large-query path and the rows that end an edge / a node (outlive their asynchronous copies)
+    std::vector<uint32_t> big_ends;
+    if (tiled_big) {
+        T.value = ix->value; T.offsets = ix->offsets; T.ck_meta = ix->ck_meta; T.ck_ent = (const uint2 *)ix->ck_ent;
+        T.kidx = c->ws[WS_CQ_KIDX].as<long long>(); T.row_meta = A.row_meta; T.q_rows = c->ws[WS_TILE_H].as<uint64_t>(); T.penalty = d_penalty;
+        T.nq = (uint32_t)nq; T.n_queries = 1; T.S = (uint32_t)S; T.first_id = (uint32_t)ix->first_id; T.NT = NT14; T.tile_log2 = 14; T.plan_log2 = 14;
+        T.NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
+        T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.compact = c->ws[WS_QT_COMPACT].as<uint2>(); T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
+        T.ghist = nullptr; T.state = nullptr; T.aux = c->ws[WS_QT_AUX].as<qt_aux>(); T.out = nullptr; T.cap = big_cap; T.dbg = nullptr;
+        // slices of roughly equal posting counts: a row's list holds ~ S / 2^idf ids (idf = log2(S / length), its fixed-point image is in the metadata)
+        std::vector<double> w(nq);
+        double tot = 0;
+        for (uint64_t r = 0; r < nq; ++r) {       // 2^-idf to a few percent: the integer part by ldexp, the fraction linearly
+            const unsigned long long fix = rows_meta[r] >> 2;
+            w[r] = ldexp(1.0 - 0.5 * (double)(fix & 4194303ull) / 4194304.0, -(int)(fix >> 22)) + 1e-7;
+            tot += w[r];
+        }
+        big_sl.push_back(0);
+        double acc = 0;
+        for (uint64_t r = 0; r < nq; ++r) {
+            acc += w[r];
+            if (big_sl.size() < big_slices && acc >= tot * (double)big_sl.size() / big_slices && r + 1 < nq) big_sl.push_back(r + 1);
+        }
+        big_sl.push_back(nq);
+        T.n_slices = (uint32_t)big_sl.size() - 1;
+        big_ends.assign((size_t)2 * big_wpr, 0u);
+        for (uint64_t r = 0; r < nq; ++r) {
+            if (rows_meta[r] & 1ull) big_ends[r >> 5] |= 1u << (r & 31u);
+            if (rows_meta[r] & 2ull) big_ends[big_wpr + (r >> 5)] |= 1u << (r & 31u);
+        }
+        uint32_t *sv = c->ws[WS_QT_SURV].as<uint32_t>();
+        T.g_bm = sv; T.g_rank = sv + (size_t)NT14 * 512; T.g_tcount = T.g_rank + (size_t)NT14 * 512; T.g_nid = T.g_tcount + NT14;
+        uint32_t *d_ends = T.g_nid + big_cap;
+        T.g_eend = d_ends; T.g_nend = d_ends + big_wpr;
+        uint64_t *d_sl = (uint64_t *)(((uintptr_t)(d_ends + 2 * big_wpr) + 63) & ~(uintptr_t)63);
+        T.slices = d_sl;
+        T.partial = c->ws[WS_QT_PARTIAL].as<unsigned long long>(); T.g_rowbits = c->ws[WS_QT_ROWBITS].as<uint32_t>(); T.g_wpr = big_wpr;
+        (void)hipMemcpyAsync(d_ends, big_ends.data(), big_ends.size() * 4, hipMemcpyHostToDevice, st);
+        (void)hipMemcpyAsync(d_sl, big_sl.data(), big_sl.size() * 8, hipMemcpyHostToDevice, st);
+    }
     std::vector<uint64_t> slices;        // outlives its asynchronous copy (every path below synchronises the stream before returning)
-    if (!tiled) {
+    if (!tiled && !tiled_big) {
         StageTimer t(c, "cq_batch", 0);
         int rs = cq_score(c, A, known_segments);
         if (rs) { free(ooff); return rs; }
@@ -1493,6 +1554,17 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
                     }
                 }
             }
+        } else if (e2 == hipSuccess && tiled_big) {
+            T.ghist = c->ws[WS_CQ_TOPN].as<uint32_t>(); T.state = c->ws[WS_MISC2].as<qt_state>(); T.out = c->ws[WS_KEYS_A].p;
+            {
+                StageTimer t(c, "cq_batch", 0);
+                if (known_kidx && rows_kidx.size() == nq) (void)hipMemcpyAsync(c->ws[WS_CQ_KIDX].p, rows_kidx.data(), nq * 8, hipMemcpyHostToDevice, st);
+                else fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
+                fd_launch_qt_plan(T, st);
+                fd_launch_qt_big_score(T, st);
+            }
+            StageTimer t(c, "cq_topn", 0);
+            fd_launch_qt_big_select(T, top_n, c->ws[WS_TILE_HO].p, st);
         } else if (e2 == hipSuccess) {
             StageTimer t(c, "cq_topn", 0);
             if (keys_only)      // keys in the compaction's position buffer, unused on this path
@@ -1666,7 +1738,7 @@ uint64_t fd_maps_hashes(uint64_t n_queries, const fd_query_map *const *qms, std:
 // of primary_hash[] — what a sharded index needs, whose make_query_map saw one shard only
 int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const uint64_t *len,
                             const uint64_t *primary_len, const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out,
-                            uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg, const long long *kidx) {
+                            uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg, const long long *kidx, bool allow_dense) {
     uint64_t nq = 0;
     int64_t W = seg ? 0 : -1;
     for (uint64_t t = 0; t < n_queries; ++t) nq += qms[t]->n;
@@ -1690,7 +1762,7 @@ int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_quer
         q_off[t + 1] = qh.size();
     }
     if (qh.empty()) { qh.push_back(0); qn.push_back(0); qe.push_back(0); qi.push_back(0.0f); W = seg ? 0 : -1; qk.clear(); }
-    return fd_count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off, true, dev, W,
+    return fd_count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off, allow_dense, dev, W,
                                      kidx && qk.size() == qh.size() ? qk.data() : nullptr);
 }
 extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty,

@@ -34,7 +34,7 @@ enum {
     WS_COUNTS, WS_CURSOR, WS_SEGOFF, WS_SCANTMP, WS_TOTAL, WS_KEYS_A, WS_IDS_A, WS_KEYS_B, WS_IDS_B, WS_GHIST, WS_TOT,
     WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
-    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES,
+    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS,
     WS_CA_PERM, WS_OK_PERM, WS_AA_PERM, WS_SEG_TAB,
     WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT,
     WS_COUNT
@@ -181,7 +181,7 @@ int fd_posting_lengths_dev(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *
 uint64_t fd_maps_hashes(uint64_t n_queries, const fd_query_map *const *qms, std::vector<uint32_t> &h);
 int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const uint64_t *len,
                             const uint64_t *primary_len, const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out,
-                            uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg = nullptr, const long long *kidx = nullptr);
+                            uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg = nullptr, const long long *kidx = nullptr, bool allow_dense = true);
 int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs, long long *kidx = nullptr);
 
 void *fd_out_alloc(size_t bytes, bool pinned = false);      // result arrays of the hot query paths: recycled blocks (fdgpu_api.hip); released with fdgpu_free like any other output
@@ -207,7 +207,8 @@ uint32_t fd_rs_seg_num_tiles(uint64_t n, uint32_t n_seg);
 uint64_t fd_rs_seg_tot_words(uint64_t n, uint32_t n_seg);
 size_t fd_rs_seg_tab_bytes(uint64_t n, uint32_t n_seg);
 int fd_radix_sort_pairs16_seg(uint32_t *keys_a, uint16_t *vals_a, uint32_t *keys_b, uint16_t *vals_b, uint64_t n, const uint64_t *seg_off, uint64_t stride,
-                              uint32_t n_seg, int shift0, int passes, uint32_t *ghist, uint64_t *tot, void *seg_tab, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr);
+                              uint32_t n_seg, int shift0, int passes, uint32_t *ghist, uint64_t *tot, void *seg_tab, hipStream_t st, fdgpu_ctx *timing_ctx = nullptr,
+                              unsigned long long *overflow = nullptr);      // overflow: set when a (bucket, digit) run reaches 2^32 keys (the result is then invalid)
 void fd_launch_row_count(const fd_batch_view &B, const fd_hash_consts &C, uint32_t *row_cnt, float cutoff, hipStream_t st);
 void fd_launch_row_emit(const fd_batch_view &B, const fd_hash_consts &C, const uint64_t *row_off, uint32_t *keys, float cutoff, uint32_t *ids,
                         uint32_t first_id, hipStream_t st, int ids_partner = 0);
@@ -254,7 +255,7 @@ struct qt_args {
     const unsigned long long *row_meta;    // [nq] idf (2^-22 fixed point) << 2 | last row of its node << 1 | last row of its edge
     const uint64_t *q_rows;                // [n_queries + 1] row ranges of the queries
     const float *penalty;                  // [S]
-    uint32_t nq, n_queries, S, first_id, NT, NC, tile_log2;
+    uint32_t nq, n_queries, S, first_id, NT, NC, tile_log2, plan_log2;      // plan_log2: structure ids per plan granule (QT_CELL_LOG2, or tile_log2 for one large query)
     uint4 *ranges;                         // [NC][nq] byte range of (row, cell): first byte lo / hi, bytes (0: decoded with an earlier cell of the tile), id before the first posting
     uint2 *compact;                        // [n_queries][NT][tile] (structure, ranking key) of the touched structures, any order
     uint32_t *ccount;                      // [n_queries][NT] entries of compact
@@ -262,12 +263,20 @@ struct qt_args {
     qt_state *state; qt_aux *aux;          // [n_queries]
     void *out; uint32_t cap;               // fd_count_rec [n_queries][cap]
     unsigned long long *dbg;               // optional (FDGPU_QT_DBG): [16] phase durations summed over the workgroups
+    // one query of ~10^5 rows (k_qt_score<..., BIG>): row slices, per-slice sums, the survivors' bitmap / slots / row bits
+    const uint64_t *slices; uint32_t n_slices;     // [n_slices + 1] row boundaries
+    unsigned long long *partial;           // [n_slices][NT][tile] count << 46 | idf sum
+    uint32_t *g_bm, *g_rank, *g_tcount, *g_nid;    // [NT][tile / 32] survivors and their slots, [NT] survivors per tile, [cap] structure of a slot
+    uint32_t *g_rowbits; uint32_t g_wpr;   // [cap][g_wpr] (row, survivor) bits
+    const uint32_t *g_eend, *g_nend;       // [g_wpr] rows that end an edge / a node
 };
 void fd_launch_ck_count(const uint64_t *offsets, uint64_t H, uint32_t NC, uint32_t *cnt, hipStream_t st);
 void fd_launch_ck_fill(const uint64_t *offsets, const uint8_t *value, uint64_t H, uint32_t NC, uint32_t S, uint32_t first_id, const uint64_t *ent_off,
                        unsigned long long *meta, void *ent, hipStream_t st);
 void fd_launch_qt_plan(const qt_args &A, hipStream_t st);
 void fd_launch_qt_score(const qt_args &A, hipStream_t st);
+void fd_launch_qt_big_score(const qt_args &A, hipStream_t st);
+void fd_launch_qt_big_select(const qt_args &A, uint32_t top_n, void *sorted, hipStream_t st);
 void fd_launch_qt_select(const qt_args &A, uint32_t top_n, void *sorted, hipStream_t st);
 
 void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,

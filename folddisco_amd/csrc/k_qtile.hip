@@ -135,15 +135,17 @@ void fd_launch_ck_fill(const uint64_t *offsets, const uint8_t *value, uint64_t H
     if (H) hipLaunchKernelGGL(k_ck_fill, dim3((unsigned)((H + 3) / 4)), dim3(256), 0, st, offsets, value, H, NC, S, first_id, ent_off, meta, (uint2 *)ent);
 }
 
-// ------------------------------------------------------------------ (row, cell) -> byte range
-// ranges[cell * nq + r] = {first byte (absolute, 64 bits), bytes, id before the first posting}: the piece of row r's list that the
-// checkpoints delimit around the cell.  A list whose entries are 2^j cells apart gives the same piece for all cells of an entry: it is
-// handed to the FIRST of them inside the tile, the others get none — a tile decodes every piece once, and no piece is longer than the
-// postings of max(2^j, 1) cells (a wavefront step or two even for the densest lists).
+// ------------------------------------------------------------------ (row, granule) -> byte range
+// ranges[g * nq + r] = {first byte (absolute, 64 bits), bytes, id before the first posting}: the piece of row r's list that the checkpoints
+// delimit around granule g = 2^plan_log2 structure ids (motif batches: one checkpoint cell, so that no piece is longer than a wavefront
+// step or two even for the densest lists; a query of 10^5 rows: a whole tile — 8x fewer, 8x longer pieces).  A list whose entries lie
+// further apart than a granule gives the same piece for all granules of an entry: it is handed to the FIRST of them inside the tile, the
+// others get none — a tile decodes every piece once.
 __global__ void k_qt_plan(qt_args A) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (uint64_t)A.nq * A.NC) return;
-    const uint32_t cell = (uint32_t)(g / A.nq), r = (uint32_t)(g % A.nq);
+    const uint32_t cpg_log2 = A.plan_log2 - QT_CELL_LOG2, n_gran = (A.NC + (1u << cpg_log2) - 1u) >> cpg_log2;
+    if (g >= (uint64_t)A.nq * n_gran) return;
+    const uint32_t gran = (uint32_t)(g / A.nq), r = (uint32_t)(g % A.nq);
     uint4 out = make_uint4(0u, 0u, 0u, 0u);
     const long long k = A.kidx[r];
     if (k >= 0) {
@@ -153,13 +155,14 @@ __global__ void k_qt_plan(qt_args A) {
         const uint2 *e = A.ck_ent + (m & ((1ull << 56) - 1ull));
         const uint32_t n_e = (uint32_t)(((uint64_t)A.NC + (1ull << j) - 1ull) >> j);
         const uint32_t cpt_log2 = A.tile_log2 - QT_CELL_LOG2;
-        const uint32_t tile_cell0 = (cell >> cpt_log2) << cpt_log2;
-        const uint32_t e0 = cell >> j;
-        const uint32_t first_cell = (e0 << j) > tile_cell0 ? (e0 << j) : tile_cell0;       // the entry's first cell inside this tile
-        if (cell == first_cell) {
+        const uint32_t c0 = gran << cpg_log2, c1 = c0 + (1u << cpg_log2) < A.NC ? c0 + (1u << cpg_log2) : A.NC;
+        const uint32_t tile_c0 = (c0 >> cpt_log2) << cpt_log2;
+        const uint32_t e0 = c0 >> j, e1 = ((c1 - 1u) >> j) + 1u;
+        const uint32_t first_c = (e0 << j) > tile_c0 ? (e0 << j) : tile_c0;       // the entry's first cell inside this tile
+        if (j <= cpg_log2 || c0 == first_c) {
             uint32_t sb = 0, prev = 0;
             if (e0 && n_e > 1u) { const uint2 x = e[e0 - 1u]; sb = x.x; prev = x.y; }
-            const uint64_t eb = (e0 + 1u >= n_e || n_e <= 1u) ? len : (uint64_t)e[e0].x;
+            const uint64_t eb = (e1 >= n_e || n_e <= 1u) ? len : (uint64_t)e[e1 - 1u].x;
             const uint64_t p = b0 + sb;
             out = make_uint4((uint32_t)p, (uint32_t)(p >> 32), (uint32_t)(eb - sb), prev);
         }
@@ -206,14 +209,17 @@ __device__ __forceinline__ uint32_t qt_groups_hit(uint32_t m, uint32_t ends, uin
 
 // RICH = false: scores of every structure of the tile (pass A).  RICH = true: the records of the survivors (pass B).
 // TL2: log2 structures per tile; NTHR threads; RB rows planned per batch; RBW words of row bits (pass B)
-template <bool RICH, int TL2, int NTHR, int RB, int RBW>
+// BIG = false: a batch of motif queries, workgroup = (query, tile), all rows of the query.  BIG = true: ONE query of ~10^5 rows (a whole
+// structure as the query), workgroup = (tile, slice of the rows): pass A leaves the tile's sums of its slice in A.partial (k_qd_reduce adds the
+// slices up and ranks), pass B takes the survivors' bitmap from k_qd_surv and sets their (row, structure) bits in a global matrix.
+template <bool RICH, int TL2, int NTHR, int RB, int RBW, bool BIG = false>
 __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
     constexpr uint32_t TILE = 1u << TL2;
     __shared__ unsigned long long s_acc[RICH ? 1 : TILE + FD_WAVE];       // A: count << 46 | idf sum per structure of the tile (+ a slot per lane for adds of nothing)
-    __shared__ uint32_t s_hist[RICH ? 1 : QT_BINS / 2];
-    __shared__ uint32_t s_bm[RICH ? TILE / 32 : 1], s_rank[RICH ? TILE / 32 : 1], s_rowbits[RICH ? RBW : 1];      // B: survivors, their ranks, their row bits
-    __shared__ unsigned long long s_meta[RICH ? QT_MAX_ROWS : 1];
-    __shared__ uint32_t s_eend[RICH ? QT_MAX_ROWS / 32 : 1], s_nend[RICH ? QT_MAX_ROWS / 32 : 1];      // B: rows that end an edge / a node
+    __shared__ uint32_t s_hist[RICH || BIG ? 1 : QT_BINS / 2];
+    __shared__ uint32_t s_bm[RICH ? TILE / 32 : 1], s_rank[RICH ? TILE / 32 : 1], s_rowbits[RICH && !BIG ? RBW : 1];      // B: survivors, their ranks, their row bits
+    __shared__ unsigned long long s_meta[RICH && !BIG ? QT_MAX_ROWS : 1];
+    __shared__ uint32_t s_eend[RICH && !BIG ? QT_MAX_ROWS / 32 : 1], s_nend[RICH && !BIG ? QT_MAX_ROWS / 32 : 1];      // B: rows that end an edge / a node
     __shared__ unsigned long long s_byte0[RB], s_add[RB];
     __shared__ uint32_t s_P[RB + 1], s_nbytes[RB], s_prev[RB];
     __shared__ uint16_t s_units[RB];
@@ -224,22 +230,22 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
     // (query, tile) of the workgroup, tiles of a query on consecutive workgroups = spread over the XCDs (all tiles of a query on ONE XCD
     // measured 25 % slower: the queries' weights differ and the XCDs finish apart)
     const uint32_t wg = blockIdx.x;
-    if (wg >= A.NT * A.n_queries) return;
-    const uint32_t t = wg % A.NT, q = wg / A.NT, tid = threadIdx.x, lane = tid & 63u;
+    if (wg >= A.NT * (BIG ? A.n_slices : A.n_queries)) return;
+    const uint32_t t = wg % A.NT, q = BIG ? 0u : wg / A.NT, slice = BIG ? wg / A.NT : 0u, tid = threadIdx.x, lane = tid & 63u;
     unsigned long long tstamp = A.dbg ? wall_clock64() : 0ull;
     auto stamp = [&](int k) {      // FDGPU_QT_DBG: phase durations of the workgroup's first thread, summed over the launch (100 MHz ticks)
         if (A.dbg && tid == 0) { const unsigned long long now = wall_clock64(); atomicAdd(&A.dbg[(RICH ? 8 : 0) + k], now - tstamp); tstamp = now; }
     };
     if (A.dbg && tid < 8) s_dbg[tid] = 0;
-    const uint64_t r0 = A.q_rows[q];
-    const uint32_t nrows = (uint32_t)(A.q_rows[q + 1] - r0);
+    const uint64_t r0 = BIG ? A.slices[slice] : A.q_rows[q];
+    const uint32_t nrows = (uint32_t)((BIG ? A.slices[slice + 1] : A.q_rows[q + 1]) - r0);
     const uint32_t tile_lo = t << TL2;
     const uint32_t tile_lim = A.S - tile_lo < TILE ? A.S - tile_lo : TILE;
     const uint32_t tile_id0 = A.first_id + tile_lo;
     const uint64_t cbase = ((uint64_t)q * A.NT + t) << TL2;
-    // work entries of the tile: (cell of the tile, row), cell-major — entry e = cell e / nrows, row e % nrows
-    constexpr uint32_t CPT = 1u << (TL2 - QT_CELL_LOG2);
-    const uint32_t cell0 = t * CPT, ncell = A.NC - cell0 < CPT ? A.NC - cell0 : CPT;
+    // work entries of the tile: (granule of the tile, row), granule-major — entry e = granule e / nrows, row e % nrows (BIG: one granule = the tile)
+    constexpr uint32_t CPT = BIG ? 1u : 1u << (TL2 - QT_CELL_LOG2);
+    const uint32_t cell0 = t * CPT, n_gran = BIG ? A.NT : A.NC, ncell = n_gran - cell0 < CPT ? n_gran - cell0 : CPT;
     const uint32_t n_ent = nrows * ncell;
     auto range_of = [&](uint32_t e) -> uint4 { return A.ranges[(uint64_t)(cell0 + e / nrows) * A.nq + r0 + e % nrows]; };
     // the first batch's ranges are requested before anything else: their latency hides behind the set-up below
@@ -249,8 +255,12 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
     uint32_t n_surv = 0, wpr = 1, per_round = 1, n_rounds = 1, out_base = 0;
     if (!RICH) {
         for (uint32_t k = tid; k < TILE; k += NTHR) s_acc[k] = 0ull;
-        for (uint32_t k = tid; k < QT_BINS / 2; k += NTHR) s_hist[k] = 0u;
+        if (!BIG) for (uint32_t k = tid; k < QT_BINS / 2; k += NTHR) s_hist[k] = 0u;
         if (tid == 0) s_cnt = 0;
+    } else if (BIG) {
+        if (A.g_tcount[t] == 0u) return;
+        for (uint32_t k = tid; k < TILE / 32; k += NTHR) { s_bm[k] = A.g_bm[(uint64_t)t * (TILE / 32) + k]; s_rank[k] = A.g_rank[(uint64_t)t * (TILE / 32) + k]; }
+        n_surv = 1; wpr = A.g_wpr; per_round = 0xffffffffu;
     } else {
         // the tile's (structure, key) list: its first entries are requested before its length is known (the buffer holds a full tile)
         constexpr int SPEC = (TILE / NTHR) < 8 ? (TILE / NTHR) : 8;
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
     stamp(0);
     for (uint32_t round = 0; round < n_rounds; ++round) {
         const uint32_t s_lo = round * per_round;
-        if (RICH) {
+        if (RICH && !BIG) {
             const uint32_t nw = (n_surv - s_lo < per_round ? n_surv - s_lo : per_round) * wpr;
             for (uint32_t k = tid; k < nw; k += NTHR) s_rowbits[k] = 0u;
             __syncthreads();
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
                 s_P[c] = ex & 0x3fffffu;
                 s_byte0[c] = (unsigned long long)rg.x | ((unsigned long long)rg.y << 32);
                 s_nbytes[c] = rg.z; s_prev[c] = rg.w;
-                s_add[c] = RICH ? (unsigned long long)((ra + tid) % nrows) : ((1ull << QT_CNT_SHIFT) | (rm >> 2));
+                s_add[c] = RICH ? (unsigned long long)((ra + tid) % nrows) + (BIG ? r0 : 0ull) : ((1ull << QT_CNT_SHIFT) | (rm >> 2));
             }
             if (tid == 0) { s_n = tot >> 22; s_P[tot >> 22] = tot & 0x3fffffu; s_nheavy = 0; s_nlight = 0; s_ucur = 0; }
             __syncthreads();
@@ -407,7 +417,15 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
                     carry = (uint32_t)__builtin_amdgcn_readlane((int)(id_first + D), 63);
                     const unsigned long long add = s_add[cur.c];
                     uint32_t id = id_first;
-                    if (!RICH) {
+                    if (!RICH && BIG) {
+                        // every structure is touched by a query of 10^5 rows: no list of touched structures, plain adds
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            id += v[i];
+                            const uint32_t x = id - tile_id0;
+                            if (((T >> i) & 1u) && x < tile_lim) atomicAdd(&s_acc[x], add);
+                        }
+                    } else if (!RICH) {
                         // one returning 64-bit LDS add per posting, eight in flight (lanes without a posting add 0 to a slot of their own);
                         // a count of 0 before the add = the structure's first posting of this query
                         uint32_t first = 0;
@@ -459,7 +477,8 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
                                 if ((hit >> i) & 1u) {
                                     const uint32_t x = id - tile_id0, wd = s_bm[x >> 5];
                                     const uint32_t rk = s_rank[x >> 5] + (uint32_t)__popc(wd & ((1u << (x & 31u)) - 1u)) - s_lo;
-                                    if (rk < per_round) atomicOr(&s_rowbits[rk * wpr + ((uint32_t)add >> 5)], 1u << ((uint32_t)add & 31u));
+                                    if (BIG) { if (rk < A.cap) atomicOr(&A.g_rowbits[(uint64_t)rk * wpr + ((uint32_t)add >> 5)], 1u << ((uint32_t)add & 31u)); }
+                                    else if (rk < per_round) atomicOr(&s_rowbits[rk * wpr + ((uint32_t)add >> 5)], 1u << ((uint32_t)add & 31u));
                                 }
                             }
                         }
@@ -482,7 +501,7 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
                 s_dbg[0] = 0; s_dbg[1] = 0; s_dbg[2] = 0; s_dbg[3] = 0;
             }
         }
-        if (RICH) {
+        if (RICH && !BIG) {
             // ---- the survivors' records, one survivor per thread: match count = set rows, edge / node counts = row groups with a set
             // row (k_topn_emit_dense walked the rows in (node, partner) order for the same numbers), idf sum over the set rows
             const uint32_t n_here = n_surv - s_lo < per_round ? n_surv - s_lo : per_round;
@@ -519,6 +538,11 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
         }
     }
     if (RICH) return;
+    if (BIG) {      // the tile's sums of this slice of the rows
+        unsigned long long *dst = A.partial + (((uint64_t)slice * A.NT + t) << TL2);
+        for (uint32_t k = tid; k < TILE; k += NTHR) dst[k] = s_acc[k];
+        return;
+    }
     // ---- pass A: ranking keys of the touched structures (listed in the order they were met), first histogram level
     const uint32_t n_t = s_cnt;
     for (uint32_t e0 = 0; e0 < n_t; e0 += 4 * NTHR) {       // four structures per thread in flight
@@ -546,6 +570,131 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
     }
     if (tid == 0) A.ccount[(uint64_t)q * A.NT + t] = n_t;
     stamp(5);
+}
+
+// ------------------------------------------------------------------ one query of ~10^5 rows: reduce, survivors, records
+// k_qd_reduce: the structures' sums over the row slices -> ranking keys of the touched structures + first histogram level (what pass A's own
+// finalize does for a motif query).  One workgroup per 1,024 structures; a tile's list is filled through its counter (zero on entry).
+template <int TL2>
+__global__ __launch_bounds__(1024) void k_qd_reduce(qt_args A) {
+    __shared__ uint32_t s_hist[QT_BINS];
+    __shared__ uint32_t s_cnt, s_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t i = blockIdx.x * 1024u + tid, t = i >> TL2;        // structure (relative id), its tile
+    for (uint32_t k = tid; k < QT_BINS; k += 1024) s_hist[k] = 0u;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    unsigned long long a = 0;
+    if (i < A.S) for (uint32_t sl = 0; sl < A.n_slices; ++sl) a += A.partial[(((uint64_t)sl * A.NT) << TL2) + i];
+    const bool touched = (a >> QT_CNT_SHIFT) != 0ull;
+    uint32_t key = 0, pos = 0;
+    if (touched) {
+        key = qt_order_key((float)((double)(a & QT_SUM_MASK) * (1.0 / QT_IDF_SCALE)) * A.penalty[i]);
+        atomicAdd(&s_hist[qt_bin(key)], 1u);
+    }
+    const uint64_t m = __ballot(touched);
+    if (m) {
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+        pos = (uint32_t)__shfl((int)base, __builtin_ctzll(m), FD_WAVE) + fd_mbcnt(m);
+    }
+    __syncthreads();
+    if (tid == 0 && s_cnt) s_base = atomicAdd(&A.ccount[t], s_cnt);      // 1,024 divides the tile: the workgroup's structures share one tile
+    __syncthreads();
+    if (touched) A.compact[((uint64_t)t << TL2) + s_base + pos] = make_uint2(i, key);
+    for (uint32_t k = tid; k < QT_BINS; k += 1024) if (s_hist[k]) atomicAdd(&A.ghist[k], s_hist[k]);
+}
+// k_qd_surv: the survivors of a tile (key >= threshold) as a bitmap + the number of survivors in the words before (local ranks) + the count
+template <int TL2>
+__global__ __launch_bounds__(512) void k_qd_surv(qt_args A) {
+    constexpr uint32_t TILE = 1u << TL2, W = TILE / 32;
+    __shared__ uint32_t s_bm[W];
+    __shared__ uint32_t s_w[8];
+    const uint32_t t = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t k = tid; k < W; k += 512) s_bm[k] = 0u;
+    __syncthreads();
+    const uint32_t n = A.ccount[t], thr = A.state[0].thr_key, tile_lo = t << TL2;
+    const uint2 *e = A.compact + ((uint64_t)t << TL2);
+    for (uint32_t i = tid; i < n; i += 512) { const uint2 x = e[i]; if (x.y >= thr) { const uint32_t z = x.x - tile_lo; atomicOr(&s_bm[z >> 5], 1u << (z & 31u)); } }
+    __syncthreads();
+    uint32_t run = 0;
+    for (uint32_t w0 = 0; w0 < W; w0 += 512) {
+        uint32_t tot;
+        const uint32_t pc = (uint32_t)__popc(s_bm[w0 + tid]);
+        const uint32_t ex = qt_block_excl<512>(pc, tid, s_w, &tot);
+        A.g_bm[(uint64_t)t * W + w0 + tid] = s_bm[w0 + tid];
+        A.g_rank[(uint64_t)t * W + w0 + tid] = run + ex;
+        run += tot;
+    }
+    if (tid == 0) A.g_tcount[t] = run;
+}
+// ... global slots: a tile's ranks start behind the survivors of the tiles before it; the survivors' structure ids by slot; the total
+template <int TL2>
+__global__ __launch_bounds__(512) void k_qd_surv_slots(qt_args A) {
+    constexpr uint32_t W = (1u << TL2) / 32;
+    __shared__ uint32_t s_base, s_tot;
+    const uint32_t t = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        uint32_t b = 0, tot = 0;
+        for (uint32_t k = 0; k < A.NT; ++k) { const uint32_t c = A.g_tcount[k]; if (k < t) b += c; tot += c; }
+        s_base = b; s_tot = tot;
+    }
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t w = tid; w < W; w += 512) {
+        uint32_t rk = A.g_rank[(uint64_t)t * W + w] + base;
+        A.g_rank[(uint64_t)t * W + w] = rk;
+        for (uint32_t bits = A.g_bm[(uint64_t)t * W + w]; bits; bits &= bits - 1u, ++rk)
+            if (rk < A.cap) A.g_nid[rk] = (t << TL2) + w * 32u + (uint32_t)__builtin_ctz(bits);
+    }
+    if (t == 0 && tid == 0) A.state[0].count = s_tot;
+}
+// k_qd_records: a survivor's record from its row bits, one wavefront per survivor: match count = set rows, edge / node counts = row groups
+// with a set row (qt_groups_hit word by word; a lane walks its share of the ~3,200 words once with and once without an incoming carry,
+// lane 0 chains the 64 shares), idf sum over the set rows
+__global__ __launch_bounds__(FD_WAVE) void k_qd_records(qt_args A) {
+    __shared__ uint32_t s_h[4][FD_WAVE];      // hits of a lane's share: edges / nodes x carry-in 0 / 1
+    const uint32_t slot = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n = A.state[0].count < A.cap ? A.state[0].count : A.cap;
+    if (slot >= n) return;
+    const uint32_t *rb = A.g_rowbits + (uint64_t)slot * A.g_wpr;
+    const uint32_t per = (A.g_wpr + FD_WAVE - 1) / FD_WAVE, w0 = lane * per, w1 = w0 + per < A.g_wpr ? w0 + per : A.g_wpr;
+    uint32_t cnt = 0, he[2] = {0, 0}, hn[2] = {0, 0}, oe[2] = {0, 1}, on[2] = {0, 1};
+    unsigned long long sum = 0;
+    for (int cin = 0; cin < 2; ++cin) {
+        uint32_t ce = (uint32_t)cin, cn = (uint32_t)cin;
+        for (uint32_t rw = w0; rw < w1; ++rw) {
+            uint32_t m = rb[rw];
+            const uint32_t left = A.nq - rw * 32u, valid = left >= 32u ? 0xffffffffu : (1u << left) - 1u;
+            he[cin] += qt_groups_hit(m, A.g_eend[rw], valid, ce);
+            hn[cin] += qt_groups_hit(m, A.g_nend[rw], valid, cn);
+            if (cin == 0) {
+                cnt += (uint32_t)__popc(m);
+                for (; m; m &= m - 1u) sum += A.row_meta[rw * 32u + (uint32_t)__builtin_ctz(m)] >> 2;
+            }
+        }
+        oe[cin] = ce; on[cin] = cn;       // an empty share hands the carry through
+    }
+    s_h[0][lane] = he[0]; s_h[1][lane] = he[1]; s_h[2][lane] = hn[0]; s_h[3][lane] = hn[1];
+    const uint64_t oe0 = __ballot(oe[0] != 0u), oe1 = __ballot(oe[1] != 0u), on0 = __ballot(on[0] != 0u), on1 = __ballot(on[1] != 0u);
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += (uint32_t)__shfl_down((int)cnt, off, FD_WAVE);
+        const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)sum, off, FD_WAVE), hi = (uint32_t)__shfl_down((int)(uint32_t)(sum >> 32), off, FD_WAVE);
+        sum += ((unsigned long long)hi << 32) | lo;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t edges = 0, nodes = 0, ce = 0, cn = 0;
+        for (uint32_t l = 0; l < FD_WAVE; ++l) {
+            edges += s_h[ce][l]; ce = (uint32_t)(((ce ? oe1 : oe0) >> l) & 1ull);
+            nodes += s_h[2 + cn][l]; cn = (uint32_t)(((cn ? on1 : on0) >> l) & 1ull);
+        }
+        const uint32_t i = A.g_nid[slot];
+        qt_rec rec;
+        rec.nid = i + A.first_id; rec.total_match_count = cnt; rec.node_count = nodes; rec.edge_count = edges;
+        rec.idf = (float)((double)sum * (1.0 / QT_IDF_SCALE)) * A.penalty[i];
+        ((qt_rec *)A.out)[slot] = rec;
+    }
 }
 
 // ------------------------------------------------------------------ threshold
@@ -664,8 +813,27 @@ __global__ __launch_bounds__(QT_SORT_T) void k_qt_sort(const qt_rec *__restrict_
 }
 
 void fd_launch_qt_plan(const qt_args &A, hipStream_t st) {
-    const uint64_t n = (uint64_t)A.nq * A.NC;
+    const uint32_t cpg_log2 = A.plan_log2 - QT_CELL_LOG2;
+    const uint64_t n = (uint64_t)A.nq * ((A.NC + (1u << cpg_log2) - 1u) >> cpg_log2);
     if (n) hipLaunchKernelGGL(k_qt_plan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A);
+}
+// one query of ~10^5 rows (a whole structure as the query): scores per (tile, slice of the rows) -> per-tile reduction + keys + histogram;
+// then threshold -> survivors -> their row bits (second decode) -> records -> ranking.  A.tile_log2 = 14, A.plan_log2 = 14.
+void fd_launch_qt_big_score(const qt_args &A, hipStream_t st) {
+    if (!A.S) return;
+    hipLaunchKernelGGL((k_qt_score<false, 14, 1024, 512, 1, true>), dim3(A.NT * A.n_slices), dim3(1024), 0, st, A);
+    (void)hipMemsetAsync(A.ccount, 0, (size_t)A.NT * 4, st);
+    hipLaunchKernelGGL(k_qd_reduce<14>, dim3((A.S + 1023u) / 1024u), dim3(1024), 0, st, A);
+}
+void fd_launch_qt_big_select(const qt_args &A, uint32_t top_n, void *sorted, hipStream_t st) {
+    if (!A.S) return;
+    hipLaunchKernelGGL(k_qt_thr, dim3(1), dim3(1024), 0, st, A, top_n);
+    hipLaunchKernelGGL(k_qd_surv<14>, dim3(A.NT), dim3(512), 0, st, A);
+    hipLaunchKernelGGL(k_qd_surv_slots<14>, dim3(A.NT), dim3(512), 0, st, A);
+    (void)hipMemsetAsync(A.g_rowbits, 0, (size_t)A.cap * A.g_wpr * 4, st);
+    hipLaunchKernelGGL((k_qt_score<true, 14, 1024, 512, 1, true>), dim3(A.NT * A.n_slices), dim3(1024), 0, st, A);
+    hipLaunchKernelGGL(k_qd_records, dim3(A.cap), dim3(FD_WAVE), 0, st, A);
+    hipLaunchKernelGGL(k_qt_sort, dim3(1), dim3(QT_SORT_T), 0, st, (const qt_rec *)A.out, A.cap, A.state, top_n, (qt_rec *)sorted);
 }
 // pass A: scores of every (query, tile) in LDS -> (structure, key) of the touched structures + first histogram level
 void fd_launch_qt_score(const qt_args &A, hipStream_t st) {

@@ -176,7 +176,9 @@ __global__ __launch_bounds__(1024) void k_rs_scan_chunks(uint64_t *__restrict__ 
 }
 __global__ __launch_bounds__(RS_BINS) void k_rs_scan_apply(uint32_t *__restrict__ ghist, uint32_t nb, const uint64_t *__restrict__ csum) {
     const uint32_t t0 = blockIdx.x * RS_SCAN_CHUNK, t1 = t0 + RS_SCAN_CHUNK < nb ? t0 + RS_SCAN_CHUNK : nb;
-    uint32_t run = (uint32_t)csum[(uint64_t)blockIdx.x * RS_BINS + threadIdx.x];   // positions inside one digit bucket fit 32 bits (n < 2^32)
+    // positions inside one digit's run of a bucket, 32 bits: the unsegmented sort takes n < 2^32 keys; the segmented sort (calls of up to 2^35
+    // keys) checks every (bucket, digit) total against 2^32 in k_rs_scan_tot_seg and flags the call (FDGPU_ERANGE) instead of wrapping here
+    uint32_t run = (uint32_t)csum[(uint64_t)blockIdx.x * RS_BINS + threadIdx.x];
 #pragma unroll 8
     for (uint32_t t = t0; t < t1; ++t) {
         uint32_t v = ghist[(uint64_t)t * RS_BINS + threadIdx.x];
@@ -450,10 +452,11 @@ __global__ __launch_bounds__(1024) void k_rs_scan_chunks_seg(uint64_t *__restric
     for (uint32_t c = c0; c < c1; ++c) { uint64_t x = csum[(uint64_t)(cb0 + c) * RS_BINS + d]; csum[(uint64_t)(cb0 + c) * RS_BINS + d] = run; run += x; }
 }
 // per bucket: digit totals -> absolute position of every digit's first key (bucket start + exclusive scan over the digits)
-__global__ __launch_bounds__(RS_BINS) void k_rs_scan_tot_seg(uint64_t *__restrict__ tot, const rs_seg_tab *__restrict__ T) {
+__global__ __launch_bounds__(RS_BINS) void k_rs_scan_tot_seg(uint64_t *__restrict__ tot, const rs_seg_tab *__restrict__ T, unsigned long long *__restrict__ overflow) {
     __shared__ uint64_t sm[17];
     const uint32_t b = blockIdx.x;
     uint64_t x = tot[(uint64_t)b * RS_BINS + threadIdx.x], t;
+    if (overflow && x >= (1ull << 32)) *overflow = 1ull;       // k_rs_scan_apply keeps a digit's positions in 32 bits
     uint64_t ex = block_excl_scan_u64(x, sm, &t);
     tot[(uint64_t)b * RS_BINS + threadIdx.x] = ex + T->bstart[b];
 }
@@ -547,7 +550,8 @@ size_t fd_rs_seg_tab_bytes(uint64_t n, uint32_t n_seg) { return ((sizeof(rs_seg_
 // Stable sort of every bucket [seg_off[b * stride], seg_off[(b + 1) * stride]) by key bits [shift0, shift0 + 8 * passes): 6-byte elements.
 // seg_off / seg_tab are device memory; nothing is synchronised.  Returns the buffer (0 = a, 1 = b) that holds the result.
 int fd_radix_sort_pairs16_seg(uint32_t *keys_a, uint16_t *vals_a, uint32_t *keys_b, uint16_t *vals_b, uint64_t n, const uint64_t *seg_off, uint64_t stride,
-                              uint32_t n_seg, int shift0, int passes, uint32_t *ghist, uint64_t *tot, void *seg_tab, hipStream_t st, fdgpu_ctx *tc) {
+                              uint32_t n_seg, int shift0, int passes, uint32_t *ghist, uint64_t *tot, void *seg_tab, hipStream_t st, fdgpu_ctx *tc,
+                              unsigned long long *overflow) {
     if (n == 0 || n_seg == 0 || n_seg > RS_MAX_SEG) return 0;
     constexpr int THREADS = 512, ITEMS = 16;
     rs_seg_tab *T = (rs_seg_tab *)seg_tab;
@@ -570,7 +574,7 @@ int fd_radix_sort_pairs16_seg(uint32_t *keys_a, uint16_t *vals_a, uint32_t *keys
             hipLaunchKernelGGL(k_rs_scan_csum, dim3(n_chunks), dim3(RS_BINS), 0, st, ghist, nbv, csum);
             hipLaunchKernelGGL(k_rs_scan_chunks_seg, dim3(RS_BINS / 16, n_seg), dim3(1024), 0, st, csum, T, tot);
             hipLaunchKernelGGL(k_rs_scan_apply, dim3(n_chunks), dim3(RS_BINS), 0, st, ghist, nbv, csum);
-            hipLaunchKernelGGL(k_rs_scan_tot_seg, dim3(n_seg), dim3(RS_BINS), 0, st, tot, T);
+            hipLaunchKernelGGL(k_rs_scan_tot_seg, dim3(n_seg), dim3(RS_BINS), 0, st, tot, T, overflow);
         }
         {
             StageTimer t(tc, "rs_scatter", n * 12);

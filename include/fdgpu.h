@@ -325,8 +325,11 @@ void fdgpu_matches_free(fd_match_rec *m, int32_t *residues);
  * (src/cli/workflows/query_pdb.rs:376-452) would call instead of the single-index count_query / retrieval: rank 0 creates a unique id and
  * hands it to the other ranks by any means (file, MPI, env), every rank calls fdgpu_comm_init on its own context / GPU, then per batch of
  * queries fdgpu_sharded_count_query[_maps] and fdgpu_sharded_retrieve.  RCCL is bound at run time (dlopen); without it these calls return
- * FDGPU_EHIP.  The collectives are issued for every world size, one included.  A rank whose local step fails still takes part in the
- * call's collectives (its message carries the error) and every rank returns an error: no rank is left waiting. */
+ * FDGPU_EHIP.  The collectives are issued for every world size, one included.  A rank whose LOCAL STEP fails (posting lengths, scoring,
+ * retrieval) still takes part in the call's collectives (zeros in the sum, its status in the gathered message) and every rank returns an
+ * error: no rank is left waiting.  The exchange buffers of ordinary calls are reserved at fdgpu_comm_init.  A rank that cannot grow them
+ * beyond that reserve, or whose HIP runtime fails between two collectives of a call, aborts the communicator (ncclCommAbort) and returns
+ * FDGPU_EHIP: the communicator is then unusable on every rank (later calls fail at once) and must be created anew. */
 #define FDGPU_COMM_ID_BYTES 128
 typedef struct fdgpu_comm fdgpu_comm;
 int fdgpu_comm_unique_id(uint8_t id[FDGPU_COMM_ID_BYTES]);

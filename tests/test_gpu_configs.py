@@ -212,7 +212,7 @@ def test_batch_of_shipped_queries_equals_singles(human):
             assert a["rmsd"] == b["rmsd"] and a["idf"] == b["idf"]
 
 
-def test_whole_structure_query_at_human_scale(human):
+def test_whole_structure_query_at_human_scale(human, monkeypatch):
     """configs[4] (no -q): a ~300-residue database structure as the query, against all 20,500 structures"""
     import folddisco_amd as fd
     from folddisco_amd import dist as fdist
@@ -241,6 +241,15 @@ def test_whole_structure_query_at_human_scale(human):
     # the same prefilter through the fused entry point (rows sliced at node boundaries, selection and ranking on the device)
     top = fd.count_query_maps(ctx, ix, [qm], human["pen"], total_structures=HUMAN, top_n=1000)[0]
     assert top.tobytes() == fdist.rank_hits(recs, 1000).tobytes()
+    # ... which scores a query of this size per (tile of structures, slice of the rows) in LDS (k_qt_score<BIG>: sums per slice, reduction,
+    # survivors' row bits by a second decode) — against the occupancy-row path (FDGPU_QTILE=0) and the ranked full list, other cuts included
+    for N in (1, 20, 3000):
+        monkeypatch.setenv("FDGPU_QTILE", "1")
+        t1 = fd.count_query_maps(ctx, ix, [qm], human["pen"], total_structures=HUMAN, top_n=N)[0]
+        monkeypatch.setenv("FDGPU_QTILE", "0")
+        t0 = fd.count_query_maps(ctx, ix, [qm], human["pen"], total_structures=HUMAN, top_n=N)[0]
+        assert t1.tobytes() == t0.tobytes() == fdist.rank_hits(recs, N).tobytes(), N
+    monkeypatch.delenv("FDGPU_QTILE")
     got = fq.retrieve(ctx, batch, None, cand, qm, qb)
     n = _check_matches(got, cand, ps, oq, om)
     assert n >= 20 and max(sum(1 for x in g["processed"] if x >= 0) for g in got) == b - a     # the structure matches itself entirely

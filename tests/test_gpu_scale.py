@@ -270,3 +270,77 @@ def test_device_merge_of_gathered_messages():
     bad = np.concatenate([fdist.build_message(ctx, per_rank[0], top_n), fdist.build_message(ctx, [per_rank[1][0][:0]] * T, top_n, status=2)])
     with pytest.raises(FdgpuError, match="rank 1 failed"):
         fdist.merge_gathered(ctx, bad, 2, T, top_n)
+
+
+def test_config2_ecoli_zinc_finger_against_oracle_outright():
+    """BASELINE.json configs[1] as written — "E. coli proteome index build + query/zinc_finger.txt on 1 MI355X" — against the oracle OUTRIGHT:
+    4,400 synthetic structures with the reference's zinc-finger motif (query/zinc_finger.txt) planted into 24 of them.  The oracle hashes
+    every structure itself and builds its own index (its dense two-pass table build); the GPU index must equal it byte for byte, the query
+    map bit for bit, count_query over ALL structures (counts exact, idf 1e-5), the device-ranked top N, and the matches of the top 32
+    candidates (residues exact, RMSD 1e-4) — no recount, no property check."""
+    import folddisco_amd as fd
+    import oracle
+    from folddisco_amd import dist as fdist
+    from folddisco_amd import query as fq
+    from folddisco_amd import structure as st
+    from folddisco_amd import synth
+    from tests.test_gpu_configs import _check_matches, _ostruct, _parse_query_file, _rot
+    ctx = fd.Context(0)
+    ps = synth.to_packed(synth.generate(ECOLI, seed=1729))
+    rng = np.random.Generator(np.random.PCG64(11))
+    path, qstr = _parse_query_file("zinc_finger.txt")
+    q = st.read_compact_structure(path)
+    res = fq.parse_query_string(qstr, q.chains[0])
+    pairs = [(q.get_index(c, r), s) for c, r, s in res]
+    idx = np.array([i for i, _ in pairs])
+    planted = np.sort(rng.permutation(ECOLI)[:24])
+    extra = np.zeros(ECOLI, np.int64)
+    ins_pos, ins = [], dict(n_xyz=[], ca_xyz=[], cb_xyz=[], aa=[])
+    for t, sid in enumerate(planted):
+        R, tr = _rot(rng), rng.normal(0, 30, 3) + 60.0
+        noise = 0.0 if t % 2 == 0 else 0.12
+        for key, src in (("n_xyz", q.n_xyz), ("ca_xyz", q.ca_xyz), ("cb_xyz", q.cb_xyz)):
+            x = src[idx].astype(np.float64) @ R.T + tr + rng.normal(0, 1, (len(idx), 3)) * noise
+            ins[key].append(np.round(x, 3).astype(np.float32))
+        ins["aa"].append(q.aa[idx])
+        ins_pos.append(np.full(len(idx), int(ps.res_off[sid + 1])))
+        extra[sid] += len(idx)
+    pos = np.concatenate(ins_pos)
+    order = np.argsort(pos, kind="stable")
+    cat = {k: np.concatenate(v)[order] for k, v in ins.items()}
+    new_off = ps.res_off.astype(np.int64).copy()
+    new_off[1:] += np.cumsum(extra)
+    ps = fd.PackedStructures(new_off.astype(np.uint64), np.insert(ps.n_xyz, pos[order], cat["n_xyz"], axis=0), np.insert(ps.ca_xyz, pos[order], cat["ca_xyz"], axis=0),
+                             np.insert(ps.cb_xyz, pos[order], cat["cb_xyz"], axis=0), np.insert(ps.aa, pos[order], cat["aa"]))
+    batch = ctx.upload(ps)
+    ix = fd.FolddiscoIndex.build(ctx, batch)
+    # --- the oracle's own index of the same structures
+    structs = [_ostruct(ps, s) for s in range(ECOLI)]
+    oh, ooff = oracle.hash_batch(structs)
+    oix = oracle.build_index_from_lists_mt(oh, ooff, 16)
+    v, h, o = ix.export()
+    assert np.array_equal(h, oix.hashes()) and np.array_equal(o, oix.offsets()) and np.array_equal(v, oix.values())
+    nres = np.diff(ps.res_off).astype(np.uint64)
+    pen = fd.length_penalty(nres, 0.5)
+    # --- query map, prefilter over all structures, ranked selection
+    qb = ctx.upload(fd.PackedStructures.concat([q.as_item()]))
+    qm = fq.make_query_map(ctx, qb, idx.astype(np.uint32), [s for _, s in pairs], ix, float(ECOLI))
+    oq = oracle.read_pdb(path)
+    om = oracle.make_query_map(oq, qstr, oix, float(ECOLI))
+    oa = om.arrays()
+    assert np.array_equal(qm.hash, oa["hash"]) and np.array_equal(qm.qi, oa["qi"]) and np.array_equal(qm.qj, oa["qj"])
+    assert np.array_equal(qm.idf.view(np.uint32), oa["idf"].view(np.uint32))
+    recs = fd.count_query(ctx, ix, qm.hash, qm.qi, qm.qj, pen, total_structures=ECOLI, as_array=True)
+    want = oracle.count_query(om, oix, nres)
+    assert [(int(r["nid"]), int(r["total_match_count"]), int(r["node_count"]), int(r["edge_count"])) for r in recs] == \
+           [(w["nid"], w["total_match_count"], w["node_count"], w["edge_count"]) for w in want]
+    assert np.allclose(recs["idf"], [w["idf"] for w in want], rtol=1e-5, atol=0)
+    assert set(planted.tolist()) <= set(int(r["nid"]) for r in recs)
+    top = fd.count_query_maps(ctx, ix, [qm], pen, total_structures=ECOLI, top_n=1000)[0]
+    assert top.tobytes() == fdist.rank_hits(recs, 1000).tobytes()
+    # --- retrieval of the top 32 candidates
+    cand = top["nid"][:32].astype(np.uint32)
+    got = fq.retrieve(ctx, batch, None, cand, qm, qb)
+    n = _check_matches(got, cand, ps, oq, om)
+    full = sum(1 for g in got if all(x >= 0 for x in g["processed"]))
+    assert n >= 12 and full >= 12          # the noise-free plants, at least, are recovered whole

@@ -17,20 +17,12 @@ def main():
     ap.add_argument("--structures", type=int, default=67750)
     a = ap.parse_args()
     import numpy as np
-    import torch
-    import folddisco_amd as fd
-    from folddisco_amd import synth
+    import folddisco_amd as fd  # noqa: F401
+    from _resident import build_resident
     from folddisco_amd.api import PackedStructures, count_query_maps, length_penalty
     from folddisco_amd.query import make_query_map, retrieve_batch
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
     S = a.structures
-    d = synth.generate(S, seed=7, device=dev)
-    ctx = fd.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
-    ro = d["res_off"].contiguous()
-    batch = ctx.wrap_device(S, int(ro[-1].item()), ro.data_ptr(), d["n_xyz"].data_ptr(), d["ca_xyz"].data_ptr(), d["cb_xyz"].data_ptr(),
-                            d["aa"].data_ptr(), None, keepalive=(ro, d))
-    ix = fd.FolddiscoIndex.build(ctx, batch)
+    ctx, batch, ix, d, ro = build_resident(S)
     roh = ro.cpu().numpy()
     nres = np.diff(roh).astype(np.uint64)
     ix.set_penalty(length_penalty(nres, 0.5))
