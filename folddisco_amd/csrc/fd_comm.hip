@@ -540,6 +540,72 @@ extern "C" int fdgpu_sharded_count_query_maps(fdgpu_ctx *c, fdgpu_comm *m, const
     return rc;
 }
 
+// What every rank runs on the gathered retrieval payloads: rank r's block (stride `bytes`) = its match records, then (at mbytes) its residue
+// ints, both in (query, slot, component) order; all_cnt[r][t] = its matches of query t.  Per query the ranks' matches are merged by candidate
+// slot (stable: a slot belongs to one rank).  Outputs as fdgpu_retrieve_batch returns them.
+static int merge_retrieved(int W, uint64_t n_queries, const uint64_t *all_cnt, const uint8_t *all, size_t bytes, size_t mbytes, const uint64_t *nres_per,
+                           fd_match_rec **matches, uint64_t **match_off, int32_t **residues, uint64_t **res_off) {
+    uint64_t tot_m = 0, tot_r = 0;
+    for (int r = 0; r < W; ++r)
+        for (uint64_t t = 0; t < n_queries; ++t) { tot_m += all_cnt[(size_t)r * (n_queries + 1) + t]; tot_r += all_cnt[(size_t)r * (n_queries + 1) + t] * nres_per[t]; }
+    fd_match_rec *om = (fd_match_rec *)malloc(std::max<uint64_t>(tot_m, 1) * sizeof(fd_match_rec));
+    int32_t *orr = (int32_t *)malloc(std::max<uint64_t>(tot_r, 1) * 4);
+    uint64_t *omo = (uint64_t *)calloc(n_queries + 1, 8), *oro = (uint64_t *)calloc(n_queries + 1, 8);
+    if (!om || !orr || !omo || !oro) { free(om); free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
+    std::vector<uint64_t> mbase((size_t)W, 0), rbase((size_t)W, 0);
+    struct Ref { uint32_t slot, rank; uint64_t mi, ri; };
+    std::vector<Ref> refs;
+    uint64_t wm = 0, wr = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        refs.clear();
+        for (int r = 0; r < W; ++r) {
+            const uint64_t k = all_cnt[(size_t)r * (n_queries + 1) + t];
+            const fd_match_rec *src = (const fd_match_rec *)(all + (size_t)r * bytes) + mbase[r];
+            for (uint64_t z = 0; z < k; ++z) refs.push_back({src[z].cand, (uint32_t)r, mbase[r] + z, rbase[r] + z * nres_per[t]});
+            mbase[r] += k; rbase[r] += k * nres_per[t];
+        }
+        std::stable_sort(refs.begin(), refs.end(), [](const Ref &a, const Ref &b) { return a.slot < b.slot; });
+        omo[t] = wm; oro[t] = wr;
+        for (const Ref &f : refs) {
+            om[wm++] = ((const fd_match_rec *)(all + (size_t)f.rank * bytes))[f.mi];
+            if (nres_per[t]) memcpy(orr + wr, (const int32_t *)(all + (size_t)f.rank * bytes + mbytes) + f.ri, nres_per[t] * 4);
+            wr += nres_per[t];
+        }
+    }
+    omo[n_queries] = wm; oro[n_queries] = wr;
+    *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
+    return FDGPU_OK;
+}
+// The unpack + merge of fdgpu_sharded_retrieve alone, on hand-made contributions of `world` ranks (tests drive ragged, empty and failing ranks
+// through it on one GPU): counts[r * (n_queries + 1) + t] = rank r's matches of query t, counts[r * (n_queries + 1) + n_queries] = its status
+// (0 = fine); rank_matches[r] / rank_residues[r] = its records (cand = slot in the query's GLOBAL candidate list) and residue ints in (query,
+// slot, component) order; nres_per[t] = residue ints per match of query t.  A non-zero status of any rank: FDGPU_EHIP, like the real call.
+extern "C" int fdgpu_debug_merge_retrieved(fdgpu_ctx *c, uint32_t world, uint64_t n_queries, const uint64_t *counts, const fd_match_rec *const *rank_matches,
+                                           const int32_t *const *rank_residues, const uint64_t *nres_per, fd_match_rec **matches, uint64_t **match_off,
+                                           int32_t **residues, uint64_t **res_off) { FD_LOCK(c);
+    if (!c || !world || !counts || !rank_matches || !rank_residues || (n_queries && !nres_per) || !matches || !match_off || !residues || !res_off) return FDGPU_EINVAL;
+    *matches = nullptr; *match_off = nullptr; *residues = nullptr; *res_off = nullptr;
+    for (uint32_t r = 0; r < world; ++r)
+        if (counts[(size_t)r * (n_queries + 1) + n_queries]) { c->err = "sharded retrieve: rank " + std::to_string(r) + " failed its local step"; return FDGPU_EHIP; }
+    uint64_t max_m = 1, max_r = 1;
+    for (uint32_t r = 0; r < world; ++r) {
+        uint64_t tm = 0, tr = 0;
+        for (uint64_t t = 0; t < n_queries; ++t) { tm += counts[(size_t)r * (n_queries + 1) + t]; tr += counts[(size_t)r * (n_queries + 1) + t] * nres_per[t]; }
+        max_m = std::max(max_m, tm); max_r = std::max(max_r, tr);
+    }
+    const size_t mbytes = max_m * sizeof(fd_match_rec), rbytes = ((max_r * 4 + 15) & ~(size_t)15), bytes = mbytes + rbytes;
+    std::vector<uint8_t> all(bytes * world, 0);        // the padded payload layout of the all-gather
+    for (uint32_t r = 0; r < world; ++r) {
+        uint64_t tm = 0, tr = 0;
+        for (uint64_t t = 0; t < n_queries; ++t) { tm += counts[(size_t)r * (n_queries + 1) + t]; tr += counts[(size_t)r * (n_queries + 1) + t] * nres_per[t]; }
+        if (tm && !rank_matches[r]) return FDGPU_EINVAL;
+        if (tr && !rank_residues[r]) return FDGPU_EINVAL;
+        if (tm) memcpy(all.data() + (size_t)r * bytes, rank_matches[r], tm * sizeof(fd_match_rec));
+        if (tr) memcpy(all.data() + (size_t)r * bytes + mbytes, rank_residues[r], tr * 4);
+    }
+    return merge_retrieved((int)world, n_queries, counts, all.data(), bytes, mbytes, nres_per, matches, match_off, residues, res_off);
+}
+
 // Sharded retrieval: query t's candidates cand_nid[cand_off[t] .. cand_off[t+1]) are GLOBAL structure ids in ranking order (what
 // fdgpu_sharded_count_query[_maps] returned, cut to the number of structures to match); this rank holds the coordinates of structures
 // first_id .. first_id + n_structures(db) - 1 and matches the candidates inside that range (fdgpu_retrieve_batch on its shard), then the
@@ -613,34 +679,9 @@ extern "C" int fdgpu_sharded_retrieve(fdgpu_ctx *c, fdgpu_comm *m, const fdgpu_b
     HCHK_C(c, m, hipMemcpyAsync(all.data(), m->recv.p, bytes * W, hipMemcpyDeviceToHost, st));
     HCHK_C(c, m, hipStreamSynchronize(st));
     // 5. merge per query by candidate slot (a slot belongs to one rank, whose matches arrive in slot / component order)
-    uint64_t tot_m = 0, tot_r = 0;
-    for (int r = 0; r < W; ++r)
-        for (uint64_t t = 0; t < n_queries; ++t) { tot_m += all_cnt[(size_t)r * (n_queries + 1) + t]; tot_r += all_cnt[(size_t)r * (n_queries + 1) + t] * nres_per[t]; }
-    fd_match_rec *om = (fd_match_rec *)malloc(std::max<uint64_t>(tot_m, 1) * sizeof(fd_match_rec));
-    int32_t *orr = (int32_t *)malloc(std::max<uint64_t>(tot_r, 1) * 4);
-    uint64_t *omo = (uint64_t *)calloc(n_queries + 1, 8), *oro = (uint64_t *)calloc(n_queries + 1, 8);
-    if (!om || !orr || !omo || !oro) { free(om); free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
-    std::vector<uint64_t> mbase((size_t)W, 0), rbase((size_t)W, 0);
-    struct Ref { uint32_t slot, rank; uint64_t mi, ri; };
-    std::vector<Ref> refs;
-    uint64_t wm = 0, wr = 0;
-    for (uint64_t t = 0; t < n_queries; ++t) {
-        refs.clear();
-        for (int r = 0; r < W; ++r) {
-            const uint64_t k = all_cnt[(size_t)r * (n_queries + 1) + t];
-            const fd_match_rec *src = (const fd_match_rec *)(all.data() + (size_t)r * bytes) + mbase[r];
-            for (uint64_t z = 0; z < k; ++z) refs.push_back({src[z].cand, (uint32_t)r, mbase[r] + z, rbase[r] + z * nres_per[t]});
-            mbase[r] += k; rbase[r] += k * nres_per[t];
-        }
-        std::stable_sort(refs.begin(), refs.end(), [](const Ref &a, const Ref &b) { return a.slot < b.slot; });
-        omo[t] = wm; oro[t] = wr;
-        for (const Ref &f : refs) {
-            om[wm++] = ((const fd_match_rec *)(all.data() + (size_t)f.rank * bytes))[f.mi];
-            if (nres_per[t]) memcpy(orr + wr, (const int32_t *)(all.data() + (size_t)f.rank * bytes + mbytes) + f.ri, nres_per[t] * 4);
-            wr += nres_per[t];
-        }
-    }
-    omo[n_queries] = wm; oro[n_queries] = wr;
+    fd_match_rec *om = nullptr; int32_t *orr = nullptr; uint64_t *omo = nullptr, *oro = nullptr;
+    int mrc = merge_retrieved(W, n_queries, all_cnt.data(), all.data(), bytes, mbytes, nres_per.data(), &om, &omo, &orr, &oro);
+    if (mrc) return mrc;
     *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
     return FDGPU_OK;
 }

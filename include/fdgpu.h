@@ -384,6 +384,14 @@ int fdgpu_count_query_maps_top_global(fdgpu_ctx *ctx, const fdgpu_index *ix, uin
 uint64_t fdgpu_comm_message_bytes(uint64_t n_queries, uint32_t top_n);
 int fdgpu_debug_merge_gathered(fdgpu_ctx *ctx, uint32_t world, uint64_t n_queries, uint32_t top_n, const uint8_t *messages,
                                fd_count_rec **out, uint64_t **out_off);
+/* The unpack + merge step of fdgpu_sharded_retrieve alone, on hand-made contributions of `world` ranks (host arrays): counts[r * (n_queries + 1) + t]
+ * = matches rank r found for query t, counts[r * (n_queries + 1) + n_queries] = its status (0 = fine); rank_matches[r] / rank_residues[r] = its
+ * records (cand = slot in the query's GLOBAL candidate list) and residue ints in (query, slot, component) order; nres_per[t] = residue ints per
+ * match of query t (2 * n_indices).  Output as fdgpu_retrieve_batch.  Lets a single-GPU test drive the multi-rank merge with ragged, empty and
+ * failing ranks. */
+int fdgpu_debug_merge_retrieved(fdgpu_ctx *ctx, uint32_t world, uint64_t n_queries, const uint64_t *counts, const fd_match_rec *const *rank_matches,
+                                const int32_t *const *rank_residues, const uint64_t *nres_per, fd_match_rec **matches, uint64_t **match_off,
+                                int32_t **residues, uint64_t **res_off);
 
 /* ---- structure ingest (host, multi-threaded) ---------------------------------------------------------------
  * PDB / mmCIF text (optionally gzip) -> the packed arrays of fd_batch_desc plus what the .lookup file and the result

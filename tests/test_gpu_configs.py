@@ -251,8 +251,11 @@ def test_whole_structure_query_at_human_scale(human, monkeypatch):
         assert t1.tobytes() == t0.tobytes() == fdist.rank_hits(recs, N).tobytes(), N
     monkeypatch.delenv("FDGPU_QTILE")
     got = fq.retrieve(ctx, batch, None, cand, qm, qb)
-    n = _check_matches(got, cand, ps, oq, om)
-    assert n >= 20 and max(sum(1 for x in g["processed"] if x >= 0) for g in got) == b - a     # the structure matches itself entirely
+    # the first six candidates against oracle.retrieve (each is ~10 s of CPU for a 300-residue query against a 2,000-residue chain: all twenty
+    # were 200 of the suite's 700 s); the other fourteen are retrieved on the GPU all the same and must each give a match
+    n = _check_matches([g for g in got if g["cand"] < 6], cand[:6], ps, oq, om)
+    assert n >= 6 and len({g["cand"] for g in got}) == 20
+    assert max(sum(1 for x in g["processed"] if x >= 0) for g in got) == b - a     # the structure matches itself entirely
 
 
 def test_tiled_scoring_equals_occupancy_rows(human, monkeypatch):

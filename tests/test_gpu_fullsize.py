@@ -361,8 +361,8 @@ def test_afdb50_scale_2000000_ids_beyond_2_21_and_whole_structure_query():
     lap("oracle query map")
     n = 0
     for slot, it in enumerate(c_items):
-        if slot not in (0, 1, 9, 19):      # the oracle needs ~20 s per 300-residue candidate of a whole-structure query: the best, the second, one from the
-            continue                       # middle and the last of the top 20 (the other slots are covered by device == host == oracle at 20,500 structures)
+        if slot not in (0, 19):            # the oracle needs ~20 s per 300-residue candidate of a whole-structure query: the best and the last of the top 20
+            continue                       # (the other slots are covered by device == host == oracle at 20,500 structures; four slots were 80 s of the suite)
         R = oracle.retrieve(_ostruct(it), oq, om)
         mine = [g for g in got if g["cand"] == slot]
         assert len(mine) == len(R["processed"]), slot
@@ -371,5 +371,5 @@ def test_afdb50_scale_2000000_ids_beyond_2_21_and_whole_structure_query():
             assert g["from_hash"] == [-1 if x is None else x[2] for x in rh["residues"]], slot
             assert abs(g["rmsd"] - rp["rmsd"]) <= 1e-4 and g["idf"] == pytest.approx(rp["idf"], rel=1e-5)
             n += 1
-    assert n >= 4 and len(got) >= 20 and max(sum(1 for x in g["processed"] if x >= 0) for g in got) == nq_res     # the structure matches itself entirely
-    lap("oracle.retrieve x 4")
+    assert n >= 2 and len(got) >= 20 and max(sum(1 for x in g["processed"] if x >= 0) for g in got) == nq_res     # the structure matches itself entirely
+    lap("oracle.retrieve x 2")

@@ -344,3 +344,71 @@ def test_config2_ecoli_zinc_finger_against_oracle_outright():
     n = _check_matches(got, cand, ps, oq, om)
     full = sum(1 for g in got if all(x >= 0 for x in g["processed"]))
     assert n >= 12 and full >= 12          # the noise-free plants, at least, are recovered whole
+
+
+def test_merge_of_gathered_retrieval_payloads():
+    """What every rank runs after fdgpu_sharded_retrieve's second all-gather (padded payloads of match records + residue lists, merged per query
+    by candidate slot) driven with hand-made contributions of 2, 3 and 8 ranks: ragged counts, ranks without matches, queries nobody matched,
+    several components per slot (their order inside a rank must survive), a rank reporting an error."""
+    import ctypes as C
+    import folddisco_amd as fd
+    from folddisco_amd._lib import MatchRec, u64p
+    from folddisco_amd.api import FdgpuError
+    from folddisco_amd.query import MATCH_DTYPE
+    ctx = fd.Context(0)
+    rng = np.random.Generator(np.random.PCG64(2027))
+    i32p = C.POINTER(C.c_int32)
+    for world in (2, 3, 8):
+        nq = 5
+        nres_per = np.array([6, 8, 6, 10, 4], np.uint64)
+        counts = np.zeros((world, nq + 1), np.uint64)
+        rank_m, rank_r = [], []
+        for r in range(world):
+            ms, rs = [], []
+            for t in range(nq):
+                if t == 3 or (r == 1 and world > 2):        # a query nobody matched; a rank without any match
+                    continue
+                slots = np.sort(rng.choice(np.arange(r, 64, world), size=int(rng.integers(0, 6)), replace=False))     # a slot belongs to ONE rank
+                for s_ in slots:
+                    for comp in range(int(rng.integers(1, 4))):      # components of a slot, in this order
+                        m = np.zeros(1, MATCH_DTYPE)
+                        m["cand"] = s_; m["same"] = comp; m["idf"] = rng.random(); m["rmsd"] = rng.random()
+                        m["rot"] = rng.random(9); m["tran"] = rng.random(3); m["metrics"] = rng.random(5)
+                        ms.append(m); rs.append(rng.integers(-1, 300, size=int(nres_per[t])).astype(np.int32))
+                        counts[r, t] += 1
+            rank_m.append(np.concatenate(ms) if ms else np.zeros(0, MATCH_DTYPE))
+            rank_r.append(np.concatenate(rs) if rs else np.zeros(0, np.int32))
+
+        def call(cnt):
+            pm = (C.POINTER(MatchRec) * world)(*[x.ctypes.data_as(C.POINTER(MatchRec)) if len(x) else None for x in rank_m])
+            pr = (i32p * world)(*[x.ctypes.data_as(i32p) if len(x) else None for x in rank_r])
+            om, omo, orr, oro = C.POINTER(MatchRec)(), u64p(), i32p(), u64p()
+            cnt = np.ascontiguousarray(cnt)
+            ctx.check(ctx.L.fdgpu_debug_merge_retrieved(ctx.h, world, nq, cnt.ctypes.data_as(u64p), pm, pr, nres_per.ctypes.data_as(u64p),
+                                                        C.byref(om), C.byref(omo), C.byref(orr), C.byref(oro)))
+            mo = np.ctypeslib.as_array(omo, (nq + 1,)).copy(); ro = np.ctypeslib.as_array(oro, (nq + 1,)).copy()
+            m = np.frombuffer(C.string_at(om, int(mo[-1]) * MATCH_DTYPE.itemsize), MATCH_DTYPE).copy() if mo[-1] else np.zeros(0, MATCH_DTYPE)
+            res = np.ctypeslib.as_array(orr, (max(int(ro[-1]), 1),)).copy()[:int(ro[-1])]
+            ctx.L.fdgpu_matches_free(om, orr); ctx.L.fdgpu_free(omo); ctx.L.fdgpu_free(oro)
+            return m, mo, res, ro
+        m, mo, res, ro = call(counts)
+        # the expected merge: per query, every rank's records in rank order, stably sorted by slot
+        at_m, at_r = [0] * world, [0] * world
+        wm, wr = [], []
+        exp_mo, exp_ro = [0], [0]
+        for t in range(nq):
+            refs = []
+            for r in range(world):
+                k = int(counts[r, t])
+                for z in range(k):
+                    refs.append((int(rank_m[r][at_m[r] + z]["cand"]), len(refs), r, at_m[r] + z, at_r[r] + z * int(nres_per[t])))
+                at_m[r] += k; at_r[r] += k * int(nres_per[t])
+            refs.sort(key=lambda x: (x[0], x[1]))
+            for _, _, r, mi, ri in refs:
+                wm.append(rank_m[r][mi:mi + 1]); wr.append(rank_r[r][ri:ri + int(nres_per[t])])
+            exp_mo.append(len(wm)); exp_ro.append(sum(len(x) for x in wr))
+        assert mo.tolist() == exp_mo and ro.tolist() == exp_ro
+        assert m.tobytes() == (np.concatenate(wm).tobytes() if wm else b"") and res.tobytes() == (np.concatenate(wr).tobytes() if wr else b"")
+        bad = counts.copy(); bad[world - 1, nq] = 5       # the last rank failed its local step: every rank returns the error
+        with pytest.raises(FdgpuError):
+            call(bad)
