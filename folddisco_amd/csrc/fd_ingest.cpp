@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -77,6 +78,24 @@ bool parse_f32(const char *s, size_t n, float *out) {
     while (n && (*s == ' ' || *s == '\t')) { ++s; --n; }
     while (n && (s[n - 1] == ' ' || s[n - 1] == '\t' || s[n - 1] == '\r')) --n;
     if (!n || n > 63) return false;
+    {
+        // the fields of a PDB file are "%8.3f" / "%6.2f": [sign] digits [. digits] with a mantissa below 2^24 and at most 10 decimals — both
+        // operands of mantissa / 10^decimals are then exact floats and ONE IEEE division gives the correctly rounded value (Clinger's fast
+        // path), the bits strtof and Rust's parser return (strtof per field was most of the parser's time)
+        static const float P10[11] = {1.0f, 1e1f, 1e2f, 1e3f, 1e4f, 1e5f, 1e6f, 1e7f, 1e8f, 1e9f, 1e10f};
+        size_t k = 0;
+        const bool neg = s[0] == '-';
+        if (s[0] == '-' || s[0] == '+') k = 1;
+        uint32_t m = 0, dec = 0, nd = 0;
+        bool dot = false, simple = k < n;
+        for (; k < n && simple; ++k) {
+            const char c = s[k];
+            if (c >= '0' && c <= '9') { m = m * 10u + (uint32_t)(c - '0'); ++nd; dec += dot ? 1u : 0u; simple = m < (1u << 24) && dec <= 10u; }
+            else if (c == '.' && !dot) dot = true;
+            else simple = false;
+        }
+        if (simple && nd) { const float v = (float)m / P10[dec]; *out = neg ? -v : v; return true; }
+    }
     char buf[64];
     bool digit = false, word = false;
     for (size_t k = 0; k < n; ++k) {
@@ -118,7 +137,27 @@ bool parse_u64(const char *s, size_t n, uint64_t *out) {
 }
 
 bool read_all(const char *path, std::string *out) {
-    gzFile f = gzopen(path, "rb");   // transparent for uncompressed files
+    {   // a file that does not open with the gzip magic is read as it is (zlib's transparent mode copies through its own buffer)
+        int fd = open(path, O_RDONLY);
+        if (fd < 0) return false;
+        unsigned char magic[2] = {0, 0};
+        struct stat sb;
+        const bool plain = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && (pread(fd, magic, 2, 0) < 2 || magic[0] != 0x1f || magic[1] != 0x8b);
+        if (plain) {
+            out->resize((size_t)sb.st_size);
+            size_t got = 0;
+            while (got < out->size()) {
+                const ssize_t r = read(fd, &(*out)[got], out->size() - got);
+                if (r <= 0) break;
+                got += (size_t)r;
+            }
+            close(fd);
+            out->resize(got);
+            return true;
+        }
+        close(fd);
+    }
+    gzFile f = gzopen(path, "rb");
     if (!f) return false;
     gzbuffer(f, 1 << 18);
     out->clear();
@@ -381,6 +420,13 @@ int pack_parsed(const std::vector<Compact> &parts, uint64_t max_residue, fd_pars
 }
 }  // namespace
 
+// where the ingest threads spend their time, summed over the threads of every fdgpu_parse_structures call of the process:
+// [0] read + inflate (zlib), [1] text -> atom records, [2] CompactStructure::build, [3] files, [4] inflated bytes
+static std::atomic<uint64_t> g_ingest_ns[5];
+extern "C" void fdgpu_ingest_stats(double out[5], int reset) {
+    for (int k = 0; k < 5; ++k) { if (out) out[k] = k < 3 ? (double)g_ingest_ns[k].load() * 1e-9 : (double)g_ingest_ns[k].load(); if (reset) g_ingest_ns[k] = 0; }
+}
+
 extern "C" int fdgpu_parse_structures(const char *const *paths, uint64_t n, uint32_t n_threads, uint64_t max_residue, fd_parsed **out) {
     if (!out || (n && !paths)) return FDGPU_EINVAL;
     *out = nullptr;
@@ -393,12 +439,20 @@ extern "C" int fdgpu_parse_structures(const char *const *paths, uint64_t n, uint
             uint64_t k = next.fetch_add(1);
             if (k >= n) break;
             Compact &C = parts[k];
+            const auto t0 = std::chrono::steady_clock::now();
             if (!paths[k] || !read_all(paths[k], &txt)) continue;
+            const auto t1 = std::chrono::steady_clock::now();
             atoms.clear();
             std::string p(paths[k]);
             if (ends_with_ci(p, ".cif") || ends_with_ci(p, ".cif.gz") || ends_with_ci(p, ".mmcif") || ends_with_ci(p, ".mmcif.gz")) parse_cif(txt, &atoms);
             else parse_pdb(txt, &atoms, ends_with_ci(p, ".gz"));
+            const auto t2 = std::chrono::steady_clock::now();
             build_compact(atoms, &C);
+            const auto t3 = std::chrono::steady_clock::now();
+            g_ingest_ns[0] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+            g_ingest_ns[1] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
+            g_ingest_ns[2] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t3 - t2).count();
+            g_ingest_ns[3] += 1; g_ingest_ns[4] += txt.size();
             if (max_residue && C.nres_raw > max_residue) {   // controller/mod.rs:313-318: id kept, no hashes, nres = 0
                 uint64_t raw = C.nres_raw;
                 uint8_t fc = C.first_chain;

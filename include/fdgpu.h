@@ -417,6 +417,9 @@ typedef struct fd_parsed {
 } fd_parsed;
 int fdgpu_parse_structures(const char *const *paths, uint64_t n, uint32_t n_threads, uint64_t max_residue, fd_parsed **out);
 void fdgpu_parsed_free(fd_parsed *p);
+/* thread-seconds the ingest spent so far (summed over the threads of all fdgpu_parse_structures calls of the process): out[0] read + inflate,
+ * out[1] text -> atom records, out[2] CompactStructure::build, out[3] files, out[4] inflated bytes; reset != 0 clears the counters */
+void fdgpu_ingest_stats(double out[5], int reset);
 
 /* Foldcomp input (reference: src/structure/io/fcz.rs — FoldcompDbReader::new :41-74, read_single_structure_by_id :203-230,
  * and the vendored decoder behind foldcomp_process, lib/foldcomp/foldcompffi.cpp).  fdgpu_foldcomp_decode turns one database

@@ -422,3 +422,28 @@ def test_bench_input_writers_round_trip_through_the_ingest(tmp_path):
     ref = structure.FoldcompDb(src)
     ps0, nres0, *_ = structure.read_packed(ref.keys, threads=2, foldcomp=ref)
     assert np.array_equal(nres2, np.tile(nres0, 3)[:60]) and np.array_equal(ps2.ca_xyz[: len(ps0.ca_xyz)], ps0.ca_xyz)
+
+
+def test_fixed_format_number_fields_parse_like_strtof(tmp_path):
+    """The ingest's fast path for "%8.3f" / "%6.2f" fields (mantissa below 2^24, one IEEE division by a power of ten) returns the bits the
+    correctly rounded decimal -> f32 conversion returns (Rust's str::parse::<f32>, glibc strtof, numpy): random coordinates over the whole
+    range of the format incl. negative zero, no fraction, leading '+', and fields that leave the fast path (8 digits, exponents)."""
+    from folddisco_amd.structure import read_compact_structures
+    rng = np.random.Generator(np.random.PCG64(404))
+    fields = ["%8.3f" % v for v in rng.uniform(-999.999, 9999.999, 3000)]
+    fields += ["  -0.000", "   0.000", "9999.999", "-999.999", "    12.5", "     100", "  +1.250", "16777.21", "99999.99", "1.25e+01", " 1677721", "16777217"]
+    lines, want = [], []
+    for k in range(0, len(fields) - 2, 3):
+        x, y, z = fields[k:k + 3]
+        r = k // 3 + 1
+        b = "%6.2f" % rng.uniform(0, 100)
+        for name in (" N  ", " CA ", " C  ", " CB "):
+            lines.append("ATOM  %5d %s ALA A%4d    %s%s%s  1.00%s           C" % (r % 100000, name, r % 10000, x.rjust(8)[:8], y.rjust(8)[:8], z.rjust(8)[:8], b))
+        want.append([np.float32(x), np.float32(y), np.float32(z)])
+    p = tmp_path / "fields.pdb"
+    p.write_text("\n".join(lines) + "\nEND\n")
+    cs = read_compact_structures([str(p)], threads=1)[0][0]
+    got = np.asarray(cs.ca_xyz, np.float32)
+    w = np.asarray(want, np.float32)[:len(got)]
+    assert len(got) >= len(want) - 1
+    assert np.array_equal(got.view(np.uint32), w.view(np.uint32))
