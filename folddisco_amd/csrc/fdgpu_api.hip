@@ -1363,7 +1363,8 @@ static uint64_t fd_rank_trim(fd_count_rec *r, uint64_t n, uint32_t top_n) {
 // takes the compacting path together with the other ranks).  Calls the device selection does not serve return host records as usual.
 int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                               const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
-                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev, int64_t known_segments, const long long *known_kidx) {
+                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev, int64_t known_segments, const long long *known_kidx,
+                              const uint64_t *known_len) {
     if (!c || !ix || !out || !out_off || !q_off || (ix->n_structures && !penalty && !ix->penalty)) return FDGPU_EINVAL;
     *out = nullptr; *out_off = nullptr;
     reset_timings(c);
@@ -1379,6 +1380,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     std::vector<uint32_t> rows_hash;
     std::vector<unsigned long long> rows_meta;
     std::vector<long long> rows_kidx;       // the rows' list positions when the caller knows them (query maps made against this index)
+    (void)known_len;                        // (lengths are per input row: only their sum matters below, no permutation needed)
     rows_hash.reserve(nq); rows_meta.reserve(nq);
     if (known_kidx) rows_kidx.reserve(nq);
     bool packed = true;
@@ -1407,7 +1409,21 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     hipError_t e = hipSuccess;
     auto need = [&](int w, size_t bytes) { if (e == hipSuccess) e = c->ws[w].ensure(bytes); };
     need(WS_MISC0, nq * 4); need(WS_MISC3, nq * 8); need(WS_TILE_H, (n_queries + 1) * 8); need(WS_MISC5, S * 4); need(WS_TOTAL, 64);
+    // the decoded stream of the tiled path (k_qt_rows): sized from the rows' posting lengths when the caller knows them — a list of n ids is at most
+    // n x (bytes of the largest id) bytes, a slot holds 16 of them, and every (row, cell) piece ends in one partly filled slot
+    uint64_t stream_cap = 0;
+    const bool qt_stream = [] { const char *e = getenv("FDGPU_QT_STREAM"); return !(e && e[0] == '0'); }();      // 0: pass B decodes the lists again (tests, measurement)
+    if (tiled && qt_stream && known_len && max_rows * (1u << (qt_tl2 - QT_CELL_LOG2)) <= (uint64_t)QT_MAXB * (qt_tl2 == 14 ? 512 : 256)) {
+        const uint64_t top_id = ix->first_id + S, vb = top_id < (1ull << 7) ? 1 : top_id < (1ull << 14) ? 2 : top_id < (1ull << 21) ? 3 : top_id < (1ull << 28) ? 4 : 5;
+        const uint64_t NCc = (S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2;
+        // a piece per (row, cell) where the list has an entry per cell; a list with entries 2^j cells apart is cut into pieces of < 96 bytes on
+        // average that every tile they span decodes once: at most 6 slots x tiles on top of its bytes
+        uint64_t slots = 0;
+        for (uint64_t r = 0; r < nq; ++r) slots += (known_len[r] * vb + 15) / 16 + NCc + 6ull * NT + 8;
+        if (slots < (1ull << 31)) stream_cap = slots + 1024;
+    }
     if (tiled) {
+        if (stream_cap) { need(WS_QT_STREAM, stream_cap * 34 + 64); need(WS_QT_STAB, (size_t)n_queries * NT * QT_MAXB * 8 + 64); }
         need(WS_CQ_KIDX, nq * 8); need(WS_CQ_NSEG, nq * 4);
         need(WS_QT_RANGES, (size_t)nq * ((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2) * 16); need(WS_QT_COMPACT, ((size_t)n_queries * NT << qt_tl2) * 8);
         need(WS_QT_COUNT, (size_t)n_queries * NT * 4); need(WS_QT_AUX, n_queries * sizeof(qt_aux) + 256);
@@ -1443,6 +1459,13 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         T.NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
         T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.compact = c->ws[WS_QT_COMPACT].as<uint2>(); T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
         T.ghist = nullptr; T.state = nullptr; T.aux = c->ws[WS_QT_AUX].as<qt_aux>(); T.out = nullptr; T.cap = 0;
+        T.stream_ids = nullptr; T.stream_row = nullptr; T.stream_tab = nullptr; T.stream_used = nullptr; T.stream_cap = 0;
+        if (stream_cap) {
+            uint8_t *sb = c->ws[WS_QT_STREAM].as<uint8_t>();
+            T.stream_ids = sb; T.stream_row = (uint16_t *)(sb + stream_cap * 32); T.stream_cap = (uint32_t)stream_cap;
+            T.stream_tab = c->ws[WS_QT_STAB].as<uint2>(); T.stream_used = (uint32_t *)(c->ws[WS_QT_STAB].as<uint8_t>() + (size_t)n_queries * NT * QT_MAXB * 8);
+            (void)hipMemsetAsync(T.stream_used, 0, 4, st);
+        }
         T.plan_log2 = QT_CELL_LOG2; T.slices = nullptr; T.n_slices = 0; T.partial = nullptr; T.g_bm = T.g_rank = T.g_tcount = T.g_nid = T.g_rowbits = nullptr;
         T.g_wpr = 0; T.g_eend = T.g_nend = nullptr;
         T.dbg = nullptr;
@@ -1460,6 +1483,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         T.NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
         T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.compact = c->ws[WS_QT_COMPACT].as<uint2>(); T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
         T.ghist = nullptr; T.state = nullptr; T.aux = c->ws[WS_QT_AUX].as<qt_aux>(); T.out = nullptr; T.cap = big_cap; T.dbg = nullptr;
+        T.stream_ids = nullptr; T.stream_row = nullptr; T.stream_tab = nullptr; T.stream_used = nullptr; T.stream_cap = 0;
         // slices of roughly equal posting counts: a row's list holds ~ S / 2^idf ids (idf = log2(S / length), its fixed-point image is in the metadata)
         std::vector<double> w(nq);
         double tot = 0;
@@ -1746,7 +1770,8 @@ int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_quer
     std::vector<uint32_t> qh, qn, qe;
     std::vector<float> qi;
     std::vector<long long> qk;
-    qh.reserve(nq); qn.reserve(nq); qe.reserve(nq); qi.reserve(nq);
+    std::vector<uint64_t> ql;       // the kept rows' posting lengths (local to this index only when the lengths are: the tiled path sizes its stream from them)
+    qh.reserve(nq); qn.reserve(nq); qe.reserve(nq); qi.reserve(nq); ql.reserve(nq);
     if (kidx) qk.reserve(nq);
     uint64_t at = 0;
     for (uint64_t t = 0; t < n_queries; ++t) {
@@ -1756,14 +1781,16 @@ int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_quer
             if (!len[at]) continue;
             qh.push_back(m->hash[k]); qn.push_back(m->qi[k]); qe.push_back(m->qj[k]);
             if (kidx) qk.push_back(kidx[at]);
+            ql.push_back(len[at]);
             qi.push_back(log2f(total_structures / (float)len[at]));       // f32 like the reference's (total / len).log2()
             if (seg) W += seg[at];
         }
         q_off[t + 1] = qh.size();
     }
-    if (qh.empty()) { qh.push_back(0); qn.push_back(0); qe.push_back(0); qi.push_back(0.0f); W = seg ? 0 : -1; qk.clear(); }
+    if (qh.empty()) { qh.push_back(0); qn.push_back(0); qe.push_back(0); qi.push_back(0.0f); W = seg ? 0 : -1; qk.clear(); ql.clear(); }
+    // (the lengths bound the LOCAL lists only when they are this index's own: the caller that passes kidx made the maps against it)
     return fd_count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off, allow_dense, dev, W,
-                                     kidx && qk.size() == qh.size() ? qk.data() : nullptr);
+                                     kidx && qk.size() == qh.size() ? qk.data() : nullptr, kidx && ql.size() == qh.size() ? ql.data() : nullptr);
 }
 extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty,
                                           float total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);

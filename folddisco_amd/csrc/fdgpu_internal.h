@@ -34,7 +34,7 @@ enum {
     WS_COUNTS, WS_CURSOR, WS_SEGOFF, WS_SCANTMP, WS_TOTAL, WS_KEYS_A, WS_IDS_A, WS_KEYS_B, WS_IDS_B, WS_GHIST, WS_TOT,
     WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
-    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS,
+    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS, WS_QT_STREAM, WS_QT_STAB,
     WS_CA_PERM, WS_OK_PERM, WS_AA_PERM, WS_SEG_TAB,
     WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT,
     WS_COUNT
@@ -176,7 +176,7 @@ struct fd_cq_dev_out { bool got = false, overflow = false; const void *recs = nu
 int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                               const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
                               fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev, int64_t known_segments = -1,
-                              const long long *known_kidx = nullptr);
+                              const long long *known_kidx = nullptr, const uint64_t *known_len = nullptr);
 int fd_posting_lengths_dev(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t **dev_lengths);
 uint64_t fd_maps_hashes(uint64_t n_queries, const fd_query_map *const *qms, std::vector<uint32_t> &h);
 int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const uint64_t *len,
@@ -246,6 +246,7 @@ struct cq_args {
 /* structures per workgroup (tile): 2^13 (64 KB of LDS accumulators, two workgroups per CU) or 2^14; qt_args.tile_log2 */
 #define QT_BINS 2048
 #define QT_MAX_ROWS 1024                   /* rows per query the survivors' row bits are laid out for */
+#define QT_MAXB 16                         /* row batches of a (query, tile) the decoded stream keeps a record of */
 struct qt_state { uint32_t thr_bin, above, thr_key, count; };      // same 16 bytes as topn_state / sel_state: consumers read .count
 struct qt_aux { uint32_t need_l2, shift2, edge, pad; };
 struct qt_args {
@@ -262,6 +263,11 @@ struct qt_args {
     uint32_t *ghist;                       // [n_queries][QT_BINS], zero on entry and left zero
     qt_state *state; qt_aux *aux;          // [n_queries]
     void *out; uint32_t cap;               // fd_count_rec [n_queries][cap]
+    // the decoded stream (motif batches, optional): pass A leaves every 16-byte slot of a tile's posting ranges as sixteen 16-bit structure ids
+    // + its row, pass B (k_qt_rows) tests them against the survivors instead of decoding the lists a second time
+    void *stream_ids; uint16_t *stream_row;        // [stream_cap][16] u16 (0xffff: none), [stream_cap]
+    uint2 *stream_tab;                     // [n_queries][NT][QT_MAXB] first record and records of a (query, tile, row batch)
+    uint32_t *stream_used; uint32_t stream_cap;    // records claimed so far (zero on entry), records the buffers hold
     unsigned long long *dbg;               // optional (FDGPU_QT_DBG): [16] phase durations summed over the workgroups
     // one query of ~10^5 rows (k_qt_score<..., BIG>): row slices, per-slice sums, the survivors' bitmap / slots / row bits
     const uint64_t *slices; uint32_t n_slices;     // [n_slices + 1] row boundaries

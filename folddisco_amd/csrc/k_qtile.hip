@@ -222,7 +222,8 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
     __shared__ uint32_t s_eend[RICH && !BIG ? QT_MAX_ROWS / 32 : 1], s_nend[RICH && !BIG ? QT_MAX_ROWS / 32 : 1];      // B: rows that end an edge / a node
     __shared__ unsigned long long s_byte0[RB], s_add[RB];
     __shared__ uint32_t s_P[RB + 1], s_nbytes[RB], s_prev[RB];
-    __shared__ uint16_t s_units[RB];
+    __shared__ uint16_t s_units[RB], s_row[RB];
+    __shared__ uint32_t s_sbase;                  // A: first record of this batch in the decoded stream
     __shared__ uint32_t s_w[NTHR / 64];
     __shared__ uint32_t s_mark[NTHR / 4];         // 64 bytes per wavefront: first lanes of the rows that begin inside a step
     __shared__ uint32_t s_nheavy, s_nlight, s_ucur, s_n, s_cnt, s_base;
@@ -328,8 +329,16 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
                 s_byte0[c] = (unsigned long long)rg.x | ((unsigned long long)rg.y << 32);
                 s_nbytes[c] = rg.z; s_prev[c] = rg.w;
                 s_add[c] = RICH ? (unsigned long long)((ra + tid) % nrows) + (BIG ? r0 : 0ull) : ((1ull << QT_CNT_SHIFT) | (rm >> 2));
+                if (!RICH && !BIG) s_row[c] = (uint16_t)((ra + tid) % nrows);
             }
-            if (tid == 0) { s_n = tot >> 22; s_P[tot >> 22] = tot & 0x3fffffu; s_nheavy = 0; s_nlight = 0; s_ucur = 0; }
+            if (tid == 0) {
+                s_n = tot >> 22; s_P[tot >> 22] = tot & 0x3fffffu; s_nheavy = 0; s_nlight = 0; s_ucur = 0;
+                if (!RICH && !BIG && A.stream_ids) {       // this batch's records of the decoded stream: one claim, remembered for k_qt_rows
+                    const uint32_t ns_b = tot & 0x3fffffu, sb = ns_b ? atomicAdd(A.stream_used, ns_b) : 0u;
+                    s_sbase = sb;
+                    A.stream_tab[((uint64_t)q * A.NT + t) * QT_MAXB + ra / RB] = make_uint2(sb, sb + ns_b <= A.stream_cap ? ns_b : 0xffffffffu);
+                }
+            }
             __syncthreads();
             stamp(1);
             const uint32_t n = s_n;
@@ -374,13 +383,16 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
                     X.nby = active ? (nbytes - 16u * X.rel < 16u ? nbytes - 16u * X.rel : 16u) : 0u;
                     __builtin_memcpy(&X.w, A.value + s_byte0[c] + 16ull * X.rel, 16);
                 };
+                // (the look-ahead only where units have many steps — a large query's tile-sized pieces; in a motif batch pieces end after a step
+                // or two and the second step's registers would be spilled)
+                constexpr bool AHEAD = BIG;
                 qt_step cur, nxt;
                 prep(s_beg, cur);
                 uint32_t carry = 0, prev_last = 0;
                 for (uint32_t base = s_beg; base < s_end; base += FD_WAVE) {
                     const bool more = base + FD_WAVE < s_end;
                     ++my_steps;
-                    if (more) prep(base + FD_WAVE, nxt);
+                    if (AHEAD && more) prep(base + FD_WAVE, nxt);
                     // ---- lane-local decode: the varints that END in these 16 bytes; the leading bytes of the first are the tail of the
                     // slot before — the lane below's last four bytes (lane 0: lane 63 of the step before)
                     uint32_t lb = (uint32_t)__shfl_up((int)cur.w[3], 1, FD_WAVE);
@@ -429,21 +441,29 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
                         // one returning 64-bit LDS add per posting, eight in flight (lanes without a posting add 0 to a slot of their own);
                         // a count of 0 before the add = the structure's first posting of this query
                         uint32_t first = 0;
+                        // the slot's postings also leave as 16-bit structure ids inside the tile (0xffff: none) for the decoded stream pass B reads
+                        // instead of decoding the lists again; four adds in flight, a quarter of the record stored as soon as it is complete
+                        // (eight in flight + the whole record in registers spilled 24 VGPRs)
+                        const bool to_stream = A.stream_ids && base + lane < s_end && (uint64_t)s_sbase + base + lane < A.stream_cap;
+                        uint2 *sdst = reinterpret_cast<uint2 *>(A.stream_ids) + 4ull * ((uint64_t)s_sbase + base + lane);
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            unsigned long long old[8];
-                            uint32_t okm = 0;
+                        for (int h = 0; h < 4; ++h) {
+                            unsigned long long old[4];
+                            uint32_t okm = 0, s2[2] = {0u, 0u};
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                id += v[h * 8 + i];
+                            for (int i = 0; i < 4; ++i) {
+                                id += v[h * 4 + i];
                                 const uint32_t x = id - tile_id0;
-                                const bool ok = ((T >> (h * 8 + i)) & 1u) && x < tile_lim;
+                                const bool ok = ((T >> (h * 4 + i)) & 1u) && x < tile_lim;
                                 okm |= ok ? (1u << i) : 0u;
                                 old[i] = atomicAdd(&s_acc[ok ? x : TILE + lane], ok ? add : 0ull);
+                                s2[i >> 1] |= (ok ? x : 0xffffu) << ((i & 1) * 16);
                             }
+                            if (to_stream) sdst[h] = make_uint2(s2[0], s2[1]);
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) if (((okm >> i) & 1u) && (old[i] >> QT_CNT_SHIFT) == 0ull) first |= 1u << (h * 8 + i);
+                            for (int i = 0; i < 4; ++i) if (((okm >> i) & 1u) && (old[i] >> QT_CNT_SHIFT) == 0ull) first |= 1u << (h * 4 + i);
                         }
+                        if (to_stream) A.stream_row[(uint64_t)s_sbase + base + lane] = s_row[cur.c];
                         // the touched structures are listed as they are met: the slots of a step's first hits by one LDS atomic per wavefront
                         const uint32_t nf = (uint32_t)__popc(first), fi = qt_wave_incl(nf, lane);
                         const uint32_t ftot = (uint32_t)__builtin_amdgcn_readlane((int)fi, 63);
@@ -483,7 +503,7 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
                             }
                         }
                     }
-                    if (more) cur = nxt;
+                    if (more) { if (AHEAD) cur = nxt; else prep(base + FD_WAVE, cur); }
                 }
             }
             if (A.dbg && lane == 0) {       // per wavefront: units, steps, time in the loop (LDS; the workgroup's first thread reports)
@@ -570,6 +590,122 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
     }
     if (tid == 0) A.ccount[(uint64_t)q * A.NT + t] = n_t;
     stamp(5);
+}
+
+// ------------------------------------------------------------------ pass B from the decoded stream
+// The survivors' records without a second decode: pass A left every 16-byte slot of the tile's posting ranges as sixteen 16-bit structure
+// ids + the slot's row (34 bytes per slot, A.stream_*).  A workgroup = (query, tile): survivors' bitmap and ranks as in k_qt_score<RICH>, then
+// one thread per slot tests its ids against the bitmap — no varint decode, no scan, no plan — and the records follow from the row bits.
+template <int TL2, int NTHR, int RBW, int RBA>
+__global__ __launch_bounds__(NTHR) void k_qt_rows(qt_args A) {
+    constexpr uint32_t TILE = 1u << TL2;
+    __shared__ uint32_t s_bm[TILE / 32], s_rank[TILE / 32], s_rowbits[RBW];
+    __shared__ unsigned long long s_meta[QT_MAX_ROWS];
+    __shared__ uint32_t s_eend[QT_MAX_ROWS / 32], s_nend[QT_MAX_ROWS / 32];
+    __shared__ uint32_t s_w[NTHR / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t wg = blockIdx.x;
+    const uint32_t t = wg % A.NT, q = wg / A.NT, tid = threadIdx.x;
+    const uint64_t r0 = A.q_rows[q];
+    const uint32_t nrows = (uint32_t)(A.q_rows[q + 1] - r0);
+    const uint32_t tile_lo = t << TL2;
+    const uint64_t cbase = ((uint64_t)q * A.NT + t) << TL2;
+    constexpr int SPEC = (TILE / NTHR) < 8 ? (TILE / NTHR) : 8;
+    uint2 x[SPEC];
+#pragma unroll
+    for (int u = 0; u < SPEC; ++u) x[u] = A.compact[cbase + u * NTHR + tid];
+    const uint32_t n = A.ccount[(uint64_t)q * A.NT + t];
+    const uint32_t thr = A.state[q].thr_key;
+    for (uint32_t k = tid; k < TILE / 32; k += NTHR) s_bm[k] = 0u;
+    for (uint32_t k = tid; k < QT_MAX_ROWS / 32; k += NTHR) { s_eend[k] = 0u; s_nend[k] = 0u; }
+    __syncthreads();
+    for (uint32_t k = tid; k < nrows; k += NTHR) {
+        const unsigned long long m = A.row_meta[r0 + k];
+        s_meta[k] = m;
+        if (m & 1ull) atomicOr(&s_eend[k >> 5], 1u << (k & 31u));
+        if (m & 2ull) atomicOr(&s_nend[k >> 5], 1u << (k & 31u));
+    }
+#pragma unroll
+    for (int u = 0; u < SPEC; ++u)
+        if ((uint32_t)u * NTHR + tid < n && x[u].y >= thr) { const uint32_t i = x[u].x - tile_lo; atomicOr(&s_bm[i >> 5], 1u << (i & 31u)); }
+    for (uint32_t e = SPEC * NTHR + tid; e < n; e += NTHR) {
+        const uint2 y = A.compact[cbase + e];
+        if (y.y >= thr) { const uint32_t i = y.x - tile_lo; atomicOr(&s_bm[i >> 5], 1u << (i & 31u)); }
+    }
+    __syncthreads();
+    uint32_t run = 0;
+    for (uint32_t w0 = 0; w0 < TILE / 32; w0 += NTHR) {
+        uint32_t tot;
+        const uint32_t pc = w0 + tid < TILE / 32 ? (uint32_t)__popc(s_bm[w0 + tid]) : 0u;
+        const uint32_t ex = qt_block_excl<NTHR>(pc, tid, s_w, &tot);
+        if (w0 + tid < TILE / 32) s_rank[w0 + tid] = run + ex;
+        run += tot;
+    }
+    const uint32_t n_surv = run;
+    if (!n_surv) return;
+    const uint32_t wpr = (nrows + 31u) >> 5, per_round = (uint32_t)RBW / wpr, n_rounds = (n_surv + per_round - 1u) / per_round;
+    if (tid == 0) s_base = atomicAdd(&A.state[q].count, n_surv);
+    constexpr uint32_t CPT = 1u << (TL2 - QT_CELL_LOG2);
+    const uint32_t cell0 = t * CPT, ncell = A.NC - cell0 < CPT ? A.NC - cell0 : CPT, n_batches = (nrows * ncell + RBA - 1u) / RBA;
+    const qt_u32x4 *ids = reinterpret_cast<const qt_u32x4 *>(A.stream_ids);
+    for (uint32_t round = 0; round < n_rounds; ++round) {
+        const uint32_t s_lo = round * per_round;
+        const uint32_t n_here = n_surv - s_lo < per_round ? n_surv - s_lo : per_round;
+        for (uint32_t k = tid; k < n_here * wpr; k += NTHR) s_rowbits[k] = 0u;
+        __syncthreads();
+        for (uint32_t b = 0; b < n_batches; ++b) {
+            const uint2 rec = A.stream_tab[((uint64_t)q * A.NT + t) * QT_MAXB + b];
+            if (rec.y == 0xffffffffu) {       // the stream did not hold this batch (its bound is the host's): the call reports an overflowing selection
+                if (tid == 0) atomicOr(&A.state[q].count, 0x80000000u);
+                return;
+            }
+            for (uint32_t sl = tid; sl < rec.y; sl += NTHR) {
+                const qt_u32x4 a0 = ids[2ull * (rec.x + sl)], a1 = ids[2ull * (rec.x + sl) + 1];
+                const uint32_t row = A.stream_row[(uint64_t)rec.x + sl];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t w2 = i < 8 ? a0[i >> 1] : a1[(i - 8) >> 1];
+                    const uint32_t xx = (i & 1) ? w2 >> 16 : w2 & 0xffffu;
+                    if (xx != 0xffffu) {
+                        const uint32_t wd = s_bm[xx >> 5];
+                        if ((wd >> (xx & 31u)) & 1u) {
+                            const uint32_t rk = s_rank[xx >> 5] + (uint32_t)__popc(wd & ((1u << (xx & 31u)) - 1u)) - s_lo;
+                            if (rk < per_round) atomicOr(&s_rowbits[rk * wpr + (row >> 5)], 1u << (row & 31u));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < n_here; k += NTHR) {
+            const uint32_t rk = s_lo + k;
+            uint32_t lo = 0, hi = TILE / 32;
+            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_rank[mid] <= rk) lo = mid; else hi = mid; }
+            uint32_t bits = s_bm[lo];
+            for (uint32_t z = rk - s_rank[lo]; z; --z) bits &= bits - 1u;
+            const uint32_t i = lo * 32u + (uint32_t)__builtin_ctz(bits);
+            const float pen = A.penalty[tile_lo + i];
+            const uint32_t *rb = s_rowbits + k * wpr;
+            uint32_t cnt = 0, edges = 0, nodes = 0, ce = 0, cn = 0;
+            unsigned long long sum = 0;
+            for (uint32_t rw = 0; rw < wpr; ++rw) {
+                uint32_t m = rb[rw];
+                const uint32_t left = nrows - rw * 32u, valid = left >= 32u ? 0xffffffffu : (1u << left) - 1u;
+                cnt += (uint32_t)__popc(m);
+                edges += qt_groups_hit(m, s_eend[rw], valid, ce);
+                nodes += qt_groups_hit(m, s_nend[rw], valid, cn);
+                for (; m; m &= m - 1u) sum += s_meta[rw * 32u + (uint32_t)__builtin_ctz(m)] >> 2;
+            }
+            const uint32_t pos = s_base + rk;
+            if (pos < A.cap) {
+                qt_rec r;
+                r.nid = tile_lo + i + A.first_id; r.total_match_count = cnt; r.node_count = nodes; r.edge_count = edges;
+                r.idf = (float)((double)sum * (1.0 / QT_IDF_SCALE)) * pen;      // count_query.rs:200 idf_sum *= nres^(-lp)
+                ((qt_rec *)A.out)[(uint64_t)q * A.cap + pos] = r;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------ one query of ~10^5 rows: reduce, survivors, records
@@ -848,7 +984,9 @@ void fd_launch_qt_select(const qt_args &A, uint32_t top_n, void *sorted, hipStre
     if (!A.n_queries || !A.S) return;
     const dim3 g(A.NT * A.n_queries);
     hipLaunchKernelGGL(k_qt_thr, dim3(A.n_queries), dim3(1024), 0, st, A, top_n);
-    if (A.tile_log2 == 14) hipLaunchKernelGGL((k_qt_score<true, 14, 1024, 512, 6144>), g, dim3(1024), 0, st, A);
+    if (A.stream_ids && A.tile_log2 == 14) hipLaunchKernelGGL((k_qt_rows<14, 512, 6144, 512>), g, dim3(512), 0, st, A);
+    else if (A.stream_ids) hipLaunchKernelGGL((k_qt_rows<13, 512, 6144, 256>), g, dim3(512), 0, st, A);
+    else if (A.tile_log2 == 14) hipLaunchKernelGGL((k_qt_score<true, 14, 1024, 512, 6144>), g, dim3(1024), 0, st, A);
     else hipLaunchKernelGGL((k_qt_score<true, 13, 512, 256, 6144>), g, dim3(512), 0, st, A);
     hipLaunchKernelGGL(k_qt_sort, dim3(A.n_queries), dim3(QT_SORT_T), 0, st, (const qt_rec *)A.out, A.cap, A.state, top_n, (qt_rec *)sorted);
 }

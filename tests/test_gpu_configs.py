@@ -291,6 +291,23 @@ def test_tiled_scoring_equals_occupancy_rows(human, monkeypatch):
         a, a14, b = run(ix, pen, HUMAN, N, True), run(ix, pen, HUMAN, N, True, "14"), run(ix, pen, HUMAN, N, False)
         for f, x, x14, y in zip(full, a, a14, b):
             assert x.tobytes() == x14.tobytes() == y.tobytes() == rank_hits(f, N).tobytes(), N
+    # query maps made against the index carry their lists' positions and lengths: pass B then reads the decoded stream pass A left
+    # (k_qt_rows) instead of decoding the lists again — both forms, both tile sizes, against the ranked full list
+    from folddisco_amd import query as fq
+    Qs = human["queries"]
+    qall = ctx.upload(fd.PackedStructures.concat([Q["q"].as_item() for Q in Qs]))
+    qms = fq.make_query_maps(ctx, qall, [(k, Q["idx"], Q["subs"]) for k, Q in enumerate(Qs)], ix, float(HUMAN))
+    monkeypatch.setenv("FDGPU_QTILE", "0")
+    full_m = fd.count_query_maps(ctx, ix, qms, pen, total_structures=HUMAN, top_n=0)
+    monkeypatch.setenv("FDGPU_QTILE", "1")
+    for N in (5, 1000):
+        for tile in ("13", "14"):
+            for stream in ("1", "0"):
+                monkeypatch.setenv("FDGPU_QT_TILE", tile); monkeypatch.setenv("FDGPU_QT_STREAM", stream)
+                got = fd.count_query_maps(ctx, ix, qms, pen, total_structures=HUMAN, top_n=N)
+                for f, x in zip(full_m, got):
+                    assert x.tobytes() == rank_hits(f, N).tobytes(), (N, tile, stream)
+    monkeypatch.delenv("FDGPU_QT_STREAM")
     # ties: a penalty of 1 makes the key a function of the matched rows alone — thousands of equal keys around the cut
     one = np.ones_like(pen)
     full1 = run(ix, one, HUMAN, 0, False)
