@@ -83,7 +83,8 @@ def pmc_traffic(stage, tag):
         for k, v in d.get("kernels", {}).items():
             if k.startswith("k_" + stage):
                 return {"bytes_per_launch": 2.0 * v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], "kernel": k,
-                        "rocprof_avg_us": v.get("avg_us"), "source": os.path.basename(f)}
+                        "rocprof_avg_us": v.get("avg_us"), "source": "committed PMC pass: profiles/" + os.path.basename(f),
+                        "measured_in_this_run": False, "fetch_correction": 2.0}
     return None
 
 

@@ -1167,9 +1167,12 @@ static bool fd_cq_rows(const uint32_t *q_hash, const uint32_t *q_node, const uin
                        std::vector<long long> *rows_kidx = nullptr) {
     std::vector<uint64_t> ord(b - a);
     for (uint64_t k = a; k < b; ++k) ord[k - a] = k;
-    bool small_ids = true;
+    bool small_ids = true, in_order = true;
     for (uint64_t k = a; k < b && small_ids; ++k) small_ids = q_node[k] < 65536u && q_edge_j[k] < 65536u;
-    if (b - a > 2048 && small_ids) {
+    // a query map lists its entries pair by pair in row-major (i, j) order (query.rs:231-329): a whole-structure query's 10^5 rows arrive sorted
+    for (uint64_t k = a + 1; k < b && in_order; ++k) in_order = q_node[k - 1] < q_node[k] || (q_node[k - 1] == q_node[k] && q_edge_j[k - 1] <= q_edge_j[k]);
+    if (in_order) {
+    } else if (b - a > 2048 && small_ids) {
         // a whole-structure query has ~10^5 rows: (node, partner) order by a stable LSD radix sort of node << 16 | partner (a comparison
         // sort of the index array took several milliseconds of the prefilter)
         std::vector<uint64_t> tmp(ord.size());

@@ -57,9 +57,16 @@ def _pmc_query_traffic(S_total, world):
     for f in sorted(glob.glob(os.path.join(root, "profiles", "*pmc_query_traffic_%s.json" % tag)), reverse=True):
         try:
             dd = json.load(open(f))
-            tot = sum(2.0 * v["fetch_bytes_per_launch"] * v.get("launches_per_batch", 1) + v["write_bytes_per_launch"] * v.get("launches_per_batch", 1)
-                      for v in dd["kernels"].values())
-            return {"bytes_per_launch": tot, "kernels": sorted(dd["kernels"]), "source": os.path.basename(f)}
+            # FETCH_SIZE counts a read request made for a 16-byte-per-lane access at half its size on gfx950: every kernel carries its own
+            # correction (1 + the share of its read bytes that such loads fetch; files of rounds 1-3: 2 for every kernel)
+            lo = mid = hi = 0.0
+            for v in dd["kernels"].values():
+                n = v.get("launches_per_batch", 1)
+                lo += (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * n
+                mid += (v["fetch_bytes_per_launch"] * v.get("fetch_correction", 2.0) + v["write_bytes_per_launch"]) * n
+                hi += (2.0 * v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * n
+            return {"bytes_per_launch": mid, "bytes_per_launch_raw_counters": lo, "bytes_per_launch_all_reads_doubled": hi, "kernels": sorted(dd["kernels"]),
+                    "source": "committed PMC pass: profiles/" + os.path.basename(f), "measured_in_this_run": False}
         except Exception:
             continue
     return None
