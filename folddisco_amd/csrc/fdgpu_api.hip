@@ -1460,7 +1460,8 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         T.kidx = c->ws[WS_CQ_KIDX].as<long long>(); T.row_meta = A.row_meta; T.q_rows = c->ws[WS_TILE_H].as<uint64_t>(); T.penalty = d_penalty;
         T.nq = (uint32_t)nq; T.n_queries = (uint32_t)n_queries; T.S = (uint32_t)S; T.first_id = (uint32_t)ix->first_id; T.NT = NT; T.tile_log2 = qt_tl2;
         T.NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
-        T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.compact = c->ws[WS_QT_COMPACT].as<uint2>(); T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
+        T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.c_nid = c->ws[WS_QT_COMPACT].as<uint32_t>(); T.c_key = T.c_nid + ((size_t)n_queries * NT << qt_tl2);
+        T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
         T.ghist = nullptr; T.state = nullptr; T.aux = c->ws[WS_QT_AUX].as<qt_aux>(); T.out = nullptr; T.cap = 0;
         T.stream_ids = nullptr; T.stream_row = nullptr; T.stream_tab = nullptr; T.stream_used = nullptr; T.stream_cap = 0;
         if (stream_cap) {
@@ -1484,7 +1485,8 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         T.kidx = c->ws[WS_CQ_KIDX].as<long long>(); T.row_meta = A.row_meta; T.q_rows = c->ws[WS_TILE_H].as<uint64_t>(); T.penalty = d_penalty;
         T.nq = (uint32_t)nq; T.n_queries = 1; T.S = (uint32_t)S; T.first_id = (uint32_t)ix->first_id; T.NT = NT14; T.tile_log2 = 14; T.plan_log2 = 14;
         T.NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
-        T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.compact = c->ws[WS_QT_COMPACT].as<uint2>(); T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
+        T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.c_nid = c->ws[WS_QT_COMPACT].as<uint32_t>(); T.c_key = T.c_nid + ((size_t)NT14 << 14);
+        T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
         T.ghist = nullptr; T.state = nullptr; T.aux = c->ws[WS_QT_AUX].as<qt_aux>(); T.out = nullptr; T.cap = big_cap; T.dbg = nullptr;
         T.stream_ids = nullptr; T.stream_row = nullptr; T.stream_tab = nullptr; T.stream_used = nullptr; T.stream_cap = 0;
         // slices of roughly equal posting counts: a row's list holds ~ S / 2^idf ids (idf = log2(S / length), its fixed-point image is in the metadata)

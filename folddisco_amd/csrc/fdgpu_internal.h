@@ -258,7 +258,8 @@ struct qt_args {
     const float *penalty;                  // [S]
     uint32_t nq, n_queries, S, first_id, NT, NC, tile_log2, plan_log2;      // plan_log2: structure ids per plan granule (QT_CELL_LOG2, or tile_log2 for one large query)
     uint4 *ranges;                         // [NC][nq] byte range of (row, cell): first byte lo / hi, bytes (0: decoded with an earlier cell of the tile), id before the first posting
-    uint2 *compact;                        // [n_queries][NT][tile] (structure, ranking key) of the touched structures, any order
+    uint32_t *c_nid, *c_key;               // [n_queries][NT][tile] each: structure and ranking key of the touched structures (any order; two arrays:
+                                           // the structure is written when it is first met, the key at the tile's end — full lines either way)
     uint32_t *ccount;                      // [n_queries][NT] entries of compact
     uint32_t *ghist;                       // [n_queries][QT_BINS], zero on entry and left zero
     qt_state *state; qt_aux *aux;          // [n_queries]

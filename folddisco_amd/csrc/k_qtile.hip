@@ -265,9 +265,9 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
     } else {
         // the tile's (structure, key) list: its first entries are requested before its length is known (the buffer holds a full tile)
         constexpr int SPEC = (TILE / NTHR) < 8 ? (TILE / NTHR) : 8;
-        uint2 x[SPEC];
+        uint32_t x[SPEC];        // ranking keys; a survivor's structure comes from the other array
 #pragma unroll
-        for (int u = 0; u < SPEC; ++u) x[u] = A.compact[cbase + u * NTHR + tid];
+        for (int u = 0; u < SPEC; ++u) x[u] = A.c_key[cbase + u * NTHR + tid];
         const uint32_t n = A.ccount[(uint64_t)q * A.NT + t];
         const uint32_t thr = A.state[q].thr_key;
         for (uint32_t k = tid; k < TILE / 32; k += NTHR) s_bm[k] = 0u;
@@ -281,11 +281,9 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
         }
 #pragma unroll
         for (int u = 0; u < SPEC; ++u)
-            if ((uint32_t)u * NTHR + tid < n && x[u].y >= thr) { const uint32_t i = x[u].x - tile_lo; atomicOr(&s_bm[i >> 5], 1u << (i & 31u)); }
-        for (uint32_t e = SPEC * NTHR + tid; e < n; e += NTHR) {
-            const uint2 y = A.compact[cbase + e];
-            if (y.y >= thr) { const uint32_t i = y.x - tile_lo; atomicOr(&s_bm[i >> 5], 1u << (i & 31u)); }
-        }
+            if ((uint32_t)u * NTHR + tid < n && x[u] >= thr) { const uint32_t i = A.c_nid[cbase + u * NTHR + tid] - tile_lo; atomicOr(&s_bm[i >> 5], 1u << (i & 31u)); }
+        for (uint32_t e = SPEC * NTHR + tid; e < n; e += NTHR)
+            if (A.c_key[cbase + e] >= thr) { const uint32_t i = A.c_nid[cbase + e] - tile_lo; atomicOr(&s_bm[i >> 5], 1u << (i & 31u)); }
         __syncthreads();
         uint32_t run = 0;
         for (uint32_t w0 = 0; w0 < TILE / 32; w0 += NTHR) {
@@ -475,7 +473,7 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
 #pragma unroll
                             for (int i = 0; i < 16; ++i) {
                                 id += v[i];
-                                if ((first >> i) & 1u) A.compact[cbase + pos++].x = id - A.first_id;
+                                if ((first >> i) & 1u) A.c_nid[cbase + pos++] = id - A.first_id;
                             }
                         }
                     } else {
@@ -568,7 +566,7 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
     for (uint32_t e0 = 0; e0 < n_t; e0 += 4 * NTHR) {       // four structures per thread in flight
         uint32_t sid[4]; float pen[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const uint32_t e = e0 + u * NTHR + tid; sid[u] = e < n_t ? A.compact[cbase + e].x : tile_lo; }
+        for (int u = 0; u < 4; ++u) { const uint32_t e = e0 + u * NTHR + tid; sid[u] = e < n_t ? A.c_nid[cbase + e] : tile_lo; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) pen[u] = A.penalty[sid[u]];
 #pragma unroll
@@ -579,7 +577,7 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
                 const uint32_t key = qt_order_key((float)((double)(a & QT_SUM_MASK) * (1.0 / QT_IDF_SCALE)) * pen[u]);
                 const uint32_t bin = qt_bin(key);
                 atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
-                A.compact[cbase + e].y = key;
+                A.c_key[cbase + e] = key;
             }
         }
     }
@@ -611,9 +609,9 @@ __global__ __launch_bounds__(NTHR) void k_qt_rows(qt_args A) {
     const uint32_t tile_lo = t << TL2;
     const uint64_t cbase = ((uint64_t)q * A.NT + t) << TL2;
     constexpr int SPEC = (TILE / NTHR) < 8 ? (TILE / NTHR) : 8;
-    uint2 x[SPEC];
+    uint32_t x[SPEC];        // ranking keys; a survivor's structure comes from the other array
 #pragma unroll
-    for (int u = 0; u < SPEC; ++u) x[u] = A.compact[cbase + u * NTHR + tid];
+    for (int u = 0; u < SPEC; ++u) x[u] = A.c_key[cbase + u * NTHR + tid];
     const uint32_t n = A.ccount[(uint64_t)q * A.NT + t];
     const uint32_t thr = A.state[q].thr_key;
     for (uint32_t k = tid; k < TILE / 32; k += NTHR) s_bm[k] = 0u;
@@ -627,11 +625,9 @@ __global__ __launch_bounds__(NTHR) void k_qt_rows(qt_args A) {
     }
 #pragma unroll
     for (int u = 0; u < SPEC; ++u)
-        if ((uint32_t)u * NTHR + tid < n && x[u].y >= thr) { const uint32_t i = x[u].x - tile_lo; atomicOr(&s_bm[i >> 5], 1u << (i & 31u)); }
-    for (uint32_t e = SPEC * NTHR + tid; e < n; e += NTHR) {
-        const uint2 y = A.compact[cbase + e];
-        if (y.y >= thr) { const uint32_t i = y.x - tile_lo; atomicOr(&s_bm[i >> 5], 1u << (i & 31u)); }
-    }
+        if ((uint32_t)u * NTHR + tid < n && x[u] >= thr) { const uint32_t i = A.c_nid[cbase + u * NTHR + tid] - tile_lo; atomicOr(&s_bm[i >> 5], 1u << (i & 31u)); }
+    for (uint32_t e = SPEC * NTHR + tid; e < n; e += NTHR)
+        if (A.c_key[cbase + e] >= thr) { const uint32_t i = A.c_nid[cbase + e] - tile_lo; atomicOr(&s_bm[i >> 5], 1u << (i & 31u)); }
     __syncthreads();
     uint32_t run = 0;
     for (uint32_t w0 = 0; w0 < TILE / 32; w0 += NTHR) {
@@ -737,7 +733,7 @@ __global__ __launch_bounds__(1024) void k_qd_reduce(qt_args A) {
     __syncthreads();
     if (tid == 0 && s_cnt) s_base = atomicAdd(&A.ccount[t], s_cnt);      // 1,024 divides the tile: the workgroup's structures share one tile
     __syncthreads();
-    if (touched) A.compact[((uint64_t)t << TL2) + s_base + pos] = make_uint2(i, key);
+    if (touched) { A.c_nid[((uint64_t)t << TL2) + s_base + pos] = i; A.c_key[((uint64_t)t << TL2) + s_base + pos] = key; }
     for (uint32_t k = tid; k < QT_BINS; k += 1024) if (s_hist[k]) atomicAdd(&A.ghist[k], s_hist[k]);
 }
 // k_qd_surv: the survivors of a tile (key >= threshold) as a bitmap + the number of survivors in the words before (local ranks) + the count
@@ -750,8 +746,8 @@ __global__ __launch_bounds__(512) void k_qd_surv(qt_args A) {
     for (uint32_t k = tid; k < W; k += 512) s_bm[k] = 0u;
     __syncthreads();
     const uint32_t n = A.ccount[t], thr = A.state[0].thr_key, tile_lo = t << TL2;
-    const uint2 *e = A.compact + ((uint64_t)t << TL2);
-    for (uint32_t i = tid; i < n; i += 512) { const uint2 x = e[i]; if (x.y >= thr) { const uint32_t z = x.x - tile_lo; atomicOr(&s_bm[z >> 5], 1u << (z & 31u)); } }
+    const uint64_t cb = (uint64_t)t << TL2;
+    for (uint32_t i = tid; i < n; i += 512) if (A.c_key[cb + i] >= thr) { const uint32_t z = A.c_nid[cb + i] - tile_lo; atomicOr(&s_bm[z >> 5], 1u << (z & 31u)); }
     __syncthreads();
     uint32_t run = 0;
     for (uint32_t w0 = 0; w0 < W; w0 += 512) {
@@ -867,9 +863,9 @@ __global__ __launch_bounds__(1024) void k_qt_thr(qt_args A, uint32_t top_n) {
         __syncthreads();
         for (uint32_t t = 0; t < A.NT; ++t) {
             const uint32_t n = A.ccount[(uint64_t)q * A.NT + t];
-            const uint2 *e = A.compact + (((uint64_t)q * A.NT + t) << A.tile_log2);
+            const uint32_t *e = A.c_key + (((uint64_t)q * A.NT + t) << A.tile_log2);
             for (uint32_t i = tid; i < n; i += 1024) {
-                const uint32_t key = e[i].y;
+                const uint32_t key = e[i];
                 if (qt_bin(key) == b1) { const uint32_t s = (key - edge) >> sh2; atomicAdd(&hist[s < QT_BINS - 1u ? s : QT_BINS - 1u], 1u); }
             }
         }

@@ -298,14 +298,14 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     traffic = _pmc_query_traffic(S_total, world)
     roofline = {
         "bound": "hbm", "kernel": "prefilter of the batched full query: cq_batch (k_qt_plan, k_qt_score<pass A: scores per tile of structures in LDS>) + cq_topn "
-                                  "(k_qt_thr, k_qt_score<pass B: records of the survivors>, k_qt_sort)",
+                                  "(k_qt_thr, k_qt_rows: records of the survivors from pass A's decoded stream, k_qt_sort)",
         "queries_per_launch": len(ks), "top_n": top_n,
         "algorithmic_bytes_per_launch": b_q, "posting_bytes": post_bytes, "touched_structures": touched, "occupancy_rows": n_rows,
         "avg_ms": t_score, "stages_ms": {k: round(v, 4) for k, v in st_score.items()},
         "achieved": b_q / (t_score * 1e-3) / 1e9 if t_score > 0 else None, "peak": hbm_peak_gbs, "unit": "GB/s",
         "frac": b_q / (t_score * 1e-3) / 1e9 / hbm_peak_gbs if t_score > 0 else None,
         "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
-        "note": "~%d KB of postings per query, decoded twice (scores, then the survivors' rows) by workgroups of one (query, 16,384-structure tile) each; "
+        "note": "~%d KB of postings per query, decoded once (scores; the survivors' rows come from the decoded stream) by workgroups of one (query, 16,384-structure tile) each; "
                 "VALU-issue and latency bound, not bandwidth bound (DESIGN §4)" % (post_bytes // max(len(ks), 1) // 1024),
         "match_pairs": {"algorithmic_bytes_per_launch": 37 * cand_res + 16 * len(marr), "candidates": int(sum(len(c) for c in cl)), "avg_ms": t_match,
                         "achieved": (37 * cand_res + 16 * len(marr)) / (t_match * 1e-3) / 1e9 if t_match > 0 else None, "unit": "GB/s",
