@@ -432,11 +432,10 @@ def count_query_maps(ctx: Context, index: FolddiscoIndex, qms, penalty=None, tot
                                                C.byref(out), C.byref(ooff)))
     off = np.frombuffer((C.c_uint64 * (T + 1)).from_address(C.addressof(ooff.contents)), dtype=np.uint64).copy()
     n = int(off[-1])
-    arr = (np.frombuffer((C.c_uint8 * (n * 20)).from_address(C.addressof(out.contents)), dtype=np.uint8).copy().view(REC_DTYPE) if n
-           else np.zeros(0, REC_DTYPE))
-    ctx.L.fdgpu_free(out)
+    arr = _lib.owned_view(ctx.L, out, n * 20, REC_DTYPE)         # the library's (pooled, page-locked) block itself, handed back when the views die
     ctx.L.fdgpu_free(ooff)
-    return [arr[int(off[t]): int(off[t + 1])] for t in range(T)]
+    offs = off.tolist()
+    return [arr[offs[t]: offs[t + 1]] for t in range(T)]
 
 
 def count_query_batch(ctx: Context, index: FolddiscoIndex, queries, penalty: np.ndarray, total_structures: int | None = None,

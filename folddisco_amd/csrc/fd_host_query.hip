@@ -213,6 +213,15 @@ static int pair_features12(fdgpu_ctx *c, const fdgpu_batch *b, const uint32_t *p
     hipLaunchKernelGGL(k_pair_features12, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, b->view(), c->ws[WS_MISC0].as<uint32_t>(),
                        c->ws[WS_MISC1].as<uint32_t>(), (uint32_t)n, p->dist_cutoff, p->hash_type, c->ws[WS_MISC2].as<float>(), c->ws[WS_MISC3].as<uint8_t>());
     HIPCHK(c, hipGetLastError());
+    uint8_t *land = (uint8_t *)c->host_pinned(2, n * 4 * FD_QF + n);      // page-locked landing block: the copies do not stage, one wait
+    if (land) {
+        HIPCHK(c, hipMemcpyAsync(land, c->ws[WS_MISC2].p, n * 4 * FD_QF, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(land + n * 4 * FD_QF, c->ws[WS_MISC3].p, n, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        memcpy(features, land, n * 4 * FD_QF);
+        memcpy(valid, land + n * 4 * FD_QF, n);
+        return FDGPU_OK;
+    }
     HIPCHK(c, hipMemcpyAsync(features, c->ws[WS_MISC2].p, n * 4 * FD_QF, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(valid, c->ws[WS_MISC3].p, n, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -321,7 +330,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     std::vector<uint32_t> vpairs;      // device path: the valid pairs, ascending
     uint64_t dev_pp = 0;
     std::vector<uint32_t> dev_keep;
-    bool dev_expand = false;
+    bool dev_expand = false, dev_dedupe = false;
     {
         bool any_subs = false;
         if (subs && n_subs) for (uint64_t a = 0; a < q_off[n_queries] && !any_subs; ++a) any_subs = subs[a] != nullptr;
@@ -330,10 +339,16 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         const uint64_t per_pair = 1 + 2 * ((uint64_t)ndi * n_dist + (uint64_t)nai * n_angle);
         const char *qd_env = getenv("FDGPU_QM_DEVICE");
         const uint64_t qd_min = qd_env && qd_env[0] == '1' ? 1 : 32768;      // 1: also for small queries (tests)
-        dev_expand = n_queries == 1 && !any_subs && p->n_multiple_bins == 0 && n_dist <= 8 && n_angle <= 8 && !(qd_env && qd_env[0] == '0') &&
-                     n_valid * per_pair >= qd_min && n_valid * per_pair < (1ull << 31);
+        // expansion + hashes on the device whenever every candidate's place follows from its pair (no substitutions, one bin configuration): a
+        // batch of motif queries too — the host then neither builds nor uploads 48 bytes per candidate; the dedupe moves along for one large query
+        dev_expand = !any_subs && p->n_multiple_bins == 0 && n_dist <= 8 && n_angle <= 8 && !(qd_env && qd_env[0] == '0') && n_valid &&
+                     n_valid * per_pair < (1ull << 31);
+        dev_dedupe = dev_expand && n_queries == 1 && n_valid * per_pair >= qd_min;
         if (dev_expand) { dev_pp = per_pair; vpairs.reserve(n_valid); for (uint64_t k = 0; k < np; ++k) if (valid[k]) vpairs.push_back((uint32_t)k); }
     }
+    std::vector<uint32_t> pair_q;       // device expansion: the query of every pair
+    if (dev_expand) { pair_q.resize(np); for (uint64_t t = 0; t < n_queries; ++t) for (uint64_t k = pair_off[t]; k < pair_off[t + 1]; ++k) pair_q[k] = (uint32_t)t; }
+    uint64_t n_valid_seen = 0;
     for (uint64_t t = 0; t < n_queries; ++t) {
         const uint64_t r0 = qb->h_res_off[q_struct[t]];
         const uint32_t *qidx = q_index + q_off[t];
@@ -350,7 +365,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             uint32_t qi = (uint32_t)(pi[k] - r0), qj = (uint32_t)(pj[k] - r0);
             // observed (aa_i, aa_j, CA distance) list (structure/core.rs:462-477: distance <= 20.0)
             if (f[9] <= 20.0f) { A.a1.push_back((uint8_t)f[10]); A.a2.push_back((uint8_t)f[11]); A.ad.push_back(f[9]); A.aq.push_back(qi); }
-            if (dev_expand) continue;
+            if (dev_expand) { ++n_valid_seen; continue; }
             push(f, qi, qj, true, (uint32_t)k);
             float near[FD_QF], far[FD_QF];
             memcpy(near, f, sizeof near);
@@ -387,14 +402,14 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             expand(di, ndi, dist_thr, n_dist);
             expand(ai, nai, athr.data(), n_angle);
         }
-        cand_off[t + 1] = dev_expand ? vpairs.size() * dev_pp : cands.size();
+        cand_off[t + 1] = dev_expand ? n_valid_seen * dev_pp : cands.size();
     }
     const uint64_t nc = dev_expand ? vpairs.size() * dev_pp : cands.size();
     // candidate z -> (query residues, observed?, pair): stored by the host expansion, implied by the position on the device path
     auto cand_at = [&](uint64_t z) -> cand_t {
         if (!dev_expand) return cands[z];
         const uint32_t k = vpairs[z / dev_pp];
-        const uint64_t r0 = qb->h_res_off[q_struct[0]];
+        const uint64_t r0 = qb->h_res_off[q_struct[pair_q[k]]];
         return cand_t{(uint32_t)(pi[k] - r0), (uint32_t)(pj[k] - r0), (uint8_t)(z % dev_pp == 0 ? 1 : 0), k};
     };
     if (qtrace) fprintf(stderr, "[fdgpu_query_map] %llu candidates expanded at %.3f ms\n", (unsigned long long)nc, q_ms());
@@ -412,6 +427,16 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         // ws[WS_MISC2] still holds the pairs' containers (pair_features12); the sort takes the build's key / id buffers
         HIPCHK(c, c->ws[WS_MISC0].ensure(nv * 4));
         HIPCHK(c, c->ws[WS_MISC1].ensure(nc * 4));
+        if (!dev_dedupe) {       // hashes only: the per-query dedupe of a motif batch is a small hash table on the host (below)
+            HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, vpairs.data(), nv * 4, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_qm_expand_hash, dim3((unsigned)((nv + 63) / 64)), dim3(64), 0, st, c->ws[WS_MISC2].as<float>(), c->ws[WS_MISC0].as<uint32_t>(), (uint32_t)nv, P,
+                               fd_make_consts(p).q, c->ws[WS_MISC1].as<uint32_t>());
+            HIPCHK(c, hipGetLastError());
+            void *land = c->host_pinned(2, nc * 4);
+            HIPCHK(c, hipMemcpyAsync(land ? land : (void *)hashes.data(), c->ws[WS_MISC1].p, nc * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (land) memcpy(hashes.data(), land, nc * 4);
+        } else {
         HIPCHK(c, c->ws[WS_KEYS_A].ensure(nc * 4)); HIPCHK(c, c->ws[WS_KEYS_B].ensure(nc * 4));
         HIPCHK(c, c->ws[WS_IDS_A].ensure(nc * 4)); HIPCHK(c, c->ws[WS_IDS_B].ensure(nc * 4));
         HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * std::max<uint32_t>(fd_rs_num_tiles(nc), 1) * 4));
@@ -444,6 +469,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         HIPCHK(c, hipStreamSynchronize(st));
         dev_keep.resize(nk);
         if (nk) HIPCHK(c, hipMemcpy(dev_keep.data(), d_keep, nk * 4, hipMemcpyDeviceToHost));
+        }
     } else
     if ((rc = hash_features_q(c, vf.data(), nc, fd_make_consts(p).q, hashes.data(), FD_QF))) return rc;
     // --multiple-bins: every candidate is inserted under every bin pair, in list order (insert_binned_hash, query.rs:59-70); the
@@ -472,14 +498,15 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         const uint64_t c0 = cand_off[t], c1 = cand_off[t + 1], n_ins = (c1 - c0) * ncfg1;
         auto hash_at = [&](uint64_t pos) { const uint64_t z = c0 + pos / ncfg1; const uint32_t k = (uint32_t)(pos % ncfg1); return n_cfg ? mh_cfg[k][z] : hashes[z]; };
         std::vector<uint32_t> &keep = keeps[t];
-        if (dev_expand) keep.swap(dev_keep);
+        if (dev_dedupe) keep.swap(dev_keep);
         else if (n_ins <= 4096) {      // a motif query's few hundred insertions: a small open-addressing table (a node-based set cost 3x this)
             uint32_t cap = 64;
             while (cap < 2 * n_ins) cap <<= 1;
             dd_tab.assign(cap, ~0ull);
             keep.reserve((size_t)n_ins);
+            const uint32_t *h1 = n_cfg ? nullptr : hashes.data() + c0;       // one bin configuration: position = candidate (no division per insertion)
             for (uint64_t pos = 0; pos < n_ins; ++pos) {
-                const uint32_t h = hash_at(pos);
+                const uint32_t h = h1 ? h1[pos] : hash_at(pos);
                 uint32_t at = (h * 2654435761u) & (cap - 1);
                 while (dd_tab[at] != ~0ull && (uint32_t)dd_tab[at] != h) at = (at + 1) & (cap - 1);
                 if (dd_tab[at] == ~0ull) { dd_tab[at] = h; keep.push_back((uint32_t)pos); }
@@ -517,7 +544,8 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         ph.reserve(n_keep + np);
         for (uint64_t t = 0; t < n_queries; ++t) {
             const uint64_t c0 = cand_off[t];
-            for (uint32_t pos : keeps[t]) { const uint64_t z = c0 + pos / ncfg1; ph.push_back(n_cfg ? mh_cfg[pos % ncfg1][z] : hashes[z]); }
+            if (!n_cfg) { for (uint32_t pos : keeps[t]) ph.push_back(hashes[c0 + pos]); }
+            else for (uint32_t pos : keeps[t]) { const uint64_t z = c0 + pos / ncfg1; ph.push_back(mh_cfg[pos % ncfg1][z]); }
         }
         if (dev_expand) { for (uint64_t v = 0; v < vpairs.size(); ++v) { ph.push_back(hashes[v * dev_pp]); pk.push_back(vpairs[v]); } }
         else
@@ -540,6 +568,17 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         auto hash_at = [&](uint64_t pos) { const uint64_t z = c0 + pos / ncfg1; const uint32_t k = (uint32_t)(pos % ncfg1); return n_cfg ? mh_cfg[k][z] : hashes[z]; };
         const std::vector<uint32_t> &keep = keeps[t];
         mh.reserve(keep.size()); mqi.reserve(keep.size()); mqj.reserve(keep.size()); mp.reserve(keep.size()); mi.reserve(keep.size()); mph.reserve(keep.size());
+        if (dev_expand && !n_cfg) {       // kept positions ascend: the pair a position belongs to advances with them (no division per entry)
+            uint64_t v = c0 / dev_pp, v_end = (v + 1) * dev_pp;      // candidates of valid pair v: [v * dev_pp, v_end)
+            const uint64_t r0 = qb->h_res_off[q_struct[t]];
+            for (uint32_t pos : keep) {
+                const uint64_t z = c0 + pos;
+                while (z >= v_end) { ++v; v_end += dev_pp; }
+                const uint32_t k = vpairs[v];
+                mh.push_back(hashes[z]); mqi.push_back((uint32_t)(pi[k] - r0)); mqj.push_back((uint32_t)(pj[k] - r0)); mp.push_back(z + dev_pp == v_end ? 1 : 0);
+                mi.push_back(pair_idf[k]); mph.push_back(pair_primary[k]);
+            }
+        } else
         for (uint32_t pos : keep) {
             const uint64_t z = c0 + pos / ncfg1;
             const cand_t cz = cand_at(z);
@@ -772,13 +811,15 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     if (dev_glue) {
         uint64_t nf_d = 0, nc_d = 0;
         fd_pair_rec *f_none = nullptr; fd_cand_rec *c_none = nullptr;
-        rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &f_none, &nf_d, &c_none, &nc_d, 19u);
-        if (rc) return rc;
-        auto D1 = t_now();
         hipStream_t st = c->stream;
-        // tables: one packed host block -> one copy
+        // tables: one packed host block -> one copy.  Built WHILE the pair scan runs (it needs none of the scan's output): the scan's launch
+        // is followed by ~0.4 ms of kernel per 128 queries that the host used to wait out before starting on this
         std::vector<rs_query_dev> qt(n_queries);
         std::vector<uint32_t> t_hash, t_kfirst, t_sym, t_qi, t_qj, t_idf, t_idx;
+        size_t o_qt = 0, o_h = 0, o_kf = 0, o_sy = 0, o_qi = 0, o_qj = 0, o_idf = 0, o_idx = 0, o_sq = 0, o_cd = 0, o_d0 = 0, words = 0;
+        std::vector<uint32_t> blk_v;
+        uint32_t *blk = nullptr;
+        const std::function<void()> build_rs_tables = [&]() {
         {
             size_t th = 0, tm = 0, ti = 0;
             for (uint64_t t = 0; t < n_queries; ++t) { th += qhs[t].size(); tm += qms[t]->n; ti += qms[t]->n_indices; }
@@ -808,12 +849,11 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         for (int len = 0; len <= 2 * FD_WAVE; ++len) d0tab[len] = len > 21 ? 1.24f * powf((float)len - 15.0f, 1.0f / 3.0f) - 1.8f : 0.5f;   // metrics.rs:117-123
         auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
         const size_t nh = t_hash.size(), nmap = t_qi.size(), nidx = t_idx.size();
-        const size_t o_qt = 0, o_h = o_qt + up4(n_queries * (sizeof(rs_query_dev) / 4)), o_kf = o_h + up4(nh), o_sy = o_kf + up4(nh), o_qi = o_sy + up4((nh + 3) / 4),
-                     o_qj = o_qi + up4(nmap), o_idf = o_qj + up4(nmap), o_idx = o_idf + up4(nmap), o_sq = o_idx + up4(nidx), o_cd = o_sq + up4(n_cand),
-                     o_d0 = o_cd + up4(n_cand), words = o_d0 + up4(2 * FD_WAVE + 1) + 4;
-        // packed in the context's pinned staging buffer (the pair scan's own block has been copied and the stream synchronised since)
-        std::vector<uint32_t> blk_v;
-        uint32_t *blk = (uint32_t *)c->host_pinned(0, words * 4);
+        o_qt = 0; o_h = o_qt + up4(n_queries * (sizeof(rs_query_dev) / 4)); o_kf = o_h + up4(nh); o_sy = o_kf + up4(nh); o_qi = o_sy + up4((nh + 3) / 4);
+        o_qj = o_qi + up4(nmap); o_idf = o_qj + up4(nmap); o_idx = o_idf + up4(nmap); o_sq = o_idx + up4(nidx); o_cd = o_sq + up4(n_cand);
+        o_d0 = o_cd + up4(n_cand); words = o_d0 + up4(2 * FD_WAVE + 1) + 4;
+        // packed in a pinned staging buffer of the context (its own: the pair scan's block in slot 0 is being copied while this runs)
+        blk = (uint32_t *)c->host_pinned(2, words * 4);
         if (!blk) { blk_v.assign(words, 0); blk = blk_v.data(); }
         memcpy(&blk[o_qt], qt.data(), n_queries * sizeof(rs_query_dev));
         if (nh) { memcpy(&blk[o_h], t_hash.data(), nh * 4); memcpy(&blk[o_kf], t_kfirst.data(), nh * 4); }
@@ -823,6 +863,12 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         memcpy(&blk[o_sq], t_slotq.data(), n_cand * 4);
         memcpy(&blk[o_cd], cand, n_cand * 4);
         memcpy(&blk[o_d0], d0tab, sizeof d0tab);
+        };
+        rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &f_none, &nf_d, &c_none, &nc_d, 19u, nullptr, nullptr, 0, nullptr, nullptr,
+                                  nullptr, nullptr, &build_rs_tables);
+        if (rc) return rc;
+        if (!blk) build_rs_tables();
+        auto D1 = t_now();
         const uint64_t cap_m = std::max<uint64_t>(4096, 4 * n_cand), cap_prob = 2 * cap_m, cap_res = cap_m * 2 * max_nq,
                        cap_pts = cap_prob * 2 * max_nq;       // a mapping holds at most one target per query residue: <= 2 max_nq [CA, CB] points
         HIPCHK(c, c->ws[WS_RS_TAB].ensure(words * 4));
@@ -846,6 +892,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         memset(&A, 0, sizeof A);
         A.found = d_found; A.cands = d_cands; A.seg_f = d_seg; A.seg_c = d_seg + (n_cand + 1); A.perm_f = d_pf; A.perm_c = d_pc;
         A.cand = dblk + o_cd; A.slot_q = dblk + o_sq;
+        A.order = getenv("FDGPU_RS_ORDER") && getenv("FDGPU_RS_ORDER")[0] == '0' ? nullptr : d_cur;      // 0: slot order (measurement)
         A.db_res_off = db->res_off; A.db_ca = db->ca_xyz; A.db_cb = db->cb_xyz; A.q_ca = qb->ca_xyz; A.q_cb = qb->cb_xyz;
         A.qt = (const rs_query_dev *)(dblk + o_qt); A.hashes = dblk + o_h; A.kfirst = dblk + o_kf; A.sym = (const uint8_t *)(dblk + o_sy);
         A.map_qi = dblk + o_qi; A.map_qj = dblk + o_qj; A.map_idf = (const float *)(dblk + o_idf); A.indices = dblk + o_idx;

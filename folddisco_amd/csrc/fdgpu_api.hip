@@ -177,7 +177,7 @@ extern "C" void fdgpu_destroy(fdgpu_ctx *c) {
     for (auto &b : c->pool) (void)hipFree(b.p);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (int k = 0; k < 8; ++k) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
-    for (int k = 0; k < 2; ++k) if (c->hbuf[k]) (void)hipHostFree(c->hbuf[k]);
+    for (int k = 0; k < 4; ++k) if (c->hbuf[k]) (void)hipHostFree(c->hbuf[k]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1088,10 +1088,22 @@ int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t 
     uint64_t *d = nullptr;
     int rc = fd_posting_lengths_dev(c, ix, q_hash, nq, &d);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(lengths, d, nq * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(segs, c->ws[WS_CQ_NSEG].p, nq * 4, hipMemcpyDeviceToHost, c->stream));
-    if (kidx) HIPCHK(c, hipMemcpyAsync(kidx, c->ws[WS_CQ_KIDX].p, nq * 8, hipMemcpyDeviceToHost, c->stream));     // both length paths leave the list positions there
+    // the three arrays land in one page-locked block (a pageable destination makes every copy a staged, blocking one)
+    uint8_t *land = (uint8_t *)c->host_pinned(3, nq * 20);
+    if (!land) {
+        HIPCHK(c, hipMemcpyAsync(lengths, d, nq * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(segs, c->ws[WS_CQ_NSEG].p, nq * 4, hipMemcpyDeviceToHost, c->stream));
+        if (kidx) HIPCHK(c, hipMemcpyAsync(kidx, c->ws[WS_CQ_KIDX].p, nq * 8, hipMemcpyDeviceToHost, c->stream));     // both length paths leave the list positions there
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return FDGPU_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(land, d, nq * 8, hipMemcpyDeviceToHost, c->stream));
+    if (kidx) HIPCHK(c, hipMemcpyAsync(land + nq * 8, c->ws[WS_CQ_KIDX].p, nq * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(land + nq * 16, c->ws[WS_CQ_NSEG].p, nq * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(lengths, land, nq * 8);
+    if (kidx) memcpy(kidx, land + nq * 8, nq * 8);
+    memcpy(segs, land + nq * 16, nq * 4);
     return FDGPU_OK;
 }
 extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths) { FD_LOCK(c);
@@ -1373,6 +1385,9 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     reset_timings(c);
     hipStream_t st = c->stream;
     const uint64_t S = ix->n_structures, nq = q_off[n_queries];
+    const bool cq_trace = getenv("FDGPU_TRACE") != nullptr;       // host-side stage stamps on stderr (measurement aid)
+    const auto cq_t0 = std::chrono::steady_clock::now();
+    auto cq_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - cq_t0).count(); };
     uint64_t *ooff = (uint64_t *)calloc(n_queries + 1, 8);
     if (!ooff) return FDGPU_ENOMEM;
     if (dev) { dev->got = false; dev->overflow = false; }
@@ -1393,6 +1408,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         packed = packed && (q_off[t + 1] - q_off[t]) < (1ull << 18);
         packed = fd_cq_rows(q_hash, q_node, q_edge_j, q_idf, q_off[t], q_off[t + 1], rows_hash, rows_meta, known_kidx, &rows_kidx) && packed;
     }
+    if (cq_trace) fprintf(stderr, "[count_query] %llu rows of %llu queries in order at %.3f ms\n", (unsigned long long)nq, (unsigned long long)n_queries, cq_ms());
     const uint32_t words = (uint32_t)((S + 31) / 32);
     const uint64_t QS = n_queries * S;
     const bool dense_topn = allow_dense && packed && top_n > 0 && top_n + 1024 <= 4096;
@@ -1556,7 +1572,9 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         }
         if (e2 == hipSuccess) e2 = c->ws[WS_MISC2].ensure(n_queries * 16);
         std::vector<uint32_t> tstate((size_t)n_queries * 4);
-        std::vector<fd_count_rec> sel((size_t)n_queries * top_n);
+        // the ranked records land in the caller's array (page-locked, pooled) at a stride of top_n and are closed up in place afterwards
+        fd_count_rec *rr = dev ? nullptr : (fd_count_rec *)fd_out_alloc(std::max<uint64_t>((uint64_t)n_queries * top_n, 1) * sizeof(fd_count_rec), true);
+        if (!dev && !rr) { free(ooff); return FDGPU_ENOMEM; }
         if (e2 == hipSuccess && tiled) {
             T.ghist = c->ws[WS_CQ_TOPN].as<uint32_t>(); T.state = c->ws[WS_MISC2].as<qt_state>(); T.out = c->ws[WS_KEYS_A].p; T.cap = cap;
             {
@@ -1604,11 +1622,13 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
                                       c->ws[WS_KEYS_A].p, c->ws[WS_MISC2].p, c->ws[WS_CQ_TOPN].as<uint32_t>(), st);
             fd_launch_cq_topn_sort(c->ws[WS_KEYS_A].p, cap, c->ws[WS_MISC2].p, (uint32_t)n_queries, top_n, c->ws[WS_TILE_HO].p, st);
         }
+        if (cq_trace) fprintf(stderr, "[count_query] launched at %.3f ms\n", cq_ms());
         if (e2 == hipSuccess) e2 = hipMemcpyAsync(tstate.data(), c->ws[WS_MISC2].p, n_queries * 16, hipMemcpyDeviceToHost, st);
-        if (e2 == hipSuccess && !dev) e2 = hipMemcpyAsync(sel.data(), c->ws[WS_TILE_HO].p, sel.size() * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
+        if (e2 == hipSuccess && !dev) e2 = hipMemcpyAsync(rr, c->ws[WS_TILE_HO].p, (size_t)n_queries * top_n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
         if (e2 == hipSuccess) e2 = hipGetLastError();
-        if (e2 != hipSuccess) { free(ooff); c->err = std::string("count_query_batch: ") + hipGetErrorString(e2); return FDGPU_EHIP; }
+        if (e2 != hipSuccess) { free(ooff); fdgpu_free(rr); c->err = std::string("count_query_batch: ") + hipGetErrorString(e2); return FDGPU_EHIP; }
+        if (cq_trace) fprintf(stderr, "[count_query] records on the host at %.3f ms\n", cq_ms());
         bool overflow = false;
         uint64_t tot = 0;
         for (uint64_t t = 0; t < n_queries; ++t) { overflow = overflow || tstate[4 * t + 3] > cap; tot += std::min<uint32_t>(tstate[4 * t + 3], top_n); }
@@ -1618,16 +1638,15 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
             return FDGPU_OK;
         }
         if (overflow) {   // more ties at the cut-off than the selection's slots hold: the compacting path ranks that call
-            free(ooff);
+            free(ooff); fdgpu_free(rr);
             return fd_count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off, false, nullptr, known_segments);
         }
-        fd_count_rec *rr = (fd_count_rec *)fd_out_alloc(std::max<uint64_t>(tot, 1) * sizeof(fd_count_rec));
-        if (!rr) { free(ooff); return FDGPU_ENOMEM; }
+        (void)tot;
         uint64_t w = 0;
         for (uint64_t t = 0; t < n_queries; ++t) {
             const uint64_t m = std::min<uint32_t>(tstate[4 * t + 3], top_n);
             ooff[t] = w;
-            if (m) memcpy(rr + w, sel.data() + (size_t)t * top_n, (size_t)m * sizeof(fd_count_rec));
+            if (m && w != t * top_n) memmove(rr + w, rr + (size_t)t * top_n, (size_t)m * sizeof(fd_count_rec));      // w <= t * top_n: forward
             w += m;
         }
         ooff[n_queries] = w;
@@ -1885,7 +1904,7 @@ static void fd_sort_found(fd_pair_rec *f, uint64_t n, uint64_t n_cand) {
 int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
                          const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
                          fd_cand_rec **cands, uint64_t *n_cands, uint32_t mode, const uint32_t *cj_mask, const uint32_t *mask_off,
-                         uint64_t mask_words, uint32_t **pk_key, uint32_t **pk_val, fd_vote_plan *votes, fd_mp_tables *tables) {
+                         uint64_t mask_words, uint32_t **pk_key, uint32_t **pk_val, fd_vote_plan *votes, fd_mp_tables *tables, const std::function<void()> *while_scanning) {
     if (!c || !db || !p || !found || !n_found || !cands || !n_cands || !cand_off || (n_queries && !qs)) return FDGPU_EINVAL;
     if ((mode & 32u) && (!votes || !cj_mask || !mask_off || (mode & 3u))) return FDGPU_EINVAL;
     const uint64_t n_cand = cand_off[n_queries];
@@ -2126,6 +2145,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
             fd_launch_match_pairs(A, true, st);
         }
         HIPCHK(c, hipGetLastError());
+        if (attempt == 0 && while_scanning && *while_scanning) (*while_scanning)();      // before the copy: one into pageable memory waits for the stream
         HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_TOTAL].p, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         if (tot[0] <= A.cap_found && tot[1] <= A.cap_cands) break;

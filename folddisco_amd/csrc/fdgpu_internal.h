@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -59,8 +60,8 @@ struct fdgpu_ctx {
     // pinned staging of large device-to-host copies (fd_d2h_big in fdgpu_api.hip): FD_PIN_SLOTS buffers of FD_PIN_BYTES, made on first use
     // pinned host buffers that outlive a call (the packed candidate pairs of a whole-structure retrieval: 2 x ~100 MB per call — as
     // malloc'd blocks their first-touch page faults and their munmap cost more than the copy)
-    void *hbuf[2] = {nullptr, nullptr};
-    size_t hbuf_cap[2] = {0, 0};
+    void *hbuf[4] = {nullptr, nullptr, nullptr, nullptr};      // 0, 1: retrieval; 2, 3: landing blocks of the query-map stage's small copies
+    size_t hbuf_cap[4] = {0, 0, 0, 0};
     void *host_pinned(int k, size_t bytes) {
         if (hbuf_cap[k] >= bytes) return hbuf[k];
         if (hbuf[k]) (void)hipHostFree(hbuf[k]);
@@ -393,6 +394,7 @@ struct rs_args {
     const fd_pair_rec *found; const fd_cand_rec *cands;
     const uint32_t *seg_f, *seg_c, *perm_f, *perm_c;     // per-slot segments of the (unordered) scan output
     const uint32_t *cand, *slot_q;                       // slot -> structure of the database batch, slot -> query
+    const uint32_t *order;                               // launch order of the slots, heaviest first (k_rs_order; null: slot order)
     const uint32_t *db_res_off; const float *db_ca, *db_cb, *q_ca, *q_cb;
     const rs_query_dev *qt;
     const uint32_t *hashes, *kfirst; const uint8_t *sym;
@@ -415,4 +417,5 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
                          const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
                          fd_cand_rec **cands, uint64_t *n_cands, uint32_t mode = 3, const uint32_t *cj_mask = nullptr,
                          const uint32_t *mask_off = nullptr, uint64_t mask_words = 0, uint32_t **pk_key = nullptr, uint32_t **pk_val = nullptr,
-                         fd_vote_plan *votes = nullptr, struct fd_mp_tables *tables = nullptr);
+                         fd_vote_plan *votes = nullptr, struct fd_mp_tables *tables = nullptr, const std::function<void()> *while_scanning = nullptr);
+// (while_scanning: host work of the caller that does not need the scan's result — run once, between the scan's launch and the wait for it)

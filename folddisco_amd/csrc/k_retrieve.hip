@@ -108,6 +108,30 @@ __global__ void k_rs_scatter(const fd_pair_rec *__restrict__ found, uint64_t nf,
     if (on) { if (is_f) perm_f[pos] = (uint32_t)x; else perm_c[pos] = (uint32_t)(x - nf); }
 }
 
+// Launch order of the slots: heaviest first.  A slot is one wavefront's serial chain (rank its edges, build the graph, votes and rescue over its
+// candidate pairs) and a batch of 128 queries has 4,096 of them for ~770 resident wavefronts: dealt in slot order the launch ends with
+// whichever heavy slot happened to start last.  Weight ~ F^2 / 16 + 8 F + C (F found triples, C candidate pairs), bucketed by its top two bits
+// (64 buckets, any order inside one: the results do not depend on the schedule, the records are ordered afterwards).
+__global__ __launch_bounds__(1024) void k_rs_order(const uint32_t *__restrict__ cnt, uint32_t n_cand, uint32_t *__restrict__ order) {
+    __shared__ uint32_t hist[64];
+    auto bucket = [&](uint32_t s) -> uint32_t {
+        const uint32_t F = cnt[s], C = cnt[n_cand + 1 + s];
+        if (!F) return 0u;
+        const uint64_t w64 = (uint64_t)F * F / 16u + 8ull * F + C;
+        const uint32_t w = w64 > 0x7fffffffull ? 0x7fffffffu : (uint32_t)w64;
+        const uint32_t top = 31u - (uint32_t)__clz((int)w);           // w >= 8
+        const uint32_t b = 2u * top + ((w >> (top - 1u)) & 1u);
+        return b < 63u ? b : 63u;
+    };
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < n_cand; s += 1024) atomicAdd(&hist[bucket(s)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int b = 63; b >= 0; --b) { const uint32_t t = hist[b]; hist[b] = run; run += t; } }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < n_cand; s += 1024) order[atomicAdd(&hist[bucket(s)], 1u)] = s;
+}
+
 __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     __shared__ uint32_t s_a[RS_LIST_CAP];      // raw i | raw j           -> votes: query residue   -> rescue: partner-residue list
     __shared__ uint32_t s_b[RS_LIST_CAP];      // raw hash | raw position -> votes: target residue  -> rescue: multiplicities
@@ -118,7 +142,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     __shared__ uint32_t s_aq[FD_WAVE], s_ar[FD_WAVE], s_qs[FD_WAVE], s_rs[FD_WAVE], s_rmx[FD_WAVE], s_rnm[FD_WAVE], s_rarg[FD_WAVE];
     __shared__ int32_t s_fh[FD_WAVE], s_pr[FD_WAVE];
     __shared__ uint32_t s_misc[2];
-    const uint32_t slot = blockIdx.x, lane = threadIdx.x;
+    const uint32_t slot = A.order ? A.order[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
     const uint32_t f0 = A.seg_f[slot], F = A.seg_f[slot + 1] - f0;
     if (F == 0) return;
     if (F > RS_EDGE_CAP) RS_OVERFLOW();
@@ -388,6 +412,8 @@ void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec
     if (n) hipLaunchKernelGGL(k_rs_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, found, nf, cands, nc, n_cand, cnt);
     hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(256), 0, st, cnt, n_cand, seg, cur);
     if (n) hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, found, nf, cands, nc, n_cand, cur, perm_f, perm_c);
+    // the cursors are spent: their array takes the slots' launch order (rs_args.order = cur)
+    if (n_cand) hipLaunchKernelGGL(k_rs_order, dim3(1), dim3(1024), 0, st, cnt, n_cand, cur);
 }
 
 void fd_launch_rs_slots(const rs_args &A, uint32_t n_cand, hipStream_t st) {

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import HashParams, MatchRec, QueryMap, f32p, u8p, u32p, u64p
+from ._lib import HashParams, MatchRec, QueryMap, f32p, owned_view, u8p, u32p, u64p
 from .api import Batch, Context, FolddiscoIndex, PackedStructures, count_query, length_penalty
 from .structure import CompactStructure
 
@@ -292,9 +292,8 @@ def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Bat
         roff = np.ctypeslib.as_array(ro, shape=(T + 1,)).copy()
         nm, nr = int(moff[-1]), int(roff[-1])
         assert C.sizeof(MatchRec) == MATCH_DTYPE.itemsize
-        marr = np.ctypeslib.as_array(C.cast(mp, C.POINTER(C.c_uint8)), shape=(max(nm, 1) * MATCH_DTYPE.itemsize,))[: nm * MATCH_DTYPE.itemsize].copy().view(MATCH_DTYPE)
-        rarr = np.ctypeslib.as_array(rp, shape=(max(nr, 1),))[:nr].copy()
-        ctx.L.fdgpu_matches_free(mp, rp)
+        marr = owned_view(ctx.L, mp, nm * MATCH_DTYPE.itemsize, MATCH_DTYPE)       # no copies: the blocks go back to the library with the arrays
+        rarr = owned_view(ctx.L, rp, nr * 4, np.int32)
         ctx.L.fdgpu_free(mo)
         ctx.L.fdgpu_free(ro)
         return marr, moff, rarr, roff
