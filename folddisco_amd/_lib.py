@@ -92,7 +92,8 @@ class QueryMap(C.Structure):
     _fields_ = [("n", C.c_uint64), ("hash", u32p), ("qi", u32p), ("qj", u32p), ("is_primary", u8p), ("idf", f32p),
                 ("n_indices", C.c_uint64), ("indices", u32p),
                 ("n_aad", C.c_uint64), ("aad_aa1", u8p), ("aad_aa2", u8p), ("aad_dist", f32p), ("aad_qi", u32p), ("primary_hash", u32p),
-                ("post_len", u64p), ("post_seg", u32p), ("post_index_uid", C.c_uint64), ("post_kidx", C.POINTER(C.c_longlong))]
+                ("post_len", u64p), ("post_seg", u32p), ("post_index_uid", C.c_uint64), ("post_kidx", C.POINTER(C.c_longlong)),
+                ("arena_bytes", C.c_uint64)]
 
 
 class MatchRec(C.Structure):

@@ -164,6 +164,35 @@ __global__ void k_qm_iota(uint32_t *__restrict__ v, uint64_t n) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) v[k] = (uint32_t)k;
 }
+// first insertion wins, per query of a motif batch: one workgroup per query, its candidates' hashes through an open-addressing table in LDS
+// that keeps the SMALLEST insertion position of every hash (a hash always walks the same probe path and slots never empty, so all
+// copies of a hash meet in one slot); a candidate is kept when it holds its hash's slot.  Queries of up to QM_DD_MAX candidates.
+#define QM_DD_MAX 2048u
+#define QM_DD_SLOTS 4096u
+__global__ __launch_bounds__(256) void k_qm_dedupe(const uint32_t *__restrict__ hash, const uint64_t *__restrict__ cand_off, uint8_t *__restrict__ first) {
+    __shared__ unsigned long long tab[QM_DD_SLOTS];
+    const uint64_t c0 = cand_off[blockIdx.x], n = cand_off[blockIdx.x + 1] - c0;
+    for (uint32_t k = threadIdx.x; k < QM_DD_SLOTS; k += 256) tab[k] = ~0ull;
+    __syncthreads();
+    for (uint32_t pos = threadIdx.x; pos < n; pos += 256) {
+        const uint32_t h = hash[c0 + pos];
+        const unsigned long long mine = ((unsigned long long)h << 32) | pos;
+        uint32_t at = (h * 2654435761u) >> 20;      // 12 bits
+        for (;;) {
+            const unsigned long long old = atomicCAS(&tab[at], ~0ull, mine);
+            if (old == ~0ull) break;
+            if ((uint32_t)(old >> 32) == h) { atomicMin(&tab[at], mine); break; }
+            at = (at + 1u) & (QM_DD_SLOTS - 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t pos = threadIdx.x; pos < n; pos += 256) {
+        const uint32_t h = hash[c0 + pos];
+        uint32_t at = (h * 2654435761u) >> 20;
+        while ((uint32_t)(tab[at] >> 32) != h) at = (at + 1u) & (QM_DD_SLOTS - 1u);
+        first[c0 + pos] = (uint32_t)tab[at] == pos ? 1 : 0;
+    }
+}
 __global__ void k_qm_keep(const uint8_t *__restrict__ first, const uint64_t *__restrict__ pos, uint64_t n, uint32_t *__restrict__ keep) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n && first[k]) keep[pos[k]] = (uint32_t)k;
@@ -251,6 +280,7 @@ template <typename T> static T *dup_vec(const std::vector<T> &v) {
 
 extern "C" void fdgpu_query_map_free(fd_query_map *m) {
     if (!m) return;
+    if (m->arena_bytes) { free(m); return; }       // the map and its arrays are one block (fdgpu_make_query_map_batch)
     free(m->hash); free(m->qi); free(m->qj); free(m->is_primary); free(m->idf); free(m->indices); free(m->primary_hash);
     free(m->aad_aa1); free(m->aad_aa2); free(m->aad_dist); free(m->aad_qi);
     free(m->post_len); free(m->post_seg); free(m->post_kidx);
@@ -330,7 +360,11 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     std::vector<uint32_t> vpairs;      // device path: the valid pairs, ascending
     uint64_t dev_pp = 0;
     std::vector<uint32_t> dev_keep;
-    bool dev_expand = false, dev_dedupe = false;
+    bool dev_expand = false, dev_dedupe = false, dev_chain = false;
+    const char *qd_env_chain = getenv("FDGPU_QM_DEVICE");      // 2: device expansion without the dedupe / length chain (tests compare the forms)
+    std::vector<uint8_t> land_v;
+    const uint8_t *ch_first = nullptr;       // the chain's results per candidate (page-locked landing block, valid until this call returns)
+    const uint64_t *ch_len = nullptr; const long long *ch_kidx = nullptr; const uint32_t *ch_seg = nullptr;
     {
         bool any_subs = false;
         if (subs && n_subs) for (uint64_t a = 0; a < q_off[n_queries] && !any_subs; ++a) any_subs = subs[a] != nullptr;
@@ -427,15 +461,53 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         // ws[WS_MISC2] still holds the pairs' containers (pair_features12); the sort takes the build's key / id buffers
         HIPCHK(c, c->ws[WS_MISC0].ensure(nv * 4));
         HIPCHK(c, c->ws[WS_MISC1].ensure(nc * 4));
-        if (!dev_dedupe) {       // hashes only: the per-query dedupe of a motif batch is a small hash table on the host (below)
-            HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, vpairs.data(), nv * 4, hipMemcpyHostToDevice, st));
+        if (!dev_dedupe) {
+            // a motif batch: expansion + hashes -> per-query first-insertion dedupe (k_qm_dedupe) -> posting lengths, segment counts and list
+            // positions of EVERY candidate's hash (the index's length table; 17 k lookups per 128 queries) — three kernels back to back, one
+            // landing block, one wait; the host neither dedupes nor makes a second round trip for the lengths.  Without the chain's
+            // preconditions: hashes only, the rest on the host as before.
+            uint64_t max_ins = 0;
+            for (uint64_t t = 0; t < n_queries; ++t) max_ins = std::max(max_ins, cand_off[t + 1] - cand_off[t]);
+            static const bool lens_cache = [] { const char *e = getenv("FDGPU_LENS_CACHE"); return !(e && e[0] == '0'); }();
+            dev_chain = max_ins <= QM_DD_MAX && !(qd_env_chain && qd_env_chain[0] == '2');
+            const bool chain_len = dev_chain && index && lens_cache && index->lens && index->n_hashes && index->n_structures;
+            const size_t up_words = nv + 2 * (n_queries + 1) + 2;
+            uint32_t *up = (uint32_t *)c->host_pinned(3, up_words * 4);
+            std::vector<uint32_t> up_v;
+            if (!up) { up_v.resize(up_words); up = up_v.data(); }
+            const size_t o_off = (nv + 1) & ~(size_t)1;      // 8-byte aligned
+            memcpy(up, vpairs.data(), nv * 4);
+            memcpy(up + o_off, cand_off.data(), (n_queries + 1) * 8);
+            HIPCHK(c, c->ws[WS_MISC0].ensure(up_words * 4));
+            HIPCHK(c, c->ws[WS_KEYS_A].ensure(nc * 4));
+            HIPCHK(c, c->ws[WS_MISC4].ensure(nc + 8));
+            HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, up, up_words * 4, hipMemcpyHostToDevice, st));
+            uint32_t *d_hash = c->ws[WS_KEYS_A].as<uint32_t>();
             hipLaunchKernelGGL(k_qm_expand_hash, dim3((unsigned)((nv + 63) / 64)), dim3(64), 0, st, c->ws[WS_MISC2].as<float>(), c->ws[WS_MISC0].as<uint32_t>(), (uint32_t)nv, P,
-                               fd_make_consts(p).q, c->ws[WS_MISC1].as<uint32_t>());
+                               fd_make_consts(p).q, d_hash);
+            if (dev_chain)
+                hipLaunchKernelGGL(k_qm_dedupe, dim3((unsigned)n_queries), dim3(256), 0, st, d_hash, (const uint64_t *)(c->ws[WS_MISC0].as<uint32_t>() + o_off),
+                                   c->ws[WS_MISC4].as<uint8_t>());
+            if (chain_len) {
+                HIPCHK(c, c->ws[WS_MISC1].ensure(nc * 8)); HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(nc * 8)); HIPCHK(c, c->ws[WS_CQ_NSEG].ensure(nc * 4));
+                fd_launch_posting_lookup(index->hashes, index->offsets, index->lens, index->n_hashes, d_hash, nc, c->ws[WS_MISC1].as<uint64_t>(),
+                                         c->ws[WS_CQ_NSEG].as<uint32_t>(), c->ws[WS_CQ_KIDX].as<long long>(), st);
+            }
             HIPCHK(c, hipGetLastError());
-            void *land = c->host_pinned(2, nc * 4);
-            HIPCHK(c, hipMemcpyAsync(land ? land : (void *)hashes.data(), c->ws[WS_MISC1].p, nc * 4, hipMemcpyDeviceToHost, st));
+            // landing block: [len u64 | kidx i64 | hash u32 | nseg u32 | first u8] x nc
+            uint8_t *land = (uint8_t *)c->host_pinned(2, nc * 25 + 64);
+            if (!land) { land_v.resize(nc * 25 + 64); land = land_v.data(); }
+            if (chain_len) {
+                HIPCHK(c, hipMemcpyAsync(land, c->ws[WS_MISC1].p, nc * 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipMemcpyAsync(land + nc * 8, c->ws[WS_CQ_KIDX].p, nc * 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipMemcpyAsync(land + nc * 20, c->ws[WS_CQ_NSEG].p, nc * 4, hipMemcpyDeviceToHost, st));
+            }
+            HIPCHK(c, hipMemcpyAsync(land + nc * 16, d_hash, nc * 4, hipMemcpyDeviceToHost, st));
+            if (dev_chain) HIPCHK(c, hipMemcpyAsync(land + nc * 24, c->ws[WS_MISC4].p, nc, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
-            if (land) memcpy(hashes.data(), land, nc * 4);
+            memcpy(hashes.data(), land + nc * 16, nc * 4);
+            if (dev_chain) ch_first = land + nc * 24;
+            if (chain_len) { ch_len = (const uint64_t *)land; ch_kidx = (const long long *)(land + nc * 8); ch_seg = (const uint32_t *)(land + nc * 20); }
         } else {
         HIPCHK(c, c->ws[WS_KEYS_A].ensure(nc * 4)); HIPCHK(c, c->ws[WS_KEYS_B].ensure(nc * 4));
         HIPCHK(c, c->ws[WS_IDS_A].ensure(nc * 4)); HIPCHK(c, c->ws[WS_IDS_B].ensure(nc * 4));
@@ -499,6 +571,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         auto hash_at = [&](uint64_t pos) { const uint64_t z = c0 + pos / ncfg1; const uint32_t k = (uint32_t)(pos % ncfg1); return n_cfg ? mh_cfg[k][z] : hashes[z]; };
         std::vector<uint32_t> &keep = keeps[t];
         if (dev_dedupe) keep.swap(dev_keep);
+        else if (ch_first) { keep.reserve((size_t)n_ins / 2 + 8); for (uint64_t pos = 0; pos < n_ins; ++pos) if (ch_first[c0 + pos]) keep.push_back((uint32_t)pos); }
         else if (n_ins <= 4096) {      // a motif query's few hundred insertions: a small open-addressing table (a node-based set cost 3x this)
             uint32_t cap = 64;
             while (cap < 2 * n_ins) cap <<= 1;
@@ -554,6 +627,14 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         ent_len.assign(std::max<size_t>(ph.size(), 1), 0);
         ent_seg.assign(std::max<size_t>(ph.size(), 1), 0);
         ent_kidx.assign(std::max<size_t>(ph.size(), 1), -1);
+        if (ch_len) {      // the chain looked every candidate up: pick the kept entries and the observed hashes, in ph's order
+            size_t w = 0;
+            for (uint64_t t = 0; t < n_queries; ++t) {
+                const uint64_t c0 = cand_off[t];
+                for (uint32_t pos : keeps[t]) { const uint64_t z = c0 + pos; ent_len[w] = ch_len[z]; ent_seg[w] = ch_seg[z]; ent_kidx[w] = ch_kidx[z]; ++w; }
+            }
+            for (uint64_t v = 0; v < vpairs.size(); ++v, ++w) { const uint64_t z = v * dev_pp; ent_len[w] = ch_len[z]; ent_seg[w] = ch_seg[z]; ent_kidx[w] = ch_kidx[z]; }
+        } else
         if ((rc = fd_posting_lengths_segs(c, index, ph.data(), ph.size(), ent_len.data(), ent_seg.data(), ent_kidx.data()))) return rc;
         for (size_t t = 0; t < pk.size(); ++t)
             pair_idf[pk[t]] = ent_len[n_keep + t] > 0 ? log2f(total_structures / (float)ent_len[n_keep + t]) : 0.0f;
@@ -561,13 +642,28 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     if (qtrace) fprintf(stderr, "[fdgpu_query_map] posting lengths at %.3f ms\n", q_ms());
     uint64_t keep_at = 0;
     for (uint64_t t = 0; t < n_queries; ++t) {
-        std::vector<uint32_t> mh, mqi, mqj, mph;
-        std::vector<uint8_t> mp;
-        std::vector<float> mi;
         const uint64_t c0 = cand_off[t];
         auto hash_at = [&](uint64_t pos) { const uint64_t z = c0 + pos / ncfg1; const uint32_t k = (uint32_t)(pos % ncfg1); return n_cfg ? mh_cfg[k][z] : hashes[z]; };
         const std::vector<uint32_t> &keep = keeps[t];
-        mh.reserve(keep.size()); mqi.reserve(keep.size()); mqj.reserve(keep.size()); mp.reserve(keep.size()); mi.reserve(keep.size()); mph.reserve(keep.size());
+        const Aad &A = aads[t];
+        // the map and all its arrays in ONE block (fd_query_map.arena_bytes != 0: fdgpu_query_map_free releases the block; a map was 15
+        // allocations, a batch of 128 queries two thousand)
+        const size_t n = keep.size(), n_idx = (size_t)(q_off[t + 1] - q_off[t]), n_aad = A.ad.size();
+        const bool with_post = index && n;
+        auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+        const size_t o_hash = up16(sizeof(fd_query_map)), o_qi = o_hash + up16(n * 4), o_qj = o_qi + up16(n * 4), o_idf = o_qj + up16(n * 4), o_ph = o_idf + up16(n * 4),
+                     o_pl = o_ph + up16(n * 4), o_pk = o_pl + (with_post ? up16(n * 8) : 0), o_ps = o_pk + (with_post ? up16(n * 8) : 0),
+                     o_idx = o_ps + (with_post ? up16(n * 4) : 0), o_ad = o_idx + up16(n_idx * 4), o_aq = o_ad + up16(n_aad * 4), o_prim = o_aq + up16(n_aad * 4),
+                     o_a1 = o_prim + up16(n), o_a2 = o_a1 + up16(n_aad), bytes = o_a2 + up16(n_aad) + 16;
+        uint8_t *blk = (uint8_t *)malloc(bytes);
+        if (!blk) { for (uint64_t u = 0; u < t; ++u) { fdgpu_query_map_free(out[u]); out[u] = nullptr; } return FDGPU_ENOMEM; }
+        fd_query_map *m = (fd_query_map *)blk;
+        memset(m, 0, sizeof *m);
+        m->arena_bytes = bytes;
+        m->n = n;
+        m->hash = (uint32_t *)(blk + o_hash); m->qi = (uint32_t *)(blk + o_qi); m->qj = (uint32_t *)(blk + o_qj); m->idf = (float *)(blk + o_idf);
+        m->primary_hash = (uint32_t *)(blk + o_ph); m->is_primary = blk + o_prim;
+        size_t w = 0;
         if (dev_expand && !n_cfg) {       // kept positions ascend: the pair a position belongs to advances with them (no division per entry)
             uint64_t v = c0 / dev_pp, v_end = (v + 1) * dev_pp;      // candidates of valid pair v: [v * dev_pp, v_end)
             const uint64_t r0 = qb->h_res_off[q_struct[t]];
@@ -575,33 +671,28 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
                 const uint64_t z = c0 + pos;
                 while (z >= v_end) { ++v; v_end += dev_pp; }
                 const uint32_t k = vpairs[v];
-                mh.push_back(hashes[z]); mqi.push_back((uint32_t)(pi[k] - r0)); mqj.push_back((uint32_t)(pj[k] - r0)); mp.push_back(z + dev_pp == v_end ? 1 : 0);
-                mi.push_back(pair_idf[k]); mph.push_back(pair_primary[k]);
+                m->hash[w] = hashes[z]; m->qi[w] = (uint32_t)(pi[k] - r0); m->qj[w] = (uint32_t)(pj[k] - r0); m->is_primary[w] = z + dev_pp == v_end ? 1 : 0;
+                m->idf[w] = pair_idf[k]; m->primary_hash[w] = pair_primary[k];
+                ++w;
             }
         } else
         for (uint32_t pos : keep) {
             const uint64_t z = c0 + pos / ncfg1;
             const cand_t cz = cand_at(z);
-            mh.push_back(hash_at(pos)); mqi.push_back(cz.qi); mqj.push_back(cz.qj); mp.push_back(cz.primary);
-            mi.push_back(pair_idf[cz.pair]); mph.push_back(pair_primary[cz.pair]);
+            m->hash[w] = hash_at(pos); m->qi[w] = cz.qi; m->qj[w] = cz.qj; m->is_primary[w] = cz.primary;
+            m->idf[w] = pair_idf[cz.pair]; m->primary_hash[w] = pair_primary[cz.pair];
+            ++w;
         }
-        fd_query_map *m = (fd_query_map *)calloc(1, sizeof *m);
-        if (!m) { for (uint64_t u = 0; u < t; ++u) { fdgpu_query_map_free(out[u]); out[u] = nullptr; } return FDGPU_ENOMEM; }
-        m->n = mh.size();
-        m->hash = dup_vec(mh); m->qi = dup_vec(mqi); m->qj = dup_vec(mqj); m->is_primary = dup_vec(mp); m->idf = dup_vec(mi); m->primary_hash = dup_vec(mph);
-        if (index && !keep.empty()) {
-            m->post_len = (uint64_t *)malloc(keep.size() * 8); m->post_seg = (uint32_t *)malloc(keep.size() * 4); m->post_kidx = (long long *)malloc(keep.size() * 8);
-            if (m->post_len && m->post_seg && m->post_kidx) {
-                memcpy(m->post_len, &ent_len[keep_at], keep.size() * 8); memcpy(m->post_seg, &ent_seg[keep_at], keep.size() * 4);
-                memcpy(m->post_kidx, &ent_kidx[keep_at], keep.size() * 8);
-                m->post_index_uid = index->uid;
-            } else { free(m->post_len); free(m->post_seg); free(m->post_kidx); m->post_len = nullptr; m->post_seg = nullptr; m->post_kidx = nullptr; }
+        if (with_post) {
+            m->post_len = (uint64_t *)(blk + o_pl); m->post_kidx = (long long *)(blk + o_pk); m->post_seg = (uint32_t *)(blk + o_ps);
+            memcpy(m->post_len, &ent_len[keep_at], n * 8); memcpy(m->post_seg, &ent_seg[keep_at], n * 4); memcpy(m->post_kidx, &ent_kidx[keep_at], n * 8);
+            m->post_index_uid = index->uid;
         }
-        keep_at += keep.size();
-        std::vector<uint32_t> idx(q_index + q_off[t], q_index + q_off[t + 1]);
-        m->n_indices = idx.size(); m->indices = dup_vec(idx);
-        const Aad &A = aads[t];
-        m->n_aad = A.ad.size(); m->aad_aa1 = dup_vec(A.a1); m->aad_aa2 = dup_vec(A.a2); m->aad_dist = dup_vec(A.ad); m->aad_qi = dup_vec(A.aq);
+        keep_at += n;
+        m->n_indices = n_idx; m->indices = (uint32_t *)(blk + o_idx);
+        if (n_idx) memcpy(m->indices, q_index + q_off[t], n_idx * 4);
+        m->n_aad = n_aad; m->aad_dist = (float *)(blk + o_ad); m->aad_qi = (uint32_t *)(blk + o_aq); m->aad_aa1 = blk + o_a1; m->aad_aa2 = blk + o_a2;
+        if (n_aad) { memcpy(m->aad_dist, A.ad.data(), n_aad * 4); memcpy(m->aad_qi, A.aq.data(), n_aad * 4); memcpy(m->aad_aa1, A.a1.data(), n_aad); memcpy(m->aad_aa2, A.a2.data(), n_aad); }
         out[t] = m;
     }
     if (qtrace) fprintf(stderr, "[fdgpu_query_map] maps built at %.3f ms\n", q_ms());
@@ -724,21 +815,24 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     std::vector<uint32_t> q_sizes(std::max<uint64_t>(n_queries, 1), 1);
     for (uint64_t t = 0; t < n_queries; ++t) {
         const fd_query_map *m = qms[t];
-        std::vector<uint64_t> key(m->n), tmp(m->n);
+        uint64_t key_small[256];          // a motif query's few dozen entries stay off the heap (two allocations per query, 128 queries per batch)
+        std::vector<uint64_t> key_v, tmp_v;
+        if (m->n > 256) { key_v.resize(m->n); tmp_v.resize(m->n); }
+        uint64_t *key = m->n > 256 ? key_v.data() : key_small, *tmp = tmp_v.data();
         for (uint64_t k = 0; k < m->n; ++k) {
             key[k] = ((uint64_t)m->hash[k] << 32) | (uint32_t)k;
             q_sizes[t] = std::max(q_sizes[t], std::max(m->qi[k], m->qj[k]) + 1);
         }
-        if (m->n > 64) {
+        if (m->n > 256) {
             for (int pass = 0; pass < 4; ++pass) {           // entries arrive in ascending k: a stable sort by hash keeps the first entry first
                 const int sh = 32 + 8 * pass;
                 size_t cnt[257] = {0};
                 for (uint64_t k = 0; k < m->n; ++k) ++cnt[((key[k] >> sh) & 255u) + 1];
                 for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
                 for (uint64_t k = 0; k < m->n; ++k) tmp[cnt[(key[k] >> sh) & 255u]++] = key[k];
-                key.swap(tmp);
+                std::swap(key, tmp);
             }
-        } else std::sort(key.begin(), key.end());
+        } else std::sort(key, key + m->n);
         qhs[t].reserve(m->n); qkf[t].reserve(m->n);
         for (uint64_t k = 0; k < m->n; ++k)
             if (k == 0 || (key[k] >> 32) != (key[k - 1] >> 32)) { qhs[t].push_back((uint32_t)(key[k] >> 32)); qkf[t].push_back((uint32_t)key[k]); }

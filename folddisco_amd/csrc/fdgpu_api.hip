@@ -1977,6 +1977,25 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         const bool no_aa = p->hash_type == FD_HASH_TERTIARY || p->hash_type == FD_HASH_HYBRID;
         Q.use_prefilter = no_aa ? 0 : q->use_aa_prefilter; Q.ca_window = q->ca_distance_cutoff;
         uint32_t *cnt = &all_start[(size_t)1025 * t];
+        if (q->n_aad <= 256) {
+            // a motif query's dozen observed distances: (group << 16 | e) keys sorted (= stable by e), the 1,025-entry start table written as
+            // a few runs — counting into it and scanning it cost 1,024 dependent adds per query, 128 times per batch
+            uint32_t keys[256];
+            uint32_t nk = 0;
+            for (uint64_t e = 0; e < q->n_aad; ++e)
+                if (q->aad_aa1[e] < 32 && q->aad_aa2[e] < 32) keys[nk++] = ((q->aad_aa1[e] * 32u + q->aad_aa2[e]) << 16) | (uint32_t)e;
+            std::sort(keys, keys + nk);
+            Q.aad_off = (uint32_t)all_dist.size(); Q.n_aad = nk;
+            all_qi.resize(Q.aad_off + nk); all_dist.resize(Q.aad_off + nk);
+            uint32_t g_next = 0;       // start[g] for g < g_next is written
+            for (uint32_t k = 0; k < nk; ++k) {
+                const uint32_t g = keys[k] >> 16, e = keys[k] & 0xffffu;
+                if (g >= g_next) { std::fill(cnt + g_next, cnt + g + 1, k); g_next = g + 1; }
+                all_qi[Q.aad_off + k] = q->aad_qi[e]; all_dist[Q.aad_off + k] = q->aad_dist[e];
+            }
+            std::fill(cnt + g_next, cnt + 1025, nk);
+            continue;
+        }
         for (uint64_t e = 0; e < q->n_aad; ++e)
             if (q->aad_aa1[e] < 32 && q->aad_aa2[e] < 32) ++cnt[q->aad_aa1[e] * 32u + q->aad_aa2[e] + 1];   // residue type 255 never passes get_single_feature
         for (int k = 0; k < 1024; ++k) cnt[k + 1] += cnt[k];

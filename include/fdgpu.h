@@ -273,6 +273,7 @@ typedef struct fd_query_map {   /* make_query_map output (src/controller/query.r
      * posting-length pass and without asking the device for its work count */
     uint64_t *post_len; uint32_t *post_seg; uint64_t post_index_uid;
     long long *post_kidx;       /* with post_len: position of every entry's hash in that index's hash array (-1: absent) — scoring skips its own search */
+    uint64_t arena_bytes;       /* private: non-zero when the struct and every array above are ONE allocation of that size (release only through fdgpu_query_map_free) */
 } fd_query_map;
 /* qb = batch holding the query structure as structure 0; q_index[k] = residue index of the k-th query
  * residue (after parse_query_string + get_index / --serial-index resolution on the caller's side);

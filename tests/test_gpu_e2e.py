@@ -681,15 +681,67 @@ def test_query_map_device_expansion_equals_host_expansion(env, monkeypatch, htyp
         for dthr, athr in (((0.5,), (5.0,)), ((0.5, 1.0, 0.25), (5.0, 10.0)), ((), (7.5,))):
             for index in (six, None):
                 got = {}
-                for mode in ("0", "1"):
-                    monkeypatch.setenv("FDGPU_QM_DEVICE", mode)
+                for mode in ("0", "1", "2", None):      # host, device incl. the sort-based dedupe, device hashes only, default (chain for small queries)
+                    if mode is None:
+                        monkeypatch.delenv("FDGPU_QM_DEVICE", raising=False)
+                    else:
+                        monkeypatch.setenv("FDGPU_QM_DEVICE", mode)
                     got[mode] = fq.make_query_map(ctx, qb, qi, None, index, float(S), dist_thr=dthr, angle_thr=athr, hash_type=htype)
-                monkeypatch.delenv("FDGPU_QM_DEVICE")
+                monkeypatch.delenv("FDGPU_QM_DEVICE", raising=False)
                 for f in fields:
-                    x, y = getattr(got["0"], f), getattr(got["1"], f)
-                    assert x.dtype == y.dtype and x.tobytes() == y.tobytes(), (htype, s, f)
+                    for mode in ("1", "2", None):
+                        x, y = getattr(got["0"], f), getattr(got[mode], f)
+                        assert x.dtype == y.dtype and x.tobytes() == y.tobytes(), (htype, s, f, mode)
                 n_checked += len(got["0"].hash)
     assert n_checked > 10000
+
+
+def test_query_map_batch_device_chain_equals_host_forms(env, monkeypatch):
+    """A batch of motif queries expands, hashes, dedupes (k_qm_dedupe: first insertion wins in an LDS table) and looks its posting lengths up in
+    one chain of kernels; FDGPU_QM_DEVICE=2 keeps the dedupe and the length pass on the host, 0 the expansion too.  The maps — and what
+    scoring makes of the lengths / list positions they remember — are identical; a query beyond the dedupe kernel's table in the batch
+    sends the whole batch down the host dedupe."""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd.api import count_query_maps, length_penalty
+    from tests.helpers import synthetic_packed
+    ctx = env[0]
+    S = 40
+    rng = np.random.default_rng(5)
+    ps = synthetic_packed(S, 911, lengths=np.concatenate([rng.integers(40, 120, S - 1), [150]]))
+    sb = ctx.upload(ps)
+    six = fd.FolddiscoIndex.build(ctx, sb)
+    six.set_penalty(length_penalty(np.diff(ps.res_off).astype(np.uint64), 0.5))
+    fields = ("hash", "qi", "qj", "is_primary", "idf", "indices", "aad_aa1", "aad_aa2", "aad_dist", "aad_qi", "primary_hash")
+    small = []
+    for s in range(0, 24):
+        n = int(ps.res_off[s + 1] - ps.res_off[s])
+        small.append((s, np.sort(rng.choice(n, size=int(rng.integers(2, 9)), replace=False)).astype(np.uint32)))
+    small.append((3, np.array([5, 5, 9], np.uint32)))            # a repeated residue: pairs (5, 5) are skipped, the rest twice
+    small.append((7, np.array([1000, 3], np.uint32)))            # an index outside the structure
+    big = small + [(S - 1, np.arange(150, dtype=np.uint32))]     # 22 k pairs x 11 candidates: beyond the dedupe kernel's table
+    n_checked = 0
+    for queries in (small, big):
+        for index in (six, None):
+            got = {}
+            for mode in ("0", "2", None):
+                if mode is None:
+                    monkeypatch.delenv("FDGPU_QM_DEVICE", raising=False)
+                else:
+                    monkeypatch.setenv("FDGPU_QM_DEVICE", mode)
+                maps = fq.make_query_maps(ctx, sb, queries, index, float(S))
+                recs = count_query_maps(ctx, six, maps, None, total_structures=S, top_n=10) if index is not None else None
+                got[mode] = (maps, recs)
+            monkeypatch.delenv("FDGPU_QM_DEVICE", raising=False)
+            for mode in ("2", None):
+                for t in range(len(queries)):
+                    for f in fields:
+                        x, y = getattr(got["0"][0][t], f), getattr(got[mode][0][t], f)
+                        assert x.dtype == y.dtype and x.tobytes() == y.tobytes(), (mode, t, f)
+                    if index is not None:
+                        assert got["0"][1][t].tobytes() == got[mode][1][t].tobytes(), (mode, t)
+                    n_checked += len(got["0"][0][t].hash)
+    assert n_checked > 20000
 
 
 def test_two_pass_retrieval_equals_single_pass(env, monkeypatch):
