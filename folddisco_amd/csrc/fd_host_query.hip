@@ -910,7 +910,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         // is followed by ~0.4 ms of kernel per 128 queries that the host used to wait out before starting on this
         std::vector<rs_query_dev> qt(n_queries);
         std::vector<uint32_t> t_hash, t_kfirst, t_sym, t_qi, t_qj, t_idf, t_idx;
-        size_t o_qt = 0, o_h = 0, o_kf = 0, o_sy = 0, o_qi = 0, o_qj = 0, o_idf = 0, o_idx = 0, o_sq = 0, o_cd = 0, o_d0 = 0, words = 0;
+        size_t o_qt = 0, o_h = 0, o_kf = 0, o_sy = 0, o_qi = 0, o_qj = 0, o_idf = 0, o_idx = 0, o_sq = 0, o_cd = 0, o_d0 = 0, o_co = 0, words = 0;
         std::vector<uint32_t> blk_v;
         uint32_t *blk = nullptr;
         const std::function<void()> build_rs_tables = [&]() {
@@ -945,7 +945,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         const size_t nh = t_hash.size(), nmap = t_qi.size(), nidx = t_idx.size();
         o_qt = 0; o_h = o_qt + up4(n_queries * (sizeof(rs_query_dev) / 4)); o_kf = o_h + up4(nh); o_sy = o_kf + up4(nh); o_qi = o_sy + up4((nh + 3) / 4);
         o_qj = o_qi + up4(nmap); o_idf = o_qj + up4(nmap); o_idx = o_idf + up4(nmap); o_sq = o_idx + up4(nidx); o_cd = o_sq + up4(n_cand);
-        o_d0 = o_cd + up4(n_cand); words = o_d0 + up4(2 * FD_WAVE + 1) + 4;
+        o_d0 = o_cd + up4(n_cand); o_co = o_d0 + up4(2 * FD_WAVE + 1); words = o_co + up4(2 * (n_queries + 1)) + 4;
         // packed in a pinned staging buffer of the context (its own: the pair scan's block in slot 0 is being copied while this runs)
         blk = (uint32_t *)c->host_pinned(2, words * 4);
         if (!blk) { blk_v.assign(words, 0); blk = blk_v.data(); }
@@ -957,6 +957,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         memcpy(&blk[o_sq], t_slotq.data(), n_cand * 4);
         memcpy(&blk[o_cd], cand, n_cand * 4);
         memcpy(&blk[o_d0], d0tab, sizeof d0tab);
+        memcpy(&blk[o_co], cand_off, (n_queries + 1) * 8);      // (o_co is a multiple of 4 words: 8-byte aligned)
         };
         rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &f_none, &nf_d, &c_none, &nc_d, 19u, nullptr, nullptr, 0, nullptr, nullptr,
                                   nullptr, nullptr, &build_rs_tables);
@@ -974,6 +975,12 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         HIPCHK(c, c->ws[WS_RS_KOFF].ensure((cap_prob + 1) * 8 + cap_prob * 4));
         HIPCHK(c, c->ws[WS_RS_SOL].ensure(cap_prob * 18 * 4));
         HIPCHK(c, c->ws[WS_RS_CNT].ensure(64));
+        // [records per slot | slot bases + first residues (2 n_cand + 2) | match_off, res_off (n_queries + 1 each, 8-byte)] for the device-side ordering
+        const size_t o_sm = 0, o_scr = o_sm + ((n_cand + 1) & ~(size_t)1), o_mo = (o_scr + 2 * n_cand + 2 + 1) & ~(size_t)1, o_ro = o_mo + 2 * (n_queries + 1),
+                     ord_words = o_ro + 2 * (n_queries + 1);
+        HIPCHK(c, c->ws[WS_RS_PLAN].ensure(ord_words * 4));
+        uint32_t *d_ord = c->ws[WS_RS_PLAN].as<uint32_t>();
+        HIPCHK(c, hipMemsetAsync(d_ord + o_sm, 0, n_cand * 4, st));
         HIPCHK(c, hipMemcpyAsync(c->ws[WS_RS_TAB].p, blk, words * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemsetAsync(c->ws[WS_RS_CNT].p, 0, 64, st));
         const uint32_t *dblk = c->ws[WS_RS_TAB].as<uint32_t>();
@@ -986,6 +993,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         memset(&A, 0, sizeof A);
         A.found = d_found; A.cands = d_cands; A.seg_f = d_seg; A.seg_c = d_seg + (n_cand + 1); A.perm_f = d_pf; A.perm_c = d_pc;
         A.cand = dblk + o_cd; A.slot_q = dblk + o_sq;
+        A.slot_matches = d_ord + o_sm;
         A.order = getenv("FDGPU_RS_ORDER") && getenv("FDGPU_RS_ORDER")[0] == '0' ? nullptr : d_cur;      // 0: slot order (measurement)
         A.db_res_off = db->res_off; A.db_ca = db->ca_xyz; A.db_cb = db->cb_xyz; A.q_ca = qb->ca_xyz; A.q_cb = qb->cb_xyz;
         A.qt = (const rs_query_dev *)(dblk + o_qt); A.hashes = dblk + o_h; A.kfirst = dblk + o_kf; A.sym = (const uint8_t *)(dblk + o_sy);
@@ -1013,6 +1021,43 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
             // and the residue lists are gathered on the device in their final order (k_rs_records) and copied straight into the caller's
             // page-locked arrays — the host loop over 23 k records of a 512-query batch (8 scattered reads + 232 bytes written each) was
             // 1.6-2.3 ms of the call
+            float *d_rmsd0 = c->ws[WS_RS_SOL].as<float>();
+            const char *ho_env = getenv("FDGPU_RS_HOST_ORDER");       // 1: the records are ordered on the host from their headers (tests compare the two)
+            if (!(ho_env && ho_env[0] == '1')) {
+                // the records' final places are computed on the device (k_rs_offsets: bases of the slots from their record counts; a record's
+                // place inside its slot was fixed when it was written) — no header copy, no host sort, no gather plan: after the counters above
+                // nothing but the finished arrays crosses the bus, with one wait
+                const uint64_t tot_res = cnt_h[2];
+                if (tot_res >= (1ull << 32)) { c->err = "retrieve_batch: residue lists beyond 2^32 entries; split the batch"; return FDGPU_ERANGE; }
+                float *d_rot0 = d_rmsd0 + nprob, *d_tran0 = d_rot0 + 9 * nprob, *d_met0 = d_tran0 + 3 * nprob;
+                uint64_t *omo = (uint64_t *)malloc((n_queries + 1) * 8), *oro = (uint64_t *)malloc((n_queries + 1) * 8);
+                fd_match_rec *om = (fd_match_rec *)fd_out_alloc(std::max<size_t>(nm, 1) * sizeof(fd_match_rec), true);
+                int32_t *orr = (int32_t *)fd_out_alloc(std::max<size_t>(tot_res, 1) * sizeof(int32_t), true);
+                if (!omo || !oro || !om || !orr) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
+                hipError_t e = c->ws[WS_RS_REC].ensure(std::max<uint64_t>(nm, 1) * sizeof(fd_match_rec));
+                if (e == hipSuccess) e = c->ws[WS_RS_RECRES].ensure(std::max<uint64_t>(tot_res, 1) * 4);
+                if (e == hipSuccess && nprob) {
+                    e = hipMemcpyAsync(A.koff + nprob, &npts, 8, hipMemcpyHostToDevice, st);
+                    fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd0, d_rot0, d_tran0, st);
+                    fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot0, d_tran0, A.d0, d_met0, st);
+                }
+                uint64_t *d_mo = (uint64_t *)(d_ord + o_mo), *d_ro = (uint64_t *)(d_ord + o_ro);
+                if (e == hipSuccess) {
+                    fd_launch_rs_records_dev(A.matches, nm, A.slot_matches, (uint32_t)n_cand, (const uint64_t *)(dblk + o_co), A.slot_q, A.qt, (uint32_t)n_queries, d_ord + o_scr,
+                                             d_mo, d_ro, d_rmsd0, d_rot0, d_tran0, d_met0, A.residues, c->ws[WS_RS_REC].p, c->ws[WS_RS_RECRES].as<int32_t>(), st);
+                    e = hipGetLastError();
+                }
+                if (e == hipSuccess && nm) e = hipMemcpyAsync(om, c->ws[WS_RS_REC].p, nm * sizeof(fd_match_rec), hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess && tot_res) e = hipMemcpyAsync(orr, c->ws[WS_RS_RECRES].p, tot_res * 4, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(omo, d_mo, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(oro, d_ro, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e != hipSuccess) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); c->err = std::string("retrieve_batch records: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+                if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue: scan %.3f ms (found %llu, cands %llu), group+slots %.3f, superpose + records ordered on the device + copy (%llu records, %llu problems) %.3f\n",
+                                   t_ms(T0, D1), (unsigned long long)nf_d, (unsigned long long)nc_d, t_ms(D1, D2), (unsigned long long)nm, (unsigned long long)nprob, t_ms(D2, t_now()));
+                *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
+                return FDGPU_OK;
+            }
             std::vector<uint8_t> land_v;
             const size_t b_hm = std::max<uint64_t>(nm, 1) * sizeof(rs_match_dev);
             uint8_t *land = (uint8_t *)c->host_pinned(1, b_hm);

@@ -389,12 +389,13 @@ struct rs_query_dev {
     uint32_t q_res0;             // first residue of the query structure in the query batch
     uint32_t pad;
 };
-struct rs_match_dev { uint32_t slot, ci, same, res_pos, prob0, prob1; float idf; uint32_t pad; };
+struct rs_match_dev { uint32_t slot, ci, same, res_pos, prob0, prob1; float idf; uint32_t ord; };      // ord: the record's place among its slot's records (components ascend)
 struct rs_args {
     const fd_pair_rec *found; const fd_cand_rec *cands;
     const uint32_t *seg_f, *seg_c, *perm_f, *perm_c;     // per-slot segments of the (unordered) scan output
     const uint32_t *cand, *slot_q;                       // slot -> structure of the database batch, slot -> query
     const uint32_t *order;                               // launch order of the slots, heaviest first (k_rs_order; null: slot order)
+    uint32_t *slot_matches;                              // records every slot wrote (zeroed before the launch; null: not kept)
     const uint32_t *db_res_off; const float *db_ca, *db_cb, *q_ca, *q_cb;
     const rs_query_dev *qt;
     const uint32_t *hashes, *kfirst; const uint8_t *sym;
@@ -413,6 +414,11 @@ void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec
 void fd_launch_rs_slots(const rs_args &A, uint32_t n_cand, hipStream_t st);
 void fd_launch_rs_records(const void *matches, const void *plan, uint64_t n, const float *rmsd, const float *rot, const float *tran, const float *met,
                           const int32_t *residues, void *out, int32_t *out_res, hipStream_t st);
+// the same with the order made on the device: slot_matches -> per-slot bases, per-query offsets (match_off / res_off, n_queries + 1 each) -> every
+// source record gathered into its final place.  scratch: (2 * n_cand + 2) words
+void fd_launch_rs_records_dev(const void *matches, uint64_t n, const uint32_t *slot_matches, uint32_t n_cand, const uint64_t *cand_off, const uint32_t *slot_q,
+                              const rs_query_dev *qt, uint32_t n_queries, uint32_t *scratch, uint64_t *match_off, uint64_t *res_off, const float *rmsd,
+                              const float *rot, const float *tran, const float *met, const int32_t *residues, void *out, int32_t *out_res, hipStream_t st);
 int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
                          const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
                          fd_cand_rec **cands, uint64_t *n_cands, uint32_t mode = 3, const uint32_t *cj_mask = nullptr,

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     RS_SYNC();
     const float *q_ca = A.q_ca + 3ull * Q.q_res0, *q_cb = A.q_cb + 3ull * Q.q_res0;
     const float *t_ca = A.db_ca + 3ull * r0, *t_cb = A.db_cb + 3ull * r0;
+    uint32_t n_emit = 0;       // records this slot has written (their order among the slot's records: components ascend)
     for (uint32_t ci = 0; ci < n_comp; ++ci) {
         const uint64_t C = s_cs[ci];
         const uint32_t csize = (uint32_t)__popcll(C);
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
         if (lane == 0) {
             rs_match_dev m;
             m.slot = slot; m.ci = ci; m.same = same ? 1u : 0u; m.res_pos = (uint32_t)rp; m.prob0 = (uint32_t)p0; m.prob1 = same ? 0xffffffffu : (uint32_t)(p0 + 1);
-            m.idf = sub_idf; m.pad = 0;
+            m.idf = sub_idf; m.ord = n_emit;
             A.matches[mi] = m;
             A.koff[p0] = pt0; A.d0[p0] = A.d0tab[2u * n_asg];
             if (!same) { A.koff[p0 + 1] = pt0 + 2ull * n_asg; A.d0[p0 + 1] = A.d0tab[2u * n_sc]; }
@@ -401,8 +402,10 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
                 }
             }
         }
+        ++n_emit;
         RS_SYNC();
     }
+    if (lane == 0 && A.slot_matches) A.slot_matches[slot] = n_emit;
 }
 
 void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec *cands, uint64_t nc, uint32_t n_cand, uint32_t *cnt, uint32_t *seg, uint32_t *cur,
@@ -445,6 +448,81 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_records(const rs_match_dev *__re
     else if (lane < 39) v = __float_as_uint(met[5ull * pf + (lane - 34)]);
     if (lane < 39) out[39ull * k + lane] = v;
     for (uint32_t z = lane; z < pl.w; z += FD_WAVE) out_res[(uint64_t)pl.z + z] = residues[(uint64_t)r.res_pos + z];
+}
+// Final places of the records without the host: exclusive scan of the slots' record counts (base of every slot), the per-query offsets the
+// caller gets (match_off[t] = base of query t's first slot, res_off = running 2 * n_idx * records) and every slot's first output residue.
+__global__ __launch_bounds__(1024) void k_rs_offsets(const uint32_t *__restrict__ slot_matches, uint32_t n_cand, const uint64_t *__restrict__ cand_off,
+                                                     const uint32_t *__restrict__ slot_q, const rs_query_dev *__restrict__ qt, uint32_t n_queries,
+                                                     uint32_t *__restrict__ mbase, uint32_t *__restrict__ rbase, uint64_t *__restrict__ match_off, uint64_t *__restrict__ res_off) {
+    __shared__ unsigned long long part[1024];
+    const uint32_t tid = threadIdx.x;
+    {   // slots
+        const uint32_t per = (n_cand + 1023u) / 1024u, a = min(n_cand, tid * per), b = min(n_cand, a + per);
+        unsigned long long s = 0;
+        for (uint32_t k = a; k < b; ++k) s += slot_matches[k];
+        part[tid] = s;
+        __syncthreads();
+        if (tid == 0) { unsigned long long run = 0; for (int k = 0; k < 1024; ++k) { const unsigned long long t = part[k]; part[k] = run; run += t; } mbase[n_cand] = (uint32_t)run; }
+        __syncthreads();
+        uint32_t run = (uint32_t)part[tid];
+        for (uint32_t k = a; k < b; ++k) { mbase[k] = run; run += slot_matches[k]; }
+        __syncthreads();
+    }
+    __threadfence_block();
+    for (uint32_t t = tid; t <= n_queries; t += 1024) match_off[t] = mbase[cand_off[t]];
+    __syncthreads();
+    {   // queries: residue ints before each
+        const uint32_t per = (n_queries + 1023u) / 1024u, a = min(n_queries, tid * per), b = min(n_queries, a + per);
+        auto ints = [&](uint32_t t) { return (match_off[t + 1] - match_off[t]) * 2ull * qt[t].n_idx; };
+        unsigned long long s = 0;
+        for (uint32_t t = a; t < b; ++t) s += ints(t);
+        part[tid] = s;
+        __syncthreads();
+        if (tid == 0) { unsigned long long run = 0; for (int k = 0; k < 1024; ++k) { const unsigned long long t = part[k]; part[k] = run; run += t; } res_off[n_queries] = run; }
+        __syncthreads();
+        unsigned long long run = part[tid];
+        for (uint32_t t = a; t < b; ++t) { res_off[t] = run; run += ints(t); }
+        __syncthreads();
+    }
+    for (uint32_t k = tid; k < n_cand; k += 1024) {
+        const uint32_t q = slot_q[k];
+        rbase[k] = (uint32_t)(res_off[q] + (unsigned long long)(mbase[k] - (uint32_t)match_off[q]) * 2ull * qt[q].n_idx);
+    }
+}
+// one wavefront per SOURCE record: its place is base of its slot + its order inside the slot
+__global__ __launch_bounds__(FD_WAVE) void k_rs_records_dev(const rs_match_dev *__restrict__ m, const uint32_t *__restrict__ mbase, const uint32_t *__restrict__ rbase,
+                                                            const uint64_t *__restrict__ cand_off, const uint32_t *__restrict__ slot_q, const rs_query_dev *__restrict__ qt,
+                                                            const float *__restrict__ rmsd, const float *__restrict__ rot, const float *__restrict__ tran,
+                                                            const float *__restrict__ met, const int32_t *__restrict__ residues, uint32_t *__restrict__ out,
+                                                            int32_t *__restrict__ out_res) {
+    const uint32_t lane = threadIdx.x;
+    const rs_match_dev r = m[blockIdx.x];
+    const uint32_t q = slot_q[r.slot], nq2 = 2u * qt[q].n_idx;
+    const uint64_t k = (uint64_t)mbase[r.slot] + r.ord;
+    const uint64_t rpos = (uint64_t)rbase[r.slot] + (uint64_t)r.ord * nq2;
+    const uint32_t pf = r.prob0, po = r.same ? r.prob0 : r.prob1;
+    uint32_t v = 0;
+    if (lane == 0) v = r.slot - (uint32_t)cand_off[q];
+    else if (lane == 1) v = r.same;
+    else if (lane == 2) v = __float_as_uint(r.idf);
+    else if (lane == 3) v = __float_as_uint(rmsd[po]);
+    else if (lane == 4) v = __float_as_uint(rmsd[pf]);
+    else if (lane < 14) v = __float_as_uint(rot[9ull * po + (lane - 5)]);
+    else if (lane < 17) v = __float_as_uint(tran[3ull * po + (lane - 14)]);
+    else if (lane < 22) v = __float_as_uint(met[5ull * po + (lane - 17)]);
+    else if (lane < 31) v = __float_as_uint(rot[9ull * pf + (lane - 22)]);
+    else if (lane < 34) v = __float_as_uint(tran[3ull * pf + (lane - 31)]);
+    else if (lane < 39) v = __float_as_uint(met[5ull * pf + (lane - 34)]);
+    if (lane < 39) out[39ull * k + lane] = v;
+    for (uint32_t z = lane; z < nq2; z += FD_WAVE) out_res[rpos + z] = residues[(uint64_t)r.res_pos + z];
+}
+void fd_launch_rs_records_dev(const void *matches, uint64_t n, const uint32_t *slot_matches, uint32_t n_cand, const uint64_t *cand_off, const uint32_t *slot_q,
+                              const rs_query_dev *qt, uint32_t n_queries, uint32_t *scratch, uint64_t *match_off, uint64_t *res_off, const float *rmsd,
+                              const float *rot, const float *tran, const float *met, const int32_t *residues, void *out, int32_t *out_res, hipStream_t st) {
+    uint32_t *mbase = scratch, *rbase = scratch + n_cand + 1;
+    hipLaunchKernelGGL(k_rs_offsets, dim3(1), dim3(1024), 0, st, slot_matches, n_cand, cand_off, slot_q, qt, n_queries, mbase, rbase, match_off, res_off);
+    if (n) hipLaunchKernelGGL(k_rs_records_dev, dim3((unsigned)n), dim3(FD_WAVE), 0, st, (const rs_match_dev *)matches, mbase, rbase, cand_off, slot_q, qt, rmsd, rot, tran, met,
+                              residues, (uint32_t *)out, out_res);
 }
 void fd_launch_rs_records(const void *matches, const void *plan, uint64_t n, const float *rmsd, const float *rot, const float *tran, const float *met,
                           const int32_t *residues, void *out, int32_t *out_res, hipStream_t st) {

@@ -1149,6 +1149,14 @@ def test_device_retrieval_glue_equals_host_glue(env, monkeypatch):
         assert "retrieve_slots" in n_dev and "retrieve_slots" not in n_host
         for a, b, what in zip(dev, host, ("matches", "match_off", "residues", "res_off")):
             assert a.tobytes() == b.tobytes(), what
+        # the records' order made on the device (slot bases from record counts) against the host's sort of the record headers,
+        # and the slots launched heaviest first against slot order
+        for env_name, val in (("FDGPU_RS_HOST_ORDER", "1"), ("FDGPU_RS_ORDER", "0")):
+            monkeypatch.setenv(env_name, val)
+            alt, _ = run(db, stdn, cl, qms_, qb, qs, ca)
+            monkeypatch.delenv(env_name)
+            for a, b, what in zip(dev, alt, ("matches", "match_off", "residues", "res_off")):
+                assert a.tobytes() == b.tobytes(), (env_name, what)
         return dev
 
     for ca in (1.0, 1.5, 3.0):
