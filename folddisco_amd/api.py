@@ -418,10 +418,11 @@ def count_query(ctx: Context, index: FolddiscoIndex, q_hash, q_node, q_edge_j, p
                  edge_count=int(r["edge_count"]), idf=float(r["idf"])) for r in arr]
 
 
-def count_query_maps(ctx: Context, index: FolddiscoIndex, qms, penalty=None, total_structures: int | None = None, top_n: int = 0):
+def count_query_maps(ctx: Context, index: FolddiscoIndex, qms, penalty=None, total_structures: int | None = None, top_n: int = 0, flat: bool = False):
     """count_query_batch for the QueryMapResults of make_query_maps, handed to the library as they are (fdgpu_count_query_maps_top:
     posting lengths, idf = log2f(S / len) per hash and the scoring in one call; penalty=None uses FolddiscoIndex.set_penalty's
-    resident copy).  -> list of REC_DTYPE arrays like count_query_batch."""
+    resident copy).  -> list of REC_DTYPE arrays like count_query_batch; flat=True: (all records, offsets[T + 1]) — the library's two
+    output arrays as they are (per-query numpy slicing of a 128-query batch costs more host time than the library call's own host side)."""
     S = index.n_structures if total_structures is None else total_structures
     T = len(qms)
     handles = (C.c_void_p * max(T, 1))(*[C.cast(q.handle, C.c_void_p) for q in qms])
@@ -434,6 +435,8 @@ def count_query_maps(ctx: Context, index: FolddiscoIndex, qms, penalty=None, tot
     n = int(off[-1])
     arr = _lib.owned_view(ctx.L, out, n * 20, REC_DTYPE)         # the library's (pooled, page-locked) block itself, handed back when the views die
     ctx.L.fdgpu_free(ooff)
+    if flat:
+        return arr, off
     offs = off.tolist()
     return [arr[offs[t]: offs[t + 1]] for t in range(T)]
 

@@ -229,8 +229,11 @@ extern "C" int fdgpu_hash_features(fdgpu_ctx *c, const float *features, uint64_t
     return hash_features_q(c, features, n, fd_make_consts(p).q, hashes);
 }
 // internal form of fdgpu_pair_features: batch-wide residue indices, FD_QF floats per pair, every encoding
+// land_out != null: the features and flags stay in the context's page-locked block (*land_out = [n x FD_QF floats | n flags]) when it can be had
+// — features / valid are then untouched; else they are copied into features / valid
 static int pair_features12(fdgpu_ctx *c, const fdgpu_batch *b, const uint32_t *pi, const uint32_t *pj, uint64_t n, const fd_hash_params *p,
-                           float *features, uint8_t *valid) {
+                           float *features, uint8_t *valid, uint8_t **land_out = nullptr) {
+    if (land_out) *land_out = nullptr;
     if (!n) return FDGPU_OK;
     hipStream_t st = c->stream;
     HIPCHK(c, c->ws[WS_MISC0].ensure(n * 4));
@@ -242,15 +245,16 @@ static int pair_features12(fdgpu_ctx *c, const fdgpu_batch *b, const uint32_t *p
     hipLaunchKernelGGL(k_pair_features12, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, b->view(), c->ws[WS_MISC0].as<uint32_t>(),
                        c->ws[WS_MISC1].as<uint32_t>(), (uint32_t)n, p->dist_cutoff, p->hash_type, c->ws[WS_MISC2].as<float>(), c->ws[WS_MISC3].as<uint8_t>());
     HIPCHK(c, hipGetLastError());
-    uint8_t *land = (uint8_t *)c->host_pinned(2, n * 4 * FD_QF + n);      // page-locked landing block: the copies do not stage, one wait
+    // page-locked landing block (slot 4, read in place by the caller until its next call): the copies do not stage, one wait, no second copy
+    uint8_t *land = land_out ? (uint8_t *)c->host_pinned(4, n * 4 * FD_QF + n) : nullptr;
     if (land) {
         HIPCHK(c, hipMemcpyAsync(land, c->ws[WS_MISC2].p, n * 4 * FD_QF, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(land + n * 4 * FD_QF, c->ws[WS_MISC3].p, n, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
-        memcpy(features, land, n * 4 * FD_QF);
-        memcpy(valid, land + n * 4 * FD_QF, n);
+        *land_out = land;
         return FDGPU_OK;
     }
+    if (land_out) return FDGPU_OK;      // no page-locked block: the caller asks again with its own arrays
     HIPCHK(c, hipMemcpyAsync(features, c->ws[WS_MISC2].p, n * 4 * FD_QF, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(valid, c->ws[WS_MISC3].p, n, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -314,11 +318,23 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     }
     const uint64_t np = pi.size();
     if (qtrace) fprintf(stderr, "[fdgpu_query_map] pairs listed at %.3f ms\n", q_ms());
-    std::vector<float> feat(std::max<uint64_t>(np, 1) * FD_QF);
-    std::vector<uint8_t> valid(std::max<uint64_t>(np, 1));
+    std::vector<float> feat_v;
+    std::vector<uint8_t> valid_v;
     CHECK_TYPE(c, p);
-    int rc = pair_features12(c, qb, pi.data(), pj.data(), np, p, feat.data(), valid.data());
+    uint8_t *feat_land = nullptr;
+    feat_v.reserve(16); valid_v.reserve(16);
+    int rc = 0;
+    {
+        // try the landing block first; the vectors only when it cannot be had
+        rc = pair_features12(c, qb, pi.data(), pj.data(), np, p, nullptr, nullptr, &feat_land);
+        if (!rc && np && !feat_land) {
+            feat_v.resize(np * FD_QF); valid_v.resize(np);
+            rc = pair_features12(c, qb, pi.data(), pj.data(), np, p, feat_v.data(), valid_v.data());
+        }
+    }
     if (rc) return rc;
+    const float *feat = feat_land ? (const float *)feat_land : feat_v.data();
+    const uint8_t *valid = feat_land ? feat_land + np * 4 * FD_QF : valid_v.data();
     if (qtrace) fprintf(stderr, "[fdgpu_query_map] %llu pairs: features at %.3f ms\n", (unsigned long long)np, q_ms());
     const float RADS_PER_DEG = 3.14159274101257324f / 180.0f;  // f32::to_radians
     std::vector<float> athr(n_angle);
@@ -663,6 +679,9 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         m->n = n;
         m->hash = (uint32_t *)(blk + o_hash); m->qi = (uint32_t *)(blk + o_qi); m->qj = (uint32_t *)(blk + o_qj); m->idf = (float *)(blk + o_idf);
         m->primary_hash = (uint32_t *)(blk + o_ph); m->is_primary = blk + o_prim;
+        uint32_t *const o_hash_p = m->hash, *const o_qi_p = m->qi, *const o_qj_p = m->qj, *const o_ph_p = m->primary_hash;
+        uint8_t *const o_pr_p = m->is_primary;
+        float *const o_idf_p = m->idf;
         size_t w = 0;
         if (dev_expand && !n_cfg) {       // kept positions ascend: the pair a position belongs to advances with them (no division per entry)
             uint64_t v = c0 / dev_pp, v_end = (v + 1) * dev_pp;      // candidates of valid pair v: [v * dev_pp, v_end)
@@ -671,16 +690,16 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
                 const uint64_t z = c0 + pos;
                 while (z >= v_end) { ++v; v_end += dev_pp; }
                 const uint32_t k = vpairs[v];
-                m->hash[w] = hashes[z]; m->qi[w] = (uint32_t)(pi[k] - r0); m->qj[w] = (uint32_t)(pj[k] - r0); m->is_primary[w] = z + dev_pp == v_end ? 1 : 0;
-                m->idf[w] = pair_idf[k]; m->primary_hash[w] = pair_primary[k];
+                o_hash_p[w] = hashes[z]; o_qi_p[w] = (uint32_t)(pi[k] - r0); o_qj_p[w] = (uint32_t)(pj[k] - r0); o_pr_p[w] = z + dev_pp == v_end ? 1 : 0;
+                o_idf_p[w] = pair_idf[k]; o_ph_p[w] = pair_primary[k];
                 ++w;
             }
         } else
         for (uint32_t pos : keep) {
             const uint64_t z = c0 + pos / ncfg1;
             const cand_t cz = cand_at(z);
-            m->hash[w] = hash_at(pos); m->qi[w] = cz.qi; m->qj[w] = cz.qj; m->is_primary[w] = cz.primary;
-            m->idf[w] = pair_idf[cz.pair]; m->primary_hash[w] = pair_primary[cz.pair];
+            o_hash_p[w] = hash_at(pos); o_qi_p[w] = cz.qi; o_qj_p[w] = cz.qj; o_pr_p[w] = cz.primary;
+            o_idf_p[w] = pair_idf[cz.pair]; o_ph_p[w] = pair_primary[cz.pair];
             ++w;
         }
         if (with_post) {

@@ -177,7 +177,7 @@ extern "C" void fdgpu_destroy(fdgpu_ctx *c) {
     for (auto &b : c->pool) (void)hipFree(b.p);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (int k = 0; k < 8; ++k) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
-    for (int k = 0; k < 4; ++k) if (c->hbuf[k]) (void)hipHostFree(c->hbuf[k]);
+    for (int k = 0; k < 6; ++k) if (c->hbuf[k]) (void)hipHostFree(c->hbuf[k]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1202,16 +1202,24 @@ static bool fd_cq_rows(const uint32_t *q_hash, const uint32_t *q_node, const uin
         return q_node[x] != q_node[y] ? q_node[x] < q_node[y] : q_edge_j[x] < q_edge_j[y];
     });
     bool fits = true;
-    for (size_t z = 0; z < ord.size(); ++z) {
-        const uint64_t k = ord[z];
+    const size_t n = ord.size(), base = rows_hash.size();
+    rows_hash.resize(base + n); rows_meta.resize(base + n);
+    const bool with_k = q_kidx && rows_kidx;
+    if (with_k) rows_kidx->resize(base + n);
+    uint32_t *const oh = rows_hash.data() + base;
+    unsigned long long *const om = rows_meta.data() + base;
+    long long *const ok = with_k ? rows_kidx->data() + base : nullptr;
+    const uint64_t *const od = ord.data();
+    for (size_t z = 0; z < n; ++z) {
+        const uint64_t k = od[z];
         const uint64_t fix = fd_idf_fix(q_idf[k]);
         fits = fits && fix < (1ull << 27);
-        const bool last = z + 1 == ord.size();
-        const bool node_end = last || q_node[ord[z + 1]] != q_node[k];
-        const bool edge_end = node_end || q_edge_j[ord[z + 1]] != q_edge_j[k];
-        rows_hash.push_back(q_hash[k]);
-        if (q_kidx && rows_kidx) rows_kidx->push_back(q_kidx[k]);
-        rows_meta.push_back(((unsigned long long)fix << 2) | (node_end ? 2ull : 0ull) | (edge_end ? 1ull : 0ull));
+        const bool last = z + 1 == n;
+        const bool node_end = last || q_node[od[z + 1]] != q_node[k];
+        const bool edge_end = node_end || q_edge_j[od[z + 1]] != q_edge_j[k];
+        oh[z] = q_hash[k];
+        if (ok) ok[z] = q_kidx[k];
+        om[z] = ((unsigned long long)fix << 2) | (node_end ? 2ull : 0ull) | (edge_end ? 1ull : 0ull);
     }
     return fits;
 }
@@ -1508,9 +1516,12 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         // slices of roughly equal posting counts: a row's list holds ~ S / 2^idf ids (idf = log2(S / length), its fixed-point image is in the metadata)
         std::vector<double> w(nq);
         double tot = 0;
-        for (uint64_t r = 0; r < nq; ++r) {       // 2^-idf to a few percent: the integer part by ldexp, the fraction linearly
+        for (uint64_t r = 0; r < nq; ++r) {       // 2^-idf to a few percent: the integer part as an exponent field, the fraction linearly
             const unsigned long long fix = rows_meta[r] >> 2;
-            w[r] = ldexp(1.0 - 0.5 * (double)(fix & 4194303ull) / 4194304.0, -(int)(fix >> 22)) + 1e-7;
+            const uint64_t eb = (uint64_t)(1023 - (int)std::min<unsigned long long>(fix >> 22, 1000ull)) << 52;
+            double p2;
+            memcpy(&p2, &eb, 8);
+            w[r] = (1.0 - 0.5 * (double)(fix & 4194303ull) / 4194304.0) * p2 + 1e-7;
             tot += w[r];
         }
         big_sl.push_back(0);
@@ -1795,22 +1806,34 @@ int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_quer
     std::vector<float> qi;
     std::vector<long long> qk;
     std::vector<uint64_t> ql;       // the kept rows' posting lengths (local to this index only when the lengths are: the tiled path sizes its stream from them)
-    qh.reserve(nq); qn.reserve(nq); qe.reserve(nq); qi.reserve(nq); ql.reserve(nq);
-    if (kidx) qk.reserve(nq);
-    uint64_t at = 0;
+    // (filled through plain pointers: a whole-structure query is 10^5 rows, six push_backs each were a third of this loop)
+    qh.resize(nq + 1); qn.resize(nq + 1); qe.resize(nq + 1); qi.resize(nq + 1); ql.resize(nq + 1);
+    if (kidx) qk.resize(nq + 1);
+    uint32_t *const p_h = qh.data(), *const p_n = qn.data(), *const p_e = qe.data();
+    float *const p_i = qi.data();
+    uint64_t *const p_l = ql.data();
+    long long *const p_k = kidx ? qk.data() : nullptr;
+    uint64_t at = 0, w = 0;
     for (uint64_t t = 0; t < n_queries; ++t) {
         const fd_query_map *m = qms[t];
-        for (uint64_t k = 0; k < m->n; ++k, ++at) {
-            if (primary_len) m->idf[k] = primary_len[at] ? log2f(total_structures / (float)primary_len[at]) : 0.0f;
-            if (!len[at]) continue;
-            qh.push_back(m->hash[k]); qn.push_back(m->qi[k]); qe.push_back(m->qj[k]);
-            if (kidx) qk.push_back(kidx[at]);
-            ql.push_back(len[at]);
-            qi.push_back(log2f(total_structures / (float)len[at]));       // f32 like the reference's (total / len).log2()
+        const uint32_t *const mh = m->hash, *const mqi = m->qi, *const mqj = m->qj;
+        float *const midf = m->idf;
+        const uint64_t mn = m->n;
+        for (uint64_t k = 0; k < mn; ++k, ++at) {
+            if (primary_len) midf[k] = primary_len[at] ? log2f(total_structures / (float)primary_len[at]) : 0.0f;
+            const uint64_t L = len[at];
+            if (!L) continue;
+            p_h[w] = mh[k]; p_n[w] = mqi[k]; p_e[w] = mqj[k];
+            if (p_k) p_k[w] = kidx[at];
+            p_l[w] = L;
+            p_i[w] = log2f(total_structures / (float)L);       // f32 like the reference's (total / len).log2()
             if (seg) W += seg[at];
+            ++w;
         }
-        q_off[t + 1] = qh.size();
+        q_off[t + 1] = w;
     }
+    qh.resize(w); qn.resize(w); qe.resize(w); qi.resize(w); ql.resize(w);
+    if (kidx) qk.resize(w);
     if (qh.empty()) { qh.push_back(0); qn.push_back(0); qe.push_back(0); qi.push_back(0.0f); W = seg ? 0 : -1; qk.clear(); ql.clear(); }
     // (the lengths bound the LOCAL lists only when they are this index's own: the caller that passes kidx made the maps against it)
     return fd_count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off, allow_dense, dev, W,

@@ -60,8 +60,8 @@ struct fdgpu_ctx {
     // pinned staging of large device-to-host copies (fd_d2h_big in fdgpu_api.hip): FD_PIN_SLOTS buffers of FD_PIN_BYTES, made on first use
     // pinned host buffers that outlive a call (the packed candidate pairs of a whole-structure retrieval: 2 x ~100 MB per call — as
     // malloc'd blocks their first-touch page faults and their munmap cost more than the copy)
-    void *hbuf[4] = {nullptr, nullptr, nullptr, nullptr};      // 0, 1: retrieval; 2, 3: landing blocks of the query-map stage's small copies
-    size_t hbuf_cap[4] = {0, 0, 0, 0};
+    void *hbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // 0, 1: retrieval; 2, 3: landing / upload blocks of the query-map stage; 4: its pair features
+    size_t hbuf_cap[6] = {0, 0, 0, 0, 0, 0};
     void *host_pinned(int k, size_t bytes) {
         if (hbuf_cap[k] >= bytes) return hbuf[k];
         if (hbuf[k]) (void)hipHostFree(hbuf[k]);

@@ -176,16 +176,29 @@ def retrieve(ctx: Context, db: Batch, resname_std, cand, qm: QueryMapResult, qba
     ctx.check(ctx.L.fdgpu_retrieve(ctx.h, db.h, None if std is None else std.ctypes.data_as(u8p), cand.ctypes.data_as(u32p), len(cand),
                                    qm.handle, qbatch.h, C.byref(p), ca_distance_cutoff, node_count, int(bool(partial_fit)), C.byref(mp), C.byref(nm), C.byref(rp)))
     nq = len(qm.indices)
-    out = []
-    for k in range(nm.value):
-        r = mp[k]
-        base = 2 * nq * k
-        out.append(dict(cand=int(r.cand), idf=float(r.idf), rmsd=float(r.rmsd), rmsd_from_hash=float(r.rmsd_from_hash), same=bool(r.same),
-                        from_hash=[rp[base + z] for z in range(nq)], processed=[rp[base + nq + z] for z in range(nq)],
-                        rot=np.array(list(r.rot), np.float32).reshape(3, 3), tran=np.array(list(r.tran), np.float32),
-                        metrics=np.array(list(r.metrics), np.float32), rot_from_hash=np.array(list(r.rot_from_hash), np.float32).reshape(3, 3),
-                        tran_from_hash=np.array(list(r.tran_from_hash), np.float32), metrics_from_hash=np.array(list(r.metrics_from_hash), np.float32)))
+    n = int(nm.value)
+    out = _match_dicts(mp, rp, n, nq)
     ctx.L.fdgpu_matches_free(mp, rp)
+    return out
+
+
+def _match_dicts(mp, rp, n, nq, first=0, res_base=0):
+    """n match records from mp[first ..) with their 2 * nq residue ints each from rp[res_base ..) as the dicts retrieve() returns — through
+    numpy views of the two arrays (element-wise ctypes reads of a whole-structure query's 10^5 residue ints cost milliseconds)"""
+    if n == 0:
+        return []
+    assert C.sizeof(MatchRec) == MATCH_DTYPE.itemsize
+    recs = np.frombuffer((C.c_uint8 * ((first + n) * MATCH_DTYPE.itemsize)).from_address(C.addressof(mp.contents)), dtype=MATCH_DTYPE)[first:].copy()
+    res = (np.frombuffer((C.c_int32 * (res_base + 2 * nq * n)).from_address(C.addressof(rp.contents)), dtype=np.int32)[res_base:].reshape(n, 2, nq).tolist()
+           if nq else [[[], []] for _ in range(n)])
+    out = []
+    for k in range(n):
+        r = recs[k]
+        out.append(dict(cand=int(r["cand"]), idf=float(r["idf"]), rmsd=float(r["rmsd"]), rmsd_from_hash=float(r["rmsd_from_hash"]), same=bool(r["same"]),
+                        from_hash=res[k][0], processed=res[k][1],
+                        rot=r["rot"].reshape(3, 3).copy(), tran=r["tran"].copy(), metrics=r["metrics"].copy(),
+                        rot_from_hash=r["rot_from_hash"].reshape(3, 3).copy(), tran_from_hash=r["tran_from_hash"].copy(),
+                        metrics_from_hash=r["metrics_from_hash"].copy()))
     return out
 
 
@@ -270,14 +283,18 @@ MATCH_DTYPE = np.dtype([("cand", np.uint32), ("same", np.uint32), ("idf", np.flo
 def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Batch, q_structs, ca_distance_cutoff=1.0, node_count=2,
                    nbin_dist=0, nbin_angle=0, dist_cutoff=20.0, as_arrays=False, partial_fit=False, hash_type=3, multiple_bins=None):
     """retrieve() for many queries with one pair scan / gather / Kabsch launch in total (fdgpu_retrieve_batch).  cands[t]:
-    candidate structure indices of query t, qms[t] its QueryMapResult, q_structs[t] its structure in qbatch.
+    candidate structure indices of query t (a list of arrays, or one [T, n] array), qms[t] its QueryMapResult, q_structs[t] its structure in qbatch.
     -> list (per query) of lists of match dicts like retrieve(); with as_arrays=True the raw tables instead:
     (matches MATCH_DTYPE[], match_off u64[T+1], residues int32[], res_off u64[T+1]) — 2 * len(qms[t].indices) residue indices
     per match (from-hash mapping, then processed mapping)."""
     T = len(qms)
-    cl = [np.ascontiguousarray(c, dtype=np.uint32) for c in cands]
-    cand_off = np.concatenate([[0], np.cumsum([len(c) for c in cl])]).astype(np.uint64)
-    cand = np.ascontiguousarray(np.concatenate(cl) if cl else np.zeros(0, np.uint32))
+    if isinstance(cands, np.ndarray) and cands.ndim == 2:       # [T, n] candidates per query as one array (no per-query list handling)
+        cand = np.ascontiguousarray(cands, dtype=np.uint32).reshape(-1)
+        cand_off = (np.arange(T + 1, dtype=np.uint64) * np.uint64(cands.shape[1]))
+    else:
+        cl = [np.ascontiguousarray(c, dtype=np.uint32) for c in cands]
+        cand_off = np.concatenate([[0], np.cumsum([len(c) for c in cl])]).astype(np.uint64)
+        cand = np.ascontiguousarray(np.concatenate(cl) if cl else np.zeros(0, np.uint32))
     std = None if resname_std is None else np.ascontiguousarray(resname_std, np.uint8)
     qs = np.ascontiguousarray(q_structs, np.uint32)
     handles = (C.POINTER(QueryMap) * max(T, 1))(*[q.handle for q in qms])
@@ -299,18 +316,7 @@ def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Bat
         return marr, moff, rarr, roff
     out = []
     for t in range(T):
-        nq = len(qms[t].indices)
-        lst = []
-        for k in range(int(mo[t]), int(mo[t + 1])):
-            r = mp[k]
-            base = int(ro[t]) + 2 * nq * (k - int(mo[t]))
-            lst.append(dict(cand=int(r.cand), idf=float(r.idf), rmsd=float(r.rmsd), rmsd_from_hash=float(r.rmsd_from_hash), same=bool(r.same),
-                            from_hash=[rp[base + z] for z in range(nq)], processed=[rp[base + nq + z] for z in range(nq)],
-                            rot=np.array(list(r.rot), np.float32).reshape(3, 3), tran=np.array(list(r.tran), np.float32),
-                            metrics=np.array(list(r.metrics), np.float32), rot_from_hash=np.array(list(r.rot_from_hash), np.float32).reshape(3, 3),
-                            tran_from_hash=np.array(list(r.tran_from_hash), np.float32),
-                            metrics_from_hash=np.array(list(r.metrics_from_hash), np.float32)))
-        out.append(lst)
+        out.append(_match_dicts(mp, rp, int(mo[t + 1]) - int(mo[t]), len(qms[t].indices), int(mo[t]), int(ro[t])))
     ctx.L.fdgpu_matches_free(mp, rp)
     ctx.L.fdgpu_free(mo)
     ctx.L.fdgpu_free(ro)

@@ -110,6 +110,14 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         marr = retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0]
         return len(fdist.allgather_array(marr, dev))
 
+    def top_cands(recs, off, n):
+        """[T, n] candidate structures = the first n records of every query's ranking, straight from the library's flat output
+        (None when a query has fewer than n records: the caller takes the per-query path)"""
+        if len(off) < 2 or int((off[1:] - off[:-1]).min()) < n:
+            return None
+        c = recs["nid"][(off[:-1, None] + np.arange(n, dtype=np.uint64)[None, :]).astype(np.int64)]
+        return c - np.uint32(first) if first else c
+
     def owned(glob, n):
         """candidate slots (local structure indices) of the first n records of the global ranking that this rank owns"""
         nid = glob["nid"][:n].astype(np.int64)
@@ -168,15 +176,17 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                 if sharded:     # the same fused entry points as the single-index leg, with the exchange in between
                     globs = sharded_prefilter(qms)
                 else:           # the query maps go back into the library as they are; the penalty is resident (set_penalty)
-                    globs = count_query_maps(ctx, ix, qms, None, total_structures=S_total, top_n=top_n)
+                    recs, off = count_query_maps(ctx, ix, qms, None, total_structures=S_total, top_n=top_n, flat=True)
                 if match:   # one pair scan / gather / Kabsch launch for the whole chunk of queries
                     if sharded:
                         tot += sharded_matches(globs, qms, ks)
-                    else:
-                        cl = [owned(g, match_top) for g in globs]
+                    else:       # one rank owns every structure: the candidates are the first match_top records of every ranking
+                        cl = top_cands(recs, off, match_top)
+                        if cl is None:
+                            cl = [recs["nid"][int(off[t]): int(off[t]) + min(match_top, int(off[t + 1] - off[t]))] - np.uint32(first) for t in range(len(qms))]
                         tot += len(retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0])
                 else:
-                    tot += sum(len(g) for g in globs)
+                    tot += sum(len(g) for g in globs) if sharded else len(recs)
             return tot
         go()
         if reps > 1:       # the headline leg: the median of several passes (a pass over 128 queries is a few milliseconds)
@@ -200,8 +210,10 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             for c0 in starts[w::workers]:
                 ks = range(c0, min(c0 + chunk, len(queries)))
                 qms = make_query_maps(cx, qall, [(k, queries[k][1]) for k in ks], ix, float(S_total))
-                recs = count_query_maps(cx, ix, qms, None, total_structures=S_total, top_n=top_n)
-                cl = [owned(g, match_top) for g in recs]
+                recs, off = count_query_maps(cx, ix, qms, None, total_structures=S_total, top_n=top_n, flat=True)
+                cl = top_cands(recs, off, match_top)
+                if cl is None:
+                    cl = [recs["nid"][int(off[t]): int(off[t]) + min(match_top, int(off[t + 1] - off[t]))] - np.uint32(first) for t in range(len(qms))]
                 tot += len(retrieve_batch(cx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0])
                 del qms
             cx.synchronize()
