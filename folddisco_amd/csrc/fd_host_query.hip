@@ -811,27 +811,24 @@ __global__ __launch_bounds__(256) void k_gather_xyz(const float *__restrict__ ca
     }
 }
 
-// retrieval_wrapper for MANY queries: one pair scan, one coordinate gather and one Kabsch launch in total.  Query t = structure
-// q_struct[t] of qb with the query map qms[t]; its candidates are cand[cand_off[t] .. cand_off[t+1]).  Matches of query t:
-// (*matches)[(*match_off)[t] .. (*match_off)[t+1]) (cand = slot inside the query's own candidate list), residues
-// (*residues)[(*res_off)[t] ...], 2 * n_indices(t) per match.
-extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand,
-                                    const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
-                                    const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches,
-                                    uint64_t **match_off, int32_t **residues, uint64_t **res_off) { FD_LOCK(c);
-    if (!c || !db || !qb || !p || !matches || !match_off || !residues || !res_off || !cand_off || (n_queries && (!qms || !q_struct))) return FDGPU_EINVAL;
-    *matches = nullptr; *match_off = nullptr; *residues = nullptr; *res_off = nullptr;
-    const uint64_t n_cand = cand_off[n_queries];
-    for (uint64_t t = 0; t < n_queries; ++t) if (!qms[t] || q_struct[t] >= qb->n_struct) return FDGPU_EINVAL;
-    const bool trace = getenv("FDGPU_TRACE") != nullptr;
-    auto t_now = [] { return std::chrono::steady_clock::now(); };
-    auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    auto T0 = t_now();
+// What a retrieval needs from the query maps alone — no candidates, no scan output: per query the sorted unique hashes + the map entry each one
+// resolves to (the FIRST entry holding it, like the reference's hash map), the pair scan's query descriptors, sizes.  A caller that knows the
+// maps before it knows the candidates (fdgpu_query_batch: the scoring kernels are still running) builds it ahead of time.
+struct fd_rb_prep {
+    std::vector<std::vector<uint32_t>> qhs, qkf;
+    std::vector<fd_match_query> mqs;
+    std::vector<uint32_t> q_sizes;
+    uint64_t max_aad = 0, max_nq = 0;
+};
+static void fd_rb_prepare(uint64_t n_queries, const fd_query_map *const *qms, float ca_distance_cutoff, fd_rb_prep &P) {
+    std::vector<std::vector<uint32_t>> &qhs = P.qhs, &qkf = P.qkf;
+    std::vector<fd_match_query> &mqs = P.mqs;
+    std::vector<uint32_t> &q_sizes = P.q_sizes;
+    qhs.assign(n_queries, {}); qkf.assign(n_queries, {});
+    mqs.assign(std::max<uint64_t>(n_queries, 1), fd_match_query{});
+    q_sizes.assign(std::max<uint64_t>(n_queries, 1), 1);
     // per query: sorted unique hashes + the map entry each one resolves to (the FIRST entry holding it, like the reference's hash map):
     // (hash << 32 | entry) keys through an LSD radix sort — a whole-structure query has 10^5 entries, a hash map cost 8 ms here
-    std::vector<std::vector<uint32_t>> qhs(n_queries), qkf(n_queries);
-    std::vector<fd_match_query> mqs(std::max<uint64_t>(n_queries, 1));
-    std::vector<uint32_t> q_sizes(std::max<uint64_t>(n_queries, 1), 1);
     for (uint64_t t = 0; t < n_queries; ++t) {
         const fd_query_map *m = qms[t];
         uint64_t key_small[256];          // a motif query's few dozen entries stay off the heap (two allocations per query, 128 queries per batch)
@@ -861,27 +858,14 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         q.ca_distance_cutoff = ca_distance_cutoff;
         q.use_aa_prefilter = qhs[t].size() <= 200 ? 1 : 0;  // PREFILTER_AA_SKIPPING_SIZE (retrieve.rs:24, 569)
     }
-    fd_pair_rec *found = nullptr; fd_cand_rec *cands = nullptr;
-    uint64_t nf = 0, nc = 0;
-    // Candidate pairs (the rescue's raw material, retrieve.rs:120-121) number ~ pairs x observed-list entries: a whole-structure
-    // query makes millions per candidate structure.  Large queries therefore scan twice: found triples only, then — once the
-    // components and their residue mappings are known — candidate pairs only for partner residues some component mapped
-    // (the rescue counts nothing else, retrieve.rs:498-511).
-    uint64_t max_aad = 0;
-    for (uint64_t t = 0; t < n_queries; ++t) max_aad = std::max<uint64_t>(max_aad, qms[t]->n_aad);
-    const char *tp_env = getenv("FDGPU_TWO_PASS");     // 1 / 0 force the choice (tests)
-    const bool two_pass = tp_env ? tp_env[0] == '1' : max_aad > 4096;
-    uint32_t *pk_key = nullptr, *pk_val = nullptr;      // packed, device-sorted candidate pairs (see fd_match_pairs_multi, mode bit 3): context-owned pinned buffers
-    struct HostBufs {   // the scan outputs live until the slots are processed; every return path below releases them
-        fd_pair_rec *&f; fd_cand_rec *&c; uint32_t *&k, *&v;
-        ~HostBufs() { free(f); free(c); k = nullptr; v = nullptr; }      // k / v: the context's pinned buffers, not ours to free
-    } host_bufs{found, cands, pk_key, pk_val};
-    int rc = 0;
-    // symmetry flags (geometry/pdb_tr.rs:158-162): aa equal and atan2(sin, cos) of the two torsion fields equal; the other encodings
-    // compare their residue fields and (Folddisco*) torsion fields (pdb_motif.rs:98, pdb_motif_sincos.rs:105, folddisco_angle.rs:133,
-    // folddisco_dist.rs:126)
-    const uint32_t htype = p->hash_type;
-    auto is_sym = [htype](uint32_t h) {
+    P.max_aad = 0; P.max_nq = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) { P.max_aad = std::max<uint64_t>(P.max_aad, qms[t]->n_aad); P.max_nq = std::max<uint64_t>(P.max_nq, qms[t]->n_indices); }
+}
+
+// symmetry flags (geometry/pdb_tr.rs:158-162): aa equal and atan2(sin, cos) of the two torsion fields equal; the other encodings
+// compare their residue fields and (Folddisco*) torsion fields (pdb_motif.rs:98, pdb_motif_sincos.rs:105, folddisco_angle.rs:133,
+// folddisco_dist.rs:126)
+static bool fd_hash_is_sym(uint32_t htype, uint32_t h) {
         const float D2 = 57.2957795130823208767981548141051703f;
         auto c3 = [](uint32_t v, float nb) { float cf = (1.0f - (-1.0f)) / (nb - 1.0f); return (float)v * cf + (-1.0f); };
         if (htype == FD_HASH_TERTIARY) return false;                                   // tertiary_interaction.rs:145-150
@@ -912,251 +896,326 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
         const float D = 57.2957795130823208767981548141051703f;
         float p1 = atan2f(cont((h >> 6) & 3), cont((h >> 4) & 3)) * D, p2 = atan2f(cont((h >> 2) & 3), cont(h & 3)) * D;
         return ((h >> 25) & 31u) == ((h >> 20) & 31u) && p1 == p2;
+}
+
+// ---- device glue (k_retrieve.hip): the scan output never leaves the GPU — per-slot grouping, graph / components / votes /
+// assignment / rescue one wavefront per candidate, superposition and metrics on the problems it wrote, then ONE copy of the match
+// records back.  Taken for motif-sized queries (<= 64 query residues, single scan, no --partial-fit); a candidate beyond the
+// kernel's limits (64 graph nodes, 1024 found triples) raises a flag and the whole call takes the host path below instead.
+// -> FDGPU_OK with *done = true and the outputs set; *done = false: the kernel declined (the caller takes the host path).
+static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand, const uint64_t *cand_off,
+                             const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct, const fd_hash_params *p, uint32_t node_count,
+                             const fd_rb_prep &P, std::chrono::steady_clock::time_point T0, fd_match_rec **matches, uint64_t **match_off, int32_t **residues,
+                             uint64_t **res_off, bool *done) {
+    *done = false;
+    const bool trace = getenv("FDGPU_TRACE") != nullptr;
+    auto t_now = [] { return std::chrono::steady_clock::now(); };
+    auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const uint64_t n_cand = cand_off[n_queries], max_nq = P.max_nq;
+    const std::vector<std::vector<uint32_t>> &qhs = P.qhs, &qkf = P.qkf;
+    const std::vector<uint32_t> &q_sizes = P.q_sizes;
+    const uint32_t htype = p->hash_type;
+    auto is_sym = [htype](uint32_t h) { return fd_hash_is_sym(htype, h); };
+    int rc = 0;
+    uint64_t nf_d = 0, nc_d = 0;
+    fd_pair_rec *f_none = nullptr; fd_cand_rec *c_none = nullptr;
+    hipStream_t st = c->stream;
+    // tables: one packed host block -> one copy.  Built WHILE the pair scan runs (it needs none of the scan's output): the scan's launch
+    // is followed by ~0.4 ms of kernel per 128 queries that the host used to wait out before starting on this
+    std::vector<rs_query_dev> qt(n_queries);
+    std::vector<uint32_t> t_hash, t_kfirst, t_sym, t_qi, t_qj, t_idf, t_idx;
+    size_t o_qt = 0, o_h = 0, o_kf = 0, o_sy = 0, o_qi = 0, o_qj = 0, o_idf = 0, o_idx = 0, o_sq = 0, o_cd = 0, o_d0 = 0, o_co = 0, words = 0;
+    std::vector<uint32_t> blk_v;
+    uint32_t *blk = nullptr;
+    const std::function<void()> build_rs_tables = [&]() {
+    {
+        size_t th = 0, tm = 0, ti = 0;
+        for (uint64_t t = 0; t < n_queries; ++t) { th += qhs[t].size(); tm += qms[t]->n; ti += qms[t]->n_indices; }
+        t_hash.reserve(th); t_kfirst.reserve(th); t_sym.reserve(th); t_qi.reserve(tm); t_qj.reserve(tm); t_idf.reserve(tm); t_idx.reserve(ti);
+    }
+    for (uint64_t t = 0; t < n_queries; ++t) {
+        const fd_query_map *m = qms[t];
+        rs_query_dev &Q = qt[t];
+        memset(&Q, 0, sizeof Q);
+        Q.qh_off = (uint32_t)t_hash.size(); Q.n_hashes = (uint32_t)qhs[t].size();
+        t_hash.insert(t_hash.end(), qhs[t].begin(), qhs[t].end());
+        t_kfirst.insert(t_kfirst.end(), qkf[t].begin(), qkf[t].end());
+        for (size_t z = 0; z < qhs[t].size(); ++z) t_sym.push_back(is_sym(qhs[t][z]) ? 1u : 0u);
+        Q.map_off = (uint32_t)t_qi.size();
+        t_qi.insert(t_qi.end(), m->qi, m->qi + m->n);
+        t_qj.insert(t_qj.end(), m->qj, m->qj + m->n);
+        t_idf.resize(t_idf.size() + m->n);
+        if (m->n) memcpy(t_idf.data() + t_idf.size() - m->n, m->idf, m->n * 4);
+        Q.idx_off = (uint32_t)t_idx.size(); Q.n_idx = (uint32_t)m->n_indices;
+        t_idx.insert(t_idx.end(), m->indices, m->indices + m->n_indices);
+        Q.q_size = q_sizes[t];
+        Q.q_res0 = (uint32_t)qb->h_res_off[q_struct[t]];
+    }
+    std::vector<uint32_t> t_slotq(n_cand);
+    for (uint64_t t = 0; t < n_queries; ++t) for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) t_slotq[k] = (uint32_t)t;
+    float d0tab[2 * FD_WAVE + 1];
+    for (int len = 0; len <= 2 * FD_WAVE; ++len) d0tab[len] = len > 21 ? 1.24f * powf((float)len - 15.0f, 1.0f / 3.0f) - 1.8f : 0.5f;   // metrics.rs:117-123
+    auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
+    const size_t nh = t_hash.size(), nmap = t_qi.size(), nidx = t_idx.size();
+    o_qt = 0; o_h = o_qt + up4(n_queries * (sizeof(rs_query_dev) / 4)); o_kf = o_h + up4(nh); o_sy = o_kf + up4(nh); o_qi = o_sy + up4((nh + 3) / 4);
+    o_qj = o_qi + up4(nmap); o_idf = o_qj + up4(nmap); o_idx = o_idf + up4(nmap); o_sq = o_idx + up4(nidx); o_cd = o_sq + up4(n_cand);
+    o_d0 = o_cd + up4(n_cand); o_co = o_d0 + up4(2 * FD_WAVE + 1); words = o_co + up4(2 * (n_queries + 1)) + 4;
+    // packed in a pinned staging buffer of the context (its own: the pair scan's block in slot 0 is being copied while this runs)
+    blk = (uint32_t *)c->host_pinned(2, words * 4);
+    if (!blk) { blk_v.assign(words, 0); blk = blk_v.data(); }
+    memcpy(&blk[o_qt], qt.data(), n_queries * sizeof(rs_query_dev));
+    if (nh) { memcpy(&blk[o_h], t_hash.data(), nh * 4); memcpy(&blk[o_kf], t_kfirst.data(), nh * 4); }
+    for (size_t k = 0; k < nh; ++k) ((uint8_t *)&blk[o_sy])[k] = (uint8_t)t_sym[k];
+    if (nmap) { memcpy(&blk[o_qi], t_qi.data(), nmap * 4); memcpy(&blk[o_qj], t_qj.data(), nmap * 4); memcpy(&blk[o_idf], t_idf.data(), nmap * 4); }
+    if (nidx) memcpy(&blk[o_idx], t_idx.data(), nidx * 4);
+    memcpy(&blk[o_sq], t_slotq.data(), n_cand * 4);
+    memcpy(&blk[o_cd], cand, n_cand * 4);
+    memcpy(&blk[o_d0], d0tab, sizeof d0tab);
+    memcpy(&blk[o_co], cand_off, (n_queries + 1) * 8);      // (o_co is a multiple of 4 words: 8-byte aligned)
     };
-    // ---- device glue (k_retrieve.hip): the scan output never leaves the GPU — per-slot grouping, graph / components / votes /
-    // assignment / rescue one wavefront per candidate, superposition and metrics on the problems it wrote, then ONE copy of the match
-    // records back.  Taken for motif-sized queries (<= 64 query residues, single scan, no --partial-fit); a candidate beyond the
-    // kernel's limits (64 graph nodes, 1024 found triples) raises a flag and the whole call takes the host path below instead.
+    rc = fd_match_pairs_multi(c, db, resname_std, n_queries, P.mqs.data(), cand, cand_off, p, &f_none, &nf_d, &c_none, &nc_d, 19u, nullptr, nullptr, 0, nullptr, nullptr,
+                              nullptr, nullptr, &build_rs_tables);
+    if (rc) return rc;
+    if (!blk) build_rs_tables();
+    auto D1 = t_now();
+    const uint64_t cap_m = std::max<uint64_t>(4096, 4 * n_cand), cap_prob = 2 * cap_m, cap_res = cap_m * 2 * max_nq,
+                   cap_pts = cap_prob * 2 * max_nq;       // a mapping holds at most one target per query residue: <= 2 max_nq [CA, CB] points
+    HIPCHK(c, c->ws[WS_RS_TAB].ensure(words * 4));
+    HIPCHK(c, c->ws[WS_RS_SEG].ensure((6 * (n_cand + 1) + nf_d + nc_d + 4) * 4));
+    HIPCHK(c, c->ws[WS_RS_OUT].ensure(cap_m * sizeof(rs_match_dev)));
+    HIPCHK(c, c->ws[WS_RS_RES].ensure(cap_res * 4));
+    HIPCHK(c, c->ws[WS_RS_KX].ensure(cap_pts * 12));
+    HIPCHK(c, c->ws[WS_RS_KY].ensure(cap_pts * 12));
+    HIPCHK(c, c->ws[WS_RS_KOFF].ensure((cap_prob + 1) * 8 + cap_prob * 4));
+    HIPCHK(c, c->ws[WS_RS_SOL].ensure(cap_prob * 18 * 4));
+    HIPCHK(c, c->ws[WS_RS_CNT].ensure(64));
+    // [records per slot | slot bases + first residues (2 n_cand + 2) | match_off, res_off (n_queries + 1 each, 8-byte)] for the device-side ordering
+    const size_t o_sm = 0, o_scr = o_sm + ((n_cand + 1) & ~(size_t)1), o_mo = (o_scr + 2 * n_cand + 2 + 1) & ~(size_t)1, o_ro = o_mo + 2 * (n_queries + 1),
+                 ord_words = o_ro + 2 * (n_queries + 1);
+    HIPCHK(c, c->ws[WS_RS_PLAN].ensure(ord_words * 4));
+    uint32_t *d_ord = c->ws[WS_RS_PLAN].as<uint32_t>();
+    HIPCHK(c, hipMemsetAsync(d_ord + o_sm, 0, n_cand * 4, st));
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_RS_TAB].p, blk, words * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_RS_CNT].p, 0, 64, st));
+    const uint32_t *dblk = c->ws[WS_RS_TAB].as<uint32_t>();
+    uint32_t *sg = c->ws[WS_RS_SEG].as<uint32_t>();
+    uint32_t *d_cnt = sg, *d_seg = sg + 2 * (n_cand + 1), *d_cur = sg + 4 * (n_cand + 1), *d_pf = sg + 6 * (n_cand + 1), *d_pc = d_pf + nf_d;
+    const fd_pair_rec *d_found = c->ws[WS_KEYS_A].as<fd_pair_rec>();
+    const fd_cand_rec *d_cands = c->ws[WS_KEYS_B].as<fd_cand_rec>();
+    fd_launch_rs_group(d_found, nf_d, d_cands, nc_d, (uint32_t)n_cand, d_cnt, d_seg, d_cur, d_pf, d_pc, st);
+    rs_args A;
+    memset(&A, 0, sizeof A);
+    A.found = d_found; A.cands = d_cands; A.seg_f = d_seg; A.seg_c = d_seg + (n_cand + 1); A.perm_f = d_pf; A.perm_c = d_pc;
+    A.cand = dblk + o_cd; A.slot_q = dblk + o_sq;
+    A.slot_matches = d_ord + o_sm;
+    A.order = getenv("FDGPU_RS_ORDER") && getenv("FDGPU_RS_ORDER")[0] == '0' ? nullptr : d_cur;      // 0: slot order (measurement)
+    A.db_res_off = db->res_off; A.db_ca = db->ca_xyz; A.db_cb = db->cb_xyz; A.q_ca = qb->ca_xyz; A.q_cb = qb->cb_xyz;
+    A.qt = (const rs_query_dev *)(dblk + o_qt); A.hashes = dblk + o_h; A.kfirst = dblk + o_kf; A.sym = (const uint8_t *)(dblk + o_sy);
+    A.map_qi = dblk + o_qi; A.map_qj = dblk + o_qj; A.map_idf = (const float *)(dblk + o_idf); A.indices = dblk + o_idx;
+    A.d0tab = (const float *)(dblk + o_d0); A.node_count = node_count;
+    { const char *nc_env = getenv("FDGPU_RS_NODE_CAP"); const long v = nc_env ? atol(nc_env) : 0; A.node_cap = v > 0 && v < FD_WAVE ? (uint32_t)v : FD_WAVE; }
+    A.counters = c->ws[WS_RS_CNT].as<unsigned long long>(); A.flags = (uint32_t *)(A.counters + 4);
+    A.matches = c->ws[WS_RS_OUT].as<rs_match_dev>(); A.residues = c->ws[WS_RS_RES].as<int32_t>();
+    A.kx = c->ws[WS_RS_KX].as<float>(); A.ky = c->ws[WS_RS_KY].as<float>();
+    A.koff = c->ws[WS_RS_KOFF].as<uint64_t>(); A.d0 = (float *)(A.koff + cap_prob + 1);
+    A.cap_matches = cap_m; A.cap_res = cap_res; A.cap_prob = cap_prob; A.cap_pts = cap_pts;
+    {
+        StageTimer tm(c, "retrieve_slots", 0);
+        fd_launch_rs_slots(A, (uint32_t)n_cand, st);
+    }
+    HIPCHK(c, hipGetLastError());
+    unsigned long long cnt_h[5] = {0, 0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(cnt_h, c->ws[WS_RS_CNT].p, 40, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const uint32_t dflags = (uint32_t)cnt_h[4];
+    auto D2 = t_now();
+    if (dflags == 0) {
+        const uint64_t nm = cnt_h[0], nprob = cnt_h[1] >> 40, npts = cnt_h[1] & ((1ull << 40) - 1ull);
+        // the 32-byte match headers come back for the ordering; the records themselves (fd_match_rec: 39 words from the solution arrays)
+        // and the residue lists are gathered on the device in their final order (k_rs_records) and copied straight into the caller's
+        // page-locked arrays — the host loop over 23 k records of a 512-query batch (8 scattered reads + 232 bytes written each) was
+        // 1.6-2.3 ms of the call
+        float *d_rmsd0 = c->ws[WS_RS_SOL].as<float>();
+        const char *ho_env = getenv("FDGPU_RS_HOST_ORDER");       // 1: the records are ordered on the host from their headers (tests compare the two)
+        if (!(ho_env && ho_env[0] == '1')) {
+            // the records' final places are computed on the device (k_rs_offsets: bases of the slots from their record counts; a record's
+            // place inside its slot was fixed when it was written) — no header copy, no host sort, no gather plan: after the counters above
+            // nothing but the finished arrays crosses the bus, with one wait
+            const uint64_t tot_res = cnt_h[2];
+            if (tot_res >= (1ull << 32)) { c->err = "retrieve_batch: residue lists beyond 2^32 entries; split the batch"; return FDGPU_ERANGE; }
+            float *d_rot0 = d_rmsd0 + nprob, *d_tran0 = d_rot0 + 9 * nprob, *d_met0 = d_tran0 + 3 * nprob;
+            uint64_t *omo = (uint64_t *)malloc((n_queries + 1) * 8), *oro = (uint64_t *)malloc((n_queries + 1) * 8);
+            fd_match_rec *om = (fd_match_rec *)fd_out_alloc(std::max<size_t>(nm, 1) * sizeof(fd_match_rec), true);
+            int32_t *orr = (int32_t *)fd_out_alloc(std::max<size_t>(tot_res, 1) * sizeof(int32_t), true);
+            if (!omo || !oro || !om || !orr) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
+            hipError_t e = c->ws[WS_RS_REC].ensure(std::max<uint64_t>(nm, 1) * sizeof(fd_match_rec));
+            if (e == hipSuccess) e = c->ws[WS_RS_RECRES].ensure(std::max<uint64_t>(tot_res, 1) * 4);
+            if (e == hipSuccess && nprob) {
+                e = hipMemcpyAsync(A.koff + nprob, &npts, 8, hipMemcpyHostToDevice, st);
+                fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd0, d_rot0, d_tran0, st);
+                fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot0, d_tran0, A.d0, d_met0, st);
+            }
+            uint64_t *d_mo = (uint64_t *)(d_ord + o_mo), *d_ro = (uint64_t *)(d_ord + o_ro);
+            if (e == hipSuccess) {
+                fd_launch_rs_records_dev(A.matches, nm, A.slot_matches, (uint32_t)n_cand, (const uint64_t *)(dblk + o_co), A.slot_q, A.qt, (uint32_t)n_queries, d_ord + o_scr,
+                                         d_mo, d_ro, d_rmsd0, d_rot0, d_tran0, d_met0, A.residues, c->ws[WS_RS_REC].p, c->ws[WS_RS_RECRES].as<int32_t>(), st);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess && nm) e = hipMemcpyAsync(om, c->ws[WS_RS_REC].p, nm * sizeof(fd_match_rec), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && tot_res) e = hipMemcpyAsync(orr, c->ws[WS_RS_RECRES].p, tot_res * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(omo, d_mo, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(oro, d_ro, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); c->err = std::string("retrieve_batch records: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+            if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue: scan %.3f ms (found %llu, cands %llu), group+slots %.3f, superpose + records ordered on the device + copy (%llu records, %llu problems) %.3f\n",
+                               t_ms(T0, D1), (unsigned long long)nf_d, (unsigned long long)nc_d, t_ms(D1, D2), (unsigned long long)nm, (unsigned long long)nprob, t_ms(D2, t_now()));
+            *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
+            *done = true;
+            return FDGPU_OK;
+        }
+        std::vector<uint8_t> land_v;
+        const size_t b_hm = std::max<uint64_t>(nm, 1) * sizeof(rs_match_dev);
+        uint8_t *land = (uint8_t *)c->host_pinned(1, b_hm);
+        if (!land) { land_v.resize(b_hm); land = land_v.data(); }
+        rs_match_dev *hm = (rs_match_dev *)land;
+        float *d_rmsd = c->ws[WS_RS_SOL].as<float>(), *d_rot = d_rmsd + nprob, *d_tran = d_rot + 9 * nprob, *d_met = d_tran + 3 * nprob;
+        if (nprob) {
+            HIPCHK(c, hipMemcpyAsync(A.koff + nprob, &npts, 8, hipMemcpyHostToDevice, st));
+            fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd, d_rot, d_tran, st);
+            fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot, d_tran, A.d0, d_met, st);
+            HIPCHK(c, hipGetLastError());
+        }
+        if (nm) {
+            HIPCHK(c, hipMemcpyAsync(hm, A.matches, nm * sizeof(rs_match_dev), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+        }
+        const auto E1 = t_now();
+        // the records arrive in append order: into (slot, component) order by a counting sort over the slots and a sort of every slot's few
+        // records (a comparison sort of all 45 k records of a 512-query batch was 3 of the stage's 3.7 ms)
+        std::vector<uint32_t> order(nm);
+        {
+            std::vector<uint32_t> at(n_cand + 2, 0);
+            bool in_range = true;
+            for (uint64_t k = 0; k < nm; ++k) { if (hm[k].slot < n_cand) ++at[hm[k].slot + 1]; else in_range = false; }
+            if (in_range) {
+                for (uint64_t z = 0; z < n_cand; ++z) at[z + 1] += at[z];
+                std::vector<uint32_t> cur(at.begin(), at.end() - 1);
+                for (uint64_t k = 0; k < nm; ++k) order[cur[hm[k].slot]++] = (uint32_t)k;
+                for (uint64_t z = 0; z < n_cand; ++z)
+                    if (at[z + 1] - at[z] > 1)
+                        std::sort(order.begin() + at[z], order.begin() + at[z + 1], [&](uint32_t a, uint32_t b) { return hm[a].ci < hm[b].ci; });
+            } else {
+                for (uint64_t k = 0; k < nm; ++k) order[k] = (uint32_t)k;
+                std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hm[a].slot != hm[b].slot ? hm[a].slot < hm[b].slot : hm[a].ci < hm[b].ci; });
+            }
+        }
+        const auto E2 = t_now();
+        // the gather plan per output record and the per-query offsets
+        uint64_t *omo = (uint64_t *)malloc((n_queries + 1) * 8), *oro = (uint64_t *)malloc((n_queries + 1) * 8);
+        if (!omo || !oro) { free(omo); free(oro); return FDGPU_ENOMEM; }
+        std::vector<uint32_t> plan_v;
+        uint32_t *plan = (uint32_t *)c->host_pinned(0, std::max<uint64_t>(nm, 1) * 16);
+        if (!plan) { plan_v.resize(std::max<uint64_t>(nm, 1) * 4); plan = plan_v.data(); }
+        uint64_t tq = 0, rpos = 0;
+        omo[0] = 0; oro[0] = 0;
+        for (uint64_t k = 0; k < nm; ++k) {
+            const rs_match_dev &m = hm[order[k]];
+            while (m.slot >= cand_off[tq + 1]) { ++tq; omo[tq] = k; oro[tq] = rpos; }
+            const uint64_t nq2 = 2 * qms[tq]->n_indices;
+            plan[4 * k] = order[k]; plan[4 * k + 1] = (uint32_t)(m.slot - cand_off[tq]); plan[4 * k + 2] = (uint32_t)rpos; plan[4 * k + 3] = (uint32_t)nq2;
+            rpos += nq2;
+        }
+        while (tq < n_queries) { ++tq; omo[tq] = nm; oro[tq] = rpos; }
+        const uint64_t tot_res = rpos;
+        if (tot_res >= (1ull << 32)) { free(omo); free(oro); c->err = "retrieve_batch: residue lists beyond 2^32 entries; split the batch"; return FDGPU_ERANGE; }
+        fd_match_rec *om = (fd_match_rec *)fd_out_alloc(std::max<size_t>(nm, 1) * sizeof(fd_match_rec), true);
+        int32_t *orr = (int32_t *)fd_out_alloc(std::max<size_t>(tot_res, 1) * sizeof(int32_t), true);
+        if (!om || !orr) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
+        const auto E3 = t_now();
+        if (nm) {
+            hipError_t e = c->ws[WS_RS_PLAN].ensure(nm * 16);
+            if (e == hipSuccess) e = c->ws[WS_RS_REC].ensure(nm * sizeof(fd_match_rec));
+            if (e == hipSuccess) e = c->ws[WS_RS_RECRES].ensure(std::max<uint64_t>(tot_res, 1) * 4);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->ws[WS_RS_PLAN].p, plan, nm * 16, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) {
+                fd_launch_rs_records(A.matches, c->ws[WS_RS_PLAN].p, nm, d_rmsd, d_rot, d_tran, d_met, A.residues, c->ws[WS_RS_REC].p, c->ws[WS_RS_RECRES].as<int32_t>(), st);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(om, c->ws[WS_RS_REC].p, nm * sizeof(fd_match_rec), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && tot_res) e = hipMemcpyAsync(orr, c->ws[WS_RS_RECRES].p, tot_res * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); c->err = std::string("retrieve_batch records: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+        }
+        if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue: scan %.3f ms (found %llu, cands %llu), group+slots %.3f, superpose+copy+assemble(%llu) %.3f (superpose + headers %.3f, order %.3f, plan %.3f, records %.3f)\n",
+                           t_ms(T0, D1), (unsigned long long)nf_d, (unsigned long long)nc_d, t_ms(D1, D2), (unsigned long long)nprob, t_ms(D2, t_now()), t_ms(D2, E1), t_ms(E1, E2),
+                           t_ms(E2, E3), t_ms(E3, t_now()));
+        *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
+        *done = true;
+        return FDGPU_OK;
+    }
+    if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue declined (flags %u): host path\n", dflags);
+    return FDGPU_OK;
+}
+
+// retrieval_wrapper for MANY queries: one pair scan, one coordinate gather and one Kabsch launch in total.  Query t = structure
+// q_struct[t] of qb with the query map qms[t]; its candidates are cand[cand_off[t] .. cand_off[t+1]).  Matches of query t:
+// (*matches)[(*match_off)[t] .. (*match_off)[t+1]) (cand = slot inside the query's own candidate list), residues
+// (*residues)[(*res_off)[t] ...], 2 * n_indices(t) per match.
+static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand,
+                                  const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
+                                  const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches,
+                                  uint64_t **match_off, int32_t **residues, uint64_t **res_off, const fd_rb_prep *prep);
+extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand,
+                                    const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
+                                    const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches,
+                                    uint64_t **match_off, int32_t **residues, uint64_t **res_off) { FD_LOCK(c);
+    return fd_retrieve_batch_impl(c, db, resname_std, n_queries, cand, cand_off, qms, qb, q_struct, p, ca_distance_cutoff, node_count, partial_fit, matches, match_off,
+                                  residues, res_off, nullptr);
+}
+// prep: the maps' tables when the caller has built them already (fd_rb_prepare with the same maps and ca_distance_cutoff), else null
+static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand,
+                                  const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
+                                  const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches,
+                                  uint64_t **match_off, int32_t **residues, uint64_t **res_off, const fd_rb_prep *prep) { FD_LOCK(c);
+    if (!c || !db || !qb || !p || !matches || !match_off || !residues || !res_off || !cand_off || (n_queries && (!qms || !q_struct))) return FDGPU_EINVAL;
+    *matches = nullptr; *match_off = nullptr; *residues = nullptr; *res_off = nullptr;
+    const uint64_t n_cand = cand_off[n_queries];
+    for (uint64_t t = 0; t < n_queries; ++t) if (!qms[t] || q_struct[t] >= qb->n_struct) return FDGPU_EINVAL;
+    const bool trace = getenv("FDGPU_TRACE") != nullptr;
+    auto t_now = [] { return std::chrono::steady_clock::now(); };
+    auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto T0 = t_now();
+    fd_rb_prep prep_own;
+    if (!prep) { fd_rb_prepare(n_queries, qms, ca_distance_cutoff, prep_own); prep = &prep_own; }
+    const std::vector<std::vector<uint32_t>> &qhs = prep->qhs, &qkf = prep->qkf;
+    const std::vector<fd_match_query> &mqs = prep->mqs;
+    const std::vector<uint32_t> &q_sizes = prep->q_sizes;
+    fd_pair_rec *found = nullptr; fd_cand_rec *cands = nullptr;
+    uint64_t nf = 0, nc = 0;
+    // Candidate pairs (the rescue's raw material, retrieve.rs:120-121) number ~ pairs x observed-list entries: a whole-structure
+    // query makes millions per candidate structure.  Large queries therefore scan twice: found triples only, then — once the
+    // components and their residue mappings are known — candidate pairs only for partner residues some component mapped
+    // (the rescue counts nothing else, retrieve.rs:498-511).
+    uint64_t max_aad = 0;
+    for (uint64_t t = 0; t < n_queries; ++t) max_aad = std::max<uint64_t>(max_aad, qms[t]->n_aad);
+    const char *tp_env = getenv("FDGPU_TWO_PASS");     // 1 / 0 force the choice (tests)
+    const bool two_pass = tp_env ? tp_env[0] == '1' : max_aad > 4096;
+    uint32_t *pk_key = nullptr, *pk_val = nullptr;      // packed, device-sorted candidate pairs (see fd_match_pairs_multi, mode bit 3): context-owned pinned buffers
+    struct HostBufs {   // the scan outputs live until the slots are processed; every return path below releases them
+        fd_pair_rec *&f; fd_cand_rec *&c; uint32_t *&k, *&v;
+        ~HostBufs() { free(f); free(c); k = nullptr; v = nullptr; }      // k / v: the context's pinned buffers, not ours to free
+    } host_bufs{found, cands, pk_key, pk_val};
+    int rc = 0;
+    const uint32_t htype = p->hash_type;
+    auto is_sym = [htype](uint32_t h) { return fd_hash_is_sym(htype, h); };
     uint64_t max_nq = 0;
     for (uint64_t t = 0; t < n_queries; ++t) max_nq = std::max<uint64_t>(max_nq, qms[t]->n_indices);
     const char *hg_env = getenv("FDGPU_HOST_GLUE");      // 1 forces the host path (tests compare the two)
     const bool dev_glue = !(hg_env && hg_env[0] == '1') && !two_pass && !partial_fit && max_nq <= FD_WAVE && max_nq > 0 && n_cand > 0 && n_cand < (1ull << 20);
     if (dev_glue) {
-        uint64_t nf_d = 0, nc_d = 0;
-        fd_pair_rec *f_none = nullptr; fd_cand_rec *c_none = nullptr;
-        hipStream_t st = c->stream;
-        // tables: one packed host block -> one copy.  Built WHILE the pair scan runs (it needs none of the scan's output): the scan's launch
-        // is followed by ~0.4 ms of kernel per 128 queries that the host used to wait out before starting on this
-        std::vector<rs_query_dev> qt(n_queries);
-        std::vector<uint32_t> t_hash, t_kfirst, t_sym, t_qi, t_qj, t_idf, t_idx;
-        size_t o_qt = 0, o_h = 0, o_kf = 0, o_sy = 0, o_qi = 0, o_qj = 0, o_idf = 0, o_idx = 0, o_sq = 0, o_cd = 0, o_d0 = 0, o_co = 0, words = 0;
-        std::vector<uint32_t> blk_v;
-        uint32_t *blk = nullptr;
-        const std::function<void()> build_rs_tables = [&]() {
-        {
-            size_t th = 0, tm = 0, ti = 0;
-            for (uint64_t t = 0; t < n_queries; ++t) { th += qhs[t].size(); tm += qms[t]->n; ti += qms[t]->n_indices; }
-            t_hash.reserve(th); t_kfirst.reserve(th); t_sym.reserve(th); t_qi.reserve(tm); t_qj.reserve(tm); t_idf.reserve(tm); t_idx.reserve(ti);
-        }
-        for (uint64_t t = 0; t < n_queries; ++t) {
-            const fd_query_map *m = qms[t];
-            rs_query_dev &Q = qt[t];
-            memset(&Q, 0, sizeof Q);
-            Q.qh_off = (uint32_t)t_hash.size(); Q.n_hashes = (uint32_t)qhs[t].size();
-            t_hash.insert(t_hash.end(), qhs[t].begin(), qhs[t].end());
-            t_kfirst.insert(t_kfirst.end(), qkf[t].begin(), qkf[t].end());
-            for (size_t z = 0; z < qhs[t].size(); ++z) t_sym.push_back(is_sym(qhs[t][z]) ? 1u : 0u);
-            Q.map_off = (uint32_t)t_qi.size();
-            t_qi.insert(t_qi.end(), m->qi, m->qi + m->n);
-            t_qj.insert(t_qj.end(), m->qj, m->qj + m->n);
-            t_idf.resize(t_idf.size() + m->n);
-            if (m->n) memcpy(t_idf.data() + t_idf.size() - m->n, m->idf, m->n * 4);
-            Q.idx_off = (uint32_t)t_idx.size(); Q.n_idx = (uint32_t)m->n_indices;
-            t_idx.insert(t_idx.end(), m->indices, m->indices + m->n_indices);
-            Q.q_size = q_sizes[t];
-            Q.q_res0 = (uint32_t)qb->h_res_off[q_struct[t]];
-        }
-        std::vector<uint32_t> t_slotq(n_cand);
-        for (uint64_t t = 0; t < n_queries; ++t) for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) t_slotq[k] = (uint32_t)t;
-        float d0tab[2 * FD_WAVE + 1];
-        for (int len = 0; len <= 2 * FD_WAVE; ++len) d0tab[len] = len > 21 ? 1.24f * powf((float)len - 15.0f, 1.0f / 3.0f) - 1.8f : 0.5f;   // metrics.rs:117-123
-        auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
-        const size_t nh = t_hash.size(), nmap = t_qi.size(), nidx = t_idx.size();
-        o_qt = 0; o_h = o_qt + up4(n_queries * (sizeof(rs_query_dev) / 4)); o_kf = o_h + up4(nh); o_sy = o_kf + up4(nh); o_qi = o_sy + up4((nh + 3) / 4);
-        o_qj = o_qi + up4(nmap); o_idf = o_qj + up4(nmap); o_idx = o_idf + up4(nmap); o_sq = o_idx + up4(nidx); o_cd = o_sq + up4(n_cand);
-        o_d0 = o_cd + up4(n_cand); o_co = o_d0 + up4(2 * FD_WAVE + 1); words = o_co + up4(2 * (n_queries + 1)) + 4;
-        // packed in a pinned staging buffer of the context (its own: the pair scan's block in slot 0 is being copied while this runs)
-        blk = (uint32_t *)c->host_pinned(2, words * 4);
-        if (!blk) { blk_v.assign(words, 0); blk = blk_v.data(); }
-        memcpy(&blk[o_qt], qt.data(), n_queries * sizeof(rs_query_dev));
-        if (nh) { memcpy(&blk[o_h], t_hash.data(), nh * 4); memcpy(&blk[o_kf], t_kfirst.data(), nh * 4); }
-        for (size_t k = 0; k < nh; ++k) ((uint8_t *)&blk[o_sy])[k] = (uint8_t)t_sym[k];
-        if (nmap) { memcpy(&blk[o_qi], t_qi.data(), nmap * 4); memcpy(&blk[o_qj], t_qj.data(), nmap * 4); memcpy(&blk[o_idf], t_idf.data(), nmap * 4); }
-        if (nidx) memcpy(&blk[o_idx], t_idx.data(), nidx * 4);
-        memcpy(&blk[o_sq], t_slotq.data(), n_cand * 4);
-        memcpy(&blk[o_cd], cand, n_cand * 4);
-        memcpy(&blk[o_d0], d0tab, sizeof d0tab);
-        memcpy(&blk[o_co], cand_off, (n_queries + 1) * 8);      // (o_co is a multiple of 4 words: 8-byte aligned)
-        };
-        rc = fd_match_pairs_multi(c, db, resname_std, n_queries, mqs.data(), cand, cand_off, p, &f_none, &nf_d, &c_none, &nc_d, 19u, nullptr, nullptr, 0, nullptr, nullptr,
-                                  nullptr, nullptr, &build_rs_tables);
-        if (rc) return rc;
-        if (!blk) build_rs_tables();
-        auto D1 = t_now();
-        const uint64_t cap_m = std::max<uint64_t>(4096, 4 * n_cand), cap_prob = 2 * cap_m, cap_res = cap_m * 2 * max_nq,
-                       cap_pts = cap_prob * 2 * max_nq;       // a mapping holds at most one target per query residue: <= 2 max_nq [CA, CB] points
-        HIPCHK(c, c->ws[WS_RS_TAB].ensure(words * 4));
-        HIPCHK(c, c->ws[WS_RS_SEG].ensure((6 * (n_cand + 1) + nf_d + nc_d + 4) * 4));
-        HIPCHK(c, c->ws[WS_RS_OUT].ensure(cap_m * sizeof(rs_match_dev)));
-        HIPCHK(c, c->ws[WS_RS_RES].ensure(cap_res * 4));
-        HIPCHK(c, c->ws[WS_RS_KX].ensure(cap_pts * 12));
-        HIPCHK(c, c->ws[WS_RS_KY].ensure(cap_pts * 12));
-        HIPCHK(c, c->ws[WS_RS_KOFF].ensure((cap_prob + 1) * 8 + cap_prob * 4));
-        HIPCHK(c, c->ws[WS_RS_SOL].ensure(cap_prob * 18 * 4));
-        HIPCHK(c, c->ws[WS_RS_CNT].ensure(64));
-        // [records per slot | slot bases + first residues (2 n_cand + 2) | match_off, res_off (n_queries + 1 each, 8-byte)] for the device-side ordering
-        const size_t o_sm = 0, o_scr = o_sm + ((n_cand + 1) & ~(size_t)1), o_mo = (o_scr + 2 * n_cand + 2 + 1) & ~(size_t)1, o_ro = o_mo + 2 * (n_queries + 1),
-                     ord_words = o_ro + 2 * (n_queries + 1);
-        HIPCHK(c, c->ws[WS_RS_PLAN].ensure(ord_words * 4));
-        uint32_t *d_ord = c->ws[WS_RS_PLAN].as<uint32_t>();
-        HIPCHK(c, hipMemsetAsync(d_ord + o_sm, 0, n_cand * 4, st));
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_RS_TAB].p, blk, words * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemsetAsync(c->ws[WS_RS_CNT].p, 0, 64, st));
-        const uint32_t *dblk = c->ws[WS_RS_TAB].as<uint32_t>();
-        uint32_t *sg = c->ws[WS_RS_SEG].as<uint32_t>();
-        uint32_t *d_cnt = sg, *d_seg = sg + 2 * (n_cand + 1), *d_cur = sg + 4 * (n_cand + 1), *d_pf = sg + 6 * (n_cand + 1), *d_pc = d_pf + nf_d;
-        const fd_pair_rec *d_found = c->ws[WS_KEYS_A].as<fd_pair_rec>();
-        const fd_cand_rec *d_cands = c->ws[WS_KEYS_B].as<fd_cand_rec>();
-        fd_launch_rs_group(d_found, nf_d, d_cands, nc_d, (uint32_t)n_cand, d_cnt, d_seg, d_cur, d_pf, d_pc, st);
-        rs_args A;
-        memset(&A, 0, sizeof A);
-        A.found = d_found; A.cands = d_cands; A.seg_f = d_seg; A.seg_c = d_seg + (n_cand + 1); A.perm_f = d_pf; A.perm_c = d_pc;
-        A.cand = dblk + o_cd; A.slot_q = dblk + o_sq;
-        A.slot_matches = d_ord + o_sm;
-        A.order = getenv("FDGPU_RS_ORDER") && getenv("FDGPU_RS_ORDER")[0] == '0' ? nullptr : d_cur;      // 0: slot order (measurement)
-        A.db_res_off = db->res_off; A.db_ca = db->ca_xyz; A.db_cb = db->cb_xyz; A.q_ca = qb->ca_xyz; A.q_cb = qb->cb_xyz;
-        A.qt = (const rs_query_dev *)(dblk + o_qt); A.hashes = dblk + o_h; A.kfirst = dblk + o_kf; A.sym = (const uint8_t *)(dblk + o_sy);
-        A.map_qi = dblk + o_qi; A.map_qj = dblk + o_qj; A.map_idf = (const float *)(dblk + o_idf); A.indices = dblk + o_idx;
-        A.d0tab = (const float *)(dblk + o_d0); A.node_count = node_count;
-        { const char *nc_env = getenv("FDGPU_RS_NODE_CAP"); const long v = nc_env ? atol(nc_env) : 0; A.node_cap = v > 0 && v < FD_WAVE ? (uint32_t)v : FD_WAVE; }
-        A.counters = c->ws[WS_RS_CNT].as<unsigned long long>(); A.flags = (uint32_t *)(A.counters + 4);
-        A.matches = c->ws[WS_RS_OUT].as<rs_match_dev>(); A.residues = c->ws[WS_RS_RES].as<int32_t>();
-        A.kx = c->ws[WS_RS_KX].as<float>(); A.ky = c->ws[WS_RS_KY].as<float>();
-        A.koff = c->ws[WS_RS_KOFF].as<uint64_t>(); A.d0 = (float *)(A.koff + cap_prob + 1);
-        A.cap_matches = cap_m; A.cap_res = cap_res; A.cap_prob = cap_prob; A.cap_pts = cap_pts;
-        {
-            StageTimer tm(c, "retrieve_slots", 0);
-            fd_launch_rs_slots(A, (uint32_t)n_cand, st);
-        }
-        HIPCHK(c, hipGetLastError());
-        unsigned long long cnt_h[5] = {0, 0, 0, 0, 0};
-        HIPCHK(c, hipMemcpyAsync(cnt_h, c->ws[WS_RS_CNT].p, 40, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        const uint32_t dflags = (uint32_t)cnt_h[4];
-        auto D2 = t_now();
-        if (dflags == 0) {
-            const uint64_t nm = cnt_h[0], nprob = cnt_h[1] >> 40, npts = cnt_h[1] & ((1ull << 40) - 1ull);
-            // the 32-byte match headers come back for the ordering; the records themselves (fd_match_rec: 39 words from the solution arrays)
-            // and the residue lists are gathered on the device in their final order (k_rs_records) and copied straight into the caller's
-            // page-locked arrays — the host loop over 23 k records of a 512-query batch (8 scattered reads + 232 bytes written each) was
-            // 1.6-2.3 ms of the call
-            float *d_rmsd0 = c->ws[WS_RS_SOL].as<float>();
-            const char *ho_env = getenv("FDGPU_RS_HOST_ORDER");       // 1: the records are ordered on the host from their headers (tests compare the two)
-            if (!(ho_env && ho_env[0] == '1')) {
-                // the records' final places are computed on the device (k_rs_offsets: bases of the slots from their record counts; a record's
-                // place inside its slot was fixed when it was written) — no header copy, no host sort, no gather plan: after the counters above
-                // nothing but the finished arrays crosses the bus, with one wait
-                const uint64_t tot_res = cnt_h[2];
-                if (tot_res >= (1ull << 32)) { c->err = "retrieve_batch: residue lists beyond 2^32 entries; split the batch"; return FDGPU_ERANGE; }
-                float *d_rot0 = d_rmsd0 + nprob, *d_tran0 = d_rot0 + 9 * nprob, *d_met0 = d_tran0 + 3 * nprob;
-                uint64_t *omo = (uint64_t *)malloc((n_queries + 1) * 8), *oro = (uint64_t *)malloc((n_queries + 1) * 8);
-                fd_match_rec *om = (fd_match_rec *)fd_out_alloc(std::max<size_t>(nm, 1) * sizeof(fd_match_rec), true);
-                int32_t *orr = (int32_t *)fd_out_alloc(std::max<size_t>(tot_res, 1) * sizeof(int32_t), true);
-                if (!omo || !oro || !om || !orr) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
-                hipError_t e = c->ws[WS_RS_REC].ensure(std::max<uint64_t>(nm, 1) * sizeof(fd_match_rec));
-                if (e == hipSuccess) e = c->ws[WS_RS_RECRES].ensure(std::max<uint64_t>(tot_res, 1) * 4);
-                if (e == hipSuccess && nprob) {
-                    e = hipMemcpyAsync(A.koff + nprob, &npts, 8, hipMemcpyHostToDevice, st);
-                    fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd0, d_rot0, d_tran0, st);
-                    fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot0, d_tran0, A.d0, d_met0, st);
-                }
-                uint64_t *d_mo = (uint64_t *)(d_ord + o_mo), *d_ro = (uint64_t *)(d_ord + o_ro);
-                if (e == hipSuccess) {
-                    fd_launch_rs_records_dev(A.matches, nm, A.slot_matches, (uint32_t)n_cand, (const uint64_t *)(dblk + o_co), A.slot_q, A.qt, (uint32_t)n_queries, d_ord + o_scr,
-                                             d_mo, d_ro, d_rmsd0, d_rot0, d_tran0, d_met0, A.residues, c->ws[WS_RS_REC].p, c->ws[WS_RS_RECRES].as<int32_t>(), st);
-                    e = hipGetLastError();
-                }
-                if (e == hipSuccess && nm) e = hipMemcpyAsync(om, c->ws[WS_RS_REC].p, nm * sizeof(fd_match_rec), hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess && tot_res) e = hipMemcpyAsync(orr, c->ws[WS_RS_RECRES].p, tot_res * 4, hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess) e = hipMemcpyAsync(omo, d_mo, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess) e = hipMemcpyAsync(oro, d_ro, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess) e = hipStreamSynchronize(st);
-                if (e != hipSuccess) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); c->err = std::string("retrieve_batch records: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-                if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue: scan %.3f ms (found %llu, cands %llu), group+slots %.3f, superpose + records ordered on the device + copy (%llu records, %llu problems) %.3f\n",
-                                   t_ms(T0, D1), (unsigned long long)nf_d, (unsigned long long)nc_d, t_ms(D1, D2), (unsigned long long)nm, (unsigned long long)nprob, t_ms(D2, t_now()));
-                *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
-                return FDGPU_OK;
-            }
-            std::vector<uint8_t> land_v;
-            const size_t b_hm = std::max<uint64_t>(nm, 1) * sizeof(rs_match_dev);
-            uint8_t *land = (uint8_t *)c->host_pinned(1, b_hm);
-            if (!land) { land_v.resize(b_hm); land = land_v.data(); }
-            rs_match_dev *hm = (rs_match_dev *)land;
-            float *d_rmsd = c->ws[WS_RS_SOL].as<float>(), *d_rot = d_rmsd + nprob, *d_tran = d_rot + 9 * nprob, *d_met = d_tran + 3 * nprob;
-            if (nprob) {
-                HIPCHK(c, hipMemcpyAsync(A.koff + nprob, &npts, 8, hipMemcpyHostToDevice, st));
-                fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd, d_rot, d_tran, st);
-                fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot, d_tran, A.d0, d_met, st);
-                HIPCHK(c, hipGetLastError());
-            }
-            if (nm) {
-                HIPCHK(c, hipMemcpyAsync(hm, A.matches, nm * sizeof(rs_match_dev), hipMemcpyDeviceToHost, st));
-                HIPCHK(c, hipStreamSynchronize(st));
-            }
-            const auto E1 = t_now();
-            // the records arrive in append order: into (slot, component) order by a counting sort over the slots and a sort of every slot's few
-            // records (a comparison sort of all 45 k records of a 512-query batch was 3 of the stage's 3.7 ms)
-            std::vector<uint32_t> order(nm);
-            {
-                std::vector<uint32_t> at(n_cand + 2, 0);
-                bool in_range = true;
-                for (uint64_t k = 0; k < nm; ++k) { if (hm[k].slot < n_cand) ++at[hm[k].slot + 1]; else in_range = false; }
-                if (in_range) {
-                    for (uint64_t z = 0; z < n_cand; ++z) at[z + 1] += at[z];
-                    std::vector<uint32_t> cur(at.begin(), at.end() - 1);
-                    for (uint64_t k = 0; k < nm; ++k) order[cur[hm[k].slot]++] = (uint32_t)k;
-                    for (uint64_t z = 0; z < n_cand; ++z)
-                        if (at[z + 1] - at[z] > 1)
-                            std::sort(order.begin() + at[z], order.begin() + at[z + 1], [&](uint32_t a, uint32_t b) { return hm[a].ci < hm[b].ci; });
-                } else {
-                    for (uint64_t k = 0; k < nm; ++k) order[k] = (uint32_t)k;
-                    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hm[a].slot != hm[b].slot ? hm[a].slot < hm[b].slot : hm[a].ci < hm[b].ci; });
-                }
-            }
-            const auto E2 = t_now();
-            // the gather plan per output record and the per-query offsets
-            uint64_t *omo = (uint64_t *)malloc((n_queries + 1) * 8), *oro = (uint64_t *)malloc((n_queries + 1) * 8);
-            if (!omo || !oro) { free(omo); free(oro); return FDGPU_ENOMEM; }
-            std::vector<uint32_t> plan_v;
-            uint32_t *plan = (uint32_t *)c->host_pinned(0, std::max<uint64_t>(nm, 1) * 16);
-            if (!plan) { plan_v.resize(std::max<uint64_t>(nm, 1) * 4); plan = plan_v.data(); }
-            uint64_t tq = 0, rpos = 0;
-            omo[0] = 0; oro[0] = 0;
-            for (uint64_t k = 0; k < nm; ++k) {
-                const rs_match_dev &m = hm[order[k]];
-                while (m.slot >= cand_off[tq + 1]) { ++tq; omo[tq] = k; oro[tq] = rpos; }
-                const uint64_t nq2 = 2 * qms[tq]->n_indices;
-                plan[4 * k] = order[k]; plan[4 * k + 1] = (uint32_t)(m.slot - cand_off[tq]); plan[4 * k + 2] = (uint32_t)rpos; plan[4 * k + 3] = (uint32_t)nq2;
-                rpos += nq2;
-            }
-            while (tq < n_queries) { ++tq; omo[tq] = nm; oro[tq] = rpos; }
-            const uint64_t tot_res = rpos;
-            if (tot_res >= (1ull << 32)) { free(omo); free(oro); c->err = "retrieve_batch: residue lists beyond 2^32 entries; split the batch"; return FDGPU_ERANGE; }
-            fd_match_rec *om = (fd_match_rec *)fd_out_alloc(std::max<size_t>(nm, 1) * sizeof(fd_match_rec), true);
-            int32_t *orr = (int32_t *)fd_out_alloc(std::max<size_t>(tot_res, 1) * sizeof(int32_t), true);
-            if (!om || !orr) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
-            const auto E3 = t_now();
-            if (nm) {
-                hipError_t e = c->ws[WS_RS_PLAN].ensure(nm * 16);
-                if (e == hipSuccess) e = c->ws[WS_RS_REC].ensure(nm * sizeof(fd_match_rec));
-                if (e == hipSuccess) e = c->ws[WS_RS_RECRES].ensure(std::max<uint64_t>(tot_res, 1) * 4);
-                if (e == hipSuccess) e = hipMemcpyAsync(c->ws[WS_RS_PLAN].p, plan, nm * 16, hipMemcpyHostToDevice, st);
-                if (e == hipSuccess) {
-                    fd_launch_rs_records(A.matches, c->ws[WS_RS_PLAN].p, nm, d_rmsd, d_rot, d_tran, d_met, A.residues, c->ws[WS_RS_REC].p, c->ws[WS_RS_RECRES].as<int32_t>(), st);
-                    e = hipGetLastError();
-                }
-                if (e == hipSuccess) e = hipMemcpyAsync(om, c->ws[WS_RS_REC].p, nm * sizeof(fd_match_rec), hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess && tot_res) e = hipMemcpyAsync(orr, c->ws[WS_RS_RECRES].p, tot_res * 4, hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess) e = hipStreamSynchronize(st);
-                if (e != hipSuccess) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); c->err = std::string("retrieve_batch records: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-            }
-            if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue: scan %.3f ms (found %llu, cands %llu), group+slots %.3f, superpose+copy+assemble(%llu) %.3f (superpose + headers %.3f, order %.3f, plan %.3f, records %.3f)\n",
-                               t_ms(T0, D1), (unsigned long long)nf_d, (unsigned long long)nc_d, t_ms(D1, D2), (unsigned long long)nprob, t_ms(D2, t_now()), t_ms(D2, E1), t_ms(E1, E2),
-                               t_ms(E2, E3), t_ms(E3, t_now()));
-            *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
-            return FDGPU_OK;
-        }
-        if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue declined (flags %u): host path\n", dflags);
+        bool done = false;
+        rc = fd_rb_device_glue(c, db, resname_std, n_queries, cand, cand_off, qms, qb, q_struct, p, node_count, *prep, T0, matches, match_off, residues, res_off, &done);
+        if (rc || done) return rc;
     }
     if (trace) fprintf(stderr, "[fdgpu_retrieve] query tables %.3f ms\n", t_ms(T0, t_now()));
     // large queries: hash -> map entry through an open-addressing table built once per query (a whole-structure query looks ~10^5 found
@@ -1657,6 +1716,106 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
     memcpy(omo, m_off.data(), (n_queries + 1) * 8);
     memcpy(oro, r_off.data(), (n_queries + 1) * 8);
     *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
+    return FDGPU_OK;
+}
+
+// The body of query_pdb.rs:376-452 for a batch of queries in ONE call: query maps -> scoring + ranked top_n -> retrieval of every query's first
+// match_top candidates.  Same results as fdgpu_make_query_map_batch + fdgpu_count_query_maps_top + fdgpu_retrieve_batch called one after the other
+// (tests compare them bit for bit); what the call adds is overlap the three blocking calls cannot have: the retrieval's query tables are built
+// while the scoring kernels run, only the candidates' ids (match_top per query) are waited for before the pair scan starts, and the ranked records
+// (n_queries x top_n x 20 bytes) cross the bus on a second stream while the retrieval's kernels run.
+extern "C" int fdgpu_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, const fdgpu_batch *db, const uint8_t *resname_std, const fdgpu_batch *qb, uint64_t n_queries,
+                                 const uint32_t *q_struct, const uint64_t *q_off, const uint32_t *q_index, const uint8_t *const *subs, const uint32_t *n_subs,
+                                 const float *dist_thr, uint64_t n_dist, const float *angle_thr_deg, uint64_t n_angle, const fd_hash_params *p, float total_structures,
+                                 const float *penalty, uint32_t top_n, uint32_t match_top, float ca_distance_cutoff, uint32_t node_count, fd_query_map **maps,
+                                 fd_count_rec **recs, uint64_t **rec_off, fd_match_rec **matches, uint64_t **match_off, int32_t **residues, uint64_t **res_off) { FD_LOCK(c);
+    if (!c || !ix || !db || !qb || !p || !maps || !recs || !rec_off || !matches || !match_off || !residues || !res_off || !q_off || (n_queries && !q_struct)) return FDGPU_EINVAL;
+    *recs = nullptr; *rec_off = nullptr; *matches = nullptr; *match_off = nullptr; *residues = nullptr; *res_off = nullptr;
+    int rc = fdgpu_make_query_map_batch(c, qb, n_queries, q_struct, q_off, q_index, subs, n_subs, dist_thr, n_dist, angle_thr_deg, n_angle, p, ix, total_structures, maps);
+    if (rc) return rc;
+    auto drop_maps = [&]() { for (uint64_t t = 0; t < n_queries; ++t) { fdgpu_query_map_free(maps[t]); maps[t] = nullptr; } };
+    fd_rb_prep prep;
+    bool prep_done = false;
+    const std::function<void()> build_prep = [&]() { fd_rb_prepare(n_queries, maps, ca_distance_cutoff, prep); prep_done = true; };
+    fd_cq_dev_out D;
+    D.while_running = &build_prep;
+    fd_count_rec *rr = nullptr;
+    uint64_t *roff = nullptr;
+    rc = fd_count_query_maps_top_impl(c, ix, n_queries, maps, penalty, total_structures, top_n, &rr, &roff, &D);
+    if (!rc && D.got && D.overflow) {      // more ties at a cut-off than the device selection holds: the compacting path, host records
+        fdgpu_free(rr); free(roff); rr = nullptr; roff = nullptr;
+        rc = fd_count_query_maps_top_impl(c, ix, n_queries, maps, penalty, total_structures, top_n, &rr, &roff, nullptr);
+        D.got = false;
+    }
+    if (rc) { drop_maps(); return rc; }
+    if (!prep_done) build_prep();
+    std::vector<uint32_t> cand;
+    std::vector<uint64_t> cand_off(n_queries + 1, 0);
+    const uint64_t first = ix->first_id;
+    bool side_copy = false;
+    if (D.got) {
+        // the candidates: the first match_top records of every query's ranking (a strided copy of 20 x match_top bytes per query)
+        hipStream_t st = c->stream;
+        const uint32_t mt = std::min(match_top, top_n);
+        std::vector<fd_count_rec> head_v;
+        const size_t head_bytes = (size_t)n_queries * std::max<uint32_t>(mt, 1) * sizeof(fd_count_rec);
+        fd_count_rec *head = (fd_count_rec *)c->host_pinned(3, head_bytes);
+        if (!head) { head_v.resize((size_t)n_queries * std::max<uint32_t>(mt, 1)); head = head_v.data(); }
+        hipError_t e = hipSuccess;
+        if (mt && n_queries)
+            e = hipMemcpy2DAsync(head, (size_t)mt * sizeof(fd_count_rec), D.recs, (size_t)top_n * sizeof(fd_count_rec), (size_t)mt * sizeof(fd_count_rec), n_queries,
+                                 hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        // the full ranking: straight into the caller's (page-locked, pooled) array on the second stream, closed up after the retrieval
+        rr = (fd_count_rec *)fd_out_alloc(std::max<uint64_t>((uint64_t)n_queries * top_n, 1) * sizeof(fd_count_rec), true);
+        roff = (uint64_t *)calloc(n_queries + 1, 8);
+        if (e == hipSuccess && (!rr || !roff)) { fdgpu_free(rr); free(roff); drop_maps(); return FDGPU_ENOMEM; }
+        if (e == hipSuccess && !c->side_stream) e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+        if (e == hipSuccess && n_queries && top_n) {
+            e = hipMemcpyAsync(rr, D.recs, (size_t)n_queries * top_n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, c->side_stream);
+            side_copy = e == hipSuccess;
+        }
+        if (e != hipSuccess) {
+            if (side_copy) (void)hipStreamSynchronize(c->side_stream);
+            fdgpu_free(rr); free(roff); drop_maps();
+            c->err = std::string("query_batch: ") + hipGetErrorString(e);
+            return FDGPU_EHIP;
+        }
+        for (uint64_t t = 0; t < n_queries; ++t) {
+            const uint32_t m = std::min<uint32_t>(std::min<uint32_t>(D.counts[t], top_n), mt);
+            for (uint32_t k = 0; k < m; ++k) cand.push_back((uint32_t)(head[(size_t)t * mt + k].nid - first));
+            cand_off[t + 1] = cand.size();
+        }
+    } else {
+        for (uint64_t t = 0; t < n_queries; ++t) {
+            const uint64_t m = std::min<uint64_t>(roff[t + 1] - roff[t], match_top);
+            for (uint64_t k = 0; k < m; ++k) cand.push_back((uint32_t)(rr[roff[t] + k].nid - first));
+            cand_off[t + 1] = cand.size();
+        }
+    }
+    rc = fd_retrieve_batch_impl(c, db, resname_std, n_queries, cand.data(), cand_off.data(), maps, qb, q_struct, p, ca_distance_cutoff, node_count, 0, matches, match_off,
+                                residues, res_off, &prep);
+    if (side_copy) {
+        const hipError_t e = hipStreamSynchronize(c->side_stream);
+        if (e != hipSuccess && !rc) { c->err = std::string("query_batch records: ") + hipGetErrorString(e); rc = FDGPU_EHIP; }
+    }
+    if (!rc && D.got) {       // close the fixed-stride ranking up in place (forward moves: the write position never passes the read position)
+        uint64_t w = 0;
+        for (uint64_t t = 0; t < n_queries; ++t) {
+            const uint64_t m = std::min<uint32_t>(D.counts[t], top_n);
+            roff[t] = w;
+            if (m && w != t * top_n) memmove(rr + w, rr + (size_t)t * top_n, (size_t)m * sizeof(fd_count_rec));
+            w += m;
+        }
+        roff[n_queries] = w;
+    }
+    if (rc) {
+        fdgpu_free(rr); free(roff); drop_maps();
+        fdgpu_free(*matches); fdgpu_free(*residues); free(*match_off); free(*res_off);
+        *matches = nullptr; *match_off = nullptr; *residues = nullptr; *res_off = nullptr;
+        return rc;
+    }
+    *recs = rr; *rec_off = roff;
     return FDGPU_OK;
 }
 

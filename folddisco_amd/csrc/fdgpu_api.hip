@@ -178,6 +178,7 @@ extern "C" void fdgpu_destroy(fdgpu_ctx *c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (int k = 0; k < 8; ++k) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
     for (int k = 0; k < 6; ++k) if (c->hbuf[k]) (void)hipHostFree(c->hbuf[k]);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1634,6 +1635,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
             fd_launch_cq_topn_sort(c->ws[WS_KEYS_A].p, cap, c->ws[WS_MISC2].p, (uint32_t)n_queries, top_n, c->ws[WS_TILE_HO].p, st);
         }
         if (cq_trace) fprintf(stderr, "[count_query] launched at %.3f ms\n", cq_ms());
+        if (dev && dev->while_running && *dev->while_running) (*dev->while_running)();
         if (e2 == hipSuccess) e2 = hipMemcpyAsync(tstate.data(), c->ws[WS_MISC2].p, n_queries * 16, hipMemcpyDeviceToHost, st);
         if (e2 == hipSuccess && !dev) e2 = hipMemcpyAsync(rr, c->ws[WS_TILE_HO].p, (size_t)n_queries * top_n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
@@ -1645,6 +1647,8 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         for (uint64_t t = 0; t < n_queries; ++t) { overflow = overflow || tstate[4 * t + 3] > cap; tot += std::min<uint32_t>(tstate[4 * t + 3], top_n); }
         if (dev) {        // the ranked selection stays where it is
             free(ooff);
+            dev->counts.resize(n_queries);
+            for (uint64_t t = 0; t < n_queries; ++t) dev->counts[t] = tstate[4 * t + 3];
             dev->got = true; dev->overflow = overflow; dev->recs = c->ws[WS_TILE_HO].p; dev->state = c->ws[WS_MISC2].p; dev->top_n = top_n; dev->cap = cap;
             return FDGPU_OK;
         }
@@ -1841,6 +1845,10 @@ int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_quer
 }
 extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty,
                                           float total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
+    return fd_count_query_maps_top_impl(c, ix, n_queries, qms, penalty, total_structures, top_n, out, out_off, nullptr);
+}
+int fd_count_query_maps_top_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty, float total_structures,
+                                 uint32_t top_n, fd_count_rec **out, uint64_t **out_off, fd_cq_dev_out *dev) { FD_LOCK(c);
     if (!c || !ix || !out || !out_off || (n_queries && !qms)) return FDGPU_EINVAL;
     uint64_t nq = 0;
     for (uint64_t t = 0; t < n_queries; ++t) { if (!qms[t]) return FDGPU_EINVAL; nq += qms[t]->n; }
@@ -1863,7 +1871,7 @@ extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, u
     }
     int rc = !remembered && nq && ix->n_structures ? fd_posting_lengths_segs(c, ix, h.data(), nq, len.data(), seg.data()) : FDGPU_OK;
     if (rc) return rc;
-    return fd_count_query_maps_len(c, ix, n_queries, qms, len.data(), nullptr, penalty, total_structures, top_n, out, out_off, nullptr, seg.data(),
+    return fd_count_query_maps_len(c, ix, n_queries, qms, len.data(), nullptr, penalty, total_structures, top_n, out, out_off, dev, seg.data(),
                                    have_kidx ? kidx.data() : nullptr);
 }
 // The two halves of the sharded form for hosts that bring their own transport (MPI, gloo, ...): the LOCAL posting lengths of the maps'

@@ -60,6 +60,7 @@ struct fdgpu_ctx {
     // pinned staging of large device-to-host copies (fd_d2h_big in fdgpu_api.hip): FD_PIN_SLOTS buffers of FD_PIN_BYTES, made on first use
     // pinned host buffers that outlive a call (the packed candidate pairs of a whole-structure retrieval: 2 x ~100 MB per call — as
     // malloc'd blocks their first-touch page faults and their munmap cost more than the copy)
+    hipStream_t side_stream = nullptr;      // second stream of the fused query call: the ranked records travel to the host while the retrieval's kernels run
     void *hbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // 0, 1: retrieval; 2, 3: landing / upload blocks of the query-map stage; 4: its pair features
     size_t hbuf_cap[6] = {0, 0, 0, 0, 0, 0};
     void *host_pinned(int k, size_t bytes) {
@@ -173,7 +174,11 @@ struct fdgpu_index {
 };
 
 // batched scoring with the ranked selection left on the device (fdgpu_api.hip; consumed by the sharded query, fd_comm.hip)
-struct fd_cq_dev_out { bool got = false, overflow = false; const void *recs = nullptr; const void *state = nullptr; uint32_t top_n = 0, cap = 0; };
+struct fd_cq_dev_out {
+    bool got = false, overflow = false; const void *recs = nullptr; const void *state = nullptr; uint32_t top_n = 0, cap = 0;
+    std::vector<uint32_t> counts;                          // got: records selected per query (before the cut to top_n)
+    const std::function<void()> *while_running = nullptr;  // host work of the caller, run once between the scoring launches and the wait for them
+};
 int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                               const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
                               fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev, int64_t known_segments = -1,
@@ -184,6 +189,9 @@ int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_quer
                             const uint64_t *primary_len, const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out,
                             uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg = nullptr, const long long *kidx = nullptr, bool allow_dense = true);
 int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs, long long *kidx = nullptr);
+// fdgpu_count_query_maps_top with the device-resident form of its result (dev != null: see fd_count_query_batch_impl)
+int fd_count_query_maps_top_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty, float total_structures,
+                                 uint32_t top_n, fd_count_rec **out, uint64_t **out_off, fd_cq_dev_out *dev);
 
 void *fd_out_alloc(size_t bytes, bool pinned = false);      // result arrays of the hot query paths: recycled blocks (fdgpu_api.hip); released with fdgpu_free like any other output
 

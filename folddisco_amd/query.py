@@ -7,6 +7,7 @@ import ctypes as C
 
 import numpy as np
 
+from . import _lib
 from ._lib import HashParams, MatchRec, QueryMap, f32p, owned_view, u8p, u32p, u64p
 from .api import Batch, Context, FolddiscoIndex, PackedStructures, count_query, length_penalty
 from .structure import CompactStructure
@@ -321,6 +322,56 @@ def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Bat
     ctx.L.fdgpu_free(mo)
     ctx.L.fdgpu_free(ro)
     return out
+
+
+def query_batch(ctx: Context, index: FolddiscoIndex, db: Batch, qbatch: Batch, queries, total_structures: float, top_n: int, match_top: int,
+                penalty=None, resname_std=None, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance_cutoff=1.0, node_count=2, nbin_dist=0, nbin_angle=0,
+                dist_cutoff=20.0, hash_type=3, multiple_bins=None):
+    """make_query_maps + count_query_maps(top_n) + retrieve_batch over the first match_top records of every ranking in ONE library call
+    (fdgpu_query_batch: the stages overlap inside it).  queries as make_query_maps.  -> (maps, (records REC_DTYPE[], rec_off), (matches
+    MATCH_DTYPE[], match_off, residues int32[], res_off)) — the arrays the three calls return."""
+    from .api import REC_DTYPE
+    nq = len(queries)
+    q_struct = np.ascontiguousarray([q[0] for q in queries], np.uint32)
+    idx = [np.ascontiguousarray(q[1], np.uint32) for q in queries]
+    q_off = np.concatenate([[0], np.cumsum([len(x) for x in idx])]).astype(np.uint64)
+    q_index = np.ascontiguousarray(np.concatenate(idx) if idx else np.zeros(0, np.uint32))
+    ntot = len(q_index)
+    sub_ptrs = (u8p * max(ntot, 1))()
+    n_subs = np.zeros(max(ntot, 1), np.uint32)
+    keep = []
+    for t, q in enumerate(queries):
+        if len(q) > 2 and q[2] is not None:
+            for k, sl in enumerate(q[2]):
+                if sl is not None:
+                    a = np.ascontiguousarray(sl if len(sl) else [0], dtype=np.uint8)
+                    keep.append(a)
+                    sub_ptrs[int(q_off[t]) + k] = a.ctypes.data_as(u8p)
+                    n_subs[int(q_off[t]) + k] = len(sl)
+    d = np.ascontiguousarray(dist_thr, np.float32)
+    a = np.ascontiguousarray(angle_thr, np.float32)
+    p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type, multiple_bins)
+    pen = None if penalty is None else np.ascontiguousarray(penalty, dtype=np.float32)
+    std = None if resname_std is None else np.ascontiguousarray(resname_std, np.uint8)
+    outs = (C.POINTER(QueryMap) * max(nq, 1))()
+    rp_, ro_ = C.POINTER(_lib.CountRec)(), u64p()
+    mp, resp = C.POINTER(MatchRec)(), C.POINTER(C.c_int32)()
+    mo, reso = u64p(), u64p()
+    ctx.check(ctx.L.fdgpu_query_batch(ctx.h, index.h, db.h, None if std is None else std.ctypes.data_as(u8p), qbatch.h, nq, q_struct.ctypes.data_as(u32p),
+                                      q_off.ctypes.data_as(u64p), q_index.ctypes.data_as(u32p), sub_ptrs, n_subs.ctypes.data_as(u32p), d.ctypes.data_as(f32p), len(d),
+                                      a.ctypes.data_as(f32p), len(a), C.byref(p), float(total_structures), None if pen is None else pen.ctypes.data_as(f32p),
+                                      int(top_n), int(match_top), ca_distance_cutoff, node_count, outs, C.byref(rp_), C.byref(ro_), C.byref(mp), C.byref(mo),
+                                      C.byref(resp), C.byref(reso)))
+    maps = [_wrap_query_map(ctx, outs[t]) for t in range(nq)]
+    rec_off = np.ctypeslib.as_array(ro_, shape=(nq + 1,)).copy()
+    moff = np.ctypeslib.as_array(mo, shape=(nq + 1,)).copy()
+    roff = np.ctypeslib.as_array(reso, shape=(nq + 1,)).copy()
+    recs = owned_view(ctx.L, rp_, int(rec_off[-1]) * 20, REC_DTYPE)
+    marr = owned_view(ctx.L, mp, int(moff[-1]) * MATCH_DTYPE.itemsize, MATCH_DTYPE)
+    rarr = owned_view(ctx.L, resp, int(roff[-1]) * 4, np.int32)
+    for x in (ro_, mo, reso):
+        ctx.L.fdgpu_free(x)
+    return maps, (recs, rec_off), (marr, moff, rarr, roff)
 
 
 def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[CompactStructure], tids: list[str], nres, plddt,

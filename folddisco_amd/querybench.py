@@ -251,14 +251,39 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
 
             def go512():
                 qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks4], ix, float(S_total))
-                globs = count_query_maps(ctx, ix, qms, None, total_structures=S_total, top_n=top_n)
-                cl = [owned(g, match_top) for g in globs]
+                recs, off = count_query_maps(ctx, ix, qms, None, total_structures=S_total, top_n=top_n, flat=True)
+                cl = top_cands(recs, off, match_top)
+                if cl is None:
+                    cl = [recs["nid"][int(off[t]): int(off[t]) + min(match_top, int(off[t + 1] - off[t]))] - np.uint32(first) for t in range(len(qms))]
                 return len(retrieve_batch(ctx, batch, None, cl, qms, qall, ks4, as_arrays=True)[0])
             go512()
             dtbm_512, nm_512 = timed(go512)
             assert nm_512 == 4 * nm_b, (nm_512, nm_b)
         except Exception as e:      # the other legs stand on their own
             dtbm_512, err_512 = None, repr(e)[:300]
+    # the same three stages as ONE library call per batch (fdgpu_query_batch: the retrieval's tables are built while the scoring kernels run, the
+    # ranked records cross the bus while the retrieval runs) — single index only (the sharded form has an exchange between the stages)
+    dt_fused, dt_fused_512, err_fused = None, None, None
+    if big and not sharded and first == 0:
+        try:
+            from .query import query_batch
+
+            def go_fused(ks_all, chunk):
+                tot = 0
+                for c0 in range(0, len(ks_all), chunk):
+                    ks = ks_all[c0:c0 + chunk]
+                    _, _, (marr, _, _, _) = query_batch(ctx, ix, batch, qall, [(k, queries[k][1]) for k in ks], float(S_total), top_n, match_top)
+                    tot += len(marr)
+                return tot
+            ks1 = list(range(len(queries)))
+            assert go_fused(ks1, big) == nm_b, "fused call: match count differs from the three calls"
+            runs = sorted((timed(lambda: go_fused(ks1, big)) for _ in range(7)), key=lambda x: x[0])
+            dt_fused = runs[len(runs) // 2][0]
+            ks4 = ks1 * 4
+            go_fused(ks4, len(ks4))
+            dt_fused_512 = timed(lambda: go_fused(ks4, len(ks4)))[0]
+        except Exception as e:
+            dt_fused, err_fused = None, repr(e)[:300]
     progress("big batch legs done")
     dtb2, mt_workers, mt_chunk, mt_all = None, 0, 32, {}
     if not sharded and len(queries) >= 64:
@@ -382,13 +407,20 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         # headline = the reference's default query (prefilter + candidate selection + matching + RMSD), 32 queries per launch set
         # headline = ONE host thread, batches of 128 full queries (what one Rust host thread per GPU drives through the ABI; fixed definition
         # since round 4 — rounds 1-3 took the best of four legs).  Several host threads with a context each are reported beside it (_mt).
-        "metric": "motif queries/sec", "value": len(queries) / (dtbm_big if dtbm_big else dtbm), "unit": "queries/s",
+        "metric": "motif queries/sec", "value": len(queries) / (dt_fused if dt_fused else dtbm_big if dtbm_big else dtbm), "unit": "queries/s",
         "n_queries": len(queries),
         "structures": S_total, "structures_per_gpu": S,
         "mode": "full query (make_query_map, count_query, all-gather + global top-%d, retrieval of the global top %d candidates on their owning "
-                "rank, Kabsch, metrics); value = batches of %d from ONE host thread (batched_with_matching_128); batches of 32 / 512 and several host "
-                "threads with one context each are reported beside it (batched_with_matching, _512, _mt)" % (top_n, match_top, big if dtbm_big else 32),
-        "ms_per_query": (dtbm_big if dtbm_big else dtbm) / len(queries) * 1e3,
+                "rank, Kabsch, metrics); value = batches of %d from ONE host thread, %s; batches of 32 / 512 and several host "
+                "threads with one context each are reported beside it (batched_with_matching, _512, _mt)"
+                % (top_n, match_top, big if dtbm_big else 32, "one fdgpu_query_batch call per batch (fused_128; the three separate calls: batched_with_matching_128)"
+                   if dt_fused else "three library calls per batch (batched_with_matching_128)"),
+        "ms_per_query": (dt_fused if dt_fused else dtbm_big if dtbm_big else dtbm) / len(queries) * 1e3,
+        "fused_128": ({"error": err_fused} if err_fused else None) if not dt_fused else {
+            "value": len(queries) / dt_fused, "ms_per_query": dt_fused / len(queries) * 1e3, "chunk": big, "host_threads": 1,
+            "mode": "fdgpu_query_batch: query maps, scoring + ranked top %d, retrieval of the top %d in ONE call per batch of 128 (median of 7 passes)" % (top_n, match_top)},
+        "fused_512": None if not dt_fused_512 else {"value": 4 * len(queries) / dt_fused_512, "ms_per_query": dt_fused_512 / (4 * len(queries)) * 1e3,
+                                                    "chunk": 4 * len(queries), "host_threads": 1},
         "batched_with_matching": {"value": len(queries) / dtbm, "ms_per_query": dtbm / len(queries) * 1e3, "matches": int(nm_b), "match_top": match_top, "chunk": 32,
                                   "host_threads": 1},
         "batched_with_matching_512": ({"error": err_512} if err_512 else None) if not dtbm_512 else {

@@ -319,6 +319,18 @@ int fdgpu_retrieve_batch(fdgpu_ctx *ctx, const fdgpu_batch *db, const uint8_t *r
                          const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, uint32_t partial_fit,
                          fd_match_rec **matches, uint64_t **match_off, int32_t **residues, uint64_t **res_off);
 void fdgpu_matches_free(fd_match_rec *m, int32_t *residues);
+/* The per-query body of the query workflow (src/cli/workflows/query_pdb.rs:376-452: make_query_map -> count_query -> sort / truncate ->
+ * retrieval_wrapper over the first candidates) for a rayon chunk of queries in ONE call: arguments as fdgpu_make_query_map_batch (queries),
+ * fdgpu_count_query_maps_top (penalty NULL = the index's resident one, top_n ranked records per query) and fdgpu_retrieve_batch over the first
+ * match_top records of every query's ranking (candidates = nid - the index's first id: db holds the index's structures in order).  Outputs
+ * are exactly those of the three calls made one after the other: maps[t] (caller's array of n_queries pointers, each released with
+ * fdgpu_query_map_free), recs / rec_off, matches / match_off / residues / res_off (fdgpu_free).  What the single call adds is overlap: the
+ * retrieval's tables are built while the scoring kernels run and the ranked records cross the bus while the retrieval runs. */
+int fdgpu_query_batch(fdgpu_ctx *ctx, const fdgpu_index *index, const fdgpu_batch *db, const uint8_t *resname_std, const fdgpu_batch *qb, uint64_t n_queries,
+                      const uint32_t *q_struct, const uint64_t *q_off, const uint32_t *q_index, const uint8_t *const *subs, const uint32_t *n_subs,
+                      const float *dist_thr, uint64_t n_dist, const float *angle_thr_deg, uint64_t n_angle, const fd_hash_params *p, float total_structures,
+                      const float *penalty, uint32_t top_n, uint32_t match_top, float ca_distance_cutoff, uint32_t node_count, fd_query_map **maps,
+                      fd_count_rec **recs, uint64_t **rec_off, fd_match_rec **matches, uint64_t **match_off, int32_t **residues, uint64_t **res_off);
 
 /* ---- multi-GPU query path (one process per GPU, RCCL over xGMI) ----------------------------------------------------
  * The index and the coordinates are sharded by structure id (every rank holds the postings and coordinates of its own id range,

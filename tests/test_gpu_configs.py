@@ -212,6 +212,39 @@ def test_batch_of_shipped_queries_equals_singles(human):
             assert a["rmsd"] == b["rmsd"] and a["idf"] == b["idf"]
 
 
+def test_fused_query_batch_equals_the_three_calls(human, monkeypatch):
+    """fdgpu_query_batch (maps -> ranked top_n -> retrieval of the first match_top candidates in one call, stages overlapped inside it) returns
+    the arrays of fdgpu_make_query_map_batch + fdgpu_count_query_maps_top + fdgpu_retrieve_batch bit for bit: the shipped motifs with their
+    substitution lists, a query with no hit at all, top_n beyond the device selection (host ranking path inside the fused call), match_top
+    above top_n, the residue-name filter."""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    from folddisco_amd.api import count_query_maps
+    ctx, ps, batch, ix = human["ctx"], human["ps"], human["batch"], human["ix"]
+    Qs = human["queries"]
+    qall = ctx.upload(fd.PackedStructures.concat([Q["q"].as_item() for Q in Qs]))
+    ix.set_penalty(human["pen"])
+    queries = [(k, Q["idx"], Q["subs"]) for k, Q in enumerate(Qs)] * 3 + [(0, np.array([0, 1], np.uint32), None)]
+    std = np.ones(int(ps.res_off[-1]), np.uint8)
+    fields = ("hash", "qi", "qj", "is_primary", "idf", "indices", "aad_aa1", "aad_aa2", "aad_dist", "aad_qi", "primary_hash")
+    n_matches = 0
+    for top_n, match_top, use_std, pen in ((1000, 25, True, None), (40, 64, False, None), (5000, 10, False, human["pen"])):
+        maps = fq.make_query_maps(ctx, qall, queries, ix, float(HUMAN))
+        recs, off = count_query_maps(ctx, ix, maps, pen, total_structures=HUMAN, top_n=top_n, flat=True)
+        cl = [recs["nid"][int(off[t]): int(off[t]) + min(match_top, int(off[t + 1] - off[t]))].astype(np.uint32) for t in range(len(queries))]
+        ref = fq.retrieve_batch(ctx, batch, std if use_std else None, cl, maps, qall, [q[0] for q in queries], as_arrays=True)
+        fmaps, (frecs, foff), got = fq.query_batch(ctx, ix, batch, qall, queries, float(HUMAN), top_n, match_top, penalty=pen,
+                                                  resname_std=std if use_std else None)
+        for a, b in zip(maps, fmaps):
+            for f in fields:
+                assert getattr(a, f).tobytes() == getattr(b, f).tobytes(), f
+        assert foff.tobytes() == off.tobytes() and frecs.tobytes() == recs.tobytes()
+        for a, b, what in zip(ref, got, ("matches", "match_off", "residues", "res_off")):
+            assert a.tobytes() == b.tobytes(), (top_n, what)
+        n_matches += len(got[0])
+    assert n_matches > 3 * 5 * N_PLANT // 2
+
+
 def test_whole_structure_query_at_human_scale(human, monkeypatch):
     """configs[4] (no -q): a ~300-residue database structure as the query, against all 20,500 structures"""
     import folddisco_amd as fd

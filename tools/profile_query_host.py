@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--chunk", default="32", help="queries per batch (a comma list measures each in turn)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--fused", action="store_true", help="one fdgpu_query_batch call per batch instead of the three calls")
     a = ap.parse_args()
     chunks = [int(x) for x in str(a.chunk).split(",")]
     a.chunk = chunks[0]
@@ -31,7 +32,7 @@ def main():
     from folddisco_amd import synth
     from folddisco_amd import dist as fdist
     from folddisco_amd.api import PackedStructures, count_query_batch, count_query_maps, length_penalty
-    from folddisco_amd.query import make_query_maps, retrieve_batch
+    from folddisco_amd.query import make_query_maps, query_batch, retrieve_batch
     from folddisco_amd.querybench import _pick_queries
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -72,6 +73,10 @@ def main():
         for c0 in range(0, len(queries), a.chunk):
             ks = range(c0, min(c0 + a.chunk, len(queries)))
             t0 = time.perf_counter()
+            if a.fused:
+                query_batch(ctx, ix, batch, qall, [(k, queries[k][1]) for k in ks], float(S), 1000, 32)
+                T["query_batch"] = T.get("query_batch", 0.0) + time.perf_counter() - t0
+                continue
             qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix, float(S))
             t1 = time.perf_counter()
             recs = count_query_maps(ctx, ix, qms, None, total_structures=S, top_n=1000)

@@ -7,10 +7,10 @@ set -u
 REPO=$(pwd); OUT=$REPO/gpurun_out; RAW=/tmp/fdprof4h
 rm -rf $RAW; mkdir -p $OUT $RAW
 export TMPDIR=/tmp
-S=${1:-542000}; REPS=${2:-20}
+S=${1:-542000}; REPS=${2:-20}; FUSED=${3:-}      # third argument --fused: one fdgpu_query_batch call per batch
 cd /tmp
-timeout 900 python $REPO/tools/profile_query_host.py --structures $S --queries 128 --chunk 128 --reps $REPS > $OUT/r4_host_wall.txt 2> $OUT/r4_host_wall.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- python $REPO/tools/profile_query_host.py --structures $S --queries 128 --chunk 128 --reps $REPS --no-profile > $OUT/r4_host_trace.log 2>&1
+timeout 900 python $REPO/tools/profile_query_host.py --structures $S --queries 128 --chunk 128 --reps $REPS $FUSED > $OUT/r4_host_wall.txt 2> $OUT/r4_host_wall.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- python $REPO/tools/profile_query_host.py --structures $S --queries 128 --chunk 128 --reps $REPS --no-profile $FUSED > $OUT/r4_host_trace.log 2>&1
 cd $REPO
 python - "$RAW" "$OUT" "$REPS" > $OUT/r4_host_share.txt <<'PY'
 import csv, glob, re, sys
