@@ -1954,6 +1954,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     // scans of a large query) passes a fd_mp_tables and the second call reuses the host block
     fd_mp_tables tb_local;
     fd_mp_tables &TB = tables ? *tables : tb_local;
+    const bool dev_items = !tables && n_cand < (1ull << 24) && !(getenv("FDGPU_MP_ITEMS") && getenv("FDGPU_MP_ITEMS")[0] == '0');      // 0: host-built items (tests)
     auto build_tables = [&]() -> int {
     // work items: (query, candidate slot, 64-residue i-tile); a handful of long candidates (whole-structure queries: the top 20)
     // would leave most of the chip idle, so the partner residues are split into spans as well until ~2000 wavefronts exist
@@ -1972,14 +1973,23 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     const uint32_t j_span = !n_tiles ? 0u : max_aad_q > 4096 ? 32u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : 256u;
     TB.j_span = j_span;
     std::vector<uint32_t> wc, wi, wq, wj;
+    // a one-off block (a batch of motif queries: 18 k work items per 128 queries) gets its work items written on the DEVICE (k_mp_items): the host
+    // sends every candidate's first item and query (8 bytes per candidate instead of 16 per item) and skips the loop below
+    std::vector<uint32_t> wbase, cq;
+    size_t n_wi = 0;
     {
-        size_t n_wi = 0;
+        if (dev_items) { wbase.resize(n_cand + 1); cq.resize(std::max<uint64_t>(n_cand, 1)); }
         for (uint64_t k = 0; k < n_cand; ++k) {
             const uint64_t len = db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]];
+            if (dev_items) wbase[k] = (uint32_t)n_wi;
             n_wi += ((len + FD_WAVE - 1) / FD_WAVE) * (j_span ? (len + j_span - 1) / j_span : (len ? 1 : 0));
         }
-        wc.reserve(n_wi); wi.reserve(n_wi); wq.reserve(n_wi); wj.reserve(n_wi);
+        if (dev_items) {
+            wbase[n_cand] = (uint32_t)n_wi;
+            for (uint64_t t = 0; t < n_queries; ++t) for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) cq[k] = (uint32_t)t;
+        } else { wc.reserve(n_wi); wi.reserve(n_wi); wq.reserve(n_wi); wj.reserve(n_wi); }
     }
+    if (!dev_items)
     for (uint64_t t = 0; t < n_queries; ++t)
         for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) {
             uint64_t r0 = db->h_res_off[cand[k]], r1 = db->h_res_off[cand[k] + 1];
@@ -2082,23 +2092,26 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
             iv_start[1025 * t + 1024] = (uint32_t)(iv_lohi.size() / 2);
         }
     }
-    const size_t nw = wc.size(), na = all_dist.size(), nh = all_hashes.size();
+    const size_t nw = dev_items ? n_wi : wc.size(), na = all_dist.size(), nh = all_hashes.size();
     TB.nw = nw; TB.want_iv = want_iv;
     // one packed host block -> one H2D copy: [cand | wc | wi | wq | hashes | start tables | dist | qi | qtab]
     auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
     const size_t o_cand = 0, o_wc = o_cand + up4(n_cand), o_wi = o_wc + up4(nw), o_wq = o_wi + up4(nw), o_wj = o_wq + up4(nw), o_h = o_wj + up4(nw),
                  o_st = o_h + up4(nh), o_d = o_st + up4(all_start.size()), o_qi = o_d + up4(na), o_qt = o_qi + up4(na),
                  o_ivs = o_qt + up4(n_queries * (sizeof(mp_query_dev) / 4)), o_iv = o_ivs + (want_iv ? up4(iv_start.size()) : 0),
-                 o_iv1 = o_iv + (want_iv ? up4(iv_lohi.size()) : 0), words = o_iv1 + (want_iv ? 1024 * n_queries : 0) + 4;
+                 o_iv1 = o_iv + (want_iv ? up4(iv_lohi.size()) : 0), o_wb = o_iv1 + (want_iv ? 1024 * n_queries : 0),
+                 words = o_wb + (dev_items ? up4(n_cand + 1) + up4(n_cand) : 0) + 4;
     const size_t offs[13] = {o_cand, o_wc, o_wi, o_wq, o_wj, o_h, o_st, o_d, o_qi, o_qt, o_ivs, o_iv, o_iv1};
     memcpy(TB.o, offs, sizeof offs);
+    TB.o_wb = dev_items ? o_wb : 0; TB.dev_items = dev_items;
     // a caller that keeps the tables (two scans of a large query) gets them in a vector; a one-off block (a batch of motif queries: ~3.5 MB
     // per 512 queries) is packed straight into the context's pinned staging buffer — the copy below is then a DMA, not a staged pageable copy
     uint32_t *blk = tables ? nullptr : (uint32_t *)c->host_pinned(0, words * 4);
     if (!blk) { TB.blk.assign(words, 0); blk = TB.blk.data(); }
     TB.data = blk; TB.words = words;
     if (n_cand) memcpy(&blk[o_cand], cand, n_cand * 4);
-    if (nw) { memcpy(&blk[o_wc], wc.data(), nw * 4); memcpy(&blk[o_wi], wi.data(), nw * 4); memcpy(&blk[o_wq], wq.data(), nw * 4); memcpy(&blk[o_wj], wj.data(), nw * 4); }
+    if (dev_items) { memcpy(&blk[o_wb], wbase.data(), (n_cand + 1) * 4); if (n_cand) memcpy(&blk[o_wb + up4(n_cand + 1)], cq.data(), n_cand * 4); }
+    else if (nw) { memcpy(&blk[o_wc], wc.data(), nw * 4); memcpy(&blk[o_wi], wi.data(), nw * 4); memcpy(&blk[o_wq], wq.data(), nw * 4); memcpy(&blk[o_wj], wj.data(), nw * 4); }
     if (nh) memcpy(&blk[o_h], all_hashes.data(), nh * 4);
     if (!all_start.empty()) memcpy(&blk[o_st], all_start.data(), all_start.size() * 4);
     if (na) { memcpy(&blk[o_d], all_dist.data(), na * 4); memcpy(&blk[o_qi], all_qi.data(), na * 4); }
@@ -2126,6 +2139,12 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     if (mp_trace) fprintf(stderr, "[match_pairs] tables at %.3f ms (%zu work items)\n", mp_ms(), nw);
     HIPCHK(c, c->ws[WS_MISC0].ensure(words * 4));
     HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
+    if (TB.dev_items) {       // the item arrays [o_wc, o_h) are not sent: the device writes them
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, TB.data, o_wc * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].as<uint32_t>() + o_h, TB.data + o_h, (words - o_h) * 4, hipMemcpyHostToDevice, st));
+        uint32_t *d = c->ws[WS_MISC0].as<uint32_t>();
+        fd_launch_mp_items(db->res_off, d + o_cand, (uint32_t)n_cand, d + TB.o_wb, d + TB.o_wb + ((n_cand + 1 + 3) & ~(size_t)3), j_span, d + o_wc, d + o_wi, d + o_wq, d + o_wj, st);
+    } else
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, TB.data, words * 4, hipMemcpyHostToDevice, st));
     const uint32_t *dblk = c->ws[WS_MISC0].as<uint32_t>();
     uint8_t *d_std = nullptr;

@@ -355,7 +355,11 @@ struct mp_args {
 struct fd_mp_tables {
     std::vector<uint32_t> blk; size_t o[13] = {0}; size_t nw = 0; bool want_iv = false; uint32_t j_span = 0; bool valid = false;
     const uint32_t *data = nullptr; size_t words = 0;      // the packed block: blk, or (tables not kept by the caller) the context's pinned staging buffer
+    bool dev_items = false; size_t o_wb = 0;                // work items written on the device from [first item | query] per candidate at o_wb (one-off blocks)
 };
+// work items of the pair scan: candidate k (structure cand[k], first item wbase[k], query cq[k]) -> one item per (64-residue tile, span of j_span partners)
+void fd_launch_mp_items(const uint32_t *db_res_off, const uint32_t *cand, uint32_t n_cand, const uint32_t *wbase, const uint32_t *cq, uint32_t j_span, uint32_t *wc,
+                        uint32_t *wi, uint32_t *wq, uint32_t *wj, hipStream_t st);
 struct fd_vote_row { uint32_t mx, nmx, arg; };
 struct fd_vote_plan {
     const uint8_t *cj_comp; uint64_t n_bits;

@@ -369,6 +369,25 @@ void fd_launch_found_key_slot(const fd_pair_rec *f, const uint32_t *val, uint64_
 void fd_launch_found_gather(const fd_pair_rec *f, const uint32_t *val, uint64_t n, fd_pair_rec *out, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_found_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f, val, n, out);
 }
+// The scan's work items, written where they are read: one wavefront per candidate, an item per (64-residue tile i, span of j_span partner
+// residues) in the order the host loop made them (tiles outer, spans inner).  j_span = 0: one span = the whole structure.
+__global__ __launch_bounds__(256) void k_mp_items(const uint32_t *__restrict__ db_res_off, const uint32_t *__restrict__ cand, uint32_t n_cand,
+                                                  const uint32_t *__restrict__ wbase, const uint32_t *__restrict__ cq, uint32_t j_span, uint32_t *__restrict__ wc,
+                                                  uint32_t *__restrict__ wi, uint32_t *__restrict__ wq, uint32_t *__restrict__ wj) {
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (k >= n_cand) return;
+    const uint32_t s = cand[k], r0 = db_res_off[s], len = db_res_off[s + 1] - r0;
+    const uint32_t base = wbase[k], n = wbase[k + 1] - base, q = cq[k];
+    const uint32_t spans = j_span ? (len + j_span - 1u) / j_span : (len ? 1u : 0u);
+    for (uint32_t x = lane; x < n; x += 64u) {
+        const uint32_t ti = x / spans, sj = x - ti * spans;
+        wc[base + x] = k; wi[base + x] = r0 + ti * FD_WAVE; wq[base + x] = q; wj[base + x] = r0 + sj * j_span;
+    }
+}
+void fd_launch_mp_items(const uint32_t *db_res_off, const uint32_t *cand, uint32_t n_cand, const uint32_t *wbase, const uint32_t *cq, uint32_t j_span, uint32_t *wc,
+                        uint32_t *wi, uint32_t *wq, uint32_t *wj, hipStream_t st) {
+    if (n_cand) hipLaunchKernelGGL(k_mp_items, dim3((n_cand + 3u) / 4u), dim3(256), 0, st, db_res_off, cand, n_cand, wbase, cq, j_span, wc, wi, wq, wj);
+}
 void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st) {
     if (!A.n_work) return;
     if (emit) hipLaunchKernelGGL(k_match_pairs<true>, dim3(A.n_work), dim3(FD_WAVE), 0, st, A);

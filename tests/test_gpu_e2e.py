@@ -1151,7 +1151,7 @@ def test_device_retrieval_glue_equals_host_glue(env, monkeypatch):
             assert a.tobytes() == b.tobytes(), what
         # the records' order made on the device (slot bases from record counts) against the host's sort of the record headers,
         # and the slots launched heaviest first against slot order
-        for env_name, val in (("FDGPU_RS_HOST_ORDER", "1"), ("FDGPU_RS_ORDER", "0")):
+        for env_name, val in (("FDGPU_RS_HOST_ORDER", "1"), ("FDGPU_RS_ORDER", "0"), ("FDGPU_MP_ITEMS", "0")):      # (the last: work items built on the host)
             monkeypatch.setenv(env_name, val)
             alt, _ = run(db, stdn, cl, qms_, qb, qs, ca)
             monkeypatch.delenv(env_name)
