@@ -988,7 +988,7 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
     HIPCHK(c, c->ws[WS_RS_KY].ensure(cap_pts * 12));
     HIPCHK(c, c->ws[WS_RS_KOFF].ensure((cap_prob + 1) * 8 + cap_prob * 4));
     HIPCHK(c, c->ws[WS_RS_SOL].ensure(cap_prob * 18 * 4));
-    HIPCHK(c, c->ws[WS_RS_CNT].ensure(64));
+    HIPCHK(c, c->ws[WS_RS_CNT].ensure((2 * RS_CNT_STRIDE + 8) * 8));
     // [records per slot | slot bases + first residues (2 n_cand + 2) | match_off, res_off (n_queries + 1 each, 8-byte)] for the device-side ordering
     const size_t o_sm = 0, o_scr = o_sm + ((n_cand + 1) & ~(size_t)1), o_mo = (o_scr + 2 * n_cand + 2 + 1) & ~(size_t)1, o_ro = o_mo + 2 * (n_queries + 1),
                  ord_words = o_ro + 2 * (n_queries + 1);
@@ -996,7 +996,7 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
     uint32_t *d_ord = c->ws[WS_RS_PLAN].as<uint32_t>();
     HIPCHK(c, hipMemsetAsync(d_ord + o_sm, 0, n_cand * 4, st));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_RS_TAB].p, blk, words * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(c->ws[WS_RS_CNT].p, 0, 64, st));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_RS_CNT].p, 0, (2 * RS_CNT_STRIDE + 8) * 8, st));
     const uint32_t *dblk = c->ws[WS_RS_TAB].as<uint32_t>();
     uint32_t *sg = c->ws[WS_RS_SEG].as<uint32_t>();
     uint32_t *d_cnt = sg, *d_seg = sg + 2 * (n_cand + 1), *d_cur = sg + 4 * (n_cand + 1), *d_pf = sg + 6 * (n_cand + 1), *d_pc = d_pf + nf_d;
@@ -1008,6 +1008,8 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
     A.found = d_found; A.cands = d_cands; A.seg_f = d_seg; A.seg_c = d_seg + (n_cand + 1); A.perm_f = d_pf; A.perm_c = d_pc;
     A.cand = dblk + o_cd; A.slot_q = dblk + o_sq;
     A.slot_matches = d_ord + o_sm;
+    const bool rs_dbg = getenv("FDGPU_RS_DBG") != nullptr;      // phase clocks of the slots on stderr (measurement aid)
+    A.dbg = rs_dbg ? c->ws[WS_RS_CNT].as<unsigned long long>() + 8 : nullptr;
     A.order = getenv("FDGPU_RS_ORDER") && getenv("FDGPU_RS_ORDER")[0] == '0' ? nullptr : d_cur;      // 0: slot order (measurement)
     A.db_res_off = db->res_off; A.db_ca = db->ca_xyz; A.db_cb = db->cb_xyz; A.q_ca = qb->ca_xyz; A.q_cb = qb->cb_xyz;
     A.qt = (const rs_query_dev *)(dblk + o_qt); A.hashes = dblk + o_h; A.kfirst = dblk + o_kf; A.sym = (const uint8_t *)(dblk + o_sy);
@@ -1024,9 +1026,21 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
         fd_launch_rs_slots(A, (uint32_t)n_cand, st);
     }
     HIPCHK(c, hipGetLastError());
-    unsigned long long cnt_h[5] = {0, 0, 0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(cnt_h, c->ws[WS_RS_CNT].p, 40, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    unsigned long long cnt_h[32] = {0};
+    {
+        std::vector<unsigned long long> cv(2 * RS_CNT_STRIDE + 8);      // the three counters live 4 KB apart (rs_args.counters)
+        HIPCHK(c, hipMemcpyAsync(cv.data(), c->ws[WS_RS_CNT].p, cv.size() * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        memcpy(cnt_h, cv.data(), 32 * 8);
+        cnt_h[1] = cv[RS_CNT_STRIDE]; cnt_h[2] = cv[2 * RS_CNT_STRIDE];
+    }
+    if (rs_dbg) {
+        const unsigned long long *d = cnt_h + 8;
+        const double ns = std::max<double>((double)n_cand, 1.0) * 100.0, nc2 = std::max<double>((double)d[7], 1.0) * 100.0;
+        fprintf(stderr, "[rs_slots] per slot (%llu slots): edges + rank %.2f, lookup %.2f, nodes %.2f, components %.2f us; per slot WITH components (%llu): order %.2f, "
+                        "components' loop %.2f us = votes %.2f + best / greedy %.2f + rescue votes %.2f + assignment %.2f + output %.2f\n", (unsigned long long)n_cand, d[0] / ns, d[1] / ns,
+                d[2] / ns, d[3] / ns, d[7], d[4] / nc2, (d[5] + d[8] + d[9] + d[10] + d[11] + d[12]) / nc2, d[8] / nc2, d[9] / nc2, d[10] / nc2, d[11] / nc2, d[12] / nc2);
+    }
     const uint32_t dflags = (uint32_t)cnt_h[4];
     auto D2 = t_now();
     if (dflags == 0) {

@@ -402,12 +402,14 @@ struct rs_query_dev {
     uint32_t pad;
 };
 struct rs_match_dev { uint32_t slot, ci, same, res_pos, prob0, prob1; float idf; uint32_t ord; };      // ord: the record's place among its slot's records (components ascend)
+#define RS_CNT_STRIDE 512      // u64 words between the slots kernel's three allocation counters
 struct rs_args {
     const fd_pair_rec *found; const fd_cand_rec *cands;
     const uint32_t *seg_f, *seg_c, *perm_f, *perm_c;     // per-slot segments of the (unordered) scan output
     const uint32_t *cand, *slot_q;                       // slot -> structure of the database batch, slot -> query
     const uint32_t *order;                               // launch order of the slots, heaviest first (k_rs_order; null: slot order)
     uint32_t *slot_matches;                              // records every slot wrote (zeroed before the launch; null: not kept)
+    unsigned long long *dbg;                             // FDGPU_RS_DBG: phase clocks summed over the slots (8 counters), else null
     const uint32_t *db_res_off; const float *db_ca, *db_cb, *q_ca, *q_cb;
     const rs_query_dev *qt;
     const uint32_t *hashes, *kfirst; const uint8_t *sym;
@@ -416,7 +418,8 @@ struct rs_args {
     const float *d0tab;                                  // d0_scale of metrics.rs:117-123 by point count (host powf)
     uint32_t node_count;
     uint32_t node_cap;                                   // graph nodes per candidate the kernel accepts (64 lanes; tests lower it to reach the fallback)
-    unsigned long long *counters;                        // [0] matches, [1] problems << 40 | points, [2] residue ints
+    unsigned long long *counters;                        // [0] matches, [RS_CNT_STRIDE] problems << 40 | points, [2 * RS_CNT_STRIDE] residue ints: 4 KB apart —
+                                                         // on one cache line the three returning atomics of 10^4 records queued behind each other (27 us per slot)
     uint32_t *flags;                                     // bit 0: a slot beyond the kernel's limits, bit 1: an output buffer too small
     rs_match_dev *matches; int32_t *residues; float *kx, *ky; uint64_t *koff; float *d0;
     uint64_t cap_matches, cap_res, cap_prob, cap_pts;

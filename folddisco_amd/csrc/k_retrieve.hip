@@ -18,6 +18,7 @@
 
 #define RS_EDGE_CAP 1024u
 #define RS_LIST_CAP 2048u
+#define RS_CAND_LDS 512u      // candidate pairs of a slot kept in LDS (more: read from global memory where they are needed)
 
 namespace {
 __device__ __forceinline__ uint64_t rs_bcast64(uint64_t v, uint32_t src) {
@@ -142,6 +143,10 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     __shared__ uint32_t s_aq[FD_WAVE], s_ar[FD_WAVE], s_qs[FD_WAVE], s_rs[FD_WAVE], s_rmx[FD_WAVE], s_rnm[FD_WAVE], s_rarg[FD_WAVE];
     __shared__ int32_t s_fh[FD_WAVE], s_pr[FD_WAVE];
     __shared__ uint32_t s_misc[2];
+    // what the chain below would otherwise fetch again and again with one dependent global load after the other (a slot is ONE wavefront: every
+    // load's latency is paid in full): the query's residue indices and the slot's candidate pairs (query residue, i, j), loaded once, in parallel
+    __shared__ uint32_t s_idx[FD_WAVE];
+    __shared__ uint32_t s_cq[RS_CAND_LDS], s_ci[RS_CAND_LDS], s_cj[RS_CAND_LDS];
     const uint32_t slot = A.order ? A.order[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
     const uint32_t f0 = A.seg_f[slot], F = A.seg_f[slot + 1] - f0;
     if (F == 0) return;
@@ -152,6 +157,11 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     const uint32_t st = A.cand[slot];
     const uint32_t r0 = A.db_res_off[st], Rt = A.db_res_off[st + 1] - r0;
     const uint32_t c0 = A.seg_c[slot], c1 = A.seg_c[slot + 1];
+    const bool cands_lds = c1 - c0 <= RS_CAND_LDS;
+    unsigned long long tstamp = A.dbg ? wall_clock64() : 0ull;
+    auto stamp = [&](int k) {      // FDGPU_RS_DBG: phase durations summed over the slots (100 MHz ticks)
+        if (A.dbg && lane == 0) { const unsigned long long now = wall_clock64(); atomicAdd(&A.dbg[k], now - tstamp); tstamp = now; }
+    };
     // ---- edges in the reference's scan order: (i, j) row-major, several bin pairs of one (i, j) in emission order
     for (uint32_t x = lane; x < F; x += FD_WAVE) {
         const uint32_t o = A.perm_f[f0 + x];
@@ -170,15 +180,21 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     }
     RS_SYNC();
     // query-map entry (first one holding the hash, like the reference's hash map) and symmetry flag of every edge
+    stamp(0);
+    // (the query's sorted hashes through s_a, free between the ranking above and the votes below: the bisection's six dependent loads stay in LDS)
+    const bool hs_lds = Q.n_hashes <= RS_LIST_CAP;
+    if (hs_lds) { for (uint32_t x = lane; x < Q.n_hashes; x += FD_WAVE) s_a[x] = A.hashes[Q.qh_off + x]; RS_SYNC(); }
     for (uint32_t x = lane; x < F; x += FD_WAVE) {
         const uint32_t h = s_h[x];
         const uint32_t *hs = A.hashes + Q.qh_off;
         uint32_t lo = 0, hi = Q.n_hashes;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (hs[mid] < h) lo = mid + 1; else hi = mid; }
-        const bool ok = lo < Q.n_hashes && hs[lo] == h;
+        if (hs_lds) { while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_a[mid] < h) lo = mid + 1; else hi = mid; } }
+        else { while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (hs[mid] < h) lo = mid + 1; else hi = mid; } }
+        const bool ok = lo < Q.n_hashes && (hs_lds ? s_a[lo] : hs[lo]) == h;
         s_k[x] = ok ? (int32_t)A.kfirst[Q.qh_off + lo] : -1;
         s_sym[x] = ok ? A.sym[Q.qh_off + lo] : (uint8_t)0;
     }
+    stamp(1);
     // ---- nodes in first-appearance order, adjacency rows
     uint32_t node_res = 0xffffffffu, n_nodes = 0;
     uint64_t adj = 0;
@@ -197,6 +213,13 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
         if (lane == 0) { s_es[e] = (uint8_t)ids[0]; s_et[e] = (uint8_t)ids[1]; }
     }
     RS_SYNC();
+    stamp(2);
+    // the edges' query-map fields (query residues of the pair, idf) take the place of i / j / hash, which nothing reads any more
+    for (uint32_t x = lane; x < F; x += FD_WAVE) {
+        const int32_t k = s_k[x];
+        if (k >= 0) { s_h[x] = A.map_qi[Q.map_off + (uint32_t)k]; s_i[x] = A.map_qj[Q.map_off + (uint32_t)k]; s_j[x] = __float_as_uint(A.map_idf[Q.map_off + (uint32_t)k]); }
+    }
+    RS_SYNC();
     // ---- strongly and weakly connected components (graph.rs:29-50)
     const uint64_t self = lane < n_nodes ? 1ull << lane : 0ull;
     uint64_t reach = adj | self, adjT = 0, reachT = 0;
@@ -213,7 +236,15 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     const bool wcc_rep = lane < n_nodes && (uint32_t)__builtin_ctzll(wcc) == lane && (uint32_t)__popcll(wcc) >= A.node_count && wcc != scc;
     const uint64_t ms = __ballot(scc_rep), mw = __ballot(wcc_rep);
     const uint32_t n_scc = (uint32_t)__popcll(ms), n_comp = n_scc + (uint32_t)__popcll(mw);
+    stamp(3);
     if (n_comp == 0) return;
+    if (lane < NQ) s_idx[lane] = A.indices[Q.idx_off + lane];
+    if (cands_lds)
+        for (uint32_t x = lane; x < c1 - c0; x += FD_WAVE) {
+            const fd_cand_rec cr = A.cands[A.perm_c[c0 + x]];
+            s_cq[x] = cr.qi; s_ci[x] = cr.i; s_cj[x] = cr.j;
+        }
+    if (A.dbg && lane == 0) atomicAdd(&A.dbg[7], 1ull);
     if (scc_rep) s_cm[fd_mbcnt(ms)] = scc;
     if (wcc_rep) s_cm[n_scc + fd_mbcnt(mw)] = wcc;
     RS_SYNC();
@@ -226,6 +257,14 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     RS_SYNC();
     const float *q_ca = A.q_ca + 3ull * Q.q_res0, *q_cb = A.q_cb + 3ull * Q.q_res0;
     const float *t_ca = A.db_ca + 3ull * r0, *t_cb = A.db_cb + 3ull * r0;
+    stamp(4);
+    // every component writes exactly one record: the slot claims its records and residue ints with ONE returning atomic each, here, long before
+    // their values are needed (the per-record claims of 10^4 records on one cache line were two thirds of the output phase)
+    unsigned long long mi0 = 0, rp0 = 0;
+    if (lane == 0) {
+        mi0 = atomicAdd(&A.counters[0], (unsigned long long)n_comp);
+        rp0 = atomicAdd(&A.counters[2 * RS_CNT_STRIDE], 2ull * NQ * n_comp);
+    }
     uint32_t n_emit = 0;       // records this slot has written (their order among the slot's records: components ascend)
     for (uint32_t ci = 0; ci < n_comp; ++ci) {
         const uint64_t C = s_cs[ci];
@@ -237,8 +276,8 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
             const uint32_t a = s_es[e], b = s_et[e];
             const int32_t k = s_k[e];
             if (!((C >> a) & 1ull) || !((C >> b) & 1ull) || k < 0) continue;
-            sub_idf += A.map_idf[Q.map_off + (uint32_t)k];
-            const uint32_t qi = A.map_qi[Q.map_off + (uint32_t)k], qj = A.map_qj[Q.map_off + (uint32_t)k];
+            sub_idf += __uint_as_float(s_j[e]);
+            const uint32_t qi = s_h[e], qj = s_i[e];
             const uint32_t ri = (uint32_t)__shfl((int)node_res, (int)a, FD_WAVE), rj = (uint32_t)__shfl((int)node_res, (int)b, FD_WAVE);
             uint32_t pq[2], pr[2];
             if (s_sym[e]) { pq[0] = min(qi, qj); pq[1] = max(qi, qj); pr[0] = min(ri, rj); pr[1] = max(ri, rj); }
@@ -258,6 +297,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
                 RS_SYNC();
             }
         }
+        stamp(8);
         // ---- per query residue: highest count, smallest target residue holding it
         uint32_t bq = 0, bc = 0, br = 0, nb = 0;
         for (uint32_t v = 0; v < nv; ++v) {
@@ -286,10 +326,11 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
         RS_SYNC();           // the vote arrays are free from here on
         if (lane < n_asg) { s_aq[lane] = my_aq; s_ar[lane] = my_ar; }
         RS_SYNC();
+        stamp(9);
         // ---- rescue votes (retrieve.rs:498-511): for a query residue without a target, the candidate pairs (query residue, i, j)
         // whose partner j some assignment mapped vote for i; the unique maximum (>= 2) joins
         for (uint32_t pos = 0; pos < NQ; ++pos) {
-            const uint32_t qi = A.indices[Q.idx_off + pos];
+            const uint32_t qi = s_idx[pos];
             uint32_t mx = 0, nmx = 0, arg = 0;
             if (__ballot(lane < n_asg && my_aq == qi) == 0ull && c1 > c0 && qi < Q.q_size) {
                 uint32_t n_t = 0;
@@ -298,10 +339,12 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
                     bool ok = false;
                     uint32_t iv = 0;
                     if (x < c1) {
-                        const fd_cand_rec cr = A.cands[A.perm_c[x]];
-                        iv = cr.i;
-                        if (cr.qi == qi && cr.i < Rt && cr.j < Rt)
-                            for (uint32_t k = 0; k < n_asg; ++k) ok |= s_ar[k] == cr.j;
+                        uint32_t c_q, c_i, c_j;
+                        if (cands_lds) { c_q = s_cq[x - c0]; c_i = s_ci[x - c0]; c_j = s_cj[x - c0]; }
+                        else { const fd_cand_rec cr = A.cands[A.perm_c[x]]; c_q = cr.qi; c_i = cr.i; c_j = cr.j; }
+                        iv = c_i;
+                        if (c_q == qi && c_i < Rt && c_j < Rt)
+                            for (uint32_t k = 0; k < n_asg; ++k) ok |= s_ar[k] == c_j;
                     }
                     const uint64_t m = __ballot(ok);
                     if (ok) { const uint32_t p = n_t + fd_mbcnt(m); if (p < RS_LIST_CAP) s_a[p] = iv; }
@@ -334,13 +377,14 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
             if (lane == 0) { s_rmx[pos] = mx; s_rnm[pos] = nmx; s_rarg[pos] = arg; }
         }
         RS_SYNC();
+        stamp(10);
         // ---- residue assignment + rescue, sequential as in the reference (retrieve.rs:430-516)
         if (lane < NQ) { s_fh[lane] = -1; s_pr[lane] = -1; }
         RS_SYNC();
         if (lane == 0) {
             uint32_t n_sc = 0;
             for (uint32_t pos = 0; pos < NQ; ++pos) {
-                const uint32_t qi = A.indices[Q.idx_off + pos];
+                const uint32_t qi = s_idx[pos];
                 int32_t mapped = -1;
                 for (uint32_t k = 0; k < n_asg; ++k) if (s_aq[k] == qi) { mapped = (int32_t)s_ar[k]; break; }
                 if (mapped >= 0) {
@@ -367,13 +411,13 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
         RS_SYNC();
         const uint32_t n_sc = s_misc[0];
         const bool same = s_misc[1] != 0;
+        stamp(11);
         // ---- outputs: one record, 2 NQ residues, one or two superposition problems of [CA, CB] points (retrieve.rs:761-767)
         const uint32_t nprob = same ? 1u : 2u, npts = 2u * n_asg + (same ? 0u : 2u * n_sc);
         unsigned long long mi = 0, rp = 0, pk = 0;
         if (lane == 0) {
-            mi = atomicAdd(&A.counters[0], 1ull);
-            rp = atomicAdd(&A.counters[2], 2ull * NQ);
-            pk = atomicAdd(&A.counters[1], ((unsigned long long)nprob << 40) | (unsigned long long)npts);
+            mi = mi0 + ci; rp = rp0 + 2ull * NQ * ci;
+            pk = atomicAdd(&A.counters[RS_CNT_STRIDE], ((unsigned long long)nprob << 40) | (unsigned long long)npts);
         }
         mi = rs_bcast64(mi, 0); rp = rs_bcast64(rp, 0); pk = rs_bcast64(pk, 0);
         const uint64_t p0 = pk >> 40, pt0 = pk & ((1ull << 40) - 1ull);
@@ -404,7 +448,10 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
         }
         ++n_emit;
         RS_SYNC();
+        stamp(12);
     }
+    stamp(5);
+    if (A.dbg && lane == 0) atomicAdd(&A.dbg[6], 1ull);
     if (lane == 0 && A.slot_matches) A.slot_matches[slot] = n_emit;
 }
 
