@@ -209,6 +209,9 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             cx, tot = ctxs[w], 0
             for c0 in starts[w::workers]:
                 ks = range(c0, min(c0 + chunk, len(queries)))
+                if first == 0:      # one fused library call per batch (fdgpu_query_batch)
+                    tot += len(query_batch(cx, ix, batch, qall, [(k, queries[k][1]) for k in ks], float(S_total), top_n, match_top)[2][0])
+                    continue
                 qms = make_query_maps(cx, qall, [(k, queries[k][1]) for k in ks], ix, float(S_total))
                 recs, off = count_query_maps(cx, ix, qms, None, total_structures=S_total, top_n=top_n, flat=True)
                 cl = top_cands(recs, off, match_top)
@@ -429,7 +432,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         "batched_with_matching_mt": None if not dtb2 else {
             "value": len(queries) * MT_REPS / dtb2, "ms_per_query": dtb2 / (len(queries) * MT_REPS) * 1e3, "host_threads": mt_workers, "chunk": mt_chunk,
             "queries": len(queries) * MT_REPS, "queries_per_s_by_threads_x_batch": {str(k): v for k, v in mt_all.items()},
-            "mode": "the same full batched query driven by several host threads with one context (stream + workspaces) each, sharing the resident index"},
+            "mode": "the same full batched query (one fdgpu_query_batch call per batch) driven by several host threads with one context (stream + workspaces) each, sharing the resident index"},
         "batched": {"value": len(queries) / dtb, "ms_per_query": dtb / len(queries) * 1e3, "chunk": 32, "avg_hits": hits_b / len(queries),
                     "mode": "prefilter only: make_query_map_batch + count_query_batch_top + all-gather"},
         "single": {"value": len(queries) / dt1, "ms_per_query": dt1 / len(queries) * 1e3, "mode": "prefilter only, one query per call"},
