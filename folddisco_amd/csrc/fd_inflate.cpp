@@ -1,0 +1,355 @@
+// fd_inflate.cpp — gzip members -> bytes, for the structure ingest (fd_ingest.cpp).
+//
+// Why not zlib: `.pdb.gz` ingest is bound by inflate (16 of 21 thread-seconds per 20,500 files with zlib 1.2.11's byte-at-a-time inner loop, 164-187
+// MB/s per thread).  This decoder is written from RFC 1951 / RFC 1952 for the case the ingest has — the whole compressed file in memory, the output
+// size known from the trailer — with the usual fast-path ingredients: a 64-bit bit buffer refilled eight bytes at a time, two-level decode tables
+// (11 bits for literals / lengths, 8 for distances) whose entries carry base value and extra-bit count, word-wise match copies into a buffer with
+// slack.  Anything it does not expect (reserved block type, over-subscribed or incomplete code, distance beyond the output, CRC / size mismatch,
+// truncated input) makes it return false and the caller falls back to zlib, which then reports the file the way it always did.
+// The reference reads gzip through the flate2 crate (src/structure/io/pdb.rs:79-124); a decoder's output is defined by the format.
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "fd_inflate.h"
+
+namespace {
+
+constexpr int LB = 11, DB = 8;         // primary table bits: literal / length codes, distance codes
+// table entry: bits 0-1 kind, 2-6 code bits to consume, 7-11 extra bits, 12-31 value (literal byte / base length / base distance / subtable offset)
+enum : uint32_t { K_LIT = 0, K_BASE = 1, K_END = 2, K_SUB = 3 };
+inline uint32_t mk(uint32_t kind, uint32_t nbits, uint32_t extra, uint32_t value) { return kind | (nbits << 2) | (extra << 7) | (value << 12); }
+
+const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+inline uint32_t rev_bits(uint32_t c, int n) {
+    uint32_t r = 0;
+    for (int k = 0; k < n; ++k) { r = (r << 1) | (c & 1u); c >>= 1; }
+    return r;
+}
+
+struct Table {
+    std::vector<uint32_t> e;
+    int pbits = 0;
+};
+
+// canonical Huffman code of lens[0 .. n) -> two-level table.  kind_of(sym) gives the entry's payload.  A COMPLETE code is required, except the
+// one-code distance alphabet RFC 1951 allows (a single code of length 1; its unused half decodes to an invalid entry).  -> false: not decodable here
+template <typename Payload>
+bool build_table(const uint8_t *lens, int n, int pbits, Table &T, bool allow_single, Payload payload) {
+    int count[16] = {0};
+    for (int s = 0; s < n; ++s) ++count[lens[s]];
+    count[0] = 0;
+    int used = 0, max_len = 0;
+    for (int l = 1; l <= 15; ++l) if (count[l]) { used += count[l]; max_len = l; }
+    if (used == 0) return false;
+    long left = 1;
+    for (int l = 1; l <= 15; ++l) { left = (left << 1) - count[l]; if (left < 0) return false; }
+    if (left != 0 && !(allow_single && used == 1 && count[1] == 1)) return false;
+    uint32_t next[16];
+    {
+        uint32_t code = 0;
+        for (int l = 1; l <= 15; ++l) { code = (code + (uint32_t)count[l - 1]) << 1; next[l] = code; }
+        next[1] = 0;      // (count[0] was zeroed: the recurrence above already gives 0 for l = 1)
+    }
+    // first pass over the long codes: how many bits the subtable of every primary prefix needs
+    T.pbits = pbits;
+    const uint32_t psize = 1u << pbits;
+    std::vector<uint8_t> sub_bits;
+    uint32_t next_l[16];
+    memcpy(next_l, next, sizeof next);
+    if (max_len > pbits) {
+        sub_bits.assign(psize, 0);
+        for (int s = 0; s < n; ++s) {
+            const int l = lens[s];
+            if (!l) continue;
+            const uint32_t r = rev_bits(next_l[l]++, l);
+            if (l > pbits) { const uint32_t p = r & (psize - 1); if (sub_bits[p] < l - pbits) sub_bits[p] = (uint8_t)(l - pbits); }
+        }
+    }
+    size_t total = psize;
+    std::vector<uint32_t> sub_off;
+    if (!sub_bits.empty()) {
+        sub_off.assign(psize, 0);
+        for (uint32_t p = 0; p < psize; ++p) if (sub_bits[p]) { sub_off[p] = (uint32_t)total; total += (size_t)1 << sub_bits[p]; }
+    }
+    T.e.assign(total, 0xffffffffu);       // 0xffffffff: no code (only reachable through the unused half of a one-code distance alphabet)
+    if (!sub_bits.empty())
+        for (uint32_t p = 0; p < psize; ++p) if (sub_bits[p]) T.e[p] = mk(K_SUB, (uint32_t)pbits, sub_bits[p], sub_off[p]);
+    for (int s = 0; s < n; ++s) {
+        const int l = lens[s];
+        if (!l) continue;
+        const uint32_t r = rev_bits(next[l]++, l);
+        uint32_t kind, extra, value;
+        if (!payload(s, &kind, &extra, &value)) return false;
+        if (l <= pbits) {
+            const uint32_t ent = mk(kind, (uint32_t)l, extra, value);
+            for (uint32_t k = r; k < psize; k += 1u << l) T.e[k] = ent;
+        } else {
+            const uint32_t p = r & (psize - 1), sb = sub_bits[p], hi = r >> pbits, ent = mk(kind, (uint32_t)(l - pbits), extra, value);
+            for (uint32_t k = hi; k < (1u << sb); k += 1u << (l - pbits)) T.e[sub_off[p] + k] = ent;
+        }
+    }
+    return true;
+}
+
+bool litlen_payload(int s, uint32_t *kind, uint32_t *extra, uint32_t *value) {
+    if (s < 256) { *kind = K_LIT; *extra = 0; *value = (uint32_t)s; return true; }
+    if (s == 256) { *kind = K_END; *extra = 0; *value = 0; return true; }
+    if (s > 285) return false;
+    *kind = K_BASE; *extra = LEN_EXTRA[s - 257]; *value = LEN_BASE[s - 257];
+    return true;
+}
+bool dist_payload(int s, uint32_t *kind, uint32_t *extra, uint32_t *value) {
+    if (s > 29) return false;
+    *kind = K_BASE; *extra = DIST_EXTRA[s]; *value = DIST_BASE[s];
+    return true;
+}
+
+struct Bits {
+    const uint8_t *p, *end;
+    uint64_t buf = 0;
+    int cnt = 0;        // valid bits in buf
+    bool over = false;  // a read past the end of the input happened
+    inline void refill() {
+        if (p + 8 <= end) {
+            uint64_t w;
+            memcpy(&w, p, 8);
+            buf |= w << cnt;
+            p += (63 - cnt) >> 3;
+            cnt |= 56;
+        } else {
+            while (cnt <= 56 && p < end) { buf |= (uint64_t)*p++ << cnt; cnt += 8; }
+        }
+    }
+    inline uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1ull)); }
+    inline void drop(int n) { if (n > cnt) { over = true; cnt = 0; buf = 0; } else { buf >>= n; cnt -= n; } }
+    inline uint32_t take(int n) { const uint32_t v = peek(n); drop(n); return v; }
+    // the symbol loop's forms: no test per field — it looks at cnt once per symbol (a negative count = the input ended inside the symbol)
+    inline void skip(int n) { buf >>= n; cnt -= n; }
+    inline uint32_t grab(int n) { const uint32_t v = peek(n); skip(n); return v; }
+    // position of the next unread byte after dropping the bits up to the next byte boundary
+    inline const uint8_t *byte_pos() { drop(cnt & 7); return p - (cnt >> 3); }
+};
+
+Table g_fixed_lit, g_fixed_dist;
+std::once_flag g_fixed_once;
+void make_fixed() {
+    uint8_t l[288];
+    for (int s = 0; s < 144; ++s) l[s] = 8;
+    for (int s = 144; s < 256; ++s) l[s] = 9;
+    for (int s = 256; s < 280; ++s) l[s] = 7;
+    for (int s = 280; s < 288; ++s) l[s] = 8;
+    // symbols 286 / 287 take part in the fixed code's construction but never occur: give them an END-less invalid payload
+    build_table(l, 288, LB, g_fixed_lit, false, [](int s, uint32_t *k, uint32_t *e, uint32_t *v) {
+        if (s > 285) { *k = K_SUB; *e = 0; *v = 0xfffffu; return true; }      // decodes as "invalid" below (a subtable pointer with 0 bits is never made otherwise)
+        return litlen_payload(s, k, e, v);
+    });
+    uint8_t d[32];
+    for (int s = 0; s < 32; ++s) d[s] = 5;
+    build_table(d, 32, DB, g_fixed_dist, false, [](int s, uint32_t *k, uint32_t *e, uint32_t *v) {
+        if (s > 29) { *k = K_SUB; *e = 0; *v = 0xfffffu; return true; }
+        return dist_payload(s, k, e, v);
+    });
+}
+
+// one deflate stream from B into out (appended); -> false on anything unexpected
+bool inflate_stream(Bits &B, std::string &out, size_t expect) {
+    const size_t start = out.size();
+    size_t cap = start + (expect ? expect : (size_t)(B.end - B.p) * 4) + 1024;
+    out.resize(cap);
+    uint8_t *base = (uint8_t *)&out[0], *o = base + start, *lim = base + cap - 320;      // 258 of a match + a word of over-copy + slack
+    auto grow = [&]() {
+        const size_t at = (size_t)(o - base);
+        cap = cap + cap / 2 + 65536;
+        out.resize(cap);
+        base = (uint8_t *)&out[0]; o = base + at; lim = base + cap - 320;
+    };
+    Table dyn_lit, dyn_dist;
+    for (;;) {
+        B.refill();
+        const uint32_t final = B.take(1), type = B.take(2);
+        if (B.over) return false;
+        if (type == 0) {
+            const uint8_t *q = B.byte_pos();
+            if (B.over || q + 4 > B.end) return false;
+            const uint32_t len = q[0] | (q[1] << 8), nlen = q[2] | (q[3] << 8);
+            if ((len ^ 0xffffu) != nlen) return false;
+            q += 4;
+            if (q + len > B.end) return false;
+            while ((size_t)(lim + 320 - o) < len + 320) grow();
+            memcpy(o, q, len);
+            o += len;
+            B.p = q + len; B.buf = 0; B.cnt = 0;
+        } else if (type == 1 || type == 2) {
+            const Table *TL, *TD;
+            if (type == 1) {
+                std::call_once(g_fixed_once, make_fixed);
+                TL = &g_fixed_lit; TD = &g_fixed_dist;
+            } else {
+                B.refill();
+                const uint32_t hlit = B.take(5) + 257, hdist = B.take(5) + 1, hclen = B.take(4) + 4;
+                if (hlit > 286 || hdist > 30) return false;
+                static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                uint8_t pl[19] = {0};
+                for (uint32_t k = 0; k < hclen; ++k) { B.refill(); pl[order[k]] = (uint8_t)B.take(3); }
+                if (B.over) return false;
+                Table pre;
+                if (!build_table(pl, 19, 7, pre, false, [](int s, uint32_t *k, uint32_t *e, uint32_t *v) { *k = K_LIT; *e = 0; *v = (uint32_t)s; return true; })) return false;
+                uint8_t lens[286 + 30];
+                uint32_t n = 0;
+                while (n < hlit + hdist) {
+                    B.refill();
+                    const uint32_t e = pre.e[B.peek(7)];
+                    if (e == 0xffffffffu) return false;
+                    B.drop((int)((e >> 2) & 31u));
+                    const uint32_t s = e >> 12;
+                    if (s < 16) { lens[n++] = (uint8_t)s; continue; }
+                    uint32_t rep, val = 0;
+                    if (s == 16) { if (!n) return false; val = lens[n - 1]; rep = 3 + B.take(2); }
+                    else if (s == 17) rep = 3 + B.take(3);
+                    else rep = 11 + B.take(7);
+                    if (n + rep > hlit + hdist) return false;
+                    memset(lens + n, (int)val, rep);
+                    n += rep;
+                }
+                if (B.over || lens[256] == 0) return false;
+                if (!build_table(lens, (int)hlit, LB, dyn_lit, false, litlen_payload)) return false;
+                // a block of literals only may send one distance code of zero length (RFC 1951 3.2.7): no table, any match is an error
+                bool any_dist = false;
+                for (uint32_t k = 0; k < hdist; ++k) any_dist = any_dist || lens[hlit + k];
+                if (any_dist) { if (!build_table(lens + hlit, (int)hdist, DB, dyn_dist, true, dist_payload)) return false; }
+                else { dyn_dist.e.assign((size_t)1 << DB, 0xffffffffu); dyn_dist.pbits = DB; }
+                TL = &dyn_lit; TD = &dyn_dist;
+            }
+            const uint32_t *L = TL->e.data(), *D = TD->e.data();
+            for (;;) {
+                if (o > lim) grow();
+                B.refill();
+                uint32_t e = L[B.peek(LB)];
+                if ((e & 3u) == K_SUB) {
+                    if (e == 0xffffffffu || ((e >> 7) & 31u) == 0) return false;
+                    B.skip(LB);
+                    e = L[(e >> 12) + B.peek((int)((e >> 7) & 31u))];
+                    if (e == 0xffffffffu || (e & 3u) == K_SUB) return false;
+                }
+                B.skip((int)((e >> 2) & 31u));
+                if ((e & 3u) == K_LIT) {
+                    *o++ = (uint8_t)(e >> 12);
+                    // up to two more literals on the bits that are left (a literal / length code is at most 15 bits: 3 x 15 <= 56)
+                    uint32_t e2 = L[B.peek(LB)];
+                    if ((e2 & 3u) == K_LIT) {
+                        B.skip((int)((e2 >> 2) & 31u));
+                        *o++ = (uint8_t)(e2 >> 12);
+                        e2 = L[B.peek(LB)];
+                        if ((e2 & 3u) == K_LIT) { B.skip((int)((e2 >> 2) & 31u)); *o++ = (uint8_t)(e2 >> 12); }
+                    }
+                    if (B.cnt < 0) return false;
+                    continue;
+                }
+                if ((e & 3u) == K_END) { if (B.cnt < 0) return false; break; }
+                // length (<= 5 extra bits), distance code (<= 15 bits), its extra bits (<= 13): 15 + 5 + 15 + 13 = 48 <= 56 bits since the refill
+                uint32_t len = (e >> 12) + B.grab((int)((e >> 7) & 31u));
+                uint32_t d = D[B.peek(DB)];
+                if ((d & 3u) == K_SUB) {
+                    if (d == 0xffffffffu || ((d >> 7) & 31u) == 0) return false;
+                    B.skip(DB);
+                    d = D[(d >> 12) + B.peek((int)((d >> 7) & 31u))];
+                    if (d == 0xffffffffu || (d & 3u) == K_SUB) return false;
+                }
+                if (d == 0xffffffffu) return false;
+                B.skip((int)((d >> 2) & 31u));
+                const uint32_t dist = (d >> 12) + B.grab((int)((d >> 7) & 31u));
+                if (B.cnt < 0 || dist > (size_t)(o - base) - start) return false;      // (matches never reach into an earlier member)
+                const uint8_t *src = o - dist;
+                uint8_t *dst = o;
+                o += len;
+                if (dist >= 8) {
+                    // words of eight: the source stays at least eight bytes behind the destination, up to seven bytes past the match are overwritten later
+                    do { uint64_t w; memcpy(&w, src, 8); memcpy(dst, &w, 8); src += 8; dst += 8; } while (dst < o);
+                } else if (dist == 1) {
+                    memset(dst, *src, len);
+                } else {
+                    do { *dst++ = *src++; } while (dst < o);
+                }
+            }
+        } else return false;
+        if (final) break;
+    }
+    out.resize((size_t)(o - base));
+    return true;
+}
+
+// CRC-32 of RFC 1952 (reflected polynomial 0xedb88320), sixteen bytes per step through sixteen tables made on first use (zlib 1.2.11's
+// four-table loop runs at 1 GB/s: a third of this decoder's time)
+uint32_t g_crc_tab[16][256];
+std::once_flag g_crc_once;
+void make_crc() {
+    for (uint32_t b = 0; b < 256; ++b) {
+        uint32_t c = b;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+        g_crc_tab[0][b] = c;
+    }
+    for (uint32_t b = 0; b < 256; ++b)
+        for (int t = 1; t < 16; ++t) g_crc_tab[t][b] = (g_crc_tab[t - 1][b] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][b] & 0xffu];
+}
+uint32_t crc32_fast(const uint8_t *p, size_t n) {
+    std::call_once(g_crc_once, make_crc);
+    uint32_t c = 0xffffffffu;
+    const uint32_t(*T)[256] = g_crc_tab;
+    while (n >= 16) {
+        uint32_t a, b, d, e;
+        memcpy(&a, p, 4); memcpy(&b, p + 4, 4); memcpy(&d, p + 8, 4); memcpy(&e, p + 12, 4);
+        a ^= c;
+        c = T[15][a & 0xffu] ^ T[14][(a >> 8) & 0xffu] ^ T[13][(a >> 16) & 0xffu] ^ T[12][a >> 24] ^
+            T[11][b & 0xffu] ^ T[10][(b >> 8) & 0xffu] ^ T[9][(b >> 16) & 0xffu] ^ T[8][b >> 24] ^
+            T[7][d & 0xffu] ^ T[6][(d >> 8) & 0xffu] ^ T[5][(d >> 16) & 0xffu] ^ T[4][d >> 24] ^
+            T[3][e & 0xffu] ^ T[2][(e >> 8) & 0xffu] ^ T[1][(e >> 16) & 0xffu] ^ T[0][e >> 24];
+        p += 16; n -= 16;
+    }
+    while (n--) c = (c >> 8) ^ T[0][(c ^ *p++) & 0xffu];
+    return ~c;
+}
+
+}  // namespace
+
+bool fd_gunzip(const uint8_t *in, size_t n, std::string *out) {
+    out->clear();
+    size_t at = 0;
+    bool any = false;
+    while (at + 18 <= n && in[at] == 0x1f && in[at + 1] == 0x8b) {
+        if (in[at + 2] != 8) return false;
+        const uint8_t flg = in[at + 3];
+        if (flg & 0xe0) return false;
+        size_t h = at + 10;
+        if (flg & 4) { if (h + 2 > n) return false; const size_t xl = in[h] | (in[h + 1] << 8); h += 2 + xl; }
+        if (flg & 8) { while (h < n && in[h]) ++h; ++h; }
+        if (flg & 16) { while (h < n && in[h]) ++h; ++h; }
+        if (flg & 2) h += 2;
+        if (h + 8 > n) return false;
+        // the size a single-member file's trailer announces (mod 2^32) sizes the output buffer; a wrong guess only costs a reallocation
+        const size_t tail = n - 4;
+        const uint32_t isize_guess = (uint32_t)in[tail] | ((uint32_t)in[tail + 1] << 8) | ((uint32_t)in[tail + 2] << 16) | ((uint32_t)in[tail + 3] << 24);
+        Bits B;
+        B.p = in + h; B.end = in + n;
+        const size_t before = out->size();
+        // (deflate cannot expand beyond 1032 : 1: a trailer that claims more is damaged, and must not size an allocation)
+        const size_t max_out = (n - h) * 1032 + 1024;
+        if (!inflate_stream(B, *out, any ? 0 : (isize_guess < max_out ? isize_guess : max_out))) return false;
+        const uint8_t *q = B.byte_pos();
+        if (B.over || q + 8 > in + n) return false;
+        const uint32_t crc = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+        const uint32_t isz = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
+        const size_t produced = out->size() - before;
+        if ((uint32_t)produced != isz) return false;
+        if (crc32_fast((const uint8_t *)out->data() + before, produced) != crc) return false;
+        at = (size_t)(q + 8 - in);
+        any = true;
+    }
+    return any;       // (bytes behind the last member that do not start another one are ignored, as zlib's gzread ignores them)
+}

@@ -33,6 +33,7 @@
 
 #include "../../include/fdgpu.h"
 #include "fd_fcz.h"
+#include "fd_inflate.h"
 
 namespace {
 
@@ -154,6 +155,19 @@ bool read_all(const char *path, std::string *out) {
             close(fd);
             out->resize(got);
             return true;
+        }
+        // gzip: the whole file through the ingest's own decoder (fd_inflate.cpp, ~2.5x zlib's inflate on PDB text); anything it declines
+        // (or cannot read) goes through zlib below, which reports damaged files the way it always did
+        if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 18 && !(getenv("FDGPU_ZLIB") && getenv("FDGPU_ZLIB")[0] == '1')) {
+            std::string comp((size_t)sb.st_size, '\0');
+            size_t got = 0;
+            while (got < comp.size()) {
+                const ssize_t r = read(fd, &comp[got], comp.size() - got);
+                if (r <= 0) break;
+                got += (size_t)r;
+            }
+            if (got == comp.size() && fd_gunzip((const uint8_t *)comp.data(), comp.size(), out)) { close(fd); return true; }
+            out->clear();
         }
         close(fd);
     }
@@ -423,6 +437,17 @@ int pack_parsed(const std::vector<Compact> &parts, uint64_t max_residue, fd_pars
 // where the ingest threads spend their time, summed over the threads of every fdgpu_parse_structures call of the process:
 // [0] read + inflate (zlib), [1] text -> atom records, [2] CompactStructure::build, [3] files, [4] inflated bytes
 static std::atomic<uint64_t> g_ingest_ns[5];
+// the ingest's gzip decoder on a buffer (tests): FDGPU_EINVAL when it declines the input (the ingest then reads the file through zlib)
+extern "C" int fdgpu_debug_gunzip(const uint8_t *in, uint64_t n, uint8_t **out, uint64_t *n_out) {
+    if (!in || !out || !n_out) return FDGPU_EINVAL;
+    std::string o;
+    if (!fd_gunzip(in, (size_t)n, &o)) return FDGPU_EINVAL;
+    uint8_t *p = (uint8_t *)malloc(o.size() ? o.size() : 1);
+    if (!p) return FDGPU_ENOMEM;
+    memcpy(p, o.data(), o.size());
+    *out = p; *n_out = o.size();
+    return FDGPU_OK;
+}
 extern "C" void fdgpu_ingest_stats(double out[5], int reset) {
     for (int k = 0; k < 5; ++k) { if (out) out[k] = k < 3 ? (double)g_ingest_ns[k].load() * 1e-9 : (double)g_ingest_ns[k].load(); if (reset) g_ingest_ns[k] = 0; }
 }

@@ -433,6 +433,10 @@ void fdgpu_parsed_free(fd_parsed *p);
 /* thread-seconds the ingest spent so far (summed over the threads of all fdgpu_parse_structures calls of the process): out[0] read + inflate,
  * out[1] text -> atom records, out[2] CompactStructure::build, out[3] files, out[4] inflated bytes; reset != 0 clears the counters */
 void fdgpu_ingest_stats(double out[5], int reset);
+/* The ingest's own gzip decoder (csrc/fd_inflate.cpp; the reference reads .gz through the flate2 crate, src/structure/io/pdb.rs:79-124) on a
+ * buffer, for tests: every member of in[0 .. n) concatenated into *out (fdgpu_free).  FDGPU_EINVAL = the decoder declines the input (damaged, or
+ * a code it does not handle); fdgpu_parse_structures then reads that file through zlib.  FDGPU_ZLIB=1 in the environment sends every file there. */
+int fdgpu_debug_gunzip(const uint8_t *in, uint64_t n, uint8_t **out, uint64_t *n_out);
 
 /* Foldcomp input (reference: src/structure/io/fcz.rs — FoldcompDbReader::new :41-74, read_single_structure_by_id :203-230,
  * and the vendored decoder behind foldcomp_process, lib/foldcomp/foldcompffi.cpp).  fdgpu_foldcomp_decode turns one database

@@ -447,3 +447,71 @@ def test_fixed_format_number_fields_parse_like_strtof(tmp_path):
     w = np.asarray(want, np.float32)[:len(got)]
     assert len(got) >= len(want) - 1
     assert np.array_equal(got.view(np.uint32), w.view(np.uint32))
+
+
+def test_own_gzip_decoder_equals_zlib(tmp_path, monkeypatch):
+    """The ingest's gzip decoder (csrc/fd_inflate.cpp, written from RFC 1951 / 1952) returns exactly what zlib returns: stored, fixed and dynamic
+    blocks at every level and strategy, sync flushes, several members, optional header fields, trailing bytes; damaged input is DECLINED (the
+    ingest then goes through zlib), never decoded to something else.  And the ingest reads the same structures through either path."""
+    import ctypes as C
+    import gzip
+    import struct
+    import zlib
+    from folddisco_amd import _lib
+    from folddisco_amd.structure import read_compact_structures
+    L = _lib.load()
+
+    def gunzip(b):
+        buf = (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b or b"\0")
+        out, n = C.POINTER(C.c_uint8)(), C.c_uint64()
+        if L.fdgpu_debug_gunzip(buf, len(b), C.byref(out), C.byref(n)):
+            return None
+        r = bytes(C.string_at(out, n.value))
+        L.fdgpu_free(out)
+        return r
+
+    rng = np.random.default_rng(1)
+    pdb = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "query", "4CHA.pdb"), "rb").read()
+    line = b"ATOM      1  N   MET A   1      12.345  23.456  34.567  1.00 50.00           N  \n"
+    texts = [b"", b"a", b"hello hello hello hello", bytes(rng.integers(0, 256, 100000, dtype=np.uint8)), bytes(rng.integers(0, 4, 300000, dtype=np.uint8)),
+             b"A" * 100000, line * 5000, pdb, pdb * 5, bytes(rng.integers(65, 70, 50, dtype=np.uint8)) * 3000]
+    n_ok = 0
+    for t in texts:
+        for lvl in (0, 1, 4, 6, 9):
+            assert gunzip(gzip.compress(t, compresslevel=lvl)) == t, (len(t), lvl)
+            n_ok += 1
+        for strat in (zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY, zlib.Z_FILTERED):
+            co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, strat)
+            assert gunzip(co.compress(t) + co.flush()) == t, (len(t), strat)
+            n_ok += 1
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        z = co.compress(t[:len(t) // 2]) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(t[len(t) // 2:]) + co.flush()
+        assert gunzip(z + gzip.compress(b"second member " + t[:1000])) == t + b"second member " + t[:1000]
+        assert gunzip(z + b"trailing bytes") == t
+    assert n_ok == 90
+    z = gzip.compress(b"payload payload payload")
+    hdr = bytearray(z[:10])
+    hdr[3] = 4 | 8 | 16
+    assert gunzip(bytes(hdr) + struct.pack("<H", 5) + b"extra" + b"name.pdb\0" + b"a comment\0" + z[10:]) == b"payload payload payload"
+    t = line * 5000
+    z = bytearray(gzip.compress(t))
+    declined = 0
+    for k in range(0, len(z), max(1, len(z) // 300)):
+        zz = bytearray(z)
+        zz[k] ^= 0x55
+        r = gunzip(bytes(zz))
+        declined += r is None
+        assert r is None or r == t, k
+    assert declined > 250
+    assert gunzip(bytes(z[:len(z) // 2])) is None and gunzip(b"\x1f\x8b" + b"\0" * 30) is None and gunzip(b"not gzip at all, plain text....") is None
+    # the ingest: same structure through the own decoder and through zlib, and a damaged file fails the same way through both
+    p = tmp_path / "q.pdb.gz"
+    p.write_bytes(gzip.compress(pdb))
+    bad = tmp_path / "bad.pdb.gz"
+    bad.write_bytes(gzip.compress(pdb)[:2000])
+    a = read_compact_structures([str(p), str(bad)], threads=1)
+    monkeypatch.setenv("FDGPU_ZLIB", "1")
+    b = read_compact_structures([str(p), str(bad)], threads=1)
+    monkeypatch.delenv("FDGPU_ZLIB")
+    assert list(a[1]) == list(b[1])
+    assert np.array_equal(np.asarray(a[0][0].ca_xyz), np.asarray(b[0][0].ca_xyz)) and len(a[0][0].ca_xyz) > 200
