@@ -260,9 +260,14 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
         if (!full) okj = okj && aaj_l < 20u && (A.resname_std == nullptr || A.resname_std[jl]) && ((Sx.aa2_mask >> aaj_l) & 1u);
         if (A.cj_mask && okj) { const uint32_t bit = A.mask_off[slot] + (jl - r0); okj = (A.cj_mask[bit >> 5] >> (bit & 31u)) & 1u; }
         const uint64_t okm = __ballot(okj);
-        const uint32_t nj = (j_hi - jb) < FD_WAVE ? (j_hi - jb) : FD_WAVE;
-        for (uint32_t k = 0; k < nj; ++k) {
-            if ((okm >> k) & 1ull) {   // wave-uniform
+        // only the partners that can pass at all (their own filters: ~1 in 5 for a motif query's residue types) are walked: the scan is
+        // instruction-bound and the scalar bookkeeping of a skipped partner was a fifth of a visited one's
+        const bool last_blk = jb + FD_WAVE >= j_hi;
+        uint64_t todo = okm;
+        while (todo) {
+            const uint32_t k = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            {
                 const uint32_t j = jb + k;
                 const uint32_t aaj = (uint32_t)__builtin_amdgcn_readlane((int)aaj_l, (int)k);
                 const fd_v3 caj = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cj.x), (int)k)),
@@ -270,8 +275,11 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cj.z), (int)k))};
                 bool pass = false;
                 if (act && i != j && aaj < 32u && ((row_mask >> aaj) & 1u)) {
-                    const float d = fd_dist(cai, caj);
-                    if (d <= A.cutoff) {
+                    // the cutoff on the SQUARED distance (d2_max = the largest f32 whose square root is <= the cutoff: the same decision as sqrt(d2) <= cutoff
+                    // without a correctly rounded square root per pair test — the scan is instruction-bound: ~40 instructions per partner residue)
+                    const float d2 = fd_dist2(cai, caj);
+                    if (d2 <= A.C.d2_max) {
+                        const float d = fd_sqrtf(d2);
                         // branch-free over the pair's own list: a short-circuit chain costs one LDS round trip per entry
                         uint32_t any = 0;
                         if (big) {
@@ -300,14 +308,19 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                     qn += (uint32_t)__popcll(m);
                 }
             }
-            const bool last = (jb + FD_WAVE >= j_hi) && (k + 1 == nj);
-            while (qn >= FD_WAVE || (last && qn)) {
+            while (qn >= FD_WAVE) {
                 __syncthreads();
-                uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
-                qn -= n;
-                match_drain<EMIT>(A, Sx, q + qn, n, slot, r0, r1, i0, st_tab, dist_tab, tab);
+                qn -= FD_WAVE;
+                match_drain<EMIT>(A, Sx, q + qn, FD_WAVE, slot, r0, r1, i0, st_tab, dist_tab, tab);
                 __syncthreads();
             }
+        }
+        while (last_blk && qn) {      // the item's last partners are behind it: what is left in the queue
+            __syncthreads();
+            const uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
+            qn -= n;
+            match_drain<EMIT>(A, Sx, q + qn, n, slot, r0, r1, i0, st_tab, dist_tab, tab);
+            __syncthreads();
         }
     }
 }
