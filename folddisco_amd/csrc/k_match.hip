@@ -246,6 +246,10 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
         if (big) for (uint32_t a2 = 0; a2 < 32u; ++a2) row_mask |= ((s_start[aai * 32u + a2] & 255u) ? 1u : 0u) << a2;
         else for (uint32_t a2 = 0; a2 < 32u; ++a2) row_mask |= (s_start[aai * 32u + a2 + 1] > s_start[aai * 32u + a2] ? 1u : 0u) << a2;
     }
+    // the loop's two thresholds in VECTOR registers: the kernel is out of scalar registers (the argument block's pointers), and a uniform value the
+    // compiler keeps "in the arguments" is a scalar memory load + wait per partner residue
+    float d2_max_v = A.C.d2_max, ca_window_v = Sx.ca_window;
+    asm volatile("" : "+v"(d2_max_v), "+v"(ca_window_v));
     uint32_t qn = 0;   // wave-uniform
     // j in blocks of 64: one coalesced load of (aa, CA) per block, then wave-uniform broadcasts (v_readlane)
     const uint32_t j_lo = A.j_span ? A.wi_j0[w] : r0;
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                     // the cutoff on the SQUARED distance (d2_max = the largest f32 whose square root is <= the cutoff: the same decision as sqrt(d2) <= cutoff
                     // without a correctly rounded square root per pair test — the scan is instruction-bound: ~40 instructions per partner residue)
                     const float d2 = fd_dist2(cai, caj);
-                    if (d2 <= A.C.d2_max) {
+                    if (d2 <= d2_max_v) {
                         const float d = fd_sqrtf(d2);
                         // branch-free over the pair's own list: a short-circuit chain costs one LDS round trip per entry
                         uint32_t any = 0;
@@ -296,8 +300,10 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                                 for (uint32_t e = v_lo; e < v_hi; ++e) { const float2 w2 = Sx.iv[e]; any |= (uint32_t)(d >= w2.x && d <= w2.y); }
                             }
                         } else {
+                            // (two loops: through the generic pointer dist_tab these would be flat loads even when the list is in LDS)
                             const uint32_t e_lo = s_start[aai * 32u + aaj], e_hi = s_start[aai * 32u + aaj + 1];
-                            for (uint32_t e = e_lo; e < e_hi; ++e) any |= (uint32_t)(fd_fabsf(d - dist_tab[e]) < Sx.ca_window);
+                            if (staged) for (uint32_t e = e_lo; e < e_hi; ++e) any |= (uint32_t)(fd_fabsf(d - s_d_buf[e]) < ca_window_v);
+                            else for (uint32_t e = e_lo; e < e_hi; ++e) any |= (uint32_t)(fd_fabsf(d - Sx.aad_dist[e]) < ca_window_v);
                         }
                         pass = any != 0;
                     }
