@@ -1964,13 +1964,14 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         n_tiles += (db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]] + FD_WAVE - 1) / FD_WAVE;
     }
     // many candidates (a batch of motif queries): spans of 256 partners cap the longest work items — the launch ends with its slowest
-    // wavefront (32 queries x 32 candidates: 218 -> 126 us; 128 and 512 measured 148 and 156)
+    // wavefront (32 queries x 32 candidates: 218 -> 126 us; 128 and 512 measured 148 and 156); from ~12 k tiles (128 queries x 32 candidates:
+    // 22 k) the launch is rounds of items and fewer, longer ones win: 351 us at 256, 333 at 384, 325 at 512, 363 uncut
     // large queries (whole-structure: the window test passes nearly every pair inside the cutoff, so a work item's time is its number of close
     // pairs x one descriptor + hash each): spans of 32 partners — a diagonal block of 64 x 128 residues was 128 drains on ONE wavefront and the
     // launch lasted as long as its slowest wavefronts (first scan of the top 20 of a 300-residue query: 5.1 ms at 128, 4.4 at 64, 3.7 at 32 and 16)
     uint64_t max_aad_q = 0;
     for (uint64_t t = 0; t < n_queries; ++t) max_aad_q = std::max<uint64_t>(max_aad_q, qs[t].n_aad);
-    const uint32_t j_span = !n_tiles ? 0u : max_aad_q > 4096 ? 32u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : 256u;
+    const uint32_t j_span = !n_tiles ? 0u : max_aad_q > 4096 ? 32u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : n_tiles < 12288 ? 256u : 512u;
     TB.j_span = j_span;
     std::vector<uint32_t> wc, wi, wq, wj;
     // a one-off block (a batch of motif queries: 18 k work items per 128 queries) gets its work items written on the DEVICE (k_mp_items): the host
