@@ -79,7 +79,7 @@ def cmd_index(a):
     t_all = time.perf_counter()
     ctx = fd.Context(a.device)
     # The reference walks its input in chunks and parses / hashes a chunk in parallel (controller/mod.rs:282-348).  Here a host thread
-    # ingests chunk k + 1 (native, multi-threaded: csrc/fd_ingest.cpp; a structure above --max-residue keeps its id but has no hashes,
+    # ingests chunk k + 1 (native, multi-threaded: csrc/fd_ingest.cpp; a structure above the reference's hard-wired 65,535 residues keeps its id but has no hashes,
     # nres 0 and plddt 0, controller/mod.rs:313-318) WHILE the GPU builds the sub-index of chunk k (one fdgpu_index_build call, < 2^32 residue
     # pairs); the sub-indices stay resident in HBM and are concatenated per hash on the device (fdgpu_index_merge, in rounds of 64), so
     # the index crosses the bus once, in the reference's on-disk layout.
@@ -123,17 +123,23 @@ def _default_index_prefix(pdbs: str) -> str:
     return p.replace("_foldcomp", "_folddisco") if p.endswith("_foldcomp") else p + "_folddisco"
 
 
+# The reference's skip threshold is NOT its -n flag: Folddisco::new hard-wires max_residue = DEFAULT_MAX_RESIDUE = 65535
+# (controller/mod.rs:40,124), set_max_residue (mod.rs:189) has no caller, and the test at mod.rs:313 therefore compares with 65535 whatever
+# -n says; -n/--residue (cli/main.rs:42, default 50000) only lands in PREFIX.type (build_index.rs:222).  A structure of 50,001 ... 65,535
+# residues is indexed by the reference, so it is indexed here.
+REF_SKIP_MAX_RESIDUE = 65535
+
+
 def _ingest(a, structure, chunk, pos0):
     """native ingest of one chunk of the input (files, or entries pos0 ... of the Foldcomp database) + the reference's warnings"""
     if a.fc is not None:
-        ps, nres_c, plddt_c, raw, ok = structure.read_packed(a.fc_keys[pos0:pos0 + len(chunk)], threads=a.threads, max_residue=a.max_residue, foldcomp=a.fc)
+        ps, nres_c, plddt_c, raw, ok = structure.read_packed(a.fc_keys[pos0:pos0 + len(chunk)], threads=a.threads, max_residue=REF_SKIP_MAX_RESIDUE, foldcomp=a.fc)
     else:
-        ps, nres_c, plddt_c, raw, ok = structure.read_packed(chunk, threads=a.threads, max_residue=a.max_residue)
+        ps, nres_c, plddt_c, raw, ok = structure.read_packed(chunk, threads=a.threads, max_residue=REF_SKIP_MAX_RESIDUE)
     for k in np.nonzero(ok == 0)[0]:
         print(f"[WARN] {chunk[k]} could not be read. Skipping", file=sys.stderr)
-    if a.max_residue > 0:
-        for k in np.nonzero(raw > a.max_residue)[0]:
-            print(f"[WARN] {chunk[k]} has too many residues. Skipping", file=sys.stderr)
+    for k in np.nonzero(raw > REF_SKIP_MAX_RESIDUE)[0]:
+        print(f"[WARN] {chunk[k]} has too many residues. Skipping", file=sys.stderr)
     return ps, nres_c, plddt_c, raw, ok
 
 
@@ -318,7 +324,7 @@ def main(argv=None):
     pi.add_argument("-a", "--angle", type=int, default=0)              # number of angle bins (0 -> 4)
     pi.add_argument("--multiple-bins", default=None)                   # d1-a1,d2-a2 e.g. 16-4,8-3 (build_index.rs:45)
     pi.add_argument("-g", "--grid", type=float, default=20.0)          # CA cutoff
-    pi.add_argument("-n", "--max-residue", type=int, default=50000)
+    pi.add_argument("-n", "--residue", "--max-residue", dest="max_residue", type=int, default=50000)   # cli/main.rs:42: written to PREFIX.type only; the skip threshold is the reference's hard-wired 65535 (REF_SKIP_MAX_RESIDUE)
     pi.add_argument("-r", "--recursive", action="store_true")
     pi.add_argument("--id", default="relpath")                          # pdb | uniprot | afdb | relpath | abspath | basename ... (build_index.rs:40)
     pi.add_argument("-v", "--verbose", action="store_true")

@@ -38,3 +38,28 @@ def packed_to_oracle_structs(ps):
 def synthetic_packed(n_struct, seed, lengths=None):
     from folddisco_amd import synth
     return synth.to_packed(synth.generate(n_struct, seed=seed, lengths=lengths))
+
+
+def write_sparse_pdb(path, n_res, seed=0):
+    """A PDB file of n_res complete residues + one trailing atom of a further residue (the reference's raw residue count — what its skip test reads,
+    controller/mod.rs:313 — is therefore n_res + 1, the compact structure holds n_res) (N, CA, C, CB) laid out as PAIRS of residues 6 A apart on a 30 A grid: every residue has exactly
+    one partner inside the 20 A cutoff (residue k pairs with k ^ 1), so a structure of 65,535 residues emits n_res ordered pairs.
+    Residue numbers wrap at 9999 (the reference splits residues on a CHANGE of the serial, structure/core.rs:104-200)."""
+    rng = np.random.default_rng(seed)
+    names = ["ALA", "SER", "HIS", "ASP", "LEU", "LYS", "GLU", "VAL"]
+    side = int(np.ceil((n_res / 2.0) ** (1.0 / 3.0))) + 1
+    lines, atom = [], 1
+    for k in range(n_res):
+        cell, half = divmod(k, 2)
+        cx, r = divmod(cell, side * side)
+        cy, cz = divmod(r, side)
+        base = np.array([cx * 30.0, cy * 30.0, cz * 30.0 + half * 6.0]) + rng.uniform(-0.4, 0.4, 3)
+        rn = names[int(rng.integers(len(names)))]
+        for an, d in ((" N  ", (-1.2, 0.6, 0.1)), (" CA ", (0.0, 0.0, 0.0)), (" C  ", (1.3, 0.7, -0.2)), (" CB ", (0.1, -1.1, 1.0 + 0.2 * half))):
+            x, y, z = base + np.array(d)
+            lines.append("ATOM  %5d %s %s A%4d    %8.3f%8.3f%8.3f  1.00%6.2f           %s" % (atom % 100000, an, rn, k % 9999 + 1, x, y, z, 50.0 + (k % 40), an.strip()[0]))
+            atom += 1
+    lines.append("ATOM  %5d  N   GLY A%4d    %8.3f%8.3f%8.3f  1.00 10.00           N" % (atom % 100000, n_res % 9999 + 1, -50.0, -50.0, -50.0))   # the flush needs a next atom
+    lines.append("END")
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")

@@ -1277,3 +1277,61 @@ def test_two_contexts_share_one_resident_index(env):
     ctx2.close()
     assert not errs, errs
     assert all(x == want for x in out["a"]) and all(x == want for x in out["b"])
+
+
+def test_cli_indexes_structures_between_dash_n_and_65535_like_the_reference(tmp_path):
+    """`index -n 50000` (the default): the reference never applies -n — its skip test reads the hard-wired 65535 (src/controller/mod.rs:40,124,313;
+    set_max_residue mod.rs:189 has no caller) and -n only lands in PREFIX.type (src/cli/main.rs:42, build_index.rs:222).  Structures whose raw
+    residue count is 50,002 and 65,535 must therefore have postings, one of 65,536 must keep its id with nres 0 / plddt 0 and no postings.
+    Expected index: the oracle's pair feature + hash on the pairs of the sparse layout (residue k pairs with k ^ 1 and with nothing else:
+    checked against the oracle's full O(R^2) enumeration on the small structure), posting lists built by the oracle's table builder."""
+    import subprocess
+    import sys
+    from folddisco_amd import indexio
+    from tests.helpers import write_sparse_pdb
+    d = tmp_path / "big"
+    d.mkdir()
+    sizes = [600, 50001, 65534, 65535]                       # raw residue counts 601, 50002, 65535, 65536
+    for k, n in enumerate(sizes):
+        write_sparse_pdb(str(d / f"s{k}.pdb"), n, seed=10 + k)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env_ = dict(os.environ, PYTHONPATH=root)
+    pre = str(tmp_path / "big_folddisco")
+    r = subprocess.run([sys.executable, "-m", "folddisco_amd", "index", "-p", str(d), "-i", pre, "-t", "4", "--residue", "50000"], cwd=tmp_path, env=env_,
+                       capture_output=True, text=True, check=True)
+    assert r.stderr.count("has too many residues. Skipping") == 1 and "s3.pdb has too many residues" in r.stderr
+    # expected lists
+    lists, nres_want, plddt_want = [], [], []
+    for k, n in enumerate(sizes):
+        s = oracle.read_pdb(str(d / f"s{k}.pdb"))
+        raw = s.ptr.contents.num_residues_raw
+        assert raw == n + 1 and s.n == n
+        if raw > 65535:
+            lists.append(np.zeros(0, np.uint32))
+            nres_want.append(0)
+            plddt_want.append(np.float32(0.0))
+            continue
+        hs = []
+        for i in range(n):
+            ph = oracle.pair_hash(s, i, i ^ 1) if (i ^ 1) < n else None
+            if ph is not None:
+                hs.append(ph[0])
+        h = np.unique(np.array(hs, np.uint32))
+        if k == 0:
+            assert np.array_equal(h, np.unique(oracle.hash_structure(s)))      # the layout's claim: no pair but (k, k ^ 1) inside the cutoff
+        lists.append(h)
+        nres_want.append(n)
+        plddt_want.append(np.float32(s.avg_plddt()))
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.uint64)
+    oix = oracle.build_index_from_lists(np.concatenate(lists), off)
+    v, h, o = indexio.read_index_files(pre)
+    assert np.array_equal(h, oix.hashes()) and np.array_equal(o, oix.offsets()) and np.array_equal(v, oix.values())
+    assert len(lists[1]) > 100 and len(lists[2]) > 100
+    ids = set()
+    for hh in oix.hashes()[:: max(1, oix.H // 64)]:
+        ids |= set(int(x) for x in oix.entries(int(hh)))
+    assert ids <= {0, 1, 2} and {1, 2} <= ids                 # ids 1 and 2 (50,002 and 65,535 raw residues) are in the posting lists, id 3 never
+    look = [l.rstrip("\n").split("\t") for l in open(pre + ".lookup")]
+    assert [int(l[2]) for l in look] == nres_want
+    assert [np.float32(float(l[3])).tobytes() for l in look] == [np.float32(x).tobytes() for x in plddt_want]
+    assert indexio.load_type(pre + ".type")["max_residue"] == 50000

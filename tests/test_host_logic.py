@@ -515,3 +515,43 @@ def test_own_gzip_decoder_equals_zlib(tmp_path, monkeypatch):
     monkeypatch.delenv("FDGPU_ZLIB")
     assert list(a[1]) == list(b[1])
     assert np.array_equal(np.asarray(a[0][0].ca_xyz), np.asarray(b[0][0].ca_xyz)) and len(a[0][0].ca_xyz) > 200
+
+
+def test_cli_skip_threshold_is_the_references_hard_wired_65535(tmp_path):
+    """The reference skips a structure when Structure.num_residues > 65535 — Folddisco::new sets max_residue = DEFAULT_MAX_RESIDUE
+    (src/controller/mod.rs:40,124), set_max_residue (mod.rs:189) has no caller, the test is mod.rs:313 — and its -n/--residue flag
+    (src/cli/main.rs:42, default 50000) only lands in PREFIX.type (build_index.rs:222).  The CLI's ingest step must do the same: raw counts
+    of 50,002 and 65,535 are indexed, 65,536 is skipped (id kept, nres 0, plddt 0), whatever -n says; the oracle agrees."""
+    import argparse
+    import inspect
+    import oracle
+    from folddisco_amd import __main__ as cli, indexio, structure
+    from tests.helpers import write_sparse_pdb
+    sizes = [30, 50001, 65534, 65535]                       # raw residue counts 31, 50002, 65535, 65536
+    paths = []
+    for k, n in enumerate(sizes):
+        paths.append(str(tmp_path / f"s{k}.pdb"))
+        write_sparse_pdb(paths[-1], n, seed=k)
+    for dash_n in (50000, 10, 70000):                       # -n never changes what is indexed
+        a = argparse.Namespace(fc=None, fc_keys=None, threads=2, max_residue=dash_n)
+        ps, nres, plddt, raw, ok = cli._ingest(a, structure, paths, 0)
+        assert ok.tolist() == [1, 1, 1, 1]
+        assert raw.tolist() == [31, 50002, 65535, 65536]
+        assert nres.tolist() == [30, 50001, 65534, 0]
+        assert np.diff(ps.res_off.astype(np.int64)).tolist() == [30, 50001, 65534, 0]
+        assert plddt[3] == 0.0 and plddt[1] > 0.0
+    assert cli.REF_SKIP_MAX_RESIDUE == 65535
+    # the oracle: same counts from its own parser, same threshold by default (strict >)
+    assert inspect.signature(oracle.build_index).parameters["max_residue"].default == 65535
+    for p, n, r, pl in zip(paths, nres.tolist(), raw.tolist(), plddt):
+        s = oracle.read_pdb(p)
+        assert s.ptr.contents.num_residues_raw == r and (s.n == n or r > 65535)
+        if n:
+            assert np.float32(s.avg_plddt()).tobytes() == np.float32(pl).tobytes()
+    small = [oracle.read_pdb(paths[0])] * 2                                   # raw count 31
+    for thr, want in ((31, [30, 30]), (30, [0, 0])):
+        _, onres, opl = oracle.build_index(small, max_residue=thr)
+        assert onres.tolist() == want and (opl[0] == 0.0) == (want[0] == 0)
+    # -n reaches PREFIX.type and nothing else (cli/config.rs:66-97)
+    indexio.save_type(str(tmp_path / "x.type"), 4, max_residue=10)
+    assert "max_residue = 10\n" in open(tmp_path / "x.type").read()
