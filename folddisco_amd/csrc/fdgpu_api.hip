@@ -172,6 +172,7 @@ extern "C" int fdgpu_spec_fallbacks(fdgpu_ctx *c, uint64_t *out) { FD_LOCK(c);
 }
 extern "C" void fdgpu_destroy(fdgpu_ctx *c) {
     if (!c) return;
+    fd_lanes_destroy(c);      // query lanes (fd_lanes.hip): queued batches run to their end, worker threads joined, sibling contexts destroyed
     if (c->spec_miss) (void)hipFree(c->spec_miss);
     for (auto &b : c->ws) b.release();
     for (auto &b : c->pool) (void)hipFree(b.p);

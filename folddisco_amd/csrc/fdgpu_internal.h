@@ -103,7 +103,9 @@ struct fdgpu_ctx {
         pool.push_back({p, cap});
     }
     size_t last_cap = 0;
+    void *lanes = nullptr;        // fd_lanes.hip: sibling contexts + worker threads behind fdgpu_query_batch_submit / _wait (made on first use)
 };
+void fd_lanes_destroy(fdgpu_ctx *c);
 
 // HIP-event stage timer (active only after fdgpu_enable_timing(ctx, 1))
 static inline hipEvent_t fd_next_event(fdgpu_ctx *c) {

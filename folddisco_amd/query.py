@@ -324,13 +324,8 @@ def retrieve_batch(ctx: Context, db: Batch, resname_std, cands, qms, qbatch: Bat
     return out
 
 
-def query_batch(ctx: Context, index: FolddiscoIndex, db: Batch, qbatch: Batch, queries, total_structures: float, top_n: int, match_top: int,
-                penalty=None, resname_std=None, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance_cutoff=1.0, node_count=2, nbin_dist=0, nbin_angle=0,
-                dist_cutoff=20.0, hash_type=3, multiple_bins=None):
-    """make_query_maps + count_query_maps(top_n) + retrieve_batch over the first match_top records of every ranking in ONE library call
-    (fdgpu_query_batch: the stages overlap inside it).  queries as make_query_maps.  -> (maps, (records REC_DTYPE[], rec_off), (matches
-    MATCH_DTYPE[], match_off, residues int32[], res_off)) — the arrays the three calls return."""
-    from .api import REC_DTYPE
+def _query_batch_args(queries, penalty, resname_std, dist_thr, angle_thr, nbin_dist, nbin_angle, dist_cutoff, hash_type, multiple_bins):
+    """the argument block fdgpu_query_batch and fdgpu_query_batch_submit share -> (ctypes arguments between qb and the outputs, objects to keep alive)"""
     nq = len(queries)
     q_struct = np.ascontiguousarray([q[0] for q in queries], np.uint32)
     idx = [np.ascontiguousarray(q[1], np.uint32) for q in queries]
@@ -353,15 +348,14 @@ def query_batch(ctx: Context, index: FolddiscoIndex, db: Batch, qbatch: Batch, q
     p = HashParams(nbin_dist, nbin_angle, dist_cutoff, hash_type, multiple_bins)
     pen = None if penalty is None else np.ascontiguousarray(penalty, dtype=np.float32)
     std = None if resname_std is None else np.ascontiguousarray(resname_std, np.uint8)
-    outs = (C.POINTER(QueryMap) * max(nq, 1))()
-    rp_, ro_ = C.POINTER(_lib.CountRec)(), u64p()
-    mp, resp = C.POINTER(MatchRec)(), C.POINTER(C.c_int32)()
-    mo, reso = u64p(), u64p()
-    ctx.check(ctx.L.fdgpu_query_batch(ctx.h, index.h, db.h, None if std is None else std.ctypes.data_as(u8p), qbatch.h, nq, q_struct.ctypes.data_as(u32p),
-                                      q_off.ctypes.data_as(u64p), q_index.ctypes.data_as(u32p), sub_ptrs, n_subs.ctypes.data_as(u32p), d.ctypes.data_as(f32p), len(d),
-                                      a.ctypes.data_as(f32p), len(a), C.byref(p), float(total_structures), None if pen is None else pen.ctypes.data_as(f32p),
-                                      int(top_n), int(match_top), ca_distance_cutoff, node_count, outs, C.byref(rp_), C.byref(ro_), C.byref(mp), C.byref(mo),
-                                      C.byref(resp), C.byref(reso)))
+    head = (None if std is None else std.ctypes.data_as(u8p),)
+    mid = (nq, q_struct.ctypes.data_as(u32p), q_off.ctypes.data_as(u64p), q_index.ctypes.data_as(u32p), sub_ptrs, n_subs.ctypes.data_as(u32p), d.ctypes.data_as(f32p), len(d),
+           a.ctypes.data_as(f32p), len(a), C.byref(p))
+    return head, mid, (None if pen is None else pen.ctypes.data_as(f32p)), (q_struct, q_off, q_index, sub_ptrs, n_subs, keep, d, a, p, pen, std)
+
+
+def _query_batch_results(ctx, nq, outs, rp_, ro_, mp, mo, resp, reso):
+    from .api import REC_DTYPE
     maps = [_wrap_query_map(ctx, outs[t]) for t in range(nq)]
     rec_off = np.ctypeslib.as_array(ro_, shape=(nq + 1,)).copy()
     moff = np.ctypeslib.as_array(mo, shape=(nq + 1,)).copy()
@@ -372,6 +366,80 @@ def query_batch(ctx: Context, index: FolddiscoIndex, db: Batch, qbatch: Batch, q
     for x in (ro_, mo, reso):
         ctx.L.fdgpu_free(x)
     return maps, (recs, rec_off), (marr, moff, rarr, roff)
+
+
+def query_batch(ctx: Context, index: FolddiscoIndex, db: Batch, qbatch: Batch, queries, total_structures: float, top_n: int, match_top: int,
+                penalty=None, resname_std=None, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance_cutoff=1.0, node_count=2, nbin_dist=0, nbin_angle=0,
+                dist_cutoff=20.0, hash_type=3, multiple_bins=None):
+    """make_query_maps + count_query_maps(top_n) + retrieve_batch over the first match_top records of every ranking in ONE library call
+    (fdgpu_query_batch: the stages overlap inside it).  queries as make_query_maps.  -> (maps, (records REC_DTYPE[], rec_off), (matches
+    MATCH_DTYPE[], match_off, residues int32[], res_off)) — the arrays the three calls return."""
+    nq = len(queries)
+    head, mid, pen, keep = _query_batch_args(queries, penalty, resname_std, dist_thr, angle_thr, nbin_dist, nbin_angle, dist_cutoff, hash_type, multiple_bins)
+    outs = (C.POINTER(QueryMap) * max(nq, 1))()
+    rp_, ro_ = C.POINTER(_lib.CountRec)(), u64p()
+    mp, resp = C.POINTER(MatchRec)(), C.POINTER(C.c_int32)()
+    mo, reso = u64p(), u64p()
+    ctx.check(ctx.L.fdgpu_query_batch(ctx.h, index.h, db.h, *head, qbatch.h, *mid, float(total_structures), pen,
+                                      int(top_n), int(match_top), ca_distance_cutoff, node_count, outs, C.byref(rp_), C.byref(ro_), C.byref(mp), C.byref(mo),
+                                      C.byref(resp), C.byref(reso)))
+    del keep
+    return _query_batch_results(ctx, nq, outs, rp_, ro_, mp, mo, resp, reso)
+
+
+class QueryJob:
+    """a batch handed to fdgpu_query_batch_submit; wait() returns what query_batch returns (once)"""
+
+    def __init__(self, ctx, handle, nq, keep):
+        self.ctx, self.h, self.nq, self._keep = ctx, handle, nq, keep
+
+    def wait(self):
+        if self.h is None:
+            raise RuntimeError("QueryJob.wait() called twice")
+        nq = self.nq
+        outs = (C.POINTER(QueryMap) * max(nq, 1))()
+        rp_, ro_ = C.POINTER(_lib.CountRec)(), u64p()
+        mp, resp = C.POINTER(MatchRec)(), C.POINTER(C.c_int32)()
+        mo, reso = u64p(), u64p()
+        h, self.h = self.h, None
+        rc = self.ctx.L.fdgpu_query_batch_wait(self.ctx.h, h, outs, C.byref(rp_), C.byref(ro_), C.byref(mp), C.byref(mo), C.byref(resp), C.byref(reso))
+        self._keep = None
+        self.ctx.check(rc)
+        return _query_batch_results(self.ctx, nq, outs, rp_, ro_, mp, mo, resp, reso)
+
+    def __del__(self):      # a job nobody waited for: collect and drop its results (the library requires exactly one wait per job)
+        try:
+            if self.h is not None and self.ctx.h:
+                h, self.h = self.h, None
+                self.ctx.L.fdgpu_query_batch_wait(self.ctx.h, h, None, None, None, None, None, None, None)
+        except Exception:
+            pass
+
+
+def query_batch_submit(ctx: Context, index: FolddiscoIndex, db: Batch, qbatch: Batch, queries, total_structures: float, top_n: int, match_top: int,
+                       penalty=None, resname_std=None, dist_thr=(0.5,), angle_thr=(5.0,), ca_distance_cutoff=1.0, node_count=2, nbin_dist=0, nbin_angle=0,
+                       dist_cutoff=20.0, hash_type=3, multiple_bins=None) -> QueryJob:
+    """query_batch without the wait: the batch goes to one of the context's query lanes (fdgpu_query_batch_submit) -> QueryJob.  One host
+    thread keeps several batches in flight: submit k, k + 1, k + 2; wait k; submit k + 3; ..."""
+    nq = len(queries)
+    head, mid, pen, keep = _query_batch_args(queries, penalty, resname_std, dist_thr, angle_thr, nbin_dist, nbin_angle, dist_cutoff, hash_type, multiple_bins)
+    job = C.c_void_p()
+    ctx.check(ctx.L.fdgpu_query_batch_submit(ctx.h, index.h, db.h, *head, qbatch.h, *mid, float(total_structures), pen, int(top_n), int(match_top),
+                                             ca_distance_cutoff, node_count, C.byref(job)))
+    return QueryJob(ctx, job, nq, (keep[-2], keep[-1], index, db, qbatch))      # borrowed until the wait: penalty, resname_std, index, batches
+
+
+def query_batch_pipelined(ctx: Context, index: FolddiscoIndex, db: Batch, qbatch: Batch, batches, total_structures: float, top_n: int, match_top: int, depth: int = 3,
+                          **kw):
+    """generator over the results of `batches` (an iterable of query lists) with `depth` batches in flight, in submission order"""
+    from collections import deque
+    pend = deque()
+    for b in batches:
+        pend.append(query_batch_submit(ctx, index, db, qbatch, b, total_structures, top_n, match_top, **kw))
+        if len(pend) >= depth:
+            yield pend.popleft().wait()
+    while pend:
+        yield pend.popleft().wait()
 
 
 def query_pdb(ctx: Context, index: FolddiscoIndex, db: Batch, db_structs: list[CompactStructure], tids: list[str], nres, plddt,

@@ -331,6 +331,26 @@ int fdgpu_query_batch(fdgpu_ctx *ctx, const fdgpu_index *index, const fdgpu_batc
                       const float *dist_thr, uint64_t n_dist, const float *angle_thr_deg, uint64_t n_angle, const fd_hash_params *p, float total_structures,
                       const float *penalty, uint32_t top_n, uint32_t match_top, float ca_distance_cutoff, uint32_t node_count, fd_query_map **maps,
                       fd_count_rec **recs, uint64_t **rec_off, fd_match_rec **matches, uint64_t **match_off, int32_t **residues, uint64_t **res_off);
+/* The same call, NON-BLOCKING: submit hands the batch to one of the context's query LANES and returns, wait collects it.  The reference keeps
+ * many queries in flight from its rayon workers (src/cli/workflows/query_pdb.rs:348 `queries.into_par_iter()`, :415 the retrieval's
+ * par_iter_mut); a host with ONE thread per GPU gets that overlap here: submit batches k, k + 1, k + 2, then wait for k, submit k + 3, ... — a
+ * lane is a private sibling context (own HIP stream, workspaces, landing blocks) driven by a library thread through fdgpu_query_batch itself, so
+ * one batch's host-side steps (table building, waits for counts, result copies) are covered by the other lanes' kernels, and the results are bit
+ * for bit those of the blocking call.  Lanes are made on the first submit (default 3, env FDGPU_QUERY_LANES, or fdgpu_query_lanes beforehand;
+ * each lane holds its own query scratch in HBM — ~1 GB for batches of 128 queries at 542,000 structures) and are torn down by fdgpu_destroy.
+ * Inputs: the per-query arrays (q_struct, q_off, q_index, subs, n_subs, thresholds, *p) are COPIED at submit; index, db, qb, resname_std and
+ * penalty are borrowed until the wait returns.  Every submitted job must be waited for exactly once (that releases it); passing NULL output
+ * pointers to wait discards the results.  Errors of the batch are returned by wait (message in fdgpu_last_error(ctx)).  Submit and wait may
+ * be called from different threads; jobs complete in any order. */
+typedef struct fdgpu_query_job fdgpu_query_job;
+int fdgpu_query_batch_submit(fdgpu_ctx *ctx, const fdgpu_index *index, const fdgpu_batch *db, const uint8_t *resname_std, const fdgpu_batch *qb, uint64_t n_queries,
+                             const uint32_t *q_struct, const uint64_t *q_off, const uint32_t *q_index, const uint8_t *const *subs, const uint32_t *n_subs,
+                             const float *dist_thr, uint64_t n_dist, const float *angle_thr_deg, uint64_t n_angle, const fd_hash_params *p, float total_structures,
+                             const float *penalty, uint32_t top_n, uint32_t match_top, float ca_distance_cutoff, uint32_t node_count, fdgpu_query_job **job);
+int fdgpu_query_batch_wait(fdgpu_ctx *ctx, fdgpu_query_job *job, fd_query_map **maps, fd_count_rec **recs, uint64_t **rec_off, fd_match_rec **matches,
+                           uint64_t **match_off, int32_t **residues, uint64_t **res_off);
+/* make sure the context has at least n_lanes lanes (1..8) -> the number it has, or a negative error code; n_lanes = 0 only reports */
+int fdgpu_query_lanes(fdgpu_ctx *ctx, uint32_t n_lanes);
 
 /* ---- multi-GPU query path (one process per GPU, RCCL over xGMI) ----------------------------------------------------
  * The index and the coordinates are sharded by structure id (every rank holds the postings and coordinates of its own id range,

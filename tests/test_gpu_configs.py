@@ -245,6 +245,57 @@ def test_fused_query_batch_equals_the_three_calls(human, monkeypatch):
     assert n_matches > 3 * 5 * N_PLANT // 2
 
 
+def test_pipelined_submit_wait_equals_the_blocking_call(human):
+    """fdgpu_query_batch_submit / fdgpu_query_batch_wait (batches in flight on the context's query lanes: sibling contexts driven by library
+    threads) return, per batch, the arrays of the blocking fdgpu_query_batch bit for bit — different batches in flight at once (different
+    queries, sizes, top_n per job), waits out of submission order, a job that is dropped without taking its results, a failing job, and the
+    caller's own context usable in between."""
+    import folddisco_amd as fd
+    from folddisco_amd import query as fq
+    ctx, ps, batch, ix = human["ctx"], human["ps"], human["batch"], human["ix"]
+    Qs = human["queries"]
+    qall = ctx.upload(fd.PackedStructures.concat([Q["q"].as_item() for Q in Qs]))
+    ix.set_penalty(human["pen"])
+    base = [(k, Q["idx"], Q["subs"]) for k, Q in enumerate(Qs)]
+    jobs_in = [(base * 2, 1000, 25), (base[:2], 40, 8), (base[::-1] + [(0, np.array([0, 1], np.uint32), None)], 1000, 32), (base[1:4] * 5, 300, 16),
+               (base, 1000, 25)]
+    fields = ("hash", "qi", "qj", "is_primary", "idf", "indices", "aad_aa1", "aad_aa2", "aad_dist", "aad_qi", "primary_hash")
+
+    def same(ref, got):
+        (m0, (r0, o0), t0), (m1, (r1, o1), t1) = ref, got
+        assert len(m0) == len(m1)
+        for a, b in zip(m0, m1):
+            for f in fields:
+                assert getattr(a, f).tobytes() == getattr(b, f).tobytes(), f
+        assert o0.tobytes() == o1.tobytes() and r0.tobytes() == r1.tobytes()
+        for a, b in zip(t0, t1):
+            assert a.tobytes() == b.tobytes()
+    refs = [fq.query_batch(ctx, ix, batch, qall, q, float(HUMAN), tn, mt) for q, tn, mt in jobs_in]
+    assert sum(len(r[2][0]) for r in refs) > 100
+    assert ctx.L.fdgpu_query_lanes(ctx.h, 0) == 0
+    for rnd in range(3):
+        jobs = [fq.query_batch_submit(ctx, ix, batch, qall, q, float(HUMAN), tn, mt) for q, tn, mt in jobs_in]
+        assert ctx.L.fdgpu_query_lanes(ctx.h, 0) == 3          # the default number of lanes, made by the first submit
+        mid = fq.query_batch(ctx, ix, batch, qall, jobs_in[1][0], float(HUMAN), 40, 8)      # the caller's own context while its lanes are busy
+        same(refs[1], mid)
+        order = list(range(len(jobs)))[::-1] if rnd == 1 else list(range(len(jobs)))
+        for k in order:
+            same(refs[k], jobs[k].wait())
+    # generator form, depth 2
+    for k, got in enumerate(fq.query_batch_pipelined(ctx, ix, batch, qall, [j[0] for j in jobs_in[:3]], float(HUMAN), 1000, 25, depth=2)):
+        same(fq.query_batch(ctx, ix, batch, qall, jobs_in[k][0], float(HUMAN), 1000, 25), got)
+    # a job nobody waits for is collected when the object goes away; a failing job reports through wait
+    j = fq.query_batch_submit(ctx, ix, batch, qall, base, float(HUMAN), 1000, 25)
+    del j
+    bad = fq.query_batch_submit(ctx, ix, batch, qall, [(len(Qs) + 7, np.array([0, 1, 2], np.uint32), None)], float(HUMAN), 1000, 25)      # no such query structure
+    with pytest.raises(fd.FdgpuError):
+        bad.wait()
+    with pytest.raises(RuntimeError):
+        bad.wait()
+    assert ctx.L.fdgpu_query_lanes(ctx.h, 4) == 4
+    same(refs[0], fq.query_batch_submit(ctx, ix, batch, qall, jobs_in[0][0], float(HUMAN), 1000, 25).wait())
+
+
 def test_whole_structure_query_at_human_scale(human, monkeypatch):
     """configs[4] (no -q): a ~300-residue database structure as the query, against all 20,500 structures"""
     import folddisco_amd as fd
