@@ -412,3 +412,31 @@ def test_merge_of_gathered_retrieval_payloads():
         bad = counts.copy(); bad[world - 1, nq] = 5       # the last rank failed its local step: every rank returns the error
         with pytest.raises(FdgpuError):
             call(bad)
+
+
+def test_bench_n_gt_1_path_runs_with_two_gloo_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` — the command the driver's scaling lease runs — executed end to end here with two ranks on ONE GPU over gloo
+    (FD_BENCH_BACKEND=gloo) at 8,000 structures: the shard build per rank, the sharded query legs with their exchange, the replica leg through
+    the query lanes, and the line's N > 1 fields.  Not a performance number: it keeps the driver's run from being the first execution of this
+    code (a typo in run_replicas / value_from would otherwise surface there)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FD_BENCH_BACKEND="gloo", PYTHONPATH=root)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--structures", "8000", "--steps", "1", "--warmup", "1", "--queries", "64",
+                        "--no-cpu-baseline", "--no-cli-index"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["config"]["structures"] == 8000 and out["config"]["structures_per_gpu"] == 4000
+    q = out["query"]
+    assert "error" not in q, q
+    assert q["value_from"] in ("replicas", "sharded") and q["sharded_value"] > 0
+    assert "error" not in q["replicas"] and q["replicas"]["value"] > 0 and q["replicas"]["replicas"] == 2
+    assert q["value"] == max(q["sharded_value"], q["replicas"]["value"])
+    assert q["exchange"] is not None and q["batched_with_matching"]["matches"] > 0
+    assert out["roofline"]["frac"] > 0 and out["export_inclusive"]["value"] > 0
