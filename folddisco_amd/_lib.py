@@ -175,6 +175,7 @@ SYMBOLS = [
     ("fdgpu_query_batch_wait", C.c_int, [VP, VP, C.POINTER(C.POINTER(QueryMap)), C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p), C.POINTER(C.POINTER(MatchRec)),
                                          C.POINTER(u64p), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(u64p)]),
     ("fdgpu_query_lanes", C.c_int, [VP, C.c_uint32]),
+    ("fdgpu_trim", None, []),
     ("fdgpu_retrieve", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(QueryMap), VP, C.POINTER(HashParams), C.c_float, C.c_uint32, C.c_uint32,
                                  C.POINTER(C.POINTER(MatchRec)), u64p, C.POINTER(C.POINTER(C.c_int32))]),
     ("fdgpu_matches_free", None, [C.POINTER(MatchRec), C.POINTER(C.c_int32)]),

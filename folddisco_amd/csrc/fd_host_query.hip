@@ -1758,7 +1758,7 @@ extern "C" int fdgpu_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, const fdgp
     rc = fd_count_query_maps_top_impl(c, ix, n_queries, maps, penalty, total_structures, top_n, &rr, &roff, &D);
     if (!rc && D.got && D.overflow) {      // more ties at a cut-off than the device selection holds: the compacting path, host records
         fdgpu_free(rr); free(roff); rr = nullptr; roff = nullptr;
-        rc = fd_count_query_maps_top_impl(c, ix, n_queries, maps, penalty, total_structures, top_n, &rr, &roff, nullptr);
+        rc = fd_count_query_maps_top_impl(c, ix, n_queries, maps, penalty, total_structures, top_n, &rr, &roff, nullptr, /*allow_dense=*/false);
         D.got = false;
     }
     if (rc) { drop_maps(); return rc; }
@@ -1810,6 +1810,8 @@ extern "C" int fdgpu_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, const fdgp
     rc = fd_retrieve_batch_impl(c, db, resname_std, n_queries, cand.data(), cand_off.data(), maps, qb, q_struct, p, ca_distance_cutoff, node_count, 0, matches, match_off,
                                 residues, res_off, &prep);
     if (side_copy) {
+        // the side-stream copy read WS_TILE_HO while the retrieval ran: correct only as long as no retrieval stage grows (= frees) or writes that buffer
+        if (c->ws[WS_TILE_HO].p != D.recs && !rc) { c->err = "query_batch: a retrieval stage re-allocated the ranking's buffer under its copy"; rc = FDGPU_EHIP; }
         const hipError_t e = hipStreamSynchronize(c->side_stream);
         if (e != hipSuccess && !rc) { c->err = std::string("query_batch records: ") + hipGetErrorString(e); rc = FDGPU_EHIP; }
     }

@@ -135,6 +135,8 @@ static int fd_selfcheck(fdgpu_ctx *c) {
 // 1 = the host's libm agrees with the restated generation, 0 = it does not, -1 = the self-check was skipped
 extern "C" int fdgpu_host_libm_matches(const fdgpu_ctx *c) { return c ? c->host_libm_matches : -1; }
 
+static std::atomic<int> fd_live_contexts{0};      // contexts with a device + stream: the last fdgpu_destroy trims the result pool
+extern "C" void fdgpu_trim(void);
 extern "C" int fdgpu_create(int device, fdgpu_ctx **out) {
     if (!out) return FDGPU_EINVAL;
     *out = nullptr;
@@ -155,6 +157,8 @@ extern "C" int fdgpu_create(int device, fdgpu_ctx **out) {
         return FDGPU_EHIP;
     }
     c->own_stream = true;
+    c->counted = true;
+    fd_live_contexts.fetch_add(1);
     if (hipMalloc((void **)&c->spec_miss, 8) == hipSuccess) (void)hipMemset(c->spec_miss, 0, 8);
     else c->spec_miss = nullptr;
     *out = c;
@@ -181,7 +185,9 @@ extern "C" void fdgpu_destroy(fdgpu_ctx *c) {
     for (int k = 0; k < 6; ++k) if (c->hbuf[k]) (void)hipHostFree(c->hbuf[k]);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    const bool last = c->counted && fd_live_contexts.fetch_sub(1) == 1;
     delete c;
+    if (last) fdgpu_trim();      // the process's last context: hand the pooled (page-locked) result blocks back
 }
 // Returns the context's workspaces (the sort buffers of the largest build so far, query scratch) and the cached blocks of destroyed indices to
 // the device.  Indices, batches and query maps stay valid; the next call allocates what it needs again.
@@ -222,7 +228,23 @@ struct fd_out_pool {
     size_t idle_bytes = 0;
 };
 fd_out_pool &out_pool() { static fd_out_pool *p = new fd_out_pool(); return *p; }     // never destroyed: callers may free after static destructors ran
-const size_t FD_OUT_POOL_BYTES = (size_t)256 << 20, FD_OUT_POOL_MIN = (size_t)64 << 10;
+const size_t FD_OUT_POOL_MIN = (size_t)64 << 10;
+size_t fd_out_pool_cap() {      // idle bytes kept for reuse: 256 MB, FDGPU_OUT_POOL_MB overrides (0: nothing is kept)
+    static const size_t cap = [] { const char *e = getenv("FDGPU_OUT_POOL_MB"); return e ? (size_t)std::max(0L, atol(e)) << 20 : (size_t)256 << 20; }();
+    return cap;
+}
+}
+// Releases the idle blocks of the result pool (page-locked ones included).  Long-lived hosts with varying batch sizes call it when a burst
+// is over; the last fdgpu_destroy of a process calls it too.  Blocks the caller still holds are untouched.
+extern "C" void fdgpu_trim(void) {
+    fd_out_pool &P = out_pool();
+    std::vector<std::pair<fd_out_blk, void *>> drop;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        drop.swap(P.idle);
+        P.idle_bytes = 0;
+    }
+    for (auto &b : drop) { if (b.first.pinned) (void)hipHostFree(b.second); else free(b.second); }
 }
 // pinned: page-locked host memory (hipHostMalloc) — the device copies its results straight into the caller's array
 void *fd_out_alloc(size_t bytes, bool pinned) {
@@ -263,7 +285,7 @@ extern "C" void fdgpu_free(void *p) {
         if (it == P.live.end()) { free(p); return; }
         b = it->second;
         P.live.erase(it);
-        if (P.idle_bytes + b.cap <= FD_OUT_POOL_BYTES) { P.idle.emplace_back(b, p); P.idle_bytes += b.cap; return; }
+        if (P.idle_bytes + b.cap <= fd_out_pool_cap()) { P.idle.emplace_back(b, p); P.idle_bytes += b.cap; return; }
     }
     if (b.pinned) (void)hipHostFree(p); else free(p);
 }
@@ -1330,11 +1352,19 @@ extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint
 static int fd_index_checkpoints(fdgpu_ctx *c, const fdgpu_index *ix) {
     std::lock_guard<std::mutex> lk(ix->lens_mu);
     if (ix->ck_meta && ix->ck_first == ix->first_id && ix->ck_S == ix->n_structures) return FDGPU_OK;
-    if (ix->ck_failed) return FDGPU_ENOMEM;
+    // a failure is remembered for the id range it happened with (a changed range is a new table of another size) and retried every 64th request:
+    // one transient hipMalloc failure must not switch the tiled path off for the life of the index
+    if (ix->ck_failed && ix->ck_first == ix->first_id && ix->ck_S == ix->n_structures && (++ix->ck_fail_skips & 63)) return FDGPU_ENOMEM;
     hipStream_t st = c->stream;
     const uint64_t H = ix->n_hashes, S = ix->n_structures;
     if (!H || !S) return FDGPU_ENOMEM;
-    if (ix->ck_meta) { (void)hipStreamSynchronize(st); (void)hipFree(ix->ck_meta); (void)hipFree(ix->ck_ent); ix->ck_meta = nullptr; ix->ck_ent = nullptr; }
+    if (ix->ck_meta) {
+        // the table of the previous id range: other contexts that share the index (query lanes, one context per host thread) may still have
+        // k_qt_plan / k_qt_score in flight on THEIR streams reading it — drain the whole device, not only this context's stream, before the free
+        (void)hipDeviceSynchronize();
+        (void)hipFree(ix->ck_meta); (void)hipFree(ix->ck_ent); ix->ck_meta = nullptr; ix->ck_ent = nullptr;
+    }
+    ix->ck_failed = false;
     const uint32_t NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
     hipError_t e = c->ws[WS_QT_COUNT].ensure(H * 4);
     if (e == hipSuccess) e = c->ws[WS_QT_RANGES].ensure((H + 2) * 8);
@@ -1362,7 +1392,7 @@ static int fd_index_checkpoints(fdgpu_ctx *c, const fdgpu_index *ix) {
         (void)hipGetLastError();
         if (meta) (void)hipFree(meta);
         if (ent) (void)hipFree(ent);
-        ix->ck_failed = true;
+        ix->ck_failed = true; ix->ck_first = ix->first_id; ix->ck_S = S;
         return FDGPU_ENOMEM;
     }
     ix->ck_meta = meta; ix->ck_ent = ent; ix->ck_n = n_ent; ix->ck_first = ix->first_id; ix->ck_S = S;
@@ -1430,10 +1460,10 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     const bool qtile_on = [] { const char *e = getenv("FDGPU_QTILE"); return !(e && e[0] == '0'); }();      // 0: occupancy rows (read per call: tests compare the two)
     const uint32_t qt_tl2 = [] { const char *e = getenv("FDGPU_QT_TILE"); return e && atoi(e) == 13 ? 13u : 14u; }();      // structures per tile (measurement)
     const uint32_t NT = (uint32_t)((S + (1u << qt_tl2) - 1) >> qt_tl2);
-    const bool tiled = keys_only && qtile_on && max_rows <= QT_MAX_ROWS && nq * (S >> QT_CELL_LOG2) < (1ull << 31) && fd_index_checkpoints(c, ix) == FDGPU_OK;
+    bool tiled = keys_only && qtile_on && max_rows <= QT_MAX_ROWS && nq * (S >> QT_CELL_LOG2) < (1ull << 31) && fd_index_checkpoints(c, ix) == FDGPU_OK;
     // one query of thousands of rows (a whole structure as the query) with a selection: the same tiles, the rows cut into slices (k_qt_score<BIG>)
     const uint32_t NT14 = (uint32_t)((S + (1u << 14) - 1) >> 14);
-    const bool tiled_big = dense_topn && sliced && qtile_on && !tiled && nq < (1ull << 18) && nq * NT14 < (1ull << 31) && fd_index_checkpoints(c, ix) == FDGPU_OK;
+    bool tiled_big = dense_topn && sliced && qtile_on && !tiled && nq < (1ull << 18) && nq * NT14 < (1ull << 31) && fd_index_checkpoints(c, ix) == FDGPU_OK;
     const uint32_t big_slices = (uint32_t)std::min<uint64_t>(32, nq), big_wpr = (uint32_t)((nq + 31) / 32), big_cap = top_n + 1024;
     hipError_t e = hipSuccess;
     auto need = [&](int w, size_t bytes) { if (e == hipSuccess) e = c->ws[w].ensure(bytes); };
@@ -1451,6 +1481,12 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         for (uint64_t r = 0; r < nq; ++r) slots += (known_len[r] * vb + 15) / 16 + NCc + 6ull * NT + 8;
         if (slots < (1ull << 31)) stream_cap = slots + 1024;
     }
+    auto need_rows = [&]() {      // the occupancy-row path's scratch
+        need(WS_COUNTS, packed ? 64 : QS * 4); need(WS_SEGOFF, QS * 8 + 16);
+        need(WS_KEYS_B, (size_t)nq * words * 4);
+        need(WS_IDS_A, QS * 4); need(WS_IDS_B, QS * 4); need(WS_MISC4, QS + 8); need(WS_TILE_BO, (QS + 2) * 8);
+        need(WS_SCANTMP, fd_scan_tmp_elems(QS) * 8 + 64);
+    };
     if (tiled) {
         if (stream_cap) { need(WS_QT_STREAM, stream_cap * 34 + 64); need(WS_QT_STAB, (size_t)n_queries * NT * QT_MAXB * 8 + 64); }
         need(WS_CQ_KIDX, nq * 8); need(WS_CQ_NSEG, nq * 4);
@@ -1462,11 +1498,11 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         need(WS_QT_PARTIAL, ((size_t)big_slices * NT14 << 14) * 8);
         need(WS_QT_SURV, ((size_t)NT14 * 512 * 2 + NT14 + big_cap + 2 * big_wpr) * 4 + (big_slices + 2) * 8 + 64);
         need(WS_QT_ROWBITS, (size_t)big_cap * big_wpr * 4);
-    } else {
-        need(WS_COUNTS, packed ? 64 : QS * 4); need(WS_SEGOFF, QS * 8 + 16);
-        need(WS_KEYS_B, (size_t)nq * words * 4);
-        need(WS_IDS_A, QS * 4); need(WS_IDS_B, QS * 4); need(WS_MISC4, QS + 8); need(WS_TILE_BO, (QS + 2) * 8);
-        need(WS_SCANTMP, fd_scan_tmp_elems(QS) * 8 + 64);
+    } else need_rows();
+    if (e != hipSuccess && (tiled || tiled_big)) {      // the tiled path's scratch did not fit (ranges, first-touch lists, decoded stream): the occupancy-row path instead
+        (void)hipGetLastError();
+        e = hipSuccess; tiled = false; tiled_big = false; stream_cap = 0;
+        need_rows();
     }
     if (e != hipSuccess) { free(ooff); c->err = std::string("count_query_batch workspace: ") + hipGetErrorString(e); return FDGPU_EHIP; }
     (void)hipMemcpyAsync(c->ws[WS_MISC0].p, rows_hash.data(), nq * 4, hipMemcpyHostToDevice, st);
@@ -1852,7 +1888,7 @@ extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, u
     return fd_count_query_maps_top_impl(c, ix, n_queries, qms, penalty, total_structures, top_n, out, out_off, nullptr);
 }
 int fd_count_query_maps_top_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty, float total_structures,
-                                 uint32_t top_n, fd_count_rec **out, uint64_t **out_off, fd_cq_dev_out *dev) { FD_LOCK(c);
+                                 uint32_t top_n, fd_count_rec **out, uint64_t **out_off, fd_cq_dev_out *dev, bool allow_dense) { FD_LOCK(c);
     if (!c || !ix || !out || !out_off || (n_queries && !qms)) return FDGPU_EINVAL;
     uint64_t nq = 0;
     for (uint64_t t = 0; t < n_queries; ++t) { if (!qms[t]) return FDGPU_EINVAL; nq += qms[t]->n; }
@@ -1876,7 +1912,7 @@ int fd_count_query_maps_top_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n
     int rc = !remembered && nq && ix->n_structures ? fd_posting_lengths_segs(c, ix, h.data(), nq, len.data(), seg.data()) : FDGPU_OK;
     if (rc) return rc;
     return fd_count_query_maps_len(c, ix, n_queries, qms, len.data(), nullptr, penalty, total_structures, top_n, out, out_off, dev, seg.data(),
-                                   have_kidx ? kidx.data() : nullptr);
+                                   have_kidx ? kidx.data() : nullptr, allow_dense);
 }
 // The two halves of the sharded form for hosts that bring their own transport (MPI, gloo, ...): the LOCAL posting lengths of the maps'
 // hash[] and primary_hash[] (2 * sum(n) values, fd_maps_hashes order) — the caller sums them over the ranks — and the scoring of the

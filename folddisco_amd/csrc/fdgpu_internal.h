@@ -33,7 +33,8 @@ struct fd_timing_entry { const char *name; hipEvent_t ev0, ev1; uint64_t bytes; 
 
 enum {
     WS_COUNTS, WS_CURSOR, WS_SEGOFF, WS_SCANTMP, WS_TOTAL, WS_KEYS_A, WS_IDS_A, WS_KEYS_B, WS_IDS_B, WS_GHIST, WS_TOT,
-    WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
+    WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO /* ranked records of a scoring call: fdgpu_query_batch copies them out on the side stream WHILE the
+    retrieval runs — no retrieval stage may ensure() or write this buffer (checked there) */, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
     WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS, WS_QT_STREAM, WS_QT_STAB,
     WS_CA_PERM, WS_OK_PERM, WS_AA_PERM, WS_SEG_TAB,
@@ -103,6 +104,7 @@ struct fdgpu_ctx {
         pool.push_back({p, cap});
     }
     size_t last_cap = 0;
+    bool counted = false;         // fdgpu_create got as far as a device + stream (live-context count behind fdgpu_trim at the last destroy)
     void *lanes = nullptr;        // fd_lanes.hip: sibling contexts + worker threads behind fdgpu_query_batch_submit / _wait (made on first use)
 };
 void fd_lanes_destroy(fdgpu_ctx *c);
@@ -172,7 +174,8 @@ struct fdgpu_index {
     mutable unsigned long long *ck_meta = nullptr;   // [H] first entry of the list | stride log2 << 56
     mutable void *ck_ent = nullptr;                  // uint2 entries {byte offset in the list, id before}
     mutable uint64_t ck_n = 0, ck_first = 0, ck_S = 0;
-    mutable bool ck_failed = false;                  // the table did not fit: the tiled path is off for this index
+    mutable bool ck_failed = false;                  // the table did not fit for the id range (ck_first, ck_S): the tiled path is off until the range changes or a retry succeeds
+    mutable uint32_t ck_fail_skips = 0;
 };
 
 // batched scoring with the ranked selection left on the device (fdgpu_api.hip; consumed by the sharded query, fd_comm.hip)
@@ -193,7 +196,9 @@ int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_quer
 int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs, long long *kidx = nullptr);
 // fdgpu_count_query_maps_top with the device-resident form of its result (dev != null: see fd_count_query_batch_impl)
 int fd_count_query_maps_top_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty, float total_structures,
-                                 uint32_t top_n, fd_count_rec **out, uint64_t **out_off, fd_cq_dev_out *dev);
+                                 uint32_t top_n, fd_count_rec **out, uint64_t **out_off, fd_cq_dev_out *dev, bool allow_dense = true);
+// (allow_dense = false: straight to the compacting path — what a caller passes when the device selection of a first attempt overflowed; the
+// overflow is deterministic, a second attempt on the same path would overflow again before falling back)
 
 void *fd_out_alloc(size_t bytes, bool pinned = false);      // result arrays of the hot query paths: recycled blocks (fdgpu_api.hip); released with fdgpu_free like any other output
 

@@ -351,6 +351,10 @@ int fdgpu_query_batch_wait(fdgpu_ctx *ctx, fdgpu_query_job *job, fd_query_map **
                            uint64_t **match_off, int32_t **residues, uint64_t **res_off);
 /* make sure the context has at least n_lanes lanes (1..8) -> the number it has, or a negative error code; n_lanes = 0 only reports */
 int fdgpu_query_lanes(fdgpu_ctx *ctx, uint32_t n_lanes);
+/* Result arrays of the query entry points come from a recycling pool (fdgpu_free puts them back; at most 256 MB of idle blocks are kept,
+ * env FDGPU_OUT_POOL_MB overrides, 0 = keep nothing).  fdgpu_trim releases the idle blocks — page-locked ones included — e.g. after a burst of
+ * large batches; the last fdgpu_destroy of the process does it too. */
+void fdgpu_trim(void);
 
 /* ---- multi-GPU query path (one process per GPU, RCCL over xGMI) ----------------------------------------------------
  * The index and the coordinates are sharded by structure id (every rank holds the postings and coordinates of its own id range,

@@ -233,6 +233,38 @@ def test_swissprot_scale_542000_index_and_planted_motifs():
         n = _check_matches(got, cand, ps, oq, om)
         full = [g for g in got if sum(1 for x in g["processed"] if x >= 0) == len(Q["idx"])]
         assert n >= 12 and len(full) >= 12 and min(g["rmsd"] for g in full) < 0.01
+    # ---- the headline's own workload at its own size: 128 motif queries (bench.py's picker), top 1000 ranked, retrieval of the top 32 — the three
+    # calls, the fused call and the non-blocking form (four batches in flight on the query lanes) return the same bytes
+    from folddisco_amd.api import count_query_maps
+    from folddisco_amd.querybench import _pick_queries
+    picked = _pick_queries(d_all, S, 128, 4242)
+    qall = ctx.upload(fd.PackedStructures.concat([it for _, _, it in picked]))
+    qlist = [(k, picked[k][1]) for k in range(len(picked))]
+    ix.set_penalty(pen)
+    maps = fq.make_query_maps(ctx, qall, qlist, ix, float(S))
+    recs3, off3 = count_query_maps(ctx, ix, maps, None, total_structures=S, top_n=1000, flat=True)
+    cl = [recs3["nid"][int(off3[t]): int(off3[t]) + min(32, int(off3[t + 1] - off3[t]))].astype(np.uint32) for t in range(len(qlist))]
+    ref = fq.retrieve_batch(ctx, db, None, cl, maps, qall, [q[0] for q in qlist], as_arrays=True)
+    assert len(ref[0]) > 5000
+    fields = ("hash", "qi", "qj", "is_primary", "idf", "indices", "aad_aa1", "aad_aa2", "aad_dist", "aad_qi", "primary_hash")
+
+    def same_as_three_calls(got, sl):
+        fmaps, (frecs, foff), (m, mo, r, ro) = got
+        for a, b in zip(maps[sl], fmaps):
+            for f in fields:
+                assert getattr(a, f).tobytes() == getattr(b, f).tobytes(), f
+        o0 = off3[sl.start:sl.stop + 1]
+        assert np.array_equal(foff, o0 - o0[0]) and frecs.tobytes() == recs3[int(o0[0]):int(o0[-1])].tobytes()
+        m0, m1, r0, r1 = int(ref[1][sl.start]), int(ref[1][sl.stop]), int(ref[3][sl.start]), int(ref[3][sl.stop])
+        assert np.array_equal(mo, ref[1][sl.start:sl.stop + 1] - m0) and np.array_equal(ro, ref[3][sl.start:sl.stop + 1] - r0)
+        assert m.tobytes() == ref[0][m0:m1].tobytes() and r.tobytes() == ref[2][r0:r1].tobytes()
+    same_as_three_calls(fq.query_batch(ctx, ix, db, qall, qlist, float(S), 1000, 32), slice(0, 128))
+    for rnd in range(2):
+        cuts = [slice(0, 128), slice(0, 32), slice(32, 128), slice(5, 77), slice(0, 128)]
+        jobs = [fq.query_batch_submit(ctx, ix, db, qall, qlist[c], float(S), 1000, 32) for c in cuts]
+        for c, j in zip(cuts, jobs):
+            same_as_three_calls(j.wait(), c)
+    del maps, recs3, ref, jobs
     # ---- the same database in ONE fdgpu_index_build call (bench.py's default plan: 542,000 structures > 2^18, so the key's eight id bits are in
     # use; 1.77e10 keys > 2^34 positions; 213 GB of sort workspace): byte-identical to the merged index of the three calls
     import xxhash

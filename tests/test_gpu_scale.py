@@ -10,6 +10,8 @@ queries on one GPU).  The oracle needs minutes at this size, so the checks are:
 * count_query on planted motifs equals a numpy recount over the decoded postings (match / node / edge counts exact, idf
   relative 1e-5 — the tolerance DESIGN.md states for the f32 sum).
 """
+import os
+
 import numpy as np
 import pytest
 
