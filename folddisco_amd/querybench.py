@@ -195,7 +195,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         return timed(go)
 
     MT_REPS = 12
-    PIPE_REPS = 24          # passes over the query set per timed run of the pipelined leg (batches of 128 -> 24 batches in the pipeline)
+    PIPE_REPS = 48          # passes over the query set per timed run of the pipelined leg (batches of 128 -> 24 batches in the pipeline)
 
     def batched_mt(workers=2, chunk=32):
         """the full batched query from `workers` host threads, one context (stream + workspaces) each, sharing the resident index and
@@ -232,6 +232,38 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             cx.close()
         return out
 
+    def run_pipe():
+        """{(lanes, in flight): queries/s}, error — batches of 128 through the context's query lanes, one host thread"""
+        out = {}
+        if not (big_ok and not sharded and first == 0):
+            return out, None
+        try:
+            from collections import deque
+            ks1 = list(range(len(queries)))
+            chunks = [[(k, queries[k][1]) for k in ks1[c0:c0 + 128]] for c0 in range(0, len(ks1), 128)]
+
+            def go_pipe(reps, depth):
+                pend, tot = deque(), 0
+                for _ in range(reps):
+                    for qs in chunks:
+                        pend.append(query_batch_submit(ctx, ix, batch, qall, qs, float(S_total), top_n, match_top))
+                        if len(pend) >= depth:
+                            tot += len(pend.popleft().wait()[2][0])
+                while pend:
+                    tot += len(pend.popleft().wait()[2][0])
+                return tot
+            nm1 = go_pipe(1, 1)
+            for lanes, depth in [tuple(int(y) for y in x.split(":")) for x in os.environ.get("FD_BENCH_PIPE", "4:6").split(",")]:
+                n_l = ctx.L.fdgpu_query_lanes(ctx.h, lanes)
+                assert n_l >= lanes, ctx.L.fdgpu_last_error(ctx.h)
+                go_pipe(2 * n_l, n_l)      # warm-up: every lane allocates its scratch
+                runs = sorted((timed(lambda: go_pipe(PIPE_REPS, depth)) for _ in range(3)), key=lambda x: x[0])
+                assert runs[1][1] == PIPE_REPS * nm1
+                out[(n_l, depth)] = len(queries) * PIPE_REPS / runs[1][0]
+            return out, None
+        except Exception as e:
+            return out, repr(e)[:300]
+
     def progress(msg):
         if os.environ.get("FD_BENCH_TRACE"):
             print("[querybench %s r%d] %s" % (time.strftime("%H:%M:%S"), rank, msg), file=sys.stderr, flush=True)
@@ -239,6 +271,11 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     progress("queries picked")
     loop(False, warm)()
     progress("warm-up done")
+    big_ok = len(queries) >= 128
+    pipe, err_pipe = {}, None
+    if os.environ.get("FD_BENCH_PIPE_EARLY"):      # measurement aid: the pipelined leg before the other legs
+        pipe, err_pipe = run_pipe()
+        progress("pipelined leg (early): %r %r" % (pipe, err_pipe))
     dt1, (hits, hashes, _) = timed(loop(False, range(len(queries))))
     progress("single prefilter leg done")
     dtb, hits_b = batched()
@@ -288,32 +325,8 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             dt_fused, err_fused = None, repr(e)[:300]
     # ... and NON-BLOCKING: the same batches handed to the context's query lanes (fdgpu_query_batch_submit / _wait), ONE host thread keeping
     # `depth` batches in flight — a batch's host-side steps (tables, waits, result copies) are covered by the other lanes' kernels
-    pipe, err_pipe = {}, None
-    if big and not sharded and first == 0:
-        try:
-            from collections import deque
-            ks1 = list(range(len(queries)))
-            chunks = [[(k, queries[k][1]) for k in ks1[c0:c0 + big]] for c0 in range(0, len(ks1), big)]
-
-            def go_pipe(reps, depth):
-                pend, tot = deque(), 0
-                for _ in range(reps):
-                    for qs in chunks:
-                        pend.append(query_batch_submit(ctx, ix, batch, qall, qs, float(S_total), top_n, match_top))
-                        if len(pend) >= depth:
-                            tot += len(pend.popleft().wait()[2][0])
-                while pend:
-                    tot += len(pend.popleft().wait()[2][0])
-                return tot
-            for depth in [int(x) for x in os.environ.get("FD_BENCH_PIPE_DEPTHS", "4").split(",")]:
-                n_l = ctx.L.fdgpu_query_lanes(ctx.h, depth)
-                assert n_l >= depth, ctx.L.fdgpu_last_error(ctx.h)
-                assert go_pipe(2 * depth, depth) == 2 * depth * nm_b, "pipelined call: match count differs from the three calls"      # warm-up: every lane allocates its scratch
-                runs = sorted((timed(lambda: go_pipe(PIPE_REPS, depth)) for _ in range(3)), key=lambda x: x[0])
-                assert runs[1][1] == PIPE_REPS * nm_b
-                pipe[depth] = len(queries) * PIPE_REPS / runs[1][0]
-        except Exception as e:
-            err_pipe = repr(e)[:300]
+    if not pipe and not err_pipe:
+        pipe, err_pipe = run_pipe()
     progress("big batch legs done")
     dtb2, mt_workers, mt_chunk, mt_all = None, 0, 32, {}
     if not sharded and len(queries) >= 64:
@@ -433,8 +446,10 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         except Exception as e:  # noqa: BLE001 — the bench line must still be printed
             cpu = {"error": repr(e)}
 
-    pipe_depth = 4 if 4 in pipe else (max(pipe) if pipe else None)      # 4 = the library's default number of lanes
-    pipe_best = pipe.get(pipe_depth) if pipe_depth else None
+    # ONE definition of the headline: the library's default 4 lanes, 6 batches in flight (FD_BENCH_PIPE adds other shapes beside it for measurements)
+    pipe_key = (4, 6) if (4, 6) in pipe else (max(pipe, key=lambda k: pipe[k]) if pipe else None)
+    pipe_best = pipe.get(pipe_key) if pipe_key else None
+    pipe_depth = pipe_key[1] if pipe_key else None
     return {
         # headline = the reference's default query (prefilter + candidate selection + matching + RMSD), 32 queries per launch set
         # headline = ONE host thread, batches of 128 full queries (what one Rust host thread per GPU drives through the ABI; fixed definition
@@ -446,16 +461,16 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                 "rank, Kabsch, metrics); value = batches of %d from ONE host thread, %s; batches of 32 / 512 and several host "
                 "threads with one context each are reported beside it (batched_with_matching, _512, _mt)"
                 % (top_n, match_top, big if dtbm_big else 32,
-                   ("fdgpu_query_batch_submit / _wait with %d batches in flight on the context's query lanes (pipelined_128; the blocking call: fused_128; the three "
-                    "separate calls: batched_with_matching_128)" % pipe_depth) if pipe_best else
+                   ("fdgpu_query_batch_submit / _wait with %d batches in flight on the context's %d query lanes (pipelined_128; the blocking call: fused_128; the three "
+                    "separate calls: batched_with_matching_128)" % (pipe_depth, pipe_key[0])) if pipe_best else
                    "one fdgpu_query_batch call per batch (fused_128; the three separate calls: batched_with_matching_128)"
                    if dt_fused else "three library calls per batch (batched_with_matching_128)"),
         "ms_per_query": 1e3 / pipe_best if pipe_best else (dt_fused if dt_fused else dtbm_big if dtbm_big else dtbm) / len(queries) * 1e3,
         "pipelined_128": ({"error": err_pipe} if err_pipe else None) if not pipe_best else {
-            "value": pipe_best, "ms_per_query": 1e3 / pipe_best, "chunk": big, "host_threads": 1, "lanes": pipe_depth, "queries": len(queries) * PIPE_REPS,
-            "queries_per_s_by_depth": {str(k): v for k, v in pipe.items()},
-            "mode": "fdgpu_query_batch_submit / fdgpu_query_batch_wait: ONE host thread keeps %d batches of 128 in flight; each runs on a library-owned lane (sibling context: "
-                    "own stream + scratch) through fdgpu_query_batch itself; %d passes over the %d queries per timed run, median of 3" % (pipe_depth, PIPE_REPS, len(queries))},
+            "value": pipe_best, "ms_per_query": 1e3 / pipe_best, "chunk": big, "host_threads": 1, "lanes": pipe_key[0], "in_flight": pipe_depth, "queries": len(queries) * PIPE_REPS,
+            "queries_per_s_by_lanes_x_in_flight": {"%dx%d" % k: v for k, v in pipe.items()},
+            "mode": "fdgpu_query_batch_submit / fdgpu_query_batch_wait: ONE host thread keeps %d batches of 128 in flight on %d library-owned lanes (sibling contexts: "
+                    "own stream + scratch, each runs fdgpu_query_batch itself); %d passes over the %d queries per timed run, median of 3" % (pipe_depth, pipe_key[0], PIPE_REPS, len(queries))},
         "fused_128": ({"error": err_fused} if err_fused else None) if not dt_fused else {
             "value": len(queries) / dt_fused, "ms_per_query": dt_fused / len(queries) * 1e3, "chunk": big, "host_threads": 1,
             "mode": "fdgpu_query_batch: query maps, scoring + ranked top %d, retrieval of the top %d in ONE call per batch of 128 (median of 7 passes)" % (top_n, match_top)},
