@@ -35,12 +35,12 @@ struct mp_sel {
 // descriptor + hash + output of one surviving (i, j) per lane (full-wave drains of the compaction queue: executed
 // divergently per survivor this part — ~3000 instructions with the exact libm chain — was 95 % of the kernel time)
 template <bool EMIT>
-__device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, const uint32_t *q, uint32_t n, uint32_t slot, uint32_t r0, uint32_t r1, uint32_t i0,
+__device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, const uint32_t *q, uint32_t n, uint32_t slot, uint32_t r0, uint32_t r1,
                                             const uint32_t *st_tab, const float *dist_tab, const uint32_t *tab) {
     const uint32_t lane = threadIdx.x;
     const bool on = lane < n;
     const uint32_t e0 = on ? q[lane] : 0u;
-    const uint32_t i = i0 + (e0 >> 16), j = r0 + (e0 & 0xffffu);
+    const uint32_t i = r0 + (e0 >> 16), j = r0 + (e0 & 0xffffu);      // queue entry: both residues relative to the candidate (a structure holds < 2^16)
     uint32_t aai = 255u, aaj = 255u, n_win = 0, h = 0, hitmask = 0;
     fd_feature feat = {0.f, 0.f, 0.f, 0.f, 0.f};
     fd_v3 cai = {0.f, 0.f, 0.f}, caj = {0.f, 0.f, 0.f};
@@ -187,6 +187,48 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     __shared__ uint32_t s_start[1025];
     const uint32_t w = blockIdx.x;
     if (w >= A.n_work) return;
+    const uint32_t slot = A.wi_cand[w];
+    const uint32_t s = A.cand[slot];
+    const uint32_t r0 = A.B.res_off[s], r1 = A.B.res_off[s + 1];
+    const uint32_t lane = threadIdx.x;
+    const bool tert = A.C.q.type == FD_HASH_TERTIARY;     // TertiaryInteraction needs no CB (feature.rs:113-160)
+    // prefilter sets (retrieve.rs:563-602); an empty set on either side switches to the full scan
+    bool full = true;
+    if (Sx.use_prefilter) {
+        uint64_t any1 = 0, any2 = 0;
+        for (uint32_t r = r0 + lane; r < r1 + lane; r += FD_WAVE) {
+            bool in = r < r1;
+            uint32_t a = in ? A.B.aa[r] : 255u;
+            bool stdn = in && a < 20u && (A.resname_std == nullptr || A.resname_std[r]);
+            any1 |= __ballot(stdn && ((Sx.aa1_mask >> a) & 1u));
+            any2 |= __ballot(stdn && ((Sx.aa2_mask >> a) & 1u));
+        }
+        full = !(any1 && any2);
+    }
+    // The i side is COMPACTED: a motif query names ~4 residue types, so only ~1 residue in 5 of a candidate can be the first residue of a pair
+    // (prefilter set, standard name, hashable — get_single_feature, controller/feature.rs:11-24, 84-99, rejects the rest).  With lane = residue of
+    // a 64-residue tile four lanes in five idled through the partner loop and a candidate's few passing pairs were spread over all its tiles'
+    // mostly empty drains.  Now lane = the (64 t + lane)-th ACTIVE residue of the candidate (t = the work item's tile number, from wi_i0 as before:
+    // the host still plans one item per 64 residues, the items beyond the last active tile return at once), found by one walk over the residue
+    // types: ballot + popcount rank, the tile's residues scattered into LDS.  Pair order inside a candidate changes; the records are grouped and
+    // ranked by (slot, i, j) downstream, as they were when several work items appended concurrently.
+    __shared__ uint32_t s_sel[FD_WAVE];
+    const uint32_t t_sel = (A.wi_i0[w] - r0) >> 6;
+    uint32_t n_act = 0;
+    for (uint32_t rb = r0; rb < r1; rb += FD_WAVE) {
+        const uint32_t r = rb + lane;
+        const bool in = r < r1;
+        const uint32_t a = in ? A.B.aa[r] : 255u;
+        const bool stdn = in && a < 20u && (A.resname_std == nullptr || A.resname_std[r]);
+        const bool ac = in && (full || (stdn && ((Sx.aa1_mask >> a) & 1u))) && a != 255u && (tert || A.B.hash_ok[r]);
+        const uint64_t m = __ballot(ac);
+        const uint32_t rank = n_act + fd_mbcnt(m);
+        if (ac && (rank >> 6) == t_sel) s_sel[rank & 63u] = r;
+        n_act += (uint32_t)__popcll(m);
+        if (n_act >= 64u * (t_sel + 1u)) break;
+    }
+    if (n_act <= 64u * t_sel) return;      // (wave-uniform) nothing left for this tile: before any table is staged
+    const uint32_t n_here = n_act - 64u * t_sel < FD_WAVE ? n_act - 64u * t_sel : FD_WAVE;
     // the query's observed (aa_i, aa_j) -> CA distance lists (aa_dist_map, controller/query.rs), grouped by residue-type pair:
     // aad_start[aa_i * 32 + aa_j] .. [+1] indexes the distance / query-residue arrays (host-sorted, stable).  Start table and,
     // for motif-sized queries, the distances live in LDS: per-pair global reads made the scan latency-bound.
@@ -213,33 +255,11 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     __syncthreads();
     const float *dist_tab = staged ? s_d_buf : Sx.aad_dist;
     const uint32_t *st_tab = big ? Sx.aad_start : s_start;
-    const uint32_t slot = A.wi_cand[w];
-    const uint32_t s = A.cand[slot];
-    const uint32_t r0 = A.B.res_off[s], r1 = A.B.res_off[s + 1];
-    const uint32_t lane = threadIdx.x;
-    // prefilter sets (retrieve.rs:563-602); an empty set on either side switches to the full scan
-    bool full = true;
-    if (Sx.use_prefilter) {
-        uint64_t any1 = 0, any2 = 0;
-        for (uint32_t r = r0 + lane; r < r1 + lane; r += FD_WAVE) {
-            bool in = r < r1;
-            uint32_t a = in ? A.B.aa[r] : 255u;
-            bool stdn = in && a < 20u && (A.resname_std == nullptr || A.resname_std[r]);
-            any1 |= __ballot(stdn && ((Sx.aa1_mask >> a) & 1u));
-            any2 |= __ballot(stdn && ((Sx.aa2_mask >> a) & 1u));
-        }
-        full = !(any1 && any2);
-    }
-    const uint32_t i0 = A.wi_i0[w];
-    const uint32_t i = i0 + lane;
-    const bool in_i = i < r1;
-    const uint32_t aai = in_i ? A.B.aa[i] : 255u;
-    const bool std_i = aai < 20u && (A.resname_std == nullptr || A.resname_std[i]);
-    // get_single_feature (controller/feature.rs:11-24, 84-99) rejects unknown residues / missing CB
-    const bool tert = A.C.q.type == FD_HASH_TERTIARY;     // TertiaryInteraction needs no CB (feature.rs:113-160)
-    const bool act = in_i && (full || (std_i && ((Sx.aa1_mask >> aai) & 1u))) && aai != 255u && (tert || A.B.hash_ok[i]);
+    const bool act = lane < n_here;
+    const uint32_t i = act ? s_sel[lane] : r0;
+    const uint32_t aai = act ? A.B.aa[i] : 255u;
     fd_v3 cai = {0.f, 0.f, 0.f};
-    if (in_i) cai = fd_load3(A.B.ca_xyz, i);
+    if (act) cai = fd_load3(A.B.ca_xyz, i);
     // partner residue types this lane's residue type has any observation with (aa < 32): one register test per pair
     uint32_t row_mask = 0;
     if (aai < 32u) {
@@ -310,14 +330,14 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                 }
                 const uint64_t m = __ballot(pass);
                 if (m) {
-                    if (pass) q[qn + fd_mbcnt(m)] = (lane << 16) | (j - r0);
+                    if (pass) q[qn + fd_mbcnt(m)] = ((i - r0) << 16) | (j - r0);
                     qn += (uint32_t)__popcll(m);
                 }
             }
             while (qn >= FD_WAVE) {
                 __syncthreads();
                 qn -= FD_WAVE;
-                match_drain<EMIT>(A, Sx, q + qn, FD_WAVE, slot, r0, r1, i0, st_tab, dist_tab, tab);
+                match_drain<EMIT>(A, Sx, q + qn, FD_WAVE, slot, r0, r1, st_tab, dist_tab, tab);
                 __syncthreads();
             }
         }
@@ -325,7 +345,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
             __syncthreads();
             const uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
             qn -= n;
-            match_drain<EMIT>(A, Sx, q + qn, n, slot, r0, r1, i0, st_tab, dist_tab, tab);
+            match_drain<EMIT>(A, Sx, q + qn, n, slot, r0, r1, st_tab, dist_tab, tab);
             __syncthreads();
         }
     }
