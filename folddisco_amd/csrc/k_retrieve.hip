@@ -496,22 +496,37 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_records(const rs_match_dev *__re
     if (lane < 39) out[39ull * k + lane] = v;
     for (uint32_t z = lane; z < pl.w; z += FD_WAVE) out_res[(uint64_t)pl.z + z] = residues[(uint64_t)r.res_pos + z];
 }
+// exclusive scan of one 64-bit value per thread over a workgroup of 1,024 (wave scans by shuffle, the sixteen wave totals through LDS; two barriers)
+__device__ __forceinline__ unsigned long long rs_block_excl64(unsigned long long v, uint32_t tid, unsigned long long *s_w, unsigned long long *total) {
+    const uint32_t lane = tid & 63u, wv = tid >> 6;
+    unsigned long long incl = v;
+    for (int off = 1; off < FD_WAVE; off <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, off, FD_WAVE), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, FD_WAVE);
+        if ((int)lane >= off) incl += ((unsigned long long)hi << 32) | lo;
+    }
+    __syncthreads();      // s_w may still be read by the scan before this one
+    if (lane == 63u) s_w[wv] = incl;
+    __syncthreads();
+    unsigned long long pre = 0, tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) { const unsigned long long x = s_w[k]; pre += k < wv ? x : 0ull; tot += x; }
+    *total = tot;
+    return pre + incl - v;
+}
 // Final places of the records without the host: exclusive scan of the slots' record counts (base of every slot), the per-query offsets the
 // caller gets (match_off[t] = base of query t's first slot, res_off = running 2 * n_idx * records) and every slot's first output residue.
 __global__ __launch_bounds__(1024) void k_rs_offsets(const uint32_t *__restrict__ slot_matches, uint32_t n_cand, const uint64_t *__restrict__ cand_off,
                                                      const uint32_t *__restrict__ slot_q, const rs_query_dev *__restrict__ qt, uint32_t n_queries,
                                                      uint32_t *__restrict__ mbase, uint32_t *__restrict__ rbase, uint64_t *__restrict__ match_off, uint64_t *__restrict__ res_off) {
-    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long part[16];
     const uint32_t tid = threadIdx.x;
     {   // slots
         const uint32_t per = (n_cand + 1023u) / 1024u, a = min(n_cand, tid * per), b = min(n_cand, a + per);
         unsigned long long s = 0;
         for (uint32_t k = a; k < b; ++k) s += slot_matches[k];
-        part[tid] = s;
-        __syncthreads();
-        if (tid == 0) { unsigned long long run = 0; for (int k = 0; k < 1024; ++k) { const unsigned long long t = part[k]; part[k] = run; run += t; } mbase[n_cand] = (uint32_t)run; }
-        __syncthreads();
-        uint32_t run = (uint32_t)part[tid];
+        unsigned long long tot;
+        uint32_t run = (uint32_t)rs_block_excl64(s, tid, part, &tot);      // (was: thread 0 walking 1,024 LDS words twice — 30 us per batch for a kernel that moves 40 KB)
+        if (tid == 0) mbase[n_cand] = (uint32_t)tot;
         for (uint32_t k = a; k < b; ++k) { mbase[k] = run; run += slot_matches[k]; }
         __syncthreads();
     }
@@ -523,11 +538,9 @@ __global__ __launch_bounds__(1024) void k_rs_offsets(const uint32_t *__restrict_
         auto ints = [&](uint32_t t) { return (match_off[t + 1] - match_off[t]) * 2ull * qt[t].n_idx; };
         unsigned long long s = 0;
         for (uint32_t t = a; t < b; ++t) s += ints(t);
-        part[tid] = s;
-        __syncthreads();
-        if (tid == 0) { unsigned long long run = 0; for (int k = 0; k < 1024; ++k) { const unsigned long long t = part[k]; part[k] = run; run += t; } res_off[n_queries] = run; }
-        __syncthreads();
-        unsigned long long run = part[tid];
+        unsigned long long tot;
+        unsigned long long run = rs_block_excl64(s, tid, part, &tot);
+        if (tid == 0) res_off[n_queries] = tot;
         for (uint32_t t = a; t < b; ++t) { res_off[t] = run; run += ints(t); }
         __syncthreads();
     }

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=128)
     ap.add_argument("--reps", type=int, default=24)
     ap.add_argument("--lanes", default="2,3,4")
+    ap.add_argument("--profile", default="", help="'blocking' or 'LANESxDEPTH' (e.g. 4x6): warm up, sleep 1 s, run ONLY that loop once (--reps passes), sleep 1 s, exit — "
+                    "for rocprofv3 --kernel-trace (tools/profile_round5_pipe.sh cuts the trace at the gaps)")
     ap.add_argument("--distinct", type=int, default=1, help="number of distinct query sets cycled through (1 = the bench's: the same 128 queries every pass)")
     a = ap.parse_args()
     import numpy as np
@@ -70,6 +72,22 @@ def main():
         r = fn()
         torch.cuda.synchronize()
         return time.perf_counter() - t0, r
+    if a.profile:
+        if a.profile == "blocking":
+            blocking(4)
+            fn = lambda: blocking(a.reps)
+        else:
+            lanes, depth = (int(x) for x in a.profile.split("x"))
+            assert ctx.L.fdgpu_query_lanes(ctx.h, lanes) >= lanes
+            piped(3 * lanes, lanes)
+            fn = lambda: piped(a.reps, depth)
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        dt, tot = timed(fn)
+        time.sleep(1.0)
+        print("PROFILE %s: %d batches of %d in %.3f ms = %.0f queries/s (%.3f ms per batch), %d matches" %
+              (a.profile, a.reps * len(sets[0][1]), a.chunk, dt * 1e3, n_q * a.reps / dt, dt / a.reps / len(sets[0][1]) * 1e3, tot), flush=True)
+        return
     want = blocking(max(2, len(sets)))
     runs = sorted(timed(lambda: blocking(a.reps))[0] for _ in range(3))
     print("blocking fdgpu_query_batch, one host thread       : %8.0f queries/s (%.3f ms per batch of %d)" % (n_q * a.reps / runs[1], runs[1] / a.reps / len(sets[0][1]) * 1e3, a.chunk), flush=True)
