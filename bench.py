@@ -160,8 +160,10 @@ def cli_index_leg(dev, seed, n_struct=20500):
     from folddisco_amd import synth
     from folddisco_amd import __main__ as cli
     work = tempfile.mkdtemp(prefix="fd_cli_bench_")
-    threads = min(64, os.cpu_count() or 1)
-    out = {"structures": n_struct, "ingest_threads": threads}
+    # ingest threads = the cores this container is really granted (cgroup quota / affinity), not the logical CPUs it can see: 64 threads on a
+    # 16-core quota are throttled in bursts (FD_BENCH_INGEST_THREADS overrides, for measurements)
+    threads = int(os.environ.get("FD_BENCH_INGEST_THREADS", "0")) or max(1, min(64, cpu_budget()["usable"]))
+    out = {"structures": n_struct, "ingest_threads": threads, "cpu_budget": cpu_budget()}
     try:
         d = synth.generate(n_struct, seed=seed + 77, device=dev)
         t0 = time.perf_counter()

@@ -11,6 +11,10 @@
 #include <atomic>
 #include <thread>
 #include "fdgpu_internal.h"
+#include <fcntl.h>
+#include <unistd.h>
+#include <cerrno>
+#include <cstring>
 
 #define HIPCHK(ctx, expr)                                                                                   \
     do {                                                                                                    \
@@ -1046,22 +1050,66 @@ extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, 
 }
 
 // byte-identical to wrapup_offset_and_save_entries + save_offset_to_file (indextable.rs:239-264, 297-326)
+// Device array -> file region, streamed: chunks of FD_PIN_BYTES land in the context's pinned slots (asynchronous copies on the context's stream) and
+// as many host threads pwrite() them straight from the pinned buffer into the file at their own offset — no host copy of the array, and the
+// page-cache copies of the chunks run in parallel (export-then-fwrite was one thread copying 976 MB twice: 0.33 of the CLI's 0.73 s at 20,500
+// structures).  io_err: first errno of a failed write.
+static hipError_t fd_d2h_to_file(fdgpu_ctx *c, int fd, uint64_t file_off, const void *src, size_t bytes, std::atomic<int> *io_err) {
+    if (!bytes) return hipSuccess;
+    for (int k = 0; k < FD_PIN_SLOTS; ++k) {
+        hipError_t e = hipSuccess;
+        if (!c->pin[k]) e = hipHostMalloc(&c->pin[k], FD_PIN_BYTES, hipHostMallocDefault);
+        if (e == hipSuccess && !c->pin_ev[k]) e = hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    const size_t n_chunks = (bytes + FD_PIN_BYTES - 1) / FD_PIN_BYTES;
+    std::vector<std::thread> drain(FD_PIN_SLOTS);
+    hipError_t err = hipSuccess;
+    const int dev = c->device;
+    for (size_t i = 0; i < n_chunks && err == hipSuccess; ++i) {
+        const int k = (int)(i % FD_PIN_SLOTS);
+        if (drain[k].joinable()) drain[k].join();                  // the slot's previous chunk is in the file
+        const size_t off = i * FD_PIN_BYTES, n = std::min(FD_PIN_BYTES, bytes - off);
+        err = hipMemcpyAsync(c->pin[k], (const uint8_t *)src + off, n, hipMemcpyDeviceToHost, c->stream);
+        if (err == hipSuccess) err = hipEventRecord(c->pin_ev[k], c->stream);
+        if (err != hipSuccess) break;
+        const uint8_t *pin = (const uint8_t *)c->pin[k];
+        hipEvent_t ev = c->pin_ev[k];
+        drain[k] = std::thread([=]() {
+            (void)hipSetDevice(dev);
+            if (hipEventSynchronize(ev) != hipSuccess) { int z = 0; io_err->compare_exchange_strong(z, EIO); return; }
+            size_t done = 0;
+            while (done < n) {
+                const ssize_t w = pwrite(fd, pin + done, n - done, (off_t)(file_off + off + done));
+                if (w < 0) { if (errno == EINTR) continue; int z = 0; io_err->compare_exchange_strong(z, errno ? errno : EIO); return; }
+                done += (size_t)w;
+            }
+        });
+    }
+    for (auto &t : drain) if (t.joinable()) t.join();
+    return err;
+}
+
+// PREFIX (value bytes) and PREFIX.offset (u64 H | u32 hashes[H] | u64 offsets[H + 1]) — byte-identical to save_offset_to_file /
+// wrapup_offset_and_save_entries (src/index/indextable.rs:239-326), written straight from the device arrays
 extern "C" int fdgpu_index_save(fdgpu_ctx *c, const fdgpu_index *ix, const char *prefix) { FD_LOCK(c);
     if (!c || !ix || !prefix) return FDGPU_EINVAL;
-    uint8_t *v = nullptr; uint32_t *h = nullptr; uint64_t *o = nullptr; uint64_t vl = 0, H = 0;
-    int rc = fdgpu_index_export(c, ix, &v, &vl, &h, &o, &H);
-    if (rc) return rc;
-    std::string p(prefix);
-    FILE *f = fopen(p.c_str(), "wb");
-    bool ok = f != nullptr;
-    if (ok && vl) ok = fwrite(v, 1, vl, f) == vl;
-    if (f) fclose(f);
-    f = ok ? fopen((p + ".offset").c_str(), "wb") : nullptr;
-    ok = ok && f != nullptr;
-    if (ok) ok = fwrite(&H, 8, 1, f) == 1 && (H == 0 || fwrite(h, 4, H, f) == H) && fwrite(o, 8, H + 1, f) == H + 1;
-    if (f) fclose(f);
-    free(v); free(h); free(o);
-    if (!ok) FAIL(c, FDGPU_EINVAL, "index save: cannot write " + p);
+    const std::string p(prefix);
+    const uint64_t H = ix->n_hashes;
+    std::atomic<int> io_err{0};
+    hipError_t e = hipSuccess;
+    const int fv = open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    const int fo = fv >= 0 ? open((p + ".offset").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644) : -1;
+    if (fv < 0 || fo < 0) { if (fv >= 0) close(fv); FAIL(c, FDGPU_EINVAL, "index save: cannot write " + p); }
+    if (pwrite(fo, &H, 8, 0) != 8) io_err = errno ? errno : EIO;
+    e = fd_d2h_to_file(c, fv, 0, ix->value, ix->value_len, &io_err);
+    if (e == hipSuccess) e = fd_d2h_to_file(c, fo, 8, ix->hashes, H * 4, &io_err);
+    if (e == hipSuccess) e = fd_d2h_to_file(c, fo, 8 + H * 4, ix->offsets, (H + 1) * 8, &io_err);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (close(fv) != 0 && !io_err) io_err = errno ? errno : EIO;
+    if (close(fo) != 0 && !io_err) io_err = errno ? errno : EIO;
+    if (e != hipSuccess) { c->err = std::string("index save: ") + hipGetErrorString(e); return FDGPU_EHIP; }
+    if (io_err) FAIL(c, FDGPU_EINVAL, "index save: cannot write " + p + " (" + strerror(io_err) + ")");
     return FDGPU_OK;
 }
 
