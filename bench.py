@@ -190,7 +190,7 @@ def cli_index_leg(dev, seed, n_struct=20500):
             sha = hashlib.sha256(open(pre, "rb").read()).hexdigest()[:16]
             out[name] = {"value": n_struct / wall, "unit": "structures/s", "wall_s": round(wall, 3), "input_bytes": nbytes,
                          "ingest_s": round(T.get("ingest_s", 0.0), 3), "gpu_build_s": round(T.get("gpu_build_s", 0.0), 3), "device_merge_s": round(T.get("merge_s", 0.0), 3),
-                         "export_and_files_s": round(T.get("export_write_s", 0.0), 3), "chunks": T.get("chunks"), "index_bytes": os.path.getsize(pre),
+                         "export_and_files_s": round(T.get("export_write_s", 0.0), 3), "save_s": round(T.get("save_s", 0.0), 3), "chunks": T.get("chunks"), "index_bytes": os.path.getsize(pre),
                          "index_sha256_16": sha,
                          "ingest_thread_s": None if not st5[3] else {"read_inflate": round(st5[0], 3), "parse_text": round(st5[1], 3), "compact_build": round(st5[2], 3),
                                                                      "files": int(st5[3]), "inflated_bytes": int(st5[4]),

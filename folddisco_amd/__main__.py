@@ -90,6 +90,7 @@ def cmd_index(a):
     T["merge_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     ix.save(prefix)                               # the library writes PREFIX and PREFIX.offset itself (byte-identical to save_offset_to_file)
+    T["save_s"] = time.perf_counter() - t0
     n_hashes, value_len = ix.num_hashes, ix.value_len
     indexio.save_lookup(prefix + ".lookup", [indexio.parse_path_by_id_type(x, a.id) for x in paths], nres, plddt, db_keys=a.fc_keys)
     indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type], multiple_bins=a.multi,

@@ -646,3 +646,69 @@ extern "C" int fdgpu_parse_foldcomp_db(const char *db_path, const uint64_t *keys
     if (db_len) munmap((void *)db, db_len);
     return pack_parsed(parts, max_residue, out);
 }
+
+// ---- PREFIX.lookup --------------------------------------------------------------------------------------------------------------
+// Rust `{}` of an f32 (what src/index/lookup.rs:44 prints for the plddt column): the shortest digits that round-trip, NEVER exponent form,
+// integral values without a fraction, "NaN" / "inf" / "-inf".  Digits = the shortest scientific form (std::to_chars), laid out positionally.
+#include <charconv>
+static size_t fd_f32_display(float v, char *out) {
+    if (v != v) { memcpy(out, "NaN", 3); return 3; }
+    if (std::isinf(v)) { const char *s = v > 0 ? "inf" : "-inf"; const size_t n = strlen(s); memcpy(out, s, n); return n; }
+    char sci[48];
+    const auto r = std::to_chars(sci, sci + sizeof sci - 1, v, std::chars_format::scientific);      // d[.ddd]e[+-]xx, shortest round-trip
+    *r.ptr = 0;      // (to_chars does not terminate: the exponent is parsed with strtol below)
+    const char *p = sci;
+    const bool neg = *p == '-';
+    if (neg) ++p;
+    char digits[24];
+    size_t nd = 0;
+    for (; p < r.ptr && *p != 'e'; ++p) if (*p != '.') digits[nd++] = *p;
+    const int ex = (int)strtol(p + 1, nullptr, 10);
+    while (nd > 1 && digits[nd - 1] == '0') --nd;
+    size_t o = 0;
+    const bool zero = nd == 1 && digits[0] == '0';
+    if (neg && !zero) out[o++] = '-';
+    if (ex < 0) {
+        out[o++] = '0'; out[o++] = '.';
+        for (int k = 0; k < -ex - 1; ++k) out[o++] = '0';
+        memcpy(out + o, digits, nd); o += nd;
+    } else if ((int)nd <= ex + 1) {
+        memcpy(out + o, digits, nd); o += nd;
+        for (int k = 0; k < ex + 1 - (int)nd; ++k) out[o++] = '0';
+    } else {
+        memcpy(out + o, digits, (size_t)ex + 1); o += (size_t)ex + 1;
+        out[o++] = '.';
+        memcpy(out + o, digits + ex + 1, nd - (size_t)ex - 1); o += nd - (size_t)ex - 1;
+    }
+    return o;
+}
+// n values -> out[k * 64 ..] NUL-terminated strings (a float's positional form has at most 1 + 39 + 1 + 9 characters)
+extern "C" int fdgpu_format_f32_display(const float *v, uint64_t n, char *out) {
+    if ((n && !v) || !out) return FDGPU_EINVAL;
+    for (uint64_t k = 0; k < n; ++k) { const size_t m = fd_f32_display(v[k], out + 64 * k); out[64 * k + m] = 0; }
+    return FDGPU_OK;
+}
+// id \t tid \t nres \t plddt \t db_key \n per structure (src/index/lookup.rs:35-56, build_index.rs:204-215).  tids: the n ids joined by '\n'
+// (an id holds no newline); db_keys NULL = the id itself.
+extern "C" int fdgpu_write_lookup(const char *path, const char *tids, uint64_t n, const uint64_t *nres, const float *plddt, const uint64_t *db_keys) {
+    if (!path || (n && (!tids || !nres || !plddt))) return FDGPU_EINVAL;
+    std::string buf;
+    buf.reserve((size_t)n * 64);
+    const char *t = tids;
+    char num[64];
+    for (uint64_t k = 0; k < n; ++k) {
+        const char *e = strchr(t, '\n');
+        const size_t len = e ? (size_t)(e - t) : strlen(t);
+        if (!e && k + 1 < n) return FDGPU_EINVAL;      // fewer ids than structures
+        buf.append(num, (size_t)snprintf(num, sizeof num, "%llu\t", (unsigned long long)k));
+        buf.append(t, len);
+        buf.append(num, (size_t)snprintf(num, sizeof num, "\t%llu\t", (unsigned long long)nres[k]));
+        buf.append(num, fd_f32_display(plddt[k], num));
+        buf.append(num, (size_t)snprintf(num, sizeof num, "\t%llu\n", (unsigned long long)(db_keys ? db_keys[k] : k)));
+        t = e ? e + 1 : t + len;
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) return FDGPU_EINVAL;
+    const bool ok = buf.empty() || fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    return fclose(f) == 0 && ok ? FDGPU_OK : FDGPU_EINVAL;
+}

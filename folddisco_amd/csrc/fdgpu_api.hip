@@ -1102,12 +1102,22 @@ extern "C" int fdgpu_index_save(fdgpu_ctx *c, const fdgpu_index *ix, const char 
     const int fo = fv >= 0 ? open((p + ".offset").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644) : -1;
     if (fv < 0 || fo < 0) { if (fv >= 0) close(fv); FAIL(c, FDGPU_EINVAL, "index save: cannot write " + p); }
     if (pwrite(fo, &H, 8, 0) != 8) io_err = errno ? errno : EIO;
-    e = fd_d2h_to_file(c, fv, 0, ix->value, ix->value_len, &io_err);
+    const bool trace = getenv("FDGPU_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    if (trace) {      // measurement aid: the page-locking of the staging slots apart from the streaming
+        for (int k = 0; k < FD_PIN_SLOTS && e == hipSuccess; ++k) if (!c->pin[k]) e = hipHostMalloc(&c->pin[k], FD_PIN_BYTES, hipHostMallocDefault);
+        fprintf(stderr, "[index_save] staging slots page-locked at %.3f ms\n", ms());
+    }
+    if (e == hipSuccess) e = fd_d2h_to_file(c, fv, 0, ix->value, ix->value_len, &io_err);
+    if (trace) fprintf(stderr, "[index_save] %llu value bytes streamed at %.3f ms\n", (unsigned long long)ix->value_len, ms());
     if (e == hipSuccess) e = fd_d2h_to_file(c, fo, 8, ix->hashes, H * 4, &io_err);
     if (e == hipSuccess) e = fd_d2h_to_file(c, fo, 8 + H * 4, ix->offsets, (H + 1) * 8, &io_err);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (trace) fprintf(stderr, "[index_save] offset file streamed at %.3f ms\n", ms());
     if (close(fv) != 0 && !io_err) io_err = errno ? errno : EIO;
     if (close(fo) != 0 && !io_err) io_err = errno ? errno : EIO;
+    if (trace) fprintf(stderr, "[index_save] files closed at %.3f ms\n", ms());
     if (e != hipSuccess) { c->err = std::string("index save: ") + hipGetErrorString(e); return FDGPU_EHIP; }
     if (io_err) FAIL(c, FDGPU_EINVAL, "index save: cannot write " + p + " (" + strerror(io_err) + ")");
     return FDGPU_OK;

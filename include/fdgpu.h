@@ -519,6 +519,13 @@ int fdgpu_enable_timing(fdgpu_ctx *ctx, int on);
  * op: 0 sinf, 1 cosf, 2 acosf, 3 atanf, 4 atan2f(a, b). */
 int fdgpu_debug_libm(fdgpu_ctx *ctx, int op, const float *a, const float *b, float *out, uint64_t n);
 
+/* ---- PREFIX.lookup (src/index/lookup.rs:35-56; written by build_index.rs:204-215) -------------------------------------------------
+ * One line per structure: id \t tid \t nres \t plddt \t db_key \n, plddt printed like Rust's `{}` of an f32 (shortest digits that
+ * round-trip, never exponent form, integral values without a fraction, NaN / inf spelled so).  tids = the n ids joined by '\n';
+ * db_keys NULL = the id.  fdgpu_format_f32_display writes the n strings NUL-terminated at out + 64 * k. */
+int fdgpu_write_lookup(const char *path, const char *tids, uint64_t n, const uint64_t *nres, const float *plddt, const uint64_t *db_keys);
+int fdgpu_format_f32_display(const float *v, uint64_t n, char *out);
+
 #ifdef __cplusplus
 }
 #endif
