@@ -193,19 +193,33 @@ def _cmd_index_sharded(a, fd, indexio, structure, paths, prefix, rank, world):
     ctx = fd.Context(a.device)
     a.timings = {}
     parts, nres, plddt = _build_chunks(a, fd, structure, ctx, paths[lo:hi], lo, resident=True)
-    _merge_resident(fd, parts).save(_shard_prefix(prefix, rank, world))      # the rank's chunks merged on the device, one export
+    local = _merge_resident(fd, parts)              # the rank's chunks merged on the device
+    local.save(_shard_prefix(prefix, rank, world))  # the shard stays on disk for the sharded query
+    # ONE index for the database without the host (Option A; csrc/fd_shard_index.hip): hash ranges of equal posting bytes, piece j of
+    # every rank's sub-index to rank j — ncclSend / ncclRecv inside the library when the ranks have a GPU each (backend nccl), torch.distributed objects
+    # under gloo —, per-hash concatenation of the pieces on the device, every rank writes its regions of PREFIX / PREFIX.offset
+    if dist.get_backend() == "nccl":
+        comm = fdist.Comm(ctx, rank, world)
+        rng, hb, vb, ht, vt = comm.single_index(local)
+    else:
+        comm = None
+        rng, hb, vb, ht, vt = fdist.single_index_over_process_group(ctx, local)
+    if rank == 0:
+        for ext in ("", ".offset"):                 # regions are written in place: a stale file of another size must not survive beside them
+            if os.path.exists(prefix + ext):
+                os.remove(prefix + ext)
+    dist.barrier()
+    rng.save_part(prefix, hb, vb, ht, vt, write_header=(rank == 0), is_last=(rank == world - 1))
+    del rng, comm
     box = [None] * world
     dist.all_gather_object(box, (nres, plddt))
     dist.barrier()
     if rank == 0:
-        shards = [indexio.read_index_files(_shard_prefix(prefix, r, world)) for r in range(world)]
-        mv, mh, mo = indexio.merge_subindices(shards)
-        indexio.write_index_files(prefix, mv, mh, mo)
         indexio.save_lookup(prefix + ".lookup", [indexio.parse_path_by_id_type(x, a.id) for x in paths], np.concatenate([b[0] for b in box]), np.concatenate([b[1] for b in box]), db_keys=a.fc_keys)
         indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type], multiple_bins=a.multi,
                           **(dict(input_format="FCZDB", foldcomp_db=a.pdbs) if a.fc is not None else {}))
         if a.verbose:
-            print(f"[DONE] {len(paths)} structures over {world} ranks, {len(mh)} hashes, {len(mv)} value bytes -> {prefix}", file=sys.stderr)
+            print(f"[DONE] {len(paths)} structures over {world} ranks, {ht} hashes, {vt} value bytes -> {prefix}", file=sys.stderr)
     dist.barrier()
     dist.destroy_process_group()
 

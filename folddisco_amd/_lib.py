@@ -199,6 +199,10 @@ SYMBOLS = [
     ("fdgpu_sharded_count_query", C.c_int, [VP, VP, VP, C.c_uint64, u64p, u32p, u32p, u32p, f32p, C.c_uint64, C.c_uint32,
                                             C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
     ("fdgpu_comm_stats", C.c_int, [VP, u64p, u64p]),
+    ("fdgpu_index_range_bounds", C.c_int, [VP, VP, C.c_uint32, u32p]),
+    ("fdgpu_index_slice", C.c_int, [VP, VP, C.c_uint64, C.c_uint64, C.POINTER(VP)]),
+    ("fdgpu_comm_single_index", C.c_int, [VP, VP, VP, C.POINTER(VP), u64p, u64p, u64p, u64p]),
+    ("fdgpu_index_save_part", C.c_int, [VP, VP, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]),
     ("fdgpu_sharded_count_query_maps", C.c_int, [VP, VP, VP, C.c_uint64, C.c_void_p, f32p, C.c_uint64, C.c_uint32,
                                                  C.POINTER(C.POINTER(CountRec)), C.POINTER(u64p)]),
     ("fdgpu_sharded_retrieve", C.c_int, [VP, VP, VP, C.c_uint64, u8p, C.c_uint64, u32p, u64p, C.POINTER(C.POINTER(QueryMap)), VP, u32p,

@@ -233,6 +233,24 @@ class FolddiscoIndex:
     def save(self, prefix: str):
         self.ctx.check(self.ctx.L.fdgpu_index_save(self.ctx.h, self.h, prefix.encode()))
 
+    # ---- one on-disk index from N ranks (fd_shard_index.hip; SURVEY §8e row 2, Option A)
+    def range_bounds(self, n_ranges: int) -> np.ndarray:
+        """n_ranges - 1 ascending hash values cutting this index into ranges of about equal posting bytes"""
+        b = np.zeros(max(n_ranges - 1, 1), np.uint32)
+        self.ctx.check(self.ctx.L.fdgpu_index_range_bounds(self.ctx.h, self.h, n_ranges, _ptr(b, u32p)))
+        return b[: n_ranges - 1]
+
+    def slice(self, hash_lo: int, hash_hi: int) -> "FolddiscoIndex":
+        """the lists with hash_lo <= hash < hash_hi as a resident index of their own (same id range)"""
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.L.fdgpu_index_slice(self.ctx.h, self.h, int(hash_lo), int(hash_hi), C.byref(h)))
+        return FolddiscoIndex(self.ctx, h, self.n_structures, self.first_id)
+
+    def save_part(self, prefix: str, hashes_before: int, value_before: int, total_hashes: int, total_value: int, write_header: bool, is_last: bool):
+        """this index = one hash range of the database's single index: its regions of PREFIX / PREFIX.offset"""
+        self.ctx.check(self.ctx.L.fdgpu_index_save_part(self.ctx.h, self.h, prefix.encode(), int(hashes_before), int(value_before), int(total_hashes), int(total_value),
+                                                        int(bool(write_header)), int(bool(is_last))))
+
     def get_entries(self, q_hash) -> list:
         """decoded posting lists (ascending structure ids) of the given hashes (get_entries, index/indextable.rs:83-86)"""
         q = np.ascontiguousarray(q_hash, dtype=np.uint32)

@@ -37,6 +37,10 @@ struct rccl_api {
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;        // optional
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;      // optional: the single-index exchange (fdgpu_comm_single_index)
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -54,6 +58,10 @@ rccl_api &rccl() {
         a.CommAbort = (decltype(a.CommAbort))dlsym(a.lib, "ncclCommAbort");
         a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
         a.AllGather = (decltype(a.AllGather))dlsym(a.lib, "ncclAllGather");
+        a.Send = (decltype(a.Send))dlsym(a.lib, "ncclSend");
+        a.Recv = (decltype(a.Recv))dlsym(a.lib, "ncclRecv");
+        a.GroupStart = (decltype(a.GroupStart))dlsym(a.lib, "ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.lib, "ncclGroupEnd");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
         a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.AllGather && a.GetErrorString;
         return a;
@@ -72,8 +80,9 @@ struct fdgpu_comm {
     fdgpu_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
-    fd_devbuf send, recv;
+    fd_devbuf send, recv, aux;      // aux: small per-call tables of the device-resident retrieval exchange
     merge_bufs mb;
+    uint64_t n_sendrecv = 0;                        // point-to-point transfers issued (fdgpu_comm_single_index)
     uint64_t n_allreduce = 0, n_allgather = 0;      // collectives issued so far (fdgpu_comm_stats: tests check that a world of one runs them)
     bool dead = false;                              // aborted after a failure between collectives: every later call fails at once
 };
@@ -134,7 +143,7 @@ extern "C" int fdgpu_comm_init(fdgpu_ctx *c, const uint8_t id[FDGPU_COMM_ID_BYTE
     if (m->send.ensure(FD_COMM_RESERVE) != hipSuccess || m->recv.ensure(FD_COMM_RESERVE * (size_t)world) != hipSuccess) {
         (void)hipGetLastError();
         c->err = "fdgpu_comm_init: exchange buffers";
-        (void)rccl().CommDestroy(m->comm); m->send.release(); m->recv.release(); delete m;
+        (void)rccl().CommDestroy(m->comm); m->send.release(); m->recv.release(); m->aux.release(); delete m;
         return FDGPU_EHIP;
     }
     *out = m;
@@ -144,7 +153,7 @@ extern "C" void fdgpu_comm_destroy(fdgpu_comm *m) {
     if (!m) return;
     FD_LOCK(m->ctx);
     if (m->comm && rccl().ok) (void)rccl().CommDestroy(m->comm);
-    m->send.release(); m->recv.release(); m->mb.release();
+    m->send.release(); m->recv.release(); m->aux.release(); m->mb.release();
     delete m;
 }
 extern "C" int fdgpu_comm_rank(const fdgpu_comm *m) { return m ? m->rank : -1; }
@@ -576,6 +585,140 @@ static int merge_retrieved(int W, uint64_t n_queries, const uint64_t *all_cnt, c
     *matches = om; *match_off = omo; *residues = orr; *res_off = oro;
     return FDGPU_OK;
 }
+// ---- one on-disk index from N ranks (Option A; fd_shard_index.hip has the transport-free pieces) --------------------------------
+// Every rank brings the resident sub-index of its id range; it gets back the resident index of ITS HASH RANGE over ALL structures and where that
+// range sits in the database's single index: hashes / value bytes before it and the totals — what fdgpu_index_save_part needs.  Steps: hash bounds of
+// about equal posting bytes from rank 0's index (all-gather, rank 0's row used), N slices per rank, an all-gather of the slices' sizes, ONE group of
+// ncclSend / ncclRecv — piece j of every rank to rank j, device to device over xGMI: the (hash, id) payload of SURVEY §8e, here already varint-encoded,
+// ~1.5 bytes per posting instead of 8 —, fdgpu_index_merge of the N received pieces (their id ranges ascend with the source rank), an all-gather of
+// the ranges' sizes.  A rank that fails between the collectives aborts the communicator (comm_broken) so that its peers do not wait for ever.
+extern "C" int fdgpu_comm_single_index(fdgpu_ctx *c, fdgpu_comm *m, const fdgpu_index *local, fdgpu_index **range_index, uint64_t *hashes_before, uint64_t *value_before,
+                                       uint64_t *total_hashes, uint64_t *total_value) { FD_LOCK(c);
+    if (!c || !m || !local || !range_index || !hashes_before || !value_before || !total_hashes || !total_value) return FDGPU_EINVAL;
+    *range_index = nullptr;
+    if (m->dead) FAIL_(c, FDGPU_EHIP, "communicator aborted by an earlier failure");
+    if (!rccl().Send || !rccl().Recv || !rccl().GroupStart || !rccl().GroupEnd) FAIL_(c, FDGPU_EHIP, "this RCCL has no ncclSend / ncclRecv");
+    const int W = m->world, me = m->rank;
+    if (W > 64) FAIL_(c, FDGPU_ERANGE, "single index: at most 64 ranks (fdgpu_index_merge takes 64 parts)");
+    hipStream_t st = c->stream;
+    // 1. hash bounds: rank 0's
+    std::vector<uint32_t> bnd((size_t)std::max(W - 1, 1), 0xffffffffu), all_bnd((size_t)W * std::max(W - 1, 1));
+    int rc = fdgpu_index_range_bounds(c, local, (uint32_t)W, bnd.data());
+    const size_t bb = bnd.size() * 4;
+    HCHK_C(c, m, m->send.ensure(bb));
+    HCHK_C(c, m, m->recv.ensure(bb * W));
+    HCHK_C(c, m, hipMemcpyAsync(m->send.p, bnd.data(), bb, hipMemcpyHostToDevice, st));
+    int rg = allgather_dev(c, m, m->send.p, m->recv.p, bb);
+    if (rg) return rg;
+    HCHK_C(c, m, hipMemcpyAsync(all_bnd.data(), m->recv.p, bb * W, hipMemcpyDeviceToHost, st));
+    HCHK_C(c, m, hipStreamSynchronize(st));
+    std::vector<uint64_t> edge((size_t)W + 1, 0);
+    for (int j = 1; j < W; ++j) edge[j] = std::max<uint64_t>(edge[j - 1], all_bnd[j - 1]);      // rank 0's row, kept monotone
+    edge[W] = 1ull << 32;
+    // 2. this rank's slices
+    std::vector<fdgpu_index *> sl((size_t)W, nullptr), got((size_t)W, nullptr);
+    auto drop = [&]() { for (auto *x : sl) fdgpu_index_destroy(x); for (auto *x : got) fdgpu_index_destroy(x); };
+    for (int j = 0; j < W && !rc; ++j) rc = fdgpu_index_slice(c, local, edge[j], edge[j + 1], &sl[j]);
+    // 3. sizes: [W][4] {hashes, value bytes, postings, has last ids} of the slices + {first id, structures, status}
+    const size_t mw = (size_t)4 * W + 3;
+    std::vector<uint64_t> meta(mw, 0), all_meta(mw * W);
+    for (int j = 0; j < W && !rc; ++j) { meta[4 * j] = sl[j]->n_hashes; meta[4 * j + 1] = sl[j]->value_len; meta[4 * j + 2] = sl[j]->n_postings; meta[4 * j + 3] = sl[j]->last_ids ? 1 : 0; }
+    meta[4 * W] = local->first_id; meta[4 * W + 1] = local->n_structures; meta[4 * W + 2] = rc ? (uint64_t)(uint32_t)(-rc) : 0;
+    hipError_t he = m->send.ensure(mw * 8);
+    if (he == hipSuccess) he = m->recv.ensure(mw * 8 * W);
+    if (he == hipSuccess) he = hipMemcpyAsync(m->send.p, meta.data(), mw * 8, hipMemcpyHostToDevice, st);
+    if (he != hipSuccess) { drop(); return comm_broken(c, m, std::string("single index: ") + hipGetErrorString(he)); }
+    if ((rg = allgather_dev(c, m, m->send.p, m->recv.p, mw * 8))) { drop(); return rg; }
+    he = hipMemcpyAsync(all_meta.data(), m->recv.p, mw * 8 * W, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he != hipSuccess) { drop(); return comm_broken(c, m, std::string("single index: ") + hipGetErrorString(he)); }
+    for (int r = 0; r < W; ++r)
+        if (all_meta[mw * r + 4 * W + 2]) {
+            if (r != me || !rc) c->err = "single index: rank " + std::to_string(r) + " failed to slice its sub-index";
+            drop();
+            return rc ? rc : FDGPU_EHIP;
+        }
+    // 4. the pieces this rank receives: piece r = rank r's slice of this rank's hash range, with rank r's id range
+    for (int r = 0; r < W; ++r) {
+        const uint64_t *mr = &all_meta[mw * r + 4 * me];
+        fdgpu_index *g = new (std::nothrow) fdgpu_index();
+        if (!g) { drop(); return comm_broken(c, m, "single index: out of memory"); }
+        got[r] = g;
+        g->ctx = c; g->n_hashes = mr[0]; g->value_len = mr[1]; g->n_postings = mr[2]; g->first_id = all_meta[mw * r + 4 * W]; g->n_structures = all_meta[mw * r + 4 * W + 1];
+        hipError_t e;
+        g->hashes = (uint32_t *)c->pool_alloc(std::max<uint64_t>(g->n_hashes, 1) * 4, &e); g->cap_hashes = c->last_cap;
+        if (e == hipSuccess) { g->offsets = (uint64_t *)c->pool_alloc((g->n_hashes + 1) * 8, &e); g->cap_offsets = c->last_cap; }
+        if (e == hipSuccess) { g->value = (uint8_t *)c->pool_alloc(g->value_len + 16, &e); g->cap_value = c->last_cap; }
+        if (e == hipSuccess && mr[3]) { g->last_ids = (uint32_t *)c->pool_alloc(std::max<uint64_t>(g->n_hashes, 1) * 4, &e); g->cap_last = c->last_cap; }
+        if (e != hipSuccess) { drop(); return comm_broken(c, m, std::string("single index: ") + hipGetErrorString(e)); }
+    }
+    ncclResult_t nr = rccl().GroupStart();
+    for (int r = 0; r < W && nr == ncclSuccess; ++r) {
+        const fdgpu_index *s = sl[r];
+        fdgpu_index *g = got[r];
+        if (s->n_hashes) {
+            nr = rccl().Send(s->hashes, s->n_hashes * 4, ncclUint8, r, m->comm, st);
+            if (nr == ncclSuccess && s->last_ids) nr = rccl().Send(s->last_ids, s->n_hashes * 4, ncclUint8, r, m->comm, st);
+        }
+        if (nr == ncclSuccess) nr = rccl().Send(s->offsets, (s->n_hashes + 1) * 8, ncclUint8, r, m->comm, st);
+        if (nr == ncclSuccess && s->value_len) nr = rccl().Send(s->value, s->value_len, ncclUint8, r, m->comm, st);
+        if (nr == ncclSuccess && g->n_hashes) {
+            nr = rccl().Recv(g->hashes, g->n_hashes * 4, ncclUint8, r, m->comm, st);
+            if (nr == ncclSuccess && g->last_ids) nr = rccl().Recv(g->last_ids, g->n_hashes * 4, ncclUint8, r, m->comm, st);
+        }
+        if (nr == ncclSuccess) nr = rccl().Recv(g->offsets, (g->n_hashes + 1) * 8, ncclUint8, r, m->comm, st);
+        if (nr == ncclSuccess && g->value_len) nr = rccl().Recv(g->value, g->value_len, ncclUint8, r, m->comm, st);
+        m->n_sendrecv += 2;
+    }
+    const ncclResult_t ne = rccl().GroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr == ncclSuccess) he = hipStreamSynchronize(st);
+    if (nr != ncclSuccess || he != hipSuccess) {
+        drop();
+        return comm_broken(c, m, std::string("single index exchange: ") + (nr != ncclSuccess ? rccl().GetErrorString(nr) : hipGetErrorString(he)));
+    }
+    for (auto *&x : sl) { fdgpu_index_destroy(x); x = nullptr; }
+    // 5. the N pieces of this rank's hash range, concatenated per hash on the device
+    fdgpu_index *range = nullptr;
+    rc = fdgpu_index_merge(c, (const fdgpu_index *const *)got.data(), (uint64_t)W, &range);
+    for (auto *&x : got) { fdgpu_index_destroy(x); x = nullptr; }
+    // 6. where the range sits
+    uint64_t mine[3] = {range ? range->n_hashes : 0, range ? range->value_len : 0, rc ? (uint64_t)(uint32_t)(-rc) : 0};
+    std::vector<uint64_t> all3((size_t)3 * W);
+    he = hipMemcpyAsync(m->send.p, mine, 24, hipMemcpyHostToDevice, st);
+    if (he != hipSuccess) { fdgpu_index_destroy(range); return comm_broken(c, m, std::string("single index: ") + hipGetErrorString(he)); }
+    if ((rg = allgather_dev(c, m, m->send.p, m->recv.p, 24))) { fdgpu_index_destroy(range); return rg; }
+    he = hipMemcpyAsync(all3.data(), m->recv.p, (size_t)24 * W, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he != hipSuccess) { fdgpu_index_destroy(range); return comm_broken(c, m, std::string("single index: ") + hipGetErrorString(he)); }
+    uint64_t hb = 0, vb = 0, ht = 0, vt = 0;
+    for (int r = 0; r < W; ++r) {
+        if (all3[3 * r + 2]) {
+            if (r != me || !rc) c->err = "single index: rank " + std::to_string(r) + " failed to merge its hash range";
+            fdgpu_index_destroy(range);
+            return rc ? rc : FDGPU_EHIP;
+        }
+        if (r < me) { hb += all3[3 * r]; vb += all3[3 * r + 1]; }
+        ht += all3[3 * r]; vt += all3[3 * r + 1];
+    }
+    *range_index = range; *hashes_before = hb; *value_before = vb; *total_hashes = ht; *total_value = vt;
+    return FDGPU_OK;
+}
+
+// match records of the local retrieval (device-resident, ordered by (query, local slot, component)) -> the message: the same records with cand =
+// the slot in the query's GLOBAL candidate list.  sizeof(fd_match_rec) = 39 words.
+__global__ void k_comm_pack_matches(const uint32_t *__restrict__ recs, uint64_t n, const uint64_t *__restrict__ match_off, const uint64_t *__restrict__ lc_off,
+                                    const uint32_t *__restrict__ slot_of, uint32_t n_queries, uint32_t *__restrict__ out) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t lo = 0, hi = n_queries;          // the query t with match_off[t] <= k < match_off[t + 1]
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (match_off[mid] <= k) lo = mid; else hi = mid; }
+    constexpr uint32_t W = sizeof(fd_match_rec) / 4;
+    const uint32_t *src = recs + k * W;
+    uint32_t *dst = out + k * W;
+    dst[0] = slot_of[lc_off[lo] + src[0]];
+    for (uint32_t w = 1; w < W; ++w) dst[w] = src[w];
+}
 // The unpack + merge of fdgpu_sharded_retrieve alone, on hand-made contributions of `world` ranks (tests drive ragged, empty and failing ranks
 // through it on one GPU): counts[r * (n_queries + 1) + t] = rank r's matches of query t, counts[r * (n_queries + 1) + n_queries] = its status
 // (0 = fine); rank_matches[r] / rank_residues[r] = its records (cand = slot in the query's GLOBAL candidate list) and residue ints in (query,
@@ -632,10 +775,12 @@ extern "C" int fdgpu_sharded_retrieve(fdgpu_ctx *c, fdgpu_comm *m, const fdgpu_b
         lc_off[t + 1] = lc.size();
     }
     if (lc.empty()) lc.push_back(0);
-    // 2. local retrieval
+    // 2. local retrieval; the device glue (motif-sized queries) leaves its ordered records and residue lists in HBM (D.got): they are gathered from
+    // there — nothing of the payload touches the host before the gathered result is copied out
     fd_match_rec *lm = nullptr; uint64_t *lmo = nullptr; int32_t *lr = nullptr; uint64_t *lro = nullptr;
-    int local_rc = fdgpu_retrieve_batch(c, db, resname_std, n_queries, lc.data(), lc_off.data(), qms, qb, q_struct, p, ca_distance_cutoff, node_count, partial_fit, &lm, &lmo,
-                                        &lr, &lro);
+    fd_rb_dev_out D;
+    int local_rc = fd_retrieve_batch_dev(c, db, resname_std, n_queries, lc.data(), lc_off.data(), qms, qb, q_struct, p, ca_distance_cutoff, node_count, partial_fit, &lm, &lmo,
+                                         &lr, &lro, &D);
     struct Rel { fd_match_rec *&a; uint64_t *&b; int32_t *&cc; uint64_t *&d; ~Rel() { fdgpu_matches_free(a, cc); free(b); free(d); } } rel{lm, lmo, lr, lro};
     // 3. counts: per query the number of matches, + status; residue ints per match = 2 * n_indices of the query (same on every rank)
     std::vector<uint64_t> cnt(n_queries + 1, 0), nres_per(n_queries, 0);
@@ -645,7 +790,7 @@ extern "C" int fdgpu_sharded_retrieve(fdgpu_ctx *c, fdgpu_comm *m, const fdgpu_b
     if (!local_rc)
         for (uint64_t t = 0; t < n_queries; ++t) {
             cnt[t] = lmo[t + 1] - lmo[t];
-            for (uint64_t k = lmo[t]; k < lmo[t + 1]; ++k) lm[k].cand = slot_of[lc_off[t] + lm[k].cand];      // local slot -> slot in the global list
+            if (!D.got) for (uint64_t k = lmo[t]; k < lmo[t + 1]; ++k) lm[k].cand = slot_of[lc_off[t] + lm[k].cand];      // local slot -> slot in the global list
             my_m += cnt[t]; my_r += cnt[t] * nres_per[t];
         }
     const size_t cb = (n_queries + 1) * 8;
@@ -672,8 +817,29 @@ extern "C" int fdgpu_sharded_retrieve(fdgpu_ctx *c, fdgpu_comm *m, const fdgpu_b
     const size_t mbytes = max_m * sizeof(fd_match_rec), rbytes = ((max_r * 4 + 15) & ~(size_t)15), bytes = mbytes + rbytes;
     HCHK_C(c, m, m->send.ensure(bytes));
     HCHK_C(c, m, m->recv.ensure(bytes * W));
-    if (my_m) HCHK_C(c, m, hipMemcpyAsync(m->send.p, lm, my_m * sizeof(fd_match_rec), hipMemcpyHostToDevice, st));
-    if (my_r) HCHK_C(c, m, hipMemcpyAsync(m->send.as<uint8_t>() + mbytes, lr, my_r * 4, hipMemcpyHostToDevice, st));
+    if (D.got) {
+        // device to device: records into the message with their slots rewritten to the query's GLOBAL list (k_comm_pack_matches: one thread per record,
+        // its query by bisection in the offsets), residue ints by a plain copy
+        if (D.n_recs != my_m || D.n_res != my_r) return comm_broken(c, m, "sharded retrieve: the device-resident result disagrees with its offsets");
+        const size_t tb = (slot_of.size() + 1) * 4 + 2 * (n_queries + 1) * 8;
+        HCHK_C(c, m, m->aux.ensure(tb));
+        std::vector<uint8_t> tabs(tb);
+        memcpy(tabs.data(), lmo, (n_queries + 1) * 8);
+        memcpy(tabs.data() + (n_queries + 1) * 8, lc_off.data(), (n_queries + 1) * 8);
+        if (!slot_of.empty()) memcpy(tabs.data() + 2 * (n_queries + 1) * 8, slot_of.data(), slot_of.size() * 4);
+        HCHK_C(c, m, hipMemcpyAsync(m->aux.p, tabs.data(), tb, hipMemcpyHostToDevice, st));
+        if (my_m) {
+            const uint64_t *d_mo = m->aux.as<uint64_t>(), *d_lo = d_mo + (n_queries + 1);
+            hipLaunchKernelGGL(k_comm_pack_matches, dim3((unsigned)((my_m + 255) / 256)), dim3(256), 0, st, (const uint32_t *)D.recs, my_m, d_mo, d_lo,
+                               (const uint32_t *)(d_lo + (n_queries + 1)), (uint32_t)n_queries, m->send.as<uint32_t>());
+            HCHK_C(c, m, hipGetLastError());
+        }
+        if (my_r) HCHK_C(c, m, hipMemcpyAsync(m->send.as<uint8_t>() + mbytes, D.residues, my_r * 4, hipMemcpyDeviceToDevice, st));
+        HCHK_C(c, m, hipStreamSynchronize(st));      // tabs leaves scope
+    } else {      // the host glue ran (whole-structure queries, --partial-fit, a candidate beyond the device glue's limits): its records are host arrays
+        if (my_m) HCHK_C(c, m, hipMemcpyAsync(m->send.p, lm, my_m * sizeof(fd_match_rec), hipMemcpyHostToDevice, st));
+        if (my_r) HCHK_C(c, m, hipMemcpyAsync(m->send.as<uint8_t>() + mbytes, lr, my_r * 4, hipMemcpyHostToDevice, st));
+    }
     if ((rc = allgather_dev(c, m, m->send.p, m->recv.p, bytes))) return rc;
     std::vector<uint8_t> all(bytes * W);
     HCHK_C(c, m, hipMemcpyAsync(all.data(), m->recv.p, bytes * W, hipMemcpyDeviceToHost, st));

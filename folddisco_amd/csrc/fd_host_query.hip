@@ -906,7 +906,7 @@ static bool fd_hash_is_sym(uint32_t htype, uint32_t h) {
 static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand, const uint64_t *cand_off,
                              const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct, const fd_hash_params *p, uint32_t node_count,
                              const fd_rb_prep &P, std::chrono::steady_clock::time_point T0, fd_match_rec **matches, uint64_t **match_off, int32_t **residues,
-                             uint64_t **res_off, bool *done) {
+                             uint64_t **res_off, bool *done, fd_rb_dev_out *dev_out = nullptr) {
     *done = false;
     const bool trace = getenv("FDGPU_TRACE") != nullptr;
     auto t_now = [] { return std::chrono::steady_clock::now(); };
@@ -1059,9 +1059,10 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
             if (tot_res >= (1ull << 32)) { c->err = "retrieve_batch: residue lists beyond 2^32 entries; split the batch"; return FDGPU_ERANGE; }
             float *d_rot0 = d_rmsd0 + nprob, *d_tran0 = d_rot0 + 9 * nprob, *d_met0 = d_tran0 + 3 * nprob;
             uint64_t *omo = (uint64_t *)malloc((n_queries + 1) * 8), *oro = (uint64_t *)malloc((n_queries + 1) * 8);
-            fd_match_rec *om = (fd_match_rec *)fd_out_alloc(std::max<size_t>(nm, 1) * sizeof(fd_match_rec), true);
-            int32_t *orr = (int32_t *)fd_out_alloc(std::max<size_t>(tot_res, 1) * sizeof(int32_t), true);
-            if (!omo || !oro || !om || !orr) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
+            // dev_out: the ordered records stay in the workspaces for the caller (sharded retrieval: gathered device to device); only the offsets return
+            fd_match_rec *om = dev_out ? nullptr : (fd_match_rec *)fd_out_alloc(std::max<size_t>(nm, 1) * sizeof(fd_match_rec), true);
+            int32_t *orr = dev_out ? nullptr : (int32_t *)fd_out_alloc(std::max<size_t>(tot_res, 1) * sizeof(int32_t), true);
+            if (!omo || !oro || (!dev_out && (!om || !orr))) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); return FDGPU_ENOMEM; }
             hipError_t e = c->ws[WS_RS_REC].ensure(std::max<uint64_t>(nm, 1) * sizeof(fd_match_rec));
             if (e == hipSuccess) e = c->ws[WS_RS_RECRES].ensure(std::max<uint64_t>(tot_res, 1) * 4);
             if (e == hipSuccess && nprob) {
@@ -1075,8 +1076,9 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
                                          d_mo, d_ro, d_rmsd0, d_rot0, d_tran0, d_met0, A.residues, c->ws[WS_RS_REC].p, c->ws[WS_RS_RECRES].as<int32_t>(), st);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess && nm) e = hipMemcpyAsync(om, c->ws[WS_RS_REC].p, nm * sizeof(fd_match_rec), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess && tot_res) e = hipMemcpyAsync(orr, c->ws[WS_RS_RECRES].p, tot_res * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && nm && !dev_out) e = hipMemcpyAsync(om, c->ws[WS_RS_REC].p, nm * sizeof(fd_match_rec), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && tot_res && !dev_out) e = hipMemcpyAsync(orr, c->ws[WS_RS_RECRES].p, tot_res * 4, hipMemcpyDeviceToHost, st);
+            if (dev_out) { dev_out->got = true; dev_out->recs = c->ws[WS_RS_REC].p; dev_out->residues = c->ws[WS_RS_RECRES].as<int32_t>(); dev_out->n_recs = nm; dev_out->n_res = tot_res; }
             if (e == hipSuccess) e = hipMemcpyAsync(omo, d_mo, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipMemcpyAsync(oro, d_ro, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1178,7 +1180,14 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
 static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand,
                                   const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
                                   const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches,
-                                  uint64_t **match_off, int32_t **residues, uint64_t **res_off, const fd_rb_prep *prep);
+                                  uint64_t **match_off, int32_t **residues, uint64_t **res_off, const fd_rb_prep *prep, fd_rb_dev_out *dev_out = nullptr);
+int fd_retrieve_batch_dev(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand, const uint64_t *cand_off,
+                          const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct, const fd_hash_params *p, float ca_distance_cutoff,
+                          uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches, uint64_t **match_off, int32_t **residues, uint64_t **res_off, fd_rb_dev_out *dev) { FD_LOCK(c);
+    if (dev) *dev = fd_rb_dev_out();
+    return fd_retrieve_batch_impl(c, db, resname_std, n_queries, cand, cand_off, qms, qb, q_struct, p, ca_distance_cutoff, node_count, partial_fit, matches, match_off,
+                                  residues, res_off, nullptr, dev);
+}
 extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand,
                                     const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
                                     const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches,
@@ -1190,7 +1199,7 @@ extern "C" int fdgpu_retrieve_batch(fdgpu_ctx *c, const fdgpu_batch *db, const u
 static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand,
                                   const uint64_t *cand_off, const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct,
                                   const fd_hash_params *p, float ca_distance_cutoff, uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches,
-                                  uint64_t **match_off, int32_t **residues, uint64_t **res_off, const fd_rb_prep *prep) { FD_LOCK(c);
+                                  uint64_t **match_off, int32_t **residues, uint64_t **res_off, const fd_rb_prep *prep, fd_rb_dev_out *dev_out) { FD_LOCK(c);
     if (!c || !db || !qb || !p || !matches || !match_off || !residues || !res_off || !cand_off || (n_queries && (!qms || !q_struct))) return FDGPU_EINVAL;
     *matches = nullptr; *match_off = nullptr; *residues = nullptr; *res_off = nullptr;
     const uint64_t n_cand = cand_off[n_queries];
@@ -1228,7 +1237,7 @@ static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uin
     const bool dev_glue = !(hg_env && hg_env[0] == '1') && !two_pass && !partial_fit && max_nq <= FD_WAVE && max_nq > 0 && n_cand > 0 && n_cand < (1ull << 20);
     if (dev_glue) {
         bool done = false;
-        rc = fd_rb_device_glue(c, db, resname_std, n_queries, cand, cand_off, qms, qb, q_struct, p, node_count, *prep, T0, matches, match_off, residues, res_off, &done);
+        rc = fd_rb_device_glue(c, db, resname_std, n_queries, cand, cand_off, qms, qb, q_struct, p, node_count, *prep, T0, matches, match_off, residues, res_off, &done, dev_out);
         if (rc || done) return rc;
     }
     if (trace) fprintf(stderr, "[fdgpu_retrieve] query tables %.3f ms\n", t_ms(T0, t_now()));

@@ -1054,7 +1054,7 @@ extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, 
 // as many host threads pwrite() them straight from the pinned buffer into the file at their own offset — no host copy of the array, and the
 // page-cache copies of the chunks run in parallel (export-then-fwrite was one thread copying 976 MB twice: 0.33 of the CLI's 0.73 s at 20,500
 // structures).  io_err: first errno of a failed write.
-static hipError_t fd_d2h_to_file(fdgpu_ctx *c, int fd, uint64_t file_off, const void *src, size_t bytes, std::atomic<int> *io_err) {
+hipError_t fd_d2h_to_file(fdgpu_ctx *c, int fd, uint64_t file_off, const void *src, size_t bytes, std::atomic<int> *io_err) {
     if (!bytes) return hipSuccess;
     for (int k = 0; k < FD_PIN_SLOTS; ++k) {
         hipError_t e = hipSuccess;

@@ -200,6 +200,14 @@ int fd_count_query_maps_top_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n
 // (allow_dense = false: straight to the compacting path — what a caller passes when the device selection of a first attempt overflowed; the
 // overflow is deterministic, a second attempt on the same path would overflow again before falling back)
 
+// fdgpu_retrieve_batch with its ordered result left ON THE DEVICE (the sharded retrieval gathers it from there, fd_comm.hip): when the device glue
+// produced the records (motif-sized queries), got = true, recs / residues point into the context's workspaces (valid until its next retrieval),
+// *matches / *residues of the call stay NULL and only the per-query offsets come back on the host.  got = false: the host glue ran, host arrays as usual.
+struct fd_rb_dev_out { bool got = false; const void *recs = nullptr; const int32_t *residues = nullptr; uint64_t n_recs = 0, n_res = 0; };
+int fd_retrieve_batch_dev(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand, const uint64_t *cand_off,
+                          const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct, const fd_hash_params *p, float ca_distance_cutoff,
+                          uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches, uint64_t **match_off, int32_t **residues, uint64_t **res_off, fd_rb_dev_out *dev);
+hipError_t fd_d2h_to_file(fdgpu_ctx *c, int fd, uint64_t file_off, const void *src, size_t bytes, std::atomic<int> *io_err);      // fdgpu_api.hip: device array -> file region through the pinned slots
 void *fd_out_alloc(size_t bytes, bool pinned = false);      // result arrays of the hot query paths: recycled blocks (fdgpu_api.hip); released with fdgpu_free like any other output
 
 // kernels / launchers implemented in the k_*.hip files

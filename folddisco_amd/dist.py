@@ -233,6 +233,19 @@ class Comm:
         self.ctx.check(self.ctx.L.fdgpu_comm_stats(self.h, a.ctypes.data_as(u64p), g.ctypes.data_as(u64p)))
         return int(a[0]), int(g[0])
 
+    def single_index(self, local):
+        """fdgpu_comm_single_index: every rank brings the resident sub-index of its id range -> (this rank's hash range of the database's single index,
+        hashes before it, value bytes before it, total hashes, total value bytes).  Device to device (ncclSend / ncclRecv), no host staging."""
+        import ctypes as C
+        from ._lib import u64p
+        from .api import FolddiscoIndex
+        h = C.c_void_p()
+        o = np.zeros(4, np.uint64)
+        p = [o[k:k + 1].ctypes.data_as(u64p) for k in range(4)]
+        self.ctx.check(self.ctx.L.fdgpu_comm_single_index(self.ctx.h, self.h, local.h, C.byref(h), *p))
+        n_total = allreduce_sum(int(local.n_structures)) if self.world > 1 else int(local.n_structures)
+        return FolddiscoIndex(self.ctx, h, n_total, 0), int(o[0]), int(o[1]), int(o[2]), int(o[3])
+
     def allreduce_lengths(self, lens: np.ndarray) -> np.ndarray:
         from ._lib import u64p
         a = np.ascontiguousarray(lens, np.uint64).copy()
@@ -367,3 +380,31 @@ def sharded_count_query_maps(ctx, index, qms, penalty_shard, total_structures: i
                                                       float(total_structures), int(top_n), C.byref(out), C.byref(ooff)))
     local = Comm._take_recs(ctx, out, ooff, T)
     return allgather_hits_many(local, device, top_n=top_n if top_n else None, ranked=bool(top_n))
+
+
+def single_index_over_process_group(ctx, local, device=None):
+    """The same exchange for launches without RCCL between the ranks (gloo: tests, several ranks on one GPU): bounds from rank 0, slices on the device, the
+    pieces through torch.distributed as host arrays (this transport has no device path), merge of the received pieces on the device.  -> as Comm.single_index"""
+    from .api import FolddiscoIndex, FolddiscoIndexSet
+    if not _active():
+        return local, 0, 0, local.num_hashes, local.value_len
+    W, me = dist.get_world_size(), dist.get_rank()
+    box = [local.range_bounds(W).tolist() if me == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    edge = [0] + [int(x) for x in box[0]] + [1 << 32]
+    for j in range(1, W):
+        edge[j] = max(edge[j], edge[j - 1])
+    pieces = []
+    for j in range(W):
+        s = local.slice(edge[j], edge[j + 1])
+        pieces.append((s.export(), int(local.first_id), int(local.n_structures)))
+        del s
+    got = [None] * W
+    for j in range(W):      # piece j of every rank to rank j
+        dist.gather_object(pieces[j], got if me == j else None, dst=j)
+    parts = [FolddiscoIndex.load(ctx, h, o, v, n, first_id=f) for (v, h, o), f, n in got]
+    rng = FolddiscoIndexSet(parts).merge() if len(parts) > 1 else parts[0]
+    sizes = [None] * W
+    dist.all_gather_object(sizes, (rng.num_hashes, rng.value_len))
+    hb, vb = sum(x[0] for x in sizes[:me]), sum(x[1] for x in sizes[:me])
+    return rng, hb, vb, sum(x[0] for x in sizes), sum(x[1] for x in sizes)

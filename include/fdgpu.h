@@ -376,6 +376,27 @@ int fdgpu_comm_rank(const fdgpu_comm *comm);
 int fdgpu_comm_world(const fdgpu_comm *comm);
 /* collectives this communicator has issued so far (ncclAllReduce / ncclAllGather calls) */
 int fdgpu_comm_stats(const fdgpu_comm *comm, uint64_t *n_allreduce, uint64_t *n_allgather);
+
+/* ---- ONE on-disk index from N ranks, without the host (Option A) -----------------------------------------------
+ * After a build sharded by structure every rank holds the resident sub-index of its id range; the reference's output contract is one
+ * PREFIX / PREFIX.offset in ascending hash order (src/index/indextable.rs:239-326).  The hash space is cut into N ranges of about equal
+ * posting bytes, every rank slices its sub-index at those bounds, piece j travels to rank j device to device, rank j concatenates the N
+ * pieces of its range per hash on the device (fdgpu_index_merge: id ranges ascend with the source rank) and writes its regions of the two
+ * files — byte-identical to the single-GPU build, because lists are (hash ascending, id ascending) either way.
+ *   fdgpu_index_range_bounds   n_ranges - 1 ascending hash values cutting `index` into ranges of about equal posting bytes (range j holds
+ *                              bounds[j - 1] <= hash < bounds[j]; one rank computes them, all ranks must use the same)
+ *   fdgpu_index_slice          the lists with hash_lo <= hash < hash_hi (hash_hi up to 2^32) as a resident index of their own (same id range)
+ *   fdgpu_comm_single_index    the whole exchange over RCCL (bounds from rank 0, slices, ncclSend / ncclRecv of piece j to rank j, merge):
+ *                              -> this rank's hash range of the database's index and its place in it
+ *   fdgpu_index_save_part      writes a range's regions of PREFIX / PREFIX.offset (see fd_shard_index.hip); ranks of one node may call it
+ *                              concurrently; write_header != 0 on the rank of the first range, is_last != 0 on the rank of the last one
+ * Hosts with another transport (MPI, gloo) use range_bounds + slice + fdgpu_index_export / _load + fdgpu_index_merge + save_part. */
+int fdgpu_index_range_bounds(fdgpu_ctx *ctx, const fdgpu_index *index, uint32_t n_ranges, uint32_t *bounds);
+int fdgpu_index_slice(fdgpu_ctx *ctx, const fdgpu_index *index, uint64_t hash_lo, uint64_t hash_hi, fdgpu_index **out);
+int fdgpu_comm_single_index(fdgpu_ctx *ctx, fdgpu_comm *comm, const fdgpu_index *local, fdgpu_index **range_index, uint64_t *hashes_before,
+                            uint64_t *value_before, uint64_t *total_hashes, uint64_t *total_value);
+int fdgpu_index_save_part(fdgpu_ctx *ctx, const fdgpu_index *part, const char *prefix, uint64_t hashes_before, uint64_t value_before,
+                          uint64_t total_hashes, uint64_t total_value, int write_header, int is_last);
 /* lengths[k] <- sum over the ranks (ncclAllReduce): posting lengths of a shard -> posting lengths over the whole database, the
  * denominator of idf = log2(S / len) (src/controller/query.rs:17-32, count_query.rs:130) */
 int fdgpu_allreduce_lengths(fdgpu_ctx *ctx, fdgpu_comm *comm, uint64_t *lengths, uint64_t n);

@@ -1335,3 +1335,71 @@ def test_cli_indexes_structures_between_dash_n_and_65535_like_the_reference(tmp_
     assert [int(l[2]) for l in look] == nres_want
     assert [np.float32(float(l[3])).tobytes() for l in look] == [np.float32(x).tobytes() for x in plddt_want]
     assert indexio.load_type(pre + ".type")["max_residue"] == 50000
+
+
+def test_one_index_from_n_ranks_by_hash_ranges(tmp_path):
+    """SURVEY §8e row 2, Option A (csrc/fd_shard_index.hip): sub-indices over consecutive id ranges (what N ranks hold after a build sharded by structure) ->
+    hash bounds of equal posting bytes -> every part sliced at the bounds -> the pieces of a range concatenated per hash on the device (fdgpu_index_merge) ->
+    every range written into its regions of PREFIX / PREFIX.offset (fdgpu_index_save_part): byte-identical to the files of ONE build, for 2, 3 and 8 hand-made
+    ranks (ragged id ranges, one rank without structures), with degenerate bounds (empty ranges), and — world of one — through the RCCL entry point
+    fdgpu_comm_single_index with its ncclSend / ncclRecv to itself."""
+    import folddisco_amd as fd
+    from folddisco_amd import dist as fdist
+    from tests.helpers import synthetic_packed
+    ctx = fd.Context(0)
+    ps = synthetic_packed(700, seed=91)
+    whole = fd.FolddiscoIndex.build(ctx, ctx.upload(ps))
+    whole.save(str(tmp_path / "one"))
+    want = [open(tmp_path / ("one" + ext), "rb").read() for ext in ("", ".offset")]
+    H, V = whole.num_hashes, whole.value_len
+    assert len(want[0]) == V and len(want[1]) == 8 + 4 * H + 8 * (H + 1)
+
+    def sub(a, b):
+        sl = slice(int(ps.res_off[a]), int(ps.res_off[b]))
+        chunk = fd.PackedStructures((ps.res_off[a:b + 1] - ps.res_off[a]).astype(np.uint64), ps.n_xyz[sl], ps.ca_xyz[sl], ps.cb_xyz[sl], ps.aa[sl])
+        return fd.FolddiscoIndex.build(ctx, ctx.upload(chunk), first_id=a)
+
+    def run(cuts, edges_override=None, tag="x"):
+        parts = [sub(a, b) for a, b in zip(cuts, cuts[1:])]
+        W = len(parts)
+        b0 = parts[0].range_bounds(W) if edges_override is None else np.array(edges_override, np.uint32)
+        assert len(b0) == W - 1 and np.all(np.diff(b0.astype(np.int64)) >= 0)
+        edge = [0] + [int(x) for x in b0] + [1 << 32]
+        pre = str(tmp_path / tag)
+        for ext in ("", ".offset"):
+            if os.path.exists(pre + ext):
+                os.remove(pre + ext)
+        ranges = []
+        for j in range(W):
+            pieces = [p.slice(edge[j], edge[j + 1]) for p in parts]
+            ranges.append(fd.FolddiscoIndexSet(pieces).merge() if W > 1 else pieces[0])
+        assert sum(r.num_hashes for r in ranges) == H and sum(r.value_len for r in ranges) == V
+        assert sum(r.num_postings for r in ranges) == whole.num_postings
+        hb = vb = 0
+        order = list(range(W))[::-1]            # ranks write concurrently in any order: here the last range first
+        pos = []
+        for r in ranges:
+            pos.append((hb, vb)); hb += r.num_hashes; vb += r.value_len
+        for j in order:
+            ranges[j].save_part(pre, pos[j][0], pos[j][1], H, V, write_header=(j == 0), is_last=(j == W - 1))
+        got = [open(pre + ext, "rb").read() for ext in ("", ".offset")]
+        assert got[0] == want[0] and got[1] == want[1], (cuts, edges_override)
+        return [r.value_len for r in ranges]
+    sizes = run([0, 350, 700], tag="w2")
+    assert min(sizes) > 0.3 * V / 2                                           # ranges of about equal posting bytes
+    run([0, 100, 460, 700], tag="w3")
+    sizes8 = run([0, 50, 50, 200, 290, 400, 555, 640, 700], tag="w8")          # a rank without structures
+    assert max(sizes8) < 3 * V / 8
+    run([0, 350, 700], edges_override=[0], tag="d0")                           # first range empty
+    run([0, 233, 466, 700], edges_override=[0xffffffff, 0xffffffff], tag="d1")  # everything in the first range
+    mid = int(whole.range_bounds(2)[0])
+    run([0, 233, 466, 700], edges_override=[mid, mid], tag="d2")               # an empty range in the middle
+    # the RCCL entry point with a world of one: bounds, slices, send / recv (to itself), merge, sizes — every line the N-rank call runs
+    comm = fdist.Comm(ctx)
+    a0, g0 = comm.stats()
+    rng, hb, vb, ht, vt = comm.single_index(whole)
+    assert (hb, vb, ht, vt) == (0, 0, H, V) and comm.stats()[1] == g0 + 3
+    rng.save_part(str(tmp_path / "rccl"), hb, vb, ht, vt, write_header=True, is_last=True)
+    assert [open(tmp_path / ("rccl" + ext), "rb").read() for ext in ("", ".offset")] == want
+    comm.close()
+    ctx.close()
