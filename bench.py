@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-query", action="store_true")
     ap.add_argument("--no-export", action="store_true")
+    ap.add_argument("--no-on-disk", action="store_true", help="skip the on-disk-inclusive step (index files written: one rank fdgpu_index_save, N ranks the device-side single index)")
     ap.add_argument("--build-chunk-blocks", type=int, default=0, help="0 (default): the rank's whole shard in ONE fdgpu_index_build call when its sort workspace fits the "
                     "device, else calls of 3 blocks.  N > 0: N generated blocks of 67,750 structures per call (3: 203,250 structures, ~6.7e9 keys; 1: as in rounds 1-2)")
     ap.add_argument("--no-cli-index", action="store_true", help="skip the drop-in `index` leg (20,500 structures as .pdb.gz files and as a Foldcomp database)")
@@ -428,6 +429,57 @@ def main():
         export = {"value": S_total / dte, "unit": "structures/s", "ms_per_step": dte * 1e3, "bytes_to_host_per_rank": int(vl.value + 12 * H.value + 8),
                   "note": "one step + fdgpu_index_export (D2H of value bytes, hashes, offsets into malloc'd host buffers)"}
 
+    # ---- on-disk inclusive: one more step that ends with the reference's PREFIX / PREFIX.offset on a file system.  One rank: fdgpu_index_save (device
+    # arrays streamed through pinned slots into pwrite).  N ranks: the single index without the host (Option A; csrc/fd_shard_index.hip):
+    # hash ranges of equal posting bytes, piece j of every rank's sub-index to rank j (ncclSend / ncclRecv under nccl), per-range device merge, every rank
+    # writes its regions of the two files.  Never `value`.
+    on_disk = None
+    if not args.no_export and not args.no_on_disk:
+        import shutil
+        import tempfile
+        try:
+            from folddisco_amd import dist as fdist
+            need = int(vlen * 1.02 + 12.5 * n_hash) * (world if world > 1 else 1) + (1 << 20)
+            cands = [d for d in (os.environ.get("FD_BENCH_DISK_DIR"), "/dev/shm", tempfile.gettempdir()) if d and os.path.isdir(d)]
+            best = max(cands, key=lambda d: shutil.disk_usage(d).free)
+            box = [None]
+            if rank == 0 and shutil.disk_usage(best).free > 1.25 * need:
+                box[0] = tempfile.mkdtemp(prefix="fd_bench_index_", dir=best)
+            if dist is not None:
+                dist.broadcast_object_list(box, src=0)
+            if box[0] is None:
+                on_disk = {"skipped": "no directory with %.1f GB free (tried %s)" % (1.25 * need / 1e9, ", ".join(cands))}
+            else:
+                prefix = os.path.join(box[0], "bench_folddisco")
+                comm_ix = fdist.Comm(ctx, rank, world) if (dist is not None and dist.get_backend() == "nccl") else None
+                ix = None
+                barrier()
+                t0d = time.perf_counter()
+                ix = build_shard()
+                if dist is None:
+                    ix.save(prefix)
+                    ht, vt = ix.num_hashes, ix.value_len
+                else:
+                    rng, hb, vb, ht, vt = comm_ix.single_index(ix) if comm_ix is not None else fdist.single_index_over_process_group(ctx, ix)
+                    rng.save_part(prefix, hb, vb, ht, vt, write_header=(rank == 0), is_last=(rank == world - 1))
+                    rng = None
+                ctx.synchronize()
+                barrier()
+                dtd = max_over_ranks(time.perf_counter() - t0d)
+                if rank == 0:
+                    sz = (os.path.getsize(prefix), os.path.getsize(prefix + ".offset"))
+                    on_disk = {"value": S_total / dtd, "unit": "structures/s", "ms_per_step": dtd * 1e3, "file_bytes": sz[0] + sz[1], "directory": best,
+                               "files_complete": bool(sz[0] == vt and sz[1] == 8 + 4 * ht + 8 * (ht + 1)),
+                               "note": ("one step + fdgpu_index_save: PREFIX and PREFIX.offset written from the device arrays" if dist is None else
+                                        "one step + the single index of all ranks WITHOUT the host: hash ranges, piece j of every rank to rank j (%s), per-range device "
+                                        "merge, every rank writes its regions of PREFIX / PREFIX.offset" % ("ncclSend / ncclRecv" if comm_ix is not None else "torch.distributed objects: gloo has no device path"))}
+                comm_ix = None
+                barrier()
+                if rank == 0:
+                    shutil.rmtree(box[0], ignore_errors=True)
+        except Exception as e:  # noqa: BLE001 — the headline line must still be printed
+            on_disk = {"error": repr(e)[:300]}
+
     # ---- per-kernel timings of one more (untimed) step with HIP events on the build stream -> roofline
     ctx.enable_timing(True)
     ix = None
@@ -581,7 +633,7 @@ def main():
                                    f"per rank {n_calls} build call(s) of <= {CALL_MAX} structures" + (" merged on the device into one resident index" if n_calls > 1 else ": one resident index, no merge"),
                        "structures": S_total, "structures_per_gpu": S, "residues": int(R_tot), "postings": int(post_tot),
                        "parallelism": f"shard-by-structure x{world}", "build_calls_per_rank": n_calls, "call_plan": call_plan},
-            "roofline": roofline, "export_inclusive": export, "cpu_baseline": cpu, "query": query, "cli_index": cli_index,
+            "roofline": roofline, "export_inclusive": export, "index_on_disk_inclusive": on_disk, "cpu_baseline": cpu, "query": query, "cli_index": cli_index,
         }
         print(json.dumps(out))
     if dist is not None:

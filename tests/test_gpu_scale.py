@@ -442,3 +442,5 @@ def test_bench_n_gt_1_path_runs_with_two_gloo_ranks_on_one_gpu():
     assert q["value"] == max(q["sharded_value"], q["replicas"]["value"])
     assert q["exchange"] is not None and q["batched_with_matching"]["matches"] > 0
     assert out["roofline"]["frac"] > 0 and out["export_inclusive"]["value"] > 0
+    disk = out["index_on_disk_inclusive"]
+    assert "error" not in disk and (disk.get("skipped") or (disk["value"] > 0 and disk["files_complete"])), disk
