@@ -25,7 +25,8 @@ struct fd_hash_consts {
     uint32_t seg_mul, seg_cfg;   // --multiple-bins: a structure's segment holds seg_mul copies of its pair list, this launch fills copy seg_cfg
     fd_quant q;
     float d2_max;   // largest f32 whose sqrt is <= dist_cutoff: sqrtf(d2) > cutoff  <=>  d2 > d2_max
-    int use_tab;    // 1: default 4 angle bins -> table form of the angle fields (fd_bin_tables.h); 2: + speculative torsions
+    int use_tab;    // 1: default 4 angle bins -> table form of the angle fields (fd_bin_tables.h); 2: + speculative torsions; 3: + default 16 distance
+                    // bins -> the distance fields from the squared-distance table (fd_dist_table.h) in the MSD build's pair kernel
     unsigned long long *spec_miss;   // device counter of pairs the speculative path handed to the exact routine (may be null)
     unsigned long long *wide_flag;   // set when a hash does not fit 30 bits (fields are OR-ed unmasked: an infinite distance sets
                                      // bits 30-31) — the 6-byte sort elements keep 30 hash bits, the build is then redone with 8-byte ones

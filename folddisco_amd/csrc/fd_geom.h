@@ -10,6 +10,7 @@
 #pragma once
 #include "fd_libm.h"
 #include "fd_bin_tables.h"
+#include "fd_dist_table.h"
 
 struct fd_v3 { float x, y, z; };
 
@@ -357,20 +358,44 @@ __device__ __forceinline__ fd_v3 fd_normalize_spec(fd_v3 v, float *rs_out) {
     return {v.x * rs, v.y * rs, v.z * rs};
 }
 
+// A distance field without the IEEE square root (index build, default 16 distance bins): the bin is a step function of the SQUARED distance x whose
+// breakpoints tab_d[k] = the smallest float of bin k were found by pushing every float through sqrtf + the quantiser (fd_dist_table.h, generated by
+// tools/gen_dist_table.c).  v_sqrt_f32 (1 ulp) gives a first guess b that is provably within one bin of the truth (the generator checks two ulps to
+// either side for every float), and x is compared with the guess's own two breakpoints: bin = b + (x >= T[b + 1]) - (x < T[b]).  ~13 VALU slots
+// against ~30 for the correctly rounded sqrt and the saturating cast's guards.  A guess beyond the table (CB distance > ~37 A, inf) clears ok:
+// the pair takes the exact routine.  NaN: guess 0, both compares false -> bin 0, what the saturating cast gives.
+__device__ __forceinline__ uint32_t fd_dist_bin_tab(float x, float disc, const uint32_t *tab_d, bool &ok) {
+    const float g = __builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_amdgcn_sqrtf(x) - 2.0f, disc, 0.5f), 0.0f, 40.0f);
+    const uint32_t b0 = (uint32_t)g;
+    const uint32_t b = b0 < (uint32_t)(FD_DIST_NTHR - 2) ? b0 : (uint32_t)(FD_DIST_NTHR - 2);
+    ok = ok && b0 == b;
+    const float t0 = fd_u2f(tab_d[b]), t1 = fd_u2f(tab_d[b + 1]);
+    return b + (x >= t1 ? 1u : 0u) - (x < t0 ? 1u : 0u);
+}
+
 // returns false when any field is not provably identical to the reference arithmetic (caller falls back to fd_pair_both_tab)
+// DT: the two distance fields from the squared-distance table tab_d (fd_dist_bin_tab) instead of sqrt + quantiser
+template <bool DT = false>
 __device__ __forceinline__ bool fd_pair_both_spec(const fd_frame &Fi, const fd_frame &Fj, uint32_t aai, uint32_t aaj, fd_quant q,
-                                                  const uint32_t *tab, const uint32_t *tab_f, uint32_t *h_ij, uint32_t *h_ji) {
-    float ca_dist = fd_dist(Fi.ca, Fj.ca);
+                                                  const uint32_t *tab, const uint32_t *tab_f, uint32_t *h_ij, uint32_t *h_ji, const uint32_t *tab_d = nullptr) {
     const fd_v3 v1 = {Fi.cb.x - Fi.ca.x, Fi.cb.y - Fi.ca.y, Fi.cb.z - Fi.ca.z};
     const fd_v3 v2 = {Fj.cb.x - Fj.ca.x, Fj.cb.y - Fj.ca.y, Fj.cb.z - Fj.ca.z};
     float dt = v1.x * v2.x + v1.y * v2.y + v1.z * v2.z;
     uint32_t kth = fd_theta_key_of(dt / (Fi.len * Fj.len), tab);     // exact: one division, no normalisation upstream
     fd_v3 v3 = fd_sub(Fj.cb, Fi.cb);
-    float cb_dist = fd_sqrtf(v3.x * v3.x + v3.y * v3.y + v3.z * v3.z);   // == fd_dist(Fi.cb, Fj.cb): (p-q)^2 == (q-p)^2 bit for bit
+    const float cb_d2 = v3.x * v3.x + v3.y * v3.y + v3.z * v3.z;        // sqrt of it == fd_dist(Fi.cb, Fj.cb): (p-q)^2 == (q-p)^2 bit for bit
+    bool fin = true;
+    uint32_t q_ca, q_cb;
+    if (DT) {
+        q_ca = fd_dist_bin_tab(fd_dist2(Fi.ca, Fj.ca), q.dist_disc, tab_d, fin);
+        q_cb = fd_dist_bin_tab(cb_d2, q.dist_disc, tab_d, fin);
+    } else {
+        q_ca = fd_q(fd_dist(Fi.ca, Fj.ca), 2.0f, q.dist_disc);
+        q_cb = fd_q(fd_sqrtf(cb_d2), 2.0f, q.dist_disc);
+    }
     float rsA, rsB, rsXA, rsXB;
     fd_v3 A = fd_normalize_spec(fd_cross(v1, v3), &rsA);
     fd_v3 B = fd_normalize_spec(fd_cross(v3, v2), &rsB);
-    bool fin = true;
     float margin = 1.0f;
     const float E1y = FD_SPEC_E1 + FD_SPEC_EY_SLACK;
     uint32_t k1 = fd_tor_key_spec(fd_dot(A, Fi.t1), fd_dot(Fi.r1, A), E1y, FD_SPEC_E1, tab_f, margin, fin);
@@ -381,7 +406,7 @@ __device__ __forceinline__ bool fd_pair_both_spec(const fd_frame &Fi, const fd_f
     const float E4c = FD_SPEC_EY4_B + FD_SPEC_EY_SLACK;
     uint32_t k2 = fd_tor_key_spec(fd_dot(Fj.s2, tB), fd_dot(rB, Fj.s2), __builtin_fmaf(FD_SPEC_EY4_A, rsXB, E4c), FD_SPEC_EX4, tab_f, margin, fin);
     uint32_t k4 = fd_tor_key_spec(fd_dot(Fi.s2, tA), fd_dot(rA, Fi.s2), __builtin_fmaf(FD_SPEC_EY4_A, rsXA, E4c), FD_SPEC_EX4, tab_f, margin, fin);
-    uint32_t mid = fd_q(ca_dist, 2.0f, q.dist_disc) << 16 | fd_q(cb_dist, 2.0f, q.dist_disc) << 12 | kth << 8;
+    uint32_t mid = q_ca << 16 | q_cb << 12 | kth << 8;
     *h_ij = aai << 25 | aaj << 20 | mid | k1 << 4 | k2;
     *h_ji = aaj << 25 | aai << 20 | mid | k3 << 4 | k4;
     // rsq of a zero / denormal cross product is inf: margins become NaN or -inf; NaN must fail, so test "> 0" positively

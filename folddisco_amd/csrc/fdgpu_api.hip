@@ -82,7 +82,7 @@ static int fd_selfcheck(fdgpu_ctx *c) {
     memset(&p, 0, sizeof p);
     p.dist_cutoff = 20.0f; p.hash_type = FDGPU_HASH_PDBTR;
     const fd_hash_consts C = make_consts(&p);
-    uint32_t *d = nullptr, h[18];
+    uint32_t *d = nullptr, h[24];
     HIPCHK(c, hipMalloc((void **)&d, sizeof h));
     fd_launch_selfcheck(C.q, d, c->stream);
     hipError_t he = hipGetLastError();
@@ -91,11 +91,11 @@ static int fd_selfcheck(fdgpu_ctx *c) {
     (void)hipFree(d);
     if (he != hipSuccess) { c->err = std::string("self-check launch: ") + hipGetErrorString(he); return FDGPU_EHIP; }
     static const uint32_t want[6] = {109329223u, 116878724u, 271858548u, 284511716u, 506948936u, 512052558u};
-    for (int k = 0; k < 18; ++k)
+    for (int k = 0; k < 24; ++k)
         if (h[k] != want[k % 6]) {
             char b[256];
             snprintf(b, sizeof b, "self-check failed: 4CHA triad hash %d (%s evaluation) is %u, the reference's literal is %u (controller/graph.rs:71-79)", k % 6,
-                     k < 6 ? "generic" : k < 12 ? "table" : "speculative", h[k], want[k % 6]);
+                     k < 6 ? "generic" : k < 12 ? "table" : k < 18 ? "speculative" : "speculative + squared-distance table", h[k], want[k % 6]);
             c->err = b;
             return FDGPU_EHIP;
         }
@@ -437,6 +437,10 @@ static fd_hash_consts make_consts_bins(const fd_hash_params *p, uint32_t nbd_req
     const char *ex = getenv("FDGPU_EXACT");   // read per call: tests flip it inside one process
     const bool exact_only = ex && ex[0] == '1';
     C.use_tab = (type == FD_HASH_PDBTR && na == 4.0f) ? (exact_only ? 1 : 2) : 0;
+    // default 16 distance bins as well: the MSD build's pair kernel takes the two distance fields from the exhaustive squared-distance table
+    // (fd_dist_table.h; FDGPU_DTAB=0 keeps sqrt + quantiser, for measurements and the tests that compare the two)
+    const char *dt = getenv("FDGPU_DTAB");
+    if (C.use_tab == 2 && nd == 16.0f && !(dt && dt[0] == '0')) C.use_tab = 3;
     C.spec_miss = nullptr;
     return C;
 }

@@ -275,7 +275,7 @@ __device__ __attribute__((noinline)) uint2 pair_both_tab_exact(const fd_frame *_
 // per bucket in LDS (two ds_add_rtn per lane), claims the slots with one global atomic per touched bucket and stores every key at its
 // own position.  The residues of a structure are visited in amino-acid order (k_frames_perm), so a drain touches a handful of buckets and
 // the partial lines of one bucket's run are completed in L2 by the drains that follow.  The sort then needs three 8-bit passes, not four.
-template <int TAB, bool IDS16, bool MSD>
+template <int TAB, bool IDS16, bool MSD, bool DT = false>
 __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *__restrict__ frames, const fd_hash_consts &C,
                                        const uint32_t *tab, const uint32_t *q, uint32_t n, uint32_t i0, uint32_t r0, uint32_t s, uint32_t id,
                                        const uint64_t *seg_off, uint32_t *cursor, uint32_t *keys, void *ids, const float4 *s_fi,
@@ -312,7 +312,7 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
             Fi.s2 = {d4.x, d4.y, d4.z}; Fi.nv2 = {d4.w, e4.x, e4.y}; Fi.len = e4.z; Fi.pad = e4.w;
             fd_frame Fj = load_frame(frames, j);
             aai = __float_as_uint(Fi.pad); aaj = __float_as_uint(Fj.pad);
-            if (!fd_pair_both_spec(Fi, Fj, aai, aaj, C.q, tab, tab + 32, &h_ij, &h_ji)) {
+            if (!fd_pair_both_spec<DT>(Fi, Fj, aai, aaj, C.q, tab, tab + 32, &h_ij, &h_ji, tab + 64)) {
                 uint2 h = pair_both_tab_exact(frames, i, j, B.aa[i], B.aa[j], C.q.dist_disc, C.q.ang_disc, tab);
                 h_ij = h.x; h_ji = h.y;
                 if (C.spec_miss) atomicAdd(C.spec_miss, 1ull);
@@ -365,15 +365,17 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
     }
 }
 
-template <int TAB, bool IDS16, bool MSD>
+template <int TAB, bool IDS16, bool MSD, bool DT = false>
 __global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_view B, const fd_frame *__restrict__ frames, fd_hash_consts C,
                                                         const uint64_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
                                                         uint32_t *__restrict__ keys, void *__restrict__ ids, uint32_t first_id) {
     __shared__ uint32_t q[2 * FD_WAVE];
-    __shared__ uint32_t tab[64];   // [0,27) exact table (bit patterns), [32,59) the same with float thresholds for the speculative path
+    __shared__ uint32_t tab[DT ? 64 + FD_DIST_NTHR + 1 : 64];   // [0,27) exact table (bit patterns), [32,59) the same with float thresholds for the speculative path,
+                                                                 // DT: [64, 64 + FD_DIST_NTHR) the squared-distance breakpoints of the two distance fields
     uint32_t w = fd_xcd_remap(blockIdx.x, B.n_work);
     if (w >= B.n_work) return;
     if (TAB) {
+        if (DT && threadIdx.x < FD_DIST_NTHR) tab[64 + threadIdx.x] = fd_dist_thr_bits[threadIdx.x];
         if (threadIdx.x == 0) {
             fd_fill_bintab(tab);
             for (int k = 0; k < FD_BINTAB_WORDS; ++k) tab[32 + k] = tab[k];
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_
                 __syncthreads();
                 uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
                 qn -= n;
-                drain2<TAB, IDS16, MSD>(B, frames, C, tab, q + qn, n, i0, r0, s, first_id + s, seg_off, cursor, keys, ids, s_fi, s_bc, s_bb, s_boff);
+                drain2<TAB, IDS16, MSD, DT>(B, frames, C, tab, q + qn, n, i0, r0, s, first_id + s, seg_off, cursor, keys, ids, s_fi, s_bc, s_bb, s_boff);
                 __syncthreads();
             }
         }
@@ -520,18 +522,19 @@ __global__ void k_hash_ok(const uint8_t *__restrict__ aa, const uint8_t *__restr
 // (fd_pair_feature + fd_hash_pdbtr: restated sinf/cosf/acosf/atan2f), the exhaustive-table form (fd_pair_both_tab) and the
 // speculative form (fd_pair_both_spec, exact fallback on refusal) — so a build whose arithmetic drifts (fast-math, FMA contraction,
 // a different table generation) fails loudly instead of producing a subtly different index.
-__global__ void k_selfcheck(fd_quant q, uint32_t *__restrict__ out /*[18]*/) {
+__global__ void k_selfcheck(fd_quant q, uint32_t *__restrict__ out /*[24]*/) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const fd_v3 N[3] = {{6.661f, 8.291f, 43.860f}, {10.483f, 7.756f, 49.260f}, {5.260f, -1.068f, 41.296f}};
     const fd_v3 CA[3] = {{6.994f, 8.354f, 42.405f}, {9.429f, 7.479f, 48.266f}, {5.547f, 0.158f, 42.050f}};
     const fd_v3 CB[3] = {{8.251f, 7.488f, 42.026f}, {10.033f, 6.489f, 47.255f}, {5.773f, 1.360f, 41.130f}};
     const uint32_t AA[3] = {8u, 3u, 15u};
     const int PI[6] = {1, 1, 0, 0, 2, 2}, PJ[6] = {0, 2, 1, 2, 1, 0};   // B102->B57, B102->C195, B57->B102, B57->C195, C195->B102, C195->B57
-    uint32_t tab[64];
+    uint32_t tab[64 + FD_DIST_NTHR + 1];
     fd_fill_bintab(tab);
     for (int k = 0; k < FD_BINTAB_WORDS; ++k) tab[32 + k] = tab[k];
     for (int m = 0; m < 4; ++m)
         for (int k = 0; k < 4; ++k) { uint32_t v = tab[32 + 7 + 5 * m + k]; tab[32 + 7 + 5 * m + k] = v > 0x7f7fffffu ? 0x7f7fffffu : v; }
+    for (int k = 0; k < FD_DIST_NTHR; ++k) tab[64 + k] = fd_dist_thr_bits[k];
     fd_frame F[3];
     for (int r = 0; r < 3; ++r) F[r] = fd_make_frame(N[r], CA[r], CB[r]);
     for (int k = 0; k < 6; ++k) {
@@ -542,6 +545,9 @@ __global__ void k_selfcheck(fd_quant q, uint32_t *__restrict__ out /*[18]*/) {
         out[6 + k] = a;
         if (!fd_pair_both_spec(F[i], F[j], AA[i], AA[j], q, tab, tab + 32, &a, &b)) fd_pair_both_tab(F[i], F[j], AA[i], AA[j], q, tab, &a, &b);
         out[12 + k] = a;
+        // ... and with the distance fields from the squared-distance table (the index build's form; valid for the default 16 distance bins the check runs with)
+        if (!fd_pair_both_spec<true>(F[i], F[j], AA[i], AA[j], q, tab, tab + 32, &a, &b, tab + 64)) fd_pair_both_tab(F[i], F[j], AA[i], AA[j], q, tab, &a, &b);
+        out[18 + k] = a;
     }
 }
 
@@ -588,8 +594,8 @@ void fd_launch_pair_emit2(const fd_batch_view &B, const void *frames, const fd_h
     if (!B.n_work) return;
     dim3 g(grid_for(B.n_work)), b(FD_WAVE);
     const fd_frame *F = (const fd_frame *)frames;
-    if (C.use_tab == 2 && ids16) hipLaunchKernelGGL((k_pair_emit2<2, true, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
-    else if (C.use_tab == 2) hipLaunchKernelGGL((k_pair_emit2<2, false, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    if (C.use_tab >= 2 && ids16) hipLaunchKernelGGL((k_pair_emit2<2, true, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
+    else if (C.use_tab >= 2) hipLaunchKernelGGL((k_pair_emit2<2, false, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
     else if (C.use_tab && ids16) hipLaunchKernelGGL((k_pair_emit2<1, true, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
     else if (C.use_tab) hipLaunchKernelGGL((k_pair_emit2<1, false, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
     else if (ids16) hipLaunchKernelGGL((k_pair_emit2<0, true, false>), g, b, 0, st, B, F, C, seg_off, cursor, keys, ids, first_id);
@@ -609,7 +615,8 @@ void fd_launch_pair_emit_msd(const fd_batch_view &B, const void *frames, const f
     if (!B.n_work) return;
     dim3 g(grid_for(B.n_work)), b(FD_WAVE);
     const fd_frame *F = (const fd_frame *)frames;
-    if (C.use_tab == 2) hipLaunchKernelGGL((k_pair_emit2<2, true, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, (void *)ids, 0u);
+    if (C.use_tab == 3) hipLaunchKernelGGL((k_pair_emit2<2, true, true, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, (void *)ids, 0u);      // + squared-distance table
+    else if (C.use_tab == 2) hipLaunchKernelGGL((k_pair_emit2<2, true, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, (void *)ids, 0u);
     else if (C.use_tab) hipLaunchKernelGGL((k_pair_emit2<1, true, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, (void *)ids, 0u);
     else hipLaunchKernelGGL((k_pair_emit2<0, true, true>), g, b, 0, st, B, F, C, seg_off, cursor, keys, (void *)ids, 0u);
 }

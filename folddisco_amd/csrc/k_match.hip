@@ -73,7 +73,7 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
             uint32_t h_ji;
             // the index build's speculative evaluation (fd_pair_both_spec: table lookups on the dot products, exact whenever it answers) with
             // the exact table form behind it for the pairs it declines — the same frames, so the same bits as the build's keys
-            if (A.C.use_tab != 2 || !fd_pair_both_spec(Fi, Fj, aai, aaj, A.C.q, tab, tab + 32, &h, &h_ji)) fd_pair_both_tab(Fi, Fj, aai, aaj, A.C.q, tab, &h, &h_ji);
+            if (A.C.use_tab < 2 || !fd_pair_both_spec(Fi, Fj, aai, aaj, A.C.q, tab, tab + 32, &h, &h_ji)) fd_pair_both_tab(Fi, Fj, aai, aaj, A.C.q, tab, &h, &h_ji);
             hitmask = ((A.mode & 1u) && hash_in_set(Sx.q_hashes, Sx.n_hashes, h)) ? 1u : 0u;
         } else {
             // one descriptor, one hash per bin pair (--multiple-bins: a found triple for every bin pair whose hash the query holds,

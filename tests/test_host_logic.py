@@ -583,3 +583,35 @@ def test_lookup_writer_prints_f32_like_rust_display(tmp_path):
     indexio.save_lookup(str(tmp_path / "c.lookup"), tids[:100], nres[:100], vals[-100:])
     t2, n2, p2, k2 = indexio.load_lookup(str(tmp_path / "c.lookup"))
     assert t2 == tids[:100] and np.array_equal(n2, nres[:100]) and p2.tobytes() == vals[-100:].tobytes() and np.array_equal(k2, np.arange(100))
+
+
+def test_squared_distance_table_equals_sqrt_and_quantiser():
+    """folddisco_amd/csrc/fd_dist_table.h (tools/gen_dist_table.c: every float squared distance pushed through sqrtf + the quantiser of
+    src/utils/convert.rs:32-36 with the default 16 distance bins, src/geometry/pdb_tr.rs:22-44): counting the breakpoints at or below x equals the
+    chain, at and around every breakpoint and on 2 M random squared distances; and the device's correction bin = b + (x >= T[b + 1]) - (x < T[b])
+    lands on it from any first guess within one bin."""
+    hdr = open(os.path.join(ROOT, "folddisco_amd", "csrc", "fd_dist_table.h")).read()
+    T = np.array([int(x, 16) for x in re.search(r"fd_dist_thr_bits\[FD_DIST_NTHR\] = \{([^}]*)\}", hdr).group(1).replace("u", "").split(",")], np.uint32)
+    thr = T.view(np.float32)
+    assert len(T) == 33 and T[0] == 0 and np.all(np.diff(T.astype(np.int64)) > 0)
+    disc = np.float32(1.0) / (np.float32(18.0) / np.float32(15.0))
+
+    def chain(x):
+        with np.errstate(invalid="ignore"):
+            v = (np.sqrt(x.astype(np.float32)) - np.float32(2.0)) * disc + np.float32(0.5)
+        return np.where(v > 0, np.floor(np.maximum(v, np.float32(0))), 0).astype(np.int64)
+
+    def table(x):
+        return np.searchsorted(thr[1:], x, side="right").astype(np.int64)
+    edge = np.concatenate([(T[1:, None].astype(np.int64) + np.arange(-3, 4)[None, :]).ravel().astype(np.uint32).view(np.float32), np.array([0.0, 1e-30, 6.75, 400.0, 424.36], np.float32)])
+    assert np.array_equal(chain(edge), table(edge))
+    rng = np.random.Generator(np.random.PCG64(3))
+    x = np.concatenate([rng.uniform(0, 1600, 1500000), rng.uniform(0, 30, 500000) ** 2]).astype(np.float32)
+    x = x[x < thr[32]]
+    want = chain(x)
+    assert np.array_equal(want, table(x)) and want.max() == 31
+    for dg in (-1, 0, 1):                                     # the device's correction from a guess one bin off
+        b = np.clip(want + dg, 0, 31)
+        got = b + (x >= thr[b + 1]).astype(np.int64) - (x < thr[b]).astype(np.int64)
+        ok = np.abs(b - want) <= 1
+        assert np.array_equal(got[ok], want[ok])

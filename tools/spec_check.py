@@ -1,5 +1,6 @@
-"""Speculative vs exact torsion evaluation of the index build: identical index bytes?  usage: spec_check.py [S] [seed]
-Runs itself twice (FDGPU_EXACT=0/1) and compares sha256 of (value, hashes, offsets)."""
+"""Speculative vs exact evaluation of the index build: identical index bytes?  usage: spec_check.py [S] [seed]
+Runs itself three times — the default (speculative torsions + squared-distance table), FDGPU_DTAB=0 (speculative torsions, sqrt + quantiser for the
+distances) and FDGPU_EXACT=1 (exact table form) — and compares sha256 of (value, hashes, offsets)."""
 import hashlib, os, subprocess, sys, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,17 +23,17 @@ if os.environ.get("FD_SPEC_CHILD"):
     miss = ctx.spec_fallbacks()
     v, h, o = ix.export()
     dig = hashlib.sha256(v.tobytes()); dig.update(h.tobytes()); dig.update(o.tobytes())
-    print(json.dumps(dict(exact=os.environ.get("FDGPU_EXACT", "0"), sha256=dig.hexdigest(), postings=ix.num_postings, hashes=ix.num_hashes,
+    print(json.dumps(dict(exact=os.environ.get("FDGPU_EXACT", "0"), dtab=os.environ.get("FDGPU_DTAB", "1"), sha256=dig.hexdigest(), postings=ix.num_postings, hashes=ix.num_hashes,
                           value_len=ix.value_len, fallback_pairs=miss, build_s=dt)))
     sys.exit(0)
 res = []
-for ex in ("0", "1"):
-    env = dict(os.environ, FD_SPEC_CHILD="1", FDGPU_EXACT=ex)
+for ex, dt in (("0", "1"), ("0", "0"), ("1", "1")):
+    env = dict(os.environ, FD_SPEC_CHILD="1", FDGPU_EXACT=ex, FDGPU_DTAB=dt)
     out = subprocess.run([sys.executable, os.path.abspath(__file__), str(S), str(seed)], env=env, capture_output=True, text=True, timeout=900)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line:
         print(out.stdout[-2000:], out.stderr[-2000:]); sys.exit(2)
     res.append(json.loads(line[-1])); print(res[-1])
-same = res[0]["sha256"] == res[1]["sha256"]
+same = res[0]["sha256"] == res[1]["sha256"] == res[2]["sha256"]
 print("IDENTICAL" if same else "MISMATCH", "fallback rate %.3g" % (res[0]["fallback_pairs"] / max(res[0]["postings"] / 2, 1)))
 sys.exit(0 if same else 1)
