@@ -19,6 +19,15 @@
 #define FD_EMIT_WAVES 5
 #endif
 #define FD_MSD_BUCKETS 40u   // MSD build: bucket = top six hash bits = aa_i << 1 | aa_j >> 4 (see drain2)
+// One wavefront per workgroup (k_pair_emit2): what the lanes need from each other goes through LDS, and a wavefront's LDS operations execute in
+// issue order, so a lane reads what another lane wrote earlier without any wait — only the COMPILER must be kept from moving or forwarding the
+// accesses (a wavefront-scope fence).  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: the vmcnt(0) made every drain wait for its own
+// four scattered key / id stores to reach L2 (and for the partner-frame gathers of the NEXT drain's prologue to...) before the filter loop could go
+// on — the waves of this kernel sat in s_waitcnt 39 % of their cycles (profiles/round3_pmc_emit_msd_ab_S67750.txt).
+__device__ __forceinline__ void fd_wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // ------------------------------------------------------------------ count pass
 // counts[s] += number of ordered pairs of structure s that will be emitted
@@ -289,14 +298,14 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
         // the buckets of a drain's keys are known before any geometry (the queue entry carries the partner's residue type): count per
         // bucket in LDS, claim the slots with one global atomic per touched bucket — its latency then hides behind the descriptor
         s_bc[lane] = 0;
-        __syncthreads();
+        fd_wave_lds_fence();
         if (lane < n) {
             const uint32_t e = q[lane], il = (e >> 16) & 63u, aj = e >> 22;
             const uint32_t ai = TAB == 2 ? __float_as_uint(s_fi[256 + il].w) : (uint32_t)B.aa[i0 + il];
             const uint32_t bf = ai * 2u + (aj >> 4), br = aj * 2u + (ai >> 4);
             slots = atomicAdd(&s_bc[bf], 1u) | atomicAdd(&s_bc[br], 1u) << 8 | bf << 16 | br << 24;      // one register across the descriptor
         }
-        __syncthreads();
+        fd_wave_lds_fence();
         if (lane < FD_MSD_BUCKETS) { const uint32_t c = s_bc[lane]; if (c) gb = atomicAdd(&cursor[(uint64_t)lane * B.n_struct + s], c); }
     }
     uint32_t h_ij = 0, h_ji = 0, aai = 0, aaj = 0;
@@ -327,7 +336,7 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
     }
     if (MSD) {
         if (lane < FD_MSD_BUCKETS) s_bb[lane] = s_boff[lane] + gb;      // first slot of this drain's keys in every bucket (a build call may hold more than 2^32 keys)
-        __syncthreads();
+        fd_wave_lds_fence();
         if (lane < n) {
             const uint32_t sf = slots & 255u, sr = (slots >> 8) & 255u, bf = (slots >> 16) & 255u, br = slots >> 24;
             // the bucket comes from the residue types like in the count pass (== hash >> 24 unless a saturated distance field bled into
@@ -434,11 +443,11 @@ __global__ __launch_bounds__(FD_WAVE, FD_EMIT_WAVES) void k_pair_emit2(fd_batch_
                 }
             }
             while (qn >= FD_WAVE || (last && qn)) {   // on the last candidate up to two drains may be pending
-                __syncthreads();
+                fd_wave_lds_fence();
                 uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
                 qn -= n;
                 drain2<TAB, IDS16, MSD, DT>(B, frames, C, tab, q + qn, n, i0, r0, s, first_id + s, seg_off, cursor, keys, ids, s_fi, s_bc, s_bb, s_boff);
-                __syncthreads();
+                fd_wave_lds_fence();
             }
         }
     }
