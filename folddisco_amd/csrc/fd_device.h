@@ -46,6 +46,16 @@ __device__ __forceinline__ uint32_t fd_xcd_remap(uint32_t b, uint32_t n) {
     return w;  // may be >= n for the padded tail; caller checks
 }
 
+// One wavefront per workgroup (k_pair_emit2, k_match_pairs): what the lanes need from each other goes through LDS, and a wavefront's LDS operations execute in
+// issue order, so a lane reads what another lane wrote earlier without any wait — only the COMPILER must be kept from moving or forwarding the
+// accesses (a wavefront-scope fence).  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: the vmcnt(0) made every drain wait for its own
+// four scattered key / id stores to reach L2 (and for the partner-frame gathers of the NEXT drain's prologue to...) before the filter loop could go
+// on — the waves of this kernel sat in s_waitcnt 39 % of their cycles (profiles/round3_pmc_emit_msd_ab_S67750.txt).
+__device__ __forceinline__ void fd_wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ uint32_t fd_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t fd_mbcnt(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));

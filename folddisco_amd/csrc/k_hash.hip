@@ -19,15 +19,6 @@
 #define FD_EMIT_WAVES 5
 #endif
 #define FD_MSD_BUCKETS 40u   // MSD build: bucket = top six hash bits = aa_i << 1 | aa_j >> 4 (see drain2)
-// One wavefront per workgroup (k_pair_emit2): what the lanes need from each other goes through LDS, and a wavefront's LDS operations execute in
-// issue order, so a lane reads what another lane wrote earlier without any wait — only the COMPILER must be kept from moving or forwarding the
-// accesses (a wavefront-scope fence).  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: the vmcnt(0) made every drain wait for its own
-// four scattered key / id stores to reach L2 (and for the partner-frame gathers of the NEXT drain's prologue to...) before the filter loop could go
-// on — the waves of this kernel sat in s_waitcnt 39 % of their cycles (profiles/round3_pmc_emit_msd_ab_S67750.txt).
-__device__ __forceinline__ void fd_wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 
 // ------------------------------------------------------------------ count pass
 // counts[s] += number of ordered pairs of structure s that will be emitted

@@ -334,19 +334,19 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                     qn += (uint32_t)__popcll(m);
                 }
             }
-            while (qn >= FD_WAVE) {
-                __syncthreads();
+            while (qn >= FD_WAVE) {      // (wave-scope fences: one wavefront per workgroup, the queue is LDS — no wait for the drain's record stores)
+                fd_wave_lds_fence();
                 qn -= FD_WAVE;
                 match_drain<EMIT>(A, Sx, q + qn, FD_WAVE, slot, r0, r1, st_tab, dist_tab, tab);
-                __syncthreads();
+                fd_wave_lds_fence();
             }
         }
         while (last_blk && qn) {      // the item's last partners are behind it: what is left in the queue
-            __syncthreads();
+            fd_wave_lds_fence();
             const uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
             qn -= n;
             match_drain<EMIT>(A, Sx, q + qn, n, slot, r0, r1, st_tab, dist_tab, tab);
-            __syncthreads();
+            fd_wave_lds_fence();
         }
     }
 }
