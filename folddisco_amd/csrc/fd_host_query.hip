@@ -1386,6 +1386,7 @@ static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uin
                 const std::vector<uint64_t> &T = e_tab[tq];
                 const uint32_t msk = e_mask[tq];
                 for (size_t e = 0; e < g.es.size(); ++e) {
+                    if (e + 12 < g.es.size()) __builtin_prefetch(&T[(g.eh[e + 12] * 2654435761u) & msk]);      // the table of a whole-structure query is ~2 MB: a miss per probe otherwise
                     uint32_t at = (g.eh[e] * 2654435761u) & msk;
                     int32_t k = -1;
                     while (T[at] != ~0ull) { if ((uint32_t)(T[at] >> 32) == g.eh[e]) { k = (int32_t)(uint32_t)T[at]; break; } at = (at + 1) & msk; }
@@ -1590,20 +1591,14 @@ static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uin
         n_thr = (unsigned)std::min<uint64_t>(std::max(1u, n_thr), std::max<uint64_t>(1, (uint64_t)nf / 2048 + 1));   // small jobs stay on the caller's thread
         n_thr = (unsigned)std::min<uint64_t>(n_thr, std::max<uint64_t>(1, n_cand));                                   // a thread per slot at most (spawning one costs ~0.1 ms)
         std::atomic<uint64_t> next(0);
-        auto worker = [&]() {
+        const std::function<void()> worker = [&]() {
             for (;;) {
                 const uint64_t slot = next.fetch_add(1);
                 if (slot >= n_cand) break;
                 do_slot(slot, plan, outs[slot]);
             }
         };
-        if (n_thr <= 1) worker();
-        else {
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t + 1 < n_thr; ++t) pool.emplace_back(worker);
-            worker();
-            for (auto &th : pool) th.join();
-        }
+        c->host_pool.run(n_thr, worker);      // the context's standing helper threads (a spawn per thread per pass was ~1 ms of the call)
         // merge in slot order
         uint64_t tq = 0;
         for (uint64_t slot = 0; slot < n_cand; ++slot) {

@@ -15,7 +15,7 @@ import torch
 from _resident import build_resident
 import folddisco_amd as fd
 from folddisco_amd.api import PackedStructures, count_query_maps, length_penalty
-from folddisco_amd.query import make_query_map, retrieve
+from folddisco_amd.query import make_query_map, retrieve, retrieve_batch
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 542000
 ctx, batch, ix, d, ro = build_resident(S)
@@ -36,7 +36,7 @@ def once():
     t1 = time.perf_counter()
     top = count_query_maps(ctx, ix, [qm], None, total_structures=S, top_n=1000)[0]
     t2 = time.perf_counter()
-    m = retrieve(ctx, batch, None, (top["nid"][:20].astype(np.int64)).astype(np.uint32), qm, qb)
+    m = retrieve_batch(ctx, batch, None, [(top["nid"][:20].astype(np.int64)).astype(np.uint32)], [qm], qb, [0], as_arrays=True)[0]
     t3 = time.perf_counter()
     return (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, len(qm.hash), len(m)
 
