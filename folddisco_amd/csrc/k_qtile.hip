@@ -436,46 +436,28 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
                             if (((T >> i) & 1u) && x < tile_lim) atomicAdd(&s_acc[x], add);
                         }
                     } else if (!RICH) {
-                        // one returning 64-bit LDS add per posting, eight in flight (lanes without a posting add 0 to a slot of their own);
-                        // a count of 0 before the add = the structure's first posting of this query
-                        uint32_t first = 0;
-                        // the slot's postings also leave as 16-bit structure ids inside the tile (0xffff: none) for the decoded stream pass B reads
-                        // instead of decoding the lists again; four adds in flight, a quarter of the record stored as soon as it is complete
-                        // (eight in flight + the whole record in registers spilled 24 VGPRs)
+                        // one 64-bit LDS add per posting (lanes without a posting add 0 to a slot of their own).  The adds do not return anything: which
+                        // structures a tile touched is read off the accumulators when the tile is done (finalize below walks them in id order) — the
+                        // first-touch list of round 4 made every add a returning one, cost an LDS claim + scattered 4-byte global stores per step and a
+                        // dependent (structure -> penalty) gather per touched structure at the end.
+                        // The slot's postings also leave as 16-bit structure ids inside the tile (0xffff: none) for the decoded stream pass B reads
+                        // instead of decoding the lists again; a quarter of the record is stored as soon as it is complete.
                         const bool to_stream = A.stream_ids && base + lane < s_end && (uint64_t)s_sbase + base + lane < A.stream_cap;
                         uint2 *sdst = reinterpret_cast<uint2 *>(A.stream_ids) + 4ull * ((uint64_t)s_sbase + base + lane);
 #pragma unroll
                         for (int h = 0; h < 4; ++h) {
-                            unsigned long long old[4];
-                            uint32_t okm = 0, s2[2] = {0u, 0u};
+                            uint32_t s2[2] = {0u, 0u};
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 id += v[h * 4 + i];
                                 const uint32_t x = id - tile_id0;
                                 const bool ok = ((T >> (h * 4 + i)) & 1u) && x < tile_lim;
-                                okm |= ok ? (1u << i) : 0u;
-                                old[i] = atomicAdd(&s_acc[ok ? x : TILE + lane], ok ? add : 0ull);
+                                atomicAdd(&s_acc[ok ? x : TILE + lane], ok ? add : 0ull);
                                 s2[i >> 1] |= (ok ? x : 0xffffu) << ((i & 1) * 16);
                             }
                             if (to_stream) sdst[h] = make_uint2(s2[0], s2[1]);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) if (((okm >> i) & 1u) && (old[i] >> QT_CNT_SHIFT) == 0ull) first |= 1u << (h * 4 + i);
                         }
                         if (to_stream) A.stream_row[(uint64_t)s_sbase + base + lane] = s_row[cur.c];
-                        // the touched structures are listed as they are met: the slots of a step's first hits by one LDS atomic per wavefront
-                        const uint32_t nf = (uint32_t)__popc(first), fi = qt_wave_incl(nf, lane);
-                        const uint32_t ftot = (uint32_t)__builtin_amdgcn_readlane((int)fi, 63);
-                        if (ftot) {
-                            uint32_t fb = 0;
-                            if (lane == 0) fb = atomicAdd(&s_cnt, ftot);
-                            uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb) + fi - nf;
-                            id = id_first;
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                id += v[i];
-                                if ((first >> i) & 1u) A.c_nid[cbase + pos++] = id - A.first_id;
-                            }
-                        }
                     } else {
                         // survivors are rare: the bitmap words of all sixteen postings first, the row bits only where one is set
                         uint32_t hit = 0;
@@ -561,27 +543,35 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
         for (uint32_t k = tid; k < TILE; k += NTHR) dst[k] = s_acc[k];
         return;
     }
-    // ---- pass A: ranking keys of the touched structures (listed in the order they were met), first histogram level
-    const uint32_t n_t = s_cnt;
-    for (uint32_t e0 = 0; e0 < n_t; e0 += 4 * NTHR) {       // four structures per thread in flight
-        uint32_t sid[4]; float pen[4];
+    // ---- pass A: the touched structures of the tile (count != 0) with their ranking keys, compacted in id order, first histogram level.  The tile's
+    // accumulators are walked once, NTHR structures at a time: the penalties are one coalesced load per step (eight steps requested together), the
+    // touched lanes of a wavefront claim their places in the tile's list with one LDS add per wavefront
+    for (uint32_t k0 = 0; k0 < TILE; k0 += 8 * NTHR) {
+        float pen[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const uint32_t e = e0 + u * NTHR + tid; sid[u] = e < n_t ? A.c_nid[cbase + e] : tile_lo; }
+        for (int u = 0; u < 8; ++u) { const uint32_t k = k0 + u * NTHR + tid; pen[u] = k < tile_lim ? A.penalty[tile_lo + k] : 0.0f; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pen[u] = A.penalty[sid[u]];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t e = e0 + u * NTHR + tid;
-            if (e < n_t) {
-                const unsigned long long a = s_acc[sid[u] - tile_lo];
-                const uint32_t key = qt_order_key((float)((double)(a & QT_SUM_MASK) * (1.0 / QT_IDF_SCALE)) * pen[u]);
-                const uint32_t bin = qt_bin(key);
-                atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
-                A.c_key[cbase + e] = key;
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t k = k0 + u * NTHR + tid;
+            const unsigned long long a = s_acc[k];
+            const bool touched = (a >> QT_CNT_SHIFT) != 0ull;       // (structures beyond the tile's end were never added to)
+            const uint64_t m = __ballot(touched);
+            if (m) {
+                uint32_t pos = 0;
+                if (lane == 0) pos = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+                pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos) + fd_mbcnt(m);
+                if (touched) {
+                    const uint32_t key = qt_order_key((float)((double)(a & QT_SUM_MASK) * (1.0 / QT_IDF_SCALE)) * pen[u]);
+                    const uint32_t bin = qt_bin(key);
+                    atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
+                    A.c_nid[cbase + pos] = tile_lo + k;
+                    A.c_key[cbase + pos] = key;
+                }
             }
         }
     }
     __syncthreads();
+    const uint32_t n_t = s_cnt;
     for (uint32_t k = tid; k < QT_BINS; k += NTHR) {
         const uint32_t cn = (s_hist[k >> 1] >> ((k & 1u) * 16u)) & 0xffffu;
         if (cn) atomicAdd(&A.ghist[(uint64_t)q * QT_BINS + k], cn);
