@@ -543,35 +543,40 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
         for (uint32_t k = tid; k < TILE; k += NTHR) dst[k] = s_acc[k];
         return;
     }
-    // ---- pass A: the touched structures of the tile (count != 0) with their ranking keys, compacted in id order, first histogram level.  The tile's
-    // accumulators are walked once, NTHR structures at a time: the penalties are one coalesced load per step (eight steps requested together), the
-    // touched lanes of a wavefront claim their places in the tile's list with one LDS add per wavefront
-    for (uint32_t k0 = 0; k0 < TILE; k0 += 8 * NTHR) {
-        float pen[8];
+    // ---- pass A: the touched structures of the tile (count != 0) with their ranking keys, compacted per wavefront in id order, first histogram level.
+    // Every thread holds the accumulators of TILE / NTHR structures (stride NTHR: a wavefront's 64 lanes are 64 consecutive structures); the
+    // penalties are coalesced loads requested before anything else; a wavefront's place in the tile's list comes from the wavefronts' counts
+    // (ballots, one LDS word per wavefront, one barrier) — a claim per wavefront per step on ONE LDS counter serialised sixteen wavefronts.
+    constexpr int STEPS = (int)(TILE / NTHR);
+    float pen[STEPS];
+    unsigned long long acc[STEPS];
+    uint32_t w_cnt = 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const uint32_t k = k0 + u * NTHR + tid; pen[u] = k < tile_lim ? A.penalty[tile_lo + k] : 0.0f; }
+    for (int u = 0; u < STEPS; ++u) { const uint32_t k = (uint32_t)u * NTHR + tid; pen[u] = k < tile_lim ? A.penalty[tile_lo + k] : 0.0f; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t k = k0 + u * NTHR + tid;
-            const unsigned long long a = s_acc[k];
-            const bool touched = (a >> QT_CNT_SHIFT) != 0ull;       // (structures beyond the tile's end were never added to)
-            const uint64_t m = __ballot(touched);
-            if (m) {
-                uint32_t pos = 0;
-                if (lane == 0) pos = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
-                pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos) + fd_mbcnt(m);
-                if (touched) {
-                    const uint32_t key = qt_order_key((float)((double)(a & QT_SUM_MASK) * (1.0 / QT_IDF_SCALE)) * pen[u]);
-                    const uint32_t bin = qt_bin(key);
-                    atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
-                    A.c_nid[cbase + pos] = tile_lo + k;
-                    A.c_key[cbase + pos] = key;
-                }
-            }
+    for (int u = 0; u < STEPS; ++u) {
+        acc[u] = s_acc[(uint32_t)u * NTHR + tid];        // (structures beyond the tile's end were never added to)
+        w_cnt += (uint32_t)__popcll(__ballot((acc[u] >> QT_CNT_SHIFT) != 0ull));
+    }
+    if (lane == 0) s_w[tid >> 6] = w_cnt;
+    __syncthreads();
+    uint32_t pos = 0, n_t = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < NTHR / 64; ++k) { const uint32_t x = s_w[k]; pos += k < (tid >> 6) ? x : 0u; n_t += x; }
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+        const bool touched = (acc[u] >> QT_CNT_SHIFT) != 0ull;
+        const uint64_t m = __ballot(touched);
+        if (touched) {
+            const uint32_t key = qt_order_key((float)((double)(acc[u] & QT_SUM_MASK) * (1.0 / QT_IDF_SCALE)) * pen[u]);
+            const uint32_t bin = qt_bin(key), at = pos + fd_mbcnt(m);
+            atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
+            A.c_nid[cbase + at] = tile_lo + (uint32_t)u * NTHR + tid;
+            A.c_key[cbase + at] = key;
         }
+        pos += (uint32_t)__popcll(m);
     }
     __syncthreads();
-    const uint32_t n_t = s_cnt;
     for (uint32_t k = tid; k < QT_BINS; k += NTHR) {
         const uint32_t cn = (s_hist[k >> 1] >> ((k & 1u) * 16u)) & 0xffffu;
         if (cn) atomicAdd(&A.ghist[(uint64_t)q * QT_BINS + k], cn);
