@@ -436,28 +436,46 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
                             if (((T >> i) & 1u) && x < tile_lim) atomicAdd(&s_acc[x], add);
                         }
                     } else if (!RICH) {
-                        // one 64-bit LDS add per posting (lanes without a posting add 0 to a slot of their own).  The adds do not return anything: which
-                        // structures a tile touched is read off the accumulators when the tile is done (finalize below walks them in id order) — the
-                        // first-touch list of round 4 made every add a returning one, cost an LDS claim + scattered 4-byte global stores per step and a
-                        // dependent (structure -> penalty) gather per touched structure at the end.
-                        // The slot's postings also leave as 16-bit structure ids inside the tile (0xffff: none) for the decoded stream pass B reads
-                        // instead of decoding the lists again; a quarter of the record is stored as soon as it is complete.
+                        // one returning 64-bit LDS add per posting, eight in flight (lanes without a posting add 0 to a slot of their own);
+                        // a count of 0 before the add = the structure's first posting of this query
+                        uint32_t first = 0;
+                        // the slot's postings also leave as 16-bit structure ids inside the tile (0xffff: none) for the decoded stream pass B reads
+                        // instead of decoding the lists again; four adds in flight, a quarter of the record stored as soon as it is complete
+                        // (eight in flight + the whole record in registers spilled 24 VGPRs)
                         const bool to_stream = A.stream_ids && base + lane < s_end && (uint64_t)s_sbase + base + lane < A.stream_cap;
                         uint2 *sdst = reinterpret_cast<uint2 *>(A.stream_ids) + 4ull * ((uint64_t)s_sbase + base + lane);
 #pragma unroll
                         for (int h = 0; h < 4; ++h) {
-                            uint32_t s2[2] = {0u, 0u};
+                            unsigned long long old[4];
+                            uint32_t okm = 0, s2[2] = {0u, 0u};
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 id += v[h * 4 + i];
                                 const uint32_t x = id - tile_id0;
                                 const bool ok = ((T >> (h * 4 + i)) & 1u) && x < tile_lim;
-                                atomicAdd(&s_acc[ok ? x : TILE + lane], ok ? add : 0ull);
+                                okm |= ok ? (1u << i) : 0u;
+                                old[i] = atomicAdd(&s_acc[ok ? x : TILE + lane], ok ? add : 0ull);
                                 s2[i >> 1] |= (ok ? x : 0xffffu) << ((i & 1) * 16);
                             }
                             if (to_stream) sdst[h] = make_uint2(s2[0], s2[1]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) if (((okm >> i) & 1u) && (old[i] >> QT_CNT_SHIFT) == 0ull) first |= 1u << (h * 4 + i);
                         }
                         if (to_stream) A.stream_row[(uint64_t)s_sbase + base + lane] = s_row[cur.c];
+                        // the touched structures are listed as they are met: the slots of a step's first hits by one LDS atomic per wavefront
+                        const uint32_t nf = (uint32_t)__popc(first), fi = qt_wave_incl(nf, lane);
+                        const uint32_t ftot = (uint32_t)__builtin_amdgcn_readlane((int)fi, 63);
+                        if (ftot) {
+                            uint32_t fb = 0;
+                            if (lane == 0) fb = atomicAdd(&s_cnt, ftot);
+                            uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb) + fi - nf;
+                            id = id_first;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                id += v[i];
+                                if ((first >> i) & 1u) A.c_nid[cbase + pos++] = id - A.first_id;
+                            }
+                        }
                     } else {
                         // survivors are rare: the bitmap words of all sixteen postings first, the row bits only where one is set
                         uint32_t hit = 0;
@@ -543,46 +561,22 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
         for (uint32_t k = tid; k < TILE; k += NTHR) dst[k] = s_acc[k];
         return;
     }
-    // ---- pass A: the touched structures of the tile (count != 0) and their ranking keys, first histogram level.  29 % of a tile is touched by a motif
-    // query, so the accumulators are first COMPACTED inside LDS — every thread takes TILE / NTHR of them into registers (stride NTHR: a wavefront's lanes
-    // are 64 consecutive structures), the wavefronts' counts give every wavefront its place (ballots, one LDS word per wavefront, one barrier), and
-    // the touched ones go back as (structure << 46 | idf sum) at the front of the accumulator array — and the keys are then computed over the
-    // dense list with every lane busy: penalty gather (L2: the tile's 64 KB), key, histogram, two fully coalesced stores per entry.
-    constexpr int STEPS = (int)(TILE / NTHR);
-    unsigned long long acc[STEPS];
-    uint32_t w_cnt = 0;
+    // ---- pass A: ranking keys of the touched structures (listed in the order they were met), first histogram level
+    const uint32_t n_t = s_cnt;
+    for (uint32_t e0 = 0; e0 < n_t; e0 += 4 * NTHR) {       // four structures per thread in flight
+        uint32_t sid[4]; float pen[4];
 #pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-        acc[u] = s_acc[(uint32_t)u * NTHR + tid];        // (structures beyond the tile's end were never added to)
-        w_cnt += (uint32_t)__popcll(__ballot((acc[u] >> QT_CNT_SHIFT) != 0ull));
-    }
-    if (lane == 0) s_w[tid >> 6] = w_cnt;
-    __syncthreads();                                     // every accumulator is in a register: the array may be overwritten
-    uint32_t pos = 0, n_t = 0;
+        for (int u = 0; u < 4; ++u) { const uint32_t e = e0 + u * NTHR + tid; sid[u] = e < n_t ? A.c_nid[cbase + e] : tile_lo; }
 #pragma unroll
-    for (uint32_t k = 0; k < NTHR / 64; ++k) { const uint32_t x = s_w[k]; pos += k < (tid >> 6) ? x : 0u; n_t += x; }
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-        const bool touched = (acc[u] >> QT_CNT_SHIFT) != 0ull;
-        const uint64_t m = __ballot(touched);
-        if (touched) s_acc[pos + fd_mbcnt(m)] = ((unsigned long long)((uint32_t)u * NTHR + tid) << QT_CNT_SHIFT) | (acc[u] & QT_SUM_MASK);
-        pos += (uint32_t)__popcll(m);
-    }
-    __syncthreads();
-    for (uint32_t e0 = 0; e0 < n_t; e0 += 4 * NTHR) {       // four entries per thread in flight
-        unsigned long long v[4]; float pen[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const uint32_t e = e0 + u * NTHR + tid; v[u] = e < n_t ? s_acc[e] : 0ull; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pen[u] = A.penalty[tile_lo + (uint32_t)(v[u] >> QT_CNT_SHIFT)];
+        for (int u = 0; u < 4; ++u) pen[u] = A.penalty[sid[u]];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t e = e0 + u * NTHR + tid;
             if (e < n_t) {
-                const uint32_t key = qt_order_key((float)((double)(v[u] & QT_SUM_MASK) * (1.0 / QT_IDF_SCALE)) * pen[u]);
+                const unsigned long long a = s_acc[sid[u] - tile_lo];
+                const uint32_t key = qt_order_key((float)((double)(a & QT_SUM_MASK) * (1.0 / QT_IDF_SCALE)) * pen[u]);
                 const uint32_t bin = qt_bin(key);
                 atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
-                A.c_nid[cbase + e] = tile_lo + (uint32_t)(v[u] >> QT_CNT_SHIFT);
                 A.c_key[cbase + e] = key;
             }
         }
