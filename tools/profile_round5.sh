@@ -1,25 +1,25 @@
 #!/bin/bash
-# tools/profile_round4.sh — the rocprofv3 evidence of round 4, one call on the GPU box (summaries land in gpurun_out/, copy to profiles/):
+# tools/profile_round5.sh — the rocprofv3 evidence of round 5, one call on the GPU box (summaries land in gpurun_out/, copy to profiles/):
 #  1. kernel trace + stats of the DEFAULT bench command (542,000 structures, query + whole-structure legs included)
 #  2. FETCH_SIZE / WRITE_SIZE passes of the build at 542,000 (bench.py reads profiles/*pmc_traffic_S542000.json)
 #  3. FETCH_SIZE / WRITE_SIZE / TCC request passes of the tiled motif prefilter (k_qt_*) at 542,000, 8 batches of 32 queries
 #     (querybench reads profiles/*pmc_query_traffic_S542000.json); the request counters calibrate the FETCH_SIZE correction per kernel
 # Every --pmc pass is its own run with no tracing domain.
 set -u
-REPO=$(pwd); OUT=$REPO/gpurun_out; RAW=/tmp/fdprof4
+REPO=$(pwd); OUT=$REPO/gpurun_out; RAW=/tmp/fdprof5
 rm -rf $RAW; mkdir -p $OUT $RAW
 export TMPDIR=/tmp
 cd /tmp
 CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-export --no-cli-index"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- $CMD > $OUT/r4_trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- $CMD > $OUT/r5_trace.log 2>&1
 CMDB="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-export --no-query --no-cli-index"
 INC='--kernel-include-regex k_.*'
-timeout 900 rocprofv3 --output-format csv $INC --pmc FETCH_SIZE -d $RAW/pmc_fetch -o pmc_fetch -- $CMDB > $OUT/r4_pmc_fetch.log 2>&1
-timeout 900 rocprofv3 --output-format csv $INC --pmc WRITE_SIZE -d $RAW/pmc_write -o pmc_write -- $CMDB > $OUT/r4_pmc_write.log 2>&1
+timeout 900 rocprofv3 --output-format csv $INC --pmc FETCH_SIZE -d $RAW/pmc_fetch -o pmc_fetch -- $CMDB > $OUT/r5_pmc_fetch.log 2>&1
+timeout 900 rocprofv3 --output-format csv $INC --pmc WRITE_SIZE -d $RAW/pmc_write -o pmc_write -- $CMDB > $OUT/r5_pmc_write.log 2>&1
 cd $REPO
-python tools/summarize_prof.py $RAW 542000 > $OUT/r4_prof_summary.txt 2>&1
-cp $RAW/prof_traffic.json $OUT/r4_prof_traffic.json 2>/dev/null
-python - "$RAW" > $OUT/r4_all_kernels.txt <<'PY'
+python tools/summarize_prof.py $RAW 542000 > $OUT/r5_prof_summary.txt 2>&1
+cp $RAW/prof_traffic.json $OUT/r5_prof_traffic.json 2>/dev/null
+python - "$RAW" > $OUT/r5_all_kernels.txt <<'PY'
 import csv, glob, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/trace/**/*kernel_stats.csv", recursive=True):
@@ -33,11 +33,11 @@ PY
 cd /tmp
 CMDQ="python $REPO/tools/profile_query_host.py --structures 542000 --reps 3 --no-profile"
 QINC='--kernel-include-regex k_qt_.*|k_cq_plan.*|k_pl_.*'
-timeout 900 rocprofv3 --output-format csv $QINC --pmc FETCH_SIZE -d $RAW/q_fetch -o q_fetch -- $CMDQ > $OUT/r4_q_fetch.log 2>&1
-timeout 900 rocprofv3 --output-format csv $QINC --pmc WRITE_SIZE -d $RAW/q_write -o q_write -- $CMDQ > $OUT/r4_q_write.log 2>&1
-timeout 900 rocprofv3 --output-format csv $QINC --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d $RAW/q_req -o q_req -- $CMDQ > $OUT/r4_q_req.log 2>&1
+timeout 900 rocprofv3 --output-format csv $QINC --pmc FETCH_SIZE -d $RAW/q_fetch -o q_fetch -- $CMDQ > $OUT/r5_q_fetch.log 2>&1
+timeout 900 rocprofv3 --output-format csv $QINC --pmc WRITE_SIZE -d $RAW/q_write -o q_write -- $CMDQ > $OUT/r5_q_write.log 2>&1
+timeout 900 rocprofv3 --output-format csv $QINC --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d $RAW/q_req -o q_req -- $CMDQ > $OUT/r5_q_req.log 2>&1
 cd $REPO
-python - "$RAW" > $OUT/r4_q_traffic_summary.txt <<'PY'
+python - "$RAW" > $OUT/r5_q_traffic_summary.txt <<'PY'
 import csv, glob, json, sys, collections
 raw = sys.argv[1]
 N_BATCH = 8
@@ -79,5 +79,5 @@ json.dump({"structures": 542000, "batches": N_BATCH, "kernels": out, "bytes_per_
                    "--no-profile; fetch_correction = 1 + share of the kernel's read bytes fetched by 16-byte-per-lane loads (gfx950 counts those requests at half their size)"},
           open(raw + "/q_traffic.json", "w"), indent=1)
 PY
-cp $RAW/q_traffic.json $OUT/r4_q_traffic.json 2>/dev/null
-head -60 $OUT/r4_all_kernels.txt; cat $OUT/r4_q_traffic_summary.txt; tail -30 $OUT/r4_prof_summary.txt
+cp $RAW/q_traffic.json $OUT/r5_q_traffic.json 2>/dev/null
+head -60 $OUT/r5_all_kernels.txt; cat $OUT/r5_q_traffic_summary.txt; tail -30 $OUT/r5_prof_summary.txt
