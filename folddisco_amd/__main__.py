@@ -83,6 +83,9 @@ def cmd_index(a):
     # nres 0 and plddt 0, controller/mod.rs:313-318) WHILE the GPU builds the sub-index of chunk k (one fdgpu_index_build call, < 2^32 residue
     # pairs); the sub-indices stay resident in HBM and are concatenated per hash on the device (fdgpu_index_merge, in rounds of 64), so
     # the index crosses the bus once, in the reference's on-disk layout.
+    from concurrent.futures import ThreadPoolExecutor
+    tid_pool = ThreadPoolExecutor(1)
+    tids_f = tid_pool.submit(lambda: [indexio.parse_path_by_id_type(x, a.id) for x in paths])      # 20 ms of Python per 20,000 paths: under the ingest
     parts, nres, plddt = _build_chunks(a, fd, structure, ctx, paths, 0, resident=True)
     t0 = time.perf_counter()
     ix = _merge_resident(fd, parts)
@@ -92,7 +95,8 @@ def cmd_index(a):
     ix.save(prefix)                               # the library writes PREFIX and PREFIX.offset itself (byte-identical to save_offset_to_file)
     T["save_s"] = time.perf_counter() - t0
     n_hashes, value_len = ix.num_hashes, ix.value_len
-    indexio.save_lookup(prefix + ".lookup", [indexio.parse_path_by_id_type(x, a.id) for x in paths], nres, plddt, db_keys=a.fc_keys)
+    indexio.save_lookup(prefix + ".lookup", tids_f.result(), nres, plddt, db_keys=a.fc_keys)
+    tid_pool.shutdown()
     indexio.save_type(prefix + ".type", len(paths), grid_width=a.grid, max_residue=a.max_residue, nbin_angle=a.angle, nbin_dist=a.distance, hash_type=HASH_TYPE_NAMES[a.hash_type], multiple_bins=a.multi,
                       **(dict(input_format="FCZDB", foldcomp_db=a.pdbs) if a.fc is not None else {}))
     T["export_write_s"] = time.perf_counter() - t0
@@ -159,6 +163,8 @@ def _build_chunks(a, fd, structure, ctx, paths, first_id, resident=False):
         return r, time.perf_counter() - t0
     with ThreadPoolExecutor(1) as pool:
         fut = pool.submit(ingest, starts[0]) if starts else None
+        if resident:
+            ctx.L.fdgpu_reserve_staging(ctx.h)      # the save's page-locked staging slots, made while the first chunk is parsed (this thread only waits otherwise)
         for k, c0 in enumerate(starts):
             (ps, nres_c, plddt_c, raw, ok), t_ing = fut.result()
             fut = pool.submit(ingest, starts[k + 1]) if k + 1 < len(starts) else None      # the next chunk is parsed while this one is built

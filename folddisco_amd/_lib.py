@@ -176,6 +176,7 @@ SYMBOLS = [
                                          C.POINTER(u64p), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(u64p)]),
     ("fdgpu_query_lanes", C.c_int, [VP, C.c_uint32]),
     ("fdgpu_trim", None, []),
+    ("fdgpu_reserve_staging", C.c_int, [VP]),
     ("fdgpu_write_lookup", C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, u64p, f32p, u64p]),
     ("fdgpu_format_f32_display", C.c_int, [f32p, C.c_uint64, C.c_char_p]),
     ("fdgpu_retrieve", C.c_int, [VP, VP, u8p, u32p, C.c_uint64, C.POINTER(QueryMap), VP, C.POINTER(HashParams), C.c_float, C.c_uint32, C.c_uint32,

@@ -8,7 +8,11 @@
 // truncated input) makes it return false and the caller falls back to zlib, which then reports the file the way it always did.
 // The reference reads gzip through the flate2 crate (src/structure/io/pdb.rs:79-124); a decoder's output is defined by the format.
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <mutex>
 #include <string>
 #include <vector>
@@ -298,9 +302,59 @@ void make_crc() {
     for (uint32_t b = 0; b < 256; ++b)
         for (int t = 1; t < 16; ++t) g_crc_tab[t][b] = (g_crc_tab[t - 1][b] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][b] & 0xffu];
 }
+#if defined(__x86_64__)
+// The same CRC by carry-less multiplication (PCLMULQDQ): four 128-bit lanes folded per 64 input bytes, then 4 -> 1, 128 -> 64 -> 32 bits and a Barrett
+// reduction, with the folding constants of the reflected gzip polynomial (x^(512+64), x^512, x^(128+64), x^128, x^96 mod P; mu and P for the reduction —
+// Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ Instruction").  ~5x the sixteen-table loop; the tables finish the tail.
+// c = the running CRC register (pre-inverted), n >= 64.  -> the register after the largest multiple of 16 bytes, *done = bytes consumed.
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc32_clmul(const uint8_t *buf, size_t n, uint32_t c, size_t *done) {
+    const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596ll, 0x0154442bd4ll), k3k4 = _mm_set_epi64x(0x00ccaa009ell, 0x01751997d0ll);
+    const __m128i k5k0 = _mm_set_epi64x(0, 0x0163cd6124ll), poly = _mm_set_epi64x(0x01f7011641ll, 0x01db710641ll);
+    const uint8_t *p = buf;
+    __m128i x1 = _mm_loadu_si128((const __m128i *)(p + 0)), x2 = _mm_loadu_si128((const __m128i *)(p + 16));
+    __m128i x3 = _mm_loadu_si128((const __m128i *)(p + 32)), x4 = _mm_loadu_si128((const __m128i *)(p + 48));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)c));
+    p += 64; n -= 64;
+    while (n >= 64) {
+        const __m128i y1 = _mm_clmulepi64_si128(x1, k1k2, 0x00), y2 = _mm_clmulepi64_si128(x2, k1k2, 0x00);
+        const __m128i y3 = _mm_clmulepi64_si128(x3, k1k2, 0x00), y4 = _mm_clmulepi64_si128(x4, k1k2, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, k1k2, 0x11); x2 = _mm_clmulepi64_si128(x2, k1k2, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, k1k2, 0x11); x4 = _mm_clmulepi64_si128(x4, k1k2, 0x11);
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, y1), _mm_loadu_si128((const __m128i *)(p + 0)));
+        x2 = _mm_xor_si128(_mm_xor_si128(x2, y2), _mm_loadu_si128((const __m128i *)(p + 16)));
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, y3), _mm_loadu_si128((const __m128i *)(p + 32)));
+        x4 = _mm_xor_si128(_mm_xor_si128(x4, y4), _mm_loadu_si128((const __m128i *)(p + 48)));
+        p += 64; n -= 64;
+    }
+#define FD_CRC_FOLD(a, b) _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128((a), k3k4, 0x11), _mm_clmulepi64_si128((a), k3k4, 0x00)), (b))
+    x1 = FD_CRC_FOLD(x1, x2); x1 = FD_CRC_FOLD(x1, x3); x1 = FD_CRC_FOLD(x1, x4);
+    while (n >= 16) { x1 = FD_CRC_FOLD(x1, _mm_loadu_si128((const __m128i *)p)); p += 16; n -= 16; }
+#undef FD_CRC_FOLD
+    // 128 -> 64 bits
+    const __m128i mask32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    __m128i t = _mm_clmulepi64_si128(x1, k3k4, 0x10);
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), t);
+    // 64 -> 32 bits
+    t = _mm_srli_si128(x1, 4);
+    x1 = _mm_and_si128(x1, mask32);
+    x1 = _mm_xor_si128(_mm_clmulepi64_si128(x1, k5k0, 0x00), t);
+    // Barrett reduction
+    t = _mm_and_si128(x1, mask32);
+    t = _mm_clmulepi64_si128(t, poly, 0x10);
+    t = _mm_and_si128(t, mask32);
+    t = _mm_clmulepi64_si128(t, poly, 0x00);
+    x1 = _mm_xor_si128(x1, t);
+    *done = (size_t)(p - buf);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+#endif
 uint32_t crc32_fast(const uint8_t *p, size_t n) {
     std::call_once(g_crc_once, make_crc);
     uint32_t c = 0xffffffffu;
+#if defined(__x86_64__)
+    static const bool have_clmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("FDGPU_CRC_TABLES");
+    if (have_clmul && n >= 64) { size_t done = 0; c = crc32_clmul(p, n, c, &done); p += done; n -= done; }
+#endif
     const uint32_t(*T)[256] = g_crc_tab;
     while (n >= 16) {
         uint32_t a, b, d, e;

@@ -185,7 +185,7 @@ extern "C" void fdgpu_destroy(fdgpu_ctx *c) {
     for (auto &b : c->ws) b.release();
     for (auto &b : c->pool) (void)hipFree(b.p);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (int k = 0; k < 8; ++k) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
+    for (int k = 0; k < 16; ++k) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
     for (int k = 0; k < 6; ++k) if (c->hbuf[k]) (void)hipHostFree(c->hbuf[k]);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -853,8 +853,8 @@ extern "C" int fdgpu_index_build(fdgpu_ctx *c, const fdgpu_batch *b, const fd_ha
 // host thread (~12 GB/s: 2.2 s for the 26 GB of a Swiss-Prot-scale index); here FD_PIN_SLOTS pinned buffers are filled by
 // asynchronous copies on the context's stream and emptied by as many host threads, which also take the destination's first-touch
 // page faults in parallel (the destination is asked for huge pages).
-#define FD_PIN_SLOTS 8
-#define FD_PIN_BYTES ((size_t)32 << 20)
+#define FD_PIN_SLOTS 16
+#define FD_PIN_BYTES ((size_t)16 << 20)
 static hipError_t fd_d2h_big(fdgpu_ctx *c, void *dst, const void *src, size_t bytes) {
     if (bytes < 4 * FD_PIN_BYTES) return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
     for (int k = 0; k < FD_PIN_SLOTS; ++k) {
@@ -1092,6 +1092,17 @@ hipError_t fd_d2h_to_file(fdgpu_ctx *c, int fd, uint64_t file_off, const void *s
     }
     for (auto &t : drain) if (t.joinable()) t.join();
     return err;
+}
+
+// The page-locked staging slots of fdgpu_index_save / _save_part / _export (16 x 16 MB), made now instead of inside the first of those calls: a host that
+// knows it will write an index (the index command) calls this while its first chunk is still being parsed — page-locking 256 MB is ~20 ms.
+extern "C" int fdgpu_reserve_staging(fdgpu_ctx *c) { FD_LOCK(c);
+    if (!c) return FDGPU_EINVAL;
+    for (int k = 0; k < FD_PIN_SLOTS; ++k) {
+        if (!c->pin[k]) HIPCHK(c, hipHostMalloc(&c->pin[k], FD_PIN_BYTES, hipHostMallocDefault));
+        if (!c->pin_ev[k]) HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming));
+    }
+    return FDGPU_OK;
 }
 
 // PREFIX (value bytes) and PREFIX.offset (u64 H | u32 hashes[H] | u64 offsets[H + 1]) — byte-identical to save_offset_to_file /

@@ -127,8 +127,8 @@ struct fdgpu_ctx {
         hbuf_cap[k] = want;
         return hbuf[k];
     }
-    void *pin[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t pin_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *pin[16] = {};
+    hipEvent_t pin_ev[16] = {};
     // device blocks of destroyed indices, reused by the next build (steady-state builds do not call
     // hipMalloc/hipFree, which would serialise the stream)
     struct pooled { void *p; size_t cap; };

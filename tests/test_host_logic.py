@@ -489,6 +489,9 @@ def test_own_gzip_decoder_equals_zlib(tmp_path, monkeypatch):
         assert gunzip(z + gzip.compress(b"second member " + t[:1000])) == t + b"second member " + t[:1000]
         assert gunzip(z + b"trailing bytes") == t
     assert n_ok == 90
+    for n in list(range(0, 300)) + [1023, 4096 + 7, 65536 + 63]:       # every tail length of the carry-less-multiplication CRC (64-byte folds, 16-byte folds, table tail)
+        t = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        assert gunzip(gzip.compress(t, compresslevel=1)) == t, n
     z = gzip.compress(b"payload payload payload")
     hdr = bytearray(z[:10])
     hdr[3] = 4 | 8 | 16
