@@ -446,7 +446,7 @@ def main():
             if rank == 0 and shutil.disk_usage(best).free > 1.25 * need:
                 box[0] = tempfile.mkdtemp(prefix="fd_bench_index_", dir=best)
             if dist is not None:
-                dist.broadcast_object_list(box, src=0)
+                dist.broadcast_object_list(box, src=0, device=dev if dist.get_backend() == "nccl" else None)
             if box[0] is None:
                 on_disk = {"skipped": "no directory with %.1f GB free (tried %s)" % (1.25 * need / 1e9, ", ".join(cands))}
             else:

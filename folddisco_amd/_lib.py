@@ -136,6 +136,7 @@ SYMBOLS = [
     ("fdgpu_index_num_hashes", C.c_uint64, [VP]),
     ("fdgpu_index_value_len", C.c_uint64, [VP]),
     ("fdgpu_index_num_postings", C.c_uint64, [VP]),
+    ("fdgpu_index_num_structures", C.c_uint64, [VP]),
     ("fdgpu_index_save", C.c_int, [VP, VP, C.c_char_p]),
     ("fdgpu_posting_lengths", C.c_int, [VP, VP, u32p, C.c_uint64, u64p]),
     ("fdgpu_count_query", C.c_int, [VP, VP, u32p, u32p, u32p, f32p, C.c_uint64, f32p, C.POINTER(C.POINTER(CountRec)), u64p]),

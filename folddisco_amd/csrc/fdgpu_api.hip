@@ -658,6 +658,7 @@ extern "C" int fdgpu_index_set_first_id(fdgpu_index *ix, uint64_t first_id) { if
 extern "C" uint64_t fdgpu_index_num_hashes(const fdgpu_index *ix) { return ix ? ix->n_hashes : 0; }
 extern "C" uint64_t fdgpu_index_value_len(const fdgpu_index *ix) { return ix ? ix->value_len : 0; }
 extern "C" uint64_t fdgpu_index_num_postings(const fdgpu_index *ix) { return ix ? ix->n_postings : 0; }
+extern "C" uint64_t fdgpu_index_num_structures(const fdgpu_index *ix) { return ix ? ix->n_structures : 0; }
 
 // force32: 8-byte sort elements.  Returns FDGPU_RETRY_WIDE (internal) when the 6-byte form met a hash beyond 30 bits.
 #define FDGPU_RETRY_WIDE 1000

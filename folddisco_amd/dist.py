@@ -243,7 +243,7 @@ class Comm:
         o = np.zeros(4, np.uint64)
         p = [o[k:k + 1].ctypes.data_as(u64p) for k in range(4)]
         self.ctx.check(self.ctx.L.fdgpu_comm_single_index(self.ctx.h, self.h, local.h, C.byref(h), *p))
-        n_total = allreduce_sum(int(local.n_structures)) if self.world > 1 else int(local.n_structures)
+        n_total = int(self.ctx.L.fdgpu_index_num_structures(h))      # the merged pieces' id ranges: every structure of the database
         return FolddiscoIndex(self.ctx, h, n_total, 0), int(o[0]), int(o[1]), int(o[2]), int(o[3])
 
     def allreduce_lengths(self, lens: np.ndarray) -> np.ndarray:

@@ -149,6 +149,7 @@ void fdgpu_index_destroy(fdgpu_index *ix);
 uint64_t fdgpu_index_num_hashes(const fdgpu_index *ix);
 uint64_t fdgpu_index_value_len(const fdgpu_index *ix);
 uint64_t fdgpu_index_num_postings(const fdgpu_index *ix);
+uint64_t fdgpu_index_num_structures(const fdgpu_index *ix);   /* structures the index covers (ids first_id ...); a merged index: the sum over its parts */
 /* write PREFIX and PREFIX.offset byte-identically to save_offset_to_file (indextable.rs:297-326) */
 int fdgpu_index_save(fdgpu_ctx *ctx, const fdgpu_index *ix, const char *prefix);
 /* optional: make the page-locked staging slots of fdgpu_index_save / _save_part / _export now (256 MB, ~20 ms) — e.g. while the first chunk is still parsed */
