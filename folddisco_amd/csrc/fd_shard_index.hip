@@ -123,23 +123,21 @@ extern "C" int fdgpu_index_save_part(fdgpu_ctx *c, const fdgpu_index *part, cons
     const std::string p(prefix);
     const uint64_t H = part->n_hashes;
     std::atomic<int> io_err{0};
-    const int fv = open(p.c_str(), O_RDWR | O_CREAT, 0644);
-    const int fo = fv >= 0 ? open((p + ".offset").c_str(), O_RDWR | O_CREAT, 0644) : -1;
+    const int fv = open(p.c_str(), O_WRONLY | O_CREAT, 0644);
+    const int fo = fv >= 0 ? open((p + ".offset").c_str(), O_WRONLY | O_CREAT, 0644) : -1;
     if (fv < 0 || fo < 0) { if (fv >= 0) close(fv); FAIL(c, FDGPU_EINVAL, "index save: cannot write " + p); }
     if (ftruncate(fv, (off_t)total_value) != 0 || ftruncate(fo, (off_t)(8 + 4 * total_hashes + 8 * (total_hashes + 1))) != 0) io_err = errno ? errno : EIO;
-    fd_file_map mv(fv, total_value), mo(fo, 8 + 4 * total_hashes + 8 * (total_hashes + 1));      // (every rank maps the whole files and stores into its own regions)
     if (write_header && pwrite(fo, &total_hashes, 8, 0) != 8) io_err = errno ? errno : EIO;
-    hipError_t e = fd_d2h_to_file(c, fv, value_before, part->value, part->value_len, &io_err, mv.p);
-    if (e == hipSuccess) e = fd_d2h_to_file(c, fo, 8 + 4 * hashes_before, part->hashes, H * 4, &io_err, mo.p);
+    hipError_t e = fd_d2h_to_file(c, fv, value_before, part->value, part->value_len, &io_err);
+    if (e == hipSuccess) e = fd_d2h_to_file(c, fo, 8 + 4 * hashes_before, part->hashes, H * 4, &io_err);
     // offsets + value_before: re-based on the device into the sort workspace's first block, then streamed like the rest
     if (e == hipSuccess) e = c->ws[WS_MISC3].ensure((H + 1) * 8);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_si_rebase, dim3((unsigned)((H + 1 + 255) / 256)), dim3(256), 0, c->stream, part->offsets, H + 1, (uint64_t)0 - value_before, c->ws[WS_MISC3].as<uint64_t>());
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = fd_d2h_to_file(c, fo, 8 + 4 * total_hashes + 8 * hashes_before, c->ws[WS_MISC3].p, (H + (is_last ? 1 : 0)) * 8, &io_err, mo.p);
+    if (e == hipSuccess) e = fd_d2h_to_file(c, fo, 8 + 4 * total_hashes + 8 * hashes_before, c->ws[WS_MISC3].p, (H + (is_last ? 1 : 0)) * 8, &io_err);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    mv.close(); mo.close();
     if (close(fv) != 0 && !io_err) io_err = errno ? errno : EIO;
     if (close(fo) != 0 && !io_err) io_err = errno ? errno : EIO;
     if (e != hipSuccess) { c->err = std::string("index save part: ") + hipGetErrorString(e); return FDGPU_EHIP; }

@@ -1059,10 +1059,7 @@ extern "C" int fdgpu_index_merge(fdgpu_ctx *c, const fdgpu_index *const *parts, 
 // as many host threads pwrite() them straight from the pinned buffer into the file at their own offset — no host copy of the array, and the
 // page-cache copies of the chunks run in parallel (export-then-fwrite was one thread copying 976 MB twice: 0.33 of the CLI's 0.73 s at 20,500
 // structures).  io_err: first errno of a failed write.
-// map != nullptr: the file is mapped (MAP_SHARED, its final length set) and the drain threads memcpy into the mapping instead of calling pwrite —
-// write() takes the inode's lock exclusively, so sixteen threads writing one file ran at one thread's page-cache copy speed (~7 GB/s on tmpfs, 26 GB
-// in 3.9 s); stores through a shared mapping fault their pages in and copy in parallel.
-hipError_t fd_d2h_to_file(fdgpu_ctx *c, int fd, uint64_t file_off, const void *src, size_t bytes, std::atomic<int> *io_err, uint8_t *map) {
+hipError_t fd_d2h_to_file(fdgpu_ctx *c, int fd, uint64_t file_off, const void *src, size_t bytes, std::atomic<int> *io_err) {
     if (!bytes) return hipSuccess;
     for (int k = 0; k < FD_PIN_SLOTS; ++k) {
         hipError_t e = hipSuccess;
@@ -1086,7 +1083,6 @@ hipError_t fd_d2h_to_file(fdgpu_ctx *c, int fd, uint64_t file_off, const void *s
         drain[k] = std::thread([=]() {
             (void)hipSetDevice(dev);
             if (hipEventSynchronize(ev) != hipSuccess) { int z = 0; io_err->compare_exchange_strong(z, EIO); return; }
-            if (map) { memcpy(map + file_off + off, pin, n); return; }
             size_t done = 0;
             while (done < n) {
                 const ssize_t w = pwrite(fd, pin + done, n - done, (off_t)(file_off + off + done));
@@ -1118,11 +1114,9 @@ extern "C" int fdgpu_index_save(fdgpu_ctx *c, const fdgpu_index *ix, const char 
     const uint64_t H = ix->n_hashes;
     std::atomic<int> io_err{0};
     hipError_t e = hipSuccess;
-    const int fv = open(p.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
-    const int fo = fv >= 0 ? open((p + ".offset").c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644) : -1;
+    const int fv = open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    const int fo = fv >= 0 ? open((p + ".offset").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644) : -1;
     if (fv < 0 || fo < 0) { if (fv >= 0) close(fv); FAIL(c, FDGPU_EINVAL, "index save: cannot write " + p); }
-    const size_t len_v = ix->value_len, len_o = 8 + 4 * H + 8 * (H + 1);
-    fd_file_map mv(fv, len_v), mo(fo, len_o);
     if (pwrite(fo, &H, 8, 0) != 8) io_err = errno ? errno : EIO;
     const bool trace = getenv("FDGPU_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1131,12 +1125,11 @@ extern "C" int fdgpu_index_save(fdgpu_ctx *c, const fdgpu_index *ix, const char 
         for (int k = 0; k < FD_PIN_SLOTS && e == hipSuccess; ++k) if (!c->pin[k]) e = hipHostMalloc(&c->pin[k], FD_PIN_BYTES, hipHostMallocDefault);
         fprintf(stderr, "[index_save] staging slots page-locked at %.3f ms\n", ms());
     }
-    if (e == hipSuccess) e = fd_d2h_to_file(c, fv, 0, ix->value, ix->value_len, &io_err, mv.p);
-    if (trace) fprintf(stderr, "[index_save] %llu value bytes streamed at %.3f ms (%s)\n", (unsigned long long)ix->value_len, ms(), mv.p ? "mapped" : "pwrite");
-    if (e == hipSuccess) e = fd_d2h_to_file(c, fo, 8, ix->hashes, H * 4, &io_err, mo.p);
-    if (e == hipSuccess) e = fd_d2h_to_file(c, fo, 8 + H * 4, ix->offsets, (H + 1) * 8, &io_err, mo.p);
+    if (e == hipSuccess) e = fd_d2h_to_file(c, fv, 0, ix->value, ix->value_len, &io_err);
+    if (trace) fprintf(stderr, "[index_save] %llu value bytes streamed at %.3f ms\n", (unsigned long long)ix->value_len, ms());
+    if (e == hipSuccess) e = fd_d2h_to_file(c, fo, 8, ix->hashes, H * 4, &io_err);
+    if (e == hipSuccess) e = fd_d2h_to_file(c, fo, 8 + H * 4, ix->offsets, (H + 1) * 8, &io_err);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    mv.close(); mo.close();
     if (trace) fprintf(stderr, "[index_save] offset file streamed at %.3f ms\n", ms());
     if (close(fv) != 0 && !io_err) io_err = errno ? errno : EIO;
     if (close(fo) != 0 && !io_err) io_err = errno ? errno : EIO;

@@ -262,25 +262,7 @@ struct fd_rb_dev_out { bool got = false; const void *recs = nullptr; const int32
 int fd_retrieve_batch_dev(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const uint32_t *cand, const uint64_t *cand_off,
                           const fd_query_map *const *qms, const fdgpu_batch *qb, const uint32_t *q_struct, const fd_hash_params *p, float ca_distance_cutoff,
                           uint32_t node_count, uint32_t partial_fit, fd_match_rec **matches, uint64_t **match_off, int32_t **residues, uint64_t **res_off, fd_rb_dev_out *dev);
-hipError_t fd_d2h_to_file(fdgpu_ctx *c, int fd, uint64_t file_off, const void *src, size_t bytes, std::atomic<int> *io_err, uint8_t *map = nullptr);
-// a file's final length set and the file mapped for writing (p == nullptr: not possible here — the callers then pwrite); FDGPU_SAVE_MMAP=0 turns it off
-#include <sys/mman.h>
-#include <sys/statvfs.h>
-#include <unistd.h>
-struct fd_file_map {
-    uint8_t *p = nullptr; size_t len = 0;
-    fd_file_map(int fd, size_t bytes) {
-        static const bool on = [] { const char *e = getenv("FDGPU_SAVE_MMAP"); return !(e && e[0] == '0'); }();
-        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0 || !bytes || !on) return;
-        // a store into a mapping of a FULL file system is a SIGBUS, not an ENOSPC: map only where the blocks are plainly there (else pwrite reports the error)
-        struct statvfs vs;
-        if (fstatvfs(fd, &vs) != 0 || (unsigned long long)vs.f_bavail * vs.f_frsize < (unsigned long long)bytes + ((unsigned long long)256 << 20)) return;
-        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        if (m != MAP_FAILED) { p = (uint8_t *)m; len = bytes; }
-    }
-    void close() { if (p) (void)munmap(p, len); p = nullptr; }
-    ~fd_file_map() { close(); }
-};      // fdgpu_api.hip: device array -> file region through the pinned slots
+hipError_t fd_d2h_to_file(fdgpu_ctx *c, int fd, uint64_t file_off, const void *src, size_t bytes, std::atomic<int> *io_err);      // fdgpu_api.hip: device array -> file region through the pinned slots
 void *fd_out_alloc(size_t bytes, bool pinned = false);      // result arrays of the hot query paths: recycled blocks (fdgpu_api.hip); released with fdgpu_free like any other output
 
 // kernels / launchers implemented in the k_*.hip files
