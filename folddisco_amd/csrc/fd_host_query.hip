@@ -995,6 +995,7 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
     HIPCHK(c, c->ws[WS_RS_RES].ensure(cap_res * 4));
     HIPCHK(c, c->ws[WS_RS_KX].ensure(cap_pts * 12));
     HIPCHK(c, c->ws[WS_RS_KY].ensure(cap_pts * 12));
+    HIPCHK(c, c->ws[WS_RS_GQ].ensure(cap_pts * 4));      // gq | gr: one entry per residue pair (two points) each
     HIPCHK(c, c->ws[WS_RS_KOFF].ensure((cap_prob + 1) * 8 + cap_prob * 4));
     HIPCHK(c, c->ws[WS_RS_SOL].ensure(cap_prob * 18 * 4));
     HIPCHK(c, c->ws[WS_RS_CNT].ensure((2 * RS_CNT_STRIDE + 8) * 8));
@@ -1028,6 +1029,7 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
     A.counters = c->ws[WS_RS_CNT].as<unsigned long long>(); A.flags = (uint32_t *)(A.counters + 4);
     A.matches = c->ws[WS_RS_OUT].as<rs_match_dev>(); A.residues = c->ws[WS_RS_RES].as<int32_t>();
     A.kx = c->ws[WS_RS_KX].as<float>(); A.ky = c->ws[WS_RS_KY].as<float>();
+    A.gq = c->ws[WS_RS_GQ].as<uint32_t>(); A.gr = A.gq + cap_pts / 2;
     A.koff = c->ws[WS_RS_KOFF].as<uint64_t>(); A.d0 = (float *)(A.koff + cap_prob + 1);
     A.cap_matches = cap_m; A.cap_res = cap_res; A.cap_prob = cap_prob; A.cap_pts = cap_pts;
     {
@@ -1076,6 +1078,7 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
             if (e == hipSuccess) e = c->ws[WS_RS_RECRES].ensure(std::max<uint64_t>(tot_res, 1) * 4);
             if (e == hipSuccess && nprob) {
                 e = hipMemcpyAsync(A.koff + nprob, &npts, 8, hipMemcpyHostToDevice, st);
+                fd_launch_rs_points(A, npts, st);
                 fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd0, d_rot0, d_tran0, st);
                 fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot0, d_tran0, A.d0, d_met0, st);
             }
@@ -1106,6 +1109,7 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
         float *d_rmsd = c->ws[WS_RS_SOL].as<float>(), *d_rot = d_rmsd + nprob, *d_tran = d_rot + 9 * nprob, *d_met = d_tran + 3 * nprob;
         if (nprob) {
             HIPCHK(c, hipMemcpyAsync(A.koff + nprob, &npts, 8, hipMemcpyHostToDevice, st));
+            fd_launch_rs_points(A, npts, st);
             fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd, d_rot, d_tran, st);
             fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot, d_tran, A.d0, d_met, st);
             HIPCHK(c, hipGetLastError());

@@ -92,7 +92,7 @@ enum {
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
     WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS, WS_QT_STREAM, WS_QT_STAB,
     WS_CA_PERM, WS_OK_PERM, WS_AA_PERM, WS_SEG_TAB,
-    WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT,
+    WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT, WS_RS_GQ,
     WS_COUNT
 };
 
@@ -492,11 +492,14 @@ struct rs_args {
                                                          // on one cache line the three returning atomics of 10^4 records queued behind each other (27 us per slot)
     uint32_t *flags;                                     // bit 0: a slot beyond the kernel's limits, bit 1: an output buffer too small
     rs_match_dev *matches; int32_t *residues; float *kx, *ky; uint64_t *koff; float *d0;
+    uint32_t *gq, *gr;                                   // per residue pair of a superposition problem (= two points, [CA, CB]): query / target residue, absolute in qb / db —
+                                                         // k_rs_points gathers the coordinates into kx / ky afterwards, with every pair its own thread (a slot is one serial wavefront)
     uint64_t cap_matches, cap_res, cap_prob, cap_pts;
 };
 void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec *cands, uint64_t nc, uint32_t n_cand, uint32_t *cnt, uint32_t *seg, uint32_t *cur,
                         uint32_t *perm_f, uint32_t *perm_c, hipStream_t st);
 void fd_launch_rs_slots(const rs_args &A, uint32_t n_cand, hipStream_t st);
+void fd_launch_rs_points(const rs_args &A, uint64_t n_points, hipStream_t st);      // the [CA, CB] point lists of the problems k_rs_slots described (before k_superpose / k_metrics)
 void fd_launch_rs_records(const void *matches, const void *plan, uint64_t n, const float *rmsd, const float *rot, const float *tran, const float *met,
                           const int32_t *residues, void *out, int32_t *out_res, hipStream_t st);
 // the same with the order made on the device: slot_matches -> per-slot bases, per-query offsets (match_off / res_off, n_queries + 1 each) -> every

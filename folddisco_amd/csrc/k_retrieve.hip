@@ -255,8 +255,6 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
         s_cs[rank] = a;
     }
     RS_SYNC();
-    const float *q_ca = A.q_ca + 3ull * Q.q_res0, *q_cb = A.q_cb + 3ull * Q.q_res0;
-    const float *t_ca = A.db_ca + 3ull * r0, *t_cb = A.db_cb + 3ull * r0;
     stamp(4);
     // every component writes exactly one record: the slot claims its records and residue ints with ONE returning atomic each, here, long before
     // their values are needed (the per-record claims of 10^4 records on one cache line were two thirds of the output phase)
@@ -439,11 +437,11 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
             const uint32_t n = w ? n_sc : n_asg;
             const uint64_t base = pt0 + (w ? 2ull * n_asg : 0ull);
             if (lane < n) {
+                // which residues the problem's points are: the coordinates themselves are gathered by k_rs_points — 12 random 4-byte loads per pair from the
+                // 7 GB coordinate arrays were 29 of a slot's 78 us when this wavefront made them, one dependent round per problem
                 const uint32_t q = w ? s_qs[lane] : s_aq[lane], r = w ? s_rs[lane] : s_ar[lane];
-                for (int z = 0; z < 3; ++z) {
-                    A.ky[3 * (base + 2 * lane) + z] = q_ca[3 * q + z]; A.ky[3 * (base + 2 * lane + 1) + z] = q_cb[3 * q + z];
-                    A.kx[3 * (base + 2 * lane) + z] = t_ca[3 * r + z]; A.kx[3 * (base + 2 * lane + 1) + z] = t_cb[3 * r + z];
-                }
+                A.gq[(base >> 1) + lane] = Q.q_res0 + q;
+                A.gr[(base >> 1) + lane] = r0 + r;
             }
         }
         ++n_emit;
@@ -464,6 +462,24 @@ void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec
     if (n) hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, found, nf, cands, nc, n_cand, cur, perm_f, perm_c);
     // the cursors are spent: their array takes the slots' launch order (rs_args.order = cur)
     if (n_cand) hipLaunchKernelGGL(k_rs_order, dim3(1), dim3(1024), 0, st, cnt, n_cand, cur);
+}
+
+// one thread per residue pair of the superposition problems: its two points [CA, CB] of the target (kx) and of the query (ky)
+__global__ __launch_bounds__(256) void k_rs_points(const uint32_t *__restrict__ gq, const uint32_t *__restrict__ gr, uint64_t n_pairs, const float *__restrict__ db_ca,
+                                                   const float *__restrict__ db_cb, const float *__restrict__ q_ca, const float *__restrict__ q_cb, float *__restrict__ kx,
+                                                   float *__restrict__ ky) {
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_pairs) return;
+    const uint64_t q = gq[k], r = gr[k];
+    float a[6], b[6];
+#pragma unroll
+    for (int z = 0; z < 3; ++z) { a[z] = db_ca[3 * r + z]; a[3 + z] = db_cb[3 * r + z]; b[z] = q_ca[3 * q + z]; b[3 + z] = q_cb[3 * q + z]; }
+#pragma unroll
+    for (int z = 0; z < 6; ++z) { kx[6 * k + z] = a[z]; ky[6 * k + z] = b[z]; }
+}
+void fd_launch_rs_points(const rs_args &A, uint64_t n_points, hipStream_t st) {
+    const uint64_t n_pairs = n_points / 2;
+    if (n_pairs) hipLaunchKernelGGL(k_rs_points, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, A.gq, A.gr, n_pairs, A.db_ca, A.db_cb, A.q_ca, A.q_cb, A.kx, A.ky);
 }
 
 void fd_launch_rs_slots(const rs_args &A, uint32_t n_cand, hipStream_t st) {
