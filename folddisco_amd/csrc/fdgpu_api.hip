@@ -2314,6 +2314,10 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     A.iv_grp = want_iv ? dblk + o_iv1 : nullptr;
     A.qtab = (const mp_query_dev *)(dblk + o_qt);
     A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.found = nullptr; A.cands = nullptr;
+    const bool mp_dbg = getenv("FDGPU_MP_DBG") != nullptr;       // per-phase clocks of the pair scan's work items on stderr (measurement aid)
+    if (mp_dbg) HIPCHK(c, c->ws[WS_TOTAL].ensure(128));
+    A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1;
+    A.dbg = mp_dbg ? A.n_found + 2 : nullptr;
     // one emitting pass into buffers sized by the previous calls; a pass that overflows only counts, the buffers grow and
     // the pass is repeated (the scan is deterministic up to record order, which is restored below)
     uint64_t tot[2] = {0, 0};
@@ -2323,10 +2327,19 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         if (capc < 4096 || capc < tot[1]) { HIPCHK(c, c->ws[WS_KEYS_B].ensure(std::max<uint64_t>(2 * tot[1], 65536) * sizeof(fd_cand_rec))); }
         A.found = c->ws[WS_KEYS_A].as<fd_pair_rec>(); A.cands = c->ws[WS_KEYS_B].as<fd_cand_rec>();
         A.cap_found = c->ws[WS_KEYS_A].cap / sizeof(fd_pair_rec); A.cap_cands = c->ws[WS_KEYS_B].cap / sizeof(fd_cand_rec);
-        HIPCHK(c, hipMemsetAsync(c->ws[WS_TOTAL].p, 0, 16, st));
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_TOTAL].p, 0, mp_dbg ? 128 : 16, st));
         {
             StageTimer t(c, "match_pairs", 0);
             fd_launch_match_pairs(A, true, st);
+        }
+        if (mp_dbg) {
+            unsigned long long d[8];
+            if (hipMemcpyAsync(d, A.dbg, 64, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+                const double live = (double)std::max<unsigned long long>(d[0], 1), us = 0.01;      // 100 MHz ticks
+                fprintf(stderr, "[mp] %llu work items: %llu live (compaction %.2f, staging %.2f, scan + drains %.2f us each; %.2f drains per item, %.2f us per drain), %llu early exits (%.2f us each)\n",
+                        (unsigned long long)nw, d[0], d[1] * us / live, d[2] * us / live, d[3] * us / live, (double)d[4] / live, d[4] ? d[5] * us / (double)d[4] : 0.0, d[6],
+                        d[6] ? d[7] * us / (double)d[6] : 0.0);
+            }
         }
         HIPCHK(c, hipGetLastError());
         if (attempt == 0 && while_scanning && *while_scanning) (*while_scanning)();      // before the copy: one into pageable memory waits for the stream

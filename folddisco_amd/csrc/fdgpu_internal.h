@@ -406,6 +406,7 @@ struct mp_args {
     const uint32_t *iv_grp;                       // with iv_start: [1024 * query] (group's first interval - query's first) << 8 | min(count, 255): the scan's LDS copy
     float ca_window;
     unsigned long long *n_found, *n_cands;
+    unsigned long long *dbg;       // FDGPU_MP_DBG: [8] live items, their compaction / staging / scan ticks, drains, drain ticks, early exits, their ticks; else null
     fd_pair_rec *found; fd_cand_rec *cands;
     unsigned long long cap_found, cap_cands;   // records the buffers hold (EMIT counts beyond them without writing)
     uint32_t n_cfg;                // --multiple-bins: bin pairs to hash every surviving pair with (1 = the single configuration in C)

@@ -159,6 +159,7 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
 }
 
 #define MP_AAD_LDS 1024
+#define MP_SCAN_BLOCKS 64      /* blocks of 64 residues whose activity masks a work item keeps in LDS (longer structures: the two-walk form) */
 template <bool EMIT>
 __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     // many queries per launch: this work item's query selects its slice of the concatenated tables (wave-uniform loads).  The
@@ -187,47 +188,86 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     __shared__ uint32_t s_start[1025];
     const uint32_t w = blockIdx.x;
     if (w >= A.n_work) return;
+    const unsigned long long tk0 = A.dbg ? wall_clock64() : 0ull;
+    unsigned long long tk_dr = 0, n_dr = 0;
     const uint32_t slot = A.wi_cand[w];
     const uint32_t s = A.cand[slot];
     const uint32_t r0 = A.B.res_off[s], r1 = A.B.res_off[s + 1];
     const uint32_t lane = threadIdx.x;
     const bool tert = A.C.q.type == FD_HASH_TERTIARY;     // TertiaryInteraction needs no CB (feature.rs:113-160)
-    // prefilter sets (retrieve.rs:563-602); an empty set on either side switches to the full scan
-    bool full = true;
-    if (Sx.use_prefilter) {
-        uint64_t any1 = 0, any2 = 0;
-        for (uint32_t r = r0 + lane; r < r1 + lane; r += FD_WAVE) {
-            bool in = r < r1;
-            uint32_t a = in ? A.B.aa[r] : 255u;
-            bool stdn = in && a < 20u && (A.resname_std == nullptr || A.resname_std[r]);
-            any1 |= __ballot(stdn && ((Sx.aa1_mask >> a) & 1u));
-            any2 |= __ballot(stdn && ((Sx.aa2_mask >> a) & 1u));
-        }
-        full = !(any1 && any2);
-    }
-    // The i side is COMPACTED: a motif query names ~4 residue types, so only ~1 residue in 5 of a candidate can be the first residue of a pair
-    // (prefilter set, standard name, hashable — get_single_feature, controller/feature.rs:11-24, 84-99, rejects the rest).  With lane = residue of
-    // a 64-residue tile four lanes in five idled through the partner loop and a candidate's few passing pairs were spread over all its tiles'
-    // mostly empty drains.  Now lane = the (64 t + lane)-th ACTIVE residue of the candidate (t = the work item's tile number, from wi_i0 as before:
-    // the host still plans one item per 64 residues, the items beyond the last active tile return at once), found by one walk over the residue
-    // types: ballot + popcount rank, the tile's residues scattered into LDS.  Pair order inside a candidate changes; the records are grouped and
-    // ranked by (slot, i, j) downstream, as they were when several work items appended concurrently.
+    // prefilter sets (retrieve.rs:563-602); an empty set on either side switches to the full scan.  ONE walk over the candidate's residue types answers both
+    // that and which residues are active: eight blocks of 64 residues are requested together (a block's ballots depend on its loads — one block at a
+    // time the walk was six dependent L2 round trips per pass, 30 us per work item, and the work items that only find out that they have nothing to do
+    // paid them too), the blocks' ballots go to LDS, and the ranks of the active residues follow from the masks alone.
+    __shared__ unsigned long long s_mf[MP_SCAN_BLOCKS], s_mp[MP_SCAN_BLOCKS];      // per block: hashable residues / those that are also in the first-residue set
     __shared__ uint32_t s_sel[FD_WAVE];
     const uint32_t t_sel = (A.wi_i0[w] - r0) >> 6;
+    const uint32_t n_blk = (r1 - r0 + FD_WAVE - 1) / FD_WAVE;
+    bool full = true;
     uint32_t n_act = 0;
-    for (uint32_t rb = r0; rb < r1; rb += FD_WAVE) {
-        const uint32_t r = rb + lane;
-        const bool in = r < r1;
-        const uint32_t a = in ? A.B.aa[r] : 255u;
-        const bool stdn = in && a < 20u && (A.resname_std == nullptr || A.resname_std[r]);
-        const bool ac = in && (full || (stdn && ((Sx.aa1_mask >> a) & 1u))) && a != 255u && (tert || A.B.hash_ok[r]);
-        const uint64_t m = __ballot(ac);
-        const uint32_t rank = n_act + fd_mbcnt(m);
-        if (ac && (rank >> 6) == t_sel) s_sel[rank & 63u] = r;
-        n_act += (uint32_t)__popcll(m);
-        if (n_act >= 64u * (t_sel + 1u)) break;
+    if (n_blk <= MP_SCAN_BLOCKS) {
+        uint64_t any1 = 0, any2 = 0;
+        for (uint32_t b0 = 0; b0 < n_blk; b0 += 8) {
+            uint32_t aa8[8], ok8[8], sd8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t r = r0 + (b0 + u) * FD_WAVE + lane;
+                const bool in = r < r1;
+                aa8[u] = in ? A.B.aa[r] : 255u;
+                ok8[u] = in ? (tert ? 1u : (uint32_t)A.B.hash_ok[r]) : 0u;
+                sd8[u] = in ? (A.resname_std == nullptr ? 1u : (uint32_t)A.resname_std[r]) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (b0 + u < n_blk) {      // wave-uniform
+                    const uint32_t a = aa8[u];
+                    const bool stdn = a < 20u && sd8[u];
+                    const bool in1 = stdn && ((Sx.aa1_mask >> a) & 1u), in2 = stdn && ((Sx.aa2_mask >> a) & 1u), base = a != 255u && ok8[u];
+                    any1 |= __ballot(in1); any2 |= __ballot(in2);
+                    const uint64_t mf = __ballot(base), mp = __ballot(base && in1);
+                    if (lane == 0) { s_mf[b0 + u] = mf; s_mp[b0 + u] = mp; }
+                }
+            }
+        }
+        full = !Sx.use_prefilter || !(any1 && any2);
+        fd_wave_lds_fence();
+        for (uint32_t b = 0; b < n_blk; ++b) {
+            const uint64_t m = full ? s_mf[b] : s_mp[b];
+            const uint32_t rank = n_act + fd_mbcnt(m);
+            if (((m >> lane) & 1ull) && (rank >> 6) == t_sel) s_sel[rank & 63u] = r0 + b * FD_WAVE + lane;
+            n_act += (uint32_t)__popcll(m);
+            if (n_act >= 64u * (t_sel + 1u)) break;
+        }
+    } else {      // a structure of more than MP_SCAN_BLOCKS x 64 residues: two walks, a block at a time
+        if (Sx.use_prefilter) {
+            uint64_t any1 = 0, any2 = 0;
+            for (uint32_t r = r0 + lane; r < r1 + lane; r += FD_WAVE) {
+                bool in = r < r1;
+                uint32_t a = in ? A.B.aa[r] : 255u;
+                bool stdn = in && a < 20u && (A.resname_std == nullptr || A.resname_std[r]);
+                any1 |= __ballot(stdn && ((Sx.aa1_mask >> a) & 1u));
+                any2 |= __ballot(stdn && ((Sx.aa2_mask >> a) & 1u));
+            }
+            full = !(any1 && any2);
+        }
+        for (uint32_t rb = r0; rb < r1; rb += FD_WAVE) {
+            const uint32_t r = rb + lane;
+            const bool in = r < r1;
+            const uint32_t a = in ? A.B.aa[r] : 255u;
+            const bool stdn = in && a < 20u && (A.resname_std == nullptr || A.resname_std[r]);
+            const bool ac = in && (full || (stdn && ((Sx.aa1_mask >> a) & 1u))) && a != 255u && (tert || A.B.hash_ok[r]);
+            const uint64_t m = __ballot(ac);
+            const uint32_t rank = n_act + fd_mbcnt(m);
+            if (ac && (rank >> 6) == t_sel) s_sel[rank & 63u] = r;
+            n_act += (uint32_t)__popcll(m);
+            if (n_act >= 64u * (t_sel + 1u)) break;
+        }
     }
-    if (n_act <= 64u * t_sel) return;      // (wave-uniform) nothing left for this tile: before any table is staged
+    if (n_act <= 64u * t_sel) {             // (wave-uniform) nothing left for this tile: before any table is staged
+        if (A.dbg && threadIdx.x == 0) { atomicAdd(&A.dbg[6], 1ull); atomicAdd(&A.dbg[7], wall_clock64() - tk0); }
+        return;
+    }
+    const unsigned long long tk1 = A.dbg ? wall_clock64() : 0ull;
     const uint32_t n_here = n_act - 64u * t_sel < FD_WAVE ? n_act - 64u * t_sel : FD_WAVE;
     // the query's observed (aa_i, aa_j) -> CA distance lists (aa_dist_map, controller/query.rs), grouped by residue-type pair:
     // aad_start[aa_i * 32 + aa_j] .. [+1] indexes the distance / query-residue arrays (host-sorted, stable).  Start table and,
@@ -253,6 +293,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
         for (uint32_t e = threadIdx.x; e < n_iv && e < 1024u; e += FD_WAVE) reinterpret_cast<float2 *>(s_d_buf)[e] = Sx.iv[iv_base + e];
     }
     __syncthreads();
+    const unsigned long long tk2 = A.dbg ? wall_clock64() : 0ull;
     const float *dist_tab = staged ? s_d_buf : Sx.aad_dist;
     const uint32_t *st_tab = big ? Sx.aad_start : s_start;
     const bool act = lane < n_here;
@@ -337,7 +378,9 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
             while (qn >= FD_WAVE) {      // (wave-scope fences: one wavefront per workgroup, the queue is LDS — no wait for the drain's record stores)
                 fd_wave_lds_fence();
                 qn -= FD_WAVE;
+                const unsigned long long td = A.dbg ? wall_clock64() : 0ull;
                 match_drain<EMIT>(A, Sx, q + qn, FD_WAVE, slot, r0, r1, st_tab, dist_tab, tab);
+                if (A.dbg) { tk_dr += wall_clock64() - td; ++n_dr; }
                 fd_wave_lds_fence();
             }
         }
@@ -345,9 +388,16 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
             fd_wave_lds_fence();
             const uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
             qn -= n;
+            const unsigned long long td = A.dbg ? wall_clock64() : 0ull;
             match_drain<EMIT>(A, Sx, q + qn, n, slot, r0, r1, st_tab, dist_tab, tab);
+            if (A.dbg) { tk_dr += wall_clock64() - td; ++n_dr; }
             fd_wave_lds_fence();
         }
+    }
+    if (A.dbg && threadIdx.x == 0) {
+        const unsigned long long t3 = wall_clock64();
+        atomicAdd(&A.dbg[0], 1ull); atomicAdd(&A.dbg[1], tk1 - tk0); atomicAdd(&A.dbg[2], tk2 - tk1); atomicAdd(&A.dbg[3], t3 - tk2);
+        atomicAdd(&A.dbg[4], n_dr); atomicAdd(&A.dbg[5], tk_dr);
     }
 }
 
