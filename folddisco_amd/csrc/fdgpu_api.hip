@@ -2251,20 +2251,28 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     if (mp_trace) fprintf(stderr, "[match_pairs] tables at %.3f ms (%zu work items)\n", mp_ms(), nw);
     HIPCHK(c, c->ws[WS_MISC0].ensure(words * 4));
     HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
-    if (TB.dev_items) {       // the item arrays [o_wc, o_h) are not sent: the device writes them
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, TB.data, o_wc * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].as<uint32_t>() + o_h, TB.data + o_h, (words - o_h) * 4, hipMemcpyHostToDevice, st));
-        uint32_t *d = c->ws[WS_MISC0].as<uint32_t>();
-        fd_launch_mp_items(db->res_off, d + o_cand, (uint32_t)n_cand, d + TB.o_wb, d + TB.o_wb + ((n_cand + 1 + 3) & ~(size_t)3), j_span, d + o_wc, d + o_wi, d + o_wq, d + o_wj, st);
-    } else
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, TB.data, words * 4, hipMemcpyHostToDevice, st));
-    const uint32_t *dblk = c->ws[WS_MISC0].as<uint32_t>();
     uint8_t *d_std = nullptr;
     if (resname_std) {
         HIPCHK(c, c->ws[WS_MISC5].ensure(std::max<uint64_t>(db->n_res, 1)));
         HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, resname_std, db->n_res, hipMemcpyHostToDevice, st));
         d_std = c->ws[WS_MISC5].as<uint8_t>();
     }
+    const uint4 *d_cinfo = nullptr;
+    const uint32_t *d_act = nullptr;
+    if (TB.dev_items) {       // the item arrays [o_wc, o_h) are not sent: the device writes them — and, per candidate, the list of its active residues
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, TB.data, o_wc * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].as<uint32_t>() + o_h, TB.data + o_h, (words - o_h) * 4, hipMemcpyHostToDevice, st));
+        uint32_t *d = c->ws[WS_MISC0].as<uint32_t>();
+        const size_t ci_bytes = ((size_t)n_cand * 16 + 255) & ~(size_t)255;
+        HIPCHK(c, c->ws[WS_MP_ACT].ensure(ci_bytes + (size_t)64 * std::max<size_t>(nw, 1) * 4));
+        d_cinfo = c->ws[WS_MP_ACT].as<uint4>();
+        d_act = (const uint32_t *)(c->ws[WS_MP_ACT].as<uint8_t>() + ci_bytes);
+        fd_launch_mp_items(db->res_off, d + o_cand, (uint32_t)n_cand, d + TB.o_wb, d + TB.o_wb + ((n_cand + 1 + 3) & ~(size_t)3), j_span, d + o_wc, d + o_wi, d + o_wq, d + o_wj, st,
+                           db->aa, db->hash_ok, d_std, fd_make_consts_cfg(p, 0).q.type == FD_HASH_TERTIARY ? 1 : 0, (const mp_query_dev *)(d + o_qt), (void *)d_cinfo,
+                           (uint32_t *)d_act);
+    } else
+    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, TB.data, words * 4, hipMemcpyHostToDevice, st));
+    const uint32_t *dblk = c->ws[WS_MISC0].as<uint32_t>();
     mp_args A;
     memset(&A, 0, sizeof A);
     A.mode = mode;
@@ -2318,6 +2326,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     if (mp_dbg) HIPCHK(c, c->ws[WS_TOTAL].ensure(128));
     A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1;
     A.dbg = mp_dbg ? A.n_found + 2 : nullptr;
+    A.cinfo = d_cinfo; A.act = d_act;
     // one emitting pass into buffers sized by the previous calls; a pass that overflows only counts, the buffers grow and
     // the pass is repeated (the scan is deterministic up to record order, which is restored below)
     uint64_t tot[2] = {0, 0};

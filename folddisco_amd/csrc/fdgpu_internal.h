@@ -92,7 +92,7 @@ enum {
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
     WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS, WS_QT_STREAM, WS_QT_STAB,
     WS_CA_PERM, WS_OK_PERM, WS_AA_PERM, WS_SEG_TAB,
-    WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT, WS_RS_GQ,
+    WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT, WS_RS_GQ, WS_MP_ACT,
     WS_COUNT
 };
 
@@ -406,6 +406,7 @@ struct mp_args {
     const uint32_t *iv_grp;                       // with iv_start: [1024 * query] (group's first interval - query's first) << 8 | min(count, 255): the scan's LDS copy
     float ca_window;
     unsigned long long *n_found, *n_cands;
+    const uint4 *cinfo; const uint32_t *act;      // optional (items written on the device): per candidate {first residue, end, active residues | full << 31, first list entry}, the lists
     unsigned long long *dbg;       // FDGPU_MP_DBG: [8] live items, their compaction / staging / scan ticks, drains, drain ticks, early exits, their ticks; else null
     fd_pair_rec *found; fd_cand_rec *cands;
     unsigned long long cap_found, cap_cands;   // records the buffers hold (EMIT counts beyond them without writing)
@@ -430,7 +431,8 @@ struct fd_mp_tables {
 };
 // work items of the pair scan: candidate k (structure cand[k], first item wbase[k], query cq[k]) -> one item per (64-residue tile, span of j_span partners)
 void fd_launch_mp_items(const uint32_t *db_res_off, const uint32_t *cand, uint32_t n_cand, const uint32_t *wbase, const uint32_t *cq, uint32_t j_span, uint32_t *wc,
-                        uint32_t *wi, uint32_t *wq, uint32_t *wj, hipStream_t st);
+                        uint32_t *wi, uint32_t *wq, uint32_t *wj, hipStream_t st, const uint8_t *aa, const uint8_t *hash_ok, const uint8_t *resname_std, int tert,
+                        const struct mp_query_dev *qtab, void *cinfo /* uint4 [n_cand] or null */, uint32_t *act /* [64 x items] */);
 struct fd_vote_row { uint32_t mx, nmx, arg; };
 struct fd_vote_plan {
     const uint8_t *cj_comp; uint64_t n_bits;

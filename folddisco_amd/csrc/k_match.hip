@@ -191,20 +191,27 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     const unsigned long long tk0 = A.dbg ? wall_clock64() : 0ull;
     unsigned long long tk_dr = 0, n_dr = 0;
     const uint32_t slot = A.wi_cand[w];
-    const uint32_t s = A.cand[slot];
-    const uint32_t r0 = A.B.res_off[s], r1 = A.B.res_off[s + 1];
     const uint32_t lane = threadIdx.x;
     const bool tert = A.C.q.type == FD_HASH_TERTIARY;     // TertiaryInteraction needs no CB (feature.rs:113-160)
+    __shared__ uint32_t s_sel[FD_WAVE];
+    uint32_t r0, r1, n_act = 0, t_sel;
+    bool full = true;
+    if (A.cinfo) {
+        // the candidate's active residues were listed once, by k_mp_items: this item's 64 are one coalesced load
+        const uint4 ci = A.cinfo[slot];
+        r0 = ci.x; r1 = ci.y; n_act = ci.z & 0x7fffffffu; full = (ci.z >> 31) != 0u;
+        t_sel = (A.wi_i0[w] - r0) >> 6;
+        if (n_act > 64u * t_sel && 64u * t_sel + lane < n_act) s_sel[lane] = A.act[ci.w + 64u * t_sel + lane];
+    } else {
+    const uint32_t s = A.cand[slot];
+    r0 = A.B.res_off[s]; r1 = A.B.res_off[s + 1];
     // prefilter sets (retrieve.rs:563-602); an empty set on either side switches to the full scan.  ONE walk over the candidate's residue types answers both
     // that and which residues are active: eight blocks of 64 residues are requested together (a block's ballots depend on its loads — one block at a
     // time the walk was six dependent L2 round trips per pass, 30 us per work item, and the work items that only find out that they have nothing to do
     // paid them too), the blocks' ballots go to LDS, and the ranks of the active residues follow from the masks alone.
     __shared__ unsigned long long s_mf[MP_SCAN_BLOCKS], s_mp[MP_SCAN_BLOCKS];      // per block: hashable residues / those that are also in the first-residue set
-    __shared__ uint32_t s_sel[FD_WAVE];
-    const uint32_t t_sel = (A.wi_i0[w] - r0) >> 6;
+    t_sel = (A.wi_i0[w] - r0) >> 6;
     const uint32_t n_blk = (r1 - r0 + FD_WAVE - 1) / FD_WAVE;
-    bool full = true;
-    uint32_t n_act = 0;
     if (n_blk <= MP_SCAN_BLOCKS) {
         uint64_t any1 = 0, any2 = 0;
         for (uint32_t b0 = 0; b0 < n_blk; b0 += 8) {
@@ -262,6 +269,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
             n_act += (uint32_t)__popcll(m);
             if (n_act >= 64u * (t_sel + 1u)) break;
         }
+    }
     }
     if (n_act <= 64u * t_sel) {             // (wave-uniform) nothing left for this tile: before any table is staged
         if (A.dbg && threadIdx.x == 0) { atomicAdd(&A.dbg[6], 1ull); atomicAdd(&A.dbg[7], wall_clock64() - tk0); }
@@ -460,22 +468,76 @@ void fd_launch_found_gather(const fd_pair_rec *f, const uint32_t *val, uint64_t 
 }
 // The scan's work items, written where they are read: one wavefront per candidate, an item per (64-residue tile i, span of j_span partner
 // residues) in the order the host loop made them (tiles outer, spans inner).  j_span = 0: one span = the whole structure.
+// Also here, once per CANDIDATE instead of once per work item: which of its residues can be the first residue of a pair at all (prefilter_amino_acid,
+// retrieve.rs:563-602: type in the query's first-residue set, standard name — or every hashable residue when a set is empty / the prefilter is off),
+// compacted into act[64 * first item ...], and cinfo[k] = {first residue, end, active residues | full << 31, first entry of its list}.  A work item then
+// reads its 64 residues with one coalesced load, and the items beyond a candidate's last active tile return after two loads.
 __global__ __launch_bounds__(256) void k_mp_items(const uint32_t *__restrict__ db_res_off, const uint32_t *__restrict__ cand, uint32_t n_cand,
                                                   const uint32_t *__restrict__ wbase, const uint32_t *__restrict__ cq, uint32_t j_span, uint32_t *__restrict__ wc,
-                                                  uint32_t *__restrict__ wi, uint32_t *__restrict__ wq, uint32_t *__restrict__ wj) {
+                                                  uint32_t *__restrict__ wi, uint32_t *__restrict__ wq, uint32_t *__restrict__ wj, const uint8_t *__restrict__ aa,
+                                                  const uint8_t *__restrict__ hash_ok, const uint8_t *__restrict__ resname_std, int tert,
+                                                  const mp_query_dev *__restrict__ qtab, uint4 *__restrict__ cinfo, uint32_t *__restrict__ act) {
     const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (k >= n_cand) return;
-    const uint32_t s = cand[k], r0 = db_res_off[s], len = db_res_off[s + 1] - r0;
+    const uint32_t s = cand[k], r0 = db_res_off[s], r1 = db_res_off[s + 1], len = r1 - r0;
     const uint32_t base = wbase[k], n = wbase[k + 1] - base, q = cq[k];
     const uint32_t spans = j_span ? (len + j_span - 1u) / j_span : (len ? 1u : 0u);
     for (uint32_t x = lane; x < n; x += 64u) {
         const uint32_t ti = x / spans, sj = x - ti * spans;
         wc[base + x] = k; wi[base + x] = r0 + ti * FD_WAVE; wq[base + x] = q; wj[base + x] = r0 + sj * j_span;
     }
+    if (!cinfo) return;
+    const mp_query_dev Q = qtab[q];
+    const uint32_t n_blk = (len + FD_WAVE - 1u) / FD_WAVE;
+    uint32_t *list = act + 64ull * base;
+    uint64_t any1 = 0, any2 = 0;
+    uint32_t n_full = 0, n_pref = 0;      // both lists are written (the prefiltered one behind the full one's worst case is not known yet): decide afterwards
+    // pass 1: is either prefilter set empty?  (eight blocks of residue types requested together)
+    if (Q.use_prefilter)
+        for (uint32_t b0 = 0; b0 < n_blk; b0 += 8) {
+            uint32_t a8[8], s8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t r = r0 + (b0 + u) * FD_WAVE + lane;
+                a8[u] = r < r1 ? aa[r] : 255u;
+                s8[u] = r < r1 ? (resname_std ? (uint32_t)resname_std[r] : 1u) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool stdn = a8[u] < 20u && s8[u];
+                any1 |= __ballot(stdn && ((Q.aa1_mask >> a8[u]) & 1u));
+                any2 |= __ballot(stdn && ((Q.aa2_mask >> a8[u]) & 1u));
+            }
+        }
+    const bool full = !Q.use_prefilter || !(any1 && any2);
+    (void)n_full; (void)n_pref;
+    uint32_t n_act = 0;
+    for (uint32_t b0 = 0; b0 < n_blk; b0 += 8) {
+        uint32_t a8[8], o8[8], s8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t r = r0 + (b0 + u) * FD_WAVE + lane;
+            const bool in = r < r1;
+            a8[u] = in ? aa[r] : 255u;
+            o8[u] = in ? (tert ? 1u : (uint32_t)hash_ok[r]) : 0u;
+            s8[u] = in ? (resname_std ? (uint32_t)resname_std[r] : 1u) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t a = a8[u];
+            const bool ac = a != 255u && o8[u] && (full || (a < 20u && s8[u] && ((Q.aa1_mask >> a) & 1u)));
+            const uint64_t m = __ballot(ac);
+            if (ac) list[n_act + fd_mbcnt(m)] = r0 + (b0 + u) * FD_WAVE + lane;
+            n_act += (uint32_t)__popcll(m);
+        }
+    }
+    if (lane == 0) cinfo[k] = make_uint4(r0, r1, n_act | (full ? 0x80000000u : 0u), 64u * base);
 }
 void fd_launch_mp_items(const uint32_t *db_res_off, const uint32_t *cand, uint32_t n_cand, const uint32_t *wbase, const uint32_t *cq, uint32_t j_span, uint32_t *wc,
-                        uint32_t *wi, uint32_t *wq, uint32_t *wj, hipStream_t st) {
-    if (n_cand) hipLaunchKernelGGL(k_mp_items, dim3((n_cand + 3u) / 4u), dim3(256), 0, st, db_res_off, cand, n_cand, wbase, cq, j_span, wc, wi, wq, wj);
+                        uint32_t *wi, uint32_t *wq, uint32_t *wj, hipStream_t st, const uint8_t *aa, const uint8_t *hash_ok, const uint8_t *resname_std, int tert,
+                        const mp_query_dev *qtab, void *cinfo, uint32_t *act) {
+    if (n_cand) hipLaunchKernelGGL(k_mp_items, dim3((n_cand + 3u) / 4u), dim3(256), 0, st, db_res_off, cand, n_cand, wbase, cq, j_span, wc, wi, wq, wj, aa, hash_ok,
+                                   resname_std, tert, qtab, (uint4 *)cinfo, act);
 }
 void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st) {
     if (!A.n_work) return;
