@@ -36,7 +36,17 @@ struct mp_sel {
 // divergently per survivor this part — ~3000 instructions with the exact libm chain — was 95 % of the kernel time)
 template <bool EMIT>
 __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, const uint32_t *q, uint32_t n, uint32_t slot, uint32_t r0, uint32_t r1,
-                                            const uint32_t *st_tab, const float *dist_tab, const uint32_t *tab) {
+                                            const uint32_t *st_tab, const float *dist_tab, const uint32_t *tab, const uint32_t *qh_lds) {
+    // is h one of the query's hashes?  From the LDS copy when the work item staged one (a motif query's ~44 hashes: the bisection through global memory
+    // was six dependent L2 round trips per drain)
+    auto in_query = [&](uint32_t h) -> bool {
+        if (qh_lds) {
+            uint32_t lo = 0, hi = Sx.n_hashes;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (qh_lds[mid] < h) lo = mid + 1; else hi = mid; }
+            return lo < Sx.n_hashes && qh_lds[lo] == h;
+        }
+        return hash_in_set(Sx.q_hashes, Sx.n_hashes, h);
+    };
     const uint32_t lane = threadIdx.x;
     const bool on = lane < n;
     const uint32_t e0 = on ? q[lane] : 0u;
@@ -60,7 +70,7 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
             float f9[FD_NFEAT];
             if (fd_feature_other(A.C.q.type, A.B, r0, r1, i, j, A.cutoff, f9)) {
                 h = fd_hash_other(A.C.q.type, f9, A.C.q);
-                hitmask = ((A.mode & 1u) && hash_in_set(Sx.q_hashes, Sx.n_hashes, h)) ? 1u : 0u;
+                hitmask = ((A.mode & 1u) && in_query(h)) ? 1u : 0u;
             } else {
                 n_win = 0; has_feat = false;
             }
@@ -74,7 +84,7 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
             // the index build's speculative evaluation (fd_pair_both_spec: table lookups on the dot products, exact whenever it answers) with
             // the exact table form behind it for the pairs it declines — the same frames, so the same bits as the build's keys
             if (A.C.use_tab < 2 || !fd_pair_both_spec(Fi, Fj, aai, aaj, A.C.q, tab, tab + 32, &h, &h_ji)) fd_pair_both_tab(Fi, Fj, aai, aaj, A.C.q, tab, &h, &h_ji);
-            hitmask = ((A.mode & 1u) && hash_in_set(Sx.q_hashes, Sx.n_hashes, h)) ? 1u : 0u;
+            hitmask = ((A.mode & 1u) && in_query(h)) ? 1u : 0u;
         } else {
             // one descriptor, one hash per bin pair (--multiple-bins: a found triple for every bin pair whose hash the query holds,
             // retrieve.rs:124-131)
@@ -82,7 +92,7 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
             for (uint32_t k = 0; k < A.n_cfg; ++k) {
                 const uint32_t hk = fd_hash_enc(aai, aaj, feat, A.qk[k]);
                 if (k == 0) h = hk;
-                if ((A.mode & 1u) && hash_in_set(Sx.q_hashes, Sx.n_hashes, hk)) hitmask |= 1u << k;
+                if ((A.mode & 1u) && in_query(hk)) hitmask |= 1u << k;
             }
         }
         hit = hitmask != 0;
@@ -159,9 +169,10 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
 }
 
 #define MP_AAD_LDS 1024
+#define MP_QH_LDS 1024        /* query hashes a work item copies into LDS for the drains' membership test */
 #define MP_SCAN_BLOCKS 64      /* blocks of 64 residues whose activity masks a work item keeps in LDS (longer structures: the two-walk form) */
 template <bool EMIT>
-__global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
+__global__ __launch_bounds__(FD_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_match_pairs(mp_args A_in) {
     // many queries per launch: this work item's query selects its slice of the concatenated tables (wave-uniform loads).  The
     // selection lives in its own few scalars: a modified COPY of the argument block — which holds arrays indexed at run time — is a
     // 480-byte private-memory object per lane, written by every wavefront at start (100 MB per launch) and read back field by field.
@@ -209,7 +220,8 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
     // that and which residues are active: eight blocks of 64 residues are requested together (a block's ballots depend on its loads — one block at a
     // time the walk was six dependent L2 round trips per pass, 30 us per work item, and the work items that only find out that they have nothing to do
     // paid them too), the blocks' ballots go to LDS, and the ranks of the active residues follow from the masks alone.
-    __shared__ unsigned long long s_mf[MP_SCAN_BLOCKS], s_mp[MP_SCAN_BLOCKS];      // per block: hashable residues / those that are also in the first-residue set
+    unsigned long long *s_mf = reinterpret_cast<unsigned long long *>(s_d_buf), *s_mp = s_mf + MP_SCAN_BLOCKS;      // per block: hashable residues / those also in the
+                                                                                                                     // first-residue set (the distance buffer is staged afterwards)
     t_sel = (A.wi_i0[w] - r0) >> 6;
     const uint32_t n_blk = (r1 - r0 + FD_WAVE - 1) / FD_WAVE;
     if (n_blk <= MP_SCAN_BLOCKS) {
@@ -289,6 +301,9 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
         for (int m = 0; m < 4; ++m)
             for (int k = 0; k < 4; ++k) { const uint32_t v = tab[32 + 7 + 5 * m + k]; tab[32 + 7 + 5 * m + k] = v > 0x7f7fffffu ? 0x7f7fffffu : v; }
     }
+    uint32_t *s_qh = reinterpret_cast<uint32_t *>(s_d_buf + 1024);      // the distance buffer's second half: only a large query's interval table reaches it
+    const bool staged_h = !big && Sx.n_hashes <= MP_QH_LDS;
+    if (staged_h) for (uint32_t e = threadIdx.x; e < Sx.n_hashes; e += FD_WAVE) s_qh[e] = Sx.q_hashes[e];
     if (!big) for (uint32_t e = threadIdx.x; e < 1025; e += FD_WAVE) s_start[e] = Sx.aad_start[e];
     if (staged)
         for (uint32_t e = threadIdx.x; e < Sx.n_aad; e += FD_WAVE) s_d_buf[e] = Sx.aad_dist[e];
@@ -387,7 +402,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
                 fd_wave_lds_fence();
                 qn -= FD_WAVE;
                 const unsigned long long td = A.dbg ? wall_clock64() : 0ull;
-                match_drain<EMIT>(A, Sx, q + qn, FD_WAVE, slot, r0, r1, st_tab, dist_tab, tab);
+                match_drain<EMIT>(A, Sx, q + qn, FD_WAVE, slot, r0, r1, st_tab, dist_tab, tab, staged_h ? s_qh : nullptr);
                 if (A.dbg) { tk_dr += wall_clock64() - td; ++n_dr; }
                 fd_wave_lds_fence();
             }
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_match_pairs(mp_args A_in) {
             const uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
             qn -= n;
             const unsigned long long td = A.dbg ? wall_clock64() : 0ull;
-            match_drain<EMIT>(A, Sx, q + qn, n, slot, r0, r1, st_tab, dist_tab, tab);
+            match_drain<EMIT>(A, Sx, q + qn, n, slot, r0, r1, st_tab, dist_tab, tab, staged_h ? s_qh : nullptr);
             if (A.dbg) { tk_dr += wall_clock64() - td; ++n_dr; }
             fd_wave_lds_fence();
         }
