@@ -2074,15 +2074,16 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         if (cand[k] >= db->n_struct) { c->err = "match_pairs: candidate id outside the batch"; return FDGPU_EINVAL; }
         n_tiles += (db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]] + FD_WAVE - 1) / FD_WAVE;
     }
-    // many candidates (a batch of motif queries): spans of 256 partners cap the longest work items — the launch ends with its slowest
-    // wavefront (32 queries x 32 candidates: 218 -> 126 us; 128 and 512 measured 148 and 156); from ~12 k tiles (128 queries x 32 candidates:
-    // 22 k) the launch is rounds of items and fewer, longer ones win: 351 us at 256, 333 at 384, 325 at 512, 363 uncut
+    // many candidates (a batch of motif queries): spans of 256 partners cap the longest work items — the scan launch ends with its slowest wavefront, and a
+    // wavefront walks its partners one at a time (128 queries x 32 candidates, k_mp_scan: 93 us at 512, 68 at 256, 60 at 128 — where the drains, one per
+    // partly filled chunk, have grown by as much)
     // large queries (whole-structure: the window test passes nearly every pair inside the cutoff, so a work item's time is its number of close
     // pairs x one descriptor + hash each): spans of 32 partners — a diagonal block of 64 x 128 residues was 128 drains on ONE wavefront and the
     // launch lasted as long as its slowest wavefronts (first scan of the top 20 of a 300-residue query: 5.1 ms at 128, 4.4 at 64, 3.7 at 32 and 16)
     uint64_t max_aad_q = 0;
     for (uint64_t t = 0; t < n_queries; ++t) max_aad_q = std::max<uint64_t>(max_aad_q, qs[t].n_aad);
-    const uint32_t j_span = !n_tiles ? 0u : max_aad_q > 4096 ? 32u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : n_tiles < 12288 ? 256u : 512u;
+    uint32_t j_span = !n_tiles ? 0u : max_aad_q > 4096 ? 32u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : 256u;
+    if (const char *js = getenv("FDGPU_MP_JSPAN")) if (n_tiles && atoi(js) >= 32) j_span = (uint32_t)atoi(js) & ~63u ? (uint32_t)atoi(js) & ~31u : 32u;      // (measurement aid)
     TB.j_span = j_span;
     std::vector<uint32_t> wc, wi, wq, wj;
     // a one-off block (a batch of motif queries: 18 k work items per 128 queries) gets its work items written on the DEVICE (k_mp_items): the host
@@ -2322,40 +2323,83 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     A.iv_grp = want_iv ? dblk + o_iv1 : nullptr;
     A.qtab = (const mp_query_dev *)(dblk + o_qt);
     A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.found = nullptr; A.cands = nullptr;
-    const bool mp_dbg = getenv("FDGPU_MP_DBG") != nullptr;       // per-phase clocks of the pair scan's work items on stderr (measurement aid)
-    if (mp_dbg) HIPCHK(c, c->ws[WS_TOTAL].ensure(128));
-    A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1;
-    A.dbg = mp_dbg ? A.n_found + 2 : nullptr;
+    const bool mp_dbg = getenv("FDGPU_MP_DBG") != nullptr;       // clocks and counts of the pair scan's work items and drains on stderr (measurement aid)
+    HIPCHK(c, c->ws[WS_TOTAL].ensure(16384));
+    // ws[WS_TOTAL] (u64): [0] found triples, [1] candidate pairs, [2] chunks drained, [4, 12) FDGPU_MP_DBG, from [16]: the 64 sub-queues' claimed chunks, one per 128-byte line
+    A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.q_cnt = A.n_found + 16;
+    A.dbg = mp_dbg ? A.n_found + 4 : nullptr;
     A.cinfo = d_cinfo; A.act = d_act;
+    A.compact = !want_iv;
+      // (want_iv: some query observes more than 1,024 distances)
     // one emitting pass into buffers sized by the previous calls; a pass that overflows only counts, the buffers grow and
     // the pass is repeated (the scan is deterministic up to record order, which is restored below)
-    uint64_t tot[2] = {0, 0};
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    static_assert(MP_SUBQ_STRIDE == 16, "ws[WS_TOTAL] layout");
+    std::vector<uint64_t> tot_v(16 + 64 * MP_SUBQ_STRIDE, 0);
+    uint64_t *tot = tot_v.data();
+    uint64_t q_max = 0;      // most chunks one sub-queue was asked for by the previous attempt
+    for (int attempt = 0; attempt < 4; ++attempt) {
         uint64_t capf = c->ws[WS_KEYS_A].cap / sizeof(fd_pair_rec), capc = c->ws[WS_KEYS_B].cap / sizeof(fd_cand_rec);
         if (capf < 4096 || capf < tot[0]) { HIPCHK(c, c->ws[WS_KEYS_A].ensure(std::max<uint64_t>(2 * tot[0], 65536) * sizeof(fd_pair_rec))); }
         if (capc < 4096 || capc < tot[1]) { HIPCHK(c, c->ws[WS_KEYS_B].ensure(std::max<uint64_t>(2 * tot[1], 65536) * sizeof(fd_cand_rec))); }
         A.found = c->ws[WS_KEYS_A].as<fd_pair_rec>(); A.cands = c->ws[WS_KEYS_B].as<fd_cand_rec>();
         A.cap_found = c->ws[WS_KEYS_A].cap / sizeof(fd_pair_rec); A.cap_cands = c->ws[WS_KEYS_B].cap / sizeof(fd_cand_rec);
-        HIPCHK(c, hipMemsetAsync(c->ws[WS_TOTAL].p, 0, mp_dbg ? 128 : 16, st));
+        {
+            // the chunk queue between the scan and the drains, ws[WS_MP_Q]: [256 B bin tables | per chunk: 16 B header, 256 B pairs, 3 x 256 B results,
+            // 8 B totals, 16 B positions], 64 sub-queues.  A work item rarely queues more than two chunks; a launch that asks for more than a sub-queue
+            // holds counts them and is repeated with the queue it asked for
+            const uint64_t per = 16 + 256 + 768 + 8 + 16, have = c->ws[WS_MP_Q].cap > 256 ? (c->ws[WS_MP_Q].cap - 256) / (per * 64) : 0;
+            uint64_t want = std::max<uint64_t>(have, std::max<uint64_t>(64, (nw + nw / 2) / 64 + 32));
+            if (q_max > have) want = std::max<uint64_t>(want, q_max + q_max / 4 + 16);
+            if (want > have) HIPCHK(c, c->ws[WS_MP_Q].ensure(256 + want * per * 64));
+            if (c->ws[WS_MP_Q].p != c->mp_bintab_at || c->ws[WS_MP_Q].cap != c->mp_bintab_cap) {      // (a new allocation: the tables once)
+                uint32_t t64[64];
+                memset(t64, 0, sizeof t64);
+                fd_fill_bintab(t64);
+                for (int k = 0; k < FD_BINTAB_WORDS; ++k) t64[32 + k] = t64[k];
+                for (int m = 0; m < 4; ++m)
+                    for (int k = 0; k < 4; ++k) { const uint32_t v = t64[32 + 7 + 5 * m + k]; t64[32 + 7 + 5 * m + k] = v > 0x7f7fffffu ? 0x7f7fffffu : v; }
+                HIPCHK(c, hipMemcpyAsync(c->ws[WS_MP_Q].p, t64, sizeof t64, hipMemcpyHostToDevice, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+                c->mp_bintab_at = c->ws[WS_MP_Q].p; c->mp_bintab_cap = c->ws[WS_MP_Q].cap;
+            }
+            const uint64_t capq = std::min<uint64_t>((c->ws[WS_MP_Q].cap - 256) / (per * 64), 0x1ffffffu), nch = capq * 64;
+            uint8_t *qb = c->ws[WS_MP_Q].as<uint8_t>() + 256;
+            A.cap_subq = (uint32_t)capq;
+            A.bintab = c->ws[WS_MP_Q].as<uint32_t>();
+            A.chunk_base = (ulonglong2 *)qb; qb += nch * 16;
+            A.chunk_hdr = (uint4 *)qb; qb += nch * 16;
+            A.chunk_cnt = (uint2 *)qb; qb += nch * 8;
+            A.chunk_ij = (uint32_t *)qb; qb += nch * 256;
+            A.res_h = (uint32_t *)qb; qb += nch * 256;
+            A.res_meta = (uint32_t *)qb; qb += nch * 256;
+            A.res_d = (float *)qb;
+        }
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_TOTAL].p, 0, tot_v.size() * 8, st));
         {
             StageTimer t(c, "match_pairs", 0);
-            fd_launch_match_pairs(A, true, st);
+            fd_launch_match_pairs(A, st);
         }
         if (mp_dbg) {
             unsigned long long d[8];
             if (hipMemcpyAsync(d, A.dbg, 64, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
                 const double live = (double)std::max<unsigned long long>(d[0], 1), us = 0.01;      // 100 MHz ticks
-                fprintf(stderr, "[mp] %llu work items: %llu live (compaction %.2f, staging %.2f, scan + drains %.2f us each; %.2f drains per item, %.2f us per drain), %llu early exits (%.2f us each)\n",
-                        (unsigned long long)nw, d[0], d[1] * us / live, d[2] * us / live, d[3] * us / live, (double)d[4] / live, d[4] ? d[5] * us / (double)d[4] : 0.0, d[6],
-                        d[6] ? d[7] * us / (double)d[6] : 0.0);
+                fprintf(stderr, "[mp] %llu work items: %llu live (%.2f us each; %.1f partners visited, %.1f pairs queued per item), %llu early exits (%.2f us each); %llu chunks drained (%.2f us each)\n",
+                        (unsigned long long)nw, d[0], d[1] * us / live, d[6] / live, d[7] / live, d[2], d[2] ? d[3] * us / (double)d[2] : 0.0, d[4], d[4] ? d[5] * us / (double)d[4] : 0.0);
             }
         }
         HIPCHK(c, hipGetLastError());
         if (attempt == 0 && while_scanning && *while_scanning) (*while_scanning)();      // before the copy: one into pageable memory waits for the stream
-        HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_TOTAL].p, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_TOTAL].p, tot_v.size() * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
+        q_max = 0;
+        for (int k = 0; k < 64; ++k) q_max = std::max<uint64_t>(q_max, tot[16 + MP_SUBQ_STRIDE * k]);
+        if (q_max > A.cap_subq) {      // the drains saw a part of the pairs only: their counts mean nothing
+            if (attempt == 3) FAIL(c, FDGPU_ERANGE, "match_pairs: the pair queue did not fit after regrowing");
+            tot[0] = tot[1] = 0;
+            continue;
+        }
         if (tot[0] <= A.cap_found && tot[1] <= A.cap_cands) break;
-        if (attempt == 2) FAIL(c, FDGPU_ERANGE, "match_pairs: output did not fit after regrowing");
+        if (attempt == 3) FAIL(c, FDGPU_ERANGE, "match_pairs: output did not fit after regrowing");
     }
     if (mp_trace) fprintf(stderr, "[match_pairs] scan done at %.3f ms (found %llu, cands %llu)\n", mp_ms(), (unsigned long long)tot[0], (unsigned long long)tot[1]);
     if (mode & 32u) {   // the rows of the vote table: (largest count, how many hold it, which) per (slot, component, query residue)

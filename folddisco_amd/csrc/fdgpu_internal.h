@@ -92,7 +92,7 @@ enum {
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
     WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS, WS_QT_STREAM, WS_QT_STAB,
     WS_CA_PERM, WS_OK_PERM, WS_AA_PERM, WS_SEG_TAB,
-    WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT, WS_RS_GQ, WS_MP_ACT,
+    WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT, WS_RS_GQ, WS_MP_ACT, WS_MP_Q,
     WS_COUNT
 };
 
@@ -159,6 +159,7 @@ struct fdgpu_ctx {
     }
     size_t last_cap = 0;
     bool counted = false;         // fdgpu_create got as far as a device + stream (live-context count behind fdgpu_trim at the last destroy)
+    const void *mp_bintab_at = nullptr; size_t mp_bintab_cap = 0;      // the WS_MP_Q allocation whose first 256 bytes hold the pair drain's bin tables
     fd_host_pool host_pool;       // helper threads of the host glue (made on first use)
     void *lanes = nullptr;        // fd_lanes.hip: sibling contexts + worker threads behind fdgpu_query_batch_submit / _wait (made on first use)
 };
@@ -388,6 +389,7 @@ struct mp_query_dev {   // per-query table of the pair scan (many queries in one
     int use_prefilter;
     float ca_window;
 };
+#define MP_SUBQ_STRIDE 16u      /* u64 words between the pair queue's sub-queue counters (one 128-byte line each) */
 struct mp_args {
     fd_batch_view B;
     fd_hash_consts C;
@@ -407,7 +409,14 @@ struct mp_args {
     float ca_window;
     unsigned long long *n_found, *n_cands;
     const uint4 *cinfo; const uint32_t *act;      // optional (items written on the device): per candidate {first residue, end, active residues | full << 31, first list entry}, the lists
-    unsigned long long *dbg;       // FDGPU_MP_DBG: [8] live items, their compaction / staging / scan ticks, drains, drain ticks, early exits, their ticks; else null
+    unsigned long long *dbg;       // FDGPU_MP_DBG: [8] live items, their ticks, early exits, their ticks, chunks drained, their ticks, partners visited, pairs queued; else null
+    // the queue between k_mp_scan and k_mp_drain: chunks of up to 64 packed pairs in 64 sub-queues of cap_subq chunks (sub-queue s: chunks
+    // [s * cap_subq, ...), q_cnt[s] claimed — beyond cap_subq: counted only), their headers {slot, pairs | query << 8, first residue, end}.  In chunk
+    // order v (sub-queue by sub-queue): the drain's results per pair, the chunk's {candidate-pair records, found triples}, their first positions
+    unsigned long long *q_cnt; uint4 *chunk_hdr; uint32_t *chunk_ij; uint32_t cap_subq;
+    uint32_t *res_h, *res_meta; float *res_d; uint2 *chunk_cnt; ulonglong2 *chunk_base;
+    const uint32_t *bintab;        // [64] fd_fill_bintab's table + its clamped copy at [32, 59) (fdgpu_api.hip fills it once per workspace)
+    int compact;                   // every query of the launch observes <= 1,024 distances and needs no interval table: the scan's small LDS layout
     fd_pair_rec *found; fd_cand_rec *cands;
     unsigned long long cap_found, cap_cands;   // records the buffers hold (EMIT counts beyond them without writing)
     uint32_t n_cfg;                // --multiple-bins: bin pairs to hash every surviving pair with (1 = the single configuration in C)
@@ -444,7 +453,7 @@ struct fd_vote_plan {
     const float *sd_dist; const uint32_t *sd_qi; uint64_t n_sd;
 };
 void fd_launch_vote_rows(const uint32_t *votes, const uint64_t *row_off, const uint32_t *row_len, uint64_t n_rows, fd_vote_row *out, hipStream_t st);
-void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st);
+void fd_launch_match_pairs(const mp_args &A, hipStream_t st);
 void fd_launch_found_key_ij(const fd_pair_rec *f, uint64_t n, uint32_t *key, uint32_t *val, hipStream_t st);
 void fd_launch_found_key_slot(const fd_pair_rec *f, const uint32_t *val, uint64_t n, uint32_t *key, hipStream_t st);
 void fd_launch_found_gather(const fd_pair_rec *f, const uint32_t *val, uint64_t n, fd_pair_rec *out, hipStream_t st);

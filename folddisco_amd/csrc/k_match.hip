@@ -34,9 +34,11 @@ struct mp_sel {
 };
 // descriptor + hash + output of one surviving (i, j) per lane (full-wave drains of the compaction queue: executed
 // divergently per survivor this part — ~3000 instructions with the exact libm chain — was 95 % of the kernel time)
-template <bool EMIT>
+// Nothing is appended here: the pair's hash, (bin pairs whose hash the query holds | window hits << 8) and CA distance go to the chunk's result row,
+// the chunk's two totals to cnt — k_mp_offsets turns the totals into record positions, k_mp_emit writes the records.  (One wavefront used to claim its
+// record ranges with two returning atomics on the launch's two counters: ~15,000 same-address atomics per launch at ~12 ns each were 150 of the 185 us.)
 __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, const uint32_t *q, uint32_t n, uint32_t slot, uint32_t r0, uint32_t r1,
-                                            const uint32_t *st_tab, const float *dist_tab, const uint32_t *tab, const uint32_t *qh_lds) {
+                                            const uint32_t *st_tab, const float *dist_tab, const uint32_t *tab, const uint32_t *qh_lds, unsigned long long v) {
     // is h one of the query's hashes?  From the LDS copy when the work item staged one (a motif query's ~44 hashes: the bisection through global memory
     // was six dependent L2 round trips per drain)
     auto in_query = [&](uint32_t h) -> bool {
@@ -56,7 +58,7 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
     fd_v3 cai = {0.f, 0.f, 0.f}, caj = {0.f, 0.f, 0.f};
     float d = 0.f;
     uint32_t key = 0, e_lo = 0, e_hi = 0;
-    bool hit = false, has_feat = true;
+    bool has_feat = true;
     if (on) {
         aai = A.B.aa[i]; aaj = A.B.aa[j];
         cai = fd_load3(A.B.ca_xyz, i); caj = fd_load3(A.B.ca_xyz, j);
@@ -95,7 +97,6 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
                 if ((A.mode & 1u) && in_query(hk)) hitmask |= 1u << k;
             }
         }
-        hit = hitmask != 0;
         if (!(A.mode & 2u)) n_win = 0;
     }
     if ((A.mode & 32u) && on && has_feat) {
@@ -118,93 +119,62 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
                 if (fd_fabsf(d - dist_tab[e]) < Sx.ca_window) { const uint32_t qi = Sx.aad_qi[e]; if (qi < nq) atomicAdd(&tabv[(uint64_t)qi * nr], 1u); }
         }
     }
-    // one atomic per counter and drain (per-record atomics on two addresses serialise in one L2 channel: that, not the
-    // arithmetic, was the kernel time)
-    uint32_t incl = n_win;
-    for (int off = 1; off < FD_WAVE; off <<= 1) {
-        uint32_t t = __shfl_up(incl, off, FD_WAVE);
-        if ((int)lane >= off) incl += t;
-    }
-    const uint32_t tot_win = __shfl(incl, FD_WAVE - 1, FD_WAVE);
-    const uint64_t hm = __ballot(hit);
-    const uint32_t n_hit = (uint32_t)__builtin_popcount(hitmask);
-    uint32_t hincl = n_hit;      // found triples per lane: one per matching bin pair
-    if (A.n_cfg > 1) {
-        for (int off = 1; off < FD_WAVE; off <<= 1) {
-            uint32_t t = __shfl_up(hincl, off, FD_WAVE);
-            if ((int)lane >= off) hincl += t;
-        }
-    }
-    const uint32_t tot_hit = A.n_cfg > 1 ? (uint32_t)__shfl((int)hincl, FD_WAVE - 1, FD_WAVE) : (uint32_t)__popcll(hm);
-    unsigned long long cbase = 0, fbase = 0;
-    if (lane == 0) {
-        if (tot_win) cbase = atomicAdd(A.n_cands, (unsigned long long)tot_win);
-        if (tot_hit) fbase = atomicAdd(A.n_found, (unsigned long long)tot_hit);
-    }
-    cbase = ((unsigned long long)(uint32_t)__shfl((int)(cbase >> 32), 0, FD_WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)cbase, 0, FD_WAVE);
-    fbase = ((unsigned long long)(uint32_t)__shfl((int)(fbase >> 32), 0, FD_WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)fbase, 0, FD_WAVE);
-    unsigned long long cpos = cbase + (incl - n_win);
-    const unsigned long long fpos = fbase + (A.n_cfg > 1 ? (unsigned long long)(hincl - n_hit) : (unsigned long long)fd_mbcnt(hm));
-    // EMIT with capacities: records beyond the caller's buffers are counted but not written (the caller grows and reruns)
-    if (EMIT && on && cpos + n_win <= A.cap_cands && (!hit || fpos + n_hit <= A.cap_found)) {
-        // only pairs that claimed candidate slots walk their list again: a found-only or vote scan (n_win = 0) used to walk the ~200 observed
-        // distances of its group here for nothing — 53 us per drain, 86 % of a whole-structure query's first scan — and a pair without a
-        // descriptor (encodings with their own) wrote its window hits over its neighbours' slots
-        if (n_win) for (uint32_t e = e_lo; e < e_hi; ++e) {
-            if (fd_fabsf(d - dist_tab[e]) < Sx.ca_window) {
-                fd_cand_rec c; c.cand = slot; c.qi = Sx.aad_qi[e]; c.i = i - r0; c.j = j - r0;
-                A.cands[cpos++] = c;
-            }
-        }
-        if (hit) {
-            fd_pair_rec p; p.cand = slot; p.i = i - r0; p.j = j - r0;
-            if (A.n_cfg == 1) { p.hash = h; A.found[fpos] = p; }
-            else {
-                unsigned long long fp = fpos;
-                for (uint32_t k = 0; k < A.n_cfg; ++k)
-                    if ((hitmask >> k) & 1u) { p.hash = k == 0 ? h : fd_hash_enc(aai, aaj, feat, A.qk[k]); A.found[fp++] = p; }
-            }
-        }
-    }
+    // the chunk's totals: candidate-pair records (window hits) and found triples (one per matching bin pair)
+    uint32_t tw = n_win, th = (uint32_t)__builtin_popcount(hitmask);
+    for (int off = 32; off > 0; off >>= 1) { tw += __shfl_xor(tw, off, FD_WAVE); th += __shfl_xor(th, off, FD_WAVE); }
+    A.res_h[v * FD_WAVE + lane] = h;
+    A.res_meta[v * FD_WAVE + lane] = (on ? hitmask : 0u) | (n_win << 8);
+    A.res_d[v * FD_WAVE + lane] = d;
+    if (lane == 0) A.chunk_cnt[v] = make_uint2(tw, th);
 }
 
 #define MP_AAD_LDS 1024
-#define MP_QH_LDS 1024        /* query hashes a work item copies into LDS for the drains' membership test */
+#define MP_QH_LDS 1024        /* query hashes a drain copies into LDS for its membership test */
+#define MP_SUBQ 64u            /* sub-queues of the chunk queue: one counter each, MP_SUBQ_STRIDE (fdgpu_internal.h) u64 = 128 B apart */
 #define MP_SCAN_BLOCKS 64      /* blocks of 64 residues whose activity masks a work item keeps in LDS (longer structures: the two-walk form) */
-template <bool EMIT>
-__global__ __launch_bounds__(FD_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_match_pairs(mp_args A_in) {
-    // many queries per launch: this work item's query selects its slice of the concatenated tables (wave-uniform loads).  The
-    // selection lives in its own few scalars: a modified COPY of the argument block — which holds arrays indexed at run time — is a
-    // 480-byte private-memory object per lane, written by every wavefront at start (100 MB per launch) and read back field by field.
+
+// many queries per launch: a work item's / chunk's query selects its slice of the concatenated tables (wave-uniform loads).  The selection lives in
+// its own few scalars: a modified COPY of the argument block — which holds arrays indexed at run time — is a 480-byte private-memory object per lane,
+// written by every wavefront at start (100 MB per launch) and read back field by field.
+__device__ __forceinline__ void mp_select(const mp_args &A_in, uint32_t tq, mp_sel &Sx) {
+    const mp_query_dev Q = A_in.qtab[tq];
+    Sx.q_hashes = A_in.q_hashes + Q.qh_off; Sx.n_hashes = Q.n_hashes;
+    Sx.aad_start = A_in.aad_start + 1025u * tq; Sx.aad_dist = A_in.aad_dist + Q.aad_off; Sx.aad_qi = A_in.aad_qi + Q.aad_off; Sx.n_aad = Q.n_aad;
+    Sx.aa1_mask = Q.aa1_mask; Sx.aa2_mask = Q.aa2_mask; Sx.use_prefilter = Q.use_prefilter; Sx.ca_window = Q.ca_window;
+    Sx.iv_start = A_in.iv_start ? A_in.iv_start + 1025u * tq : nullptr;      // interval offsets are absolute into A.iv
+    Sx.iv = A_in.iv;
+    Sx.iv_grp = A_in.iv_grp ? A_in.iv_grp + 1024u * tq : nullptr;
+    Sx.sd_dist = A_in.sd_dist ? A_in.sd_dist + Q.aad_off : nullptr; Sx.sd_qi = A_in.sd_qi ? A_in.sd_qi + Q.aad_off : nullptr;
+}
+
+// The pair scan is two kernels since round 5.  As ONE kernel (scan, and a drain whenever 64 pairs had queued) every wavefront carried the drain's
+// ~170 registers — three wavefronts per SIMD — through a scan that is a chain of dependent loads (item -> candidate -> active residues -> tables ->
+// partner blocks): the wavefronts waited 73 % of their cycles, the launch took 250 us for 45 us of vector issue (profiles/round5_pmc_query_kernels).
+//   k_mp_scan   one wavefront per work item: the window test of every (first residue, partner) pair; survivors leave in CHUNKS of up to 64 packed
+//               (i, j) with a header {candidate slot, count | query << 8, first residue, end} — few registers, little LDS: many wavefronts per SIMD.
+//   k_mp_drain  one wavefront per chunk: descriptor + hash + records of its pairs (match_drain), the query's hashes and observed distances in LDS.
+// COMPACT: every query of the launch observes <= 1,024 distances (motif queries): 16-bit group starts and a 4 KB distance buffer — 7 KB of LDS per
+// work item instead of 13.
+template <bool COMPACT>
+__global__ __launch_bounds__(FD_WAVE) void k_mp_scan(mp_args A_in) {
     const mp_args &A = A_in;
-    mp_sel Sx;
-    Sx.q_hashes = A_in.q_hashes; Sx.n_hashes = A_in.n_hashes; Sx.aad_start = A_in.aad_start; Sx.aad_dist = A_in.aad_dist; Sx.aad_qi = A_in.aad_qi;
-    Sx.n_aad = A_in.n_aad; Sx.aa1_mask = A_in.aa1_mask; Sx.aa2_mask = A_in.aa2_mask; Sx.use_prefilter = A_in.use_prefilter; Sx.ca_window = A_in.ca_window;
-    Sx.iv_start = A_in.iv_start; Sx.iv = A_in.iv; Sx.iv_grp = A_in.iv_grp; Sx.sd_dist = A_in.sd_dist; Sx.sd_qi = A_in.sd_qi;
-    if (blockIdx.x < A_in.n_work) {
-        const uint32_t tq = A_in.wi_query[blockIdx.x];
-        const mp_query_dev Q = A_in.qtab[tq];
-        Sx.q_hashes = A_in.q_hashes + Q.qh_off; Sx.n_hashes = Q.n_hashes;
-        Sx.aad_start = A_in.aad_start + 1025u * tq; Sx.aad_dist = A_in.aad_dist + Q.aad_off; Sx.aad_qi = A_in.aad_qi + Q.aad_off; Sx.n_aad = Q.n_aad;
-        Sx.aa1_mask = Q.aa1_mask; Sx.aa2_mask = Q.aa2_mask; Sx.use_prefilter = Q.use_prefilter; Sx.ca_window = Q.ca_window;
-        Sx.iv_start = A_in.iv_start ? A_in.iv_start + 1025u * tq : nullptr;      // interval offsets are absolute into A.iv
-        Sx.iv_grp = A_in.iv_grp ? A_in.iv_grp + 1024u * tq : nullptr;
-        Sx.sd_dist = A_in.sd_dist ? A_in.sd_dist + Q.aad_off : nullptr; Sx.sd_qi = A_in.sd_qi ? A_in.sd_qi + Q.aad_off : nullptr;
-    }
-    __shared__ uint32_t q[2 * FD_WAVE];
-    __shared__ uint32_t tab[64];      // [0, 27) the exact bin tables (bit patterns), [32, 59) the same with clamped float thresholds for the speculative path
-    // motif-sized queries: the observed distances (4 KB) and the start table.  Large queries: the first 1,024 merged pass intervals of the query (8 KB;
-    // a 300-residue query at a 1 A window has ~700) and, in the start table's place, per (aa_i, aa_j) group (first interval << 8 | count)
-    __shared__ __attribute__((aligned(8))) float s_d_buf[2 * 1024];
-    __shared__ uint32_t s_start[1025];
     const uint32_t w = blockIdx.x;
     if (w >= A.n_work) return;
+    const uint32_t tq = A_in.wi_query[w];
+    mp_sel Sx;
+    mp_select(A_in, tq, Sx);
+    typedef typename std::conditional<COMPACT, uint16_t, uint32_t>::type start_t;
+    __shared__ uint32_t q[2 * FD_WAVE];
+    // motif-sized queries: the observed distances (4 KB) and the start table.  Large queries: the first 1,024 merged pass intervals of the query (8 KB;
+    // a 300-residue query at a 1 A window has ~700) and, in the start table's place, per (aa_i, aa_j) group (first interval << 8 | count)
+    __shared__ __attribute__((aligned(8))) float s_d_buf[COMPACT ? 1024 : 2048];
+    __shared__ start_t s_start[1026];
+    __shared__ uint32_t s_sel[FD_WAVE];
     const unsigned long long tk0 = A.dbg ? wall_clock64() : 0ull;
-    unsigned long long tk_dr = 0, n_dr = 0;
+    unsigned long long n_vis = 0, n_q = 0;
     const uint32_t slot = A.wi_cand[w];
     const uint32_t lane = threadIdx.x;
     const bool tert = A.C.q.type == FD_HASH_TERTIARY;     // TertiaryInteraction needs no CB (feature.rs:113-160)
-    __shared__ uint32_t s_sel[FD_WAVE];
     uint32_t r0, r1, n_act = 0, t_sel;
     bool full = true;
     if (A.cinfo) {
@@ -282,29 +252,41 @@ __global__ __launch_bounds__(FD_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3)))
             if (n_act >= 64u * (t_sel + 1u)) break;
         }
     }
+    fd_wave_lds_fence();      // the masks' buffer is the distance buffer
     }
     if (n_act <= 64u * t_sel) {             // (wave-uniform) nothing left for this tile: before any table is staged
-        if (A.dbg && threadIdx.x == 0) { atomicAdd(&A.dbg[6], 1ull); atomicAdd(&A.dbg[7], wall_clock64() - tk0); }
+        if (A.dbg && threadIdx.x == 0) { atomicAdd(&A.dbg[2], 1ull); atomicAdd(&A.dbg[3], wall_clock64() - tk0); }
         return;
     }
-    const unsigned long long tk1 = A.dbg ? wall_clock64() : 0ull;
     const uint32_t n_here = n_act - 64u * t_sel < FD_WAVE ? n_act - 64u * t_sel : FD_WAVE;
     // the query's observed (aa_i, aa_j) -> CA distance lists (aa_dist_map, controller/query.rs), grouped by residue-type pair:
     // aad_start[aa_i * 32 + aa_j] .. [+1] indexes the distance / query-residue arrays (host-sorted, stable).  Start table and,
     // for motif-sized queries, the distances live in LDS: per-pair global reads made the scan latency-bound.
-    const bool staged = Sx.n_aad <= MP_AAD_LDS;
-    const bool big = !staged && Sx.iv_start != nullptr;      // large query: the only table a work item stages is the dense interval table (8 KB, 16
-                                                              // independent loads per lane) — the start table stays in global memory for the drains
-    if (threadIdx.x == 0 && A.C.use_tab) {
-        fd_fill_bintab(tab);
-        for (int k = 0; k < FD_BINTAB_WORDS; ++k) tab[32 + k] = tab[k];
-        for (int m = 0; m < 4; ++m)
-            for (int k = 0; k < 4; ++k) { const uint32_t v = tab[32 + 7 + 5 * m + k]; tab[32 + 7 + 5 * m + k] = v > 0x7f7fffffu ? 0x7f7fffffu : v; }
+    // partner residues in groups of four blocks of 64: one coalesced load of (aa, CA, filters) per block and lane, the group's loads issued together — and
+    // the first group's HERE, before the tables are staged — (a block at a time, an item of 512 partners was eight dependent round trips through L2 on top of
+    // the item -> candidate -> active residues -> tables -> first residues chain: 94 us per launch for 5 us of arithmetic)
+    const uint32_t j_lo = A.j_span ? A.wi_j0[w] : r0;
+    const uint32_t j_hi = A.j_span ? (j_lo + A.j_span < r1 ? j_lo + A.j_span : r1) : r1;
+    const uint32_t mbit0 = A.cj_mask ? A.mask_off[slot] : 0u;
+    uint32_t pa[4], pok[4];
+    fd_v3 pc[4];
+#define MP_LOAD_GROUP(g0)                                                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                                        \
+        const uint32_t jl = (g0) + (uint32_t)u * FD_WAVE + lane;                                                                           \
+        const bool jin = jl < j_hi;                                                                                                        \
+        pa[u] = jin ? (uint32_t)A.B.aa[jl] : 255u;                                                                                         \
+        pc[u] = {0.f, 0.f, 0.f};                                                                                                           \
+        if (jin) pc[u] = fd_load3(A.B.ca_xyz, jl);                                                                                         \
+        uint32_t ok = jin ? (tert ? 1u : (uint32_t)A.B.hash_ok[jl]) : 0u;                                                                  \
+        if (!full && jin && A.resname_std) ok &= (uint32_t)A.resname_std[jl] ? 1u : 0u;                                                    \
+        if (A.cj_mask && jin) { const uint32_t bit = mbit0 + (jl - r0); ok &= (A.cj_mask[bit >> 5] >> (bit & 31u)) & 1u; }                  \
+        pok[u] = ok;                                                                                                                       \
     }
-    uint32_t *s_qh = reinterpret_cast<uint32_t *>(s_d_buf + 1024);      // the distance buffer's second half: only a large query's interval table reaches it
-    const bool staged_h = !big && Sx.n_hashes <= MP_QH_LDS;
-    if (staged_h) for (uint32_t e = threadIdx.x; e < Sx.n_hashes; e += FD_WAVE) s_qh[e] = Sx.q_hashes[e];
-    if (!big) for (uint32_t e = threadIdx.x; e < 1025; e += FD_WAVE) s_start[e] = Sx.aad_start[e];
+    MP_LOAD_GROUP(j_lo)
+    const bool staged = COMPACT || Sx.n_aad <= MP_AAD_LDS;
+    const bool big = !COMPACT && !staged && Sx.iv_start != nullptr;      // large query: the only table a work item stages is the dense interval table (8 KB, 16
+                                                                          // independent loads per lane)
+    if (!big) for (uint32_t e = threadIdx.x; e < 1025; e += FD_WAVE) s_start[e] = (start_t)Sx.aad_start[e];
     if (staged)
         for (uint32_t e = threadIdx.x; e < Sx.n_aad; e += FD_WAVE) s_d_buf[e] = Sx.aad_dist[e];
     uint32_t iv_base = 0;
@@ -312,13 +294,10 @@ __global__ __launch_bounds__(FD_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3)))
         iv_base = Sx.iv_start[0];
         const uint32_t n_iv = Sx.iv_start[1024] - iv_base;
 #pragma unroll
-        for (uint32_t g = 0; g < 1024; g += FD_WAVE) s_start[g + threadIdx.x] = Sx.iv_grp[g + threadIdx.x];
+        for (uint32_t g = 0; g < 1024; g += FD_WAVE) s_start[g + threadIdx.x] = (start_t)Sx.iv_grp[g + threadIdx.x];
         for (uint32_t e = threadIdx.x; e < n_iv && e < 1024u; e += FD_WAVE) reinterpret_cast<float2 *>(s_d_buf)[e] = Sx.iv[iv_base + e];
     }
     __syncthreads();
-    const unsigned long long tk2 = A.dbg ? wall_clock64() : 0ull;
-    const float *dist_tab = staged ? s_d_buf : Sx.aad_dist;
-    const uint32_t *st_tab = big ? Sx.aad_start : s_start;
     const bool act = lane < n_here;
     const uint32_t i = act ? s_sel[lane] : r0;
     const uint32_t aai = act ? A.B.aa[i] : 255u;
@@ -330,97 +309,231 @@ __global__ __launch_bounds__(FD_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3)))
         if (big) for (uint32_t a2 = 0; a2 < 32u; ++a2) row_mask |= ((s_start[aai * 32u + a2] & 255u) ? 1u : 0u) << a2;
         else for (uint32_t a2 = 0; a2 < 32u; ++a2) row_mask |= (s_start[aai * 32u + a2 + 1] > s_start[aai * 32u + a2] ? 1u : 0u) << a2;
     }
-    // the loop's two thresholds in VECTOR registers: the kernel is out of scalar registers (the argument block's pointers), and a uniform value the
-    // compiler keeps "in the arguments" is a scalar memory load + wait per partner residue
+    // the loop's two thresholds in VECTOR registers: a uniform value the compiler keeps "in the arguments" is a scalar memory load + wait per partner residue
     float d2_max_v = A.C.d2_max, ca_window_v = Sx.ca_window;
     asm volatile("" : "+v"(d2_max_v), "+v"(ca_window_v));
+    // a full queue leaves as one chunk: {candidate slot, pairs | query << 8, first residue, end} + 64 packed (i - r0) << 16 | (j - r0)
+    // (64 sub-queues, the item's is w mod 64: chunk slots are claimed with an atomic, and ~8,000 claims on ONE counter took 50 us of the launch)
+    auto push = [&](const uint32_t *src, uint32_t n) {
+        const uint32_t sq = w & (MP_SUBQ - 1u);
+        uint32_t k = 0;
+        if (lane == 0) k = (uint32_t)atomicAdd(A.q_cnt + MP_SUBQ_STRIDE * sq, 1ull);
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+        if (k < A.cap_subq) {      // beyond the sub-queue: counted only (the caller grows the queue and reruns)
+            const uint64_t cidx = (uint64_t)sq * A.cap_subq + k;
+            if (lane < n) A.chunk_ij[cidx * FD_WAVE + lane] = src[lane];
+            if (lane == 0) A.chunk_hdr[cidx] = make_uint4(slot, n | (tq << 8), r0, r1);
+        }
+        n_q += n;
+    };
     uint32_t qn = 0;   // wave-uniform
-    // j in blocks of 64: one coalesced load of (aa, CA) per block, then wave-uniform broadcasts (v_readlane)
-    const uint32_t j_lo = A.j_span ? A.wi_j0[w] : r0;
-    const uint32_t j_hi = A.j_span ? (j_lo + A.j_span < r1 ? j_lo + A.j_span : r1) : r1;
-    for (uint32_t jb = j_lo; jb < j_hi; jb += FD_WAVE) {
-        const uint32_t jl = jb + lane;
-        const bool jin = jl < j_hi;
-        const uint32_t aaj_l = jin ? A.B.aa[jl] : 255u;
-        fd_v3 cj = {0.f, 0.f, 0.f};
-        if (jin) cj = fd_load3(A.B.ca_xyz, jl);
-        bool okj = jin && aaj_l != 255u && (tert || A.B.hash_ok[jl]);
-        if (!full) okj = okj && aaj_l < 20u && (A.resname_std == nullptr || A.resname_std[jl]) && ((Sx.aa2_mask >> aaj_l) & 1u);
-        if (A.cj_mask && okj) { const uint32_t bit = A.mask_off[slot] + (jl - r0); okj = (A.cj_mask[bit >> 5] >> (bit & 31u)) & 1u; }
+    // per block: the partners that can pass at all (their own filters: ~1 in 5 for a motif query's residue types) are walked, wave-uniform broadcasts (v_readlane)
+    for (uint32_t g0 = j_lo; g0 < j_hi; g0 += 4u * FD_WAVE) {
+        if (g0 != j_lo) { MP_LOAD_GROUP(g0) }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t jb = g0 + (uint32_t)u * FD_WAVE;
+        if (jb >= j_hi) break;      // (wave-uniform)
+        const uint32_t aaj_l = pa[u];
+        const fd_v3 cj = pc[u];
+        bool okj = aaj_l != 255u && pok[u];
+        if (!full) okj = okj && aaj_l < 20u && ((Sx.aa2_mask >> aaj_l) & 1u);
         const uint64_t okm = __ballot(okj);
-        // only the partners that can pass at all (their own filters: ~1 in 5 for a motif query's residue types) are walked: the scan is
-        // instruction-bound and the scalar bookkeeping of a skipped partner was a fifth of a visited one's
-        const bool last_blk = jb + FD_WAVE >= j_hi;
         uint64_t todo = okm;
+        if (A.dbg) n_vis += (unsigned long long)__popcll(okm);
         while (todo) {
             const uint32_t k = (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1ull;
-            {
-                const uint32_t j = jb + k;
-                const uint32_t aaj = (uint32_t)__builtin_amdgcn_readlane((int)aaj_l, (int)k);
-                const fd_v3 caj = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cj.x), (int)k)),
-                                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cj.y), (int)k)),
-                                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cj.z), (int)k))};
-                bool pass = false;
-                if (act && i != j && aaj < 32u && ((row_mask >> aaj) & 1u)) {
-                    // the cutoff on the SQUARED distance (d2_max = the largest f32 whose square root is <= the cutoff: the same decision as sqrt(d2) <= cutoff
-                    // without a correctly rounded square root per pair test — the scan is instruction-bound: ~40 instructions per partner residue)
-                    const float d2 = fd_dist2(cai, caj);
-                    if (d2 <= d2_max_v) {
-                        const float d = fd_sqrtf(d2);
-                        // branch-free over the pair's own list: a short-circuit chain costs one LDS round trip per entry
-                        uint32_t any = 0;
-                        if (big) {
-                            // a whole-structure query observes ~100 distances per residue-type pair and keeps them in global memory.  The
-                            // window test only asks whether ANY of them is within the window of d: the host merged, per pair of types, the
-                            // float intervals [lo_x, hi_x] = {d : |d - x| < window} of all observed x (exact: |d - x| is monotone in d on
-                            // either side of x) — usually ONE interval per pair of types — so the test is one offset load and one or two
-                            // independent interval loads instead of a walk over the list
-                            const uint32_t gw = s_start[aai * 32u + aaj], v0 = gw >> 8, vn = gw & 255u;      // the group's intervals, from LDS
-                            if (vn < 255u && v0 + vn <= 1024u) {
-                                for (uint32_t e = 0; e < vn; ++e) { const float2 w2 = reinterpret_cast<const float2 *>(s_d_buf)[v0 + e]; any |= (uint32_t)(d >= w2.x && d <= w2.y); }
-                            } else {
-                                const uint32_t v_lo = Sx.iv_start[aai * 32u + aaj], v_hi = Sx.iv_start[aai * 32u + aaj + 1];
-                                for (uint32_t e = v_lo; e < v_hi; ++e) { const float2 w2 = Sx.iv[e]; any |= (uint32_t)(d >= w2.x && d <= w2.y); }
-                            }
+            const uint32_t j = jb + k;
+            const uint32_t aaj = (uint32_t)__builtin_amdgcn_readlane((int)aaj_l, (int)k);
+            const fd_v3 caj = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cj.x), (int)k)),
+                               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cj.y), (int)k)),
+                               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cj.z), (int)k))};
+            bool pass = false;
+            if (act && i != j && aaj < 32u && ((row_mask >> aaj) & 1u)) {
+                // the cutoff on the SQUARED distance (d2_max = the largest f32 whose square root is <= the cutoff: the same decision as sqrt(d2) <= cutoff
+                // without a correctly rounded square root per pair test)
+                const float d2 = fd_dist2(cai, caj);
+                if (d2 <= d2_max_v) {
+                    const float d = fd_sqrtf(d2);
+                    // branch-free over the pair's own list: a short-circuit chain costs one LDS round trip per entry
+                    uint32_t any = 0;
+                    if (big) {
+                        // a whole-structure query observes ~100 distances per residue-type pair and keeps them in global memory.  The
+                        // window test only asks whether ANY of them is within the window of d: the host merged, per pair of types, the
+                        // float intervals [lo_x, hi_x] = {d : |d - x| < window} of all observed x (exact: |d - x| is monotone in d on
+                        // either side of x) — usually ONE interval per pair of types — so the test is one offset load and one or two
+                        // independent interval loads instead of a walk over the list
+                        const uint32_t gw = s_start[aai * 32u + aaj], v0 = gw >> 8, vn = gw & 255u;      // the group's intervals, from LDS
+                        if (vn < 255u && v0 + vn <= 1024u) {
+                            for (uint32_t e = 0; e < vn; ++e) { const float2 w2 = reinterpret_cast<const float2 *>(s_d_buf)[v0 + e]; any |= (uint32_t)(d >= w2.x && d <= w2.y); }
                         } else {
-                            // (two loops: through the generic pointer dist_tab these would be flat loads even when the list is in LDS)
-                            const uint32_t e_lo = s_start[aai * 32u + aaj], e_hi = s_start[aai * 32u + aaj + 1];
-                            if (staged) for (uint32_t e = e_lo; e < e_hi; ++e) any |= (uint32_t)(fd_fabsf(d - s_d_buf[e]) < ca_window_v);
-                            else for (uint32_t e = e_lo; e < e_hi; ++e) any |= (uint32_t)(fd_fabsf(d - Sx.aad_dist[e]) < ca_window_v);
+                            const uint32_t v_lo = Sx.iv_start[aai * 32u + aaj], v_hi = Sx.iv_start[aai * 32u + aaj + 1];
+                            for (uint32_t e = v_lo; e < v_hi; ++e) { const float2 w2 = Sx.iv[e]; any |= (uint32_t)(d >= w2.x && d <= w2.y); }
                         }
-                        pass = any != 0;
+                    } else {
+                        const uint32_t e_lo = s_start[aai * 32u + aaj], e_hi = s_start[aai * 32u + aaj + 1];
+                        if (staged) for (uint32_t e = e_lo; e < e_hi; ++e) any |= (uint32_t)(fd_fabsf(d - s_d_buf[e]) < ca_window_v);
+                        else for (uint32_t e = e_lo; e < e_hi; ++e) any |= (uint32_t)(fd_fabsf(d - Sx.aad_dist[e]) < ca_window_v);
                     }
-                }
-                const uint64_t m = __ballot(pass);
-                if (m) {
-                    if (pass) q[qn + fd_mbcnt(m)] = ((i - r0) << 16) | (j - r0);
-                    qn += (uint32_t)__popcll(m);
+                    pass = any != 0;
                 }
             }
-            while (qn >= FD_WAVE) {      // (wave-scope fences: one wavefront per workgroup, the queue is LDS — no wait for the drain's record stores)
-                fd_wave_lds_fence();
-                qn -= FD_WAVE;
-                const unsigned long long td = A.dbg ? wall_clock64() : 0ull;
-                match_drain<EMIT>(A, Sx, q + qn, FD_WAVE, slot, r0, r1, st_tab, dist_tab, tab, staged_h ? s_qh : nullptr);
-                if (A.dbg) { tk_dr += wall_clock64() - td; ++n_dr; }
-                fd_wave_lds_fence();
+            const uint64_t m = __ballot(pass);
+            if (m) {
+                if (pass) q[qn + fd_mbcnt(m)] = ((i - r0) << 16) | (j - r0);
+                qn += (uint32_t)__popcll(m);
+                if (qn >= FD_WAVE) {      // (wave-scope fences: one wavefront per workgroup, the queue is LDS)
+                    fd_wave_lds_fence();
+                    qn -= FD_WAVE;
+                    push(q + qn, FD_WAVE);
+                    fd_wave_lds_fence();
+                }
             }
-        }
-        while (last_blk && qn) {      // the item's last partners are behind it: what is left in the queue
-            fd_wave_lds_fence();
-            const uint32_t n = qn < FD_WAVE ? qn : FD_WAVE;
-            qn -= n;
-            const unsigned long long td = A.dbg ? wall_clock64() : 0ull;
-            match_drain<EMIT>(A, Sx, q + qn, n, slot, r0, r1, st_tab, dist_tab, tab, staged_h ? s_qh : nullptr);
-            if (A.dbg) { tk_dr += wall_clock64() - td; ++n_dr; }
-            fd_wave_lds_fence();
         }
     }
+    }
+#undef MP_LOAD_GROUP
+    if (qn) { fd_wave_lds_fence(); push(q, qn); }
     if (A.dbg && threadIdx.x == 0) {
-        const unsigned long long t3 = wall_clock64();
-        atomicAdd(&A.dbg[0], 1ull); atomicAdd(&A.dbg[1], tk1 - tk0); atomicAdd(&A.dbg[2], tk2 - tk1); atomicAdd(&A.dbg[3], t3 - tk2);
-        atomicAdd(&A.dbg[4], n_dr); atomicAdd(&A.dbg[5], tk_dr);
+        atomicAdd(&A.dbg[0], 1ull); atomicAdd(&A.dbg[1], wall_clock64() - tk0); atomicAdd(&A.dbg[6], n_vis); atomicAdd(&A.dbg[7], n_q);
+    }
+}
+
+// the chunks of the 64 sub-queues in one order: v in [0, total) -> the chunk's slot.  Every lane loads one sub-queue's count; returns the total
+__device__ __forceinline__ uint32_t mp_chunk_prefix(const mp_args &A, uint32_t lane, uint32_t &incl) {
+    const unsigned long long cn = A.q_cnt[MP_SUBQ_STRIDE * lane];
+    uint32_t x = cn > A.cap_subq ? A.cap_subq : (uint32_t)cn;
+    for (int off = 1; off < FD_WAVE; off <<= 1) { const uint32_t t = __shfl_up(x, off, FD_WAVE); if ((int)lane >= off) x += t; }
+    incl = x;
+    return (uint32_t)__shfl((int)x, FD_WAVE - 1, FD_WAVE);
+}
+__device__ __forceinline__ uint64_t mp_chunk_slot(const mp_args &A, uint32_t incl, uint32_t v) {
+    const uint32_t sq = (uint32_t)__popcll(__ballot(incl <= v));      // sub-queues that end at or before v (wave-uniform)
+    const uint32_t before = sq ? (uint32_t)__shfl((int)incl, (int)sq - 1, FD_WAVE) : 0u;
+    return (uint64_t)sq * A.cap_subq + (v - before);
+}
+
+// one wavefront per chunk of queued pairs (grid-stride: the chunk count stays on the device)
+__global__ __launch_bounds__(FD_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_mp_drain(mp_args A_in) {
+    const mp_args &A = A_in;
+    __shared__ uint32_t tab[64];      // [0, 27) the exact bin tables (bit patterns), [32, 59) the same with clamped float thresholds for the speculative path
+    __shared__ float s_d[MP_AAD_LDS];
+    __shared__ uint32_t s_qh[MP_QH_LDS];
+    const uint32_t lane = threadIdx.x;
+    uint32_t incl;
+    const uint32_t nc = mp_chunk_prefix(A, lane, incl);
+    if (blockIdx.x >= nc) return;
+    tab[lane] = A.bintab[lane];
+    for (uint32_t v = blockIdx.x; v < nc; v += gridDim.x) {
+        const unsigned long long td = A.dbg ? wall_clock64() : 0ull;
+        const uint64_t c = mp_chunk_slot(A, incl, v);
+        const uint4 hd = A.chunk_hdr[c];
+        const uint32_t slot = hd.x, n = hd.y & 255u, tq = hd.y >> 8, r0 = hd.z, r1 = hd.w;
+        mp_sel Sx;
+        mp_select(A_in, tq, Sx);
+        // a motif query's ~44 hashes and its observed distances in LDS: the membership bisection through global memory was six dependent L2 round trips
+        // per drain, every list entry of the window walks one more
+        const bool staged = Sx.n_aad <= MP_AAD_LDS, staged_h = Sx.n_hashes <= MP_QH_LDS;
+        __syncthreads();      // the previous chunk's readers
+        if (staged_h) for (uint32_t e = lane; e < Sx.n_hashes; e += FD_WAVE) s_qh[e] = Sx.q_hashes[e];
+        if (staged) for (uint32_t e = lane; e < Sx.n_aad; e += FD_WAVE) s_d[e] = Sx.aad_dist[e];
+        __syncthreads();
+        match_drain(A, Sx, A.chunk_ij + c * FD_WAVE, n, slot, r0, r1, Sx.aad_start, staged ? s_d : Sx.aad_dist, tab, staged_h ? s_qh : nullptr, v);
+        if (A.dbg && lane == 0) { atomicAdd(&A.dbg[4], 1ull); atomicAdd(&A.dbg[5], wall_clock64() - td); }
+    }
+}
+
+// chunk totals -> first record of every chunk (exclusive sums in chunk order) and the launch's two totals.  One workgroup: a motif batch has ~8,000
+// chunks, a whole-structure query's scan a few ten thousand.
+__global__ __launch_bounds__(1024) void k_mp_offsets(mp_args A) {
+    __shared__ unsigned long long s_w[16], s_h[16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    uint32_t incl;
+    const uint32_t nc = mp_chunk_prefix(A, lane, incl);
+    // thread t owns the chunks [t * per, (t + 1) * per): its sums, one scan over the 1,024 threads, then its chunks' positions (a tile of 1,024 chunks per
+    // round was eight rounds of three barriers for a motif batch: 19 us)
+    const uint32_t per = (nc + 1023u) / 1024u, v0 = t * per, v1 = v0 + per < nc ? v0 + per : nc;
+    unsigned long long xw = 0, xh = 0;
+    uint2 c8[8];      // the thread's first eight totals stay in registers (a motif batch: all of them) — and their loads are independent
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c8[u] = v0 + u < v1 ? A.chunk_cnt[v0 + u] : make_uint2(0u, 0u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { xw += c8[u].x; xh += c8[u].y; }
+    for (uint32_t v = v0 + 8u; v < v1; ++v) { const uint2 cn = A.chunk_cnt[v]; xw += cn.x; xh += cn.y; }
+    const unsigned long long mw = xw, mh = xh;
+    for (int off = 1; off < FD_WAVE; off <<= 1) {
+        const unsigned long long tw = __shfl_up(xw, off, FD_WAVE), th = __shfl_up(xh, off, FD_WAVE);
+        if ((int)lane >= off) { xw += tw; xh += th; }
+    }
+    if (lane == 63u) { s_w[wv] = xw; s_h[wv] = xh; }
+    __syncthreads();
+    unsigned long long bw = xw - mw, bh = xh - mh;      // exclusive inside the wavefront
+    for (uint32_t k = 0; k < wv; ++k) { bw += s_w[k]; bh += s_h[k]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (v0 + u < v1) { A.chunk_base[v0 + u] = make_ulonglong2(bw, bh); bw += c8[u].x; bh += c8[u].y; }
+    for (uint32_t v = v0 + 8u; v < v1; ++v) {
+        const uint2 cn = A.chunk_cnt[v];
+        A.chunk_base[v] = make_ulonglong2(bw, bh);
+        bw += cn.x; bh += cn.y;
+    }
+    if (t == 1023u) { *A.n_cands = bw; *A.n_found = bh; A.n_found[2] = nc; }
+}
+
+// the records of one chunk per wavefront: candidate pairs (one per observed distance inside the pair's window) and found triples (one per bin pair
+// whose hash the query holds), at the positions k_mp_offsets gave the chunk.  Records beyond the caller's buffers are not written (the totals say so:
+// the caller grows the buffers and repeats the launch).
+__global__ __launch_bounds__(FD_WAVE) void k_mp_emit(mp_args A_in) {
+    const mp_args &A = A_in;
+    const uint32_t lane = threadIdx.x;
+    uint32_t incl;
+    const uint32_t nc = mp_chunk_prefix(A, lane, incl);
+    for (uint32_t v = blockIdx.x; v < nc; v += gridDim.x) {
+        const uint2 cn = A.chunk_cnt[v];
+        if (!(cn.x | cn.y)) continue;      // (wave-uniform)
+        const uint64_t c = mp_chunk_slot(A, incl, v);
+        const uint4 hd = A.chunk_hdr[c];
+        const uint32_t slot = hd.x, n = hd.y & 255u, tq = hd.y >> 8, r0 = hd.z;
+        const ulonglong2 base = A.chunk_base[v];
+        const bool on = lane < n;
+        const uint32_t e0 = on ? A.chunk_ij[c * FD_WAVE + lane] : 0u;
+        const uint32_t i = r0 + (e0 >> 16), j = r0 + (e0 & 0xffffu);
+        const uint32_t meta = on ? A.res_meta[(uint64_t)v * FD_WAVE + lane] : 0u, h = A.res_h[(uint64_t)v * FD_WAVE + lane];
+        const float d = A.res_d[(uint64_t)v * FD_WAVE + lane];
+        const uint32_t n_win = meta >> 8, hitmask = meta & 255u, n_hit = (uint32_t)__builtin_popcount(hitmask);
+        uint32_t wi = n_win, hi = n_hit;
+        for (int off = 1; off < FD_WAVE; off <<= 1) {
+            const uint32_t tw = __shfl_up(wi, off, FD_WAVE), th = __shfl_up(hi, off, FD_WAVE);
+            if ((int)lane >= off) { wi += tw; hi += th; }
+        }
+        unsigned long long cpos = base.x + (wi - n_win);
+        const unsigned long long fpos = base.y + (hi - n_hit);
+        const bool fits = on && cpos + n_win <= A.cap_cands && (!n_hit || fpos + n_hit <= A.cap_found);
+        if (fits && n_win) {
+            mp_sel Sx;
+            mp_select(A_in, tq, Sx);
+            const uint32_t key = ((uint32_t)A.B.aa[i] & 31u) * 32u + ((uint32_t)A.B.aa[j] & 31u);
+            const uint32_t e_lo = Sx.aad_start[key], e_hi = Sx.aad_start[key + 1];
+            for (uint32_t e = e_lo; e < e_hi; ++e)
+                if (fd_fabsf(d - Sx.aad_dist[e]) < Sx.ca_window) {
+                    fd_cand_rec cr; cr.cand = slot; cr.qi = Sx.aad_qi[e]; cr.i = i - r0; cr.j = j - r0;
+                    A.cands[cpos++] = cr;
+                }
+        }
+        if (fits && n_hit) {
+            fd_pair_rec p; p.cand = slot; p.i = i - r0; p.j = j - r0;
+            if (A.n_cfg == 1 || hitmask == 1u) { p.hash = h; A.found[fpos] = p; }
+            else {
+                // --multiple-bins: the hash of every bin pair that matched, from the pair's descriptor again (retrieve.rs:124-131)
+                const uint32_t aai = A.B.aa[i], aaj = A.B.aa[j];
+                const fd_feature feat = fd_pair_feature(fd_load3(A.B.n_xyz, i), fd_load3(A.B.ca_xyz, i), fd_load3(A.B.cb_xyz, i),
+                                                        fd_load3(A.B.n_xyz, j), fd_load3(A.B.ca_xyz, j), fd_load3(A.B.cb_xyz, j));
+                unsigned long long fp = fpos;
+                for (uint32_t k = 0; k < A.n_cfg; ++k)
+                    if ((hitmask >> k) & 1u) { p.hash = k == 0 ? h : fd_hash_enc(aai, aaj, feat, A.qk[k]); A.found[fp++] = p; }
+            }
+        }
     }
 }
 
@@ -554,10 +667,15 @@ void fd_launch_mp_items(const uint32_t *db_res_off, const uint32_t *cand, uint32
     if (n_cand) hipLaunchKernelGGL(k_mp_items, dim3((n_cand + 3u) / 4u), dim3(256), 0, st, db_res_off, cand, n_cand, wbase, cq, j_span, wc, wi, wq, wj, aa, hash_ok,
                                    resname_std, tert, qtab, (uint4 *)cinfo, act);
 }
-void fd_launch_match_pairs(const mp_args &A, bool emit, hipStream_t st) {
+void fd_launch_match_pairs(const mp_args &A, hipStream_t st) {
     if (!A.n_work) return;
-    if (emit) hipLaunchKernelGGL(k_match_pairs<true>, dim3(A.n_work), dim3(FD_WAVE), 0, st, A);
-    else hipLaunchKernelGGL(k_match_pairs<false>, dim3(A.n_work), dim3(FD_WAVE), 0, st, A);
+    if (A.compact) hipLaunchKernelGGL(k_mp_scan<true>, dim3(A.n_work), dim3(FD_WAVE), 0, st, A);
+    else hipLaunchKernelGGL(k_mp_scan<false>, dim3(A.n_work), dim3(FD_WAVE), 0, st, A);
+    const uint64_t cap = (uint64_t)A.cap_subq * MP_SUBQ;
+    const uint32_t grid = cap < 8192u ? (cap ? (uint32_t)cap : 1u) : 8192u;
+    hipLaunchKernelGGL(k_mp_drain, dim3(grid), dim3(FD_WAVE), 0, st, A);
+    hipLaunchKernelGGL(k_mp_offsets, dim3(1), dim3(1024), 0, st, A);
+    hipLaunchKernelGGL(k_mp_emit, dim3(grid), dim3(FD_WAVE), 0, st, A);
 }
 
 // ------------------------------------------------------------------------------------------ superposition + similarity metrics
