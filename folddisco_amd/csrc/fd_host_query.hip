@@ -1020,6 +1020,10 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
     A.slot_matches = d_ord + o_sm;
     const bool rs_dbg = getenv("FDGPU_RS_DBG") != nullptr;      // phase clocks of the slots on stderr (measurement aid)
     A.dbg = rs_dbg ? c->ws[WS_RS_CNT].as<unsigned long long>() + 8 : nullptr;
+    uint4 *dbg_slot = nullptr;
+    if (rs_dbg && hipMalloc((void **)&dbg_slot, std::max<uint64_t>(n_cand, 1) * 16) == hipSuccess) (void)hipMemsetAsync(dbg_slot, 0, n_cand * 16, st);
+    struct DbgFree { uint4 *p; ~DbgFree() { if (p) (void)hipFree(p); } } dbg_free{dbg_slot};
+    A.dbg_slot = dbg_slot;
     A.order = getenv("FDGPU_RS_ORDER") && getenv("FDGPU_RS_ORDER")[0] == '0' ? nullptr : d_cur;      // 0: slot order (measurement)
     A.db_res_off = db->res_off; A.db_ca = db->ca_xyz; A.db_cb = db->cb_xyz; A.q_ca = qb->ca_xyz; A.q_cb = qb->cb_xyz;
     A.qt = (const rs_query_dev *)(dblk + o_qt); A.hashes = dblk + o_h; A.kfirst = dblk + o_kf; A.sym = (const uint8_t *)(dblk + o_sy);
@@ -1044,6 +1048,20 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
         HIPCHK(c, hipStreamSynchronize(st));
         memcpy(cnt_h, cv.data(), 32 * 8);
         cnt_h[1] = cv[RS_CNT_STRIDE]; cnt_h[2] = cv[2 * RS_CNT_STRIDE];
+    }
+    if (rs_dbg && dbg_slot) {      // the slots by duration: is the launch its longest slot?
+        std::vector<uint4> ds(n_cand);
+        if (hipMemcpy(ds.data(), dbg_slot, n_cand * 16, hipMemcpyDeviceToHost) == hipSuccess) {
+            std::vector<uint32_t> idx(n_cand);
+            for (uint64_t k = 0; k < n_cand; ++k) idx[k] = (uint32_t)k;
+            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return ds[a].w > ds[b].w; });
+            double sum = 0; uint64_t live = 0, big = 0;
+            for (uint64_t k = 0; k < n_cand; ++k) { sum += ds[k].w; live += ds[k].w ? 1 : 0; big += ds[k].y > 512 ? 1 : 0; }
+            fprintf(stderr, "[rs_slots] %llu slots, %llu with found triples (%llu with more candidate pairs than LDS holds), mean %.1f us; longest (us: found, cands, components):", (unsigned long long)n_cand,
+                    (unsigned long long)live, (unsigned long long)big, live ? sum / live / 100.0 : 0.0);
+            for (uint64_t k = 0; k < std::min<uint64_t>(n_cand, 24); ++k) fprintf(stderr, " %.0f:%u,%u,%u", ds[idx[k]].w / 100.0, ds[idx[k]].x, ds[idx[k]].y, ds[idx[k]].z);
+            fprintf(stderr, "; percentiles 50/90/99: %.0f / %.0f / %.0f us\n", ds[idx[n_cand / 2]].w / 100.0, ds[idx[n_cand / 10]].w / 100.0, ds[idx[n_cand / 100]].w / 100.0);
+        }
     }
     if (rs_dbg) {
         const unsigned long long *d = cnt_h + 8;

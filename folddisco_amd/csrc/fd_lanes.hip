@@ -75,7 +75,8 @@ static void lane_main(fd_lane_pool *P, fdgpu_ctx *lc) {
 
 static uint32_t fd_default_lanes() {
     const char *e = getenv("FDGPU_QUERY_LANES");
-    long v = e ? atol(e) : 4;      // measured at 542,000 structures, batches of 128: 2 lanes 64 k queries/s, 3: 90 k, 4: 105-112 k, 5: 121 k, 8: 117 k (HISTORY.md)
+    long v = e ? atol(e) : 6;      // measured at 542,000 structures, batches of 128 (lanes x batches in flight, warmed): 4x6 150 k queries/s, 4x12 154 k, 5x8 149 k, 6x10 159 k,
+                                   // 8x16 161 k (HISTORY.md); a lane is a sibling context: its own stream, scratch (~1 GB at this size) and worker thread
     return (uint32_t)std::min<long>(std::max<long>(v, 1), 8);
 }
 

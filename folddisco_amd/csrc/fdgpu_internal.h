@@ -492,6 +492,7 @@ struct rs_args {
     const uint32_t *order;                               // launch order of the slots, heaviest first (k_rs_order; null: slot order)
     uint32_t *slot_matches;                              // records every slot wrote (zeroed before the launch; null: not kept)
     unsigned long long *dbg;                             // FDGPU_RS_DBG: phase clocks summed over the slots (8 counters), else null
+    uint4 *dbg_slot;                                     // FDGPU_RS_DBG: per slot {found triples, candidate pairs, components, 100 MHz ticks}, else null
     const uint32_t *db_res_off; const float *db_ca, *db_cb, *q_ca, *q_cb;
     const rs_query_dev *qt;
     const uint32_t *hashes, *kfirst; const uint8_t *sym;

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     const uint32_t c0 = A.seg_c[slot], c1 = A.seg_c[slot + 1];
     const bool cands_lds = c1 - c0 <= RS_CAND_LDS;
     unsigned long long tstamp = A.dbg ? wall_clock64() : 0ull;
+    const unsigned long long t_slot0 = tstamp;
     auto stamp = [&](int k) {      // FDGPU_RS_DBG: phase durations summed over the slots (100 MHz ticks)
         if (A.dbg && lane == 0) { const unsigned long long now = wall_clock64(); atomicAdd(&A.dbg[k], now - tstamp); tstamp = now; }
     };
@@ -237,7 +238,10 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     const uint64_t ms = __ballot(scc_rep), mw = __ballot(wcc_rep);
     const uint32_t n_scc = (uint32_t)__popcll(ms), n_comp = n_scc + (uint32_t)__popcll(mw);
     stamp(3);
-    if (n_comp == 0) return;
+    if (n_comp == 0) {
+        if (A.dbg_slot && lane == 0) A.dbg_slot[slot] = make_uint4(F, c1 - c0, 0u, (uint32_t)(wall_clock64() - t_slot0));
+        return;
+    }
     if (lane < NQ) s_idx[lane] = A.indices[Q.idx_off + lane];
     if (cands_lds)
         for (uint32_t x = lane; x < c1 - c0; x += FD_WAVE) {
@@ -449,6 +453,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
         stamp(12);
     }
     stamp(5);
+    if (A.dbg_slot && lane == 0) A.dbg_slot[slot] = make_uint4(F, c1 - c0, n_comp, (uint32_t)(wall_clock64() - t_slot0));
     if (A.dbg && lane == 0) atomicAdd(&A.dbg[6], 1ull);
     if (lane == 0 && A.slot_matches) A.slot_matches[slot] = n_emit;
 }

@@ -197,6 +197,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         return timed(go)
 
     MT_REPS = 12
+    PIPE_SHAPE = (6, 10)    # lanes, batches in flight of the headline leg (the library's default lane count; swept in round 5: 4x6 150 k, 4x12 154 k, 6x10 159 k, 8x16 161 k queries/s)
     PIPE_REPS = 48          # passes over the query set per timed run of the pipelined leg (batches of 128 -> 24 batches in the pipeline)
 
     def batched_mt(workers=2, chunk=32):
@@ -255,10 +256,13 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                     tot += len(pend.popleft().wait()[2][0])
                 return tot
             nm1 = go_pipe(1, 1)
-            for lanes, depth in [tuple(int(y) for y in x.split(":")) for x in os.environ.get("FD_BENCH_PIPE", "4:6").split(",")]:
+            for lanes, depth in [tuple(int(y) for y in x.split(":")) for x in os.environ.get("FD_BENCH_PIPE", "%d:%d" % PIPE_SHAPE).split(",")]:
                 n_l = ctx.L.fdgpu_query_lanes(ctx.h, lanes)
                 assert n_l >= lanes, ctx.L.fdgpu_last_error(ctx.h)
-                go_pipe(2 * n_l, n_l)      # warm-up: every lane allocates its scratch
+                # warm-up AT THE SHAPE that is timed: every lane allocates its scratch, and the result blocks of `depth` batches in flight are page-locked
+                # once (warmed with fewer in flight than timed, the first shape of a run measured 12-18 % below the same shape measured later)
+                go_pipe(2 * n_l, n_l)
+                go_pipe(max(PIPE_REPS // 4, 2), depth)
                 runs = sorted((timed(lambda: go_pipe(PIPE_REPS, depth)) for _ in range(3)), key=lambda x: x[0])
                 assert runs[1][1] == PIPE_REPS * nm1
                 out[(n_l, depth)] = len(queries) * PIPE_REPS / runs[1][0]
@@ -462,8 +466,8 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         except Exception as e:  # noqa: BLE001 — the bench line must still be printed
             cpu = {"error": repr(e)}
 
-    # ONE definition of the headline: the library's default 4 lanes, 6 batches in flight (FD_BENCH_PIPE adds other shapes beside it for measurements)
-    pipe_key = (4, 6) if (4, 6) in pipe else (max(pipe, key=lambda k: pipe[k]) if pipe else None)
+    # ONE definition of the headline: the library's default 6 lanes, 10 batches in flight (FD_BENCH_PIPE adds other shapes beside it for measurements)
+    pipe_key = PIPE_SHAPE if PIPE_SHAPE in pipe else (max(pipe, key=lambda k: pipe[k]) if pipe else None)
     pipe_best = pipe.get(pipe_key) if pipe_key else None
     pipe_depth = pipe_key[1] if pipe_key else None
     return {

@@ -339,7 +339,7 @@ int fdgpu_query_batch(fdgpu_ctx *ctx, const fdgpu_index *index, const fdgpu_batc
  * par_iter_mut); a host with ONE thread per GPU gets that overlap here: submit batches k, k + 1, k + 2, then wait for k, submit k + 3, ... — a
  * lane is a private sibling context (own HIP stream, workspaces, landing blocks) driven by a library thread through fdgpu_query_batch itself, so
  * one batch's host-side steps (table building, waits for counts, result copies) are covered by the other lanes' kernels, and the results are bit
- * for bit those of the blocking call.  Lanes are made on the first submit (default 4, env FDGPU_QUERY_LANES, or fdgpu_query_lanes beforehand;
+ * for bit those of the blocking call.  Lanes are made on the first submit (default 6, env FDGPU_QUERY_LANES, or fdgpu_query_lanes beforehand;
  * each lane holds its own query scratch in HBM — ~1 GB for batches of 128 queries at 542,000 structures) and are torn down by fdgpu_destroy.
  * Inputs: the per-query arrays (q_struct, q_off, q_index, subs, n_subs, thresholds, *p) are COPIED at submit; index, db, qb, resname_std and
  * penalty are borrowed until the wait returns.  Every submitted job must be waited for exactly once (that releases it); passing NULL output

@@ -47,7 +47,7 @@ print("== ONE host thread, batches of 128 full motif queries, %s structures: too
 for tag, name in (("block", "blocking fdgpu_query_batch"), ("pipe", "fdgpu_query_batch_submit / _wait, lanes x in flight = " + shape)):
     plain, traced = line(out + "/r5_pp_%s_plain.log" % tag), line(out + "/r5_pp_%s_traced.log" % tag)
     rows = timed_region(load(tag))
-    n_b = sum(1 for r in rows if r[2].startswith("k_match_pairs")) or 1
+    n_b = sum(1 for r in rows if r[2].startswith("k_mp_scan")) or 1
     span = rows[-1][1] - rows[0][0] if rows else 0
     busy = union(rows)
     print("\n-- %s --" % name)
