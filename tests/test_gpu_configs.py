@@ -275,7 +275,7 @@ def test_pipelined_submit_wait_equals_the_blocking_call(human):
     assert ctx.L.fdgpu_query_lanes(ctx.h, 0) == 0
     for rnd in range(3):
         jobs = [fq.query_batch_submit(ctx, ix, batch, qall, q, float(HUMAN), tn, mt) for q, tn, mt in jobs_in]
-        assert ctx.L.fdgpu_query_lanes(ctx.h, 0) == 4          # the default number of lanes, made by the first submit
+        assert ctx.L.fdgpu_query_lanes(ctx.h, 0) == 6          # the default number of lanes, made by the first submit
         mid = fq.query_batch(ctx, ix, batch, qall, jobs_in[1][0], float(HUMAN), 40, 8)      # the caller's own context while its lanes are busy
         same(refs[1], mid)
         order = list(range(len(jobs)))[::-1] if rnd == 1 else list(range(len(jobs)))
@@ -292,7 +292,8 @@ def test_pipelined_submit_wait_equals_the_blocking_call(human):
         bad.wait()
     with pytest.raises(RuntimeError):
         bad.wait()
-    assert ctx.L.fdgpu_query_lanes(ctx.h, 5) == 5
+    assert ctx.L.fdgpu_query_lanes(ctx.h, 5) == 6          # lanes are only added: five asked for, six there
+    assert ctx.L.fdgpu_query_lanes(ctx.h, 7) == 7
     same(refs[0], fq.query_batch_submit(ctx, ix, batch, qall, jobs_in[0][0], float(HUMAN), 1000, 25).wait())
 
 
