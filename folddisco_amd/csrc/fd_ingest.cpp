@@ -186,6 +186,41 @@ bool read_all(const char *path, std::string *out) {
     return true;
 }
 
+// The common shapes of a PDB record's numeric columns, read without the general parsers: a right-aligned "%W.Df" field = [spaces][-]digits '.' D digits
+// filling the column, a right-aligned unsigned integer = [spaces]digits.  Value = mantissa / 10^D in ONE f32 division, exactly what parse_f32's own fast
+// path computes for the same characters; anything else (exponents, '+', inner blanks, no digit before the point, short lines) -> false and the caller takes
+// the general parser, which decides as Rust's str::parse does.
+template <int W, int D>
+inline bool fixed_f32(const char *s, float *out) {
+    static const float P10[4] = {1.0f, 1e1f, 1e2f, 1e3f};
+    constexpr int I = W - D - 1;      // index of the decimal point
+    if (s[I] != '.') return false;
+    uint32_t frac = 0;
+    for (int k = I + 1; k < W; ++k) { const uint32_t d = (uint32_t)(s[k] - '0'); if (d > 9u) return false; frac = frac * 10u + d; }
+    int k = 0;
+    while (k < I && s[k] == ' ') ++k;
+    const bool neg = k < I && s[k] == '-';
+    k += neg ? 1 : 0;
+    if (k >= I) return false;         // no digit before the point
+    uint32_t ip = 0;
+    for (; k < I; ++k) { const uint32_t d = (uint32_t)(s[k] - '0'); if (d > 9u) return false; ip = ip * 10u + d; }
+    uint32_t sc = 1;
+    for (int z = 0; z < D; ++z) sc *= 10u;
+    const float v = (float)(ip * sc + frac) / P10[D];      // ip < 10^4, D <= 3: the mantissa is below 2^24
+    *out = neg ? -v : v;
+    return true;
+}
+template <int W>
+inline bool fixed_u64(const char *s, uint64_t *out) {
+    int k = 0;
+    while (k < W && s[k] == ' ') ++k;
+    if (k >= W) return false;
+    uint64_t v = 0;
+    for (; k < W; ++k) { const uint32_t d = (uint32_t)(s[k] - '0'); if (d > 9u) return false; v = v * 10u + d; }
+    *out = v;
+    return true;
+}
+
 // all_models: the reference's gzip reader (read_structure_from_gz, structure/io/pdb.rs:79-124) has no MODEL handling — it keeps the
 // ATOM records of EVERY model, unlike the plain-file reader (pdb.rs:37-77) which stops behind the first one
 void parse_pdb(const std::string &txt, std::vector<Atom> *atoms, bool all_models) {
@@ -204,10 +239,11 @@ void parse_pdb(const std::string &txt, std::vector<Atom> *atoms, bool all_models
         if (memcmp(L, "ATOM  ", 6) || len < 54) continue;
         Atom a;
         uint64_t aser;
-        if (!parse_f32(L + 30, 8, &a.x) || !parse_f32(L + 38, 8, &a.y) || !parse_f32(L + 46, 8, &a.z)) continue;
-        if (!parse_u64(L + 6, 5, &aser) || !parse_u64(L + 22, 4, &a.rser)) continue;
+        if (!(fixed_f32<8, 3>(L + 30, &a.x) || parse_f32(L + 30, 8, &a.x)) || !(fixed_f32<8, 3>(L + 38, &a.y) || parse_f32(L + 38, 8, &a.y)) ||
+            !(fixed_f32<8, 3>(L + 46, &a.z) || parse_f32(L + 46, 8, &a.z))) continue;
+        if (!(fixed_u64<5>(L + 6, &aser) || parse_u64(L + 6, 5, &aser)) || !(fixed_u64<4>(L + 22, &a.rser) || parse_u64(L + 22, 4, &a.rser))) continue;
         a.b = 1.0f;
-        if (len >= 66 && !parse_f32(L + 60, 6, &a.b)) continue;
+        if (len >= 66 && !(fixed_f32<6, 2>(L + 60, &a.b) || parse_f32(L + 60, 6, &a.b))) continue;
         memcpy(a.name, L + 12, 4);
         memcpy(a.res, L + 17, 3);
         a.chain = (uint8_t)L[21];
