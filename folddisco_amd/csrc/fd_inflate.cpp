@@ -6,7 +6,8 @@
 // (10 bits for literals / lengths, 9 for distances) whose entries carry base value, extra-bit count and the symbol's TOTAL bit count, word-wise match
 // copies into a buffer with slack.  PDB text decodes as ~99 % short matches (average length 8: the previous line's columns), so the loop is shaped for the
 // chain lookup -> shift -> lookup of a match: one shift per symbol (extra bits are read from the buffer as it was before the shift), the table index taken
-// from the bits left over before the refill's load arrives, sixteen bytes copied without a length test (round 5: 620 -> 870 MB/s per thread here).  Anything it does not expect (reserved block type, over-subscribed or incomplete code, distance beyond the output, CRC / size mismatch,
+// from the bits left over before the refill's load arrives, sixteen bytes copied without a length test (round 5: 620 -> 870 MB/s per thread here).
+// Anything it does not expect (reserved block type, over-subscribed or incomplete code, distance beyond the output, CRC / size mismatch,
 // truncated input) makes it return false and the caller falls back to zlib, which then reports the file the way it always did.
 // The reference reads gzip through the flate2 crate (src/structure/io/pdb.rs:79-124); a decoder's output is defined by the format.
 #include <cstdint>
@@ -163,15 +164,17 @@ void make_fixed() {
 }
 
 // one deflate stream from B into out (appended); -> false on anything unexpected
-bool inflate_stream(Bits &B, std::string &out, size_t expect) {
-    const size_t start = out.size();
+// `start` = bytes of out that are output already (earlier members); what out holds behind them is scratch: the string is only ever GROWN here (a
+// std::string zero-fills what resize adds — the caller reuses one string per thread, so after the first files nothing is filled) and cut to the
+// produced length by the caller at the very end; *end = start + the bytes this stream produced
+bool inflate_stream(Bits &B, std::string &out, size_t start, size_t expect, size_t *end) {
     size_t cap = start + (expect ? expect : (size_t)(B.end - B.p) * 4) + 1024;
-    out.resize(cap);
+    if (out.size() < cap) out.resize(cap); else cap = out.size();
     uint8_t *base = (uint8_t *)&out[0], *o = base + start, *lim = base + cap - 320;      // 258 of a match + a word of over-copy + slack
     auto grow = [&]() {
         const size_t at = (size_t)(o - base);
         cap = cap + cap / 2 + 65536;
-        out.resize(cap);
+        out.resize(cap);      // (keeps the bytes written so far)
         base = (uint8_t *)&out[0]; o = base + at; lim = base + cap - 320;
     };
     Table dyn_lit, dyn_dist;
@@ -298,7 +301,7 @@ bool inflate_stream(Bits &B, std::string &out, size_t expect) {
         } else return false;
         if (final) break;
     }
-    out.resize((size_t)(o - base));
+    *end = (size_t)(o - base);
     return true;
 }
 
@@ -386,8 +389,8 @@ uint32_t crc32_fast(const uint8_t *p, size_t n) {
 }  // namespace
 
 bool fd_gunzip(const uint8_t *in, size_t n, std::string *out) {
-    out->clear();
-    size_t at = 0;
+    size_t at = 0, have = 0;      // have: output bytes so far (out itself is cut to it on return)
+    struct Cut { std::string *s; size_t *n; bool ok = false; ~Cut() { s->resize(ok ? *n : 0); } } cut{out, &have};
     bool any = false;
     while (at + 18 <= n && in[at] == 0x1f && in[at + 1] == 0x8b) {
         if (in[at + 2] != 8) return false;
@@ -404,19 +407,20 @@ bool fd_gunzip(const uint8_t *in, size_t n, std::string *out) {
         const uint32_t isize_guess = (uint32_t)in[tail] | ((uint32_t)in[tail + 1] << 8) | ((uint32_t)in[tail + 2] << 16) | ((uint32_t)in[tail + 3] << 24);
         Bits B;
         B.p = in + h; B.end = in + n;
-        const size_t before = out->size();
+        const size_t before = have;
         // (deflate cannot expand beyond 1032 : 1: a trailer that claims more is damaged, and must not size an allocation)
         const size_t max_out = (n - h) * 1032 + 1024;
-        if (!inflate_stream(B, *out, any ? 0 : (isize_guess < max_out ? isize_guess : max_out))) return false;
+        if (!inflate_stream(B, *out, before, any ? 0 : (isize_guess < max_out ? isize_guess : max_out), &have)) return false;
         const uint8_t *q = B.byte_pos();
         if (B.over || q + 8 > in + n) return false;
         const uint32_t crc = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
         const uint32_t isz = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
-        const size_t produced = out->size() - before;
+        const size_t produced = have - before;
         if ((uint32_t)produced != isz) return false;
         if (crc32_fast((const uint8_t *)out->data() + before, produced) != crc) return false;
         at = (size_t)(q + 8 - in);
         any = true;
     }
+    cut.ok = any;
     return any;       // (bytes behind the last member that do not start another one are ignored, as zlib's gzread ignores them)
 }
