@@ -2078,11 +2078,13 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     // wavefront walks its partners one at a time (128 queries x 32 candidates, k_mp_scan: 93 us at 512, 68 at 256, 60 at 128 — where the drains, one per
     // partly filled chunk, have grown by as much)
     // large queries (whole-structure: the window test passes nearly every pair inside the cutoff, so a work item's time is its number of close
-    // pairs x one descriptor + hash each): spans of 32 partners — a diagonal block of 64 x 128 residues was 128 drains on ONE wavefront and the
-    // launch lasted as long as its slowest wavefronts (first scan of the top 20 of a 300-residue query: 5.1 ms at 128, 4.4 at 64, 3.7 at 32 and 16)
+    // pairs x one descriptor + hash each): while scan and drain were one kernel, a diagonal block of 64 x 128 residues was 128 drains on ONE wavefront and
+    // spans of 32 partners measured best (5.1 ms at 128, 4.4 at 64, 3.7 at 32).  With the drains in their own launch (k_mp_drain, a wavefront per chunk) the
+    // scan's work items only test and queue: 128 partners per item (first + second scan of the top 20 of a 300-residue query: 1.64 + 1.45 ms at 32,
+    // 1.32 + 1.19 at 64, 1.21 + 1.02 at 128, 1.24 + 1.00 at 256)
     uint64_t max_aad_q = 0;
     for (uint64_t t = 0; t < n_queries; ++t) max_aad_q = std::max<uint64_t>(max_aad_q, qs[t].n_aad);
-    uint32_t j_span = !n_tiles ? 0u : max_aad_q > 4096 ? 32u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : 256u;
+    uint32_t j_span = !n_tiles ? 0u : max_aad_q > 4096 ? 128u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : 256u;
     if (const char *js = getenv("FDGPU_MP_JSPAN")) if (n_tiles && atoi(js) >= 32) j_span = (uint32_t)atoi(js) & ~63u ? (uint32_t)atoi(js) & ~31u : 32u;      // (measurement aid)
     TB.j_span = j_span;
     std::vector<uint32_t> wc, wi, wq, wj;
