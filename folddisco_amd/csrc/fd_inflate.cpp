@@ -6,7 +6,7 @@
 // (10 bits for literals / lengths, 9 for distances) whose entries carry base value, extra-bit count and the symbol's TOTAL bit count, word-wise match
 // copies into a buffer with slack.  PDB text decodes as ~99 % short matches (average length 8: the previous line's columns), so the loop is shaped for the
 // chain lookup -> shift -> lookup of a match: one shift per symbol (extra bits are read from the buffer as it was before the shift), the table index taken
-// from the bits left over before the refill's load arrives, sixteen bytes copied without a length test (round 5: 620 -> 870 MB/s per thread here).
+// from the bits left over before the refill's load arrives, thirty-two bytes copied without a length test (round 5: 620 -> 880 MB/s per thread here).
 // Anything it does not expect (reserved block type, over-subscribed or incomplete code, distance beyond the output, CRC / size mismatch,
 // truncated input) makes it return false and the caller falls back to zlib, which then reports the file the way it always did.
 // The reference reads gzip through the flate2 crate (src/structure/io/pdb.rs:79-124); a decoder's output is defined by the format.
@@ -164,6 +164,82 @@ void make_fixed() {
 }
 
 // one deflate stream from B into out (appended); -> false on anything unexpected
+// one block's symbols: -> 0 at the end-of-block code, 1 when the output is within 320 bytes of its limit (the caller grows the buffer and calls again:
+// the state is in B and o), -1 on anything unexpected.  out0 = first byte of this member's output (matches do not reach behind it).
+__attribute__((noinline)) int decode_symbols(const uint32_t *__restrict__ L, const uint32_t *__restrict__ D, Bits &Bref, uint8_t *&oref, const uint8_t *lim, const uint8_t *out0) {
+    Bits B = Bref;
+    uint8_t *o = oref;
+    int ret;
+    for (;;) {
+        if (o > lim) { ret = 1; break; }
+        // the symbol's table index from the bits that are LEFT when they suffice (nearly always: a match takes ~20 of the >= 56 bits of a refill):
+        // the refill's load then feeds only the upper bits and stays off the chain lookup -> shift -> lookup
+        uint32_t idx;
+        if (__builtin_expect(B.cnt >= LB, 1)) { idx = B.peek(LB); B.refill(); } else { B.refill(); idx = B.peek(LB); }
+        uint32_t e = L[idx];
+        if ((e & 3u) == K_SUB) {
+            if (e == 0xffffffffu || ((e >> 7) & 31u) == 0) { ret = -1; goto done; }
+            B.skip(LB);
+            e = L[(e >> 12) + B.peek((int)((e >> 7) & 31u))];
+            if (e == 0xffffffffu || (e & 3u) == K_SUB) { ret = -1; goto done; }
+        }
+        uint64_t saved = B.buf;
+        B.skip((int)((e >> 2) & 31u));
+        if ((e & 3u) == K_LIT) {
+            *o++ = (uint8_t)(e >> 12);
+            // up to two more literals on the bits that are left (a literal / length code is at most 15 bits: 3 x 15 <= 56)
+            uint32_t e2 = L[B.peek(LB)];
+            if ((e2 & 3u) == K_LIT) {
+                B.skip((int)((e2 >> 2) & 31u));
+                *o++ = (uint8_t)(e2 >> 12);
+                e2 = L[B.peek(LB)];
+                if ((e2 & 3u) == K_LIT) { B.skip((int)((e2 >> 2) & 31u)); *o++ = (uint8_t)(e2 >> 12); }
+            }
+            if (B.cnt < 0) { ret = -1; goto done; }
+            continue;
+        }
+        if ((e & 3u) == K_END) { ret = B.cnt < 0 ? -1 : 0; break; }
+        // length (code <= 15 bits + <= 5 extra), distance (<= 15 + <= 13): 48 <= 56 bits since the refill.  The extra bits are read from the buffer as it
+        // was before the symbol's one shift
+        const uint32_t l_ex = (e >> 7) & 31u;
+        const uint32_t len = (e >> 12) + ((uint32_t)(saved >> (((e >> 2) & 31u) - l_ex)) & ((1u << l_ex) - 1u));
+        uint32_t d = D[B.peek(DB)];
+        if ((d & 3u) == K_SUB) {
+            if (d == 0xffffffffu || ((d >> 7) & 31u) == 0) { ret = -1; goto done; }
+            B.skip(DB);
+            d = D[(d >> 12) + B.peek((int)((d >> 7) & 31u))];
+            if (d == 0xffffffffu || (d & 3u) == K_SUB) { ret = -1; goto done; }
+        }
+        saved = B.buf;
+        B.skip((int)((d >> 2) & 31u));
+        const uint32_t d_ex = (d >> 7) & 31u;
+        const uint32_t dist = (d >> 12) + ((uint32_t)(saved >> (((d >> 2) & 31u) - d_ex)) & ((1u << d_ex) - 1u));
+        if (B.cnt < 0 || dist > (size_t)(o - out0)) { ret = -1; goto done; }      // (matches never reach into an earlier member)
+        const uint8_t *src = o - dist;
+        uint8_t *dst = o;
+        o += len;
+        if (dist >= 8) {
+            // words of eight: the source stays at least eight bytes behind the destination; up to 29 bytes past the match are written (and overwritten
+            // later: the buffer keeps 320 bytes of slack).  Four words without a test — half the matches of PDB text are longer than eight bytes, a
+            // fifth longer than sixteen: a coin flip per match for the branch predictor; a word may read what the one before it wrote (program order)
+            { uint64_t w; memcpy(&w, src, 8); memcpy(dst, &w, 8); memcpy(&w, src + 8, 8); memcpy(dst + 8, &w, 8);
+              memcpy(&w, src + 16, 8); memcpy(dst + 16, &w, 8); memcpy(&w, src + 24, 8); memcpy(dst + 24, &w, 8); }
+            if (len > 32) {
+                src += 32; dst += 32;
+                do { uint64_t w; memcpy(&w, src, 8); memcpy(dst, &w, 8); src += 8; dst += 8; } while (dst < o);
+            }
+        } else if (dist == 1) {
+            memset(dst, *src, len);
+        } else {
+            do { *dst++ = *src++; } while (dst < o);
+        }
+    }
+done:
+    Bref = B;
+    oref = o;
+    return ret;
+}
+
 // `start` = bytes of out that are output already (earlier members); what out holds behind them is scratch: the string is only ever GROWN here (a
 // std::string zero-fills what resize adds — the caller reuses one string per thread, so after the first files nothing is filled) and cut to the
 // produced length by the caller at the very end; *end = start + the bytes this stream produced
@@ -234,69 +310,13 @@ bool inflate_stream(Bits &B, std::string &out, size_t start, size_t expect, size
                 else { dyn_dist.e.assign((size_t)1 << DB, 0xffffffffu); dyn_dist.pbits = DB; }
                 TL = &dyn_lit; TD = &dyn_dist;
             }
-            const uint32_t *L = TL->e.data(), *D = TD->e.data();
+            // the symbols of the block (decode_symbols, its own function: as part of this one its bit count and input pointers lived on the stack);
+            // 1 = the output buffer is nearly full: grown here, continued
             for (;;) {
-                if (o > lim) grow();
-                // the symbol's table index from the bits that are LEFT when they suffice (nearly always: a match takes ~20 of the >= 56 bits of a refill):
-                // the refill's load then feeds only the upper bits and stays off the chain lookup -> shift -> lookup
-                uint32_t idx;
-                if (__builtin_expect(B.cnt >= LB, 1)) { idx = B.peek(LB); B.refill(); } else { B.refill(); idx = B.peek(LB); }
-                uint32_t e = L[idx];
-                if ((e & 3u) == K_SUB) {
-                    if (e == 0xffffffffu || ((e >> 7) & 31u) == 0) return false;
-                    B.skip(LB);
-                    e = L[(e >> 12) + B.peek((int)((e >> 7) & 31u))];
-                    if (e == 0xffffffffu || (e & 3u) == K_SUB) return false;
-                }
-                uint64_t saved = B.buf;
-                B.skip((int)((e >> 2) & 31u));
-                if ((e & 3u) == K_LIT) {
-                    *o++ = (uint8_t)(e >> 12);
-                    // up to two more literals on the bits that are left (a literal / length code is at most 15 bits: 3 x 15 <= 56)
-                    uint32_t e2 = L[B.peek(LB)];
-                    if ((e2 & 3u) == K_LIT) {
-                        B.skip((int)((e2 >> 2) & 31u));
-                        *o++ = (uint8_t)(e2 >> 12);
-                        e2 = L[B.peek(LB)];
-                        if ((e2 & 3u) == K_LIT) { B.skip((int)((e2 >> 2) & 31u)); *o++ = (uint8_t)(e2 >> 12); }
-                    }
-                    if (B.cnt < 0) return false;
-                    continue;
-                }
-                if ((e & 3u) == K_END) { if (B.cnt < 0) return false; break; }
-                // length (code <= 15 bits + <= 5 extra), distance (<= 15 + <= 13): 48 <= 56 bits since the refill.  The extra bits are read from the buffer as it
-                // was before the symbol's one shift
-                const uint32_t l_ex = (e >> 7) & 31u;
-                const uint32_t len = (e >> 12) + ((uint32_t)(saved >> (((e >> 2) & 31u) - l_ex)) & ((1u << l_ex) - 1u));
-                uint32_t d = D[B.peek(DB)];
-                if ((d & 3u) == K_SUB) {
-                    if (d == 0xffffffffu || ((d >> 7) & 31u) == 0) return false;
-                    B.skip(DB);
-                    d = D[(d >> 12) + B.peek((int)((d >> 7) & 31u))];
-                    if (d == 0xffffffffu || (d & 3u) == K_SUB) return false;
-                }
-                saved = B.buf;
-                B.skip((int)((d >> 2) & 31u));
-                const uint32_t d_ex = (d >> 7) & 31u;
-                const uint32_t dist = (d >> 12) + ((uint32_t)(saved >> (((d >> 2) & 31u) - d_ex)) & ((1u << d_ex) - 1u));
-                if (B.cnt < 0 || dist > (size_t)(o - base) - start) return false;      // (matches never reach into an earlier member)
-                const uint8_t *src = o - dist;
-                uint8_t *dst = o;
-                o += len;
-                if (dist >= 8) {
-                    // words of eight: the source stays at least eight bytes behind the destination, up to seven bytes past the match are overwritten later
-                    // (two words without a test — half the matches of PDB text are longer than eight bytes, a coin flip per match for the branch predictor; the
-                    // second word may read what the first one wrote: the copies are in program order)
-                    { uint64_t w; memcpy(&w, src, 8); memcpy(dst, &w, 8); memcpy(&w, src + 8, 8); memcpy(dst + 8, &w, 8); }
-                    if (len > 16) {
-                        src += 16; dst += 16;
-                        do { uint64_t w; memcpy(&w, src, 8); memcpy(dst, &w, 8); src += 8; dst += 8; } while (dst < o);
-                    }
-                } else if (dist == 1) {
-                    memset(dst, *src, len);
-                } else {
-                    do { *dst++ = *src++; } while (dst < o);
-                }
+                const int rc = decode_symbols(TL->e.data(), TD->e.data(), B, o, lim, base + start);
+                if (rc == 0) break;
+                if (rc < 0) return false;
+                grow();
             }
         } else return false;
         if (final) break;
