@@ -62,15 +62,35 @@ const char *AA_GROUPS[20] = {
     "SER CSH SEP DSN SAC GYS DHA OAS", "THR TPO CRO DTH BMT CRF", "TRP DTR TRQ TOX 0AF", "TYR PTR TYS TPQ DTY OMY",
     "VAL DVA MVA FVA"};
 
-uint8_t map_aa(const char r[3], bool *is_std) {
-    *is_std = false;
-    for (int k = 0; k < 20; ++k) {
-        const char *g = AA_GROUPS[k];
-        for (int pos = 0; g[pos]; pos += 4) {
-            if (g[pos] == r[0] && g[pos + 1] == r[1] && g[pos + 2] == r[2]) { *is_std = pos == 0; return (uint8_t)k; }
-            if (!g[pos + 3]) break;
+// residue name -> amino-acid index (src/utils/convert.rs:53-81), is_std = the group's first (canonical) name.  A 1,024-slot open-addressing table over
+// the ~120 names, made on first use: the walk over the twenty groups was ~60 three-byte comparisons per residue
+struct AaTab {
+    uint32_t key[1024];      // name bytes | 1 << 24 (0 = empty)
+    uint8_t val[1024];       // index | is_std << 7
+    AaTab() {
+        memset(key, 0, sizeof key); memset(val, 0, sizeof val);
+        for (int k = 0; k < 20; ++k) {
+            const char *g = AA_GROUPS[k];
+            for (int pos = 0;; pos += 4) {
+                const uint32_t nm = (uint32_t)(uint8_t)g[pos] | ((uint32_t)(uint8_t)g[pos + 1] << 8) | ((uint32_t)(uint8_t)g[pos + 2] << 16) | (1u << 24);
+                uint32_t at = slot(nm);
+                while (key[at] && key[at] != nm) at = (at + 1) & 1023u;
+                if (!key[at]) { key[at] = nm; val[at] = (uint8_t)(k | (pos == 0 ? 0x80 : 0)); }      // (a name listed twice keeps its first group, as the walk did)
+                if (!g[pos + 3]) break;
+            }
         }
     }
+    static uint32_t slot(uint32_t nm) { return ((nm * 2654435761u) >> 22) & 1023u; }
+};
+uint8_t map_aa(const char r[3], bool *is_std) {
+    static const AaTab T;
+    const uint32_t nm = (uint32_t)(uint8_t)r[0] | ((uint32_t)(uint8_t)r[1] << 8) | ((uint32_t)(uint8_t)r[2] << 16) | (1u << 24);
+    uint32_t at = AaTab::slot(nm);
+    while (T.key[at]) {
+        if (T.key[at] == nm) { *is_std = (T.val[at] & 0x80) != 0; return (uint8_t)(T.val[at] & 0x7f); }
+        at = (at + 1) & 1023u;
+    }
+    *is_std = false;
     return 255;
 }
 
@@ -379,6 +399,11 @@ void build_compact(const std::vector<Atom> &atoms, Compact *C) {
     if (!atoms.empty()) C->first_chain = atoms[0].chain;
     uint64_t rec_serial = 0;
     for (const Atom &a : atoms) if (rec_serial != a.rser) { ++C->nres_raw; rec_serial = a.rser; }
+    {   // at most one residue per change of the residue number
+        const size_t r = (size_t)C->nres_raw;
+        C->n.reserve(3 * r); C->ca.reserve(3 * r); C->cb.reserve(3 * r); C->cb_ok.reserve(r); C->serial.reserve(r); C->resname.reserve(3 * r);
+        C->aa.reserve(r); C->std_name.reserve(r); C->chain.reserve(r); C->bfac.reserve(r);
+    }
     bool have_prev = false, hn = false, hca = false, hcb = false, hc = false, hgn = false, hgc = false;
     uint64_t prev_serial = 0;
     char prev_name[3] = {' ', ' ', ' '};

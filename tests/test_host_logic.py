@@ -618,3 +618,30 @@ def test_squared_distance_table_equals_sqrt_and_quantiser():
         got = b + (x >= thr[b + 1]).astype(np.int64) - (x < thr[b]).astype(np.int64)
         ok = np.abs(b - want) <= 1
         assert np.array_equal(got[ok], want[ok])
+
+
+def test_residue_name_table_matches_oracle(tmp_path):
+    """The ingest's residue-name table (a hash table since round 5; src/utils/convert.rs:53-81) against the oracle's map for every listed name — canonical
+    and modified — plus names it must not know (lower case, shifted, nucleotides, water); resname_std is set for the canonical names only."""
+    import oracle
+    from folddisco_amd.structure import read_compact_structures
+    groups = ["ALA ABA ORN DAL AIB ALC MDO MAA DAB", "ARG DAR CIR AGM", "ASN DSG MEN SNN", "ASP 0TD DAS IAS PHD BFD ASX",
+              "CYS CSO CSD CME OCS CAS CSX CSS YCM DCY SMC SCH SCY CAF SNC SEC", "GLN DGN CRQ MEQ", "GLU PCA DGL CGU FGA B3E GLX", "GLY CR2 SAR GHP GL3",
+              "HIS HIC DHI NEP CR8 MHS", "ILE DIL", "LEU DLE NLE MLE MK8", "LYS KCX LLP MLY M3L ALY MLZ DLY KPI PYL", "MET MSE FME NRQ CXM SME MHO MED",
+              "PHE DPN PHI MEA PHL", "PRO HYP DPR", "SER CSH SEP DSN SAC GYS DHA OAS", "THR TPO CRO DTH BMT CRF", "TRP DTR TRQ TOX 0AF", "TYR PTR TYS TPQ DTY OMY",
+              "VAL DVA MVA FVA"]
+    names = [n for g in groups for n in g.split()] + ["UNK", "XXX", "HOH", "A  ", " DA", "ala", "GLy", "AL ", "  A"]
+    lines, ser = [], 1
+    for r, nm in enumerate(names, 1):
+        for an, xyz in ((" N  ", (0.0, 0.0, 0.0)), (" CA ", (1.458, 0.0, 0.0)), (" C  ", (2.0, 1.4, 0.0)), (" CB ", (2.0, -0.7, 1.2))):
+            lines.append("ATOM  %5d %s %s A%4d    %8.3f%8.3f%8.3f  1.00 50.00           C" % (ser, an, nm, r, xyz[0] + r * 3.8, xyz[1], xyz[2]))
+            ser += 1
+    p = tmp_path / "names.pdb"
+    p.write_text("\n".join(lines) + "\nEND\n")
+    want = oracle.read_pdb(str(p)).arrays()
+    cs = read_compact_structures([str(p)], threads=1)[0][0]
+    assert len(cs.aa) == len(names)
+    assert np.array_equal(np.asarray(cs.aa), np.asarray(want["aa"]))
+    canonical = {g.split()[0] for g in groups}
+    assert [bool(x) for x in cs.resname_std()] == [n in canonical for n in names]
+    assert [int(a) for a in cs.aa[:9]] == [0] * 9 and int(cs.aa[len(names) - 9]) == 255
