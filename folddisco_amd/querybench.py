@@ -522,7 +522,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
     }
 
 
-def run_replicas(ctx, batch, ix, d, S_total, world, rank, dist, dev, n_queries=64, top_n=1000, match_top=32, seed=4242, chunk=32, reps=12):
+def run_replicas(ctx, batch, ix, d, S_total, world, rank, dist, dev, n_queries=64, top_n=1000, match_top=32, seed=4242, chunk=128, reps=0):
     """SURVEY §8e, last row: the index (26 GB at Swiss-Prot scale, of 288) and the coordinates REPLICATED on every GPU, the queries sharded —
     batch b of `chunk` queries runs on rank b % world through the single-index fused path (no data-path collective), the outputs are
     gathered at the end (here: their counts).  queries/s = all queries / max-over-ranks wall time."""
@@ -535,8 +535,12 @@ def run_replicas(ctx, batch, ix, d, S_total, world, rank, dist, dev, n_queries=6
     ix.set_penalty(length_penalty(nres, 0.5))
     qall = ctx.upload(PackedStructures.concat([it for _, _, it in queries]))
     first = ix.first_id
+    chunk = min(chunk, len(queries))
+    # the shape of the single-GPU headline leg on every rank: batches of 128, ten in flight on the rank's six lanes, 48 batches per rank in the timed run
+    # (twelve batches of 32 dealt to eight ranks was a 2 ms timed region)
+    reps = reps or max(1, (48 * world * chunk) // max(len(queries), 1))
     starts = list(range(0, len(queries), chunk)) * reps
-    LANES = 4
+    LANES = 10
 
     def go():
         tot = 0
