@@ -40,18 +40,41 @@ inline float angle_deg(f3 a, f3 b, f3 c) {
     const float cs = (float)((double)inner / sqrt((double)(s1 * s2)));
     return (float)(acos((double)cs) * 180.0 / M_PI);
 }
-// next atom from three predecessors, bond length, bond angle and torsion (degrees).  This routine mirrors the vendored decoder's
-// place_atom (lib/foldcomp/src/nerf.cpp:39-95) operation for operation — same intermediate roundings — because the coordinates must come out
-// bit-identical to it; everything around it is written from the format.
-inline f3 place_atom(const f3 prev[3], float bond_length, float bond_angle, float torsion_angle) {
-    const f3 a = prev[0], b = prev[1], c = prev[2];
+// sine / cosine of an angle given in degrees, rounded where the format's decoder rounds: degrees -> radians in double, to float, then the
+// float routines.  One sincosf call where the C library's sincosf returns what its sinf and cosf return (glibc: one implementation behind the
+// three, checked exhaustively for |x| <= 16 by tools/check_sincosf.c and sampled again here at start-up); otherwise the two calls.
+struct sc { float c, s; };
+static bool sincosf_is_sinf_cosf() {
+    uint32_t w = 0x9E3779B9u;
+    for (int k = 0; k < 20000; ++k) {
+        w = w * 1664525u + 1013904223u;
+        const float x = (float)((double)(int32_t)w * (3.5 / 2147483648.0));      // [-3.5, 3.5): every angle here is a float of [-pi, pi]
+        float s, c;
+        sincosf(x, &s, &c);
+        const float s2 = sinf(x), c2 = cosf(x);
+        if (memcmp(&s, &s2, 4) || memcmp(&c, &c2, 4)) return false;
+    }
+    return true;
+}
+static const bool g_one_call = sincosf_is_sinf_cosf();
+inline sc sc_deg(float deg) {
+    const float r = (float)((double)deg * M_PI / 180.0);
+    sc o;
+    if (g_one_call) sincosf(r, &o.s, &o.c);
+    else { o.c = cosf(r); o.s = sinf(r); }
+    return o;
+}
+// next atom from three predecessors, bond length, bond angle and torsion (their cosines / sines from sc_deg).  This routine mirrors the
+// vendored decoder's place_atom (lib/foldcomp/src/nerf.cpp:39-95) operation for operation — same intermediate roundings — because the
+// coordinates must come out bit-identical to it; everything around it is written from the format.  The decoder calls cosf / sinf of the two
+// angles inside the routine, five calls per atom; here the values arrive from the caller, which knows that most of them repeat (a torsion
+// serves the forward and the backward chain, the bond angles of the forward chain are 8-bit codes, O and CB have per-type angles and
+// 8-bit torsions): ~7 libm calls per residue instead of 40, the same bits.
+inline f3 place_atom(const f3 &a, const f3 &b, const f3 &c, float bond_length, sc bond, sc tors) {
     const f3 ab = {b.x - a.x, b.y - a.y, b.z - a.z}, bc = {c.x - b.x, c.y - b.y, c.z - b.z};
     const float bc_norm = norm(bc);
     const f3 bcn = {bc.x / bc_norm, bc.y / bc_norm, bc.z / bc_norm};
-    bond_angle = (float)((double)bond_angle * M_PI / 180.0);
-    torsion_angle = (float)((double)torsion_angle * M_PI / 180.0);
-    const f3 cur = {-1 * bond_length * cosf(bond_angle), bond_length * cosf(torsion_angle) * sinf(bond_angle),
-                    bond_length * sinf(torsion_angle) * sinf(bond_angle)};
+    const f3 cur = {-1 * bond_length * bond.c, bond_length * tors.c * bond.s, bond_length * tors.s * bond.s};
     f3 n = cross(ab, bcn);
     const float n_norm = norm(n);
     n.x = n.x / n_norm; n.y = n.y / n_norm; n.z = n.z / n_norm;
@@ -112,6 +135,25 @@ inline void set_name(char out[4], const char *nm, size_t len) {
     out[0] = ' '; out[1] = nm[0]; out[2] = len > 1 ? nm[1] : ' '; out[3] = len > 2 ? nm[2] : ' ';
 }
 
+// per-thread scratch of the decoder: an ingest thread decodes ~10^4 entries a second, none of them allocates once the vectors have grown
+struct scratch {
+    std::vector<int32_t> anchor_idx;
+    std::vector<float> anchors, bang;
+    std::vector<res_code> code;
+    std::vector<res_angles> ang;
+    std::vector<uint8_t> side, bq, tors_have;
+    std::vector<sc> tors_sc;
+    std::vector<f3> bb, fw, rec;
+    sc bond_sc[3][256];
+    uint8_t bond_have[3][256];
+};
+// O and CB: the bond angle is a constant of the residue type, the torsion one of 256 codes (-180 + 360 / 255 * code) — their sines / cosines
+// come from tables filled once per process by the same sc_deg
+struct side_tables {
+    sc o_bond[20], cb_bond[20], tors[256];
+    float tor_deg[256];
+};
+
 struct reader {
     const uint8_t *p; size_t n, at = 0;
     bool ok = true;
@@ -119,7 +161,10 @@ struct reader {
 };
 }  // namespace
 
+static const side_tables &side_tab();
+
 int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out) {
+    static thread_local scratch S;
     out->clear();
     reader r{data, len};
     char magic[4];
@@ -132,7 +177,8 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
     // remain before anything is allocated or indexed with it
     const size_t remain = len - r.at;
     if ((size_t)n_anchor > remain / 4 || (size_t)nres > remain / 8 || (size_t)H.n_side_torsion > remain || (size_t)H.len_title > remain) return -1;
-    std::vector<int32_t> anchor_idx(n_anchor);
+    std::vector<int32_t> &anchor_idx = S.anchor_idx;
+    anchor_idx.resize(n_anchor);
     if (!r.get(anchor_idx.data(), (size_t)n_anchor * 4)) return -1;
     for (int k = 0; k < n_anchor; ++k)      // anchors are residue indices in strictly ascending order
         if (anchor_idx[k] < 0 || anchor_idx[k] >= nres || (k && anchor_idx[k] <= anchor_idx[k - 1])) return -1;
@@ -140,14 +186,15 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
     r.at += H.len_title;
     float first[9], last[9], oxt[3];
     if (!r.get(first, sizeof first)) return -1;
-    std::vector<float> anchors;     // per segment end: N, CA, C (inner anchors, then the last atoms)
+    std::vector<float> &anchors = S.anchors;     // per segment end: N, CA, C (inner anchors, then the last atoms)
     anchors.resize((size_t)(n_anchor - 1) * 9);
     if (n_anchor > 2 && !r.get(anchors.data(), (size_t)(n_anchor - 2) * 36)) return -1;
     if (!r.get(last, sizeof last)) return -1;
     memcpy(&anchors[(size_t)(n_anchor - 2) * 9], last, sizeof last);
     char has_oxt;
     if (!r.get(&has_oxt, 1) || !r.get(oxt, sizeof oxt)) return -1;
-    std::vector<res_code> code(nres);
+    std::vector<res_code> &code = S.code;
+    code.resize(nres);
     for (int i = 0; i < nres; ++i) {
         uint8_t b[8];
         if (!r.get(b, 8)) return -1;
@@ -159,15 +206,18 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
         if (code[i].type >= 20 && code[i].type <= 22) return -2;   // ASX / GLX / STP: the format's decoder has no entry for them (its lookup throws)
         if (code[i].type > 23) code[i].type = 23;                  // every other code reads as UNK (backbone only)
     }
-    std::vector<uint8_t> side(H.n_side_torsion);
+    std::vector<uint8_t> &side = S.side;
+    side.resize(H.n_side_torsion);
     if (H.n_side_torsion && !r.get(side.data(), H.n_side_torsion)) return -1;
     float b_min, b_step;
     if (!r.get(&b_min, 4) || !r.get(&b_step, 4)) return -1;
-    std::vector<uint8_t> bq(nres);
+    std::vector<uint8_t> &bq = S.bq;
+    bq.resize(nres);
     if (!r.get(bq.data(), nres)) return -1;
 
     // continuous angles: min + code * step (float)
-    std::vector<res_angles> ang(nres);
+    std::vector<res_angles> &ang = S.ang;
+    ang.resize(nres);
     for (int i = 0; i < nres; ++i) {
         ang[i].phi = H.mins[0] + ((float)code[i].phi * H.cont_fs[0]);
         ang[i].psi = H.mins[1] + ((float)code[i].psi * H.cont_fs[1]);
@@ -176,52 +226,70 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
         ang[i].ca_c_n = H.mins[4] + ((float)code[i].ca_c_n * H.cont_fs[4]);
         ang[i].c_n_ca = H.mins[5] + ((float)code[i].c_n_ca * H.cont_fs[5]);
     }
-    // torsion list of the whole chain: psi, omega, phi of residues 0 .. n-2
-    std::vector<float> tors;
-    for (int i = 0; i + 1 < nres; ++i) { tors.push_back(ang[i].psi); tors.push_back(ang[i].omega); tors.push_back(ang[i].phi); }
+    // torsion list of the whole chain: psi, omega, phi of residues 0 .. n-2 — entry t is kind t % 3 of residue t / 3.  Its sine / cosine
+    // pairs are computed when the forward chain first needs them and serve the backward chain of the same segment
+    const int n_tors = 3 * (nres - 1), tmax = n_tors - 1;
+    auto tors_at = [&](int t) { const res_angles &A = ang[t / 3]; return t % 3 == 0 ? A.psi : t % 3 == 1 ? A.omega : A.phi; };
+    S.tors_sc.resize((size_t)std::max(n_tors, 1));
+    S.tors_have.assign((size_t)std::max(n_tors, 1), 0);
+    auto tors_sc = [&](int t) -> sc {
+        if (!S.tors_have[t]) { S.tors_sc[t] = sc_deg(tors_at(t)); S.tors_have[t] = 1; }
+        return S.tors_sc[t];
+    };
+    // bond angles of the forward chain: three quantisers of 256 codes each, one sine / cosine pair per (quantiser, code) and entry
+    memset(S.bond_have, 0, sizeof S.bond_have);
+    auto bond_sc = [&](int q, uint32_t cd, float deg) -> sc {
+        if (!S.bond_have[q][cd]) { S.bond_sc[q][cd] = sc_deg(deg); S.bond_have[q][cd] = 1; }
+        return S.bond_sc[q][cd];
+    };
 
     // ---- backbone, anchor segment by anchor segment
-    std::vector<f3> bb;                       // N, CA, C of every residue
+    std::vector<f3> &bb = S.bb;                       // N, CA, C of every residue
+    bb.clear();
+    bb.reserve((size_t)nres * 3);
+    std::vector<f3> &fw = S.fw, &rec = S.rec;
+    std::vector<float> &bang = S.bang;
     f3 prev[3] = {{first[0], first[1], first[2]}, {first[3], first[4], first[5]}, {first[6], first[7], first[8]}};
     for (int sgm = 0; sgm < n_anchor - 1; ++sgm) {
         const int max_idx = nres - 1;
+        const bool last_sgm = sgm == n_anchor - 2;
         const int i0 = anchor_idx[sgm] < max_idx ? anchor_idx[sgm] : max_idx;
-        int i1 = anchor_idx[sgm + 1] + 1 < max_idx ? anchor_idx[sgm + 1] + 1 : max_idx;
+        const int i1 = anchor_idx[sgm + 1] + 1 < max_idx ? anchor_idx[sgm + 1] + 1 : max_idx;
         if (i0 < 0 || i1 < i0) return -1;
-        std::vector<int> sub;
-        for (int i = i0; i < i1; ++i) sub.push_back(i);
-        if (sgm == n_anchor - 2) sub.push_back(nres - 1);
-        // forward chain
-        std::vector<f3> fw = {prev[0], prev[1], prev[2]};
-        for (size_t k = 0; k + 1 < sub.size(); ++k) {
-            const res_angles &A = ang[sub[k]];
-            f3 pc[3] = {fw[3 * k], fw[3 * k + 1], fw[3 * k + 2]};
-            const f3 nn = place_atom(pc, (float)1.3311, A.ca_c_n, A.psi);
-            pc[0] = pc[1]; pc[1] = pc[2]; pc[2] = nn;
-            const f3 ca = place_atom(pc, code[sub[k]].type != 14 ? (float)1.4581 : (float)1.353, A.c_n_ca, A.omega);
-            pc[0] = pc[1]; pc[1] = pc[2]; pc[2] = ca;
-            const f3 cc = place_atom(pc, (float)1.5281, A.n_ca_c, A.phi);
+        // residues of the segment: i0 .. i1 - 1, plus the chain's last residue behind the last segment; all but the last listed one extend
+        // the forward chain
+        const int n_sub = i1 - i0 + (last_sgm ? 1 : 0), n_ext = n_sub > 0 ? n_sub - 1 : 0;
+        fw.clear();
+        fw.push_back(prev[0]); fw.push_back(prev[1]); fw.push_back(prev[2]);
+        for (int k = 0; k < n_ext; ++k) {
+            const int r = i0 + k;              // (k < n_sub - 1: never the appended last residue)
+            const res_angles &A = ang[r];
+            const bool cached = 3 * r + 2 <= tmax;
+            const f3 p0 = fw[3 * k], p1 = fw[3 * k + 1], p2 = fw[3 * k + 2];
+            const f3 nn = place_atom(p0, p1, p2, (float)1.3311, bond_sc(0, code[r].ca_c_n, A.ca_c_n), cached ? tors_sc(3 * r) : sc_deg(A.psi));
+            const f3 ca = place_atom(p1, p2, nn, code[r].type != 14 ? (float)1.4581 : (float)1.353, bond_sc(1, code[r].c_n_ca, A.c_n_ca),
+                                     cached ? tors_sc(3 * r + 1) : sc_deg(A.omega));
+            const f3 cc = place_atom(p2, nn, ca, (float)1.5281, bond_sc(2, code[r].n_ca_c, A.n_ca_c), cached ? tors_sc(3 * r + 2) : sc_deg(A.phi));
             fw.push_back(nn); fw.push_back(ca); fw.push_back(cc);
         }
-        // torsions of the segment
-        const int tmax = (int)tors.size() - 1;
-        std::vector<float> st;
+        // torsions of the segment: entries t0 .. t1 - 1 of the chain's list, plus its last entry behind the last segment
+        int t0 = 0, n_st = 0;
         if (tmax >= 0) {
             const int64_t a0 = (int64_t)anchor_idx[sgm] * 3, a1 = (int64_t)anchor_idx[sgm + 1] * 3;      // 64-bit: 3 * index must not wrap
-            const int t0 = (int)std::min<int64_t>(std::max<int64_t>(a0, 0), tmax), t1 = (int)std::min<int64_t>(std::max<int64_t>(a1, 0), tmax);
-            for (int t = t0; t < t1; ++t) st.push_back(tors[t]);
-            if (sgm == n_anchor - 2) st.push_back(tors.back());
+            t0 = (int)std::min<int64_t>(std::max<int64_t>(a0, 0), tmax);
+            const int t1 = (int)std::min<int64_t>(std::max<int64_t>(a1, 0), tmax);
+            n_st = std::max(t1 - t0, 0) + (last_sgm ? 1 : 0);
         }
-        // backward chain from the stored anchor atoms, bond angles measured on the forward chain
+        const int n_range = n_st - (last_sgm && tmax >= 0 ? 1 : 0);
+        auto st_index = [&](int j) { return j < n_range ? t0 + j : tmax; };      // entry j of the segment's torsions -> entry of the chain's list
+        // backward chain from the stored anchor atoms (C, CA, N of the segment's end first), bond angles measured on the forward chain
         const size_t na = fw.size();
-        std::vector<f3> back = fw;
         const float *an = &anchors[(size_t)sgm * 9];
-        back[na - 3] = {an[0], an[1], an[2]}; back[na - 2] = {an[3], an[4], an[5]}; back[na - 1] = {an[6], an[7], an[8]};
-        std::vector<float> bang;
+        bang.clear();
         for (size_t i = 1; i + 1 < na; ++i) bang.push_back(angle_deg(fw[i - 1], fw[i], fw[i + 1]));
-        std::vector<f3> rev(back.rbegin(), back.rend());
-        std::vector<float> rt(st.rbegin(), st.rend()), ra(bang.rbegin(), bang.rend());
-        std::vector<f3> rec = {rev[0], rev[1], rev[2]};
+        const size_t n_bang = bang.size();
+        rec.clear();
+        rec.push_back({an[6], an[7], an[8]}); rec.push_back({an[3], an[4], an[5]}); rec.push_back({an[0], an[1], an[2]});
         for (size_t i = 0; i + 3 < na; ++i) {
             // atom i + 3 of the reversed chain: kinds cycle C, CA, N from the end; the bond runs from atom i + 3 to atom i + 2
             const int kind_cur = (int)((na - 1 - (i + 3)) % 3), kind_prev = (int)((na - 1 - (i + 2)) % 3);   // 0 N, 1 CA, 2 C
@@ -229,29 +297,31 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
             if (kind_cur == 0 && kind_prev == 1) bl = 1.4581f;        // N_TO_CA
             else if (kind_cur == 1 && kind_prev == 2) bl = 1.5281f;   // CA_TO_C
             else bl = 1.3311f;                                        // C_TO_N
-            if (i >= rt.size() || i + 1 >= ra.size()) return -1;
-            const f3 pc[3] = {rec[i], rec[i + 1], rec[i + 2]};
-            rec.push_back(place_atom(pc, bl, ra[i + 1], rt[i]));
+            if (i >= (size_t)n_st || i + 1 >= n_bang) return -1;
+            // reversed lists: torsion i = the segment's torsion n_st - 1 - i, bond angle i + 1 = measured angle n_bang - 2 - i
+            rec.push_back(place_atom(rec[i], rec[i + 1], rec[i + 2], bl, sc_deg(bang[n_bang - 2 - i]), tors_sc(st_index(n_st - 1 - (int)i))));
         }
-        std::vector<f3> bw(rec.rbegin(), rec.rend());
-        // position-weighted average
-        std::vector<f3> avg(na);
+        // position-weighted average of the forward chain and the backward chain (read back to front)
         const int total = (int)na;
+        const size_t keep = !last_sgm ? na - 3 : na;
+        f3 tail[3];
         for (int i = 0; i < total; ++i) {
-            avg[i].x = ((fw[i].x * (float)(total - i)) + (bw[i].x * (float)i)) / (float)total;
-            avg[i].y = ((fw[i].y * (float)(total - i)) + (bw[i].y * (float)i)) / (float)total;
-            avg[i].z = ((fw[i].z * (float)(total - i)) + (bw[i].z * (float)i)) / (float)total;
+            const f3 b = rec[na - 1 - i];
+            f3 v;
+            v.x = ((fw[i].x * (float)(total - i)) + (b.x * (float)i)) / (float)total;
+            v.y = ((fw[i].y * (float)(total - i)) + (b.y * (float)i)) / (float)total;
+            v.z = ((fw[i].z * (float)(total - i)) + (b.z * (float)i)) / (float)total;
+            if ((size_t)i < keep) bb.push_back(v);
+            if (i >= total - 3) tail[i - (total - 3)] = v;
         }
-        const size_t keep = sgm != n_anchor - 2 ? na - 3 : na;
-        bb.insert(bb.end(), avg.begin(), avg.begin() + keep);
-        prev[0] = avg[na - 3]; prev[1] = avg[na - 2]; prev[2] = avg[na - 1];
+        prev[0] = tail[0]; prev[1] = tail[1]; prev[2] = tail[2];
     }
     if (bb.size() != (size_t)nres * 3) return -1;
 
     // ---- atom records: N, CA, C, then the residue type's side atoms (O and CB placed, the rest without coordinates)
     size_t tpos = 0;
-    uint64_t atom_index = H.idx_atom;
-    (void)atom_index;
+    const side_tables &ST = side_tab();
+    out->reserve((size_t)H.n_atom + 8);
     for (int i = 0; i < nres; ++i) {
         const aa_info &T = code[i].type < 20 ? AA[code[i].type] : AA_UNK;
         const f3 N = bb[3 * i], CA = bb[3 * i + 1], C = bb[3 * i + 2];
@@ -274,12 +344,11 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
             while (*e && *e != ' ') ++e;
             const size_t nl = (size_t)(e - s);
             if (tpos >= side.size()) return -1;
-            const float tor_step = (180.0f - -180.0f) / (float)255u;            // FixedAngleDiscretizer(255): float division
-            const float tor = ((float)side[tpos] * tor_step) + -180.0f;
+            const uint8_t tc = side[tpos];
             ++tpos;
             f3 xyz = {0.0f, 0.0f, 0.0f};
-            if (k == 0) { const f3 pc[3] = {N, CA, C}; O = xyz = place_atom(pc, T.c_o, T.ca_c_o, tor); }
-            else if (k == 1) { const f3 pc[3] = {O, C, CA}; xyz = place_atom(pc, T.ca_cb, T.c_ca_cb, tor); }
+            if (k == 0) O = xyz = place_atom(N, CA, C, T.c_o, ST.o_bond[code[i].type], ST.tors[tc]);
+            else if (k == 1) xyz = place_atom(O, C, CA, T.ca_cb, ST.cb_bond[code[i].type], ST.tors[tc]);
             push(s, nl, xyz);
             ++k;
             s = *e ? e + 1 : e;
@@ -297,4 +366,15 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
         out->push_back(a);
     }
     return 0;
+}
+
+static const side_tables &side_tab() {
+    static const side_tables T = [] {
+        side_tables t;
+        for (int a = 0; a < 20; ++a) { t.o_bond[a] = sc_deg(AA[a].ca_c_o); t.cb_bond[a] = sc_deg(AA[a].c_ca_cb); }
+        const float tor_step = (180.0f - -180.0f) / (float)255u;            // FixedAngleDiscretizer(255): float division
+        for (int c = 0; c < 256; ++c) { t.tor_deg[c] = ((float)c * tor_step) + -180.0f; t.tors[c] = sc_deg(t.tor_deg[c]); }
+        return t;
+    }();
+    return T;
 }

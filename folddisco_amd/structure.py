@@ -284,22 +284,44 @@ def read_compact_structures(paths, threads: int = 0, max_residue: int = 0, foldc
     return res, okf
 
 
+class _ParsedOwner:
+    """keeps one fd_parsed alive for the numpy views read_packed hands out (freed when the last view goes)"""
+
+    def __init__(self, L, out):
+        self.L, self.out = L, out
+
+    def __del__(self):
+        if self.out is not None:
+            self.L.fdgpu_parsed_free(self.out)
+            self.out = None
+
+
+class _ParsedView:
+    """one array of an fd_parsed as numpy sees it (the array's base is this object, which holds the owner)"""
+
+    def __init__(self, owner, ptr, n, dtype):
+        import ctypes as C
+        self.owner = owner
+        self.__array_interface__ = {"data": (C.cast(ptr, C.c_void_p).value or 0, False), "shape": (n,), "typestr": np.dtype(dtype).str, "version": 3}
+
+
 def read_packed(paths, threads: int = 0, max_residue: int = 0, foldcomp=None):
     """Native ingest straight into the flat batch layout (no per-structure Python objects): -> (PackedStructures, nres u64[S],
     plddt f32[S], nres_raw u64[S], ok u8[S]).  What the index workflow needs: coordinates for the GPU, nres / plddt for .lookup.
-    With foldcomp = FoldcompDb, paths are database keys."""
-    import ctypes as C
+    With foldcomp = FoldcompDb, paths are database keys.  The coordinate / residue-type arrays are views of the library's arrays (a copy
+    of them was a fifth of the ingest's wall time: ~40 bytes per residue into fresh pages); the per-structure columns are copies."""
     from . import _lib
     from .api import PackedStructures
     L = _lib.load()
     out = _native_parse(paths, threads, max_residue, foldcomp)
     P = out.contents
     S, R = P.n_struct, P.n_res
+    own = _ParsedOwner(L, out)
+    zero = lambda ptr, n, dt: np.asarray(_ParsedView(own, ptr, n, dt)) if n else np.zeros(0, dt)
     view = lambda ptr, n, dt: (np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].astype(dt, copy=True))
     off = view(P.res_off, S + 1, np.uint64)
-    ps = PackedStructures(off, view(P.n_xyz, 3 * R, np.float32).reshape(-1, 3), view(P.ca_xyz, 3 * R, np.float32).reshape(-1, 3),
-                          view(P.cb_xyz, 3 * R, np.float32).reshape(-1, 3), view(P.aa, R, np.uint8), view(P.cb_valid, R, np.uint8))
+    ps = PackedStructures(off, zero(P.n_xyz, 3 * R, np.float32).reshape(-1, 3), zero(P.ca_xyz, 3 * R, np.float32).reshape(-1, 3),
+                          zero(P.cb_xyz, 3 * R, np.float32).reshape(-1, 3), zero(P.aa, R, np.uint8), zero(P.cb_valid, R, np.uint8))
     nres = np.diff(off).astype(np.uint64)
     plddt, raw, okf = view(P.plddt, S, np.float32), view(P.nres_raw, S, np.uint64), view(P.ok, S, np.uint8)
-    L.fdgpu_parsed_free(out)
     return ps, nres, plddt, raw, okf
