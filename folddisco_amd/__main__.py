@@ -351,7 +351,8 @@ def main(argv=None):
     pi.add_argument("-v", "--verbose", action="store_true")
     pi.add_argument("--device", type=int, default=0)
     pi.add_argument("--chunk", type=int, default=16384, help="structures per ingest step and GPU build call (the next chunk is parsed while this one is built; the sub-indices are merged on the device)")
-    pi.add_argument("--mmap-on-disk", action="store_true", help="NOT SUPPORTED (the reference's on-disk build mode, indextable.rs:215-226): the index is built in HBM")
+    pi.add_argument("--mmap-on-disk", action="store_true", help="accepted for the reference's command lines (indextable.rs:215-226,247: there the posting array is filled in a file-backed "
+                    "mapping of PREFIX instead of anonymous memory, the files are the same): here the array is filled in HBM and streamed to PREFIX either way")
     pq = sub.add_parser("query")
     pq.add_argument("-p", "--pdb", default="")
     pq.add_argument("-q", "--query", default="")
@@ -423,9 +424,10 @@ def main(argv=None):
         analyze.save_summary(analyze.summarize(a.index), out, a.top)
         return
     if a.cmd == "index":
-        if a.mmap_on_disk:
-            sys.exit("[FAIL] --mmap-on-disk is not supported: this build keeps the index in HBM (a Swiss-Prot-scale index is 26 GB of the 288 GB) and "
-                     "writes PREFIX / PREFIX.offset once; run without the flag")
+        if a.mmap_on_disk and a.verbose:
+            # the reference's switch chooses WHERE the posting array lives while it is filled (a mapping of PREFIX on disk, indextable.rs:215-226, or
+            # anonymous memory copied to PREFIX afterwards, :247-270); PREFIX, PREFIX.offset, .lookup and .type are byte for byte the same in both modes
+            print("[INFO] --mmap-on-disk: the posting array is filled in HBM and streamed to PREFIX (same files as without the flag)", file=sys.stderr)
         try:
             a.hash_type = hash_type_index(a.type)
         except ValueError:
