@@ -142,10 +142,17 @@ void fd_launch_ck_fill(const uint64_t *offsets, const uint8_t *value, uint64_t H
 // further apart than a granule gives the same piece for all granules of an entry: it is handed to the FIRST of them inside the tile, the
 // others get none — a tile decodes every piece once.
 __global__ void k_qt_plan(qt_args A) {
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // thread t = r * n_gran + gran: the lanes of a wavefront walk the granules of ONE row (two at a row boundary), so offsets / ck_meta are one
+    // address per wavefront and the entries e[...] neighbours — with gran-major threads (lane = row) every lane chased its own list's three
+    // cache lines (39 us per 128 queries, the longest kernel of the prefilter after the scoring itself).  The ranges keep their gran-major
+    // layout (a scoring workgroup reads the rows of its query side by side), so the 16-byte stores are the scattered side now.
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t cpg_log2 = A.plan_log2 - QT_CELL_LOG2, n_gran = (A.NC + (1u << cpg_log2) - 1u) >> cpg_log2;
-    if (g >= (uint64_t)A.nq * n_gran) return;
-    const uint32_t gran = (uint32_t)(g / A.nq), r = (uint32_t)(g % A.nq);
+    if (t >= (uint64_t)A.nq * n_gran) return;
+    uint32_t gran, r;
+    if (((uint64_t)A.nq * n_gran) >> 32) { r = (uint32_t)(t / n_gran); gran = (uint32_t)(t % n_gran); }
+    else { r = (uint32_t)t / n_gran; gran = (uint32_t)t - r * n_gran; }
+    const uint64_t g = (uint64_t)gran * A.nq + r;
     uint4 out = make_uint4(0u, 0u, 0u, 0u);
     const long long k = A.kidx[r];
     if (k >= 0) {

@@ -1,0 +1,21 @@
+// exhaustive: sincosf(x) == (sinf(x), cosf(x)) bit for bit, all floats |x| <= 16 (both signs), 8 threads
+#define _GNU_SOURCE
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+static unsigned long long bad[8];
+static void *run(void *arg) {
+    long t = (long)arg; unsigned long long b = 0;
+    for (uint32_t u = (uint32_t)t; u <= 0x41800000u; u += 8) {
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            uint32_t w = u | (sgn ? 0x80000000u : 0); float x, s, c; memcpy(&x, &w, 4);
+            sincosf(x, &s, &c);
+            float s2 = sinf(x), c2 = cosf(x);
+            if (memcmp(&s, &s2, 4) || memcmp(&c, &c2, 4)) ++b;
+        }
+    }
+    bad[t] = b; return 0;
+}
+int main() { pthread_t th[8]; for (long t = 0; t < 8; ++t) pthread_create(&th[t], 0, run, (void *)t); unsigned long long b = 0; for (int t = 0; t < 8; ++t) { pthread_join(th[t], 0); b += bad[t]; } printf("mismatches %llu\n", b); return 0; }
