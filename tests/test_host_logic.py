@@ -424,6 +424,43 @@ def test_bench_input_writers_round_trip_through_the_ingest(tmp_path):
     assert np.array_equal(nres2, np.tile(nres0, 3)[:60]) and np.array_equal(ps2.ca_xyz[: len(ps0.ca_xyz)], ps0.ca_xyz)
 
 
+def test_read_packed_views_outlive_the_call_and_equal_the_per_structure_arrays(tmp_path):
+    """read_packed hands out VIEWS of the library's packed arrays (no copy: the coordinates are ~40 bytes per residue) and the library copies
+    the per-structure parts into them on several threads: the views must stay valid after the call's other results are dropped and garbage
+    is collected, be released with the last view, and hold what read_compact_structures returns structure by structure — for one thread,
+    for more threads than structures, and for enough structures that every copying thread gets several blocks of 64."""
+    import gc
+    from folddisco_amd import structure
+    src = os.path.join(ROOT, "tests", "golden", "foldcomp", "example_db")
+    db = str(tmp_path / "rep_foldcomp")
+    from folddisco_amd import synth
+    synth.replicate_foldcomp_db(src, db, 700)
+    fc = structure.FoldcompDb(db)
+    keys = np.asarray(fc.keys, np.uint64)
+    cs, okc = structure.read_compact_structures(keys[:40], threads=3, foldcomp=fc)
+    for n_keys, threads in ((40, 1), (3, 8), (700, 4)):
+        ps, nres, plddt, raw, ok = structure.read_packed(keys[:n_keys], threads=threads, foldcomp=fc)
+        ca = ps.ca_xyz
+        assert not ca.flags.owndata and ca.base is not None      # a view, kept alive through its base
+        del ps, nres, plddt, raw, ok
+        gc.collect()
+        junk = [np.full(1 << 20, 7, np.uint8) for _ in range(8)]   # freed memory would be handed out again here
+        off = 0
+        for k in range(min(n_keys, 40)):
+            m = cs[k].n
+            assert np.array_equal(ca[off:off + m], cs[k].ca_xyz), (n_keys, threads, k)
+            off += m
+        del junk
+    ps, nres, *_ = structure.read_packed(keys, threads=4, foldcomp=fc)
+    P = len(structure.FoldcompDb(src).keys)                    # the database repeats the fixture's entries with this period
+    per = np.array([c.n for c in cs[:P]], np.uint64)
+    assert np.array_equal(nres, np.tile(per, 700 // P + 1)[:700])
+    ro = ps.res_off.astype(np.int64)
+    last = 699 % P
+    assert np.array_equal(ps.n_xyz[ro[699]:ro[700]], ps.n_xyz[ro[last]:ro[last + 1]]) and np.array_equal(ps.cb_xyz[ro[699]:ro[700]], ps.cb_xyz[ro[last]:ro[last + 1]])
+    assert np.array_equal(ps.aa[:ro[P]], ps.aa[ro[P]:ro[2 * P]])
+
+
 def test_fixed_format_number_fields_parse_like_strtof(tmp_path):
     """The ingest's fast path for "%8.3f" / "%6.2f" fields (mantissa below 2^24, one IEEE division by a power of ten) returns the bits the
     correctly rounded decimal -> f32 conversion returns (Rust's str::parse::<f32>, glibc strtof, numpy): random coordinates over the whole
