@@ -409,6 +409,45 @@ def main():
     n_post, n_hash, vlen = ix.num_postings, ix.num_hashes, ix.value_len
 
     progress("timed build done")
+    # ---- N > 1: the legs behind this point (single index over ncclSend / ncclRecv, sharded queries with RCCL exchanges, replicas) run collectives that no
+    # machine with fewer than N GPUs can have executed; a rank that waits in one of them for ever would take the measured headline with it.  A watchdog
+    # per rank therefore bounds them: when FD_BENCH_WATCHDOG_S (default 1500 s, 0 = off) pass behind the timed build without the line being printed, rank 0
+    # prints the line with the legs that did finish (and says so under "watchdog"), and every rank leaves.  One rank (N = 1) has no watchdog.
+    import threading
+    wd_done, wd_printed = threading.Event(), threading.Event()
+    wd_limit = float(os.environ.get("FD_BENCH_WATCHDOG_S", "1500")) if world > 1 else 0.0
+
+    def partial_line():
+        def got(fn):
+            try:
+                return fn()
+            except NameError:       # the leg had not started when the watchdog fired
+                return None
+        return {"metric": "structures/sec indexed", "value": value, "unit": "structures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
+                "config": {"workload": f"Swiss-Prot scale: {S_total} synthetic AFDB-shaped structures index build, PDBTrRosetta default; {world} rank(s), contiguous id ranges",
+                           "structures": S_total, "structures_per_gpu": S, "parallelism": f"shard-by-structure x{world}"},
+                "roofline": got(lambda: roofline), "export_inclusive": got(lambda: export), "index_on_disk_inclusive": got(lambda: on_disk), "cpu_baseline": None,
+                "query": got(lambda: query), "cli_index": None}
+
+    def watchdog():
+        if wd_done.wait(wd_limit):
+            return
+        if rank == 0 and not wd_printed.is_set():
+            line = partial_line()
+            line["watchdog"] = {"fired_after_s": wd_limit, "note": "a leg behind the timed build did not return on some rank; value / ms_per_step are the completed "
+                                                                    "measurement, legs that are null or partial did not finish"}
+            try:
+                print(json.dumps(line), flush=True)
+            except Exception:  # noqa: BLE001 — a leg's half-built dictionary must not cost the headline
+                for k in ("roofline", "export_inclusive", "index_on_disk_inclusive", "query"):
+                    line[k] = None
+                print(json.dumps(line), flush=True)
+        else:
+            time.sleep(2.0)
+        os._exit(0)
+    if wd_limit > 0:
+        threading.Thread(target=watchdog, daemon=True).start()
     # ---- export-inclusive: one more step that also brings the index to the host in the on-disk layout (fdgpu_index_export)
     export = None
     if not args.no_export:
@@ -635,10 +674,13 @@ def main():
                        "parallelism": f"shard-by-structure x{world}", "build_calls_per_rank": n_calls, "call_plan": call_plan},
             "roofline": roofline, "export_inclusive": export, "index_on_disk_inclusive": on_disk, "cpu_baseline": cpu, "query": query, "cli_index": cli_index,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+        wd_printed.set()
     if dist is not None:
-        dist.barrier()
+        dist.barrier()      # (still under the watchdog: a rank that never arrives must not keep the others here)
+        wd_done.set()
         dist.destroy_process_group()
+    wd_done.set()
 
 
 if __name__ == "__main__":

@@ -444,3 +444,12 @@ def test_bench_n_gt_1_path_runs_with_two_gloo_ranks_on_one_gpu():
     assert out["roofline"]["frac"] > 0 and out["export_inclusive"]["value"] > 0
     disk = out["index_on_disk_inclusive"]
     assert "error" not in disk and (disk.get("skipped") or (disk["value"] > 0 and disk["files_complete"])), disk
+    # the N > 1 watchdog: with a limit shorter than the legs behind the timed build, rank 0 prints the line with the completed measurement and every
+    # rank leaves with status 0 — what keeps a rank stuck in a never-executed collective from taking the headline with it
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--structures", "8000", "--steps", "1", "--warmup", "0", "--queries", "64",
+                        "--no-cpu-baseline", "--no-cli-index"], cwd=root, env=dict(env, FD_BENCH_WATCHDOG_S="0.05"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["watchdog"]["fired_after_s"] == 0.05 and out["n_gpus"] == 2 and out["value"] > 0 and out["ms_per_step"] > 0 and out["query"] is None
