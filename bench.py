@@ -30,6 +30,9 @@ import socket
 import subprocess
 import sys
 import time
+import threading
+
+_WD_FIRED, _WD_LEFT, _WD_ARMED = threading.Event(), threading.Event(), []      # the N > 1 watchdog of main()
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -433,6 +436,7 @@ def main():
     def watchdog():
         if wd_done.wait(wd_limit):
             return
+        _WD_FIRED.set()
         if rank == 0 and not wd_printed.is_set():
             line = partial_line()
             line["watchdog"] = {"fired_after_s": wd_limit, "note": "a leg behind the timed build did not return on some rank; value / ms_per_step are the completed "
@@ -443,10 +447,10 @@ def main():
                 for k in ("roofline", "export_inclusive", "index_on_disk_inclusive", "query"):
                     line[k] = None
                 print(json.dumps(line), flush=True)
-        else:
-            time.sleep(2.0)
-        os._exit(0)
+        _WD_LEFT.set()
+        os._exit(0)      # every rank leaves within milliseconds of the others (the limit counts from the barrier behind the timed build)
     if wd_limit > 0:
+        _WD_ARMED.append(True)
         threading.Thread(target=watchdog, daemon=True).start()
     # ---- export-inclusive: one more step that also brings the index to the host in the on-disk layout (fdgpu_index_export)
     export = None
@@ -684,4 +688,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        # N > 1 under the watchdog: a rank whose peers have just left through it sees its collective fail ("connection closed by peer") a moment before
+        # its own limit — that is the watchdog's exit, not an error of this rank
+        if _WD_ARMED and _WD_FIRED.wait(10.0):
+            _WD_LEFT.wait(30.0)
+            os._exit(0)
+        raise

@@ -28,7 +28,7 @@
 #include <string.h>
 
 #ifndef FD_FCZ_PIPE
-#define FD_FCZ_PIPE 1      /* 0: a segment's backward chain after the next segment's forward chain instead of beside it (tools/fcz_decode_bench.cpp measures both) */
+#define FD_FCZ_PIPE 0      /* 1: a segment's backward chain placed atom by atom BESIDE the next segment's forward chain instead of after it (see below) */
 #endif
 
 namespace {
@@ -165,6 +165,8 @@ struct scratch {
 struct side_tables {
     sc o_bond[20], cb_bond[20], tors[256];
     float tor_deg[256];
+    uint32_t n_side[20];            // atoms behind N, CA, C of the residue type
+    char side_name[20][12][4];      // their names as PDB columns 13-16
 };
 
 struct reader {
@@ -256,11 +258,12 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
         return S.bond_sc[q][cd];
     };
 
-    // ---- backbone, anchor segment by anchor segment.  Placing an atom is one chain of ~190 dependent cycles (two double square roots, two
-    // rounds of divisions, the accumulations) and a segment's forward chain, its backward chain and the next segment's forward chain look
-    // like one after the other — but the next segment starts from the average of this segment's LAST three atoms, whose backward side is the
-    // stored anchor itself: the forward chain of segment s + 1 needs nothing from the backward chain of segment s.  The two are therefore
-    // placed alternately, atom by atom, and the core runs the two dependency chains side by side (decoding 83 -> 60 us per entry).
+    // ---- backbone, anchor segment by anchor segment.  Placing an atom is one chain of dependent operations (two double square roots, two
+    // rounds of divisions, the accumulations), and the next segment starts from the average of this segment's LAST three atoms, whose
+    // backward side is the stored anchor itself: the forward chain of segment s + 1 needs nothing from the backward chain of segment s.  The
+    // loop is therefore written so that the two can be placed alternately (FD_FCZ_PIPE = 1).  Measured with tools/fcz_decode_bench.cpp: no gain
+    // — 41.6 us per entry one after the other against 42.8 alternately on the MI355X host (EPYC 9575F), 80 against 80 on a 2.1 GHz Xeon; the
+    // cores already overlap what there is to overlap.  The default places a segment's backward chain after the next segment's forward chain.
     std::vector<f3> &bb = S.bb;                       // N, CA, C of every residue
     bb.clear();
     bb.reserve((size_t)nres * 3);
@@ -364,37 +367,30 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
     // ---- atom records: N, CA, C, then the residue type's side atoms (O and CB placed, the rest without coordinates)
     size_t tpos = 0;
     const side_tables &ST = side_tab();
-    out->reserve((size_t)H.n_atom + 8);
+    size_t n_rec = has_oxt ? 1 : 0;
+    for (int i = 0; i < nres; ++i) n_rec += 3u + (code[i].type < 20 ? ST.n_side[code[i].type] : 0u);
+    out->resize(n_rec);
+    fd_fcz_atom *w = out->data();
     for (int i = 0; i < nres; ++i) {
-        const aa_info &T = code[i].type < 20 ? AA[code[i].type] : AA_UNK;
+        const uint32_t ty = code[i].type;
+        const aa_info &T = ty < 20 ? AA[ty] : AA_UNK;
         const f3 N = bb[3 * i], CA = bb[3 * i + 1], C = bb[3 * i + 2];
-        const float bf = ((float)bq[i] * b_step) + b_min;
-        auto push = [&](const char *nm, size_t nl, f3 xyz) {
-            fd_fcz_atom a;
-            a.x = xyz.x; a.y = xyz.y; a.z = xyz.z; a.b = bf;
-            set_name(a.name, nm, nl);
-            memcpy(a.res, T.three, 3);
-            a.chain = (uint8_t)H.chain;
-            a.rser = (uint64_t)H.idx_residue + (uint64_t)i;
-            out->push_back(a);
-        };
-        push("N", 1, N); push("CA", 2, CA); push("C", 1, C);
+        fd_fcz_atom a;      // the residue's record: name and coordinates change from atom to atom
+        a.b = ((float)bq[i] * b_step) + b_min;
+        memcpy(a.res, T.three, 3);
+        a.chain = (uint8_t)H.chain;
+        a.rser = (uint64_t)H.idx_residue + (uint64_t)i;
+        auto push = [&](const char nm[4], f3 xyz) { a.x = xyz.x; a.y = xyz.y; a.z = xyz.z; memcpy(a.name, nm, 4); *w++ = a; };
+        push(" N  ", N); push(" CA ", CA); push(" C  ", C);
+        const uint32_t ns = ty < 20 ? ST.n_side[ty] : 0u;
+        if (ns > side.size() - tpos) return -1;
         f3 O = {0, 0, 0};
-        const char *s = T.side;
-        int k = 0;
-        while (*s) {
-            const char *e = s;
-            while (*e && *e != ' ') ++e;
-            const size_t nl = (size_t)(e - s);
-            if (tpos >= side.size()) return -1;
-            const uint8_t tc = side[tpos];
-            ++tpos;
+        for (uint32_t k = 0; k < ns; ++k) {
+            const uint8_t tc = side[tpos++];
             f3 xyz = {0.0f, 0.0f, 0.0f};
-            if (k == 0) O = xyz = place_atom(N, CA, C, T.c_o, ST.o_bond[code[i].type], ST.tors[tc]);
-            else if (k == 1) xyz = place_atom(O, C, CA, T.ca_cb, ST.cb_bond[code[i].type], ST.tors[tc]);
-            push(s, nl, xyz);
-            ++k;
-            s = *e ? e + 1 : e;
+            if (k == 0) O = xyz = place_atom(N, CA, C, T.c_o, ST.o_bond[ty], ST.tors[tc]);
+            else if (k == 1) xyz = place_atom(O, C, CA, T.ca_cb, ST.cb_bond[ty], ST.tors[tc]);
+            push(ST.side_name[ty][k], xyz);
         }
     }
     if (has_oxt) {
@@ -406,7 +402,7 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
         memcpy(a.res, hit ? AA[hit - "ARNDCQEGHILKMFPSTWYV"].three : "UNK", 3);
         a.chain = (uint8_t)H.chain;
         a.rser = (uint64_t)H.n_residue;
-        out->push_back(a);
+        *w++ = a;
     }
     return 0;
 }
@@ -417,6 +413,16 @@ static const side_tables &side_tab() {
         for (int a = 0; a < 20; ++a) { t.o_bond[a] = sc_deg(AA[a].ca_c_o); t.cb_bond[a] = sc_deg(AA[a].c_ca_cb); }
         const float tor_step = (180.0f - -180.0f) / (float)255u;            // FixedAngleDiscretizer(255): float division
         for (int c = 0; c < 256; ++c) { t.tor_deg[c] = ((float)c * tor_step) + -180.0f; t.tors[c] = sc_deg(t.tor_deg[c]); }
+        for (int a = 0; a < 20; ++a) {
+            uint32_t k = 0;
+            for (const char *s = AA[a].side; *s;) {
+                const char *e = s;
+                while (*e && *e != ' ') ++e;
+                set_name(t.side_name[a][k++], s, (size_t)(e - s));
+                s = *e ? e + 1 : e;
+            }
+            t.n_side[a] = k;
+        }
         return t;
     }();
     return T;
