@@ -235,6 +235,8 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             cx.close()
         return out
 
+    pipe_runs = {}      # queries/s of the three timed runs of every shape (the median is the leg's value)
+
     def run_pipe():
         """{(lanes, in flight): queries/s}, error — batches of 128 through the context's query lanes, one host thread"""
         out = {}
@@ -266,6 +268,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                 runs = sorted((timed(lambda: go_pipe(PIPE_REPS, depth)) for _ in range(3)), key=lambda x: x[0])
                 assert runs[1][1] == PIPE_REPS * nm1
                 out[(n_l, depth)] = len(queries) * PIPE_REPS / runs[1][0]
+                pipe_runs[(n_l, depth)] = [len(queries) * PIPE_REPS / r[0] for r in runs]
             return out, None
         except Exception as e:
             return out, repr(e)[:300]
@@ -489,6 +492,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         "pipelined_128": ({"error": err_pipe} if err_pipe else None) if not pipe_best else {
             "value": pipe_best, "ms_per_query": 1e3 / pipe_best, "chunk": big, "host_threads": 1, "lanes": pipe_key[0], "in_flight": pipe_depth, "queries": len(queries) * PIPE_REPS,
             "queries_per_s_by_lanes_x_in_flight": {"%dx%d" % k: v for k, v in pipe.items()},
+            "runs_queries_per_s": {"%dx%d" % k: [round(x, 1) for x in v] for k, v in pipe_runs.items()},
             "mode": "fdgpu_query_batch_submit / fdgpu_query_batch_wait: ONE host thread keeps %d batches of 128 in flight on %d library-owned lanes (sibling contexts: "
                     "own stream + scratch, each runs fdgpu_query_batch itself); %d passes over the %d queries per timed run, median of 3" % (pipe_depth, pipe_key[0], PIPE_REPS, len(queries))},
         "fused_128": ({"error": err_fused} if err_fused else None) if not dt_fused else {
