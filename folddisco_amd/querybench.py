@@ -263,12 +263,16 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                 assert n_l >= lanes, ctx.L.fdgpu_last_error(ctx.h)
                 # warm-up AT THE SHAPE that is timed: every lane allocates its scratch, and the result blocks of `depth` batches in flight are page-locked
                 # once (warmed with fewer in flight than timed, the first shape of a run measured 12-18 % below the same shape measured later)
+                # ... and LONG enough: tools/pipe_variance.py, ten timed runs of 48 batches in one process behind a warm-up of 24 batches: 120, 133, 164, 161,
+                # 163, 161, 162, 162 k queries/s — the lanes reach their pace after ~100 batches (the same on either NUMA node), and a median of three
+                # runs behind a short warm-up came out at 135 k or at 160 k from one bench run to the next
                 go_pipe(2 * n_l, n_l)
-                go_pipe(max(PIPE_REPS // 4, 2), depth)
-                runs = sorted((timed(lambda: go_pipe(PIPE_REPS, depth)) for _ in range(3)), key=lambda x: x[0])
-                assert runs[1][1] == PIPE_REPS * nm1
-                out[(n_l, depth)] = len(queries) * PIPE_REPS / runs[1][0]
-                pipe_runs[(n_l, depth)] = [len(queries) * PIPE_REPS / r[0] for r in runs]
+                go_pipe(2 * PIPE_REPS, depth)
+                raw = [timed(lambda: go_pipe(PIPE_REPS, depth)) for _ in range(5)]
+                runs = sorted(raw, key=lambda x: x[0])
+                assert runs[2][1] == PIPE_REPS * nm1
+                out[(n_l, depth)] = len(queries) * PIPE_REPS / runs[2][0]
+                pipe_runs[(n_l, depth)] = [len(queries) * PIPE_REPS / r[0] for r in raw]      # in the order they ran
             return out, None
         except Exception as e:
             return out, repr(e)[:300]
@@ -494,7 +498,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
             "queries_per_s_by_lanes_x_in_flight": {"%dx%d" % k: v for k, v in pipe.items()},
             "runs_queries_per_s": {"%dx%d" % k: [round(x, 1) for x in v] for k, v in pipe_runs.items()},
             "mode": "fdgpu_query_batch_submit / fdgpu_query_batch_wait: ONE host thread keeps %d batches of 128 in flight on %d library-owned lanes (sibling contexts: "
-                    "own stream + scratch, each runs fdgpu_query_batch itself); %d passes over the %d queries per timed run, median of 3" % (pipe_depth, pipe_key[0], PIPE_REPS, len(queries))},
+                    "own stream + scratch, each runs fdgpu_query_batch itself); %d passes over the %d queries per timed run, median of 5 behind a warm-up of two such runs" % (pipe_depth, pipe_key[0], PIPE_REPS, len(queries))},
         "fused_128": ({"error": err_fused} if err_fused else None) if not dt_fused else {
             "value": len(queries) / dt_fused, "ms_per_query": dt_fused / len(queries) * 1e3, "chunk": big, "host_threads": 1,
             "mode": "fdgpu_query_batch: query maps, scoring + ranked top %d, retrieval of the top %d in ONE call per batch of 128 (median of 7 passes)" % (top_n, match_top)},
@@ -567,7 +571,8 @@ def run_replicas(ctx, batch, ix, d, S_total, world, rank, dist, dev, n_queries=6
             tot += len(retrieve_batch(ctx, batch, None, cl, qms, qall, list(ks), as_arrays=True)[0])
         ctx.synchronize()
         return tot
-    go()
+    for _ in range(3 if first == 0 else 1):      # the lanes reach their pace after ~100 batches (tools/pipe_variance.py)
+        go()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
