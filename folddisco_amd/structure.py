@@ -291,9 +291,12 @@ class _ParsedOwner:
         self.L, self.out = L, out
 
     def __del__(self):
-        if self.out is not None:
-            self.L.fdgpu_parsed_free(self.out)
-            self.out = None
+        try:
+            if self.out is not None:
+                self.L.fdgpu_parsed_free(self.out)
+                self.out = None
+        except Exception:      # interpreter shutdown: the library handle may already be gone
+            pass
 
 
 class _ParsedView:
