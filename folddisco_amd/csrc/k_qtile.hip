@@ -142,16 +142,23 @@ void fd_launch_ck_fill(const uint64_t *offsets, const uint8_t *value, uint64_t H
 // further apart than a granule gives the same piece for all granules of an entry: it is handed to the FIRST of them inside the tile, the
 // others get none — a tile decodes every piece once.
 __global__ void k_qt_plan(qt_args A) {
-    // thread t = r * n_gran + gran: the lanes of a wavefront walk the granules of ONE row (two at a row boundary), so offsets / ck_meta are one
-    // address per wavefront and the entries e[...] neighbours — with gran-major threads (lane = row) every lane chased its own list's three
-    // cache lines (39 us per 128 queries, the longest kernel of the prefilter after the scoring itself).  The ranges keep their gran-major
-    // layout (a scoring workgroup reads the rows of its query side by side), so the 16-byte stores are the scattered side now.
+    // a wavefront = 8 rows x 8 granules (lane = row + 8 * granule), wavefronts walk a row group's granules first.  Threads in granule-major order
+    // (lane = row) made every lane chase its own list's offsets, checkpoint metadata and entries — three scattered lines per thread, 39 us per
+    // 128 queries, the longest kernel of the prefilter after the scoring itself; row-major order (a wavefront = 64 granules of one row) read one
+    // address per wavefront but scattered the 16-byte range stores over 64 lines (25 us, and PMC counted every store as a 32-byte write).  This
+    // shape reads 8 lists per wavefront (each address shared by the 8 lanes of a row) and stores 8 full 128-byte lines (the rows of a granule
+    // side by side: the table keeps its granule-major layout, a scoring workgroup reads its query's rows side by side).
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t cpg_log2 = A.plan_log2 - QT_CELL_LOG2, n_gran = (A.NC + (1u << cpg_log2) - 1u) >> cpg_log2;
-    if (t >= (uint64_t)A.nq * n_gran) return;
-    uint32_t gran, r;
-    if (((uint64_t)A.nq * n_gran) >> 32) { r = (uint32_t)(t / n_gran); gran = (uint32_t)(t % n_gran); }
-    else { r = (uint32_t)t / n_gran; gran = (uint32_t)t - r * n_gran; }
+    const uint32_t n_gg = (n_gran + 7u) >> 3;
+    const uint64_t wave = t >> 6;
+    const uint32_t lane = (uint32_t)t & 63u;
+    const uint64_t rg = wave / n_gg;
+    const uint32_t gg = (uint32_t)(wave - rg * n_gg);
+    const uint64_t r64 = rg * 8u + (lane & 7u);
+    const uint32_t gran = gg * 8u + (lane >> 3);
+    if (r64 >= A.nq || gran >= n_gran) return;
+    const uint32_t r = (uint32_t)r64;
     const uint64_t g = (uint64_t)gran * A.nq + r;
     uint4 out = make_uint4(0u, 0u, 0u, 0u);
     const long long k = A.kidx[r];
@@ -953,8 +960,9 @@ __global__ __launch_bounds__(QT_SORT_T) void k_qt_sort(const qt_rec *__restrict_
 
 void fd_launch_qt_plan(const qt_args &A, hipStream_t st) {
     const uint32_t cpg_log2 = A.plan_log2 - QT_CELL_LOG2;
-    const uint64_t n = (uint64_t)A.nq * ((A.NC + (1u << cpg_log2) - 1u) >> cpg_log2);
-    if (n) hipLaunchKernelGGL(k_qt_plan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A);
+    const uint64_t n_gran = (A.NC + (1u << cpg_log2) - 1u) >> cpg_log2;
+    const uint64_t n = (((uint64_t)A.nq + 7u) >> 3) * ((n_gran + 7u) >> 3) * 64u;      // wavefronts of 8 rows x 8 granules
+    if (A.nq && n_gran) hipLaunchKernelGGL(k_qt_plan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A);
 }
 // one query of ~10^5 rows (a whole structure as the query): scores per (tile, slice of the rows) -> per-tile reduction + keys + histogram;
 // then threshold -> survivors -> their row bits (second decode) -> records -> ranking.  A.tile_log2 = 14, A.plan_log2 = 14.
