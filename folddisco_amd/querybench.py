@@ -268,7 +268,17 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                 # runs behind a short warm-up came out at 135 k or at 160 k from one bench run to the next
                 go_pipe(2 * n_l, n_l)
                 go_pipe(2 * PIPE_REPS, depth)
-                raw = [timed(lambda: go_pipe(PIPE_REPS, depth)) for _ in range(5)]
+                # (the host here is Python: its cyclic collector is kept out of the 40 ms runs — one run in five came out 7 ms long in every bench line,
+                # always the second; a Rust host has no such pauses)
+                import gc
+                gc.collect()
+                gc_was = gc.isenabled()
+                gc.disable()
+                try:
+                    raw = [timed(lambda: go_pipe(PIPE_REPS, depth)) for _ in range(5)]
+                finally:
+                    if gc_was:
+                        gc.enable()
                 runs = sorted(raw, key=lambda x: x[0])
                 assert runs[2][1] == PIPE_REPS * nm1
                 out[(n_l, depth)] = len(queries) * PIPE_REPS / runs[2][0]

@@ -9,6 +9,7 @@ set -u
 REPO=$(pwd); OUT=$REPO/gpurun_out; RAW=/tmp/fdprof5
 rm -rf $RAW; mkdir -p $OUT $RAW
 export TMPDIR=/tmp
+if [ -z "${R5_ONLY_QUERY:-}" ]; then      # R5_ONLY_QUERY=1: part 3 alone (the query prefilter's PMC passes)
 cd /tmp
 CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-export --no-cli-index"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- $CMD > $OUT/r5_trace.log 2>&1
@@ -29,6 +30,7 @@ print("== rocprofv3 --kernel-trace --stats: python bench.py --steps 2 --warmup 1
 for r in rows[:80]:
     print("%-90s calls=%-7s total_ms=%10.3f avg_us=%11.2f pct=%s" % (r["Name"][:90], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
 PY
+fi
 # ---- 3. query prefilter traffic: 8 batches of 32 full queries (tools/profile_query_host.py: 1 warm-up + 3 timed rounds of 64 queries)
 cd /tmp
 CMDQ="python $REPO/tools/profile_query_host.py --structures 542000 --reps 3 --no-profile"
@@ -80,4 +82,4 @@ json.dump({"structures": 542000, "batches": N_BATCH, "kernels": out, "bytes_per_
           open(raw + "/q_traffic.json", "w"), indent=1)
 PY
 cp $RAW/q_traffic.json $OUT/r5_q_traffic.json 2>/dev/null
-head -60 $OUT/r5_all_kernels.txt; cat $OUT/r5_q_traffic_summary.txt; tail -30 $OUT/r5_prof_summary.txt
+[ -z "${R5_ONLY_QUERY:-}" ] && head -60 $OUT/r5_all_kernels.txt; cat $OUT/r5_q_traffic_summary.txt; [ -z "${R5_ONLY_QUERY:-}" ] && tail -30 $OUT/r5_prof_summary.txt
