@@ -268,8 +268,8 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                 # runs behind a short warm-up came out at 135 k or at 160 k from one bench run to the next
                 go_pipe(2 * n_l, n_l)
                 go_pipe(2 * PIPE_REPS, depth)
-                # (the host here is Python: its cyclic collector is kept out of the 40 ms runs — one run in five came out 7 ms long in every bench line,
-                # always the second; a Rust host has no such pauses)
+                # (the host here is Python: its cyclic collector is kept out of the 40 ms runs.  One run in five comes out ~6 ms long in every bench line —
+                # with the collector off as well, so it is not the collector; the value is the median)
                 import gc
                 gc.collect()
                 gc_was = gc.isenabled()
