@@ -662,7 +662,7 @@ def test_whole_structure_query_matches_oracle():
 @pytest.mark.parametrize("htype", [3, 0, 1, 2, 4, 5, 6, 7, 8])
 def test_query_map_device_expansion_equals_host_expansion(env, monkeypatch, htype):
     """Large queries without substitutions expand, hash and dedupe their candidates on the device (k_qm_expand_hash + sort + first-of-run,
-    fd_host_query.hip); FDGPU_QM_DEVICE=1 takes that path for any size, 0 the host loop: every array of the query map is identical — every
+    fd_query_map.hip); FDGPU_QM_DEVICE=1 takes that path for any size, 0 the host loop: every array of the query map is identical — every
     encoding (their own threshold fields), several threshold lists (the f32 restore drift of expand_and_insert accumulates over them), motif and
     whole-structure queries, with and without an index."""
     import folddisco_amd as fd
