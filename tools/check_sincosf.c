@@ -1,4 +1,6 @@
-// exhaustive: sincosf(x) == (sinf(x), cosf(x)) bit for bit, all floats |x| <= 16 (both signs), 8 threads
+// tools/check_sincosf.c — exhaustive: sincosf(x) == (sinf(x), cosf(x)) bit for bit for all floats of |x| <= 16 (both signs; 2.2e9 values, 8 threads, ~6 s).
+// What csrc/fd_fcz.cpp relies on when it takes an angle's sine and cosine from ONE libm call (it samples the same property at start-up and falls back
+// to the two calls otherwise).      gcc -O2 -fno-builtin tools/check_sincosf.c -o /tmp/check_sincosf -lm -lpthread && /tmp/check_sincosf   ->   mismatches 0
 #define _GNU_SOURCE
 #include <math.h>
 #include <pthread.h>
