@@ -383,7 +383,7 @@ int fd_fcz_decode(const uint8_t *data, size_t len, std::vector<fd_fcz_atom> *out
         auto push = [&](const char nm[4], f3 xyz) { a.x = xyz.x; a.y = xyz.y; a.z = xyz.z; memcpy(a.name, nm, 4); *w++ = a; };
         push(" N  ", N); push(" CA ", CA); push(" C  ", C);
         const uint32_t ns = ty < 20 ? ST.n_side[ty] : 0u;
-        if (ns > side.size() - tpos) return -1;
+        if (ns > side.size() - tpos) { out->clear(); return -1; }      // (no partly written records for a caller that ignores the code)
         f3 O = {0, 0, 0};
         for (uint32_t k = 0; k < ns; ++k) {
             const uint8_t tc = side[tpos++];

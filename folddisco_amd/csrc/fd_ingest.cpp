@@ -747,8 +747,7 @@ static size_t fd_f32_display(float v, char *out) {
     const int ex = (int)strtol(p + 1, nullptr, 10);
     while (nd > 1 && digits[nd - 1] == '0') --nd;
     size_t o = 0;
-    const bool zero = nd == 1 && digits[0] == '0';
-    if (neg && !zero) out[o++] = '-';
+    if (neg) out[o++] = '-';        // -0.0 prints as "-0" (Rust's Display keeps the sign of a negative zero)
     if (ex < 0) {
         out[o++] = '0'; out[o++] = '.';
         for (int k = 0; k < -ex - 1; ++k) out[o++] = '0';

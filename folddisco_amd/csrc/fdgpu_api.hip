@@ -1515,12 +1515,16 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     (void)known_len;                        // (lengths are per input row: only their sum matters below, no permutation needed)
     rows_hash.reserve(nq); rows_meta.reserve(nq);
     if (known_kidx) rows_kidx.reserve(nq);
-    bool packed = true;
+    bool packed = true, sums_fit32 = true;
     uint64_t max_rows = 0;
     for (uint64_t t = 0; t < n_queries; ++t) {
         max_rows = std::max<uint64_t>(max_rows, q_off[t + 1] - q_off[t]);
         packed = packed && (q_off[t + 1] - q_off[t]) < (1ull << 18);
         packed = fd_cq_rows(q_hash, q_node, q_edge_j, q_idf, q_off[t], q_off[t + 1], rows_hash, rows_meta, known_kidx, &rows_kidx) && packed;
+        // 32-bit accumulators serve the batch when no row adds nothing (touched <=> sum != 0) and no query's idf units can reach 2^32
+        unsigned long long units = 0;
+        for (uint64_t r = q_off[t]; r < q_off[t + 1]; ++r) { const unsigned long long fix = rows_meta[r] >> 2; units += fix; sums_fit32 = sums_fit32 && fix != 0ull; }
+        sums_fit32 = sums_fit32 && units < (1ull << 32);
     }
     if (cq_trace) fprintf(stderr, "[count_query] %llu rows of %llu queries in order at %.3f ms\n", (unsigned long long)nq, (unsigned long long)n_queries, cq_ms());
     const uint32_t words = (uint32_t)((S + 31) / 32);
@@ -1532,9 +1536,16 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     const bool sliced = n_queries == 1 && nq >= 4096;
     const bool keys_only = dense_topn && !sliced;
     const bool qtile_on = [] { const char *e = getenv("FDGPU_QTILE"); return !(e && e[0] == '0'); }();      // 0: occupancy rows (read per call: tests compare the two)
-    const uint32_t qt_tl2 = [] { const char *e = getenv("FDGPU_QT_TILE"); return e && atoi(e) == 13 ? 13u : 14u; }();      // structures per tile (measurement)
+    // k_qscore32.hip (32-bit sums, planned slot stream; needs the rows' posting lengths for the stream's bound): FDGPU_QT32=0 keeps the 64-bit kernel
+    // (read per call: tests compare the two), FDGPU_QT32=15 takes tiles of 2^15 structures (one workgroup per CU) instead of 2^14 (two per CU)
+    const int qt32_env = [] { const char *e = getenv("FDGPU_QT32"); return e ? atoi(e) : 14; }();
+    bool qt32 = keys_only && qtile_on && qt32_env != 0 && sums_fit32 && known_len;
+    const uint32_t qt_tl2 = qt32 ? (qt32_env == 15 ? 15u : 14u)
+                                 : [] { const char *e = getenv("FDGPU_QT_TILE"); return e && atoi(e) == 13 ? 13u : 14u; }();      // structures per tile (measurement)
     const uint32_t NT = (uint32_t)((S + (1u << qt_tl2) - 1) >> qt_tl2);
     bool tiled = keys_only && qtile_on && max_rows <= QT_MAX_ROWS && nq * (S >> QT_CELL_LOG2) < (1ull << 31) && fd_index_checkpoints(c, ix) == FDGPU_OK;
+    qt32 = qt32 && tiled;
+    const uint32_t qt_wpr = (1u << (qt_tl2 - 8)) + 2u;      // windows a row can need in a tile: < 2 bytes per posting of a tile, windows at least half full, + its pieces' tails
     // one query of thousands of rows (a whole structure as the query) with a selection: the same tiles, the rows cut into slices (k_qt_score<BIG>)
     const uint32_t NT14 = (uint32_t)((S + (1u << 14) - 1) >> 14);
     bool tiled_big = dense_topn && sliced && qtile_on && !tiled && nq < (1ull << 18) && nq * NT14 < (1ull << 31) && fd_index_checkpoints(c, ix) == FDGPU_OK;
@@ -1546,14 +1557,17 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     // n x (bytes of the largest id) bytes, a slot holds 16 of them, and every (row, cell) piece ends in one partly filled slot
     uint64_t stream_cap = 0;
     const bool qt_stream = [] { const char *e = getenv("FDGPU_QT_STREAM"); return !(e && e[0] == '0'); }();      // 0: pass B decodes the lists again (tests, measurement)
-    if (tiled && qt_stream && known_len && max_rows * (1u << (qt_tl2 - QT_CELL_LOG2)) <= (uint64_t)QT_MAXB * (qt_tl2 == 14 ? 512 : 256)) {
+    if (tiled && (qt32 || (qt_stream && known_len && max_rows * (1u << (qt_tl2 - QT_CELL_LOG2)) <= (uint64_t)QT_MAXB * (qt_tl2 == 14 ? 512 : 256)))) {
         const uint64_t top_id = ix->first_id + S, vb = top_id < (1ull << 7) ? 1 : top_id < (1ull << 14) ? 2 : top_id < (1ull << 21) ? 3 : top_id < (1ull << 28) ? 4 : 5;
         const uint64_t NCc = (S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2;
         // a piece per (row, cell) where the list has an entry per cell; a list with entries 2^j cells apart is cut into pieces of < 96 bytes on
         // average that every tile they span decodes once: at most 6 slots x tiles on top of its bytes
         uint64_t slots = 0;
         for (uint64_t r = 0; r < nq; ++r) slots += (known_len[r] * vb + 15) / 16 + NCc + 6ull * NT + 8;
+        // (the planned stream pads its windows: a piece that would straddle a 64-slot boundary starts the next window — windows stay at least half full)
+        if (qt32) slots = 2 * slots + 64ull * n_queries * NT;
         if (slots < (1ull << 31)) stream_cap = slots + 1024;
+        else qt32 = false;
     }
     auto need_rows = [&]() {      // the occupancy-row path's scratch
         need(WS_COUNTS, packed ? 64 : QS * 4); need(WS_SEGOFF, QS * 8 + 16);
@@ -1566,6 +1580,11 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         need(WS_CQ_KIDX, nq * 8); need(WS_CQ_NSEG, nq * 4);
         need(WS_QT_RANGES, (size_t)nq * ((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2) * 16); need(WS_QT_COMPACT, ((size_t)n_queries * NT << qt_tl2) * 8);
         need(WS_QT_COUNT, (size_t)n_queries * NT * 4); need(WS_QT_AUX, n_queries * sizeof(qt_aux) + 256);
+        if (qt32) {       // pieces in WS_QT_RANGES ([nq x NT x cells per tile] >= the ranges table: sized below), their first slots, the window tables, the heads
+            const size_t ent = (size_t)nq * NT << (qt_tl2 - QT_CELL_LOG2);
+            need(WS_QT_RANGES, ent * 16); need(WS_QT_PIECEP, ent * 4);
+            need(WS_QT_WIN, ((size_t)nq * NT * qt_wpr + 2 * (size_t)n_queries * NT) * 4); need(WS_QT_HEAD, (size_t)n_queries * NT * 16);
+        }
     } else if (tiled_big) {
         need(WS_CQ_KIDX, nq * 8); need(WS_CQ_NSEG, nq * 4);
         need(WS_QT_RANGES, (size_t)nq * NT14 * 16); need(WS_QT_COMPACT, ((size_t)NT14 << 14) * 8); need(WS_QT_COUNT, (size_t)NT14 * 4); need(WS_QT_AUX, sizeof(qt_aux) + 256);
@@ -1575,7 +1594,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     } else need_rows();
     if (e != hipSuccess && (tiled || tiled_big)) {      // the tiled path's scratch did not fit (ranges, first-touch lists, decoded stream): the occupancy-row path instead
         (void)hipGetLastError();
-        e = hipSuccess; tiled = false; tiled_big = false; stream_cap = 0;
+        e = hipSuccess; tiled = false; tiled_big = false; qt32 = false; stream_cap = 0;
         need_rows();
     }
     if (e != hipSuccess) { free(ooff); c->err = std::string("count_query_batch workspace: ") + hipGetErrorString(e); return FDGPU_EHIP; }
@@ -1604,11 +1623,16 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
             uint8_t *sb = c->ws[WS_QT_STREAM].as<uint8_t>();
             T.stream_ids = sb; T.stream_row = (uint16_t *)(sb + stream_cap * 32); T.stream_cap = (uint32_t)stream_cap;
             T.stream_tab = c->ws[WS_QT_STAB].as<uint2>(); T.stream_used = (uint32_t *)(c->ws[WS_QT_STAB].as<uint8_t>() + (size_t)n_queries * NT * QT_MAXB * 8);
-            (void)hipMemsetAsync(T.stream_used, 0, 4, st);
+            if (!qt32) (void)hipMemsetAsync(T.stream_used, 0, 4, st);       // (the 32-bit path scans the tiles' windows instead of claiming records: k_qt_bases)
         }
         T.plan_log2 = QT_CELL_LOG2; T.slices = nullptr; T.n_slices = 0; T.partial = nullptr; T.g_bm = T.g_rank = T.g_tcount = T.g_nid = T.g_rowbits = nullptr;
         T.g_wpr = 0; T.g_eend = T.g_nend = nullptr;
         T.dbg = nullptr;
+        T.pieces = nullptr; T.piece_p = nullptr; T.win = nullptr; T.heads = nullptr; T.win_per_row = 0; T.top_n = top_n;
+        if (qt32) {
+            T.pieces = c->ws[WS_QT_RANGES].as<uint4>(); T.piece_p = c->ws[WS_QT_PIECEP].as<uint32_t>(); T.win = c->ws[WS_QT_WIN].as<uint32_t>();
+            T.heads = c->ws[WS_QT_HEAD].as<uint4>(); T.win_per_row = qt_wpr;
+        }
         if (getenv("FDGPU_QT_DBG")) {       // phase durations of the tile kernels (measurement aid)
             T.dbg = (unsigned long long *)(c->ws[WS_QT_AUX].as<uint8_t>() + n_queries * sizeof(qt_aux));
             (void)hipMemsetAsync(T.dbg, 0, 256, st);
@@ -1625,6 +1649,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
         T.ghist = nullptr; T.state = nullptr; T.aux = c->ws[WS_QT_AUX].as<qt_aux>(); T.out = nullptr; T.cap = big_cap; T.dbg = nullptr;
         T.stream_ids = nullptr; T.stream_row = nullptr; T.stream_tab = nullptr; T.stream_used = nullptr; T.stream_cap = 0;
+        T.pieces = nullptr; T.piece_p = nullptr; T.win = nullptr; T.heads = nullptr; T.win_per_row = 0; T.top_n = top_n;
         // slices of roughly equal posting counts: a row's list holds ~ S / 2^idf ids (idf = log2(S / length), its fixed-point image is in the metadata)
         std::vector<double> w(nq);
         double tot = 0;
@@ -1706,12 +1731,19 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
             {
                 StageTimer t(c, "cq_batch", 0);
                 if (!have_k) fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
-                fd_launch_qt_plan(T, st);
-                fd_launch_qt_score(T, st);
+                if (qt32) { fd_launch_qt_layout(T, st); fd_launch_qt_score32(T, st); }
+                else { fd_launch_qt_plan(T, st); fd_launch_qt_score(T, st); }
             }
             StageTimer t(c, "cq_topn", 0);
             fd_launch_qt_select(T, top_n, c->ws[WS_TILE_HO].p, st);
-            if (T.dbg) {
+            if (T.dbg && qt32) {
+                unsigned long long d[32];
+                if (hipMemcpyAsync(d, T.dbg, 256, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+                    const double wg = (double)NT * (double)n_queries * 100.0;      // ticks of 10 ns -> us per workgroup
+                    fprintf(stderr, "[qt32] set-up %.2f decode (first wavefront) %.2f wait %.2f keys %.2f cut %.2f emit %.2f us/WG, %.1f windows/WG (%u x %llu WGs)\n",
+                            d[0] / wg, d[1] / wg, d[2] / wg, d[3] / wg, d[4] / wg, d[5] / wg, d[17] / ((double)NT * (double)n_queries), NT, (unsigned long long)n_queries);
+                }
+            } else if (T.dbg) {
                 unsigned long long d[32];
                 if (hipMemcpyAsync(d, T.dbg, 256, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
                     const double wg = (double)NT * (double)n_queries * 100.0;      // ticks of 10 ns -> us per workgroup
@@ -2099,6 +2131,8 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
             if (dev_items) wbase[k] = (uint32_t)n_wi;
             n_wi += ((len + FD_WAVE - 1) / FD_WAVE) * (j_span ? (len + j_span - 1) / j_span : (len ? 1 : 0));
         }
+        // (k_mp_items keeps a candidate's first entry of the active-residue list as the 32-bit word 64 x first item)
+        if (dev_items && n_wi >= (1ull << 26)) FAIL(c, FDGPU_ERANGE, "match_pairs: more than 2^26 work items in one call; split the candidates");
         if (dev_items) {
             wbase[n_cand] = (uint32_t)n_wi;
             for (uint64_t t = 0; t < n_queries; ++t) for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) cq[k] = (uint32_t)t;
@@ -2377,6 +2411,8 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
             A.res_d = (float *)qb;
         }
         HIPCHK(c, hipMemsetAsync(c->ws[WS_TOTAL].p, 0, tot_v.size() * 8, st));
+        // a repeated launch drains its chunks again: the rescue votes of the attempt before (atomic adds of the chunks that did fit) must not count twice
+        if (attempt && (mode & 32u)) HIPCHK(c, hipMemsetAsync(c->ws[WS_IDS_A].p, 0, std::max<uint64_t>(votes->n_counters, 1) * 4, st));
         {
             StageTimer t(c, "match_pairs", 0);
             fd_launch_match_pairs(A, st);

@@ -90,7 +90,7 @@ enum {
     WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO /* ranked records of a scoring call: fdgpu_query_batch copies them out on the side stream WHILE the
     retrieval runs — no retrieval stage may ensure() or write this buffer (checked there) */, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
-    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS, WS_QT_STREAM, WS_QT_STAB,
+    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS, WS_QT_STREAM, WS_QT_STAB, WS_QT_PIECEP, WS_QT_WIN, WS_QT_HEAD,
     WS_CA_PERM, WS_OK_PERM, WS_AA_PERM, WS_SEG_TAB,
     WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT, WS_RS_GQ, WS_MP_ACT, WS_MP_Q,
     WS_COUNT
@@ -350,6 +350,13 @@ struct qt_args {
     uint2 *stream_tab;                     // [n_queries][NT][QT_MAXB] first record and records of a (query, tile, row batch)
     uint32_t *stream_used; uint32_t stream_cap;    // records claimed so far (zero on entry), records the buffers hold
     unsigned long long *dbg;               // optional (FDGPU_QT_DBG): [16] phase durations summed over the workgroups
+    // the 32-bit path (k_qscore32.hip): k_qt_layout leaves, per (query, tile), its non-empty pieces laid out as a stream of 16-byte slots in
+    // 64-slot WINDOWS (a piece of <= 64 slots never straddles a window), k_qt_score32 gives every wavefront whole windows
+    uint4 *pieces;                         // [nq x NC] region of (query, tile): {first byte lo, first byte hi (16 bits) | row << 16, bytes, id before}
+    uint32_t *piece_p;                     // [nq x NC] first slot of the piece inside its (query, tile) stream
+    uint32_t *win;                         // per (query, tile) [rows x win_per_row + 2]: first piece that ends behind the window's first slot | QT_WIN_CONT
+    uint4 *heads;                          // [n_queries][NT] {pieces, windows, first record of the decoded stream, flags (1: a table did not hold the tile)}
+    uint32_t win_per_row, top_n;
     // one query of ~10^5 rows (k_qt_score<..., BIG>): row slices, per-slice sums, the survivors' bitmap / slots / row bits
     const uint64_t *slices; uint32_t n_slices;     // [n_slices + 1] row boundaries
     unsigned long long *partial;           // [n_slices][NT][tile] count << 46 | idf sum
@@ -365,6 +372,9 @@ void fd_launch_qt_score(const qt_args &A, hipStream_t st);
 void fd_launch_qt_big_score(const qt_args &A, hipStream_t st);
 void fd_launch_qt_big_select(const qt_args &A, uint32_t top_n, void *sorted, hipStream_t st);
 void fd_launch_qt_select(const qt_args &A, uint32_t top_n, void *sorted, hipStream_t st);
+#define QT_WIN_CONT 0x80000000u            /* the window begins inside a piece of more than 64 slots: decoded by the wavefront that decoded the window before */
+void fd_launch_qt_layout(const qt_args &A, hipStream_t st);
+void fd_launch_qt_score32(const qt_args &A, hipStream_t st);
 
 void fd_launch_posting_lengths(const uint32_t *hashes, const uint64_t *offsets, const uint8_t *value, uint64_t H, const uint32_t *q_hash,
                                uint64_t nq, uint64_t *lengths, long long *kidx, uint32_t *nseg, uint64_t *wstart, uint64_t *scan_tmp, uint64_t *total,

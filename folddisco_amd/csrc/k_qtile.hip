@@ -3,43 +3,28 @@
 // Replaces, for batches of motif queries with a top-N selection, the k_cq_seg / k_cq_rows_keys / k_topn_*_dense chain of k_query.hip
 // (count_query, src/controller/count_query.rs:82-220, followed by the candidate selection of src/cli/workflows/query_pdb.rs:404-411).
 // That chain wrote one occupancy row per query hash (rows x S/8 bytes), read it twice and wrote / re-read one ranking key per structure:
-// 5-7x the bytes SURVEY §8(d) counts for a query.  Here a workgroup owns (query, tile of 16,384 structures):
-//   * the index carries CHECKPOINTS (fd_index_checkpoints, built once per index like the posting lengths): for every list long enough,
-//     the byte position and the preceding id at every 2^j-th boundary of 8,192 ids — a delta stream can be entered there.  The on-disk
-//     format is untouched (the table is derived, device-only);
-//   * k_qt_plan turns (row, tile) into a byte range of the row's posting list; k_qt_score<false> decodes the tile's ranges 16 bytes per
-//     lane (lane-local varint decode with a 4-byte look-back, one wave scan per 1 KB instead of one per 64 bytes) and adds
-//     count << 46 | idf into the tile's 128 KB of LDS accumulators with ds_add_u64 — postings are read once, nothing else is written
-//     but (structure, ranking key) of the TOUCHED structures (8 bytes each, the 8·T of §8(d)) and a 2,048-bin histogram per query;
-//   * k_qt_thr / k_qt_hist2 find the key threshold of the top N (bins of 1.5 % relative width: the second level runs only when the
-//     threshold bin holds more than the selection's slack);
-//   * k_qt_score<true> decodes the same ranges again for the SURVIVORS only (a bitmap of the tile + ranks): their (row, structure)
-//     bits go into LDS, and match / edge / node counts and the exact idf sum follow from the rows in (node, partner) order exactly as
-//     k_topn_emit_dense derived them;
-//   * k_topn_sort ranks the survivors (unchanged).
+// 5-7x the bytes SURVEY §8(d) counts for a query.  Here a workgroup owns (query, tile of 2^14 structures):
+//   * the index carries CHECKPOINTS (k_ck_count / k_ck_fill, built once per index like the posting lengths): for every list long enough, the
+//     byte position and the preceding id at every 2^j-th boundary of 2,048 ids (QT_CELL_LOG2) — a delta stream can be entered there.  The
+//     on-disk format is untouched (the table is derived, device-only);
+//   * pass A, two forms.  k_qt_plan + k_qt_score<false> (this file; any batch): (row, cell) -> byte range; the tile's ranges decoded 16 bytes per
+//     lane (lane-local varint decode with a 4-byte look-back, one wave scan per 1 KB) into count << 46 | idf in 128 KB of LDS accumulators with one
+//     returning ds_add_u64 per posting — a count of zero before the add lists the structure (first touch).  k_qt_layout + k_qt_score32
+//     (k_qscore32.hip; batches whose idf sums fit 32 bits — the default for motif queries): planned slot stream, u32 sums, no first-touch list,
+//     the tile's own cut.  Either way pass A leaves: (structure, ranking key) lists per (query, tile), a 2,048-bin key histogram per query, and
+//     the DECODED STREAM — every 16-byte slot of the tile's ranges as sixteen 16-bit tile-local ids + the slot's row;
+//   * k_qt_thr finds the key threshold of the top N (bins of 1.5 % relative width; a second level over the lists only when the threshold
+//     bin holds more than the selection's slack);
+//   * pass B = k_qt_rows: survivors (key >= threshold) as a bitmap of the tile + ranks, one thread per stream slot tests its ids against the
+//     bitmap — no second decode — and sets (row, survivor) bits in LDS; match / edge / node counts and the exact idf sum follow from the rows
+//     in (node, partner) order exactly as k_topn_emit_dense derived them.  (k_qt_score<true> = pass B by a second decode: calls without the
+//     rows' posting lengths, FDGPU_QT_STREAM=0);
+//   * k_qt_sort ranks the survivors;
+//   * one query of ~10^5 rows (whole-structure mode): k_qt_score<.., BIG> per (tile, row slice) + k_qd_*.
 // Arithmetic (fixed-point idf sums, the ranking key, the record) is the arithmetic of k_query.hip: same bits.
 #include <algorithm>
 #include "fdgpu_internal.h"
-
-#define QT_IDF_SCALE 4194304.0 /* 2^22 */
-#define QT_CNT_SHIFT 46
-#define QT_SUM_MASK ((1ull << QT_CNT_SHIFT) - 1ull)
-struct qt_rec { uint32_t nid, total_match_count, node_count, edge_count; float idf; };      // = fd_count_rec
-
-__device__ __forceinline__ uint32_t qt_order_key(float v) {
-    uint32_t b = __float_as_uint(v + 0.0f);   // -0 -> +0
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-// first selection level: 2,048 bins over the order-preserving key; bins 1..2046 are 2^17 keys wide (64 per binade: 1.5 % relative
-// width) from 2^-16 up, bin 0 holds everything below (idf 0, negative penalties), bin 2047 everything from ~2^16 up
-#define QT_K0 0xB7800000u
-__device__ __forceinline__ uint32_t qt_bin(uint32_t key) {
-    if (key < QT_K0) return 0u;
-    const uint32_t b = ((key - QT_K0) >> 17) + 1u;
-    return b < (QT_BINS - 1u) ? b : (QT_BINS - 1u);
-}
-__device__ __forceinline__ uint32_t qt_edge(uint32_t bin) { return bin ? QT_K0 + ((bin - 1u) << 17) : 0u; }
-__device__ __forceinline__ uint32_t qt_shift2(uint32_t bin) { return bin == 0u ? 21u : bin == QT_BINS - 1u ? 20u : 6u; }
+#include "k_qtile.h"
 
 // ------------------------------------------------------------------ checkpoints of an index
 // entries of list k: stride 2^j cells (one cell = 2^QT_CELL_LOG2 structure ids), n_e = ceil(NC / 2^j) chunks, the boundaries 1..n_e-1
@@ -160,67 +145,11 @@ __global__ void k_qt_plan(qt_args A) {
     if (r64 >= A.nq || gran >= n_gran) return;
     const uint32_t r = (uint32_t)r64;
     const uint64_t g = (uint64_t)gran * A.nq + r;
-    uint4 out = make_uint4(0u, 0u, 0u, 0u);
-    const long long k = A.kidx[r];
-    if (k >= 0) {
-        const uint64_t b0 = A.offsets[k], len = A.offsets[k + 1] - b0;
-        const unsigned long long m = A.ck_meta[k];
-        const uint32_t j = (uint32_t)(m >> 56);
-        const uint2 *e = A.ck_ent + (m & ((1ull << 56) - 1ull));
-        const uint32_t n_e = (uint32_t)(((uint64_t)A.NC + (1ull << j) - 1ull) >> j);
-        const uint32_t cpt_log2 = A.tile_log2 - QT_CELL_LOG2;
-        const uint32_t c0 = gran << cpg_log2, c1 = c0 + (1u << cpg_log2) < A.NC ? c0 + (1u << cpg_log2) : A.NC;
-        const uint32_t tile_c0 = (c0 >> cpt_log2) << cpt_log2;
-        const uint32_t e0 = c0 >> j, e1 = ((c1 - 1u) >> j) + 1u;
-        const uint32_t first_c = (e0 << j) > tile_c0 ? (e0 << j) : tile_c0;       // the entry's first cell inside this tile
-        if (j <= cpg_log2 || c0 == first_c) {
-            uint32_t sb = 0, prev = 0;
-            if (e0 && n_e > 1u) { const uint2 x = e[e0 - 1u]; sb = x.x; prev = x.y; }
-            const uint64_t eb = (e1 >= n_e || n_e <= 1u) ? len : (uint64_t)e[e1 - 1u].x;
-            const uint64_t p = b0 + sb;
-            out = make_uint4((uint32_t)p, (uint32_t)(p >> 32), (uint32_t)(eb - sb), prev);
-        }
-    }
+    const uint4 out = qt_piece_range(A, r, gran, cpg_log2);
     A.ranges[g] = out;
 }
 
 // ------------------------------------------------------------------ tile scoring
-// inclusive prefix sum over the wavefront in six DPP adds (row_shr 1/2/4/8 inside the rows of 16 lanes, then row_bcast:15 / row_bcast:31
-// carry the row totals across) — __shfl_up costs a ds_bpermute round trip per step
-__device__ __forceinline__ uint32_t qt_wave_incl(uint32_t v, uint32_t /*lane*/) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-    return v;
-}
-// exclusive scan over the workgroup's NTHR values (two barriers); s_w: NTHR / 64 words of LDS
-template <int NTHR>
-__device__ __forceinline__ uint32_t qt_block_excl(uint32_t v, uint32_t tid, uint32_t *s_w, uint32_t *total) {
-    const uint32_t lane = tid & 63u, wv = tid >> 6;
-    const uint32_t incl = qt_wave_incl(v, lane);
-    if (lane == 63u) s_w[wv] = incl;
-    __syncthreads();
-    uint32_t pre = 0, tot = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < NTHR / 64; ++k) { const uint32_t x = s_w[k]; pre += k < wv ? x : 0u; tot += x; }
-    __syncthreads();
-    *total = tot;
-    return pre + incl - v;
-}
-typedef unsigned int qt_u32x4 __attribute__((ext_vector_type(4)));
-struct qt_step { qt_u32x4 w; uint32_t c, pstart, nby, rel; };
-
-// groups (runs of rows that end at a set bit of `ends`) holding at least one set bit of `m`, one 32-row word of a longer row list:
-// adding the non-end hits to the non-end positions lets a hit's carry run up to its group's end bit; carry = the group straddles the word
-__device__ __forceinline__ uint32_t qt_groups_hit(uint32_t m, uint32_t ends, uint32_t valid, uint32_t &carry) {
-    const unsigned long long sum = (unsigned long long)(m & ~ends) + (unsigned long long)(~ends & valid) + carry;
-    carry = (uint32_t)(sum >> 32);
-    return (uint32_t)__popc((((uint32_t)sum) & ends) | (m & ends));
-}
-
 // RICH = false: scores of every structure of the tile (pass A).  RICH = true: the records of the survivors (pass B).
 // TL2: log2 structures per tile; NTHR threads; RB rows planned per batch; RBW words of row bits (pass B)
 // BIG = false: a batch of motif queries, workgroup = (query, tile), all rows of the query.  BIG = true: ONE query of ~10^5 rows (a whole
@@ -656,7 +585,8 @@ __global__ __launch_bounds__(NTHR) void k_qt_rows(qt_args A) {
     const uint32_t wpr = (nrows + 31u) >> 5, per_round = (uint32_t)RBW / wpr, n_rounds = (n_surv + per_round - 1u) / per_round;
     if (tid == 0) s_base = atomicAdd(&A.state[q].count, n_surv);
     constexpr uint32_t CPT = 1u << (TL2 - QT_CELL_LOG2);
-    const uint32_t cell0 = t * CPT, ncell = A.NC - cell0 < CPT ? A.NC - cell0 : CPT, n_batches = (nrows * ncell + RBA - 1u) / RBA;
+    // (k_qt_score32 leaves one run of records per (query, tile): first record + slot)
+    const uint32_t cell0 = t * CPT, ncell = A.NC - cell0 < CPT ? A.NC - cell0 : CPT, n_batches = A.heads ? 1u : (nrows * ncell + RBA - 1u) / RBA;
     const qt_u32x4 *ids = reinterpret_cast<const qt_u32x4 *>(A.stream_ids);
     for (uint32_t round = 0; round < n_rounds; ++round) {
         const uint32_t s_lo = round * per_round;
@@ -995,7 +925,8 @@ void fd_launch_qt_select(const qt_args &A, uint32_t top_n, void *sorted, hipStre
     if (!A.n_queries || !A.S) return;
     const dim3 g(A.NT * A.n_queries);
     hipLaunchKernelGGL(k_qt_thr, dim3(A.n_queries), dim3(1024), 0, st, A, top_n);
-    if (A.stream_ids && A.tile_log2 == 14) hipLaunchKernelGGL((k_qt_rows<14, 512, 6144, 512>), g, dim3(512), 0, st, A);
+    if (A.stream_ids && A.tile_log2 == 15) hipLaunchKernelGGL((k_qt_rows<15, 512, 6144, 512>), g, dim3(512), 0, st, A);
+    else if (A.stream_ids && A.tile_log2 == 14) hipLaunchKernelGGL((k_qt_rows<14, 512, 6144, 512>), g, dim3(512), 0, st, A);
     else if (A.stream_ids) hipLaunchKernelGGL((k_qt_rows<13, 512, 6144, 256>), g, dim3(512), 0, st, A);
     else if (A.tile_log2 == 14) hipLaunchKernelGGL((k_qt_score<true, 14, 1024, 512, 6144>), g, dim3(1024), 0, st, A);
     else hipLaunchKernelGGL((k_qt_score<true, 13, 512, 256, 6144>), g, dim3(512), 0, st, A);

@@ -34,7 +34,7 @@ def format_f32_display(v) -> str:
         out = digits + "0" * (ex + 1 - len(digits))
     else:
         out = digits[: ex + 1] + "." + digits[ex + 1:]
-    return ("-" if neg and out.strip("0.") else "") + out
+    return ("-" if neg else "") + out          # -0.0 -> "-0" like Rust
 
 
 _ID_TYPES = {"Pdb": "pdb", "PDB": "pdb", "pdb": "pdb", "Afdb": "afdb", "AFDB": "afdb", "afdb": "afdb", "Uniprot": "uniprot", "UniProt": "uniprot",

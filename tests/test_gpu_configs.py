@@ -385,6 +385,7 @@ def test_tiled_scoring_equals_occupancy_rows(human, monkeypatch):
     monkeypatch.setenv("FDGPU_QTILE", "0")
     full_m = fd.count_query_maps(ctx, ix, qms, pen, total_structures=HUMAN, top_n=0)
     monkeypatch.setenv("FDGPU_QTILE", "1")
+    monkeypatch.setenv("FDGPU_QT32", "0")
     for N in (5, 1000):
         for tile in ("13", "14"):
             for stream in ("1", "0"):
@@ -393,6 +394,32 @@ def test_tiled_scoring_equals_occupancy_rows(human, monkeypatch):
                 for f, x in zip(full_m, got):
                     assert x.tobytes() == rank_hits(f, N).tobytes(), (N, tile, stream)
     monkeypatch.delenv("FDGPU_QT_STREAM")
+    # ... and the default since round 6: 32-bit sums over a planned slot stream (k_qscore32.hip; tiles of 2^14 or 2^15 structures), every cut
+    # incl. the ones that take the whole tile's keys (more than the tile holds), ties around the cut, a shard's sub-range of the ids
+    for mode in ("14", "15"):
+        monkeypatch.setenv("FDGPU_QT32", mode)
+        for N in (1, 5, 1000, 3000):
+            got = fd.count_query_maps(ctx, ix, qms, pen, total_structures=HUMAN, top_n=N)
+            for f, x in zip(full_m, got):
+                assert x.tobytes() == rank_hits(f, N).tobytes(), (N, mode)
+    monkeypatch.setenv("FDGPU_QTILE", "0")
+    ones = np.ones_like(pen)
+    full_1 = fd.count_query_maps(ctx, ix, qms, ones, total_structures=HUMAN, top_n=0)
+    sub_m = fd.FolddiscoIndex.load(ctx, h, o, v, 17000, first_id=3000)
+    qms_s = fq.make_query_maps(ctx, qall, [(k, Q["idx"], Q["subs"]) for k, Q in enumerate(Qs)], sub_m, float(HUMAN))      # (a map remembers ITS index's lists)
+    full_sm = fd.count_query_maps(ctx, sub_m, qms_s, pen[3000:20000].copy(), total_structures=HUMAN, top_n=0)
+    assert all((f["nid"] >= 3000).all() and (f["nid"] < 20000).all() for f in full_sm if len(f))
+    monkeypatch.setenv("FDGPU_QTILE", "1")
+    for mode in ("14", "15"):
+        monkeypatch.setenv("FDGPU_QT32", mode)
+        for N in (50, 1000):
+            got = fd.count_query_maps(ctx, ix, qms, ones, total_structures=HUMAN, top_n=N)
+            for f, x in zip(full_1, got):
+                assert x.tobytes() == rank_hits(f, N).tobytes(), (N, mode, "ties")
+            got = fd.count_query_maps(ctx, sub_m, qms_s, pen[3000:20000].copy(), total_structures=HUMAN, top_n=N)
+            for f, x in zip(full_sm, got):
+                assert x.tobytes() == rank_hits(f, N).tobytes(), (N, mode, "shard")
+    monkeypatch.delenv("FDGPU_QT32")
     # ties: a penalty of 1 makes the key a function of the matched rows alone — thousands of equal keys around the cut
     one = np.ones_like(pen)
     full1 = run(ix, one, HUMAN, 0, False)

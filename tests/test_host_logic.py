@@ -603,13 +603,13 @@ def test_lookup_writer_prints_f32_like_rust_display(tmp_path):
     50,000 random bit patterns; the file round-trips through load_lookup."""
     import ctypes as C
     from folddisco_amd import _lib, indexio
-    fixed = {50.0: "50", 0.0: "0", 100.0: "100", 0.1: "0.1", 1e-7: "0.0000001", 3.4028235e38: "340282350000000000000000000000000000000", 1e10: "10000000000",
-             13.540356: "13.540356", 16777216.0: "16777216", 0.5: "0.5", 1.5e-5: "0.000015", -2.5: "-2.5"}
-    v = np.array(list(fixed), np.float32)
+    fixed = [(50.0, "50"), (0.0, "0"), (100.0, "100"), (0.1, "0.1"), (1e-7, "0.0000001"), (3.4028235e38, "340282350000000000000000000000000000000"), (1e10, "10000000000"),
+             (13.540356, "13.540356"), (16777216.0, "16777216"), (0.5, "0.5"), (1.5e-5, "0.000015"), (-2.5, "-2.5"), (-0.0, "-0")]
+    v = np.array([x for x, _ in fixed], np.float32)
     out = C.create_string_buffer(64 * len(v))
     assert _lib.load().fdgpu_format_f32_display(v.ctypes.data_as(_lib.f32p), len(v), out) == 0
     got = [out.raw[64 * k:64 * k + 64].split(b"\0")[0].decode() for k in range(len(v))]
-    assert got == list(fixed.values()) and got == [indexio.format_f32_display(x) for x in v]
+    assert got == [w for _, w in fixed] and got == [indexio.format_f32_display(x) for x in v]
     rng = np.random.default_rng(5)
     with np.errstate(all="ignore"):
         vals = np.concatenate([rng.integers(0, 2 ** 32, 50000, dtype=np.uint64).astype(np.uint32).view(np.float32),

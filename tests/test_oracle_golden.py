@@ -255,7 +255,7 @@ def test_f32_display():
     L = oracle.lib()
     buf = C.create_string_buffer(64)
     for v, want in [(50.0, "50"), (0.0, "0"), (13.540419, "13.540419"), (0.1, "0.1"), (1e-7, "0.0000001"),
-                    (float("nan"), "NaN"), (1.5e10, "15000000000"), (34.239895, "34.239895")]:
+                    (float("nan"), "NaN"), (1.5e10, "15000000000"), (34.239895, "34.239895"), (-0.0, "-0"), (-2.5, "-2.5")]:
         L.fdo_format_f32_display(v, buf, 64)
         assert buf.value.decode() == want, (v, buf.value)
 
