@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libfdgpu.so")
 # k_hash.hip: the SLP vectoriser packs the pair geometry into v_pk_* ops at the price of ~2 v_mov per packed op; the pair
 # kernel is VALU-issue bound, scalar code is ~10 % fewer instructions (measured faster)
 EXTRA_FLAGS = {"k_hash.hip": os.environ.get("FD_KHASH_FLAGS", "-fno-slp-vectorize").split()}
-SOURCES = ["fdgpu_api.hip", "k_hash.hip", "k_sort.hip", "k_index.hip", "k_merge.hip", "k_query.hip", "k_qtile.hip", "k_qscore32.hip", "k_match.hip", "k_retrieve.hip", "fd_query_map.hip", "fd_host_query.hip", "fd_comm.hip", "fd_lanes.hip", "fd_shard_index.hip", "fd_ingest.cpp", "fd_inflate.cpp", "fd_fcz.cpp"]
+SOURCES = ["fdgpu_api.hip", "fd_api_count.hip", "fd_api_match.hip", "k_hash.hip", "k_sort.hip", "k_index.hip", "k_merge.hip", "k_query.hip", "k_qtile.hip", "k_qscore32.hip", "k_match.hip", "k_retrieve.hip", "fd_query_map.hip", "fd_host_query.hip", "fd_comm.hip", "fd_lanes.hip", "fd_shard_index.hip", "fd_ingest.cpp", "fd_inflate.cpp", "fd_fcz.cpp"]
 
 
 def hipcc() -> str:

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "../../include/fdgpu.h"
+#include "../../include/fdgpu_debug.h"
 #include "fd_fcz.h"
 #include "fd_inflate.h"
 

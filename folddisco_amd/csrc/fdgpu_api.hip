@@ -16,18 +16,7 @@
 #include <cerrno>
 #include <cstring>
 
-#define HIPCHK(ctx, expr)                                                                                   \
-    do {                                                                                                    \
-        hipError_t _e = (expr);                                                                             \
-        if (_e != hipSuccess) {                                                                             \
-            char _b[512];                                                                                   \
-            snprintf(_b, sizeof _b, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));  \
-            (ctx)->err = _b;                                                                                \
-            return FDGPU_EHIP;                                                                              \
-        }                                                                                                   \
-    } while (0)
-
-#define FAIL(ctx, code, msg) do { (ctx)->err = (msg); return (code); } while (0)
+#include "fd_api_common.h"
 
 // ---- small kernels used only here ------------------------------------------------------------------
 __global__ void k_uniq_flags(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ids, uint64_t n, uint8_t *__restrict__ flags) {
@@ -62,7 +51,6 @@ __global__ __launch_bounds__(256) void k_count_postings(const uint8_t *__restric
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
-static void reset_timings(fdgpu_ctx *c) { c->timings.clear(); c->event_used = 0; }
 
 // ---- context ------------------------------------------------------------------------------------------------
 extern "C" const char *fdgpu_version(void) { return "folddisco_amd 0.1 (gfx950)"; }
@@ -74,7 +62,6 @@ extern "C" const char *fdgpu_version(void) { return "folddisco_amd 0.1 (gfx950)"
 //     build on a host whose libm rounds differently (e.g. glibc >= 2.40 CORE-MATH) would hash differently from this library, so the
 //     same restatement compiled for the host is compared with the host's libm around every quantiser threshold; the verdict is
 //     kept in the context (fdgpu_host_libm_matches) and a mismatch is reported once on stderr.
-static fd_hash_consts make_consts(const fd_hash_params *p);
 static int fd_selfcheck(fdgpu_ctx *c) {
     const char *e = getenv("FDGPU_SELFCHECK");
     if (e && e[0] == '0') return FDGPU_OK;
@@ -397,7 +384,7 @@ bool fd_hash_type_supported(uint32_t t) { return t <= 8u; }   // HashType::get_w
 // nbd / nba: requested bin counts.  either_zero_defaults: the rule of the single-configuration callers (either count 0 -> both
 // defaults, controller/feature.rs:216-223, query.rs:72-77); the per-encoding perfect_hash itself treats the two counts
 // independently (pdb_tr.rs:22-35 etc.), which is what the --multiple-bins list reaches (zero counts are rejected there).
-static fd_hash_consts make_consts_bins(const fd_hash_params *p, uint32_t nbd_req, uint32_t nba_req, bool either_zero_defaults) {
+fd_hash_consts make_consts_bins(const fd_hash_params *p, uint32_t nbd_req, uint32_t nba_req, bool either_zero_defaults) {
     // convert.rs:32-36 quantiser factors evaluated in f32 exactly like the reference
     const uint32_t type = p->hash_type;
     uint32_t cap_d = 16, def_d = 16, cap_a = 4, def_a = 4;
@@ -445,7 +432,7 @@ static fd_hash_consts make_consts_bins(const fd_hash_params *p, uint32_t nbd_req
     return C;
 }
 
-static fd_hash_consts make_consts(const fd_hash_params *p) { return make_consts_bins(p, p->nbin_dist, p->nbin_angle, true); }
+fd_hash_consts make_consts(const fd_hash_params *p) { return make_consts_bins(p, p->nbin_dist, p->nbin_angle, true); }
 fd_hash_consts fd_make_consts(const fd_hash_params *p) { return make_consts(p); }
 // configuration k of the --multiple-bins list (k < n_multiple_bins), or the single configuration when the list is empty
 uint32_t fd_num_bin_configs(const fd_hash_params *p) { return p->n_multiple_bins ? p->n_multiple_bins : 1u; }
@@ -460,7 +447,7 @@ bool fd_multiple_bins_valid(const fd_hash_params *p) {
     return true;
 }
 
-static int d2h_u64(fdgpu_ctx *c, const uint64_t *dev, uint64_t *host) {
+int d2h_u64(fdgpu_ctx *c, const uint64_t *dev, uint64_t *host) {
     HIPCHK(c, hipMemcpyAsync(host, dev, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FDGPU_OK;
@@ -506,7 +493,7 @@ static int ensure_sort_ws(fdgpu_ctx *c, uint64_t P, size_t id_bytes = 4) {
 
 // stable sort of (keys, vals) by the low key_bits of keys; FDGPU_SORT=classic selects the 3-kernel LSD variant
 static int sort_mode();
-static int sort_pairs(fdgpu_ctx *c, uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb, uint64_t n, int key_bits) {
+int sort_pairs(fdgpu_ctx *c, uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb, uint64_t n, int key_bits) {
     (void)sort_mode();
     return fd_radix_sort_pairs(ka, va, kb, vb, n, key_bits, c->ws[WS_GHIST].as<uint32_t>(), c->ws[WS_TOT].as<uint64_t>(), c->stream, c);
 }
@@ -1136,1524 +1123,6 @@ extern "C" int fdgpu_index_save(fdgpu_ctx *c, const fdgpu_index *ix, const char 
     if (trace) fprintf(stderr, "[index_save] files closed at %.3f ms\n", ms());
     if (e != hipSuccess) { c->err = std::string("index save: ") + hipGetErrorString(e); return FDGPU_EHIP; }
     if (io_err) FAIL(c, FDGPU_EINVAL, "index save: cannot write " + p + " (" + strerror(io_err) + ")");
-    return FDGPU_OK;
-}
-
-// ---- S3 ---------------------------------------------------------------------------------------------------------------
-// posting lengths of nq query hashes (host array) left ON THE DEVICE in the context's WS_MISC1 (u64 [nq]); the sharded query all-reduces
-// them there (fd_comm.hip).  No synchronisation.
-int fd_posting_lengths_dev(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t **dev_lengths) {
-    hipStream_t st = c->stream;
-    HIPCHK(c, c->ws[WS_MISC0].ensure(std::max<uint64_t>(nq, 1) * 4));
-    HIPCHK(c, c->ws[WS_MISC1].ensure(std::max<uint64_t>(nq, 1) * 8));
-    *dev_lengths = c->ws[WS_MISC1].as<uint64_t>();
-    if (!nq) return FDGPU_OK;
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(nq * 8));
-    HIPCHK(c, c->ws[WS_CQ_NSEG].ensure(nq * 4));
-    static const bool lens_cache = [] { const char *e = getenv("FDGPU_LENS_CACHE"); return !(e && e[0] == '0'); }();
-    if (lens_cache && ix->n_hashes) {
-        // the index remembers the length of every list (4 bytes per hash, one pass over the value bytes on the first request)
-        {
-            std::lock_guard<std::mutex> lk(ix->lens_mu);
-            if (!ix->lens) {
-                uint32_t *l = nullptr;
-                HIPCHK(c, hipMalloc((void **)&l, ix->n_hashes * 4));
-                fd_launch_index_lens(ix->offsets, ix->value, ix->n_hashes, l, st);
-                hipError_t le = hipGetLastError();
-                if (le == hipSuccess) le = hipStreamSynchronize(st);      // other contexts read it from their own streams
-                if (le != hipSuccess) { (void)hipFree(l); c->err = std::string("posting lengths of the index: ") + hipGetErrorString(le); return FDGPU_EHIP; }
-                ix->lens = l;
-            }
-        }
-        fd_launch_posting_lookup(ix->hashes, ix->offsets, ix->lens, ix->n_hashes, c->ws[WS_MISC0].as<uint32_t>(), nq, c->ws[WS_MISC1].as<uint64_t>(),
-                                 c->ws[WS_CQ_NSEG].as<uint32_t>(), c->ws[WS_CQ_KIDX].as<long long>(), st);
-        HIPCHK(c, hipGetLastError());
-        return FDGPU_OK;
-    }
-    HIPCHK(c, c->ws[WS_CQ_WSTART].ensure((nq + 2) * 8));
-    HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(nq) * 8 + 64));
-    HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
-    fd_launch_posting_lengths(ix->hashes, ix->offsets, ix->value, ix->n_hashes, c->ws[WS_MISC0].as<uint32_t>(), nq, c->ws[WS_MISC1].as<uint64_t>(),
-                              c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), c->ws[WS_CQ_WSTART].as<uint64_t>(),
-                              c->ws[WS_SCANTMP].as<uint64_t>(), c->ws[WS_TOTAL].as<uint64_t>(), st);
-    HIPCHK(c, hipGetLastError());
-    return FDGPU_OK;
-}
-// lengths and the number of CQ_SEG-byte scoring segments of every hash (what k_cq_plan will find again), one synchronisation
-int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs, long long *kidx) {
-    if (!nq) return FDGPU_OK;
-    uint64_t *d = nullptr;
-    int rc = fd_posting_lengths_dev(c, ix, q_hash, nq, &d);
-    if (rc) return rc;
-    // the three arrays land in one page-locked block (a pageable destination makes every copy a staged, blocking one)
-    uint8_t *land = (uint8_t *)c->host_pinned(3, nq * 20);
-    if (!land) {
-        HIPCHK(c, hipMemcpyAsync(lengths, d, nq * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(segs, c->ws[WS_CQ_NSEG].p, nq * 4, hipMemcpyDeviceToHost, c->stream));
-        if (kidx) HIPCHK(c, hipMemcpyAsync(kidx, c->ws[WS_CQ_KIDX].p, nq * 8, hipMemcpyDeviceToHost, c->stream));     // both length paths leave the list positions there
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        return FDGPU_OK;
-    }
-    HIPCHK(c, hipMemcpyAsync(land, d, nq * 8, hipMemcpyDeviceToHost, c->stream));
-    if (kidx) HIPCHK(c, hipMemcpyAsync(land + nq * 8, c->ws[WS_CQ_KIDX].p, nq * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(land + nq * 16, c->ws[WS_CQ_NSEG].p, nq * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    memcpy(lengths, land, nq * 8);
-    if (kidx) memcpy(kidx, land + nq * 8, nq * 8);
-    memcpy(segs, land + nq * 16, nq * 4);
-    return FDGPU_OK;
-}
-extern "C" int fdgpu_posting_lengths(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths) { FD_LOCK(c);
-    if (!c || !ix || (nq && (!q_hash || !lengths))) return FDGPU_EINVAL;
-    if (!nq) return FDGPU_OK;
-    uint64_t *d = nullptr;
-    int rc = fd_posting_lengths_dev(c, ix, q_hash, nq, &d);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(lengths, d, nq * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return FDGPU_OK;
-}
-
-void fd_launch_posting_bytes(const uint32_t *hashes, const uint64_t *offsets, uint64_t H, const uint32_t *q_hash, uint64_t nq, uint64_t *bytes, hipStream_t st);
-extern "C" int fdgpu_posting_bytes(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *bytes) { FD_LOCK(c);
-    if (!c || !ix || (nq && (!q_hash || !bytes))) return FDGPU_EINVAL;
-    if (!nq) return FDGPU_OK;
-    hipStream_t st = c->stream;
-    HIPCHK(c, c->ws[WS_MISC0].ensure(nq * 4));
-    HIPCHK(c, c->ws[WS_MISC1].ensure(nq * 8));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st));
-    fd_launch_posting_bytes(ix->hashes, ix->offsets, ix->n_hashes, c->ws[WS_MISC0].as<uint32_t>(), nq, c->ws[WS_MISC1].as<uint64_t>(), st);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(bytes, c->ws[WS_MISC1].p, nq * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    return FDGPU_OK;
-}
-
-// get_entries for many hashes: ids of hash k = (*ids)[(*ids_off)[k] .. (*ids_off)[k+1])
-extern "C" int fdgpu_get_entries(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint32_t **ids, uint64_t **ids_off) { FD_LOCK(c);
-    if (!c || !ix || !ids || !ids_off || (nq && !q_hash)) return FDGPU_EINVAL;
-    *ids = nullptr; *ids_off = nullptr;
-    uint64_t *off = (uint64_t *)calloc(nq + 1, 8);
-    if (!off) return FDGPU_ENOMEM;
-    std::vector<uint64_t> lens(std::max<uint64_t>(nq, 1));
-    int rc = fdgpu_posting_lengths(c, ix, q_hash, nq, lens.data());
-    if (rc) { free(off); return rc; }
-    for (uint64_t k = 0; k < nq; ++k) off[k + 1] = off[k] + lens[k];
-    const uint64_t tot = off[nq];
-    uint32_t *out = (uint32_t *)malloc(std::max<uint64_t>(tot, 1) * 4);
-    if (!out) { free(off); return FDGPU_ENOMEM; }
-    if (tot) {
-        hipStream_t st = c->stream;
-        hipError_t e = c->ws[WS_MISC0].ensure(nq * 4);
-        if (e == hipSuccess) e = c->ws[WS_MISC1].ensure((nq + 1) * 8);
-        if (e == hipSuccess) e = c->ws[WS_MISC2].ensure(tot * 4);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->ws[WS_MISC0].p, q_hash, nq * 4, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->ws[WS_MISC1].p, off, (nq + 1) * 8, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) {
-            fd_launch_get_entries(ix->hashes, ix->offsets, ix->value, ix->n_hashes, c->ws[WS_MISC0].as<uint32_t>(), nq, c->ws[WS_MISC1].as<uint64_t>(),
-                                  c->ws[WS_MISC2].as<uint32_t>(), st);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(out, c->ws[WS_MISC2].p, tot * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { free(off); free(out); c->err = std::string("get_entries: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-    }
-    *ids = out; *ids_off = off;
-    return FDGPU_OK;
-}
-
-// plan (list positions, CQ_SEG-byte segments) + segment-parallel scoring of the query hashes in A (k_query.hip)
-// idf of a query hash in the accumulators' fixed point (2^-22; count_query.rs:181-200 sums f32 in hash-map order, here the sum is exact
-// and order-independent to 2.4e-7 per addend)
-static inline uint64_t fd_idf_fix(float idf) {
-    const double v = (double)idf;
-    return (v > 0.0 && v < 1.0e6) ? (uint64_t)(v * 4194304.0 + 0.5) : 0ull;
-}
-// The rows of one query in (node, partner) order with their metadata word: idf (2^-22 fixed point) << 2 | last row of its node << 1 |
-// last row of its edge.  -> false when an idf does not fit the packed accumulator (>= 32).
-static bool fd_cq_rows(const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, uint64_t a, uint64_t b,
-                       std::vector<uint32_t> &rows_hash, std::vector<unsigned long long> &rows_meta, const long long *q_kidx = nullptr,
-                       std::vector<long long> *rows_kidx = nullptr) {
-    std::vector<uint64_t> ord(b - a);
-    for (uint64_t k = a; k < b; ++k) ord[k - a] = k;
-    bool small_ids = true, in_order = true;
-    for (uint64_t k = a; k < b && small_ids; ++k) small_ids = q_node[k] < 65536u && q_edge_j[k] < 65536u;
-    // a query map lists its entries pair by pair in row-major (i, j) order (query.rs:231-329): a whole-structure query's 10^5 rows arrive sorted
-    for (uint64_t k = a + 1; k < b && in_order; ++k) in_order = q_node[k - 1] < q_node[k] || (q_node[k - 1] == q_node[k] && q_edge_j[k - 1] <= q_edge_j[k]);
-    if (in_order) {
-    } else if (b - a > 2048 && small_ids) {
-        // a whole-structure query has ~10^5 rows: (node, partner) order by a stable LSD radix sort of node << 16 | partner (a comparison
-        // sort of the index array took several milliseconds of the prefilter)
-        std::vector<uint64_t> tmp(ord.size());
-        for (int pass = 0; pass < 4; ++pass) {
-            const int sh = 8 * pass;
-            size_t cnt[257] = {0};
-            auto key = [&](uint64_t k) { return ((q_node[k] << 16) | q_edge_j[k]) >> sh & 255u; };
-            for (uint64_t k : ord) ++cnt[key(k) + 1];
-            for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
-            for (uint64_t k : ord) tmp[cnt[key(k)]++] = k;
-            ord.swap(tmp);
-        }
-    } else
-    std::stable_sort(ord.begin(), ord.end(), [&](uint64_t x, uint64_t y) {
-        return q_node[x] != q_node[y] ? q_node[x] < q_node[y] : q_edge_j[x] < q_edge_j[y];
-    });
-    bool fits = true;
-    const size_t n = ord.size(), base = rows_hash.size();
-    rows_hash.resize(base + n); rows_meta.resize(base + n);
-    const bool with_k = q_kidx && rows_kidx;
-    if (with_k) rows_kidx->resize(base + n);
-    uint32_t *const oh = rows_hash.data() + base;
-    unsigned long long *const om = rows_meta.data() + base;
-    long long *const ok = with_k ? rows_kidx->data() + base : nullptr;
-    const uint64_t *const od = ord.data();
-    for (size_t z = 0; z < n; ++z) {
-        const uint64_t k = od[z];
-        const uint64_t fix = fd_idf_fix(q_idf[k]);
-        fits = fits && fix < (1ull << 27);
-        const bool last = z + 1 == n;
-        const bool node_end = last || q_node[od[z + 1]] != q_node[k];
-        const bool edge_end = node_end || q_edge_j[od[z + 1]] != q_edge_j[k];
-        oh[z] = q_hash[k];
-        if (ok) ok[z] = q_kidx[k];
-        om[z] = ((unsigned long long)fix << 2) | (node_end ? 2ull : 0ull) | (edge_end ? 1ull : 0ull);
-    }
-    return fits;
-}
-static int cq_score(fdgpu_ctx *c, const cq_args &A, int64_t known_segments = -1) {
-    hipStream_t st = c->stream;
-    HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(A.nq * 8));
-    HIPCHK(c, c->ws[WS_CQ_NSEG].ensure(A.nq * 4));
-    HIPCHK(c, c->ws[WS_CQ_WSTART].ensure((A.nq + 2) * 8));
-    HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(A.nq) * 8 + 64));
-    HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
-    fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
-    fd_exclusive_scan<uint32_t>(c->ws[WS_CQ_NSEG].as<uint32_t>(), A.nq, c->ws[WS_CQ_WSTART].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
-                                c->ws[WS_TOTAL].as<uint64_t>(), st);
-    HIPCHK(c, hipGetLastError());
-    uint64_t W = (uint64_t)known_segments;      // the caller knows the work count (query maps remember their hashes' segments): no round trip
-    if (known_segments < 0) {
-        int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &W);
-        if (rc) return rc;
-    }
-    HIPCHK(c, c->ws[WS_CQ_SEGSUM].ensure(std::max<uint64_t>(W, 1) * 4));
-    fd_launch_cq_seg(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_WSTART].as<uint64_t>(), c->ws[WS_CQ_SEGSUM].as<uint32_t>(), W, W > 0, st);
-    return FDGPU_OK;
-}
-
-extern "C" int fdgpu_count_query(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, const uint32_t *q_node, const uint32_t *q_edge_j,
-                                 const float *q_idf, uint64_t nq, const float *penalty, fd_count_rec **out, uint64_t *n_out) { FD_LOCK(c);
-    if (!c || !ix || !out || !n_out || (nq && (!q_hash || !q_node || !q_edge_j || !q_idf)) || (ix->n_structures && !penalty && !ix->penalty)) return FDGPU_EINVAL;
-    *out = nullptr; *n_out = 0;
-    reset_timings(c);
-    hipStream_t st = c->stream;
-    const uint64_t S = ix->n_structures;
-    if (S == 0 || nq == 0) { *out = (fd_count_rec *)malloc(sizeof(fd_count_rec)); return *out ? FDGPU_OK : FDGPU_ENOMEM; }
-    if (S >= 0xffffffe0ull) FAIL(c, FDGPU_ERANGE, "too many structures");
-    std::vector<uint32_t> rows_hash;
-    std::vector<unsigned long long> rows_meta;
-    rows_hash.reserve(nq); rows_meta.reserve(nq);
-    const bool packed = fd_cq_rows(q_hash, q_node, q_edge_j, q_idf, 0, nq, rows_hash, rows_meta) && nq < (1ull << 18);
-    const uint32_t words = (uint32_t)((S + 31) / 32);
-    // workspace
-    HIPCHK(c, c->ws[WS_MISC0].ensure(nq * 4));   // query hashes in row order
-    HIPCHK(c, c->ws[WS_MISC3].ensure(nq * 8));   // row metadata
-    HIPCHK(c, c->ws[WS_COUNTS].ensure(S * 4));   // match counts (wide form)
-    HIPCHK(c, c->ws[WS_SEGOFF].ensure((S + 2) * 8));  // (count, idf sum)
-    HIPCHK(c, c->ws[WS_KEYS_B].ensure((size_t)nq * words * 4));   // occupancy rows
-    HIPCHK(c, c->ws[WS_IDS_A].ensure(S * 4));    // node counts
-    HIPCHK(c, c->ws[WS_IDS_B].ensure(S * 4));    // edge counts
-    HIPCHK(c, c->ws[WS_MISC4].ensure(S + 8));    // flags
-    HIPCHK(c, c->ws[WS_TILE_BO].ensure((S + 2) * 8));  // positions
-    HIPCHK(c, c->ws[WS_MISC5].ensure(S * 4));    // penalty
-    HIPCHK(c, c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(S) * 8 + 64));
-    HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, rows_hash.data(), nq * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC3].p, rows_meta.data(), nq * 8, hipMemcpyHostToDevice, st));
-    if (penalty) HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st));
-    const float *d_penalty = penalty ? c->ws[WS_MISC5].as<float>() : ix->penalty;
-    cq_args A;
-    A.hashes = ix->hashes; A.offsets = ix->offsets; A.value = ix->value; A.H = ix->n_hashes;
-    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.nq = nq;
-    A.hash_bits = c->ws[WS_KEYS_B].as<uint32_t>(); A.row_meta = c->ws[WS_MISC3].as<unsigned long long>();
-    A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>(); A.packed = packed ? 1 : 0;
-    A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
-    {
-        StageTimer t(c, "cq_accumulate", 0);
-        int rs = cq_score(c, A);
-        if (rs) return rs;
-    }
-    std::vector<uint64_t> slices;        // outlives the asynchronous copy below (the stream is synchronised before this function returns)
-    {
-        StageTimer t(c, "cq_finalize", (uint64_t)nq * words * 4 + S * 16);
-        // thousands of rows (whole-structure queries): S / 4096 workgroups of word columns do not fill the chip — cut the rows into ~32
-        // slices at node boundaries
-        if (nq >= 4096) {
-            const uint64_t per = (nq + 31) / 32;
-            slices.push_back(0);
-            for (uint64_t r = 0; r + 1 < nq; ++r)
-                if ((rows_meta[r] & 2ull) && r + 1 - slices.back() >= per) slices.push_back(r + 1);
-            slices.push_back(nq);
-            HIPCHK(c, c->ws[WS_TILE_B].ensure(slices.size() * 8));
-            HIPCHK(c, hipMemcpyAsync(c->ws[WS_TILE_B].p, slices.data(), slices.size() * 8, hipMemcpyHostToDevice, st));
-        }
-        fd_launch_cq_rows_finalize(A, nullptr, 1, slices.empty() ? nullptr : c->ws[WS_TILE_B].as<uint64_t>(), slices.empty() ? 0u : (uint32_t)slices.size() - 1,
-                                   c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(), nq, st);
-        fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), S, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
-                                   c->ws[WS_TOTAL].as<uint64_t>(), st);
-    }
-    HIPCHK(c, hipGetLastError());
-    uint64_t n = 0;
-    int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &n);
-    if (rc) return rc;
-    fd_count_rec *r = (fd_count_rec *)malloc(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec));
-    if (!r) return FDGPU_ENOMEM;
-    HIPCHK(c, c->ws[WS_TILE_HO].ensure(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec)));
-    fd_launch_cq_compact(packed ? nullptr : A.match, A.idf, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(),
-                         c->ws[WS_TILE_BO].as<uint64_t>(), d_penalty, (uint32_t)S, (uint32_t)ix->first_id, c->ws[WS_TILE_HO].p, st);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess && n) e = hipMemcpyAsync(r, c->ws[WS_TILE_HO].p, n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { free(r); c->err = std::string("count_query: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-    *out = r; *n_out = n;
-    return FDGPU_OK;
-}
-
-// The index's checkpoint table for tiled scoring (k_qtile.hip), made on first use for the id range the index has then: sizes per list ->
-// exclusive scan -> one sequential decode of every list long enough to hold entries.  -> FDGPU_OK with the table published, FDGPU_ENOMEM
-// when it does not fit (remembered: the caller keeps the occupancy-row path for this index).
-static int fd_index_checkpoints(fdgpu_ctx *c, const fdgpu_index *ix) {
-    std::lock_guard<std::mutex> lk(ix->lens_mu);
-    if (ix->ck_meta && ix->ck_first == ix->first_id && ix->ck_S == ix->n_structures) return FDGPU_OK;
-    // a failure is remembered for the id range it happened with (a changed range is a new table of another size) and retried every 64th request:
-    // one transient hipMalloc failure must not switch the tiled path off for the life of the index
-    if (ix->ck_failed && ix->ck_first == ix->first_id && ix->ck_S == ix->n_structures && (++ix->ck_fail_skips & 63)) return FDGPU_ENOMEM;
-    hipStream_t st = c->stream;
-    const uint64_t H = ix->n_hashes, S = ix->n_structures;
-    if (!H || !S) return FDGPU_ENOMEM;
-    if (ix->ck_meta) {
-        // the table of the previous id range: other contexts that share the index (query lanes, one context per host thread) may still have
-        // k_qt_plan / k_qt_score in flight on THEIR streams reading it — drain the whole device, not only this context's stream, before the free
-        (void)hipDeviceSynchronize();
-        (void)hipFree(ix->ck_meta); (void)hipFree(ix->ck_ent); ix->ck_meta = nullptr; ix->ck_ent = nullptr;
-    }
-    ix->ck_failed = false;
-    const uint32_t NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
-    hipError_t e = c->ws[WS_QT_COUNT].ensure(H * 4);
-    if (e == hipSuccess) e = c->ws[WS_QT_RANGES].ensure((H + 2) * 8);
-    if (e == hipSuccess) e = c->ws[WS_SCANTMP].ensure(fd_scan_tmp_elems(H) * 8 + 64);
-    if (e == hipSuccess) e = c->ws[WS_TOTAL].ensure(64);
-    unsigned long long *meta = nullptr;
-    void *ent = nullptr;
-    uint64_t n_ent = 0;
-    if (e == hipSuccess) {
-        fd_launch_ck_count(ix->offsets, H, NC, c->ws[WS_QT_COUNT].as<uint32_t>(), st);
-        fd_exclusive_scan<uint32_t>(c->ws[WS_QT_COUNT].as<uint32_t>(), H, c->ws[WS_QT_RANGES].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
-                                    c->ws[WS_TOTAL].as<uint64_t>(), st);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(&n_ent, c->ws[WS_TOTAL].p, 8, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess) e = hipMalloc((void **)&meta, H * 8);
-    if (e == hipSuccess) e = hipMalloc(&ent, std::max<uint64_t>(n_ent, 1) * 8);
-    if (e == hipSuccess) {
-        fd_launch_ck_fill(ix->offsets, ix->value, H, NC, (uint32_t)S, (uint32_t)ix->first_id, c->ws[WS_QT_RANGES].as<uint64_t>(), meta, ent, st);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);      // other contexts read the table from their own streams
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        if (meta) (void)hipFree(meta);
-        if (ent) (void)hipFree(ent);
-        ix->ck_failed = true; ix->ck_first = ix->first_id; ix->ck_S = S;
-        return FDGPU_ENOMEM;
-    }
-    ix->ck_meta = meta; ix->ck_ent = ent; ix->ck_n = n_ent; ix->ck_first = ix->first_id; ix->ck_S = S;
-    return FDGPU_OK;
-}
-
-// batched count_query: queries [q_off[t], q_off[t+1]) of the concatenated hash arrays; results of query t are
-// (*out)[(*out_off)[t] .. (*out_off)[t+1])
-// idf descending, ties by ascending structure id (the candidate ranking of query_pdb.rs:404-411), cut to top_n; -> records kept
-static uint64_t fd_rank_trim(fd_count_rec *r, uint64_t n, uint32_t top_n) {
-    auto key = [](const fd_count_rec &x) {
-        float v = x.idf + 0.0f;
-        uint32_t b; memcpy(&b, &v, 4);
-        const uint32_t o = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-        return ((uint64_t)(~o) << 32) | x.nid;
-    };
-    std::sort(r, r + n, [&](const fd_count_rec &a, const fd_count_rec &b) { return key(a) < key(b); });
-    return std::min<uint64_t>(n, top_n);
-}
-// dev != null: a call whose candidate selection runs on the device (dense_topn below) leaves its result THERE — dev->recs = [n_queries][top_n]
-// ranked records, dev->state = the per-query selection state (count = records selected) — and returns without host records (dev->got); the
-// sharded query all-gathers those buffers (fd_comm.hip).  dev->overflow: more ties at a cut-off than the selection holds (the caller
-// takes the compacting path together with the other ranks).  Calls the device selection does not serve return host records as usual.
-int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
-                              const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,
-                              fd_count_rec **out, uint64_t **out_off, bool allow_dense, fd_cq_dev_out *dev, int64_t known_segments, const long long *known_kidx,
-                              const uint64_t *known_len) {
-    if (!c || !ix || !out || !out_off || !q_off || (ix->n_structures && !penalty && !ix->penalty)) return FDGPU_EINVAL;
-    *out = nullptr; *out_off = nullptr;
-    reset_timings(c);
-    hipStream_t st = c->stream;
-    const uint64_t S = ix->n_structures, nq = q_off[n_queries];
-    const bool cq_trace = getenv("FDGPU_TRACE") != nullptr;       // host-side stage stamps on stderr (measurement aid)
-    const auto cq_t0 = std::chrono::steady_clock::now();
-    auto cq_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - cq_t0).count(); };
-    uint64_t *ooff = (uint64_t *)calloc(n_queries + 1, 8);
-    if (!ooff) return FDGPU_ENOMEM;
-    if (dev) { dev->got = false; dev->overflow = false; }
-    if (S == 0 || nq == 0 || n_queries == 0) { *out = (fd_count_rec *)malloc(sizeof(fd_count_rec)); *out_off = ooff; return *out ? FDGPU_OK : FDGPU_ENOMEM; }
-    if (!q_hash || !q_node || !q_edge_j || !q_idf) { free(ooff); return FDGPU_EINVAL; }
-    if (S >= 0xffffffe0ull || n_queries * S >= (1ull << 34)) { free(ooff); FAIL(c, FDGPU_ERANGE, "count_query_batch: n_queries x n_structures too large; split the batch"); }
-    // occupancy rows: the query hashes of the whole batch, per query in (node, partner) order
-    std::vector<uint32_t> rows_hash;
-    std::vector<unsigned long long> rows_meta;
-    std::vector<long long> rows_kidx;       // the rows' list positions when the caller knows them (query maps made against this index)
-    (void)known_len;                        // (lengths are per input row: only their sum matters below, no permutation needed)
-    rows_hash.reserve(nq); rows_meta.reserve(nq);
-    if (known_kidx) rows_kidx.reserve(nq);
-    bool packed = true, sums_fit32 = true;
-    uint64_t max_rows = 0;
-    for (uint64_t t = 0; t < n_queries; ++t) {
-        max_rows = std::max<uint64_t>(max_rows, q_off[t + 1] - q_off[t]);
-        packed = packed && (q_off[t + 1] - q_off[t]) < (1ull << 18);
-        packed = fd_cq_rows(q_hash, q_node, q_edge_j, q_idf, q_off[t], q_off[t + 1], rows_hash, rows_meta, known_kidx, &rows_kidx) && packed;
-        // 32-bit accumulators serve the batch when no row adds nothing (touched <=> sum != 0) and no query's idf units can reach 2^32
-        unsigned long long units = 0;
-        for (uint64_t r = q_off[t]; r < q_off[t + 1]; ++r) { const unsigned long long fix = rows_meta[r] >> 2; units += fix; sums_fit32 = sums_fit32 && fix != 0ull; }
-        sums_fit32 = sums_fit32 && units < (1ull << 32);
-    }
-    if (cq_trace) fprintf(stderr, "[count_query] %llu rows of %llu queries in order at %.3f ms\n", (unsigned long long)nq, (unsigned long long)n_queries, cq_ms());
-    const uint32_t words = (uint32_t)((S + 31) / 32);
-    const uint64_t QS = n_queries * S;
-    const bool dense_topn = allow_dense && packed && top_n > 0 && top_n + 1024 <= 4096;
-    // one query with thousands of rows (whole-structure mode): its rows are walked in slices that add into the dense results; motif
-    // queries with a selection skip the dense results altogether: scores per tile of structures in LDS (k_qtile.hip), or, when the
-    // index has no checkpoint table, ranking keys from occupancy rows (k_cq_rows_keys); records only for the survivors either way
-    const bool sliced = n_queries == 1 && nq >= 4096;
-    const bool keys_only = dense_topn && !sliced;
-    const bool qtile_on = [] { const char *e = getenv("FDGPU_QTILE"); return !(e && e[0] == '0'); }();      // 0: occupancy rows (read per call: tests compare the two)
-    // k_qscore32.hip (32-bit sums, planned slot stream; needs the rows' posting lengths for the stream's bound): FDGPU_QT32=0 keeps the 64-bit kernel
-    // (read per call: tests compare the two), FDGPU_QT32=15 takes tiles of 2^15 structures (one workgroup per CU) instead of 2^14 (two per CU)
-    const int qt32_env = [] { const char *e = getenv("FDGPU_QT32"); return e ? atoi(e) : 14; }();
-    bool qt32 = keys_only && qtile_on && qt32_env != 0 && sums_fit32 && known_len;
-    const uint32_t qt_tl2 = qt32 ? (qt32_env == 15 ? 15u : 14u)
-                                 : [] { const char *e = getenv("FDGPU_QT_TILE"); return e && atoi(e) == 13 ? 13u : 14u; }();      // structures per tile (measurement)
-    const uint32_t NT = (uint32_t)((S + (1u << qt_tl2) - 1) >> qt_tl2);
-    bool tiled = keys_only && qtile_on && max_rows <= QT_MAX_ROWS && nq * (S >> QT_CELL_LOG2) < (1ull << 31) && fd_index_checkpoints(c, ix) == FDGPU_OK;
-    qt32 = qt32 && tiled;
-    const uint32_t qt_wpr = (1u << (qt_tl2 - 8)) + 2u;      // windows a row can need in a tile: < 2 bytes per posting of a tile, windows at least half full, + its pieces' tails
-    // one query of thousands of rows (a whole structure as the query) with a selection: the same tiles, the rows cut into slices (k_qt_score<BIG>)
-    const uint32_t NT14 = (uint32_t)((S + (1u << 14) - 1) >> 14);
-    bool tiled_big = dense_topn && sliced && qtile_on && !tiled && nq < (1ull << 18) && nq * NT14 < (1ull << 31) && fd_index_checkpoints(c, ix) == FDGPU_OK;
-    const uint32_t big_slices = (uint32_t)std::min<uint64_t>(32, nq), big_wpr = (uint32_t)((nq + 31) / 32), big_cap = top_n + 1024;
-    hipError_t e = hipSuccess;
-    auto need = [&](int w, size_t bytes) { if (e == hipSuccess) e = c->ws[w].ensure(bytes); };
-    need(WS_MISC0, nq * 4); need(WS_MISC3, nq * 8); need(WS_TILE_H, (n_queries + 1) * 8); need(WS_MISC5, S * 4); need(WS_TOTAL, 64);
-    // the decoded stream of the tiled path (k_qt_rows): sized from the rows' posting lengths when the caller knows them — a list of n ids is at most
-    // n x (bytes of the largest id) bytes, a slot holds 16 of them, and every (row, cell) piece ends in one partly filled slot
-    uint64_t stream_cap = 0;
-    const bool qt_stream = [] { const char *e = getenv("FDGPU_QT_STREAM"); return !(e && e[0] == '0'); }();      // 0: pass B decodes the lists again (tests, measurement)
-    if (tiled && (qt32 || (qt_stream && known_len && max_rows * (1u << (qt_tl2 - QT_CELL_LOG2)) <= (uint64_t)QT_MAXB * (qt_tl2 == 14 ? 512 : 256)))) {
-        const uint64_t top_id = ix->first_id + S, vb = top_id < (1ull << 7) ? 1 : top_id < (1ull << 14) ? 2 : top_id < (1ull << 21) ? 3 : top_id < (1ull << 28) ? 4 : 5;
-        const uint64_t NCc = (S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2;
-        // a piece per (row, cell) where the list has an entry per cell; a list with entries 2^j cells apart is cut into pieces of < 96 bytes on
-        // average that every tile they span decodes once: at most 6 slots x tiles on top of its bytes
-        uint64_t slots = 0;
-        for (uint64_t r = 0; r < nq; ++r) slots += (known_len[r] * vb + 15) / 16 + NCc + 6ull * NT + 8;
-        // (the planned stream pads its windows: a piece that would straddle a 64-slot boundary starts the next window — windows stay at least half full)
-        if (qt32) slots = 2 * slots + 64ull * n_queries * NT;
-        if (slots < (1ull << 31)) stream_cap = slots + 1024;
-        else qt32 = false;
-    }
-    auto need_rows = [&]() {      // the occupancy-row path's scratch
-        need(WS_COUNTS, packed ? 64 : QS * 4); need(WS_SEGOFF, QS * 8 + 16);
-        need(WS_KEYS_B, (size_t)nq * words * 4);
-        need(WS_IDS_A, QS * 4); need(WS_IDS_B, QS * 4); need(WS_MISC4, QS + 8); need(WS_TILE_BO, (QS + 2) * 8);
-        need(WS_SCANTMP, fd_scan_tmp_elems(QS) * 8 + 64);
-    };
-    if (tiled) {
-        if (stream_cap) { need(WS_QT_STREAM, stream_cap * 34 + 64); need(WS_QT_STAB, (size_t)n_queries * NT * QT_MAXB * 8 + 64); }
-        need(WS_CQ_KIDX, nq * 8); need(WS_CQ_NSEG, nq * 4);
-        need(WS_QT_RANGES, (size_t)nq * ((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2) * 16); need(WS_QT_COMPACT, ((size_t)n_queries * NT << qt_tl2) * 8);
-        need(WS_QT_COUNT, (size_t)n_queries * NT * 4); need(WS_QT_AUX, n_queries * sizeof(qt_aux) + 256);
-        if (qt32) {       // pieces in WS_QT_RANGES ([nq x NT x cells per tile] >= the ranges table: sized below), their first slots, the window tables, the heads
-            const size_t ent = (size_t)nq * NT << (qt_tl2 - QT_CELL_LOG2);
-            need(WS_QT_RANGES, ent * 16); need(WS_QT_PIECEP, ent * 4);
-            need(WS_QT_WIN, ((size_t)nq * NT * qt_wpr + 2 * (size_t)n_queries * NT) * 4); need(WS_QT_HEAD, (size_t)n_queries * NT * 16);
-        }
-    } else if (tiled_big) {
-        need(WS_CQ_KIDX, nq * 8); need(WS_CQ_NSEG, nq * 4);
-        need(WS_QT_RANGES, (size_t)nq * NT14 * 16); need(WS_QT_COMPACT, ((size_t)NT14 << 14) * 8); need(WS_QT_COUNT, (size_t)NT14 * 4); need(WS_QT_AUX, sizeof(qt_aux) + 256);
-        need(WS_QT_PARTIAL, ((size_t)big_slices * NT14 << 14) * 8);
-        need(WS_QT_SURV, ((size_t)NT14 * 512 * 2 + NT14 + big_cap + 2 * big_wpr) * 4 + (big_slices + 2) * 8 + 64);
-        need(WS_QT_ROWBITS, (size_t)big_cap * big_wpr * 4);
-    } else need_rows();
-    if (e != hipSuccess && (tiled || tiled_big)) {      // the tiled path's scratch did not fit (ranges, first-touch lists, decoded stream): the occupancy-row path instead
-        (void)hipGetLastError();
-        e = hipSuccess; tiled = false; tiled_big = false; qt32 = false; stream_cap = 0;
-        need_rows();
-    }
-    if (e != hipSuccess) { free(ooff); c->err = std::string("count_query_batch workspace: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-    (void)hipMemcpyAsync(c->ws[WS_MISC0].p, rows_hash.data(), nq * 4, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(c->ws[WS_MISC3].p, rows_meta.data(), nq * 8, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(c->ws[WS_TILE_H].p, q_off, (n_queries + 1) * 8, hipMemcpyHostToDevice, st);
-    if (penalty) (void)hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st);
-    const float *d_penalty = penalty ? c->ws[WS_MISC5].as<float>() : ix->penalty;
-    cq_args A;
-    A.hashes = ix->hashes; A.offsets = ix->offsets; A.value = ix->value; A.H = ix->n_hashes;
-    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.nq = nq;
-    A.hash_bits = c->ws[WS_KEYS_B].as<uint32_t>(); A.row_meta = c->ws[WS_MISC3].as<unsigned long long>();
-    A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>(); A.packed = packed ? 1 : 0;
-    A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
-    qt_args T;
-    if (tiled) {
-        T.value = ix->value; T.offsets = ix->offsets; T.ck_meta = ix->ck_meta; T.ck_ent = (const uint2 *)ix->ck_ent;
-        T.kidx = c->ws[WS_CQ_KIDX].as<long long>(); T.row_meta = A.row_meta; T.q_rows = c->ws[WS_TILE_H].as<uint64_t>(); T.penalty = d_penalty;
-        T.nq = (uint32_t)nq; T.n_queries = (uint32_t)n_queries; T.S = (uint32_t)S; T.first_id = (uint32_t)ix->first_id; T.NT = NT; T.tile_log2 = qt_tl2;
-        T.NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
-        T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.c_nid = c->ws[WS_QT_COMPACT].as<uint32_t>(); T.c_key = T.c_nid + ((size_t)n_queries * NT << qt_tl2);
-        T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
-        T.ghist = nullptr; T.state = nullptr; T.aux = c->ws[WS_QT_AUX].as<qt_aux>(); T.out = nullptr; T.cap = 0;
-        T.stream_ids = nullptr; T.stream_row = nullptr; T.stream_tab = nullptr; T.stream_used = nullptr; T.stream_cap = 0;
-        if (stream_cap) {
-            uint8_t *sb = c->ws[WS_QT_STREAM].as<uint8_t>();
-            T.stream_ids = sb; T.stream_row = (uint16_t *)(sb + stream_cap * 32); T.stream_cap = (uint32_t)stream_cap;
-            T.stream_tab = c->ws[WS_QT_STAB].as<uint2>(); T.stream_used = (uint32_t *)(c->ws[WS_QT_STAB].as<uint8_t>() + (size_t)n_queries * NT * QT_MAXB * 8);
-            if (!qt32) (void)hipMemsetAsync(T.stream_used, 0, 4, st);       // (the 32-bit path scans the tiles' windows instead of claiming records: k_qt_bases)
-        }
-        T.plan_log2 = QT_CELL_LOG2; T.slices = nullptr; T.n_slices = 0; T.partial = nullptr; T.g_bm = T.g_rank = T.g_tcount = T.g_nid = T.g_rowbits = nullptr;
-        T.g_wpr = 0; T.g_eend = T.g_nend = nullptr;
-        T.dbg = nullptr;
-        T.pieces = nullptr; T.piece_p = nullptr; T.win = nullptr; T.heads = nullptr; T.win_per_row = 0; T.top_n = top_n;
-        if (qt32) {
-            T.pieces = c->ws[WS_QT_RANGES].as<uint4>(); T.piece_p = c->ws[WS_QT_PIECEP].as<uint32_t>(); T.win = c->ws[WS_QT_WIN].as<uint32_t>();
-            T.heads = c->ws[WS_QT_HEAD].as<uint4>(); T.win_per_row = qt_wpr;
-        }
-        if (getenv("FDGPU_QT_DBG")) {       // phase durations of the tile kernels (measurement aid)
-            T.dbg = (unsigned long long *)(c->ws[WS_QT_AUX].as<uint8_t>() + n_queries * sizeof(qt_aux));
-            (void)hipMemsetAsync(T.dbg, 0, 256, st);
-        }
-    }
-    std::vector<uint64_t> big_sl;        // row slices of the large-query path and the rows that end an edge / a node (outlive their asynchronous copies)
-    std::vector<uint32_t> big_ends;
-    if (tiled_big) {
-        T.value = ix->value; T.offsets = ix->offsets; T.ck_meta = ix->ck_meta; T.ck_ent = (const uint2 *)ix->ck_ent;
-        T.kidx = c->ws[WS_CQ_KIDX].as<long long>(); T.row_meta = A.row_meta; T.q_rows = c->ws[WS_TILE_H].as<uint64_t>(); T.penalty = d_penalty;
-        T.nq = (uint32_t)nq; T.n_queries = 1; T.S = (uint32_t)S; T.first_id = (uint32_t)ix->first_id; T.NT = NT14; T.tile_log2 = 14; T.plan_log2 = 14;
-        T.NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
-        T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.c_nid = c->ws[WS_QT_COMPACT].as<uint32_t>(); T.c_key = T.c_nid + ((size_t)NT14 << 14);
-        T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
-        T.ghist = nullptr; T.state = nullptr; T.aux = c->ws[WS_QT_AUX].as<qt_aux>(); T.out = nullptr; T.cap = big_cap; T.dbg = nullptr;
-        T.stream_ids = nullptr; T.stream_row = nullptr; T.stream_tab = nullptr; T.stream_used = nullptr; T.stream_cap = 0;
-        T.pieces = nullptr; T.piece_p = nullptr; T.win = nullptr; T.heads = nullptr; T.win_per_row = 0; T.top_n = top_n;
-        // slices of roughly equal posting counts: a row's list holds ~ S / 2^idf ids (idf = log2(S / length), its fixed-point image is in the metadata)
-        std::vector<double> w(nq);
-        double tot = 0;
-        for (uint64_t r = 0; r < nq; ++r) {       // 2^-idf to a few percent: the integer part as an exponent field, the fraction linearly
-            const unsigned long long fix = rows_meta[r] >> 2;
-            const uint64_t eb = (uint64_t)(1023 - (int)std::min<unsigned long long>(fix >> 22, 1000ull)) << 52;
-            double p2;
-            memcpy(&p2, &eb, 8);
-            w[r] = (1.0 - 0.5 * (double)(fix & 4194303ull) / 4194304.0) * p2 + 1e-7;
-            tot += w[r];
-        }
-        big_sl.push_back(0);
-        double acc = 0;
-        for (uint64_t r = 0; r < nq; ++r) {
-            acc += w[r];
-            if (big_sl.size() < big_slices && acc >= tot * (double)big_sl.size() / big_slices && r + 1 < nq) big_sl.push_back(r + 1);
-        }
-        big_sl.push_back(nq);
-        T.n_slices = (uint32_t)big_sl.size() - 1;
-        big_ends.assign((size_t)2 * big_wpr, 0u);
-        for (uint64_t r = 0; r < nq; ++r) {
-            if (rows_meta[r] & 1ull) big_ends[r >> 5] |= 1u << (r & 31u);
-            if (rows_meta[r] & 2ull) big_ends[big_wpr + (r >> 5)] |= 1u << (r & 31u);
-        }
-        uint32_t *sv = c->ws[WS_QT_SURV].as<uint32_t>();
-        T.g_bm = sv; T.g_rank = sv + (size_t)NT14 * 512; T.g_tcount = T.g_rank + (size_t)NT14 * 512; T.g_nid = T.g_tcount + NT14;
-        uint32_t *d_ends = T.g_nid + big_cap;
-        T.g_eend = d_ends; T.g_nend = d_ends + big_wpr;
-        uint64_t *d_sl = (uint64_t *)(((uintptr_t)(d_ends + 2 * big_wpr) + 63) & ~(uintptr_t)63);
-        T.slices = d_sl;
-        T.partial = c->ws[WS_QT_PARTIAL].as<unsigned long long>(); T.g_rowbits = c->ws[WS_QT_ROWBITS].as<uint32_t>(); T.g_wpr = big_wpr;
-        (void)hipMemcpyAsync(d_ends, big_ends.data(), big_ends.size() * 4, hipMemcpyHostToDevice, st);
-        (void)hipMemcpyAsync(d_sl, big_sl.data(), big_sl.size() * 8, hipMemcpyHostToDevice, st);
-    }
-    std::vector<uint64_t> slices;        // outlives its asynchronous copy (every path below synchronises the stream before returning)
-    if (!tiled && !tiled_big) {
-        StageTimer t(c, "cq_batch", 0);
-        int rs = cq_score(c, A, known_segments);
-        if (rs) { free(ooff); return rs; }
-        if (sliced) {      // slices at node boundaries (see fdgpu_count_query)
-            const uint64_t per = (nq + 31) / 32;
-            slices.push_back(0);
-            for (uint64_t r = 0; r + 1 < nq; ++r)
-                if ((rows_meta[r] & 2ull) && r + 1 - slices.back() >= per) slices.push_back(r + 1);
-            slices.push_back(nq);
-            hipError_t es = c->ws[WS_TILE_B].ensure(slices.size() * 8);
-            if (es == hipSuccess) es = hipMemcpyAsync(c->ws[WS_TILE_B].p, slices.data(), slices.size() * 8, hipMemcpyHostToDevice, st);
-            if (es != hipSuccess) slices.clear();
-        }
-        if (!keys_only)
-            fd_launch_cq_rows_finalize(A, c->ws[WS_TILE_H].as<uint64_t>(), (uint32_t)n_queries, slices.empty() ? nullptr : c->ws[WS_TILE_B].as<uint64_t>(),
-                                       slices.empty() ? 0u : (uint32_t)slices.size() - 1, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(),
-                                       c->ws[WS_MISC4].as<uint8_t>(), max_rows, st);
-        if (!dense_topn)
-            fd_exclusive_scan<uint8_t>(c->ws[WS_MISC4].as<uint8_t>(), QS, c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_SCANTMP].as<uint64_t>(),
-                                       c->ws[WS_TOTAL].as<uint64_t>(), st);
-    }
-    if (dense_topn) {
-        // candidate selection straight from the dense accumulators (k_topn_*_dense + k_topn_sort): no flag scan, no compaction of every
-        // touched structure, one synchronisation instead of three
-        const uint32_t cap = top_n + 1024;
-        hipError_t e2 = c->ws[WS_KEYS_A].ensure((size_t)n_queries * cap * sizeof(fd_count_rec));
-        if (e2 == hipSuccess) e2 = c->ws[WS_TILE_HO].ensure((size_t)n_queries * top_n * sizeof(fd_count_rec));
-        const size_t topn_bytes = (size_t)n_queries * 2048 * 4;
-        if (e2 == hipSuccess && c->ws[WS_CQ_TOPN].cap < topn_bytes) {
-            e2 = c->ws[WS_CQ_TOPN].ensure(topn_bytes);
-            if (e2 == hipSuccess) e2 = hipMemsetAsync(c->ws[WS_CQ_TOPN].p, 0, c->ws[WS_CQ_TOPN].cap, st);
-        }
-        if (e2 == hipSuccess) e2 = c->ws[WS_MISC2].ensure(n_queries * 16);
-        std::vector<uint32_t> tstate((size_t)n_queries * 4);
-        // the ranked records land in the caller's array (page-locked, pooled) at a stride of top_n and are closed up in place afterwards
-        fd_count_rec *rr = dev ? nullptr : (fd_count_rec *)fd_out_alloc(std::max<uint64_t>((uint64_t)n_queries * top_n, 1) * sizeof(fd_count_rec), true);
-        if (!dev && !rr) { free(ooff); return FDGPU_ENOMEM; }
-        if (e2 == hipSuccess && tiled) {
-            T.ghist = c->ws[WS_CQ_TOPN].as<uint32_t>(); T.state = c->ws[WS_MISC2].as<qt_state>(); T.out = c->ws[WS_KEYS_A].p; T.cap = cap;
-            // (the rows' list positions are an input like their hashes: uploaded before the timed stage)
-            const bool have_k = known_kidx && rows_kidx.size() == nq;
-            if (have_k) (void)hipMemcpyAsync(c->ws[WS_CQ_KIDX].p, rows_kidx.data(), nq * 8, hipMemcpyHostToDevice, st);
-            {
-                StageTimer t(c, "cq_batch", 0);
-                if (!have_k) fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
-                if (qt32) { fd_launch_qt_layout(T, st); fd_launch_qt_score32(T, st); }
-                else { fd_launch_qt_plan(T, st); fd_launch_qt_score(T, st); }
-            }
-            StageTimer t(c, "cq_topn", 0);
-            fd_launch_qt_select(T, top_n, c->ws[WS_TILE_HO].p, st);
-            if (T.dbg && qt32) {
-                unsigned long long d[32];
-                if (hipMemcpyAsync(d, T.dbg, 256, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
-                    const double wg = (double)NT * (double)n_queries * 100.0;      // ticks of 10 ns -> us per workgroup
-                    fprintf(stderr, "[qt32] set-up %.2f decode (first wavefront) %.2f wait %.2f keys %.2f cut %.2f emit %.2f us/WG, %.1f windows/WG (%u x %llu WGs)\n",
-                            d[0] / wg, d[1] / wg, d[2] / wg, d[3] / wg, d[4] / wg, d[5] / wg, d[17] / ((double)NT * (double)n_queries), NT, (unsigned long long)n_queries);
-                }
-            } else if (T.dbg) {
-                unsigned long long d[32];
-                if (hipMemcpyAsync(d, T.dbg, 256, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
-                    const double wg = (double)NT * (double)n_queries * 100.0;      // ticks of 10 ns -> us per workgroup
-                    fprintf(stderr, "[qt] A: setup %.2f plan %.2f units %.2f decode %.2f wait %.2f final %.2f | B: setup %.2f plan %.2f units %.2f decode %.2f wait %.2f records %.2f us/WG (%u x %llu WGs)\n",
-                            d[0] / wg, d[1] / wg, d[2] / wg, d[3] / wg, d[4] / wg, d[5] / wg, d[8] / wg, d[9] / wg, d[10] / wg, d[11] / wg, d[12] / wg, d[13] / wg, NT,
-                            (unsigned long long)n_queries);
-                    for (int z = 0; z < 2; ++z) {
-                        const unsigned long long *e = d + 16 + 8 * z;
-                        const double nw = (double)NT * (double)n_queries;
-                        fprintf(stderr, "[qt] %c unit loop: units/WG %.1f steps/WG %.1f, wave time mean %.2f us, slowest wave mean %.2f us\n", z ? 'B' : 'A', e[0] / nw, e[1] / nw,
-                                e[3] / (nw * (qt_tl2 == 14 ? 16 : 8) * 100.0), e[2] / (nw * 100.0));
-                    }
-                }
-            }
-        } else if (e2 == hipSuccess && tiled_big) {
-            T.ghist = c->ws[WS_CQ_TOPN].as<uint32_t>(); T.state = c->ws[WS_MISC2].as<qt_state>(); T.out = c->ws[WS_KEYS_A].p;
-            const bool have_k = known_kidx && rows_kidx.size() == nq;
-            if (have_k) (void)hipMemcpyAsync(c->ws[WS_CQ_KIDX].p, rows_kidx.data(), nq * 8, hipMemcpyHostToDevice, st);
-            {
-                StageTimer t(c, "cq_batch", 0);
-                if (!have_k) fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
-                fd_launch_qt_plan(T, st);
-                fd_launch_qt_big_score(T, st);
-            }
-            StageTimer t(c, "cq_topn", 0);
-            fd_launch_qt_big_select(T, top_n, c->ws[WS_TILE_HO].p, st);
-        } else if (e2 == hipSuccess) {
-            StageTimer t(c, "cq_topn", 0);
-            if (keys_only)      // keys in the compaction's position buffer, unused on this path
-                fd_launch_cq_topn_dense(A, c->ws[WS_TILE_H].as<uint64_t>(), d_penalty, c->ws[WS_TILE_BO].as<uint32_t>(), (uint32_t)n_queries, top_n, cap,
-                                        c->ws[WS_KEYS_A].p, c->ws[WS_MISC2].p, c->ws[WS_CQ_TOPN].as<uint32_t>(), st);
-            else
-                fd_launch_cq_topn_acc(A, d_penalty, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), (uint32_t)n_queries, top_n, cap,
-                                      c->ws[WS_KEYS_A].p, c->ws[WS_MISC2].p, c->ws[WS_CQ_TOPN].as<uint32_t>(), st);
-            fd_launch_cq_topn_sort(c->ws[WS_KEYS_A].p, cap, c->ws[WS_MISC2].p, (uint32_t)n_queries, top_n, c->ws[WS_TILE_HO].p, st);
-        }
-        if (cq_trace) fprintf(stderr, "[count_query] launched at %.3f ms\n", cq_ms());
-        if (dev && dev->while_running && *dev->while_running) (*dev->while_running)();
-        if (e2 == hipSuccess) e2 = hipMemcpyAsync(tstate.data(), c->ws[WS_MISC2].p, n_queries * 16, hipMemcpyDeviceToHost, st);
-        if (e2 == hipSuccess && !dev) e2 = hipMemcpyAsync(rr, c->ws[WS_TILE_HO].p, (size_t)n_queries * top_n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
-        if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
-        if (e2 == hipSuccess) e2 = hipGetLastError();
-        if (e2 != hipSuccess) { free(ooff); fdgpu_free(rr); c->err = std::string("count_query_batch: ") + hipGetErrorString(e2); return FDGPU_EHIP; }
-        if (cq_trace) fprintf(stderr, "[count_query] records on the host at %.3f ms\n", cq_ms());
-        bool overflow = false;
-        uint64_t tot = 0;
-        for (uint64_t t = 0; t < n_queries; ++t) { overflow = overflow || tstate[4 * t + 3] > cap; tot += std::min<uint32_t>(tstate[4 * t + 3], top_n); }
-        if (dev) {        // the ranked selection stays where it is
-            free(ooff);
-            dev->counts.resize(n_queries);
-            for (uint64_t t = 0; t < n_queries; ++t) dev->counts[t] = tstate[4 * t + 3];
-            dev->got = true; dev->overflow = overflow; dev->recs = c->ws[WS_TILE_HO].p; dev->state = c->ws[WS_MISC2].p; dev->top_n = top_n; dev->cap = cap;
-            return FDGPU_OK;
-        }
-        if (overflow) {   // more ties at the cut-off than the selection's slots hold: the compacting path ranks that call
-            free(ooff); fdgpu_free(rr);
-            return fd_count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off, false, nullptr, known_segments);
-        }
-        (void)tot;
-        uint64_t w = 0;
-        for (uint64_t t = 0; t < n_queries; ++t) {
-            const uint64_t m = std::min<uint32_t>(tstate[4 * t + 3], top_n);
-            ooff[t] = w;
-            if (m && w != t * top_n) memmove(rr + w, rr + (size_t)t * top_n, (size_t)m * sizeof(fd_count_rec));      // w <= t * top_n: forward
-            w += m;
-        }
-        ooff[n_queries] = w;
-        *out = rr; *out_off = ooff;
-        return FDGPU_OK;
-    }
-    uint64_t n = 0;
-    int rc = d2h_u64(c, c->ws[WS_TOTAL].as<uint64_t>(), &n);
-    if (rc) { free(ooff); return rc; }
-    const bool select = top_n > 0 && n > (uint64_t)top_n * n_queries;   // worth preselecting on the device
-    fd_count_rec *r = select ? nullptr : (fd_count_rec *)malloc(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec));
-    if (!select && !r) { free(ooff); return FDGPU_ENOMEM; }
-    e = c->ws[WS_TILE_HO].ensure(std::max<uint64_t>(n, 1) * sizeof(fd_count_rec));
-    if (e == hipSuccess) e = c->ws[WS_TILE_PO].ensure((n_queries + 1) * 8 + 64);
-    if (e == hipSuccess) {
-        fd_launch_cq_compact_batch(A, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), c->ws[WS_MISC4].as<uint8_t>(),
-                                   c->ws[WS_TILE_BO].as<uint64_t>(), d_penalty, QS, c->ws[WS_TILE_HO].p, st);
-        // out_off[t] = scan position at t * S
-        std::vector<uint64_t> idx(n_queries + 1);
-        for (uint64_t t = 0; t <= n_queries; ++t) idx[t] = t * S;
-        e = c->ws[WS_MISC1].ensure((n_queries + 1) * 8);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->ws[WS_MISC1].p, idx.data(), (n_queries + 1) * 8, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) {
-            fd_launch_gather_u64(c->ws[WS_TILE_BO].as<uint64_t>(), c->ws[WS_MISC1].as<uint64_t>(), n_queries + 1, c->ws[WS_TILE_PO].as<uint64_t>(), st);
-            e = hipMemcpyAsync(ooff, c->ws[WS_TILE_PO].p, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(st);   // idx must outlive the copy
-    }
-    if (e == hipSuccess && select) {
-        // per-query preselection of the top_n by idf on the device (k_cq_topn); a query whose threshold bin overflows the
-        // fixed-stride output falls back to its full list
-        const uint32_t cap = top_n + 1024;
-        const bool dev_sort = cap <= 4096;          // k_topn_sort ranks and cuts on the device: only top_n records per query cross the bus
-        const uint32_t stride = dev_sort ? top_n : cap;
-        std::vector<uint32_t> cnt(n_queries);
-        std::vector<fd_count_rec> sel((size_t)n_queries * stride);
-        e = c->ws[WS_KEYS_A].ensure((size_t)n_queries * cap * sizeof(fd_count_rec));
-        if (e == hipSuccess && dev_sort) e = c->ws[WS_KEYS_B].ensure((size_t)n_queries * top_n * sizeof(fd_count_rec));
-        const size_t topn_bytes = (size_t)n_queries * 2048 * 4;
-        if (e == hipSuccess && c->ws[WS_CQ_TOPN].cap < topn_bytes) {     // histogram table: zeroed when (re)allocated, the kernels leave it zero
-            e = c->ws[WS_CQ_TOPN].ensure(topn_bytes);
-            if (e == hipSuccess) e = hipMemsetAsync(c->ws[WS_CQ_TOPN].p, 0, c->ws[WS_CQ_TOPN].cap, st);
-        }
-        if (e == hipSuccess) e = c->ws[WS_MISC2].ensure(n_queries * 16);
-        std::vector<uint32_t> tstate((size_t)n_queries * 4);
-        if (e == hipSuccess) {
-            fd_launch_cq_topn(c->ws[WS_TILE_HO].p, c->ws[WS_TILE_PO].as<uint64_t>(), (uint32_t)n_queries, top_n, cap, c->ws[WS_KEYS_A].p, c->ws[WS_MISC2].p,
-                              c->ws[WS_CQ_TOPN].as<uint32_t>(), st);
-            if (dev_sort) fd_launch_cq_topn_sort(c->ws[WS_KEYS_A].p, cap, c->ws[WS_MISC2].p, (uint32_t)n_queries, top_n, c->ws[WS_KEYS_B].p, st);
-            e = hipMemcpyAsync(tstate.data(), c->ws[WS_MISC2].p, n_queries * 16, hipMemcpyDeviceToHost, st);
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(sel.data(), dev_sort ? c->ws[WS_KEYS_B].p : c->ws[WS_KEYS_A].p, sel.size() * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e != hipSuccess) { free(ooff); c->err = std::string("count_query_batch: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-        for (uint64_t t = 0; t < n_queries; ++t) cnt[t] = tstate[4 * t + 3];
-        uint64_t tot = 0;
-        for (uint64_t t = 0; t < n_queries; ++t) tot += cnt[t] <= cap ? (dev_sort ? std::min<uint32_t>(cnt[t], top_n) : cnt[t]) : (ooff[t + 1] - ooff[t]);
-        r = (fd_count_rec *)malloc(std::max<uint64_t>(tot, 1) * sizeof(fd_count_rec));
-        if (!r) { free(ooff); return FDGPU_ENOMEM; }
-        std::vector<uint64_t> noff(n_queries + 1, 0);
-        for (uint64_t t = 0; t < n_queries; ++t) {
-            if (cnt[t] <= cap) {
-                uint64_t m = dev_sort ? std::min<uint32_t>(cnt[t], top_n) : cnt[t];
-                memcpy(r + noff[t], sel.data() + (size_t)t * stride, (size_t)m * sizeof(fd_count_rec));
-                if (!dev_sort) m = fd_rank_trim(r + noff[t], m, top_n);
-                noff[t + 1] = noff[t] + m;
-            } else {
-                uint64_t m = ooff[t + 1] - ooff[t];
-                if (hipMemcpy(r + noff[t], (const fd_count_rec *)c->ws[WS_TILE_HO].p + ooff[t], m * sizeof(fd_count_rec), hipMemcpyDeviceToHost) != hipSuccess) {
-                    free(r); free(ooff); c->err = "count_query_batch: fallback copy failed"; return FDGPU_EHIP;
-                }
-                noff[t + 1] = noff[t] + fd_rank_trim(r + noff[t], m, top_n);
-            }
-        }
-        memcpy(ooff, noff.data(), (n_queries + 1) * 8);
-        *out = r; *out_off = ooff;
-        return FDGPU_OK;
-    }
-    if (e == hipSuccess && n) e = hipMemcpyAsync(r, c->ws[WS_TILE_HO].p, n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e != hipSuccess) { free(r); free(ooff); c->err = std::string("count_query_batch: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-    if (top_n > 0) {     // few records: ranked and cut on the host, same contract as the device selection
-        uint64_t w = 0;
-        for (uint64_t t = 0; t < n_queries; ++t) {
-            const uint64_t a = ooff[t], m = fd_rank_trim(r + a, ooff[t + 1] - a, top_n);
-            if (w != a) memmove(r + w, r + a, m * sizeof(fd_count_rec));
-            ooff[t] = w; w += m;
-        }
-        ooff[n_queries] = w;
-    }
-    *out = r; *out_off = ooff;
-    return FDGPU_OK;
-}
-extern "C" int fdgpu_count_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
-                                       const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty,
-                                       fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
-    return fd_count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, 0, out, out_off, true, nullptr);
-}
-// as above, but per query only the top_n records come back, RANKED as the candidate selection of query_pdb.rs:404-411 ranks them (idf
-// descending, ties by ascending structure id): radix selection + LDS bitonic sort on the device, top_n records per query over the bus
-extern "C" int fdgpu_count_query_batch_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
-                                           const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty,
-                                           uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
-    return fd_count_query_batch_impl(c, ix, n_queries, q_off, q_hash, q_node, q_edge_j, q_idf, penalty, top_n, out, out_off, true, nullptr);
-}
-
-// The length penalty nres^(-lp) of the index's structures (count_query.rs:200), kept on the device: count queries may then pass
-// penalty = NULL instead of uploading S floats per call.  penalty = NULL drops the resident copy.
-extern "C" int fdgpu_index_set_penalty(fdgpu_ctx *c, fdgpu_index *ix, const float *penalty) { FD_LOCK(c);
-    if (!c || !ix) return FDGPU_EINVAL;
-    if (ix->penalty) { (void)hipFree(ix->penalty); ix->penalty = nullptr; }
-    if (!penalty || !ix->n_structures) return FDGPU_OK;
-    HIPCHK(c, hipMalloc((void **)&ix->penalty, ix->n_structures * 4));
-    HIPCHK(c, hipMemcpy(ix->penalty, penalty, ix->n_structures * 4, hipMemcpyHostToDevice));
-    return FDGPU_OK;
-}
-
-// count_query for the query maps fdgpu_make_query_map[_batch] returned, without a round trip through the caller: the entries of
-// every map (hash, (qi, qj)) are scored with idf = log2(total_structures / posting length) of the hash ITSELF (count_query.rs:181-200;
-// the idf inside the map belongs to the pair's observed hash and feeds the retrieval's subgraph idf instead); hashes the index does
-// not hold are dropped.  Output as fdgpu_count_query_batch_top.
-// every map's hash[] (all queries), then every map's primary_hash[]: the 2 * sum(n) hashes whose posting lengths a sharded query needs
-// over the WHOLE database
-uint64_t fd_maps_hashes(uint64_t n_queries, const fd_query_map *const *qms, std::vector<uint32_t> &h) {
-    uint64_t nq = 0;
-    for (uint64_t t = 0; t < n_queries; ++t) nq += qms[t]->n;
-    h.assign(std::max<uint64_t>(2 * nq, 1), 0);
-    uint64_t at = 0;
-    for (uint64_t t = 0; t < n_queries; ++t) { if (qms[t]->n) memcpy(&h[at], qms[t]->hash, qms[t]->n * 4); at += qms[t]->n; }
-    for (uint64_t t = 0; t < n_queries; ++t) { if (qms[t]->n) memcpy(&h[at], qms[t]->primary_hash, qms[t]->n * 4); at += qms[t]->n; }
-    return nq;
-}
-// scoring of query maps with the posting lengths given: len[0 .. nq) belong to the maps' hash[] in order (idf = log2f(total / len), absent
-// hashes drop out); with primary_len the maps' own idf[] (the retrieval's subgraph idf, query.rs:283-288) is rewritten from the lengths
-// of primary_hash[] — what a sharded index needs, whose make_query_map saw one shard only
-int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const uint64_t *len,
-                            const uint64_t *primary_len, const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out,
-                            uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg, const long long *kidx, bool allow_dense) {
-    uint64_t nq = 0;
-    int64_t W = seg ? 0 : -1;
-    for (uint64_t t = 0; t < n_queries; ++t) nq += qms[t]->n;
-    std::vector<uint64_t> q_off(n_queries + 1, 0);
-    std::vector<uint32_t> qh, qn, qe;
-    std::vector<float> qi;
-    std::vector<long long> qk;
-    std::vector<uint64_t> ql;       // the kept rows' posting lengths (local to this index only when the lengths are: the tiled path sizes its stream from them)
-    // (filled through plain pointers: a whole-structure query is 10^5 rows, six push_backs each were a third of this loop)
-    qh.resize(nq + 1); qn.resize(nq + 1); qe.resize(nq + 1); qi.resize(nq + 1); ql.resize(nq + 1);
-    if (kidx) qk.resize(nq + 1);
-    uint32_t *const p_h = qh.data(), *const p_n = qn.data(), *const p_e = qe.data();
-    float *const p_i = qi.data();
-    uint64_t *const p_l = ql.data();
-    long long *const p_k = kidx ? qk.data() : nullptr;
-    uint64_t at = 0, w = 0;
-    for (uint64_t t = 0; t < n_queries; ++t) {
-        const fd_query_map *m = qms[t];
-        const uint32_t *const mh = m->hash, *const mqi = m->qi, *const mqj = m->qj;
-        float *const midf = m->idf;
-        const uint64_t mn = m->n;
-        for (uint64_t k = 0; k < mn; ++k, ++at) {
-            if (primary_len) midf[k] = primary_len[at] ? log2f(total_structures / (float)primary_len[at]) : 0.0f;
-            const uint64_t L = len[at];
-            if (!L) continue;
-            p_h[w] = mh[k]; p_n[w] = mqi[k]; p_e[w] = mqj[k];
-            if (p_k) p_k[w] = kidx[at];
-            p_l[w] = L;
-            p_i[w] = log2f(total_structures / (float)L);       // f32 like the reference's (total / len).log2()
-            if (seg) W += seg[at];
-            ++w;
-        }
-        q_off[t + 1] = w;
-    }
-    qh.resize(w); qn.resize(w); qe.resize(w); qi.resize(w); ql.resize(w);
-    if (kidx) qk.resize(w);
-    if (qh.empty()) { qh.push_back(0); qn.push_back(0); qe.push_back(0); qi.push_back(0.0f); W = seg ? 0 : -1; qk.clear(); ql.clear(); }
-    // (the lengths bound the LOCAL lists only when they are this index's own: the caller that passes kidx made the maps against it)
-    return fd_count_query_batch_impl(c, ix, n_queries, q_off.data(), qh.data(), qn.data(), qe.data(), qi.data(), penalty, top_n, out, out_off, allow_dense, dev, W,
-                                     kidx && qk.size() == qh.size() ? qk.data() : nullptr, kidx && ql.size() == qh.size() ? ql.data() : nullptr);
-}
-extern "C" int fdgpu_count_query_maps_top(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty,
-                                          float total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
-    return fd_count_query_maps_top_impl(c, ix, n_queries, qms, penalty, total_structures, top_n, out, out_off, nullptr);
-}
-int fd_count_query_maps_top_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty, float total_structures,
-                                 uint32_t top_n, fd_count_rec **out, uint64_t **out_off, fd_cq_dev_out *dev, bool allow_dense) { FD_LOCK(c);
-    if (!c || !ix || !out || !out_off || (n_queries && !qms)) return FDGPU_EINVAL;
-    uint64_t nq = 0;
-    for (uint64_t t = 0; t < n_queries; ++t) { if (!qms[t]) return FDGPU_EINVAL; nq += qms[t]->n; }
-    std::vector<uint32_t> h(std::max<uint64_t>(nq, 1));
-    std::vector<uint64_t> len(std::max<uint64_t>(nq, 1), 0);
-    std::vector<uint32_t> seg(std::max<uint64_t>(nq, 1), 0);
-    std::vector<long long> kidx(std::max<uint64_t>(nq, 1), -1);
-    bool remembered = nq > 0;       // maps made against THIS index carry their hashes' posting lengths, segment counts and list positions
-    for (uint64_t t = 0; t < n_queries; ++t) remembered = remembered && (!qms[t]->n || (qms[t]->post_len && qms[t]->post_seg && qms[t]->post_index_uid == ix->uid));
-    bool have_kidx = remembered;
-    for (uint64_t t = 0; t < n_queries; ++t) have_kidx = have_kidx && (!qms[t]->n || qms[t]->post_kidx);
-    uint64_t at = 0;
-    for (uint64_t t = 0; t < n_queries; ++t) {
-        if (qms[t]->n) {
-            if (have_kidx) memcpy(&kidx[at], qms[t]->post_kidx, qms[t]->n * 8);
-            if (remembered) { memcpy(&len[at], qms[t]->post_len, qms[t]->n * 8); memcpy(&seg[at], qms[t]->post_seg, qms[t]->n * 4); }
-            else memcpy(&h[at], qms[t]->hash, qms[t]->n * 4);
-        }
-        at += qms[t]->n;
-    }
-    int rc = !remembered && nq && ix->n_structures ? fd_posting_lengths_segs(c, ix, h.data(), nq, len.data(), seg.data()) : FDGPU_OK;
-    if (rc) return rc;
-    return fd_count_query_maps_len(c, ix, n_queries, qms, len.data(), nullptr, penalty, total_structures, top_n, out, out_off, dev, seg.data(),
-                                   have_kidx ? kidx.data() : nullptr, allow_dense);
-}
-// The two halves of the sharded form for hosts that bring their own transport (MPI, gloo, ...): the LOCAL posting lengths of the maps'
-// hash[] and primary_hash[] (2 * sum(n) values, fd_maps_hashes order) — the caller sums them over the ranks — and the scoring of the
-// local shard with those GLOBAL lengths (maps' idf[] rewritten from the primary lengths).  With RCCL: fdgpu_sharded_count_query_maps.
-extern "C" int fdgpu_query_maps_lengths(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, uint64_t *lengths) { FD_LOCK(c);
-    if (!c || !ix || (n_queries && !qms) || !lengths) return FDGPU_EINVAL;
-    for (uint64_t t = 0; t < n_queries; ++t) if (!qms[t]) return FDGPU_EINVAL;
-    std::vector<uint32_t> h;
-    const uint64_t nq = fd_maps_hashes(n_queries, qms, h);
-    return nq ? fdgpu_posting_lengths(c, ix, h.data(), 2 * nq, lengths) : FDGPU_OK;
-}
-extern "C" int fdgpu_count_query_maps_top_global(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, fd_query_map *const *qms, const uint64_t *global_lengths,
-                                                 const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out, uint64_t **out_off) { FD_LOCK(c);
-    if (!c || !ix || !out || !out_off || (n_queries && !qms)) return FDGPU_EINVAL;
-    uint64_t nq = 0;
-    for (uint64_t t = 0; t < n_queries; ++t) { if (!qms[t]) return FDGPU_EINVAL; nq += qms[t]->n; }
-    if (nq && !global_lengths) return FDGPU_EINVAL;
-    const uint64_t zero = 0;
-    return fd_count_query_maps_len(c, ix, n_queries, qms, nq ? global_lengths : &zero, nq ? global_lengths + nq : nullptr, penalty, total_structures, top_n,
-                                   out, out_off, nullptr);
-}
-
-// found triples in the reference's scan order — (slot, i, j), several bin pairs of one (i, j) in emission order — from the kernel's
-// append order: counting sort by slot (stable), then the slots' runs sorted independently on host threads (a whole-structure query
-// returns ~10^5 triples for a handful of slots: one 20 ms std::stable_sort otherwise)
-static void fd_sort_found(fd_pair_rec *f, uint64_t n, uint64_t n_cand) {
-    if (n < 2) return;
-    auto by_ij = [](const fd_pair_rec &a, const fd_pair_rec &b) { return a.i != b.i ? a.i < b.i : a.j < b.j; };
-    if (n < 4096 || n_cand == 0) {
-        std::stable_sort(f, f + n, [&](const fd_pair_rec &a, const fd_pair_rec &b) { return a.cand != b.cand ? a.cand < b.cand : by_ij(a, b); });
-        return;
-    }
-    std::vector<uint64_t> start(n_cand + 2, 0);
-    for (uint64_t k = 0; k < n; ++k) ++start[std::min<uint64_t>(f[k].cand, n_cand) + 1];
-    for (uint64_t s = 0; s <= n_cand; ++s) start[s + 1] += start[s];
-    std::vector<fd_pair_rec> tmp(n);
-    {
-        std::vector<uint64_t> cur(start.begin(), start.end() - 1);
-        for (uint64_t k = 0; k < n; ++k) tmp[cur[std::min<uint64_t>(f[k].cand, n_cand)]++] = f[k];
-    }
-    std::atomic<uint64_t> next(0);
-    auto work = [&]() {
-        for (;;) {
-            const uint64_t s = next.fetch_add(1);
-            if (s > n_cand) break;
-            std::stable_sort(tmp.begin() + start[s], tmp.begin() + start[s + 1], by_ij);
-        }
-    };
-    const unsigned T = (unsigned)std::min<uint64_t>(std::min<uint64_t>(16, std::max(1u, std::thread::hardware_concurrency())), n_cand + 1);
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < T; ++t) th.emplace_back(work);
-    work();
-    for (auto &t : th) t.join();
-    memcpy(f, tmp.data(), n * sizeof(fd_pair_rec));
-}
-
-// ---- S4 ---------------------------------------------------------------------------------------------------------------
-// Pair scan for MANY queries in one launch: query t scans the candidates cand[cand_off[t] .. cand_off[t+1]); the records carry the
-// GLOBAL slot (position in cand) and come back sorted by (slot, i, j).
-int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, uint64_t n_queries, const fd_match_query *qs,
-                         const uint32_t *cand, const uint64_t *cand_off, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
-                         fd_cand_rec **cands, uint64_t *n_cands, uint32_t mode, const uint32_t *cj_mask, const uint32_t *mask_off,
-                         uint64_t mask_words, uint32_t **pk_key, uint32_t **pk_val, fd_vote_plan *votes, fd_mp_tables *tables, const std::function<void()> *while_scanning) {
-    if (!c || !db || !p || !found || !n_found || !cands || !n_cands || !cand_off || (n_queries && !qs)) return FDGPU_EINVAL;
-    if ((mode & 32u) && (!votes || !cj_mask || !mask_off || (mode & 3u))) return FDGPU_EINVAL;
-    const uint64_t n_cand = cand_off[n_queries];
-    if (n_cand && !cand) return FDGPU_EINVAL;
-    *found = nullptr; *cands = nullptr; *n_found = 0; *n_cands = 0;
-    if (!fd_hash_type_supported(p->hash_type)) FAIL(c, FDGPU_EINVAL, "hash_type: only the encodings over the (d_CA, d_CB, theta, tau1, tau2) descriptor are built (0, 1, 3, 7, 8)");
-    reset_timings(c);
-    hipStream_t st = c->stream;
-    const bool mp_trace = getenv("FDGPU_TRACE") != nullptr;
-    const auto mp_t0 = std::chrono::steady_clock::now();
-    auto mp_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - mp_t0).count(); };
-    // work items and query tables (below) depend on the queries and candidates only: a caller that scans the same candidates twice (the two
-    // scans of a large query) passes a fd_mp_tables and the second call reuses the host block
-    fd_mp_tables tb_local;
-    fd_mp_tables &TB = tables ? *tables : tb_local;
-    const bool dev_items = !tables && n_cand < (1ull << 24) && !(getenv("FDGPU_MP_ITEMS") && getenv("FDGPU_MP_ITEMS")[0] == '0');      // 0: host-built items (tests)
-    auto build_tables = [&]() -> int {
-    // work items: (query, candidate slot, 64-residue i-tile); a handful of long candidates (whole-structure queries: the top 20)
-    // would leave most of the chip idle, so the partner residues are split into spans as well until ~2000 wavefronts exist
-    uint64_t n_tiles = 0;
-    for (uint64_t k = 0; k < n_cand; ++k) {
-        if (cand[k] >= db->n_struct) { c->err = "match_pairs: candidate id outside the batch"; return FDGPU_EINVAL; }
-        n_tiles += (db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]] + FD_WAVE - 1) / FD_WAVE;
-    }
-    // many candidates (a batch of motif queries): spans of 256 partners cap the longest work items — the scan launch ends with its slowest wavefront, and a
-    // wavefront walks its partners one at a time (128 queries x 32 candidates, k_mp_scan: 93 us at 512, 68 at 256, 60 at 128 — where the drains, one per
-    // partly filled chunk, have grown by as much)
-    // large queries (whole-structure: the window test passes nearly every pair inside the cutoff, so a work item's time is its number of close
-    // pairs x one descriptor + hash each): while scan and drain were one kernel, a diagonal block of 64 x 128 residues was 128 drains on ONE wavefront and
-    // spans of 32 partners measured best (5.1 ms at 128, 4.4 at 64, 3.7 at 32).  With the drains in their own launch (k_mp_drain, a wavefront per chunk) the
-    // scan's work items only test and queue: 128 partners per item (first + second scan of the top 20 of a 300-residue query: 1.64 + 1.45 ms at 32,
-    // 1.32 + 1.19 at 64, 1.21 + 1.02 at 128, 1.24 + 1.00 at 256)
-    uint64_t max_aad_q = 0;
-    for (uint64_t t = 0; t < n_queries; ++t) max_aad_q = std::max<uint64_t>(max_aad_q, qs[t].n_aad);
-    uint32_t j_span = !n_tiles ? 0u : max_aad_q > 4096 ? 128u : n_tiles < 256 ? 64u : n_tiles < 1024 ? 128u : 256u;
-    if (const char *js = getenv("FDGPU_MP_JSPAN")) if (n_tiles && atoi(js) >= 32) j_span = (uint32_t)atoi(js) & ~63u ? (uint32_t)atoi(js) & ~31u : 32u;      // (measurement aid)
-    TB.j_span = j_span;
-    std::vector<uint32_t> wc, wi, wq, wj;
-    // a one-off block (a batch of motif queries: 18 k work items per 128 queries) gets its work items written on the DEVICE (k_mp_items): the host
-    // sends every candidate's first item and query (8 bytes per candidate instead of 16 per item) and skips the loop below
-    std::vector<uint32_t> wbase, cq;
-    size_t n_wi = 0;
-    {
-        if (dev_items) { wbase.resize(n_cand + 1); cq.resize(std::max<uint64_t>(n_cand, 1)); }
-        for (uint64_t k = 0; k < n_cand; ++k) {
-            const uint64_t len = db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]];
-            if (dev_items) wbase[k] = (uint32_t)n_wi;
-            n_wi += ((len + FD_WAVE - 1) / FD_WAVE) * (j_span ? (len + j_span - 1) / j_span : (len ? 1 : 0));
-        }
-        // (k_mp_items keeps a candidate's first entry of the active-residue list as the 32-bit word 64 x first item)
-        if (dev_items && n_wi >= (1ull << 26)) FAIL(c, FDGPU_ERANGE, "match_pairs: more than 2^26 work items in one call; split the candidates");
-        if (dev_items) {
-            wbase[n_cand] = (uint32_t)n_wi;
-            for (uint64_t t = 0; t < n_queries; ++t) for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) cq[k] = (uint32_t)t;
-        } else { wc.reserve(n_wi); wi.reserve(n_wi); wq.reserve(n_wi); wj.reserve(n_wi); }
-    }
-    if (!dev_items)
-    for (uint64_t t = 0; t < n_queries; ++t)
-        for (uint64_t k = cand_off[t]; k < cand_off[t + 1]; ++k) {
-            uint64_t r0 = db->h_res_off[cand[k]], r1 = db->h_res_off[cand[k] + 1];
-            for (uint64_t r = r0; r < r1; r += FD_WAVE)
-                for (uint64_t j0 = r0; j0 < r1; j0 += j_span ? j_span : (r1 - r0)) {
-                    wc.push_back((uint32_t)k); wi.push_back((uint32_t)r); wq.push_back((uint32_t)t); wj.push_back((uint32_t)j0);
-                }
-        }
-    // per-query tables: sorted hash set, residue-type masks, aa_dist_map grouped by (aa_i, aa_j) — stable order inside a group =
-    // the observed-list order the reference emits in
-    std::vector<mp_query_dev> qtab(std::max<uint64_t>(n_queries, 1));
-    std::vector<uint32_t> all_hashes, all_start, all_qi;
-    std::vector<float> all_dist;
-    all_start.assign((size_t)1025 * n_queries, 0u);      // one start table per query, filled in place (a batch of 512 motif queries: 2 MB)
-    std::vector<uint32_t> cur(1024);
-    for (uint64_t t = 0; t < n_queries; ++t) {
-        const fd_match_query *q = &qs[t];
-        mp_query_dev &Q = qtab[t];
-        Q.qh_off = (uint32_t)all_hashes.size(); Q.n_hashes = (uint32_t)q->n_hashes;
-        all_hashes.insert(all_hashes.end(), q->hashes, q->hashes + q->n_hashes);
-        Q.aa1_mask = Q.aa2_mask = 0;
-        for (uint64_t k = 0; k < q->n_hashes; ++k) {
-            uint32_t a1, a2;
-            fd_hash_aa_pair(p->hash_type, q->hashes[k], &a1, &a2);
-            Q.aa1_mask |= 1u << (a1 & 31u); Q.aa2_mask |= 1u << (a2 & 31u);
-        }
-        // TertiaryInteraction / Hybrid hashes carry no residue types: the reference's prefilter unwraps a None there
-        // (retrieve.rs:576) and panics for queries of <= 200 hashes; every pair is scanned instead
-        const bool no_aa = p->hash_type == FD_HASH_TERTIARY || p->hash_type == FD_HASH_HYBRID;
-        Q.use_prefilter = no_aa ? 0 : q->use_aa_prefilter; Q.ca_window = q->ca_distance_cutoff;
-        uint32_t *cnt = &all_start[(size_t)1025 * t];
-        if (q->n_aad <= 256) {
-            // a motif query's dozen observed distances: (group << 16 | e) keys sorted (= stable by e), the 1,025-entry start table written as
-            // a few runs — counting into it and scanning it cost 1,024 dependent adds per query, 128 times per batch
-            uint32_t keys[256];
-            uint32_t nk = 0;
-            for (uint64_t e = 0; e < q->n_aad; ++e)
-                if (q->aad_aa1[e] < 32 && q->aad_aa2[e] < 32) keys[nk++] = ((q->aad_aa1[e] * 32u + q->aad_aa2[e]) << 16) | (uint32_t)e;
-            std::sort(keys, keys + nk);
-            Q.aad_off = (uint32_t)all_dist.size(); Q.n_aad = nk;
-            all_qi.resize(Q.aad_off + nk); all_dist.resize(Q.aad_off + nk);
-            uint32_t g_next = 0;       // start[g] for g < g_next is written
-            for (uint32_t k = 0; k < nk; ++k) {
-                const uint32_t g = keys[k] >> 16, e = keys[k] & 0xffffu;
-                if (g >= g_next) { std::fill(cnt + g_next, cnt + g + 1, k); g_next = g + 1; }
-                all_qi[Q.aad_off + k] = q->aad_qi[e]; all_dist[Q.aad_off + k] = q->aad_dist[e];
-            }
-            std::fill(cnt + g_next, cnt + 1025, nk);
-            continue;
-        }
-        for (uint64_t e = 0; e < q->n_aad; ++e)
-            if (q->aad_aa1[e] < 32 && q->aad_aa2[e] < 32) ++cnt[q->aad_aa1[e] * 32u + q->aad_aa2[e] + 1];   // residue type 255 never passes get_single_feature
-        for (int k = 0; k < 1024; ++k) cnt[k + 1] += cnt[k];
-        Q.aad_off = (uint32_t)all_dist.size(); Q.n_aad = cnt[1024];
-        all_qi.resize(Q.aad_off + Q.n_aad); all_dist.resize(Q.aad_off + Q.n_aad);
-        memcpy(cur.data(), cnt, 1024 * 4);
-        for (uint64_t e = 0; e < q->n_aad; ++e)
-            if (q->aad_aa1[e] < 32 && q->aad_aa2[e] < 32) {
-                uint32_t k = Q.aad_off + cur[q->aad_aa1[e] * 32u + q->aad_aa2[e]]++;
-                all_qi[k] = q->aad_qi[e]; all_dist[k] = q->aad_dist[e];
-            }
-    }
-    // queries whose observed-distance lists do not fit the kernel's LDS copy (whole-structure queries: ~10^2 distances per residue-type
-    // pair): per group the union of the float intervals {d : |d - x| < window} over its observed x, merged — the scan's window test reads
-    // one or two intervals instead of walking the list.  Exact: fl(d - x) is monotone in d, so the set of passing d of one x is an interval
-    // of floats whose ends are found by stepping from x -/+ window to the last float that still passes.
-    bool want_iv = false;
-    for (uint64_t t = 0; t < n_queries; ++t) want_iv = want_iv || qtab[t].n_aad > 1024u;
-    std::vector<uint32_t> iv_start;
-    std::vector<float> iv_lohi;      // lo, hi interleaved (float2 on the device)
-    if (want_iv) {
-        iv_start.assign((size_t)1025 * n_queries, 0);
-        std::vector<std::pair<float, float>> tmp;
-        for (uint64_t t = 0; t < n_queries; ++t) {
-            const uint32_t *stt = &all_start[1025 * t];
-            const float *base = all_dist.data() + qtab[t].aad_off;
-            const float w = qtab[t].ca_window;
-            for (int g = 0; g < 1024; ++g) {
-                iv_start[1025 * t + g] = (uint32_t)(iv_lohi.size() / 2);
-                tmp.clear();
-                for (uint32_t e = stt[g]; e < stt[g + 1]; ++e) {
-                    const float x = base[e];
-                    if (!(fabsf(x - x) < w)) continue;                  // window <= 0 or NaN: nothing passes
-                    float hi = x + w, lo = x - w;
-                    while (!(fabsf(hi - x) < w)) hi = nextafterf(hi, -INFINITY);
-                    for (float n2 = nextafterf(hi, INFINITY); fabsf(n2 - x) < w; n2 = nextafterf(hi, INFINITY)) hi = n2;
-                    while (!(fabsf(lo - x) < w)) lo = nextafterf(lo, INFINITY);
-                    for (float n2 = nextafterf(lo, -INFINITY); fabsf(n2 - x) < w; n2 = nextafterf(lo, -INFINITY)) lo = n2;
-                    tmp.emplace_back(lo, hi);
-                }
-                std::sort(tmp.begin(), tmp.end());
-                for (size_t k = 0; k < tmp.size();) {
-                    float lo = tmp[k].first, hi = tmp[k].second;
-                    size_t z = k + 1;
-                    while (z < tmp.size() && tmp[z].first <= nextafterf(hi, INFINITY)) { hi = std::max(hi, tmp[z].second); ++z; }
-                    iv_lohi.push_back(lo); iv_lohi.push_back(hi);
-                    k = z;
-                }
-            }
-            iv_start[1025 * t + 1024] = (uint32_t)(iv_lohi.size() / 2);
-        }
-    }
-    const size_t nw = dev_items ? n_wi : wc.size(), na = all_dist.size(), nh = all_hashes.size();
-    TB.nw = nw; TB.want_iv = want_iv;
-    // one packed host block -> one H2D copy: [cand | wc | wi | wq | hashes | start tables | dist | qi | qtab]
-    auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
-    const size_t o_cand = 0, o_wc = o_cand + up4(n_cand), o_wi = o_wc + up4(nw), o_wq = o_wi + up4(nw), o_wj = o_wq + up4(nw), o_h = o_wj + up4(nw),
-                 o_st = o_h + up4(nh), o_d = o_st + up4(all_start.size()), o_qi = o_d + up4(na), o_qt = o_qi + up4(na),
-                 o_ivs = o_qt + up4(n_queries * (sizeof(mp_query_dev) / 4)), o_iv = o_ivs + (want_iv ? up4(iv_start.size()) : 0),
-                 o_iv1 = o_iv + (want_iv ? up4(iv_lohi.size()) : 0), o_wb = o_iv1 + (want_iv ? 1024 * n_queries : 0),
-                 words = o_wb + (dev_items ? up4(n_cand + 1) + up4(n_cand) : 0) + 4;
-    const size_t offs[13] = {o_cand, o_wc, o_wi, o_wq, o_wj, o_h, o_st, o_d, o_qi, o_qt, o_ivs, o_iv, o_iv1};
-    memcpy(TB.o, offs, sizeof offs);
-    TB.o_wb = dev_items ? o_wb : 0; TB.dev_items = dev_items;
-    // a caller that keeps the tables (two scans of a large query) gets them in a vector; a one-off block (a batch of motif queries: ~3.5 MB
-    // per 512 queries) is packed straight into the context's pinned staging buffer — the copy below is then a DMA, not a staged pageable copy
-    uint32_t *blk = tables ? nullptr : (uint32_t *)c->host_pinned(0, words * 4);
-    if (!blk) { TB.blk.assign(words, 0); blk = TB.blk.data(); }
-    TB.data = blk; TB.words = words;
-    if (n_cand) memcpy(&blk[o_cand], cand, n_cand * 4);
-    if (dev_items) { memcpy(&blk[o_wb], wbase.data(), (n_cand + 1) * 4); if (n_cand) memcpy(&blk[o_wb + up4(n_cand + 1)], cq.data(), n_cand * 4); }
-    else if (nw) { memcpy(&blk[o_wc], wc.data(), nw * 4); memcpy(&blk[o_wi], wi.data(), nw * 4); memcpy(&blk[o_wq], wq.data(), nw * 4); memcpy(&blk[o_wj], wj.data(), nw * 4); }
-    if (nh) memcpy(&blk[o_h], all_hashes.data(), nh * 4);
-    if (!all_start.empty()) memcpy(&blk[o_st], all_start.data(), all_start.size() * 4);
-    if (na) { memcpy(&blk[o_d], all_dist.data(), na * 4); memcpy(&blk[o_qi], all_qi.data(), na * 4); }
-    if (want_iv) {
-        memcpy(&blk[o_ivs], iv_start.data(), iv_start.size() * 4);
-        if (!iv_lohi.empty()) memcpy(&blk[o_iv], iv_lohi.data(), iv_lohi.size() * 4);
-        // the scan's LDS copy: per query and group (first interval relative to the query's first) << 8 | number of intervals (a window of 1 A
-        // leaves 1-5 disjoint intervals per group of a 300-residue query, ~700 in all; 255+ intervals of one group: the count saturates and
-        // the scan walks that group in global memory)
-        for (uint64_t t = 0; t < n_queries; ++t)
-            for (int g = 0; g < 1024; ++g) {
-                const uint32_t v_lo = iv_start[1025 * t + g], v_hi = iv_start[1025 * t + g + 1], rel = v_lo - iv_start[1025 * t];
-                blk[o_iv1 + 1024 * t + g] = (std::min<uint32_t>(rel, 0xffffffu) << 8) | std::min<uint32_t>(v_hi - v_lo, 255u);
-            }
-    }
-    if (n_queries) memcpy(&blk[o_qt], qtab.data(), n_queries * sizeof(mp_query_dev));
-    TB.valid = true;
-    return FDGPU_OK;
-    };
-    if (!TB.valid) { const int rcb = build_tables(); if (rcb) return rcb; }
-    const size_t o_cand = TB.o[0], o_wc = TB.o[1], o_wi = TB.o[2], o_wq = TB.o[3], o_wj = TB.o[4], o_h = TB.o[5], o_st = TB.o[6], o_d = TB.o[7], o_qi = TB.o[8],
-                 o_qt = TB.o[9], o_ivs = TB.o[10], o_iv = TB.o[11], o_iv1 = TB.o[12], nw = TB.nw, words = TB.words;
-    const bool want_iv = TB.want_iv;
-    const uint32_t j_span = TB.j_span;
-    if (mp_trace) fprintf(stderr, "[match_pairs] tables at %.3f ms (%zu work items)\n", mp_ms(), nw);
-    HIPCHK(c, c->ws[WS_MISC0].ensure(words * 4));
-    HIPCHK(c, c->ws[WS_TOTAL].ensure(64));
-    uint8_t *d_std = nullptr;
-    if (resname_std) {
-        HIPCHK(c, c->ws[WS_MISC5].ensure(std::max<uint64_t>(db->n_res, 1)));
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, resname_std, db->n_res, hipMemcpyHostToDevice, st));
-        d_std = c->ws[WS_MISC5].as<uint8_t>();
-    }
-    const uint4 *d_cinfo = nullptr;
-    const uint32_t *d_act = nullptr;
-    if (TB.dev_items) {       // the item arrays [o_wc, o_h) are not sent: the device writes them — and, per candidate, the list of its active residues
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, TB.data, o_wc * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].as<uint32_t>() + o_h, TB.data + o_h, (words - o_h) * 4, hipMemcpyHostToDevice, st));
-        uint32_t *d = c->ws[WS_MISC0].as<uint32_t>();
-        const size_t ci_bytes = ((size_t)n_cand * 16 + 255) & ~(size_t)255;
-        HIPCHK(c, c->ws[WS_MP_ACT].ensure(ci_bytes + (size_t)64 * std::max<size_t>(nw, 1) * 4));
-        d_cinfo = c->ws[WS_MP_ACT].as<uint4>();
-        d_act = (const uint32_t *)(c->ws[WS_MP_ACT].as<uint8_t>() + ci_bytes);
-        fd_launch_mp_items(db->res_off, d + o_cand, (uint32_t)n_cand, d + TB.o_wb, d + TB.o_wb + ((n_cand + 1 + 3) & ~(size_t)3), j_span, d + o_wc, d + o_wi, d + o_wq, d + o_wj, st,
-                           db->aa, db->hash_ok, d_std, fd_make_consts_cfg(p, 0).q.type == FD_HASH_TERTIARY ? 1 : 0, (const mp_query_dev *)(d + o_qt), (void *)d_cinfo,
-                           (uint32_t *)d_act);
-    } else
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, TB.data, words * 4, hipMemcpyHostToDevice, st));
-    const uint32_t *dblk = c->ws[WS_MISC0].as<uint32_t>();
-    mp_args A;
-    memset(&A, 0, sizeof A);
-    A.mode = mode;
-    if (cj_mask && mask_off) {   // partner-residue filter (second pass of a large query's retrieval)
-        HIPCHK(c, c->ws[WS_MISC1].ensure((mask_words + n_cand + 2) * 4));
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, cj_mask, mask_words * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].as<uint32_t>() + mask_words, mask_off, n_cand * 4, hipMemcpyHostToDevice, st));
-        A.cj_mask = c->ws[WS_MISC1].as<uint32_t>(); A.mask_off = A.cj_mask + mask_words;
-    }
-    fd_vote_row *d_rows = nullptr;
-    if (mode & 32u) {   // rescue votes stay on the device: counters in ws[WS_IDS_A], their tables in ws[WS_IDS_B]
-        const uint64_t nb = votes->n_bits, nr = votes->n_rows;
-        auto up8 = [](uint64_t x) { return (x + 7) & ~(uint64_t)7; };
-        const uint64_t o_off = 0, o_roff = o_off + up8(n_cand * 8), o_rows = o_roff + up8(nr * 8), o_qs = o_rows + up8(nr * sizeof(fd_vote_row)),
-                       o_rlen = o_qs + up8(n_cand * 4), o_comp = o_rlen + up8(nr * 4), o_sdd = o_comp + up8(nb), o_sdq = o_sdd + up8(votes->n_sd * 4),
-                       bytes = o_sdq + up8(votes->n_sd * 4) + 8;
-        HIPCHK(c, c->ws[WS_IDS_A].ensure(std::max<uint64_t>(votes->n_counters, 1) * 4));
-        HIPCHK(c, c->ws[WS_IDS_B].ensure(bytes));
-        uint8_t *base = c->ws[WS_IDS_B].as<uint8_t>();
-        HIPCHK(c, hipMemsetAsync(c->ws[WS_IDS_A].p, 0, std::max<uint64_t>(votes->n_counters, 1) * 4, st));
-        HIPCHK(c, hipMemcpyAsync(base + o_off, votes->vt_off, n_cand * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(base + o_qs, votes->vt_qs, n_cand * 4, hipMemcpyHostToDevice, st));
-        if (nr) {
-            HIPCHK(c, hipMemcpyAsync(base + o_roff, votes->row_off, nr * 8, hipMemcpyHostToDevice, st));
-            HIPCHK(c, hipMemcpyAsync(base + o_rlen, votes->row_len, nr * 4, hipMemcpyHostToDevice, st));
-        }
-        if (nb) HIPCHK(c, hipMemcpyAsync(base + o_comp, votes->cj_comp, nb, hipMemcpyHostToDevice, st));
-        A.votes = c->ws[WS_IDS_A].as<uint32_t>(); A.vt_off = (const uint64_t *)(base + o_off); A.vt_qs = (const uint32_t *)(base + o_qs);
-        A.cj_comp = base + o_comp;
-        if (votes->sd_dist && votes->sd_qi && votes->n_sd) {
-            HIPCHK(c, hipMemcpyAsync(base + o_sdd, votes->sd_dist, votes->n_sd * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(c, hipMemcpyAsync(base + o_sdq, votes->sd_qi, votes->n_sd * 4, hipMemcpyHostToDevice, st));
-            A.sd_dist = (const float *)(base + o_sdd); A.sd_qi = (const uint32_t *)(base + o_sdq);
-        }
-        d_rows = (fd_vote_row *)(base + o_rows);
-    }
-    if (!fd_multiple_bins_valid(p)) FAIL(c, FDGPU_EINVAL, "multiple_bins: at most 8 (dist, angle) bin pairs, no zero counts");
-    A.B = db->view(); A.C = fd_make_consts_cfg(p, 0); A.cutoff = p->dist_cutoff;
-    A.n_cfg = fd_num_bin_configs(p);
-    for (uint32_t k = 0; k < A.n_cfg; ++k) A.qk[k] = fd_make_consts_cfg(p, k).q;
-    A.cand = dblk + o_cand; A.n_cand = (uint32_t)n_cand;
-    A.wi_cand = dblk + o_wc; A.wi_i0 = dblk + o_wi; A.wi_query = dblk + o_wq; A.n_work = (uint32_t)nw;
-    A.wi_j0 = dblk + o_wj; A.j_span = j_span;
-    A.resname_std = d_std;
-    A.q_hashes = dblk + o_h; A.aad_start = dblk + o_st; A.aad_dist = (const float *)(dblk + o_d); A.aad_qi = dblk + o_qi;
-    A.iv_start = want_iv ? dblk + o_ivs : nullptr; A.iv = want_iv ? (const float2 *)(dblk + o_iv) : nullptr;
-    A.iv_grp = want_iv ? dblk + o_iv1 : nullptr;
-    A.qtab = (const mp_query_dev *)(dblk + o_qt);
-    A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.found = nullptr; A.cands = nullptr;
-    const bool mp_dbg = getenv("FDGPU_MP_DBG") != nullptr;       // clocks and counts of the pair scan's work items and drains on stderr (measurement aid)
-    HIPCHK(c, c->ws[WS_TOTAL].ensure(16384));
-    // ws[WS_TOTAL] (u64): [0] found triples, [1] candidate pairs, [2] chunks drained, [4, 12) FDGPU_MP_DBG, from [16]: the 64 sub-queues' claimed chunks, one per 128-byte line
-    A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.q_cnt = A.n_found + 16;
-    A.dbg = mp_dbg ? A.n_found + 4 : nullptr;
-    A.cinfo = d_cinfo; A.act = d_act;
-    A.compact = !want_iv;
-      // (want_iv: some query observes more than 1,024 distances)
-    // one emitting pass into buffers sized by the previous calls; a pass that overflows only counts, the buffers grow and
-    // the pass is repeated (the scan is deterministic up to record order, which is restored below)
-    static_assert(MP_SUBQ_STRIDE == 16, "ws[WS_TOTAL] layout");
-    std::vector<uint64_t> tot_v(16 + 64 * MP_SUBQ_STRIDE, 0);
-    uint64_t *tot = tot_v.data();
-    uint64_t q_max = 0;      // most chunks one sub-queue was asked for by the previous attempt
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        uint64_t capf = c->ws[WS_KEYS_A].cap / sizeof(fd_pair_rec), capc = c->ws[WS_KEYS_B].cap / sizeof(fd_cand_rec);
-        if (capf < 4096 || capf < tot[0]) { HIPCHK(c, c->ws[WS_KEYS_A].ensure(std::max<uint64_t>(2 * tot[0], 65536) * sizeof(fd_pair_rec))); }
-        if (capc < 4096 || capc < tot[1]) { HIPCHK(c, c->ws[WS_KEYS_B].ensure(std::max<uint64_t>(2 * tot[1], 65536) * sizeof(fd_cand_rec))); }
-        A.found = c->ws[WS_KEYS_A].as<fd_pair_rec>(); A.cands = c->ws[WS_KEYS_B].as<fd_cand_rec>();
-        A.cap_found = c->ws[WS_KEYS_A].cap / sizeof(fd_pair_rec); A.cap_cands = c->ws[WS_KEYS_B].cap / sizeof(fd_cand_rec);
-        {
-            // the chunk queue between the scan and the drains, ws[WS_MP_Q]: [256 B bin tables | per chunk: 16 B header, 256 B pairs, 3 x 256 B results,
-            // 8 B totals, 16 B positions], 64 sub-queues.  A work item rarely queues more than two chunks; a launch that asks for more than a sub-queue
-            // holds counts them and is repeated with the queue it asked for
-            const uint64_t per = 16 + 256 + 768 + 8 + 16, have = c->ws[WS_MP_Q].cap > 256 ? (c->ws[WS_MP_Q].cap - 256) / (per * 64) : 0;
-            uint64_t want = std::max<uint64_t>(have, std::max<uint64_t>(64, (nw + nw / 2) / 64 + 32));
-            if (q_max > have) want = std::max<uint64_t>(want, q_max + q_max / 4 + 16);
-            if (want > have) HIPCHK(c, c->ws[WS_MP_Q].ensure(256 + want * per * 64));
-            if (c->ws[WS_MP_Q].p != c->mp_bintab_at || c->ws[WS_MP_Q].cap != c->mp_bintab_cap) {      // (a new allocation: the tables once)
-                uint32_t t64[64];
-                memset(t64, 0, sizeof t64);
-                fd_fill_bintab(t64);
-                for (int k = 0; k < FD_BINTAB_WORDS; ++k) t64[32 + k] = t64[k];
-                for (int m = 0; m < 4; ++m)
-                    for (int k = 0; k < 4; ++k) { const uint32_t v = t64[32 + 7 + 5 * m + k]; t64[32 + 7 + 5 * m + k] = v > 0x7f7fffffu ? 0x7f7fffffu : v; }
-                HIPCHK(c, hipMemcpyAsync(c->ws[WS_MP_Q].p, t64, sizeof t64, hipMemcpyHostToDevice, st));
-                HIPCHK(c, hipStreamSynchronize(st));
-                c->mp_bintab_at = c->ws[WS_MP_Q].p; c->mp_bintab_cap = c->ws[WS_MP_Q].cap;
-            }
-            const uint64_t capq = std::min<uint64_t>((c->ws[WS_MP_Q].cap - 256) / (per * 64), 0x1ffffffu), nch = capq * 64;
-            uint8_t *qb = c->ws[WS_MP_Q].as<uint8_t>() + 256;
-            A.cap_subq = (uint32_t)capq;
-            A.bintab = c->ws[WS_MP_Q].as<uint32_t>();
-            A.chunk_base = (ulonglong2 *)qb; qb += nch * 16;
-            A.chunk_hdr = (uint4 *)qb; qb += nch * 16;
-            A.chunk_cnt = (uint2 *)qb; qb += nch * 8;
-            A.chunk_ij = (uint32_t *)qb; qb += nch * 256;
-            A.res_h = (uint32_t *)qb; qb += nch * 256;
-            A.res_meta = (uint32_t *)qb; qb += nch * 256;
-            A.res_d = (float *)qb;
-        }
-        HIPCHK(c, hipMemsetAsync(c->ws[WS_TOTAL].p, 0, tot_v.size() * 8, st));
-        // a repeated launch drains its chunks again: the rescue votes of the attempt before (atomic adds of the chunks that did fit) must not count twice
-        if (attempt && (mode & 32u)) HIPCHK(c, hipMemsetAsync(c->ws[WS_IDS_A].p, 0, std::max<uint64_t>(votes->n_counters, 1) * 4, st));
-        {
-            StageTimer t(c, "match_pairs", 0);
-            fd_launch_match_pairs(A, st);
-        }
-        if (mp_dbg) {
-            unsigned long long d[8];
-            if (hipMemcpyAsync(d, A.dbg, 64, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
-                const double live = (double)std::max<unsigned long long>(d[0], 1), us = 0.01;      // 100 MHz ticks
-                fprintf(stderr, "[mp] %llu work items: %llu live (%.2f us each; %.1f partners visited, %.1f pairs queued per item), %llu early exits (%.2f us each); %llu chunks drained (%.2f us each)\n",
-                        (unsigned long long)nw, d[0], d[1] * us / live, d[6] / live, d[7] / live, d[2], d[2] ? d[3] * us / (double)d[2] : 0.0, d[4], d[4] ? d[5] * us / (double)d[4] : 0.0);
-            }
-        }
-        HIPCHK(c, hipGetLastError());
-        if (attempt == 0 && while_scanning && *while_scanning) (*while_scanning)();      // before the copy: one into pageable memory waits for the stream
-        HIPCHK(c, hipMemcpyAsync(tot, c->ws[WS_TOTAL].p, tot_v.size() * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        q_max = 0;
-        for (int k = 0; k < 64; ++k) q_max = std::max<uint64_t>(q_max, tot[16 + MP_SUBQ_STRIDE * k]);
-        if (q_max > A.cap_subq) {      // the drains saw a part of the pairs only: their counts mean nothing
-            if (attempt == 3) FAIL(c, FDGPU_ERANGE, "match_pairs: the pair queue did not fit after regrowing");
-            tot[0] = tot[1] = 0;
-            continue;
-        }
-        if (tot[0] <= A.cap_found && tot[1] <= A.cap_cands) break;
-        if (attempt == 3) FAIL(c, FDGPU_ERANGE, "match_pairs: output did not fit after regrowing");
-    }
-    if (mp_trace) fprintf(stderr, "[match_pairs] scan done at %.3f ms (found %llu, cands %llu)\n", mp_ms(), (unsigned long long)tot[0], (unsigned long long)tot[1]);
-    if (mode & 32u) {   // the rows of the vote table: (largest count, how many hold it, which) per (slot, component, query residue)
-        const uint8_t *base = c->ws[WS_IDS_B].as<uint8_t>();
-        const uint64_t nr = votes->n_rows;
-        auto up8 = [](uint64_t x) { return (x + 7) & ~(uint64_t)7; };
-        const uint64_t o_roff = up8(n_cand * 8), o_rows = o_roff + up8(nr * 8), o_rlen = o_rows + up8(nr * sizeof(fd_vote_row)) + up8(n_cand * 4);
-        fd_launch_vote_rows(A.votes, (const uint64_t *)(base + o_roff), (const uint32_t *)(base + o_rlen), nr, d_rows, st);
-        HIPCHK(c, hipGetLastError());
-        if (nr) HIPCHK(c, hipMemcpyAsync(votes->rows, d_rows, nr * sizeof(fd_vote_row), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        if (mp_trace) fprintf(stderr, "[match_pairs] vote rows done at %.3f ms (%llu rows, %llu counters)\n", mp_ms(), (unsigned long long)nr, (unsigned long long)votes->n_counters);
-        return FDGPU_OK;
-    }
-    // mode bit 4: the records stay on the device (ws[WS_KEYS_A] = found triples, ws[WS_KEYS_B] = candidate pairs, in append order) for
-    // the device-side retrieval glue (k_retrieve.hip); only the counts return
-    if (mode & 16u) { *n_found = tot[0]; *n_cands = tot[1]; return FDGPU_OK; }
-    // mode bit 3 (with pk_key / pk_val): the candidate pairs come back packed — key = slot << 16 | partner residue j, value =
-    // query residue << 16 | residue i — and sorted by key on the device: half the bytes over PCIe and no bucketing on the host
-    // (the rescue walks the pairs of one partner residue at a time).  Needs slots, residues and query residues below 2^16.
-    const char *pm_env = getenv("FDGPU_PACK_MIN");      // tests force the packed form on small inputs
-    const uint64_t pack_min = pm_env ? strtoull(pm_env, nullptr, 10) : (1ull << 18);   // a motif query's few thousand pairs are cheaper as they are
-    const bool packed = (mode & 8u) && pk_key && pk_val && n_cand < 65536 && tot[1] >= pack_min;
-    if (pk_key) *pk_key = nullptr;
-    if (pk_val) *pk_val = nullptr;
-    if (packed) {
-        const uint64_t n = tot[1];
-        // the packed pairs land in pinned buffers the CONTEXT keeps (valid until the next packed scan on this context; never freed by the caller)
-        uint32_t *hk = (uint32_t *)c->host_pinned(0, std::max<uint64_t>(n, 1) * 4), *hv = (uint32_t *)c->host_pinned(1, std::max<uint64_t>(n, 1) * 4);
-        fd_pair_rec *hf2 = (fd_pair_rec *)malloc(std::max<uint64_t>(tot[0], 1) * sizeof(fd_pair_rec));
-        if (!hk || !hv || !hf2) { free(hf2); return FDGPU_ENOMEM; }
-        if (n) {
-            HIPCHK(c, c->ws[WS_MISC2].ensure(n * 4)); HIPCHK(c, c->ws[WS_MISC3].ensure(n * 4));
-            HIPCHK(c, c->ws[WS_MISC4].ensure(n * 4)); HIPCHK(c, c->ws[WS_MISC5].ensure(n * 4));
-            HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * std::max<uint32_t>(fd_rs_num_tiles(n), 1) * 4));
-            HIPCHK(c, c->ws[WS_TOT].ensure((256 + (size_t)(fd_rs_num_tiles(n) / 128 + 2) * 256) * 8));
-            uint32_t *ka = c->ws[WS_MISC2].as<uint32_t>(), *va = c->ws[WS_MISC3].as<uint32_t>(), *kb = c->ws[WS_MISC4].as<uint32_t>(),
-                     *vb = c->ws[WS_MISC5].as<uint32_t>();
-            fd_launch_pack_cands(A.cands, n, ka, va, st);
-            int bits = 17;
-            while (bits < 32 && (1ull << (bits - 16)) < std::max<uint64_t>(n_cand, 2)) ++bits;
-            const int cur = sort_pairs(c, ka, va, kb, vb, n, bits);
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipMemcpyAsync(hk, cur ? kb : ka, n * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipMemcpyAsync(hv, cur ? vb : va, n * 4, hipMemcpyDeviceToHost, st));
-        }
-        if (tot[0]) HIPCHK(c, hipMemcpyAsync(hf2, A.found, tot[0] * sizeof(fd_pair_rec), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        if (mp_trace) fprintf(stderr, "[match_pairs] packed copy done at %.3f ms\n", mp_ms());
-        fd_sort_found(hf2, tot[0], n_cand);
-        if (mp_trace) fprintf(stderr, "[match_pairs] found sorted at %.3f ms\n", mp_ms());
-        *found = hf2; *n_found = tot[0]; *cands = nullptr; *n_cands = n; *pk_key = hk; *pk_val = hv;
-        return FDGPU_OK;
-    }
-    // many found triples and no candidate pairs to keep (first scan of a large query: ~10^5 triples, most of them in the slot of the query's own
-    // structure): (slot, i, j) order is made on the device — two stable radix sorts over the record index — instead of one host thread's
-    // stable_sort of that slot.  FDGPU_FOUND_SORT=host: the host form (tests)
-    bool sorted_on_device = false;
-    {
-        uint64_t max_len = 0;
-        for (uint64_t k = 0; k < n_cand; ++k) max_len = std::max<uint64_t>(max_len, db->h_res_off[cand[k] + 1] - db->h_res_off[cand[k]]);
-        const char *fs_env = getenv("FDGPU_FOUND_SORT");
-        const uint64_t fs_min = fs_env && !strcmp(fs_env, "device") ? 2 : 32768;
-        if (tot[0] >= fs_min && tot[1] == 0 && n_cand < 65536 && max_len < 65536 && !(fs_env && !strcmp(fs_env, "host"))) {
-            const uint64_t n = tot[0];
-            HIPCHK(c, c->ws[WS_MISC2].ensure(n * 4)); HIPCHK(c, c->ws[WS_MISC3].ensure(n * 4));
-            HIPCHK(c, c->ws[WS_MISC4].ensure(n * 4)); HIPCHK(c, c->ws[WS_MISC5].ensure(n * 4));
-            HIPCHK(c, c->ws[WS_IDS_A].ensure(n * sizeof(fd_pair_rec)));
-            HIPCHK(c, c->ws[WS_GHIST].ensure((size_t)256 * std::max<uint32_t>(fd_rs_num_tiles(n), 1) * 4));
-            HIPCHK(c, c->ws[WS_TOT].ensure((256 + (size_t)(fd_rs_num_tiles(n) / 128 + 2) * 256) * 8));
-            uint32_t *ka = c->ws[WS_MISC2].as<uint32_t>(), *va = c->ws[WS_MISC3].as<uint32_t>(), *kb = c->ws[WS_MISC4].as<uint32_t>(), *vb = c->ws[WS_MISC5].as<uint32_t>();
-            fd_launch_found_key_ij(A.found, n, ka, va, st);
-            int cur = sort_pairs(c, ka, va, kb, vb, n, 32);
-            uint32_t *k1 = cur ? kb : ka, *v1 = cur ? vb : va, *k2 = cur ? ka : kb, *v2 = cur ? va : vb;
-            fd_launch_found_key_slot(A.found, v1, n, k1, st);
-            int bits = 1;
-            while (bits < 16 && (1ull << bits) < std::max<uint64_t>(n_cand, 2)) ++bits;
-            cur = sort_pairs(c, k1, v1, k2, v2, n, bits);
-            fd_launch_found_gather(A.found, cur ? v2 : v1, n, c->ws[WS_IDS_A].as<fd_pair_rec>(), st);
-            HIPCHK(c, hipGetLastError());
-            sorted_on_device = true;
-        }
-    }
-    fd_pair_rec *hf = (fd_pair_rec *)malloc(std::max<uint64_t>(tot[0], 1) * sizeof(fd_pair_rec));
-    fd_cand_rec *hc = (fd_cand_rec *)malloc(std::max<uint64_t>(tot[1], 1) * sizeof(fd_cand_rec));
-    if (!hf || !hc) { free(hf); free(hc); return FDGPU_ENOMEM; }
-    hipError_t e = hipSuccess;
-    if (sorted_on_device) e = hipMemcpyAsync(hf, c->ws[WS_IDS_A].p, tot[0] * sizeof(fd_pair_rec), hipMemcpyDeviceToHost, st);
-    if (!sorted_on_device && tot[0]) e = hipMemcpyAsync(hf, A.found, tot[0] * sizeof(fd_pair_rec), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && tot[1]) e = hipMemcpyAsync(hc, A.cands, tot[1] * sizeof(fd_cand_rec), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { free(hf); free(hc); c->err = std::string("match_pairs: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-    // restore the reference's scan order (row-major over the prefilter sets, retrieve.rs:146-153): the
-    // kernel appends with atomics, one contiguous run per (i, j) in observed-list order
-    if (mp_trace) fprintf(stderr, "[match_pairs] copy done at %.3f ms\n", mp_ms());
-    if (!sorted_on_device) fd_sort_found(hf, tot[0], n_cand);
-    if (mp_trace) fprintf(stderr, "[match_pairs] found sorted at %.3f ms%s\n", mp_ms(), sorted_on_device ? " (on the device)" : "");
-    // mode bit 2: the caller buckets the candidate pairs itself and does not depend on their order (the rescue only counts them)
-    if (!(mode & 4u)) std::stable_sort(hc, hc + tot[1], [](const fd_cand_rec &a, const fd_cand_rec &b) {
-        if (a.cand != b.cand) return a.cand < b.cand;
-        if (a.i != b.i) return a.i < b.i;
-        return a.j < b.j;
-    });
-    *found = hf; *n_found = tot[0]; *cands = hc; *n_cands = tot[1];
-    return FDGPU_OK;
-}
-extern "C" int fdgpu_match_pairs(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *resname_std, const uint32_t *cand, uint64_t n_cand,
-                                 const fd_match_query *q, const fd_hash_params *p, fd_pair_rec **found, uint64_t *n_found,
-                                 fd_cand_rec **cands, uint64_t *n_cands) { FD_LOCK(c);
-    if (!q) return FDGPU_EINVAL;
-    const uint64_t off[2] = {0, n_cand};
-    return fd_match_pairs_multi(c, db, resname_std, 1, q, cand, off, p, found, n_found, cands, n_cands);
-}
-
-// Similarity metrics of n superpositions on the device (k_metrics): problem k compares ref[off[k] .. off[k+1]) (fixed points) with
-// rot[k] * mov[...] + tran[k]; metrics[5k ..] = {tm_score, gdt_ts, gdt_ha, chamfer, hausdorff} (src/structure/metrics.rs:62-251).
-extern "C" int fdgpu_metrics_batch(fdgpu_ctx *c, const float *ref, const float *mov, const uint64_t *off, uint64_t n, const float *rot, const float *tran,
-                                   float *metrics) { FD_LOCK(c);
-    if (!c || (n && (!ref || !mov || !off || !rot || !tran || !metrics))) return FDGPU_EINVAL;
-    if (!n) return FDGPU_OK;
-    hipStream_t st = c->stream;
-    const uint64_t npts = off[n];
-    std::vector<float> d0(n);
-    for (uint64_t k = 0; k < n; ++k) {   // d0_scale (metrics.rs:117-123) with the host's powf, like the reference
-        const uint64_t len = off[k + 1] - off[k];
-        d0[k] = len > 21 ? 1.24f * powf((float)len - 15.0f, 1.0f / 3.0f) - 1.8f : 0.5f;
-    }
-    HIPCHK(c, c->ws[WS_MISC0].ensure(std::max<uint64_t>(npts, 1) * 12));
-    HIPCHK(c, c->ws[WS_MISC1].ensure(std::max<uint64_t>(npts, 1) * 12));
-    HIPCHK(c, c->ws[WS_MISC2].ensure((n + 1) * 8));
-    HIPCHK(c, c->ws[WS_MISC3].ensure(n * 4));
-    HIPCHK(c, c->ws[WS_MISC4].ensure(n * 36));
-    HIPCHK(c, c->ws[WS_MISC5].ensure(n * 12));
-    HIPCHK(c, c->ws[WS_TILE_PO].ensure(n * 20));
-    if (npts) {
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, ref, npts * 12, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, mov, npts * 12, hipMemcpyHostToDevice, st));
-    }
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC3].p, d0.data(), n * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC4].p, rot, n * 36, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, tran, n * 12, hipMemcpyHostToDevice, st));
-    fd_launch_metrics(c->ws[WS_MISC0].as<float>(), c->ws[WS_MISC1].as<float>(), c->ws[WS_MISC2].as<uint64_t>(), n, c->ws[WS_MISC4].as<float>(),
-                      c->ws[WS_MISC5].as<float>(), c->ws[WS_MISC3].as<float>(), c->ws[WS_TILE_PO].as<float>(), st);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(metrics, c->ws[WS_TILE_PO].p, n * 20, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    return FDGPU_OK;
-}
-
-extern "C" int fdgpu_kabsch_batch(fdgpu_ctx *c, const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot,
-                                  float *tran) { FD_LOCK(c);
-    if (!c || (n && (!x || !y || !off || !rmsd || !rot || !tran))) return FDGPU_EINVAL;
-    if (!n) return FDGPU_OK;
-    hipStream_t st = c->stream;
-    uint64_t npts = off[n];
-    const bool tr = getenv("FDGPU_TRACE") != nullptr;
-    auto k0 = std::chrono::steady_clock::now();
-    if (tr) { (void)hipStreamSynchronize(st); fprintf(stderr, "[kabsch] entry sync %.3f ms, %llu problems, %llu points\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - k0).count(), (unsigned long long)n, (unsigned long long)npts); }
-    HIPCHK(c, c->ws[WS_MISC0].ensure(std::max<uint64_t>(npts, 1) * 12));
-    HIPCHK(c, c->ws[WS_MISC1].ensure(std::max<uint64_t>(npts, 1) * 12));
-    HIPCHK(c, c->ws[WS_MISC2].ensure((n + 1) * 8));
-    HIPCHK(c, c->ws[WS_MISC3].ensure(n * 4));
-    HIPCHK(c, c->ws[WS_MISC4].ensure(n * 36));
-    HIPCHK(c, c->ws[WS_MISC5].ensure(n * 12));
-    if (npts) {
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, x, npts * 12, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, y, npts * 12, hipMemcpyHostToDevice, st));
-    }
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
-    fd_launch_kabsch(c->ws[WS_MISC0].as<float>(), c->ws[WS_MISC1].as<float>(), c->ws[WS_MISC2].as<uint64_t>(), n, c->ws[WS_MISC3].as<float>(),
-                     c->ws[WS_MISC4].as<float>(), c->ws[WS_MISC5].as<float>(), st);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(rmsd, c->ws[WS_MISC3].p, n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(rot, c->ws[WS_MISC4].p, n * 36, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(tran, c->ws[WS_MISC5].p, n * 12, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    if (tr) fprintf(stderr, "[kabsch] total %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - k0).count());
-    return FDGPU_OK;
-}
-
-// --partial-fit: LmsQcpSuperimposer with its default parameters (src/structure/lms_qcp.rs), one wavefront per problem
-extern "C" int fdgpu_lms_qcp_batch(fdgpu_ctx *c, const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot,
-                                   float *tran, uint32_t *core_len, uint32_t *core) { FD_LOCK(c);
-    if (!c || (n && (!x || !y || !off || !rmsd || !rot || !tran))) return FDGPU_EINVAL;
-    if (!n) return FDGPU_OK;
-    for (uint64_t k = 0; k < n; ++k)
-        if (off[k + 1] < off[k] + 3 || off[k + 1] - off[k] > 0xffffffffull) {   // the reference asserts >= 3 pairs (lms_qcp.rs:84)
-            c->err = "fdgpu_lms_qcp_batch: every problem needs at least 3 point pairs";
-            return FDGPU_EINVAL;
-        }
-    hipStream_t st = c->stream;
-    const uint64_t npts = off[n];
-    HIPCHK(c, c->ws[WS_MISC0].ensure(npts * 12));
-    HIPCHK(c, c->ws[WS_MISC1].ensure(npts * 12));
-    HIPCHK(c, c->ws[WS_MISC2].ensure((n + 1) * 8));
-    HIPCHK(c, c->ws[WS_MISC3].ensure(n * 8));       // rmsd f32[n] | core_len u32[n]
-    HIPCHK(c, c->ws[WS_MISC4].ensure(n * 48));      // rot f32[9n] | tran f32[3n]
-    HIPCHK(c, c->ws[WS_MISC5].ensure(npts * 5));    // order u32[npts] | flags u8[npts]
-    float *d_rmsd = c->ws[WS_MISC3].as<float>();
-    uint32_t *d_core = (uint32_t *)(d_rmsd + n);
-    float *d_rot = c->ws[WS_MISC4].as<float>(), *d_tran = d_rot + 9 * n;
-    uint32_t *d_order = c->ws[WS_MISC5].as<uint32_t>();
-    uint8_t *d_flags = (uint8_t *)(d_order + npts);
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, x, npts * 12, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, y, npts * 12, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
-    fd_launch_lms_qcp(c->ws[WS_MISC0].as<float>(), c->ws[WS_MISC1].as<float>(), c->ws[WS_MISC2].as<uint64_t>(), n, d_rmsd, d_rot, d_tran, d_core,
-                      d_flags, d_order, st);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(rmsd, d_rmsd, n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(rot, d_rot, n * 36, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(tran, d_tran, n * 12, hipMemcpyDeviceToHost, st));
-    if (core_len) HIPCHK(c, hipMemcpyAsync(core_len, d_core, n * 4, hipMemcpyDeviceToHost, st));
-    if (core) HIPCHK(c, hipMemcpyAsync(core, d_order, npts * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
     return FDGPU_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include "../../include/fdgpu.h"
+#include "../../include/fdgpu_debug.h"
 #include "fd_device.h"
 #include "fd_geom_other.h"
 

@@ -439,20 +439,8 @@ int fdgpu_count_query_maps_top_global(fdgpu_ctx *ctx, const fdgpu_index *ix, uin
                                       const uint64_t *global_lengths, const float *penalty, float total_structures, uint32_t top_n,
                                       fd_count_rec **out, uint64_t **out_off);
 /* The per-rank message of the device exchange: {u32 status, n_queries, top_n, cap} | {u32 x3, u32 count}[n_queries] |
- * fd_count_rec[n_queries][top_n], padded to 16 bytes.  fdgpu_debug_merge_gathered runs what every rank runs after the all-gather — unpack,
- * global selection, ranking, all on the device — on `world` such messages given as one host array (tests drive the multi-rank code with it
- * on a single GPU).  0 < top_n <= 3072. */
+ * fd_count_rec[n_queries][top_n], padded to 16 bytes (include/fdgpu_debug.h: the post-gather merges on hand-made messages).  0 < top_n <= 3072. */
 uint64_t fdgpu_comm_message_bytes(uint64_t n_queries, uint32_t top_n);
-int fdgpu_debug_merge_gathered(fdgpu_ctx *ctx, uint32_t world, uint64_t n_queries, uint32_t top_n, const uint8_t *messages,
-                               fd_count_rec **out, uint64_t **out_off);
-/* The unpack + merge step of fdgpu_sharded_retrieve alone, on hand-made contributions of `world` ranks (host arrays): counts[r * (n_queries + 1) + t]
- * = matches rank r found for query t, counts[r * (n_queries + 1) + n_queries] = its status (0 = fine); rank_matches[r] / rank_residues[r] = its
- * records (cand = slot in the query's GLOBAL candidate list) and residue ints in (query, slot, component) order; nres_per[t] = residue ints per
- * match of query t (2 * n_indices).  Output as fdgpu_retrieve_batch.  Lets a single-GPU test drive the multi-rank merge with ragged, empty and
- * failing ranks. */
-int fdgpu_debug_merge_retrieved(fdgpu_ctx *ctx, uint32_t world, uint64_t n_queries, const uint64_t *counts, const fd_match_rec *const *rank_matches,
-                                const int32_t *const *rank_residues, const uint64_t *nres_per, fd_match_rec **matches, uint64_t **match_off,
-                                int32_t **residues, uint64_t **res_off);
 
 /* ---- structure ingest (host, multi-threaded) ---------------------------------------------------------------
  * PDB / mmCIF text (optionally gzip) -> the packed arrays of fd_batch_desc plus what the .lookup file and the result
@@ -481,10 +469,6 @@ void fdgpu_parsed_free(fd_parsed *p);
 /* thread-seconds the ingest spent so far (summed over the threads of all fdgpu_parse_structures calls of the process): out[0] read + inflate,
  * out[1] text -> atom records, out[2] CompactStructure::build, out[3] files, out[4] inflated bytes; reset != 0 clears the counters */
 void fdgpu_ingest_stats(double out[5], int reset);
-/* The ingest's own gzip decoder (csrc/fd_inflate.cpp; the reference reads .gz through the flate2 crate, src/structure/io/pdb.rs:79-124) on a
- * buffer, for tests: every member of in[0 .. n) concatenated into *out (fdgpu_free).  FDGPU_EINVAL = the decoder declines the input (damaged, or
- * a code it does not handle); fdgpu_parse_structures then reads that file through zlib.  FDGPU_ZLIB=1 in the environment sends every file there. */
-int fdgpu_debug_gunzip(const uint8_t *in, uint64_t n, uint8_t **out, uint64_t *n_out);
 
 /* Foldcomp input (reference: src/structure/io/fcz.rs — FoldcompDbReader::new :41-74, read_single_structure_by_id :203-230,
  * and the vendored decoder behind foldcomp_process, lib/foldcomp/foldcompffi.cpp).  fdgpu_foldcomp_decode turns one database
@@ -536,12 +520,6 @@ int fdgpu_spec_fallbacks(fdgpu_ctx *ctx, uint64_t *out);
  * entries written (<= cap). */
 int fdgpu_last_timings(const fdgpu_ctx *ctx, const char **names, float *ms, uint64_t *bytes, int cap);
 int fdgpu_enable_timing(fdgpu_ctx *ctx, int on);
-
-/* ---- diagnostics ---------------------------------------------------------------------------------------
- * Evaluates the device restatements of glibc's sinf/cosf/acosf/atanf/atan2f (csrc/fd_libm.h) or the
- * pair descriptor on arrays, so that tests can compare the gfx950 arithmetic bit-for-bit with the host.
- * op: 0 sinf, 1 cosf, 2 acosf, 3 atanf, 4 atan2f(a, b). */
-int fdgpu_debug_libm(fdgpu_ctx *ctx, int op, const float *a, const float *b, float *out, uint64_t n);
 
 /* ---- PREFIX.lookup (src/index/lookup.rs:35-56; written by build_index.rs:204-215) -------------------------------------------------
  * One line per structure: id \t tid \t nres \t plddt \t db_key \n, plddt printed like Rust's `{}` of an f32 (shortest digits that

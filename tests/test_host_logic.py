@@ -21,13 +21,19 @@ def test_library_loads_and_exports_every_declared_symbol():
     fb.build()
     L = _lib.load()
     header = open(os.path.join(ROOT, "include", "fdgpu.h")).read()
-    declared = set(re.findall(r"\b(fdgpu_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) >= 30
+    public = set(re.findall(r"\b(fdgpu_[a-z0-9_]+)\s*\(", header))
+    debug = set(re.findall(r"\b(fdgpu_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "fdgpu_debug.h")).read()))
+    declared = public | debug
+    assert len(public) >= 30 and debug and all(n.startswith("fdgpu_debug_") for n in debug) and not any(n.startswith("fdgpu_debug_") for n in public)
     for name in sorted(declared):
-        assert hasattr(L, name), f"{name} declared in include/fdgpu.h but not exported"
+        assert hasattr(L, name), f"{name} declared in include/ but not exported"
     bound = {n for n, _, _ in _lib.SYMBOLS}
     assert declared <= bound, f"unbound: {declared - bound}"
     assert b"gfx950" in L.fdgpu_version()
+    # the reference-side binding a maintainer would add (INTEGRATION.md's extern "C" block) names every public entry point
+    rust = set(re.findall(r"\bfn (fdgpu_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
+    assert public <= rust, f"not in INTEGRATION.md: {sorted(public - rust)}"
+    assert not (rust - public), f"INTEGRATION.md binds what include/fdgpu.h does not declare: {sorted(rust - public)}"
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
