@@ -229,6 +229,11 @@ def cpu_baseline_query(ix, d, nres, res_off_h, qlist, top_n, match_top, S):
                     "stage_thread_s": {k: round(x, 2) for k, x in r64["stage_thread_s"].items()}}}
 
 
+def PAR_NOTE(world):
+    return "" if world == 1 else ("; the headline times INDEPENDENT shard builds (no data-path collective); single_index_inclusive = the same step + the hash-range "
+                                  "exchange and per-range merge that make them one index")
+
+
 def progress(msg):
     """FD_BENCH_TRACE=1: a line per leg on stderr (where a multi-rank run spends its time)"""
     if os.environ.get("FD_BENCH_TRACE"):
@@ -429,8 +434,9 @@ def main():
         return {"metric": "structures/sec indexed", "value": value, "unit": "structures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
                 "config": {"workload": f"Swiss-Prot scale: {S_total} synthetic AFDB-shaped structures index build, PDBTrRosetta default; {world} rank(s), contiguous id ranges",
-                           "structures": S_total, "structures_per_gpu": S, "parallelism": f"shard-by-structure x{world}"},
-                "roofline": got(lambda: roofline), "export_inclusive": got(lambda: export), "index_on_disk_inclusive": got(lambda: on_disk), "cpu_baseline": None,
+                           "structures": S_total, "structures_per_gpu": S, "parallelism": f"shard-by-structure x{world}" + PAR_NOTE(world)},
+                "roofline": got(lambda: roofline), "export_inclusive": got(lambda: export), "single_index_inclusive": got(lambda: single_index),
+                "index_on_disk_inclusive": got(lambda: on_disk), "cpu_baseline": None,
                 "query": got(lambda: query), "cli_index": None}
 
     def watchdog():
@@ -444,7 +450,7 @@ def main():
             try:
                 print(json.dumps(line), flush=True)
             except Exception:  # noqa: BLE001 — a leg's half-built dictionary must not cost the headline
-                for k in ("roofline", "export_inclusive", "index_on_disk_inclusive", "query"):
+                for k in ("roofline", "export_inclusive", "single_index_inclusive", "index_on_disk_inclusive", "query"):
                     line[k] = None
                 print(json.dumps(line), flush=True)
         _WD_LEFT.set()
@@ -471,6 +477,37 @@ def main():
         dte = max_over_ranks(t1e - t0e)
         export = {"value": S_total / dte, "unit": "structures/s", "ms_per_step": dte * 1e3, "bytes_to_host_per_rank": int(vl.value + 12 * H.value + 8),
                   "note": "one step + fdgpu_index_export (D2H of value bytes, hashes, offsets into malloc'd host buffers)"}
+
+    # ---- N > 1, single-index inclusive: one more step that ends with ONE index of the whole database spread over the ranks by hash range (what
+    # `folddisco index` must produce: SURVEY §8e row 2) — the timed shard build + hash bounds of equal posting bytes from rank 0 + piece j of every
+    # rank's sub-index to rank j (ncclSend / ncclRecv under nccl; host objects under gloo) + per-range device merge.  NO file I/O.  The headline
+    # above times independent shard builds and contains no exchange: this is the number that does.  Expected bytes leaving a rank:
+    # (its value bytes + 12 B per hash) x (N - 1) / N.
+    single_index = None
+    if world > 1 and not args.no_export:
+        try:
+            from folddisco_amd import dist as fdist
+            comm_si = fdist.Comm(ctx, rank, world) if dist.get_backend() == "nccl" else None
+            ix = None
+            barrier()
+            t0s = time.perf_counter()
+            ix = build_shard()
+            sent = int((ix.value_len + 12 * ix.num_hashes) * (world - 1) / world)
+            rng, hb_, vb_, ht_, vt_ = comm_si.single_index(ix) if comm_si is not None else fdist.single_index_over_process_group(ctx, ix)
+            ctx.synchronize()
+            t1s = time.perf_counter()
+            barrier()
+            dts = max_over_ranks(t1s - t0s)
+            held = (rng.num_hashes, rng.value_len)
+            rng = None
+            comm_si = None
+            single_index = {"value": S_total / dts, "unit": "structures/s", "ms_per_step": dts * 1e3, "exchange_bytes_sent_by_rank0_estimate": sent,
+                            "total_hashes": int(ht_), "total_value_bytes": int(vt_), "rank0_range_hashes": int(held[0]), "rank0_range_value_bytes": int(held[1]),
+                            "transport": "ncclSend / ncclRecv, device to device" if dist.get_backend() == "nccl" else "torch.distributed objects over gloo (host staging: not the RCCL path)",
+                            "note": "one step + fdgpu_comm_single_index (bounds, slices, exchange, per-range merge), no files; max over ranks"}
+        except Exception as e:  # noqa: BLE001 — the headline line must still be printed
+            single_index = {"error": repr(e)[:300]}
+        progress("single-index leg done")
 
     # ---- on-disk inclusive: one more step that ends with the reference's PREFIX / PREFIX.offset on a file system.  One rank: fdgpu_index_save (device
     # arrays streamed through pinned slots into pwrite).  N ranks: the single index without the host (Option A; csrc/fd_shard_index.hip):
@@ -675,8 +712,9 @@ def main():
                                    f"{int(vlen_tot)} value bytes) index build, PDBTrRosetta default; {world} rank(s), contiguous id ranges, "
                                    f"per rank {n_calls} build call(s) of <= {CALL_MAX} structures" + (" merged on the device into one resident index" if n_calls > 1 else ": one resident index, no merge"),
                        "structures": S_total, "structures_per_gpu": S, "residues": int(R_tot), "postings": int(post_tot),
-                       "parallelism": f"shard-by-structure x{world}", "build_calls_per_rank": n_calls, "call_plan": call_plan},
-            "roofline": roofline, "export_inclusive": export, "index_on_disk_inclusive": on_disk, "cpu_baseline": cpu, "query": query, "cli_index": cli_index,
+                       "parallelism": f"shard-by-structure x{world}" + PAR_NOTE(world), "build_calls_per_rank": n_calls, "call_plan": call_plan},
+            "roofline": roofline, "export_inclusive": export, "single_index_inclusive": single_index, "index_on_disk_inclusive": on_disk, "cpu_baseline": cpu,
+            "query": query, "cli_index": cli_index,
         }
         print(json.dumps(out), flush=True)
         wd_printed.set()

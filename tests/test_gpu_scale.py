@@ -442,6 +442,10 @@ def test_bench_n_gt_1_path_runs_with_two_gloo_ranks_on_one_gpu():
     assert q["value"] == max(q["sharded_value"], q["replicas"]["value"])
     assert q["exchange"] is not None and q["batched_with_matching"]["matches"] > 0
     assert out["roofline"]["frac"] > 0 and out["export_inclusive"]["value"] > 0
+    # the N > 1 line carries BOTH build figures: independent shard builds (the headline) and the same step + the exchange that makes them one index
+    si = out["single_index_inclusive"]
+    assert "error" not in si and si["value"] > 0 and si["ms_per_step"] > out["ms_per_step"] * 0.5 and si["total_value_bytes"] > 0 and si["exchange_bytes_sent_by_rank0_estimate"] > 0, si
+    assert "INDEPENDENT shard builds" in out["config"]["parallelism"]
     disk = out["index_on_disk_inclusive"]
     assert "error" not in disk and (disk.get("skipped") or (disk["value"] > 0 and disk["files_complete"])), disk
     # the N > 1 watchdog: with a limit shorter than the legs behind the timed build, rank 0 prints the line with the completed measurement and every
