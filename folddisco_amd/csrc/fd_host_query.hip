@@ -341,6 +341,19 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
     A.gq = c->ws[WS_RS_GQ].as<uint32_t>(); A.gr = A.gq + cap_pts / 2;
     A.koff = c->ws[WS_RS_KOFF].as<uint64_t>(); A.d0 = (float *)(A.koff + cap_prob + 1);
     A.cap_matches = cap_m; A.cap_res = cap_res; A.cap_prob = cap_prob; A.cap_pts = cap_pts;
+    // the split form of the glue (k_rs_setup + a wavefront per component, k_retrieve.hip); FDGPU_RS_SPLIT=0: k_rs_slots alone (read per call: tests compare the two)
+    if (!(getenv("FDGPU_RS_SPLIT") && getenv("FDGPU_RS_SPLIT")[0] == '0') && !rs_dbg) {
+        auto up16 = [](size_t n) { return (n + 15) & ~(size_t)15; };
+        const size_t o_big = 0, o_head = o_big + up16(n_cand * 4), o_nodes = o_head + n_cand * 32, o_comps = o_nodes + n_cand * FD_WAVE * 4,
+                     o_work = o_comps + n_cand * 2 * FD_WAVE * 8, o_np = o_work + up16(cap_m * 8), o_gq = o_np + cap_m * 16, o_gr = o_gq + cap_m * 2 * FD_WAVE * 4,
+                     o_edges = o_gr + cap_m * 2 * FD_WAVE * 4, sp_bytes = o_edges + (size_t)nf_d * 16 + 16;
+        HIPCHK(c, c->ws[WS_RS_SPLIT].ensure(sp_bytes));
+        uint8_t *sp = c->ws[WS_RS_SPLIT].as<uint8_t>();
+        A.sp_big = (uint32_t *)(sp + o_big); A.sp_head = (uint4 *)(sp + o_head); A.sp_nodes = (uint32_t *)(sp + o_nodes);
+        A.sp_comps = (unsigned long long *)(sp + o_comps); A.sp_work = (uint2 *)(sp + o_work); A.sp_edges = (uint4 *)(sp + o_edges);
+        A.sp_np = (uint4 *)(sp + o_np); A.sp_gq = (uint32_t *)(sp + o_gq); A.sp_gr = (uint32_t *)(sp + o_gr);
+        A.sp_big_n = (uint32_t *)(c->ws[WS_RS_CNT].as<unsigned long long>() + 6);      // zeroed with the counters above (flags at + 4, clocks from + 8)
+    }
     {
         StageTimer tm(c, "retrieve_slots", 0);
         fd_launch_rs_slots(A, (uint32_t)n_cand, st);

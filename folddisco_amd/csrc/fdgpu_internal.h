@@ -91,7 +91,7 @@ enum {
     WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO /* ranked records of a scoring call: fdgpu_query_batch copies them out on the side stream WHILE the
     retrieval runs — no retrieval stage may ensure() or write this buffer (checked there) */, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
-    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS, WS_QT_STREAM, WS_QT_STAB, WS_QT_PIECEP, WS_QT_WIN, WS_QT_HEAD,
+    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS, WS_QT_STREAM, WS_QT_STAB, WS_QT_PIECEP, WS_QT_WIN, WS_QT_HEAD, WS_RS_SPLIT,
     WS_CA_PERM, WS_OK_PERM, WS_AA_PERM, WS_SEG_TAB,
     WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT, WS_RS_GQ, WS_MP_ACT, WS_MP_Q,
     WS_COUNT
@@ -519,6 +519,16 @@ struct rs_args {
     uint32_t *gq, *gr;                                   // per residue pair of a superposition problem (= two points, [CA, CB]): query / target residue, absolute in qb / db —
                                                          // k_rs_points gathers the coordinates into kx / ky afterwards, with every pair its own thread (a slot is one serial wavefront)
     uint64_t cap_matches, cap_res, cap_prob, cap_pts;
+    // the split form (k_rs_setup + k_rs_comp; null sp_work: k_rs_slots alone): what a slot's set-up leaves for its components
+    uint4 *sp_edges;                                     // [found triples] per edge, at its slot's segment: nodes | symmetric | in the map, query residues, idf
+    uint32_t *sp_nodes;                                  // [slots][64] residue of node v
+    unsigned long long *sp_comps;                        // [slots][128] the components' node sets, in the reference's order
+    uint4 *sp_head;                                      // [slots][2] {triples, components, nodes, -}, {first record lo / hi, first residue int lo / hi}
+    uint2 *sp_work;                                      // [cap_matches] (slot, component) of record k
+    uint4 *sp_np;                                        // [cap_matches] {problems, points, assigned pairs, rescued-list pairs} of record k
+    uint32_t *sp_gq, *sp_gr;                             // [cap_matches][128] its residue pairs (query / target residue), first problem then second
+    uint32_t *sp_big, *sp_big_n;                         // [slots] the slots left to k_rs_slots, their number (zero on entry)
+    const uint32_t *n_listed;                            // k_rs_slots: slots in order[] (null: the grid)
 };
 void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec *cands, uint64_t nc, uint32_t n_cand, uint32_t *cnt, uint32_t *seg, uint32_t *cur,
                         uint32_t *perm_f, uint32_t *perm_c, hipStream_t st);

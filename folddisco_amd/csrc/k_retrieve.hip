@@ -147,6 +147,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     // load's latency is paid in full): the query's residue indices and the slot's candidate pairs (query residue, i, j), loaded once, in parallel
     __shared__ uint32_t s_idx[FD_WAVE];
     __shared__ uint32_t s_cq[RS_CAND_LDS], s_ci[RS_CAND_LDS], s_cj[RS_CAND_LDS];
+    if (A.n_listed && blockIdx.x >= *A.n_listed) return;      // launched over the slots k_rs_setup left to this kernel: order[0 .. *n_listed)
     const uint32_t slot = A.order ? A.order[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
     const uint32_t f0 = A.seg_f[slot], F = A.seg_f[slot + 1] - f0;
     if (F == 0) return;
@@ -458,6 +459,438 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     if (lane == 0 && A.slot_matches) A.slot_matches[slot] = n_emit;
 }
 
+// exclusive scan of one 64-bit value per thread over a workgroup of 1,024 (wave scans by shuffle, the sixteen wave totals through LDS; two barriers)
+__device__ __forceinline__ unsigned long long rs_block_excl64(unsigned long long v, uint32_t tid, unsigned long long *s_w, unsigned long long *total) {
+    const uint32_t lane = tid & 63u, wv = tid >> 6;
+    unsigned long long incl = v;
+    for (int off = 1; off < FD_WAVE; off <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, off, FD_WAVE), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, FD_WAVE);
+        if ((int)lane >= off) incl += ((unsigned long long)hi << 32) | lo;
+    }
+    __syncthreads();      // s_w may still be read by the scan before this one
+    if (lane == 63u) s_w[wv] = incl;
+    __syncthreads();
+    unsigned long long pre = 0, tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) { const unsigned long long x = s_w[k]; pre += k < wv ? x : 0ull; tot += x; }
+    *total = tot;
+    return pre + incl - v;
+}
+// ------------------------------------------------------------------ the same glue, a wavefront per COMPONENT
+// k_rs_slots runs a slot's components one after the other on one wavefront: a launch lasts as long as its heaviest slot (12 components x ~17 us
+// at 128 queries per batch), and its 48 KB of LDS — sized for 1,024 found triples — keep three slots per CU resident.  The two kernels below split
+// the slot at the component loop:
+//   * k_rs_setup (a wavefront per slot, LDS for 128 found triples: all slots of a batch resident at once): edges in scan order, query-map
+//     entries, graph, strongly / weakly connected components in the reference's order — everything up to the loop — and the slot's claim of
+//     records; what the components need goes to global memory (an edge's node pair, symmetry flag and query-map fields in 16 bytes; the
+//     nodes' residues; the components' node sets), one work item per component lands at the place of its record.  A slot with more found
+//     triples is listed for k_rs_slots (launched behind, over that list only);
+//   * k_rs_comp (a wavefront per component): votes, greedy assignment, rescue, outputs — the loop body of k_rs_slots, statement for statement,
+//     with one change that cannot alter a result: the slot's candidate pairs whose partner residue the assignment mapped are filtered ONCE per
+//     component (the test does not depend on the query residue) instead of being read again, through two dependent global loads per 64 pairs,
+//     for every unmatched query residue — the chain that made the slots with ~1,000 candidate pairs the launch's tail.
+#define RS_S_EDGE 128u        // found triples of a slot the split form takes
+#define RS_S_LIST 512u        // votes (two per edge at most) and rescue tallies of one component
+#define RS_S_FILT 512u        // candidate pairs with an assigned partner, per component (more: the unfiltered walk of k_rs_slots)
+#define RS_WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")      /* one wavefront per workgroup: LDS traffic is in order, nothing to wait for in global memory */
+
+__global__ __launch_bounds__(FD_WAVE) void k_rs_setup(rs_args A) {
+    __shared__ uint32_t s_a[2 * RS_S_EDGE];    // raw i | raw j           -> the query's sorted hashes
+    __shared__ uint32_t s_b[2 * RS_S_EDGE];    // raw hash | raw position
+    __shared__ uint32_t s_i[RS_S_EDGE], s_j[RS_S_EDGE], s_h[RS_S_EDGE];   // edges in (i, j, emission) order
+    __shared__ int32_t s_k[RS_S_EDGE];         // query-map entry of the edge's hash
+    __shared__ uint8_t s_es[RS_S_EDGE], s_et[RS_S_EDGE], s_sym[RS_S_EDGE];
+    __shared__ uint64_t s_cm[2 * FD_WAVE], s_cs[2 * FD_WAVE];
+    const uint32_t slot = A.order ? A.order[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
+    const uint32_t f0 = A.seg_f[slot], F = A.seg_f[slot + 1] - f0;
+    if (F == 0) return;
+    if (F > RS_S_EDGE) {       // k_rs_slots takes it
+        if (lane == 0) { const uint32_t p = atomicAdd(A.sp_big_n, 1u); A.sp_big[p] = slot; }
+        return;
+    }
+    const rs_query_dev Q = A.qt[A.slot_q[slot]];
+    const uint32_t NQ = Q.n_idx;
+    if (NQ > FD_WAVE) RS_OVERFLOW();
+    // ---- edges in the reference's scan order: (i, j) row-major, several bin pairs of one (i, j) in emission order
+    for (uint32_t x = lane; x < F; x += FD_WAVE) {
+        const uint32_t o = A.perm_f[f0 + x];
+        const fd_pair_rec p = A.found[o];
+        s_a[x] = p.i; s_a[RS_S_EDGE + x] = p.j; s_b[x] = p.hash; s_b[RS_S_EDGE + x] = o;
+    }
+    RS_WSYNC();
+    for (uint32_t x = lane; x < F; x += FD_WAVE) {
+        const uint32_t i = s_a[x], j = s_a[RS_S_EDGE + x], o = s_b[RS_S_EDGE + x];
+        uint32_t rank = 0;
+        for (uint32_t y = 0; y < F; ++y) {
+            const uint32_t yi = s_a[y], yj = s_a[RS_S_EDGE + y], yo = s_b[RS_S_EDGE + y];
+            rank += (yi < i || (yi == i && (yj < j || (yj == j && yo < o)))) ? 1u : 0u;
+        }
+        s_i[rank] = i; s_j[rank] = j; s_h[rank] = s_b[x];
+    }
+    RS_WSYNC();
+    // query-map entry (first one holding the hash, like the reference's hash map) and symmetry flag of every edge
+    const bool hs_lds = Q.n_hashes <= 2 * RS_S_EDGE;
+    if (hs_lds) { for (uint32_t x = lane; x < Q.n_hashes; x += FD_WAVE) s_a[x] = A.hashes[Q.qh_off + x]; RS_WSYNC(); }
+    for (uint32_t x = lane; x < F; x += FD_WAVE) {
+        const uint32_t h = s_h[x];
+        const uint32_t *hs = A.hashes + Q.qh_off;
+        uint32_t lo = 0, hi = Q.n_hashes;
+        if (hs_lds) { while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_a[mid] < h) lo = mid + 1; else hi = mid; } }
+        else { while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (hs[mid] < h) lo = mid + 1; else hi = mid; } }
+        const bool ok = lo < Q.n_hashes && (hs_lds ? s_a[lo] : hs[lo]) == h;
+        s_k[x] = ok ? (int32_t)A.kfirst[Q.qh_off + lo] : -1;
+        s_sym[x] = ok ? A.sym[Q.qh_off + lo] : (uint8_t)0;
+    }
+    // ---- nodes in first-appearance order, adjacency rows
+    uint32_t node_res = 0xffffffffu, n_nodes = 0;
+    uint64_t adj = 0;
+    for (uint32_t e = 0; e < F; ++e) {
+        uint32_t ids[2];
+        for (int z = 0; z < 2; ++z) {
+            const uint32_t r = z ? s_j[e] : s_i[e];
+            const uint64_t m = __ballot(lane < n_nodes && node_res == r);
+            if (m == 0ull) {
+                if (n_nodes == A.node_cap) RS_OVERFLOW();
+                if (lane == n_nodes) node_res = r;
+                ids[z] = n_nodes++;
+            } else ids[z] = (uint32_t)__builtin_ctzll(m);
+        }
+        if (lane == ids[0]) adj |= 1ull << ids[1];
+        if (lane == 0) { s_es[e] = (uint8_t)ids[0]; s_et[e] = (uint8_t)ids[1]; }
+    }
+    RS_WSYNC();
+    // ---- strongly and weakly connected components (graph.rs:29-50)
+    const uint64_t self = lane < n_nodes ? 1ull << lane : 0ull;
+    uint64_t reach = adj | self, adjT = 0, reachT = 0;
+    for (uint32_t k = 0; k < n_nodes; ++k) { const uint64_t rk = rs_bcast64(reach, k); if ((reach >> k) & 1ull) reach |= rk; }
+    for (uint32_t u = 0; u < n_nodes; ++u) {
+        const uint64_t au = rs_bcast64(adj, u), ru = rs_bcast64(reach, u);
+        if ((au >> lane) & 1ull) adjT |= 1ull << u;
+        if ((ru >> lane) & 1ull) reachT |= 1ull << u;
+    }
+    uint64_t wcc = lane < n_nodes ? (adj | adjT | self) : 0ull;
+    for (uint32_t k = 0; k < n_nodes; ++k) { const uint64_t uk = rs_bcast64(wcc, k); if ((wcc >> k) & 1ull) wcc |= uk; }
+    const uint64_t scc = reach & reachT;
+    const bool scc_rep = lane < n_nodes && (uint32_t)__builtin_ctzll(scc) == lane && (uint32_t)__popcll(scc) >= A.node_count;
+    const bool wcc_rep = lane < n_nodes && (uint32_t)__builtin_ctzll(wcc) == lane && (uint32_t)__popcll(wcc) >= A.node_count && wcc != scc;
+    const uint64_t ms = __ballot(scc_rep), mw = __ballot(wcc_rep);
+    const uint32_t n_scc = (uint32_t)__popcll(ms), n_comp = n_scc + (uint32_t)__popcll(mw);
+    if (n_comp == 0) return;
+    if (scc_rep) s_cm[fd_mbcnt(ms)] = scc;
+    if (wcc_rep) s_cm[n_scc + fd_mbcnt(mw)] = wcc;
+    RS_WSYNC();
+    for (uint32_t x = lane; x < n_comp; x += FD_WAVE) {
+        const uint64_t a = s_cm[x];
+        uint32_t rank = 0;
+        for (uint32_t y = 0; y < n_comp; ++y) { const uint64_t b = s_cm[y]; if (b != a && rs_less(b, a)) ++rank; }
+        s_cs[rank] = a;
+    }
+    RS_WSYNC();
+    // ---- what the components need: per edge {source node | target node << 8 | symmetric << 16 | in the query map << 24, the entry's two query
+    // residues, its idf}, the nodes' residues, the components in order.  No claim of records here: k_rs_bases scans the slots' component counts
+    // (a returning atomic on ONE address completes every ~20 ns whoever issues it: the 13,000 claims of a 128-query batch — records and
+    // residue ints per slot, problems | points per component — WERE the 226 us of k_rs_slots)
+    for (uint32_t x = lane; x < F; x += FD_WAVE) {
+        const int32_t k = s_k[x];
+        uint4 ed = make_uint4((uint32_t)s_es[x] | ((uint32_t)s_et[x] << 8) | ((uint32_t)s_sym[x] << 16) | (k >= 0 ? 1u << 24 : 0u), 0u, 0u, 0u);
+        if (k >= 0) { ed.y = A.map_qi[Q.map_off + (uint32_t)k]; ed.z = A.map_qj[Q.map_off + (uint32_t)k]; ed.w = __float_as_uint(A.map_idf[Q.map_off + (uint32_t)k]); }
+        A.sp_edges[f0 + x] = ed;
+    }
+    A.sp_nodes[(uint64_t)slot * FD_WAVE + lane] = node_res;
+    for (uint32_t x = lane; x < n_comp; x += FD_WAVE) A.sp_comps[(uint64_t)slot * (2 * FD_WAVE) + x] = s_cs[x];
+    if (lane == 0) {
+        A.sp_head[2ull * slot] = make_uint4(F, n_comp, n_nodes, NQ);
+        A.slot_matches[slot] = n_comp;
+    }
+}
+// first record and first residue int of every slot: exclusive scans of the slots' component counts (x 2 NQ for the residue ints) in slot order,
+// one work item (slot, component) per record, the totals where k_rs_slots' claims continue (one workgroup)
+__global__ __launch_bounds__(1024) void k_rs_bases(rs_args A, uint32_t n_cand) {
+    __shared__ unsigned long long s_w[16];
+    const uint32_t tid = threadIdx.x;
+    unsigned long long run_m = 0, run_r = 0;
+    for (uint32_t s0 = 0; s0 < n_cand; s0 += 1024u) {
+        const uint32_t slot = s0 + tid;
+        uint32_t nc = 0, NQ = 0;
+        if (slot < n_cand) { nc = A.slot_matches[slot]; if (nc) NQ = A.sp_head[2ull * slot].w; }
+        unsigned long long tot_m, tot_r;
+        const unsigned long long mi0 = run_m + rs_block_excl64((unsigned long long)nc, tid, s_w, &tot_m);
+        const unsigned long long rp0 = run_r + rs_block_excl64(2ull * NQ * nc, tid, s_w, &tot_r);
+        if (nc) {
+            A.sp_head[2ull * slot + 1] = make_uint4((uint32_t)mi0, (uint32_t)(mi0 >> 32), (uint32_t)rp0, (uint32_t)(rp0 >> 32));
+            for (uint32_t x = 0; x < nc; ++x)
+                if (mi0 + x < A.cap_matches) A.sp_work[mi0 + x] = make_uint2(slot, x);
+        }
+        run_m += tot_m; run_r += tot_r;
+    }
+    if (tid == 0) {
+        A.counters[0] = run_m; A.counters[2 * RS_CNT_STRIDE] = run_r;
+        if (run_m > A.cap_matches || run_r > A.cap_res) atomicOr(A.flags, 2u);
+    }
+}
+// problems and points of the records k_rs_comp wrote: exclusive scans of (problems, points) over the records, then every record's places — its
+// problems' first points and d0, its residue pairs side by side in gq / gr (k_rs_points gathers the coordinates) — and the totals (one workgroup)
+__global__ __launch_bounds__(1024) void k_rs_pack(rs_args A) {
+    __shared__ unsigned long long s_w[16];
+    const uint32_t tid = threadIdx.x;
+    const unsigned long long n_all = A.counters[0];
+    const uint64_t n_rec = n_all < A.cap_matches ? n_all : A.cap_matches;
+    unsigned long long run = 0;       // problems << 40 | points
+    for (uint64_t k0 = 0; k0 < n_rec; k0 += 1024u) {
+        const uint64_t k = k0 + tid;
+        uint4 np = make_uint4(0u, 0u, 0u, 0u);      // {problems, points, assigned, rescued list}
+        if (k < n_rec) np = A.sp_np[k];
+        if (np.x > 2u || np.y > 4u * FD_WAVE) np = make_uint4(0u, 0u, 0u, 0u);      // (a component that bailed out — the call's overflow flag is up — left its entry unwritten)
+        unsigned long long tot;
+        const unsigned long long pk = run + rs_block_excl64(((unsigned long long)np.x << 40) | np.y, tid, s_w, &tot);
+        run += tot;
+        if (k < n_rec && np.x) {
+            const uint64_t p0 = pk >> 40, pt0 = pk & ((1ull << 40) - 1ull);
+            if (p0 + np.x > A.cap_prob || pt0 + np.y > A.cap_pts) { atomicOr(A.flags, 2u); continue; }
+            A.matches[k].prob0 = (uint32_t)p0; A.matches[k].prob1 = np.x == 2u ? (uint32_t)(p0 + 1) : 0xffffffffu;
+            A.koff[p0] = pt0; A.d0[p0] = A.d0tab[2u * np.z];
+            if (np.x == 2u) { A.koff[p0 + 1] = pt0 + 2ull * np.z; A.d0[p0 + 1] = A.d0tab[2u * np.w]; }
+            A.sp_np[k].w = (uint32_t)(pt0 >> 1);        // first residue pair of the record in gq / gr (k_rs_pairs)
+        } else if (k < n_rec) A.sp_np[k].y = 0u;
+    }
+    if (tid == 0) A.counters[RS_CNT_STRIDE] = run;
+}
+// a record's residue pairs from its own place to the problems' (a wavefront per record)
+__global__ __launch_bounds__(FD_WAVE) void k_rs_pairs(rs_args A) {
+    const unsigned long long n_all = A.counters[0];
+    const uint64_t n_rec = n_all < A.cap_matches ? n_all : A.cap_matches;
+    for (uint64_t k = blockIdx.x; k < n_rec; k += gridDim.x) {
+        const uint4 np = A.sp_np[k];
+        const uint32_t n_pairs = np.y >> 1;
+        for (uint32_t x = threadIdx.x; x < n_pairs && x < 2 * FD_WAVE; x += FD_WAVE) {
+            A.gq[(uint64_t)np.w + x] = A.sp_gq[k * (2 * FD_WAVE) + x];
+            A.gr[(uint64_t)np.w + x] = A.sp_gr[k * (2 * FD_WAVE) + x];
+        }
+    }
+}
+
+__global__ __launch_bounds__(FD_WAVE) void k_rs_comp(rs_args A) {
+    __shared__ uint32_t s_a[RS_S_LIST];        // votes: query residue   -> rescue: partner-residue list
+    __shared__ uint32_t s_b[RS_S_LIST];        // votes: target residue  -> rescue: multiplicities
+    __shared__ uint8_t s_vc[RS_S_LIST];
+    __shared__ uint32_t s_i[RS_S_EDGE], s_j[RS_S_EDGE], s_h[RS_S_EDGE];   // an edge's query-map fields: second query residue, idf, first query residue
+    __shared__ uint8_t s_es[RS_S_EDGE], s_et[RS_S_EDGE], s_sym[RS_S_EDGE], s_kv[RS_S_EDGE];
+    __shared__ uint32_t s_aq[FD_WAVE], s_ar[FD_WAVE], s_qs[FD_WAVE], s_rs[FD_WAVE], s_rmx[FD_WAVE], s_rnm[FD_WAVE], s_rarg[FD_WAVE];
+    __shared__ int32_t s_fh[FD_WAVE], s_pr[FD_WAVE];
+    __shared__ uint32_t s_misc[2];
+    __shared__ uint32_t s_idx[FD_WAVE];
+    __shared__ uint32_t s_fq[RS_S_FILT], s_fi[RS_S_FILT];     // candidate pairs (query residue, i) whose partner j the assignment mapped
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long n_all = A.counters[0];
+    const uint64_t n_work = n_all < A.cap_matches ? n_all : A.cap_matches;
+    for (uint64_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const uint2 wk = A.sp_work[wi];
+        const uint32_t slot = wk.x, ci = wk.y;
+        const uint4 h0 = A.sp_head[2ull * slot], h1 = A.sp_head[2ull * slot + 1];
+        const uint32_t F = h0.x, n_nodes = h0.z;
+        const unsigned long long mi0 = (unsigned long long)h1.x | ((unsigned long long)h1.y << 32), rp0 = (unsigned long long)h1.z | ((unsigned long long)h1.w << 32);
+        const uint32_t f0 = A.seg_f[slot];
+        const rs_query_dev Q = A.qt[A.slot_q[slot]];
+        const uint32_t NQ = Q.n_idx;
+        const uint32_t st = A.cand[slot];
+        const uint32_t r0 = A.db_res_off[st], Rt = A.db_res_off[st + 1] - r0;
+        const uint32_t c0 = A.seg_c[slot], c1 = A.seg_c[slot + 1];
+        const uint64_t C = A.sp_comps[(uint64_t)slot * (2 * FD_WAVE) + ci];
+        const uint32_t csize = (uint32_t)__popcll(C);
+        const uint32_t node_res = lane < n_nodes ? A.sp_nodes[(uint64_t)slot * FD_WAVE + lane] : 0xffffffffu;
+        for (uint32_t x = lane; x < F; x += FD_WAVE) {
+            const uint4 ed = A.sp_edges[f0 + x];
+            s_es[x] = (uint8_t)ed.x; s_et[x] = (uint8_t)(ed.x >> 8); s_sym[x] = (uint8_t)(ed.x >> 16); s_kv[x] = (uint8_t)(ed.x >> 24);
+            s_h[x] = ed.y; s_i[x] = ed.z; s_j[x] = ed.w;
+        }
+        if (lane < NQ) s_idx[lane] = A.indices[Q.idx_off + lane];
+        RS_WSYNC();
+        // ---- votes (query residue, target residue) -> saturating u8 count (retrieve.rs:631-666), subgraph idf (:705-719)
+        uint32_t nv = 0;
+        float sub_idf = 0.0f;
+        for (uint32_t e = 0; e < F; ++e) {
+            const uint32_t a = s_es[e], b = s_et[e];
+            if (!((C >> a) & 1ull) || !((C >> b) & 1ull) || !s_kv[e]) continue;
+            sub_idf += __uint_as_float(s_j[e]);
+            const uint32_t qi = s_h[e], qj = s_i[e];
+            const uint32_t ri = (uint32_t)__shfl((int)node_res, (int)a, FD_WAVE), rj = (uint32_t)__shfl((int)node_res, (int)b, FD_WAVE);
+            uint32_t pq[2], pr[2];
+            if (s_sym[e]) { pq[0] = min(qi, qj); pq[1] = max(qi, qj); pr[0] = min(ri, rj); pr[1] = max(ri, rj); }
+            else { pq[0] = qi; pr[0] = ri; pq[1] = qj; pr[1] = rj; }
+            for (int z = 0; z < 2; ++z) {
+                int32_t at = -1;
+                for (uint32_t base = 0; base < nv && at < 0; base += FD_WAVE) {
+                    const uint32_t x = base + lane;
+                    const uint64_t m = __ballot(x < nv && s_a[x] == pq[z] && s_b[x] == pr[z]);
+                    if (m) at = (int32_t)(base + (uint32_t)__builtin_ctzll(m));
+                }
+                if (at < 0) {
+                    if (nv == RS_S_LIST) RS_OVERFLOW();
+                    if (lane == 0) { s_a[nv] = pq[z]; s_b[nv] = pr[z]; s_vc[nv] = 1; }
+                    ++nv;
+                } else if (lane == 0 && s_vc[at] < 255) ++s_vc[at];
+                RS_WSYNC();
+            }
+        }
+        // ---- per query residue: highest count, smallest target residue holding it
+        uint32_t bq = 0, bc = 0, br = 0, nb = 0;
+        for (uint32_t v = 0; v < nv; ++v) {
+            const uint32_t q = s_a[v], r = s_b[v], c = s_vc[v];
+            const uint64_t m = __ballot(lane < nb && bq == q);
+            if (m == 0ull) {
+                if (nb == FD_WAVE) RS_OVERFLOW();
+                if (lane == nb) { bq = q; bc = c; br = r; }
+                ++nb;
+            } else if (lane == (uint32_t)__builtin_ctzll(m) && (c > bc || (c == bc && r < br))) { bc = c; br = r; }
+        }
+        // ---- greedy assignment in (count descending, query residue ascending) order (retrieve.rs:668-690)
+        uint32_t my_aq = 0xffffffffu, my_ar = 0xffffffffu, n_asg = 0;
+        bool rem = lane < nb;
+        for (uint32_t it = 0; it < nb && n_asg < csize; ++it) {
+            const uint64_t key = rem ? (((uint64_t)bc << 32) | (0xffffffffu - bq)) : 0ull;
+            const uint64_t mx = rs_wave_max64(key);
+            const uint32_t w = (uint32_t)__builtin_ctzll(__ballot(rem && key == mx));
+            const uint32_t q = (uint32_t)__shfl((int)bq, (int)w, FD_WAVE), r = (uint32_t)__shfl((int)br, (int)w, FD_WAVE);
+            if (__ballot(lane < n_asg && my_ar == r) == 0ull) {
+                if (lane == n_asg) { my_aq = q; my_ar = r; }
+                ++n_asg;
+            }
+            if (lane == w) rem = false;
+        }
+        RS_WSYNC();           // the vote arrays are free from here on
+        if (lane < n_asg) { s_aq[lane] = my_aq; s_ar[lane] = my_ar; }
+        RS_WSYNC();
+        // ---- the slot's candidate pairs (query residue, i, j) whose partner j some assignment mapped, in their order: what can vote in the rescue
+        uint32_t n_f = 0;
+        for (uint32_t base = c0; base < c1; base += FD_WAVE) {
+            const uint32_t x = base + lane;
+            bool ok = false;
+            uint32_t c_q = 0, c_i = 0;
+            if (x < c1) {
+                const fd_cand_rec cr = A.cands[A.perm_c[x]];
+                c_q = cr.qi; c_i = cr.i;
+                if (cr.i < Rt && cr.j < Rt)
+                    for (uint32_t k = 0; k < n_asg; ++k) ok |= s_ar[k] == cr.j;
+            }
+            const uint64_t m = __ballot(ok);
+            if (ok) { const uint32_t p = n_f + fd_mbcnt(m); if (p < RS_S_FILT) { s_fq[p] = c_q; s_fi[p] = c_i; } }
+            n_f += (uint32_t)__popcll(m);
+        }
+        const bool filt = n_f <= RS_S_FILT;
+        RS_WSYNC();
+        // ---- rescue votes (retrieve.rs:498-511): for a query residue without a target, those pairs of it vote for i; the unique maximum (>= 2) joins
+        for (uint32_t pos = 0; pos < NQ; ++pos) {
+            const uint32_t qi = s_idx[pos];
+            uint32_t mx = 0, nmx = 0, arg = 0;
+            if (__ballot(lane < n_asg && my_aq == qi) == 0ull && c1 > c0 && qi < Q.q_size) {
+                uint32_t n_t = 0;
+                const uint32_t lo = filt ? 0u : c0, hi = filt ? n_f : c1;
+                for (uint32_t base = lo; base < hi; base += FD_WAVE) {
+                    const uint32_t x = base + lane;
+                    bool ok = false;
+                    uint32_t iv = 0;
+                    if (x < hi) {
+                        if (filt) { iv = s_fi[x]; ok = s_fq[x] == qi; }
+                        else {
+                            const fd_cand_rec cr = A.cands[A.perm_c[x]];
+                            iv = cr.i;
+                            if (cr.qi == qi && cr.i < Rt && cr.j < Rt)
+                                for (uint32_t k = 0; k < n_asg; ++k) ok |= s_ar[k] == cr.j;
+                        }
+                    }
+                    const uint64_t m = __ballot(ok);
+                    if (ok) { const uint32_t p = n_t + fd_mbcnt(m); if (p < RS_S_LIST) s_a[p] = iv; }
+                    n_t += (uint32_t)__popcll(m);
+                }
+                if (n_t > RS_S_LIST) RS_OVERFLOW();
+                RS_WSYNC();
+                uint32_t lmx = 0;
+                for (uint32_t base = 0; base < n_t; base += FD_WAVE) {
+                    const uint32_t x = base + lane;
+                    if (x < n_t) {
+                        const uint32_t v = s_a[x];
+                        uint32_t cnt = 0;
+                        for (uint32_t y = 0; y < n_t; ++y) cnt += s_a[y] == v ? 1u : 0u;
+                        s_b[x] = cnt;
+                        lmx = max(lmx, cnt);
+                    }
+                }
+                mx = rs_wave_max32(lmx);
+                RS_WSYNC();
+                uint32_t n_eq = 0;
+                for (uint32_t base = 0; base < n_t; base += FD_WAVE) {
+                    const uint32_t x = base + lane;
+                    const uint64_t m = __ballot(x < n_t && s_b[x] == mx);
+                    if (m) { n_eq += (uint32_t)__popcll(m); arg = s_a[base + (uint32_t)__builtin_ctzll(m)]; }
+                }
+                nmx = mx ? n_eq / mx : 0u;
+                RS_WSYNC();
+            }
+            if (lane == 0) { s_rmx[pos] = mx; s_rnm[pos] = nmx; s_rarg[pos] = arg; }
+        }
+        RS_WSYNC();
+        // ---- residue assignment + rescue, sequential as in the reference (retrieve.rs:430-516)
+        if (lane < NQ) { s_fh[lane] = -1; s_pr[lane] = -1; }
+        RS_WSYNC();
+        if (lane == 0) {
+            uint32_t n_sc = 0;
+            for (uint32_t pos = 0; pos < NQ; ++pos) {
+                const uint32_t qi = s_idx[pos];
+                int32_t mapped = -1;
+                for (uint32_t k = 0; k < n_asg; ++k) if (s_aq[k] == qi) { mapped = (int32_t)s_ar[k]; break; }
+                if (mapped >= 0) {
+                    s_fh[pos] = mapped;
+                    uint32_t pp = n_sc;
+                    for (uint32_t k = 0; k < n_sc; ++k) if (s_rs[k] == (uint32_t)mapped) { pp = k; break; }
+                    if (pp == n_sc) { s_pr[pos] = mapped; s_qs[n_sc] = qi; s_rs[n_sc] = (uint32_t)mapped; ++n_sc; }
+                    else {
+                        if (pp < NQ) s_pr[pp] = -1;          // the reference indexes its residue vector with the scanned position
+                        s_pr[pos] = mapped;
+                        for (uint32_t k = pp; k + 1 < n_sc; ++k) { s_qs[k] = s_qs[k + 1]; s_rs[k] = s_rs[k + 1]; }
+                        s_qs[n_sc - 1] = qi; s_rs[n_sc - 1] = (uint32_t)mapped;
+                    }
+                } else if (qi < Q.q_size && s_rnm[pos] == 1 && s_rmx[pos] >= 2) {
+                    bool taken = false;
+                    for (uint32_t k = 0; k < n_sc; ++k) taken |= s_rs[k] == s_rarg[pos];
+                    if (!taken && n_sc < FD_WAVE) { s_pr[pos] = (int32_t)s_rarg[pos]; s_qs[n_sc] = qi; s_rs[n_sc] = s_rarg[pos]; ++n_sc; }
+                }
+            }
+            bool same = true;
+            for (uint32_t pos = 0; pos < NQ; ++pos) same &= s_fh[pos] == s_pr[pos];
+            s_misc[0] = n_sc; s_misc[1] = same ? 1u : 0u;
+        }
+        RS_WSYNC();
+        const uint32_t n_sc = s_misc[0];
+        const bool same = s_misc[1] != 0;
+        // ---- outputs: one record, 2 NQ residues, one or two superposition problems of [CA, CB] points (retrieve.rs:761-767)
+        const uint32_t nprob = same ? 1u : 2u, npts = 2u * n_asg + (same ? 0u : 2u * n_sc);
+        // (the problems' places follow from a scan over the records: k_rs_pack; here the record, its residues, and its residue pairs at the record's own place)
+        const unsigned long long mi = mi0 + ci, rp = rp0 + 2ull * NQ * ci;
+        if (rp + 2ull * NQ > A.cap_res) {
+            if (lane == 0) { atomicOr(A.flags, 2u); A.sp_np[mi] = make_uint4(0u, 0u, 0u, 0u); }
+            RS_WSYNC();
+            continue;
+        }
+        if (lane == 0) {
+            rs_match_dev m;
+            m.slot = slot; m.ci = ci; m.same = same ? 1u : 0u; m.res_pos = (uint32_t)rp; m.prob0 = 0u; m.prob1 = 0xffffffffu;
+            m.idf = sub_idf; m.ord = ci;
+            A.matches[mi] = m;
+            A.sp_np[mi] = make_uint4(nprob, npts, n_asg, n_sc);
+        }
+        if (lane < NQ) { A.residues[rp + lane] = s_fh[lane]; A.residues[rp + NQ + lane] = s_pr[lane]; }
+        for (uint32_t w = 0; w < nprob; ++w) {
+            const uint32_t n = w ? n_sc : n_asg, base = w ? n_asg : 0u;
+            if (lane < n) {
+                const uint32_t q = w ? s_qs[lane] : s_aq[lane], r = w ? s_rs[lane] : s_ar[lane];
+                A.sp_gq[mi * (2 * FD_WAVE) + base + lane] = Q.q_res0 + q;
+                A.sp_gr[mi * (2 * FD_WAVE) + base + lane] = r0 + r;
+            }
+        }
+        RS_WSYNC();
+    }
+}
+
 void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec *cands, uint64_t nc, uint32_t n_cand, uint32_t *cnt, uint32_t *seg, uint32_t *cur,
                         uint32_t *perm_f, uint32_t *perm_c, hipStream_t st) {
     const uint64_t n = nf + nc;
@@ -488,7 +921,18 @@ void fd_launch_rs_points(const rs_args &A, uint64_t n_points, hipStream_t st) {
 }
 
 void fd_launch_rs_slots(const rs_args &A, uint32_t n_cand, hipStream_t st) {
-    if (n_cand) hipLaunchKernelGGL(k_rs_slots, dim3(n_cand), dim3(FD_WAVE), 0, st, A);
+    if (!n_cand) return;
+    if (!A.sp_work) { hipLaunchKernelGGL(k_rs_slots, dim3(n_cand), dim3(FD_WAVE), 0, st, A); return; }
+    // split form: set-up per slot, a wavefront per component, then k_rs_slots over the slots with more found triples than the split form takes
+    hipLaunchKernelGGL(k_rs_setup, dim3(n_cand), dim3(FD_WAVE), 0, st, A);
+    hipLaunchKernelGGL(k_rs_bases, dim3(1), dim3(1024), 0, st, A, n_cand);
+    const uint64_t grid = A.cap_matches < 16384 ? A.cap_matches : 16384;
+    hipLaunchKernelGGL(k_rs_comp, dim3((unsigned)grid), dim3(FD_WAVE), 0, st, A);
+    hipLaunchKernelGGL(k_rs_pack, dim3(1), dim3(1024), 0, st, A);
+    hipLaunchKernelGGL(k_rs_pairs, dim3((unsigned)grid), dim3(FD_WAVE), 0, st, A);
+    rs_args B = A;
+    B.order = A.sp_big; B.n_listed = A.sp_big_n;
+    hipLaunchKernelGGL(k_rs_slots, dim3(n_cand), dim3(FD_WAVE), 0, st, B);
 }
 
 // The caller's match records (fd_match_rec, 39 words) and residue lists in their final order, gathered on the device: one wavefront per
@@ -516,23 +960,6 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_records(const rs_match_dev *__re
     else if (lane < 39) v = __float_as_uint(met[5ull * pf + (lane - 34)]);
     if (lane < 39) out[39ull * k + lane] = v;
     for (uint32_t z = lane; z < pl.w; z += FD_WAVE) out_res[(uint64_t)pl.z + z] = residues[(uint64_t)r.res_pos + z];
-}
-// exclusive scan of one 64-bit value per thread over a workgroup of 1,024 (wave scans by shuffle, the sixteen wave totals through LDS; two barriers)
-__device__ __forceinline__ unsigned long long rs_block_excl64(unsigned long long v, uint32_t tid, unsigned long long *s_w, unsigned long long *total) {
-    const uint32_t lane = tid & 63u, wv = tid >> 6;
-    unsigned long long incl = v;
-    for (int off = 1; off < FD_WAVE; off <<= 1) {
-        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, off, FD_WAVE), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, FD_WAVE);
-        if ((int)lane >= off) incl += ((unsigned long long)hi << 32) | lo;
-    }
-    __syncthreads();      // s_w may still be read by the scan before this one
-    if (lane == 63u) s_w[wv] = incl;
-    __syncthreads();
-    unsigned long long pre = 0, tot = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) { const unsigned long long x = s_w[k]; pre += k < wv ? x : 0ull; tot += x; }
-    *total = tot;
-    return pre + incl - v;
 }
 // Final places of the records without the host: exclusive scan of the slots' record counts (base of every slot), the per-query offsets the
 // caller gets (match_off[t] = base of query t's first slot, res_off = running 2 * n_idx * records) and every slot's first output residue.

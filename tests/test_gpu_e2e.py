@@ -1152,7 +1152,8 @@ def test_device_retrieval_glue_equals_host_glue(env, monkeypatch):
             assert a.tobytes() == b.tobytes(), what
         # the records' order made on the device (slot bases from record counts) against the host's sort of the record headers,
         # and the slots launched heaviest first against slot order
-        for env_name, val in (("FDGPU_RS_HOST_ORDER", "1"), ("FDGPU_RS_ORDER", "0"), ("FDGPU_MP_ITEMS", "0")):      # (the last: work items built on the host)
+        # ... and the split glue (set-up per slot + a wavefront per component, the default) against k_rs_slots alone
+        for env_name, val in (("FDGPU_RS_HOST_ORDER", "1"), ("FDGPU_RS_ORDER", "0"), ("FDGPU_MP_ITEMS", "0"), ("FDGPU_RS_SPLIT", "0")):      # (MP_ITEMS: work items built on the host)
             monkeypatch.setenv(env_name, val)
             alt, _ = run(db, stdn, cl, qms_, qb, qs, ca)
             monkeypatch.delenv(env_name)
