@@ -501,7 +501,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         T.plan_log2 = QT_CELL_LOG2; T.slices = nullptr; T.n_slices = 0; T.partial = nullptr; T.g_bm = T.g_rank = T.g_tcount = T.g_nid = T.g_rowbits = nullptr;
         T.g_wpr = 0; T.g_eend = T.g_nend = nullptr;
         T.dbg = nullptr;
-        T.pieces = nullptr; T.piece_p = nullptr; T.win = nullptr; T.heads = nullptr; T.win_per_row = 0; T.top_n = top_n;
+        T.pieces = nullptr; T.piece_p = nullptr; T.win = nullptr; T.heads = nullptr; T.win_per_row = 0; T.top_n = top_n; T.max_rows = (uint32_t)max_rows;
         if (qt32) {
             T.pieces = c->ws[WS_QT_RANGES].as<uint4>(); T.piece_p = c->ws[WS_QT_PIECEP].as<uint32_t>(); T.win = c->ws[WS_QT_WIN].as<uint32_t>();
             T.heads = c->ws[WS_QT_HEAD].as<uint4>(); T.win_per_row = qt_wpr;
@@ -522,7 +522,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         T.ccount = c->ws[WS_QT_COUNT].as<uint32_t>();
         T.ghist = nullptr; T.state = nullptr; T.aux = c->ws[WS_QT_AUX].as<qt_aux>(); T.out = nullptr; T.cap = big_cap; T.dbg = nullptr;
         T.stream_ids = nullptr; T.stream_row = nullptr; T.stream_tab = nullptr; T.stream_used = nullptr; T.stream_cap = 0;
-        T.pieces = nullptr; T.piece_p = nullptr; T.win = nullptr; T.heads = nullptr; T.win_per_row = 0; T.top_n = top_n;
+        T.pieces = nullptr; T.piece_p = nullptr; T.win = nullptr; T.heads = nullptr; T.win_per_row = 0; T.top_n = top_n; T.max_rows = (uint32_t)max_rows;
         // slices of roughly equal posting counts: a row's list holds ~ S / 2^idf ids (idf = log2(S / length), its fixed-point image is in the metadata)
         std::vector<double> w(nq);
         double tot = 0;

@@ -358,6 +358,7 @@ struct qt_args {
     uint32_t *win;                         // per (query, tile) [rows x win_per_row + 2]: first piece that ends behind the window's first slot | QT_WIN_CONT
     uint4 *heads;                          // [n_queries][NT] {pieces, windows, first record of the decoded stream, flags (1: a table did not hold the tile)}
     uint32_t win_per_row, top_n;
+    uint32_t max_rows;                     // rows of the batch's largest query (0: unknown) — k_qt_rows picks its table sizes by it
     // one query of ~10^5 rows (k_qt_score<..., BIG>): row slices, per-slice sums, the survivors' bitmap / slots / row bits
     const uint64_t *slices; uint32_t n_slices;     // [n_slices + 1] row boundaries
     unsigned long long *partial;           // [n_slices][NT][tile] count << 46 | idf sum

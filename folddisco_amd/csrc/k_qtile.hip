@@ -537,12 +537,14 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
 // The survivors' records without a second decode: pass A left every 16-byte slot of the tile's posting ranges as sixteen 16-bit structure
 // ids + the slot's row (34 bytes per slot, A.stream_*).  A workgroup = (query, tile): survivors' bitmap and ranks as in k_qt_score<RICH>, then
 // one thread per slot tests its ids against the bitmap — no varint decode, no scan, no plan — and the records follow from the row bits.
-template <int TL2, int NTHR, int RBW, int RBA>
+// MR: rows per query the workgroup's tables hold (a batch of motif queries has ~44: the 1,024-row tables and row bits for 3,072 survivors per round were
+// 32 of the workgroup's 37 KB of LDS — four workgroups per CU for a kernel that is a chain of five dependent loads and seven barriers)
+template <int TL2, int NTHR, int RBW, int RBA, int MR = QT_MAX_ROWS>
 __global__ __launch_bounds__(NTHR) void k_qt_rows(qt_args A) {
     constexpr uint32_t TILE = 1u << TL2;
     __shared__ uint32_t s_bm[TILE / 32], s_rank[TILE / 32], s_rowbits[RBW];
-    __shared__ unsigned long long s_meta[QT_MAX_ROWS];
-    __shared__ uint32_t s_eend[QT_MAX_ROWS / 32], s_nend[QT_MAX_ROWS / 32];
+    __shared__ unsigned long long s_meta[MR];
+    __shared__ uint32_t s_eend[MR / 32], s_nend[MR / 32];
     __shared__ uint32_t s_w[NTHR / 64];
     __shared__ uint32_t s_base;
     const uint32_t wg = blockIdx.x;
@@ -551,14 +553,15 @@ __global__ __launch_bounds__(NTHR) void k_qt_rows(qt_args A) {
     const uint32_t nrows = (uint32_t)(A.q_rows[q + 1] - r0);
     const uint32_t tile_lo = t << TL2;
     const uint64_t cbase = ((uint64_t)q * A.NT + t) << TL2;
-    constexpr int SPEC = (TILE / NTHR) < 8 ? (TILE / NTHR) : 8;
+    // (keys requested before the list's length is known: the 32-bit pass A lists ~top_n keys per tile, the 64-bit one every touched structure)
+    constexpr int SPEC0 = MR <= 128 ? 3 : 8, SPEC = (TILE / NTHR) < SPEC0 ? (TILE / NTHR) : SPEC0;
     uint32_t x[SPEC];        // ranking keys; a survivor's structure comes from the other array
 #pragma unroll
     for (int u = 0; u < SPEC; ++u) x[u] = A.c_key[cbase + u * NTHR + tid];
     const uint32_t n = A.ccount[(uint64_t)q * A.NT + t];
     const uint32_t thr = A.state[q].thr_key;
     for (uint32_t k = tid; k < TILE / 32; k += NTHR) s_bm[k] = 0u;
-    for (uint32_t k = tid; k < QT_MAX_ROWS / 32; k += NTHR) { s_eend[k] = 0u; s_nend[k] = 0u; }
+    for (uint32_t k = tid; k < MR / 32; k += NTHR) { s_eend[k] = 0u; s_nend[k] = 0u; }
     __syncthreads();
     for (uint32_t k = tid; k < nrows; k += NTHR) {
         const unsigned long long m = A.row_meta[r0 + k];
@@ -926,6 +929,9 @@ void fd_launch_qt_select(const qt_args &A, uint32_t top_n, void *sorted, hipStre
     const dim3 g(A.NT * A.n_queries);
     hipLaunchKernelGGL(k_qt_thr, dim3(A.n_queries), dim3(1024), 0, st, A, top_n);
     if (A.stream_ids && A.tile_log2 == 15) hipLaunchKernelGGL((k_qt_rows<15, 512, 6144, 512>), g, dim3(512), 0, st, A);
+    else if (A.stream_ids && A.tile_log2 == 14 && A.max_rows && A.max_rows <= 128u) {
+        hipLaunchKernelGGL((k_qt_rows<14, 512, 1024, 512, 128>), g, dim3(512), 0, st, A);       // (256 / 128 threads per workgroup: 75 / 97 us against 75)
+    }
     else if (A.stream_ids && A.tile_log2 == 14) hipLaunchKernelGGL((k_qt_rows<14, 512, 6144, 512>), g, dim3(512), 0, st, A);
     else if (A.stream_ids) hipLaunchKernelGGL((k_qt_rows<13, 512, 6144, 256>), g, dim3(512), 0, st, A);
     else if (A.tile_log2 == 14) hipLaunchKernelGGL((k_qt_score<true, 14, 1024, 512, 6144>), g, dim3(1024), 0, st, A);

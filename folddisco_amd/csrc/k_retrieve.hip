@@ -48,6 +48,23 @@ __device__ __forceinline__ bool rs_less(uint64_t a, uint64_t b) {
 }
 }  // namespace
 
+// exclusive scan of one 64-bit value per thread over a workgroup of 1,024 (wave scans by shuffle, the sixteen wave totals through LDS; two barriers)
+__device__ __forceinline__ unsigned long long rs_block_excl64(unsigned long long v, uint32_t tid, unsigned long long *s_w, unsigned long long *total) {
+    const uint32_t lane = tid & 63u, wv = tid >> 6;
+    unsigned long long incl = v;
+    for (int off = 1; off < FD_WAVE; off <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, off, FD_WAVE), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, FD_WAVE);
+        if ((int)lane >= off) incl += ((unsigned long long)hi << 32) | lo;
+    }
+    __syncthreads();      // s_w may still be read by the scan before this one
+    if (lane == 63u) s_w[wv] = incl;
+    __syncthreads();
+    unsigned long long pre = 0, tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) { const unsigned long long x = s_w[k]; pre += k < wv ? x : 0ull; tot += x; }
+    *total = tot;
+    return pre + incl - v;
+}
 #define RS_SYNC() __syncthreads()
 #define RS_OVERFLOW() do { if (threadIdx.x == 0) atomicOr(A.flags, 1u); return; } while (0)
 
@@ -78,23 +95,22 @@ __global__ void k_rs_count(const fd_pair_rec *__restrict__ found, uint64_t nf, c
     (void)rs_agg_add(cnt, on, key);
 }
 
-// exclusive scans of the two count arrays (one block; n_cand is a few thousand at most) -> segment starts + scatter cursors
-__global__ __launch_bounds__(256) void k_rs_scan(const uint32_t *__restrict__ cnt, uint32_t n_cand, uint32_t *__restrict__ seg, uint32_t *__restrict__ cur) {
-    __shared__ uint32_t part[256];
-    for (uint32_t which = 0; which < 2; ++which) {
-        const uint32_t *c = cnt + which * (n_cand + 1);
-        uint32_t *sg = seg + which * (n_cand + 1), *cu = cur + which * (n_cand + 1);
-        const uint32_t per = (n_cand + 255u) / 256u, a = threadIdx.x * per, b = min(n_cand, a + per);
-        uint32_t s = 0;
-        for (uint32_t k = a; k < b; ++k) s += c[k];
-        part[threadIdx.x] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) { uint32_t run = 0; for (int k = 0; k < 256; ++k) { const uint32_t t = part[k]; part[k] = run; run += t; } sg[n_cand] = run; }
-        __syncthreads();
-        uint32_t run = part[threadIdx.x];
-        for (uint32_t k = a; k < b; ++k) { sg[k] = run; cu[k] = run; run += c[k]; }
-        __syncthreads();
+// exclusive scans of the two count arrays (one block; n_cand is a few thousand at most) -> segment starts + scatter cursors.  Both counts ride
+// in one 64-bit word (found triples in the upper half), a thread takes `per` neighbouring slots: ONE scan of the 1,024 threads' sums
+__global__ __launch_bounds__(1024) void k_rs_scan(const uint32_t *__restrict__ cnt, uint32_t n_cand, uint32_t *__restrict__ seg, uint32_t *__restrict__ cur) {
+    __shared__ unsigned long long s_w[16];
+    const uint32_t tid = threadIdx.x, per = (n_cand + 1023u) / 1024u, a = tid * per, b = min(n_cand, a + per);
+    const uint32_t *cf = cnt, *cc = cnt + (n_cand + 1);
+    unsigned long long mine = 0;
+    for (uint32_t k = a; k < b; ++k) mine += ((unsigned long long)cf[k] << 32) | cc[k];
+    unsigned long long tot;
+    unsigned long long run = rs_block_excl64(mine, tid, s_w, &tot);
+    for (uint32_t k = a; k < b; ++k) {
+        const uint32_t rf = (uint32_t)(run >> 32), rc = (uint32_t)run;
+        seg[k] = rf; cur[k] = rf; seg[n_cand + 1 + k] = rc; cur[n_cand + 1 + k] = rc;
+        run += ((unsigned long long)cf[k] << 32) | cc[k];
     }
+    if (tid == 0) { seg[n_cand] = (uint32_t)(tot >> 32); seg[2 * n_cand + 1] = (uint32_t)tot; }
 }
 
 __global__ void k_rs_scatter(const fd_pair_rec *__restrict__ found, uint64_t nf, const fd_cand_rec *__restrict__ cands, uint64_t nc, uint32_t n_cand,
@@ -459,23 +475,6 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_slots(rs_args A) {
     if (lane == 0 && A.slot_matches) A.slot_matches[slot] = n_emit;
 }
 
-// exclusive scan of one 64-bit value per thread over a workgroup of 1,024 (wave scans by shuffle, the sixteen wave totals through LDS; two barriers)
-__device__ __forceinline__ unsigned long long rs_block_excl64(unsigned long long v, uint32_t tid, unsigned long long *s_w, unsigned long long *total) {
-    const uint32_t lane = tid & 63u, wv = tid >> 6;
-    unsigned long long incl = v;
-    for (int off = 1; off < FD_WAVE; off <<= 1) {
-        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, off, FD_WAVE), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, FD_WAVE);
-        if ((int)lane >= off) incl += ((unsigned long long)hi << 32) | lo;
-    }
-    __syncthreads();      // s_w may still be read by the scan before this one
-    if (lane == 63u) s_w[wv] = incl;
-    __syncthreads();
-    unsigned long long pre = 0, tot = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) { const unsigned long long x = s_w[k]; pre += k < wv ? x : 0ull; tot += x; }
-    *total = tot;
-    return pre + incl - v;
-}
 // ------------------------------------------------------------------ the same glue, a wavefront per COMPONENT
 // k_rs_slots runs a slot's components one after the other on one wavefront: a launch lasts as long as its heaviest slot (12 components x ~17 us
 // at 128 queries per batch), and its 48 KB of LDS — sized for 1,024 found triples — keep three slots per CU resident.  The two kernels below split
@@ -609,19 +608,27 @@ __global__ __launch_bounds__(1024) void k_rs_bases(rs_args A, uint32_t n_cand) {
     __shared__ unsigned long long s_w[16];
     const uint32_t tid = threadIdx.x;
     unsigned long long run_m = 0, run_r = 0;
-    for (uint32_t s0 = 0; s0 < n_cand; s0 += 1024u) {
-        const uint32_t slot = s0 + tid;
-        uint32_t nc = 0, NQ = 0;
-        if (slot < n_cand) { nc = A.slot_matches[slot]; if (nc) NQ = A.sp_head[2ull * slot].w; }
-        unsigned long long tot_m, tot_r;
-        const unsigned long long mi0 = run_m + rs_block_excl64((unsigned long long)nc, tid, s_w, &tot_m);
-        const unsigned long long rp0 = run_r + rs_block_excl64(2ull * NQ * nc, tid, s_w, &tot_r);
-        if (nc) {
-            A.sp_head[2ull * slot + 1] = make_uint4((uint32_t)mi0, (uint32_t)(mi0 >> 32), (uint32_t)rp0, (uint32_t)(rp0 >> 32));
-            for (uint32_t x = 0; x < nc; ++x)
-                if (mi0 + x < A.cap_matches) A.sp_work[mi0 + x] = make_uint2(slot, x);
+    // passes of 8 x 1,024 slots (slot = pass + 1,024 u + thread: neighbouring threads read neighbouring slots), the pass's loads issued together — a scan
+    // per 1,024 slots that waits for its own loads pays a global round trip per scan
+    for (uint32_t s0 = 0; s0 < n_cand; s0 += 8192u) {
+        uint32_t nc[8], nq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const uint32_t slot = s0 + 1024u * (uint32_t)u + tid; nc[u] = slot < n_cand ? A.slot_matches[slot] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const uint32_t slot = s0 + 1024u * (uint32_t)u + tid; nq[u] = nc[u] ? A.sp_head[2ull * slot].w : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (s0 + 1024u * (uint32_t)u >= n_cand) break;
+            const uint32_t slot = s0 + 1024u * (uint32_t)u + tid;
+            unsigned long long tot_m, tot_r;
+            const unsigned long long mi0 = run_m + rs_block_excl64((unsigned long long)nc[u], tid, s_w, &tot_m);
+            const unsigned long long rp0 = run_r + rs_block_excl64(2ull * nq[u] * nc[u], tid, s_w, &tot_r);
+            if (nc[u]) {
+                A.sp_head[2ull * slot + 1] = make_uint4((uint32_t)mi0, (uint32_t)(mi0 >> 32), (uint32_t)rp0, (uint32_t)(rp0 >> 32));
+                for (uint32_t x = 0; x < nc[u]; ++x) if (mi0 + x < A.cap_matches) A.sp_work[mi0 + x] = make_uint2(slot, x);
+            }
+            run_m += tot_m; run_r += tot_r;
         }
-        run_m += tot_m; run_r += tot_r;
     }
     if (tid == 0) {
         A.counters[0] = run_m; A.counters[2 * RS_CNT_STRIDE] = run_r;
@@ -632,26 +639,37 @@ __global__ __launch_bounds__(1024) void k_rs_bases(rs_args A, uint32_t n_cand) {
 // problems' first points and d0, its residue pairs side by side in gq / gr (k_rs_points gathers the coordinates) — and the totals (one workgroup)
 __global__ __launch_bounds__(1024) void k_rs_pack(rs_args A) {
     __shared__ unsigned long long s_w[16];
+    __shared__ float s_d0[2 * FD_WAVE + 1];
     const uint32_t tid = threadIdx.x;
     const unsigned long long n_all = A.counters[0];
     const uint64_t n_rec = n_all < A.cap_matches ? n_all : A.cap_matches;
+    if (tid <= 2 * FD_WAVE) s_d0[tid] = A.d0tab[tid];
+    __syncthreads();
     unsigned long long run = 0;       // problems << 40 | points
-    for (uint64_t k0 = 0; k0 < n_rec; k0 += 1024u) {
-        const uint64_t k = k0 + tid;
-        uint4 np = make_uint4(0u, 0u, 0u, 0u);      // {problems, points, assigned, rescued list}
-        if (k < n_rec) np = A.sp_np[k];
-        if (np.x > 2u || np.y > 4u * FD_WAVE) np = make_uint4(0u, 0u, 0u, 0u);      // (a component that bailed out — the call's overflow flag is up — left its entry unwritten)
-        unsigned long long tot;
-        const unsigned long long pk = run + rs_block_excl64(((unsigned long long)np.x << 40) | np.y, tid, s_w, &tot);
-        run += tot;
-        if (k < n_rec && np.x) {
+    for (uint64_t k0 = 0; k0 < n_rec; k0 += 8192u) {       // passes of 8 x 1,024 records, the pass's loads issued together (as k_rs_bases)
+        uint4 np[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint64_t k = k0 + 1024u * (uint32_t)u + tid;
+            np[u] = k < n_rec ? A.sp_np[k] : make_uint4(0u, 0u, 0u, 0u);        // {problems, points, assigned, rescued list}
+            if (np[u].x > 2u || np[u].y > 4u * FD_WAVE) np[u] = make_uint4(0u, 0u, 0u, 0u);      // (a component that bailed out — the call's overflow flag is up — left its entry unwritten)
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (k0 + 1024u * (uint32_t)u >= n_rec) break;
+            const uint64_t k = k0 + 1024u * (uint32_t)u + tid;
+            unsigned long long tot;
+            const unsigned long long pk = run + rs_block_excl64(((unsigned long long)np[u].x << 40) | np[u].y, tid, s_w, &tot);
+            run += tot;
+            if (k >= n_rec) continue;
             const uint64_t p0 = pk >> 40, pt0 = pk & ((1ull << 40) - 1ull);
-            if (p0 + np.x > A.cap_prob || pt0 + np.y > A.cap_pts) { atomicOr(A.flags, 2u); continue; }
-            A.matches[k].prob0 = (uint32_t)p0; A.matches[k].prob1 = np.x == 2u ? (uint32_t)(p0 + 1) : 0xffffffffu;
-            A.koff[p0] = pt0; A.d0[p0] = A.d0tab[2u * np.z];
-            if (np.x == 2u) { A.koff[p0 + 1] = pt0 + 2ull * np.z; A.d0[p0 + 1] = A.d0tab[2u * np.w]; }
+            if (!np[u].x) { A.sp_np[k].y = 0u; continue; }
+            if (p0 + np[u].x > A.cap_prob || pt0 + np[u].y > A.cap_pts) { atomicOr(A.flags, 2u); A.sp_np[k].y = 0u; continue; }
+            A.matches[k].prob0 = (uint32_t)p0; A.matches[k].prob1 = np[u].x == 2u ? (uint32_t)(p0 + 1) : 0xffffffffu;
+            A.koff[p0] = pt0; A.d0[p0] = s_d0[2u * np[u].z];
+            if (np[u].x == 2u) { A.koff[p0 + 1] = pt0 + 2ull * np[u].z; A.d0[p0 + 1] = s_d0[2u * np[u].w]; }
             A.sp_np[k].w = (uint32_t)(pt0 >> 1);        // first residue pair of the record in gq / gr (k_rs_pairs)
-        } else if (k < n_rec) A.sp_np[k].y = 0u;
+        }
     }
     if (tid == 0) A.counters[RS_CNT_STRIDE] = run;
 }
@@ -896,7 +914,7 @@ void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec
     const uint64_t n = nf + nc;
     (void)hipMemsetAsync(cnt, 0, (size_t)2 * (n_cand + 1) * 4, st);
     if (n) hipLaunchKernelGGL(k_rs_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, found, nf, cands, nc, n_cand, cnt);
-    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(256), 0, st, cnt, n_cand, seg, cur);
+    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, st, cnt, n_cand, seg, cur);
     if (n) hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, found, nf, cands, nc, n_cand, cur, perm_f, perm_c);
     // the cursors are spent: their array takes the slots' launch order (rs_args.order = cur)
     if (n_cand) hipLaunchKernelGGL(k_rs_order, dim3(1), dim3(1024), 0, st, cnt, n_cand, cur);
