@@ -312,6 +312,11 @@ __device__ __forceinline__ void drain2(const fd_batch_view &B, const fd_frame *_
             Fi.s2 = {d4.x, d4.y, d4.z}; Fi.nv2 = {d4.w, e4.x, e4.y}; Fi.len = e4.z; Fi.pad = e4.w;
             fd_frame Fj = load_frame(frames, j);
             aai = __float_as_uint(Fi.pad); aaj = __float_as_uint(Fj.pad);
+#if defined(FD_EMIT_STUB) && FD_EMIT_STUB == 1
+            // measurement build (tools/attrib_emit.sh): the drain without the descriptor — frames loaded, slots claimed, keys stored
+            h_ij = aai << 25 | aaj << 20 | (__float_as_uint(Fj.ca.x) & 0xfffffu); h_ji = aaj << 25 | aai << 20 | (__float_as_uint(Fi.ca.x) & 0xfffffu);
+            if (false)
+#endif
             if (!fd_pair_both_spec<DT>(Fi, Fj, aai, aaj, C.q, tab, tab + 32, &h_ij, &h_ji, tab + 64)) {
                 uint2 h = pair_both_tab_exact(frames, i, j, B.aa[i], B.aa[j], C.q.dist_disc, C.q.ang_disc, tab);
                 h_ij = h.x; h_ji = h.y;

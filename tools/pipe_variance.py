@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--structures", type=int, default=542000)
     ap.add_argument("--runs", type=int, default=10)
     ap.add_argument("--reps", type=int, default=48)
+    ap.add_argument("--gc-ab", action="store_true", help="the runs twice: Python's cyclic collector on, then off (is the long run the harness?)")
     ap.add_argument("--node", type=int, default=-2, help="-2: the unconfined process only; -1: every NUMA node in turn (one fresh context each); k: node k")
     a = ap.parse_args()
     import numpy as np
@@ -56,25 +57,37 @@ def main():
         ix.set_penalty(length_penalty(np.diff(ro.cpu().numpy()).astype(np.uint64), 0.5))
         assert ctx.L.fdgpu_query_lanes(ctx.h, 6) >= 6
 
+        done_at = []          # when every wait() returned (the gaps between them: is a slow run ONE stall or many small ones?)
+
         def piped(reps, depth):
             pend, tot = deque(), 0
             for _ in range(reps):
                 pend.append(query_batch_submit(ctx, ix, batch, qall, chunk, float(S), 1000, 32))
                 if len(pend) >= depth:
-                    tot += len(pend.popleft().wait()[2][0])
+                    tot += len(pend.popleft().wait()[2][0]); done_at.append(time.perf_counter())
             while pend:
-                tot += len(pend.popleft().wait()[2][0])
+                tot += len(pend.popleft().wait()[2][0]); done_at.append(time.perf_counter())
             return tot
         piped(12, 6)
         piped(12, 10)
-        vals = []
-        for _ in range(a.runs):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            piped(a.reps, 10)
-            torch.cuda.synchronize()
-            vals.append(128 * a.reps / (time.perf_counter() - t0))
-        print("%-28s %s  (min %.0f median %.0f max %.0f queries/s)" % (tag, " ".join("%.0f" % (v / 1e3) for v in vals), min(vals), sorted(vals)[len(vals) // 2], max(vals)), flush=True)
+        import gc
+        for mode in (("python gc on", True), ("python gc OFF", False)) if a.gc_ab else (("", True),):
+            if not mode[1]:
+                gc.collect(); gc.disable()
+            vals, gaps = [], []
+            for _ in range(a.runs):
+                torch.cuda.synchronize()
+                del done_at[:]
+                t0 = time.perf_counter()
+                piped(a.reps, 10)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                vals.append(128 * a.reps / dt)
+                g = np.diff(np.array([t0] + done_at))
+                gaps.append((float(g.max()) * 1e3, float(np.median(g)) * 1e3, int(g.argmax())))
+            gc.enable()
+            print("%-28s %s  (min %.0f median %.0f max %.0f queries/s) %s" % (tag, " ".join("%.0f" % (v / 1e3) for v in vals), min(vals), sorted(vals)[len(vals) // 2], max(vals), mode[0]), flush=True)
+            print("%-28s longest gap between two completed batches per run, ms (median gap, position): %s" % ("", " ".join("%.2f(%.2f,%d)" % x for x in gaps)), flush=True)
         ctx.L.fdgpu_query_lanes(ctx.h, 0)
         del ix, batch, qall
         ctx.close()
