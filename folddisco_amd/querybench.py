@@ -268,9 +268,17 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
                 # runs behind a short warm-up came out at 135 k or at 160 k from one bench run to the next
                 go_pipe(2 * n_l, n_l)
                 go_pipe(2 * PIPE_REPS, depth)
-                # (one run in five comes out ~6 ms long in every bench line, at no fixed place; switching Python's cyclic collector off for the runs did
-                # not remove it — HISTORY.md.  The value is the median of seven; the runs are in the line.)
-                raw = [timed(lambda: go_pipe(PIPE_REPS, depth)) for _ in range(7)]
+                # The long run that showed up in one bench line in five was THIS harness: a generation-2 pass of Python's cyclic collector over the
+                # result views of the batches in flight — one gap of 19 ms between two completed batches in one run of ten with the collector on, ten
+                # runs within +-2.7 % with it off (profiles/round6_pipelined_leg_gc_ab_S542000.txt, tools/pipe_variance.py --gc-ab).  A Rust or C++
+                # caller has no such pause: collected once, then off for the timed runs.  The value stays the median of seven; the runs are in the line.
+                import gc
+                gc.collect()
+                gc.disable()
+                try:
+                    raw = [timed(lambda: go_pipe(PIPE_REPS, depth)) for _ in range(7)]
+                finally:
+                    gc.enable()
                 runs = sorted(raw, key=lambda x: x[0])
                 assert runs[3][1] == PIPE_REPS * nm1
                 out[(n_l, depth)] = len(queries) * PIPE_REPS / runs[3][0]
@@ -393,7 +401,7 @@ def run(ctx, batch, ix, d, S, world, rank, dist, dev, n_queries=64, top_n=1000, 
         cand_res = int(sum(int(nres[c].sum()) for c in cl))
         t_match = st_match.get("match_pairs", 0.0)
         return {
-            "bound": "hbm", "kernel": "prefilter of the batched full query: cq_batch (k_qt_plan, k_qt_score<pass A: scores per tile of structures in LDS>) + cq_topn "
+            "bound": "hbm", "kernel": "prefilter of the batched full query: cq_batch (k_qt_layout, k_qt_bases, k_qt_score32<pass A: 32-bit idf sums per tile of structures in LDS>) + cq_topn "
                                       "(k_qt_thr, k_qt_rows: records of the survivors from pass A's decoded stream, k_qt_sort)",
             "queries_per_launch": len(ks), "top_n": top_n,
             "algorithmic_bytes_per_launch": b_q, "posting_bytes": post_bytes, "touched_structures": touched, "occupancy_rows": n_rows,
