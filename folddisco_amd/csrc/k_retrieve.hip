@@ -779,20 +779,26 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_comp(rs_args A) {
         if (lane < n_asg) { s_aq[lane] = my_aq; s_ar[lane] = my_ar; }
         RS_WSYNC();
         // ---- the slot's candidate pairs (query residue, i, j) whose partner j some assignment mapped, in their order: what can vote in the rescue
+        // (eight chunks of 64 pairs at a time: their positions, then their records, requested together — a chunk per step paid two dependent
+        // global round trips per 64 pairs, ~40 us for a slot with a thousand pairs: the tail of the launch)
         uint32_t n_f = 0;
-        for (uint32_t base = c0; base < c1; base += FD_WAVE) {
-            const uint32_t x = base + lane;
-            bool ok = false;
-            uint32_t c_q = 0, c_i = 0;
-            if (x < c1) {
-                const fd_cand_rec cr = A.cands[A.perm_c[x]];
-                c_q = cr.qi; c_i = cr.i;
-                if (cr.i < Rt && cr.j < Rt)
-                    for (uint32_t k = 0; k < n_asg; ++k) ok |= s_ar[k] == cr.j;
+        for (uint32_t base0 = c0; base0 < c1; base0 += 8u * FD_WAVE) {
+            uint32_t pc[8];
+            fd_cand_rec cr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t x = base0 + (uint32_t)u * FD_WAVE + lane; pc[u] = x < c1 ? A.perm_c[x] : 0xffffffffu; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { cr[u].cand = 0; cr[u].qi = 0; cr[u].i = 0xffffffffu; cr[u].j = 0xffffffffu; if (pc[u] != 0xffffffffu) cr[u] = A.cands[pc[u]]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (base0 + (uint32_t)u * FD_WAVE >= c1) break;
+                bool ok = false;
+                if (pc[u] != 0xffffffffu && cr[u].i < Rt && cr[u].j < Rt)
+                    for (uint32_t k = 0; k < n_asg; ++k) ok |= s_ar[k] == cr[u].j;
+                const uint64_t m = __ballot(ok);
+                if (ok) { const uint32_t p = n_f + fd_mbcnt(m); if (p < RS_S_FILT) { s_fq[p] = cr[u].qi; s_fi[p] = cr[u].i; } }
+                n_f += (uint32_t)__popcll(m);
             }
-            const uint64_t m = __ballot(ok);
-            if (ok) { const uint32_t p = n_f + fd_mbcnt(m); if (p < RS_S_FILT) { s_fq[p] = c_q; s_fi[p] = c_i; } }
-            n_f += (uint32_t)__popcll(m);
         }
         const bool filt = n_f <= RS_S_FILT;
         RS_WSYNC();
