@@ -413,7 +413,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     // (read per call: tests compare the two), FDGPU_QT32=15 takes tiles of 2^15 structures (one workgroup per CU) instead of 2^14 (two per CU)
     const int qt32_env = [] { const char *e = getenv("FDGPU_QT32"); return e ? atoi(e) : 14; }();
     bool qt32 = keys_only && qtile_on && qt32_env != 0 && sums_fit32 && known_len;
-    const uint32_t qt_tl2 = qt32 ? (qt32_env == 15 ? 15u : 14u)
+    const uint32_t qt_tl2 = qt32 ? (qt32_env == 15 ? 15u : qt32_env == 13 ? 13u : 14u)
                                  : [] { const char *e = getenv("FDGPU_QT_TILE"); return e && atoi(e) == 13 ? 13u : 14u; }();      // structures per tile (measurement)
     const uint32_t NT = (uint32_t)((S + (1u << qt_tl2) - 1) >> qt_tl2);
     bool tiled = keys_only && qtile_on && max_rows <= QT_MAX_ROWS && nq * (S >> QT_CELL_LOG2) < (1ull << 31) && fd_index_checkpoints(c, ix) == FDGPU_OK;

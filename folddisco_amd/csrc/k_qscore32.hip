@@ -134,19 +134,26 @@ __global__ __launch_bounds__(FD_WAVE) void k_qt_layout(qt_args A) {
 // counter — 4,352 returning atomics on one address — was 50 of k_qt_layout's 67 us per 128 queries)
 __global__ __launch_bounds__(1024) void k_qt_bases(qt_args A) {
     __shared__ uint32_t s_w[16];
-    // a thread takes `per` neighbouring (query, tile)s: one scan of the threads' sums instead of one per 1,024 entries
-    const uint32_t n = A.n_queries * A.NT, tid = threadIdx.x, per = (n + 1023u) / 1024u, i0 = tid * per, i1 = i0 + per < n ? i0 + per : n;
-    uint32_t mine = 0;
-    for (uint32_t i = i0; i < i1; ++i) mine += A.heads[i].y << 6;
-    uint32_t tot;
-    uint32_t sb = qt_block_excl<1024>(mine, tid, s_w, &tot);
-    for (uint32_t i = i0; i < i1; ++i) {
-        const uint4 hd = A.heads[i];
-        const uint32_t v = hd.y << 6;
-        const bool fits = (uint64_t)sb + v <= A.stream_cap;
-        A.heads[i] = make_uint4(hd.x, hd.y, sb, hd.w | (fits ? 0u : 2u));
-        A.stream_tab[(uint64_t)i * QT_MAXB] = make_uint2(sb, fits && !hd.w ? v : 0xffffffffu);
-        sb += v;
+    // passes of 8 x 1,024 entries (entry = pass + 1,024 u + thread: neighbouring threads read neighbouring entries), the pass's loads issued together
+    const uint32_t n = A.n_queries * A.NT, tid = threadIdx.x;
+    uint32_t run = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 8192u) {
+        uint4 hd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + 1024u * (uint32_t)u + tid; hd[u] = i < n ? A.heads[i] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + 1024u * (uint32_t)u >= n) break;
+            const uint32_t i = i0 + 1024u * (uint32_t)u + tid, v = hd[u].y << 6;
+            uint32_t tot;
+            const uint32_t sb = run + qt_block_excl<1024>(v, tid, s_w, &tot);
+            run += tot;
+            if (i < n) {
+                const bool fits = (uint64_t)sb + v <= A.stream_cap;
+                A.heads[i] = make_uint4(hd[u].x, hd[u].y, sb, hd[u].w | (fits ? 0u : 2u));
+                A.stream_tab[(uint64_t)i * QT_MAXB] = make_uint2(sb, fits && !hd[u].w ? v : 0xffffffffu);
+            }
+        }
     }
 }
 
@@ -461,5 +468,6 @@ void fd_launch_qt_score32(const qt_args &A, hipStream_t st) {
     if (!A.n_queries || !A.S) return;
     const dim3 g(A.NT * A.n_queries);
     if (A.tile_log2 == 15) hipLaunchKernelGGL((k_qt_score32<15, 1024>), g, dim3(1024), 0, st, A);
+    else if (A.tile_log2 == 13) hipLaunchKernelGGL((k_qt_score32<13, 256>), g, dim3(256), 0, st, A);
     else hipLaunchKernelGGL((k_qt_score32<14, 512>), g, dim3(512), 0, st, A);
 }

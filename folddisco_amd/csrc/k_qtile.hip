@@ -831,8 +831,9 @@ __global__ __launch_bounds__(1024) void k_qt_thr(qt_args A, uint32_t top_n) {
 #define QT_SORT_T 1024
 __global__ __launch_bounds__(QT_SORT_T) void k_qt_sort(const qt_rec *__restrict__ sel, uint32_t cap, const qt_state *__restrict__ st, uint32_t top_n,
                                                         qt_rec *__restrict__ out) {
-    __shared__ unsigned long long s_k[4096];
-    __shared__ uint16_t s_i[4096];
+    __shared__ unsigned long long s_k[2 * 4096];
+    __shared__ uint16_t s_i[2 * 4096];
+    bool flip = false;
     const uint32_t q = blockIdx.x, cnt = st[q].count, tid = threadIdx.x;
     if (cnt > cap || cnt == 0 || cnt > 4096u) return;
     uint32_t n2 = 64;
@@ -870,13 +871,16 @@ __global__ __launch_bounds__(QT_SORT_T) void k_qt_sort(const qt_rec *__restrict_
                         cx(e, e * 1024u + tid, K, j, b, bi); cx(e + 1, (e + 1) * 1024u + tid, K, j, a, ai);
                     }
                 }
-            } else if (j >= 64u) {     // partner in another wavefront
+            } else if (j >= 64u) {     // partner in another wavefront: through LDS, two buffers in turn — ONE barrier per step (a step's reads are
+                                       // over when every wavefront has passed the next step's barrier, and that step writes the other buffer)
+                unsigned long long *const bk = s_k + (flip ? 4096 : 0);
+                uint16_t *const bi = s_i + (flip ? 4096 : 0);
+                flip = !flip;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if ((uint32_t)e < E) { s_k[e * 1024u + tid] = key[e]; s_i[e * 1024u + tid] = (uint16_t)idx[e]; }
+                for (int e = 0; e < 4; ++e) if ((uint32_t)e < E) { bk[e * 1024u + tid] = key[e]; bi[e * 1024u + tid] = (uint16_t)idx[e]; }
                 __syncthreads();
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if ((uint32_t)e < E) { const uint32_t i = e * 1024u + tid, l = i ^ j; cx(e, i, K, j, s_k[l], s_i[l]); }
-                __syncthreads();
+                for (int e = 0; e < 4; ++e) if ((uint32_t)e < E) { const uint32_t i = e * 1024u + tid, l = i ^ j; cx(e, i, K, j, bk[l], bi[l]); }
             } else {                   // partner in this wavefront
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if ((uint32_t)e < E) {
@@ -933,6 +937,7 @@ void fd_launch_qt_select(const qt_args &A, uint32_t top_n, void *sorted, hipStre
         hipLaunchKernelGGL((k_qt_rows<14, 512, 1024, 512, 128>), g, dim3(512), 0, st, A);       // (256 / 128 threads per workgroup: 75 / 97 us against 75)
     }
     else if (A.stream_ids && A.tile_log2 == 14) hipLaunchKernelGGL((k_qt_rows<14, 512, 6144, 512>), g, dim3(512), 0, st, A);
+    else if (A.stream_ids && A.heads && A.max_rows && A.max_rows <= 128u) hipLaunchKernelGGL((k_qt_rows<13, 256, 1024, 256, 128>), g, dim3(256), 0, st, A);
     else if (A.stream_ids) hipLaunchKernelGGL((k_qt_rows<13, 512, 6144, 256>), g, dim3(512), 0, st, A);
     else if (A.tile_log2 == 14) hipLaunchKernelGGL((k_qt_score<true, 14, 1024, 512, 6144>), g, dim3(1024), 0, st, A);
     else hipLaunchKernelGGL((k_qt_score<true, 13, 512, 256, 6144>), g, dim3(512), 0, st, A);

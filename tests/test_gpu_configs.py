@@ -396,7 +396,7 @@ def test_tiled_scoring_equals_occupancy_rows(human, monkeypatch):
     monkeypatch.delenv("FDGPU_QT_STREAM")
     # ... and the default since round 6: 32-bit sums over a planned slot stream (k_qscore32.hip; tiles of 2^14 or 2^15 structures), every cut
     # incl. the ones that take the whole tile's keys (more than the tile holds), ties around the cut, a shard's sub-range of the ids
-    for mode in ("14", "15"):
+    for mode in ("13", "14", "15"):
         monkeypatch.setenv("FDGPU_QT32", mode)
         for N in (1, 5, 1000, 3000):
             got = fd.count_query_maps(ctx, ix, qms, pen, total_structures=HUMAN, top_n=N)
@@ -410,7 +410,7 @@ def test_tiled_scoring_equals_occupancy_rows(human, monkeypatch):
     full_sm = fd.count_query_maps(ctx, sub_m, qms_s, pen[3000:20000].copy(), total_structures=HUMAN, top_n=0)
     assert all((f["nid"] >= 3000).all() and (f["nid"] < 20000).all() for f in full_sm if len(f))
     monkeypatch.setenv("FDGPU_QTILE", "1")
-    for mode in ("14", "15"):
+    for mode in ("13", "14", "15"):
         monkeypatch.setenv("FDGPU_QT32", mode)
         for N in (50, 1000):
             got = fd.count_query_maps(ctx, ix, qms, ones, total_structures=HUMAN, top_n=N)

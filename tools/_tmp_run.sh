@@ -1,4 +1,4 @@
 set -u
 cd /root/repo
-python -m pytest tests/test_gpu_e2e.py tests/test_gpu_configs.py -x -q -m gpu -k "glue or retriev or fused or pipelined or shipped" 2>&1 | grep -E "passed|failed|error" | tail -3
-bash tools/profile_round6_qt.sh 542000 24 "14" 2>&1 | grep -E "blocking|6 lanes|k_rs_|kernels per batch"
+python -m pytest tests/test_gpu_configs.py -x -q -m gpu -k "tiled or fused or pipelined or shipped" 2>&1 | grep -E "passed|failed|error|assert" | tail -5
+bash tools/profile_round6_qt.sh 542000 24 "13 14" 2>&1 | grep -E "FDGPU_QT32|blocking|6 lanes|phase|k_qt_|kernels per batch"
