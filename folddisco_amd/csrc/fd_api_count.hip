@@ -412,7 +412,8 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     // k_qscore32.hip (32-bit sums, planned slot stream; needs the rows' posting lengths for the stream's bound): FDGPU_QT32=0 keeps the 64-bit kernel
     // (read per call: tests compare the two), FDGPU_QT32=15 takes tiles of 2^15 structures (one workgroup per CU) instead of 2^14 (two per CU)
     const int qt32_env = [] { const char *e = getenv("FDGPU_QT32"); return e ? atoi(e) : 14; }();
-    bool qt32 = keys_only && qtile_on && qt32_env != 0 && sums_fit32 && known_len;
+    // (queries of more than 128 rows keep the 64-bit kernel as well: their idf units reach 2^32 on any real index, and k_qt_rows' small tables are sized for 128)
+    bool qt32 = keys_only && qtile_on && qt32_env != 0 && sums_fit32 && known_len && max_rows <= 128;
     const uint32_t qt_tl2 = qt32 ? (qt32_env == 15 ? 15u : qt32_env == 13 ? 13u : 14u)
                                  : [] { const char *e = getenv("FDGPU_QT_TILE"); return e && atoi(e) == 13 ? 13u : 14u; }();      // structures per tile (measurement)
     const uint32_t NT = (uint32_t)((S + (1u << qt_tl2) - 1) >> qt_tl2);
@@ -441,6 +442,8 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         if (qt32) slots = 2 * slots + 64ull * n_queries * NT;
         if (slots < (1ull << 31)) stream_cap = slots + 1024;
         else qt32 = false;
+        // FDGPU_QT_STREAM_CAP=n (tests): a stream of n records — the tiles that do not fit raise the selection's overflow flag and the call is ranked by the compacting path
+        if (const char *e = getenv("FDGPU_QT_STREAM_CAP")) { const long v = atol(e); if (v > 0 && (uint64_t)v < stream_cap) stream_cap = (uint64_t)v; }
     }
     auto need_rows = [&]() {      // the occupancy-row path's scratch
         need(WS_COUNTS, packed ? 64 : QS * 4); need(WS_SEGOFF, QS * 8 + 16);

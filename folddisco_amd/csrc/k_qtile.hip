@@ -584,6 +584,9 @@ __global__ __launch_bounds__(NTHR) void k_qt_rows(qt_args A) {
         run += tot;
     }
     const uint32_t n_surv = run;
+    // (a tile k_qt_layout / k_qt_bases could not place — window table or decoded stream too small — was not scored at all by k_qt_score32: it has no
+    // survivors to trip the check in the loop below, so the query is flagged here)
+    if (A.heads && A.stream_tab[((uint64_t)q * A.NT + t) * QT_MAXB].y == 0xffffffffu) { if (tid == 0) atomicOr(&A.state[q].count, 0x80000000u); return; }
     if (!n_surv) return;
     const uint32_t wpr = (nrows + 31u) >> 5, per_round = (uint32_t)RBW / wpr, n_rounds = (n_surv + per_round - 1u) / per_round;
     if (tid == 0) s_base = atomicAdd(&A.state[q].count, n_surv);

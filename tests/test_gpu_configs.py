@@ -402,6 +402,15 @@ def test_tiled_scoring_equals_occupancy_rows(human, monkeypatch):
             got = fd.count_query_maps(ctx, ix, qms, pen, total_structures=HUMAN, top_n=N)
             for f, x in zip(full_m, got):
                 assert x.tobytes() == rank_hits(f, N).tobytes(), (N, mode)
+    # a decoded stream too small for the batch (FDGPU_QT_STREAM_CAP: the bound the host sizes it by, cut down): the tiles that do not fit are not scored,
+    # their queries raise the selection's overflow flag and the call is ranked by the compacting path — same records
+    monkeypatch.setenv("FDGPU_QT32", "14")
+    for cap_recs in ("64", "20000"):
+        monkeypatch.setenv("FDGPU_QT_STREAM_CAP", cap_recs)
+        got = fd.count_query_maps(ctx, ix, qms, pen, total_structures=HUMAN, top_n=1000)
+        for f, x in zip(full_m, got):
+            assert x.tobytes() == rank_hits(f, 1000).tobytes(), cap_recs
+    monkeypatch.delenv("FDGPU_QT_STREAM_CAP")
     monkeypatch.setenv("FDGPU_QTILE", "0")
     ones = np.ones_like(pen)
     full_1 = fd.count_query_maps(ctx, ix, qms, ones, total_structures=HUMAN, top_n=0)
