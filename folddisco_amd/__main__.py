@@ -204,7 +204,9 @@ def _cmd_index_sharded(a, fd, indexio, structure, paths, prefix, rank, world):
     # ONE index for the database without the host (Option A; csrc/fd_shard_index.hip): hash ranges of equal posting bytes, piece j of
     # every rank's sub-index to rank j — ncclSend / ncclRecv inside the library when the ranks have a GPU each (backend nccl), torch.distributed objects
     # under gloo —, per-hash concatenation of the pieces on the device, every rank writes its regions of PREFIX / PREFIX.offset
-    if dist.get_backend() == "nccl":
+    # (FD_INDEX_EXCHANGE=objects keeps the transport-free form reachable under nccl as well: a fall-back should the N-rank ncclSend / ncclRecv group —
+    # executed so far with a world of one only — misbehave on a node)
+    if dist.get_backend() == "nccl" and os.environ.get("FD_INDEX_EXCHANGE", "rccl") != "objects":
         comm = fdist.Comm(ctx, rank, world)
         rng, hb, vb, ht, vt = comm.single_index(local)
     else:

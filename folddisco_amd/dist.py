@@ -400,8 +400,16 @@ def single_index_over_process_group(ctx, local, device=None):
         pieces.append((s.export(), int(local.first_id), int(local.n_structures)))
         del s
     got = [None] * W
-    for j in range(W):      # piece j of every rank to rank j
-        dist.gather_object(pieces[j], got if me == j else None, dst=j)
+    if dist.get_backend() == "nccl":      # (ProcessGroupNCCL has no gather: every rank takes every rank's piece j in turn and keeps its own range's — W x the bytes, a fall-back only)
+        for j in range(W):
+            box_j = [None] * W
+            dist.all_gather_object(box_j, pieces[j])
+            if me == j:
+                got = box_j
+            del box_j
+    else:
+        for j in range(W):      # piece j of every rank to rank j
+            dist.gather_object(pieces[j], got if me == j else None, dst=j)
     parts = [FolddiscoIndex.load(ctx, h, o, v, n, first_id=f) for (v, h, o), f, n in got]
     rng = FolddiscoIndexSet(parts).merge() if len(parts) > 1 else parts[0]
     sizes = [None] * W
