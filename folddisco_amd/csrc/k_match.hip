@@ -897,8 +897,19 @@ __global__ __launch_bounds__(64) void k_metrics(const float *__restrict__ refs, 
         const double ts[4] = {1.0, 2.0, 4.0, 8.0}, ha[4] = {0.5, 1.0, 2.0, 4.0};
 #pragma unroll
         for (int k = 0; k < 4; ++k) { c_ts[k] += dii <= ts[k] * ts[k] ? 1u : 0u; c_ha[k] += dii <= ha[k] * ha[k] ? 1u : 0u; }
-        float mn = sp_dist(ref, 0, tx, ty, tz);
-        for (uint64_t j = 1; j < n; ++j) mn = fminf(mn, sp_dist(ref, j, tx, ty, tz));
+        // nearest reference point: (float)sqrt(.) is monotone, so the smallest distance is the image of the smallest SQUARED distance — nine f64 operations per
+        // candidate instead of a double-precision square root each (a whole-structure query's problems have ~600 points: 3.5·10^5 roots per problem, 0.75 ms
+        // of kernel for its 367 problems); same bits: min of the images = image of the min, fmin drops a NaN on either side like fminf did
+        double m2;
+        {
+            const double dx = (double)ref[0] - (double)tx, dy = (double)ref[1] - (double)ty, dz = (double)ref[2] - (double)tz;
+            m2 = dx * dx + dy * dy + dz * dz;
+        }
+        for (uint64_t j = 1; j < n; ++j) {
+            const double dx = (double)ref[3 * j] - (double)tx, dy = (double)ref[3 * j + 1] - (double)ty, dz = (double)ref[3 * j + 2] - (double)tz;
+            m2 = fmin(m2, dx * dx + dy * dy + dz * dz);
+        }
+        const float mn = (float)sqrt(m2);
         ch += (double)mn;
         hd = fmaxf(hd, mn);
     }
