@@ -451,34 +451,36 @@ __global__ __launch_bounds__(1024) void k_mp_offsets(mp_args A) {
     const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     uint32_t incl;
     const uint32_t nc = mp_chunk_prefix(A, lane, incl);
-    // thread t owns the chunks [t * per, (t + 1) * per): its sums, one scan over the 1,024 threads, then its chunks' positions (a tile of 1,024 chunks per
-    // round was eight rounds of three barriers for a motif batch: 19 us)
-    const uint32_t per = (nc + 1023u) / 1024u, v0 = t * per, v1 = v0 + per < nc ? v0 + per : nc;
-    unsigned long long xw = 0, xh = 0;
-    uint2 c8[8];      // the thread's first eight totals stay in registers (a motif batch: all of them) — and their loads are independent
+    // passes of 8,192 chunks: thread t owns eight neighbouring chunks of the pass — their totals are loaded together and stay in registers —, one scan over the
+    // 1,024 threads' sums, then the chunks' positions (a tile of 1,024 chunks per round was eight rounds of three barriers for a motif batch: 19 us; ONE pass with
+    // `per` chunks per thread walked a whole-structure scan's 40-60 k chunks through a loop of dependent loads: 0.22 ms per launch, two launches per query)
+    unsigned long long run_w = 0, run_h = 0;
+    for (uint32_t p0 = 0; p0 < nc; p0 += 8192u) {
+        const uint32_t v0 = p0 + t * 8u;
+        uint2 c8[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) c8[u] = v0 + u < v1 ? A.chunk_cnt[v0 + u] : make_uint2(0u, 0u);
+        for (int u = 0; u < 8; ++u) c8[u] = v0 + u < nc ? A.chunk_cnt[v0 + u] : make_uint2(0u, 0u);
+        unsigned long long xw = 0, xh = 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { xw += c8[u].x; xh += c8[u].y; }
-    for (uint32_t v = v0 + 8u; v < v1; ++v) { const uint2 cn = A.chunk_cnt[v]; xw += cn.x; xh += cn.y; }
-    const unsigned long long mw = xw, mh = xh;
-    for (int off = 1; off < FD_WAVE; off <<= 1) {
-        const unsigned long long tw = __shfl_up(xw, off, FD_WAVE), th = __shfl_up(xh, off, FD_WAVE);
-        if ((int)lane >= off) { xw += tw; xh += th; }
+        for (int u = 0; u < 8; ++u) { xw += c8[u].x; xh += c8[u].y; }
+        const unsigned long long mw = xw, mh = xh;
+        for (int off = 1; off < FD_WAVE; off <<= 1) {
+            const unsigned long long tw = __shfl_up(xw, off, FD_WAVE), th = __shfl_up(xh, off, FD_WAVE);
+            if ((int)lane >= off) { xw += tw; xh += th; }
+        }
+        __syncthreads();      // (the pass before has read the wave totals)
+        if (lane == 63u) { s_w[wv] = xw; s_h[wv] = xh; }
+        __syncthreads();
+        unsigned long long bw = run_w + xw - mw, bh = run_h + xh - mh;      // exclusive inside the wavefront
+        unsigned long long tot_w = 0, tot_h = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) { const unsigned long long a = s_w[k], c = s_h[k]; if (k < wv) { bw += a; bh += c; } tot_w += a; tot_h += c; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v0 + u < nc) { A.chunk_base[v0 + u] = make_ulonglong2(bw, bh); bw += c8[u].x; bh += c8[u].y; }
+        run_w += tot_w; run_h += tot_h;
     }
-    if (lane == 63u) { s_w[wv] = xw; s_h[wv] = xh; }
-    __syncthreads();
-    unsigned long long bw = xw - mw, bh = xh - mh;      // exclusive inside the wavefront
-    for (uint32_t k = 0; k < wv; ++k) { bw += s_w[k]; bh += s_h[k]; }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-        if (v0 + u < v1) { A.chunk_base[v0 + u] = make_ulonglong2(bw, bh); bw += c8[u].x; bh += c8[u].y; }
-    for (uint32_t v = v0 + 8u; v < v1; ++v) {
-        const uint2 cn = A.chunk_cnt[v];
-        A.chunk_base[v] = make_ulonglong2(bw, bh);
-        bw += cn.x; bh += cn.y;
-    }
-    if (t == 1023u) { *A.n_cands = bw; *A.n_found = bh; A.n_found[2] = nc; }
+    if (t == 0u) { *A.n_cands = run_w; *A.n_found = run_h; A.n_found[2] = nc; }
 }
 
 // the records of one chunk per wavefront: candidate pairs (one per observed distance inside the pair's window) and found triples (one per bin pair
