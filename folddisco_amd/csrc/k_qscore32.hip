@@ -168,8 +168,8 @@ struct q32_slot { qt_u32x4 x4; uint32_t add, nby, rel, pstart, prev, row; };   /
 template <int TL2, int NTHR>
 __global__ __launch_bounds__(NTHR) void k_qt_score32(qt_args A) {
     constexpr uint32_t TILE = 1u << TL2, NW = NTHR / 64;
-    __shared__ uint32_t s_acc[TILE];               // idf sum (2^-22 units) per structure of the tile
-    __shared__ uint32_t s_hist[QT_BINS / 2];       // 16-bit counts, two bins per word
+    __shared__ __attribute__((aligned(16))) uint32_t s_acc[TILE];               // idf sum (2^-22 units) per structure of the tile
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[QT_BINS / 2];       // 16-bit counts, two bins per word
     __shared__ uint32_t s_mark[NTHR / 4];          // 64 bytes per wavefront: first lanes of the pieces that begin inside a window
     __shared__ uint32_t s_cnt;                     // (structure, key) pairs listed so far
     const uint32_t wg = blockIdx.x;

@@ -784,23 +784,38 @@ __global__ __launch_bounds__(FD_WAVE) void k_qd_records(qt_args A) {
 // that many survivors fit the selection's slots the bin's lower edge is the threshold; else (rare: the cut falls into a crowd of nearly
 // equal keys) the workgroup splits the bin once more over the query's (structure, key) lists.  One workgroup per query; the table is left zero.
 __global__ __launch_bounds__(1024) void k_qt_thr(qt_args A, uint32_t top_n) {
-    __shared__ uint32_t hist[QT_BINS];
-    __shared__ uint32_t part[256];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[QT_BINS];
     __shared__ uint32_t s_bin, s_above, s_at;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     uint32_t *h = A.ghist + (uint64_t)q * QT_BINS;
     for (uint32_t k = tid; k < QT_BINS; k += 1024) { hist[k] = h[k]; h[k] = 0u; }
     __syncthreads();
-    auto search = [&](uint32_t above0) {       // -> s_bin, s_above, s_at
-        if (tid < 256) { uint32_t mine = 0; for (int k = 0; k < 8; ++k) mine += hist[tid * 8 + k]; part[tid] = mine; }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t acc = above0;
-            int t = 255;
-            for (; t > 0; --t) { if (acc + part[t] >= top_n) break; acc += part[t]; }
-            int b = t * 8 + 7;
-            for (; b > t * 8; --b) { if (acc + hist[b] >= top_n) break; acc += hist[b]; }
-            s_bin = (uint32_t)b; s_above = acc; s_at = hist[b];
+    // -> s_bin = the highest bin b with above0 + (keys in the bins above b) + hist[b] >= top_n (bin 0 when there are fewer keys), s_above = the keys above it,
+    // s_at = hist[b].  One wavefront: lane l sums bins 32 l .. 32 l + 31, a wave scan finds the lane where the count from the top crosses top_n, its 32 bins are
+    // split over the lanes once more (thread 0 walking 256 partial sums and then 8 bins through dependent LDS reads was 3-4 of the kernel's 9-12 us)
+    auto search = [&](uint32_t above0) {
+        if (tid < FD_WAVE) {
+            const uint32_t lane = tid;
+            uint32_t tot = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < 32; u += 4) {
+                const qt_u32x4 hw = *reinterpret_cast<const qt_u32x4 *>(&hist[32u * lane + u]);
+                tot += hw[0] + hw[1] + hw[2] + hw[3];
+            }
+            const uint32_t incl = qt_wave_incl(tot, lane), all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t above_l = above0 + (all - incl);                   // keys in the lanes above this one
+            const uint64_t mk = __ballot(above_l + tot >= top_n);
+            if (!mk) { if (lane == 0) { s_bin = 0u; s_above = above0 + all - hist[0]; s_at = hist[0]; } }
+            else {
+                const uint32_t L = 63u - (uint32_t)__clzll((long long)mk);
+                const uint32_t accL = (uint32_t)__builtin_amdgcn_readlane((int)above_l, (int)L);
+                const uint32_t h = lane < 32u ? hist[32u * L + lane] : 0u;
+                const uint32_t i2 = qt_wave_incl(h, lane), all2 = (uint32_t)__builtin_amdgcn_readlane((int)i2, 63);
+                const uint32_t above_j = accL + (all2 - i2);
+                const uint64_t mk2 = __ballot(lane < 32u && above_j + h >= top_n);      // never empty: lane 0 sees the whole of lane L's count
+                const uint32_t j = 63u - (uint32_t)__clzll((long long)mk2);
+                if (lane == j) { s_bin = 32u * L + j; s_above = above_j; s_at = h; }
+            }
         }
         __syncthreads();
     };
