@@ -121,6 +121,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     // per-query tables: sorted hash set, residue-type masks, aa_dist_map grouped by (aa_i, aa_j) — stable order inside a group =
     // the observed-list order the reference emits in
     std::vector<mp_query_dev> qtab(std::max<uint64_t>(n_queries, 1));
+    uint64_t qset_slots = 0, qset_max_hashes = 0;
     std::vector<uint32_t> all_hashes, all_start, all_qi;
     std::vector<float> all_dist;
     all_start.assign((size_t)1025 * n_queries, 0u);      // one start table per query, filled in place (a batch of 512 motif queries: 2 MB)
@@ -129,6 +130,13 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
         const fd_match_query *q = &qs[t];
         mp_query_dev &Q = qtab[t];
         Q.qh_off = (uint32_t)all_hashes.size(); Q.n_hashes = (uint32_t)q->n_hashes;
+        Q.qs_off = 0; Q.qs_mask = 0;
+        if (q->n_hashes > MP_QH_LDS && qset_slots + 4 * q->n_hashes < (1ull << 31)) {      // a hash set for the drains' membership test (k_mp_qset_build fills it)
+            uint64_t slots = 2048;
+            while (slots < 2 * q->n_hashes) slots <<= 1;
+            Q.qs_off = (uint32_t)qset_slots; Q.qs_mask = (uint32_t)(slots - 1);
+            qset_slots += slots; qset_max_hashes = std::max<uint64_t>(qset_max_hashes, q->n_hashes);
+        }
         all_hashes.insert(all_hashes.end(), q->hashes, q->hashes + q->n_hashes);
         Q.aa1_mask = Q.aa2_mask = 0;
         for (uint64_t k = 0; k < q->n_hashes; ++k) {
@@ -248,6 +256,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
             }
     }
     if (n_queries) memcpy(&blk[o_qt], qtab.data(), n_queries * sizeof(mp_query_dev));
+    TB.qset_slots = qset_slots; TB.qset_max_hashes = qset_max_hashes;
     TB.valid = true;
     return FDGPU_OK;
     };
@@ -329,6 +338,13 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     A.iv_start = want_iv ? dblk + o_ivs : nullptr; A.iv = want_iv ? (const float2 *)(dblk + o_iv) : nullptr;
     A.iv_grp = want_iv ? dblk + o_iv1 : nullptr;
     A.qtab = (const mp_query_dev *)(dblk + o_qt);
+    A.qset = nullptr;
+    if ((mode & 1u) && TB.qset_slots) {      // found triples wanted and some query holds more hashes than a drain stages in LDS: their hash sets
+        HIPCHK(c, c->ws[WS_MP_QSET].ensure(TB.qset_slots * 4));
+        HIPCHK(c, hipMemsetAsync(c->ws[WS_MP_QSET].p, 0xff, TB.qset_slots * 4, st));
+        fd_launch_mp_qset_build(A.qtab, (uint32_t)n_queries, (uint32_t)TB.qset_max_hashes, dblk + o_h, c->ws[WS_MP_QSET].as<uint32_t>(), st);
+        A.qset = c->ws[WS_MP_QSET].as<uint32_t>();
+    }
     A.n_found = c->ws[WS_TOTAL].as<unsigned long long>(); A.n_cands = A.n_found + 1; A.found = nullptr; A.cands = nullptr;
     const bool mp_dbg = getenv("FDGPU_MP_DBG") != nullptr;       // clocks and counts of the pair scan's work items and drains on stderr (measurement aid)
     HIPCHK(c, c->ws[WS_TOTAL].ensure(16384));

@@ -91,7 +91,7 @@ enum {
     WS_TILE_B, WS_TILE_H, WS_TILE_P, WS_TILE_BO, WS_TILE_HO /* ranked records of a scoring call: fdgpu_query_batch copies them out on the side stream WHILE the
     retrieval runs — no retrieval stage may ensure() or write this buffer (checked there) */, WS_TILE_PO, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_FRAMES,
     WS_CQ_KIDX, WS_CQ_NSEG, WS_CQ_WSTART, WS_CQ_SEGSUM, WS_CQ_TOPN,
-    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS, WS_QT_STREAM, WS_QT_STAB, WS_QT_PIECEP, WS_QT_WIN, WS_QT_HEAD, WS_RS_SPLIT,
+    WS_QT_RANGES, WS_QT_COMPACT, WS_QT_COUNT, WS_QT_AUX, WS_RS_PLAN, WS_RS_REC, WS_RS_RECRES, WS_QT_PARTIAL, WS_QT_SURV, WS_QT_ROWBITS, WS_QT_STREAM, WS_QT_STAB, WS_QT_PIECEP, WS_QT_WIN, WS_QT_HEAD, WS_RS_SPLIT, WS_MP_QSET,
     WS_CA_PERM, WS_OK_PERM, WS_AA_PERM, WS_SEG_TAB,
     WS_RS_TAB, WS_RS_SEG, WS_RS_OUT, WS_RS_RES, WS_RS_KX, WS_RS_KY, WS_RS_KOFF, WS_RS_SOL, WS_RS_CNT, WS_RS_GQ, WS_MP_ACT, WS_MP_Q,
     WS_COUNT
@@ -400,7 +400,9 @@ struct mp_query_dev {   // per-query table of the pair scan (many queries in one
     uint32_t aa1_mask, aa2_mask; // residue types of the hashes' first / second residue (prefilter_amino_acid)
     int use_prefilter;
     float ca_window;
+    uint32_t qs_off, qs_mask;    // more than MP_QH_LDS hashes: an open-addressing set of them, qset[qs_off .. + qs_mask + 1) (0xffffffff = empty); qs_mask = 0: none
 };
+#define MP_QH_LDS 1024          /* query hashes a drain copies into LDS for its membership test; larger sets are probed in their hash table (qset) */
 #define MP_SUBQ_STRIDE 16u      /* u64 words between the pair queue's sub-queue counters (one 128-byte line each) */
 struct mp_args {
     fd_batch_view B;
@@ -410,6 +412,7 @@ struct mp_args {
     const uint32_t *wi_cand; const uint32_t *wi_i0; const uint32_t *wi_query; uint32_t n_work;
     const uint32_t *wi_j0; uint32_t j_span;   // j_span != 0: a work item scans partner residues [wi_j0, wi_j0 + j_span) only (few, long candidates)
     const mp_query_dev *qtab;
+    const uint32_t *qset;        // the large queries' hash sets (null: none)
     const uint8_t *resname_std;
     uint32_t aa1_mask, aa2_mask;
     int use_prefilter;
@@ -449,6 +452,7 @@ struct fd_mp_tables {
     std::vector<uint32_t> blk; size_t o[13] = {0}; size_t nw = 0; bool want_iv = false; uint32_t j_span = 0; bool valid = false;
     const uint32_t *data = nullptr; size_t words = 0;      // the packed block: blk, or (tables not kept by the caller) the context's pinned staging buffer
     bool dev_items = false; size_t o_wb = 0;                // work items written on the device from [first item | query] per candidate at o_wb (one-off blocks)
+    uint64_t qset_slots = 0, qset_max_hashes = 0;           // slots of the large queries' hash sets (mp_query_dev.qs_off / qs_mask), their largest hash count
 };
 // work items of the pair scan: candidate k (structure cand[k], first item wbase[k], query cq[k]) -> one item per (64-residue tile, span of j_span partners)
 void fd_launch_mp_items(const uint32_t *db_res_off, const uint32_t *cand, uint32_t n_cand, const uint32_t *wbase, const uint32_t *cq, uint32_t j_span, uint32_t *wc,
@@ -466,6 +470,7 @@ struct fd_vote_plan {
 };
 void fd_launch_vote_rows(const uint32_t *votes, const uint64_t *row_off, const uint32_t *row_len, uint64_t n_rows, fd_vote_row *out, hipStream_t st);
 void fd_launch_match_pairs(const mp_args &A, hipStream_t st);
+void fd_launch_mp_qset_build(const mp_query_dev *qtab, uint32_t n_queries, uint32_t max_hashes, const uint32_t *q_hashes, uint32_t *qset, hipStream_t st);
 void fd_launch_found_key_ij(const fd_pair_rec *f, uint64_t n, uint32_t *key, uint32_t *val, hipStream_t st);
 void fd_launch_found_key_slot(const fd_pair_rec *f, const uint32_t *val, uint64_t n, uint32_t *key, hipStream_t st);
 void fd_launch_found_gather(const fd_pair_rec *f, const uint32_t *val, uint64_t n, fd_pair_rec *out, hipStream_t st);

@@ -31,6 +31,7 @@ struct mp_sel {
     const uint32_t *iv_start; const float2 *iv;      // large queries: per (aa_i, aa_j) group the merged intervals of distances that pass the window test
     const uint32_t *iv_grp;                          // ... and per group (first interval << 8 | count), the form the work item copies into LDS
     const float *sd_dist; const uint32_t *sd_qi;     // vote mode, optional: the group lists sorted by distance
+    const uint32_t *qset; uint32_t qs_mask;          // large queries: the hashes as an open-addressing set (qs_mask = slots - 1; 0: none)
 };
 // descriptor + hash + output of one surviving (i, j) per lane (full-wave drains of the compaction queue: executed
 // divergently per survivor this part — ~3000 instructions with the exact libm chain — was 95 % of the kernel time)
@@ -46,6 +47,17 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
             uint32_t lo = 0, hi = Sx.n_hashes;
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (qh_lds[mid] < h) lo = mid + 1; else hi = mid; }
             return lo < Sx.n_hashes && qh_lds[lo] == h;
+        }
+        if (Sx.qs_mask) {
+            // a whole-structure query holds ~10^5 hashes: the bisection through global memory is 17 dependent round trips per drain (the wavefront waits for its
+            // slowest lane); the set is probed in two or three (load factor <= 1/2, linear probing: every lane ends at its hash or at an empty slot)
+            uint32_t at = (h * 2654435761u) >> __clz((int)Sx.qs_mask);       // the product's HIGH bits (its low bits repeat the hash's own low fields: long probe runs)
+            for (;;) {
+                const uint32_t x = Sx.qset[at];
+                if (x == h) return true;
+                if (x == 0xffffffffu) return false;
+                at = (at + 1u) & Sx.qs_mask;
+            }
         }
         return hash_in_set(Sx.q_hashes, Sx.n_hashes, h);
     };
@@ -129,7 +141,6 @@ __device__ __forceinline__ void match_drain(const mp_args &A, const mp_sel &Sx, 
 }
 
 #define MP_AAD_LDS 1024
-#define MP_QH_LDS 1024        /* query hashes a drain copies into LDS for its membership test */
 #define MP_SUBQ 64u            /* sub-queues of the chunk queue: one counter each, MP_SUBQ_STRIDE (fdgpu_internal.h) u64 = 128 B apart */
 #define MP_SCAN_BLOCKS 64      /* blocks of 64 residues whose activity masks a work item keeps in LDS (longer structures: the two-walk form) */
 
@@ -145,6 +156,23 @@ __device__ __forceinline__ void mp_select(const mp_args &A_in, uint32_t tq, mp_s
     Sx.iv = A_in.iv;
     Sx.iv_grp = A_in.iv_grp ? A_in.iv_grp + 1024u * tq : nullptr;
     Sx.sd_dist = A_in.sd_dist ? A_in.sd_dist + Q.aad_off : nullptr; Sx.sd_qi = A_in.sd_qi ? A_in.sd_qi + Q.aad_off : nullptr;
+    Sx.qset = A_in.qset ? A_in.qset + Q.qs_off : nullptr; Sx.qs_mask = A_in.qset ? Q.qs_mask : 0u;
+}
+// the hash sets of the launch's large queries: one thread per (query, hash), linear probing from the high bits of hash x 2654435761 (the slots are 0xffffffff on entry;
+// a 30-bit hash never is)
+__global__ __launch_bounds__(256) void k_mp_qset_build(const mp_query_dev *__restrict__ qtab, const uint32_t *__restrict__ q_hashes, uint32_t *__restrict__ qset) {
+    const mp_query_dev Q = qtab[blockIdx.y];
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (!Q.qs_mask || k >= Q.n_hashes) return;
+    const uint32_t h = q_hashes[Q.qh_off + k];
+    uint32_t *T = qset + Q.qs_off;
+    for (uint32_t at = (h * 2654435761u) >> __clz((int)Q.qs_mask);; at = (at + 1u) & Q.qs_mask) {
+        const uint32_t old = atomicCAS(&T[at], 0xffffffffu, h);
+        if (old == 0xffffffffu || old == h) return;
+    }
+}
+void fd_launch_mp_qset_build(const mp_query_dev *qtab, uint32_t n_queries, uint32_t max_hashes, const uint32_t *q_hashes, uint32_t *qset, hipStream_t st) {
+    if (n_queries && max_hashes) hipLaunchKernelGGL(k_mp_qset_build, dim3((max_hashes + 255u) / 256u, n_queries), dim3(256), 0, st, qtab, q_hashes, qset);
 }
 
 // The pair scan is two kernels since round 5.  As ONE kernel (scan, and a drain whenever 64 pairs had queued) every wavefront carried the drain's

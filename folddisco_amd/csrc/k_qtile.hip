@@ -421,16 +421,28 @@ __global__ __launch_bounds__(NTHR) void k_qt_score(qt_args A) {
                         }
                     } else {
                         // survivors are rare: the bitmap words of all sixteen postings first, the row bits only where one is set
-                        uint32_t hit = 0;
+                        uint32_t hit = 0, hx = 0;       // hx: the LAST hit's place in the tile
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             id += v[i];
                             const uint32_t x = id - tile_id0;
                             const bool ok = ((T >> i) & 1u) && x < tile_lim;
                             const uint32_t wd = s_bm[ok ? x >> 5 : 0u];
-                            hit |= (ok && ((wd >> (x & 31u)) & 1u)) ? (1u << i) : 0u;
+                            const bool h1 = ok && ((wd >> (x & 31u)) & 1u);
+                            hit |= h1 ? (1u << i) : 0u;
+                            hx = h1 ? x : hx;
                         }
-                        if (hit) {
+                        // a wavefront step of a whole-structure query meets ~1.6 survivors among its ~450 postings: nearly every step has a hit somewhere, nearly never
+                        // two in one lane — one hit per lane is handled from hx; the sixteen-step walk below only when some lane holds two
+                        const bool multi = (hit & (hit - 1u)) != 0u;
+                        if (!__ballot(multi)) {
+                            if (hit) {
+                                const uint32_t wd = s_bm[hx >> 5];
+                                const uint32_t rk = s_rank[hx >> 5] + (uint32_t)__popc(wd & ((1u << (hx & 31u)) - 1u)) - s_lo;
+                                if (BIG) { if (rk < A.cap) atomicOr(&A.g_rowbits[(uint64_t)rk * wpr + ((uint32_t)add >> 5)], 1u << ((uint32_t)add & 31u)); }
+                                else if (rk < per_round) atomicOr(&s_rowbits[rk * wpr + ((uint32_t)add >> 5)], 1u << ((uint32_t)add & 31u));
+                            }
+                        } else if (hit) {
                             id = id_first;
 #pragma unroll
                             for (int i = 0; i < 16; ++i) {
