@@ -474,21 +474,49 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         need_rows();
     }
     if (e != hipSuccess) { free(ooff); c->err = std::string("count_query_batch workspace: ") + hipGetErrorString(e); return FDGPU_EHIP; }
-    (void)hipMemcpyAsync(c->ws[WS_MISC0].p, rows_hash.data(), nq * 4, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(c->ws[WS_MISC3].p, rows_meta.data(), nq * 8, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(c->ws[WS_TILE_H].p, q_off, (n_queries + 1) * 8, hipMemcpyHostToDevice, st);
+    // the rows' inputs: hashes, metadata, the queries' row ranges and — when the caller knows them — the rows' list positions.  The tiled motif path
+    // sends them up in ONE block packed in page-locked memory ([metadata | list positions | row ranges | hashes] in ws[WS_MISC3]): one copy launch, not four
+    uint32_t *d_qhash = c->ws[WS_MISC0].as<uint32_t>();
+    unsigned long long *d_meta = c->ws[WS_MISC3].as<unsigned long long>();
+    uint64_t *d_qoff = c->ws[WS_TILE_H].as<uint64_t>();
+    long long *d_kidx = c->ws[WS_CQ_KIDX].as<long long>();
+    const bool have_k = known_kidx && rows_kidx.size() == nq;
+    bool k_up = false;      // the list positions are on the device already
+    if (tiled) {
+        const size_t o_k = nq * 8, o_off = 2 * nq * 8, o_h = o_off + (n_queries + 1) * 8, up_bytes = o_h + nq * 4;
+        uint8_t *up = c->ws[WS_MISC3].ensure(up_bytes + 64) == hipSuccess ? (uint8_t *)c->host_pinned(5, up_bytes) : nullptr;
+        if (up) {
+            memcpy(up, rows_meta.data(), nq * 8);
+            if (have_k) memcpy(up + o_k, rows_kidx.data(), nq * 8);
+            memcpy(up + o_off, q_off, (n_queries + 1) * 8);
+            memcpy(up + o_h, rows_hash.data(), nq * 4);
+            uint8_t *d_blk = c->ws[WS_MISC3].as<uint8_t>();
+            d_meta = (unsigned long long *)d_blk; d_kidx = (long long *)(d_blk + o_k); d_qoff = (uint64_t *)(d_blk + o_off); d_qhash = (uint32_t *)(d_blk + o_h);
+            (void)hipMemcpyAsync(d_blk, up, up_bytes, hipMemcpyHostToDevice, st);
+            k_up = have_k;
+        } else {
+            (void)hipGetLastError();
+            if (c->ws[WS_MISC3].ensure(nq * 8) != hipSuccess) { free(ooff); c->err = "count_query_batch workspace"; return FDGPU_EHIP; }
+            d_meta = c->ws[WS_MISC3].as<unsigned long long>();
+        }
+    }
+    if (d_meta == c->ws[WS_MISC3].as<unsigned long long>() && d_qhash == c->ws[WS_MISC0].as<uint32_t>()) {
+        (void)hipMemcpyAsync(d_qhash, rows_hash.data(), nq * 4, hipMemcpyHostToDevice, st);
+        (void)hipMemcpyAsync(d_meta, rows_meta.data(), nq * 8, hipMemcpyHostToDevice, st);
+        (void)hipMemcpyAsync(d_qoff, q_off, (n_queries + 1) * 8, hipMemcpyHostToDevice, st);
+    }
     if (penalty) (void)hipMemcpyAsync(c->ws[WS_MISC5].p, penalty, S * 4, hipMemcpyHostToDevice, st);
     const float *d_penalty = penalty ? c->ws[WS_MISC5].as<float>() : ix->penalty;
     cq_args A;
     A.hashes = ix->hashes; A.offsets = ix->offsets; A.value = ix->value; A.H = ix->n_hashes;
-    A.q_hash = c->ws[WS_MISC0].as<uint32_t>(); A.nq = nq;
-    A.hash_bits = c->ws[WS_KEYS_B].as<uint32_t>(); A.row_meta = c->ws[WS_MISC3].as<unsigned long long>();
+    A.q_hash = d_qhash; A.nq = nq;
+    A.hash_bits = c->ws[WS_KEYS_B].as<uint32_t>(); A.row_meta = d_meta;
     A.match = c->ws[WS_COUNTS].as<uint32_t>(); A.idf = c->ws[WS_SEGOFF].as<unsigned long long>(); A.packed = packed ? 1 : 0;
     A.words = words; A.first_id = (uint32_t)ix->first_id; A.S = (uint32_t)S;
     qt_args T;
     if (tiled) {
         T.value = ix->value; T.offsets = ix->offsets; T.ck_meta = ix->ck_meta; T.ck_ent = (const uint2 *)ix->ck_ent;
-        T.kidx = c->ws[WS_CQ_KIDX].as<long long>(); T.row_meta = A.row_meta; T.q_rows = c->ws[WS_TILE_H].as<uint64_t>(); T.penalty = d_penalty;
+        T.kidx = d_kidx; T.row_meta = A.row_meta; T.q_rows = d_qoff; T.penalty = d_penalty;
         T.nq = (uint32_t)nq; T.n_queries = (uint32_t)n_queries; T.S = (uint32_t)S; T.first_id = (uint32_t)ix->first_id; T.NT = NT; T.tile_log2 = qt_tl2;
         T.NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
         T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.c_nid = c->ws[WS_QT_COMPACT].as<uint32_t>(); T.c_key = T.c_nid + ((size_t)n_queries * NT << qt_tl2);
@@ -518,7 +546,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
     std::vector<uint32_t> big_ends;
     if (tiled_big) {
         T.value = ix->value; T.offsets = ix->offsets; T.ck_meta = ix->ck_meta; T.ck_ent = (const uint2 *)ix->ck_ent;
-        T.kidx = c->ws[WS_CQ_KIDX].as<long long>(); T.row_meta = A.row_meta; T.q_rows = c->ws[WS_TILE_H].as<uint64_t>(); T.penalty = d_penalty;
+        T.kidx = d_kidx; T.row_meta = A.row_meta; T.q_rows = d_qoff; T.penalty = d_penalty;
         T.nq = (uint32_t)nq; T.n_queries = 1; T.S = (uint32_t)S; T.first_id = (uint32_t)ix->first_id; T.NT = NT14; T.tile_log2 = 14; T.plan_log2 = 14;
         T.NC = (uint32_t)((S + (1u << QT_CELL_LOG2) - 1) >> QT_CELL_LOG2);
         T.ranges = c->ws[WS_QT_RANGES].as<uint4>(); T.c_nid = c->ws[WS_QT_COMPACT].as<uint32_t>(); T.c_key = T.c_nid + ((size_t)NT14 << 14);
@@ -576,7 +604,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
             if (es != hipSuccess) slices.clear();
         }
         if (!keys_only)
-            fd_launch_cq_rows_finalize(A, c->ws[WS_TILE_H].as<uint64_t>(), (uint32_t)n_queries, slices.empty() ? nullptr : c->ws[WS_TILE_B].as<uint64_t>(),
+            fd_launch_cq_rows_finalize(A, d_qoff, (uint32_t)n_queries, slices.empty() ? nullptr : c->ws[WS_TILE_B].as<uint64_t>(),
                                        slices.empty() ? 0u : (uint32_t)slices.size() - 1, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(),
                                        c->ws[WS_MISC4].as<uint8_t>(), max_rows, st);
         if (!dense_topn)
@@ -602,11 +630,10 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         if (e2 == hipSuccess && tiled) {
             T.ghist = c->ws[WS_CQ_TOPN].as<uint32_t>(); T.state = c->ws[WS_MISC2].as<qt_state>(); T.out = c->ws[WS_KEYS_A].p; T.cap = cap;
             // (the rows' list positions are an input like their hashes: uploaded before the timed stage)
-            const bool have_k = known_kidx && rows_kidx.size() == nq;
-            if (have_k) (void)hipMemcpyAsync(c->ws[WS_CQ_KIDX].p, rows_kidx.data(), nq * 8, hipMemcpyHostToDevice, st);
+            if (have_k && !k_up) (void)hipMemcpyAsync(d_kidx, rows_kidx.data(), nq * 8, hipMemcpyHostToDevice, st);
             {
                 StageTimer t(c, "cq_batch", 0);
-                if (!have_k) fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
+                if (!have_k) fd_launch_cq_plan(A, d_kidx, c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
                 if (qt32) { fd_launch_qt_layout(T, st); fd_launch_qt_score32(T, st); }
                 else { fd_launch_qt_plan(T, st); fd_launch_qt_score(T, st); }
             }
@@ -636,11 +663,10 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
             }
         } else if (e2 == hipSuccess && tiled_big) {
             T.ghist = c->ws[WS_CQ_TOPN].as<uint32_t>(); T.state = c->ws[WS_MISC2].as<qt_state>(); T.out = c->ws[WS_KEYS_A].p;
-            const bool have_k = known_kidx && rows_kidx.size() == nq;
-            if (have_k) (void)hipMemcpyAsync(c->ws[WS_CQ_KIDX].p, rows_kidx.data(), nq * 8, hipMemcpyHostToDevice, st);
+            if (have_k && !k_up) (void)hipMemcpyAsync(d_kidx, rows_kidx.data(), nq * 8, hipMemcpyHostToDevice, st);
             {
                 StageTimer t(c, "cq_batch", 0);
-                if (!have_k) fd_launch_cq_plan(A, c->ws[WS_CQ_KIDX].as<long long>(), c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
+                if (!have_k) fd_launch_cq_plan(A, d_kidx, c->ws[WS_CQ_NSEG].as<uint32_t>(), st);
                 fd_launch_qt_plan(T, st);
                 fd_launch_qt_big_score(T, st);
             }
@@ -649,7 +675,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         } else if (e2 == hipSuccess) {
             StageTimer t(c, "cq_topn", 0);
             if (keys_only)      // keys in the compaction's position buffer, unused on this path
-                fd_launch_cq_topn_dense(A, c->ws[WS_TILE_H].as<uint64_t>(), d_penalty, c->ws[WS_TILE_BO].as<uint32_t>(), (uint32_t)n_queries, top_n, cap,
+                fd_launch_cq_topn_dense(A, d_qoff, d_penalty, c->ws[WS_TILE_BO].as<uint32_t>(), (uint32_t)n_queries, top_n, cap,
                                         c->ws[WS_KEYS_A].p, c->ws[WS_MISC2].p, c->ws[WS_CQ_TOPN].as<uint32_t>(), st);
             else
                 fd_launch_cq_topn_acc(A, d_penalty, c->ws[WS_IDS_A].as<uint32_t>(), c->ws[WS_IDS_B].as<uint32_t>(), (uint32_t)n_queries, top_n, cap,

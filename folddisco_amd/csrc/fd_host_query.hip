@@ -303,15 +303,14 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
     HIPCHK(c, c->ws[WS_RS_GQ].ensure(cap_pts * 4));      // gq | gr: one entry per residue pair (two points) each
     HIPCHK(c, c->ws[WS_RS_KOFF].ensure((cap_prob + 1) * 8 + cap_prob * 4));
     HIPCHK(c, c->ws[WS_RS_SOL].ensure(cap_prob * 18 * 4));
-    HIPCHK(c, c->ws[WS_RS_CNT].ensure((2 * RS_CNT_STRIDE + 8) * 8));
-    // [records per slot | slot bases + first residues (2 n_cand + 2) | match_off, res_off (n_queries + 1 each, 8-byte)] for the device-side ordering
+    HIPCHK(c, c->ws[WS_RS_CNT].ensure((2 * RS_CNT_STRIDE + 8) * 8 + (n_cand + 2) * 4));      // the counters, then the slots' record counts: zeroed by one fill
+    // [(records per slot: behind the counters) | slot bases + first residues (2 n_cand + 2) | match_off, res_off (n_queries + 1 each, 8-byte)] for the device-side ordering
     const size_t o_sm = 0, o_scr = o_sm + ((n_cand + 1) & ~(size_t)1), o_mo = (o_scr + 2 * n_cand + 2 + 1) & ~(size_t)1, o_ro = o_mo + 2 * (n_queries + 1),
                  ord_words = o_ro + 2 * (n_queries + 1);
     HIPCHK(c, c->ws[WS_RS_PLAN].ensure(ord_words * 4));
     uint32_t *d_ord = c->ws[WS_RS_PLAN].as<uint32_t>();
-    HIPCHK(c, hipMemsetAsync(d_ord + o_sm, 0, n_cand * 4, st));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_RS_TAB].p, blk, words * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(c->ws[WS_RS_CNT].p, 0, (2 * RS_CNT_STRIDE + 8) * 8, st));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_RS_CNT].p, 0, (2 * RS_CNT_STRIDE + 8) * 8 + n_cand * 4, st));
     const uint32_t *dblk = c->ws[WS_RS_TAB].as<uint32_t>();
     uint32_t *sg = c->ws[WS_RS_SEG].as<uint32_t>();
     uint32_t *d_cnt = sg, *d_seg = sg + 2 * (n_cand + 1), *d_cur = sg + 4 * (n_cand + 1), *d_pf = sg + 6 * (n_cand + 1), *d_pc = d_pf + nf_d;
@@ -322,7 +321,7 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
     memset(&A, 0, sizeof A);
     A.found = d_found; A.cands = d_cands; A.seg_f = d_seg; A.seg_c = d_seg + (n_cand + 1); A.perm_f = d_pf; A.perm_c = d_pc;
     A.cand = dblk + o_cd; A.slot_q = dblk + o_sq;
-    A.slot_matches = d_ord + o_sm;
+    A.slot_matches = (uint32_t *)(c->ws[WS_RS_CNT].as<unsigned long long>() + 2 * RS_CNT_STRIDE + 8);
     const bool rs_dbg = getenv("FDGPU_RS_DBG") != nullptr;      // phase clocks of the slots on stderr (measurement aid)
     A.dbg = rs_dbg ? c->ws[WS_RS_CNT].as<unsigned long long>() + 8 : nullptr;
     uint4 *dbg_slot = nullptr;
@@ -413,8 +412,7 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
             hipError_t e = c->ws[WS_RS_REC].ensure(std::max<uint64_t>(nm, 1) * sizeof(fd_match_rec));
             if (e == hipSuccess) e = c->ws[WS_RS_RECRES].ensure(std::max<uint64_t>(tot_res, 1) * 4);
             if (e == hipSuccess && nprob) {
-                e = hipMemcpyAsync(A.koff + nprob, &npts, 8, hipMemcpyHostToDevice, st);
-                fd_launch_rs_points(A, npts, st);
+                fd_launch_rs_points(A, nprob, npts, st);
                 fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd0, d_rot0, d_tran0, st);
                 fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot0, d_tran0, A.d0, d_met0, st);
             }
@@ -427,9 +425,13 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
             if (e == hipSuccess && nm && !dev_out) e = hipMemcpyAsync(om, c->ws[WS_RS_REC].p, nm * sizeof(fd_match_rec), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess && tot_res && !dev_out) e = hipMemcpyAsync(orr, c->ws[WS_RS_RECRES].p, tot_res * 4, hipMemcpyDeviceToHost, st);
             if (dev_out) { dev_out->got = true; dev_out->recs = c->ws[WS_RS_REC].p; dev_out->residues = c->ws[WS_RS_RECRES].as<int32_t>(); dev_out->n_recs = nm; dev_out->n_res = tot_res; }
-            if (e == hipSuccess) e = hipMemcpyAsync(omo, d_mo, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(oro, d_ro, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
+            // the two offset arrays lie side by side on the device: one copy into the context's page-locked block, parted on the host
+            uint64_t *off_land = d_ro == d_mo + (n_queries + 1) ? (uint64_t *)c->host_pinned(1, 2 * (n_queries + 1) * 8) : nullptr;
+            if (e == hipSuccess && off_land) e = hipMemcpyAsync(off_land, d_mo, 2 * (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && !off_land) e = hipMemcpyAsync(omo, d_mo, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && !off_land) e = hipMemcpyAsync(oro, d_ro, (n_queries + 1) * 8, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess && off_land) { memcpy(omo, off_land, (n_queries + 1) * 8); memcpy(oro, off_land + (n_queries + 1), (n_queries + 1) * 8); }
             if (e != hipSuccess) { fdgpu_free(om); fdgpu_free(orr); free(omo); free(oro); c->err = std::string("retrieve_batch records: ") + hipGetErrorString(e); return FDGPU_EHIP; }
             if (trace) fprintf(stderr, "[fdgpu_retrieve] device glue: scan %.3f ms (found %llu, cands %llu), group+slots %.3f, superpose + records ordered on the device + copy (%llu records, %llu problems) %.3f\n",
                                t_ms(T0, D1), (unsigned long long)nf_d, (unsigned long long)nc_d, t_ms(D1, D2), (unsigned long long)nm, (unsigned long long)nprob, t_ms(D2, t_now()));
@@ -444,8 +446,7 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
         rs_match_dev *hm = (rs_match_dev *)land;
         float *d_rmsd = c->ws[WS_RS_SOL].as<float>(), *d_rot = d_rmsd + nprob, *d_tran = d_rot + 9 * nprob, *d_met = d_tran + 3 * nprob;
         if (nprob) {
-            HIPCHK(c, hipMemcpyAsync(A.koff + nprob, &npts, 8, hipMemcpyHostToDevice, st));
-            fd_launch_rs_points(A, npts, st);
+            fd_launch_rs_points(A, nprob, npts, st);
             fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd, d_rot, d_tran, st);
             fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot, d_tran, A.d0, d_met, st);
             HIPCHK(c, hipGetLastError());

@@ -233,27 +233,33 @@ static int pair_features12(fdgpu_ctx *c, const fdgpu_batch *b, const uint32_t *p
     if (land_out) *land_out = nullptr;
     if (!n) return FDGPU_OK;
     hipStream_t st = c->stream;
-    HIPCHK(c, c->ws[WS_MISC0].ensure(n * 4));
-    HIPCHK(c, c->ws[WS_MISC1].ensure(n * 4));
-    HIPCHK(c, c->ws[WS_MISC2].ensure(n * 4 * FD_QF));
-    HIPCHK(c, c->ws[WS_MISC3].ensure(n));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, pi, n * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC1].p, pj, n * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_pair_features12, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, b->view(), c->ws[WS_MISC0].as<uint32_t>(),
-                       c->ws[WS_MISC1].as<uint32_t>(), (uint32_t)n, p->dist_cutoff, p->hash_type, c->ws[WS_MISC2].as<float>(), c->ws[WS_MISC3].as<uint8_t>());
+    // one block up ([pi | pj], packed in page-locked memory when it can be had) and one block down ([features | flags]): two copy launches per call, not four
+    HIPCHK(c, c->ws[WS_MISC0].ensure(2 * n * 4));
+    HIPCHK(c, c->ws[WS_MISC2].ensure(n * 4 * FD_QF + n));
+    uint32_t *d_pi = c->ws[WS_MISC0].as<uint32_t>(), *d_pj = d_pi + n;
+    uint8_t *d_valid = c->ws[WS_MISC2].as<uint8_t>() + n * 4 * FD_QF;
+    uint32_t *up = (uint32_t *)c->host_pinned(5, 2 * n * 4);
+    if (up) {
+        memcpy(up, pi, n * 4); memcpy(up + n, pj, n * 4);
+        HIPCHK(c, hipMemcpyAsync(d_pi, up, 2 * n * 4, hipMemcpyHostToDevice, st));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(d_pi, pi, n * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(d_pj, pj, n * 4, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(k_pair_features12, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, b->view(), d_pi, d_pj, (uint32_t)n, p->dist_cutoff, p->hash_type,
+                       c->ws[WS_MISC2].as<float>(), d_valid);
     HIPCHK(c, hipGetLastError());
-    // page-locked landing block (slot 4, read in place by the caller until its next call): the copies do not stage, one wait, no second copy
+    // page-locked landing block (slot 4, read in place by the caller until its next call): the copy does not stage, one wait, no second copy
     uint8_t *land = land_out ? (uint8_t *)c->host_pinned(4, n * 4 * FD_QF + n) : nullptr;
     if (land) {
-        HIPCHK(c, hipMemcpyAsync(land, c->ws[WS_MISC2].p, n * 4 * FD_QF, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipMemcpyAsync(land + n * 4 * FD_QF, c->ws[WS_MISC3].p, n, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(land, c->ws[WS_MISC2].p, n * 4 * FD_QF + n, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         *land_out = land;
         return FDGPU_OK;
     }
     if (land_out) return FDGPU_OK;      // no page-locked block: the caller asks again with its own arrays
     HIPCHK(c, hipMemcpyAsync(features, c->ws[WS_MISC2].p, n * 4 * FD_QF, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(valid, c->ws[WS_MISC3].p, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(valid, d_valid, n, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     return FDGPU_OK;
 }
@@ -492,31 +498,25 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             memcpy(up, vpairs.data(), nv * 4);
             memcpy(up + o_off, cand_off.data(), (n_queries + 1) * 8);
             HIPCHK(c, c->ws[WS_MISC0].ensure(up_words * 4));
-            HIPCHK(c, c->ws[WS_KEYS_A].ensure(nc * 4));
-            HIPCHK(c, c->ws[WS_MISC4].ensure(nc + 8));
+            // the chain's outputs in ONE device block laid out like the landing block — [len u64 | kidx i64 | hash u32 | nseg u32 | first u8] x nc —
+            // so that they come home in one copy launch (they were five)
+            HIPCHK(c, c->ws[WS_MISC1].ensure(nc * 25 + 64));
+            uint8_t *d_blk = c->ws[WS_MISC1].as<uint8_t>();
+            uint64_t *d_len = (uint64_t *)d_blk;
+            long long *d_kidx = (long long *)(d_blk + nc * 8);
+            uint32_t *d_hash = (uint32_t *)(d_blk + nc * 16), *d_nseg = (uint32_t *)(d_blk + nc * 20);
+            uint8_t *d_first = d_blk + nc * 24;
             HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC0].p, up, up_words * 4, hipMemcpyHostToDevice, st));
-            uint32_t *d_hash = c->ws[WS_KEYS_A].as<uint32_t>();
             hipLaunchKernelGGL(k_qm_expand_hash, dim3((unsigned)((nv + 63) / 64)), dim3(64), 0, st, c->ws[WS_MISC2].as<float>(), c->ws[WS_MISC0].as<uint32_t>(), (uint32_t)nv, P,
                                fd_make_consts(p).q, d_hash);
             if (dev_chain)
-                hipLaunchKernelGGL(k_qm_dedupe, dim3((unsigned)n_queries), dim3(256), 0, st, d_hash, (const uint64_t *)(c->ws[WS_MISC0].as<uint32_t>() + o_off),
-                                   c->ws[WS_MISC4].as<uint8_t>());
-            if (chain_len) {
-                HIPCHK(c, c->ws[WS_MISC1].ensure(nc * 8)); HIPCHK(c, c->ws[WS_CQ_KIDX].ensure(nc * 8)); HIPCHK(c, c->ws[WS_CQ_NSEG].ensure(nc * 4));
-                fd_launch_posting_lookup(index->hashes, index->offsets, index->lens, index->n_hashes, d_hash, nc, c->ws[WS_MISC1].as<uint64_t>(),
-                                         c->ws[WS_CQ_NSEG].as<uint32_t>(), c->ws[WS_CQ_KIDX].as<long long>(), st);
-            }
+                hipLaunchKernelGGL(k_qm_dedupe, dim3((unsigned)n_queries), dim3(256), 0, st, d_hash, (const uint64_t *)(c->ws[WS_MISC0].as<uint32_t>() + o_off), d_first);
+            if (chain_len) fd_launch_posting_lookup(index->hashes, index->offsets, index->lens, index->n_hashes, d_hash, nc, d_len, d_nseg, d_kidx, st);
             HIPCHK(c, hipGetLastError());
-            // landing block: [len u64 | kidx i64 | hash u32 | nseg u32 | first u8] x nc
             uint8_t *land = (uint8_t *)c->host_pinned(2, nc * 25 + 64);
             if (!land) { land_v.resize(nc * 25 + 64); land = land_v.data(); }
-            if (chain_len) {
-                HIPCHK(c, hipMemcpyAsync(land, c->ws[WS_MISC1].p, nc * 8, hipMemcpyDeviceToHost, st));
-                HIPCHK(c, hipMemcpyAsync(land + nc * 8, c->ws[WS_CQ_KIDX].p, nc * 8, hipMemcpyDeviceToHost, st));
-                HIPCHK(c, hipMemcpyAsync(land + nc * 20, c->ws[WS_CQ_NSEG].p, nc * 4, hipMemcpyDeviceToHost, st));
-            }
-            HIPCHK(c, hipMemcpyAsync(land + nc * 16, d_hash, nc * 4, hipMemcpyDeviceToHost, st));
-            if (dev_chain) HIPCHK(c, hipMemcpyAsync(land + nc * 24, c->ws[WS_MISC4].p, nc, hipMemcpyDeviceToHost, st));
+            if (chain_len) HIPCHK(c, hipMemcpyAsync(land, d_blk, nc * 25, hipMemcpyDeviceToHost, st));
+            else HIPCHK(c, hipMemcpyAsync(land + nc * 16, d_blk + nc * 16, dev_chain ? nc * 9 : nc * 4, hipMemcpyDeviceToHost, st));      // hashes (and first-insertion flags; the segment counts between them are not read)
             HIPCHK(c, hipStreamSynchronize(st));
             memcpy(hashes.data(), land + nc * 16, nc * 4);
             if (dev_chain) ch_first = land + nc * 24;

@@ -117,7 +117,7 @@ struct fdgpu_ctx {
     // pinned host buffers that outlive a call (the packed candidate pairs of a whole-structure retrieval: 2 x ~100 MB per call — as
     // malloc'd blocks their first-touch page faults and their munmap cost more than the copy)
     hipStream_t side_stream = nullptr;      // second stream of the fused query call: the ranked records travel to the host while the retrieval's kernels run
-    void *hbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // 0, 1: retrieval; 2, 3: landing / upload blocks of the query-map stage; 4: its pair features
+    void *hbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // 0, 1: retrieval; 2, 3: landing / upload blocks of the query-map stage; 4: its pair features; 5: their (i, j) upload
     size_t hbuf_cap[6] = {0, 0, 0, 0, 0, 0};
     void *host_pinned(int k, size_t bytes) {
         if (hbuf_cap[k] >= bytes) return hbuf[k];
@@ -539,7 +539,7 @@ struct rs_args {
 void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec *cands, uint64_t nc, uint32_t n_cand, uint32_t *cnt, uint32_t *seg, uint32_t *cur,
                         uint32_t *perm_f, uint32_t *perm_c, hipStream_t st);
 void fd_launch_rs_slots(const rs_args &A, uint32_t n_cand, hipStream_t st);
-void fd_launch_rs_points(const rs_args &A, uint64_t n_points, hipStream_t st);      // the [CA, CB] point lists of the problems k_rs_slots described (before k_superpose / k_metrics)
+void fd_launch_rs_points(const rs_args &A, uint64_t n_prob, uint64_t n_points, hipStream_t st);      // the [CA, CB] point lists of the problems k_rs_slots described and koff[n_prob] (before k_superpose / k_metrics)
 void fd_launch_rs_records(const void *matches, const void *plan, uint64_t n, const float *rmsd, const float *rot, const float *tran, const float *met,
                           const int32_t *residues, void *out, int32_t *out_res, hipStream_t st);
 // the same with the order made on the device: slot_matches -> per-slot bases, per-query offsets (match_off / res_off, n_queries + 1 each) -> every

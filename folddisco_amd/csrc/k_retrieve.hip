@@ -927,10 +927,12 @@ void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec
 }
 
 // one thread per residue pair of the superposition problems: its two points [CA, CB] of the target (kx) and of the query (ky)
+// (and the end of the last problem's points, koff[n_prob] — the host knows both totals from the counters it waited for: written here, not by an 8-byte copy)
 __global__ __launch_bounds__(256) void k_rs_points(const uint32_t *__restrict__ gq, const uint32_t *__restrict__ gr, uint64_t n_pairs, const float *__restrict__ db_ca,
                                                    const float *__restrict__ db_cb, const float *__restrict__ q_ca, const float *__restrict__ q_cb, float *__restrict__ kx,
-                                                   float *__restrict__ ky) {
+                                                   float *__restrict__ ky, uint64_t *__restrict__ koff_end, uint64_t n_points) {
     const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k == 0) *koff_end = n_points;
     if (k >= n_pairs) return;
     const uint64_t q = gq[k], r = gr[k];
     float a[6], b[6];
@@ -939,9 +941,10 @@ __global__ __launch_bounds__(256) void k_rs_points(const uint32_t *__restrict__ 
 #pragma unroll
     for (int z = 0; z < 6; ++z) { kx[6 * k + z] = a[z]; ky[6 * k + z] = b[z]; }
 }
-void fd_launch_rs_points(const rs_args &A, uint64_t n_points, hipStream_t st) {
+void fd_launch_rs_points(const rs_args &A, uint64_t n_prob, uint64_t n_points, hipStream_t st) {
     const uint64_t n_pairs = n_points / 2;
-    if (n_pairs) hipLaunchKernelGGL(k_rs_points, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, A.gq, A.gr, n_pairs, A.db_ca, A.db_cb, A.q_ca, A.q_cb, A.kx, A.ky);
+    hipLaunchKernelGGL(k_rs_points, dim3((unsigned)std::max<uint64_t>((n_pairs + 255) / 256, 1)), dim3(256), 0, st, A.gq, A.gr, n_pairs, A.db_ca, A.db_cb, A.q_ca, A.q_cb, A.kx,
+                       A.ky, A.koff + n_prob, n_points);
 }
 
 void fd_launch_rs_slots(const rs_args &A, uint32_t n_cand, hipStream_t st) {
