@@ -686,6 +686,13 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
         if (dev && dev->while_running && *dev->while_running) (*dev->while_running)();
         if (e2 == hipSuccess) e2 = hipMemcpyAsync(tstate.data(), c->ws[WS_MISC2].p, n_queries * 16, hipMemcpyDeviceToHost, st);
         if (e2 == hipSuccess && !dev) e2 = hipMemcpyAsync(rr, c->ws[WS_TILE_HO].p, (size_t)n_queries * top_n * sizeof(fd_count_rec), hipMemcpyDeviceToHost, st);
+        fd_count_rec *head = nullptr;      // the caller's candidates (fdgpu_query_batch: match_top per query) ride on the same wait
+        if (e2 == hipSuccess && dev && dev->head_n) {
+            const uint32_t mt = std::min(dev->head_n, top_n);
+            head = (fd_count_rec *)c->host_pinned(3, (size_t)n_queries * mt * sizeof(fd_count_rec));
+            if (head) e2 = hipMemcpy2DAsync(head, (size_t)mt * sizeof(fd_count_rec), c->ws[WS_TILE_HO].p, (size_t)top_n * sizeof(fd_count_rec), (size_t)mt * sizeof(fd_count_rec), n_queries,
+                                            hipMemcpyDeviceToHost, st);
+        }
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
         if (e2 == hipSuccess) e2 = hipGetLastError();
         if (e2 != hipSuccess) { free(ooff); fdgpu_free(rr); c->err = std::string("count_query_batch: ") + hipGetErrorString(e2); return FDGPU_EHIP; }
@@ -697,6 +704,7 @@ int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_qu
             free(ooff);
             dev->counts.resize(n_queries);
             for (uint64_t t = 0; t < n_queries; ++t) dev->counts[t] = tstate[4 * t + 3];
+            dev->head = head;
             dev->got = true; dev->overflow = overflow; dev->recs = c->ws[WS_TILE_HO].p; dev->state = c->ws[WS_MISC2].p; dev->top_n = top_n; dev->cap = cap;
             return FDGPU_OK;
         }

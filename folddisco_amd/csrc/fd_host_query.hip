@@ -303,17 +303,17 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
     HIPCHK(c, c->ws[WS_RS_GQ].ensure(cap_pts * 4));      // gq | gr: one entry per residue pair (two points) each
     HIPCHK(c, c->ws[WS_RS_KOFF].ensure((cap_prob + 1) * 8 + cap_prob * 4));
     HIPCHK(c, c->ws[WS_RS_SOL].ensure(cap_prob * 18 * 4));
-    HIPCHK(c, c->ws[WS_RS_CNT].ensure((2 * RS_CNT_STRIDE + 8) * 8 + (n_cand + 2) * 4));      // the counters, then the slots' record counts: zeroed by one fill
+    HIPCHK(c, c->ws[WS_RS_CNT].ensure((2 * RS_CNT_STRIDE + 8) * 8 + (3 * n_cand + 4) * 4));      // the counters, the slots' record counts, the grouping's counts: zeroed by one fill
     // [(records per slot: behind the counters) | slot bases + first residues (2 n_cand + 2) | match_off, res_off (n_queries + 1 each, 8-byte)] for the device-side ordering
     const size_t o_sm = 0, o_scr = o_sm + ((n_cand + 1) & ~(size_t)1), o_mo = (o_scr + 2 * n_cand + 2 + 1) & ~(size_t)1, o_ro = o_mo + 2 * (n_queries + 1),
                  ord_words = o_ro + 2 * (n_queries + 1);
     HIPCHK(c, c->ws[WS_RS_PLAN].ensure(ord_words * 4));
     uint32_t *d_ord = c->ws[WS_RS_PLAN].as<uint32_t>();
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_RS_TAB].p, blk, words * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(c->ws[WS_RS_CNT].p, 0, (2 * RS_CNT_STRIDE + 8) * 8 + n_cand * 4, st));
+    HIPCHK(c, hipMemsetAsync(c->ws[WS_RS_CNT].p, 0, (2 * RS_CNT_STRIDE + 8) * 8 + (3 * n_cand + 4) * 4, st));
     const uint32_t *dblk = c->ws[WS_RS_TAB].as<uint32_t>();
     uint32_t *sg = c->ws[WS_RS_SEG].as<uint32_t>();
-    uint32_t *d_cnt = sg, *d_seg = sg + 2 * (n_cand + 1), *d_cur = sg + 4 * (n_cand + 1), *d_pf = sg + 6 * (n_cand + 1), *d_pc = d_pf + nf_d;
+    uint32_t *d_cnt = (uint32_t *)(c->ws[WS_RS_CNT].as<unsigned long long>() + 2 * RS_CNT_STRIDE + 8) + (n_cand + 2), *d_seg = sg + 2 * (n_cand + 1), *d_cur = sg + 4 * (n_cand + 1), *d_pf = sg + 6 * (n_cand + 1), *d_pc = d_pf + nf_d;
     const fd_pair_rec *d_found = c->ws[WS_KEYS_A].as<fd_pair_rec>();
     const fd_cand_rec *d_cands = c->ws[WS_KEYS_B].as<fd_cand_rec>();
     fd_launch_rs_group(d_found, nf_d, d_cands, nc_d, (uint32_t)n_cand, d_cnt, d_seg, d_cur, d_pf, d_pc, st);
@@ -1107,6 +1107,7 @@ extern "C" int fdgpu_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, const fdgp
     const std::function<void()> build_prep = [&]() { fd_rb_prepare(n_queries, maps, ca_distance_cutoff, prep); prep_done = true; };
     fd_cq_dev_out D;
     D.while_running = &build_prep;
+    D.head_n = std::min(match_top, top_n);
     fd_count_rec *rr = nullptr;
     uint64_t *roff = nullptr;
     rc = fd_count_query_maps_top_impl(c, ix, n_queries, maps, penalty, total_structures, top_n, &rr, &roff, &D);
@@ -1127,13 +1128,17 @@ extern "C" int fdgpu_query_batch(fdgpu_ctx *c, const fdgpu_index *ix, const fdgp
         const uint32_t mt = std::min(match_top, top_n);
         std::vector<fd_count_rec> head_v;
         const size_t head_bytes = (size_t)n_queries * std::max<uint32_t>(mt, 1) * sizeof(fd_count_rec);
-        fd_count_rec *head = (fd_count_rec *)c->host_pinned(3, head_bytes);
-        if (!head) { head_v.resize((size_t)n_queries * std::max<uint32_t>(mt, 1)); head = head_v.data(); }
+        const fd_count_rec *head = D.head;       // came with the selection's state (one wait)
         hipError_t e = hipSuccess;
-        if (mt && n_queries)
-            e = hipMemcpy2DAsync(head, (size_t)mt * sizeof(fd_count_rec), D.recs, (size_t)top_n * sizeof(fd_count_rec), (size_t)mt * sizeof(fd_count_rec), n_queries,
-                                 hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (!head) {
+            fd_count_rec *h2 = (fd_count_rec *)c->host_pinned(3, head_bytes);
+            if (!h2) { head_v.resize((size_t)n_queries * std::max<uint32_t>(mt, 1)); h2 = head_v.data(); }
+            if (mt && n_queries)
+                e = hipMemcpy2DAsync(h2, (size_t)mt * sizeof(fd_count_rec), D.recs, (size_t)top_n * sizeof(fd_count_rec), (size_t)mt * sizeof(fd_count_rec), n_queries,
+                                     hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            head = h2;
+        }
         // the full ranking: straight into the caller's (page-locked, pooled) array on the second stream, closed up after the retrieval
         rr = (fd_count_rec *)fd_out_alloc(std::max<uint64_t>((uint64_t)n_queries * top_n, 1) * sizeof(fd_count_rec), true);
         roff = (uint64_t *)calloc(n_queries + 1, 8);

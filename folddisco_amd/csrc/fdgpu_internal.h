@@ -240,6 +240,8 @@ struct fd_cq_dev_out {
     bool got = false, overflow = false; const void *recs = nullptr; const void *state = nullptr; uint32_t top_n = 0, cap = 0;
     std::vector<uint32_t> counts;                          // got: records selected per query (before the cut to top_n)
     const std::function<void()> *while_running = nullptr;  // host work of the caller, run once between the scoring launches and the wait for them
+    uint32_t head_n = 0;                                   // in: the first head_n records of every query's ranking are wanted on the host as well ...
+    const fd_count_rec *head = nullptr;                    // ... got: [n_queries][min(head_n, top_n)] in the context's page-locked block 3 (same wait as the state), or null
 };
 int fd_count_query_batch_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const uint64_t *q_off, const uint32_t *q_hash,
                               const uint32_t *q_node, const uint32_t *q_edge_j, const float *q_idf, const float *penalty, uint32_t top_n,

@@ -917,8 +917,7 @@ __global__ __launch_bounds__(FD_WAVE) void k_rs_comp(rs_args A) {
 
 void fd_launch_rs_group(const fd_pair_rec *found, uint64_t nf, const fd_cand_rec *cands, uint64_t nc, uint32_t n_cand, uint32_t *cnt, uint32_t *seg, uint32_t *cur,
                         uint32_t *perm_f, uint32_t *perm_c, hipStream_t st) {
-    const uint64_t n = nf + nc;
-    (void)hipMemsetAsync(cnt, 0, (size_t)2 * (n_cand + 1) * 4, st);
+    const uint64_t n = nf + nc;      // (cnt[2 (n_cand + 1)] arrives zeroed: the caller's one fill covers it together with the glue's counters)
     if (n) hipLaunchKernelGGL(k_rs_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, found, nf, cands, nc, n_cand, cnt);
     hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, st, cnt, n_cand, seg, cur);
     if (n) hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, found, nf, cands, nc, n_cand, cur, perm_f, perm_c);
