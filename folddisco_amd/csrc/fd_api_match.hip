@@ -568,7 +568,7 @@ extern "C" int fdgpu_metrics_batch(fdgpu_ctx *c, const float *ref, const float *
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC4].p, rot, n * 36, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC5].p, tran, n * 12, hipMemcpyHostToDevice, st));
     fd_launch_metrics(c->ws[WS_MISC0].as<float>(), c->ws[WS_MISC1].as<float>(), c->ws[WS_MISC2].as<uint64_t>(), n, c->ws[WS_MISC4].as<float>(),
-                      c->ws[WS_MISC5].as<float>(), c->ws[WS_MISC3].as<float>(), c->ws[WS_TILE_PO].as<float>(), st);
+                      c->ws[WS_MISC5].as<float>(), c->ws[WS_MISC3].as<float>(), c->ws[WS_TILE_PO].as<float>(), st, npts);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(metrics, c->ws[WS_TILE_PO].p, n * 20, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -596,7 +596,7 @@ extern "C" int fdgpu_kabsch_batch(fdgpu_ctx *c, const float *x, const float *y, 
     }
     HIPCHK(c, hipMemcpyAsync(c->ws[WS_MISC2].p, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
     fd_launch_kabsch(c->ws[WS_MISC0].as<float>(), c->ws[WS_MISC1].as<float>(), c->ws[WS_MISC2].as<uint64_t>(), n, c->ws[WS_MISC3].as<float>(),
-                     c->ws[WS_MISC4].as<float>(), c->ws[WS_MISC5].as<float>(), st);
+                     c->ws[WS_MISC4].as<float>(), c->ws[WS_MISC5].as<float>(), st, npts);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(rmsd, c->ws[WS_MISC3].p, n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(rot, c->ws[WS_MISC4].p, n * 36, hipMemcpyDeviceToHost, st));

@@ -413,8 +413,8 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
             if (e == hipSuccess) e = c->ws[WS_RS_RECRES].ensure(std::max<uint64_t>(tot_res, 1) * 4);
             if (e == hipSuccess && nprob) {
                 fd_launch_rs_points(A, nprob, npts, st);
-                fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd0, d_rot0, d_tran0, st);
-                fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot0, d_tran0, A.d0, d_met0, st);
+                fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd0, d_rot0, d_tran0, st, npts);
+                fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot0, d_tran0, A.d0, d_met0, st, npts);
             }
             uint64_t *d_mo = (uint64_t *)(d_ord + o_mo), *d_ro = (uint64_t *)(d_ord + o_ro);
             if (e == hipSuccess) {
@@ -447,8 +447,8 @@ static int fd_rb_device_glue(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t 
         float *d_rmsd = c->ws[WS_RS_SOL].as<float>(), *d_rot = d_rmsd + nprob, *d_tran = d_rot + 9 * nprob, *d_met = d_tran + 3 * nprob;
         if (nprob) {
             fd_launch_rs_points(A, nprob, npts, st);
-            fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd, d_rot, d_tran, st);
-            fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot, d_tran, A.d0, d_met, st);
+            fd_launch_kabsch(A.kx, A.ky, A.koff, nprob, d_rmsd, d_rot, d_tran, st, npts);
+            fd_launch_metrics(A.ky, A.kx, A.koff, nprob, d_rot, d_tran, A.d0, d_met, st, npts);
             HIPCHK(c, hipGetLastError());
         }
         if (nm) {

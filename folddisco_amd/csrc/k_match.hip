@@ -724,8 +724,10 @@ void fd_launch_match_pairs(const mp_args &A, hipStream_t st) {
 // rmsd -> f32::MAX (kabsch.rs:537-553).
 struct sp_sym3 { double xx, xy, yy, xz, yz, zz; };   // packed symmetric 3x3 (upper triangle by columns)
 
+template <int G = 64>
 __device__ __forceinline__ double sp_wave_sum(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 // eigenvalues of a positive semi-definite symmetric 3x3 (trigonometric form of the cubic), descending
@@ -787,19 +789,20 @@ __device__ __forceinline__ bool sp_orthonormal(const double u[3], double w[3]) {
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_superpose(const float *__restrict__ xs, const float *__restrict__ ys, const uint64_t *__restrict__ off, uint64_t n_prob,
-                                                  float *__restrict__ rmsd_out, float *__restrict__ rot_out, float *__restrict__ tran_out) {
-    const uint64_t prob = blockIdx.x;
-    if (prob >= n_prob) return;
-    const uint32_t lane = threadIdx.x;
-    const uint64_t p0 = off[prob], n = off[prob + 1] - p0;
+// G = the lanes that own the problem: 64 (the wavefront), or 16 — four problems of at most 16 points side by side.  A point sits in the lane of its
+// index either way and the other lanes add +0.0, so the butterfly's steps over 32 and 16 lanes change nothing: the sums of a small problem are the
+// same bits in both forms (the 3x3 algebra ran redundantly in every lane already: four problems' worth costs what one did).
+template <int G>
+__device__ __forceinline__ void sp_superpose(const float *__restrict__ xs, const float *__restrict__ ys, const uint64_t *__restrict__ off, uint64_t prob, bool live, uint32_t lane,
+                                             float *__restrict__ rmsd_out, float *__restrict__ rot_out, float *__restrict__ tran_out) {
+    const uint64_t p0 = live ? off[prob] : 0, n = live ? off[prob + 1] - p0 : 0;
     const float *x = xs + 3 * p0, *y = ys + 3 * p0;
     double U[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, T[3] = {0, 0, 0};
     float rms = 3.40282347e+38f;
     if (n > 0) {
         // centroid sums and the raw second moments  S[a][b] = sum x_a y_b
         double sx[3] = {0, 0, 0}, sy[3] = {0, 0, 0}, S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        for (uint64_t i = lane; i < n; i += 64) {
+        for (uint64_t i = lane; i < n; i += G) {
             const double xv[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]}, yv[3] = {y[3 * i], y[3 * i + 1], y[3 * i + 2]};
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -810,9 +813,9 @@ __global__ __launch_bounds__(64) void k_superpose(const float *__restrict__ xs, 
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            sx[a] = sp_wave_sum(sx[a]); sy[a] = sp_wave_sum(sy[a]);
+            sx[a] = sp_wave_sum<G>(sx[a]); sy[a] = sp_wave_sum<G>(sy[a]);
 #pragma unroll
-            for (int b = 0; b < 3; ++b) S[a][b] = sp_wave_sum(S[a][b]);
+            for (int b = 0; b < 3; ++b) S[a][b] = sp_wave_sum<G>(S[a][b]);
         }
         const double dn = (double)n;
         const double xc[3] = {sx[0] / dn, sx[1] / dn, sx[2] / dn}, yc[3] = {sy[0] / dn, sy[1] / dn, sy[2] / dn};
@@ -875,16 +878,16 @@ __global__ __launch_bounds__(64) void k_superpose(const float *__restrict__ xs, 
 #pragma unroll
             for (int r = 0; r < 3; ++r) T[r] = yc[r] - (U[r][0] * xc[0] + U[r][1] * xc[1] + U[r][2] * xc[2]);
         double ss = 0.0;
-        for (uint64_t i = lane; i < n; i += 64) {
+        for (uint64_t i = lane; i < n; i += G) {
             const double X = x[3 * i], Y = x[3 * i + 1], Z = x[3 * i + 2];
 #pragma unroll
             for (int r = 0; r < 3; ++r) { const double d = U[r][0] * X + U[r][1] * Y + U[r][2] * Z + T[r] - (double)y[3 * i + r]; ss += d * d; }
         }
-        ss = sp_wave_sum(ss);
+        ss = sp_wave_sum<G>(ss);
         rms = (float)sqrt(ss / dn);
         if (rms != rms) rms = 3.40282347e+38f;
     }
-    if (lane != 0) return;
+    if (lane != 0 || !live) return;
     rmsd_out[prob] = rms;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -892,6 +895,22 @@ __global__ __launch_bounds__(64) void k_superpose(const float *__restrict__ xs, 
         for (int cc = 0; cc < 3; ++cc) rot_out[9 * prob + 3 * r + cc] = (float)U[r][cc];
         tran_out[3 * prob + r] = (float)T[r];
     }
+}
+
+__global__ __launch_bounds__(64) void k_superpose(const float *__restrict__ xs, const float *__restrict__ ys, const uint64_t *__restrict__ off, uint64_t n_prob,
+                                                  float *__restrict__ rmsd_out, float *__restrict__ rot_out, float *__restrict__ tran_out) {
+    if (blockIdx.x < n_prob) sp_superpose<64>(xs, ys, off, blockIdx.x, true, threadIdx.x, rmsd_out, rot_out, tran_out);
+}
+// four problems per wavefront when all four are small (motif batches: ~10 points per problem, 10-20 k problems per 128 queries — a wavefront each was
+// 40 us of a batch's kernels); a group with a larger one runs its four one after the other on the whole wavefront
+__global__ __launch_bounds__(64) void k_superpose4(const float *__restrict__ xs, const float *__restrict__ ys, const uint64_t *__restrict__ off, uint64_t n_prob,
+                                                   float *__restrict__ rmsd_out, float *__restrict__ rot_out, float *__restrict__ tran_out) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t base = 4ull * blockIdx.x, mine = base + (lane >> 4);
+    const bool live = mine < n_prob;
+    const bool small = !live || off[mine + 1] - off[mine] <= 16u;
+    if (__all(small)) { sp_superpose<16>(xs, ys, off, mine, live, lane & 15u, rmsd_out, rot_out, tran_out); return; }
+    for (uint64_t k = base; k < base + 4u && k < n_prob; ++k) sp_superpose<64>(xs, ys, off, k, true, lane, rmsd_out, rot_out, tran_out);
 }
 
 // Similarity metrics of a superposition (metrics.rs:62-251 on KabschSuperimposer's reference / transformed coordinates,
@@ -902,12 +921,11 @@ __device__ __forceinline__ float sp_dist(const float *__restrict__ ref, uint64_t
     const double dx = (double)ref[3 * r] - (double)tx, dy = (double)ref[3 * r + 1] - (double)ty, dz = (double)ref[3 * r + 2] - (double)tz;
     return (float)sqrt(dx * dx + dy * dy + dz * dz);
 }
-__global__ __launch_bounds__(64) void k_metrics(const float *__restrict__ refs, const float *__restrict__ movs, const uint64_t *__restrict__ off, uint64_t n_prob,
-                                                const float *__restrict__ rot, const float *__restrict__ tran, const float *__restrict__ d0s,
-                                                float *__restrict__ out) {
-    const uint64_t prob = blockIdx.x;
-    if (prob >= n_prob) return;
-    const uint32_t lane = threadIdx.x;
+// (G lanes per problem as in sp_superpose: the sums, counts and maxima of a problem of at most 16 points are the same bits in both forms)
+template <int G>
+__device__ __forceinline__ void sp_metrics(const float *__restrict__ refs, const float *__restrict__ movs, const uint64_t *__restrict__ off, uint64_t prob, bool live, uint32_t lane,
+                                           const float *__restrict__ rot, const float *__restrict__ tran, const float *__restrict__ d0s, float *__restrict__ out) {
+    if (!live) return;      // (a group's lanes share `live` and n: the shuffles below stay inside the group)
     const uint64_t p0 = off[prob], n = off[prob + 1] - p0;
     float *o = out + 5 * prob;
     if (n == 0) { if (lane == 0) { o[0] = o[1] = o[2] = 0.0f; o[3] = o[4] = __builtin_inff(); } return; }
@@ -917,7 +935,7 @@ __global__ __launch_bounds__(64) void k_metrics(const float *__restrict__ refs, 
     double tm = 0.0, ch = 0.0;
     float hd = -1.0f;
     uint32_t c_ts[4] = {0, 0, 0, 0}, c_ha[4] = {0, 0, 0, 0};
-    for (uint64_t i = lane; i < n; i += 64) {
+    for (uint64_t i = lane; i < n; i += G) {
         const float mx = mov[3 * i], my = mov[3 * i + 1], mz = mov[3 * i + 2];
         const float tx = (Rm[0] * mx + Rm[1] * my + Rm[2] * mz) + Tv[0];
         const float ty = (Rm[3] * mx + Rm[4] * my + Rm[5] * mz) + Tv[1];
@@ -943,8 +961,9 @@ __global__ __launch_bounds__(64) void k_metrics(const float *__restrict__ refs, 
         ch += (double)mn;
         hd = fmaxf(hd, mn);
     }
-    tm = sp_wave_sum(tm); ch = sp_wave_sum(ch);
-    for (int ofs = 32; ofs > 0; ofs >>= 1) {
+    tm = sp_wave_sum<G>(tm); ch = sp_wave_sum<G>(ch);
+#pragma unroll
+    for (int ofs = G / 2; ofs > 0; ofs >>= 1) {
         hd = fmaxf(hd, __shfl_xor(hd, ofs));
 #pragma unroll
         for (int k = 0; k < 4; ++k) { c_ts[k] += __shfl_xor(c_ts[k], ofs); c_ha[k] += __shfl_xor(c_ha[k], ofs); }
@@ -959,12 +978,36 @@ __global__ __launch_bounds__(64) void k_metrics(const float *__restrict__ refs, 
     o[4] = hd;
 }
 
-void fd_launch_kabsch(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_superpose, dim3((unsigned)n), dim3(64), 0, st, x, y, off, n, rmsd, rot, tran);
+__global__ __launch_bounds__(64) void k_metrics(const float *__restrict__ refs, const float *__restrict__ movs, const uint64_t *__restrict__ off, uint64_t n_prob,
+                                                const float *__restrict__ rot, const float *__restrict__ tran, const float *__restrict__ d0s,
+                                                float *__restrict__ out) {
+    if (blockIdx.x < n_prob) sp_metrics<64>(refs, movs, off, blockIdx.x, true, threadIdx.x, rot, tran, d0s, out);
+}
+__global__ __launch_bounds__(64) void k_metrics4(const float *__restrict__ refs, const float *__restrict__ movs, const uint64_t *__restrict__ off, uint64_t n_prob,
+                                                 const float *__restrict__ rot, const float *__restrict__ tran, const float *__restrict__ d0s,
+                                                 float *__restrict__ out) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t base = 4ull * blockIdx.x, mine = base + (lane >> 4);
+    const bool live = mine < n_prob;
+    const bool small = !live || off[mine + 1] - off[mine] <= 16u;
+    if (__all(small)) { sp_metrics<16>(refs, movs, off, mine, live, lane & 15u, rot, tran, d0s, out); return; }
+    for (uint64_t k = base; k < base + 4u && k < n_prob; ++k) sp_metrics<64>(refs, movs, off, k, true, lane, rot, tran, d0s, out);
+}
+
+// n_points = the problems' points in all when the caller knows them (0: not known): batches of small problems (16 points a problem or fewer on average)
+// take the four-per-wavefront kernels
+// (FDGPU_SP_PACK=0: a wavefront per problem always — read per call: tests compare the two forms bit for bit)
+static bool sp_pack_on() { const char *e = getenv("FDGPU_SP_PACK"); return !(e && e[0] == '0'); }
+void fd_launch_kabsch(const float *x, const float *y, const uint64_t *off, uint64_t n, float *rmsd, float *rot, float *tran, hipStream_t st, uint64_t n_points) {
+    if (!n) return;
+    if (n_points && n_points <= 16 * n && sp_pack_on()) hipLaunchKernelGGL(k_superpose4, dim3((unsigned)((n + 3) / 4)), dim3(64), 0, st, x, y, off, n, rmsd, rot, tran);
+    else hipLaunchKernelGGL(k_superpose, dim3((unsigned)n), dim3(64), 0, st, x, y, off, n, rmsd, rot, tran);
 }
 void fd_launch_metrics(const float *ref, const float *mov, const uint64_t *off, uint64_t n, const float *rot, const float *tran, const float *d0, float *out,
-                       hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_metrics, dim3((unsigned)n), dim3(64), 0, st, ref, mov, off, n, rot, tran, d0, out);
+                       hipStream_t st, uint64_t n_points) {
+    if (!n) return;
+    if (n_points && n_points <= 16 * n && sp_pack_on()) hipLaunchKernelGGL(k_metrics4, dim3((unsigned)((n + 3) / 4)), dim3(64), 0, st, ref, mov, off, n, rot, tran, d0, out);
+    else hipLaunchKernelGGL(k_metrics, dim3((unsigned)n), dim3(64), 0, st, ref, mov, off, n, rot, tran, d0, out);
 }
 
 // ------------------------------------------------------------------------------------------ LMS-QCP partial fit

@@ -620,6 +620,48 @@ def test_kabsch_large_problems_wave_path(ctx):
 
 
 @pytest.mark.gpu
+def test_small_superpositions_four_to_a_wavefront_equal_the_wavefront_form(ctx, monkeypatch):
+    """Batches of small problems (<= 16 points on average) run four to a wavefront (k_superpose4 / k_metrics4): same bits as a wavefront per
+    problem (FDGPU_SP_PACK=0) — including groups of four that hold a larger problem (run one after the other), empty problems, degenerate inputs
+    and a problem count that is not a multiple of four — and within the oracle's tolerance."""
+    from folddisco_amd import match
+    rng = np.random.default_rng(17)
+    sizes = [int(v) for v in rng.integers(0, 17, size=397)]
+    sizes[5] = 40; sizes[6] = 0; sizes[100] = 17; sizes[101] = 16; sizes[396] = 64        # a few groups of four take the sequential path
+    probs = []
+    for k, n in enumerate(sizes):
+        y = (rng.normal(size=(n, 3)) * 9).astype(np.float32)
+        if k % 29 == 3 and n:
+            x = np.repeat(y[:1], n, axis=0)                                               # every moving point the same
+        elif k % 31 == 4 and n > 2:
+            x = (y[0] + np.outer(np.arange(n), [1.0, 0.5, -0.25])).astype(np.float32)     # collinear
+        else:
+            x = (y + rng.normal(size=(n, 3)) * rng.choice([0.1, 1.0, 5.0])).astype(np.float32)
+        probs.append((x, y))
+    xs = np.concatenate([p[0] for p in probs]); ys = np.concatenate([p[1] for p in probs])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    assert off[-1] <= 16 * len(sizes)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FDGPU_SP_PACK", mode)
+        rmsd, rot, tran = match.kabsch_batch(ctx, xs, ys, off)
+        met = match.metrics_batch(ctx, ys, xs, off, rot, tran)
+        res[mode] = (rmsd, rot, tran, met)
+    monkeypatch.delenv("FDGPU_SP_PACK")
+    for a, b in zip(res["1"], res["0"]):
+        assert a.tobytes() == b.tobytes()
+    rmsd, rot, tran, met = res["1"]
+    for k in range(0, len(probs), 7):
+        x, y = probs[k]
+        if len(x) == 0:
+            continue
+        r, R, T = oracle.kabsch(x, y)
+        assert (abs(rmsd[k] - r) <= 1e-4 * max(1.0, abs(r))) or (rmsd[k] == r), (k, rmsd[k], r)
+        want = oracle.metrics(y, x, rot[k].reshape(9), tran[k])
+        assert np.allclose(met[k], want, rtol=1e-6, atol=1e-6), (k, len(x), met[k], want)
+
+
+@pytest.mark.gpu
 def test_device_merge_of_loaded_indices(ctx):
     """parts that came through fdgpu_index_load carry no per-list last ids: the merge computes them with one decode pass"""
     import folddisco_amd as fd
