@@ -800,6 +800,10 @@ static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uin
             }
             std::unordered_map<uint64_t, uint32_t> vote_at;     // (q, r) -> position in votes (first-seen order kept in the vector)
             for (size_t e = 0; e < g.es.size(); ++e) {
+                if (e + 16 < g.es.size() && edge_k[e + 16] >= 0) {      // the map's arrays of a whole-structure query are ~1 MB: a miss per edge and array otherwise
+                    const int32_t k2 = edge_k[e + 16];
+                    __builtin_prefetch(&qm->idf[k2]); __builtin_prefetch(&qm->qi[k2]); __builtin_prefetch(&qm->qj[k2]);
+                }
                 if (!inc[g.es[e]] || !inc[g.et[e]] || edge_k[e] < 0) continue;
                 const uint32_t k = (uint32_t)edge_k[e];
                 sub_idf += qm->idf[k];                      // calculate_subgraph_idf (retrieve.rs:705-719)

@@ -310,6 +310,11 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     auto q_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - q_t0).count(); };
     std::vector<uint32_t> pi, pj;
     std::vector<uint64_t> pair_off(n_queries + 1, 0);
+    {       // (a whole-structure query lists ~10^5 pairs: growing the two arrays by doubling was a third of this stage)
+        uint64_t n_pairs_max = 0;
+        for (uint64_t t = 0; t < n_queries; ++t) { const uint64_t n_q = q_off[t + 1] - q_off[t]; n_pairs_max += n_q * (n_q ? n_q - 1 : 0); }
+        pi.reserve(n_pairs_max); pj.reserve(n_pairs_max);
+    }
     for (uint64_t t = 0; t < n_queries; ++t) {
         const uint64_t r0 = qb->h_res_off[q_struct[t]], R = qb->h_res_off[q_struct[t] + 1] - r0;
         const uint32_t *qi = q_index + q_off[t];
@@ -412,6 +417,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             for (uint64_t a = 0; a < n_q; ++a)
                 if (subs[q_off[t] + a]) sub_of[qidx[a]] = std::make_pair(subs[q_off[t] + a], n_subs[q_off[t] + a]);
         Aad &A = aads[t];
+        { const size_t n_p = (size_t)(pair_off[t + 1] - pair_off[t]); A.a1.reserve(n_p); A.a2.reserve(n_p); A.ad.reserve(n_p); A.aq.reserve(n_p); }
         for (uint64_t k = pair_off[t]; k < pair_off[t + 1]; ++k) {
             if (!valid[k]) continue;
             const float *f = &feat[(size_t)FD_QF * k];
