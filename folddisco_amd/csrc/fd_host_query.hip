@@ -5,6 +5,7 @@
 //   fdgpu_query_batch      query maps (fd_query_map.hip), ranked scoring and retrieval of the top candidates in one call
 //   fdgpu_merge_subindices, fdgpu_hypergeom_enrichment
 // The reference is compiled code, so this glue is C++ behind the same C ABI; it contains no f32 arithmetic that decides a hash bit.
+#include <array>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -62,26 +63,35 @@ struct Graph {
     }
 };
 
-// SCCs (Tarjan) and weakly connected components, as sorted node lists (graph.rs:29-50)
+// SCCs (Tarjan) and weakly connected components of at least min_nodes nodes, as sorted node lists, sorted and without duplicates (graph.rs:29-50).
+// Flat arrays throughout: a 2,500-residue candidate of a whole-structure query has ~2,500 nodes, nearly all of them components of one node — a vector
+// per node's neighbours and a map entry + a vector per component were 0.5 ms of such a slot
 static std::vector<std::vector<uint32_t>> components(const Graph &g, size_t min_nodes) {
     const uint32_t n = (uint32_t)g.w.size();
-    std::vector<std::vector<uint32_t>> adj(n);
-    for (size_t e = 0; e < g.es.size(); ++e) adj[g.es[e]].push_back(g.et[e]);
+    const size_t E = g.es.size();
+    std::vector<uint32_t> a_off(n + 1, 0), a_to(E);
+    for (size_t e = 0; e < E; ++e) ++a_off[g.es[e] + 1];
+    for (uint32_t v = 0; v < n; ++v) a_off[v + 1] += a_off[v];
+    {
+        std::vector<uint32_t> cur(a_off.begin(), a_off.end() - 1);
+        for (size_t e = 0; e < E; ++e) a_to[cur[g.es[e]]++] = g.et[e];       // a node's neighbours in edge order
+    }
     std::vector<int> idx(n, -1), low(n, 0), comp(n, -1);
     std::vector<char> on(n, 0);
     std::vector<uint32_t> stk;
     int counter = 0, ncomp = 0;
-    struct Fr { uint32_t v; size_t it; };
+    struct Fr { uint32_t v; uint32_t it; };
+    std::vector<Fr> cs;
     for (uint32_t root = 0; root < n; ++root) {
         if (idx[root] >= 0) continue;
-        std::vector<Fr> cs;
-        cs.push_back({root, 0});
+        cs.clear();
+        cs.push_back({root, a_off[root]});
         idx[root] = low[root] = counter++; stk.push_back(root); on[root] = 1;
         while (!cs.empty()) {
             Fr &f = cs.back();
-            if (f.it < adj[f.v].size()) {
-                uint32_t x = adj[f.v][f.it++];
-                if (idx[x] < 0) { idx[x] = low[x] = counter++; stk.push_back(x); on[x] = 1; cs.push_back({x, 0}); }
+            if (f.it < a_off[f.v + 1]) {
+                uint32_t x = a_to[f.it++];
+                if (idx[x] < 0) { idx[x] = low[x] = counter++; stk.push_back(x); on[x] = 1; cs.push_back({x, a_off[x]}); }
                 else if (on[x]) low[f.v] = std::min(low[f.v], idx[x]);
             } else {
                 uint32_t v = f.v;
@@ -98,13 +108,25 @@ static std::vector<std::vector<uint32_t>> components(const Graph &g, size_t min_
     std::vector<uint32_t> uf(n);
     for (uint32_t v = 0; v < n; ++v) uf[v] = v;
     auto find = [&](uint32_t x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; };
-    for (size_t e = 0; e < g.es.size(); ++e) { uint32_t a = find(g.es[e]), b = find(g.et[e]); if (a != b) uf[a] = b; }
-    std::map<int, std::vector<uint32_t>> by_scc, by_wcc;
-    for (uint32_t v = 0; v < n; ++v) { by_scc[comp[v]].push_back(v); by_wcc[(int)find(v)].push_back(v); }
+    for (size_t e = 0; e < E; ++e) { uint32_t a = find(g.es[e]), b = find(g.et[e]); if (a != b) uf[a] = b; }
+    // the sets of at least min_nodes nodes, their nodes ascending (a walk over the nodes in order); the result is the SORTED list of sets without
+    // duplicates, so the order they are gathered in does not matter
     std::vector<std::vector<uint32_t>> all;
-    for (auto &kv : by_scc) if (kv.second.size() >= min_nodes) all.push_back(kv.second);
-    for (auto &kv : by_wcc) if (kv.second.size() >= min_nodes) all.push_back(kv.second);
-    for (auto &cc : all) std::sort(cc.begin(), cc.end());
+    auto gather = [&](const std::vector<uint32_t> &label, uint32_t n_labels) {
+        std::vector<uint32_t> size(n_labels, 0), at(n_labels, 0xffffffffu);
+        for (uint32_t v = 0; v < n; ++v) ++size[label[v]];
+        for (uint32_t v = 0; v < n; ++v) {
+            const uint32_t l = label[v];
+            if (size[l] < min_nodes || size[l] == 0) continue;
+            if (at[l] == 0xffffffffu) { at[l] = (uint32_t)all.size(); all.emplace_back(); all.back().reserve(size[l]); }
+            all[at[l]].push_back(v);
+        }
+    };
+    std::vector<uint32_t> label(n);
+    for (uint32_t v = 0; v < n; ++v) label[v] = (uint32_t)comp[v];
+    gather(label, (uint32_t)ncomp);
+    for (uint32_t v = 0; v < n; ++v) label[v] = find(v);
+    gather(label, n);
     std::sort(all.begin(), all.end());
     all.erase(std::unique(all.begin(), all.end()), all.end());
     return all;
@@ -206,10 +228,16 @@ static bool fd_hash_is_sym(uint32_t htype, uint32_t h) {
             const uint32_t p1 = htype == FD_HASH_FD_ANGLE ? (h >> 5) & 31u : (h >> 4) & 15u, p2 = htype == FD_HASH_FD_ANGLE ? h & 31u : h & 15u;
             return pair / 20u == pair % 20u && p1 == p2;
         }
-        auto cont = [](uint32_t v) { float cf = (1.0f - (-1.0f)) / (4.0f - 1.0f); return (float)v * cf + (-1.0f); };
-        const float D = 57.2957795130823208767981548141051703f;
-        float p1 = atan2f(cont((h >> 6) & 3), cont((h >> 4) & 3)) * D, p2 = atan2f(cont((h >> 2) & 3), cont(h & 3)) * D;
-        return ((h >> 25) & 31u) == ((h >> 20) & 31u) && p1 == p2;
+        // the default encoding: the two torsion angles from their (sin, cos) bin pairs — sixteen possible pairs, atan2f of each evaluated once (the same
+        // call on the same arguments: same floats); two atan2f per found edge were 0.8 ms of a whole-structure query's plan pass (25,162 edges of the self hit)
+        static const std::array<float, 16> ang = [] {
+            std::array<float, 16> t{};
+            auto cont = [](uint32_t v) { float cf = (1.0f - (-1.0f)) / (4.0f - 1.0f); return (float)v * cf + (-1.0f); };
+            const float D = 57.2957795130823208767981548141051703f;
+            for (uint32_t v = 0; v < 16; ++v) t[v] = atan2f(cont(v >> 2), cont(v & 3u)) * D;
+            return t;
+        }();
+        return ((h >> 25) & 31u) == ((h >> 20) & 31u) && ang[(h >> 4) & 15u] == ang[h & 15u];
 }
 
 // ---- device glue (k_retrieve.hip): the scan output never leaves the GPU — per-slot grouping, graph / components / votes /
@@ -717,7 +745,7 @@ static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uin
         Graph g;
         std::vector<std::vector<uint32_t>> comps;
         std::vector<int32_t> edge_k;
-        const bool big_trace = trace && fpos - f0 > 20000;
+        const bool big_trace = trace && fpos - f0 > 4000;
         const auto s_t0 = t_now();
         if (!cached) {
             if (fpos - f0 > 256) g.dense.assign((size_t)(g_dst[slot + 1] - g_dst[slot]), -1);
@@ -746,6 +774,27 @@ static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uin
             for (size_t e = 0; e < g.es.size(); ++e) {
                 const auto it = std::lower_bound(e_hash.begin(), e_hash.end(), g.eh[e]);
                 edge_k[e] = (it == e_hash.end() || *it != g.eh[e]) ? -1 : (int32_t)e_first[(size_t)(it - e_hash.begin())];
+            }
+        }
+        // the edges of every component, ascending: an edge belongs to a component that holds both its ends (components overlap: a strongly connected set
+        // and the weakly connected set around it).  The component loop below walked ALL edges per component — 12 components x 12 k edges for a 2,500-residue
+        // candidate of a whole-structure query
+        std::vector<std::vector<uint32_t>> comp_edges(comps.size());
+        if (!cached && !comps.empty()) {
+            const size_t nn = g.w.size();
+            std::vector<uint32_t> n_off(nn + 1, 0), n_list;
+            for (const auto &cc : comps) for (uint32_t v : cc) ++n_off[v + 1];
+            for (size_t v = 0; v < nn; ++v) n_off[v + 1] += n_off[v];
+            n_list.resize(n_off[nn]);
+            {
+                std::vector<uint32_t> cur(n_off.begin(), n_off.end() - 1);
+                for (size_t ci = 0; ci < comps.size(); ++ci) for (uint32_t v : comps[ci]) n_list[cur[v]++] = (uint32_t)ci;      // per node: its components, ascending
+            }
+            for (size_t e = 0; e < g.es.size(); ++e) {
+                const uint32_t u = g.es[e], v = g.et[e];
+                for (uint32_t x = n_off[u]; x < n_off[u + 1]; ++x)
+                    for (uint32_t y = n_off[v]; y < n_off[v + 1]; ++y)
+                        if (n_list[x] == n_list[y]) comp_edges[n_list[x]].push_back((uint32_t)e);
             }
         }
         const size_t n_comps = cached ? plan_cache[slot].size() : comps.size();
@@ -782,8 +831,7 @@ static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uin
             if (cached) { q_idx = plan_cache[slot][ci].q_idx; r_idx = plan_cache[slot][ci].r_idx; sub_idf = plan_cache[slot][ci].sub_idf; }
             else {
             const std::vector<uint32_t> &cc = comps[ci];
-            std::vector<char> inc(g.w.size(), 0);
-            for (uint32_t v : cc) inc[v] = 1;
+            const std::vector<uint32_t> &ce = comp_edges[ci];
             // votes (query residue, target residue) -> saturating u8 count (retrieve.rs:631-666).  Sparse: a component has a
             // handful of edges, the dense q_size x r_size table of the reference is ~1 MB per component for a motif taken
             // from a long chain.  best_c[q] = max count, best_r[q] = smallest target residue holding it (what the
@@ -799,12 +847,13 @@ static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uin
                 if (vote_pos.size() < (size_t)q_size * n_tr) vote_pos.assign((size_t)q_size * n_tr, 0u);      // 0 = no vote yet, else 1 + position in votes; cleared below
             }
             std::unordered_map<uint64_t, uint32_t> vote_at;     // (q, r) -> position in votes (first-seen order kept in the vector)
-            for (size_t e = 0; e < g.es.size(); ++e) {
-                if (e + 16 < g.es.size() && edge_k[e + 16] >= 0) {      // the map's arrays of a whole-structure query are ~1 MB: a miss per edge and array otherwise
-                    const int32_t k2 = edge_k[e + 16];
+            for (size_t z = 0; z < ce.size(); ++z) {
+                const size_t e = ce[z];
+                if (z + 16 < ce.size() && edge_k[ce[z + 16]] >= 0) {      // the map's arrays of a whole-structure query are ~1 MB: a miss per edge and array otherwise
+                    const int32_t k2 = edge_k[ce[z + 16]];
                     __builtin_prefetch(&qm->idf[k2]); __builtin_prefetch(&qm->qi[k2]); __builtin_prefetch(&qm->qj[k2]);
                 }
-                if (!inc[g.es[e]] || !inc[g.et[e]] || edge_k[e] < 0) continue;
+                if (edge_k[e] < 0) continue;
                 const uint32_t k = (uint32_t)edge_k[e];
                 sub_idf += qm->idf[k];                      // calculate_subgraph_idf (retrieve.rs:705-719)
                 uint32_t qi = qm->qi[k], qj = qm->qj[k], ri = g.w[g.es[e]], rj = g.w[g.et[e]];
@@ -924,7 +973,7 @@ static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uin
             add_problem(q_idx, r_idx, 0);
             if (!rec.same) add_problem(qs_sc, rs_sc, 1);
         }
-        if (big_trace) fprintf(stderr, "[slot %llu] components done at %.3f ms (%s)\n", (unsigned long long)slot, t_ms(s_t0, t_now()), plan ? "plan" : "full");
+        if (big_trace) fprintf(stderr, "[slot %llu] components done at %.3f ms (%s; the slot began %.3f ms into the stage)\n", (unsigned long long)slot, t_ms(s_t0, t_now()), plan ? "plan" : "full", t_ms(T2, s_t0));
     };
     if (e_tab_thread.joinable()) e_tab_thread.join();
     auto run_slots = [&](const bool plan) {
@@ -952,7 +1001,9 @@ static int fd_retrieve_batch_impl(fdgpu_ctx *c, const fdgpu_batch *db, const uin
                 do_slot(slot, plan, outs[slot]);
             }
         };
+        const auto rs_t0 = t_now();
         c->host_pool.run(n_thr, worker);      // the context's standing helper threads (a spawn per thread per pass was ~1 ms of the call)
+        if (trace) fprintf(stderr, "[fdgpu_retrieve] %s pass: %u threads over %llu slots took %.3f ms\n", plan ? "plan" : "full", n_thr, (unsigned long long)n_cand, t_ms(rs_t0, t_now()));
         // merge in slot order
         uint64_t tq = 0;
         for (uint64_t slot = 0; slot < n_cand; ++slot) {
