@@ -190,34 +190,52 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
     std::vector<float> iv_lohi;      // lo, hi interleaved (float2 on the device)
     if (want_iv) {
         iv_start.assign((size_t)1025 * n_queries, 0);
-        std::vector<std::pair<float, float>> tmp;
         for (uint64_t t = 0; t < n_queries; ++t) {
             const uint32_t *stt = &all_start[1025 * t];
             const float *base = all_dist.data() + qtab[t].aad_off;
             const float w = qtab[t].ca_window;
-            for (int g = 0; g < 1024; ++g) {
-                iv_start[1025 * t + g] = (uint32_t)(iv_lohi.size() / 2);
-                tmp.clear();
-                for (uint32_t e = stt[g]; e < stt[g + 1]; ++e) {
-                    const float x = base[e];
-                    if (!(fabsf(x - x) < w)) continue;                  // window <= 0 or NaN: nothing passes
-                    float hi = x + w, lo = x - w;
-                    while (!(fabsf(hi - x) < w)) hi = nextafterf(hi, -INFINITY);
-                    for (float n2 = nextafterf(hi, INFINITY); fabsf(n2 - x) < w; n2 = nextafterf(hi, INFINITY)) hi = n2;
-                    while (!(fabsf(lo - x) < w)) lo = nextafterf(lo, INFINITY);
-                    for (float n2 = nextafterf(lo, -INFINITY); fabsf(n2 - x) < w; n2 = nextafterf(lo, -INFINITY)) lo = n2;
-                    tmp.emplace_back(lo, hi);
+            // the 1,024 groups are independent: eight parts of 128 groups on the context's helper threads when the query observes enough distances to pay
+            // for waking them (a whole-structure query: ~3·10^4 observed distances, six nextafterf each), stitched in group order afterwards
+            constexpr unsigned NP = 8;
+            std::vector<float> part_lohi[NP];
+            uint32_t g_cnt[1024];
+            auto groups = [&](unsigned part) {
+                std::vector<std::pair<float, float>> tmp;
+                std::vector<float> &out = part_lohi[part];
+                for (int g = 128 * (int)part; g < 128 * ((int)part + 1); ++g) {
+                    const size_t before = out.size();
+                    tmp.clear();
+                    for (uint32_t e = stt[g]; e < stt[g + 1]; ++e) {
+                        const float x = base[e];
+                        if (!(fabsf(x - x) < w)) continue;                  // window <= 0 or NaN: nothing passes
+                        float hi = x + w, lo = x - w;
+                        while (!(fabsf(hi - x) < w)) hi = nextafterf(hi, -INFINITY);
+                        for (float n2 = nextafterf(hi, INFINITY); fabsf(n2 - x) < w; n2 = nextafterf(hi, INFINITY)) hi = n2;
+                        while (!(fabsf(lo - x) < w)) lo = nextafterf(lo, INFINITY);
+                        for (float n2 = nextafterf(lo, -INFINITY); fabsf(n2 - x) < w; n2 = nextafterf(lo, -INFINITY)) lo = n2;
+                        tmp.emplace_back(lo, hi);
+                    }
+                    std::sort(tmp.begin(), tmp.end());
+                    for (size_t k = 0; k < tmp.size();) {
+                        float lo = tmp[k].first, hi = tmp[k].second;
+                        size_t z = k + 1;
+                        while (z < tmp.size() && tmp[z].first <= nextafterf(hi, INFINITY)) { hi = std::max(hi, tmp[z].second); ++z; }
+                        out.push_back(lo); out.push_back(hi);
+                        k = z;
+                    }
+                    g_cnt[g] = (uint32_t)((out.size() - before) / 2);
                 }
-                std::sort(tmp.begin(), tmp.end());
-                for (size_t k = 0; k < tmp.size();) {
-                    float lo = tmp[k].first, hi = tmp[k].second;
-                    size_t z = k + 1;
-                    while (z < tmp.size() && tmp[z].first <= nextafterf(hi, INFINITY)) { hi = std::max(hi, tmp[z].second); ++z; }
-                    iv_lohi.push_back(lo); iv_lohi.push_back(hi);
-                    k = z;
-                }
+            };
+            if (stt[1024] - stt[0] < 8192u) { for (unsigned k = 0; k < NP; ++k) groups(k); }
+            else {
+                std::atomic<unsigned> next_part(0);
+                const std::function<void()> wk = [&]() { for (;;) { const unsigned k = next_part.fetch_add(1); if (k >= NP) break; groups(k); } };
+                c->host_pool.run(std::min(NP, std::max(1u, std::thread::hardware_concurrency())), wk);
             }
-            iv_start[1025 * t + 1024] = (uint32_t)(iv_lohi.size() / 2);
+            uint32_t run = (uint32_t)(iv_lohi.size() / 2);
+            for (unsigned k = 0; k < NP; ++k) iv_lohi.insert(iv_lohi.end(), part_lohi[k].begin(), part_lohi[k].end());      // the parts in group order
+            for (int g = 0; g < 1024; ++g) { iv_start[1025 * t + g] = run; run += g_cnt[g]; }
+            iv_start[1025 * t + 1024] = run;
         }
     }
     const size_t nw = dev_items ? n_wi : wc.size(), na = all_dist.size(), nh = all_hashes.size();
