@@ -428,6 +428,37 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
                 if (subs[q_off[t] + a]) sub_of[qidx[a]] = std::make_pair(subs[q_off[t] + a], n_subs[q_off[t] + a]);
         Aad &A = aads[t];
         { const size_t n_p = (size_t)(pair_off[t + 1] - pair_off[t]); A.a1.reserve(n_p); A.a2.reserve(n_p); A.ad.reserve(n_p); A.aq.reserve(n_p); }
+        if (dev_expand && pair_off[t + 1] - pair_off[t] >= 16384) {
+            // a whole-structure query on the device path: all that is left here is the observed-distance list, read from the page-locked landing block (a cache
+            // miss per pair: the copy engine wrote it) — eight parts on the context's helper threads, joined in pair order
+            constexpr unsigned NP = 8;
+            Aad part[NP];
+            uint64_t n_val[NP] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const uint64_t k0 = pair_off[t], k1 = pair_off[t + 1];
+            auto scan = [&](unsigned z) {
+                Aad P;              // (locals: the parts' counters and vector headers share cache lines)
+                uint64_t nv = 0;
+                const uint64_t ka = k0 + (k1 - k0) * z / NP, kb = k0 + (k1 - k0) * (z + 1) / NP;
+                P.a1.reserve(kb - ka); P.a2.reserve(kb - ka); P.ad.reserve(kb - ka); P.aq.reserve(kb - ka);
+                for (uint64_t k = ka; k < kb; ++k) {
+                    if (!valid[k]) continue;
+                    const float *f = &feat[(size_t)FD_QF * k];
+                    if (f[9] <= 20.0f) { P.a1.push_back((uint8_t)f[10]); P.a2.push_back((uint8_t)f[11]); P.ad.push_back(f[9]); P.aq.push_back((uint32_t)(pi[k] - r0)); }
+                    ++nv;
+                }
+                part[z] = std::move(P); n_val[z] = nv;
+            };
+            std::atomic<unsigned> nxt(0);
+            const std::function<void()> wk = [&]() { for (;;) { const unsigned z = nxt.fetch_add(1); if (z >= NP) break; scan(z); } };
+            c->host_pool.run(std::min(NP, std::max(1u, std::thread::hardware_concurrency())), wk);
+            for (unsigned z = 0; z < NP; ++z) {
+                A.a1.insert(A.a1.end(), part[z].a1.begin(), part[z].a1.end()); A.a2.insert(A.a2.end(), part[z].a2.begin(), part[z].a2.end());
+                A.ad.insert(A.ad.end(), part[z].ad.begin(), part[z].ad.end()); A.aq.insert(A.aq.end(), part[z].aq.begin(), part[z].aq.end());
+                n_valid_seen += n_val[z];
+            }
+            cand_off[t + 1] = n_valid_seen * dev_pp;
+            continue;
+        }
         for (uint64_t k = pair_off[t]; k < pair_off[t + 1]; ++k) {
             if (!valid[k]) continue;
             const float *f = &feat[(size_t)FD_QF * k];
@@ -641,6 +672,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
     std::vector<uint64_t> ent_len;
     std::vector<uint32_t> ent_seg;
     std::vector<long long> ent_kidx;
+    const uint64_t *e_len = nullptr; const uint32_t *e_seg = nullptr; const long long *e_kidx = nullptr;      // the three arrays as the loops read them (the vectors, or the landing block)
     if (index) {
         std::vector<uint32_t> ph, pk;
         ph.reserve(n_keep + np);
@@ -656,6 +688,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         ent_len.assign(std::max<size_t>(ph.size(), 1), 0);
         ent_seg.assign(std::max<size_t>(ph.size(), 1), 0);
         ent_kidx.assign(std::max<size_t>(ph.size(), 1), -1);
+        e_len = ent_len.data(); e_seg = ent_seg.data(); e_kidx = ent_kidx.data();
         if (ch_len) {      // the chain looked every candidate up: pick the kept entries and the observed hashes, in ph's order
             size_t w = 0;
             for (uint64_t t = 0; t < n_queries; ++t) {
@@ -664,10 +697,14 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             }
             for (uint64_t v = 0; v < vpairs.size(); ++v, ++w) { const uint64_t z = v * dev_pp; ent_len[w] = ch_len[z]; ent_seg[w] = ch_seg[z]; ent_kidx[w] = ch_kidx[z]; }
         } else
-        if ((rc = fd_posting_lengths_segs(c, index, ph.data(), ph.size(), ent_len.data(), ent_seg.data(), ent_kidx.data()))) return rc;
+        {
+            const uint8_t *pl_land = nullptr;       // large requests stay in the page-locked block (read once, in place, by the loops below)
+            if ((rc = fd_posting_lengths_segs(c, index, ph.data(), ph.size(), ent_len.data(), ent_seg.data(), ent_kidx.data(), ph.size() >= 16384 ? &pl_land : nullptr))) return rc;
+            if (pl_land) { e_len = (const uint64_t *)pl_land; e_kidx = (const long long *)(pl_land + ph.size() * 8); e_seg = (const uint32_t *)(pl_land + ph.size() * 16); }
+        }
         // idf of the observed hash of every pair: log2f is ~8 ns a call — 0.7 ms for the 88 k pairs of a whole-structure query on one thread
         auto idf_range = [&](size_t a, size_t b) {
-            for (size_t t = a; t < b; ++t) pair_idf[pk[t]] = ent_len[n_keep + t] > 0 ? log2f(total_structures / (float)ent_len[n_keep + t]) : 0.0f;
+            for (size_t t = a; t < b; ++t) pair_idf[pk[t]] = e_len[n_keep + t] > 0 ? log2f(total_structures / (float)e_len[n_keep + t]) : 0.0f;
         };
         if (pk.size() < 16384) idf_range(0, pk.size());
         else {
@@ -736,7 +773,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
         }
         if (with_post) {
             m->post_len = (uint64_t *)(blk + o_pl); m->post_kidx = (long long *)(blk + o_pk); m->post_seg = (uint32_t *)(blk + o_ps);
-            memcpy(m->post_len, &ent_len[keep_at], n * 8); memcpy(m->post_seg, &ent_seg[keep_at], n * 4); memcpy(m->post_kidx, &ent_kidx[keep_at], n * 8);
+            memcpy(m->post_len, e_len + keep_at, n * 8); memcpy(m->post_seg, e_seg + keep_at, n * 4); memcpy(m->post_kidx, e_kidx + keep_at, n * 8);
             m->post_index_uid = index->uid;
         }
         keep_at += n;

@@ -252,7 +252,8 @@ uint64_t fd_maps_hashes(uint64_t n_queries, const fd_query_map *const *qms, std:
 int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const uint64_t *len,
                             const uint64_t *primary_len, const float *penalty, float total_structures, uint32_t top_n, fd_count_rec **out,
                             uint64_t **out_off, fd_cq_dev_out *dev, const uint32_t *seg = nullptr, const long long *kidx = nullptr, bool allow_dense = true);
-int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs, long long *kidx = nullptr);
+int fd_posting_lengths_segs(fdgpu_ctx *c, const fdgpu_index *ix, const uint32_t *q_hash, uint64_t nq, uint64_t *lengths, uint32_t *segs, long long *kidx = nullptr,
+                            const uint8_t **land_out = nullptr);
 // fdgpu_count_query_maps_top with the device-resident form of its result (dev != null: see fd_count_query_batch_impl)
 int fd_count_query_maps_top_impl(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_queries, const fd_query_map *const *qms, const float *penalty, float total_structures,
                                  uint32_t top_n, fd_count_rec **out, uint64_t **out_off, fd_cq_dev_out *dev, bool allow_dense = true);
