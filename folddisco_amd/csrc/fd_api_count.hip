@@ -905,7 +905,7 @@ int fd_count_query_maps_len(fdgpu_ctx *c, const fdgpu_index *ix, uint64_t n_quer
         const unsigned nt = 8;
         std::atomic<unsigned> part(0);
         const std::function<void()> wk = [&]() { for (;;) { const unsigned k = part.fetch_add(1); if (k >= nt) break; idf_rows(w * k / nt, w * (k + 1) / nt); } };
-        c->host_pool.run(std::min(nt, std::max(1u, std::thread::hardware_concurrency())), wk);
+        c->host_pool.run(c->small_par(nt), wk);
     }
     qh.resize(w); qn.resize(w); qe.resize(w); qi.resize(w); ql.resize(w);
     if (kidx) qk.resize(w);

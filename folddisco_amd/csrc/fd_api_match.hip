@@ -230,7 +230,7 @@ int fd_match_pairs_multi(fdgpu_ctx *c, const fdgpu_batch *db, const uint8_t *res
             else {
                 std::atomic<unsigned> next_part(0);
                 const std::function<void()> wk = [&]() { for (;;) { const unsigned k = next_part.fetch_add(1); if (k >= NP) break; groups(k); } };
-                c->host_pool.run(std::min(NP, std::max(1u, std::thread::hardware_concurrency())), wk);
+                c->host_pool.run(c->small_par(NP), wk);
             }
             uint32_t run = (uint32_t)(iv_lohi.size() / 2);
             for (unsigned k = 0; k < NP; ++k) iv_lohi.insert(iv_lohi.end(), part_lohi[k].begin(), part_lohi[k].end());      // the parts in group order

@@ -88,6 +88,7 @@ static int fd_lanes_ensure(fdgpu_ctx *c, uint32_t want) {
         fdgpu_ctx *lc = nullptr;
         const int rc = fdgpu_create(c->device, &lc);
         if (rc) { c->err = std::string("query lane: ") + (lc ? fdgpu_last_error(lc) : "out of memory"); if (lc) fdgpu_destroy(lc); return rc; }
+        lc->is_lane = true;
         P->ctxs.push_back(lc);
         P->threads.emplace_back(lane_main, P, lc);
     }

@@ -450,7 +450,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
             };
             std::atomic<unsigned> nxt(0);
             const std::function<void()> wk = [&]() { for (;;) { const unsigned z = nxt.fetch_add(1); if (z >= NP) break; scan(z); } };
-            c->host_pool.run(std::min(NP, std::max(1u, std::thread::hardware_concurrency())), wk);
+            c->host_pool.run(c->small_par(NP), wk);
             for (unsigned z = 0; z < NP; ++z) {
                 A.a1.insert(A.a1.end(), part[z].a1.begin(), part[z].a1.end()); A.a2.insert(A.a2.end(), part[z].a2.begin(), part[z].a2.end());
                 A.ad.insert(A.ad.end(), part[z].ad.begin(), part[z].ad.end()); A.aq.insert(A.aq.end(), part[z].aq.begin(), part[z].aq.end());
@@ -760,7 +760,7 @@ extern "C" int fdgpu_make_query_map_batch(fdgpu_ctx *c, const fdgpu_batch *qb, u
                 const unsigned nt = 8;
                 std::atomic<unsigned> part(0);
                 const std::function<void()> wk = [&]() { for (;;) { const unsigned k = part.fetch_add(1); if (k >= nt) break; fill(n * k / nt, n * (k + 1) / nt); } };
-                c->host_pool.run(std::min(nt, std::max(1u, std::thread::hardware_concurrency())), wk);
+                c->host_pool.run(c->small_par(nt), wk);
             }
             w = n;
         } else

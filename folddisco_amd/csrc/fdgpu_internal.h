@@ -162,6 +162,9 @@ struct fdgpu_ctx {
     bool counted = false;         // fdgpu_create got as far as a device + stream (live-context count behind fdgpu_trim at the last destroy)
     const void *mp_bintab_at = nullptr; size_t mp_bintab_cap = 0;      // the WS_MP_Q allocation whose first 256 bytes hold the pair drain's bin tables
     fd_host_pool host_pool;       // helper threads of the host glue (made on first use)
+    bool is_lane = false;         // a query lane's private context: its short host loops stay on the lane's thread (the other lanes' queries are the parallelism)
+    // helper threads for a short host loop of a large query: n on a caller's own context, 1 (inline) on a lane
+    unsigned small_par(unsigned n) const { return is_lane ? 1u : std::min(n, std::max(1u, std::thread::hardware_concurrency())); }
     void *lanes = nullptr;        // fd_lanes.hip: sibling contexts + worker threads behind fdgpu_query_batch_submit / _wait (made on first use)
 };
 void fd_lanes_destroy(fdgpu_ctx *c);
