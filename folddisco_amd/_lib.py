@@ -218,6 +218,8 @@ SYMBOLS = [
     ("fdgpu_debug_libm", C.c_int, [VP, C.c_int, f32p, f32p, f32p, C.c_uint64]),
     ("fdgpu_ingest_stats", None, [C.POINTER(C.c_double), C.c_int]),
     ("fdgpu_debug_gunzip", C.c_int, [u8p, C.c_uint64, C.POINTER(u8p), u64p]),
+    ("fdgpu_debug_host_components", C.c_int, [u32p, u32p, C.c_uint64, C.c_uint32, C.POINTER(u32p), C.POINTER(u64p), u64p]),
+    ("fdgpu_debug_hash_is_symmetric", C.c_int, [C.c_uint32, u32p, C.c_uint64, u8p]),
     ("fdgpu_debug_merge_retrieved", C.c_int, [VP, C.c_uint32, C.c_uint64, u64p, C.POINTER(C.POINTER(MatchRec)), C.POINTER(C.POINTER(C.c_int32)), u64p,
                                               C.POINTER(C.POINTER(MatchRec)), C.POINTER(u64p), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(u64p)]),
 ]

@@ -135,6 +135,35 @@ static std::vector<std::vector<uint32_t>> components(const Graph &g, size_t min_
 
 extern "C" void fdgpu_matches_free(fd_match_rec *m, int32_t *residues) { fdgpu_free(m); fdgpu_free(residues); }
 
+static bool fd_hash_is_sym(uint32_t htype, uint32_t h);
+// test-only (include/fdgpu_debug.h): the host glue's graph of found (i, j) residue pairs — nodes in first-appearance order — and its components of at least
+// node_count nodes, as the retrieval of > 64-node graphs computes them; and the symmetry flag of hashes.  Pure host code: CPU tests call them without a GPU.
+extern "C" int fdgpu_debug_host_components(const uint32_t *edge_i, const uint32_t *edge_j, uint64_t n_edges, uint32_t node_count, uint32_t **residues,
+                                           uint64_t **comp_off, uint64_t *n_comps) {
+    if ((n_edges && (!edge_i || !edge_j)) || !residues || !comp_off || !n_comps) return FDGPU_EINVAL;
+    Graph g;
+    for (uint64_t e = 0; e < n_edges; ++e) {
+        const uint32_t a = g.node_of(edge_i[e]), b = g.node_of(edge_j[e]);
+        g.es.push_back(a); g.et.push_back(b); g.eh.push_back(0u);
+    }
+    const std::vector<std::vector<uint32_t>> comps = components(g, node_count);
+    uint64_t tot = 0;
+    for (const auto &cc : comps) tot += cc.size();
+    uint32_t *r = (uint32_t *)malloc(std::max<uint64_t>(tot, 1) * 4);
+    uint64_t *o = (uint64_t *)malloc((comps.size() + 1) * 8);
+    if (!r || !o) { free(r); free(o); return FDGPU_ENOMEM; }
+    uint64_t w = 0;
+    o[0] = 0;
+    for (size_t k = 0; k < comps.size(); ++k) { for (uint32_t v : comps[k]) r[w++] = g.w[v]; o[k + 1] = w; }      // a component's nodes ascending, as residues
+    *residues = r; *comp_off = o; *n_comps = comps.size();
+    return FDGPU_OK;
+}
+extern "C" int fdgpu_debug_hash_is_symmetric(uint32_t hash_type, const uint32_t *hashes, uint64_t n, uint8_t *out) {
+    if (n && (!hashes || !out)) return FDGPU_EINVAL;
+    for (uint64_t k = 0; k < n; ++k) out[k] = fd_hash_is_sym(hash_type, hashes[k]) ? 1 : 0;
+    return FDGPU_OK;
+}
+
 
 // coordinates of all candidates in one launch + one copy (a hipMemcpy per candidate costs more than the pair scan)
 __global__ __launch_bounds__(256) void k_gather_xyz(const float *__restrict__ ca, const float *__restrict__ cb, const uint64_t *__restrict__ src,

@@ -28,6 +28,17 @@ int fdgpu_debug_gunzip(const uint8_t *in, uint64_t n, uint8_t **out, uint64_t *n
  * gfx950 arithmetic bit for bit with the host.  op: 0 sinf, 1 cosf, 2 acosf, 3 atanf, 4 atan2f(a, b). */
 int fdgpu_debug_libm(fdgpu_ctx *ctx, int op, const float *a, const float *b, float *out, uint64_t n);
 
+/* Host-only pieces of the retrieval glue for graphs of more than 64 nodes (csrc/fd_host_query.hip), callable without a GPU.
+ * fdgpu_debug_host_components: the graph of the found residue pairs (edge_i[e] -> edge_j[e], nodes numbered by first appearance,
+ * src/controller/graph.rs:16-26) and its strongly + weakly connected components of at least node_count nodes, each sorted by node, the list sorted
+ * and without duplicates (graph.rs:29-50).  Component k holds (*residues)[(*comp_off)[k] .. (*comp_off)[k + 1]) — the RESIDUES of its nodes in node
+ * order; both arrays are released with libc free().
+ * fdgpu_debug_hash_is_symmetric: out[k] = the symmetry flag of hashes[k] for the encoding (geometry/pdb_tr.rs:158-162 and the other encodings'
+ * is_symmetric). */
+int fdgpu_debug_host_components(const uint32_t *edge_i, const uint32_t *edge_j, uint64_t n_edges, uint32_t node_count, uint32_t **residues,
+                                uint64_t **comp_off, uint64_t *n_comps);
+int fdgpu_debug_hash_is_symmetric(uint32_t hash_type, const uint32_t *hashes, uint64_t n, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -688,3 +688,67 @@ def test_residue_name_table_matches_oracle(tmp_path):
     canonical = {g.split()[0] for g in groups}
     assert [bool(x) for x in cs.resname_std()] == [n in canonical for n in names]
     assert [int(a) for a in cs.aa[:9]] == [0] * 9 and int(cs.aa[len(names) - 9]) == 255
+
+
+def test_host_glue_components_and_symmetry_flags_without_a_gpu():
+    """The host pieces of the retrieval of > 64-node graphs (csrc/fd_host_query.hip), called without a GPU: the components of the found-pair graph
+    (graph.rs:16-50: nodes by first appearance, strongly + weakly connected sets of at least node_count nodes, sorted, without duplicates) against
+    scipy's labels on random directed graphs of up to 3,000 nodes; the default encoding's symmetry flag (a 16-entry table of the torsion angles,
+    geometry/pdb_tr.rs:158-162) against the oracle over every residue-type pair x every combination of the four angle-bin fields."""
+    import ctypes as C
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import connected_components
+    from folddisco_amd import _lib
+    L = _lib.load()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(23)
+
+    def want(ei, ej, node_count):
+        node = {}
+        for a, b in zip(ei.tolist(), ej.tolist()):
+            node.setdefault(a, len(node)); node.setdefault(b, len(node))
+        res = np.array(list(node.keys()), np.uint32)
+        n = len(node)
+        if n == 0:
+            return []
+        u = np.array([node[a] for a in ei.tolist()]); v = np.array([node[b] for b in ej.tolist()])
+        g = csr_matrix((np.ones(len(u)), (u, v)), shape=(n, n))
+        sets = set()
+        for conn in ("strong", "weak"):
+            _, lab = connected_components(g, directed=True, connection=conn)
+            for l in np.unique(lab):
+                members = tuple(np.nonzero(lab == l)[0].tolist())
+                if len(members) >= node_count:
+                    sets.add(members)
+        return [res[list(m)].tolist() for m in sorted(sets)]
+
+    def got(ei, ej, node_count):
+        r, o, nc = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint64)(), C.c_uint64()
+        rc = L.fdgpu_debug_host_components(ei.ctypes.data_as(C.POINTER(C.c_uint32)), ej.ctypes.data_as(C.POINTER(C.c_uint32)), len(ei), node_count, C.byref(r), C.byref(o),
+                                           C.byref(nc))
+        assert rc == 0
+        off = np.ctypeslib.as_array(o, shape=(nc.value + 1,)).copy()
+        res = np.ctypeslib.as_array(r, shape=(max(int(off[-1]), 1),)).copy()
+        libc.free(C.cast(r, C.c_void_p)); libc.free(C.cast(o, C.c_void_p))
+        return [res[off[k]:off[k + 1]].tolist() for k in range(nc.value)]
+
+    cases = [(0, 0, 2), (5, 4, 1), (12, 30, 2), (70, 90, 3), (70, 400, 4), (300, 350, 2), (300, 25000, 4), (3000, 4000, 2), (3000, 12000, 4)]
+    for n_nodes, n_edges, node_count in cases:
+        ids = rng.permutation(70000)[:max(n_nodes, 1)].astype(np.uint32)
+        ei = ids[rng.integers(0, max(n_nodes, 1), n_edges)].astype(np.uint32) if n_edges else np.zeros(0, np.uint32)
+        ej = ids[rng.integers(0, max(n_nodes, 1), n_edges)].astype(np.uint32) if n_edges else np.zeros(0, np.uint32)
+        assert got(ei, ej, node_count) == want(ei, ej, node_count), (n_nodes, n_edges, node_count)
+    # chains and rings: strongly connected rings inside a weakly connected whole
+    ei = np.array([1, 2, 3, 3, 10, 11, 12, 20], np.uint32); ej = np.array([2, 3, 1, 10, 11, 12, 10, 21], np.uint32)
+    assert got(ei, ej, 2) == want(ei, ej, 2) and got(ei, ej, 3) == want(ei, ej, 3) and got(ei, ej, 7) == want(ei, ej, 7)
+
+    # symmetry flags of the default encoding (hash type 3): every (aa1, aa2) x every value of the low eight bits, plus random hashes
+    aa1, aa2, low = np.meshgrid(np.arange(32, dtype=np.uint32), np.arange(32, dtype=np.uint32), np.arange(256, dtype=np.uint32), indexing="ij")
+    mid = rng.integers(0, 1 << 12, size=aa1.size, dtype=np.uint32)
+    h = np.concatenate([(aa1.ravel() << 25) | (aa2.ravel() << 20) | (mid << 8) | low.ravel(), rng.integers(0, 1 << 30, size=20000, dtype=np.uint32)]).astype(np.uint32)
+    out = np.zeros(len(h), np.uint8)
+    assert L.fdgpu_debug_hash_is_symmetric(3, h.ctypes.data_as(C.POINTER(C.c_uint32)), len(h), out.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    OL = oracle.lib()
+    exp = np.fromiter((OL.fdo_hash_is_symmetric(int(x)) for x in h[::7]), np.uint8)
+    assert np.array_equal(out[::7], exp) and 0 < int(out.sum()) < len(out)
